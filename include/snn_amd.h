@@ -1,0 +1,204 @@
+/*
+ * snn_amd.h -- C ABI of the MI355X-native spiking-lattice time-stepper.
+ *
+ * Drop-in boundary for ONE path of NikhilMukraj/spiking-neural-networks: the
+ * GPU lattice seam of the `backend` crate (all paths relative to
+ * /root/reference/backend/src/):
+ *
+ *   LatticeGPU::from_lattice            neuron/gpu_lattices/mod.rs:496-511
+ *   RunLattice for LatticeGPU           neuron/gpu_lattices/mod.rs:1081-1100
+ *   LatticeNetworkGPU::from_network     neuron/gpu_lattices/mod.rs:1636-1651
+ *   RunNetwork for LatticeNetworkGPU    neuron/gpu_lattices/mod.rs:3183-3212
+ *   IterateAndSpikeGPU::convert_to_gpu / convert_to_cpu
+ *                                       neuron/iterate_and_spike/mod.rs:3156-3189
+ *   GraphToGPU / InterleavingGraphGPU   graph/mod.rs:97-107, 300-404, 579-943
+ *   SpikeTrainGPU                       neuron/spike_train/mod.rs:216-255
+ *   LatticeHistoryGPU                   neuron/gpu_lattices/mod.rs:178-280
+ *   GPUError                            error/mod.rs:221-238
+ *
+ * Plain pointers and sizes only.  A handle owns device memory on ONE GPU and,
+ * optionally, one contiguous shard [post_begin, post_end) of the postsynaptic
+ * population (multi-GPU: one process and one handle per GPU).  Calls on one
+ * handle are blocking and not re-entrant; distinct handles may be used from
+ * distinct threads.  The library never frees or retains caller memory.
+ *
+ * Index space ("interleaved", graph/mod.rs:668-727): neurons of all neuron
+ * lattices in ascending lattice id, row-major inside a lattice; spike-train
+ * cells of all spike-train lattices after them, same ordering.  n_tot =
+ * n_neurons + n_cells.  Spike-train cells are never postsynaptic.
+ *
+ * Per-cell attributes keep the reference's buffer names (struct field names,
+ * `$` for nesting -- neuron/integrate_and_fire/mod.rs:729-773,
+ * neuron/iterate_and_spike/mod.rs:209-243, 1369-1422, 2653) and its three
+ * scalar types Float / UInt / OptionalUInt (iterate_and_spike/mod.rs:3112-3134):
+ * f32, u32, and i32 with -1 == None.  Attributes with a per-type dimension
+ * (neurotransmitters$*, receptors$flags) are laid out [cell * 3 + type] with
+ * type AMPA = 0, NMDA = 1, GABA = 2 (iterate_and_spike/mod.rs:1323-1333), as the
+ * reference's kernels index them (gpu_lattices/mod.rs:117-127).
+ */
+#ifndef SNN_AMD_H
+#define SNN_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SNN_ABI_VERSION 1
+#define SNN_NUM_NT_TYPES 3
+/* canonical reduction chunk: presynaptic indices are summed in runs of 256 */
+#define SNN_REDUCTION_CHUNK 256
+
+typedef struct snn_network snn_network_t;
+
+/* 1..8 mirror GPUError's variants in declaration order (error/mod.rs:221-238) */
+typedef enum snn_status {
+    SNN_OK = 0,
+    SNN_ERR_PROGRAM_COMPILE = 1,
+    SNN_ERR_KERNEL_COMPILE = 2,
+    SNN_ERR_BUFFER_CREATE = 3,
+    SNN_ERR_BUFFER_WRITE = 4,
+    SNN_ERR_BUFFER_READ = 5,
+    SNN_ERR_WAIT = 6,
+    SNN_ERR_GET_DEVICE = 7,
+    SNN_ERR_QUEUE = 8,
+    SNN_ERR_BAD_ATTR = 9,        /* unknown attribute name / wrong scalar type */
+    SNN_ERR_DIM_MISMATCH = 10,   /* GraphError::DimensionsDoNotMatch, error/mod.rs:24 */
+    SNN_ERR_BAD_ARG = 11,
+    SNN_ERR_BAD_STATE = 12       /* call order (e.g. add_lattice after finalize) */
+} snn_status;
+
+/* neuron models: IzhikevichNeuron integrate_and_fire/mod.rs:1159-1268,
+ * LeakyIntegrateAndFireNeuron :108-215, HodgkinHuxleyNeuron hodgkin_huxley/mod.rs:49-241 */
+typedef enum { SNN_MODEL_IZHIKEVICH = 0, SNN_MODEL_LIF = 1, SNN_MODEL_HODGKIN_HUXLEY = 2 } snn_model;
+/* NeurotransmitterKinetics: Approximate iterate_and_spike/mod.rs:161-205, Destexhe :122-159 */
+typedef enum { SNN_NT_APPROXIMATE = 0, SNN_NT_DESTEXHE = 1 } snn_nt_kinetics;
+/* ReceptorKinetics: Approximate iterate_and_spike/mod.rs:427-446, Destexhe :394-425 */
+typedef enum { SNN_RC_APPROXIMATE = 0, SNN_RC_DESTEXHE = 1 } snn_rc_kinetics;
+/* SpikeTrain: PoissonNeuron spike_train/mod.rs:259-371 (GPU generator :380-435), RateSpikeTrain :975-1031 */
+typedef enum { SNN_ST_NONE = 0, SNN_ST_POISSON = 1, SNN_ST_RATE = 2 } snn_spike_train_model;
+
+/* ---- construction (≙ from_lattice / from_network) -------------------------------------- */
+
+/* device: HIP ordinal.  Errors: SNN_ERR_GET_DEVICE, SNN_ERR_QUEUE. */
+int snn_network_create(int device, int neuron_model, int nt_kinetics, int receptor_kinetics,
+                       int spike_train_model, snn_network_t **out);
+int snn_network_destroy(snn_network_t *net);
+
+/* Register a neuron lattice / spike-train lattice by id (LatticeNetwork::add_lattice
+ * neuron/mod.rs:1663-1679, add_spike_train_lattice :1682-1699; a duplicate id is an error).  Zero-sized grids are legal. */
+int snn_network_add_lattice(snn_network_t *net, uint32_t id, uint32_t rows, uint32_t cols);
+int snn_network_add_spike_train_lattice(snn_network_t *net, uint32_t id, uint32_t rows, uint32_t cols);
+
+/* Fix the interleaved index space and allocate device state (reference defaults) plus the
+ * dense graph of this handle's postsynaptic columns.  snn_network_finalize: whole population.
+ * snn_network_finalize_shard: shard `shard_index` of `n_shards` equal slots of
+ * stride = round_up(ceil(n_neurons / n_shards), 64) neurons; shard r owns neurons
+ * [r*stride, min(n_neurons, (r+1)*stride)).  Errors: SNN_ERR_BUFFER_CREATE. */
+int snn_network_finalize(snn_network_t *net);
+int snn_network_finalize_shard(snn_network_t *net, uint32_t shard_index, uint32_t n_shards);
+
+int snn_network_sizes(const snn_network_t *net, uint32_t *n_neurons, uint32_t *n_cells,
+                      uint32_t *post_begin, uint32_t *post_end);
+/* first interleaved index and cell count of a lattice (InterleavingGraphGPU::calculate_index) */
+int snn_network_lattice_range(const snn_network_t *net, uint32_t id, uint32_t *first, uint32_t *count);
+
+/* ---- per-cell state (≙ convert_to_gpu / convert_to_cpu) ------------------------------- */
+
+/* `id` selects the lattice; `count` must equal rows*cols (times 3 for per-type attributes).
+ * Unknown name or wrong type: SNN_ERR_BAD_ATTR; wrong count: SNN_ERR_DIM_MISMATCH. */
+int snn_set_attr_f32(snn_network_t *net, uint32_t id, const char *name, const float *src, size_t count);
+int snn_get_attr_f32(snn_network_t *net, uint32_t id, const char *name, float *dst, size_t count);
+int snn_set_attr_u32(snn_network_t *net, uint32_t id, const char *name, const uint32_t *src, size_t count);
+int snn_get_attr_u32(snn_network_t *net, uint32_t id, const char *name, uint32_t *dst, size_t count);
+int snn_set_attr_i32(snn_network_t *net, uint32_t id, const char *name, const int32_t *src, size_t count);
+int snn_get_attr_i32(snn_network_t *net, uint32_t id, const char *name, int32_t *dst, size_t count);
+
+/* ---- graph (≙ GraphToGPU::convert_to_gpu / InterleavingGraphGPU::convert_to_gpu) ------- */
+
+/* The reference's flattened form: weights f32[n_tot*n_tot], connections u32[n_tot*n_tot],
+ * element [pre*n_tot + post]; connections == 0 means None (graph/mod.rs:310-320, 729-770).
+ * Columns of spike-train cells are ignored (they are never postsynaptic). */
+int snn_set_graph_dense(snn_network_t *net, const float *weights, const uint32_t *connections, size_t n_tot);
+int snn_get_graph_dense(snn_network_t *net, float *weights, uint32_t *connections, size_t n_tot);
+/* Row-block form for matrices that do not fit one host buffer: presynaptic rows
+ * [pre_begin, pre_begin+pre_count), n_neurons columns each ([row*n_neurons + post]). */
+int snn_set_graph_rows(snn_network_t *net, uint32_t pre_begin, uint32_t pre_count,
+                       const float *weights, const uint32_t *connections);
+int snn_get_graph_rows(snn_network_t *net, uint32_t pre_begin, uint32_t pre_count,
+                       float *weights, uint32_t *connections);
+/* Device-side synthetic graph: weight(pre,post) = lo + (hi-lo)*u24(hash(seed, pre*n_neurons+post)),
+ * connected unless pre == post (or always, with_diagonal != 0).  Nothing crosses PCIe. */
+int snn_fill_graph_synthetic(snn_network_t *net, uint64_t seed, float lo, float hi, int with_diagonal);
+
+/* ---- switches (Lattice / LatticeNetwork pub fields, neuron/mod.rs:570-586, 1577-1588) -- */
+
+int snn_set_synapses(snn_network_t *net, int electrical_synapse, int chemical_synapse);
+/* STDP of one lattice (plasticity/mod.rs:16-39) and its do_plasticity switch */
+int snn_set_plasticity(snn_network_t *net, uint32_t id, float a_plus, float a_minus,
+                       float tau_plus, float tau_minus, float dt, int do_plasticity);
+/* update_grid_history for GridVoltageHistory (f32 snapshot per step) and the spike raster */
+int snn_set_history(snn_network_t *net, int voltage_history, int spike_history);
+int snn_reset_history(snn_network_t *net);
+int snn_get_clock(const snn_network_t *net, uint64_t *clock);
+/* reset_timing (neuron/mod.rs:405-420, 1710-1717): clock = 0, last_firing_time = None everywhere */
+int snn_reset_timing(snn_network_t *net);
+
+/* ---- the hot path (≙ run_lattice / run_lattices) --------------------------------------- */
+
+/* Advance `iterations` time-steps.  iterations == 0, an empty network, or both synapse kinds
+ * off is a successful no-op (gpu_lattices/mod.rs:1089-1091, 3196-3203).  Requires a whole
+ * population handle; sharded handles are driven with the three calls below. */
+int snn_run(snn_network_t *net, uint64_t iterations);
+
+/* Multi-GPU stepping of one shard: (1) snn_step_begin computes the local neurons' step from the
+ * replicated presynaptic state and writes their new exchanged state into the local slice of the
+ * exchange buffer; (2) the caller all-gathers the exchange buffer across ranks (RCCL, in place);
+ * (3) snn_step_end applies the gathered state (last_firing_time, plasticity on the local columns,
+ * spike trains, clock). */
+int snn_step_begin(snn_network_t *net);
+int snn_step_end(snn_network_t *net);
+/* Device pointer / layout of the exchange buffer: `words_per_neuron` 32-bit words per neuron,
+ * neuron-major planes: plane j occupies [j*n_padded, (j+1)*n_padded); the local slice of each
+ * plane is [post_begin, post_end).  n_padded = shard_stride * n_shards. */
+int snn_exchange_buffer(snn_network_t *net, void **device_ptr, uint32_t *words_per_neuron,
+                        uint32_t *n_padded);
+/* HIP stream the handle launches on (hipStream_t), for ordering collectives against it */
+int snn_stream(snn_network_t *net, void **hip_stream);
+
+/* ---- histories (≙ LatticeHistoryGPU::add_from_gpu, gpu_lattices/mod.rs:215-280) -------- */
+
+int snn_history_steps(const snn_network_t *net, uint64_t *steps);
+/* [steps][rows*cols] of lattice `id`, oldest step first */
+int snn_get_voltage_history(snn_network_t *net, uint32_t id, float *dst, size_t count);
+int snn_get_spike_history(snn_network_t *net, uint32_t id, uint8_t *dst, size_t count);
+
+/* ---- measurement ----------------------------------------------------------------------- */
+
+/* When enabled, every launch of the synaptic-input kernel is bracketed by HIP events on the
+ * handle's stream; snn_profile_read returns the launch count and summed duration since the
+ * last snn_profile_reset. */
+int snn_profile_enable(snn_network_t *net, int enable);
+int snn_profile_reset(snn_network_t *net);
+int snn_profile_read(snn_network_t *net, uint64_t *launches, double *total_ms);
+/* Algorithmic bytes ONE launch of the synaptic-input kernel moves (DESIGN.md "Roofline") */
+int snn_input_kernel_bytes(const snn_network_t *net, uint64_t *bytes);
+
+/* ---- errors ----------------------------------------------------------------------------- */
+
+/* Message of the calling thread's last failing call ("" if none). */
+const char *snn_last_error(void);
+int snn_abi_version(void);
+
+/* ---- device-function probes (parity tests of the shared scalar formulas) ---------------- */
+
+/* out[i] = f(in[i]) evaluated ON THE GPU by the same device functions the stepper uses:
+ * which = 0 exp, 1 pow3, 2 pow4. */
+int snn_probe_math(int device, int which, const float *in, float *out, size_t count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SNN_AMD_H */

@@ -1,0 +1,505 @@
+/*
+ * oracle/snn_oracle.c -- TEST INFRASTRUCTURE ONLY.  See snn_oracle.h for scope,
+ * parity status and the canonical choices.  Every function cites the reference
+ * lines (relative to /root/reference/backend/src/) whose arithmetic it restates;
+ * f32 operation order is kept literally (build: -ffp-contract=off, no fast-math).
+ */
+#include "snn_oracle.h"
+#include "snn_oracle_math.h"
+
+#include <stddef.h>
+
+/* ---------- small helpers ---------- */
+
+/* f32::max / f32::min as Rust defines them: a NaN operand yields the other one. */
+static inline float o_max(float a, float b)
+{
+    if (a != a) return b;
+    if (b != b) return a;
+    return (a > b) ? a : b;
+}
+static inline float o_min(float a, float b)
+{
+    if (a != a) return b;
+    if (b != b) return a;
+    return (a < b) ? a : b;
+}
+static inline float o_abs(float x)
+{
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    u &= 0x7FFFFFFFu;
+    memcpy(&x, &u, 4);
+    return x;
+}
+
+/* spike_train/mod.rs:380-388 (the reference's GPU generator) */
+uint32_t snn_o_xorshift32(uint32_t seed)
+{
+    uint32_t x = seed;
+    x ^= x << 13;
+    x ^= x >> 17;
+    x ^= x << 5;
+    return x;
+}
+
+/* DeltaDiracRefractoriness::get_effect, spike_train/mod.rs:67-88:
+ *   a * ((-1. / (k / dt)) * time_difference.powf(2.)).exp() + v_resting
+ * powf(2.) is folded to x*x by LLVM without fast-math. */
+float snn_o_delta_dirac_effect(int64_t timestep, int32_t last_firing_time,
+                               float v_th, float v_resting, float k, float dt)
+{
+    float a = v_th - v_resting;
+    float td = (float)(timestep - (int64_t)last_firing_time);
+    return a * snn_o_expf((-1.0f / (k / dt)) * (td * td)) + v_resting;
+}
+
+/* STDP::update_weight, plasticity/mod.rs:45-66 (returns delta_w) */
+float snn_o_stdp_delta(int32_t t_pre, int32_t t_post, float a_plus, float a_minus,
+                       float tau_plus, float tau_minus, float dt)
+{
+    if (t_pre < 0 || t_post < 0) return 0.0f;          /* either side None */
+    float tp = (float)t_pre, tq = (float)t_post;
+    if (tp < tq)
+        return a_plus * snn_o_expf(-1.0f * o_abs((tp - tq) * dt) / tau_plus);
+    if (tp > tq)
+        return -1.0f * a_minus * snn_o_expf(-1.0f * o_abs((tq - tp) * dt) / tau_minus);
+    return 0.0f;
+}
+
+float snn_o_expf_export(float x) { return snn_o_expf(x); }
+float snn_o_pow3f_export(float x) { return snn_o_pow3f(x); }
+float snn_o_pow4f_export(float x) { return snn_o_pow4f(x); }
+
+/* ---------- synthetic data ---------- */
+
+/* splitmix64 finaliser over (seed, index); upper 32 bits */
+uint32_t snn_o_hash32(uint64_t seed, uint64_t index)
+{
+    uint64_t x = index + seed * 0x9E3779B97F4A7C15ull;
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 27; x *= 0x94D049BB133111EBull;
+    x ^= x >> 31;
+    return (uint32_t)(x >> 32);
+}
+
+float snn_o_uniform(uint64_t seed, uint64_t index, float lo, float hi)
+{
+    float u = (float)(snn_o_hash32(seed, index) >> 8) * (1.0f / 16777216.0f);  /* [0,1) exact */
+    return lo + (hi - lo) * u;
+}
+
+void snn_o_fill_graph(float *weights, uint8_t *connections, uint32_t n_tot, uint32_t n_neurons,
+                      uint64_t seed, float lo, float hi, int with_diagonal)
+{
+    for (uint32_t p = 0; p < n_tot; ++p)
+        for (uint32_t q = 0; q < n_neurons; ++q) {
+            size_t i = (size_t)p * n_neurons + q;
+            int c = with_diagonal || p != q;
+            connections[i] = (uint8_t)c;
+            weights[i] = c ? snn_o_uniform(seed, i, lo, hi) : 0.0f;
+        }
+}
+
+/* ---------- step 1: inputs ---------- */
+
+/*
+ * One postsynaptic neuron q.
+ *   electrical: Lattice::calculate_internal_electrical_input_from_positions  neuron/mod.rs:702-730
+ *               LatticeNetwork::calculate_electrical_input_from_positions    neuron/mod.rs:2115-2167
+ *               gap_junction mod.rs:54-60, spike_train_gap_junction mod.rs:119-137
+ *   chemical:   calculate_*_neurotransmitter_input_from_positions mod.rs:733-754 / 2169-2210,
+ *               weight_/aggregate_neurotransmitter_concentration(s) iterate_and_spike/mod.rs:2837-2866
+ */
+static void inputs_column(snn_o_net *n, uint32_t q)
+{
+    const uint32_t nn = n->n_neurons;
+    const uint32_t n_tot = nn + n->n_cells;
+    const float vq = n->current_voltage[q];
+    const float gq = n->gap_conductance[q];
+
+    float sum = 0.0f;
+    float tsum[SNN_O_K] = {0.0f, 0.0f, 0.0f};
+    uint32_t n_in = 0;
+    uint32_t tcnt[SNN_O_K] = {0, 0, 0};
+
+    for (uint32_t c0 = 0; c0 < n_tot; c0 += SNN_O_CHUNK) {
+        uint32_t c1 = c0 + SNN_O_CHUNK;
+        if (c1 > n_tot) c1 = n_tot;
+        float part = 0.0f;
+        float tpart[SNN_O_K] = {0.0f, 0.0f, 0.0f};
+
+        for (uint32_t p = c0; p < c1; ++p) {
+            size_t i = (size_t)p * nn + q;
+            if (!n->connections[i]) continue;
+            const float w = n->weights[i];
+            ++n_in;
+
+            if (n->electrical) {
+                float term;
+                if (p < nn) {
+                    term = gq * (n->current_voltage[p] - vq);
+                } else {
+                    uint32_t s = p - nn;
+                    if (n->st_last_firing_time[s] < 0)
+                        term = n->st_v_resting[s];         /* no conductance factor, mod.rs:126-128 */
+                    else
+                        term = gq * snn_o_delta_dirac_effect(n->clock, n->st_last_firing_time[s],
+                                                             n->st_v_th[s], n->st_v_resting[s],
+                                                             n->st_k[s], n->st_dt[s]);
+                }
+                part += term * w;
+            }
+            if (n->chemical) {
+                for (int k = 0; k < SNN_O_K; ++k) {
+                    uint32_t flag; float t;
+                    if (p < nn) { flag = n->nt_flags[(size_t)p * SNN_O_K + k]; t = n->nt_t[(size_t)p * SNN_O_K + k]; }
+                    else { uint32_t s = p - nn; flag = n->st_nt_flags[(size_t)s * SNN_O_K + k]; t = n->st_nt_t[(size_t)s * SNN_O_K + k]; }
+                    if (flag) { tpart[k] += t * w; ++tcnt[k]; }
+                }
+            }
+        }
+        sum += part;
+        for (int k = 0; k < SNN_O_K; ++k) tsum[k] += tpart[k];
+    }
+
+    if (n->electrical) {
+        float averager = (n_in == 0) ? 1.0f : (float)n_in;   /* mod.rs:722-727 */
+        n->input_current[q] = sum / averager;
+    } else {
+        n->input_current[q] = 0.0f;                          /* mod.rs:929-931 */
+    }
+    if (n->chemical) {
+        for (int k = 0; k < SNN_O_K; ++k) {
+            n->input_count[(size_t)q * SNN_O_K + k] = (float)tcnt[k];
+            n->input_t[(size_t)q * SNN_O_K + k] = tcnt[k] ? tsum[k] / (float)tcnt[k] : 0.0f;
+        }
+    }
+}
+
+void snn_o_inputs_range(snn_o_net *n, uint32_t q0, uint32_t q1)
+{
+#if defined(_OPENMP)
+    int nt = n->n_threads > 1 ? n->n_threads : 1;
+    #pragma omp parallel for schedule(static) num_threads(nt)
+#endif
+    for (int64_t q = q0; q < (int64_t)q1; ++q) inputs_column(n, (uint32_t)q);
+}
+
+void snn_o_inputs(snn_o_net *n) { snn_o_inputs_range(n, 0, n->n_neurons); }
+
+/* ---------- step 2: neuron update ---------- */
+
+/* NeurotransmitterKinetics::apply_t_change: Approximate iterate_and_spike/mod.rs:193-196,
+ * Destexhe :148-150.  `spiking` is what NeurotransmittersIntermediate carries
+ * (intermediate_delegate/mod.rs:17-23). */
+static inline float nt_apply(int kind, float t, float t_max, float clearance, float v_p, float k_p,
+                             float voltage, uint32_t spiking, float dt)
+{
+    if (kind == SNN_O_NT_DESTEXHE)
+        return t_max / (1.0f + snn_o_expf(-(voltage - v_p) / k_p));
+    t += dt * -clearance * t + ((spiking ? 1.0f : 0.0f) * t_max);
+    return o_min(t_max, o_max(t, 0.0f));
+}
+
+static inline void neuron_nt_update(snn_o_net *n, uint32_t q, float voltage, uint32_t spiking_prev)
+{
+    for (int k = 0; k < SNN_O_K; ++k) {
+        size_t i = (size_t)q * SNN_O_K + k;
+        if (!n->nt_flags || !n->nt_flags[i]) continue;
+        n->nt_t[i] = nt_apply(n->nt_kind, n->nt_t[i], n->nt_t_max[i],
+                              n->nt_clearance ? n->nt_clearance[i] : 0.0f,
+                              n->nt_v_p ? n->nt_v_p[i] : 0.0f, n->nt_k_p ? n->nt_k_p[i] : 1.0f,
+                              voltage, spiking_prev, n->dt[q]);
+    }
+}
+
+/* Ionotropic::update_receptor_kinetics + set_receptor_currents, iterate_and_spike/mod.rs:1186-1284;
+ * kinetics :404-406 (Destexhe) / :435-437 (Approximate); currents :1103-1105, 1132-1137, 1164-1166.
+ * A type absent from the aggregated input (count 0) leaves r untouched. */
+static inline void receptors_update(snn_o_net *n, uint32_t q, float v_old)
+{
+    const float dt = n->dt[q];
+    for (int k = 0; k < SNN_O_K; ++k) {
+        size_t i = (size_t)q * SNN_O_K + k;
+        if (!n->rc_flags[i]) continue;
+        if (n->input_count[i] != 0.0f) {
+            float t = n->input_t[i];
+            if (n->rc_kind == SNN_O_RC_DESTEXHE) {
+                float r = n->rc_r[i];
+                n->rc_r[i] = r + (n->rc_alpha[i] * t * (1.0f - r) - n->rc_beta[i] * r) * dt;
+            } else {
+                n->rc_r[i] = t;
+            }
+        }
+    }
+    for (int k = 0; k < SNN_O_K; ++k) {
+        size_t i = (size_t)q * SNN_O_K + k;
+        if (!n->rc_flags[i]) continue;
+        float r = n->rc_r[i];
+        if (k == 1) {   /* NMDA */
+            n->rc_current[i] = ((1.0f / (1.0f + ((snn_o_expf(-0.062f * v_old) * n->rc_mg[i]) / 3.75f))
+                                 * n->rc_g[i]) * r) * (v_old - n->rc_e[i]);
+        } else {
+            n->rc_current[i] = (n->rc_g[i] * r) * (v_old - n->rc_e[i]);
+        }
+    }
+}
+
+/* Ionotropic::get_receptor_currents, iterate_and_spike/mod.rs:1286-1304 */
+static inline float receptor_currents(const snn_o_net *n, uint32_t q)
+{
+    float total = 0.0f;
+    if (n->rc_flags) {
+        for (int k = 0; k < SNN_O_K; ++k) {
+            size_t i = (size_t)q * SNN_O_K + k;
+            if (n->rc_flags[i]) total += n->rc_current[i];
+        }
+    }
+    return total * (n->dt[q] / n->c_m[q]);
+}
+
+/* IzhikevichNeuron, integrate_and_fire/mod.rs:1222-1267 via impl_iterate_and_spike! :217-255 */
+static uint32_t step_izhikevich(snn_o_net *n, uint32_t q)
+{
+    const float v = n->current_voltage[q], w = n->w_value[q], dt = n->dt[q];
+    const float i = n->input_current[q];
+    const uint32_t spiking_prev = n->is_spiking[q];
+
+    if (n->chemical) receptors_update(n, q, v);
+
+    float dv = (0.04f * (v * v) + 5.0f * v + 140.0f - w + i) * (dt / n->c_m[q]);
+    float dw = (n->a[q] * (n->b[q] * v - w)) * (dt / n->tau_m[q]);
+
+    float v_new, w_new;
+    if (n->chemical) {
+        float neurotransmitter_dv = -receptor_currents(n, q);
+        v_new = v + (dv + neurotransmitter_dv);
+    } else {
+        v_new = v + dv;
+    }
+    w_new = w + dw;
+
+    neuron_nt_update(n, q, v_new, spiking_prev);
+
+    uint32_t spike = 0;
+    if (v_new >= n->v_th[q]) {
+        spike = 1;
+        v_new = n->c[q];
+        w_new += n->d[q];
+    }
+    n->current_voltage[q] = v_new;
+    n->w_value[q] = w_new;
+    return spike;
+}
+
+/* LeakyIntegrateAndFireNeuron, integrate_and_fire/mod.rs:173-215, handle_spiking :87-102 */
+static uint32_t step_lif(snn_o_net *n, uint32_t q)
+{
+    const float v = n->current_voltage[q], dt = n->dt[q];
+    const float i = n->input_current[q];
+    const uint32_t spiking_prev = n->is_spiking[q];
+
+    if (n->chemical) receptors_update(n, q, v);
+
+    float dv = ((n->leak_constant[q] * (v - n->e_l[q])) +
+                (n->integration_constant[q] * (i / n->g_l[q]))) * (dt / n->tau_m[q]);
+    float v_new;
+    if (n->chemical) {
+        float neurotransmitter_dv = -receptor_currents(n, q);
+        v_new = v + (dv + neurotransmitter_dv);
+    } else {
+        v_new = v + dv;
+    }
+
+    neuron_nt_update(n, q, v_new, spiking_prev);
+
+    uint32_t spike = 0;
+    float rc = n->refractory_count[q];
+    if (rc > 0.0f) {
+        v_new = n->v_reset[q];
+        rc -= 1.0f;
+    } else if (v_new >= n->v_th[q]) {
+        spike = 1;
+        v_new = n->v_reset[q];
+        rc = n->tref[q] / dt;
+    }
+    n->refractory_count[q] = rc;
+    n->current_voltage[q] = v_new;
+    return spike;
+}
+
+/* BasicGatingVariable::update, ion_channels/mod.rs:40-44 */
+static inline float gate_update(float state, float alpha, float beta, float dt)
+{
+    float alpha_state = alpha * (1.0f - state);
+    float beta_state = beta * state;
+    return state + dt * (alpha_state - beta_state);
+}
+
+/* HodgkinHuxleyNeuron, hodgkin_huxley/mod.rs:156-241; channels ion_channels/mod.rs:219-316 */
+static uint32_t step_hh(snn_o_net *n, uint32_t q)
+{
+    const float v = n->current_voltage[q], dt = n->dt[q];
+    const float i = n->input_current[q];
+    const uint32_t spiking_prev = n->is_spiking[q];
+
+    if (n->chemical) receptors_update(n, q, v);            /* update_receptors :176-179 */
+
+    /* update_gates :182-186, all at the old voltage */
+    float m_a = 0.1f * ((v + 40.0f) / (1.0f - snn_o_expf(-(v + 40.0f) / 10.0f)));
+    float m_b = 4.0f * snn_o_expf(-(v + 65.0f) / 18.0f);
+    float h_a = 0.07f * snn_o_expf(-(v + 65.0f) / 20.0f);
+    float h_b = 1.0f / (snn_o_expf(-(v + 35.0f) / 10.0f) + 1.0f);
+    float m = gate_update(n->m_state[q], m_a, m_b, dt);
+    float h = gate_update(n->h_state[q], h_a, h_b, dt);
+    float i_na = snn_o_pow3f(m) * h * n->g_na[q] * (v - n->e_na[q]);
+
+    float n_a = 0.01f * (v + 55.0f) / (1.0f - snn_o_expf(-(v + 55.0f) / 10.0f));
+    float n_b = 0.125f * snn_o_expf(-(v + 65.0f) / 80.0f);
+    float ng = gate_update(n->n_state[q], n_a, n_b, dt);
+    float i_k = snn_o_pow4f(ng) * n->g_k[q] * (v - n->e_k[q]);
+
+    float i_kl = n->g_k_leak[q] * (v - n->e_k_leak[q]);
+
+    n->m_alpha[q] = m_a; n->m_beta[q] = m_b; n->h_alpha[q] = h_a; n->h_beta[q] = h_b;
+    n->n_alpha[q] = n_a; n->n_beta[q] = n_b;
+    n->m_state[q] = m; n->h_state[q] = h; n->n_state[q] = ng;
+    n->na_current[q] = i_na; n->k_current[q] = i_k; n->k_leak_current[q] = i_kl;
+
+    /* update_cell_voltage :156-166 (stored receptor currents are used even when chemical is off) */
+    float i_ligand_gates = receptor_currents(n, q);
+    float i_sum = i - (i_na + i_k + i_kl);
+    float v_new = v + (dt * i_sum / n->c_m[q] - i_ligand_gates);
+
+    neuron_nt_update(n, q, v_new, spiking_prev);            /* :169-171 */
+
+    /* :207-220 */
+    uint32_t increasing_right_now = v < v_new;
+    uint32_t threshold_crossed = v_new > n->v_th[q];
+    uint32_t spike = threshold_crossed && n->was_increasing[q] && !increasing_right_now;
+    n->was_increasing[q] = increasing_right_now;
+    n->current_voltage[q] = v_new;
+    return spike;
+}
+
+/* Lattice::iterate* neuron/mod.rs:884-982, LatticeNetwork::iterate* :2420-2594 (neuron loop part) */
+void snn_o_update_neurons(snn_o_net *n)
+{
+    for (uint32_t q = 0; q < n->n_neurons; ++q) {
+        uint32_t spike;
+        switch (n->model) {
+        case SNN_O_LIF: spike = step_lif(n, q); break;
+        case SNN_O_HH:  spike = step_hh(n, q); break;
+        default:        spike = step_izhikevich(n, q); break;
+        }
+        n->is_spiking[q] = spike;
+        if (spike) n->last_firing_time[q] = (int32_t)n->clock;   /* mod.rs:964-966 / 2555-2557 */
+    }
+}
+
+/* ---------- step 3: plasticity (deferred form) ---------- */
+
+/*
+ * LatticeNetwork::update_weights_from_neurons_{across,within}_lattices, neuron/mod.rs:2308-2417,
+ * driven from :2573-2576; gating :2559-2562.  Every edge (p,q) incident to a gated spiking neuron
+ * receives `w += delta(lft[p], lft[q])` with the plasticity of q's lattice -- once as an incoming
+ * edge of q, once more as an outgoing edge of p when p is gated too (delta is 0 then: tp == tq).
+ */
+void snn_o_plasticity(snn_o_net *n)
+{
+    const uint32_t nn = n->n_neurons;
+    const uint32_t n_tot = nn + n->n_cells;
+    if (!n->do_plasticity) return;
+
+    for (uint32_t j = 0; j < nn; ++j) {
+        if (!(n->is_spiking[j] && n->do_plasticity[n->lattice[j]])) continue;
+        /* incoming edges of j */
+        {
+            uint32_t l = n->lattice[j];
+            for (uint32_t p = 0; p < n_tot; ++p) {
+                size_t i = (size_t)p * nn + j;
+                if (!n->connections[i]) continue;
+                int32_t tp = (p < nn) ? n->last_firing_time[p] : n->st_last_firing_time[p - nn];
+                n->weights[i] += snn_o_stdp_delta(tp, n->last_firing_time[j], n->stdp_a_plus[l],
+                                                  n->stdp_a_minus[l], n->stdp_tau_plus[l],
+                                                  n->stdp_tau_minus[l], n->stdp_dt[l]);
+            }
+        }
+        /* outgoing edges of j */
+        for (uint32_t r = 0; r < nn; ++r) {
+            size_t i = (size_t)j * nn + r;
+            if (!n->connections[i]) continue;
+            uint32_t l = n->lattice[r];
+            n->weights[i] += snn_o_stdp_delta(n->last_firing_time[j], n->last_firing_time[r],
+                                              n->stdp_a_plus[l], n->stdp_a_minus[l],
+                                              n->stdp_tau_plus[l], n->stdp_tau_minus[l], n->stdp_dt[l]);
+        }
+    }
+}
+
+/* ---------- step 6: spike trains ---------- */
+
+/* SpikeTrainLattice::iterate neuron/mod.rs:1377-1393; PoissonNeuron (GPU form) spike_train/mod.rs:411-435;
+ * RateSpikeTrain::iterate spike_train/mod.rs:1016-1031 */
+void snn_o_spike_trains(snn_o_net *n)
+{
+    for (uint32_t s = 0; s < n->n_cells; ++s) {
+        uint32_t spike;
+        if (n->st_kind == SNN_O_ST_POISSON) {
+            uint32_t new_seed = snn_o_xorshift32(n->st_seed[s]);
+            n->st_seed[s] = new_seed;
+            float random_number = (float)new_seed / 4294967296.0f;   /* (float)seed / 0xFFFFFFFF */
+            spike = random_number < n->st_chance_of_firing[s];
+        } else {
+            float step = n->st_step[s] + n->st_dt[s];
+            spike = (n->st_rate[s] != 0.0f) && (step >= n->st_rate[s]);
+            if (spike) step = 0.0f;
+            n->st_step[s] = step;
+        }
+        float v = spike ? n->st_v_th[s] : n->st_v_resting[s];
+        n->st_current_voltage[s] = v;
+        n->st_is_spiking[s] = spike;
+        if (n->st_nt_flags) {
+            for (int k = 0; k < SNN_O_K; ++k) {
+                size_t i = (size_t)s * SNN_O_K + k;
+                if (!n->st_nt_flags[i]) continue;
+                n->st_nt_t[i] = nt_apply(n->nt_kind, n->st_nt_t[i], n->st_nt_t_max[i],
+                                         n->st_nt_clearance ? n->st_nt_clearance[i] : 0.0f,
+                                         n->st_nt_v_p ? n->st_nt_v_p[i] : 0.0f,
+                                         n->st_nt_k_p ? n->st_nt_k_p[i] : 1.0f,
+                                         v, spike, n->st_dt[s]);
+            }
+        }
+        if (spike) n->st_last_firing_time[s] = (int32_t)n->st_clock[n->st_lattice[s]];
+    }
+    for (uint32_t l = 0; l < n->n_st_lattices; ++l) n->st_clock[l] += 1;
+}
+
+/* ---------- whole loop ---------- */
+
+/* run_lattice_* neuron/mod.rs:1035-1088, run_lattices_* :2598-2651; (false,false) is a no-op :1217 */
+void snn_o_run(snn_o_net *n, uint64_t iterations)
+{
+    if (!n->electrical && !n->chemical) return;
+    for (uint64_t it = 0; it < iterations; ++it) {
+        if (n->n_neurons) {
+            snn_o_inputs(n);
+            snn_o_update_neurons(n);
+            snn_o_plasticity(n);
+            if (n->voltage_history)
+                memcpy(n->voltage_history + (size_t)it * n->n_neurons, n->current_voltage,
+                       sizeof(float) * n->n_neurons);
+            if (n->spike_history)
+                for (uint32_t q = 0; q < n->n_neurons; ++q)
+                    n->spike_history[(size_t)it * n->n_neurons + q] = (uint8_t)n->is_spiking[q];
+        }
+        n->clock += 1;
+        if (n->n_cells) {
+            snn_o_spike_trains(n);
+            if (n->st_voltage_history)
+                memcpy(n->st_voltage_history + (size_t)it * n->n_cells, n->st_current_voltage,
+                       sizeof(float) * n->n_cells);
+        }
+    }
+}

@@ -1,0 +1,164 @@
+/*
+ * oracle/snn_oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement (plain C99) of the reference's lattice time-stepper hot
+ * path, NikhilMukraj/spiking-neural-networks `backend` crate:
+ *   RunLattice::run_lattice      backend/src/neuron/mod.rs:1199-1220
+ *   RunNetwork::run_lattices     backend/src/neuron/mod.rs:2654-2675
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library; the product (spiking-neural-networks_amd/) never does.
+ *
+ * PARITY STATUS -- bit level: UNPINNED BY THE REFERENCE.  The reference is a
+ * Rust crate (no rustc/cargo in this image), holds no golden vectors, seeds
+ * every test from thread_rng, and sums synaptic inputs in HashSet iteration
+ * order (mod.rs:710-720), i.e. its own CPU results are not bit-reproducible
+ * run to run.  What IS pinned (tests/test_oracle_reference_pins.py): the
+ * reference's known-answer tests for this path -- RateSpikeTrain spike
+ * positions/counts (backend/tests/rate_spike_train.rs:28-72), AdjacencyMatrix
+ * None-vs-Some semantics (graph/mod.rs:113-137), zero-size no-ops
+ * (tests/size_zero_cases.rs), Poisson->neuron spike-count behaviour
+ * (tests/spike_train_neuron_interaction.rs:91-203), interleaved index
+ * placement (tests/interleaving_graph_conversion.rs) -- plus hand-derived
+ * single-step values of every formula cited below.
+ *
+ * Canonical choices where the reference leaves the result unspecified
+ * (DESIGN.md "Canonical semantics"):
+ *  - synaptic sums: presynaptic index space cut into chunks of SNN_O_CHUNK
+ *    consecutive indices; inside a chunk strictly ascending sequential f32
+ *    adds starting from 0.0f; chunk partials then added in ascending chunk
+ *    order starting from 0.0f.
+ *  - plasticity: the deferred (LatticeNetwork) form for single lattices too
+ *    (mod.rs:2573-2576); the inline single-Lattice form (mod.rs:968-970)
+ *    depends on a randomised HashSet order.
+ *  - Poisson spike trains: the reference's GPU generator (xorshift32,
+ *    spike_train/mod.rs:380-388, 411-435) with explicit seeds; the CPU form
+ *    draws from an unseedable thread_rng (spike_train/mod.rs:354).
+ *  - exp / powf: see snn_oracle_math.h.
+ *
+ * Index space: neurons of all lattices first (ascending lattice id, row-major
+ * inside a lattice), spike-train cells after them -- the interleaved order of
+ * InterleavingGraphGPU, backend/src/graph/mod.rs:668-727.  Spike-train cells
+ * are never postsynaptic (mod.rs:1852-1854), so the weight matrix is stored
+ * n_tot rows (pre) x n_neurons columns (post), row-major.
+ */
+#ifndef SNN_ORACLE_H
+#define SNN_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SNN_O_K      3     /* AMPA=0, NMDA=1, GABA=2  (iterate_and_spike/mod.rs:1323-1333) */
+#define SNN_O_CHUNK  256   /* canonical reduction chunk (presynaptic indices) */
+
+enum { SNN_O_IZHIKEVICH = 0, SNN_O_LIF = 1, SNN_O_HH = 2 };
+enum { SNN_O_NT_APPROX = 0, SNN_O_NT_DESTEXHE = 1 };
+enum { SNN_O_RC_APPROX = 0, SNN_O_RC_DESTEXHE = 1 };
+enum { SNN_O_ST_NONE = 0, SNN_O_ST_POISSON = 1, SNN_O_ST_RATE = 2 };
+
+typedef struct snn_o_net {
+    /* ---- sizes / switches ---- */
+    uint32_t n_neurons;      /* postsynaptic-capable cells */
+    uint32_t n_cells;        /* spike-train cells (presynaptic only) */
+    int32_t  model;          /* SNN_O_IZHIKEVICH | LIF | HH */
+    int32_t  nt_kind;        /* neurotransmitter kinetics of neurons AND cells */
+    int32_t  rc_kind;        /* receptor kinetics */
+    int32_t  st_kind;        /* spike-train model */
+    int32_t  electrical;     /* electrical_synapse  mod.rs:574 */
+    int32_t  chemical;       /* chemical_synapse    mod.rs:576 */
+    int64_t  clock;          /* internal_clock      mod.rs:586 */
+
+    /* ---- neuron SoA, length n_neurons (names = reference struct fields) ---- */
+    float    *current_voltage, *gap_conductance, *dt, *c_m, *v_th;
+    uint32_t *is_spiking;
+    int32_t  *last_firing_time;            /* -1 == None */
+    /* Izhikevich (integrate_and_fire/mod.rs:1159-1194); tau_m shared with LIF */
+    float    *w_value, *a, *b, *c, *d, *tau_m;
+    /* LIF (integrate_and_fire/mod.rs:108-147) */
+    float    *v_reset, *refractory_count, *tref, *leak_constant,
+             *integration_constant, *e_l, *g_l;
+    /* Hodgkin-Huxley (hodgkin_huxley/mod.rs:49-79, ion_channels/mod.rs) */
+    float    *m_state, *h_state, *n_state;      /* na_channel.m/h, k_channel.n */
+    float    *m_alpha, *m_beta, *h_alpha, *h_beta, *n_alpha, *n_beta;
+    float    *g_na, *e_na, *g_k, *e_k, *g_k_leak, *e_k_leak;
+    float    *na_current, *k_current, *k_leak_current;
+    uint32_t *was_increasing;
+
+    /* ---- neurotransmitters of neurons, [n_neurons * K], index n*K+k ---- */
+    float    *nt_t, *nt_t_max, *nt_clearance, *nt_v_p, *nt_k_p;
+    uint32_t *nt_flags;
+    /* ---- receptors of neurons, [n_neurons * K] (mg: only k=NMDA is read) ---- */
+    float    *rc_g, *rc_e, *rc_mg, *rc_r, *rc_alpha, *rc_beta, *rc_current;
+    uint32_t *rc_flags;
+
+    /* ---- spike-train cells, length n_cells ---- */
+    float    *st_current_voltage, *st_v_th, *st_v_resting, *st_dt, *st_k;
+    float    *st_chance_of_firing;         /* Poisson */
+    float    *st_rate, *st_step;           /* Rate    */
+    uint32_t *st_seed;                     /* Poisson xorshift32 state */
+    uint32_t *st_is_spiking;
+    int32_t  *st_last_firing_time;
+    float    *st_nt_t, *st_nt_t_max, *st_nt_clearance, *st_nt_v_p, *st_nt_k_p; /* [n_cells*K] */
+    uint32_t *st_nt_flags;
+    uint32_t *st_lattice;                  /* [n_cells] -> spike-train lattice slot */
+    uint32_t n_st_lattices;
+    int64_t  *st_clock;                    /* [n_st_lattices] own internal clocks mod.rs:1391 */
+
+    /* ---- graph: dense, row-major [n_tot][n_neurons]; conn==0 <=> None ---- */
+    float    *weights;
+    uint8_t  *connections;
+
+    /* ---- lattices (plasticity is per lattice, mod.rs:578-580) ---- */
+    uint32_t *lattice;                     /* [n_neurons] -> lattice slot */
+    uint32_t n_lattices;
+    float    *stdp_a_plus, *stdp_a_minus, *stdp_tau_plus, *stdp_tau_minus, *stdp_dt; /* [n_lattices] */
+    uint32_t *do_plasticity;               /* [n_lattices] */
+
+    /* ---- optional per-step outputs (NULL = off) ---- */
+    float    *voltage_history;             /* [iterations][n_neurons]  GridVoltageHistory */
+    uint8_t  *spike_history;               /* [iterations][n_neurons]  SpikeHistory */
+    float    *st_voltage_history;          /* [iterations][n_cells] */
+
+    /* ---- scratch supplied by the caller ---- */
+    float    *input_current;               /* [n_neurons] */
+    float    *input_t;                     /* [n_neurons*K] */
+    float    *input_count;                 /* [n_neurons*K] (#pres that carry type k) */
+    int32_t  n_threads;                    /* >1: OpenMP over postsynaptic neurons (≙ rayon par_, mod.rs:775-790) */
+} snn_o_net;
+
+/* Step 1 of SURVEY §8(g): electrical + chemical inputs for every neuron from state S(t). */
+void snn_o_inputs(snn_o_net *net);
+/* Same, restricted to postsynaptic columns [q0, q1) (bounded CPU-baseline sample / column checks). */
+void snn_o_inputs_range(snn_o_net *net, uint32_t q0, uint32_t q1);
+/* Step 2: advance every neuron once with the inputs in net->input_*; stamps last_firing_time. */
+void snn_o_update_neurons(snn_o_net *net);
+/* Step 3: deferred STDP for every neuron that spiked in this step. */
+void snn_o_plasticity(snn_o_net *net);
+/* Step 6: iterate every spike-train cell once. */
+void snn_o_spike_trains(snn_o_net *net);
+/* Whole loop (steps 1-6) `iterations` times, filling the optional histories. */
+void snn_o_run(snn_o_net *net, uint64_t iterations);
+
+/* Single-formula entry points (known-answer tests, GPU device-function parity). */
+float snn_o_expf_export(float x);
+float snn_o_pow3f_export(float x);
+float snn_o_pow4f_export(float x);
+float snn_o_stdp_delta(int32_t t_pre, int32_t t_post, float a_plus, float a_minus,
+                       float tau_plus, float tau_minus, float dt);
+float snn_o_delta_dirac_effect(int64_t timestep, int32_t last_firing_time,
+                               float v_th, float v_resting, float k, float dt);
+uint32_t snn_o_xorshift32(uint32_t seed);
+
+/* Synthetic data shared by tests and bench: counter-based, order independent. */
+uint32_t snn_o_hash32(uint64_t seed, uint64_t index);
+float    snn_o_uniform(uint64_t seed, uint64_t index, float lo, float hi);
+/* weights[p][q] = U[lo,hi) from (seed, p*n_neurons+q); conn = (p != q) unless with_diagonal */
+void snn_o_fill_graph(float *weights, uint8_t *connections, uint32_t n_tot, uint32_t n_neurons,
+                      uint64_t seed, float lo, float hi, int with_diagonal);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SNN_ORACLE_H */

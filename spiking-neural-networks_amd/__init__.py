@@ -1,0 +1,15 @@
+"""MI355X-native spiking-lattice time-stepper (host side, Python).
+
+One hot path of NikhilMukraj/spiking-neural-networks -- `run_lattice` / `run_lattices`
+(backend/src/neuron/mod.rs:1199-1220, 2654-2675) -- as hand-written HIP kernels for gfx950
+behind the C ABI of include/snn_amd.h.  The directory name carries a hyphen, so import it
+through the root-level shim: `import snn_amd`.
+"""
+from . import _lib
+from ._lib import SnnError, SnnLibraryError, build
+from .network import (DeviceNetwork, HODGKIN_HUXLEY, IZHIKEVICH, LIF, NT_APPROXIMATE, NT_DESTEXHE,
+                      NUM_NT_TYPES, RC_APPROXIMATE, RC_DESTEXHE, ST_NONE, ST_POISSON, ST_RATE, probe_math)
+
+__all__ = ["DeviceNetwork", "SnnError", "SnnLibraryError", "build", "probe_math",
+           "IZHIKEVICH", "LIF", "HODGKIN_HUXLEY", "NT_APPROXIMATE", "NT_DESTEXHE",
+           "RC_APPROXIMATE", "RC_DESTEXHE", "ST_NONE", "ST_POISSON", "ST_RATE", "NUM_NT_TYPES"]

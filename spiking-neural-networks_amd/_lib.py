@@ -1,0 +1,126 @@
+"""ctypes binding of the C ABI declared in include/snn_amd.h.
+
+The shared library is built in-tree (csrc/libsnn_amd.so) by `build()` below or by
+`__graft_entry__.build()`.  There is NO CPU fallback: if the library is missing or
+does not load, importing callers get a loud `SnnLibraryError`.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libsnn_amd.so")
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "snn_amd.h")
+
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+               "-Wall", "-Wno-unused-result", "-Wno-pass-failed"]
+
+
+class SnnLibraryError(RuntimeError):
+    pass
+
+
+class SnnError(RuntimeError):
+    """A failing C-ABI call; `.code` is the snn_status (1..8 mirror the reference's GPUError)."""
+
+    def __init__(self, code, message):
+        super().__init__(f"snn_amd error {code}: {message}")
+        self.code = code
+
+
+def build(force=False):
+    """Compile every HIP source for gfx950 into csrc/libsnn_amd.so (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".hpp"))]
+    srcs.append(HEADER)
+    if not force and os.path.exists(LIB_PATH):
+        if os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(s) for s in srcs):
+            return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIB_PATH, os.path.join(CSRC, "snn_network.hip")]
+    subprocess.run(cmd, check=True, cwd=CSRC)
+    return LIB_PATH
+
+
+f32p = C.POINTER(C.c_float)
+u32p = C.POINTER(C.c_uint32)
+i32p = C.POINTER(C.c_int32)
+u8p = C.POINTER(C.c_uint8)
+u64p = C.POINTER(C.c_uint64)
+H = C.c_void_p   # snn_network_t*
+
+# name -> (restype, argtypes); kept in one place so tests can check it against the header
+SIGNATURES = {
+    "snn_abi_version": (C.c_int, []),
+    "snn_last_error": (C.c_char_p, []),
+    "snn_network_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(H)]),
+    "snn_network_destroy": (C.c_int, [H]),
+    "snn_network_add_lattice": (C.c_int, [H, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "snn_network_add_spike_train_lattice": (C.c_int, [H, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "snn_network_finalize": (C.c_int, [H]),
+    "snn_network_finalize_shard": (C.c_int, [H, C.c_uint32, C.c_uint32]),
+    "snn_network_sizes": (C.c_int, [H, u32p, u32p, u32p, u32p]),
+    "snn_network_lattice_range": (C.c_int, [H, C.c_uint32, u32p, u32p]),
+    "snn_set_attr_f32": (C.c_int, [H, C.c_uint32, C.c_char_p, f32p, C.c_size_t]),
+    "snn_get_attr_f32": (C.c_int, [H, C.c_uint32, C.c_char_p, f32p, C.c_size_t]),
+    "snn_set_attr_u32": (C.c_int, [H, C.c_uint32, C.c_char_p, u32p, C.c_size_t]),
+    "snn_get_attr_u32": (C.c_int, [H, C.c_uint32, C.c_char_p, u32p, C.c_size_t]),
+    "snn_set_attr_i32": (C.c_int, [H, C.c_uint32, C.c_char_p, i32p, C.c_size_t]),
+    "snn_get_attr_i32": (C.c_int, [H, C.c_uint32, C.c_char_p, i32p, C.c_size_t]),
+    "snn_set_graph_dense": (C.c_int, [H, f32p, u32p, C.c_size_t]),
+    "snn_get_graph_dense": (C.c_int, [H, f32p, u32p, C.c_size_t]),
+    "snn_set_graph_rows": (C.c_int, [H, C.c_uint32, C.c_uint32, f32p, u32p]),
+    "snn_get_graph_rows": (C.c_int, [H, C.c_uint32, C.c_uint32, f32p, u32p]),
+    "snn_fill_graph_synthetic": (C.c_int, [H, C.c_uint64, C.c_float, C.c_float, C.c_int]),
+    "snn_set_synapses": (C.c_int, [H, C.c_int, C.c_int]),
+    "snn_set_plasticity": (C.c_int, [H, C.c_uint32] + [C.c_float] * 5 + [C.c_int]),
+    "snn_set_history": (C.c_int, [H, C.c_int, C.c_int]),
+    "snn_reset_history": (C.c_int, [H]),
+    "snn_get_clock": (C.c_int, [H, u64p]),
+    "snn_reset_timing": (C.c_int, [H]),
+    "snn_run": (C.c_int, [H, C.c_uint64]),
+    "snn_step_begin": (C.c_int, [H]),
+    "snn_step_end": (C.c_int, [H]),
+    "snn_exchange_buffer": (C.c_int, [H, C.POINTER(C.c_void_p), u32p, u32p]),
+    "snn_stream": (C.c_int, [H, C.POINTER(C.c_void_p)]),
+    "snn_history_steps": (C.c_int, [H, u64p]),
+    "snn_get_voltage_history": (C.c_int, [H, C.c_uint32, f32p, C.c_size_t]),
+    "snn_get_spike_history": (C.c_int, [H, C.c_uint32, u8p, C.c_size_t]),
+    "snn_profile_enable": (C.c_int, [H, C.c_int]),
+    "snn_profile_reset": (C.c_int, [H]),
+    "snn_profile_read": (C.c_int, [H, u64p, C.POINTER(C.c_double)]),
+    "snn_input_kernel_bytes": (C.c_int, [H, u64p]),
+    "snn_probe_math": (C.c_int, [C.c_int, C.c_int, f32p, f32p, C.c_size_t]),
+}
+
+_lib = None
+
+
+def load():
+    """Load csrc/libsnn_amd.so and declare every entry point; raises SnnLibraryError if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SnnLibraryError(
+            f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(the stepper has no CPU fallback)")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:
+        raise SnnLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise SnnLibraryError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code):
+    if code != 0:
+        msg = load().snn_last_error()
+        raise SnnError(code, msg.decode("utf-8", "replace") if msg else "")

@@ -1,0 +1,223 @@
+// Everything around the two hot kernels: graph import/export (NaN-sentinel fusion of the
+// reference's weights f32[N^2] + connections u32[N^2], graph/mod.rs:310-333, 729-770), the
+// device-side synthetic graph, spike-train cells (neuron/spike_train/mod.rs:411-435, 1016-1031;
+// SpikeTrainLattice::iterate neuron/mod.rs:1377-1393), wave-ballot spike compaction and the STDP
+// column/row updates (neuron/plasticity/mod.rs:45-66 driven as neuron/mod.rs:2308-2417, 2573-2576).
+#pragma once
+#include "snn_layout.hpp"
+#include "snn_math.hpp"
+
+namespace snn {
+
+__device__ __forceinline__ float quiet_nan() { return __int_as_float(0x7FC00000); }
+
+// ---- generic fills -------------------------------------------------------------------------
+__global__ void k_fill_f32(float *p, size_t n, float v)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+__global__ void k_fill_u32(uint32_t *p, size_t n, uint32_t v)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+__global__ void k_iota_u32(uint32_t *p, size_t n, uint32_t first)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = first + (uint32_t)i;
+}
+
+// ---- graph import / export ----------------------------------------------------------------
+// src rows are `src_ld` wide and hold GLOBAL postsynaptic columns; the handle keeps columns
+// [q0, q0+n_loc).  Rows [row0, row0+rows) of W are written; padding columns get the sentinel.
+__global__ void k_graph_import(float *W, uint32_t ld, uint32_t n_loc, uint32_t q0, uint32_t row0, uint32_t rows,
+                               const float *src_w, const uint32_t *src_c, size_t src_ld)
+{
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t r = blockIdx.y;
+    if (q >= ld || r >= rows) return;
+    float out = quiet_nan();
+    if (q < n_loc) {
+        const size_t i = (size_t)r * src_ld + q0 + q;
+        if (src_c[i] != 0) out = src_w[i];
+    }
+    W[(size_t)(row0 + r) * ld + q] = out;
+}
+
+// inverse: absent edges export as weight 0 / connection 0 (graph/mod.rs:310-320)
+__global__ void k_graph_export(const float *W, uint32_t ld, uint32_t n_loc, uint32_t q0, uint32_t row0, uint32_t rows,
+                               float *dst_w, uint32_t *dst_c, size_t dst_ld)
+{
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t r = blockIdx.y;
+    if (q >= n_loc || r >= rows) return;
+    const float w = W[(size_t)(row0 + r) * ld + q];
+    const size_t i = (size_t)r * dst_ld + q0 + q;
+    const bool edge = (w == w);
+    dst_w[i] = edge ? w : 0.0f;
+    dst_c[i] = edge ? 1u : 0u;
+}
+
+__global__ void k_graph_synthetic(float *W, uint32_t ld, uint32_t n_loc, uint32_t q0, uint32_t n_neurons,
+                                  uint32_t n_tot, uint64_t seed, float lo, float hi, int with_diagonal)
+{
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= ld) return;
+    for (uint32_t p = blockIdx.y; p < n_tot; p += gridDim.y) {
+        float out = quiet_nan();
+        if (q < n_loc) {
+            const uint32_t gq = q0 + q;
+            if (with_diagonal || p != gq) out = uniform_from_hash(seed, (uint64_t)p * n_neurons + gq, lo, hi);
+        }
+        W[(size_t)p * ld + q] = out;
+    }
+}
+
+// ---- spike-train cells ---------------------------------------------------------------------
+struct SpikeTrainArgs {
+    CellArrays c;
+    uint32_t n_cells;
+    int st_kind;            // 1 Poisson (xorshift32), 2 Rate
+    int nt_kind;
+    int iterate;            // 0: only refresh presyn_value for `view_clock`
+    const long long *lattice_clock;   // [n_st_lattices] clocks at the start of this run call
+    long long step_offset;            // steps done since then
+    long long view_clock;             // network clock of the NEXT input calculation
+    float *vhist_row;                 // [c_pad] or null
+};
+
+__global__ __launch_bounds__(256) void k_spike_trains(const SpikeTrainArgs a)
+{
+    const uint32_t s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= a.n_cells) return;
+    const CellArrays &c = a.c;
+    if (a.iterate) {
+        uint32_t spike;
+        if (a.st_kind == 1) {
+            const uint32_t new_seed = xorshift32(c.seed[s]);
+            c.seed[s] = new_seed;
+            const float random_number = (float)new_seed / 4294967296.0f;   // (float) seed / 0xFFFFFFFF
+            spike = random_number < c.chance_of_firing[s];
+        } else {
+            float step = c.step[s] + c.dt[s];
+            spike = (c.rate[s] != 0.0f) && (step >= c.rate[s]);
+            if (spike) step = 0.0f;
+            c.step[s] = step;
+        }
+        const float v = spike ? c.v_th[s] : c.v_resting[s];
+        c.current_voltage[s] = v;
+        c.is_spiking[s] = spike;
+#pragma unroll
+        for (int k = 0; k < K_TYPES; ++k) {
+            const size_t i = (size_t)k * c.c_pad + s;
+            if (!c.nt_flags[i]) continue;
+            // spike trains release on their CURRENT spike flag (spike_train/mod.rs:363-365)
+            float t = c.nt_t[i];
+            if (a.nt_kind == 1) {
+                t = c.nt_t_max[i] / (1.0f + expf_portable(-(v - c.nt_v_p[i]) / c.nt_k_p[i]));
+            } else {
+                t += c.dt[s] * -c.nt_clearance[i] * t + ((spike ? 1.0f : 0.0f) * c.nt_t_max[i]);
+                t = min_rs(c.nt_t_max[i], max_rs(t, 0.0f));
+            }
+            c.nt_t[i] = t;
+        }
+        if (spike) c.last_firing_time[s] = (int32_t)(a.lattice_clock[c.lattice_slot[s]] + a.step_offset);
+        if (a.vhist_row) a.vhist_row[s] = v;
+    }
+    // presynaptic value of the next input calculation (spike_train_gap_junction, neuron/mod.rs:119-137):
+    // never fired -> v_resting (used WITHOUT the conductance factor), else the refractoriness effect
+    const int32_t lft = c.last_firing_time[s];
+    c.presyn_value[s] = (lft < 0) ? c.v_resting[s]
+                                  : delta_dirac_effect(a.view_clock, lft, c.v_th[s], c.v_resting[s], c.k[s], c.dt[s]);
+}
+
+// ---- plasticity ------------------------------------------------------------------------------
+struct StdpArgs {
+    float *W;
+    uint32_t ld, n_loc, q0, n_neurons, n_tot;
+    const float *xbuf;
+    XLayout xl;
+    const int32_t *last_firing_time;      // neurons (all shards, replicated)
+    const int32_t *st_last_firing_time;   // cells
+    const uint32_t *lattice_slot;         // [n_pad] neuron -> lattice slot
+    const float *stdp;                    // [n_lattices][5]: a_plus, a_minus, tau_plus, tau_minus, dt
+    const uint32_t *do_plasticity;        // [n_lattices]
+    uint32_t *spike_list;                 // compacted gated spiking neurons (global indices)
+    uint32_t *spike_count;
+};
+
+// Wave-ballot + popcount prefix compaction of the neurons that spiked in this step and whose
+// lattice has do_plasticity set (the reference's positions_to_update, neuron/mod.rs:2544-2563).
+__global__ __launch_bounds__(256) void k_spike_compact(const StdpArgs a)
+{
+    const uint32_t q = blockIdx.x * 256 + threadIdx.x;
+    bool hit = false;
+    if (q < a.n_neurons) {
+        const uint32_t spk = reinterpret_cast<const uint32_t *>(a.xbuf)[a.xl.at(q, PLANE_SPIKE)];
+        hit = spk && a.do_plasticity[a.lattice_slot[q]];
+    }
+    const unsigned long long mask = __ballot(hit);
+    if (mask == 0) return;
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(a.spike_count, (uint32_t)__popcll(mask));
+    base = __shfl(base, 0, 64);
+    if (hit) {
+        const uint32_t prefix = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        a.spike_list[base + prefix] = q;
+    }
+}
+
+// incoming edges of every listed neuron that is local: column j, one thread per presynaptic row
+__global__ __launch_bounds__(256) void k_stdp_columns(const StdpArgs a)
+{
+    const uint32_t count = *a.spike_count;
+    const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= a.n_tot) return;
+    const int32_t tp = (p < a.n_neurons) ? a.last_firing_time[p] : a.st_last_firing_time[p - a.n_neurons];
+    for (uint32_t s = blockIdx.y; s < count; s += gridDim.y) {
+        const uint32_t j = a.spike_list[s];
+        if (j < a.q0 || j >= a.q0 + a.n_loc) continue;
+        float *wp = a.W + (size_t)p * a.ld + (j - a.q0);
+        const float w = *wp;
+        if (w == w) {
+            const float *prm = a.stdp + 5 * a.lattice_slot[j];
+            *wp = w + stdp_delta(tp, a.last_firing_time[j], prm[0], prm[1], prm[2], prm[3], prm[4]);
+        }
+    }
+}
+
+// outgoing edges of every listed neuron: row j, one thread per local postsynaptic column
+__global__ __launch_bounds__(256) void k_stdp_rows(const StdpArgs a)
+{
+    const uint32_t count = *a.spike_count;
+    const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= a.n_loc) return;
+    const uint32_t gr = a.q0 + r;
+    const int32_t tr = a.last_firing_time[gr];
+    const float *prm = a.stdp + 5 * a.lattice_slot[gr];
+    for (uint32_t s = blockIdx.y; s < count; s += gridDim.y) {
+        const uint32_t j = a.spike_list[s];
+        float *wp = a.W + (size_t)j * a.ld + r;
+        const float w = *wp;
+        if (w == w) *wp = w + stdp_delta(a.last_firing_time[j], tr, prm[0], prm[1], prm[2], prm[3], prm[4]);
+    }
+}
+
+// last_firing_time of REMOTE neurons from the gathered spike plane (sharded handles only)
+__global__ void k_stamp_remote(const float *xbuf, XLayout xl, int32_t *last_firing_time, uint32_t n_neurons,
+                               uint32_t q0, uint32_t n_loc, long long clock)
+{
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n_neurons || (q >= q0 && q < q0 + n_loc)) return;
+    if (reinterpret_cast<const uint32_t *>(xbuf)[xl.at(q, PLANE_SPIKE)]) last_firing_time[q] = (int32_t)clock;
+}
+
+// device-function probe for the parity tests of the scalar formulas
+__global__ void k_probe_math(int which, const float *in, float *out, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = in[i];
+    out[i] = which == 0 ? expf_portable(x) : (which == 1 ? pow3f_portable(x) : pow4f_portable(x));
+}
+
+} // namespace snn

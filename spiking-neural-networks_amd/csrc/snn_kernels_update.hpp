@@ -1,0 +1,225 @@
+// k_update<MODEL> -- one thread per local neuron: fixed-order combine of the chunk partials,
+// averaging, receptor kinetics + currents, the model's Euler step, the neuron's own
+// neurotransmitter release, spike test / reset, last_firing_time stamp, spike-raster ballot and the
+// optional voltage-history store, all in one launch.  It supersedes the reference's per-model
+// iterate kernels plus set_last_firing_time and add_grid_voltage_history
+// (neuron/gpu_lattices/mod.rs:141-155, 282-296; integrate_and_fire/mod.rs:379-416, 633-694) and
+// provides what the reference GPU path lacks: Izhikevich, LIF and Hodgkin-Huxley steps of the
+// backend structs (integrate_and_fire/mod.rs:173-255, 1222-1267; hodgkin_huxley/mod.rs:156-241;
+// ion_channels/mod.rs:40-44, 219-316).
+//
+// Step order per neuron = SURVEY §8(g) step 2; every expression keeps the reference's f32
+// operation order (no FMA contraction in this TU).
+#pragma once
+#include "snn_layout.hpp"
+#include "snn_math.hpp"
+
+namespace snn {
+
+struct UpdateArgs {
+    NeuronArrays n;
+    const float *part_i;       // [n_chunks][ld]
+    const float *part_t;       // [3][n_chunks][ld]
+    const uint32_t *n_in;      // [ld]
+    const uint32_t *tcount;    // [3][ld]
+    uint32_t ld, n_chunks, q0, n_loc;
+    long long clock;
+    int electrical, chemical, nt_kind, rc_kind;
+    float *vhist_row;          // this step's row of the voltage history (global neuron index) or null
+    unsigned long long *spike_row;   // this step's row of the bit-packed raster or null
+};
+
+// NeurotransmitterKinetics::apply_t_change: Approximate iterate_and_spike/mod.rs:193-196,
+// Destexhe :148-150
+__device__ __forceinline__ float nt_apply(int kind, float t, float t_max, float clearance, float v_p,
+                                          float k_p, float voltage, uint32_t spiking, float dt)
+{
+    if (kind == 1) return t_max / (1.0f + expf_portable(-(voltage - v_p) / k_p));
+    t += dt * -clearance * t + ((spiking ? 1.0f : 0.0f) * t_max);
+    return min_rs(t_max, max_rs(t, 0.0f));
+}
+
+__device__ __forceinline__ void neuron_nt_update(const UpdateArgs &a, uint32_t q, float voltage,
+                                                 uint32_t spiking_prev, float dt)
+{
+#pragma unroll
+    for (int k = 0; k < K_TYPES; ++k) {
+        const size_t i = (size_t)k * a.n.n_pad + q;
+        if (!a.n.nt_flags[i]) continue;
+        float *tp = a.n.xbuf + a.n.xl.at(q, PLANE_T0 + k);
+        *tp = nt_apply(a.nt_kind, *tp, a.n.nt_t_max[i], a.n.nt_clearance[i], a.n.nt_v_p[i],
+                       a.n.nt_k_p[i], voltage, spiking_prev, dt);
+    }
+}
+
+// Ionotropic::update_receptor_kinetics + set_receptor_currents (iterate_and_spike/mod.rs:1186-1284)
+__device__ __forceinline__ void receptors_update(const UpdateArgs &a, uint32_t q, uint32_t ql,
+                                                 float v_old, float dt)
+{
+#pragma unroll
+    for (int k = 0; k < K_TYPES; ++k) {
+        const size_t i = (size_t)k * a.n.n_pad + q;
+        if (!a.n.rc_flags[i]) continue;
+        const uint32_t cnt = a.tcount[(size_t)k * a.ld + ql];
+        if (cnt != 0) {
+            // second level of the canonical sum, then the per-type average
+            float s = 0.0f;
+            const float *pt = a.part_t + (size_t)k * a.n_chunks * a.ld + ql;
+            for (uint32_t c = 0; c < a.n_chunks; ++c) s += pt[(size_t)c * a.ld];
+            const float t = s / (float)cnt;
+            if (a.rc_kind == 1) {
+                const float r = a.n.rc_r[i];
+                a.n.rc_r[i] = r + (a.n.rc_alpha[i] * t * (1.0f - r) - a.n.rc_beta[i] * r) * dt;
+            } else {
+                a.n.rc_r[i] = t;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < K_TYPES; ++k) {
+        const size_t i = (size_t)k * a.n.n_pad + q;
+        if (!a.n.rc_flags[i]) continue;
+        const float r = a.n.rc_r[i];
+        if (k == 1) {
+            a.n.rc_current[i] = ((1.0f / (1.0f + ((expf_portable(-0.062f * v_old) * a.n.rc_mg[i]) / 3.75f))
+                                  * a.n.rc_g[i]) * r) * (v_old - a.n.rc_e[i]);
+        } else {
+            a.n.rc_current[i] = (a.n.rc_g[i] * r) * (v_old - a.n.rc_e[i]);
+        }
+    }
+}
+
+// Ionotropic::get_receptor_currents (iterate_and_spike/mod.rs:1286-1304)
+__device__ __forceinline__ float receptor_currents(const UpdateArgs &a, uint32_t q, float dt, float c_m)
+{
+    float total = 0.0f;
+#pragma unroll
+    for (int k = 0; k < K_TYPES; ++k) {
+        const size_t i = (size_t)k * a.n.n_pad + q;
+        if (a.n.rc_flags[i]) total += a.n.rc_current[i];
+    }
+    return total * (dt / c_m);
+}
+
+__device__ __forceinline__ float gate_update(float state, float alpha, float beta, float dt)
+{
+    const float alpha_state = alpha * (1.0f - state);
+    const float beta_state = beta * state;
+    return state + dt * (alpha_state - beta_state);
+}
+
+template <int MODEL>
+__global__ __launch_bounds__(256) void k_update(const UpdateArgs a)
+{
+    const uint32_t ql = blockIdx.x * 256 + threadIdx.x;
+    const bool active = ql < a.n_loc;
+    uint32_t spike = 0;
+
+    if (active) {
+        const uint32_t q = a.q0 + ql;
+        float *vptr = a.n.xbuf + a.n.xl.at(q, PLANE_V);
+        uint32_t *sptr = reinterpret_cast<uint32_t *>(a.n.xbuf) + a.n.xl.at(q, PLANE_SPIKE);
+        const float v = *vptr;
+        const float dt = a.n.dt[q];
+        const float c_m = a.n.c_m[q];
+        const uint32_t spiking_prev = *sptr;
+
+        // input current: chunk partials in ascending order, then the averager (neuron/mod.rs:722-729)
+        float i_in = 0.0f;
+        if (a.electrical) {
+            float s = 0.0f;
+            const float *pi = a.part_i + ql;
+            for (uint32_t c = 0; c < a.n_chunks; ++c) s += pi[(size_t)c * a.ld];
+            const uint32_t cnt = a.n_in[ql];
+            i_in = s / (cnt == 0 ? 1.0f : (float)cnt);
+        }
+
+        if (a.chemical) receptors_update(a, q, ql, v, dt);
+
+        float v_new;
+        if (MODEL == 0) {            // Izhikevich
+            const float w = a.n.w_value[q];
+            const float dv = (0.04f * (v * v) + 5.0f * v + 140.0f - w + i_in) * (dt / c_m);
+            const float dw = (a.n.a[q] * (a.n.b[q] * v - w)) * (dt / a.n.tau_m[q]);
+            if (a.chemical) {
+                const float neurotransmitter_dv = -receptor_currents(a, q, dt, c_m);
+                v_new = v + (dv + neurotransmitter_dv);
+            } else {
+                v_new = v + dv;
+            }
+            float w_new = w + dw;
+            neuron_nt_update(a, q, v_new, spiking_prev, dt);
+            if (v_new >= a.n.v_th[q]) {
+                spike = 1;
+                v_new = a.n.c[q];
+                w_new += a.n.d[q];
+            }
+            a.n.w_value[q] = w_new;
+        } else if (MODEL == 1) {     // leaky integrate-and-fire
+            const float dv = ((a.n.leak_constant[q] * (v - a.n.e_l[q])) +
+                              (a.n.integration_constant[q] * (i_in / a.n.g_l[q]))) * (dt / a.n.tau_m[q]);
+            if (a.chemical) {
+                const float neurotransmitter_dv = -receptor_currents(a, q, dt, c_m);
+                v_new = v + (dv + neurotransmitter_dv);
+            } else {
+                v_new = v + dv;
+            }
+            neuron_nt_update(a, q, v_new, spiking_prev, dt);
+            float rc = a.n.refractory_count[q];
+            if (rc > 0.0f) {
+                v_new = a.n.v_reset[q];
+                rc -= 1.0f;
+            } else if (v_new >= a.n.v_th[q]) {
+                spike = 1;
+                v_new = a.n.v_reset[q];
+                rc = a.n.tref[q] / dt;
+            }
+            a.n.refractory_count[q] = rc;
+        } else {                     // Hodgkin-Huxley
+            const float m_a = 0.1f * ((v + 40.0f) / (1.0f - expf_portable(-(v + 40.0f) / 10.0f)));
+            const float m_b = 4.0f * expf_portable(-(v + 65.0f) / 18.0f);
+            const float h_a = 0.07f * expf_portable(-(v + 65.0f) / 20.0f);
+            const float h_b = 1.0f / (expf_portable(-(v + 35.0f) / 10.0f) + 1.0f);
+            const float m = gate_update(a.n.m_state[q], m_a, m_b, dt);
+            const float h = gate_update(a.n.h_state[q], h_a, h_b, dt);
+            const float i_na = pow3f_portable(m) * h * a.n.g_na[q] * (v - a.n.e_na[q]);
+
+            const float n_a = 0.01f * (v + 55.0f) / (1.0f - expf_portable(-(v + 55.0f) / 10.0f));
+            const float n_b = 0.125f * expf_portable(-(v + 65.0f) / 80.0f);
+            const float ng = gate_update(a.n.n_state[q], n_a, n_b, dt);
+            const float i_k = pow4f_portable(ng) * a.n.g_k[q] * (v - a.n.e_k[q]);
+
+            const float i_kl = a.n.g_k_leak[q] * (v - a.n.e_k_leak[q]);
+
+            a.n.m_alpha[q] = m_a; a.n.m_beta[q] = m_b; a.n.h_alpha[q] = h_a; a.n.h_beta[q] = h_b;
+            a.n.n_alpha[q] = n_a; a.n.n_beta[q] = n_b;
+            a.n.m_state[q] = m; a.n.h_state[q] = h; a.n.n_state[q] = ng;
+            a.n.na_current[q] = i_na; a.n.k_current[q] = i_k; a.n.k_leak_current[q] = i_kl;
+
+            const float i_ligand_gates = receptor_currents(a, q, dt, c_m);
+            const float i_sum = i_in - (i_na + i_k + i_kl);
+            v_new = v + (dt * i_sum / c_m - i_ligand_gates);
+
+            neuron_nt_update(a, q, v_new, spiking_prev, dt);
+
+            const uint32_t increasing_right_now = v < v_new;
+            const uint32_t threshold_crossed = v_new > a.n.v_th[q];
+            spike = threshold_crossed && a.n.was_increasing[q] && !increasing_right_now;
+            a.n.was_increasing[q] = increasing_right_now;
+        }
+
+        *vptr = v_new;
+        *sptr = spike;
+        if (spike) a.n.last_firing_time[q] = (int32_t)a.clock;   // neuron/mod.rs:964-966, 2555-2557
+        if (a.vhist_row) a.vhist_row[q] = v_new;
+    }
+
+    // spike raster: one 64-bit ballot word per wavefront (shard boundaries are multiples of 64)
+    if (a.spike_row) {
+        const unsigned long long word = __ballot(spike != 0);
+        if ((threadIdx.x & 63) == 0 && (blockIdx.x * 256 + threadIdx.x) < a.ld)
+            a.spike_row[(a.q0 + ql) >> 6] = word;
+    }
+}
+
+} // namespace snn

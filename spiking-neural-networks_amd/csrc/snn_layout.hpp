@@ -1,0 +1,81 @@
+// Device-memory layout shared by the kernels and the host-side handle.
+//
+// HBM layout (per handle = per GPU):
+//   W        dense synapse matrix of the local postsynaptic shard, row-major
+//            [n_tot rows (presynaptic, interleaved index)][ld floats], ld = round_up(n_local, 64).
+//            An absent edge (None in the reference's Vec<Vec<Option<f32>>>, graph/mod.rs:139-150)
+//            is stored as a quiet NaN, so `connections` needs no second matrix and the averager
+//            count n_in[post] is precomputed once per graph upload.  4 B per synapse, read once
+//            per step.
+//   xbuf     the state every rank needs of every neuron ("exchanged planes"), blocked by shard:
+//            [shard][plane][stride] 32-bit words; planes: 0 current_voltage (f32),
+//            1 is_spiking (u32), 2..4 neurotransmitter concentration t of type AMPA/NMDA/GABA.
+//            One in-place all-gather of contiguous per-shard blocks refreshes it each step.
+//   SoA      one array per reference struct field, length n_neurons padded to 256; per-type
+//            attributes are stored type-major [3][n_pad] so that lanes = consecutive neurons
+//            stay coalesced.
+//   partials [n_chunks][ld] f32 per accumulated quantity: the fixed-order two-level sum.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace snn {
+
+constexpr int K_TYPES = 3;
+constexpr int CHUNK = 256;        // canonical reduction chunk (SNN_REDUCTION_CHUNK)
+constexpr int TILE_POSTS = 1024;  // postsynaptic columns per workgroup: 4 waves x 64 lanes x float4
+constexpr int NUM_PLANES = 5;
+enum Plane { PLANE_V = 0, PLANE_SPIKE = 1, PLANE_T0 = 2 };
+
+// Exchanged-plane addressing: global neuron index -> word offset inside xbuf.
+struct XLayout {
+    uint32_t stride;       // neurons per shard slot (multiple of 64)
+    uint32_t n_shards;
+    __host__ __device__ __forceinline__ size_t at(uint32_t neuron, int plane) const
+    {
+        const uint32_t shard = neuron / stride;
+        const uint32_t i = neuron - shard * stride;
+        return ((size_t)shard * NUM_PLANES + plane) * stride + i;
+    }
+};
+
+// Pointers the per-neuron update kernels need.  All arrays are device memory.
+struct NeuronArrays {
+    // exchanged planes
+    float *xbuf;
+    XLayout xl;
+    // common
+    float *gap_conductance, *dt, *c_m, *v_th;
+    int32_t *last_firing_time;
+    // Izhikevich / LIF
+    float *w_value, *a, *b, *c, *d, *tau_m;
+    float *v_reset, *refractory_count, *tref, *leak_constant, *integration_constant, *e_l, *g_l;
+    // Hodgkin-Huxley
+    float *m_state, *h_state, *n_state;
+    float *m_alpha, *m_beta, *h_alpha, *h_beta, *n_alpha, *n_beta;
+    float *g_na, *e_na, *g_k, *e_k, *g_k_leak, *e_k_leak;
+    float *na_current, *k_current, *k_leak_current;
+    uint32_t *was_increasing;
+    // neurotransmitters [3][n_pad] (t lives in xbuf planes 2..4)
+    float *nt_t_max, *nt_clearance, *nt_v_p, *nt_k_p;
+    uint32_t *nt_flags;
+    // receptors [3][n_pad]
+    float *rc_g, *rc_e, *rc_mg, *rc_r, *rc_alpha, *rc_beta, *rc_current;
+    uint32_t *rc_flags;
+    uint32_t n_pad;
+};
+
+// Spike-train cells (presynaptic only), length n_cells padded to 256.
+struct CellArrays {
+    float *current_voltage, *v_th, *v_resting, *dt, *k;
+    float *chance_of_firing, *rate, *step;
+    uint32_t *seed, *is_spiking;
+    int32_t *last_firing_time;
+    float *nt_t, *nt_t_max, *nt_clearance, *nt_v_p, *nt_k_p;   // [3][c_pad]
+    uint32_t *nt_flags;
+    uint32_t *lattice_slot;     // [c_pad] -> spike-train lattice slot
+    float *presyn_value;        // per-step presynaptic gap-junction value (see k_spike_train_view)
+    uint32_t c_pad;
+};
+
+} // namespace snn

@@ -1,0 +1,126 @@
+// Device-side scalar math of the lattice stepper (gfx950).
+//
+// The reference evaluates f32::exp / f32::powf through the platform libm
+// (backend/src/neuron/ion_channels/mod.rs:224-228,234,270-271,280;
+//  iterate_and_spike/mod.rs:149,1133; plasticity/mod.rs:52-54;
+//  spike_train/mod.rs:85).  ocml's expf/powf are not bit-compatible with any CPU
+// libm, so the stepper carries its own exp: range reduction by ln2, a degree-13
+// Taylor polynomial by Horner's rule in binary64 with plain v_mul_f64/v_add_f64
+// (this translation unit is compiled with -ffp-contract=off: no FMA anywhere),
+// one rounding to binary32.  MI355X issues FP64 vector ops at half the FP32 rate,
+// and the stepper is HBM-bound, so the f64 polynomial is free in practice.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace snn {
+
+__device__ __forceinline__ float expf_portable(float x)
+{
+    if (!(x == x)) return x;
+    if (x > 89.0f) return __builtin_inff();
+    if (x < -104.0f) return 0.0f;
+
+    const double inv_ln2 = 1.4426950408889634;
+    const double ln2_hi = 6.93147180369123816490e-01;
+    const double ln2_lo = 1.90821492927058770002e-10;
+    const double shift = 6755399441055744.0;   // 1.5 * 2^52
+
+    const double xd = (double)x;
+    const double kd = (xd * inv_ln2 + shift) - shift;
+    const double r = (xd - kd * ln2_hi) - kd * ln2_lo;
+
+    double p = 1.6059043836821613e-10;
+    p = p * r + 2.08767569878681e-09;
+    p = p * r + 2.505210838544172e-08;
+    p = p * r + 2.755731922398589e-07;
+    p = p * r + 2.7557319223985893e-06;
+    p = p * r + 2.48015873015873e-05;
+    p = p * r + 1.984126984126984e-04;
+    p = p * r + 1.388888888888889e-03;
+    p = p * r + 8.333333333333333e-03;
+    p = p * r + 4.1666666666666664e-02;
+    p = p * r + 1.6666666666666666e-01;
+    p = p * r + 0.5;
+    p = p * r + 1.0;
+    p = p * r + 1.0;
+
+    const int k = (int)kd;   // |k| <= 151
+    const double scale = __longlong_as_double((long long)(k + 1023) << 52);
+    return (float)(p * scale);
+}
+
+// powf(x, 3.) / powf(x, 4.) of the Na / K channel currents (ion_channels/mod.rs:234, 280):
+// exact square in binary64, one rounding each.
+__device__ __forceinline__ float pow3f_portable(float x)
+{
+    const double d = (double)x;
+    return (float)((d * d) * d);
+}
+__device__ __forceinline__ float pow4f_portable(float x)
+{
+    const double d = (double)x;
+    const double d2 = d * d;
+    return (float)(d2 * d2);
+}
+
+// f32::max / f32::min as Rust defines them (a NaN operand yields the other one)
+__device__ __forceinline__ float max_rs(float a, float b)
+{
+    if (a != a) return b;
+    if (b != b) return a;
+    return (a > b) ? a : b;
+}
+__device__ __forceinline__ float min_rs(float a, float b)
+{
+    if (a != a) return b;
+    if (b != b) return a;
+    return (a < b) ? a : b;
+}
+
+// xorshift32 of the reference's Poisson kernel (spike_train/mod.rs:380-388)
+__device__ __forceinline__ uint32_t xorshift32(uint32_t x)
+{
+    x ^= x << 13;
+    x ^= x >> 17;
+    x ^= x << 5;
+    return x;
+}
+
+// DeltaDiracRefractoriness::get_effect (spike_train/mod.rs:67-88)
+__device__ __forceinline__ float delta_dirac_effect(long long timestep, int last_firing_time,
+                                                    float v_th, float v_resting, float k, float dt)
+{
+    const float a = v_th - v_resting;
+    const float td = (float)(timestep - (long long)last_firing_time);
+    return a * expf_portable((-1.0f / (k / dt)) * (td * td)) + v_resting;
+}
+
+// STDP::update_weight (plasticity/mod.rs:45-66): the delta added to the weight
+__device__ __forceinline__ float stdp_delta(int t_pre, int t_post, float a_plus, float a_minus,
+                                            float tau_plus, float tau_minus, float dt)
+{
+    if (t_pre < 0 || t_post < 0) return 0.0f;
+    const float tp = (float)t_pre, tq = (float)t_post;
+    if (tp < tq) return a_plus * expf_portable(-1.0f * __builtin_fabsf((tp - tq) * dt) / tau_plus);
+    if (tp > tq) return -1.0f * a_minus * expf_portable(-1.0f * __builtin_fabsf((tq - tp) * dt) / tau_minus);
+    return 0.0f;
+}
+
+// Counter-based synthetic data (splitmix64 finaliser), used by the device-side
+// graph / state generators so that benchmark-size inputs never cross PCIe.
+__host__ __device__ __forceinline__ uint32_t hash32(uint64_t seed, uint64_t index)
+{
+    uint64_t x = index + seed * 0x9E3779B97F4A7C15ull;
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 27; x *= 0x94D049BB133111EBull;
+    x ^= x >> 31;
+    return (uint32_t)(x >> 32);
+}
+__host__ __device__ __forceinline__ float uniform_from_hash(uint64_t seed, uint64_t index, float lo, float hi)
+{
+    const float u = (float)(hash32(seed, index) >> 8) * (1.0f / 16777216.0f);
+    return lo + (hi - lo) * u;
+}
+
+} // namespace snn

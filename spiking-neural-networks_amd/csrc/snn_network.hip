@@ -1,0 +1,1136 @@
+// C ABI of the MI355X-native spiking-lattice stepper (include/snn_amd.h).
+// Host side of the handle: index space, device allocations, attribute registry (the reference's
+// HashMap<String, BufferGPU> of IterateAndSpikeGPU::convert_to_gpu, neuron/iterate_and_spike/
+// mod.rs:3156-3189), graph import/export, the step loop of run_lattice / run_lattices
+// (neuron/gpu_lattices/mod.rs:791-896, 2284-2583) and histories.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/snn_amd.h"
+#include "snn_kernels_inputs.hpp"
+#include "snn_kernels_misc.hpp"
+#include "snn_kernels_update.hpp"
+#include "snn_layout.hpp"
+
+using namespace snn;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string &msg)
+{
+    g_last_error = msg;
+    return code;
+}
+
+#define HIP_TRY(expr, code)                                                                      \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return fail((code), std::string(#expr) + ": " + hipGetErrorString(e_));              \
+    } while (0)
+
+inline uint32_t round_up(uint32_t x, uint32_t m) { return (x + m - 1) / m * m; }
+
+enum AttrType { T_F32 = 0, T_U32 = 1, T_I32 = 2 };
+enum AttrStore { S_PLAIN = 0, S_PLAIN_K = 1, S_XPLANE = 2, S_XPLANE_K = 3 };
+
+struct Attr {
+    AttrType type;
+    AttrStore store;
+    void *base;        // S_PLAIN / S_PLAIN_K: device array; planes: unused
+    int plane;         // S_XPLANE / S_XPLANE_K
+    uint32_t pad;      // stride between types for S_PLAIN_K
+    int dirties;       // 1: invalidates the static per-column counts
+};
+
+struct LatticeInfo {
+    uint32_t id, rows, cols, first, count, slot;
+    bool spike_train;
+};
+
+} // namespace
+
+struct snn_network {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int model = 0, nt_kind = 0, rc_kind = 0, st_kind = 0;
+    bool finalized = false;
+    int electrical = 1, chemical = 0;
+    long long clock = 0;
+
+    std::vector<LatticeInfo> lattices;      // neuron lattices, ascending id after finalize
+    std::vector<LatticeInfo> st_lattices;   // spike-train lattices
+    std::vector<long long> st_clock;        // own clocks of the spike-train lattices
+    std::vector<float> stdp_host;           // [n_lattices][5]
+    std::vector<uint32_t> plast_host;       // [n_lattices]
+    bool any_plasticity = false;
+
+    uint32_t nn = 0, nc = 0, n_tot = 0, n_pad = 0, c_pad = 0;
+    uint32_t q0 = 0, q1 = 0, n_loc = 0, ld = 0, n_chunks = 0;
+    XLayout xl{0, 1};
+
+    std::vector<void *> allocs;
+    float *W = nullptr;
+    float *xbuf = nullptr;
+    float *part_i = nullptr, *part_t = nullptr;
+    uint32_t *n_in = nullptr, *tcount = nullptr;
+    bool counts_dirty = true;
+    NeuronArrays na{};
+    CellArrays ca{};
+    uint32_t *lattice_slot = nullptr;
+    float *stdp_dev = nullptr;
+    uint32_t *plast_dev = nullptr;
+    uint32_t *spike_list = nullptr, *spike_count = nullptr;
+    long long *st_clock_dev = nullptr;
+    long long run_step_offset = 0;
+
+    std::map<std::string, Attr> neuron_attrs, cell_attrs;
+
+    // histories
+    int want_vhist = 0, want_raster = 0;
+    uint64_t hist_steps = 0, hist_cap = 0;
+    float *vhist = nullptr, *st_vhist = nullptr;
+    unsigned long long *raster = nullptr;
+
+    // profiling of the synaptic-input kernel
+    int profile = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    size_t ev_used = 0;
+    uint64_t prof_launches = 0;
+    double prof_ms = 0.0;
+};
+
+namespace {
+
+int dev_alloc(snn_network *net, void **out, size_t bytes)
+{
+    *out = nullptr;
+    if (bytes == 0) bytes = 256;
+    HIP_TRY(hipMalloc(out, bytes), SNN_ERR_BUFFER_CREATE);
+    net->allocs.push_back(*out);
+    return SNN_OK;
+}
+
+template <typename T>
+int dev_alloc_t(snn_network *net, T **out, size_t count)
+{
+    return dev_alloc(net, reinterpret_cast<void **>(out), count * sizeof(T));
+}
+
+int fill_f32(snn_network *net, float *p, size_t n, float v)
+{
+    if (n == 0) return SNN_OK;
+    const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_fill_f32, dim3(blocks), dim3(256), 0, net->stream, p, n, v);
+    HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+    return SNN_OK;
+}
+int fill_u32(snn_network *net, uint32_t *p, size_t n, uint32_t v)
+{
+    if (n == 0) return SNN_OK;
+    const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_fill_u32, dim3(blocks), dim3(256), 0, net->stream, p, n, v);
+    HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+    return SNN_OK;
+}
+
+const LatticeInfo *find_lattice(const snn_network *net, uint32_t id)
+{
+    for (const auto &l : net->lattices) if (l.id == id) return &l;
+    for (const auto &l : net->st_lattices) if (l.id == id) return &l;
+    return nullptr;
+}
+
+void reg(std::map<std::string, Attr> &m, const char *name, AttrType t, AttrStore s, void *base, int plane,
+         uint32_t pad, int dirties = 0)
+{
+    m[name] = Attr{t, s, base, plane, pad, dirties};
+}
+
+// Allocate one f32 per-neuron array, fill with `def`, register under `name`.
+int neuron_f32(snn_network *net, float **field, const char *name, float def)
+{
+    int rc = dev_alloc_t(net, field, net->n_pad);
+    if (rc) return rc;
+    rc = fill_f32(net, *field, net->n_pad, def);
+    if (rc) return rc;
+    if (name) reg(net->neuron_attrs, name, T_F32, S_PLAIN, *field, 0, 0);
+    return SNN_OK;
+}
+int cell_f32(snn_network *net, float **field, const char *name, float def)
+{
+    int rc = dev_alloc_t(net, field, net->c_pad);
+    if (rc) return rc;
+    rc = fill_f32(net, *field, net->c_pad, def);
+    if (rc) return rc;
+    if (name) reg(net->cell_attrs, name, T_F32, S_PLAIN, *field, 0, 0);
+    return SNN_OK;
+}
+// [3][pad] block with per-type defaults
+int typed_f32(snn_network *net, float **field, uint32_t pad, float d0, float d1, float d2)
+{
+    int rc = dev_alloc_t(net, field, (size_t)K_TYPES * pad);
+    if (rc) return rc;
+    const float d[3] = {d0, d1, d2};
+    for (int k = 0; k < K_TYPES; ++k) {
+        rc = fill_f32(net, *field + (size_t)k * pad, pad, d[k]);
+        if (rc) return rc;
+    }
+    return SNN_OK;
+}
+
+#define TRY(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
+
+int build_state(snn_network *net)
+{
+    NeuronArrays &n = net->na;
+    CellArrays &c = net->ca;
+    const uint32_t np = net->n_pad, cp = net->c_pad;
+    auto &A = net->neuron_attrs;
+    auto &CA = net->cell_attrs;
+
+    // exchanged planes
+    TRY(dev_alloc_t(net, &net->xbuf, (size_t)net->xl.n_shards * NUM_PLANES * net->xl.stride));
+    HIP_TRY(hipMemsetAsync(net->xbuf, 0, (size_t)net->xl.n_shards * NUM_PLANES * net->xl.stride * 4, net->stream),
+            SNN_ERR_BUFFER_WRITE);
+    n.xbuf = net->xbuf;
+    n.xl = net->xl;
+    n.n_pad = np;
+    reg(A, "current_voltage", T_F32, S_XPLANE, nullptr, PLANE_V, 0);
+    reg(A, "is_spiking", T_U32, S_XPLANE, nullptr, PLANE_SPIKE, 0);
+    reg(A, "neurotransmitters$t", T_F32, S_XPLANE_K, nullptr, PLANE_T0, 0);
+
+    // reference defaults: Izhikevich integrate_and_fire/mod.rs:1198-1220, LIF :149-171,
+    // Hodgkin-Huxley hodgkin_huxley/mod.rs:80-98 + ion_channels/mod.rs:23-31, 205-215, 255-264, 299-307
+    const bool izh = net->model == SNN_MODEL_IZHIKEVICH, lif = net->model == SNN_MODEL_LIF;
+    const float v0 = lif ? -75.0f : -65.0f;
+    {
+        // initial voltage into plane V of every shard slot
+        for (uint32_t s = 0; s < net->xl.n_shards; ++s)
+            TRY(fill_f32(net, net->xbuf + ((size_t)s * NUM_PLANES + PLANE_V) * net->xl.stride, net->xl.stride, v0));
+    }
+    TRY(neuron_f32(net, &n.gap_conductance, "gap_conductance", 7.0f));
+    TRY(neuron_f32(net, &n.dt, "dt", net->model == SNN_MODEL_HODGKIN_HUXLEY ? 0.01f : 0.1f));
+    TRY(neuron_f32(net, &n.c_m, "c_m", net->model == SNN_MODEL_HODGKIN_HUXLEY ? 1.0f : 100.0f));
+    TRY(neuron_f32(net, &n.v_th, "v_th", izh ? 30.0f : (lif ? -55.0f : 0.0f)));
+    TRY(dev_alloc_t(net, &n.last_firing_time, np));
+    HIP_TRY(hipMemsetAsync(n.last_firing_time, 0xFF, (size_t)np * 4, net->stream), SNN_ERR_BUFFER_WRITE);
+    reg(A, "last_firing_time", T_I32, S_PLAIN, n.last_firing_time, 0, 0);
+
+    TRY(neuron_f32(net, &n.w_value, izh ? "w_value" : nullptr, 30.0f));
+    TRY(neuron_f32(net, &n.a, izh ? "a" : nullptr, 0.02f));
+    TRY(neuron_f32(net, &n.b, izh ? "b" : nullptr, 0.2f));
+    TRY(neuron_f32(net, &n.c, izh ? "c" : nullptr, -55.0f));
+    TRY(neuron_f32(net, &n.d, izh ? "d" : nullptr, 8.0f));
+    TRY(neuron_f32(net, &n.tau_m, (izh || lif) ? "tau_m" : nullptr, izh ? 1.0f : 10.0f));
+
+    TRY(neuron_f32(net, &n.v_reset, lif ? "v_reset" : nullptr, -75.0f));
+    TRY(neuron_f32(net, &n.refractory_count, lif ? "refractory_count" : nullptr, 0.0f));
+    TRY(neuron_f32(net, &n.tref, lif ? "tref" : nullptr, 10.0f));
+    TRY(neuron_f32(net, &n.leak_constant, lif ? "leak_constant" : nullptr, -1.0f));
+    TRY(neuron_f32(net, &n.integration_constant, lif ? "integration_constant" : nullptr, 1.0f));
+    TRY(neuron_f32(net, &n.e_l, lif ? "e_l" : nullptr, -75.0f));
+    TRY(neuron_f32(net, &n.g_l, lif ? "g_l" : nullptr, 10.0f));
+
+    const bool hh = net->model == SNN_MODEL_HODGKIN_HUXLEY;
+    TRY(neuron_f32(net, &n.m_state, hh ? "na_channel$m$state" : nullptr, 0.0f));
+    TRY(neuron_f32(net, &n.h_state, hh ? "na_channel$h$state" : nullptr, 0.0f));
+    TRY(neuron_f32(net, &n.n_state, hh ? "k_channel$n$state" : nullptr, 0.0f));
+    TRY(neuron_f32(net, &n.m_alpha, hh ? "na_channel$m$alpha" : nullptr, 0.0f));
+    TRY(neuron_f32(net, &n.m_beta, hh ? "na_channel$m$beta" : nullptr, 0.0f));
+    TRY(neuron_f32(net, &n.h_alpha, hh ? "na_channel$h$alpha" : nullptr, 0.0f));
+    TRY(neuron_f32(net, &n.h_beta, hh ? "na_channel$h$beta" : nullptr, 0.0f));
+    TRY(neuron_f32(net, &n.n_alpha, hh ? "k_channel$n$alpha" : nullptr, 0.0f));
+    TRY(neuron_f32(net, &n.n_beta, hh ? "k_channel$n$beta" : nullptr, 0.0f));
+    TRY(neuron_f32(net, &n.g_na, hh ? "na_channel$g_na" : nullptr, 120.0f));
+    TRY(neuron_f32(net, &n.e_na, hh ? "na_channel$e_na" : nullptr, 50.0f));
+    TRY(neuron_f32(net, &n.g_k, hh ? "k_channel$g_k" : nullptr, 36.0f));
+    TRY(neuron_f32(net, &n.e_k, hh ? "k_channel$e_k" : nullptr, -77.0f));
+    TRY(neuron_f32(net, &n.g_k_leak, hh ? "k_leak_channel$g_k_leak" : nullptr, 0.3f));
+    TRY(neuron_f32(net, &n.e_k_leak, hh ? "k_leak_channel$e_k_leak" : nullptr, -55.0f));
+    TRY(neuron_f32(net, &n.na_current, hh ? "na_channel$current" : nullptr, 0.0f));
+    TRY(neuron_f32(net, &n.k_current, hh ? "k_channel$current" : nullptr, 0.0f));
+    TRY(neuron_f32(net, &n.k_leak_current, hh ? "k_leak_channel$current" : nullptr, 0.0f));
+    TRY(dev_alloc_t(net, &n.was_increasing, np));
+    TRY(fill_u32(net, n.was_increasing, np, 0));
+    if (hh) reg(A, "was_increasing", T_U32, S_PLAIN, n.was_increasing, 0, 0);
+
+    // neurotransmitters (iterate_and_spike/mod.rs:136-145, 174-182) -- absent by default (flags 0)
+    TRY(typed_f32(net, &n.nt_t_max, np, 1.0f, 1.0f, 1.0f));
+    TRY(typed_f32(net, &n.nt_clearance, np, 0.01f, 0.01f, 0.01f));
+    TRY(typed_f32(net, &n.nt_v_p, np, 2.0f, 2.0f, 2.0f));
+    TRY(typed_f32(net, &n.nt_k_p, np, 5.0f, 5.0f, 5.0f));
+    TRY(dev_alloc_t(net, &n.nt_flags, (size_t)K_TYPES * np));
+    TRY(fill_u32(net, n.nt_flags, (size_t)K_TYPES * np, 0));
+    reg(A, "neurotransmitters$t_max", T_F32, S_PLAIN_K, n.nt_t_max, 0, np);
+    reg(A, "neurotransmitters$clearance_constant", T_F32, S_PLAIN_K, n.nt_clearance, 0, np);
+    reg(A, "neurotransmitters$v_p", T_F32, S_PLAIN_K, n.nt_v_p, 0, np);
+    reg(A, "neurotransmitters$k_p", T_F32, S_PLAIN_K, n.nt_k_p, 0, np);
+    reg(A, "neurotransmitters$flags", T_U32, S_PLAIN_K, n.nt_flags, 0, np, 1);
+
+    // receptors (iterate_and_spike/mod.rs:1085-1094, 1115-1125, 1148-1157, 417-425)
+    TRY(typed_f32(net, &n.rc_g, np, 1.0f, 0.6f, 1.2f));
+    TRY(typed_f32(net, &n.rc_e, np, 0.0f, 0.0f, -80.0f));
+    TRY(typed_f32(net, &n.rc_mg, np, 0.0f, 0.3f, 0.0f));
+    TRY(typed_f32(net, &n.rc_r, np, 0.0f, 0.0f, 0.0f));
+    TRY(typed_f32(net, &n.rc_alpha, np, 1.0f, 1.0f, 1.0f));
+    TRY(typed_f32(net, &n.rc_beta, np, 1.0f, 1.0f, 1.0f));
+    TRY(typed_f32(net, &n.rc_current, np, 0.0f, 0.0f, 0.0f));
+    TRY(dev_alloc_t(net, &n.rc_flags, (size_t)K_TYPES * np));
+    TRY(fill_u32(net, n.rc_flags, (size_t)K_TYPES * np, 0));
+    reg(A, "receptors$flags", T_U32, S_PLAIN_K, n.rc_flags, 0, np);
+    static const char *TN[3] = {"AMPA", "NMDA", "GABA"};
+    for (int k = 0; k < K_TYPES; ++k) {
+        const std::string p = std::string("receptors$") + TN[k];
+        reg(A, (p + "_g").c_str(), T_F32, S_PLAIN, n.rc_g + (size_t)k * np, 0, 0);
+        reg(A, (p + "_e").c_str(), T_F32, S_PLAIN, n.rc_e + (size_t)k * np, 0, 0);
+        reg(A, (p + "_current").c_str(), T_F32, S_PLAIN, n.rc_current + (size_t)k * np, 0, 0);
+        reg(A, (p + "$r$kinetics$r").c_str(), T_F32, S_PLAIN, n.rc_r + (size_t)k * np, 0, 0);
+        reg(A, (p + "$r$kinetics$alpha").c_str(), T_F32, S_PLAIN, n.rc_alpha + (size_t)k * np, 0, 0);
+        reg(A, (p + "$r$kinetics$beta").c_str(), T_F32, S_PLAIN, n.rc_beta + (size_t)k * np, 0, 0);
+    }
+    reg(A, "receptors$NMDA_mg", T_F32, S_PLAIN, n.rc_mg + (size_t)1 * np, 0, 0);
+
+    // lattice slot per neuron + plasticity tables
+    TRY(dev_alloc_t(net, &net->lattice_slot, np));
+    TRY(fill_u32(net, net->lattice_slot, np, 0));
+    for (const auto &l : net->lattices) TRY(fill_u32(net, net->lattice_slot + l.first, l.count, l.slot));
+    const size_t nl = std::max<size_t>(1, net->lattices.size());
+    net->stdp_host.assign(nl * 5, 0.0f);
+    net->plast_host.assign(nl, 0);
+    for (size_t l = 0; l < nl; ++l) {   // plasticity/mod.rs:29-39
+        float *s = &net->stdp_host[l * 5];
+        s[0] = 2.0f; s[1] = 2.0f; s[2] = 4.5f; s[3] = 4.5f; s[4] = 0.1f;
+    }
+    TRY(dev_alloc_t(net, &net->stdp_dev, nl * 5));
+    TRY(dev_alloc_t(net, &net->plast_dev, nl));
+    HIP_TRY(hipMemcpyAsync(net->stdp_dev, net->stdp_host.data(), nl * 5 * 4, hipMemcpyHostToDevice, net->stream),
+            SNN_ERR_BUFFER_WRITE);
+    HIP_TRY(hipMemcpyAsync(net->plast_dev, net->plast_host.data(), nl * 4, hipMemcpyHostToDevice, net->stream),
+            SNN_ERR_BUFFER_WRITE);
+    TRY(dev_alloc_t(net, &net->spike_list, np));
+    TRY(dev_alloc_t(net, &net->spike_count, 1));
+
+    // spike-train cells (spike_train/mod.rs:299-313, 998-1013, 50-56)
+    c.c_pad = cp;
+    TRY(cell_f32(net, &c.current_voltage, "current_voltage", 0.0f));
+    TRY(cell_f32(net, &c.v_th, "v_th", 30.0f));
+    TRY(cell_f32(net, &c.v_resting, "v_resting", 0.0f));
+    TRY(cell_f32(net, &c.dt, "dt", 0.1f));
+    TRY(cell_f32(net, &c.k, "neural_refractoriness$k", 10000.0f));
+    TRY(cell_f32(net, &c.chance_of_firing, net->st_kind == SNN_ST_POISSON ? "chance_of_firing" : nullptr, 0.0f));
+    TRY(cell_f32(net, &c.rate, net->st_kind == SNN_ST_RATE ? "rate" : nullptr, 0.0f));
+    TRY(cell_f32(net, &c.step, net->st_kind == SNN_ST_RATE ? "step" : nullptr, 0.0f));
+    TRY(cell_f32(net, &c.presyn_value, nullptr, 0.0f));
+    TRY(dev_alloc_t(net, &c.seed, cp));
+    if (cp) {
+        hipLaunchKernelGGL(k_iota_u32, dim3((cp + 255) / 256), dim3(256), 0, net->stream, c.seed, (size_t)cp, 1u);
+        HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+    }
+    if (net->st_kind == SNN_ST_POISSON) reg(CA, "seed", T_U32, S_PLAIN, c.seed, 0, 0);
+    TRY(dev_alloc_t(net, &c.is_spiking, cp));
+    TRY(fill_u32(net, c.is_spiking, cp, 0));
+    reg(CA, "is_spiking", T_U32, S_PLAIN, c.is_spiking, 0, 0);
+    TRY(dev_alloc_t(net, &c.last_firing_time, cp));
+    HIP_TRY(hipMemsetAsync(c.last_firing_time, 0xFF, (size_t)std::max<uint32_t>(cp, 1) * 4, net->stream),
+            SNN_ERR_BUFFER_WRITE);
+    reg(CA, "last_firing_time", T_I32, S_PLAIN, c.last_firing_time, 0, 0);
+    TRY(typed_f32(net, &c.nt_t, cp, 0.0f, 0.0f, 0.0f));
+    TRY(typed_f32(net, &c.nt_t_max, cp, 1.0f, 1.0f, 1.0f));
+    TRY(typed_f32(net, &c.nt_clearance, cp, 0.01f, 0.01f, 0.01f));
+    TRY(typed_f32(net, &c.nt_v_p, cp, 2.0f, 2.0f, 2.0f));
+    TRY(typed_f32(net, &c.nt_k_p, cp, 5.0f, 5.0f, 5.0f));
+    TRY(dev_alloc_t(net, &c.nt_flags, (size_t)K_TYPES * cp));
+    TRY(fill_u32(net, c.nt_flags, (size_t)K_TYPES * cp, 0));
+    reg(CA, "neurotransmitters$t", T_F32, S_PLAIN_K, c.nt_t, 0, cp);
+    reg(CA, "neurotransmitters$t_max", T_F32, S_PLAIN_K, c.nt_t_max, 0, cp);
+    reg(CA, "neurotransmitters$clearance_constant", T_F32, S_PLAIN_K, c.nt_clearance, 0, cp);
+    reg(CA, "neurotransmitters$v_p", T_F32, S_PLAIN_K, c.nt_v_p, 0, cp);
+    reg(CA, "neurotransmitters$k_p", T_F32, S_PLAIN_K, c.nt_k_p, 0, cp);
+    reg(CA, "neurotransmitters$flags", T_U32, S_PLAIN_K, c.nt_flags, 0, cp, 1);
+    TRY(dev_alloc_t(net, &c.lattice_slot, cp));
+    TRY(fill_u32(net, c.lattice_slot, cp, 0));
+    for (const auto &l : net->st_lattices)
+        TRY(fill_u32(net, c.lattice_slot + (l.first - net->nn), l.count, l.slot));
+    net->st_clock.assign(std::max<size_t>(1, net->st_lattices.size()), 0);
+    TRY(dev_alloc_t(net, &net->st_clock_dev, net->st_clock.size()));
+
+    // graph + partials + counts
+    TRY(dev_alloc_t(net, &net->W, (size_t)net->n_tot * net->ld));
+    if ((size_t)net->n_tot * net->ld) {
+        // no edges until a graph is set: all sentinel
+        hipLaunchKernelGGL(k_fill_u32, dim3(4096), dim3(256), 0, net->stream,
+                           reinterpret_cast<uint32_t *>(net->W), (size_t)net->n_tot * net->ld, 0x7FC00000u);
+        HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+    }
+    TRY(dev_alloc_t(net, &net->part_i, (size_t)net->n_chunks * net->ld));
+    TRY(dev_alloc_t(net, &net->part_t, (size_t)K_TYPES * net->n_chunks * net->ld));
+    TRY(dev_alloc_t(net, &net->n_in, net->ld));
+    TRY(dev_alloc_t(net, &net->tcount, (size_t)K_TYPES * net->ld));
+    net->counts_dirty = true;
+    HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
+    return SNN_OK;
+}
+
+// ---- attribute transfer ------------------------------------------------------------------------
+
+// copy `count` 32-bit words between host and plane `plane` for global indices [first, first+count)
+int xplane_copy(snn_network *net, int plane, uint32_t first, uint32_t count, void *host, bool to_device)
+{
+    uint32_t done = 0;
+    while (done < count) {
+        const uint32_t g = first + done;
+        const uint32_t shard = g / net->xl.stride;
+        const uint32_t in_shard = g - shard * net->xl.stride;
+        const uint32_t seg = std::min(count - done, net->xl.stride - in_shard);
+        float *dev = net->xbuf + net->xl.at(g, plane);
+        char *h = static_cast<char *>(host) + (size_t)done * 4;
+        if (to_device) HIP_TRY(hipMemcpy(dev, h, (size_t)seg * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
+        else HIP_TRY(hipMemcpy(h, dev, (size_t)seg * 4, hipMemcpyDeviceToHost), SNN_ERR_BUFFER_READ);
+        done += seg;
+    }
+    return SNN_OK;
+}
+
+int attr_io(snn_network *net, uint32_t id, const char *name, AttrType type, void *host, size_t count, bool set)
+{
+    if (!net || !name || (!host && count)) return fail(SNN_ERR_BAD_ARG, "null argument");
+    if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
+    const LatticeInfo *l = find_lattice(net, id);
+    if (!l) return fail(SNN_ERR_BAD_ARG, "unknown lattice id " + std::to_string(id));
+    auto &table = l->spike_train ? net->cell_attrs : net->neuron_attrs;
+    auto it = table.find(name);
+    if (it == table.end()) return fail(SNN_ERR_BAD_ATTR, std::string("unknown attribute '") + name + "'");
+    const Attr &a = it->second;
+    if (a.type != type) return fail(SNN_ERR_BAD_ATTR, std::string("attribute '") + name + "' has another scalar type");
+    const bool typed = (a.store == S_PLAIN_K || a.store == S_XPLANE_K);
+    const size_t expect = (size_t)l->count * (typed ? K_TYPES : 1);
+    if (count != expect)
+        return fail(SNN_ERR_DIM_MISMATCH, std::string("attribute '") + name + "': expected " +
+                                              std::to_string(expect) + " values, got " + std::to_string(count));
+    if (l->count == 0) return SNN_OK;
+    HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
+    const uint32_t first = l->spike_train ? l->first - net->nn : l->first;   // index inside its own arrays
+
+    if (!typed) {
+        if (a.store == S_PLAIN) {
+            char *dev = static_cast<char *>(a.base) + (size_t)first * 4;
+            if (set) HIP_TRY(hipMemcpy(dev, host, count * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
+            else HIP_TRY(hipMemcpy(host, dev, count * 4, hipMemcpyDeviceToHost), SNN_ERR_BUFFER_READ);
+        } else {
+            TRY(xplane_copy(net, a.plane, first, l->count, host, set));
+        }
+    } else {
+        // host layout [cell*3 + k] (gpu_lattices/mod.rs:117-127) <-> device type-major planes
+        std::vector<uint32_t> tmp(l->count);
+        uint32_t *h = static_cast<uint32_t *>(host);
+        for (int k = 0; k < K_TYPES; ++k) {
+            if (set) for (uint32_t i = 0; i < l->count; ++i) tmp[i] = h[(size_t)i * K_TYPES + k];
+            if (a.store == S_PLAIN_K) {
+                char *dev = static_cast<char *>(a.base) + ((size_t)k * a.pad + first) * 4;
+                if (set) HIP_TRY(hipMemcpy(dev, tmp.data(), (size_t)l->count * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
+                else HIP_TRY(hipMemcpy(tmp.data(), dev, (size_t)l->count * 4, hipMemcpyDeviceToHost), SNN_ERR_BUFFER_READ);
+            } else {
+                TRY(xplane_copy(net, a.plane + k, first, l->count, tmp.data(), set));
+            }
+            if (!set) for (uint32_t i = 0; i < l->count; ++i) h[(size_t)i * K_TYPES + k] = tmp[i];
+        }
+    }
+    if (set && a.dirties) net->counts_dirty = true;
+    return SNN_OK;
+}
+
+// ---- per-step launches -------------------------------------------------------------------------
+
+int ensure_counts(snn_network *net)
+{
+    if (!net->counts_dirty || net->n_loc == 0) { net->counts_dirty = false; return SNN_OK; }
+    HIP_TRY(hipMemsetAsync(net->n_in, 0, (size_t)net->ld * 4, net->stream), SNN_ERR_BUFFER_WRITE);
+    HIP_TRY(hipMemsetAsync(net->tcount, 0, (size_t)K_TYPES * net->ld * 4, net->stream), SNN_ERR_BUFFER_WRITE);
+    if (net->n_tot) {
+        CountArgs a{};
+        a.W = net->W; a.ld = net->ld; a.n_loc = net->n_loc; a.n_neurons = net->nn; a.n_tot = net->n_tot;
+        a.nt_flags = net->na.nt_flags; a.n_pad = net->n_pad;
+        a.st_nt_flags = net->ca.nt_flags; a.c_pad = net->c_pad;
+        a.n_in = net->n_in; a.tcount = net->tcount;
+        a.rows_per_block = 256;
+        dim3 grid((net->n_loc + 255) / 256, (net->n_tot + 255) / 256);
+        hipLaunchKernelGGL(k_graph_count, grid, dim3(256), 0, net->stream, a);
+        HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+    }
+    net->counts_dirty = false;
+    return SNN_OK;
+}
+
+int launch_spike_trains(snn_network *net, int iterate, long long step_offset, long long view_clock)
+{
+    if (net->nc == 0) return SNN_OK;
+    SpikeTrainArgs a{};
+    a.c = net->ca; a.n_cells = net->nc; a.st_kind = net->st_kind; a.nt_kind = net->nt_kind;
+    a.iterate = iterate; a.lattice_clock = net->st_clock_dev; a.step_offset = step_offset;
+    a.view_clock = view_clock;
+    a.vhist_row = (iterate && net->want_vhist && net->st_vhist) ? net->st_vhist + (size_t)net->hist_steps * net->c_pad : nullptr;
+    hipLaunchKernelGGL(k_spike_trains, dim3((net->nc + 255) / 256), dim3(256), 0, net->stream, a);
+    HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+    return SNN_OK;
+}
+
+int launch_inputs(snn_network *net)
+{
+    if (net->n_loc == 0 || net->n_tot == 0) return SNN_OK;
+    InputsArgs a{};
+    a.W = net->W; a.ld = net->ld; a.n_loc = net->n_loc; a.q0 = net->q0; a.n_neurons = net->nn; a.n_tot = net->n_tot;
+    a.xbuf = net->xbuf; a.xl = net->xl; a.gap_conductance = net->na.gap_conductance;
+    a.st_value = net->ca.presyn_value; a.st_last_firing_time = net->ca.last_firing_time;
+    a.st_nt_t = net->ca.nt_t; a.st_nt_flags = net->ca.nt_flags; a.c_pad = net->c_pad;
+    a.nt_flags = net->na.nt_flags; a.n_pad = net->n_pad;
+    a.part_i = net->part_i; a.part_t = net->part_t; a.n_chunks = net->n_chunks;
+    dim3 grid((net->ld + TILE_POSTS - 1) / TILE_POSTS, net->n_chunks);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (net->profile) {
+        if (net->ev_used == net->ev_pool.size()) {
+            hipEvent_t x, y;
+            HIP_TRY(hipEventCreate(&x), SNN_ERR_QUEUE);
+            HIP_TRY(hipEventCreate(&y), SNN_ERR_QUEUE);
+            net->ev_pool.emplace_back(x, y);
+        }
+        e0 = net->ev_pool[net->ev_used].first;
+        e1 = net->ev_pool[net->ev_used].second;
+        ++net->ev_used;
+        HIP_TRY(hipEventRecord(e0, net->stream), SNN_ERR_QUEUE);
+    }
+    if (net->electrical && net->chemical)
+        hipLaunchKernelGGL((k_inputs_dense<true, true>), grid, dim3(256), 0, net->stream, a);
+    else if (net->electrical)
+        hipLaunchKernelGGL((k_inputs_dense<true, false>), grid, dim3(256), 0, net->stream, a);
+    else
+        hipLaunchKernelGGL((k_inputs_dense<false, true>), grid, dim3(256), 0, net->stream, a);
+    HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+    if (net->profile) HIP_TRY(hipEventRecord(e1, net->stream), SNN_ERR_QUEUE);
+    return SNN_OK;
+}
+
+int launch_update(snn_network *net)
+{
+    if (net->n_loc == 0) return SNN_OK;
+    UpdateArgs a{};
+    a.n = net->na;
+    a.part_i = net->part_i; a.part_t = net->part_t; a.n_in = net->n_in; a.tcount = net->tcount;
+    a.ld = net->ld; a.n_chunks = net->n_tot ? net->n_chunks : 0; a.q0 = net->q0; a.n_loc = net->n_loc;
+    a.clock = net->clock;
+    a.electrical = net->electrical; a.chemical = net->chemical; a.nt_kind = net->nt_kind; a.rc_kind = net->rc_kind;
+    a.vhist_row = (net->want_vhist && net->vhist) ? net->vhist + (size_t)net->hist_steps * net->n_pad : nullptr;
+    a.spike_row = (net->want_raster && net->raster) ? net->raster + (size_t)net->hist_steps * (net->n_pad / 64) : nullptr;
+    dim3 grid((net->ld + 255) / 256);
+    switch (net->model) {
+    case SNN_MODEL_LIF: hipLaunchKernelGGL((k_update<1>), grid, dim3(256), 0, net->stream, a); break;
+    case SNN_MODEL_HODGKIN_HUXLEY: hipLaunchKernelGGL((k_update<2>), grid, dim3(256), 0, net->stream, a); break;
+    default: hipLaunchKernelGGL((k_update<0>), grid, dim3(256), 0, net->stream, a); break;
+    }
+    HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+    return SNN_OK;
+}
+
+int launch_plasticity(snn_network *net)
+{
+    if (!net->any_plasticity || net->nn == 0) return SNN_OK;
+    StdpArgs a{};
+    a.W = net->W; a.ld = net->ld; a.n_loc = net->n_loc; a.q0 = net->q0; a.n_neurons = net->nn; a.n_tot = net->n_tot;
+    a.xbuf = net->xbuf; a.xl = net->xl;
+    a.last_firing_time = net->na.last_firing_time; a.st_last_firing_time = net->ca.last_firing_time;
+    a.lattice_slot = net->lattice_slot; a.stdp = net->stdp_dev; a.do_plasticity = net->plast_dev;
+    a.spike_list = net->spike_list; a.spike_count = net->spike_count;
+    HIP_TRY(hipMemsetAsync(net->spike_count, 0, 4, net->stream), SNN_ERR_BUFFER_WRITE);
+    hipLaunchKernelGGL(k_spike_compact, dim3((net->nn + 255) / 256), dim3(256), 0, net->stream, a);
+    HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+    if (net->n_loc == 0) return SNN_OK;
+    const unsigned sy = 64;   // spiking neurons processed concurrently; the rest grid-strides
+    hipLaunchKernelGGL(k_stdp_columns, dim3((net->n_tot + 255) / 256, sy), dim3(256), 0, net->stream, a);
+    HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+    hipLaunchKernelGGL(k_stdp_rows, dim3((net->n_loc + 255) / 256, sy), dim3(256), 0, net->stream, a);
+    HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+    return SNN_OK;
+}
+
+// first half of a step: inputs from S(t) and the local neurons' update
+int step_begin(snn_network *net)
+{
+    TRY(launch_inputs(net));
+    TRY(launch_update(net));
+    return SNN_OK;
+}
+
+// second half: remote last_firing_time, plasticity, histories, clock, spike trains (steps 3-6)
+int step_end(snn_network *net)
+{
+    if (net->xl.n_shards > 1 && net->nn) {
+        hipLaunchKernelGGL(k_stamp_remote, dim3((net->nn + 255) / 256), dim3(256), 0, net->stream,
+                           net->xbuf, net->xl, net->na.last_firing_time, net->nn, net->q0, net->n_loc, net->clock);
+        HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+    }
+    TRY(launch_plasticity(net));
+    net->clock += 1;
+    TRY(launch_spike_trains(net, 1, net->run_step_offset, net->clock));
+    net->run_step_offset += 1;
+    if (net->want_vhist || net->want_raster) net->hist_steps += 1;
+    return SNN_OK;
+}
+
+int grow_history(snn_network *net, uint64_t extra)
+{
+    if (!net->want_vhist && !net->want_raster) return SNN_OK;
+    const uint64_t need = net->hist_steps + extra;
+    if (need <= net->hist_cap && (!net->want_vhist || net->vhist) && (!net->want_raster || net->raster)) return SNN_OK;
+    const uint64_t cap = std::max<uint64_t>(need, net->hist_cap);
+    auto regrow = [&](void **buf, size_t row_bytes, bool wanted) -> int {
+        if (!wanted || row_bytes == 0) return SNN_OK;
+        void *nb = nullptr;
+        HIP_TRY(hipMalloc(&nb, std::max<size_t>(256, cap * row_bytes)), SNN_ERR_BUFFER_CREATE);
+        if (*buf && net->hist_steps)
+            HIP_TRY(hipMemcpyAsync(nb, *buf, net->hist_steps * row_bytes, hipMemcpyDeviceToDevice, net->stream),
+                    SNN_ERR_BUFFER_WRITE);
+        HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
+        if (*buf) (void)hipFree(*buf);
+        *buf = nb;
+        return SNN_OK;
+    };
+    TRY(regrow(reinterpret_cast<void **>(&net->vhist), (size_t)net->n_pad * 4, net->want_vhist));
+    TRY(regrow(reinterpret_cast<void **>(&net->st_vhist), (size_t)net->c_pad * 4, net->want_vhist));
+    TRY(regrow(reinterpret_cast<void **>(&net->raster), (size_t)(net->n_pad / 64) * 8, net->want_raster));
+    net->hist_cap = cap;
+    return SNN_OK;
+}
+
+int begin_run(snn_network *net, uint64_t iterations)
+{
+    TRY(ensure_counts(net));
+    TRY(grow_history(net, iterations));
+    if (net->nc) {
+        HIP_TRY(hipMemcpyAsync(net->st_clock_dev, net->st_clock.data(), net->st_clock.size() * sizeof(long long),
+                               hipMemcpyHostToDevice, net->stream), SNN_ERR_BUFFER_WRITE);
+        TRY(launch_spike_trains(net, 0, 0, net->clock));
+    }
+    net->run_step_offset = 0;
+    return SNN_OK;
+}
+
+int end_run(snn_network *net)
+{
+    HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
+    for (auto &c : net->st_clock) c += net->run_step_offset;
+    net->run_step_offset = 0;
+    return SNN_OK;
+}
+
+int collect_profile(snn_network *net)
+{
+    HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
+    for (size_t i = 0; i < net->ev_used; ++i) {
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, net->ev_pool[i].first, net->ev_pool[i].second), SNN_ERR_WAIT);
+        net->prof_ms += ms;
+        net->prof_launches += 1;
+    }
+    net->ev_used = 0;
+    return SNN_OK;
+}
+
+int graph_rows_io(snn_network *net, uint32_t pre_begin, uint32_t pre_count, float *weights, uint32_t *conns,
+                  size_t host_ld, bool set)
+{
+    if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
+    if ((uint64_t)pre_begin + pre_count > net->n_tot) return fail(SNN_ERR_DIM_MISMATCH, "row range exceeds n_tot");
+    if (pre_count == 0 || net->nn == 0) return SNN_OK;
+    if (!weights || !conns) return fail(SNN_ERR_BAD_ARG, "null graph pointer");
+    HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
+    // staged through a bounded device buffer: <= 64 MiB of host rows per hop
+    const uint32_t hop = (uint32_t)std::max<size_t>(1, std::min<size_t>(pre_count, (64u << 20) / (host_ld * 4)));
+    float *dw = nullptr;
+    uint32_t *dc = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dw), (size_t)hop * host_ld * 4), SNN_ERR_BUFFER_CREATE);
+    if (hipMalloc(reinterpret_cast<void **>(&dc), (size_t)hop * host_ld * 4) != hipSuccess) {
+        (void)hipFree(dw);
+        return fail(SNN_ERR_BUFFER_CREATE, "staging allocation failed");
+    }
+    int rc = SNN_OK;
+    for (uint32_t r = 0; r < pre_count && rc == SNN_OK; r += hop) {
+        const uint32_t rows = std::min(hop, pre_count - r);
+        const size_t bytes = (size_t)rows * host_ld * 4;
+        if (set) {
+            if (hipMemcpyAsync(dw, weights + (size_t)r * host_ld, bytes, hipMemcpyHostToDevice, net->stream) != hipSuccess ||
+                hipMemcpyAsync(dc, conns + (size_t)r * host_ld, bytes, hipMemcpyHostToDevice, net->stream) != hipSuccess) {
+                rc = fail(SNN_ERR_BUFFER_WRITE, "graph upload failed");
+                break;
+            }
+            hipLaunchKernelGGL(k_graph_import, dim3((net->ld + 255) / 256, rows), dim3(256), 0, net->stream,
+                               net->W, net->ld, net->n_loc, net->q0, pre_begin + r, rows, dw, dc, host_ld);
+        } else {
+            // columns outside the shard are left untouched in the caller's buffers
+            if (hipMemcpyAsync(dw, weights + (size_t)r * host_ld, bytes, hipMemcpyHostToDevice, net->stream) != hipSuccess ||
+                hipMemcpyAsync(dc, conns + (size_t)r * host_ld, bytes, hipMemcpyHostToDevice, net->stream) != hipSuccess) {
+                rc = fail(SNN_ERR_BUFFER_WRITE, "graph staging failed");
+                break;
+            }
+            if (net->n_loc)
+                hipLaunchKernelGGL(k_graph_export, dim3((net->n_loc + 255) / 256, rows), dim3(256), 0, net->stream,
+                                   net->W, net->ld, net->n_loc, net->q0, pre_begin + r, rows, dw, dc, host_ld);
+            if (hipMemcpyAsync(weights + (size_t)r * host_ld, dw, bytes, hipMemcpyDeviceToHost, net->stream) != hipSuccess ||
+                hipMemcpyAsync(conns + (size_t)r * host_ld, dc, bytes, hipMemcpyDeviceToHost, net->stream) != hipSuccess) {
+                rc = fail(SNN_ERR_BUFFER_READ, "graph download failed");
+                break;
+            }
+        }
+        if (hipGetLastError() != hipSuccess) { rc = fail(SNN_ERR_QUEUE, "graph kernel launch failed"); break; }
+        if (hipStreamSynchronize(net->stream) != hipSuccess) { rc = fail(SNN_ERR_WAIT, "graph transfer wait failed"); break; }
+    }
+    (void)hipFree(dw);
+    (void)hipFree(dc);
+    if (set) net->counts_dirty = true;
+    return rc;
+}
+
+} // namespace
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" {
+
+int snn_abi_version(void) { return SNN_ABI_VERSION; }
+const char *snn_last_error(void) { return g_last_error.c_str(); }
+
+int snn_network_create(int device, int neuron_model, int nt_kinetics, int receptor_kinetics,
+                       int spike_train_model, snn_network_t **out)
+{
+    if (!out) return fail(SNN_ERR_BAD_ARG, "out is null");
+    *out = nullptr;
+    if (neuron_model < 0 || neuron_model > 2 || nt_kinetics < 0 || nt_kinetics > 1 || receptor_kinetics < 0 ||
+        receptor_kinetics > 1 || spike_train_model < 0 || spike_train_model > 2)
+        return fail(SNN_ERR_BAD_ARG, "unknown model / kinetics selector");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(SNN_ERR_GET_DEVICE, "no HIP device visible");
+    if (device < 0 || device >= ndev) return fail(SNN_ERR_GET_DEVICE, "device ordinal out of range");
+    HIP_TRY(hipSetDevice(device), SNN_ERR_GET_DEVICE);
+    snn_network *net = new snn_network();
+    net->device = device;
+    net->model = neuron_model; net->nt_kind = nt_kinetics; net->rc_kind = receptor_kinetics;
+    net->st_kind = spike_train_model;
+    if (hipStreamCreateWithFlags(&net->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete net;
+        return fail(SNN_ERR_QUEUE, "hipStreamCreate failed");
+    }
+    *out = net;
+    return SNN_OK;
+}
+
+int snn_network_destroy(snn_network_t *net)
+{
+    if (!net) return SNN_OK;
+    (void)hipSetDevice(net->device);
+    if (net->stream) (void)hipStreamSynchronize(net->stream);
+    for (void *p : net->allocs) (void)hipFree(p);
+    if (net->vhist) (void)hipFree(net->vhist);
+    if (net->st_vhist) (void)hipFree(net->st_vhist);
+    if (net->raster) (void)hipFree(net->raster);
+    for (auto &e : net->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    if (net->stream) (void)hipStreamDestroy(net->stream);
+    delete net;
+    return SNN_OK;
+}
+
+static int add_lattice_impl(snn_network_t *net, uint32_t id, uint32_t rows, uint32_t cols, bool st)
+{
+    if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
+    if (net->finalized) return fail(SNN_ERR_BAD_STATE, "lattices cannot be added after finalize");
+    if (find_lattice(net, id))   // LatticeNetworkError::GraphIDAlreadyPresent, neuron/mod.rs:1669-1671
+        return fail(SNN_ERR_BAD_ARG, "lattice id " + std::to_string(id) + " already present");
+    if (st && net->st_kind == SNN_ST_NONE) return fail(SNN_ERR_BAD_STATE, "network was created without a spike-train model");
+    if ((uint64_t)rows * cols > 0x7FFFFFFFull) return fail(SNN_ERR_DIM_MISMATCH, "lattice too large");
+    LatticeInfo l{id, rows, cols, 0, rows * cols, 0, st};
+    (st ? net->st_lattices : net->lattices).push_back(l);
+    return SNN_OK;
+}
+
+int snn_network_add_lattice(snn_network_t *net, uint32_t id, uint32_t rows, uint32_t cols)
+{
+    return add_lattice_impl(net, id, rows, cols, false);
+}
+int snn_network_add_spike_train_lattice(snn_network_t *net, uint32_t id, uint32_t rows, uint32_t cols)
+{
+    return add_lattice_impl(net, id, rows, cols, true);
+}
+
+static int finalize_impl(snn_network_t *net, bool whole, uint32_t post_begin, uint32_t post_end, uint32_t n_shards,
+                         uint32_t stride)
+{
+    if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
+    if (net->finalized) return fail(SNN_ERR_BAD_STATE, "already finalized");
+    HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
+    auto by_id = [](const LatticeInfo &a, const LatticeInfo &b) { return a.id < b.id; };
+    std::sort(net->lattices.begin(), net->lattices.end(), by_id);
+    std::sort(net->st_lattices.begin(), net->st_lattices.end(), by_id);
+    uint64_t off = 0;
+    uint32_t slot = 0;
+    for (auto &l : net->lattices) { l.first = (uint32_t)off; l.slot = slot++; off += l.count; }
+    net->nn = (uint32_t)off;
+    slot = 0;
+    for (auto &l : net->st_lattices) { l.first = (uint32_t)off; l.slot = slot++; off += l.count; }
+    if (off > 0x7FFFFFFFull) return fail(SNN_ERR_DIM_MISMATCH, "network too large");
+    net->n_tot = (uint32_t)off;
+    net->nc = net->n_tot - net->nn;
+    net->n_pad = std::max<uint32_t>(256, round_up(net->nn, 256));
+    net->c_pad = std::max<uint32_t>(256, round_up(net->nc, 256));
+    if (whole) {
+        net->q0 = 0; net->q1 = net->nn;
+        net->xl = XLayout{net->n_pad, 1};
+    } else {
+        if (post_begin > post_end || post_end > net->nn) return fail(SNN_ERR_DIM_MISMATCH, "shard range outside the population");
+        if (stride == 0 || stride % 64 != 0 || n_shards == 0 || (uint64_t)stride * n_shards < net->nn)
+            return fail(SNN_ERR_BAD_ARG, "shard stride must be a multiple of 64 covering the population");
+        net->q0 = post_begin; net->q1 = post_end;
+        net->xl = XLayout{stride, n_shards};
+        net->n_pad = std::max<uint32_t>(net->n_pad, round_up(stride * n_shards, 256));
+    }
+    net->n_loc = net->q1 - net->q0;
+    net->ld = std::max<uint32_t>(64, round_up(net->n_loc, 64));
+    net->n_chunks = (net->n_tot + CHUNK - 1) / CHUNK;
+    int rc = build_state(net);
+    if (rc) return rc;
+    net->finalized = true;
+    return SNN_OK;
+}
+
+int snn_network_finalize(snn_network_t *net) { return finalize_impl(net, true, 0, 0, 1, 0); }
+
+int snn_network_finalize_shard(snn_network_t *net, uint32_t shard_index, uint32_t n_shards)
+{
+    // equal slots: stride = ceil(n_neurons / n_shards) rounded up to a wavefront (64 neurons); shard r owns
+    // neurons [r*stride, min(n, (r+1)*stride)) -- trailing shards may be short or empty
+    if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
+    if (n_shards == 0 || shard_index >= n_shards) return fail(SNN_ERR_BAD_ARG, "shard_index must be < n_shards");
+    uint64_t nn = 0;
+    for (const auto &l : net->lattices) nn += l.count;
+    const uint32_t stride = std::max<uint32_t>(64, round_up((uint32_t)((nn + n_shards - 1) / n_shards), 64));
+    const uint32_t begin = (uint32_t)std::min<uint64_t>(nn, (uint64_t)shard_index * stride);
+    const uint32_t end = (uint32_t)std::min<uint64_t>(nn, (uint64_t)begin + stride);
+    return finalize_impl(net, false, begin, end, n_shards, stride);
+}
+
+int snn_network_sizes(const snn_network_t *net, uint32_t *n_neurons, uint32_t *n_cells, uint32_t *post_begin,
+                      uint32_t *post_end)
+{
+    if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
+    if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
+    if (n_neurons) *n_neurons = net->nn;
+    if (n_cells) *n_cells = net->nc;
+    if (post_begin) *post_begin = net->q0;
+    if (post_end) *post_end = net->q1;
+    return SNN_OK;
+}
+
+int snn_network_lattice_range(const snn_network_t *net, uint32_t id, uint32_t *first, uint32_t *count)
+{
+    if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
+    if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
+    const LatticeInfo *l = find_lattice(net, id);
+    if (!l) return fail(SNN_ERR_BAD_ARG, "unknown lattice id");
+    if (first) *first = l->first;
+    if (count) *count = l->count;
+    return SNN_OK;
+}
+
+int snn_set_attr_f32(snn_network_t *net, uint32_t id, const char *name, const float *src, size_t count)
+{ return attr_io(net, id, name, T_F32, const_cast<float *>(src), count, true); }
+int snn_get_attr_f32(snn_network_t *net, uint32_t id, const char *name, float *dst, size_t count)
+{ return attr_io(net, id, name, T_F32, dst, count, false); }
+int snn_set_attr_u32(snn_network_t *net, uint32_t id, const char *name, const uint32_t *src, size_t count)
+{ return attr_io(net, id, name, T_U32, const_cast<uint32_t *>(src), count, true); }
+int snn_get_attr_u32(snn_network_t *net, uint32_t id, const char *name, uint32_t *dst, size_t count)
+{ return attr_io(net, id, name, T_U32, dst, count, false); }
+int snn_set_attr_i32(snn_network_t *net, uint32_t id, const char *name, const int32_t *src, size_t count)
+{ return attr_io(net, id, name, T_I32, const_cast<int32_t *>(src), count, true); }
+int snn_get_attr_i32(snn_network_t *net, uint32_t id, const char *name, int32_t *dst, size_t count)
+{ return attr_io(net, id, name, T_I32, dst, count, false); }
+
+int snn_set_graph_rows(snn_network_t *net, uint32_t pre_begin, uint32_t pre_count, const float *weights,
+                       const uint32_t *connections)
+{
+    if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
+    return graph_rows_io(net, pre_begin, pre_count, const_cast<float *>(weights),
+                         const_cast<uint32_t *>(connections), net->nn, true);
+}
+int snn_get_graph_rows(snn_network_t *net, uint32_t pre_begin, uint32_t pre_count, float *weights, uint32_t *connections)
+{
+    if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
+    return graph_rows_io(net, pre_begin, pre_count, weights, connections, net->nn, false);
+}
+int snn_set_graph_dense(snn_network_t *net, const float *weights, const uint32_t *connections, size_t n_tot)
+{
+    if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
+    if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
+    if (n_tot != net->n_tot) return fail(SNN_ERR_DIM_MISMATCH, "graph size does not match the network");
+    return graph_rows_io(net, 0, net->n_tot, const_cast<float *>(weights), const_cast<uint32_t *>(connections),
+                         net->n_tot, true);
+}
+int snn_get_graph_dense(snn_network_t *net, float *weights, uint32_t *connections, size_t n_tot)
+{
+    if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
+    if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
+    if (n_tot != net->n_tot) return fail(SNN_ERR_DIM_MISMATCH, "graph size does not match the network");
+    return graph_rows_io(net, 0, net->n_tot, weights, connections, net->n_tot, false);
+}
+
+int snn_fill_graph_synthetic(snn_network_t *net, uint64_t seed, float lo, float hi, int with_diagonal)
+{
+    if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
+    if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
+    HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
+    if (net->n_tot && net->ld) {
+        const unsigned gy = std::min<uint32_t>(net->n_tot, 4096);
+        hipLaunchKernelGGL(k_graph_synthetic, dim3((net->ld + 255) / 256, gy), dim3(256), 0, net->stream, net->W,
+                           net->ld, net->n_loc, net->q0, net->nn, net->n_tot, seed, lo, hi, with_diagonal);
+        HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+        HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
+    }
+    net->counts_dirty = true;
+    return SNN_OK;
+}
+
+int snn_set_synapses(snn_network_t *net, int electrical_synapse, int chemical_synapse)
+{
+    if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
+    net->electrical = electrical_synapse ? 1 : 0;
+    net->chemical = chemical_synapse ? 1 : 0;
+    return SNN_OK;
+}
+
+int snn_set_plasticity(snn_network_t *net, uint32_t id, float a_plus, float a_minus, float tau_plus,
+                       float tau_minus, float dt, int do_plasticity)
+{
+    if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
+    if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
+    const LatticeInfo *l = find_lattice(net, id);
+    if (!l || l->spike_train) return fail(SNN_ERR_BAD_ARG, "plasticity belongs to neuron lattices");
+    HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
+    float *s = &net->stdp_host[(size_t)l->slot * 5];
+    s[0] = a_plus; s[1] = a_minus; s[2] = tau_plus; s[3] = tau_minus; s[4] = dt;
+    net->plast_host[l->slot] = do_plasticity ? 1u : 0u;
+    net->any_plasticity = false;
+    for (uint32_t p : net->plast_host) net->any_plasticity |= (p != 0);
+    HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
+    HIP_TRY(hipMemcpy(net->stdp_dev, net->stdp_host.data(), net->stdp_host.size() * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
+    HIP_TRY(hipMemcpy(net->plast_dev, net->plast_host.data(), net->plast_host.size() * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
+    return SNN_OK;
+}
+
+int snn_set_history(snn_network_t *net, int voltage_history, int spike_history)
+{
+    if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
+    if ((voltage_history != 0) != (net->want_vhist != 0) || (spike_history != 0) != (net->want_raster != 0)) {
+        // switching what is recorded restarts the record so that all rows cover the same steps
+        net->hist_steps = 0;
+    }
+    net->want_vhist = voltage_history ? 1 : 0;
+    net->want_raster = spike_history ? 1 : 0;
+    return SNN_OK;
+}
+
+int snn_reset_history(snn_network_t *net)
+{
+    if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
+    net->hist_steps = 0;
+    return SNN_OK;
+}
+
+int snn_get_clock(const snn_network_t *net, uint64_t *clock)
+{
+    if (!net || !clock) return fail(SNN_ERR_BAD_ARG, "null argument");
+    *clock = (uint64_t)net->clock;
+    return SNN_OK;
+}
+
+int snn_reset_timing(snn_network_t *net)
+{
+    if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
+    if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
+    HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
+    net->clock = 0;
+    for (auto &c : net->st_clock) c = 0;
+    HIP_TRY(hipMemsetAsync(net->na.last_firing_time, 0xFF, (size_t)net->n_pad * 4, net->stream), SNN_ERR_BUFFER_WRITE);
+    HIP_TRY(hipMemsetAsync(net->ca.last_firing_time, 0xFF, (size_t)net->c_pad * 4, net->stream), SNN_ERR_BUFFER_WRITE);
+    HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
+    return SNN_OK;
+}
+
+int snn_run(snn_network_t *net, uint64_t iterations)
+{
+    if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
+    if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
+    if (net->xl.n_shards > 1) return fail(SNN_ERR_BAD_STATE, "sharded handles are stepped with snn_step_begin/end");
+    if (iterations == 0 || net->n_tot == 0) return SNN_OK;          // gpu_lattices/mod.rs:1089-1091, 3196-3203
+    if (!net->electrical && !net->chemical) return SNN_OK;           // neuron/mod.rs:1217, 2672
+    HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
+    TRY(begin_run(net, iterations));
+    for (uint64_t it = 0; it < iterations; ++it) {
+        if (net->nn) TRY(step_begin(net));
+        TRY(step_end(net));
+        if (net->profile && net->ev_used >= 8192) TRY(collect_profile(net));
+    }
+    return end_run(net);
+}
+
+int snn_step_begin(snn_network_t *net)
+{
+    if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
+    if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
+    HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
+    if (net->run_step_offset == 0) TRY(begin_run(net, 1));
+    else TRY(grow_history(net, 1));
+    if (net->nn) TRY(step_begin(net));
+    HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
+    return SNN_OK;
+}
+
+int snn_step_end(snn_network_t *net)
+{
+    if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
+    if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
+    HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
+    TRY(step_end(net));
+    HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
+    // keep the spike-train lattice clocks current after every externally driven step
+    for (auto &c : net->st_clock) c += net->run_step_offset;
+    net->run_step_offset = 0;
+    return SNN_OK;
+}
+
+int snn_exchange_buffer(snn_network_t *net, void **device_ptr, uint32_t *words_per_neuron, uint32_t *n_padded)
+{
+    if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
+    if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
+    if (device_ptr) *device_ptr = net->xbuf;
+    if (words_per_neuron) *words_per_neuron = NUM_PLANES;
+    if (n_padded) *n_padded = net->xl.stride * net->xl.n_shards;
+    return SNN_OK;
+}
+
+int snn_stream(snn_network_t *net, void **hip_stream)
+{
+    if (!net || !hip_stream) return fail(SNN_ERR_BAD_ARG, "null argument");
+    *hip_stream = net->stream;
+    return SNN_OK;
+}
+
+int snn_history_steps(const snn_network_t *net, uint64_t *steps)
+{
+    if (!net || !steps) return fail(SNN_ERR_BAD_ARG, "null argument");
+    *steps = net->hist_steps;
+    return SNN_OK;
+}
+
+int snn_get_voltage_history(snn_network_t *net, uint32_t id, float *dst, size_t count)
+{
+    if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
+    if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
+    const LatticeInfo *l = find_lattice(net, id);
+    if (!l) return fail(SNN_ERR_BAD_ARG, "unknown lattice id");
+    if (!net->want_vhist) return fail(SNN_ERR_BAD_STATE, "voltage history is off");
+    if (count != net->hist_steps * l->count) return fail(SNN_ERR_DIM_MISMATCH, "history size mismatch");
+    if (count == 0) return SNN_OK;
+    if (!dst) return fail(SNN_ERR_BAD_ARG, "dst is null");
+    HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
+    HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
+    const float *src = l->spike_train ? net->st_vhist + (l->first - net->nn) : net->vhist + l->first;
+    const size_t pitch = (size_t)(l->spike_train ? net->c_pad : net->n_pad) * 4;
+    HIP_TRY(hipMemcpy2D(dst, (size_t)l->count * 4, src, pitch, (size_t)l->count * 4, net->hist_steps, hipMemcpyDeviceToHost),
+            SNN_ERR_BUFFER_READ);
+    return SNN_OK;
+}
+
+int snn_get_spike_history(snn_network_t *net, uint32_t id, uint8_t *dst, size_t count)
+{
+    if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
+    if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
+    const LatticeInfo *l = find_lattice(net, id);
+    if (!l || l->spike_train) return fail(SNN_ERR_BAD_ARG, "spike history exists for neuron lattices");
+    if (!net->want_raster) return fail(SNN_ERR_BAD_STATE, "spike history is off");
+    if (count != net->hist_steps * l->count) return fail(SNN_ERR_DIM_MISMATCH, "history size mismatch");
+    if (count == 0) return SNN_OK;
+    if (!dst) return fail(SNN_ERR_BAD_ARG, "dst is null");
+    HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
+    HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
+    const size_t words = net->n_pad / 64;
+    std::vector<unsigned long long> host(net->hist_steps * words);
+    HIP_TRY(hipMemcpy(host.data(), net->raster, host.size() * 8, hipMemcpyDeviceToHost), SNN_ERR_BUFFER_READ);
+    for (uint64_t s = 0; s < net->hist_steps; ++s)
+        for (uint32_t i = 0; i < l->count; ++i) {
+            const uint32_t q = l->first + i;
+            dst[s * l->count + i] = (uint8_t)((host[s * words + (q >> 6)] >> (q & 63)) & 1ull);
+        }
+    return SNN_OK;
+}
+
+int snn_profile_enable(snn_network_t *net, int enable)
+{
+    if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
+    net->profile = enable ? 1 : 0;
+    return SNN_OK;
+}
+int snn_profile_reset(snn_network_t *net)
+{
+    if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
+    HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
+    HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
+    net->ev_used = 0; net->prof_launches = 0; net->prof_ms = 0.0;
+    return SNN_OK;
+}
+int snn_profile_read(snn_network_t *net, uint64_t *launches, double *total_ms)
+{
+    if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
+    HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
+    TRY(collect_profile(net));
+    if (launches) *launches = net->prof_launches;
+    if (total_ms) *total_ms = net->prof_ms;
+    return SNN_OK;
+}
+int snn_input_kernel_bytes(const snn_network_t *net, uint64_t *bytes)
+{
+    if (!net || !bytes) return fail(SNN_ERR_BAD_ARG, "null argument");
+    if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
+    *bytes = (uint64_t)4 * net->n_tot * net->n_loc;   // every synapse weight of the shard, read once
+    return SNN_OK;
+}
+
+int snn_probe_math(int device, int which, const float *in, float *out, size_t count)
+{
+    if (!in || !out) return fail(SNN_ERR_BAD_ARG, "null argument");
+    if (which < 0 || which > 2) return fail(SNN_ERR_BAD_ARG, "unknown function selector");
+    HIP_TRY(hipSetDevice(device), SNN_ERR_GET_DEVICE);
+    if (count == 0) return SNN_OK;
+    float *di = nullptr, *dout = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&di), count * 4), SNN_ERR_BUFFER_CREATE);
+    if (hipMalloc(reinterpret_cast<void **>(&dout), count * 4) != hipSuccess) { (void)hipFree(di); return fail(SNN_ERR_BUFFER_CREATE, "hipMalloc failed"); }
+    int rc = SNN_OK;
+    if (hipMemcpy(di, in, count * 4, hipMemcpyHostToDevice) != hipSuccess) rc = fail(SNN_ERR_BUFFER_WRITE, "upload failed");
+    if (rc == SNN_OK) {
+        hipLaunchKernelGGL(k_probe_math, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, 0, which, di, dout, count);
+        if (hipDeviceSynchronize() != hipSuccess) rc = fail(SNN_ERR_WAIT, "probe kernel failed");
+    }
+    if (rc == SNN_OK && hipMemcpy(out, dout, count * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(SNN_ERR_BUFFER_READ, "download failed");
+    (void)hipFree(di);
+    (void)hipFree(dout);
+    return rc;
+}
+
+} // extern "C"

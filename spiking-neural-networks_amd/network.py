@@ -1,0 +1,223 @@
+"""`DeviceNetwork`: thin numpy-facing owner of one C-ABI handle (include/snn_amd.h).
+
+Mirrors the reference's GPU containers at buffer level -- `LatticeGPU` /
+`LatticeNetworkGPU` (backend/src/neuron/gpu_lattices/mod.rs:327-350, 1517-1558):
+named per-cell buffers (`IterateAndSpikeGPU::convert_to_gpu`,
+neuron/iterate_and_spike/mod.rs:3156-3189), the flattened graph
+(`InterleavingGraphGPU`, graph/mod.rs:579-943) and `run_lattices`.
+The Lixirnet-style classes in `lattice.py` sit on top of this.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+IZHIKEVICH, LIF, HODGKIN_HUXLEY = 0, 1, 2
+NT_APPROXIMATE, NT_DESTEXHE = 0, 1
+RC_APPROXIMATE, RC_DESTEXHE = 0, 1
+ST_NONE, ST_POISSON, ST_RATE = 0, 1, 2
+NUM_NT_TYPES = 3
+
+_DT = {np.dtype(np.float32): "f32", np.dtype(np.uint32): "u32", np.dtype(np.int32): "i32"}
+_PTR = {"f32": _lib.f32p, "u32": _lib.u32p, "i32": _lib.i32p}
+
+
+class DeviceNetwork:
+    def __init__(self, model=IZHIKEVICH, nt_kinetics=NT_APPROXIMATE, receptor_kinetics=RC_APPROXIMATE,
+                 spike_train=ST_NONE, device=0):
+        self._L = _lib.load()
+        self._h = _lib.H()
+        _lib.check(self._L.snn_network_create(device, model, nt_kinetics, receptor_kinetics, spike_train,
+                                              C.byref(self._h)))
+        self.model = model
+        self.lattices = {}          # id -> (rows, cols, is_spike_train)
+        self.finalized = False
+
+    # ---- lifetime -------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._L.snn_network_destroy(self._h)
+            self._h = _lib.H()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # ---- construction ---------------------------------------------------------------------
+    def add_lattice(self, id, rows, cols):
+        _lib.check(self._L.snn_network_add_lattice(self._h, id, rows, cols))
+        self.lattices[id] = (rows, cols, False)
+
+    def add_spike_train_lattice(self, id, rows, cols):
+        _lib.check(self._L.snn_network_add_spike_train_lattice(self._h, id, rows, cols))
+        self.lattices[id] = (rows, cols, True)
+
+    def finalize(self, shard_index=None, n_shards=None):
+        if shard_index is None:
+            _lib.check(self._L.snn_network_finalize(self._h))
+        else:
+            _lib.check(self._L.snn_network_finalize_shard(self._h, shard_index, n_shards))
+        self.finalized = True
+        nn, nc, q0, q1 = (C.c_uint32() for _ in range(4))
+        _lib.check(self._L.snn_network_sizes(self._h, C.byref(nn), C.byref(nc), C.byref(q0), C.byref(q1)))
+        self.n_neurons, self.n_cells = nn.value, nc.value
+        self.n_tot = self.n_neurons + self.n_cells
+        self.post_begin, self.post_end = q0.value, q1.value
+        return self
+
+    def lattice_range(self, id):
+        first, count = C.c_uint32(), C.c_uint32()
+        _lib.check(self._L.snn_network_lattice_range(self._h, id, C.byref(first), C.byref(count)))
+        return first.value, count.value
+
+    # ---- attributes -----------------------------------------------------------------------
+    def set_attr(self, id, name, values):
+        a = np.ascontiguousarray(values)
+        if a.dtype not in _DT:
+            raise TypeError(f"attribute arrays must be float32 / uint32 / int32, not {a.dtype}")
+        kind = _DT[a.dtype]
+        fn = getattr(self._L, f"snn_set_attr_{kind}")
+        _lib.check(fn(self._h, id, name.encode(), a.ctypes.data_as(_PTR[kind]), a.size))
+
+    def get_attr(self, id, name, dtype=np.float32, per_type=False):
+        rows, cols, _ = self.lattices[id]
+        n = rows * cols
+        out = np.empty((n, NUM_NT_TYPES) if per_type else (n,), dtype=dtype)
+        kind = _DT[np.dtype(dtype)]
+        fn = getattr(self._L, f"snn_get_attr_{kind}")
+        _lib.check(fn(self._h, id, name.encode(), out.ctypes.data_as(_PTR[kind]), out.size))
+        return out
+
+    # ---- graph ----------------------------------------------------------------------------
+    def set_graph_dense(self, weights, connections):
+        w = np.ascontiguousarray(weights, dtype=np.float32)
+        c = np.ascontiguousarray(connections, dtype=np.uint32)
+        if w.shape != c.shape or w.ndim != 2 or w.shape[0] != w.shape[1]:
+            raise ValueError("weights / connections must be equal square matrices [n_tot, n_tot]")
+        _lib.check(self._L.snn_set_graph_dense(self._h, w.ctypes.data_as(_lib.f32p), c.ctypes.data_as(_lib.u32p),
+                                               w.shape[0]))
+
+    def get_graph_dense(self):
+        n = self.n_tot
+        w = np.zeros((n, n), np.float32)
+        c = np.zeros((n, n), np.uint32)
+        _lib.check(self._L.snn_get_graph_dense(self._h, w.ctypes.data_as(_lib.f32p), c.ctypes.data_as(_lib.u32p), n))
+        return w, c
+
+    def set_graph_rows(self, pre_begin, weights, connections):
+        """rows [pre_begin, pre_begin+len) of the [n_tot, n_neurons] matrix"""
+        w = np.ascontiguousarray(weights, dtype=np.float32)
+        c = np.ascontiguousarray(connections, dtype=np.uint32)
+        if w.shape != c.shape or w.ndim != 2 or w.shape[1] != self.n_neurons:
+            raise ValueError("row blocks must be [rows, n_neurons]")
+        _lib.check(self._L.snn_set_graph_rows(self._h, pre_begin, w.shape[0], w.ctypes.data_as(_lib.f32p),
+                                              c.ctypes.data_as(_lib.u32p)))
+
+    def get_graph_rows(self, pre_begin, pre_count):
+        w = np.zeros((pre_count, self.n_neurons), np.float32)
+        c = np.zeros((pre_count, self.n_neurons), np.uint32)
+        _lib.check(self._L.snn_get_graph_rows(self._h, pre_begin, pre_count, w.ctypes.data_as(_lib.f32p),
+                                              c.ctypes.data_as(_lib.u32p)))
+        return w, c
+
+    def fill_graph_synthetic(self, seed, lo, hi, with_diagonal=False):
+        _lib.check(self._L.snn_fill_graph_synthetic(self._h, seed, lo, hi, int(with_diagonal)))
+
+    # ---- switches -------------------------------------------------------------------------
+    def set_synapses(self, electrical=True, chemical=False):
+        _lib.check(self._L.snn_set_synapses(self._h, int(electrical), int(chemical)))
+
+    def set_plasticity(self, id, a_plus=2.0, a_minus=2.0, tau_plus=4.5, tau_minus=4.5, dt=0.1, do_plasticity=True):
+        _lib.check(self._L.snn_set_plasticity(self._h, id, a_plus, a_minus, tau_plus, tau_minus, dt,
+                                              int(do_plasticity)))
+
+    def set_history(self, voltage=False, spikes=False):
+        _lib.check(self._L.snn_set_history(self._h, int(voltage), int(spikes)))
+
+    def reset_history(self):
+        _lib.check(self._L.snn_reset_history(self._h))
+
+    def reset_timing(self):
+        _lib.check(self._L.snn_reset_timing(self._h))
+
+    @property
+    def clock(self):
+        v = C.c_uint64()
+        _lib.check(self._L.snn_get_clock(self._h, C.byref(v)))
+        return v.value
+
+    # ---- stepping -------------------------------------------------------------------------
+    def run(self, iterations):
+        _lib.check(self._L.snn_run(self._h, iterations))
+
+    def step_begin(self):
+        _lib.check(self._L.snn_step_begin(self._h))
+
+    def step_end(self):
+        _lib.check(self._L.snn_step_end(self._h))
+
+    def exchange_buffer(self):
+        """(device pointer, words per neuron, padded neuron count) of the all-gather buffer"""
+        p, w, n = C.c_void_p(), C.c_uint32(), C.c_uint32()
+        _lib.check(self._L.snn_exchange_buffer(self._h, C.byref(p), C.byref(w), C.byref(n)))
+        return p.value, w.value, n.value
+
+    def stream(self):
+        p = C.c_void_p()
+        _lib.check(self._L.snn_stream(self._h, C.byref(p)))
+        return p.value
+
+    # ---- histories ------------------------------------------------------------------------
+    def history_steps(self):
+        v = C.c_uint64()
+        _lib.check(self._L.snn_history_steps(self._h, C.byref(v)))
+        return v.value
+
+    def voltage_history(self, id):
+        rows, cols, _ = self.lattices[id]
+        steps = self.history_steps()
+        out = np.empty((steps, rows * cols), np.float32)
+        _lib.check(self._L.snn_get_voltage_history(self._h, id, out.ctypes.data_as(_lib.f32p), out.size))
+        return out
+
+    def spike_history(self, id):
+        rows, cols, _ = self.lattices[id]
+        steps = self.history_steps()
+        out = np.empty((steps, rows * cols), np.uint8)
+        _lib.check(self._L.snn_get_spike_history(self._h, id, out.ctypes.data_as(_lib.u8p), out.size))
+        return out
+
+    # ---- measurement ----------------------------------------------------------------------
+    def profile_enable(self, on=True):
+        _lib.check(self._L.snn_profile_enable(self._h, int(on)))
+
+    def profile_reset(self):
+        _lib.check(self._L.snn_profile_reset(self._h))
+
+    def profile_read(self):
+        n, ms = C.c_uint64(), C.c_double()
+        _lib.check(self._L.snn_profile_read(self._h, C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
+    def input_kernel_bytes(self):
+        v = C.c_uint64()
+        _lib.check(self._L.snn_input_kernel_bytes(self._h, C.byref(v)))
+        return v.value
+
+
+def probe_math(which, x, device=0):
+    """Evaluate the stepper's device functions (0 exp, 1 pow3, 2 pow4) on the GPU."""
+    L = _lib.load()
+    a = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.empty_like(a)
+    _lib.check(L.snn_probe_math(device, which, a.ctypes.data_as(_lib.f32p), out.ctypes.data_as(_lib.f32p), a.size))
+    return out

@@ -1,0 +1,194 @@
+"""Shared parity harness: build the SAME network for the CPU oracle and the HIP stepper,
+run both, compare every state array bit for bit.  Test infrastructure only."""
+import numpy as np
+
+import oracle_binding as ob
+
+TYPE_NAMES = ("AMPA", "NMDA", "GABA")
+
+# oracle array name -> C-ABI attribute name (reference buffer names), per model
+COMMON = {"current_voltage": "current_voltage", "gap_conductance": "gap_conductance", "dt": "dt",
+          "c_m": "c_m", "v_th": "v_th", "is_spiking": "is_spiking", "last_firing_time": "last_firing_time"}
+MODEL_ATTRS = {
+    ob.IZHIKEVICH: {k: k for k in ("w_value", "a", "b", "c", "d", "tau_m")},
+    ob.LIF: {k: k for k in ("tau_m", "v_reset", "refractory_count", "tref", "leak_constant",
+                            "integration_constant", "e_l", "g_l")},
+    ob.HH: {"m_state": "na_channel$m$state", "h_state": "na_channel$h$state", "n_state": "k_channel$n$state",
+            "m_alpha": "na_channel$m$alpha", "m_beta": "na_channel$m$beta",
+            "h_alpha": "na_channel$h$alpha", "h_beta": "na_channel$h$beta",
+            "n_alpha": "k_channel$n$alpha", "n_beta": "k_channel$n$beta",
+            "g_na": "na_channel$g_na", "e_na": "na_channel$e_na", "g_k": "k_channel$g_k", "e_k": "k_channel$e_k",
+            "g_k_leak": "k_leak_channel$g_k_leak", "e_k_leak": "k_leak_channel$e_k_leak",
+            "na_current": "na_channel$current", "k_current": "k_channel$current",
+            "k_leak_current": "k_leak_channel$current", "was_increasing": "was_increasing"},
+}
+NT_ATTRS = {"nt_t": "neurotransmitters$t", "nt_t_max": "neurotransmitters$t_max",
+            "nt_clearance": "neurotransmitters$clearance_constant", "nt_v_p": "neurotransmitters$v_p",
+            "nt_k_p": "neurotransmitters$k_p", "nt_flags": "neurotransmitters$flags"}
+RC_PER_TYPE = {"rc_g": "receptors${T}_g", "rc_e": "receptors${T}_e", "rc_current": "receptors${T}_current",
+               "rc_r": "receptors${T}$r$kinetics$r", "rc_alpha": "receptors${T}$r$kinetics$alpha",
+               "rc_beta": "receptors${T}$r$kinetics$beta"}
+CELL_ATTRS = {"st_current_voltage": "current_voltage", "st_v_th": "v_th", "st_v_resting": "v_resting",
+              "st_dt": "dt", "st_k": "neural_refractoriness$k", "st_is_spiking": "is_spiking",
+              "st_last_firing_time": "last_firing_time"}
+CELL_KIND_ATTRS = {ob.ST_POISSON: {"st_chance_of_firing": "chance_of_firing", "st_seed": "seed"},
+                   ob.ST_RATE: {"st_rate": "rate", "st_step": "step"}}
+
+
+class Layout:
+    """Lattice ids and shapes of a network: neuron lattices then spike-train lattices (ascending id)."""
+
+    def __init__(self, lattices, st_lattices=()):
+        self.lattices = sorted(lattices)          # (id, rows, cols)
+        self.st_lattices = sorted(st_lattices)
+        self.n_neurons = sum(r * c for _, r, c in self.lattices)
+        self.n_cells = sum(r * c for _, r, c in self.st_lattices)
+
+    def ranges(self):
+        off = 0
+        out = {}
+        for i, r, c in self.lattices:
+            out[i] = (off, r * c, False)
+            off += r * c
+        off = 0
+        for i, r, c in self.st_lattices:
+            out[i] = (off, r * c, True)
+            off += r * c
+        return out
+
+
+def make_oracle(layout, **kw):
+    net = ob.Net(layout.n_neurons, n_cells=layout.n_cells, n_lattices=max(1, len(layout.lattices)),
+                 n_st_lattices=len(layout.st_lattices), **kw)
+    rng = layout.ranges()
+    for slot, (i, r, c) in enumerate(layout.lattices):
+        first, count, _ = rng[i]
+        net["lattice"][first:first + count] = slot
+    for slot, (i, r, c) in enumerate(layout.st_lattices):
+        first, count, _ = rng[i]
+        net["st_lattice"][first:first + count] = slot
+    net.layout = layout
+    return net
+
+
+def device_from_oracle(snn, net, shard=None, device=0):
+    """Create a DeviceNetwork holding exactly the oracle net's state."""
+    lay = net.layout
+    dn = snn.DeviceNetwork(model=net.model, nt_kinetics=net.nt_kind, receptor_kinetics=net.rc_kind,
+                           spike_train=net.st_kind, device=device)
+    for i, r, c in lay.lattices:
+        dn.add_lattice(i, r, c)
+    for i, r, c in lay.st_lattices:
+        dn.add_spike_train_lattice(i, r, c)
+    if shard is None:
+        dn.finalize()
+    else:
+        dn.finalize(*shard)
+    push_state(dn, net)
+    nn = net.n_neurons
+    if net.n_tot and nn:
+        dn.set_graph_rows(0, net["weights"], net["connections"].astype(np.uint32))
+    dn.set_synapses(net.electrical, net.chemical)
+    for slot, (i, r, c) in enumerate(lay.lattices):
+        dn.set_plasticity(i, float(net["stdp_a_plus"][slot]), float(net["stdp_a_minus"][slot]),
+                          float(net["stdp_tau_plus"][slot]), float(net["stdp_tau_minus"][slot]),
+                          float(net["stdp_dt"][slot]), bool(net["do_plasticity"][slot]))
+    return dn
+
+
+def _neuron_names(net):
+    names = dict(COMMON)
+    names.update(MODEL_ATTRS[net.model])
+    return names
+
+
+def push_state(dn, net):
+    rng = net.layout.ranges()
+    for i, (first, count, is_st) in rng.items():
+        if count == 0:
+            continue
+        sl = slice(first, first + count)
+        if not is_st:
+            for o, a in _neuron_names(net).items():
+                dn.set_attr(i, a, net[o][sl])
+            for o, a in NT_ATTRS.items():
+                dn.set_attr(i, a, net[o][sl])
+            dn.set_attr(i, "receptors$flags", net["rc_flags"][sl])
+            for k, t in enumerate(TYPE_NAMES):
+                for o, pat in RC_PER_TYPE.items():
+                    dn.set_attr(i, pat.replace("{T}", t), np.ascontiguousarray(net[o][sl, k]))
+            dn.set_attr(i, "receptors$NMDA_mg", np.ascontiguousarray(net["rc_mg"][sl, 1]))
+        else:
+            for o, a in CELL_ATTRS.items():
+                dn.set_attr(i, a, net[o][sl])
+            for o, a in CELL_KIND_ATTRS.get(net.st_kind, {}).items():
+                dn.set_attr(i, a, net[o][sl])
+            for o, a in NT_ATTRS.items():
+                dn.set_attr(i, a, net["st_" + o][sl])
+
+
+def pull_state(dn, net):
+    """Download the device state into a dict keyed like the oracle's arrays."""
+    out = {}
+    rng = net.layout.ranges()
+
+    def put(name, sl, val):
+        if name not in out:
+            out[name] = np.zeros_like(net[name])
+        out[name][sl] = val.reshape(out[name][sl].shape)
+
+    for i, (first, count, is_st) in rng.items():
+        if count == 0:
+            continue
+        sl = slice(first, first + count)
+        if not is_st:
+            for o, a in _neuron_names(net).items():
+                put(o, sl, dn.get_attr(i, a, dtype=net[o].dtype))
+            for o, a in NT_ATTRS.items():
+                put(o, sl, dn.get_attr(i, a, dtype=net[o].dtype, per_type=True))
+            put("rc_flags", sl, dn.get_attr(i, "receptors$flags", dtype=np.uint32, per_type=True))
+            for k, t in enumerate(TYPE_NAMES):
+                for o, pat in RC_PER_TYPE.items():
+                    if o not in out:
+                        out[o] = np.zeros_like(net[o])
+                    out[o][sl, k] = dn.get_attr(i, pat.replace("{T}", t))
+        else:
+            for o, a in CELL_ATTRS.items():
+                put(o, sl, dn.get_attr(i, a, dtype=net[o].dtype))
+            for o, a in CELL_KIND_ATTRS.get(net.st_kind, {}).items():
+                put(o, sl, dn.get_attr(i, a, dtype=net[o].dtype))
+            for o, a in NT_ATTRS.items():
+                put("st_" + o, sl, dn.get_attr(i, a, dtype=net["st_" + o].dtype, per_type=True))
+    return out
+
+
+def bits(a):
+    a = np.ascontiguousarray(a)
+    return a.view(np.uint32) if a.dtype == np.float32 else a
+
+
+def assert_state_equal(net, dev_state, skip=()):
+    """Bit-exact comparison (NaN payloads included) of every downloaded array."""
+    bad = []
+    for name, dv in dev_state.items():
+        if name in skip:
+            continue
+        ov = net[name]
+        if not np.array_equal(bits(ov), bits(dv)):
+            idx = np.argwhere(bits(ov) != bits(dv))
+            first = tuple(idx[0])
+            bad.append(f"{name}: {len(idx)} mismatches, first at {first}: oracle={ov[first]!r} hip={dv[first]!r}")
+    assert not bad, "state differs from the oracle:\n  " + "\n  ".join(bad)
+
+
+def assert_graph_equal(net, dn):
+    if net.n_tot == 0 or net.n_neurons == 0:
+        return
+    w, c = dn.get_graph_rows(0, net.n_tot)
+    oc = net["connections"].astype(np.uint32)
+    assert np.array_equal(c, oc), "connection masks differ"
+    ow = np.where(oc != 0, net["weights"], np.float32(0))
+    if not np.array_equal(bits(ow), bits(w)):
+        idx = np.argwhere(bits(ow) != bits(w))
+        f = tuple(idx[0])
+        raise AssertionError(f"weights differ at {len(idx)} places, first {f}: oracle={ow[f]!r} hip={w[f]!r}")
