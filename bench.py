@@ -1,0 +1,158 @@
+#!/usr/bin/env python3
+"""bench.py -- neuron-steps/s of the dense 256x256 Izhikevich lattice (BASELINE.json configs[1]).
+
+One "step" = one time-step of the whole lattice (inputs -> neuron update), state and the 17.18 GB
+synapse matrix resident in HBM before the timed region.  `--gpus N` > 1 (launched by torchrun, one
+rank per GPU) shards the SAME lattice by postsynaptic population (strong scaling) with one RCCL
+all-gather of the exchanged planes per step.
+
+Prints ONE JSON line (rank 0) with the driver's contract keys plus `roofline` (dominant kernel
+k_inputs_dense timed with HIP events on the stepper's own stream) and `cpu_baseline` (the oracle --
+a C restatement of the reference's CPU path -- timed on a bounded column sample, rank 0, N = 1).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ROWS = COLS = 256
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling is ~6.3 TB/s
+
+
+def cpu_baseline(n, sample_cols, steps, threads):
+    """Time the oracle (kind "port") on `sample_cols` postsynaptic neurons of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import oracle_binding as ob
+    net = ob.Net(n, model=ob.IZHIKEVICH)
+    # column window [0, sample_cols) of the same synthetic graph
+    net.arr["weights"] = np.empty((n, sample_cols), np.float32)
+    net.arr["connections"] = np.empty((n, sample_cols), np.uint8)
+    net.w_col0, net.w_ld = 0, sample_cols
+    ob.lib().snn_o_fill_graph_window(net["weights"].ctypes.data_as(ob.f32p), net["connections"].ctypes.data_as(ob.u8p),
+                                     n, n, 0, sample_cols, 2, 0.5, 1.5, 0)
+    net["gap_conductance"] = 10.0
+    net["current_voltage"] = ob.uniform_array(1, n, -65.0, 30.0)
+    net.n_threads = threads
+    t0 = time.perf_counter()
+    net.inputs(0, sample_cols)            # warm-up (page-in) + calibration of the sample length
+    one = time.perf_counter() - t0
+    if steps is None:                     # aim at ~15 s of CPU work
+        steps = int(min(200, max(2, 15.0 / max(one, 1e-3))))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        net.inputs(0, sample_cols)        # O(N) synapses per sampled neuron: the whole per-neuron cost
+        net.update_neurons()              # O(1) per neuron (all N, negligible)
+    dt = time.perf_counter() - t0
+    return sample_cols * steps / dt, dt, steps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--rows", type=int, default=ROWS)
+    ap.add_argument("--cols", type=int, default=COLS)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import snn_amd
+    from snn_amd import parallel, synthetic
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    n = args.rows * args.cols
+    dn = snn_amd.DeviceNetwork(model=snn_amd.IZHIKEVICH, device=local_rank)
+    dn.add_lattice(0, args.rows, args.cols)
+    if world > 1:
+        dn.finalize(rank, world)
+    else:
+        dn.finalize()
+    # BASELINE.md C2 inputs: defaults, gap_conductance 10, V0 ~ U[-65,30] seed 1, weights U[0.5,1.5] seed 2, x != y
+    dn.set_attr(0, "gap_conductance", np.full(n, 10.0, np.float32))
+    dn.set_attr(0, "current_voltage", synthetic.uniform(1, n, -65.0, 30.0))
+    dn.fill_graph_synthetic(2, 0.5, 1.5, with_diagonal=False)
+
+    if world > 1:
+        buf = parallel.exchange_tensor(dn, torch.device("cuda", local_rank))
+        stepper = parallel.ShardedStepper(dn, buf, rank, world, sync=torch.cuda.synchronize)
+        run = stepper.run
+    else:
+        run = dn.run
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run(args.warmup)
+    dn.profile_enable(True)
+    dn.profile_reset()
+    barrier()
+    t0 = time.perf_counter()
+    run(args.steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    launches, kern_ms = dn.profile_read()
+    dn.profile_enable(False)
+
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        value = n * args.steps / elapsed
+        bytes_per_launch = dn.input_kernel_bytes()
+        avg_ms = kern_ms / max(1, launches)
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if launches else 0.0
+        out = {
+            "metric": "neuron-steps/sec", "value": value, "unit": "neuron-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.rows}x{args.cols} Izhikevich lattice, dense gap-junction connectivity "
+                                   f"(all-to-all, x != y), dt=0.1, weights U[0.5,1.5]",
+                       "neurons": n, "synapses_per_step": n * (n - 1),
+                       "parallelism": f"post-population shards x{world}" if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_inputs_dense", "launches": launches, "avg_launch_ms": avg_ms,
+                         "algorithmic_bytes_per_launch": bytes_per_launch},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            threads = os.cpu_count() or 1
+            sample = 4096 if n >= 4096 else n
+            v, secs, cpu_steps = cpu_baseline(n, sample, None, threads)
+            out["cpu_baseline"] = {"value": v, "unit": "neuron-steps/s", "cores": threads, "kind": "port",
+                                   "sample": f"oracle (C restatement, OpenMP x{threads}) on {sample} of {n} postsynaptic "
+                                             f"neurons x {cpu_steps} steps ({secs:.1f} s); each sampled neuron sums all "
+                                             f"{n} presynaptic terms, i.e. the full per-neuron-step cost"}
+        print(json.dumps(out), flush=True)
+
+    dn.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

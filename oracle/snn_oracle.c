@@ -101,89 +101,139 @@ void snn_o_fill_graph(float *weights, uint8_t *connections, uint32_t n_tot, uint
         }
 }
 
+/* columns [col0, col0+ncols) of the same synthetic graph, stored [n_tot][ncols] */
+void snn_o_fill_graph_window(float *weights, uint8_t *connections, uint32_t n_tot, uint32_t n_neurons,
+                             uint32_t col0, uint32_t ncols, uint64_t seed, float lo, float hi,
+                             int with_diagonal)
+{
+#if defined(_OPENMP)
+    #pragma omp parallel for schedule(static)
+#endif
+    for (int64_t p = 0; p < (int64_t)n_tot; ++p)
+        for (uint32_t j = 0; j < ncols; ++j) {
+            uint32_t q = col0 + j;
+            size_t i = (size_t)p * ncols + j;
+            int c = with_diagonal || (uint32_t)p != q;
+            connections[i] = (uint8_t)c;
+            weights[i] = c ? snn_o_uniform(seed, (uint64_t)p * n_neurons + q, lo, hi) : 0.0f;
+        }
+}
+
 /* ---------- step 1: inputs ---------- */
 
 /*
- * One postsynaptic neuron q.
+ * Postsynaptic neurons [q0, q0+nq), nq <= SNN_O_QBLOCK, advanced together so that each 64-byte line
+ * of the row-major matrix is read once; per column the arithmetic is exactly the sequential chunked
+ * sum of the header.
  *   electrical: Lattice::calculate_internal_electrical_input_from_positions  neuron/mod.rs:702-730
  *               LatticeNetwork::calculate_electrical_input_from_positions    neuron/mod.rs:2115-2167
  *               gap_junction mod.rs:54-60, spike_train_gap_junction mod.rs:119-137
  *   chemical:   calculate_*_neurotransmitter_input_from_positions mod.rs:733-754 / 2169-2210,
  *               weight_/aggregate_neurotransmitter_concentration(s) iterate_and_spike/mod.rs:2837-2866
  */
-static void inputs_column(snn_o_net *n, uint32_t q)
+#define SNN_O_QBLOCK 16
+
+static void inputs_block(snn_o_net *n, uint32_t q0, uint32_t nq)
 {
     const uint32_t nn = n->n_neurons;
     const uint32_t n_tot = nn + n->n_cells;
-    const float vq = n->current_voltage[q];
-    const float gq = n->gap_conductance[q];
+    const size_t ld = n->w_ld ? n->w_ld : nn;
+    const uint32_t col0 = n->w_col0;
 
-    float sum = 0.0f;
-    float tsum[SNN_O_K] = {0.0f, 0.0f, 0.0f};
-    uint32_t n_in = 0;
-    uint32_t tcnt[SNN_O_K] = {0, 0, 0};
+    float vq[SNN_O_QBLOCK], gq[SNN_O_QBLOCK], sum[SNN_O_QBLOCK], part[SNN_O_QBLOCK];
+    float tsum[SNN_O_K][SNN_O_QBLOCK], tpart[SNN_O_K][SNN_O_QBLOCK];
+    uint32_t n_in[SNN_O_QBLOCK], tcnt[SNN_O_K][SNN_O_QBLOCK];
+    for (uint32_t j = 0; j < nq; ++j) {
+        vq[j] = n->current_voltage[q0 + j];
+        gq[j] = n->gap_conductance[q0 + j];
+        sum[j] = 0.0f; n_in[j] = 0;
+        for (int k = 0; k < SNN_O_K; ++k) { tsum[k][j] = 0.0f; tcnt[k][j] = 0; }
+    }
 
     for (uint32_t c0 = 0; c0 < n_tot; c0 += SNN_O_CHUNK) {
         uint32_t c1 = c0 + SNN_O_CHUNK;
         if (c1 > n_tot) c1 = n_tot;
-        float part = 0.0f;
-        float tpart[SNN_O_K] = {0.0f, 0.0f, 0.0f};
-
+        for (uint32_t j = 0; j < nq; ++j) {
+            part[j] = 0.0f;
+            for (int k = 0; k < SNN_O_K; ++k) tpart[k][j] = 0.0f;
+        }
         for (uint32_t p = c0; p < c1; ++p) {
-            size_t i = (size_t)p * nn + q;
-            if (!n->connections[i]) continue;
-            const float w = n->weights[i];
-            ++n_in;
-
-            if (n->electrical) {
-                float term;
-                if (p < nn) {
-                    term = gq * (n->current_voltage[p] - vq);
-                } else {
-                    uint32_t s = p - nn;
-                    if (n->st_last_firing_time[s] < 0)
-                        term = n->st_v_resting[s];         /* no conductance factor, mod.rs:126-128 */
-                    else
-                        term = gq * snn_o_delta_dirac_effect(n->clock, n->st_last_firing_time[s],
-                                                             n->st_v_th[s], n->st_v_resting[s],
-                                                             n->st_k[s], n->st_dt[s]);
+            const float *wrow = n->weights + (size_t)p * ld + (q0 - col0);
+            const uint8_t *crow = n->connections + (size_t)p * ld + (q0 - col0);
+            /* presynaptic side, once per row */
+            int kind = 0;                 /* 0 neuron, 1 silent spike train, 2 fired spike train */
+            float pv = 0.0f;
+            uint32_t s = 0;
+            if (p < nn) {
+                pv = n->current_voltage[p];
+            } else {
+                s = p - nn;
+                if (n->st_last_firing_time[s] < 0) { kind = 1; pv = n->st_v_resting[s]; }
+                else {
+                    kind = 2;
+                    pv = snn_o_delta_dirac_effect(n->clock, n->st_last_firing_time[s], n->st_v_th[s],
+                                                  n->st_v_resting[s], n->st_k[s], n->st_dt[s]);
                 }
-                part += term * w;
             }
+            if (n->electrical) {
+                if (kind == 0) {
+                    for (uint32_t j = 0; j < nq; ++j)
+                        if (crow[j]) part[j] += (gq[j] * (pv - vq[j])) * wrow[j];
+                } else if (kind == 1) {
+                    for (uint32_t j = 0; j < nq; ++j)      /* no conductance factor, mod.rs:126-128 */
+                        if (crow[j]) part[j] += pv * wrow[j];
+                } else {
+                    for (uint32_t j = 0; j < nq; ++j)
+                        if (crow[j]) part[j] += (gq[j] * pv) * wrow[j];
+                }
+            }
+            for (uint32_t j = 0; j < nq; ++j) n_in[j] += crow[j] ? 1u : 0u;
             if (n->chemical) {
                 for (int k = 0; k < SNN_O_K; ++k) {
                     uint32_t flag; float t;
                     if (p < nn) { flag = n->nt_flags[(size_t)p * SNN_O_K + k]; t = n->nt_t[(size_t)p * SNN_O_K + k]; }
-                    else { uint32_t s = p - nn; flag = n->st_nt_flags[(size_t)s * SNN_O_K + k]; t = n->st_nt_t[(size_t)s * SNN_O_K + k]; }
-                    if (flag) { tpart[k] += t * w; ++tcnt[k]; }
+                    else { flag = n->st_nt_flags[(size_t)s * SNN_O_K + k]; t = n->st_nt_t[(size_t)s * SNN_O_K + k]; }
+                    if (!flag) continue;
+                    for (uint32_t j = 0; j < nq; ++j)
+                        if (crow[j]) { tpart[k][j] += t * wrow[j]; ++tcnt[k][j]; }
                 }
             }
         }
-        sum += part;
-        for (int k = 0; k < SNN_O_K; ++k) tsum[k] += tpart[k];
+        for (uint32_t j = 0; j < nq; ++j) {
+            sum[j] += part[j];
+            for (int k = 0; k < SNN_O_K; ++k) tsum[k][j] += tpart[k][j];
+        }
     }
 
-    if (n->electrical) {
-        float averager = (n_in == 0) ? 1.0f : (float)n_in;   /* mod.rs:722-727 */
-        n->input_current[q] = sum / averager;
-    } else {
-        n->input_current[q] = 0.0f;                          /* mod.rs:929-931 */
-    }
-    if (n->chemical) {
-        for (int k = 0; k < SNN_O_K; ++k) {
-            n->input_count[(size_t)q * SNN_O_K + k] = (float)tcnt[k];
-            n->input_t[(size_t)q * SNN_O_K + k] = tcnt[k] ? tsum[k] / (float)tcnt[k] : 0.0f;
+    for (uint32_t j = 0; j < nq; ++j) {
+        const uint32_t q = q0 + j;
+        if (n->electrical) {
+            float averager = (n_in[j] == 0) ? 1.0f : (float)n_in[j];   /* mod.rs:722-727 */
+            n->input_current[q] = sum[j] / averager;
+        } else {
+            n->input_current[q] = 0.0f;                                /* mod.rs:929-931 */
+        }
+        if (n->chemical) {
+            for (int k = 0; k < SNN_O_K; ++k) {
+                n->input_count[(size_t)q * SNN_O_K + k] = (float)tcnt[k][j];
+                n->input_t[(size_t)q * SNN_O_K + k] = tcnt[k][j] ? tsum[k][j] / (float)tcnt[k][j] : 0.0f;
+            }
         }
     }
 }
 
 void snn_o_inputs_range(snn_o_net *n, uint32_t q0, uint32_t q1)
 {
+    const int64_t nblocks = ((int64_t)q1 - q0 + SNN_O_QBLOCK - 1) / SNN_O_QBLOCK;
 #if defined(_OPENMP)
     int nt = n->n_threads > 1 ? n->n_threads : 1;
     #pragma omp parallel for schedule(static) num_threads(nt)
 #endif
-    for (int64_t q = q0; q < (int64_t)q1; ++q) inputs_column(n, (uint32_t)q);
+    for (int64_t b = 0; b < nblocks; ++b) {
+        uint32_t b0 = q0 + (uint32_t)b * SNN_O_QBLOCK;
+        uint32_t nq = (q1 - b0 < SNN_O_QBLOCK) ? (q1 - b0) : SNN_O_QBLOCK;
+        inputs_block(n, b0, nq);
+    }
 }
 
 void snn_o_inputs(snn_o_net *n) { snn_o_inputs_range(n, 0, n->n_neurons); }

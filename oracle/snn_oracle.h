@@ -126,6 +126,9 @@ typedef struct snn_o_net {
     float    *input_t;                     /* [n_neurons*K] */
     float    *input_count;                 /* [n_neurons*K] (#pres that carry type k) */
     int32_t  n_threads;                    /* >1: OpenMP over postsynaptic neurons (≙ rayon par_, mod.rs:775-790) */
+    /* column window of `weights`/`connections` (bounded CPU-baseline samples of a large matrix):
+     * the arrays hold columns [w_col0, w_col0 + w_ld) only; w_ld == 0 means the full n_neurons. */
+    uint32_t w_col0, w_ld;
 } snn_o_net;
 
 /* Step 1 of SURVEY §8(g): electrical + chemical inputs for every neuron from state S(t). */
@@ -157,6 +160,10 @@ float    snn_o_uniform(uint64_t seed, uint64_t index, float lo, float hi);
 /* weights[p][q] = U[lo,hi) from (seed, p*n_neurons+q); conn = (p != q) unless with_diagonal */
 void snn_o_fill_graph(float *weights, uint8_t *connections, uint32_t n_tot, uint32_t n_neurons,
                       uint64_t seed, float lo, float hi, int with_diagonal);
+
+void snn_o_fill_graph_window(float *weights, uint8_t *connections, uint32_t n_tot, uint32_t n_neurons,
+                             uint32_t col0, uint32_t ncols, uint64_t seed, float lo, float hi,
+                             int with_diagonal);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,76 @@
+"""Multi-GPU stepping: one process per GPU, the postsynaptic population sharded in equal slots.
+
+The reference has no distributed path at all; the sharding follows from the step's data
+flow (backend/src/neuron/mod.rs:1077-1085, 2640-2647): every neuron's input at step t depends only on
+the state S(t) of its presynaptic cells, so a rank that owns the columns W[:, shard] of the dense
+synapse matrix needs, per step, exactly the other shards' exchanged planes (voltage, spike flag,
+neurotransmitter concentrations) -- ONE in-place all-gather of contiguous per-rank blocks over
+RCCL/xGMI (`torch.distributed`, backend "nccl"), no other collective.  Spike-train cells are
+replicated (deterministic xorshift32), plasticity is applied by the owner of the column.
+
+`ShardedStepper` is backend-agnostic on purpose: the product passes a `DeviceNetwork` shard, the CPU
+tests (gloo, world_size 2) pass an oracle-backed object with the same four members.
+"""
+import ctypes
+
+import numpy as np
+
+
+class _DeviceWords:
+    """Expose a raw device allocation to torch through __cuda_array_interface__ (no copy)."""
+
+    def __init__(self, ptr, n_words):
+        self.__cuda_array_interface__ = {"shape": (int(n_words),), "typestr": "<f4",
+                                         "data": (int(ptr), False), "version": 2}
+
+
+def exchange_tensor(dn, device):
+    """torch view of a DeviceNetwork's exchange buffer: [n_shards * words_per_neuron * stride] f32."""
+    import torch
+    ptr, words, n_padded = dn.exchange_buffer()
+    return torch.as_tensor(_DeviceWords(ptr, words * n_padded), device=device)
+
+
+def shard_geometry(n_neurons, n_shards):
+    """Slot size and [begin, end) of every shard -- same rule as snn_network_finalize_shard."""
+    per = -(-n_neurons // n_shards)            # ceil
+    stride = max(64, -(-per // 64) * 64)       # rounded up to a wavefront
+    out = []
+    for r in range(n_shards):
+        b = min(n_neurons, r * stride)
+        out.append((b, min(n_neurons, b + stride)))
+    return stride, out
+
+
+class ShardedStepper:
+    """Drives one shard: step_begin -> all-gather of the exchanged planes -> step_end.
+
+    backend members used: step_begin(), step_end(); `buf` is a 1-D torch tensor over the backend's
+    exchange buffer laid out [shard][plane][stride] so that shard r's block is contiguous.
+    """
+
+    def __init__(self, backend, buf, rank, world_size, group=None, sync=None):
+        import torch.distributed as dist
+        self.backend, self.buf, self.rank, self.world = backend, buf, rank, world_size
+        self.group = group
+        self.dist = dist
+        assert buf.numel() % world_size == 0, "exchange buffer must split evenly over the ranks"
+        self.block = buf.numel() // world_size
+        self.local = buf[rank * self.block:(rank + 1) * self.block]
+        self._sync = sync or (lambda: None)
+
+    def exchange(self):
+        if self.world == 1:
+            return
+        if self.buf.is_cuda:
+            self.dist.all_gather_into_tensor(self.buf, self.local, group=self.group)
+        else:   # gloo has no all_gather_into_tensor on every build: gather into per-rank views
+            views = [self.buf[r * self.block:(r + 1) * self.block] for r in range(self.world)]
+            self.dist.all_gather(views, self.local.clone(), group=self.group)
+        self._sync()
+
+    def run(self, iterations):
+        for _ in range(int(iterations)):
+            self.backend.step_begin()
+            self.exchange()
+            self.backend.step_end()

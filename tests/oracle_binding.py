@@ -60,6 +60,7 @@ _FIELDS = [
     ("voltage_history", f32p), ("spike_history", u8p), ("st_voltage_history", f32p),
     ("input_current", f32p), ("input_t", f32p), ("input_count", f32p),
     ("n_threads", C.c_int32),
+    ("w_col0", C.c_uint32), ("w_ld", C.c_uint32),
 ]
 
 
@@ -107,6 +108,9 @@ def lib():
         L.snn_o_fill_graph.argtypes = [f32p, u8p, C.c_uint32, C.c_uint32, C.c_uint64,
                                        C.c_float, C.c_float, C.c_int]
         L.snn_o_fill_graph.restype = None
+        L.snn_o_fill_graph_window.argtypes = [f32p, u8p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                              C.c_uint64, C.c_float, C.c_float, C.c_int]
+        L.snn_o_fill_graph_window.restype = None
         _lib = L
     return _lib
 
@@ -162,6 +166,8 @@ class Net:
         self.n_lattices = int(n_lattices)
         self.n_st_lattices = int(n_st_lattices if n_st_lattices is not None else (1 if n_cells else 0))
         self.n_threads = 1
+        self.w_col0 = 0
+        self.w_ld = 0
         self.arr = {}
         nn, nc = self.n_neurons, self.n_cells
         for name, ct in _FIELDS:
