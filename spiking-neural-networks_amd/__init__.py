@@ -5,7 +5,7 @@ One hot path of NikhilMukraj/spiking-neural-networks -- `run_lattice` / `run_lat
 behind the C ABI of include/snn_amd.h.  The directory name carries a hyphen, so import it
 through the root-level shim: `import snn_amd`.
 """
-from . import _lib
+from . import _lib, parallel, synthetic
 from ._lib import SnnError, SnnLibraryError, build
 from .network import (DeviceNetwork, HODGKIN_HUXLEY, IZHIKEVICH, LIF, NT_APPROXIMATE, NT_DESTEXHE,
                       NUM_NT_TYPES, RC_APPROXIMATE, RC_DESTEXHE, ST_NONE, ST_POISSON, ST_RATE, probe_math)

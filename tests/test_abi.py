@@ -1,0 +1,74 @@
+"""The C-ABI shared library loads and exports every symbol include/snn_amd.h declares; the Python
+binding declares exactly that set; failures are loud (no CPU fallback).  No compute calls here."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import snn_amd
+from snn_amd import _lib
+
+HEADER = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "snn_amd.h")
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(snn_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported_and_bound():
+    names = declared_functions()
+    assert len(names) >= 40
+    lib = _lib.load()
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(raw, n), f"{n} is declared in snn_amd.h but not exported by libsnn_amd.so"
+    assert sorted(_lib.SIGNATURES) == names, "python binding and header disagree on the entry points"
+    assert lib.snn_abi_version() == 1
+
+
+def test_header_cites_the_reference_interface():
+    text = open(HEADER).read()
+    for needle in ("gpu_lattices/mod.rs:496-511", "gpu_lattices/mod.rs:1081-1100", "gpu_lattices/mod.rs:3183-3212",
+                   "iterate_and_spike/mod.rs:3156-3189", "graph/mod.rs", "error/mod.rs:221-238"):
+        assert needle in text
+
+
+def test_error_codes_mirror_gpu_error_order():
+    text = open(HEADER).read()
+    order = ["PROGRAM_COMPILE", "KERNEL_COMPILE", "BUFFER_CREATE", "BUFFER_WRITE", "BUFFER_READ", "WAIT",
+             "GET_DEVICE", "QUEUE"]
+    for i, n in enumerate(order, start=1):
+        assert re.search(rf"SNN_ERR_{n}\s*=\s*{i}\b", text)
+
+
+def test_no_device_fails_loudly_not_silently():
+    """Without a GPU the library must report GetDeviceFailure (7), never fall back to a CPU path."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(snn_amd.SnnError) as e:
+        snn_amd.DeviceNetwork()
+    assert e.value.code == 7 and "device" in str(e.value).lower()
+
+
+def test_null_and_bad_arguments_return_codes():
+    L = _lib.load()
+    assert L.snn_network_destroy(None) == 0
+    assert L.snn_network_create(0, 99, 0, 0, 0, ctypes.byref(_lib.H())) == 11      # SNN_ERR_BAD_ARG
+    assert L.snn_network_create(0, 0, 0, 0, 0, None) == 11
+    assert L.snn_run(None, 1) == 11
+    assert b"null" in L.snn_last_error()
+
+
+def test_product_never_touches_the_oracle():
+    """Nothing under the product package may import / load / link anything from oracle/ or tests/."""
+    pkg = os.path.dirname(_lib.__file__)
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f), errors="replace").read()
+                for needle in ("oracle/", "snn_oracle", "oracle_binding", "libsnn_oracle", "snn_o_"):
+                    assert needle not in src, f"{f} references the oracle ({needle})"

@@ -1,0 +1,306 @@
+"""Pin the oracle to every known-answer / behavioural test the reference holds for the hot path
+ and to hand-derived values of each formula.  The reference has no golden vectors and its
+own CPU sums run in HashSet order, so bit-level parity with the Rust crate is unpinned; these are the
+anchors that exist.  Citations relative to /root/reference/backend/."""
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+import parity
+
+f32 = np.float32
+
+
+# ---- tests/rate_spike_train.rs:28-72 -------------------------------------------------------------
+@pytest.mark.parametrize("rate", [0, 100, 200, 300, 400, 500])
+def test_rate_spike_train_expected_rate(rate):
+    """test_expected_rate: 10 000 iterations at the default dt = 0.1 fire ITER/(rate/0.1) +- 1 times."""
+    net = ob.Net(0, n_cells=1, st_kind=ob.ST_RATE)
+    net["st_rate"] = rate
+    spikes = 0
+    for _ in range(10_000):
+        net.spike_trains()
+        spikes += int(net["st_is_spiking"][0])
+    if rate == 0:
+        assert spikes == 0
+    else:
+        assert abs(spikes - 10_000 / (rate / 0.1)) <= 1.0
+
+
+def test_rate_spike_train_spacing():
+    """test_spacing: rate = 100, dt = 1 fires exactly when (i + 1) % 100 == 0 (and never at i == 0)."""
+    net = ob.Net(0, n_cells=1, st_kind=ob.ST_RATE)
+    net["st_rate"] = 100.0
+    net["st_dt"] = 1.0
+    for i in range(1001):
+        net.spike_trains()
+        expect = not (i == 0 or (i + 1) % 100 != 0)
+        assert bool(net["st_is_spiking"][0]) == expect, i
+    # last_firing_time is stamped with the spike-train lattice's own clock (src/neuron/mod.rs:1377-1393)
+    assert net["st_last_firing_time"][0] == 999
+    assert net["st_clock"][0] == 1001
+
+
+# ---- src/graph/mod.rs:113-137 (doc-test) ---------------------------------------------------------
+def test_none_is_not_some_zero_in_the_averager():
+    """lookup_weight distinguishes None from Some(w); an edge Some(0.0) still counts as an input
+    (src/neuron/mod.rs:722-727 divides by input_positions.len())."""
+    net = ob.Net(3)
+    net["current_voltage"] = np.array([-60.0, -50.0, -40.0], f32)
+    net["gap_conductance"] = 2.0
+    # edges into neuron 1: from 0 with w = 0.5, from 2 with w = Some(0.0)
+    net["connections"][0, 1] = 1
+    net["weights"][0, 1] = 0.5
+    net["connections"][2, 1] = 1
+    net["weights"][2, 1] = 0.0
+    net.inputs()
+    expect = (f32(2.0) * (f32(-60.0) - f32(-50.0))) * f32(0.5) + (f32(2.0) * (f32(-40.0) - f32(-50.0))) * f32(0.0)
+    assert net["input_current"][1] == f32(expect) / f32(2.0)          # two inputs, not one
+    # removing the zero-weight edge (edit_weight(.., None)) changes the averager
+    net["connections"][2, 1] = 0
+    net.inputs()
+    assert net["input_current"][1] == f32(-10.0)
+    assert net["input_current"][0] == 0.0 and net["input_current"][2] == 0.0   # no inputs -> 0 / 1
+
+
+# ---- tests/size_zero_cases.rs ----------------------------------------------------------------------
+def test_zero_size_lattice_is_a_noop():
+    net = ob.Net(0)
+    net.run(25)
+    assert net.clock == 25          # CPU run_lattice still counts steps on an empty grid (mod.rs:979)
+    net = ob.Net(4)
+    net.electrical = net.chemical = False
+    before = net["current_voltage"].copy()
+    net.run(10)
+    assert net.clock == 0 and np.array_equal(before, net["current_voltage"])   # (false,false) => Ok(())
+
+
+# ---- tests/spike_train_neuron_interaction.rs:91-203 ------------------------------------------------
+def _poisson_to_neuron(model, synapses, dt, iterations, hh=False):
+    lay = parity.Layout([(1, 1, 1)], [(0, 1, 1)])
+    net = parity.make_oracle(lay, model=model, st_kind=ob.ST_POISSON, electrical=synapses[0], chemical=synapses[1])
+    net["gap_conductance"] = 7.0 if hh else 10.0
+    net["nt_flags"][:, 0] = 1
+    net["st_nt_flags"][:, 0] = 1
+    net["rc_flags"][:, 0] = 1
+    net["dt"] = dt
+    net["st_dt"] = dt
+    net["stdp_dt"] = dt
+    net["connections"][1, 0] = 1        # spike-train cell (index 1) -> neuron 0, x == y, weight 1
+    net["weights"][1, 0] = 1.0
+    net["st_seed"] = 12345
+    net.run(iterations, spike_history=True)
+    first = int(net.spike_history.sum())
+    net["st_chance_of_firing"] = (dt / 1.0) * 0.01
+    net.run(iterations, spike_history=True)
+    return first, int(net.spike_history.sum())
+
+
+def test_poisson_drives_izhikevich_through_gap_junction():
+    first, second = _poisson_to_neuron(ob.IZHIKEVICH, (True, False), 1.0, 2500)
+    assert first <= 1 and second > 2
+
+
+def test_poisson_drives_izhikevich_through_ampa():
+    first, second = _poisson_to_neuron(ob.IZHIKEVICH, (False, True), 1.0, 2500)
+    assert first <= 1 and second > 2
+
+
+def test_poisson_drives_hodgkin_huxley_through_ampa():
+    first, second = _poisson_to_neuron(ob.HH, (False, True), 0.01, 100_000, hh=True)
+    assert first <= 1 and second > 2
+
+
+# ---- hand-derived single-step values -----------------------------------------------------------------
+def test_izhikevich_default_first_step():
+    """default neuron, I = 0: dv = (((0.04*65*65 - 325) + 140) - 30 + 0) * (0.1/100)."""
+    net = ob.Net(1)
+    net.run(1)
+    v, w = f32(-65.0), f32(30.0)
+    dv = ((((f32(0.04) * (v * v)) + f32(5.0) * v) + f32(140.0)) - w + f32(0.0)) * (f32(0.1) / f32(100.0))
+    dw = (f32(0.02) * (f32(0.2) * v - w)) * (f32(0.1) / f32(1.0))
+    assert net["current_voltage"][0] == v + dv
+    assert net["w_value"][0] == w + dw
+    assert net["is_spiking"][0] == 0 and net["last_firing_time"][0] == -1
+
+
+def test_izhikevich_spike_reset_and_stamp():
+    net = ob.Net(1)
+    net["current_voltage"] = 29.99
+    net.clock = 41
+    net.run(1)
+    assert net["is_spiking"][0] == 1 and net["current_voltage"][0] == f32(-55.0)
+    assert net["last_firing_time"][0] == 41 and net.clock == 42
+
+
+def test_lif_step_and_refractory_period():
+    """integrate_and_fire/mod.rs:87-102, 173-179: default LIF with input 300 crosses threshold, then
+    stays at v_reset for tref/dt = 100 steps."""
+    net = ob.Net(1, model=ob.LIF)
+    v = f32(-75.0)
+    net["connections"][0, 0] = 1          # self-edge contributes g*(V-V)*w = 0 but exercises the averager
+    net["weights"][0, 0] = 1.0
+    net.run(1)
+    dv = ((f32(-1.0) * (v - f32(-75.0))) + (f32(1.0) * (f32(0.0) / f32(10.0)))) * (f32(0.1) / f32(10.0))
+    assert net["current_voltage"][0] == v + dv
+    net["current_voltage"] = -54.0
+    net.run(1)
+    assert net["is_spiking"][0] == 1 and net["refractory_count"][0] == f32(10.0) / f32(0.1)
+    net.run(100)
+    assert net["refractory_count"][0] == 0.0 and net["current_voltage"][0] == f32(-75.0)
+
+
+def test_stdp_delta_known_answers():
+    """plasticity/mod.rs:45-66 with defaults (2, 2, 4.5, 4.5, 0.1): (tp,tq) = (10,15) -> 2*exp(-|-5*0.1|/4.5)."""
+    L = ob.lib()
+    d = L.snn_o_stdp_delta(10, 15, 2.0, 2.0, 4.5, 4.5, 0.1)
+    assert d == f32(2.0) * f32(ob.expf(f32(-1.0) * abs((f32(10.0) - f32(15.0)) * f32(0.1)) / f32(4.5)))
+    assert abs(d - 2.0 * np.exp(-0.5 / 4.5)) < 1e-6
+    d = L.snn_o_stdp_delta(15, 10, 2.0, 2.0, 4.5, 4.5, 0.1)
+    assert abs(d + 2.0 * np.exp(-0.5 / 4.5)) < 1e-6
+    assert L.snn_o_stdp_delta(7, 7, 2.0, 2.0, 4.5, 4.5, 0.1) == 0.0
+    assert L.snn_o_stdp_delta(-1, 7, 2.0, 2.0, 4.5, 4.5, 0.1) == 0.0      # pre never fired
+    assert L.snn_o_stdp_delta(7, -1, 2.0, 2.0, 4.5, 4.5, 0.1) == 0.0
+
+
+def test_delta_dirac_and_spike_train_gap_junction():
+    """spike_train/mod.rs:84-86, neuron/mod.rs:119-137."""
+    L = ob.lib()
+    e = L.snn_o_delta_dirac_effect(12, 10, 30.0, 0.0, 10000.0, 0.1)
+    assert abs(e - 30.0 * np.exp(-(1.0 / (10000.0 / 0.1)) * 4.0)) < 1e-5
+    lay = parity.Layout([(1, 1, 1)], [(0, 1, 1)])
+    net = parity.make_oracle(lay, st_kind=ob.ST_RATE)
+    net["connections"][1, 0] = 1
+    net["weights"][1, 0] = 0.5
+    net["st_v_resting"] = -3.0
+    net.inputs()
+    assert net["input_current"][0] == f32(-3.0) * f32(0.5)          # never fired: v_resting, no conductance
+    net["st_last_firing_time"] = 10
+    net.clock = 12
+    net.inputs()
+    eff = L.snn_o_delta_dirac_effect(12, 10, 30.0, -3.0, 10000.0, 0.1)
+    assert net["input_current"][0] == (f32(7.0) * f32(eff)) * f32(0.5)
+
+
+def test_xorshift32_and_poisson_threshold():
+    """spike_train/mod.rs:380-388, 419-426."""
+    L = ob.lib()
+    x = 1
+    for _ in range(3):
+        x = L.snn_o_xorshift32(x)
+    ref = 1
+    for _ in range(3):
+        ref ^= (ref << 13) & 0xFFFFFFFF
+        ref ^= ref >> 17
+        ref ^= (ref << 5) & 0xFFFFFFFF
+    assert x == ref
+    net = ob.Net(0, n_cells=4, st_kind=ob.ST_POISSON)
+    net["st_chance_of_firing"] = 0.25
+    seeds = net["st_seed"].copy()
+    net.spike_trains()
+    for s in range(4):
+        ns = L.snn_o_xorshift32(int(seeds[s]))
+        assert net["st_seed"][s] == ns
+        assert bool(net["st_is_spiking"][s]) == (f32(ns) / f32(4294967296.0) < f32(0.25))
+        assert net["st_current_voltage"][s] == (30.0 if net["st_is_spiking"][s] else 0.0)
+
+
+def test_approximate_neurotransmitter_and_receptor_currents():
+    """iterate_and_spike/mod.rs:193-196 (t uses the PREVIOUS step's is_spiking), :1103-1105, :1132-1137,
+    :1286-1304."""
+    net = ob.Net(1, chemical=True, electrical=False)
+    net["nt_flags"][0, :] = 1
+    net["nt_t"][0, :] = 0.5
+    net["is_spiking"] = 1
+    net.run(1)
+    t = f32(0.5) + (f32(0.1) * f32(-0.01) * f32(0.5) + f32(1.0) * f32(1.0))
+    assert np.all(net["nt_t"][0] == min(f32(1.0), max(t, f32(0.0))))
+    # receptor currents from a hand-set gating value
+    net = ob.Net(1, chemical=True, electrical=False)
+    net["rc_flags"][0, :] = 1
+    net["rc_r"][0, :] = 0.25
+    v = f32(-65.0)
+    net.run(1)
+    i_ampa = (f32(1.0) * f32(0.25)) * (v - f32(0.0))
+    i_nmda = ((f32(1.0) / (f32(1.0) + ((f32(ob.expf(f32(-0.062) * v)) * f32(0.3)) / f32(3.75))) * f32(0.6)) * f32(0.25)) * (v - f32(0.0))
+    i_gaba = (f32(1.2) * f32(0.25)) * (v - f32(-80.0))
+    assert net["rc_current"][0, 0] == i_ampa and net["rc_current"][0, 1] == i_nmda and net["rc_current"][0, 2] == i_gaba
+    total = ((f32(0.0) + i_ampa) + i_nmda) + i_gaba
+    dv = (f32(0.04) * (v * v) + f32(5.0) * v + f32(140.0) - f32(30.0) + f32(0.0)) * (f32(0.1) / f32(100.0))
+    assert net["current_voltage"][0] == v + (dv + -(total * (f32(0.1) / f32(100.0))))
+
+
+def test_hodgkin_huxley_first_step():
+    """hodgkin_huxley/mod.rs:156-201, ion_channels/mod.rs:40-44, 219-236, 267-282, 309-312 at V = -65,
+    gates starting from 0 (the reference never calls init_state)."""
+    net = ob.Net(1, model=ob.HH)
+    net["connections"][0, 0] = 0
+    net.run(1)
+    e = lambda x: f32(ob.expf(f32(x)))
+    v, dt = f32(-65.0), f32(0.01)
+    m_a = f32(0.1) * ((v + f32(40.0)) / (f32(1.0) - e(-(v + f32(40.0)) / f32(10.0))))
+    m_b = f32(4.0) * e(-(v + f32(65.0)) / f32(18.0))
+    h_a = f32(0.07) * e(-(v + f32(65.0)) / f32(20.0))
+    h_b = f32(1.0) / (e(-(v + f32(35.0)) / f32(10.0)) + f32(1.0))
+    n_a = f32(0.01) * (v + f32(55.0)) / (f32(1.0) - e(-(v + f32(55.0)) / f32(10.0)))
+    n_b = f32(0.125) * e(-(v + f32(65.0)) / f32(80.0))
+    m = f32(0.0) + dt * (m_a * (f32(1.0) - f32(0.0)) - m_b * f32(0.0))
+    h = f32(0.0) + dt * (h_a * f32(1.0) - h_b * f32(0.0))
+    n = f32(0.0) + dt * (n_a * f32(1.0) - n_b * f32(0.0))
+    assert net["m_state"][0] == m and net["h_state"][0] == h and net["n_state"][0] == n
+    i_na = f32(np.float64(m) ** 3) * h * f32(120.0) * (v - f32(50.0))
+    i_k = f32(np.float64(n) ** 4) * f32(36.0) * (v - f32(-77.0))
+    i_l = f32(0.3) * (v - f32(-55.0))
+    assert net["na_current"][0] == i_na and net["k_current"][0] == i_k and net["k_leak_current"][0] == i_l
+    i_sum = f32(0.0) - (i_na + i_k + i_l)
+    assert net["current_voltage"][0] == v + (dt * i_sum / f32(1.0) - f32(0.0))
+
+
+def test_hodgkin_huxley_fires_under_constant_drive():
+    """Behavioural: a constant suprathreshold input makes the default HH neuron spike repeatedly
+    (peak detection, hodgkin_huxley/mod.rs:207-220)."""
+    lay = parity.Layout([(0, 1, 2)])
+    net = parity.make_oracle(lay, model=ob.HH)
+    # neuron 1 is clamped far above neuron 0 through a strong gap junction -> sustained drive
+    net["connections"][1, 0] = 1
+    net["weights"][1, 0] = 1.0
+    net["gap_conductance"][0] = 0.5
+    net["current_voltage"][1] = 0.0
+    net["g_na"][1] = 0.0
+    net["g_k"][1] = 0.0
+    net["g_k_leak"][1] = 0.0            # neuron 1 has no currents: its voltage stays at 0 mV
+    net.run(20_000, spike_history=True)
+    assert net.spike_history[:, 0].sum() >= 3
+    assert net["current_voltage"][1] == 0.0
+
+
+def test_deferred_plasticity_is_applied_per_incident_edge():
+    """neuron/mod.rs:2308-2417, 2573-2576: when neuron j spikes, every incoming edge (p,j) gets
+    stdp(lft[p], t) and every outgoing edge (j,r) gets stdp(t, lft[r]); both-spiking pairs get +0."""
+    net = ob.Net(3)
+    net.connect_all_to_all(1.0)
+    net["do_plasticity"] = 1
+    net["last_firing_time"] = np.array([5, -1, 8], np.int32)
+    net["current_voltage"] = np.array([-65.0, 29.999, -65.0], f32)   # only neuron 1 will spike
+    net["gap_conductance"] = 0.0
+    net.clock = 10
+    net.run(1)
+    assert list(net["is_spiking"]) == [0, 1, 0] and net["last_firing_time"][1] == 10
+    L = ob.lib()
+    w = net["weights"]
+    assert w[0, 1] == f32(1.0) + L.snn_o_stdp_delta(5, 10, 2, 2, 4.5, 4.5, 0.1)     # incoming, pre before post: +
+    assert w[2, 1] == f32(1.0) + L.snn_o_stdp_delta(8, 10, 2, 2, 4.5, 4.5, 0.1)
+    assert w[1, 0] == f32(1.0) + L.snn_o_stdp_delta(10, 5, 2, 2, 4.5, 4.5, 0.1)     # outgoing, post before pre: -
+    assert w[1, 2] == f32(1.0) + L.snn_o_stdp_delta(10, 8, 2, 2, 4.5, 4.5, 0.1)
+    assert w[0, 2] == 1.0 and w[2, 0] == 1.0                                         # not incident to the spike
+    assert w[0, 1] > 1.0 > w[1, 0]
+
+
+# ---- tests/interleaving_graph_conversion.rs (index placement) -----------------------------------------
+def test_interleaved_index_space():
+    """Lattices in ascending id, row-major; spike-train lattices after all neurons (graph/mod.rs:668-727)."""
+    lay = parity.Layout([(3, 2, 2), (1, 1, 3)], [(2, 1, 2), (0, 2, 1)])
+    r = lay.ranges()
+    assert r[1] == (0, 3, False) and r[3] == (3, 4, False)
+    assert r[0] == (0, 2, True) and r[2] == (2, 2, True)        # offsets inside the cell block
+    assert lay.n_neurons == 7 and lay.n_cells == 4

@@ -1,0 +1,43 @@
+"""Cross-check the C oracle against the independent numpy float32 restatement (tests/numpy_ref.py)."""
+import numpy as np
+import pytest
+
+import numpy_ref as nr
+import oracle_binding as ob
+
+
+def _state(net, names):
+    return {k: net[k].copy() for k in names}
+
+
+@pytest.mark.parametrize("n,seed", [(4, 1), (16, 2), (37, 3), (300, 4)])
+def test_izhikevich_lattice_matches_numpy(n, seed):
+    net = ob.Net(n)
+    net["gap_conductance"] = 10.0
+    net["current_voltage"] = ob.uniform_array(seed, n, -65.0, 30.0)
+    net.fill_graph(seed + 10, 0.5, 1.5)
+    s = _state(net, ["current_voltage", "w_value", "a", "b", "c", "d", "v_th", "tau_m", "c_m", "dt"])
+    steps = 700 if n < 100 else 320       # long enough for the first spikes (and resets) to occur
+    vh, sh, lft = nr.run_lattice(nr.izhikevich_step, s, net["gap_conductance"].copy(), net["weights"].copy(),
+                                 net["connections"].copy(), steps)
+    net.run(steps, voltage_history=True, spike_history=True)
+    assert sh.sum() > 0
+    assert np.array_equal(sh, net.spike_history)
+    assert np.array_equal(vh.view(np.uint32), net.voltage_history.view(np.uint32))
+    assert np.array_equal(lft, net["last_firing_time"])
+
+
+def test_lif_lattice_matches_numpy():
+    n = 25
+    net = ob.Net(n, model=ob.LIF)
+    net["current_voltage"] = ob.uniform_array(5, n, -80.0, -50.0)
+    net["gap_conductance"] = 10.0
+    net["tref"] = 1.0
+    net.fill_graph(6, 0.5, 1.5)
+    s = _state(net, ["current_voltage", "refractory_count", "leak_constant", "integration_constant", "e_l", "g_l",
+                     "tau_m", "dt", "v_th", "v_reset", "tref"])
+    vh, sh, lft = nr.run_lattice(nr.lif_step, s, net["gap_conductance"].copy(), net["weights"].copy(),
+                                 net["connections"].copy(), 150)
+    net.run(150, voltage_history=True, spike_history=True)
+    assert np.array_equal(sh, net.spike_history)
+    assert np.array_equal(vh.view(np.uint32), net.voltage_history.view(np.uint32))
