@@ -434,9 +434,12 @@ static uint32_t step_hh(snn_o_net *n, uint32_t q)
 }
 
 /* Lattice::iterate* neuron/mod.rs:884-982, LatticeNetwork::iterate* :2420-2594 (neuron loop part) */
-void snn_o_update_neurons(snn_o_net *n)
+void snn_o_update_neurons(snn_o_net *n) { snn_o_update_neurons_range(n, 0, n->n_neurons); }
+
+/* neurons [q0, q1) only: the per-shard half of a multi-GPU step (tests of the sharding protocol) */
+void snn_o_update_neurons_range(snn_o_net *n, uint32_t q0, uint32_t q1)
 {
-    for (uint32_t q = 0; q < n->n_neurons; ++q) {
+    for (uint32_t q = q0; q < q1; ++q) {
         uint32_t spike;
         switch (n->model) {
         case SNN_O_LIF: spike = step_lif(n, q); break;
@@ -456,7 +459,10 @@ void snn_o_update_neurons(snn_o_net *n)
  * receives `w += delta(lft[p], lft[q])` with the plasticity of q's lattice -- once as an incoming
  * edge of q, once more as an outgoing edge of p when p is gated too (delta is 0 then: tp == tq).
  */
-void snn_o_plasticity(snn_o_net *n)
+void snn_o_plasticity(snn_o_net *n) { snn_o_plasticity_cols(n, 0, n->n_neurons); }
+
+/* the same, touching only weights whose postsynaptic column lies in [c0, c1) (one shard's columns) */
+void snn_o_plasticity_cols(snn_o_net *n, uint32_t c0, uint32_t c1)
 {
     const uint32_t nn = n->n_neurons;
     const uint32_t n_tot = nn + n->n_cells;
@@ -465,7 +471,7 @@ void snn_o_plasticity(snn_o_net *n)
     for (uint32_t j = 0; j < nn; ++j) {
         if (!(n->is_spiking[j] && n->do_plasticity[n->lattice[j]])) continue;
         /* incoming edges of j */
-        {
+        if (j >= c0 && j < c1) {
             uint32_t l = n->lattice[j];
             for (uint32_t p = 0; p < n_tot; ++p) {
                 size_t i = (size_t)p * nn + j;
@@ -477,7 +483,7 @@ void snn_o_plasticity(snn_o_net *n)
             }
         }
         /* outgoing edges of j */
-        for (uint32_t r = 0; r < nn; ++r) {
+        for (uint32_t r = c0; r < c1; ++r) {
             size_t i = (size_t)j * nn + r;
             if (!n->connections[i]) continue;
             uint32_t l = n->lattice[r];

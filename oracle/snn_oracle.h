@@ -137,8 +137,10 @@ void snn_o_inputs(snn_o_net *net);
 void snn_o_inputs_range(snn_o_net *net, uint32_t q0, uint32_t q1);
 /* Step 2: advance every neuron once with the inputs in net->input_*; stamps last_firing_time. */
 void snn_o_update_neurons(snn_o_net *net);
+void snn_o_update_neurons_range(snn_o_net *net, uint32_t q0, uint32_t q1);
 /* Step 3: deferred STDP for every neuron that spiked in this step. */
 void snn_o_plasticity(snn_o_net *net);
+void snn_o_plasticity_cols(snn_o_net *net, uint32_t c0, uint32_t c1);
 /* Step 6: iterate every spike-train cell once. */
 void snn_o_spike_trains(snn_o_net *net);
 /* Whole loop (steps 1-6) `iterations` times, filling the optional histories. */

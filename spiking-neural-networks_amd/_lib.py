@@ -101,6 +101,14 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7; if it is loaded AFTER
+    # the system copy this library links to, the process ends up with two runtimes and torch sees no
+    # GPU.  Importing torch first makes both resolve to the same (torch's) runtime, which is also what
+    # RCCL inside torch.distributed must share with the exchange buffer (parallel.py).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise SnnLibraryError(
             f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "

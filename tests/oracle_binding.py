@@ -88,8 +88,9 @@ def lib():
         for fn in ("snn_o_inputs", "snn_o_update_neurons", "snn_o_plasticity", "snn_o_spike_trains"):
             getattr(L, fn).argtypes = [P]
             getattr(L, fn).restype = None
-        L.snn_o_inputs_range.argtypes = [P, C.c_uint32, C.c_uint32]
-        L.snn_o_inputs_range.restype = None
+        for fn in ("snn_o_inputs_range", "snn_o_update_neurons_range", "snn_o_plasticity_cols"):
+            getattr(L, fn).argtypes = [P, C.c_uint32, C.c_uint32]
+            getattr(L, fn).restype = None
         L.snn_o_run.argtypes = [P, C.c_uint64]
         L.snn_o_run.restype = None
         for fn in ("snn_o_expf_export", "snn_o_pow3f_export", "snn_o_pow4f_export"):
@@ -256,13 +257,19 @@ class Net:
         else:
             lib().snn_o_inputs_range(C.byref(c), q0, q1)
 
-    def update_neurons(self):
+    def update_neurons(self, q0=None, q1=None):
         c = self._cnet()
-        lib().snn_o_update_neurons(C.byref(c))
+        if q0 is None:
+            lib().snn_o_update_neurons(C.byref(c))
+        else:
+            lib().snn_o_update_neurons_range(C.byref(c), q0, q1)
 
-    def plasticity(self):
+    def plasticity(self, c0=None, c1=None):
         c = self._cnet()
-        lib().snn_o_plasticity(C.byref(c))
+        if c0 is None:
+            lib().snn_o_plasticity(C.byref(c))
+        else:
+            lib().snn_o_plasticity_cols(C.byref(c), c0, c1)
 
     def spike_trains(self):
         c = self._cnet()

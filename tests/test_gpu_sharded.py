@@ -1,0 +1,87 @@
+"""The HIP sharded path (snn_network_finalize_shard / snn_step_begin / snn_step_end / exchange buffer) on
+ONE GPU: G shard handles on cuda:0, the all-gather emulated by device-to-device copies of each shard's
+contiguous block.  Merged result must equal the oracle bit for bit -- rasters, voltages, adaptation
+variables, last_firing_time and the STDP-updated weight columns."""
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+import parity
+
+pytestmark = pytest.mark.gpu
+
+
+def build(chemical):
+    lay = parity.Layout([(0, 9, 10), (3, 12, 12)], [(5, 3, 4)])
+    net = parity.make_oracle(lay, st_kind=ob.ST_RATE, chemical=chemical)
+    nn, nc = net.n_neurons, net.n_cells
+    net["current_voltage"] = ob.uniform_array(1, nn, -65.0, 30.0)
+    net["gap_conductance"] = 10.0
+    net["nt_flags"][:, 0] = 1
+    net["rc_flags"][:, 0] = 1
+    net["rc_g"][:, 0] = 2.0
+    net["st_nt_flags"][:, 0] = 1
+    net["st_rate"] = ob.uniform_array(4, nc, 1.0, 5.0)
+    net.fill_graph(2, 0.5, 1.5)
+    rng = np.random.default_rng(3)
+    net["connections"][rng.random(net["connections"].shape) < 0.3] = 0
+    net["do_plasticity"] = 1
+    return net
+
+
+@pytest.mark.parametrize("n_shards,chemical", [(2, False), (3, True), (8, False)])
+def test_sharded_handles_equal_oracle(snn, n_shards, chemical):
+    import torch
+    from snn_amd import parallel
+    net = build(chemical)
+    steps = 300
+    handles = [parity.device_from_oracle(snn, net, shard=(r, n_shards)) for r in range(n_shards)]
+    stride, shards = parallel.shard_geometry(net.n_neurons, n_shards)
+    for h, (b, e) in zip(handles, shards):
+        assert (h.post_begin, h.post_end) == (b, e)
+        h.set_history(voltage=True, spikes=True)
+    bufs = [parallel.exchange_tensor(h, torch.device("cuda", 0)) for h in handles]
+    block = bufs[0].numel() // n_shards
+    for _ in range(steps):
+        for h in handles:
+            h.step_begin()
+        for r in range(n_shards):
+            src = bufs[r][r * block:(r + 1) * block]
+            for o in range(n_shards):
+                if o != r:
+                    bufs[o][r * block:(r + 1) * block].copy_(src)
+        torch.cuda.synchronize()
+        for h in handles:
+            h.step_end()
+    net.run(steps, voltage_history=True, spike_history=True)
+    assert net.spike_history.sum() > 20
+
+    rng = net.layout.ranges()
+    for r, h in enumerate(handles):
+        b, e = shards[r]
+        assert h.clock == net.clock
+        st = parity.pull_state(h, net)
+        # exchanged planes and last_firing_time are complete on every shard
+        for name in ("current_voltage", "is_spiking", "last_firing_time", "nt_t", "st_last_firing_time",
+                     "st_current_voltage", "st_step"):
+            assert np.array_equal(parity.bits(st[name]), parity.bits(net[name])), (r, name)
+        # owned state
+        for name in ("w_value", "rc_r", "rc_current"):
+            assert np.array_equal(parity.bits(st[name][b:e]), parity.bits(net[name][b:e])), (r, name)
+        w, c = h.get_graph_rows(0, net.n_tot)
+        oc = net["connections"].astype(np.uint32)
+        ow = np.where(oc != 0, net["weights"], np.float32(0))
+        assert np.array_equal(c[:, b:e], oc[:, b:e])
+        assert np.array_equal(parity.bits(w[:, b:e]), parity.bits(ow[:, b:e])), f"weights of shard {r}"
+        # histories hold the local neurons
+        for i, _, _ in net.layout.lattices:
+            first, count, _ = rng[i]
+            lo, hi = max(first, b), min(first + count, e)
+            if lo >= hi:
+                continue
+            vh = h.voltage_history(i)[:, lo - first:hi - first]
+            assert np.array_equal(parity.bits(vh), parity.bits(net.voltage_history[:, lo:hi]))
+            sh = h.spike_history(i)[:, lo - first:hi - first]
+            assert np.array_equal(sh, net.spike_history[:, lo:hi])
+    for h in handles:
+        h.close()

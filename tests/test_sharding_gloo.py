@@ -1,0 +1,83 @@
+"""N > 1 path on CPU: two processes, gloo, the product's ShardedStepper + shard geometry with
+oracle-backed shards.  Each rank owns half of the postsynaptic population and the matching columns of
+the weight matrix; after every step ONE all-gather of the exchanged planes.  The union of the ranks'
+states must equal the single-process oracle bit for bit (rasters, voltages, weights)."""
+import os
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+STEPS = 400
+
+
+def build_net():
+    import oracle_binding as ob
+    import parity
+    lay = parity.Layout([(0, 6, 6), (1, 10, 10)], [(7, 4, 5)])
+    net = parity.make_oracle(lay, st_kind=ob.ST_POISSON, chemical=True)
+    nn, nc = net.n_neurons, net.n_cells
+    net["current_voltage"] = ob.uniform_array(1, nn, -65.0, 30.0)
+    net["gap_conductance"] = 10.0
+    net["nt_flags"][:, 0] = 1
+    net["rc_flags"][:, 0] = 1
+    net["rc_g"][:, 0] = 2.0
+    net["st_nt_flags"][:, 0] = 1
+    net["st_chance_of_firing"] = 0.03
+    net.fill_graph(2, 0.5, 1.5)
+    rng = np.random.default_rng(3)
+    net["connections"][rng.random(net["connections"].shape) < 0.3] = 0
+    net["do_plasticity"] = 1
+    return net
+
+
+def worker(rank, world, init_file, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import snn_amd
+    from snn_amd import parallel
+    from oracle_shard_backend import OracleShard
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    net = build_net()
+    stride, shards = parallel.shard_geometry(net.n_neurons, world)
+    shard = OracleShard(net, rank, world, stride)
+    stepper = parallel.ShardedStepper(shard, shard.buf, rank, world)
+    raster = []
+    for _ in range(STEPS):
+        stepper.run(1)
+        raster.append(net["is_spiking"].copy())
+    q0, q1 = shards[rank]
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), q0=q0, q1=q1, v=net["current_voltage"], w=net["w_value"],
+             lft=net["last_firing_time"], weights=net["weights"], raster=np.array(raster), clock=net.clock,
+             t=net["nt_t"], st_lft=net["st_last_firing_time"])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_sharded_run_equals_single_process():
+    world = 2
+    with tempfile.TemporaryDirectory() as d:
+        init_file = os.path.join(d, "rendezvous")
+        mp.spawn(worker, args=(world, init_file, d), nprocs=world, join=True)
+        ref = build_net()
+        ref.run(STEPS, spike_history=True)
+        assert ref.spike_history.sum() > 20
+        for r in range(world):
+            z = np.load(os.path.join(d, f"rank{r}.npz"))
+            q0, q1 = int(z["q0"]), int(z["q1"])
+            assert int(z["clock"]) == STEPS
+            # exchanged state is complete on every rank
+            assert np.array_equal(z["v"].view(np.uint32), ref["current_voltage"].view(np.uint32))
+            assert np.array_equal(z["raster"], ref.spike_history)
+            assert np.array_equal(z["lft"], ref["last_firing_time"])
+            assert np.array_equal(z["t"].view(np.uint32), ref["nt_t"].view(np.uint32))
+            assert np.array_equal(z["st_lft"], ref["st_last_firing_time"])
+            # owned state: local neurons' adaptation variable and the local weight columns
+            assert np.array_equal(z["w"][q0:q1].view(np.uint32), ref["w_value"][q0:q1].view(np.uint32))
+            assert np.array_equal(z["weights"][:, q0:q1].view(np.uint32), ref["weights"][:, q0:q1].view(np.uint32))
