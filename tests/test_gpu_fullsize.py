@@ -1,0 +1,123 @@
+"""Parity at BASELINE.json's full sizes.
+
+* configs[1] (256x256 Izhikevich, dense, 17.18 GB of weights generated on the device): the oracle cannot hold
+  the matrix, so it is teacher-forced on WINDOWS of postsynaptic columns -- for each step the oracle
+  recomputes, from the GPU's own state S(t) and the same counter-based weights, the inputs and the update
+  of every sampled neuron and must reproduce the GPU's S(t+1) for them bit for bit.
+* configs[2] (128x128 Hodgkin-Huxley + Na/K + Destexhe AMPA, electrical + chemical): full oracle run.
+* configs[3]-shaped excitatory/inhibitory network with STDP at a size the host can hold (20 480 neurons).
+"""
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+import parity
+
+pytestmark = pytest.mark.gpu
+
+
+def test_c2_256x256_sampled_columns_teacher_forced(snn):
+    from snn_amd import synthetic
+    rows = cols = 256
+    n = rows * cols
+    dn = snn.DeviceNetwork(model=snn.IZHIKEVICH)
+    dn.add_lattice(0, rows, cols)
+    dn.finalize()
+    v0 = synthetic.uniform(1, n, -65.0, 30.0)
+    v0[[100, 1000, 32768, n - 5, 5000]] = 40.0          # above threshold: these spike (and reset) in step 0
+    dn.set_attr(0, "gap_conductance", np.full(n, 10.0, np.float32))
+    dn.set_attr(0, "current_voltage", v0)
+    dn.fill_graph_synthetic(2, 0.5, 1.5, with_diagonal=False)
+
+    # the device-side generator against the oracle's, on sampled rows
+    for p in (0, 255, 256, 40000, n - 1):
+        w, c = dn.get_graph_rows(p, 1)
+        want = ob.uniform_array(2, n, 0.5, 1.5, offset=p * n)
+        want[p] = 0.0
+        assert np.array_equal(w[0].view(np.uint32), want.view(np.uint32)) and c[0].sum() == n - 1 and c[0, p] == 0
+
+    windows = [(0, 128), (960, 1088), (32768 - 64, 32768 + 64), (n - 128, n)]   # tile / shard / end boundaries
+    nets = []
+    for c0, c1 in windows:
+        net = ob.Net(n, model=ob.IZHIKEVICH)
+        net.arr["weights"] = np.empty((n, c1 - c0), np.float32)
+        net.arr["connections"] = np.empty((n, c1 - c0), np.uint8)
+        net.w_col0, net.w_ld = c0, c1 - c0
+        ob.lib().snn_o_fill_graph_window(net["weights"].ctypes.data_as(ob.f32p), net["connections"].ctypes.data_as(ob.u8p),
+                                         n, n, c0, c1 - c0, 2, 0.5, 1.5, 0)
+        net["gap_conductance"] = 10.0
+        net.n_threads = 8
+        nets.append(net)
+
+    state = {k: dn.get_attr(0, k) for k in ("current_voltage", "w_value")}
+    spikes_seen = 0
+    for step in range(6):
+        dn.run(1)
+        new = {k: dn.get_attr(0, k) for k in ("current_voltage", "w_value")}
+        spk = dn.get_attr(0, "is_spiking", dtype=np.uint32)
+        lft = dn.get_attr(0, "last_firing_time", dtype=np.int32)
+        spikes_seen += int(spk.sum())
+        for net, (c0, c1) in zip(nets, windows):
+            net["current_voltage"] = state["current_voltage"]
+            net["w_value"] = state["w_value"]
+            net.clock = step
+            net.inputs(c0, c1)
+            net.update_neurons(c0, c1)
+            for k in ("current_voltage", "w_value"):
+                assert np.array_equal(net[k][c0:c1].view(np.uint32), new[k][c0:c1].view(np.uint32)), (step, k, c0)
+            assert np.array_equal(net["is_spiking"][c0:c1], spk[c0:c1])
+            hit = spk[c0:c1] != 0
+            assert np.all(lft[c0:c1][hit] == step)
+        state = new
+    assert np.isfinite(state["current_voltage"]).all()
+    assert spikes_seen >= 5
+    dn.close()
+
+
+def test_c3_128x128_hodgkin_huxley_ampa_full_oracle(snn):
+    """BASELINE configs[2]: HH defaults dt = 0.01, Destexhe NT + Destexhe receptor (AMPA g = 1, e = 0),
+    electrical + chemical, all-to-all, V0 ~ U[-70, -60] seed 3; 40 steps, everything bit-identical."""
+    lay = parity.Layout([(0, 128, 128)])
+    net = parity.make_oracle(lay, model=ob.HH, nt_kind=ob.NT_DESTEXHE, rc_kind=ob.RC_DESTEXHE, chemical=True)
+    n = net.n_neurons
+    net["current_voltage"] = ob.uniform_array(3, n, -70.0, -60.0)
+    net["nt_flags"][:, 0] = 1
+    net["rc_flags"][:, 0] = 1
+    net.fill_graph(4, 0.5, 1.5)
+    net.n_threads = 16
+    dn = parity.device_from_oracle(snn, net)
+    dn.set_history(voltage=True, spikes=True)
+    dn.run(40)
+    net.run(40, voltage_history=True, spike_history=True)
+    assert np.array_equal(dn.spike_history(0), net.spike_history)
+    assert np.array_equal(parity.bits(dn.voltage_history(0)), parity.bits(net.voltage_history))
+    parity.assert_state_equal(net, parity.pull_state(dn, net))
+    # north_star tolerance for membrane traces (1e-5 relative) is met with margin zero: they are identical
+    dn.close()
+
+
+def test_c4_shaped_network_with_stdp_20480_neurons(snn):
+    """configs[3] scaled to host memory: exc 128x128 (id 1) + inh 64x64 (id 0), dense, STDP on both."""
+    lay = parity.Layout([(0, 64, 64), (1, 128, 128)])
+    net = parity.make_oracle(lay)
+    n = net.n_neurons
+    r = lay.ranges()
+    inh = slice(r[0][0], r[0][0] + r[0][1])
+    net["current_voltage"] = ob.uniform_array(4, n, -65.0, 30.0)
+    net["gap_conductance"] = 10.0
+    net.fill_graph(5, 0.5, 1.5)
+    net["weights"][inh, :] *= -1.0
+    net["do_plasticity"] = 1
+    net.n_threads = 16
+    dn = parity.device_from_oracle(snn, net)
+    dn.set_history(voltage=False, spikes=True)
+    dn.run(12)
+    net.run(12, spike_history=True)
+    total = int(net.spike_history.sum())
+    assert total > 20, total
+    for i in (0, 1):
+        first, count, _ = r[i]
+        assert np.array_equal(dn.spike_history(i), net.spike_history[:, first:first + count])
+    parity.assert_state_equal(net, parity.pull_state(dn, net))
+    parity.assert_graph_equal(net, dn)
+    dn.close()
