@@ -51,11 +51,67 @@ def cpu_baseline(n, sample_cols, steps, threads):
     return sample_cols * steps / dt, dt, steps
 
 
+def build_config(args, snn_amd, synthetic, np, rank, world, local_rank):
+    """BASELINE.json configs as synthetic inputs.  Returns (handle, neurons, text, kernel)."""
+    cfg = args.config
+    fin = (lambda d: d.finalize(rank, world)) if world > 1 else (lambda d: d.finalize())
+    if cfg in ("c1", "c2"):
+        rows, cols = (32, 32) if cfg == "c1" else (args.rows, args.cols)
+        n = rows * cols
+        dn = snn_amd.DeviceNetwork(model=snn_amd.IZHIKEVICH, device=local_rank)
+        dn.add_lattice(0, rows, cols)
+        fin(dn)
+        # defaults, gap_conductance 10, V0 ~ U[-65,30] seed 1, weights U[0.5,1.5] seed 2, x != y
+        dn.set_attr(0, "gap_conductance", np.full(n, 10.0, np.float32))
+        dn.set_attr(0, "current_voltage", synthetic.uniform(1, n, -65.0, 30.0))
+        dn.fill_graph_synthetic(2, 0.5, 1.5, with_diagonal=False)
+        text = (f"{rows}x{cols} Izhikevich lattice, dense gap-junction connectivity (all-to-all, x != y), dt=0.1, "
+                f"weights U[0.5,1.5]")
+        return dn, n, text, "k_inputs_dense<true,false>"
+    if cfg == "c3":
+        rows = cols = 128
+        n = rows * cols
+        dn = snn_amd.DeviceNetwork(model=snn_amd.HODGKIN_HUXLEY, nt_kinetics=snn_amd.NT_DESTEXHE,
+                                   receptor_kinetics=snn_amd.RC_DESTEXHE, device=local_rank)
+        dn.add_lattice(0, rows, cols)
+        fin(dn)
+        dn.set_attr(0, "current_voltage", synthetic.uniform(3, n, -70.0, -60.0))
+        flags = np.zeros((n, 3), np.uint32)
+        flags[:, 0] = 1                                   # AMPA
+        dn.set_attr(0, "neurotransmitters$flags", flags)
+        dn.set_attr(0, "receptors$flags", flags)
+        dn.fill_graph_synthetic(4, 0.5, 1.5, with_diagonal=False)
+        dn.set_synapses(True, True)
+        return dn, n, ("128x128 Hodgkin-Huxley lattice (Na/K/K-leak gating) + Destexhe AMPA neurotransmitter and "
+                       "receptor kinetics, electrical + chemical, dense, dt=0.01"), "k_inputs_dense<true,true>"
+    if cfg == "c4":
+        n_inh, n_exc = 128 * 128, 256 * 256
+        n = n_inh + n_exc
+        dn = snn_amd.DeviceNetwork(model=snn_amd.IZHIKEVICH, device=local_rank)
+        dn.add_lattice(0, 128, 128)                       # inhibitory pool, id 0
+        dn.add_lattice(1, 256, 256)                       # excitatory pool, id 1
+        fin(dn)
+        for i, m in ((0, n_inh), (1, n_exc)):
+            dn.set_attr(i, "gap_conductance", np.full(m, 10.0, np.float32))
+        dn.set_attr(0, "current_voltage", synthetic.uniform(4, n_inh, -65.0, 30.0))
+        dn.set_attr(1, "current_voltage", synthetic.uniform(4, n_exc, -65.0, 30.0, offset=n_inh))
+        # magnitudes U[0.5,1.5]; the sign structure of interacting_pools (inh -> * negative) does not change
+        # the traffic and is exercised at test size (tests/test_gpu_network.py)
+        dn.fill_graph_synthetic(5, 0.5, 1.5, with_diagonal=False)
+        dn.set_plasticity(0)
+        dn.set_plasticity(1)
+        return dn, n, ("256x256 excitatory + 128x128 inhibitory Izhikevich LatticeNetwork, dense interleaved "
+                       "matrix (81 920 neurons), STDP on both lattices, dt=0.1"), "k_inputs_dense<true,false>"
+    raise SystemExit(f"unknown --config {cfg}")
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="c2", choices=["c1", "c2", "c3", "c4"],
+                    help="BASELINE.json configs[0..3]; the headline metric is quoted on c2 (default)")
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--rows", type=int, default=ROWS)
     ap.add_argument("--cols", type=int, default=COLS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -79,17 +135,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    n = args.rows * args.cols
-    dn = snn_amd.DeviceNetwork(model=snn_amd.IZHIKEVICH, device=local_rank)
-    dn.add_lattice(0, args.rows, args.cols)
-    if world > 1:
-        dn.finalize(rank, world)
-    else:
-        dn.finalize()
-    # BASELINE.md C2 inputs: defaults, gap_conductance 10, V0 ~ U[-65,30] seed 1, weights U[0.5,1.5] seed 2, x != y
-    dn.set_attr(0, "gap_conductance", np.full(n, 10.0, np.float32))
-    dn.set_attr(0, "current_voltage", synthetic.uniform(1, n, -65.0, 30.0))
-    dn.fill_graph_synthetic(2, 0.5, 1.5, with_diagonal=False)
+    dn, n, workload, kernel_name = build_config(args, snn_amd, synthetic, np, rank, world, local_rank)
 
     if world > 1:
         buf = parallel.exchange_tensor(dn, torch.device("cuda", local_rank))
@@ -130,16 +176,14 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.rows}x{args.cols} Izhikevich lattice, dense gap-junction connectivity "
-                                   f"(all-to-all, x != y), dt=0.1, weights U[0.5,1.5]",
-                       "neurons": n, "synapses_per_step": n * (n - 1),
+            "config": {"workload": workload, "neurons": n, "synapses_per_step": n * (n - 1),
                        "parallelism": f"post-population shards x{world}" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_inputs_dense", "launches": launches, "avg_launch_ms": avg_ms,
+                         "kernel": kernel_name, "launches": launches, "avg_launch_ms": avg_ms,
                          "algorithmic_bytes_per_launch": bytes_per_launch},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.config in ("c1", "c2"):
             threads = os.cpu_count() or 1
             sample = 4096 if n >= 4096 else n
             v, secs, cpu_steps = cpu_baseline(n, sample, None, threads)

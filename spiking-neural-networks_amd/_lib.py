@@ -10,7 +10,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libsnn_amd.so")
+LIB_PATH = os.environ.get("SNN_AMD_LIB", os.path.join(CSRC, "libsnn_amd.so"))   # override: A/B builds
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "snn_amd.h")
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
