@@ -21,6 +21,17 @@ sys.path.insert(0, ROOT)
 
 ROWS = COLS = 256
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling is ~6.3 TB/s
+# HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of THIS command (FETCH_SIZE and
+# WRITE_SIZE cannot share a pass); their summaries are committed under profiles/ and quoted here per launch.
+PMC_TRAFFIC = {"c2": os.path.join(ROOT, "profiles", "r01", "c2_izhikevich_256x256_pmc_traffic.json")}
+
+
+def pmc_traffic(config, world, rows, cols):
+    path = PMC_TRAFFIC.get(config)
+    if world != 1 or path is None or (rows, cols) != (ROWS, COLS) or not os.path.exists(path):
+        return None
+    dom = json.load(open(path)).get("dominant_kernel")
+    return dom["hbm_traffic_bytes_per_launch"] if dom else None
 
 
 def cpu_baseline(n, sample_cols, steps, threads):
@@ -179,7 +190,8 @@ def main():
             "config": {"workload": workload, "neurons": n, "synapses_per_step": n * (n - 1),
                        "parallelism": f"post-population shards x{world}" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": pmc_traffic(args.config, world, args.rows, args.cols),
                          "kernel": kernel_name, "launches": launches, "avg_launch_ms": avg_ms,
                          "algorithmic_bytes_per_launch": bytes_per_launch},
         }
