@@ -5,10 +5,12 @@ One hot path of NikhilMukraj/spiking-neural-networks -- `run_lattice` / `run_lat
 behind the C ABI of include/snn_amd.h.  The directory name carries a hyphen, so import it
 through the root-level shim: `import snn_amd`.
 """
-from . import _lib, parallel, synthetic
+from . import _lib, lattice, parallel, synthetic
 from ._lib import SnnError, SnnLibraryError, build
 from .network import (DeviceNetwork, HODGKIN_HUXLEY, IZHIKEVICH, LIF, NT_APPROXIMATE, NT_DESTEXHE,
                       NUM_NT_TYPES, RC_APPROXIMATE, RC_DESTEXHE, ST_NONE, ST_POISSON, ST_RATE, probe_math)
+
+from .lattice import *  # noqa: F401,F403  (Lixirnet-style names)
 
 __all__ = ["DeviceNetwork", "SnnError", "SnnLibraryError", "build", "probe_math",
            "IZHIKEVICH", "LIF", "HODGKIN_HUXLEY", "NT_APPROXIMATE", "NT_DESTEXHE",

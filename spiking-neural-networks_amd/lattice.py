@@ -1,0 +1,721 @@
+"""Lixirnet-style classes over the HIP stepper.
+
+Same class / method names and argument meaning as the reference's Python interface
+(interface_gpu/lixirnet/src/lattices/mod.rs:314-568 `impl_lattice_gpu!`, :1450-2117 `impl_network_gpu!`;
+class list interface_gpu/lixirnet/src/lib.rs:463-482) for the containers on the hot path, with the
+backend crate's own model types (backend/src/neuron/integrate_and_fire/mod.rs, hodgkin_huxley/mod.rs,
+iterate_and_spike/mod.rs, spike_train/mod.rs, plasticity/mod.rs).
+
+The host-side containers (`*Lattice`, `*Network`) only BUILD a lattice (populate / connect / apply ...);
+stepping exists on the `*GPU` classes alone -- there is no CPU stepper in this package.
+"""
+import copy
+import enum
+
+import numpy as np
+
+from .network import (DeviceNetwork, HODGKIN_HUXLEY, IZHIKEVICH, LIF, NT_APPROXIMATE, NT_DESTEXHE,
+                      RC_APPROXIMATE, RC_DESTEXHE, ST_NONE, ST_POISSON, ST_RATE)
+
+
+class IonotropicNeurotransmitterType(enum.IntEnum):      # iterate_and_spike/mod.rs:1068-1073
+    AMPA = 0
+    NMDA = 1
+    GABA = 2
+
+
+class _Record:
+    _defaults = {}
+
+    def __init__(self, **kw):
+        for k, v in self._defaults.items():
+            setattr(self, k, copy.deepcopy(v))
+        for k, v in kw.items():
+            if k not in self._defaults:
+                raise AttributeError(f"{type(self).__name__} has no field {k}")
+            setattr(self, k, v)
+
+    def __repr__(self):
+        return f"{type(self).__name__}({', '.join(f'{k}={getattr(self, k)!r}' for k in self._defaults)})"
+
+
+class ApproximateNeurotransmitter(_Record):              # iterate_and_spike/mod.rs:161-182
+    _defaults = dict(t_max=1.0, t=0.0, clearance_constant=0.01)
+    kinetics = NT_APPROXIMATE
+
+
+class DestexheNeurotransmitter(_Record):                 # iterate_and_spike/mod.rs:122-145
+    _defaults = dict(t_max=1.0, t=0.0, v_p=2.0, k_p=5.0)
+    kinetics = NT_DESTEXHE
+
+
+class ApproximateReceptor(_Record):                      # iterate_and_spike/mod.rs:427-446
+    _defaults = dict(r=0.0)
+    kinetics = RC_APPROXIMATE
+
+
+class DestexheReceptor(_Record):                         # iterate_and_spike/mod.rs:394-425
+    _defaults = dict(r=0.0, alpha=1.0, beta=1.0)
+    kinetics = RC_DESTEXHE
+
+
+class AMPAReceptor(_Record):                             # iterate_and_spike/mod.rs:1078-1094
+    _defaults = dict(current=0.0, g=1.0, e=0.0, r=ApproximateReceptor())
+    type = IonotropicNeurotransmitterType.AMPA
+
+
+class NMDAReceptor(_Record):                             # iterate_and_spike/mod.rs:1107-1125
+    _defaults = dict(current=0.0, g=0.6, mg=0.3, e=0.0, r=ApproximateReceptor())
+    type = IonotropicNeurotransmitterType.NMDA
+
+
+class GABAReceptor(_Record):                             # iterate_and_spike/mod.rs:1140-1157
+    _defaults = dict(current=0.0, g=1.2, e=-80.0, r=ApproximateReceptor())
+    type = IonotropicNeurotransmitterType.GABA
+
+
+class Ionotropic(dict):                                  # iterate_and_spike/mod.rs:1177-1257
+    def insert(self, neurotransmitter_type, receptor):
+        if IonotropicNeurotransmitterType(neurotransmitter_type) != receptor.type:
+            raise ValueError("ReceptorNeurotransmitterError::MismatchedTypes")
+        self[IonotropicNeurotransmitterType(neurotransmitter_type)] = receptor
+
+
+class STDP(_Record):                                     # plasticity/mod.rs:16-39
+    _defaults = dict(a_plus=2.0, a_minus=2.0, tau_plus=4.5, tau_minus=4.5, dt=0.1)
+
+
+class GraphPosition:                                     # graph/mod.rs:24-30
+    def __init__(self, id, pos):
+        self.id, self.pos = id, tuple(pos)
+
+    def __eq__(self, o):
+        return (self.id, self.pos) == (o.id, o.pos)
+
+    def __hash__(self):
+        return hash((self.id, self.pos))
+
+
+class _Neuron(_Record):
+    _common = dict(is_spiking=False, last_firing_time=None)
+    model = None
+    abi_names = {}          # python field -> C-ABI attribute (when they differ)
+
+    def __init__(self, **kw):
+        self.synaptic_neurotransmitters = {}
+        self.receptors = Ionotropic()
+        super().__init__(**kw)
+
+    def set_synaptic_neurotransmitters(self, d):
+        self.synaptic_neurotransmitters = {IonotropicNeurotransmitterType(k): v for k, v in d.items()}
+
+    def set_receptors(self, r):
+        self.receptors = r
+
+
+class IzhikevichNeuron(_Neuron):                         # integrate_and_fire/mod.rs:1159-1220
+    model = IZHIKEVICH
+    _defaults = dict(current_voltage=-65.0, v_th=30.0, v_init=-65.0, a=0.02, b=0.2, c=-55.0, d=8.0, w_value=30.0,
+                     w_init=30.0, gap_conductance=7.0, tau_m=1.0, c_m=100.0, dt=0.1, **_Neuron._common)
+    state_fields = ("w_value", "a", "b", "c", "d", "tau_m")
+
+
+class LeakyIntegrateAndFireNeuron(_Neuron):              # integrate_and_fire/mod.rs:108-171
+    model = LIF
+    _defaults = dict(current_voltage=-75.0, v_th=-55.0, v_reset=-75.0, v_init=-75.0, refractory_count=0.0, tref=10.0,
+                     leak_constant=-1.0, integration_constant=1.0, gap_conductance=7.0, e_l=-75.0, g_l=10.0,
+                     tau_m=10.0, c_m=100.0, dt=0.1, **_Neuron._common)
+    state_fields = ("v_reset", "refractory_count", "tref", "leak_constant", "integration_constant", "e_l", "g_l", "tau_m")
+
+
+class HodgkinHuxleyNeuron(_Neuron):                      # hodgkin_huxley/mod.rs:49-98, ion_channels/mod.rs
+    model = HODGKIN_HUXLEY
+    _defaults = dict(current_voltage=-65.0, gap_conductance=7.0, dt=0.01, c_m=1.0, v_th=0.0,
+                     m=0.0, h=0.0, n=0.0, g_na=120.0, e_na=50.0, g_k=36.0, e_k=-77.0, g_k_leak=0.3, e_k_leak=-55.0,
+                     na_current=0.0, k_current=0.0, k_leak_current=0.0, was_increasing=False, **_Neuron._common)
+    state_fields = ("m", "h", "n", "g_na", "e_na", "g_k", "e_k", "g_k_leak", "e_k_leak", "na_current", "k_current",
+                    "k_leak_current")
+    abi_names = dict(m="na_channel$m$state", h="na_channel$h$state", n="k_channel$n$state", g_na="na_channel$g_na",
+                     e_na="na_channel$e_na", g_k="k_channel$g_k", e_k="k_channel$e_k",
+                     g_k_leak="k_leak_channel$g_k_leak", e_k_leak="k_leak_channel$e_k_leak",
+                     na_current="na_channel$current", k_current="k_channel$current",
+                     k_leak_current="k_leak_channel$current")
+
+
+class _SpikeTrain(_Record):
+    kind = ST_NONE
+
+    def __init__(self, **kw):
+        self.synaptic_neurotransmitters = {}
+        super().__init__(**kw)
+
+    def set_synaptic_neurotransmitters(self, d):
+        self.synaptic_neurotransmitters = {IonotropicNeurotransmitterType(k): v for k, v in d.items()}
+
+
+class PoissonNeuron(_SpikeTrain):                        # spike_train/mod.rs:259-313 (+ GPU generator :380-435)
+    kind = ST_POISSON
+    _defaults = dict(current_voltage=0.0, v_th=30.0, v_resting=0.0, is_spiking=False, last_firing_time=None,
+                     chance_of_firing=0.0, dt=0.1, k=10000.0, seed=1)
+
+    @classmethod
+    def from_firing_rate(cls, hertz, dt):                # spike_train/mod.rs:327-334
+        return cls(dt=dt, chance_of_firing=1.0 / ((1000.0 / dt) / hertz))
+
+
+class RateSpikeTrain(_SpikeTrain):                       # spike_train/mod.rs:975-1013
+    kind = ST_RATE
+    _defaults = dict(current_voltage=0.0, v_th=30.0, v_resting=0.0, rate=0.0, step=0.0, is_spiking=False,
+                     last_firing_time=None, dt=0.1, k=10000.0)
+
+
+# ---------------------------------------------------------------------------------------------------
+# host-side containers
+# ---------------------------------------------------------------------------------------------------
+class Lattice:
+    """Lattice<T, AdjacencyMatrix, GridVoltageHistory, STDP> builder (backend/src/neuron/mod.rs:556-1157)."""
+    neuron_type = IzhikevichNeuron
+
+    def __init__(self, id=0):
+        self.id = id
+        self.cell_grid = []
+        self.weights = np.zeros((0, 0), np.float32)            # AdjacencyMatrix, index = row*cols + col
+        self.connections = np.zeros((0, 0), np.uint32)
+        self.update_grid_history = False
+        self.electrical_synapse = True
+        self.chemical_synapse = False
+        self.do_plasticity = False
+        self.plasticity = STDP()
+        self.internal_clock = 0
+
+    # -- shape ------------------------------------------------------------------------------------
+    @property
+    def rows(self):
+        return len(self.cell_grid)
+
+    @property
+    def cols(self):
+        return len(self.cell_grid[0]) if self.cell_grid else 0
+
+    def _index(self, pos):
+        r, c = pos
+        if not (0 <= r < self.rows and 0 <= c < self.cols):
+            raise KeyError(f"GraphError::PositionNotFound({pos})")
+        return r * self.cols + c
+
+    @property
+    def position_to_index(self):
+        return {(r, c): r * self.cols + c for r in range(self.rows) for c in range(self.cols)}
+
+    def get_every_node(self):
+        return set(self.position_to_index)
+
+    # -- building ---------------------------------------------------------------------------------
+    def populate(self, neuron, num_rows, num_cols):             # neuron/mod.rs:1105-1126
+        self.cell_grid = [[copy.deepcopy(neuron) for _ in range(num_cols)] for _ in range(num_rows)]
+        n = num_rows * num_cols
+        self.weights = np.zeros((n, n), np.float32)
+        self.connections = np.zeros((n, n), np.uint32)
+
+    def connect(self, connection_conditional, weight_logic=None):   # neuron/mod.rs:1134-1157
+        pos = [(r, c) for r in range(self.rows) for c in range(self.cols)]
+        for i, a in enumerate(pos):
+            for j, b in enumerate(pos):
+                if connection_conditional(a, b):
+                    self.connections[i, j] = 1
+                    self.weights[i, j] = 1.0 if weight_logic is None else weight_logic(a, b)
+                else:
+                    self.connections[i, j] = 0
+                    self.weights[i, j] = 0.0
+
+    def apply(self, function):
+        for row in self.cell_grid:
+            for n in row:
+                function(n)
+
+    def apply_given_position(self, function):
+        for r, row in enumerate(self.cell_grid):
+            for c, n in enumerate(row):
+                function((r, c), n)
+
+    def get_neuron(self, row, col):
+        self._index((row, col))
+        return copy.deepcopy(self.cell_grid[row][col])
+
+    def set_neuron(self, row, col, neuron):
+        self._index((row, col))
+        self.cell_grid[row][col] = copy.deepcopy(neuron)
+
+    def get_weight(self, presynaptic, postsynaptic):
+        i, j = self._index(presynaptic), self._index(postsynaptic)
+        if not self.connections[i, j]:
+            raise KeyError("no connection")                      # lookup_weight -> None
+        return float(self.weights[i, j])
+
+    def get_incoming_connections(self, position):
+        j = self._index(position)
+        return {(i // self.cols, i % self.cols) for i in np.nonzero(self.connections[:, j])[0]}
+
+    def get_outgoing_connections(self, position):
+        i = self._index(position)
+        return {(j // self.cols, j % self.cols) for j in np.nonzero(self.connections[i])[0]}
+
+    def set_dt(self, dt):                                       # neuron/mod.rs:649-652
+        self.apply(lambda n: setattr(n, "dt", dt))
+        self.plasticity.dt = dt
+
+    def reset_timing(self):                                     # neuron/mod.rs:405-420
+        self.internal_clock = 0
+        self.apply(lambda n: setattr(n, "last_firing_time", None))
+
+    def run_lattice(self, iterations):
+        raise NotImplementedError("this package steps lattices on the GPU only: use "
+                                  f"{type(self).__name__}GPU.from_lattice(lattice).run_lattice(iterations)")
+
+
+class SpikeTrainLattice:
+    """SpikeTrainLattice builder (backend/src/neuron/mod.rs:1292-1436)."""
+    spike_train_type = RateSpikeTrain
+
+    def __init__(self, id=0):
+        self.id = id
+        self.cell_grid = []
+        self.update_grid_history = False
+        self.internal_clock = 0
+
+    rows = Lattice.rows
+    cols = Lattice.cols
+
+    def populate(self, spike_train, num_rows, num_cols):
+        self.cell_grid = [[copy.deepcopy(spike_train) for _ in range(num_cols)] for _ in range(num_rows)]
+
+    apply = Lattice.apply
+    apply_given_position = Lattice.apply_given_position
+
+    def get_neuron(self, row, col):
+        return copy.deepcopy(self.cell_grid[row][col])
+
+    def set_neuron(self, row, col, neuron):
+        self.cell_grid[row][col] = copy.deepcopy(neuron)
+
+    def set_dt(self, dt):
+        self.apply(lambda n: setattr(n, "dt", dt))
+
+
+class LatticeNetwork:
+    """LatticeNetwork builder (backend/src/neuron/mod.rs:1538-2075)."""
+
+    def __init__(self):
+        self.lattices, self.spike_train_lattices = {}, {}
+        self.connecting = {}              # (GraphPosition pre, GraphPosition post) -> weight
+        self.electrical_synapse, self.chemical_synapse = True, False
+        self.internal_clock = 0
+
+    @classmethod
+    def generate_network(cls, lattices=(), spike_train_lattices=()):
+        net = cls()
+        for l in lattices:
+            net.add_lattice(l)
+        for l in spike_train_lattices:
+            net.add_spike_train_lattice(l)
+        return net
+
+    def get_all_ids(self):
+        return set(self.lattices) | set(self.spike_train_lattices)
+
+    def add_lattice(self, lattice):                             # neuron/mod.rs:1663-1679
+        if lattice.id in self.get_all_ids():
+            raise KeyError(f"LatticeNetworkError::GraphIDAlreadyPresent({lattice.id})")
+        self.lattices[lattice.id] = lattice
+
+    def add_spike_train_lattice(self, lattice):
+        if lattice.id in self.get_all_ids():
+            raise KeyError(f"LatticeNetworkError::GraphIDAlreadyPresent({lattice.id})")
+        self.spike_train_lattices[lattice.id] = lattice
+
+    def get_lattice(self, id):
+        return self.lattices[id]
+
+    def get_spike_train_lattice(self, id):
+        return self.spike_train_lattices[id]
+
+    def connect_internally(self, id, connection_conditional, weight_logic=None):
+        self.lattices[id].connect(connection_conditional, weight_logic)
+
+    def connect(self, presynaptic_id, postsynaptic_id, connection_conditional, weight_logic=None):   # mod.rs:1845-1935
+        if postsynaptic_id in self.spike_train_lattices:
+            raise KeyError("LatticeNetworkError::PostsynapticLatticeCannotBeSpikeTrain")
+        if postsynaptic_id not in self.lattices:
+            raise KeyError(f"LatticeNetworkError::PostsynapticIDNotFound({postsynaptic_id})")
+        if presynaptic_id not in self.get_all_ids():
+            raise KeyError(f"LatticeNetworkError::PresynapticIDNotFound({presynaptic_id})")
+        if presynaptic_id == postsynaptic_id:
+            return self.connect_internally(presynaptic_id, connection_conditional, weight_logic)
+        pre = self.lattices.get(presynaptic_id) or self.spike_train_lattices[presynaptic_id]
+        post = self.lattices[postsynaptic_id]
+        for a in ((r, c) for r in range(pre.rows) for c in range(pre.cols)):
+            for b in ((r, c) for r in range(post.rows) for c in range(post.cols)):
+                key = (GraphPosition(presynaptic_id, a), GraphPosition(postsynaptic_id, b))
+                if connection_conditional(a, b):
+                    self.connecting[key] = 1.0 if weight_logic is None else float(weight_logic(a, b))
+                else:
+                    self.connecting.pop(key, None)
+
+    def set_dt(self, dt):
+        for l in list(self.lattices.values()) + list(self.spike_train_lattices.values()):
+            l.set_dt(dt)
+
+
+# ---------------------------------------------------------------------------------------------------
+# AoS <-> named SoA buffers (IterateAndSpikeGPU::convert_to_gpu / convert_to_cpu)
+# ---------------------------------------------------------------------------------------------------
+def _kinetics_of(cells, default_nt=NT_APPROXIMATE, default_rc=RC_APPROXIMATE):
+    nt, rc = None, None
+    for c in cells:
+        for v in c.synaptic_neurotransmitters.values():
+            nt = v.kinetics if nt is None else nt
+            if v.kinetics != nt:
+                raise TypeError("one neurotransmitter kinetics type per network (a type parameter in the reference)")
+        for v in getattr(c, "receptors", {}).values():
+            rc = v.r.kinetics if rc is None else rc
+            if v.r.kinetics != rc:
+                raise TypeError("one receptor kinetics type per network (a type parameter in the reference)")
+    return (default_nt if nt is None else nt), (default_rc if rc is None else rc)
+
+
+def _lft(cells):
+    return np.array([-1 if c.last_firing_time is None else int(c.last_firing_time) for c in cells], np.int32)
+
+
+def _upload_nt(dn, id, cells):
+    n = len(cells)
+    arr = {k: np.zeros((n, 3), np.float32) for k in ("t", "t_max", "clearance_constant", "v_p", "k_p")}
+    arr["t_max"][...] = 1.0
+    arr["clearance_constant"][...] = 0.01
+    arr["v_p"][...] = 2.0
+    arr["k_p"][...] = 5.0
+    flags = np.zeros((n, 3), np.uint32)
+    for i, c in enumerate(cells):
+        for t, v in c.synaptic_neurotransmitters.items():
+            flags[i, int(t)] = 1
+            for k in arr:
+                if hasattr(v, k):
+                    arr[k][i, int(t)] = getattr(v, k)
+    dn.set_attr(id, "neurotransmitters$flags", flags)
+    for k, a in arr.items():
+        dn.set_attr(id, f"neurotransmitters${k}", a)
+
+
+def _upload_neurons(dn, id, cells):
+    if not cells:
+        return
+    cls = type(cells[0])
+    f32 = lambda k: np.array([getattr(c, k) for c in cells], np.float32)
+    for k in ("current_voltage", "gap_conductance", "dt", "c_m", "v_th") + tuple(cls.state_fields):
+        dn.set_attr(id, cls.abi_names.get(k, k), f32(k))
+    dn.set_attr(id, "is_spiking", np.array([c.is_spiking for c in cells], np.uint32))
+    dn.set_attr(id, "last_firing_time", _lft(cells))
+    if cls.model == HODGKIN_HUXLEY:
+        dn.set_attr(id, "was_increasing", np.array([c.was_increasing for c in cells], np.uint32))
+    _upload_nt(dn, id, cells)
+    n = len(cells)
+    flags = np.zeros((n, 3), np.uint32)
+    for t in IonotropicNeurotransmitterType:
+        vals = {k: np.zeros(n, np.float32) for k in ("g", "e", "current", "r", "alpha", "beta", "mg")}
+        proto = {0: AMPAReceptor, 1: NMDAReceptor, 2: GABAReceptor}[int(t)]()
+        for i, c in enumerate(cells):
+            rec = c.receptors.get(t)
+            flags[i, int(t)] = rec is not None
+            rec = rec or proto
+            vals["g"][i], vals["e"][i], vals["current"][i] = rec.g, rec.e, rec.current
+            vals["mg"][i] = getattr(rec, "mg", 0.0)
+            vals["r"][i] = rec.r.r
+            vals["alpha"][i], vals["beta"][i] = getattr(rec.r, "alpha", 1.0), getattr(rec.r, "beta", 1.0)
+        p = f"receptors${t.name}"
+        dn.set_attr(id, p + "_g", vals["g"])
+        dn.set_attr(id, p + "_e", vals["e"])
+        dn.set_attr(id, p + "_current", vals["current"])
+        dn.set_attr(id, p + "$r$kinetics$r", vals["r"])
+        dn.set_attr(id, p + "$r$kinetics$alpha", vals["alpha"])
+        dn.set_attr(id, p + "$r$kinetics$beta", vals["beta"])
+        if t == IonotropicNeurotransmitterType.NMDA:
+            dn.set_attr(id, p + "_mg", vals["mg"])
+    dn.set_attr(id, "receptors$flags", flags)
+
+
+def _download_neurons(dn, id, cells):
+    if not cells:
+        return
+    cls = type(cells[0])
+    for k in ("current_voltage",) + tuple(cls.state_fields):
+        for c, v in zip(cells, dn.get_attr(id, cls.abi_names.get(k, k))):
+            setattr(c, k, float(v))
+    spk = dn.get_attr(id, "is_spiking", dtype=np.uint32)
+    lft = dn.get_attr(id, "last_firing_time", dtype=np.int32)
+    t = dn.get_attr(id, "neurotransmitters$t", per_type=True)
+    for i, c in enumerate(cells):
+        c.is_spiking = bool(spk[i])
+        c.last_firing_time = None if lft[i] < 0 else int(lft[i])
+        for ty, v in c.synaptic_neurotransmitters.items():
+            v.t = float(t[i, int(ty)])
+    if cls.model == HODGKIN_HUXLEY:
+        for c, v in zip(cells, dn.get_attr(id, "was_increasing", dtype=np.uint32)):
+            c.was_increasing = bool(v)
+    for ty in IonotropicNeurotransmitterType:
+        r = dn.get_attr(id, f"receptors${ty.name}$r$kinetics$r")
+        cur = dn.get_attr(id, f"receptors${ty.name}_current")
+        for i, c in enumerate(cells):
+            rec = c.receptors.get(ty)
+            if rec is not None:
+                rec.r.r, rec.current = float(r[i]), float(cur[i])
+
+
+def _upload_cells(dn, id, cells):
+    if not cells:
+        return
+    f32 = lambda k: np.array([getattr(c, k) for c in cells], np.float32)
+    for k, a in (("current_voltage", "current_voltage"), ("v_th", "v_th"), ("v_resting", "v_resting"), ("dt", "dt"),
+                 ("k", "neural_refractoriness$k")):
+        dn.set_attr(id, a, f32(k))
+    if cells[0].kind == ST_POISSON:
+        dn.set_attr(id, "chance_of_firing", f32("chance_of_firing"))
+        dn.set_attr(id, "seed", np.array([c.seed for c in cells], np.uint32))
+    else:
+        dn.set_attr(id, "rate", f32("rate"))
+        dn.set_attr(id, "step", f32("step"))
+    dn.set_attr(id, "is_spiking", np.array([c.is_spiking for c in cells], np.uint32))
+    dn.set_attr(id, "last_firing_time", _lft(cells))
+    _upload_nt(dn, id, cells)
+
+
+def _flat(lattice):
+    return [c for row in lattice.cell_grid for c in row]
+
+
+class LatticeNetworkGPU:
+    """LatticeNetworkGPU (backend/src/neuron/gpu_lattices/mod.rs:1517-3212) over one DeviceNetwork."""
+
+    def __init__(self, network, device=0):
+        self.network = network
+        neurons = [c for l in network.lattices.values() for c in _flat(l)]
+        cells = [c for l in network.spike_train_lattices.values() for c in _flat(l)]
+        models = {type(c).model for c in neurons} or {IZHIKEVICH}
+        kinds = {c.kind for c in cells} or {ST_NONE}
+        if len(models) > 1 or len(kinds) > 1:
+            raise TypeError("one neuron model and one spike-train model per network (type parameters in the reference)")
+        nt, rc = _kinetics_of(neurons + cells)
+        self._dn = DeviceNetwork(model=models.pop(), nt_kinetics=nt, receptor_kinetics=rc, spike_train=kinds.pop(),
+                                 device=device)
+        for id, l in network.lattices.items():
+            self._dn.add_lattice(id, l.rows, l.cols)
+        for id, l in network.spike_train_lattices.items():
+            self._dn.add_spike_train_lattice(id, l.rows, l.cols)
+        self._dn.finalize()
+        self._upload()
+
+    @classmethod
+    def from_network(cls, network, device=0):                   # gpu_lattices/mod.rs:1636-1651
+        return cls(network, device=device)
+
+    # InterleavingGraphGPU::convert_to_gpu (graph/mod.rs:644-807)
+    def _upload(self):
+        dn, net = self._dn, self.network
+        for id, l in net.lattices.items():
+            _upload_neurons(dn, id, _flat(l))
+            p = l.plasticity
+            dn.set_plasticity(id, p.a_plus, p.a_minus, p.tau_plus, p.tau_minus, p.dt, l.do_plasticity)
+        for id, l in net.spike_train_lattices.items():
+            _upload_cells(dn, id, _flat(l))
+        nn, nt = dn.n_neurons, dn.n_tot
+        if nn == 0 or nt == 0:
+            return
+        w = np.zeros((nt, nn), np.float32)
+        c = np.zeros((nt, nn), np.uint32)
+        for id, l in net.lattices.items():
+            first, count = dn.lattice_range(id)
+            w[first:first + count, first:first + count] = l.weights
+            c[first:first + count, first:first + count] = l.connections
+        for (pre, post), weight in net.connecting.items():
+            i, j = self._global(pre), self._global(post)
+            w[i, j], c[i, j] = weight, 1
+        dn.set_graph_rows(0, w, c)
+
+    def _global(self, gp):
+        first, _ = self._dn.lattice_range(gp.id)
+        l = self.network.lattices.get(gp.id) or self.network.spike_train_lattices[gp.id]
+        return first + gp.pos[0] * l.cols + gp.pos[1]
+
+    def run_lattices(self, iterations):                         # gpu_lattices/mod.rs:3183-3212
+        dn, net = self._dn, self.network
+        dn.set_synapses(net.electrical_synapse, net.chemical_synapse)
+        hist = any(l.update_grid_history for l in list(net.lattices.values()) + list(net.spike_train_lattices.values()))
+        dn.set_history(voltage=hist, spikes=False)
+        dn.run(iterations)
+        self._download()
+
+    def _download(self):
+        dn, net = self._dn, self.network
+        net.internal_clock = dn.clock
+        nn, nt = dn.n_neurons, dn.n_tot
+        w = c = None
+        if nn and nt:
+            w, c = dn.get_graph_rows(0, nt)
+        for id, l in net.lattices.items():
+            _download_neurons(dn, id, _flat(l))
+            l.internal_clock = net.internal_clock
+            if w is not None:
+                first, count = dn.lattice_range(id)
+                l.weights = w[first:first + count, first:first + count].copy()
+                l.connections = c[first:first + count, first:first + count].copy()
+        for id, l in net.spike_train_lattices.items():
+            cells = _flat(l)
+            if cells:
+                for cell, v, s, t in zip(cells, dn.get_attr(id, "current_voltage"),
+                                         dn.get_attr(id, "is_spiking", dtype=np.uint32),
+                                         dn.get_attr(id, "last_firing_time", dtype=np.int32)):
+                    cell.current_voltage, cell.is_spiking = float(v), bool(s)
+                    cell.last_firing_time = None if t < 0 else int(t)
+        if w is not None:
+            for key in net.connecting:
+                net.connecting[key] = float(w[self._global(key[0]), self._global(key[1])])
+
+    def get_lattice(self, id):
+        return self.network.lattices[id]
+
+    def get_spike_train_lattice(self, id):
+        return self.network.spike_train_lattices[id]
+
+    def history(self, id):
+        """[steps][rows][cols] voltages of lattice `id` (GridVoltageHistory, gpu_lattices/mod.rs:189-280)."""
+        l = self.network.lattices.get(id) or self.network.spike_train_lattices[id]
+        return self._dn.voltage_history(id).reshape(-1, l.rows, l.cols)
+
+    def reset_history(self):
+        self._dn.reset_history()
+
+    def reset_timing(self):
+        self._dn.reset_timing()
+        for l in self.network.lattices.values():
+            l.reset_timing()
+
+    @property
+    def connecting_weights(self):
+        return dict(self.network.connecting)
+
+    def close(self):
+        self._dn.close()
+
+
+class LatticeGPU:
+    """LatticeGPU (backend/src/neuron/gpu_lattices/mod.rs:327-1118): a network of one lattice."""
+    lattice_type = Lattice
+
+    def __init__(self, id=0, device=0):
+        self._lattice = self.lattice_type(id)
+        self._device = device
+        self._net = None
+
+    @classmethod
+    def from_lattice(cls, lattice, device=0):                   # gpu_lattices/mod.rs:496-511
+        g = cls(lattice.id, device=device)
+        g._lattice = copy.deepcopy(lattice)
+        return g
+
+    def _ensure(self):
+        if self._net is None:
+            host = LatticeNetwork.generate_network([self._lattice])
+            self._net = LatticeNetworkGPU(host, device=self._device)
+        return self._net
+
+    def _dirty(self):
+        if self._net is not None:
+            self._net.close()
+            self._net = None
+
+    # building methods forward to the host lattice (and invalidate the device copy)
+    def populate(self, neuron, num_rows, num_cols):
+        self._dirty()
+        self._lattice.populate(neuron, num_rows, num_cols)
+
+    def connect(self, connection_conditional, weight_logic=None):
+        self._dirty()
+        self._lattice.connect(connection_conditional, weight_logic)
+
+    def apply(self, function):
+        self._dirty()
+        self._lattice.apply(function)
+
+    def apply_given_position(self, function):
+        self._dirty()
+        self._lattice.apply_given_position(function)
+
+    def set_neuron(self, row, col, neuron):
+        self._dirty()
+        self._lattice.set_neuron(row, col, neuron)
+
+    def set_dt(self, dt):
+        self._dirty()
+        self._lattice.set_dt(dt)
+
+    def __getattr__(self, name):        # get_neuron, get_weight, get_*_connections, position_to_index, flags ...
+        if name.startswith("_"):
+            raise AttributeError(name)
+        return getattr(self._lattice, name)
+
+    def __setattr__(self, name, value):
+        if name.startswith("_") or name in ("lattice_type",):
+            return object.__setattr__(self, name, value)
+        if name in ("update_grid_history", "electrical_synapse", "chemical_synapse", "do_plasticity", "plasticity", "id"):
+            if name in ("do_plasticity", "plasticity", "id"):
+                self._dirty()
+            return setattr(self._lattice, name, value)
+        object.__setattr__(self, name, value)
+
+    def run_lattice(self, iterations):                          # gpu_lattices/mod.rs:1081-1100
+        net = self._ensure()
+        net.network.electrical_synapse = self._lattice.electrical_synapse
+        net.network.chemical_synapse = self._lattice.chemical_synapse
+        net.run_lattices(iterations)
+
+    @property
+    def history(self):
+        if self._net is None:
+            return np.zeros((0, self._lattice.rows, self._lattice.cols), np.float32)
+        return self._net.history(self._lattice.id)
+
+    @property
+    def weights(self):
+        return self._lattice.weights
+
+    def reset_history(self):
+        if self._net is not None:
+            self._net.reset_history()
+
+    def reset_timing(self):
+        if self._net is not None:
+            self._net.reset_timing()
+        else:
+            self._lattice.reset_timing()
+
+    def close(self):
+        self._dirty()
+
+
+def _named(base, name, **attrs):
+    return type(name, (base,), attrs)
+
+
+# class names as in Lixirnet (interface_gpu/lixirnet/src/lib.rs:463-482), one family per backend model
+IzhikevichNeuronLattice = _named(Lattice, "IzhikevichNeuronLattice", neuron_type=IzhikevichNeuron)
+LeakyIntegrateAndFireNeuronLattice = _named(Lattice, "LeakyIntegrateAndFireNeuronLattice",
+                                            neuron_type=LeakyIntegrateAndFireNeuron)
+HodgkinHuxleyNeuronLattice = _named(Lattice, "HodgkinHuxleyNeuronLattice", neuron_type=HodgkinHuxleyNeuron)
+IzhikevichNeuronLatticeGPU = _named(LatticeGPU, "IzhikevichNeuronLatticeGPU", lattice_type=IzhikevichNeuronLattice)
+LeakyIntegrateAndFireNeuronLatticeGPU = _named(LatticeGPU, "LeakyIntegrateAndFireNeuronLatticeGPU",
+                                               lattice_type=LeakyIntegrateAndFireNeuronLattice)
+HodgkinHuxleyNeuronLatticeGPU = _named(LatticeGPU, "HodgkinHuxleyNeuronLatticeGPU",
+                                       lattice_type=HodgkinHuxleyNeuronLattice)
+RateSpikeTrainLattice = _named(SpikeTrainLattice, "RateSpikeTrainLattice", spike_train_type=RateSpikeTrain)
+PoissonNeuronLattice = _named(SpikeTrainLattice, "PoissonNeuronLattice", spike_train_type=PoissonNeuron)
+IzhikevichNeuronNetwork = _named(LatticeNetwork, "IzhikevichNeuronNetwork")
+IzhikevichNeuronNetworkGPU = _named(LatticeNetworkGPU, "IzhikevichNeuronNetworkGPU")

@@ -1,0 +1,98 @@
+// Exercises the C++ host mirror (spiking-neural-networks_amd/host/snn_lattice.hpp) the way the
+// reference's examples drive Lattice / LatticeGPU / LatticeNetworkGPU
+// (backend/examples/gpu_lattice/main.rs:27-51, backend/examples/lattice_network).  Writes results as raw
+// little-endian arrays that tests/test_gpu_cpp_host.py compares with the oracle.
+#include <cmath>
+#include <cstdio>
+#include <string>
+
+#include "../../spiking-neural-networks_amd/host/snn_lattice.hpp"
+
+using namespace snn_host;
+
+static void dump(const std::string &path, const std::vector<float> &v)
+{
+    FILE *f = std::fopen(path.c_str(), "wb");
+    std::fwrite(v.data(), sizeof(float), v.size(), f);
+    std::fclose(f);
+}
+
+static float v_init(size_t i, size_t j) { return -65.0f + 5.0f * (float)((i * 7 + j * 3) % 19); }
+static float weight(Position a, Position b)
+{
+    return 0.5f + 0.0625f * (float)((a.first + 2 * a.second + 3 * b.first + 5 * b.second) % 16);
+}
+
+int main(int argc, char **argv)
+{
+    const std::string out = argc > 1 ? argv[1] : ".";
+    try {
+        // ---- single lattice: LatticeGPU::from_lattice + run_lattice ----
+        IzhikevichNeuron base;
+        base.gap_conductance = 10.0f;
+        Lattice<IzhikevichNeuron> lattice;
+        lattice.populate(base, 6, 7);
+        lattice.apply_given_position([](Position p, IzhikevichNeuron &n) { n.current_voltage = v_init(p.first, p.second); });
+        lattice.connect([](Position a, Position b) { return a != b; }, weight);
+        lattice.update_grid_history = true;
+        auto gpu = LatticeGPU<IzhikevichNeuron>::from_lattice(lattice);
+        gpu.run_lattice(250);
+        gpu.run_lattice(0);                                  // no-op
+        std::vector<float> hist;
+        for (const auto &step : gpu.grid_history())
+            for (const auto &row : step) for (float v : row) hist.push_back(v);
+        dump(out + "/lattice_history.f32", hist);
+        std::vector<float> fin;
+        for (const auto &row : gpu.cell_grid())
+            for (const auto &n : row) {
+                fin.push_back(n.current_voltage);
+                fin.push_back(n.w_value);
+                fin.push_back(n.last_firing_time ? (float)*n.last_firing_time : -1.0f);
+            }
+        dump(out + "/lattice_final.f32", fin);
+        if (gpu.internal_clock() != 250) { std::fprintf(stderr, "clock %zu\n", gpu.internal_clock()); return 2; }
+
+        // ---- network: RateSpikeTrain lattice (id 0) -> Izhikevich lattice (id 1), STDP on ----
+        LatticeNetwork<IzhikevichNeuron, RateSpikeTrain> net;
+        Lattice<IzhikevichNeuron> l1;
+        l1.set_id(1);
+        l1.populate(base, 4, 4);
+        l1.apply_given_position([](Position p, IzhikevichNeuron &n) { n.current_voltage = v_init(p.second, p.first); });
+        l1.connect([](Position a, Position b) { return a != b; }, weight);
+        l1.do_plasticity = true;
+        RateSpikeTrain st;
+        st.rate = 3.0f;
+        SpikeTrainLattice<RateSpikeTrain> s0;
+        s0.set_id(0);
+        s0.populate(st, 4, 4);
+        net.add_lattice(l1);
+        net.add_spike_train_lattice(s0);
+        net.connect(0, 1, [](Position a, Position b) { return a == b; }, [](Position, Position) { return 2.0f; });
+        bool dup = false;
+        try { net.add_lattice(l1); } catch (const LatticeNetworkError &) { dup = true; }   // GraphIDAlreadyPresent
+        if (!dup) return 3;
+        auto gnet = LatticeNetworkGPU<IzhikevichNeuron, RateSpikeTrain>::from_network(net);
+        gnet.run_lattices(400);
+        std::vector<float> wout;
+        const auto &m = gnet.network.lattices.at(1).graph.matrix;
+        for (const auto &row : m) for (const auto &w : row) wout.push_back(w ? *w : NAN);
+        dump(out + "/network_weights.f32", wout);
+        std::vector<float> cw;
+        for (const auto &e : gnet.network.connecting_edges) cw.push_back(std::get<2>(e));
+        dump(out + "/network_connecting_weights.f32", cw);
+        std::vector<float> vfin;
+        for (const auto &row : gnet.network.lattices.at(1).cell_grid) for (const auto &n : row) vfin.push_back(n.current_voltage);
+        dump(out + "/network_final_v.f32", vfin);
+
+        // ---- error behaviour: a bad device ordinal surfaces as GPUError::GetDeviceFailure (7) ----
+        bool threw = false;
+        try { LatticeGPU<IzhikevichNeuron>::from_lattice(lattice, SNN_NT_APPROXIMATE, SNN_RC_APPROXIMATE, 4096); }
+        catch (const GPUError &e) { threw = e.code == SNN_ERR_GET_DEVICE; }
+        if (!threw) return 4;
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "host_lattice_test: %s\n", e.what());
+        return 1;
+    }
+    std::puts("host_lattice_test ok");
+    return 0;
+}

@@ -1,0 +1,120 @@
+"""The Lixirnet-style Python classes (spiking-neural-networks_amd/lattice.py) following the PROCEDURE of the
+reference's own Python CPU-vs-GPU tests (interface_gpu/lixirnet/tests/lattices.py:11-59, networks.py), with the
+oracle standing in for the reference's CPU class and bit-exact equality instead of the 2 mV tolerance."""
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+import parity
+
+pytestmark = pytest.mark.gpu
+
+exc_n = 3
+iterations = 1000
+
+
+def test_single_lattice_electrical_using_from(snn):
+    ln = snn
+    neuron = ln.IzhikevichNeuron()
+    neuron.gap_conductance = 10
+    neuron.c_m = 25
+    rng = np.random.default_rng(0)
+    init_state = rng.uniform(neuron.c, neuron.v_th, (exc_n, exc_n)).astype(np.float32)
+
+    lattice = ln.IzhikevichNeuronLattice(0)
+    lattice.populate(neuron, exc_n, exc_n)
+    lattice.apply_given_position(lambda pos, n: setattr(n, "current_voltage", float(init_state[pos])))
+    lattice.connect(lambda x, y: x != y, lambda x, y: 5)
+    lattice.update_grid_history = True
+    lattice.electrical_synapse = True
+    lattice.chemical_synapse = False
+
+    gpu_lattice = ln.IzhikevichNeuronLatticeGPU.from_lattice(lattice)
+    for a in lattice.get_every_node():
+        for b in lattice.get_every_node():
+            if a != b:
+                assert lattice.get_weight(a, b) == gpu_lattice.get_weight(a, b) == 5.0
+        assert lattice.get_neuron(*a).current_voltage == gpu_lattice.get_neuron(*a).current_voltage
+    with pytest.raises(KeyError):
+        gpu_lattice.get_weight((0, 0), (0, 0))             # diagonal is None
+    with pytest.raises(NotImplementedError):
+        lattice.run_lattice(1)                              # no CPU stepper in the product
+
+    gpu_lattice.run_lattice(iterations)
+    hist = gpu_lattice.history
+    assert hist.shape == (iterations, exc_n, exc_n)
+
+    lay = parity.Layout([(0, exc_n, exc_n)])
+    net = parity.make_oracle(lay)
+    net["gap_conductance"] = 10.0
+    net["c_m"] = 25.0
+    net["current_voltage"] = init_state.reshape(-1)
+    net.connect_all_to_all(5.0)
+    net.run(iterations, voltage_history=True)
+    assert np.array_equal(hist.reshape(iterations, -1).view(np.uint32), net.voltage_history.view(np.uint32))
+    assert gpu_lattice.get_neuron(1, 1).current_voltage == float(net["current_voltage"][4])
+    assert gpu_lattice.internal_clock == iterations
+    gpu_lattice.close()
+
+
+def test_network_with_rate_spike_train_chemical_and_stdp(snn):
+    ln = snn
+    glu = {ln.IonotropicNeurotransmitterType.AMPA: ln.ApproximateNeurotransmitter()}
+    receptors = ln.Ionotropic()
+    receptors.insert(ln.IonotropicNeurotransmitterType.AMPA, ln.AMPAReceptor(g=3.0))
+    neuron = ln.IzhikevichNeuron(gap_conductance=10.0)
+    neuron.set_synaptic_neurotransmitters(glu)
+    neuron.set_receptors(receptors)
+    rng = np.random.default_rng(1)
+    init = rng.uniform(-65, 30, (4, 5)).astype(np.float32)
+
+    l1 = ln.IzhikevichNeuronLattice(1)
+    l1.populate(neuron, 4, 5)
+    l1.apply_given_position(lambda pos, n: setattr(n, "current_voltage", float(init[pos])))
+    l1.connect(lambda x, y: x != y, lambda x, y: 0.5 + 0.125 * ((x[0] + y[1]) % 4))
+    l1.do_plasticity = True
+    l1.update_grid_history = True
+    st = ln.RateSpikeTrain(rate=2.5)
+    st.set_synaptic_neurotransmitters({ln.IonotropicNeurotransmitterType.AMPA: ln.ApproximateNeurotransmitter()})
+    s0 = ln.RateSpikeTrainLattice(0)
+    s0.populate(st, 4, 5)
+    net = ln.IzhikevichNeuronNetwork.generate_network([l1], [s0])
+    net.connect(0, 1, lambda x, y: x == y, lambda x, y: 2.0)
+    with pytest.raises(KeyError):
+        net.connect(1, 0, lambda x, y: True)               # PostsynapticLatticeCannotBeSpikeTrain
+    with pytest.raises(KeyError):
+        net.add_lattice(ln.IzhikevichNeuronLattice(1))      # GraphIDAlreadyPresent
+    net.electrical_synapse = True
+    net.chemical_synapse = True
+
+    gpu = ln.IzhikevichNeuronNetworkGPU.from_network(net)
+    gpu.run_lattices(600)
+
+    lay = parity.Layout([(1, 4, 5)], [(0, 4, 5)])
+    o = parity.make_oracle(lay, st_kind=ob.ST_RATE, chemical=True)
+    o["gap_conductance"] = 10.0
+    o["current_voltage"] = init.reshape(-1)
+    o["nt_flags"][:, 0] = 1
+    o["st_nt_flags"][:, 0] = 1
+    o["rc_flags"][:, 0] = 1
+    o["rc_g"][:, 0] = 3.0
+    o["st_rate"] = 2.5
+    pos = [(r, c) for r in range(4) for c in range(5)]
+    for i, a in enumerate(pos):
+        for j, b in enumerate(pos):
+            if a != b:
+                o["connections"][i, j] = 1
+                o["weights"][i, j] = 0.5 + 0.125 * ((a[0] + b[1]) % 4)
+        o["connections"][20 + i, i] = 1
+        o["weights"][20 + i, i] = 2.0
+    o["do_plasticity"] = 1
+    o.run(600, voltage_history=True)
+    assert np.array_equal(gpu.history(1).reshape(600, -1).view(np.uint32), o.voltage_history.view(np.uint32))
+    lat = gpu.get_lattice(1)
+    assert np.array_equal(lat.weights.view(np.uint32), np.where(o["connections"][:20] != 0, o["weights"][:20], 0).astype(np.float32).view(np.uint32))
+    cw = gpu.connecting_weights
+    for i, a in enumerate(pos):
+        key = (ln.GraphPosition(0, a), ln.GraphPosition(1, a))
+        assert np.float32(cw[key]) == o["weights"][20 + i, i]
+    assert lat.get_neuron(0, 0).last_firing_time == (None if o["last_firing_time"][0] < 0 else int(o["last_firing_time"][0]))
+    gpu.close()
