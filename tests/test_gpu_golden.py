@@ -1,0 +1,39 @@
+"""The HIP stepper against the COMMITTED golden vectors (no oracle run involved): raster, voltage traces,
+final state and the case-specific arrays (gates, weights, receptor state, RNG seeds) bit for bit."""
+import os
+
+import numpy as np
+import pytest
+
+import golden_cases
+import parity
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("name", sorted(golden_cases.CASES))
+def test_hip_matches_golden(snn, name):
+    net, steps = golden_cases.CASES[name]()          # inputs only; the oracle is not stepped
+    want = np.load(os.path.join(GOLDEN, name + ".npz"))
+    dn = parity.device_from_oracle(snn, net)
+    dn.set_history(voltage=True, spikes=True)
+    dn.run(steps)
+    lat = net.layout.lattices[0][0]
+    raster = dn.spike_history(lat)
+    assert np.packbits(raster, axis=1).tobytes() == want["raster"].tobytes()
+    stride = int(want["trace_stride"])
+    assert dn.voltage_history(lat)[::stride].tobytes() == want["voltage_trace"].tobytes()
+    st = parity.pull_state(dn, net)
+    assert st["current_voltage"].tobytes() == want["final_voltage"].tobytes()
+    assert st["last_firing_time"].tobytes() == want["last_firing_time"].tobytes()
+    if net.n_cells:
+        sid = net.layout.st_lattices[0][0]
+        assert np.packbits(dn.voltage_history(sid) > 0, axis=1).tobytes() == want["st_voltage_spikes"].tobytes()
+    for k in golden_cases.EXTRA.get(name, ()):
+        if k == "weights":
+            w, c = dn.get_graph_rows(0, net.n_tot)
+            assert w.tobytes() == np.where(net["connections"] != 0, want[k], np.float32(0)).astype(np.float32).tobytes()
+        else:
+            assert st[k].tobytes() == want[k].tobytes(), k
+    dn.close()
