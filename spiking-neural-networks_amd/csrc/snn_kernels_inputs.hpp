@@ -60,9 +60,32 @@ constexpr uint32_t KIND_NEURON = 0, KIND_ST_SILENT = 1, KIND_ST_FIRED = 2;
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-// W is read exactly once per step: stream it past the caches (global_load_dwordx4 ... nt).
-// Measured on MI355X at 256x256 (same box, A/B): nt 6.18 TB/s vs default cache policy 5.75 TB/s.
-__device__ __forceinline__ v4f load_w4(const v4f *p) { return __builtin_nontemporal_load(p); }
+// Two shapes of the same kernel (identical arithmetic, chosen by the size of W):
+//  STREAM  (W larger than the caches): 256 threads, 4 adjacent columns per lane, one
+//          global_load_dwordx4 ... nt per wave-row -- W is read exactly once per step, so it is streamed
+//          past the caches.  Measured on MI355X at 256x256 (same box, A/B): nt 6.18 TB/s vs default cache
+//          policy 5.75 TB/s.  Rows in batches of 8 loads; occupancy covers the HBM latency.
+//  !STREAM (W stays resident in the L2s / Infinity Cache between steps, i.e. small lattices): one
+//          wavefront per workgroup, ONE column per lane, default cache policy, 32 rows per round trip.
+//          A 32x32 lattice then spreads over 64 CUs instead of 4 -- each CU's vector-L1 bandwidth
+//          (64 B/clk) is what bounds a cache-resident pass, not HBM.
+template <bool STREAM> struct InputsShape {
+    static constexpr int VEC = STREAM ? 4 : 1;
+    static constexpr int THREADS = STREAM ? 256 : 64;
+    static constexpr int TILE = VEC * THREADS;            // columns per workgroup
+    static constexpr uint32_t ROW_BATCH = STREAM ? 8 : 32;
+};
+
+template <bool STREAM>
+__device__ __forceinline__ void load_w(const float *p, float (&w)[InputsShape<STREAM>::VEC])
+{
+    if constexpr (STREAM) {
+        const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(p));
+        w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+    } else {
+        w[0] = *p;
+    }
+}
 
 __device__ __forceinline__ float acc_if_edge(float acc, float term, float w)
 {
@@ -70,9 +93,13 @@ __device__ __forceinline__ float acc_if_edge(float acc, float term, float w)
     return (w == w) ? acc + term * w : acc;
 }
 
-template <bool ELEC, bool CHEM>
-__global__ __launch_bounds__(256) void k_inputs_dense(const InputsArgs a)
+template <bool ELEC, bool CHEM, bool STREAM = true>
+__global__ __launch_bounds__(InputsShape<STREAM>::THREADS) void k_inputs_dense(const InputsArgs a)
 {
+    using S = InputsShape<STREAM>;
+    constexpr int VEC = S::VEC;
+    constexpr uint32_t ROW_BATCH = S::ROW_BATCH;
+
     __shared__ float s_val[CHUNK];
     __shared__ uint32_t s_kind[CHUNK];
     __shared__ float s_t[CHEM ? K_TYPES : 1][CHUNK];
@@ -82,9 +109,9 @@ __global__ __launch_bounds__(256) void k_inputs_dense(const InputsArgs a)
     const uint32_t rows = min((uint32_t)CHUNK, a.n_tot - p0);
     const uint32_t tid = threadIdx.x;
 
-    // ---- stage the chunk's presynaptic values in LDS (one coalesced read per array) ----
-    if (tid < rows) {
-        const uint32_t p = p0 + tid;
+    // ---- stage the chunk's presynaptic values in LDS (coalesced reads, one pass per array) ----
+    for (uint32_t i = tid; i < rows; i += S::THREADS) {
+        const uint32_t p = p0 + i;
         float val;
         uint32_t kind;
         if (p < a.n_neurons) {
@@ -95,7 +122,7 @@ __global__ __launch_bounds__(256) void k_inputs_dense(const InputsArgs a)
                 for (int k = 0; k < K_TYPES; ++k) {
                     const uint32_t f = a.nt_flags[(size_t)k * a.n_pad + p];
                     kind |= f ? (0x100u << k) : 0u;
-                    s_t[k][tid] = a.xbuf[a.xl.at(p, PLANE_T0 + k)];
+                    s_t[k][i] = a.xbuf[a.xl.at(p, PLANE_T0 + k)];
                 }
             }
         } else {
@@ -107,22 +134,22 @@ __global__ __launch_bounds__(256) void k_inputs_dense(const InputsArgs a)
                 for (int k = 0; k < K_TYPES; ++k) {
                     const uint32_t f = a.st_nt_flags[(size_t)k * a.c_pad + s];
                     kind |= f ? (0x100u << k) : 0u;
-                    s_t[k][tid] = a.st_nt_t[(size_t)k * a.c_pad + s];
+                    s_t[k][i] = a.st_nt_t[(size_t)k * a.c_pad + s];
                 }
             }
         }
-        s_val[tid] = val;
-        s_kind[tid] = kind;
+        s_val[i] = val;
+        s_kind[i] = kind;
     }
     __syncthreads();
 
-    const uint32_t ql = blockIdx.x * TILE_POSTS + tid * 4;   // first of this lane's 4 local columns
+    const uint32_t ql = blockIdx.x * S::TILE + tid * VEC;   // first of this lane's VEC local columns
     if (ql >= a.ld) return;
 
     // ---- this lane's postsynaptic voltage / conductance, kept in registers ----
-    float vq[4], gq[4];
+    float vq[VEC], gq[VEC];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < VEC; ++j) {
         const uint32_t q = ql + j;
         if (ELEC && q < a.n_loc) {
             vq[j] = a.xbuf[a.xl.at(a.q0 + q, PLANE_V)];
@@ -133,56 +160,60 @@ __global__ __launch_bounds__(256) void k_inputs_dense(const InputsArgs a)
         }
     }
 
-    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    float tacc[CHEM ? K_TYPES : 1][4];
+    float acc[VEC];
+    float tacc[CHEM ? K_TYPES : 1][VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[j] = 0.0f;
 #pragma unroll
     for (int k = 0; k < (CHEM ? K_TYPES : 1); ++k)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) tacc[k][j] = 0.0f;
+        for (int j = 0; j < VEC; ++j) tacc[k][j] = 0.0f;
 
-    const v4f *wrow = reinterpret_cast<const v4f *>(a.W + (size_t)p0 * a.ld + ql);
-    const size_t ld4 = a.ld / 4;
+    const float *wrow = a.W + (size_t)p0 * a.ld + ql;
+    const size_t ld = a.ld;
 
     // Rows are consumed in batches of ROW_BATCH: all loads of a batch are issued before the first use,
-    // so every wave keeps ROW_BATCH KiB of HBM reads in flight regardless of the branches in the body.
-    constexpr uint32_t ROW_BATCH = 8;
+    // so every wave keeps ROW_BATCH wave-rows of reads in flight regardless of the branches in the body.
+    auto sweep = [&](auto body) {
+        uint32_t r = 0;
+        for (; r + ROW_BATCH <= rows; r += ROW_BATCH) {
+            float wb[ROW_BATCH][VEC];
+#pragma unroll
+            for (uint32_t u = 0; u < ROW_BATCH; ++u) load_w<STREAM>(wrow + (size_t)(r + u) * ld, wb[u]);
+#pragma unroll
+            for (uint32_t u = 0; u < ROW_BATCH; ++u) body(r + u, wb[u]);
+        }
+        for (; r < rows; ++r) {
+            float w[VEC];
+            load_w<STREAM>(wrow + (size_t)r * ld, w);
+            body(r, w);
+        }
+    };
 
     const bool plain = !CHEM && (p0 + rows <= a.n_neurons);   // workgroup-uniform
     if (plain) {
         // all presynaptic rows are neurons, electrical only: the C1/C2 inner loop
-        auto body = [&](uint32_t r, const v4f w) {
+        sweep([&](uint32_t r, const float (&w)[VEC]) {
             const float vp = s_val[r];
-            acc[0] = acc_if_edge(acc[0], gq[0] * (vp - vq[0]), w.x);
-            acc[1] = acc_if_edge(acc[1], gq[1] * (vp - vq[1]), w.y);
-            acc[2] = acc_if_edge(acc[2], gq[2] * (vp - vq[2]), w.z);
-            acc[3] = acc_if_edge(acc[3], gq[3] * (vp - vq[3]), w.w);
-        };
-        uint32_t r = 0;
-        for (; r + ROW_BATCH <= rows; r += ROW_BATCH) {
-            v4f wb[ROW_BATCH];
 #pragma unroll
-            for (uint32_t u = 0; u < ROW_BATCH; ++u) wb[u] = load_w4(wrow + (size_t)(r + u) * ld4);
-#pragma unroll
-            for (uint32_t u = 0; u < ROW_BATCH; ++u) body(r + u, wb[u]);
-        }
-        for (; r < rows; ++r) body(r, load_w4(wrow + (size_t)r * ld4));
+            for (int j = 0; j < VEC; ++j) acc[j] = acc_if_edge(acc[j], gq[j] * (vp - vq[j]), w[j]);
+        });
     } else {
-        auto body = [&](uint32_t r, const v4f w4) {
-            const float w[4] = {w4.x, w4.y, w4.z, w4.w};
+        sweep([&](uint32_t r, const float (&w)[VEC]) {
             const uint32_t kind = __builtin_amdgcn_readfirstlane(s_kind[r]);
             if (ELEC) {
                 const float vp = s_val[r];
                 const uint32_t src = kind & 3u;
                 if (src == KIND_NEURON) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[j] = acc_if_edge(acc[j], gq[j] * (vp - vq[j]), w[j]);
+                    for (int j = 0; j < VEC; ++j) acc[j] = acc_if_edge(acc[j], gq[j] * (vp - vq[j]), w[j]);
                 } else if (src == KIND_ST_SILENT) {
                     // never fired: v_resting without the conductance factor (neuron/mod.rs:126-128)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[j] = acc_if_edge(acc[j], vp, w[j]);
+                    for (int j = 0; j < VEC; ++j) acc[j] = acc_if_edge(acc[j], vp, w[j]);
                 } else {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[j] = acc_if_edge(acc[j], gq[j] * vp, w[j]);
+                    for (int j = 0; j < VEC; ++j) acc[j] = acc_if_edge(acc[j], gq[j] * vp, w[j]);
                 }
             }
             if (CHEM) {
@@ -191,31 +222,24 @@ __global__ __launch_bounds__(256) void k_inputs_dense(const InputsArgs a)
                     if (kind & (0x100u << k)) {
                         const float t = s_t[k][r];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) tacc[k][j] = acc_if_edge(tacc[k][j], t, w[j]);
+                        for (int j = 0; j < VEC; ++j) tacc[k][j] = acc_if_edge(tacc[k][j], t, w[j]);
                     }
                 }
             }
-        };
-        uint32_t r = 0;
-        for (; r + ROW_BATCH <= rows; r += ROW_BATCH) {
-            v4f wb[ROW_BATCH];
-#pragma unroll
-            for (uint32_t u = 0; u < ROW_BATCH; ++u) wb[u] = load_w4(wrow + (size_t)(r + u) * ld4);
-#pragma unroll
-            for (uint32_t u = 0; u < ROW_BATCH; ++u) body(r + u, wb[u]);
-        }
-        for (; r < rows; ++r) body(r, load_w4(wrow + (size_t)r * ld4));
+        });
     }
 
     if (ELEC) {
-        float4 *dst = reinterpret_cast<float4 *>(a.part_i + (size_t)chunk * a.ld + ql);
-        *dst = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        float *dst = a.part_i + (size_t)chunk * a.ld + ql;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) dst[j] = acc[j];
     }
     if (CHEM) {
 #pragma unroll
         for (int k = 0; k < K_TYPES; ++k) {
-            float4 *dst = reinterpret_cast<float4 *>(a.part_t + ((size_t)k * a.n_chunks + chunk) * a.ld + ql);
-            *dst = make_float4(tacc[k][0], tacc[k][1], tacc[k][2], tacc[k][3]);
+            float *dst = a.part_t + ((size_t)k * a.n_chunks + chunk) * a.ld + ql;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) dst[j] = tacc[k][j];
         }
     }
 }

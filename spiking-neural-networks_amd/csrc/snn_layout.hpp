@@ -23,7 +23,6 @@ namespace snn {
 
 constexpr int K_TYPES = 3;
 constexpr int CHUNK = 256;        // canonical reduction chunk (SNN_REDUCTION_CHUNK)
-constexpr int TILE_POSTS = 1024;  // postsynaptic columns per workgroup: 4 waves x 64 lanes x float4
 constexpr int NUM_PLANES = 5;
 enum Plane { PLANE_V = 0, PLANE_SPIKE = 1, PLANE_T0 = 2 };
 

@@ -496,7 +496,6 @@ int launch_inputs(snn_network *net)
     a.st_nt_t = net->ca.nt_t; a.st_nt_flags = net->ca.nt_flags; a.c_pad = net->c_pad;
     a.nt_flags = net->na.nt_flags; a.n_pad = net->n_pad;
     a.part_i = net->part_i; a.part_t = net->part_t; a.n_chunks = net->n_chunks;
-    dim3 grid((net->ld + TILE_POSTS - 1) / TILE_POSTS, net->n_chunks);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (net->profile) {
         if (net->ev_used == net->ev_pool.size()) {
@@ -510,12 +509,22 @@ int launch_inputs(snn_network *net)
         ++net->ev_used;
         HIP_TRY(hipEventRecord(e0, net->stream), SNN_ERR_QUEUE);
     }
-    if (net->electrical && net->chemical)
-        hipLaunchKernelGGL((k_inputs_dense<true, true>), grid, dim3(256), 0, net->stream, a);
-    else if (net->electrical)
-        hipLaunchKernelGGL((k_inputs_dense<true, false>), grid, dim3(256), 0, net->stream, a);
-    else
-        hipLaunchKernelGGL((k_inputs_dense<false, true>), grid, dim3(256), 0, net->stream, a);
+    // matrices that stay cache-resident between steps take the latency-oriented variant
+    const bool stream = (size_t)net->n_tot * net->ld * 4 > ((size_t)64 << 20);
+#define SNN_LAUNCH_INPUTS(E, C)                                                                          \
+    do {                                                                                                 \
+        constexpr int T1 = InputsShape<true>::TILE, T0 = InputsShape<false>::TILE;                       \
+        if (stream)                                                                                      \
+            hipLaunchKernelGGL((k_inputs_dense<E, C, true>), dim3((net->ld + T1 - 1) / T1, net->n_chunks), \
+                               dim3(InputsShape<true>::THREADS), 0, net->stream, a);                     \
+        else                                                                                             \
+            hipLaunchKernelGGL((k_inputs_dense<E, C, false>), dim3((net->ld + T0 - 1) / T0, net->n_chunks), \
+                               dim3(InputsShape<false>::THREADS), 0, net->stream, a);                    \
+    } while (0)
+    if (net->electrical && net->chemical) SNN_LAUNCH_INPUTS(true, true);
+    else if (net->electrical) SNN_LAUNCH_INPUTS(true, false);
+    else SNN_LAUNCH_INPUTS(false, true);
+#undef SNN_LAUNCH_INPUTS
     HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
     if (net->profile) HIP_TRY(hipEventRecord(e1, net->stream), SNN_ERR_QUEUE);
     return SNN_OK;
