@@ -133,6 +133,18 @@ int snn_get_graph_rows(snn_network_t *net, uint32_t pre_begin, uint32_t pre_coun
  * connected unless pre == post (or always, with_diagonal != 0).  Nothing crosses PCIe. */
 int snn_fill_graph_synthetic(snn_network_t *net, uint64_t seed, float lo, float hi, int with_diagonal);
 
+/* Sparse form, CSR by LOCAL postsynaptic neuron (the reference's sparse graph, AdjacencyList
+ * graph/mod.rs:974-1118, has no GPU form; needed where a dense N x N matrix cannot exist, e.g.
+ * BASELINE configs[4]).  snn_network_use_csr must precede finalize; a handle is dense or CSR for life.
+ * row_ptr[n_local + 1] (row_ptr[0] == 0, row_ptr[n_local] == nnz), pre_index[nnz] = interleaved
+ * presynaptic index, STRICTLY ascending inside each row, weights[nnz].  Stored edges are Some(w),
+ * everything else is None.  Same arithmetic as the dense form, bit for bit. */
+int snn_network_use_csr(snn_network_t *net, int enable);
+int snn_set_graph_csr(snn_network_t *net, const uint64_t *row_ptr, const uint32_t *pre_index,
+                      const float *weights, uint64_t nnz);
+/* weights in the order they were set (plasticity changes values, never the structure) */
+int snn_get_graph_csr(snn_network_t *net, float *weights, uint64_t nnz);
+
 /* ---- switches (Lattice / LatticeNetwork pub fields, neuron/mod.rs:570-586, 1577-1588) -- */
 
 int snn_set_synapses(snn_network_t *net, int electrical_synapse, int chemical_synapse);

@@ -72,6 +72,9 @@ SIGNATURES = {
     "snn_set_graph_rows": (C.c_int, [H, C.c_uint32, C.c_uint32, f32p, u32p]),
     "snn_get_graph_rows": (C.c_int, [H, C.c_uint32, C.c_uint32, f32p, u32p]),
     "snn_fill_graph_synthetic": (C.c_int, [H, C.c_uint64, C.c_float, C.c_float, C.c_int]),
+    "snn_network_use_csr": (C.c_int, [H, C.c_int]),
+    "snn_set_graph_csr": (C.c_int, [H, u64p, u32p, f32p, C.c_uint64]),
+    "snn_get_graph_csr": (C.c_int, [H, f32p, C.c_uint64]),
     "snn_set_synapses": (C.c_int, [H, C.c_int, C.c_int]),
     "snn_set_plasticity": (C.c_int, [H, C.c_uint32] + [C.c_float] * 5 + [C.c_int]),
     "snn_set_history": (C.c_int, [H, C.c_int, C.c_int]),

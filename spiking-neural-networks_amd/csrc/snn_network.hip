@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "../../include/snn_amd.h"
+#include "snn_kernels_csr.hpp"
 #include "snn_kernels_inputs.hpp"
 #include "snn_kernels_misc.hpp"
 #include "snn_kernels_update.hpp"
@@ -81,6 +82,11 @@ struct snn_network {
     XLayout xl{0, 1};
 
     std::vector<void *> allocs;
+    // sparse form (CSR by local postsynaptic row); the arrays are replaced by every snn_set_graph_csr
+    bool csr = false;
+    uint64_t nnz = 0;
+    uint32_t *csr_ptr = nullptr, *csr_pre = nullptr, *csr_post = nullptr, *csr_t_ptr = nullptr, *csr_t_edge = nullptr;
+    float *csr_w = nullptr;
     float *W = nullptr;
     float *xbuf = nullptr;
     float *part_i = nullptr, *part_t = nullptr;
@@ -367,8 +373,9 @@ int build_state(snn_network *net)
     TRY(dev_alloc_t(net, &net->st_clock_dev, net->st_clock.size()));
 
     // graph + partials + counts
-    TRY(dev_alloc_t(net, &net->W, (size_t)net->n_tot * net->ld));
-    if ((size_t)net->n_tot * net->ld) {
+    if (net->csr) net->n_chunks = 1;     // the CSR kernel writes the finished two-level sum
+    TRY(dev_alloc_t(net, &net->W, net->csr ? 0 : (size_t)net->n_tot * net->ld));
+    if (!net->csr && (size_t)net->n_tot * net->ld) {
         // no edges until a graph is set: all sentinel
         hipLaunchKernelGGL(k_fill_u32, dim3(4096), dim3(256), 0, net->stream,
                            reinterpret_cast<uint32_t *>(net->W), (size_t)net->n_tot * net->ld, 0x7FC00000u);
@@ -453,12 +460,31 @@ int attr_io(snn_network *net, uint32_t id, const char *name, AttrType type, void
 
 // ---- per-step launches -------------------------------------------------------------------------
 
+CsrGraph csr_graph(const snn_network *net)
+{
+    CsrGraph g{};
+    g.ptr = net->csr_ptr; g.pre = net->csr_pre; g.w = net->csr_w; g.post = net->csr_post;
+    g.t_ptr = net->csr_t_ptr; g.t_edge = net->csr_t_edge; g.n_loc = net->n_loc;
+    return g;
+}
+
 int ensure_counts(snn_network *net)
 {
     if (!net->counts_dirty || net->n_loc == 0) { net->counts_dirty = false; return SNN_OK; }
     HIP_TRY(hipMemsetAsync(net->n_in, 0, (size_t)net->ld * 4, net->stream), SNN_ERR_BUFFER_WRITE);
     HIP_TRY(hipMemsetAsync(net->tcount, 0, (size_t)K_TYPES * net->ld * 4, net->stream), SNN_ERR_BUFFER_WRITE);
-    if (net->n_tot) {
+    if (net->csr) {
+        if (net->csr_ptr) {
+            CsrCountArgs a{};
+            a.g = csr_graph(net);
+            a.n_neurons = net->nn; a.ld = net->ld;
+            a.nt_flags = net->na.nt_flags; a.n_pad = net->n_pad;
+            a.st_nt_flags = net->ca.nt_flags; a.c_pad = net->c_pad;
+            a.n_in = net->n_in; a.tcount = net->tcount;
+            hipLaunchKernelGGL(k_csr_count, dim3((net->n_loc + 255) / 256), dim3(256), 0, net->stream, a);
+            HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+        }
+    } else if (net->n_tot) {
         CountArgs a{};
         a.W = net->W; a.ld = net->ld; a.n_loc = net->n_loc; a.n_neurons = net->nn; a.n_tot = net->n_tot;
         a.nt_flags = net->na.nt_flags; a.n_pad = net->n_pad;
@@ -508,6 +534,23 @@ int launch_inputs(snn_network *net)
         e1 = net->ev_pool[net->ev_used].second;
         ++net->ev_used;
         HIP_TRY(hipEventRecord(e0, net->stream), SNN_ERR_QUEUE);
+    }
+    if (net->csr) {
+        if (net->csr_ptr) {
+            CsrInputsArgs ca{};
+            ca.g = csr_graph(net);
+            ca.in = a;
+            dim3 g((net->n_loc + 255) / 256);
+            if (net->electrical && net->chemical) hipLaunchKernelGGL((k_inputs_csr<true, true>), g, dim3(256), 0, net->stream, ca);
+            else if (net->electrical) hipLaunchKernelGGL((k_inputs_csr<true, false>), g, dim3(256), 0, net->stream, ca);
+            else hipLaunchKernelGGL((k_inputs_csr<false, true>), g, dim3(256), 0, net->stream, ca);
+        } else {   // no graph set: no edges
+            HIP_TRY(hipMemsetAsync(net->part_i, 0, (size_t)net->ld * 4, net->stream), SNN_ERR_BUFFER_WRITE);
+            HIP_TRY(hipMemsetAsync(net->part_t, 0, (size_t)K_TYPES * net->ld * 4, net->stream), SNN_ERR_BUFFER_WRITE);
+        }
+        HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+        if (net->profile) HIP_TRY(hipEventRecord(e1, net->stream), SNN_ERR_QUEUE);
+        return SNN_OK;
     }
     // matrices that stay cache-resident between steps take the latency-oriented variant
     const bool stream = (size_t)net->n_tot * net->ld * 4 > ((size_t)64 << 20);
@@ -564,6 +607,17 @@ int launch_plasticity(snn_network *net)
     hipLaunchKernelGGL(k_spike_compact, dim3((net->nn + 255) / 256), dim3(256), 0, net->stream, a);
     HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
     if (net->n_loc == 0) return SNN_OK;
+    if (net->csr) {
+        if (!net->csr_ptr) return SNN_OK;
+        CsrStdpArgs ca{};
+        ca.g = csr_graph(net);
+        ca.s = a;
+        hipLaunchKernelGGL(k_stdp_csr_in, dim3(1024), dim3(64), 0, net->stream, ca);
+        HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+        hipLaunchKernelGGL(k_stdp_csr_out, dim3(1024), dim3(64), 0, net->stream, ca);
+        HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+        return SNN_OK;
+    }
     const unsigned sy = 64;   // spiking neurons processed concurrently; the rest grid-strides
     hipLaunchKernelGGL(k_stdp_columns, dim3((net->n_tot + 255) / 256, sy), dim3(256), 0, net->stream, a);
     HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
@@ -659,6 +713,7 @@ int graph_rows_io(snn_network *net, uint32_t pre_begin, uint32_t pre_count, floa
                   size_t host_ld, bool set)
 {
     if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
+    if (net->csr) return fail(SNN_ERR_BAD_STATE, "handle holds a CSR graph: use snn_set_graph_csr / snn_get_graph_csr");
     if ((uint64_t)pre_begin + pre_count > net->n_tot) return fail(SNN_ERR_DIM_MISMATCH, "row range exceeds n_tot");
     if (pre_count == 0 || net->nn == 0) return SNN_OK;
     if (!weights || !conns) return fail(SNN_ERR_BAD_ARG, "null graph pointer");
@@ -750,6 +805,9 @@ int snn_network_destroy(snn_network_t *net)
     (void)hipSetDevice(net->device);
     if (net->stream) (void)hipStreamSynchronize(net->stream);
     for (void *p : net->allocs) (void)hipFree(p);
+    for (void *p : {(void *)net->csr_ptr, (void *)net->csr_pre, (void *)net->csr_post, (void *)net->csr_t_ptr,
+                    (void *)net->csr_t_edge, (void *)net->csr_w})
+        if (p) (void)hipFree(p);
     if (net->vhist) (void)hipFree(net->vhist);
     if (net->st_vhist) (void)hipFree(net->st_vhist);
     if (net->raster) (void)hipFree(net->raster);
@@ -905,6 +963,7 @@ int snn_fill_graph_synthetic(snn_network_t *net, uint64_t seed, float lo, float 
 {
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
     if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
+    if (net->csr) return fail(SNN_ERR_BAD_STATE, "the synthetic dense graph needs a dense handle");
     HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
     if (net->n_tot && net->ld) {
         const unsigned gy = std::min<uint32_t>(net->n_tot, 4096);
@@ -914,6 +973,78 @@ int snn_fill_graph_synthetic(snn_network_t *net, uint64_t seed, float lo, float 
         HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
     }
     net->counts_dirty = true;
+    return SNN_OK;
+}
+
+int snn_network_use_csr(snn_network_t *net, int enable)
+{
+    if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
+    if (net->finalized) return fail(SNN_ERR_BAD_STATE, "the graph form is fixed at finalize");
+    net->csr = enable != 0;
+    return SNN_OK;
+}
+
+int snn_set_graph_csr(snn_network_t *net, const uint64_t *row_ptr, const uint32_t *pre_index, const float *weights,
+                      uint64_t nnz)
+{
+    if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
+    if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
+    if (!net->csr) return fail(SNN_ERR_BAD_STATE, "handle holds a dense graph: call snn_network_use_csr before finalize");
+    if (!row_ptr || (nnz && (!pre_index || !weights))) return fail(SNN_ERR_BAD_ARG, "null graph pointer");
+    if (nnz >= 0xFFFFFFFFull) return fail(SNN_ERR_DIM_MISMATCH, "more than 2^32-1 stored synapses per handle");
+    const uint32_t n_loc = net->n_loc;
+    if (row_ptr[0] != 0 || row_ptr[n_loc] != nnz) return fail(SNN_ERR_DIM_MISMATCH, "row_ptr must run from 0 to nnz");
+    std::vector<uint32_t> ptr(n_loc + 1), post(nnz), t_ptr((size_t)net->n_tot + 1, 0), t_edge(nnz);
+    for (uint32_t q = 0; q < n_loc; ++q) {
+        if (row_ptr[q + 1] < row_ptr[q]) return fail(SNN_ERR_DIM_MISMATCH, "row_ptr is not monotone");
+        for (uint64_t e = row_ptr[q]; e < row_ptr[q + 1]; ++e) {
+            if (pre_index[e] >= net->n_tot) return fail(SNN_ERR_DIM_MISMATCH, "presynaptic index out of range");
+            if (e > row_ptr[q] && pre_index[e] <= pre_index[e - 1])
+                return fail(SNN_ERR_BAD_ARG, "presynaptic indices of a row must be strictly ascending");
+            post[e] = q;
+            ++t_ptr[pre_index[e] + 1];
+        }
+    }
+    for (uint32_t q = 0; q <= n_loc; ++q) ptr[q] = (uint32_t)row_ptr[q];
+    for (size_t p = 0; p < net->n_tot; ++p) t_ptr[p + 1] += t_ptr[p];
+    {
+        std::vector<uint32_t> fill(t_ptr.begin(), t_ptr.end() - 1);
+        for (uint64_t e = 0; e < nnz; ++e) t_edge[fill[pre_index[e]]++] = (uint32_t)e;
+    }
+    HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
+    HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
+    for (void **p : {(void **)&net->csr_ptr, (void **)&net->csr_pre, (void **)&net->csr_post, (void **)&net->csr_t_ptr,
+                     (void **)&net->csr_t_edge, (void **)&net->csr_w}) {
+        if (*p) (void)hipFree(*p);
+        *p = nullptr;
+    }
+    auto up = [&](void **dst, const void *src, size_t bytes) -> int {
+        HIP_TRY(hipMalloc(dst, std::max<size_t>(bytes, 256)), SNN_ERR_BUFFER_CREATE);
+        if (bytes) HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
+        return SNN_OK;
+    };
+    TRY(up((void **)&net->csr_ptr, ptr.data(), ptr.size() * 4));
+    TRY(up((void **)&net->csr_pre, pre_index, nnz * 4));
+    TRY(up((void **)&net->csr_w, weights, nnz * 4));
+    TRY(up((void **)&net->csr_post, post.data(), nnz * 4));
+    TRY(up((void **)&net->csr_t_ptr, t_ptr.data(), t_ptr.size() * 4));
+    TRY(up((void **)&net->csr_t_edge, t_edge.data(), nnz * 4));
+    net->nnz = nnz;
+    net->counts_dirty = true;
+    return SNN_OK;
+}
+
+int snn_get_graph_csr(snn_network_t *net, float *weights, uint64_t nnz)
+{
+    if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
+    if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
+    if (!net->csr) return fail(SNN_ERR_BAD_STATE, "handle holds a dense graph");
+    if (nnz != net->nnz) return fail(SNN_ERR_DIM_MISMATCH, "nnz does not match the stored graph");
+    if (nnz == 0) return SNN_OK;
+    if (!weights) return fail(SNN_ERR_BAD_ARG, "weights is null");
+    HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
+    HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
+    HIP_TRY(hipMemcpy(weights, net->csr_w, nnz * 4, hipMemcpyDeviceToHost), SNN_ERR_BUFFER_READ);
     return SNN_OK;
 }
 
@@ -1118,7 +1249,8 @@ int snn_input_kernel_bytes(const snn_network_t *net, uint64_t *bytes)
 {
     if (!net || !bytes) return fail(SNN_ERR_BAD_ARG, "null argument");
     if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
-    *bytes = (uint64_t)4 * net->n_tot * net->n_loc;   // every synapse weight of the shard, read once
+    *bytes = net->csr ? (uint64_t)8 * net->nnz                 // CSR: index + weight of every stored synapse
+                      : (uint64_t)4 * net->n_tot * net->n_loc; // dense: every weight of the shard, read once
     return SNN_OK;
 }
 

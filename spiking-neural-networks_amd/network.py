@@ -61,7 +61,11 @@ class DeviceNetwork:
         _lib.check(self._L.snn_network_add_spike_train_lattice(self._h, id, rows, cols))
         self.lattices[id] = (rows, cols, True)
 
-    def finalize(self, shard_index=None, n_shards=None):
+    def finalize(self, shard_index=None, n_shards=None, csr=False):
+        """csr=True: the handle holds a sparse CSR graph (set_graph_csr) instead of a dense matrix"""
+        if csr:
+            _lib.check(self._L.snn_network_use_csr(self._h, 1))
+        self.csr = bool(csr)
         if shard_index is None:
             _lib.check(self._L.snn_network_finalize(self._h))
         else:
@@ -128,6 +132,22 @@ class DeviceNetwork:
         _lib.check(self._L.snn_get_graph_rows(self._h, pre_begin, pre_count, w.ctypes.data_as(_lib.f32p),
                                               c.ctypes.data_as(_lib.u32p)))
         return w, c
+
+    def set_graph_csr(self, row_ptr, pre_index, weights):
+        """CSR by local postsynaptic neuron: row_ptr[n_local+1], pre_index ascending inside each row"""
+        rp = np.ascontiguousarray(row_ptr, dtype=np.uint64)
+        pi = np.ascontiguousarray(pre_index, dtype=np.uint32)
+        w = np.ascontiguousarray(weights, dtype=np.float32)
+        if rp.size != (self.post_end - self.post_begin) + 1 or pi.size != w.size:
+            raise ValueError("row_ptr must have n_local + 1 entries and pre_index / weights equal lengths")
+        self._nnz = int(w.size)
+        _lib.check(self._L.snn_set_graph_csr(self._h, rp.ctypes.data_as(_lib.u64p), pi.ctypes.data_as(_lib.u32p),
+                                             w.ctypes.data_as(_lib.f32p), w.size))
+
+    def get_graph_csr(self):
+        w = np.empty(getattr(self, "_nnz", 0), np.float32)
+        _lib.check(self._L.snn_get_graph_csr(self._h, w.ctypes.data_as(_lib.f32p), w.size))
+        return w
 
     def fill_graph_synthetic(self, seed, lo, hi, with_diagonal=False):
         _lib.check(self._L.snn_fill_graph_synthetic(self._h, seed, lo, hi, int(with_diagonal)))

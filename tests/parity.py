@@ -71,8 +71,26 @@ def make_oracle(layout, **kw):
     return net
 
 
-def device_from_oracle(snn, net, shard=None, device=0):
-    """Create a DeviceNetwork holding exactly the oracle net's state."""
+def csr_from_dense(net, q0, q1):
+    """CSR (by postsynaptic neuron q0..q1) of the oracle's dense masked matrix: ascending presynaptic index."""
+    conn = net["connections"][:, q0:q1]
+    pre, post = np.nonzero(conn.T)[::-1]                 # iterate posts (rows of conn.T) in order, pres ascending
+    counts = conn.sum(axis=0, dtype=np.uint64)
+    row_ptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64)
+    weights = net["weights"][:, q0:q1].T[conn.T != 0]
+    return row_ptr, pre.astype(np.uint32), weights.astype(np.float32)
+
+
+def dense_from_csr(net, q0, q1, csr_weights):
+    """Scatter CSR-ordered weights back into a dense [n_tot, q1-q0] block (absent edges 0)."""
+    conn = net["connections"][:, q0:q1]
+    out = np.zeros(conn.T.shape, np.float32)
+    out[conn.T != 0] = csr_weights
+    return out.T
+
+
+def device_from_oracle(snn, net, shard=None, device=0, csr=False):
+    """Create a DeviceNetwork holding exactly the oracle net's state (dense or CSR graph form)."""
     lay = net.layout
     dn = snn.DeviceNetwork(model=net.model, nt_kinetics=net.nt_kind, receptor_kinetics=net.rc_kind,
                            spike_train=net.st_kind, device=device)
@@ -81,12 +99,14 @@ def device_from_oracle(snn, net, shard=None, device=0):
     for i, r, c in lay.st_lattices:
         dn.add_spike_train_lattice(i, r, c)
     if shard is None:
-        dn.finalize()
+        dn.finalize(csr=csr)
     else:
-        dn.finalize(*shard)
+        dn.finalize(*shard, csr=csr)
     push_state(dn, net)
     nn = net.n_neurons
-    if net.n_tot and nn:
+    if csr:
+        dn.set_graph_csr(*csr_from_dense(net, dn.post_begin, dn.post_end))
+    elif net.n_tot and nn:
         dn.set_graph_rows(0, net["weights"], net["connections"].astype(np.uint32))
     dn.set_synapses(net.electrical, net.chemical)
     for slot, (i, r, c) in enumerate(lay.lattices):
@@ -184,8 +204,14 @@ def assert_state_equal(net, dev_state, skip=()):
 def assert_graph_equal(net, dn):
     if net.n_tot == 0 or net.n_neurons == 0:
         return
-    w, c = dn.get_graph_rows(0, net.n_tot)
     oc = net["connections"].astype(np.uint32)
+    if getattr(dn, "csr", False):
+        b, e = dn.post_begin, dn.post_end
+        w = dense_from_csr(net, b, e, dn.get_graph_csr())
+        ow = np.where(oc[:, b:e] != 0, net["weights"][:, b:e], np.float32(0))
+        assert np.array_equal(bits(ow), bits(w)), "CSR weights differ"
+        return
+    w, c = dn.get_graph_rows(0, net.n_tot)
     assert np.array_equal(c, oc), "connection masks differ"
     ow = np.where(oc != 0, net["weights"], np.float32(0))
     if not np.array_equal(bits(ow), bits(w)):

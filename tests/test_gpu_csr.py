@@ -1,0 +1,166 @@
+"""The sparse (CSR-by-post) graph form: same results as the oracle's dense masked matrix, bit for bit --
+inputs (electrical + chemical), STDP through the row and the transpose index, spike-train presynaptic
+cells, sharded handles.  Includes BASELINE configs[4]'s structure (4 lattices with radius-2 neighbourhoods,
+one Poisson lattice per neuron lattice wired one-to-one, ring k -> k+1) at test size."""
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+import parity
+
+pytestmark = pytest.mark.gpu
+
+
+def random_sparse_net(chemical, density=0.03, seed=5):
+    lay = parity.Layout([(0, 12, 13), (4, 20, 20)], [(2, 6, 7)])
+    net = parity.make_oracle(lay, st_kind=ob.ST_POISSON, chemical=chemical)
+    nn, nc = net.n_neurons, net.n_cells
+    rng = np.random.default_rng(seed)
+    net["current_voltage"] = ob.uniform_array(seed, nn, -65.0, 30.0)
+    net["gap_conductance"] = 10.0
+    net["nt_flags"][:, 0] = 1
+    net["nt_flags"][::3, 2] = 1
+    net["rc_flags"][:, 0] = 1
+    net["rc_flags"][::2, 2] = 1
+    net["rc_g"][:, 0] = 3.0
+    net["st_nt_flags"][:, 0] = 1
+    net["st_chance_of_firing"] = 0.05
+    net["st_seed"] = np.arange(7, 7 + nc, dtype=np.uint32)
+    net.fill_graph(seed + 1, 0.5, 2.5, with_diagonal=True)
+    net["connections"][...] = rng.random(net["connections"].shape) < density
+    net["connections"][:, 5] = 0                     # a neuron without any input
+    net["connections"][7, :] = 0                     # a neuron without any output
+    net["weights"][...] *= net["connections"]
+    net["do_plasticity"] = 1
+    return net
+
+
+def check(dn, net):
+    rng = net.layout.ranges()
+    for i, _, _ in net.layout.lattices:
+        first, count, _ = rng[i]
+        assert np.array_equal(dn.spike_history(i), net.spike_history[:, first:first + count])
+        assert np.array_equal(parity.bits(dn.voltage_history(i)), parity.bits(net.voltage_history[:, first:first + count]))
+    parity.assert_state_equal(net, parity.pull_state(dn, net))
+    parity.assert_graph_equal(net, dn)
+
+
+@pytest.mark.parametrize("chemical", [False, True])
+def test_csr_handle_equals_oracle(snn, chemical):
+    net = random_sparse_net(chemical)
+    dn = parity.device_from_oracle(snn, net, csr=True)
+    dn.set_history(voltage=True, spikes=True)
+    dn.run(400)
+    dn.run(200)
+    net.run(600, voltage_history=True, spike_history=True)
+    assert net.spike_history.sum() > 20
+    check(dn, net)
+    assert dn.input_kernel_bytes() == 8 * int(net["connections"].sum())
+    dn.close()
+
+
+def test_csr_and_dense_handles_agree(snn):
+    net = random_sparse_net(True, density=0.2, seed=9)
+    a = parity.device_from_oracle(snn, net, csr=True)
+    b = parity.device_from_oracle(snn, net, csr=False)
+    for h in (a, b):
+        h.set_history(voltage=True, spikes=False)
+        h.run(300)
+    for i, _, _ in net.layout.lattices:
+        assert np.array_equal(parity.bits(a.voltage_history(i)), parity.bits(b.voltage_history(i)))
+    wa = parity.dense_from_csr(net, 0, net.n_neurons, a.get_graph_csr())
+    wb, _ = b.get_graph_rows(0, net.n_tot)
+    assert np.array_equal(parity.bits(wa), parity.bits(wb))
+    a.close()
+    b.close()
+
+
+def c5_structure(side, seed=11):
+    """4 neuron lattices (ids 0-3) side x side, internal radius-<=2 neighbourhood (<= 12 in-edges, w = 1),
+    Poisson lattices ids 4-7 wired one-to-one (w = 1), lattice k -> k+1 (mod 4) one-to-one (w = 1)."""
+    lay = parity.Layout([(k, side, side) for k in range(4)], [(4 + k, side, side) for k in range(4)])
+    net = parity.make_oracle(lay, st_kind=ob.ST_POISSON)
+    m = side * side
+    nn = 4 * m
+    net["current_voltage"] = ob.uniform_array(seed, nn, -65.0, 30.0)
+    net["gap_conductance"] = 10.0
+    net["st_chance_of_firing"] = 0.01
+    net["st_seed"] = np.arange(1, 4 * m + 1, dtype=np.uint32)         # seeds = cell index + 1
+    conn, w = net["connections"], net["weights"]
+    offs = [(dr, dc) for dr in range(-2, 3) for dc in range(-2, 3) if 0 < dr * dr + dc * dc <= 4]
+    assert len(offs) == 12
+    for k in range(4):
+        base = k * m
+        for r in range(side):
+            for c in range(side):
+                q = base + r * side + c
+                for dr, dc in offs:
+                    rr, cc = r + dr, c + dc
+                    if 0 <= rr < side and 0 <= cc < side:
+                        conn[base + rr * side + cc, q] = 1
+                conn[nn + k * m + r * side + c, q] = 1                 # its Poisson cell
+                conn[((k - 1) % 4) * m + r * side + c, q] = 1          # lattice k-1 -> k
+    w[...] = conn
+    return net
+
+
+def test_c5_structure_csr(snn):
+    net = c5_structure(12)
+    assert net["connections"].sum(axis=0).max() == 14
+    dn = parity.device_from_oracle(snn, net, csr=True)
+    dn.set_history(voltage=True, spikes=True)
+    dn.run(500)
+    net.run(500, voltage_history=True, spike_history=True)
+    assert net.spike_history.sum() > 50
+    check(dn, net)
+    dn.close()
+
+
+@pytest.mark.parametrize("n_shards", [2, 4])
+def test_c5_structure_csr_sharded(snn, n_shards):
+    """configs[4]'s multi-GPU shape on one device: shard handles + emulated all-gather of the exchanged planes."""
+    import torch
+    from snn_amd import parallel
+    net = c5_structure(8)
+    net["do_plasticity"] = 1
+    handles = [parity.device_from_oracle(snn, net, shard=(r, n_shards), csr=True) for r in range(n_shards)]
+    bufs = [parallel.exchange_tensor(h, torch.device("cuda", 0)) for h in handles]
+    block = bufs[0].numel() // n_shards
+    for _ in range(300):
+        for h in handles:
+            h.step_begin()
+        for r in range(n_shards):
+            for o in range(n_shards):
+                if o != r:
+                    bufs[o][r * block:(r + 1) * block].copy_(bufs[r][r * block:(r + 1) * block])
+        torch.cuda.synchronize()
+        for h in handles:
+            h.step_end()
+    net.run(300, spike_history=True)
+    assert net.spike_history.sum() > 20
+    for h in handles:
+        st = parity.pull_state(h, net)
+        for name in ("current_voltage", "is_spiking", "last_firing_time", "st_last_firing_time", "st_seed"):
+            assert np.array_equal(parity.bits(st[name]), parity.bits(net[name])), name
+        b, e = h.post_begin, h.post_end
+        assert np.array_equal(parity.bits(st["w_value"][b:e]), parity.bits(net["w_value"][b:e]))
+        parity.assert_graph_equal(net, h)
+        h.close()
+
+
+def test_csr_validation(snn):
+    dn = snn.DeviceNetwork()
+    dn.add_lattice(0, 2, 2)
+    dn.finalize(csr=True)
+    with pytest.raises(snn.SnnError) as e:           # unsorted presynaptic indices
+        dn.set_graph_csr([0, 2, 2, 2, 2], [3, 1], [1.0, 1.0])
+    assert e.value.code == 11
+    with pytest.raises(snn.SnnError) as e:           # index out of range
+        dn.set_graph_csr([0, 1, 1, 1, 1], [9], [1.0])
+    assert e.value.code == 10
+    with pytest.raises(snn.SnnError) as e:           # dense API on a CSR handle
+        dn.fill_graph_synthetic(1, 0.0, 1.0)
+    assert e.value.code == 12
+    dn.run(5)                                        # no graph set: no edges, still steps
+    assert dn.clock == 5
+    dn.close()
