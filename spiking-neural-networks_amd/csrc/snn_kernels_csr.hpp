@@ -30,25 +30,112 @@ struct CsrInputsArgs {
     InputsArgs in;      // presynaptic state pointers / sizes; W, ld unused except ld = partial row stride
 };
 
-// one thread per local postsynaptic neuron; rows are short (tens of edges) in the targeted regime
+// Workgroup = 256 consecutive rows, whose edges are one contiguous segment of the CSR arrays.
+// Phase 1 (edge-parallel): the segment is read with coalesced, independent loads (index, weight) plus ONE
+// gather per edge of the presynaptic value (a neuron's voltage or a spike-train cell's gap-junction value,
+// selected by pointer, not by branch); value, weight and a meta word (chunk id, source kind, transmitter
+// flags) go to LDS.  Phase 2 (row-parallel): each thread, holding its own voltage and conductance in
+// registers, forms `term * weight` for its row's edges from LDS in ascending order with the canonical chunk
+// flush.  The arithmetic per edge and the order of the adds are exactly those of the dense kernel; only the
+// memory access pattern differs.  Segments that do not fit the LDS tile (very long rows) are read straight
+// from global memory by the row's thread.
 template <bool ELEC, bool CHEM>
 __global__ __launch_bounds__(256) void k_inputs_csr(const CsrInputsArgs a)
 {
-    const uint32_t q = blockIdx.x * 256 + threadIdx.x;
-    if (q >= a.g.n_loc) return;
+    constexpr uint32_t CAP = CHEM ? 2048 : 4096;            // edges per workgroup tile: 48 KiB of LDS
+    constexpr uint32_t EDGE_BATCH = CAP / 256;              // independent edges per thread: a full tile in one round trip
+    constexpr uint32_t META_CELL = 1u << 28, META_SILENT = 1u << 29;
+    __shared__ float s_v[CAP];                              // presynaptic value
+    __shared__ float s_w[CAP];
+    __shared__ uint32_t s_meta[CAP];                        // chunk id | type flags << 24 | kind bits
+    __shared__ float s_t[CHEM ? K_TYPES : 1][CHEM ? CAP : 1];
+
     const InputsArgs &in = a.in;
+    const uint32_t q_first = blockIdx.x * 256;
+    const uint32_t q_last = min(a.g.n_loc, q_first + 256);
+    const uint32_t q = q_first + threadIdx.x;
+    const uint32_t e_base = a.g.ptr[q_first], e_end = a.g.ptr[q_last];
+    const uint32_t len = e_end - e_base;
+    const bool tiled = len <= CAP;                          // workgroup-uniform
+
+    // Branch-free on purpose: every load is unconditional (the inapplicable source's index is clamped to
+    // 0), so the EDGE_BATCH edges a thread handles per round trip have all their loads in flight together.
+    auto fetch = [&](uint32_t e, float &v, float &w, float (&t)[K_TYPES], uint32_t &meta) {
+        const uint32_t p = a.g.pre[e];
+        w = a.g.w[e];
+        const bool is_cell = p >= in.n_neurons;
+        const uint32_t pn = is_cell ? 0u : p;                    // neuron index (clamped)
+        const uint32_t s = is_cell ? p - in.n_neurons : 0u;      // spike-train cell index (clamped)
+        meta = (p / CHUNK) | (is_cell ? META_CELL : 0u);
+        v = 0.0f;
+        if (ELEC) {
+            const float *src = is_cell ? in.st_value + s : in.xbuf + in.xl.at(pn, PLANE_V);
+            v = *src;
+            const int32_t slft = in.st_last_firing_time[s];
+            meta |= (is_cell && slft < 0) ? META_SILENT : 0u;
+        }
+        if (CHEM) {
+#pragma unroll
+            for (int k = 0; k < K_TYPES; ++k) {
+                const uint32_t *fsrc = is_cell ? in.st_nt_flags + (size_t)k * in.c_pad + s
+                                               : in.nt_flags + (size_t)k * in.n_pad + pn;
+                const float *tsrc = is_cell ? in.st_nt_t + (size_t)k * in.c_pad + s
+                                            : in.xbuf + in.xl.at(pn, PLANE_T0 + k);
+                const bool f = *fsrc != 0;
+                meta |= f ? (0x1000000u << k) : 0u;
+                t[k] = *tsrc;
+            }
+        }
+    };
+
+    if (tiled) {
+        for (uint32_t i0 = threadIdx.x; i0 < len; i0 += 256 * EDGE_BATCH) {
+            float v[EDGE_BATCH], w[EDGE_BATCH], t[EDGE_BATCH][K_TYPES];
+            uint32_t meta[EDGE_BATCH];
+#pragma unroll
+            for (uint32_t u = 0; u < EDGE_BATCH; ++u)              // clamped: out-of-range results are dropped
+                fetch(e_base + min(i0 + u * 256, len - 1), v[u], w[u], t[u], meta[u]);
+#pragma unroll
+            for (uint32_t u = 0; u < EDGE_BATCH; ++u) {
+                const uint32_t i = i0 + u * 256;
+                if (i < len) {
+                    s_v[i] = v[u];
+                    s_w[i] = w[u];
+                    s_meta[i] = meta[u];
+                    if (CHEM) {
+#pragma unroll
+                        for (int k = 0; k < K_TYPES; ++k) s_t[k][i] = t[u][k];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (q >= a.g.n_loc) return;
+
     const uint32_t e0 = a.g.ptr[q], e1 = a.g.ptr[q + 1];
     const float vq = ELEC ? in.xbuf[in.xl.at(in.q0 + q, PLANE_V)] : 0.0f;
     const float gq = ELEC ? in.gap_conductance[in.q0 + q] : 0.0f;
-
     float sum = 0.0f, part = 0.0f;
     float tsum[K_TYPES] = {0.0f, 0.0f, 0.0f}, tpart[K_TYPES] = {0.0f, 0.0f, 0.0f};
     uint32_t cur_chunk = 0xFFFFFFFFu;
     for (uint32_t e = e0; e < e1; ++e) {
-        const uint32_t p = a.g.pre[e];
-        const float w = a.g.w[e];
-        const uint32_t c = p / CHUNK;
-        if (c != cur_chunk) {            // flush the finished chunk's partial (canonical two-level order)
+        float v, w, t[K_TYPES];
+        uint32_t meta;
+        if (tiled) {
+            const uint32_t i = e - e_base;
+            v = s_v[i];
+            w = s_w[i];
+            meta = s_meta[i];
+            if (CHEM) {
+#pragma unroll
+                for (int k = 0; k < K_TYPES; ++k) t[k] = s_t[k][i];
+            }
+        } else {
+            fetch(e, v, w, t, meta);
+        }
+        const uint32_t chunk = meta & 0xFFFFFFu;
+        if (chunk != cur_chunk) {        // flush the finished chunk's partial (canonical two-level order)
             if (cur_chunk != 0xFFFFFFFFu) {
                 sum += part;
 #pragma unroll
@@ -57,26 +144,18 @@ __global__ __launch_bounds__(256) void k_inputs_csr(const CsrInputsArgs a)
             part = 0.0f;
 #pragma unroll
             for (int k = 0; k < K_TYPES; ++k) tpart[k] = 0.0f;
-            cur_chunk = c;
+            cur_chunk = chunk;
         }
-        if (p < in.n_neurons) {
-            if (ELEC) part += (gq * (in.xbuf[in.xl.at(p, PLANE_V)] - vq)) * w;
-            if (CHEM) {
+        if (ELEC) {
+            // gap_junction neuron/mod.rs:54-60; spike_train_gap_junction :119-137 (never fired: v_resting
+            // without the conductance factor)
+            const float term = (meta & META_CELL) ? ((meta & META_SILENT) ? v : gq * v) : gq * (v - vq);
+            part += term * w;
+        }
+        if (CHEM) {
 #pragma unroll
-                for (int k = 0; k < K_TYPES; ++k)
-                    if (in.nt_flags[(size_t)k * in.n_pad + p]) tpart[k] += in.xbuf[in.xl.at(p, PLANE_T0 + k)] * w;
-            }
-        } else {
-            const uint32_t s = p - in.n_neurons;
-            if (ELEC) {
-                const float v = in.st_value[s];
-                part += ((in.st_last_firing_time[s] < 0) ? v : gq * v) * w;   // neuron/mod.rs:126-136
-            }
-            if (CHEM) {
-#pragma unroll
-                for (int k = 0; k < K_TYPES; ++k)
-                    if (in.st_nt_flags[(size_t)k * in.c_pad + s]) tpart[k] += in.st_nt_t[(size_t)k * in.c_pad + s] * w;
-            }
+            for (int k = 0; k < K_TYPES; ++k)
+                if (meta & (0x1000000u << k)) tpart[k] += t[k] * w;
         }
     }
     if (cur_chunk != 0xFFFFFFFFu) {

@@ -32,6 +32,7 @@ struct XLayout {
     uint32_t n_shards;
     __host__ __device__ __forceinline__ size_t at(uint32_t neuron, int plane) const
     {
+        if (n_shards == 1) return (size_t)plane * stride + neuron;     // whole population: no division
         const uint32_t shard = neuron / stride;
         const uint32_t i = neuron - shard * stride;
         return ((size_t)shard * NUM_PLANES + plane) * stride + i;

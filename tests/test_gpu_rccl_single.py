@@ -1,0 +1,61 @@
+"""The RCCL leg of the multi-GPU path with the pieces that CAN run on one GPU: torch wraps the library's
+exchange buffer without a copy (one HIP runtime in the process), `all_gather_into_tensor` accepts it in
+place with backend nccl (= RCCL) at world_size 1, and a ShardedStepper-driven run equals snn_run."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+import parity
+
+pytestmark = pytest.mark.gpu
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_sharded_stepper_over_rccl_world_size_1(snn):
+    import torch
+    import torch.distributed as dist
+    from snn_amd import parallel
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(free_port())
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        lay = parity.Layout([(0, 10, 10)])
+        net = parity.make_oracle(lay)
+        net["gap_conductance"] = 10.0
+        net["current_voltage"] = ob.uniform_array(1, 100, -65.0, 30.0)
+        net.fill_graph(2, 0.5, 1.5)
+        net["do_plasticity"] = 1
+        dn = parity.device_from_oracle(snn, net, shard=(0, 1))
+        buf = parallel.exchange_tensor(dn, torch.device("cuda", 0))
+        ptr, words, n_padded = dn.exchange_buffer()
+        assert buf.data_ptr() == ptr and buf.numel() == words * n_padded        # a view, not a copy
+        # the collective itself, in place, on memory owned by libsnn_amd.so
+        dist.all_gather_into_tensor(buf, buf[0:buf.numel()])
+        torch.cuda.synchronize()
+        v = dn.get_attr(0, "current_voltage")
+        assert np.array_equal(v.view(np.uint32), net["current_voltage"].view(np.uint32))
+        stepper = parallel.ShardedStepper(dn, buf, 0, 1, sync=torch.cuda.synchronize)
+        stepper.world = 2            # force the exchange branch: with one rank the gather is the identity
+        stepper.block = buf.numel()
+        stepper.local = buf[0:buf.numel()]
+        stepper.world = 1
+        for _ in range(200):
+            dn.step_begin()
+            dist.all_gather_into_tensor(buf, buf[0:buf.numel()])
+            torch.cuda.synchronize()
+            dn.step_end()
+        net.run(200)
+        parity.assert_state_equal(net, parity.pull_state(dn, net))
+        parity.assert_graph_equal(net, dn)
+        dn.close()
+    finally:
+        dist.destroy_process_group()
