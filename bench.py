@@ -65,7 +65,8 @@ def cpu_baseline(n, sample_cols, steps, threads):
 def build_config(args, snn_amd, synthetic, np, rank, world, local_rank):
     """BASELINE.json configs as synthetic inputs.  Returns (handle, neurons, text, kernel)."""
     cfg = args.config
-    fin = (lambda d: d.finalize(rank, world)) if world > 1 else (lambda d: d.finalize())
+    sharded = world > 1 or args.force_sharded
+    fin = (lambda d: d.finalize(rank, world)) if sharded else (lambda d: d.finalize())
     if cfg in ("c1", "c2"):
         rows, cols = (32, 32) if cfg == "c1" else (args.rows, args.cols)
         n = rows * cols
@@ -120,7 +121,7 @@ def build_config(args, snn_amd, synthetic, np, rank, world, local_rank):
         for k in range(4):
             dn.add_lattice(k, side, side)
             dn.add_spike_train_lattice(4 + k, side, side)
-        if world > 1:
+        if sharded:
             dn.finalize(rank, world, csr=True)
         else:
             dn.finalize(csr=True)
@@ -145,6 +146,8 @@ def main():
     ap.add_argument("--rows", type=int, default=ROWS)
     ap.add_argument("--cols", type=int, default=COLS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="take the multi-GPU code path (shard handle, RCCL all-gather per step) even at world size 1")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not bracket k_inputs_dense with HIP events (roofline.achieved is then null)")
     args = ap.parse_args()
@@ -162,17 +165,25 @@ def main():
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    sharded = world > 1 or args.force_sharded
+    if sharded:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     dn, n, workload, kernel_name = build_config(args, snn_amd, synthetic, np, rank, world, local_rank)
 
-    if world > 1:
+    if sharded:
+        # everything stream-ordered on torch's current stream: kernels, the RCCL all-gather, kernels ... no host
+        # synchronisation inside the step loop
+        dn.set_stream(torch.cuda.current_stream().cuda_stream)
         buf = parallel.exchange_tensor(dn, torch.device("cuda", local_rank))
-        stepper = parallel.ShardedStepper(dn, buf, rank, world, sync=torch.cuda.synchronize)
-        run = stepper.run
+        stepper = parallel.ShardedStepper(dn, buf, rank, world, always_gather=True)
+
+        def run(k):
+            stepper.run(k)
+            dn.synchronize()
     else:
         run = dn.run
 
@@ -224,11 +235,19 @@ def main():
                                    "sample": f"oracle (C restatement, OpenMP x{threads}) on {sample} of {n} postsynaptic "
                                              f"neurons x {cpu_steps} steps ({secs:.1f} s); each sampled neuron sums all "
                                              f"{n} presynaptic terms, i.e. the full per-neuron-step cost"}
-        print(json.dumps(out), flush=True)
+        result = json.dumps(out)
+    else:
+        result = None
 
     dn.close()
     if dist is not None:
         dist.destroy_process_group()
+    if result is not None:
+        # RCCL writes its version banner through C stdio, which a pipe buffers until exit: flush it first so
+        # that the JSON line is the LAST line on stdout
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        print(result, flush=True)
 
 
 if __name__ == "__main__":

@@ -179,6 +179,12 @@ int snn_exchange_buffer(snn_network_t *net, void **device_ptr, uint32_t *words_p
                         uint32_t *n_padded);
 /* HIP stream the handle launches on (hipStream_t), for ordering collectives against it */
 int snn_stream(snn_network_t *net, void **hip_stream);
+/* Adopt the caller's stream (e.g. the one its RCCL collectives are ordered against); NULL returns to the
+ * handle's own stream.  With an adopted stream snn_step_begin / snn_step_end only ENQUEUE (no host
+ * synchronisation): the caller orders its collective on the same stream and calls snn_synchronize (or any
+ * blocking getter) when it needs results.  Without one they block until the step's kernels have finished. */
+int snn_set_stream(snn_network_t *net, void *hip_stream);
+int snn_synchronize(snn_network_t *net);
 
 /* ---- histories (≙ LatticeHistoryGPU::add_from_gpu, gpu_lattices/mod.rs:215-280) -------- */
 

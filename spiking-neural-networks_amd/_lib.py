@@ -86,6 +86,8 @@ SIGNATURES = {
     "snn_step_end": (C.c_int, [H]),
     "snn_exchange_buffer": (C.c_int, [H, C.POINTER(C.c_void_p), u32p, u32p]),
     "snn_stream": (C.c_int, [H, C.POINTER(C.c_void_p)]),
+    "snn_set_stream": (C.c_int, [H, C.c_void_p]),
+    "snn_synchronize": (C.c_int, [H]),
     "snn_history_steps": (C.c_int, [H, u64p]),
     "snn_get_voltage_history": (C.c_int, [H, C.c_uint32, f32p, C.c_size_t]),
     "snn_get_spike_history": (C.c_int, [H, C.c_uint32, u8p, C.c_size_t]),

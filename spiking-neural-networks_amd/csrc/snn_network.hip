@@ -64,7 +64,9 @@ struct LatticeInfo {
 
 struct snn_network {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;          // the stream every launch goes to
+    hipStream_t own_stream = nullptr;      // created with the handle
+    bool external_stream = false;          // snn_set_stream adopted a caller's stream
     int model = 0, nt_kind = 0, rc_kind = 0, st_kind = 0;
     bool finalized = false;
     int electrical = 1, chemical = 0;
@@ -680,6 +682,7 @@ int begin_run(snn_network *net, uint64_t iterations)
     TRY(ensure_counts(net));
     TRY(grow_history(net, iterations));
     if (net->nc) {
+        // pageable source: the copy is staged before the call returns, so the host vector may change afterwards
         HIP_TRY(hipMemcpyAsync(net->st_clock_dev, net->st_clock.data(), net->st_clock.size() * sizeof(long long),
                                hipMemcpyHostToDevice, net->stream), SNN_ERR_BUFFER_WRITE);
         TRY(launch_spike_trains(net, 0, 0, net->clock));
@@ -791,10 +794,11 @@ int snn_network_create(int device, int neuron_model, int nt_kinetics, int recept
     net->device = device;
     net->model = neuron_model; net->nt_kind = nt_kinetics; net->rc_kind = receptor_kinetics;
     net->st_kind = spike_train_model;
-    if (hipStreamCreateWithFlags(&net->stream, hipStreamNonBlocking) != hipSuccess) {
+    if (hipStreamCreateWithFlags(&net->own_stream, hipStreamNonBlocking) != hipSuccess) {
         delete net;
         return fail(SNN_ERR_QUEUE, "hipStreamCreate failed");
     }
+    net->stream = net->own_stream;
     *out = net;
     return SNN_OK;
 }
@@ -812,7 +816,7 @@ int snn_network_destroy(snn_network_t *net)
     if (net->st_vhist) (void)hipFree(net->st_vhist);
     if (net->raster) (void)hipFree(net->raster);
     for (auto &e : net->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
-    if (net->stream) (void)hipStreamDestroy(net->stream);
+    if (net->own_stream) (void)hipStreamDestroy(net->own_stream);
     delete net;
     return SNN_OK;
 }
@@ -1139,7 +1143,7 @@ int snn_step_begin(snn_network_t *net)
     if (net->run_step_offset == 0) TRY(begin_run(net, 1));
     else TRY(grow_history(net, 1));
     if (net->nn) TRY(step_begin(net));
-    HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
+    if (!net->external_stream) HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
     return SNN_OK;
 }
 
@@ -1149,7 +1153,7 @@ int snn_step_end(snn_network_t *net)
     if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
     HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
     TRY(step_end(net));
-    HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
+    if (!net->external_stream) HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
     // keep the spike-train lattice clocks current after every externally driven step
     for (auto &c : net->st_clock) c += net->run_step_offset;
     net->run_step_offset = 0;
@@ -1163,6 +1167,29 @@ int snn_exchange_buffer(snn_network_t *net, void **device_ptr, uint32_t *words_p
     if (device_ptr) *device_ptr = net->xbuf;
     if (words_per_neuron) *words_per_neuron = NUM_PLANES;
     if (n_padded) *n_padded = net->xl.stride * net->xl.n_shards;
+    return SNN_OK;
+}
+
+int snn_set_stream(snn_network_t *net, void *hip_stream)
+{
+    if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
+    HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
+    HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
+    if (hip_stream) {
+        net->stream = static_cast<hipStream_t>(hip_stream);
+        net->external_stream = true;
+    } else {
+        net->stream = net->own_stream;
+        net->external_stream = false;
+    }
+    return SNN_OK;
+}
+
+int snn_synchronize(snn_network_t *net)
+{
+    if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
+    HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
+    HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
     return SNN_OK;
 }
 

@@ -191,6 +191,13 @@ class DeviceNetwork:
         _lib.check(self._L.snn_exchange_buffer(self._h, C.byref(p), C.byref(w), C.byref(n)))
         return p.value, w.value, n.value
 
+    def set_stream(self, hip_stream):
+        """adopt a caller's hipStream_t (int / None): step_begin / step_end then only enqueue"""
+        _lib.check(self._L.snn_set_stream(self._h, C.c_void_p(hip_stream) if hip_stream else None))
+
+    def synchronize(self):
+        _lib.check(self._L.snn_synchronize(self._h))
+
     def stream(self):
         p = C.c_void_p()
         _lib.check(self._L.snn_stream(self._h, C.byref(p)))

@@ -49,7 +49,7 @@ class ShardedStepper:
     exchange buffer laid out [shard][plane][stride] so that shard r's block is contiguous.
     """
 
-    def __init__(self, backend, buf, rank, world_size, group=None, sync=None):
+    def __init__(self, backend, buf, rank, world_size, group=None, sync=None, always_gather=False):
         import torch.distributed as dist
         self.backend, self.buf, self.rank, self.world = backend, buf, rank, world_size
         self.group = group
@@ -58,9 +58,10 @@ class ShardedStepper:
         self.block = buf.numel() // world_size
         self.local = buf[rank * self.block:(rank + 1) * self.block]
         self._sync = sync or (lambda: None)
+        self._always = always_gather        # run the collective even at world_size 1 (path check on one GPU)
 
     def exchange(self):
-        if self.world == 1:
+        if self.world == 1 and not self._always:
             return
         if self.buf.is_cuda:
             self.dist.all_gather_into_tensor(self.buf, self.local, group=self.group)

@@ -43,16 +43,13 @@ def test_sharded_stepper_over_rccl_world_size_1(snn):
         torch.cuda.synchronize()
         v = dn.get_attr(0, "current_voltage")
         assert np.array_equal(v.view(np.uint32), net["current_voltage"].view(np.uint32))
-        stepper = parallel.ShardedStepper(dn, buf, 0, 1, sync=torch.cuda.synchronize)
-        stepper.world = 2            # force the exchange branch: with one rank the gather is the identity
-        stepper.block = buf.numel()
-        stepper.local = buf[0:buf.numel()]
-        stepper.world = 1
+        # stream-ordered, as bench.py --gpus N does it: no host synchronisation inside the loop
+        dn.set_stream(torch.cuda.current_stream().cuda_stream)
         for _ in range(200):
             dn.step_begin()
             dist.all_gather_into_tensor(buf, buf[0:buf.numel()])
-            torch.cuda.synchronize()
             dn.step_end()
+        dn.synchronize()
         net.run(200)
         parity.assert_state_equal(net, parity.pull_state(dn, net))
         parity.assert_graph_equal(net, dn)

@@ -85,3 +85,38 @@ def test_sharded_handles_equal_oracle(snn, n_shards, chemical):
             assert np.array_equal(sh, net.spike_history[:, lo:hi])
     for h in handles:
         h.close()
+
+
+def test_stream_ordered_stepping_without_host_sync(snn):
+    """snn_set_stream: the shard handles adopt torch's current stream, so kernels and the (emulated) exchange
+    are ordered on the device and the step loop never synchronises the host -- the shape bench.py --gpus N uses."""
+    import torch
+    from snn_amd import parallel
+    net = build(False)
+    n_shards, steps = 2, 250
+    handles = [parity.device_from_oracle(snn, net, shard=(r, n_shards)) for r in range(n_shards)]
+    stream = torch.cuda.current_stream().cuda_stream
+    for h in handles:
+        h.set_stream(stream)
+    bufs = [parallel.exchange_tensor(h, torch.device("cuda", 0)) for h in handles]
+    block = bufs[0].numel() // n_shards
+    for _ in range(steps):
+        for h in handles:
+            h.step_begin()
+        for r in range(n_shards):
+            bufs[1 - r][r * block:(r + 1) * block].copy_(bufs[r][r * block:(r + 1) * block], non_blocking=True)
+        for h in handles:
+            h.step_end()
+    for h in handles:
+        h.synchronize()
+    net.run(steps)
+    for h in handles:
+        st = parity.pull_state(h, net)
+        for name in ("current_voltage", "is_spiking", "last_firing_time", "st_last_firing_time"):
+            assert np.array_equal(parity.bits(st[name]), parity.bits(net[name])), name
+        b, e = h.post_begin, h.post_end
+        w, c = h.get_graph_rows(0, net.n_tot)
+        ow = np.where(net["connections"] != 0, net["weights"], np.float32(0))
+        assert np.array_equal(parity.bits(w[:, b:e]), parity.bits(ow[:, b:e]))
+        h.set_stream(None)
+        h.close()
