@@ -172,6 +172,11 @@ int snn_run(snn_network_t *net, uint64_t iterations);
  * spike trains, clock). */
 int snn_step_begin(snn_network_t *net);
 int snn_step_end(snn_network_t *net);
+/* Optional overlap: enqueue, BEFORE the all-gather of the previous step has been waited for, the part of
+ * this step's synaptic-input pass that only needs the shard's own neurons as presynaptic rows; the
+ * following snn_step_begin then processes the remaining rows.  A no-op when plasticity is on (STDP
+ * rewrites W in snn_step_end) or the graph is CSR.  Results do not depend on whether it is called. */
+int snn_step_begin_local(snn_network_t *net);
 /* Device pointer / layout of the exchange buffer: `words_per_neuron` 32-bit words per neuron,
  * neuron-major planes: plane j occupies [j*n_padded, (j+1)*n_padded); the local slice of each
  * plane is [post_begin, post_end).  n_padded = shard_stride * n_shards. */

@@ -84,6 +84,7 @@ SIGNATURES = {
     "snn_run": (C.c_int, [H, C.c_uint64]),
     "snn_step_begin": (C.c_int, [H]),
     "snn_step_end": (C.c_int, [H]),
+    "snn_step_begin_local": (C.c_int, [H]),
     "snn_exchange_buffer": (C.c_int, [H, C.POINTER(C.c_void_p), u32p, u32p]),
     "snn_stream": (C.c_int, [H, C.POINTER(C.c_void_p)]),
     "snn_set_stream": (C.c_int, [H, C.c_void_p]),

@@ -52,6 +52,9 @@ struct InputsArgs {
     float *part_i;          // [n_chunks][ld]
     float *part_t;          // [3][n_chunks][ld]
     uint32_t n_chunks;
+    // chunk subset of this launch: chunk = chunk_first + blockIdx.y, skipping [hole_begin, hole_begin+hole_count)
+    // (multi-GPU: the chunks of LOCAL presynaptic rows run while the all-gather of the remote state is in flight)
+    uint32_t chunk_first, hole_begin, hole_count;
 };
 
 // kind word per staged presynaptic row: bits 0..1 = 0 neuron | 1 spike train that never fired |
@@ -104,7 +107,8 @@ __global__ __launch_bounds__(InputsShape<STREAM>::THREADS) void k_inputs_dense(c
     __shared__ uint32_t s_kind[CHUNK];
     __shared__ float s_t[CHEM ? K_TYPES : 1][CHUNK];
 
-    const uint32_t chunk = blockIdx.y;
+    uint32_t chunk = a.chunk_first + blockIdx.y;
+    if (chunk >= a.hole_begin) chunk += a.hole_count;
     const uint32_t p0 = chunk * CHUNK;
     const uint32_t rows = min((uint32_t)CHUNK, a.n_tot - p0);
     const uint32_t tid = threadIdx.x;

@@ -102,6 +102,9 @@ struct snn_network {
     uint32_t *spike_list = nullptr, *spike_count = nullptr;
     long long *st_clock_dev = nullptr;
     long long run_step_offset = 0;
+    bool run_active = false;        // a (possibly externally driven) run is open: device clocks are ahead of st_clock
+    bool view_dirty = true;         // spike-train gap-junction values must be refreshed before the next inputs
+    bool local_inputs_done = false; // this step's LOCAL chunk partials are already enqueued
 
     std::map<std::string, Attr> neuron_attrs, cell_attrs;
 
@@ -114,6 +117,7 @@ struct snn_network {
     // profiling of the synaptic-input kernel
     int profile = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    std::vector<int> ev_counts;     // 1: the launch closes a pass over the graph, 0: first half of a split pass
     size_t ev_used = 0;
     uint64_t prof_launches = 0;
     double prof_ms = 0.0;
@@ -392,6 +396,8 @@ int build_state(snn_network *net)
     return SNN_OK;
 }
 
+int end_run(snn_network *net);
+
 // ---- attribute transfer ------------------------------------------------------------------------
 
 // copy `count` 32-bit words between host and plane `plane` for global indices [first, first+count)
@@ -429,7 +435,9 @@ int attr_io(snn_network *net, uint32_t id, const char *name, AttrType type, void
         return fail(SNN_ERR_DIM_MISMATCH, std::string("attribute '") + name + "': expected " +
                                               std::to_string(expect) + " values, got " + std::to_string(count));
     if (l->count == 0) return SNN_OK;
-    HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
+    HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
+    TRY(end_run(net));
+    if (set && l->spike_train) net->view_dirty = true;
     const uint32_t first = l->spike_train ? l->first - net->nn : l->first;   // index inside its own arrays
 
     if (!typed) {
@@ -514,10 +522,27 @@ int launch_spike_trains(snn_network *net, int iterate, long long step_offset, lo
     return SNN_OK;
 }
 
-int launch_inputs(snn_network *net)
+enum InputsPart { INPUTS_ALL = 0, INPUTS_LOCAL = 1, INPUTS_REMOTE = 2 };
+
+// chunks whose presynaptic rows all belong to this shard's own neurons
+void local_chunks(const snn_network *net, uint32_t *begin, uint32_t *count)
+{
+    const uint32_t cb = (net->q0 + CHUNK - 1) / CHUNK, ce = net->q1 / CHUNK;
+    *begin = cb;
+    *count = ce > cb ? ce - cb : 0;
+}
+
+int launch_inputs(snn_network *net, InputsPart part = INPUTS_ALL)
 {
     if (net->n_loc == 0 || net->n_tot == 0) return SNN_OK;
+    uint32_t lc_begin = 0, lc_count = 0;
+    local_chunks(net, &lc_begin, &lc_count);
+    uint32_t grid_chunks = net->n_chunks;
     InputsArgs a{};
+    a.chunk_first = 0; a.hole_begin = net->n_chunks; a.hole_count = 0;
+    if (part == INPUTS_LOCAL) { a.chunk_first = lc_begin; grid_chunks = lc_count; }
+    if (part == INPUTS_REMOTE) { a.hole_begin = lc_begin; a.hole_count = lc_count; grid_chunks = net->n_chunks - lc_count; }
+    if (grid_chunks == 0) return SNN_OK;
     a.W = net->W; a.ld = net->ld; a.n_loc = net->n_loc; a.q0 = net->q0; a.n_neurons = net->nn; a.n_tot = net->n_tot;
     a.xbuf = net->xbuf; a.xl = net->xl; a.gap_conductance = net->na.gap_conductance;
     a.st_value = net->ca.presyn_value; a.st_last_firing_time = net->ca.last_firing_time;
@@ -534,6 +559,8 @@ int launch_inputs(snn_network *net)
         }
         e0 = net->ev_pool[net->ev_used].first;
         e1 = net->ev_pool[net->ev_used].second;
+        net->ev_counts.resize(net->ev_pool.size(), 1);
+        net->ev_counts[net->ev_used] = (part == INPUTS_LOCAL) ? 0 : 1;   // LOCAL + REMOTE = one pass over W
         ++net->ev_used;
         HIP_TRY(hipEventRecord(e0, net->stream), SNN_ERR_QUEUE);
     }
@@ -560,10 +587,10 @@ int launch_inputs(snn_network *net)
     do {                                                                                                 \
         constexpr int T1 = InputsShape<true>::TILE, T0 = InputsShape<false>::TILE;                       \
         if (stream)                                                                                      \
-            hipLaunchKernelGGL((k_inputs_dense<E, C, true>), dim3((net->ld + T1 - 1) / T1, net->n_chunks), \
+            hipLaunchKernelGGL((k_inputs_dense<E, C, true>), dim3((net->ld + T1 - 1) / T1, grid_chunks), \
                                dim3(InputsShape<true>::THREADS), 0, net->stream, a);                     \
         else                                                                                             \
-            hipLaunchKernelGGL((k_inputs_dense<E, C, false>), dim3((net->ld + T0 - 1) / T0, net->n_chunks), \
+            hipLaunchKernelGGL((k_inputs_dense<E, C, false>), dim3((net->ld + T0 - 1) / T0, grid_chunks), \
                                dim3(InputsShape<false>::THREADS), 0, net->stream, a);                    \
     } while (0)
     if (net->electrical && net->chemical) SNN_LAUNCH_INPUTS(true, true);
@@ -631,7 +658,8 @@ int launch_plasticity(snn_network *net)
 // first half of a step: inputs from S(t) and the local neurons' update
 int step_begin(snn_network *net)
 {
-    TRY(launch_inputs(net));
+    TRY(launch_inputs(net, net->local_inputs_done ? INPUTS_REMOTE : INPUTS_ALL));
+    net->local_inputs_done = false;
     TRY(launch_update(net));
     return SNN_OK;
 }
@@ -657,7 +685,7 @@ int grow_history(snn_network *net, uint64_t extra)
     if (!net->want_vhist && !net->want_raster) return SNN_OK;
     const uint64_t need = net->hist_steps + extra;
     if (need <= net->hist_cap && (!net->want_vhist || net->vhist) && (!net->want_raster || net->raster)) return SNN_OK;
-    const uint64_t cap = std::max<uint64_t>(need, net->hist_cap);
+    const uint64_t cap = std::max<uint64_t>(need, net->hist_cap + net->hist_cap / 2);   // geometric: O(T) copies overall
     auto regrow = [&](void **buf, size_t row_bytes, bool wanted) -> int {
         if (!wanted || row_bytes == 0) return SNN_OK;
         void *nb = nullptr;
@@ -677,25 +705,35 @@ int grow_history(snn_network *net, uint64_t extra)
     return SNN_OK;
 }
 
+// Opens a run (snn_run, or a sequence of externally driven steps): static counts, history capacity, the
+// spike-train lattices' clocks on the device and -- only when cell state or the clock changed behind the
+// stepper's back -- the spike-train gap-junction values for the current clock.
 int begin_run(snn_network *net, uint64_t iterations)
 {
     TRY(ensure_counts(net));
     TRY(grow_history(net, iterations));
+    if (net->run_active) return SNN_OK;
     if (net->nc) {
         // pageable source: the copy is staged before the call returns, so the host vector may change afterwards
         HIP_TRY(hipMemcpyAsync(net->st_clock_dev, net->st_clock.data(), net->st_clock.size() * sizeof(long long),
                                hipMemcpyHostToDevice, net->stream), SNN_ERR_BUFFER_WRITE);
-        TRY(launch_spike_trains(net, 0, 0, net->clock));
+        if (net->view_dirty) TRY(launch_spike_trains(net, 0, 0, net->clock));
     }
+    net->view_dirty = false;
     net->run_step_offset = 0;
+    net->run_active = true;
     return SNN_OK;
 }
 
+// Closes the open run: waits for the stream and folds the steps done into the host-side lattice clocks.
 int end_run(snn_network *net)
 {
     HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
-    for (auto &c : net->st_clock) c += net->run_step_offset;
-    net->run_step_offset = 0;
+    if (net->run_active) {
+        for (auto &c : net->st_clock) c += net->run_step_offset;
+        net->run_step_offset = 0;
+        net->run_active = false;
+    }
     return SNN_OK;
 }
 
@@ -706,7 +744,7 @@ int collect_profile(snn_network *net)
         float ms = 0.0f;
         HIP_TRY(hipEventElapsedTime(&ms, net->ev_pool[i].first, net->ev_pool[i].second), SNN_ERR_WAIT);
         net->prof_ms += ms;
-        net->prof_launches += 1;
+        net->prof_launches += (i < net->ev_counts.size()) ? net->ev_counts[i] : 1;
     }
     net->ev_used = 0;
     return SNN_OK;
@@ -721,6 +759,7 @@ int graph_rows_io(snn_network *net, uint32_t pre_begin, uint32_t pre_count, floa
     if (pre_count == 0 || net->nn == 0) return SNN_OK;
     if (!weights || !conns) return fail(SNN_ERR_BAD_ARG, "null graph pointer");
     HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
+    TRY(end_run(net));
     // staged through a bounded device buffer: <= 64 MiB of host rows per hop
     const uint32_t hop = (uint32_t)std::max<size_t>(1, std::min<size_t>(pre_count, (64u << 20) / (host_ld * 4)));
     float *dw = nullptr;
@@ -1016,7 +1055,7 @@ int snn_set_graph_csr(snn_network_t *net, const uint64_t *row_ptr, const uint32_
         for (uint64_t e = 0; e < nnz; ++e) t_edge[fill[pre_index[e]]++] = (uint32_t)e;
     }
     HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
-    HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
+    TRY(end_run(net));
     for (void **p : {(void **)&net->csr_ptr, (void **)&net->csr_pre, (void **)&net->csr_post, (void **)&net->csr_t_ptr,
                      (void **)&net->csr_t_edge, (void **)&net->csr_w}) {
         if (*p) (void)hipFree(*p);
@@ -1047,7 +1086,7 @@ int snn_get_graph_csr(snn_network_t *net, float *weights, uint64_t nnz)
     if (nnz == 0) return SNN_OK;
     if (!weights) return fail(SNN_ERR_BAD_ARG, "weights is null");
     HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
-    HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
+    TRY(end_run(net));
     HIP_TRY(hipMemcpy(weights, net->csr_w, nnz * 4, hipMemcpyDeviceToHost), SNN_ERR_BUFFER_READ);
     return SNN_OK;
 }
@@ -1073,7 +1112,7 @@ int snn_set_plasticity(snn_network_t *net, uint32_t id, float a_plus, float a_mi
     net->plast_host[l->slot] = do_plasticity ? 1u : 0u;
     net->any_plasticity = false;
     for (uint32_t p : net->plast_host) net->any_plasticity |= (p != 0);
-    HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
+    TRY(end_run(net));
     HIP_TRY(hipMemcpy(net->stdp_dev, net->stdp_host.data(), net->stdp_host.size() * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
     HIP_TRY(hipMemcpy(net->plast_dev, net->plast_host.data(), net->plast_host.size() * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
     return SNN_OK;
@@ -1110,7 +1149,9 @@ int snn_reset_timing(snn_network_t *net)
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
     if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
     HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
+    TRY(end_run(net));
     net->clock = 0;
+    net->view_dirty = true;
     for (auto &c : net->st_clock) c = 0;
     HIP_TRY(hipMemsetAsync(net->na.last_firing_time, 0xFF, (size_t)net->n_pad * 4, net->stream), SNN_ERR_BUFFER_WRITE);
     HIP_TRY(hipMemsetAsync(net->ca.last_firing_time, 0xFF, (size_t)net->c_pad * 4, net->stream), SNN_ERR_BUFFER_WRITE);
@@ -1135,13 +1176,29 @@ int snn_run(snn_network_t *net, uint64_t iterations)
     return end_run(net);
 }
 
+int snn_step_begin_local(snn_network_t *net)
+{
+    if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
+    if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
+    if (!net->electrical && !net->chemical) return SNN_OK;
+    HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
+    TRY(begin_run(net, 1));
+    // Only when nothing of the previous step is still pending for these chunks: STDP rewrites W in
+    // snn_step_end and needs the gathered spikes first, so with plasticity on the split is not taken.
+    if (net->nn && !net->csr && !net->any_plasticity && !net->local_inputs_done) {
+        TRY(launch_inputs(net, INPUTS_LOCAL));
+        net->local_inputs_done = true;
+    }
+    return SNN_OK;
+}
+
 int snn_step_begin(snn_network_t *net)
 {
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
     if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
+    if (!net->electrical && !net->chemical) return SNN_OK;           // neuron/mod.rs:1217, 2672
     HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
-    if (net->run_step_offset == 0) TRY(begin_run(net, 1));
-    else TRY(grow_history(net, 1));
+    TRY(begin_run(net, 1));
     if (net->nn) TRY(step_begin(net));
     if (!net->external_stream) HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
     return SNN_OK;
@@ -1151,12 +1208,11 @@ int snn_step_end(snn_network_t *net)
 {
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
     if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
+    if (!net->electrical && !net->chemical) return SNN_OK;
     HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
+    if (!net->run_active) return fail(SNN_ERR_BAD_STATE, "snn_step_end without snn_step_begin");
     TRY(step_end(net));
     if (!net->external_stream) HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
-    // keep the spike-train lattice clocks current after every externally driven step
-    for (auto &c : net->st_clock) c += net->run_step_offset;
-    net->run_step_offset = 0;
     return SNN_OK;
 }
 
@@ -1174,7 +1230,7 @@ int snn_set_stream(snn_network_t *net, void *hip_stream)
 {
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
     HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
-    HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
+    TRY(end_run(net));
     if (hip_stream) {
         net->stream = static_cast<hipStream_t>(hip_stream);
         net->external_stream = true;
@@ -1189,8 +1245,7 @@ int snn_synchronize(snn_network_t *net)
 {
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
     HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
-    HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
-    return SNN_OK;
+    return end_run(net);
 }
 
 int snn_stream(snn_network_t *net, void **hip_stream)
@@ -1218,7 +1273,7 @@ int snn_get_voltage_history(snn_network_t *net, uint32_t id, float *dst, size_t 
     if (count == 0) return SNN_OK;
     if (!dst) return fail(SNN_ERR_BAD_ARG, "dst is null");
     HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
-    HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
+    TRY(end_run(net));
     const float *src = l->spike_train ? net->st_vhist + (l->first - net->nn) : net->vhist + l->first;
     const size_t pitch = (size_t)(l->spike_train ? net->c_pad : net->n_pad) * 4;
     HIP_TRY(hipMemcpy2D(dst, (size_t)l->count * 4, src, pitch, (size_t)l->count * 4, net->hist_steps, hipMemcpyDeviceToHost),
@@ -1237,7 +1292,7 @@ int snn_get_spike_history(snn_network_t *net, uint32_t id, uint8_t *dst, size_t 
     if (count == 0) return SNN_OK;
     if (!dst) return fail(SNN_ERR_BAD_ARG, "dst is null");
     HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
-    HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
+    TRY(end_run(net));
     const size_t words = net->n_pad / 64;
     std::vector<unsigned long long> host(net->hist_steps * words);
     HIP_TRY(hipMemcpy(host.data(), net->raster, host.size() * 8, hipMemcpyDeviceToHost), SNN_ERR_BUFFER_READ);

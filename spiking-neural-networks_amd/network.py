@@ -185,6 +185,9 @@ class DeviceNetwork:
     def step_end(self):
         _lib.check(self._L.snn_step_end(self._h))
 
+    def step_begin_local(self):
+        _lib.check(self._L.snn_step_begin_local(self._h))
+
     def exchange_buffer(self):
         """(device pointer, words per neuron, padded neuron count) of the all-gather buffer"""
         p, w, n = C.c_void_p(), C.c_uint32(), C.c_uint32()

@@ -60,18 +60,42 @@ class ShardedStepper:
         self._sync = sync or (lambda: None)
         self._always = always_gather        # run the collective even at world_size 1 (path check on one GPU)
 
-    def exchange(self):
+    def exchange(self, async_op=False):
+        """all-gather the exchanged planes in place; async_op=True returns the pending work handle"""
         if self.world == 1 and not self._always:
-            return
+            return None
         if self.buf.is_cuda:
-            self.dist.all_gather_into_tensor(self.buf, self.local, group=self.group)
+            work = self.dist.all_gather_into_tensor(self.buf, self.local, group=self.group, async_op=async_op)
         else:   # gloo has no all_gather_into_tensor on every build: gather into per-rank views
             views = [self.buf[r * self.block:(r + 1) * self.block] for r in range(self.world)]
-            self.dist.all_gather(views, self.local.clone(), group=self.group)
-        self._sync()
+            work = self.dist.all_gather(views, self.local.clone(), group=self.group, async_op=async_op)
+        if not async_op:
+            self._sync()
+        return work if async_op else None
 
-    def run(self, iterations):
+    def run(self, iterations, overlap=True):
+        """`iterations` steps.  overlap (GPU backends): the collective of step t runs on RCCL's stream while
+        step t+1's synaptic-input pass over the shard's OWN presynaptic rows is already executing; only the
+        rows fed by other shards wait for it (backend.step_begin_local, a no-op when it would not be valid)."""
+        overlap = overlap and self.buf.is_cuda and hasattr(self.backend, "step_begin_local")
+        if not overlap:
+            for _ in range(int(iterations)):
+                self.backend.step_begin()
+                self.exchange()
+                self.backend.step_end()
+            return
+        pending = None
+        started = False
         for _ in range(int(iterations)):
+            self.backend.step_begin_local()
+            if started:
+                if pending is not None:
+                    pending.wait()                 # the compute stream waits for the gather, the host does not
+                self.backend.step_end()
             self.backend.step_begin()
-            self.exchange()
+            pending = self.exchange(async_op=True)
+            started = True
+        if started:
+            if pending is not None:
+                pending.wait()
             self.backend.step_end()

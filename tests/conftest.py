@@ -11,6 +11,11 @@ for p in (ROOT, os.path.dirname(os.path.abspath(__file__))):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the in-tree native pieces are git-ignored build products: (re)build them when missing or stale
+    import subprocess
+    import snn_amd
+    snn_amd.build()
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=True)
 
 
 @pytest.fixture(scope="session")

@@ -50,7 +50,14 @@ def test_sharded_stepper_over_rccl_world_size_1(snn):
             dist.all_gather_into_tensor(buf, buf[0:buf.numel()])
             dn.step_end()
         dn.synchronize()
+        # the overlapped schedule of ShardedStepper.run (step_begin_local before the previous gather is waited for)
+        stepper = parallel.ShardedStepper(dn, buf, 0, 1, always_gather=True)
+        dn.set_plasticity(0, do_plasticity=False)
+        net["do_plasticity"] = 0
         net.run(200)
+        stepper.run(150)
+        dn.synchronize()
+        net.run(150)
         parity.assert_state_equal(net, parity.pull_state(dn, net))
         parity.assert_graph_equal(net, dn)
         dn.close()

@@ -120,3 +120,50 @@ def test_stream_ordered_stepping_without_host_sync(snn):
         assert np.array_equal(parity.bits(w[:, b:e]), parity.bits(ow[:, b:e]))
         h.set_stream(None)
         h.close()
+
+
+@pytest.mark.parametrize("plastic", [False, True])
+def test_split_input_pass_is_result_neutral(snn, plastic):
+    """snn_step_begin_local + snn_step_begin (own-rows chunks first, the rest later) == one full pass; with
+    plasticity on the split is refused internally and the schedule still yields the oracle's result."""
+    import torch
+    from snn_amd import parallel
+    net = build(False)
+    net["do_plasticity"] = int(plastic)
+    n_shards, steps = 3, 200
+    handles = [parity.device_from_oracle(snn, net, shard=(r, n_shards)) for r in range(n_shards)]
+    bufs = [parallel.exchange_tensor(h, torch.device("cuda", 0)) for h in handles]
+    block = bufs[0].numel() // n_shards
+
+    def gather():
+        for r in range(n_shards):
+            for o in range(n_shards):
+                if o != r:
+                    bufs[o][r * block:(r + 1) * block].copy_(bufs[r][r * block:(r + 1) * block])
+        torch.cuda.synchronize()
+
+    started = False
+    for _ in range(steps):
+        for h in handles:
+            h.step_begin_local()          # before the previous step's exchange has been applied
+        if started:
+            gather()
+            for h in handles:
+                h.step_end()
+        for h in handles:
+            h.step_begin()
+        started = True
+    gather()
+    for h in handles:
+        h.step_end()
+    net.run(steps)
+    for h in handles:
+        st = parity.pull_state(h, net)
+        for name in ("current_voltage", "is_spiking", "last_firing_time", "st_last_firing_time"):
+            assert np.array_equal(parity.bits(st[name]), parity.bits(net[name])), name
+        b, e = h.post_begin, h.post_end
+        assert np.array_equal(parity.bits(st["w_value"][b:e]), parity.bits(net["w_value"][b:e]))
+        w, c = h.get_graph_rows(0, net.n_tot)
+        ow = np.where(net["connections"] != 0, net["weights"], np.float32(0))
+        assert np.array_equal(parity.bits(w[:, b:e]), parity.bits(ow[:, b:e]))
+        h.close()
