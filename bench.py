@@ -35,7 +35,9 @@ def pmc_traffic(config, world, rows, cols):
 
 
 def cpu_baseline(n, sample_cols, steps, threads):
-    """Time the oracle (kind "port") on `sample_cols` postsynaptic neurons of the same workload."""
+    """Time the oracle (kind "port": a C restatement of the reference's CPU path, dense arrays, OpenMP over
+    postsynaptic neurons = the reference's rayon par_iter, backend/src/neuron/mod.rs:775-790) on `sample_cols`
+    postsynaptic neurons of the same workload.  Returns the all-cores figure plus side measurements."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
     import oracle_binding as ob
@@ -52,14 +54,32 @@ def cpu_baseline(n, sample_cols, steps, threads):
     t0 = time.perf_counter()
     net.inputs(0, sample_cols)            # warm-up (page-in) + calibration of the sample length
     one = time.perf_counter() - t0
-    if steps is None:                     # aim at ~15 s of CPU work
-        steps = int(min(200, max(2, 15.0 / max(one, 1e-3))))
+    if steps is None:                     # aim at ~12 s of CPU work
+        steps = int(min(200, max(2, 12.0 / max(one, 1e-3))))
     t0 = time.perf_counter()
     for _ in range(steps):
         net.inputs(0, sample_cols)        # O(N) synapses per sampled neuron: the whole per-neuron cost
         net.update_neurons()              # O(1) per neuron (all N, negligible)
     dt = time.perf_counter() - t0
-    return sample_cols * steps / dt, dt, steps
+    extra = {}
+    # single thread (the reference's parallel = false), on a slice of the sample
+    net.n_threads = 1
+    cols1 = min(sample_cols, 256)
+    t0 = time.perf_counter()
+    net.inputs(0, cols1)
+    extra["single_thread_value"] = cols1 / (time.perf_counter() - t0)
+    # BASELINE configs[0] in full: 32x32, 1000 steps, the reference's own CPU-runnable case
+    c1 = ob.Net(1024, model=ob.IZHIKEVICH)
+    c1["gap_conductance"] = 10.0
+    c1["current_voltage"] = ob.uniform_array(1, 1024, -65.0, 30.0)
+    c1.fill_graph(2, 0.5, 1.5)
+    few = min(threads, 8)               # 1024 neurons = 64 column blocks: more threads only add fork/join cost
+    for nthreads, key in ((1, "c1_32x32_1000_steps_single_thread_s"), (few, f"c1_32x32_1000_steps_{few}_threads_s")):
+        c1.n_threads = nthreads
+        t0 = time.perf_counter()
+        c1.run(1000)
+        extra[key] = time.perf_counter() - t0
+    return sample_cols * steps / dt, dt, steps, extra
 
 
 def build_config(args, snn_amd, synthetic, np, rank, world, local_rank):
@@ -203,6 +223,18 @@ def main():
     launches, kern_ms = dn.profile_read()
     dn.profile_enable(False)
 
+    hist_value = None
+    if not sharded and args.config == "c2":
+        # also report the rate with GridVoltageHistory capture on (one extra 4 B store per neuron-step)
+        dn.set_history(voltage=True, spikes=True)
+        hsteps = min(args.steps, 100)
+        barrier()
+        t0 = time.perf_counter()
+        run(hsteps)
+        barrier()
+        hist_value = n * hsteps / (time.perf_counter() - t0)
+        dn.set_history(voltage=False, spikes=False)
+
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -221,6 +253,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "neurons": n,
                        "parallelism": f"post-population shards x{world}" if world > 1 else "single GPU"},
+            "value_with_voltage_and_spike_history": hist_value,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic(args.config, world, args.rows, args.cols),
@@ -229,9 +262,9 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline and args.config in ("c1", "c2"):
             threads = os.cpu_count() or 1
-            sample = 4096 if n >= 4096 else n
-            v, secs, cpu_steps = cpu_baseline(n, sample, None, threads)
-            out["cpu_baseline"] = {"value": v, "unit": "neuron-steps/s", "cores": threads, "kind": "port",
+            sample = min(n, max(4096, 64 * threads))      # >= 4 column blocks of 16 per thread
+            v, secs, cpu_steps, extra = cpu_baseline(n, sample, None, threads)
+            out["cpu_baseline"] = {"value": v, "unit": "neuron-steps/s", "cores": threads, "kind": "port", **extra,
                                    "sample": f"oracle (C restatement, OpenMP x{threads}) on {sample} of {n} postsynaptic "
                                              f"neurons x {cpu_steps} steps ({secs:.1f} s); each sampled neuron sums all "
                                              f"{n} presynaptic terms, i.e. the full per-neuron-step cost"}
