@@ -29,6 +29,24 @@ struct UpdateArgs {
     unsigned long long *spike_row;   // this step's row of the bit-packed raster or null
 };
 
+// Second level of the canonical sum: chunk partials added in ascending chunk order from 0.0f.  The loads of
+// a batch are issued together (the adds stay strictly sequential), so a thread keeps 16 reads in flight.
+__device__ __forceinline__ float combine_partials(const float *p, uint32_t n_chunks, size_t ld)
+{
+    constexpr uint32_t B = 16;
+    float s = 0.0f;
+    uint32_t c = 0;
+    for (; c + B <= n_chunks; c += B) {
+        float v[B];
+#pragma unroll
+        for (uint32_t u = 0; u < B; ++u) v[u] = p[(size_t)(c + u) * ld];
+#pragma unroll
+        for (uint32_t u = 0; u < B; ++u) s += v[u];
+    }
+    for (; c < n_chunks; ++c) s += p[(size_t)c * ld];
+    return s;
+}
+
 // NeurotransmitterKinetics::apply_t_change: Approximate iterate_and_spike/mod.rs:193-196,
 // Destexhe :148-150
 __device__ __forceinline__ float nt_apply(int kind, float t, float t_max, float clearance, float v_p,
@@ -63,9 +81,7 @@ __device__ __forceinline__ void receptors_update(const UpdateArgs &a, uint32_t q
         const uint32_t cnt = a.tcount[(size_t)k * a.ld + ql];
         if (cnt != 0) {
             // second level of the canonical sum, then the per-type average
-            float s = 0.0f;
-            const float *pt = a.part_t + (size_t)k * a.n_chunks * a.ld + ql;
-            for (uint32_t c = 0; c < a.n_chunks; ++c) s += pt[(size_t)c * a.ld];
+            const float s = combine_partials(a.part_t + (size_t)k * a.n_chunks * a.ld + ql, a.n_chunks, a.ld);
             const float t = s / (float)cnt;
             if (a.rc_kind == 1) {
                 const float r = a.n.rc_r[i];
@@ -127,9 +143,7 @@ __global__ __launch_bounds__(256) void k_update(const UpdateArgs a)
         // input current: chunk partials in ascending order, then the averager (neuron/mod.rs:722-729)
         float i_in = 0.0f;
         if (a.electrical) {
-            float s = 0.0f;
-            const float *pi = a.part_i + ql;
-            for (uint32_t c = 0; c < a.n_chunks; ++c) s += pi[(size_t)c * a.ld];
+            const float s = combine_partials(a.part_i + ql, a.n_chunks, a.ld);
             const uint32_t cnt = a.n_in[ql];
             i_in = s / (cnt == 0 ? 1.0f : (float)cnt);
         }
