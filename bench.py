@@ -240,6 +240,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    ceilings = None
+    if rank == 0 and not sharded and args.config == "c2":
+        dn.synchronize()
+        rd, cp = snn_amd.probe_bandwidth(8 << 30, 5, local_rank)     # this device's own HBM ceilings
+        ceilings = {"read_only_GBps": rd, "copy_GBps": cp}
+
     if rank == 0:
         value = n * args.steps / elapsed
         bytes_per_launch = dn.input_kernel_bytes()
@@ -257,7 +263,9 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic(args.config, world, args.rows, args.cols),
-                         "kernel": kernel_name, "launches": launches, "avg_launch_ms": avg_ms,
+                         "kernel": kernel_name, "measured_device_ceilings": ceilings,
+                         "frac_of_measured_read_ceiling": (achieved / ceilings["read_only_GBps"]) if ceilings else None,
+                         "launches": launches, "avg_launch_ms": avg_ms,
                          "algorithmic_bytes_per_launch": bytes_per_launch},
         }
         if world == 1 and not args.no_cpu_baseline and args.config in ("c1", "c2"):

@@ -215,6 +215,10 @@ int snn_input_kernel_bytes(const snn_network_t *net, uint64_t *bytes);
 const char *snn_last_error(void);
 int snn_abi_version(void);
 
+/* HBM ceilings of the device with the stepper's own access shape (16 B per lane, non-temporal): GB/s of a
+ * read-only stream and of a copy (read + write bytes) over `bytes` of device memory, `repeats` launches. */
+int snn_probe_bandwidth(int device, uint64_t bytes, int repeats, double *read_gbps, double *copy_gbps);
+
 /* ---- device-function probes (parity tests of the shared scalar formulas) ---------------- */
 
 /* out[i] = f(in[i]) evaluated ON THE GPU by the same device functions the stepper uses:

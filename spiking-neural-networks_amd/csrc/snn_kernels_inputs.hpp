@@ -180,6 +180,32 @@ __global__ __launch_bounds__(InputsShape<STREAM>::THREADS) void k_inputs_dense(c
     // so every wave keeps ROW_BATCH wave-rows of reads in flight regardless of the branches in the body.
     auto sweep = [&](auto body) {
         uint32_t r = 0;
+        if constexpr (STREAM && !CHEM) {
+            // Electrical-only streaming pass (the 256x256 headline): two register buffers, so the next batch of
+            // 8 rows is already in flight while the current one is consumed (+1 % over a single buffer, measured
+            // in-process at 256x256; the chemical variants keep one buffer -- they need the registers for their
+            // 12 extra accumulators).
+            constexpr uint32_t B = ROW_BATCH;
+            if (rows >= 2 * B) {
+                float wa[B][VEC], wb[B][VEC];
+#pragma unroll
+                for (uint32_t u = 0; u < B; ++u) load_w<STREAM>(wrow + (size_t)u * ld, wa[u]);
+                for (; r + 3 * B <= rows; r += 2 * B) {
+#pragma unroll
+                    for (uint32_t u = 0; u < B; ++u) load_w<STREAM>(wrow + (size_t)(r + B + u) * ld, wb[u]);
+#pragma unroll
+                    for (uint32_t u = 0; u < B; ++u) body(r + u, wa[u]);
+#pragma unroll
+                    for (uint32_t u = 0; u < B; ++u) load_w<STREAM>(wrow + (size_t)(r + 2 * B + u) * ld, wa[u]);
+#pragma unroll
+                    for (uint32_t u = 0; u < B; ++u) body(r + B + u, wb[u]);
+                }
+                // wa holds rows r .. r+B-1
+#pragma unroll
+                for (uint32_t u = 0; u < B; ++u) body(r + u, wa[u]);
+                r += B;
+            }
+        }
         for (; r + ROW_BATCH <= rows; r += ROW_BATCH) {
             float wb[ROW_BATCH][VEC];
 #pragma unroll

@@ -211,6 +211,25 @@ __global__ void k_stamp_remote(const float *xbuf, XLayout xl, int32_t *last_firi
     if (reinterpret_cast<const uint32_t *>(xbuf)[xl.at(q, PLANE_SPIKE)]) last_firing_time[q] = (int32_t)clock;
 }
 
+// HBM ceilings of THIS device, measured with the access shape of k_inputs_dense (16 B per lane, nt):
+// read-only stream (what the synaptic-input pass can reach at best) and read+write copy.
+typedef float probe_v4f __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_probe_read(const probe_v4f *src, size_t n4, float *sink)
+{
+    probe_v4f acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const probe_v4f v = __builtin_nontemporal_load(src + i);
+        acc += v;
+    }
+    const float s = acc.x + acc.y + acc.z + acc.w;
+    if (s == 12345.678f) *sink = s;      // never true for the zero-filled buffer: keeps the loads alive
+}
+__global__ __launch_bounds__(256) void k_probe_copy(const probe_v4f *src, probe_v4f *dst, size_t n4)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256)
+        __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+}
+
 // device-function probe for the parity tests of the scalar formulas
 __global__ void k_probe_math(int which, const float *in, float *out, size_t n)
 {

@@ -251,3 +251,11 @@ def probe_math(which, x, device=0):
     out = np.empty_like(a)
     _lib.check(L.snn_probe_math(device, which, a.ctypes.data_as(_lib.f32p), out.ctypes.data_as(_lib.f32p), a.size))
     return out
+
+
+def probe_bandwidth(nbytes=8 << 30, repeats=5, device=0):
+    """(read-only GB/s, copy GB/s) of the device with the stepper's access shape"""
+    L = _lib.load()
+    r, c = C.c_double(), C.c_double()
+    _lib.check(L.snn_probe_bandwidth(device, nbytes, repeats, C.byref(r), C.byref(c)))
+    return r.value, c.value
