@@ -72,19 +72,26 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 //          wavefront per workgroup, ONE column per lane, default cache policy, 32 rows per round trip.
 //          A 32x32 lattice then spreads over 64 CUs instead of 4 -- each CU's vector-L1 bandwidth
 //          (64 B/clk) is what bounds a cache-resident pass, not HBM.
-template <bool STREAM> struct InputsShape {
-    static constexpr int VEC = STREAM ? 4 : 1;
+//  STREAM == 2: the streaming shape with TWO columns per lane (512-B wave-rows): twice the wavefronts for
+//          matrices too small to fill the chip with the 4-column shape (e.g. 128x128: 4096 -> 8192 waves).
+template <int STREAM> struct InputsShape {
+    static constexpr int VEC = STREAM == 1 ? 4 : (STREAM == 2 ? 2 : 1);
     static constexpr int THREADS = STREAM ? 256 : 64;
     static constexpr int TILE = VEC * THREADS;            // columns per workgroup
     static constexpr uint32_t ROW_BATCH = STREAM ? 8 : 32;
 };
 
-template <bool STREAM>
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+template <int STREAM>
 __device__ __forceinline__ void load_w(const float *p, float (&w)[InputsShape<STREAM>::VEC])
 {
-    if constexpr (STREAM) {
+    if constexpr (STREAM == 1) {
         const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(p));
         w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+    } else if constexpr (STREAM == 2) {
+        const v2f v = __builtin_nontemporal_load(reinterpret_cast<const v2f *>(p));
+        w[0] = v.x; w[1] = v.y;
     } else {
         w[0] = *p;
     }
@@ -96,7 +103,7 @@ __device__ __forceinline__ float acc_if_edge(float acc, float term, float w)
     return (w == w) ? acc + term * w : acc;
 }
 
-template <bool ELEC, bool CHEM, bool STREAM = true>
+template <bool ELEC, bool CHEM, int STREAM = 1>
 __global__ __launch_bounds__(InputsShape<STREAM>::THREADS) void k_inputs_dense(const InputsArgs a)
 {
     using S = InputsShape<STREAM>;
@@ -180,7 +187,7 @@ __global__ __launch_bounds__(InputsShape<STREAM>::THREADS) void k_inputs_dense(c
     // so every wave keeps ROW_BATCH wave-rows of reads in flight regardless of the branches in the body.
     auto sweep = [&](auto body) {
         uint32_t r = 0;
-        if constexpr (STREAM && !CHEM) {
+        if constexpr (STREAM == 1 && !CHEM) {
             // Electrical-only streaming pass (the 256x256 headline): two register buffers, so the next batch of
             // 8 rows is already in flight while the current one is consumed (+1 % over a single buffer, measured
             // in-process at 256x256; the chemical variants keep one buffer -- they need the registers for their

@@ -581,22 +581,26 @@ int launch_inputs(snn_network *net, InputsPart part = INPUTS_ALL)
         if (net->profile) HIP_TRY(hipEventRecord(e1, net->stream), SNN_ERR_QUEUE);
         return SNN_OK;
     }
-    // matrices that stay cache-resident between steps take the latency-oriented variant
-    const bool stream = (size_t)net->n_tot * net->ld * 4 > ((size_t)64 << 20);
+    // shape of the pass: cache-resident matrices take the latency-oriented one-wave shape; streamed matrices the
+    // 4-columns-per-lane shape, or the 2-column shape while that would leave the chip under-filled
+    const bool resident = (size_t)net->n_tot * net->ld * 4 <= ((size_t)64 << 20);
+    const uint64_t waves4 = (uint64_t)((net->ld + 255) / 256) * grid_chunks;
+    const int shape = resident ? 0 : (waves4 < 8192 ? 2 : 1);     // 8192 = 256 CUs x 32 wave slots
+#define SNN_LAUNCH_SHAPE(E, C, SH)                                                                        \
+    hipLaunchKernelGGL((k_inputs_dense<E, C, SH>),                                                       \
+                       dim3((net->ld + InputsShape<SH>::TILE - 1) / InputsShape<SH>::TILE, grid_chunks), \
+                       dim3(InputsShape<SH>::THREADS), 0, net->stream, a)
 #define SNN_LAUNCH_INPUTS(E, C)                                                                          \
     do {                                                                                                 \
-        constexpr int T1 = InputsShape<true>::TILE, T0 = InputsShape<false>::TILE;                       \
-        if (stream)                                                                                      \
-            hipLaunchKernelGGL((k_inputs_dense<E, C, true>), dim3((net->ld + T1 - 1) / T1, grid_chunks), \
-                               dim3(InputsShape<true>::THREADS), 0, net->stream, a);                     \
-        else                                                                                             \
-            hipLaunchKernelGGL((k_inputs_dense<E, C, false>), dim3((net->ld + T0 - 1) / T0, grid_chunks), \
-                               dim3(InputsShape<false>::THREADS), 0, net->stream, a);                    \
+        if (shape == 1) SNN_LAUNCH_SHAPE(E, C, 1);                                                       \
+        else if (shape == 2) SNN_LAUNCH_SHAPE(E, C, 2);                                                  \
+        else SNN_LAUNCH_SHAPE(E, C, 0);                                                                  \
     } while (0)
     if (net->electrical && net->chemical) SNN_LAUNCH_INPUTS(true, true);
     else if (net->electrical) SNN_LAUNCH_INPUTS(true, false);
     else SNN_LAUNCH_INPUTS(false, true);
 #undef SNN_LAUNCH_INPUTS
+#undef SNN_LAUNCH_SHAPE
     HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
     if (net->profile) HIP_TRY(hipEventRecord(e1, net->stream), SNN_ERR_QUEUE);
     return SNN_OK;
