@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -381,12 +382,6 @@ int build_state(snn_network *net)
     // graph + partials + counts
     if (net->csr) net->n_chunks = 1;     // the CSR kernel writes the finished two-level sum
     TRY(dev_alloc_t(net, &net->W, net->csr ? 0 : (size_t)net->n_tot * net->ld));
-    if (!net->csr && (size_t)net->n_tot * net->ld) {
-        // no edges until a graph is set: all sentinel
-        hipLaunchKernelGGL(k_fill_u32, dim3(4096), dim3(256), 0, net->stream,
-                           reinterpret_cast<uint32_t *>(net->W), (size_t)net->n_tot * net->ld, 0x7FC00000u);
-        HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
-    }
     TRY(dev_alloc_t(net, &net->part_i, (size_t)net->n_chunks * net->ld));
     TRY(dev_alloc_t(net, &net->part_t, (size_t)K_TYPES * net->n_chunks * net->ld));
     TRY(dev_alloc_t(net, &net->n_in, net->ld));
@@ -659,6 +654,68 @@ int launch_plasticity(snn_network *net)
     return SNN_OK;
 }
 
+// The synapse matrix is the one allocation whose HBM placement matters: on MI355X two 17 GB allocations of one
+// process can differ by 5-6 % in the sustained rate of the input pass (stable per allocation, different from
+// process to process).  For matrices >= 1 GiB a second candidate is allocated while the first is held, the real
+// kernel is timed on both (one warm + one timed pass each, once per handle) and the faster allocation is kept.
+int time_input_pass(snn_network *net, float *ms)
+{
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return fail(SNN_ERR_QUEUE, "hipEventCreate failed");
+    int rc = launch_inputs(net);
+    if (rc == SNN_OK && hipEventRecord(e0, net->stream) != hipSuccess) rc = fail(SNN_ERR_QUEUE, "hipEventRecord failed");
+    if (rc == SNN_OK) rc = launch_inputs(net);
+    if (rc == SNN_OK && (hipEventRecord(e1, net->stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
+                         hipEventElapsedTime(ms, e0, e1) != hipSuccess))
+        rc = fail(SNN_ERR_WAIT, "placement timing failed");
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return rc;
+}
+
+int choose_matrix_placement(snn_network *net)
+{
+    const size_t count = net->csr ? 0 : (size_t)net->n_tot * net->ld;
+    const size_t bytes = count * sizeof(float);
+    if (bytes >= ((size_t)1 << 30) && net->n_loc) {
+        const int prof = net->profile;
+        net->profile = 0;
+        float best_ms = 0.0f;
+        int rc = time_input_pass(net, &best_ms);
+        // up to three more candidates, each allocated while the best so far is held (different HBM regions)
+        for (int cand = 0; cand < 3 && rc == SNN_OK; ++cand) {
+            size_t free_b = 0, total_b = 0;
+            void *b = nullptr;
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + (bytes >> 2) ||
+                hipMalloc(&b, bytes) != hipSuccess)
+                break;
+            float *a = net->W;
+            float ms_b = 0.0f;
+            net->W = static_cast<float *>(b);
+            rc = time_input_pass(net, &ms_b);
+            if (getenv("SNN_DEBUG_PLACEMENT"))
+                fprintf(stderr, "[snn] matrix placement: held %p %.3f ms, candidate %p %.3f ms\n", (void *)a, best_ms, b, ms_b);
+            if (rc == SNN_OK && ms_b < best_ms * 0.99f) {       // the candidate wins
+                for (auto &p : net->allocs) if (p == a) p = b;
+                (void)hipFree(a);
+                best_ms = ms_b;
+            } else {
+                net->W = a;
+                (void)hipFree(b);
+            }
+        }
+        net->profile = prof;
+        if (rc != SNN_OK) return rc;
+    }
+    if (count) {   // no edges until a graph is set: every entry is the absent-edge sentinel
+        hipLaunchKernelGGL(k_fill_u32, dim3(4096), dim3(256), 0, net->stream,
+                           reinterpret_cast<uint32_t *>(net->W), count, 0x7FC00000u);
+        HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+        HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
+    }
+    return SNN_OK;
+}
+
 // first half of a step: inputs from S(t) and the local neurons' update
 int step_begin(snn_network *net)
 {
@@ -924,6 +981,8 @@ static int finalize_impl(snn_network_t *net, bool whole, uint32_t post_begin, ui
     if (net->ld % 1024 == 0) net->ld += 64;
     net->n_chunks = (net->n_tot + CHUNK - 1) / CHUNK;
     int rc = build_state(net);
+    if (rc) return rc;
+    rc = choose_matrix_placement(net);
     if (rc) return rc;
     net->finalized = true;
     return SNN_OK;
