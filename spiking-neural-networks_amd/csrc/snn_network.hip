@@ -822,7 +822,9 @@ int graph_rows_io(snn_network *net, uint32_t pre_begin, uint32_t pre_count, floa
     HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
     TRY(end_run(net));
     // staged through a bounded device buffer: <= 64 MiB of host rows per hop
-    const uint32_t hop = (uint32_t)std::max<size_t>(1, std::min<size_t>(pre_count, (64u << 20) / (host_ld * 4)));
+    // <= 64 MiB of host rows per hop and <= 32768 rows (grid.y of the import / export kernels)
+    const uint32_t hop = (uint32_t)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(pre_count, 32768),
+                                                                        (64u << 20) / (host_ld * 4)));
     float *dw = nullptr;
     uint32_t *dc = nullptr;
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dw), (size_t)hop * host_ld * 4), SNN_ERR_BUFFER_CREATE);

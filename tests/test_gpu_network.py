@@ -120,3 +120,21 @@ def test_two_spike_train_lattices_and_resume(snn):
     dn = run_both(snn, net, 300, chunks=3)
     assert net["st_last_firing_time"].min() > 0 and list(net["st_clock"]) == [300, 300]
     dn.close()
+
+
+def test_many_spike_train_rows_few_neurons(snn):
+    """More than 65 535 presynaptic rows into a handful of neurons (graph import in row hops; chunked sum over a
+    long column): bit-identical inputs."""
+    lay = parity.Layout([(0, 1, 3)], [(1, 300, 256)])          # 76 800 spike-train cells
+    net = parity.make_oracle(lay, st_kind=ob.ST_RATE)
+    nn, nc = net.n_neurons, net.n_cells
+    net["st_rate"] = ob.uniform_array(1, nc, 0.5, 30.0)
+    rng = np.random.default_rng(2)
+    net["connections"][nn:, :] = rng.random((nc, nn)) < 0.5
+    net["weights"][nn:, :] = ob.uniform_array(3, nc * nn, 0.0, 1.0).reshape(nc, nn) * net["connections"][nn:, :]
+    net["connections"][:nn, :] = 1
+    net["weights"][:nn, :] = 1.0
+    net.n_threads = 8
+    dn = run_both(snn, net, 60)
+    assert net["st_last_firing_time"].max() > 0
+    dn.close()
