@@ -88,8 +88,12 @@ struct snn_network {
     // sparse form (CSR by local postsynaptic row); the arrays are replaced by every snn_set_graph_csr
     bool csr = false;
     uint64_t nnz = 0;
+    // device: SELL-64 rows (slice_ptr / pre / w / row_len) + per-CSR-edge slot, local row and the transpose index
     uint32_t *csr_ptr = nullptr, *csr_pre = nullptr, *csr_post = nullptr, *csr_t_ptr = nullptr, *csr_t_edge = nullptr;
+    uint32_t *csr_row_len = nullptr, *csr_edge_slot = nullptr;
     float *csr_w = nullptr;
+    uint64_t sell_entries = 0;
+    std::vector<uint32_t> edge_slot_host;   // CSR edge -> SELL entry (for snn_get_graph_csr)
     float *W = nullptr;
     float *xbuf = nullptr;
     float *part_i = nullptr, *part_t = nullptr;
@@ -465,11 +469,13 @@ int attr_io(snn_network *net, uint32_t id, const char *name, AttrType type, void
 
 // ---- per-step launches -------------------------------------------------------------------------
 
-CsrGraph csr_graph(const snn_network *net)
+SellGraph csr_graph(const snn_network *net)
 {
-    CsrGraph g{};
-    g.ptr = net->csr_ptr; g.pre = net->csr_pre; g.w = net->csr_w; g.post = net->csr_post;
-    g.t_ptr = net->csr_t_ptr; g.t_edge = net->csr_t_edge; g.n_loc = net->n_loc;
+    SellGraph g{};
+    g.slice_ptr = net->csr_ptr; g.pre = net->csr_pre; g.w = net->csr_w; g.row_len = net->csr_row_len;
+    g.edge_slot = net->csr_edge_slot; g.edge_post = net->csr_post;
+    g.t_ptr = net->csr_t_ptr; g.t_edge = net->csr_t_edge;
+    g.n_loc = net->n_loc; g.n_slices = (net->n_loc + 63) / 64;
     return g;
 }
 
@@ -564,7 +570,7 @@ int launch_inputs(snn_network *net, InputsPart part = INPUTS_ALL)
             CsrInputsArgs ca{};
             ca.g = csr_graph(net);
             ca.in = a;
-            dim3 g((net->n_loc + 255) / 256);
+            dim3 g((((net->n_loc + 63) / 64) * 64 + 255) / 256);
             if (net->electrical && net->chemical) hipLaunchKernelGGL((k_inputs_csr<true, true>), g, dim3(256), 0, net->stream, ca);
             else if (net->electrical) hipLaunchKernelGGL((k_inputs_csr<true, false>), g, dim3(256), 0, net->stream, ca);
             else hipLaunchKernelGGL((k_inputs_csr<false, true>), g, dim3(256), 0, net->stream, ca);
@@ -912,7 +918,7 @@ int snn_network_destroy(snn_network_t *net)
     if (net->stream) (void)hipStreamSynchronize(net->stream);
     for (void *p : net->allocs) (void)hipFree(p);
     for (void *p : {(void *)net->csr_ptr, (void *)net->csr_pre, (void *)net->csr_post, (void *)net->csr_t_ptr,
-                    (void *)net->csr_t_edge, (void *)net->csr_w})
+                    (void *)net->csr_t_edge, (void *)net->csr_w, (void *)net->csr_row_len, (void *)net->csr_edge_slot})
         if (p) (void)hipFree(p);
     if (net->vhist) (void)hipFree(net->vhist);
     if (net->st_vhist) (void)hipFree(net->st_vhist);
@@ -1105,9 +1111,12 @@ int snn_set_graph_csr(snn_network_t *net, const uint64_t *row_ptr, const uint32_
     if (nnz >= 0xFFFFFFFFull) return fail(SNN_ERR_DIM_MISMATCH, "more than 2^32-1 stored synapses per handle");
     const uint32_t n_loc = net->n_loc;
     if (row_ptr[0] != 0 || row_ptr[n_loc] != nnz) return fail(SNN_ERR_DIM_MISMATCH, "row_ptr must run from 0 to nnz");
-    std::vector<uint32_t> ptr(n_loc + 1), post(nnz), t_ptr((size_t)net->n_tot + 1, 0), t_edge(nnz);
+    const uint32_t n_slices = (n_loc + 63) / 64;
+    std::vector<uint32_t> slice_ptr((size_t)n_slices + 1, 0), row_len((size_t)n_slices * 64, 0), post(nnz),
+        t_ptr((size_t)net->n_tot + 1, 0), t_edge(nnz), edge_slot(nnz);
     for (uint32_t q = 0; q < n_loc; ++q) {
         if (row_ptr[q + 1] < row_ptr[q]) return fail(SNN_ERR_DIM_MISMATCH, "row_ptr is not monotone");
+        row_len[q] = (uint32_t)(row_ptr[q + 1] - row_ptr[q]);
         for (uint64_t e = row_ptr[q]; e < row_ptr[q + 1]; ++e) {
             if (pre_index[e] >= net->n_tot) return fail(SNN_ERR_DIM_MISMATCH, "presynaptic index out of range");
             if (e > row_ptr[q] && pre_index[e] <= pre_index[e - 1])
@@ -1116,7 +1125,27 @@ int snn_set_graph_csr(snn_network_t *net, const uint64_t *row_ptr, const uint32_
             ++t_ptr[pre_index[e] + 1];
         }
     }
-    for (uint32_t q = 0; q <= n_loc; ++q) ptr[q] = (uint32_t)row_ptr[q];
+    // SELL-64: every slice (64 rows) is padded to its longest row
+    uint64_t entries = 0;
+    for (uint32_t sl = 0; sl < n_slices; ++sl) {
+        uint32_t width = 0;
+        for (uint32_t r = sl * 64; r < sl * 64 + 64; ++r) width = std::max(width, row_len[r]);
+        slice_ptr[sl] = (uint32_t)entries;
+        entries += (uint64_t)width * 64;
+        if (entries >= 0xFFFFFFFFull) return fail(SNN_ERR_DIM_MISMATCH, "sparse graph too large for 32-bit slots");
+    }
+    slice_ptr[n_slices] = (uint32_t)entries;
+    std::vector<uint32_t> sell_pre(entries, SELL_PAD);
+    std::vector<float> sell_w(entries, 0.0f);
+    for (uint32_t q = 0; q < n_loc; ++q) {
+        const uint32_t base = slice_ptr[q >> 6] + (q & 63u);
+        for (uint64_t e = row_ptr[q]; e < row_ptr[q + 1]; ++e) {
+            const uint32_t slot = base + (uint32_t)(e - row_ptr[q]) * 64;
+            sell_pre[slot] = pre_index[e];
+            sell_w[slot] = weights[e];
+            edge_slot[e] = slot;
+        }
+    }
     for (size_t p = 0; p < net->n_tot; ++p) t_ptr[p + 1] += t_ptr[p];
     {
         std::vector<uint32_t> fill(t_ptr.begin(), t_ptr.end() - 1);
@@ -1125,7 +1154,8 @@ int snn_set_graph_csr(snn_network_t *net, const uint64_t *row_ptr, const uint32_
     HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
     TRY(end_run(net));
     for (void **p : {(void **)&net->csr_ptr, (void **)&net->csr_pre, (void **)&net->csr_post, (void **)&net->csr_t_ptr,
-                     (void **)&net->csr_t_edge, (void **)&net->csr_w}) {
+                     (void **)&net->csr_t_edge, (void **)&net->csr_w, (void **)&net->csr_row_len,
+                     (void **)&net->csr_edge_slot}) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
     }
@@ -1134,13 +1164,17 @@ int snn_set_graph_csr(snn_network_t *net, const uint64_t *row_ptr, const uint32_
         if (bytes) HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
         return SNN_OK;
     };
-    TRY(up((void **)&net->csr_ptr, ptr.data(), ptr.size() * 4));
-    TRY(up((void **)&net->csr_pre, pre_index, nnz * 4));
-    TRY(up((void **)&net->csr_w, weights, nnz * 4));
+    TRY(up((void **)&net->csr_ptr, slice_ptr.data(), slice_ptr.size() * 4));
+    TRY(up((void **)&net->csr_pre, sell_pre.data(), entries * 4));
+    TRY(up((void **)&net->csr_w, sell_w.data(), entries * 4));
+    TRY(up((void **)&net->csr_row_len, row_len.data(), row_len.size() * 4));
+    TRY(up((void **)&net->csr_edge_slot, edge_slot.data(), nnz * 4));
     TRY(up((void **)&net->csr_post, post.data(), nnz * 4));
     TRY(up((void **)&net->csr_t_ptr, t_ptr.data(), t_ptr.size() * 4));
     TRY(up((void **)&net->csr_t_edge, t_edge.data(), nnz * 4));
     net->nnz = nnz;
+    net->sell_entries = entries;
+    net->edge_slot_host.swap(edge_slot);
     net->counts_dirty = true;
     return SNN_OK;
 }
@@ -1155,7 +1189,9 @@ int snn_get_graph_csr(snn_network_t *net, float *weights, uint64_t nnz)
     if (!weights) return fail(SNN_ERR_BAD_ARG, "weights is null");
     HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
     TRY(end_run(net));
-    HIP_TRY(hipMemcpy(weights, net->csr_w, nnz * 4, hipMemcpyDeviceToHost), SNN_ERR_BUFFER_READ);
+    std::vector<float> sell((size_t)net->sell_entries);
+    HIP_TRY(hipMemcpy(sell.data(), net->csr_w, sell.size() * 4, hipMemcpyDeviceToHost), SNN_ERR_BUFFER_READ);
+    for (uint64_t e = 0; e < nnz; ++e) weights[e] = sell[net->edge_slot_host[e]];
     return SNN_OK;
 }
 
@@ -1399,7 +1435,7 @@ int snn_input_kernel_bytes(const snn_network_t *net, uint64_t *bytes)
 {
     if (!net || !bytes) return fail(SNN_ERR_BAD_ARG, "null argument");
     if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
-    *bytes = net->csr ? (uint64_t)8 * net->nnz                 // CSR: index + weight of every stored synapse
+    *bytes = net->csr ? (uint64_t)8 * net->nnz                 // sparse: index + weight of every stored synapse
                       : (uint64_t)4 * net->n_tot * net->n_loc; // dense: every weight of the shard, read once
     return SNN_OK;
 }
