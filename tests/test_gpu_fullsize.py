@@ -121,3 +121,94 @@ def test_c4_shaped_network_with_stdp_20480_neurons(snn):
     parity.assert_state_equal(net, parity.pull_state(dn, net))
     parity.assert_graph_equal(net, dn)
     dn.close()
+
+
+def test_c4_full_size_network_with_stdp_sampled(snn):
+    """BASELINE configs[3] at FULL size (256x256 excitatory + 128x128 inhibitory = 81 920 neurons, 26.8 GB of
+    weights generated on the device, > 2^32 matrix elements): teacher-forced windows of postsynaptic columns as in
+    the configs[1] test, plus the STDP updates of sampled edges re-derived from the downloaded spike times."""
+    from snn_amd import synthetic
+    n_inh, n_exc = 128 * 128, 256 * 256
+    n = n_inh + n_exc
+    dn = snn.DeviceNetwork(model=snn.IZHIKEVICH)
+    dn.add_lattice(0, 128, 128)
+    dn.add_lattice(1, 256, 256)
+    dn.finalize()
+    v0 = synthetic.uniform(4, n, -65.0, 30.0)
+    hot = np.array([5, 1000, n_inh - 1, n_inh, n_inh + 7, 40000, n - 2])
+    v0[hot] = 40.0                                  # spike (and trigger STDP) in step 0
+    dn.set_attr(0, "gap_conductance", np.full(n_inh, 10.0, np.float32))
+    dn.set_attr(1, "gap_conductance", np.full(n_exc, 10.0, np.float32))
+    dn.set_attr(0, "current_voltage", v0[:n_inh])
+    dn.set_attr(1, "current_voltage", v0[n_inh:])
+    dn.fill_graph_synthetic(5, 0.5, 1.5, with_diagonal=False)
+    dn.set_plasticity(0, a_plus=1.5)
+    dn.set_plasticity(1, tau_minus=3.0)
+    params = {0: (1.5, 2.0, 4.5, 4.5, 0.1), 1: (2.0, 2.0, 4.5, 3.0, 0.1)}
+
+    def state(name, dtype=np.float32):
+        return np.concatenate([dn.get_attr(0, name, dtype=dtype), dn.get_attr(1, name, dtype=dtype)])
+
+    windows = [(0, 64), (n_inh - 32, n_inh + 32), (n - 64, n)]
+    nets = []
+    for c0, c1 in windows:
+        net = ob.Net(n, model=ob.IZHIKEVICH)
+        net.arr["weights"] = np.empty((n, c1 - c0), np.float32)
+        net.arr["connections"] = np.empty((n, c1 - c0), np.uint8)
+        net.w_col0, net.w_ld = c0, c1 - c0
+        ob.lib().snn_o_fill_graph_window(net["weights"].ctypes.data_as(ob.f32p), net["connections"].ctypes.data_as(ob.u8p),
+                                         n, n, c0, c1 - c0, 5, 0.5, 1.5, 0)
+        net["gap_conductance"] = 10.0
+        net.n_threads = 8
+        nets.append(net)
+    L = ob.lib()
+    sample_rows = [5, n_inh, 40000, n - 2, 12345]          # rows (presynaptic) whose weights are tracked
+    w_track = {p: dn.get_graph_rows(p, 1)[0][0].copy() for p in sample_rows}
+    prev = {"current_voltage": state("current_voltage"), "w_value": state("w_value")}
+    lft_prev = state("last_firing_time", np.int32)
+    total_spikes = 0
+    for step in range(3):
+        dn.run(1)
+        new = {"current_voltage": state("current_voltage"), "w_value": state("w_value")}
+        spk = state("is_spiking", np.uint32)
+        lft = state("last_firing_time", np.int32)
+        total_spikes += int(spk.sum())
+        for net, (c0, c1) in zip(nets, windows):
+            net["current_voltage"] = prev["current_voltage"]
+            net["w_value"] = prev["w_value"]
+            net.clock = step
+            net.inputs(c0, c1)              # window weights are re-synchronised with the device after every step
+            net.update_neurons(c0, c1)
+            for k in ("current_voltage", "w_value"):
+                assert np.array_equal(net[k][c0:c1].view(np.uint32), new[k][c0:c1].view(np.uint32)), (step, k, c0)
+            assert np.array_equal(net["is_spiking"][c0:c1], spk[c0:c1])
+        # STDP of the tracked rows: every edge incident to a spiking neuron gets stdp(lft[p], lft[q]) with the
+        # plasticity of q's lattice, once per incident spiking end (neuron/mod.rs:2308-2417)
+        for p in sample_rows:
+            got = dn.get_graph_rows(p, 1)[0][0]
+            want = w_track[p].copy()
+            cols = np.nonzero(spk)[0] if not spk[p] else np.arange(n)
+            for q in cols:
+                if q == p:
+                    continue
+                prm = params[0 if q < n_inh else 1]
+                times = int(spk[q] != 0) + int(spk[p] != 0)
+                d = L.snn_o_stdp_delta(int(lft[p]), int(lft[q]), *prm)
+                for _ in range(times):
+                    want[q] = np.float32(want[q] + np.float32(d))
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (step, p)
+            w_track[p] = got
+        prev, lft_prev = new, lft
+        # the windows' own columns changed only if one of their neurons or a presynaptic neuron spiked: reload them
+        if spk.any():
+            rows_changed = np.nonzero(spk)[0]
+            for net, (c0, c1) in zip(nets, windows):
+                for p in rows_changed:                       # outgoing rows of spiking neurons
+                    net["weights"][p, :] = dn.get_graph_rows(int(p), 1)[0][0][c0:c1]
+                win_spk = np.nonzero(spk[c0:c1])[0]
+                if len(win_spk):                             # incoming columns of spiking window neurons
+                    for p0 in range(0, n, 8192):
+                        blk = dn.get_graph_rows(p0, min(8192, n - p0))[0]
+                        net["weights"][p0:p0 + blk.shape[0], win_spk] = blk[:, c0 + win_spk]
+    assert total_spikes >= len(hot)
+    dn.close()
