@@ -72,7 +72,13 @@ typedef enum snn_status {
 
 /* neuron models: IzhikevichNeuron integrate_and_fire/mod.rs:1159-1268,
  * LeakyIntegrateAndFireNeuron :108-215, HodgkinHuxleyNeuron hodgkin_huxley/mod.rs:49-241 */
-typedef enum { SNN_MODEL_IZHIKEVICH = 0, SNN_MODEL_LIF = 1, SNN_MODEL_HODGKIN_HUXLEY = 2 } snn_model;
+typedef enum {
+    SNN_MODEL_IZHIKEVICH = 0, SNN_MODEL_LIF = 1, SNN_MODEL_HODGKIN_HUXLEY = 2,
+    /* the two models the reference's own GPU path implements (IterateAndSpikeGPU):
+     * QuadraticIntegrateAndFireNeuron integrate_and_fire/mod.rs:259-917, buffers :729-773;
+     * SimpleLeakyIntegrateAndFire :1523-1801 */
+    SNN_MODEL_QUADRATIC_INTEGRATE_AND_FIRE = 3, SNN_MODEL_SIMPLE_LIF = 4
+} snn_model;
 /* NeurotransmitterKinetics: Approximate iterate_and_spike/mod.rs:161-205, Destexhe :122-159 */
 typedef enum { SNN_NT_APPROXIMATE = 0, SNN_NT_DESTEXHE = 1 } snn_nt_kinetics;
 /* ReceptorKinetics: Approximate iterate_and_spike/mod.rs:427-446, Destexhe :394-425 */

@@ -379,6 +379,71 @@ static uint32_t step_lif(snn_o_net *n, uint32_t q)
     return spike;
 }
 
+/* QuadraticIntegrateAndFireNeuron, integrate_and_fire/mod.rs:324-365, handle_spiking :87-102 */
+static uint32_t step_qif(snn_o_net *n, uint32_t q)
+{
+    const float v = n->current_voltage[q], dt = n->dt[q];
+    const float i = n->input_current[q];
+    const uint32_t spiking_prev = n->is_spiking[q];
+
+    if (n->chemical) receptors_update(n, q, v);
+
+    float dv = ((n->qif_alpha[q] * (v - n->v_reset[q]) * (v - n->qif_v_c[q])) +
+                n->integration_constant[q] * i) * (dt / n->tau_m[q]);
+    float v_new;
+    if (n->chemical) {
+        float neurotransmitter_dv = -receptor_currents(n, q);
+        v_new = v + (dv + neurotransmitter_dv);
+    } else {
+        v_new = v + dv;
+    }
+
+    neuron_nt_update(n, q, v_new, spiking_prev);
+
+    uint32_t spike = 0;
+    float rc = n->refractory_count[q];
+    if (rc > 0.0f) {
+        v_new = n->v_reset[q];
+        rc -= 1.0f;
+    } else if (v_new >= n->v_th[q]) {
+        spike = 1;
+        v_new = n->v_reset[q];
+        rc = n->tref[q] / dt;
+    }
+    n->refractory_count[q] = rc;
+    n->current_voltage[q] = v_new;
+    return spike;
+}
+
+/* SimpleLeakyIntegrateAndFire, integrate_and_fire/mod.rs:1577-1630 */
+static uint32_t step_simple_lif(snn_o_net *n, uint32_t q)
+{
+    const float v = n->current_voltage[q], dt = n->dt[q];
+    const float i = n->input_current[q];
+    const uint32_t spiking_prev = n->is_spiking[q];
+
+    if (n->chemical) receptors_update(n, q, v);
+
+    float dv = (n->slif_g[q] * (v - n->slif_e[q]) + i) * dt;
+    float v_new;
+    if (n->chemical) {
+        float neurotransmitter_dv = -receptor_currents(n, q);
+        v_new = v + (dv + neurotransmitter_dv);
+    } else {
+        v_new = v + dv;
+    }
+
+    neuron_nt_update(n, q, v_new, spiking_prev);
+
+    uint32_t spike = 0;
+    if (v_new >= n->v_th[q]) {
+        spike = 1;
+        v_new = n->v_reset[q];
+    }
+    n->current_voltage[q] = v_new;
+    return spike;
+}
+
 /* BasicGatingVariable::update, ion_channels/mod.rs:40-44 */
 static inline float gate_update(float state, float alpha, float beta, float dt)
 {
@@ -444,6 +509,8 @@ void snn_o_update_neurons_range(snn_o_net *n, uint32_t q0, uint32_t q1)
         switch (n->model) {
         case SNN_O_LIF: spike = step_lif(n, q); break;
         case SNN_O_HH:  spike = step_hh(n, q); break;
+        case SNN_O_QIF: spike = step_qif(n, q); break;
+        case SNN_O_SIMPLE_LIF: spike = step_simple_lif(n, q); break;
         default:        spike = step_izhikevich(n, q); break;
         }
         n->is_spiking[q] = spike;

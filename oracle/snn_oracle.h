@@ -53,7 +53,7 @@ extern "C" {
 #define SNN_O_K      3     /* AMPA=0, NMDA=1, GABA=2  (iterate_and_spike/mod.rs:1323-1333) */
 #define SNN_O_CHUNK  256   /* canonical reduction chunk (presynaptic indices) */
 
-enum { SNN_O_IZHIKEVICH = 0, SNN_O_LIF = 1, SNN_O_HH = 2 };
+enum { SNN_O_IZHIKEVICH = 0, SNN_O_LIF = 1, SNN_O_HH = 2, SNN_O_QIF = 3, SNN_O_SIMPLE_LIF = 4 };
 enum { SNN_O_NT_APPROX = 0, SNN_O_NT_DESTEXHE = 1 };
 enum { SNN_O_RC_APPROX = 0, SNN_O_RC_DESTEXHE = 1 };
 enum { SNN_O_ST_NONE = 0, SNN_O_ST_POISSON = 1, SNN_O_ST_RATE = 2 };
@@ -129,6 +129,10 @@ typedef struct snn_o_net {
     /* column window of `weights`/`connections` (bounded CPU-baseline samples of a large matrix):
      * the arrays hold columns [w_col0, w_col0 + w_ld) only; w_ld == 0 means the full n_neurons. */
     uint32_t w_col0, w_ld;
+    /* QuadraticIntegrateAndFireNeuron (integrate_and_fire/mod.rs:259-322; shares v_reset, refractory_count, tref,
+     * integration_constant, tau_m with LIF) and SimpleLeakyIntegrateAndFire (:1523-1575; shares v_reset) -- the two
+     * models the reference's own GPU path implements */
+    float    *qif_alpha, *qif_v_c, *slif_g, *slif_e;
 } snn_o_net;
 
 /* Step 1 of SURVEY §8(g): electrical + chemical inputs for every neuron from state S(t). */

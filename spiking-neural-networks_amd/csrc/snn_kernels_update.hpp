@@ -189,6 +189,39 @@ __global__ __launch_bounds__(256) void k_update(const UpdateArgs a)
                 rc = a.n.tref[q] / dt;
             }
             a.n.refractory_count[q] = rc;
+        } else if (MODEL == 3) {     // quadratic integrate-and-fire (integrate_and_fire/mod.rs:324-365)
+            const float dv = ((a.n.qif_alpha[q] * (v - a.n.v_reset[q]) * (v - a.n.qif_v_c[q])) +
+                              a.n.integration_constant[q] * i_in) * (dt / a.n.tau_m[q]);
+            if (a.chemical) {
+                const float neurotransmitter_dv = -receptor_currents(a, q, dt, c_m);
+                v_new = v + (dv + neurotransmitter_dv);
+            } else {
+                v_new = v + dv;
+            }
+            neuron_nt_update(a, q, v_new, spiking_prev, dt);
+            float rc = a.n.refractory_count[q];
+            if (rc > 0.0f) {
+                v_new = a.n.v_reset[q];
+                rc -= 1.0f;
+            } else if (v_new >= a.n.v_th[q]) {
+                spike = 1;
+                v_new = a.n.v_reset[q];
+                rc = a.n.tref[q] / dt;
+            }
+            a.n.refractory_count[q] = rc;
+        } else if (MODEL == 4) {     // simple leaky integrate-and-fire (integrate_and_fire/mod.rs:1577-1630)
+            const float dv = (a.n.slif_g[q] * (v - a.n.slif_e[q]) + i_in) * dt;
+            if (a.chemical) {
+                const float neurotransmitter_dv = -receptor_currents(a, q, dt, c_m);
+                v_new = v + (dv + neurotransmitter_dv);
+            } else {
+                v_new = v + dv;
+            }
+            neuron_nt_update(a, q, v_new, spiking_prev, dt);
+            if (v_new >= a.n.v_th[q]) {
+                spike = 1;
+                v_new = a.n.v_reset[q];
+            }
         } else {                     // Hodgkin-Huxley
             const float m_a = 0.1f * ((v + 40.0f) / (1.0f - expf_portable(-(v + 40.0f) / 10.0f)));
             const float m_b = 4.0f * expf_portable(-(v + 65.0f) / 18.0f);

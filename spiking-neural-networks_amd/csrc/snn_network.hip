@@ -231,16 +231,17 @@ int build_state(snn_network *net)
     // reference defaults: Izhikevich integrate_and_fire/mod.rs:1198-1220, LIF :149-171,
     // Hodgkin-Huxley hodgkin_huxley/mod.rs:80-98 + ion_channels/mod.rs:23-31, 205-215, 255-264, 299-307
     const bool izh = net->model == SNN_MODEL_IZHIKEVICH, lif = net->model == SNN_MODEL_LIF;
-    const float v0 = lif ? -75.0f : -65.0f;
+    const bool qif = net->model == SNN_MODEL_QUADRATIC_INTEGRATE_AND_FIRE, slif = net->model == SNN_MODEL_SIMPLE_LIF;
+    const float v0 = (lif || qif || slif) ? -75.0f : -65.0f;
     {
         // initial voltage into plane V of every shard slot
         for (uint32_t s = 0; s < net->xl.n_shards; ++s)
             TRY(fill_f32(net, net->xbuf + ((size_t)s * NUM_PLANES + PLANE_V) * net->xl.stride, net->xl.stride, v0));
     }
-    TRY(neuron_f32(net, &n.gap_conductance, "gap_conductance", 7.0f));
+    TRY(neuron_f32(net, &n.gap_conductance, "gap_conductance", slif ? 10.0f : 7.0f));
     TRY(neuron_f32(net, &n.dt, "dt", net->model == SNN_MODEL_HODGKIN_HUXLEY ? 0.01f : 0.1f));
     TRY(neuron_f32(net, &n.c_m, "c_m", net->model == SNN_MODEL_HODGKIN_HUXLEY ? 1.0f : 100.0f));
-    TRY(neuron_f32(net, &n.v_th, "v_th", izh ? 30.0f : (lif ? -55.0f : 0.0f)));
+    TRY(neuron_f32(net, &n.v_th, "v_th", izh ? 30.0f : ((lif || qif || slif) ? -55.0f : 0.0f)));
     TRY(dev_alloc_t(net, &n.last_firing_time, np));
     HIP_TRY(hipMemsetAsync(n.last_firing_time, 0xFF, (size_t)np * 4, net->stream), SNN_ERR_BUFFER_WRITE);
     reg(A, "last_firing_time", T_I32, S_PLAIN, n.last_firing_time, 0, 0);
@@ -250,13 +251,19 @@ int build_state(snn_network *net)
     TRY(neuron_f32(net, &n.b, izh ? "b" : nullptr, 0.2f));
     TRY(neuron_f32(net, &n.c, izh ? "c" : nullptr, -55.0f));
     TRY(neuron_f32(net, &n.d, izh ? "d" : nullptr, 8.0f));
-    TRY(neuron_f32(net, &n.tau_m, (izh || lif) ? "tau_m" : nullptr, izh ? 1.0f : 10.0f));
+    TRY(neuron_f32(net, &n.tau_m, (izh || lif || qif) ? "tau_m" : nullptr, izh ? 1.0f : (qif ? 100.0f : 10.0f)));
 
-    TRY(neuron_f32(net, &n.v_reset, lif ? "v_reset" : nullptr, -75.0f));
-    TRY(neuron_f32(net, &n.refractory_count, lif ? "refractory_count" : nullptr, 0.0f));
-    TRY(neuron_f32(net, &n.tref, lif ? "tref" : nullptr, 10.0f));
+    TRY(neuron_f32(net, &n.v_reset, (lif || qif || slif) ? "v_reset" : nullptr, -75.0f));
+    TRY(neuron_f32(net, &n.refractory_count, (lif || qif) ? "refractory_count" : nullptr, 0.0f));
+    TRY(neuron_f32(net, &n.tref, (lif || qif) ? "tref" : nullptr, 10.0f));
     TRY(neuron_f32(net, &n.leak_constant, lif ? "leak_constant" : nullptr, -1.0f));
-    TRY(neuron_f32(net, &n.integration_constant, lif ? "integration_constant" : nullptr, 1.0f));
+    TRY(neuron_f32(net, &n.integration_constant, (lif || qif) ? "integration_constant" : nullptr, 1.0f));
+    // reference buffer names of the two models with a reference GPU implementation
+    // (integrate_and_fire/mod.rs:729-773, 1700-1740)
+    TRY(neuron_f32(net, &n.qif_alpha, qif ? "alpha" : nullptr, 1.0f));
+    TRY(neuron_f32(net, &n.qif_v_c, qif ? "v_c" : nullptr, -60.0f));
+    TRY(neuron_f32(net, &n.slif_g, slif ? "g" : nullptr, -0.1f));
+    TRY(neuron_f32(net, &n.slif_e, slif ? "e" : nullptr, 0.0f));
     TRY(neuron_f32(net, &n.e_l, lif ? "e_l" : nullptr, -75.0f));
     TRY(neuron_f32(net, &n.g_l, lif ? "g_l" : nullptr, 10.0f));
 
@@ -622,6 +629,8 @@ int launch_update(snn_network *net)
     switch (net->model) {
     case SNN_MODEL_LIF: hipLaunchKernelGGL((k_update<1>), grid, dim3(256), 0, net->stream, a); break;
     case SNN_MODEL_HODGKIN_HUXLEY: hipLaunchKernelGGL((k_update<2>), grid, dim3(256), 0, net->stream, a); break;
+    case SNN_MODEL_QUADRATIC_INTEGRATE_AND_FIRE: hipLaunchKernelGGL((k_update<3>), grid, dim3(256), 0, net->stream, a); break;
+    case SNN_MODEL_SIMPLE_LIF: hipLaunchKernelGGL((k_update<4>), grid, dim3(256), 0, net->stream, a); break;
     default: hipLaunchKernelGGL((k_update<0>), grid, dim3(256), 0, net->stream, a); break;
     }
     HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
@@ -890,7 +899,7 @@ int snn_network_create(int device, int neuron_model, int nt_kinetics, int recept
 {
     if (!out) return fail(SNN_ERR_BAD_ARG, "out is null");
     *out = nullptr;
-    if (neuron_model < 0 || neuron_model > 2 || nt_kinetics < 0 || nt_kinetics > 1 || receptor_kinetics < 0 ||
+    if (neuron_model < 0 || neuron_model > 4 || nt_kinetics < 0 || nt_kinetics > 1 || receptor_kinetics < 0 ||
         receptor_kinetics > 1 || spike_train_model < 0 || spike_train_model > 2)
         return fail(SNN_ERR_BAD_ARG, "unknown model / kinetics selector");
     int ndev = 0;

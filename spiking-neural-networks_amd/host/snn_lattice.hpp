@@ -94,6 +94,31 @@ struct LeakyIntegrateAndFireNeuron : NeuronBase {   // integrate_and_fire/mod.rs
     }
 };
 
+struct QuadraticIntegrateAndFireNeuron : NeuronBase {   // integrate_and_fire/mod.rs:259-322 (has a reference GPU impl)
+    float v_reset = -75.0f, v_init = -75.0f, refractory_count = 0.0f, tref = 10.0f, alpha = 1.0f, v_c = -60.0f,
+          integration_constant = 1.0f, tau_m = 100.0f;
+    QuadraticIntegrateAndFireNeuron() { current_voltage = -75.0f; dt = 0.1f; c_m = 100.0f; v_th = -55.0f; }
+    static constexpr int MODEL = SNN_MODEL_QUADRATIC_INTEGRATE_AND_FIRE;
+    static std::vector<std::pair<const char *, float QuadraticIntegrateAndFireNeuron::*>> fields()
+    {
+        using T = QuadraticIntegrateAndFireNeuron;
+        return {{"v_reset", &T::v_reset}, {"refractory_count", &T::refractory_count}, {"tref", &T::tref},
+                {"alpha", &T::alpha}, {"v_c", &T::v_c}, {"integration_constant", &T::integration_constant},
+                {"tau_m", &T::tau_m}};
+    }
+};
+
+struct SimpleLeakyIntegrateAndFire : NeuronBase {       // integrate_and_fire/mod.rs:1523-1570 (has a reference GPU impl)
+    float g = -0.1f, e = 0.0f, v_reset = -75.0f, v_init = -75.0f;
+    SimpleLeakyIntegrateAndFire() { current_voltage = -75.0f; gap_conductance = 10.0f; dt = 0.1f; c_m = 100.0f; v_th = -55.0f; }
+    static constexpr int MODEL = SNN_MODEL_SIMPLE_LIF;
+    static std::vector<std::pair<const char *, float SimpleLeakyIntegrateAndFire::*>> fields()
+    {
+        using T = SimpleLeakyIntegrateAndFire;
+        return {{"g", &T::g}, {"e", &T::e}, {"v_reset", &T::v_reset}};
+    }
+};
+
 struct HodgkinHuxleyNeuron : NeuronBase {      // hodgkin_huxley/mod.rs:49-98, ion_channels/mod.rs:192-317
     float m_state = 0.0f, h_state = 0.0f, n_state = 0.0f;
     float g_na = 120.0f, e_na = 50.0f, g_k = 36.0f, e_k = -77.0f, g_k_leak = 0.3f, e_k_leak = -55.0f;

@@ -14,7 +14,8 @@ import enum
 
 import numpy as np
 
-from .network import (DeviceNetwork, HODGKIN_HUXLEY, IZHIKEVICH, LIF, NT_APPROXIMATE, NT_DESTEXHE,
+from .network import (DeviceNetwork, HODGKIN_HUXLEY, IZHIKEVICH, LIF, QUADRATIC_INTEGRATE_AND_FIRE, SIMPLE_LIF,
+                      NT_APPROXIMATE, NT_DESTEXHE,
                       RC_APPROXIMATE, RC_DESTEXHE, ST_NONE, ST_POISSON, ST_RATE)
 
 
@@ -126,6 +127,21 @@ class LeakyIntegrateAndFireNeuron(_Neuron):              # integrate_and_fire/mo
                      leak_constant=-1.0, integration_constant=1.0, gap_conductance=7.0, e_l=-75.0, g_l=10.0,
                      tau_m=10.0, c_m=100.0, dt=0.1, **_Neuron._common)
     state_fields = ("v_reset", "refractory_count", "tref", "leak_constant", "integration_constant", "e_l", "g_l", "tau_m")
+
+
+class QuadraticIntegrateAndFireNeuron(_Neuron):          # integrate_and_fire/mod.rs:259-322
+    model = QUADRATIC_INTEGRATE_AND_FIRE
+    _defaults = dict(current_voltage=-75.0, v_th=-55.0, v_reset=-75.0, v_init=-75.0, refractory_count=0.0, tref=10.0,
+                     alpha=1.0, v_c=-60.0, integration_constant=1.0, gap_conductance=7.0, tau_m=100.0, c_m=100.0,
+                     dt=0.1, **_Neuron._common)
+    state_fields = ("v_reset", "refractory_count", "tref", "alpha", "v_c", "integration_constant", "tau_m")
+
+
+class SimpleLeakyIntegrateAndFire(_Neuron):              # integrate_and_fire/mod.rs:1523-1570
+    model = SIMPLE_LIF
+    _defaults = dict(current_voltage=-75.0, g=-0.1, e=0.0, v_th=-55.0, v_reset=-75.0, v_init=-75.0,
+                     gap_conductance=10.0, c_m=100.0, dt=0.1, **_Neuron._common)
+    state_fields = ("g", "e", "v_reset")
 
 
 class HodgkinHuxleyNeuron(_Neuron):                      # hodgkin_huxley/mod.rs:49-98, ion_channels/mod.rs
@@ -710,6 +726,14 @@ IzhikevichNeuronLattice = _named(Lattice, "IzhikevichNeuronLattice", neuron_type
 LeakyIntegrateAndFireNeuronLattice = _named(Lattice, "LeakyIntegrateAndFireNeuronLattice",
                                             neuron_type=LeakyIntegrateAndFireNeuron)
 HodgkinHuxleyNeuronLattice = _named(Lattice, "HodgkinHuxleyNeuronLattice", neuron_type=HodgkinHuxleyNeuron)
+QuadraticIntegrateAndFireNeuronLattice = _named(Lattice, "QuadraticIntegrateAndFireNeuronLattice",
+                                                neuron_type=QuadraticIntegrateAndFireNeuron)
+SimpleLeakyIntegrateAndFireLattice = _named(Lattice, "SimpleLeakyIntegrateAndFireLattice",
+                                            neuron_type=SimpleLeakyIntegrateAndFire)
+QuadraticIntegrateAndFireNeuronLatticeGPU = _named(LatticeGPU, "QuadraticIntegrateAndFireNeuronLatticeGPU",
+                                                   lattice_type=QuadraticIntegrateAndFireNeuronLattice)
+SimpleLeakyIntegrateAndFireLatticeGPU = _named(LatticeGPU, "SimpleLeakyIntegrateAndFireLatticeGPU",
+                                               lattice_type=SimpleLeakyIntegrateAndFireLattice)
 IzhikevichNeuronLatticeGPU = _named(LatticeGPU, "IzhikevichNeuronLatticeGPU", lattice_type=IzhikevichNeuronLattice)
 LeakyIntegrateAndFireNeuronLatticeGPU = _named(LatticeGPU, "LeakyIntegrateAndFireNeuronLatticeGPU",
                                                lattice_type=LeakyIntegrateAndFireNeuronLattice)

@@ -13,7 +13,7 @@ import numpy as np
 
 from . import _lib
 
-IZHIKEVICH, LIF, HODGKIN_HUXLEY = 0, 1, 2
+IZHIKEVICH, LIF, HODGKIN_HUXLEY, QUADRATIC_INTEGRATE_AND_FIRE, SIMPLE_LIF = 0, 1, 2, 3, 4
 NT_APPROXIMATE, NT_DESTEXHE = 0, 1
 RC_APPROXIMATE, RC_DESTEXHE = 0, 1
 ST_NONE, ST_POISSON, ST_RATE = 0, 1, 2

@@ -55,6 +55,31 @@ def lif_step(s, i_in):
     return spike
 
 
+def qif_step(s, i_in):
+    """integrate_and_fire/mod.rs:324-345 + handle_spiking :87-102 (electrical only)."""
+    v = s["current_voltage"]
+    dv = ((((s["qif_alpha"] * (v - s["v_reset"]).astype(f32)).astype(f32) * (v - s["qif_v_c"]).astype(f32)).astype(f32) +
+           (s["integration_constant"] * i_in).astype(f32)).astype(f32) * (s["dt"] / s["tau_m"]).astype(f32)).astype(f32)
+    v_new = (v + dv).astype(f32)
+    rc = s["refractory_count"]
+    refr = rc > 0
+    spike = (~refr) & (v_new >= s["v_th"])
+    s["current_voltage"] = np.where(refr | spike, s["v_reset"], v_new).astype(f32)
+    s["refractory_count"] = np.where(refr, (rc - f32(1)).astype(f32),
+                                     np.where(spike, (s["tref"] / s["dt"]).astype(f32), rc)).astype(f32)
+    return spike
+
+
+def simple_lif_step(s, i_in):
+    """integrate_and_fire/mod.rs:1577-1605 (electrical only)."""
+    v = s["current_voltage"]
+    dv = (((s["slif_g"] * (v - s["slif_e"]).astype(f32)).astype(f32) + i_in).astype(f32) * s["dt"]).astype(f32)
+    v_new = (v + dv).astype(f32)
+    spike = v_new >= s["v_th"]
+    s["current_voltage"] = np.where(spike, s["v_reset"], v_new).astype(f32)
+    return spike
+
+
 def run_lattice(step_fn, s, g, weights, conn, steps):
     """run_lattice_electrical_synapses_only, neuron/mod.rs:1073-1088: returns (V history, raster)."""
     vh, sh = [], []

@@ -12,7 +12,7 @@ import numpy as np
 
 K = 3          # AMPA, NMDA, GABA
 CHUNK = 256
-IZHIKEVICH, LIF, HH = 0, 1, 2
+IZHIKEVICH, LIF, HH, QIF, SIMPLE_LIF = 0, 1, 2, 3, 4
 NT_APPROX, NT_DESTEXHE = 0, 1
 RC_APPROX, RC_DESTEXHE = 0, 1
 ST_NONE, ST_POISSON, ST_RATE = 0, 1, 2
@@ -61,6 +61,7 @@ _FIELDS = [
     ("input_current", f32p), ("input_t", f32p), ("input_count", f32p),
     ("n_threads", C.c_int32),
     ("w_col0", C.c_uint32), ("w_ld", C.c_uint32),
+    ("qif_alpha", f32p), ("qif_v_c", f32p), ("slif_g", f32p), ("slif_e", f32p),
 ]
 
 
@@ -130,6 +131,12 @@ NEURON_DEFAULTS = {
     # hodgkin_huxley/mod.rs:80-98, ion_channels/mod.rs:23-31,205-215,255-264,299-307
     HH: dict(current_voltage=-65.0, gap_conductance=7.0, dt=0.01, c_m=1.0, v_th=0.0,
              g_na=120.0, e_na=50.0, g_k=36.0, e_k=-77.0, g_k_leak=0.3, e_k_leak=-55.0),
+    # integrate_and_fire/mod.rs:299-322
+    QIF: dict(current_voltage=-75.0, refractory_count=0.0, integration_constant=1.0, gap_conductance=7.0,
+              qif_alpha=1.0, v_th=-55.0, v_reset=-75.0, qif_v_c=-60.0, tau_m=100.0, c_m=100.0, tref=10.0, dt=0.1),
+    # integrate_and_fire/mod.rs:1552-1570
+    SIMPLE_LIF: dict(current_voltage=-75.0, gap_conductance=10.0, v_th=-55.0, v_reset=-75.0, c_m=100.0,
+                     slif_g=-0.1, slif_e=0.0, dt=0.1),
 }
 # iterate_and_spike/mod.rs:174-182 (Approximate), :136-145 (Destexhe)
 NT_DEFAULTS = dict(nt_t=0.0, nt_t_max=1.0, nt_clearance=0.01, nt_v_p=2.0, nt_k_p=5.0)
@@ -143,7 +150,8 @@ ST_DEFAULTS = dict(st_current_voltage=0.0, st_v_th=30.0, st_v_resting=0.0, st_dt
 STDP_DEFAULTS = dict(stdp_a_plus=2.0, stdp_a_minus=2.0, stdp_tau_plus=4.5, stdp_tau_minus=4.5, stdp_dt=0.1)
 
 _NAMES = [n for n, _ in _FIELDS]
-_PER_NEURON = set(_NAMES[_NAMES.index("current_voltage"):_NAMES.index("was_increasing") + 1])
+_PER_NEURON = set(_NAMES[_NAMES.index("current_voltage"):_NAMES.index("was_increasing") + 1]) | {
+    "qif_alpha", "qif_v_c", "slif_g", "slif_e"}
 _PER_NEURON_K = {"nt_t", "nt_t_max", "nt_clearance", "nt_v_p", "nt_k_p", "nt_flags",
                  "rc_g", "rc_e", "rc_mg", "rc_r", "rc_alpha", "rc_beta", "rc_current", "rc_flags",
                  "input_t", "input_count"}

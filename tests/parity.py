@@ -13,6 +13,9 @@ MODEL_ATTRS = {
     ob.IZHIKEVICH: {k: k for k in ("w_value", "a", "b", "c", "d", "tau_m")},
     ob.LIF: {k: k for k in ("tau_m", "v_reset", "refractory_count", "tref", "leak_constant",
                             "integration_constant", "e_l", "g_l")},
+    ob.QIF: {"qif_alpha": "alpha", "qif_v_c": "v_c", "v_reset": "v_reset", "refractory_count": "refractory_count",
+             "tref": "tref", "integration_constant": "integration_constant", "tau_m": "tau_m"},
+    ob.SIMPLE_LIF: {"slif_g": "g", "slif_e": "e", "v_reset": "v_reset"},
     ob.HH: {"m_state": "na_channel$m$state", "h_state": "na_channel$h$state", "n_state": "k_channel$n$state",
             "m_alpha": "na_channel$m$alpha", "m_beta": "na_channel$m$beta",
             "h_alpha": "na_channel$h$alpha", "h_beta": "na_channel$h$beta",

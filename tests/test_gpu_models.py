@@ -108,3 +108,37 @@ def test_lif_chemical_only(snn):
     net["tref"] = 1.0
     net.fill_graph(18, 0.5, 1.5)
     compare(snn, net, 500)
+
+
+@pytest.mark.parametrize("chemical", [False, True])
+def test_quadratic_integrate_and_fire(snn, chemical):
+    """QuadraticIntegrateAndFireNeuron -- one of the two models the reference's own GPU path implements
+    (integrate_and_fire/mod.rs:368-917); buffer names alpha, v_c, v_reset, integration_constant, tau_m, ..."""
+    lay = parity.Layout([(0, 6, 7)])
+    net = parity.make_oracle(lay, model=ob.QIF, chemical=chemical)
+    n = net.n_neurons
+    net["current_voltage"] = ob.uniform_array(7, n, -75.0, -56.0)
+    net["gap_conductance"] = 3.0
+    net["tref"] = ob.uniform_array(8, n, 0.3, 1.5)
+    net["tau_m"] = 10.0
+    net["nt_flags"][:, 0] = 1
+    net["rc_flags"][:, 0] = 1
+    net.fill_graph(9, 0.5, 1.5)
+    compare(snn, net, 600, chunks=2)
+    assert net.spike_history.sum() > 0
+
+
+@pytest.mark.parametrize("chemical", [False, True])
+def test_simple_leaky_integrate_and_fire(snn, chemical):
+    """SimpleLeakyIntegrateAndFire (integrate_and_fire/mod.rs:1523-1801), buffer names g, e, v_reset."""
+    lay = parity.Layout([(0, 5, 8)])
+    net = parity.make_oracle(lay, model=ob.SIMPLE_LIF, chemical=chemical)
+    n = net.n_neurons
+    net["current_voltage"] = ob.uniform_array(9, n, -75.0, -56.0)
+    net["slif_g"] = 0.5
+    net["slif_e"] = -76.0
+    net["nt_flags"][:, 0] = 1
+    net["rc_flags"][:, 0] = 1
+    net.fill_graph(10, 0.5, 1.5)
+    compare(snn, net, 600, chunks=3)
+    assert net.spike_history.sum() > 0

@@ -41,3 +41,37 @@ def test_lif_lattice_matches_numpy():
     net.run(150, voltage_history=True, spike_history=True)
     assert np.array_equal(sh, net.spike_history)
     assert np.array_equal(vh.view(np.uint32), net.voltage_history.view(np.uint32))
+
+
+def test_qif_lattice_matches_numpy():
+    n = 20
+    net = ob.Net(n, model=ob.QIF)
+    net["current_voltage"] = ob.uniform_array(7, n, -75.0, -56.0)
+    net["gap_conductance"] = 3.0
+    net["tref"] = 0.7
+    net["tau_m"] = 10.0
+    net.fill_graph(8, 0.5, 1.5)
+    s = _state(net, ["current_voltage", "refractory_count", "qif_alpha", "qif_v_c", "integration_constant", "tau_m",
+                     "dt", "v_th", "v_reset", "tref"])
+    vh, sh, lft = nr.run_lattice(nr.qif_step, s, net["gap_conductance"].copy(), net["weights"].copy(),
+                                 net["connections"].copy(), 400)
+    net.run(400, voltage_history=True, spike_history=True)
+    assert sh.sum() > 0
+    assert np.array_equal(sh, net.spike_history)
+    assert np.array_equal(vh.view(np.uint32), net.voltage_history.view(np.uint32))
+
+
+def test_simple_lif_lattice_matches_numpy():
+    n = 20
+    net = ob.Net(n, model=ob.SIMPLE_LIF)
+    net["current_voltage"] = ob.uniform_array(9, n, -75.0, -56.0)
+    net["slif_g"] = 0.5                       # positive feedback so that cells cross threshold
+    net["slif_e"] = -76.0
+    net.fill_graph(10, 0.5, 1.5)
+    s = _state(net, ["current_voltage", "slif_g", "slif_e", "dt", "v_th", "v_reset"])
+    vh, sh, lft = nr.run_lattice(nr.simple_lif_step, s, net["gap_conductance"].copy(), net["weights"].copy(),
+                                 net["connections"].copy(), 400)
+    net.run(400, voltage_history=True, spike_history=True)
+    assert sh.sum() > 0
+    assert np.array_equal(sh, net.spike_history)
+    assert np.array_equal(vh.view(np.uint32), net.voltage_history.view(np.uint32))
