@@ -14,8 +14,10 @@
 // Mapping (wave64, gfx950): workgroup = 256 threads = 4 waves; a workgroup owns CHUNK = 256
 // consecutive presynaptic rows x 1024 consecutive postsynaptic columns; every lane owns 4 adjacent
 // columns, so one wave-row is ONE 1 KiB global_load_dwordx4 and a workgroup-row is 4 KiB contiguous.
-// blockIdx.x = column tile (fastest in dispatch order), blockIdx.y = row chunk: the workgroups in
-// flight at any moment sweep whole matrix rows, i.e. long contiguous HBM bursts.  The presynaptic
+// blockIdx.y = row chunk, blockIdx.x (fastest in dispatch order) = column tile rotated by the chunk index: the
+// workgroups in flight at any moment sweep whole matrix rows (long contiguous HBM bursts) while every XCD -- which
+// receives every 8th workgroup -- touches all column groups instead of a fixed eighth of them (measured: -17 % time
+// at 128x128, -2..3 % at 256x256).  The presynaptic
 // values of the chunk (voltages, spike-train values, neurotransmitter concentrations and flags) are
 // staged once in LDS and read back as wave-uniform broadcasts; the per-lane postsynaptic voltage and
 // gap conductance stay in registers.  No reuse of W exists (0.5 flop/byte), so there is nothing for
@@ -154,8 +156,12 @@ __global__ __launch_bounds__(InputsShape<STREAM>::THREADS) void k_inputs_dense(c
     }
     __syncthreads();
 
-    const uint32_t ql = blockIdx.x * S::TILE + tid * VEC;   // first of this lane's VEC local columns
-    if (ql >= a.ld) return;
+    // Column tile of this workgroup, rotated by the chunk index: workgroups are dealt round-robin over the 8
+    // XCDs, so with a power-of-two tile count an unrotated mapping would pin every XCD (and its L2 / fabric
+    // ports) to the same 1/8 of the columns for the whole pass.
+    const uint32_t tile = (blockIdx.x + blockIdx.y) % gridDim.x;
+    const uint32_t ql = tile * S::TILE + tid * VEC;          // first of this lane's VEC local columns
+    if (ql >= a.n_loc) return;                               // padding columns (n_loc .. ld) carry no neuron
 
     // ---- this lane's postsynaptic voltage / conductance, kept in registers ----
     float vq[VEC], gq[VEC];

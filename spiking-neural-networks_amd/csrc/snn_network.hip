@@ -592,11 +592,11 @@ int launch_inputs(snn_network *net, InputsPart part = INPUTS_ALL)
     // shape of the pass: cache-resident matrices take the latency-oriented one-wave shape; streamed matrices the
     // 4-columns-per-lane shape, or the 2-column shape while that would leave the chip under-filled
     const bool resident = (size_t)net->n_tot * net->ld * 4 <= ((size_t)64 << 20);
-    const uint64_t waves4 = (uint64_t)((net->ld + 255) / 256) * grid_chunks;
+    const uint64_t waves4 = (uint64_t)((net->n_loc + 255) / 256) * grid_chunks;
     const int shape = resident ? 0 : (waves4 < 8192 ? 2 : 1);     // 8192 = 256 CUs x 32 wave slots
 #define SNN_LAUNCH_SHAPE(E, C, SH)                                                                        \
     hipLaunchKernelGGL((k_inputs_dense<E, C, SH>),                                                       \
-                       dim3((net->ld + InputsShape<SH>::TILE - 1) / InputsShape<SH>::TILE, grid_chunks), \
+                       dim3((net->n_loc + InputsShape<SH>::TILE - 1) / InputsShape<SH>::TILE, grid_chunks), \
                        dim3(InputsShape<SH>::THREADS), 0, net->stream, a)
 #define SNN_LAUNCH_INPUTS(E, C)                                                                          \
     do {                                                                                                 \
@@ -697,8 +697,10 @@ int choose_matrix_placement(snn_network *net)
         net->profile = 0;
         float best_ms = 0.0f;
         int rc = time_input_pass(net, &best_ms);
-        // up to three more candidates, each allocated while the best so far is held (different HBM regions)
-        for (int cand = 0; cand < 3 && rc == SNN_OK; ++cand) {
+        // up to four more candidates; every loser stays allocated until the end so that each new candidate is
+        // forced into a different HBM region (a freed block would simply be handed out again)
+        std::vector<void *> losers;
+        for (int cand = 0; cand < 4 && rc == SNN_OK; ++cand) {
             size_t free_b = 0, total_b = 0;
             void *b = nullptr;
             if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + (bytes >> 2) ||
@@ -712,13 +714,14 @@ int choose_matrix_placement(snn_network *net)
                 fprintf(stderr, "[snn] matrix placement: held %p %.3f ms, candidate %p %.3f ms\n", (void *)a, best_ms, b, ms_b);
             if (rc == SNN_OK && ms_b < best_ms * 0.99f) {       // the candidate wins
                 for (auto &p : net->allocs) if (p == a) p = b;
-                (void)hipFree(a);
+                losers.push_back(a);
                 best_ms = ms_b;
             } else {
                 net->W = a;
-                (void)hipFree(b);
+                losers.push_back(b);
             }
         }
+        for (void *p : losers) (void)hipFree(p);
         net->profile = prof;
         if (rc != SNN_OK) return rc;
     }
