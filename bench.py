@@ -255,7 +255,8 @@ def main():
             "metric": "neuron-steps/sec", "value": value, "unit": "neuron-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
+            "scaling": "strong",      # --gpus N shards the SAME lattice: total work fixed as N grows
+            "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "neurons": n,
                        "parallelism": f"post-population shards x{world}" if world > 1 else "single GPU"},
