@@ -197,9 +197,10 @@ def main():
     if sharded:
         # everything stream-ordered on torch's current stream: kernels, the RCCL all-gather, kernels ... no host
         # synchronisation inside the step loop
-        dn.set_stream(torch.cuda.current_stream().cuda_stream)
+        side = torch.cuda.Stream()                      # a real (non-default) stream shared by kernels and RCCL ordering
+        dn.set_stream(side.cuda_stream)
         buf = parallel.exchange_tensor(dn, torch.device("cuda", local_rank))
-        stepper = parallel.ShardedStepper(dn, buf, rank, world, always_gather=True)
+        stepper = parallel.ShardedStepper(dn, buf, rank, world, always_gather=True, stream=side)
 
         def run(k):
             stepper.run(k)

@@ -195,8 +195,15 @@ class DeviceNetwork:
         return p.value, w.value, n.value
 
     def set_stream(self, hip_stream):
-        """adopt a caller's hipStream_t (int / None): step_begin / step_end then only enqueue"""
-        _lib.check(self._L.snn_set_stream(self._h, C.c_void_p(hip_stream) if hip_stream else None))
+        """Adopt a caller's hipStream_t (int handle): step_begin / step_end then only enqueue on it.
+        None returns to the handle's own stream.  The legacy default stream (handle 0) cannot be adopted --
+        create a real stream (e.g. torch.cuda.Stream()) so that collectives can be ordered against it."""
+        if hip_stream is None:
+            _lib.check(self._L.snn_set_stream(self._h, None))
+            return
+        if int(hip_stream) == 0:
+            raise ValueError("the default (null) stream cannot be adopted: pass a non-default stream handle")
+        _lib.check(self._L.snn_set_stream(self._h, C.c_void_p(int(hip_stream))))
 
     def synchronize(self):
         _lib.check(self._L.snn_synchronize(self._h))

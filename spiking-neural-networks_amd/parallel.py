@@ -49,7 +49,7 @@ class ShardedStepper:
     exchange buffer laid out [shard][plane][stride] so that shard r's block is contiguous.
     """
 
-    def __init__(self, backend, buf, rank, world_size, group=None, sync=None, always_gather=False):
+    def __init__(self, backend, buf, rank, world_size, group=None, sync=None, always_gather=False, stream=None):
         import torch.distributed as dist
         self.backend, self.buf, self.rank, self.world = backend, buf, rank, world_size
         self.group = group
@@ -59,6 +59,9 @@ class ShardedStepper:
         self.local = buf[rank * self.block:(rank + 1) * self.block]
         self._sync = sync or (lambda: None)
         self._always = always_gather        # run the collective even at world_size 1 (path check on one GPU)
+        # GPU backends: a NON-default torch.cuda.Stream that the backend has adopted (backend.set_stream); all
+        # kernels, the collective's stream dependencies and `work.wait()` are ordered on it
+        self.stream = stream
 
     def exchange(self, async_op=False):
         """all-gather the exchanged planes in place; async_op=True returns the pending work handle"""
@@ -77,7 +80,15 @@ class ShardedStepper:
         """`iterations` steps.  overlap (GPU backends): the collective of step t runs on RCCL's stream while
         step t+1's synaptic-input pass over the shard's OWN presynaptic rows is already executing; only the
         rows fed by other shards wait for it (backend.step_begin_local, a no-op when it would not be valid)."""
-        overlap = overlap and self.buf.is_cuda and hasattr(self.backend, "step_begin_local")
+        overlap = overlap and self.buf.is_cuda and hasattr(self.backend, "step_begin_local") and self.stream is not None
+        if self.stream is not None:
+            import torch
+            with torch.cuda.stream(self.stream):     # collectives synchronise with the CURRENT stream: make it ours
+                self._run(iterations, overlap)
+        else:
+            self._run(iterations, overlap)
+
+    def _run(self, iterations, overlap):
         if not overlap:
             for _ in range(int(iterations)):
                 self.backend.step_begin()

@@ -19,12 +19,15 @@ def free_port():
         return s.getsockname()[1]
 
 
+@pytest.mark.timeout(600)
 def test_sharded_stepper_over_rccl_world_size_1(snn):
     import torch
     import torch.distributed as dist
     from snn_amd import parallel
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(free_port())
+    os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")        # single node: no interface discovery
+    os.environ.setdefault("NCCL_IB_DISABLE", "1")
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
@@ -44,14 +47,18 @@ def test_sharded_stepper_over_rccl_world_size_1(snn):
         v = dn.get_attr(0, "current_voltage")
         assert np.array_equal(v.view(np.uint32), net["current_voltage"].view(np.uint32))
         # stream-ordered, as bench.py --gpus N does it: no host synchronisation inside the loop
-        dn.set_stream(torch.cuda.current_stream().cuda_stream)
-        for _ in range(200):
-            dn.step_begin()
-            dist.all_gather_into_tensor(buf, buf[0:buf.numel()])
-            dn.step_end()
+        side = torch.cuda.Stream()
+        with pytest.raises(ValueError):
+            dn.set_stream(0)                      # the legacy default stream cannot be adopted
+        dn.set_stream(side.cuda_stream)
+        with torch.cuda.stream(side):
+            for _ in range(200):
+                dn.step_begin()
+                dist.all_gather_into_tensor(buf, buf[0:buf.numel()])
+                dn.step_end()
         dn.synchronize()
         # the overlapped schedule of ShardedStepper.run (step_begin_local before the previous gather is waited for)
-        stepper = parallel.ShardedStepper(dn, buf, 0, 1, always_gather=True)
+        stepper = parallel.ShardedStepper(dn, buf, 0, 1, always_gather=True, stream=side)
         dn.set_plasticity(0, do_plasticity=False)
         net["do_plasticity"] = 0
         net.run(200)

@@ -95,18 +95,19 @@ def test_stream_ordered_stepping_without_host_sync(snn):
     net = build(False)
     n_shards, steps = 2, 250
     handles = [parity.device_from_oracle(snn, net, shard=(r, n_shards)) for r in range(n_shards)]
-    stream = torch.cuda.current_stream().cuda_stream
+    side = torch.cuda.Stream()
     for h in handles:
-        h.set_stream(stream)
+        h.set_stream(side.cuda_stream)
     bufs = [parallel.exchange_tensor(h, torch.device("cuda", 0)) for h in handles]
     block = bufs[0].numel() // n_shards
-    for _ in range(steps):
-        for h in handles:
-            h.step_begin()
-        for r in range(n_shards):
-            bufs[1 - r][r * block:(r + 1) * block].copy_(bufs[r][r * block:(r + 1) * block], non_blocking=True)
-        for h in handles:
-            h.step_end()
+    with torch.cuda.stream(side):
+        for _ in range(steps):
+            for h in handles:
+                h.step_begin()
+            for r in range(n_shards):
+                bufs[1 - r][r * block:(r + 1) * block].copy_(bufs[r][r * block:(r + 1) * block], non_blocking=True)
+            for h in handles:
+                h.step_end()
     for h in handles:
         h.synchronize()
     net.run(steps)
