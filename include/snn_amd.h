@@ -204,6 +204,24 @@ int snn_history_steps(const snn_network_t *net, uint64_t *steps);
 int snn_get_voltage_history(snn_network_t *net, uint32_t id, float *dst, size_t count);
 int snn_get_spike_history(snn_network_t *net, uint32_t id, uint8_t *dst, size_t count);
 
+/* Strided capture: store the history rows (voltage, raster, reduced rows) of every `every`-th step only -- steps
+ * 0, every, 2*every, ... counted from the last (re)start of the record; 1 = every step (the reference's
+ * behaviour).  Changing the stride restarts the record.  Spike totals (below) always count every step. */
+int snn_set_history_stride(snn_network_t *net, uint32_t every);
+
+/* Reduced histories computed on the device, so that observing a long run does not need the T x N voltage
+ * history: per step and neuron lattice the AverageVoltageHistory value (neuron/mod.rs:305-322) and the EEGHistory
+ * value (:233-284; defaults reference_voltage 0.007, distance 0.8, conductivity 251), and per neuron the spike total
+ * of SpikeHistory::aggregate (:331-360; accumulates until snn_reset_history).  The sums use the canonical
+ * 256-chunk order (the reference adds strictly sequentially).  A shard handle reduces over whole lattices (after
+ * the exchange it holds every shard's voltages); its spike totals cover the neurons it owns.  Rows share the step
+ * axis of snn_history_steps; switching the average or the EEG rows on or off restarts that axis. */
+int snn_set_reduced_history(snn_network_t *net, int average_voltage, int eeg, int spike_counts,
+                            float reference_voltage, float distance, float conductivity);
+int snn_get_average_voltage_history(snn_network_t *net, uint32_t id, float *dst, size_t steps);
+int snn_get_eeg_history(snn_network_t *net, uint32_t id, float *dst, size_t steps);
+int snn_get_spike_counts(snn_network_t *net, uint32_t id, uint32_t *dst, size_t count);
+
 /* ---- measurement ----------------------------------------------------------------------- */
 
 /* When enabled, every launch of the synaptic-input kernel is bracketed by HIP events on the

@@ -599,6 +599,35 @@ void snn_o_spike_trains(snn_o_net *n)
     for (uint32_t l = 0; l < n->n_st_lattices; ++l) n->st_clock[l] += 1;
 }
 
+/* ---------- reduced histories ---------- */
+
+/* AverageVoltageHistory::update neuron/mod.rs:311-317: sum / length; EEGHistory::update :262-277:
+ * (1 / (4 * PI * conductivity * distance)) * sum(V - reference_voltage).  Chunked canonical order. */
+static void lattice_summaries(snn_o_net *n, uint64_t it)
+{
+    const float pi = 3.14159274101257324f;       /* std::f32::consts::PI */
+    for (uint32_t l = 0; l < n->n_lattices; ++l) {
+        const uint32_t first = n->lattice_first[l], count = n->lattice_count[l];
+        float tot = 0.0f, tot_e = 0.0f;
+        for (uint32_t c0 = 0; c0 < count; c0 += SNN_O_CHUNK) {
+            uint32_t c1 = c0 + SNN_O_CHUNK;
+            if (c1 > count) c1 = count;
+            float part = 0.0f, part_e = 0.0f;
+            for (uint32_t i = c0; i < c1; ++i) {
+                const float v = n->current_voltage[first + i];
+                part += v;
+                part_e += v - n->eeg_reference_voltage;
+            }
+            tot += part;
+            tot_e += part_e;
+        }
+        if (n->avg_history) n->avg_history[it * n->n_lattices + l] = tot / (float)count;
+        if (n->eeg_history)
+            n->eeg_history[it * n->n_lattices + l] =
+                (1.0f / (4.0f * pi * n->eeg_conductivity * n->eeg_distance)) * tot_e;
+    }
+}
+
 /* ---------- whole loop ---------- */
 
 /* run_lattice_* neuron/mod.rs:1035-1088, run_lattices_* :2598-2651; (false,false) is a no-op :1217 */
@@ -616,6 +645,9 @@ void snn_o_run(snn_o_net *n, uint64_t iterations)
             if (n->spike_history)
                 for (uint32_t q = 0; q < n->n_neurons; ++q)
                     n->spike_history[(size_t)it * n->n_neurons + q] = (uint8_t)n->is_spiking[q];
+            if (n->spike_counts)
+                for (uint32_t q = 0; q < n->n_neurons; ++q) n->spike_counts[q] += n->is_spiking[q] ? 1u : 0u;
+            if (n->avg_history || n->eeg_history) lattice_summaries(n, it);
         }
         n->clock += 1;
         if (n->n_cells) {

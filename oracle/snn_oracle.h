@@ -133,6 +133,14 @@ typedef struct snn_o_net {
      * integration_constant, tau_m with LIF) and SimpleLeakyIntegrateAndFire (:1523-1575; shares v_reset) -- the two
      * models the reference's own GPU path implements */
     float    *qif_alpha, *qif_v_c, *slif_g, *slif_e;
+    /* Reduced per-lattice histories (AverageVoltageHistory neuron/mod.rs:305-322, EEGHistory :233-284) and
+     * SpikeHistory::aggregate (:331-360).  Lattice l owns neurons [lattice_first[l], +lattice_count[l]).  Sums use
+     * the canonical chunked order (chunks of SNN_O_CHUNK consecutive neurons of the lattice); the reference sums
+     * strictly sequentially -- deterministic, but not parallelisable, see DESIGN.md. */
+    uint32_t *lattice_first, *lattice_count;   /* [n_lattices] */
+    float    *avg_history, *eeg_history;       /* [iterations][n_lattices] or NULL */
+    float    eeg_reference_voltage, eeg_distance, eeg_conductivity;
+    uint32_t *spike_counts;                    /* [n_neurons] accumulated over the run, or NULL */
 } snn_o_net;
 
 /* Step 1 of SURVEY §8(g): electrical + chemical inputs for every neuron from state S(t). */

@@ -211,6 +211,53 @@ __global__ void k_stamp_remote(const float *xbuf, XLayout xl, int32_t *last_firi
     if (reinterpret_cast<const uint32_t *>(xbuf)[xl.at(q, PLANE_SPIKE)]) last_firing_time[q] = (int32_t)clock;
 }
 
+// ---- reduced per-lattice histories ---------------------------------------------------------------
+// AverageVoltageHistory (neuron/mod.rs:305-322) and EEGHistory (:233-284) on the device: one float per lattice
+// and step instead of the T x N voltage history.  One workgroup per lattice; every thread sums one 256-neuron
+// chunk sequentially, thread 0 adds the chunk partials in ascending order -- the canonical chunked order the
+// oracle uses (the reference sums strictly sequentially).
+struct SummaryArgs {
+    const float *xbuf;
+    XLayout xl;
+    const uint32_t *first, *count;     // [n_lattices]
+    float *avg_row, *eeg_row;          // this step's rows [n_lattices] (either may be null)
+    float reference_voltage, distance, conductivity;
+};
+
+__global__ __launch_bounds__(256) void k_lattice_summary(const SummaryArgs a)
+{
+    __shared__ float s_sum[256], s_eeg[256];
+    const uint32_t l = blockIdx.x;
+    const uint32_t first = a.first[l], count = a.count[l];
+    const uint32_t n_chunks = (count + CHUNK - 1) / CHUNK;
+    float tot = 0.0f, tot_e = 0.0f;
+    for (uint32_t g = 0; g < n_chunks; g += 256) {
+        const uint32_t c = g + threadIdx.x;
+        float part = 0.0f, part_e = 0.0f;
+        if (c < n_chunks) {
+            const uint32_t i1 = min(count, (c + 1) * CHUNK);
+            for (uint32_t i = c * CHUNK; i < i1; ++i) {
+                const float v = a.xbuf[a.xl.at(first + i, PLANE_V)];
+                part += v;
+                part_e += v - a.reference_voltage;
+            }
+        }
+        s_sum[threadIdx.x] = part;
+        s_eeg[threadIdx.x] = part_e;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t m = min(256u, n_chunks - g);
+            for (uint32_t t = 0; t < m; ++t) { tot += s_sum[t]; tot_e += s_eeg[t]; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float pi = 3.14159274101257324f;     // std::f32::consts::PI
+        if (a.avg_row) a.avg_row[l] = tot / (float)count;
+        if (a.eeg_row) a.eeg_row[l] = (1.0f / (4.0f * pi * a.conductivity * a.distance)) * tot_e;
+    }
+}
+
 // HBM ceilings of THIS device, measured with the access shape of k_inputs_dense (16 B per lane, nt):
 // read-only stream (what the synaptic-input pass can reach at best) and read+write copy.
 typedef float probe_v4f __attribute__((ext_vector_type(4)));

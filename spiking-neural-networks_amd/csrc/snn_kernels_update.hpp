@@ -27,6 +27,7 @@ struct UpdateArgs {
     int electrical, chemical, nt_kind, rc_kind;
     float *vhist_row;          // this step's row of the voltage history (global neuron index) or null
     unsigned long long *spike_row;   // this step's row of the bit-packed raster or null
+    uint32_t *spike_counts;          // per-neuron spike totals (SpikeHistory::aggregate) or null
 };
 
 // Second level of the canonical sum: chunk partials added in ascending chunk order from 0.0f.  The loads of
@@ -259,6 +260,7 @@ __global__ __launch_bounds__(256) void k_update(const UpdateArgs a)
         *sptr = spike;
         if (spike) a.n.last_firing_time[q] = (int32_t)a.clock;   // neuron/mod.rs:964-966, 2555-2557
         if (a.vhist_row) a.vhist_row[q] = v_new;
+        if (a.spike_counts && spike) a.spike_counts[q] += 1;
     }
 
     // spike raster: one 64-bit ballot word per wavefront (shard boundaries are multiples of 64)

@@ -115,7 +115,14 @@ struct snn_network {
 
     // histories
     int want_vhist = 0, want_raster = 0;
+    // reduced histories: per-lattice average voltage / EEG value per step, per-neuron spike totals
+    int want_avg = 0, want_eeg = 0, want_counts = 0;
+    float eeg_ref = 0.007f, eeg_dist = 0.8f, eeg_cond = 251.0f;     // EEGHistory defaults, neuron/mod.rs:246-255
+    float *summ_avg = nullptr, *summ_eeg = nullptr;                 // [cap][n_lattices]
+    uint32_t *spike_counts = nullptr, *lat_first_dev = nullptr, *lat_count_dev = nullptr;
     uint64_t hist_steps = 0, hist_cap = 0;
+    uint64_t hist_tick = 0;                // steps seen since the record was (re)started
+    uint32_t hist_every = 1;               // a row is stored when hist_tick % hist_every == 0
     float *vhist = nullptr, *st_vhist = nullptr;
     unsigned long long *raster = nullptr;
 
@@ -127,6 +134,18 @@ struct snn_network {
     uint64_t prof_launches = 0;
     double prof_ms = 0.0;
 };
+
+namespace {
+inline bool recording(const snn_network *net)
+{
+    return net->want_vhist || net->want_raster || net->want_avg || net->want_eeg;
+}
+// does the step being computed store its history rows (strided capture: every hist_every-th step)
+inline bool record_now(const snn_network *net)
+{
+    return recording(net) && net->hist_tick % net->hist_every == 0;
+}
+} // namespace
 
 namespace {
 
@@ -331,6 +350,16 @@ int build_state(snn_network *net)
     TRY(fill_u32(net, net->lattice_slot, np, 0));
     for (const auto &l : net->lattices) TRY(fill_u32(net, net->lattice_slot + l.first, l.count, l.slot));
     const size_t nl = std::max<size_t>(1, net->lattices.size());
+    {
+        std::vector<uint32_t> lf(nl, 0), lc(nl, 0);
+        for (const auto &l : net->lattices) { lf[l.slot] = l.first; lc[l.slot] = l.count; }
+        TRY(dev_alloc_t(net, &net->lat_first_dev, nl));
+        TRY(dev_alloc_t(net, &net->lat_count_dev, nl));
+        HIP_TRY(hipMemcpy(net->lat_first_dev, lf.data(), nl * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
+        HIP_TRY(hipMemcpy(net->lat_count_dev, lc.data(), nl * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
+        TRY(dev_alloc_t(net, &net->spike_counts, np));
+        TRY(fill_u32(net, net->spike_counts, np, 0));
+    }
     net->stdp_host.assign(nl * 5, 0.0f);
     net->plast_host.assign(nl, 0);
     for (size_t l = 0; l < nl; ++l) {   // plasticity/mod.rs:29-39
@@ -524,7 +553,7 @@ int launch_spike_trains(snn_network *net, int iterate, long long step_offset, lo
     a.c = net->ca; a.n_cells = net->nc; a.st_kind = net->st_kind; a.nt_kind = net->nt_kind;
     a.iterate = iterate; a.lattice_clock = net->st_clock_dev; a.step_offset = step_offset;
     a.view_clock = view_clock;
-    a.vhist_row = (iterate && net->want_vhist && net->st_vhist) ? net->st_vhist + (size_t)net->hist_steps * net->c_pad : nullptr;
+    a.vhist_row = (iterate && record_now(net) && net->want_vhist && net->st_vhist) ? net->st_vhist + (size_t)net->hist_steps * net->c_pad : nullptr;
     hipLaunchKernelGGL(k_spike_trains, dim3((net->nc + 255) / 256), dim3(256), 0, net->stream, a);
     HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
     return SNN_OK;
@@ -623,8 +652,9 @@ int launch_update(snn_network *net)
     a.ld = net->ld; a.n_chunks = net->n_tot ? net->n_chunks : 0; a.q0 = net->q0; a.n_loc = net->n_loc;
     a.clock = net->clock;
     a.electrical = net->electrical; a.chemical = net->chemical; a.nt_kind = net->nt_kind; a.rc_kind = net->rc_kind;
-    a.vhist_row = (net->want_vhist && net->vhist) ? net->vhist + (size_t)net->hist_steps * net->n_pad : nullptr;
-    a.spike_row = (net->want_raster && net->raster) ? net->raster + (size_t)net->hist_steps * (net->n_pad / 64) : nullptr;
+    a.vhist_row = (record_now(net) && net->want_vhist && net->vhist) ? net->vhist + (size_t)net->hist_steps * net->n_pad : nullptr;
+    a.spike_row = (record_now(net) && net->want_raster && net->raster) ? net->raster + (size_t)net->hist_steps * (net->n_pad / 64) : nullptr;
+    a.spike_counts = net->want_counts ? net->spike_counts : nullptr;
     dim3 grid((net->ld + 255) / 256);
     switch (net->model) {
     case SNN_MODEL_LIF: hipLaunchKernelGGL((k_update<1>), grid, dim3(256), 0, net->stream, a); break;
@@ -752,18 +782,32 @@ int step_end(snn_network *net)
         HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
     }
     TRY(launch_plasticity(net));
+    if ((net->want_avg || net->want_eeg) && record_now(net) && !net->lattices.empty()) {
+        // after the exchange, so that a sharded handle reduces over every lattice's full population
+        const size_t nl = net->lattices.size();
+        SummaryArgs sa{};
+        sa.xbuf = net->xbuf; sa.xl = net->xl; sa.first = net->lat_first_dev; sa.count = net->lat_count_dev;
+        sa.avg_row = net->want_avg ? net->summ_avg + (size_t)net->hist_steps * nl : nullptr;
+        sa.eeg_row = net->want_eeg ? net->summ_eeg + (size_t)net->hist_steps * nl : nullptr;
+        sa.reference_voltage = net->eeg_ref; sa.distance = net->eeg_dist; sa.conductivity = net->eeg_cond;
+        hipLaunchKernelGGL(k_lattice_summary, dim3((unsigned)nl), dim3(256), 0, net->stream, sa);
+        HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+    }
     net->clock += 1;
     TRY(launch_spike_trains(net, 1, net->run_step_offset, net->clock));
     net->run_step_offset += 1;
-    if (net->want_vhist || net->want_raster) net->hist_steps += 1;
+    if (record_now(net)) net->hist_steps += 1;
+    if (recording(net)) net->hist_tick += 1;
     return SNN_OK;
 }
 
 int grow_history(snn_network *net, uint64_t extra)
 {
-    if (!net->want_vhist && !net->want_raster) return SNN_OK;
-    const uint64_t need = net->hist_steps + extra;
-    if (need <= net->hist_cap && (!net->want_vhist || net->vhist) && (!net->want_raster || net->raster)) return SNN_OK;
+    if (!recording(net)) return SNN_OK;
+    const uint64_t need = net->hist_steps + (extra + net->hist_every - 1) / net->hist_every + 1;
+    if (need <= net->hist_cap && (!net->want_vhist || net->vhist) && (!net->want_raster || net->raster) &&
+        (!net->want_avg || net->summ_avg) && (!net->want_eeg || net->summ_eeg))
+        return SNN_OK;
     const uint64_t cap = std::max<uint64_t>(need, net->hist_cap + net->hist_cap / 2);   // geometric: O(T) copies overall
     auto regrow = [&](void **buf, size_t row_bytes, bool wanted) -> int {
         if (!wanted || row_bytes == 0) return SNN_OK;
@@ -780,6 +824,8 @@ int grow_history(snn_network *net, uint64_t extra)
     TRY(regrow(reinterpret_cast<void **>(&net->vhist), (size_t)net->n_pad * 4, net->want_vhist));
     TRY(regrow(reinterpret_cast<void **>(&net->st_vhist), (size_t)net->c_pad * 4, net->want_vhist));
     TRY(regrow(reinterpret_cast<void **>(&net->raster), (size_t)(net->n_pad / 64) * 8, net->want_raster));
+    TRY(regrow(reinterpret_cast<void **>(&net->summ_avg), net->lattices.size() * 4, net->want_avg));
+    TRY(regrow(reinterpret_cast<void **>(&net->summ_eeg), net->lattices.size() * 4, net->want_eeg));
     net->hist_cap = cap;
     return SNN_OK;
 }
@@ -935,6 +981,8 @@ int snn_network_destroy(snn_network_t *net)
     if (net->vhist) (void)hipFree(net->vhist);
     if (net->st_vhist) (void)hipFree(net->st_vhist);
     if (net->raster) (void)hipFree(net->raster);
+    if (net->summ_avg) (void)hipFree(net->summ_avg);
+    if (net->summ_eeg) (void)hipFree(net->summ_eeg);
     for (auto &e : net->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (net->own_stream) (void)hipStreamDestroy(net->own_stream);
     delete net;
@@ -1239,7 +1287,7 @@ int snn_set_history(snn_network_t *net, int voltage_history, int spike_history)
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
     if ((voltage_history != 0) != (net->want_vhist != 0) || (spike_history != 0) != (net->want_raster != 0)) {
         // switching what is recorded restarts the record so that all rows cover the same steps
-        net->hist_steps = 0;
+        net->hist_steps = 0; net->hist_tick = 0;
     }
     net->want_vhist = voltage_history ? 1 : 0;
     net->want_raster = spike_history ? 1 : 0;
@@ -1249,7 +1297,72 @@ int snn_set_history(snn_network_t *net, int voltage_history, int spike_history)
 int snn_reset_history(snn_network_t *net)
 {
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
-    net->hist_steps = 0;
+    net->hist_steps = 0; net->hist_tick = 0;
+    if (net->finalized && net->spike_counts) {
+        HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
+        TRY(end_run(net));
+        HIP_TRY(hipMemset(net->spike_counts, 0, (size_t)net->n_pad * 4), SNN_ERR_BUFFER_WRITE);
+    }
+    return SNN_OK;
+}
+
+int snn_set_history_stride(snn_network_t *net, uint32_t every)
+{
+    if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
+    if (every == 0) return fail(SNN_ERR_BAD_ARG, "stride must be at least 1");
+    if (every != net->hist_every) { net->hist_steps = 0; net->hist_tick = 0; }
+    net->hist_every = every;
+    return SNN_OK;
+}
+
+int snn_set_reduced_history(snn_network_t *net, int average_voltage, int eeg, int spike_counts,
+                            float reference_voltage, float distance, float conductivity)
+{
+    if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
+    if ((average_voltage != 0) != (net->want_avg != 0) || (eeg != 0) != (net->want_eeg != 0))
+        net->hist_steps = 0, net->hist_tick = 0;      // all recorded rows must cover the same steps
+    net->want_avg = average_voltage ? 1 : 0;
+    net->want_eeg = eeg ? 1 : 0;
+    net->want_counts = spike_counts ? 1 : 0;
+    net->eeg_ref = reference_voltage; net->eeg_dist = distance; net->eeg_cond = conductivity;
+    return SNN_OK;
+}
+
+static int get_summary(snn_network_t *net, uint32_t id, float *dst, size_t steps, bool eeg)
+{
+    if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
+    if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
+    const LatticeInfo *l = find_lattice(net, id);
+    if (!l || l->spike_train) return fail(SNN_ERR_BAD_ARG, "reduced histories exist for neuron lattices");
+    if (!(eeg ? net->want_eeg : net->want_avg)) return fail(SNN_ERR_BAD_STATE, "this reduced history is off");
+    if (steps != net->hist_steps) return fail(SNN_ERR_DIM_MISMATCH, "history size mismatch");
+    if (steps == 0) return SNN_OK;
+    if (!dst) return fail(SNN_ERR_BAD_ARG, "dst is null");
+    HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
+    TRY(end_run(net));
+    const size_t nl = net->lattices.size();
+    const float *src = (eeg ? net->summ_eeg : net->summ_avg) + l->slot;
+    HIP_TRY(hipMemcpy2D(dst, 4, src, nl * 4, 4, steps, hipMemcpyDeviceToHost), SNN_ERR_BUFFER_READ);
+    return SNN_OK;
+}
+
+int snn_get_average_voltage_history(snn_network_t *net, uint32_t id, float *dst, size_t steps)
+{ return get_summary(net, id, dst, steps, false); }
+int snn_get_eeg_history(snn_network_t *net, uint32_t id, float *dst, size_t steps)
+{ return get_summary(net, id, dst, steps, true); }
+
+int snn_get_spike_counts(snn_network_t *net, uint32_t id, uint32_t *dst, size_t count)
+{
+    if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
+    if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
+    const LatticeInfo *l = find_lattice(net, id);
+    if (!l || l->spike_train) return fail(SNN_ERR_BAD_ARG, "spike counts exist for neuron lattices");
+    if (count != l->count) return fail(SNN_ERR_DIM_MISMATCH, "count must equal rows*cols");
+    if (count == 0) return SNN_OK;
+    if (!dst) return fail(SNN_ERR_BAD_ARG, "dst is null");
+    HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
+    TRY(end_run(net));
+    HIP_TRY(hipMemcpy(dst, net->spike_counts + l->first, count * 4, hipMemcpyDeviceToHost), SNN_ERR_BUFFER_READ);
     return SNN_OK;
 }
 

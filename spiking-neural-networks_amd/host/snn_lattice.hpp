@@ -550,9 +550,39 @@ public:
     }
     snn_network_t *handle() const { return h_; }
 
+    // Reduced histories kept on the device (the CPU lattices' AverageVoltageHistory / EEGHistory /
+    // SpikeHistory::aggregate, neuron/mod.rs:233-360) and strided capture of every history row.
+    void set_reduced_history(bool average_voltage, bool eeg, bool spike_counts, float reference_voltage = 0.007f,
+                             float distance = 0.8f, float conductivity = 251.0f)
+    {
+        check(snn_set_reduced_history(h_, average_voltage, eeg, spike_counts, reference_voltage, distance, conductivity));
+    }
+    void set_history_stride(uint32_t every) { check(snn_set_history_stride(h_, every)); }
+    std::vector<float> average_voltage_history(size_t id) { return reduced(id, false); }
+    std::vector<float> eeg_history(size_t id) { return reduced(id, true); }
+    std::vector<std::vector<uint32_t>> spike_counts(size_t id)
+    {
+        const auto &l = network.lattices.at(id);
+        std::vector<uint32_t> flat(l.rows() * l.cols());
+        check(snn_get_spike_counts(h_, (uint32_t)id, flat.data(), flat.size()));
+        std::vector<std::vector<uint32_t>> out(l.rows(), std::vector<uint32_t>(l.cols()));
+        for (size_t r = 0; r < l.rows(); ++r)
+            for (size_t c = 0; c < l.cols(); ++c) out[r][c] = flat[r * l.cols() + c];
+        return out;
+    }
+
 private:
     snn_network_t *h_ = nullptr;
     void release() { if (h_) { snn_network_destroy(h_); h_ = nullptr; } }
+
+    std::vector<float> reduced(size_t id, bool eeg)
+    {
+        uint64_t steps = 0;
+        check(snn_history_steps(h_, &steps));
+        std::vector<float> out(steps);
+        check((eeg ? snn_get_eeg_history : snn_get_average_voltage_history)(h_, (uint32_t)id, out.data(), out.size()));
+        return out;
+    }
 
     void upload()
     {

@@ -606,6 +606,25 @@ class LatticeNetworkGPU:
         l = self.network.lattices.get(id) or self.network.spike_train_lattices[id]
         return self._dn.voltage_history(id).reshape(-1, l.rows, l.cols)
 
+    # Reduced histories kept on the device (the CPU lattices' other LatticeHistory types, neuron/mod.rs:233-360;
+    # the reference's GPU lattices only carry GridVoltageHistory).
+    def set_reduced_history(self, average_voltage=False, eeg=False, spike_counts=False,
+                            reference_voltage=0.007, distance=0.8, conductivity=251.0):
+        self._dn.set_reduced_history(average_voltage, eeg, spike_counts, reference_voltage, distance, conductivity)
+
+    def average_voltage_history(self, id):
+        """one value per step (AverageVoltageHistory, neuron/mod.rs:305-322)"""
+        return self._dn.average_voltage_history(id)
+
+    def eeg_history(self, id):
+        """one value per step (EEGHistory, neuron/mod.rs:233-284)"""
+        return self._dn.eeg_history(id)
+
+    def spike_counts(self, id):
+        """[rows][cols] spike totals since the last reset (SpikeHistory::aggregate, neuron/mod.rs:331-360)"""
+        l = self.network.lattices[id]
+        return self._dn.spike_counts(id).reshape(l.rows, l.cols)
+
     def reset_history(self):
         self._dn.reset_history()
 

@@ -233,6 +233,30 @@ class DeviceNetwork:
         _lib.check(self._L.snn_get_spike_history(self._h, id, out.ctypes.data_as(_lib.u8p), out.size))
         return out
 
+    def set_history_stride(self, every):
+        _lib.check(self._L.snn_set_history_stride(self._h, int(every)))
+
+    def set_reduced_history(self, average_voltage=False, eeg=False, spike_counts=False,
+                            reference_voltage=0.007, distance=0.8, conductivity=251.0):
+        _lib.check(self._L.snn_set_reduced_history(self._h, int(average_voltage), int(eeg), int(spike_counts),
+                                                   reference_voltage, distance, conductivity))
+
+    def average_voltage_history(self, id):
+        out = np.empty(self.history_steps(), np.float32)
+        _lib.check(self._L.snn_get_average_voltage_history(self._h, id, out.ctypes.data_as(_lib.f32p), out.size))
+        return out
+
+    def eeg_history(self, id):
+        out = np.empty(self.history_steps(), np.float32)
+        _lib.check(self._L.snn_get_eeg_history(self._h, id, out.ctypes.data_as(_lib.f32p), out.size))
+        return out
+
+    def spike_counts(self, id):
+        rows, cols, _ = self.lattices[id]
+        out = np.empty(rows * cols, np.uint32)
+        _lib.check(self._L.snn_get_spike_counts(self._h, id, out.ctypes.data_as(_lib.u32p), out.size))
+        return out
+
     # ---- measurement ----------------------------------------------------------------------
     def profile_enable(self, on=True):
         _lib.check(self._L.snn_profile_enable(self._h, int(on)))

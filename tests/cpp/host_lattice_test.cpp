@@ -72,7 +72,13 @@ int main(int argc, char **argv)
         try { net.add_lattice(l1); } catch (const LatticeNetworkError &) { dup = true; }   // GraphIDAlreadyPresent
         if (!dup) return 3;
         auto gnet = LatticeNetworkGPU<IzhikevichNeuron, RateSpikeTrain>::from_network(net);
+        gnet.set_reduced_history(true, true, true);
         gnet.run_lattices(400);
+        dump(out + "/network_average_voltage.f32", gnet.average_voltage_history(1));
+        dump(out + "/network_eeg.f32", gnet.eeg_history(1));
+        std::vector<float> counts;
+        for (const auto &row : gnet.spike_counts(1)) for (uint32_t c : row) counts.push_back((float)c);
+        dump(out + "/network_spike_counts.f32", counts);
         std::vector<float> wout;
         const auto &m = gnet.network.lattices.at(1).graph.matrix;
         for (const auto &row : m) for (const auto &w : row) wout.push_back(w ? *w : NAN);

@@ -62,6 +62,9 @@ _FIELDS = [
     ("n_threads", C.c_int32),
     ("w_col0", C.c_uint32), ("w_ld", C.c_uint32),
     ("qif_alpha", f32p), ("qif_v_c", f32p), ("slif_g", f32p), ("slif_e", f32p),
+    ("lattice_first", u32p), ("lattice_count", u32p), ("avg_history", f32p), ("eeg_history", f32p),
+    ("eeg_reference_voltage", C.c_float), ("eeg_distance", C.c_float), ("eeg_conductivity", C.c_float),
+    ("spike_counts", u32p),
 ]
 
 
@@ -158,7 +161,8 @@ _PER_NEURON_K = {"nt_t", "nt_t_max", "nt_clearance", "nt_v_p", "nt_k_p", "nt_fla
 _PER_CELL = {"st_current_voltage", "st_v_th", "st_v_resting", "st_dt", "st_k", "st_chance_of_firing",
              "st_rate", "st_step", "st_seed", "st_is_spiking", "st_last_firing_time", "st_lattice"}
 _PER_CELL_K = {"st_nt_t", "st_nt_t_max", "st_nt_clearance", "st_nt_v_p", "st_nt_k_p", "st_nt_flags"}
-_PER_LATTICE = {"stdp_a_plus", "stdp_a_minus", "stdp_tau_plus", "stdp_tau_minus", "stdp_dt", "do_plasticity"}
+_PER_LATTICE = {"stdp_a_plus", "stdp_a_minus", "stdp_tau_plus", "stdp_tau_minus", "stdp_dt", "do_plasticity",
+                "lattice_first", "lattice_count"}
 
 
 class Net:
@@ -177,6 +181,9 @@ class Net:
         self.n_threads = 1
         self.w_col0 = 0
         self.w_ld = 0
+        # EEGHistory defaults, neuron/mod.rs:246-255
+        self.eeg_reference_voltage, self.eeg_distance, self.eeg_conductivity = 0.007, 0.8, 251.0
+        self.avg_history = self.eeg_history = self.spike_counts = None
         self.arr = {}
         nn, nc = self.n_neurons, self.n_cells
         for name, ct in _FIELDS:
@@ -219,6 +226,8 @@ class Net:
         for k, v in STDP_DEFAULTS.items():
             a[k][...] = v
         a["st_seed"][...] = np.arange(1, nc + 1, dtype=np.uint32)
+        a["lattice_count"][...] = 0
+        a["lattice_count"][0] = nn              # single lattice by default; parity.make_oracle sets real ranges
         self.voltage_history = self.spike_history = self.st_voltage_history = None
 
     def __getitem__(self, name):
@@ -251,6 +260,8 @@ class Net:
                 else:
                     assert arr.flags["C_CONTIGUOUS"] and arr.dtype == _PTR_DTYPE[ct], name
                     setattr(c, name, arr.ctypes.data_as(ct))
+            elif ct is C.c_float:
+                setattr(c, name, float(getattr(self, name)))
             else:
                 setattr(c, name, int(getattr(self, name)))
         return c
@@ -283,8 +294,15 @@ class Net:
         c = self._cnet()
         lib().snn_o_spike_trains(C.byref(c))
 
-    def run(self, iterations, voltage_history=False, spike_history=False, st_voltage_history=False):
+    def run(self, iterations, voltage_history=False, spike_history=False, st_voltage_history=False,
+            summaries=False, spike_counts=False):
         it = int(iterations)
+        self.avg_history = np.zeros((it, self.n_lattices), np.float32) if summaries else None
+        self.eeg_history = np.zeros((it, self.n_lattices), np.float32) if summaries else None
+        if spike_counts and self.spike_counts is None:
+            self.spike_counts = np.zeros(self.n_neurons, np.uint32)
+        if not spike_counts:
+            self.spike_counts = None
         self.voltage_history = np.zeros((it, self.n_neurons), np.float32) if voltage_history else None
         self.spike_history = np.zeros((it, self.n_neurons), np.uint8) if spike_history else None
         self.st_voltage_history = np.zeros((it, self.n_cells), np.float32) if st_voltage_history else None

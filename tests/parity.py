@@ -64,9 +64,11 @@ def make_oracle(layout, **kw):
     net = ob.Net(layout.n_neurons, n_cells=layout.n_cells, n_lattices=max(1, len(layout.lattices)),
                  n_st_lattices=len(layout.st_lattices), **kw)
     rng = layout.ranges()
+    net["lattice_count"][...] = 0
     for slot, (i, r, c) in enumerate(layout.lattices):
         first, count, _ = rng[i]
         net["lattice"][first:first + count] = slot
+        net["lattice_first"][slot], net["lattice_count"][slot] = first, count
     for slot, (i, r, c) in enumerate(layout.st_lattices):
         first, count, _ = rng[i]
         net["st_lattice"][first:first + count] = slot

@@ -66,7 +66,13 @@ def test_cpp_host_lattice_and_network(tmp_path, snn):
         net["weights"][16 + a, a] = 2.0
     net["st_rate"] = 3.0
     net["do_plasticity"] = 1
-    net.run(400)
+    net.run(400, summaries=True, spike_counts=True)
+    avg = np.fromfile(tmp_path / "network_average_voltage.f32", np.float32)
+    eeg = np.fromfile(tmp_path / "network_eeg.f32", np.float32)
+    assert np.array_equal(avg.view(np.uint32), net.avg_history[:, 0].view(np.uint32))
+    assert np.array_equal(eeg.view(np.uint32), net.eeg_history[:, 0].view(np.uint32))
+    counts = np.fromfile(tmp_path / "network_spike_counts.f32", np.float32)
+    assert np.array_equal(counts.astype(np.uint32), net.spike_counts)
     w = np.fromfile(tmp_path / "network_weights.f32", np.float32).reshape(16, 16)
     ow = np.where(net["connections"][:16] != 0, net["weights"][:16], np.float32(np.nan))
     assert np.array_equal(np.isnan(w), np.isnan(ow))

@@ -88,6 +88,7 @@ def test_network_with_rate_spike_train_chemical_and_stdp(snn):
     net.chemical_synapse = True
 
     gpu = ln.IzhikevichNeuronNetworkGPU.from_network(net)
+    gpu.set_reduced_history(average_voltage=True, eeg=True, spike_counts=True)
     gpu.run_lattices(600)
 
     lay = parity.Layout([(1, 4, 5)], [(0, 4, 5)])
@@ -108,8 +109,11 @@ def test_network_with_rate_spike_train_chemical_and_stdp(snn):
         o["connections"][20 + i, i] = 1
         o["weights"][20 + i, i] = 2.0
     o["do_plasticity"] = 1
-    o.run(600, voltage_history=True)
+    o.run(600, voltage_history=True, summaries=True, spike_counts=True)
     assert np.array_equal(gpu.history(1).reshape(600, -1).view(np.uint32), o.voltage_history.view(np.uint32))
+    assert np.array_equal(gpu.average_voltage_history(1).view(np.uint32), o.avg_history[:, 0].view(np.uint32))
+    assert np.array_equal(gpu.eeg_history(1).view(np.uint32), o.eeg_history[:, 0].view(np.uint32))
+    assert np.array_equal(gpu.spike_counts(1), o.spike_counts.reshape(4, 5)) and o.spike_counts.sum() > 0
     lat = gpu.get_lattice(1)
     assert np.array_equal(lat.weights.view(np.uint32), np.where(o["connections"][:20] != 0, o["weights"][:20], 0).astype(np.float32).view(np.uint32))
     cw = gpu.connecting_weights

@@ -75,3 +75,37 @@ def test_simple_lif_lattice_matches_numpy():
     assert sh.sum() > 0
     assert np.array_equal(sh, net.spike_history)
     assert np.array_equal(vh.view(np.uint32), net.voltage_history.view(np.uint32))
+
+
+def test_reduced_histories_against_numpy():
+    """lattice_summaries (oracle) vs the voltage history reduced with numpy in the same chunked order, and the
+    spike totals vs the column sums of the raster (SpikeHistory::aggregate, neuron/mod.rs:331-360)."""
+    import parity
+    lay = parity.Layout([(0, 5, 5), (4, 24, 24)])
+    net = parity.make_oracle(lay)
+    n = net.n_neurons
+    net["current_voltage"] = ob.uniform_array(3, n, -65.0, 30.0)
+    net["gap_conductance"] = 10.0
+    net.fill_graph(4, 0.5, 1.5)
+    net.run(300, voltage_history=True, spike_history=True, summaries=True, spike_counts=True)
+    assert net.spike_history.sum() > 10
+    assert np.array_equal(net.spike_counts, net.spike_history.sum(axis=0).astype(np.uint32))
+    f = np.float32
+    for slot, (i, r, c) in enumerate(lay.lattices):
+        first, count, _ = lay.ranges()[i]
+        v = net.voltage_history[:, first:first + count]
+        avg = np.zeros(300, f)
+        eeg = np.zeros(300, f)
+        for t in range(300):
+            tot, tot_e = f(0), f(0)
+            for c0 in range(0, count, 256):
+                p, pe = f(0), f(0)
+                for x in v[t, c0:c0 + 256]:
+                    p = f(p + x)
+                    pe = f(pe + f(x - f(0.007)))
+                tot, tot_e = f(tot + p), f(tot_e + pe)
+            avg[t] = f(tot / f(count))
+            k = f(f(1) / f(f(f(f(4) * f(np.pi)) * f(251.0)) * f(0.8)))
+            eeg[t] = f(k * tot_e)
+        assert np.array_equal(avg.view(np.uint32), net.avg_history[:, slot].view(np.uint32))
+        assert np.array_equal(eeg.view(np.uint32), net.eeg_history[:, slot].view(np.uint32))
