@@ -77,7 +77,12 @@ typedef enum {
     /* the two models the reference's own GPU path implements (IterateAndSpikeGPU):
      * QuadraticIntegrateAndFireNeuron integrate_and_fire/mod.rs:259-917, buffers :729-773;
      * SimpleLeakyIntegrateAndFire :1523-1801 */
-    SNN_MODEL_QUADRATIC_INTEGRATE_AND_FIRE = 3, SNN_MODEL_SIMPLE_LIF = 4
+    SNN_MODEL_QUADRATIC_INTEGRATE_AND_FIRE = 3, SNN_MODEL_SIMPLE_LIF = 4,
+    /* further integrate-and-fire models of the CPU path (no reference GPU form; attribute names = field names):
+     * AdaptiveLeakyIntegrateAndFireNeuron integrate_and_fire/mod.rs:918-1049 (alpha, beta, w_value + the LIF set),
+     * AdaptiveExpLeakyIntegrateAndFireNeuron :1051-1155 (+ slope_factor),
+     * LeakyIzhikevichNeuron :1270-1356 (the Izhikevich set + e_l) */
+    SNN_MODEL_ADAPTIVE_LIF = 5, SNN_MODEL_ADAPTIVE_EXP_LIF = 6, SNN_MODEL_LEAKY_IZHIKEVICH = 7
 } snn_model;
 /* NeurotransmitterKinetics: Approximate iterate_and_spike/mod.rs:161-205, Destexhe :122-159 */
 typedef enum { SNN_NT_APPROXIMATE = 0, SNN_NT_DESTEXHE = 1 } snn_nt_kinetics;

@@ -444,6 +444,86 @@ static uint32_t step_simple_lif(snn_o_net *n, uint32_t q)
     return spike;
 }
 
+/* AdaptiveLeakyIntegrateAndFireNeuron (exponential = 0) integrate_and_fire/mod.rs:1033-1049 and
+ * AdaptiveExpLeakyIntegrateAndFireNeuron (exponential = 1) :1132-1155; adaptive_get_dw_change :1003-1010,
+ * adaptive_handle_spiking :1014-1030 */
+static uint32_t step_adaptive(snn_o_net *n, uint32_t q, int exponential)
+{
+    const float v = n->current_voltage[q], w = n->w_value[q], dt = n->dt[q];
+    const float i = n->input_current[q];
+    const uint32_t spiking_prev = n->is_spiking[q];
+
+    if (n->chemical) receptors_update(n, q, v);
+
+    float acc = n->leak_constant[q] * (v - n->e_l[q]);
+    if (exponential)
+        acc = acc + (n->slope_factor[q] * snn_o_expf((v - n->v_th[q]) / n->slope_factor[q]));
+    float dv = (acc + (n->integration_constant[q] * (i / n->g_l[q])) - (w / n->g_l[q])) * (dt / n->c_m[q]);
+    float dw = (n->adp_alpha[q] * (v - n->e_l[q]) - w) * (dt / n->tau_m[q]);
+
+    float v_new;
+    if (n->chemical) {
+        float neurotransmitter_dv = -receptor_currents(n, q);
+        v_new = v + (dv + neurotransmitter_dv);
+    } else {
+        v_new = v + dv;
+    }
+    float w_new = w + dw;
+
+    neuron_nt_update(n, q, v_new, spiking_prev);
+
+    uint32_t spike = 0;
+    float rc = n->refractory_count[q];
+    if (rc > 0.0f) {
+        v_new = n->v_reset[q];
+        rc -= 1.0f;
+    } else if (v_new >= n->v_th[q]) {
+        spike = 1;
+        v_new = n->v_reset[q];
+        w_new += n->adp_beta[q];
+        rc = n->tref[q] / dt;
+    }
+    n->refractory_count[q] = rc;
+    n->current_voltage[q] = v_new;
+    n->w_value[q] = w_new;
+    return spike;
+}
+
+/* LeakyIzhikevichNeuron, integrate_and_fire/mod.rs:1336-1356 (dw and spike handling are Izhikevich's, :1222-1247).
+ * `current_voltage.powf(2.0)` is taken as v * v (the correctly rounded square). */
+static uint32_t step_leaky_izhikevich(snn_o_net *n, uint32_t q)
+{
+    const float v = n->current_voltage[q], w = n->w_value[q], dt = n->dt[q];
+    const float i = n->input_current[q];
+    const uint32_t spiking_prev = n->is_spiking[q];
+
+    if (n->chemical) receptors_update(n, q, v);
+
+    float dv = (0.04f * (v * v) + 5.0f * v + 140.0f - w * (v - n->e_l[q]) + i) * (dt / n->c_m[q]);
+    float dw = (n->a[q] * (n->b[q] * v - w)) * (dt / n->tau_m[q]);
+
+    float v_new;
+    if (n->chemical) {
+        float neurotransmitter_dv = -receptor_currents(n, q);
+        v_new = v + (dv + neurotransmitter_dv);
+    } else {
+        v_new = v + dv;
+    }
+    float w_new = w + dw;
+
+    neuron_nt_update(n, q, v_new, spiking_prev);
+
+    uint32_t spike = 0;
+    if (v_new >= n->v_th[q]) {
+        spike = 1;
+        v_new = n->c[q];
+        w_new += n->d[q];
+    }
+    n->current_voltage[q] = v_new;
+    n->w_value[q] = w_new;
+    return spike;
+}
+
 /* BasicGatingVariable::update, ion_channels/mod.rs:40-44 */
 static inline float gate_update(float state, float alpha, float beta, float dt)
 {
@@ -511,6 +591,9 @@ void snn_o_update_neurons_range(snn_o_net *n, uint32_t q0, uint32_t q1)
         case SNN_O_HH:  spike = step_hh(n, q); break;
         case SNN_O_QIF: spike = step_qif(n, q); break;
         case SNN_O_SIMPLE_LIF: spike = step_simple_lif(n, q); break;
+        case SNN_O_ADAPTIVE_LIF: spike = step_adaptive(n, q, 0); break;
+        case SNN_O_ADAPTIVE_EXP_LIF: spike = step_adaptive(n, q, 1); break;
+        case SNN_O_LEAKY_IZHIKEVICH: spike = step_leaky_izhikevich(n, q); break;
         default:        spike = step_izhikevich(n, q); break;
         }
         n->is_spiking[q] = spike;

@@ -53,7 +53,8 @@ extern "C" {
 #define SNN_O_K      3     /* AMPA=0, NMDA=1, GABA=2  (iterate_and_spike/mod.rs:1323-1333) */
 #define SNN_O_CHUNK  256   /* canonical reduction chunk (presynaptic indices) */
 
-enum { SNN_O_IZHIKEVICH = 0, SNN_O_LIF = 1, SNN_O_HH = 2, SNN_O_QIF = 3, SNN_O_SIMPLE_LIF = 4 };
+enum { SNN_O_IZHIKEVICH = 0, SNN_O_LIF = 1, SNN_O_HH = 2, SNN_O_QIF = 3, SNN_O_SIMPLE_LIF = 4,
+       SNN_O_ADAPTIVE_LIF = 5, SNN_O_ADAPTIVE_EXP_LIF = 6, SNN_O_LEAKY_IZHIKEVICH = 7 };
 enum { SNN_O_NT_APPROX = 0, SNN_O_NT_DESTEXHE = 1 };
 enum { SNN_O_RC_APPROX = 0, SNN_O_RC_DESTEXHE = 1 };
 enum { SNN_O_ST_NONE = 0, SNN_O_ST_POISSON = 1, SNN_O_ST_RATE = 2 };
@@ -141,6 +142,10 @@ typedef struct snn_o_net {
     float    *avg_history, *eeg_history;       /* [iterations][n_lattices] or NULL */
     float    eeg_reference_voltage, eeg_distance, eeg_conductivity;
     uint32_t *spike_counts;                    /* [n_neurons] accumulated over the run, or NULL */
+    /* AdaptiveLeakyIntegrateAndFireNeuron (integrate_and_fire/mod.rs:918-1049) and
+     * AdaptiveExpLeakyIntegrateAndFireNeuron (:1051-1155): alpha, beta (+ slope_factor) next to the LIF arrays and
+     * w_value; LeakyIzhikevichNeuron (:1270-1356) uses the Izhikevich arrays + e_l */
+    float    *adp_alpha, *adp_beta, *slope_factor;
 } snn_o_net;
 
 /* Step 1 of SURVEY §8(g): electrical + chemical inputs for every neuron from state S(t). */

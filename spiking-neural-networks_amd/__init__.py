@@ -7,11 +7,12 @@ through the root-level shim: `import snn_amd`.
 """
 from . import _lib, lattice, parallel, synthetic
 from ._lib import SnnError, SnnLibraryError, build
-from .network import (DeviceNetwork, HODGKIN_HUXLEY, IZHIKEVICH, LIF, QUADRATIC_INTEGRATE_AND_FIRE, SIMPLE_LIF, NT_APPROXIMATE, NT_DESTEXHE,
+from .network import (DeviceNetwork, HODGKIN_HUXLEY, IZHIKEVICH, LIF, QUADRATIC_INTEGRATE_AND_FIRE, SIMPLE_LIF,
+                      ADAPTIVE_LIF, ADAPTIVE_EXP_LIF, LEAKY_IZHIKEVICH, NT_APPROXIMATE, NT_DESTEXHE,
                       NUM_NT_TYPES, RC_APPROXIMATE, RC_DESTEXHE, ST_NONE, ST_POISSON, ST_RATE, probe_bandwidth, probe_math)
 
 from .lattice import *  # noqa: F401,F403  (Lixirnet-style names)
 
 __all__ = ["DeviceNetwork", "SnnError", "SnnLibraryError", "build", "probe_math", "probe_bandwidth",
-           "IZHIKEVICH", "LIF", "HODGKIN_HUXLEY", "QUADRATIC_INTEGRATE_AND_FIRE", "SIMPLE_LIF", "NT_APPROXIMATE", "NT_DESTEXHE",
+           "IZHIKEVICH", "LIF", "HODGKIN_HUXLEY", "QUADRATIC_INTEGRATE_AND_FIRE", "SIMPLE_LIF", "ADAPTIVE_LIF", "ADAPTIVE_EXP_LIF", "LEAKY_IZHIKEVICH", "NT_APPROXIMATE", "NT_DESTEXHE",
            "RC_APPROXIMATE", "RC_DESTEXHE", "ST_NONE", "ST_POISSON", "ST_RATE", "NUM_NT_TYPES"]

@@ -223,6 +223,55 @@ __global__ __launch_bounds__(256) void k_update(const UpdateArgs a)
                 spike = 1;
                 v_new = a.n.v_reset[q];
             }
+        } else if (MODEL == 5 || MODEL == 6) {
+            // adaptive (5) and adaptive exponential (6) leaky integrate-and-fire, integrate_and_fire/mod.rs:1001-1049,
+            // 1132-1155; adaptive_get_dw_change / adaptive_handle_spiking :1001-1031
+            const float w = a.n.w_value[q], e_l = a.n.e_l[q], g_l = a.n.g_l[q];
+            float acc = a.n.leak_constant[q] * (v - e_l);
+            if (MODEL == 6) {
+                const float sf = a.n.slope_factor[q];
+                acc = acc + (sf * expf_portable((v - a.n.v_th[q]) / sf));
+            }
+            const float dv = (acc + (a.n.integration_constant[q] * (i_in / g_l)) - (w / g_l)) * (dt / c_m);
+            const float dw = (a.n.adp_alpha[q] * (v - e_l) - w) * (dt / a.n.tau_m[q]);
+            if (a.chemical) {
+                const float neurotransmitter_dv = -receptor_currents(a, q, dt, c_m);
+                v_new = v + (dv + neurotransmitter_dv);
+            } else {
+                v_new = v + dv;
+            }
+            float w_new = w + dw;
+            neuron_nt_update(a, q, v_new, spiking_prev, dt);
+            float rc = a.n.refractory_count[q];
+            if (rc > 0.0f) {
+                v_new = a.n.v_reset[q];
+                rc -= 1.0f;
+            } else if (v_new >= a.n.v_th[q]) {
+                spike = 1;
+                v_new = a.n.v_reset[q];
+                w_new += a.n.adp_beta[q];
+                rc = a.n.tref[q] / dt;
+            }
+            a.n.refractory_count[q] = rc;
+            a.n.w_value[q] = w_new;
+        } else if (MODEL == 7) {     // leaky Izhikevich (integrate_and_fire/mod.rs:1336-1356), powf(2.0) taken as v * v
+            const float w = a.n.w_value[q];
+            const float dv = (0.04f * (v * v) + 5.0f * v + 140.0f - w * (v - a.n.e_l[q]) + i_in) * (dt / c_m);
+            const float dw = (a.n.a[q] * (a.n.b[q] * v - w)) * (dt / a.n.tau_m[q]);
+            if (a.chemical) {
+                const float neurotransmitter_dv = -receptor_currents(a, q, dt, c_m);
+                v_new = v + (dv + neurotransmitter_dv);
+            } else {
+                v_new = v + dv;
+            }
+            float w_new = w + dw;
+            neuron_nt_update(a, q, v_new, spiking_prev, dt);
+            if (v_new >= a.n.v_th[q]) {
+                spike = 1;
+                v_new = a.n.c[q];
+                w_new += a.n.d[q];
+            }
+            a.n.w_value[q] = w_new;
         } else {                     // Hodgkin-Huxley
             const float m_a = 0.1f * ((v + 40.0f) / (1.0f - expf_portable(-(v + 40.0f) / 10.0f)));
             const float m_b = 4.0f * expf_portable(-(v + 65.0f) / 18.0f);

@@ -52,6 +52,8 @@ struct NeuronArrays {
     float *v_reset, *refractory_count, *tref, *leak_constant, *integration_constant, *e_l, *g_l;
     // quadratic integrate-and-fire / simple leaky integrate-and-fire
     float *qif_alpha, *qif_v_c, *slif_g, *slif_e;
+    // adaptive (exponential) leaky integrate-and-fire
+    float *adp_alpha, *adp_beta, *slope_factor;
     // Hodgkin-Huxley
     float *m_state, *h_state, *n_state;
     float *m_alpha, *m_beta, *h_alpha, *h_beta, *n_alpha, *n_beta;

@@ -251,7 +251,9 @@ int build_state(snn_network *net)
     // Hodgkin-Huxley hodgkin_huxley/mod.rs:80-98 + ion_channels/mod.rs:23-31, 205-215, 255-264, 299-307
     const bool izh = net->model == SNN_MODEL_IZHIKEVICH, lif = net->model == SNN_MODEL_LIF;
     const bool qif = net->model == SNN_MODEL_QUADRATIC_INTEGRATE_AND_FIRE, slif = net->model == SNN_MODEL_SIMPLE_LIF;
-    const float v0 = (lif || qif || slif) ? -75.0f : -65.0f;
+    const bool alif = net->model == SNN_MODEL_ADAPTIVE_LIF, aelif = net->model == SNN_MODEL_ADAPTIVE_EXP_LIF;
+    const bool adp = alif || aelif, lizh = net->model == SNN_MODEL_LEAKY_IZHIKEVICH;
+    const float v0 = (lif || qif || slif || adp) ? -75.0f : -65.0f;
     {
         // initial voltage into plane V of every shard slot
         for (uint32_t s = 0; s < net->xl.n_shards; ++s)
@@ -260,31 +262,36 @@ int build_state(snn_network *net)
     TRY(neuron_f32(net, &n.gap_conductance, "gap_conductance", slif ? 10.0f : 7.0f));
     TRY(neuron_f32(net, &n.dt, "dt", net->model == SNN_MODEL_HODGKIN_HUXLEY ? 0.01f : 0.1f));
     TRY(neuron_f32(net, &n.c_m, "c_m", net->model == SNN_MODEL_HODGKIN_HUXLEY ? 1.0f : 100.0f));
-    TRY(neuron_f32(net, &n.v_th, "v_th", izh ? 30.0f : ((lif || qif || slif) ? -55.0f : 0.0f)));
+    TRY(neuron_f32(net, &n.v_th, "v_th", (izh || lizh) ? 30.0f : ((lif || qif || slif || adp) ? -55.0f : 0.0f)));
     TRY(dev_alloc_t(net, &n.last_firing_time, np));
     HIP_TRY(hipMemsetAsync(n.last_firing_time, 0xFF, (size_t)np * 4, net->stream), SNN_ERR_BUFFER_WRITE);
     reg(A, "last_firing_time", T_I32, S_PLAIN, n.last_firing_time, 0, 0);
 
-    TRY(neuron_f32(net, &n.w_value, izh ? "w_value" : nullptr, 30.0f));
-    TRY(neuron_f32(net, &n.a, izh ? "a" : nullptr, 0.02f));
-    TRY(neuron_f32(net, &n.b, izh ? "b" : nullptr, 0.2f));
-    TRY(neuron_f32(net, &n.c, izh ? "c" : nullptr, -55.0f));
-    TRY(neuron_f32(net, &n.d, izh ? "d" : nullptr, 8.0f));
-    TRY(neuron_f32(net, &n.tau_m, (izh || lif || qif) ? "tau_m" : nullptr, izh ? 1.0f : (qif ? 100.0f : 10.0f)));
+    const bool izh_like = izh || lizh, lif_like = lif || adp;
+    TRY(neuron_f32(net, &n.w_value, (izh_like || adp) ? "w_value" : nullptr, adp ? 0.0f : 30.0f));
+    TRY(neuron_f32(net, &n.a, izh_like ? "a" : nullptr, 0.02f));
+    TRY(neuron_f32(net, &n.b, izh_like ? "b" : nullptr, 0.2f));
+    TRY(neuron_f32(net, &n.c, izh_like ? "c" : nullptr, -55.0f));
+    TRY(neuron_f32(net, &n.d, izh_like ? "d" : nullptr, 8.0f));
+    TRY(neuron_f32(net, &n.tau_m, (izh_like || lif_like || qif) ? "tau_m" : nullptr, izh ? 1.0f : (qif ? 100.0f : 10.0f)));
 
-    TRY(neuron_f32(net, &n.v_reset, (lif || qif || slif) ? "v_reset" : nullptr, -75.0f));
-    TRY(neuron_f32(net, &n.refractory_count, (lif || qif) ? "refractory_count" : nullptr, 0.0f));
-    TRY(neuron_f32(net, &n.tref, (lif || qif) ? "tref" : nullptr, 10.0f));
-    TRY(neuron_f32(net, &n.leak_constant, lif ? "leak_constant" : nullptr, -1.0f));
-    TRY(neuron_f32(net, &n.integration_constant, (lif || qif) ? "integration_constant" : nullptr, 1.0f));
+    TRY(neuron_f32(net, &n.v_reset, (lif_like || qif || slif) ? "v_reset" : nullptr, -75.0f));
+    TRY(neuron_f32(net, &n.refractory_count, (lif_like || qif) ? "refractory_count" : nullptr, 0.0f));
+    TRY(neuron_f32(net, &n.tref, (lif_like || qif) ? "tref" : nullptr, 10.0f));
+    TRY(neuron_f32(net, &n.leak_constant, lif_like ? "leak_constant" : nullptr, -1.0f));
+    TRY(neuron_f32(net, &n.integration_constant, (lif_like || qif) ? "integration_constant" : nullptr, 1.0f));
+    // adaptive models, integrate_and_fire/mod.rs:969-996, 1105-1130
+    TRY(neuron_f32(net, &n.adp_alpha, adp ? "alpha" : nullptr, 6.0f));
+    TRY(neuron_f32(net, &n.adp_beta, adp ? "beta" : nullptr, 10.0f));
+    TRY(neuron_f32(net, &n.slope_factor, aelif ? "slope_factor" : nullptr, 1.0f));
     // reference buffer names of the two models with a reference GPU implementation
     // (integrate_and_fire/mod.rs:729-773, 1700-1740)
     TRY(neuron_f32(net, &n.qif_alpha, qif ? "alpha" : nullptr, 1.0f));
     TRY(neuron_f32(net, &n.qif_v_c, qif ? "v_c" : nullptr, -60.0f));
     TRY(neuron_f32(net, &n.slif_g, slif ? "g" : nullptr, -0.1f));
     TRY(neuron_f32(net, &n.slif_e, slif ? "e" : nullptr, 0.0f));
-    TRY(neuron_f32(net, &n.e_l, lif ? "e_l" : nullptr, -75.0f));
-    TRY(neuron_f32(net, &n.g_l, lif ? "g_l" : nullptr, 10.0f));
+    TRY(neuron_f32(net, &n.e_l, (lif_like || lizh) ? "e_l" : nullptr, lizh ? -65.0f : -75.0f));
+    TRY(neuron_f32(net, &n.g_l, lif_like ? "g_l" : nullptr, 10.0f));
 
     const bool hh = net->model == SNN_MODEL_HODGKIN_HUXLEY;
     TRY(neuron_f32(net, &n.m_state, hh ? "na_channel$m$state" : nullptr, 0.0f));
@@ -661,6 +668,9 @@ int launch_update(snn_network *net)
     case SNN_MODEL_HODGKIN_HUXLEY: hipLaunchKernelGGL((k_update<2>), grid, dim3(256), 0, net->stream, a); break;
     case SNN_MODEL_QUADRATIC_INTEGRATE_AND_FIRE: hipLaunchKernelGGL((k_update<3>), grid, dim3(256), 0, net->stream, a); break;
     case SNN_MODEL_SIMPLE_LIF: hipLaunchKernelGGL((k_update<4>), grid, dim3(256), 0, net->stream, a); break;
+    case SNN_MODEL_ADAPTIVE_LIF: hipLaunchKernelGGL((k_update<5>), grid, dim3(256), 0, net->stream, a); break;
+    case SNN_MODEL_ADAPTIVE_EXP_LIF: hipLaunchKernelGGL((k_update<6>), grid, dim3(256), 0, net->stream, a); break;
+    case SNN_MODEL_LEAKY_IZHIKEVICH: hipLaunchKernelGGL((k_update<7>), grid, dim3(256), 0, net->stream, a); break;
     default: hipLaunchKernelGGL((k_update<0>), grid, dim3(256), 0, net->stream, a); break;
     }
     HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
@@ -948,7 +958,7 @@ int snn_network_create(int device, int neuron_model, int nt_kinetics, int recept
 {
     if (!out) return fail(SNN_ERR_BAD_ARG, "out is null");
     *out = nullptr;
-    if (neuron_model < 0 || neuron_model > 4 || nt_kinetics < 0 || nt_kinetics > 1 || receptor_kinetics < 0 ||
+    if (neuron_model < 0 || neuron_model > 7 || nt_kinetics < 0 || nt_kinetics > 1 || receptor_kinetics < 0 ||
         receptor_kinetics > 1 || spike_train_model < 0 || spike_train_model > 2)
         return fail(SNN_ERR_BAD_ARG, "unknown model / kinetics selector");
     int ndev = 0;

@@ -119,6 +119,51 @@ struct SimpleLeakyIntegrateAndFire : NeuronBase {       // integrate_and_fire/mo
     }
 };
 
+struct AdaptiveLeakyIntegrateAndFireNeuron : NeuronBase {   // integrate_and_fire/mod.rs:918-996
+    float v_reset = -75.0f, v_init = -75.0f, refractory_count = 0.0f, tref = 10.0f, alpha = 6.0f, beta = 10.0f,
+          w_value = 0.0f, w_init = 0.0f, leak_constant = -1.0f, integration_constant = 1.0f, e_l = -75.0f, g_l = 10.0f,
+          tau_m = 10.0f;
+    AdaptiveLeakyIntegrateAndFireNeuron() { current_voltage = -75.0f; dt = 0.1f; c_m = 100.0f; v_th = -55.0f; }
+    static constexpr int MODEL = SNN_MODEL_ADAPTIVE_LIF;
+    static std::vector<std::pair<const char *, float AdaptiveLeakyIntegrateAndFireNeuron::*>> fields()
+    {
+        using T = AdaptiveLeakyIntegrateAndFireNeuron;
+        return {{"v_reset", &T::v_reset}, {"refractory_count", &T::refractory_count}, {"tref", &T::tref},
+                {"alpha", &T::alpha}, {"beta", &T::beta}, {"w_value", &T::w_value}, {"leak_constant", &T::leak_constant},
+                {"integration_constant", &T::integration_constant}, {"e_l", &T::e_l}, {"g_l", &T::g_l},
+                {"tau_m", &T::tau_m}};
+    }
+};
+
+struct AdaptiveExpLeakyIntegrateAndFireNeuron : NeuronBase {   // integrate_and_fire/mod.rs:1051-1130
+    float v_reset = -75.0f, v_init = -75.0f, refractory_count = 0.0f, tref = 10.0f, alpha = 6.0f, beta = 10.0f,
+          slope_factor = 1.0f, w_value = 0.0f, w_init = 0.0f, leak_constant = -1.0f, integration_constant = 1.0f,
+          e_l = -75.0f, g_l = 10.0f, tau_m = 10.0f;
+    AdaptiveExpLeakyIntegrateAndFireNeuron() { current_voltage = -75.0f; dt = 0.1f; c_m = 100.0f; v_th = -55.0f; }
+    static constexpr int MODEL = SNN_MODEL_ADAPTIVE_EXP_LIF;
+    static std::vector<std::pair<const char *, float AdaptiveExpLeakyIntegrateAndFireNeuron::*>> fields()
+    {
+        using T = AdaptiveExpLeakyIntegrateAndFireNeuron;
+        return {{"v_reset", &T::v_reset}, {"refractory_count", &T::refractory_count}, {"tref", &T::tref},
+                {"alpha", &T::alpha}, {"beta", &T::beta}, {"slope_factor", &T::slope_factor}, {"w_value", &T::w_value},
+                {"leak_constant", &T::leak_constant}, {"integration_constant", &T::integration_constant},
+                {"e_l", &T::e_l}, {"g_l", &T::g_l}, {"tau_m", &T::tau_m}};
+    }
+};
+
+struct LeakyIzhikevichNeuron : NeuronBase {     // integrate_and_fire/mod.rs:1270-1331
+    float v_init = -65.0f, a = 0.02f, b = 0.2f, c = -55.0f, d = 8.0f, w_value = 30.0f, w_init = 30.0f, e_l = -65.0f,
+          tau_m = 10.0f;
+    LeakyIzhikevichNeuron() { current_voltage = -65.0f; dt = 0.1f; c_m = 100.0f; v_th = 30.0f; }
+    static constexpr int MODEL = SNN_MODEL_LEAKY_IZHIKEVICH;
+    static std::vector<std::pair<const char *, float LeakyIzhikevichNeuron::*>> fields()
+    {
+        using T = LeakyIzhikevichNeuron;
+        return {{"w_value", &T::w_value}, {"a", &T::a}, {"b", &T::b}, {"c", &T::c}, {"d", &T::d}, {"tau_m", &T::tau_m},
+                {"e_l", &T::e_l}};
+    }
+};
+
 struct HodgkinHuxleyNeuron : NeuronBase {      // hodgkin_huxley/mod.rs:49-98, ion_channels/mod.rs:192-317
     float m_state = 0.0f, h_state = 0.0f, n_state = 0.0f;
     float g_na = 120.0f, e_na = 50.0f, g_k = 36.0f, e_k = -77.0f, g_k_leak = 0.3f, e_k_leak = -55.0f;

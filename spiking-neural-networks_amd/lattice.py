@@ -15,6 +15,7 @@ import enum
 import numpy as np
 
 from .network import (DeviceNetwork, HODGKIN_HUXLEY, IZHIKEVICH, LIF, QUADRATIC_INTEGRATE_AND_FIRE, SIMPLE_LIF,
+                      ADAPTIVE_LIF, ADAPTIVE_EXP_LIF, LEAKY_IZHIKEVICH,
                       NT_APPROXIMATE, NT_DESTEXHE,
                       RC_APPROXIMATE, RC_DESTEXHE, ST_NONE, ST_POISSON, ST_RATE)
 
@@ -142,6 +143,28 @@ class SimpleLeakyIntegrateAndFire(_Neuron):              # integrate_and_fire/mo
     _defaults = dict(current_voltage=-75.0, g=-0.1, e=0.0, v_th=-55.0, v_reset=-75.0, v_init=-75.0,
                      gap_conductance=10.0, c_m=100.0, dt=0.1, **_Neuron._common)
     state_fields = ("g", "e", "v_reset")
+
+
+class AdaptiveLeakyIntegrateAndFireNeuron(_Neuron):      # integrate_and_fire/mod.rs:918-996
+    model = ADAPTIVE_LIF
+    _defaults = dict(current_voltage=-75.0, v_th=-55.0, v_reset=-75.0, v_init=-75.0, refractory_count=0.0, tref=10.0,
+                     alpha=6.0, beta=10.0, w_value=0.0, w_init=0.0, leak_constant=-1.0, integration_constant=1.0,
+                     gap_conductance=7.0, e_l=-75.0, g_l=10.0, tau_m=10.0, c_m=100.0, dt=0.1, **_Neuron._common)
+    state_fields = ("v_reset", "refractory_count", "tref", "alpha", "beta", "w_value", "leak_constant",
+                    "integration_constant", "e_l", "g_l", "tau_m")
+
+
+class AdaptiveExpLeakyIntegrateAndFireNeuron(_Neuron):   # integrate_and_fire/mod.rs:1051-1130
+    model = ADAPTIVE_EXP_LIF
+    _defaults = dict(AdaptiveLeakyIntegrateAndFireNeuron._defaults, slope_factor=1.0)
+    state_fields = AdaptiveLeakyIntegrateAndFireNeuron.state_fields + ("slope_factor",)
+
+
+class LeakyIzhikevichNeuron(_Neuron):                    # integrate_and_fire/mod.rs:1270-1331
+    model = LEAKY_IZHIKEVICH
+    _defaults = dict(current_voltage=-65.0, v_th=30.0, v_init=-65.0, a=0.02, b=0.2, c=-55.0, d=8.0, w_value=30.0,
+                     w_init=30.0, e_l=-65.0, gap_conductance=7.0, tau_m=10.0, c_m=100.0, dt=0.1, **_Neuron._common)
+    state_fields = ("w_value", "a", "b", "c", "d", "tau_m", "e_l")
 
 
 class HodgkinHuxleyNeuron(_Neuron):                      # hodgkin_huxley/mod.rs:49-98, ion_channels/mod.rs
@@ -753,6 +776,17 @@ QuadraticIntegrateAndFireNeuronLatticeGPU = _named(LatticeGPU, "QuadraticIntegra
                                                    lattice_type=QuadraticIntegrateAndFireNeuronLattice)
 SimpleLeakyIntegrateAndFireLatticeGPU = _named(LatticeGPU, "SimpleLeakyIntegrateAndFireLatticeGPU",
                                                lattice_type=SimpleLeakyIntegrateAndFireLattice)
+AdaptiveLeakyIntegrateAndFireNeuronLattice = _named(Lattice, "AdaptiveLeakyIntegrateAndFireNeuronLattice",
+                                                    neuron_type=AdaptiveLeakyIntegrateAndFireNeuron)
+AdaptiveExpLeakyIntegrateAndFireNeuronLattice = _named(Lattice, "AdaptiveExpLeakyIntegrateAndFireNeuronLattice",
+                                                       neuron_type=AdaptiveExpLeakyIntegrateAndFireNeuron)
+LeakyIzhikevichNeuronLattice = _named(Lattice, "LeakyIzhikevichNeuronLattice", neuron_type=LeakyIzhikevichNeuron)
+AdaptiveLeakyIntegrateAndFireNeuronLatticeGPU = _named(LatticeGPU, "AdaptiveLeakyIntegrateAndFireNeuronLatticeGPU",
+                                                       lattice_type=AdaptiveLeakyIntegrateAndFireNeuronLattice)
+AdaptiveExpLeakyIntegrateAndFireNeuronLatticeGPU = _named(LatticeGPU, "AdaptiveExpLeakyIntegrateAndFireNeuronLatticeGPU",
+                                                          lattice_type=AdaptiveExpLeakyIntegrateAndFireNeuronLattice)
+LeakyIzhikevichNeuronLatticeGPU = _named(LatticeGPU, "LeakyIzhikevichNeuronLatticeGPU",
+                                         lattice_type=LeakyIzhikevichNeuronLattice)
 IzhikevichNeuronLatticeGPU = _named(LatticeGPU, "IzhikevichNeuronLatticeGPU", lattice_type=IzhikevichNeuronLattice)
 LeakyIntegrateAndFireNeuronLatticeGPU = _named(LatticeGPU, "LeakyIntegrateAndFireNeuronLatticeGPU",
                                                lattice_type=LeakyIntegrateAndFireNeuronLattice)

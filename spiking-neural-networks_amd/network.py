@@ -14,6 +14,7 @@ import numpy as np
 from . import _lib
 
 IZHIKEVICH, LIF, HODGKIN_HUXLEY, QUADRATIC_INTEGRATE_AND_FIRE, SIMPLE_LIF = 0, 1, 2, 3, 4
+ADAPTIVE_LIF, ADAPTIVE_EXP_LIF, LEAKY_IZHIKEVICH = 5, 6, 7
 NT_APPROXIMATE, NT_DESTEXHE = 0, 1
 RC_APPROXIMATE, RC_DESTEXHE = 0, 1
 ST_NONE, ST_POISSON, ST_RATE = 0, 1, 2

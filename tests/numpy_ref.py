@@ -80,6 +80,46 @@ def simple_lif_step(s, i_in):
     return spike
 
 
+def adaptive_step(s, i_in, expf=None):
+    """AdaptiveLeakyIntegrateAndFireNeuron integrate_and_fire/mod.rs:1001-1049; with `expf` (elementwise float32
+    exponential) the exponential variant :1132-1155 (electrical only)."""
+    v, w = s["current_voltage"], s["w_value"]
+    acc = (s["leak_constant"] * (v - s["e_l"]).astype(f32)).astype(f32)
+    if expf is not None:
+        e = expf(((v - s["v_th"]).astype(f32) / s["slope_factor"]).astype(f32)).astype(f32)
+        acc = (acc + (s["slope_factor"] * e).astype(f32)).astype(f32)
+    acc = (acc + (s["integration_constant"] * (i_in / s["g_l"]).astype(f32)).astype(f32)).astype(f32)
+    acc = (acc - (w / s["g_l"]).astype(f32)).astype(f32)
+    dv = (acc * (s["dt"] / s["c_m"]).astype(f32)).astype(f32)
+    dw = (((s["adp_alpha"] * (v - s["e_l"]).astype(f32)).astype(f32) - w).astype(f32) *
+          (s["dt"] / s["tau_m"]).astype(f32)).astype(f32)
+    v_new = (v + dv).astype(f32)
+    w_new = (w + dw).astype(f32)
+    rc = s["refractory_count"]
+    refr = rc > 0
+    spike = (~refr) & (v_new >= s["v_th"])
+    s["current_voltage"] = np.where(refr | spike, s["v_reset"], v_new).astype(f32)
+    s["w_value"] = np.where(spike, (w_new + s["adp_beta"]).astype(f32), w_new).astype(f32)
+    s["refractory_count"] = np.where(refr, (rc - f32(1)).astype(f32),
+                                     np.where(spike, (s["tref"] / s["dt"]).astype(f32), rc)).astype(f32)
+    return spike
+
+
+def leaky_izhikevich_step(s, i_in):
+    """LeakyIzhikevichNeuron integrate_and_fire/mod.rs:1336-1356 (electrical only)."""
+    v, w = s["current_voltage"], s["w_value"]
+    dv = (((f32(0.04) * (v * v).astype(f32)).astype(f32) + (f32(5.0) * v).astype(f32)).astype(f32) + f32(140.0)).astype(f32)
+    dv = (dv - (w * (v - s["e_l"]).astype(f32)).astype(f32)).astype(f32)
+    dv = ((dv + i_in).astype(f32) * (s["dt"] / s["c_m"]).astype(f32)).astype(f32)
+    dw = ((s["a"] * ((s["b"] * v).astype(f32) - w).astype(f32)).astype(f32) * (s["dt"] / s["tau_m"]).astype(f32)).astype(f32)
+    v_new = (v + dv).astype(f32)
+    w_new = (w + dw).astype(f32)
+    spike = v_new >= s["v_th"]
+    s["current_voltage"] = np.where(spike, s["c"], v_new).astype(f32)
+    s["w_value"] = np.where(spike, (w_new + s["d"]).astype(f32), w_new).astype(f32)
+    return spike
+
+
 def run_lattice(step_fn, s, g, weights, conn, steps):
     """run_lattice_electrical_synapses_only, neuron/mod.rs:1073-1088: returns (V history, raster)."""
     vh, sh = [], []

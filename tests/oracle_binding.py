@@ -12,7 +12,7 @@ import numpy as np
 
 K = 3          # AMPA, NMDA, GABA
 CHUNK = 256
-IZHIKEVICH, LIF, HH, QIF, SIMPLE_LIF = 0, 1, 2, 3, 4
+IZHIKEVICH, LIF, HH, QIF, SIMPLE_LIF, ADAPTIVE_LIF, ADAPTIVE_EXP_LIF, LEAKY_IZHIKEVICH = 0, 1, 2, 3, 4, 5, 6, 7
 NT_APPROX, NT_DESTEXHE = 0, 1
 RC_APPROX, RC_DESTEXHE = 0, 1
 ST_NONE, ST_POISSON, ST_RATE = 0, 1, 2
@@ -65,6 +65,7 @@ _FIELDS = [
     ("lattice_first", u32p), ("lattice_count", u32p), ("avg_history", f32p), ("eeg_history", f32p),
     ("eeg_reference_voltage", C.c_float), ("eeg_distance", C.c_float), ("eeg_conductivity", C.c_float),
     ("spike_counts", u32p),
+    ("adp_alpha", f32p), ("adp_beta", f32p), ("slope_factor", f32p),
 ]
 
 
@@ -140,6 +141,17 @@ NEURON_DEFAULTS = {
     # integrate_and_fire/mod.rs:1552-1570
     SIMPLE_LIF: dict(current_voltage=-75.0, gap_conductance=10.0, v_th=-55.0, v_reset=-75.0, c_m=100.0,
                      slif_g=-0.1, slif_e=0.0, dt=0.1),
+    # integrate_and_fire/mod.rs:969-996
+    ADAPTIVE_LIF: dict(current_voltage=-75.0, refractory_count=0.0, leak_constant=-1.0, integration_constant=1.0,
+                       gap_conductance=7.0, w_value=0.0, adp_alpha=6.0, adp_beta=10.0, v_th=-55.0, v_reset=-75.0,
+                       tau_m=10.0, c_m=100.0, g_l=10.0, e_l=-75.0, tref=10.0, dt=0.1),
+    # integrate_and_fire/mod.rs:1105-1130
+    ADAPTIVE_EXP_LIF: dict(current_voltage=-75.0, refractory_count=0.0, leak_constant=-1.0, integration_constant=1.0,
+                           gap_conductance=7.0, w_value=0.0, adp_alpha=6.0, adp_beta=10.0, slope_factor=1.0,
+                           v_th=-55.0, v_reset=-75.0, tau_m=10.0, c_m=100.0, g_l=10.0, e_l=-75.0, tref=10.0, dt=0.1),
+    # integrate_and_fire/mod.rs:1310-1331
+    LEAKY_IZHIKEVICH: dict(current_voltage=-65.0, gap_conductance=7.0, w_value=30.0, a=0.02, b=0.2, c=-55.0, d=8.0,
+                           v_th=30.0, tau_m=10.0, c_m=100.0, e_l=-65.0, dt=0.1),
 }
 # iterate_and_spike/mod.rs:174-182 (Approximate), :136-145 (Destexhe)
 NT_DEFAULTS = dict(nt_t=0.0, nt_t_max=1.0, nt_clearance=0.01, nt_v_p=2.0, nt_k_p=5.0)
@@ -154,7 +166,7 @@ STDP_DEFAULTS = dict(stdp_a_plus=2.0, stdp_a_minus=2.0, stdp_tau_plus=4.5, stdp_
 
 _NAMES = [n for n, _ in _FIELDS]
 _PER_NEURON = set(_NAMES[_NAMES.index("current_voltage"):_NAMES.index("was_increasing") + 1]) | {
-    "qif_alpha", "qif_v_c", "slif_g", "slif_e"}
+    "qif_alpha", "qif_v_c", "slif_g", "slif_e", "adp_alpha", "adp_beta", "slope_factor"}
 _PER_NEURON_K = {"nt_t", "nt_t_max", "nt_clearance", "nt_v_p", "nt_k_p", "nt_flags",
                  "rc_g", "rc_e", "rc_mg", "rc_r", "rc_alpha", "rc_beta", "rc_current", "rc_flags",
                  "input_t", "input_count"}

@@ -142,3 +142,45 @@ def test_simple_leaky_integrate_and_fire(snn, chemical):
     net.fill_graph(10, 0.5, 1.5)
     compare(snn, net, 600, chunks=3)
     assert net.spike_history.sum() > 0
+
+
+@pytest.mark.parametrize("chemical", [False, True])
+@pytest.mark.parametrize("exponential", [False, True])
+def test_adaptive_leaky_integrate_and_fire(snn, exponential, chemical):
+    """AdaptiveLeakyIntegrateAndFireNeuron (integrate_and_fire/mod.rs:918-1049) and the exponential variant
+    (:1051-1155): attributes alpha, beta, slope_factor, w_value next to the LIF set; heterogeneous parameters."""
+    lay = parity.Layout([(0, 6, 7)])
+    net = parity.make_oracle(lay, model=ob.ADAPTIVE_EXP_LIF if exponential else ob.ADAPTIVE_LIF, chemical=chemical)
+    n = net.n_neurons
+    net["current_voltage"] = ob.uniform_array(21, n, -75.0, -56.0)
+    net["gap_conductance"] = 3.0
+    net["tref"] = ob.uniform_array(22, n, 0.3, 1.5)
+    net["adp_beta"] = ob.uniform_array(23, n, 1.0, 4.0)
+    net["adp_alpha"] = ob.uniform_array(24, n, 3.0, 8.0)
+    net["leak_constant"] = 1.0
+    net["c_m"] = 1.0
+    net["v_reset"] = -73.0
+    if exponential:
+        net["slope_factor"] = ob.uniform_array(25, n, 0.5, 3.0)
+    net["nt_flags"][:, 0] = 1
+    net["rc_flags"][:, 0] = 1
+    net.fill_graph(26, 0.5, 1.5)
+    compare(snn, net, 600, chunks=2)
+    assert net.spike_history.sum() > 0
+
+
+@pytest.mark.parametrize("chemical", [False, True])
+def test_leaky_izhikevich(snn, chemical):
+    """LeakyIzhikevichNeuron (integrate_and_fire/mod.rs:1270-1356): the Izhikevich attributes + e_l."""
+    lay = parity.Layout([(0, 7, 6)])
+    net = parity.make_oracle(lay, model=ob.LEAKY_IZHIKEVICH, chemical=chemical)
+    n = net.n_neurons
+    net["current_voltage"] = ob.uniform_array(27, n, -65.0, 30.0)
+    net["gap_conductance"] = 10.0
+    net["w_value"] = ob.uniform_array(28, n, 0.0, 1.0)
+    net["e_l"] = ob.uniform_array(29, n, -70.0, -60.0)
+    net["nt_flags"][:, 0] = 1
+    net["rc_flags"][:, 0] = 1
+    net.fill_graph(30, 0.5, 1.5)
+    compare(snn, net, 600, chunks=3)
+    assert net.spike_history.sum() > 0

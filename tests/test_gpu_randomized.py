@@ -9,7 +9,7 @@ import parity
 
 pytestmark = pytest.mark.gpu
 
-MODELS = [ob.IZHIKEVICH, ob.LIF, ob.HH, ob.QIF, ob.SIMPLE_LIF]
+MODELS = [ob.IZHIKEVICH, ob.LIF, ob.HH, ob.QIF, ob.SIMPLE_LIF, ob.ADAPTIVE_LIF, ob.ADAPTIVE_EXP_LIF, ob.LEAKY_IZHIKEVICH]
 
 
 def draw(seed):
@@ -27,15 +27,25 @@ def draw(seed):
                              nt_kind=int(rng.integers(0, 2)), rc_kind=int(rng.integers(0, 2)))
     nn, nc = net.n_neurons, net.n_cells
     lo, hi = {ob.IZHIKEVICH: (-65, 30), ob.LIF: (-80, -50), ob.HH: (-75, -40), ob.QIF: (-75, -56),
-              ob.SIMPLE_LIF: (-75, -56)}[model]
+              ob.SIMPLE_LIF: (-75, -56), ob.ADAPTIVE_LIF: (-75, -56), ob.ADAPTIVE_EXP_LIF: (-75, -56),
+              ob.LEAKY_IZHIKEVICH: (-65, 30)}[model]
     net["current_voltage"] = ob.uniform_array(seed, nn, lo, hi)
     net["gap_conductance"] = ob.uniform_array(seed + 1, nn, 0.5, 12.0)
     if model == ob.SIMPLE_LIF:
         net["slif_g"] = 0.3
         net["slif_e"] = -76.0
-    if model in (ob.LIF, ob.QIF):
+    if model in (ob.LIF, ob.QIF, ob.ADAPTIVE_LIF, ob.ADAPTIVE_EXP_LIF):
         net["tref"] = ob.uniform_array(seed + 2, nn, 0.2, 2.0)
         net["tau_m"] = 10.0
+    if model in (ob.ADAPTIVE_LIF, ob.ADAPTIVE_EXP_LIF):
+        net["leak_constant"] = 1.0
+        net["c_m"] = 1.0
+        net["v_reset"] = -73.0
+        net["adp_beta"] = ob.uniform_array(seed + 7, nn, 0.5, 4.0)
+    if model == ob.ADAPTIVE_EXP_LIF:
+        net["slope_factor"] = ob.uniform_array(seed + 8, nn, 0.5, 3.0)
+    if model == ob.LEAKY_IZHIKEVICH:
+        net["w_value"] = ob.uniform_array(seed + 7, nn, 0.0, 1.0)
     net["nt_flags"][...] = rng.random((nn, 3)) < 0.5
     net["rc_flags"][...] = rng.random((nn, 3)) < 0.5
     net["rc_g"][...] *= ob.uniform_array(seed + 3, 3 * nn, 0.5, 3.0).reshape(nn, 3)
@@ -62,7 +72,7 @@ def draw(seed):
     return net, plan
 
 
-@pytest.mark.parametrize("seed", list(range(40)))
+@pytest.mark.parametrize("seed", list(range(48)))
 def test_random_network(snn, seed):
     import torch
     from snn_amd import parallel

@@ -77,6 +77,51 @@ def test_simple_lif_lattice_matches_numpy():
     assert np.array_equal(vh.view(np.uint32), net.voltage_history.view(np.uint32))
 
 
+@pytest.mark.parametrize("exponential", [False, True])
+def test_adaptive_lif_lattice_matches_numpy(exponential):
+    n = 20
+    net = ob.Net(n, model=ob.ADAPTIVE_EXP_LIF if exponential else ob.ADAPTIVE_LIF)
+    net["current_voltage"] = ob.uniform_array(11, n, -75.0, -56.0)
+    net["gap_conductance"] = 3.0
+    net["tref"] = 0.7
+    net["adp_beta"] = 3.0
+    net["leak_constant"] = 1.0                # positive feedback away from e_l so that cells cross threshold
+    net["c_m"] = 1.0
+    net["v_reset"] = -73.0
+    names = ["current_voltage", "w_value", "refractory_count", "leak_constant", "integration_constant", "e_l", "g_l",
+             "tau_m", "c_m", "dt", "v_th", "v_reset", "tref", "adp_alpha", "adp_beta"]
+    if exponential:
+        net["slope_factor"] = 2.0
+        names.append("slope_factor")
+    net.fill_graph(12, 0.5, 1.5)
+    s = _state(net, names)
+    expf = np.vectorize(ob.expf, otypes=[np.float32]) if exponential else None
+    vh, sh, lft = nr.run_lattice(lambda st, i: nr.adaptive_step(st, i, expf), s, net["gap_conductance"].copy(),
+                                 net["weights"].copy(), net["connections"].copy(), 600)
+    net.run(600, voltage_history=True, spike_history=True)
+    assert sh.sum() > 0
+    assert np.array_equal(sh, net.spike_history)
+    assert np.array_equal(vh.view(np.uint32), net.voltage_history.view(np.uint32))
+    assert np.array_equal(s["w_value"].view(np.uint32), net["w_value"].view(np.uint32))
+
+
+def test_leaky_izhikevich_lattice_matches_numpy():
+    n = 20
+    net = ob.Net(n, model=ob.LEAKY_IZHIKEVICH)
+    net["current_voltage"] = ob.uniform_array(13, n, -65.0, 30.0)
+    net["gap_conductance"] = 10.0
+    net["w_value"] = 0.5
+    net.fill_graph(14, 0.5, 1.5)
+    s = _state(net, ["current_voltage", "w_value", "a", "b", "c", "d", "e_l", "tau_m", "c_m", "dt", "v_th"])
+    vh, sh, lft = nr.run_lattice(nr.leaky_izhikevich_step, s, net["gap_conductance"].copy(), net["weights"].copy(),
+                                 net["connections"].copy(), 600)
+    net.run(600, voltage_history=True, spike_history=True)
+    assert sh.sum() > 0
+    assert np.array_equal(sh, net.spike_history)
+    assert np.array_equal(vh.view(np.uint32), net.voltage_history.view(np.uint32))
+    assert np.array_equal(s["w_value"].view(np.uint32), net["w_value"].view(np.uint32))
+
+
 def test_reduced_histories_against_numpy():
     """lattice_summaries (oracle) vs the voltage history reduced with numpy in the same chunked order, and the
     spike totals vs the column sums of the raster (SpikeHistory::aggregate, neuron/mod.rs:331-360)."""
