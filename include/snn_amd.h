@@ -85,11 +85,15 @@ typedef enum {
     SNN_MODEL_ADAPTIVE_LIF = 5, SNN_MODEL_ADAPTIVE_EXP_LIF = 6, SNN_MODEL_LEAKY_IZHIKEVICH = 7
 } snn_model;
 /* NeurotransmitterKinetics: Approximate iterate_and_spike/mod.rs:161-205, Destexhe :122-159 */
-typedef enum { SNN_NT_APPROXIMATE = 0, SNN_NT_DESTEXHE = 1 } snn_nt_kinetics;
+/* DiscreteSpikeNeurotransmitter :287-317; ExponentialDecayNeurotransmitter :323-366 (attribute
+ * neurotransmitters$decay_constant) */
+typedef enum { SNN_NT_APPROXIMATE = 0, SNN_NT_DESTEXHE = 1, SNN_NT_DISCRETE_SPIKE = 2, SNN_NT_EXPONENTIAL_DECAY = 3 } snn_nt_kinetics;
 /* ReceptorKinetics: Approximate iterate_and_spike/mod.rs:427-446, Destexhe :394-425 */
-typedef enum { SNN_RC_APPROXIMATE = 0, SNN_RC_DESTEXHE = 1 } snn_rc_kinetics;
+/* ExponentialDecayReceptor :497-533 (attributes receptors$<T>$r$kinetics$r_max, ...$decay_constant) */
+typedef enum { SNN_RC_APPROXIMATE = 0, SNN_RC_DESTEXHE = 1, SNN_RC_EXPONENTIAL_DECAY = 2 } snn_rc_kinetics;
 /* SpikeTrain: PoissonNeuron spike_train/mod.rs:259-371 (GPU generator :380-435), RateSpikeTrain :975-1031 */
-typedef enum { SNN_ST_NONE = 0, SNN_ST_POISSON = 1, SNN_ST_RATE = 2 } snn_spike_train_model;
+/* PresetSpikeTrain :753-833 (attributes internal_clock, counter; firing times via snn_set_firing_times) */
+typedef enum { SNN_ST_NONE = 0, SNN_ST_POISSON = 1, SNN_ST_RATE = 2, SNN_ST_PRESET = 3 } snn_spike_train_model;
 
 /* ---- construction (≙ from_lattice / from_network) -------------------------------------- */
 
@@ -208,6 +212,11 @@ int snn_history_steps(const snn_network_t *net, uint64_t *steps);
 /* [steps][rows*cols] of lattice `id`, oldest step first */
 int snn_get_voltage_history(snn_network_t *net, uint32_t id, float *dst, size_t count);
 int snn_get_spike_history(snn_network_t *net, uint32_t id, uint8_t *dst, size_t count);
+
+/* PresetSpikeTrain::firing_times (spike_train/mod.rs:772) of every cell of spike-train lattice `id`: cell i (row-major)
+ * fires through times[cell_ptr[i] .. cell_ptr[i+1]), cyclically; cell_ptr has rows*cols + 1 entries, starts at 0 and
+ * ends at n_times.  A cell with no times never fires.  Only with SNN_ST_PRESET (else SNN_ERR_BAD_STATE). */
+int snn_set_firing_times(snn_network_t *net, uint32_t id, const uint32_t *cell_ptr, const float *times, size_t n_times);
 
 /* Strided capture: store the history rows (voltage, raster, reduced rows) of every `every`-th step only -- steps
  * 0, every, 2*every, ... counted from the last (re)start of the record; 1 = every step (the reference's

@@ -243,12 +243,24 @@ void snn_o_inputs(snn_o_net *n) { snn_o_inputs_range(n, 0, n->n_neurons); }
 /* NeurotransmitterKinetics::apply_t_change: Approximate iterate_and_spike/mod.rs:193-196,
  * Destexhe :148-150.  `spiking` is what NeurotransmittersIntermediate carries
  * (intermediate_delegate/mod.rs:17-23). */
+/* exp_decay, iterate_and_spike/mod.rs:345-347 */
+static inline float exp_decay(float x, float l, float dt)
+{
+    return -x * snn_o_expf(dt / -l);
+}
+
 static inline float nt_apply(int kind, float t, float t_max, float clearance, float v_p, float k_p,
                              float voltage, uint32_t spiking, float dt)
 {
+    const float s = spiking ? 1.0f : 0.0f;
     if (kind == SNN_O_NT_DESTEXHE)
         return t_max / (1.0f + snn_o_expf(-(voltage - v_p) / k_p));
-    t += dt * -clearance * t + ((spiking ? 1.0f : 0.0f) * t_max);
+    if (kind == SNN_O_NT_DISCRETE_SPIKE)            /* DiscreteSpikeNeurotransmitter :300-302 */
+        return t_max * s;
+    if (kind == SNN_O_NT_EXPONENTIAL_DECAY)         /* ExponentialDecayNeurotransmitter :350-354, clearance = decay_constant */
+        t += exp_decay(t, clearance, dt) + (s * t_max);
+    else
+        t += dt * -clearance * t + (s * t_max);
     return o_min(t_max, o_max(t, 0.0f));
 }
 
@@ -278,6 +290,11 @@ static inline void receptors_update(snn_o_net *n, uint32_t q, float v_old)
             if (n->rc_kind == SNN_O_RC_DESTEXHE) {
                 float r = n->rc_r[i];
                 n->rc_r[i] = r + (n->rc_alpha[i] * t * (1.0f - r) - n->rc_beta[i] * r) * dt;
+            } else if (n->rc_kind == SNN_O_RC_EXPONENTIAL_DECAY) {
+                /* ExponentialDecayReceptor::apply_r_change :510-513; rc_alpha = r_max, rc_beta = decay_constant */
+                float r = n->rc_r[i];
+                r += exp_decay(r, n->rc_beta[i], dt) + t;
+                n->rc_r[i] = o_min(n->rc_alpha[i], o_max(r, 0.0f));
             } else {
                 n->rc_r[i] = t;
             }
@@ -657,6 +674,17 @@ void snn_o_spike_trains(snn_o_net *n)
             n->st_seed[s] = new_seed;
             float random_number = (float)new_seed / 4294967296.0f;   /* (float)seed / 0xFFFFFFFF */
             spike = random_number < n->st_chance_of_firing[s];
+        } else if (n->st_kind == SNN_O_ST_PRESET) {
+            /* PresetSpikeTrain::iterate spike_train/mod.rs:803-827; an empty list never fires */
+            float clock = n->st_step[s] + n->st_dt[s];
+            uint32_t f0 = n->st_firing_ptr[s], len = n->st_firing_ptr[s + 1] - f0;
+            spike = len != 0 && clock > n->st_firing_times[f0 + n->st_counter[s]];
+            if (spike) {
+                clock = 0.0f;
+                n->st_counter[s] += 1;
+                if (n->st_counter[s] == len) n->st_counter[s] = 0;
+            }
+            n->st_step[s] = clock;
         } else {
             float step = n->st_step[s] + n->st_dt[s];
             spike = (n->st_rate[s] != 0.0f) && (step >= n->st_rate[s]);

@@ -55,9 +55,9 @@ extern "C" {
 
 enum { SNN_O_IZHIKEVICH = 0, SNN_O_LIF = 1, SNN_O_HH = 2, SNN_O_QIF = 3, SNN_O_SIMPLE_LIF = 4,
        SNN_O_ADAPTIVE_LIF = 5, SNN_O_ADAPTIVE_EXP_LIF = 6, SNN_O_LEAKY_IZHIKEVICH = 7 };
-enum { SNN_O_NT_APPROX = 0, SNN_O_NT_DESTEXHE = 1 };
-enum { SNN_O_RC_APPROX = 0, SNN_O_RC_DESTEXHE = 1 };
-enum { SNN_O_ST_NONE = 0, SNN_O_ST_POISSON = 1, SNN_O_ST_RATE = 2 };
+enum { SNN_O_NT_APPROX = 0, SNN_O_NT_DESTEXHE = 1, SNN_O_NT_DISCRETE_SPIKE = 2, SNN_O_NT_EXPONENTIAL_DECAY = 3 };
+enum { SNN_O_RC_APPROX = 0, SNN_O_RC_DESTEXHE = 1, SNN_O_RC_EXPONENTIAL_DECAY = 2 };
+enum { SNN_O_ST_NONE = 0, SNN_O_ST_POISSON = 1, SNN_O_ST_RATE = 2, SNN_O_ST_PRESET = 3 };
 
 typedef struct snn_o_net {
     /* ---- sizes / switches ---- */
@@ -146,6 +146,13 @@ typedef struct snn_o_net {
      * AdaptiveExpLeakyIntegrateAndFireNeuron (:1051-1155): alpha, beta (+ slope_factor) next to the LIF arrays and
      * w_value; LeakyIzhikevichNeuron (:1270-1356) uses the Izhikevich arrays + e_l */
     float    *adp_alpha, *adp_beta, *slope_factor;
+    /* PresetSpikeTrain (spike_train/mod.rs:753-833): firing times of cell s are
+     * st_firing_times[st_firing_ptr[s] .. st_firing_ptr[s+1]); st_step holds its internal_clock.
+     * Further kinetics reuse arrays: ExponentialDecayNeurotransmitter's decay_constant lives in nt_clearance /
+     * st_nt_clearance, ExponentialDecayReceptor's r_max in rc_alpha and its decay_constant in rc_beta. */
+    uint32_t *st_firing_ptr;                   /* [n_cells + 1] */
+    float    *st_firing_times;
+    uint32_t *st_counter;                      /* [n_cells] */
 } snn_o_net;
 
 /* Step 1 of SURVEY §8(g): electrical + chemical inputs for every neuron from state S(t). */

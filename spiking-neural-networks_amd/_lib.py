@@ -92,6 +92,7 @@ SIGNATURES = {
     "snn_history_steps": (C.c_int, [H, u64p]),
     "snn_get_voltage_history": (C.c_int, [H, C.c_uint32, f32p, C.c_size_t]),
     "snn_get_spike_history": (C.c_int, [H, C.c_uint32, u8p, C.c_size_t]),
+    "snn_set_firing_times": (C.c_int, [H, C.c_uint32, u32p, f32p, C.c_size_t]),
     "snn_set_history_stride": (C.c_int, [H, C.c_uint32]),
     "snn_set_reduced_history": (C.c_int, [H, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float]),
     "snn_get_average_voltage_history": (C.c_int, [H, C.c_uint32, f32p, C.c_size_t]),

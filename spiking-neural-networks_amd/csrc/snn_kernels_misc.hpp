@@ -75,7 +75,7 @@ __global__ void k_graph_synthetic(float *W, uint32_t ld, uint32_t n_loc, uint32_
 struct SpikeTrainArgs {
     CellArrays c;
     uint32_t n_cells;
-    int st_kind;            // 1 Poisson (xorshift32), 2 Rate
+    int st_kind;            // 1 Poisson (xorshift32), 2 Rate, 3 Preset
     int nt_kind;
     int iterate;            // 0: only refresh presyn_value for `view_clock`
     const long long *lattice_clock;   // [n_st_lattices] clocks at the start of this run call
@@ -96,6 +96,20 @@ __global__ __launch_bounds__(256) void k_spike_trains(const SpikeTrainArgs a)
             c.seed[s] = new_seed;
             const float random_number = (float)new_seed / 4294967296.0f;   // (float) seed / 0xFFFFFFFF
             spike = random_number < c.chance_of_firing[s];
+        } else if (a.st_kind == 3) {
+            // PresetSpikeTrain::iterate, spike_train/mod.rs:803-827 (`step` holds internal_clock).  A cell
+            // without firing times never fires (the reference would index an empty Vec).
+            float clock = c.step[s] + c.dt[s];
+            const uint32_t f0 = c.preset_ptr[s], len = c.preset_ptr[s + 1] - f0;
+            uint32_t counter = c.counter[s];
+            spike = len != 0 && clock > c.preset_times[f0 + counter];
+            if (spike) {
+                clock = 0.0f;
+                counter += 1;
+                if (counter == len) counter = 0;
+                c.counter[s] = counter;
+            }
+            c.step[s] = clock;
         } else {
             float step = c.step[s] + c.dt[s];
             spike = (c.rate[s] != 0.0f) && (step >= c.rate[s]);
@@ -110,14 +124,8 @@ __global__ __launch_bounds__(256) void k_spike_trains(const SpikeTrainArgs a)
             const size_t i = (size_t)k * c.c_pad + s;
             if (!c.nt_flags[i]) continue;
             // spike trains release on their CURRENT spike flag (spike_train/mod.rs:363-365)
-            float t = c.nt_t[i];
-            if (a.nt_kind == 1) {
-                t = c.nt_t_max[i] / (1.0f + expf_portable(-(v - c.nt_v_p[i]) / c.nt_k_p[i]));
-            } else {
-                t += c.dt[s] * -c.nt_clearance[i] * t + ((spike ? 1.0f : 0.0f) * c.nt_t_max[i]);
-                t = min_rs(c.nt_t_max[i], max_rs(t, 0.0f));
-            }
-            c.nt_t[i] = t;
+            c.nt_t[i] = nt_apply(a.nt_kind, c.nt_t[i], c.nt_t_max[i], c.nt_clearance[i], c.nt_v_p[i], c.nt_k_p[i],
+                                 v, spike, c.dt[s]);
         }
         if (spike) c.last_firing_time[s] = (int32_t)(a.lattice_clock[c.lattice_slot[s]] + a.step_offset);
         if (a.vhist_row) a.vhist_row[s] = v;

@@ -50,14 +50,6 @@ __device__ __forceinline__ float combine_partials(const float *p, uint32_t n_chu
 
 // NeurotransmitterKinetics::apply_t_change: Approximate iterate_and_spike/mod.rs:193-196,
 // Destexhe :148-150
-__device__ __forceinline__ float nt_apply(int kind, float t, float t_max, float clearance, float v_p,
-                                          float k_p, float voltage, uint32_t spiking, float dt)
-{
-    if (kind == 1) return t_max / (1.0f + expf_portable(-(voltage - v_p) / k_p));
-    t += dt * -clearance * t + ((spiking ? 1.0f : 0.0f) * t_max);
-    return min_rs(t_max, max_rs(t, 0.0f));
-}
-
 __device__ __forceinline__ void neuron_nt_update(const UpdateArgs &a, uint32_t q, float voltage,
                                                  uint32_t spiking_prev, float dt)
 {
@@ -84,12 +76,7 @@ __device__ __forceinline__ void receptors_update(const UpdateArgs &a, uint32_t q
             // second level of the canonical sum, then the per-type average
             const float s = combine_partials(a.part_t + (size_t)k * a.n_chunks * a.ld + ql, a.n_chunks, a.ld);
             const float t = s / (float)cnt;
-            if (a.rc_kind == 1) {
-                const float r = a.n.rc_r[i];
-                a.n.rc_r[i] = r + (a.n.rc_alpha[i] * t * (1.0f - r) - a.n.rc_beta[i] * r) * dt;
-            } else {
-                a.n.rc_r[i] = t;
-            }
+            a.n.rc_r[i] = rc_apply(a.rc_kind, a.n.rc_r[i], t, a.n.rc_alpha[i], a.n.rc_beta[i], dt);
         }
     }
 #pragma unroll

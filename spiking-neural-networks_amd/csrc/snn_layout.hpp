@@ -74,6 +74,11 @@ struct CellArrays {
     float *current_voltage, *v_th, *v_resting, *dt, *k;
     float *chance_of_firing, *rate, *step;
     uint32_t *seed, *is_spiking;
+    // PresetSpikeTrain: firing times of cell s = preset_times[preset_ptr[s] .. preset_ptr[s + 1]); `step` holds
+    // its internal_clock
+    uint32_t *counter;
+    const uint32_t *preset_ptr;
+    const float *preset_times;
     int32_t *last_firing_time;
     float *nt_t, *nt_t_max, *nt_clearance, *nt_v_p, *nt_k_p;   // [3][c_pad]
     uint32_t *nt_flags;

@@ -107,6 +107,39 @@ __device__ __forceinline__ float stdp_delta(int t_pre, int t_post, float a_plus,
     return 0.0f;
 }
 
+// ---- neurotransmitter / receptor kinetics ------------------------------------------------------
+// exp_decay, iterate_and_spike/mod.rs:345-347
+__device__ __forceinline__ float exp_decay(float x, float l, float dt)
+{
+    return -x * expf_portable(dt / -l);
+}
+
+// NeurotransmitterKinetics::apply_t_change.  kind 0 Approximate (iterate_and_spike/mod.rs:193-196), 1 Destexhe
+// (:148-150), 2 DiscreteSpike (:300-302), 3 ExponentialDecay (:350-354; `c` = decay_constant instead of the
+// clearance constant).
+__device__ __forceinline__ float nt_apply(int kind, float t, float t_max, float c, float v_p, float k_p,
+                                          float voltage, uint32_t spiking, float dt)
+{
+    const float s = spiking ? 1.0f : 0.0f;
+    if (kind == 1) return t_max / (1.0f + expf_portable(-(voltage - v_p) / k_p));
+    if (kind == 2) return t_max * s;
+    if (kind == 3) t += exp_decay(t, c, dt) + (s * t_max);
+    else t += dt * -c * t + (s * t_max);
+    return min_rs(t_max, max_rs(t, 0.0f));
+}
+
+// ReceptorKinetics::apply_r_change.  kind 0 Approximate (iterate_and_spike/mod.rs:435-437), 1 Destexhe (:404-406),
+// 2 ExponentialDecay (:510-513; alpha = r_max, beta = decay_constant).
+__device__ __forceinline__ float rc_apply(int kind, float r, float t, float alpha, float beta, float dt)
+{
+    if (kind == 1) return r + (alpha * t * (1.0f - r) - beta * r) * dt;
+    if (kind == 2) {
+        r += exp_decay(r, beta, dt) + t;
+        return min_rs(alpha, max_rs(r, 0.0f));
+    }
+    return t;
+}
+
 // Counter-based synthetic data (splitmix64 finaliser), used by the device-side
 // graph / state generators so that benchmark-size inputs never cross PCIe.
 __host__ __device__ __forceinline__ uint32_t hash32(uint64_t seed, uint64_t index)

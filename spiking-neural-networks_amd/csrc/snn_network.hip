@@ -121,6 +121,8 @@ struct snn_network {
     float *summ_avg = nullptr, *summ_eeg = nullptr;                 // [cap][n_lattices]
     uint32_t *spike_counts = nullptr, *lat_first_dev = nullptr, *lat_count_dev = nullptr;
     uint64_t hist_steps = 0, hist_cap = 0;
+    std::vector<std::vector<float>> preset_host;   // PresetSpikeTrain firing times per cell
+    float *preset_times_dev = nullptr;
     uint64_t hist_tick = 0;                // steps seen since the record was (re)started
     uint32_t hist_every = 1;               // a row is stored when hist_tick % hist_every == 0
     float *vhist = nullptr, *st_vhist = nullptr;
@@ -318,13 +320,16 @@ int build_state(snn_network *net)
 
     // neurotransmitters (iterate_and_spike/mod.rs:136-145, 174-182) -- absent by default (flags 0)
     TRY(typed_f32(net, &n.nt_t_max, np, 1.0f, 1.0f, 1.0f));
-    TRY(typed_f32(net, &n.nt_clearance, np, 0.01f, 0.01f, 0.01f));
+    // clearance_constant of the Approximate kinetics / decay_constant of ExponentialDecay (:336-343) share storage
+    const float nt_c = net->nt_kind == SNN_NT_EXPONENTIAL_DECAY ? 2.0f : 0.01f;
+    TRY(typed_f32(net, &n.nt_clearance, np, nt_c, nt_c, nt_c));
     TRY(typed_f32(net, &n.nt_v_p, np, 2.0f, 2.0f, 2.0f));
     TRY(typed_f32(net, &n.nt_k_p, np, 5.0f, 5.0f, 5.0f));
     TRY(dev_alloc_t(net, &n.nt_flags, (size_t)K_TYPES * np));
     TRY(fill_u32(net, n.nt_flags, (size_t)K_TYPES * np, 0));
     reg(A, "neurotransmitters$t_max", T_F32, S_PLAIN_K, n.nt_t_max, 0, np);
     reg(A, "neurotransmitters$clearance_constant", T_F32, S_PLAIN_K, n.nt_clearance, 0, np);
+    reg(A, "neurotransmitters$decay_constant", T_F32, S_PLAIN_K, n.nt_clearance, 0, np);
     reg(A, "neurotransmitters$v_p", T_F32, S_PLAIN_K, n.nt_v_p, 0, np);
     reg(A, "neurotransmitters$k_p", T_F32, S_PLAIN_K, n.nt_k_p, 0, np);
     reg(A, "neurotransmitters$flags", T_U32, S_PLAIN_K, n.nt_flags, 0, np, 1);
@@ -335,7 +340,9 @@ int build_state(snn_network *net)
     TRY(typed_f32(net, &n.rc_mg, np, 0.0f, 0.3f, 0.0f));
     TRY(typed_f32(net, &n.rc_r, np, 0.0f, 0.0f, 0.0f));
     TRY(typed_f32(net, &n.rc_alpha, np, 1.0f, 1.0f, 1.0f));
-    TRY(typed_f32(net, &n.rc_beta, np, 1.0f, 1.0f, 1.0f));
+    // ExponentialDecayReceptor (:501-533): r_max lives in the alpha array, decay_constant in the beta array
+    const float rc_b = net->rc_kind == SNN_RC_EXPONENTIAL_DECAY ? 2.0f : 1.0f;
+    TRY(typed_f32(net, &n.rc_beta, np, rc_b, rc_b, rc_b));
     TRY(typed_f32(net, &n.rc_current, np, 0.0f, 0.0f, 0.0f));
     TRY(dev_alloc_t(net, &n.rc_flags, (size_t)K_TYPES * np));
     TRY(fill_u32(net, n.rc_flags, (size_t)K_TYPES * np, 0));
@@ -349,6 +356,8 @@ int build_state(snn_network *net)
         reg(A, (p + "$r$kinetics$r").c_str(), T_F32, S_PLAIN, n.rc_r + (size_t)k * np, 0, 0);
         reg(A, (p + "$r$kinetics$alpha").c_str(), T_F32, S_PLAIN, n.rc_alpha + (size_t)k * np, 0, 0);
         reg(A, (p + "$r$kinetics$beta").c_str(), T_F32, S_PLAIN, n.rc_beta + (size_t)k * np, 0, 0);
+        reg(A, (p + "$r$kinetics$r_max").c_str(), T_F32, S_PLAIN, n.rc_alpha + (size_t)k * np, 0, 0);
+        reg(A, (p + "$r$kinetics$decay_constant").c_str(), T_F32, S_PLAIN, n.rc_beta + (size_t)k * np, 0, 0);
     }
     reg(A, "receptors$NMDA_mg", T_F32, S_PLAIN, n.rc_mg + (size_t)1 * np, 0, 0);
 
@@ -391,7 +400,19 @@ int build_state(snn_network *net)
     TRY(cell_f32(net, &c.k, "neural_refractoriness$k", 10000.0f));
     TRY(cell_f32(net, &c.chance_of_firing, net->st_kind == SNN_ST_POISSON ? "chance_of_firing" : nullptr, 0.0f));
     TRY(cell_f32(net, &c.rate, net->st_kind == SNN_ST_RATE ? "rate" : nullptr, 0.0f));
-    TRY(cell_f32(net, &c.step, net->st_kind == SNN_ST_RATE ? "step" : nullptr, 0.0f));
+    TRY(cell_f32(net, &c.step, net->st_kind == SNN_ST_RATE ? "step" : (net->st_kind == SNN_ST_PRESET ? "internal_clock" : nullptr), 0.0f));
+    TRY(dev_alloc_t(net, &c.counter, cp));
+    TRY(fill_u32(net, c.counter, cp, 0));
+    if (net->st_kind == SNN_ST_PRESET) reg(CA, "counter", T_U32, S_PLAIN, c.counter, 0, 0);
+    {
+        // no firing times until snn_set_firing_times: every cell's list is empty
+        uint32_t *ptr = nullptr;
+        TRY(dev_alloc_t(net, &ptr, (size_t)cp + 1));
+        TRY(fill_u32(net, ptr, (size_t)cp + 1, 0));
+        c.preset_ptr = ptr;
+        c.preset_times = nullptr;
+        net->preset_host.assign(net->nc, {});
+    }
     TRY(cell_f32(net, &c.presyn_value, nullptr, 0.0f));
     TRY(dev_alloc_t(net, &c.seed, cp));
     if (cp) {
@@ -408,7 +429,7 @@ int build_state(snn_network *net)
     reg(CA, "last_firing_time", T_I32, S_PLAIN, c.last_firing_time, 0, 0);
     TRY(typed_f32(net, &c.nt_t, cp, 0.0f, 0.0f, 0.0f));
     TRY(typed_f32(net, &c.nt_t_max, cp, 1.0f, 1.0f, 1.0f));
-    TRY(typed_f32(net, &c.nt_clearance, cp, 0.01f, 0.01f, 0.01f));
+    TRY(typed_f32(net, &c.nt_clearance, cp, nt_c, nt_c, nt_c));
     TRY(typed_f32(net, &c.nt_v_p, cp, 2.0f, 2.0f, 2.0f));
     TRY(typed_f32(net, &c.nt_k_p, cp, 5.0f, 5.0f, 5.0f));
     TRY(dev_alloc_t(net, &c.nt_flags, (size_t)K_TYPES * cp));
@@ -416,6 +437,7 @@ int build_state(snn_network *net)
     reg(CA, "neurotransmitters$t", T_F32, S_PLAIN_K, c.nt_t, 0, cp);
     reg(CA, "neurotransmitters$t_max", T_F32, S_PLAIN_K, c.nt_t_max, 0, cp);
     reg(CA, "neurotransmitters$clearance_constant", T_F32, S_PLAIN_K, c.nt_clearance, 0, cp);
+    reg(CA, "neurotransmitters$decay_constant", T_F32, S_PLAIN_K, c.nt_clearance, 0, cp);
     reg(CA, "neurotransmitters$v_p", T_F32, S_PLAIN_K, c.nt_v_p, 0, cp);
     reg(CA, "neurotransmitters$k_p", T_F32, S_PLAIN_K, c.nt_k_p, 0, cp);
     reg(CA, "neurotransmitters$flags", T_U32, S_PLAIN_K, c.nt_flags, 0, cp, 1);
@@ -958,8 +980,8 @@ int snn_network_create(int device, int neuron_model, int nt_kinetics, int recept
 {
     if (!out) return fail(SNN_ERR_BAD_ARG, "out is null");
     *out = nullptr;
-    if (neuron_model < 0 || neuron_model > 7 || nt_kinetics < 0 || nt_kinetics > 1 || receptor_kinetics < 0 ||
-        receptor_kinetics > 1 || spike_train_model < 0 || spike_train_model > 2)
+    if (neuron_model < 0 || neuron_model > 7 || nt_kinetics < 0 || nt_kinetics > 3 || receptor_kinetics < 0 ||
+        receptor_kinetics > 2 || spike_train_model < 0 || spike_train_model > 3)
         return fail(SNN_ERR_BAD_ARG, "unknown model / kinetics selector");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -991,6 +1013,7 @@ int snn_network_destroy(snn_network_t *net)
     if (net->vhist) (void)hipFree(net->vhist);
     if (net->st_vhist) (void)hipFree(net->st_vhist);
     if (net->raster) (void)hipFree(net->raster);
+    if (net->preset_times_dev) (void)hipFree(net->preset_times_dev);
     if (net->summ_avg) (void)hipFree(net->summ_avg);
     if (net->summ_eeg) (void)hipFree(net->summ_eeg);
     for (auto &e : net->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -1313,6 +1336,40 @@ int snn_reset_history(snn_network_t *net)
         TRY(end_run(net));
         HIP_TRY(hipMemset(net->spike_counts, 0, (size_t)net->n_pad * 4), SNN_ERR_BUFFER_WRITE);
     }
+    return SNN_OK;
+}
+
+int snn_set_firing_times(snn_network_t *net, uint32_t id, const uint32_t *cell_ptr, const float *times, size_t n_times)
+{
+    if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
+    if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
+    if (net->st_kind != SNN_ST_PRESET) return fail(SNN_ERR_BAD_STATE, "the spike-train model is not SNN_ST_PRESET");
+    const LatticeInfo *l = find_lattice(net, id);
+    if (!l || !l->spike_train) return fail(SNN_ERR_BAD_ARG, "no such spike-train lattice");
+    if (l->count == 0) return SNN_OK;
+    if (!cell_ptr || (n_times && !times)) return fail(SNN_ERR_BAD_ARG, "null pointer");
+    if (cell_ptr[0] != 0 || cell_ptr[l->count] != n_times) return fail(SNN_ERR_DIM_MISMATCH, "cell_ptr must run from 0 to n_times");
+    for (uint32_t i = 0; i < l->count; ++i)
+        if (cell_ptr[i] > cell_ptr[i + 1]) return fail(SNN_ERR_BAD_ARG, "cell_ptr must be non-decreasing");
+    HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
+    TRY(end_run(net));
+    const uint32_t c0 = l->first - net->nn;
+    for (uint32_t i = 0; i < l->count; ++i) net->preset_host[c0 + i].assign(times + cell_ptr[i], times + cell_ptr[i + 1]);
+    std::vector<uint32_t> ptr((size_t)net->c_pad + 1, 0);
+    std::vector<float> flat;
+    for (uint32_t s = 0; s < net->nc; ++s) {
+        ptr[s] = (uint32_t)flat.size();
+        flat.insert(flat.end(), net->preset_host[s].begin(), net->preset_host[s].end());
+    }
+    for (size_t s = net->nc; s <= net->c_pad; ++s) ptr[s] = (uint32_t)flat.size();
+    float *nt = nullptr;
+    HIP_TRY(hipMalloc(&nt, std::max<size_t>(256, flat.size() * 4)), SNN_ERR_BUFFER_CREATE);
+    if (!flat.empty()) HIP_TRY(hipMemcpy(nt, flat.data(), flat.size() * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
+    HIP_TRY(hipMemcpy(const_cast<uint32_t *>(net->ca.preset_ptr), ptr.data(), ptr.size() * 4, hipMemcpyHostToDevice),
+            SNN_ERR_BUFFER_WRITE);
+    if (net->preset_times_dev) (void)hipFree(net->preset_times_dev);
+    net->preset_times_dev = nt;
+    net->ca.preset_times = nt;
     return SNN_OK;
 }
 

@@ -14,7 +14,8 @@ import enum
 
 import numpy as np
 
-from .network import (DeviceNetwork, HODGKIN_HUXLEY, IZHIKEVICH, LIF, QUADRATIC_INTEGRATE_AND_FIRE, SIMPLE_LIF,
+from .network import (NT_DISCRETE_SPIKE, NT_EXPONENTIAL_DECAY, RC_EXPONENTIAL_DECAY, ST_PRESET,
+                      DeviceNetwork, HODGKIN_HUXLEY, IZHIKEVICH, LIF, QUADRATIC_INTEGRATE_AND_FIRE, SIMPLE_LIF,
                       ADAPTIVE_LIF, ADAPTIVE_EXP_LIF, LEAKY_IZHIKEVICH,
                       NT_APPROXIMATE, NT_DESTEXHE,
                       RC_APPROXIMATE, RC_DESTEXHE, ST_NONE, ST_POISSON, ST_RATE)
@@ -51,6 +52,16 @@ class DestexheNeurotransmitter(_Record):                 # iterate_and_spike/mod
     kinetics = NT_DESTEXHE
 
 
+class DiscreteSpikeNeurotransmitter(_Record):            # iterate_and_spike/mod.rs:287-317
+    _defaults = dict(t_max=1.0, t=0.0)
+    kinetics = NT_DISCRETE_SPIKE
+
+
+class ExponentialDecayNeurotransmitter(_Record):         # iterate_and_spike/mod.rs:323-366
+    _defaults = dict(t_max=1.0, t=0.0, decay_constant=2.0)
+    kinetics = NT_EXPONENTIAL_DECAY
+
+
 class ApproximateReceptor(_Record):                      # iterate_and_spike/mod.rs:427-446
     _defaults = dict(r=0.0)
     kinetics = RC_APPROXIMATE
@@ -59,6 +70,11 @@ class ApproximateReceptor(_Record):                      # iterate_and_spike/mod
 class DestexheReceptor(_Record):                         # iterate_and_spike/mod.rs:394-425
     _defaults = dict(r=0.0, alpha=1.0, beta=1.0)
     kinetics = RC_DESTEXHE
+
+
+class ExponentialDecayReceptor(_Record):                 # iterate_and_spike/mod.rs:497-533
+    _defaults = dict(r_max=1.0, r=0.0, decay_constant=2.0)
+    kinetics = RC_EXPONENTIAL_DECAY
 
 
 class AMPAReceptor(_Record):                             # iterate_and_spike/mod.rs:1078-1094
@@ -206,6 +222,12 @@ class RateSpikeTrain(_SpikeTrain):                       # spike_train/mod.rs:97
     kind = ST_RATE
     _defaults = dict(current_voltage=0.0, v_th=30.0, v_resting=0.0, rate=0.0, step=0.0, is_spiking=False,
                      last_firing_time=None, dt=0.1, k=10000.0)
+
+
+class PresetSpikeTrain(_SpikeTrain):                     # spike_train/mod.rs:753-800
+    kind = ST_PRESET
+    _defaults = dict(current_voltage=0.0, v_th=30.0, v_resting=0.0, is_spiking=False, last_firing_time=None,
+                     firing_times=(), internal_clock=0.0, counter=0, dt=0.1, k=10000.0)
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -440,6 +462,8 @@ def _upload_nt(dn, id, cells):
             for k in arr:
                 if hasattr(v, k):
                     arr[k][i, int(t)] = getattr(v, k)
+            if hasattr(v, "decay_constant"):         # ExponentialDecay: same storage as the clearance constant
+                arr["clearance_constant"][i, int(t)] = v.decay_constant
     dn.set_attr(id, "neurotransmitters$flags", flags)
     for k, a in arr.items():
         dn.set_attr(id, f"neurotransmitters${k}", a)
@@ -469,7 +493,9 @@ def _upload_neurons(dn, id, cells):
             vals["g"][i], vals["e"][i], vals["current"][i] = rec.g, rec.e, rec.current
             vals["mg"][i] = getattr(rec, "mg", 0.0)
             vals["r"][i] = rec.r.r
-            vals["alpha"][i], vals["beta"][i] = getattr(rec.r, "alpha", 1.0), getattr(rec.r, "beta", 1.0)
+            # ExponentialDecayReceptor keeps r_max / decay_constant where Destexhe keeps alpha / beta
+            vals["alpha"][i] = getattr(rec.r, "alpha", getattr(rec.r, "r_max", 1.0))
+            vals["beta"][i] = getattr(rec.r, "beta", getattr(rec.r, "decay_constant", 1.0))
         p = f"receptors${t.name}"
         dn.set_attr(id, p + "_g", vals["g"])
         dn.set_attr(id, p + "_e", vals["e"])
@@ -519,6 +545,12 @@ def _upload_cells(dn, id, cells):
     if cells[0].kind == ST_POISSON:
         dn.set_attr(id, "chance_of_firing", f32("chance_of_firing"))
         dn.set_attr(id, "seed", np.array([c.seed for c in cells], np.uint32))
+    elif cells[0].kind == ST_PRESET:
+        dn.set_attr(id, "internal_clock", f32("internal_clock"))
+        dn.set_attr(id, "counter", np.array([c.counter for c in cells], np.uint32))
+        ptr = np.concatenate([[0], np.cumsum([len(c.firing_times) for c in cells])]).astype(np.uint32)
+        times = np.array([t for c in cells for t in c.firing_times], np.float32)
+        dn.set_firing_times(id, ptr, times)
     else:
         dn.set_attr(id, "rate", f32("rate"))
         dn.set_attr(id, "step", f32("step"))
@@ -614,6 +646,10 @@ class LatticeNetworkGPU:
                                          dn.get_attr(id, "last_firing_time", dtype=np.int32)):
                     cell.current_voltage, cell.is_spiking = float(v), bool(s)
                     cell.last_firing_time = None if t < 0 else int(t)
+                if cells[0].kind == ST_PRESET:
+                    for cell, clk, cnt in zip(cells, dn.get_attr(id, "internal_clock"),
+                                              dn.get_attr(id, "counter", dtype=np.uint32)):
+                        cell.internal_clock, cell.counter = float(clk), int(cnt)
         if w is not None:
             for key in net.connecting:
                 net.connecting[key] = float(w[self._global(key[0]), self._global(key[1])])
@@ -794,5 +830,6 @@ HodgkinHuxleyNeuronLatticeGPU = _named(LatticeGPU, "HodgkinHuxleyNeuronLatticeGP
                                        lattice_type=HodgkinHuxleyNeuronLattice)
 RateSpikeTrainLattice = _named(SpikeTrainLattice, "RateSpikeTrainLattice", spike_train_type=RateSpikeTrain)
 PoissonNeuronLattice = _named(SpikeTrainLattice, "PoissonNeuronLattice", spike_train_type=PoissonNeuron)
+PresetSpikeTrainLattice = _named(SpikeTrainLattice, "PresetSpikeTrainLattice", spike_train_type=PresetSpikeTrain)
 IzhikevichNeuronNetwork = _named(LatticeNetwork, "IzhikevichNeuronNetwork")
 IzhikevichNeuronNetworkGPU = _named(LatticeNetworkGPU, "IzhikevichNeuronNetworkGPU")

@@ -15,9 +15,9 @@ from . import _lib
 
 IZHIKEVICH, LIF, HODGKIN_HUXLEY, QUADRATIC_INTEGRATE_AND_FIRE, SIMPLE_LIF = 0, 1, 2, 3, 4
 ADAPTIVE_LIF, ADAPTIVE_EXP_LIF, LEAKY_IZHIKEVICH = 5, 6, 7
-NT_APPROXIMATE, NT_DESTEXHE = 0, 1
-RC_APPROXIMATE, RC_DESTEXHE = 0, 1
-ST_NONE, ST_POISSON, ST_RATE = 0, 1, 2
+NT_APPROXIMATE, NT_DESTEXHE, NT_DISCRETE_SPIKE, NT_EXPONENTIAL_DECAY = 0, 1, 2, 3
+RC_APPROXIMATE, RC_DESTEXHE, RC_EXPONENTIAL_DECAY = 0, 1, 2
+ST_NONE, ST_POISSON, ST_RATE, ST_PRESET = 0, 1, 2, 3
 NUM_NT_TYPES = 3
 
 _DT = {np.dtype(np.float32): "f32", np.dtype(np.uint32): "u32", np.dtype(np.int32): "i32"}
@@ -233,6 +233,17 @@ class DeviceNetwork:
         out = np.empty((steps, rows * cols), np.uint8)
         _lib.check(self._L.snn_get_spike_history(self._h, id, out.ctypes.data_as(_lib.u8p), out.size))
         return out
+
+    def set_firing_times(self, id, cell_ptr, times):
+        """PresetSpikeTrain firing times of spike-train lattice `id`: cell i fires through
+        times[cell_ptr[i]:cell_ptr[i+1]] cyclically (spike_train/mod.rs:753-833)."""
+        cp = np.ascontiguousarray(cell_ptr, dtype=np.uint32)
+        t = np.ascontiguousarray(times, dtype=np.float32)
+        rows, cols, _ = self.lattices[id]
+        if cp.size != rows * cols + 1:
+            raise ValueError("cell_ptr must have rows*cols + 1 entries")
+        _lib.check(self._L.snn_set_firing_times(self._h, id, cp.ctypes.data_as(_lib.u32p),
+                                                t.ctypes.data_as(_lib.f32p), t.size))
 
     def set_history_stride(self, every):
         _lib.check(self._L.snn_set_history_stride(self._h, int(every)))

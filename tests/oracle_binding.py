@@ -13,9 +13,9 @@ import numpy as np
 K = 3          # AMPA, NMDA, GABA
 CHUNK = 256
 IZHIKEVICH, LIF, HH, QIF, SIMPLE_LIF, ADAPTIVE_LIF, ADAPTIVE_EXP_LIF, LEAKY_IZHIKEVICH = 0, 1, 2, 3, 4, 5, 6, 7
-NT_APPROX, NT_DESTEXHE = 0, 1
-RC_APPROX, RC_DESTEXHE = 0, 1
-ST_NONE, ST_POISSON, ST_RATE = 0, 1, 2
+NT_APPROX, NT_DESTEXHE, NT_DISCRETE_SPIKE, NT_EXPONENTIAL_DECAY = 0, 1, 2, 3
+RC_APPROX, RC_DESTEXHE, RC_EXPONENTIAL_DECAY = 0, 1, 2
+ST_NONE, ST_POISSON, ST_RATE, ST_PRESET = 0, 1, 2, 3
 
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _ORACLE_DIR = os.path.join(_ROOT, "oracle")
@@ -66,6 +66,7 @@ _FIELDS = [
     ("eeg_reference_voltage", C.c_float), ("eeg_distance", C.c_float), ("eeg_conductivity", C.c_float),
     ("spike_counts", u32p),
     ("adp_alpha", f32p), ("adp_beta", f32p), ("slope_factor", f32p),
+    ("st_firing_ptr", u32p), ("st_firing_times", f32p), ("st_counter", u32p),
 ]
 
 
@@ -171,7 +172,7 @@ _PER_NEURON_K = {"nt_t", "nt_t_max", "nt_clearance", "nt_v_p", "nt_k_p", "nt_fla
                  "rc_g", "rc_e", "rc_mg", "rc_r", "rc_alpha", "rc_beta", "rc_current", "rc_flags",
                  "input_t", "input_count"}
 _PER_CELL = {"st_current_voltage", "st_v_th", "st_v_resting", "st_dt", "st_k", "st_chance_of_firing",
-             "st_rate", "st_step", "st_seed", "st_is_spiking", "st_last_firing_time", "st_lattice"}
+             "st_rate", "st_step", "st_seed", "st_is_spiking", "st_last_firing_time", "st_lattice", "st_counter"}
 _PER_CELL_K = {"st_nt_t", "st_nt_t_max", "st_nt_clearance", "st_nt_v_p", "st_nt_k_p", "st_nt_flags"}
 _PER_LATTICE = {"stdp_a_plus", "stdp_a_minus", "stdp_tau_plus", "stdp_tau_minus", "stdp_dt", "do_plasticity",
                 "lattice_first", "lattice_count"}
@@ -237,6 +238,13 @@ class Net:
             a[k][...] = v
         for k, v in STDP_DEFAULTS.items():
             a[k][...] = v
+        if nt_kind == NT_EXPONENTIAL_DECAY:       # decay_constant, iterate_and_spike/mod.rs:336-343
+            a["nt_clearance"][...] = 2.0
+            a["st_nt_clearance"][...] = 2.0
+        if rc_kind == RC_EXPONENTIAL_DECAY:       # r_max (alpha array) 1, decay_constant (beta array) 2, :525-533
+            a["rc_beta"][...] = 2.0
+        a["st_firing_ptr"] = np.zeros(nc + 1, np.uint32)
+        a["st_firing_times"] = np.zeros(0, np.float32)
         a["st_seed"][...] = np.arange(1, nc + 1, dtype=np.uint32)
         a["lattice_count"][...] = 0
         a["lattice_count"][0] = nn              # single lattice by default; parity.make_oracle sets real ranges
@@ -247,6 +255,14 @@ class Net:
 
     def __setitem__(self, name, value):
         self.arr[name][...] = value
+
+    def set_firing_times(self, per_cell):
+        """PresetSpikeTrain::firing_times for every cell (list of sequences, one per cell)."""
+        assert len(per_cell) == self.n_cells
+        lens = np.array([len(x) for x in per_cell], np.uint32)
+        self.arr["st_firing_ptr"] = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint32)
+        self.arr["st_firing_times"] = np.ascontiguousarray(
+            np.concatenate([np.asarray(x, np.float32) for x in per_cell]) if lens.sum() else np.zeros(0, np.float32))
 
     def connect_all_to_all(self, weight=1.0, with_diagonal=False):
         self.arr["connections"][...] = 1

@@ -42,7 +42,8 @@ CELL_ATTRS = {"st_current_voltage": "current_voltage", "st_v_th": "v_th", "st_v_
               "st_dt": "dt", "st_k": "neural_refractoriness$k", "st_is_spiking": "is_spiking",
               "st_last_firing_time": "last_firing_time"}
 CELL_KIND_ATTRS = {ob.ST_POISSON: {"st_chance_of_firing": "chance_of_firing", "st_seed": "seed"},
-                   ob.ST_RATE: {"st_rate": "rate", "st_step": "step"}}
+                   ob.ST_RATE: {"st_rate": "rate", "st_step": "step"},
+                   ob.ST_PRESET: {"st_step": "internal_clock", "st_counter": "counter"}}
 
 
 class Layout:
@@ -115,6 +116,13 @@ def device_from_oracle(snn, net, shard=None, device=0, csr=False):
     else:
         dn.finalize(*shard, csr=csr)
     push_state(dn, net)
+    if net.st_kind == ob.ST_PRESET:
+        rng = lay.ranges()
+        ptr, times = net["st_firing_ptr"], net["st_firing_times"]
+        for i, r, c in lay.st_lattices:
+            first, count, _ = rng[i]
+            lo, hi = int(ptr[first]), int(ptr[first + count])
+            dn.set_firing_times(i, ptr[first:first + count + 1] - ptr[first], times[lo:hi])
     nn = net.n_neurons
     if csr:
         dn.set_graph_csr(*csr_from_dense(net, dn.post_begin, dn.post_end))

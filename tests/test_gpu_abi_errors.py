@@ -61,10 +61,28 @@ def test_bad_device_and_selectors(snn):
     assert L.snn_network_create(4096, 0, 0, 0, 0, C.byref(h)) == 7                 # GetDeviceFailure
     assert L.snn_network_create(-1, 0, 0, 0, 0, C.byref(h)) == 7
     assert L.snn_network_create(0, 8, 0, 0, 0, C.byref(h)) == BAD_ARG
-    assert L.snn_network_create(0, 0, 2, 0, 0, C.byref(h)) == BAD_ARG
+    assert L.snn_network_create(0, 0, 4, 0, 0, C.byref(h)) == BAD_ARG
+    assert L.snn_network_create(0, 0, 0, 3, 0, C.byref(h)) == BAD_ARG
+    assert L.snn_network_create(0, 0, 0, 0, 4, C.byref(h)) == BAD_ARG
     assert b"selector" in L.snn_last_error()
     dn = snn.DeviceNetwork()                                                        # no spike-train model
     assert code(snn, lambda: dn.add_spike_train_lattice(1, 2, 2)) == BAD_STATE
+    dn.close()
+    # firing times only exist for the preset spike-train model; the pointer array must span the time array
+    dn = snn.DeviceNetwork(spike_train=snn.ST_RATE)
+    dn.add_lattice(0, 1, 1)
+    dn.add_spike_train_lattice(1, 1, 2)
+    dn.finalize()
+    assert code(snn, lambda: dn.set_firing_times(1, [0, 1, 2], [1.0, 2.0])) == BAD_STATE
+    dn.close()
+    dn = snn.DeviceNetwork(spike_train=snn.ST_PRESET)
+    dn.add_lattice(0, 1, 1)
+    dn.add_spike_train_lattice(1, 1, 2)
+    dn.finalize()
+    assert code(snn, lambda: dn.set_firing_times(1, [0, 1, 3], [1.0, 2.0])) == DIM_MISMATCH
+    assert code(snn, lambda: dn.set_firing_times(1, [0, 2, 1], [1.0])) == BAD_ARG
+    assert code(snn, lambda: dn.set_firing_times(0, [0, 1], [1.0])) == BAD_ARG        # a neuron lattice
+    dn.set_firing_times(1, [0, 1, 2], [1.0, 2.0])
     dn.close()
 
 

@@ -122,3 +122,60 @@ def test_network_with_rate_spike_train_chemical_and_stdp(snn):
         assert np.float32(cw[key]) == o["weights"][20 + i, i]
     assert lat.get_neuron(0, 0).last_firing_time == (None if o["last_firing_time"][0] < 0 else int(o["last_firing_time"][0]))
     gpu.close()
+
+
+def test_preset_spike_trains_with_exponential_decay_kinetics_and_stdp(snn):
+    """The procedure of backend/examples/stdp/main.rs:41-99: PresetSpikeTrain cells with one firing time each drive
+    a postsynaptic neuron lattice with STDP on; here with ExponentialDecay neurotransmitter / receptor kinetics."""
+    ln = snn
+    ampa = ln.IonotropicNeurotransmitterType.AMPA
+    receptors = ln.Ionotropic()
+    receptors.insert(ampa, ln.AMPAReceptor(g=3.0, r=ln.ExponentialDecayReceptor(decay_constant=1.5)))
+    neuron = ln.IzhikevichNeuron(gap_conductance=10.0)
+    neuron.set_synaptic_neurotransmitters({ampa: ln.ExponentialDecayNeurotransmitter(decay_constant=3.0)})
+    neuron.set_receptors(receptors)
+    post = ln.IzhikevichNeuronLattice(1)
+    post.populate(neuron, 1, 2)
+    post.connect(lambda x, y: x != y, lambda x, y: 1.0)
+    post.do_plasticity = True
+    post.update_grid_history = True
+    firing = [5.0, 6.0, 2.5]
+    st = ln.PresetSpikeTrain()
+    st.set_synaptic_neurotransmitters({ampa: ln.ExponentialDecayNeurotransmitter()})
+    pre = ln.PresetSpikeTrainLattice(0)
+    pre.populate(st, len(firing), 1)
+    pre.apply_given_position(lambda pos, cell: setattr(cell, "firing_times", [firing[pos[0]]]))
+    net = ln.IzhikevichNeuronNetwork.generate_network([post], [pre])
+    net.connect(0, 1, lambda x, y: True, lambda x, y: 1.5)
+    net.electrical_synapse = True
+    net.chemical_synapse = True
+    gpu = ln.IzhikevichNeuronNetworkGPU.from_network(net)
+    gpu.run_lattices(1500)
+
+    lay = parity.Layout([(1, 1, 2)], [(0, 3, 1)])
+    o = parity.make_oracle(lay, st_kind=ob.ST_PRESET, nt_kind=ob.NT_EXPONENTIAL_DECAY, rc_kind=ob.RC_EXPONENTIAL_DECAY,
+                           chemical=True)
+    o["gap_conductance"] = 10.0
+    o["nt_flags"][:, 0] = 1
+    o["nt_clearance"][:, 0] = 3.0
+    o["st_nt_flags"][:, 0] = 1
+    o["rc_flags"][:, 0] = 1
+    o["rc_g"][:, 0] = 3.0
+    o["rc_beta"][:, 0] = 1.5
+    o.set_firing_times([[t] for t in firing])
+    o["connections"][0, 1] = o["connections"][1, 0] = 1
+    o["weights"][0, 1] = o["weights"][1, 0] = 1.0
+    o["connections"][2:, :] = 1
+    o["weights"][2:, :] = 1.5
+    o["do_plasticity"] = 1
+    o.run(1500, voltage_history=True)
+    assert np.array_equal(gpu.history(1).reshape(1500, -1).view(np.uint32), o.voltage_history.view(np.uint32))
+    cw = gpu.connecting_weights
+    for i in range(3):
+        for j in range(2):
+            assert np.float32(cw[(ln.GraphPosition(0, (i, 0)), ln.GraphPosition(1, (0, j)))]) == o["weights"][2 + i, j]
+    assert not np.all(o["weights"][2:, :] == np.float32(1.5)), "STDP must have moved the connecting weights"
+    cell = gpu.get_spike_train_lattice(0).cell_grid[2][0]
+    assert cell.counter == 0 and np.float32(cell.internal_clock) == o["st_step"][2]
+    assert cell.last_firing_time == int(o["st_last_firing_time"][2])
+    gpu.close()

@@ -184,3 +184,31 @@ def test_leaky_izhikevich(snn, chemical):
     net.fill_graph(30, 0.5, 1.5)
     compare(snn, net, 600, chunks=3)
     assert net.spike_history.sum() > 0
+
+
+@pytest.mark.parametrize("nt_kind,rc_kind", [(ob.NT_EXPONENTIAL_DECAY, ob.RC_EXPONENTIAL_DECAY),
+                                             (ob.NT_DISCRETE_SPIKE, ob.RC_APPROX),
+                                             (ob.NT_EXPONENTIAL_DECAY, ob.RC_DESTEXHE),
+                                             (ob.NT_APPROX, ob.RC_EXPONENTIAL_DECAY)])
+def test_exponential_decay_and_discrete_spike_kinetics(snn, nt_kind, rc_kind):
+    """ExponentialDecayNeurotransmitter / DiscreteSpikeNeurotransmitter (iterate_and_spike/mod.rs:287-366) and
+    ExponentialDecayReceptor (:497-533) with heterogeneous decay constants and r_max, all three receptor types."""
+    lay = parity.Layout([(0, 8, 9)])
+    net = parity.make_oracle(lay, model=ob.IZHIKEVICH, nt_kind=nt_kind, rc_kind=rc_kind, chemical=True)
+    n = net.n_neurons
+    rng = np.random.default_rng(31)
+    net["current_voltage"] = ob.uniform_array(31, n, -65.0, 30.0)
+    net["gap_conductance"] = 10.0
+    net["nt_flags"][...] = rng.random((n, 3)) < 0.7
+    net["rc_flags"][...] = rng.random((n, 3)) < 0.7
+    if nt_kind == ob.NT_EXPONENTIAL_DECAY:
+        net["nt_clearance"][...] = ob.uniform_array(32, 3 * n, 0.5, 4.0).reshape(n, 3)      # decay_constant
+    if rc_kind == ob.RC_EXPONENTIAL_DECAY:
+        net["rc_alpha"][...] = ob.uniform_array(33, 3 * n, 0.3, 1.0).reshape(n, 3)         # r_max
+        net["rc_beta"][...] = ob.uniform_array(34, 3 * n, 0.5, 4.0).reshape(n, 3)          # decay_constant
+    net.fill_graph(35, 0.5, 1.5)
+    net["connections"][rng.random(net["connections"].shape) < 0.3] = 0
+    compare(snn, net, 800, chunks=2)
+    assert net.spike_history.sum() > 0
+    if nt_kind != ob.NT_DISCRETE_SPIKE:          # a discrete release is over one step after the last spike
+        assert net["rc_r"].max() > 0

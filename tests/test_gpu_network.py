@@ -74,7 +74,7 @@ def test_c4_small_excitatory_inhibitory_network_with_stdp(snn):
     dn.close()
 
 
-@pytest.mark.parametrize("st_kind", [ob.ST_POISSON, ob.ST_RATE])
+@pytest.mark.parametrize("st_kind", [ob.ST_POISSON, ob.ST_RATE, ob.ST_PRESET])
 @pytest.mark.parametrize("synapses", [(True, False), (True, True), (False, True)])
 def test_spike_train_lattice_drives_neurons(snn, st_kind, synapses):
     """Spike-train lattice (id 0) -> neuron lattice (id 1), one-to-one plus some random extra edges;
@@ -92,6 +92,10 @@ def test_spike_train_lattice_drives_neurons(snn, st_kind, synapses):
     if st_kind == ob.ST_POISSON:
         net["st_chance_of_firing"] = ob.uniform_array(7, nc, 0.0, 0.05)
         net["st_seed"] = np.arange(100, 100 + nc, dtype=np.uint32)
+    elif st_kind == ob.ST_PRESET:
+        # 0..3 firing times per cell (PresetSpikeTrain, spike_train/mod.rs:753-833); cell 0 has none
+        r = np.random.default_rng(7)
+        net.set_firing_times([list(r.uniform(0.5, 6.0, int(k))) for k in [0] + list(r.integers(1, 4, nc - 1))])
     else:
         net["st_rate"] = ob.uniform_array(7, nc, 2.0, 9.0)
         net["st_rate"][0] = 0.0             # rate 0 never fires (rate_spike_train.rs:44)

@@ -17,14 +17,14 @@ def draw(seed):
     model = MODELS[seed % len(MODELS)]
     n_lat = int(rng.integers(1, 4))
     lattices = [(int(i * 2 + rng.integers(0, 2)), int(rng.integers(1, 9)), int(rng.integers(1, 12))) for i in range(n_lat)]
-    st_kind = [ob.ST_NONE, ob.ST_POISSON, ob.ST_RATE][int(rng.integers(0, 3))]
+    st_kind = [ob.ST_NONE, ob.ST_POISSON, ob.ST_RATE, ob.ST_PRESET][int(rng.integers(0, 4))]
     st_lattices = []
     if st_kind != ob.ST_NONE:
         st_lattices = [(100 + i, int(rng.integers(1, 6)), int(rng.integers(1, 8))) for i in range(int(rng.integers(1, 3)))]
     electrical, chemical = [(True, False), (True, True), (False, True)][int(rng.integers(0, 3))]
     lay = parity.Layout(lattices, st_lattices)
     net = parity.make_oracle(lay, model=model, st_kind=st_kind, electrical=electrical, chemical=chemical,
-                             nt_kind=int(rng.integers(0, 2)), rc_kind=int(rng.integers(0, 2)))
+                             nt_kind=int(rng.integers(0, 4)), rc_kind=int(rng.integers(0, 3)))
     nn, nc = net.n_neurons, net.n_cells
     lo, hi = {ob.IZHIKEVICH: (-65, 30), ob.LIF: (-80, -50), ob.HH: (-75, -40), ob.QIF: (-75, -56),
               ob.SIMPLE_LIF: (-75, -56), ob.ADAPTIVE_LIF: (-75, -56), ob.ADAPTIVE_EXP_LIF: (-75, -56),
@@ -55,6 +55,8 @@ def draw(seed):
         net["st_seed"] = rng.integers(1, 2**32 - 1, nc, dtype=np.uint32)
         net["st_chance_of_firing"] = ob.uniform_array(seed + 4, nc, 0.0, 0.08)
         net["st_rate"] = ob.uniform_array(seed + 5, nc, 0.0, 6.0)
+        if st_kind == ob.ST_PRESET:
+            net.set_firing_times([list(rng.uniform(0.3, 5.0, int(k))) for k in rng.integers(0, 4, nc)])
     net.fill_graph(seed + 6, -0.5, 2.0, with_diagonal=bool(rng.integers(0, 2)))
     density = float(rng.choice([0.05, 0.3, 0.8, 1.0]))
     net["connections"][...] &= (rng.random(net["connections"].shape) < density)

@@ -304,3 +304,82 @@ def test_interleaved_index_space():
     assert r[1] == (0, 3, False) and r[3] == (3, 4, False)
     assert r[0] == (0, 2, True) and r[2] == (2, 2, True)        # offsets inside the cell block
     assert lay.n_neurons == 7 and lay.n_cells == 4
+
+
+# ---- further kinetics and the preset spike train (hand-derived single steps) -----------------------
+def _one_cell(nt_kind, st_kind=ob.ST_RATE):
+    net = ob.Net(0, n_cells=1, st_kind=st_kind, nt_kind=nt_kind)
+    net["st_nt_flags"][0, 0] = 1
+    return net
+
+
+def test_exponential_decay_neurotransmitter_single_steps():
+    """ExponentialDecayNeurotransmitter::apply_t_change (iterate_and_spike/mod.rs:345-354):
+    t += (-t * exp(dt / -decay)) + spike * t_max, clamped to [0, t_max]; default decay_constant 2."""
+    net = _one_cell(ob.NT_EXPONENTIAL_DECAY)
+    assert net["st_nt_clearance"][0, 0] == f32(2.0)
+    net["st_nt_t"][0, 0] = 0.5
+    net.spike_trains()                                      # rate 0: no spike
+    e = f32(ob.expf(f32(0.1) / f32(-2.0)))
+    expect = f32(f32(0.5) + f32(f32(f32(-0.5) * e) + f32(0.0)))
+    assert net["st_nt_t"][0, 0] == expect
+    assert abs(float(expect) - (0.5 - 0.5 * np.exp(-0.05))) < 1e-7
+    # a spiking cell adds t_max and the clamp holds it at t_max
+    net["st_rate"] = 0.1
+    net["st_step"] = 0.0
+    net.spike_trains()
+    assert net["st_is_spiking"][0] == 1 and net["st_nt_t"][0, 0] == f32(1.0)
+
+
+def test_discrete_spike_neurotransmitter():
+    """DiscreteSpikeNeurotransmitter (iterate_and_spike/mod.rs:300-302): t = t_max * is_spiking."""
+    net = _one_cell(ob.NT_DISCRETE_SPIKE)
+    net["st_nt_t_max"][0, 0] = 0.7
+    net["st_nt_t"][0, 0] = 0.3
+    net["st_rate"] = 0.2
+    seen = []
+    for _ in range(6):
+        net.spike_trains()
+        seen.append((int(net["st_is_spiking"][0]), float(net["st_nt_t"][0, 0])))
+    assert seen == [(0, 0.0), (1, float(f32(0.7))), (0, 0.0), (1, float(f32(0.7))), (0, 0.0), (1, float(f32(0.7)))]
+
+
+def test_exponential_decay_receptor_single_step():
+    """ExponentialDecayReceptor::apply_r_change (iterate_and_spike/mod.rs:510-513): r += (-r * exp(dt / -decay)) + t,
+    clamped to [0, r_max]; defaults r_max 1, decay_constant 2."""
+    net = ob.Net(2, rc_kind=ob.RC_EXPONENTIAL_DECAY, chemical=True, electrical=False)
+    assert net["rc_beta"][0, 0] == f32(2.0) and net["rc_alpha"][0, 0] == f32(1.0)
+    net["nt_flags"][0, 0] = 1
+    net["nt_t"][0, 0] = 0.25
+    net["rc_flags"][1, 0] = 1
+    net["rc_r"][1, 0] = 0.5
+    net["connections"][0, 1] = 1
+    net["weights"][0, 1] = 1.0
+    net.inputs()
+    net.update_neurons()
+    e = f32(ob.expf(f32(0.1) / f32(-2.0)))
+    expect = f32(f32(0.5) + f32(f32(f32(-0.5) * e) + f32(0.25)))
+    assert net["rc_r"][1, 0] == expect
+    # r_max clamps
+    net["rc_alpha"][1, 0] = 0.2
+    net.inputs()
+    net.update_neurons()
+    assert net["rc_r"][1, 0] == f32(0.2)
+
+
+def test_preset_spike_train_cycles_through_its_firing_times():
+    """PresetSpikeTrain::iterate (spike_train/mod.rs:803-827): the clock advances by dt, a spike happens when it
+    EXCEEDS firing_times[counter], which resets the clock and advances the counter cyclically (the reference's
+    backend/examples/stdp/main.rs:59-64 drives STDP with such cells)."""
+    net = ob.Net(0, n_cells=2, st_kind=ob.ST_PRESET)
+    net["st_dt"] = 1.0
+    net.set_firing_times([[3.0, 1.0], []])
+    spikes = []
+    for i in range(14):
+        net.spike_trains()
+        spikes.append(int(net["st_is_spiking"][0]))
+        assert net["st_is_spiking"][1] == 0                 # no firing times: never fires
+    # clock 1,2,3,4(>3: spike, counter 1) | 1, 2(>1: spike, counter 0) | 1,2,3,4(spike) | 1,2(spike) | 1, 2
+    assert spikes == [0, 0, 0, 1, 0, 1, 0, 0, 0, 1, 0, 1, 0, 0]
+    assert net["st_counter"][0] == 0 and net["st_last_firing_time"][0] == 11
+    assert net["st_current_voltage"][0] == f32(0.0) and net["st_step"][0] == f32(2.0)
