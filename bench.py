@@ -87,7 +87,7 @@ def build_config(args, snn_amd, synthetic, np, rank, world, local_rank):
     cfg = args.config
     sharded = world > 1 or args.force_sharded
     fin = (lambda d: d.finalize(rank, world)) if sharded else (lambda d: d.finalize())
-    if cfg in ("c1", "c2"):
+    if cfg in ("c1", "c2", "c6"):
         rows, cols = (32, 32) if cfg == "c1" else (args.rows, args.cols)
         n = rows * cols
         dn = snn_amd.DeviceNetwork(model=snn_amd.IZHIKEVICH, device=local_rank)
@@ -99,6 +99,12 @@ def build_config(args, snn_amd, synthetic, np, rank, world, local_rank):
         dn.fill_graph_synthetic(2, 0.5, 1.5, with_diagonal=False)
         text = (f"{rows}x{cols} Izhikevich lattice, dense gap-junction connectivity (all-to-all, x != y), dt=0.1, "
                 f"weights U[0.5,1.5]")
+        if cfg == "c6":
+            # SURVEY 8f rank 3, not a BASELINE config: the same lattice as a RewardModulatedLattice -- every synapse's
+            # weight and trace are rewritten every step (16 B/synapse on top of the 4 B/synapse input pass)
+            dn.set_reward_modulator(0, tau_c=0.05, tau_d=5.0, a_plus=0.002, a_minus=0.0015)
+            dn.apply_reward(0.01)
+            text = "reward-modulated (R-STDP, trace per synapse) " + text
         return dn, n, text, "k_inputs_dense<true,false>"
     if cfg == "c3":
         rows = cols = 128
@@ -158,7 +164,7 @@ def build_config(args, snn_amd, synthetic, np, rank, world, local_rank):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--config", default="c2", choices=["c1", "c2", "c3", "c4", "c5"],
+    ap.add_argument("--config", default="c2", choices=["c1", "c2", "c3", "c4", "c5", "c6"],
                     help="BASELINE.json configs[0..3]; the headline metric is quoted on c2 (default)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)

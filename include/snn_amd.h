@@ -213,6 +213,29 @@ int snn_history_steps(const snn_network_t *net, uint64_t *steps);
 int snn_get_voltage_history(snn_network_t *net, uint32_t id, float *dst, size_t count);
 int snn_get_spike_history(snn_network_t *net, uint32_t id, uint8_t *dst, size_t count);
 
+/* ---- reward modulation (≙ RewardModulatedLattice neuron/mod.rs:2719-3417) ---------------- */
+
+/* Makes lattice `id` a reward-modulated lattice: its internal edges carry a TraceRSTDP (plasticity/mod.rs:126-154;
+ * `weight` is the graph weight, `c` the trace, 0 initially) and are updated EVERY step by RewardModulatedSTDP
+ * (:158-242; defaults dopamine 0, tau_d 20, tau_c 0.0001, a_plus/a_minus 2, tau_plus/tau_minus 4.5, dt 0.1) in the
+ * deferred form (both per-step visits of an edge see the step's final last_firing_times; the reference's in-loop
+ * form depends on HashSet order).  do_modulation = RewardModulatedLattice::do_modulation; enabling it switches the
+ * lattice's STDP off.  16 B per internal synapse are streamed per step. */
+int snn_set_reward_modulator(snn_network_t *net, uint32_t id, float dopamine, float tau_d, float tau_c, float a_plus,
+                             float a_minus, float tau_plus, float tau_minus, float dt, int do_modulation);
+int snn_get_dopamine(snn_network_t *net, uint32_t id, float *dopamine);
+/* RewardModulator::update(reward) on every modulated lattice (plasticity/mod.rs:199-201); enqueued on the handle's
+ * stream, to be followed by a step.  snn_run_with_reward = Agent::update_and_apply_reward (neuron/mod.rs:3402-3407):
+ * apply the reward, then one step; snn_run alone = Agent::update / run_lattice (no reward update). */
+int snn_apply_reward(snn_network_t *net, float reward);
+int snn_run_with_reward(snn_network_t *net, float reward);
+/* TraceRSTDP::c per edge: dense rows [pre_count][n_neurons] (a shard handle touches its own columns), or in the
+ * edge order of snn_set_graph_csr. */
+int snn_set_trace_rows(snn_network_t *net, uint32_t pre_begin, uint32_t pre_count, const float *traces);
+int snn_get_trace_rows(snn_network_t *net, uint32_t pre_begin, uint32_t pre_count, float *traces);
+int snn_set_traces_csr(snn_network_t *net, const float *traces, uint64_t nnz);
+int snn_get_traces_csr(snn_network_t *net, float *traces, uint64_t nnz);
+
 /* PresetSpikeTrain::firing_times (spike_train/mod.rs:772) of every cell of spike-train lattice `id`: cell i (row-major)
  * fires through times[cell_ptr[i] .. cell_ptr[i+1]), cyclically; cell_ptr has rows*cols + 1 entries, starts at 0 and
  * ends at n_times.  A cell with no times never fires.  Only with SNN_ST_PRESET (else SNN_ERR_BAD_STATE). */

@@ -661,6 +661,55 @@ void snn_o_plasticity_cols(snn_o_net *n, uint32_t c0, uint32_t c1)
     }
 }
 
+/* ---------- reward modulation ---------- */
+
+/* RewardModulatedSTDP::update, plasticity/mod.rs:199-201, on every modulated lattice */
+void snn_o_apply_reward(snn_o_net *n, float reward)
+{
+    if (!n->rm_do_modulation) return;
+    for (uint32_t l = 0; l < n->n_lattices; ++l) {
+        if (!n->rm_do_modulation[l]) continue;
+        n->rm_dopamine[l] = n->rm_dopamine[l] * snn_o_expf(-n->rm_dt[l] / n->rm_tau_d[l]) + n->rm_tau_d[l] * reward;
+    }
+}
+
+/* RewardModulatedLattice::update_weights_from_neurons (neuron/mod.rs:3022-3054) with
+ * RewardModulatedSTDP::update_weight (plasticity/mod.rs:203-237).  do_update is always true (:239-241), so every
+ * step every internal edge (p,q) of a modulated lattice is visited exactly twice: as an outgoing edge of p and as
+ * an incoming edge of q.  The reference does this inside its neuron loop (HashSet order), where the two visits may
+ * see different last_firing_times; the deferred form used here (all neurons of the step updated first -- the same
+ * choice as for STDP, and what the reference's network form does) makes both visits see the same delta:
+ *   visit 1: dw = 0 + delta; counter 0 -> 1;                                  weight += c * dopamine
+ *   visit 2: dw += delta; c = c * exp(-dt / tau_c) + tau_c * dw; counter, dw -> 0;  weight += c * dopamine */
+void snn_o_reward_modulation(snn_o_net *n) { snn_o_reward_modulation_cols(n, 0, n->n_neurons); }
+
+void snn_o_reward_modulation_cols(snn_o_net *n, uint32_t c0, uint32_t c1)
+{
+    const uint32_t nn = n->n_neurons;
+    if (!n->rm_do_modulation || !n->traces) return;
+    for (uint32_t p = 0; p < nn; ++p) {
+        const uint32_t l = n->lattice[p];
+        if (!n->rm_do_modulation[l]) continue;
+        const float dopamine = n->rm_dopamine[l], dt = n->rm_dt[l], tau_c = n->rm_tau_c[l];
+        const float decay = snn_o_expf(-dt / tau_c);
+        for (uint32_t q = c0; q < c1; ++q) {
+            size_t i = (size_t)p * nn + q;
+            if (n->lattice[q] != l || !n->connections[i]) continue;
+            float delta_w = snn_o_stdp_delta(n->last_firing_time[p], n->last_firing_time[q], n->rm_a_plus[l],
+                                             n->rm_a_minus[l], n->rm_tau_plus[l], n->rm_tau_minus[l], dt);
+            float w = n->weights[i], c = n->traces[i];
+            float dw = 0.0f;
+            dw += delta_w;
+            w += c * dopamine;
+            dw += delta_w;
+            c = c * decay + tau_c * dw;
+            w += c * dopamine;
+            n->weights[i] = w;
+            n->traces[i] = c;
+        }
+    }
+}
+
 /* ---------- step 6: spike trains ---------- */
 
 /* SpikeTrainLattice::iterate neuron/mod.rs:1377-1393; PoissonNeuron (GPU form) spike_train/mod.rs:411-435;
@@ -746,10 +795,12 @@ void snn_o_run(snn_o_net *n, uint64_t iterations)
 {
     if (!n->electrical && !n->chemical) return;
     for (uint64_t it = 0; it < iterations; ++it) {
+        if (n->rewards) snn_o_apply_reward(n, n->rewards[it]);
         if (n->n_neurons) {
             snn_o_inputs(n);
             snn_o_update_neurons(n);
             snn_o_plasticity(n);
+            snn_o_reward_modulation(n);
             if (n->voltage_history)
                 memcpy(n->voltage_history + (size_t)it * n->n_neurons, n->current_voltage,
                        sizeof(float) * n->n_neurons);

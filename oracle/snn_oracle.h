@@ -153,6 +153,15 @@ typedef struct snn_o_net {
     uint32_t *st_firing_ptr;                   /* [n_cells + 1] */
     float    *st_firing_times;
     uint32_t *st_counter;                      /* [n_cells] */
+    /* Reward modulation of a lattice's internal edges: RewardModulatedLattice (neuron/mod.rs:2719-3417) with
+     * RewardModulatedSTDP + TraceRSTDP (plasticity/mod.rs:126-242), in the deferred form (see snn_o_reward_modulation).
+     * rm_* are per lattice; `traces` holds TraceRSTDP::c per edge in the layout of `weights` (TraceRSTDP::weight IS
+     * the entry of `weights`; counter and dw are 0 at every step boundary in the deferred form).  `rewards[it]` is
+     * applied before step `it` of snn_o_run (Agent::update_and_apply_reward, :3402-3407); NULL = run without reward. */
+    float    *traces;
+    uint32_t *rm_do_modulation;
+    float    *rm_dopamine, *rm_tau_d, *rm_tau_c, *rm_a_plus, *rm_a_minus, *rm_tau_plus, *rm_tau_minus, *rm_dt;
+    const float *rewards;
 } snn_o_net;
 
 /* Step 1 of SURVEY §8(g): electrical + chemical inputs for every neuron from state S(t). */
@@ -164,6 +173,9 @@ void snn_o_update_neurons(snn_o_net *net);
 void snn_o_update_neurons_range(snn_o_net *net, uint32_t q0, uint32_t q1);
 /* Step 3: deferred STDP for every neuron that spiked in this step. */
 void snn_o_plasticity(snn_o_net *net);
+void snn_o_apply_reward(snn_o_net *n, float reward);
+void snn_o_reward_modulation(snn_o_net *n);
+void snn_o_reward_modulation_cols(snn_o_net *n, uint32_t c0, uint32_t c1);
 void snn_o_plasticity_cols(snn_o_net *net, uint32_t c0, uint32_t c1);
 /* Step 6: iterate every spike-train cell once. */
 void snn_o_spike_trains(snn_o_net *net);

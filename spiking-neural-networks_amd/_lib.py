@@ -92,6 +92,14 @@ SIGNATURES = {
     "snn_history_steps": (C.c_int, [H, u64p]),
     "snn_get_voltage_history": (C.c_int, [H, C.c_uint32, f32p, C.c_size_t]),
     "snn_get_spike_history": (C.c_int, [H, C.c_uint32, u8p, C.c_size_t]),
+    "snn_set_reward_modulator": (C.c_int, [H, C.c_uint32] + [C.c_float] * 8 + [C.c_int]),
+    "snn_get_dopamine": (C.c_int, [H, C.c_uint32, f32p]),
+    "snn_apply_reward": (C.c_int, [H, C.c_float]),
+    "snn_run_with_reward": (C.c_int, [H, C.c_float]),
+    "snn_set_trace_rows": (C.c_int, [H, C.c_uint32, C.c_uint32, f32p]),
+    "snn_get_trace_rows": (C.c_int, [H, C.c_uint32, C.c_uint32, f32p]),
+    "snn_set_traces_csr": (C.c_int, [H, f32p, C.c_uint64]),
+    "snn_get_traces_csr": (C.c_int, [H, f32p, C.c_uint64]),
     "snn_set_firing_times": (C.c_int, [H, C.c_uint32, u32p, f32p, C.c_size_t]),
     "snn_set_history_stride": (C.c_int, [H, C.c_uint32]),
     "snn_set_reduced_history": (C.c_int, [H, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float]),

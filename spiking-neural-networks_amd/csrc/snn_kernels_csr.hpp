@@ -215,4 +215,37 @@ __global__ __launch_bounds__(64) void k_stdp_csr_out(const CsrStdpArgs a)
     }
 }
 
+// Reward modulation on the sparse form: one thread per SELL entry (weights and traces share the entry index).
+struct CsrRewardArgs {
+    SellGraph g;
+    float *c;                              // [entries] TraceRSTDP::c
+    uint32_t q0, n_neurons;
+    const int32_t *last_firing_time;
+    const uint32_t *lattice_slot;
+    const float *rm;
+    const uint32_t *rm_on;
+};
+
+__global__ __launch_bounds__(256) void k_rstdp_csr(const CsrRewardArgs a)
+{
+    const uint32_t q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= a.g.n_loc) return;
+    const uint32_t gq = a.q0 + q;
+    const uint32_t sq = a.lattice_slot[gq];
+    if (!a.rm_on[sq]) return;
+    const float *m = a.rm + (size_t)sq * RM_STRIDE;
+    const int32_t tq = a.last_firing_time[gq];
+    const uint32_t base = a.g.slice_ptr[q >> 6] + (q & 63u);
+    const uint32_t len = a.g.row_len[q];
+    for (uint32_t k = 0; k < len; ++k) {
+        const size_t e = base + (size_t)k * 64;
+        const uint32_t p = a.g.pre[e];
+        if (p >= a.n_neurons || a.lattice_slot[p] != sq) continue;
+        float w = a.g.w[e], c = a.c[e];
+        rstdp_edge(w, c, a.last_firing_time[p], tq, m);
+        a.g.w[e] = w;
+        a.c[e] = c;
+    }
+}
+
 } // namespace snn

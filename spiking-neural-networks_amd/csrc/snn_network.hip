@@ -79,6 +79,13 @@ struct snn_network {
     std::vector<float> stdp_host;           // [n_lattices][5]
     std::vector<uint32_t> plast_host;       // [n_lattices]
     bool any_plasticity = false;
+    // reward modulation (RewardModulatedLattice): per-lattice modulator table + per-edge trace, allocated on first use
+    bool any_modulation = false;
+    std::vector<float> rm_host;            // [n_lattices][RM_STRIDE]
+    std::vector<uint32_t> rm_on_host;
+    float *rm_dev = nullptr;
+    uint32_t *rm_on_dev = nullptr;
+    float *trace = nullptr;                // dense: [n_tot][ld]; CSR: [sell_entries]
 
     uint32_t nn = 0, nc = 0, n_tot = 0, n_pad = 0, c_pad = 0;
     uint32_t q0 = 0, q1 = 0, n_loc = 0, ld = 0, n_chunks = 0;
@@ -387,6 +394,19 @@ int build_state(snn_network *net)
     HIP_TRY(hipMemcpyAsync(net->stdp_dev, net->stdp_host.data(), nl * 5 * 4, hipMemcpyHostToDevice, net->stream),
             SNN_ERR_BUFFER_WRITE);
     HIP_TRY(hipMemcpyAsync(net->plast_dev, net->plast_host.data(), nl * 4, hipMemcpyHostToDevice, net->stream),
+            SNN_ERR_BUFFER_WRITE);
+    // RewardModulatedSTDP defaults, plasticity/mod.rs:176-189
+    net->rm_host.assign(nl * RM_STRIDE, 0.0f);
+    net->rm_on_host.assign(nl, 0);
+    for (size_t l = 0; l < nl; ++l) {
+        float *m = &net->rm_host[l * RM_STRIDE];
+        m[0] = 0.0f; m[1] = 20.0f; m[2] = 0.0001f; m[3] = 2.0f; m[4] = 2.0f; m[5] = 4.5f; m[6] = 4.5f; m[7] = 0.1f;
+    }
+    TRY(dev_alloc_t(net, &net->rm_dev, nl * RM_STRIDE));
+    TRY(dev_alloc_t(net, &net->rm_on_dev, nl));
+    HIP_TRY(hipMemcpyAsync(net->rm_dev, net->rm_host.data(), nl * RM_STRIDE * 4, hipMemcpyHostToDevice, net->stream),
+            SNN_ERR_BUFFER_WRITE);
+    HIP_TRY(hipMemcpyAsync(net->rm_on_dev, net->rm_on_host.data(), nl * 4, hipMemcpyHostToDevice, net->stream),
             SNN_ERR_BUFFER_WRITE);
     TRY(dev_alloc_t(net, &net->spike_list, np));
     TRY(dev_alloc_t(net, &net->spike_count, 1));
@@ -731,6 +751,31 @@ int launch_plasticity(snn_network *net)
     return SNN_OK;
 }
 
+// RewardModulatedLattice::update_weights_from_neurons for every modulated lattice (deferred form)
+int launch_reward_modulation(snn_network *net)
+{
+    if (!net->any_modulation || net->nn == 0 || net->n_loc == 0 || !net->trace) return SNN_OK;
+    if (net->csr) {
+        if (!net->csr_ptr) return SNN_OK;
+        CsrRewardArgs a{};
+        a.g = csr_graph(net); a.c = net->trace; a.q0 = net->q0; a.n_neurons = net->nn;
+        a.last_firing_time = net->na.last_firing_time; a.lattice_slot = net->lattice_slot;
+        a.rm = net->rm_dev; a.rm_on = net->rm_on_dev;
+        hipLaunchKernelGGL(k_rstdp_csr, dim3((net->n_loc + 255) / 256), dim3(256), 0, net->stream, a);
+        HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+        return SNN_OK;
+    }
+    RewardArgs a{};
+    a.W = net->W; a.C = net->trace; a.ld = net->ld; a.n_loc = net->n_loc; a.q0 = net->q0; a.n_neurons = net->nn;
+    a.last_firing_time = net->na.last_firing_time; a.lattice_slot = net->lattice_slot;
+    a.rm = net->rm_dev; a.rm_on = net->rm_on_dev;
+    const unsigned gx = (net->n_loc + 1023) / 1024;
+    const unsigned gy = std::max(1u, std::min<unsigned>(net->nn, 8192u / gx));     // ~8192 workgroups in flight
+    hipLaunchKernelGGL(k_rstdp_dense, dim3(gx, gy), dim3(256), 0, net->stream, a);
+    HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+    return SNN_OK;
+}
+
 // The synapse matrix is the one allocation whose HBM placement matters: on MI355X two 17 GB allocations of one
 // process can differ by 5-6 % in the sustained rate of the input pass (stable per allocation, different from
 // process to process).  For matrices >= 1 GiB a second candidate is allocated while the first is held, the real
@@ -814,6 +859,7 @@ int step_end(snn_network *net)
         HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
     }
     TRY(launch_plasticity(net));
+    TRY(launch_reward_modulation(net));
     if ((net->want_avg || net->want_eeg) && record_now(net) && !net->lattices.empty()) {
         // after the exchange, so that a sharded handle reduces over every lattice's full population
         const size_t nl = net->lattices.size();
@@ -1014,6 +1060,7 @@ int snn_network_destroy(snn_network_t *net)
     if (net->st_vhist) (void)hipFree(net->st_vhist);
     if (net->raster) (void)hipFree(net->raster);
     if (net->preset_times_dev) (void)hipFree(net->preset_times_dev);
+    if (net->trace) (void)hipFree(net->trace);
     if (net->summ_avg) (void)hipFree(net->summ_avg);
     if (net->summ_eeg) (void)hipFree(net->summ_eeg);
     for (auto &e : net->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -1265,6 +1312,7 @@ int snn_set_graph_csr(snn_network_t *net, const uint64_t *row_ptr, const uint32_
     TRY(up((void **)&net->csr_post, post.data(), nnz * 4));
     TRY(up((void **)&net->csr_t_ptr, t_ptr.data(), t_ptr.size() * 4));
     TRY(up((void **)&net->csr_t_edge, t_edge.data(), nnz * 4));
+    if (net->trace) { (void)hipFree(net->trace); net->trace = nullptr; }      // traces belong to the replaced edges
     net->nnz = nnz;
     net->sell_entries = entries;
     net->edge_slot_host.swap(edge_slot);
@@ -1314,6 +1362,140 @@ int snn_set_plasticity(snn_network_t *net, uint32_t id, float a_plus, float a_mi
     HIP_TRY(hipMemcpy(net->plast_dev, net->plast_host.data(), net->plast_host.size() * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
     return SNN_OK;
 }
+
+namespace {
+size_t trace_elems(const snn_network *net) { return net->csr ? (size_t)net->sell_entries : (size_t)net->n_tot * net->ld; }
+
+int ensure_traces(snn_network *net)
+{
+    if (net->trace) return SNN_OK;
+    const size_t n = std::max<size_t>(trace_elems(net), 64);
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&net->trace), n * 4), SNN_ERR_BUFFER_CREATE);
+    HIP_TRY(hipMemsetAsync(net->trace, 0, n * 4, net->stream), SNN_ERR_BUFFER_WRITE);
+    return SNN_OK;
+}
+} // namespace
+
+int snn_set_reward_modulator(snn_network_t *net, uint32_t id, float dopamine, float tau_d, float tau_c, float a_plus,
+                             float a_minus, float tau_plus, float tau_minus, float dt, int do_modulation)
+{
+    if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
+    if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
+    const LatticeInfo *l = find_lattice(net, id);
+    if (!l || l->spike_train) return fail(SNN_ERR_BAD_ARG, "reward modulation belongs to neuron lattices");
+    HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
+    TRY(end_run(net));
+    const size_t nl = net->rm_on_host.size();
+    // dopamine of the other lattices evolves on the device: refresh the host copy before rewriting the table
+    HIP_TRY(hipMemcpy(net->rm_host.data(), net->rm_dev, nl * RM_STRIDE * 4, hipMemcpyDeviceToHost), SNN_ERR_BUFFER_READ);
+    float *m = &net->rm_host[(size_t)l->slot * RM_STRIDE];
+    m[0] = dopamine; m[1] = tau_d; m[2] = tau_c; m[3] = a_plus; m[4] = a_minus; m[5] = tau_plus; m[6] = tau_minus; m[7] = dt;
+    net->rm_on_host[l->slot] = do_modulation ? 1u : 0u;
+    net->any_modulation = false;
+    for (uint32_t v : net->rm_on_host) net->any_modulation |= (v != 0);
+    if (do_modulation) {
+        // a RewardModulatedLattice has no STDP rule of its own
+        net->plast_host[l->slot] = 0;
+        net->any_plasticity = false;
+        for (uint32_t p : net->plast_host) net->any_plasticity |= (p != 0);
+        HIP_TRY(hipMemcpy(net->plast_dev, net->plast_host.data(), net->plast_host.size() * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
+        if (net->csr && !net->csr_ptr) return fail(SNN_ERR_BAD_STATE, "set the sparse graph before enabling reward modulation");
+        TRY(ensure_traces(net));
+    }
+    HIP_TRY(hipMemcpy(net->rm_dev, net->rm_host.data(), nl * RM_STRIDE * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
+    HIP_TRY(hipMemcpy(net->rm_on_dev, net->rm_on_host.data(), nl * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
+    hipLaunchKernelGGL(k_modulator_update, dim3((unsigned)((nl + 63) / 64)), dim3(64), 0, net->stream, net->rm_dev,
+                       net->rm_on_dev, (uint32_t)nl, 0.0f, 1);
+    HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+    return SNN_OK;
+}
+
+int snn_get_dopamine(snn_network_t *net, uint32_t id, float *dopamine)
+{
+    if (!net || !dopamine) return fail(SNN_ERR_BAD_ARG, "null pointer");
+    if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
+    const LatticeInfo *l = find_lattice(net, id);
+    if (!l || l->spike_train) return fail(SNN_ERR_BAD_ARG, "reward modulation belongs to neuron lattices");
+    HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
+    TRY(end_run(net));
+    HIP_TRY(hipMemcpy(dopamine, net->rm_dev + (size_t)l->slot * RM_STRIDE, 4, hipMemcpyDeviceToHost), SNN_ERR_BUFFER_READ);
+    return SNN_OK;
+}
+
+int snn_apply_reward(snn_network_t *net, float reward)
+{
+    if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
+    if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
+    if (!net->any_modulation) return SNN_OK;
+    HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
+    const size_t nl = net->rm_on_host.size();
+    hipLaunchKernelGGL(k_modulator_update, dim3((unsigned)((nl + 63) / 64)), dim3(64), 0, net->stream, net->rm_dev,
+                       net->rm_on_dev, (uint32_t)nl, reward, 0);
+    HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+    return SNN_OK;
+}
+
+int snn_run_with_reward(snn_network_t *net, float reward)
+{
+    int rc = snn_apply_reward(net, reward);
+    return rc ? rc : snn_run(net, 1);
+}
+
+// TraceRSTDP::c of the edges in presynaptic rows [pre_begin, pre_begin + pre_count), row-major [pre_count][n_neurons];
+// a shard handle reads / writes its own columns only.
+static int trace_rows_io(snn_network_t *net, uint32_t pre_begin, uint32_t pre_count, float *traces, bool set)
+{
+    if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
+    if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
+    if (net->csr) return fail(SNN_ERR_BAD_STATE, "handle holds a CSR graph: use snn_set_traces_csr / snn_get_traces_csr");
+    if ((uint64_t)pre_begin + pre_count > net->n_tot) return fail(SNN_ERR_DIM_MISMATCH, "row range exceeds n_tot");
+    if (pre_count == 0 || net->nn == 0 || net->n_loc == 0) return SNN_OK;
+    if (!traces) return fail(SNN_ERR_BAD_ARG, "traces is null");
+    HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
+    TRY(end_run(net));
+    TRY(ensure_traces(net));
+    HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
+    float *dev = net->trace + (size_t)pre_begin * net->ld;
+    float *host = traces + net->q0;
+    if (set)
+        HIP_TRY(hipMemcpy2D(dev, (size_t)net->ld * 4, host, (size_t)net->nn * 4, (size_t)net->n_loc * 4, pre_count,
+                            hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
+    else
+        HIP_TRY(hipMemcpy2D(host, (size_t)net->nn * 4, dev, (size_t)net->ld * 4, (size_t)net->n_loc * 4, pre_count,
+                            hipMemcpyDeviceToHost), SNN_ERR_BUFFER_READ);
+    return SNN_OK;
+}
+int snn_set_trace_rows(snn_network_t *net, uint32_t pre_begin, uint32_t pre_count, const float *traces)
+{ return trace_rows_io(net, pre_begin, pre_count, const_cast<float *>(traces), true); }
+int snn_get_trace_rows(snn_network_t *net, uint32_t pre_begin, uint32_t pre_count, float *traces)
+{ return trace_rows_io(net, pre_begin, pre_count, traces, false); }
+
+static int traces_csr_io(snn_network_t *net, float *traces, uint64_t nnz, bool set)
+{
+    if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
+    if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
+    if (!net->csr) return fail(SNN_ERR_BAD_STATE, "handle holds a dense graph");
+    if (nnz != net->nnz) return fail(SNN_ERR_DIM_MISMATCH, "nnz does not match the stored graph");
+    if (nnz == 0) return SNN_OK;
+    if (!traces) return fail(SNN_ERR_BAD_ARG, "traces is null");
+    HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
+    TRY(end_run(net));
+    TRY(ensure_traces(net));
+    HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
+    std::vector<float> sell((size_t)net->sell_entries);
+    HIP_TRY(hipMemcpy(sell.data(), net->trace, sell.size() * 4, hipMemcpyDeviceToHost), SNN_ERR_BUFFER_READ);
+    if (set) {
+        for (uint64_t e = 0; e < nnz; ++e) sell[net->edge_slot_host[e]] = traces[e];
+        HIP_TRY(hipMemcpy(net->trace, sell.data(), sell.size() * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
+    } else {
+        for (uint64_t e = 0; e < nnz; ++e) traces[e] = sell[net->edge_slot_host[e]];
+    }
+    return SNN_OK;
+}
+int snn_set_traces_csr(snn_network_t *net, const float *traces, uint64_t nnz)
+{ return traces_csr_io(net, const_cast<float *>(traces), nnz, true); }
+int snn_get_traces_csr(snn_network_t *net, float *traces, uint64_t nnz)
+{ return traces_csr_io(net, traces, nnz, false); }
 
 int snn_set_history(snn_network_t *net, int voltage_history, int spike_history)
 {
@@ -1481,7 +1663,7 @@ int snn_step_begin_local(snn_network_t *net)
     TRY(begin_run(net, 1));
     // Only when nothing of the previous step is still pending for these chunks: STDP rewrites W in
     // snn_step_end and needs the gathered spikes first, so with plasticity on the split is not taken.
-    if (net->nn && !net->csr && !net->any_plasticity && !net->local_inputs_done) {
+    if (net->nn && !net->csr && !net->any_plasticity && !net->any_modulation && !net->local_inputs_done) {
         TRY(launch_inputs(net, INPUTS_LOCAL));
         net->local_inputs_done = true;
     }

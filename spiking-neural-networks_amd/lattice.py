@@ -103,6 +103,14 @@ class STDP(_Record):                                     # plasticity/mod.rs:16-
     _defaults = dict(a_plus=2.0, a_minus=2.0, tau_plus=4.5, tau_minus=4.5, dt=0.1)
 
 
+class TraceRSTDP(_Record):                               # plasticity/mod.rs:126-146
+    _defaults = dict(counter=0, dw=0.0, weight=0.0, c=0.0)
+
+
+class RewardModulatedSTDP(_Record):                      # plasticity/mod.rs:158-190
+    _defaults = dict(dopamine=0.0, tau_d=20.0, tau_c=0.0001, a_plus=2.0, a_minus=2.0, tau_plus=4.5, tau_minus=4.5, dt=0.1)
+
+
 class GraphPosition:                                     # graph/mod.rs:24-30
     def __init__(self, id, pos):
         self.id, self.pos = id, tuple(pos)
@@ -332,6 +340,45 @@ class Lattice:
     def run_lattice(self, iterations):
         raise NotImplementedError("this package steps lattices on the GPU only: use "
                                   f"{type(self).__name__}GPU.from_lattice(lattice).run_lattice(iterations)")
+
+
+class RewardModulatedLattice(Lattice):
+    """RewardModulatedLattice<TraceRSTDP, T, AdjacencyMatrix, GridVoltageHistory, RewardModulatedSTDP> builder
+    (backend/src/neuron/mod.rs:2719-3417): every edge carries a TraceRSTDP, `weights` holds TraceRSTDP::weight and
+    `traces` TraceRSTDP::c."""
+
+    def __init__(self, id=0):
+        super().__init__(id)
+        self.traces = np.zeros((0, 0), np.float32)
+        self.do_modulation = True
+        self.reward_modulator = RewardModulatedSTDP()
+
+    def populate(self, neuron, num_rows, num_cols):
+        super().populate(neuron, num_rows, num_cols)
+        self.traces = np.zeros_like(self.weights)
+
+    def connect(self, connection_conditional, weight_logic=None):      # neuron/mod.rs:3301-3321
+        pos = [(r, c) for r in range(self.rows) for c in range(self.cols)]
+        for i, a in enumerate(pos):
+            for j, b in enumerate(pos):
+                on = bool(connection_conditional(a, b))
+                t = (weight_logic(a, b) if weight_logic is not None else TraceRSTDP(weight=1.0)) if on else TraceRSTDP()
+                if not isinstance(t, TraceRSTDP):
+                    t = TraceRSTDP(weight=float(t))
+                if t.counter != 0 or t.dw != 0.0:
+                    raise ValueError("a TraceRSTDP enters the stepper between steps: counter and dw must be 0")
+                self.connections[i, j] = int(on)
+                self.weights[i, j], self.traces[i, j] = t.weight, t.c
+
+    def get_weight(self, presynaptic, postsynaptic):
+        i, j = self._index(presynaptic), self._index(postsynaptic)
+        if not self.connections[i, j]:
+            raise KeyError("no connection")
+        return TraceRSTDP(weight=float(self.weights[i, j]), c=float(self.traces[i, j]))
+
+    def set_dt(self, dt):
+        self.apply(lambda n: setattr(n, "dt", dt))
+        self.reward_modulator.dt = dt
 
 
 class SpikeTrainLattice:
@@ -610,6 +657,15 @@ class LatticeNetworkGPU:
             i, j = self._global(pre), self._global(post)
             w[i, j], c[i, j] = weight, 1
         dn.set_graph_rows(0, w, c)
+        for id, l in net.lattices.items():
+            if isinstance(l, RewardModulatedLattice):
+                m = l.reward_modulator
+                dn.set_reward_modulator(id, m.dopamine, m.tau_d, m.tau_c, m.a_plus, m.a_minus, m.tau_plus, m.tau_minus,
+                                        m.dt, l.do_modulation)
+                first, count = dn.lattice_range(id)
+                t = np.zeros((count, nn), np.float32)
+                t[:, first:first + count] = l.traces
+                dn.set_trace_rows(first, t)
 
     def _global(self, gp):
         first, _ = self._dn.lattice_range(gp.id)
@@ -623,6 +679,18 @@ class LatticeNetworkGPU:
         dn.set_history(voltage=hist, spikes=False)
         dn.run(iterations)
         self._download()
+
+    def run_lattices_with_reward(self, reward, download=True):
+        """One step preceded by RewardModulator::update(reward) on every reward-modulated lattice
+        (RewardModulatedLatticeNetwork::run_lattices_with_reward, neuron/mod.rs:5385-5408).  `download=False` leaves
+        the results on the device until the next downloading call (an agent loop steps thousands of times)."""
+        dn, net = self._dn, self.network
+        dn.set_synapses(net.electrical_synapse, net.chemical_synapse)
+        hist = any(l.update_grid_history for l in list(net.lattices.values()) + list(net.spike_train_lattices.values()))
+        dn.set_history(voltage=hist, spikes=False)
+        dn.run_with_reward(float(reward))
+        if download:
+            self._download()
 
     def _download(self):
         dn, net = self._dn, self.network
@@ -638,6 +706,9 @@ class LatticeNetworkGPU:
                 first, count = dn.lattice_range(id)
                 l.weights = w[first:first + count, first:first + count].copy()
                 l.connections = c[first:first + count, first:first + count].copy()
+                if isinstance(l, RewardModulatedLattice):
+                    l.traces = dn.get_trace_rows(first, count)[:, first:first + count].copy()
+                    l.reward_modulator.dopamine = float(dn.dopamine(id))
         for id, l in net.spike_train_lattices.items():
             cells = _flat(l)
             if cells:
@@ -793,6 +864,41 @@ class LatticeGPU:
 
     def close(self):
         self._dirty()
+
+
+class RewardModulatedLatticeGPU(LatticeGPU):
+    """A RewardModulatedLattice stepped on the device (the reference has no GPU form of it).  Agent interface:
+    update_and_apply_reward / update (neuron/mod.rs:3402-3415)."""
+    lattice_type = RewardModulatedLattice
+
+    def __setattr__(self, name, value):
+        if name in ("do_modulation", "reward_modulator"):
+            self._dirty()
+            return setattr(self._lattice, name, value)
+        super().__setattr__(name, value)
+
+    def run_lattice_with_reward(self, reward, download=True):       # neuron/mod.rs:3250-3257
+        net = self._ensure()
+        net.network.electrical_synapse = self._lattice.electrical_synapse
+        net.network.chemical_synapse = self._lattice.chemical_synapse
+        net.run_lattices_with_reward(reward, download=download)
+
+    def update_and_apply_reward(self, reward):
+        self.run_lattice_with_reward(reward, download=False)
+
+    def update(self):
+        net = self._ensure()
+        net._dn.set_synapses(self._lattice.electrical_synapse, self._lattice.chemical_synapse)
+        net._dn.run(1)
+
+    def sync(self):
+        """Bring weights, traces, dopamine and neuron state back after a series of non-downloading steps."""
+        if self._net is not None:
+            self._net._download()
+
+    @property
+    def traces(self):
+        return self._lattice.traces
 
 
 def _named(base, name, **attrs):

@@ -234,6 +234,43 @@ class DeviceNetwork:
         _lib.check(self._L.snn_get_spike_history(self._h, id, out.ctypes.data_as(_lib.u8p), out.size))
         return out
 
+    # ---- reward modulation (RewardModulatedLattice, neuron/mod.rs:2719-3417) -----------------
+    def set_reward_modulator(self, id, dopamine=0.0, tau_d=20.0, tau_c=0.0001, a_plus=2.0, a_minus=2.0, tau_plus=4.5,
+                             tau_minus=4.5, dt=0.1, do_modulation=True):
+        _lib.check(self._L.snn_set_reward_modulator(self._h, id, dopamine, tau_d, tau_c, a_plus, a_minus, tau_plus,
+                                                    tau_minus, dt, int(do_modulation)))
+
+    def dopamine(self, id):
+        out = C.c_float()
+        _lib.check(self._L.snn_get_dopamine(self._h, id, C.byref(out)))
+        return np.float32(out.value)
+
+    def apply_reward(self, reward):
+        _lib.check(self._L.snn_apply_reward(self._h, reward))
+
+    def run_with_reward(self, reward):
+        _lib.check(self._L.snn_run_with_reward(self._h, reward))
+
+    def set_trace_rows(self, pre_begin, traces):
+        t = np.ascontiguousarray(traces, dtype=np.float32)
+        if t.ndim != 2 or t.shape[1] != self.n_neurons:
+            raise ValueError("traces must be [rows][n_neurons]")
+        _lib.check(self._L.snn_set_trace_rows(self._h, pre_begin, t.shape[0], t.ctypes.data_as(_lib.f32p)))
+
+    def get_trace_rows(self, pre_begin, pre_count):
+        t = np.zeros((pre_count, self.n_neurons), np.float32)
+        _lib.check(self._L.snn_get_trace_rows(self._h, pre_begin, pre_count, t.ctypes.data_as(_lib.f32p)))
+        return t
+
+    def set_traces_csr(self, traces):
+        t = np.ascontiguousarray(traces, dtype=np.float32)
+        _lib.check(self._L.snn_set_traces_csr(self._h, t.ctypes.data_as(_lib.f32p), t.size))
+
+    def get_traces_csr(self):
+        t = np.empty(getattr(self, "_nnz", 0), np.float32)
+        _lib.check(self._L.snn_get_traces_csr(self._h, t.ctypes.data_as(_lib.f32p), t.size))
+        return t
+
     def set_firing_times(self, id, cell_ptr, times):
         """PresetSpikeTrain firing times of spike-train lattice `id`: cell i fires through
         times[cell_ptr[i]:cell_ptr[i+1]] cyclically (spike_train/mod.rs:753-833)."""

@@ -67,6 +67,9 @@ _FIELDS = [
     ("spike_counts", u32p),
     ("adp_alpha", f32p), ("adp_beta", f32p), ("slope_factor", f32p),
     ("st_firing_ptr", u32p), ("st_firing_times", f32p), ("st_counter", u32p),
+    ("traces", f32p), ("rm_do_modulation", u32p), ("rm_dopamine", f32p), ("rm_tau_d", f32p), ("rm_tau_c", f32p),
+    ("rm_a_plus", f32p), ("rm_a_minus", f32p), ("rm_tau_plus", f32p), ("rm_tau_minus", f32p), ("rm_dt", f32p),
+    ("rewards", f32p),
 ]
 
 
@@ -91,12 +94,17 @@ def lib():
             build_oracle()
         L = C.CDLL(_LIB_PATH)
         P = C.POINTER(_CNet)
-        for fn in ("snn_o_inputs", "snn_o_update_neurons", "snn_o_plasticity", "snn_o_spike_trains"):
+        for fn in ("snn_o_inputs", "snn_o_update_neurons", "snn_o_plasticity", "snn_o_spike_trains",
+                   "snn_o_reward_modulation"):
             getattr(L, fn).argtypes = [P]
             getattr(L, fn).restype = None
         for fn in ("snn_o_inputs_range", "snn_o_update_neurons_range", "snn_o_plasticity_cols"):
             getattr(L, fn).argtypes = [P, C.c_uint32, C.c_uint32]
             getattr(L, fn).restype = None
+        L.snn_o_apply_reward.argtypes = [P, C.c_float]
+        L.snn_o_apply_reward.restype = None
+        L.snn_o_reward_modulation_cols.argtypes = [P, C.c_uint32, C.c_uint32]
+        L.snn_o_reward_modulation_cols.restype = None
         L.snn_o_run.argtypes = [P, C.c_uint64]
         L.snn_o_run.restype = None
         for fn in ("snn_o_expf_export", "snn_o_pow3f_export", "snn_o_pow4f_export"):
@@ -164,6 +172,9 @@ ST_DEFAULTS = dict(st_current_voltage=0.0, st_v_th=30.0, st_v_resting=0.0, st_dt
                    st_chance_of_firing=0.0, st_rate=0.0, st_step=0.0)
 # plasticity/mod.rs:29-39
 STDP_DEFAULTS = dict(stdp_a_plus=2.0, stdp_a_minus=2.0, stdp_tau_plus=4.5, stdp_tau_minus=4.5, stdp_dt=0.1)
+# RewardModulatedSTDP, plasticity/mod.rs:176-189
+RM_DEFAULTS = dict(rm_dopamine=0.0, rm_tau_d=20.0, rm_tau_c=0.0001, rm_a_plus=2.0, rm_a_minus=2.0, rm_tau_plus=4.5,
+                   rm_tau_minus=4.5, rm_dt=0.1)
 
 _NAMES = [n for n, _ in _FIELDS]
 _PER_NEURON = set(_NAMES[_NAMES.index("current_voltage"):_NAMES.index("was_increasing") + 1]) | {
@@ -175,7 +186,7 @@ _PER_CELL = {"st_current_voltage", "st_v_th", "st_v_resting", "st_dt", "st_k", "
              "st_rate", "st_step", "st_seed", "st_is_spiking", "st_last_firing_time", "st_lattice", "st_counter"}
 _PER_CELL_K = {"st_nt_t", "st_nt_t_max", "st_nt_clearance", "st_nt_v_p", "st_nt_k_p", "st_nt_flags"}
 _PER_LATTICE = {"stdp_a_plus", "stdp_a_minus", "stdp_tau_plus", "stdp_tau_minus", "stdp_dt", "do_plasticity",
-                "lattice_first", "lattice_count"}
+                "lattice_first", "lattice_count", "rm_do_modulation", *RM_DEFAULTS}
 
 
 class Net:
@@ -217,7 +228,7 @@ class Net:
                 shape = (nn,)
             elif name == "st_clock":
                 shape = (self.n_st_lattices,)
-            elif name in ("weights", "connections"):
+            elif name in ("weights", "connections", "traces"):
                 shape = (self.n_tot, nn)
             elif name == "input_current":
                 shape = (nn,)
@@ -238,6 +249,9 @@ class Net:
             a[k][...] = v
         for k, v in STDP_DEFAULTS.items():
             a[k][...] = v
+        for k, v in RM_DEFAULTS.items():
+            a[k][...] = v
+        self.rewards = None
         if nt_kind == NT_EXPONENTIAL_DECAY:       # decay_constant, iterate_and_spike/mod.rs:336-343
             a["nt_clearance"][...] = 2.0
             a["st_nt_clearance"][...] = 2.0
@@ -318,13 +332,23 @@ class Net:
         else:
             lib().snn_o_plasticity_cols(C.byref(c), c0, c1)
 
+    def apply_reward(self, reward):
+        c = self._cnet()
+        lib().snn_o_apply_reward(C.byref(c), C.c_float(reward))
+
+    def reward_modulation(self):
+        c = self._cnet()
+        lib().snn_o_reward_modulation(C.byref(c))
+
     def spike_trains(self):
         c = self._cnet()
         lib().snn_o_spike_trains(C.byref(c))
 
     def run(self, iterations, voltage_history=False, spike_history=False, st_voltage_history=False,
-            summaries=False, spike_counts=False):
+            summaries=False, spike_counts=False, rewards=None):
         it = int(iterations)
+        self.rewards = None if rewards is None else np.ascontiguousarray(rewards, np.float32)
+        assert self.rewards is None or self.rewards.size == it
         self.avg_history = np.zeros((it, self.n_lattices), np.float32) if summaries else None
         self.eeg_history = np.zeros((it, self.n_lattices), np.float32) if summaries else None
         if spike_counts and self.spike_counts is None:

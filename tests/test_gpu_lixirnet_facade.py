@@ -179,3 +179,61 @@ def test_preset_spike_trains_with_exponential_decay_kinetics_and_stdp(snn):
     assert cell.counter == 0 and np.float32(cell.internal_clock) == o["st_step"][2]
     assert cell.last_firing_time == int(o["st_last_firing_time"][2])
     gpu.close()
+
+
+def test_reward_modulated_lattice_follows_the_rstdp_example(snn):
+    """The procedure of backend/examples/rstdp_lattice/main.rs:66-92: a 5x5 RewardModulatedLattice, neighbours within
+    radius 2, TraceRSTDP weights in [0.7, 1.5], voltages in [v_init, v_th], an Environment loop that rewards every
+    2000th step -- here 4100 steps with seeded draws, weights / traces / dopamine checked against the oracle."""
+    ln = snn
+    rng = np.random.default_rng(21)
+    keep = rng.random((25, 25)) <= 0.8
+    wts = rng.uniform(0.7, 1.5, (25, 25)).astype(np.float32)
+    v0 = rng.uniform(-65.0, 30.0, (5, 5)).astype(np.float32)
+    idx = lambda p: p[0] * 5 + p[1]
+
+    def cond(x, y):
+        return ((x[0] - y[0]) ** 2 + (x[1] - y[1]) ** 2) ** 0.5 <= 2.0 and bool(keep[idx(x), idx(y)]) and x != y
+
+    lattice = ln.RewardModulatedLattice(0)
+    lattice.populate(ln.IzhikevichNeuron(), 5, 5)
+    lattice.connect(cond, lambda x, y: ln.TraceRSTDP(weight=float(wts[idx(x), idx(y)])))
+    lattice.apply_given_position(lambda pos, n: setattr(n, "current_voltage", float(v0[pos])))
+    lattice.reward_modulator = ln.RewardModulatedSTDP(tau_c=0.05, a_plus=0.01, a_minus=0.01)
+    gpu = ln.RewardModulatedLatticeGPU.from_lattice(lattice)
+
+    steps = 4100
+    rewards = np.zeros(steps, np.float32)
+    dopamine_history = []
+    for t in range(steps):
+        reward = 1.0 if (t % 2000 == 0 and t != 0) else 0.0          # reward_function, main.rs:56-64
+        rewards[t] = reward
+        gpu.update_and_apply_reward(reward)
+        if t in (1999, 2000, 2001, 4000):
+            gpu.sync()
+            dopamine_history.append(gpu.reward_modulator.dopamine)
+    gpu.sync()
+
+    lay = parity.Layout([(0, 5, 5)])
+    o = parity.make_oracle(lay)
+    o["current_voltage"] = v0.reshape(-1)
+    pos = [(r, c) for r in range(5) for c in range(5)]
+    for i, a in enumerate(pos):
+        for j, b in enumerate(pos):
+            if cond(a, b):
+                o["connections"][i, j] = 1
+                o["weights"][i, j] = wts[i, j]
+    o["rm_do_modulation"] = 1
+    o["rm_tau_c"] = 0.05
+    o["rm_a_plus"] = 0.01
+    o["rm_a_minus"] = 0.01
+    w0 = o["weights"].copy()
+    o.run(steps, rewards=rewards)
+    assert np.array_equal(gpu.weights.view(np.uint32), np.where(o["connections"] != 0, o["weights"], 0).astype(np.float32).view(np.uint32))
+    assert np.array_equal(gpu.traces.view(np.uint32), o["traces"].view(np.uint32))
+    assert np.float32(gpu.reward_modulator.dopamine) == o["rm_dopamine"][0]
+    assert dopamine_history[0] == 0.0 and dopamine_history[1] > 0.0 and dopamine_history[2] < dopamine_history[1]
+    assert not np.array_equal(w0, o["weights"]), "rewarded traces must have moved the weights"
+    assert gpu.get_neuron(2, 2).current_voltage == float(o["current_voltage"][12])
+    assert gpu.get_weight((0, 0), (0, 1)).c == float(o["traces"][0, 1]) if cond((0, 0), (0, 1)) else True
+    gpu.close()

@@ -1,0 +1,189 @@
+"""GPU parity for reward modulation: RewardModulatedLattice (neuron/mod.rs:2719-3417) with
+RewardModulatedSTDP + TraceRSTDP (plasticity/mod.rs:126-242) -- every internal edge of a modulated lattice is
+updated every step (dopamine-gated trace), in the deferred form.  Weights, traces, dopamine and all neuron state
+bit-identical to the oracle; dense, sparse and sharded handles."""
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+import parity
+
+pytestmark = pytest.mark.gpu
+
+
+def build(lattices=((0, 7, 8),), modulated=(0,), st=(), seed=1, density=0.7):
+    lay = parity.Layout(list(lattices), list(st))
+    net = parity.make_oracle(lay, st_kind=ob.ST_RATE if st else ob.ST_NONE)
+    n = net.n_neurons
+    net["current_voltage"] = ob.uniform_array(seed, n, -65.0, 30.0)
+    net["gap_conductance"] = 10.0
+    if st:
+        net["st_rate"] = ob.uniform_array(seed + 3, net.n_cells, 1.0, 5.0)
+    net.fill_graph(seed + 1, 0.5, 1.5)
+    rng = np.random.default_rng(seed)
+    net["connections"][rng.random(net["connections"].shape) > density] = 0
+    net["weights"][...] *= net["connections"]
+    ids = [i for i, _, _ in lay.lattices]
+    for slot, i in enumerate(ids):
+        if i in modulated:
+            net["rm_do_modulation"][slot] = 1
+            net["rm_tau_c"][slot] = 0.05 + 0.01 * slot
+            net["rm_tau_d"][slot] = 5.0 + slot
+            net["rm_a_plus"][slot] = 0.002
+            net["rm_a_minus"][slot] = 0.0015
+        else:
+            net["do_plasticity"][slot] = 1
+    net["traces"][...] = ob.uniform_array(seed + 5, net["traces"].size, -0.001, 0.001).reshape(net["traces"].shape)
+    net["traces"][...] *= net["connections"]
+    return net
+
+
+def to_device(snn, net, **kw):
+    dn = parity.device_from_oracle(snn, net, **kw)
+    for slot, (i, _, _) in enumerate(net.layout.lattices):
+        if net["rm_do_modulation"][slot]:
+            dn.set_reward_modulator(i, *(float(net[k][slot]) for k in (
+                "rm_dopamine", "rm_tau_d", "rm_tau_c", "rm_a_plus", "rm_a_minus", "rm_tau_plus", "rm_tau_minus", "rm_dt")),
+                do_modulation=True)
+    return dn
+
+
+def rewards_for(steps, seed):
+    r = ob.uniform_array(seed, steps, -0.02, 0.03)
+    r[::3] = 0.0
+    return r
+
+
+def check_dense(dn, net, b=0, e=None):
+    e = net.n_neurons if e is None else e
+    w, c = dn.get_graph_rows(0, net.n_tot)
+    oc = net["connections"].astype(np.uint32)
+    ow = np.where(oc != 0, net["weights"], np.float32(0))
+    assert np.array_equal(c[:, b:e], oc[:, b:e])
+    assert np.array_equal(parity.bits(w[:, b:e]), parity.bits(ow[:, b:e])), "weights"
+    t = dn.get_trace_rows(0, net.n_tot)
+    assert np.array_equal(parity.bits(t[:, b:e]), parity.bits(net["traces"][:, b:e])), "traces"
+
+
+@pytest.mark.parametrize("case", ["single", "two_lattices_one_modulated", "both_modulated_with_spike_trains"])
+def test_reward_modulated_lattice_equals_oracle(snn, case):
+    if case == "single":
+        net = build()
+    elif case == "two_lattices_one_modulated":
+        net = build(lattices=((0, 5, 6), (2, 6, 7)), modulated=(2,), seed=3)     # lattice 0 keeps plain STDP
+    else:
+        net = build(lattices=((0, 5, 6), (2, 6, 7)), modulated=(0, 2), st=((5, 2, 3),), seed=5)
+    steps = 400
+    rewards = rewards_for(steps, 9)
+    dn = to_device(snn, net)
+    dn.set_trace_rows(0, net["traces"])
+    dn.set_history(voltage=True, spikes=True)
+    for r in rewards:
+        dn.run_with_reward(float(r))
+    w0 = net["weights"].copy()
+    net.run(steps, voltage_history=True, spike_history=True, rewards=rewards)
+    assert net.spike_history.sum() > 10 and not np.array_equal(w0, net["weights"])
+    rng = net.layout.ranges()
+    for slot, (i, _, _) in enumerate(net.layout.lattices):
+        first, count, _ = rng[i]
+        assert np.array_equal(dn.spike_history(i), net.spike_history[:, first:first + count])
+        assert np.array_equal(parity.bits(dn.voltage_history(i)), parity.bits(net.voltage_history[:, first:first + count]))
+        if net["rm_do_modulation"][slot]:
+            assert dn.dopamine(i) == net["rm_dopamine"][slot] and net["rm_dopamine"][slot] != 0
+    check_dense(dn, net)
+    parity.assert_state_equal(net, parity.pull_state(dn, net))
+    dn.close()
+
+
+def test_run_without_reward_keeps_dopamine(snn):
+    """RunLattice::run_lattice on a reward-modulated lattice (neuron/mod.rs:3361-3375) iterates without touching the
+    modulator: dopamine stays, traces and weights still move; a mixed sequence of both calls matches the oracle."""
+    net = build(seed=7)
+    net["rm_dopamine"][0] = 0.01
+    dn = to_device(snn, net)
+    dn.set_trace_rows(0, net["traces"])
+    dn.run(50)
+    net.run(50)
+    assert dn.dopamine(0) == np.float32(0.01)
+    dn.run_with_reward(0.5)
+    dn.run(30)
+    net.run(1, rewards=[0.5])
+    net.run(30)
+    assert dn.dopamine(0) == net["rm_dopamine"][0]
+    check_dense(dn, net)
+    # do_modulation = false freezes weights and traces (neuron/mod.rs:3142-3144)
+    dn.set_reward_modulator(0, *(float(net[k][0]) for k in ("rm_dopamine", "rm_tau_d", "rm_tau_c", "rm_a_plus", "rm_a_minus",
+                                                            "rm_tau_plus", "rm_tau_minus", "rm_dt")), do_modulation=False)
+    w, _ = dn.get_graph_rows(0, net.n_tot)
+    dn.run_with_reward(0.3)
+    dn.run(20)
+    w2, _ = dn.get_graph_rows(0, net.n_tot)
+    assert np.array_equal(parity.bits(w), parity.bits(w2))
+    dn.close()
+
+
+def test_sparse_handle_matches_dense(snn):
+    net = build(lattices=((0, 6, 6), (1, 5, 7)), modulated=(0, 1), st=((4, 2, 2),), seed=11, density=0.3)
+    steps = 300
+    rewards = rewards_for(steps, 12)
+    dn = to_device(snn, net, csr=True)
+    ptr, pre, w = parity.csr_from_dense(net, 0, net.n_neurons)
+    traces_csr = np.concatenate([net["traces"][pre[ptr[q]:ptr[q + 1]], q] for q in range(net.n_neurons)])
+    dn.set_traces_csr(traces_csr)
+    for r in rewards:
+        dn.run_with_reward(float(r))
+    net.run(steps, rewards=rewards)
+    expect_w = np.concatenate([net["weights"][pre[ptr[q]:ptr[q + 1]], q] for q in range(net.n_neurons)])
+    expect_c = np.concatenate([net["traces"][pre[ptr[q]:ptr[q + 1]], q] for q in range(net.n_neurons)])
+    assert np.array_equal(parity.bits(dn.get_graph_csr()), parity.bits(expect_w))
+    assert np.array_equal(parity.bits(dn.get_traces_csr()), parity.bits(expect_c))
+    parity.assert_state_equal(net, parity.pull_state(dn, net))
+    dn.close()
+
+
+@pytest.mark.parametrize("n_shards", [2, 3])
+def test_sharded_handles(snn, n_shards):
+    """Each shard owns its postsynaptic columns of W and of the trace matrix; dopamine is replicated."""
+    import torch
+    from snn_amd import parallel
+    net = build(lattices=((0, 8, 8), (3, 9, 10)), modulated=(0, 3), st=((5, 2, 3),), seed=13)
+    steps = 250
+    rewards = rewards_for(steps, 14)
+    handles = [to_device(snn, net, shard=(r, n_shards)) for r in range(n_shards)]
+    for h in handles:
+        h.set_trace_rows(0, net["traces"])
+    bufs = [parallel.exchange_tensor(h, torch.device("cuda", 0)) for h in handles]
+    block = bufs[0].numel() // n_shards
+    for rwd in rewards:
+        for h in handles:
+            h.apply_reward(float(rwd))
+            h.step_begin_local()          # refused internally while modulation is on
+            h.step_begin()
+        for r in range(n_shards):
+            for o in range(n_shards):
+                if o != r:
+                    bufs[o][r * block:(r + 1) * block].copy_(bufs[r][r * block:(r + 1) * block])
+        torch.cuda.synchronize()
+        for h in handles:
+            h.step_end()
+    net.run(steps, rewards=rewards)
+    for h in handles:
+        check_dense(h, net, h.post_begin, h.post_end)
+        assert h.dopamine(3) == net["rm_dopamine"][1]
+        h.close()
+
+
+def test_reward_errors(snn):
+    net = build(st=((4, 1, 2),))
+    dn = parity.device_from_oracle(snn, net)
+    with pytest.raises(snn.SnnError):
+        dn.set_reward_modulator(4)                 # a spike-train lattice
+    with pytest.raises(snn.SnnError):
+        dn.set_reward_modulator(99)
+    with pytest.raises(snn.SnnError):
+        dn.get_traces_csr()                        # dense handle
+    with pytest.raises(snn.SnnError):
+        dn.get_trace_rows(0, net.n_tot + 1)
+    dn.apply_reward(1.0)                           # nothing modulated: a no-op
+    dn.run(2)
+    dn.close()

@@ -383,3 +383,36 @@ def test_preset_spike_train_cycles_through_its_firing_times():
     assert spikes == [0, 0, 0, 1, 0, 1, 0, 0, 0, 1, 0, 1, 0, 0]
     assert net["st_counter"][0] == 0 and net["st_last_firing_time"][0] == 11
     assert net["st_current_voltage"][0] == f32(0.0) and net["st_step"][0] == f32(2.0)
+
+
+# ---- reward modulation (plasticity/mod.rs:126-242) ---------------------------------------------------
+def test_reward_modulated_stdp_hand_derived():
+    """RewardModulatedSTDP::update (dopamine = dopamine * exp(-dt / tau_d) + tau_d * reward) and the two
+    update_weight visits every edge receives per step (do_update is always true): dw accumulates the STDP delta
+    twice, the trace becomes c * exp(-dt / tau_c) + tau_c * dw on the second visit and the weight moves by
+    c * dopamine on both."""
+    net = ob.Net(2)
+    net["rm_do_modulation"] = 1
+    net["rm_tau_c"] = 0.5
+    net["rm_dopamine"] = 0.25
+    net["connections"][0, 1] = 1
+    net["weights"][0, 1] = 1.0
+    net["traces"][0, 1] = 0.125
+    net["last_firing_time"][...] = [10, 15]
+    net.apply_reward(0.5)
+    dop = f32(f32(f32(0.25) * f32(ob.expf(f32(-0.1) / f32(20.0)))) + f32(f32(20.0) * f32(0.5)))
+    assert net["rm_dopamine"][0] == dop
+    net.reward_modulation()
+    delta = f32(f32(2.0) * f32(ob.expf(f32(f32(-1.0) * abs(f32(f32(10.0) - f32(15.0)) * f32(0.1))) / f32(4.5))))
+    assert delta == f32(lib_stdp(10, 15))
+    w1 = f32(f32(1.0) + f32(f32(0.125) * dop))
+    dw = f32(delta + delta)
+    c = f32(f32(f32(0.125) * f32(ob.expf(f32(-0.1) / f32(0.5)))) + f32(f32(0.5) * dw))
+    w2 = f32(w1 + f32(c * dop))
+    assert net["traces"][0, 1] == c and net["weights"][0, 1] == w2
+    # an absent edge and an edge of a lattice without modulation stay untouched
+    assert net["weights"][1, 0] == 0 and net["traces"][1, 0] == 0
+
+
+def lib_stdp(tp, tq):
+    return ob.lib().snn_o_stdp_delta(tp, tq, 2.0, 2.0, 4.5, 4.5, 0.1)
