@@ -28,6 +28,10 @@ struct UpdateArgs {
     float *vhist_row;          // this step's row of the voltage history (global neuron index) or null
     unsigned long long *spike_row;   // this step's row of the bit-packed raster or null
     uint32_t *spike_counts;          // per-neuron spike totals (SpikeHistory::aggregate) or null
+    // Where the exchanged state (V, spike flag, t) of the step is stored: `xout` = the handle's exchange buffer
+    // (= n.xbuf on the two-kernel path, which updates in place); the fused small-lattice step reads S(t) from a
+    // shadow copy (n.xbuf) while it writes S(t+1) to the exchange buffer and to the other shadow (`xout2`).
+    float *xout, *xout2;
 };
 
 // Second level of the canonical sum: chunk partials added in ascending chunk order from 0.0f.  The loads of
@@ -57,15 +61,29 @@ __device__ __forceinline__ void neuron_nt_update(const UpdateArgs &a, uint32_t q
     for (int k = 0; k < K_TYPES; ++k) {
         const size_t i = (size_t)k * a.n.n_pad + q;
         if (!a.n.nt_flags[i]) continue;
-        float *tp = a.n.xbuf + a.n.xl.at(q, PLANE_T0 + k);
-        *tp = nt_apply(a.nt_kind, *tp, a.n.nt_t_max[i], a.n.nt_clearance[i], a.n.nt_v_p[i],
-                       a.n.nt_k_p[i], voltage, spiking_prev, dt);
+        const size_t at = a.n.xl.at(q, PLANE_T0 + k);
+        const float t = nt_apply(a.nt_kind, a.n.xbuf[at], a.n.nt_t_max[i], a.n.nt_clearance[i], a.n.nt_v_p[i],
+                                 a.n.nt_k_p[i], voltage, spiking_prev, dt);
+        a.xout[at] = t;
+        if (a.xout2) a.xout2[at] = t;
     }
 }
 
+// Where a column's second-level sums come from: the chunk partials in global memory (two-kernel path) ...
+struct GlobalSums {
+    const UpdateArgs &a;
+    uint32_t ql;
+    __device__ __forceinline__ float elec() const { return combine_partials(a.part_i + ql, a.n_chunks, a.ld); }
+    __device__ __forceinline__ float chem(int k) const
+    {
+        return combine_partials(a.part_t + (size_t)k * a.n_chunks * a.ld + ql, a.n_chunks, a.ld);
+    }
+};
+
 // Ionotropic::update_receptor_kinetics + set_receptor_currents (iterate_and_spike/mod.rs:1186-1284)
+template <class Sums>
 __device__ __forceinline__ void receptors_update(const UpdateArgs &a, uint32_t q, uint32_t ql,
-                                                 float v_old, float dt)
+                                                 float v_old, float dt, const Sums &sums)
 {
 #pragma unroll
     for (int k = 0; k < K_TYPES; ++k) {
@@ -74,7 +92,7 @@ __device__ __forceinline__ void receptors_update(const UpdateArgs &a, uint32_t q
         const uint32_t cnt = a.tcount[(size_t)k * a.ld + ql];
         if (cnt != 0) {
             // second level of the canonical sum, then the per-type average
-            const float s = combine_partials(a.part_t + (size_t)k * a.n_chunks * a.ld + ql, a.n_chunks, a.ld);
+            const float s = sums.chem(k);
             const float t = s / (float)cnt;
             a.n.rc_r[i] = rc_apply(a.rc_kind, a.n.rc_r[i], t, a.n.rc_alpha[i], a.n.rc_beta[i], dt);
         }
@@ -112,31 +130,28 @@ __device__ __forceinline__ float gate_update(float state, float alpha, float bet
     return state + dt * (alpha_state - beta_state);
 }
 
-template <int MODEL>
-__global__ __launch_bounds__(256) void k_update(const UpdateArgs a)
+// One neuron's step (local column ql); returns its spike flag.
+template <int MODEL, class Sums>
+__device__ __forceinline__ uint32_t update_neuron(const UpdateArgs &a, uint32_t ql, const Sums &sums)
 {
-    const uint32_t ql = blockIdx.x * 256 + threadIdx.x;
-    const bool active = ql < a.n_loc;
     uint32_t spike = 0;
-
-    if (active) {
+    {
         const uint32_t q = a.q0 + ql;
-        float *vptr = a.n.xbuf + a.n.xl.at(q, PLANE_V);
-        uint32_t *sptr = reinterpret_cast<uint32_t *>(a.n.xbuf) + a.n.xl.at(q, PLANE_SPIKE);
-        const float v = *vptr;
+        const size_t v_at = a.n.xl.at(q, PLANE_V), s_at = a.n.xl.at(q, PLANE_SPIKE);
+        const float v = a.n.xbuf[v_at];
         const float dt = a.n.dt[q];
         const float c_m = a.n.c_m[q];
-        const uint32_t spiking_prev = *sptr;
+        const uint32_t spiking_prev = reinterpret_cast<const uint32_t *>(a.n.xbuf)[s_at];
 
         // input current: chunk partials in ascending order, then the averager (neuron/mod.rs:722-729)
         float i_in = 0.0f;
         if (a.electrical) {
-            const float s = combine_partials(a.part_i + ql, a.n_chunks, a.ld);
+            const float s = sums.elec();
             const uint32_t cnt = a.n_in[ql];
             i_in = s / (cnt == 0 ? 1.0f : (float)cnt);
         }
 
-        if (a.chemical) receptors_update(a, q, ql, v, dt);
+        if (a.chemical) receptors_update(a, q, ql, v, dt, sums);
 
         float v_new;
         if (MODEL == 0) {            // Izhikevich
@@ -292,12 +307,24 @@ __global__ __launch_bounds__(256) void k_update(const UpdateArgs a)
             a.n.was_increasing[q] = increasing_right_now;
         }
 
-        *vptr = v_new;
-        *sptr = spike;
+        a.xout[v_at] = v_new;
+        reinterpret_cast<uint32_t *>(a.xout)[s_at] = spike;
+        if (a.xout2) {
+            a.xout2[v_at] = v_new;
+            reinterpret_cast<uint32_t *>(a.xout2)[s_at] = spike;
+        }
         if (spike) a.n.last_firing_time[q] = (int32_t)a.clock;   // neuron/mod.rs:964-966, 2555-2557
         if (a.vhist_row) a.vhist_row[q] = v_new;
         if (a.spike_counts && spike) a.spike_counts[q] += 1;
     }
+    return spike;
+}
+
+template <int MODEL>
+__global__ __launch_bounds__(256) void k_update(const UpdateArgs a)
+{
+    const uint32_t ql = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t spike = (ql < a.n_loc) ? update_neuron<MODEL>(a, ql, GlobalSums{a, ql}) : 0u;
 
     // spike raster: one 64-bit ballot word per wavefront (shard boundaries are multiples of 64)
     if (a.spike_row) {

@@ -20,6 +20,7 @@
 #include "snn_kernels_csr.hpp"
 #include "snn_kernels_inputs.hpp"
 #include "snn_kernels_misc.hpp"
+#include "snn_kernels_resident.hpp"
 #include "snn_kernels_update.hpp"
 #include "snn_layout.hpp"
 
@@ -115,6 +116,11 @@ struct snn_network {
     long long *st_clock_dev = nullptr;
     long long run_step_offset = 0;
     bool run_active = false;        // a (possibly externally driven) run is open: device clocks are ahead of st_clock
+    // fused small-lattice step (k_step_resident): two shadow copies of the exchange buffer + per-tile tickets
+    float *shadow[2] = {nullptr, nullptr};
+    int shadow_cur = 0;
+    bool shadow_valid = false;      // shadow[shadow_cur] == exchange buffer
+    int fused_step = 1;             // 0: always take the two-kernel path (SNN_AMD_FUSED_STEP=0)
     bool view_dirty = true;         // spike-train gap-junction values must be refreshed before the next inputs
     bool local_inputs_done = false; // this step's LOCAL chunk partials are already enqueued
 
@@ -522,6 +528,7 @@ int attr_io(snn_network *net, uint32_t id, const char *name, AttrType type, void
     HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
     TRY(end_run(net));
     if (set && l->spike_train) net->view_dirty = true;
+    if (set) net->shadow_valid = false;
     const uint32_t first = l->spike_train ? l->first - net->nn : l->first;   // index inside its own arrays
 
     if (!typed) {
@@ -704,6 +711,8 @@ int launch_update(snn_network *net)
     a.vhist_row = (record_now(net) && net->want_vhist && net->vhist) ? net->vhist + (size_t)net->hist_steps * net->n_pad : nullptr;
     a.spike_row = (record_now(net) && net->want_raster && net->raster) ? net->raster + (size_t)net->hist_steps * (net->n_pad / 64) : nullptr;
     a.spike_counts = net->want_counts ? net->spike_counts : nullptr;
+    a.xout = net->xbuf; a.xout2 = nullptr;
+    net->shadow_valid = false;            // the exchange buffer moves on without the shadows
     dim3 grid((net->ld + 255) / 256);
     switch (net->model) {
     case SNN_MODEL_LIF: hipLaunchKernelGGL((k_update<1>), grid, dim3(256), 0, net->stream, a); break;
@@ -841,9 +850,92 @@ int choose_matrix_placement(snn_network *net)
     return SNN_OK;
 }
 
+// Small dense lattices on an unsharded handle: inputs + update in ONE launch (snn_kernels_resident.hpp).
+bool fused_step_applies(const snn_network *net)
+{
+    return net->fused_step && !net->csr && net->xl.n_shards == 1 && net->n_loc && net->n_tot && !net->local_inputs_done &&
+           net->n_chunks <= RESIDENT_MAX_CHUNKS && (size_t)net->n_tot * net->ld * 4 <= ((size_t)64 << 20);
+}
+
+int launch_step_resident(snn_network *net)
+{
+    const size_t xelems = (size_t)net->xl.n_shards * NUM_PLANES * net->xl.stride;
+    if (!net->shadow[0]) {
+        TRY(dev_alloc_t(net, &net->shadow[0], xelems));
+        TRY(dev_alloc_t(net, &net->shadow[1], xelems));
+        net->shadow_valid = false;
+    }
+    if (!net->shadow_valid) {
+        // both shadows: entries the step never rewrites (absent transmitter types, padding) must agree everywhere
+        for (int i = 0; i < 2; ++i)
+            HIP_TRY(hipMemcpyAsync(net->shadow[i], net->xbuf, xelems * 4, hipMemcpyDeviceToDevice, net->stream),
+                    SNN_ERR_BUFFER_WRITE);
+        net->shadow_valid = true;
+    }
+    float *cur = net->shadow[net->shadow_cur], *next = net->shadow[net->shadow_cur ^ 1];
+    ResidentArgs r{};
+    InputsArgs &a = r.in;
+    a.chunk_first = 0; a.hole_begin = net->n_chunks; a.hole_count = 0;
+    a.W = net->W; a.ld = net->ld; a.n_loc = net->n_loc; a.q0 = net->q0; a.n_neurons = net->nn; a.n_tot = net->n_tot;
+    a.xbuf = cur; a.xl = net->xl; a.gap_conductance = net->na.gap_conductance;
+    a.st_value = net->ca.presyn_value; a.st_last_firing_time = net->ca.last_firing_time;
+    a.st_nt_t = net->ca.nt_t; a.st_nt_flags = net->ca.nt_flags; a.c_pad = net->c_pad;
+    a.nt_flags = net->na.nt_flags; a.n_pad = net->n_pad;
+    a.part_i = net->part_i; a.part_t = net->part_t; a.n_chunks = net->n_chunks;
+    UpdateArgs &u = r.up;
+    u.n = net->na;
+    u.n.xbuf = cur;
+    u.part_i = net->part_i; u.part_t = net->part_t; u.n_in = net->n_in; u.tcount = net->tcount;
+    u.ld = net->ld; u.n_chunks = net->n_chunks; u.q0 = net->q0; u.n_loc = net->n_loc;
+    u.clock = net->clock;
+    u.electrical = net->electrical; u.chemical = net->chemical; u.nt_kind = net->nt_kind; u.rc_kind = net->rc_kind;
+    u.vhist_row = (record_now(net) && net->want_vhist && net->vhist) ? net->vhist + (size_t)net->hist_steps * net->n_pad : nullptr;
+    u.spike_row = (record_now(net) && net->want_raster && net->raster) ? net->raster + (size_t)net->hist_steps * (net->n_pad / 64) : nullptr;
+    u.spike_counts = net->want_counts ? net->spike_counts : nullptr;
+    u.xout = net->xbuf; u.xout2 = next;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (net->profile) {
+        if (net->ev_used == net->ev_pool.size()) {
+            hipEvent_t x, y;
+            HIP_TRY(hipEventCreate(&x), SNN_ERR_QUEUE);
+            HIP_TRY(hipEventCreate(&y), SNN_ERR_QUEUE);
+            net->ev_pool.emplace_back(x, y);
+        }
+        e0 = net->ev_pool[net->ev_used].first;
+        e1 = net->ev_pool[net->ev_used].second;
+        net->ev_counts.resize(net->ev_pool.size(), 1);
+        net->ev_counts[net->ev_used] = 1;
+        ++net->ev_used;
+        HIP_TRY(hipEventRecord(e0, net->stream), SNN_ERR_QUEUE);
+    }
+    const dim3 grid((net->n_loc + 63) / 64), block(64 * net->n_chunks);
+#define SNN_RESIDENT(M)                                                                                              \
+    do {                                                                                                             \
+        if (net->electrical && net->chemical) hipLaunchKernelGGL((k_step_resident<M, true, true>), grid, block, 0, net->stream, r);  \
+        else if (net->electrical) hipLaunchKernelGGL((k_step_resident<M, true, false>), grid, block, 0, net->stream, r);             \
+        else hipLaunchKernelGGL((k_step_resident<M, false, true>), grid, block, 0, net->stream, r);                                  \
+    } while (0)
+    switch (net->model) {
+    case 1: SNN_RESIDENT(1); break;
+    case 2: SNN_RESIDENT(2); break;
+    case 3: SNN_RESIDENT(3); break;
+    case 4: SNN_RESIDENT(4); break;
+    case 5: SNN_RESIDENT(5); break;
+    case 6: SNN_RESIDENT(6); break;
+    case 7: SNN_RESIDENT(7); break;
+    default: SNN_RESIDENT(0); break;
+    }
+#undef SNN_RESIDENT
+    HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+    if (net->profile) HIP_TRY(hipEventRecord(e1, net->stream), SNN_ERR_QUEUE);
+    net->shadow_cur ^= 1;
+    return SNN_OK;
+}
+
 // first half of a step: inputs from S(t) and the local neurons' update
 int step_begin(snn_network *net)
 {
+    if (fused_step_applies(net)) return launch_step_resident(net);
     TRY(launch_inputs(net, net->local_inputs_done ? INPUTS_REMOTE : INPUTS_ALL));
     net->local_inputs_done = false;
     TRY(launch_update(net));
@@ -1036,6 +1128,7 @@ int snn_network_create(int device, int neuron_model, int nt_kinetics, int recept
     HIP_TRY(hipSetDevice(device), SNN_ERR_GET_DEVICE);
     snn_network *net = new snn_network();
     net->device = device;
+    if (const char *e = getenv("SNN_AMD_FUSED_STEP")) net->fused_step = (e[0] != '0');
     net->model = neuron_model; net->nt_kind = nt_kinetics; net->rc_kind = receptor_kinetics;
     net->st_kind = spike_train_model;
     if (hipStreamCreateWithFlags(&net->own_stream, hipStreamNonBlocking) != hipSuccess) {
