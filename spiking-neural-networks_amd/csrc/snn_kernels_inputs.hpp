@@ -123,6 +123,7 @@ __global__ __launch_bounds__(InputsShape<STREAM>::THREADS) void k_inputs_dense(c
     const uint32_t tid = threadIdx.x;
 
     // ---- stage the chunk's presynaptic values in LDS (coalesced reads, one pass per array) ----
+    uint32_t kinds_and = 0x703u, kinds_or = 0u;              // over the rows this thread stages
     for (uint32_t i = tid; i < rows; i += S::THREADS) {
         const uint32_t p = p0 + i;
         float val;
@@ -153,8 +154,27 @@ __global__ __launch_bounds__(InputsShape<STREAM>::THREADS) void k_inputs_dense(c
         }
         s_val[i] = val;
         s_kind[i] = kind;
+        kinds_and &= kind | ~0x703u;
+        kinds_or |= kind;
     }
-    __syncthreads();
+    // Homogeneous chunks (every row a neuron; each transmitter type carried by all rows or by none -- any lattice
+    // populated from one base neuron) take a row body without per-row kind tests: workgroup-uniform votes, which
+    // also are the barrier that publishes the staged values.
+    bool uniform_chunk = false, type_on[CHEM ? K_TYPES : 1];
+    if (CHEM) {
+        int ok = __syncthreads_and((kinds_or & 3u) == 0u);
+#pragma unroll
+        for (int k = 0; k < K_TYPES; ++k) {
+            const int all_k = __syncthreads_and((kinds_and >> (8 + k)) & 1u);
+            const int any_k = __syncthreads_or((kinds_or >> (8 + k)) & 1u);
+            type_on[k] = all_k != 0;
+            ok = ok && (all_k || !any_k);
+        }
+        uniform_chunk = ok != 0;
+    } else {
+        type_on[0] = false;
+        __syncthreads();
+    }
 
     // Column tile of this workgroup, rotated by the chunk index: workgroups are dealt round-robin over the 8
     // XCDs, so with a power-of-two tile count an unrotated mapping would pin every XCD (and its L2 / fabric
@@ -193,7 +213,7 @@ __global__ __launch_bounds__(InputsShape<STREAM>::THREADS) void k_inputs_dense(c
     // so every wave keeps ROW_BATCH wave-rows of reads in flight regardless of the branches in the body.
     auto sweep = [&](auto body) {
         uint32_t r = 0;
-        if constexpr (STREAM == 1 && !CHEM) {
+        if constexpr ((STREAM == 1 && !CHEM) || STREAM == 2) {
             // Electrical-only streaming pass (the 256x256 headline): two register buffers, so the next batch of
             // 8 rows is already in flight while the current one is consumed (+1 % over a single buffer, measured
             // in-process at 256x256; the chemical variants keep one buffer -- they need the registers for their
@@ -240,6 +260,22 @@ __global__ __launch_bounds__(InputsShape<STREAM>::THREADS) void k_inputs_dense(c
             const float vp = s_val[r];
 #pragma unroll
             for (int j = 0; j < VEC; ++j) acc[j] = acc_if_edge(acc[j], gq[j] * (vp - vq[j]), w[j]);
+        });
+    } else if (uniform_chunk) {
+        sweep([&](uint32_t r, const float (&w)[VEC]) {
+            if (ELEC) {
+                const float vp = s_val[r];
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) acc[j] = acc_if_edge(acc[j], gq[j] * (vp - vq[j]), w[j]);
+            }
+#pragma unroll
+            for (int k = 0; k < K_TYPES; ++k) {
+                if (type_on[CHEM ? k : 0]) {
+                    const float t = s_t[CHEM ? k : 0][r];
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) tacc[CHEM ? k : 0][j] = acc_if_edge(tacc[CHEM ? k : 0][j], t, w[j]);
+                }
+            }
         });
     } else {
         sweep([&](uint32_t r, const float (&w)[VEC]) {
