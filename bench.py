@@ -23,7 +23,9 @@ ROWS = COLS = 256
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling is ~6.3 TB/s
 # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of THIS command (FETCH_SIZE and
 # WRITE_SIZE cannot share a pass); their summaries are committed under profiles/ and quoted here per launch.
-PMC_TRAFFIC = {"c2": os.path.join(ROOT, "profiles", "r01", "c2_izhikevich_256x256_pmc_traffic.json")}
+PMC_TRAFFIC = {"c2": os.path.join(ROOT, "profiles", "r01", "c2_izhikevich_256x256_pmc_traffic.json"),
+               "c3": os.path.join(ROOT, "profiles", "r01", "c3_pmc_traffic.json"),
+               "c4": os.path.join(ROOT, "profiles", "r01", "c4_pmc_traffic.json")}
 
 
 def pmc_traffic(config, world, rows, cols):
