@@ -1,6 +1,8 @@
-"""Randomised differential test: many small networks drawn from a seeded generator -- model, kinetics,
-synapse kinds, lattice shapes, connectivity density, spike-train inputs, plasticity, graph form (dense / sparse),
-whole or sharded stepping, run split into several calls -- each compared bit for bit with the oracle."""
+"""Randomised differential test: many small networks drawn from a seeded generator -- model (8), neurotransmitter /
+receptor kinetics (4 x 3), synapse kinds, lattice shapes, connectivity density, spike-train inputs (Poisson, rate,
+preset), per-lattice plasticity (none / STDP / reward-modulated with a random reward sequence), graph form (dense /
+sparse), whole or sharded stepping, run split into several calls, reduced histories with a random stride -- each
+compared bit for bit with the oracle."""
 import numpy as np
 import pytest
 
@@ -62,49 +64,115 @@ def draw(seed):
     net["connections"][...] &= (rng.random(net["connections"].shape) < density)
     net["weights"][...] *= net["connections"]
     for slot in range(len(lattices)):
-        net["do_plasticity"][slot] = int(rng.integers(0, 2))
+        mode = int(rng.integers(0, 3))                  # 0 static weights, 1 STDP, 2 reward-modulated (R-STDP traces)
+        net["do_plasticity"][slot] = int(mode == 1)
         net["stdp_a_plus"][slot] = float(rng.uniform(0.5, 2.5))
         net["stdp_tau_minus"][slot] = float(rng.uniform(2.0, 6.0))
+        if mode == 2:
+            net["rm_do_modulation"][slot] = 1
+            net["rm_dopamine"][slot] = float(rng.uniform(0.0, 0.02))
+            net["rm_tau_d"][slot] = float(rng.uniform(2.0, 10.0))
+            net["rm_tau_c"][slot] = float(rng.uniform(0.02, 0.2))
+            net["rm_a_plus"][slot] = float(rng.uniform(0.001, 0.01))
+            net["rm_a_minus"][slot] = float(rng.uniform(0.001, 0.01))
+    net["traces"][...] = ob.uniform_array(seed + 9, net["traces"].size, -0.001, 0.001).reshape(net["traces"].shape)
+    net["traces"][...] *= net["connections"]
     dt = 0.01 if model == ob.HH else float(rng.choice([0.05, 0.1, 0.2]))
     net["dt"] = dt
     net["st_dt"] = dt
     net["stdp_dt"] = dt
+    net["rm_dt"] = dt
     plan = dict(csr=bool(rng.integers(0, 2)), shards=int(rng.choice([1, 1, 2, 3])),
-                steps=int(rng.integers(80, 260)), calls=int(rng.integers(1, 4)))
+                steps=int(rng.integers(80, 260)), calls=int(rng.integers(1, 4)), stride=int(rng.choice([1, 1, 2, 5])))
+    plan["rewards"] = None
+    if net["rm_do_modulation"].any():
+        r = ob.uniform_array(seed + 10, plan["steps"], -0.02, 0.03)
+        r[::4] = 0.0
+        plan["rewards"] = r
     return net, plan
 
 
-@pytest.mark.parametrize("seed", list(range(48)))
+RM_KEYS = ("rm_dopamine", "rm_tau_d", "rm_tau_c", "rm_a_plus", "rm_a_minus", "rm_tau_plus", "rm_tau_minus", "rm_dt")
+
+
+def csr_order(net, dense, b, e):
+    """values of a dense [n_tot][n_neurons] array in the CSR-by-post edge order of columns b..e"""
+    ptr, pre, _ = parity.csr_from_dense(net, b, e)
+    return np.concatenate([dense[pre[ptr[q]:ptr[q + 1]], b + q] for q in range(e - b)]) if e > b else np.zeros(0, np.float32)
+
+
+def make_handle(snn, net, plan, shard=None):
+    dn = parity.device_from_oracle(snn, net, shard=shard, csr=plan["csr"])
+    if plan["rewards"] is not None:
+        for slot, (i, _, _) in enumerate(net.layout.lattices):
+            if net["rm_do_modulation"][slot]:
+                dn.set_reward_modulator(i, *(float(net[k][slot]) for k in RM_KEYS), do_modulation=True)
+        if plan["csr"]:
+            dn.set_traces_csr(csr_order(net, net["traces"], dn.post_begin, dn.post_end))
+        elif net.n_neurons and net.n_tot:
+            dn.set_trace_rows(0, net["traces"])
+    return dn
+
+
+def check_modulation(dn, net, plan):
+    if plan["rewards"] is None:
+        return
+    b, e = dn.post_begin, dn.post_end
+    if plan["csr"]:
+        assert np.array_equal(parity.bits(dn.get_traces_csr()), parity.bits(csr_order(net, net["traces"], b, e)))
+    elif net.n_neurons and net.n_tot:
+        t = dn.get_trace_rows(0, net.n_tot)
+        assert np.array_equal(parity.bits(t[:, b:e]), parity.bits(net["traces"][:, b:e]))
+    for slot, (i, _, _) in enumerate(net.layout.lattices):
+        if net["rm_do_modulation"][slot]:
+            assert np.array_equal(parity.bits(np.array([dn.dopamine(i)])), parity.bits(net["rm_dopamine"][slot:slot + 1]))
+
+
+@pytest.mark.parametrize("seed", list(range(64)))
 def test_random_network(snn, seed):
     import torch
     from snn_amd import parallel
     net, plan = draw(1000 + seed)
     steps = plan["steps"]
     if plan["shards"] == 1:
-        dn = parity.device_from_oracle(snn, net, csr=plan["csr"])
+        dn = make_handle(snn, net, plan)
         dn.set_history(voltage=True, spikes=True)
-        done = 0
-        for c in range(plan["calls"]):
-            k = steps // plan["calls"] if c < plan["calls"] - 1 else steps - done
-            dn.run(k)
-            done += k
-        net.run(steps, voltage_history=True, spike_history=True)
+        dn.set_reduced_history(True, True, True)
+        dn.set_history_stride(plan["stride"])
+        if plan["rewards"] is not None:
+            for r in plan["rewards"]:
+                dn.run_with_reward(float(r))
+        else:
+            done = 0
+            for c in range(plan["calls"]):
+                k = steps // plan["calls"] if c < plan["calls"] - 1 else steps - done
+                dn.run(k)
+                done += k
+        net.run(steps, voltage_history=True, spike_history=True, summaries=True, spike_counts=True, rewards=plan["rewards"])
+        keep = np.arange(0, steps, plan["stride"])
         rng = net.layout.ranges()
-        for i, _, _ in net.layout.lattices:
+        for slot, (i, _, _) in enumerate(net.layout.lattices):
             first, count, _ = rng[i]
-            assert np.array_equal(dn.spike_history(i), net.spike_history[:, first:first + count])
-            assert np.array_equal(parity.bits(dn.voltage_history(i)), parity.bits(net.voltage_history[:, first:first + count]))
+            assert np.array_equal(dn.spike_history(i), net.spike_history[keep, first:first + count])
+            assert np.array_equal(parity.bits(dn.voltage_history(i)), parity.bits(net.voltage_history[keep, first:first + count]))
+            assert np.array_equal(dn.spike_counts(i), net.spike_counts[first:first + count])
+            if count:
+                assert np.array_equal(parity.bits(dn.average_voltage_history(i)), parity.bits(net.avg_history[keep, slot]))
+                assert np.array_equal(parity.bits(dn.eeg_history(i)), parity.bits(net.eeg_history[keep, slot]))
         parity.assert_state_equal(net, parity.pull_state(dn, net))
         parity.assert_graph_equal(net, dn)
+        check_modulation(dn, net, plan)
         assert dn.clock == net.clock
         dn.close()
         return
     g = plan["shards"]
-    handles = [parity.device_from_oracle(snn, net, shard=(r, g), csr=plan["csr"]) for r in range(g)]
+    handles = [make_handle(snn, net, plan, shard=(r, g)) for r in range(g)]
     bufs = [parallel.exchange_tensor(h, torch.device("cuda", 0)) for h in handles]
     block = bufs[0].numel() // g
-    for _ in range(steps):
+    for step in range(steps):
         for h in handles:
+            if plan["rewards"] is not None:
+                h.apply_reward(float(plan["rewards"][step]))
             h.step_begin_local()
             h.step_begin()
         for r in range(g):
@@ -114,8 +182,9 @@ def test_random_network(snn, seed):
         torch.cuda.synchronize()
         for h in handles:
             h.step_end()
-    net.run(steps)
+    net.run(steps, rewards=plan["rewards"])
     for h in handles:
+        check_modulation(h, net, plan)
         st = parity.pull_state(h, net)
         for name in ("current_voltage", "is_spiking", "last_firing_time", "nt_t"):
             assert np.array_equal(parity.bits(st[name]), parity.bits(net[name])), name
