@@ -76,10 +76,15 @@ class ShardedStepper:
             self._sync()
         return work if async_op else None
 
-    def run(self, iterations, overlap=True):
+    def run(self, iterations, overlap=True, rewards=None):
         """`iterations` steps.  overlap (GPU backends): the collective of step t runs on RCCL's stream while
         step t+1's synaptic-input pass over the shard's OWN presynaptic rows is already executing; only the
-        rows fed by other shards wait for it (backend.step_begin_local, a no-op when it would not be valid)."""
+        rows fed by other shards wait for it (backend.step_begin_local, a no-op when it would not be valid).
+        rewards: one value per step, applied to the reward-modulated lattices before that step (every rank passes
+        the same sequence: the modulators are replicated)."""
+        if rewards is not None and len(rewards) != int(iterations):
+            raise ValueError("rewards must hold one value per step")
+        self._rewards = rewards
         overlap = overlap and self.buf.is_cuda and hasattr(self.backend, "step_begin_local") and self.stream is not None
         if self.stream is not None:
             import torch
@@ -89,20 +94,25 @@ class ShardedStepper:
             self._run(iterations, overlap)
 
     def _run(self, iterations, overlap):
+        rewards = self._rewards
         if not overlap:
-            for _ in range(int(iterations)):
+            for i in range(int(iterations)):
+                if rewards is not None:
+                    self.backend.apply_reward(float(rewards[i]))
                 self.backend.step_begin()
                 self.exchange()
                 self.backend.step_end()
             return
         pending = None
         started = False
-        for _ in range(int(iterations)):
+        for i in range(int(iterations)):
             self.backend.step_begin_local()
             if started:
                 if pending is not None:
                     pending.wait()                 # the compute stream waits for the gather, the host does not
                 self.backend.step_end()
+            if rewards is not None:                # after the previous step's weight update, before this step
+                self.backend.apply_reward(float(rewards[i]))
             self.backend.step_begin()
             pending = self.exchange(async_op=True)
             started = True

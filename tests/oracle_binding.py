@@ -336,9 +336,12 @@ class Net:
         c = self._cnet()
         lib().snn_o_apply_reward(C.byref(c), C.c_float(reward))
 
-    def reward_modulation(self):
+    def reward_modulation(self, c0=None, c1=None):
         c = self._cnet()
-        lib().snn_o_reward_modulation(C.byref(c))
+        if c0 is None:
+            lib().snn_o_reward_modulation(C.byref(c))
+        else:
+            lib().snn_o_reward_modulation_cols(C.byref(c), c0, c1)
 
     def spike_trains(self):
         c = self._cnet()

@@ -35,6 +35,9 @@ class OracleShard:
         for k in range(3):
             self._plane(self.rank, 2 + k)[:m] = n["nt_t"][q0:q1, k]
 
+    def apply_reward(self, reward):                               # modulators are replicated on every rank
+        self.net.apply_reward(reward)
+
     def step_end(self):
         n = self.net
         nn = n.n_neurons
@@ -53,6 +56,7 @@ class OracleShard:
             for k in range(3):
                 n["nt_t"][b:e, k] = self._plane(r, 2 + k)[:m]
         n.plasticity(self.q0, self.q1)                            # owner of the column applies STDP
+        n.reward_modulation(self.q0, self.q1)                     # ... and the reward-modulated update
         n.clock += 1
         if n.n_cells:
             n.spike_trains()                                      # replicated on every rank

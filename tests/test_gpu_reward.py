@@ -187,3 +187,27 @@ def test_reward_errors(snn):
     dn.apply_reward(1.0)                           # nothing modulated: a no-op
     dn.run(2)
     dn.close()
+
+
+def test_sharded_stepper_applies_rewards_in_step_order(snn):
+    """parallel.ShardedStepper.run(k, rewards=...) on a shard handle (world size 1, stream-ordered overlap loop):
+    each reward must land after the previous step's weight update and before its own step."""
+    import torch
+    from snn_amd import parallel
+    net = build(lattices=((0, 8, 8), (3, 6, 7)), modulated=(0,), st=((5, 2, 3),), seed=17)
+    steps = 200
+    rewards = rewards_for(steps, 18)
+    dn = to_device(snn, net, shard=(0, 1))
+    dn.set_trace_rows(0, net["traces"])
+    side = torch.cuda.Stream()
+    dn.set_stream(side.cuda_stream)
+    buf = parallel.exchange_tensor(dn, torch.device("cuda", 0))
+    stepper = parallel.ShardedStepper(dn, buf, 0, 1, stream=side)
+    stepper.run(steps // 2, rewards=rewards[:steps // 2])
+    stepper.run(steps - steps // 2, rewards=rewards[steps // 2:])
+    dn.synchronize()
+    net.run(steps, rewards=rewards)
+    check_dense(dn, net)
+    assert dn.dopamine(0) == net["rm_dopamine"][0]
+    parity.assert_state_equal(net, parity.pull_state(dn, net))
+    dn.close()

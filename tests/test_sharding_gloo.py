@@ -33,7 +33,21 @@ def build_net():
     rng = np.random.default_rng(3)
     net["connections"][rng.random(net["connections"].shape) < 0.3] = 0
     net["do_plasticity"] = 1
+    # lattice 1 is reward-modulated (R-STDP traces on its internal edges), lattice 0 keeps plain STDP
+    net["do_plasticity"][1] = 0
+    net["rm_do_modulation"][1] = 1
+    net["rm_tau_c"][1] = 0.05
+    net["rm_tau_d"][1] = 5.0
+    net["rm_a_plus"][1] = 0.002
+    net["rm_a_minus"][1] = 0.0015
     return net
+
+
+def rewards():
+    import oracle_binding as ob
+    r = ob.uniform_array(11, STEPS, -0.02, 0.03)
+    r[::3] = 0.0
+    return r
 
 
 def worker(rank, world, init_file, out_dir):
@@ -48,13 +62,14 @@ def worker(rank, world, init_file, out_dir):
     shard = OracleShard(net, rank, world, stride)
     stepper = parallel.ShardedStepper(shard, shard.buf, rank, world)
     raster = []
-    for _ in range(STEPS):
-        stepper.run(1)
+    rw = rewards()
+    for i in range(STEPS):
+        stepper.run(1, rewards=rw[i:i + 1])
         raster.append(net["is_spiking"].copy())
     q0, q1 = shards[rank]
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), q0=q0, q1=q1, v=net["current_voltage"], w=net["w_value"],
              lft=net["last_firing_time"], weights=net["weights"], raster=np.array(raster), clock=net.clock,
-             t=net["nt_t"], st_lft=net["st_last_firing_time"])
+             t=net["nt_t"], st_lft=net["st_last_firing_time"], traces=net["traces"], dopamine=net["rm_dopamine"])
     dist.barrier()
     dist.destroy_process_group()
 
@@ -66,8 +81,10 @@ def test_two_rank_sharded_run_equals_single_process():
         init_file = os.path.join(d, "rendezvous")
         mp.spawn(worker, args=(world, init_file, d), nprocs=world, join=True)
         ref = build_net()
-        ref.run(STEPS, spike_history=True)
-        assert ref.spike_history.sum() > 20
+        w0 = ref["weights"].copy()
+        ref.run(STEPS, spike_history=True, rewards=rewards())
+        assert ref.spike_history.sum() > 20 and np.abs(ref["traces"]).max() > 0
+        assert not np.array_equal(w0[36:136, 36:136], ref["weights"][36:136, 36:136])      # the modulated block moved
         for r in range(world):
             z = np.load(os.path.join(d, f"rank{r}.npz"))
             q0, q1 = int(z["q0"]), int(z["q1"])
@@ -81,3 +98,5 @@ def test_two_rank_sharded_run_equals_single_process():
             # owned state: local neurons' adaptation variable and the local weight columns
             assert np.array_equal(z["w"][q0:q1].view(np.uint32), ref["w_value"][q0:q1].view(np.uint32))
             assert np.array_equal(z["weights"][:, q0:q1].view(np.uint32), ref["weights"][:, q0:q1].view(np.uint32))
+            assert np.array_equal(z["traces"][:, q0:q1].view(np.uint32), ref["traces"][:, q0:q1].view(np.uint32))
+            assert np.array_equal(z["dopamine"].view(np.uint32), ref["rm_dopamine"].view(np.uint32))
