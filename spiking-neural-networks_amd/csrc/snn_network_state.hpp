@@ -1,0 +1,604 @@
+// Host-side state of a handle: the snn_network struct, device allocations, the attribute registry (the reference's
+// HashMap<String, BufferGPU> of IterateAndSpikeGPU::convert_to_gpu, neuron/iterate_and_spike/mod.rs:3156-3189),
+// attribute transfers and the static per-column counts.  Included by snn_network.hip only (one translation unit).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/snn_amd.h"
+#include "snn_kernels_csr.hpp"
+#include "snn_kernels_inputs.hpp"
+#include "snn_kernels_misc.hpp"
+#include "snn_kernels_resident.hpp"
+#include "snn_kernels_update.hpp"
+#include "snn_layout.hpp"
+
+using namespace snn;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string &msg)
+{
+    g_last_error = msg;
+    return code;
+}
+
+#define HIP_TRY(expr, code)                                                                      \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return fail((code), std::string(#expr) + ": " + hipGetErrorString(e_));              \
+    } while (0)
+
+inline uint32_t round_up(uint32_t x, uint32_t m) { return (x + m - 1) / m * m; }
+
+enum AttrType { T_F32 = 0, T_U32 = 1, T_I32 = 2 };
+enum AttrStore { S_PLAIN = 0, S_PLAIN_K = 1, S_XPLANE = 2, S_XPLANE_K = 3 };
+
+struct Attr {
+    AttrType type;
+    AttrStore store;
+    void *base;        // S_PLAIN / S_PLAIN_K: device array; planes: unused
+    int plane;         // S_XPLANE / S_XPLANE_K
+    uint32_t pad;      // stride between types for S_PLAIN_K
+    int dirties;       // 1: invalidates the static per-column counts
+};
+
+struct LatticeInfo {
+    uint32_t id, rows, cols, first, count, slot;
+    bool spike_train;
+};
+
+} // namespace
+
+struct snn_network {
+    int device = 0;
+    hipStream_t stream = nullptr;          // the stream every launch goes to
+    hipStream_t own_stream = nullptr;      // created with the handle
+    bool external_stream = false;          // snn_set_stream adopted a caller's stream
+    int model = 0, nt_kind = 0, rc_kind = 0, st_kind = 0;
+    bool finalized = false;
+    int electrical = 1, chemical = 0;
+    long long clock = 0;
+
+    std::vector<LatticeInfo> lattices;      // neuron lattices, ascending id after finalize
+    std::vector<LatticeInfo> st_lattices;   // spike-train lattices
+    std::vector<long long> st_clock;        // own clocks of the spike-train lattices
+    std::vector<float> stdp_host;           // [n_lattices][5]
+    std::vector<uint32_t> plast_host;       // [n_lattices]
+    bool any_plasticity = false;
+    // reward modulation (RewardModulatedLattice): per-lattice modulator table + per-edge trace, allocated on first use
+    bool any_modulation = false;
+    std::vector<float> rm_host;            // [n_lattices][RM_STRIDE]
+    std::vector<uint32_t> rm_on_host;
+    float *rm_dev = nullptr;
+    uint32_t *rm_on_dev = nullptr;
+    float *trace = nullptr;                // dense: [n_tot][ld]; CSR: [sell_entries]
+
+    uint32_t nn = 0, nc = 0, n_tot = 0, n_pad = 0, c_pad = 0;
+    uint32_t q0 = 0, q1 = 0, n_loc = 0, ld = 0, n_chunks = 0;
+    XLayout xl{0, 1};
+
+    std::vector<void *> allocs;
+    // sparse form (CSR by local postsynaptic row); the arrays are replaced by every snn_set_graph_csr
+    bool csr = false;
+    uint64_t nnz = 0;
+    // device: SELL-64 rows (slice_ptr / pre / w / row_len) + per-CSR-edge slot, local row and the transpose index
+    uint32_t *csr_ptr = nullptr, *csr_pre = nullptr, *csr_post = nullptr, *csr_t_ptr = nullptr, *csr_t_edge = nullptr;
+    uint32_t *csr_row_len = nullptr, *csr_edge_slot = nullptr;
+    float *csr_w = nullptr;
+    uint64_t sell_entries = 0;
+    std::vector<uint32_t> edge_slot_host;   // CSR edge -> SELL entry (for snn_get_graph_csr)
+    float *W = nullptr;
+    float *xbuf = nullptr;
+    float *part_i = nullptr, *part_t = nullptr;
+    uint32_t *n_in = nullptr, *tcount = nullptr;
+    bool counts_dirty = true;
+    NeuronArrays na{};
+    CellArrays ca{};
+    uint32_t *lattice_slot = nullptr;
+    float *stdp_dev = nullptr;
+    uint32_t *plast_dev = nullptr;
+    uint32_t *spike_list = nullptr, *spike_count = nullptr;
+    long long *st_clock_dev = nullptr;
+    long long run_step_offset = 0;
+    bool run_active = false;        // a (possibly externally driven) run is open: device clocks are ahead of st_clock
+    // fused small-lattice step (k_step_resident): two shadow copies of the exchange buffer + per-tile tickets
+    float *shadow[2] = {nullptr, nullptr};
+    int shadow_cur = 0;
+    bool shadow_valid = false;      // shadow[shadow_cur] == exchange buffer
+    int fused_step = 1;             // 0: always take the two-kernel path (SNN_AMD_FUSED_STEP=0)
+    bool view_dirty = true;         // spike-train gap-junction values must be refreshed before the next inputs
+    bool local_inputs_done = false; // this step's LOCAL chunk partials are already enqueued
+
+    std::map<std::string, Attr> neuron_attrs, cell_attrs;
+
+    // histories
+    int want_vhist = 0, want_raster = 0;
+    // reduced histories: per-lattice average voltage / EEG value per step, per-neuron spike totals
+    int want_avg = 0, want_eeg = 0, want_counts = 0;
+    float eeg_ref = 0.007f, eeg_dist = 0.8f, eeg_cond = 251.0f;     // EEGHistory defaults, neuron/mod.rs:246-255
+    float *summ_avg = nullptr, *summ_eeg = nullptr;                 // [cap][n_lattices]
+    uint32_t *spike_counts = nullptr, *lat_first_dev = nullptr, *lat_count_dev = nullptr;
+    uint64_t hist_steps = 0, hist_cap = 0;
+    std::vector<std::vector<float>> preset_host;   // PresetSpikeTrain firing times per cell
+    float *preset_times_dev = nullptr;
+    uint64_t hist_tick = 0;                // steps seen since the record was (re)started
+    uint32_t hist_every = 1;               // a row is stored when hist_tick % hist_every == 0
+    float *vhist = nullptr, *st_vhist = nullptr;
+    unsigned long long *raster = nullptr;
+
+    // profiling of the synaptic-input kernel
+    int profile = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    std::vector<int> ev_counts;     // 1: the launch closes a pass over the graph, 0: first half of a split pass
+    size_t ev_used = 0;
+    uint64_t prof_launches = 0;
+    double prof_ms = 0.0;
+};
+
+namespace {
+inline bool recording(const snn_network *net)
+{
+    return net->want_vhist || net->want_raster || net->want_avg || net->want_eeg;
+}
+// does the step being computed store its history rows (strided capture: every hist_every-th step)
+inline bool record_now(const snn_network *net)
+{
+    return recording(net) && net->hist_tick % net->hist_every == 0;
+}
+} // namespace
+
+namespace {
+
+int dev_alloc(snn_network *net, void **out, size_t bytes)
+{
+    *out = nullptr;
+    if (bytes == 0) bytes = 256;
+    HIP_TRY(hipMalloc(out, bytes), SNN_ERR_BUFFER_CREATE);
+    net->allocs.push_back(*out);
+    return SNN_OK;
+}
+
+template <typename T>
+int dev_alloc_t(snn_network *net, T **out, size_t count)
+{
+    return dev_alloc(net, reinterpret_cast<void **>(out), count * sizeof(T));
+}
+
+int fill_f32(snn_network *net, float *p, size_t n, float v)
+{
+    if (n == 0) return SNN_OK;
+    const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_fill_f32, dim3(blocks), dim3(256), 0, net->stream, p, n, v);
+    HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+    return SNN_OK;
+}
+int fill_u32(snn_network *net, uint32_t *p, size_t n, uint32_t v)
+{
+    if (n == 0) return SNN_OK;
+    const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_fill_u32, dim3(blocks), dim3(256), 0, net->stream, p, n, v);
+    HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+    return SNN_OK;
+}
+
+const LatticeInfo *find_lattice(const snn_network *net, uint32_t id)
+{
+    for (const auto &l : net->lattices) if (l.id == id) return &l;
+    for (const auto &l : net->st_lattices) if (l.id == id) return &l;
+    return nullptr;
+}
+
+void reg(std::map<std::string, Attr> &m, const char *name, AttrType t, AttrStore s, void *base, int plane,
+         uint32_t pad, int dirties = 0)
+{
+    m[name] = Attr{t, s, base, plane, pad, dirties};
+}
+
+// Allocate one f32 per-neuron array, fill with `def`, register under `name`.
+int neuron_f32(snn_network *net, float **field, const char *name, float def)
+{
+    int rc = dev_alloc_t(net, field, net->n_pad);
+    if (rc) return rc;
+    rc = fill_f32(net, *field, net->n_pad, def);
+    if (rc) return rc;
+    if (name) reg(net->neuron_attrs, name, T_F32, S_PLAIN, *field, 0, 0);
+    return SNN_OK;
+}
+int cell_f32(snn_network *net, float **field, const char *name, float def)
+{
+    int rc = dev_alloc_t(net, field, net->c_pad);
+    if (rc) return rc;
+    rc = fill_f32(net, *field, net->c_pad, def);
+    if (rc) return rc;
+    if (name) reg(net->cell_attrs, name, T_F32, S_PLAIN, *field, 0, 0);
+    return SNN_OK;
+}
+// [3][pad] block with per-type defaults
+int typed_f32(snn_network *net, float **field, uint32_t pad, float d0, float d1, float d2)
+{
+    int rc = dev_alloc_t(net, field, (size_t)K_TYPES * pad);
+    if (rc) return rc;
+    const float d[3] = {d0, d1, d2};
+    for (int k = 0; k < K_TYPES; ++k) {
+        rc = fill_f32(net, *field + (size_t)k * pad, pad, d[k]);
+        if (rc) return rc;
+    }
+    return SNN_OK;
+}
+
+#define TRY(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
+
+int build_state(snn_network *net)
+{
+    NeuronArrays &n = net->na;
+    CellArrays &c = net->ca;
+    const uint32_t np = net->n_pad, cp = net->c_pad;
+    auto &A = net->neuron_attrs;
+    auto &CA = net->cell_attrs;
+
+    // exchanged planes
+    TRY(dev_alloc_t(net, &net->xbuf, (size_t)net->xl.n_shards * NUM_PLANES * net->xl.stride));
+    HIP_TRY(hipMemsetAsync(net->xbuf, 0, (size_t)net->xl.n_shards * NUM_PLANES * net->xl.stride * 4, net->stream),
+            SNN_ERR_BUFFER_WRITE);
+    n.xbuf = net->xbuf;
+    n.xl = net->xl;
+    n.n_pad = np;
+    reg(A, "current_voltage", T_F32, S_XPLANE, nullptr, PLANE_V, 0);
+    reg(A, "is_spiking", T_U32, S_XPLANE, nullptr, PLANE_SPIKE, 0);
+    reg(A, "neurotransmitters$t", T_F32, S_XPLANE_K, nullptr, PLANE_T0, 0);
+
+    // reference defaults: Izhikevich integrate_and_fire/mod.rs:1198-1220, LIF :149-171,
+    // Hodgkin-Huxley hodgkin_huxley/mod.rs:80-98 + ion_channels/mod.rs:23-31, 205-215, 255-264, 299-307
+    const bool izh = net->model == SNN_MODEL_IZHIKEVICH, lif = net->model == SNN_MODEL_LIF;
+    const bool qif = net->model == SNN_MODEL_QUADRATIC_INTEGRATE_AND_FIRE, slif = net->model == SNN_MODEL_SIMPLE_LIF;
+    const bool alif = net->model == SNN_MODEL_ADAPTIVE_LIF, aelif = net->model == SNN_MODEL_ADAPTIVE_EXP_LIF;
+    const bool adp = alif || aelif, lizh = net->model == SNN_MODEL_LEAKY_IZHIKEVICH;
+    const float v0 = (lif || qif || slif || adp) ? -75.0f : -65.0f;
+    {
+        // initial voltage into plane V of every shard slot
+        for (uint32_t s = 0; s < net->xl.n_shards; ++s)
+            TRY(fill_f32(net, net->xbuf + ((size_t)s * NUM_PLANES + PLANE_V) * net->xl.stride, net->xl.stride, v0));
+    }
+    TRY(neuron_f32(net, &n.gap_conductance, "gap_conductance", slif ? 10.0f : 7.0f));
+    TRY(neuron_f32(net, &n.dt, "dt", net->model == SNN_MODEL_HODGKIN_HUXLEY ? 0.01f : 0.1f));
+    TRY(neuron_f32(net, &n.c_m, "c_m", net->model == SNN_MODEL_HODGKIN_HUXLEY ? 1.0f : 100.0f));
+    TRY(neuron_f32(net, &n.v_th, "v_th", (izh || lizh) ? 30.0f : ((lif || qif || slif || adp) ? -55.0f : 0.0f)));
+    TRY(dev_alloc_t(net, &n.last_firing_time, np));
+    HIP_TRY(hipMemsetAsync(n.last_firing_time, 0xFF, (size_t)np * 4, net->stream), SNN_ERR_BUFFER_WRITE);
+    reg(A, "last_firing_time", T_I32, S_PLAIN, n.last_firing_time, 0, 0);
+
+    const bool izh_like = izh || lizh, lif_like = lif || adp;
+    TRY(neuron_f32(net, &n.w_value, (izh_like || adp) ? "w_value" : nullptr, adp ? 0.0f : 30.0f));
+    TRY(neuron_f32(net, &n.a, izh_like ? "a" : nullptr, 0.02f));
+    TRY(neuron_f32(net, &n.b, izh_like ? "b" : nullptr, 0.2f));
+    TRY(neuron_f32(net, &n.c, izh_like ? "c" : nullptr, -55.0f));
+    TRY(neuron_f32(net, &n.d, izh_like ? "d" : nullptr, 8.0f));
+    TRY(neuron_f32(net, &n.tau_m, (izh_like || lif_like || qif) ? "tau_m" : nullptr, izh ? 1.0f : (qif ? 100.0f : 10.0f)));
+
+    TRY(neuron_f32(net, &n.v_reset, (lif_like || qif || slif) ? "v_reset" : nullptr, -75.0f));
+    TRY(neuron_f32(net, &n.refractory_count, (lif_like || qif) ? "refractory_count" : nullptr, 0.0f));
+    TRY(neuron_f32(net, &n.tref, (lif_like || qif) ? "tref" : nullptr, 10.0f));
+    TRY(neuron_f32(net, &n.leak_constant, lif_like ? "leak_constant" : nullptr, -1.0f));
+    TRY(neuron_f32(net, &n.integration_constant, (lif_like || qif) ? "integration_constant" : nullptr, 1.0f));
+    // adaptive models, integrate_and_fire/mod.rs:969-996, 1105-1130
+    TRY(neuron_f32(net, &n.adp_alpha, adp ? "alpha" : nullptr, 6.0f));
+    TRY(neuron_f32(net, &n.adp_beta, adp ? "beta" : nullptr, 10.0f));
+    TRY(neuron_f32(net, &n.slope_factor, aelif ? "slope_factor" : nullptr, 1.0f));
+    // reference buffer names of the two models with a reference GPU implementation
+    // (integrate_and_fire/mod.rs:729-773, 1700-1740)
+    TRY(neuron_f32(net, &n.qif_alpha, qif ? "alpha" : nullptr, 1.0f));
+    TRY(neuron_f32(net, &n.qif_v_c, qif ? "v_c" : nullptr, -60.0f));
+    TRY(neuron_f32(net, &n.slif_g, slif ? "g" : nullptr, -0.1f));
+    TRY(neuron_f32(net, &n.slif_e, slif ? "e" : nullptr, 0.0f));
+    TRY(neuron_f32(net, &n.e_l, (lif_like || lizh) ? "e_l" : nullptr, lizh ? -65.0f : -75.0f));
+    TRY(neuron_f32(net, &n.g_l, lif_like ? "g_l" : nullptr, 10.0f));
+
+    const bool hh = net->model == SNN_MODEL_HODGKIN_HUXLEY;
+    TRY(neuron_f32(net, &n.m_state, hh ? "na_channel$m$state" : nullptr, 0.0f));
+    TRY(neuron_f32(net, &n.h_state, hh ? "na_channel$h$state" : nullptr, 0.0f));
+    TRY(neuron_f32(net, &n.n_state, hh ? "k_channel$n$state" : nullptr, 0.0f));
+    TRY(neuron_f32(net, &n.m_alpha, hh ? "na_channel$m$alpha" : nullptr, 0.0f));
+    TRY(neuron_f32(net, &n.m_beta, hh ? "na_channel$m$beta" : nullptr, 0.0f));
+    TRY(neuron_f32(net, &n.h_alpha, hh ? "na_channel$h$alpha" : nullptr, 0.0f));
+    TRY(neuron_f32(net, &n.h_beta, hh ? "na_channel$h$beta" : nullptr, 0.0f));
+    TRY(neuron_f32(net, &n.n_alpha, hh ? "k_channel$n$alpha" : nullptr, 0.0f));
+    TRY(neuron_f32(net, &n.n_beta, hh ? "k_channel$n$beta" : nullptr, 0.0f));
+    TRY(neuron_f32(net, &n.g_na, hh ? "na_channel$g_na" : nullptr, 120.0f));
+    TRY(neuron_f32(net, &n.e_na, hh ? "na_channel$e_na" : nullptr, 50.0f));
+    TRY(neuron_f32(net, &n.g_k, hh ? "k_channel$g_k" : nullptr, 36.0f));
+    TRY(neuron_f32(net, &n.e_k, hh ? "k_channel$e_k" : nullptr, -77.0f));
+    TRY(neuron_f32(net, &n.g_k_leak, hh ? "k_leak_channel$g_k_leak" : nullptr, 0.3f));
+    TRY(neuron_f32(net, &n.e_k_leak, hh ? "k_leak_channel$e_k_leak" : nullptr, -55.0f));
+    TRY(neuron_f32(net, &n.na_current, hh ? "na_channel$current" : nullptr, 0.0f));
+    TRY(neuron_f32(net, &n.k_current, hh ? "k_channel$current" : nullptr, 0.0f));
+    TRY(neuron_f32(net, &n.k_leak_current, hh ? "k_leak_channel$current" : nullptr, 0.0f));
+    TRY(dev_alloc_t(net, &n.was_increasing, np));
+    TRY(fill_u32(net, n.was_increasing, np, 0));
+    if (hh) reg(A, "was_increasing", T_U32, S_PLAIN, n.was_increasing, 0, 0);
+
+    // neurotransmitters (iterate_and_spike/mod.rs:136-145, 174-182) -- absent by default (flags 0)
+    TRY(typed_f32(net, &n.nt_t_max, np, 1.0f, 1.0f, 1.0f));
+    // clearance_constant of the Approximate kinetics / decay_constant of ExponentialDecay (:336-343) share storage
+    const float nt_c = net->nt_kind == SNN_NT_EXPONENTIAL_DECAY ? 2.0f : 0.01f;
+    TRY(typed_f32(net, &n.nt_clearance, np, nt_c, nt_c, nt_c));
+    TRY(typed_f32(net, &n.nt_v_p, np, 2.0f, 2.0f, 2.0f));
+    TRY(typed_f32(net, &n.nt_k_p, np, 5.0f, 5.0f, 5.0f));
+    TRY(dev_alloc_t(net, &n.nt_flags, (size_t)K_TYPES * np));
+    TRY(fill_u32(net, n.nt_flags, (size_t)K_TYPES * np, 0));
+    reg(A, "neurotransmitters$t_max", T_F32, S_PLAIN_K, n.nt_t_max, 0, np);
+    reg(A, "neurotransmitters$clearance_constant", T_F32, S_PLAIN_K, n.nt_clearance, 0, np);
+    reg(A, "neurotransmitters$decay_constant", T_F32, S_PLAIN_K, n.nt_clearance, 0, np);
+    reg(A, "neurotransmitters$v_p", T_F32, S_PLAIN_K, n.nt_v_p, 0, np);
+    reg(A, "neurotransmitters$k_p", T_F32, S_PLAIN_K, n.nt_k_p, 0, np);
+    reg(A, "neurotransmitters$flags", T_U32, S_PLAIN_K, n.nt_flags, 0, np, 1);
+
+    // receptors (iterate_and_spike/mod.rs:1085-1094, 1115-1125, 1148-1157, 417-425)
+    TRY(typed_f32(net, &n.rc_g, np, 1.0f, 0.6f, 1.2f));
+    TRY(typed_f32(net, &n.rc_e, np, 0.0f, 0.0f, -80.0f));
+    TRY(typed_f32(net, &n.rc_mg, np, 0.0f, 0.3f, 0.0f));
+    TRY(typed_f32(net, &n.rc_r, np, 0.0f, 0.0f, 0.0f));
+    TRY(typed_f32(net, &n.rc_alpha, np, 1.0f, 1.0f, 1.0f));
+    // ExponentialDecayReceptor (:501-533): r_max lives in the alpha array, decay_constant in the beta array
+    const float rc_b = net->rc_kind == SNN_RC_EXPONENTIAL_DECAY ? 2.0f : 1.0f;
+    TRY(typed_f32(net, &n.rc_beta, np, rc_b, rc_b, rc_b));
+    TRY(typed_f32(net, &n.rc_current, np, 0.0f, 0.0f, 0.0f));
+    TRY(dev_alloc_t(net, &n.rc_flags, (size_t)K_TYPES * np));
+    TRY(fill_u32(net, n.rc_flags, (size_t)K_TYPES * np, 0));
+    reg(A, "receptors$flags", T_U32, S_PLAIN_K, n.rc_flags, 0, np);
+    static const char *TN[3] = {"AMPA", "NMDA", "GABA"};
+    for (int k = 0; k < K_TYPES; ++k) {
+        const std::string p = std::string("receptors$") + TN[k];
+        reg(A, (p + "_g").c_str(), T_F32, S_PLAIN, n.rc_g + (size_t)k * np, 0, 0);
+        reg(A, (p + "_e").c_str(), T_F32, S_PLAIN, n.rc_e + (size_t)k * np, 0, 0);
+        reg(A, (p + "_current").c_str(), T_F32, S_PLAIN, n.rc_current + (size_t)k * np, 0, 0);
+        reg(A, (p + "$r$kinetics$r").c_str(), T_F32, S_PLAIN, n.rc_r + (size_t)k * np, 0, 0);
+        reg(A, (p + "$r$kinetics$alpha").c_str(), T_F32, S_PLAIN, n.rc_alpha + (size_t)k * np, 0, 0);
+        reg(A, (p + "$r$kinetics$beta").c_str(), T_F32, S_PLAIN, n.rc_beta + (size_t)k * np, 0, 0);
+        reg(A, (p + "$r$kinetics$r_max").c_str(), T_F32, S_PLAIN, n.rc_alpha + (size_t)k * np, 0, 0);
+        reg(A, (p + "$r$kinetics$decay_constant").c_str(), T_F32, S_PLAIN, n.rc_beta + (size_t)k * np, 0, 0);
+    }
+    reg(A, "receptors$NMDA_mg", T_F32, S_PLAIN, n.rc_mg + (size_t)1 * np, 0, 0);
+
+    // lattice slot per neuron + plasticity tables
+    TRY(dev_alloc_t(net, &net->lattice_slot, np));
+    TRY(fill_u32(net, net->lattice_slot, np, 0));
+    for (const auto &l : net->lattices) TRY(fill_u32(net, net->lattice_slot + l.first, l.count, l.slot));
+    const size_t nl = std::max<size_t>(1, net->lattices.size());
+    {
+        std::vector<uint32_t> lf(nl, 0), lc(nl, 0);
+        for (const auto &l : net->lattices) { lf[l.slot] = l.first; lc[l.slot] = l.count; }
+        TRY(dev_alloc_t(net, &net->lat_first_dev, nl));
+        TRY(dev_alloc_t(net, &net->lat_count_dev, nl));
+        HIP_TRY(hipMemcpy(net->lat_first_dev, lf.data(), nl * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
+        HIP_TRY(hipMemcpy(net->lat_count_dev, lc.data(), nl * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
+        TRY(dev_alloc_t(net, &net->spike_counts, np));
+        TRY(fill_u32(net, net->spike_counts, np, 0));
+    }
+    net->stdp_host.assign(nl * 5, 0.0f);
+    net->plast_host.assign(nl, 0);
+    for (size_t l = 0; l < nl; ++l) {   // plasticity/mod.rs:29-39
+        float *s = &net->stdp_host[l * 5];
+        s[0] = 2.0f; s[1] = 2.0f; s[2] = 4.5f; s[3] = 4.5f; s[4] = 0.1f;
+    }
+    TRY(dev_alloc_t(net, &net->stdp_dev, nl * 5));
+    TRY(dev_alloc_t(net, &net->plast_dev, nl));
+    HIP_TRY(hipMemcpyAsync(net->stdp_dev, net->stdp_host.data(), nl * 5 * 4, hipMemcpyHostToDevice, net->stream),
+            SNN_ERR_BUFFER_WRITE);
+    HIP_TRY(hipMemcpyAsync(net->plast_dev, net->plast_host.data(), nl * 4, hipMemcpyHostToDevice, net->stream),
+            SNN_ERR_BUFFER_WRITE);
+    // RewardModulatedSTDP defaults, plasticity/mod.rs:176-189
+    net->rm_host.assign(nl * RM_STRIDE, 0.0f);
+    net->rm_on_host.assign(nl, 0);
+    for (size_t l = 0; l < nl; ++l) {
+        float *m = &net->rm_host[l * RM_STRIDE];
+        m[0] = 0.0f; m[1] = 20.0f; m[2] = 0.0001f; m[3] = 2.0f; m[4] = 2.0f; m[5] = 4.5f; m[6] = 4.5f; m[7] = 0.1f;
+    }
+    TRY(dev_alloc_t(net, &net->rm_dev, nl * RM_STRIDE));
+    TRY(dev_alloc_t(net, &net->rm_on_dev, nl));
+    HIP_TRY(hipMemcpyAsync(net->rm_dev, net->rm_host.data(), nl * RM_STRIDE * 4, hipMemcpyHostToDevice, net->stream),
+            SNN_ERR_BUFFER_WRITE);
+    HIP_TRY(hipMemcpyAsync(net->rm_on_dev, net->rm_on_host.data(), nl * 4, hipMemcpyHostToDevice, net->stream),
+            SNN_ERR_BUFFER_WRITE);
+    TRY(dev_alloc_t(net, &net->spike_list, np));
+    TRY(dev_alloc_t(net, &net->spike_count, 1));
+
+    // spike-train cells (spike_train/mod.rs:299-313, 998-1013, 50-56)
+    c.c_pad = cp;
+    TRY(cell_f32(net, &c.current_voltage, "current_voltage", 0.0f));
+    TRY(cell_f32(net, &c.v_th, "v_th", 30.0f));
+    TRY(cell_f32(net, &c.v_resting, "v_resting", 0.0f));
+    TRY(cell_f32(net, &c.dt, "dt", 0.1f));
+    TRY(cell_f32(net, &c.k, "neural_refractoriness$k", 10000.0f));
+    TRY(cell_f32(net, &c.chance_of_firing, net->st_kind == SNN_ST_POISSON ? "chance_of_firing" : nullptr, 0.0f));
+    TRY(cell_f32(net, &c.rate, net->st_kind == SNN_ST_RATE ? "rate" : nullptr, 0.0f));
+    TRY(cell_f32(net, &c.step, net->st_kind == SNN_ST_RATE ? "step" : (net->st_kind == SNN_ST_PRESET ? "internal_clock" : nullptr), 0.0f));
+    TRY(dev_alloc_t(net, &c.counter, cp));
+    TRY(fill_u32(net, c.counter, cp, 0));
+    if (net->st_kind == SNN_ST_PRESET) reg(CA, "counter", T_U32, S_PLAIN, c.counter, 0, 0);
+    {
+        // no firing times until snn_set_firing_times: every cell's list is empty
+        uint32_t *ptr = nullptr;
+        TRY(dev_alloc_t(net, &ptr, (size_t)cp + 1));
+        TRY(fill_u32(net, ptr, (size_t)cp + 1, 0));
+        c.preset_ptr = ptr;
+        c.preset_times = nullptr;
+        net->preset_host.assign(net->nc, {});
+    }
+    TRY(cell_f32(net, &c.presyn_value, nullptr, 0.0f));
+    TRY(dev_alloc_t(net, &c.seed, cp));
+    if (cp) {
+        hipLaunchKernelGGL(k_iota_u32, dim3((cp + 255) / 256), dim3(256), 0, net->stream, c.seed, (size_t)cp, 1u);
+        HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+    }
+    if (net->st_kind == SNN_ST_POISSON) reg(CA, "seed", T_U32, S_PLAIN, c.seed, 0, 0);
+    TRY(dev_alloc_t(net, &c.is_spiking, cp));
+    TRY(fill_u32(net, c.is_spiking, cp, 0));
+    reg(CA, "is_spiking", T_U32, S_PLAIN, c.is_spiking, 0, 0);
+    TRY(dev_alloc_t(net, &c.last_firing_time, cp));
+    HIP_TRY(hipMemsetAsync(c.last_firing_time, 0xFF, (size_t)std::max<uint32_t>(cp, 1) * 4, net->stream),
+            SNN_ERR_BUFFER_WRITE);
+    reg(CA, "last_firing_time", T_I32, S_PLAIN, c.last_firing_time, 0, 0);
+    TRY(typed_f32(net, &c.nt_t, cp, 0.0f, 0.0f, 0.0f));
+    TRY(typed_f32(net, &c.nt_t_max, cp, 1.0f, 1.0f, 1.0f));
+    TRY(typed_f32(net, &c.nt_clearance, cp, nt_c, nt_c, nt_c));
+    TRY(typed_f32(net, &c.nt_v_p, cp, 2.0f, 2.0f, 2.0f));
+    TRY(typed_f32(net, &c.nt_k_p, cp, 5.0f, 5.0f, 5.0f));
+    TRY(dev_alloc_t(net, &c.nt_flags, (size_t)K_TYPES * cp));
+    TRY(fill_u32(net, c.nt_flags, (size_t)K_TYPES * cp, 0));
+    reg(CA, "neurotransmitters$t", T_F32, S_PLAIN_K, c.nt_t, 0, cp);
+    reg(CA, "neurotransmitters$t_max", T_F32, S_PLAIN_K, c.nt_t_max, 0, cp);
+    reg(CA, "neurotransmitters$clearance_constant", T_F32, S_PLAIN_K, c.nt_clearance, 0, cp);
+    reg(CA, "neurotransmitters$decay_constant", T_F32, S_PLAIN_K, c.nt_clearance, 0, cp);
+    reg(CA, "neurotransmitters$v_p", T_F32, S_PLAIN_K, c.nt_v_p, 0, cp);
+    reg(CA, "neurotransmitters$k_p", T_F32, S_PLAIN_K, c.nt_k_p, 0, cp);
+    reg(CA, "neurotransmitters$flags", T_U32, S_PLAIN_K, c.nt_flags, 0, cp, 1);
+    TRY(dev_alloc_t(net, &c.lattice_slot, cp));
+    TRY(fill_u32(net, c.lattice_slot, cp, 0));
+    for (const auto &l : net->st_lattices)
+        TRY(fill_u32(net, c.lattice_slot + (l.first - net->nn), l.count, l.slot));
+    net->st_clock.assign(std::max<size_t>(1, net->st_lattices.size()), 0);
+    TRY(dev_alloc_t(net, &net->st_clock_dev, net->st_clock.size()));
+
+    // graph + partials + counts
+    if (net->csr) net->n_chunks = 1;     // the CSR kernel writes the finished two-level sum
+    TRY(dev_alloc_t(net, &net->W, net->csr ? 0 : (size_t)net->n_tot * net->ld));
+    TRY(dev_alloc_t(net, &net->part_i, (size_t)net->n_chunks * net->ld));
+    TRY(dev_alloc_t(net, &net->part_t, (size_t)K_TYPES * net->n_chunks * net->ld));
+    TRY(dev_alloc_t(net, &net->n_in, net->ld));
+    TRY(dev_alloc_t(net, &net->tcount, (size_t)K_TYPES * net->ld));
+    net->counts_dirty = true;
+    HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
+    return SNN_OK;
+}
+
+int end_run(snn_network *net);
+
+// ---- attribute transfer ------------------------------------------------------------------------
+
+// copy `count` 32-bit words between host and plane `plane` for global indices [first, first+count)
+int xplane_copy(snn_network *net, int plane, uint32_t first, uint32_t count, void *host, bool to_device)
+{
+    uint32_t done = 0;
+    while (done < count) {
+        const uint32_t g = first + done;
+        const uint32_t shard = g / net->xl.stride;
+        const uint32_t in_shard = g - shard * net->xl.stride;
+        const uint32_t seg = std::min(count - done, net->xl.stride - in_shard);
+        float *dev = net->xbuf + net->xl.at(g, plane);
+        char *h = static_cast<char *>(host) + (size_t)done * 4;
+        if (to_device) HIP_TRY(hipMemcpy(dev, h, (size_t)seg * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
+        else HIP_TRY(hipMemcpy(h, dev, (size_t)seg * 4, hipMemcpyDeviceToHost), SNN_ERR_BUFFER_READ);
+        done += seg;
+    }
+    return SNN_OK;
+}
+
+int attr_io(snn_network *net, uint32_t id, const char *name, AttrType type, void *host, size_t count, bool set)
+{
+    if (!net || !name || (!host && count)) return fail(SNN_ERR_BAD_ARG, "null argument");
+    if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
+    const LatticeInfo *l = find_lattice(net, id);
+    if (!l) return fail(SNN_ERR_BAD_ARG, "unknown lattice id " + std::to_string(id));
+    auto &table = l->spike_train ? net->cell_attrs : net->neuron_attrs;
+    auto it = table.find(name);
+    if (it == table.end()) return fail(SNN_ERR_BAD_ATTR, std::string("unknown attribute '") + name + "'");
+    const Attr &a = it->second;
+    if (a.type != type) return fail(SNN_ERR_BAD_ATTR, std::string("attribute '") + name + "' has another scalar type");
+    const bool typed = (a.store == S_PLAIN_K || a.store == S_XPLANE_K);
+    const size_t expect = (size_t)l->count * (typed ? K_TYPES : 1);
+    if (count != expect)
+        return fail(SNN_ERR_DIM_MISMATCH, std::string("attribute '") + name + "': expected " +
+                                              std::to_string(expect) + " values, got " + std::to_string(count));
+    if (l->count == 0) return SNN_OK;
+    HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
+    TRY(end_run(net));
+    if (set && l->spike_train) net->view_dirty = true;
+    if (set) net->shadow_valid = false;
+    const uint32_t first = l->spike_train ? l->first - net->nn : l->first;   // index inside its own arrays
+
+    if (!typed) {
+        if (a.store == S_PLAIN) {
+            char *dev = static_cast<char *>(a.base) + (size_t)first * 4;
+            if (set) HIP_TRY(hipMemcpy(dev, host, count * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
+            else HIP_TRY(hipMemcpy(host, dev, count * 4, hipMemcpyDeviceToHost), SNN_ERR_BUFFER_READ);
+        } else {
+            TRY(xplane_copy(net, a.plane, first, l->count, host, set));
+        }
+    } else {
+        // host layout [cell*3 + k] (gpu_lattices/mod.rs:117-127) <-> device type-major planes
+        std::vector<uint32_t> tmp(l->count);
+        uint32_t *h = static_cast<uint32_t *>(host);
+        for (int k = 0; k < K_TYPES; ++k) {
+            if (set) for (uint32_t i = 0; i < l->count; ++i) tmp[i] = h[(size_t)i * K_TYPES + k];
+            if (a.store == S_PLAIN_K) {
+                char *dev = static_cast<char *>(a.base) + ((size_t)k * a.pad + first) * 4;
+                if (set) HIP_TRY(hipMemcpy(dev, tmp.data(), (size_t)l->count * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
+                else HIP_TRY(hipMemcpy(tmp.data(), dev, (size_t)l->count * 4, hipMemcpyDeviceToHost), SNN_ERR_BUFFER_READ);
+            } else {
+                TRY(xplane_copy(net, a.plane + k, first, l->count, tmp.data(), set));
+            }
+            if (!set) for (uint32_t i = 0; i < l->count; ++i) h[(size_t)i * K_TYPES + k] = tmp[i];
+        }
+    }
+    if (set && a.dirties) net->counts_dirty = true;
+    return SNN_OK;
+}
+
+// ---- per-step launches -------------------------------------------------------------------------
+
+SellGraph csr_graph(const snn_network *net)
+{
+    SellGraph g{};
+    g.slice_ptr = net->csr_ptr; g.pre = net->csr_pre; g.w = net->csr_w; g.row_len = net->csr_row_len;
+    g.edge_slot = net->csr_edge_slot; g.edge_post = net->csr_post;
+    g.t_ptr = net->csr_t_ptr; g.t_edge = net->csr_t_edge;
+    g.n_loc = net->n_loc; g.n_slices = (net->n_loc + 63) / 64;
+    return g;
+}
+
+int ensure_counts(snn_network *net)
+{
+    if (!net->counts_dirty || net->n_loc == 0) { net->counts_dirty = false; return SNN_OK; }
+    HIP_TRY(hipMemsetAsync(net->n_in, 0, (size_t)net->ld * 4, net->stream), SNN_ERR_BUFFER_WRITE);
+    HIP_TRY(hipMemsetAsync(net->tcount, 0, (size_t)K_TYPES * net->ld * 4, net->stream), SNN_ERR_BUFFER_WRITE);
+    if (net->csr) {
+        if (net->csr_ptr) {
+            CsrCountArgs a{};
+            a.g = csr_graph(net);
+            a.n_neurons = net->nn; a.ld = net->ld;
+            a.nt_flags = net->na.nt_flags; a.n_pad = net->n_pad;
+            a.st_nt_flags = net->ca.nt_flags; a.c_pad = net->c_pad;
+            a.n_in = net->n_in; a.tcount = net->tcount;
+            hipLaunchKernelGGL(k_csr_count, dim3((net->n_loc + 255) / 256), dim3(256), 0, net->stream, a);
+            HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+        }
+    } else if (net->n_tot) {
+        CountArgs a{};
+        a.W = net->W; a.ld = net->ld; a.n_loc = net->n_loc; a.n_neurons = net->nn; a.n_tot = net->n_tot;
+        a.nt_flags = net->na.nt_flags; a.n_pad = net->n_pad;
+        a.st_nt_flags = net->ca.nt_flags; a.c_pad = net->c_pad;
+        a.n_in = net->n_in; a.tcount = net->tcount;
+        a.rows_per_block = 256;
+        dim3 grid((net->n_loc + 255) / 256, (net->n_tot + 255) / 256);
+        hipLaunchKernelGGL(k_graph_count, grid, dim3(256), 0, net->stream, a);
+        HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+    }
+    net->counts_dirty = false;
+    return SNN_OK;
+}
+
+} // namespace

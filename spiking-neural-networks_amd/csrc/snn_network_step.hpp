@@ -1,0 +1,511 @@
+// Kernel launches and the step loop of run_lattice / run_lattices (neuron/gpu_lattices/mod.rs:791-896, 2284-2583):
+// input pass, neuron update (two kernels or the one-launch small-lattice step), plasticity, reward modulation,
+// histories, HBM placement of the synapse matrix, run bookkeeping and dense graph transfers.
+// Included by snn_network.hip only (one translation unit).
+#pragma once
+#include "snn_network_state.hpp"
+
+namespace {
+
+int launch_spike_trains(snn_network *net, int iterate, long long step_offset, long long view_clock)
+{
+    if (net->nc == 0) return SNN_OK;
+    SpikeTrainArgs a{};
+    a.c = net->ca; a.n_cells = net->nc; a.st_kind = net->st_kind; a.nt_kind = net->nt_kind;
+    a.iterate = iterate; a.lattice_clock = net->st_clock_dev; a.step_offset = step_offset;
+    a.view_clock = view_clock;
+    a.vhist_row = (iterate && record_now(net) && net->want_vhist && net->st_vhist) ? net->st_vhist + (size_t)net->hist_steps * net->c_pad : nullptr;
+    hipLaunchKernelGGL(k_spike_trains, dim3((net->nc + 255) / 256), dim3(256), 0, net->stream, a);
+    HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+    return SNN_OK;
+}
+
+enum InputsPart { INPUTS_ALL = 0, INPUTS_LOCAL = 1, INPUTS_REMOTE = 2 };
+
+// chunks whose presynaptic rows all belong to this shard's own neurons
+void local_chunks(const snn_network *net, uint32_t *begin, uint32_t *count)
+{
+    const uint32_t cb = (net->q0 + CHUNK - 1) / CHUNK, ce = net->q1 / CHUNK;
+    *begin = cb;
+    *count = ce > cb ? ce - cb : 0;
+}
+
+int launch_inputs(snn_network *net, InputsPart part = INPUTS_ALL)
+{
+    if (net->n_loc == 0 || net->n_tot == 0) return SNN_OK;
+    uint32_t lc_begin = 0, lc_count = 0;
+    local_chunks(net, &lc_begin, &lc_count);
+    uint32_t grid_chunks = net->n_chunks;
+    InputsArgs a{};
+    a.chunk_first = 0; a.hole_begin = net->n_chunks; a.hole_count = 0;
+    if (part == INPUTS_LOCAL) { a.chunk_first = lc_begin; grid_chunks = lc_count; }
+    if (part == INPUTS_REMOTE) { a.hole_begin = lc_begin; a.hole_count = lc_count; grid_chunks = net->n_chunks - lc_count; }
+    if (grid_chunks == 0) return SNN_OK;
+    a.W = net->W; a.ld = net->ld; a.n_loc = net->n_loc; a.q0 = net->q0; a.n_neurons = net->nn; a.n_tot = net->n_tot;
+    a.xbuf = net->xbuf; a.xl = net->xl; a.gap_conductance = net->na.gap_conductance;
+    a.st_value = net->ca.presyn_value; a.st_last_firing_time = net->ca.last_firing_time;
+    a.st_nt_t = net->ca.nt_t; a.st_nt_flags = net->ca.nt_flags; a.c_pad = net->c_pad;
+    a.nt_flags = net->na.nt_flags; a.n_pad = net->n_pad;
+    a.part_i = net->part_i; a.part_t = net->part_t; a.n_chunks = net->n_chunks;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (net->profile) {
+        if (net->ev_used == net->ev_pool.size()) {
+            hipEvent_t x, y;
+            HIP_TRY(hipEventCreate(&x), SNN_ERR_QUEUE);
+            HIP_TRY(hipEventCreate(&y), SNN_ERR_QUEUE);
+            net->ev_pool.emplace_back(x, y);
+        }
+        e0 = net->ev_pool[net->ev_used].first;
+        e1 = net->ev_pool[net->ev_used].second;
+        net->ev_counts.resize(net->ev_pool.size(), 1);
+        net->ev_counts[net->ev_used] = (part == INPUTS_LOCAL) ? 0 : 1;   // LOCAL + REMOTE = one pass over W
+        ++net->ev_used;
+        HIP_TRY(hipEventRecord(e0, net->stream), SNN_ERR_QUEUE);
+    }
+    if (net->csr) {
+        if (net->csr_ptr) {
+            CsrInputsArgs ca{};
+            ca.g = csr_graph(net);
+            ca.in = a;
+            dim3 g((((net->n_loc + 63) / 64) * 64 + 255) / 256);
+            if (net->electrical && net->chemical) hipLaunchKernelGGL((k_inputs_csr<true, true>), g, dim3(256), 0, net->stream, ca);
+            else if (net->electrical) hipLaunchKernelGGL((k_inputs_csr<true, false>), g, dim3(256), 0, net->stream, ca);
+            else hipLaunchKernelGGL((k_inputs_csr<false, true>), g, dim3(256), 0, net->stream, ca);
+        } else {   // no graph set: no edges
+            HIP_TRY(hipMemsetAsync(net->part_i, 0, (size_t)net->ld * 4, net->stream), SNN_ERR_BUFFER_WRITE);
+            HIP_TRY(hipMemsetAsync(net->part_t, 0, (size_t)K_TYPES * net->ld * 4, net->stream), SNN_ERR_BUFFER_WRITE);
+        }
+        HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+        if (net->profile) HIP_TRY(hipEventRecord(e1, net->stream), SNN_ERR_QUEUE);
+        return SNN_OK;
+    }
+    // shape of the pass: cache-resident matrices take the latency-oriented one-wave shape; streamed matrices the
+    // 4-columns-per-lane shape, or the 2-column shape while that would leave the chip under-filled
+    const bool resident = (size_t)net->n_tot * net->ld * 4 <= ((size_t)64 << 20);
+    const uint64_t waves4 = (uint64_t)((net->n_loc + 255) / 256) * grid_chunks;
+    const int shape = resident ? 0 : (waves4 < 8192 ? 2 : 1);     // 8192 = 256 CUs x 32 wave slots
+#define SNN_LAUNCH_SHAPE(E, C, SH)                                                                        \
+    hipLaunchKernelGGL((k_inputs_dense<E, C, SH>),                                                       \
+                       dim3((net->n_loc + InputsShape<SH>::TILE - 1) / InputsShape<SH>::TILE, grid_chunks), \
+                       dim3(InputsShape<SH>::THREADS), 0, net->stream, a)
+#define SNN_LAUNCH_INPUTS(E, C)                                                                          \
+    do {                                                                                                 \
+        if (shape == 1) SNN_LAUNCH_SHAPE(E, C, 1);                                                       \
+        else if (shape == 2) SNN_LAUNCH_SHAPE(E, C, 2);                                                  \
+        else SNN_LAUNCH_SHAPE(E, C, 0);                                                                  \
+    } while (0)
+    if (net->electrical && net->chemical) SNN_LAUNCH_INPUTS(true, true);
+    else if (net->electrical) SNN_LAUNCH_INPUTS(true, false);
+    else SNN_LAUNCH_INPUTS(false, true);
+#undef SNN_LAUNCH_INPUTS
+#undef SNN_LAUNCH_SHAPE
+    HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+    if (net->profile) HIP_TRY(hipEventRecord(e1, net->stream), SNN_ERR_QUEUE);
+    return SNN_OK;
+}
+
+int launch_update(snn_network *net)
+{
+    if (net->n_loc == 0) return SNN_OK;
+    UpdateArgs a{};
+    a.n = net->na;
+    a.part_i = net->part_i; a.part_t = net->part_t; a.n_in = net->n_in; a.tcount = net->tcount;
+    a.ld = net->ld; a.n_chunks = net->n_tot ? net->n_chunks : 0; a.q0 = net->q0; a.n_loc = net->n_loc;
+    a.clock = net->clock;
+    a.electrical = net->electrical; a.chemical = net->chemical; a.nt_kind = net->nt_kind; a.rc_kind = net->rc_kind;
+    a.vhist_row = (record_now(net) && net->want_vhist && net->vhist) ? net->vhist + (size_t)net->hist_steps * net->n_pad : nullptr;
+    a.spike_row = (record_now(net) && net->want_raster && net->raster) ? net->raster + (size_t)net->hist_steps * (net->n_pad / 64) : nullptr;
+    a.spike_counts = net->want_counts ? net->spike_counts : nullptr;
+    a.xout = net->xbuf; a.xout2 = nullptr;
+    net->shadow_valid = false;            // the exchange buffer moves on without the shadows
+    dim3 grid((net->ld + 255) / 256);
+    switch (net->model) {
+    case SNN_MODEL_LIF: hipLaunchKernelGGL((k_update<1>), grid, dim3(256), 0, net->stream, a); break;
+    case SNN_MODEL_HODGKIN_HUXLEY: hipLaunchKernelGGL((k_update<2>), grid, dim3(256), 0, net->stream, a); break;
+    case SNN_MODEL_QUADRATIC_INTEGRATE_AND_FIRE: hipLaunchKernelGGL((k_update<3>), grid, dim3(256), 0, net->stream, a); break;
+    case SNN_MODEL_SIMPLE_LIF: hipLaunchKernelGGL((k_update<4>), grid, dim3(256), 0, net->stream, a); break;
+    case SNN_MODEL_ADAPTIVE_LIF: hipLaunchKernelGGL((k_update<5>), grid, dim3(256), 0, net->stream, a); break;
+    case SNN_MODEL_ADAPTIVE_EXP_LIF: hipLaunchKernelGGL((k_update<6>), grid, dim3(256), 0, net->stream, a); break;
+    case SNN_MODEL_LEAKY_IZHIKEVICH: hipLaunchKernelGGL((k_update<7>), grid, dim3(256), 0, net->stream, a); break;
+    default: hipLaunchKernelGGL((k_update<0>), grid, dim3(256), 0, net->stream, a); break;
+    }
+    HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+    return SNN_OK;
+}
+
+int launch_plasticity(snn_network *net)
+{
+    if (!net->any_plasticity || net->nn == 0) return SNN_OK;
+    StdpArgs a{};
+    a.W = net->W; a.ld = net->ld; a.n_loc = net->n_loc; a.q0 = net->q0; a.n_neurons = net->nn; a.n_tot = net->n_tot;
+    a.xbuf = net->xbuf; a.xl = net->xl;
+    a.last_firing_time = net->na.last_firing_time; a.st_last_firing_time = net->ca.last_firing_time;
+    a.lattice_slot = net->lattice_slot; a.stdp = net->stdp_dev; a.do_plasticity = net->plast_dev;
+    a.spike_list = net->spike_list; a.spike_count = net->spike_count;
+    HIP_TRY(hipMemsetAsync(net->spike_count, 0, 4, net->stream), SNN_ERR_BUFFER_WRITE);
+    hipLaunchKernelGGL(k_spike_compact, dim3((net->nn + 255) / 256), dim3(256), 0, net->stream, a);
+    HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+    if (net->n_loc == 0) return SNN_OK;
+    if (net->csr) {
+        if (!net->csr_ptr) return SNN_OK;
+        CsrStdpArgs ca{};
+        ca.g = csr_graph(net);
+        ca.s = a;
+        hipLaunchKernelGGL(k_stdp_csr_in, dim3(1024), dim3(64), 0, net->stream, ca);
+        HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+        hipLaunchKernelGGL(k_stdp_csr_out, dim3(1024), dim3(64), 0, net->stream, ca);
+        HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+        return SNN_OK;
+    }
+    const unsigned sy = 64;   // spiking neurons processed concurrently; the rest grid-strides
+    hipLaunchKernelGGL(k_stdp_columns, dim3((net->n_tot + 255) / 256, sy), dim3(256), 0, net->stream, a);
+    HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+    hipLaunchKernelGGL(k_stdp_rows, dim3((net->n_loc + 255) / 256, sy), dim3(256), 0, net->stream, a);
+    HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+    return SNN_OK;
+}
+
+// RewardModulatedLattice::update_weights_from_neurons for every modulated lattice (deferred form)
+int launch_reward_modulation(snn_network *net)
+{
+    if (!net->any_modulation || net->nn == 0 || net->n_loc == 0 || !net->trace) return SNN_OK;
+    if (net->csr) {
+        if (!net->csr_ptr) return SNN_OK;
+        CsrRewardArgs a{};
+        a.g = csr_graph(net); a.c = net->trace; a.q0 = net->q0; a.n_neurons = net->nn;
+        a.last_firing_time = net->na.last_firing_time; a.lattice_slot = net->lattice_slot;
+        a.rm = net->rm_dev; a.rm_on = net->rm_on_dev;
+        hipLaunchKernelGGL(k_rstdp_csr, dim3((net->n_loc + 255) / 256), dim3(256), 0, net->stream, a);
+        HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+        return SNN_OK;
+    }
+    RewardArgs a{};
+    a.W = net->W; a.C = net->trace; a.ld = net->ld; a.n_loc = net->n_loc; a.q0 = net->q0; a.n_neurons = net->nn;
+    a.last_firing_time = net->na.last_firing_time; a.lattice_slot = net->lattice_slot;
+    a.rm = net->rm_dev; a.rm_on = net->rm_on_dev;
+    const unsigned gx = (net->n_loc + 1023) / 1024;
+    const unsigned gy = std::max(1u, std::min<unsigned>(net->nn, 8192u / gx));     // ~8192 workgroups in flight
+    hipLaunchKernelGGL(k_rstdp_dense, dim3(gx, gy), dim3(256), 0, net->stream, a);
+    HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+    return SNN_OK;
+}
+
+// The synapse matrix is the one allocation whose HBM placement matters: on MI355X two 17 GB allocations of one
+// process can differ by 5-6 % in the sustained rate of the input pass (stable per allocation, different from
+// process to process).  For matrices >= 1 GiB a second candidate is allocated while the first is held, the real
+// kernel is timed on both (one warm + one timed pass each, once per handle) and the faster allocation is kept.
+int time_input_pass(snn_network *net, float *ms)
+{
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return fail(SNN_ERR_QUEUE, "hipEventCreate failed");
+    int rc = launch_inputs(net);
+    if (rc == SNN_OK && hipEventRecord(e0, net->stream) != hipSuccess) rc = fail(SNN_ERR_QUEUE, "hipEventRecord failed");
+    if (rc == SNN_OK) rc = launch_inputs(net);
+    if (rc == SNN_OK && (hipEventRecord(e1, net->stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
+                         hipEventElapsedTime(ms, e0, e1) != hipSuccess))
+        rc = fail(SNN_ERR_WAIT, "placement timing failed");
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return rc;
+}
+
+int choose_matrix_placement(snn_network *net)
+{
+    const size_t count = net->csr ? 0 : (size_t)net->n_tot * net->ld;
+    const size_t bytes = count * sizeof(float);
+    if (bytes >= ((size_t)1 << 30) && net->n_loc) {
+        const int prof = net->profile;
+        net->profile = 0;
+        float best_ms = 0.0f;
+        int rc = time_input_pass(net, &best_ms);
+        // up to four more candidates; every loser stays allocated until the end so that each new candidate is
+        // forced into a different HBM region (a freed block would simply be handed out again)
+        std::vector<void *> losers;
+        for (int cand = 0; cand < 4 && rc == SNN_OK; ++cand) {
+            size_t free_b = 0, total_b = 0;
+            void *b = nullptr;
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + (bytes >> 2) ||
+                hipMalloc(&b, bytes) != hipSuccess)
+                break;
+            float *a = net->W;
+            float ms_b = 0.0f;
+            net->W = static_cast<float *>(b);
+            rc = time_input_pass(net, &ms_b);
+            if (getenv("SNN_DEBUG_PLACEMENT"))
+                fprintf(stderr, "[snn] matrix placement: held %p %.3f ms, candidate %p %.3f ms\n", (void *)a, best_ms, b, ms_b);
+            if (rc == SNN_OK && ms_b < best_ms * 0.99f) {       // the candidate wins
+                for (auto &p : net->allocs) if (p == a) p = b;
+                losers.push_back(a);
+                best_ms = ms_b;
+            } else {
+                net->W = a;
+                losers.push_back(b);
+            }
+        }
+        for (void *p : losers) (void)hipFree(p);
+        net->profile = prof;
+        if (rc != SNN_OK) return rc;
+    }
+    if (count) {   // no edges until a graph is set: every entry is the absent-edge sentinel
+        hipLaunchKernelGGL(k_fill_u32, dim3(4096), dim3(256), 0, net->stream,
+                           reinterpret_cast<uint32_t *>(net->W), count, 0x7FC00000u);
+        HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+        HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
+    }
+    return SNN_OK;
+}
+
+// Small dense lattices on an unsharded handle: inputs + update in ONE launch (snn_kernels_resident.hpp).
+bool fused_step_applies(const snn_network *net)
+{
+    return net->fused_step && !net->csr && net->xl.n_shards == 1 && net->n_loc && net->n_tot && !net->local_inputs_done &&
+           net->n_chunks <= RESIDENT_MAX_CHUNKS && (size_t)net->n_tot * net->ld * 4 <= ((size_t)64 << 20);
+}
+
+int launch_step_resident(snn_network *net)
+{
+    const size_t xelems = (size_t)net->xl.n_shards * NUM_PLANES * net->xl.stride;
+    if (!net->shadow[0]) {
+        TRY(dev_alloc_t(net, &net->shadow[0], xelems));
+        TRY(dev_alloc_t(net, &net->shadow[1], xelems));
+        net->shadow_valid = false;
+    }
+    if (!net->shadow_valid) {
+        // both shadows: entries the step never rewrites (absent transmitter types, padding) must agree everywhere
+        for (int i = 0; i < 2; ++i)
+            HIP_TRY(hipMemcpyAsync(net->shadow[i], net->xbuf, xelems * 4, hipMemcpyDeviceToDevice, net->stream),
+                    SNN_ERR_BUFFER_WRITE);
+        net->shadow_valid = true;
+    }
+    float *cur = net->shadow[net->shadow_cur], *next = net->shadow[net->shadow_cur ^ 1];
+    ResidentArgs r{};
+    InputsArgs &a = r.in;
+    a.chunk_first = 0; a.hole_begin = net->n_chunks; a.hole_count = 0;
+    a.W = net->W; a.ld = net->ld; a.n_loc = net->n_loc; a.q0 = net->q0; a.n_neurons = net->nn; a.n_tot = net->n_tot;
+    a.xbuf = cur; a.xl = net->xl; a.gap_conductance = net->na.gap_conductance;
+    a.st_value = net->ca.presyn_value; a.st_last_firing_time = net->ca.last_firing_time;
+    a.st_nt_t = net->ca.nt_t; a.st_nt_flags = net->ca.nt_flags; a.c_pad = net->c_pad;
+    a.nt_flags = net->na.nt_flags; a.n_pad = net->n_pad;
+    a.part_i = net->part_i; a.part_t = net->part_t; a.n_chunks = net->n_chunks;
+    UpdateArgs &u = r.up;
+    u.n = net->na;
+    u.n.xbuf = cur;
+    u.part_i = net->part_i; u.part_t = net->part_t; u.n_in = net->n_in; u.tcount = net->tcount;
+    u.ld = net->ld; u.n_chunks = net->n_chunks; u.q0 = net->q0; u.n_loc = net->n_loc;
+    u.clock = net->clock;
+    u.electrical = net->electrical; u.chemical = net->chemical; u.nt_kind = net->nt_kind; u.rc_kind = net->rc_kind;
+    u.vhist_row = (record_now(net) && net->want_vhist && net->vhist) ? net->vhist + (size_t)net->hist_steps * net->n_pad : nullptr;
+    u.spike_row = (record_now(net) && net->want_raster && net->raster) ? net->raster + (size_t)net->hist_steps * (net->n_pad / 64) : nullptr;
+    u.spike_counts = net->want_counts ? net->spike_counts : nullptr;
+    u.xout = net->xbuf; u.xout2 = next;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (net->profile) {
+        if (net->ev_used == net->ev_pool.size()) {
+            hipEvent_t x, y;
+            HIP_TRY(hipEventCreate(&x), SNN_ERR_QUEUE);
+            HIP_TRY(hipEventCreate(&y), SNN_ERR_QUEUE);
+            net->ev_pool.emplace_back(x, y);
+        }
+        e0 = net->ev_pool[net->ev_used].first;
+        e1 = net->ev_pool[net->ev_used].second;
+        net->ev_counts.resize(net->ev_pool.size(), 1);
+        net->ev_counts[net->ev_used] = 1;
+        ++net->ev_used;
+        HIP_TRY(hipEventRecord(e0, net->stream), SNN_ERR_QUEUE);
+    }
+    const dim3 grid((net->n_loc + 63) / 64), block(64 * net->n_chunks);
+#define SNN_RESIDENT(M)                                                                                              \
+    do {                                                                                                             \
+        if (net->electrical && net->chemical) hipLaunchKernelGGL((k_step_resident<M, true, true>), grid, block, 0, net->stream, r);  \
+        else if (net->electrical) hipLaunchKernelGGL((k_step_resident<M, true, false>), grid, block, 0, net->stream, r);             \
+        else hipLaunchKernelGGL((k_step_resident<M, false, true>), grid, block, 0, net->stream, r);                                  \
+    } while (0)
+    switch (net->model) {
+    case 1: SNN_RESIDENT(1); break;
+    case 2: SNN_RESIDENT(2); break;
+    case 3: SNN_RESIDENT(3); break;
+    case 4: SNN_RESIDENT(4); break;
+    case 5: SNN_RESIDENT(5); break;
+    case 6: SNN_RESIDENT(6); break;
+    case 7: SNN_RESIDENT(7); break;
+    default: SNN_RESIDENT(0); break;
+    }
+#undef SNN_RESIDENT
+    HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+    if (net->profile) HIP_TRY(hipEventRecord(e1, net->stream), SNN_ERR_QUEUE);
+    net->shadow_cur ^= 1;
+    return SNN_OK;
+}
+
+// first half of a step: inputs from S(t) and the local neurons' update
+int step_begin(snn_network *net)
+{
+    if (fused_step_applies(net)) return launch_step_resident(net);
+    TRY(launch_inputs(net, net->local_inputs_done ? INPUTS_REMOTE : INPUTS_ALL));
+    net->local_inputs_done = false;
+    TRY(launch_update(net));
+    return SNN_OK;
+}
+
+// second half: remote last_firing_time, plasticity, histories, clock, spike trains (steps 3-6)
+int step_end(snn_network *net)
+{
+    if (net->xl.n_shards > 1 && net->nn) {
+        hipLaunchKernelGGL(k_stamp_remote, dim3((net->nn + 255) / 256), dim3(256), 0, net->stream,
+                           net->xbuf, net->xl, net->na.last_firing_time, net->nn, net->q0, net->n_loc, net->clock);
+        HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+    }
+    TRY(launch_plasticity(net));
+    TRY(launch_reward_modulation(net));
+    if ((net->want_avg || net->want_eeg) && record_now(net) && !net->lattices.empty()) {
+        // after the exchange, so that a sharded handle reduces over every lattice's full population
+        const size_t nl = net->lattices.size();
+        SummaryArgs sa{};
+        sa.xbuf = net->xbuf; sa.xl = net->xl; sa.first = net->lat_first_dev; sa.count = net->lat_count_dev;
+        sa.avg_row = net->want_avg ? net->summ_avg + (size_t)net->hist_steps * nl : nullptr;
+        sa.eeg_row = net->want_eeg ? net->summ_eeg + (size_t)net->hist_steps * nl : nullptr;
+        sa.reference_voltage = net->eeg_ref; sa.distance = net->eeg_dist; sa.conductivity = net->eeg_cond;
+        hipLaunchKernelGGL(k_lattice_summary, dim3((unsigned)nl), dim3(256), 0, net->stream, sa);
+        HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+    }
+    net->clock += 1;
+    TRY(launch_spike_trains(net, 1, net->run_step_offset, net->clock));
+    net->run_step_offset += 1;
+    if (record_now(net)) net->hist_steps += 1;
+    if (recording(net)) net->hist_tick += 1;
+    return SNN_OK;
+}
+
+int grow_history(snn_network *net, uint64_t extra)
+{
+    if (!recording(net)) return SNN_OK;
+    const uint64_t need = net->hist_steps + (extra + net->hist_every - 1) / net->hist_every + 1;
+    if (need <= net->hist_cap && (!net->want_vhist || net->vhist) && (!net->want_raster || net->raster) &&
+        (!net->want_avg || net->summ_avg) && (!net->want_eeg || net->summ_eeg))
+        return SNN_OK;
+    const uint64_t cap = std::max<uint64_t>(need, net->hist_cap + net->hist_cap / 2);   // geometric: O(T) copies overall
+    auto regrow = [&](void **buf, size_t row_bytes, bool wanted) -> int {
+        if (!wanted || row_bytes == 0) return SNN_OK;
+        void *nb = nullptr;
+        HIP_TRY(hipMalloc(&nb, std::max<size_t>(256, cap * row_bytes)), SNN_ERR_BUFFER_CREATE);
+        if (*buf && net->hist_steps)
+            HIP_TRY(hipMemcpyAsync(nb, *buf, net->hist_steps * row_bytes, hipMemcpyDeviceToDevice, net->stream),
+                    SNN_ERR_BUFFER_WRITE);
+        HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
+        if (*buf) (void)hipFree(*buf);
+        *buf = nb;
+        return SNN_OK;
+    };
+    TRY(regrow(reinterpret_cast<void **>(&net->vhist), (size_t)net->n_pad * 4, net->want_vhist));
+    TRY(regrow(reinterpret_cast<void **>(&net->st_vhist), (size_t)net->c_pad * 4, net->want_vhist));
+    TRY(regrow(reinterpret_cast<void **>(&net->raster), (size_t)(net->n_pad / 64) * 8, net->want_raster));
+    TRY(regrow(reinterpret_cast<void **>(&net->summ_avg), net->lattices.size() * 4, net->want_avg));
+    TRY(regrow(reinterpret_cast<void **>(&net->summ_eeg), net->lattices.size() * 4, net->want_eeg));
+    net->hist_cap = cap;
+    return SNN_OK;
+}
+
+// Opens a run (snn_run, or a sequence of externally driven steps): static counts, history capacity, the
+// spike-train lattices' clocks on the device and -- only when cell state or the clock changed behind the
+// stepper's back -- the spike-train gap-junction values for the current clock.
+int begin_run(snn_network *net, uint64_t iterations)
+{
+    TRY(ensure_counts(net));
+    TRY(grow_history(net, iterations));
+    if (net->run_active) return SNN_OK;
+    if (net->nc) {
+        // pageable source: the copy is staged before the call returns, so the host vector may change afterwards
+        HIP_TRY(hipMemcpyAsync(net->st_clock_dev, net->st_clock.data(), net->st_clock.size() * sizeof(long long),
+                               hipMemcpyHostToDevice, net->stream), SNN_ERR_BUFFER_WRITE);
+        if (net->view_dirty) TRY(launch_spike_trains(net, 0, 0, net->clock));
+    }
+    net->view_dirty = false;
+    net->run_step_offset = 0;
+    net->run_active = true;
+    return SNN_OK;
+}
+
+// Closes the open run: waits for the stream and folds the steps done into the host-side lattice clocks.
+int end_run(snn_network *net)
+{
+    HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
+    if (net->run_active) {
+        for (auto &c : net->st_clock) c += net->run_step_offset;
+        net->run_step_offset = 0;
+        net->run_active = false;
+    }
+    return SNN_OK;
+}
+
+int collect_profile(snn_network *net)
+{
+    HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
+    for (size_t i = 0; i < net->ev_used; ++i) {
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, net->ev_pool[i].first, net->ev_pool[i].second), SNN_ERR_WAIT);
+        net->prof_ms += ms;
+        net->prof_launches += (i < net->ev_counts.size()) ? net->ev_counts[i] : 1;
+    }
+    net->ev_used = 0;
+    return SNN_OK;
+}
+
+int graph_rows_io(snn_network *net, uint32_t pre_begin, uint32_t pre_count, float *weights, uint32_t *conns,
+                  size_t host_ld, bool set)
+{
+    if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
+    if (net->csr) return fail(SNN_ERR_BAD_STATE, "handle holds a CSR graph: use snn_set_graph_csr / snn_get_graph_csr");
+    if ((uint64_t)pre_begin + pre_count > net->n_tot) return fail(SNN_ERR_DIM_MISMATCH, "row range exceeds n_tot");
+    if (pre_count == 0 || net->nn == 0) return SNN_OK;
+    if (!weights || !conns) return fail(SNN_ERR_BAD_ARG, "null graph pointer");
+    HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
+    TRY(end_run(net));
+    // staged through a bounded device buffer: <= 64 MiB of host rows per hop
+    // <= 64 MiB of host rows per hop and <= 32768 rows (grid.y of the import / export kernels)
+    const uint32_t hop = (uint32_t)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(pre_count, 32768),
+                                                                        (64u << 20) / (host_ld * 4)));
+    float *dw = nullptr;
+    uint32_t *dc = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dw), (size_t)hop * host_ld * 4), SNN_ERR_BUFFER_CREATE);
+    if (hipMalloc(reinterpret_cast<void **>(&dc), (size_t)hop * host_ld * 4) != hipSuccess) {
+        (void)hipFree(dw);
+        return fail(SNN_ERR_BUFFER_CREATE, "staging allocation failed");
+    }
+    int rc = SNN_OK;
+    for (uint32_t r = 0; r < pre_count && rc == SNN_OK; r += hop) {
+        const uint32_t rows = std::min(hop, pre_count - r);
+        const size_t bytes = (size_t)rows * host_ld * 4;
+        if (set) {
+            if (hipMemcpyAsync(dw, weights + (size_t)r * host_ld, bytes, hipMemcpyHostToDevice, net->stream) != hipSuccess ||
+                hipMemcpyAsync(dc, conns + (size_t)r * host_ld, bytes, hipMemcpyHostToDevice, net->stream) != hipSuccess) {
+                rc = fail(SNN_ERR_BUFFER_WRITE, "graph upload failed");
+                break;
+            }
+            hipLaunchKernelGGL(k_graph_import, dim3((net->ld + 255) / 256, rows), dim3(256), 0, net->stream,
+                               net->W, net->ld, net->n_loc, net->q0, pre_begin + r, rows, dw, dc, host_ld);
+        } else {
+            // columns outside the shard are left untouched in the caller's buffers
+            if (hipMemcpyAsync(dw, weights + (size_t)r * host_ld, bytes, hipMemcpyHostToDevice, net->stream) != hipSuccess ||
+                hipMemcpyAsync(dc, conns + (size_t)r * host_ld, bytes, hipMemcpyHostToDevice, net->stream) != hipSuccess) {
+                rc = fail(SNN_ERR_BUFFER_WRITE, "graph staging failed");
+                break;
+            }
+            if (net->n_loc)
+                hipLaunchKernelGGL(k_graph_export, dim3((net->n_loc + 255) / 256, rows), dim3(256), 0, net->stream,
+                                   net->W, net->ld, net->n_loc, net->q0, pre_begin + r, rows, dw, dc, host_ld);
+            if (hipMemcpyAsync(weights + (size_t)r * host_ld, dw, bytes, hipMemcpyDeviceToHost, net->stream) != hipSuccess ||
+                hipMemcpyAsync(conns + (size_t)r * host_ld, dc, bytes, hipMemcpyDeviceToHost, net->stream) != hipSuccess) {
+                rc = fail(SNN_ERR_BUFFER_READ, "graph download failed");
+                break;
+            }
+        }
+        if (hipGetLastError() != hipSuccess) { rc = fail(SNN_ERR_QUEUE, "graph kernel launch failed"); break; }
+        if (hipStreamSynchronize(net->stream) != hipSuccess) { rc = fail(SNN_ERR_WAIT, "graph transfer wait failed"); break; }
+    }
+    (void)hipFree(dw);
+    (void)hipFree(dc);
+    if (set) net->counts_dirty = true;
+    return rc;
+}
+
+} // namespace
