@@ -107,7 +107,8 @@ def build_config(args, snn_amd, synthetic, np, rank, world, local_rank):
             dn.set_reward_modulator(0, tau_c=0.05, tau_d=5.0, a_plus=0.002, a_minus=0.0015)
             dn.apply_reward(0.01)
             text = "reward-modulated (R-STDP, trace per synapse) " + text
-        return dn, n, text, "k_inputs_dense<true,false>"
+        # 32x32 takes the one-launch small-lattice step (inputs + update in k_step_resident)
+        return dn, n, text, ("k_step_resident<0,true,false>" if cfg == "c1" else "k_inputs_dense<true,false>")
     if cfg == "c3":
         rows = cols = 128
         n = rows * cols
