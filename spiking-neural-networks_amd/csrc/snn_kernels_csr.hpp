@@ -17,6 +17,7 @@
 #pragma once
 #include "snn_kernels_inputs.hpp"
 #include "snn_kernels_misc.hpp"
+#include "snn_kernels_reward.hpp"
 
 namespace snn {
 
@@ -224,6 +225,7 @@ struct CsrRewardArgs {
     const uint32_t *lattice_slot;
     const float *rm;
     const uint32_t *rm_on;
+    int dop;
 };
 
 __global__ __launch_bounds__(256) void k_rstdp_csr(const CsrRewardArgs a)
@@ -242,7 +244,7 @@ __global__ __launch_bounds__(256) void k_rstdp_csr(const CsrRewardArgs a)
         const uint32_t p = a.g.pre[e];
         if (p >= a.n_neurons || a.lattice_slot[p] != sq) continue;
         float w = a.g.w[e], c = a.c[e];
-        rstdp_edge(w, c, a.last_firing_time[p], tq, m);
+        rstdp_edge(w, c, a.last_firing_time[p], tq, m, a.dop);
         a.g.w[e] = w;
         a.c[e] = c;
     }

@@ -219,84 +219,6 @@ __global__ void k_stamp_remote(const float *xbuf, XLayout xl, int32_t *last_firi
     if (reinterpret_cast<const uint32_t *>(xbuf)[xl.at(q, PLANE_SPIKE)]) last_firing_time[q] = (int32_t)clock;
 }
 
-// ---- reward modulation ------------------------------------------------------------------------------
-// RewardModulatedLattice (neuron/mod.rs:2719-3417) with RewardModulatedSTDP + TraceRSTDP (plasticity/mod.rs:126-242).
-// Per lattice: RM_STRIDE floats {dopamine, tau_d, tau_c, a_plus, a_minus, tau_plus, tau_minus, dt, exp(-dt/tau_c)}.
-constexpr int RM_STRIDE = 9;
-
-// RewardModulatedSTDP::update (plasticity/mod.rs:199-201) on every modulated lattice; reward < 0 or > 0 alike.
-// `refresh_only`: recompute the cached trace decay after the parameters changed.
-__global__ void k_modulator_update(float *rm, const uint32_t *rm_on, uint32_t n_lattices, float reward, int refresh_only)
-{
-    const uint32_t l = blockIdx.x * blockDim.x + threadIdx.x;
-    if (l >= n_lattices) return;
-    float *m = rm + (size_t)l * RM_STRIDE;
-    m[8] = expf_portable(-m[7] / m[2]);
-    if (refresh_only || !rm_on[l]) return;
-    m[0] = m[0] * expf_portable(-m[7] / m[1]) + m[1] * reward;
-}
-
-// The two update_weight visits every internal edge of a modulated lattice receives per step (do_update is always
-// true, plasticity/mod.rs:239-241), deferred form: both visits see the same delta
-//   dw = 0 + delta; w += c * dopamine; dw += delta; c = c * exp(-dt / tau_c) + tau_c * dw; w += c * dopamine
-__device__ __forceinline__ void rstdp_edge(float &w, float &c, int32_t tp, int32_t tq, const float *m)
-{
-    const float delta_w = stdp_delta(tp, tq, m[3], m[4], m[5], m[6], m[7]);
-    const float dopamine = m[0];
-    float dw = 0.0f;
-    dw += delta_w;
-    w += c * dopamine;
-    dw += delta_w;
-    c = c * m[8] + m[2] * dw;
-    w += c * dopamine;
-}
-
-struct RewardArgs {
-    float *W, *C;                          // weights and TraceRSTDP::c, both [n_tot rows][ld]
-    uint32_t ld, n_loc, q0, n_neurons;
-    const int32_t *last_firing_time;
-    const uint32_t *lattice_slot;
-    const float *rm;
-    const uint32_t *rm_on;
-};
-
-// One streaming read-modify-write pass over the neuron rows of W and C: 16 B per synapse.
-// Thread = 4 adjacent columns (dwordx4), rows grid-strided over blockIdx.y; the presynaptic side (row) is
-// wave-uniform, the postsynaptic side lives in registers.
-__global__ __launch_bounds__(256) void k_rstdp_dense(const RewardArgs a)
-{
-    typedef float v4f __attribute__((ext_vector_type(4)));
-    const uint32_t c0 = (blockIdx.x * 256 + threadIdx.x) * 4;
-    if (c0 >= a.n_loc) return;
-    int32_t tq[4];
-    uint32_t sq[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const uint32_t q = a.q0 + min(c0 + j, a.n_loc - 1);
-        tq[j] = a.last_firing_time[q];
-        sq[j] = (c0 + j < a.n_loc) ? a.lattice_slot[q] : 0xFFFFFFFFu;
-    }
-    for (uint32_t p = blockIdx.y; p < a.n_neurons; p += gridDim.y) {
-        const uint32_t sp = a.lattice_slot[p];
-        if (!a.rm_on[sp]) continue;
-        if (sq[0] != sp && sq[1] != sp && sq[2] != sp && sq[3] != sp) continue;
-        const float *m = a.rm + (size_t)sp * RM_STRIDE;
-        const int32_t tp = a.last_firing_time[p];
-        v4f *wp = reinterpret_cast<v4f *>(a.W + (size_t)p * a.ld + c0);
-        v4f *cp = reinterpret_cast<v4f *>(a.C + (size_t)p * a.ld + c0);
-        v4f w = *wp, c = *cp;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (sq[j] != sp || w[j] != w[j]) continue;      // other lattice / padding / absent edge (NaN)
-            float wj = w[j], cj = c[j];
-            rstdp_edge(wj, cj, tp, tq[j], m);
-            w[j] = wj; c[j] = cj;
-        }
-        *wp = w;
-        *cp = c;
-    }
-}
-
 // ---- reduced per-lattice histories ---------------------------------------------------------------
 // AverageVoltageHistory (neuron/mod.rs:305-322) and EEGHistory (:233-284) on the device: one float per lattice
 // and step instead of the T x N voltage history.  One workgroup per lattice; every thread sums one 256-neuron

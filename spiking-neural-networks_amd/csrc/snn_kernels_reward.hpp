@@ -1,0 +1,278 @@
+// Reward modulation: the dopamine ODE, the per-synapse R-STDP update as a standalone streaming pass and fused into
+// the synaptic-input pass.
+#pragma once
+#include "snn_kernels_inputs.hpp"
+
+namespace snn {
+
+// ---- reward modulation ------------------------------------------------------------------------------
+// RewardModulatedLattice (neuron/mod.rs:2719-3417) with RewardModulatedSTDP + TraceRSTDP (plasticity/mod.rs:126-242).
+// Per lattice: RM_STRIDE floats {dopamine, tau_d, tau_c, a_plus, a_minus, tau_plus, tau_minus, dt, exp(-dt/tau_c),
+// dopamine before the latest reward}.  The last slot serves the deferred weight update (k_inputs_rstdp): the update
+// of step t is applied at the start of step t+1 and must use the dopamine of step t even if the reward of step t+1
+// has been applied in between.
+constexpr int RM_STRIDE = 10;
+constexpr int RM_DOPAMINE = 0, RM_DOPAMINE_BEFORE = 9;
+
+// RewardModulatedSTDP::update (plasticity/mod.rs:199-201) on every modulated lattice; reward < 0 or > 0 alike.
+// `refresh_only`: recompute the cached trace decay after the parameters changed.
+__global__ void k_modulator_update(float *rm, const uint32_t *rm_on, uint32_t n_lattices, float reward, int refresh_only)
+{
+    const uint32_t l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= n_lattices) return;
+    float *m = rm + (size_t)l * RM_STRIDE;
+    m[8] = expf_portable(-m[7] / m[2]);
+    if (refresh_only || !rm_on[l]) return;
+    m[RM_DOPAMINE_BEFORE] = m[RM_DOPAMINE];
+    m[RM_DOPAMINE] = m[RM_DOPAMINE] * expf_portable(-m[7] / m[1]) + m[1] * reward;
+}
+
+// The two update_weight visits every internal edge of a modulated lattice receives per step (do_update is always
+// true, plasticity/mod.rs:239-241), deferred form: both visits see the same delta
+//   dw = 0 + delta; w += c * dopamine; dw += delta; c = c * exp(-dt / tau_c) + tau_c * dw; w += c * dopamine
+__device__ __forceinline__ void rstdp_edge(float &w, float &c, int32_t tp, int32_t tq, const float *m, int dop)
+{
+    const float delta_w = stdp_delta(tp, tq, m[3], m[4], m[5], m[6], m[7]);
+    const float dopamine = m[dop];
+    float dw = 0.0f;
+    dw += delta_w;
+    w += c * dopamine;
+    dw += delta_w;
+    c = c * m[8] + m[2] * dw;
+    w += c * dopamine;
+}
+
+struct RewardArgs {
+    float *W, *C;                          // weights and TraceRSTDP::c, both [n_tot rows][ld]
+    uint32_t ld, n_loc, q0, n_neurons;
+    const int32_t *last_firing_time;
+    const uint32_t *lattice_slot;
+    const float *rm;
+    const uint32_t *rm_on;
+    int dop;                               // RM_DOPAMINE, or RM_DOPAMINE_BEFORE when a newer reward is already in
+};
+
+// One streaming read-modify-write pass over the neuron rows of W and C: 16 B per synapse.
+// Thread = 4 adjacent columns (dwordx4), rows grid-strided over blockIdx.y; the presynaptic side (row) is
+// wave-uniform, the postsynaptic side lives in registers.
+__global__ __launch_bounds__(256) void k_rstdp_dense(const RewardArgs a)
+{
+    const uint32_t c0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (c0 >= a.n_loc) return;
+    int32_t tq[4];
+    uint32_t sq[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t q = a.q0 + min(c0 + j, a.n_loc - 1);
+        tq[j] = a.last_firing_time[q];
+        sq[j] = (c0 + j < a.n_loc) ? a.lattice_slot[q] : 0xFFFFFFFFu;
+    }
+    for (uint32_t p = blockIdx.y; p < a.n_neurons; p += gridDim.y) {
+        const uint32_t sp = a.lattice_slot[p];
+        if (!a.rm_on[sp]) continue;
+        if (sq[0] != sp && sq[1] != sp && sq[2] != sp && sq[3] != sp) continue;
+        const float *m = a.rm + (size_t)sp * RM_STRIDE;
+        const int32_t tp = a.last_firing_time[p];
+        v4f *wp = reinterpret_cast<v4f *>(a.W + (size_t)p * a.ld + c0);
+        v4f *cp = reinterpret_cast<v4f *>(a.C + (size_t)p * a.ld + c0);
+        v4f w = *wp, c = *cp;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (sq[j] != sp || w[j] != w[j]) continue;      // other lattice / padding / absent edge (NaN)
+            float wj = w[j], cj = c[j];
+            rstdp_edge(wj, cj, tp, tq[j], m, a.dop);
+            w[j] = wj; c[j] = cj;
+        }
+        *wp = w;
+        *cp = c;
+    }
+}
+
+// The same update FUSED into the next step's synaptic-input pass: W and the trace are read, updated, written back,
+// and the fresh weight feeds the input sums -- 16 B per synapse per step for a reward-modulated lattice instead of
+// 16 (k_rstdp_dense) + 4 (k_inputs_dense).  The host defers the update of step t to the start of step t+1 (nothing
+// reads W in between; any host access flushes it with k_rstdp_dense).  Staging, shapes and the accumulation are
+// those of k_inputs_dense (kept separate so that the plain input pass stays untouched); single register buffer.
+struct RstdpInputsArgs {
+    InputsArgs in;
+    float *W, *C;
+    const int32_t *last_firing_time;
+    const uint32_t *lattice_slot;
+    const float *rm;
+    const uint32_t *rm_on;
+    int dop;
+};
+
+template <int STREAM>
+__device__ __forceinline__ void store_w(float *p, const float (&w)[InputsShape<STREAM>::VEC])
+{
+    if constexpr (STREAM == 1) {
+        v4f v; v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
+        __builtin_nontemporal_store(v, reinterpret_cast<v4f *>(p));
+    } else if constexpr (STREAM == 2) {
+        v2f v; v.x = w[0]; v.y = w[1];
+        __builtin_nontemporal_store(v, reinterpret_cast<v2f *>(p));
+    } else {
+        *p = w[0];
+    }
+}
+
+template <bool ELEC, bool CHEM, int STREAM>
+__global__ __launch_bounds__(InputsShape<STREAM>::THREADS) void k_inputs_rstdp(const RstdpInputsArgs ra)
+{
+    using S = InputsShape<STREAM>;
+    constexpr int VEC = S::VEC;
+    constexpr uint32_t ROW_BATCH = 8;
+    constexpr uint32_t NONE = 0xFFFFFFFFu;
+    const InputsArgs &a = ra.in;
+
+    __shared__ float s_val[CHUNK];
+    __shared__ uint32_t s_kind[CHUNK];
+    __shared__ float s_t[CHEM ? K_TYPES : 1][CHUNK];
+    __shared__ uint32_t s_mod[CHUNK];          // lattice slot of a row whose lattice is modulated, else NONE
+    __shared__ int32_t s_lft[CHUNK];
+
+    const uint32_t chunk = blockIdx.y;
+    const uint32_t p0 = chunk * CHUNK;
+    const uint32_t rows = min((uint32_t)CHUNK, a.n_tot - p0);
+    const uint32_t tid = threadIdx.x;
+
+    for (uint32_t i = tid; i < rows; i += S::THREADS) {
+        const uint32_t p = p0 + i;
+        float val;
+        uint32_t kind, mod = NONE;
+        int32_t lft = -1;
+        if (p < a.n_neurons) {
+            val = a.xbuf[a.xl.at(p, PLANE_V)];
+            kind = KIND_NEURON;
+            if (CHEM) {
+#pragma unroll
+                for (int k = 0; k < K_TYPES; ++k) {
+                    kind |= a.nt_flags[(size_t)k * a.n_pad + p] ? (0x100u << k) : 0u;
+                    s_t[k][i] = a.xbuf[a.xl.at(p, PLANE_T0 + k)];
+                }
+            }
+            const uint32_t slot = ra.lattice_slot[p];
+            if (ra.rm_on[slot]) mod = slot;
+            lft = ra.last_firing_time[p];
+        } else {
+            const uint32_t s = p - a.n_neurons;
+            val = a.st_value[s];
+            kind = (a.st_last_firing_time[s] < 0) ? KIND_ST_SILENT : KIND_ST_FIRED;
+            if (CHEM) {
+#pragma unroll
+                for (int k = 0; k < K_TYPES; ++k) {
+                    kind |= a.st_nt_flags[(size_t)k * a.c_pad + s] ? (0x100u << k) : 0u;
+                    s_t[k][i] = a.st_nt_t[(size_t)k * a.c_pad + s];
+                }
+            }
+        }
+        s_val[i] = val;
+        s_kind[i] = kind;
+        s_mod[i] = mod;
+        s_lft[i] = lft;
+    }
+    __syncthreads();
+
+    const uint32_t tile = (blockIdx.x + blockIdx.y) % gridDim.x;
+    const uint32_t ql = tile * S::TILE + tid * VEC;
+    if (ql >= a.n_loc) return;
+
+    float vq[VEC], gq[VEC];
+    int32_t tq[VEC];
+    uint32_t sq[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        const uint32_t q = ql + j;
+        const bool in = q < a.n_loc;
+        const uint32_t gqi = a.q0 + (in ? q : a.n_loc - 1);
+        vq[j] = (ELEC && in) ? a.xbuf[a.xl.at(gqi, PLANE_V)] : 0.0f;
+        gq[j] = (ELEC && in) ? a.gap_conductance[gqi] : 0.0f;
+        tq[j] = ra.last_firing_time[gqi];
+        sq[j] = in ? ra.lattice_slot[gqi] : NONE - 1;
+    }
+
+    float acc[VEC];
+    float tacc[CHEM ? K_TYPES : 1][VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[j] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < (CHEM ? K_TYPES : 1); ++k)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) tacc[k][j] = 0.0f;
+
+    const size_t ld = a.ld;
+    float *wrow = ra.W + (size_t)p0 * ld + ql;
+    float *crow = ra.C + (size_t)p0 * ld + ql;
+
+    auto row = [&](uint32_t r, float (&w)[VEC], float (&c)[VEC]) {
+        const uint32_t mod = __builtin_amdgcn_readfirstlane(s_mod[r]);
+        if (mod != NONE) {
+            const float *m = ra.rm + (size_t)mod * RM_STRIDE;
+            const int32_t tp = s_lft[r];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j)
+                if (sq[j] == mod && w[j] == w[j]) rstdp_edge(w[j], c[j], tp, tq[j], m, ra.dop);
+            store_w<STREAM>(wrow + (size_t)r * ld, w);
+            store_w<STREAM>(crow + (size_t)r * ld, c);
+        }
+        const uint32_t kind = __builtin_amdgcn_readfirstlane(s_kind[r]);
+        if (ELEC) {
+            const float vp = s_val[r];
+            const uint32_t src = kind & 3u;
+            if (src == KIND_NEURON) {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) acc[j] = acc_if_edge(acc[j], gq[j] * (vp - vq[j]), w[j]);
+            } else if (src == KIND_ST_SILENT) {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) acc[j] = acc_if_edge(acc[j], vp, w[j]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) acc[j] = acc_if_edge(acc[j], gq[j] * vp, w[j]);
+            }
+        }
+        if (CHEM) {
+#pragma unroll
+            for (int k = 0; k < K_TYPES; ++k) {
+                if (kind & (0x100u << k)) {
+                    const float t = s_t[k][r];
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) tacc[k][j] = acc_if_edge(tacc[k][j], t, w[j]);
+                }
+            }
+        }
+    };
+
+    uint32_t r = 0;
+    for (; r + ROW_BATCH <= rows; r += ROW_BATCH) {
+        float wb[ROW_BATCH][VEC], cb[ROW_BATCH][VEC];
+#pragma unroll
+        for (uint32_t u = 0; u < ROW_BATCH; ++u) load_w<STREAM>(wrow + (size_t)(r + u) * ld, wb[u]);
+#pragma unroll
+        for (uint32_t u = 0; u < ROW_BATCH; ++u) load_w<STREAM>(crow + (size_t)(r + u) * ld, cb[u]);
+#pragma unroll
+        for (uint32_t u = 0; u < ROW_BATCH; ++u) row(r + u, wb[u], cb[u]);
+    }
+    for (; r < rows; ++r) {
+        float w[VEC], c[VEC];
+        load_w<STREAM>(wrow + (size_t)r * ld, w);
+        load_w<STREAM>(crow + (size_t)r * ld, c);
+        row(r, w, c);
+    }
+
+    if (ELEC) {
+        float *dst = a.part_i + (size_t)chunk * a.ld + ql;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) dst[j] = acc[j];
+    }
+    if (CHEM) {
+#pragma unroll
+        for (int k = 0; k < K_TYPES; ++k) {
+            float *dst = a.part_t + ((size_t)k * a.n_chunks + chunk) * a.ld + ql;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) dst[j] = tacc[k][j];
+        }
+    }
+}
+
+} // namespace snn

@@ -28,6 +28,7 @@ int snn_network_create(int device, int neuron_model, int nt_kinetics, int recept
     snn_network *net = new snn_network();
     net->device = device;
     if (const char *e = getenv("SNN_AMD_FUSED_STEP")) net->fused_step = (e[0] != '0');
+    if (const char *e = getenv("SNN_AMD_DEFER_RSTDP")) net->defer_rstdp = (e[0] != '0');
     net->model = neuron_model; net->nt_kind = nt_kinetics; net->rc_kind = receptor_kinetics;
     net->st_kind = spike_train_model;
     if (hipStreamCreateWithFlags(&net->own_stream, hipStreamNonBlocking) != hipSuccess) {
@@ -382,6 +383,7 @@ int snn_set_reward_modulator(snn_network_t *net, uint32_t id, float dopamine, fl
     HIP_TRY(hipMemcpy(net->rm_host.data(), net->rm_dev, nl * RM_STRIDE * 4, hipMemcpyDeviceToHost), SNN_ERR_BUFFER_READ);
     float *m = &net->rm_host[(size_t)l->slot * RM_STRIDE];
     m[0] = dopamine; m[1] = tau_d; m[2] = tau_c; m[3] = a_plus; m[4] = a_minus; m[5] = tau_plus; m[6] = tau_minus; m[7] = dt;
+    m[RM_DOPAMINE_BEFORE] = dopamine;
     net->rm_on_host[l->slot] = do_modulation ? 1u : 0u;
     net->any_modulation = false;
     for (uint32_t v : net->rm_on_host) net->any_modulation |= (v != 0);
@@ -420,6 +422,9 @@ int snn_apply_reward(snn_network_t *net, float reward)
     if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
     if (!net->any_modulation) return SNN_OK;
     HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
+    // a deferred weight update keeps ONE earlier dopamine value: a second reward before the next step applies it first
+    if (net->rstdp_pending && net->reward_since_defer) TRY(flush_rstdp(net));
+    if (net->rstdp_pending) net->reward_since_defer = true;
     const size_t nl = net->rm_on_host.size();
     hipLaunchKernelGGL(k_modulator_update, dim3((unsigned)((nl + 63) / 64)), dim3(64), 0, net->stream, net->rm_dev,
                        net->rm_on_dev, (uint32_t)nl, reward, 0);

@@ -86,6 +86,11 @@ struct snn_network {
     float *rm_dev = nullptr;
     uint32_t *rm_on_dev = nullptr;
     float *trace = nullptr;                // dense: [n_tot][ld]; CSR: [sell_entries]
+    // Dense handles defer the weight update of step t to the input pass of step t+1 (k_inputs_rstdp: one pass over
+    // W and the traces instead of two); any host access to weights / traces / timing flushes it first.
+    int defer_rstdp = 1;                   // 0: always the standalone pass (SNN_AMD_DEFER_RSTDP=0)
+    bool rstdp_pending = false;
+    bool reward_since_defer = false;       // a reward was applied after the deferral: use RM_DOPAMINE_BEFORE
 
     uint32_t nn = 0, nc = 0, n_tot = 0, n_pad = 0, c_pad = 0;
     uint32_t q0 = 0, q1 = 0, n_loc = 0, ld = 0, n_chunks = 0;
@@ -406,6 +411,7 @@ int build_state(snn_network *net)
     for (size_t l = 0; l < nl; ++l) {
         float *m = &net->rm_host[l * RM_STRIDE];
         m[0] = 0.0f; m[1] = 20.0f; m[2] = 0.0001f; m[3] = 2.0f; m[4] = 2.0f; m[5] = 4.5f; m[6] = 4.5f; m[7] = 0.1f;
+        m[RM_DOPAMINE_BEFORE] = 0.0f;
     }
     TRY(dev_alloc_t(net, &net->rm_dev, nl * RM_STRIDE));
     TRY(dev_alloc_t(net, &net->rm_on_dev, nl));

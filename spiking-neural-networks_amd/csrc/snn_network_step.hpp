@@ -21,6 +21,7 @@ int launch_spike_trains(snn_network *net, int iterate, long long step_offset, lo
 }
 
 enum InputsPart { INPUTS_ALL = 0, INPUTS_LOCAL = 1, INPUTS_REMOTE = 2 };
+int flush_rstdp(snn_network *net);
 
 // chunks whose presynaptic rows all belong to this shard's own neurons
 void local_chunks(const snn_network *net, uint32_t *begin, uint32_t *count)
@@ -84,6 +85,34 @@ int launch_inputs(snn_network *net, InputsPart part = INPUTS_ALL)
     const bool resident = (size_t)net->n_tot * net->ld * 4 <= ((size_t)64 << 20);
     const uint64_t waves4 = (uint64_t)((net->n_loc + 255) / 256) * grid_chunks;
     const int shape = resident ? 0 : (waves4 < 8192 ? 2 : 1);     // 8192 = 256 CUs x 32 wave slots
+    if (net->rstdp_pending && part != INPUTS_ALL) TRY(flush_rstdp(net));
+    if (net->rstdp_pending) {
+        // the reward-modulated weight update of the previous step rides on this pass over W
+        net->rstdp_pending = false;
+        RstdpInputsArgs ra{};
+        ra.in = a; ra.W = net->W; ra.C = net->trace;
+        ra.last_firing_time = net->na.last_firing_time; ra.lattice_slot = net->lattice_slot;
+        ra.rm = net->rm_dev; ra.rm_on = net->rm_on_dev;
+        ra.dop = net->reward_since_defer ? RM_DOPAMINE_BEFORE : RM_DOPAMINE;
+#define SNN_LAUNCH_RSHAPE(E, C, SH)                                                                       \
+    hipLaunchKernelGGL((k_inputs_rstdp<E, C, SH>),                                                       \
+                       dim3((net->n_loc + InputsShape<SH>::TILE - 1) / InputsShape<SH>::TILE, grid_chunks), \
+                       dim3(InputsShape<SH>::THREADS), 0, net->stream, ra)
+#define SNN_LAUNCH_RINPUTS(E, C)                                                                         \
+    do {                                                                                                 \
+        if (shape == 1) SNN_LAUNCH_RSHAPE(E, C, 1);                                                      \
+        else if (shape == 2) SNN_LAUNCH_RSHAPE(E, C, 2);                                                 \
+        else SNN_LAUNCH_RSHAPE(E, C, 0);                                                                 \
+    } while (0)
+        if (net->electrical && net->chemical) SNN_LAUNCH_RINPUTS(true, true);
+        else if (net->electrical) SNN_LAUNCH_RINPUTS(true, false);
+        else SNN_LAUNCH_RINPUTS(false, true);
+#undef SNN_LAUNCH_RINPUTS
+#undef SNN_LAUNCH_RSHAPE
+        HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+        if (net->profile) HIP_TRY(hipEventRecord(e1, net->stream), SNN_ERR_QUEUE);
+        return SNN_OK;
+    }
 #define SNN_LAUNCH_SHAPE(E, C, SH)                                                                        \
     hipLaunchKernelGGL((k_inputs_dense<E, C, SH>),                                                       \
                        dim3((net->n_loc + InputsShape<SH>::TILE - 1) / InputsShape<SH>::TILE, grid_chunks), \
@@ -165,16 +194,23 @@ int launch_plasticity(snn_network *net)
     return SNN_OK;
 }
 
-// RewardModulatedLattice::update_weights_from_neurons for every modulated lattice (deferred form)
-int launch_reward_modulation(snn_network *net)
+// sizes served by the one-launch small-lattice step (snn_kernels_resident.hpp)
+bool fused_step_possible(const snn_network *net)
 {
-    if (!net->any_modulation || net->nn == 0 || net->n_loc == 0 || !net->trace) return SNN_OK;
+    return net->fused_step && !net->csr && net->xl.n_shards == 1 && net->n_loc && net->n_tot &&
+           net->n_chunks <= RESIDENT_MAX_CHUNKS && (size_t)net->n_tot * net->ld * 4 <= ((size_t)64 << 20);
+}
+
+// RewardModulatedLattice::update_weights_from_neurons for every modulated lattice (deferred form), as a standalone
+// pass over the weights and traces.  `dop`: which dopamine slot of the modulator table applies.
+int launch_rstdp_pass(snn_network *net, int dop)
+{
     if (net->csr) {
         if (!net->csr_ptr) return SNN_OK;
         CsrRewardArgs a{};
         a.g = csr_graph(net); a.c = net->trace; a.q0 = net->q0; a.n_neurons = net->nn;
         a.last_firing_time = net->na.last_firing_time; a.lattice_slot = net->lattice_slot;
-        a.rm = net->rm_dev; a.rm_on = net->rm_on_dev;
+        a.rm = net->rm_dev; a.rm_on = net->rm_on_dev; a.dop = dop;
         hipLaunchKernelGGL(k_rstdp_csr, dim3((net->n_loc + 255) / 256), dim3(256), 0, net->stream, a);
         HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
         return SNN_OK;
@@ -182,12 +218,34 @@ int launch_reward_modulation(snn_network *net)
     RewardArgs a{};
     a.W = net->W; a.C = net->trace; a.ld = net->ld; a.n_loc = net->n_loc; a.q0 = net->q0; a.n_neurons = net->nn;
     a.last_firing_time = net->na.last_firing_time; a.lattice_slot = net->lattice_slot;
-    a.rm = net->rm_dev; a.rm_on = net->rm_on_dev;
+    a.rm = net->rm_dev; a.rm_on = net->rm_on_dev; a.dop = dop;
     const unsigned gx = (net->n_loc + 1023) / 1024;
     const unsigned gy = std::max(1u, std::min<unsigned>(net->nn, 8192u / gx));     // ~8192 workgroups in flight
     hipLaunchKernelGGL(k_rstdp_dense, dim3(gx, gy), dim3(256), 0, net->stream, a);
     HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
     return SNN_OK;
+}
+
+// End of a step: dense handles only NOTE that the update is due -- the next step's input pass applies it while it
+// streams W anyway (launch_inputs -> k_inputs_rstdp); sparse handles and the one-launch small-lattice step run the
+// standalone pass right away.
+int launch_reward_modulation(snn_network *net)
+{
+    if (!net->any_modulation || net->nn == 0 || net->n_loc == 0 || !net->trace) return SNN_OK;
+    if (!net->csr && net->defer_rstdp && !fused_step_possible(net)) {
+        net->rstdp_pending = true;
+        net->reward_since_defer = false;
+        return SNN_OK;
+    }
+    return launch_rstdp_pass(net, RM_DOPAMINE);
+}
+
+// Apply a deferred update now (a host access to weights, traces or firing times is about to happen).
+int flush_rstdp(snn_network *net)
+{
+    if (!net->rstdp_pending) return SNN_OK;
+    net->rstdp_pending = false;
+    return launch_rstdp_pass(net, net->reward_since_defer ? RM_DOPAMINE_BEFORE : RM_DOPAMINE);
 }
 
 // The synapse matrix is the one allocation whose HBM placement matters: on MI355X two 17 GB allocations of one
@@ -258,8 +316,7 @@ int choose_matrix_placement(snn_network *net)
 // Small dense lattices on an unsharded handle: inputs + update in ONE launch (snn_kernels_resident.hpp).
 bool fused_step_applies(const snn_network *net)
 {
-    return net->fused_step && !net->csr && net->xl.n_shards == 1 && net->n_loc && net->n_tot && !net->local_inputs_done &&
-           net->n_chunks <= RESIDENT_MAX_CHUNKS && (size_t)net->n_tot * net->ld * 4 <= ((size_t)64 << 20);
+    return fused_step_possible(net) && !net->local_inputs_done;
 }
 
 int launch_step_resident(snn_network *net)
@@ -428,6 +485,7 @@ int begin_run(snn_network *net, uint64_t iterations)
 // Closes the open run: waits for the stream and folds the steps done into the host-side lattice clocks.
 int end_run(snn_network *net)
 {
+    TRY(flush_rstdp(net));
     HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
     if (net->run_active) {
         for (auto &c : net->st_clock) c += net->run_step_offset;

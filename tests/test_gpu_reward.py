@@ -1,7 +1,8 @@
 """GPU parity for reward modulation: RewardModulatedLattice (neuron/mod.rs:2719-3417) with
 RewardModulatedSTDP + TraceRSTDP (plasticity/mod.rs:126-242) -- every internal edge of a modulated lattice is
 updated every step (dopamine-gated trace), in the deferred form.  Weights, traces, dopamine and all neuron state
-bit-identical to the oracle; dense, sparse and sharded handles."""
+bit-identical to the oracle; dense, sparse and sharded handles; the update as a standalone pass and fused into the
+next step's input pass."""
 import numpy as np
 import pytest
 
@@ -211,3 +212,92 @@ def test_sharded_stepper_applies_rewards_in_step_order(snn):
     assert dn.dopamine(0) == net["rm_dopamine"][0]
     parity.assert_state_equal(net, parity.pull_state(dn, net))
     dn.close()
+
+
+def _env(name, value):
+    import contextlib
+    import os
+
+    @contextlib.contextmanager
+    def cm():
+        old = os.environ.get(name)
+        os.environ[name] = value
+        try:
+            yield
+        finally:
+            if old is None:
+                del os.environ[name]
+            else:
+                os.environ[name] = old
+    return cm()
+
+
+@pytest.mark.parametrize("case", ["two_kernel_small", "five_chunks", "streaming_shape"])
+def test_weight_update_deferred_into_the_next_input_pass(snn, case):
+    """Dense handles on the two-kernel path apply the update of step t inside the input pass of step t+1
+    (k_inputs_rstdp).  Same results as the oracle, with host reads in between (which flush the pending update), two
+    rewards before one step, and a reward arriving between the deferral and the pass."""
+    if case == "two_kernel_small":
+        net = build(lattices=((0, 9, 9), (2, 7, 8)), modulated=(0, 2), st=((5, 2, 3),), seed=21)
+        steps, env = 240, ("SNN_AMD_FUSED_STEP", "0")
+    elif case == "five_chunks":
+        net = build(lattices=((0, 34, 34),), seed=23)            # 1156 rows: beyond the one-launch step
+        steps, env = 90, ("SNN_AMD_FUSED_STEP", "1")
+    else:
+        net = build(lattices=((0, 66, 64),), seed=25, density=0.9)   # 71 MB matrix: streamed (2 columns per lane)
+        steps, env = 12, ("SNN_AMD_FUSED_STEP", "1")
+    rewards = rewards_for(steps, 26)
+    with _env(*env):
+        dn = to_device(snn, net)
+    dn.set_trace_rows(0, net["traces"])
+    third = steps // 3
+    for r in rewards[:third]:
+        dn.run_with_reward(float(r))
+    net.run(third, rewards=rewards[:third])
+    check_dense(dn, net)                                     # host read: flushes the pending update
+    # two rewards before one step (the second must not disturb the dopamine of the pending update)
+    dn.apply_reward(0.02)
+    dn.apply_reward(-0.01)
+    dn.run(1)
+    net.apply_reward(0.02)
+    net.apply_reward(-0.01)
+    net.run(1)
+    for r in rewards[third:]:
+        dn.run_with_reward(float(r))
+    net.run(steps - third, rewards=rewards[third:])
+    check_dense(dn, net)
+    assert dn.dopamine(0) == net["rm_dopamine"][0]
+    parity.assert_state_equal(net, parity.pull_state(dn, net))
+    dn.close()
+
+
+def test_deferred_and_standalone_update_agree_at_streaming_size(snn):
+    """160x160 neurons (2.6 GB matrix + 2.6 GB of traces: the 4-columns-per-lane streaming shape, too large for the
+    oracle): the deferred update (k_inputs_rstdp) against the standalone pass (SNN_AMD_DEFER_RSTDP=0), device against
+    device, sampled rows bit-identical."""
+    n = 160 * 160
+    out = []
+    for defer in ("1", "0"):
+        with _env("SNN_AMD_DEFER_RSTDP", defer):
+            dn = snn.DeviceNetwork(model=snn.IZHIKEVICH)
+        dn.add_lattice(0, 160, 160)
+        dn.finalize()
+        dn.set_attr(0, "gap_conductance", np.full(n, 10.0, np.float32))
+        dn.set_attr(0, "current_voltage", ob.uniform_array(31, n, -65.0, 30.0))
+        dn.fill_graph_synthetic(32, 0.5, 1.5)
+        # firing times on record from the start, so that every pair of neurons has a non-zero STDP delta
+        dn.set_attr(0, "last_firing_time", np.random.default_rng(34).integers(0, 60, n).astype(np.int32))
+        dn.set_reward_modulator(0, tau_c=0.05, tau_d=5.0, a_plus=0.002, a_minus=0.0015)
+        for r in rewards_for(40, 33):
+            dn.run_with_reward(float(r))
+        rows = [0, 1, 255, 256, 12345, n - 1]
+        w = np.stack([dn.get_graph_rows(p, 1)[0][0] for p in rows])
+        t = np.stack([dn.get_trace_rows(p, 1)[0] for p in rows])
+        v = dn.get_attr(0, "current_voltage")
+        lft = dn.get_attr(0, "last_firing_time", dtype=np.int32)
+        out.append((w, t, v, lft, dn.dopamine(0)))
+        dn.close()
+    a, b = out
+    assert np.abs(a[1]).max() > 0 and a[4] != 0, "traces and dopamine must have moved"
+    for x, y in zip(a, b):
+        assert np.array_equal(parity.bits(np.asarray(x)), parity.bits(np.asarray(y)))
