@@ -122,7 +122,7 @@ __global__ __launch_bounds__(InputsShape<STREAM>::THREADS) void k_inputs_rstdp(c
 {
     using S = InputsShape<STREAM>;
     constexpr int VEC = S::VEC;
-    constexpr uint32_t ROW_BATCH = 8;
+    constexpr uint32_t ROW_BATCH = 16;         // rows of W and of the traces in flight per lane (32 spills)
     constexpr uint32_t NONE = 0xFFFFFFFFu;
     const InputsArgs &a = ra.in;
 
