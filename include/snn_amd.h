@@ -241,6 +241,13 @@ int snn_get_traces_csr(snn_network_t *net, float *traces, uint64_t nnz);
  * ends at n_times.  A cell with no times never fires.  Only with SNN_ST_PRESET (else SNN_ERR_BAD_STATE). */
 int snn_set_firing_times(snn_network_t *net, uint32_t id, const uint32_t *cell_ptr, const float *times, size_t n_times);
 
+/* update_graph_history (Lattice::update_graph_history, neuron/mod.rs:572; AdjacencyMatrix::update_history
+ * graph/mod.rs:278-280): one snapshot of lattice `id`'s internal weights per recorded step, taken AFTER the step's
+ * weight update (the single-lattice order, neuron/mod.rs:908-910), [steps][rows*cols][rows*cols] (presynaptic index
+ * first, absent edges 0), on the step axis of snn_history_steps.  Dense unsharded handles. */
+int snn_set_graph_history(snn_network_t *net, uint32_t id, int enable);
+int snn_get_graph_history(snn_network_t *net, uint32_t id, float *dst, size_t steps);
+
 /* Strided capture: store the history rows (voltage, raster, reduced rows) of every `every`-th step only -- steps
  * 0, every, 2*every, ... counted from the last (re)start of the record; 1 = every step (the reference's
  * behaviour).  Changing the stride restarts the record.  Spike totals (below) always count every step. */

@@ -101,6 +101,8 @@ SIGNATURES = {
     "snn_set_traces_csr": (C.c_int, [H, f32p, C.c_uint64]),
     "snn_get_traces_csr": (C.c_int, [H, f32p, C.c_uint64]),
     "snn_set_firing_times": (C.c_int, [H, C.c_uint32, u32p, f32p, C.c_size_t]),
+    "snn_set_graph_history": (C.c_int, [H, C.c_uint32, C.c_int]),
+    "snn_get_graph_history": (C.c_int, [H, C.c_uint32, f32p, C.c_size_t]),
     "snn_set_history_stride": (C.c_int, [H, C.c_uint32]),
     "snn_set_reduced_history": (C.c_int, [H, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float]),
     "snn_get_average_voltage_history": (C.c_int, [H, C.c_uint32, f32p, C.c_size_t]),

@@ -56,6 +56,17 @@ __global__ void k_graph_export(const float *W, uint32_t ld, uint32_t n_loc, uint
     dst_c[i] = edge ? 1u : 0u;
 }
 
+// one step's snapshot of a lattice's internal weights (AdjacencyMatrix::update_history, graph/mod.rs:278-280): [count][count],
+// absent edges as 0
+__global__ void k_weight_snapshot(const float *W, uint32_t ld, uint32_t first, uint32_t count, float *dst)
+{
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t r = blockIdx.y;
+    if (c >= count) return;
+    const float w = W[(size_t)(first + r) * ld + first + c];
+    dst[(size_t)r * count + c] = (w == w) ? w : 0.0f;
+}
+
 __global__ void k_graph_synthetic(float *W, uint32_t ld, uint32_t n_loc, uint32_t q0, uint32_t n_neurons,
                                   uint32_t n_tot, uint64_t seed, float lo, float hi, int with_diagonal)
 {

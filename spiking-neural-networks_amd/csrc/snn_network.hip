@@ -54,6 +54,7 @@ int snn_network_destroy(snn_network_t *net)
     if (net->raster) (void)hipFree(net->raster);
     if (net->preset_times_dev) (void)hipFree(net->preset_times_dev);
     if (net->trace) (void)hipFree(net->trace);
+    for (float *b : net->whist) if (b) (void)hipFree(b);
     if (net->summ_avg) (void)hipFree(net->summ_avg);
     if (net->summ_eeg) (void)hipFree(net->summ_eeg);
     for (auto &e : net->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -549,6 +550,38 @@ int snn_set_firing_times(snn_network_t *net, uint32_t id, const uint32_t *cell_p
     if (net->preset_times_dev) (void)hipFree(net->preset_times_dev);
     net->preset_times_dev = nt;
     net->ca.preset_times = nt;
+    return SNN_OK;
+}
+
+int snn_set_graph_history(snn_network_t *net, uint32_t id, int enable)
+{
+    if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
+    if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
+    const LatticeInfo *l = find_lattice(net, id);
+    if (!l || l->spike_train) return fail(SNN_ERR_BAD_ARG, "graph histories belong to neuron lattices");
+    if (net->csr || net->xl.n_shards != 1) return fail(SNN_ERR_BAD_STATE, "graph histories need a dense, unsharded handle");
+    HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
+    TRY(end_run(net));
+    if ((enable != 0) != (net->want_whist[l->slot] != 0)) { net->hist_steps = 0; net->hist_tick = 0; }
+    net->want_whist[l->slot] = enable ? 1 : 0;
+    net->any_whist = false;
+    for (int v : net->want_whist) net->any_whist |= (v != 0);
+    return SNN_OK;
+}
+
+int snn_get_graph_history(snn_network_t *net, uint32_t id, float *dst, size_t steps)
+{
+    if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
+    if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
+    const LatticeInfo *l = find_lattice(net, id);
+    if (!l || l->spike_train) return fail(SNN_ERR_BAD_ARG, "graph histories belong to neuron lattices");
+    if (!net->want_whist[l->slot]) return fail(SNN_ERR_BAD_STATE, "graph history is off for this lattice");
+    if (steps != net->hist_steps) return fail(SNN_ERR_DIM_MISMATCH, "history size mismatch");
+    if (steps == 0 || l->count == 0) return SNN_OK;
+    if (!dst) return fail(SNN_ERR_BAD_ARG, "dst is null");
+    HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
+    TRY(end_run(net));
+    HIP_TRY(hipMemcpy(dst, net->whist[l->slot], steps * (size_t)l->count * l->count * 4, hipMemcpyDeviceToHost), SNN_ERR_BUFFER_READ);
     return SNN_OK;
 }
 

@@ -134,6 +134,10 @@ struct snn_network {
     int want_vhist = 0, want_raster = 0;
     // reduced histories: per-lattice average voltage / EEG value per step, per-neuron spike totals
     int want_avg = 0, want_eeg = 0, want_counts = 0;
+    // per-lattice weight snapshots (update_graph_history): [cap][count*count] per neuron lattice slot
+    std::vector<int> want_whist;
+    std::vector<float *> whist;
+    bool any_whist = false;
     float eeg_ref = 0.007f, eeg_dist = 0.8f, eeg_cond = 251.0f;     // EEGHistory defaults, neuron/mod.rs:246-255
     float *summ_avg = nullptr, *summ_eeg = nullptr;                 // [cap][n_lattices]
     uint32_t *spike_counts = nullptr, *lat_first_dev = nullptr, *lat_count_dev = nullptr;
@@ -157,7 +161,7 @@ struct snn_network {
 namespace {
 inline bool recording(const snn_network *net)
 {
-    return net->want_vhist || net->want_raster || net->want_avg || net->want_eeg;
+    return net->want_vhist || net->want_raster || net->want_avg || net->want_eeg || net->any_whist;
 }
 // does the step being computed store its history rows (strided capture: every hist_every-th step)
 inline bool record_now(const snn_network *net)
@@ -393,6 +397,8 @@ int build_state(snn_network *net)
         TRY(dev_alloc_t(net, &net->spike_counts, np));
         TRY(fill_u32(net, net->spike_counts, np, 0));
     }
+    net->want_whist.assign(nl, 0);
+    net->whist.assign(nl, nullptr);
     net->stdp_host.assign(nl * 5, 0.0f);
     net->plast_host.assign(nl, 0);
     for (size_t l = 0; l < nl; ++l) {   // plasticity/mod.rs:29-39

@@ -232,7 +232,7 @@ int launch_rstdp_pass(snn_network *net, int dop)
 int launch_reward_modulation(snn_network *net)
 {
     if (!net->any_modulation || net->nn == 0 || net->n_loc == 0 || !net->trace) return SNN_OK;
-    if (!net->csr && net->defer_rstdp && !fused_step_possible(net)) {
+    if (!net->csr && net->defer_rstdp && !net->any_whist && !fused_step_possible(net)) {
         net->rstdp_pending = true;
         net->reward_since_defer = false;
         return SNN_OK;
@@ -414,6 +414,15 @@ int step_end(snn_network *net)
     }
     TRY(launch_plasticity(net));
     TRY(launch_reward_modulation(net));
+    if (net->any_whist && record_now(net)) {
+        for (const auto &l : net->lattices) {
+            if (!net->want_whist[l.slot] || l.count == 0) continue;
+            float *dst = net->whist[l.slot] + (size_t)net->hist_steps * l.count * l.count;
+            hipLaunchKernelGGL(k_weight_snapshot, dim3((l.count + 255) / 256, l.count), dim3(256), 0, net->stream,
+                               net->W, net->ld, l.first, l.count, dst);
+            HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+        }
+    }
     if ((net->want_avg || net->want_eeg) && record_now(net) && !net->lattices.empty()) {
         // after the exchange, so that a sharded handle reduces over every lattice's full population
         const size_t nl = net->lattices.size();
@@ -438,8 +447,11 @@ int grow_history(snn_network *net, uint64_t extra)
     if (!recording(net)) return SNN_OK;
     const uint64_t need = net->hist_steps + (extra + net->hist_every - 1) / net->hist_every + 1;
     if (need <= net->hist_cap && (!net->want_vhist || net->vhist) && (!net->want_raster || net->raster) &&
-        (!net->want_avg || net->summ_avg) && (!net->want_eeg || net->summ_eeg))
-        return SNN_OK;
+        (!net->want_avg || net->summ_avg) && (!net->want_eeg || net->summ_eeg)) {
+        bool ok = true;
+        for (const auto &l : net->lattices) ok = ok && (!net->want_whist[l.slot] || net->whist[l.slot] || l.count == 0);
+        if (ok) return SNN_OK;
+    }
     const uint64_t cap = std::max<uint64_t>(need, net->hist_cap + net->hist_cap / 2);   // geometric: O(T) copies overall
     auto regrow = [&](void **buf, size_t row_bytes, bool wanted) -> int {
         if (!wanted || row_bytes == 0) return SNN_OK;
@@ -458,6 +470,8 @@ int grow_history(snn_network *net, uint64_t extra)
     TRY(regrow(reinterpret_cast<void **>(&net->raster), (size_t)(net->n_pad / 64) * 8, net->want_raster));
     TRY(regrow(reinterpret_cast<void **>(&net->summ_avg), net->lattices.size() * 4, net->want_avg));
     TRY(regrow(reinterpret_cast<void **>(&net->summ_eeg), net->lattices.size() * 4, net->want_eeg));
+    for (const auto &l : net->lattices)
+        TRY(regrow(reinterpret_cast<void **>(&net->whist[l.slot]), (size_t)l.count * l.count * 4, net->want_whist[l.slot] != 0));
     net->hist_cap = cap;
     return SNN_OK;
 }

@@ -251,6 +251,7 @@ class Lattice:
         self.weights = np.zeros((0, 0), np.float32)            # AdjacencyMatrix, index = row*cols + col
         self.connections = np.zeros((0, 0), np.uint32)
         self.update_grid_history = False
+        self.update_graph_history = False
         self.electrical_synapse = True
         self.chemical_synapse = False
         self.do_plasticity = False
@@ -615,6 +616,7 @@ class LatticeNetworkGPU:
 
     def __init__(self, network, device=0):
         self.network = network
+        self._graph_hist = {}
         neurons = [c for l in network.lattices.values() for c in _flat(l)]
         cells = [c for l in network.spike_train_lattices.values() for c in _flat(l)]
         models = {type(c).model for c in neurons} or {IZHIKEVICH}
@@ -672,11 +674,23 @@ class LatticeNetworkGPU:
         l = self.network.lattices.get(gp.id) or self.network.spike_train_lattices[gp.id]
         return first + gp.pos[0] * l.cols + gp.pos[1]
 
+    def _history_flags(self):
+        dn, net = self._dn, self.network
+        hist = any(l.update_grid_history for l in list(net.lattices.values()) + list(net.spike_train_lattices.values()))
+        dn.set_history(voltage=hist, spikes=False)
+        for id, l in net.lattices.items():                      # update_graph_history, neuron/mod.rs:572
+            if getattr(l, "update_graph_history", False) != self._graph_hist.get(id, False):
+                dn.set_graph_history(id, l.update_graph_history)
+                self._graph_hist[id] = l.update_graph_history
+
+    def graph_history(self, id):
+        """[steps][n][n] internal weights of lattice `id` after every step (AdjacencyMatrix::history)."""
+        return self._dn.graph_history(id)
+
     def run_lattices(self, iterations):                         # gpu_lattices/mod.rs:3183-3212
         dn, net = self._dn, self.network
         dn.set_synapses(net.electrical_synapse, net.chemical_synapse)
-        hist = any(l.update_grid_history for l in list(net.lattices.values()) + list(net.spike_train_lattices.values()))
-        dn.set_history(voltage=hist, spikes=False)
+        self._history_flags()
         dn.run(iterations)
         self._download()
 
@@ -686,8 +700,7 @@ class LatticeNetworkGPU:
         the results on the device until the next downloading call (an agent loop steps thousands of times)."""
         dn, net = self._dn, self.network
         dn.set_synapses(net.electrical_synapse, net.chemical_synapse)
-        hist = any(l.update_grid_history for l in list(net.lattices.values()) + list(net.spike_train_lattices.values()))
-        dn.set_history(voltage=hist, spikes=False)
+        self._history_flags()
         dn.run_with_reward(float(reward))
         if download:
             self._download()
@@ -830,7 +843,8 @@ class LatticeGPU:
     def __setattr__(self, name, value):
         if name.startswith("_") or name in ("lattice_type",):
             return object.__setattr__(self, name, value)
-        if name in ("update_grid_history", "electrical_synapse", "chemical_synapse", "do_plasticity", "plasticity", "id"):
+        if name in ("update_grid_history", "update_graph_history", "electrical_synapse", "chemical_synapse",
+                    "do_plasticity", "plasticity", "id"):
             if name in ("do_plasticity", "plasticity", "id"):
                 self._dirty()
             return setattr(self._lattice, name, value)
@@ -851,6 +865,13 @@ class LatticeGPU:
     @property
     def weights(self):
         return self._lattice.weights
+
+    @property
+    def graph_history(self):
+        n = self._lattice.rows * self._lattice.cols
+        if self._net is None:
+            return np.zeros((0, n, n), np.float32)
+        return self._net.graph_history(self._lattice.id)
 
     def reset_history(self):
         if self._net is not None:

@@ -282,6 +282,17 @@ class DeviceNetwork:
         _lib.check(self._L.snn_set_firing_times(self._h, id, cp.ctypes.data_as(_lib.u32p),
                                                 t.ctypes.data_as(_lib.f32p), t.size))
 
+    def set_graph_history(self, id, enable=True):
+        _lib.check(self._L.snn_set_graph_history(self._h, id, int(enable)))
+
+    def graph_history(self, id):
+        """[steps][n][n] snapshots of lattice `id`'s internal weights (update_graph_history)"""
+        rows, cols, _ = self.lattices[id]
+        n = rows * cols
+        out = np.empty((self.history_steps(), n, n), np.float32)
+        _lib.check(self._L.snn_get_graph_history(self._h, id, out.ctypes.data_as(_lib.f32p), out.shape[0]))
+        return out
+
     def set_history_stride(self, every):
         _lib.check(self._L.snn_set_history_stride(self._h, int(every)))
 

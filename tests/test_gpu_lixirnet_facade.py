@@ -200,6 +200,7 @@ def test_reward_modulated_lattice_follows_the_rstdp_example(snn):
     lattice.connect(cond, lambda x, y: ln.TraceRSTDP(weight=float(wts[idx(x), idx(y)])))
     lattice.apply_given_position(lambda pos, n: setattr(n, "current_voltage", float(v0[pos])))
     lattice.reward_modulator = ln.RewardModulatedSTDP(tau_c=0.05, a_plus=0.01, a_minus=0.01)
+    lattice.update_graph_history = True                               # main.rs:69
     gpu = ln.RewardModulatedLatticeGPU.from_lattice(lattice)
 
     steps = 4100
@@ -228,7 +229,15 @@ def test_reward_modulated_lattice_follows_the_rstdp_example(snn):
     o["rm_a_plus"] = 0.01
     o["rm_a_minus"] = 0.01
     w0 = o["weights"].copy()
-    o.run(steps, rewards=rewards)
+    snaps = []
+    for t in range(steps):
+        o.run(1, rewards=rewards[t:t + 1])
+        if t % 500 == 0:
+            snaps.append((t, np.where(o["connections"] != 0, o["weights"], 0).astype(np.float32).copy()))
+    hist = gpu.graph_history                                          # env.agent.graph.history, main.rs:96-108
+    assert hist.shape == (steps, 25, 25)
+    for t, w in snaps:
+        assert np.array_equal(hist[t].view(np.uint32), w.view(np.uint32)), t
     assert np.array_equal(gpu.weights.view(np.uint32), np.where(o["connections"] != 0, o["weights"], 0).astype(np.float32).view(np.uint32))
     assert np.array_equal(gpu.traces.view(np.uint32), o["traces"].view(np.uint32))
     assert np.float32(gpu.reward_modulator.dopamine) == o["rm_dopamine"][0]

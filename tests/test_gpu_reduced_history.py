@@ -202,3 +202,39 @@ def test_strided_capture(snn, every):
     with pytest.raises(snn.SnnError):
         dn.set_history_stride(0)
     dn.close()
+
+
+@pytest.mark.parametrize("plasticity", ["stdp", "reward"])
+def test_graph_history(snn, plasticity):
+    """update_graph_history: the lattice's internal weights after every recorded step (stride 3), for STDP and for a
+    reward-modulated lattice (which then keeps its weight update as a standalone pass), next to a second lattice
+    without history; the oracle is stepped one step at a time and its weights snapshotted."""
+    net = build([(0, 6, 7), (3, 5, 5)], seed=3)
+    if plasticity == "stdp":
+        net["do_plasticity"] = 1
+    else:
+        net["rm_do_modulation"][0] = 1
+        net["rm_tau_c"][0] = 0.05
+        net["rm_a_plus"][0] = 0.01
+        net["rm_a_minus"][0] = 0.01
+        net["rm_dopamine"][0] = 0.02
+    steps, every = 600, 3
+    dn = parity.device_from_oracle(snn, net)
+    if plasticity == "reward":
+        dn.set_reward_modulator(0, dopamine=0.02, tau_c=0.05, a_plus=0.01, a_minus=0.01)
+    dn.set_graph_history(0)
+    dn.set_history_stride(every)
+    dn.run(steps)
+    n0 = 6 * 7
+    snaps = []
+    for t in range(steps):
+        net.run(1)
+        if t % every == 0:
+            snaps.append(np.where(net["connections"][:n0, :n0] != 0, net["weights"][:n0, :n0], np.float32(0)).copy())
+    hist = dn.graph_history(0)
+    assert hist.shape == (len(snaps), n0, n0)
+    assert np.array_equal(parity.bits(hist), parity.bits(np.array(snaps)))
+    assert not np.array_equal(hist[0], hist[-1]), "weights must have moved"
+    with pytest.raises(snn.SnnError):
+        dn.graph_history(3)                      # off for that lattice
+    dn.close()
