@@ -213,11 +213,11 @@ __global__ __launch_bounds__(InputsShape<STREAM>::THREADS) void k_inputs_dense(c
     // so every wave keeps ROW_BATCH wave-rows of reads in flight regardless of the branches in the body.
     auto sweep = [&](auto body) {
         uint32_t r = 0;
-        if constexpr ((STREAM == 1 && !CHEM) || STREAM == 2) {
-            // Electrical-only streaming pass (the 256x256 headline): two register buffers, so the next batch of
-            // 8 rows is already in flight while the current one is consumed (+1 % over a single buffer, measured
-            // in-process at 256x256; the chemical variants keep one buffer -- they need the registers for their
-            // 12 extra accumulators).
+        if constexpr ((STREAM == 1 && !CHEM) || STREAM == 2 || STREAM == 0) {
+            // Two register buffers, so the next batch of rows is already in flight while the current one is
+            // consumed: +1 % over a single buffer for the electrical-only 4-column pass at 256x256 (its chemical
+            // variants keep one buffer -- they need the registers for their 12 extra accumulators), -5 % time at
+            // 96x96 for the 2-column shape, -24 % at 64x64 for the one-column cache-resident shape (2 x 32 rows).
             constexpr uint32_t B = ROW_BATCH;
             if (rows >= 2 * B) {
                 float wa[B][VEC], wb[B][VEC];
