@@ -92,7 +92,9 @@ typedef enum { SNN_NT_APPROXIMATE = 0, SNN_NT_DESTEXHE = 1, SNN_NT_DISCRETE_SPIK
 /* ExponentialDecayReceptor :497-533 (attributes receptors$<T>$r$kinetics$r_max, ...$decay_constant) */
 typedef enum { SNN_RC_APPROXIMATE = 0, SNN_RC_DESTEXHE = 1, SNN_RC_EXPONENTIAL_DECAY = 2 } snn_rc_kinetics;
 /* SpikeTrain: PoissonNeuron spike_train/mod.rs:259-371 (GPU generator :380-435), RateSpikeTrain :975-1031 */
-/* PresetSpikeTrain :753-833 (attributes internal_clock, counter; firing times via snn_set_firing_times) */
+/* PresetSpikeTrain :753-833 (attributes internal_clock, counter; firing times via snn_set_firing_times).
+ * NeuralRefractoriness of a cell: attribute neural_refractoriness$kind (u32; 0 DeltaDirac :79-88, the default,
+ * 1 ExponentialDecay :164-178), decay constant neural_refractoriness$k. */
 typedef enum { SNN_ST_NONE = 0, SNN_ST_POISSON = 1, SNN_ST_RATE = 2, SNN_ST_PRESET = 3 } snn_spike_train_model;
 
 /* ---- construction (≙ from_lattice / from_network) -------------------------------------- */

@@ -54,6 +54,16 @@ float snn_o_delta_dirac_effect(int64_t timestep, int32_t last_firing_time,
     return a * snn_o_expf((-1.0f / (k / dt)) * (td * td)) + v_resting;
 }
 
+/* ExponentialDecayRefractoriness::get_effect, spike_train/mod.rs:164-178:
+ *   a * ((-1. / (k / dt)) * time_difference).exp() + v_resting */
+float snn_o_exponential_decay_effect(int64_t timestep, int32_t last_firing_time,
+                                     float v_th, float v_resting, float k, float dt)
+{
+    float a = v_th - v_resting;
+    float td = (float)(timestep - (int64_t)last_firing_time);
+    return a * snn_o_expf((-1.0f / (k / dt)) * td) + v_resting;
+}
+
 /* STDP::update_weight, plasticity/mod.rs:45-66 (returns delta_w) */
 float snn_o_stdp_delta(int32_t t_pre, int32_t t_post, float a_plus, float a_minus,
                        float tau_plus, float tau_minus, float dt)
@@ -171,8 +181,11 @@ static void inputs_block(snn_o_net *n, uint32_t q0, uint32_t nq)
                 if (n->st_last_firing_time[s] < 0) { kind = 1; pv = n->st_v_resting[s]; }
                 else {
                     kind = 2;
-                    pv = snn_o_delta_dirac_effect(n->clock, n->st_last_firing_time[s], n->st_v_th[s],
-                                                  n->st_v_resting[s], n->st_k[s], n->st_dt[s]);
+                    pv = (n->st_refractoriness && n->st_refractoriness[s])
+                        ? snn_o_exponential_decay_effect(n->clock, n->st_last_firing_time[s], n->st_v_th[s],
+                                                         n->st_v_resting[s], n->st_k[s], n->st_dt[s])
+                        : snn_o_delta_dirac_effect(n->clock, n->st_last_firing_time[s], n->st_v_th[s],
+                                                   n->st_v_resting[s], n->st_k[s], n->st_dt[s]);
                 }
             }
             if (n->electrical) {

@@ -162,6 +162,9 @@ typedef struct snn_o_net {
     uint32_t *rm_do_modulation;
     float    *rm_dopamine, *rm_tau_d, *rm_tau_c, *rm_a_plus, *rm_a_minus, *rm_tau_plus, *rm_tau_minus, *rm_dt;
     const float *rewards;
+    /* NeuralRefractoriness of each spike-train cell: 0 DeltaDiracRefractoriness (spike_train/mod.rs:79-88),
+     * 1 ExponentialDecayRefractoriness (:164-178); NULL = all DeltaDirac */
+    uint32_t *st_refractoriness;
 } snn_o_net;
 
 /* Step 1 of SURVEY §8(g): electrical + chemical inputs for every neuron from state S(t). */
@@ -188,6 +191,8 @@ float snn_o_pow3f_export(float x);
 float snn_o_pow4f_export(float x);
 float snn_o_stdp_delta(int32_t t_pre, int32_t t_post, float a_plus, float a_minus,
                        float tau_plus, float tau_minus, float dt);
+float snn_o_exponential_decay_effect(int64_t timestep, int32_t last_firing_time,
+                                     float v_th, float v_resting, float k, float dt);
 float snn_o_delta_dirac_effect(int64_t timestep, int32_t last_firing_time,
                                float v_th, float v_resting, float k, float dt);
 uint32_t snn_o_xorshift32(uint32_t seed);

@@ -145,7 +145,8 @@ __global__ __launch_bounds__(256) void k_spike_trains(const SpikeTrainArgs a)
     // never fired -> v_resting (used WITHOUT the conductance factor), else the refractoriness effect
     const int32_t lft = c.last_firing_time[s];
     c.presyn_value[s] = (lft < 0) ? c.v_resting[s]
-                                  : delta_dirac_effect(a.view_clock, lft, c.v_th[s], c.v_resting[s], c.k[s], c.dt[s]);
+                    : (c.refractoriness[s] ? exponential_decay_effect(a.view_clock, lft, c.v_th[s], c.v_resting[s], c.k[s], c.dt[s])
+                                           : delta_dirac_effect(a.view_clock, lft, c.v_th[s], c.v_resting[s], c.k[s], c.dt[s]));
 }
 
 // ---- plasticity ------------------------------------------------------------------------------

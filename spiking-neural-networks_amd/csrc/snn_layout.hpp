@@ -74,6 +74,7 @@ struct CellArrays {
     float *current_voltage, *v_th, *v_resting, *dt, *k;
     float *chance_of_firing, *rate, *step;
     uint32_t *seed, *is_spiking;
+    uint32_t *refractoriness;   // NeuralRefractoriness: 0 DeltaDirac, 1 ExponentialDecay
     // PresetSpikeTrain: firing times of cell s = preset_times[preset_ptr[s] .. preset_ptr[s + 1]); `step` holds
     // its internal_clock
     uint32_t *counter;

@@ -96,6 +96,15 @@ __device__ __forceinline__ float delta_dirac_effect(long long timestep, int last
     return a * expf_portable((-1.0f / (k / dt)) * (td * td)) + v_resting;
 }
 
+// ExponentialDecayRefractoriness::get_effect (spike_train/mod.rs:164-178)
+__device__ __forceinline__ float exponential_decay_effect(long long timestep, int last_firing_time,
+                                                          float v_th, float v_resting, float k, float dt)
+{
+    const float a = v_th - v_resting;
+    const float td = (float)(timestep - (long long)last_firing_time);
+    return a * expf_portable((-1.0f / (k / dt)) * td) + v_resting;
+}
+
 // STDP::update_weight (plasticity/mod.rs:45-66): the delta added to the weight
 __device__ __forceinline__ float stdp_delta(int t_pre, int t_post, float a_plus, float a_minus,
                                             float tau_plus, float tau_minus, float dt)

@@ -435,6 +435,11 @@ int build_state(snn_network *net)
     TRY(cell_f32(net, &c.v_resting, "v_resting", 0.0f));
     TRY(cell_f32(net, &c.dt, "dt", 0.1f));
     TRY(cell_f32(net, &c.k, "neural_refractoriness$k", 10000.0f));
+    // which NeuralRefractoriness (a type parameter in the reference): 0 DeltaDirac spike_train/mod.rs:79-88,
+    // 1 ExponentialDecay :164-178
+    TRY(dev_alloc_t(net, &c.refractoriness, cp));
+    TRY(fill_u32(net, c.refractoriness, cp, 0));
+    reg(CA, "neural_refractoriness$kind", T_U32, S_PLAIN, c.refractoriness, 0, 0);
     TRY(cell_f32(net, &c.chance_of_firing, net->st_kind == SNN_ST_POISSON ? "chance_of_firing" : nullptr, 0.0f));
     TRY(cell_f32(net, &c.rate, net->st_kind == SNN_ST_RATE ? "rate" : nullptr, 0.0f));
     TRY(cell_f32(net, &c.step, net->st_kind == SNN_ST_RATE ? "step" : (net->st_kind == SNN_ST_PRESET ? "internal_clock" : nullptr), 0.0f));

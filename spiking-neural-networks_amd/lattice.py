@@ -205,8 +205,19 @@ class HodgkinHuxleyNeuron(_Neuron):                      # hodgkin_huxley/mod.rs
                      k_leak_current="k_leak_channel$current")
 
 
+class DeltaDiracRefractoriness(_Record):                 # spike_train/mod.rs:79-88
+    _defaults = dict(k=10000.0)
+    kind = 0
+
+
+class ExponentialDecayRefractoriness(_Record):           # spike_train/mod.rs:164-178
+    _defaults = dict(k=10000.0)
+    kind = 1
+
+
 class _SpikeTrain(_Record):
     kind = ST_NONE
+    neural_refractoriness = None            # a DeltaDiracRefractoriness / ExponentialDecayRefractoriness; None: the `k` field, delta dirac
 
     def __init__(self, **kw):
         self.synaptic_neurotransmitters = {}
@@ -587,9 +598,11 @@ def _upload_cells(dn, id, cells):
     if not cells:
         return
     f32 = lambda k: np.array([getattr(c, k) for c in cells], np.float32)
-    for k, a in (("current_voltage", "current_voltage"), ("v_th", "v_th"), ("v_resting", "v_resting"), ("dt", "dt"),
-                 ("k", "neural_refractoriness$k")):
+    for k, a in (("current_voltage", "current_voltage"), ("v_th", "v_th"), ("v_resting", "v_resting"), ("dt", "dt")):
         dn.set_attr(id, a, f32(k))
+    refr = [c.neural_refractoriness for c in cells]
+    dn.set_attr(id, "neural_refractoriness$k", np.array([c.k if r is None else r.k for c, r in zip(cells, refr)], np.float32))
+    dn.set_attr(id, "neural_refractoriness$kind", np.array([0 if r is None else r.kind for r in refr], np.uint32))
     if cells[0].kind == ST_POISSON:
         dn.set_attr(id, "chance_of_firing", f32("chance_of_firing"))
         dn.set_attr(id, "seed", np.array([c.seed for c in cells], np.uint32))

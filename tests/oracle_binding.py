@@ -69,7 +69,7 @@ _FIELDS = [
     ("st_firing_ptr", u32p), ("st_firing_times", f32p), ("st_counter", u32p),
     ("traces", f32p), ("rm_do_modulation", u32p), ("rm_dopamine", f32p), ("rm_tau_d", f32p), ("rm_tau_c", f32p),
     ("rm_a_plus", f32p), ("rm_a_minus", f32p), ("rm_tau_plus", f32p), ("rm_tau_minus", f32p), ("rm_dt", f32p),
-    ("rewards", f32p),
+    ("rewards", f32p), ("st_refractoriness", u32p),
 ]
 
 
@@ -114,6 +114,8 @@ def lib():
         L.snn_o_stdp_delta.restype = C.c_float
         L.snn_o_delta_dirac_effect.argtypes = [C.c_int64, C.c_int32] + [C.c_float] * 4
         L.snn_o_delta_dirac_effect.restype = C.c_float
+        L.snn_o_exponential_decay_effect.argtypes = [C.c_int64, C.c_int32] + [C.c_float] * 4
+        L.snn_o_exponential_decay_effect.restype = C.c_float
         L.snn_o_xorshift32.argtypes = [C.c_uint32]
         L.snn_o_xorshift32.restype = C.c_uint32
         L.snn_o_hash32.argtypes = [C.c_uint64, C.c_uint64]
@@ -183,7 +185,8 @@ _PER_NEURON_K = {"nt_t", "nt_t_max", "nt_clearance", "nt_v_p", "nt_k_p", "nt_fla
                  "rc_g", "rc_e", "rc_mg", "rc_r", "rc_alpha", "rc_beta", "rc_current", "rc_flags",
                  "input_t", "input_count"}
 _PER_CELL = {"st_current_voltage", "st_v_th", "st_v_resting", "st_dt", "st_k", "st_chance_of_firing",
-             "st_rate", "st_step", "st_seed", "st_is_spiking", "st_last_firing_time", "st_lattice", "st_counter"}
+             "st_rate", "st_step", "st_seed", "st_is_spiking", "st_last_firing_time", "st_lattice", "st_counter",
+             "st_refractoriness"}
 _PER_CELL_K = {"st_nt_t", "st_nt_t_max", "st_nt_clearance", "st_nt_v_p", "st_nt_k_p", "st_nt_flags"}
 _PER_LATTICE = {"stdp_a_plus", "stdp_a_minus", "stdp_tau_plus", "stdp_tau_minus", "stdp_dt", "do_plasticity",
                 "lattice_first", "lattice_count", "rm_do_modulation", *RM_DEFAULTS}

@@ -39,7 +39,8 @@ RC_PER_TYPE = {"rc_g": "receptors${T}_g", "rc_e": "receptors${T}_e", "rc_current
                "rc_r": "receptors${T}$r$kinetics$r", "rc_alpha": "receptors${T}$r$kinetics$alpha",
                "rc_beta": "receptors${T}$r$kinetics$beta"}
 CELL_ATTRS = {"st_current_voltage": "current_voltage", "st_v_th": "v_th", "st_v_resting": "v_resting",
-              "st_dt": "dt", "st_k": "neural_refractoriness$k", "st_is_spiking": "is_spiking",
+              "st_dt": "dt", "st_k": "neural_refractoriness$k", "st_refractoriness": "neural_refractoriness$kind",
+              "st_is_spiking": "is_spiking",
               "st_last_firing_time": "last_firing_time"}
 CELL_KIND_ATTRS = {ob.ST_POISSON: {"st_chance_of_firing": "chance_of_firing", "st_seed": "seed"},
                    ob.ST_RATE: {"st_rate": "rate", "st_step": "step"},

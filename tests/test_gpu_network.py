@@ -89,6 +89,8 @@ def test_spike_train_lattice_drives_neurons(snn, st_kind, synapses):
     net["rc_g"][:, 0] = 3.0
     net["st_nt_flags"][:, 0] = 1
     net["st_nt_flags"][::2, 2] = 1          # some cells also release GABA nobody listens to
+    net["st_refractoriness"][1::3] = 1      # every third cell: ExponentialDecayRefractoriness (spike_train/mod.rs:164-178)
+    net["st_k"][1::3] = 200.0
     if st_kind == ob.ST_POISSON:
         net["st_chance_of_firing"] = ob.uniform_array(7, nc, 0.0, 0.05)
         net["st_seed"] = np.arange(100, 100 + nc, dtype=np.uint32)

@@ -57,6 +57,8 @@ def draw(seed):
         net["st_seed"] = rng.integers(1, 2**32 - 1, nc, dtype=np.uint32)
         net["st_chance_of_firing"] = ob.uniform_array(seed + 4, nc, 0.0, 0.08)
         net["st_rate"] = ob.uniform_array(seed + 5, nc, 0.0, 6.0)
+        net["st_refractoriness"][...] = rng.integers(0, 2, nc)        # DeltaDirac / ExponentialDecay per cell
+        net["st_k"] = ob.uniform_array(seed + 11, nc, 20.0, 10000.0)
         if st_kind == ob.ST_PRESET:
             net.set_firing_times([list(rng.uniform(0.3, 5.0, int(k))) for k in rng.integers(0, 4, nc)])
     net.fill_graph(seed + 6, -0.5, 2.0, with_diagonal=bool(rng.integers(0, 2)))

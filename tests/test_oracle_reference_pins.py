@@ -416,3 +416,26 @@ def test_reward_modulated_stdp_hand_derived():
 
 def lib_stdp(tp, tq):
     return ob.lib().snn_o_stdp_delta(tp, tq, 2.0, 2.0, 4.5, 4.5, 0.1)
+
+
+def test_exponential_decay_refractoriness_hand_derived():
+    """ExponentialDecayRefractoriness::get_effect (spike_train/mod.rs:164-178): a * exp((-1 / (k / dt)) * Δ) + v_resting
+    -- the delta-dirac form without the square; chosen per cell, used as the presynaptic value of a fired cell."""
+    L = ob.lib()
+    e = L.snn_o_exponential_decay_effect(14, 10, 30.0, -3.0, 50.0, 0.1)
+    expect = f32(f32(f32(33.0) * f32(ob.expf(f32(f32(-1.0) / f32(f32(50.0) / f32(0.1))) * f32(4.0)))) + f32(-3.0))
+    assert f32(e) == expect
+    assert abs(float(e) - (33.0 * np.exp(-4.0 / 500.0) - 3.0)) < 1e-5
+    net = ob.Net(1, n_cells=2, st_kind=ob.ST_RATE)
+    net["st_k"] = 50.0
+    net["st_v_resting"] = -3.0
+    net["st_last_firing_time"][...] = 10
+    net["st_refractoriness"][1] = 1
+    net["connections"][1:, 0] = 1
+    net["weights"][1:, 0] = 1.0
+    net["gap_conductance"] = 2.0
+    net.clock = 14
+    net.inputs()
+    dd = f32(L.snn_o_delta_dirac_effect(14, 10, 30.0, -3.0, 50.0, 0.1))
+    total = f32(f32(f32(f32(2.0) * dd) * f32(1.0)) + f32(f32(f32(2.0) * f32(e)) * f32(1.0)))
+    assert net["input_current"][0] == f32(total / f32(2.0))
