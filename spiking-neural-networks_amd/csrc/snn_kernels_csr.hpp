@@ -18,6 +18,7 @@
 #include "snn_kernels_inputs.hpp"
 #include "snn_kernels_misc.hpp"
 #include "snn_kernels_reward.hpp"
+#include "snn_kernels_update.hpp"
 
 namespace snn {
 
@@ -40,14 +41,14 @@ struct CsrInputsArgs {
     InputsArgs in;      // presynaptic state pointers / sizes; ld = stride of the partial rows
 };
 
+// The canonical sums of one postsynaptic row (thread q of a wavefront = row q of a SELL slice).  Returns with
+// `sum` / `tsum` holding the second-level sums; rows past n_loc compute on row 0 and are discarded by the caller.
 template <bool ELEC, bool CHEM>
-__global__ __launch_bounds__(256) void k_inputs_csr(const CsrInputsArgs a)
+__device__ __forceinline__ void csr_row_sums(const CsrInputsArgs &a, uint32_t q, float &sum, float (&tsum)[K_TYPES])
 {
     constexpr uint32_t EDGE_BATCH = CHEM ? 4 : 8;
     const InputsArgs &in = a.in;
-    const uint32_t q = blockIdx.x * 256 + threadIdx.x;
     const uint32_t slice = q >> 6;
-    if (slice >= a.g.n_slices) return;                       // whole wavefront
     const uint32_t s0 = a.g.slice_ptr[slice];
     const uint32_t width = (a.g.slice_ptr[slice + 1] - s0) >> 6;   // wave-uniform
     const uint32_t base = s0 + (q & 63u);
@@ -57,9 +58,12 @@ __global__ __launch_bounds__(256) void k_inputs_csr(const CsrInputsArgs a)
     const float vq = ELEC ? in.xbuf[in.xl.at(in.q0 + qq, PLANE_V)] : 0.0f;
     const float gq = ELEC ? in.gap_conductance[in.q0 + qq] : 0.0f;
 
-    float sum = 0.0f, part = 0.0f;
-    float tsum[K_TYPES] = {0.0f, 0.0f, 0.0f}, tpart[K_TYPES] = {0.0f, 0.0f, 0.0f};
+    float part = 0.0f;
+    float tpart[K_TYPES] = {0.0f, 0.0f, 0.0f};
     uint32_t cur_chunk = 0xFFFFFFFFu;
+    sum = 0.0f;
+#pragma unroll
+    for (int kk = 0; kk < K_TYPES; ++kk) tsum[kk] = 0.0f;
 
     for (uint32_t k0 = 0; k0 < width; k0 += EDGE_BATCH) {
         uint32_t p[EDGE_BATCH];
@@ -133,13 +137,54 @@ __global__ __launch_bounds__(256) void k_inputs_csr(const CsrInputsArgs a)
 #pragma unroll
         for (int kk = 0; kk < K_TYPES; ++kk) tsum[kk] += tpart[kk];
     }
-    if (!row_valid) return;
     // Chunks without edges contribute +0.0f partials in the dense form; x + 0.0f == x for every x this sum
     // can hold (it starts at +0.0f, so it is never -0.0f): skipping them is exact.
+}
+
+template <bool ELEC, bool CHEM>
+__global__ __launch_bounds__(256) void k_inputs_csr(const CsrInputsArgs a)
+{
+    const InputsArgs &in = a.in;
+    const uint32_t q = blockIdx.x * 256 + threadIdx.x;
+    if ((q >> 6) >= a.g.n_slices) return;                    // whole wavefront
+    float sum, tsum[K_TYPES];
+    csr_row_sums<ELEC, CHEM>(a, q, sum, tsum);
+    if (q >= a.g.n_loc) return;
     if (ELEC) in.part_i[q] = sum;
     if (CHEM) {
 #pragma unroll
         for (int kk = 0; kk < K_TYPES; ++kk) in.part_t[(size_t)kk * in.ld + q] = tsum[kk];
+    }
+}
+
+// Sums held in registers (the one-launch sparse step)
+struct RegisterSums {
+    float i, t[K_TYPES];
+    __device__ __forceinline__ float elec() const { return i; }
+    __device__ __forceinline__ float chem(int k) const { return t[k]; }
+};
+
+// Inputs + neuron update of an unsharded sparse handle in ONE launch: row thread = neuron thread, so the sums never
+// leave registers.  Other rows may still be gathering S(t) while a neuron writes S(t+1): as in k_step_resident the
+// exchanged state is read from a shadow copy (in.xbuf = up.n.xbuf) and written to the exchange buffer and the other
+// shadow (up.xout / up.xout2).
+struct CsrStepArgs {
+    CsrInputsArgs c;
+    UpdateArgs up;
+};
+
+template <int MODEL, bool ELEC, bool CHEM>
+__global__ __launch_bounds__(256) void k_step_csr(const CsrStepArgs a)
+{
+    const uint32_t q = blockIdx.x * 256 + threadIdx.x;
+    if ((q >> 6) >= a.c.g.n_slices) return;                  // whole wavefront
+    RegisterSums s;
+    csr_row_sums<ELEC, CHEM>(a.c, q, s.i, s.t);
+    uint32_t spike = 0;
+    if (q < a.c.g.n_loc) spike = update_neuron<MODEL>(a.up, q, s);
+    if (a.up.spike_row) {
+        const unsigned long long word = __ballot(spike != 0);
+        if ((threadIdx.x & 63u) == 0) a.up.spike_row[(a.up.q0 + q) >> 6] = word;
     }
 }
 

@@ -319,7 +319,9 @@ bool fused_step_applies(const snn_network *net)
     return fused_step_possible(net) && !net->local_inputs_done;
 }
 
-int launch_step_resident(snn_network *net)
+// Arguments of a one-launch step: S(t) is read from the current shadow of the exchange buffer, S(t+1) goes to the
+// exchange buffer and to the other shadow (flipped by the caller after the launch).
+int fused_step_args(snn_network *net, InputsArgs &a, UpdateArgs &u)
 {
     const size_t xelems = (size_t)net->xl.n_shards * NUM_PLANES * net->xl.stride;
     if (!net->shadow[0]) {
@@ -335,8 +337,7 @@ int launch_step_resident(snn_network *net)
         net->shadow_valid = true;
     }
     float *cur = net->shadow[net->shadow_cur], *next = net->shadow[net->shadow_cur ^ 1];
-    ResidentArgs r{};
-    InputsArgs &a = r.in;
+    a = InputsArgs{};
     a.chunk_first = 0; a.hole_begin = net->n_chunks; a.hole_count = 0;
     a.W = net->W; a.ld = net->ld; a.n_loc = net->n_loc; a.q0 = net->q0; a.n_neurons = net->nn; a.n_tot = net->n_tot;
     a.xbuf = cur; a.xl = net->xl; a.gap_conductance = net->na.gap_conductance;
@@ -344,7 +345,7 @@ int launch_step_resident(snn_network *net)
     a.st_nt_t = net->ca.nt_t; a.st_nt_flags = net->ca.nt_flags; a.c_pad = net->c_pad;
     a.nt_flags = net->na.nt_flags; a.n_pad = net->n_pad;
     a.part_i = net->part_i; a.part_t = net->part_t; a.n_chunks = net->n_chunks;
-    UpdateArgs &u = r.up;
+    u = UpdateArgs{};
     u.n = net->na;
     u.n.xbuf = cur;
     u.part_i = net->part_i; u.part_t = net->part_t; u.n_in = net->n_in; u.tcount = net->tcount;
@@ -355,21 +356,47 @@ int launch_step_resident(snn_network *net)
     u.spike_row = (record_now(net) && net->want_raster && net->raster) ? net->raster + (size_t)net->hist_steps * (net->n_pad / 64) : nullptr;
     u.spike_counts = net->want_counts ? net->spike_counts : nullptr;
     u.xout = net->xbuf; u.xout2 = next;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (net->profile) {
-        if (net->ev_used == net->ev_pool.size()) {
-            hipEvent_t x, y;
-            HIP_TRY(hipEventCreate(&x), SNN_ERR_QUEUE);
-            HIP_TRY(hipEventCreate(&y), SNN_ERR_QUEUE);
-            net->ev_pool.emplace_back(x, y);
-        }
-        e0 = net->ev_pool[net->ev_used].first;
-        e1 = net->ev_pool[net->ev_used].second;
-        net->ev_counts.resize(net->ev_pool.size(), 1);
-        net->ev_counts[net->ev_used] = 1;
-        ++net->ev_used;
-        HIP_TRY(hipEventRecord(e0, net->stream), SNN_ERR_QUEUE);
+    return SNN_OK;
+}
+
+// HIP events around the launch that streams the graph (snn_profile_*)
+int profile_open(snn_network *net, hipEvent_t *e1)
+{
+    *e1 = nullptr;
+    if (!net->profile) return SNN_OK;
+    if (net->ev_used == net->ev_pool.size()) {
+        hipEvent_t x, y;
+        HIP_TRY(hipEventCreate(&x), SNN_ERR_QUEUE);
+        HIP_TRY(hipEventCreate(&y), SNN_ERR_QUEUE);
+        net->ev_pool.emplace_back(x, y);
     }
+    hipEvent_t e0 = net->ev_pool[net->ev_used].first;
+    *e1 = net->ev_pool[net->ev_used].second;
+    net->ev_counts.resize(net->ev_pool.size(), 1);
+    net->ev_counts[net->ev_used] = 1;
+    ++net->ev_used;
+    HIP_TRY(hipEventRecord(e0, net->stream), SNN_ERR_QUEUE);
+    return SNN_OK;
+}
+
+#define SNN_FOR_MODEL(MACRO)                                                                                         \
+    switch (net->model) {                                                                                            \
+    case 1: MACRO(1); break;                                                                                         \
+    case 2: MACRO(2); break;                                                                                         \
+    case 3: MACRO(3); break;                                                                                         \
+    case 4: MACRO(4); break;                                                                                         \
+    case 5: MACRO(5); break;                                                                                         \
+    case 6: MACRO(6); break;                                                                                         \
+    case 7: MACRO(7); break;                                                                                         \
+    default: MACRO(0); break;                                                                                        \
+    }
+
+int launch_step_resident(snn_network *net)
+{
+    ResidentArgs r{};
+    TRY(fused_step_args(net, r.in, r.up));
+    hipEvent_t e1 = nullptr;
+    TRY(profile_open(net, &e1));
     const dim3 grid((net->n_loc + 63) / 64), block(64 * net->n_chunks);
 #define SNN_RESIDENT(M)                                                                                              \
     do {                                                                                                             \
@@ -377,19 +404,38 @@ int launch_step_resident(snn_network *net)
         else if (net->electrical) hipLaunchKernelGGL((k_step_resident<M, true, false>), grid, block, 0, net->stream, r);             \
         else hipLaunchKernelGGL((k_step_resident<M, false, true>), grid, block, 0, net->stream, r);                                  \
     } while (0)
-    switch (net->model) {
-    case 1: SNN_RESIDENT(1); break;
-    case 2: SNN_RESIDENT(2); break;
-    case 3: SNN_RESIDENT(3); break;
-    case 4: SNN_RESIDENT(4); break;
-    case 5: SNN_RESIDENT(5); break;
-    case 6: SNN_RESIDENT(6); break;
-    case 7: SNN_RESIDENT(7); break;
-    default: SNN_RESIDENT(0); break;
-    }
+    SNN_FOR_MODEL(SNN_RESIDENT)
 #undef SNN_RESIDENT
     HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
-    if (net->profile) HIP_TRY(hipEventRecord(e1, net->stream), SNN_ERR_QUEUE);
+    if (e1) HIP_TRY(hipEventRecord(e1, net->stream), SNN_ERR_QUEUE);
+    net->shadow_cur ^= 1;
+    return SNN_OK;
+}
+
+// Unsharded sparse handles: row sums + neuron update in one launch (k_step_csr).
+bool fused_csr_step_applies(const snn_network *net)
+{
+    return net->fused_step && net->csr && net->csr_ptr && net->xl.n_shards == 1 && net->n_loc && !net->local_inputs_done;
+}
+
+int launch_step_csr(snn_network *net)
+{
+    CsrStepArgs c{};
+    TRY(fused_step_args(net, c.c.in, c.up));
+    c.c.g = csr_graph(net);
+    hipEvent_t e1 = nullptr;
+    TRY(profile_open(net, &e1));
+    const dim3 grid((((net->n_loc + 63) / 64) * 64 + 255) / 256), block(256);
+#define SNN_CSR_STEP(M)                                                                                              \
+    do {                                                                                                             \
+        if (net->electrical && net->chemical) hipLaunchKernelGGL((k_step_csr<M, true, true>), grid, block, 0, net->stream, c);  \
+        else if (net->electrical) hipLaunchKernelGGL((k_step_csr<M, true, false>), grid, block, 0, net->stream, c);             \
+        else hipLaunchKernelGGL((k_step_csr<M, false, true>), grid, block, 0, net->stream, c);                                  \
+    } while (0)
+    SNN_FOR_MODEL(SNN_CSR_STEP)
+#undef SNN_CSR_STEP
+    HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+    if (e1) HIP_TRY(hipEventRecord(e1, net->stream), SNN_ERR_QUEUE);
     net->shadow_cur ^= 1;
     return SNN_OK;
 }
@@ -398,6 +444,7 @@ int launch_step_resident(snn_network *net)
 int step_begin(snn_network *net)
 {
     if (fused_step_applies(net)) return launch_step_resident(net);
+    if (fused_csr_step_applies(net)) return launch_step_csr(net);
     TRY(launch_inputs(net, net->local_inputs_done ? INPUTS_REMOTE : INPUTS_ALL));
     net->local_inputs_done = false;
     TRY(launch_update(net));

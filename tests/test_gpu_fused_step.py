@@ -1,5 +1,5 @@
-"""The one-launch step of small dense lattices (k_step_resident: n_tot <= 1024 presynaptic rows, unsharded handle)
-against the two-kernel step (k_inputs_dense + k_update, forced with SNN_AMD_FUSED_STEP=0) and the oracle: all three
+"""The one-launch steps (k_step_resident: small dense lattices, n_tot <= 1024 presynaptic rows; k_step_csr: sparse
+handles; both unsharded) against the two-kernel step (k_inputs_dense + k_update, forced with SNN_AMD_FUSED_STEP=0) and the oracle: all three
 bit-identical, for every model family, synapse kind, spike-train rows, ragged sizes and split runs.  Every other
 small-lattice GPU test already runs through the fused step; this file keeps the two-kernel path covered at the
 same sizes."""
@@ -41,11 +41,11 @@ def build(model, electrical, chemical, lattices, st, seed):
     return net
 
 
-def run_device(snn, net, steps, fused):
+def run_device(snn, net, steps, fused, csr=False):
     old = os.environ.get("SNN_AMD_FUSED_STEP")
     os.environ["SNN_AMD_FUSED_STEP"] = "1" if fused else "0"
     try:
-        dn = parity.device_from_oracle(snn, net)
+        dn = parity.device_from_oracle(snn, net, csr=csr)
     finally:
         if old is None:
             del os.environ["SNN_AMD_FUSED_STEP"]
@@ -54,7 +54,8 @@ def run_device(snn, net, steps, fused):
     dn.set_history(voltage=True, spikes=True)
     dn.run(steps // 3)
     dn.run(steps - steps // 3)
-    out = {"state": parity.pull_state(dn, net), "graph": dn.get_graph_rows(0, net.n_tot)}
+    out = {"state": parity.pull_state(dn, net),
+           "graph": (dn.get_graph_csr(),) if csr else dn.get_graph_rows(0, net.n_tot)}
     for i, _, _ in net.layout.lattices:
         out[("v", i)] = dn.voltage_history(i)
         out[("s", i)] = dn.spike_history(i)
@@ -81,6 +82,30 @@ def test_fused_step_equals_two_kernel_step_and_oracle(snn, model, electrical, ch
     steps = 300 if (model != ob.HH and (chemical or model != ob.IZHIKEVICH)) else 900
     a = run_device(snn, net, steps, fused=True)
     b = run_device(snn, net, steps, fused=False)
+    for key in a:
+        if key in ("state", "graph"):
+            continue
+        assert np.array_equal(parity.bits(a[key]), parity.bits(b[key])), key
+    for name in a["state"]:
+        assert np.array_equal(parity.bits(a["state"][name]), parity.bits(b["state"][name])), name
+    assert np.array_equal(parity.bits(a["graph"][0]), parity.bits(b["graph"][0]))
+    net.run(steps, voltage_history=True, spike_history=True)
+    parity.assert_state_equal(net, a["state"])
+    rng = net.layout.ranges()
+    for i, _, _ in net.layout.lattices:
+        first, count, _ = rng[i]
+        assert np.array_equal(a[("s", i)], net.spike_history[:, first:first + count])
+        assert np.array_equal(parity.bits(a[("v", i)]), parity.bits(net.voltage_history[:, first:first + count]))
+    assert net.spike_history.sum() > 0
+
+
+@pytest.mark.parametrize("model,electrical,chemical,lattices,st,seed", [CASES[4], CASES[5], CASES[7]])
+def test_fused_sparse_step_equals_two_kernel_step_and_oracle(snn, model, electrical, chemical, lattices, st, seed):
+    """Sparse (SELL-64) handles: k_step_csr (row sums + neuron update in one launch) against k_inputs_csr + k_update."""
+    net = build(model, electrical, chemical, lattices, st, seed)
+    steps = 300
+    a = run_device(snn, net, steps, fused=True, csr=True)
+    b = run_device(snn, net, steps, fused=False, csr=True)
     for key in a:
         if key in ("state", "graph"):
             continue
