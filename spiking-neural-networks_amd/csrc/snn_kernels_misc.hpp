@@ -93,6 +93,7 @@ struct SpikeTrainArgs {
     long long step_offset;            // steps done since then
     long long view_clock;             // network clock of the NEXT input calculation
     float *vhist_row;                 // [c_pad] or null
+    int has_nt;                       // some cell releases a neurotransmitter (else the flag planes are not read)
 };
 
 __global__ __launch_bounds__(256) void k_spike_trains(const SpikeTrainArgs a)
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(256) void k_spike_trains(const SpikeTrainArgs a)
 #pragma unroll
         for (int k = 0; k < K_TYPES; ++k) {
             const size_t i = (size_t)k * c.c_pad + s;
-            if (!c.nt_flags[i]) continue;
+            if (!a.has_nt || !c.nt_flags[i]) continue;
             // spike trains release on their CURRENT spike flag (spike_train/mod.rs:363-365)
             c.nt_t[i] = nt_apply(a.nt_kind, c.nt_t[i], c.nt_t_max[i], c.nt_clearance[i], c.nt_v_p[i], c.nt_k_p[i],
                                  v, spike, c.dt[s]);

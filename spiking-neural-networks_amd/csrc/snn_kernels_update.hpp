@@ -32,6 +32,7 @@ struct UpdateArgs {
     // (= n.xbuf on the two-kernel path, which updates in place); the fused small-lattice step reads S(t) from a
     // shadow copy (n.xbuf) while it writes S(t+1) to the exchange buffer and to the other shadow (`xout2`).
     float *xout, *xout2;
+    int has_nt;                 // some neuron of the handle releases a neurotransmitter (else the flag planes are not read)
 };
 
 // Second level of the canonical sum: chunk partials added in ascending chunk order from 0.0f.  The loads of
@@ -57,6 +58,7 @@ __device__ __forceinline__ float combine_partials(const float *p, uint32_t n_chu
 __device__ __forceinline__ void neuron_nt_update(const UpdateArgs &a, uint32_t q, float voltage,
                                                  uint32_t spiking_prev, float dt)
 {
+    if (!a.has_nt) return;
 #pragma unroll
     for (int k = 0; k < K_TYPES; ++k) {
         const size_t i = (size_t)k * a.n.n_pad + q;

@@ -79,6 +79,8 @@ struct snn_network {
     std::vector<float> stdp_host;           // [n_lattices][5]
     std::vector<uint32_t> plast_host;       // [n_lattices]
     bool any_plasticity = false;
+    std::map<uint32_t, bool> lattice_has_nt;    // lattice id -> some neurotransmitters$flags entry is set
+    bool any_nt_neurons = false, any_nt_cells = false;
     // reward modulation (RewardModulatedLattice): per-lattice modulator table + per-edge trace, allocated on first use
     bool any_modulation = false;
     std::vector<float> rm_host;            // [n_lattices][RM_STRIDE]
@@ -572,6 +574,19 @@ int attr_io(snn_network *net, uint32_t id, const char *name, AttrType type, void
         }
     }
     if (set && a.dirties) net->counts_dirty = true;
+    if (set && a.dirties && type == T_U32 && typed) {
+        // "neurotransmitters$flags": remember which lattices release anything at all, so that networks without
+        // neurotransmitters do not read three flag planes per neuron / cell and step
+        const uint32_t *h = static_cast<const uint32_t *>(host);
+        bool any = false;
+        for (size_t i = 0; i < count && !any; ++i) any = h[i] != 0;
+        net->lattice_has_nt[id] = any;
+        net->any_nt_neurons = net->any_nt_cells = false;
+        for (const auto &kv : net->lattice_has_nt) {
+            const LatticeInfo *li = find_lattice(net, kv.first);
+            if (kv.second && li) (li->spike_train ? net->any_nt_cells : net->any_nt_neurons) = true;
+        }
+    }
     return SNN_OK;
 }
 

@@ -13,6 +13,7 @@ int launch_spike_trains(snn_network *net, int iterate, long long step_offset, lo
     SpikeTrainArgs a{};
     a.c = net->ca; a.n_cells = net->nc; a.st_kind = net->st_kind; a.nt_kind = net->nt_kind;
     a.iterate = iterate; a.lattice_clock = net->st_clock_dev; a.step_offset = step_offset;
+    a.has_nt = net->any_nt_cells ? 1 : 0;
     a.view_clock = view_clock;
     a.vhist_row = (iterate && record_now(net) && net->want_vhist && net->st_vhist) ? net->st_vhist + (size_t)net->hist_steps * net->c_pad : nullptr;
     hipLaunchKernelGGL(k_spike_trains, dim3((net->nc + 255) / 256), dim3(256), 0, net->stream, a);
@@ -146,6 +147,7 @@ int launch_update(snn_network *net)
     a.spike_row = (record_now(net) && net->want_raster && net->raster) ? net->raster + (size_t)net->hist_steps * (net->n_pad / 64) : nullptr;
     a.spike_counts = net->want_counts ? net->spike_counts : nullptr;
     a.xout = net->xbuf; a.xout2 = nullptr;
+    a.has_nt = net->any_nt_neurons ? 1 : 0;
     net->shadow_valid = false;            // the exchange buffer moves on without the shadows
     dim3 grid((net->ld + 255) / 256);
     switch (net->model) {
@@ -356,6 +358,7 @@ int fused_step_args(snn_network *net, InputsArgs &a, UpdateArgs &u)
     u.spike_row = (record_now(net) && net->want_raster && net->raster) ? net->raster + (size_t)net->hist_steps * (net->n_pad / 64) : nullptr;
     u.spike_counts = net->want_counts ? net->spike_counts : nullptr;
     u.xout = net->xbuf; u.xout2 = next;
+    u.has_nt = net->any_nt_neurons ? 1 : 0;
     return SNN_OK;
 }
 
