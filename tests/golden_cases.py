@@ -78,12 +78,79 @@ def spike_trains_rate():
     return net, 1000
 
 
+def adaptive_exp_lif_3x3():
+    """AdaptiveExpLeakyIntegrateAndFireNeuron (integrate_and_fire/mod.rs:1051-1155), heterogeneous slope / beta"""
+    net = parity.make_oracle(parity.Layout([(0, 3, 3)]), model=ob.ADAPTIVE_EXP_LIF)
+    net["current_voltage"] = ob.uniform_array(3, 9, -75.0, -56.0)
+    net["gap_conductance"] = 3.0
+    net["leak_constant"] = 1.0
+    net["c_m"] = 1.0
+    net["v_reset"] = -73.0
+    net["tref"] = 0.7
+    net["adp_beta"] = ob.uniform_array(4, 9, 1.0, 4.0)
+    net["slope_factor"] = ob.uniform_array(5, 9, 0.5, 3.0)
+    net.fill_graph(6, 0.5, 1.5)
+    return net, 600
+
+
+def leaky_izhikevich_3x3():
+    """LeakyIzhikevichNeuron (integrate_and_fire/mod.rs:1270-1356)"""
+    net = parity.make_oracle(parity.Layout([(0, 3, 3)]), model=ob.LEAKY_IZHIKEVICH)
+    net["current_voltage"] = ob.uniform_array(7, 9, -65.0, 30.0)
+    net["gap_conductance"] = 10.0
+    net["w_value"] = 0.5
+    net.fill_graph(8, 0.5, 1.5)
+    return net, 600
+
+
+def preset_exponential_decay_kinetics():
+    """PresetSpikeTrain cells (spike_train/mod.rs:753-833, one with ExponentialDecayRefractoriness :164-178) into two
+    neurons with ExponentialDecay neurotransmitter / receptor kinetics (iterate_and_spike/mod.rs:323-366, 497-533)"""
+    net = parity.make_oracle(parity.Layout([(1, 1, 2)], [(0, 1, 3)]), st_kind=ob.ST_PRESET,
+                             nt_kind=ob.NT_EXPONENTIAL_DECAY, rc_kind=ob.RC_EXPONENTIAL_DECAY, chemical=True)
+    net["gap_conductance"] = 10.0
+    net["nt_flags"][:, 0] = 1
+    net["nt_clearance"][:, 0] = 3.0
+    net["st_nt_flags"][:, 0] = 1
+    net["rc_flags"][:, 0] = 1
+    net["rc_g"][:, 0] = 3.0
+    net["rc_beta"][:, 0] = 1.5
+    net["st_refractoriness"][1] = 1
+    net["st_k"][1] = 200.0
+    net.set_firing_times([[5.0], [6.0, 2.5], [1.5, 2.0, 4.0]])
+    net["connections"][0, 1] = net["connections"][1, 0] = 1
+    net["weights"][0, 1] = net["weights"][1, 0] = 1.0
+    net["connections"][2:, :] = 1
+    net["weights"][2:, :] = 1.5
+    return net, 1200
+
+
+def reward_modulated_4x4():
+    """RewardModulatedLattice + RewardModulatedSTDP / TraceRSTDP (neuron/mod.rs:2719-3417, plasticity/mod.rs:126-242),
+    constant dopamine (run without reward), deferred form"""
+    net = parity.make_oracle(parity.Layout([(0, 4, 4)]))
+    net["current_voltage"] = ob.uniform_array(1, 16, -65.0, 30.0)
+    net["gap_conductance"] = 10.0
+    net.fill_graph(2, 0.5, 1.5)
+    net["rm_do_modulation"] = 1
+    net["rm_dopamine"] = 0.02
+    net["rm_tau_c"] = 0.05
+    net["rm_a_plus"] = 0.01
+    net["rm_a_minus"] = 0.01
+    net["traces"][...] = 0.001 * net["connections"]
+    return net, 900
+
+
 CASES = {f.__name__: f for f in (izh_4x4_ones, izh_4x4_random, izh_32x32_random, stdp_3_neurons, hh_pair, ampa_pair,
-                                 spike_trains_poisson, spike_trains_rate)}
+                                 spike_trains_poisson, spike_trains_rate, adaptive_exp_lif_3x3, leaky_izhikevich_3x3,
+                                 preset_exponential_decay_kinetics, reward_modulated_4x4)}
 
 EXTRA = {"hh_pair": ("m_state", "h_state", "n_state"), "stdp_3_neurons": ("weights",),
          "ampa_pair": ("nt_t", "rc_r", "rc_current"), "spike_trains_poisson": ("st_seed", "st_last_firing_time"),
-         "spike_trains_rate": ("st_step", "st_last_firing_time")}
+         "spike_trains_rate": ("st_step", "st_last_firing_time"),
+         "adaptive_exp_lif_3x3": ("w_value", "refractory_count"), "leaky_izhikevich_3x3": ("w_value",),
+         "preset_exponential_decay_kinetics": ("nt_t", "rc_r", "st_step", "st_counter", "st_last_firing_time"),
+         "reward_modulated_4x4": ("weights", "traces")}
 
 
 def outputs(name, net, steps):

@@ -17,6 +17,11 @@ def test_hip_matches_golden(snn, name):
     net, steps = golden_cases.CASES[name]()          # inputs only; the oracle is not stepped
     want = np.load(os.path.join(GOLDEN, name + ".npz"))
     dn = parity.device_from_oracle(snn, net)
+    for slot, (i, _, _) in enumerate(net.layout.lattices):
+        if net["rm_do_modulation"][slot]:
+            dn.set_reward_modulator(i, *(float(net[k][slot]) for k in (
+                "rm_dopamine", "rm_tau_d", "rm_tau_c", "rm_a_plus", "rm_a_minus", "rm_tau_plus", "rm_tau_minus", "rm_dt")))
+            dn.set_trace_rows(0, net["traces"])
     dn.set_history(voltage=True, spikes=True)
     dn.run(steps)
     lat = net.layout.lattices[0][0]
@@ -34,6 +39,8 @@ def test_hip_matches_golden(snn, name):
         if k == "weights":
             w, c = dn.get_graph_rows(0, net.n_tot)
             assert w.tobytes() == np.where(net["connections"] != 0, want[k], np.float32(0)).astype(np.float32).tobytes()
+        elif k == "traces":
+            assert dn.get_trace_rows(0, net.n_tot).tobytes() == want[k].tobytes()
         else:
             assert st[k].tobytes() == want[k].tobytes(), k
     dn.close()
