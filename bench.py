@@ -181,6 +181,8 @@ def main():
                     help="do not bracket k_inputs_dense with HIP events (roofline.achieved is then null)")
     args = ap.parse_args()
 
+    # dmabuf IPC is the only mode the host driver supports (RCCL across processes); exported by the harness, kept here
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import numpy as np
     import torch
     import snn_amd
