@@ -82,7 +82,10 @@ typedef enum {
      * AdaptiveLeakyIntegrateAndFireNeuron integrate_and_fire/mod.rs:918-1049 (alpha, beta, w_value + the LIF set),
      * AdaptiveExpLeakyIntegrateAndFireNeuron :1051-1155 (+ slope_factor),
      * LeakyIzhikevichNeuron :1270-1356 (the Izhikevich set + e_l) */
-    SNN_MODEL_ADAPTIVE_LIF = 5, SNN_MODEL_ADAPTIVE_EXP_LIF = 6, SNN_MODEL_LEAKY_IZHIKEVICH = 7
+    SNN_MODEL_ADAPTIVE_LIF = 5, SNN_MODEL_ADAPTIVE_EXP_LIF = 6, SNN_MODEL_LEAKY_IZHIKEVICH = 7,
+    /* BCMIzhikevichNeuron :1358-1518: Izhikevich + BCMActivity bookkeeping (attributes average_activity,
+     * current_activity, firing_rate_clock, firing_rate_window f32; period, num_spikes u32) */
+    SNN_MODEL_BCM_IZHIKEVICH = 8
 } snn_model;
 /* NeurotransmitterKinetics: Approximate iterate_and_spike/mod.rs:161-205, Destexhe :122-159 */
 /* DiscreteSpikeNeurotransmitter :287-317; ExponentialDecayNeurotransmitter :323-366 (attribute
@@ -95,7 +98,8 @@ typedef enum { SNN_RC_APPROXIMATE = 0, SNN_RC_DESTEXHE = 1, SNN_RC_EXPONENTIAL_D
 /* PresetSpikeTrain :753-833 (attributes internal_clock, counter; firing times via snn_set_firing_times).
  * NeuralRefractoriness of a cell: attribute neural_refractoriness$kind (u32; 0 DeltaDirac :79-88, the default,
  * 1 ExponentialDecay :164-178), decay constant neural_refractoriness$k. */
-typedef enum { SNN_ST_NONE = 0, SNN_ST_POISSON = 1, SNN_ST_RATE = 2, SNN_ST_PRESET = 3 } snn_spike_train_model;
+/* BCMPoissonNeuron :835-970: the Poisson cell + the same activity attributes */
+typedef enum { SNN_ST_NONE = 0, SNN_ST_POISSON = 1, SNN_ST_RATE = 2, SNN_ST_PRESET = 3, SNN_ST_BCM_POISSON = 4 } snn_spike_train_model;
 
 /* ---- construction (≙ from_lattice / from_network) -------------------------------------- */
 
@@ -214,6 +218,13 @@ int snn_history_steps(const snn_network_t *net, uint64_t *steps);
 /* [steps][rows*cols] of lattice `id`, oldest step first */
 int snn_get_voltage_history(snn_network_t *net, uint32_t id, float *dst, size_t count);
 int snn_get_spike_history(snn_network_t *net, uint32_t id, uint8_t *dst, size_t count);
+
+/* BCM rule for lattice `id` instead of STDP (plasticity/mod.rs:72-116; defaults decay 0.1, average_scalar 0.1, dt 0.1):
+ * same gating and edge visits as STDP (`do_update` = the neuron spiked), per visit
+ * w += (post.activity * (post.activity - post.average_activity / average_scalar) * pre.activity - decay * w) * dt.
+ * Needs SNN_MODEL_BCM_IZHIKEVICH (and SNN_ST_BCM_POISSON for spike-train presynaptic cells); unsharded handles.
+ * snn_set_plasticity on the same lattice switches back to STDP. */
+int snn_set_bcm(snn_network_t *net, uint32_t id, float decay, float average_scalar, float dt, int do_plasticity);
 
 /* ---- reward modulation (≙ RewardModulatedLattice neuron/mod.rs:2719-3417) ---------------- */
 

@@ -339,6 +339,22 @@ static inline float receptor_currents(const snn_o_net *n, uint32_t q)
     return total * (n->dt[q] / n->c_m[q]);
 }
 
+/* The firing-rate bookkeeping both BCM cells share (BCMIzhikevichNeuron::iterate_and_spike
+ * integrate_and_fire/mod.rs:1458-1469 / :1484-1495, BCMPoissonNeuron::iterate spike_train/mod.rs:943-954): num_spikes
+ * is never reset by the reference.  `rate_per_dt`: the electrical-only neuron path and the spike train divide by
+ * (window * dt), the neuron's neurotransmission path by the window alone. */
+static inline void bcm_window_update(float *clock, float window, float dt, uint32_t num_spikes, uint32_t period,
+                                     float *current_activity, float *average_activity, int rate_per_dt)
+{
+    *clock += dt;
+    if (*clock >= window) {
+        *clock = 0.0f;
+        *current_activity = rate_per_dt ? (float)num_spikes / (window * dt) : (float)num_spikes / window;
+        *average_activity -= *average_activity / (float)period;
+        *average_activity += *current_activity / (float)period;
+    }
+}
+
 /* IzhikevichNeuron, integrate_and_fire/mod.rs:1222-1267 via impl_iterate_and_spike! :217-255 */
 static uint32_t step_izhikevich(snn_o_net *n, uint32_t q)
 {
@@ -624,6 +640,13 @@ void snn_o_update_neurons_range(snn_o_net *n, uint32_t q0, uint32_t q1)
         case SNN_O_ADAPTIVE_LIF: spike = step_adaptive(n, q, 0); break;
         case SNN_O_ADAPTIVE_EXP_LIF: spike = step_adaptive(n, q, 1); break;
         case SNN_O_LEAKY_IZHIKEVICH: spike = step_leaky_izhikevich(n, q); break;
+        case SNN_O_BCM_IZHIKEVICH:
+            /* activity bookkeeping first (previous step's spike flag), then the Izhikevich step */
+            if (n->is_spiking[q]) n->bcm_num_spikes[q] += 1;
+            bcm_window_update(&n->bcm_clock[q], n->bcm_window[q], n->dt[q], n->bcm_num_spikes[q], n->bcm_period[q],
+                              &n->bcm_current_activity[q], &n->bcm_average_activity[q], !n->chemical);
+            spike = step_izhikevich(n, q);
+            break;
         default:        spike = step_izhikevich(n, q); break;
         }
         n->is_spiking[q] = spike;
@@ -642,6 +665,15 @@ void snn_o_update_neurons_range(snn_o_net *n, uint32_t q0, uint32_t q1)
 void snn_o_plasticity(snn_o_net *n) { snn_o_plasticity_cols(n, 0, n->n_neurons); }
 
 /* the same, touching only weights whose postsynaptic column lies in [c0, c1) (one shard's columns) */
+/* BCM::update_weight, plasticity/mod.rs:102-107 */
+static inline float bcm_weight(const snn_o_net *n, uint32_t l, float w, float pre_activity, uint32_t post)
+{
+    float sliding_threshold = n->bcm_average_activity[post] / n->bcm_average_scalar[l];
+    float activity_term = n->bcm_current_activity[post] * (n->bcm_current_activity[post] - sliding_threshold);
+    float weight_decay = n->bcm_decay[l] * w;
+    return w + (activity_term * pre_activity - weight_decay) * n->bcm_dt[l];
+}
+
 void snn_o_plasticity_cols(snn_o_net *n, uint32_t c0, uint32_t c1)
 {
     const uint32_t nn = n->n_neurons;
@@ -656,6 +688,11 @@ void snn_o_plasticity_cols(snn_o_net *n, uint32_t c0, uint32_t c1)
             for (uint32_t p = 0; p < n_tot; ++p) {
                 size_t i = (size_t)p * nn + j;
                 if (!n->connections[i]) continue;
+                if (n->plasticity_kind && n->plasticity_kind[l]) {
+                    float pre = (p < nn) ? n->bcm_current_activity[p] : n->st_bcm_current_activity[p - nn];
+                    n->weights[i] = bcm_weight(n, l, n->weights[i], pre, j);
+                    continue;
+                }
                 int32_t tp = (p < nn) ? n->last_firing_time[p] : n->st_last_firing_time[p - nn];
                 n->weights[i] += snn_o_stdp_delta(tp, n->last_firing_time[j], n->stdp_a_plus[l],
                                                   n->stdp_a_minus[l], n->stdp_tau_plus[l],
@@ -667,6 +704,10 @@ void snn_o_plasticity_cols(snn_o_net *n, uint32_t c0, uint32_t c1)
             size_t i = (size_t)j * nn + r;
             if (!n->connections[i]) continue;
             uint32_t l = n->lattice[r];
+            if (n->plasticity_kind && n->plasticity_kind[l]) {
+                n->weights[i] = bcm_weight(n, l, n->weights[i], n->bcm_current_activity[j], r);
+                continue;
+            }
             n->weights[i] += snn_o_stdp_delta(n->last_firing_time[j], n->last_firing_time[r],
                                               n->stdp_a_plus[l], n->stdp_a_minus[l],
                                               n->stdp_tau_plus[l], n->stdp_tau_minus[l], n->stdp_dt[l]);
@@ -731,7 +772,7 @@ void snn_o_spike_trains(snn_o_net *n)
 {
     for (uint32_t s = 0; s < n->n_cells; ++s) {
         uint32_t spike;
-        if (n->st_kind == SNN_O_ST_POISSON) {
+        if (n->st_kind == SNN_O_ST_POISSON || n->st_kind == SNN_O_ST_BCM_POISSON) {
             uint32_t new_seed = snn_o_xorshift32(n->st_seed[s]);
             n->st_seed[s] = new_seed;
             float random_number = (float)new_seed / 4294967296.0f;   /* (float)seed / 0xFFFFFFFF */
@@ -754,6 +795,14 @@ void snn_o_spike_trains(snn_o_net *n)
             n->st_step[s] = step;
         }
         float v = spike ? n->st_v_th[s] : n->st_v_resting[s];
+        if (n->st_kind == SNN_O_ST_BCM_POISSON) {
+            /* BCMPoissonNeuron::iterate spike_train/mod.rs:931-954: activity = voltage change, replaced by the firing
+             * rate at the end of a window */
+            n->st_bcm_current_activity[s] = v - n->st_current_voltage[s];
+            if (spike) n->st_bcm_num_spikes[s] += 1;
+            bcm_window_update(&n->st_bcm_clock[s], n->st_bcm_window[s], n->st_dt[s], n->st_bcm_num_spikes[s],
+                              n->st_bcm_period[s], &n->st_bcm_current_activity[s], &n->st_bcm_average_activity[s], 1);
+        }
         n->st_current_voltage[s] = v;
         n->st_is_spiking[s] = spike;
         if (n->st_nt_flags) {

@@ -54,10 +54,11 @@ extern "C" {
 #define SNN_O_CHUNK  256   /* canonical reduction chunk (presynaptic indices) */
 
 enum { SNN_O_IZHIKEVICH = 0, SNN_O_LIF = 1, SNN_O_HH = 2, SNN_O_QIF = 3, SNN_O_SIMPLE_LIF = 4,
-       SNN_O_ADAPTIVE_LIF = 5, SNN_O_ADAPTIVE_EXP_LIF = 6, SNN_O_LEAKY_IZHIKEVICH = 7 };
+       SNN_O_ADAPTIVE_LIF = 5, SNN_O_ADAPTIVE_EXP_LIF = 6, SNN_O_LEAKY_IZHIKEVICH = 7,
+       SNN_O_BCM_IZHIKEVICH = 8 };
 enum { SNN_O_NT_APPROX = 0, SNN_O_NT_DESTEXHE = 1, SNN_O_NT_DISCRETE_SPIKE = 2, SNN_O_NT_EXPONENTIAL_DECAY = 3 };
 enum { SNN_O_RC_APPROX = 0, SNN_O_RC_DESTEXHE = 1, SNN_O_RC_EXPONENTIAL_DECAY = 2 };
-enum { SNN_O_ST_NONE = 0, SNN_O_ST_POISSON = 1, SNN_O_ST_RATE = 2, SNN_O_ST_PRESET = 3 };
+enum { SNN_O_ST_NONE = 0, SNN_O_ST_POISSON = 1, SNN_O_ST_RATE = 2, SNN_O_ST_PRESET = 3, SNN_O_ST_BCM_POISSON = 4 };
 
 typedef struct snn_o_net {
     /* ---- sizes / switches ---- */
@@ -165,6 +166,15 @@ typedef struct snn_o_net {
     /* NeuralRefractoriness of each spike-train cell: 0 DeltaDiracRefractoriness (spike_train/mod.rs:79-88),
      * 1 ExponentialDecayRefractoriness (:164-178); NULL = all DeltaDirac */
     uint32_t *st_refractoriness;
+    /* BCM (plasticity/mod.rs:72-116): plasticity_kind[l] 0 = STDP, 1 = BCM with bcm_* parameters; the activity state of
+     * BCMIzhikevichNeuron (integrate_and_fire/mod.rs:1358-1518) per neuron and of BCMPoissonNeuron
+     * (spike_train/mod.rs:835-970) per cell */
+    uint32_t *plasticity_kind;                         /* [n_lattices] */
+    float    *bcm_decay, *bcm_average_scalar, *bcm_dt; /* [n_lattices] */
+    float    *bcm_average_activity, *bcm_current_activity, *bcm_clock, *bcm_window;   /* [n_neurons] */
+    uint32_t *bcm_period, *bcm_num_spikes;                                             /* [n_neurons] */
+    float    *st_bcm_average_activity, *st_bcm_current_activity, *st_bcm_clock, *st_bcm_window;   /* [n_cells] */
+    uint32_t *st_bcm_period, *st_bcm_num_spikes;                                                   /* [n_cells] */
 } snn_o_net;
 
 /* Step 1 of SURVEY §8(g): electrical + chemical inputs for every neuron from state S(t). */

@@ -92,6 +92,7 @@ SIGNATURES = {
     "snn_history_steps": (C.c_int, [H, u64p]),
     "snn_get_voltage_history": (C.c_int, [H, C.c_uint32, f32p, C.c_size_t]),
     "snn_get_spike_history": (C.c_int, [H, C.c_uint32, u8p, C.c_size_t]),
+    "snn_set_bcm": (C.c_int, [H, C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_int]),
     "snn_set_reward_modulator": (C.c_int, [H, C.c_uint32] + [C.c_float] * 8 + [C.c_int]),
     "snn_get_dopamine": (C.c_int, [H, C.c_uint32, f32p]),
     "snn_apply_reward": (C.c_int, [H, C.c_float]),

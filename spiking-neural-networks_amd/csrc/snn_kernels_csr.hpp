@@ -232,7 +232,9 @@ __global__ __launch_bounds__(64) void k_stdp_csr_in(const CsrStdpArgs a)
         const uint32_t j = a.s.spike_list[i];
         if (j < a.s.q0 || j >= a.s.q0 + a.s.n_loc) continue;
         const uint32_t r = j - a.s.q0;
-        const float *prm = a.s.stdp + 5 * a.s.lattice_slot[j];
+        const float *prm = a.s.stdp + PL_STRIDE * a.s.lattice_slot[j];
+        const bool bcm = prm[5] != 0.0f;
+        const float post_act = bcm ? a.s.act[j] : 0.0f, post_avg = bcm ? a.s.avg[j] : 0.0f;
         const int32_t tj = a.s.last_firing_time[j];
         const uint32_t base = a.g.slice_ptr[r >> 6] + (r & 63u);
         const uint32_t len = a.g.row_len[r];
@@ -240,7 +242,8 @@ __global__ __launch_bounds__(64) void k_stdp_csr_in(const CsrStdpArgs a)
             const size_t e = base + (size_t)k * 64;
             const uint32_t p = a.g.pre[e];
             const int32_t tp = (p < a.s.n_neurons) ? a.s.last_firing_time[p] : a.s.st_last_firing_time[p - a.s.n_neurons];
-            a.g.w[e] = a.g.w[e] + stdp_delta(tp, tj, prm[0], prm[1], prm[2], prm[3], prm[4]);
+            const float pre = bcm ? ((p < a.s.n_neurons) ? a.s.act[p] : a.s.st_act[p - a.s.n_neurons]) : 0.0f;
+            a.g.w[e] = plasticity_weight(prm, a.g.w[e], tp, tj, pre, post_act, post_avg);
         }
     }
 }
@@ -255,8 +258,10 @@ __global__ __launch_bounds__(64) void k_stdp_csr_out(const CsrStdpArgs a)
             const uint32_t edge = a.g.t_edge[t];
             const uint32_t e = a.g.edge_slot[edge];
             const uint32_t gr = a.s.q0 + a.g.edge_post[edge];
-            const float *prm = a.s.stdp + 5 * a.s.lattice_slot[gr];
-            a.g.w[e] = a.g.w[e] + stdp_delta(tj, a.s.last_firing_time[gr], prm[0], prm[1], prm[2], prm[3], prm[4]);
+            const float *prm = a.s.stdp + PL_STRIDE * a.s.lattice_slot[gr];
+            const bool bcm = prm[5] != 0.0f;
+            a.g.w[e] = plasticity_weight(prm, a.g.w[e], tj, a.s.last_firing_time[gr], bcm ? a.s.act[j] : 0.0f,
+                                         bcm ? a.s.act[gr] : 0.0f, bcm ? a.s.avg[gr] : 0.0f);
         }
     }
 }

@@ -86,7 +86,7 @@ __global__ void k_graph_synthetic(float *W, uint32_t ld, uint32_t n_loc, uint32_
 struct SpikeTrainArgs {
     CellArrays c;
     uint32_t n_cells;
-    int st_kind;            // 1 Poisson (xorshift32), 2 Rate, 3 Preset
+    int st_kind;            // 1 Poisson (xorshift32), 2 Rate, 3 Preset, 4 BCM Poisson
     int nt_kind;
     int iterate;            // 0: only refresh presyn_value for `view_clock`
     const long long *lattice_clock;   // [n_st_lattices] clocks at the start of this run call
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void k_spike_trains(const SpikeTrainArgs a)
     const CellArrays &c = a.c;
     if (a.iterate) {
         uint32_t spike;
-        if (a.st_kind == 1) {
+        if (a.st_kind == 1 || a.st_kind == 4) {
             const uint32_t new_seed = xorshift32(c.seed[s]);
             c.seed[s] = new_seed;
             const float random_number = (float)new_seed / 4294967296.0f;   // (float) seed / 0xFFFFFFFF
@@ -129,6 +129,14 @@ __global__ __launch_bounds__(256) void k_spike_trains(const SpikeTrainArgs a)
             c.step[s] = step;
         }
         const float v = spike ? c.v_th[s] : c.v_resting[s];
+        if (a.st_kind == 4) {
+            // BCMPoissonNeuron::iterate (spike_train/mod.rs:931-954): activity = voltage change, replaced by the
+            // firing rate when a window closes
+            float cur = v - c.current_voltage[s], avg = c.bcm_avg[s], clock = c.bcm_clock[s];
+            uint32_t num = c.bcm_num_spikes[s] + (spike ? 1u : 0u);
+            bcm_window_update(clock, c.bcm_window[s], c.dt[s], num, c.bcm_period[s], cur, avg, true);
+            c.bcm_cur[s] = cur; c.bcm_avg[s] = avg; c.bcm_clock[s] = clock; c.bcm_num_spikes[s] = num;
+        }
         c.current_voltage[s] = v;
         c.is_spiking[s] = spike;
 #pragma unroll
@@ -159,7 +167,9 @@ struct StdpArgs {
     const int32_t *last_firing_time;      // neurons (all shards, replicated)
     const int32_t *st_last_firing_time;   // cells
     const uint32_t *lattice_slot;         // [n_pad] neuron -> lattice slot
-    const float *stdp;                    // [n_lattices][5]: a_plus, a_minus, tau_plus, tau_minus, dt
+    const float *stdp;                    // [n_lattices][PL_STRIDE], see plasticity_weight
+    // BCMActivity of neurons / cells (read only by lattices whose rule is BCM)
+    const float *act, *avg, *st_act;
     const uint32_t *do_plasticity;        // [n_lattices]
     uint32_t *spike_list;                 // compacted gated spiking neurons (global indices)
     uint32_t *spike_count;
@@ -200,8 +210,10 @@ __global__ __launch_bounds__(256) void k_stdp_columns(const StdpArgs a)
         float *wp = a.W + (size_t)p * a.ld + (j - a.q0);
         const float w = *wp;
         if (w == w) {
-            const float *prm = a.stdp + 5 * a.lattice_slot[j];
-            *wp = w + stdp_delta(tp, a.last_firing_time[j], prm[0], prm[1], prm[2], prm[3], prm[4]);
+            const float *prm = a.stdp + PL_STRIDE * a.lattice_slot[j];
+            const bool bcm = prm[5] != 0.0f;
+            const float pre = bcm ? ((p < a.n_neurons) ? a.act[p] : a.st_act[p - a.n_neurons]) : 0.0f;
+            *wp = plasticity_weight(prm, w, tp, a.last_firing_time[j], pre, bcm ? a.act[j] : 0.0f, bcm ? a.avg[j] : 0.0f);
         }
     }
 }
@@ -214,12 +226,14 @@ __global__ __launch_bounds__(256) void k_stdp_rows(const StdpArgs a)
     if (r >= a.n_loc) return;
     const uint32_t gr = a.q0 + r;
     const int32_t tr = a.last_firing_time[gr];
-    const float *prm = a.stdp + 5 * a.lattice_slot[gr];
+    const float *prm = a.stdp + PL_STRIDE * a.lattice_slot[gr];
+    const bool bcm = prm[5] != 0.0f;
+    const float post_act = bcm ? a.act[gr] : 0.0f, post_avg = bcm ? a.avg[gr] : 0.0f;
     for (uint32_t s = blockIdx.y; s < count; s += gridDim.y) {
         const uint32_t j = a.spike_list[s];
         float *wp = a.W + (size_t)j * a.ld + r;
         const float w = *wp;
-        if (w == w) *wp = w + stdp_delta(a.last_firing_time[j], tr, prm[0], prm[1], prm[2], prm[3], prm[4]);
+        if (w == w) *wp = plasticity_weight(prm, w, a.last_firing_time[j], tr, bcm ? a.act[j] : 0.0f, post_act, post_avg);
     }
 }
 

@@ -33,6 +33,7 @@ struct UpdateArgs {
     // shadow copy (n.xbuf) while it writes S(t+1) to the exchange buffer and to the other shadow (`xout2`).
     float *xout, *xout2;
     int has_nt;                 // some neuron of the handle releases a neurotransmitter (else the flag planes are not read)
+    int bcm;                    // BCMIzhikevichNeuron: keep the activity bookkeeping (the step itself is Izhikevich's)
 };
 
 // Second level of the canonical sum: chunk partials added in ascending chunk order from 0.0f.  The loads of
@@ -144,6 +145,13 @@ __device__ __forceinline__ uint32_t update_neuron(const UpdateArgs &a, uint32_t 
         const float dt = a.n.dt[q];
         const float c_m = a.n.c_m[q];
         const uint32_t spiking_prev = reinterpret_cast<const uint32_t *>(a.n.xbuf)[s_at];
+        if (MODEL == 0 && a.bcm) {
+            // BCMIzhikevichNeuron::iterate_and_spike, integrate_and_fire/mod.rs:1458-1469 (electrical) / :1484-1495
+            float cur = a.n.bcm_cur[q], avg = a.n.bcm_avg[q], clock = a.n.bcm_clock[q];
+            const uint32_t num = a.n.bcm_num_spikes[q] + (spiking_prev ? 1u : 0u);
+            bcm_window_update(clock, a.n.bcm_window[q], dt, num, a.n.bcm_period[q], cur, avg, !a.chemical);
+            a.n.bcm_cur[q] = cur; a.n.bcm_avg[q] = avg; a.n.bcm_clock[q] = clock; a.n.bcm_num_spikes[q] = num;
+        }
 
         // input current: chunk partials in ascending order, then the averager (neuron/mod.rs:722-729)
         float i_in = 0.0f;

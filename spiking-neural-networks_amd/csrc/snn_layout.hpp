@@ -54,6 +54,9 @@ struct NeuronArrays {
     float *qif_alpha, *qif_v_c, *slif_g, *slif_e;
     // adaptive (exponential) leaky integrate-and-fire
     float *adp_alpha, *adp_beta, *slope_factor;
+    // BCMActivity bookkeeping (BCMIzhikevichNeuron): average / current activity, window clock and length, period, spike count
+    float *bcm_avg, *bcm_cur, *bcm_clock, *bcm_window;
+    uint32_t *bcm_period, *bcm_num_spikes;
     // Hodgkin-Huxley
     float *m_state, *h_state, *n_state;
     float *m_alpha, *m_beta, *h_alpha, *h_beta, *n_alpha, *n_beta;
@@ -75,6 +78,9 @@ struct CellArrays {
     float *chance_of_firing, *rate, *step;
     uint32_t *seed, *is_spiking;
     uint32_t *refractoriness;   // NeuralRefractoriness: 0 DeltaDirac, 1 ExponentialDecay
+    // BCMActivity bookkeeping (BCMPoissonNeuron)
+    float *bcm_avg, *bcm_cur, *bcm_clock, *bcm_window;
+    uint32_t *bcm_period, *bcm_num_spikes;
     // PresetSpikeTrain: firing times of cell s = preset_times[preset_ptr[s] .. preset_ptr[s + 1]); `step` holds
     // its internal_clock
     uint32_t *counter;

@@ -116,6 +116,38 @@ __device__ __forceinline__ float stdp_delta(int t_pre, int t_post, float a_plus,
     return 0.0f;
 }
 
+// Firing-rate bookkeeping shared by BCMIzhikevichNeuron (integrate_and_fire/mod.rs:1458-1469, 1484-1495) and
+// BCMPoissonNeuron (spike_train/mod.rs:943-954); num_spikes is never reset by the reference.  per_dt: the electrical-only
+// neuron path and the spike train divide by (window * dt), the neuron's neurotransmission path by the window alone.
+__device__ __forceinline__ void bcm_window_update(float &clock, float window, float dt, uint32_t num_spikes,
+                                                  uint32_t period, float &current_activity, float &average_activity,
+                                                  bool per_dt)
+{
+    clock += dt;
+    if (clock >= window) {
+        clock = 0.0f;
+        current_activity = per_dt ? (float)num_spikes / (window * dt) : (float)num_spikes / window;
+        average_activity -= average_activity / (float)period;
+        average_activity += current_activity / (float)period;
+    }
+}
+
+// One weight update of a lattice's plasticity rule.  Table row of PL_STRIDE floats per lattice:
+// {a_plus, a_minus, tau_plus, tau_minus, dt, kind (0 STDP, 1 BCM), bcm decay, bcm average_scalar}.
+// STDP::update_weight plasticity/mod.rs:45-66; BCM::update_weight :102-107 (dt shared with slot 4).
+constexpr int PL_STRIDE = 8;
+__device__ __forceinline__ float plasticity_weight(const float *prm, float w, int t_pre, int t_post,
+                                                   float pre_activity, float post_activity, float post_average)
+{
+    if (prm[5] != 0.0f) {
+        const float sliding_threshold = post_average / prm[7];
+        const float activity_term = post_activity * (post_activity - sliding_threshold);
+        const float weight_decay = prm[6] * w;
+        return w + (activity_term * pre_activity - weight_decay) * prm[4];
+    }
+    return w + stdp_delta(t_pre, t_post, prm[0], prm[1], prm[2], prm[3], prm[4]);
+}
+
 // ---- neurotransmitter / receptor kinetics ------------------------------------------------------
 // exp_decay, iterate_and_spike/mod.rs:345-347
 __device__ __forceinline__ float exp_decay(float x, float l, float dt)

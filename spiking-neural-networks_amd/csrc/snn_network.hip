@@ -17,8 +17,8 @@ int snn_network_create(int device, int neuron_model, int nt_kinetics, int recept
 {
     if (!out) return fail(SNN_ERR_BAD_ARG, "out is null");
     *out = nullptr;
-    if (neuron_model < 0 || neuron_model > 7 || nt_kinetics < 0 || nt_kinetics > 3 || receptor_kinetics < 0 ||
-        receptor_kinetics > 2 || spike_train_model < 0 || spike_train_model > 3)
+    if (neuron_model < 0 || neuron_model > 8 || nt_kinetics < 0 || nt_kinetics > 3 || receptor_kinetics < 0 ||
+        receptor_kinetics > 2 || spike_train_model < 0 || spike_train_model > 4)
         return fail(SNN_ERR_BAD_ARG, "unknown model / kinetics selector");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -346,8 +346,29 @@ int snn_set_plasticity(snn_network_t *net, uint32_t id, float a_plus, float a_mi
     const LatticeInfo *l = find_lattice(net, id);
     if (!l || l->spike_train) return fail(SNN_ERR_BAD_ARG, "plasticity belongs to neuron lattices");
     HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
-    float *s = &net->stdp_host[(size_t)l->slot * 5];
-    s[0] = a_plus; s[1] = a_minus; s[2] = tau_plus; s[3] = tau_minus; s[4] = dt;
+    float *s = &net->stdp_host[(size_t)l->slot * PL_STRIDE];
+    s[0] = a_plus; s[1] = a_minus; s[2] = tau_plus; s[3] = tau_minus; s[4] = dt; s[5] = 0.0f;
+    net->plast_host[l->slot] = do_plasticity ? 1u : 0u;
+    net->any_plasticity = false;
+    for (uint32_t p : net->plast_host) net->any_plasticity |= (p != 0);
+    TRY(end_run(net));
+    HIP_TRY(hipMemcpy(net->stdp_dev, net->stdp_host.data(), net->stdp_host.size() * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
+    HIP_TRY(hipMemcpy(net->plast_dev, net->plast_host.data(), net->plast_host.size() * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
+    return SNN_OK;
+}
+
+int snn_set_bcm(snn_network_t *net, uint32_t id, float decay, float average_scalar, float dt, int do_plasticity)
+{
+    if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
+    if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
+    const LatticeInfo *l = find_lattice(net, id);
+    if (!l || l->spike_train) return fail(SNN_ERR_BAD_ARG, "plasticity belongs to neuron lattices");
+    if (net->model != SNN_MODEL_BCM_IZHIKEVICH)
+        return fail(SNN_ERR_BAD_STATE, "the BCM rule needs neurons with BCMActivity (SNN_MODEL_BCM_IZHIKEVICH)");
+    if (net->xl.n_shards != 1) return fail(SNN_ERR_BAD_STATE, "the BCM rule is not available on shard handles (activities are not exchanged)");
+    HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
+    float *s = &net->stdp_host[(size_t)l->slot * PL_STRIDE];
+    s[4] = dt; s[5] = 1.0f; s[6] = decay; s[7] = average_scalar;
     net->plast_host[l->slot] = do_plasticity ? 1u : 0u;
     net->any_plasticity = false;
     for (uint32_t p : net->plast_host) net->any_plasticity |= (p != 0);

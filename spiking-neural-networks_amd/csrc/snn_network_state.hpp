@@ -76,7 +76,7 @@ struct snn_network {
     std::vector<LatticeInfo> lattices;      // neuron lattices, ascending id after finalize
     std::vector<LatticeInfo> st_lattices;   // spike-train lattices
     std::vector<long long> st_clock;        // own clocks of the spike-train lattices
-    std::vector<float> stdp_host;           // [n_lattices][5]
+    std::vector<float> stdp_host;           // [n_lattices][PL_STRIDE], see plasticity_weight
     std::vector<uint32_t> plast_host;       // [n_lattices]
     bool any_plasticity = false;
     std::map<uint32_t, bool> lattice_has_nt;    // lattice id -> some neurotransmitters$flags entry is set
@@ -274,7 +274,8 @@ int build_state(snn_network *net)
 
     // reference defaults: Izhikevich integrate_and_fire/mod.rs:1198-1220, LIF :149-171,
     // Hodgkin-Huxley hodgkin_huxley/mod.rs:80-98 + ion_channels/mod.rs:23-31, 205-215, 255-264, 299-307
-    const bool izh = net->model == SNN_MODEL_IZHIKEVICH, lif = net->model == SNN_MODEL_LIF;
+    const bool bcm = net->model == SNN_MODEL_BCM_IZHIKEVICH;
+    const bool izh = net->model == SNN_MODEL_IZHIKEVICH || bcm, lif = net->model == SNN_MODEL_LIF;
     const bool qif = net->model == SNN_MODEL_QUADRATIC_INTEGRATE_AND_FIRE, slif = net->model == SNN_MODEL_SIMPLE_LIF;
     const bool alif = net->model == SNN_MODEL_ADAPTIVE_LIF, aelif = net->model == SNN_MODEL_ADAPTIVE_EXP_LIF;
     const bool adp = alif || aelif, lizh = net->model == SNN_MODEL_LEAKY_IZHIKEVICH;
@@ -309,6 +310,19 @@ int build_state(snn_network *net)
     TRY(neuron_f32(net, &n.adp_alpha, adp ? "alpha" : nullptr, 6.0f));
     TRY(neuron_f32(net, &n.adp_beta, adp ? "beta" : nullptr, 10.0f));
     TRY(neuron_f32(net, &n.slope_factor, aelif ? "slope_factor" : nullptr, 1.0f));
+    // BCMIzhikevichNeuron's activity bookkeeping, integrate_and_fire/mod.rs:1385-1396, defaults :1425-1430
+    TRY(neuron_f32(net, &n.bcm_avg, bcm ? "average_activity" : nullptr, 0.0f));
+    TRY(neuron_f32(net, &n.bcm_cur, bcm ? "current_activity" : nullptr, 0.0f));
+    TRY(neuron_f32(net, &n.bcm_clock, bcm ? "firing_rate_clock" : nullptr, 0.0f));
+    TRY(neuron_f32(net, &n.bcm_window, bcm ? "firing_rate_window" : nullptr, 500.0f));
+    TRY(dev_alloc_t(net, &n.bcm_period, np));
+    TRY(fill_u32(net, n.bcm_period, np, 3));
+    TRY(dev_alloc_t(net, &n.bcm_num_spikes, np));
+    TRY(fill_u32(net, n.bcm_num_spikes, np, 0));
+    if (bcm) {
+        reg(A, "period", T_U32, S_PLAIN, n.bcm_period, 0, 0);
+        reg(A, "num_spikes", T_U32, S_PLAIN, n.bcm_num_spikes, 0, 0);
+    }
     // reference buffer names of the two models with a reference GPU implementation
     // (integrate_and_fire/mod.rs:729-773, 1700-1740)
     TRY(neuron_f32(net, &n.qif_alpha, qif ? "alpha" : nullptr, 1.0f));
@@ -401,15 +415,16 @@ int build_state(snn_network *net)
     }
     net->want_whist.assign(nl, 0);
     net->whist.assign(nl, nullptr);
-    net->stdp_host.assign(nl * 5, 0.0f);
+    net->stdp_host.assign(nl * PL_STRIDE, 0.0f);
     net->plast_host.assign(nl, 0);
     for (size_t l = 0; l < nl; ++l) {   // plasticity/mod.rs:29-39
-        float *s = &net->stdp_host[l * 5];
+        float *s = &net->stdp_host[l * PL_STRIDE];
         s[0] = 2.0f; s[1] = 2.0f; s[2] = 4.5f; s[3] = 4.5f; s[4] = 0.1f;
+        s[5] = 0.0f; s[6] = 0.1f; s[7] = 0.1f;        // STDP; BCM defaults decay 0.1, average_scalar 0.1 (plasticity/mod.rs:91-95)
     }
-    TRY(dev_alloc_t(net, &net->stdp_dev, nl * 5));
+    TRY(dev_alloc_t(net, &net->stdp_dev, nl * PL_STRIDE));
     TRY(dev_alloc_t(net, &net->plast_dev, nl));
-    HIP_TRY(hipMemcpyAsync(net->stdp_dev, net->stdp_host.data(), nl * 5 * 4, hipMemcpyHostToDevice, net->stream),
+    HIP_TRY(hipMemcpyAsync(net->stdp_dev, net->stdp_host.data(), nl * PL_STRIDE * 4, hipMemcpyHostToDevice, net->stream),
             SNN_ERR_BUFFER_WRITE);
     HIP_TRY(hipMemcpyAsync(net->plast_dev, net->plast_host.data(), nl * 4, hipMemcpyHostToDevice, net->stream),
             SNN_ERR_BUFFER_WRITE);
@@ -442,7 +457,21 @@ int build_state(snn_network *net)
     TRY(dev_alloc_t(net, &c.refractoriness, cp));
     TRY(fill_u32(net, c.refractoriness, cp, 0));
     reg(CA, "neural_refractoriness$kind", T_U32, S_PLAIN, c.refractoriness, 0, 0);
-    TRY(cell_f32(net, &c.chance_of_firing, net->st_kind == SNN_ST_POISSON ? "chance_of_firing" : nullptr, 0.0f));
+    const bool st_bcm = net->st_kind == SNN_ST_BCM_POISSON, st_poisson = net->st_kind == SNN_ST_POISSON || st_bcm;
+    TRY(cell_f32(net, &c.chance_of_firing, st_poisson ? "chance_of_firing" : nullptr, 0.0f));
+    // BCMPoissonNeuron's activity bookkeeping, spike_train/mod.rs:846-857, defaults :876-881
+    TRY(cell_f32(net, &c.bcm_avg, st_bcm ? "average_activity" : nullptr, 0.0f));
+    TRY(cell_f32(net, &c.bcm_cur, st_bcm ? "current_activity" : nullptr, 0.0f));
+    TRY(cell_f32(net, &c.bcm_clock, st_bcm ? "firing_rate_clock" : nullptr, 0.0f));
+    TRY(cell_f32(net, &c.bcm_window, st_bcm ? "firing_rate_window" : nullptr, 500.0f));
+    TRY(dev_alloc_t(net, &c.bcm_period, cp));
+    TRY(fill_u32(net, c.bcm_period, cp, 3));
+    TRY(dev_alloc_t(net, &c.bcm_num_spikes, cp));
+    TRY(fill_u32(net, c.bcm_num_spikes, cp, 0));
+    if (st_bcm) {
+        reg(CA, "period", T_U32, S_PLAIN, c.bcm_period, 0, 0);
+        reg(CA, "num_spikes", T_U32, S_PLAIN, c.bcm_num_spikes, 0, 0);
+    }
     TRY(cell_f32(net, &c.rate, net->st_kind == SNN_ST_RATE ? "rate" : nullptr, 0.0f));
     TRY(cell_f32(net, &c.step, net->st_kind == SNN_ST_RATE ? "step" : (net->st_kind == SNN_ST_PRESET ? "internal_clock" : nullptr), 0.0f));
     TRY(dev_alloc_t(net, &c.counter, cp));
@@ -463,7 +492,7 @@ int build_state(snn_network *net)
         hipLaunchKernelGGL(k_iota_u32, dim3((cp + 255) / 256), dim3(256), 0, net->stream, c.seed, (size_t)cp, 1u);
         HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
     }
-    if (net->st_kind == SNN_ST_POISSON) reg(CA, "seed", T_U32, S_PLAIN, c.seed, 0, 0);
+    if (st_poisson) reg(CA, "seed", T_U32, S_PLAIN, c.seed, 0, 0);
     TRY(dev_alloc_t(net, &c.is_spiking, cp));
     TRY(fill_u32(net, c.is_spiking, cp, 0));
     reg(CA, "is_spiking", T_U32, S_PLAIN, c.is_spiking, 0, 0);

@@ -148,6 +148,7 @@ int launch_update(snn_network *net)
     a.spike_counts = net->want_counts ? net->spike_counts : nullptr;
     a.xout = net->xbuf; a.xout2 = nullptr;
     a.has_nt = net->any_nt_neurons ? 1 : 0;
+    a.bcm = net->model == SNN_MODEL_BCM_IZHIKEVICH;
     net->shadow_valid = false;            // the exchange buffer moves on without the shadows
     dim3 grid((net->ld + 255) / 256);
     switch (net->model) {
@@ -172,6 +173,7 @@ int launch_plasticity(snn_network *net)
     a.xbuf = net->xbuf; a.xl = net->xl;
     a.last_firing_time = net->na.last_firing_time; a.st_last_firing_time = net->ca.last_firing_time;
     a.lattice_slot = net->lattice_slot; a.stdp = net->stdp_dev; a.do_plasticity = net->plast_dev;
+    a.act = net->na.bcm_cur; a.avg = net->na.bcm_avg; a.st_act = net->ca.bcm_cur;
     a.spike_list = net->spike_list; a.spike_count = net->spike_count;
     HIP_TRY(hipMemsetAsync(net->spike_count, 0, 4, net->stream), SNN_ERR_BUFFER_WRITE);
     hipLaunchKernelGGL(k_spike_compact, dim3((net->nn + 255) / 256), dim3(256), 0, net->stream, a);
@@ -359,6 +361,7 @@ int fused_step_args(snn_network *net, InputsArgs &a, UpdateArgs &u)
     u.spike_counts = net->want_counts ? net->spike_counts : nullptr;
     u.xout = net->xbuf; u.xout2 = next;
     u.has_nt = net->any_nt_neurons ? 1 : 0;
+    u.bcm = net->model == SNN_MODEL_BCM_IZHIKEVICH;
     return SNN_OK;
 }
 

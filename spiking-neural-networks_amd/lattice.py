@@ -14,7 +14,7 @@ import enum
 
 import numpy as np
 
-from .network import (NT_DISCRETE_SPIKE, NT_EXPONENTIAL_DECAY, RC_EXPONENTIAL_DECAY, ST_PRESET,
+from .network import (NT_DISCRETE_SPIKE, NT_EXPONENTIAL_DECAY, RC_EXPONENTIAL_DECAY, ST_PRESET, BCM_IZHIKEVICH, ST_BCM_POISSON,
                       DeviceNetwork, HODGKIN_HUXLEY, IZHIKEVICH, LIF, QUADRATIC_INTEGRATE_AND_FIRE, SIMPLE_LIF,
                       ADAPTIVE_LIF, ADAPTIVE_EXP_LIF, LEAKY_IZHIKEVICH,
                       NT_APPROXIMATE, NT_DESTEXHE,
@@ -111,6 +111,10 @@ class RewardModulatedSTDP(_Record):                      # plasticity/mod.rs:158
     _defaults = dict(dopamine=0.0, tau_d=20.0, tau_c=0.0001, a_plus=2.0, a_minus=2.0, tau_plus=4.5, tau_minus=4.5, dt=0.1)
 
 
+class BCM(_Record):                                      # plasticity/mod.rs:80-94
+    _defaults = dict(decay=0.1, average_scalar=0.1, dt=0.1)
+
+
 class GraphPosition:                                     # graph/mod.rs:24-30
     def __init__(self, id, pos):
         self.id, self.pos = id, tuple(pos)
@@ -191,6 +195,15 @@ class LeakyIzhikevichNeuron(_Neuron):                    # integrate_and_fire/mo
     state_fields = ("w_value", "a", "b", "c", "d", "tau_m", "e_l")
 
 
+class BCMIzhikevichNeuron(_Neuron):                      # integrate_and_fire/mod.rs:1358-1436
+    model = BCM_IZHIKEVICH
+    _defaults = dict(IzhikevichNeuron._defaults, average_activity=0.0, current_activity=0.0, period=3, num_spikes=0,
+                     firing_rate_clock=0.0, firing_rate_window=500.0)
+    state_fields = IzhikevichNeuron.state_fields + ("average_activity", "current_activity", "firing_rate_clock",
+                                                    "firing_rate_window")
+    counter_fields = ("period", "num_spikes")
+
+
 class HodgkinHuxleyNeuron(_Neuron):                      # hodgkin_huxley/mod.rs:49-98, ion_channels/mod.rs
     model = HODGKIN_HUXLEY
     _defaults = dict(current_voltage=-65.0, gap_conductance=7.0, dt=0.01, c_m=1.0, v_th=0.0,
@@ -234,6 +247,16 @@ class PoissonNeuron(_SpikeTrain):                        # spike_train/mod.rs:25
 
     @classmethod
     def from_firing_rate(cls, hertz, dt):                # spike_train/mod.rs:327-334
+        return cls(dt=dt, chance_of_firing=1.0 / ((1000.0 / dt) / hertz))
+
+
+class BCMPoissonNeuron(_SpikeTrain):                     # spike_train/mod.rs:835-884
+    kind = ST_BCM_POISSON
+    _defaults = dict(PoissonNeuron._defaults, average_activity=0.0, current_activity=0.0, period=3, num_spikes=0,
+                     firing_rate_clock=0.0, firing_rate_window=500.0)
+
+    @classmethod
+    def from_firing_rate(cls, hertz, dt):                # spike_train/mod.rs:903-910
         return cls(dt=dt, chance_of_firing=1.0 / ((1000.0 / dt) / hertz))
 
 
@@ -537,6 +560,8 @@ def _upload_neurons(dn, id, cells):
         dn.set_attr(id, cls.abi_names.get(k, k), f32(k))
     dn.set_attr(id, "is_spiking", np.array([c.is_spiking for c in cells], np.uint32))
     dn.set_attr(id, "last_firing_time", _lft(cells))
+    for k in getattr(cls, "counter_fields", ()):
+        dn.set_attr(id, k, np.array([getattr(c, k) for c in cells], np.uint32))
     if cls.model == HODGKIN_HUXLEY:
         dn.set_attr(id, "was_increasing", np.array([c.was_increasing for c in cells], np.uint32))
     _upload_nt(dn, id, cells)
@@ -574,6 +599,9 @@ def _download_neurons(dn, id, cells):
     for k in ("current_voltage",) + tuple(cls.state_fields):
         for c, v in zip(cells, dn.get_attr(id, cls.abi_names.get(k, k))):
             setattr(c, k, float(v))
+    for k in getattr(cls, "counter_fields", ()):
+        for c, v in zip(cells, dn.get_attr(id, k, dtype=np.uint32)):
+            setattr(c, k, int(v))
     spk = dn.get_attr(id, "is_spiking", dtype=np.uint32)
     lft = dn.get_attr(id, "last_firing_time", dtype=np.int32)
     t = dn.get_attr(id, "neurotransmitters$t", per_type=True)
@@ -603,9 +631,14 @@ def _upload_cells(dn, id, cells):
     refr = [c.neural_refractoriness for c in cells]
     dn.set_attr(id, "neural_refractoriness$k", np.array([c.k if r is None else r.k for c, r in zip(cells, refr)], np.float32))
     dn.set_attr(id, "neural_refractoriness$kind", np.array([0 if r is None else r.kind for r in refr], np.uint32))
-    if cells[0].kind == ST_POISSON:
+    if cells[0].kind in (ST_POISSON, ST_BCM_POISSON):
         dn.set_attr(id, "chance_of_firing", f32("chance_of_firing"))
         dn.set_attr(id, "seed", np.array([c.seed for c in cells], np.uint32))
+        if cells[0].kind == ST_BCM_POISSON:
+            for k in ("average_activity", "current_activity", "firing_rate_clock", "firing_rate_window"):
+                dn.set_attr(id, k, f32(k))
+            for k in ("period", "num_spikes"):
+                dn.set_attr(id, k, np.array([getattr(c, k) for c in cells], np.uint32))
     elif cells[0].kind == ST_PRESET:
         dn.set_attr(id, "internal_clock", f32("internal_clock"))
         dn.set_attr(id, "counter", np.array([c.counter for c in cells], np.uint32))
@@ -656,7 +689,10 @@ class LatticeNetworkGPU:
         for id, l in net.lattices.items():
             _upload_neurons(dn, id, _flat(l))
             p = l.plasticity
-            dn.set_plasticity(id, p.a_plus, p.a_minus, p.tau_plus, p.tau_minus, p.dt, l.do_plasticity)
+            if isinstance(p, BCM):
+                dn.set_bcm(id, p.decay, p.average_scalar, p.dt, l.do_plasticity)
+            else:
+                dn.set_plasticity(id, p.a_plus, p.a_minus, p.tau_plus, p.tau_minus, p.dt, l.do_plasticity)
         for id, l in net.spike_train_lattices.items():
             _upload_cells(dn, id, _flat(l))
         nn, nt = dn.n_neurons, dn.n_tot
@@ -971,5 +1007,8 @@ HodgkinHuxleyNeuronLatticeGPU = _named(LatticeGPU, "HodgkinHuxleyNeuronLatticeGP
 RateSpikeTrainLattice = _named(SpikeTrainLattice, "RateSpikeTrainLattice", spike_train_type=RateSpikeTrain)
 PoissonNeuronLattice = _named(SpikeTrainLattice, "PoissonNeuronLattice", spike_train_type=PoissonNeuron)
 PresetSpikeTrainLattice = _named(SpikeTrainLattice, "PresetSpikeTrainLattice", spike_train_type=PresetSpikeTrain)
+BCMPoissonNeuronLattice = _named(SpikeTrainLattice, "BCMPoissonNeuronLattice", spike_train_type=BCMPoissonNeuron)
+BCMIzhikevichNeuronLattice = _named(Lattice, "BCMIzhikevichNeuronLattice", neuron_type=BCMIzhikevichNeuron)
+BCMIzhikevichNeuronLatticeGPU = _named(LatticeGPU, "BCMIzhikevichNeuronLatticeGPU", lattice_type=BCMIzhikevichNeuronLattice)
 IzhikevichNeuronNetwork = _named(LatticeNetwork, "IzhikevichNeuronNetwork")
 IzhikevichNeuronNetworkGPU = _named(LatticeNetworkGPU, "IzhikevichNeuronNetworkGPU")

@@ -14,10 +14,10 @@ import numpy as np
 from . import _lib
 
 IZHIKEVICH, LIF, HODGKIN_HUXLEY, QUADRATIC_INTEGRATE_AND_FIRE, SIMPLE_LIF = 0, 1, 2, 3, 4
-ADAPTIVE_LIF, ADAPTIVE_EXP_LIF, LEAKY_IZHIKEVICH = 5, 6, 7
+ADAPTIVE_LIF, ADAPTIVE_EXP_LIF, LEAKY_IZHIKEVICH, BCM_IZHIKEVICH = 5, 6, 7, 8
 NT_APPROXIMATE, NT_DESTEXHE, NT_DISCRETE_SPIKE, NT_EXPONENTIAL_DECAY = 0, 1, 2, 3
 RC_APPROXIMATE, RC_DESTEXHE, RC_EXPONENTIAL_DECAY = 0, 1, 2
-ST_NONE, ST_POISSON, ST_RATE, ST_PRESET = 0, 1, 2, 3
+ST_NONE, ST_POISSON, ST_RATE, ST_PRESET, ST_BCM_POISSON = 0, 1, 2, 3, 4
 NUM_NT_TYPES = 3
 
 _DT = {np.dtype(np.float32): "f32", np.dtype(np.uint32): "u32", np.dtype(np.int32): "i32"}
@@ -233,6 +233,10 @@ class DeviceNetwork:
         out = np.empty((steps, rows * cols), np.uint8)
         _lib.check(self._L.snn_get_spike_history(self._h, id, out.ctypes.data_as(_lib.u8p), out.size))
         return out
+
+    def set_bcm(self, id, decay=0.1, average_scalar=0.1, dt=0.1, do_plasticity=True):
+        """BCM rule (plasticity/mod.rs:72-116) for lattice `id` instead of STDP"""
+        _lib.check(self._L.snn_set_bcm(self._h, id, decay, average_scalar, dt, int(do_plasticity)))
 
     # ---- reward modulation (RewardModulatedLattice, neuron/mod.rs:2719-3417) -----------------
     def set_reward_modulator(self, id, dopamine=0.0, tau_d=20.0, tau_c=0.0001, a_plus=2.0, a_minus=2.0, tau_plus=4.5,

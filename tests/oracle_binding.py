@@ -12,10 +12,10 @@ import numpy as np
 
 K = 3          # AMPA, NMDA, GABA
 CHUNK = 256
-IZHIKEVICH, LIF, HH, QIF, SIMPLE_LIF, ADAPTIVE_LIF, ADAPTIVE_EXP_LIF, LEAKY_IZHIKEVICH = 0, 1, 2, 3, 4, 5, 6, 7
+IZHIKEVICH, LIF, HH, QIF, SIMPLE_LIF, ADAPTIVE_LIF, ADAPTIVE_EXP_LIF, LEAKY_IZHIKEVICH, BCM_IZHIKEVICH = range(9)
 NT_APPROX, NT_DESTEXHE, NT_DISCRETE_SPIKE, NT_EXPONENTIAL_DECAY = 0, 1, 2, 3
 RC_APPROX, RC_DESTEXHE, RC_EXPONENTIAL_DECAY = 0, 1, 2
-ST_NONE, ST_POISSON, ST_RATE, ST_PRESET = 0, 1, 2, 3
+ST_NONE, ST_POISSON, ST_RATE, ST_PRESET, ST_BCM_POISSON = 0, 1, 2, 3, 4
 
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _ORACLE_DIR = os.path.join(_ROOT, "oracle")
@@ -70,6 +70,11 @@ _FIELDS = [
     ("traces", f32p), ("rm_do_modulation", u32p), ("rm_dopamine", f32p), ("rm_tau_d", f32p), ("rm_tau_c", f32p),
     ("rm_a_plus", f32p), ("rm_a_minus", f32p), ("rm_tau_plus", f32p), ("rm_tau_minus", f32p), ("rm_dt", f32p),
     ("rewards", f32p), ("st_refractoriness", u32p),
+    ("plasticity_kind", u32p), ("bcm_decay", f32p), ("bcm_average_scalar", f32p), ("bcm_dt", f32p),
+    ("bcm_average_activity", f32p), ("bcm_current_activity", f32p), ("bcm_clock", f32p), ("bcm_window", f32p),
+    ("bcm_period", u32p), ("bcm_num_spikes", u32p),
+    ("st_bcm_average_activity", f32p), ("st_bcm_current_activity", f32p), ("st_bcm_clock", f32p), ("st_bcm_window", f32p),
+    ("st_bcm_period", u32p), ("st_bcm_num_spikes", u32p),
 ]
 
 
@@ -163,7 +168,13 @@ NEURON_DEFAULTS = {
     # integrate_and_fire/mod.rs:1310-1331
     LEAKY_IZHIKEVICH: dict(current_voltage=-65.0, gap_conductance=7.0, w_value=30.0, a=0.02, b=0.2, c=-55.0, d=8.0,
                            v_th=30.0, tau_m=10.0, c_m=100.0, e_l=-65.0, dt=0.1),
+    # integrate_and_fire/mod.rs:1409-1436
+    BCM_IZHIKEVICH: dict(current_voltage=-65.0, gap_conductance=7.0, w_value=30.0, a=0.02, b=0.2, c=-55.0, d=8.0,
+                         v_th=30.0, tau_m=1.0, c_m=100.0, dt=0.1),
 }
+# activity bookkeeping of BCMIzhikevichNeuron / BCMPoissonNeuron; BCM rule plasticity/mod.rs:91-95
+BCM_CELL_DEFAULTS = dict(average_activity=0.0, current_activity=0.0, clock=0.0, window=500.0, period=3, num_spikes=0)
+BCM_DEFAULTS = dict(bcm_decay=0.1, bcm_average_scalar=0.1, bcm_dt=0.1)
 # iterate_and_spike/mod.rs:174-182 (Approximate), :136-145 (Destexhe)
 NT_DEFAULTS = dict(nt_t=0.0, nt_t_max=1.0, nt_clearance=0.01, nt_v_p=2.0, nt_k_p=5.0)
 # iterate_and_spike/mod.rs:1085-1094, 1115-1125, 1148-1157; Destexhe receptor :417-425
@@ -180,16 +191,18 @@ RM_DEFAULTS = dict(rm_dopamine=0.0, rm_tau_d=20.0, rm_tau_c=0.0001, rm_a_plus=2.
 
 _NAMES = [n for n, _ in _FIELDS]
 _PER_NEURON = set(_NAMES[_NAMES.index("current_voltage"):_NAMES.index("was_increasing") + 1]) | {
-    "qif_alpha", "qif_v_c", "slif_g", "slif_e", "adp_alpha", "adp_beta", "slope_factor"}
+    "qif_alpha", "qif_v_c", "slif_g", "slif_e", "adp_alpha", "adp_beta", "slope_factor",
+    "bcm_average_activity", "bcm_current_activity", "bcm_clock", "bcm_window", "bcm_period", "bcm_num_spikes"}
 _PER_NEURON_K = {"nt_t", "nt_t_max", "nt_clearance", "nt_v_p", "nt_k_p", "nt_flags",
                  "rc_g", "rc_e", "rc_mg", "rc_r", "rc_alpha", "rc_beta", "rc_current", "rc_flags",
                  "input_t", "input_count"}
 _PER_CELL = {"st_current_voltage", "st_v_th", "st_v_resting", "st_dt", "st_k", "st_chance_of_firing",
              "st_rate", "st_step", "st_seed", "st_is_spiking", "st_last_firing_time", "st_lattice", "st_counter",
-             "st_refractoriness"}
+             "st_refractoriness", "st_bcm_average_activity", "st_bcm_current_activity", "st_bcm_clock", "st_bcm_window",
+             "st_bcm_period", "st_bcm_num_spikes"}
 _PER_CELL_K = {"st_nt_t", "st_nt_t_max", "st_nt_clearance", "st_nt_v_p", "st_nt_k_p", "st_nt_flags"}
 _PER_LATTICE = {"stdp_a_plus", "stdp_a_minus", "stdp_tau_plus", "stdp_tau_minus", "stdp_dt", "do_plasticity",
-                "lattice_first", "lattice_count", "rm_do_modulation", *RM_DEFAULTS}
+                "lattice_first", "lattice_count", "rm_do_modulation", *RM_DEFAULTS, "plasticity_kind", *BCM_DEFAULTS}
 
 
 class Net:
@@ -254,6 +267,11 @@ class Net:
             a[k][...] = v
         for k, v in RM_DEFAULTS.items():
             a[k][...] = v
+        for k, v in BCM_DEFAULTS.items():
+            a[k][...] = v
+        for k, v in BCM_CELL_DEFAULTS.items():
+            a["bcm_" + k][...] = v
+            a["st_bcm_" + k][...] = v
         self.rewards = None
         if nt_kind == NT_EXPONENTIAL_DECAY:       # decay_constant, iterate_and_spike/mod.rs:336-343
             a["nt_clearance"][...] = 2.0

@@ -23,6 +23,10 @@ MODEL_ATTRS = {
                                             "integration_constant", "e_l", "g_l", "w_value", "slope_factor")},
                           "adp_alpha": "alpha", "adp_beta": "beta"},
     ob.LEAKY_IZHIKEVICH: {k: k for k in ("w_value", "a", "b", "c", "d", "tau_m", "e_l")},
+    ob.BCM_IZHIKEVICH: {**{k: k for k in ("w_value", "a", "b", "c", "d", "tau_m")},
+                        "bcm_average_activity": "average_activity", "bcm_current_activity": "current_activity",
+                        "bcm_clock": "firing_rate_clock", "bcm_window": "firing_rate_window", "bcm_period": "period",
+                        "bcm_num_spikes": "num_spikes"},
     ob.HH: {"m_state": "na_channel$m$state", "h_state": "na_channel$h$state", "n_state": "k_channel$n$state",
             "m_alpha": "na_channel$m$alpha", "m_beta": "na_channel$m$beta",
             "h_alpha": "na_channel$h$alpha", "h_beta": "na_channel$h$beta",
@@ -44,7 +48,12 @@ CELL_ATTRS = {"st_current_voltage": "current_voltage", "st_v_th": "v_th", "st_v_
               "st_last_firing_time": "last_firing_time"}
 CELL_KIND_ATTRS = {ob.ST_POISSON: {"st_chance_of_firing": "chance_of_firing", "st_seed": "seed"},
                    ob.ST_RATE: {"st_rate": "rate", "st_step": "step"},
-                   ob.ST_PRESET: {"st_step": "internal_clock", "st_counter": "counter"}}
+                   ob.ST_PRESET: {"st_step": "internal_clock", "st_counter": "counter"},
+                   ob.ST_BCM_POISSON: {"st_chance_of_firing": "chance_of_firing", "st_seed": "seed",
+                                       "st_bcm_average_activity": "average_activity",
+                                       "st_bcm_current_activity": "current_activity", "st_bcm_clock": "firing_rate_clock",
+                                       "st_bcm_window": "firing_rate_window", "st_bcm_period": "period",
+                                       "st_bcm_num_spikes": "num_spikes"}}
 
 
 class Layout:
@@ -131,6 +140,10 @@ def device_from_oracle(snn, net, shard=None, device=0, csr=False):
         dn.set_graph_rows(0, net["weights"], net["connections"].astype(np.uint32))
     dn.set_synapses(net.electrical, net.chemical)
     for slot, (i, r, c) in enumerate(lay.lattices):
+        if net["plasticity_kind"][slot]:
+            dn.set_bcm(i, float(net["bcm_decay"][slot]), float(net["bcm_average_scalar"][slot]),
+                       float(net["bcm_dt"][slot]), bool(net["do_plasticity"][slot]))
+            continue
         dn.set_plasticity(i, float(net["stdp_a_plus"][slot]), float(net["stdp_a_minus"][slot]),
                           float(net["stdp_tau_plus"][slot]), float(net["stdp_tau_minus"][slot]),
                           float(net["stdp_dt"][slot]), bool(net["do_plasticity"][slot]))

@@ -60,10 +60,10 @@ def test_bad_device_and_selectors(snn):
     h = snn._lib.H()
     assert L.snn_network_create(4096, 0, 0, 0, 0, C.byref(h)) == 7                 # GetDeviceFailure
     assert L.snn_network_create(-1, 0, 0, 0, 0, C.byref(h)) == 7
-    assert L.snn_network_create(0, 8, 0, 0, 0, C.byref(h)) == BAD_ARG
+    assert L.snn_network_create(0, 9, 0, 0, 0, C.byref(h)) == BAD_ARG
     assert L.snn_network_create(0, 0, 4, 0, 0, C.byref(h)) == BAD_ARG
     assert L.snn_network_create(0, 0, 0, 3, 0, C.byref(h)) == BAD_ARG
-    assert L.snn_network_create(0, 0, 0, 0, 4, C.byref(h)) == BAD_ARG
+    assert L.snn_network_create(0, 0, 0, 0, 5, C.byref(h)) == BAD_ARG
     assert b"selector" in L.snn_last_error()
     dn = snn.DeviceNetwork()                                                        # no spike-train model
     assert code(snn, lambda: dn.add_spike_train_lattice(1, 2, 2)) == BAD_STATE

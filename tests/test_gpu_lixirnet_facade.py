@@ -246,3 +246,46 @@ def test_reward_modulated_lattice_follows_the_rstdp_example(snn):
     assert gpu.get_neuron(2, 2).current_voltage == float(o["current_voltage"][12])
     assert gpu.get_weight((0, 0), (0, 1)).c == float(o["traces"][0, 1]) if cond((0, 0), (0, 1)) else True
     gpu.close()
+
+
+def test_bcm_network_follows_the_bcm_example(snn):
+    """The procedure of backend/examples/bcm/main.rs:53-88 with the Lixirnet-style classes: BCMPoissonNeuron spike
+    trains into one BCMIzhikevichNeuron whose lattice carries the BCM rule."""
+    ln = snn
+    chances = [0.25, 0.125]
+    st = ln.BCMPoissonNeuron(firing_rate_window=5.0)
+    pre = ln.BCMPoissonNeuronLattice(0)
+    pre.populate(st, len(chances), 1)
+    pre.apply_given_position(lambda pos, cell: (setattr(cell, "chance_of_firing", chances[pos[0]]),
+                                                setattr(cell, "seed", 11 + pos[0])))
+    neuron = ln.BCMIzhikevichNeuron(c_m=50.0, gap_conductance=5.0, firing_rate_window=5.0)
+    post = ln.BCMIzhikevichNeuronLattice(1)
+    post.populate(neuron, 1, 1)
+    post.plasticity = ln.BCM()
+    post.do_plasticity = True
+    net = ln.IzhikevichNeuronNetwork.generate_network([post], [pre])
+    wts = [1.45, 1.62]
+    net.connect(0, 1, lambda x, y: True, lambda x, y: wts[x[0]])
+    gpu = ln.IzhikevichNeuronNetworkGPU.from_network(net)
+    gpu.run_lattices(3000)
+
+    lay = parity.Layout([(1, 1, 1)], [(0, 2, 1)])
+    o = parity.make_oracle(lay, model=ob.BCM_IZHIKEVICH, st_kind=ob.ST_BCM_POISSON)
+    o["c_m"] = 50.0
+    o["gap_conductance"] = 5.0
+    o["st_chance_of_firing"] = np.array(chances, np.float32)
+    o["st_seed"] = np.array([11, 12], np.uint32)
+    o["bcm_window"] = 5.0
+    o["st_bcm_window"] = 5.0
+    o["connections"][1:, 0] = 1
+    o["weights"][1:, 0] = np.array(wts, np.float32)
+    o["do_plasticity"] = 1
+    o["plasticity_kind"] = 1
+    o.run(3000)
+    cw = gpu.connecting_weights
+    for i in range(2):
+        assert np.float32(cw[(ln.GraphPosition(0, (i, 0)), ln.GraphPosition(1, (0, 0)))]) == o["weights"][1 + i, 0]
+    n = gpu.get_lattice(1).get_neuron(0, 0)
+    assert np.float32(n.average_activity) == o["bcm_average_activity"][0] and n.num_spikes == int(o["bcm_num_spikes"][0])
+    assert n.num_spikes > 0 and o["weights"][1, 0] != np.float32(1.45)
+    gpu.close()

@@ -439,3 +439,61 @@ def test_exponential_decay_refractoriness_hand_derived():
     dd = f32(L.snn_o_delta_dirac_effect(14, 10, 30.0, -3.0, 50.0, 0.1))
     total = f32(f32(f32(f32(2.0) * dd) * f32(1.0)) + f32(f32(f32(2.0) * f32(e)) * f32(1.0)))
     assert net["input_current"][0] == f32(total / f32(2.0))
+
+
+# ---- BCM (plasticity/mod.rs:72-116, integrate_and_fire/mod.rs:1358-1518, spike_train/mod.rs:835-970) -------------
+def test_bcm_rule_and_activity_bookkeeping_hand_derived():
+    """BCM::update_weight: w += (post.act * (post.act - post.avg / average_scalar) * pre.act - decay * w) * dt on the
+    edges of a spiking neuron; BCMIzhikevichNeuron counts the PREVIOUS step's spike, closes a window when the clock
+    reaches firing_rate_window (rate = num_spikes / (window * dt) without neurotransmission, / window with it) and
+    moves the average by 1/period; num_spikes is never reset."""
+    net = ob.Net(2, model=ob.BCM_IZHIKEVICH)
+    net["plasticity_kind"] = 1
+    net["do_plasticity"] = 1
+    net["bcm_current_activity"][...] = [0.5, 2.0]
+    net["bcm_average_activity"][...] = [0.1, 0.3]
+    net["connections"][0, 1] = 1
+    net["weights"][0, 1] = 1.5
+    net["is_spiking"][1] = 1                       # the postsynaptic neuron spiked: its incoming edge is visited once
+    net.plasticity()
+    sliding = f32(f32(0.3) / f32(0.1))
+    term = f32(f32(2.0) * f32(f32(2.0) - sliding))
+    expect = f32(f32(1.5) + f32(f32(f32(term * f32(0.5)) - f32(f32(0.1) * f32(1.5))) * f32(0.1)))
+    assert net["weights"][0, 1] == expect
+    # both ends spiking: the edge is visited twice (incoming of 1, outgoing of 0), each visit from the current weight
+    net["is_spiking"][0] = 1
+    net.plasticity()
+    w1 = f32(expect + f32(f32(f32(term * f32(0.5)) - f32(f32(0.1) * expect)) * f32(0.1)))
+    w2 = f32(w1 + f32(f32(f32(term * f32(0.5)) - f32(f32(0.1) * w1)) * f32(0.1)))
+    assert net["weights"][0, 1] == w2
+
+    net = ob.Net(1, model=ob.BCM_IZHIKEVICH)
+    net["bcm_window"] = 0.3                        # three steps of dt = 0.1 (clock: 0.1, 0.2, 0.3 in float32)
+    net["is_spiking"][0] = 1
+    net["current_voltage"] = -70.0
+    clock = f32(0)
+    for step in range(3):
+        net.inputs()
+        net.update_neurons()
+        clock = f32(clock + f32(0.1))
+    closes = clock >= f32(0.3)
+    assert net["bcm_num_spikes"][0] == 1           # only the first step saw a previous spike
+    if closes:
+        rate = f32(f32(1.0) / f32(f32(0.3) * f32(0.1)))
+        assert net["bcm_current_activity"][0] == rate and net["bcm_clock"][0] == 0
+        assert net["bcm_average_activity"][0] == f32(f32(0) - f32(0) / f32(3)) + f32(rate / f32(3))
+    else:
+        assert net["bcm_current_activity"][0] == 0 and net["bcm_clock"][0] == clock
+
+
+def test_bcm_poisson_cell_activity():
+    """BCMPoissonNeuron::iterate: activity = voltage change of the step (v_th - V or v_resting - V), then the window."""
+    net = ob.Net(0, n_cells=1, st_kind=ob.ST_BCM_POISSON)
+    net["st_chance_of_firing"] = 1.0               # xorshift32 draw / 2^32 < 1: fires every step
+    net.spike_trains()
+    assert net["st_is_spiking"][0] == 1 and net["st_bcm_current_activity"][0] == f32(30.0) and net["st_bcm_num_spikes"][0] == 1
+    net.spike_trains()
+    assert net["st_bcm_current_activity"][0] == f32(0.0)       # 30 - 30
+    net["st_chance_of_firing"] = 0.0
+    net.spike_trains()
+    assert net["st_bcm_current_activity"][0] == f32(-30.0) and net["st_bcm_num_spikes"][0] == 2
