@@ -1,6 +1,6 @@
-"""Randomised differential test: many small networks drawn from a seeded generator -- model (8), neurotransmitter /
+"""Randomised differential test: many small networks drawn from a seeded generator -- model (9), neurotransmitter /
 receptor kinetics (4 x 3), synapse kinds, lattice shapes, connectivity density, spike-train inputs (Poisson, rate,
-preset), per-lattice plasticity (none / STDP / reward-modulated with a random reward sequence), graph form (dense /
+preset, BCM Poisson), per-lattice plasticity (none / STDP / BCM / reward-modulated with a random reward sequence), graph form (dense /
 sparse), whole or sharded stepping, run split into several calls, reduced histories with a random stride -- each
 compared bit for bit with the oracle."""
 import numpy as np
@@ -11,7 +11,8 @@ import parity
 
 pytestmark = pytest.mark.gpu
 
-MODELS = [ob.IZHIKEVICH, ob.LIF, ob.HH, ob.QIF, ob.SIMPLE_LIF, ob.ADAPTIVE_LIF, ob.ADAPTIVE_EXP_LIF, ob.LEAKY_IZHIKEVICH]
+MODELS = [ob.IZHIKEVICH, ob.LIF, ob.HH, ob.QIF, ob.SIMPLE_LIF, ob.ADAPTIVE_LIF, ob.ADAPTIVE_EXP_LIF, ob.LEAKY_IZHIKEVICH,
+          ob.BCM_IZHIKEVICH]
 
 
 def draw(seed):
@@ -19,7 +20,7 @@ def draw(seed):
     model = MODELS[seed % len(MODELS)]
     n_lat = int(rng.integers(1, 4))
     lattices = [(int(i * 2 + rng.integers(0, 2)), int(rng.integers(1, 9)), int(rng.integers(1, 12))) for i in range(n_lat)]
-    st_kind = [ob.ST_NONE, ob.ST_POISSON, ob.ST_RATE, ob.ST_PRESET][int(rng.integers(0, 4))]
+    st_kind = [ob.ST_NONE, ob.ST_POISSON, ob.ST_RATE, ob.ST_PRESET, ob.ST_BCM_POISSON][int(rng.integers(0, 5))]
     st_lattices = []
     if st_kind != ob.ST_NONE:
         st_lattices = [(100 + i, int(rng.integers(1, 6)), int(rng.integers(1, 8))) for i in range(int(rng.integers(1, 3)))]
@@ -30,7 +31,7 @@ def draw(seed):
     nn, nc = net.n_neurons, net.n_cells
     lo, hi = {ob.IZHIKEVICH: (-65, 30), ob.LIF: (-80, -50), ob.HH: (-75, -40), ob.QIF: (-75, -56),
               ob.SIMPLE_LIF: (-75, -56), ob.ADAPTIVE_LIF: (-75, -56), ob.ADAPTIVE_EXP_LIF: (-75, -56),
-              ob.LEAKY_IZHIKEVICH: (-65, 30)}[model]
+              ob.LEAKY_IZHIKEVICH: (-65, 30), ob.BCM_IZHIKEVICH: (-65, 30)}[model]
     net["current_voltage"] = ob.uniform_array(seed, nn, lo, hi)
     net["gap_conductance"] = ob.uniform_array(seed + 1, nn, 0.5, 12.0)
     if model == ob.SIMPLE_LIF:
@@ -68,6 +69,10 @@ def draw(seed):
     for slot in range(len(lattices)):
         mode = int(rng.integers(0, 3))                  # 0 static weights, 1 STDP, 2 reward-modulated (R-STDP traces)
         net["do_plasticity"][slot] = int(mode == 1)
+        if mode == 1 and model == ob.BCM_IZHIKEVICH and rng.integers(0, 2):
+            net["plasticity_kind"][slot] = 1                    # the BCM rule instead of STDP
+            net["bcm_decay"][slot] = float(rng.uniform(0.01, 0.2))
+            net["bcm_average_scalar"][slot] = float(rng.uniform(0.1, 1.0))
         net["stdp_a_plus"][slot] = float(rng.uniform(0.5, 2.5))
         net["stdp_tau_minus"][slot] = float(rng.uniform(2.0, 6.0))
         if mode == 2:
@@ -84,8 +89,17 @@ def draw(seed):
     net["st_dt"] = dt
     net["stdp_dt"] = dt
     net["rm_dt"] = dt
+    net["bcm_dt"] = dt
+    if model == ob.BCM_IZHIKEVICH:
+        net["bcm_window"] = ob.uniform_array(seed + 12, nn, 5 * dt, 40 * dt)
+        net["bcm_period"] = rng.integers(1, 6, nn).astype(np.uint32)
+    if st_kind == ob.ST_BCM_POISSON:
+        net["st_bcm_window"] = ob.uniform_array(seed + 13, nc, 5 * dt, 40 * dt)
+        net["st_bcm_period"] = rng.integers(1, 6, nc).astype(np.uint32)
     plan = dict(csr=bool(rng.integers(0, 2)), shards=int(rng.choice([1, 1, 2, 3])),
                 steps=int(rng.integers(80, 260)), calls=int(rng.integers(1, 4)), stride=int(rng.choice([1, 1, 2, 5])))
+    if net["plasticity_kind"].any():
+        plan["shards"] = 1                                      # BCM activities are not exchanged between shards
     plan["rewards"] = None
     if net["rm_do_modulation"].any():
         r = ob.uniform_array(seed + 10, plan["steps"], -0.02, 0.03)
@@ -130,7 +144,7 @@ def check_modulation(dn, net, plan):
             assert np.array_equal(parity.bits(np.array([dn.dopamine(i)])), parity.bits(net["rm_dopamine"][slot:slot + 1]))
 
 
-@pytest.mark.parametrize("seed", list(range(64)))
+@pytest.mark.parametrize("seed", list(range(72)))
 def test_random_network(snn, seed):
     import torch
     from snn_amd import parallel
