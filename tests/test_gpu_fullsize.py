@@ -6,6 +6,9 @@
   of every sampled neuron and must reproduce the GPU's S(t+1) for them bit for bit.
 * configs[2] (128x128 Hodgkin-Huxley + Na/K + Destexhe AMPA, electrical + chemical): full oracle run.
 * configs[3]-shaped excitatory/inhibitory network with STDP at a size the host can hold (20 480 neurons).
+* configs[4] (4 x 512^2 Izhikevich neurons + 4 x 512^2 Poisson cells, sparse): the oracle's dense matrix would need
+  4.4 TB; a vectorised numpy restatement of the sparse step (canonical chunked order over <= 14 sorted entries per
+  row, float32 with one rounding per operation) runs the full size next to the device.
 """
 import numpy as np
 import pytest
@@ -211,4 +214,97 @@ def test_c4_full_size_network_with_stdp_sampled(snn):
                         blk = dn.get_graph_rows(p0, min(8192, n - p0))[0]
                         net["weights"][p0:p0 + blk.shape[0], win_spk] = blk[:, c0 + win_spk]
     assert total_spikes >= len(hot)
+    dn.close()
+
+
+def test_c5_full_size_sparse_network_against_numpy(snn):
+    """BASELINE configs[4] at full size: 1 048 576 neurons, 1 048 576 Poisson cells, 14.6 M synapses, 30 steps.
+    Voltages, adaptation variables, spikes, firing times and the cells' generator state bit-identical to a numpy
+    restatement of the same sparse step (gap junctions from neurons and from Poisson cells with the delta-dirac
+    refractoriness, the canonical 256-chunk summation order, Izhikevich update, xorshift32 cells)."""
+    from snn_amd import synthetic
+    import numpy_ref as nr
+    f32 = np.float32
+    side, steps = 512, 30
+    m = side * side
+    nn = nc = 4 * m
+    ptr, pre, w = synthetic.c5_csr(side)
+    dn = snn.DeviceNetwork(model=snn.IZHIKEVICH, spike_train=snn.ST_POISSON)
+    for k in range(4):
+        dn.add_lattice(k, side, side)
+        dn.add_spike_train_lattice(4 + k, side, side)
+    dn.finalize(csr=True)
+    v0 = np.concatenate([synthetic.uniform(6, m, -65.0, 30.0, offset=k * m) for k in range(4)])
+    for k in range(4):
+        dn.set_attr(k, "gap_conductance", np.full(m, 10.0, f32))
+        dn.set_attr(k, "current_voltage", v0[k * m:(k + 1) * m])
+        dn.set_attr(4 + k, "chance_of_firing", np.full(m, 0.01, f32))
+        dn.set_attr(4 + k, "seed", np.arange(k * m + 1, (k + 1) * m + 1, dtype=np.uint32))
+    dn.set_graph_csr(ptr, pre, w)
+    dn.run(steps)
+
+    # ---- numpy restatement ----
+    deg = np.diff(ptr).astype(np.int64)
+    K = int(deg.max())
+    idx = np.full((nn, K), -1, np.int64)
+    rows = np.repeat(np.arange(nn), deg)
+    idx[rows, np.arange(pre.size) - np.repeat(ptr[:-1].astype(np.int64), deg)] = pre
+    n_in = deg.astype(f32)
+    st = {"current_voltage": v0.copy(), "w_value": np.full(nn, 30.0, f32), "a": np.full(nn, 0.02, f32),
+          "b": np.full(nn, 0.2, f32), "c": np.full(nn, -55.0, f32), "d": np.full(nn, 8.0, f32),
+          "v_th": np.full(nn, 30.0, f32), "tau_m": np.full(nn, 1.0, f32), "c_m": np.full(nn, 100.0, f32),
+          "dt": np.full(nn, 0.1, f32)}
+    g = f32(10.0)
+    lft = np.full(nn, -1, np.int32)
+    seed = np.arange(1, nc + 1, dtype=np.uint32)
+    st_lft = np.full(nc, -1, np.int32)
+    expf = np.vectorize(ob.expf, otypes=[np.float32])
+    total_spikes = 0
+    for t in range(steps):
+        # presynaptic value of the cells at clock t (spike_train_gap_junction, neuron/mod.rs:119-137)
+        fired = st_lft >= 0
+        eff = np.zeros(nc, f32)
+        td = (t - st_lft[fired]).astype(f32)
+        scale = f32(f32(-1.0) / f32(f32(10000.0) / f32(0.1)))
+        eff[fired] = (f32(30.0) * expf((scale * (td * td).astype(f32)).astype(f32))).astype(f32) + f32(0.0)
+        v = st["current_voltage"]
+        total = np.zeros(nn, f32)
+        part = np.zeros(nn, f32)
+        cur = np.full(nn, -1, np.int64)
+        for j in range(K):
+            p = idx[:, j]
+            valid = p >= 0
+            pc = np.where(valid, p, 0)
+            is_cell = pc >= nn
+            cell = np.where(is_cell, pc - nn, 0)
+            term_n = (g * (v[np.where(is_cell, 0, pc)] - v).astype(f32)).astype(f32)
+            term_c = np.where(fired[cell], (g * eff[cell]).astype(f32), f32(0.0)).astype(f32)   # never fired: v_resting
+            term = np.where(is_cell, term_c, term_n).astype(f32)
+            chunk = pc // 256
+            flush = valid & (chunk != cur) & (cur >= 0)
+            total = np.where(flush, (total + part).astype(f32), total)
+            part = np.where(valid & (chunk != cur), f32(0.0), part)
+            cur = np.where(valid, chunk, cur)
+            part = np.where(valid, (part + (term * f32(1.0)).astype(f32)).astype(f32), part)
+        total = np.where(cur >= 0, (total + part).astype(f32), total)
+        i_in = (total / n_in).astype(f32)
+        spike = nr.izhikevich_step(st, i_in)
+        lft[spike] = t
+        total_spikes += int(spike.sum())
+        # Poisson cells (GPU generator of the reference, spike_train/mod.rs:380-388, 419-426)
+        with np.errstate(over="ignore"):
+            seed ^= seed << np.uint32(13)
+            seed ^= seed >> np.uint32(17)
+            seed ^= seed << np.uint32(5)
+        cs = (seed.astype(f32) / f32(4294967296.0)).astype(f32) < f32(0.01)
+        st_lft[cs] = t
+    assert total_spikes > 100 and (st_lft >= 0).sum() > 100_000
+
+    for k in range(4):
+        sl = slice(k * m, (k + 1) * m)
+        assert np.array_equal(parity.bits(dn.get_attr(k, "current_voltage")), parity.bits(st["current_voltage"][sl])), k
+        assert np.array_equal(parity.bits(dn.get_attr(k, "w_value")), parity.bits(st["w_value"][sl])), k
+        assert np.array_equal(dn.get_attr(k, "last_firing_time", dtype=np.int32), lft[sl]), k
+        assert np.array_equal(dn.get_attr(4 + k, "seed", dtype=np.uint32), seed[sl]), k
+        assert np.array_equal(dn.get_attr(4 + k, "last_firing_time", dtype=np.int32), st_lft[sl]), k
     dn.close()
