@@ -42,6 +42,28 @@ def build(force=False):
     return LIB_PATH
 
 
+def build_custom(model, force=False):
+    """Compile a library that carries the generated neuron model `model` (modelgen.NeuronModel) as SNN_MODEL_CUSTOM:
+    csrc/generated/<name>.hpp + csrc/generated/libsnn_amd_<name>.so.  Returns the library path."""
+    from . import modelgen
+    gen = os.path.join(CSRC, "generated")
+    os.makedirs(gen, exist_ok=True)
+    header = os.path.join(gen, model.name + ".hpp")
+    out = os.path.join(gen, f"libsnn_amd_{model.name}.so")
+    text = modelgen.hip_source(model)
+    if force or not os.path.exists(header) or open(header).read() != text:
+        with open(header, "w") as f:
+            f.write(text)
+    srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".hpp"))] + [HEADER, header]
+    if not force and os.path.exists(out) and os.path.getmtime(out) >= max(os.path.getmtime(s) for s in srcs):
+        return out
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    define = '-DSNN_CUSTOM_MODEL_HEADER="generated/%s.hpp"' % model.name
+    cmd = [hipcc] + HIPCC_FLAGS + [define, "-o", out, os.path.join(CSRC, "snn_network.hip")]
+    subprocess.run(cmd, check=True, cwd=CSRC)
+    return out
+
+
 f32p = C.POINTER(C.c_float)
 u32p = C.POINTER(C.c_uint32)
 i32p = C.POINTER(C.c_int32)
@@ -53,6 +75,7 @@ H = C.c_void_p   # snn_network_t*
 SIGNATURES = {
     "snn_abi_version": (C.c_int, []),
     "snn_last_error": (C.c_char_p, []),
+    "snn_custom_model": (C.c_char_p, []),
     "snn_network_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(H)]),
     "snn_network_destroy": (C.c_int, [H]),
     "snn_network_add_lattice": (C.c_int, [H, C.c_uint32, C.c_uint32, C.c_uint32]),
@@ -120,9 +143,19 @@ SIGNATURES = {
 _lib = None
 
 
-def load():
-    """Load csrc/libsnn_amd.so and declare every entry point; raises SnnLibraryError if absent."""
+_custom_libs = {}
+
+
+def load(path=None):
+    """Load csrc/libsnn_amd.so (or, with `path`, a library built by build_custom) and declare every entry point;
+    raises SnnLibraryError if absent."""
     global _lib
+    if path is not None:
+        path = os.path.abspath(path)
+        if path not in _custom_libs:
+            load()                                   # torch / HIP runtime ordering as for the default library
+            _custom_libs[path] = _declare(path)
+        return _custom_libs[path]
     if _lib is not None:
         return _lib
     # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7; if it is loaded AFTER
@@ -133,26 +166,30 @@ def load():
         import torch  # noqa: F401
     except ImportError:
         pass
-    if not os.path.exists(LIB_PATH):
+    _lib = _declare(LIB_PATH)
+    return _lib
+
+
+def _declare(path):
+    if not os.path.exists(path):
         raise SnnLibraryError(
-            f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(the stepper has no CPU fallback)")
     try:
-        lib = C.CDLL(LIB_PATH)
+        lib = C.CDLL(path)
     except OSError as e:
-        raise SnnLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+        raise SnnLibraryError(f"cannot load {path}: {e}") from e
     for name, (res, args) in SIGNATURES.items():
         try:
             fn = getattr(lib, name)
         except AttributeError as e:
-            raise SnnLibraryError(f"{LIB_PATH} does not export {name}") from e
+            raise SnnLibraryError(f"{path} does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
-    _lib = lib
     return lib
 
 
-def check(code):
+def check(code, lib=None):
     if code != 0:
-        msg = load().snn_last_error()
+        msg = (lib or load()).snn_last_error()
         raise SnnError(code, msg.decode("utf-8", "replace") if msg else "")

@@ -11,6 +11,7 @@
 // Step order per neuron = SURVEY §8(g) step 2; every expression keeps the reference's f32
 // operation order (no FMA contraction in this TU).
 #pragma once
+#include "snn_custom_model.hpp"
 #include "snn_layout.hpp"
 #include "snn_math.hpp"
 
@@ -284,6 +285,22 @@ __device__ __forceinline__ uint32_t update_neuron(const UpdateArgs &a, uint32_t 
                 w_new += a.n.d[q];
             }
             a.n.w_value[q] = w_new;
+        } else if (MODEL == CUSTOM_MODEL) {
+            // generated model, nb_macro semantics (build_test/nb_macro/src/lib.rs:2259-2345; hand expansion
+            // tests/lif_reference.rs): on_iteration, transmitter release, spike detection, on_spike.  Stepped with
+            // electrical synapses only for now (the host refuses chemical ones for this model).
+            float x[custom::NSTORE];
+#pragma unroll
+            for (int k = 0; k < custom::NVARS; ++k) x[k] = a.n.custom[k][q];
+            const float g_gap = a.n.gap_conductance[q];
+            float vc = v;
+            custom::on_iteration(vc, x, i_in, dt, c_m, g_gap);
+            neuron_nt_update(a, q, vc, spiking_prev, dt);
+            spike = custom::spike_detection(vc, x, i_in, dt, c_m, g_gap) ? 1u : 0u;
+            if (spike) custom::on_spike(vc, x, i_in, dt, c_m, g_gap);
+            v_new = vc;
+#pragma unroll
+            for (int k = 0; k < custom::NVARS; ++k) a.n.custom[k][q] = x[k];
         } else {                     // Hodgkin-Huxley
             const float m_a = 0.1f * ((v + 40.0f) / (1.0f - expf_portable(-(v + 40.0f) / 10.0f)));
             const float m_b = 4.0f * expf_portable(-(v + 65.0f) / 18.0f);

@@ -10,6 +10,7 @@
 extern "C" {
 
 int snn_abi_version(void) { return SNN_ABI_VERSION; }
+const char *snn_custom_model(void) { return custom::TYPE_NAME; }
 const char *snn_last_error(void) { return g_last_error.c_str(); }
 
 int snn_network_create(int device, int neuron_model, int nt_kinetics, int receptor_kinetics,
@@ -17,7 +18,8 @@ int snn_network_create(int device, int neuron_model, int nt_kinetics, int recept
 {
     if (!out) return fail(SNN_ERR_BAD_ARG, "out is null");
     *out = nullptr;
-    if (neuron_model < 0 || neuron_model > 8 || nt_kinetics < 0 || nt_kinetics > 3 || receptor_kinetics < 0 ||
+    const bool custom_ok = SNN_HAVE_CUSTOM_MODEL && neuron_model == SNN_MODEL_CUSTOM;
+    if (((neuron_model < 0 || neuron_model > 8) && !custom_ok) || nt_kinetics < 0 || nt_kinetics > 3 || receptor_kinetics < 0 ||
         receptor_kinetics > 2 || spike_train_model < 0 || spike_train_model > 4)
         return fail(SNN_ERR_BAD_ARG, "unknown model / kinetics selector");
     int ndev = 0;
@@ -333,6 +335,8 @@ int snn_get_graph_csr(snn_network_t *net, float *weights, uint64_t nnz)
 int snn_set_synapses(snn_network_t *net, int electrical_synapse, int chemical_synapse)
 {
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
+    if (net->model == SNN_MODEL_CUSTOM && chemical_synapse)
+        return fail(SNN_ERR_BAD_STATE, "generated models are stepped with electrical synapses only");
     net->electrical = electrical_synapse ? 1 : 0;
     net->chemical = chemical_synapse ? 1 : 0;
     return SNN_OK;

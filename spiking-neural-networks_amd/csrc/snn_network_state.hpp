@@ -275,19 +275,20 @@ int build_state(snn_network *net)
     // reference defaults: Izhikevich integrate_and_fire/mod.rs:1198-1220, LIF :149-171,
     // Hodgkin-Huxley hodgkin_huxley/mod.rs:80-98 + ion_channels/mod.rs:23-31, 205-215, 255-264, 299-307
     const bool bcm = net->model == SNN_MODEL_BCM_IZHIKEVICH;
+    const bool cust = net->model == SNN_MODEL_CUSTOM;
     const bool izh = net->model == SNN_MODEL_IZHIKEVICH || bcm, lif = net->model == SNN_MODEL_LIF;
     const bool qif = net->model == SNN_MODEL_QUADRATIC_INTEGRATE_AND_FIRE, slif = net->model == SNN_MODEL_SIMPLE_LIF;
     const bool alif = net->model == SNN_MODEL_ADAPTIVE_LIF, aelif = net->model == SNN_MODEL_ADAPTIVE_EXP_LIF;
     const bool adp = alif || aelif, lizh = net->model == SNN_MODEL_LEAKY_IZHIKEVICH;
-    const float v0 = (lif || qif || slif || adp) ? -75.0f : -65.0f;
+    const float v0 = cust ? custom::DEFAULT_VOLTAGE : ((lif || qif || slif || adp) ? -75.0f : -65.0f);
     {
         // initial voltage into plane V of every shard slot
         for (uint32_t s = 0; s < net->xl.n_shards; ++s)
             TRY(fill_f32(net, net->xbuf + ((size_t)s * NUM_PLANES + PLANE_V) * net->xl.stride, net->xl.stride, v0));
     }
-    TRY(neuron_f32(net, &n.gap_conductance, "gap_conductance", slif ? 10.0f : 7.0f));
-    TRY(neuron_f32(net, &n.dt, "dt", net->model == SNN_MODEL_HODGKIN_HUXLEY ? 0.01f : 0.1f));
-    TRY(neuron_f32(net, &n.c_m, "c_m", net->model == SNN_MODEL_HODGKIN_HUXLEY ? 1.0f : 100.0f));
+    TRY(neuron_f32(net, &n.gap_conductance, "gap_conductance", cust ? custom::DEFAULT_GAP : (slif ? 10.0f : 7.0f)));
+    TRY(neuron_f32(net, &n.dt, "dt", cust ? custom::DEFAULT_DT : (net->model == SNN_MODEL_HODGKIN_HUXLEY ? 0.01f : 0.1f)));
+    TRY(neuron_f32(net, &n.c_m, "c_m", cust ? custom::DEFAULT_C_M : (net->model == SNN_MODEL_HODGKIN_HUXLEY ? 1.0f : 100.0f)));
     TRY(neuron_f32(net, &n.v_th, "v_th", (izh || lizh) ? 30.0f : ((lif || qif || slif || adp) ? -55.0f : 0.0f)));
     TRY(dev_alloc_t(net, &n.last_firing_time, np));
     HIP_TRY(hipMemsetAsync(n.last_firing_time, 0xFF, (size_t)np * 4, net->stream), SNN_ERR_BUFFER_WRITE);
@@ -310,6 +311,10 @@ int build_state(snn_network *net)
     TRY(neuron_f32(net, &n.adp_alpha, adp ? "alpha" : nullptr, 6.0f));
     TRY(neuron_f32(net, &n.adp_beta, adp ? "beta" : nullptr, 10.0f));
     TRY(neuron_f32(net, &n.slope_factor, aelif ? "slope_factor" : nullptr, 1.0f));
+    // variables of the generated model: registered under their DSL names (a name such as v_th replaces the common one)
+    for (int k = 0; k < CUSTOM_MAX_VARS; ++k) n.custom[k] = nullptr;
+    if (cust)
+        for (int k = 0; k < custom::NVARS; ++k) TRY(neuron_f32(net, &n.custom[k], custom::NAMES[k], custom::DEFAULTS[k]));
     // BCMIzhikevichNeuron's activity bookkeeping, integrate_and_fire/mod.rs:1385-1396, defaults :1425-1430
     TRY(neuron_f32(net, &n.bcm_avg, bcm ? "average_activity" : nullptr, 0.0f));
     TRY(neuron_f32(net, &n.bcm_cur, bcm ? "current_activity" : nullptr, 0.0f));

@@ -159,6 +159,9 @@ int launch_update(snn_network *net)
     case SNN_MODEL_ADAPTIVE_LIF: hipLaunchKernelGGL((k_update<5>), grid, dim3(256), 0, net->stream, a); break;
     case SNN_MODEL_ADAPTIVE_EXP_LIF: hipLaunchKernelGGL((k_update<6>), grid, dim3(256), 0, net->stream, a); break;
     case SNN_MODEL_LEAKY_IZHIKEVICH: hipLaunchKernelGGL((k_update<7>), grid, dim3(256), 0, net->stream, a); break;
+#if SNN_HAVE_CUSTOM_MODEL
+    case SNN_MODEL_CUSTOM: hipLaunchKernelGGL((k_update<CUSTOM_MODEL>), grid, dim3(256), 0, net->stream, a); break;
+#endif
     default: hipLaunchKernelGGL((k_update<0>), grid, dim3(256), 0, net->stream, a); break;
     }
     HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
@@ -201,7 +204,7 @@ int launch_plasticity(snn_network *net)
 // sizes served by the one-launch small-lattice step (snn_kernels_resident.hpp)
 bool fused_step_possible(const snn_network *net)
 {
-    return net->fused_step && !net->csr && net->xl.n_shards == 1 && net->n_loc && net->n_tot &&
+    return net->fused_step && net->model != SNN_MODEL_CUSTOM && !net->csr && net->xl.n_shards == 1 && net->n_loc && net->n_tot &&
            net->n_chunks <= RESIDENT_MAX_CHUNKS && (size_t)net->n_tot * net->ld * 4 <= ((size_t)64 << 20);
 }
 
@@ -421,7 +424,8 @@ int launch_step_resident(snn_network *net)
 // Unsharded sparse handles: row sums + neuron update in one launch (k_step_csr).
 bool fused_csr_step_applies(const snn_network *net)
 {
-    return net->fused_step && net->csr && net->csr_ptr && net->xl.n_shards == 1 && net->n_loc && !net->local_inputs_done;
+    return net->fused_step && net->model != SNN_MODEL_CUSTOM && net->csr && net->csr_ptr && net->xl.n_shards == 1 &&
+           net->n_loc && !net->local_inputs_done;
 }
 
 int launch_step_csr(snn_network *net)

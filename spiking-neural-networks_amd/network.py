@@ -15,6 +15,7 @@ from . import _lib
 
 IZHIKEVICH, LIF, HODGKIN_HUXLEY, QUADRATIC_INTEGRATE_AND_FIRE, SIMPLE_LIF = 0, 1, 2, 3, 4
 ADAPTIVE_LIF, ADAPTIVE_EXP_LIF, LEAKY_IZHIKEVICH, BCM_IZHIKEVICH = 5, 6, 7, 8
+CUSTOM = 100          # the generated model of a library built by _lib.build_custom (modelgen.py)
 NT_APPROXIMATE, NT_DESTEXHE, NT_DISCRETE_SPIKE, NT_EXPONENTIAL_DECAY = 0, 1, 2, 3
 RC_APPROXIMATE, RC_DESTEXHE, RC_EXPONENTIAL_DECAY = 0, 1, 2
 ST_NONE, ST_POISSON, ST_RATE, ST_PRESET, ST_BCM_POISSON = 0, 1, 2, 3, 4
@@ -26,14 +27,17 @@ _PTR = {"f32": _lib.f32p, "u32": _lib.u32p, "i32": _lib.i32p}
 
 class DeviceNetwork:
     def __init__(self, model=IZHIKEVICH, nt_kinetics=NT_APPROXIMATE, receptor_kinetics=RC_APPROXIMATE,
-                 spike_train=ST_NONE, device=0):
-        self._L = _lib.load()
+                 spike_train=ST_NONE, device=0, lib_path=None):
+        self._L = _lib.load(lib_path)
         self._h = _lib.H()
-        _lib.check(self._L.snn_network_create(device, model, nt_kinetics, receptor_kinetics, spike_train,
+        self._check(self._L.snn_network_create(device, model, nt_kinetics, receptor_kinetics, spike_train,
                                               C.byref(self._h)))
         self.model = model
         self.lattices = {}          # id -> (rows, cols, is_spike_train)
         self.finalized = False
+
+    def _check(self, code):
+        _lib.check(code, self._L)
 
     # ---- lifetime -------------------------------------------------------------------------
     def close(self):
@@ -55,25 +59,25 @@ class DeviceNetwork:
 
     # ---- construction ---------------------------------------------------------------------
     def add_lattice(self, id, rows, cols):
-        _lib.check(self._L.snn_network_add_lattice(self._h, id, rows, cols))
+        self._check(self._L.snn_network_add_lattice(self._h, id, rows, cols))
         self.lattices[id] = (rows, cols, False)
 
     def add_spike_train_lattice(self, id, rows, cols):
-        _lib.check(self._L.snn_network_add_spike_train_lattice(self._h, id, rows, cols))
+        self._check(self._L.snn_network_add_spike_train_lattice(self._h, id, rows, cols))
         self.lattices[id] = (rows, cols, True)
 
     def finalize(self, shard_index=None, n_shards=None, csr=False):
         """csr=True: the handle holds a sparse CSR graph (set_graph_csr) instead of a dense matrix"""
         if csr:
-            _lib.check(self._L.snn_network_use_csr(self._h, 1))
+            self._check(self._L.snn_network_use_csr(self._h, 1))
         self.csr = bool(csr)
         if shard_index is None:
-            _lib.check(self._L.snn_network_finalize(self._h))
+            self._check(self._L.snn_network_finalize(self._h))
         else:
-            _lib.check(self._L.snn_network_finalize_shard(self._h, shard_index, n_shards))
+            self._check(self._L.snn_network_finalize_shard(self._h, shard_index, n_shards))
         self.finalized = True
         nn, nc, q0, q1 = (C.c_uint32() for _ in range(4))
-        _lib.check(self._L.snn_network_sizes(self._h, C.byref(nn), C.byref(nc), C.byref(q0), C.byref(q1)))
+        self._check(self._L.snn_network_sizes(self._h, C.byref(nn), C.byref(nc), C.byref(q0), C.byref(q1)))
         self.n_neurons, self.n_cells = nn.value, nc.value
         self.n_tot = self.n_neurons + self.n_cells
         self.post_begin, self.post_end = q0.value, q1.value
@@ -81,7 +85,7 @@ class DeviceNetwork:
 
     def lattice_range(self, id):
         first, count = C.c_uint32(), C.c_uint32()
-        _lib.check(self._L.snn_network_lattice_range(self._h, id, C.byref(first), C.byref(count)))
+        self._check(self._L.snn_network_lattice_range(self._h, id, C.byref(first), C.byref(count)))
         return first.value, count.value
 
     # ---- attributes -----------------------------------------------------------------------
@@ -108,14 +112,14 @@ class DeviceNetwork:
         c = np.ascontiguousarray(connections, dtype=np.uint32)
         if w.shape != c.shape or w.ndim != 2 or w.shape[0] != w.shape[1]:
             raise ValueError("weights / connections must be equal square matrices [n_tot, n_tot]")
-        _lib.check(self._L.snn_set_graph_dense(self._h, w.ctypes.data_as(_lib.f32p), c.ctypes.data_as(_lib.u32p),
+        self._check(self._L.snn_set_graph_dense(self._h, w.ctypes.data_as(_lib.f32p), c.ctypes.data_as(_lib.u32p),
                                                w.shape[0]))
 
     def get_graph_dense(self):
         n = self.n_tot
         w = np.zeros((n, n), np.float32)
         c = np.zeros((n, n), np.uint32)
-        _lib.check(self._L.snn_get_graph_dense(self._h, w.ctypes.data_as(_lib.f32p), c.ctypes.data_as(_lib.u32p), n))
+        self._check(self._L.snn_get_graph_dense(self._h, w.ctypes.data_as(_lib.f32p), c.ctypes.data_as(_lib.u32p), n))
         return w, c
 
     def set_graph_rows(self, pre_begin, weights, connections):
@@ -124,13 +128,13 @@ class DeviceNetwork:
         c = np.ascontiguousarray(connections, dtype=np.uint32)
         if w.shape != c.shape or w.ndim != 2 or w.shape[1] != self.n_neurons:
             raise ValueError("row blocks must be [rows, n_neurons]")
-        _lib.check(self._L.snn_set_graph_rows(self._h, pre_begin, w.shape[0], w.ctypes.data_as(_lib.f32p),
+        self._check(self._L.snn_set_graph_rows(self._h, pre_begin, w.shape[0], w.ctypes.data_as(_lib.f32p),
                                               c.ctypes.data_as(_lib.u32p)))
 
     def get_graph_rows(self, pre_begin, pre_count):
         w = np.zeros((pre_count, self.n_neurons), np.float32)
         c = np.zeros((pre_count, self.n_neurons), np.uint32)
-        _lib.check(self._L.snn_get_graph_rows(self._h, pre_begin, pre_count, w.ctypes.data_as(_lib.f32p),
+        self._check(self._L.snn_get_graph_rows(self._h, pre_begin, pre_count, w.ctypes.data_as(_lib.f32p),
                                               c.ctypes.data_as(_lib.u32p)))
         return w, c
 
@@ -142,57 +146,57 @@ class DeviceNetwork:
         if rp.size != (self.post_end - self.post_begin) + 1 or pi.size != w.size:
             raise ValueError("row_ptr must have n_local + 1 entries and pre_index / weights equal lengths")
         self._nnz = int(w.size)
-        _lib.check(self._L.snn_set_graph_csr(self._h, rp.ctypes.data_as(_lib.u64p), pi.ctypes.data_as(_lib.u32p),
+        self._check(self._L.snn_set_graph_csr(self._h, rp.ctypes.data_as(_lib.u64p), pi.ctypes.data_as(_lib.u32p),
                                              w.ctypes.data_as(_lib.f32p), w.size))
 
     def get_graph_csr(self):
         w = np.empty(getattr(self, "_nnz", 0), np.float32)
-        _lib.check(self._L.snn_get_graph_csr(self._h, w.ctypes.data_as(_lib.f32p), w.size))
+        self._check(self._L.snn_get_graph_csr(self._h, w.ctypes.data_as(_lib.f32p), w.size))
         return w
 
     def fill_graph_synthetic(self, seed, lo, hi, with_diagonal=False):
-        _lib.check(self._L.snn_fill_graph_synthetic(self._h, seed, lo, hi, int(with_diagonal)))
+        self._check(self._L.snn_fill_graph_synthetic(self._h, seed, lo, hi, int(with_diagonal)))
 
     # ---- switches -------------------------------------------------------------------------
     def set_synapses(self, electrical=True, chemical=False):
-        _lib.check(self._L.snn_set_synapses(self._h, int(electrical), int(chemical)))
+        self._check(self._L.snn_set_synapses(self._h, int(electrical), int(chemical)))
 
     def set_plasticity(self, id, a_plus=2.0, a_minus=2.0, tau_plus=4.5, tau_minus=4.5, dt=0.1, do_plasticity=True):
-        _lib.check(self._L.snn_set_plasticity(self._h, id, a_plus, a_minus, tau_plus, tau_minus, dt,
+        self._check(self._L.snn_set_plasticity(self._h, id, a_plus, a_minus, tau_plus, tau_minus, dt,
                                               int(do_plasticity)))
 
     def set_history(self, voltage=False, spikes=False):
-        _lib.check(self._L.snn_set_history(self._h, int(voltage), int(spikes)))
+        self._check(self._L.snn_set_history(self._h, int(voltage), int(spikes)))
 
     def reset_history(self):
-        _lib.check(self._L.snn_reset_history(self._h))
+        self._check(self._L.snn_reset_history(self._h))
 
     def reset_timing(self):
-        _lib.check(self._L.snn_reset_timing(self._h))
+        self._check(self._L.snn_reset_timing(self._h))
 
     @property
     def clock(self):
         v = C.c_uint64()
-        _lib.check(self._L.snn_get_clock(self._h, C.byref(v)))
+        self._check(self._L.snn_get_clock(self._h, C.byref(v)))
         return v.value
 
     # ---- stepping -------------------------------------------------------------------------
     def run(self, iterations):
-        _lib.check(self._L.snn_run(self._h, iterations))
+        self._check(self._L.snn_run(self._h, iterations))
 
     def step_begin(self):
-        _lib.check(self._L.snn_step_begin(self._h))
+        self._check(self._L.snn_step_begin(self._h))
 
     def step_end(self):
-        _lib.check(self._L.snn_step_end(self._h))
+        self._check(self._L.snn_step_end(self._h))
 
     def step_begin_local(self):
-        _lib.check(self._L.snn_step_begin_local(self._h))
+        self._check(self._L.snn_step_begin_local(self._h))
 
     def exchange_buffer(self):
         """(device pointer, words per neuron, padded neuron count) of the all-gather buffer"""
         p, w, n = C.c_void_p(), C.c_uint32(), C.c_uint32()
-        _lib.check(self._L.snn_exchange_buffer(self._h, C.byref(p), C.byref(w), C.byref(n)))
+        self._check(self._L.snn_exchange_buffer(self._h, C.byref(p), C.byref(w), C.byref(n)))
         return p.value, w.value, n.value
 
     def set_stream(self, hip_stream):
@@ -200,79 +204,79 @@ class DeviceNetwork:
         None returns to the handle's own stream.  The legacy default stream (handle 0) cannot be adopted --
         create a real stream (e.g. torch.cuda.Stream()) so that collectives can be ordered against it."""
         if hip_stream is None:
-            _lib.check(self._L.snn_set_stream(self._h, None))
+            self._check(self._L.snn_set_stream(self._h, None))
             return
         if int(hip_stream) == 0:
             raise ValueError("the default (null) stream cannot be adopted: pass a non-default stream handle")
-        _lib.check(self._L.snn_set_stream(self._h, C.c_void_p(int(hip_stream))))
+        self._check(self._L.snn_set_stream(self._h, C.c_void_p(int(hip_stream))))
 
     def synchronize(self):
-        _lib.check(self._L.snn_synchronize(self._h))
+        self._check(self._L.snn_synchronize(self._h))
 
     def stream(self):
         p = C.c_void_p()
-        _lib.check(self._L.snn_stream(self._h, C.byref(p)))
+        self._check(self._L.snn_stream(self._h, C.byref(p)))
         return p.value
 
     # ---- histories ------------------------------------------------------------------------
     def history_steps(self):
         v = C.c_uint64()
-        _lib.check(self._L.snn_history_steps(self._h, C.byref(v)))
+        self._check(self._L.snn_history_steps(self._h, C.byref(v)))
         return v.value
 
     def voltage_history(self, id):
         rows, cols, _ = self.lattices[id]
         steps = self.history_steps()
         out = np.empty((steps, rows * cols), np.float32)
-        _lib.check(self._L.snn_get_voltage_history(self._h, id, out.ctypes.data_as(_lib.f32p), out.size))
+        self._check(self._L.snn_get_voltage_history(self._h, id, out.ctypes.data_as(_lib.f32p), out.size))
         return out
 
     def spike_history(self, id):
         rows, cols, _ = self.lattices[id]
         steps = self.history_steps()
         out = np.empty((steps, rows * cols), np.uint8)
-        _lib.check(self._L.snn_get_spike_history(self._h, id, out.ctypes.data_as(_lib.u8p), out.size))
+        self._check(self._L.snn_get_spike_history(self._h, id, out.ctypes.data_as(_lib.u8p), out.size))
         return out
 
     def set_bcm(self, id, decay=0.1, average_scalar=0.1, dt=0.1, do_plasticity=True):
         """BCM rule (plasticity/mod.rs:72-116) for lattice `id` instead of STDP"""
-        _lib.check(self._L.snn_set_bcm(self._h, id, decay, average_scalar, dt, int(do_plasticity)))
+        self._check(self._L.snn_set_bcm(self._h, id, decay, average_scalar, dt, int(do_plasticity)))
 
     # ---- reward modulation (RewardModulatedLattice, neuron/mod.rs:2719-3417) -----------------
     def set_reward_modulator(self, id, dopamine=0.0, tau_d=20.0, tau_c=0.0001, a_plus=2.0, a_minus=2.0, tau_plus=4.5,
                              tau_minus=4.5, dt=0.1, do_modulation=True):
-        _lib.check(self._L.snn_set_reward_modulator(self._h, id, dopamine, tau_d, tau_c, a_plus, a_minus, tau_plus,
+        self._check(self._L.snn_set_reward_modulator(self._h, id, dopamine, tau_d, tau_c, a_plus, a_minus, tau_plus,
                                                     tau_minus, dt, int(do_modulation)))
 
     def dopamine(self, id):
         out = C.c_float()
-        _lib.check(self._L.snn_get_dopamine(self._h, id, C.byref(out)))
+        self._check(self._L.snn_get_dopamine(self._h, id, C.byref(out)))
         return np.float32(out.value)
 
     def apply_reward(self, reward):
-        _lib.check(self._L.snn_apply_reward(self._h, reward))
+        self._check(self._L.snn_apply_reward(self._h, reward))
 
     def run_with_reward(self, reward):
-        _lib.check(self._L.snn_run_with_reward(self._h, reward))
+        self._check(self._L.snn_run_with_reward(self._h, reward))
 
     def set_trace_rows(self, pre_begin, traces):
         t = np.ascontiguousarray(traces, dtype=np.float32)
         if t.ndim != 2 or t.shape[1] != self.n_neurons:
             raise ValueError("traces must be [rows][n_neurons]")
-        _lib.check(self._L.snn_set_trace_rows(self._h, pre_begin, t.shape[0], t.ctypes.data_as(_lib.f32p)))
+        self._check(self._L.snn_set_trace_rows(self._h, pre_begin, t.shape[0], t.ctypes.data_as(_lib.f32p)))
 
     def get_trace_rows(self, pre_begin, pre_count):
         t = np.zeros((pre_count, self.n_neurons), np.float32)
-        _lib.check(self._L.snn_get_trace_rows(self._h, pre_begin, pre_count, t.ctypes.data_as(_lib.f32p)))
+        self._check(self._L.snn_get_trace_rows(self._h, pre_begin, pre_count, t.ctypes.data_as(_lib.f32p)))
         return t
 
     def set_traces_csr(self, traces):
         t = np.ascontiguousarray(traces, dtype=np.float32)
-        _lib.check(self._L.snn_set_traces_csr(self._h, t.ctypes.data_as(_lib.f32p), t.size))
+        self._check(self._L.snn_set_traces_csr(self._h, t.ctypes.data_as(_lib.f32p), t.size))
 
     def get_traces_csr(self):
         t = np.empty(getattr(self, "_nnz", 0), np.float32)
-        _lib.check(self._L.snn_get_traces_csr(self._h, t.ctypes.data_as(_lib.f32p), t.size))
+        self._check(self._L.snn_get_traces_csr(self._h, t.ctypes.data_as(_lib.f32p), t.size))
         return t
 
     def set_firing_times(self, id, cell_ptr, times):
@@ -283,59 +287,59 @@ class DeviceNetwork:
         rows, cols, _ = self.lattices[id]
         if cp.size != rows * cols + 1:
             raise ValueError("cell_ptr must have rows*cols + 1 entries")
-        _lib.check(self._L.snn_set_firing_times(self._h, id, cp.ctypes.data_as(_lib.u32p),
+        self._check(self._L.snn_set_firing_times(self._h, id, cp.ctypes.data_as(_lib.u32p),
                                                 t.ctypes.data_as(_lib.f32p), t.size))
 
     def set_graph_history(self, id, enable=True):
-        _lib.check(self._L.snn_set_graph_history(self._h, id, int(enable)))
+        self._check(self._L.snn_set_graph_history(self._h, id, int(enable)))
 
     def graph_history(self, id):
         """[steps][n][n] snapshots of lattice `id`'s internal weights (update_graph_history)"""
         rows, cols, _ = self.lattices[id]
         n = rows * cols
         out = np.empty((self.history_steps(), n, n), np.float32)
-        _lib.check(self._L.snn_get_graph_history(self._h, id, out.ctypes.data_as(_lib.f32p), out.shape[0]))
+        self._check(self._L.snn_get_graph_history(self._h, id, out.ctypes.data_as(_lib.f32p), out.shape[0]))
         return out
 
     def set_history_stride(self, every):
-        _lib.check(self._L.snn_set_history_stride(self._h, int(every)))
+        self._check(self._L.snn_set_history_stride(self._h, int(every)))
 
     def set_reduced_history(self, average_voltage=False, eeg=False, spike_counts=False,
                             reference_voltage=0.007, distance=0.8, conductivity=251.0):
-        _lib.check(self._L.snn_set_reduced_history(self._h, int(average_voltage), int(eeg), int(spike_counts),
+        self._check(self._L.snn_set_reduced_history(self._h, int(average_voltage), int(eeg), int(spike_counts),
                                                    reference_voltage, distance, conductivity))
 
     def average_voltage_history(self, id):
         out = np.empty(self.history_steps(), np.float32)
-        _lib.check(self._L.snn_get_average_voltage_history(self._h, id, out.ctypes.data_as(_lib.f32p), out.size))
+        self._check(self._L.snn_get_average_voltage_history(self._h, id, out.ctypes.data_as(_lib.f32p), out.size))
         return out
 
     def eeg_history(self, id):
         out = np.empty(self.history_steps(), np.float32)
-        _lib.check(self._L.snn_get_eeg_history(self._h, id, out.ctypes.data_as(_lib.f32p), out.size))
+        self._check(self._L.snn_get_eeg_history(self._h, id, out.ctypes.data_as(_lib.f32p), out.size))
         return out
 
     def spike_counts(self, id):
         rows, cols, _ = self.lattices[id]
         out = np.empty(rows * cols, np.uint32)
-        _lib.check(self._L.snn_get_spike_counts(self._h, id, out.ctypes.data_as(_lib.u32p), out.size))
+        self._check(self._L.snn_get_spike_counts(self._h, id, out.ctypes.data_as(_lib.u32p), out.size))
         return out
 
     # ---- measurement ----------------------------------------------------------------------
     def profile_enable(self, on=True):
-        _lib.check(self._L.snn_profile_enable(self._h, int(on)))
+        self._check(self._L.snn_profile_enable(self._h, int(on)))
 
     def profile_reset(self):
-        _lib.check(self._L.snn_profile_reset(self._h))
+        self._check(self._L.snn_profile_reset(self._h))
 
     def profile_read(self):
         n, ms = C.c_uint64(), C.c_double()
-        _lib.check(self._L.snn_profile_read(self._h, C.byref(n), C.byref(ms)))
+        self._check(self._L.snn_profile_read(self._h, C.byref(n), C.byref(ms)))
         return n.value, ms.value
 
     def input_kernel_bytes(self):
         v = C.c_uint64()
-        _lib.check(self._L.snn_input_kernel_bytes(self._h, C.byref(v)))
+        self._check(self._L.snn_input_kernel_bytes(self._h, C.byref(v)))
         return v.value
 
 

@@ -1,0 +1,102 @@
+"""The neuron-description front end (spiking-neural-networks_amd/modelgen.py) on the CPU: it reads the reference's own
+DSL file, refuses what it does not implement, and emits the expected HIP for the pieces that carry the arithmetic."""
+import os
+
+import numpy as np
+import pytest
+
+import snn_amd
+from snn_amd import modelgen
+
+LIF_NB = """
+[neuron]
+    type: BasicIntegrateAndFire
+    vars: e = 0, v_reset = -75, v_th = -55
+    on_spike:
+        v = v_reset
+    spike_detection: v >= v_th
+    on_iteration:
+        dv/dt = (v - e) + i
+[end]"""          # = /root/reference/build_test/nb_macro/tests/lif.nb (the reference's fixture, restated as data)
+
+IZH_DSL = """
+[neuron]
+    type: DslIzhikevich
+    vars: a = 0.02, b = 0.2, c = -55, d = 8, w = 30, v_th = 30, tau_m = 1, c_m = 100, current_voltage = -65
+    on_spike:
+        v = c
+        w += d
+    spike_detection: v >= v_th
+    on_iteration:
+        dv/dt = (0.04 * v * v + 5 * v + 140 - w + i) / c_m
+        dw/dt = (a * (b * v - w)) / tau_m
+[end]"""
+
+
+def test_parses_the_reference_fixture():
+    m = modelgen.parse(LIF_NB)
+    assert m.name == "BasicIntegrateAndFire"
+    assert m.variables == [("e", 0.0), ("v_reset", -75.0), ("v_th", -55.0)]
+    assert m.mandatory == {"current_voltage": 0.0, "dt": 0.1, "c_m": 1.0, "gap_conductance": 10.0}
+    assert m.on_iteration == [("diff", "v", ("bin", "+", ("bin", "-", ("var", "v"), ("var", "e")), ("var", "i")))]
+    assert m.spike_detection == ("bin", ">=", ("var", "v"), ("var", "v_th"))
+    assert m.on_spike == [("assign", "v", "=", ("var", "v_reset"))]
+    src = modelgen.hip_source(m)
+    assert "const float d_v = (((v - x[0]) + i_in)) * dt;" in src and "v += d_v;" in src
+    assert "return (v >= x[2]);" in src and "v = x[1];" in src
+    path = "/root/reference/build_test/nb_macro/tests/lif.nb"
+    if os.path.exists(path):                       # this container only: the committed text equals the reference's file
+        assert modelgen.parse(open(path).read()).variables == m.variables
+
+
+def test_mandatory_overrides_precedence_and_order_of_application():
+    m = modelgen.parse(IZH_DSL)
+    assert m.mandatory["c_m"] == 100.0 and m.mandatory["current_voltage"] == -65.0
+    assert [n for n, _ in m.variables] == ["a", "b", "c", "d", "w", "v_th", "tau_m"]
+    src = modelgen.hip_source(m)
+    # left-to-right, one operation per node; both derivatives are formed before either variable moves
+    assert "(((((0.03999999910593033f * v) * v) + (5.0f * v)) + 140.0f) - x[4]) + i_in) / c_m)" in src
+    i_dv, i_dw, i_apply = src.index("const float d_v"), src.index("const float d_w"), src.index("v += d_v;")
+    assert i_dv < i_dw < i_apply < src.index("x[4] += d_w;")
+    assert "x[4] += x[3];" in src                  # on_spike: w += d
+
+
+@pytest.mark.parametrize("text,needle", [
+    (LIF_NB.replace("dv/dt = (v - e) + i", "dv/dt = (v - e) ^ 2"), "'^'"),
+    (LIF_NB.replace("dv/dt = (v - e) + i", "dv/dt = tanh(v)"), "tanh"),
+    (LIF_NB.replace("spike_detection: v >= v_th", "spike_detection: continuous()"), "continuous"),
+    (LIF_NB.replace("vars: e = 0", "vars: flag = true, e = 0"), "bool"),
+    (LIF_NB.replace("dv/dt = (v - e) + i", "dv/dt = (v - q) + i"), "unknown variable"),
+    (LIF_NB.replace("[neuron]", "[ion_channel]"), "exactly one [neuron]"),
+    (LIF_NB.replace("on_iteration:", "ion_channels: k = K\n    on_iteration:"), "ion_channels"),
+    (LIF_NB.replace("v = v_reset", "dt = 1"), "cannot assign"),
+])
+def test_unsupported_descriptions_are_refused_with_a_reason(text, needle):
+    with pytest.raises(modelgen.ModelError) as e:
+        modelgen.parse(text)
+    assert needle in str(e.value)
+
+
+def test_interpreter_reproduces_the_reference_hand_expansion():
+    """build_test/nb_macro/tests/lif_reference.rs (the struct basic_lif.rs compares the generated code with):
+    dv = ((V - e) + I) * dt; V += dv; spike = V >= v_th; if spike V = v_reset -- 1000 iterations for each input of
+    basic_lif.rs:22."""
+    import modelgen_ref
+    f32 = np.float32
+    m = modelgen.parse(LIF_NB)
+    step = modelgen_ref.make_step(m)
+    currents = np.array([-50., -40., -30., -20., -10., 0., 10., 20., 30., 40., 50.], f32)
+    n = currents.size
+    st = {"current_voltage": np.zeros(n, f32), "dt": np.full(n, 0.1, f32), "c_m": np.ones(n, f32),
+          "gap_conductance": np.full(n, 10.0, f32), "e": np.zeros(n, f32), "v_reset": np.full(n, -75.0, f32),
+          "v_th": np.full(n, -55.0, f32)}
+    v = np.zeros(n, f32)
+    old = np.seterr(over="ignore", invalid="ignore")       # the leak is positive: voltages run away to -inf
+    for _ in range(1000):
+        spike = step(st, currents)
+        dv = (((v - f32(0.0)).astype(f32) + currents).astype(f32) * f32(0.1)).astype(f32)
+        v = (v + dv).astype(f32)
+        ref_spike = v >= f32(-55.0)
+        v = np.where(ref_spike, f32(-75.0), v).astype(f32)
+        assert np.array_equal(spike, ref_spike) and np.array_equal(st["current_voltage"].view(np.uint32), v.view(np.uint32))
+    np.seterr(**old)
