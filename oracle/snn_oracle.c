@@ -570,6 +570,75 @@ static uint32_t step_leaky_izhikevich(snn_o_net *n, uint32_t q)
     return spike;
 }
 
+/* A generated model as a stack program (see snn_oracle.h).  Slots: 0 v, 1 i, 2 dt, 3 c_m, 4 gap_conductance,
+ * 5.. model variables.  Values are float32; comparisons / logic leave 1.0f or 0.0f. */
+enum { OP_END = 0, OP_CONST = 1, OP_LOAD = 2, OP_STORE = 3, OP_DIFF = 4, OP_NEG = 5, OP_NOT = 6, OP_ADD = 7, OP_SUB = 8,
+       OP_MUL = 9, OP_DIV = 10, OP_EXP = 11, OP_EQ = 12, OP_NE = 13, OP_GE = 14, OP_LE = 15, OP_GT = 16, OP_LT = 17,
+       OP_AND = 18, OP_OR = 19 };
+
+static float custom_run(const snn_o_net *n, uint32_t pc, float *slot, int apply_diffs)
+{
+    float stack[64], diff[32];
+    uint32_t diff_slot[32];
+    int sp = 0, nd = 0;
+    const int32_t *c = n->custom_code;
+    for (;;) {
+        int32_t op = c[pc++];
+        if (op == OP_END) break;
+        switch (op) {
+        case OP_CONST: stack[sp++] = n->custom_consts[c[pc++]]; break;
+        case OP_LOAD:  stack[sp++] = slot[c[pc++]]; break;
+        case OP_STORE: slot[c[pc++]] = stack[--sp]; break;
+        case OP_DIFF:  diff[nd] = stack[--sp] * slot[2]; diff_slot[nd++] = (uint32_t)c[pc++]; break;   /* (expr) * dt */
+        case OP_NEG:   stack[sp - 1] = -stack[sp - 1]; break;
+        case OP_NOT:   stack[sp - 1] = (stack[sp - 1] != 0.0f) ? 0.0f : 1.0f; break;
+        case OP_EXP:   stack[sp - 1] = snn_o_expf(stack[sp - 1]); break;
+        default: {
+            float b = stack[--sp], a = stack[--sp], r = 0.0f;
+            switch (op) {
+            case OP_ADD: r = a + b; break;
+            case OP_SUB: r = a - b; break;
+            case OP_MUL: r = a * b; break;
+            case OP_DIV: r = a / b; break;
+            case OP_EQ: r = (a == b); break;
+            case OP_NE: r = (a != b); break;
+            case OP_GE: r = (a >= b); break;
+            case OP_LE: r = (a <= b); break;
+            case OP_GT: r = (a > b); break;
+            case OP_LT: r = (a < b); break;
+            case OP_AND: r = (a != 0.0f && b != 0.0f); break;
+            case OP_OR: r = (a != 0.0f || b != 0.0f); break;
+            }
+            stack[sp++] = r;
+        } }
+    }
+    if (apply_diffs)
+        for (int k = 0; k < nd; ++k) slot[diff_slot[k]] += diff[k];    /* every `x += dx` after the last statement */
+    return sp ? stack[sp - 1] : 0.0f;
+}
+
+/* neuron_builder!-generated iterate_and_spike / iterate_with_neurotransmitter_and_spike,
+ * build_test/nb_macro/src/lib.rs:2259-2345 (hand expansion: build_test/nb_macro/tests/lif_reference.rs) */
+static uint32_t step_custom(snn_o_net *n, uint32_t q)
+{
+    const uint32_t nn = n->n_neurons, spiking_prev = n->is_spiking[q];
+    float slot[5 + 32];
+    slot[0] = n->current_voltage[q]; slot[1] = n->input_current[q]; slot[2] = n->dt[q]; slot[3] = n->c_m[q];
+    slot[4] = n->gap_conductance[q];
+    for (uint32_t k = 0; k < n->custom_nvars; ++k) slot[5 + k] = n->custom_vars[(size_t)k * nn + q];
+
+    if (n->chemical) receptors_update(n, q, slot[0]);
+    custom_run(n, n->custom_section[0], slot, 1);
+    if (n->chemical) slot[0] -= receptor_currents(n, q);
+    neuron_nt_update(n, q, slot[0], spiking_prev);
+    uint32_t spike = custom_run(n, n->custom_section[1], slot, 0) != 0.0f;
+    if (spike) custom_run(n, n->custom_section[2], slot, 0);
+
+    n->current_voltage[q] = slot[0];
+    for (uint32_t k = 0; k < n->custom_nvars; ++k) n->custom_vars[(size_t)k * nn + q] = slot[5 + k];
+    return spike;
+}
+
 /* BasicGatingVariable::update, ion_channels/mod.rs:40-44 */
 static inline float gate_update(float state, float alpha, float beta, float dt)
 {
@@ -640,6 +709,7 @@ void snn_o_update_neurons_range(snn_o_net *n, uint32_t q0, uint32_t q1)
         case SNN_O_ADAPTIVE_LIF: spike = step_adaptive(n, q, 0); break;
         case SNN_O_ADAPTIVE_EXP_LIF: spike = step_adaptive(n, q, 1); break;
         case SNN_O_LEAKY_IZHIKEVICH: spike = step_leaky_izhikevich(n, q); break;
+        case SNN_O_CUSTOM: spike = step_custom(n, q); break;
         case SNN_O_BCM_IZHIKEVICH:
             /* activity bookkeeping first (previous step's spike flag), then the Izhikevich step */
             if (n->is_spiking[q]) n->bcm_num_spikes[q] += 1;

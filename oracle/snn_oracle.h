@@ -55,7 +55,7 @@ extern "C" {
 
 enum { SNN_O_IZHIKEVICH = 0, SNN_O_LIF = 1, SNN_O_HH = 2, SNN_O_QIF = 3, SNN_O_SIMPLE_LIF = 4,
        SNN_O_ADAPTIVE_LIF = 5, SNN_O_ADAPTIVE_EXP_LIF = 6, SNN_O_LEAKY_IZHIKEVICH = 7,
-       SNN_O_BCM_IZHIKEVICH = 8 };
+       SNN_O_BCM_IZHIKEVICH = 8, SNN_O_CUSTOM = 100 };
 enum { SNN_O_NT_APPROX = 0, SNN_O_NT_DESTEXHE = 1, SNN_O_NT_DISCRETE_SPIKE = 2, SNN_O_NT_EXPONENTIAL_DECAY = 3 };
 enum { SNN_O_RC_APPROX = 0, SNN_O_RC_DESTEXHE = 1, SNN_O_RC_EXPONENTIAL_DECAY = 2 };
 enum { SNN_O_ST_NONE = 0, SNN_O_ST_POISSON = 1, SNN_O_ST_RATE = 2, SNN_O_ST_PRESET = 3, SNN_O_ST_BCM_POISSON = 4 };
@@ -175,6 +175,16 @@ typedef struct snn_o_net {
     uint32_t *bcm_period, *bcm_num_spikes;                                             /* [n_neurons] */
     float    *st_bcm_average_activity, *st_bcm_current_activity, *st_bcm_clock, *st_bcm_window;   /* [n_cells] */
     uint32_t *st_bcm_period, *st_bcm_num_spikes;                                                   /* [n_cells] */
+    /* SNN_O_CUSTOM: a neuron model given as a small stack program (tests/modelgen_ref.py compiles it from the same
+     * description the product turns into HIP; semantics of the reference's neuron_builder! output,
+     * build_test/nb_macro/src/lib.rs:2259-2345).  custom_code = int32 words, three sections starting at
+     * custom_section[0..2] (on_iteration, spike_detection, on_spike), each ended by OP_END; custom_vars[k] is the
+     * k-th model variable, [n_neurons]. */
+    const int32_t *custom_code;
+    const float   *custom_consts;
+    uint32_t custom_section[3];
+    uint32_t custom_nvars;
+    float    *custom_vars;                     /* [custom_nvars][n_neurons] */
 } snn_o_net;
 
 /* Step 1 of SURVEY §8(g): electrical + chemical inputs for every neuron from state S(t). */

@@ -287,14 +287,15 @@ __device__ __forceinline__ uint32_t update_neuron(const UpdateArgs &a, uint32_t 
             a.n.w_value[q] = w_new;
         } else if (MODEL == CUSTOM_MODEL) {
             // generated model, nb_macro semantics (build_test/nb_macro/src/lib.rs:2259-2345; hand expansion
-            // tests/lif_reference.rs): on_iteration, transmitter release, spike detection, on_spike.  Stepped with
-            // electrical synapses only for now (the host refuses chemical ones for this model).
+            // tests/lif_reference.rs): on_iteration, `v -= receptor currents` with neurotransmission (the receptor
+            // kinetics and currents were taken at the old voltage above), transmitter release, spike detection, on_spike
             float x[custom::NSTORE];
 #pragma unroll
             for (int k = 0; k < custom::NVARS; ++k) x[k] = a.n.custom[k][q];
             const float g_gap = a.n.gap_conductance[q];
             float vc = v;
             custom::on_iteration(vc, x, i_in, dt, c_m, g_gap);
+            if (a.chemical) vc -= receptor_currents(a, q, dt, c_m);
             neuron_nt_update(a, q, vc, spiking_prev, dt);
             spike = custom::spike_detection(vc, x, i_in, dt, c_m, g_gap) ? 1u : 0u;
             if (spike) custom::on_spike(vc, x, i_in, dt, c_m, g_gap);

@@ -335,8 +335,6 @@ int snn_get_graph_csr(snn_network_t *net, float *weights, uint64_t nnz)
 int snn_set_synapses(snn_network_t *net, int electrical_synapse, int chemical_synapse)
 {
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
-    if (net->model == SNN_MODEL_CUSTOM && chemical_synapse)
-        return fail(SNN_ERR_BAD_STATE, "generated models are stepped with electrical synapses only");
     net->electrical = electrical_synapse ? 1 : 0;
     net->chemical = chemical_synapse ? 1 : 0;
     return SNN_OK;

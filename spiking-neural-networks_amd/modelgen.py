@@ -20,7 +20,8 @@ the reference tests against is build_test/nb_macro/tests/lif_reference.rs):
     `x += dx` is applied after the last statement, in statement order;
   * electrical step: on_iteration; neurotransmitter release; is_spiking = spike_detection; on_spike if spiking;
     with neurotransmission: receptor kinetics and currents at the old voltage first, and
-    `v -= receptor currents * (dt / c_m)` right after on_iteration;
+    `v -= receptor currents * (dt / c_m)` right after on_iteration (the Ionotropic AMPA/NMDA/GABA receptors of the
+    hot path stand where the generated Rust uses its receptor type);
   * every binary operation is one float32 operation, evaluated left to right as written (no contraction).
 
 `hip_source(model)` emits the header that csrc/snn_custom_model.hpp includes when the library is compiled with

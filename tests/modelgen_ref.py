@@ -64,3 +64,75 @@ def make_step(model):
             state[name] = env[name]
         return spike
     return step
+
+
+# ---- stack program for the C oracle (oracle/snn_oracle.c::custom_run) -------------------------------------
+_OPS = dict(END=0, CONST=1, LOAD=2, STORE=3, DIFF=4, NEG=5, NOT=6, ADD=7, SUB=8, MUL=9, DIV=10, EXP=11, EQ=12, NE=13,
+            GE=14, LE=15, GT=16, LT=17, AND=18, OR=19)
+_BIN = {"+": "ADD", "-": "SUB", "*": "MUL", "/": "DIV", "==": "EQ", "!=": "NE", ">=": "GE", "<=": "LE", ">": "GT",
+        "<": "LT", "&&": "AND", "||": "OR"}
+_BASE_SLOTS = {"v": 0, "i": 1, "dt": 2, "c_m": 3, "gap_conductance": 4}
+
+
+def compile_program(model):
+    """(code int32[], consts float32[], sections uint32[3]) of the oracle's stack machine"""
+    slots = dict(_BASE_SLOTS)
+    for k, (name, _) in enumerate(model.variables):
+        slots[name] = 5 + k
+    code, consts = [], []
+
+    def emit_expr(e):
+        kind = e[0]
+        if kind == "num":
+            consts.append(np.float32(e[1]))
+            code.extend([_OPS["CONST"], len(consts) - 1])
+        elif kind == "var":
+            code.extend([_OPS["LOAD"], slots[e[1]]])
+        elif kind in ("neg", "not"):
+            emit_expr(e[1])
+            code.append(_OPS["NEG" if kind == "neg" else "NOT"])
+        elif kind == "call":
+            emit_expr(e[2][0])
+            code.append(_OPS["EXP"])
+        else:
+            emit_expr(e[2])
+            emit_expr(e[3])
+            code.append(_OPS[_BIN[e[1]]])
+
+    def emit_block(stmts):
+        start = len(code)
+        for s in stmts:
+            if s[0] == "diff":
+                emit_expr(s[2])
+                code.extend([_OPS["DIFF"], slots[s[1]]])
+            else:
+                _, name, op, expr = s
+                emit_expr(expr if op == "=" else ("bin", op[0], ("var", name), expr))
+                code.extend([_OPS["STORE"], slots[name]])
+        code.append(_OPS["END"])
+        return start
+
+    s0 = emit_block(model.on_iteration)
+    s1 = len(code)
+    emit_expr(model.spike_detection)
+    code.append(_OPS["END"])
+    s2 = emit_block(model.on_spike)
+    return (np.array(code, np.int32), np.array(consts if consts else [0.0], np.float32),
+            np.array([s0, s1, s2], np.uint32))
+
+
+def attach(net, model):
+    """Make an oracle Net (created with model=ob.CUSTOM) step `model`: program + variable arrays + DSL defaults."""
+    code, consts, sections = compile_program(model)
+    net.custom_model = model
+    net.arr["custom_code"], net.arr["custom_consts"] = code, consts
+    net.custom_section = sections
+    net.custom_nvars = len(model.variables)
+    net.arr["custom_vars"] = np.zeros((max(1, len(model.variables)), net.n_neurons), np.float32)
+    for k, (_, default) in enumerate(model.variables):
+        net.arr["custom_vars"][k] = default
+    net["current_voltage"] = model.mandatory["current_voltage"]
+    net["dt"] = model.mandatory["dt"]
+    net["c_m"] = model.mandatory["c_m"]
+    net["gap_conductance"] = model.mandatory["gap_conductance"]
+    return net

@@ -13,6 +13,7 @@ import numpy as np
 K = 3          # AMPA, NMDA, GABA
 CHUNK = 256
 IZHIKEVICH, LIF, HH, QIF, SIMPLE_LIF, ADAPTIVE_LIF, ADAPTIVE_EXP_LIF, LEAKY_IZHIKEVICH, BCM_IZHIKEVICH = range(9)
+CUSTOM = 100
 NT_APPROX, NT_DESTEXHE, NT_DISCRETE_SPIKE, NT_EXPONENTIAL_DECAY = 0, 1, 2, 3
 RC_APPROX, RC_DESTEXHE, RC_EXPONENTIAL_DECAY = 0, 1, 2
 ST_NONE, ST_POISSON, ST_RATE, ST_PRESET, ST_BCM_POISSON = 0, 1, 2, 3, 4
@@ -75,6 +76,8 @@ _FIELDS = [
     ("bcm_period", u32p), ("bcm_num_spikes", u32p),
     ("st_bcm_average_activity", f32p), ("st_bcm_current_activity", f32p), ("st_bcm_clock", f32p), ("st_bcm_window", f32p),
     ("st_bcm_period", u32p), ("st_bcm_num_spikes", u32p),
+    ("custom_code", C.POINTER(C.c_int32)), ("custom_consts", f32p), ("custom_section", C.c_uint32 * 3),
+    ("custom_nvars", C.c_uint32), ("custom_vars", f32p),
 ]
 
 
@@ -171,6 +174,8 @@ NEURON_DEFAULTS = {
     # integrate_and_fire/mod.rs:1409-1436
     BCM_IZHIKEVICH: dict(current_voltage=-65.0, gap_conductance=7.0, w_value=30.0, a=0.02, b=0.2, c=-55.0, d=8.0,
                          v_th=30.0, tau_m=1.0, c_m=100.0, dt=0.1),
+    # generated model: the DSL's mandatory defaults (build_test/nb_macro/src/lib.rs:2200-2211); modelgen_ref.attach
+    CUSTOM: dict(current_voltage=0.0, gap_conductance=10.0, c_m=1.0, dt=0.1),
 }
 # activity bookkeeping of BCMIzhikevichNeuron / BCMPoissonNeuron; BCM rule plasticity/mod.rs:91-95
 BCM_CELL_DEFAULTS = dict(average_activity=0.0, current_activity=0.0, clock=0.0, window=500.0, period=3, num_spikes=0)
@@ -273,6 +278,8 @@ class Net:
             a["bcm_" + k][...] = v
             a["st_bcm_" + k][...] = v
         self.rewards = None
+        self.custom_section = np.zeros(3, np.uint32)
+        self.custom_nvars = 0
         if nt_kind == NT_EXPONENTIAL_DECAY:       # decay_constant, iterate_and_spike/mod.rs:336-343
             a["nt_clearance"][...] = 2.0
             a["st_nt_clearance"][...] = 2.0
@@ -325,6 +332,8 @@ class Net:
                     setattr(c, name, arr.ctypes.data_as(ct))
             elif ct is C.c_float:
                 setattr(c, name, float(getattr(self, name)))
+            elif name == "custom_section":
+                setattr(c, name, (C.c_uint32 * 3)(*[int(x) for x in self.custom_section]))
             else:
                 setattr(c, name, int(getattr(self, name)))
         return c

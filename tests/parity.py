@@ -116,7 +116,7 @@ def device_from_oracle(snn, net, shard=None, device=0, csr=False):
     """Create a DeviceNetwork holding exactly the oracle net's state (dense or CSR graph form)."""
     lay = net.layout
     dn = snn.DeviceNetwork(model=net.model, nt_kinetics=net.nt_kind, receptor_kinetics=net.rc_kind,
-                           spike_train=net.st_kind, device=device)
+                           spike_train=net.st_kind, device=device, lib_path=getattr(net, "custom_lib", None))
     for i, r, c in lay.lattices:
         dn.add_lattice(i, r, c)
     for i, r, c in lay.st_lattices:
@@ -152,6 +152,11 @@ def device_from_oracle(snn, net, shard=None, device=0, csr=False):
 
 def _neuron_names(net):
     names = dict(COMMON)
+    if net.model == ob.CUSTOM:
+        # a DSL variable may carry a common name (v_th): the generated model's attribute replaces it
+        for name, _ in net.custom_model.variables:
+            names = {o: a for o, a in names.items() if a != name}
+        return names
     names.update(MODEL_ATTRS[net.model])
     return names
 
@@ -165,6 +170,9 @@ def push_state(dn, net):
         if not is_st:
             for o, a in _neuron_names(net).items():
                 dn.set_attr(i, a, net[o][sl])
+            if net.model == ob.CUSTOM:
+                for k, (name, _) in enumerate(net.custom_model.variables):
+                    dn.set_attr(i, name, np.ascontiguousarray(net["custom_vars"][k, sl]))
             for o, a in NT_ATTRS.items():
                 dn.set_attr(i, a, net[o][sl])
             dn.set_attr(i, "receptors$flags", net["rc_flags"][sl])
@@ -198,6 +206,11 @@ def pull_state(dn, net):
         if not is_st:
             for o, a in _neuron_names(net).items():
                 put(o, sl, dn.get_attr(i, a, dtype=net[o].dtype))
+            if net.model == ob.CUSTOM:
+                if "custom_vars" not in out:
+                    out["custom_vars"] = np.zeros_like(net["custom_vars"])
+                for k, (name, _) in enumerate(net.custom_model.variables):
+                    out["custom_vars"][k, sl] = dn.get_attr(i, name)
             for o, a in NT_ATTRS.items():
                 put(o, sl, dn.get_attr(i, a, dtype=net[o].dtype, per_type=True))
             put("rc_flags", sl, dn.get_attr(i, "receptors$flags", dtype=np.uint32, per_type=True))

@@ -59,8 +59,6 @@ def test_reference_known_answer_for_the_generated_lif(snn, libs):
             assert np.array_equal(sh[t].astype(bool), spike), t
             assert np.array_equal(parity.bits(vh[t]), parity.bits(v)), t
     assert sh.sum() >= n                           # every neuron starts above v_th, fires once and then runs away
-    with pytest.raises(snn.SnnError):
-        dn.set_synapses(True, True)                  # generated models: electrical synapses only
     dn.close()
 
 
@@ -99,6 +97,78 @@ def test_generated_izhikevich_lattice_equals_the_interpreter(snn, libs):
     assert np.array_equal(parity.bits(dn.voltage_history(0)), parity.bits(vh))
     assert np.array_equal(parity.bits(dn.get_attr(0, "w")), parity.bits(st["w"]))
     assert np.array_equal(dn.get_attr(0, "last_firing_time", dtype=np.int32), lft)
+    dn.close()
+
+
+@pytest.mark.parametrize("variant", ["electrical_stdp", "both_synapses", "chemical_only", "sparse", "sharded"])
+def test_generated_model_in_a_network_equals_the_oracle(snn, libs, variant):
+    """The DSL-written Izhikevich neuron through the whole path -- two lattices, Poisson spike-train rows, electrical
+    and/or chemical synapses (AMPA + NMDA receptors), STDP, a sparse handle, shard handles -- against the C oracle,
+    which steps the same description as a stack program (oracle/snn_oracle.c::step_custom)."""
+    import torch
+    from snn_amd import parallel
+    model, lib = libs["DslIzhikevich"]
+    electrical = variant != "chemical_only"
+    chemical = variant in ("both_synapses", "chemical_only", "sharded")
+    lay = parity.Layout([(0, 6, 7), (2, 5, 5)], [(5, 3, 4)])
+    net = parity.make_oracle(lay, model=ob.CUSTOM, st_kind=ob.ST_POISSON, electrical=electrical, chemical=chemical)
+    modelgen_ref.attach(net, model)
+    net.custom_lib = lib
+    n, nc = net.n_neurons, net.n_cells
+    rng = np.random.default_rng(8)
+    net["current_voltage"] = ob.uniform_array(8, n, -65.0, 30.0)
+    net["custom_vars"][0] = ob.uniform_array(9, n, 0.01, 0.05)                 # a, heterogeneous
+    net["nt_flags"][...] = rng.random((n, 3)) < 0.7
+    net["nt_flags"][:, 0] = 1
+    net["rc_flags"][:, :2] = 1
+    net["rc_g"][:, 0] = 2.0
+    net["st_nt_flags"][:, 0] = 1
+    net["st_chance_of_firing"] = ob.uniform_array(10, nc, 0.0, 0.05)
+    net["st_seed"] = np.arange(70, 70 + nc, dtype=np.uint32)
+    net.fill_graph(11, 0.5, 1.5)
+    net["connections"][rng.random(net["connections"].shape) < 0.3] = 0
+    net["weights"][...] *= net["connections"]
+    net["do_plasticity"] = 1
+    steps = 600
+    if variant == "sharded":
+        handles = [parity.device_from_oracle(snn, net, shard=(r, 2)) for r in range(2)]
+        bufs = [parallel.exchange_tensor(h, torch.device("cuda", 0)) for h in handles]
+        block = bufs[0].numel() // 2
+        for _ in range(steps):
+            for h in handles:
+                h.step_begin()
+            for r in range(2):
+                bufs[1 - r][r * block:(r + 1) * block].copy_(bufs[r][r * block:(r + 1) * block])
+            torch.cuda.synchronize()
+            for h in handles:
+                h.step_end()
+        net.run(steps, spike_history=True)
+        for h in handles:
+            st = parity.pull_state(h, net)
+            b, e = h.post_begin, h.post_end
+            for name in ("current_voltage", "is_spiking", "last_firing_time", "nt_t"):
+                assert np.array_equal(parity.bits(st[name]), parity.bits(net[name])), name
+            assert np.array_equal(parity.bits(st["custom_vars"][:, b:e]), parity.bits(net["custom_vars"][:, b:e]))
+            w, c = h.get_graph_rows(0, net.n_tot)
+            ow = np.where(net["connections"] != 0, net["weights"], np.float32(0))
+            assert np.array_equal(parity.bits(w[:, b:e]), parity.bits(ow[:, b:e]))
+            h.close()
+        assert net.spike_history.sum() > 20
+        return
+    dn = parity.device_from_oracle(snn, net, csr=(variant == "sparse"))
+    dn.set_history(voltage=True, spikes=True)
+    dn.run(steps // 2)
+    dn.run(steps - steps // 2)
+    w0 = net["weights"].copy()
+    net.run(steps, voltage_history=True, spike_history=True)
+    ranges = net.layout.ranges()
+    for i, _, _ in net.layout.lattices:
+        first, count, _ = ranges[i]
+        assert np.array_equal(dn.spike_history(i), net.spike_history[:, first:first + count])
+        assert np.array_equal(parity.bits(dn.voltage_history(i)), parity.bits(net.voltage_history[:, first:first + count]))
+    parity.assert_state_equal(net, parity.pull_state(dn, net))
+    parity.assert_graph_equal(net, dn)
+    assert net.spike_history.sum() > 20 and not np.array_equal(w0, net["weights"])
     dn.close()
 
 

@@ -100,3 +100,29 @@ def test_interpreter_reproduces_the_reference_hand_expansion():
         v = np.where(ref_spike, f32(-75.0), v).astype(f32)
         assert np.array_equal(spike, ref_spike) and np.array_equal(st["current_voltage"].view(np.uint32), v.view(np.uint32))
     np.seterr(**old)
+
+
+def test_oracle_stack_program_equals_the_numpy_interpreter():
+    """Two independent evaluators of the same description: the C oracle's stack program (snn_oracle.c::step_custom,
+    compiled by modelgen_ref.compile_program) and the numpy interpreter inside numpy_ref.run_lattice."""
+    import modelgen_ref
+    import numpy_ref as nr
+    import oracle_binding as ob
+    import parity
+    m = modelgen.parse(IZH_DSL)
+    net = parity.make_oracle(parity.Layout([(0, 5, 6)]), model=ob.CUSTOM)
+    modelgen_ref.attach(net, m)
+    n = net.n_neurons
+    net["current_voltage"] = ob.uniform_array(3, n, -65.0, 30.0)
+    net["gap_conductance"] = 4.0
+    net.fill_graph(4, 0.5, 1.5)
+    st = {k: net[k].copy() for k in ("current_voltage", "dt", "c_m", "gap_conductance")}
+    for k, (name, _) in enumerate(m.variables):
+        st[name] = net["custom_vars"][k].copy()
+    vh, sh, lft = nr.run_lattice(modelgen_ref.make_step(m), st, st["gap_conductance"].copy(), net["weights"].copy(),
+                                 net["connections"].copy(), 900)
+    net.run(900, voltage_history=True, spike_history=True)
+    assert sh.sum() > 5
+    assert np.array_equal(sh, net.spike_history)
+    assert np.array_equal(vh.view(np.uint32), net.voltage_history.view(np.uint32))
+    assert np.array_equal(st["w"].view(np.uint32), net["custom_vars"][4].view(np.uint32))
