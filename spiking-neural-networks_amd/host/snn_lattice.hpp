@@ -211,6 +211,13 @@ struct RateSpikeTrain : SpikeTrainBase {
 struct STDP {
     float a_plus = 2.0f, a_minus = 2.0f, tau_plus = 4.5f, tau_minus = 4.5f, dt = 0.1f;
 };
+struct BCM {                                   // plasticity/mod.rs:80-95
+    float decay = 0.1f, average_scalar = 0.1f, dt = 0.1f;
+};
+struct RewardModulatedSTDP {                   // plasticity/mod.rs:158-190
+    float dopamine = 0.0f, tau_d = 20.0f, tau_c = 0.0001f, a_plus = 2.0f, a_minus = 2.0f, tau_plus = 4.5f,
+          tau_minus = 4.5f, dt = 0.1f;
+};
 
 // ---- AdjacencyMatrix (graph/mod.rs:139-297): dense Option<f32>, index = insertion order --------
 struct AdjacencyMatrix {
@@ -594,6 +601,45 @@ public:
         download();
     }
     snn_network_t *handle() const { return h_; }
+
+    // Reward modulation of lattice `id`'s internal edges (RewardModulatedLattice, neuron/mod.rs:2719-3417): the
+    // lattice's weights become TraceRSTDP::weight, traces start at 0.  update_and_apply_reward = one step preceded by
+    // RewardModulator::update(reward) (Agent, :3402-3407); results stay on the device until sync().
+    void set_reward_modulator(size_t id, const RewardModulatedSTDP &m, bool do_modulation = true)
+    {
+        check(snn_set_reward_modulator(h_, (uint32_t)id, m.dopamine, m.tau_d, m.tau_c, m.a_plus, m.a_minus, m.tau_plus,
+                                       m.tau_minus, m.dt, do_modulation));
+    }
+    void update_and_apply_reward(float reward)
+    {
+        check(snn_set_synapses(h_, network.electrical_synapse, network.chemical_synapse));
+        check(snn_run_with_reward(h_, reward));
+    }
+    void sync() { download(); }
+    float dopamine(size_t id)
+    {
+        float d = 0.0f;
+        check(snn_get_dopamine(h_, (uint32_t)id, &d));
+        return d;
+    }
+    // TraceRSTDP::c of lattice `id`'s internal edges, [n][n] presynaptic index first
+    std::vector<std::vector<float>> traces(size_t id)
+    {
+        uint32_t first = 0, count = 0, nn = 0;
+        check(snn_network_lattice_range(h_, (uint32_t)id, &first, &count));
+        check(snn_network_sizes(h_, &nn, nullptr, nullptr, nullptr));
+        std::vector<float> rows((size_t)count * nn);
+        check(snn_get_trace_rows(h_, first, count, rows.data()));
+        std::vector<std::vector<float>> out(count, std::vector<float>(count));
+        for (uint32_t p = 0; p < count; ++p)
+            for (uint32_t q = 0; q < count; ++q) out[p][q] = rows[(size_t)p * nn + first + q];
+        return out;
+    }
+    // BCM rule for lattice `id` (needs BCMActivity neurons: SNN_MODEL_BCM_IZHIKEVICH)
+    void set_bcm(size_t id, const BCM &b, bool do_plasticity = true)
+    {
+        check(snn_set_bcm(h_, (uint32_t)id, b.decay, b.average_scalar, b.dt, do_plasticity));
+    }
 
     // Reduced histories kept on the device (the CPU lattices' AverageVoltageHistory / EEGHistory /
     // SpikeHistory::aggregate, neuron/mod.rs:233-360) and strided capture of every history row.

@@ -90,6 +90,31 @@ int main(int argc, char **argv)
         for (const auto &row : gnet.network.lattices.at(1).cell_grid) for (const auto &n : row) vfin.push_back(n.current_voltage);
         dump(out + "/network_final_v.f32", vfin);
 
+        // ---- reward modulation through the C++ mirror: a 3x3 lattice, reward every 50th step ----
+        {
+            Lattice<IzhikevichNeuron> rl;
+            rl.set_id(0);
+            IzhikevichNeuron base;
+            base.gap_conductance = 10.0f;
+            rl.populate(base, 3, 3);
+            rl.apply_given_position([](Position p, IzhikevichNeuron &n) { n.current_voltage = v_init(p.second, p.first); });
+            rl.connect([](Position a, Position b) { return a != b; }, weight);
+            LatticeNetwork<IzhikevichNeuron, RateSpikeTrain> rnet;
+            rnet.add_lattice(rl);
+            auto rgpu = LatticeNetworkGPU<IzhikevichNeuron, RateSpikeTrain>::from_network(rnet);
+            RewardModulatedSTDP rm;
+            rm.tau_c = 0.05f; rm.a_plus = 0.01f; rm.a_minus = 0.01f;
+            rgpu.set_reward_modulator(0, rm);
+            for (int t = 0; t < 600; ++t) rgpu.update_and_apply_reward(t % 50 == 0 ? 0.5f : 0.0f);
+            rgpu.sync();
+            std::vector<float> rw, rt;
+            for (const auto &row : rgpu.network.lattices.at(0).graph.matrix) for (const auto &w : row) rw.push_back(w ? *w : NAN);
+            for (const auto &row : rgpu.traces(0)) for (float c : row) rt.push_back(c);
+            dump(out + "/reward_weights.f32", rw);
+            dump(out + "/reward_traces.f32", rt);
+            dump(out + "/reward_dopamine.f32", std::vector<float>{rgpu.dopamine(0)});
+        }
+
         // ---- error behaviour: a bad device ordinal surfaces as GPUError::GetDeviceFailure (7) ----
         bool threw = false;
         try { LatticeGPU<IzhikevichNeuron>::from_lattice(lattice, SNN_NT_APPROXIMATE, SNN_RC_APPROXIMATE, 4096); }

@@ -81,3 +81,28 @@ def test_cpp_host_lattice_and_network(tmp_path, snn):
     assert np.array_equal(cw.view(np.uint32), net["weights"][16:][np.arange(16), np.arange(16)].view(np.uint32))
     vf = np.fromfile(tmp_path / "network_final_v.f32", np.float32)
     assert np.array_equal(vf.view(np.uint32), net["current_voltage"].view(np.uint32))
+
+    # ---- reward-modulated lattice through the C++ mirror ----
+    lay = parity.Layout([(0, 3, 3)])
+    net = parity.make_oracle(lay)
+    net["gap_conductance"] = 10.0
+    pos = [(i, j) for i in range(3) for j in range(3)]
+    net["current_voltage"] = np.array([v_init(j, i) for i, j in pos], np.float32)
+    for a, pa in enumerate(pos):
+        for b, pb in enumerate(pos):
+            if pa != pb:
+                net["connections"][a, b] = 1
+                net["weights"][a, b] = weight(pa, pb)
+    net["rm_do_modulation"] = 1
+    net["rm_tau_c"] = 0.05
+    net["rm_a_plus"] = 0.01
+    net["rm_a_minus"] = 0.01
+    rewards = np.array([0.5 if t % 50 == 0 else 0.0 for t in range(600)], np.float32)
+    net.run(600, rewards=rewards)
+    rw = np.fromfile(tmp_path / "reward_weights.f32", np.float32).reshape(9, 9)
+    ow = np.where(net["connections"] != 0, net["weights"], np.float32(np.nan))
+    assert np.array_equal(np.isnan(rw), np.isnan(ow))
+    assert np.array_equal(np.nan_to_num(rw).view(np.uint32), np.nan_to_num(ow).view(np.uint32))
+    rt = np.fromfile(tmp_path / "reward_traces.f32", np.float32).reshape(9, 9)
+    assert np.array_equal(rt.view(np.uint32), net["traces"].view(np.uint32))
+    assert np.fromfile(tmp_path / "reward_dopamine.f32", np.float32)[0] == net["rm_dopamine"][0] != 0
