@@ -574,7 +574,7 @@ static uint32_t step_leaky_izhikevich(snn_o_net *n, uint32_t q)
  * 5.. model variables.  Values are float32; comparisons / logic leave 1.0f or 0.0f. */
 enum { OP_END = 0, OP_CONST = 1, OP_LOAD = 2, OP_STORE = 3, OP_DIFF = 4, OP_NEG = 5, OP_NOT = 6, OP_ADD = 7, OP_SUB = 8,
        OP_MUL = 9, OP_DIV = 10, OP_EXP = 11, OP_EQ = 12, OP_NE = 13, OP_GE = 14, OP_LE = 15, OP_GT = 16, OP_LT = 17,
-       OP_AND = 18, OP_OR = 19 };
+       OP_AND = 18, OP_OR = 19, OP_JZ = 20, OP_JMP = 21 };
 
 static float custom_run(const snn_o_net *n, uint32_t pc, float *slot, int apply_diffs)
 {
@@ -593,6 +593,8 @@ static float custom_run(const snn_o_net *n, uint32_t pc, float *slot, int apply_
         case OP_NEG:   stack[sp - 1] = -stack[sp - 1]; break;
         case OP_NOT:   stack[sp - 1] = (stack[sp - 1] != 0.0f) ? 0.0f : 1.0f; break;
         case OP_EXP:   stack[sp - 1] = snn_o_expf(stack[sp - 1]); break;
+        case OP_JZ:    { uint32_t target = (uint32_t)c[pc++]; if (stack[--sp] == 0.0f) pc = target; } break;
+        case OP_JMP:   pc = (uint32_t)c[pc]; break;
         default: {
             float b = stack[--sp], a = stack[--sp], r = 0.0f;
             switch (op) {

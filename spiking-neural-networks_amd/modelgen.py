@@ -24,9 +24,13 @@ the reference tests against is build_test/nb_macro/tests/lif_reference.rs):
     hot path stand where the generated Rust uses its receptor type);
   * every binary operation is one float32 operation, evaluated left to right as written (no contraction).
 
+  * `[if] cond [then] ... [elseif] cond [then] ... [else] ... [end]` (nestable, lib.rs:405-470) in on_iteration and
+    on_spike; differential equations stay at the top level of on_iteration (a branch-local `dx` would be out of
+    scope where the generated Rust applies it).
+
 `hip_source(model)` emits the header that csrc/snn_custom_model.hpp includes when the library is compiled with
 -DSNN_CUSTOM_MODEL_HEADER; `_lib.build_custom(model)` compiles such a library.  Not supported (rejected with a
-message): ion channels, receptors / kinetics blocks, if statements, bool variables, `^`, functions other than exp,
+message): ion channels, receptors / kinetics blocks, bool variables, `^`, functions other than exp,
 `continuous()` spike detection, on_electrochemical_iteration.
 """
 import re
@@ -144,7 +148,50 @@ def _statement(line):
     m = _ASSIGN.match(line)
     if m:
         return ("assign", m.group(1), m.group(2), parse_expr(m.group(3)))
-    raise ModelError(f"cannot read statement {line!r} (if statements and struct calls are not supported)")
+    raise ModelError(f"cannot read statement {line!r} (struct calls are not supported)")
+
+
+_IF = re.compile(r"^\[(if|elseif)\]\s*(.+?)\s*\[then\]$")
+
+
+def _block(lines, pos=0, nested=False):
+    """statements of lines[pos:] up to the [elseif] / [else] / [end] that closes the enclosing [if];
+    ("if", [(cond, stmts), ...], else_stmts | None)"""
+    out = []
+    while pos < len(lines):
+        line = lines[pos]
+        m = _IF.match(line)
+        if m and m.group(1) == "if":
+            branches, otherwise = [], None
+            cond = parse_expr(m.group(2))
+            body, pos = _block(lines, pos + 1, nested=True)
+            branches.append((cond, body))
+            while True:
+                if pos >= len(lines):
+                    raise ModelError("[if] without [end]")
+                m2 = _IF.match(lines[pos])
+                if m2 and m2.group(1) == "elseif":
+                    body, pos2 = _block(lines, pos + 1, nested=True)
+                    branches.append((parse_expr(m2.group(2)), body))
+                    pos = pos2
+                elif lines[pos] == "[else]":
+                    otherwise, pos = _block(lines, pos + 1, nested=True)
+                elif lines[pos] == "[end]":
+                    pos += 1
+                    break
+                else:
+                    raise ModelError(f"expected [elseif] / [else] / [end], got {lines[pos]!r}")
+            out.append(("if", branches, otherwise))
+            continue
+        if line in ("[else]", "[end]") or (m and m.group(1) == "elseif"):
+            if not nested:
+                raise ModelError(f"{line!r} without [if]")
+            return out, pos
+        out.append(_statement(line))
+        pos += 1
+    if nested:
+        raise ModelError("[if] without [end]")
+    return out, pos
 
 
 class NeuronModel:
@@ -157,15 +204,27 @@ class NeuronModel:
 
 def parse(text):
     """Parse ONE [neuron] block of the DSL subset described in the module docstring."""
-    blocks = re.findall(r"\[(\w+)\](.*?)\[end\]", text, flags=re.S)
-    if len(blocks) != 1 or blocks[0][0] != "neuron":
+    lines_all = [l.strip() for l in text.splitlines() if l.strip()]
+    heads = [l for l in lines_all if re.fullmatch(r"\[(neuron|ion_channel|receptors|neurotransmitter_kinetics|"
+                                                  r"receptor_kinetics|spike_train|neural_refractoriness)\]", l)]
+    if heads != ["[neuron]"] or lines_all[0] != "[neuron]":
         raise ModelError("expected exactly one [neuron] ... [end] block (ion channels, receptors, kinetics and spike "
                          "trains are not supported)")
+    depth, body = 0, None
+    for k, l in enumerate(lines_all[1:], start=1):
+        if _IF.match(l) and l.startswith("[if]"):
+            depth += 1
+        elif l == "[end]":
+            if depth == 0:
+                body = lines_all[1:k]
+                if k != len(lines_all) - 1:
+                    raise ModelError("text after the [neuron] block")
+                break
+            depth -= 1
+    if body is None:
+        raise ModelError("[neuron] without [end]")
     sections, current = {}, None
-    for raw in blocks[0][1].splitlines():
-        line = raw.strip()
-        if not line:
-            continue
+    for line in body:
         m = re.match(r"^(type|vars|on_spike|spike_detection|on_iteration|on_electrochemical_iteration|ion_channels|"
                      r"kinetics|receptors)\s*:\s*(.*)$", line)
         if m:
@@ -211,10 +270,22 @@ def parse(text):
     if detect.replace(" ", "") == "continuous()":
         raise ModelError("continuous() spike detection is not supported")
     model.spike_detection = parse_expr(detect)
-    model.on_iteration = [_statement(l) for l in sections["on_iteration"]]
-    model.on_spike = [_statement(l) for l in sections.get("on_spike", [])]
-    if any(s[0] == "diff" for s in model.on_spike):
-        raise ModelError("differential equations belong to on_iteration")
+    model.on_iteration = _block(sections["on_iteration"])[0]
+    model.on_spike = _block(sections.get("on_spike", []))[0]
+
+    def no_diffs(stmts, where):
+        for s in stmts:
+            if s[0] == "diff":
+                raise ModelError(f"differential equations belong to the top level of on_iteration, not {where}")
+            if s[0] == "if":
+                for _, body_ in s[1]:
+                    no_diffs(body_, "an [if] branch")
+                if s[2] is not None:
+                    no_diffs(s[2], "an [if] branch")
+    no_diffs(model.on_spike, "on_spike")
+    for s in model.on_iteration:
+        if s[0] == "if":
+            no_diffs([s], "an [if] branch")
     known = {"v", "i", "dt", "c_m", "gap_conductance"} | {n for n, _ in model.variables}
 
     def check(e):
@@ -226,10 +297,19 @@ def parse(text):
             elif isinstance(sub, list):
                 for x in sub:
                     check(x)
-    for s in model.on_iteration + model.on_spike:
-        if s[1] not in known - {"i"} or s[1] in ("dt", "c_m", "gap_conductance"):
-            raise ModelError(f"cannot assign to {s[1]!r}")
-        check(s[-1])
+    def check_block(stmts):
+        for s in stmts:
+            if s[0] == "if":
+                for cond, body_ in s[1]:
+                    check(cond)
+                    check_block(body_)
+                if s[2] is not None:
+                    check_block(s[2])
+                continue
+            if s[1] not in known - {"i"} or s[1] in ("dt", "c_m", "gap_conductance"):
+                raise ModelError(f"cannot assign to {s[1]!r}")
+            check(s[-1])
+    check_block(model.on_iteration + model.on_spike)
     check(model.spike_detection)
     return model
 
@@ -258,16 +338,25 @@ def _hip_expr(e, index):
     return f"({_hip_expr(lhs, index)} {op} {_hip_expr(rhs, index)})"
 
 
-def _hip_statements(stmts, index, with_diffs):
+def _hip_statements(stmts, index, with_diffs, indent="    "):
     lines, diffs = [], []
     for s in stmts:
+        if s[0] == "if":
+            for k, (cond, body) in enumerate(s[1]):
+                lines.append(f"{indent}{'if' if k == 0 else '} else if'} ({_hip_expr(cond, index)}) {{")
+                lines.append(_hip_statements(body, index, False, indent + "    "))
+            if s[2] is not None:
+                lines.append(f"{indent}}} else {{")
+                lines.append(_hip_statements(s[2], index, False, indent + "    "))
+            lines.append(f"{indent}}}")
+            continue
         target = "v" if s[1] == "v" else f"x[{index[s[1]]}]"
         if s[0] == "diff":
-            lines.append(f"    const float d_{s[1]} = ({_hip_expr(s[2], index)}) * dt;")
-            diffs.append(f"    {target} += d_{s[1]};")
+            lines.append(f"{indent}const float d_{s[1]} = ({_hip_expr(s[2], index)}) * dt;")
+            diffs.append(f"{indent}{target} += d_{s[1]};")
         else:
-            lines.append(f"    {target} {s[2]} {_hip_expr(s[3], index)};")
-    return "\n".join(lines + (diffs if with_diffs else []))
+            lines.append(f"{indent}{target} {s[2]} {_hip_expr(s[3], index)};")
+    return "\n".join(l for l in lines + (diffs if with_diffs else []) if l)
 
 
 def hip_source(model):

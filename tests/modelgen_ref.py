@@ -35,6 +35,16 @@ def evaluate(e, env):
 def _run(stmts, env, mask=None):
     diffs = []
     for s in stmts:
+        if s[0] == "if":
+            shape = env["v"].shape
+            remaining = np.ones(shape, bool) if mask is None else mask.copy()
+            for cond, body in s[1]:
+                take = remaining & np.broadcast_to(evaluate(cond, env), shape)
+                _run(body, env, mask=take)
+                remaining &= ~take
+            if s[2] is not None:
+                _run(s[2], env, mask=remaining)
+            continue
         if s[0] == "diff":
             diffs.append((s[1], (evaluate(s[2], env) * env["dt"]).astype(f32)))
             continue
@@ -68,7 +78,7 @@ def make_step(model):
 
 # ---- stack program for the C oracle (oracle/snn_oracle.c::custom_run) -------------------------------------
 _OPS = dict(END=0, CONST=1, LOAD=2, STORE=3, DIFF=4, NEG=5, NOT=6, ADD=7, SUB=8, MUL=9, DIV=10, EXP=11, EQ=12, NE=13,
-            GE=14, LE=15, GT=16, LT=17, AND=18, OR=19)
+            GE=14, LE=15, GT=16, LT=17, AND=18, OR=19, JZ=20, JMP=21)
 _BIN = {"+": "ADD", "-": "SUB", "*": "MUL", "/": "DIV", "==": "EQ", "!=": "NE", ">=": "GE", "<=": "LE", ">": "GT",
         "<": "LT", "&&": "AND", "||": "OR"}
 _BASE_SLOTS = {"v": 0, "i": 1, "dt": 2, "c_m": 3, "gap_conductance": 4}
@@ -99,9 +109,23 @@ def compile_program(model):
             emit_expr(e[3])
             code.append(_OPS[_BIN[e[1]]])
 
-    def emit_block(stmts):
-        start = len(code)
+    def emit_statements(stmts):
         for s in stmts:
+            if s[0] == "if":
+                exits = []
+                for cond, body in s[1]:
+                    emit_expr(cond)
+                    code.extend([_OPS["JZ"], -1])
+                    skip = len(code) - 1
+                    emit_statements(body)
+                    code.extend([_OPS["JMP"], -1])
+                    exits.append(len(code) - 1)
+                    code[skip] = len(code)
+                if s[2] is not None:
+                    emit_statements(s[2])
+                for e in exits:
+                    code[e] = len(code)
+                continue
             if s[0] == "diff":
                 emit_expr(s[2])
                 code.extend([_OPS["DIFF"], slots[s[1]]])
@@ -109,6 +133,10 @@ def compile_program(model):
                 _, name, op, expr = s
                 emit_expr(expr if op == "=" else ("bin", op[0], ("var", name), expr))
                 code.extend([_OPS["STORE"], slots[name]])
+
+    def emit_block(stmts):
+        start = len(code)
+        emit_statements(stmts)
         code.append(_OPS["END"])
         return start
 

@@ -9,7 +9,7 @@ import numpy_ref as nr
 import oracle_binding as ob
 import modelgen_ref
 import parity
-from test_modelgen import IZH_DSL, LIF_NB
+from test_modelgen import CURRENTS, EXPECTED_FLAG, IF_DSL, IZH_DSL, LIF_NB, lif_reference_trace
 
 pytestmark = pytest.mark.gpu
 f32 = np.float32
@@ -19,7 +19,7 @@ f32 = np.float32
 def libs(snn):
     from snn_amd import _lib, modelgen
     out = {}
-    for text in (LIF_NB, IZH_DSL):
+    for text in (LIF_NB, IZH_DSL, IF_DSL):
         m = modelgen.parse(text)
         out[m.name] = (m, _lib.build_custom(m))
     return out
@@ -59,6 +59,31 @@ def test_reference_known_answer_for_the_generated_lif(snn, libs):
             assert np.array_equal(sh[t].astype(bool), spike), t
             assert np.array_equal(parity.bits(vh[t]), parity.bits(v)), t
     assert sh.sum() >= n                           # every neuron starts above v_th, fires once and then runs away
+    dn.close()
+
+
+def test_if_statements_known_answers(snn, libs):
+    """The nested if / elseif / else model of build_test/nb_macro/tests/if_statements.rs on the device: the flag every
+    input current must leave (its assert_eq! lines) and the plain LIF voltages."""
+    model, lib = libs["ElseIfNestedBasicIntegrateAndFire"]
+    n = CURRENTS.size
+    dn = snn.DeviceNetwork(model=snn.CUSTOM, spike_train=snn.ST_RATE, lib_path=lib)
+    dn.add_lattice(1, 1, n)
+    dn.add_spike_train_lattice(0, 1, n)
+    dn.finalize()
+    assert np.array_equal(dn.get_attr(1, "flag"), np.zeros(n, f32))
+    dn.set_attr(0, "v_resting", CURRENTS)
+    w = np.zeros((2 * n, n), f32)
+    c = np.zeros((2 * n, n), np.uint32)
+    w[n + np.arange(n), np.arange(n)] = 1.0
+    c[n + np.arange(n), np.arange(n)] = 1
+    dn.set_graph_rows(0, w, c)
+    dn.set_history(voltage=True, spikes=False)
+    dn.run(1)
+    assert np.array_equal(dn.get_attr(1, "flag"), EXPECTED_FLAG)
+    dn.run(299)
+    assert np.array_equal(dn.get_attr(1, "flag"), EXPECTED_FLAG)
+    assert np.array_equal(parity.bits(dn.voltage_history(1)), parity.bits(lif_reference_trace(300)))
     dn.close()
 
 

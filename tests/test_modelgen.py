@@ -126,3 +126,87 @@ def test_oracle_stack_program_equals_the_numpy_interpreter():
     assert np.array_equal(sh, net.spike_history)
     assert np.array_equal(vh.view(np.uint32), net.voltage_history.view(np.uint32))
     assert np.array_equal(st["w"].view(np.uint32), net["custom_vars"][4].view(np.uint32))
+
+
+IF_DSL = """
+[neuron]
+    type: ElseIfNestedBasicIntegrateAndFire
+    vars: e = 0, v_reset = -75, v_th = -55, flag = 0
+    on_spike:
+        v = v_reset
+    spike_detection: v >= v_th
+    on_iteration:
+        dv/dt = (v - e) + i
+        [if] i < 0 [then]
+            flag = 1
+        [elseif] i > 20 [then]
+            [if] i >= 40 [then]
+                flag = 2
+            [else]
+                flag = 3
+            [end]
+        [else]
+            flag = 4
+        [end]
+[end]"""          # the last model of build_test/nb_macro/tests/if_statements.rs (restated as data)
+
+CURRENTS = np.array([-50., -40., -30., -20., -10., 0., 10., 20., 30., 40., 50.], np.float32)      # if_statements.rs:127
+EXPECTED_FLAG = np.where(CURRENTS < 0, 1.0, np.where(CURRENTS > 20, np.where(CURRENTS >= 40, 2.0, 3.0), 4.0)).astype(np.float32)
+
+
+def lif_reference_trace(steps):
+    """ReferenceIntegrateAndFire (build_test/nb_macro/tests/lif_reference.rs) for the eleven input currents"""
+    f32 = np.float32
+    v = np.zeros(CURRENTS.size, f32)
+    out = []
+    with np.errstate(over="ignore", invalid="ignore"):
+        for _ in range(steps):
+            dv = (((v - f32(0.0)).astype(f32) + CURRENTS).astype(f32) * f32(0.1)).astype(f32)
+            v = (v + dv).astype(f32)
+            v = np.where(v >= f32(-55.0), f32(-75.0), v).astype(f32)
+            out.append(v.copy())
+    return np.array(out)
+
+
+def test_if_statements_known_answers_on_both_cpu_evaluators():
+    """if_statements.rs: the branches taken depend on the input current only; voltages stay those of the plain LIF.
+    Checked on the numpy interpreter and on the C oracle's stack program (jumps)."""
+    import modelgen_ref
+    import oracle_binding as ob
+    import parity
+    f32 = np.float32
+    m = modelgen.parse(IF_DSL)
+    assert m.on_iteration[1][0] == "if" and len(m.on_iteration[1][1]) == 2 and m.on_iteration[1][2] is not None
+    src = modelgen.hip_source(m)
+    assert "} else if ((i_in > 20.0f)) {" in src and "if ((i_in >= 40.0f)) {" in src
+    n = CURRENTS.size
+    ref = lif_reference_trace(300)
+    # numpy interpreter
+    step = modelgen_ref.make_step(m)
+    st = {"current_voltage": np.zeros(n, f32), "dt": np.full(n, 0.1, f32), "c_m": np.ones(n, f32),
+          "gap_conductance": np.full(n, 10.0, f32), "e": np.zeros(n, f32), "v_reset": np.full(n, -75.0, f32),
+          "v_th": np.full(n, -55.0, f32), "flag": np.zeros(n, f32)}
+    with np.errstate(over="ignore", invalid="ignore"):
+        for t in range(300):
+            step(st, CURRENTS)
+            assert np.array_equal(st["flag"], EXPECTED_FLAG)
+            assert np.array_equal(st["current_voltage"].view(np.uint32), ref[t].view(np.uint32))
+    # C oracle: each neuron gets its current from a never-firing cell (v_resting enters the sum as it is)
+    lay = parity.Layout([(1, 1, n)], [(0, 1, n)])
+    net = parity.make_oracle(lay, model=ob.CUSTOM, st_kind=ob.ST_RATE)
+    modelgen_ref.attach(net, m)
+    net["st_v_resting"] = CURRENTS
+    net["connections"][n + np.arange(n), np.arange(n)] = 1
+    net["weights"][n + np.arange(n), np.arange(n)] = 1.0
+    net.run(300, voltage_history=True)
+    assert np.array_equal(net["custom_vars"][3], EXPECTED_FLAG)
+    assert np.array_equal(net.voltage_history.view(np.uint32), ref.view(np.uint32))
+
+
+def test_if_statement_errors():
+    for text, needle in [(IF_DSL.replace("            [end]\n        [else]", "        [else]"), "[end]"),
+                         (IF_DSL.replace("flag = 1", "dflag/dt = 1"), "top level"),
+                         (IF_DSL.replace("[elseif] i > 20 [then]", "[elseif] i > 20"), "cannot read statement")]:
+        with pytest.raises(modelgen.ModelError) as e:
+            modelgen.parse(text)
+        assert needle in str(e.value), (needle, str(e.value))
