@@ -28,7 +28,7 @@ IZH_DSL = """
         w += d
     spike_detection: v >= v_th
     on_iteration:
-        dv/dt = (0.04 * v * v + 5 * v + 140 - w + i) / c_m
+        dv/dt = (0.04 * v * v + 5 * v + 140 - w + i + 0.5 * exp((v - v_th) / 20)) / c_m
         dw/dt = (a * (b * v - w)) / tau_m
 [end]"""
 
@@ -55,7 +55,8 @@ def test_mandatory_overrides_precedence_and_order_of_application():
     assert [n for n, _ in m.variables] == ["a", "b", "c", "d", "w", "v_th", "tau_m"]
     src = modelgen.hip_source(m)
     # left-to-right, one operation per node; both derivatives are formed before either variable moves
-    assert "(((((0.03999999910593033f * v) * v) + (5.0f * v)) + 140.0f) - x[4]) + i_in) / c_m)" in src
+    assert "((((((0.03999999910593033f * v) * v) + (5.0f * v)) + 140.0f) - x[4]) + i_in) + " in src
+    assert "(0.5f * expf_portable(((v - x[5]) / 20.0f)))) / c_m)" in src
     i_dv, i_dw, i_apply = src.index("const float d_v"), src.index("const float d_w"), src.index("v += d_v;")
     assert i_dv < i_dw < i_apply < src.index("x[4] += d_w;")
     assert "x[4] += x[3];" in src                  # on_spike: w += d
