@@ -204,7 +204,7 @@ int launch_plasticity(snn_network *net)
 // sizes served by the one-launch small-lattice step (snn_kernels_resident.hpp)
 bool fused_step_possible(const snn_network *net)
 {
-    return net->fused_step && net->model != SNN_MODEL_CUSTOM && !net->csr && net->xl.n_shards == 1 && net->n_loc && net->n_tot &&
+    return !SNN_HAVE_CUSTOM_MODEL && net->fused_step && !net->csr && net->xl.n_shards == 1 && net->n_loc && net->n_tot &&
            net->n_chunks <= RESIDENT_MAX_CHUNKS && (size_t)net->n_tot * net->ld * 4 <= ((size_t)64 << 20);
 }
 
@@ -413,7 +413,11 @@ int launch_step_resident(snn_network *net)
         else if (net->electrical) hipLaunchKernelGGL((k_step_resident<M, true, false>), grid, block, 0, net->stream, r);             \
         else hipLaunchKernelGGL((k_step_resident<M, false, true>), grid, block, 0, net->stream, r);                                  \
     } while (0)
+#if !SNN_HAVE_CUSTOM_MODEL        // a library carrying a generated model keeps to the two-kernel step (shorter compile)
     SNN_FOR_MODEL(SNN_RESIDENT)
+#else
+    (void)grid, (void)block;
+#endif
 #undef SNN_RESIDENT
     HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
     if (e1) HIP_TRY(hipEventRecord(e1, net->stream), SNN_ERR_QUEUE);
@@ -424,7 +428,7 @@ int launch_step_resident(snn_network *net)
 // Unsharded sparse handles: row sums + neuron update in one launch (k_step_csr).
 bool fused_csr_step_applies(const snn_network *net)
 {
-    return net->fused_step && net->model != SNN_MODEL_CUSTOM && net->csr && net->csr_ptr && net->xl.n_shards == 1 &&
+    return !SNN_HAVE_CUSTOM_MODEL && net->fused_step && net->csr && net->csr_ptr && net->xl.n_shards == 1 &&
            net->n_loc && !net->local_inputs_done;
 }
 
@@ -442,7 +446,11 @@ int launch_step_csr(snn_network *net)
         else if (net->electrical) hipLaunchKernelGGL((k_step_csr<M, true, false>), grid, block, 0, net->stream, c);             \
         else hipLaunchKernelGGL((k_step_csr<M, false, true>), grid, block, 0, net->stream, c);                                  \
     } while (0)
+#if !SNN_HAVE_CUSTOM_MODEL
     SNN_FOR_MODEL(SNN_CSR_STEP)
+#else
+    (void)grid, (void)block;
+#endif
 #undef SNN_CSR_STEP
     HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
     if (e1) HIP_TRY(hipEventRecord(e1, net->stream), SNN_ERR_QUEUE);
