@@ -80,6 +80,10 @@ float snn_o_stdp_delta(int32_t t_pre, int32_t t_post, float a_plus, float a_minu
 float snn_o_expf_export(float x) { return snn_o_expf(x); }
 float snn_o_pow3f_export(float x) { return snn_o_pow3f(x); }
 float snn_o_pow4f_export(float x) { return snn_o_pow4f(x); }
+float snn_o_tanhf_export(float x) { return snn_o_tanhf(x); }
+float snn_o_sinhf_export(float x) { return snn_o_sinhf(x); }
+float snn_o_coshf_export(float x) { return snn_o_coshf(x); }
+float snn_o_powif_export(float x, int n) { return snn_o_powif(x, n); }
 
 /* ---------- synthetic data ---------- */
 
@@ -574,13 +578,14 @@ static uint32_t step_leaky_izhikevich(snn_o_net *n, uint32_t q)
  * 5.. model variables.  Values are float32; comparisons / logic leave 1.0f or 0.0f. */
 enum { OP_END = 0, OP_CONST = 1, OP_LOAD = 2, OP_STORE = 3, OP_DIFF = 4, OP_NEG = 5, OP_NOT = 6, OP_ADD = 7, OP_SUB = 8,
        OP_MUL = 9, OP_DIV = 10, OP_EXP = 11, OP_EQ = 12, OP_NE = 13, OP_GE = 14, OP_LE = 15, OP_GT = 16, OP_LT = 17,
-       OP_AND = 18, OP_OR = 19, OP_JZ = 20, OP_JMP = 21 };
+       OP_AND = 18, OP_OR = 19, OP_JZ = 20, OP_JMP = 21, OP_TANH = 22, OP_SINH = 23, OP_COSH = 24, OP_MIN = 25,
+       OP_MAX = 26, OP_HEAVISIDE = 27, OP_POWI = 28, OP_MARK = 29, OP_FLUSH = 30 };
 
 static float custom_run(const snn_o_net *n, uint32_t pc, float *slot, int apply_diffs)
 {
     float stack[64], diff[32];
     uint32_t diff_slot[32];
-    int sp = 0, nd = 0;
+    int sp = 0, nd = 0, mark = 0;
     const int32_t *c = n->custom_code;
     for (;;) {
         int32_t op = c[pc++];
@@ -593,6 +598,14 @@ static float custom_run(const snn_o_net *n, uint32_t pc, float *slot, int apply_
         case OP_NEG:   stack[sp - 1] = -stack[sp - 1]; break;
         case OP_NOT:   stack[sp - 1] = (stack[sp - 1] != 0.0f) ? 0.0f : 1.0f; break;
         case OP_EXP:   stack[sp - 1] = snn_o_expf(stack[sp - 1]); break;
+        case OP_TANH:  stack[sp - 1] = snn_o_tanhf(stack[sp - 1]); break;
+        case OP_SINH:  stack[sp - 1] = snn_o_sinhf(stack[sp - 1]); break;
+        case OP_COSH:  stack[sp - 1] = snn_o_coshf(stack[sp - 1]); break;
+        case OP_HEAVISIDE: stack[sp - 1] = (stack[sp - 1] < 0.0f) ? 0.0f : stack[sp - 1]; break;   /* lib.rs:9176 */
+        case OP_POWI:  stack[sp - 1] = snn_o_powif(stack[sp - 1], c[pc++]); break;
+        /* an inlined ion channel's update_current (lib.rs:4043-4063): its own `x += dx` at the end of ITS body */
+        case OP_MARK:  mark = nd; break;
+        case OP_FLUSH: for (int k = mark; k < nd; ++k) slot[diff_slot[k]] += diff[k]; nd = mark; break;
         case OP_JZ:    { uint32_t target = (uint32_t)c[pc++]; if (stack[--sp] == 0.0f) pc = target; } break;
         case OP_JMP:   pc = (uint32_t)c[pc]; break;
         default: {
@@ -610,6 +623,8 @@ static float custom_run(const snn_o_net *n, uint32_t pc, float *slot, int apply_
             case OP_LT: r = (a < b); break;
             case OP_AND: r = (a != 0.0f && b != 0.0f); break;
             case OP_OR: r = (a != 0.0f || b != 0.0f); break;
+            case OP_MIN: r = o_min(a, b); break;
+            case OP_MAX: r = o_max(a, b); break;
             }
             stack[sp++] = r;
         } }

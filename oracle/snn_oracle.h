@@ -209,6 +209,10 @@ void snn_o_run(snn_o_net *net, uint64_t iterations);
 float snn_o_expf_export(float x);
 float snn_o_pow3f_export(float x);
 float snn_o_pow4f_export(float x);
+float snn_o_tanhf_export(float x);
+float snn_o_sinhf_export(float x);
+float snn_o_coshf_export(float x);
+float snn_o_powif_export(float x, int n);
 float snn_o_stdp_delta(int32_t t_pre, int32_t t_post, float a_plus, float a_minus,
                        float tau_plus, float tau_minus, float dt);
 float snn_o_exponential_decay_effect(int64_t timestep, int32_t last_firing_time,

@@ -34,18 +34,14 @@
 #include <stdint.h>
 #include <string.h>
 
-static inline float snn_o_expf(float x)
+/* exp of a binary64 argument, |x| < 700: the polynomial core of snn_o_expf and of the hyperbolic functions below */
+static inline double snn_o_exp_core(double xd)
 {
-    if (!(x == x)) return x;                 /* NaN in, NaN out */
-    if (x > 89.0f) return __builtin_inff();  /* expf overflows above 88.72 */
-    if (x < -104.0f) return 0.0f;            /* below half the least subnormal */
-
     const double INV_LN2 = 1.4426950408889634;       /* 0x3FF71547652B82FE */
     const double LN2_HI  = 6.93147180369123816490e-01; /* 0x3FE62E42FEE00000 */
     const double LN2_LO  = 1.90821492927058770002e-10; /* 0x3DEA39EF35793C76 */
     const double SHIFT   = 6755399441055744.0;        /* 1.5 * 2^52 */
 
-    double xd = (double)x;
     double kd = (xd * INV_LN2 + SHIFT) - SHIFT;   /* rint under round-to-nearest */
     double r  = (xd - kd * LN2_HI) - kd * LN2_LO;
 
@@ -65,11 +61,79 @@ static inline float snn_o_expf(float x)
     p = p * r + 1.0;
     p = p * r + 1.0;
 
-    int64_t k = (int64_t)kd;                      /* |k| <= 151 */
+    int64_t k = (int64_t)kd;                      /* |k| <= 1010 */
     uint64_t bits = (uint64_t)(k + 1023) << 52;   /* 2^k as a normal double */
     double scale;
     memcpy(&scale, &bits, sizeof scale);
-    return (float)(p * scale);
+    return p * scale;
+}
+
+static inline float snn_o_expf(float x)
+{
+    if (!(x == x)) return x;                 /* NaN in, NaN out */
+    if (x > 89.0f) return __builtin_inff();  /* expf overflows above 88.72 */
+    if (x < -104.0f) return 0.0f;            /* below half the least subnormal */
+    return (float)snn_o_exp_core((double)x);
+}
+
+/* f32::tanh / sinh / cosh for generated models (build_test/nb_macro/src/lib.rs:9152-9163 forward to libm):
+ * binary64 through the exp core, Taylor series where e^x - e^-x cancels, one rounding to binary32. */
+static inline float snn_o_tanhf(float x)
+{
+    if (!(x == x)) return x;
+    double d = (double)x, a = (d < 0.0) ? -d : d, t;
+    if (a < 0.05) {
+        double z = a * a;
+        double p = 62.0 / 2835.0;
+        p = p * z - 17.0 / 315.0;
+        p = p * z + 2.0 / 15.0;
+        p = p * z - 1.0 / 3.0;
+        p = p * z + 1.0;
+        t = a * p;
+    } else if (a > 20.0) {
+        t = 1.0;
+    } else {
+        t = 1.0 - 2.0 / (snn_o_exp_core(2.0 * a) + 1.0);
+    }
+    return (float)((d < 0.0) ? -t : t);
+}
+
+static inline float snn_o_sinhf(float x)
+{
+    if (!(x == x)) return x;
+    double d = (double)x, a = (d < 0.0) ? -d : d, t;
+    if (a < 0.05) {
+        double z = a * a;
+        double p = 1.0 / 5040.0;
+        p = p * z + 1.0 / 120.0;
+        p = p * z + 1.0 / 6.0;
+        p = p * z + 1.0;
+        t = a * p;
+    } else if (a > 90.0) {
+        t = (double)__builtin_inff();
+    } else {
+        double e = snn_o_exp_core(a);
+        t = (e - 1.0 / e) * 0.5;
+    }
+    return (float)((d < 0.0) ? -t : t);
+}
+
+static inline float snn_o_coshf(float x)
+{
+    if (!(x == x)) return x;
+    double d = (double)x, a = (d < 0.0) ? -d : d;
+    if (a > 90.0) return __builtin_inff();
+    double e = snn_o_exp_core(a);
+    return (float)((e + 1.0 / e) * 0.5);
+}
+
+/* x.powf(n), n an integer literal: left-to-right product in binary64, one rounding */
+static inline float snn_o_powif(float x, int n)
+{
+    double d = (double)x, p = 1.0;
+    int m = (n < 0) ? -n : n;
+    for (int k = 0; k < m; ++k) p = p * d;
+    return (float)((n < 0) ? 1.0 / p : p);
 }
 
 /* x^3 as libm powf(x, 3.) returns it (ion_channels/mod.rs:234) */

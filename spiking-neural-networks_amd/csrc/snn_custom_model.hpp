@@ -28,6 +28,6 @@ __device__ __forceinline__ void on_spike(float &, float (&)[NSTORE], float, floa
 
 namespace snn {
 constexpr int CUSTOM_MODEL = 100;        // SNN_MODEL_CUSTOM
-constexpr int CUSTOM_MAX_VARS = 16;
+constexpr int CUSTOM_MAX_VARS = 32;
 static_assert(custom::NVARS <= CUSTOM_MAX_VARS, "too many variables in the generated model");
 } // namespace snn

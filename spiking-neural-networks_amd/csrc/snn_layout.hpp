@@ -55,7 +55,7 @@ struct NeuronArrays {
     // adaptive (exponential) leaky integrate-and-fire
     float *adp_alpha, *adp_beta, *slope_factor;
     // variables of the generated model (snn_custom_model.hpp), one array each
-    float *custom[16];
+    float *custom[32];
     // BCMActivity bookkeeping (BCMIzhikevichNeuron): average / current activity, window clock and length, period, spike count
     float *bcm_avg, *bcm_cur, *bcm_clock, *bcm_window;
     uint32_t *bcm_period, *bcm_num_spikes;

@@ -15,18 +15,14 @@
 
 namespace snn {
 
-__device__ __forceinline__ float expf_portable(float x)
+// exp of a binary64 argument, |x| < 700: the polynomial core shared by expf_portable and the hyperbolic functions
+__device__ __forceinline__ double exp_core(double xd)
 {
-    if (!(x == x)) return x;
-    if (x > 89.0f) return __builtin_inff();
-    if (x < -104.0f) return 0.0f;
-
     const double inv_ln2 = 1.4426950408889634;
     const double ln2_hi = 6.93147180369123816490e-01;
     const double ln2_lo = 1.90821492927058770002e-10;
     const double shift = 6755399441055744.0;   // 1.5 * 2^52
 
-    const double xd = (double)x;
     const double kd = (xd * inv_ln2 + shift) - shift;
     const double r = (xd - kd * ln2_hi) - kd * ln2_lo;
 
@@ -45,10 +41,83 @@ __device__ __forceinline__ float expf_portable(float x)
     p = p * r + 1.0;
     p = p * r + 1.0;
 
-    const int k = (int)kd;   // |k| <= 151
+    const int k = (int)kd;   // |k| <= 1010
     const double scale = __longlong_as_double((long long)(k + 1023) << 52);
-    return (float)(p * scale);
+    return p * scale;
 }
+
+__device__ __forceinline__ float expf_portable(float x)
+{
+    if (!(x == x)) return x;
+    if (x > 89.0f) return __builtin_inff();
+    if (x < -104.0f) return 0.0f;
+    return (float)exp_core((double)x);
+}
+
+// f32::tanh / sinh / cosh of generated models (build_test/nb_macro/src/lib.rs:9152-9163 forward to the platform
+// libm): binary64 through exp_core, a Taylor polynomial where e^x - e^-x would cancel, one rounding to binary32.
+__device__ __forceinline__ float tanhf_portable(float x)
+{
+    if (!(x == x)) return x;
+    const double d = (double)x, a = (d < 0.0) ? -d : d;
+    double t;
+    if (a < 0.05) {
+        const double z = a * a;
+        double p = 62.0 / 2835.0;
+        p = p * z - 17.0 / 315.0;
+        p = p * z + 2.0 / 15.0;
+        p = p * z - 1.0 / 3.0;
+        p = p * z + 1.0;
+        t = a * p;
+    } else if (a > 20.0) {
+        t = 1.0;
+    } else {
+        t = 1.0 - 2.0 / (exp_core(2.0 * a) + 1.0);
+    }
+    return (float)((d < 0.0) ? -t : t);
+}
+__device__ __forceinline__ float sinhf_portable(float x)
+{
+    if (!(x == x)) return x;
+    const double d = (double)x, a = (d < 0.0) ? -d : d;
+    double t;
+    if (a < 0.05) {
+        const double z = a * a;
+        double p = 1.0 / 5040.0;
+        p = p * z + 1.0 / 120.0;
+        p = p * z + 1.0 / 6.0;
+        p = p * z + 1.0;
+        t = a * p;
+    } else if (a > 90.0) {
+        t = (double)__builtin_inff();
+    } else {
+        const double e = exp_core(a);
+        t = (e - 1.0 / e) * 0.5;
+    }
+    return (float)((d < 0.0) ? -t : t);
+}
+__device__ __forceinline__ float coshf_portable(float x)
+{
+    if (!(x == x)) return x;
+    const double d = (double)x, a = (d < 0.0) ? -d : d;
+    if (a > 90.0) return __builtin_inff();
+    const double e = exp_core(a);
+    return (float)((e + 1.0 / e) * 0.5);
+}
+
+// x.powf(n) for an integer literal n (the only exponents the generator accepts): left-to-right product in binary64,
+// one rounding to binary32; n < 0 -> reciprocal of the product
+__device__ __forceinline__ float powif_portable(float x, int n)
+{
+    const double d = (double)x;
+    const int m = (n < 0) ? -n : n;
+    double p = 1.0;
+    for (int k = 0; k < m; ++k) p = p * d;
+    return (float)((n < 0) ? 1.0 / p : p);
+}
+
+// nb_macro's heaviside (lib.rs:9176-9178): `if x < 0 { 0 } else { x }`
+__device__ __forceinline__ float heaviside_rs(float x) { return (x < 0.0f) ? 0.0f : x; }
 
 // powf(x, 3.) / powf(x, 4.) of the Na / K channel currents (ion_channels/mod.rs:234, 280):
 // exact square in binary64, one rounding each.

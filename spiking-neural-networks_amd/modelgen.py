@@ -28,16 +28,32 @@ the reference tests against is build_test/nb_macro/tests/lif_reference.rs):
     on_spike; differential equations stay at the top level of on_iteration (a branch-local `dx` would be out of
     scope where the generated Rust applies it).
 
+  * `[ion_channel]` blocks (lib.rs:3960-4075) and `ion_channels: name = Type, ...` in the neuron: a channel has
+    `vars`, optional `gating_vars` (BasicGatingVariable: alpha, beta, state = 0; backend ion_channels/mod.rs:14-45)
+    and an on_iteration that assigns `current`; `g.update(dt)`, `g.init_state()` are the struct calls of a gate.  The
+    neuron calls `name.update_current(v)` -- `(v, dt)` when the channel has a differential equation or passes `dt`
+    to a gate (lib.rs:3967-3997) -- and reads `name.current`, `name.var`, `name.gate.state`.  The generator inlines
+    the channel body at the call (the channel's own `x += dx` at the end of ITS body) and stores its fields as the
+    neuron variables `name$var`, `name$gate$alpha|beta|state`, `name$current` (the reference's attribute names);
+  * functions exp, tanh, sinh, cosh, min, max, heaviside (lib.rs:9139-9178; heaviside as written there:
+    x < 0 -> 0, else x) and `base ^ n` with an integer literal n (`powf`; binds tighter than * and /,
+    left-associative: pest_ast/mod.rs:183-186; a leading unary minus of the base ends up OUTSIDE the power, see
+    _power).
+
 `hip_source(model)` emits the header that csrc/snn_custom_model.hpp includes when the library is compiled with
 -DSNN_CUSTOM_MODEL_HEADER; `_lib.build_custom(model)` compiles such a library.  Not supported (rejected with a
-message): ion channels, receptors / kinetics blocks, bool variables, `^`, functions other than exp,
-`continuous()` spike detection, on_electrochemical_iteration.
+message): receptors / kinetics / spike-train / refractoriness blocks, bool variables, `^` with a non-literal or
+fractional exponent, sin / cos / tan / isnan, on_electrochemical_iteration, and `continuous()` spike detection --
+the code the reference generates for it reads a `last_voltage` that is never defined (lib.rs:984-990), so there is
+no behaviour to match.
 """
 import re
 import struct
 
 MANDATORY = {"current_voltage": 0.0, "dt": 0.1, "c_m": 1.0, "gap_conductance": 10.0}
-MAX_VARS = 16
+MAX_VARS = 32
+FUNCTIONS = {"exp": 1, "tanh": 1, "sinh": 1, "cosh": 1, "heaviside": 1, "min": 2, "max": 2}
+MAX_POWER = 16
 
 
 class ModelError(ValueError):
@@ -45,7 +61,7 @@ class ModelError(ValueError):
 
 
 # ---- tokens -----------------------------------------------------------------------------------------
-_TOKEN = re.compile(r"\s*(?:(\d+\.\d*(?:[eE][+-]?\d+)?|\.\d+(?:[eE][+-]?\d+)?|\d+(?:[eE][+-]?\d+)?)|([A-Za-z_][A-Za-z_0-9]*)|"
+_TOKEN = re.compile(r"\s*(?:(\d+\.\d*(?:[eE][+-]?\d+)?|\.\d+(?:[eE][+-]?\d+)?|\d+(?:[eE][+-]?\d+)?)|([A-Za-z_][A-Za-z_0-9]*(?:\.[A-Za-z_][A-Za-z_0-9]*)*)|"
                     r"(\|\||&&|==|!=|>=|<=|[-+*/()<>!,^]))")
 
 
@@ -63,7 +79,26 @@ def _tokens(text):
 
 
 # ---- expressions: ("num", f) | ("var", name) | ("neg", e) | ("not", e) | ("bin", op, l, r) | ("call", name, [args])
-_LEVELS = [("||",), ("&&",), ("==", "!=", ">=", "<=", ">", "<"), ("+", "-"), ("*", "/")]
+#                   | ("powi", base, n)
+_LEVELS = [("||",), ("&&",), ("==", "!=", ">=", "<=", ">", "<"), ("+", "-"), ("*", "/"), ("^",)]
+
+
+def _integer_literal(e):
+    if e[0] == "neg":
+        n = _integer_literal(e[1])
+        return None if n is None else -n
+    if e[0] == "num" and float(e[1]).is_integer() and abs(e[1]) <= MAX_POWER:
+        return int(e[1])
+    return None
+
+
+def _power(base, n):
+    """`base ^ n` as the generated Rust evaluates it: the reference prints a unary minus as "-<operand>" and the power
+    as "(<lhs>.powf(n))" (lib.rs:126, 135), and in Rust the method call binds tighter than the minus -- `-s ^ 2` is
+    -(s^2) (tests/timestep_dependent_ion_channel.rs compares it with `-self.s.state.powf(2.)`)."""
+    if base[0] == "neg":
+        return ("neg", _power(base[1], n))
+    return ("powi", base, n)
 
 
 class _Parser:
@@ -84,7 +119,14 @@ class _Parser:
         lhs = self.expr(level + 1)
         while self.peek()[0] == "op" and self.peek()[1] in _LEVELS[level]:
             op = self.take()[1]
-            lhs = ("bin", op, lhs, self.expr(level + 1))
+            rhs = self.expr(level + 1)
+            if op == "^":
+                n = _integer_literal(rhs)
+                if n is None:
+                    raise ModelError(f"'^' needs an integer literal exponent (|n| <= {MAX_POWER})")
+                lhs = _power(lhs, n)
+            else:
+                lhs = ("bin", op, lhs, rhs)
         return lhs
 
     def unary(self):
@@ -112,8 +154,10 @@ class _Parser:
                         args.append(self.expr())
                 if self.take() != ("op", ")"):
                     raise ModelError("missing ')' after function arguments")
-                if val != "exp" or len(args) != 1:
-                    raise ModelError(f"function {val}() is not supported (only exp(x))")
+                if val not in FUNCTIONS:
+                    raise ModelError(f"function {val}() is not supported ({', '.join(sorted(FUNCTIONS))})")
+                if len(args) != FUNCTIONS[val]:
+                    raise ModelError(f"{val}() takes {FUNCTIONS[val]} argument(s)")
                 return ("call", val, args)
             return ("var", val)
         if (kind, val) == ("op", "("):
@@ -121,8 +165,6 @@ class _Parser:
             if self.take() != ("op", ")"):
                 raise ModelError("missing ')'")
             return e
-        if (kind, val) == ("op", "^"):
-            raise ModelError("'^' is not supported")
         raise ModelError(f"unexpected token {val!r}")
 
 
@@ -130,15 +172,16 @@ def parse_expr(text):
     p = _Parser(_tokens(text))
     e = p.expr()
     if p.peek() != (None, None):
-        if p.peek() == ("op", "^"):
-            raise ModelError("'^' is not supported")
         raise ModelError(f"trailing input in expression {text!r}")
     return e
 
 
-# ---- statements: ("diff", name, expr) | ("assign", name, op, expr) -------------------------------------
-_DIFF = re.compile(r"^d([A-Za-z_][A-Za-z_0-9]*)\s*/\s*dt\s*=\s*(.+)$")
-_ASSIGN = re.compile(r"^([A-Za-z_][A-Za-z_0-9]*)\s*(=|\+=|-=|\*=|/=)\s*(.+)$")
+# ---- statements: ("diff", name, expr) | ("assign", name, op, expr) | ("struct_call", name, method, [args])
+#                  | ("if", ...) | ("scope", stmts): an inlined channel body, its diffs applied at its end
+_NAME = r"[A-Za-z_][A-Za-z_0-9]*"
+_DIFF = re.compile(rf"^d({_NAME})\s*/\s*dt\s*=\s*(.+)$")
+_ASSIGN = re.compile(rf"^({_NAME}(?:\.{_NAME})*)\s*(=|\+=|-=|\*=|/=)\s*(.+)$")
+_STRUCT_CALL = re.compile(rf"^({_NAME}(?:\.{_NAME})*)\.({_NAME})\s*\((.*)\)$")
 
 
 def _statement(line):
@@ -146,9 +189,23 @@ def _statement(line):
     if m:
         return ("diff", m.group(1), parse_expr(m.group(2)))
     m = _ASSIGN.match(line)
-    if m:
+    if m and not m.group(3).startswith("="):
         return ("assign", m.group(1), m.group(2), parse_expr(m.group(3)))
-    raise ModelError(f"cannot read statement {line!r} (struct calls are not supported)")
+    m = _STRUCT_CALL.match(line)
+    if m:
+        inner = m.group(3).strip()
+        if not inner:
+            return ("struct_call", m.group(1), m.group(2), [])
+        # arguments: parse `f(a, b)` and take the argument list
+        p = _Parser(_tokens(inner))
+        args = [p.expr()]
+        while p.peek() == ("op", ","):
+            p.take()
+            args.append(p.expr())
+        if p.peek() != (None, None):
+            raise ModelError(f"cannot read the arguments of {line!r}")
+        return ("struct_call", m.group(1), m.group(2), args)
+    raise ModelError(f"cannot read statement {line!r}")
 
 
 _IF = re.compile(r"^\[(if|elseif)\]\s*(.+?)\s*\[then\]$")
@@ -197,36 +254,68 @@ def _block(lines, pos=0, nested=False):
 class NeuronModel:
     def __init__(self, name, variables, on_iteration, spike_detection, on_spike):
         self.name = name
-        self.variables = variables          # [(name, default)] in declaration order, without the mandatory ones
+        self.variables = variables          # [(name, default)] in declaration order, without the mandatory ones;
+                                            # the fields of ion channel `c` follow as c$var, c$gate$alpha, ..., c$current
         self.mandatory = dict(MANDATORY)    # defaults of current_voltage / dt / c_m / gap_conductance
         self.on_iteration, self.spike_detection, self.on_spike = on_iteration, spike_detection, on_spike
+        self.ion_channels = []              # [(instance name, channel type name)]
 
 
-def parse(text):
-    """Parse ONE [neuron] block of the DSL subset described in the module docstring."""
-    lines_all = [l.strip() for l in text.splitlines() if l.strip()]
-    heads = [l for l in lines_all if re.fullmatch(r"\[(neuron|ion_channel|receptors|neurotransmitter_kinetics|"
-                                                  r"receptor_kinetics|spike_train|neural_refractoriness)\]", l)]
-    if heads != ["[neuron]"] or lines_all[0] != "[neuron]":
-        raise ModelError("expected exactly one [neuron] ... [end] block (ion channels, receptors, kinetics and spike "
-                         "trains are not supported)")
-    depth, body = 0, None
-    for k, l in enumerate(lines_all[1:], start=1):
-        if _IF.match(l) and l.startswith("[if]"):
-            depth += 1
-        elif l == "[end]":
-            if depth == 0:
-                body = lines_all[1:k]
-                if k != len(lines_all) - 1:
-                    raise ModelError("text after the [neuron] block")
-                break
-            depth -= 1
-    if body is None:
-        raise ModelError("[neuron] without [end]")
+class IonChannel:
+    def __init__(self, name, variables, gating_vars, on_iteration):
+        self.name, self.variables, self.gating_vars, self.on_iteration = name, variables, gating_vars, on_iteration
+        # lib.rs:3967-3997: update_current takes dt when the body has a differential equation or hands `dt` to a call
+        self.uses_timestep = any(
+            st[0] == "diff" or (st[0] == "struct_call" and any(a == ("var", "dt") for a in st[3]))
+            for st in on_iteration)
+
+    def fields(self):
+        """[(field, default)] in the order of the generated struct (lib.rs:4006-4035): vars, gates, current"""
+        out = list(self.variables)
+        for g in self.gating_vars:
+            out += [(f"{g}$alpha", 0.0), (f"{g}$beta", 0.0), (f"{g}$state", 0.0)]
+        if "current" not in dict(self.variables):
+            out.append(("current", 0.0))
+        return out
+
+
+_BLOCK_HEAD = re.compile(r"\[(neuron|ion_channel|receptors|neurotransmitter_kinetics|receptor_kinetics|spike_train|"
+                         r"neural_refractoriness)\]")
+
+
+def _split_blocks(text):
+    """[(kind, body lines)] of the top-level [kind] ... [end] blocks"""
+    lines = [l.strip() for l in text.splitlines() if l.strip()]
+    blocks, k = [], 0
+    while k < len(lines):
+        m = _BLOCK_HEAD.fullmatch(lines[k])
+        if not m:
+            raise ModelError(f"text outside a block: {lines[k]!r}")
+        depth, start, k = 0, k + 1, k + 1
+        while True:
+            if k >= len(lines):
+                raise ModelError(f"[{m.group(1)}] without [end]")
+            l = lines[k]
+            if _BLOCK_HEAD.fullmatch(l):
+                raise ModelError(f"[{m.group(1)}] without [end]")
+            if _IF.match(l) and l.startswith("[if]"):
+                depth += 1
+            elif l == "[end]":
+                if depth == 0:
+                    break
+                depth -= 1
+            k += 1
+        blocks.append((m.group(1), lines[start:k]))
+        k += 1
+    return blocks
+
+
+def _sections(body, allowed):
     sections, current = {}, None
+    head = re.compile(r"^(type|vars|gating_vars|on_spike|spike_detection|on_iteration|on_electrochemical_iteration|"
+                      r"ion_channels|kinetics|receptors)\s*:\s*(.*)$")
     for line in body:
-        m = re.match(r"^(type|vars|on_spike|spike_detection|on_iteration|on_electrochemical_iteration|ion_channels|"
-                     r"kinetics|receptors)\s*:\s*(.*)$", line)
+        m = head.match(line)
         if m:
             current = m.group(1)
             sections.setdefault(current, [])
@@ -236,81 +325,234 @@ def parse(text):
             raise ModelError(f"text outside a section: {line!r}")
         else:
             sections[current].append(line)
-    for bad in ("on_electrochemical_iteration", "ion_channels", "kinetics", "receptors"):
-        if bad in sections:
-            raise ModelError(f"section '{bad}' is not supported")
-    for need in ("type", "on_iteration", "spike_detection"):
-        if not sections.get(need):
-            raise ModelError(f"section '{need}' is missing")
-    name = sections["type"][0].strip()
-    if not re.fullmatch(r"[A-Za-z_][A-Za-z_0-9]*", name):
-        raise ModelError(f"bad type name {name!r}")
-    model = NeuronModel(name, [], [], None, [])
-    for item in ",".join(sections.get("vars", [])).split(","):
+    for name in sections:
+        if name not in allowed:
+            raise ModelError(f"section '{name}' is not supported")
+    name = (sections.get("type") or [""])[0].strip()
+    if not re.fullmatch(_NAME, name):
+        raise ModelError(f"bad or missing type name {name!r}")
+    return sections, name
+
+
+def _variables(items, reserved):
+    out = []
+    for item in ",".join(items).split(","):
         item = item.strip()
         if not item:
             continue
-        m = re.fullmatch(r"([A-Za-z_][A-Za-z_0-9]*)\s*=\s*(-?\s*[0-9.eE+-]+|true|false)", item)
+        m = re.fullmatch(rf"({_NAME})\s*=\s*(-?\s*[0-9.eE+-]+|true|false)", item)
         if not m:
             raise ModelError(f"cannot read variable {item!r}")
         if m.group(2) in ("true", "false"):
             raise ModelError("bool variables are not supported")
         var, value = m.group(1), float(m.group(2).replace(" ", ""))
-        if var in ("v", "i", "is_spiking", "last_firing_time"):
+        if var in reserved:
             raise ModelError(f"'{var}' is reserved")
+        if var in dict(out):
+            raise ModelError(f"variable {var} is defined twice")
+        out.append((var, value))
+    return out
+
+
+def _walk(stmts):
+    for s in stmts:
+        yield s
+        if s[0] == "if":
+            for _, body in s[1]:
+                yield from _walk(body)
+            if s[2] is not None:
+                yield from _walk(s[2])
+        elif s[0] == "scope":
+            yield from _walk(s[1])
+
+
+def _map_expr(e, rename):
+    kind = e[0]
+    if kind == "num":
+        return e
+    if kind == "var":
+        return rename(e[1])
+    if kind in ("neg", "not"):
+        return (kind, _map_expr(e[1], rename))
+    if kind == "call":
+        return ("call", e[1], [_map_expr(a, rename) for a in e[2]])
+    if kind == "powi":
+        return ("powi", _map_expr(e[1], rename), e[2])
+    return ("bin", e[1], _map_expr(e[2], rename), _map_expr(e[3], rename))
+
+
+def _expr_vars(e):
+    if e[0] == "var":
+        yield e[1]
+    for sub in e[1:]:
+        if isinstance(sub, tuple):
+            yield from _expr_vars(sub)
+        elif isinstance(sub, list):
+            for x in sub:
+                yield from _expr_vars(x)
+
+
+def _parse_channel(body):
+    sections, name = _sections(body, ("type", "vars", "gating_vars", "on_iteration"))
+    if not sections.get("on_iteration"):
+        raise ModelError(f"ion channel {name}: section 'on_iteration' is missing")
+    gates = [g.strip() for g in ",".join(sections.get("gating_vars", [])).split(",") if g.strip()]
+    for g in gates:
+        if not re.fullmatch(_NAME, g):
+            raise ModelError(f"bad gating variable name {g!r}")
+    variables = _variables(sections.get("vars", []), ("v", "i", "dt") + tuple(gates))
+    stmts = _block(sections["on_iteration"])[0]
+    for st in stmts:
+        if st[0] == "if":
+            for inner in _walk([st]):
+                if inner[0] == "diff":
+                    raise ModelError("differential equations belong to the top level of on_iteration")
+    return IonChannel(name, variables, gates, stmts)
+
+
+def _inline_channel(inst, ch, args):
+    """the body of `inst.update_current(args)` over the neuron's variables inst$field"""
+    if len(args) != (2 if ch.uses_timestep else 1):
+        raise ModelError(f"{inst}.update_current takes {'(v, dt)' if ch.uses_timestep else '(v)'} for channel {ch.name}")
+    fields = dict(ch.fields())
+    for a in args:
+        for n in _expr_vars(a):
+            if n.startswith(inst + "$"):
+                raise ModelError(f"the arguments of {inst}.update_current must not read {inst}'s own fields")
+
+    def rename(n):
+        if n == "v":
+            return args[0]
+        if n == "dt":
+            if "dt" in fields:
+                return ("var", f"{inst}$dt")
+            if not ch.uses_timestep:
+                raise ModelError(f"ion channel {ch.name} reads dt but its update_current takes no timestep "
+                                 "(no differential equation, no dt argument to a gate)")
+            return args[1]
+        key = n.replace(".", "$")
+        if key not in fields:
+            raise ModelError(f"ion channel {ch.name}: unknown variable {n!r}")
+        return ("var", f"{inst}${key}")
+
+    def target(n):
+        key = n.replace(".", "$")
+        if key not in fields:
+            raise ModelError(f"ion channel {ch.name}: cannot assign to {n!r}")
+        return f"{inst}${key}"
+
+    def convert(stmts):
+        out = []
+        for st in stmts:
+            if st[0] == "if":
+                out.append(("if", [(_map_expr(c, rename), convert(b)) for c, b in st[1]],
+                            None if st[2] is None else convert(st[2])))
+            elif st[0] == "diff":
+                if args[1] != ("var", "dt"):
+                    raise ModelError(f"{inst}.update_current: a channel with a differential equation takes the "
+                                     "neuron's dt as its timestep")
+                out.append(("diff", target(st[1]), _map_expr(st[2], rename)))
+            elif st[0] == "assign":
+                out.append(("assign", target(st[1]), st[2], _map_expr(st[3], rename)))
+            else:                                  # gate.update(dt) / gate.init_state()
+                _, gate, method, cargs = st
+                if gate not in ch.gating_vars:
+                    raise ModelError(f"ion channel {ch.name}: {gate!r} is not a gating variable")
+                al, be, stt = (("var", f"{inst}${gate}${f}") for f in ("alpha", "beta", "state"))
+                if method == "update" and len(cargs) == 1:
+                    # BasicGatingVariable::update (ion_channels/mod.rs:40-44)
+                    step = _map_expr(cargs[0], rename)
+                    alpha_state = ("bin", "*", al, ("bin", "-", ("num", 1.0), stt))
+                    beta_state = ("bin", "*", be, stt)
+                    out.append(("assign", stt[1], "+=", ("bin", "*", step, ("bin", "-", alpha_state, beta_state))))
+                elif method == "init_state" and not cargs:          # :35-37
+                    out.append(("assign", stt[1], "=", ("bin", "/", al, ("bin", "+", al, be))))
+                else:
+                    raise ModelError(f"gating variables have update(dt) and init_state(), not {method}")
+        return out
+
+    return ("scope", convert(ch.on_iteration))
+
+
+def parse(text):
+    """Parse zero or more [ion_channel] blocks and ONE [neuron] block of the DSL subset in the module docstring."""
+    blocks = _split_blocks(text)
+    channels = {}
+    for kind, body in blocks:
+        if kind == "ion_channel":
+            ch = _parse_channel(body)
+            if ch.name in channels:
+                raise ModelError(f"ion channel {ch.name} is defined twice")
+            channels[ch.name] = ch
+        elif kind != "neuron":
+            raise ModelError(f"[{kind}] blocks are not supported (only [ion_channel] and [neuron])")
+    neurons = [body for kind, body in blocks if kind == "neuron"]
+    if len(neurons) != 1:
+        raise ModelError("expected exactly one [neuron] ... [end] block")
+    sections, name = _sections(neurons[0], ("type", "vars", "on_spike", "spike_detection", "on_iteration",
+                                            "ion_channels"))
+    for need in ("on_iteration", "spike_detection"):
+        if not sections.get(need):
+            raise ModelError(f"section '{need}' is missing")
+    model = NeuronModel(name, [], [], None, [])
+    for var, value in _variables(sections.get("vars", []), ("v", "i", "is_spiking", "last_firing_time")):
         if var in model.mandatory:
             model.mandatory[var] = value
-        elif var in dict(model.variables):
-            raise ModelError(f"variable {var} is defined twice")
         else:
             model.variables.append((var, value))
+    instances = {}
+    for item in ",".join(sections.get("ion_channels", [])).split(","):
+        item = item.strip()
+        if not item:
+            continue
+        m = re.fullmatch(rf"({_NAME})\s*=\s*({_NAME})", item)
+        if not m:
+            raise ModelError(f"cannot read ion channel {item!r}")
+        inst, type_name = m.groups()
+        if type_name not in channels:
+            raise ModelError(f"unknown ion channel type {type_name!r}")
+        if inst in instances or inst in dict(model.variables) or inst in model.mandatory or inst in ("v", "i"):
+            raise ModelError(f"name {inst!r} is already taken")
+        instances[inst] = channels[type_name]
+        model.ion_channels.append((inst, type_name))
+        model.variables += [(f"{inst}${f}", d) for f, d in channels[type_name].fields()]
     if len(model.variables) > MAX_VARS:
         raise ModelError(f"more than {MAX_VARS} variables")
     detect = " ".join(sections["spike_detection"]).strip()
     if detect.replace(" ", "") == "continuous()":
-        raise ModelError("continuous() spike detection is not supported")
-    model.spike_detection = parse_expr(detect)
-    model.on_iteration = _block(sections["on_iteration"])[0]
-    model.on_spike = _block(sections.get("on_spike", []))[0]
-
-    def no_diffs(stmts, where):
-        for s in stmts:
-            if s[0] == "diff":
-                raise ModelError(f"differential equations belong to the top level of on_iteration, not {where}")
-            if s[0] == "if":
-                for _, body_ in s[1]:
-                    no_diffs(body_, "an [if] branch")
-                if s[2] is not None:
-                    no_diffs(s[2], "an [if] branch")
-    no_diffs(model.on_spike, "on_spike")
-    for s in model.on_iteration:
-        if s[0] == "if":
-            no_diffs([s], "an [if] branch")
+        raise ModelError("continuous() spike detection is not supported (the reference generates code that reads an "
+                         "undefined last_voltage)")
     known = {"v", "i", "dt", "c_m", "gap_conductance"} | {n for n, _ in model.variables}
 
-    def check(e):
-        if e[0] == "var" and e[1] not in known:
-            raise ModelError(f"unknown variable {e[1]!r}")
-        for sub in e[1:]:
-            if isinstance(sub, tuple):
-                check(sub)
-            elif isinstance(sub, list):
-                for x in sub:
-                    check(x)
-    def check_block(stmts):
-        for s in stmts:
-            if s[0] == "if":
-                for cond, body_ in s[1]:
-                    check(cond)
-                    check_block(body_)
-                if s[2] is not None:
-                    check_block(s[2])
-                continue
-            if s[1] not in known - {"i"} or s[1] in ("dt", "c_m", "gap_conductance"):
-                raise ModelError(f"cannot assign to {s[1]!r}")
-            check(s[-1])
-    check_block(model.on_iteration + model.on_spike)
-    check(model.spike_detection)
+    def rename(n):                                  # c.current -> c$current
+        key = n.replace(".", "$")
+        if key not in known:
+            raise ModelError(f"unknown variable {n!r}")
+        return ("var", key)
+
+    def convert(stmts, where):
+        out = []
+        for st in stmts:
+            if st[0] == "if":
+                out.append(("if", [(_map_expr(c, rename), convert(b, "an [if] branch")) for c, b in st[1]],
+                            None if st[2] is None else convert(st[2], "an [if] branch")))
+            elif st[0] == "struct_call":
+                _, inst, method, args = st
+                if inst not in instances or method != "update_current":
+                    raise ModelError(f"cannot call {inst}.{method}(): only <ion channel>.update_current(...)")
+                out.append(_inline_channel(inst, instances[inst], [_map_expr(a, rename) for a in args]))
+            else:
+                if st[0] == "diff" and where != "on_iteration":
+                    raise ModelError(f"differential equations belong to the top level of on_iteration, not {where}")
+                tgt = st[1].replace(".", "$")
+                if tgt not in known - {"i"} or tgt in ("dt", "c_m", "gap_conductance"):
+                    raise ModelError(f"cannot assign to {st[1]!r}")
+                out.append((st[0], tgt) + tuple(st[2:-1]) + (_map_expr(st[-1], rename),))
+        return out
+
+    model.spike_detection = _map_expr(parse_expr(detect), rename)
+    model.on_iteration = convert(_block(sections["on_iteration"])[0], "on_iteration")
+    model.on_spike = convert(_block(sections.get("on_spike", []))[0], "on_spike")
     return model
 
 
@@ -333,7 +575,11 @@ def _hip_expr(e, index):
     if kind == "not":
         return f"(!{_hip_expr(e[1], index)})"
     if kind == "call":
-        return f"expf_portable({_hip_expr(e[2][0], index)})"
+        fn = {"exp": "expf_portable", "tanh": "tanhf_portable", "sinh": "sinhf_portable", "cosh": "coshf_portable",
+              "heaviside": "heaviside_rs", "min": "min_rs", "max": "max_rs"}[e[1]]
+        return f"{fn}({', '.join(_hip_expr(a, index) for a in e[2])})"
+    if kind == "powi":
+        return f"powif_portable({_hip_expr(e[1], index)}, {e[2]})"
     _, op, lhs, rhs = e
     return f"({_hip_expr(lhs, index)} {op} {_hip_expr(rhs, index)})"
 
@@ -350,10 +596,16 @@ def _hip_statements(stmts, index, with_diffs, indent="    "):
                 lines.append(_hip_statements(s[2], index, False, indent + "    "))
             lines.append(f"{indent}}}")
             continue
+        if s[0] == "scope":                 # an inlined ion channel: its `x += dx` at the end of its own body
+            lines.append(f"{indent}{{")
+            lines.append(_hip_statements(s[1], index, True, indent + "    "))
+            lines.append(f"{indent}}}")
+            continue
         target = "v" if s[1] == "v" else f"x[{index[s[1]]}]"
         if s[0] == "diff":
-            lines.append(f"{indent}const float d_{s[1]} = ({_hip_expr(s[2], index)}) * dt;")
-            diffs.append(f"{indent}{target} += d_{s[1]};")
+            d = "d_v" if s[1] == "v" else f"d_x{index[s[1]]}"
+            lines.append(f"{indent}const float {d} = ({_hip_expr(s[2], index)}) * dt;")
+            diffs.append(f"{indent}{target} += {d};")
         else:
             lines.append(f"{indent}{target} {s[2]} {_hip_expr(s[3], index)};")
     return "\n".join(l for l in lines + (diffs if with_diffs else []) if l)

@@ -6,7 +6,17 @@ import numpy as np
 import oracle_binding as ob
 
 f32 = np.float32
-_expf = np.vectorize(ob.expf, otypes=[np.float32])
+_FUNCTIONS = {name: np.vectorize(fn, otypes=[np.float32]) for name, fn in
+              (("exp", ob.expf), ("tanh", ob.tanhf), ("sinh", ob.sinhf), ("cosh", ob.coshf))}
+_powif = np.vectorize(ob.powif, otypes=[np.float32])
+
+
+def _rust_min(a, b):       # f32::min: a NaN operand yields the other one
+    return np.where(np.isnan(a), b, np.where(np.isnan(b), a, np.where(a < b, a, b))).astype(f32)
+
+
+def _rust_max(a, b):
+    return np.where(np.isnan(a), b, np.where(np.isnan(b), a, np.where(a > b, a, b))).astype(f32)
 
 
 def evaluate(e, env):
@@ -20,7 +30,16 @@ def evaluate(e, env):
     if kind == "not":
         return ~evaluate(e[1], env)
     if kind == "call":
-        return _expf(np.asarray(evaluate(e[2][0], env), f32))
+        args = [np.asarray(evaluate(a, env), f32) for a in e[2]]
+        if e[1] == "min":
+            return _rust_min(*args)
+        if e[1] == "max":
+            return _rust_max(*args)
+        if e[1] == "heaviside":                    # nb_macro lib.rs:9176-9178: x < 0 -> 0, else x
+            return np.where(args[0] < 0, f32(0), args[0]).astype(f32)
+        return _FUNCTIONS[e[1]](args[0])
+    if kind == "powi":
+        return _powif(np.asarray(evaluate(e[1], env), f32), e[2])
     _, op, l, r = e
     a, b = evaluate(l, env), evaluate(r, env)
     if op in ("+", "-", "*", "/"):
@@ -45,6 +64,9 @@ def _run(stmts, env, mask=None):
             if s[2] is not None:
                 _run(s[2], env, mask=remaining)
             continue
+        if s[0] == "scope":                       # inlined ion channel: own diffs, applied at the end of its body
+            _run(s[1], env, mask=mask)
+            continue
         if s[0] == "diff":
             diffs.append((s[1], (evaluate(s[2], env) * env["dt"]).astype(f32)))
             continue
@@ -55,7 +77,8 @@ def _run(stmts, env, mask=None):
         new = np.broadcast_to(val, env[name].shape).astype(f32)
         env[name] = np.where(mask, new, env[name]).astype(f32) if mask is not None else new
     for name, d in diffs:
-        env[name] = (env[name] + d).astype(f32)
+        new = (env[name] + d).astype(f32)
+        env[name] = np.where(mask, new, env[name]).astype(f32) if mask is not None else new
 
 
 def make_step(model):
@@ -78,7 +101,8 @@ def make_step(model):
 
 # ---- stack program for the C oracle (oracle/snn_oracle.c::custom_run) -------------------------------------
 _OPS = dict(END=0, CONST=1, LOAD=2, STORE=3, DIFF=4, NEG=5, NOT=6, ADD=7, SUB=8, MUL=9, DIV=10, EXP=11, EQ=12, NE=13,
-            GE=14, LE=15, GT=16, LT=17, AND=18, OR=19, JZ=20, JMP=21)
+            GE=14, LE=15, GT=16, LT=17, AND=18, OR=19, JZ=20, JMP=21, TANH=22, SINH=23, COSH=24, MIN=25, MAX=26,
+            HEAVISIDE=27, POWI=28, MARK=29, FLUSH=30)
 _BIN = {"+": "ADD", "-": "SUB", "*": "MUL", "/": "DIV", "==": "EQ", "!=": "NE", ">=": "GE", "<=": "LE", ">": "GT",
         "<": "LT", "&&": "AND", "||": "OR"}
 _BASE_SLOTS = {"v": 0, "i": 1, "dt": 2, "c_m": 3, "gap_conductance": 4}
@@ -102,8 +126,12 @@ def compile_program(model):
             emit_expr(e[1])
             code.append(_OPS["NEG" if kind == "neg" else "NOT"])
         elif kind == "call":
-            emit_expr(e[2][0])
-            code.append(_OPS["EXP"])
+            for a in e[2]:
+                emit_expr(a)
+            code.append(_OPS[e[1].upper()])
+        elif kind == "powi":
+            emit_expr(e[1])
+            code.extend([_OPS["POWI"], e[2]])
         else:
             emit_expr(e[2])
             emit_expr(e[3])
@@ -125,6 +153,11 @@ def compile_program(model):
                     emit_statements(s[2])
                 for e in exits:
                     code[e] = len(code)
+                continue
+            if s[0] == "scope":
+                code.append(_OPS["MARK"])
+                emit_statements(s[1])
+                code.append(_OPS["FLUSH"])
                 continue
             if s[0] == "diff":
                 emit_expr(s[2])

@@ -115,9 +115,12 @@ def lib():
         L.snn_o_reward_modulation_cols.restype = None
         L.snn_o_run.argtypes = [P, C.c_uint64]
         L.snn_o_run.restype = None
-        for fn in ("snn_o_expf_export", "snn_o_pow3f_export", "snn_o_pow4f_export"):
+        for fn in ("snn_o_expf_export", "snn_o_pow3f_export", "snn_o_pow4f_export", "snn_o_tanhf_export",
+                   "snn_o_sinhf_export", "snn_o_coshf_export"):
             getattr(L, fn).argtypes = [C.c_float]
             getattr(L, fn).restype = C.c_float
+        L.snn_o_powif_export.argtypes = [C.c_float, C.c_int]
+        L.snn_o_powif_export.restype = C.c_float
         L.snn_o_stdp_delta.argtypes = [C.c_int32, C.c_int32] + [C.c_float] * 5
         L.snn_o_stdp_delta.restype = C.c_float
         L.snn_o_delta_dirac_effect.argtypes = [C.c_int64, C.c_int32] + [C.c_float] * 4
@@ -399,6 +402,22 @@ class Net:
 
 def expf(x):
     return lib().snn_o_expf_export(float(np.float32(x)))
+
+
+def tanhf(x):
+    return lib().snn_o_tanhf_export(float(np.float32(x)))
+
+
+def sinhf(x):
+    return lib().snn_o_sinhf_export(float(np.float32(x)))
+
+
+def coshf(x):
+    return lib().snn_o_coshf_export(float(np.float32(x)))
+
+
+def powif(x, n):
+    return lib().snn_o_powif_export(float(np.float32(x)), int(n))
 
 
 def uniform(seed, index, lo, hi):

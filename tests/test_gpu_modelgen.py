@@ -10,6 +10,25 @@ import oracle_binding as ob
 import modelgen_ref
 import parity
 from test_modelgen import CURRENTS, EXPECTED_FLAG, IF_DSL, IZH_DSL, LIF_NB, lif_reference_trace
+from test_modelgen_channels import CALCIUM_CLAMP, MORRIS_LECAR, VOLTAGES, calcium_reference
+
+FUNCTIONS_DSL = """
+[neuron]
+    type: FunctionSampler
+    vars: v_th = 50000000, f_exp = 0, f_tanh = 0, f_sinh = 0, f_cosh = 0, f_min = 0, f_max = 0, f_heaviside = 0, f_cube = 0, f_inverse_square = 0, f_minus_square = 0
+    spike_detection: v >= v_th
+    on_iteration:
+        f_exp = exp(i)
+        f_tanh = tanh(i)
+        f_sinh = sinh(i)
+        f_cosh = cosh(i)
+        f_min = min(0.5, i)
+        f_max = max(0.5, i)
+        f_heaviside = heaviside(i)
+        f_cube = i ^ 3
+        f_inverse_square = i ^ -2
+        f_minus_square = -i ^ 2
+[end]"""          # the functions of build_test/nb_macro/tests/function_usage.rs in one model
 
 pytestmark = pytest.mark.gpu
 f32 = np.float32
@@ -18,11 +37,11 @@ f32 = np.float32
 @pytest.fixture(scope="module")
 def libs(snn):
     from snn_amd import _lib, modelgen
-    out = {}
-    for text in (LIF_NB, IZH_DSL, IF_DSL):
-        m = modelgen.parse(text)
-        out[m.name] = (m, _lib.build_custom(m))
-    return out
+    from concurrent.futures import ThreadPoolExecutor
+    models = [modelgen.parse(text) for text in (LIF_NB, IZH_DSL, IF_DSL, CALCIUM_CLAMP, MORRIS_LECAR, FUNCTIONS_DSL)]
+    with ThreadPoolExecutor(max_workers=3) as pool:          # one hipcc each
+        paths = list(pool.map(_lib.build_custom, models))
+    return {m.name: (m, path) for m, path in zip(models, paths)}
 
 
 def test_reference_known_answer_for_the_generated_lif(snn, libs):
@@ -194,6 +213,111 @@ def test_generated_model_in_a_network_equals_the_oracle(snn, libs, variant):
     parity.assert_state_equal(net, parity.pull_state(dn, net))
     parity.assert_graph_equal(net, dn)
     assert net.spike_history.sum() > 20 and not np.array_equal(w0, net["weights"])
+    dn.close()
+
+
+def test_gated_ion_channel_known_answer(snn, libs):
+    """timestep_dependent_ion_channel.rs on the device: the calcium channel (one gating variable, exp, `^ 2`) inside a
+    neuron that holds its voltage, 1000 iterations at each of the test's voltages with the channel state carried
+    over -- current and gate equal to the float32 hand expansion of ReferenceCalciumIonChannel."""
+    model, lib = libs["VoltageClamp"]
+    want, (alpha, beta, state) = calcium_reference(VOLTAGES, 1000, 0.01)
+    dn = snn.DeviceNetwork(model=snn.CUSTOM, lib_path=lib)
+    dn.add_lattice(0, 1, 1)
+    dn.finalize()
+    assert dn.get_attr(0, "dt")[0] == f32(0.01) and dn.get_attr(0, "ca$g")[0] == f32(0.025)
+    for k, v in enumerate(VOLTAGES):
+        dn.set_attr(0, "current_voltage", np.full(1, v, f32))
+        dn.run(999)
+        assert parity.bits(dn.get_attr(0, "ca$current"))[0] == parity.bits(want[1000 * k + 998:1000 * k + 999])[0]
+        dn.run(1)
+        assert parity.bits(dn.get_attr(0, "ca$current"))[0] == parity.bits(want[1000 * (k + 1) - 1:1000 * (k + 1)])[0]
+        assert dn.get_attr(0, "current_voltage")[0] == f32(v)
+    assert (dn.get_attr(0, "ca$s$alpha")[0], dn.get_attr(0, "ca$s$beta")[0], dn.get_attr(0, "ca$s$state")[0]) == \
+        (alpha, beta, state)
+    dn.close()
+
+
+def test_functions_and_powers_equal_the_oracle(snn, libs):
+    """exp / tanh / sinh / cosh / min / max / heaviside / integer powers: one model that stores f(i) for each, fed a
+    spread of inputs through never-firing rate cells -- bit-identical to the C oracle's own implementations, and
+    within 1 ULP of the exact value."""
+    model, lib = libs["FunctionSampler"]
+    x = np.concatenate([np.array([-88.0, -30.0, -9.5, -3.0, -1.0, -0.3, -0.05, -0.01, -1e-6, 0.0, 1e-6, 0.02, 0.05, 0.5,
+                                  1.0, 2.5, 7.25, 11.0, 19.9, 20.1, 45.0, 88.0, 91.0], f32),
+                        ob.uniform_array(12, 233, -12.0, 12.0)])
+    n = x.size
+    lay = parity.Layout([(1, 1, n)], [(0, 1, n)])
+    net = parity.make_oracle(lay, model=ob.CUSTOM, st_kind=ob.ST_RATE)
+    modelgen_ref.attach(net, model)
+    net.custom_lib = lib
+    net["st_v_resting"] = x
+    net["connections"][n + np.arange(n), np.arange(n)] = 1
+    net["weights"][n + np.arange(n), np.arange(n)] = 1.0
+    dn = parity.device_from_oracle(snn, net)
+    dn.run(2)
+    net.run(2)
+    names = [name for name, _ in model.variables]
+    exact = {"f_exp": np.exp, "f_tanh": np.tanh, "f_sinh": np.sinh, "f_cosh": np.cosh}
+    with np.errstate(all="ignore"):
+        for k, name in enumerate(names):
+            got = dn.get_attr(1, name)
+            assert np.array_equal(parity.bits(got), parity.bits(net["custom_vars"][k])), name
+            if name in exact:
+                want = exact[name](x.astype(np.float64)).astype(f32)
+                ok = np.isfinite(want) & (np.abs(want) > 1e-37)
+                ulp = np.abs(got[ok].view(np.int32).astype(np.int64) - want[ok].view(np.int32).astype(np.int64))
+                assert ulp.max() <= 1, (name, ulp.max())
+                assert np.array_equal(np.isinf(got), np.isinf(want)), name
+    assert np.array_equal(dn.get_attr(1, "f_minus_square"), -(x * x))
+    dn.close()
+
+
+@pytest.mark.parametrize("variant", ["electrical", "both_synapses", "sparse"])
+def test_morris_lecar_network_equals_the_oracle(snn, libs, variant):
+    """A Morris-Lecar neuron assembled from three DSL ion channels (tanh, cosh, a channel-local differential equation,
+    19 generated variables) in two lattices with Poisson rows, gap junctions and AMPA/NMDA synapses, STDP on:
+    raster, voltages, every channel variable and the weights bit-identical to the C oracle."""
+    model, lib = libs["MorrisLecarNeuron"]
+    chemical = variant == "both_synapses"
+    lay = parity.Layout([(0, 6, 6), (2, 4, 5)], [(5, 3, 3)])
+    net = parity.make_oracle(lay, model=ob.CUSTOM, st_kind=ob.ST_POISSON, electrical=True, chemical=chemical)
+    modelgen_ref.attach(net, model)
+    net.custom_lib = lib
+    n, nc = net.n_neurons, net.n_cells
+    names = [name for name, _ in model.variables]
+    rng = np.random.default_rng(21)
+    net["current_voltage"] = ob.uniform_array(21, n, -70.0, -20.0)
+    net["gap_conductance"] = 1.0                      # explicit Euler at dt = 0.1: stronger coupling diverges
+    net["custom_vars"][names.index("k_channel$phi")] = ob.uniform_array(22, n, 0.04, 0.09)      # heterogeneous
+    net["nt_flags"][:, 0] = 1
+    net["nt_flags"][:, 1] = rng.random(n) < 0.5
+    net["rc_flags"][:, :2] = 1
+    net["rc_g"][:, 0] = 1.5
+    net["st_nt_flags"][:, 0] = 1
+    net["st_chance_of_firing"] = ob.uniform_array(23, nc, 0.0, 0.03)
+    net["st_seed"] = np.arange(170, 170 + nc, dtype=np.uint32)
+    net.fill_graph(24, 0.5, 1.5)
+    net["connections"][rng.random(net["connections"].shape) < 0.4] = 0
+    net["weights"][...] *= net["connections"]
+    net["do_plasticity"] = 1
+    steps = 2400
+    dn = parity.device_from_oracle(snn, net, csr=(variant == "sparse"))
+    dn.set_history(voltage=True, spikes=True)
+    dn.run(steps // 2)
+    dn.run(steps - steps // 2)
+    w0 = net["weights"].copy()
+    net.run(steps, voltage_history=True, spike_history=True)
+    ranges = net.layout.ranges()
+    for i, _, _ in net.layout.lattices:
+        first, count, _ = ranges[i]
+        assert np.array_equal(dn.spike_history(i), net.spike_history[:, first:first + count])
+        assert np.array_equal(parity.bits(dn.voltage_history(i)), parity.bits(net.voltage_history[:, first:first + count]))
+    parity.assert_state_equal(net, parity.pull_state(dn, net))
+    parity.assert_graph_equal(net, dn)
+    vh = net.voltage_history
+    assert np.isfinite(vh).all() and vh.max() > 0.0 and net.spike_history.sum() > 10
+    assert not np.array_equal(w0, net["weights"])
     dn.close()
 
 

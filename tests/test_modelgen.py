@@ -57,19 +57,23 @@ def test_mandatory_overrides_precedence_and_order_of_application():
     # left-to-right, one operation per node; both derivatives are formed before either variable moves
     assert "((((((0.03999999910593033f * v) * v) + (5.0f * v)) + 140.0f) - x[4]) + i_in) + " in src
     assert "(0.5f * expf_portable(((v - x[5]) / 20.0f)))) / c_m)" in src
-    i_dv, i_dw, i_apply = src.index("const float d_v"), src.index("const float d_w"), src.index("v += d_v;")
-    assert i_dv < i_dw < i_apply < src.index("x[4] += d_w;")
+    i_dv, i_dw, i_apply = src.index("const float d_v"), src.index("const float d_x4"), src.index("v += d_v;")
+    assert i_dv < i_dw < i_apply < src.index("x[4] += d_x4;")
     assert "x[4] += x[3];" in src                  # on_spike: w += d
 
 
 @pytest.mark.parametrize("text,needle", [
-    (LIF_NB.replace("dv/dt = (v - e) + i", "dv/dt = (v - e) ^ 2"), "'^'"),
-    (LIF_NB.replace("dv/dt = (v - e) + i", "dv/dt = tanh(v)"), "tanh"),
+    (LIF_NB.replace("dv/dt = (v - e) + i", "dv/dt = (v - e) ^ 2.5"), "integer literal exponent"),
+    (LIF_NB.replace("dv/dt = (v - e) + i", "dv/dt = (v - e) ^ e"), "integer literal exponent"),
+    (LIF_NB.replace("dv/dt = (v - e) + i", "dv/dt = sin(v)"), "sin"),
+    (LIF_NB.replace("dv/dt = (v - e) + i", "dv/dt = min(v)"), "argument"),
     (LIF_NB.replace("spike_detection: v >= v_th", "spike_detection: continuous()"), "continuous"),
     (LIF_NB.replace("vars: e = 0", "vars: flag = true, e = 0"), "bool"),
     (LIF_NB.replace("dv/dt = (v - e) + i", "dv/dt = (v - q) + i"), "unknown variable"),
-    (LIF_NB.replace("[neuron]", "[ion_channel]"), "exactly one [neuron]"),
-    (LIF_NB.replace("on_iteration:", "ion_channels: k = K\n    on_iteration:"), "ion_channels"),
+    (LIF_NB.replace("[neuron]", "[receptors]"), "[receptors] blocks are not supported"),
+    (LIF_NB + "\n" + LIF_NB, "exactly one [neuron]"),
+    (LIF_NB.replace("on_iteration:", "ion_channels: k = K\n    on_iteration:"), "unknown ion channel type"),
+    (LIF_NB.replace("dv/dt = (v - e) + i", "k.update_current(v)\n        dv/dt = (v - e) + i"), "cannot call"),
     (LIF_NB.replace("v = v_reset", "dt = 1"), "cannot assign"),
 ])
 def test_unsupported_descriptions_are_refused_with_a_reason(text, needle):
