@@ -40,9 +40,13 @@ the reference tests against is build_test/nb_macro/tests/lif_reference.rs):
     left-associative: pest_ast/mod.rs:183-186; a leading unary minus of the base ends up OUTSIDE the power, see
     _power).
 
+  * bool variables (`flag = false`, tests/bool_vars.rs): stored as 1.0 / 0.0 in a float plane (set them to 0 or 1
+    only), typed like the generated Rust -- conditions, `!`, `&&`, `||` take bools, arithmetic and comparisons take
+    numbers, and a description rustc would refuse for mixing them is refused here.
+
 `hip_source(model)` emits the header that csrc/snn_custom_model.hpp includes when the library is compiled with
 -DSNN_CUSTOM_MODEL_HEADER; `_lib.build_custom(model)` compiles such a library.  Not supported (rejected with a
-message): receptors / kinetics / spike-train / refractoriness blocks, bool variables, `^` with a non-literal or
+message): receptors / kinetics / spike-train / refractoriness blocks, `^` with a non-literal or
 fractional exponent, sin / cos / tan / isnan, on_electrochemical_iteration, and `continuous()` spike detection --
 the code the reference generates for it reads a `last_voltage` that is never defined (lib.rs:984-990), so there is
 no behaviour to match.
@@ -159,6 +163,8 @@ class _Parser:
                 if len(args) != FUNCTIONS[val]:
                     raise ModelError(f"{val}() takes {FUNCTIONS[val]} argument(s)")
                 return ("call", val, args)
+            if val in ("true", "false"):
+                return ("bool", val == "true")
             return ("var", val)
         if (kind, val) == ("op", "("):
             e = self.expr()
@@ -259,11 +265,13 @@ class NeuronModel:
         self.mandatory = dict(MANDATORY)    # defaults of current_voltage / dt / c_m / gap_conductance
         self.on_iteration, self.spike_detection, self.on_spike = on_iteration, spike_detection, on_spike
         self.ion_channels = []              # [(instance name, channel type name)]
+        self.bools = set()                  # variables declared true / false: stored as 1.0 / 0.0
 
 
 class IonChannel:
-    def __init__(self, name, variables, gating_vars, on_iteration):
+    def __init__(self, name, variables, gating_vars, on_iteration, bools=()):
         self.name, self.variables, self.gating_vars, self.on_iteration = name, variables, gating_vars, on_iteration
+        self.bools = set(bools)
         # lib.rs:3967-3997: update_current takes dt when the body has a differential equation or hands `dt` to a call
         self.uses_timestep = any(
             st[0] == "diff" or (st[0] == "struct_call" and any(a == ("var", "dt") for a in st[3]))
@@ -334,7 +342,8 @@ def _sections(body, allowed):
     return sections, name
 
 
-def _variables(items, reserved):
+def _variables(items, reserved, bools):
+    """[(name, default)]; bool variables (stored as 1.0 / 0.0) are added to the set `bools`"""
     out = []
     for item in ",".join(items).split(","):
         item = item.strip()
@@ -343,9 +352,12 @@ def _variables(items, reserved):
         m = re.fullmatch(rf"({_NAME})\s*=\s*(-?\s*[0-9.eE+-]+|true|false)", item)
         if not m:
             raise ModelError(f"cannot read variable {item!r}")
+        var = m.group(1)
         if m.group(2) in ("true", "false"):
-            raise ModelError("bool variables are not supported")
-        var, value = m.group(1), float(m.group(2).replace(" ", ""))
+            value = 1.0 if m.group(2) == "true" else 0.0
+            bools.add(var)
+        else:
+            value = float(m.group(2).replace(" ", ""))
         if var in reserved:
             raise ModelError(f"'{var}' is reserved")
         if var in dict(out):
@@ -368,7 +380,7 @@ def _walk(stmts):
 
 def _map_expr(e, rename):
     kind = e[0]
-    if kind == "num":
+    if kind in ("num", "bool"):
         return e
     if kind == "var":
         return rename(e[1])
@@ -400,14 +412,17 @@ def _parse_channel(body):
     for g in gates:
         if not re.fullmatch(_NAME, g):
             raise ModelError(f"bad gating variable name {g!r}")
-    variables = _variables(sections.get("vars", []), ("v", "i", "dt") + tuple(gates))
+    bools = set()
+    variables = _variables(sections.get("vars", []), ("v", "i", "dt") + tuple(gates), bools)
     stmts = _block(sections["on_iteration"])[0]
     for st in stmts:
         if st[0] == "if":
             for inner in _walk([st]):
                 if inner[0] == "diff":
                     raise ModelError("differential equations belong to the top level of on_iteration")
-    return IonChannel(name, variables, gates, stmts)
+    if "current" in bools:
+        raise ModelError(f"ion channel {name}: 'current' is a number")
+    return IonChannel(name, variables, gates, stmts, bools)
 
 
 def _inline_channel(inst, ch, args):
@@ -495,8 +510,10 @@ def parse(text):
         if not sections.get(need):
             raise ModelError(f"section '{need}' is missing")
     model = NeuronModel(name, [], [], None, [])
-    for var, value in _variables(sections.get("vars", []), ("v", "i", "is_spiking", "last_firing_time")):
+    for var, value in _variables(sections.get("vars", []), ("v", "i", "is_spiking", "last_firing_time"), model.bools):
         if var in model.mandatory:
+            if var in model.bools:
+                raise ModelError(f"'{var}' is a number")
             model.mandatory[var] = value
         else:
             model.variables.append((var, value))
@@ -516,6 +533,7 @@ def parse(text):
         instances[inst] = channels[type_name]
         model.ion_channels.append((inst, type_name))
         model.variables += [(f"{inst}${f}", d) for f, d in channels[type_name].fields()]
+        model.bools |= {f"{inst}${b}" for b in channels[type_name].bools}
     if len(model.variables) > MAX_VARS:
         raise ModelError(f"more than {MAX_VARS} variables")
     detect = " ".join(sections["spike_detection"]).strip()
@@ -553,7 +571,62 @@ def parse(text):
     model.spike_detection = _map_expr(parse_expr(detect), rename)
     model.on_iteration = convert(_block(sections["on_iteration"])[0], "on_iteration")
     model.on_spike = convert(_block(sections.get("on_spike", []))[0], "on_spike")
+    _check_types(model)
     return model
+
+
+def _check_types(model):
+    """The generated Rust is typed (f32 / bool fields): a description that rustc would refuse is refused here."""
+    def kind(e):
+        k = e[0]
+        if k == "num":
+            return "number"
+        if k == "bool":
+            return "bool"
+        if k == "var":
+            return "bool" if e[1] in model.bools else "number"
+        if k == "neg" or k == "powi":
+            need(e[1], "number", "arithmetic")
+            return "number"
+        if k == "not":
+            need(e[1], "bool", "'!'")
+            return "bool"
+        if k == "call":
+            for a in e[2]:
+                need(a, "number", f"{e[1]}()")
+            return "number"
+        _, op, lhs, rhs = e
+        if op in ("&&", "||"):
+            need(lhs, "bool", f"'{op}'")
+            need(rhs, "bool", f"'{op}'")
+            return "bool"
+        if op in ("==", "!="):
+            if kind(lhs) != kind(rhs):
+                raise ModelError(f"'{op}' compares a number with a bool")
+            return "bool"
+        need(lhs, "number", f"'{op}'")
+        need(rhs, "number", f"'{op}'")
+        return "bool" if op in (">=", "<=", ">", "<") else "number"
+
+    def need(e, want, where):
+        got = kind(e)
+        if got != want:
+            raise ModelError(f"{where} needs a {want}, not a {got}")
+
+    need(model.spike_detection, "bool", "spike_detection")
+    for st in _walk(model.on_iteration + model.on_spike):
+        if st[0] == "if":
+            for cond, _ in st[1]:
+                need(cond, "bool", "[if]")
+        elif st[0] == "diff":
+            if st[1] in model.bools:
+                raise ModelError(f"d{st[1]}/dt: {st[1]} is a bool")
+            need(st[2], "number", "a differential equation")
+        elif st[0] == "assign":
+            want = "bool" if st[1] in model.bools else "number"
+            if want == "bool" and st[2] != "=":
+                raise ModelError(f"'{st[2]}' on the bool variable {st[1]}")
+            need(st[3], want, f"assignment to {st[1].replace('$', '.')}")
 
 
 # ---- HIP -------------------------------------------------------------------------------------------------
@@ -566,9 +639,13 @@ def _hip_expr(e, index):
     kind = e[0]
     if kind == "num":
         return _f32_literal(e[1])
+    if kind == "bool":
+        return "true" if e[1] else "false"
     if kind == "var":
         if e[1] in ("v", "i", "dt", "c_m", "gap_conductance"):
             return {"v": "v", "i": "i_in", "dt": "dt", "c_m": "c_m", "gap_conductance": "g_gap"}[e[1]]
+        if e[1] in index.get("$bools", ()):
+            return f"(x[{index[e[1]]}] != 0.0f)"
         return f"x[{index[e[1]]}]"
     if kind == "neg":
         return f"(-{_hip_expr(e[1], index)})"
@@ -606,6 +683,8 @@ def _hip_statements(stmts, index, with_diffs, indent="    "):
             d = "d_v" if s[1] == "v" else f"d_x{index[s[1]]}"
             lines.append(f"{indent}const float {d} = ({_hip_expr(s[2], index)}) * dt;")
             diffs.append(f"{indent}{target} += {d};")
+        elif s[1] in index.get("$bools", ()):
+            lines.append(f"{indent}{target} = {_hip_expr(s[3], index)} ? 1.0f : 0.0f;")
         else:
             lines.append(f"{indent}{target} {s[2]} {_hip_expr(s[3], index)};")
     return "\n".join(l for l in lines + (diffs if with_diffs else []) if l)
@@ -614,6 +693,7 @@ def _hip_statements(stmts, index, with_diffs, indent="    "):
 def hip_source(model):
     """The generated header: variable table + on_iteration / spike_detection / on_spike as device functions."""
     index = {n: k for k, (n, _) in enumerate(model.variables)}
+    index["$bools"] = model.bools
     nv = max(1, len(model.variables))
     names = ", ".join(f'"{n}"' for n, _ in model.variables) or '""'
     defaults = ", ".join(_f32_literal(d) for _, d in model.variables) or "0.0f"

@@ -23,8 +23,10 @@ def evaluate(e, env):
     kind = e[0]
     if kind == "num":
         return f32(e[1])
+    if kind == "bool":
+        return np.bool_(e[1])
     if kind == "var":
-        return env[e[1]]
+        return (env[e[1]] != 0) if e[1] in env.get("$bools", ()) else env[e[1]]
     if kind == "neg":
         return (-evaluate(e[1], env)).astype(f32)
     if kind == "not":
@@ -74,7 +76,7 @@ def _run(stmts, env, mask=None):
         val = evaluate(expr, env)
         if op != "=":
             val = evaluate(("bin", op[0], ("var", name), expr), env)
-        new = np.broadcast_to(val, env[name].shape).astype(f32)
+        new = np.broadcast_to(val, env[name].shape).astype(f32)          # a bool becomes 1.0 / 0.0
         env[name] = np.where(mask, new, env[name]).astype(f32) if mask is not None else new
     for name, d in diffs:
         new = (env[name] + d).astype(f32)
@@ -86,7 +88,7 @@ def make_step(model):
     variables as float32 arrays (updated in place)."""
     def step(state, i_in):
         env = {"v": state["current_voltage"], "i": i_in, "dt": state["dt"], "c_m": state["c_m"],
-               "gap_conductance": state["gap_conductance"]}
+               "gap_conductance": state["gap_conductance"], "$bools": model.bools}
         for name, _ in model.variables:
             env[name] = state[name]
         _run(model.on_iteration, env)
@@ -117,7 +119,7 @@ def compile_program(model):
 
     def emit_expr(e):
         kind = e[0]
-        if kind == "num":
+        if kind in ("num", "bool"):
             consts.append(np.float32(e[1]))
             code.extend([_OPS["CONST"], len(consts) - 1])
         elif kind == "var":

@@ -9,7 +9,8 @@ import numpy_ref as nr
 import oracle_binding as ob
 import modelgen_ref
 import parity
-from test_modelgen import CURRENTS, EXPECTED_FLAG, IF_DSL, IZH_DSL, LIF_NB, lif_reference_trace
+from test_modelgen import (BOOL_DSL, CURRENTS, EXPECTED_FLAG, IF_DSL, IZH_DSL, LIF_NB, bool_expected_out,
+                           lif_reference_trace)
 from test_modelgen_channels import CALCIUM_CLAMP, MORRIS_LECAR, VOLTAGES, calcium_reference
 
 FUNCTIONS_DSL = """
@@ -38,8 +39,9 @@ f32 = np.float32
 def libs(snn):
     from snn_amd import _lib, modelgen
     from concurrent.futures import ThreadPoolExecutor
-    models = [modelgen.parse(text) for text in (LIF_NB, IZH_DSL, IF_DSL, CALCIUM_CLAMP, MORRIS_LECAR, FUNCTIONS_DSL)]
-    with ThreadPoolExecutor(max_workers=3) as pool:          # one hipcc each
+    models = [modelgen.parse(text) for text in (LIF_NB, IZH_DSL, IF_DSL, CALCIUM_CLAMP, MORRIS_LECAR, FUNCTIONS_DSL,
+                                                 BOOL_DSL)]
+    with ThreadPoolExecutor(max_workers=4) as pool:          # one hipcc each
         paths = list(pool.map(_lib.build_custom, models))
     return {m.name: (m, path) for m, path in zip(models, paths)}
 
@@ -103,6 +105,36 @@ def test_if_statements_known_answers(snn, libs):
     dn.run(299)
     assert np.array_equal(dn.get_attr(1, "flag"), EXPECTED_FLAG)
     assert np.array_equal(parity.bits(dn.voltage_history(1)), parity.bits(lif_reference_trace(300)))
+    dn.close()
+
+
+def test_bool_variables_known_answers(snn, libs):
+    """build_test/nb_macro/tests/bool_vars.rs on the device: `out` is 1 / 2 by the bool `flag` for every input current,
+    a bool written by on_spike is read back through `!`, `&&`, `==`, and the voltages stay the plain LIF's."""
+    model, lib = libs["BoolIntegrateAndFire"]
+    currents = np.concatenate([CURRENTS, CURRENTS])
+    flag = np.concatenate([np.zeros(CURRENTS.size, bool), np.ones(CURRENTS.size, bool)])
+    n = currents.size
+    dn = snn.DeviceNetwork(model=snn.CUSTOM, spike_train=snn.ST_RATE, lib_path=lib)
+    dn.add_lattice(1, 1, n)
+    dn.add_spike_train_lattice(0, 1, n)
+    dn.finalize()
+    assert np.array_equal(dn.get_attr(1, "flag"), np.zeros(n, f32))                 # false
+    dn.set_attr(1, "flag", flag.astype(f32))
+    dn.set_attr(0, "v_resting", currents)
+    w = np.zeros((2 * n, n), f32)
+    c = np.zeros((2 * n, n), np.uint32)
+    w[n + np.arange(n), np.arange(n)] = 1.0
+    c[n + np.arange(n), np.arange(n)] = 1
+    dn.set_graph_rows(0, w, c)
+    dn.set_history(voltage=True, spikes=False)
+    dn.run(1)
+    assert np.array_equal(dn.get_attr(1, "out"), bool_expected_out(flag, 1))
+    dn.run(299)
+    assert np.array_equal(dn.get_attr(1, "out"), bool_expected_out(flag, 300))
+    assert np.array_equal(dn.get_attr(1, "seen"), np.ones(n, f32))
+    ref = np.concatenate([lif_reference_trace(300)] * 2, axis=1)
+    assert np.array_equal(parity.bits(dn.voltage_history(1)), parity.bits(ref))
     dn.close()
 
 

@@ -68,7 +68,11 @@ def test_mandatory_overrides_precedence_and_order_of_application():
     (LIF_NB.replace("dv/dt = (v - e) + i", "dv/dt = sin(v)"), "sin"),
     (LIF_NB.replace("dv/dt = (v - e) + i", "dv/dt = min(v)"), "argument"),
     (LIF_NB.replace("spike_detection: v >= v_th", "spike_detection: continuous()"), "continuous"),
-    (LIF_NB.replace("vars: e = 0", "vars: flag = true, e = 0"), "bool"),
+    (LIF_NB.replace("vars: e = 0", "vars: flag = true, e = 0").replace("(v - e) + i", "(v - e) + flag"), "needs a number"),
+    (LIF_NB.replace("spike_detection: v >= v_th", "spike_detection: v"), "spike_detection needs a bool"),
+    (LIF_NB.replace("vars: e = 0", "vars: flag = true, e = 0").replace("v = v_reset", "flag = 3"), "assignment to flag"),
+    (LIF_NB.replace("vars: e = 0", "vars: flag = true, e = 0").replace("v = v_reset", "flag += true"), "on the bool variable"),
+    (LIF_NB.replace("vars: e = 0", "vars: dt = true, e = 0"), "is a number"),
     (LIF_NB.replace("dv/dt = (v - e) + i", "dv/dt = (v - q) + i"), "unknown variable"),
     (LIF_NB.replace("[neuron]", "[receptors]"), "[receptors] blocks are not supported"),
     (LIF_NB + "\n" + LIF_NB, "exactly one [neuron]"),
@@ -205,6 +209,74 @@ def test_if_statements_known_answers_on_both_cpu_evaluators():
     net["weights"][n + np.arange(n), np.arange(n)] = 1.0
     net.run(300, voltage_history=True)
     assert np.array_equal(net["custom_vars"][3], EXPECTED_FLAG)
+    assert np.array_equal(net.voltage_history.view(np.uint32), ref.view(np.uint32))
+
+
+BOOL_DSL = """
+[neuron]
+    type: BoolIntegrateAndFire
+    vars: e = 0, v_reset = -75, v_th = -55, flag = false, out = 0, seen = false
+    on_spike:
+        v = v_reset
+        seen = true
+    spike_detection: v >= v_th
+    on_iteration:
+        [if] flag [then]
+            out = 1
+        [else]
+            out = 2
+        [end]
+        [if] !flag && seen == true [then]
+            out = out + 10
+        [end]
+
+        dv/dt = (v - e) + i
+[end]"""          # build_test/nb_macro/tests/bool_vars.rs:10-26 plus a bool written by on_spike and read through ! && ==
+
+
+def bool_expected_out(flag, steps):
+    """out after `steps` iterations: 1 / 2 by flag (bool_vars.rs:56-60), +10 once the neuron has fired and flag is false
+    (the plain LIF above threshold fires on its first step for every current of CURRENTS >= -50: v starts at 0)"""
+    fired_before = steps > 1
+    return np.where(flag, 1.0, np.where(fired_before, 12.0, 2.0)).astype(np.float32)
+
+
+def test_bool_variables_known_answers_on_both_cpu_evaluators():
+    import modelgen_ref
+    import oracle_binding as ob
+    import parity
+    f32 = np.float32
+    m = modelgen.parse(BOOL_DSL)
+    assert m.bools == {"flag", "seen"} and dict(m.variables)["flag"] == 0.0
+    src = modelgen.hip_source(m)
+    assert "if ((x[3] != 0.0f)) {" in src and "x[5] = true ? 1.0f : 0.0f;" in src
+    currents = np.concatenate([CURRENTS, CURRENTS])
+    flag = np.concatenate([np.zeros(CURRENTS.size, bool), np.ones(CURRENTS.size, bool)])
+    n = currents.size
+    ref = np.concatenate([lif_reference_trace(300)] * 2, axis=1)
+    step = modelgen_ref.make_step(m)
+    st = {"current_voltage": np.zeros(n, f32), "dt": np.full(n, 0.1, f32), "c_m": np.ones(n, f32),
+          "gap_conductance": np.full(n, 10.0, f32)}
+    for name, default in m.variables:
+        st[name] = np.full(n, default, f32)
+    st["flag"] = flag.astype(f32)
+    with np.errstate(over="ignore", invalid="ignore"):
+        for t in range(300):
+            step(st, currents)
+            assert np.array_equal(st["out"], bool_expected_out(flag, t + 1)), t
+            assert np.array_equal(st["current_voltage"].view(np.uint32), ref[t].view(np.uint32))
+    assert st["seen"].all()
+    lay = parity.Layout([(1, 1, n)], [(0, 1, n)])
+    net = parity.make_oracle(lay, model=ob.CUSTOM, st_kind=ob.ST_RATE)
+    modelgen_ref.attach(net, m)
+    names = [name for name, _ in m.variables]
+    net["custom_vars"][names.index("flag")] = flag.astype(f32)
+    net["st_v_resting"] = currents
+    net["connections"][n + np.arange(n), np.arange(n)] = 1
+    net["weights"][n + np.arange(n), np.arange(n)] = 1.0
+    net.run(300, voltage_history=True)
+    assert np.array_equal(net["custom_vars"][names.index("out")], bool_expected_out(flag, 300))
+    assert np.array_equal(net["custom_vars"][names.index("seen")], np.ones(n, f32))
     assert np.array_equal(net.voltage_history.view(np.uint32), ref.view(np.uint32))
 
 
