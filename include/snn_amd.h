@@ -103,7 +103,12 @@ typedef enum { SNN_RC_APPROXIMATE = 0, SNN_RC_DESTEXHE = 1, SNN_RC_EXPONENTIAL_D
  * NeuralRefractoriness of a cell: attribute neural_refractoriness$kind (u32; 0 DeltaDirac :79-88, the default,
  * 1 ExponentialDecay :164-178), decay constant neural_refractoriness$k. */
 /* BCMPoissonNeuron :835-970: the Poisson cell + the same activity attributes */
-typedef enum { SNN_ST_NONE = 0, SNN_ST_POISSON = 1, SNN_ST_RATE = 2, SNN_ST_PRESET = 3, SNN_ST_BCM_POISSON = 4 } snn_spike_train_model;
+/* SNN_ST_CUSTOM: the ONE spike train generated from a `[spike_train]` block (build_test/nb_macro/src/lib.rs:4812-4905)
+ * that a library built with -DSNN_CUSTOM_MODEL_HEADER carries; its variables are attributes under their DSL names.
+ * Such a library may also carry a generated NeuralRefractoriness (`[neural_refractoriness]`, lib.rs:5677-5762):
+ * neural_refractoriness$kind 2, variables neural_refractoriness$<name>, `decay` = neural_refractoriness$k. */
+typedef enum { SNN_ST_NONE = 0, SNN_ST_POISSON = 1, SNN_ST_RATE = 2, SNN_ST_PRESET = 3, SNN_ST_BCM_POISSON = 4,
+               SNN_ST_CUSTOM = 100 } snn_spike_train_model;
 
 /* ---- construction (≙ from_lattice / from_network) -------------------------------------- */
 
@@ -300,6 +305,9 @@ int snn_input_kernel_bytes(const snn_network_t *net, uint64_t *bytes);
 const char *snn_last_error(void);
 int snn_abi_version(void);
 const char *snn_custom_model(void);
+/* type names of the generated spike train / refractoriness this library carries ("" when it has none) */
+const char *snn_custom_spike_train(void);
+const char *snn_custom_refractoriness(void);
 
 /* HBM ceilings of the device with the stepper's own access shape (16 B per lane, non-temporal): GB/s of a
  * read-only stream and of a copy (read + write bytes) over `bytes` of device memory, `repeats` launches. */

@@ -9,6 +9,8 @@
 
 #include <stddef.h>
 
+static float custom_refractoriness_effect(const snn_o_net *n, uint32_t s);
+
 /* ---------- small helpers ---------- */
 
 /* f32::max / f32::min as Rust defines them: a NaN operand yields the other one. */
@@ -185,7 +187,8 @@ static void inputs_block(snn_o_net *n, uint32_t q0, uint32_t nq)
                 if (n->st_last_firing_time[s] < 0) { kind = 1; pv = n->st_v_resting[s]; }
                 else {
                     kind = 2;
-                    pv = (n->st_refractoriness && n->st_refractoriness[s])
+                    pv = (n->st_refractoriness && n->st_refractoriness[s] == 2) ? custom_refractoriness_effect(n, s)
+                        : (n->st_refractoriness && n->st_refractoriness[s])
                         ? snn_o_exponential_decay_effect(n->clock, n->st_last_firing_time[s], n->st_v_th[s],
                                                          n->st_v_resting[s], n->st_k[s], n->st_dt[s])
                         : snn_o_delta_dirac_effect(n->clock, n->st_last_firing_time[s], n->st_v_th[s],
@@ -581,17 +584,16 @@ enum { OP_END = 0, OP_CONST = 1, OP_LOAD = 2, OP_STORE = 3, OP_DIFF = 4, OP_NEG 
        OP_AND = 18, OP_OR = 19, OP_JZ = 20, OP_JMP = 21, OP_TANH = 22, OP_SINH = 23, OP_COSH = 24, OP_MIN = 25,
        OP_MAX = 26, OP_HEAVISIDE = 27, OP_POWI = 28, OP_MARK = 29, OP_FLUSH = 30 };
 
-static float custom_run(const snn_o_net *n, uint32_t pc, float *slot, int apply_diffs)
+static float program_run(const int32_t *c, const float *consts, uint32_t pc, float *slot, int apply_diffs)
 {
     float stack[64], diff[32];
     uint32_t diff_slot[32];
     int sp = 0, nd = 0, mark = 0;
-    const int32_t *c = n->custom_code;
     for (;;) {
         int32_t op = c[pc++];
         if (op == OP_END) break;
         switch (op) {
-        case OP_CONST: stack[sp++] = n->custom_consts[c[pc++]]; break;
+        case OP_CONST: stack[sp++] = consts[c[pc++]]; break;
         case OP_LOAD:  stack[sp++] = slot[c[pc++]]; break;
         case OP_STORE: slot[c[pc++]] = stack[--sp]; break;
         case OP_DIFF:  diff[nd] = stack[--sp] * slot[2]; diff_slot[nd++] = (uint32_t)c[pc++]; break;   /* (expr) * dt */
@@ -632,6 +634,21 @@ static float custom_run(const snn_o_net *n, uint32_t pc, float *slot, int apply_
     if (apply_diffs)
         for (int k = 0; k < nd; ++k) slot[diff_slot[k]] += diff[k];    /* every `x += dx` after the last statement */
     return sp ? stack[sp - 1] : 0.0f;
+}
+
+static float custom_run(const snn_o_net *n, uint32_t pc, float *slot, int apply_diffs)
+{
+    return program_run(n->custom_code, n->custom_consts, pc, slot, apply_diffs);
+}
+
+/* generated NeuralRefractoriness::get_effect, build_test/nb_macro/src/lib.rs:5736-5750 */
+static float custom_refractoriness_effect(const snn_o_net *n, uint32_t s)
+{
+    float slot[5 + 8];
+    slot[0] = (float)(n->clock - (int64_t)n->st_last_firing_time[s]);      /* (timestep - last_firing_time) as f32 */
+    slot[1] = n->st_v_th[s]; slot[2] = n->st_dt[s]; slot[3] = n->st_v_resting[s]; slot[4] = n->st_k[s];
+    for (uint32_t k = 0; k < n->refr_nvars; ++k) slot[5 + k] = n->refr_vars[(size_t)k * n->n_cells + s];
+    return program_run(n->refr_code, n->refr_consts, 0, slot, 0);
 }
 
 /* neuron_builder!-generated iterate_and_spike / iterate_with_neurotransmitter_and_spike,
@@ -859,7 +876,18 @@ void snn_o_spike_trains(snn_o_net *n)
 {
     for (uint32_t s = 0; s < n->n_cells; ++s) {
         uint32_t spike;
-        if (n->st_kind == SNN_O_ST_POISSON || n->st_kind == SNN_O_ST_BCM_POISSON) {
+        float custom_v = 0.0f;
+        if (n->st_kind == SNN_O_ST_CUSTOM) {
+            /* generated SpikeTrain::iterate, build_test/nb_macro/src/lib.rs:4884-4891 */
+            float slot[5 + 16];
+            slot[0] = n->st_current_voltage[s]; slot[1] = n->st_is_spiking[s] ? 1.0f : 0.0f; slot[2] = n->st_dt[s];
+            slot[3] = n->st_v_resting[s]; slot[4] = n->st_v_th[s];
+            for (uint32_t k = 0; k < n->st_custom_nvars; ++k) slot[5 + k] = n->st_custom_vars[(size_t)k * n->n_cells + s];
+            program_run(n->st_custom_code, n->st_custom_consts, 0, slot, 1);
+            for (uint32_t k = 0; k < n->st_custom_nvars; ++k) n->st_custom_vars[(size_t)k * n->n_cells + s] = slot[5 + k];
+            spike = slot[1] != 0.0f;
+            custom_v = slot[0];
+        } else if (n->st_kind == SNN_O_ST_POISSON || n->st_kind == SNN_O_ST_BCM_POISSON) {
             uint32_t new_seed = snn_o_xorshift32(n->st_seed[s]);
             n->st_seed[s] = new_seed;
             float random_number = (float)new_seed / 4294967296.0f;   /* (float)seed / 0xFFFFFFFF */
@@ -881,7 +909,7 @@ void snn_o_spike_trains(snn_o_net *n)
             if (spike) step = 0.0f;
             n->st_step[s] = step;
         }
-        float v = spike ? n->st_v_th[s] : n->st_v_resting[s];
+        float v = (n->st_kind == SNN_O_ST_CUSTOM) ? custom_v : (spike ? n->st_v_th[s] : n->st_v_resting[s]);
         if (n->st_kind == SNN_O_ST_BCM_POISSON) {
             /* BCMPoissonNeuron::iterate spike_train/mod.rs:931-954: activity = voltage change, replaced by the firing
              * rate at the end of a window */

@@ -58,7 +58,8 @@ enum { SNN_O_IZHIKEVICH = 0, SNN_O_LIF = 1, SNN_O_HH = 2, SNN_O_QIF = 3, SNN_O_S
        SNN_O_BCM_IZHIKEVICH = 8, SNN_O_CUSTOM = 100 };
 enum { SNN_O_NT_APPROX = 0, SNN_O_NT_DESTEXHE = 1, SNN_O_NT_DISCRETE_SPIKE = 2, SNN_O_NT_EXPONENTIAL_DECAY = 3 };
 enum { SNN_O_RC_APPROX = 0, SNN_O_RC_DESTEXHE = 1, SNN_O_RC_EXPONENTIAL_DECAY = 2 };
-enum { SNN_O_ST_NONE = 0, SNN_O_ST_POISSON = 1, SNN_O_ST_RATE = 2, SNN_O_ST_PRESET = 3, SNN_O_ST_BCM_POISSON = 4 };
+enum { SNN_O_ST_NONE = 0, SNN_O_ST_POISSON = 1, SNN_O_ST_RATE = 2, SNN_O_ST_PRESET = 3, SNN_O_ST_BCM_POISSON = 4,
+       SNN_O_ST_CUSTOM = 100 };
 
 typedef struct snn_o_net {
     /* ---- sizes / switches ---- */
@@ -185,6 +186,18 @@ typedef struct snn_o_net {
     uint32_t custom_section[3];
     uint32_t custom_nvars;
     float    *custom_vars;                     /* [custom_nvars][n_neurons] */
+    /* SNN_O_ST_CUSTOM: a generated spike train (nb_macro lib.rs:4812-4905) as a stack program -- one section, the
+     * on_iteration; slots 0 current_voltage, 1 is_spiking (1.0 / 0.0), 2 dt, 3 v_resting, 4 v_th, 5.. variables. */
+    const int32_t *st_custom_code;
+    const float   *st_custom_consts;
+    uint32_t st_custom_nvars;
+    float    *st_custom_vars;                  /* [st_custom_nvars][n_cells] */
+    /* st_refractoriness == 2: a generated NeuralRefractoriness::get_effect (lib.rs:5677-5762) as ONE expression;
+     * slots 0 time_difference, 1 v_th, 2 dt, 3 v_resting, 4 decay (= st_k), 5.. variables. */
+    const int32_t *refr_code;
+    const float   *refr_consts;
+    uint32_t refr_nvars;
+    float    *refr_vars;                       /* [refr_nvars][n_cells] */
 } snn_o_net;
 
 /* Step 1 of SURVEY §8(g): electrical + chemical inputs for every neuron from state S(t). */

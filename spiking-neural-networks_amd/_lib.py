@@ -43,7 +43,8 @@ def build(force=False):
 
 
 def build_custom(model, force=False):
-    """Compile a library that carries the generated neuron model `model` (modelgen.NeuronModel) as SNN_MODEL_CUSTOM:
+    """Compile a library that carries the generated neuron model `model` (modelgen.NeuronModel) as SNN_MODEL_CUSTOM --
+    or every block of a modelgen.Description: neuron, spike train (SNN_ST_CUSTOM), refractoriness (kind 2):
     csrc/generated/<name>.hpp + csrc/generated/libsnn_amd_<name>.so.  Returns the library path."""
     from . import modelgen
     gen = os.path.join(CSRC, "generated")
@@ -76,6 +77,8 @@ SIGNATURES = {
     "snn_abi_version": (C.c_int, []),
     "snn_last_error": (C.c_char_p, []),
     "snn_custom_model": (C.c_char_p, []),
+    "snn_custom_spike_train": (C.c_char_p, []),
+    "snn_custom_refractoriness": (C.c_char_p, []),
     "snn_network_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(H)]),
     "snn_network_destroy": (C.c_int, [H]),
     "snn_network_add_lattice": (C.c_int, [H, C.c_uint32, C.c_uint32, C.c_uint32]),

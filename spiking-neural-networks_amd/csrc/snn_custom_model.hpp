@@ -1,16 +1,23 @@
-// Hook for ONE generated neuron model (model id SNN_MODEL_CUSTOM): spiking-neural-networks_amd/modelgen.py turns a
-// neuron description in the reference's neuron_builder! DSL (build_test/nb_macro) into a header with the model's
-// variable table and its on_iteration / spike_detection / on_spike as device functions; a library compiled with
-// -DSNN_CUSTOM_MODEL_HEADER="\"generated/<name>.hpp\"" carries that model next to the built-in ones.  Without the
-// define the hook is empty and SNN_MODEL_CUSTOM is refused.
+// Hook for ONE generated description: spiking-neural-networks_amd/modelgen.py turns blocks of the reference's
+// neuron_builder! DSL (build_test/nb_macro) into a header with, per block, a variable table and the block's code as
+// device functions:
+//   [neuron] (+ [ion_channel]s)   -> namespace custom       = neuron model SNN_MODEL_CUSTOM
+//   [spike_train]                 -> namespace custom_st    = spike-train model SNN_ST_CUSTOM
+//   [neural_refractoriness]       -> namespace custom_refr  = neural_refractoriness$kind 2
+// A library compiled with -DSNN_CUSTOM_MODEL_HEADER="\"generated/<name>.hpp\"" carries them next to the built-in
+// models.  Without the define (or for a block the description does not have) the hook is an empty stub and the
+// selector is refused.
 #pragma once
 #include "snn_math.hpp"
 
 #ifdef SNN_CUSTOM_MODEL_HEADER
 #include SNN_CUSTOM_MODEL_HEADER
-#define SNN_HAVE_CUSTOM_MODEL 1
+#define SNN_HAVE_CUSTOM_MODEL 1            // a generated library: two-kernel step only (shorter compile)
 #else
 #define SNN_HAVE_CUSTOM_MODEL 0
+#endif
+#ifndef SNN_HAVE_CUSTOM_NEURON
+#define SNN_HAVE_CUSTOM_NEURON 0
 namespace snn {
 namespace custom {
 constexpr int NVARS = 0;
@@ -25,9 +32,41 @@ __device__ __forceinline__ void on_spike(float &, float (&)[NSTORE], float, floa
 } // namespace custom
 } // namespace snn
 #endif
+#ifndef SNN_HAVE_CUSTOM_SPIKE_TRAIN
+#define SNN_HAVE_CUSTOM_SPIKE_TRAIN 0
+namespace snn {
+namespace custom_st {
+constexpr int NVARS = 0;
+constexpr int NSTORE = 1;
+static const char *const TYPE_NAME = "";
+static const char *const NAMES[NSTORE] = {""};
+static const float DEFAULTS[NSTORE] = {0.0f};
+constexpr float DEFAULT_VOLTAGE = 0.0f, DEFAULT_DT = 0.1f, DEFAULT_V_RESTING = 0.0f, DEFAULT_V_TH = 30.0f;
+__device__ __forceinline__ void on_iteration(float &, bool &, float (&)[NSTORE], float, float, float) {}
+} // namespace custom_st
+} // namespace snn
+#endif
+#ifndef SNN_HAVE_CUSTOM_REFRACTORINESS
+#define SNN_HAVE_CUSTOM_REFRACTORINESS 0
+namespace snn {
+namespace custom_refr {
+constexpr int NVARS = 0;
+constexpr int NSTORE = 1;
+static const char *const TYPE_NAME = "";
+static const char *const NAMES[NSTORE] = {""};
+static const float DEFAULTS[NSTORE] = {0.0f};
+constexpr float DEFAULT_DECAY = 10000.0f;
+__device__ __forceinline__ float effect(float, float, float v_resting, float, float, const float (&)[NSTORE]) { return v_resting; }
+} // namespace custom_refr
+} // namespace snn
+#endif
 
 namespace snn {
 constexpr int CUSTOM_MODEL = 100;        // SNN_MODEL_CUSTOM
-constexpr int CUSTOM_MAX_VARS = 32;
-static_assert(custom::NVARS <= CUSTOM_MAX_VARS, "too many variables in the generated model");
+constexpr int CUSTOM_SPIKE_TRAIN = 100;  // SNN_ST_CUSTOM
+constexpr uint32_t CUSTOM_REFRACTORINESS = 2;
+constexpr int CUSTOM_MAX_VARS = 32, CUSTOM_ST_MAX_VARS = 16, CUSTOM_REFR_MAX_VARS = 8;
+static_assert(custom::NVARS <= CUSTOM_MAX_VARS, "too many variables in the generated neuron model");
+static_assert(custom_st::NVARS <= CUSTOM_ST_MAX_VARS, "too many variables in the generated spike train");
+static_assert(custom_refr::NVARS <= CUSTOM_REFR_MAX_VARS, "too many variables in the generated refractoriness");
 } // namespace snn

@@ -6,6 +6,7 @@
 #pragma once
 #include "snn_layout.hpp"
 #include "snn_math.hpp"
+#include "snn_custom_model.hpp"
 
 namespace snn {
 
@@ -103,11 +104,24 @@ __global__ __launch_bounds__(256) void k_spike_trains(const SpikeTrainArgs a)
     const CellArrays &c = a.c;
     if (a.iterate) {
         uint32_t spike;
+        float custom_v = 0.0f;
         if (a.st_kind == 1 || a.st_kind == 4) {
             const uint32_t new_seed = xorshift32(c.seed[s]);
             c.seed[s] = new_seed;
             const float random_number = (float)new_seed / 4294967296.0f;   // (float) seed / 0xFFFFFFFF
             spike = random_number < c.chance_of_firing[s];
+        } else if (a.st_kind == CUSTOM_SPIKE_TRAIN) {
+            // generated spike train (nb_macro lib.rs:4884-4891): its on_iteration writes the voltage and the flag
+            float x[custom_st::NSTORE];
+#pragma unroll
+            for (int k = 0; k < custom_st::NVARS; ++k) x[k] = c.custom[k][s];
+            float vc = c.current_voltage[s];
+            bool sp = c.is_spiking[s] != 0;
+            custom_st::on_iteration(vc, sp, x, c.dt[s], c.v_resting[s], c.v_th[s]);
+#pragma unroll
+            for (int k = 0; k < custom_st::NVARS; ++k) c.custom[k][s] = x[k];
+            spike = sp ? 1u : 0u;
+            custom_v = vc;
         } else if (a.st_kind == 3) {
             // PresetSpikeTrain::iterate, spike_train/mod.rs:803-827 (`step` holds internal_clock).  A cell
             // without firing times never fires (the reference would index an empty Vec).
@@ -128,7 +142,7 @@ __global__ __launch_bounds__(256) void k_spike_trains(const SpikeTrainArgs a)
             if (spike) step = 0.0f;
             c.step[s] = step;
         }
-        const float v = spike ? c.v_th[s] : c.v_resting[s];
+        const float v = (a.st_kind == CUSTOM_SPIKE_TRAIN) ? custom_v : (spike ? c.v_th[s] : c.v_resting[s]);
         if (a.st_kind == 4) {
             // BCMPoissonNeuron::iterate (spike_train/mod.rs:931-954): activity = voltage change, replaced by the
             // firing rate when a window closes
@@ -153,9 +167,21 @@ __global__ __launch_bounds__(256) void k_spike_trains(const SpikeTrainArgs a)
     // presynaptic value of the next input calculation (spike_train_gap_junction, neuron/mod.rs:119-137):
     // never fired -> v_resting (used WITHOUT the conductance factor), else the refractoriness effect
     const int32_t lft = c.last_firing_time[s];
-    c.presyn_value[s] = (lft < 0) ? c.v_resting[s]
-                    : (c.refractoriness[s] ? exponential_decay_effect(a.view_clock, lft, c.v_th[s], c.v_resting[s], c.k[s], c.dt[s])
-                                           : delta_dirac_effect(a.view_clock, lft, c.v_th[s], c.v_resting[s], c.k[s], c.dt[s]));
+    const uint32_t refr = c.refractoriness[s];
+    float value;
+    if (lft < 0) {
+        value = c.v_resting[s];
+    } else if (SNN_HAVE_CUSTOM_REFRACTORINESS && refr == CUSTOM_REFRACTORINESS) {
+        // generated get_effect (nb_macro lib.rs:5736-5750): time_difference = (timestep - last_firing_time) as f32
+        float xr[custom_refr::NSTORE] = {};
+#pragma unroll
+        for (int k = 0; k < custom_refr::NVARS; ++k) xr[k] = c.refr_custom[k][s];
+        value = custom_refr::effect((float)(a.view_clock - (long long)lft), c.v_th[s], c.v_resting[s], c.dt[s], c.k[s], xr);
+    } else {
+        value = refr ? exponential_decay_effect(a.view_clock, lft, c.v_th[s], c.v_resting[s], c.k[s], c.dt[s])
+                     : delta_dirac_effect(a.view_clock, lft, c.v_th[s], c.v_resting[s], c.k[s], c.dt[s]);
+    }
+    c.presyn_value[s] = value;
 }
 
 // ---- plasticity ------------------------------------------------------------------------------

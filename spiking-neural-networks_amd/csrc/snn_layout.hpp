@@ -79,7 +79,9 @@ struct CellArrays {
     float *current_voltage, *v_th, *v_resting, *dt, *k;
     float *chance_of_firing, *rate, *step;
     uint32_t *seed, *is_spiking;
-    uint32_t *refractoriness;   // NeuralRefractoriness: 0 DeltaDirac, 1 ExponentialDecay
+    uint32_t *refractoriness;   // NeuralRefractoriness: 0 DeltaDirac, 1 ExponentialDecay, 2 generated (custom_refr)
+    float *custom[16];          // variables of a generated spike train (custom_st)
+    float *refr_custom[8];      // variables of a generated refractoriness other than `decay` (= k)
     // BCMActivity bookkeeping (BCMPoissonNeuron)
     float *bcm_avg, *bcm_cur, *bcm_clock, *bcm_window;
     uint32_t *bcm_period, *bcm_num_spikes;

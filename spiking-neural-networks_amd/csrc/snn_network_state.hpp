@@ -452,11 +452,25 @@ int build_state(snn_network *net)
 
     // spike-train cells (spike_train/mod.rs:299-313, 998-1013, 50-56)
     c.c_pad = cp;
-    TRY(cell_f32(net, &c.current_voltage, "current_voltage", 0.0f));
-    TRY(cell_f32(net, &c.v_th, "v_th", 30.0f));
-    TRY(cell_f32(net, &c.v_resting, "v_resting", 0.0f));
-    TRY(cell_f32(net, &c.dt, "dt", 0.1f));
-    TRY(cell_f32(net, &c.k, "neural_refractoriness$k", 10000.0f));
+    const bool st_custom = net->st_kind == SNN_ST_CUSTOM;          // generated spike train: the description's defaults
+    TRY(cell_f32(net, &c.current_voltage, "current_voltage", st_custom ? custom_st::DEFAULT_VOLTAGE : 0.0f));
+    TRY(cell_f32(net, &c.v_th, "v_th", st_custom ? custom_st::DEFAULT_V_TH : 30.0f));
+    TRY(cell_f32(net, &c.v_resting, "v_resting", st_custom ? custom_st::DEFAULT_V_RESTING : 0.0f));
+    TRY(cell_f32(net, &c.dt, "dt", st_custom ? custom_st::DEFAULT_DT : 0.1f));
+    for (int k = 0; k < CUSTOM_ST_MAX_VARS; ++k) c.custom[k] = nullptr;
+    if (st_custom)
+        for (int k = 0; k < custom_st::NVARS; ++k) TRY(cell_f32(net, &c.custom[k], custom_st::NAMES[k], custom_st::DEFAULTS[k]));
+    // `decay` of a generated refractoriness lives in the k plane (set_decay / get_decay, nb_macro lib.rs:5738-5744)
+    TRY(cell_f32(net, &c.k, "neural_refractoriness$k", SNN_HAVE_CUSTOM_REFRACTORINESS ? custom_refr::DEFAULT_DECAY : 10000.0f));
+    for (int k = 0; k < CUSTOM_REFR_MAX_VARS; ++k) c.refr_custom[k] = nullptr;
+    if (SNN_HAVE_CUSTOM_REFRACTORINESS) {
+        reg(CA, "neural_refractoriness$decay", T_F32, S_PLAIN, c.k, 0, 0);
+        for (int k = 0; k < custom_refr::NVARS; ++k) {
+            const std::string name = std::string("neural_refractoriness$") + custom_refr::NAMES[k];
+            TRY(cell_f32(net, &c.refr_custom[k], nullptr, custom_refr::DEFAULTS[k]));
+            reg(CA, name.c_str(), T_F32, S_PLAIN, c.refr_custom[k], 0, 0);
+        }
+    }
     // which NeuralRefractoriness (a type parameter in the reference): 0 DeltaDirac spike_train/mod.rs:79-88,
     // 1 ExponentialDecay :164-178
     TRY(dev_alloc_t(net, &c.refractoriness, cp));
@@ -571,6 +585,14 @@ int attr_io(snn_network *net, uint32_t id, const char *name, AttrType type, void
     if (it == table.end()) return fail(SNN_ERR_BAD_ATTR, std::string("unknown attribute '") + name + "'");
     const Attr &a = it->second;
     if (a.type != type) return fail(SNN_ERR_BAD_ATTR, std::string("attribute '") + name + "' has another scalar type");
+    if (set && l->spike_train && std::strcmp(name, "neural_refractoriness$kind") == 0) {
+        const uint32_t top = SNN_HAVE_CUSTOM_REFRACTORINESS ? CUSTOM_REFRACTORINESS : 1u;
+        const uint32_t *h = static_cast<const uint32_t *>(host);
+        for (size_t i = 0; i < count; ++i)
+            if (h[i] > top)
+                return fail(SNN_ERR_BAD_ARG, "neural_refractoriness$kind: 0 DeltaDirac, 1 ExponentialDecay" +
+                                                 std::string(top == 2 ? ", 2 the generated one" : "") + "; got " + std::to_string(h[i]));
+    }
     const bool typed = (a.store == S_PLAIN_K || a.store == S_XPLANE_K);
     const size_t expect = (size_t)l->count * (typed ? K_TYPES : 1);
     if (count != expect)

@@ -159,7 +159,7 @@ int launch_update(snn_network *net)
     case SNN_MODEL_ADAPTIVE_LIF: hipLaunchKernelGGL((k_update<5>), grid, dim3(256), 0, net->stream, a); break;
     case SNN_MODEL_ADAPTIVE_EXP_LIF: hipLaunchKernelGGL((k_update<6>), grid, dim3(256), 0, net->stream, a); break;
     case SNN_MODEL_LEAKY_IZHIKEVICH: hipLaunchKernelGGL((k_update<7>), grid, dim3(256), 0, net->stream, a); break;
-#if SNN_HAVE_CUSTOM_MODEL
+#if SNN_HAVE_CUSTOM_NEURON
     case SNN_MODEL_CUSTOM: hipLaunchKernelGGL((k_update<CUSTOM_MODEL>), grid, dim3(256), 0, net->stream, a); break;
 #endif
     default: hipLaunchKernelGGL((k_update<0>), grid, dim3(256), 0, net->stream, a); break;

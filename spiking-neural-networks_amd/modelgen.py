@@ -44,9 +44,17 @@ the reference tests against is build_test/nb_macro/tests/lif_reference.rs):
     only), typed like the generated Rust -- conditions, `!`, `&&`, `||` take bools, arithmetic and comparisons take
     numbers, and a description rustc would refuse for mixing them is refused here.
 
+  * `[spike_train]` blocks (lib.rs:4812-4905; `parse_description`): `vars` plus the mandatory dt = 0.1, v_resting = 0,
+    v_th = 30, current_voltage = 0, is_spiking = false; iterate() = on_iteration (which writes `current_voltage` / `v`
+    and the bool `is_spiking`), then the neurotransmitter update on the new flag -> spike-train model SNN_ST_CUSTOM;
+  * `[neural_refractoriness]` blocks (lib.rs:5677-5762): `effect:` is one expression over v_th, v_resting, dt,
+    time_difference = (timestep - last_firing_time) as f32, `decay` (always there, default 10000, stored where the
+    built-in kinds keep k) and the block's own vars -> neural_refractoriness$kind 2.
+    One library carries at most one neuron, one spike train and one refractoriness.
+
 `hip_source(model)` emits the header that csrc/snn_custom_model.hpp includes when the library is compiled with
 -DSNN_CUSTOM_MODEL_HEADER; `_lib.build_custom(model)` compiles such a library.  Not supported (rejected with a
-message): receptors / kinetics / spike-train / refractoriness blocks, `^` with a non-literal or
+message): receptors / kinetics blocks, `^` with a non-literal or
 fractional exponent, sin / cos / tan / isnan, on_electrochemical_iteration, and `continuous()` spike detection --
 the code the reference generates for it reads a `last_voltage` that is never defined (lib.rs:984-990), so there is
 no behaviour to match.
@@ -58,6 +66,8 @@ MANDATORY = {"current_voltage": 0.0, "dt": 0.1, "c_m": 1.0, "gap_conductance": 1
 MAX_VARS = 32
 FUNCTIONS = {"exp": 1, "tanh": 1, "sinh": 1, "cosh": 1, "heaviside": 1, "min": 2, "max": 2}
 MAX_POWER = 16
+MAX_ST_VARS = 16
+MAX_REFRACTORINESS_VARS = 8
 
 
 class ModelError(ValueError):
@@ -489,23 +499,174 @@ def _inline_channel(inst, ch, args):
     return ("scope", convert(ch.on_iteration))
 
 
-def parse(text):
-    """Parse zero or more [ion_channel] blocks and ONE [neuron] block of the DSL subset in the module docstring."""
+class SpikeTrainModel:
+    """[spike_train] (lib.rs:4812-4905): iterate() = on_iteration, then the neurotransmitter update, returns
+    is_spiking.  `v` / `current_voltage` and the bool `is_spiking` are written by the description."""
+    MANDATORY = {"dt": 0.1, "v_resting": 0.0, "v_th": 30.0, "current_voltage": 0.0}
+
+    def __init__(self, name, variables, bools, on_iteration):
+        self.name, self.variables, self.on_iteration = name, variables, on_iteration
+        self.bools = set(bools) | {"is_spiking"}
+        self.mandatory = dict(self.MANDATORY)
+
+
+class RefractorinessModel:
+    """[neural_refractoriness] (lib.rs:5677-5762): get_effect(timestep, last_firing_time, v_th, v_resting, dt) with
+    time_difference = (timestep - last_firing_time) as f32; `decay` (default 10000) always exists."""
+    def __init__(self, name, variables, effect):
+        self.name, self.variables, self.effect = name, variables, effect       # variables without `decay`
+        self.decay = 10000.0
+
+
+class Description:
+    def __init__(self, neuron=None, spike_train=None, refractoriness=None):
+        self.neuron, self.spike_train, self.refractoriness = neuron, spike_train, refractoriness
+
+    @property
+    def name(self):
+        return "_".join(m.name for m in (self.neuron, self.spike_train, self.refractoriness) if m is not None)
+
+
+def _convert_plain(stmts, rename, assignable, where):
+    out = []
+    for st in stmts:
+        if st[0] == "if":
+            out.append(("if", [(_map_expr(c, rename), _convert_plain(b, rename, assignable, "an [if] branch"))
+                               for c, b in st[1]],
+                        None if st[2] is None else _convert_plain(st[2], rename, assignable, "an [if] branch")))
+        elif st[0] == "struct_call":
+            raise ModelError(f"cannot call {st[1]}.{st[2]}() here")
+        else:
+            if st[0] == "diff" and where != "on_iteration":
+                raise ModelError(f"differential equations belong to the top level of on_iteration, not {where}")
+            tgt = rename(st[1])[1] if st[1] in ("current_voltage",) else st[1]
+            if tgt not in assignable:
+                raise ModelError(f"cannot assign to {st[1]!r}")
+            out.append((st[0], tgt) + tuple(st[2:-1]) + (_map_expr(st[-1], rename),))
+    return out
+
+
+def _parse_spike_train(body):
+    sections, name = _sections(body, ("type", "vars", "on_iteration"))
+    if not sections.get("on_iteration"):
+        raise ModelError(f"spike train {name}: section 'on_iteration' is missing")
+    bools = set()
+    variables = []
+    model = SpikeTrainModel(name, variables, bools, [])
+    for var, value in _variables(sections.get("vars", []), ("v", "i", "last_firing_time"), bools):
+        if var == "is_spiking":
+            if var not in bools:
+                raise ModelError("'is_spiking' is a bool")
+            continue                                   # always starts false on the device (spike_train/mod.rs defaults)
+        if var in model.mandatory:
+            if var in bools:
+                raise ModelError(f"'{var}' is a number")
+            model.mandatory[var] = value
+        else:
+            variables.append((var, value))
+    if len(variables) > MAX_ST_VARS:
+        raise ModelError(f"more than {MAX_ST_VARS} spike-train variables")
+    model.bools = set(bools) | {"is_spiking"}
+    known = {"v", "is_spiking", "dt", "v_resting", "v_th"} | {n for n, _ in variables}
+
+    def rename(n):
+        n = "v" if n == "current_voltage" else n
+        if n not in known:
+            raise ModelError(f"unknown variable {n!r}")
+        return ("var", n)
+
+    model.on_iteration = _convert_plain(_block(sections["on_iteration"])[0], rename,
+                                        known - {"dt", "v_resting", "v_th"}, "on_iteration")
+    _check_types(model.on_iteration, model.bools)
+    return model
+
+
+def _parse_refractoriness(body):
+    sections, current = {}, None
+    for line in body:
+        m = re.match(r"^(type|vars|effect)\s*:\s*(.*)$", line)
+        if m:
+            current = m.group(1)
+            sections.setdefault(current, [])
+            if m.group(2):
+                sections[current].append(m.group(2))
+        elif current is None:
+            raise ModelError(f"text outside a section: {line!r}")
+        else:
+            sections[current].append(line)
+    name = (sections.get("type") or [""])[0].strip()
+    if not re.fullmatch(_NAME, name):
+        raise ModelError(f"bad or missing type name {name!r}")
+    if not sections.get("effect"):
+        raise ModelError(f"refractoriness {name}: section 'effect' is missing")
+    bools = set()
+    variables = _variables(sections.get("vars", []), ("v_th", "v_resting", "dt", "time_difference", "last_firing_time"),
+                           bools)
+    if bools:
+        raise ModelError("bool variables have no use in a refractoriness effect")
+    model = RefractorinessModel(name, [(n, d) for n, d in variables if n != "decay"], None)
+    model.decay = dict(variables).get("decay", 10000.0)          # lib.rs:5685-5706
+    if len(model.variables) > MAX_REFRACTORINESS_VARS:
+        raise ModelError(f"more than {MAX_REFRACTORINESS_VARS} refractoriness variables")
+    known = {"v_th", "v_resting", "dt", "time_difference", "decay"} | {n for n, _ in model.variables}
+
+    def rename(n):
+        if n not in known:
+            raise ModelError(f"unknown variable {n!r}")
+        return ("var", n)
+
+    model.effect = _map_expr(parse_expr(" ".join(sections["effect"])), rename)
+    _check_types([], set(), number=model.effect)
+    return model
+
+
+def parse_description(text):
+    """Every block of a description: [ion_channel]s, at most one [neuron], one [spike_train] and one
+    [neural_refractoriness] (one generated library carries one of each)."""
     blocks = _split_blocks(text)
     channels = {}
+    desc = Description()
     for kind, body in blocks:
         if kind == "ion_channel":
             ch = _parse_channel(body)
             if ch.name in channels:
                 raise ModelError(f"ion channel {ch.name} is defined twice")
             channels[ch.name] = ch
+        elif kind == "spike_train":
+            if desc.spike_train is not None:
+                raise ModelError("more than one [spike_train] block")
+            desc.spike_train = _parse_spike_train(body)
+        elif kind == "neural_refractoriness":
+            if desc.refractoriness is not None:
+                raise ModelError("more than one [neural_refractoriness] block")
+            desc.refractoriness = _parse_refractoriness(body)
         elif kind != "neuron":
-            raise ModelError(f"[{kind}] blocks are not supported (only [ion_channel] and [neuron])")
+            raise ModelError(f"[{kind}] blocks are not supported (only [ion_channel], [neuron], [spike_train] and "
+                             "[neural_refractoriness])")
     neurons = [body for kind, body in blocks if kind == "neuron"]
-    if len(neurons) != 1:
+    if len(neurons) > 1:
         raise ModelError("expected exactly one [neuron] ... [end] block")
-    sections, name = _sections(neurons[0], ("type", "vars", "on_spike", "spike_detection", "on_iteration",
-                                            "ion_channels"))
+    if neurons:
+        desc.neuron = _parse_neuron(neurons[0], channels)
+    elif channels:
+        raise ModelError("[ion_channel] blocks without a [neuron] that uses them")
+    if desc.neuron is None and desc.spike_train is None and desc.refractoriness is None:
+        raise ModelError("empty description")
+    return desc
+
+
+def parse(text):
+    """Parse zero or more [ion_channel] blocks and ONE [neuron] block of the DSL subset in the module docstring."""
+    desc = parse_description(text)
+    if desc.neuron is None or desc.spike_train is not None or desc.refractoriness is not None:
+        raise ModelError("expected exactly one [neuron] ... [end] block (parse_description reads spike trains and "
+                         "refractoriness)")
+    return desc.neuron
+
+
+def _parse_neuron(body, channels):
+    sections, name = _sections(body, ("type", "vars", "on_spike", "spike_detection", "on_iteration",
+                                      "ion_channels"))
     for need in ("on_iteration", "spike_detection"):
         if not sections.get(need):
             raise ModelError(f"section '{need}' is missing")
@@ -571,11 +732,11 @@ def parse(text):
     model.spike_detection = _map_expr(parse_expr(detect), rename)
     model.on_iteration = convert(_block(sections["on_iteration"])[0], "on_iteration")
     model.on_spike = convert(_block(sections.get("on_spike", []))[0], "on_spike")
-    _check_types(model)
+    _check_types(model.on_iteration + model.on_spike, model.bools, condition=model.spike_detection)
     return model
 
 
-def _check_types(model):
+def _check_types(stmts, bools, condition=None, number=None):
     """The generated Rust is typed (f32 / bool fields): a description that rustc would refuse is refused here."""
     def kind(e):
         k = e[0]
@@ -584,7 +745,7 @@ def _check_types(model):
         if k == "bool":
             return "bool"
         if k == "var":
-            return "bool" if e[1] in model.bools else "number"
+            return "bool" if e[1] in bools else "number"
         if k == "neg" or k == "powi":
             need(e[1], "number", "arithmetic")
             return "number"
@@ -613,17 +774,20 @@ def _check_types(model):
         if got != want:
             raise ModelError(f"{where} needs a {want}, not a {got}")
 
-    need(model.spike_detection, "bool", "spike_detection")
-    for st in _walk(model.on_iteration + model.on_spike):
+    if condition is not None:
+        need(condition, "bool", "spike_detection")
+    if number is not None:
+        need(number, "number", "effect")
+    for st in _walk(stmts):
         if st[0] == "if":
             for cond, _ in st[1]:
                 need(cond, "bool", "[if]")
         elif st[0] == "diff":
-            if st[1] in model.bools:
+            if st[1] in bools:
                 raise ModelError(f"d{st[1]}/dt: {st[1]} is a bool")
             need(st[2], "number", "a differential equation")
         elif st[0] == "assign":
-            want = "bool" if st[1] in model.bools else "number"
+            want = "bool" if st[1] in bools else "number"
             if want == "bool" and st[2] != "=":
                 raise ModelError(f"'{st[2]}' on the bool variable {st[1]}")
             need(st[3], want, f"assignment to {st[1].replace('$', '.')}")
@@ -642,8 +806,8 @@ def _hip_expr(e, index):
     if kind == "bool":
         return "true" if e[1] else "false"
     if kind == "var":
-        if e[1] in ("v", "i", "dt", "c_m", "gap_conductance"):
-            return {"v": "v", "i": "i_in", "dt": "dt", "c_m": "c_m", "gap_conductance": "g_gap"}[e[1]]
+        if e[1] in index["$base"]:
+            return index["$base"][e[1]]
         if e[1] in index.get("$bools", ()):
             return f"(x[{index[e[1]]}] != 0.0f)"
         return f"x[{index[e[1]]}]"
@@ -678,36 +842,40 @@ def _hip_statements(stmts, index, with_diffs, indent="    "):
             lines.append(_hip_statements(s[1], index, True, indent + "    "))
             lines.append(f"{indent}}}")
             continue
-        target = "v" if s[1] == "v" else f"x[{index[s[1]]}]"
+        target = index["$base"][s[1]] if s[1] in index["$base"] else f"x[{index[s[1]]}]"
         if s[0] == "diff":
             d = "d_v" if s[1] == "v" else f"d_x{index[s[1]]}"
             lines.append(f"{indent}const float {d} = ({_hip_expr(s[2], index)}) * dt;")
             diffs.append(f"{indent}{target} += {d};")
-        elif s[1] in index.get("$bools", ()):
+        elif s[1] in index.get("$bools", ()) and s[1] not in index["$base"]:
             lines.append(f"{indent}{target} = {_hip_expr(s[3], index)} ? 1.0f : 0.0f;")
         else:
             lines.append(f"{indent}{target} {s[2]} {_hip_expr(s[3], index)};")
     return "\n".join(l for l in lines + (diffs if with_diffs else []) if l)
 
 
-def hip_source(model):
-    """The generated header: variable table + on_iteration / spike_detection / on_spike as device functions."""
+_NEURON_BASE = {"v": "v", "i": "i_in", "dt": "dt", "c_m": "c_m", "gap_conductance": "g_gap"}
+_ST_BASE = {"v": "v", "is_spiking": "is_spiking", "dt": "dt", "v_resting": "v_resting", "v_th": "v_th"}
+_REFR_BASE = {"time_difference": "time_difference", "v_th": "v_th", "v_resting": "v_resting", "dt": "dt", "decay": "decay"}
+
+
+def _table(variables):
+    names = ", ".join(f'"{n}"' for n, _ in variables) or '""'
+    defaults = ", ".join(_f32_literal(d) for _, d in variables) or "0.0f"
+    return f"""constexpr int NVARS = {len(variables)};
+constexpr int NSTORE = {max(1, len(variables))};
+static const char *const NAMES[NSTORE] = {{{names}}};
+static const float DEFAULTS[NSTORE] = {{{defaults}}};"""
+
+
+def _neuron_source(model):
     index = {n: k for k, (n, _) in enumerate(model.variables)}
     index["$bools"] = model.bools
-    nv = max(1, len(model.variables))
-    names = ", ".join(f'"{n}"' for n, _ in model.variables) or '""'
-    defaults = ", ".join(_f32_literal(d) for _, d in model.variables) or "0.0f"
+    index["$base"] = _NEURON_BASE
     m = model.mandatory
-    return f"""// GENERATED by spiking-neural-networks_amd/modelgen.py from the neuron description of type {model.name}
-// (nb_macro semantics, see modelgen.py).  Included through csrc/snn_custom_model.hpp.
-#pragma once
-namespace snn {{
-namespace custom {{
-constexpr int NVARS = {len(model.variables)};
-constexpr int NSTORE = {nv};
+    return f"""namespace custom {{
 static const char *const TYPE_NAME = "{model.name}";
-static const char *const NAMES[NSTORE] = {{{names}}};
-static const float DEFAULTS[NSTORE] = {{{defaults}}};
+{_table(model.variables)}
 constexpr float DEFAULT_VOLTAGE = {_f32_literal(m['current_voltage'])}, DEFAULT_DT = {_f32_literal(m['dt'])},
                 DEFAULT_C_M = {_f32_literal(m['c_m'])}, DEFAULT_GAP = {_f32_literal(m['gap_conductance'])};
 
@@ -724,5 +892,65 @@ __device__ __forceinline__ void on_spike(float &v, float (&x)[NSTORE], float i_i
 {_hip_statements(model.on_spike, index, False)}
 }}
 }} // namespace custom
-}} // namespace snn
+"""
+
+
+def _spike_train_source(model):
+    index = {n: k for k, (n, _) in enumerate(model.variables)}
+    index["$bools"] = model.bools
+    index["$base"] = _ST_BASE
+    m = model.mandatory
+    return f"""#define SNN_HAVE_CUSTOM_SPIKE_TRAIN 1
+namespace custom_st {{
+static const char *const TYPE_NAME = "{model.name}";
+{_table(model.variables)}
+constexpr float DEFAULT_VOLTAGE = {_f32_literal(m['current_voltage'])}, DEFAULT_DT = {_f32_literal(m['dt'])},
+                DEFAULT_V_RESTING = {_f32_literal(m['v_resting'])}, DEFAULT_V_TH = {_f32_literal(m['v_th'])};
+
+// iterate() of the generated spike train (nb_macro lib.rs:4884-4891) up to the neurotransmitter update
+__device__ __forceinline__ void on_iteration(float &v, bool &is_spiking, float (&x)[NSTORE], float dt, float v_resting,
+                                             float v_th)
+{{
+{_hip_statements(model.on_iteration, index, True)}
+}}
+}} // namespace custom_st
+"""
+
+
+def _refractoriness_source(model):
+    index = {n: k for k, (n, _) in enumerate(model.variables)}
+    index["$bools"] = set()
+    index["$base"] = _REFR_BASE
+    return f"""#define SNN_HAVE_CUSTOM_REFRACTORINESS 1
+namespace custom_refr {{
+static const char *const TYPE_NAME = "{model.name}";
+{_table(model.variables)}
+constexpr float DEFAULT_DECAY = {_f32_literal(model.decay)};
+
+// get_effect of the generated NeuralRefractoriness (nb_macro lib.rs:5736-5750)
+__device__ __forceinline__ float effect(float time_difference, float v_th, float v_resting, float dt, float decay,
+                                        const float (&x)[NSTORE])
+{{
+    return {_hip_expr(model.effect, index)};
+}}
+}} // namespace custom_refr
+"""
+
+
+def hip_source(model):
+    """The generated header for a NeuronModel or a Description: per block a variable table and its code as device
+    functions (namespaces custom / custom_st / custom_refr)."""
+    desc = model if isinstance(model, Description) else Description(neuron=model)
+    parts = []
+    if desc.neuron is not None:
+        parts.append("#define SNN_HAVE_CUSTOM_NEURON 1\n" + _neuron_source(desc.neuron))
+    if desc.spike_train is not None:
+        parts.append(_spike_train_source(desc.spike_train))
+    if desc.refractoriness is not None:
+        parts.append(_refractoriness_source(desc.refractoriness))
+    return f"""// GENERATED by spiking-neural-networks_amd/modelgen.py from the description of {desc.name}
+// (nb_macro semantics, see modelgen.py).  Included through csrc/snn_custom_model.hpp.
+#pragma once
+namespace snn {{
+{chr(10).join(parts)}}} // namespace snn
 """

@@ -19,6 +19,8 @@ CUSTOM = 100          # the generated model of a library built by _lib.build_cus
 NT_APPROXIMATE, NT_DESTEXHE, NT_DISCRETE_SPIKE, NT_EXPONENTIAL_DECAY = 0, 1, 2, 3
 RC_APPROXIMATE, RC_DESTEXHE, RC_EXPONENTIAL_DECAY = 0, 1, 2
 ST_NONE, ST_POISSON, ST_RATE, ST_PRESET, ST_BCM_POISSON = 0, 1, 2, 3, 4
+ST_CUSTOM = 100       # the generated spike train of a library built by _lib.build_custom (modelgen.parse_description)
+REFRACTORINESS_CUSTOM = 2   # neural_refractoriness$kind of the generated refractoriness of such a library
 NUM_NT_TYPES = 3
 
 _DT = {np.dtype(np.float32): "f32", np.dtype(np.uint32): "u32", np.dtype(np.int32): "i32"}

@@ -83,6 +83,30 @@ def _run(stmts, env, mask=None):
         env[name] = np.where(mask, new, env[name]).astype(f32) if mask is not None else new
 
 
+def make_spike_train_step(model):
+    """iterate(state) -> is_spiking for a modelgen.SpikeTrainModel; state: current_voltage, is_spiking (float 0/1), dt,
+    v_resting, v_th and the model's variables as float32 arrays (updated in place)"""
+    def iterate(state):
+        env = {"v": state["current_voltage"], "is_spiking": state["is_spiking"], "dt": state["dt"],
+               "v_resting": state["v_resting"], "v_th": state["v_th"], "$bools": model.bools}
+        for name, _ in model.variables:
+            env[name] = state[name]
+        _run(model.on_iteration, env)
+        state["current_voltage"], state["is_spiking"] = env["v"], env["is_spiking"]
+        for name, _ in model.variables:
+            state[name] = env[name]
+        return state["is_spiking"] != 0
+    return iterate
+
+
+def refractoriness_effect(model, time_difference, v_th, v_resting, dt, decay=None, **variables):
+    env = {"time_difference": f32(time_difference), "v_th": f32(v_th), "v_resting": f32(v_resting), "dt": f32(dt),
+           "decay": f32(model.decay if decay is None else decay)}
+    for name, default in model.variables:
+        env[name] = f32(variables.get(name, default))
+    return evaluate(model.effect, env)
+
+
 def make_step(model):
     """step(state, i_in) -> spike mask; state: dict with current_voltage, dt, c_m, gap_conductance and the model's
     variables as float32 arrays (updated in place)."""
@@ -110,9 +134,14 @@ _BIN = {"+": "ADD", "-": "SUB", "*": "MUL", "/": "DIV", "==": "EQ", "!=": "NE", 
 _BASE_SLOTS = {"v": 0, "i": 1, "dt": 2, "c_m": 3, "gap_conductance": 4}
 
 
-def compile_program(model):
-    """(code int32[], consts float32[], sections uint32[3]) of the oracle's stack machine"""
-    slots = dict(_BASE_SLOTS)
+_ST_SLOTS = {"v": 0, "is_spiking": 1, "dt": 2, "v_resting": 3, "v_th": 4}
+_REFR_SLOTS = {"time_difference": 0, "v_th": 1, "dt": 2, "v_resting": 3, "decay": 4}
+
+
+def compile_program(model, base=None, blocks=None):
+    """(code int32[], consts float32[], section starts) of the oracle's stack machine.  Default: a neuron model's
+    on_iteration / spike_detection / on_spike; `blocks` = [("statements", stmts) | ("expression", e)] otherwise."""
+    slots = dict(_BASE_SLOTS if base is None else base)
     for k, (name, _) in enumerate(model.variables):
         slots[name] = 5 + k
     code, consts = [], []
@@ -175,13 +204,48 @@ def compile_program(model):
         code.append(_OPS["END"])
         return start
 
-    s0 = emit_block(model.on_iteration)
-    s1 = len(code)
-    emit_expr(model.spike_detection)
-    code.append(_OPS["END"])
-    s2 = emit_block(model.on_spike)
-    return (np.array(code, np.int32), np.array(consts if consts else [0.0], np.float32),
-            np.array([s0, s1, s2], np.uint32))
+    if blocks is None:
+        blocks = [("statements", model.on_iteration), ("expression", model.spike_detection),
+                  ("statements", model.on_spike)]
+    starts = []
+    for what, item in blocks:
+        if what == "statements":
+            starts.append(emit_block(item))
+        else:
+            starts.append(len(code))
+            emit_expr(item)
+            code.append(_OPS["END"])
+    return (np.array(code, np.int32), np.array(consts if consts else [0.0], np.float32), np.array(starts, np.uint32))
+
+
+def attach_spike_train(net, model):
+    """Make an oracle Net (created with st_kind=ob.ST_CUSTOM) iterate the generated spike train `model`."""
+    code, consts, _ = compile_program(model, _ST_SLOTS, [("statements", model.on_iteration)])
+    net.st_custom_model = model
+    net.arr["st_custom_code"], net.arr["st_custom_consts"] = code, consts
+    net.st_custom_nvars = len(model.variables)
+    net.arr["st_custom_vars"] = np.zeros((max(1, len(model.variables)), net.n_cells), np.float32)
+    for k, (_, default) in enumerate(model.variables):
+        net.arr["st_custom_vars"][k] = default
+    net["st_current_voltage"] = model.mandatory["current_voltage"]
+    net["st_dt"] = model.mandatory["dt"]
+    net["st_v_resting"] = model.mandatory["v_resting"]
+    net["st_v_th"] = model.mandatory["v_th"]
+    return net
+
+
+def attach_refractoriness(net, model):
+    """Give every spike-train cell of an oracle Net the generated refractoriness `model` (kind 2)."""
+    code, consts, _ = compile_program(model, _REFR_SLOTS, [("expression", model.effect)])
+    net.refr_model = model
+    net.arr["refr_code"], net.arr["refr_consts"] = code, consts
+    net.refr_nvars = len(model.variables)
+    net.arr["refr_vars"] = np.zeros((max(1, len(model.variables)), net.n_cells), np.float32)
+    for k, (_, default) in enumerate(model.variables):
+        net.arr["refr_vars"][k] = default
+    net["st_refractoriness"] = ob.REFRACTORINESS_CUSTOM
+    net["st_k"] = model.decay
+    return net
 
 
 def attach(net, model):

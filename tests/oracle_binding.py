@@ -17,6 +17,8 @@ CUSTOM = 100
 NT_APPROX, NT_DESTEXHE, NT_DISCRETE_SPIKE, NT_EXPONENTIAL_DECAY = 0, 1, 2, 3
 RC_APPROX, RC_DESTEXHE, RC_EXPONENTIAL_DECAY = 0, 1, 2
 ST_NONE, ST_POISSON, ST_RATE, ST_PRESET, ST_BCM_POISSON = 0, 1, 2, 3, 4
+ST_CUSTOM = 100
+REFRACTORINESS_CUSTOM = 2
 
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _ORACLE_DIR = os.path.join(_ROOT, "oracle")
@@ -78,6 +80,9 @@ _FIELDS = [
     ("st_bcm_period", u32p), ("st_bcm_num_spikes", u32p),
     ("custom_code", C.POINTER(C.c_int32)), ("custom_consts", f32p), ("custom_section", C.c_uint32 * 3),
     ("custom_nvars", C.c_uint32), ("custom_vars", f32p),
+    ("st_custom_code", C.POINTER(C.c_int32)), ("st_custom_consts", f32p), ("st_custom_nvars", C.c_uint32),
+    ("st_custom_vars", f32p),
+    ("refr_code", C.POINTER(C.c_int32)), ("refr_consts", f32p), ("refr_nvars", C.c_uint32), ("refr_vars", f32p),
 ]
 
 
@@ -283,6 +288,8 @@ class Net:
         self.rewards = None
         self.custom_section = np.zeros(3, np.uint32)
         self.custom_nvars = 0
+        self.st_custom_nvars = 0
+        self.refr_nvars = 0
         if nt_kind == NT_EXPONENTIAL_DECAY:       # decay_constant, iterate_and_spike/mod.rs:336-343
             a["nt_clearance"][...] = 2.0
             a["st_nt_clearance"][...] = 2.0

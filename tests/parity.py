@@ -185,6 +185,12 @@ def push_state(dn, net):
                 dn.set_attr(i, a, net[o][sl])
             for o, a in CELL_KIND_ATTRS.get(net.st_kind, {}).items():
                 dn.set_attr(i, a, net[o][sl])
+            if net.st_kind == ob.ST_CUSTOM:
+                for k, (name, _) in enumerate(net.st_custom_model.variables):
+                    dn.set_attr(i, name, np.ascontiguousarray(net["st_custom_vars"][k, sl]))
+            if getattr(net, "refr_model", None) is not None:
+                for k, (name, _) in enumerate(net.refr_model.variables):
+                    dn.set_attr(i, "neural_refractoriness$" + name, np.ascontiguousarray(net["refr_vars"][k, sl]))
             for o, a in NT_ATTRS.items():
                 dn.set_attr(i, a, net["st_" + o][sl])
 
@@ -224,6 +230,11 @@ def pull_state(dn, net):
                 put(o, sl, dn.get_attr(i, a, dtype=net[o].dtype))
             for o, a in CELL_KIND_ATTRS.get(net.st_kind, {}).items():
                 put(o, sl, dn.get_attr(i, a, dtype=net[o].dtype))
+            if net.st_kind == ob.ST_CUSTOM:
+                if "st_custom_vars" not in out:
+                    out["st_custom_vars"] = np.zeros_like(net["st_custom_vars"])
+                for k, (name, _) in enumerate(net.st_custom_model.variables):
+                    out["st_custom_vars"][k, sl] = dn.get_attr(i, name)
             for o, a in NT_ATTRS.items():
                 put("st_" + o, sl, dn.get_attr(i, a, dtype=net["st_" + o].dtype, per_type=True))
     return out

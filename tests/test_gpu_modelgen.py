@@ -12,6 +12,7 @@ import parity
 from test_modelgen import (BOOL_DSL, CURRENTS, EXPECTED_FLAG, IF_DSL, IZH_DSL, LIF_NB, bool_expected_out,
                            lif_reference_trace)
 from test_modelgen_channels import CALCIUM_CLAMP, MORRIS_LECAR, VOLTAGES, calcium_reference
+from test_modelgen_spike_trains import BURST_DSL, RATE_DSL, REFRACTORINESS_DSL, _mixed_network
 
 FUNCTIONS_DSL = """
 [neuron]
@@ -41,6 +42,7 @@ def libs(snn):
     from concurrent.futures import ThreadPoolExecutor
     models = [modelgen.parse(text) for text in (LIF_NB, IZH_DSL, IF_DSL, CALCIUM_CLAMP, MORRIS_LECAR, FUNCTIONS_DSL,
                                                  BOOL_DSL)]
+    models += [modelgen.parse_description(text) for text in (RATE_DSL + REFRACTORINESS_DSL, IZH_DSL + BURST_DSL)]
     with ThreadPoolExecutor(max_workers=4) as pool:          # one hipcc each
         paths = list(pool.map(_lib.build_custom, models))
     return {m.name: (m, path) for m, path in zip(models, paths)}
@@ -353,7 +355,142 @@ def test_morris_lecar_network_equals_the_oracle(snn, libs, variant):
     dn.close()
 
 
+def test_generated_rate_train_and_refractoriness_on_the_device(snn, libs):
+    """The reference's RateSpikeTrain and delta-Dirac refractoriness descriptions (rate_spike_train.rs,
+    delta_dirac_refractoriness.rs) compiled into a library: a two-lattice Izhikevich network driven by them is
+    bit-identical to the C oracle stepping the same descriptions -- and therefore (test_modelgen_spike_trains.py) to the
+    built-in pair they restate, which the default library runs here for a direct comparison."""
+    desc, lib = libs["RateSpikeTrain_TestRefractoriness"]
+    L = snn._lib.load(lib)
+    assert (L.snn_custom_model(), L.snn_custom_spike_train(), L.snn_custom_refractoriness()) == \
+        (b"", b"RateSpikeTrain", b"TestRefractoriness")
+    rates = np.array([3.1, 0.0, 7.7, 12.0, 5.0, 1.3, 40.0, 9.9], f32)
+    decay = ob.uniform_array(33, 8, 50.0, 4000.0)
+    net = _mixed_network(ob, parity, ob.ST_CUSTOM)
+    modelgen_ref.attach_spike_train(net, desc.spike_train)
+    modelgen_ref.attach_refractoriness(net, desc.refractoriness)
+    net.custom_lib = lib
+    net["st_custom_vars"][1] = rates
+    net["st_k"] = decay
+    built_in = _mixed_network(ob, parity, ob.ST_RATE)
+    built_in["st_rate"] = rates
+    built_in["st_k"] = decay
+    steps = 700
+    dn = parity.device_from_oracle(snn, net)
+    assert np.array_equal(dn.get_attr(5, "neural_refractoriness$decay"), decay)       # alias of neural_refractoriness$k
+    dn0 = parity.device_from_oracle(snn, built_in)                                    # default library, built-in pair
+    for d in (dn, dn0):
+        d.set_history(voltage=True, spikes=True)
+        d.run(steps // 2)
+        d.run(steps - steps // 2)
+    net.run(steps, voltage_history=True, spike_history=True, st_voltage_history=True)
+    ranges = net.layout.ranges()
+    for i, _, _ in net.layout.lattices:
+        first, count, _ = ranges[i]
+        assert np.array_equal(dn.spike_history(i), net.spike_history[:, first:first + count])
+        assert np.array_equal(parity.bits(dn.voltage_history(i)), parity.bits(net.voltage_history[:, first:first + count]))
+        assert np.array_equal(parity.bits(dn.voltage_history(i)), parity.bits(dn0.voltage_history(i)))
+    assert np.array_equal(parity.bits(dn.voltage_history(5)), parity.bits(net.st_voltage_history))
+    assert np.array_equal(parity.bits(dn.voltage_history(5)), parity.bits(dn0.voltage_history(5)))
+    parity.assert_state_equal(net, parity.pull_state(dn, net))
+    parity.assert_graph_equal(net, dn)
+    assert np.array_equal(parity.bits(dn.get_attr(5, "step")), parity.bits(dn0.get_attr(5, "step")))
+    assert (net.st_voltage_history == f32(30.0)).sum() > 100 and net.spike_history.sum() > 20
+    with pytest.raises(snn.SnnError):
+        dn.set_attr(5, "neural_refractoriness$kind", np.full(8, 3, np.uint32))
+    dn.close()
+    dn0.close()
+
+
+@pytest.mark.parametrize("variant", ["dense", "sparse", "sharded"])
+def test_whole_description_in_one_library_equals_the_oracle(snn, libs, variant):
+    """One library carrying all three generated blocks -- the DSL Izhikevich neuron, a bursting spike train
+    (differential equation, exp, its own bool) and a refractoriness with an extra variable -- through a network with
+    gap junctions, AMPA / NMDA synapses and STDP, on dense, sparse and shard handles, against the C oracle."""
+    import torch
+    from snn_amd import parallel
+    desc, lib = libs["DslIzhikevich_BurstSpikeTrain_PlateauRefractoriness"]
+    lay = parity.Layout([(0, 6, 7), (2, 5, 5)], [(5, 3, 4)])
+    net = parity.make_oracle(lay, model=ob.CUSTOM, st_kind=ob.ST_CUSTOM, electrical=True, chemical=True)
+    modelgen_ref.attach(net, desc.neuron)
+    modelgen_ref.attach_spike_train(net, desc.spike_train)
+    modelgen_ref.attach_refractoriness(net, desc.refractoriness)
+    net.custom_lib = lib
+    n, nc = net.n_neurons, net.n_cells
+    rng = np.random.default_rng(41)
+    st_names = [name for name, _ in desc.spike_train.variables]
+    net["current_voltage"] = ob.uniform_array(41, n, -65.0, 30.0)
+    net["custom_vars"][0] = ob.uniform_array(42, n, 0.01, 0.05)
+    net["st_custom_vars"][st_names.index("freq")] = ob.uniform_array(43, nc, 0.01, 0.06)
+    net["refr_vars"][0] = ob.uniform_array(44, nc, 0.0, 8.0)                    # plateau
+    net["st_k"] = ob.uniform_array(45, nc, 200.0, 4000.0)
+    net["nt_flags"][:, 0] = 1
+    net["nt_flags"][:, 1] = rng.random(n) < 0.6
+    net["rc_flags"][:, :2] = 1
+    net["rc_g"][:, 0] = 2.0
+    net["st_nt_flags"][:, 0] = 1
+    net.fill_graph(46, 0.5, 1.5)
+    net["connections"][rng.random(net["connections"].shape) < 0.3] = 0
+    net["weights"][...] *= net["connections"]
+    net["do_plasticity"] = 1
+    steps = 900
+    if variant == "sharded":
+        handles = [parity.device_from_oracle(snn, net, shard=(r, 2)) for r in range(2)]
+        bufs = [parallel.exchange_tensor(h, torch.device("cuda", 0)) for h in handles]
+        block = bufs[0].numel() // 2
+        for _ in range(steps):
+            for h in handles:
+                h.step_begin()
+            for r in range(2):
+                bufs[1 - r][r * block:(r + 1) * block].copy_(bufs[r][r * block:(r + 1) * block])
+            torch.cuda.synchronize()
+            for h in handles:
+                h.step_end()
+        net.run(steps, spike_history=True)
+        for h in handles:
+            st = parity.pull_state(h, net)
+            b, e = h.post_begin, h.post_end
+            for name in ("current_voltage", "is_spiking", "last_firing_time", "nt_t", "st_current_voltage",
+                         "st_last_firing_time", "st_custom_vars", "st_nt_t"):
+                assert np.array_equal(parity.bits(st[name]), parity.bits(net[name])), name
+            assert np.array_equal(parity.bits(st["custom_vars"][:, b:e]), parity.bits(net["custom_vars"][:, b:e]))
+            w, c = h.get_graph_rows(0, net.n_tot)
+            ow = np.where(net["connections"] != 0, net["weights"], np.float32(0))
+            assert np.array_equal(parity.bits(w[:, b:e]), parity.bits(ow[:, b:e]))
+            h.close()
+        assert net.spike_history.sum() > 20
+        return
+    dn = parity.device_from_oracle(snn, net, csr=(variant == "sparse"))
+    dn.set_history(voltage=True, spikes=True)
+    dn.run(steps // 2)
+    dn.run(steps - steps // 2)
+    w0 = net["weights"].copy()
+    net.run(steps, voltage_history=True, spike_history=True, st_voltage_history=True)
+    ranges = net.layout.ranges()
+    for i, _, _ in net.layout.lattices:
+        first, count, _ = ranges[i]
+        assert np.array_equal(dn.spike_history(i), net.spike_history[:, first:first + count])
+        assert np.array_equal(parity.bits(dn.voltage_history(i)), parity.bits(net.voltage_history[:, first:first + count]))
+    assert np.array_equal(parity.bits(dn.voltage_history(5)), parity.bits(net.st_voltage_history))
+    parity.assert_state_equal(net, parity.pull_state(dn, net))
+    parity.assert_graph_equal(net, dn)
+    fired = net.st_voltage_history == f32(25.0)
+    assert fired.sum() > 50 and net.spike_history.sum() > 20 and not np.array_equal(w0, net["weights"])
+    dn.close()
+
+
 def test_default_library_has_no_generated_model(snn):
-    assert snn._lib.load().snn_custom_model() == b""
+    L = snn._lib.load()
+    assert (L.snn_custom_model(), L.snn_custom_spike_train(), L.snn_custom_refractoriness()) == (b"", b"", b"")
     with pytest.raises(snn.SnnError):
         snn.DeviceNetwork(model=snn.CUSTOM)
+    with pytest.raises(snn.SnnError):
+        snn.DeviceNetwork(model=snn.IZHIKEVICH, spike_train=snn.ST_CUSTOM)
+    dn = snn.DeviceNetwork(model=snn.IZHIKEVICH, spike_train=snn.ST_RATE)
+    dn.add_lattice(0, 2, 2)
+    dn.add_spike_train_lattice(1, 1, 3)
+    dn.finalize()
+    dn.set_attr(1, "neural_refractoriness$kind", np.ones(3, np.uint32))
+    with pytest.raises(snn.SnnError):
+        dn.set_attr(1, "neural_refractoriness$kind", np.full(3, 2, np.uint32))          # needs a generated refractoriness
+    dn.close()
