@@ -94,10 +94,14 @@ typedef enum {
 /* NeurotransmitterKinetics: Approximate iterate_and_spike/mod.rs:161-205, Destexhe :122-159 */
 /* DiscreteSpikeNeurotransmitter :287-317; ExponentialDecayNeurotransmitter :323-366 (attribute
  * neurotransmitters$decay_constant) */
-typedef enum { SNN_NT_APPROXIMATE = 0, SNN_NT_DESTEXHE = 1, SNN_NT_DISCRETE_SPIKE = 2, SNN_NT_EXPONENTIAL_DECAY = 3 } snn_nt_kinetics;
+/* SNN_NT_CUSTOM / SNN_RC_CUSTOM: the kinetics generated from a `[neurotransmitter_kinetics]` / `[receptor_kinetics]`
+ * block (build_test/nb_macro/src/lib.rs:6468-6540, 6757-6826) that a library built with -DSNN_CUSTOM_MODEL_HEADER
+ * carries; variables are the attributes neurotransmitters$<name> / receptors$<TYPE>$r$kinetics$<name>. */
+typedef enum { SNN_NT_APPROXIMATE = 0, SNN_NT_DESTEXHE = 1, SNN_NT_DISCRETE_SPIKE = 2, SNN_NT_EXPONENTIAL_DECAY = 3,
+               SNN_NT_CUSTOM = 100 } snn_nt_kinetics;
 /* ReceptorKinetics: Approximate iterate_and_spike/mod.rs:427-446, Destexhe :394-425 */
 /* ExponentialDecayReceptor :497-533 (attributes receptors$<T>$r$kinetics$r_max, ...$decay_constant) */
-typedef enum { SNN_RC_APPROXIMATE = 0, SNN_RC_DESTEXHE = 1, SNN_RC_EXPONENTIAL_DECAY = 2 } snn_rc_kinetics;
+typedef enum { SNN_RC_APPROXIMATE = 0, SNN_RC_DESTEXHE = 1, SNN_RC_EXPONENTIAL_DECAY = 2, SNN_RC_CUSTOM = 100 } snn_rc_kinetics;
 /* SpikeTrain: PoissonNeuron spike_train/mod.rs:259-371 (GPU generator :380-435), RateSpikeTrain :975-1031 */
 /* PresetSpikeTrain :753-833 (attributes internal_clock, counter; firing times via snn_set_firing_times).
  * NeuralRefractoriness of a cell: attribute neural_refractoriness$kind (u32; 0 DeltaDirac :79-88, the default,
@@ -308,6 +312,8 @@ const char *snn_custom_model(void);
 /* type names of the generated spike train / refractoriness this library carries ("" when it has none) */
 const char *snn_custom_spike_train(void);
 const char *snn_custom_refractoriness(void);
+const char *snn_custom_neurotransmitter_kinetics(void);
+const char *snn_custom_receptor_kinetics(void);
 
 /* HBM ceilings of the device with the stepper's own access shape (16 B per lane, non-temporal): GB/s of a
  * read-only stream and of a copy (read + write bytes) over `bytes` of device memory, `repeats` launches. */

@@ -10,6 +10,7 @@
 #include <stddef.h>
 
 static float custom_refractoriness_effect(const snn_o_net *n, uint32_t s);
+static float program_run(const int32_t *c, const float *consts, uint32_t pc, float *slot, int apply_diffs);
 
 /* ---------- small helpers ---------- */
 
@@ -284,11 +285,28 @@ static inline float nt_apply(int kind, float t, float t_max, float clearance, fl
     return o_min(t_max, o_max(t, 0.0f));
 }
 
+/* generated apply_t_change, build_test/nb_macro/src/lib.rs:6489-6498: cell i of `vars` ([nt_nvars][count]) */
+static float custom_nt_apply(const snn_o_net *n, float *vars, size_t count, size_t i, float t, float voltage,
+                             uint32_t spiking, float dt)
+{
+    float slot[5 + 8];
+    slot[0] = t; slot[1] = spiking ? 1.0f : 0.0f; slot[2] = dt; slot[3] = voltage; slot[4] = 0.0f;
+    for (uint32_t j = 0; j < n->nt_nvars; ++j) slot[5 + j] = vars[(size_t)j * count + i];
+    program_run(n->nt_code, n->nt_consts, 0, slot, 1);
+    for (uint32_t j = 0; j < n->nt_nvars; ++j) vars[(size_t)j * count + i] = slot[5 + j];
+    return slot[0];
+}
+
 static inline void neuron_nt_update(snn_o_net *n, uint32_t q, float voltage, uint32_t spiking_prev)
 {
     for (int k = 0; k < SNN_O_K; ++k) {
         size_t i = (size_t)q * SNN_O_K + k;
         if (!n->nt_flags || !n->nt_flags[i]) continue;
+        if (n->nt_kind == SNN_O_NT_CUSTOM) {
+            n->nt_t[i] = custom_nt_apply(n, n->nt_custom_vars, (size_t)n->n_neurons * SNN_O_K, i, n->nt_t[i], voltage,
+                                         spiking_prev, n->dt[q]);
+            continue;
+        }
         n->nt_t[i] = nt_apply(n->nt_kind, n->nt_t[i], n->nt_t_max[i],
                               n->nt_clearance ? n->nt_clearance[i] : 0.0f,
                               n->nt_v_p ? n->nt_v_p[i] : 0.0f, n->nt_k_p ? n->nt_k_p[i] : 1.0f,
@@ -307,7 +325,16 @@ static inline void receptors_update(snn_o_net *n, uint32_t q, float v_old)
         if (!n->rc_flags[i]) continue;
         if (n->input_count[i] != 0.0f) {
             float t = n->input_t[i];
-            if (n->rc_kind == SNN_O_RC_DESTEXHE) {
+            if (n->rc_kind == SNN_O_RC_CUSTOM) {
+                /* generated apply_r_change, build_test/nb_macro/src/lib.rs:6778-6786 */
+                const size_t count = (size_t)n->n_neurons * SNN_O_K;
+                float slot[5 + 8];
+                slot[0] = n->rc_r[i]; slot[1] = t; slot[2] = dt; slot[3] = 0.0f; slot[4] = 0.0f;
+                for (uint32_t j = 0; j < n->rc_nvars; ++j) slot[5 + j] = n->rc_custom_vars[(size_t)j * count + i];
+                program_run(n->rc_code, n->rc_consts, 0, slot, 1);
+                for (uint32_t j = 0; j < n->rc_nvars; ++j) n->rc_custom_vars[(size_t)j * count + i] = slot[5 + j];
+                n->rc_r[i] = slot[0];
+            } else if (n->rc_kind == SNN_O_RC_DESTEXHE) {
                 float r = n->rc_r[i];
                 n->rc_r[i] = r + (n->rc_alpha[i] * t * (1.0f - r) - n->rc_beta[i] * r) * dt;
             } else if (n->rc_kind == SNN_O_RC_EXPONENTIAL_DECAY) {
@@ -924,6 +951,11 @@ void snn_o_spike_trains(snn_o_net *n)
             for (int k = 0; k < SNN_O_K; ++k) {
                 size_t i = (size_t)s * SNN_O_K + k;
                 if (!n->st_nt_flags[i]) continue;
+                if (n->nt_kind == SNN_O_NT_CUSTOM) {
+                    n->st_nt_t[i] = custom_nt_apply(n, n->st_nt_custom_vars, (size_t)n->n_cells * SNN_O_K, i, n->st_nt_t[i],
+                                                    v, spike, n->st_dt[s]);
+                    continue;
+                }
                 n->st_nt_t[i] = nt_apply(n->nt_kind, n->st_nt_t[i], n->st_nt_t_max[i],
                                          n->st_nt_clearance ? n->st_nt_clearance[i] : 0.0f,
                                          n->st_nt_v_p ? n->st_nt_v_p[i] : 0.0f,

@@ -56,8 +56,9 @@ extern "C" {
 enum { SNN_O_IZHIKEVICH = 0, SNN_O_LIF = 1, SNN_O_HH = 2, SNN_O_QIF = 3, SNN_O_SIMPLE_LIF = 4,
        SNN_O_ADAPTIVE_LIF = 5, SNN_O_ADAPTIVE_EXP_LIF = 6, SNN_O_LEAKY_IZHIKEVICH = 7,
        SNN_O_BCM_IZHIKEVICH = 8, SNN_O_CUSTOM = 100 };
-enum { SNN_O_NT_APPROX = 0, SNN_O_NT_DESTEXHE = 1, SNN_O_NT_DISCRETE_SPIKE = 2, SNN_O_NT_EXPONENTIAL_DECAY = 3 };
-enum { SNN_O_RC_APPROX = 0, SNN_O_RC_DESTEXHE = 1, SNN_O_RC_EXPONENTIAL_DECAY = 2 };
+enum { SNN_O_NT_APPROX = 0, SNN_O_NT_DESTEXHE = 1, SNN_O_NT_DISCRETE_SPIKE = 2, SNN_O_NT_EXPONENTIAL_DECAY = 3,
+       SNN_O_NT_CUSTOM = 100 };
+enum { SNN_O_RC_APPROX = 0, SNN_O_RC_DESTEXHE = 1, SNN_O_RC_EXPONENTIAL_DECAY = 2, SNN_O_RC_CUSTOM = 100 };
 enum { SNN_O_ST_NONE = 0, SNN_O_ST_POISSON = 1, SNN_O_ST_RATE = 2, SNN_O_ST_PRESET = 3, SNN_O_ST_BCM_POISSON = 4,
        SNN_O_ST_CUSTOM = 100 };
 
@@ -198,6 +199,19 @@ typedef struct snn_o_net {
     const float   *refr_consts;
     uint32_t refr_nvars;
     float    *refr_vars;                       /* [refr_nvars][n_cells] */
+    /* nt_kind == SNN_O_NT_CUSTOM: generated NeurotransmitterKinetics::apply_t_change (lib.rs:6468-6540) as a stack
+     * program; slots 0 t, 1 is_spiking, 2 dt, 3 voltage, 4 unused, 5.. variables (one value per cell and type, indexed
+     * like nt_t).  rc_kind == SNN_O_RC_CUSTOM: generated ReceptorKinetics::apply_r_change (lib.rs:6757-6826); slots
+     * 0 r, 1 t, 2 dt, 5.. variables (indexed like rc_r). */
+    const int32_t *nt_code;
+    const float   *nt_consts;
+    uint32_t nt_nvars;
+    float    *nt_custom_vars;                  /* [nt_nvars][n_neurons * 3] */
+    float    *st_nt_custom_vars;               /* [nt_nvars][n_cells * 3] */
+    const int32_t *rc_code;
+    const float   *rc_consts;
+    uint32_t rc_nvars;
+    float    *rc_custom_vars;                  /* [rc_nvars][n_neurons * 3] */
 } snn_o_net;
 
 /* Step 1 of SURVEY §8(g): electrical + chemical inputs for every neuron from state S(t). */

@@ -11,7 +11,7 @@ from .network import (DeviceNetwork, HODGKIN_HUXLEY, IZHIKEVICH, LIF, QUADRATIC_
                       ADAPTIVE_LIF, ADAPTIVE_EXP_LIF, LEAKY_IZHIKEVICH, NT_APPROXIMATE, NT_DESTEXHE,
                       NUM_NT_TYPES, RC_APPROXIMATE, RC_DESTEXHE, ST_NONE, ST_POISSON, ST_RATE, probe_bandwidth, probe_math,
                       NT_DISCRETE_SPIKE, NT_EXPONENTIAL_DECAY, RC_EXPONENTIAL_DECAY, ST_PRESET, BCM_IZHIKEVICH, ST_BCM_POISSON, CUSTOM, ST_CUSTOM,
-                      REFRACTORINESS_CUSTOM)
+                      REFRACTORINESS_CUSTOM, NT_CUSTOM, RC_CUSTOM)
 
 from . import modelgen  # noqa: F401
 from .lattice import *  # noqa: F401,F403  (Lixirnet-style names)
@@ -20,4 +20,4 @@ __all__ = ["DeviceNetwork", "SnnError", "SnnLibraryError", "build", "probe_math"
            "IZHIKEVICH", "LIF", "HODGKIN_HUXLEY", "QUADRATIC_INTEGRATE_AND_FIRE", "SIMPLE_LIF", "ADAPTIVE_LIF", "ADAPTIVE_EXP_LIF", "LEAKY_IZHIKEVICH", "NT_APPROXIMATE", "NT_DESTEXHE",
            "RC_APPROXIMATE", "RC_DESTEXHE", "ST_NONE", "ST_POISSON", "ST_RATE", "NUM_NT_TYPES",
            "NT_DISCRETE_SPIKE", "NT_EXPONENTIAL_DECAY", "RC_EXPONENTIAL_DECAY", "ST_PRESET", "BCM_IZHIKEVICH", "ST_BCM_POISSON", "CUSTOM", "ST_CUSTOM",
-           "REFRACTORINESS_CUSTOM", "modelgen"]
+           "REFRACTORINESS_CUSTOM", "NT_CUSTOM", "RC_CUSTOM", "modelgen"]

@@ -4,6 +4,8 @@
 //   [neuron] (+ [ion_channel]s)   -> namespace custom       = neuron model SNN_MODEL_CUSTOM
 //   [spike_train]                 -> namespace custom_st    = spike-train model SNN_ST_CUSTOM
 //   [neural_refractoriness]       -> namespace custom_refr  = neural_refractoriness$kind 2
+//   [neurotransmitter_kinetics]   -> namespace custom_nt    = neurotransmitter kinetics SNN_NT_CUSTOM
+//   [receptor_kinetics]           -> namespace custom_rc    = receptor kinetics SNN_RC_CUSTOM
 // A library compiled with -DSNN_CUSTOM_MODEL_HEADER="\"generated/<name>.hpp\"" carries them next to the built-in
 // models.  Without the define (or for a block the description does not have) the hook is an empty stub and the
 // selector is refused.
@@ -61,11 +63,41 @@ __device__ __forceinline__ float effect(float, float, float v_resting, float, fl
 } // namespace snn
 #endif
 
+#ifndef SNN_HAVE_CUSTOM_NT
+#define SNN_HAVE_CUSTOM_NT 0
+namespace snn {
+namespace custom_nt {
+constexpr int NVARS = 0;
+constexpr int NSTORE = 1;
+static const char *const TYPE_NAME = "";
+static const char *const NAMES[NSTORE] = {""};
+static const float DEFAULTS[NSTORE] = {0.0f};
+__device__ __forceinline__ void apply(float &, float (&)[NSTORE], float, bool, float) {}
+} // namespace custom_nt
+} // namespace snn
+#endif
+#ifndef SNN_HAVE_CUSTOM_RC
+#define SNN_HAVE_CUSTOM_RC 0
+namespace snn {
+namespace custom_rc {
+constexpr int NVARS = 0;
+constexpr int NSTORE = 1;
+static const char *const TYPE_NAME = "";
+static const char *const NAMES[NSTORE] = {""};
+static const float DEFAULTS[NSTORE] = {0.0f};
+__device__ __forceinline__ void apply(float &, float (&)[NSTORE], float, float) {}
+} // namespace custom_rc
+} // namespace snn
+#endif
+
 namespace snn {
 constexpr int CUSTOM_MODEL = 100;        // SNN_MODEL_CUSTOM
 constexpr int CUSTOM_SPIKE_TRAIN = 100;  // SNN_ST_CUSTOM
 constexpr uint32_t CUSTOM_REFRACTORINESS = 2;
-constexpr int CUSTOM_MAX_VARS = 32, CUSTOM_ST_MAX_VARS = 16, CUSTOM_REFR_MAX_VARS = 8;
+constexpr int CUSTOM_KINETICS = 100;     // SNN_NT_CUSTOM / SNN_RC_CUSTOM
+constexpr int CUSTOM_MAX_VARS = 32, CUSTOM_ST_MAX_VARS = 16, CUSTOM_REFR_MAX_VARS = 8, CUSTOM_KINETICS_MAX_VARS = 8;
+static_assert(custom_nt::NVARS <= CUSTOM_KINETICS_MAX_VARS, "too many variables in the generated neurotransmitter kinetics");
+static_assert(custom_rc::NVARS <= CUSTOM_KINETICS_MAX_VARS, "too many variables in the generated receptor kinetics");
 static_assert(custom::NVARS <= CUSTOM_MAX_VARS, "too many variables in the generated neuron model");
 static_assert(custom_st::NVARS <= CUSTOM_ST_MAX_VARS, "too many variables in the generated spike train");
 static_assert(custom_refr::NVARS <= CUSTOM_REFR_MAX_VARS, "too many variables in the generated refractoriness");

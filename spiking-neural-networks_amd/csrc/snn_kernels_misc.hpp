@@ -158,6 +158,17 @@ __global__ __launch_bounds__(256) void k_spike_trains(const SpikeTrainArgs a)
             const size_t i = (size_t)k * c.c_pad + s;
             if (!a.has_nt || !c.nt_flags[i]) continue;
             // spike trains release on their CURRENT spike flag (spike_train/mod.rs:363-365)
+            if (SNN_HAVE_CUSTOM_NT && a.nt_kind == CUSTOM_KINETICS) {
+                float x[custom_nt::NSTORE];
+#pragma unroll
+                for (int j = 0; j < custom_nt::NVARS; ++j) x[j] = c.nt_custom[j][i];
+                float t = c.nt_t[i];
+                custom_nt::apply(t, x, v, spike != 0, c.dt[s]);
+#pragma unroll
+                for (int j = 0; j < custom_nt::NVARS; ++j) c.nt_custom[j][i] = x[j];
+                c.nt_t[i] = t;
+                continue;
+            }
             c.nt_t[i] = nt_apply(a.nt_kind, c.nt_t[i], c.nt_t_max[i], c.nt_clearance[i], c.nt_v_p[i], c.nt_k_p[i],
                                  v, spike, c.dt[s]);
         }

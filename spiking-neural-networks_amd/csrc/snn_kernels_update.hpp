@@ -66,8 +66,20 @@ __device__ __forceinline__ void neuron_nt_update(const UpdateArgs &a, uint32_t q
         const size_t i = (size_t)k * a.n.n_pad + q;
         if (!a.n.nt_flags[i]) continue;
         const size_t at = a.n.xl.at(q, PLANE_T0 + k);
-        const float t = nt_apply(a.nt_kind, a.n.xbuf[at], a.n.nt_t_max[i], a.n.nt_clearance[i], a.n.nt_v_p[i],
-                                 a.n.nt_k_p[i], voltage, spiking_prev, dt);
+        float t;
+        if (SNN_HAVE_CUSTOM_NT && a.nt_kind == CUSTOM_KINETICS) {
+            // generated apply_t_change (nb_macro lib.rs:6489-6498); a neuron releases on its previous spike flag
+            float x[custom_nt::NSTORE];
+#pragma unroll
+            for (int j = 0; j < custom_nt::NVARS; ++j) x[j] = a.n.nt_custom[j][i];
+            t = a.n.xbuf[at];
+            custom_nt::apply(t, x, voltage, spiking_prev != 0, dt);
+#pragma unroll
+            for (int j = 0; j < custom_nt::NVARS; ++j) a.n.nt_custom[j][i] = x[j];
+        } else {
+            t = nt_apply(a.nt_kind, a.n.xbuf[at], a.n.nt_t_max[i], a.n.nt_clearance[i], a.n.nt_v_p[i],
+                         a.n.nt_k_p[i], voltage, spiking_prev, dt);
+        }
         a.xout[at] = t;
         if (a.xout2) a.xout2[at] = t;
     }
@@ -98,7 +110,19 @@ __device__ __forceinline__ void receptors_update(const UpdateArgs &a, uint32_t q
             // second level of the canonical sum, then the per-type average
             const float s = sums.chem(k);
             const float t = s / (float)cnt;
-            a.n.rc_r[i] = rc_apply(a.rc_kind, a.n.rc_r[i], t, a.n.rc_alpha[i], a.n.rc_beta[i], dt);
+            if (SNN_HAVE_CUSTOM_RC && a.rc_kind == CUSTOM_KINETICS) {
+                // generated apply_r_change (nb_macro lib.rs:6778-6786)
+                float x[custom_rc::NSTORE];
+#pragma unroll
+                for (int j = 0; j < custom_rc::NVARS; ++j) x[j] = a.n.rc_custom[j][i];
+                float r = a.n.rc_r[i];
+                custom_rc::apply(r, x, t, dt);
+#pragma unroll
+                for (int j = 0; j < custom_rc::NVARS; ++j) a.n.rc_custom[j][i] = x[j];
+                a.n.rc_r[i] = r;
+            } else {
+                a.n.rc_r[i] = rc_apply(a.rc_kind, a.n.rc_r[i], t, a.n.rc_alpha[i], a.n.rc_beta[i], dt);
+            }
         }
     }
 #pragma unroll

@@ -67,6 +67,7 @@ struct NeuronArrays {
     uint32_t *was_increasing;
     // neurotransmitters [3][n_pad] (t lives in xbuf planes 2..4)
     float *nt_t_max, *nt_clearance, *nt_v_p, *nt_k_p;
+    float *nt_custom[8], *rc_custom[8];   // variables of generated kinetics (custom_nt / custom_rc), [3][n_pad] each
     uint32_t *nt_flags;
     // receptors [3][n_pad]
     float *rc_g, *rc_e, *rc_mg, *rc_r, *rc_alpha, *rc_beta, *rc_current;
@@ -92,6 +93,7 @@ struct CellArrays {
     const float *preset_times;
     int32_t *last_firing_time;
     float *nt_t, *nt_t_max, *nt_clearance, *nt_v_p, *nt_k_p;   // [3][c_pad]
+    float *nt_custom[8];        // variables of generated neurotransmitter kinetics, [3][c_pad] each
     uint32_t *nt_flags;
     uint32_t *lattice_slot;     // [c_pad] -> spike-train lattice slot
     float *presyn_value;        // per-step presynaptic gap-junction value (see k_spike_train_view)

@@ -13,6 +13,8 @@ int snn_abi_version(void) { return SNN_ABI_VERSION; }
 const char *snn_custom_model(void) { return custom::TYPE_NAME; }
 const char *snn_custom_spike_train(void) { return custom_st::TYPE_NAME; }
 const char *snn_custom_refractoriness(void) { return custom_refr::TYPE_NAME; }
+const char *snn_custom_neurotransmitter_kinetics(void) { return custom_nt::TYPE_NAME; }
+const char *snn_custom_receptor_kinetics(void) { return custom_rc::TYPE_NAME; }
 const char *snn_last_error(void) { return g_last_error.c_str(); }
 
 int snn_network_create(int device, int neuron_model, int nt_kinetics, int receptor_kinetics,
@@ -22,8 +24,11 @@ int snn_network_create(int device, int neuron_model, int nt_kinetics, int recept
     *out = nullptr;
     const bool custom_ok = SNN_HAVE_CUSTOM_NEURON && neuron_model == SNN_MODEL_CUSTOM;
     const bool custom_st_ok = SNN_HAVE_CUSTOM_SPIKE_TRAIN && spike_train_model == SNN_ST_CUSTOM;
-    if (((neuron_model < 0 || neuron_model > 8) && !custom_ok) || nt_kinetics < 0 || nt_kinetics > 3 || receptor_kinetics < 0 ||
-        receptor_kinetics > 2 || ((spike_train_model < 0 || spike_train_model > 4) && !custom_st_ok))
+    const bool custom_nt_ok = SNN_HAVE_CUSTOM_NT && nt_kinetics == SNN_NT_CUSTOM;
+    const bool custom_rc_ok = SNN_HAVE_CUSTOM_RC && receptor_kinetics == SNN_RC_CUSTOM;
+    if (((neuron_model < 0 || neuron_model > 8) && !custom_ok) || ((nt_kinetics < 0 || nt_kinetics > 3) && !custom_nt_ok) ||
+        ((receptor_kinetics < 0 || receptor_kinetics > 2) && !custom_rc_ok) ||
+        ((spike_train_model < 0 || spike_train_model > 4) && !custom_st_ok))
         return fail(SNN_ERR_BAD_ARG, "unknown model / kinetics selector");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)

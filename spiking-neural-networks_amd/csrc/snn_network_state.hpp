@@ -375,6 +375,13 @@ int build_state(snn_network *net)
     reg(A, "neurotransmitters$v_p", T_F32, S_PLAIN_K, n.nt_v_p, 0, np);
     reg(A, "neurotransmitters$k_p", T_F32, S_PLAIN_K, n.nt_k_p, 0, np);
     reg(A, "neurotransmitters$flags", T_U32, S_PLAIN_K, n.nt_flags, 0, np, 1);
+    for (int j = 0; j < CUSTOM_KINETICS_MAX_VARS; ++j) n.nt_custom[j] = n.rc_custom[j] = nullptr;
+    if (net->nt_kind == SNN_NT_CUSTOM)             // generated kinetics: its variables, one value per type
+        for (int j = 0; j < custom_nt::NVARS; ++j) {
+            const float d = custom_nt::DEFAULTS[j];
+            TRY(typed_f32(net, &n.nt_custom[j], np, d, d, d));
+            reg(A, (std::string("neurotransmitters$") + custom_nt::NAMES[j]).c_str(), T_F32, S_PLAIN_K, n.nt_custom[j], 0, np);
+        }
 
     // receptors (iterate_and_spike/mod.rs:1085-1094, 1115-1125, 1148-1157, 417-425)
     TRY(typed_f32(net, &n.rc_g, np, 1.0f, 0.6f, 1.2f));
@@ -402,6 +409,14 @@ int build_state(snn_network *net)
         reg(A, (p + "$r$kinetics$decay_constant").c_str(), T_F32, S_PLAIN, n.rc_beta + (size_t)k * np, 0, 0);
     }
     reg(A, "receptors$NMDA_mg", T_F32, S_PLAIN, n.rc_mg + (size_t)1 * np, 0, 0);
+    if (net->rc_kind == SNN_RC_CUSTOM)
+        for (int j = 0; j < custom_rc::NVARS; ++j) {
+            const float d = custom_rc::DEFAULTS[j];
+            TRY(typed_f32(net, &n.rc_custom[j], np, d, d, d));
+            for (int k = 0; k < K_TYPES; ++k)
+                reg(A, (std::string("receptors$") + TN[k] + "$r$kinetics$" + custom_rc::NAMES[j]).c_str(), T_F32, S_PLAIN,
+                    n.rc_custom[j] + (size_t)k * np, 0, 0);
+        }
 
     // lattice slot per neuron + plasticity tables
     TRY(dev_alloc_t(net, &net->lattice_slot, np));
@@ -533,6 +548,13 @@ int build_state(snn_network *net)
     reg(CA, "neurotransmitters$v_p", T_F32, S_PLAIN_K, c.nt_v_p, 0, cp);
     reg(CA, "neurotransmitters$k_p", T_F32, S_PLAIN_K, c.nt_k_p, 0, cp);
     reg(CA, "neurotransmitters$flags", T_U32, S_PLAIN_K, c.nt_flags, 0, cp, 1);
+    for (int j = 0; j < CUSTOM_KINETICS_MAX_VARS; ++j) c.nt_custom[j] = nullptr;
+    if (net->nt_kind == SNN_NT_CUSTOM)
+        for (int j = 0; j < custom_nt::NVARS; ++j) {
+            const float d = custom_nt::DEFAULTS[j];
+            TRY(typed_f32(net, &c.nt_custom[j], cp, d, d, d));
+            reg(CA, (std::string("neurotransmitters$") + custom_nt::NAMES[j]).c_str(), T_F32, S_PLAIN_K, c.nt_custom[j], 0, cp);
+        }
     TRY(dev_alloc_t(net, &c.lattice_slot, cp));
     TRY(fill_u32(net, c.lattice_slot, cp, 0));
     for (const auto &l : net->st_lattices)

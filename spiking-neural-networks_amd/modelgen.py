@@ -50,11 +50,15 @@ the reference tests against is build_test/nb_macro/tests/lif_reference.rs):
   * `[neural_refractoriness]` blocks (lib.rs:5677-5762): `effect:` is one expression over v_th, v_resting, dt,
     time_difference = (timestep - last_firing_time) as f32, `decay` (always there, default 10000, stored where the
     built-in kinds keep k) and the block's own vars -> neural_refractoriness$kind 2.
-    One library carries at most one neuron, one spike train and one refractoriness.
+  * `[neurotransmitter_kinetics]` (lib.rs:6468-6540; NT kinetics selector 100) and `[receptor_kinetics]`
+    (lib.rs:6757-6826; receptor kinetics selector 100) blocks: on_iteration over the state (`t` / `r`, default 0), the
+    block's vars -- one value per neurotransmitter type, attributes neurotransmitters$<name> /
+    receptors$<TYPE>$r$kinetics$<name> -- and the inputs is_spiking, v, dt / t, dt.
+    One library carries at most one neuron, spike train, refractoriness and kinetics block of each kind.
 
 `hip_source(model)` emits the header that csrc/snn_custom_model.hpp includes when the library is compiled with
 -DSNN_CUSTOM_MODEL_HEADER; `_lib.build_custom(model)` compiles such a library.  Not supported (rejected with a
-message): receptors / kinetics blocks, `^` with a non-literal or
+message): [receptors] blocks, `^` with a non-literal or
 fractional exponent, sin / cos / tan / isnan, on_electrochemical_iteration, and `continuous()` spike detection --
 the code the reference generates for it reads a `last_voltage` that is never defined (lib.rs:984-990), so there is
 no behaviour to match.
@@ -68,6 +72,7 @@ FUNCTIONS = {"exp": 1, "tanh": 1, "sinh": 1, "cosh": 1, "heaviside": 1, "min": 2
 MAX_POWER = 16
 MAX_ST_VARS = 16
 MAX_REFRACTORINESS_VARS = 8
+MAX_KINETICS_VARS = 8
 
 
 class ModelError(ValueError):
@@ -518,13 +523,28 @@ class RefractorinessModel:
         self.decay = 10000.0
 
 
+class KineticsModel:
+    """[neurotransmitter_kinetics] (lib.rs:6468-6540): apply_t_change(neuron) = on_iteration over the state `t`, the
+    block's vars and the releasing cell's is_spiking / v / dt.  [receptor_kinetics] (lib.rs:6757-6826):
+    apply_r_change(t, dt) = on_iteration over the state `r`, the vars, the neurotransmitter concentration `t` and dt.
+    `state` is "t" or "r" (default 0 unless listed in vars); every variable exists once per neurotransmitter type."""
+    def __init__(self, name, state, variables, bools, on_iteration, state_default):
+        self.name, self.state, self.variables, self.on_iteration = name, state, variables, on_iteration
+        self.bools, self.state_default = set(bools), state_default
+
+
 class Description:
-    def __init__(self, neuron=None, spike_train=None, refractoriness=None):
+    def __init__(self, neuron=None, spike_train=None, refractoriness=None, nt_kinetics=None, receptor_kinetics=None):
         self.neuron, self.spike_train, self.refractoriness = neuron, spike_train, refractoriness
+        self.nt_kinetics, self.receptor_kinetics = nt_kinetics, receptor_kinetics
+
+    def parts(self):
+        return [m for m in (self.neuron, self.spike_train, self.refractoriness, self.nt_kinetics,
+                            self.receptor_kinetics) if m is not None]
 
     @property
     def name(self):
-        return "_".join(m.name for m in (self.neuron, self.spike_train, self.refractoriness) if m is not None)
+        return "_".join(m.name for m in self.parts())
 
 
 def _convert_plain(stmts, rename, assignable, where):
@@ -620,6 +640,36 @@ def _parse_refractoriness(body):
     return model
 
 
+def _parse_kinetics(body, state):
+    what = "neurotransmitter kinetics" if state == "t" else "receptor kinetics"
+    sections, name = _sections(body, ("type", "vars", "on_iteration"))
+    if not sections.get("on_iteration"):
+        raise ModelError(f"{what} {name}: section 'on_iteration' is missing")
+    bools = set()
+    reserved = ("v", "current_voltage", "is_spiking", "dt") if state == "t" else ("t", "dt")
+    listed = _variables(sections.get("vars", []), reserved, bools)
+    if state in bools:
+        raise ModelError(f"'{state}' is a number")
+    variables = [(n, d) for n, d in listed if n != state]
+    if dict(listed).get(state, 0.0) != 0.0:
+        raise ModelError(f"{what} {name}: '{state}' starts at 0 on the device (set the attribute after finalize)")
+    if len(variables) > MAX_KINETICS_VARS:
+        raise ModelError(f"more than {MAX_KINETICS_VARS} {what} variables")
+    inputs = {"v", "is_spiking", "dt"} if state == "t" else {"t", "dt"}
+    known = inputs | {state} | {n for n, _ in variables}
+    all_bools = set(bools) | ({"is_spiking"} if state == "t" else set())
+
+    def rename(n):
+        n = "v" if (n == "current_voltage" and state == "t") else n
+        if n not in known:
+            raise ModelError(f"unknown variable {n!r}")
+        return ("var", n)
+
+    stmts = _convert_plain(_block(sections["on_iteration"])[0], rename, known - inputs, "on_iteration")
+    _check_types(stmts, all_bools)
+    return KineticsModel(name, state, variables, all_bools, stmts, dict(listed).get(state, 0.0))
+
+
 def parse_description(text):
     """Every block of a description: [ion_channel]s, at most one [neuron], one [spike_train] and one
     [neural_refractoriness] (one generated library carries one of each)."""
@@ -640,9 +690,17 @@ def parse_description(text):
             if desc.refractoriness is not None:
                 raise ModelError("more than one [neural_refractoriness] block")
             desc.refractoriness = _parse_refractoriness(body)
+        elif kind == "neurotransmitter_kinetics":
+            if desc.nt_kinetics is not None:
+                raise ModelError("more than one [neurotransmitter_kinetics] block")
+            desc.nt_kinetics = _parse_kinetics(body, "t")
+        elif kind == "receptor_kinetics":
+            if desc.receptor_kinetics is not None:
+                raise ModelError("more than one [receptor_kinetics] block")
+            desc.receptor_kinetics = _parse_kinetics(body, "r")
         elif kind != "neuron":
-            raise ModelError(f"[{kind}] blocks are not supported (only [ion_channel], [neuron], [spike_train] and "
-                             "[neural_refractoriness])")
+            raise ModelError(f"[{kind}] blocks are not supported ([ion_channel], [neuron], [spike_train], "
+                             "[neural_refractoriness], [neurotransmitter_kinetics] and [receptor_kinetics] are)")
     neurons = [body for kind, body in blocks if kind == "neuron"]
     if len(neurons) > 1:
         raise ModelError("expected exactly one [neuron] ... [end] block")
@@ -650,7 +708,7 @@ def parse_description(text):
         desc.neuron = _parse_neuron(neurons[0], channels)
     elif channels:
         raise ModelError("[ion_channel] blocks without a [neuron] that uses them")
-    if desc.neuron is None and desc.spike_train is None and desc.refractoriness is None:
+    if not desc.parts():
         raise ModelError("empty description")
     return desc
 
@@ -658,7 +716,7 @@ def parse_description(text):
 def parse(text):
     """Parse zero or more [ion_channel] blocks and ONE [neuron] block of the DSL subset in the module docstring."""
     desc = parse_description(text)
-    if desc.neuron is None or desc.spike_train is not None or desc.refractoriness is not None:
+    if desc.neuron is None or len(desc.parts()) != 1:
         raise ModelError("expected exactly one [neuron] ... [end] block (parse_description reads spike trains and "
                          "refractoriness)")
     return desc.neuron
@@ -844,7 +902,7 @@ def _hip_statements(stmts, index, with_diffs, indent="    "):
             continue
         target = index["$base"][s[1]] if s[1] in index["$base"] else f"x[{index[s[1]]}]"
         if s[0] == "diff":
-            d = "d_v" if s[1] == "v" else f"d_x{index[s[1]]}"
+            d = f"d_{s[1]}" if s[1] in index["$base"] else f"d_x{index[s[1]]}"
             lines.append(f"{indent}const float {d} = ({_hip_expr(s[2], index)}) * dt;")
             diffs.append(f"{indent}{target} += {d};")
         elif s[1] in index.get("$bools", ()) and s[1] not in index["$base"]:
@@ -937,6 +995,32 @@ __device__ __forceinline__ float effect(float time_difference, float v_th, float
 """
 
 
+def _kinetics_source(model):
+    index = {n: k for k, (n, _) in enumerate(model.variables)}
+    index["$bools"] = model.bools
+    if model.state == "t":
+        index["$base"] = {"t": "t", "v": "v", "is_spiking": "is_spiking", "dt": "dt"}
+        ns, macro, args = "custom_nt", "SNN_HAVE_CUSTOM_NT", "float &t, float (&x)[NSTORE], float v, bool is_spiking, float dt"
+        cite = "apply_t_change of the generated NeurotransmitterKinetics (nb_macro lib.rs:6489-6498)"
+    else:
+        index["$base"] = {"r": "r", "t": "t", "dt": "dt"}
+        ns, macro, args = "custom_rc", "SNN_HAVE_CUSTOM_RC", "float &r, float (&x)[NSTORE], float t, float dt"
+        cite = "apply_r_change of the generated ReceptorKinetics (nb_macro lib.rs:6778-6786)"
+    return f"""#define {macro} 1
+namespace {ns} {{
+static const char *const TYPE_NAME = "{model.name}";
+{_table(model.variables)}
+constexpr float DEFAULT_STATE = {_f32_literal(model.state_default)};
+
+// {cite}
+__device__ __forceinline__ void apply({args})
+{{
+{_hip_statements(model.on_iteration, index, True)}
+}}
+}} // namespace {ns}
+"""
+
+
 def hip_source(model):
     """The generated header for a NeuronModel or a Description: per block a variable table and its code as device
     functions (namespaces custom / custom_st / custom_refr)."""
@@ -948,6 +1032,10 @@ def hip_source(model):
         parts.append(_spike_train_source(desc.spike_train))
     if desc.refractoriness is not None:
         parts.append(_refractoriness_source(desc.refractoriness))
+    if desc.nt_kinetics is not None:
+        parts.append(_kinetics_source(desc.nt_kinetics))
+    if desc.receptor_kinetics is not None:
+        parts.append(_kinetics_source(desc.receptor_kinetics))
     return f"""// GENERATED by spiking-neural-networks_amd/modelgen.py from the description of {desc.name}
 // (nb_macro semantics, see modelgen.py).  Included through csrc/snn_custom_model.hpp.
 #pragma once

@@ -20,6 +20,7 @@ NT_APPROXIMATE, NT_DESTEXHE, NT_DISCRETE_SPIKE, NT_EXPONENTIAL_DECAY = 0, 1, 2, 
 RC_APPROXIMATE, RC_DESTEXHE, RC_EXPONENTIAL_DECAY = 0, 1, 2
 ST_NONE, ST_POISSON, ST_RATE, ST_PRESET, ST_BCM_POISSON = 0, 1, 2, 3, 4
 ST_CUSTOM = 100       # the generated spike train of a library built by _lib.build_custom (modelgen.parse_description)
+NT_CUSTOM = RC_CUSTOM = 100   # generated [neurotransmitter_kinetics] / [receptor_kinetics] of such a library
 REFRACTORINESS_CUSTOM = 2   # neural_refractoriness$kind of the generated refractoriness of such a library
 NUM_NT_TYPES = 3
 

@@ -99,6 +99,25 @@ def make_spike_train_step(model):
     return iterate
 
 
+def make_kinetics_step(model):
+    """apply(state, **inputs): one apply_t_change (inputs is_spiking, v, dt) or apply_r_change (inputs t, dt) of a
+    modelgen.KineticsModel; state holds the kinetics' own `t` / `r` and variables as float32 arrays"""
+    def apply(state, **inputs):
+        env = {"$bools": model.bools, model.state: state[model.state]}
+        for k, val in inputs.items():
+            env[k] = np.asarray(val) if k == "is_spiking" else np.asarray(val, f32)
+        if "is_spiking" in env:
+            env["is_spiking"] = env["is_spiking"].astype(f32)        # stored like every bool: 1.0 / 0.0
+        env.setdefault("v", state[model.state])                      # _run sizes masks by env["v"]
+        for name, _ in model.variables:
+            env[name] = state[name]
+        _run(model.on_iteration, env)
+        state[model.state] = env[model.state]
+        for name, _ in model.variables:
+            state[name] = env[name]
+    return apply
+
+
 def refractoriness_effect(model, time_difference, v_th, v_resting, dt, decay=None, **variables):
     env = {"time_difference": f32(time_difference), "v_th": f32(v_th), "v_resting": f32(v_resting), "dt": f32(dt),
            "decay": f32(model.decay if decay is None else decay)}
@@ -135,6 +154,8 @@ _BASE_SLOTS = {"v": 0, "i": 1, "dt": 2, "c_m": 3, "gap_conductance": 4}
 
 
 _ST_SLOTS = {"v": 0, "is_spiking": 1, "dt": 2, "v_resting": 3, "v_th": 4}
+_NT_SLOTS = {"t": 0, "is_spiking": 1, "dt": 2, "v": 3}
+_RC_SLOTS = {"r": 0, "t": 1, "dt": 2}
 _REFR_SLOTS = {"time_difference": 0, "v_th": 1, "dt": 2, "v_resting": 3, "decay": 4}
 
 
@@ -262,4 +283,31 @@ def attach(net, model):
     net["dt"] = model.mandatory["dt"]
     net["c_m"] = model.mandatory["c_m"]
     net["gap_conductance"] = model.mandatory["gap_conductance"]
+    return net
+
+
+def attach_nt_kinetics(net, model):
+    """Make an oracle Net (created with nt_kind=ob.NT_CUSTOM) use the generated neurotransmitter kinetics `model`."""
+    code, consts, _ = compile_program(model, _NT_SLOTS, [("statements", model.on_iteration)])
+    net.nt_model = model
+    net.arr["nt_code"], net.arr["nt_consts"] = code, consts
+    net.nt_nvars = len(model.variables)
+    nv = max(1, len(model.variables))
+    net.arr["nt_custom_vars"] = np.zeros((nv, net.n_neurons, 3), np.float32)
+    net.arr["st_nt_custom_vars"] = np.zeros((nv, max(1, net.n_cells), 3), np.float32)
+    for k, (_, default) in enumerate(model.variables):
+        net.arr["nt_custom_vars"][k] = default
+        net.arr["st_nt_custom_vars"][k] = default
+    return net
+
+
+def attach_receptor_kinetics(net, model):
+    """Make an oracle Net (created with rc_kind=ob.RC_CUSTOM) use the generated receptor kinetics `model`."""
+    code, consts, _ = compile_program(model, _RC_SLOTS, [("statements", model.on_iteration)])
+    net.rc_model = model
+    net.arr["rc_code"], net.arr["rc_consts"] = code, consts
+    net.rc_nvars = len(model.variables)
+    net.arr["rc_custom_vars"] = np.zeros((max(1, len(model.variables)), net.n_neurons, 3), np.float32)
+    for k, (_, default) in enumerate(model.variables):
+        net.arr["rc_custom_vars"][k] = default
     return net

@@ -18,6 +18,7 @@ NT_APPROX, NT_DESTEXHE, NT_DISCRETE_SPIKE, NT_EXPONENTIAL_DECAY = 0, 1, 2, 3
 RC_APPROX, RC_DESTEXHE, RC_EXPONENTIAL_DECAY = 0, 1, 2
 ST_NONE, ST_POISSON, ST_RATE, ST_PRESET, ST_BCM_POISSON = 0, 1, 2, 3, 4
 ST_CUSTOM = 100
+NT_CUSTOM = RC_CUSTOM = 100
 REFRACTORINESS_CUSTOM = 2
 
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -83,6 +84,9 @@ _FIELDS = [
     ("st_custom_code", C.POINTER(C.c_int32)), ("st_custom_consts", f32p), ("st_custom_nvars", C.c_uint32),
     ("st_custom_vars", f32p),
     ("refr_code", C.POINTER(C.c_int32)), ("refr_consts", f32p), ("refr_nvars", C.c_uint32), ("refr_vars", f32p),
+    ("nt_code", C.POINTER(C.c_int32)), ("nt_consts", f32p), ("nt_nvars", C.c_uint32), ("nt_custom_vars", f32p),
+    ("st_nt_custom_vars", f32p),
+    ("rc_code", C.POINTER(C.c_int32)), ("rc_consts", f32p), ("rc_nvars", C.c_uint32), ("rc_custom_vars", f32p),
 ]
 
 
@@ -290,6 +294,8 @@ class Net:
         self.custom_nvars = 0
         self.st_custom_nvars = 0
         self.refr_nvars = 0
+        self.nt_nvars = 0
+        self.rc_nvars = 0
         if nt_kind == NT_EXPONENTIAL_DECAY:       # decay_constant, iterate_and_spike/mod.rs:336-343
             a["nt_clearance"][...] = 2.0
             a["st_nt_clearance"][...] = 2.0

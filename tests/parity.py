@@ -161,6 +161,23 @@ def _neuron_names(net):
     return names
 
 
+def _nt_attrs(net):
+    """built-in neurotransmitter attributes that a generated kinetics variable of the same name does not replace"""
+    taken = {"neurotransmitters$" + name for name in _kinetics_names(net, "nt_model")}
+    return {o: a for o, a in NT_ATTRS.items() if a not in taken}
+
+
+def _rc_per_type(net):
+    """built-in per-type receptor attributes that a generated receptor-kinetics variable does not replace"""
+    taken = {"$r$kinetics$" + name for name in _kinetics_names(net, "rc_model")}
+    return {o: pat for o, pat in RC_PER_TYPE.items() if not any(pat.endswith(t) for t in taken)}
+
+
+def _kinetics_names(net, which):
+    model = getattr(net, which, None)
+    return [name for name, _ in model.variables] if model is not None else []
+
+
 def push_state(dn, net):
     rng = net.layout.ranges()
     for i, (first, count, is_st) in rng.items():
@@ -173,11 +190,16 @@ def push_state(dn, net):
             if net.model == ob.CUSTOM:
                 for k, (name, _) in enumerate(net.custom_model.variables):
                     dn.set_attr(i, name, np.ascontiguousarray(net["custom_vars"][k, sl]))
-            for o, a in NT_ATTRS.items():
+            for o, a in _nt_attrs(net).items():
                 dn.set_attr(i, a, net[o][sl])
+            for k, name in enumerate(_kinetics_names(net, "nt_model")):
+                dn.set_attr(i, "neurotransmitters$" + name, np.ascontiguousarray(net["nt_custom_vars"][k, sl]))
+            for k, name in enumerate(_kinetics_names(net, "rc_model")):
+                for ty, t in enumerate(TYPE_NAMES):
+                    dn.set_attr(i, f"receptors${t}$r$kinetics${name}", np.ascontiguousarray(net["rc_custom_vars"][k, sl, ty]))
             dn.set_attr(i, "receptors$flags", net["rc_flags"][sl])
             for k, t in enumerate(TYPE_NAMES):
-                for o, pat in RC_PER_TYPE.items():
+                for o, pat in _rc_per_type(net).items():
                     dn.set_attr(i, pat.replace("{T}", t), np.ascontiguousarray(net[o][sl, k]))
             dn.set_attr(i, "receptors$NMDA_mg", np.ascontiguousarray(net["rc_mg"][sl, 1]))
         else:
@@ -191,8 +213,10 @@ def push_state(dn, net):
             if getattr(net, "refr_model", None) is not None:
                 for k, (name, _) in enumerate(net.refr_model.variables):
                     dn.set_attr(i, "neural_refractoriness$" + name, np.ascontiguousarray(net["refr_vars"][k, sl]))
-            for o, a in NT_ATTRS.items():
+            for o, a in _nt_attrs(net).items():
                 dn.set_attr(i, a, net["st_" + o][sl])
+            for k, name in enumerate(_kinetics_names(net, "nt_model")):
+                dn.set_attr(i, "neurotransmitters$" + name, np.ascontiguousarray(net["st_nt_custom_vars"][k, sl]))
 
 
 def pull_state(dn, net):
@@ -217,11 +241,20 @@ def pull_state(dn, net):
                     out["custom_vars"] = np.zeros_like(net["custom_vars"])
                 for k, (name, _) in enumerate(net.custom_model.variables):
                     out["custom_vars"][k, sl] = dn.get_attr(i, name)
-            for o, a in NT_ATTRS.items():
+            for o, a in _nt_attrs(net).items():
                 put(o, sl, dn.get_attr(i, a, dtype=net[o].dtype, per_type=True))
+            for k, name in enumerate(_kinetics_names(net, "nt_model")):
+                if "nt_custom_vars" not in out:
+                    out["nt_custom_vars"] = np.zeros_like(net["nt_custom_vars"])
+                out["nt_custom_vars"][k, sl] = dn.get_attr(i, "neurotransmitters$" + name, per_type=True).reshape(-1, 3)
+            for k, name in enumerate(_kinetics_names(net, "rc_model")):
+                if "rc_custom_vars" not in out:
+                    out["rc_custom_vars"] = np.zeros_like(net["rc_custom_vars"])
+                for ty, t in enumerate(TYPE_NAMES):
+                    out["rc_custom_vars"][k, sl, ty] = dn.get_attr(i, f"receptors${t}$r$kinetics${name}")
             put("rc_flags", sl, dn.get_attr(i, "receptors$flags", dtype=np.uint32, per_type=True))
             for k, t in enumerate(TYPE_NAMES):
-                for o, pat in RC_PER_TYPE.items():
+                for o, pat in _rc_per_type(net).items():
                     if o not in out:
                         out[o] = np.zeros_like(net[o])
                     out[o][sl, k] = dn.get_attr(i, pat.replace("{T}", t))
@@ -235,8 +268,12 @@ def pull_state(dn, net):
                     out["st_custom_vars"] = np.zeros_like(net["st_custom_vars"])
                 for k, (name, _) in enumerate(net.st_custom_model.variables):
                     out["st_custom_vars"][k, sl] = dn.get_attr(i, name)
-            for o, a in NT_ATTRS.items():
+            for o, a in _nt_attrs(net).items():
                 put("st_" + o, sl, dn.get_attr(i, a, dtype=net["st_" + o].dtype, per_type=True))
+            for k, name in enumerate(_kinetics_names(net, "nt_model")):
+                if "st_nt_custom_vars" not in out:
+                    out["st_nt_custom_vars"] = np.zeros_like(net["st_nt_custom_vars"])
+                out["st_nt_custom_vars"][k, sl] = dn.get_attr(i, "neurotransmitters$" + name, per_type=True).reshape(-1, 3)
     return out
 
 

@@ -13,6 +13,8 @@ from test_modelgen import (BOOL_DSL, CURRENTS, EXPECTED_FLAG, IF_DSL, IZH_DSL, L
                            lif_reference_trace)
 from test_modelgen_channels import CALCIUM_CLAMP, MORRIS_LECAR, VOLTAGES, calcium_reference
 from test_modelgen_spike_trains import BURST_DSL, RATE_DSL, REFRACTORINESS_DSL, _mixed_network
+from test_modelgen_kinetics import (APPROXIMATE_NT, BOUNDED_RC, DESTEXHE_PAIR, built_in_approximate, chemical_network,
+                                    generated_approximate)
 
 FUNCTIONS_DSL = """
 [neuron]
@@ -42,7 +44,8 @@ def libs(snn):
     from concurrent.futures import ThreadPoolExecutor
     models = [modelgen.parse(text) for text in (LIF_NB, IZH_DSL, IF_DSL, CALCIUM_CLAMP, MORRIS_LECAR, FUNCTIONS_DSL,
                                                  BOOL_DSL)]
-    models += [modelgen.parse_description(text) for text in (RATE_DSL + REFRACTORINESS_DSL, IZH_DSL + BURST_DSL)]
+    models += [modelgen.parse_description(text) for text in (RATE_DSL + REFRACTORINESS_DSL, APPROXIMATE_NT + BOUNDED_RC,
+                                                             IZH_DSL + BURST_DSL + DESTEXHE_PAIR)]
     with ThreadPoolExecutor(max_workers=4) as pool:          # one hipcc each
         paths = list(pool.map(_lib.build_custom, models))
     return {m.name: (m, path) for m, path in zip(models, paths)}
@@ -402,19 +405,61 @@ def test_generated_rate_train_and_refractoriness_on_the_device(snn, libs):
     dn0.close()
 
 
+def test_generated_kinetics_on_the_device(snn, libs):
+    """Transmitter and receptor kinetics from descriptions (the reference's receptor_kinetics.rs block and the
+    Approximate transmitter kinetics written with the built-in's association) in a two-lattice network with Poisson
+    rows, AMPA / NMDA / GABA, STDP: bit-identical to the C oracle stepping the same descriptions, and to the default
+    library's built-in Approximate kinetics they restate."""
+    desc, lib = libs["ApproximateKinetics_BoundedReceptorKinetics"]
+    _, net = generated_approximate(ob, parity, modelgen_ref)
+    net.custom_lib = lib
+    built_in = built_in_approximate(ob, parity)
+    steps = 600
+    dn = parity.device_from_oracle(snn, net)
+    dn0 = parity.device_from_oracle(snn, built_in)
+    for d in (dn, dn0):
+        d.set_history(voltage=True, spikes=True)
+        d.run(steps // 2)
+        d.run(steps - steps // 2)
+    net.run(steps, voltage_history=True, spike_history=True)
+    ranges = net.layout.ranges()
+    for i, _, _ in net.layout.lattices:
+        first, count, _ = ranges[i]
+        assert np.array_equal(dn.spike_history(i), net.spike_history[:, first:first + count])
+        assert np.array_equal(parity.bits(dn.voltage_history(i)), parity.bits(net.voltage_history[:, first:first + count]))
+        assert np.array_equal(parity.bits(dn.voltage_history(i)), parity.bits(dn0.voltage_history(i)))
+        assert np.array_equal(parity.bits(dn.get_attr(i, "neurotransmitters$t", per_type=True)),
+                              parity.bits(dn0.get_attr(i, "neurotransmitters$t", per_type=True)))
+    parity.assert_state_equal(net, parity.pull_state(dn, net))
+    parity.assert_graph_equal(net, dn)
+    assert net.spike_history.sum() > 20 and net["rc_r"].max() > 0.01 and net["nt_t"].max() > 0.1
+    dn.close()
+    dn0.close()
+
+
 @pytest.mark.parametrize("variant", ["dense", "sparse", "sharded"])
 def test_whole_description_in_one_library_equals_the_oracle(snn, libs, variant):
-    """One library carrying all three generated blocks -- the DSL Izhikevich neuron, a bursting spike train
-    (differential equation, exp, its own bool) and a refractoriness with an extra variable -- through a network with
-    gap junctions, AMPA / NMDA synapses and STDP, on dense, sparse and shard handles, against the C oracle."""
+    """One library carrying all five generated blocks -- the DSL Izhikevich neuron, a bursting spike train
+    (differential equation, exp, its own bool), a refractoriness with an extra variable, Destexhe transmitter and
+    receptor kinetics written in the DSL -- through a network with gap junctions, AMPA / NMDA synapses and STDP, on
+    dense, sparse and shard handles, against the C oracle."""
     import torch
     from snn_amd import parallel
-    desc, lib = libs["DslIzhikevich_BurstSpikeTrain_PlateauRefractoriness"]
+    desc, lib = libs["DslIzhikevich_BurstSpikeTrain_PlateauRefractoriness_DslDestexheNeurotransmitter_DslDestexheReceptor"]
+    L = snn._lib.load(lib)
+    assert (L.snn_custom_neurotransmitter_kinetics(), L.snn_custom_receptor_kinetics()) == \
+        (b"DslDestexheNeurotransmitter", b"DslDestexheReceptor")
     lay = parity.Layout([(0, 6, 7), (2, 5, 5)], [(5, 3, 4)])
-    net = parity.make_oracle(lay, model=ob.CUSTOM, st_kind=ob.ST_CUSTOM, electrical=True, chemical=True)
+    net = parity.make_oracle(lay, model=ob.CUSTOM, st_kind=ob.ST_CUSTOM, nt_kind=ob.NT_CUSTOM, rc_kind=ob.RC_CUSTOM,
+                             electrical=True, chemical=True)
     modelgen_ref.attach(net, desc.neuron)
     modelgen_ref.attach_spike_train(net, desc.spike_train)
     modelgen_ref.attach_refractoriness(net, desc.refractoriness)
+    modelgen_ref.attach_nt_kinetics(net, desc.nt_kinetics)
+    modelgen_ref.attach_receptor_kinetics(net, desc.receptor_kinetics)
+    net["nt_custom_vars"][2] = ob.uniform_array(47, net.n_neurons * 3, 3.0, 8.0).reshape(-1, 3)         # k_p
+    net["st_nt_custom_vars"][0] = ob.uniform_array(48, net.n_cells * 3, 0.5, 1.0).reshape(-1, 3)         # t_max
+    net["rc_custom_vars"][1] = ob.uniform_array(49, net.n_neurons * 3, 0.5, 2.0).reshape(-1, 3)         # beta
     net.custom_lib = lib
     n, nc = net.n_neurons, net.n_cells
     rng = np.random.default_rng(41)
@@ -451,9 +496,11 @@ def test_whole_description_in_one_library_equals_the_oracle(snn, libs, variant):
             st = parity.pull_state(h, net)
             b, e = h.post_begin, h.post_end
             for name in ("current_voltage", "is_spiking", "last_firing_time", "nt_t", "st_current_voltage",
-                         "st_last_firing_time", "st_custom_vars", "st_nt_t"):
+                         "st_last_firing_time", "st_custom_vars", "st_nt_t", "st_nt_custom_vars"):
                 assert np.array_equal(parity.bits(st[name]), parity.bits(net[name])), name
             assert np.array_equal(parity.bits(st["custom_vars"][:, b:e]), parity.bits(net["custom_vars"][:, b:e]))
+            for name in ("rc_r", "rc_current"):
+                assert np.array_equal(parity.bits(st[name][b:e]), parity.bits(net[name][b:e])), name
             w, c = h.get_graph_rows(0, net.n_tot)
             ow = np.where(net["connections"] != 0, net["weights"], np.float32(0))
             assert np.array_equal(parity.bits(w[:, b:e]), parity.bits(ow[:, b:e]))
@@ -466,6 +513,7 @@ def test_whole_description_in_one_library_equals_the_oracle(snn, libs, variant):
     dn.run(steps - steps // 2)
     w0 = net["weights"].copy()
     net.run(steps, voltage_history=True, spike_history=True, st_voltage_history=True)
+    assert net["rc_r"].max() > 0.01 and net["nt_t"].max() > 0.1
     ranges = net.layout.ranges()
     for i, _, _ in net.layout.lattices:
         first, count, _ = ranges[i]
@@ -481,11 +529,16 @@ def test_whole_description_in_one_library_equals_the_oracle(snn, libs, variant):
 
 def test_default_library_has_no_generated_model(snn):
     L = snn._lib.load()
-    assert (L.snn_custom_model(), L.snn_custom_spike_train(), L.snn_custom_refractoriness()) == (b"", b"", b"")
+    assert (L.snn_custom_model(), L.snn_custom_spike_train(), L.snn_custom_refractoriness(),
+            L.snn_custom_neurotransmitter_kinetics(), L.snn_custom_receptor_kinetics()) == (b"",) * 5
     with pytest.raises(snn.SnnError):
         snn.DeviceNetwork(model=snn.CUSTOM)
     with pytest.raises(snn.SnnError):
         snn.DeviceNetwork(model=snn.IZHIKEVICH, spike_train=snn.ST_CUSTOM)
+    with pytest.raises(snn.SnnError):
+        snn.DeviceNetwork(model=snn.IZHIKEVICH, nt_kinetics=snn.NT_CUSTOM)
+    with pytest.raises(snn.SnnError):
+        snn.DeviceNetwork(model=snn.IZHIKEVICH, receptor_kinetics=snn.RC_CUSTOM)
     dn = snn.DeviceNetwork(model=snn.IZHIKEVICH, spike_train=snn.ST_RATE)
     dn.add_lattice(0, 2, 2)
     dn.add_spike_train_lattice(1, 1, 3)
