@@ -10,7 +10,13 @@
 #include <stddef.h>
 
 static float custom_refractoriness_effect(const snn_o_net *n, uint32_t s);
-static float program_run(const int32_t *c, const float *consts, uint32_t pc, float *slot, int apply_diffs);
+typedef struct { snn_o_net *n; uint32_t q, spiking_prev; } program_ctx;   /* the neuron an on_electrochemical_iteration runs on */
+static float program_run_ctx(const int32_t *c, const float *consts, uint32_t pc, float *slot, int apply_diffs,
+                             const program_ctx *ctx);
+static float program_run(const int32_t *c, const float *consts, uint32_t pc, float *slot, int apply_diffs)
+{
+    return program_run_ctx(c, consts, pc, slot, apply_diffs, NULL);
+}
 
 /* ---------- small helpers ---------- */
 
@@ -317,7 +323,7 @@ static inline void neuron_nt_update(snn_o_net *n, uint32_t q, float voltage, uin
 /* Ionotropic::update_receptor_kinetics + set_receptor_currents, iterate_and_spike/mod.rs:1186-1284;
  * kinetics :404-406 (Destexhe) / :435-437 (Approximate); currents :1103-1105, 1132-1137, 1164-1166.
  * A type absent from the aggregated input (count 0) leaves r untouched. */
-static inline void receptors_update(snn_o_net *n, uint32_t q, float v_old)
+static inline void receptors_kinetics(snn_o_net *n, uint32_t q)
 {
     const float dt = n->dt[q];
     for (int k = 0; k < SNN_O_K; ++k) {
@@ -347,6 +353,10 @@ static inline void receptors_update(snn_o_net *n, uint32_t q, float v_old)
             }
         }
     }
+}
+
+static inline void receptors_set_currents(snn_o_net *n, uint32_t q, float v_old)
+{
     for (int k = 0; k < SNN_O_K; ++k) {
         size_t i = (size_t)q * SNN_O_K + k;
         if (!n->rc_flags[i]) continue;
@@ -361,7 +371,13 @@ static inline void receptors_update(snn_o_net *n, uint32_t q, float v_old)
 }
 
 /* Ionotropic::get_receptor_currents, iterate_and_spike/mod.rs:1286-1304 */
-static inline float receptor_currents(const snn_o_net *n, uint32_t q)
+static inline void receptors_update(snn_o_net *n, uint32_t q, float v_old)
+{
+    receptors_kinetics(n, q);
+    receptors_set_currents(n, q, v_old);
+}
+
+static inline float receptor_currents_scaled(const snn_o_net *n, uint32_t q, float dt, float c_m)
 {
     float total = 0.0f;
     if (n->rc_flags) {
@@ -370,7 +386,12 @@ static inline float receptor_currents(const snn_o_net *n, uint32_t q)
             if (n->rc_flags[i]) total += n->rc_current[i];
         }
     }
-    return total * (n->dt[q] / n->c_m[q]);
+    return total * (dt / c_m);
+}
+
+static inline float receptor_currents(const snn_o_net *n, uint32_t q)
+{
+    return receptor_currents_scaled(n, q, n->dt[q], n->c_m[q]);
 }
 
 /* The firing-rate bookkeeping both BCM cells share (BCMIzhikevichNeuron::iterate_and_spike
@@ -609,9 +630,11 @@ static uint32_t step_leaky_izhikevich(snn_o_net *n, uint32_t q)
 enum { OP_END = 0, OP_CONST = 1, OP_LOAD = 2, OP_STORE = 3, OP_DIFF = 4, OP_NEG = 5, OP_NOT = 6, OP_ADD = 7, OP_SUB = 8,
        OP_MUL = 9, OP_DIV = 10, OP_EXP = 11, OP_EQ = 12, OP_NE = 13, OP_GE = 14, OP_LE = 15, OP_GT = 16, OP_LT = 17,
        OP_AND = 18, OP_OR = 19, OP_JZ = 20, OP_JMP = 21, OP_TANH = 22, OP_SINH = 23, OP_COSH = 24, OP_MIN = 25,
-       OP_MAX = 26, OP_HEAVISIDE = 27, OP_POWI = 28, OP_MARK = 29, OP_FLUSH = 30 };
+       OP_MAX = 26, OP_HEAVISIDE = 27, OP_POWI = 28, OP_MARK = 29, OP_FLUSH = 30, OP_RC_UPDATE = 31, OP_RC_SET = 32,
+       OP_RC_GET = 33, OP_NT_APPLY = 34 };
 
-static float program_run(const int32_t *c, const float *consts, uint32_t pc, float *slot, int apply_diffs)
+static float program_run_ctx(const int32_t *c, const float *consts, uint32_t pc, float *slot, int apply_diffs,
+                             const program_ctx *ctx)
 {
     float stack[64], diff[32];
     uint32_t diff_slot[32];
@@ -633,6 +656,12 @@ static float program_run(const int32_t *c, const float *consts, uint32_t pc, flo
         case OP_HEAVISIDE: stack[sp - 1] = (stack[sp - 1] < 0.0f) ? 0.0f : stack[sp - 1]; break;   /* lib.rs:9176 */
         case OP_POWI:  stack[sp - 1] = snn_o_powif(stack[sp - 1], c[pc++]); break;
         /* an inlined ion channel's update_current (lib.rs:4043-4063): its own `x += dx` at the end of ITS body */
+        /* the calls of an on_electrochemical_iteration, nb_macro lib.rs:2275-2293 */
+        case OP_RC_UPDATE: receptors_kinetics(ctx->n, ctx->q); break;
+        case OP_RC_SET:    receptors_set_currents(ctx->n, ctx->q, stack[--sp]); break;
+        case OP_RC_GET:    { float cm = stack[--sp], step = stack[--sp];
+                             stack[sp++] = receptor_currents_scaled(ctx->n, ctx->q, step, cm); } break;
+        case OP_NT_APPLY:  neuron_nt_update(ctx->n, ctx->q, slot[0], ctx->spiking_prev); break;
         case OP_MARK:  mark = nd; break;
         case OP_FLUSH: for (int k = mark; k < nd; ++k) slot[diff_slot[k]] += diff[k]; nd = mark; break;
         case OP_JZ:    { uint32_t target = (uint32_t)c[pc++]; if (stack[--sp] == 0.0f) pc = target; } break;
@@ -688,10 +717,16 @@ static uint32_t step_custom(snn_o_net *n, uint32_t q)
     slot[4] = n->gap_conductance[q];
     for (uint32_t k = 0; k < n->custom_nvars; ++k) slot[5 + k] = n->custom_vars[(size_t)k * nn + q];
 
-    if (n->chemical) receptors_update(n, q, slot[0]);
-    custom_run(n, n->custom_section[0], slot, 1);
-    if (n->chemical) slot[0] -= receptor_currents(n, q);
-    neuron_nt_update(n, q, slot[0], spiking_prev);
+    if (n->chemical && n->custom_has_chem) {
+        /* on_electrochemical_iteration replaces the default sequence, lib.rs:2280-2316 */
+        program_ctx ctx = { n, q, spiking_prev };
+        program_run_ctx(n->custom_code, n->custom_consts, n->custom_chem_section, slot, 1, &ctx);
+    } else {
+        if (n->chemical) receptors_update(n, q, slot[0]);
+        custom_run(n, n->custom_section[0], slot, 1);
+        if (n->chemical) slot[0] -= receptor_currents(n, q);
+        neuron_nt_update(n, q, slot[0], spiking_prev);
+    }
     uint32_t spike = custom_run(n, n->custom_section[1], slot, 0) != 0.0f;
     if (spike) custom_run(n, n->custom_section[2], slot, 0);
 

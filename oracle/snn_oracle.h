@@ -212,6 +212,9 @@ typedef struct snn_o_net {
     const float   *rc_consts;
     uint32_t rc_nvars;
     float    *rc_custom_vars;                  /* [rc_nvars][n_neurons * 3] */
+    /* SNN_O_CUSTOM with an on_electrochemical_iteration (lib.rs:2280-2316): a fourth section of custom_code that
+     * replaces the default chemical step (receptor update, on_iteration, v -= currents, transmitter update) */
+    uint32_t custom_has_chem, custom_chem_section;
 } snn_o_net;
 
 /* Step 1 of SURVEY §8(g): electrical + chemical inputs for every neuron from state S(t). */

@@ -31,6 +31,9 @@ constexpr float DEFAULT_VOLTAGE = 0.0f, DEFAULT_DT = 0.1f, DEFAULT_C_M = 1.0f, D
 __device__ __forceinline__ void on_iteration(float &, float (&)[NSTORE], float, float, float, float) {}
 __device__ __forceinline__ bool spike_detection(float, const float (&)[NSTORE], float, float, float, float) { return false; }
 __device__ __forceinline__ void on_spike(float &, float (&)[NSTORE], float, float, float, float) {}
+constexpr bool HAS_ELECTROCHEMICAL = false;
+template <class Chem>
+__device__ __forceinline__ void on_electrochemical_iteration(float &, float (&)[NSTORE], float, float, float, float, Chem &) {}
 } // namespace custom
 } // namespace snn
 #endif

@@ -98,8 +98,7 @@ struct GlobalSums {
 
 // Ionotropic::update_receptor_kinetics + set_receptor_currents (iterate_and_spike/mod.rs:1186-1284)
 template <class Sums>
-__device__ __forceinline__ void receptors_update(const UpdateArgs &a, uint32_t q, uint32_t ql,
-                                                 float v_old, float dt, const Sums &sums)
+__device__ __forceinline__ void receptors_kinetics(const UpdateArgs &a, uint32_t q, uint32_t ql, float dt, const Sums &sums)
 {
 #pragma unroll
     for (int k = 0; k < K_TYPES; ++k) {
@@ -125,6 +124,11 @@ __device__ __forceinline__ void receptors_update(const UpdateArgs &a, uint32_t q
             }
         }
     }
+}
+
+// Ionotropic::set_receptor_currents (iterate_and_spike/mod.rs:1260-1284; currents :1103-1105, 1132-1137, 1164-1166)
+__device__ __forceinline__ void receptors_set_currents(const UpdateArgs &a, uint32_t q, float v_old)
+{
 #pragma unroll
     for (int k = 0; k < K_TYPES; ++k) {
         const size_t i = (size_t)k * a.n.n_pad + q;
@@ -139,6 +143,14 @@ __device__ __forceinline__ void receptors_update(const UpdateArgs &a, uint32_t q
     }
 }
 
+template <class Sums>
+__device__ __forceinline__ void receptors_update(const UpdateArgs &a, uint32_t q, uint32_t ql,
+                                                 float v_old, float dt, const Sums &sums)
+{
+    receptors_kinetics(a, q, ql, dt, sums);
+    receptors_set_currents(a, q, v_old);
+}
+
 // Ionotropic::get_receptor_currents (iterate_and_spike/mod.rs:1286-1304)
 __device__ __forceinline__ float receptor_currents(const UpdateArgs &a, uint32_t q, float dt, float c_m)
 {
@@ -150,6 +162,19 @@ __device__ __forceinline__ float receptor_currents(const UpdateArgs &a, uint32_t
     }
     return total * (dt / c_m);
 }
+
+// What a generated on_electrochemical_iteration (nb_macro lib.rs:2280-2316) may call on its neuron
+template <class Sums>
+struct ChemicalStep {
+    const UpdateArgs &a;
+    uint32_t q, ql, spiking_prev;
+    float dt;
+    const Sums &sums;
+    __device__ __forceinline__ void update_receptor_kinetics() { receptors_kinetics(a, q, ql, dt, sums); }
+    __device__ __forceinline__ void set_receptor_currents(float voltage) { receptors_set_currents(a, q, voltage); }
+    __device__ __forceinline__ float get_receptor_currents(float step, float c_m) { return receptor_currents(a, q, step, c_m); }
+    __device__ __forceinline__ void apply_t_changes(float voltage) { neuron_nt_update(a, q, voltage, spiking_prev, dt); }
+};
 
 __device__ __forceinline__ float gate_update(float state, float alpha, float beta, float dt)
 {
@@ -186,7 +211,8 @@ __device__ __forceinline__ uint32_t update_neuron(const UpdateArgs &a, uint32_t 
             i_in = s / (cnt == 0 ? 1.0f : (float)cnt);
         }
 
-        if (a.chemical) receptors_update(a, q, ql, v, dt, sums);
+        constexpr bool own_chemical_step = MODEL == CUSTOM_MODEL && custom::HAS_ELECTROCHEMICAL;
+        if (a.chemical && !own_chemical_step) receptors_update(a, q, ql, v, dt, sums);
 
         float v_new;
         if (MODEL == 0) {            // Izhikevich
@@ -318,9 +344,14 @@ __device__ __forceinline__ uint32_t update_neuron(const UpdateArgs &a, uint32_t 
             for (int k = 0; k < custom::NVARS; ++k) x[k] = a.n.custom[k][q];
             const float g_gap = a.n.gap_conductance[q];
             float vc = v;
-            custom::on_iteration(vc, x, i_in, dt, c_m, g_gap);
-            if (a.chemical) vc -= receptor_currents(a, q, dt, c_m);
-            neuron_nt_update(a, q, vc, spiking_prev, dt);
+            if (own_chemical_step && a.chemical) {
+                ChemicalStep<Sums> chem{a, q, ql, spiking_prev, dt, sums};
+                custom::on_electrochemical_iteration(vc, x, i_in, dt, c_m, g_gap, chem);
+            } else {
+                custom::on_iteration(vc, x, i_in, dt, c_m, g_gap);
+                if (a.chemical) vc -= receptor_currents(a, q, dt, c_m);
+                neuron_nt_update(a, q, vc, spiking_prev, dt);
+            }
             spike = custom::spike_detection(vc, x, i_in, dt, c_m, g_gap) ? 1u : 0u;
             if (spike) custom::on_spike(vc, x, i_in, dt, c_m, g_gap);
             v_new = vc;

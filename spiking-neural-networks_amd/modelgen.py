@@ -40,6 +40,11 @@ the reference tests against is build_test/nb_macro/tests/lif_reference.rs):
     left-associative: pest_ast/mod.rs:183-186; a leading unary minus of the base ends up OUTSIDE the power, see
     _power).
 
+  * `on_electrochemical_iteration:` (lib.rs:2280-2316) replaces the default chemical step by the listed statements:
+    `receptors.update_receptor_kinetics(t, dt)`, `receptors.set_receptor_currents(<voltage>, dt)`,
+    `receptors.get_receptor_currents(<dt>, <c_m>)` (an expression: total current * (dt / c_m)),
+    `synaptic_neurotransmitters.apply_t_changes()`, assignments and differential equations (applied after the last
+    statement); spike handling follows as in the electrical step;
   * bool variables (`flag = false`, tests/bool_vars.rs): stored as 1.0 / 0.0 in a float plane (set them to 0 or 1
     only), typed like the generated Rust -- conditions, `!`, `&&`, `||` take bools, arithmetic and comparisons take
     numbers, and a description rustc would refuse for mixing them is refused here.
@@ -59,7 +64,7 @@ the reference tests against is build_test/nb_macro/tests/lif_reference.rs):
 `hip_source(model)` emits the header that csrc/snn_custom_model.hpp includes when the library is compiled with
 -DSNN_CUSTOM_MODEL_HEADER; `_lib.build_custom(model)` compiles such a library.  Not supported (rejected with a
 message): [receptors] blocks, `^` with a non-literal or
-fractional exponent, sin / cos / tan / isnan, on_electrochemical_iteration, and `continuous()` spike detection --
+fractional exponent, sin / cos / tan / isnan, and `continuous()` spike detection --
 the code the reference generates for it reads a `last_voltage` that is never defined (lib.rs:984-990), so there is
 no behaviour to match.
 """
@@ -173,6 +178,10 @@ class _Parser:
                         args.append(self.expr())
                 if self.take() != ("op", ")"):
                     raise ModelError("missing ')' after function arguments")
+                if val == "receptors.get_receptor_currents":
+                    if len(args) != 2:
+                        raise ModelError("receptors.get_receptor_currents takes (dt, c_m)")
+                    return ("rc_get", args[0], args[1])
                 if val not in FUNCTIONS:
                     raise ModelError(f"function {val}() is not supported ({', '.join(sorted(FUNCTIONS))})")
                 if len(args) != FUNCTIONS[val]:
@@ -280,6 +289,7 @@ class NeuronModel:
         self.mandatory = dict(MANDATORY)    # defaults of current_voltage / dt / c_m / gap_conductance
         self.on_iteration, self.spike_detection, self.on_spike = on_iteration, spike_detection, on_spike
         self.ion_channels = []              # [(instance name, channel type name)]
+        self.on_electrochemical_iteration = None   # statements replacing the default chemical step (lib.rs:2280-2316)
         self.bools = set()                  # variables declared true / false: stored as 1.0 / 0.0
 
 
@@ -405,6 +415,8 @@ def _map_expr(e, rename):
         return ("call", e[1], [_map_expr(a, rename) for a in e[2]])
     if kind == "powi":
         return ("powi", _map_expr(e[1], rename), e[2])
+    if kind == "rc_get":
+        return ("rc_get", _map_expr(e[1], rename), _map_expr(e[2], rename))
     return ("bin", e[1], _map_expr(e[2], rename), _map_expr(e[3], rename))
 
 
@@ -724,7 +736,7 @@ def parse(text):
 
 def _parse_neuron(body, channels):
     sections, name = _sections(body, ("type", "vars", "on_spike", "spike_detection", "on_iteration",
-                                      "ion_channels"))
+                                      "on_electrochemical_iteration", "ion_channels"))
     for need in ("on_iteration", "spike_detection"):
         if not sections.get(need):
             raise ModelError(f"section '{need}' is missing")
@@ -773,13 +785,31 @@ def _parse_neuron(body, channels):
             if st[0] == "if":
                 out.append(("if", [(_map_expr(c, rename), convert(b, "an [if] branch")) for c, b in st[1]],
                             None if st[2] is None else convert(st[2], "an [if] branch")))
+            elif st[0] == "struct_call" and where == "on_electrochemical_iteration" and \
+                    st[1] in ("receptors", "synaptic_neurotransmitters"):
+                # lib.rs:2275-2293: the calls the generated iterate_with_neurotransmitter_and_spike knows
+                _, inst, method, args = st
+                if (inst, method) == ("receptors", "update_receptor_kinetics"):
+                    if args != [("var", "t"), ("var", "dt")]:
+                        raise ModelError("receptors.update_receptor_kinetics takes (t, dt)")
+                    out.append(("rc_update",))
+                elif (inst, method) == ("receptors", "set_receptor_currents"):
+                    if len(args) != 2 or args[1] != ("var", "dt"):
+                        raise ModelError("receptors.set_receptor_currents takes (voltage, dt)")
+                    out.append(("rc_set", _map_expr(args[0], rename)))
+                elif (inst, method) == ("synaptic_neurotransmitters", "apply_t_changes"):
+                    if args:
+                        raise ModelError("synaptic_neurotransmitters.apply_t_changes takes no arguments")
+                    out.append(("nt_apply",))
+                else:
+                    raise ModelError(f"cannot call {inst}.{method}()")
             elif st[0] == "struct_call":
                 _, inst, method, args = st
                 if inst not in instances or method != "update_current":
                     raise ModelError(f"cannot call {inst}.{method}(): only <ion channel>.update_current(...)")
                 out.append(_inline_channel(inst, instances[inst], [_map_expr(a, rename) for a in args]))
             else:
-                if st[0] == "diff" and where != "on_iteration":
+                if st[0] == "diff" and where not in ("on_iteration", "on_electrochemical_iteration"):
                     raise ModelError(f"differential equations belong to the top level of on_iteration, not {where}")
                 tgt = st[1].replace(".", "$")
                 if tgt not in known - {"i"} or tgt in ("dt", "c_m", "gap_conductance"):
@@ -790,8 +820,27 @@ def _parse_neuron(body, channels):
     model.spike_detection = _map_expr(parse_expr(detect), rename)
     model.on_iteration = convert(_block(sections["on_iteration"])[0], "on_iteration")
     model.on_spike = convert(_block(sections.get("on_spike", []))[0], "on_spike")
-    _check_types(model.on_iteration + model.on_spike, model.bools, condition=model.spike_detection)
+    model.on_electrochemical_iteration = None
+    if sections.get("on_electrochemical_iteration"):
+        model.on_electrochemical_iteration = convert(_block(sections["on_electrochemical_iteration"])[0],
+                                                     "on_electrochemical_iteration")
+    for where, stmts in (("on_iteration", model.on_iteration), ("on_spike", model.on_spike)):
+        for st in _walk(stmts):
+            exprs = [c for c, _ in st[1]] if st[0] == "if" else [st[-1]] if st[0] in ("diff", "assign") else []
+            if any(_has_rc_get(e) for e in exprs):
+                raise ModelError(f"receptors.get_receptor_currents belongs to on_electrochemical_iteration, not {where}")
+    if _has_rc_get(model.spike_detection):
+        raise ModelError("receptors.get_receptor_currents belongs to on_electrochemical_iteration, not spike_detection")
+    _check_types(model.on_iteration + model.on_spike + (model.on_electrochemical_iteration or []), model.bools,
+                 condition=model.spike_detection)
     return model
+
+
+def _has_rc_get(e):
+    if e[0] == "rc_get":
+        return True
+    return any(_has_rc_get(sub) for sub in e[1:] if isinstance(sub, tuple)) or \
+        any(_has_rc_get(x) for sub in e[1:] if isinstance(sub, list) for x in sub)
 
 
 def _check_types(stmts, bools, condition=None, number=None):
@@ -806,6 +855,10 @@ def _check_types(stmts, bools, condition=None, number=None):
             return "bool" if e[1] in bools else "number"
         if k == "neg" or k == "powi":
             need(e[1], "number", "arithmetic")
+            return "number"
+        if k == "rc_get":
+            need(e[1], "number", "get_receptor_currents")
+            need(e[2], "number", "get_receptor_currents")
             return "number"
         if k == "not":
             need(e[1], "bool", "'!'")
@@ -844,6 +897,8 @@ def _check_types(stmts, bools, condition=None, number=None):
             if st[1] in bools:
                 raise ModelError(f"d{st[1]}/dt: {st[1]} is a bool")
             need(st[2], "number", "a differential equation")
+        elif st[0] == "rc_set":
+            need(st[1], "number", "set_receptor_currents")
         elif st[0] == "assign":
             want = "bool" if st[1] in bools else "number"
             if want == "bool" and st[2] != "=":
@@ -879,6 +934,8 @@ def _hip_expr(e, index):
         return f"{fn}({', '.join(_hip_expr(a, index) for a in e[2])})"
     if kind == "powi":
         return f"powif_portable({_hip_expr(e[1], index)}, {e[2]})"
+    if kind == "rc_get":
+        return f"chem.get_receptor_currents({_hip_expr(e[1], index)}, {_hip_expr(e[2], index)})"
     _, op, lhs, rhs = e
     return f"({_hip_expr(lhs, index)} {op} {_hip_expr(rhs, index)})"
 
@@ -899,6 +956,15 @@ def _hip_statements(stmts, index, with_diffs, indent="    "):
             lines.append(f"{indent}{{")
             lines.append(_hip_statements(s[1], index, True, indent + "    "))
             lines.append(f"{indent}}}")
+            continue
+        if s[0] == "rc_update":
+            lines.append(f"{indent}chem.update_receptor_kinetics();")
+            continue
+        if s[0] == "rc_set":
+            lines.append(f"{indent}chem.set_receptor_currents({_hip_expr(s[1], index)});")
+            continue
+        if s[0] == "nt_apply":
+            lines.append(f"{indent}chem.apply_t_changes(v);")
             continue
         target = index["$base"][s[1]] if s[1] in index["$base"] else f"x[{index[s[1]]}]"
         if s[0] == "diff":
@@ -948,6 +1014,14 @@ __device__ __forceinline__ bool spike_detection(float v, const float (&x)[NSTORE
 __device__ __forceinline__ void on_spike(float &v, float (&x)[NSTORE], float i_in, float dt, float c_m, float g_gap)
 {{
 {_hip_statements(model.on_spike, index, False)}
+}}
+// on_electrochemical_iteration (nb_macro lib.rs:2280-2316): `chem` = the receptors / transmitters of this neuron
+constexpr bool HAS_ELECTROCHEMICAL = {'true' if model.on_electrochemical_iteration is not None else 'false'};
+template <class Chem>
+__device__ __forceinline__ void on_electrochemical_iteration(float &v, float (&x)[NSTORE], float i_in, float dt, float c_m,
+                                                             float g_gap, Chem &chem)
+{{
+{_hip_statements(model.on_electrochemical_iteration or [], index, True)}
 }}
 }} // namespace custom
 """

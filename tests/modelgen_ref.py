@@ -147,7 +147,7 @@ def make_step(model):
 # ---- stack program for the C oracle (oracle/snn_oracle.c::custom_run) -------------------------------------
 _OPS = dict(END=0, CONST=1, LOAD=2, STORE=3, DIFF=4, NEG=5, NOT=6, ADD=7, SUB=8, MUL=9, DIV=10, EXP=11, EQ=12, NE=13,
             GE=14, LE=15, GT=16, LT=17, AND=18, OR=19, JZ=20, JMP=21, TANH=22, SINH=23, COSH=24, MIN=25, MAX=26,
-            HEAVISIDE=27, POWI=28, MARK=29, FLUSH=30)
+            HEAVISIDE=27, POWI=28, MARK=29, FLUSH=30, RC_UPDATE=31, RC_SET=32, RC_GET=33, NT_APPLY=34)
 _BIN = {"+": "ADD", "-": "SUB", "*": "MUL", "/": "DIV", "==": "EQ", "!=": "NE", ">=": "GE", "<=": "LE", ">": "GT",
         "<": "LT", "&&": "AND", "||": "OR"}
 _BASE_SLOTS = {"v": 0, "i": 1, "dt": 2, "c_m": 3, "gap_conductance": 4}
@@ -184,6 +184,10 @@ def compile_program(model, base=None, blocks=None):
         elif kind == "powi":
             emit_expr(e[1])
             code.extend([_OPS["POWI"], e[2]])
+        elif kind == "rc_get":
+            emit_expr(e[1])
+            emit_expr(e[2])
+            code.append(_OPS["RC_GET"])
         else:
             emit_expr(e[2])
             emit_expr(e[3])
@@ -205,6 +209,13 @@ def compile_program(model, base=None, blocks=None):
                     emit_statements(s[2])
                 for e in exits:
                     code[e] = len(code)
+                continue
+            if s[0] in ("rc_update", "nt_apply"):
+                code.append(_OPS["RC_UPDATE" if s[0] == "rc_update" else "NT_APPLY"])
+                continue
+            if s[0] == "rc_set":
+                emit_expr(s[1])
+                code.append(_OPS["RC_SET"])
                 continue
             if s[0] == "scope":
                 code.append(_OPS["MARK"])
@@ -228,6 +239,8 @@ def compile_program(model, base=None, blocks=None):
     if blocks is None:
         blocks = [("statements", model.on_iteration), ("expression", model.spike_detection),
                   ("statements", model.on_spike)]
+        if getattr(model, "on_electrochemical_iteration", None) is not None:
+            blocks.append(("statements", model.on_electrochemical_iteration))
     starts = []
     for what, item in blocks:
         if what == "statements":
@@ -274,7 +287,9 @@ def attach(net, model):
     code, consts, sections = compile_program(model)
     net.custom_model = model
     net.arr["custom_code"], net.arr["custom_consts"] = code, consts
-    net.custom_section = sections
+    net.custom_section = sections[:3]
+    net.custom_has_chem = int(len(sections) == 4)
+    net.custom_chem_section = int(sections[3]) if len(sections) == 4 else 0
     net.custom_nvars = len(model.variables)
     net.arr["custom_vars"] = np.zeros((max(1, len(model.variables)), net.n_neurons), np.float32)
     for k, (_, default) in enumerate(model.variables):

@@ -87,6 +87,7 @@ _FIELDS = [
     ("nt_code", C.POINTER(C.c_int32)), ("nt_consts", f32p), ("nt_nvars", C.c_uint32), ("nt_custom_vars", f32p),
     ("st_nt_custom_vars", f32p),
     ("rc_code", C.POINTER(C.c_int32)), ("rc_consts", f32p), ("rc_nvars", C.c_uint32), ("rc_custom_vars", f32p),
+    ("custom_has_chem", C.c_uint32), ("custom_chem_section", C.c_uint32),
 ]
 
 
@@ -295,6 +296,8 @@ class Net:
         self.st_custom_nvars = 0
         self.refr_nvars = 0
         self.nt_nvars = 0
+        self.custom_has_chem = 0
+        self.custom_chem_section = 0
         self.rc_nvars = 0
         if nt_kind == NT_EXPONENTIAL_DECAY:       # decay_constant, iterate_and_spike/mod.rs:336-343
             a["nt_clearance"][...] = 2.0

@@ -13,7 +13,8 @@ from test_modelgen import (BOOL_DSL, CURRENTS, EXPECTED_FLAG, IF_DSL, IZH_DSL, L
                            lif_reference_trace)
 from test_modelgen_channels import CALCIUM_CLAMP, MORRIS_LECAR, VOLTAGES, calcium_reference
 from test_modelgen_spike_trains import BURST_DSL, RATE_DSL, REFRACTORINESS_DSL, _mixed_network
-from test_modelgen_kinetics import (APPROXIMATE_NT, BOUNDED_RC, DESTEXHE_PAIR, built_in_approximate, chemical_network,
+from test_modelgen_kinetics import (APPROXIMATE_NT, BOUNDED_RC, DESTEXHE_PAIR, ELECTROCHEMICAL_REF, RESTATED_STEP,
+                                    built_in_approximate, chemical_network, custom_chemical_network,
                                     generated_approximate)
 
 FUNCTIONS_DSL = """
@@ -43,7 +44,7 @@ def libs(snn):
     from snn_amd import _lib, modelgen
     from concurrent.futures import ThreadPoolExecutor
     models = [modelgen.parse(text) for text in (LIF_NB, IZH_DSL, IF_DSL, CALCIUM_CLAMP, MORRIS_LECAR, FUNCTIONS_DSL,
-                                                 BOOL_DSL)]
+                                                 BOOL_DSL, ELECTROCHEMICAL_REF, RESTATED_STEP)]
     models += [modelgen.parse_description(text) for text in (RATE_DSL + REFRACTORINESS_DSL, APPROXIMATE_NT + BOUNDED_RC,
                                                              IZH_DSL + BURST_DSL + DESTEXHE_PAIR)]
     with ThreadPoolExecutor(max_workers=4) as pool:          # one hipcc each
@@ -435,6 +436,34 @@ def test_generated_kinetics_on_the_device(snn, libs):
     assert net.spike_history.sum() > 20 and net["rc_r"].max() > 0.01 and net["nt_t"].max() > 0.1
     dn.close()
     dn0.close()
+
+
+@pytest.mark.parametrize("which", ["ElectroChemicalIntegrateAndFire", "RestatedStep"])
+@pytest.mark.parametrize("variant", ["dense", "sparse", "electrical_only"])
+def test_on_electrochemical_iteration_equals_the_oracle(snn, libs, which, variant):
+    """Neurons with their own chemical step (the reference's gpu_custom_electrochemical.rs model; the default sequence
+    written out by hand) in a network with Poisson rows and AMPA / NMDA / GABA synapses: raster, voltages, receptor and
+    transmitter state bit-identical to the C oracle; with transmission off the plain on_iteration runs."""
+    model, lib = libs[which]
+    text = ELECTROCHEMICAL_REF if which == "ElectroChemicalIntegrateAndFire" else RESTATED_STEP
+    _, net = custom_chemical_network(ob, parity, modelgen_ref, text, chemical=(variant != "electrical_only"))
+    net.custom_lib = lib
+    steps = 400
+    dn = parity.device_from_oracle(snn, net, csr=(variant == "sparse"))
+    dn.set_history(voltage=True, spikes=True)
+    dn.run(steps // 2)
+    dn.run(steps - steps // 2)
+    net.run(steps, voltage_history=True, spike_history=True)
+    ranges = net.layout.ranges()
+    for i, _, _ in net.layout.lattices:
+        first, count, _ = ranges[i]
+        assert np.array_equal(dn.spike_history(i), net.spike_history[:, first:first + count])
+        assert np.array_equal(parity.bits(dn.voltage_history(i)), parity.bits(net.voltage_history[:, first:first + count]))
+    parity.assert_state_equal(net, parity.pull_state(dn, net))
+    assert np.isfinite(net.voltage_history).all()
+    if variant != "electrical_only":
+        assert net["rc_r"].max() > 0.01 and np.abs(net["rc_current"]).max() > 0.0
+    dn.close()
 
 
 @pytest.mark.parametrize("variant", ["dense", "sparse", "sharded"])

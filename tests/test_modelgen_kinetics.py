@@ -193,3 +193,120 @@ def test_kinetics_errors_name_the_problem(text, needle):
     with pytest.raises(modelgen.ModelError) as e:
         modelgen.parse_description(text)
     assert needle in str(e.value), (needle, str(e.value))
+
+
+# ---- on_electrochemical_iteration ------------------------------------------------------------------------
+ELECTROCHEMICAL_REF = """
+[neuron]
+    type: ElectroChemicalIntegrateAndFire
+    vars: e = 0, v_reset = -75, v_th = -55, modifier = 2
+    on_spike:
+        v = v_reset
+    spike_detection: v >= v_th
+    on_iteration:
+        dv/dt = -(v - e) + i
+    on_electrochemical_iteration:
+        receptors.update_receptor_kinetics(t, dt)
+        receptors.set_receptor_currents(v, dt)
+        dv/dt = -(v - e) + i
+        v = (modifier * -receptors.get_receptor_currents(dt, (modifier / 2) * c_m)) + v
+        synaptic_neurotransmitters.apply_t_changes()
+[end]"""          # build_test/nb_macro/tests/gpu_custom_electrochemical.rs:10-26, restated as data
+
+# the default chemical step (lib.rs:2317-2333: receptor update, on_iteration, v -= currents, transmitter update) written
+# out by hand, next to the same neuron without the section
+PLAIN_STEP = """
+[neuron]
+    type: PlainStep
+    vars: e = -48, v_reset = -70, v_th = -50, current_voltage = -65, c_m = 2, gap_conductance = 1
+    on_spike:
+        v = v_reset
+    spike_detection: v >= v_th
+    on_iteration:
+        v = v + (-(v - e) + i) * dt
+[end]"""
+RESTATED_STEP = PLAIN_STEP.replace("PlainStep", "RestatedStep").replace("[end]", """    on_electrochemical_iteration:
+        receptors.update_receptor_kinetics(t, dt)
+        receptors.set_receptor_currents(v, dt)
+        v = v + (-(v - e) + i) * dt
+        v -= receptors.get_receptor_currents(dt, c_m)
+        synaptic_neurotransmitters.apply_t_changes()
+[end]""")
+
+
+def custom_chemical_network(ob, parity, modelgen_ref, text, electrical=True, chemical=True):
+    m = modelgen.parse(text)
+    net = chemical_network(ob, parity, ob.NT_APPROX, ob.RC_APPROX, model=ob.CUSTOM)
+    net.electrical, net.chemical = int(electrical), int(chemical)
+    modelgen_ref.attach(net, m)
+    net["current_voltage"] = ob.uniform_array(80, net.n_neurons, -68.0, -52.0)
+    net["do_plasticity"] = 0            # these fast-firing leaky neurons drive STDP weights (and with them t) without bound
+    return m, net
+
+
+def test_electrochemical_section_is_parsed_and_emitted():
+    m = modelgen.parse(ELECTROCHEMICAL_REF)
+    kinds = [st[0] for st in m.on_electrochemical_iteration]
+    assert kinds == ["rc_update", "rc_set", "diff", "assign", "nt_apply"]
+    src = modelgen.hip_source(m)
+    assert "constexpr bool HAS_ELECTROCHEMICAL = true;" in src
+    body = src[src.index("void on_electrochemical_iteration"):]
+    order = [body.index(t) for t in ("chem.update_receptor_kinetics();", "chem.set_receptor_currents(v);",
+                                     "const float d_v", "chem.get_receptor_currents(dt, ((x[3] / 2.0f) * c_m))",
+                                     "chem.apply_t_changes(v);", "v += d_v;")]
+    assert order == sorted(order)                      # the differential equation is applied after the last statement
+    assert "HAS_ELECTROCHEMICAL = false" in modelgen.hip_source(modelgen.parse(PLAIN_STEP))
+
+
+def test_restated_default_step_equals_the_default_step():
+    """With transmission on, a neuron whose on_electrochemical_iteration spells out the default sequence is
+    bit-identical to the same neuron without the section; with transmission off the section is not used at all."""
+    import modelgen_ref
+    import oracle_binding as ob
+    import parity
+    for chemical in (True, False):
+        runs = []
+        for text in (PLAIN_STEP, RESTATED_STEP):
+            _, net = custom_chemical_network(ob, parity, modelgen_ref, text, chemical=chemical)
+            net.run(500, voltage_history=True, spike_history=True)
+            runs.append(net)
+        a, b = runs
+        assert a.custom_has_chem == 0 and b.custom_has_chem == 1
+        assert a.spike_history.sum() > 20
+        assert np.array_equal(a.spike_history, b.spike_history)
+        assert np.array_equal(a.voltage_history.view(np.uint32), b.voltage_history.view(np.uint32))
+        for name in ("nt_t", "rc_r", "rc_current", "weights"):
+            assert np.array_equal(a[name].view(np.uint32), b[name].view(np.uint32)), name
+        if chemical:
+            assert a["rc_r"].max() > 0.01 and np.abs(a["rc_current"]).max() > 0.0
+
+
+def test_reference_electrochemical_model_differs_from_its_default_step():
+    """gpu_custom_electrochemical.rs's model doubles the receptor current's effect (modifier = 2 with c_m scaled by
+    modifier / 2): its chemical run is NOT the run of the same neuron without the section -- the section is in use."""
+    import modelgen_ref
+    import oracle_binding as ob
+    import parity
+    _, with_section = custom_chemical_network(ob, parity, modelgen_ref, ELECTROCHEMICAL_REF)
+    _, without = custom_chemical_network(
+        ob, parity, modelgen_ref, ELECTROCHEMICAL_REF[:ELECTROCHEMICAL_REF.index("    on_electrochemical_iteration:")] + "[end]")
+    for net in (with_section, without):
+        net.run(300, voltage_history=True)
+    assert np.isfinite(with_section.voltage_history).all()
+    assert not np.array_equal(with_section.voltage_history, without.voltage_history)
+
+
+@pytest.mark.parametrize("text,needle", [
+    (ELECTROCHEMICAL_REF.replace("update_receptor_kinetics(t, dt)", "update_receptor_kinetics(dt)"), "takes (t, dt)"),
+    (ELECTROCHEMICAL_REF.replace("set_receptor_currents(v, dt)", "set_receptor_currents(v)"), "takes (voltage, dt)"),
+    (ELECTROCHEMICAL_REF.replace("apply_t_changes()", "apply_t_changes(v)"), "takes no arguments"),
+    (ELECTROCHEMICAL_REF.replace("receptors.set_receptor_currents(v, dt)", "receptors.reset()"), "cannot call receptors.reset()"),
+    (ELECTROCHEMICAL_REF.replace("        dv/dt = -(v - e) + i\n    on_electrochemical",
+                                 "        dv/dt = -(v - e) + i - receptors.get_receptor_currents(dt, c_m)\n    on_electrochemical"),
+     "belongs to on_electrochemical_iteration"),
+    (PLAIN_STEP.replace("v = v + (-(v - e) + i) * dt", "receptors.update_receptor_kinetics(t, dt)"), "cannot call"),
+])
+def test_electrochemical_errors_name_the_problem(text, needle):
+    with pytest.raises(modelgen.ModelError) as e:
+        modelgen.parse(text)
+    assert needle in str(e.value), (needle, str(e.value))
