@@ -93,6 +93,9 @@ float snn_o_tanhf_export(float x) { return snn_o_tanhf(x); }
 float snn_o_sinhf_export(float x) { return snn_o_sinhf(x); }
 float snn_o_coshf_export(float x) { return snn_o_coshf(x); }
 float snn_o_powif_export(float x, int n) { return snn_o_powif(x, n); }
+float snn_o_sinf_export(float x) { return snn_o_sinf(x); }
+float snn_o_cosf_export(float x) { return snn_o_cosf(x); }
+float snn_o_tanf_export(float x) { return snn_o_tanf(x); }
 
 /* ---------- synthetic data ---------- */
 
@@ -631,7 +634,7 @@ enum { OP_END = 0, OP_CONST = 1, OP_LOAD = 2, OP_STORE = 3, OP_DIFF = 4, OP_NEG 
        OP_MUL = 9, OP_DIV = 10, OP_EXP = 11, OP_EQ = 12, OP_NE = 13, OP_GE = 14, OP_LE = 15, OP_GT = 16, OP_LT = 17,
        OP_AND = 18, OP_OR = 19, OP_JZ = 20, OP_JMP = 21, OP_TANH = 22, OP_SINH = 23, OP_COSH = 24, OP_MIN = 25,
        OP_MAX = 26, OP_HEAVISIDE = 27, OP_POWI = 28, OP_MARK = 29, OP_FLUSH = 30, OP_RC_UPDATE = 31, OP_RC_SET = 32,
-       OP_RC_GET = 33, OP_NT_APPLY = 34 };
+       OP_RC_GET = 33, OP_NT_APPLY = 34, OP_SIN = 35, OP_COS = 36, OP_TAN = 37, OP_ISNAN = 38 };
 
 static float program_run_ctx(const int32_t *c, const float *consts, uint32_t pc, float *slot, int apply_diffs,
                              const program_ctx *ctx)
@@ -653,6 +656,10 @@ static float program_run_ctx(const int32_t *c, const float *consts, uint32_t pc,
         case OP_TANH:  stack[sp - 1] = snn_o_tanhf(stack[sp - 1]); break;
         case OP_SINH:  stack[sp - 1] = snn_o_sinhf(stack[sp - 1]); break;
         case OP_COSH:  stack[sp - 1] = snn_o_coshf(stack[sp - 1]); break;
+        case OP_SIN:   stack[sp - 1] = snn_o_sinf(stack[sp - 1]); break;
+        case OP_COS:   stack[sp - 1] = snn_o_cosf(stack[sp - 1]); break;
+        case OP_TAN:   stack[sp - 1] = snn_o_tanf(stack[sp - 1]); break;
+        case OP_ISNAN: stack[sp - 1] = (stack[sp - 1] != stack[sp - 1]) ? 1.0f : 0.0f; break;
         case OP_HEAVISIDE: stack[sp - 1] = (stack[sp - 1] < 0.0f) ? 0.0f : stack[sp - 1]; break;   /* lib.rs:9176 */
         case OP_POWI:  stack[sp - 1] = snn_o_powif(stack[sp - 1], c[pc++]); break;
         /* an inlined ion channel's update_current (lib.rs:4043-4063): its own `x += dx` at the end of ITS body */

@@ -127,6 +127,64 @@ static inline float snn_o_coshf(float x)
     return (float)((e + 1.0 / e) * 0.5);
 }
 
+/* sin / cos / tan of generated models (nb_macro lib.rs:9164-9175 forward to the platform libm): Cody-Waite reduction */
+/* by pi/2 in binary64 (k * PIO2_HI is exact for |k| < 2^20, i.e. |x| < 1.6e6; beyond that the result stays */
+/* deterministic but loses accuracy), Taylor polynomials on [-pi/4, pi/4], one rounding to binary32. */
+static inline void snn_o_sincos_core(double x, double *sp, double *cp)
+{
+    const double two_over_pi = 6.36619772367581382433e-01;
+    const double pio2_hi = 1.57079632673412561417e+00;     /* first 33 bits of pi/2 */
+    const double pio2_lo = 6.07710050650619224932e-11;     /* pi/2 - pio2_hi */
+    const double shift = 6755399441055744.0;               /* 1.5 * 2^52 */
+    const double kd = (x * two_over_pi + shift) - shift;
+    const double r = (x - kd * pio2_hi) - kd * pio2_lo;
+    const double z = r * r;
+    double ps = -1.0 / 355687428096000.0;                  /* -1/17! */
+    ps = ps * z + 1.0 / 1307674368000.0;                   /* 1/15! */
+    ps = ps * z - 1.0 / 6227020800.0;                      /* -1/13! */
+    ps = ps * z + 1.0 / 39916800.0;                        /* 1/11! */
+    ps = ps * z - 1.0 / 362880.0;                          /* -1/9! */
+    ps = ps * z + 1.0 / 5040.0;                            /* 1/7! */
+    ps = ps * z - 1.0 / 120.0;                             /* -1/5! */
+    ps = ps * z + 1.0 / 6.0;                               /* 1/3!  (sign folded below) */
+    const double sr = r - (r * z) * ps;
+    double pc = 1.0 / 20922789888000.0;                    /* 1/16! */
+    pc = pc * z - 1.0 / 87178291200.0;                     /* -1/14! */
+    pc = pc * z + 1.0 / 479001600.0;                       /* 1/12! */
+    pc = pc * z - 1.0 / 3628800.0;                         /* -1/10! */
+    pc = pc * z + 1.0 / 40320.0;                           /* 1/8! */
+    pc = pc * z - 1.0 / 720.0;                             /* -1/6! */
+    pc = pc * z + 1.0 / 24.0;                              /* 1/4! */
+    pc = pc * z - 0.5;                                     /* -1/2! */
+    const double cr = pc * z + 1.0;
+    const long long q = (long long)kd & 3ll;
+    *sp = (q == 0) ? sr : (q == 1) ? cr : (q == 2) ? -sr : -cr;
+    *cp = (q == 0) ? cr : (q == 1) ? -sr : (q == 2) ? -cr : sr;
+}
+static inline float snn_o_sinf(float x)
+{
+    if (!(x == x) || x - x != 0.0f) return x - x;          /* NaN, +-inf -> NaN */
+    if (x == 0.0f) return x;                               /* keeps the sign of zero */
+    double s, c;
+    snn_o_sincos_core((double)x, &s, &c);
+    return (float)s;
+}
+static inline float snn_o_cosf(float x)
+{
+    if (!(x == x) || x - x != 0.0f) return x - x;
+    double s, c;
+    snn_o_sincos_core((double)x, &s, &c);
+    return (float)c;
+}
+static inline float snn_o_tanf(float x)
+{
+    if (!(x == x) || x - x != 0.0f) return x - x;
+    if (x == 0.0f) return x;                               /* keeps the sign of zero */
+    double s, c;
+    snn_o_sincos_core((double)x, &s, &c);
+    return (float)(s / c);
+}
+
 /* x.powf(n), n an integer literal: left-to-right product in binary64, one rounding */
 static inline float snn_o_powif(float x, int n)
 {

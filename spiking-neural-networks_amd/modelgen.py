@@ -35,8 +35,8 @@ the reference tests against is build_test/nb_macro/tests/lif_reference.rs):
     to a gate (lib.rs:3967-3997) -- and reads `name.current`, `name.var`, `name.gate.state`.  The generator inlines
     the channel body at the call (the channel's own `x += dx` at the end of ITS body) and stores its fields as the
     neuron variables `name$var`, `name$gate$alpha|beta|state`, `name$current` (the reference's attribute names);
-  * functions exp, tanh, sinh, cosh, min, max, heaviside (lib.rs:9139-9178; heaviside as written there:
-    x < 0 -> 0, else x) and `base ^ n` with an integer literal n (`powf`; binds tighter than * and /,
+  * functions exp, tanh, sinh, cosh, sin, cos, tan, min, max, heaviside, isnan (lib.rs:9139-9182; heaviside as
+    written there: x < 0 -> 0, else x; isnan yields a bool) and `base ^ n` with an integer literal n (`powf`; binds tighter than * and /,
     left-associative: pest_ast/mod.rs:183-186; a leading unary minus of the base ends up OUTSIDE the power, see
     _power).
 
@@ -64,7 +64,7 @@ the reference tests against is build_test/nb_macro/tests/lif_reference.rs):
 `hip_source(model)` emits the header that csrc/snn_custom_model.hpp includes when the library is compiled with
 -DSNN_CUSTOM_MODEL_HEADER; `_lib.build_custom(model)` compiles such a library.  Not supported (rejected with a
 message): [receptors] blocks, `^` with a non-literal or
-fractional exponent, sin / cos / tan / isnan, and `continuous()` spike detection --
+fractional exponent, and `continuous()` spike detection --
 the code the reference generates for it reads a `last_voltage` that is never defined (lib.rs:984-990), so there is
 no behaviour to match.
 """
@@ -73,7 +73,8 @@ import struct
 
 MANDATORY = {"current_voltage": 0.0, "dt": 0.1, "c_m": 1.0, "gap_conductance": 10.0}
 MAX_VARS = 32
-FUNCTIONS = {"exp": 1, "tanh": 1, "sinh": 1, "cosh": 1, "heaviside": 1, "min": 2, "max": 2}
+FUNCTIONS = {"exp": 1, "tanh": 1, "sinh": 1, "cosh": 1, "sin": 1, "cos": 1, "tan": 1, "heaviside": 1, "isnan": 1,
+             "min": 2, "max": 2}
 MAX_POWER = 16
 MAX_ST_VARS = 16
 MAX_REFRACTORINESS_VARS = 8
@@ -866,7 +867,7 @@ def _check_types(stmts, bools, condition=None, number=None):
         if k == "call":
             for a in e[2]:
                 need(a, "number", f"{e[1]}()")
-            return "number"
+            return "bool" if e[1] == "isnan" else "number"
         _, op, lhs, rhs = e
         if op in ("&&", "||"):
             need(lhs, "bool", f"'{op}'")
@@ -929,7 +930,11 @@ def _hip_expr(e, index):
     if kind == "not":
         return f"(!{_hip_expr(e[1], index)})"
     if kind == "call":
+        if e[1] == "isnan":
+            arg = _hip_expr(e[2][0], index)
+            return f"({arg} != {arg})"
         fn = {"exp": "expf_portable", "tanh": "tanhf_portable", "sinh": "sinhf_portable", "cosh": "coshf_portable",
+              "sin": "sinf_portable", "cos": "cosf_portable", "tan": "tanf_portable",
               "heaviside": "heaviside_rs", "min": "min_rs", "max": "max_rs"}[e[1]]
         return f"{fn}({', '.join(_hip_expr(a, index) for a in e[2])})"
     if kind == "powi":

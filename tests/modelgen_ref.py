@@ -7,7 +7,8 @@ import oracle_binding as ob
 
 f32 = np.float32
 _FUNCTIONS = {name: np.vectorize(fn, otypes=[np.float32]) for name, fn in
-              (("exp", ob.expf), ("tanh", ob.tanhf), ("sinh", ob.sinhf), ("cosh", ob.coshf))}
+              (("exp", ob.expf), ("tanh", ob.tanhf), ("sinh", ob.sinhf), ("cosh", ob.coshf), ("sin", ob.sinf),
+               ("cos", ob.cosf), ("tan", ob.tanf))}
 _powif = np.vectorize(ob.powif, otypes=[np.float32])
 
 
@@ -37,6 +38,8 @@ def evaluate(e, env):
             return _rust_min(*args)
         if e[1] == "max":
             return _rust_max(*args)
+        if e[1] == "isnan":
+            return np.isnan(args[0])
         if e[1] == "heaviside":                    # nb_macro lib.rs:9176-9178: x < 0 -> 0, else x
             return np.where(args[0] < 0, f32(0), args[0]).astype(f32)
         return _FUNCTIONS[e[1]](args[0])
@@ -147,7 +150,7 @@ def make_step(model):
 # ---- stack program for the C oracle (oracle/snn_oracle.c::custom_run) -------------------------------------
 _OPS = dict(END=0, CONST=1, LOAD=2, STORE=3, DIFF=4, NEG=5, NOT=6, ADD=7, SUB=8, MUL=9, DIV=10, EXP=11, EQ=12, NE=13,
             GE=14, LE=15, GT=16, LT=17, AND=18, OR=19, JZ=20, JMP=21, TANH=22, SINH=23, COSH=24, MIN=25, MAX=26,
-            HEAVISIDE=27, POWI=28, MARK=29, FLUSH=30, RC_UPDATE=31, RC_SET=32, RC_GET=33, NT_APPLY=34)
+            HEAVISIDE=27, POWI=28, MARK=29, FLUSH=30, RC_UPDATE=31, RC_SET=32, RC_GET=33, NT_APPLY=34, SIN=35, COS=36, TAN=37, ISNAN=38)
 _BIN = {"+": "ADD", "-": "SUB", "*": "MUL", "/": "DIV", "==": "EQ", "!=": "NE", ">=": "GE", "<=": "LE", ">": "GT",
         "<": "LT", "&&": "AND", "||": "OR"}
 _BASE_SLOTS = {"v": 0, "i": 1, "dt": 2, "c_m": 3, "gap_conductance": 4}

@@ -126,7 +126,8 @@ def lib():
         L.snn_o_run.argtypes = [P, C.c_uint64]
         L.snn_o_run.restype = None
         for fn in ("snn_o_expf_export", "snn_o_pow3f_export", "snn_o_pow4f_export", "snn_o_tanhf_export",
-                   "snn_o_sinhf_export", "snn_o_coshf_export"):
+                   "snn_o_sinhf_export", "snn_o_coshf_export", "snn_o_sinf_export", "snn_o_cosf_export",
+                   "snn_o_tanf_export"):
             getattr(L, fn).argtypes = [C.c_float]
             getattr(L, fn).restype = C.c_float
         L.snn_o_powif_export.argtypes = [C.c_float, C.c_int]
@@ -430,6 +431,18 @@ def sinhf(x):
 
 def coshf(x):
     return lib().snn_o_coshf_export(float(np.float32(x)))
+
+
+def sinf(x):
+    return lib().snn_o_sinf_export(float(np.float32(x)))
+
+
+def cosf(x):
+    return lib().snn_o_cosf_export(float(np.float32(x)))
+
+
+def tanf(x):
+    return lib().snn_o_tanf_export(float(np.float32(x)))
 
 
 def powif(x, n):

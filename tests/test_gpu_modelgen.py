@@ -20,13 +20,17 @@ from test_modelgen_kinetics import (APPROXIMATE_NT, BOUNDED_RC, DESTEXHE_PAIR, E
 FUNCTIONS_DSL = """
 [neuron]
     type: FunctionSampler
-    vars: v_th = 50000000, f_exp = 0, f_tanh = 0, f_sinh = 0, f_cosh = 0, f_min = 0, f_max = 0, f_heaviside = 0, f_cube = 0, f_inverse_square = 0, f_minus_square = 0
+    vars: v_th = 50000000, f_exp = 0, f_tanh = 0, f_sinh = 0, f_cosh = 0, f_sin = 0, f_cos = 0, f_tan = 0, f_min = 0, f_max = 0, f_heaviside = 0, f_cube = 0, f_inverse_square = 0, f_minus_square = 0, f_nan = false
     spike_detection: v >= v_th
     on_iteration:
         f_exp = exp(i)
         f_tanh = tanh(i)
         f_sinh = sinh(i)
         f_cosh = cosh(i)
+        f_sin = sin(i)
+        f_cos = cos(i)
+        f_tan = tan(i)
+        f_nan = isnan(i - i) || isnan(f_exp - f_exp)
         f_min = min(0.5, i)
         f_max = max(0.5, i)
         f_heaviside = heaviside(i)
@@ -296,7 +300,8 @@ def test_functions_and_powers_equal_the_oracle(snn, libs):
     dn.run(2)
     net.run(2)
     names = [name for name, _ in model.variables]
-    exact = {"f_exp": np.exp, "f_tanh": np.tanh, "f_sinh": np.sinh, "f_cosh": np.cosh}
+    exact = {"f_exp": np.exp, "f_tanh": np.tanh, "f_sinh": np.sinh, "f_cosh": np.cosh, "f_sin": np.sin, "f_cos": np.cos,
+             "f_tan": np.tan}
     with np.errstate(all="ignore"):
         for k, name in enumerate(names):
             got = dn.get_attr(1, name)
@@ -308,6 +313,7 @@ def test_functions_and_powers_equal_the_oracle(snn, libs):
                 assert ulp.max() <= 1, (name, ulp.max())
                 assert np.array_equal(np.isinf(got), np.isinf(want)), name
     assert np.array_equal(dn.get_attr(1, "f_minus_square"), -(x * x))
+    assert np.array_equal(dn.get_attr(1, "f_nan") != 0, x > f32(88.73))            # exp overflows: inf - inf
     dn.close()
 
 

@@ -65,7 +65,8 @@ def test_mandatory_overrides_precedence_and_order_of_application():
 @pytest.mark.parametrize("text,needle", [
     (LIF_NB.replace("dv/dt = (v - e) + i", "dv/dt = (v - e) ^ 2.5"), "integer literal exponent"),
     (LIF_NB.replace("dv/dt = (v - e) + i", "dv/dt = (v - e) ^ e"), "integer literal exponent"),
-    (LIF_NB.replace("dv/dt = (v - e) + i", "dv/dt = sin(v)"), "sin"),
+    (LIF_NB.replace("dv/dt = (v - e) + i", "dv/dt = log(v)"), "log"),
+    (LIF_NB.replace("dv/dt = (v - e) + i", "dv/dt = isnan(v)"), "needs a number"),
     (LIF_NB.replace("dv/dt = (v - e) + i", "dv/dt = min(v)"), "argument"),
     (LIF_NB.replace("spike_detection: v >= v_th", "spike_detection: continuous()"), "continuous"),
     (LIF_NB.replace("vars: e = 0", "vars: flag = true, e = 0").replace("(v - e) + i", "(v - e) + flag"), "needs a number"),

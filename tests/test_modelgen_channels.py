@@ -240,7 +240,8 @@ def test_gating_variable_fields_enter_the_current_as_written():
 
 
 FUNCTION_CASES = [("exp", "exp(i)", np.exp), ("tanh", "tanh(i)", np.tanh), ("sinh", "sinh(i)", np.sinh),
-                  ("cosh", "cosh(i)", np.cosh), ("min", "min(0, i)", lambda x: np.minimum(0, x)),
+                  ("cosh", "cosh(i)", np.cosh), ("sin", "sin(i)", np.sin), ("cos", "cos(i)", np.cos), ("tan", "tan(i)", np.tan),
+                  ("min", "min(0, i)", lambda x: np.minimum(0, x)),
                   ("max", "max(0, i)", lambda x: np.maximum(0, x)),
                   ("heaviside", "heaviside(i)", lambda x: np.where(x < 0, 0, x)),
                   ("cube", "i ^ 3", lambda x: x ** 3), ("inverse square", "i ^ -2", lambda x: x ** -2.0),
