@@ -68,3 +68,34 @@ def test_synthetic_generator_twins_agree():
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
     assert np.array_equal(a.view(np.uint32), c.view(np.uint32))
     assert a.min() >= -65.0 and a.max() < 30.0
+
+
+def test_generated_model_functions_within_one_ulp_of_libm():
+    """tanh / sinh / cosh / sin / cos / tan of generated models (the reference forwards them to libm,
+    build_test/nb_macro/src/lib.rs:9152-9175) and integer powers against glibc's float functions.  Ours are the correctly rounded values
+    (test_modelgen_channels / test_gpu_modelgen compare them with binary64 results); glibc documents up to 2 ULP for
+    the hyperbolic functions and tanf, 1 ULP for sinf / cosf -- so that is the distance allowed here."""
+    rng = np.random.default_rng(2)
+    xs = np.concatenate([rng.uniform(-12, 12, 6000), rng.uniform(-0.1, 0.1, 1500), rng.uniform(-100, 100, 3000),
+                         rng.uniform(-1e5, 1e5, 1500), [0.0, -0.0, 0.05, -0.05, 20.5, -45.0]]).astype(np.float32)
+    for name, bar in (("tanhf", 2), ("sinhf", 2), ("coshf", 2), ("sinf", 1), ("cosf", 1), ("tanf", 2)):
+        ref = getattr(libm, name)
+        ref.argtypes, ref.restype = [ctypes.c_float], ctypes.c_float
+        ours = getattr(ob, name)
+        worst, mism = 0, 0
+        for x in xs:
+            if name in ("sinhf", "coshf") and abs(x) > 88.0:
+                continue
+            a, b = np.float32(ours(x)), np.float32(ref(float(x)))
+            if a.view(np.uint32) != b.view(np.uint32):
+                mism += 1
+                worst = max(worst, ulp_diff(a, b))
+        assert worst <= bar, (name, worst)
+        assert mism / len(xs) < 0.25, f"{name}: {mism} of {len(xs)} differ from libm"
+    for n in (2, 3, 4, 7, -1, -2):
+        for x in xs[:2000]:
+            if x == 0 and n < 0:
+                continue
+            assert ulp_diff(ob.powif(x, n), libm.powf(float(x), float(n))) <= 1, (x, n)
+    assert np.isnan(ob.sinf(np.inf)) and np.isnan(ob.tanf(np.nan)) and ob.coshf(200.0) == np.inf
+    assert np.signbit(np.float32(ob.sinf(np.float32(-0.0)))) and ob.tanhf(50.0) == 1.0
