@@ -314,6 +314,9 @@ const char *snn_custom_spike_train(void);
 const char *snn_custom_refractoriness(void);
 const char *snn_custom_neurotransmitter_kinetics(void);
 const char *snn_custom_receptor_kinetics(void);
+/* the `[receptors]` set of the generated neuron (lib.rs:7017-7600): up to three neurotransmitter types in the exchange's
+ * three slots, variables receptors$<name> / receptors$<TYPE>$<name>, kinetics receptors$<TYPE>$r$kinetics$r */
+const char *snn_custom_receptors(void);
 
 /* HBM ceilings of the device with the stepper's own access shape (16 B per lane, non-temporal): GB/s of a
  * read-only stream and of a copy (read + write bytes) over `bytes` of device memory, `repeats` launches. */

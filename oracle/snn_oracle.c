@@ -360,6 +360,21 @@ static inline void receptors_kinetics(snn_o_net *n, uint32_t q)
 
 static inline void receptors_set_currents(snn_o_net *n, uint32_t q, float v_old)
 {
+    if (n->model == SNN_O_CUSTOM && n->rx_ntypes) {
+        /* generated receptor set, build_test/nb_macro/src/lib.rs:7512-7543: every receptor present iterates, in
+         * declaration order, over the set's variables */
+        float slot[5 + 24];
+        slot[0] = v_old; slot[2] = slot[3] = slot[4] = 0.0f;
+        for (uint32_t j = 0; j < n->rx_nvars; ++j) slot[5 + j] = n->rx_vars[(size_t)j * n->n_neurons + q];
+        for (uint32_t k = 0; k < n->rx_ntypes; ++k) {
+            size_t i = (size_t)q * SNN_O_K + k;
+            if (!n->rc_flags[i]) continue;
+            slot[1] = n->rc_r[i];
+            program_run(n->rx_code, n->rx_consts, n->rx_section[k], slot, 0);
+        }
+        for (uint32_t j = 0; j < n->rx_nvars; ++j) n->rx_vars[(size_t)j * n->n_neurons + q] = slot[5 + j];
+        return;
+    }
     for (int k = 0; k < SNN_O_K; ++k) {
         size_t i = (size_t)q * SNN_O_K + k;
         if (!n->rc_flags[i]) continue;
@@ -383,6 +398,13 @@ static inline void receptors_update(snn_o_net *n, uint32_t q, float v_old)
 static inline float receptor_currents_scaled(const snn_o_net *n, uint32_t q, float dt, float c_m)
 {
     float total = 0.0f;
+    if (n->model == SNN_O_CUSTOM && n->rx_ntypes) {      /* lib.rs:7546-7566 */
+        for (uint32_t k = 0; k < n->rx_ntypes; ++k) {
+            if (n->rx_current_index[k] < 0 || !n->rc_flags[(size_t)q * SNN_O_K + k]) continue;
+            total += n->rx_vars[(size_t)n->rx_current_index[k] * n->n_neurons + q];
+        }
+        return total * (dt / c_m);
+    }
     if (n->rc_flags) {
         for (int k = 0; k < SNN_O_K; ++k) {
             size_t i = (size_t)q * SNN_O_K + k;

@@ -215,6 +215,15 @@ typedef struct snn_o_net {
     /* SNN_O_CUSTOM with an on_electrochemical_iteration (lib.rs:2280-2316): a fourth section of custom_code that
      * replaces the default chemical step (receptor update, on_iteration, v -= currents, transmitter update) */
     uint32_t custom_has_chem, custom_chem_section;
+    /* the generated neuron's [receptors] set (lib.rs:7017-7600): rx_ntypes (0 = the ionotropic AMPA/NMDA/GABA set)
+     * neurotransmitter types in slots 0.., one program section per type (slots 0 v, 1 r, 5.. the set's variables),
+     * rx_current_index[k] = the variable holding type k's current or -1 */
+    const int32_t *rx_code;
+    const float   *rx_consts;
+    uint32_t rx_ntypes, rx_nvars;
+    uint32_t rx_section[3];
+    int32_t  rx_current_index[3];
+    float    *rx_vars;                         /* [rx_nvars][n_neurons] */
 } snn_o_net;
 
 /* Step 1 of SURVEY §8(g): electrical + chemical inputs for every neuron from state S(t). */

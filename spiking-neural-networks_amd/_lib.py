@@ -81,6 +81,7 @@ SIGNATURES = {
     "snn_custom_refractoriness": (C.c_char_p, []),
     "snn_custom_neurotransmitter_kinetics": (C.c_char_p, []),
     "snn_custom_receptor_kinetics": (C.c_char_p, []),
+    "snn_custom_receptors": (C.c_char_p, []),
     "snn_network_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(H)]),
     "snn_network_destroy": (C.c_int, [H]),
     "snn_network_add_lattice": (C.c_int, [H, C.c_uint32, C.c_uint32, C.c_uint32]),

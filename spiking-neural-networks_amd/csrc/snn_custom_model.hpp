@@ -6,6 +6,7 @@
 //   [neural_refractoriness]       -> namespace custom_refr  = neural_refractoriness$kind 2
 //   [neurotransmitter_kinetics]   -> namespace custom_nt    = neurotransmitter kinetics SNN_NT_CUSTOM
 //   [receptor_kinetics]           -> namespace custom_rc    = receptor kinetics SNN_RC_CUSTOM
+//   [receptors] (of the [neuron]) -> namespace custom_receptors: the neuron's receptor set in place of AMPA/NMDA/GABA
 // A library compiled with -DSNN_CUSTOM_MODEL_HEADER="\"generated/<name>.hpp\"" carries them next to the built-in
 // models.  Without the define (or for a block the description does not have) the hook is an empty stub and the
 // selector is refused.
@@ -93,6 +94,23 @@ __device__ __forceinline__ void apply(float &, float (&)[NSTORE], float, float) 
 } // namespace snn
 #endif
 
+#ifndef SNN_HAVE_CUSTOM_RECEPTORS
+#define SNN_HAVE_CUSTOM_RECEPTORS 0
+namespace snn {
+namespace custom_receptors {
+static const char *const TYPE_NAME = "";
+constexpr int NTYPES = 0;
+static const char *const NT_NAMES[3] = {"", "", ""};
+constexpr int NVARS = 0;
+constexpr int NSTORE = 1;
+static const char *const NAMES[NSTORE] = {""};
+static const float DEFAULTS[NSTORE] = {0.0f};
+constexpr int CURRENT_INDEX[3] = {-1, -1, -1};
+__device__ __forceinline__ void iterate(int, float, float, float (&)[NSTORE]) {}
+} // namespace custom_receptors
+} // namespace snn
+#endif
+
 namespace snn {
 constexpr int CUSTOM_MODEL = 100;        // SNN_MODEL_CUSTOM
 constexpr int CUSTOM_SPIKE_TRAIN = 100;  // SNN_ST_CUSTOM
@@ -101,6 +119,8 @@ constexpr int CUSTOM_KINETICS = 100;     // SNN_NT_CUSTOM / SNN_RC_CUSTOM
 constexpr int CUSTOM_MAX_VARS = 32, CUSTOM_ST_MAX_VARS = 16, CUSTOM_REFR_MAX_VARS = 8, CUSTOM_KINETICS_MAX_VARS = 8;
 static_assert(custom_nt::NVARS <= CUSTOM_KINETICS_MAX_VARS, "too many variables in the generated neurotransmitter kinetics");
 static_assert(custom_rc::NVARS <= CUSTOM_KINETICS_MAX_VARS, "too many variables in the generated receptor kinetics");
+constexpr int CUSTOM_RECEPTORS_MAX_VARS = 24;
+static_assert(custom_receptors::NVARS <= CUSTOM_RECEPTORS_MAX_VARS, "too many variables in the generated receptor set");
 static_assert(custom::NVARS <= CUSTOM_MAX_VARS, "too many variables in the generated neuron model");
 static_assert(custom_st::NVARS <= CUSTOM_ST_MAX_VARS, "too many variables in the generated spike train");
 static_assert(custom_refr::NVARS <= CUSTOM_REFR_MAX_VARS, "too many variables in the generated refractoriness");

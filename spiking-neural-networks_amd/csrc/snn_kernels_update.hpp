@@ -35,6 +35,7 @@ struct UpdateArgs {
     float *xout, *xout2;
     int has_nt;                 // some neuron of the handle releases a neurotransmitter (else the flag planes are not read)
     int bcm;                    // BCMIzhikevichNeuron: keep the activity bookkeeping (the step itself is Izhikevich's)
+    int model_is_custom;        // the generated neuron model: it uses the library's generated receptor set, if any
 };
 
 // Second level of the canonical sum: chunk partials added in ascending chunk order from 0.0f.  The loads of
@@ -129,6 +130,21 @@ __device__ __forceinline__ void receptors_kinetics(const UpdateArgs &a, uint32_t
 // Ionotropic::set_receptor_currents (iterate_and_spike/mod.rs:1260-1284; currents :1103-1105, 1132-1137, 1164-1166)
 __device__ __forceinline__ void receptors_set_currents(const UpdateArgs &a, uint32_t q, float v_old)
 {
+    if (SNN_HAVE_CUSTOM_RECEPTORS && a.model_is_custom) {
+        // generated receptor set (nb_macro lib.rs:7512-7543): the on_iteration of every receptor present, in
+        // declaration order, over the set's variables
+        float x[custom_receptors::NSTORE];
+#pragma unroll
+        for (int j = 0; j < custom_receptors::NVARS; ++j) x[j] = a.n.rx_custom[j][q];
+#pragma unroll
+        for (int k = 0; k < custom_receptors::NTYPES; ++k) {
+            const size_t i = (size_t)k * a.n.n_pad + q;
+            if (a.n.rc_flags[i]) custom_receptors::iterate(k, v_old, a.n.rc_r[i], x);
+        }
+#pragma unroll
+        for (int j = 0; j < custom_receptors::NVARS; ++j) a.n.rx_custom[j][q] = x[j];
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < K_TYPES; ++k) {
         const size_t i = (size_t)k * a.n.n_pad + q;
@@ -155,6 +171,14 @@ __device__ __forceinline__ void receptors_update(const UpdateArgs &a, uint32_t q
 __device__ __forceinline__ float receptor_currents(const UpdateArgs &a, uint32_t q, float dt, float c_m)
 {
     float total = 0.0f;
+    if (SNN_HAVE_CUSTOM_RECEPTORS && a.model_is_custom) {      // lib.rs:7546-7566: the `current`s of the receptors present
+#pragma unroll
+        for (int k = 0; k < custom_receptors::NTYPES; ++k) {
+            if (custom_receptors::CURRENT_INDEX[k] < 0) continue;
+            if (a.n.rc_flags[(size_t)k * a.n.n_pad + q]) total += a.n.rx_custom[custom_receptors::CURRENT_INDEX[k]][q];
+        }
+        return total * (dt / c_m);
+    }
 #pragma unroll
     for (int k = 0; k < K_TYPES; ++k) {
         const size_t i = (size_t)k * a.n.n_pad + q;

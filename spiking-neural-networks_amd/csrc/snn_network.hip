@@ -15,6 +15,7 @@ const char *snn_custom_spike_train(void) { return custom_st::TYPE_NAME; }
 const char *snn_custom_refractoriness(void) { return custom_refr::TYPE_NAME; }
 const char *snn_custom_neurotransmitter_kinetics(void) { return custom_nt::TYPE_NAME; }
 const char *snn_custom_receptor_kinetics(void) { return custom_rc::TYPE_NAME; }
+const char *snn_custom_receptors(void) { return custom_receptors::TYPE_NAME; }
 const char *snn_last_error(void) { return g_last_error.c_str(); }
 
 int snn_network_create(int device, int neuron_model, int nt_kinetics, int receptor_kinetics,

@@ -409,6 +409,19 @@ int build_state(snn_network *net)
         reg(A, (p + "$r$kinetics$decay_constant").c_str(), T_F32, S_PLAIN, n.rc_beta + (size_t)k * np, 0, 0);
     }
     reg(A, "receptors$NMDA_mg", T_F32, S_PLAIN, n.rc_mg + (size_t)1 * np, 0, 0);
+    for (int j = 0; j < CUSTOM_RECEPTORS_MAX_VARS; ++j) n.rx_custom[j] = nullptr;
+    if (SNN_HAVE_CUSTOM_RECEPTORS && cust) {
+        // the generated neuron's receptor set: its variables, and the kinetics of type k under the type's own name
+        for (int j = 0; j < custom_receptors::NVARS; ++j)
+            TRY(neuron_f32(net, &n.rx_custom[j], (std::string("receptors$") + custom_receptors::NAMES[j]).c_str(),
+                           custom_receptors::DEFAULTS[j]));
+        for (int k = 0; k < custom_receptors::NTYPES; ++k) {
+            const std::string p = std::string("receptors$") + custom_receptors::NT_NAMES[k];
+            reg(A, (p + "$r$kinetics$r").c_str(), T_F32, S_PLAIN, n.rc_r + (size_t)k * np, 0, 0);
+            reg(A, (p + "$r$kinetics$alpha").c_str(), T_F32, S_PLAIN, n.rc_alpha + (size_t)k * np, 0, 0);
+            reg(A, (p + "$r$kinetics$beta").c_str(), T_F32, S_PLAIN, n.rc_beta + (size_t)k * np, 0, 0);
+        }
+    }
     if (net->rc_kind == SNN_RC_CUSTOM)
         for (int j = 0; j < custom_rc::NVARS; ++j) {
             const float d = custom_rc::DEFAULTS[j];

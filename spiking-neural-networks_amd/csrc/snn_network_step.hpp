@@ -149,6 +149,7 @@ int launch_update(snn_network *net)
     a.xout = net->xbuf; a.xout2 = nullptr;
     a.has_nt = net->any_nt_neurons ? 1 : 0;
     a.bcm = net->model == SNN_MODEL_BCM_IZHIKEVICH;
+    a.model_is_custom = net->model == SNN_MODEL_CUSTOM;
     net->shadow_valid = false;            // the exchange buffer moves on without the shadows
     dim3 grid((net->ld + 255) / 256);
     switch (net->model) {

@@ -59,11 +59,17 @@ the reference tests against is build_test/nb_macro/tests/lif_reference.rs):
     (lib.rs:6757-6826; receptor kinetics selector 100) blocks: on_iteration over the state (`t` / `r`, default 0), the
     block's vars -- one value per neurotransmitter type, attributes neurotransmitters$<name> /
     receptors$<TYPE>$r$kinetics$<name> -- and the inputs is_spiking, v, dt / t, dt.
-    One library carries at most one neuron, spike train, refractoriness and kinetics block of each kind.
+  * `[receptors]` blocks (lib.rs:7017-7600) used by the neuron through `receptors: <type>`: optional top-level vars
+    and one to three `neurotransmitter: <Name>` groups (they take the exchange's three slots in order), each with vars
+    and an on_iteration over v, its receptor state `r`, its vars and the top-level vars.  set_receptor_currents runs
+    the on_iteration of every receptor present (receptors$flags) in declaration order, get_receptor_currents sums the
+    `current` variables; attributes receptors$<var>, receptors$<Name>$<var>, receptors$<Name>$r$kinetics$r.
+    One library carries at most one neuron (with its receptor set), spike train, refractoriness and kinetics block
+    of each kind.
 
 `hip_source(model)` emits the header that csrc/snn_custom_model.hpp includes when the library is compiled with
 -DSNN_CUSTOM_MODEL_HEADER; `_lib.build_custom(model)` compiles such a library.  Not supported (rejected with a
-message): [receptors] blocks, `^` with a non-literal or
+message): several receptor states per neurotransmitter (`receptors: r1, r2`), `^` with a non-literal or
 fractional exponent, and `continuous()` spike detection --
 the code the reference generates for it reads a `last_voltage` that is never defined (lib.rs:984-990), so there is
 no behaviour to match.
@@ -79,6 +85,7 @@ MAX_POWER = 16
 MAX_ST_VARS = 16
 MAX_REFRACTORINESS_VARS = 8
 MAX_KINETICS_VARS = 8
+MAX_RECEPTOR_VARS = 24
 
 
 class ModelError(ValueError):
@@ -291,6 +298,7 @@ class NeuronModel:
         self.on_iteration, self.spike_detection, self.on_spike = on_iteration, spike_detection, on_spike
         self.ion_channels = []              # [(instance name, channel type name)]
         self.on_electrochemical_iteration = None   # statements replacing the default chemical step (lib.rs:2280-2316)
+        self.receptors = None               # name of the [receptors] block the neuron uses (default: ionotropic set)
         self.bools = set()                  # variables declared true / false: stored as 1.0 / 0.0
 
 
@@ -546,14 +554,25 @@ class KineticsModel:
         self.bools, self.state_default = set(bools), state_default
 
 
+class ReceptorsModel:
+    """[receptors] (lib.rs:7017-7600): up to three neurotransmitter types, each with its own vars and an on_iteration
+    over v, its receptor state `r`, its vars and the block's top-level vars; set_receptor_currents runs the
+    on_iterations of the receptors present in declaration order, get_receptor_currents sums the `current` variables.
+    `variables` is the flattened table: top-level vars under their names, the vars of type T as "T$name"."""
+    def __init__(self, name, types, variables, bools):
+        self.name, self.types, self.variables, self.bools = name, types, variables, set(bools)
+        # types: [(type name, statements, index of its `current` in `variables` or None)]
+
+
 class Description:
-    def __init__(self, neuron=None, spike_train=None, refractoriness=None, nt_kinetics=None, receptor_kinetics=None):
+    def __init__(self, neuron=None, spike_train=None, refractoriness=None, nt_kinetics=None, receptor_kinetics=None,
+                 receptors=None):
         self.neuron, self.spike_train, self.refractoriness = neuron, spike_train, refractoriness
-        self.nt_kinetics, self.receptor_kinetics = nt_kinetics, receptor_kinetics
+        self.nt_kinetics, self.receptor_kinetics, self.receptors = nt_kinetics, receptor_kinetics, receptors
 
     def parts(self):
         return [m for m in (self.neuron, self.spike_train, self.refractoriness, self.nt_kinetics,
-                            self.receptor_kinetics) if m is not None]
+                            self.receptor_kinetics, self.receptors) if m is not None]
 
     @property
     def name(self):
@@ -683,6 +702,98 @@ def _parse_kinetics(body, state):
     return KineticsModel(name, state, variables, all_bools, stmts, dict(listed).get(state, 0.0))
 
 
+def _parse_receptors(body):
+    if not body or not body[0].startswith("type"):
+        raise ModelError("[receptors]: 'type' comes first")
+    m = re.match(r"^type\s*:\s*(.*)$", body[0])
+    name = m.group(1).strip() if m else ""
+    if not re.fullmatch(_NAME, name):
+        raise ModelError(f"bad or missing type name {name!r}")
+    groups, current, section = [{"name": None, "vars": [], "on_iteration": []}], None, None
+    for line in body[1:]:
+        m = re.match(r"^(neurotransmitter|vars|on_iteration|receptors)\s*:\s*(.*)$", line)
+        if m and m.group(1) == "neurotransmitter":
+            nt = m.group(2).strip()
+            if not re.fullmatch(_NAME, nt):
+                raise ModelError(f"bad neurotransmitter name {nt!r}")
+            groups.append({"name": nt, "vars": [], "on_iteration": []})
+            section = None
+        elif m and m.group(1) == "receptors":
+            raise ModelError("[receptors]: several receptor states per neurotransmitter (`receptors: r1, r2`) are not "
+                             "supported -- every type has the one state `r`")
+        elif m:
+            section = m.group(1)
+            if section == "on_iteration" and groups[-1]["name"] is None:
+                raise ModelError("[receptors]: on_iteration belongs to a neurotransmitter")
+            if m.group(2):
+                groups[-1][section].append(m.group(2))
+        elif section is None:
+            raise ModelError(f"text outside a section: {line!r}")
+        else:
+            groups[-1][section].append(line)
+    types = groups[1:]
+    if not 1 <= len(types) <= 3:
+        raise ModelError("[receptors] takes one to three neurotransmitter types (the exchange carries three)")
+    if len({g["name"] for g in types}) != len(types):
+        raise ModelError("[receptors]: a neurotransmitter is listed twice")
+    bools, variables = set(), []
+    top = _variables(groups[0]["vars"], ("v", "r", "dt", "t", "current"), bools)
+    variables += top
+    top_names = {n for n, _ in top}
+    out_types = []
+    for g in types:
+        own_bools = set()
+        own = _variables(g["vars"], ("v", "r", "dt", "t") + tuple(top_names), own_bools)
+        if "current" in own_bools:
+            raise ModelError("'current' is a number")
+        base = len(variables)
+        variables += [(f"{g['name']}${n}", d) for n, d in own]
+        bools |= {f"{g['name']}${n}" for n in own_bools}
+        own_names = {n for n, _ in own}
+        if not g["on_iteration"]:
+            raise ModelError(f"[receptors]: neurotransmitter {g['name']} has no on_iteration")
+
+        def rename(n, g=g, own_names=own_names):
+            if n in ("v", "current_voltage"):
+                return ("var", "v")
+            if n == "r":
+                return ("var", "r")
+            if n in own_names:
+                return ("var", f"{g['name']}${n}")
+            if n in top_names:
+                return ("var", n)
+            raise ModelError(f"[receptors] {g['name']}: unknown variable {n!r}")
+
+        assignable = {f"{g['name']}${n}" for n in own_names} | top_names
+        raw = _block(g["on_iteration"])[0]
+        for st in _walk(raw):
+            if st[0] == "diff":
+                raise ModelError("[receptors]: on_iteration takes assignments, not differential equations")
+        # targets are renamed through the same table
+        def fix_targets(stmts):
+            fixed = []
+            for st in stmts:
+                if st[0] == "if":
+                    fixed.append(("if", [(c, fix_targets(b)) for c, b in st[1]], None if st[2] is None else fix_targets(st[2])))
+                elif st[0] == "assign":
+                    fixed.append(("assign", rename(st[1])[1]) + tuple(st[2:]))
+                else:
+                    fixed.append(st)
+            return fixed
+        stmts = _convert_plain(fix_targets(raw), lambda n, rn=rename: ("var", n) if "$" in n else rn(n), assignable,
+                               "on_iteration")
+        cur = f"{g['name']}$current"
+        names = [n for n, _ in variables]
+        out_types.append((g["name"], stmts, names.index(cur) if cur in names else None))
+        del base
+    if len(variables) > MAX_RECEPTOR_VARS:
+        raise ModelError(f"more than {MAX_RECEPTOR_VARS} receptor variables")
+    model = ReceptorsModel(name, out_types, variables, bools)
+    for _, stmts, _ in out_types:
+        _check_types(stmts, bools)
+    return model
+
+
 def parse_description(text):
     """Every block of a description: [ion_channel]s, at most one [neuron], one [spike_train] and one
     [neural_refractoriness] (one generated library carries one of each)."""
@@ -711,14 +822,26 @@ def parse_description(text):
             if desc.receptor_kinetics is not None:
                 raise ModelError("more than one [receptor_kinetics] block")
             desc.receptor_kinetics = _parse_kinetics(body, "r")
+        elif kind == "receptors":
+            if desc.receptors is not None:
+                raise ModelError("more than one [receptors] block (one library carries one receptor set)")
+            desc.receptors = _parse_receptors(body)
         elif kind != "neuron":
-            raise ModelError(f"[{kind}] blocks are not supported ([ion_channel], [neuron], [spike_train], "
-                             "[neural_refractoriness], [neurotransmitter_kinetics] and [receptor_kinetics] are)")
+            raise ModelError(f"[{kind}] blocks are not supported")
     neurons = [body for kind, body in blocks if kind == "neuron"]
     if len(neurons) > 1:
         raise ModelError("expected exactly one [neuron] ... [end] block")
     if neurons:
         desc.neuron = _parse_neuron(neurons[0], channels)
+        wanted = desc.neuron.receptors
+        if wanted is not None and (desc.receptors is None or desc.receptors.name != wanted):
+            raise ModelError(f"neuron {desc.neuron.name}: unknown receptors type {wanted!r}")
+        if wanted is None and desc.receptors is not None:
+            raise ModelError(f"[receptors] {desc.receptors.name} is not used: the neuron needs `receptors: "
+                             f"{desc.receptors.name}`")
+    elif desc.receptors is not None:
+        raise ModelError("[receptors] blocks belong to a generated [neuron] (`receptors: <type>`); the built-in neurons "
+                         "carry the ionotropic AMPA / NMDA / GABA set")
     elif channels:
         raise ModelError("[ion_channel] blocks without a [neuron] that uses them")
     if not desc.parts():
@@ -729,7 +852,7 @@ def parse_description(text):
 def parse(text):
     """Parse zero or more [ion_channel] blocks and ONE [neuron] block of the DSL subset in the module docstring."""
     desc = parse_description(text)
-    if desc.neuron is None or len(desc.parts()) != 1:
+    if desc.neuron is None or [m for m in desc.parts() if m is not desc.receptors] != [desc.neuron]:
         raise ModelError("expected exactly one [neuron] ... [end] block (parse_description reads spike trains and "
                          "refractoriness)")
     return desc.neuron
@@ -737,7 +860,7 @@ def parse(text):
 
 def _parse_neuron(body, channels):
     sections, name = _sections(body, ("type", "vars", "on_spike", "spike_detection", "on_iteration",
-                                      "on_electrochemical_iteration", "ion_channels"))
+                                      "on_electrochemical_iteration", "ion_channels", "receptors"))
     for need in ("on_iteration", "spike_detection"):
         if not sections.get(need):
             raise ModelError(f"section '{need}' is missing")
@@ -821,6 +944,11 @@ def _parse_neuron(body, channels):
     model.spike_detection = _map_expr(parse_expr(detect), rename)
     model.on_iteration = convert(_block(sections["on_iteration"])[0], "on_iteration")
     model.on_spike = convert(_block(sections.get("on_spike", []))[0], "on_spike")
+    model.receptors = None
+    if sections.get("receptors"):
+        model.receptors = " ".join(sections["receptors"]).strip()
+        if not re.fullmatch(_NAME, model.receptors):
+            raise ModelError(f"bad receptors type {model.receptors!r}")
     model.on_electrochemical_iteration = None
     if sections.get("on_electrochemical_iteration"):
         model.on_electrochemical_iteration = convert(_block(sections["on_electrochemical_iteration"])[0],
@@ -1100,6 +1228,34 @@ __device__ __forceinline__ void apply({args})
 """
 
 
+def _receptors_source(model):
+    index = {n: k for k, (n, _) in enumerate(model.variables)}
+    index["$bools"] = model.bools
+    index["$base"] = {"v": "v", "r": "r"}
+    bodies = []
+    for k, (nt, stmts, _) in enumerate(model.types):
+        bodies.append(f"    {'if' if k == 0 else '} else if'} (k == {k}) {{        // {nt}\n"
+                      + _hip_statements(stmts, index, False, "        "))
+    nt_names = ", ".join(f'"{t[0]}"' for t in model.types) + ', ""' * (3 - len(model.types))
+    cur = ", ".join(str(-1 if t[2] is None else t[2]) for t in model.types) + ", -1" * (3 - len(model.types))
+    return f"""#define SNN_HAVE_CUSTOM_RECEPTORS 1
+namespace custom_receptors {{
+static const char *const TYPE_NAME = "{model.name}";
+constexpr int NTYPES = {len(model.types)};
+static const char *const NT_NAMES[3] = {{{nt_names}}};
+{_table(model.variables)}
+constexpr int CURRENT_INDEX[3] = {{{cur}}};          // the type's `current` in x, -1: the type carries no current
+
+// <Type>Receptor::iterate of the generated receptor set (nb_macro lib.rs:7296-7340): type k's on_iteration
+__device__ __forceinline__ void iterate(int k, float v, float r, float (&x)[NSTORE])
+{{
+{chr(10).join(bodies)}
+    }}
+}}
+}} // namespace custom_receptors
+"""
+
+
 def hip_source(model):
     """The generated header for a NeuronModel or a Description: per block a variable table and its code as device
     functions (namespaces custom / custom_st / custom_refr)."""
@@ -1115,6 +1271,8 @@ def hip_source(model):
         parts.append(_kinetics_source(desc.nt_kinetics))
     if desc.receptor_kinetics is not None:
         parts.append(_kinetics_source(desc.receptor_kinetics))
+    if desc.receptors is not None:
+        parts.append(_receptors_source(desc.receptors))
     return f"""// GENERATED by spiking-neural-networks_amd/modelgen.py from the description of {desc.name}
 // (nb_macro semantics, see modelgen.py).  Included through csrc/snn_custom_model.hpp.
 #pragma once

@@ -329,3 +329,21 @@ def attach_receptor_kinetics(net, model):
     for k, (_, default) in enumerate(model.variables):
         net.arr["rc_custom_vars"][k] = default
     return net
+
+
+_RX_SLOTS = {"v": 0, "r": 1}
+
+
+def attach_receptors(net, model):
+    """Give the generated neurons of an oracle Net (model=ob.CUSTOM) the generated receptor set `model`."""
+    code, consts, starts = compile_program(model, _RX_SLOTS, [("statements", stmts) for _, stmts, _ in model.types])
+    net.rx_model = model
+    net.arr["rx_code"], net.arr["rx_consts"] = code, consts
+    net.rx_ntypes, net.rx_nvars = len(model.types), len(model.variables)
+    net.rx_section = np.concatenate([starts, np.zeros(3 - len(starts), np.uint32)]).astype(np.uint32)
+    net.rx_current_index = np.array([(-1 if t[2] is None else t[2]) for t in model.types] + [-1] * (3 - len(model.types)),
+                                    np.int32)
+    net.arr["rx_vars"] = np.zeros((max(1, len(model.variables)), net.n_neurons), np.float32)
+    for k, (_, default) in enumerate(model.variables):
+        net.arr["rx_vars"][k] = default
+    return net

@@ -88,6 +88,8 @@ _FIELDS = [
     ("st_nt_custom_vars", f32p),
     ("rc_code", C.POINTER(C.c_int32)), ("rc_consts", f32p), ("rc_nvars", C.c_uint32), ("rc_custom_vars", f32p),
     ("custom_has_chem", C.c_uint32), ("custom_chem_section", C.c_uint32),
+    ("rx_code", C.POINTER(C.c_int32)), ("rx_consts", f32p), ("rx_ntypes", C.c_uint32), ("rx_nvars", C.c_uint32),
+    ("rx_section", C.c_uint32 * 3), ("rx_current_index", C.c_int32 * 3), ("rx_vars", f32p),
 ]
 
 
@@ -298,6 +300,10 @@ class Net:
         self.refr_nvars = 0
         self.nt_nvars = 0
         self.custom_has_chem = 0
+        self.rx_ntypes = 0
+        self.rx_nvars = 0
+        self.rx_section = np.zeros(3, np.uint32)
+        self.rx_current_index = np.full(3, -1, np.int32)
         self.custom_chem_section = 0
         self.rc_nvars = 0
         if nt_kind == NT_EXPONENTIAL_DECAY:       # decay_constant, iterate_and_spike/mod.rs:336-343
@@ -352,8 +358,10 @@ class Net:
                     setattr(c, name, arr.ctypes.data_as(ct))
             elif ct is C.c_float:
                 setattr(c, name, float(getattr(self, name)))
-            elif name == "custom_section":
-                setattr(c, name, (C.c_uint32 * 3)(*[int(x) for x in self.custom_section]))
+            elif name in ("custom_section", "rx_section"):
+                setattr(c, name, (C.c_uint32 * 3)(*[int(x) for x in getattr(self, name)]))
+            elif name == "rx_current_index":
+                setattr(c, name, (C.c_int32 * 3)(*[int(x) for x in self.rx_current_index]))
             else:
                 setattr(c, name, int(getattr(self, name)))
         return c

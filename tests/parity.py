@@ -194,6 +194,8 @@ def push_state(dn, net):
                 dn.set_attr(i, a, net[o][sl])
             for k, name in enumerate(_kinetics_names(net, "nt_model")):
                 dn.set_attr(i, "neurotransmitters$" + name, np.ascontiguousarray(net["nt_custom_vars"][k, sl]))
+            for k, name in enumerate(_kinetics_names(net, "rx_model")):
+                dn.set_attr(i, "receptors$" + name, np.ascontiguousarray(net["rx_vars"][k, sl]))
             for k, name in enumerate(_kinetics_names(net, "rc_model")):
                 for ty, t in enumerate(TYPE_NAMES):
                     dn.set_attr(i, f"receptors${t}$r$kinetics${name}", np.ascontiguousarray(net["rc_custom_vars"][k, sl, ty]))
@@ -247,6 +249,10 @@ def pull_state(dn, net):
                 if "nt_custom_vars" not in out:
                     out["nt_custom_vars"] = np.zeros_like(net["nt_custom_vars"])
                 out["nt_custom_vars"][k, sl] = dn.get_attr(i, "neurotransmitters$" + name, per_type=True).reshape(-1, 3)
+            for k, name in enumerate(_kinetics_names(net, "rx_model")):
+                if "rx_vars" not in out:
+                    out["rx_vars"] = np.zeros_like(net["rx_vars"])
+                out["rx_vars"][k, sl] = dn.get_attr(i, "receptors$" + name)
             for k, name in enumerate(_kinetics_names(net, "rc_model")):
                 if "rc_custom_vars" not in out:
                     out["rc_custom_vars"] = np.zeros_like(net["rc_custom_vars"])

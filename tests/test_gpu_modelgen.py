@@ -12,6 +12,7 @@ import parity
 from test_modelgen import (BOOL_DSL, CURRENTS, EXPECTED_FLAG, IF_DSL, IZH_DSL, LIF_NB, bool_expected_out,
                            lif_reference_trace)
 from test_modelgen_channels import CALCIUM_CLAMP, MORRIS_LECAR, VOLTAGES, calcium_reference
+from test_modelgen_receptors import IONOTROPIC_LIKE, LIF, MIXED, MULTIPLE, STEP_NEURON
 from test_modelgen_spike_trains import BURST_DSL, RATE_DSL, REFRACTORINESS_DSL, _mixed_network
 from test_modelgen_kinetics import (APPROXIMATE_NT, BOUNDED_RC, DESTEXHE_PAIR, ELECTROCHEMICAL_REF, RESTATED_STEP,
                                     built_in_approximate, chemical_network, custom_chemical_network,
@@ -49,8 +50,10 @@ def libs(snn):
     from concurrent.futures import ThreadPoolExecutor
     models = [modelgen.parse(text) for text in (LIF_NB, IZH_DSL, IF_DSL, CALCIUM_CLAMP, MORRIS_LECAR, FUNCTIONS_DSL,
                                                  BOOL_DSL, ELECTROCHEMICAL_REF, RESTATED_STEP)]
-    models += [modelgen.parse_description(text) for text in (RATE_DSL + REFRACTORINESS_DSL, APPROXIMATE_NT + BOUNDED_RC,
-                                                             IZH_DSL + BURST_DSL + DESTEXHE_PAIR)]
+    models += [modelgen.parse_description(text) for text in (
+        RATE_DSL + REFRACTORINESS_DSL, APPROXIMATE_NT + BOUNDED_RC, IZH_DSL + BURST_DSL + DESTEXHE_PAIR,
+        MIXED + LIF.format(name="MixedIntegrateAndFire", receptors="MixedReceptors"),
+        IONOTROPIC_LIKE + STEP_NEURON.format(name="OwnReceptors", receptors="receptors: AmpaGabaReceptors\n    "))]
     with ThreadPoolExecutor(max_workers=4) as pool:          # one hipcc each
         paths = list(pool.map(_lib.build_custom, models))
     return {m.name: (m, path) for m, path in zip(models, paths)}
@@ -472,6 +475,47 @@ def test_on_electrochemical_iteration_equals_the_oracle(snn, libs, which, varian
     dn.close()
 
 
+@pytest.mark.parametrize("which", ["OwnReceptors_AmpaGabaReceptors", "MixedIntegrateAndFire_MixedReceptors"])
+@pytest.mark.parametrize("variant", ["dense", "sparse"])
+def test_generated_receptor_sets_equal_the_oracle(snn, libs, which, variant):
+    """Generated neurons with their own [receptors] set -- one that spells out the AMPA / GABA currents (bit-identical
+    to the built-in ionotropic receptors on the oracle, test_modelgen_receptors.py) and shared_receptors.rs's
+    ionotropic + metabotropic pair -- in a network with Poisson rows: raster, voltages, receptor states and the set's
+    variables bit-identical to the C oracle."""
+    desc, lib = libs[which]
+    assert snn._lib.load(lib).snn_custom_receptors() == desc.receptors.name.encode()
+    net = chemical_network(ob, parity, ob.NT_APPROX, ob.RC_APPROX, model=ob.CUSTOM)
+    modelgen_ref.attach(net, desc.neuron)
+    modelgen_ref.attach_receptors(net, desc.receptors)
+    net.custom_lib = lib
+    names = [n for n, _ in desc.receptors.variables]
+    if which.startswith("Own"):
+        net["current_voltage"] = ob.uniform_array(80, net.n_neurons, -68.0, -52.0)
+        net["rx_vars"][names.index("AMPA$g")] = ob.uniform_array(81, net.n_neurons, 0.5, 2.0)
+        net["rc_flags"][:, 1] = 0
+    else:
+        net["current_voltage"] = ob.uniform_array(82, net.n_neurons, -80.0, -56.0)
+        net["custom_vars"][0] = -60.0                                               # e: a stable leak would need -(v - e)
+        net["rx_vars"][names.index("Meta$s")] = ob.uniform_array(83, net.n_neurons, 0.5, 1.5)
+        net["rc_flags"][:, 2] = 0
+    net["do_plasticity"] = 0
+    steps = 300
+    dn = parity.device_from_oracle(snn, net, csr=(variant == "sparse"))
+    assert np.array_equal(dn.get_attr(0, "receptors$" + names[1]), net["rx_vars"][1][:25])
+    dn.set_history(voltage=True, spikes=True)
+    dn.run(steps // 2)
+    dn.run(steps - steps // 2)
+    net.run(steps, voltage_history=True, spike_history=True)
+    ranges = net.layout.ranges()
+    for i, _, _ in net.layout.lattices:
+        first, count, _ = ranges[i]
+        assert np.array_equal(dn.spike_history(i), net.spike_history[:, first:first + count])
+        assert np.array_equal(parity.bits(dn.voltage_history(i)), parity.bits(net.voltage_history[:, first:first + count]))
+    parity.assert_state_equal(net, parity.pull_state(dn, net), skip=("rc_current",))       # the set keeps its own currents
+    assert net["rc_r"].max() > 0.01 and np.abs(net["rx_vars"][names.index(names[1])]).max() > 0.0
+    dn.close()
+
+
 @pytest.mark.parametrize("variant", ["dense", "sparse", "sharded"])
 def test_whole_description_in_one_library_equals_the_oracle(snn, libs, variant):
     """One library carrying all five generated blocks -- the DSL Izhikevich neuron, a bursting spike train
@@ -565,7 +609,8 @@ def test_whole_description_in_one_library_equals_the_oracle(snn, libs, variant):
 def test_default_library_has_no_generated_model(snn):
     L = snn._lib.load()
     assert (L.snn_custom_model(), L.snn_custom_spike_train(), L.snn_custom_refractoriness(),
-            L.snn_custom_neurotransmitter_kinetics(), L.snn_custom_receptor_kinetics()) == (b"",) * 5
+            L.snn_custom_neurotransmitter_kinetics(), L.snn_custom_receptor_kinetics(), L.snn_custom_receptors()) == \
+        (b"",) * 6
     with pytest.raises(snn.SnnError):
         snn.DeviceNetwork(model=snn.CUSTOM)
     with pytest.raises(snn.SnnError):

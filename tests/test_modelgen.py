@@ -75,7 +75,7 @@ def test_mandatory_overrides_precedence_and_order_of_application():
     (LIF_NB.replace("vars: e = 0", "vars: flag = true, e = 0").replace("v = v_reset", "flag += true"), "on the bool variable"),
     (LIF_NB.replace("vars: e = 0", "vars: dt = true, e = 0"), "is a number"),
     (LIF_NB.replace("dv/dt = (v - e) + i", "dv/dt = (v - q) + i"), "unknown variable"),
-    (LIF_NB.replace("[neuron]", "[receptors]"), "[receptors] blocks are not supported"),
+    (LIF_NB.replace("[neuron]", "[synapse]"), "text outside a block"),
     (LIF_NB + "\n" + LIF_NB, "exactly one [neuron]"),
     (LIF_NB.replace("on_iteration:", "ion_channels: k = K\n    on_iteration:"), "unknown ion channel type"),
     (LIF_NB.replace("dv/dt = (v - e) + i", "k.update_current(v)\n        dv/dt = (v - e) + i"), "cannot call"),

@@ -187,7 +187,6 @@ def test_generated_destexhe_kinetics_equal_the_built_in_ones():
     (BASIC_NT + BASIC_NT, "more than one [neurotransmitter_kinetics]"),
     (BOUNDED_RC.replace("r = min(max(t, 0), r_max)", "r = min(max(t, 0), r_max) * v"), "unknown variable 'v'"),
     (BOUNDED_RC.replace("r = min(max(t, 0), r_max)", "t = 0"), "cannot assign to 't'"),
-    (BOUNDED_RC.replace("[receptor_kinetics]", "[receptors]"), "[receptors] blocks are not supported"),
 ])
 def test_kinetics_errors_name_the_problem(text, needle):
     with pytest.raises(modelgen.ModelError) as e:
