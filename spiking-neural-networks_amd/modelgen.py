@@ -591,7 +591,7 @@ def _convert_plain(stmts, rename, assignable, where):
         else:
             if st[0] == "diff" and where != "on_iteration":
                 raise ModelError(f"differential equations belong to the top level of on_iteration, not {where}")
-            tgt = rename(st[1])[1] if st[1] in ("current_voltage",) else st[1]
+            tgt = rename(st[1])[1]                     # the target goes through the same name table as the reads
             if tgt not in assignable:
                 raise ModelError(f"cannot assign to {st[1]!r}")
             out.append((st[0], tgt) + tuple(st[2:-1]) + (_map_expr(st[-1], rename),))
@@ -746,7 +746,6 @@ def _parse_receptors(body):
         own = _variables(g["vars"], ("v", "r", "dt", "t") + tuple(top_names), own_bools)
         if "current" in own_bools:
             raise ModelError("'current' is a number")
-        base = len(variables)
         variables += [(f"{g['name']}${n}", d) for n, d in own]
         bools |= {f"{g['name']}${n}" for n in own_bools}
         own_names = {n for n, _ in own}
@@ -769,23 +768,10 @@ def _parse_receptors(body):
         for st in _walk(raw):
             if st[0] == "diff":
                 raise ModelError("[receptors]: on_iteration takes assignments, not differential equations")
-        # targets are renamed through the same table
-        def fix_targets(stmts):
-            fixed = []
-            for st in stmts:
-                if st[0] == "if":
-                    fixed.append(("if", [(c, fix_targets(b)) for c, b in st[1]], None if st[2] is None else fix_targets(st[2])))
-                elif st[0] == "assign":
-                    fixed.append(("assign", rename(st[1])[1]) + tuple(st[2:]))
-                else:
-                    fixed.append(st)
-            return fixed
-        stmts = _convert_plain(fix_targets(raw), lambda n, rn=rename: ("var", n) if "$" in n else rn(n), assignable,
-                               "on_iteration")
+        stmts = _convert_plain(raw, rename, assignable, "on_iteration")
         cur = f"{g['name']}$current"
         names = [n for n, _ in variables]
         out_types.append((g["name"], stmts, names.index(cur) if cur in names else None))
-        del base
     if len(variables) > MAX_RECEPTOR_VARS:
         raise ModelError(f"more than {MAX_RECEPTOR_VARS} receptor variables")
     model = ReceptorsModel(name, out_types, variables, bools)
