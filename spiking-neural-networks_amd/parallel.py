@@ -11,9 +11,6 @@ replicated (deterministic xorshift32), plasticity is applied by the owner of the
 `ShardedStepper` is backend-agnostic on purpose: the product passes a `DeviceNetwork` shard, the CPU
 tests (gloo, world_size 2) pass an oracle-backed object with the same four members.
 """
-import ctypes
-
-import numpy as np
 
 
 class _DeviceWords:

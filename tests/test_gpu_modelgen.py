@@ -12,7 +12,7 @@ import parity
 from test_modelgen import (BOOL_DSL, CURRENTS, EXPECTED_FLAG, IF_DSL, IZH_DSL, LIF_NB, bool_expected_out,
                            lif_reference_trace)
 from test_modelgen_channels import CALCIUM_CLAMP, MORRIS_LECAR, VOLTAGES, calcium_reference
-from test_modelgen_receptors import IONOTROPIC_LIKE, LIF, MIXED, MULTIPLE, STEP_NEURON
+from test_modelgen_receptors import IONOTROPIC_LIKE, LIF, MIXED, STEP_NEURON
 from test_modelgen_spike_trains import BURST_DSL, RATE_DSL, REFRACTORINESS_DSL, _mixed_network
 from test_modelgen_kinetics import (APPROXIMATE_NT, BOUNDED_RC, DESTEXHE_PAIR, ELECTROCHEMICAL_REF, RESTATED_STEP,
                                     built_in_approximate, chemical_network, custom_chemical_network,

@@ -5,7 +5,6 @@ import os
 import numpy as np
 import pytest
 
-import snn_amd
 from snn_amd import modelgen
 
 LIF_NB = """

@@ -53,7 +53,6 @@ def rewards():
 def worker(rank, world, init_file, out_dir):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import snn_amd
     from snn_amd import parallel
     from oracle_shard_backend import OracleShard
     dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
