@@ -47,11 +47,14 @@ def build_custom(model, force=False):
     or every block of a modelgen.Description: neuron, spike train (SNN_ST_CUSTOM), refractoriness (kind 2):
     csrc/generated/<name>.hpp + csrc/generated/libsnn_amd_<name>.so.  Returns the library path."""
     from . import modelgen
+    import hashlib
     gen = os.path.join(CSRC, "generated")
     os.makedirs(gen, exist_ok=True)
-    header = os.path.join(gen, model.name + ".hpp")
-    out = os.path.join(gen, f"libsnn_amd_{model.name}.so")
     text = modelgen.hip_source(model)
+    # the file name carries the content: two descriptions that share a type name never share (or overwrite) a library
+    stem = f"{model.name}_{hashlib.sha1(text.encode()).hexdigest()[:10]}"
+    header = os.path.join(gen, stem + ".hpp")
+    out = os.path.join(gen, f"libsnn_amd_{stem}.so")
     if force or not os.path.exists(header) or open(header).read() != text:
         with open(header, "w") as f:
             f.write(text)
@@ -59,7 +62,7 @@ def build_custom(model, force=False):
     if not force and os.path.exists(out) and os.path.getmtime(out) >= max(os.path.getmtime(s) for s in srcs):
         return out
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    define = '-DSNN_CUSTOM_MODEL_HEADER="generated/%s.hpp"' % model.name
+    define = '-DSNN_CUSTOM_MODEL_HEADER="generated/%s.hpp"' % stem
     cmd = [hipcc] + HIPCC_FLAGS + [define, "-o", out, os.path.join(CSRC, "snn_network.hip")]
     subprocess.run(cmd, check=True, cwd=CSRC)
     return out

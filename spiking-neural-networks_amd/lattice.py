@@ -14,7 +14,7 @@ import enum
 
 import numpy as np
 
-from .network import (NT_DISCRETE_SPIKE, NT_EXPONENTIAL_DECAY, RC_EXPONENTIAL_DECAY, ST_PRESET, BCM_IZHIKEVICH, ST_BCM_POISSON,
+from .network import (CUSTOM, NT_DISCRETE_SPIKE, NT_EXPONENTIAL_DECAY, RC_EXPONENTIAL_DECAY, ST_PRESET, BCM_IZHIKEVICH, ST_BCM_POISSON,
                       DeviceNetwork, HODGKIN_HUXLEY, IZHIKEVICH, LIF, QUADRATIC_INTEGRATE_AND_FIRE, SIMPLE_LIF,
                       ADAPTIVE_LIF, ADAPTIVE_EXP_LIF, LEAKY_IZHIKEVICH,
                       NT_APPROXIMATE, NT_DESTEXHE,
@@ -216,6 +216,32 @@ class HodgkinHuxleyNeuron(_Neuron):                      # hodgkin_huxley/mod.rs
                      g_k_leak="k_leak_channel$g_k_leak", e_k_leak="k_leak_channel$e_k_leak",
                      na_current="na_channel$current", k_current="k_channel$current",
                      k_leak_current="k_leak_channel$current")
+
+
+def neuron_builder(text):
+    """The reference's `neuron_builder!("[neuron] ...")` (build_test/nb_macro/src/lib.rs) for this façade: parse the
+    description (ion channels included), compile its library (modelgen -> hipcc, cached under csrc/generated) and
+    return (NeuronClass, LatticeClass, LatticeGPUClass) -- the neuron's fields are `current_voltage`, `dt`, `c_m`,
+    `gap_conductance` and the description's variables under their DSL names (`getattr(n, "k$current")` for an ion
+    channel field).  Receptors are the ionotropic AMPA / NMDA / GABA set; descriptions with their own [receptors],
+    spike trains or kinetics go through DeviceNetwork(lib_path=...) directly."""
+    from . import _lib, modelgen
+    model = modelgen.parse(text)
+    if model.receptors is not None:
+        raise NotImplementedError("neuron_builder: a description with its own [receptors] set needs DeviceNetwork")
+    fields = dict(model.variables)
+    for b in model.bools:
+        fields[b] = bool(fields[b])
+    defaults = dict(current_voltage=model.mandatory["current_voltage"], dt=model.mandatory["dt"],
+                    c_m=model.mandatory["c_m"], gap_conductance=model.mandatory["gap_conductance"], **_Neuron._common)
+    defaults.update(fields)
+    defaults.setdefault("v_th", 0.0)            # the common attribute exists on the device whether the model reads it or not
+    neuron = type(model.name, (_Neuron,), dict(model=CUSTOM, _defaults=defaults, state_fields=tuple(fields),
+                                               lib_path=_lib.build_custom(model), description=model,
+                                               __doc__=f"generated from a neuron description ({model.name})"))
+    lattice = type(model.name + "Lattice", (Lattice,), dict(neuron_type=neuron))
+    lattice_gpu = type(model.name + "LatticeGPU", (LatticeGPU,), dict(lattice_type=lattice))
+    return neuron, lattice, lattice_gpu
 
 
 class DeltaDiracRefractoriness(_Record):                 # spike_train/mod.rs:79-88
@@ -670,8 +696,11 @@ class LatticeNetworkGPU:
         if len(models) > 1 or len(kinds) > 1:
             raise TypeError("one neuron model and one spike-train model per network (type parameters in the reference)")
         nt, rc = _kinetics_of(neurons + cells)
+        libs = {getattr(type(c), "lib_path", None) for c in neurons}      # generated neuron models carry their library
+        if len(libs) > 1:
+            raise TypeError("neurons of one network come from one library")
         self._dn = DeviceNetwork(model=models.pop(), nt_kinetics=nt, receptor_kinetics=rc, spike_train=kinds.pop(),
-                                 device=device)
+                                 device=device, lib_path=(libs.pop() if libs else None))
         for id, l in network.lattices.items():
             self._dn.add_lattice(id, l.rows, l.cols)
         for id, l in network.spike_train_lattices.items():

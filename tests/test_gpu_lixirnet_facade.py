@@ -289,3 +289,46 @@ def test_bcm_network_follows_the_bcm_example(snn):
     assert np.float32(n.average_activity) == o["bcm_average_activity"][0] and n.num_spikes == int(o["bcm_num_spikes"][0])
     assert n.num_spikes > 0 and o["weights"][1, 0] != np.float32(1.45)
     gpu.close()
+
+
+def test_neuron_builder_facade(snn):
+    """`neuron_builder` (the reference's macro of that name, build_test/nb_macro): a description with an ion channel
+    becomes neuron / lattice / GPU-lattice classes; a 4x5 lattice run through the generated LatticeGPU equals the numpy
+    interpreter of the description inside the canonical lattice step."""
+    import modelgen_ref
+    import numpy_ref as nr
+    from test_modelgen_channels import LEAK_NEURON
+    text = LEAK_NEURON.replace("vars: v_reset = -75, v_th = -55", "vars: v_reset = -75, v_th = -55, c_m = 25, ready = true") \
+                      .replace("dv/dt = l.current + i", "dv/dt = (i - l.current) / c_m")
+    Neuron, LatticeCls, LatticeGPUCls = snn.neuron_builder(text)
+    neuron = Neuron()
+    assert Neuron.__name__ == "BasicIntegrateAndFire" and neuron.c_m == 25.0 and neuron.ready is True
+    assert getattr(neuron, "l$g") == 1.0 and neuron.v_th == -55.0
+    neuron.gap_conductance = 4.0
+    rng = np.random.default_rng(3)
+    init = rng.uniform(-75, -56, (4, 5)).astype(np.float32)
+    leak = rng.uniform(0.5, 2.0, (4, 5)).astype(np.float32)
+    lattice = LatticeCls(0)
+    lattice.populate(neuron, 4, 5)
+    lattice.apply_given_position(lambda pos, n: (setattr(n, "current_voltage", float(init[pos])),
+                                                 setattr(n, "l$g", float(leak[pos])), setattr(n, "l$e", -40.0)))
+    lattice.connect(lambda x, y: x != y, lambda x, y: 1.0 + 0.1 * x[0] + 0.01 * y[1])
+    lattice.update_grid_history = True
+    gpu = LatticeGPUCls.from_lattice(lattice)
+    gpu.run_lattice(600)
+    hist = gpu.history
+    model = Neuron.description
+    n = 20
+    st = {"current_voltage": init.reshape(-1).copy(), "dt": np.full(n, 0.1, np.float32), "c_m": np.full(n, 25.0, np.float32),
+          "gap_conductance": np.full(n, 4.0, np.float32)}
+    for name, default in model.variables:
+        st[name] = np.full(n, default, np.float32)
+    st["l$g"], st["l$e"] = leak.reshape(-1).copy(), np.full(n, -40.0, np.float32)
+    vh, sh, lft = nr.run_lattice(modelgen_ref.make_step(model), st, st["gap_conductance"].copy(), lattice.weights.copy(),
+                                 lattice.connections.astype(np.uint8), 600)
+    assert sh.sum() > 10
+    assert np.array_equal(parity.bits(hist.reshape(600, -1)), parity.bits(vh))
+    cell = gpu.get_neuron(2, 3)
+    assert cell.current_voltage == float(st["current_voltage"][13]) and getattr(cell, "l$current") == float(st["l$current"][13])
+    assert cell.last_firing_time == (None if lft[13] < 0 else int(lft[13]))
+    gpu.close()
