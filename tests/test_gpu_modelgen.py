@@ -40,7 +40,10 @@ FUNCTIONS_DSL = """
         f_minus_square = -i ^ 2
 [end]"""          # the functions of build_test/nb_macro/tests/function_usage.rs in one model
 
+import random_descriptions
+
 pytestmark = pytest.mark.gpu
+RANDOM_DSL = [random_descriptions.description(seed, count=28, name=f"RandomExpressions{seed}") for seed in (7, 8)]
 f32 = np.float32
 
 
@@ -49,7 +52,7 @@ def libs(snn):
     from snn_amd import _lib, modelgen
     from concurrent.futures import ThreadPoolExecutor
     models = [modelgen.parse(text) for text in (LIF_NB, IZH_DSL, IF_DSL, CALCIUM_CLAMP, MORRIS_LECAR, FUNCTIONS_DSL,
-                                                 BOOL_DSL, ELECTROCHEMICAL_REF, RESTATED_STEP)]
+                                                 BOOL_DSL, ELECTROCHEMICAL_REF, RESTATED_STEP, *RANDOM_DSL)]
     models += [modelgen.parse_description(text) for text in (
         RATE_DSL + REFRACTORINESS_DSL, APPROXIMATE_NT + BOUNDED_RC, IZH_DSL + BURST_DSL + DESTEXHE_PAIR,
         MIXED + LIF.format(name="MixedIntegrateAndFire", receptors="MixedReceptors"),
@@ -317,6 +320,37 @@ def test_functions_and_powers_equal_the_oracle(snn, libs):
                 assert np.array_equal(np.isinf(got), np.isinf(want)), name
     assert np.array_equal(dn.get_attr(1, "f_minus_square"), -(x * x))
     assert np.array_equal(dn.get_attr(1, "f_nan") != 0, x > f32(88.73))            # exp overflows: inf - inf
+    dn.close()
+
+
+@pytest.mark.parametrize("seed", [7, 8])
+def test_random_descriptions_equal_the_oracle(snn, libs, seed):
+    """Property test of the HIP emitter: 28 random statements (every operator and function, powers, if / else with
+    && || ! isnan, earlier results as operands) compiled into a model, 256 neurons with different inputs and
+    parameters -- every variable bit-identical to the C oracle's stack program (which the numpy interpreter checks on
+    the CPU side, test_modelgen.py)."""
+    model, lib = libs[f"RandomExpressions{seed}"]
+    n = 256
+    x = ob.uniform_array(100 + seed, n, -4.0, 4.0)
+    lay = parity.Layout([(1, 1, n)], [(0, 1, n)])
+    net = parity.make_oracle(lay, model=ob.CUSTOM, st_kind=ob.ST_RATE)
+    modelgen_ref.attach(net, model)
+    net.custom_lib = lib
+    names = [name for name, _ in model.variables]
+    for k, (name, lo, hi) in enumerate((("a", -2.0, 2.0), ("b", -2.0, 2.0), ("c", 0.1, 3.0))):
+        net["custom_vars"][names.index(name)] = ob.uniform_array(200 + 100 * k + seed, n, lo, hi)
+    net["st_v_resting"] = x
+    net["connections"][n + np.arange(n), np.arange(n)] = 1
+    net["weights"][n + np.arange(n), np.arange(n)] = 1.0
+    dn = parity.device_from_oracle(snn, net)
+    dn.run(3)
+    net.run(3)
+    finite = 0
+    for k, name in enumerate(names):
+        got = dn.get_attr(1, name)
+        assert np.array_equal(parity.bits(got), parity.bits(net["custom_vars"][k])), (seed, name)
+        finite += int(np.isfinite(got).sum())
+    assert finite > 0.7 * n * len(names)
     dn.close()
 
 

@@ -287,3 +287,42 @@ def test_if_statement_errors():
         with pytest.raises(modelgen.ModelError) as e:
             modelgen.parse(text)
         assert needle in str(e.value), (needle, str(e.value))
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_descriptions_cpu_evaluators_agree(seed):
+    """Property test of the two CPU evaluators the device is held to: random expressions (every operator and function,
+    if / else, earlier results as operands) through the numpy interpreter and through the C oracle's stack program."""
+    import modelgen_ref
+    import oracle_binding as ob
+    import parity
+    import random_descriptions
+    m = modelgen.parse(random_descriptions.description(seed))
+    n = 48
+    x = ob.uniform_array(100 + seed, n, -4.0, 4.0)
+    params = {"a": ob.uniform_array(200 + seed, n, -2.0, 2.0), "b": ob.uniform_array(300 + seed, n, -2.0, 2.0),
+              "c": ob.uniform_array(400 + seed, n, 0.1, 3.0)}
+    names = [name for name, _ in m.variables]
+    step = modelgen_ref.make_step(m)
+    st = {"current_voltage": np.zeros(n, np.float32), "dt": np.full(n, 0.1, np.float32), "c_m": np.ones(n, np.float32),
+          "gap_conductance": np.full(n, 10.0, np.float32)}
+    for name, default in m.variables:
+        st[name] = np.full(n, default, np.float32)
+    st.update({k: v.copy() for k, v in params.items()})
+    with np.errstate(all="ignore"):
+        step(st, x)
+        step(st, x)
+    lay = parity.Layout([(1, 1, n)], [(0, 1, n)])
+    net = parity.make_oracle(lay, model=ob.CUSTOM, st_kind=ob.ST_RATE)
+    modelgen_ref.attach(net, m)
+    for k, v in params.items():
+        net["custom_vars"][names.index(k)] = v
+    net["st_v_resting"] = x
+    net["connections"][n + np.arange(n), np.arange(n)] = 1
+    net["weights"][n + np.arange(n), np.arange(n)] = 1.0
+    net.run(2)
+    finite = 0
+    for k, name in enumerate(names):
+        assert np.array_equal(parity.bits(net["custom_vars"][k]), parity.bits(st[name])), (seed, name)
+        finite += int(np.isfinite(st[name]).sum())
+    assert finite > 0.7 * n * len(names)
