@@ -252,7 +252,26 @@ def compile_program(model, base=None, blocks=None):
             starts.append(len(code))
             emit_expr(item)
             code.append(_OPS["END"])
+    assert _stack_depth(code) <= 64, "expression too deep for the oracle's 64-entry evaluation stack"
     return (np.array(code, np.int32), np.array(consts if consts else [0.0], np.float32), np.array(starts, np.uint32))
+
+
+def _stack_depth(code):
+    """upper bound of the evaluation-stack depth of a compiled program (straight-line scan; jumps keep the depth)"""
+    push = {_OPS["CONST"], _OPS["LOAD"]}
+    with_operand = {_OPS[k] for k in ("CONST", "LOAD", "STORE", "DIFF", "JZ", "JMP", "POWI")}
+    pop1 = {_OPS[k] for k in ("STORE", "DIFF", "JZ", "RC_SET")}
+    pop_binary = {_OPS[k] for k in ("ADD", "SUB", "MUL", "DIV", "EQ", "NE", "GE", "LE", "GT", "LT", "AND", "OR", "MIN",
+                                    "MAX", "RC_GET")}
+    depth = worst = pc = 0
+    while pc < len(code):
+        op = code[pc]
+        pc += 2 if op in with_operand else 1
+        depth += 1 if op in push else -1 if (op in pop1 or op in pop_binary) else 0
+        if op == _OPS["END"]:
+            depth = 0
+        worst = max(worst, depth)
+    return worst
 
 
 def attach_spike_train(net, model):
