@@ -60,7 +60,8 @@ int launch_inputs(snn_network *net, InputsPart part = INPUTS_ALL)
         e0 = net->ev_pool[net->ev_used].first;
         e1 = net->ev_pool[net->ev_used].second;
         net->ev_counts.resize(net->ev_pool.size(), 1);
-        net->ev_counts[net->ev_used] = (part == INPUTS_LOCAL) ? 0 : 1;   // LOCAL + REMOTE = one pass over W
+        // LOCAL + REMOTE = one pass over W (counted on the REMOTE half; a lone shard has no REMOTE half)
+        net->ev_counts[net->ev_used] = (part == INPUTS_LOCAL && lc_count < net->n_chunks) ? 0 : 1;
         ++net->ev_used;
         HIP_TRY(hipEventRecord(e0, net->stream), SNN_ERR_QUEUE);
     }
