@@ -14,7 +14,7 @@ import enum
 
 import numpy as np
 
-from .network import (CUSTOM, NT_DISCRETE_SPIKE, NT_EXPONENTIAL_DECAY, RC_EXPONENTIAL_DECAY, ST_PRESET, BCM_IZHIKEVICH, ST_BCM_POISSON,
+from .network import (CUSTOM, REFRACTORINESS_CUSTOM, ST_CUSTOM, NT_DISCRETE_SPIKE, NT_EXPONENTIAL_DECAY, RC_EXPONENTIAL_DECAY, ST_PRESET, BCM_IZHIKEVICH, ST_BCM_POISSON,
                       DeviceNetwork, HODGKIN_HUXLEY, IZHIKEVICH, LIF, QUADRATIC_INTEGRATE_AND_FIRE, SIMPLE_LIF,
                       ADAPTIVE_LIF, ADAPTIVE_EXP_LIF, LEAKY_IZHIKEVICH,
                       NT_APPROXIMATE, NT_DESTEXHE,
@@ -223,25 +223,59 @@ def neuron_builder(text):
     description (ion channels included), compile its library (modelgen -> hipcc, cached under csrc/generated) and
     return (NeuronClass, LatticeClass, LatticeGPUClass) -- the neuron's fields are `current_voltage`, `dt`, `c_m`,
     `gap_conductance` and the description's variables under their DSL names (`getattr(n, "k$current")` for an ion
-    channel field).  Receptors are the ionotropic AMPA / NMDA / GABA set; descriptions with their own [receptors],
-    spike trains or kinetics go through DeviceNetwork(lib_path=...) directly."""
+    channel field).  Receptors are the ionotropic AMPA / NMDA / GABA set.  See description_builder for texts that also
+    hold a spike train or a refractoriness."""
+    from . import modelgen
+    modelgen.parse(text)                      # a neuron and nothing else
+    out = description_builder(text)
+    return out.Neuron, out.Lattice, out.LatticeGPU
+
+
+class GeneratedDescription:
+    """What `description_builder` returns: the classes of the blocks the description has (None for the others), all
+    living in ONE compiled library (`library`)."""
+    Neuron = Lattice = LatticeGPU = SpikeTrain = SpikeTrainLattice = Refractoriness = None
+    library = description = None
+
+
+def description_builder(text):
+    """`neuron_builder!` over a text with several blocks: a [neuron] (with its [ion_channel]s), a [spike_train] and a
+    [neural_refractoriness] become façade classes that share one compiled library, so that they can meet in one
+    LatticeNetwork.  Generated kinetics and receptor sets are reached through DeviceNetwork(lib_path=...)."""
     from . import _lib, modelgen
-    model = modelgen.parse(text)
-    if model.receptors is not None:
-        raise NotImplementedError("neuron_builder: a description with its own [receptors] set needs DeviceNetwork")
-    fields = dict(model.variables)
-    for b in model.bools:
-        fields[b] = bool(fields[b])
-    defaults = dict(current_voltage=model.mandatory["current_voltage"], dt=model.mandatory["dt"],
-                    c_m=model.mandatory["c_m"], gap_conductance=model.mandatory["gap_conductance"], **_Neuron._common)
-    defaults.update(fields)
-    defaults.setdefault("v_th", 0.0)            # the common attribute exists on the device whether the model reads it or not
-    neuron = type(model.name, (_Neuron,), dict(model=CUSTOM, _defaults=defaults, state_fields=tuple(fields),
-                                               lib_path=_lib.build_custom(model), description=model,
-                                               __doc__=f"generated from a neuron description ({model.name})"))
-    lattice = type(model.name + "Lattice", (Lattice,), dict(neuron_type=neuron))
-    lattice_gpu = type(model.name + "LatticeGPU", (LatticeGPU,), dict(lattice_type=lattice))
-    return neuron, lattice, lattice_gpu
+    desc = modelgen.parse_description(text)
+    if desc.nt_kinetics is not None or desc.receptor_kinetics is not None or desc.receptors is not None:
+        raise NotImplementedError("description_builder: generated kinetics / receptor sets need DeviceNetwork")
+    out = GeneratedDescription()
+    out.description, out.library = desc, _lib.build_custom(desc)
+    if desc.neuron is not None:
+        model = desc.neuron
+        fields = {k: (bool(v) if k in model.bools else v) for k, v in model.variables}
+        defaults = dict(current_voltage=model.mandatory["current_voltage"], dt=model.mandatory["dt"],
+                        c_m=model.mandatory["c_m"], gap_conductance=model.mandatory["gap_conductance"], **_Neuron._common)
+        defaults.update(fields)
+        defaults.setdefault("v_th", 0.0)        # the common attribute exists on the device whether the model reads it or not
+        out.Neuron = type(model.name, (_Neuron,), dict(model=CUSTOM, _defaults=defaults, state_fields=tuple(fields),
+                                                       lib_path=out.library, description=model,
+                                                       __doc__=f"generated from a neuron description ({model.name})"))
+        out.Lattice = type(model.name + "Lattice", (Lattice,), dict(neuron_type=out.Neuron))
+        out.LatticeGPU = type(model.name + "LatticeGPU", (LatticeGPU,), dict(lattice_type=out.Lattice))
+    if desc.spike_train is not None:
+        st = desc.spike_train
+        fields = {k: (bool(v) if k in st.bools else v) for k, v in st.variables}
+        defaults = dict(current_voltage=st.mandatory["current_voltage"], v_th=st.mandatory["v_th"],
+                        v_resting=st.mandatory["v_resting"], dt=st.mandatory["dt"], is_spiking=False,
+                        last_firing_time=None, k=10000.0)
+        defaults.update(fields)
+        out.SpikeTrain = type(st.name, (_SpikeTrain,), dict(kind=ST_CUSTOM, _defaults=defaults, state_fields=tuple(fields),
+                                                            lib_path=out.library, description=st))
+        out.SpikeTrainLattice = type(st.name + "Lattice", (SpikeTrainLattice,), dict(spike_train_type=out.SpikeTrain))
+    if desc.refractoriness is not None:
+        rf = desc.refractoriness
+        out.Refractoriness = type(rf.name, (_Record,), dict(kind=REFRACTORINESS_CUSTOM, description=rf,
+                                                            _defaults=dict(k=rf.decay, **dict(rf.variables)),
+                                                            state_fields=tuple(n for n, _ in rf.variables)))
+    return out
 
 
 class DeltaDiracRefractoriness(_Record):                 # spike_train/mod.rs:79-88
@@ -622,9 +656,10 @@ def _download_neurons(dn, id, cells):
     if not cells:
         return
     cls = type(cells[0])
+    bools = getattr(getattr(cls, "description", None), "bools", ())       # bool variables of a generated model
     for k in ("current_voltage",) + tuple(cls.state_fields):
         for c, v in zip(cells, dn.get_attr(id, cls.abi_names.get(k, k))):
-            setattr(c, k, float(v))
+            setattr(c, k, bool(v) if k in bools else float(v))
     for k in getattr(cls, "counter_fields", ()):
         for c, v in zip(cells, dn.get_attr(id, k, dtype=np.uint32)):
             setattr(c, k, int(v))
@@ -657,6 +692,8 @@ def _upload_cells(dn, id, cells):
     refr = [c.neural_refractoriness for c in cells]
     dn.set_attr(id, "neural_refractoriness$k", np.array([c.k if r is None else r.k for c, r in zip(cells, refr)], np.float32))
     dn.set_attr(id, "neural_refractoriness$kind", np.array([0 if r is None else r.kind for r in refr], np.uint32))
+    for k in getattr(type(refr[0]), "state_fields", ()) if refr[0] is not None else ():     # generated refractoriness
+        dn.set_attr(id, "neural_refractoriness$" + k, np.array([getattr(r, k) for r in refr], np.float32))
     if cells[0].kind in (ST_POISSON, ST_BCM_POISSON):
         dn.set_attr(id, "chance_of_firing", f32("chance_of_firing"))
         dn.set_attr(id, "seed", np.array([c.seed for c in cells], np.uint32))
@@ -665,6 +702,9 @@ def _upload_cells(dn, id, cells):
                 dn.set_attr(id, k, f32(k))
             for k in ("period", "num_spikes"):
                 dn.set_attr(id, k, np.array([getattr(c, k) for c in cells], np.uint32))
+    elif cells[0].kind == ST_CUSTOM:
+        for k in type(cells[0]).state_fields:
+            dn.set_attr(id, k, f32(k))
     elif cells[0].kind == ST_PRESET:
         dn.set_attr(id, "internal_clock", f32("internal_clock"))
         dn.set_attr(id, "counter", np.array([c.counter for c in cells], np.uint32))
@@ -696,9 +736,10 @@ class LatticeNetworkGPU:
         if len(models) > 1 or len(kinds) > 1:
             raise TypeError("one neuron model and one spike-train model per network (type parameters in the reference)")
         nt, rc = _kinetics_of(neurons + cells)
-        libs = {getattr(type(c), "lib_path", None) for c in neurons}      # generated neuron models carry their library
+        # generated models carry their library; everything generated in one network comes from ONE description
+        libs = {getattr(type(c), "lib_path", None) for c in neurons + cells} - {None}
         if len(libs) > 1:
-            raise TypeError("neurons of one network come from one library")
+            raise TypeError("the generated models of one network come from one description_builder call")
         self._dn = DeviceNetwork(model=models.pop(), nt_kinetics=nt, receptor_kinetics=rc, spike_train=kinds.pop(),
                                  device=device, lib_path=(libs.pop() if libs else None))
         for id, l in network.lattices.items():
@@ -808,6 +849,11 @@ class LatticeNetworkGPU:
                                          dn.get_attr(id, "last_firing_time", dtype=np.int32)):
                     cell.current_voltage, cell.is_spiking = float(v), bool(s)
                     cell.last_firing_time = None if t < 0 else int(t)
+                if cells[0].kind == ST_CUSTOM:
+                    bools = type(cells[0]).description.bools
+                    for k in type(cells[0]).state_fields:
+                        for cell, v in zip(cells, dn.get_attr(id, k)):
+                            setattr(cell, k, bool(v) if k in bools else float(v))
                 if cells[0].kind == ST_PRESET:
                     for cell, clk, cnt in zip(cells, dn.get_attr(id, "internal_clock"),
                                               dn.get_attr(id, "counter", dtype=np.uint32)):

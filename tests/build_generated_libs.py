@@ -23,7 +23,7 @@ def descriptions():
                         .replace("dv/dt = l.current + i", "dv/dt = (i - l.current) / c_m")
     return [LIF_NB, IZH_DSL, IF_DSL, CALCIUM_CLAMP, MORRIS_LECAR, FUNCTIONS_DSL, BOOL_DSL, ELECTROCHEMICAL_REF,
             RESTATED_STEP, *RANDOM_DSL, facade, RATE_DSL + REFRACTORINESS_DSL, APPROXIMATE_NT + BOUNDED_RC,
-            IZH_DSL + BURST_DSL + DESTEXHE_PAIR,
+            IZH_DSL + BURST_DSL + DESTEXHE_PAIR, IZH_DSL + BURST_DSL,
             MIXED + LIF.format(name="MixedIntegrateAndFire", receptors="MixedReceptors"),
             IONOTROPIC_LIKE + STEP_NEURON.format(name="OwnReceptors", receptors="receptors: AmpaGabaReceptors\n    ")]
 

@@ -332,3 +332,60 @@ def test_neuron_builder_facade(snn):
     assert cell.current_voltage == float(st["current_voltage"][13]) and getattr(cell, "l$current") == float(st["l$current"][13])
     assert cell.last_firing_time == (None if lft[13] < 0 else int(lft[13]))
     gpu.close()
+
+
+def test_description_builder_facade(snn):
+    """description_builder: a text with a neuron, a spike train and a refractoriness gives façade classes that share one
+    library; a LatticeNetwork built from them (Izhikevich in the DSL driven by the bursting train of
+    test_modelgen_spike_trains.py) equals the C oracle stepping the same description."""
+    import modelgen_ref
+    from test_modelgen import IZH_DSL
+    from test_modelgen_spike_trains import BURST_DSL
+    ln = snn
+    g = ln.description_builder(IZH_DSL + BURST_DSL)
+    assert g.Neuron.lib_path == g.SpikeTrain.lib_path == g.library
+    assert g.SpikeTrain().v_th == 25.0 and g.SpikeTrain().bursting is False and g.Refractoriness().plateau == 3.0
+    rng = np.random.default_rng(9)
+    init = rng.uniform(-65, 30, (4, 4)).astype(np.float32)
+    freq = rng.uniform(0.01, 0.06, (2, 3)).astype(np.float32)
+    lattice = g.Lattice(0)
+    lattice.populate(g.Neuron(gap_conductance=6.0), 4, 4)
+    lattice.apply_given_position(lambda pos, n: setattr(n, "current_voltage", float(init[pos])))
+    lattice.update_grid_history = True
+    train = g.SpikeTrain()
+    train.neural_refractoriness = g.Refractoriness(k=1500.0, plateau=5.0)
+    trains = g.SpikeTrainLattice(1)
+    trains.populate(train, 2, 3)
+    for (r, c), f in np.ndenumerate(freq):
+        cell = trains.get_neuron(r, c)                  # a copy, as in the reference's Python classes
+        cell.freq = float(f)
+        trains.set_neuron(r, c, cell)
+    trains.update_grid_history = True
+    network = ln.LatticeNetwork.generate_network([lattice], [trains])
+    network.connect_internally(0, lambda x, y: x != y, lambda x, y: 1.0)
+    network.connect(1, 0, lambda x, y: (x[0] + x[1] + y[0]) % 2 == 0, lambda x, y: 2.0)
+    gpu = ln.LatticeNetworkGPU.from_network(network)
+    gpu.run_lattices(700)
+
+    desc = g.description
+    lay = parity.Layout([(0, 4, 4)], [(1, 2, 3)])
+    net = parity.make_oracle(lay, model=ob.CUSTOM, st_kind=ob.ST_CUSTOM)
+    modelgen_ref.attach(net, desc.neuron)
+    modelgen_ref.attach_spike_train(net, desc.spike_train)
+    modelgen_ref.attach_refractoriness(net, desc.refractoriness)
+    st_names = [n for n, _ in desc.spike_train.variables]
+    net["current_voltage"] = init.reshape(-1)
+    net["gap_conductance"] = 6.0
+    net["st_custom_vars"][st_names.index("freq")] = freq.reshape(-1)
+    net["st_k"] = 1500.0
+    net["refr_vars"][0] = 5.0
+    w, c = gpu._dn.get_graph_rows(0, net.n_tot)
+    net["weights"][...] = w
+    net["connections"][...] = c
+    net.run(700, voltage_history=True, st_voltage_history=True)
+    assert np.array_equal(parity.bits(gpu.history(0).reshape(700, -1)), parity.bits(net.voltage_history))
+    assert np.array_equal(parity.bits(gpu.history(1).reshape(700, -1)), parity.bits(net.st_voltage_history))
+    cell = gpu.get_spike_train_lattice(1).get_neuron(1, 2)
+    assert cell.phase == float(net["st_custom_vars"][st_names.index("phase")][5])
+    assert isinstance(cell.bursting, bool) and (net.st_voltage_history == np.float32(25.0)).sum() > 30
+    gpu.close()
