@@ -141,16 +141,36 @@ def reward_modulated_4x4():
     return net, 900
 
 
+def generated_morris_lecar_3x3():
+    """a generated model (SNN_MODEL_CUSTOM): the three-channel Morris-Lecar description of test_modelgen_channels.py in a
+    3x3 lattice driven by two Poisson cells; the oracle steps it as a stack program, the device as generated HIP"""
+    import modelgen_ref
+    from snn_amd import modelgen
+    from test_modelgen_channels import MORRIS_LECAR
+    model = modelgen.parse(MORRIS_LECAR)
+    net = parity.make_oracle(parity.Layout([(0, 3, 3)], [(1, 1, 2)]), model=ob.CUSTOM, st_kind=ob.ST_POISSON)
+    modelgen_ref.attach(net, model)
+    names = [n for n, _ in model.variables]
+    net["current_voltage"] = ob.uniform_array(11, 9, -70.0, -20.0)
+    net["gap_conductance"] = 1.0
+    net["custom_vars"][names.index("k_channel$phi")] = ob.uniform_array(12, 9, 0.04, 0.09)
+    net["st_chance_of_firing"] = np.array([0.02, 0.05], np.float32)
+    net["st_seed"] = np.array([77, 78], np.uint32)
+    net.fill_graph(13, 0.5, 1.5)
+    net["do_plasticity"] = 1
+    return net, 2400
+
+
 CASES = {f.__name__: f for f in (izh_4x4_ones, izh_4x4_random, izh_32x32_random, stdp_3_neurons, hh_pair, ampa_pair,
                                  spike_trains_poisson, spike_trains_rate, adaptive_exp_lif_3x3, leaky_izhikevich_3x3,
-                                 preset_exponential_decay_kinetics, reward_modulated_4x4)}
+                                 preset_exponential_decay_kinetics, reward_modulated_4x4, generated_morris_lecar_3x3)}
 
 EXTRA = {"hh_pair": ("m_state", "h_state", "n_state"), "stdp_3_neurons": ("weights",),
          "ampa_pair": ("nt_t", "rc_r", "rc_current"), "spike_trains_poisson": ("st_seed", "st_last_firing_time"),
          "spike_trains_rate": ("st_step", "st_last_firing_time"),
          "adaptive_exp_lif_3x3": ("w_value", "refractory_count"), "leaky_izhikevich_3x3": ("w_value",),
          "preset_exponential_decay_kinetics": ("nt_t", "rc_r", "st_step", "st_counter", "st_last_firing_time"),
-         "reward_modulated_4x4": ("weights", "traces")}
+         "reward_modulated_4x4": ("weights", "traces"), "generated_morris_lecar_3x3": ("custom_vars", "weights")}
 
 
 def outputs(name, net, steps):

@@ -16,6 +16,8 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 def test_hip_matches_golden(snn, name):
     net, steps = golden_cases.CASES[name]()          # inputs only; the oracle is not stepped
     want = np.load(os.path.join(GOLDEN, name + ".npz"))
+    if getattr(net, "custom_model", None) is not None:          # a generated model: its library (hipcc, cached)
+        net.custom_lib = snn._lib.build_custom(net.custom_model)
     dn = parity.device_from_oracle(snn, net)
     for slot, (i, _, _) in enumerate(net.layout.lattices):
         if net["rm_do_modulation"][slot]:
