@@ -32,6 +32,6 @@ if __name__ == "__main__":
     from snn_amd import _lib, modelgen
     models = [modelgen.parse_description(text) for text in descriptions()]
     t0 = time.time()
-    with ThreadPoolExecutor(max_workers=4) as pool:
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
         paths = list(pool.map(_lib.build_custom, models))
     print(f"{len(paths)} libraries in {time.time() - t0:.0f} s")

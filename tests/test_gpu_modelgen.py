@@ -2,6 +2,8 @@
 its own library (`_lib.build_custom`) and stepped through the same C ABI.  Checked against (a) the hand expansion the
 reference's own test compares its generated code with (build_test/nb_macro/tests/basic_lif.rs:22-50 with
 tests/lif_reference.rs) and (b) a numpy float32 interpreter of the description inside the canonical lattice step."""
+import os
+
 import numpy as np
 import pytest
 
@@ -57,7 +59,7 @@ def libs(snn):
         RATE_DSL + REFRACTORINESS_DSL, APPROXIMATE_NT + BOUNDED_RC, IZH_DSL + BURST_DSL + DESTEXHE_PAIR,
         MIXED + LIF.format(name="MixedIntegrateAndFire", receptors="MixedReceptors"),
         IONOTROPIC_LIKE + STEP_NEURON.format(name="OwnReceptors", receptors="receptors: AmpaGabaReceptors\n    "))]
-    with ThreadPoolExecutor(max_workers=4) as pool:          # one hipcc each
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:          # one hipcc each
         paths = list(pool.map(_lib.build_custom, models))
     return {m.name: (m, path) for m, path in zip(models, paths)}
 
