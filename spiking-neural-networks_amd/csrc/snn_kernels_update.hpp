@@ -97,7 +97,8 @@ struct GlobalSums {
     }
 };
 
-// Ionotropic::update_receptor_kinetics + set_receptor_currents (iterate_and_spike/mod.rs:1186-1284)
+// Ionotropic::update_receptor_kinetics (iterate_and_spike/mod.rs:1186-1205); a type absent from the aggregated input
+// (count 0) leaves r untouched
 template <class Sums>
 __device__ __forceinline__ void receptors_kinetics(const UpdateArgs &a, uint32_t q, uint32_t ql, float dt, const Sums &sums)
 {
