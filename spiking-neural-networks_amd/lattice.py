@@ -231,6 +231,17 @@ def neuron_builder(text):
     return out.Neuron, out.Lattice, out.LatticeGPU
 
 
+def neuron_builder_from_file(path):
+    """`neuron_builder_from_file!("model.nb")` (build_test/nb_macro/src/lib.rs:9360): neuron_builder on a file's text"""
+    with open(path) as f:
+        return neuron_builder(f.read())
+
+
+def description_builder_from_file(path):
+    with open(path) as f:
+        return description_builder(f.read())
+
+
 class GeneratedDescription:
     """What `description_builder` returns: the classes of the blocks the description has (None for the others), all
     living in ONE compiled library (`library`)."""

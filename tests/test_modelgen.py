@@ -326,3 +326,20 @@ def test_random_descriptions_cpu_evaluators_agree(seed):
         assert np.array_equal(parity.bits(net["custom_vars"][k]), parity.bits(st[name])), (seed, name)
         finite += int(np.isfinite(st[name]).sum())
     assert finite > 0.7 * n * len(names)
+
+
+def test_description_file_reader(tmp_path, monkeypatch):
+    """neuron_builder_from_file (the reference's macro of that name, basic_lif_from_file.rs:9): the file's text goes
+    through neuron_builder; here with the compile step stubbed out (hipcc runs in the GPU suite)."""
+    import snn_amd
+    from snn_amd import _lib
+    path = tmp_path / "lif.nb"
+    path.write_text(LIF_NB)
+    monkeypatch.setattr(_lib, "build_custom", lambda model, force=False: "/nonexistent/" + model.name + ".so")
+    Neuron, LatticeCls, LatticeGPUCls = snn_amd.neuron_builder_from_file(str(path))
+    assert Neuron.__name__ == "BasicIntegrateAndFire" and Neuron().v_reset == -75.0 and Neuron.model == snn_amd.CUSTOM
+    assert LatticeCls.neuron_type is Neuron and LatticeGPUCls.lattice_type is LatticeCls
+    assert Neuron.lib_path.endswith("BasicIntegrateAndFire.so")
+    with pytest.raises(modelgen.ModelError):
+        path.write_text(LIF_NB.replace("[end]", ""))
+        snn_amd.neuron_builder_from_file(str(path))
