@@ -14,7 +14,7 @@ import enum
 
 import numpy as np
 
-from .network import (CUSTOM, REFRACTORINESS_CUSTOM, ST_CUSTOM, NT_DISCRETE_SPIKE, NT_EXPONENTIAL_DECAY, RC_EXPONENTIAL_DECAY, ST_PRESET, BCM_IZHIKEVICH, ST_BCM_POISSON,
+from .network import (CUSTOM, NT_CUSTOM, RC_CUSTOM, REFRACTORINESS_CUSTOM, ST_CUSTOM, NT_DISCRETE_SPIKE, NT_EXPONENTIAL_DECAY, RC_EXPONENTIAL_DECAY, ST_PRESET, BCM_IZHIKEVICH, ST_BCM_POISSON,
                       DeviceNetwork, HODGKIN_HUXLEY, IZHIKEVICH, LIF, QUADRATIC_INTEGRATE_AND_FIRE, SIMPLE_LIF,
                       ADAPTIVE_LIF, ADAPTIVE_EXP_LIF, LEAKY_IZHIKEVICH,
                       NT_APPROXIMATE, NT_DESTEXHE,
@@ -246,17 +246,20 @@ class GeneratedDescription:
     """What `description_builder` returns: the classes of the blocks the description has (None for the others), all
     living in ONE compiled library (`library`)."""
     Neuron = Lattice = LatticeGPU = SpikeTrain = SpikeTrainLattice = Refractoriness = None
+    Neurotransmitter = ReceptorKinetics = None
     library = description = None
 
 
 def description_builder(text):
     """`neuron_builder!` over a text with several blocks: a [neuron] (with its [ion_channel]s), a [spike_train] and a
-    [neural_refractoriness] become façade classes that share one compiled library, so that they can meet in one
-    LatticeNetwork.  Generated kinetics and receptor sets are reached through DeviceNetwork(lib_path=...)."""
+    [neural_refractoriness], a [neurotransmitter_kinetics] and a [receptor_kinetics] become façade classes that share
+    one compiled library, so that they can meet in one LatticeNetwork (the kinetics classes stand where
+    ApproximateNeurotransmitter / ApproximateReceptor do: `AMPAReceptor(r=g.ReceptorKinetics())`).  Generated receptor
+    sets are reached through DeviceNetwork(lib_path=...)."""
     from . import _lib, modelgen
     desc = modelgen.parse_description(text)
-    if desc.nt_kinetics is not None or desc.receptor_kinetics is not None or desc.receptors is not None:
-        raise NotImplementedError("description_builder: generated kinetics / receptor sets need DeviceNetwork")
+    if desc.receptors is not None:
+        raise NotImplementedError("description_builder: a generated receptor set needs DeviceNetwork")
     out = GeneratedDescription()
     out.description, out.library = desc, _lib.build_custom(desc)
     if desc.neuron is not None:
@@ -286,6 +289,13 @@ def description_builder(text):
         out.Refractoriness = type(rf.name, (_Record,), dict(kind=REFRACTORINESS_CUSTOM, description=rf,
                                                             _defaults=dict(k=rf.decay, **dict(rf.variables)),
                                                             state_fields=tuple(n for n, _ in rf.variables)))
+    for attr, model, selector in (("Neurotransmitter", desc.nt_kinetics, NT_CUSTOM),
+                                  ("ReceptorKinetics", desc.receptor_kinetics, RC_CUSTOM)):
+        if model is not None:
+            fields = {k: (bool(v) if k in model.bools else v) for k, v in model.variables}
+            setattr(out, attr, type(model.name, (_Record,), dict(kinetics=selector, description=model, lib_path=out.library,
+                                                                 _defaults={model.state: 0.0, **fields},
+                                                                 state_fields=tuple(fields))))
     return out
 
 
@@ -620,6 +630,13 @@ def _upload_nt(dn, id, cells):
     dn.set_attr(id, "neurotransmitters$flags", flags)
     for k, a in arr.items():
         dn.set_attr(id, f"neurotransmitters${k}", a)
+    generated = [type(v) for c in cells for v in c.synaptic_neurotransmitters.values() if v.kinetics == NT_CUSTOM]
+    for k in generated[0].state_fields if generated else ():            # variables of generated kinetics, per type
+        a = np.full((n, 3), generated[0]._defaults[k], np.float32)
+        for i, c in enumerate(cells):
+            for t, v in c.synaptic_neurotransmitters.items():
+                a[i, int(t)] = getattr(v, k)
+        dn.set_attr(id, f"neurotransmitters${k}", a)
 
 
 def _upload_neurons(dn, id, cells):
@@ -660,6 +677,10 @@ def _upload_neurons(dn, id, cells):
         dn.set_attr(id, p + "$r$kinetics$beta", vals["beta"])
         if t == IonotropicNeurotransmitterType.NMDA:
             dn.set_attr(id, p + "_mg", vals["mg"])
+        generated = [type(c.receptors[t].r) for c in cells if t in c.receptors and c.receptors[t].r.kinetics == RC_CUSTOM]
+        for k in generated[0].state_fields if generated else ():        # variables of generated receptor kinetics
+            dn.set_attr(id, f"{p}$r$kinetics${k}", np.array(
+                [getattr(c.receptors[t].r, k) if t in c.receptors else generated[0]._defaults[k] for c in cells], np.float32))
     dn.set_attr(id, "receptors$flags", flags)
 
 
@@ -692,6 +713,17 @@ def _download_neurons(dn, id, cells):
             rec = c.receptors.get(ty)
             if rec is not None:
                 rec.r.r, rec.current = float(r[i]), float(cur[i])
+        generated = [type(c.receptors[ty].r) for c in cells if ty in c.receptors and c.receptors[ty].r.kinetics == RC_CUSTOM]
+        for k in generated[0].state_fields if generated else ():
+            for c, v in zip(cells, dn.get_attr(id, f"receptors${ty.name}$r$kinetics${k}")):
+                if ty in c.receptors:
+                    setattr(c.receptors[ty].r, k, float(v))
+    generated = [type(v) for c in cells for v in c.synaptic_neurotransmitters.values() if v.kinetics == NT_CUSTOM]
+    for k in generated[0].state_fields if generated else ():
+        a = dn.get_attr(id, f"neurotransmitters${k}", per_type=True)
+        for i, c in enumerate(cells):
+            for ty, v in c.synaptic_neurotransmitters.items():
+                setattr(v, k, float(a[i, int(ty)]))
 
 
 def _upload_cells(dn, id, cells):
@@ -748,7 +780,10 @@ class LatticeNetworkGPU:
             raise TypeError("one neuron model and one spike-train model per network (type parameters in the reference)")
         nt, rc = _kinetics_of(neurons + cells)
         # generated models carry their library; everything generated in one network comes from ONE description
-        libs = {getattr(type(c), "lib_path", None) for c in neurons + cells} - {None}
+        libs = {getattr(type(c), "lib_path", None) for c in neurons + cells}
+        libs |= {getattr(type(v), "lib_path", None) for c in neurons + cells for v in c.synaptic_neurotransmitters.values()}
+        libs |= {getattr(type(v.r), "lib_path", None) for c in neurons for v in c.receptors.values()}
+        libs -= {None}
         if len(libs) > 1:
             raise TypeError("the generated models of one network come from one description_builder call")
         self._dn = DeviceNetwork(model=models.pop(), nt_kinetics=nt, receptor_kinetics=rc, spike_train=kinds.pop(),

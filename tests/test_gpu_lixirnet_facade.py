@@ -389,3 +389,54 @@ def test_description_builder_facade(snn):
     assert cell.phase == float(net["st_custom_vars"][st_names.index("phase")][5])
     assert isinstance(cell.bursting, bool) and (net.st_voltage_history == np.float32(25.0)).sum() > 30
     gpu.close()
+
+
+def test_generated_kinetics_facade(snn):
+    """description_builder's kinetics classes stand where ApproximateNeurotransmitter / ApproximateReceptor do: a
+    network whose transmitter and receptor kinetics come from a description that restates the Approximate kinetics
+    runs bit-identically to the same network on the built-in classes (test_modelgen_kinetics.py holds the oracle to
+    the same equality)."""
+    from test_modelgen_kinetics import APPROXIMATE_NT, BOUNDED_RC
+    ln = snn
+    g = ln.description_builder(APPROXIMATE_NT + BOUNDED_RC)
+    rng = np.random.default_rng(12)
+    init = rng.uniform(-65, 30, (4, 5)).astype(np.float32)
+    t_max = rng.uniform(0.5, 1.0, (4, 5)).astype(np.float32)
+    histories, final_t, final_r = [], [], []
+    for generated in (False, True):
+        if generated:
+            release = lambda tm: g.Neurotransmitter(t_max=tm, c=0.03)
+            kinetics = g.ReceptorKinetics
+        else:
+            release = lambda tm: ln.ApproximateNeurotransmitter(t_max=tm, clearance_constant=0.03)
+            kinetics = ln.ApproximateReceptor
+        receptors = ln.Ionotropic()
+        receptors.insert(ln.IonotropicNeurotransmitterType.AMPA, ln.AMPAReceptor(g=2.5, r=kinetics()))
+        receptors.insert(ln.IonotropicNeurotransmitterType.GABA, ln.GABAReceptor(r=kinetics()))
+        neuron = ln.IzhikevichNeuron(gap_conductance=10.0, c_m=25.0)
+        neuron.set_receptors(receptors)
+        lattice = ln.IzhikevichNeuronLattice(0)
+        lattice.populate(neuron, 4, 5)
+
+        def setup(pos, n):
+            n.current_voltage = float(init[pos])
+            which = ln.IonotropicNeurotransmitterType.AMPA if (pos[0] + pos[1]) % 3 else ln.IonotropicNeurotransmitterType.GABA
+            n.set_synaptic_neurotransmitters({which: release(float(t_max[pos]))})
+        lattice.apply_given_position(setup)
+        lattice.connect(lambda x, y: x != y, lambda x, y: 1.0 + 0.05 * y[1])
+        lattice.electrical_synapse = True
+        lattice.chemical_synapse = True
+        lattice.update_grid_history = True
+        gpu = ln.IzhikevichNeuronLatticeGPU.from_lattice(lattice)
+        gpu.run_lattice(500)
+        histories.append(gpu.history.copy())
+        cell = gpu.get_neuron(2, 3)
+        cells = [gpu.get_neuron(r, c) for r in range(4) for c in range(5)]
+        final_t.append([next(iter(n.synaptic_neurotransmitters.values())).t for n in cells])
+        final_r.append([n.receptors[ln.IonotropicNeurotransmitterType.AMPA].r.r for n in cells])
+        if generated:
+            assert cell.receptors[ln.IonotropicNeurotransmitterType.AMPA].r.r_max == 1.0
+            assert next(iter(cell.synaptic_neurotransmitters.values())).t_max == float(t_max[2, 3])
+        gpu.close()
+    assert np.array_equal(parity.bits(histories[0]), parity.bits(histories[1]))
+    assert final_t[0] == final_t[1] and final_r[0] == final_r[1] and max(final_t[0]) > 0.1 and max(final_r[0]) > 0.1
