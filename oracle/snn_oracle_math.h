@@ -185,13 +185,17 @@ static inline float snn_o_tanf(float x)
     return (float)(s / c);
 }
 
-/* x.powf(n), n an integer literal: left-to-right product in binary64, one rounding */
+/* x.powf(n), n an integer literal: square-and-multiply in binary64, one rounding */
 static inline float snn_o_powif(float x, int n)
 {
-    double d = (double)x, p = 1.0;
+    double b = (double)x, r = 1.0;
     int m = (n < 0) ? -n : n;
-    for (int k = 0; k < m; ++k) p = p * d;
-    return (float)((n < 0) ? 1.0 / p : p);
+    while (m) {                      /* square and multiply: x^3 = x * x^2, x^4 = (x^2)^2 as snn_o_pow3f / snn_o_pow4f form them */
+        if (m & 1) r = r * b;
+        m >>= 1;
+        if (m) b = b * b;
+    }
+    return (float)((n < 0) ? 1.0 / r : r);
 }
 
 /* x^3 as libm powf(x, 3.) returns it (ion_channels/mod.rs:234) */

@@ -30,7 +30,7 @@ static const char *const NAMES[NSTORE] = {""};
 static const float DEFAULTS[NSTORE] = {0.0f};
 constexpr float DEFAULT_VOLTAGE = 0.0f, DEFAULT_DT = 0.1f, DEFAULT_C_M = 1.0f, DEFAULT_GAP = 10.0f;
 __device__ __forceinline__ void on_iteration(float &, float (&)[NSTORE], float, float, float, float) {}
-__device__ __forceinline__ bool spike_detection(float, const float (&)[NSTORE], float, float, float, float) { return false; }
+__device__ __forceinline__ bool spike_detection(float, float (&)[NSTORE], float, float, float, float) { return false; }
 __device__ __forceinline__ void on_spike(float &, float (&)[NSTORE], float, float, float, float) {}
 constexpr bool HAS_ELECTROCHEMICAL = false;
 template <class Chem>

@@ -163,15 +163,18 @@ __device__ __forceinline__ float tanf_portable(float x)
     return (float)(s / c);
 }
 
-// x.powf(n) for an integer literal n (the only exponents the generator accepts): left-to-right product in binary64,
+// x.powf(n) for an integer literal n (the only exponents the generator accepts): square-and-multiply in binary64,
 // one rounding to binary32; n < 0 -> reciprocal of the product
 __device__ __forceinline__ float powif_portable(float x, int n)
 {
-    const double d = (double)x;
-    const int m = (n < 0) ? -n : n;
-    double p = 1.0;
-    for (int k = 0; k < m; ++k) p = p * d;
-    return (float)((n < 0) ? 1.0 / p : p);
+    double b = (double)x, r = 1.0;
+    int m = (n < 0) ? -n : n;
+    while (m) {                      // square and multiply: x^3 = x * x^2, x^4 = (x^2)^2 as pow3f / pow4f form them
+        if (m & 1) r = r * b;
+        m >>= 1;
+        if (m) b = b * b;
+    }
+    return (float)((n < 0) ? 1.0 / r : r);
 }
 
 // nb_macro's heaviside (lib.rs:9176-9178): `if x < 0 { 0 } else { x }`

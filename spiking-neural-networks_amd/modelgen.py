@@ -70,9 +70,10 @@ the reference tests against is build_test/nb_macro/tests/lif_reference.rs):
 `hip_source(model)` emits the header that csrc/snn_custom_model.hpp includes when the library is compiled with
 -DSNN_CUSTOM_MODEL_HEADER; `_lib.build_custom(model)` compiles such a library.  Not supported (rejected with a
 message): several receptor states per neurotransmitter (`receptors: r1, r2`), `^` with a non-literal or
-fractional exponent, and `continuous()` spike detection --
-the code the reference generates for it reads a `last_voltage` that is never defined (lib.rs:984-990), so there is
-no behaviour to match.
+fractional exponent.  `spike_detection: continuous()`: the Rust the reference prints for it (lib.rs:984-990) reads
+a `last_voltage` it never defines; the detector it spells out is the built-in HodgkinHuxleyNeuron's
+(hodgkin_huxley/mod.rs:207-220: a peak above v_th), and that is what is generated, with last_voltage = the voltage at
+the start of the iteration and the bool `was_increasing` as an extra variable.
 """
 import re
 import struct
@@ -299,6 +300,7 @@ class NeuronModel:
         self.ion_channels = []              # [(instance name, channel type name)]
         self.on_electrochemical_iteration = None   # statements replacing the default chemical step (lib.rs:2280-2316)
         self.receptors = None               # name of the [receptors] block the neuron uses (default: ionotropic set)
+        self.after_detection = []           # statements run right after spike_detection is evaluated (continuous())
         self.bools = set()                  # variables declared true / false: stored as 1.0 / 0.0
 
 
@@ -878,9 +880,22 @@ def _parse_neuron(body, channels):
     if len(model.variables) > MAX_VARS:
         raise ModelError(f"more than {MAX_VARS} variables")
     detect = " ".join(sections["spike_detection"]).strip()
-    if detect.replace(" ", "") == "continuous()":
-        raise ModelError("continuous() spike detection is not supported (the reference generates code that reads an "
-                         "undefined last_voltage)")
+    continuous = detect.replace(" ", "") == "continuous()"
+    if continuous:
+        # lib.rs:984-990 prints the peak detector of the built-in HodgkinHuxleyNeuron (hodgkin_huxley/mod.rs:207-220)
+        # but forgets to define `last_voltage`; what is built here is that detector with last_voltage = the voltage at
+        # the start of the iteration, exactly as the built-in neuron has it
+        if "v_th" not in dict(model.variables):
+            raise ModelError("continuous() compares with v_th: list it in vars")
+        for hidden, is_bool in (("last_voltage", False), ("was_increasing", True)):
+            if hidden in dict(model.variables):
+                raise ModelError(f"continuous() keeps its own '{hidden}'")
+            model.variables.append((hidden, 0.0))
+            if is_bool:
+                model.bools.add(hidden)
+        detect = "v > v_th && was_increasing && !(last_voltage < v)"
+    if len(model.variables) > MAX_VARS:
+        raise ModelError(f"more than {MAX_VARS} variables")
     known = {"v", "i", "dt", "c_m", "gap_conductance"} | {n for n, _ in model.variables}
 
     def rename(n):                                  # c.current -> c$current
@@ -930,6 +945,10 @@ def _parse_neuron(body, channels):
     model.spike_detection = _map_expr(parse_expr(detect), rename)
     model.on_iteration = convert(_block(sections["on_iteration"])[0], "on_iteration")
     model.on_spike = convert(_block(sections.get("on_spike", []))[0], "on_spike")
+    if continuous:
+        remember = ("assign", "last_voltage", "=", ("var", "v"))
+        model.on_iteration.insert(0, remember)
+        model.after_detection = [("assign", "was_increasing", "=", ("bin", "<", ("var", "last_voltage"), ("var", "v")))]
     model.receptors = None
     if sections.get("receptors"):
         model.receptors = " ".join(sections["receptors"]).strip()
@@ -939,6 +958,8 @@ def _parse_neuron(body, channels):
     if sections.get("on_electrochemical_iteration"):
         model.on_electrochemical_iteration = convert(_block(sections["on_electrochemical_iteration"])[0],
                                                      "on_electrochemical_iteration")
+        if continuous:
+            model.on_electrochemical_iteration.insert(0, remember)
     for where, stmts in (("on_iteration", model.on_iteration), ("on_spike", model.on_spike)):
         for st in _walk(stmts):
             exprs = [c for c, _ in st[1]] if st[0] == "if" else [st[-1]] if st[0] in ("diff", "assign") else []
@@ -946,8 +967,8 @@ def _parse_neuron(body, channels):
                 raise ModelError(f"receptors.get_receptor_currents belongs to on_electrochemical_iteration, not {where}")
     if _has_rc_get(model.spike_detection):
         raise ModelError("receptors.get_receptor_currents belongs to on_electrochemical_iteration, not spike_detection")
-    _check_types(model.on_iteration + model.on_spike + (model.on_electrochemical_iteration or []), model.bools,
-                 condition=model.spike_detection)
+    _check_types(model.on_iteration + model.on_spike + (model.on_electrochemical_iteration or []) + model.after_detection,
+                 model.bools, condition=model.spike_detection)
     return model
 
 
@@ -1126,9 +1147,11 @@ __device__ __forceinline__ void on_iteration(float &v, float (&x)[NSTORE], float
 {{
 {_hip_statements(model.on_iteration, index, True)}
 }}
-__device__ __forceinline__ bool spike_detection(float v, const float (&x)[NSTORE], float i_in, float dt, float c_m, float g_gap)
+__device__ __forceinline__ bool spike_detection(float v, float (&x)[NSTORE], float i_in, float dt, float c_m, float g_gap)
 {{
-    return {_hip_expr(model.spike_detection, index)};
+    const bool spiking = {_hip_expr(model.spike_detection, index)};
+{_hip_statements(model.after_detection, index, False)}
+    return spiking;
 }}
 __device__ __forceinline__ void on_spike(float &v, float (&x)[NSTORE], float i_in, float dt, float c_m, float g_gap)
 {{

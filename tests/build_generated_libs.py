@@ -14,7 +14,7 @@ def descriptions():
     import random_descriptions
     from test_gpu_modelgen import FUNCTIONS_DSL, RANDOM_DSL
     from test_modelgen import BOOL_DSL, IF_DSL, IZH_DSL, LIF_NB
-    from test_modelgen_channels import CALCIUM_CLAMP, LEAK_NEURON, MORRIS_LECAR
+    from test_modelgen_channels import CALCIUM_CLAMP, HODGKIN_HUXLEY, LEAK_NEURON, MORRIS_LECAR
     from test_modelgen_kinetics import APPROXIMATE_NT, BOUNDED_RC, DESTEXHE_PAIR, ELECTROCHEMICAL_REF, RESTATED_STEP
     from test_modelgen_receptors import IONOTROPIC_LIKE, LIF, MIXED, STEP_NEURON
     from test_modelgen_spike_trains import BURST_DSL, RATE_DSL, REFRACTORINESS_DSL
@@ -22,7 +22,7 @@ def descriptions():
     facade = LEAK_NEURON.replace("vars: v_reset = -75, v_th = -55", "vars: v_reset = -75, v_th = -55, c_m = 25, ready = true") \
                         .replace("dv/dt = l.current + i", "dv/dt = (i - l.current) / c_m")
     return [LIF_NB, IZH_DSL, IF_DSL, CALCIUM_CLAMP, MORRIS_LECAR, FUNCTIONS_DSL, BOOL_DSL, ELECTROCHEMICAL_REF,
-            RESTATED_STEP, *RANDOM_DSL, facade, RATE_DSL + REFRACTORINESS_DSL, APPROXIMATE_NT + BOUNDED_RC,
+            RESTATED_STEP, HODGKIN_HUXLEY, *RANDOM_DSL, facade, RATE_DSL + REFRACTORINESS_DSL, APPROXIMATE_NT + BOUNDED_RC,
             IZH_DSL + BURST_DSL + DESTEXHE_PAIR, IZH_DSL + BURST_DSL,
             MIXED + LIF.format(name="MixedIntegrateAndFire", receptors="MixedReceptors"),
             IONOTROPIC_LIKE + STEP_NEURON.format(name="OwnReceptors", receptors="receptors: AmpaGabaReceptors\n    ")]

@@ -139,6 +139,7 @@ def make_step(model):
             env[name] = state[name]
         _run(model.on_iteration, env)
         spike = np.broadcast_to(evaluate(model.spike_detection, env), env["v"].shape).copy()
+        _run(getattr(model, "after_detection", []), env)
         _run(model.on_spike, env, mask=spike)
         state["current_voltage"] = env["v"]
         for name, _ in model.variables:
@@ -251,6 +252,8 @@ def compile_program(model, base=None, blocks=None):
         else:
             starts.append(len(code))
             emit_expr(item)
+            if item is getattr(model, "spike_detection", None):      # balanced statements: the flag stays on the stack
+                emit_statements(getattr(model, "after_detection", []))
             code.append(_OPS["END"])
     assert _stack_depth(code) <= 64, "expression too deep for the oracle's 64-entry evaluation stack"
     return (np.array(code, np.int32), np.array(consts if consts else [0.0], np.float32), np.array(starts, np.uint32))

@@ -13,7 +13,7 @@ import modelgen_ref
 import parity
 from test_modelgen import (BOOL_DSL, CURRENTS, EXPECTED_FLAG, IF_DSL, IZH_DSL, LIF_NB, bool_expected_out,
                            lif_reference_trace)
-from test_modelgen_channels import CALCIUM_CLAMP, MORRIS_LECAR, VOLTAGES, calcium_reference
+from test_modelgen_channels import CALCIUM_CLAMP, HODGKIN_HUXLEY, MORRIS_LECAR, VOLTAGES, calcium_reference
 from test_modelgen_receptors import IONOTROPIC_LIKE, LIF, MIXED, STEP_NEURON
 from test_modelgen_spike_trains import BURST_DSL, RATE_DSL, REFRACTORINESS_DSL, _mixed_network
 from test_modelgen_kinetics import (APPROXIMATE_NT, BOUNDED_RC, DESTEXHE_PAIR, ELECTROCHEMICAL_REF, RESTATED_STEP,
@@ -54,7 +54,7 @@ def libs(snn):
     from snn_amd import _lib, modelgen
     from concurrent.futures import ThreadPoolExecutor
     models = [modelgen.parse(text) for text in (LIF_NB, IZH_DSL, IF_DSL, CALCIUM_CLAMP, MORRIS_LECAR, FUNCTIONS_DSL,
-                                                 BOOL_DSL, ELECTROCHEMICAL_REF, RESTATED_STEP, *RANDOM_DSL)]
+                                                 BOOL_DSL, ELECTROCHEMICAL_REF, RESTATED_STEP, HODGKIN_HUXLEY, *RANDOM_DSL)]
     models += [modelgen.parse_description(text) for text in (
         RATE_DSL + REFRACTORINESS_DSL, APPROXIMATE_NT + BOUNDED_RC, IZH_DSL + BURST_DSL + DESTEXHE_PAIR,
         MIXED + LIF.format(name="MixedIntegrateAndFire", receptors="MixedReceptors"),
@@ -323,6 +323,47 @@ def test_functions_and_powers_equal_the_oracle(snn, libs):
     assert np.array_equal(dn.get_attr(1, "f_minus_square"), -(x * x))
     assert np.array_equal(dn.get_attr(1, "f_nan") != 0, x > f32(88.73))            # exp overflows: inf - inf
     dn.close()
+
+
+def test_hodgkin_huxley_in_the_dsl_equals_the_built_in_neuron(snn, libs):
+    """HodgkinHuxleyNeuron written in the DSL (three ion channels with gating variables, `^ 3` / `^ 4`,
+    continuous() spike detection) in a gap-junction lattice: the generated library against the oracle's stack program
+    AND against the default library's built-in Hodgkin-Huxley model -- same voltages, same raster, same gates."""
+    model, lib = libs["DslHodgkinHuxley"]
+    names = [n for n, _ in model.variables]
+    v0 = ob.uniform_array(90, 12, -70.0, -40.0)
+    gates = {k: ob.uniform_array(91 + j, 12, 0.05, 0.6) for j, k in enumerate(("m", "h", "n"))}
+    nets = []
+    for generated in (False, True):
+        net = parity.make_oracle(parity.Layout([(0, 3, 4)]), model=ob.CUSTOM if generated else ob.HH)
+        if generated:
+            modelgen_ref.attach(net, model)
+            net.custom_lib = lib
+        net["current_voltage"] = v0
+        net["gap_conductance"] = 0.5
+        for k, arr in gates.items():
+            if generated:
+                net["custom_vars"][names.index(f"{'k_channel' if k == 'n' else 'na_channel'}${k}$state")] = arr
+            else:
+                net[f"{k}_state"] = arr
+        net.fill_graph(94, 0.5, 1.5)
+        nets.append(net)
+    steps = 6000
+    devices = [parity.device_from_oracle(snn, net) for net in nets]
+    for dn in devices:
+        dn.set_history(voltage=True, spikes=True)
+        dn.run(steps)
+    nets[1].run(steps, voltage_history=True, spike_history=True)
+    built_in, gen = devices
+    assert np.array_equal(gen.spike_history(0), nets[1].spike_history) and nets[1].spike_history.sum() > 5
+    assert np.array_equal(parity.bits(gen.voltage_history(0)), parity.bits(nets[1].voltage_history))
+    assert np.array_equal(gen.spike_history(0), built_in.spike_history(0))
+    assert np.array_equal(parity.bits(gen.voltage_history(0)), parity.bits(built_in.voltage_history(0)))
+    for attr in ("na_channel$m$state", "na_channel$h$state", "k_channel$n$state", "na_channel$current", "k_channel$current"):
+        assert np.array_equal(parity.bits(gen.get_attr(0, attr)), parity.bits(built_in.get_attr(0, attr))), attr
+    parity.assert_state_equal(nets[1], parity.pull_state(gen, nets[1]))
+    for dn in devices:
+        dn.close()
 
 
 @pytest.mark.parametrize("seed", [7, 8])

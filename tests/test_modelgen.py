@@ -42,7 +42,7 @@ def test_parses_the_reference_fixture():
     assert m.on_spike == [("assign", "v", "=", ("var", "v_reset"))]
     src = modelgen.hip_source(m)
     assert "const float d_v = (((v - x[0]) + i_in)) * dt;" in src and "v += d_v;" in src
-    assert "return (v >= x[2]);" in src and "v = x[1];" in src
+    assert "const bool spiking = (v >= x[2]);" in src and "v = x[1];" in src
     path = "/root/reference/build_test/nb_macro/tests/lif.nb"
     if os.path.exists(path):                       # this container only: the committed text equals the reference's file
         assert modelgen.parse(open(path).read()).variables == m.variables
@@ -67,7 +67,10 @@ def test_mandatory_overrides_precedence_and_order_of_application():
     (LIF_NB.replace("dv/dt = (v - e) + i", "dv/dt = log(v)"), "log"),
     (LIF_NB.replace("dv/dt = (v - e) + i", "dv/dt = isnan(v)"), "needs a number"),
     (LIF_NB.replace("dv/dt = (v - e) + i", "dv/dt = min(v)"), "argument"),
-    (LIF_NB.replace("spike_detection: v >= v_th", "spike_detection: continuous()"), "continuous"),
+    (LIF_NB.replace("spike_detection: v >= v_th", "spike_detection: continuous()").replace(", v_th = -55", ""),
+     "continuous() compares with v_th"),
+    (LIF_NB.replace("spike_detection: v >= v_th", "spike_detection: continuous()").replace("vars: e = 0", "vars: last_voltage = 0, e = 0"),
+     "keeps its own 'last_voltage'"),
     (LIF_NB.replace("vars: e = 0", "vars: flag = true, e = 0").replace("(v - e) + i", "(v - e) + flag"), "needs a number"),
     (LIF_NB.replace("spike_detection: v >= v_th", "spike_detection: v"), "spike_detection needs a bool"),
     (LIF_NB.replace("vars: e = 0", "vars: flag = true, e = 0").replace("v = v_reset", "flag = 3"), "assignment to flag"),

@@ -100,6 +100,94 @@ MORRIS_LECAR = """
                   # with a flag, in place of continuous())
 
 
+# HodgkinHuxleyNeuron (hodgkin_huxley/mod.rs:49-241 with the channels of ion_channels/mod.rs:219-316) written in the
+# DSL, operation for operation: three ion channels with gating variables, continuous() spike detection
+HODGKIN_HUXLEY = """
+[ion_channel]
+    type: NaIonChannel
+    vars: g_na = 120, e_na = 50
+    gating_vars: m, h
+    on_iteration:
+        m.alpha = 0.1 * ((v + 40) / (1 - exp(-(v + 40) / 10)))
+        m.beta = 4 * exp(-(v + 65) / 18)
+        h.alpha = 0.07 * exp(-(v + 65) / 20)
+        h.beta = 1 / (exp(-(v + 35) / 10) + 1)
+        m.update(dt)
+        h.update(dt)
+        current = m.state ^ 3 * h.state * g_na * (v - e_na)
+[end]
+
+[ion_channel]
+    type: KIonChannel
+    vars: g_k = 36, e_k = -77
+    gating_vars: n
+    on_iteration:
+        n.alpha = 0.01 * (v + 55) / (1 - exp(-(v + 55) / 10))
+        n.beta = 0.125 * exp(-(v + 65) / 80)
+        n.update(dt)
+        current = n.state ^ 4 * g_k * (v - e_k)
+[end]
+
+[ion_channel]
+    type: KLeakChannel
+    vars: g_k_leak = 0.3, e_k_leak = -55
+    on_iteration:
+        current = g_k_leak * (v - e_k_leak)
+[end]
+
+[neuron]
+    type: DslHodgkinHuxley
+    ion_channels: na_channel = NaIonChannel, k_channel = KIonChannel, k_leak_channel = KLeakChannel
+    vars: current_voltage = -65, dt = 0.01, c_m = 1, gap_conductance = 7, v_th = 0
+    spike_detection: continuous()
+    on_iteration:
+        na_channel.update_current(v, dt)
+        k_channel.update_current(v, dt)
+        k_leak_channel.update_current(v)
+        v = v + dt * (i - (na_channel.current + k_channel.current + k_leak_channel.current)) / c_m
+[end]"""
+
+
+def test_hodgkin_huxley_in_the_dsl_equals_the_built_in_neuron():
+    """Every channel variable of the description has the built-in model's attribute name (na_channel$m$state ...), and
+    a gap-junction lattice of the generated neuron runs bit-identically to the built-in HodgkinHuxleyNeuron: voltages,
+    gates, currents, and the raster of the continuous() peak detector."""
+    import modelgen_ref
+    import oracle_binding as ob
+    import parity
+    m = modelgen.parse(HODGKIN_HUXLEY)
+    names = [n for n, _ in m.variables]
+    assert {"na_channel$m$state", "k_channel$n$alpha", "k_leak_channel$current", "was_increasing", "last_voltage"} <= set(names)
+    assert m.bools == {"was_increasing"} and m.after_detection
+    runs = []
+    for generated in (False, True):
+        net = parity.make_oracle(parity.Layout([(0, 3, 4)]), model=ob.CUSTOM if generated else ob.HH)
+        if generated:
+            modelgen_ref.attach(net, m)
+        net["current_voltage"] = ob.uniform_array(90, 12, -70.0, -40.0)
+        net["gap_conductance"] = 0.5
+        gates = {k: ob.uniform_array(91 + j, 12, 0.05, 0.6) for j, k in enumerate(("m", "h", "n"))}
+        for k, arr in gates.items():
+            if generated:
+                channel = "k_channel" if k == "n" else "na_channel"
+                net["custom_vars"][names.index(f"{channel}${k}$state")] = arr
+            else:
+                net[f"{k}_state"] = arr
+        net.fill_graph(94, 0.5, 1.5)
+        net.run(6000, voltage_history=True, spike_history=True)
+        runs.append(net)
+    built_in, gen = runs
+    assert built_in.spike_history.sum() > 5 and built_in.voltage_history.max() > 20.0
+    assert np.array_equal(gen.spike_history, built_in.spike_history)
+    assert np.array_equal(gen.voltage_history.view(np.uint32), built_in.voltage_history.view(np.uint32))
+    for dsl, own in (("na_channel$m$state", "m_state"), ("na_channel$h$state", "h_state"), ("k_channel$n$state", "n_state"),
+                     ("na_channel$current", "na_current"), ("k_channel$current", "k_current"),
+                     ("k_leak_channel$current", "k_leak_current"), ("na_channel$m$alpha", "m_alpha"),
+                     ("k_channel$n$beta", "n_beta")):
+        assert np.array_equal(gen["custom_vars"][names.index(dsl)].view(np.uint32), built_in[own].view(np.uint32)), dsl
+    assert np.array_equal(gen["custom_vars"][names.index("was_increasing")] != 0, built_in["was_increasing"] != 0)
+
+
 def _state(model, n):
     st = {"current_voltage": np.full(n, model.mandatory["current_voltage"], f32),
           "dt": np.full(n, model.mandatory["dt"], f32), "c_m": np.full(n, model.mandatory["c_m"], f32),
