@@ -1,6 +1,8 @@
-"""Neuron-model description -> HIP: a first slice of the reference's `neuron_builder!` DSL
-(/root/reference/build_test/nb_macro/src/lib.rs; grammar build_test/nb_macro/src/ast.pest) for integrate-and-fire
-models -- one `[neuron]` block with `type`, `vars`, `on_iteration`, `spike_detection` and `on_spike`:
+"""Model description -> HIP: the reference's `neuron_builder!` DSL (/root/reference/build_test/nb_macro/src/lib.rs;
+grammar in src/pest_ast) -- `[neuron]`, `[ion_channel]`, `[spike_train]`, `[neural_refractoriness]`,
+`[neurotransmitter_kinetics]`, `[receptor_kinetics]` and `[receptors]` blocks.  `parse(text)` reads a neuron (with its
+ion channels), `parse_description(text)` every block; `hip_source` emits the header a generated library is compiled
+with (`_lib.build_custom`).  The simplest description is one `[neuron]` block:
 
     [neuron]
         type: BasicIntegrateAndFire
