@@ -131,13 +131,16 @@ class _Neuron(_Record):
     model = None
     abi_names = {}          # python field -> C-ABI attribute (when they differ)
 
+    receptors_type = None       # the receptor container of the class (Ionotropic unless the model brings its own set)
+    receptor_set = None         # modelgen.ReceptorsModel of a generated neuron with its own [receptors]
+
     def __init__(self, **kw):
         self.synaptic_neurotransmitters = {}
-        self.receptors = Ionotropic()
+        self.receptors = (self.receptors_type or Ionotropic)()
         super().__init__(**kw)
 
     def set_synaptic_neurotransmitters(self, d):
-        self.synaptic_neurotransmitters = {IonotropicNeurotransmitterType(k): v for k, v in d.items()}
+        self.synaptic_neurotransmitters = {IonotropicNeurotransmitterType(int(k)): v for k, v in d.items()}
 
     def set_receptors(self, r):
         self.receptors = r
@@ -242,11 +245,30 @@ def description_builder_from_file(path):
         return description_builder(f.read())
 
 
+class GeneratedReceptors(dict):
+    """The receptor set of a generated neuron (a `[receptors]` block): receptors keyed by the set's own
+    neurotransmitter type (slot 0.. of the exchange), the block's top-level variables as attributes."""
+    model = None
+    NeurotransmitterType = None
+
+    def __init__(self):
+        super().__init__()
+        for name, default in self.model.variables:
+            if "$" not in name:
+                setattr(self, name, bool(default) if name in self.model.bools else default)
+
+    def insert(self, neurotransmitter_type, receptor):
+        if self.NeurotransmitterType(neurotransmitter_type) != receptor.type:
+            raise ValueError("ReceptorNeurotransmitterError::MismatchedTypes")
+        self[self.NeurotransmitterType(neurotransmitter_type)] = receptor
+
+
 class GeneratedDescription:
     """What `description_builder` returns: the classes of the blocks the description has (None for the others), all
     living in ONE compiled library (`library`)."""
     Neuron = Lattice = LatticeGPU = SpikeTrain = SpikeTrainLattice = Refractoriness = None
-    Neurotransmitter = ReceptorKinetics = None
+    Neurotransmitter = ReceptorKinetics = Receptors = NeurotransmitterType = None
+    receptor_types = None                       # {neurotransmitter name: receptor record class} of a generated receptor set
     library = description = None
 
 
@@ -254,14 +276,24 @@ def description_builder(text):
     """`neuron_builder!` over a text with several blocks: a [neuron] (with its [ion_channel]s), a [spike_train] and a
     [neural_refractoriness], a [neurotransmitter_kinetics] and a [receptor_kinetics] become façade classes that share
     one compiled library, so that they can meet in one LatticeNetwork (the kinetics classes stand where
-    ApproximateNeurotransmitter / ApproximateReceptor do: `AMPAReceptor(r=g.ReceptorKinetics())`).  Generated receptor
-    sets are reached through DeviceNetwork(lib_path=...)."""
+    ApproximateNeurotransmitter / ApproximateReceptor do: `AMPAReceptor(r=g.ReceptorKinetics())`).  A [receptors] block
+    gives the neuron its own container `g.Receptors` (top-level variables as attributes) with one record class per
+    neurotransmitter in `g.receptor_types`, keyed by `g.NeurotransmitterType`."""
     from . import _lib, modelgen
     desc = modelgen.parse_description(text)
-    if desc.receptors is not None:
-        raise NotImplementedError("description_builder: a generated receptor set needs DeviceNetwork")
     out = GeneratedDescription()
     out.description, out.library = desc, _lib.build_custom(desc)
+    receptors_type = None
+    if desc.receptors is not None:
+        rx = desc.receptors
+        out.NeurotransmitterType = enum.IntEnum(rx.name + "NeurotransmitterType", {t[0]: k for k, t in enumerate(rx.types)})
+        out.receptor_types = {}
+        for k, (nt, _, _) in enumerate(rx.types):
+            own = {n.split("$", 1)[1]: (bool(d) if n in rx.bools else d) for n, d in rx.variables if n.startswith(nt + "$")}
+            out.receptor_types[nt] = type(nt + "Receptor", (_Record,), dict(
+                type=out.NeurotransmitterType(k), state_fields=tuple(own), _defaults=dict(own, r=ApproximateReceptor())))
+        receptors_type = out.Receptors = type(rx.name, (GeneratedReceptors,), dict(
+            model=rx, NeurotransmitterType=out.NeurotransmitterType))
     if desc.neuron is not None:
         model = desc.neuron
         fields = {k: (bool(v) if k in model.bools else v) for k, v in model.variables}
@@ -271,6 +303,7 @@ def description_builder(text):
         defaults.setdefault("v_th", 0.0)        # the common attribute exists on the device whether the model reads it or not
         out.Neuron = type(model.name, (_Neuron,), dict(model=CUSTOM, _defaults=defaults, state_fields=tuple(fields),
                                                        lib_path=out.library, description=model,
+                                                       receptors_type=receptors_type, receptor_set=desc.receptors,
                                                        __doc__=f"generated from a neuron description ({model.name})"))
         out.Lattice = type(model.name + "Lattice", (Lattice,), dict(neuron_type=out.Neuron))
         out.LatticeGPU = type(model.name + "LatticeGPU", (LatticeGPU,), dict(lattice_type=out.Lattice))
@@ -655,6 +688,25 @@ def _upload_neurons(dn, id, cells):
     _upload_nt(dn, id, cells)
     n = len(cells)
     flags = np.zeros((n, 3), np.uint32)
+    if cls.receptor_set is not None:                 # the generated neuron's own receptor set
+        rx = cls.receptor_set
+        for name, default in rx.variables:
+            if "$" not in name:
+                dn.set_attr(id, "receptors$" + name, np.array([getattr(c.receptors, name) for c in cells], np.float32))
+        for k, (nt, _, _) in enumerate(rx.types):
+            recs = [c.receptors.get(k) for c in cells]
+            flags[:, k] = [r is not None for r in recs]
+            for name, default in rx.variables:
+                if name.startswith(nt + "$"):
+                    var = name.split("$", 1)[1]
+                    dn.set_attr(id, "receptors$" + name,
+                                np.array([default if r is None else getattr(r, var) for r in recs], np.float32))
+            kin = lambda field, d: np.array([d if r is None else getattr(r.r, field, d) for r in recs], np.float32)
+            dn.set_attr(id, f"receptors${nt}$r$kinetics$r", kin("r", 0.0))
+            dn.set_attr(id, f"receptors${nt}$r$kinetics$alpha", kin("alpha", 1.0))
+            dn.set_attr(id, f"receptors${nt}$r$kinetics$beta", kin("beta", 1.0))
+        dn.set_attr(id, "receptors$flags", flags)
+        return
     for t in IonotropicNeurotransmitterType:
         vals = {k: np.zeros(n, np.float32) for k in ("g", "e", "current", "r", "alpha", "beta", "mg")}
         proto = {0: AMPAReceptor, 1: NMDAReceptor, 2: GABAReceptor}[int(t)]()
@@ -706,6 +758,24 @@ def _download_neurons(dn, id, cells):
     if cls.model == HODGKIN_HUXLEY:
         for c, v in zip(cells, dn.get_attr(id, "was_increasing", dtype=np.uint32)):
             c.was_increasing = bool(v)
+    if cls.receptor_set is not None:
+        rx = cls.receptor_set
+        for name, _ in rx.variables:
+            values = dn.get_attr(id, "receptors$" + name)
+            for c, v in zip(cells, values):
+                value = bool(v) if name in rx.bools else float(v)
+                if "$" not in name:
+                    setattr(c.receptors, name, value)
+                else:
+                    nt, var = name.split("$", 1)
+                    rec = c.receptors.get([t[0] for t in rx.types].index(nt))
+                    if rec is not None:
+                        setattr(rec, var, value)
+        for k, (nt, _, _) in enumerate(rx.types):
+            for c, v in zip(cells, dn.get_attr(id, f"receptors${nt}$r$kinetics$r")):
+                if c.receptors.get(k) is not None:
+                    c.receptors[k].r.r = float(v)
+        return
     for ty in IonotropicNeurotransmitterType:
         r = dn.get_attr(id, f"receptors${ty.name}$r$kinetics$r")
         cur = dn.get_attr(id, f"receptors${ty.name}_current")

@@ -25,7 +25,8 @@ def descriptions():
             RESTATED_STEP, HODGKIN_HUXLEY, *RANDOM_DSL, facade, RATE_DSL + REFRACTORINESS_DSL, APPROXIMATE_NT + BOUNDED_RC,
             IZH_DSL + BURST_DSL + DESTEXHE_PAIR, IZH_DSL + BURST_DSL,
             MIXED + LIF.format(name="MixedIntegrateAndFire", receptors="MixedReceptors"),
-            IONOTROPIC_LIKE + STEP_NEURON.format(name="OwnReceptors", receptors="receptors: AmpaGabaReceptors\n    ")]
+            IONOTROPIC_LIKE + STEP_NEURON.format(name="OwnReceptors", receptors="receptors: AmpaGabaReceptors\n    "),
+            MIXED + STEP_NEURON.format(name="MixedStep", receptors="receptors: MixedReceptors\n    ")]
 
 
 if __name__ == "__main__":

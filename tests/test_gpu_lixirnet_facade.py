@@ -440,3 +440,60 @@ def test_generated_kinetics_facade(snn):
         gpu.close()
     assert np.array_equal(parity.bits(histories[0]), parity.bits(histories[1]))
     assert final_t[0] == final_t[1] and final_r[0] == final_r[1] and max(final_t[0]) > 0.1 and max(final_r[0]) > 0.1
+
+
+def test_generated_receptor_set_facade(snn):
+    """A generated neuron with its own [receptors] set through the façade: shared_receptors.rs's ionotropic +
+    metabotropic pair, receptors inserted per neuron, transmitters keyed by the set's own type -- history, the set's
+    variables and the receptor states equal the C oracle stepping the same description."""
+    import modelgen_ref
+    from test_modelgen_receptors import MIXED, STEP_NEURON
+    ln = snn
+    g = ln.description_builder(MIXED + STEP_NEURON.format(name="MixedStep", receptors="receptors: MixedReceptors\n    "))
+    NT = g.NeurotransmitterType
+    rng = np.random.default_rng(21)
+    init = rng.uniform(-68, -52, (4, 4)).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, (4, 4)).astype(np.float32)
+    lattice = g.Lattice(0)
+    lattice.populate(g.Neuron(gap_conductance=2.0), 4, 4)
+
+    def setup(pos, n):
+        n.current_voltage = float(init[pos])
+        n.receptors.insert(NT.Iono, g.receptor_types["Iono"](g=1.5))
+        if (pos[0] + pos[1]) % 2 == 0:
+            n.receptors.insert(NT.Meta, g.receptor_types["Meta"](s=float(scale[pos])))
+        n.set_synaptic_neurotransmitters({NT.Iono if pos[1] % 2 else NT.Meta: ln.ApproximateNeurotransmitter(t_max=0.8)})
+    lattice.apply_given_position(setup)
+    lattice.connect(lambda x, y: x != y, lambda x, y: 1.0)
+    lattice.chemical_synapse = True
+    lattice.update_grid_history = True
+    gpu = g.LatticeGPU.from_lattice(lattice)
+    steps = 200
+    gpu.run_lattice(steps)
+
+    desc = g.description
+    net = parity.make_oracle(parity.Layout([(0, 4, 4)]), model=ob.CUSTOM, chemical=True)
+    modelgen_ref.attach(net, desc.neuron)
+    modelgen_ref.attach_receptors(net, desc.receptors)
+    names = [n for n, _ in desc.receptors.variables]
+    net["current_voltage"] = init.reshape(-1)
+    net["gap_conductance"] = 2.0
+    net["rx_vars"][names.index("Iono$g")] = 1.5
+    net["rc_flags"][:, 0] = 1
+    for q in range(16):
+        r, c = divmod(q, 4)
+        if (r + c) % 2 == 0:
+            net["rc_flags"][q, 1] = 1
+            net["rx_vars"][names.index("Meta$s")][q] = scale[r, c]
+        net["nt_flags"][q, 0 if c % 2 else 1] = 1
+        net["nt_t_max"][q, 0 if c % 2 else 1] = 0.8
+    net.connect_all_to_all(1.0)
+    with np.errstate(all="ignore"):
+        net.run(steps, voltage_history=True, spike_history=True)
+    assert np.array_equal(parity.bits(gpu.history.reshape(steps, -1)), parity.bits(net.voltage_history))
+    cell = gpu.get_neuron(2, 2)
+    assert cell.receptors.m == float(net["rx_vars"][names.index("m")][10])
+    assert cell.receptors[NT.Iono].current == float(net["rx_vars"][names.index("Iono$current")][10])
+    assert cell.receptors[NT.Meta].r.r == float(net["rc_r"][10, 1]) and cell.receptors[NT.Meta].s == float(scale[2, 2])
+    assert net["rc_r"].max() > 0.1 and np.abs(net["rx_vars"][names.index("Iono$current")]).max() > 0.0
+    gpu.close()
