@@ -96,6 +96,18 @@ float snn_o_powif_export(float x, int n) { return snn_o_powif(x, n); }
 float snn_o_sinf_export(float x) { return snn_o_sinf(x); }
 float snn_o_cosf_export(float x) { return snn_o_cosf(x); }
 float snn_o_tanf_export(float x) { return snn_o_tanf(x); }
+float snn_o_powf_export(float x, float y) { return snn_o_powf(x, y); }
+
+/* out[i] = f(the float whose bit pattern is first + i * stride): which = 0 expf, 1 powf(x, 3.), 2 powf(x, 4.),
+ * 3 powf(x, y).  All cores; the GPU parity test walks the whole 2^32 pattern space in chunks with it. */
+void snn_o_math_bits(int which, uint32_t first, uint32_t stride, uint64_t count, float y, float *out)
+{
+#pragma omp parallel for schedule(static)
+    for (uint64_t i = 0; i < count; i++) {
+        const float x = snn_o_asfloat(first + (uint32_t)i * stride);
+        out[i] = which == 0 ? snn_o_expf(x) : which == 1 ? snn_o_pow3f(x) : which == 2 ? snn_o_pow4f(x) : snn_o_powf(x, y);
+    }
+}
 
 /* ---------- synthetic data ---------- */
 

@@ -255,6 +255,8 @@ float snn_o_powif_export(float x, int n);
 float snn_o_sinf_export(float x);
 float snn_o_cosf_export(float x);
 float snn_o_tanf_export(float x);
+float snn_o_powf_export(float x, float y);
+void snn_o_math_bits(int which, uint32_t first, uint32_t stride, uint64_t count, float y, float *out);
 float snn_o_stdp_delta(int32_t t_pre, int32_t t_post, float a_plus, float a_minus,
                        float tau_plus, float tau_minus, float dt);
 float snn_o_exponential_decay_effect(int64_t timestep, int32_t last_firing_time,

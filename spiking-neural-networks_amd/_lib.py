@@ -147,6 +147,7 @@ SIGNATURES = {
     "snn_input_kernel_bytes": (C.c_int, [H, u64p]),
     "snn_probe_bandwidth": (C.c_int, [C.c_int, C.c_uint64, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "snn_probe_math": (C.c_int, [C.c_int, C.c_int, f32p, f32p, C.c_size_t]),
+    "snn_probe_math_bits": (C.c_int, [C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_float, f32p, C.c_size_t]),
 }
 
 _lib = None

@@ -57,6 +57,9 @@ struct InputsArgs {
     // chunk subset of this launch: chunk = chunk_first + blockIdx.y, skipping [hole_begin, hole_begin+hole_count)
     // (multi-GPU: the chunks of LOCAL presynaptic rows run while the all-gather of the remote state is in flight)
     uint32_t chunk_first, hole_begin, hole_count;
+    // transmitter types some neuron or cell of the handle releases (launch-uniform): slot s of a kernel specialised
+    // on NT live types handles type live_type[s]; the partial planes of the other types stay zero
+    uint32_t live_type[K_TYPES];
 };
 
 // kind word per staged presynaptic row: bits 0..1 = 0 neuron | 1 spike train that never fired |
@@ -105,22 +108,43 @@ __device__ __forceinline__ float acc_if_edge(float acc, float term, float w)
     return (w == w) ? acc + term * w : acc;
 }
 
-template <bool ELEC, bool CHEM, int STREAM = 1>
+// NT: number of live transmitter types the launch is specialised on (1..3; only read when CHEM).  A network whose
+// cells all release one type (BASELINE configs[2]: AMPA) then carries VEC accumulators for it instead of 3 * VEC, no
+// per-row tests of the other types, and the two-register-buffer sweep of the electrical pass.
+template <bool ELEC, bool CHEM, int STREAM = 1, int NT = K_TYPES>
 __global__ __launch_bounds__(InputsShape<STREAM>::THREADS) void k_inputs_dense(const InputsArgs a)
 {
     using S = InputsShape<STREAM>;
     constexpr int VEC = S::VEC;
     constexpr uint32_t ROW_BATCH = S::ROW_BATCH;
+    constexpr int TS = CHEM ? NT : 1;                        // transmitter slots of this instantiation
 
     __shared__ float s_val[CHUNK];
     __shared__ uint32_t s_kind[CHUNK];
-    __shared__ float s_t[CHEM ? K_TYPES : 1][CHUNK];
+    __shared__ float s_t[TS][CHUNK];
 
     uint32_t chunk = a.chunk_first + blockIdx.y;
     if (chunk >= a.hole_begin) chunk += a.hole_count;
     const uint32_t p0 = chunk * CHUNK;
     const uint32_t rows = min((uint32_t)CHUNK, a.n_tot - p0);
     const uint32_t tid = threadIdx.x;
+
+    // Column tile of this workgroup, rotated by the chunk index: workgroups are dealt round-robin over the 8
+    // XCDs, so with a power-of-two tile count an unrotated mapping would pin every XCD (and its L2 / fabric
+    // ports) to the same 1/8 of the columns for the whole pass.
+    const uint32_t tile = (blockIdx.x + blockIdx.y) % gridDim.x;
+    const uint32_t ql = tile * S::TILE + tid * VEC;          // first of this lane's VEC local columns
+    const float *wrow = a.W + (size_t)p0 * a.ld + ql;
+    const size_t ld = a.ld;
+
+    // The first batch of matrix rows is requested BEFORE the presynaptic values are staged: all workgroups of a
+    // launch start together, and without this the whole chip would leave HBM idle for the staging round trip.
+    float pre[ROW_BATCH][VEC];
+    const bool have_pre = rows >= ROW_BATCH && ql < a.n_loc;
+    if (have_pre) {
+#pragma unroll
+        for (uint32_t u = 0; u < ROW_BATCH; ++u) load_w<STREAM>(wrow + (size_t)u * ld, pre[u]);
+    }
 
     // ---- stage the chunk's presynaptic values in LDS (coalesced reads, one pass per array) ----
     uint32_t kinds_and = 0x703u, kinds_or = 0u;              // over the rows this thread stages
@@ -133,10 +157,11 @@ __global__ __launch_bounds__(InputsShape<STREAM>::THREADS) void k_inputs_dense(c
             kind = KIND_NEURON;
             if (CHEM) {
 #pragma unroll
-                for (int k = 0; k < K_TYPES; ++k) {
-                    const uint32_t f = a.nt_flags[(size_t)k * a.n_pad + p];
+                for (int k = 0; k < TS; ++k) {
+                    const uint32_t ty = a.live_type[k];
+                    const uint32_t f = a.nt_flags[(size_t)ty * a.n_pad + p];
                     kind |= f ? (0x100u << k) : 0u;
-                    s_t[k][i] = a.xbuf[a.xl.at(p, PLANE_T0 + k)];
+                    s_t[k][i] = a.xbuf[a.xl.at(p, PLANE_T0 + ty)];
                 }
             }
         } else {
@@ -145,10 +170,11 @@ __global__ __launch_bounds__(InputsShape<STREAM>::THREADS) void k_inputs_dense(c
             kind = (a.st_last_firing_time[s] < 0) ? KIND_ST_SILENT : KIND_ST_FIRED;
             if (CHEM) {
 #pragma unroll
-                for (int k = 0; k < K_TYPES; ++k) {
-                    const uint32_t f = a.st_nt_flags[(size_t)k * a.c_pad + s];
+                for (int k = 0; k < TS; ++k) {
+                    const uint32_t ty = a.live_type[k];
+                    const uint32_t f = a.st_nt_flags[(size_t)ty * a.c_pad + s];
                     kind |= f ? (0x100u << k) : 0u;
-                    s_t[k][i] = a.st_nt_t[(size_t)k * a.c_pad + s];
+                    s_t[k][i] = a.st_nt_t[(size_t)ty * a.c_pad + s];
                 }
             }
         }
@@ -160,27 +186,23 @@ __global__ __launch_bounds__(InputsShape<STREAM>::THREADS) void k_inputs_dense(c
     // Homogeneous chunks (every row a neuron; each transmitter type carried by all rows or by none -- any lattice
     // populated from one base neuron) take a row body without per-row kind tests: workgroup-uniform votes, which
     // also are the barrier that publishes the staged values.
-    bool uniform_chunk = false, type_on[CHEM ? K_TYPES : 1];
+    bool uniform_chunk = false, type_on[TS];
     if (CHEM) {
         int ok = __syncthreads_and((kinds_or & 3u) == 0u);
 #pragma unroll
-        for (int k = 0; k < K_TYPES; ++k) {
+        for (int k = 0; k < TS; ++k) {
             const int all_k = __syncthreads_and((kinds_and >> (8 + k)) & 1u);
             const int any_k = __syncthreads_or((kinds_or >> (8 + k)) & 1u);
             type_on[k] = all_k != 0;
             ok = ok && (all_k || !any_k);
         }
-        uniform_chunk = ok != 0;
+        // a launch specialised on ONE live type tests nothing per row: its uniform chunks are those that carry the type
+        uniform_chunk = ok != 0 && (NT > 1 || type_on[0]);
     } else {
         type_on[0] = false;
         __syncthreads();
     }
 
-    // Column tile of this workgroup, rotated by the chunk index: workgroups are dealt round-robin over the 8
-    // XCDs, so with a power-of-two tile count an unrotated mapping would pin every XCD (and its L2 / fabric
-    // ports) to the same 1/8 of the columns for the whole pass.
-    const uint32_t tile = (blockIdx.x + blockIdx.y) % gridDim.x;
-    const uint32_t ql = tile * S::TILE + tid * VEC;          // first of this lane's VEC local columns
     if (ql >= a.n_loc) return;                               // padding columns (n_loc .. ld) carry no neuron
 
     // ---- this lane's postsynaptic voltage / conductance, kept in registers ----
@@ -198,31 +220,28 @@ __global__ __launch_bounds__(InputsShape<STREAM>::THREADS) void k_inputs_dense(c
     }
 
     float acc[VEC];
-    float tacc[CHEM ? K_TYPES : 1][VEC];
+    float tacc[TS][VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) acc[j] = 0.0f;
 #pragma unroll
-    for (int k = 0; k < (CHEM ? K_TYPES : 1); ++k)
+    for (int k = 0; k < TS; ++k)
 #pragma unroll
         for (int j = 0; j < VEC; ++j) tacc[k][j] = 0.0f;
-
-    const float *wrow = a.W + (size_t)p0 * a.ld + ql;
-    const size_t ld = a.ld;
 
     // Rows are consumed in batches of ROW_BATCH: all loads of a batch are issued before the first use,
     // so every wave keeps ROW_BATCH wave-rows of reads in flight regardless of the branches in the body.
     auto sweep = [&](auto body) {
         uint32_t r = 0;
-        if constexpr ((STREAM == 1 && !CHEM) || STREAM == 2 || STREAM == 0) {
+        if constexpr ((STREAM == 1 && (!CHEM || NT == 1)) || STREAM == 2 || STREAM == 0) {
             // Two register buffers, so the next batch of rows is already in flight while the current one is
             // consumed: +1 % over a single buffer for the electrical-only 4-column pass at 256x256 (its chemical
-            // variants keep one buffer -- they need the registers for their 12 extra accumulators), -5 % time at
-            // 96x96 for the 2-column shape, -24 % at 64x64 for the one-column cache-resident shape (2 x 32 rows).
+            // variants with 2-3 live types keep one buffer -- they need the registers for their extra accumulators),
+            // -5 % time at 96x96 for the 2-column shape, -24 % at 64x64 for the one-column cache-resident shape
+            // (2 x 32 rows).
             constexpr uint32_t B = ROW_BATCH;
             if (rows >= 2 * B) {
-                float wa[B][VEC], wb[B][VEC];
-#pragma unroll
-                for (uint32_t u = 0; u < B; ++u) load_w<STREAM>(wrow + (size_t)u * ld, wa[u]);
+                float (&wa)[B][VEC] = pre;        // rows 0 .. B-1, requested before the staging phase
+                float wb[B][VEC];
                 for (; r + 3 * B <= rows; r += 2 * B) {
 #pragma unroll
                     for (uint32_t u = 0; u < B; ++u) load_w<STREAM>(wrow + (size_t)(r + B + u) * ld, wb[u]);
@@ -238,6 +257,11 @@ __global__ __launch_bounds__(InputsShape<STREAM>::THREADS) void k_inputs_dense(c
                 for (uint32_t u = 0; u < B; ++u) body(r + u, wa[u]);
                 r += B;
             }
+        }
+        if (r == 0 && have_pre) {
+#pragma unroll
+            for (uint32_t u = 0; u < ROW_BATCH; ++u) body(u, pre[u]);
+            r = ROW_BATCH;
         }
         for (; r + ROW_BATCH <= rows; r += ROW_BATCH) {
             float wb[ROW_BATCH][VEC];
@@ -269,11 +293,11 @@ __global__ __launch_bounds__(InputsShape<STREAM>::THREADS) void k_inputs_dense(c
                 for (int j = 0; j < VEC; ++j) acc[j] = acc_if_edge(acc[j], gq[j] * (vp - vq[j]), w[j]);
             }
 #pragma unroll
-            for (int k = 0; k < K_TYPES; ++k) {
-                if (type_on[CHEM ? k : 0]) {
-                    const float t = s_t[CHEM ? k : 0][r];
+            for (int k = 0; k < TS; ++k) {
+                if (NT == 1 || type_on[k]) {
+                    const float t = s_t[k][r];
 #pragma unroll
-                    for (int j = 0; j < VEC; ++j) tacc[CHEM ? k : 0][j] = acc_if_edge(tacc[CHEM ? k : 0][j], t, w[j]);
+                    for (int j = 0; j < VEC; ++j) tacc[k][j] = acc_if_edge(tacc[k][j], t, w[j]);
                 }
             }
         });
@@ -297,7 +321,7 @@ __global__ __launch_bounds__(InputsShape<STREAM>::THREADS) void k_inputs_dense(c
             }
             if (CHEM) {
 #pragma unroll
-                for (int k = 0; k < K_TYPES; ++k) {
+                for (int k = 0; k < TS; ++k) {
                     if (kind & (0x100u << k)) {
                         const float t = s_t[k][r];
 #pragma unroll
@@ -315,8 +339,8 @@ __global__ __launch_bounds__(InputsShape<STREAM>::THREADS) void k_inputs_dense(c
     }
     if (CHEM) {
 #pragma unroll
-        for (int k = 0; k < K_TYPES; ++k) {
-            float *dst = a.part_t + ((size_t)k * a.n_chunks + chunk) * a.ld + ql;
+        for (int k = 0; k < TS; ++k) {
+            float *dst = a.part_t + ((size_t)a.live_type[k] * a.n_chunks + chunk) * a.ld + ql;
 #pragma unroll
             for (int j = 0; j < VEC; ++j) dst[j] = tacc[k][j];
         }

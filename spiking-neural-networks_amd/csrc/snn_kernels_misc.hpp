@@ -355,7 +355,16 @@ __global__ void k_probe_math(int which, const float *in, float *out, size_t n)
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float x = in[i];
-    out[i] = which == 0 ? expf_portable(x) : (which == 1 ? pow3f_portable(x) : pow4f_portable(x));
+    out[i] = which == 0 ? expf_glibc(x) : (which == 1 ? pow3f_glibc(x) : pow4f_glibc(x));
+}
+
+// the same over a range of float bit patterns generated on the device: x = asfloat(first + i * stride); which = 3: powf(x, y)
+__global__ void k_probe_math_bits(int which, uint32_t first, uint32_t stride, float y, float *out, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = __uint_as_float(first + (uint32_t)i * stride);
+    out[i] = which == 0 ? expf_glibc(x) : which == 1 ? pow3f_glibc(x) : which == 2 ? pow4f_glibc(x) : powf_glibc(x, y);
 }
 
 } // namespace snn

@@ -21,10 +21,10 @@ __global__ void k_modulator_update(float *rm, const uint32_t *rm_on, uint32_t n_
     const uint32_t l = blockIdx.x * blockDim.x + threadIdx.x;
     if (l >= n_lattices) return;
     float *m = rm + (size_t)l * RM_STRIDE;
-    m[8] = expf_portable(-m[7] / m[2]);
+    m[8] = expf_glibc(-m[7] / m[2]);
     if (refresh_only || !rm_on[l]) return;
     m[RM_DOPAMINE_BEFORE] = m[RM_DOPAMINE];
-    m[RM_DOPAMINE] = m[RM_DOPAMINE] * expf_portable(-m[7] / m[1]) + m[1] * reward;
+    m[RM_DOPAMINE] = m[RM_DOPAMINE] * expf_glibc(-m[7] / m[1]) + m[1] * reward;
 }
 
 // The two update_weight visits every internal edge of a modulated lattice receives per step (do_update is always

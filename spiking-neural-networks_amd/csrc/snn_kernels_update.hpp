@@ -152,7 +152,7 @@ __device__ __forceinline__ void receptors_set_currents(const UpdateArgs &a, uint
         if (!a.n.rc_flags[i]) continue;
         const float r = a.n.rc_r[i];
         if (k == 1) {
-            a.n.rc_current[i] = ((1.0f / (1.0f + ((expf_portable(-0.062f * v_old) * a.n.rc_mg[i]) / 3.75f))
+            a.n.rc_current[i] = ((1.0f / (1.0f + ((expf_glibc(-0.062f * v_old) * a.n.rc_mg[i]) / 3.75f))
                                   * a.n.rc_g[i]) * r) * (v_old - a.n.rc_e[i]);
         } else {
             a.n.rc_current[i] = (a.n.rc_g[i] * r) * (v_old - a.n.rc_e[i]);
@@ -318,7 +318,7 @@ __device__ __forceinline__ uint32_t update_neuron(const UpdateArgs &a, uint32_t 
             float acc = a.n.leak_constant[q] * (v - e_l);
             if (MODEL == 6) {
                 const float sf = a.n.slope_factor[q];
-                acc = acc + (sf * expf_portable((v - a.n.v_th[q]) / sf));
+                acc = acc + (sf * expf_glibc((v - a.n.v_th[q]) / sf));
             }
             const float dv = (acc + (a.n.integration_constant[q] * (i_in / g_l)) - (w / g_l)) * (dt / c_m);
             const float dw = (a.n.adp_alpha[q] * (v - e_l) - w) * (dt / a.n.tau_m[q]);
@@ -383,18 +383,18 @@ __device__ __forceinline__ uint32_t update_neuron(const UpdateArgs &a, uint32_t 
 #pragma unroll
             for (int k = 0; k < custom::NVARS; ++k) a.n.custom[k][q] = x[k];
         } else {                     // Hodgkin-Huxley
-            const float m_a = 0.1f * ((v + 40.0f) / (1.0f - expf_portable(-(v + 40.0f) / 10.0f)));
-            const float m_b = 4.0f * expf_portable(-(v + 65.0f) / 18.0f);
-            const float h_a = 0.07f * expf_portable(-(v + 65.0f) / 20.0f);
-            const float h_b = 1.0f / (expf_portable(-(v + 35.0f) / 10.0f) + 1.0f);
+            const float m_a = 0.1f * ((v + 40.0f) / (1.0f - expf_glibc(-(v + 40.0f) / 10.0f)));
+            const float m_b = 4.0f * expf_glibc(-(v + 65.0f) / 18.0f);
+            const float h_a = 0.07f * expf_glibc(-(v + 65.0f) / 20.0f);
+            const float h_b = 1.0f / (expf_glibc(-(v + 35.0f) / 10.0f) + 1.0f);
             const float m = gate_update(a.n.m_state[q], m_a, m_b, dt);
             const float h = gate_update(a.n.h_state[q], h_a, h_b, dt);
-            const float i_na = pow3f_portable(m) * h * a.n.g_na[q] * (v - a.n.e_na[q]);
+            const float i_na = pow3f_glibc(m) * h * a.n.g_na[q] * (v - a.n.e_na[q]);
 
-            const float n_a = 0.01f * (v + 55.0f) / (1.0f - expf_portable(-(v + 55.0f) / 10.0f));
-            const float n_b = 0.125f * expf_portable(-(v + 65.0f) / 80.0f);
+            const float n_a = 0.01f * (v + 55.0f) / (1.0f - expf_glibc(-(v + 55.0f) / 10.0f));
+            const float n_b = 0.125f * expf_glibc(-(v + 65.0f) / 80.0f);
             const float ng = gate_update(a.n.n_state[q], n_a, n_b, dt);
-            const float i_k = pow4f_portable(ng) * a.n.g_k[q] * (v - a.n.e_k[q]);
+            const float i_k = pow4f_glibc(ng) * a.n.g_k[q] * (v - a.n.e_k[q]);
 
             const float i_kl = a.n.g_k_leak[q] * (v - a.n.e_k_leak[q]);
 

@@ -1,21 +1,23 @@
 // Device-side scalar math of the lattice stepper (gfx950).
 //
-// The reference evaluates f32::exp / f32::powf through the platform libm
+// The reference evaluates f32::exp / f32::powf through the platform libm, i.e. glibc expf / powf
 // (backend/src/neuron/ion_channels/mod.rs:224-228,234,270-271,280;
 //  iterate_and_spike/mod.rs:149,1133; plasticity/mod.rs:52-54;
-//  spike_train/mod.rs:85).  ocml's expf/powf are not bit-compatible with any CPU
-// libm, so the stepper carries its own exp: range reduction by ln2, a degree-13
-// Taylor polynomial by Horner's rule in binary64 with plain v_mul_f64/v_add_f64
-// (this translation unit is compiled with -ffp-contract=off: no FMA anywhere),
-// one rounding to binary32.  MI355X issues FP64 vector ops at half the FP32 rate,
-// and the stepper is HBM-bound, so the f64 polynomial is free in practice.
+//  spike_train/mod.rs:85).  ocml's expf/powf are not bit-compatible with it, so the stepper carries glibc's
+// published algorithm (sysdeps/ieee754/flt-32/e_expf.c, e_powf.c and their two tables) in the form glibc >= 2.27
+// runs on every x86-64 CPU with FMA: binary64 throughout, a 32-entry 2^(i/32) table, a 16-entry log2 table, and
+// v_fma_f64 exactly where the FMA build of glibc fuses (written as explicit fma(); the translation unit is compiled
+// with -ffp-contract=off, so nothing else fuses), one rounding to binary32 at the end.  The test suite's CPU twin of
+// these functions is pinned against libm.so.6 on all 2^32 inputs and tests/test_gpu_math.py holds the device functions
+// to that twin on 2^28+ inputs.  MI355X issues FP64 vector ops at half the FP32 rate and the stepper is
+// HBM-bound, so the f64 evaluation is free in practice.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace snn {
 
-// exp of a binary64 argument, |x| < 700: the polynomial core shared by expf_portable and the hyperbolic functions
+// exp of a binary64 argument, |x| < 700: the polynomial core of the hyperbolic functions of generated models
 __device__ __forceinline__ double exp_core(double xd)
 {
     const double inv_ln2 = 1.4426950408889634;
@@ -46,12 +48,142 @@ __device__ __forceinline__ double exp_core(double xd)
     return p * scale;
 }
 
-__device__ __forceinline__ float expf_portable(float x)
+// glibc __exp2f_data.tab (EXP2F_TABLE_BITS = 5): bits(2^(i/32)) - (i << 47)
+static __device__ const uint64_t EXP2F_TAB[32] = {
+    0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull,
+    0x3fef72b83c7d517bull, 0x3fef54873168b9aaull, 0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull,
+    0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull, 0x3feedea64c123422ull, 0x3feece086061892dull,
+    0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull, 0x3feea47eb03a5585ull,
+    0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull, 0x3feea11473eb0187ull, 0x3feea589994cce13ull,
+    0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull,
+    0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull,
+    0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full, 0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull,
+};
+// glibc __powf_log2_data.tab (POWF_LOG2_TABLE_BITS = 4): {1/c, log2(c)}
+static __device__ const double POWF_LOG2_TAB[16][2] = {
+    {0x1.661ec79f8f3bep+0, -0x1.efec65b963019p-2}, {0x1.571ed4aaf883dp+0, -0x1.b0b6832d4fca4p-2},
+    {0x1.49539f0f010bp+0, -0x1.7418b0a1fb77bp-2},  {0x1.3c995b0b80385p+0, -0x1.39de91a6dcf7bp-2},
+    {0x1.30d190c8864a5p+0, -0x1.01d9bf3f2b631p-2}, {0x1.25e227b0b8eap+0, -0x1.97c1d1b3b7afp-3},
+    {0x1.1bb4a4a1a343fp+0, -0x1.2f9e393af3c9fp-3}, {0x1.12358f08ae5bap+0, -0x1.960cbbf788d5cp-4},
+    {0x1.0953f419900a7p+0, -0x1.a6f9db6475fcep-5}, {0x1p+0, 0x0p+0},
+    {0x1.e608cfd9a47acp-1, 0x1.338ca9f24f53dp-4},  {0x1.ca4b31f026aap-1, 0x1.476a9543891bap-3},
+    {0x1.b2036576afce6p-1, 0x1.e840b4ac4e4d2p-3},  {0x1.9c2d163a1aa2dp-1, 0x1.40645f0c6651cp-2},
+    {0x1.886e6037841edp-1, 0x1.88e9c2c1b9ff8p-2},  {0x1.767dcf5534862p-1, 0x1.ce0a44eb17bccp-2},
+};
+constexpr double EXP2F_C0 = 0x1.c6af84b912394p-5, EXP2F_C1 = 0x1.ebfce50fac4f3p-3, EXP2F_C2 = 0x1.62e42ff0c52d6p-1;
+
+// expf as glibc computes it (e_expf.c, FMA build): k + r = x * 32/ln2 without rounding the product on its own,
+// 2^(k/32) from the table, a cubic in r.
+__device__ __forceinline__ float expf_glibc(float x)
 {
-    if (!(x == x)) return x;
-    if (x > 89.0f) return __builtin_inff();
-    if (x < -104.0f) return 0.0f;
-    return (float)exp_core((double)x);
+    constexpr double inv_ln2_n = 0x1.71547652b82fep+0 * 32.0;
+    constexpr double shift = 0x1.8p+52;
+    const uint32_t ux = __float_as_uint(x);
+    const uint32_t abstop = (ux >> 20) & 0x7ff;
+    const double xd = (double)x;
+    if (abstop >= 0x42b) {                                   // |x| >= 88 or NaN
+        if (ux == 0xff800000u) return 0.0f;
+        if (abstop >= 0x7f8) return x + x;
+        if (x > 0x1.62e42ep6f) return __builtin_inff();      // x > log(2^128)
+        if (x < -0x1.9fe368p6f) return 0.0f;                 // x < log(2^-150)
+        if (x < -0x1.9d1d9ep6f) return 0x1p-149f;            // x < log(2^-149)
+    }
+    double kd = __builtin_fma(inv_ln2_n, xd, shift);
+    const uint64_t ki = (uint64_t)__double_as_longlong(kd);
+    kd -= shift;
+    const double r = __builtin_fma(inv_ln2_n, xd, -kd);
+    const double s = __longlong_as_double((long long)(EXP2F_TAB[ki & 31] + (ki << 47)));
+    const double z = __builtin_fma(r, EXP2F_C0 / 32.0 / 32.0 / 32.0, EXP2F_C1 / 32.0 / 32.0);
+    const double r2 = r * r;
+    double y = __builtin_fma(r, EXP2F_C2 / 32.0, 1.0);
+    y = __builtin_fma(z, r2, y);
+    y = y * s;
+    return (float)y;
+}
+
+// checkint of e_powf.c: 0 = not an integer, 1 = odd, 2 = even
+__device__ __forceinline__ int powf_checkint(uint32_t iy)
+{
+    const int e = (int)(iy >> 23 & 0xff);
+    if (e < 0x7f) return 0;
+    if (e > 0x7f + 23) return 2;
+    if (iy & ((1u << (0x7f + 23 - e)) - 1)) return 0;
+    if (iy & (1u << (0x7f + 23 - e))) return 1;
+    return 2;
+}
+__device__ __forceinline__ bool powf_zeroinfnan(uint32_t ix) { return 2 * ix - 1 >= 2u * 0x7f800000u - 1; }
+
+// powf as glibc computes it (e_powf.c, FMA build): log2(x) from a 16-entry table + quartic, times y, then exp2.
+// With a literal y (3.f, 4.f) the compiler folds every test on y.
+__device__ __forceinline__ float powf_glibc(float x, float y)
+{
+    uint64_t sign_bias = 0;
+    uint32_t ix = __float_as_uint(x);
+    const uint32_t iy = __float_as_uint(y);
+    if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u || powf_zeroinfnan(iy)) {
+        if (powf_zeroinfnan(iy)) {
+            if (2 * iy == 0) return ((ix & 0x7fc00000u) == 0x7f800000u && (ix & 0x003fffffu)) ? x + y : 1.0f;
+            if (ix == 0x3f800000u) return ((iy & 0x7fc00000u) == 0x7f800000u && (iy & 0x003fffffu)) ? x + y : 1.0f;
+            if (2 * ix > 2u * 0x7f800000u || 2 * iy > 2u * 0x7f800000u) return x + y;
+            if (2 * ix == 2 * 0x3f800000u) return 1.0f;
+            if ((2 * ix < 2 * 0x3f800000u) == !(iy & 0x80000000u)) return 0.0f;
+            return y * y;
+        }
+        if (powf_zeroinfnan(ix)) {
+            float x2 = x * x;
+            bool neg = false;
+            if ((ix & 0x80000000u) && powf_checkint(iy) == 1) { x2 = -x2; neg = true; }
+            if (2 * ix == 0 && (iy & 0x80000000u)) return neg ? -__builtin_inff() : __builtin_inff();
+            return (iy & 0x80000000u) ? 1 / x2 : x2;
+        }
+        if (ix & 0x80000000u) {                              // finite x < 0
+            const int yint = powf_checkint(iy);
+            if (yint == 0) return (x - x) / (x - x);
+            if (yint == 1) sign_bias = 1ull << 16;
+            ix &= 0x7fffffffu;
+        }
+        if (ix < 0x00800000u) {                              // subnormal x: normalise
+            ix = __float_as_uint(x * 0x1p23f);
+            ix &= 0x7fffffffu;
+            ix -= 23u << 23;
+        }
+    }
+    const uint32_t tmp = ix - 0x3f330000u;
+    const int i = (int)((tmp >> 19) & 15);
+    const uint32_t top = tmp & 0xff800000u;
+    const uint32_t iz = ix - top;
+    const int k = (int32_t)top >> 23;
+    const double invc = POWF_LOG2_TAB[i][0], logc = POWF_LOG2_TAB[i][1];
+    const double z = (double)__uint_as_float(iz);
+    const double r = __builtin_fma(z, invc, -1.0);
+    const double y0 = logc + (double)k;
+    constexpr double A0 = 0x1.27616c9496e0bp-2, A1 = -0x1.71969a075c67ap-2, A2 = 0x1.ec70a6ca7baddp-2,
+                     A3 = -0x1.7154748bef6c8p-1, A4 = 0x1.71547652ab82bp0;
+    const double r2 = r * r;
+    double yy = __builtin_fma(A0, r, A1);
+    const double p = __builtin_fma(A2, r, A3);
+    const double r4 = r2 * r2;
+    double q = __builtin_fma(A4, r, y0);
+    q = __builtin_fma(p, r2, q);
+    yy = __builtin_fma(yy, r4, q);
+    const double ylogx = (double)y * yy;
+    if (((uint64_t)__double_as_longlong(ylogx) >> 47 & 0xffff) >= (0x405f800000000000ull >> 47)) {   // |y log2 x| >= 126
+        if (ylogx > 0x1.fffffffd1d571p+6) return sign_bias ? -__builtin_inff() : __builtin_inff();
+        if (ylogx <= -150.0) return sign_bias ? -0.0f : 0.0f;
+        if (ylogx < -149.0) return sign_bias ? -0x1p-149f : 0x1p-149f;
+    }
+    constexpr double shift_scaled = 0x1.8p+52 / 32.0;
+    double kd = ylogx + shift_scaled;
+    const uint64_t ki = (uint64_t)__double_as_longlong(kd);
+    kd -= shift_scaled;
+    const double rr = ylogx - kd;
+    const double s = __longlong_as_double((long long)(EXP2F_TAB[ki & 31] + ((ki + sign_bias) << 47)));
+    const double zz = __builtin_fma(EXP2F_C0, rr, EXP2F_C1);
+    const double rr2 = rr * rr;
+    double out = __builtin_fma(EXP2F_C2, rr, 1.0);
+    out = __builtin_fma(zz, rr2, out);
+    out = out * s;
+    return (float)out;
 }
 
 // f32::tanh / sinh / cosh of generated models (build_test/nb_macro/src/lib.rs:9152-9163 forward to the platform
@@ -163,36 +295,24 @@ __device__ __forceinline__ float tanf_portable(float x)
     return (float)(s / c);
 }
 
-// x.powf(n) for an integer literal n (the only exponents the generator accepts): square-and-multiply in binary64,
-// one rounding to binary32; n < 0 -> reciprocal of the product
-__device__ __forceinline__ float powif_portable(float x, int n)
+// x.powf(n) for an integer literal n (the only exponents the generator accepts) as rustc -O compiles it: LLVM folds
+// powf(x, 2.) to x * x, powf(x, 1.) to x, powf(x, 0.) to 1 and powf(x, -1.) to 1 / x without fast-math flags; every other
+// exponent stays a libm call.
+__device__ __forceinline__ float powif_glibc(float x, int n)
 {
-    double b = (double)x, r = 1.0;
-    int m = (n < 0) ? -n : n;
-    while (m) {                      // square and multiply: x^3 = x * x^2, x^4 = (x^2)^2 as pow3f / pow4f form them
-        if (m & 1) r = r * b;
-        m >>= 1;
-        if (m) b = b * b;
-    }
-    return (float)((n < 0) ? 1.0 / r : r);
+    if (n == 2) return x * x;
+    if (n == 1) return x;
+    if (n == 0) return 1.0f;
+    if (n == -1) return 1.0f / x;
+    return powf_glibc(x, (float)n);
 }
 
 // nb_macro's heaviside (lib.rs:9176-9178): `if x < 0 { 0 } else { x }`
 __device__ __forceinline__ float heaviside_rs(float x) { return (x < 0.0f) ? 0.0f : x; }
 
-// powf(x, 3.) / powf(x, 4.) of the Na / K channel currents (ion_channels/mod.rs:234, 280):
-// exact square in binary64, one rounding each.
-__device__ __forceinline__ float pow3f_portable(float x)
-{
-    const double d = (double)x;
-    return (float)((d * d) * d);
-}
-__device__ __forceinline__ float pow4f_portable(float x)
-{
-    const double d = (double)x;
-    const double d2 = d * d;
-    return (float)(d2 * d2);
-}
+// powf(x, 3.) / powf(x, 4.) of the Na / K channel currents (ion_channels/mod.rs:234, 280): genuine libm calls
+__device__ __forceinline__ float pow3f_glibc(float x) { return powf_glibc(x, 3.0f); }
+__device__ __forceinline__ float pow4f_glibc(float x) { return powf_glibc(x, 4.0f); }
 
 // f32::max / f32::min as Rust defines them (a NaN operand yields the other one)
 __device__ __forceinline__ float max_rs(float a, float b)
@@ -223,7 +343,7 @@ __device__ __forceinline__ float delta_dirac_effect(long long timestep, int last
 {
     const float a = v_th - v_resting;
     const float td = (float)(timestep - (long long)last_firing_time);
-    return a * expf_portable((-1.0f / (k / dt)) * (td * td)) + v_resting;
+    return a * expf_glibc((-1.0f / (k / dt)) * (td * td)) + v_resting;
 }
 
 // ExponentialDecayRefractoriness::get_effect (spike_train/mod.rs:164-178)
@@ -232,7 +352,7 @@ __device__ __forceinline__ float exponential_decay_effect(long long timestep, in
 {
     const float a = v_th - v_resting;
     const float td = (float)(timestep - (long long)last_firing_time);
-    return a * expf_portable((-1.0f / (k / dt)) * td) + v_resting;
+    return a * expf_glibc((-1.0f / (k / dt)) * td) + v_resting;
 }
 
 // STDP::update_weight (plasticity/mod.rs:45-66): the delta added to the weight
@@ -241,8 +361,8 @@ __device__ __forceinline__ float stdp_delta(int t_pre, int t_post, float a_plus,
 {
     if (t_pre < 0 || t_post < 0) return 0.0f;
     const float tp = (float)t_pre, tq = (float)t_post;
-    if (tp < tq) return a_plus * expf_portable(-1.0f * __builtin_fabsf((tp - tq) * dt) / tau_plus);
-    if (tp > tq) return -1.0f * a_minus * expf_portable(-1.0f * __builtin_fabsf((tq - tp) * dt) / tau_minus);
+    if (tp < tq) return a_plus * expf_glibc(-1.0f * __builtin_fabsf((tp - tq) * dt) / tau_plus);
+    if (tp > tq) return -1.0f * a_minus * expf_glibc(-1.0f * __builtin_fabsf((tq - tp) * dt) / tau_minus);
     return 0.0f;
 }
 
@@ -282,7 +402,7 @@ __device__ __forceinline__ float plasticity_weight(const float *prm, float w, in
 // exp_decay, iterate_and_spike/mod.rs:345-347
 __device__ __forceinline__ float exp_decay(float x, float l, float dt)
 {
-    return -x * expf_portable(dt / -l);
+    return -x * expf_glibc(dt / -l);
 }
 
 // NeurotransmitterKinetics::apply_t_change.  kind 0 Approximate (iterate_and_spike/mod.rs:193-196), 1 Destexhe
@@ -292,7 +412,7 @@ __device__ __forceinline__ float nt_apply(int kind, float t, float t_max, float 
                                           float voltage, uint32_t spiking, float dt)
 {
     const float s = spiking ? 1.0f : 0.0f;
-    if (kind == 1) return t_max / (1.0f + expf_portable(-(voltage - v_p) / k_p));
+    if (kind == 1) return t_max / (1.0f + expf_glibc(-(voltage - v_p) / k_p));
     if (kind == 2) return t_max * s;
     if (kind == 3) t += exp_decay(t, c, dt) + (s * t_max);
     else t += dt * -c * t + (s * t_max);

@@ -941,4 +941,20 @@ int snn_probe_math(int device, int which, const float *in, float *out, size_t co
     return rc;
 }
 
+int snn_probe_math_bits(int device, int which, uint32_t first, uint32_t stride, float y, float *out, size_t count)
+{
+    if (!out) return fail(SNN_ERR_BAD_ARG, "null argument");
+    if (which < 0 || which > 3) return fail(SNN_ERR_BAD_ARG, "unknown function selector");
+    HIP_TRY(hipSetDevice(device), SNN_ERR_GET_DEVICE);
+    if (count == 0) return SNN_OK;
+    float *dout = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dout), count * 4), SNN_ERR_BUFFER_CREATE);
+    int rc = SNN_OK;
+    hipLaunchKernelGGL(k_probe_math_bits, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, 0, which, first, stride, y, dout, count);
+    if (hipDeviceSynchronize() != hipSuccess) rc = fail(SNN_ERR_WAIT, "probe kernel failed");
+    if (rc == SNN_OK && hipMemcpy(out, dout, count * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(SNN_ERR_BUFFER_READ, "download failed");
+    (void)hipFree(dout);
+    return rc;
+}
+
 } // extern "C"

@@ -81,6 +81,11 @@ struct snn_network {
     bool any_plasticity = false;
     std::map<uint32_t, bool> lattice_has_nt;    // lattice id -> some neurotransmitters$flags entry is set
     bool any_nt_neurons = false, any_nt_cells = false;
+    std::map<uint32_t, uint32_t> lattice_nt_mask;   // lattice id -> bit k: some cell of it releases transmitter type k
+    // live transmitter types of the handle (the union over its lattices), refreshed with the static counts: the dense
+    // input pass is specialised on their number and leaves the partial planes of the other types untouched (zero)
+    uint32_t n_live = K_TYPES, live_type[K_TYPES] = {0, 1, 2};
+    uint32_t live_mask_applied = 0xFFFFFFFFu;
     // reward modulation (RewardModulatedLattice): per-lattice modulator table + per-edge trace, allocated on first use
     bool any_modulation = false;
     std::vector<float> rm_host;            // [n_lattices][RM_STRIDE]
@@ -672,6 +677,9 @@ int attr_io(snn_network *net, uint32_t id, const char *name, AttrType type, void
         bool any = false;
         for (size_t i = 0; i < count && !any; ++i) any = h[i] != 0;
         net->lattice_has_nt[id] = any;
+        uint32_t mask = 0;
+        for (size_t i = 0; i < count; ++i) mask |= h[i] ? (1u << (i % K_TYPES)) : 0u;
+        net->lattice_nt_mask[id] = mask;
         net->any_nt_neurons = net->any_nt_cells = false;
         for (const auto &kv : net->lattice_has_nt) {
             const LatticeInfo *li = find_lattice(net, kv.first);
@@ -696,6 +704,22 @@ SellGraph csr_graph(const snn_network *net)
 int ensure_counts(snn_network *net)
 {
     if (!net->counts_dirty || net->n_loc == 0) { net->counts_dirty = false; return SNN_OK; }
+    {
+        // live transmitter types: slots of the specialised input pass; planes of dead types must read as zero
+        uint32_t mask = 0;
+        for (const auto &kv : net->lattice_nt_mask) mask |= kv.second;
+        if (mask != net->live_mask_applied) {
+            net->n_live = 0;
+            for (uint32_t k = 0; k < K_TYPES; ++k)
+                if (mask >> k & 1u) net->live_type[net->n_live++] = k;
+            for (uint32_t s = net->n_live, k = 0; s < K_TYPES; ++k)          // unused slots: the remaining types
+                if (!(mask >> k & 1u)) net->live_type[s++] = k;
+            if (net->n_live == 0) net->n_live = 1;                            // nothing released: slot 0 sums zeros
+            HIP_TRY(hipMemsetAsync(net->part_t, 0, (size_t)K_TYPES * net->n_chunks * net->ld * 4, net->stream),
+                    SNN_ERR_BUFFER_WRITE);
+            net->live_mask_applied = mask;
+        }
+    }
     HIP_TRY(hipMemsetAsync(net->n_in, 0, (size_t)net->ld * 4, net->stream), SNN_ERR_BUFFER_WRITE);
     HIP_TRY(hipMemsetAsync(net->tcount, 0, (size_t)K_TYPES * net->ld * 4, net->stream), SNN_ERR_BUFFER_WRITE);
     if (net->csr) {

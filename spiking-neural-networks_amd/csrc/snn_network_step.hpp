@@ -49,6 +49,7 @@ int launch_inputs(snn_network *net, InputsPart part = INPUTS_ALL)
     a.st_nt_t = net->ca.nt_t; a.st_nt_flags = net->ca.nt_flags; a.c_pad = net->c_pad;
     a.nt_flags = net->na.nt_flags; a.n_pad = net->n_pad;
     a.part_i = net->part_i; a.part_t = net->part_t; a.n_chunks = net->n_chunks;
+    for (int k = 0; k < K_TYPES; ++k) a.live_type[k] = net->live_type[k];
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (net->profile) {
         if (net->ev_used == net->ev_pool.size()) {
@@ -115,19 +116,26 @@ int launch_inputs(snn_network *net, InputsPart part = INPUTS_ALL)
         if (net->profile) HIP_TRY(hipEventRecord(e1, net->stream), SNN_ERR_QUEUE);
         return SNN_OK;
     }
-#define SNN_LAUNCH_SHAPE(E, C, SH)                                                                        \
-    hipLaunchKernelGGL((k_inputs_dense<E, C, SH>),                                                       \
+#define SNN_LAUNCH_SHAPE(E, C, SH, NT)                                                                    \
+    hipLaunchKernelGGL((k_inputs_dense<E, C, SH, NT>),                                                   \
                        dim3((net->n_loc + InputsShape<SH>::TILE - 1) / InputsShape<SH>::TILE, grid_chunks), \
                        dim3(InputsShape<SH>::THREADS), 0, net->stream, a)
-#define SNN_LAUNCH_INPUTS(E, C)                                                                          \
+#define SNN_LAUNCH_INPUTS(E, C, NT)                                                                      \
     do {                                                                                                 \
-        if (shape == 1) SNN_LAUNCH_SHAPE(E, C, 1);                                                       \
-        else if (shape == 2) SNN_LAUNCH_SHAPE(E, C, 2);                                                  \
-        else SNN_LAUNCH_SHAPE(E, C, 0);                                                                  \
+        if (shape == 1) SNN_LAUNCH_SHAPE(E, C, 1, NT);                                                   \
+        else if (shape == 2) SNN_LAUNCH_SHAPE(E, C, 2, NT);                                              \
+        else SNN_LAUNCH_SHAPE(E, C, 0, NT);                                                              \
     } while (0)
-    if (net->electrical && net->chemical) SNN_LAUNCH_INPUTS(true, true);
-    else if (net->electrical) SNN_LAUNCH_INPUTS(true, false);
-    else SNN_LAUNCH_INPUTS(false, true);
+#define SNN_LAUNCH_CHEM(E)                                                                               \
+    do {                                                                                                 \
+        if (net->n_live == 1) SNN_LAUNCH_INPUTS(E, true, 1);                                             \
+        else if (net->n_live == 2) SNN_LAUNCH_INPUTS(E, true, 2);                                        \
+        else SNN_LAUNCH_INPUTS(E, true, 3);                                                              \
+    } while (0)
+    if (net->electrical && net->chemical) SNN_LAUNCH_CHEM(true);
+    else if (net->electrical) SNN_LAUNCH_INPUTS(true, false, 3);
+    else SNN_LAUNCH_CHEM(false);
+#undef SNN_LAUNCH_CHEM
 #undef SNN_LAUNCH_INPUTS
 #undef SNN_LAUNCH_SHAPE
     HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
@@ -354,6 +362,7 @@ int fused_step_args(snn_network *net, InputsArgs &a, UpdateArgs &u)
     a.st_nt_t = net->ca.nt_t; a.st_nt_flags = net->ca.nt_flags; a.c_pad = net->c_pad;
     a.nt_flags = net->na.nt_flags; a.n_pad = net->n_pad;
     a.part_i = net->part_i; a.part_t = net->part_t; a.n_chunks = net->n_chunks;
+    for (int k = 0; k < K_TYPES; ++k) a.live_type[k] = (uint32_t)k;
     u = UpdateArgs{};
     u.n = net->na;
     u.n.xbuf = cur;

@@ -1070,12 +1070,12 @@ def _hip_expr(e, index):
         if e[1] == "isnan":
             arg = _hip_expr(e[2][0], index)
             return f"({arg} != {arg})"
-        fn = {"exp": "expf_portable", "tanh": "tanhf_portable", "sinh": "sinhf_portable", "cosh": "coshf_portable",
+        fn = {"exp": "expf_glibc", "tanh": "tanhf_portable", "sinh": "sinhf_portable", "cosh": "coshf_portable",
               "sin": "sinf_portable", "cos": "cosf_portable", "tan": "tanf_portable",
               "heaviside": "heaviside_rs", "min": "min_rs", "max": "max_rs"}[e[1]]
         return f"{fn}({', '.join(_hip_expr(a, index) for a in e[2])})"
     if kind == "powi":
-        return f"powif_portable({_hip_expr(e[1], index)}, {e[2]})"
+        return f"powif_glibc({_hip_expr(e[1], index)}, {e[2]})"
     if kind == "rc_get":
         return f"chem.get_receptor_currents({_hip_expr(e[1], index)}, {_hip_expr(e[2], index)})"
     _, op, lhs, rhs = e

@@ -355,6 +355,15 @@ def probe_math(which, x, device=0):
     return out
 
 
+def probe_math_bits(which, first, count, stride=1, y=0.0, device=0):
+    """The same over float BIT PATTERNS first + i * stride formed on the device; which = 3: powf(x, y)."""
+    L = _lib.load()
+    out = np.empty(count, np.float32)
+    _lib.check(L.snn_probe_math_bits(device, which, first & 0xFFFFFFFF, stride, float(y), out.ctypes.data_as(_lib.f32p),
+                                     count))
+    return out
+
+
 def probe_bandwidth(nbytes=8 << 30, repeats=5, device=0):
     """(read-only GB/s, copy GB/s) of the device with the stepper's access shape"""
     L = _lib.load()

@@ -134,6 +134,10 @@ def lib():
             getattr(L, fn).restype = C.c_float
         L.snn_o_powif_export.argtypes = [C.c_float, C.c_int]
         L.snn_o_powif_export.restype = C.c_float
+        L.snn_o_powf_export.argtypes = [C.c_float, C.c_float]
+        L.snn_o_powf_export.restype = C.c_float
+        L.snn_o_math_bits.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_uint64, C.c_float, C.POINTER(C.c_float)]
+        L.snn_o_math_bits.restype = None
         L.snn_o_stdp_delta.argtypes = [C.c_int32, C.c_int32] + [C.c_float] * 5
         L.snn_o_stdp_delta.restype = C.c_float
         L.snn_o_delta_dirac_effect.argtypes = [C.c_int64, C.c_int32] + [C.c_float] * 4
@@ -455,6 +459,17 @@ def tanf(x):
 
 def powif(x, n):
     return lib().snn_o_powif_export(float(np.float32(x)), int(n))
+
+
+def powf(x, y):
+    return lib().snn_o_powf_export(float(np.float32(x)), float(np.float32(y)))
+
+
+def math_bits(which, first, count, stride=1, y=0.0):
+    """f(float with bit pattern first + i * stride), i < count: which = 0 expf, 1 powf(x, 3), 2 powf(x, 4), 3 powf(x, y)"""
+    out = np.empty(count, np.float32)
+    lib().snn_o_math_bits(which, first & 0xFFFFFFFF, stride, count, float(y), out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out
 
 
 def uniform(seed, index, lo, hi):

@@ -55,7 +55,7 @@ def test_mandatory_overrides_precedence_and_order_of_application():
     src = modelgen.hip_source(m)
     # left-to-right, one operation per node; both derivatives are formed before either variable moves
     assert "((((((0.03999999910593033f * v) * v) + (5.0f * v)) + 140.0f) - x[4]) + i_in) + " in src
-    assert "(0.5f * expf_portable(((v - x[5]) / 20.0f)))) / c_m)" in src
+    assert "(0.5f * expf_glibc(((v - x[5]) / 20.0f)))) / c_m)" in src
     i_dv, i_dw, i_apply = src.index("const float d_v"), src.index("const float d_x4"), src.index("v += d_v;")
     assert i_dv < i_dw < i_apply < src.index("x[4] += d_x4;")
     assert "x[4] += x[3];" in src                  # on_spike: w += d

@@ -85,7 +85,7 @@ def test_blocks_are_parsed_and_emitted():
     src = modelgen.hip_source(d)
     assert "namespace custom_st {" in src and "namespace custom_refr {" in src and "namespace custom {" not in src
     assert "is_spiking = true;" in src and "v = v_th;" in src
-    assert "powif_portable(time_difference, 2)" in src
+    assert "powif_glibc(time_difference, 2)" in src
     b = modelgen.parse_description(BURST_DSL)
     assert b.spike_train.mandatory["v_th"] == 25.0 and b.spike_train.bools == {"bursting", "is_spiking"}
     assert b.refractoriness.variables == [("plateau", 3.0)] and b.refractoriness.decay == 2000.0
