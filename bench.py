@@ -176,7 +176,10 @@ def main():
     ap.add_argument("--cols", type=int, default=COLS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-sharded", action="store_true",
-                    help="take the multi-GPU code path (shard handle, RCCL all-gather per step) even at world size 1")
+                    help="take the multi-GPU code path (shard handle, RCCL exchange per step) even at world size 1")
+    ap.add_argument("--stepper", default="library", choices=["library", "torch"],
+                    help="who drives a sharded run: snn_run_sharded (the library calls RCCL itself, default) or "
+                         "parallel.ShardedStepper (torch.distributed moves the segments)")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not bracket k_inputs_dense with HIP events (roofline.achieved is then null)")
     args = ap.parse_args()
@@ -205,13 +208,21 @@ def main():
 
     dn, n, workload, kernel_name = build_config(args, snn_amd, synthetic, np, rank, world, local_rank)
 
-    if sharded:
-        # everything stream-ordered on torch's current stream: kernels, the RCCL all-gather, kernels ... no host
-        # synchronisation inside the step loop
+    comm = None
+    if sharded and args.stepper == "library":
+        # the whole step loop inside libsnn_amd.so: kernels -> pack -> RCCL (called by the library on its own second
+        # stream) -> unpack -> kernels, ONE host call per run; torch.distributed only carries the 128-byte RCCL id
+        comm = parallel.LibraryComm(rank, world, local_rank)
+
+        def run(k):
+            dn.run_sharded(comm, k)
+    elif sharded:
+        # torch.distributed moves the segments; everything stream-ordered on torch's current stream: kernels, the
+        # RCCL collective, kernels ... no host synchronisation inside the step loop
         side = torch.cuda.Stream()                      # a real (non-default) stream shared by kernels and RCCL ordering
         dn.set_stream(side.cuda_stream)
-        buf = parallel.exchange_tensor(dn, torch.device("cuda", local_rank))
-        stepper = parallel.ShardedStepper(dn, buf, rank, world, always_gather=True, stream=side)
+        stepper = parallel.ShardedStepper(dn, rank, world, always_exchange=True, stream=side,
+                                          device=torch.device("cuda", local_rank))
 
         def run(k):
             stepper.run(k)
@@ -294,6 +305,8 @@ def main():
         result = None
 
     dn.close()
+    if comm is not None:
+        comm.close()
     if dist is not None:
         dist.destroy_process_group()
     if result is not None:

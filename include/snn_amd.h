@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define SNN_ABI_VERSION 1
+#define SNN_ABI_VERSION 2
 #define SNN_NUM_NT_TYPES 3
 /* canonical reduction chunk: presynaptic indices are summed in runs of 256 */
 #define SNN_REDUCTION_CHUNK 256
@@ -199,23 +199,76 @@ int snn_reset_timing(snn_network_t *net);
  * population handle; sharded handles are driven with the three calls below. */
 int snn_run(snn_network_t *net, uint64_t iterations);
 
-/* Multi-GPU stepping of one shard: (1) snn_step_begin computes the local neurons' step from the
- * replicated presynaptic state and writes their new exchanged state into the local slice of the
- * exchange buffer; (2) the caller all-gathers the exchange buffer across ranks (RCCL, in place);
- * (3) snn_step_end applies the gathered state (last_firing_time, plasticity on the local columns,
- * spike trains, clock). */
+/* ---- multi-GPU: one process and one shard handle per GPU ----------------------------------------------
+ * The reference has no distributed path; the sharding follows the step's data dependence (neuron/mod.rs:2640-2647:
+ * every input of step t reads the state of step t - 1 only).  A shard handle owns the postsynaptic neurons
+ * [post_begin, post_end), their columns of the graph and their state; per step it needs the presynaptic state of the
+ * neurons owned elsewhere that its rows read.  That is ONE exchange per step, sized by the handle's EXCHANGE PLAN:
+ *
+ *   per neuron on the wire: 4 B current_voltage (only with electrical synapses) + 4 B per transmitter type that some
+ *   NEURON of the network releases (only with chemical synapses) + 1 BIT for the spike;
+ *   SNN_EXCHANGE_ALLGATHER (dense graph): every rank's whole slot, one in-place all-gather;
+ *   SNN_EXCHANGE_HALO (CSR graph, after snn_halo_commit): per peer exactly the neurons that peer's rows reference,
+ *   an all-to-all-v.
+ *
+ * Three ways to drive it:
+ *   (a) snn_run_sharded: the whole step loop inside the library, RCCL called directly (one host call per run);
+ *   (b) snn_step_begin -> snn_exchange (RCCL, on the handle's stream) -> snn_step_end;
+ *   (c) snn_step_begin -> the caller moves the segments described by snn_exchange_plan_get / snn_exchange_peers with
+ *       its own transport (torch.distributed, device-to-device copies between handles of one process) -> snn_step_end.
+ * snn_step_begin computes the local neurons' step and packs the outgoing segments; snn_step_end applies the incoming
+ * segments (state mirror, last_firing_time), then plasticity on the local columns, histories, clock, spike trains. */
 int snn_step_begin(snn_network_t *net);
 int snn_step_end(snn_network_t *net);
-/* Optional overlap: enqueue, BEFORE the all-gather of the previous step has been waited for, the part of
+/* Optional overlap: enqueue, BEFORE the exchange of the previous step has been waited for, the part of
  * this step's synaptic-input pass that only needs the shard's own neurons as presynaptic rows; the
  * following snn_step_begin then processes the remaining rows.  A no-op when plasticity is on (STDP
  * rewrites W in snn_step_end) or the graph is CSR.  Results do not depend on whether it is called. */
 int snn_step_begin_local(snn_network_t *net);
-/* Device pointer / layout of the exchange buffer: `words_per_neuron` 32-bit words per neuron,
- * neuron-major planes: plane j occupies [j*n_padded, (j+1)*n_padded); the local slice of each
- * plane is [post_begin, post_end).  n_padded = shard_stride * n_shards. */
-int snn_exchange_buffer(snn_network_t *net, void **device_ptr, uint32_t *words_per_neuron,
-                        uint32_t *n_padded);
+
+enum { SNN_EXCHANGE_ALLGATHER = 0, SNN_EXCHANGE_HALO = 1 };
+typedef struct snn_exchange_plan {
+    int32_t mode;                 /* SNN_EXCHANGE_ALLGATHER | SNN_EXCHANGE_HALO */
+    uint32_t n_shards, shard_index, shard_stride;
+    uint32_t planes;              /* 32-bit planes per neuron on the wire (0..4) */
+    uint32_t plane_id[4];         /* what plane s carries: 0 current_voltage, 2 + k transmitter type k */
+    void *send, *recv;            /* device buffers of 32-bit words; all-gather: send lies inside recv (in place) */
+    uint64_t send_words, recv_words;
+} snn_exchange_plan;
+/* The plan in force for the next step (it follows snn_set_synapses, the neurotransmitters$flags of the neuron
+ * lattices and snn_halo_commit; query it after configuring and before stepping; buffers stay valid until then). */
+int snn_exchange_plan_get(snn_network_t *net, snn_exchange_plan *plan);
+/* Per peer p (arrays of n_shards entries, 32-bit words): the segment this handle sends to p is
+ * send[send_offset[p] .. + send_words[p]), the segment it receives from p goes to recv[recv_offset[p] .. +
+ * recv_words[p]).  All-gather: every peer gets the same segment (own slot) and recv_offset[p] = p * block.  A segment
+ * of n neurons holds planes * n words followed by ceil(n / 32) words of spike bits. */
+int snn_exchange_peers(snn_network_t *net, uint64_t *send_offset, uint64_t *send_words, uint64_t *recv_offset,
+                       uint64_t *recv_words);
+
+/* Halo plan of a CSR shard handle.  snn_set_graph_csr derives, per peer, the ascending global indices of that peer's
+ * neurons the local rows read (snn_halo_needs: count, and the list when `indices` has room for it).  Every rank tells
+ * every peer what it needs; snn_halo_set_sends stores what `peer` needs from this handle; snn_halo_commit (after all
+ * peers' lists are in) switches the handle to SNN_EXCHANGE_HALO.  snn_run_sharded / snn_comm_exchange_halo_lists do
+ * this exchange over RCCL themselves.  Without a commit the handle all-gathers whole slots (correct, larger). */
+int snn_halo_needs(snn_network_t *net, uint32_t peer, uint32_t *indices, uint32_t capacity, uint32_t *count);
+int snn_halo_set_sends(snn_network_t *net, uint32_t peer, const uint32_t *indices, uint32_t count);
+int snn_halo_commit(snn_network_t *net);
+
+/* RCCL, called by the library itself (librccl.so.1 is opened on first use; a process that already loaded a copy --
+ * e.g. PyTorch's -- shares it).  `nccl_comm` is an ncclComm_t: the host's own, or one made by the two helpers below
+ * (snn_comm_unique_id on rank 0 -> the 128 bytes travel to every rank by the host's means -> snn_comm_init_rank). */
+int snn_comm_unique_id(void *id_128_bytes);
+int snn_comm_init_rank(const void *id_128_bytes, int world_size, int rank, int device, void **nccl_comm);
+int snn_comm_destroy(void *nccl_comm);
+/* CSR shard handles: all ranks call it once after snn_set_graph_csr; trades the need lists and commits the halo plan */
+int snn_comm_exchange_halo_lists(snn_network_t *net, void *nccl_comm);
+/* One exchange of the packed segments, enqueued on the handle's stream (between snn_step_begin and snn_step_end) */
+int snn_exchange(snn_network_t *net, void *nccl_comm);
+/* `iterations` steps of a shard handle, every rank of the communicator calling it with its own handle: per step
+ * kernels -> pack -> ncclAllGather / grouped ncclSend+ncclRecv on a second stream -> unpack -> rest of the step, with
+ * the next step's own-rows input pass overlapping the collective where that is valid (see snn_step_begin_local).
+ * Blocks until the last step has finished.  Results are identical to (b) and (c) and to a single-GPU snn_run. */
+int snn_run_sharded(snn_network_t *net, void *nccl_comm, uint64_t iterations);
 /* HIP stream the handle launches on (hipStream_t), for ordering collectives against it */
 int snn_stream(snn_network_t *net, void **hip_stream);
 /* Adopt the caller's stream (e.g. the one its RCCL collectives are ordered against); NULL returns to the

@@ -68,6 +68,15 @@ def build_custom(model, force=False):
     return out
 
 
+class ExchangePlan(C.Structure):
+    """snn_exchange_plan of include/snn_amd.h"""
+    _fields_ = [("mode", C.c_int32), ("n_shards", C.c_uint32), ("shard_index", C.c_uint32), ("shard_stride", C.c_uint32),
+                ("planes", C.c_uint32), ("plane_id", C.c_uint32 * 4), ("send", C.c_void_p), ("recv", C.c_void_p),
+                ("send_words", C.c_uint64), ("recv_words", C.c_uint64)]
+
+
+EXCHANGE_ALLGATHER, EXCHANGE_HALO = 0, 1
+
 f32p = C.POINTER(C.c_float)
 u32p = C.POINTER(C.c_uint32)
 i32p = C.POINTER(C.c_int32)
@@ -117,7 +126,17 @@ SIGNATURES = {
     "snn_step_begin": (C.c_int, [H]),
     "snn_step_end": (C.c_int, [H]),
     "snn_step_begin_local": (C.c_int, [H]),
-    "snn_exchange_buffer": (C.c_int, [H, C.POINTER(C.c_void_p), u32p, u32p]),
+    "snn_exchange_plan_get": (C.c_int, [H, C.c_void_p]),
+    "snn_exchange_peers": (C.c_int, [H, u64p, u64p, u64p, u64p]),
+    "snn_halo_needs": (C.c_int, [H, C.c_uint32, u32p, C.c_uint32, u32p]),
+    "snn_halo_set_sends": (C.c_int, [H, C.c_uint32, u32p, C.c_uint32]),
+    "snn_halo_commit": (C.c_int, [H]),
+    "snn_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "snn_comm_init_rank": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "snn_comm_destroy": (C.c_int, [C.c_void_p]),
+    "snn_comm_exchange_halo_lists": (C.c_int, [H, C.c_void_p]),
+    "snn_exchange": (C.c_int, [H, C.c_void_p]),
+    "snn_run_sharded": (C.c_int, [H, C.c_void_p, C.c_uint64]),
     "snn_stream": (C.c_int, [H, C.POINTER(C.c_void_p)]),
     "snn_set_stream": (C.c_int, [H, C.c_void_p]),
     "snn_synchronize": (C.c_int, [H]),

@@ -274,15 +274,6 @@ __global__ __launch_bounds__(256) void k_stdp_rows(const StdpArgs a)
     }
 }
 
-// last_firing_time of REMOTE neurons from the gathered spike plane (sharded handles only)
-__global__ void k_stamp_remote(const float *xbuf, XLayout xl, int32_t *last_firing_time, uint32_t n_neurons,
-                               uint32_t q0, uint32_t n_loc, long long clock)
-{
-    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= n_neurons || (q >= q0 && q < q0 + n_loc)) return;
-    if (reinterpret_cast<const uint32_t *>(xbuf)[xl.at(q, PLANE_SPIKE)]) last_firing_time[q] = (int32_t)clock;
-}
-
 // ---- reduced per-lattice histories ---------------------------------------------------------------
 // AverageVoltageHistory (neuron/mod.rs:305-322) and EEGHistory (:233-284) on the device: one float per lattice
 // and step instead of the T x N voltage history.  One workgroup per lattice; every thread sums one 256-neuron

@@ -7,10 +7,11 @@
 //            is stored as a quiet NaN, so `connections` needs no second matrix and the averager
 //            count n_in[post] is precomputed once per graph upload.  4 B per synapse, read once
 //            per step.
-//   xbuf     the state every rank needs of every neuron ("exchanged planes"), blocked by shard:
-//            [shard][plane][stride] 32-bit words; planes: 0 current_voltage (f32),
-//            1 is_spiking (u32), 2..4 neurotransmitter concentration t of type AMPA/NMDA/GABA.
-//            One in-place all-gather of contiguous per-shard blocks refreshes it each step.
+//   xbuf     the state every kernel reads of presynaptic neurons (the "mirror"), neuron-major planes indexed by
+//            the GLOBAL neuron index: [plane][n_pad] 32-bit words; planes: 0 current_voltage (f32),
+//            1 is_spiking (u32), 2..4 neurotransmitter concentration t of type AMPA/NMDA/GABA.  A shard handle
+//            keeps the entries of its own neurons current itself and refreshes the remote entries it reads
+//            from the per-step exchange (wire buffers, snn_kernels_exchange.hpp).
 //   SoA      one array per reference struct field, length n_neurons padded to 256; per-type
 //            attributes are stored type-major [3][n_pad] so that lanes = consecutive neurons
 //            stay coalesced.
@@ -26,16 +27,12 @@ constexpr int CHUNK = 256;        // canonical reduction chunk (SNN_REDUCTION_CH
 constexpr int NUM_PLANES = 5;
 enum Plane { PLANE_V = 0, PLANE_SPIKE = 1, PLANE_T0 = 2 };
 
-// Exchanged-plane addressing: global neuron index -> word offset inside xbuf.
+// Mirror addressing: global neuron index -> word offset inside xbuf.
 struct XLayout {
-    uint32_t stride;       // neurons per shard slot (multiple of 64)
-    uint32_t n_shards;
+    uint32_t stride;       // words per plane (= n_pad)
     __host__ __device__ __forceinline__ size_t at(uint32_t neuron, int plane) const
     {
-        if (n_shards == 1) return (size_t)plane * stride + neuron;     // whole population: no division
-        const uint32_t shard = neuron / stride;
-        const uint32_t i = neuron - shard * stride;
-        return ((size_t)shard * NUM_PLANES + plane) * stride + i;
+        return (size_t)plane * stride + neuron;
     }
 };
 

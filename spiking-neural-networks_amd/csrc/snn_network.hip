@@ -3,6 +3,7 @@
 // attribute registry), snn_network_step.hpp the kernel launches and the step loop, snn_kernels_*.hpp the kernels.
 #include "snn_network_state.hpp"
 #include "snn_network_step.hpp"
+#include "snn_network_exchange.hpp"
 
 // ================================================================================================
 // C ABI
@@ -69,6 +70,14 @@ int snn_network_destroy(snn_network_t *net)
     if (net->summ_avg) (void)hipFree(net->summ_avg);
     if (net->summ_eeg) (void)hipFree(net->summ_eeg);
     for (auto &e : net->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    for (void *p : {(void *)net->halo_send_buf, (void *)net->halo_recv_buf, (void *)net->halo_send_idx, (void *)net->halo_recv_idx,
+                    (void *)net->seg_count_dev[0], (void *)net->seg_count_dev[1], (void *)net->seg_first_dev[0],
+                    (void *)net->seg_first_dev[1], (void *)net->seg_offset_dev[0], (void *)net->seg_offset_dev[1],
+                    (void *)net->seg_loff_dev[0], (void *)net->seg_loff_dev[1]})
+        if (p) (void)hipFree(p);
+    if (net->comm_stream) { (void)hipStreamSynchronize(net->comm_stream); (void)hipStreamDestroy(net->comm_stream); }
+    if (net->ev_packed) (void)hipEventDestroy(net->ev_packed);
+    if (net->ev_exchanged) (void)hipEventDestroy(net->ev_exchanged);
     if (net->own_stream) (void)hipStreamDestroy(net->own_stream);
     delete net;
     return SNN_OK;
@@ -97,7 +106,7 @@ int snn_network_add_spike_train_lattice(snn_network_t *net, uint32_t id, uint32_
 }
 
 static int finalize_impl(snn_network_t *net, bool whole, uint32_t post_begin, uint32_t post_end, uint32_t n_shards,
-                         uint32_t stride)
+                         uint32_t stride, uint32_t shard_index)
 {
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
     if (net->finalized) return fail(SNN_ERR_BAD_STATE, "already finalized");
@@ -118,15 +127,16 @@ static int finalize_impl(snn_network_t *net, bool whole, uint32_t post_begin, ui
     net->c_pad = std::max<uint32_t>(256, round_up(net->nc, 256));
     if (whole) {
         net->q0 = 0; net->q1 = net->nn;
-        net->xl = XLayout{net->n_pad, 1};
     } else {
         if (post_begin > post_end || post_end > net->nn) return fail(SNN_ERR_DIM_MISMATCH, "shard range outside the population");
         if (stride == 0 || stride % 64 != 0 || n_shards == 0 || (uint64_t)stride * n_shards < net->nn)
             return fail(SNN_ERR_BAD_ARG, "shard stride must be a multiple of 64 covering the population");
         net->q0 = post_begin; net->q1 = post_end;
-        net->xl = XLayout{stride, n_shards};
+        net->sharded = true;
+        net->n_shards = n_shards; net->shard_stride = stride; net->shard_index = shard_index;
         net->n_pad = std::max<uint32_t>(net->n_pad, round_up(stride * n_shards, 256));
     }
+    net->xl = XLayout{net->n_pad};
     net->n_loc = net->q1 - net->q0;
     net->ld = std::max<uint32_t>(64, round_up(net->n_loc, 64));
     // A row stride that is a multiple of 4 KiB puts the same columns of consecutive rows on the same HBM
@@ -141,7 +151,7 @@ static int finalize_impl(snn_network_t *net, bool whole, uint32_t post_begin, ui
     return SNN_OK;
 }
 
-int snn_network_finalize(snn_network_t *net) { return finalize_impl(net, true, 0, 0, 1, 0); }
+int snn_network_finalize(snn_network_t *net) { return finalize_impl(net, true, 0, 0, 1, 0, 0); }
 
 int snn_network_finalize_shard(snn_network_t *net, uint32_t shard_index, uint32_t n_shards)
 {
@@ -154,7 +164,7 @@ int snn_network_finalize_shard(snn_network_t *net, uint32_t shard_index, uint32_
     const uint32_t stride = std::max<uint32_t>(64, round_up((uint32_t)((nn + n_shards - 1) / n_shards), 64));
     const uint32_t begin = (uint32_t)std::min<uint64_t>(nn, (uint64_t)shard_index * stride);
     const uint32_t end = (uint32_t)std::min<uint64_t>(nn, (uint64_t)begin + stride);
-    return finalize_impl(net, false, begin, end, n_shards, stride);
+    return finalize_impl(net, false, begin, end, n_shards, stride, shard_index);
 }
 
 int snn_network_sizes(const snn_network_t *net, uint32_t *n_neurons, uint32_t *n_cells, uint32_t *post_begin,
@@ -322,6 +332,7 @@ int snn_set_graph_csr(snn_network_t *net, const uint64_t *row_ptr, const uint32_
     net->sell_entries = entries;
     net->edge_slot_host.swap(edge_slot);
     net->counts_dirty = true;
+    halo_needs_from_rows(net, pre_index, nnz);      // the new rows decide what is read from the other shards
     return SNN_OK;
 }
 
@@ -346,6 +357,7 @@ int snn_set_synapses(snn_network_t *net, int electrical_synapse, int chemical_sy
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
     net->electrical = electrical_synapse ? 1 : 0;
     net->chemical = chemical_synapse ? 1 : 0;
+    net->x_dirty = true;                 // which planes travel between shards follows the synapse kinds
     return SNN_OK;
 }
 
@@ -376,7 +388,7 @@ int snn_set_bcm(snn_network_t *net, uint32_t id, float decay, float average_scal
     if (!l || l->spike_train) return fail(SNN_ERR_BAD_ARG, "plasticity belongs to neuron lattices");
     if (net->model != SNN_MODEL_BCM_IZHIKEVICH)
         return fail(SNN_ERR_BAD_STATE, "the BCM rule needs neurons with BCMActivity (SNN_MODEL_BCM_IZHIKEVICH)");
-    if (net->xl.n_shards != 1) return fail(SNN_ERR_BAD_STATE, "the BCM rule is not available on shard handles (activities are not exchanged)");
+    if (net->sharded) return fail(SNN_ERR_BAD_STATE, "the BCM rule is not available on shard handles (activities are not exchanged)");
     HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
     float *s = &net->stdp_host[(size_t)l->slot * PL_STRIDE];
     s[4] = dt; s[5] = 1.0f; s[6] = decay; s[7] = average_scalar;
@@ -591,7 +603,7 @@ int snn_set_graph_history(snn_network_t *net, uint32_t id, int enable)
     if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
     const LatticeInfo *l = find_lattice(net, id);
     if (!l || l->spike_train) return fail(SNN_ERR_BAD_ARG, "graph histories belong to neuron lattices");
-    if (net->csr || net->xl.n_shards != 1) return fail(SNN_ERR_BAD_STATE, "graph histories need a dense, unsharded handle");
+    if (net->csr || net->sharded) return fail(SNN_ERR_BAD_STATE, "graph histories need a dense, unsharded handle");
     HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
     TRY(end_run(net));
     if ((enable != 0) != (net->want_whist[l->slot] != 0)) { net->hist_steps = 0; net->hist_tick = 0; }
@@ -703,7 +715,7 @@ int snn_run(snn_network_t *net, uint64_t iterations)
 {
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
     if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
-    if (net->xl.n_shards > 1) return fail(SNN_ERR_BAD_STATE, "sharded handles are stepped with snn_step_begin/end");
+    if (net->n_shards > 1) return fail(SNN_ERR_BAD_STATE, "sharded handles are stepped with snn_step_begin/end or snn_run_sharded");
     if (iterations == 0 || net->n_tot == 0) return SNN_OK;          // gpu_lattices/mod.rs:1089-1091, 3196-3203
     if (!net->electrical && !net->chemical) return SNN_OK;           // neuron/mod.rs:1217, 2672
     HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
@@ -740,6 +752,7 @@ int snn_step_begin(snn_network_t *net)
     HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
     TRY(begin_run(net, 1));
     if (net->nn) TRY(step_begin(net));
+    TRY(launch_exchange_pack(net));
     if (!net->external_stream) HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
     return SNN_OK;
 }
@@ -756,14 +769,227 @@ int snn_step_end(snn_network_t *net)
     return SNN_OK;
 }
 
-int snn_exchange_buffer(snn_network_t *net, void **device_ptr, uint32_t *words_per_neuron, uint32_t *n_padded)
+int snn_exchange_plan_get(snn_network_t *net, snn_exchange_plan *plan)
+{
+    if (!net || !plan) return fail(SNN_ERR_BAD_ARG, "null argument");
+    if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
+    if (!net->sharded) return fail(SNN_ERR_BAD_STATE, "not a shard handle (snn_network_finalize_shard)");
+    HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
+    TRY(ensure_exchange_plan(net));
+    *plan = snn_exchange_plan{};
+    plan->mode = net->x_mode;
+    plan->n_shards = net->n_shards; plan->shard_index = net->shard_index; plan->shard_stride = net->shard_stride;
+    plan->planes = net->x_planes;
+    for (uint32_t s = 0; s < 4; ++s) plan->plane_id[s] = s < net->x_planes ? net->x_plane_id[s] : 0;
+    if (net->x_mode == SNN_EXCHANGE_ALLGATHER) {
+        plan->recv = net->wire;
+        plan->send = net->wire + (size_t)net->shard_index * net->x_block_words;
+        plan->send_words = net->x_block_words;
+        plan->recv_words = net->x_block_words * net->n_shards;
+    } else {
+        plan->send = net->halo_send_buf;
+        plan->recv = net->halo_recv_buf;
+        for (uint32_t p = 0; p < net->n_shards; ++p) {
+            plan->send_words += net->x_send_words[p];
+            plan->recv_words += net->x_recv_words[p];
+        }
+    }
+    return SNN_OK;
+}
+
+int snn_exchange_peers(snn_network_t *net, uint64_t *send_offset, uint64_t *send_words, uint64_t *recv_offset,
+                       uint64_t *recv_words)
 {
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
-    if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
-    if (device_ptr) *device_ptr = net->xbuf;
-    if (words_per_neuron) *words_per_neuron = NUM_PLANES;
-    if (n_padded) *n_padded = net->xl.stride * net->xl.n_shards;
+    if (!net->finalized || !net->sharded) return fail(SNN_ERR_BAD_STATE, "not a finalized shard handle");
+    HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
+    TRY(ensure_exchange_plan(net));
+    for (uint32_t p = 0; p < net->n_shards; ++p) {
+        if (send_offset) send_offset[p] = net->x_send_off[p];
+        if (send_words) send_words[p] = net->x_send_words[p];
+        if (recv_offset) recv_offset[p] = net->x_recv_off[p];
+        if (recv_words) recv_words[p] = net->x_recv_words[p];
+    }
     return SNN_OK;
+}
+
+int snn_halo_needs(snn_network_t *net, uint32_t peer, uint32_t *indices, uint32_t capacity, uint32_t *count)
+{
+    if (!net || !count) return fail(SNN_ERR_BAD_ARG, "null argument");
+    if (!net->finalized || !net->sharded || !net->csr) return fail(SNN_ERR_BAD_STATE, "halo plans belong to finalized CSR shard handles");
+    if (peer >= net->n_shards) return fail(SNN_ERR_BAD_ARG, "peer out of range");
+    if (net->halo_need.size() != net->n_shards) halo_reset(net);
+    const auto &l = net->halo_need[peer];
+    *count = (uint32_t)l.size();
+    if (indices && capacity >= l.size() && !l.empty()) std::memcpy(indices, l.data(), l.size() * 4);
+    return SNN_OK;
+}
+
+int snn_halo_set_sends(snn_network_t *net, uint32_t peer, const uint32_t *indices, uint32_t count)
+{
+    if (!net || (count && !indices)) return fail(SNN_ERR_BAD_ARG, "null argument");
+    if (!net->finalized || !net->sharded || !net->csr) return fail(SNN_ERR_BAD_STATE, "halo plans belong to finalized CSR shard handles");
+    if (peer >= net->n_shards || peer == net->shard_index) return fail(SNN_ERR_BAD_ARG, "peer must be another shard");
+    if (net->halo_send.size() != net->n_shards) halo_reset(net);
+    for (uint32_t i = 0; i < count; ++i)
+        if (indices[i] < net->q0 || indices[i] >= net->q1)
+            return fail(SNN_ERR_DIM_MISMATCH, "a send list may only name neurons this handle owns");
+    TRY(end_run(net));
+    net->halo_send[peer].assign(indices, indices + count);
+    net->halo_committed = false;
+    net->x_dirty = true;
+    return SNN_OK;
+}
+
+int snn_halo_commit(snn_network_t *net)
+{
+    if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
+    if (!net->finalized || !net->sharded || !net->csr) return fail(SNN_ERR_BAD_STATE, "halo plans belong to finalized CSR shard handles");
+    if (net->halo_need.size() != net->n_shards) halo_reset(net);
+    HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
+    TRY(end_run(net));
+    net->halo_committed = true;
+    net->x_dirty = true;
+    return ensure_exchange_plan(net);
+}
+
+int snn_comm_unique_id(void *id_128_bytes)
+{
+    if (!id_128_bytes) return fail(SNN_ERR_BAD_ARG, "null argument");
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    RCCL_LIB(R);
+    ncclUniqueId id;
+    RCCL_TRY(R, R->GetUniqueId(&id));
+    std::memcpy(id_128_bytes, &id, sizeof id);
+    return SNN_OK;
+}
+
+int snn_comm_init_rank(const void *id_128_bytes, int world_size, int rank, int device, void **nccl_comm)
+{
+    if (!id_128_bytes || !nccl_comm) return fail(SNN_ERR_BAD_ARG, "null argument");
+    if (world_size < 1 || rank < 0 || rank >= world_size) return fail(SNN_ERR_BAD_ARG, "rank must be in [0, world_size)");
+    RCCL_LIB(R);
+    HIP_TRY(hipSetDevice(device), SNN_ERR_GET_DEVICE);
+    ncclUniqueId id;
+    std::memcpy(&id, id_128_bytes, sizeof id);
+    ncclComm_t comm = nullptr;
+    RCCL_TRY(R, R->CommInitRank(&comm, world_size, id, rank));
+    *nccl_comm = comm;
+    return SNN_OK;
+}
+
+int snn_comm_destroy(void *nccl_comm)
+{
+    if (!nccl_comm) return SNN_OK;
+    RCCL_LIB(R);
+    RCCL_TRY(R, R->CommDestroy(static_cast<ncclComm_t>(nccl_comm)));
+    return SNN_OK;
+}
+
+int snn_comm_exchange_halo_lists(snn_network_t *net, void *nccl_comm)
+{
+    if (!net || !nccl_comm) return fail(SNN_ERR_BAD_ARG, "null argument");
+    if (!net->finalized || !net->sharded || !net->csr) return fail(SNN_ERR_BAD_STATE, "halo plans belong to finalized CSR shard handles");
+    RCCL_LIB(R);
+    ncclComm_t comm = static_cast<ncclComm_t>(nccl_comm);
+    HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
+    TRY(comm_geometry(R, net, comm));
+    TRY(end_run(net));
+    if (net->halo_need.size() != net->n_shards) halo_reset(net);
+    const uint32_t G = net->n_shards, me = net->shard_index;
+    // (1) counts: row `me` of a G x G matrix, all-gathered; (2) the lists themselves, grouped send / recv
+    std::vector<uint32_t> counts((size_t)G * G, 0);
+    for (uint32_t p = 0; p < G; ++p) counts[(size_t)me * G + p] = (uint32_t)net->halo_need[p].size();
+    uint32_t *d_counts = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_counts), counts.size() * 4), SNN_ERR_BUFFER_CREATE);
+    int rc = SNN_OK;
+    uint32_t *d_need = nullptr, *d_send = nullptr;
+    auto cleanup = [&]() { (void)hipFree(d_counts); if (d_need) (void)hipFree(d_need); if (d_send) (void)hipFree(d_send); };
+#define HALO_STEP(expr) do { rc = (expr); if (rc) { cleanup(); return rc; } } while (0)
+    auto hip_ok = [&](hipError_t e, int code, const char *what) { return e == hipSuccess ? SNN_OK : fail(code, std::string(what) + ": " + hipGetErrorString(e)); };
+    auto nccl_ok = [&](ncclResult_t r, const char *what) { return r == ncclSuccess ? SNN_OK : fail(SNN_ERR_QUEUE, std::string(what) + ": " + R->GetErrorString(r)); };
+    HALO_STEP(hip_ok(hipMemcpy(d_counts, counts.data(), counts.size() * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE, "counts upload"));
+    HALO_STEP(nccl_ok(R->AllGather(d_counts + (size_t)me * G, d_counts, G, ncclUint32, comm, net->stream), "ncclAllGather(counts)"));
+    HALO_STEP(hip_ok(hipStreamSynchronize(net->stream), SNN_ERR_WAIT, "counts wait"));
+    HALO_STEP(hip_ok(hipMemcpy(counts.data(), d_counts, counts.size() * 4, hipMemcpyDeviceToHost), SNN_ERR_BUFFER_READ, "counts download"));
+    std::vector<uint64_t> need_off(G + 1, 0), send_off(G + 1, 0);
+    for (uint32_t p = 0; p < G; ++p) {
+        need_off[p + 1] = need_off[p] + counts[(size_t)me * G + p];        // what I ask of p
+        send_off[p + 1] = send_off[p] + counts[(size_t)p * G + me];        // what p asks of me
+    }
+    std::vector<uint32_t> need_flat(need_off[G]), send_flat(send_off[G]);
+    for (uint32_t p = 0; p < G; ++p) std::copy(net->halo_need[p].begin(), net->halo_need[p].end(), need_flat.begin() + need_off[p]);
+    HALO_STEP(hip_ok(hipMalloc(reinterpret_cast<void **>(&d_need), std::max<size_t>(need_flat.size() * 4, 256)), SNN_ERR_BUFFER_CREATE, "hipMalloc"));
+    HALO_STEP(hip_ok(hipMalloc(reinterpret_cast<void **>(&d_send), std::max<size_t>(send_flat.size() * 4, 256)), SNN_ERR_BUFFER_CREATE, "hipMalloc"));
+    if (!need_flat.empty())
+        HALO_STEP(hip_ok(hipMemcpy(d_need, need_flat.data(), need_flat.size() * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE, "lists upload"));
+    HALO_STEP(nccl_ok(R->GroupStart(), "ncclGroupStart"));
+    for (uint32_t p = 0; p < G; ++p) {
+        if (p == me) continue;
+        if (need_off[p + 1] > need_off[p])
+            HALO_STEP(nccl_ok(R->Send(d_need + need_off[p], need_off[p + 1] - need_off[p], ncclUint32, (int)p, comm, net->stream), "ncclSend(list)"));
+        if (send_off[p + 1] > send_off[p])
+            HALO_STEP(nccl_ok(R->Recv(d_send + send_off[p], send_off[p + 1] - send_off[p], ncclUint32, (int)p, comm, net->stream), "ncclRecv(list)"));
+    }
+    HALO_STEP(nccl_ok(R->GroupEnd(), "ncclGroupEnd"));
+    HALO_STEP(hip_ok(hipStreamSynchronize(net->stream), SNN_ERR_WAIT, "lists wait"));
+    if (!send_flat.empty())
+        HALO_STEP(hip_ok(hipMemcpy(send_flat.data(), d_send, send_flat.size() * 4, hipMemcpyDeviceToHost), SNN_ERR_BUFFER_READ, "lists download"));
+#undef HALO_STEP
+    cleanup();
+    for (uint32_t p = 0; p < G; ++p) {
+        if (p == me) continue;
+        TRY(snn_halo_set_sends(net, p, send_flat.data() + send_off[p], (uint32_t)(send_off[p + 1] - send_off[p])));
+    }
+    return snn_halo_commit(net);
+}
+
+int snn_exchange(snn_network_t *net, void *nccl_comm)
+{
+    if (!net || !nccl_comm) return fail(SNN_ERR_BAD_ARG, "null argument");
+    if (!net->finalized || !net->sharded) return fail(SNN_ERR_BAD_STATE, "not a finalized shard handle");
+    RCCL_LIB(R);
+    HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
+    TRY(ensure_exchange_plan(net));
+    TRY(comm_geometry(R, net, static_cast<ncclComm_t>(nccl_comm)));
+    TRY(enqueue_exchange(R, net, static_cast<ncclComm_t>(nccl_comm), net->stream));
+    if (!net->external_stream) HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
+    return SNN_OK;
+}
+
+int snn_run_sharded(snn_network_t *net, void *nccl_comm, uint64_t iterations)
+{
+    if (!net || !nccl_comm) return fail(SNN_ERR_BAD_ARG, "null argument");
+    if (!net->finalized || !net->sharded) return fail(SNN_ERR_BAD_STATE, "not a finalized shard handle");
+    if (iterations == 0 || net->n_tot == 0) return SNN_OK;
+    if (!net->electrical && !net->chemical) return SNN_OK;
+    RCCL_LIB(R);
+    ncclComm_t comm = static_cast<ncclComm_t>(nccl_comm);
+    HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
+    TRY(comm_geometry(R, net, comm));
+    if (net->csr && net->n_shards > 1 && !net->halo_committed && net->csr_ptr) TRY(snn_comm_exchange_halo_lists(net, nccl_comm));
+    TRY(begin_run(net, iterations));
+    TRY(ensure_comm_objects(net));
+    // The own-rows part of step t + 1's input pass does not read what the exchange of step t delivers: it is enqueued
+    // before the compute stream waits for the collective (dense handles, no weight updates pending in step_end).
+    const bool split = !net->csr && !net->any_plasticity && !net->any_modulation && net->n_shards > 1;
+    for (uint64_t it = 0; it < iterations; ++it) {
+        if (net->nn) TRY(step_begin(net));
+        TRY(launch_exchange_pack(net));
+        HIP_TRY(hipEventRecord(net->ev_packed, net->stream), SNN_ERR_QUEUE);
+        HIP_TRY(hipStreamWaitEvent(net->comm_stream, net->ev_packed, 0), SNN_ERR_QUEUE);
+        TRY(enqueue_exchange(R, net, comm, net->comm_stream));
+        HIP_TRY(hipEventRecord(net->ev_exchanged, net->comm_stream), SNN_ERR_QUEUE);
+        if (split && it + 1 < iterations && net->nn && !net->local_inputs_done) {
+            // step_end below advances the clock and the spike trains; the LOCAL chunks read neither
+            TRY(launch_inputs(net, INPUTS_LOCAL));
+            net->local_inputs_done = true;
+        }
+        HIP_TRY(hipStreamWaitEvent(net->stream, net->ev_exchanged, 0), SNN_ERR_QUEUE);
+        TRY(step_end(net));
+        if (net->profile && net->ev_used >= 8192) TRY(collect_profile(net));
+    }
+    return end_run(net);
 }
 
 int snn_set_stream(snn_network_t *net, void *hip_stream)

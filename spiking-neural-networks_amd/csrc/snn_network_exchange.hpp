@@ -1,0 +1,252 @@
+// Exchange plan of a shard handle, pack / unpack launches, the halo lists of sparse handles, and the in-library
+// collective (RCCL called directly: all-gather of whole slots or grouped send/recv of halo segments) with the
+// sharded step loop snn_run_sharded.  Kernels and wire format: snn_kernels_exchange.hpp.
+// Included by snn_network.hip only (one translation unit).
+#pragma once
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include "snn_network_step.hpp"
+
+namespace {
+
+inline uint64_t segment_words(uint32_t planes, uint64_t count) { return (uint64_t)planes * count + (count + 31) / 32; }
+
+template <typename T>
+int upload_table(T **dev, const std::vector<T> &host)
+{
+    if (*dev) { (void)hipFree(*dev); *dev = nullptr; }
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(dev), std::max<size_t>(host.size() * sizeof(T), 256)), SNN_ERR_BUFFER_CREATE);
+    if (!host.empty())
+        HIP_TRY(hipMemcpy(*dev, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
+    return SNN_OK;
+}
+
+// (Re)builds the plan: planes on the wire, per-peer segments, device tables.  which = 0 pack, 1 unpack.
+int ensure_exchange_plan(snn_network *net)
+{
+    if (!net->x_dirty) return SNN_OK;
+    if (!net->sharded) { net->x_dirty = false; return SNN_OK; }
+    HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);        // nothing in flight reads the old tables
+    // planes: voltage for gap junctions; t of the types some NEURON releases for chemical synapses
+    net->x_planes = 0;
+    if (net->electrical) net->x_plane_id[net->x_planes++] = PLANE_V;
+    if (net->chemical) {
+        uint32_t mask = 0;
+        for (const auto &kv : net->lattice_nt_mask) {
+            const LatticeInfo *li = find_lattice(net, kv.first);
+            if (li && !li->spike_train) mask |= kv.second;
+        }
+        for (uint32_t k = 0; k < K_TYPES; ++k)
+            if (mask >> k & 1u) net->x_plane_id[net->x_planes++] = PLANE_T0 + k;
+    }
+    const uint32_t G = net->n_shards, me = net->shard_index, P = net->x_planes;
+    net->x_send_off.assign(G, 0); net->x_send_words.assign(G, 0);
+    net->x_recv_off.assign(G, 0); net->x_recv_words.assign(G, 0);
+    std::vector<uint32_t> cnt[2], first[2];
+    std::vector<uint64_t> off[2], loff[2];
+    net->x_mode = (net->csr && net->halo_committed) ? SNN_EXCHANGE_HALO : SNN_EXCHANGE_ALLGATHER;
+    if (net->x_mode == SNN_EXCHANGE_ALLGATHER) {
+        net->x_block_words = segment_words(P, net->shard_stride);
+        for (uint32_t p = 0; p < G; ++p) {
+            net->x_send_off[p] = 0; net->x_send_words[p] = net->x_block_words;
+            net->x_recv_off[p] = (uint64_t)p * net->x_block_words; net->x_recv_words[p] = net->x_block_words;
+            cnt[1].push_back(net->shard_stride); off[1].push_back((uint64_t)p * net->x_block_words);
+            first[1].push_back(p * net->shard_stride); loff[1].push_back(0);
+        }
+        cnt[0].push_back(net->shard_stride); off[0].push_back((uint64_t)me * net->x_block_words);
+        first[0].push_back(me * net->shard_stride); loff[0].push_back(0);
+    } else {
+        std::vector<uint32_t> send_idx, recv_idx;
+        uint64_t so = 0, ro = 0;
+        for (uint32_t p = 0; p < G; ++p) {
+            const auto &sl = net->halo_send[p];
+            const auto &nl = net->halo_need[p];
+            net->x_send_off[p] = so; net->x_send_words[p] = sl.empty() ? 0 : segment_words(P, sl.size());
+            net->x_recv_off[p] = ro; net->x_recv_words[p] = nl.empty() ? 0 : segment_words(P, nl.size());
+            if (!sl.empty()) {
+                cnt[0].push_back((uint32_t)sl.size()); off[0].push_back(so); first[0].push_back(0); loff[0].push_back(send_idx.size());
+                send_idx.insert(send_idx.end(), sl.begin(), sl.end());
+            }
+            if (!nl.empty()) {
+                cnt[1].push_back((uint32_t)nl.size()); off[1].push_back(ro); first[1].push_back(0); loff[1].push_back(recv_idx.size());
+                recv_idx.insert(recv_idx.end(), nl.begin(), nl.end());
+            }
+            so += net->x_send_words[p];
+            ro += net->x_recv_words[p];
+        }
+        TRY(upload_table(&net->halo_send_idx, send_idx));
+        TRY(upload_table(&net->halo_recv_idx, recv_idx));
+        for (uint32_t **b : {&net->halo_send_buf, &net->halo_recv_buf})
+            if (*b) { (void)hipFree(*b); *b = nullptr; }
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&net->halo_send_buf), std::max<uint64_t>(so * 4, 256)), SNN_ERR_BUFFER_CREATE);
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&net->halo_recv_buf), std::max<uint64_t>(ro * 4, 256)), SNN_ERR_BUFFER_CREATE);
+        HIP_TRY(hipMemset(net->halo_send_buf, 0, std::max<uint64_t>(so * 4, 256)), SNN_ERR_BUFFER_WRITE);
+        HIP_TRY(hipMemset(net->halo_recv_buf, 0, std::max<uint64_t>(ro * 4, 256)), SNN_ERR_BUFFER_WRITE);
+    }
+    for (int w = 0; w < 2; ++w) {
+        net->seg_n[w] = (uint32_t)cnt[w].size();
+        net->seg_max[w] = 0;
+        for (uint32_t c : cnt[w]) net->seg_max[w] = std::max(net->seg_max[w], c);
+        TRY(upload_table(&net->seg_count_dev[w], cnt[w]));
+        TRY(upload_table(&net->seg_offset_dev[w], off[w]));
+        TRY(upload_table(&net->seg_first_dev[w], first[w]));
+        TRY(upload_table(&net->seg_loff_dev[w], loff[w]));
+    }
+    net->x_dirty = false;
+    return SNN_OK;
+}
+
+WireArgs wire_args(snn_network *net, int which)
+{
+    WireArgs a{};
+    a.xbuf = net->xbuf; a.xl = net->xl; a.n_neurons = net->nn; a.planes = net->x_planes;
+    for (int s = 0; s < WIRE_MAX_PLANES; ++s) a.plane_id[s] = net->x_plane_id[s];
+    const bool halo = net->x_mode == SNN_EXCHANGE_HALO;
+    a.buf = halo ? (which == 0 ? net->halo_send_buf : net->halo_recv_buf) : net->wire;
+    a.seg_count = net->seg_count_dev[which]; a.seg_offset = net->seg_offset_dev[which];
+    a.seg_first = net->seg_first_dev[which]; a.seg_list_offset = net->seg_loff_dev[which];
+    a.list = halo ? (which == 0 ? net->halo_send_idx : net->halo_recv_idx) : nullptr;
+    a.skip = (!halo && which == 1) ? net->shard_index : 0xFFFFFFFFu;
+    a.last_firing_time = net->na.last_firing_time;
+    a.clock = net->clock;
+    return a;
+}
+
+// outgoing segments of the step just computed (after the neuron update)
+int launch_exchange_pack(snn_network *net)
+{
+    if (!net->sharded || net->seg_n[0] == 0 || net->seg_max[0] == 0) return SNN_OK;
+    hipLaunchKernelGGL(k_exchange_pack, dim3((net->seg_max[0] + 255) / 256, net->seg_n[0]), dim3(256), 0, net->stream,
+                       wire_args(net, 0));
+    HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+    return SNN_OK;
+}
+
+// incoming segments -> mirror + last_firing_time of the neurons owned elsewhere
+int launch_exchange_unpack(snn_network *net)
+{
+    if (!net->sharded || net->seg_n[1] == 0 || net->seg_max[1] == 0 || net->nn == 0) return SNN_OK;
+    if (net->x_mode == SNN_EXCHANGE_ALLGATHER && net->n_shards == 1) return SNN_OK;
+    hipLaunchKernelGGL(k_exchange_unpack, dim3((net->seg_max[1] + 255) / 256, net->seg_n[1]), dim3(256), 0, net->stream,
+                       wire_args(net, 1));
+    HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+    return SNN_OK;
+}
+
+// ---- halo need lists of a sparse shard handle -------------------------------------------------------------------
+void halo_reset(snn_network *net)
+{
+    net->halo_need.assign(net->n_shards, {});
+    net->halo_send.assign(net->n_shards, {});
+    net->halo_committed = false;
+    net->x_dirty = true;
+}
+
+// per peer: the distinct neurons of that peer among the presynaptic indices of the local rows (ascending)
+void halo_needs_from_rows(snn_network *net, const uint32_t *pre_index, uint64_t nnz)
+{
+    halo_reset(net);
+    if (!net->sharded || net->n_shards < 2) return;
+    std::vector<uint8_t> seen(net->nn, 0);
+    for (uint64_t e = 0; e < nnz; ++e) {
+        const uint32_t p = pre_index[e];
+        if (p < net->nn && (p < net->q0 || p >= net->q1)) seen[p] = 1;
+    }
+    for (uint32_t p = 0; p < net->nn; ++p)
+        if (seen[p]) net->halo_need[p / net->shard_stride].push_back(p);
+}
+
+// ---- RCCL, resolved at first use ---------------------------------------------------------------------------------
+struct Rccl {
+    void *lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+Rccl *rccl()
+{
+    static Rccl r;
+    static bool tried = false;
+    if (tried) return r.lib ? &r : nullptr;
+    tried = true;
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (r.lib) break;
+    }
+    if (!r.lib) return nullptr;
+    bool ok = true;
+    auto sym = [&](const char *n) { void *p = dlsym(r.lib, n); ok = ok && p; return p; };
+    r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
+    r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
+    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+    r.CommCount = reinterpret_cast<decltype(r.CommCount)>(sym("ncclCommCount"));
+    r.CommUserRank = reinterpret_cast<decltype(r.CommUserRank)>(sym("ncclCommUserRank"));
+    r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
+    r.Send = reinterpret_cast<decltype(r.Send)>(sym("ncclSend"));
+    r.Recv = reinterpret_cast<decltype(r.Recv)>(sym("ncclRecv"));
+    r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
+    r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
+    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+    if (!ok) { dlclose(r.lib); r.lib = nullptr; return nullptr; }
+    return &r;
+}
+
+#define RCCL_LIB(R)                                                                               \
+    Rccl *R = rccl();                                                                              \
+    if (!R) return fail(SNN_ERR_BAD_STATE, std::string("librccl.so.1 could not be loaded: ") + (dlerror() ? dlerror() : "symbols missing"))
+#define RCCL_TRY(R, expr)                                                                         \
+    do {                                                                                           \
+        ncclResult_t r_ = (expr);                                                                  \
+        if (r_ != ncclSuccess) return fail(SNN_ERR_QUEUE, std::string(#expr) + ": " + (R)->GetErrorString(r_)); \
+    } while (0)
+
+int comm_geometry(Rccl *R, snn_network *net, ncclComm_t comm)
+{
+    int world = 0, rank = -1;
+    RCCL_TRY(R, R->CommCount(comm, &world));
+    RCCL_TRY(R, R->CommUserRank(comm, &rank));
+    if (!net->sharded || (uint32_t)world != net->n_shards || (uint32_t)rank != net->shard_index)
+        return fail(SNN_ERR_BAD_STATE, "communicator size / rank do not match the handle's shard geometry");
+    return SNN_OK;
+}
+
+// the collective of the packed segments on `stream`
+int enqueue_exchange(Rccl *R, snn_network *net, ncclComm_t comm, hipStream_t stream)
+{
+    if (net->x_mode == SNN_EXCHANGE_ALLGATHER) {
+        if (net->x_block_words == 0) return SNN_OK;
+        RCCL_TRY(R, R->AllGather(net->wire + (size_t)net->shard_index * net->x_block_words, net->wire, net->x_block_words,
+                                 ncclUint32, comm, stream));
+        return SNN_OK;
+    }
+    RCCL_TRY(R, R->GroupStart());
+    for (uint32_t p = 0; p < net->n_shards; ++p) {
+        if (p == net->shard_index) continue;
+        if (net->x_send_words[p])
+            RCCL_TRY(R, R->Send(net->halo_send_buf + net->x_send_off[p], net->x_send_words[p], ncclUint32, (int)p, comm, stream));
+        if (net->x_recv_words[p])
+            RCCL_TRY(R, R->Recv(net->halo_recv_buf + net->x_recv_off[p], net->x_recv_words[p], ncclUint32, (int)p, comm, stream));
+    }
+    RCCL_TRY(R, R->GroupEnd());
+    return SNN_OK;
+}
+
+int ensure_comm_objects(snn_network *net)
+{
+    if (!net->comm_stream) HIP_TRY(hipStreamCreateWithFlags(&net->comm_stream, hipStreamNonBlocking), SNN_ERR_QUEUE);
+    if (!net->ev_packed) HIP_TRY(hipEventCreateWithFlags(&net->ev_packed, hipEventDisableTiming), SNN_ERR_QUEUE);
+    if (!net->ev_exchanged) HIP_TRY(hipEventCreateWithFlags(&net->ev_exchanged, hipEventDisableTiming), SNN_ERR_QUEUE);
+    return SNN_OK;
+}
+
+} // namespace

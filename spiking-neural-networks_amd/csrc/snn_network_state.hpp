@@ -17,6 +17,7 @@
 
 #include "../../include/snn_amd.h"
 #include "snn_kernels_csr.hpp"
+#include "snn_kernels_exchange.hpp"
 #include "snn_kernels_inputs.hpp"
 #include "snn_kernels_misc.hpp"
 #include "snn_kernels_resident.hpp"
@@ -101,7 +102,30 @@ struct snn_network {
 
     uint32_t nn = 0, nc = 0, n_tot = 0, n_pad = 0, c_pad = 0;
     uint32_t q0 = 0, q1 = 0, n_loc = 0, ld = 0, n_chunks = 0;
-    XLayout xl{0, 1};
+    XLayout xl{0};
+    // post-population sharding (snn_network_finalize_shard): this handle owns neurons [q0, q1) = slot shard_index of
+    // n_shards equal slots of shard_stride neurons
+    bool sharded = false;
+    uint32_t n_shards = 1, shard_index = 0, shard_stride = 0;
+    // ---- exchange plan (snn_kernels_exchange.hpp), rebuilt by ensure_exchange_plan when x_dirty ----
+    bool x_dirty = true;
+    int x_mode = SNN_EXCHANGE_ALLGATHER;
+    uint32_t x_planes = 0, x_plane_id[WIRE_MAX_PLANES] = {0, 0, 0, 0};
+    uint64_t x_block_words = 0;                 // all-gather: words per shard slot
+    uint32_t *wire = nullptr;                   // all-gather: [n_shards][block words at the largest plan]
+    // halo (sparse handles): per peer, the neurons of that peer this handle's rows read (need) and the own neurons
+    // that peer reads (send); buffers and segment tables sized by the plan
+    std::vector<std::vector<uint32_t>> halo_need, halo_send;
+    bool halo_committed = false;
+    uint32_t *halo_send_buf = nullptr, *halo_recv_buf = nullptr, *halo_send_idx = nullptr, *halo_recv_idx = nullptr;
+    std::vector<uint64_t> x_send_off, x_send_words, x_recv_off, x_recv_words;     // per peer, in words
+    // device segment tables of the pack / unpack launches: {count, offset, first, list offset} per segment
+    uint32_t *seg_count_dev[2] = {nullptr, nullptr}, *seg_first_dev[2] = {nullptr, nullptr};
+    uint64_t *seg_offset_dev[2] = {nullptr, nullptr}, *seg_loff_dev[2] = {nullptr, nullptr};
+    uint32_t seg_n[2] = {0, 0}, seg_max[2] = {0, 0};
+    // in-library collective (snn_run_sharded): RCCL is ordered on its own stream against the compute stream
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_packed = nullptr, ev_exchanged = nullptr;
 
     std::vector<void *> allocs;
     // sparse form (CSR by local postsynaptic row); the arrays are replaced by every snn_set_graph_csr
@@ -267,9 +291,14 @@ int build_state(snn_network *net)
     auto &CA = net->cell_attrs;
 
     // exchanged planes
-    TRY(dev_alloc_t(net, &net->xbuf, (size_t)net->xl.n_shards * NUM_PLANES * net->xl.stride));
-    HIP_TRY(hipMemsetAsync(net->xbuf, 0, (size_t)net->xl.n_shards * NUM_PLANES * net->xl.stride * 4, net->stream),
-            SNN_ERR_BUFFER_WRITE);
+    TRY(dev_alloc_t(net, &net->xbuf, (size_t)NUM_PLANES * net->xl.stride));
+    HIP_TRY(hipMemsetAsync(net->xbuf, 0, (size_t)NUM_PLANES * net->xl.stride * 4, net->stream), SNN_ERR_BUFFER_WRITE);
+    if (net->sharded) {
+        // all-gather wire buffer at its largest plan: 4 planes + the spike bitmap per slot
+        const size_t words = (size_t)net->n_shards * ((size_t)WIRE_MAX_PLANES * net->shard_stride + net->shard_stride / 32);
+        TRY(dev_alloc_t(net, &net->wire, words));
+        HIP_TRY(hipMemsetAsync(net->wire, 0, words * 4, net->stream), SNN_ERR_BUFFER_WRITE);
+    }
     n.xbuf = net->xbuf;
     n.xl = net->xl;
     n.n_pad = np;
@@ -286,11 +315,7 @@ int build_state(snn_network *net)
     const bool alif = net->model == SNN_MODEL_ADAPTIVE_LIF, aelif = net->model == SNN_MODEL_ADAPTIVE_EXP_LIF;
     const bool adp = alif || aelif, lizh = net->model == SNN_MODEL_LEAKY_IZHIKEVICH;
     const float v0 = cust ? custom::DEFAULT_VOLTAGE : ((lif || qif || slif || adp) ? -75.0f : -65.0f);
-    {
-        // initial voltage into plane V of every shard slot
-        for (uint32_t s = 0; s < net->xl.n_shards; ++s)
-            TRY(fill_f32(net, net->xbuf + ((size_t)s * NUM_PLANES + PLANE_V) * net->xl.stride, net->xl.stride, v0));
-    }
+    TRY(fill_f32(net, net->xbuf + (size_t)PLANE_V * net->xl.stride, net->xl.stride, v0));    // initial voltage
     TRY(neuron_f32(net, &n.gap_conductance, "gap_conductance", cust ? custom::DEFAULT_GAP : (slif ? 10.0f : 7.0f)));
     TRY(neuron_f32(net, &n.dt, "dt", cust ? custom::DEFAULT_DT : (net->model == SNN_MODEL_HODGKIN_HUXLEY ? 0.01f : 0.1f)));
     TRY(neuron_f32(net, &n.c_m, "c_m", cust ? custom::DEFAULT_C_M : (net->model == SNN_MODEL_HODGKIN_HUXLEY ? 1.0f : 100.0f)));
@@ -599,18 +624,9 @@ int end_run(snn_network *net);
 // copy `count` 32-bit words between host and plane `plane` for global indices [first, first+count)
 int xplane_copy(snn_network *net, int plane, uint32_t first, uint32_t count, void *host, bool to_device)
 {
-    uint32_t done = 0;
-    while (done < count) {
-        const uint32_t g = first + done;
-        const uint32_t shard = g / net->xl.stride;
-        const uint32_t in_shard = g - shard * net->xl.stride;
-        const uint32_t seg = std::min(count - done, net->xl.stride - in_shard);
-        float *dev = net->xbuf + net->xl.at(g, plane);
-        char *h = static_cast<char *>(host) + (size_t)done * 4;
-        if (to_device) HIP_TRY(hipMemcpy(dev, h, (size_t)seg * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
-        else HIP_TRY(hipMemcpy(h, dev, (size_t)seg * 4, hipMemcpyDeviceToHost), SNN_ERR_BUFFER_READ);
-        done += seg;
-    }
+    float *dev = net->xbuf + net->xl.at(first, plane);
+    if (to_device) HIP_TRY(hipMemcpy(dev, host, (size_t)count * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
+    else HIP_TRY(hipMemcpy(host, dev, (size_t)count * 4, hipMemcpyDeviceToHost), SNN_ERR_BUFFER_READ);
     return SNN_OK;
 }
 
@@ -680,6 +696,7 @@ int attr_io(snn_network *net, uint32_t id, const char *name, AttrType type, void
         uint32_t mask = 0;
         for (size_t i = 0; i < count; ++i) mask |= h[i] ? (1u << (i % K_TYPES)) : 0u;
         net->lattice_nt_mask[id] = mask;
+        net->x_dirty = true;                       // the planes on the wire follow the transmitter types in use
         net->any_nt_neurons = net->any_nt_cells = false;
         for (const auto &kv : net->lattice_has_nt) {
             const LatticeInfo *li = find_lattice(net, kv.first);

@@ -23,6 +23,9 @@ int launch_spike_trains(snn_network *net, int iterate, long long step_offset, lo
 
 enum InputsPart { INPUTS_ALL = 0, INPUTS_LOCAL = 1, INPUTS_REMOTE = 2 };
 int flush_rstdp(snn_network *net);
+// snn_network_exchange.hpp
+int ensure_exchange_plan(snn_network *net);
+int launch_exchange_unpack(snn_network *net);
 
 // chunks whose presynaptic rows all belong to this shard's own neurons
 void local_chunks(const snn_network *net, uint32_t *begin, uint32_t *count)
@@ -214,7 +217,7 @@ int launch_plasticity(snn_network *net)
 // sizes served by the one-launch small-lattice step (snn_kernels_resident.hpp)
 bool fused_step_possible(const snn_network *net)
 {
-    return !SNN_HAVE_CUSTOM_MODEL && net->fused_step && !net->csr && net->xl.n_shards == 1 && net->n_loc && net->n_tot &&
+    return !SNN_HAVE_CUSTOM_MODEL && net->fused_step && !net->csr && !net->sharded && net->n_loc && net->n_tot &&
            net->n_chunks <= RESIDENT_MAX_CHUNKS && (size_t)net->n_tot * net->ld * 4 <= ((size_t)64 << 20);
 }
 
@@ -340,7 +343,7 @@ bool fused_step_applies(const snn_network *net)
 // exchange buffer and to the other shadow (flipped by the caller after the launch).
 int fused_step_args(snn_network *net, InputsArgs &a, UpdateArgs &u)
 {
-    const size_t xelems = (size_t)net->xl.n_shards * NUM_PLANES * net->xl.stride;
+    const size_t xelems = (size_t)NUM_PLANES * net->xl.stride;
     if (!net->shadow[0]) {
         TRY(dev_alloc_t(net, &net->shadow[0], xelems));
         TRY(dev_alloc_t(net, &net->shadow[1], xelems));
@@ -439,7 +442,7 @@ int launch_step_resident(snn_network *net)
 // Unsharded sparse handles: row sums + neuron update in one launch (k_step_csr).
 bool fused_csr_step_applies(const snn_network *net)
 {
-    return !SNN_HAVE_CUSTOM_MODEL && net->fused_step && net->csr && net->csr_ptr && net->xl.n_shards == 1 &&
+    return !SNN_HAVE_CUSTOM_MODEL && net->fused_step && net->csr && net->csr_ptr && !net->sharded &&
            net->n_loc && !net->local_inputs_done;
 }
 
@@ -483,11 +486,7 @@ int step_begin(snn_network *net)
 // second half: remote last_firing_time, plasticity, histories, clock, spike trains (steps 3-6)
 int step_end(snn_network *net)
 {
-    if (net->xl.n_shards > 1 && net->nn) {
-        hipLaunchKernelGGL(k_stamp_remote, dim3((net->nn + 255) / 256), dim3(256), 0, net->stream,
-                           net->xbuf, net->xl, net->na.last_firing_time, net->nn, net->q0, net->n_loc, net->clock);
-        HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
-    }
+    TRY(launch_exchange_unpack(net));      // shard handles: the other ranks' state of this step, their last_firing_time
     TRY(launch_plasticity(net));
     TRY(launch_reward_modulation(net));
     if (net->any_whist && record_now(net)) {
@@ -558,6 +557,7 @@ int grow_history(snn_network *net, uint64_t extra)
 int begin_run(snn_network *net, uint64_t iterations)
 {
     TRY(ensure_counts(net));
+    TRY(ensure_exchange_plan(net));
     TRY(grow_history(net, iterations));
     if (net->run_active) return SNN_OK;
     if (net->nc) {

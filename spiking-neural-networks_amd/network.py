@@ -196,11 +196,47 @@ class DeviceNetwork:
     def step_begin_local(self):
         self._check(self._L.snn_step_begin_local(self._h))
 
-    def exchange_buffer(self):
-        """(device pointer, words per neuron, padded neuron count) of the all-gather buffer"""
-        p, w, n = C.c_void_p(), C.c_uint32(), C.c_uint32()
-        self._check(self._L.snn_exchange_buffer(self._h, C.byref(p), C.byref(w), C.byref(n)))
-        return p.value, w.value, n.value
+    def exchange_plan(self):
+        """The shard handle's exchange plan (snn_exchange_plan + per-peer segments): a dict with mode ("allgather" |
+        "halo"), n_shards, shard_index, shard_stride, planes, plane_id, send / recv (device pointers), send_words /
+        recv_words, and per-peer arrays send_offset / send_count / recv_offset / recv_count in 32-bit words."""
+        plan = _lib.ExchangePlan()
+        self._check(self._L.snn_exchange_plan_get(self._h, C.byref(plan)))
+        g = plan.n_shards
+        arrs = [np.zeros(g, np.uint64) for _ in range(4)]
+        self._check(self._L.snn_exchange_peers(self._h, *[a.ctypes.data_as(_lib.u64p) for a in arrs]))
+        return {"mode": "halo" if plan.mode == _lib.EXCHANGE_HALO else "allgather", "n_shards": g,
+                "shard_index": plan.shard_index, "shard_stride": plan.shard_stride, "planes": plan.planes,
+                "plane_id": list(plan.plane_id)[:plan.planes], "send": plan.send, "recv": plan.recv,
+                "send_words": plan.send_words, "recv_words": plan.recv_words,
+                "send_offset": arrs[0], "send_count": arrs[1], "recv_offset": arrs[2], "recv_count": arrs[3]}
+
+    def halo_needs(self, peer):
+        """ascending global indices of shard `peer`'s neurons that this handle's CSR rows read"""
+        n = C.c_uint32()
+        self._check(self._L.snn_halo_needs(self._h, peer, None, 0, C.byref(n)))
+        out = np.empty(n.value, np.uint32)
+        if n.value:
+            self._check(self._L.snn_halo_needs(self._h, peer, out.ctypes.data_as(_lib.u32p), out.size, C.byref(n)))
+        return out
+
+    def halo_set_sends(self, peer, indices):
+        a = np.ascontiguousarray(indices, dtype=np.uint32)
+        self._check(self._L.snn_halo_set_sends(self._h, peer, a.ctypes.data_as(_lib.u32p), a.size))
+
+    def halo_commit(self):
+        self._check(self._L.snn_halo_commit(self._h))
+
+    def exchange(self, comm):
+        """one RCCL exchange of the packed segments on the handle's stream (comm: parallel.LibraryComm or ncclComm_t)"""
+        self._check(self._L.snn_exchange(self._h, C.c_void_p(int(comm))))
+
+    def exchange_halo_lists(self, comm):
+        self._check(self._L.snn_comm_exchange_halo_lists(self._h, C.c_void_p(int(comm))))
+
+    def run_sharded(self, comm, iterations):
+        """`iterations` steps with the library's own RCCL loop (every rank calls it with its shard handle)"""
+        self._check(self._L.snn_run_sharded(self._h, C.c_void_p(int(comm)), int(iterations)))
 
     def set_stream(self, hip_stream):
         """Adopt a caller's hipStream_t (int handle): step_begin / step_end then only enqueue on it.

@@ -1,31 +1,142 @@
 """Multi-GPU stepping: one process per GPU, the postsynaptic population sharded in equal slots.
 
-The reference has no distributed path at all (SURVEY §5); the sharding follows from the step's data
+The reference has no distributed path at all (SURVEY section 5); the sharding follows from the step's data
 flow (backend/src/neuron/mod.rs:1077-1085, 2640-2647): every neuron's input at step t depends only on
-the state S(t) of its presynaptic cells, so a rank that owns the columns W[:, shard] of the dense
-synapse matrix needs, per step, exactly the other shards' exchanged planes (voltage, spike flag,
-neurotransmitter concentrations) -- ONE in-place all-gather of contiguous per-rank blocks over
-RCCL/xGMI (`torch.distributed`, backend "nccl"), no other collective.  Spike-train cells are
-replicated (deterministic xorshift32), plasticity is applied by the owner of the column.
+the state S(t) of its presynaptic cells, so a rank that owns the columns W[:, shard] of the synapse matrix
+needs, per step, exactly the presynaptic state of the neurons owned elsewhere that its rows read -- ONE
+exchange per step, sized by the handle's exchange plan (include/snn_amd.h): per neuron 4 B of voltage (gap
+junctions on), 4 B per transmitter type in use (chemical synapses on) and one bit for the spike; dense
+handles all-gather whole slots in place, sparse (CSR) handles trade exactly the neurons each peer's rows
+reference (halo segments, all-to-all-v).  Spike-train cells are replicated (deterministic xorshift32),
+plasticity is applied by the owner of the column.
 
-`ShardedStepper` is backend-agnostic on purpose: the product passes a `DeviceNetwork` shard, the CPU
-tests (gloo, world_size 2) pass an oracle-backed object with the same four members.
+Two drivers:
+  * `DeviceNetwork.run_sharded(LibraryComm(...), n)` -- the step loop and RCCL inside libsnn_amd.so (one host call);
+  * `ShardedStepper` -- the same protocol with torch.distributed moving the segments.  It is backend-agnostic on
+    purpose: the product passes a `DeviceNetwork` shard, the CPU tests (gloo, world_size 2) pass an oracle-backed
+    object with the same members (step_begin, step_end, exchange_plan).
 """
+import ctypes as C
 
 
 class _DeviceWords:
     """Expose a raw device allocation to torch through __cuda_array_interface__ (no copy)."""
 
     def __init__(self, ptr, n_words):
-        self.__cuda_array_interface__ = {"shape": (int(n_words),), "typestr": "<f4",
+        self.__cuda_array_interface__ = {"shape": (int(n_words),), "typestr": "<i4",
                                          "data": (int(ptr), False), "version": 2}
 
 
-def exchange_tensor(dn, device):
-    """torch view of a DeviceNetwork's exchange buffer: [n_shards * words_per_neuron * stride] f32."""
+def device_words(ptr, n_words, device):
+    """torch int32 view of `n_words` 32-bit words of device memory owned by the library"""
     import torch
-    ptr, words, n_padded = dn.exchange_buffer()
-    return torch.as_tensor(_DeviceWords(ptr, words * n_padded), device=device)
+    if not n_words:
+        return torch.empty(0, dtype=torch.int32, device=device)
+    return torch.as_tensor(_DeviceWords(ptr, n_words), device=device)
+
+
+def exchange_tensors(plan, device):
+    """(send, recv) torch views of a plan's buffers; backends without device memory put tensors in the plan"""
+    if "send_tensor" in plan:
+        return plan["send_tensor"], plan["recv_tensor"]
+    return device_words(plan["send"], plan["send_words"], device), device_words(plan["recv"], plan["recv_words"], device)
+
+
+class LibraryComm:
+    """An RCCL communicator created by libsnn_amd.so itself (snn_comm_unique_id / snn_comm_init_rank); the 128-byte
+    id travels from rank 0 through `torch.distributed` (any backend) or a caller-supplied `broadcast(bytes) -> bytes`.
+    int(comm) is the ncclComm_t for DeviceNetwork.run_sharded / exchange."""
+
+    def __init__(self, rank, world_size, device, broadcast=None, lib=None):
+        from . import _lib
+        self._L = lib or _lib.load()
+        self._check = lambda code: _lib.check(code, self._L)
+        ident = C.create_string_buffer(128)
+        if rank == 0:
+            self._check(self._L.snn_comm_unique_id(ident))
+        raw = bytes(ident.raw)
+        if world_size > 1:
+            if broadcast is None:
+                import torch.distributed as dist
+                box = [raw]
+                dist.broadcast_object_list(box, src=0)
+                raw = box[0]
+            else:
+                raw = broadcast(raw)
+        h = C.c_void_p()
+        self._check(self._L.snn_comm_init_rank(C.create_string_buffer(raw, 128), world_size, rank, device, C.byref(h)))
+        self._h = h.value
+
+    def __int__(self):
+        return int(self._h)
+
+    def close(self):
+        if self._h:
+            self._check(self._L.snn_comm_destroy(C.c_void_p(self._h)))
+            self._h = None
+
+
+def wire_halo_lists(handles):
+    """Halo plans of G CSR shard handles living in ONE process (tests, single-GPU emulation): every handle's need
+    lists become its peers' send lists, then all commit."""
+    g = len(handles)
+    for r, h in enumerate(handles):
+        for p in range(g):
+            if p != r:
+                handles[p].halo_set_sends(r, h.halo_needs(p))
+    for h in handles:
+        h.halo_commit()
+
+
+def copy_segments(plans, tensors):
+    """The exchange between G shard handles of one process: device-to-device (or host) copies of every segment
+    plans[r] sends to p into plans[p]'s receive segment for r.  tensors[r] = (send, recv)."""
+    g = len(plans)
+    for r in range(g):
+        send = tensors[r][0]
+        for p in range(g):
+            if p == r:
+                continue
+            n = int(plans[r]["send_count"][p])
+            if n == 0:
+                continue
+            so, ro = int(plans[r]["send_offset"][p]), int(plans[p]["recv_offset"][r])
+            assert n == int(plans[p]["recv_count"][r]), "send / receive segment sizes disagree"
+            tensors[p][1][ro:ro + n].copy_(send[so:so + n])
+
+
+class LocalExchange:
+    """G shard handles of ONE process (tests and the single-GPU emulation of the multi-GPU path): the exchange is a
+    set of device-to-device copies between the handles' send and receive buffers, segment by segment."""
+
+    def __init__(self, handles, device, halo=False):
+        self.handles, self.device = list(handles), device
+        if halo:
+            wire_halo_lists(self.handles)
+        self.refresh()
+
+    def refresh(self):
+        """(re)read the plans -- after set_synapses / transmitter flags / halo_commit on the handles"""
+        self.plans = [h.exchange_plan() for h in self.handles]
+        self.tensors = [exchange_tensors(p, self.device) for p in self.plans]
+
+    def exchange(self, sync=True):
+        copy_segments(self.plans, self.tensors)
+        if sync:
+            import torch
+            torch.cuda.synchronize()
+
+    def step(self, sync=True):
+        for h in self.handles:
+            h.step_begin()
+        self.exchange(sync)
+        for h in self.handles:
+            h.step_end()
+
+    def bytes_per_step(self):
+        """bytes each handle receives per step"""
+        return [4 * sum(int(p["recv_count"][q]) for q in range(len(self.plans)) if q != r)
+                for r, p in enumerate(self.plans)]
 
 
 def shard_geometry(n_neurons, n_shards):
@@ -40,35 +151,50 @@ def shard_geometry(n_neurons, n_shards):
 
 
 class ShardedStepper:
-    """Drives one shard: step_begin -> all-gather of the exchanged planes -> step_end.
+    """Drives one shard with torch.distributed: step_begin -> exchange of the packed segments -> step_end.
 
-    backend members used: step_begin(), step_end(); `buf` is a 1-D torch tensor over the backend's
-    exchange buffer laid out [shard][plane][stride] so that shard r's block is contiguous.
+    backend members used: step_begin(), step_end(), exchange_plan() (and step_begin_local / apply_reward when present).
     """
 
-    def __init__(self, backend, buf, rank, world_size, group=None, sync=None, always_gather=False, stream=None):
+    def __init__(self, backend, rank, world_size, group=None, sync=None, always_exchange=False, stream=None, device=None):
         import torch.distributed as dist
-        self.backend, self.buf, self.rank, self.world = backend, buf, rank, world_size
+        self.backend, self.rank, self.world = backend, rank, world_size
         self.group = group
         self.dist = dist
-        assert buf.numel() % world_size == 0, "exchange buffer must split evenly over the ranks"
-        self.block = buf.numel() // world_size
-        self.local = buf[rank * self.block:(rank + 1) * self.block]
+        self.device = device
         self._sync = sync or (lambda: None)
-        self._always = always_gather        # run the collective even at world_size 1 (path check on one GPU)
+        self._always = always_exchange      # run the collective even at world_size 1 (path check on one GPU)
         # GPU backends: a NON-default torch.cuda.Stream that the backend has adopted (backend.set_stream); all
         # kernels, the collective's stream dependencies and `work.wait()` are ordered on it
         self.stream = stream
+        self.refresh_plan()
+
+    def refresh_plan(self):
+        """(re)read the backend's exchange plan -- after set_synapses / transmitter flags / halo_commit"""
+        self.plan = self.backend.exchange_plan()
+        self.send, self.recv = exchange_tensors(self.plan, self.device)
+        assert self.plan["n_shards"] == self.world and self.plan["shard_index"] == self.rank
+        self.is_cuda = self.recv.is_cuda or self.send.is_cuda
 
     def exchange(self, async_op=False):
-        """all-gather the exchanged planes in place; async_op=True returns the pending work handle"""
+        """move the packed segments; async_op=True returns the pending work handle"""
         if self.world == 1 and not self._always:
             return None
-        if self.buf.is_cuda:
-            work = self.dist.all_gather_into_tensor(self.buf, self.local, group=self.group, async_op=async_op)
-        else:   # gloo has no all_gather_into_tensor on every build: gather into per-rank views
-            views = [self.buf[r * self.block:(r + 1) * self.block] for r in range(self.world)]
-            work = self.dist.all_gather(views, self.local.clone(), group=self.group, async_op=async_op)
+        plan = self.plan
+        if plan["mode"] == "allgather":
+            if self.recv.numel() == 0:
+                return None
+            if self.is_cuda:
+                work = self.dist.all_gather_into_tensor(self.recv, self.send, group=self.group, async_op=async_op)
+            else:   # gloo has no all_gather_into_tensor on every build: gather into per-rank views
+                block = self.send.numel()
+                views = [self.recv[r * block:(r + 1) * block] for r in range(self.world)]
+                work = self.dist.all_gather(views, self.send.clone(), group=self.group, async_op=async_op)
+        else:
+            ins = [int(x) for x in plan["send_count"]]
+            outs = [int(x) for x in plan["recv_count"]]
+            work = self.dist.all_to_all_single(self.recv, self.send, output_split_sizes=outs, input_split_sizes=ins,
+                                               group=self.group, async_op=async_op)
         if not async_op:
             self._sync()
         return work if async_op else None
@@ -82,7 +208,7 @@ class ShardedStepper:
         if rewards is not None and len(rewards) != int(iterations):
             raise ValueError("rewards must hold one value per step")
         self._rewards = rewards
-        overlap = overlap and self.buf.is_cuda and hasattr(self.backend, "step_begin_local") and self.stream is not None
+        overlap = overlap and self.is_cuda and hasattr(self.backend, "step_begin_local") and self.stream is not None
         if self.stream is not None:
             import torch
             with torch.cuda.stream(self.stream):     # collectives synchronise with the CURRENT stream: make it ours

@@ -327,3 +327,28 @@ def assert_graph_equal(net, dn):
         idx = np.argwhere(bits(ow) != bits(w))
         f = tuple(idx[0])
         raise AssertionError(f"weights differ at {len(idx)} places, first {f}: oracle={ow[f]!r} hip={w[f]!r}")
+
+
+def assert_shard_view_equal(h, st, net):
+    """The part of the OTHER shards' state a shard handle holds after snn_step_end -- the planes of its exchange plan
+    (voltage with gap junctions, t of the transmitter types in use with chemical synapses, the spike bit and with it
+    last_firing_time), for every neuron (all-gather) or for the neurons its rows read (halo) -- and all of its own."""
+    plan = h.exchange_plan()
+    nn = net.n_neurons
+    known = np.zeros(nn, bool)
+    own = np.zeros(nn, bool)
+    own[h.post_begin:h.post_end] = True
+    if plan["mode"] == "halo":
+        for p in range(plan["n_shards"]):
+            if p != plan["shard_index"]:
+                known[h.halo_needs(p)] = True
+    else:
+        known[:] = True
+    known |= own
+    for name in ("is_spiking", "last_firing_time"):
+        assert np.array_equal(bits(st[name][known]), bits(net[name][known])), name
+    v = known if 0 in plan["plane_id"] else own
+    assert np.array_equal(bits(st["current_voltage"][v]), bits(net["current_voltage"][v])), "current_voltage"
+    for k in range(3):
+        m = known if (2 + k) in plan["plane_id"] else own
+        assert np.array_equal(bits(st["nt_t"][m, k]), bits(net["nt_t"][m, k])), f"nt_t type {k}"

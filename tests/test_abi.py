@@ -26,7 +26,7 @@ def test_header_symbols_are_exported_and_bound():
     for n in names:
         assert hasattr(raw, n), f"{n} is declared in snn_amd.h but not exported by libsnn_amd.so"
     assert sorted(_lib.SIGNATURES) == names, "python binding and header disagree on the entry points"
-    assert lib.snn_abi_version() == 1
+    assert lib.snn_abi_version() == 2
 
 
 def test_header_cites_the_reference_interface():

@@ -116,31 +116,39 @@ def test_c5_structure_csr(snn):
     dn.close()
 
 
-@pytest.mark.parametrize("n_shards", [2, 4])
-def test_c5_structure_csr_sharded(snn, n_shards):
-    """configs[4]'s multi-GPU shape on one device: shard handles + emulated all-gather of the exchanged planes."""
+@pytest.mark.parametrize("n_shards,halo", [(2, False), (4, False), (2, True), (4, True), (8, True)])
+def test_c5_structure_csr_sharded(snn, n_shards, halo):
+    """configs[4]'s multi-GPU shape on one device: sparse shard handles + the emulated exchange -- whole slots
+    (all-gather) or, with a committed halo plan, exactly the neurons each peer's rows reference."""
     import torch
     from snn_amd import parallel
     net = c5_structure(8)
     net["do_plasticity"] = 1
     handles = [parity.device_from_oracle(snn, net, shard=(r, n_shards), csr=True) for r in range(n_shards)]
-    bufs = [parallel.exchange_tensor(h, torch.device("cuda", 0)) for h in handles]
-    block = bufs[0].numel() // n_shards
+    ex = parallel.LocalExchange(handles, torch.device("cuda", 0), halo=halo)
+    assert all(p["mode"] == ("halo" if halo else "allgather") and p["planes"] == 1 for p in ex.plans)
+    read = []                                    # per handle: own neurons + what its rows read
+    for r, h in enumerate(handles):
+        k = np.zeros(net.n_neurons, bool)
+        k[h.post_begin:h.post_end] = True
+        if halo:
+            for p in range(n_shards):
+                if p != r:
+                    k[h.halo_needs(p)] = True
+            # radius-2 neighbourhoods + one ring edge per neuron: a strict subset of the other shards
+            assert k.sum() < net.n_neurons
+        else:
+            k[:] = True
+        read.append(k)
     for _ in range(300):
-        for h in handles:
-            h.step_begin()
-        for r in range(n_shards):
-            for o in range(n_shards):
-                if o != r:
-                    bufs[o][r * block:(r + 1) * block].copy_(bufs[r][r * block:(r + 1) * block])
-        torch.cuda.synchronize()
-        for h in handles:
-            h.step_end()
+        ex.step()
     net.run(300, spike_history=True)
     assert net.spike_history.sum() > 20
-    for h in handles:
+    for h, k in zip(handles, read):
         st = parity.pull_state(h, net)
-        for name in ("current_voltage", "is_spiking", "last_firing_time", "st_last_firing_time", "st_seed"):
+        for name in ("current_voltage", "is_spiking", "last_firing_time"):
+            assert np.array_equal(parity.bits(st[name][k]), parity.bits(net[name][k])), name
+        for name in ("st_last_firing_time", "st_seed"):
             assert np.array_equal(parity.bits(st[name]), parity.bits(net[name])), name
         b, e = h.post_begin, h.post_end
         assert np.array_equal(parity.bits(st["w_value"][b:e]), parity.bits(net["w_value"][b:e]))

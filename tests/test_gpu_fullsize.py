@@ -217,30 +217,45 @@ def test_c4_full_size_network_with_stdp_sampled(snn):
     dn.close()
 
 
+def c5_handle(snn, side, v0, shard=None):
+    """BASELINE configs[4] on a (shard) handle: 4 Izhikevich lattices + 4 Poisson lattices, CSR rows of the handle"""
+    from snn_amd import synthetic
+    f32 = np.float32
+    m = side * side
+    dn = snn.DeviceNetwork(model=snn.IZHIKEVICH, spike_train=snn.ST_POISSON)
+    for k in range(4):
+        dn.add_lattice(k, side, side)
+        dn.add_spike_train_lattice(4 + k, side, side)
+    if shard is None:
+        dn.finalize(csr=True)
+    else:
+        dn.finalize(shard[0], shard[1], csr=True)
+    for k in range(4):
+        dn.set_attr(k, "gap_conductance", np.full(m, 10.0, f32))
+        dn.set_attr(k, "current_voltage", v0[k * m:(k + 1) * m])
+        dn.set_attr(4 + k, "chance_of_firing", np.full(m, 0.01, f32))
+        dn.set_attr(4 + k, "seed", np.arange(k * m + 1, (k + 1) * m + 1, dtype=np.uint32))
+    dn.set_graph_csr(*synthetic.c5_csr(side, dn.post_begin, dn.post_end))
+    return dn
+
+
 def test_c5_full_size_sparse_network_against_numpy(snn):
     """BASELINE configs[4] at full size: 1 048 576 neurons, 1 048 576 Poisson cells, 14.6 M synapses, 30 steps.
     Voltages, adaptation variables, spikes, firing times and the cells' generator state bit-identical to a numpy
     restatement of the same sparse step (gap junctions from neurons and from Poisson cells with the delta-dirac
-    refractoriness, the canonical 256-chunk summation order, Izhikevich update, xorshift32 cells)."""
-    from snn_amd import synthetic
+    refractoriness, the canonical 256-chunk summation order, Izhikevich update, xorshift32 cells) -- on ONE handle and
+    on EIGHT shard handles (configs[4]'s multi-GPU shape on one device) that trade halo segments: per handle the
+    two lattice rows either side of its slab and the half lattice the ring edge k -> k + 1 reads, not whole slots."""
+    import torch
+    from snn_amd import parallel, synthetic
     import numpy_ref as nr
     f32 = np.float32
     side, steps = 512, 30
     m = side * side
     nn = nc = 4 * m
     ptr, pre, w = synthetic.c5_csr(side)
-    dn = snn.DeviceNetwork(model=snn.IZHIKEVICH, spike_train=snn.ST_POISSON)
-    for k in range(4):
-        dn.add_lattice(k, side, side)
-        dn.add_spike_train_lattice(4 + k, side, side)
-    dn.finalize(csr=True)
     v0 = np.concatenate([synthetic.uniform(6, m, -65.0, 30.0, offset=k * m) for k in range(4)])
-    for k in range(4):
-        dn.set_attr(k, "gap_conductance", np.full(m, 10.0, f32))
-        dn.set_attr(k, "current_voltage", v0[k * m:(k + 1) * m])
-        dn.set_attr(4 + k, "chance_of_firing", np.full(m, 0.01, f32))
-        dn.set_attr(4 + k, "seed", np.arange(k * m + 1, (k + 1) * m + 1, dtype=np.uint32))
-    dn.set_graph_csr(ptr, pre, w)
+    dn = c5_handle(snn, side, v0)
     dn.run(steps)
 
     # ---- numpy restatement ----
@@ -308,3 +323,40 @@ def test_c5_full_size_sparse_network_against_numpy(snn):
         assert np.array_equal(dn.get_attr(4 + k, "seed", dtype=np.uint32), seed[sl]), k
         assert np.array_equal(dn.get_attr(4 + k, "last_firing_time", dtype=np.int32), st_lft[sl]), k
     dn.close()
+
+    # ---- eight shard handles on this GPU, halo exchange ----
+    g = 8
+    handles = [c5_handle(snn, side, v0, shard=(r, g)) for r in range(g)]
+    ex = parallel.LocalExchange(handles, torch.device("cuda", 0), halo=True)
+    assert all(p["mode"] == "halo" and p["plane_id"] == [0] for p in ex.plans)
+    # per handle and step: the half lattice behind the ring edge (131 072 neurons) + 2 x 2 lattice rows of 512, at
+    # 4 B + 1 bit each -- 0.54 MB instead of the 4.3 MB of whole slots (and of the 21 MB of the five-plane all-gather
+    # this replaces)
+    per_step = ex.bytes_per_step()
+    assert max(per_step) <= 4 * ((m // 2 + 4 * side) + (m // 2 + 4 * side) // 32 + 8), per_step
+    for _ in range(steps):
+        ex.step()
+    for h in handles:
+        b, e = h.post_begin, h.post_end
+        for k in range(4):
+            lo, hi = max(b, k * m), min(e, (k + 1) * m)
+            if lo >= hi:
+                continue
+            own = slice(lo - k * m, hi - k * m)
+            assert np.array_equal(parity.bits(h.get_attr(k, "current_voltage")[own]), parity.bits(st["current_voltage"][lo:hi])), k
+            assert np.array_equal(parity.bits(h.get_attr(k, "w_value")[own]), parity.bits(st["w_value"][lo:hi])), k
+            assert np.array_equal(h.get_attr(k, "last_firing_time", dtype=np.int32)[own], lft[lo:hi]), k
+            # the replicated cells agree everywhere
+            assert np.array_equal(h.get_attr(4 + k, "seed", dtype=np.uint32), seed[k * m:(k + 1) * m]), k
+            assert np.array_equal(h.get_attr(4 + k, "last_firing_time", dtype=np.int32), st_lft[k * m:(k + 1) * m]), k
+        # what the handle reads of the others: voltage and firing times of its halo
+        r = ex.plans[handles.index(h)]["shard_index"]
+        for p in range(g):
+            need = h.halo_needs(p) if p != r else np.zeros(0, np.uint32)
+            if need.size:
+                v_all = np.concatenate([h.get_attr(k, "current_voltage") for k in range(4)])
+                l_all = np.concatenate([h.get_attr(k, "last_firing_time", dtype=np.int32) for k in range(4)])
+                assert np.array_equal(parity.bits(v_all[need]), parity.bits(st["current_voltage"][need])), (r, p)
+                assert np.array_equal(l_all[need], lft[need]), (r, p)
+                break                           # one peer per handle keeps the test short
+        h.close()

@@ -226,22 +226,14 @@ def test_generated_model_in_a_network_equals_the_oracle(snn, libs, variant):
     steps = 600
     if variant == "sharded":
         handles = [parity.device_from_oracle(snn, net, shard=(r, 2)) for r in range(2)]
-        bufs = [parallel.exchange_tensor(h, torch.device("cuda", 0)) for h in handles]
-        block = bufs[0].numel() // 2
+        ex = parallel.LocalExchange(handles, torch.device("cuda", 0))
         for _ in range(steps):
-            for h in handles:
-                h.step_begin()
-            for r in range(2):
-                bufs[1 - r][r * block:(r + 1) * block].copy_(bufs[r][r * block:(r + 1) * block])
-            torch.cuda.synchronize()
-            for h in handles:
-                h.step_end()
+            ex.step()
         net.run(steps, spike_history=True)
         for h in handles:
             st = parity.pull_state(h, net)
             b, e = h.post_begin, h.post_end
-            for name in ("current_voltage", "is_spiking", "last_firing_time", "nt_t"):
-                assert np.array_equal(parity.bits(st[name]), parity.bits(net[name])), name
+            parity.assert_shard_view_equal(h, st, net)
             assert np.array_equal(parity.bits(st["custom_vars"][:, b:e]), parity.bits(net["custom_vars"][:, b:e]))
             w, c = h.get_graph_rows(0, net.n_tot)
             ow = np.where(net["connections"] != 0, net["weights"], np.float32(0))
@@ -637,22 +629,15 @@ def test_whole_description_in_one_library_equals_the_oracle(snn, libs, variant):
     steps = 900
     if variant == "sharded":
         handles = [parity.device_from_oracle(snn, net, shard=(r, 2)) for r in range(2)]
-        bufs = [parallel.exchange_tensor(h, torch.device("cuda", 0)) for h in handles]
-        block = bufs[0].numel() // 2
+        ex = parallel.LocalExchange(handles, torch.device("cuda", 0))
         for _ in range(steps):
-            for h in handles:
-                h.step_begin()
-            for r in range(2):
-                bufs[1 - r][r * block:(r + 1) * block].copy_(bufs[r][r * block:(r + 1) * block])
-            torch.cuda.synchronize()
-            for h in handles:
-                h.step_end()
+            ex.step()
         net.run(steps, spike_history=True)
         for h in handles:
             st = parity.pull_state(h, net)
             b, e = h.post_begin, h.post_end
-            for name in ("current_voltage", "is_spiking", "last_firing_time", "nt_t", "st_current_voltage",
-                         "st_last_firing_time", "st_custom_vars", "st_nt_t", "st_nt_custom_vars"):
+            parity.assert_shard_view_equal(h, st, net)
+            for name in ("st_current_voltage", "st_last_firing_time", "st_custom_vars", "st_nt_t", "st_nt_custom_vars"):
                 assert np.array_equal(parity.bits(st[name]), parity.bits(net[name])), name
             assert np.array_equal(parity.bits(st["custom_vars"][:, b:e]), parity.bits(net["custom_vars"][:, b:e]))
             for name in ("rc_r", "rc_current"):

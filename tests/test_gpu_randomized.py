@@ -183,27 +183,21 @@ def test_random_network(snn, seed):
         return
     g = plan["shards"]
     handles = [make_handle(snn, net, plan, shard=(r, g)) for r in range(g)]
-    bufs = [parallel.exchange_tensor(h, torch.device("cuda", 0)) for h in handles]
-    block = bufs[0].numel() // g
+    ex = parallel.LocalExchange(handles, torch.device("cuda", 0), halo=plan["csr"] and bool(plan.get("halo", True)))
     for step in range(steps):
         for h in handles:
             if plan["rewards"] is not None:
                 h.apply_reward(float(plan["rewards"][step]))
             h.step_begin_local()
             h.step_begin()
-        for r in range(g):
-            for o in range(g):
-                if o != r:
-                    bufs[o][r * block:(r + 1) * block].copy_(bufs[r][r * block:(r + 1) * block])
-        torch.cuda.synchronize()
+        ex.exchange()
         for h in handles:
             h.step_end()
     net.run(steps, rewards=plan["rewards"])
     for h in handles:
         check_modulation(h, net, plan)
         st = parity.pull_state(h, net)
-        for name in ("current_voltage", "is_spiking", "last_firing_time", "nt_t"):
-            assert np.array_equal(parity.bits(st[name]), parity.bits(net[name])), name
+        parity.assert_shard_view_equal(h, st, net)
         b, e = h.post_begin, h.post_end
         for name in ("rc_r", "rc_current"):
             assert np.array_equal(parity.bits(st[name][b:e]), parity.bits(net[name][b:e])), name

@@ -1,5 +1,5 @@
-"""The RCCL leg of the multi-GPU path with the pieces that CAN run on one GPU: torch wraps the library's
-exchange buffer without a copy (one HIP runtime in the process), `all_gather_into_tensor` accepts it in
+"""The torch.distributed leg of the multi-GPU path with the pieces that CAN run on one GPU: torch wraps the library's
+exchange buffers without a copy (one HIP runtime in the process), `all_gather_into_tensor` accepts them in
 place with backend nccl (= RCCL) at world_size 1, and a ShardedStepper-driven run equals snn_run."""
 import os
 import socket
@@ -38,11 +38,14 @@ def test_sharded_stepper_over_rccl_world_size_1(snn):
         net.fill_graph(2, 0.5, 1.5)
         net["do_plasticity"] = 1
         dn = parity.device_from_oracle(snn, net, shard=(0, 1))
-        buf = parallel.exchange_tensor(dn, torch.device("cuda", 0))
-        ptr, words, n_padded = dn.exchange_buffer()
-        assert buf.data_ptr() == ptr and buf.numel() == words * n_padded        # a view, not a copy
+        plan = dn.exchange_plan()
+        send, recv = parallel.exchange_tensors(plan, torch.device("cuda", 0))
+        assert recv.data_ptr() == plan["recv"] and send.data_ptr() == plan["send"]      # views, not copies
+        stride = plan["shard_stride"]
+        assert plan["mode"] == "allgather" and plan["plane_id"] == [0]                 # electrical only: voltage + bits
+        assert send.numel() == recv.numel() == stride + stride // 32                    # 4 B + 1 bit per neuron
         # the collective itself, in place, on memory owned by libsnn_amd.so
-        dist.all_gather_into_tensor(buf, buf[0:buf.numel()])
+        dist.all_gather_into_tensor(recv, send)
         torch.cuda.synchronize()
         v = dn.get_attr(0, "current_voltage")
         assert np.array_equal(v.view(np.uint32), net["current_voltage"].view(np.uint32))
@@ -54,11 +57,11 @@ def test_sharded_stepper_over_rccl_world_size_1(snn):
         with torch.cuda.stream(side):
             for _ in range(200):
                 dn.step_begin()
-                dist.all_gather_into_tensor(buf, buf[0:buf.numel()])
+                dist.all_gather_into_tensor(recv, send)
                 dn.step_end()
         dn.synchronize()
         # the overlapped schedule of ShardedStepper.run (step_begin_local before the previous gather is waited for)
-        stepper = parallel.ShardedStepper(dn, buf, 0, 1, always_gather=True, stream=side)
+        stepper = parallel.ShardedStepper(dn, 0, 1, always_exchange=True, stream=side, device=torch.device("cuda", 0))
         dn.set_plasticity(0, do_plasticity=False)
         net["do_plasticity"] = 0
         net.run(200)

@@ -108,18 +108,9 @@ def test_sharded_handles_reduce_over_the_whole_lattice(snn, n_shards):
     handles = [parity.device_from_oracle(snn, net, shard=(r, n_shards)) for r in range(n_shards)]
     for h in handles:
         h.set_reduced_history(True, True, True)
-    bufs = [parallel.exchange_tensor(h, torch.device("cuda", 0)) for h in handles]
-    block = bufs[0].numel() // n_shards
+    ex = parallel.LocalExchange(handles, torch.device("cuda", 0))
     for _ in range(steps):
-        for h in handles:
-            h.step_begin()
-        for r in range(n_shards):
-            for o in range(n_shards):
-                if o != r:
-                    bufs[o][r * block:(r + 1) * block].copy_(bufs[r][r * block:(r + 1) * block])
-        torch.cuda.synchronize()
-        for h in handles:
-            h.step_end()
+        ex.step()
     net.run(steps, summaries=True, spike_counts=True)
     assert net.spike_counts.sum() > 10
     rng = net.layout.ranges()

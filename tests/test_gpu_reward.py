@@ -153,18 +153,13 @@ def test_sharded_handles(snn, n_shards):
     handles = [to_device(snn, net, shard=(r, n_shards)) for r in range(n_shards)]
     for h in handles:
         h.set_trace_rows(0, net["traces"])
-    bufs = [parallel.exchange_tensor(h, torch.device("cuda", 0)) for h in handles]
-    block = bufs[0].numel() // n_shards
+    ex = parallel.LocalExchange(handles, torch.device("cuda", 0))
     for rwd in rewards:
         for h in handles:
             h.apply_reward(float(rwd))
             h.step_begin_local()          # refused internally while modulation is on
             h.step_begin()
-        for r in range(n_shards):
-            for o in range(n_shards):
-                if o != r:
-                    bufs[o][r * block:(r + 1) * block].copy_(bufs[r][r * block:(r + 1) * block])
-        torch.cuda.synchronize()
+        ex.exchange()
         for h in handles:
             h.step_end()
     net.run(steps, rewards=rewards)
@@ -202,8 +197,7 @@ def test_sharded_stepper_applies_rewards_in_step_order(snn):
     dn.set_trace_rows(0, net["traces"])
     side = torch.cuda.Stream()
     dn.set_stream(side.cuda_stream)
-    buf = parallel.exchange_tensor(dn, torch.device("cuda", 0))
-    stepper = parallel.ShardedStepper(dn, buf, 0, 1, stream=side)
+    stepper = parallel.ShardedStepper(dn, 0, 1, stream=side, device=torch.device("cuda", 0))
     stepper.run(steps // 2, rewards=rewards[:steps // 2])
     stepper.run(steps - steps // 2, rewards=rewards[steps // 2:])
     dn.synchronize()

@@ -1,6 +1,6 @@
-"""The HIP sharded path (snn_network_finalize_shard / snn_step_begin / snn_step_end / exchange buffer) on
+"""The HIP sharded path (snn_network_finalize_shard / snn_step_begin / snn_step_end / exchange plan) on
 ONE GPU: G shard handles on cuda:0, the all-gather emulated by device-to-device copies of each shard's
-contiguous block.  Merged result must equal the oracle bit for bit -- rasters, voltages, adaptation
+packed segment (voltage / live transmitter planes / spike bitmap).  Merged result must equal the oracle bit for bit -- rasters, voltages, adaptation
 variables, last_firing_time and the STDP-updated weight columns."""
 import numpy as np
 import pytest
@@ -40,19 +40,13 @@ def test_sharded_handles_equal_oracle(snn, n_shards, chemical):
     for h, (b, e) in zip(handles, shards):
         assert (h.post_begin, h.post_end) == (b, e)
         h.set_history(voltage=True, spikes=True)
-    bufs = [parallel.exchange_tensor(h, torch.device("cuda", 0)) for h in handles]
-    block = bufs[0].numel() // n_shards
+    ex = parallel.LocalExchange(handles, torch.device("cuda", 0))
+    # what travels: 4 B voltage (+ 4 B for the one transmitter type in use) + 1 bit per neuron of every other slot
+    planes = 2 if chemical else 1
+    assert all(p["mode"] == "allgather" and p["planes"] == planes for p in ex.plans)
+    assert ex.bytes_per_step() == [4 * (n_shards - 1) * (planes * stride + stride // 32)] * n_shards
     for _ in range(steps):
-        for h in handles:
-            h.step_begin()
-        for r in range(n_shards):
-            src = bufs[r][r * block:(r + 1) * block]
-            for o in range(n_shards):
-                if o != r:
-                    bufs[o][r * block:(r + 1) * block].copy_(src)
-        torch.cuda.synchronize()
-        for h in handles:
-            h.step_end()
+        ex.step()
     net.run(steps, voltage_history=True, spike_history=True)
     assert net.spike_history.sum() > 20
 
@@ -61,9 +55,11 @@ def test_sharded_handles_equal_oracle(snn, n_shards, chemical):
         b, e = shards[r]
         assert h.clock == net.clock
         st = parity.pull_state(h, net)
-        # exchanged planes and last_firing_time are complete on every shard
-        for name in ("current_voltage", "is_spiking", "last_firing_time", "nt_t", "st_last_firing_time",
-                     "st_current_voltage", "st_step"):
+        # what is exchanged (voltage, spikes -> last_firing_time, t when chemical synapses read it) is complete on
+        # every shard; the replicated cells agree everywhere
+        parity.assert_shard_view_equal(h, st, net)
+        for name in ("current_voltage", "is_spiking", "last_firing_time", "st_last_firing_time", "st_current_voltage",
+                     "st_step") + (("nt_t",) if chemical else ()):
             assert np.array_equal(parity.bits(st[name]), parity.bits(net[name])), (r, name)
         # owned state
         for name in ("w_value", "rc_r", "rc_current"):
@@ -98,16 +94,10 @@ def test_stream_ordered_stepping_without_host_sync(snn):
     side = torch.cuda.Stream()
     for h in handles:
         h.set_stream(side.cuda_stream)
-    bufs = [parallel.exchange_tensor(h, torch.device("cuda", 0)) for h in handles]
-    block = bufs[0].numel() // n_shards
+    ex = parallel.LocalExchange(handles, torch.device("cuda", 0))
     with torch.cuda.stream(side):
         for _ in range(steps):
-            for h in handles:
-                h.step_begin()
-            for r in range(n_shards):
-                bufs[1 - r][r * block:(r + 1) * block].copy_(bufs[r][r * block:(r + 1) * block], non_blocking=True)
-            for h in handles:
-                h.step_end()
+            ex.step(sync=False)
     for h in handles:
         h.synchronize()
     net.run(steps)
@@ -133,15 +123,8 @@ def test_split_input_pass_is_result_neutral(snn, plastic):
     net["do_plasticity"] = int(plastic)
     n_shards, steps = 3, 200
     handles = [parity.device_from_oracle(snn, net, shard=(r, n_shards)) for r in range(n_shards)]
-    bufs = [parallel.exchange_tensor(h, torch.device("cuda", 0)) for h in handles]
-    block = bufs[0].numel() // n_shards
-
-    def gather():
-        for r in range(n_shards):
-            for o in range(n_shards):
-                if o != r:
-                    bufs[o][r * block:(r + 1) * block].copy_(bufs[r][r * block:(r + 1) * block])
-        torch.cuda.synchronize()
+    ex = parallel.LocalExchange(handles, torch.device("cuda", 0))
+    gather = ex.exchange
 
     started = False
     for _ in range(steps):

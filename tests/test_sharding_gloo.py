@@ -1,7 +1,9 @@
-"""N > 1 path on CPU: two processes, gloo, the product's ShardedStepper + shard geometry with
-oracle-backed shards.  Each rank owns half of the postsynaptic population and the matching columns of
-the weight matrix; after every step ONE all-gather of the exchanged planes.  The union of the ranks'
-states must equal the single-process oracle bit for bit (rasters, voltages, weights)."""
+"""N > 1 path on CPU: two / three processes, gloo, the product's ShardedStepper + shard geometry with
+oracle-backed shards that speak the product's wire format.  Each rank owns a slot of the postsynaptic
+population and the matching columns of the weight matrix; after every step ONE exchange -- an all-gather of
+whole slots (voltage, live transmitter planes, spike bitmap) or, in halo mode, an all-to-all-v of exactly the
+neurons each peer's columns read.  The union of the ranks' states must equal the single-process oracle bit for
+bit (rasters, voltages, weights)."""
 import os
 import sys
 import tempfile
@@ -16,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 STEPS = 400
 
 
-def build_net():
+def build_net(sparse=False):
     import oracle_binding as ob
     import parity
     lay = parity.Layout([(0, 6, 6), (1, 10, 10)], [(7, 4, 5)])
@@ -31,7 +33,7 @@ def build_net():
     net["st_chance_of_firing"] = 0.03
     net.fill_graph(2, 0.5, 1.5)
     rng = np.random.default_rng(3)
-    net["connections"][rng.random(net["connections"].shape) < 0.3] = 0
+    net["connections"][rng.random(net["connections"].shape) < (0.97 if sparse else 0.3)] = 0
     net["do_plasticity"] = 1
     # lattice 1 is reward-modulated (R-STDP traces on its internal edges), lattice 0 keeps plain STDP
     net["do_plasticity"][1] = 0
@@ -50,23 +52,31 @@ def rewards():
     return r
 
 
-def worker(rank, world, init_file, out_dir):
+def worker(rank, world, init_file, out_dir, mode="allgather"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from snn_amd import parallel
     from oracle_shard_backend import OracleShard
     dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
-    net = build_net()
+    net = build_net(sparse=(mode == "halo"))
     stride, shards = parallel.shard_geometry(net.n_neurons, world)
-    shard = OracleShard(net, rank, world, stride)
-    stepper = parallel.ShardedStepper(shard, shard.buf, rank, world)
+    shard = OracleShard(net, rank, world, stride, mode=mode)
+    stepper = parallel.ShardedStepper(shard, rank, world)
+    if mode == "halo":      # a genuinely partial exchange: some neurons of the other shards are never read here
+        assert sum(len(i) for i in shard.recv_idx) < net.n_neurons - (shard.q1 - shard.q0)
+    else:                   # 4 B voltage + 4 B for the one live transmitter type + 1 bit per neuron, not 20 B
+        assert shard.send.numel() == 2 * stride + stride // 32
     raster = []
     rw = rewards()
     for i in range(STEPS):
         stepper.run(1, rewards=rw[i:i + 1])
         raster.append(net["is_spiking"].copy())
     q0, q1 = shards[rank]
-    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), q0=q0, q1=q1, v=net["current_voltage"], w=net["w_value"],
+    needed = np.zeros(net.n_neurons, bool)
+    needed[q0:q1] = True
+    for idx in shard.recv_idx:
+        needed[np.asarray(idx)[np.asarray(idx) < net.n_neurons]] = True
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), q0=q0, q1=q1, needed=needed, v=net["current_voltage"], w=net["w_value"],
              lft=net["last_firing_time"], weights=net["weights"], raster=np.array(raster), clock=net.clock,
              t=net["nt_t"], st_lft=net["st_last_firing_time"], traces=net["traces"], dopamine=net["rm_dopamine"])
     dist.barrier()
@@ -74,28 +84,32 @@ def worker(rank, world, init_file, out_dir):
 
 
 @pytest.mark.timeout(600)
-def test_two_rank_sharded_run_equals_single_process():
-    world = 2
+@pytest.mark.parametrize("world,mode", [(2, "allgather"), (3, "halo")])
+def test_sharded_run_equals_single_process(world, mode):
     with tempfile.TemporaryDirectory() as d:
         init_file = os.path.join(d, "rendezvous")
-        mp.spawn(worker, args=(world, init_file, d), nprocs=world, join=True)
-        ref = build_net()
+        mp.spawn(worker, args=(world, init_file, d, mode), nprocs=world, join=True)
+        ref = build_net(sparse=(mode == "halo"))
         w0 = ref["weights"].copy()
         ref.run(STEPS, spike_history=True, rewards=rewards())
         assert ref.spike_history.sum() > 20 and np.abs(ref["traces"]).max() > 0
         assert not np.array_equal(w0[36:136, 36:136], ref["weights"][36:136, 36:136])      # the modulated block moved
+        covered = np.zeros(ref.n_neurons, bool)
         for r in range(world):
             z = np.load(os.path.join(d, f"rank{r}.npz"))
             q0, q1 = int(z["q0"]), int(z["q1"])
             assert int(z["clock"]) == STEPS
-            # exchanged state is complete on every rank
-            assert np.array_equal(z["v"].view(np.uint32), ref["current_voltage"].view(np.uint32))
-            assert np.array_equal(z["raster"], ref.spike_history)
-            assert np.array_equal(z["lft"], ref["last_firing_time"])
-            assert np.array_equal(z["t"].view(np.uint32), ref["nt_t"].view(np.uint32))
+            # exchanged state: complete on every rank (all-gather) / complete for what the rank reads (halo)
+            k = z["needed"] if mode == "halo" else np.ones(ref.n_neurons, bool)
+            covered[q0:q1] = True
+            assert np.array_equal(z["v"][k].view(np.uint32), ref["current_voltage"][k].view(np.uint32))
+            assert np.array_equal(z["raster"][:, k], ref.spike_history[:, k])
+            assert np.array_equal(z["lft"][k], ref["last_firing_time"][k])
+            assert np.array_equal(z["t"][k].view(np.uint32), ref["nt_t"][k].view(np.uint32))
             assert np.array_equal(z["st_lft"], ref["st_last_firing_time"])
             # owned state: local neurons' adaptation variable and the local weight columns
             assert np.array_equal(z["w"][q0:q1].view(np.uint32), ref["w_value"][q0:q1].view(np.uint32))
             assert np.array_equal(z["weights"][:, q0:q1].view(np.uint32), ref["weights"][:, q0:q1].view(np.uint32))
             assert np.array_equal(z["traces"][:, q0:q1].view(np.uint32), ref["traces"][:, q0:q1].view(np.uint32))
             assert np.array_equal(z["dopamine"].view(np.uint32), ref["rm_dopamine"].view(np.uint32))
+        assert covered.all()
