@@ -36,40 +36,65 @@ def pmc_traffic(config, world, rows, cols):
     return dom["hbm_traffic_bytes_per_launch"] if dom else None
 
 
-def cpu_baseline(n, sample_cols, steps, threads):
-    """Time the oracle (kind "port": a C restatement of the reference's CPU path, dense arrays, OpenMP over
-    postsynaptic neurons = the reference's rayon par_iter, backend/src/neuron/mod.rs:775-790) on `sample_cols`
-    postsynaptic neurons of the same workload.  Returns the all-cores figure plus side measurements."""
+def pmc_source(config, world, rows, cols):
+    """where roofline.traffic comes from: it is NOT measured by this run (PMC counters need their own rocprofv3 passes)"""
+    path = PMC_TRAFFIC.get(config)
+    if pmc_traffic(config, world, rows, cols) is None:
+        return None
+    return {"file": os.path.relpath(path, ROOT), "collected": json.load(open(path)).get("collected"),
+            "how": "two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of this command, gfx950 corrections of "
+                   "MI355X_MICROARCH.md, per launch of the dominant kernel"}
+
+
+def mem_available_bytes():
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                return int(line.split()[1]) * 1024
+    except OSError:
+        pass
+    return 16 << 30
+
+
+def cpu_baseline(n, threads, budget_s=15.0):
+    """Time the oracle (kind "port": a C restatement of the reference's CPU path, dense arrays, all cores = the
+    reference's rayon par_iter over postsynaptic neurons, backend/src/neuron/mod.rs:775-790) on the same workload: the
+    synaptic-input sums of ALL n postsynaptic neurons when host memory holds the matrix (5 B per synapse: f32 weight +
+    u8 connection flag), else of the largest column window that fits in a quarter of MemAvailable.  The matrix is
+    streamed in tiles of 1024 columns x 256 rows (snn_o_inputs_tiled: whole 4 KiB row segments per thread, first touched
+    by the thread that streams them).  Returns (neuron-steps/s, seconds, steps, sample columns, side measurements)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
     import oracle_binding as ob
+    block = 1024
+    fit = int(mem_available_bytes() // 4 // (5 * n)) // block * block
+    sample_cols = n if fit >= n else max(min(n, block), fit)
     net = ob.Net(n, model=ob.IZHIKEVICH)
-    # column window [0, sample_cols) of the same synthetic graph
     net.arr["weights"] = np.empty((n, sample_cols), np.float32)
     net.arr["connections"] = np.empty((n, sample_cols), np.uint8)
     net.w_col0, net.w_ld = 0, sample_cols
-    ob.lib().snn_o_fill_graph_window(net["weights"].ctypes.data_as(ob.f32p), net["connections"].ctypes.data_as(ob.u8p),
-                                     n, n, 0, sample_cols, 2, 0.5, 1.5, 0)
+    ob.lib().snn_o_fill_graph_window_blocked(net["weights"].ctypes.data_as(ob.f32p), net["connections"].ctypes.data_as(ob.u8p),
+                                             n, n, 0, sample_cols, block, 2, 0.5, 1.5, 0, threads)
     net["gap_conductance"] = 10.0
     net["current_voltage"] = ob.uniform_array(1, n, -65.0, 30.0)
     net.n_threads = threads
     t0 = time.perf_counter()
-    net.inputs(0, sample_cols)            # warm-up (page-in) + calibration of the sample length
+    net.inputs_tiled(0, sample_cols, block)            # warm-up + calibration of the sample length
     one = time.perf_counter() - t0
-    if steps is None:                     # aim at ~12 s of CPU work
-        steps = int(min(200, max(2, 12.0 / max(one, 1e-3))))
+    steps = int(min(50, max(10 if one < 3.0 else 3, budget_s / max(one, 1e-3))))
     t0 = time.perf_counter()
     for _ in range(steps):
-        net.inputs(0, sample_cols)        # O(N) synapses per sampled neuron: the whole per-neuron cost
-        net.update_neurons()              # O(1) per neuron (all N, negligible)
+        net.inputs_tiled(0, sample_cols, block)        # O(N) synapses per neuron: the whole per-neuron cost
+        net.update_neurons()                           # O(1) per neuron (all N, negligible)
     dt = time.perf_counter() - t0
-    extra = {}
-    # single thread (the reference's parallel = false), on a slice of the sample
+    extra = {"host_stream_GBps": 5.0 * n * sample_cols * steps / dt / 1e9}
+    # single thread (the reference's parallel = false), on one tile column of the sample
     net.n_threads = 1
-    cols1 = min(sample_cols, 256)
+    cols1 = min(sample_cols, block)
     t0 = time.perf_counter()
-    net.inputs(0, cols1)
+    net.inputs_tiled(0, cols1, block)
     extra["single_thread_value"] = cols1 / (time.perf_counter() - t0)
+    extra["all_core_speedup_over_single_thread"] = (sample_cols * steps / dt) / extra["single_thread_value"]
     # BASELINE configs[0] in full: 32x32, 1000 steps, the reference's own CPU-runnable case
     c1 = ob.Net(1024, model=ob.IZHIKEVICH)
     c1["gap_conductance"] = 10.0
@@ -81,7 +106,7 @@ def cpu_baseline(n, sample_cols, steps, threads):
         t0 = time.perf_counter()
         c1.run(1000)
         extra[key] = time.perf_counter() - t0
-    return sample_cols * steps / dt, dt, steps, extra
+    return sample_cols * steps / dt, dt, steps, sample_cols, extra
 
 
 def build_config(args, snn_amd, synthetic, np, rank, world, local_rank):
@@ -172,9 +197,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="timed repetitions of --steps steps inside this process; the line reports the median")
     ap.add_argument("--rows", type=int, default=ROWS)
     ap.add_argument("--cols", type=int, default=COLS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--spike-fraction", type=float, default=0.0,
+                    help="synthetic drive: before every step this fraction of the neurons is raised above threshold "
+                         "(device-side generator, snn_set_synthetic_drive), e.g. --config c4 --spike-fraction 0.001 to "
+                         "time STDP under load; 0 (default) leaves the workload as BASELINE.md defines it")
     ap.add_argument("--force-sharded", action="store_true",
                     help="take the multi-GPU code path (shard handle, RCCL exchange per step) even at world size 1")
     ap.add_argument("--stepper", default="library", choices=["library", "torch"],
@@ -235,16 +266,40 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.spike_fraction > 0:
+        dn.set_synthetic_drive(12345, args.spike_fraction, 35.0)
+    dn.set_reduced_history(False, False, True)           # per-neuron spike totals (4 B per neuron, in k_update)
+    def own_spike_total():
+        return sum(int(dn.spike_counts(i).sum()) for i, (_, _, st) in dn.lattices.items() if not st)
+
     run(args.warmup)
+    spikes_before = own_spike_total()
     dn.profile_enable(not args.no_kernel_events)
     dn.profile_reset()
-    barrier()
-    t0 = time.perf_counter()
-    run(args.steps)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    # the timed region (EXACTLY --steps steps between barrier + synchronize on both sides, max over ranks)
+    # is repeated --repeats times back to back; the line reports the MEDIAN repetition and lists all of them
+    runs = []
+    for _ in range(max(1, args.repeats)):
+        barrier()
+        t0 = time.perf_counter()
+        run(args.steps)
+        barrier()
+        e = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([e], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            e = float(t.item())
+        runs.append(e)
+    elapsed = sorted(runs)[len(runs) // 2]
     launches, kern_ms = dn.profile_read()
+    pl_steps, pl_ms = dn.profile_read_plasticity()
     dn.profile_enable(False)
+    spikes = own_spike_total() - spikes_before           # of this rank's own neurons
+    if dist is not None:
+        t = torch.tensor([spikes], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        spikes = int(t.item())
+    total_steps = args.steps * len(runs)
 
     hist_value = None
     if not sharded and args.config == "c2":
@@ -257,11 +312,6 @@ def main():
         barrier()
         hist_value = n * hsteps / (time.perf_counter() - t0)
         dn.set_history(voltage=False, spikes=False)
-
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
 
     ceilings = None
     if rank == 0 and not sharded and args.config == "c2":
@@ -278,6 +328,13 @@ def main():
             "metric": "neuron-steps/sec", "value": value, "unit": "neuron-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "repeats": len(runs), "ms_per_step_runs": [r / args.steps * 1e3 for r in runs],
+            "ms_per_step_min": min(runs) / args.steps * 1e3, "ms_per_step_max": max(runs) / args.steps * 1e3,
+            "spikes_per_step": spikes / total_steps,
+            "plasticity": ({"ms_per_step": pl_ms / pl_steps, "steps_measured": pl_steps,
+                            "touched_bytes_per_step": 8.0 * (dn.n_tot + (dn.post_end - dn.post_begin)) * spikes / total_steps / world,
+                            "note": "spike compaction + column/row weight updates of this rank, HIP events; touched bytes = "
+                                    "8 B x (n_tot + n_local) per spiking neuron"} if pl_steps else None),
             "scaling": "strong",      # --gpus N shards the SAME lattice: total work fixed as N grows
             "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
@@ -287,19 +344,20 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic(args.config, world, args.rows, args.cols),
+                         "traffic_source": pmc_source(args.config, world, args.rows, args.cols),
                          "kernel": kernel_name, "measured_device_ceilings": ceilings,
                          "frac_of_measured_read_ceiling": (achieved / ceilings["read_only_GBps"]) if ceilings else None,
                          "launches": launches, "avg_launch_ms": avg_ms,
                          "algorithmic_bytes_per_launch": bytes_per_launch},
         }
         if world == 1 and not args.no_cpu_baseline and args.config in ("c1", "c2"):
-            threads = os.cpu_count() or 1
-            sample = min(n, max(4096, 64 * threads))      # >= 4 column blocks of 16 per thread
-            v, secs, cpu_steps, extra = cpu_baseline(n, sample, None, threads)
+            threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            v, secs, cpu_steps, sample, extra = cpu_baseline(n, threads)
             out["cpu_baseline"] = {"value": v, "unit": "neuron-steps/s", "cores": threads, "kind": "port", **extra,
-                                   "sample": f"oracle (C restatement, OpenMP x{threads}) on {sample} of {n} postsynaptic "
-                                             f"neurons x {cpu_steps} steps ({secs:.1f} s); each sampled neuron sums all "
-                                             f"{n} presynaptic terms, i.e. the full per-neuron-step cost"}
+                                   "sample": f"oracle (C restatement, OpenMP x{threads}, tiles of 1024 columns x 256 rows) on "
+                                             f"{sample} of {n} postsynaptic neurons x {cpu_steps} steps ({secs:.1f} s); every "
+                                             f"sampled neuron sums all {n} presynaptic terms, i.e. the full per-neuron-step "
+                                             f"cost; bound by host memory bandwidth (host_stream_GBps, 5 B per synapse)"}
         result = json.dumps(out)
     else:
         result = None

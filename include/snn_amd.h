@@ -321,9 +321,11 @@ int snn_get_traces_csr(snn_network_t *net, float *traces, uint64_t nnz);
 int snn_set_firing_times(snn_network_t *net, uint32_t id, const uint32_t *cell_ptr, const float *times, size_t n_times);
 
 /* update_graph_history (Lattice::update_graph_history, neuron/mod.rs:572; AdjacencyMatrix::update_history
- * graph/mod.rs:278-280): one snapshot of lattice `id`'s internal weights per recorded step, taken AFTER the step's
- * weight update (the single-lattice order, neuron/mod.rs:908-910), [steps][rows*cols][rows*cols] (presynaptic index
- * first, absent edges 0), on the step axis of snn_history_steps.  Dense unsharded handles. */
+ * graph/mod.rs:278-280): one snapshot of lattice `id`'s internal weights per recorded step,
+ * [steps][rows*cols][rows*cols] (presynaptic index first, absent edges 0), on the step axis of snn_history_steps.
+ * enable = 1: taken AFTER the step's weight updates (a lone Lattice, neuron/mod.rs:904-910); enable = 2: BEFORE them
+ * (LatticeNetwork::iterate / iterate_with_neurotransmission, neuron/mod.rs:2450-2461, 2566-2577); 0 = off.
+ * Dense unsharded handles. */
 int snn_set_graph_history(snn_network_t *net, uint32_t id, int enable);
 int snn_get_graph_history(snn_network_t *net, uint32_t id, float *dst, size_t steps);
 
@@ -353,6 +355,14 @@ int snn_get_spike_counts(snn_network_t *net, uint32_t id, uint32_t *dst, size_t 
 int snn_profile_enable(snn_network_t *net, int enable);
 int snn_profile_reset(snn_network_t *net);
 int snn_profile_read(snn_network_t *net, uint64_t *launches, double *total_ms);
+/* The same for the plasticity launches of a step (spike compaction + weight updates): steps measured, summed ms */
+int snn_profile_read_plasticity(snn_network_t *net, uint64_t *steps, double *total_ms);
+/* Synthetic drive -- a device-side input generator for benchmarks and load tests, OFF by default (fraction 0), not part
+ * of the reference's semantics: before the step at clock t every neuron q with hash32(seed, t * n_neurons + q) <
+ * fraction * 2^32 (the splitmix64 generator of snn_fill_graph_synthetic) has current_voltage set to `voltage`.  With
+ * `voltage` above the spike threshold a chosen fraction of the population spikes every step, so STDP can be measured
+ * under load.  Applied identically on every shard handle. */
+int snn_set_synthetic_drive(snn_network_t *net, uint64_t seed, float fraction, float voltage);
 /* Algorithmic bytes ONE launch of the synaptic-input kernel moves (DESIGN.md "Roofline") */
 int snn_input_kernel_bytes(const snn_network_t *net, uint64_t *bytes);
 

@@ -8,6 +8,7 @@
 #include "snn_oracle_math.h"
 
 #include <stddef.h>
+#include <stdlib.h>
 
 static float custom_refractoriness_effect(const snn_o_net *n, uint32_t s);
 typedef struct { snn_o_net *n; uint32_t q, spiking_prev; } program_ctx;   /* the neuron an on_electrochemical_iteration runs on */
@@ -279,6 +280,96 @@ void snn_o_inputs_range(snn_o_net *n, uint32_t q0, uint32_t q1)
 }
 
 void snn_o_inputs(snn_o_net *n) { snn_o_inputs_range(n, 0, n->n_neurons); }
+
+/*
+ * The same electrical input sums for postsynaptic neurons [q0, q1), arranged for memory bandwidth on many cores (the
+ * all-core CPU baseline of bench.py; rayon's par_iter over postsynaptic neurons in the reference,
+ * neuron/mod.rs:775-790): the matrix is cut into tiles of `block` adjacent columns x one reduction chunk of 256
+ * presynaptic rows, every thread streams whole `block`-wide row segments (block = 1024 floats = one 4 KiB page per
+ * row), the inner loop runs across the columns of the segment (one independent sequential sum per column -- SIMD
+ * across columns does not change any column's order of additions), and the chunk partials are then added per
+ * column in ascending chunk order from 0.0f.  Bit-identical to snn_o_inputs_range (tests/test_oracle_vs_numpy.py).
+ * Restricted to what the baseline workload needs: electrical synapses, every presynaptic row a neuron; anything
+ * else takes the general routine.
+ */
+void snn_o_inputs_tiled(snn_o_net *n, uint32_t q0, uint32_t q1, uint32_t block)
+{
+    const uint32_t nn = n->n_neurons;
+    if (n->chemical || !n->electrical || n->n_cells || q1 <= q0 || block == 0) { snn_o_inputs_range(n, q0, q1); return; }
+    const size_t ld = n->w_ld ? n->w_ld : nn;
+    const uint32_t col0 = n->w_col0;
+    const uint32_t ncols = q1 - q0;
+    const int64_t nblk = (ncols + block - 1) / block;
+    const int64_t nchunks = (nn + SNN_O_CHUNK - 1) / SNN_O_CHUNK;
+    float *part = (float *)malloc((size_t)nchunks * ncols * sizeof(float));
+    uint32_t *pcnt = (uint32_t *)malloc((size_t)nchunks * ncols * sizeof(uint32_t));
+    if (!part || !pcnt) { free(part); free(pcnt); snn_o_inputs_range(n, q0, q1); return; }
+#if defined(_OPENMP)
+    int nt = n->n_threads > 1 ? n->n_threads : 1;
+    #pragma omp parallel for collapse(2) schedule(static) num_threads(nt)
+#endif
+    for (int64_t b = 0; b < nblk; ++b)
+        for (int64_t c = 0; c < nchunks; ++c) {
+            const uint32_t j0 = (uint32_t)b * block;
+            const uint32_t w = (ncols - j0 < block) ? ncols - j0 : block;
+            float *acc = part + (size_t)c * ncols + j0;
+            uint32_t *cnt = pcnt + (size_t)c * ncols + j0;
+            const float *vq = n->current_voltage + q0 + j0, *gq = n->gap_conductance + q0 + j0;
+            for (uint32_t j = 0; j < w; ++j) { acc[j] = 0.0f; cnt[j] = 0; }
+            const uint32_t p1 = ((uint32_t)(c + 1) * SNN_O_CHUNK < nn) ? (uint32_t)(c + 1) * SNN_O_CHUNK : nn;
+            for (uint32_t p = (uint32_t)c * SNN_O_CHUNK; p < p1; ++p) {
+                const float *wrow = n->weights + (size_t)p * ld + (q0 - col0) + j0;
+                const uint8_t *crow = n->connections + (size_t)p * ld + (q0 - col0) + j0;
+                const float pv = n->current_voltage[p];
+#if defined(_OPENMP)
+                #pragma omp simd
+#endif
+                for (uint32_t j = 0; j < w; ++j) {
+                    const float term = (gq[j] * (pv - vq[j])) * wrow[j];
+                    acc[j] = crow[j] ? acc[j] + term : acc[j];
+                    cnt[j] += crow[j] ? 1u : 0u;
+                }
+            }
+        }
+#if defined(_OPENMP)
+    #pragma omp parallel for schedule(static) num_threads(nt)
+#endif
+    for (int64_t j = 0; j < (int64_t)ncols; ++j) {
+        float sum = 0.0f;
+        uint32_t n_in = 0;
+        for (int64_t c = 0; c < nchunks; ++c) { sum += part[(size_t)c * ncols + j]; n_in += pcnt[(size_t)c * ncols + j]; }
+        n->input_current[q0 + j] = sum / ((n_in == 0) ? 1.0f : (float)n_in);      /* mod.rs:722-727 */
+    }
+    free(part);
+    free(pcnt);
+}
+
+/* first touch of a [n_tot][ncols] window by the threads that will stream it in snn_o_inputs_tiled (column blocks) */
+void snn_o_fill_graph_window_blocked(float *weights, uint8_t *connections, uint32_t n_tot, uint32_t n_neurons,
+                                     uint32_t col0, uint32_t ncols, uint32_t block, uint64_t seed, float lo, float hi,
+                                     int with_diagonal, int n_threads)
+{
+    const int64_t nblk = (ncols + block - 1) / block;
+    const int64_t nchunks = (n_tot + SNN_O_CHUNK - 1) / SNN_O_CHUNK;
+#if defined(_OPENMP)
+    int nt = n_threads > 1 ? n_threads : 1;
+    #pragma omp parallel for collapse(2) schedule(static) num_threads(nt)
+#endif
+    for (int64_t b = 0; b < nblk; ++b)
+        for (int64_t c = 0; c < nchunks; ++c) {
+            const uint32_t j0 = (uint32_t)b * block;
+            const uint32_t j1 = (j0 + block < ncols) ? j0 + block : ncols;
+            const uint32_t p1 = ((uint32_t)(c + 1) * SNN_O_CHUNK < n_tot) ? (uint32_t)(c + 1) * SNN_O_CHUNK : n_tot;
+            for (uint32_t p = (uint32_t)c * SNN_O_CHUNK; p < p1; ++p)
+                for (uint32_t j = j0; j < j1; ++j) {
+                    const uint32_t q = col0 + j;
+                    const size_t i = (size_t)p * ncols + j;
+                    const int e = with_diagonal || p != q;
+                    connections[i] = (uint8_t)e;
+                    weights[i] = e ? snn_o_uniform(seed, (uint64_t)p * n_neurons + q, lo, hi) : 0.0f;
+                }
+        }
+}
 
 /* ---------- step 2: neuron update ---------- */
 

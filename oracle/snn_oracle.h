@@ -243,6 +243,11 @@ void snn_o_plasticity_cols(snn_o_net *net, uint32_t c0, uint32_t c1);
 void snn_o_spike_trains(snn_o_net *net);
 /* Whole loop (steps 1-6) `iterations` times, filling the optional histories. */
 void snn_o_run(snn_o_net *net, uint64_t iterations);
+/* Step 1 for [q0, q1) arranged for all-core memory bandwidth (bench.py's cpu_baseline); same results bit for bit */
+void snn_o_inputs_tiled(snn_o_net *n, uint32_t q0, uint32_t q1, uint32_t block);
+void snn_o_fill_graph_window_blocked(float *weights, uint8_t *connections, uint32_t n_tot, uint32_t n_neurons,
+                                     uint32_t col0, uint32_t ncols, uint32_t block, uint64_t seed, float lo, float hi,
+                                     int with_diagonal, int n_threads);
 
 /* Single-formula entry points (known-answer tests, GPU device-function parity). */
 float snn_o_expf_export(float x);

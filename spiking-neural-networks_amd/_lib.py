@@ -163,6 +163,8 @@ SIGNATURES = {
     "snn_profile_enable": (C.c_int, [H, C.c_int]),
     "snn_profile_reset": (C.c_int, [H]),
     "snn_profile_read": (C.c_int, [H, u64p, C.POINTER(C.c_double)]),
+    "snn_profile_read_plasticity": (C.c_int, [H, u64p, C.POINTER(C.c_double)]),
+    "snn_set_synthetic_drive": (C.c_int, [H, C.c_uint64, C.c_float, C.c_float]),
     "snn_input_kernel_bytes": (C.c_int, [H, u64p]),
     "snn_probe_bandwidth": (C.c_int, [C.c_int, C.c_uint64, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "snn_probe_math": (C.c_int, [C.c_int, C.c_int, f32p, f32p, C.c_size_t]),

@@ -60,7 +60,25 @@ struct InputsArgs {
     // transmitter types some neuron or cell of the handle releases (launch-uniform): slot s of a kernel specialised
     // on NT live types handles type live_type[s]; the partial planes of the other types stay zero
     uint32_t live_type[K_TYPES];
+    // STDP of the previous step riding on this pass (k_inputs_dense<..., STDP = true>, see StdpDeferred below)
+    float *W_rw;                      // = W, writable
+    const uint32_t *stdp_count;       // neurons that spiked in the previous step and whose lattice is plastic; 0: plain pass
+    const uint32_t *stdp_flag;        // [n_pad] 1 for those neurons
+    const float *stdp_dcol;           // [n_lattices][dcol_stride] delta of edge (p -> a post of lattice l that just spiked)
+    const float *stdp_drow;           // [ld] delta of edge (a pre that just spiked -> local post r)
+    const uint32_t *lattice_slot;     // [n_pad]
+    uint32_t dcol_stride, n_lattices;
 };
+
+// Deferred STDP (dense handles): what STDP::update_weight (plasticity/mod.rs:45-66) adds to an edge in the deferred
+// form depends on ONE end of the edge only once the other end is a neuron that spiked in the step
+// being closed at clock t: an incoming edge p -> j of a spiking j gets delta(last_firing_time[p], t) -- a function of
+// the row p and of j's lattice parameters; an outgoing edge j -> r gets delta(t, last_firing_time[r]) -- a function
+// of the column r.  k_stdp_prepare evaluates both vectors at the end of step t (before the spike trains advance);
+// the weight itself is rewritten by the NEXT step's input pass, which streams the whole matrix anyway: a lane that
+// owns a flagged column adds dcol[row], a flagged row adds drow[column], column first then row as the standalone
+// kernels do, and only changed words are stored.  The read half of the scattered column update disappears.
+constexpr int STDP_MAX_LATTICES = 4;
 
 // kind word per staged presynaptic row: bits 0..1 = 0 neuron | 1 spike train that never fired |
 // 2 spike train that fired; bits 8..10 = carries neurotransmitter type k
@@ -111,7 +129,7 @@ __device__ __forceinline__ float acc_if_edge(float acc, float term, float w)
 // NT: number of live transmitter types the launch is specialised on (1..3; only read when CHEM).  A network whose
 // cells all release one type (BASELINE configs[2]: AMPA) then carries VEC accumulators for it instead of 3 * VEC, no
 // per-row tests of the other types, and the two-register-buffer sweep of the electrical pass.
-template <bool ELEC, bool CHEM, int STREAM = 1, int NT = K_TYPES>
+template <bool ELEC, bool CHEM, int STREAM = 1, int NT = K_TYPES, bool STDP = false>
 __global__ __launch_bounds__(InputsShape<STREAM>::THREADS) void k_inputs_dense(const InputsArgs a)
 {
     using S = InputsShape<STREAM>;
@@ -122,6 +140,10 @@ __global__ __launch_bounds__(InputsShape<STREAM>::THREADS) void k_inputs_dense(c
     __shared__ float s_val[CHUNK];
     __shared__ uint32_t s_kind[CHUNK];
     __shared__ float s_t[TS][CHUNK];
+    __shared__ float s_dcol[STDP ? STDP_MAX_LATTICES : 1][STDP ? CHUNK : 1];
+    __shared__ uint32_t s_rowflag[STDP ? CHUNK : 1];
+    // the previous step's weight updates ride on this pass only if some plastic neuron spiked in it (launch-uniform)
+    const bool stdp_live = STDP && *a.stdp_count != 0u;
 
     uint32_t chunk = a.chunk_first + blockIdx.y;
     if (chunk >= a.hole_begin) chunk += a.hole_count;
@@ -178,6 +200,12 @@ __global__ __launch_bounds__(InputsShape<STREAM>::THREADS) void k_inputs_dense(c
                 }
             }
         }
+        if (STDP && stdp_live) {
+            s_rowflag[i] = (p < a.n_neurons) ? a.stdp_flag[p] : 0u;
+#pragma unroll
+            for (int l = 0; l < STDP_MAX_LATTICES; ++l)
+                if ((uint32_t)l < a.n_lattices) s_dcol[l][i] = a.stdp_dcol[(size_t)l * a.dcol_stride + p];
+        }
         s_val[i] = val;
         s_kind[i] = kind;
         kinds_and &= kind | ~0x703u;
@@ -218,6 +246,79 @@ __global__ __launch_bounds__(InputsShape<STREAM>::THREADS) void k_inputs_dense(c
             gq[j] = 0.0f;
         }
     }
+
+    // deferred STDP: this lane's columns that spiked in the previous step, their lattice and the row-update deltas
+    bool cf[VEC];
+    uint32_t clat[VEC];
+    float dr[VEC];
+    bool wave_cols = false;
+    uint32_t wave_lat = 0;        // lattice of the wave's flagged columns when they share one (the usual case), else ~0
+    if (STDP && stdp_live) {
+        uint32_t lat_mask = 0;    // lattices among this lane's flagged columns
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const uint32_t q = ql + j;
+            const bool in = q < a.n_loc;
+            cf[j] = in && a.stdp_flag[a.q0 + q] != 0u;
+            clat[j] = in ? a.lattice_slot[a.q0 + q] : 0u;
+            dr[j] = in ? a.stdp_drow[q] : 0.0f;
+            lat_mask |= cf[j] ? (1u << clat[j]) : 0u;
+        }
+        uint32_t wave_mask = 0;
+#pragma unroll
+        for (int l = 0; l < STDP_MAX_LATTICES; ++l) wave_mask |= __any((lat_mask >> l) & 1u) ? (1u << l) : 0u;
+        wave_cols = wave_mask != 0u;
+        wave_lat = (wave_mask & (wave_mask - 1u)) ? 0xFFFFFFFFu : (uint32_t)__builtin_ctz(wave_mask | 0x80000000u);
+    }
+    // one row of the deferred update: column delta first, then row delta (the order of the standalone kernels);
+    // absent edges stay absent; only words that changed are written back.  Branch-free per column: the delta of the
+    // row is a wave-uniform LDS broadcast (one per lattice present), selected per lane.
+    auto stdp_row = [&](uint32_t r, float (&w)[VEC], bool row_spiked) {
+        float dl[STDP_MAX_LATTICES];
+        if (wave_lat != 0xFFFFFFFFu) {
+            dl[0] = s_dcol[wave_lat][r];
+        } else {
+#pragma unroll
+            for (int l = 0; l < STDP_MAX_LATTICES; ++l) dl[l] = ((uint32_t)l < a.n_lattices) ? s_dcol[l][r] : 0.0f;
+        }
+        bool changed[VEC];
+        bool any_changed = false;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            float d = dl[0];
+            if (wave_lat == 0xFFFFFFFFu) {
+#pragma unroll
+                for (int l = 1; l < STDP_MAX_LATTICES; ++l) d = (clat[j] == (uint32_t)l) ? dl[l] : d;
+            }
+            const float w0 = w[j];
+            float wn = cf[j] ? w0 + d : w0;
+            wn = row_spiked ? wn + dr[j] : wn;
+            changed[j] = (w0 == w0) && __float_as_uint(wn) != __float_as_uint(w0);
+            w[j] = changed[j] ? wn : w0;
+            any_changed = any_changed || changed[j];
+        }
+        // Write-back in whole 128-byte lines: a lone 4-byte store makes the memory side read the rest of the line
+        // before it can write it; when any lane of the 128 B-aligned lane group changed a word, every lane of the
+        // group stores its (unchanged or changed) VEC words, so the line is overwritten in full.
+        constexpr uint32_t GROUP = 128 / (4 * VEC);                // lanes per 128 B: 8 (VEC 4), 16 (VEC 2)
+        const unsigned long long votes = __ballot(any_changed);
+        if (votes) {
+            const uint32_t lane = tid & 63u;
+            const unsigned long long mine = (votes >> (lane & ~(GROUP - 1u))) & ((1ull << GROUP) - 1ull);
+            if (mine) {
+                float *dst = a.W_rw + (size_t)(p0 + r) * ld + ql;
+                if constexpr (STREAM == 1) {
+                    v4f v; v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
+                    *reinterpret_cast<v4f *>(dst) = v;
+                } else if constexpr (STREAM == 2) {
+                    v2f v; v.x = w[0]; v.y = w[1];
+                    *reinterpret_cast<v2f *>(dst) = v;
+                } else {
+                    dst[0] = w[0];
+                }
+            }
+        }
+    };
 
     float acc[VEC];
     float tacc[TS][VEC];
@@ -280,13 +381,27 @@ __global__ __launch_bounds__(InputsShape<STREAM>::THREADS) void k_inputs_dense(c
     const bool plain = !CHEM && (p0 + rows <= a.n_neurons);   // workgroup-uniform
     if (plain) {
         // all presynaptic rows are neurons, electrical only: the C1/C2 inner loop
-        sweep([&](uint32_t r, const float (&w)[VEC]) {
+        sweep([&](uint32_t r, const float (&w_in)[VEC]) {
+            float w[VEC];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) w[j] = w_in[j];
+            if (STDP && stdp_live) {
+                const bool rs = __builtin_amdgcn_readfirstlane(s_rowflag[r]) != 0u;
+                if (wave_cols || rs) stdp_row(r, w, rs);
+            }
             const float vp = s_val[r];
 #pragma unroll
             for (int j = 0; j < VEC; ++j) acc[j] = acc_if_edge(acc[j], gq[j] * (vp - vq[j]), w[j]);
         });
     } else if (uniform_chunk) {
-        sweep([&](uint32_t r, const float (&w)[VEC]) {
+        sweep([&](uint32_t r, const float (&w_in)[VEC]) {
+            float w[VEC];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) w[j] = w_in[j];
+            if (STDP && stdp_live) {
+                const bool rs = __builtin_amdgcn_readfirstlane(s_rowflag[r]) != 0u;
+                if (wave_cols || rs) stdp_row(r, w, rs);
+            }
             if (ELEC) {
                 const float vp = s_val[r];
 #pragma unroll
@@ -302,7 +417,14 @@ __global__ __launch_bounds__(InputsShape<STREAM>::THREADS) void k_inputs_dense(c
             }
         });
     } else {
-        sweep([&](uint32_t r, const float (&w)[VEC]) {
+        sweep([&](uint32_t r, const float (&w_in)[VEC]) {
+            float w[VEC];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) w[j] = w_in[j];
+            if (STDP && stdp_live) {
+                const bool rs = __builtin_amdgcn_readfirstlane(s_rowflag[r]) != 0u;
+                if (wave_cols || rs) stdp_row(r, w, rs);
+            }
             const uint32_t kind = __builtin_amdgcn_readfirstlane(s_kind[r]);
             if (ELEC) {
                 const float vp = s_val[r];

@@ -210,6 +210,12 @@ struct StdpArgs {
     const uint32_t *do_plasticity;        // [n_lattices]
     uint32_t *spike_list;                 // compacted gated spiking neurons (global indices)
     uint32_t *spike_count;
+    // deferred STDP (dense handles, see snn_kernels_inputs.hpp): flag per neuron + the two delta vectors
+    uint32_t *flag;                       // [n_pad] or null: 1 for every listed neuron, 0 otherwise
+    float *dcol;                          // [n_lattices][dcol_stride]
+    float *drow;                          // [ld]
+    uint32_t dcol_stride, n_lattices;
+    long long clock;                      // the step being closed (= last_firing_time of the listed neurons)
 };
 
 // Wave-ballot + popcount prefix compaction of the neurons that spiked in this step and whose
@@ -221,6 +227,7 @@ __global__ __launch_bounds__(256) void k_spike_compact(const StdpArgs a)
     if (q < a.n_neurons) {
         const uint32_t spk = reinterpret_cast<const uint32_t *>(a.xbuf)[a.xl.at(q, PLANE_SPIKE)];
         hit = spk && a.do_plasticity[a.lattice_slot[q]];
+        if (a.flag) a.flag[q] = hit ? 1u : 0u;
     }
     const unsigned long long mask = __ballot(hit);
     if (mask == 0) return;
@@ -231,6 +238,58 @@ __global__ __launch_bounds__(256) void k_spike_compact(const StdpArgs a)
     if (hit) {
         const uint32_t prefix = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
         a.spike_list[base + prefix] = q;
+    }
+}
+
+// Deferred STDP, evaluated at the end of the step that produced the spike list (before the spike trains advance):
+//   dcol[l][p] = what an incoming edge p -> j gains when j (lattice l) spiked now:  stdp_delta(lft[p], clock; l)
+//   drow[r]    = what an outgoing edge j -> r gains when j spiked now:              stdp_delta(clock, lft[q0 + r]; lattice of r)
+// -- exactly the deltas k_stdp_columns / k_stdp_rows add (t_post resp. t_pre of a listed neuron is the clock).
+__global__ __launch_bounds__(256) void k_stdp_prepare(const StdpArgs a)
+{
+    if (*a.spike_count == 0u) return;
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const int32_t now = (int32_t)a.clock;
+    if (i < a.n_tot) {
+        const int32_t tp = (i < a.n_neurons) ? a.last_firing_time[i] : a.st_last_firing_time[i - a.n_neurons];
+        for (uint32_t l = 0; l < a.n_lattices; ++l) {
+            const float *prm = a.stdp + PL_STRIDE * l;
+            a.dcol[(size_t)l * a.dcol_stride + i] = stdp_delta(tp, now, prm[0], prm[1], prm[2], prm[3], prm[4]);
+        }
+    }
+    if (i < a.n_loc) {
+        const uint32_t gr = a.q0 + i;
+        const float *prm = a.stdp + PL_STRIDE * a.lattice_slot[gr];
+        a.drow[i] = stdp_delta(now, a.last_firing_time[gr], prm[0], prm[1], prm[2], prm[3], prm[4]);
+    }
+}
+
+// The deferred update as standalone passes (a host access to the weights, the end of a run): the same two scatters as
+// k_stdp_columns / k_stdp_rows with the prepared deltas.
+__global__ __launch_bounds__(256) void k_stdp_apply_columns(const StdpArgs a)
+{
+    const uint32_t count = *a.spike_count;
+    const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= a.n_tot) return;
+    for (uint32_t s = blockIdx.y; s < count; s += gridDim.y) {
+        const uint32_t j = a.spike_list[s];
+        if (j < a.q0 || j >= a.q0 + a.n_loc) continue;
+        float *wp = a.W + (size_t)p * a.ld + (j - a.q0);
+        const float w = *wp;
+        if (w == w) *wp = w + a.dcol[(size_t)a.lattice_slot[j] * a.dcol_stride + p];
+    }
+}
+__global__ __launch_bounds__(256) void k_stdp_apply_rows(const StdpArgs a)
+{
+    const uint32_t count = *a.spike_count;
+    const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= a.n_loc) return;
+    const float d = a.drow[r];
+    for (uint32_t s = blockIdx.y; s < count; s += gridDim.y) {
+        const uint32_t j = a.spike_list[s];
+        float *wp = a.W + (size_t)j * a.ld + r;
+        const float w = *wp;
+        if (w == w) *wp = w + d;
     }
 }
 
@@ -338,6 +397,16 @@ __global__ __launch_bounds__(256) void k_probe_copy(const probe_v4f *src, probe_
 {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256)
         __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+}
+
+// Synthetic drive (benchmarks and load tests only, off by default): before the step at `clock`, every neuron q with
+// hash32(seed, clock * n + q) < threshold has its membrane voltage set to `voltage` -- a device-side generator of a
+// chosen spike rate, so that plasticity can be measured under load without the host touching the state each step.
+__global__ void k_synthetic_drive(float *xbuf, XLayout xl, uint32_t n, uint64_t seed, long long clock, uint32_t threshold,
+                                  float voltage)
+{
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < n && hash32(seed, (uint64_t)clock * n + q) < threshold) xbuf[xl.at(q, PLANE_V)] = voltage;
 }
 
 // device-function probe for the parity tests of the scalar formulas

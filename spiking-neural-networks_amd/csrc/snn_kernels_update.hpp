@@ -437,7 +437,8 @@ __global__ __launch_bounds__(256) void k_update(const UpdateArgs a)
     // spike raster: one 64-bit ballot word per wavefront (shard boundaries are multiples of 64)
     if (a.spike_row) {
         const unsigned long long word = __ballot(spike != 0);
-        if ((threadIdx.x & 63) == 0 && (blockIdx.x * 256 + threadIdx.x) < a.ld)
+        // a raster row holds n_pad / 64 words; ld may exceed the padded population by one wavefront (row de-alignment)
+        if ((threadIdx.x & 63) == 0 && ql < a.ld && (a.q0 + ql) < a.n.n_pad)
             a.spike_row[(a.q0 + ql) >> 6] = word;
     }
 }

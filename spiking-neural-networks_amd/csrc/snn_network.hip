@@ -41,6 +41,7 @@ int snn_network_create(int device, int neuron_model, int nt_kinetics, int recept
     net->device = device;
     if (const char *e = getenv("SNN_AMD_FUSED_STEP")) net->fused_step = (e[0] != '0');
     if (const char *e = getenv("SNN_AMD_DEFER_RSTDP")) net->defer_rstdp = (e[0] != '0');
+    if (const char *e = getenv("SNN_AMD_DEFER_STDP")) net->defer_stdp = (e[0] != '0');
     net->model = neuron_model; net->nt_kind = nt_kinetics; net->rc_kind = receptor_kinetics;
     net->st_kind = spike_train_model;
     if (hipStreamCreateWithFlags(&net->own_stream, hipStreamNonBlocking) != hipSuccess) {
@@ -70,6 +71,7 @@ int snn_network_destroy(snn_network_t *net)
     if (net->summ_avg) (void)hipFree(net->summ_avg);
     if (net->summ_eeg) (void)hipFree(net->summ_eeg);
     for (auto &e : net->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    for (auto &e : net->ev_pool_pl) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     for (void *p : {(void *)net->halo_send_buf, (void *)net->halo_recv_buf, (void *)net->halo_send_idx, (void *)net->halo_recv_idx,
                     (void *)net->seg_count_dev[0], (void *)net->seg_count_dev[1], (void *)net->seg_first_dev[0],
                     (void *)net->seg_first_dev[1], (void *)net->seg_offset_dev[0], (void *)net->seg_offset_dev[1],
@@ -237,6 +239,9 @@ int snn_fill_graph_synthetic(snn_network_t *net, uint64_t seed, float lo, float 
     if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
     if (net->csr) return fail(SNN_ERR_BAD_STATE, "the synthetic dense graph needs a dense handle");
     HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
+    TRY(end_run(net));                     // a deferred reward-modulated update belongs to the OLD weights: apply it first
+    if (net->trace)                        // traces of the replaced edges do not carry over
+        HIP_TRY(hipMemsetAsync(net->trace, 0, std::max<size_t>((size_t)net->n_tot * net->ld, 64) * 4, net->stream), SNN_ERR_BUFFER_WRITE);
     if (net->n_tot && net->ld) {
         const unsigned gy = std::min<uint32_t>(net->n_tot, 4096);
         hipLaunchKernelGGL(k_graph_synthetic, dim3((net->ld + 255) / 256, gy), dim3(256), 0, net->stream, net->W,
@@ -256,8 +261,10 @@ int snn_network_use_csr(snn_network_t *net, int enable)
     return SNN_OK;
 }
 
-int snn_set_graph_csr(snn_network_t *net, const uint64_t *row_ptr, const uint32_t *pre_index, const float *weights,
-                      uint64_t nnz)
+namespace { int ensure_traces(snn_network *net); }
+
+static int set_graph_csr_impl(snn_network_t *net, const uint64_t *row_ptr, const uint32_t *pre_index, const float *weights,
+                              uint64_t nnz)
 {
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
     if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
@@ -333,7 +340,19 @@ int snn_set_graph_csr(snn_network_t *net, const uint64_t *row_ptr, const uint32_
     net->edge_slot_host.swap(edge_slot);
     net->counts_dirty = true;
     halo_needs_from_rows(net, pre_index, nnz);      // the new rows decide what is read from the other shards
+    // a reward-modulated handle keeps modulating: zeroed traces for the new edges (the old ones went with their edges)
+    if (net->any_modulation) TRY(ensure_traces(net));
     return SNN_OK;
+}
+
+int snn_set_graph_csr(snn_network_t *net, const uint64_t *row_ptr, const uint32_t *pre_index, const float *weights,
+                      uint64_t nnz)
+{
+    try {
+        return set_graph_csr_impl(net, row_ptr, pre_index, weights, nnz);
+    } catch (const std::bad_alloc &) {       // the host-side index arrays are sized by nnz: never let it cross the C ABI
+        return fail(SNN_ERR_BUFFER_CREATE, "out of host memory while building the sparse graph");
+    }
 }
 
 int snn_get_graph_csr(snn_network_t *net, float *weights, uint64_t nnz)
@@ -479,6 +498,8 @@ int snn_apply_reward(snn_network_t *net, float reward)
 
 int snn_run_with_reward(snn_network_t *net, float reward)
 {
+    // run_lattice_with_reward does nothing at all with both synapse kinds off (neuron/mod.rs:3250-3257)
+    if (net && net->finalized && !net->electrical && !net->chemical) return SNN_OK;
     int rc = snn_apply_reward(net, reward);
     return rc ? rc : snn_run(net, 1);
 }
@@ -606,8 +627,9 @@ int snn_set_graph_history(snn_network_t *net, uint32_t id, int enable)
     if (net->csr || net->sharded) return fail(SNN_ERR_BAD_STATE, "graph histories need a dense, unsharded handle");
     HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
     TRY(end_run(net));
+    if (enable < 0 || enable > 2) return fail(SNN_ERR_BAD_ARG, "enable: 0 off, 1 after the weight updates, 2 before them");
     if ((enable != 0) != (net->want_whist[l->slot] != 0)) { net->hist_steps = 0; net->hist_tick = 0; }
-    net->want_whist[l->slot] = enable ? 1 : 0;
+    net->want_whist[l->slot] = enable;
     net->any_whist = false;
     for (int v : net->want_whist) net->any_whist |= (v != 0);
     return SNN_OK;
@@ -723,7 +745,7 @@ int snn_run(snn_network_t *net, uint64_t iterations)
     for (uint64_t it = 0; it < iterations; ++it) {
         if (net->nn) TRY(step_begin(net));
         TRY(step_end(net));
-        if (net->profile && net->ev_used >= 8192) TRY(collect_profile(net));
+        if (net->profile && (net->ev_used >= 8192 || net->ev_used_pl >= 8192)) TRY(collect_profile(net));
     }
     return end_run(net);
 }
@@ -737,7 +759,7 @@ int snn_step_begin_local(snn_network_t *net)
     TRY(begin_run(net, 1));
     // Only when nothing of the previous step is still pending for these chunks: STDP rewrites W in
     // snn_step_end and needs the gathered spikes first, so with plasticity on the split is not taken.
-    if (net->nn && !net->csr && !net->any_plasticity && !net->any_modulation && !net->local_inputs_done) {
+    if (net->nn && !net->csr && !net->any_plasticity && !net->any_modulation && !net->drive_threshold && !net->local_inputs_done) {
         TRY(launch_inputs(net, INPUTS_LOCAL));
         net->local_inputs_done = true;
     }
@@ -972,7 +994,7 @@ int snn_run_sharded(snn_network_t *net, void *nccl_comm, uint64_t iterations)
     TRY(ensure_comm_objects(net));
     // The own-rows part of step t + 1's input pass does not read what the exchange of step t delivers: it is enqueued
     // before the compute stream waits for the collective (dense handles, no weight updates pending in step_end).
-    const bool split = !net->csr && !net->any_plasticity && !net->any_modulation && net->n_shards > 1;
+    const bool split = !net->csr && !net->any_plasticity && !net->any_modulation && !net->drive_threshold && net->n_shards > 1;
     for (uint64_t it = 0; it < iterations; ++it) {
         if (net->nn) TRY(step_begin(net));
         TRY(launch_exchange_pack(net));
@@ -1082,6 +1104,7 @@ int snn_profile_reset(snn_network_t *net)
     HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
     HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
     net->ev_used = 0; net->prof_launches = 0; net->prof_ms = 0.0;
+    net->ev_used_pl = 0; net->prof_launches_pl = 0; net->prof_ms_pl = 0.0;
     return SNN_OK;
 }
 int snn_profile_read(snn_network_t *net, uint64_t *launches, double *total_ms)
@@ -1093,6 +1116,29 @@ int snn_profile_read(snn_network_t *net, uint64_t *launches, double *total_ms)
     if (total_ms) *total_ms = net->prof_ms;
     return SNN_OK;
 }
+int snn_profile_read_plasticity(snn_network_t *net, uint64_t *steps, double *total_ms)
+{
+    if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
+    HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
+    TRY(collect_profile(net));
+    if (steps) *steps = net->prof_launches_pl;
+    if (total_ms) *total_ms = net->prof_ms_pl;
+    return SNN_OK;
+}
+
+int snn_set_synthetic_drive(snn_network_t *net, uint64_t seed, float fraction, float voltage)
+{
+    if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
+    if (!(fraction >= 0.0f && fraction <= 1.0f)) return fail(SNN_ERR_BAD_ARG, "fraction must be in [0, 1]");
+    HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
+    if (net->finalized) TRY(end_run(net));
+    net->drive_seed = seed;
+    net->drive_threshold = (uint32_t)std::min<double>(4294967295.0, (double)fraction * 4294967296.0);
+    net->drive_voltage = voltage;
+    net->shadow_valid = false;
+    return SNN_OK;
+}
+
 int snn_input_kernel_bytes(const snn_network_t *net, uint64_t *bytes)
 {
     if (!net || !bytes) return fail(SNN_ERR_BAD_ARG, "null argument");

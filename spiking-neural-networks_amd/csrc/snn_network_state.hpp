@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <new>
 #include <string>
 #include <utility>
 #include <vector>
@@ -148,6 +149,12 @@ struct snn_network {
     float *stdp_dev = nullptr;
     uint32_t *plast_dev = nullptr;
     uint32_t *spike_list = nullptr, *spike_count = nullptr;
+    // deferred STDP (dense handles): the update of step t is applied by the input pass of step t + 1
+    int defer_stdp = 1;                    // 0: always the standalone kernels (SNN_AMD_DEFER_STDP=0)
+    bool stdp_pending = false;
+    uint32_t *stdp_flag = nullptr;
+    float *stdp_dcol = nullptr, *stdp_drow = nullptr;
+    uint32_t dcol_stride = 0;
     long long *st_clock_dev = nullptr;
     long long run_step_offset = 0;
     bool run_active = false;        // a (possibly externally driven) run is open: device clocks are ahead of st_clock
@@ -180,6 +187,15 @@ struct snn_network {
     float *vhist = nullptr, *st_vhist = nullptr;
     unsigned long long *raster = nullptr;
 
+    // synthetic drive (snn_set_synthetic_drive): off when drive_threshold == 0
+    uint64_t drive_seed = 0;
+    uint32_t drive_threshold = 0;
+    float drive_voltage = 0.0f;
+    // profiling of the plasticity launches (spike compaction + weight updates), same switch as below
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool_pl;
+    size_t ev_used_pl = 0;
+    uint64_t prof_launches_pl = 0;
+    double prof_ms_pl = 0.0;
     // profiling of the synaptic-input kernel
     int profile = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
@@ -507,6 +523,14 @@ int build_state(snn_network *net)
             SNN_ERR_BUFFER_WRITE);
     TRY(dev_alloc_t(net, &net->spike_list, np));
     TRY(dev_alloc_t(net, &net->spike_count, 1));
+    HIP_TRY(hipMemsetAsync(net->spike_count, 0, 4, net->stream), SNN_ERR_BUFFER_WRITE);
+    if (!net->csr) {
+        net->dcol_stride = round_up(std::max<uint32_t>(net->n_tot, 1), 256);
+        TRY(dev_alloc_t(net, &net->stdp_flag, np));
+        TRY(fill_u32(net, net->stdp_flag, np, 0));
+        TRY(dev_alloc_t(net, &net->stdp_dcol, (size_t)STDP_MAX_LATTICES * net->dcol_stride));
+        TRY(dev_alloc_t(net, &net->stdp_drow, net->ld));
+    }
 
     // spike-train cells (spike_train/mod.rs:299-313, 998-1013, 50-56)
     c.c_pad = cp;

@@ -23,6 +23,41 @@ int launch_spike_trains(snn_network *net, int iterate, long long step_offset, lo
 
 enum InputsPart { INPUTS_ALL = 0, INPUTS_LOCAL = 1, INPUTS_REMOTE = 2 };
 int flush_rstdp(snn_network *net);
+int flush_stdp(snn_network *net);
+bool fused_step_possible(const snn_network *net);
+
+// the dense synapse matrix is streamed (not cache resident): the shapes the fused weight updates exist for
+inline bool matrix_streamed(const snn_network *net)
+{
+    return !net->csr && (size_t)net->n_tot * net->ld * 4 > ((size_t)64 << 20);
+}
+
+// STDP of step t applied by the input pass of step t + 1 (k_inputs_dense<..., STDP>): dense streamed matrices, plain
+// STDP everywhere (the BCM rule reads the weight itself), nothing else rewriting or snapshotting W in step_end
+bool stdp_deferral_applies(const snn_network *net)
+{
+    if (!net->defer_stdp || !net->any_plasticity || net->any_modulation || net->any_whist || !matrix_streamed(net) ||
+        net->lattices.size() > (size_t)STDP_MAX_LATTICES || net->n_loc == 0)
+        return false;
+    for (size_t l = 0; l < net->lattices.size(); ++l)
+        if (net->stdp_host[l * PL_STRIDE + 5] != 0.0f) return false;
+    return true;
+}
+
+StdpArgs stdp_args(snn_network *net)
+{
+    StdpArgs a{};
+    a.W = net->W; a.ld = net->ld; a.n_loc = net->n_loc; a.q0 = net->q0; a.n_neurons = net->nn; a.n_tot = net->n_tot;
+    a.xbuf = net->xbuf; a.xl = net->xl;
+    a.last_firing_time = net->na.last_firing_time; a.st_last_firing_time = net->ca.last_firing_time;
+    a.lattice_slot = net->lattice_slot; a.stdp = net->stdp_dev; a.do_plasticity = net->plast_dev;
+    a.act = net->na.bcm_cur; a.avg = net->na.bcm_avg; a.st_act = net->ca.bcm_cur;
+    a.spike_list = net->spike_list; a.spike_count = net->spike_count;
+    a.flag = nullptr; a.dcol = net->stdp_dcol; a.drow = net->stdp_drow;
+    a.dcol_stride = net->dcol_stride; a.n_lattices = (uint32_t)net->lattices.size();
+    a.clock = net->clock;
+    return a;
+}
 // snn_network_exchange.hpp
 int ensure_exchange_plan(snn_network *net);
 int launch_exchange_unpack(snn_network *net);
@@ -92,6 +127,33 @@ int launch_inputs(snn_network *net, InputsPart part = INPUTS_ALL)
     const uint64_t waves4 = (uint64_t)((net->n_loc + 255) / 256) * grid_chunks;
     const int shape = resident ? 0 : (waves4 < 8192 ? 2 : 1);     // 8192 = 256 CUs x 32 wave slots
     if (net->rstdp_pending && part != INPUTS_ALL) TRY(flush_rstdp(net));
+    const bool stdp_fused = net->stdp_pending && !net->rstdp_pending && part == INPUTS_ALL && shape != 0;
+    if (net->stdp_pending && !stdp_fused) TRY(flush_stdp(net));
+    if (stdp_fused) {
+        // the STDP update of the previous step rides on this pass over W
+        net->stdp_pending = false;
+        a.W_rw = net->W; a.stdp_count = net->spike_count; a.stdp_flag = net->stdp_flag;
+        a.stdp_dcol = net->stdp_dcol; a.stdp_drow = net->stdp_drow; a.lattice_slot = net->lattice_slot;
+        a.dcol_stride = net->dcol_stride; a.n_lattices = (uint32_t)net->lattices.size();
+#define SNN_LAUNCH_SSHAPE(E, C, SH)                                                                       \
+    hipLaunchKernelGGL((k_inputs_dense<E, C, SH, K_TYPES, true>),                                        \
+                       dim3((net->n_loc + InputsShape<SH>::TILE - 1) / InputsShape<SH>::TILE, grid_chunks), \
+                       dim3(InputsShape<SH>::THREADS), 0, net->stream, a)
+#define SNN_LAUNCH_SINPUTS(E, C)                                                                         \
+    do {                                                                                                 \
+        if (shape == 1) SNN_LAUNCH_SSHAPE(E, C, 1);                                                      \
+        else SNN_LAUNCH_SSHAPE(E, C, 2);                                                                 \
+    } while (0)
+        for (int k = 0; k < K_TYPES; ++k) a.live_type[k] = (uint32_t)k;     // the generic three-slot chemical variant
+        if (net->electrical && net->chemical) SNN_LAUNCH_SINPUTS(true, true);
+        else if (net->electrical) SNN_LAUNCH_SINPUTS(true, false);
+        else SNN_LAUNCH_SINPUTS(false, true);
+#undef SNN_LAUNCH_SINPUTS
+#undef SNN_LAUNCH_SSHAPE
+        HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+        if (net->profile) HIP_TRY(hipEventRecord(e1, net->stream), SNN_ERR_QUEUE);
+        return SNN_OK;
+    }
     if (net->rstdp_pending) {
         // the reward-modulated weight update of the previous step rides on this pass over W
         net->rstdp_pending = false;
@@ -181,20 +243,42 @@ int launch_update(snn_network *net)
     return SNN_OK;
 }
 
+int launch_plasticity_kernels(snn_network *net);
+
+// spike compaction + weight updates of the step, bracketed by HIP events while profiling is on
 int launch_plasticity(snn_network *net)
 {
     if (!net->any_plasticity || net->nn == 0) return SNN_OK;
-    StdpArgs a{};
-    a.W = net->W; a.ld = net->ld; a.n_loc = net->n_loc; a.q0 = net->q0; a.n_neurons = net->nn; a.n_tot = net->n_tot;
-    a.xbuf = net->xbuf; a.xl = net->xl;
-    a.last_firing_time = net->na.last_firing_time; a.st_last_firing_time = net->ca.last_firing_time;
-    a.lattice_slot = net->lattice_slot; a.stdp = net->stdp_dev; a.do_plasticity = net->plast_dev;
-    a.act = net->na.bcm_cur; a.avg = net->na.bcm_avg; a.st_act = net->ca.bcm_cur;
-    a.spike_list = net->spike_list; a.spike_count = net->spike_count;
+    if (!net->profile) return launch_plasticity_kernels(net);
+    if (net->ev_used_pl == net->ev_pool_pl.size()) {
+        hipEvent_t x, y;
+        HIP_TRY(hipEventCreate(&x), SNN_ERR_QUEUE);
+        HIP_TRY(hipEventCreate(&y), SNN_ERR_QUEUE);
+        net->ev_pool_pl.emplace_back(x, y);
+    }
+    const auto ev = net->ev_pool_pl[net->ev_used_pl++];
+    HIP_TRY(hipEventRecord(ev.first, net->stream), SNN_ERR_QUEUE);
+    TRY(launch_plasticity_kernels(net));
+    HIP_TRY(hipEventRecord(ev.second, net->stream), SNN_ERR_QUEUE);
+    return SNN_OK;
+}
+
+int launch_plasticity_kernels(snn_network *net)
+{
+    StdpArgs a = stdp_args(net);
+    const bool defer = stdp_deferral_applies(net);
+    if (defer) a.flag = net->stdp_flag;
     HIP_TRY(hipMemsetAsync(net->spike_count, 0, 4, net->stream), SNN_ERR_BUFFER_WRITE);
     hipLaunchKernelGGL(k_spike_compact, dim3((net->nn + 255) / 256), dim3(256), 0, net->stream, a);
     HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
     if (net->n_loc == 0) return SNN_OK;
+    if (defer) {
+        // only the two delta vectors now; the weights are rewritten by the next input pass (or by flush_stdp)
+        hipLaunchKernelGGL(k_stdp_prepare, dim3((std::max(net->n_tot, net->n_loc) + 255) / 256), dim3(256), 0, net->stream, a);
+        HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+        net->stdp_pending = true;
+        return SNN_OK;
+    }
     if (net->csr) {
         if (!net->csr_ptr) return SNN_OK;
         CsrStdpArgs ca{};
@@ -217,7 +301,7 @@ int launch_plasticity(snn_network *net)
 // sizes served by the one-launch small-lattice step (snn_kernels_resident.hpp)
 bool fused_step_possible(const snn_network *net)
 {
-    return !SNN_HAVE_CUSTOM_MODEL && net->fused_step && !net->csr && !net->sharded && net->n_loc && net->n_tot &&
+    return !SNN_HAVE_CUSTOM_MODEL && net->fused_step && !net->csr && !net->sharded && !net->drive_threshold && net->n_loc && net->n_tot &&
            net->n_chunks <= RESIDENT_MAX_CHUNKS && (size_t)net->n_tot * net->ld * 4 <= ((size_t)64 << 20);
 }
 
@@ -258,6 +342,22 @@ int launch_reward_modulation(snn_network *net)
         return SNN_OK;
     }
     return launch_rstdp_pass(net, RM_DOPAMINE);
+}
+
+// The deferred STDP update as standalone passes (a host access to the weights, the end of a run, an input pass that
+// cannot carry it).
+int flush_stdp(snn_network *net)
+{
+    if (!net->stdp_pending) return SNN_OK;
+    net->stdp_pending = false;
+    if (net->n_loc == 0 || net->nn == 0) return SNN_OK;
+    StdpArgs a = stdp_args(net);
+    const unsigned sy = 64;
+    hipLaunchKernelGGL(k_stdp_apply_columns, dim3((net->n_tot + 255) / 256, sy), dim3(256), 0, net->stream, a);
+    HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+    hipLaunchKernelGGL(k_stdp_apply_rows, dim3((net->n_loc + 255) / 256, sy), dim3(256), 0, net->stream, a);
+    HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+    return SNN_OK;
 }
 
 // Apply a deferred update now (a host access to weights, traces or firing times is about to happen).
@@ -442,7 +542,7 @@ int launch_step_resident(snn_network *net)
 // Unsharded sparse handles: row sums + neuron update in one launch (k_step_csr).
 bool fused_csr_step_applies(const snn_network *net)
 {
-    return !SNN_HAVE_CUSTOM_MODEL && net->fused_step && net->csr && net->csr_ptr && !net->sharded &&
+    return !SNN_HAVE_CUSTOM_MODEL && net->fused_step && net->csr && net->csr_ptr && !net->sharded && !net->drive_threshold &&
            net->n_loc && !net->local_inputs_done;
 }
 
@@ -475,6 +575,11 @@ int launch_step_csr(snn_network *net)
 // first half of a step: inputs from S(t) and the local neurons' update
 int step_begin(snn_network *net)
 {
+    if (net->drive_threshold && net->nn) {
+        hipLaunchKernelGGL(k_synthetic_drive, dim3((net->nn + 255) / 256), dim3(256), 0, net->stream, net->xbuf, net->xl,
+                           net->nn, net->drive_seed, net->clock, net->drive_threshold, net->drive_voltage);
+        HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+    }
     if (fused_step_applies(net)) return launch_step_resident(net);
     if (fused_csr_step_applies(net)) return launch_step_csr(net);
     TRY(launch_inputs(net, net->local_inputs_done ? INPUTS_REMOTE : INPUTS_ALL));
@@ -487,17 +592,23 @@ int step_begin(snn_network *net)
 int step_end(snn_network *net)
 {
     TRY(launch_exchange_unpack(net));      // shard handles: the other ranks' state of this step, their last_firing_time
-    TRY(launch_plasticity(net));
-    TRY(launch_reward_modulation(net));
-    if (net->any_whist && record_now(net)) {
+    // weight snapshots: order 2 = before the step's weight updates (LatticeNetwork::iterate, neuron/mod.rs:2450-2461),
+    // order 1 = after them (a lone Lattice, neuron/mod.rs:904-910)
+    auto snapshots = [&](int order) -> int {
+        if (!net->any_whist || !record_now(net)) return SNN_OK;
         for (const auto &l : net->lattices) {
-            if (!net->want_whist[l.slot] || l.count == 0) continue;
+            if (net->want_whist[l.slot] != order || l.count == 0) continue;
             float *dst = net->whist[l.slot] + (size_t)net->hist_steps * l.count * l.count;
             hipLaunchKernelGGL(k_weight_snapshot, dim3((l.count + 255) / 256, l.count), dim3(256), 0, net->stream,
                                net->W, net->ld, l.first, l.count, dst);
             HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
         }
-    }
+        return SNN_OK;
+    };
+    TRY(snapshots(2));
+    TRY(launch_plasticity(net));
+    TRY(launch_reward_modulation(net));
+    TRY(snapshots(1));
     if ((net->want_avg || net->want_eeg) && record_now(net) && !net->lattices.empty()) {
         // after the exchange, so that a sharded handle reduces over every lattice's full population
         const size_t nl = net->lattices.size();
@@ -576,6 +687,7 @@ int begin_run(snn_network *net, uint64_t iterations)
 int end_run(snn_network *net)
 {
     TRY(flush_rstdp(net));
+    TRY(flush_stdp(net));
     HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
     if (net->run_active) {
         for (auto &c : net->st_clock) c += net->run_step_offset;
@@ -595,6 +707,13 @@ int collect_profile(snn_network *net)
         net->prof_launches += (i < net->ev_counts.size()) ? net->ev_counts[i] : 1;
     }
     net->ev_used = 0;
+    for (size_t i = 0; i < net->ev_used_pl; ++i) {
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, net->ev_pool_pl[i].first, net->ev_pool_pl[i].second), SNN_ERR_WAIT);
+        net->prof_ms_pl += ms;
+        net->prof_launches_pl += 1;
+    }
+    net->ev_used_pl = 0;
     return SNN_OK;
 }
 

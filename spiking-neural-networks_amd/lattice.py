@@ -839,9 +839,12 @@ def _flat(lattice):
 class LatticeNetworkGPU:
     """LatticeNetworkGPU (backend/src/neuron/gpu_lattices/mod.rs:1517-3212) over one DeviceNetwork."""
 
-    def __init__(self, network, device=0):
+    def __init__(self, network, device=0, graph_history_order=2):
         self.network = network
         self._graph_hist = {}
+        # when a lattice's weight snapshot is taken: 2 = before the step's weight updates (LatticeNetwork::iterate,
+        # neuron/mod.rs:2450-2461), 1 = after them (a lone Lattice, neuron/mod.rs:904-910 -- what LatticeGPU passes)
+        self._graph_hist_order = graph_history_order
         neurons = [c for l in network.lattices.values() for c in _flat(l)]
         cells = [c for l in network.spike_train_lattices.values() for c in _flat(l)]
         models = {type(c).model for c in neurons} or {IZHIKEVICH}
@@ -915,7 +918,7 @@ class LatticeNetworkGPU:
         dn.set_history(voltage=hist, spikes=False)
         for id, l in net.lattices.items():                      # update_graph_history, neuron/mod.rs:572
             if getattr(l, "update_graph_history", False) != self._graph_hist.get(id, False):
-                dn.set_graph_history(id, l.update_graph_history)
+                dn.set_graph_history(id, self._graph_hist_order if l.update_graph_history else 0)
                 self._graph_hist[id] = l.update_graph_history
 
     def graph_history(self, id):
@@ -1042,7 +1045,7 @@ class LatticeGPU:
     def _ensure(self):
         if self._net is None:
             host = LatticeNetwork.generate_network([self._lattice])
-            self._net = LatticeNetworkGPU(host, device=self._device)
+            self._net = LatticeNetworkGPU(host, device=self._device, graph_history_order=1)
         return self._net
 
     def _dirty(self):

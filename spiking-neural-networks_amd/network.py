@@ -98,7 +98,7 @@ class DeviceNetwork:
             raise TypeError(f"attribute arrays must be float32 / uint32 / int32, not {a.dtype}")
         kind = _DT[a.dtype]
         fn = getattr(self._L, f"snn_set_attr_{kind}")
-        _lib.check(fn(self._h, id, name.encode(), a.ctypes.data_as(_PTR[kind]), a.size))
+        self._check(fn(self._h, id, name.encode(), a.ctypes.data_as(_PTR[kind]), a.size))
 
     def get_attr(self, id, name, dtype=np.float32, per_type=False):
         rows, cols, _ = self.lattices[id]
@@ -106,7 +106,7 @@ class DeviceNetwork:
         out = np.empty((n, NUM_NT_TYPES) if per_type else (n,), dtype=dtype)
         kind = _DT[np.dtype(dtype)]
         fn = getattr(self._L, f"snn_get_attr_{kind}")
-        _lib.check(fn(self._h, id, name.encode(), out.ctypes.data_as(_PTR[kind]), out.size))
+        self._check(fn(self._h, id, name.encode(), out.ctypes.data_as(_PTR[kind]), out.size))
         return out
 
     # ---- graph ----------------------------------------------------------------------------
@@ -330,6 +330,8 @@ class DeviceNetwork:
                                                 t.ctypes.data_as(_lib.f32p), t.size))
 
     def set_graph_history(self, id, enable=True):
+        """enable: 0 off, 1 (True) snapshot after the step's weight updates (a lone Lattice), 2 before them (the order of
+        LatticeNetwork::iterate)"""
         self._check(self._L.snn_set_graph_history(self._h, id, int(enable)))
 
     def graph_history(self, id):
@@ -375,6 +377,16 @@ class DeviceNetwork:
         n, ms = C.c_uint64(), C.c_double()
         self._check(self._L.snn_profile_read(self._h, C.byref(n), C.byref(ms)))
         return n.value, ms.value
+
+    def profile_read_plasticity(self):
+        """(steps measured, summed ms) of the plasticity launches (spike compaction + weight updates)"""
+        n, ms = C.c_uint64(), C.c_double()
+        self._check(self._L.snn_profile_read_plasticity(self._h, C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
+    def set_synthetic_drive(self, seed, fraction, voltage):
+        """benchmark / load-test input: before every step a pseudo-random `fraction` of the neurons is set to `voltage`"""
+        self._check(self._L.snn_set_synthetic_drive(self._h, int(seed), float(fraction), float(voltage)))
 
     def input_kernel_bytes(self):
         v = C.c_uint64()

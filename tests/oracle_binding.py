@@ -156,6 +156,11 @@ def lib():
         L.snn_o_fill_graph_window.argtypes = [f32p, u8p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                               C.c_uint64, C.c_float, C.c_float, C.c_int]
         L.snn_o_fill_graph_window.restype = None
+        L.snn_o_fill_graph_window_blocked.argtypes = [f32p, u8p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                                      C.c_uint64, C.c_float, C.c_float, C.c_int, C.c_int]
+        L.snn_o_fill_graph_window_blocked.restype = None
+        L.snn_o_inputs_tiled.argtypes = [P, C.c_uint32, C.c_uint32, C.c_uint32]
+        L.snn_o_inputs_tiled.restype = None
         _lib = L
     return _lib
 
@@ -379,6 +384,11 @@ class Net:
             lib().snn_o_inputs(C.byref(c))
         else:
             lib().snn_o_inputs_range(C.byref(c), q0, q1)
+
+    def inputs_tiled(self, q0, q1, block=1024):
+        """step 1 for [q0, q1) with the all-core tiling of bench.py's cpu_baseline (same results bit for bit)"""
+        c = self._cnet()
+        lib().snn_o_inputs_tiled(C.byref(c), q0, q1, block)
 
     def update_neurons(self, q0=None, q1=None):
         c = self._cnet()

@@ -195,8 +195,8 @@ def test_strided_capture(snn, every):
     dn.close()
 
 
-@pytest.mark.parametrize("plasticity", ["stdp", "reward"])
-def test_graph_history(snn, plasticity):
+@pytest.mark.parametrize("plasticity,order", [("stdp", 1), ("reward", 1), ("stdp", 2)])
+def test_graph_history(snn, plasticity, order):
     """update_graph_history: the lattice's internal weights after every recorded step (stride 3), for STDP and for a
     reward-modulated lattice (which then keeps its weight update as a standalone pass), next to a second lattice
     without history; the oracle is stepped one step at a time and its weights snapshotted."""
@@ -213,15 +213,18 @@ def test_graph_history(snn, plasticity):
     dn = parity.device_from_oracle(snn, net)
     if plasticity == "reward":
         dn.set_reward_modulator(0, dopamine=0.02, tau_c=0.05, a_plus=0.01, a_minus=0.01)
-    dn.set_graph_history(0)
+    dn.set_graph_history(0, order)          # 1: after the step's weight updates (Lattice), 2: before (LatticeNetwork)
     dn.set_history_stride(every)
     dn.run(steps)
     n0 = 6 * 7
     snaps = []
     for t in range(steps):
-        net.run(1)
+        if order == 1:
+            net.run(1)
         if t % every == 0:
             snaps.append(np.where(net["connections"][:n0, :n0] != 0, net["weights"][:n0, :n0], np.float32(0)).copy())
+        if order == 2:
+            net.run(1)
     hist = dn.graph_history(0)
     assert hist.shape == (len(snaps), n0, n0)
     assert np.array_equal(parity.bits(hist), parity.bits(np.array(snaps)))

@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 from snn_amd import modelgen
+from snn_amd.examples_dsl import IZH_DSL  # noqa: E402,F401
 
 LIF_NB = """
 [neuron]
@@ -18,18 +19,6 @@ LIF_NB = """
         dv/dt = (v - e) + i
 [end]"""          # = /root/reference/build_test/nb_macro/tests/lif.nb (the reference's fixture, restated as data)
 
-IZH_DSL = """
-[neuron]
-    type: DslIzhikevich
-    vars: a = 0.02, b = 0.2, c = -55, d = 8, w = 30, v_th = 30, tau_m = 1, c_m = 100, current_voltage = -65
-    on_spike:
-        v = c
-        w += d
-    spike_detection: v >= v_th
-    on_iteration:
-        dv/dt = (0.04 * v * v + 5 * v + 140 - w + i + 0.5 * exp((v - v_th) / 20)) / c_m
-        dw/dt = (a * (b * v - w)) / tau_m
-[end]"""
 
 
 def test_parses_the_reference_fixture():

@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 
 from snn_amd import modelgen
+from snn_amd.examples_dsl import DESTEXHE_PAIR  # noqa: E402,F401
 
 f32 = np.float32
 
@@ -39,20 +40,6 @@ APPROXIMATE_NT = BASIC_NT.replace("BasicNeurotransmitterKinetics", "ApproximateK
                          .replace("t = t + dt * -c * t + conc", "t += dt * -c * t + conc")
 
 # DestexheNeurotransmitter (:148-150) and DestexheReceptor (:404-406)
-DESTEXHE_PAIR = """
-[neurotransmitter_kinetics]
-    type: DslDestexheNeurotransmitter
-    vars: t_max = 1, v_p = 2, k_p = 5
-    on_iteration:
-        t = t_max / (1 + exp(-(v - v_p) / k_p))
-[end]
-
-[receptor_kinetics]
-    type: DslDestexheReceptor
-    vars: alpha = 1, beta = 1
-    on_iteration:
-        dr/dt = alpha * t * (1 - r) - beta * r
-[end]"""
 
 
 def test_blocks_are_parsed_and_emitted():

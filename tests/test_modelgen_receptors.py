@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 
 from snn_amd import modelgen
+from snn_amd.examples_dsl import MIXED, STEP_NEURON  # noqa: E402,F401
 
 f32 = np.float32
 
@@ -33,19 +34,6 @@ MULTIPLE = """
         current = 2 * g * r * (v - e)
 [end]"""          # shared_receptors.rs:5-15
 
-MIXED = """
-[receptors]
-    type: MixedReceptors
-    vars: m = 0
-    neurotransmitter: Iono
-    vars: current = 0, g = 1, e = 0
-    on_iteration:
-        current = g * m * r * (v - e)
-    neurotransmitter: Meta
-    vars: s = 1
-    on_iteration:
-        m = s * r
-[end]"""          # shared_receptors.rs:17-28
 
 # Ionotropic AMPA and GABA currents (iterate_and_spike/mod.rs:1103-1105, 1164-1166) in slots 0 and 2 of the exchange,
 # nothing in slot 1
@@ -66,16 +54,6 @@ IONOTROPIC_LIKE = """
         current = g * r * (v - e)
 [end]"""
 
-STEP_NEURON = """
-[neuron]
-    type: {name}
-    {receptors}vars: e = -48, v_reset = -70, v_th = -50, current_voltage = -65, c_m = 2, gap_conductance = 1
-    on_spike:
-        v = v_reset
-    spike_detection: v >= v_th
-    on_iteration:
-        v = v + (-(v - e) + i) * dt
-[end]"""
 
 
 def test_receptor_sets_are_parsed_and_emitted():

@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 from snn_amd import modelgen
+from snn_amd.examples_dsl import BURST_DSL  # noqa: E402,F401
 
 f32 = np.float32
 
@@ -33,37 +34,6 @@ REFRACTORINESS_DSL = """
 
 # a train the reference has no built-in for: a phase oscillator (differential equation, exp, a bool of its own) whose
 # spikes come in bursts, with a refractoriness that has a variable besides `decay`
-BURST_DSL = """
-[spike_train]
-    type: BurstSpikeTrain
-    vars: phase = 0, freq = 0.02, envelope = 0, tau = 40, bursting = false, v_th = 25, v_resting = -5
-    on_iteration:
-        dphase/dt = freq
-        [if] phase >= 1 [then]
-            phase = phase - 1
-            bursting = true
-        [end]
-        envelope = exp(-phase * tau / 10)
-        [if] bursting && envelope < 0.5 [then]
-            bursting = false
-        [end]
-        [if] bursting [then]
-            is_spiking = !is_spiking
-        [else]
-            is_spiking = false
-        [end]
-        [if] is_spiking [then]
-            v = v_th
-        [else]
-            v = v_resting + envelope
-        [end]
-[end]
-
-[neural_refractoriness]
-    type: PlateauRefractoriness
-    vars: decay = 2000, plateau = 3
-    effect: (v_th - v_resting) * exp((-1 / (decay / dt)) * max(time_difference - plateau, 0)) + v_resting
-[end]"""
 
 
 def _st_state(model, n):

@@ -154,3 +154,25 @@ def test_reduced_histories_against_numpy():
             eeg[t] = f(k * tot_e)
         assert np.array_equal(avg.view(np.uint32), net.avg_history[:, slot].view(np.uint32))
         assert np.array_equal(eeg.view(np.uint32), net.eeg_history[:, slot].view(np.uint32))
+
+
+@pytest.mark.parametrize("n,block,threads", [(700, 64, 3), (1030, 1024, 4), (300, 1024, 1)])
+def test_tiled_all_core_inputs_equal_the_general_routine(n, block, threads):
+    """bench.py's cpu_baseline streams the matrix in (1024 columns x 256 rows) tiles over all cores: same sums bit for
+    bit as the general routine (ragged last chunk / last block, masked edges, column windows)."""
+    net = ob.Net(n, model=ob.IZHIKEVICH)
+    net["gap_conductance"] = ob.uniform_array(2, n, 1.0, 12.0)
+    net["current_voltage"] = ob.uniform_array(1, n, -65.0, 30.0)
+    net.fill_graph(3, -0.5, 1.5)
+    rng = np.random.default_rng(n)
+    net["connections"][rng.random(net["connections"].shape) < 0.3] = 0
+    net["connections"][:, 5] = 0                      # a column without any edge: averager 1
+    net.n_threads = threads
+    net.inputs()
+    want = net["input_current"].copy()
+    net["input_current"][...] = np.float32(np.nan)
+    q0, q1 = 17, n - 3
+    net.inputs_tiled(q0, q1, block)
+    got = net["input_current"]
+    assert np.array_equal(got[q0:q1].view(np.uint32), want[q0:q1].view(np.uint32))
+    assert np.isnan(got[:q0]).all() and np.isnan(got[q1:]).all()
