@@ -23,9 +23,9 @@ ROWS = COLS = 256
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling is ~6.3 TB/s
 # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of THIS command (FETCH_SIZE and
 # WRITE_SIZE cannot share a pass); their summaries are committed under profiles/ and quoted here per launch.
-PMC_TRAFFIC = {"c2": os.path.join(ROOT, "profiles", "r01", "c2_izhikevich_256x256_pmc_traffic.json"),
-               "c3": os.path.join(ROOT, "profiles", "r01", "c3_pmc_traffic.json"),
-               "c4": os.path.join(ROOT, "profiles", "r01", "c4_pmc_traffic.json")}
+PMC_TRAFFIC = {"c2": os.path.join(ROOT, "profiles", "r02", "c2_pmc_traffic.json"),
+               "c3": os.path.join(ROOT, "profiles", "r02", "c3_pmc_traffic.json"),
+               "c4": os.path.join(ROOT, "profiles", "r02", "c4_pmc_traffic.json")}
 
 
 def pmc_traffic(config, world, rows, cols):
@@ -56,6 +56,21 @@ def mem_available_bytes():
     return 16 << 30
 
 
+def cgroup_cpu_quota():
+    """CPUs the container may use at once (cgroup v2 cpu.max / v1 cfs quota), None when unlimited or unknown"""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(p)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / p
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(n, threads, budget_s=15.0):
     """Time the oracle (kind "port": a C restatement of the reference's CPU path, dense arrays, all cores = the
     reference's rayon par_iter over postsynaptic neurons, backend/src/neuron/mod.rs:775-790) on the same workload: the
@@ -77,6 +92,25 @@ def cpu_baseline(n, threads, budget_s=15.0):
                                              n, n, 0, sample_cols, block, 2, 0.5, 1.5, 0, threads)
     net["gap_conductance"] = 10.0
     net["current_voltage"] = ob.uniform_array(1, n, -65.0, 30.0)
+    # The visible CPU count can exceed what the container may actually run at once (a CPU quota): take the thread
+    # count that streams a slice of the sample fastest, halving from the visible count.
+    probe_cols = min(sample_cols, 8 * block)
+    net.n_threads = threads
+    net.inputs_tiled(0, probe_cols, block)             # page-in
+    best, tried = (0.0, threads), {}
+    t = threads
+    while t >= 1:
+        net.n_threads = t
+        t0 = time.perf_counter()
+        net.inputs_tiled(0, probe_cols, block)
+        rate = probe_cols / (time.perf_counter() - t0)
+        tried[t] = rate
+        if rate > best[0] * 1.05:
+            best = (rate, t)
+        if t <= 4:
+            break
+        t //= 2
+    visible, threads = threads, best[1]
     net.n_threads = threads
     t0 = time.perf_counter()
     net.inputs_tiled(0, sample_cols, block)            # warm-up + calibration of the sample length
@@ -87,7 +121,9 @@ def cpu_baseline(n, threads, budget_s=15.0):
         net.inputs_tiled(0, sample_cols, block)        # O(N) synapses per neuron: the whole per-neuron cost
         net.update_neurons()                           # O(1) per neuron (all N, negligible)
     dt = time.perf_counter() - t0
-    extra = {"host_stream_GBps": 5.0 * n * sample_cols * steps / dt / 1e9}
+    extra = {"host_stream_GBps": 5.0 * n * sample_cols * steps / dt / 1e9, "visible_cpus": visible,
+             "cgroup_cpu_quota": cgroup_cpu_quota(),
+             "thread_count_probe_neuron_steps_per_s": {str(k): v for k, v in tried.items()}}
     # single thread (the reference's parallel = false), on one tile column of the sample
     net.n_threads = 1
     cols1 = min(sample_cols, block)
@@ -106,7 +142,7 @@ def cpu_baseline(n, threads, budget_s=15.0):
         t0 = time.perf_counter()
         c1.run(1000)
         extra[key] = time.perf_counter() - t0
-    return sample_cols * steps / dt, dt, steps, sample_cols, extra
+    return sample_cols * steps / dt, dt, steps, sample_cols, threads, extra
 
 
 def build_config(args, snn_amd, synthetic, np, rank, world, local_rank):
@@ -352,7 +388,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline and args.config in ("c1", "c2"):
             threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-            v, secs, cpu_steps, sample, extra = cpu_baseline(n, threads)
+            v, secs, cpu_steps, sample, threads, extra = cpu_baseline(n, threads)
             out["cpu_baseline"] = {"value": v, "unit": "neuron-steps/s", "cores": threads, "kind": "port", **extra,
                                    "sample": f"oracle (C restatement, OpenMP x{threads}, tiles of 1024 columns x 256 rows) on "
                                              f"{sample} of {n} postsynaptic neurons x {cpu_steps} steps ({secs:.1f} s); every "

@@ -1,0 +1,43 @@
+#!/bin/bash
+# Collects the per-round evidence on a GPU box:  bash profiles/collect.sh rNN  (writes gpurun_out/rNN/, to be copied
+# into profiles/rNN/).  Per config: rocprofv3 --kernel-trace --stats of bench.py (kernel stats csv + the bench line of
+# that profiled process), then two separate --pmc passes (FETCH_SIZE, WRITE_SIZE) reduced by summarize_pmc.py.
+set -u
+R=${1:-r02}
+OUT=$PWD/gpurun_out/$R
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp && cd "$OLDPWD"
+DATE=$(date -u +%Y-%m-%d)
+prof() {   # name, bench args...
+    local name=$1; shift
+    rm -rf "$OUT/prof_$name"
+    rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_$name" -- python3 bench.py "$@" --no-cpu-baseline \
+        > "$OUT/${name}_bench_under_rocprof.json" 2> "$OUT/${name}_rocprof.err"
+    find "$OUT/prof_$name" -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} "$OUT/${name}_kernel_stats.csv"
+    tail -1 "$OUT/${name}_bench_under_rocprof.json" > "$OUT/${name}_bench_line.json"; mv "$OUT/${name}_bench_line.json" "$OUT/${name}_bench_under_rocprof.json"
+    rm -rf "$OUT/prof_$name"
+    head -4 "$OUT/${name}_kernel_stats.csv"
+}
+pmc() {    # name, kernel substring, bench args...
+    local name=$1 needle=$2; shift 2
+    for c in FETCH_SIZE WRITE_SIZE; do
+        rm -rf "$OUT/pmc_${name}_$c"
+        rocprofv3 --pmc $c --output-format csv -d "$OUT/pmc_${name}_$c" -- python3 bench.py "$@" --no-cpu-baseline --no-kernel-events \
+            > /dev/null 2> "$OUT/${name}_pmc_$c.err"
+    done
+    python3 profiles/summarize_pmc.py "$(find "$OUT/pmc_${name}_FETCH_SIZE" -name '*counter_collection.csv' | head -1)" \
+        "$(find "$OUT/pmc_${name}_WRITE_SIZE" -name '*counter_collection.csv' | head -1)" "$OUT/${name}_pmc_traffic.json" "$needle" "$DATE" | tail -12
+    rm -rf "$OUT/pmc_${name}_FETCH_SIZE" "$OUT/pmc_${name}_WRITE_SIZE"
+}
+prof c2 --config c2 --steps 50 --warmup 10 --repeats 2
+prof c3 --config c3 --steps 100 --warmup 10 --repeats 2
+prof c4 --config c4 --steps 50 --warmup 10 --repeats 2
+prof c4_spiking_0p1pct --config c4 --spike-fraction 0.001 --steps 50 --warmup 100 --repeats 2
+prof c5 --config c5 --steps 500 --warmup 20 --repeats 2 --no-kernel-events
+prof c1 --config c1 --steps 2000 --warmup 50 --repeats 2 --no-kernel-events
+prof c2_sharded_world1 --config c2 --force-sharded --steps 50 --warmup 10 --repeats 2
+prof c5_sharded_world1 --config c5 --force-sharded --steps 500 --warmup 20 --repeats 2 --no-kernel-events
+pmc c2 k_inputs_dense --config c2 --steps 20 --warmup 3 --repeats 1
+pmc c3 k_inputs_dense --config c3 --steps 20 --warmup 3 --repeats 1
+pmc c4 k_inputs_dense --config c4 --steps 20 --warmup 3 --repeats 1
+ls "$OUT"
