@@ -269,6 +269,13 @@ int snn_exchange(snn_network_t *net, void *nccl_comm);
  * the next step's own-rows input pass overlapping the collective where that is valid (see snn_step_begin_local).
  * Blocks until the last step has finished.  Results are identical to (b) and (c) and to a single-GPU snn_run. */
 int snn_run_sharded(snn_network_t *net, void *nccl_comm, uint64_t iterations);
+/* The same loop with the HOST'S OWN TRANSPORT (MPI, UCX, a test harness ...) in place of RCCL: once per step, after the
+ * outgoing segments have been enqueued on `hip_stream`, `exchange(user, hip_stream)` must move the segments the plan
+ * describes (snn_exchange_plan_get / snn_exchange_peers) and return 0; work enqueued on `hip_stream` after it returns
+ * must see the received segments (a blocking implementation synchronises the stream, moves the bytes, returns).  A
+ * non-zero return stops the run with SNN_ERR_QUEUE.  No overlap of the next step's input pass with the exchange. */
+typedef int (*snn_exchange_fn)(void *user, void *hip_stream);
+int snn_run_sharded_custom(snn_network_t *net, snn_exchange_fn exchange, void *user, uint64_t iterations);
 /* HIP stream the handle launches on (hipStream_t), for ordering collectives against it */
 int snn_stream(snn_network_t *net, void **hip_stream);
 /* Adopt the caller's stream (e.g. the one its RCCL collectives are ordered against); NULL returns to the

@@ -77,6 +77,8 @@ class ExchangePlan(C.Structure):
 
 EXCHANGE_ALLGATHER, EXCHANGE_HALO = 0, 1
 
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)      # snn_exchange_fn(user, hip_stream)
+
 f32p = C.POINTER(C.c_float)
 u32p = C.POINTER(C.c_uint32)
 i32p = C.POINTER(C.c_int32)
@@ -137,6 +139,7 @@ SIGNATURES = {
     "snn_comm_exchange_halo_lists": (C.c_int, [H, C.c_void_p]),
     "snn_exchange": (C.c_int, [H, C.c_void_p]),
     "snn_run_sharded": (C.c_int, [H, C.c_void_p, C.c_uint64]),
+    "snn_run_sharded_custom": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_uint64]),
     "snn_stream": (C.c_int, [H, C.POINTER(C.c_void_p)]),
     "snn_set_stream": (C.c_int, [H, C.c_void_p]),
     "snn_synchronize": (C.c_int, [H]),

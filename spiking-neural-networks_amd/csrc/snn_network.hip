@@ -979,6 +979,24 @@ int snn_exchange(snn_network_t *net, void *nccl_comm)
     return SNN_OK;
 }
 
+int snn_run_sharded_custom(snn_network_t *net, snn_exchange_fn exchange, void *user, uint64_t iterations)
+{
+    if (!net || !exchange) return fail(SNN_ERR_BAD_ARG, "null argument");
+    if (!net->finalized || !net->sharded) return fail(SNN_ERR_BAD_STATE, "not a finalized shard handle");
+    if (iterations == 0 || net->n_tot == 0) return SNN_OK;
+    if (!net->electrical && !net->chemical) return SNN_OK;
+    HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
+    TRY(begin_run(net, iterations));
+    for (uint64_t it = 0; it < iterations; ++it) {
+        if (net->nn) TRY(step_begin(net));
+        TRY(launch_exchange_pack(net));
+        if (exchange(user, net->stream) != 0) return fail(SNN_ERR_QUEUE, "the caller's exchange function failed");
+        TRY(step_end(net));
+        if (net->profile && (net->ev_used >= 8192 || net->ev_used_pl >= 8192)) TRY(collect_profile(net));
+    }
+    return end_run(net);
+}
+
 int snn_run_sharded(snn_network_t *net, void *nccl_comm, uint64_t iterations)
 {
     if (!net || !nccl_comm) return fail(SNN_ERR_BAD_ARG, "null argument");

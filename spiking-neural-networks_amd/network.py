@@ -234,6 +234,27 @@ class DeviceNetwork:
     def exchange_halo_lists(self, comm):
         self._check(self._L.snn_comm_exchange_halo_lists(self._h, C.c_void_p(int(comm))))
 
+    def run_sharded_custom(self, exchange, iterations):
+        """the library's sharded step loop with the caller's transport: `exchange(hip_stream)` is called once per step
+        after the outgoing segments were enqueued and must have moved the plan's segments when it returns"""
+        err = []
+
+        def thunk(_user, stream):
+            try:
+                exchange(stream)
+                return 0
+            except BaseException as e:      # never let an exception cross the C frame
+                err.append(e)
+                return 1
+
+        cb = _lib.EXCHANGE_FN(thunk)
+        try:
+            self._check(self._L.snn_run_sharded_custom(self._h, C.cast(cb, C.c_void_p), None, int(iterations)))
+        except Exception:
+            if err:
+                raise err[0]
+            raise
+
     def run_sharded(self, comm, iterations):
         """`iterations` steps with the library's own RCCL loop (every rank calls it with its shard handle)"""
         self._check(self._L.snn_run_sharded(self._h, C.c_void_p(int(comm)), int(iterations)))
