@@ -212,7 +212,8 @@ def build_config(args, snn_amd, synthetic, np, rank, world, local_rank):
             dn.add_lattice(k, side, side)
             dn.add_spike_train_lattice(4 + k, side, side)
         if sharded:
-            dn.finalize(rank, world, csr=True)
+            # every rank owns the same slab of each of the four lattices: the ring edge k -> k+1 stays inside a rank
+            dn.finalize(rank, world, csr=True, by_lattice=True)
         else:
             dn.finalize(csr=True)
         for k in range(4):
@@ -220,7 +221,7 @@ def build_config(args, snn_amd, synthetic, np, rank, world, local_rank):
             dn.set_attr(k, "current_voltage", synthetic.uniform(6, m, -65.0, 30.0, offset=k * m))
             dn.set_attr(4 + k, "chance_of_firing", np.full(m, 0.01, np.float32))
             dn.set_attr(4 + k, "seed", np.arange(k * m + 1, (k + 1) * m + 1, dtype=np.uint32))   # cell index + 1
-        dn.set_graph_csr(*synthetic.c5_csr(side, dn.post_begin, dn.post_end))
+        dn.set_graph_csr(*synthetic.c5_csr(side, posts=dn.owned))
         return dn, 4 * m, (f"4 x ({side}x{side}) Izhikevich lattices (radius-2 neighbourhoods) + 4 Poisson spike-train "
                            f"lattices one-to-one + ring k->k+1, CSR, dt=0.1"), ("k_inputs_csr<true,false>" if sharded else "k_step_csr<0,true,false>")
     raise SystemExit(f"unknown --config {cfg}")
@@ -368,7 +369,7 @@ def main():
             "ms_per_step_min": min(runs) / args.steps * 1e3, "ms_per_step_max": max(runs) / args.steps * 1e3,
             "spikes_per_step": spikes / total_steps,
             "plasticity": ({"ms_per_step": pl_ms / pl_steps, "steps_measured": pl_steps,
-                            "touched_bytes_per_step": 8.0 * (dn.n_tot + (dn.post_end - dn.post_begin)) * spikes / total_steps / world,
+                            "touched_bytes_per_step": 8.0 * (dn.n_tot + sum(e - b for b, e in dn.ranges)) * spikes / total_steps / world,
                             "note": "spike compaction + column/row weight updates of this rank, HIP events; touched bytes = "
                                     "8 B x (n_tot + n_local) per spiking neuron"} if pl_steps else None),
             "scaling": "strong",      # --gpus N shards the SAME lattice: total work fixed as N grows

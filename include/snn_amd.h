@@ -220,6 +220,15 @@ int snn_run(snn_network_t *net, uint64_t iterations);
  * segments (state mirror, last_firing_time), then plasticity on the local columns, histories, clock, spike trains. */
 int snn_step_begin(snn_network_t *net);
 int snn_step_end(snn_network_t *net);
+/* Sparse handles may shard BY LATTICE instead of by one contiguous slot of the index space: shard s owns slab s (equal
+ * slabs of ceil(rows*cols / n_shards) neurons rounded up to 64) of EVERY neuron lattice.  For networks whose lattices
+ * are wired position to position (BASELINE configs[4]'s ring k -> k+1) the edges between lattices then stay inside a
+ * rank and only the borders of the slabs travel.  Call instead of snn_network_finalize_shard, after
+ * snn_network_use_csr(net, 1).  snn_set_graph_csr then takes the rows of the OWNED neurons in ascending global order
+ * (snn_shard_ranges lists them; a contiguous shard reports its one range).  Without a committed halo plan such a handle
+ * trades whole ownerships with every peer (the all-gather's content as an all-to-all-v). */
+int snn_network_finalize_shard_by_lattice(snn_network_t *net, uint32_t shard_index, uint32_t n_shards);
+int snn_shard_ranges(const snn_network_t *net, uint32_t *begin, uint32_t *end, uint32_t capacity, uint32_t *count);
 /* Optional overlap: enqueue, BEFORE the exchange of the previous step has been waited for, the part of
  * this step's synaptic-input pass that only needs the shard's own neurons as presynaptic rows; the
  * following snn_step_begin then processes the remaining rows.  A no-op when plasticity is on (STDP

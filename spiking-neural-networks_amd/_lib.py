@@ -102,6 +102,8 @@ SIGNATURES = {
     "snn_network_add_spike_train_lattice": (C.c_int, [H, C.c_uint32, C.c_uint32, C.c_uint32]),
     "snn_network_finalize": (C.c_int, [H]),
     "snn_network_finalize_shard": (C.c_int, [H, C.c_uint32, C.c_uint32]),
+    "snn_network_finalize_shard_by_lattice": (C.c_int, [H, C.c_uint32, C.c_uint32]),
+    "snn_shard_ranges": (C.c_int, [H, u32p, u32p, C.c_uint32, u32p]),
     "snn_network_sizes": (C.c_int, [H, u32p, u32p, u32p, u32p]),
     "snn_network_lattice_range": (C.c_int, [H, C.c_uint32, u32p, u32p]),
     "snn_set_attr_f32": (C.c_int, [H, C.c_uint32, C.c_char_p, f32p, C.c_size_t]),

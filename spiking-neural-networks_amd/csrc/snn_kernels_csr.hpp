@@ -55,8 +55,9 @@ __device__ __forceinline__ void csr_row_sums(const CsrInputsArgs &a, uint32_t q,
     const bool row_valid = q < a.g.n_loc;
     const uint32_t qq = row_valid ? q : 0u;
 
-    const float vq = ELEC ? in.xbuf[in.xl.at(in.q0 + qq, PLANE_V)] : 0.0f;
-    const float gq = ELEC ? in.gap_conductance[in.q0 + qq] : 0.0f;
+    const uint32_t gq_index = in.rows.global_of(qq);           // a hole row (no edges) reads some neuron's state, unused
+    const float vq = ELEC ? in.xbuf[in.xl.at(gq_index, PLANE_V)] : 0.0f;
+    const float gq = ELEC ? in.gap_conductance[gq_index] : 0.0f;
 
     float part = 0.0f;
     float tpart[K_TYPES] = {0.0f, 0.0f, 0.0f};
@@ -230,8 +231,8 @@ __global__ __launch_bounds__(64) void k_stdp_csr_in(const CsrStdpArgs a)
     const uint32_t count = *a.s.spike_count;
     for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
         const uint32_t j = a.s.spike_list[i];
-        if (j < a.s.q0 || j >= a.s.q0 + a.s.n_loc) continue;
-        const uint32_t r = j - a.s.q0;
+        const uint32_t r = a.s.rows.local_of(j, a.s.n_loc);
+        if (r == 0xFFFFFFFFu) continue;
         const float *prm = a.s.stdp + PL_STRIDE * a.s.lattice_slot[j];
         const bool bcm = prm[5] != 0.0f;
         const float post_act = bcm ? a.s.act[j] : 0.0f, post_avg = bcm ? a.s.avg[j] : 0.0f;
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(64) void k_stdp_csr_out(const CsrStdpArgs a)
         for (uint32_t t = a.g.t_ptr[j] + threadIdx.x; t < a.g.t_ptr[j + 1]; t += 64) {
             const uint32_t edge = a.g.t_edge[t];
             const uint32_t e = a.g.edge_slot[edge];
-            const uint32_t gr = a.s.q0 + a.g.edge_post[edge];
+            const uint32_t gr = a.s.rows.global_of(a.g.edge_post[edge]);
             const float *prm = a.s.stdp + PL_STRIDE * a.s.lattice_slot[gr];
             const bool bcm = prm[5] != 0.0f;
             a.g.w[e] = plasticity_weight(prm, a.g.w[e], tj, a.s.last_firing_time[gr], bcm ? a.s.act[j] : 0.0f,
@@ -271,6 +272,7 @@ struct CsrRewardArgs {
     SellGraph g;
     float *c;                              // [entries] TraceRSTDP::c
     uint32_t q0, n_neurons;
+    RowMap rows;
     const int32_t *last_firing_time;
     const uint32_t *lattice_slot;
     const float *rm;
@@ -281,8 +283,8 @@ struct CsrRewardArgs {
 __global__ __launch_bounds__(256) void k_rstdp_csr(const CsrRewardArgs a)
 {
     const uint32_t q = blockIdx.x * 256 + threadIdx.x;
-    if (q >= a.g.n_loc) return;
-    const uint32_t gq = a.q0 + q;
+    if (q >= a.g.n_loc || !a.rows.active(q, a.g.n_loc)) return;
+    const uint32_t gq = a.rows.global_of(q);
     const uint32_t sq = a.lattice_slot[gq];
     if (!a.rm_on[sq]) return;
     const float *m = a.rm + (size_t)sq * RM_STRIDE;

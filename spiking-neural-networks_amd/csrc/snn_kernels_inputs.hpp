@@ -36,6 +36,7 @@ struct InputsArgs {
     uint32_t ld;            // floats per matrix row (multiple of 64)
     uint32_t n_loc;         // local postsynaptic columns
     uint32_t q0;            // global neuron index of local column 0
+    RowMap rows;            // sparse handles: local row -> global neuron (rows.q0 = q0 for contiguous shards)
     uint32_t n_neurons;
     uint32_t n_tot;
     const float *xbuf;

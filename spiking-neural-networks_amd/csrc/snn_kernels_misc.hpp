@@ -199,6 +199,7 @@ __global__ __launch_bounds__(256) void k_spike_trains(const SpikeTrainArgs a)
 struct StdpArgs {
     float *W;
     uint32_t ld, n_loc, q0, n_neurons, n_tot;
+    RowMap rows;                          // sparse handles: local row <-> global neuron
     const float *xbuf;
     XLayout xl;
     const int32_t *last_firing_time;      // neurons (all shards, replicated)

@@ -24,6 +24,7 @@ struct UpdateArgs {
     const uint32_t *n_in;      // [ld]
     const uint32_t *tcount;    // [3][ld]
     uint32_t ld, n_chunks, q0, n_loc;
+    RowMap rows;               // local row -> global neuron (rows.q0 = q0 unless the shard owns a set of ranges)
     long long clock;
     int electrical, chemical, nt_kind, rc_kind;
     float *vhist_row;          // this step's row of the voltage history (global neuron index) or null
@@ -214,7 +215,7 @@ __device__ __forceinline__ uint32_t update_neuron(const UpdateArgs &a, uint32_t 
 {
     uint32_t spike = 0;
     {
-        const uint32_t q = a.q0 + ql;
+        const uint32_t q = a.rows.global_of(ql);
         const size_t v_at = a.n.xl.at(q, PLANE_V), s_at = a.n.xl.at(q, PLANE_SPIKE);
         const float v = a.n.xbuf[v_at];
         const float dt = a.n.dt[q];
@@ -432,14 +433,17 @@ template <int MODEL>
 __global__ __launch_bounds__(256) void k_update(const UpdateArgs a)
 {
     const uint32_t ql = blockIdx.x * 256 + threadIdx.x;
-    const uint32_t spike = (ql < a.n_loc) ? update_neuron<MODEL>(a, ql, GlobalSums{a, ql}) : 0u;
+    const uint32_t spike = (ql < a.n_loc && a.rows.active(ql, a.n_loc)) ? update_neuron<MODEL>(a, ql, GlobalSums{a, ql}) : 0u;
 
-    // spike raster: one 64-bit ballot word per wavefront (shard boundaries are multiples of 64)
+    // spike raster: one 64-bit ballot word per wavefront = one aligned 64-block of the global index space (shard
+    // boundaries are multiples of 64; a range-set shard maps every wavefront to such a block, holes contribute 0)
     if (a.spike_row) {
         const unsigned long long word = __ballot(spike != 0);
         // a raster row holds n_pad / 64 words; ld may exceed the padded population by one wavefront (row de-alignment)
-        if ((threadIdx.x & 63) == 0 && ql < a.ld && (a.q0 + ql) < a.n.n_pad)
-            a.spike_row[(a.q0 + ql) >> 6] = word;
+        if ((threadIdx.x & 63) == 0 && ql < a.ld) {
+            const uint32_t g = a.rows.block ? (ql < a.n_loc ? a.rows.block[ql >> 6] * 64u : a.n.n_pad) : a.q0 + ql;
+            if (g < a.n.n_pad) a.spike_row[g >> 6] = word;
+        }
     }
 }
 

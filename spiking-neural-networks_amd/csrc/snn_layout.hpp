@@ -36,6 +36,28 @@ struct XLayout {
     }
 };
 
+// Local row <-> global neuron of a handle.  A whole-population handle and a contiguous shard own [q0, q0 + n_loc):
+// row l is neuron q0 + l.  A shard that owns a SET of ranges (the same slab of every lattice, sparse handles only)
+// lays its rows out as the list of global 64-neuron blocks that hold at least one owned neuron: row l is neuron
+// block[l / 64] * 64 + l % 64 and is active when bit l % 64 of mask[l / 64] is set -- a wavefront still maps to one
+// aligned 64-block of the global index space (ballot word = raster word), rows of neurons owned elsewhere are holes.
+struct RowMap {
+    uint32_t q0;
+    const uint32_t *block;               // null: contiguous
+    const unsigned long long *mask;
+    const uint32_t *local_row;           // [n_pad] global neuron -> local row, 0xFFFFFFFF when not owned (block form only)
+    __device__ __forceinline__ uint32_t global_of(uint32_t l) const { return block ? block[l >> 6] * 64u + (l & 63u) : q0 + l; }
+    __device__ __forceinline__ bool active(uint32_t l, uint32_t n_loc) const
+    {
+        return block ? ((mask[l >> 6] >> (l & 63u)) & 1ull) != 0ull : l < n_loc;
+    }
+    __device__ __forceinline__ uint32_t local_of(uint32_t q, uint32_t n_loc) const      // 0xFFFFFFFF: not a local neuron
+    {
+        if (block) return local_row[q];
+        return (q >= q0 && q < q0 + n_loc) ? q - q0 : 0xFFFFFFFFu;
+    }
+};
+
 // Pointers the per-neuron update kernels need.  All arrays are device memory.
 struct NeuronArrays {
     // exchanged planes

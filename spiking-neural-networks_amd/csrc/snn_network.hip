@@ -107,9 +107,11 @@ int snn_network_add_spike_train_lattice(snn_network_t *net, uint32_t id, uint32_
     return add_lattice_impl(net, id, rows, cols, true);
 }
 
-static int finalize_impl(snn_network_t *net, bool whole, uint32_t post_begin, uint32_t post_end, uint32_t n_shards,
+// kind: 0 whole population, 1 contiguous shard [post_begin, post_end), 2 by lattice (slab shard_index of every lattice)
+static int finalize_impl(snn_network_t *net, int kind, uint32_t post_begin, uint32_t post_end, uint32_t n_shards,
                          uint32_t stride, uint32_t shard_index)
 {
+    const bool whole = kind == 0;
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
     if (net->finalized) return fail(SNN_ERR_BAD_STATE, "already finalized");
     HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
@@ -129,7 +131,7 @@ static int finalize_impl(snn_network_t *net, bool whole, uint32_t post_begin, ui
     net->c_pad = std::max<uint32_t>(256, round_up(net->nc, 256));
     if (whole) {
         net->q0 = 0; net->q1 = net->nn;
-    } else {
+    } else if (kind == 1) {
         if (post_begin > post_end || post_end > net->nn) return fail(SNN_ERR_DIM_MISMATCH, "shard range outside the population");
         if (stride == 0 || stride % 64 != 0 || n_shards == 0 || (uint64_t)stride * n_shards < net->nn)
             return fail(SNN_ERR_BAD_ARG, "shard stride must be a multiple of 64 covering the population");
@@ -137,9 +139,56 @@ static int finalize_impl(snn_network_t *net, bool whole, uint32_t post_begin, ui
         net->sharded = true;
         net->n_shards = n_shards; net->shard_stride = stride; net->shard_index = shard_index;
         net->n_pad = std::max<uint32_t>(net->n_pad, round_up(stride * n_shards, 256));
+    } else {
+        net->q0 = 0; net->q1 = 0;
+        net->sharded = true;
+        net->n_shards = n_shards; net->shard_stride = 0; net->shard_index = shard_index;
     }
     net->xl = XLayout{net->n_pad};
     net->n_loc = net->q1 - net->q0;
+    net->ranges.clear();
+    if (kind != 2) {
+        if (net->q1 > net->q0) net->ranges.emplace_back(net->q0, net->q1);
+        net->n_owned = net->n_loc;
+        net->rowmap = RowMap{net->q0, nullptr, nullptr, nullptr};
+    } else {
+        // slab `shard_index` of every neuron lattice; local rows = the global 64-blocks holding an owned neuron
+        net->block_mode = true;
+        net->lattice_slab.assign(net->lattices.size(), 64);
+        net->local_row_host.assign(net->n_pad, 0xFFFFFFFFu);
+        std::vector<uint32_t> blocks;
+        std::vector<unsigned long long> masks;
+        net->n_owned = 0;
+        for (const auto &l : net->lattices) {
+            const uint32_t slab = std::max<uint32_t>(64, round_up((l.count + n_shards - 1) / n_shards, 64));
+            net->lattice_slab[l.slot] = slab;
+            const uint64_t b = std::min<uint64_t>(l.count, (uint64_t)shard_index * slab), e = std::min<uint64_t>(l.count, b + slab);
+            if (e <= b) continue;
+            const uint32_t gb = l.first + (uint32_t)b, ge = l.first + (uint32_t)e;
+            if (!net->ranges.empty() && net->ranges.back().second == gb) net->ranges.back().second = ge;
+            else net->ranges.emplace_back(gb, ge);
+            for (uint32_t q = gb; q < ge; ++q) {
+                if (blocks.empty() || blocks.back() != (q >> 6)) { blocks.push_back(q >> 6); masks.push_back(0ull); }
+                masks.back() |= 1ull << (q & 63u);
+                net->local_row_host[q] = (uint32_t)(blocks.size() - 1) * 64u + (q & 63u);
+                net->owned_local_host.push_back(net->local_row_host[q]);
+                ++net->n_owned;
+            }
+        }
+        if (blocks.empty()) { blocks.push_back(0); masks.push_back(0ull); }
+        net->q0 = 0; net->q1 = 0;
+        net->n_loc = (uint32_t)blocks.size() * 64u;
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&net->own_block_dev), blocks.size() * 4), SNN_ERR_BUFFER_CREATE);
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&net->own_mask_dev), masks.size() * 8), SNN_ERR_BUFFER_CREATE);
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&net->local_row_dev), (size_t)net->n_pad * 4), SNN_ERR_BUFFER_CREATE);
+        HIP_TRY(hipMemcpy(net->own_block_dev, blocks.data(), blocks.size() * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
+        HIP_TRY(hipMemcpy(net->own_mask_dev, masks.data(), masks.size() * 8, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
+        HIP_TRY(hipMemcpy(net->local_row_dev, net->local_row_host.data(), (size_t)net->n_pad * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
+        net->allocs.push_back(net->own_block_dev);
+        net->allocs.push_back(net->own_mask_dev);
+        net->allocs.push_back(net->local_row_dev);
+        net->rowmap = RowMap{0, net->own_block_dev, net->own_mask_dev, net->local_row_dev};
+    }
     net->ld = std::max<uint32_t>(64, round_up(net->n_loc, 64));
     // A row stride that is a multiple of 4 KiB puts the same columns of consecutive rows on the same HBM
     // channels; 256 B of padding per row de-aligns them (measured at 256x256, same process: +2 % bandwidth).
@@ -153,7 +202,25 @@ static int finalize_impl(snn_network_t *net, bool whole, uint32_t post_begin, ui
     return SNN_OK;
 }
 
-int snn_network_finalize(snn_network_t *net) { return finalize_impl(net, true, 0, 0, 1, 0, 0); }
+int snn_network_finalize(snn_network_t *net) { return finalize_impl(net, 0, 0, 0, 1, 0, 0); }
+
+int snn_network_finalize_shard_by_lattice(snn_network_t *net, uint32_t shard_index, uint32_t n_shards)
+{
+    if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
+    if (n_shards == 0 || shard_index >= n_shards) return fail(SNN_ERR_BAD_ARG, "shard_index must be < n_shards");
+    if (!net->csr) return fail(SNN_ERR_BAD_STATE, "sharding by lattice needs a sparse handle: call snn_network_use_csr first");
+    return finalize_impl(net, 2, 0, 0, n_shards, 64, shard_index);
+}
+
+int snn_shard_ranges(const snn_network_t *net, uint32_t *begin, uint32_t *end, uint32_t capacity, uint32_t *count)
+{
+    if (!net || !count) return fail(SNN_ERR_BAD_ARG, "null argument");
+    if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
+    *count = (uint32_t)net->ranges.size();
+    if (begin && end && capacity >= net->ranges.size())
+        for (size_t i = 0; i < net->ranges.size(); ++i) { begin[i] = net->ranges[i].first; end[i] = net->ranges[i].second; }
+    return SNN_OK;
+}
 
 int snn_network_finalize_shard(snn_network_t *net, uint32_t shard_index, uint32_t n_shards)
 {
@@ -166,7 +233,7 @@ int snn_network_finalize_shard(snn_network_t *net, uint32_t shard_index, uint32_
     const uint32_t stride = std::max<uint32_t>(64, round_up((uint32_t)((nn + n_shards - 1) / n_shards), 64));
     const uint32_t begin = (uint32_t)std::min<uint64_t>(nn, (uint64_t)shard_index * stride);
     const uint32_t end = (uint32_t)std::min<uint64_t>(nn, (uint64_t)begin + stride);
-    return finalize_impl(net, false, begin, end, n_shards, stride, shard_index);
+    return finalize_impl(net, 1, begin, end, n_shards, stride, shard_index);
 }
 
 int snn_network_sizes(const snn_network_t *net, uint32_t *n_neurons, uint32_t *n_cells, uint32_t *post_begin,
@@ -271,17 +338,21 @@ static int set_graph_csr_impl(snn_network_t *net, const uint64_t *row_ptr, const
     if (!net->csr) return fail(SNN_ERR_BAD_STATE, "handle holds a dense graph: call snn_network_use_csr before finalize");
     if (!row_ptr || (nnz && (!pre_index || !weights))) return fail(SNN_ERR_BAD_ARG, "null graph pointer");
     if (nnz >= 0xFFFFFFFFull) return fail(SNN_ERR_DIM_MISMATCH, "more than 2^32-1 stored synapses per handle");
-    const uint32_t n_loc = net->n_loc;
-    if (row_ptr[0] != 0 || row_ptr[n_loc] != nnz) return fail(SNN_ERR_DIM_MISMATCH, "row_ptr must run from 0 to nnz");
+    // the caller's rows are the OWNED neurons in ascending order; a range-set shard places them on its local rows
+    // (global 64-blocks, holes in between keep length 0)
+    const uint32_t n_loc = net->n_loc, n_rows = net->n_owned;
+    auto local = [&](uint32_t k) { return net->block_mode ? net->owned_local_host[k] : k; };
+    if (row_ptr[0] != 0 || row_ptr[n_rows] != nnz) return fail(SNN_ERR_DIM_MISMATCH, "row_ptr must run from 0 to nnz");
     const uint32_t n_slices = (n_loc + 63) / 64;
     std::vector<uint32_t> slice_ptr((size_t)n_slices + 1, 0), row_len((size_t)n_slices * 64, 0), post(nnz),
         t_ptr((size_t)net->n_tot + 1, 0), t_edge(nnz), edge_slot(nnz);
-    for (uint32_t q = 0; q < n_loc; ++q) {
-        if (row_ptr[q + 1] < row_ptr[q]) return fail(SNN_ERR_DIM_MISMATCH, "row_ptr is not monotone");
-        row_len[q] = (uint32_t)(row_ptr[q + 1] - row_ptr[q]);
-        for (uint64_t e = row_ptr[q]; e < row_ptr[q + 1]; ++e) {
+    for (uint32_t k = 0; k < n_rows; ++k) {
+        const uint32_t q = local(k);
+        if (row_ptr[k + 1] < row_ptr[k]) return fail(SNN_ERR_DIM_MISMATCH, "row_ptr is not monotone");
+        row_len[q] = (uint32_t)(row_ptr[k + 1] - row_ptr[k]);
+        for (uint64_t e = row_ptr[k]; e < row_ptr[k + 1]; ++e) {
             if (pre_index[e] >= net->n_tot) return fail(SNN_ERR_DIM_MISMATCH, "presynaptic index out of range");
-            if (e > row_ptr[q] && pre_index[e] <= pre_index[e - 1])
+            if (e > row_ptr[k] && pre_index[e] <= pre_index[e - 1])
                 return fail(SNN_ERR_BAD_ARG, "presynaptic indices of a row must be strictly ascending");
             post[e] = q;
             ++t_ptr[pre_index[e] + 1];
@@ -299,10 +370,11 @@ static int set_graph_csr_impl(snn_network_t *net, const uint64_t *row_ptr, const
     slice_ptr[n_slices] = (uint32_t)entries;
     std::vector<uint32_t> sell_pre(entries, SELL_PAD);
     std::vector<float> sell_w(entries, 0.0f);
-    for (uint32_t q = 0; q < n_loc; ++q) {
+    for (uint32_t k = 0; k < n_rows; ++k) {
+        const uint32_t q = local(k);
         const uint32_t base = slice_ptr[q >> 6] + (q & 63u);
-        for (uint64_t e = row_ptr[q]; e < row_ptr[q + 1]; ++e) {
-            const uint32_t slot = base + (uint32_t)(e - row_ptr[q]) * 64;
+        for (uint64_t e = row_ptr[k]; e < row_ptr[k + 1]; ++e) {
+            const uint32_t slot = base + (uint32_t)(e - row_ptr[k]) * 64;
             sell_pre[slot] = pre_index[e];
             sell_w[slot] = weights[e];
             edge_slot[e] = slot;
@@ -854,7 +926,7 @@ int snn_halo_set_sends(snn_network_t *net, uint32_t peer, const uint32_t *indice
     if (peer >= net->n_shards || peer == net->shard_index) return fail(SNN_ERR_BAD_ARG, "peer must be another shard");
     if (net->halo_send.size() != net->n_shards) halo_reset(net);
     for (uint32_t i = 0; i < count; ++i)
-        if (indices[i] < net->q0 || indices[i] >= net->q1)
+        if (indices[i] >= net->nn || !owns(net, indices[i]))
             return fail(SNN_ERR_DIM_MISMATCH, "a send list may only name neurons this handle owns");
     TRY(end_run(net));
     net->halo_send[peer].assign(indices, indices + count);

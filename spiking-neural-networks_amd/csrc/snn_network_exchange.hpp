@@ -22,6 +22,36 @@ int upload_table(T **dev, const std::vector<T> &host)
     return SNN_OK;
 }
 
+// which shard owns neuron p
+uint32_t owner_of(const snn_network *net, uint32_t p)
+{
+    if (!net->block_mode) return net->shard_stride ? p / net->shard_stride : 0u;
+    for (const auto &l : net->lattices)
+        if (p >= l.first && p < l.first + l.count) return (p - l.first) / net->lattice_slab[l.slot];
+    return 0u;
+}
+bool owns(const snn_network *net, uint32_t p)
+{
+    return net->block_mode ? net->local_row_host[p] != 0xFFFFFFFFu : (p >= net->q0 && p < net->q1);
+}
+
+// A range-set shard without a committed halo plan trades whole ownerships (what the all-gather does for contiguous
+// shards): it reads every neuron of every peer and sends all of its own to each.
+void synthesize_full_lists(snn_network *net)
+{
+    net->halo_need.assign(net->n_shards, {});
+    net->halo_send.assign(net->n_shards, {});
+    for (uint32_t p = 0; p < net->nn; ++p) {
+        const uint32_t o = owner_of(net, p);
+        if (o == net->shard_index) {
+            for (uint32_t s = 0; s < net->n_shards; ++s)
+                if (s != net->shard_index) net->halo_send[s].push_back(p);
+        } else if (o < net->n_shards) {
+            net->halo_need[o].push_back(p);
+        }
+    }
+}
+
 // (Re)builds the plan: planes on the wire, per-peer segments, device tables.  which = 0 pack, 1 unpack.
 int ensure_exchange_plan(snn_network *net)
 {
@@ -45,7 +75,8 @@ int ensure_exchange_plan(snn_network *net)
     net->x_recv_off.assign(G, 0); net->x_recv_words.assign(G, 0);
     std::vector<uint32_t> cnt[2], first[2];
     std::vector<uint64_t> off[2], loff[2];
-    net->x_mode = (net->csr && net->halo_committed) ? SNN_EXCHANGE_HALO : SNN_EXCHANGE_ALLGATHER;
+    net->x_mode = ((net->csr && net->halo_committed) || net->block_mode) ? SNN_EXCHANGE_HALO : SNN_EXCHANGE_ALLGATHER;
+    if (net->block_mode && !net->halo_committed) synthesize_full_lists(net);
     if (net->x_mode == SNN_EXCHANGE_ALLGATHER) {
         net->x_block_words = segment_words(P, net->shard_stride);
         for (uint32_t p = 0; p < G; ++p) {
@@ -151,10 +182,10 @@ void halo_needs_from_rows(snn_network *net, const uint32_t *pre_index, uint64_t 
     std::vector<uint8_t> seen(net->nn, 0);
     for (uint64_t e = 0; e < nnz; ++e) {
         const uint32_t p = pre_index[e];
-        if (p < net->nn && (p < net->q0 || p >= net->q1)) seen[p] = 1;
+        if (p < net->nn && !owns(net, p)) seen[p] = 1;
     }
     for (uint32_t p = 0; p < net->nn; ++p)
-        if (seen[p]) net->halo_need[p / net->shard_stride].push_back(p);
+        if (seen[p]) net->halo_need[owner_of(net, p)].push_back(p);
 }
 
 // ---- RCCL, resolved at first use ---------------------------------------------------------------------------------

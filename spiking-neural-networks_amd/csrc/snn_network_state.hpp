@@ -108,6 +108,17 @@ struct snn_network {
     // n_shards equal slots of shard_stride neurons
     bool sharded = false;
     uint32_t n_shards = 1, shard_index = 0, shard_stride = 0;
+    // Range-set ownership (snn_network_finalize_shard_by_lattice, sparse handles): shard s owns slab s of EVERY neuron
+    // lattice; local rows = the global 64-blocks that hold an owned neuron (RowMap, snn_layout.hpp)
+    bool block_mode = false;
+    std::vector<uint32_t> lattice_slab;                         // per neuron lattice slot: neurons per slab
+    std::vector<std::pair<uint32_t, uint32_t>> ranges;          // owned [begin, end), ascending (every handle has them)
+    uint32_t n_owned = 0;
+    std::vector<uint32_t> owned_local_host;                     // k-th owned neuron (ascending) -> local row
+    std::vector<uint32_t> local_row_host;                       // [nn] global neuron -> local row or 0xFFFFFFFF
+    uint32_t *own_block_dev = nullptr, *local_row_dev = nullptr;
+    unsigned long long *own_mask_dev = nullptr;
+    RowMap rowmap{};
     // ---- exchange plan (snn_kernels_exchange.hpp), rebuilt by ensure_exchange_plan when x_dirty ----
     bool x_dirty = true;
     int x_mode = SNN_EXCHANGE_ALLGATHER;

@@ -47,7 +47,7 @@ bool stdp_deferral_applies(const snn_network *net)
 StdpArgs stdp_args(snn_network *net)
 {
     StdpArgs a{};
-    a.W = net->W; a.ld = net->ld; a.n_loc = net->n_loc; a.q0 = net->q0; a.n_neurons = net->nn; a.n_tot = net->n_tot;
+    a.W = net->W; a.ld = net->ld; a.n_loc = net->n_loc; a.q0 = net->q0; a.rows = net->rowmap; a.n_neurons = net->nn; a.n_tot = net->n_tot;
     a.xbuf = net->xbuf; a.xl = net->xl;
     a.last_firing_time = net->na.last_firing_time; a.st_last_firing_time = net->ca.last_firing_time;
     a.lattice_slot = net->lattice_slot; a.stdp = net->stdp_dev; a.do_plasticity = net->plast_dev;
@@ -81,7 +81,7 @@ int launch_inputs(snn_network *net, InputsPart part = INPUTS_ALL)
     if (part == INPUTS_LOCAL) { a.chunk_first = lc_begin; grid_chunks = lc_count; }
     if (part == INPUTS_REMOTE) { a.hole_begin = lc_begin; a.hole_count = lc_count; grid_chunks = net->n_chunks - lc_count; }
     if (grid_chunks == 0) return SNN_OK;
-    a.W = net->W; a.ld = net->ld; a.n_loc = net->n_loc; a.q0 = net->q0; a.n_neurons = net->nn; a.n_tot = net->n_tot;
+    a.W = net->W; a.ld = net->ld; a.n_loc = net->n_loc; a.q0 = net->q0; a.rows = net->rowmap; a.n_neurons = net->nn; a.n_tot = net->n_tot;
     a.xbuf = net->xbuf; a.xl = net->xl; a.gap_conductance = net->na.gap_conductance;
     a.st_value = net->ca.presyn_value; a.st_last_firing_time = net->ca.last_firing_time;
     a.st_nt_t = net->ca.nt_t; a.st_nt_flags = net->ca.nt_flags; a.c_pad = net->c_pad;
@@ -214,7 +214,7 @@ int launch_update(snn_network *net)
     UpdateArgs a{};
     a.n = net->na;
     a.part_i = net->part_i; a.part_t = net->part_t; a.n_in = net->n_in; a.tcount = net->tcount;
-    a.ld = net->ld; a.n_chunks = net->n_tot ? net->n_chunks : 0; a.q0 = net->q0; a.n_loc = net->n_loc;
+    a.ld = net->ld; a.n_chunks = net->n_tot ? net->n_chunks : 0; a.q0 = net->q0; a.n_loc = net->n_loc; a.rows = net->rowmap;
     a.clock = net->clock;
     a.electrical = net->electrical; a.chemical = net->chemical; a.nt_kind = net->nt_kind; a.rc_kind = net->rc_kind;
     a.vhist_row = (record_now(net) && net->want_vhist && net->vhist) ? net->vhist + (size_t)net->hist_steps * net->n_pad : nullptr;
@@ -312,7 +312,7 @@ int launch_rstdp_pass(snn_network *net, int dop)
     if (net->csr) {
         if (!net->csr_ptr) return SNN_OK;
         CsrRewardArgs a{};
-        a.g = csr_graph(net); a.c = net->trace; a.q0 = net->q0; a.n_neurons = net->nn;
+        a.g = csr_graph(net); a.c = net->trace; a.q0 = net->q0; a.rows = net->rowmap; a.n_neurons = net->nn;
         a.last_firing_time = net->na.last_firing_time; a.lattice_slot = net->lattice_slot;
         a.rm = net->rm_dev; a.rm_on = net->rm_on_dev; a.dop = dop;
         hipLaunchKernelGGL(k_rstdp_csr, dim3((net->n_loc + 255) / 256), dim3(256), 0, net->stream, a);
@@ -459,7 +459,7 @@ int fused_step_args(snn_network *net, InputsArgs &a, UpdateArgs &u)
     float *cur = net->shadow[net->shadow_cur], *next = net->shadow[net->shadow_cur ^ 1];
     a = InputsArgs{};
     a.chunk_first = 0; a.hole_begin = net->n_chunks; a.hole_count = 0;
-    a.W = net->W; a.ld = net->ld; a.n_loc = net->n_loc; a.q0 = net->q0; a.n_neurons = net->nn; a.n_tot = net->n_tot;
+    a.W = net->W; a.ld = net->ld; a.n_loc = net->n_loc; a.q0 = net->q0; a.rows = net->rowmap; a.n_neurons = net->nn; a.n_tot = net->n_tot;
     a.xbuf = cur; a.xl = net->xl; a.gap_conductance = net->na.gap_conductance;
     a.st_value = net->ca.presyn_value; a.st_last_firing_time = net->ca.last_firing_time;
     a.st_nt_t = net->ca.nt_t; a.st_nt_flags = net->ca.nt_flags; a.c_pad = net->c_pad;
@@ -470,7 +470,7 @@ int fused_step_args(snn_network *net, InputsArgs &a, UpdateArgs &u)
     u.n = net->na;
     u.n.xbuf = cur;
     u.part_i = net->part_i; u.part_t = net->part_t; u.n_in = net->n_in; u.tcount = net->tcount;
-    u.ld = net->ld; u.n_chunks = net->n_chunks; u.q0 = net->q0; u.n_loc = net->n_loc;
+    u.ld = net->ld; u.n_chunks = net->n_chunks; u.q0 = net->q0; u.n_loc = net->n_loc; u.rows = net->rowmap;
     u.clock = net->clock;
     u.electrical = net->electrical; u.chemical = net->chemical; u.nt_kind = net->nt_kind; u.rc_kind = net->rc_kind;
     u.vhist_row = (record_now(net) && net->want_vhist && net->vhist) ? net->vhist + (size_t)net->hist_steps * net->n_pad : nullptr;
@@ -669,6 +669,10 @@ int begin_run(snn_network *net, uint64_t iterations)
 {
     TRY(ensure_counts(net));
     TRY(ensure_exchange_plan(net));
+    if ((net->want_avg || net->want_eeg) && net->sharded && net->n_shards > 1 &&
+        (net->x_mode != SNN_EXCHANGE_ALLGATHER || !net->electrical))
+        return fail(SNN_ERR_BAD_STATE, "per-lattice voltage reductions on a shard handle need every neuron's voltage: "
+                                       "an all-gather exchange with electrical synapses on");
     TRY(grow_history(net, iterations));
     if (net->run_active) return SNN_OK;
     if (net->nc) {

@@ -69,13 +69,16 @@ class DeviceNetwork:
         self._check(self._L.snn_network_add_spike_train_lattice(self._h, id, rows, cols))
         self.lattices[id] = (rows, cols, True)
 
-    def finalize(self, shard_index=None, n_shards=None, csr=False):
-        """csr=True: the handle holds a sparse CSR graph (set_graph_csr) instead of a dense matrix"""
+    def finalize(self, shard_index=None, n_shards=None, csr=False, by_lattice=False):
+        """csr=True: the handle holds a sparse CSR graph (set_graph_csr) instead of a dense matrix; by_lattice=True
+        (sparse shard handles): the shard owns slab `shard_index` of EVERY neuron lattice instead of one contiguous slot"""
         if csr:
             self._check(self._L.snn_network_use_csr(self._h, 1))
         self.csr = bool(csr)
         if shard_index is None:
             self._check(self._L.snn_network_finalize(self._h))
+        elif by_lattice:
+            self._check(self._L.snn_network_finalize_shard_by_lattice(self._h, shard_index, n_shards))
         else:
             self._check(self._L.snn_network_finalize_shard(self._h, shard_index, n_shards))
         self.finalized = True
@@ -84,7 +87,19 @@ class DeviceNetwork:
         self.n_neurons, self.n_cells = nn.value, nc.value
         self.n_tot = self.n_neurons + self.n_cells
         self.post_begin, self.post_end = q0.value, q1.value
+        n = C.c_uint32()
+        self._check(self._L.snn_shard_ranges(self._h, None, None, 0, C.byref(n)))
+        b, e = np.zeros(n.value, np.uint32), np.zeros(n.value, np.uint32)
+        if n.value:
+            self._check(self._L.snn_shard_ranges(self._h, b.ctypes.data_as(_lib.u32p), e.ctypes.data_as(_lib.u32p), n.value, C.byref(n)))
+        self.ranges = [(int(x), int(y)) for x, y in zip(b, e)]          # owned [begin, end), ascending
         return self
+
+    @property
+    def owned(self):
+        """global indices of the neurons this handle owns, ascending (the row order of set_graph_csr)"""
+        return (np.concatenate([np.arange(b, e, dtype=np.int64) for b, e in self.ranges]) if self.ranges
+                else np.zeros(0, np.int64))
 
     def lattice_range(self, id):
         first, count = C.c_uint32(), C.c_uint32()
@@ -142,12 +157,13 @@ class DeviceNetwork:
         return w, c
 
     def set_graph_csr(self, row_ptr, pre_index, weights):
-        """CSR by local postsynaptic neuron: row_ptr[n_local+1], pre_index ascending inside each row"""
+        """CSR by OWNED postsynaptic neuron in ascending global order (self.owned): row_ptr[n_owned + 1], pre_index
+        ascending inside each row"""
         rp = np.ascontiguousarray(row_ptr, dtype=np.uint64)
         pi = np.ascontiguousarray(pre_index, dtype=np.uint32)
         w = np.ascontiguousarray(weights, dtype=np.float32)
-        if rp.size != (self.post_end - self.post_begin) + 1 or pi.size != w.size:
-            raise ValueError("row_ptr must have n_local + 1 entries and pre_index / weights equal lengths")
+        if rp.size != sum(e - b for b, e in self.ranges) + 1 or pi.size != w.size:
+            raise ValueError("row_ptr must have one entry per owned neuron + 1 and pre_index / weights equal lengths")
         self._nnz = int(w.size)
         self._check(self._L.snn_set_graph_csr(self._h, rp.ctypes.data_as(_lib.u64p), pi.ctypes.data_as(_lib.u32p),
                                              w.ctypes.data_as(_lib.f32p), w.size))

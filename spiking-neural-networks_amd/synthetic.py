@@ -26,8 +26,8 @@ def uniform(seed, count, lo, hi, offset=0):
     return (np.float32(lo) + (np.float32(hi) - np.float32(lo)) * u).astype(np.float32)
 
 
-def c5_csr(side, q0=None, q1=None):
-    """CSR rows (local posts q0..q1) of BASELINE configs[4]: four side x side neuron
+def c5_csr(side, q0=None, q1=None, posts=None):
+    """CSR rows (posts q0..q1, or the ascending global indices `posts`) of BASELINE configs[4]: four side x side neuron
     lattices (ids 0-3), internal radius-<=2 neighbourhood (<= 12 in-edges, w = 1), one Poisson lattice per
     neuron lattice (ids 4-7) wired one-to-one (w = 1), lattice k -> k+1 (mod 4) one-to-one (w = 1).
     Returns (row_ptr uint64, pre_index uint32 ascending per row, weights float32)."""
@@ -35,7 +35,7 @@ def c5_csr(side, q0=None, q1=None):
     nn = 4 * m
     q0 = 0 if q0 is None else q0
     q1 = nn if q1 is None else q1
-    q = np.arange(q0, q1, dtype=np.int64)
+    q = np.arange(q0, q1, dtype=np.int64) if posts is None else np.asarray(posts, dtype=np.int64)
     k, rem = q // m, q % m
     r, c = rem // side, rem % side
     offs = [(dr, dc) for dr in range(-2, 3) for dc in range(-2, 3) if 0 < dr * dr + dc * dc <= 4]

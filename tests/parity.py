@@ -104,6 +104,17 @@ def csr_from_dense(net, q0, q1):
     return row_ptr, pre.astype(np.uint32), weights.astype(np.float32)
 
 
+def csr_for_posts(net, posts):
+    """CSR rows of the postsynaptic neurons `posts` (ascending global indices) of the oracle's dense masked matrix"""
+    posts = np.asarray(posts, dtype=np.int64)
+    conn = net["connections"][:, posts]
+    pre, _ = np.nonzero(conn.T)[::-1]
+    counts = conn.sum(axis=0, dtype=np.uint64)
+    row_ptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64)
+    weights = net["weights"][:, posts].T[conn.T != 0]
+    return row_ptr, pre.astype(np.uint32), weights.astype(np.float32)
+
+
 def dense_from_csr(net, q0, q1, csr_weights):
     """Scatter CSR-ordered weights back into a dense [n_tot, q1-q0] block (absent edges 0)."""
     conn = net["connections"][:, q0:q1]
@@ -112,8 +123,9 @@ def dense_from_csr(net, q0, q1, csr_weights):
     return out.T
 
 
-def device_from_oracle(snn, net, shard=None, device=0, csr=False):
-    """Create a DeviceNetwork holding exactly the oracle net's state (dense or CSR graph form)."""
+def device_from_oracle(snn, net, shard=None, device=0, csr=False, by_lattice=False):
+    """Create a DeviceNetwork holding exactly the oracle net's state (dense or CSR graph form).  shard = (index, count);
+    by_lattice: the shard owns that slab of every lattice (sparse handles)."""
     lay = net.layout
     dn = snn.DeviceNetwork(model=net.model, nt_kinetics=net.nt_kind, receptor_kinetics=net.rc_kind,
                            spike_train=net.st_kind, device=device, lib_path=getattr(net, "custom_lib", None))
@@ -124,7 +136,7 @@ def device_from_oracle(snn, net, shard=None, device=0, csr=False):
     if shard is None:
         dn.finalize(csr=csr)
     else:
-        dn.finalize(*shard, csr=csr)
+        dn.finalize(*shard, csr=csr, by_lattice=by_lattice)
     push_state(dn, net)
     if net.st_kind == ob.ST_PRESET:
         rng = lay.ranges()
@@ -135,7 +147,7 @@ def device_from_oracle(snn, net, shard=None, device=0, csr=False):
             dn.set_firing_times(i, ptr[first:first + count + 1] - ptr[first], times[lo:hi])
     nn = net.n_neurons
     if csr:
-        dn.set_graph_csr(*csr_from_dense(net, dn.post_begin, dn.post_end))
+        dn.set_graph_csr(*csr_for_posts(net, dn.owned))
     elif net.n_tot and nn:
         dn.set_graph_rows(0, net["weights"], net["connections"].astype(np.uint32))
     dn.set_synapses(net.electrical, net.chemical)
@@ -315,10 +327,8 @@ def assert_graph_equal(net, dn):
         return
     oc = net["connections"].astype(np.uint32)
     if getattr(dn, "csr", False):
-        b, e = dn.post_begin, dn.post_end
-        w = dense_from_csr(net, b, e, dn.get_graph_csr())
-        ow = np.where(oc[:, b:e] != 0, net["weights"][:, b:e], np.float32(0))
-        assert np.array_equal(bits(ow), bits(w)), "CSR weights differ"
+        _, _, want = csr_for_posts(net, dn.owned)
+        assert np.array_equal(bits(want), bits(dn.get_graph_csr())), "CSR weights differ"
         return
     w, c = dn.get_graph_rows(0, net.n_tot)
     assert np.array_equal(c, oc), "connection masks differ"
@@ -337,7 +347,7 @@ def assert_shard_view_equal(h, st, net):
     nn = net.n_neurons
     known = np.zeros(nn, bool)
     own = np.zeros(nn, bool)
-    own[h.post_begin:h.post_end] = True
+    own[h.owned] = True
     if plan["mode"] == "halo":
         for p in range(plan["n_shards"]):
             if p != plan["shard_index"]:

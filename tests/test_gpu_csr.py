@@ -116,21 +116,31 @@ def test_c5_structure_csr(snn):
     dn.close()
 
 
-@pytest.mark.parametrize("n_shards,halo", [(2, False), (4, False), (2, True), (4, True), (8, True)])
-def test_c5_structure_csr_sharded(snn, n_shards, halo):
+@pytest.mark.parametrize("n_shards,halo,by_lattice", [(2, False, False), (4, False, False), (2, True, False), (4, True, False),
+                                                      (8, True, False), (2, True, True), (3, True, True), (4, False, True)])
+def test_c5_structure_csr_sharded(snn, n_shards, halo, by_lattice):
     """configs[4]'s multi-GPU shape on one device: sparse shard handles + the emulated exchange -- whole slots
     (all-gather) or, with a committed halo plan, exactly the neurons each peer's rows reference."""
     import torch
     from snn_amd import parallel
-    net = c5_structure(8)
+    side = 16 if by_lattice else 8               # slabs are multiples of 64 neurons: 16 x 16 lattices split 2 to 4 ways
+    net = c5_structure(side)
     net["do_plasticity"] = 1
-    handles = [parity.device_from_oracle(snn, net, shard=(r, n_shards), csr=True) for r in range(n_shards)]
+    handles = [parity.device_from_oracle(snn, net, shard=(r, n_shards), csr=True, by_lattice=by_lattice)
+               for r in range(n_shards)]
     ex = parallel.LocalExchange(handles, torch.device("cuda", 0), halo=halo)
-    assert all(p["mode"] == ("halo" if halo else "allgather") and p["planes"] == 1 for p in ex.plans)
+    # a shard that owns a slab of EVERY lattice always trades lists (whole ownerships until a halo plan is committed)
+    assert all(p["mode"] == ("halo" if halo or by_lattice else "allgather") and p["planes"] == 1 for p in ex.plans)
+    if by_lattice:
+        owned = np.concatenate([h.owned for h in handles])
+        assert np.array_equal(np.sort(owned), np.arange(net.n_neurons))          # a partition of the population
+        assert all(len(h.ranges) in (0, 4) for h in handles)                     # one slab per lattice (or nothing: 3 shards)
+        if halo:    # the ring edge k -> k+1 stays inside the shard: only the two lattice rows either side of a slab travel
+            assert max(ex.bytes_per_step()) <= 4 * (4 * 4 * side + 4 * 4 * side // 32 + 8)
     read = []                                    # per handle: own neurons + what its rows read
     for r, h in enumerate(handles):
         k = np.zeros(net.n_neurons, bool)
-        k[h.post_begin:h.post_end] = True
+        k[h.owned] = True
         if halo:
             for p in range(n_shards):
                 if p != r:
@@ -150,8 +160,8 @@ def test_c5_structure_csr_sharded(snn, n_shards, halo):
             assert np.array_equal(parity.bits(st[name][k]), parity.bits(net[name][k])), name
         for name in ("st_last_firing_time", "st_seed"):
             assert np.array_equal(parity.bits(st[name]), parity.bits(net[name])), name
-        b, e = h.post_begin, h.post_end
-        assert np.array_equal(parity.bits(st["w_value"][b:e]), parity.bits(net["w_value"][b:e]))
+        o = h.owned
+        assert np.array_equal(parity.bits(st["w_value"][o]), parity.bits(net["w_value"][o]))
         parity.assert_graph_equal(net, h)
         h.close()
 

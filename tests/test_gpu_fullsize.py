@@ -217,7 +217,7 @@ def test_c4_full_size_network_with_stdp_sampled(snn):
     dn.close()
 
 
-def c5_handle(snn, side, v0, shard=None):
+def c5_handle(snn, side, v0, shard=None, by_lattice=False):
     """BASELINE configs[4] on a (shard) handle: 4 Izhikevich lattices + 4 Poisson lattices, CSR rows of the handle"""
     from snn_amd import synthetic
     f32 = np.float32
@@ -229,13 +229,13 @@ def c5_handle(snn, side, v0, shard=None):
     if shard is None:
         dn.finalize(csr=True)
     else:
-        dn.finalize(shard[0], shard[1], csr=True)
+        dn.finalize(shard[0], shard[1], csr=True, by_lattice=by_lattice)
     for k in range(4):
         dn.set_attr(k, "gap_conductance", np.full(m, 10.0, f32))
         dn.set_attr(k, "current_voltage", v0[k * m:(k + 1) * m])
         dn.set_attr(4 + k, "chance_of_firing", np.full(m, 0.01, f32))
         dn.set_attr(4 + k, "seed", np.arange(k * m + 1, (k + 1) * m + 1, dtype=np.uint32))
-    dn.set_graph_csr(*synthetic.c5_csr(side, dn.post_begin, dn.post_end))
+    dn.set_graph_csr(*synthetic.c5_csr(side, posts=dn.owned))
     return dn
 
 
@@ -359,4 +359,29 @@ def test_c5_full_size_sparse_network_against_numpy(snn):
                 assert np.array_equal(parity.bits(v_all[need]), parity.bits(st["current_voltage"][need])), (r, p)
                 assert np.array_equal(l_all[need], lft[need]), (r, p)
                 break                           # one peer per handle keeps the test short
+        h.close()
+
+    # ---- eight shard handles that own the same slab of EVERY lattice: the ring edge k -> k+1 stays inside a handle ----
+    handles = [c5_handle(snn, side, v0, shard=(r, g), by_lattice=True) for r in range(g)]
+    ex = parallel.LocalExchange(handles, torch.device("cuda", 0), halo=True)
+    # per handle and step: two lattice rows of 512 either side of each of its four slabs (fewer at the lattice edges),
+    # 4 B + 1 bit each: <= 33.8 KB instead of 545 KB
+    per_step = ex.bytes_per_step()
+    assert max(per_step) <= 4 * (4 * 4 * side + 4 * 4 * side // 32 + 8), per_step
+    for _ in range(steps):
+        ex.step()
+    for h in handles:
+        o = h.owned
+        assert len(h.ranges) == 4 and o.size == nn // g
+        v_all = np.concatenate([h.get_attr(k, "current_voltage") for k in range(4)])
+        w_all = np.concatenate([h.get_attr(k, "w_value") for k in range(4)])
+        l_all = np.concatenate([h.get_attr(k, "last_firing_time", dtype=np.int32) for k in range(4)])
+        assert np.array_equal(parity.bits(v_all[o]), parity.bits(st["current_voltage"][o]))
+        assert np.array_equal(parity.bits(w_all[o]), parity.bits(st["w_value"][o]))
+        assert np.array_equal(l_all[o], lft[o])
+        r = ex.plans[handles.index(h)]["shard_index"]
+        need = np.concatenate([h.halo_needs(p) for p in range(g) if p != r])
+        assert np.array_equal(parity.bits(v_all[need]), parity.bits(st["current_voltage"][need]))
+        assert np.array_equal(l_all[need], lft[need])
+        assert np.array_equal(h.get_attr(5, "seed", dtype=np.uint32), seed[m:2 * m])
         h.close()

@@ -96,7 +96,7 @@ def draw(seed):
     if st_kind == ob.ST_BCM_POISSON:
         net["st_bcm_window"] = ob.uniform_array(seed + 13, nc, 5 * dt, 40 * dt)
         net["st_bcm_period"] = rng.integers(1, 6, nc).astype(np.uint32)
-    plan = dict(csr=bool(rng.integers(0, 2)), shards=int(rng.choice([1, 1, 2, 3])),
+    plan = dict(csr=bool(rng.integers(0, 2)), shards=int(rng.choice([1, 1, 2, 3])), by_lattice=bool(rng.integers(0, 2)),
                 steps=int(rng.integers(80, 260)), calls=int(rng.integers(1, 4)), stride=int(rng.choice([1, 1, 2, 5])))
     if net["plasticity_kind"].any():
         plan["shards"] = 1                                      # BCM activities are not exchanged between shards
@@ -111,20 +111,22 @@ def draw(seed):
 RM_KEYS = ("rm_dopamine", "rm_tau_d", "rm_tau_c", "rm_a_plus", "rm_a_minus", "rm_tau_plus", "rm_tau_minus", "rm_dt")
 
 
-def csr_order(net, dense, b, e):
-    """values of a dense [n_tot][n_neurons] array in the CSR-by-post edge order of columns b..e"""
-    ptr, pre, _ = parity.csr_from_dense(net, b, e)
-    return np.concatenate([dense[pre[ptr[q]:ptr[q + 1]], b + q] for q in range(e - b)]) if e > b else np.zeros(0, np.float32)
+def csr_order(net, dense, posts):
+    """values of a dense [n_tot][n_neurons] array in the CSR-by-post edge order of the columns `posts`"""
+    ptr, pre, _ = parity.csr_for_posts(net, posts)
+    return (np.concatenate([dense[pre[ptr[k]:ptr[k + 1]], q] for k, q in enumerate(posts)]) if len(posts)
+            else np.zeros(0, np.float32))
 
 
 def make_handle(snn, net, plan, shard=None):
-    dn = parity.device_from_oracle(snn, net, shard=shard, csr=plan["csr"])
+    dn = parity.device_from_oracle(snn, net, shard=shard, csr=plan["csr"],
+                                   by_lattice=bool(shard is not None and plan["csr"] and plan.get("by_lattice")))
     if plan["rewards"] is not None:
         for slot, (i, _, _) in enumerate(net.layout.lattices):
             if net["rm_do_modulation"][slot]:
                 dn.set_reward_modulator(i, *(float(net[k][slot]) for k in RM_KEYS), do_modulation=True)
         if plan["csr"]:
-            dn.set_traces_csr(csr_order(net, net["traces"], dn.post_begin, dn.post_end))
+            dn.set_traces_csr(csr_order(net, net["traces"], dn.owned))
         elif net.n_neurons and net.n_tot:
             dn.set_trace_rows(0, net["traces"])
     return dn
@@ -135,7 +137,7 @@ def check_modulation(dn, net, plan):
         return
     b, e = dn.post_begin, dn.post_end
     if plan["csr"]:
-        assert np.array_equal(parity.bits(dn.get_traces_csr()), parity.bits(csr_order(net, net["traces"], b, e)))
+        assert np.array_equal(parity.bits(dn.get_traces_csr()), parity.bits(csr_order(net, net["traces"], dn.owned)))
     elif net.n_neurons and net.n_tot:
         t = dn.get_trace_rows(0, net.n_tot)
         assert np.array_equal(parity.bits(t[:, b:e]), parity.bits(net["traces"][:, b:e]))
@@ -200,7 +202,7 @@ def test_random_network(snn, seed):
         parity.assert_shard_view_equal(h, st, net)
         b, e = h.post_begin, h.post_end
         for name in ("rc_r", "rc_current"):
-            assert np.array_equal(parity.bits(st[name][b:e]), parity.bits(net[name][b:e])), name
+            assert np.array_equal(parity.bits(st[name][h.owned]), parity.bits(net[name][h.owned])), name
         if h.csr:
             parity.assert_graph_equal(net, h)
         elif net.n_neurons and net.n_tot:

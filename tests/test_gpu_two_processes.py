@@ -19,9 +19,9 @@ STEPS = 300
 def build(form):
     import oracle_binding as ob
     import parity
-    if form == "csr":
+    if form.startswith("csr"):
         from test_gpu_csr import c5_structure
-        net = c5_structure(8)
+        net = c5_structure(16 if form == "csr_by_lattice" else 8)
         net["do_plasticity"] = 1
         return net
     lay = parity.Layout([(0, 9, 10), (3, 12, 12)], [(5, 3, 4)])
@@ -51,8 +51,9 @@ def worker(rank, world, init_file, out_dir, form):
     import parity
     dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
     net = build(form)
-    dn = parity.device_from_oracle(snn_amd, net, shard=(rank, world), csr=(form == "csr"))
-    if form == "csr":
+    dn = parity.device_from_oracle(snn_amd, net, shard=(rank, world), csr=form.startswith("csr"),
+                                   by_lattice=(form == "csr_by_lattice"))
+    if form.startswith("csr"):
         # the need lists cross the process boundary too: what I read of peer p becomes p's send list for me
         needs = [dn.halo_needs(p) if p != rank else np.zeros(0, np.uint32) for p in range(world)]
         gathered = [None] * world
@@ -89,15 +90,17 @@ def worker(rank, world, init_file, out_dir, form):
     dn.run_sharded_custom(exchange, STEPS - STEPS // 2)
     st = parity.pull_state(dn, net)
     known = np.zeros(net.n_neurons, bool)
-    known[dn.post_begin:dn.post_end] = True
+    own = np.zeros(net.n_neurons, bool)
+    own[dn.owned] = True
+    known |= own
     if plan["mode"] == "halo":
         for p in range(world):
             if p != rank:
                 known[dn.halo_needs(p)] = True
     else:
         known[:] = True
-    w = dn.get_graph_csr() if form == "csr" else dn.get_graph_rows(0, net.n_tot)[0]
-    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), q0=dn.post_begin, q1=dn.post_end, known=known, mode=plan["mode"],
+    w = dn.get_graph_csr() if form.startswith("csr") else dn.get_graph_rows(0, net.n_tot)[0]
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), own=own, known=known, mode=plan["mode"], recv_words=plan["recv_words"],
              weights=w, clock=dn.clock, **{k: st[k] for k in ("current_voltage", "is_spiking", "last_firing_time", "w_value", "nt_t")})
     dn.close()
     dist.barrier()
@@ -105,7 +108,7 @@ def worker(rank, world, init_file, out_dir, form):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("form,world", [("dense", 2), ("csr", 2), ("csr", 3)])
+@pytest.mark.parametrize("form,world", [("dense", 2), ("csr", 2), ("csr", 3), ("csr_by_lattice", 2)])
 def test_library_step_loop_across_processes_on_one_gpu(snn, form, world):
     import torch.multiprocessing as mp
     import parity
@@ -118,19 +121,21 @@ def test_library_step_loop_across_processes_on_one_gpu(snn, form, world):
         covered = np.zeros(ref.n_neurons, bool)
         for r in range(world):
             z = np.load(os.path.join(d, f"rank{r}.npz"))
-            q0, q1, k = int(z["q0"]), int(z["q1"]), z["known"]
-            assert str(z["mode"]) == ("halo" if form == "csr" else "allgather") and int(z["clock"]) == STEPS
+            own, k = z["own"], z["known"]
+            assert str(z["mode"]) == ("halo" if form.startswith("csr") else "allgather") and int(z["clock"]) == STEPS
             if form == "csr" and world > 2:
                 assert not k.all()                     # a genuinely partial view
-            covered[q0:q1] = True
+            if form == "csr_by_lattice":               # only the slab borders travel: 2 lattice rows x 16 x 4 lattices
+                assert int(z["recv_words"]) <= 4 * 2 * 16 + 8
+            covered |= own
             for name in ("current_voltage", "is_spiking", "last_firing_time"):
                 assert np.array_equal(parity.bits(z[name][k]), parity.bits(ref[name][k])), (r, name)
-            assert np.array_equal(parity.bits(z["nt_t"][q0:q1]), parity.bits(ref["nt_t"][q0:q1]))
-            assert np.array_equal(parity.bits(z["w_value"][q0:q1]), parity.bits(ref["w_value"][q0:q1]))
-            if form == "csr":
-                _, _, want = parity.csr_from_dense(ref, q0, q1)
+            assert np.array_equal(parity.bits(z["nt_t"][own]), parity.bits(ref["nt_t"][own]))
+            assert np.array_equal(parity.bits(z["w_value"][own]), parity.bits(ref["w_value"][own]))
+            if form.startswith("csr"):
+                _, _, want = parity.csr_for_posts(ref, np.flatnonzero(own))
                 assert np.array_equal(parity.bits(z["weights"]), parity.bits(want))
             else:
                 ow = np.where(ref["connections"] != 0, ref["weights"], np.float32(0))
-                assert np.array_equal(parity.bits(z["weights"][:, q0:q1]), parity.bits(ow[:, q0:q1]))
+                assert np.array_equal(parity.bits(z["weights"][:, own]), parity.bits(ow[:, own]))
         assert covered.all()
