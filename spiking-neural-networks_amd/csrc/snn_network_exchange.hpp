@@ -4,6 +4,7 @@
 // Included by snn_network.hip only (one translation unit).
 #pragma once
 #include <dlfcn.h>
+#include <mutex>
 #include <rccl/rccl.h>
 
 #include "snn_network_step.hpp"
@@ -204,17 +205,23 @@ struct Rccl {
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
 };
 
+void rccl_resolve(Rccl &r);
+
 Rccl *rccl()
 {
     static Rccl r;
-    static bool tried = false;
-    if (tried) return r.lib ? &r : nullptr;
-    tried = true;
+    static std::once_flag once;               // handles of different threads may reach for RCCL at the same time
+    std::call_once(once, [] { rccl_resolve(r); });
+    return r.lib ? &r : nullptr;
+}
+
+void rccl_resolve(Rccl &r)
+{
     for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
         r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
         if (r.lib) break;
     }
-    if (!r.lib) return nullptr;
+    if (!r.lib) return;
     bool ok = true;
     auto sym = [&](const char *n) { void *p = dlsym(r.lib, n); ok = ok && p; return p; };
     r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
@@ -228,8 +235,7 @@ Rccl *rccl()
     r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
     r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
     r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
-    if (!ok) { dlclose(r.lib); r.lib = nullptr; return nullptr; }
-    return &r;
+    if (!ok) { dlclose(r.lib); r.lib = nullptr; }
 }
 
 #define RCCL_LIB(R)                                                                               \

@@ -36,6 +36,7 @@ inline bool matrix_streamed(const snn_network *net)
 // STDP everywhere (the BCM rule reads the weight itself), nothing else rewriting or snapshotting W in step_end
 bool stdp_deferral_applies(const snn_network *net)
 {
+    if (SNN_HAVE_CUSTOM_MODEL) return false;      // a library carrying generated code keeps the standalone kernels (shorter compile)
     if (!net->defer_stdp || !net->any_plasticity || net->any_modulation || net->any_whist || !matrix_streamed(net) ||
         net->lattices.size() > (size_t)STDP_MAX_LATTICES || net->n_loc == 0)
         return false;
@@ -129,6 +130,7 @@ int launch_inputs(snn_network *net, InputsPart part = INPUTS_ALL)
     if (net->rstdp_pending && part != INPUTS_ALL) TRY(flush_rstdp(net));
     const bool stdp_fused = net->stdp_pending && !net->rstdp_pending && part == INPUTS_ALL && shape != 0;
     if (net->stdp_pending && !stdp_fused) TRY(flush_stdp(net));
+#if !SNN_HAVE_CUSTOM_MODEL
     if (stdp_fused) {
         // the STDP update of the previous step rides on this pass over W
         net->stdp_pending = false;
@@ -154,6 +156,7 @@ int launch_inputs(snn_network *net, InputsPart part = INPUTS_ALL)
         if (net->profile) HIP_TRY(hipEventRecord(e1, net->stream), SNN_ERR_QUEUE);
         return SNN_OK;
     }
+#endif
     if (net->rstdp_pending) {
         // the reward-modulated weight update of the previous step rides on this pass over W
         net->rstdp_pending = false;
@@ -191,12 +194,20 @@ int launch_inputs(snn_network *net, InputsPart part = INPUTS_ALL)
         else if (shape == 2) SNN_LAUNCH_SHAPE(E, C, 2, NT);                                              \
         else SNN_LAUNCH_SHAPE(E, C, 0, NT);                                                              \
     } while (0)
+#if !SNN_HAVE_CUSTOM_MODEL
 #define SNN_LAUNCH_CHEM(E)                                                                               \
     do {                                                                                                 \
         if (net->n_live == 1) SNN_LAUNCH_INPUTS(E, true, 1);                                             \
         else if (net->n_live == 2) SNN_LAUNCH_INPUTS(E, true, 2);                                        \
         else SNN_LAUNCH_INPUTS(E, true, 3);                                                              \
     } while (0)
+#else       // a library carrying generated code: the generic three-slot variant only (shorter compile)
+#define SNN_LAUNCH_CHEM(E)                                                                               \
+    do {                                                                                                 \
+        for (int k = 0; k < K_TYPES; ++k) a.live_type[k] = (uint32_t)k;                                  \
+        SNN_LAUNCH_INPUTS(E, true, 3);                                                                   \
+    } while (0)
+#endif
     if (net->electrical && net->chemical) SNN_LAUNCH_CHEM(true);
     else if (net->electrical) SNN_LAUNCH_INPUTS(true, false, 3);
     else SNN_LAUNCH_CHEM(false);
