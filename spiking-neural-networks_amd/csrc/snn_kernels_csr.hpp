@@ -57,7 +57,7 @@ __device__ __forceinline__ void csr_row_sums(const CsrInputsArgs &a, uint32_t q,
 
     const uint32_t gq_index = in.rows.global_of(qq);           // a hole row (no edges) reads some neuron's state, unused
     const float vq = ELEC ? in.xbuf[in.xl.at(gq_index, PLANE_V)] : 0.0f;
-    const float gq = ELEC ? in.gap_conductance[gq_index] : 0.0f;
+    const float gq = ELEC ? uload(in.uni, NP_GAP, in.gap_conductance, gq_index) : 0.0f;
 
     float part = 0.0f;
     float tpart[K_TYPES] = {0.0f, 0.0f, 0.0f};

@@ -42,6 +42,7 @@ struct InputsArgs {
     const float *xbuf;
     XLayout xl;
     const float *gap_conductance;
+    const UniformTable *uni;          // NeuronParam slots (NP_GAP)
     // spike-train cells
     const float *st_value;
     const int32_t *st_last_firing_time;

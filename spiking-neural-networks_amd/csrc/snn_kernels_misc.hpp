@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void k_spike_trains(const SpikeTrainArgs a)
             const uint32_t new_seed = xorshift32(c.seed[s]);
             c.seed[s] = new_seed;
             const float random_number = (float)new_seed / 4294967296.0f;   // (float) seed / 0xFFFFFFFF
-            spike = random_number < c.chance_of_firing[s];
+            spike = random_number < uload(c.uni, CP_CHANCE, c.chance_of_firing, s);
         } else if (a.st_kind == CUSTOM_SPIKE_TRAIN) {
             // generated spike train (nb_macro lib.rs:4884-4891): its on_iteration writes the voltage and the flag
             float x[custom_st::NSTORE];
@@ -142,7 +142,8 @@ __global__ __launch_bounds__(256) void k_spike_trains(const SpikeTrainArgs a)
             if (spike) step = 0.0f;
             c.step[s] = step;
         }
-        const float v = (a.st_kind == CUSTOM_SPIKE_TRAIN) ? custom_v : (spike ? c.v_th[s] : c.v_resting[s]);
+        const float cell_v_th = uload(c.uni, CP_V_TH, c.v_th, s), cell_v_resting = uload(c.uni, CP_V_RESTING, c.v_resting, s);
+        const float v = (a.st_kind == CUSTOM_SPIKE_TRAIN) ? custom_v : (spike ? cell_v_th : cell_v_resting);
         if (a.st_kind == 4) {
             // BCMPoissonNeuron::iterate (spike_train/mod.rs:931-954): activity = voltage change, replaced by the
             // firing rate when a window closes
@@ -178,19 +179,21 @@ __global__ __launch_bounds__(256) void k_spike_trains(const SpikeTrainArgs a)
     // presynaptic value of the next input calculation (spike_train_gap_junction, neuron/mod.rs:119-137):
     // never fired -> v_resting (used WITHOUT the conductance factor), else the refractoriness effect
     const int32_t lft = c.last_firing_time[s];
-    const uint32_t refr = c.refractoriness[s];
+    const uint32_t refr = uload(c.uni, CP_REFR, c.refractoriness, s);
+    const float p_v_th = uload(c.uni, CP_V_TH, c.v_th, s), p_v_resting = uload(c.uni, CP_V_RESTING, c.v_resting, s);
+    const float p_dt = uload(c.uni, CP_DT, c.dt, s), p_k = uload(c.uni, CP_K, c.k, s);
     float value;
     if (lft < 0) {
-        value = c.v_resting[s];
+        value = p_v_resting;
     } else if (SNN_HAVE_CUSTOM_REFRACTORINESS && refr == CUSTOM_REFRACTORINESS) {
         // generated get_effect (nb_macro lib.rs:5736-5750): time_difference = (timestep - last_firing_time) as f32
         float xr[custom_refr::NSTORE] = {};
 #pragma unroll
         for (int k = 0; k < custom_refr::NVARS; ++k) xr[k] = c.refr_custom[k][s];
-        value = custom_refr::effect((float)(a.view_clock - (long long)lft), c.v_th[s], c.v_resting[s], c.dt[s], c.k[s], xr);
+        value = custom_refr::effect((float)(a.view_clock - (long long)lft), p_v_th, p_v_resting, p_dt, p_k, xr);
     } else {
-        value = refr ? exponential_decay_effect(a.view_clock, lft, c.v_th[s], c.v_resting[s], c.k[s], c.dt[s])
-                     : delta_dirac_effect(a.view_clock, lft, c.v_th[s], c.v_resting[s], c.k[s], c.dt[s]);
+        value = refr ? exponential_decay_effect(a.view_clock, lft, p_v_th, p_v_resting, p_k, p_dt)
+                     : delta_dirac_effect(a.view_clock, lft, p_v_th, p_v_resting, p_k, p_dt);
     }
     c.presyn_value[s] = value;
 }
@@ -408,6 +411,20 @@ __global__ void k_synthetic_drive(float *xbuf, XLayout xl, uint32_t n, uint64_t 
 {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q < n && hash32(seed, (uint64_t)clock * n + q) < threshold) xbuf[xl.at(q, PLANE_V)] = voltage;
+}
+
+// Uniform-parameter scan (UniformTable, snn_layout.hpp): slot <- {1, bits of arr[0]}, cleared by any element that differs
+__global__ void k_uniform_begin(UniformTable *t, int slot, const uint32_t *arr, uint32_t n)
+{
+    t->flag[slot] = n ? 1u : 0u;
+    t->bits[slot] = n ? arr[0] : 0u;
+}
+__global__ __launch_bounds__(256) void k_uniform_scan(UniformTable *t, int slot, const uint32_t *arr, uint32_t n)
+{
+    const uint32_t first = arr[0];
+    bool differs = false;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) differs = differs || arr[i] != first;
+    if (differs) t->flag[slot] = 0u;
 }
 
 // device-function probe for the parity tests of the scalar formulas

@@ -218,8 +218,8 @@ __device__ __forceinline__ uint32_t update_neuron(const UpdateArgs &a, uint32_t 
         const uint32_t q = a.rows.global_of(ql);
         const size_t v_at = a.n.xl.at(q, PLANE_V), s_at = a.n.xl.at(q, PLANE_SPIKE);
         const float v = a.n.xbuf[v_at];
-        const float dt = a.n.dt[q];
-        const float c_m = a.n.c_m[q];
+        const float dt = uload(a.n.uni, NP_DT, a.n.dt, q);
+        const float c_m = uload(a.n.uni, NP_C_M, a.n.c_m, q);
         const uint32_t spiking_prev = reinterpret_cast<const uint32_t *>(a.n.xbuf)[s_at];
         if (MODEL == 0 && a.bcm) {
             // BCMIzhikevichNeuron::iterate_and_spike, integrate_and_fire/mod.rs:1458-1469 (electrical) / :1484-1495
@@ -244,7 +244,8 @@ __device__ __forceinline__ uint32_t update_neuron(const UpdateArgs &a, uint32_t 
         if (MODEL == 0) {            // Izhikevich
             const float w = a.n.w_value[q];
             const float dv = (0.04f * (v * v) + 5.0f * v + 140.0f - w + i_in) * (dt / c_m);
-            const float dw = (a.n.a[q] * (a.n.b[q] * v - w)) * (dt / a.n.tau_m[q]);
+            const float dw = (uload(a.n.uni, NP_A, a.n.a, q) * (uload(a.n.uni, NP_B, a.n.b, q) * v - w)) *
+                             (dt / uload(a.n.uni, NP_TAU_M, a.n.tau_m, q));
             if (a.chemical) {
                 const float neurotransmitter_dv = -receptor_currents(a, q, dt, c_m);
                 v_new = v + (dv + neurotransmitter_dv);
@@ -253,10 +254,10 @@ __device__ __forceinline__ uint32_t update_neuron(const UpdateArgs &a, uint32_t 
             }
             float w_new = w + dw;
             neuron_nt_update(a, q, v_new, spiking_prev, dt);
-            if (v_new >= a.n.v_th[q]) {
+            if (v_new >= uload(a.n.uni, NP_V_TH, a.n.v_th, q)) {
                 spike = 1;
-                v_new = a.n.c[q];
-                w_new += a.n.d[q];
+                v_new = uload(a.n.uni, NP_C, a.n.c, q);
+                w_new += uload(a.n.uni, NP_D, a.n.d, q);
             }
             a.n.w_value[q] = w_new;
         } else if (MODEL == 1) {     // leaky integrate-and-fire

@@ -58,11 +58,32 @@ struct RowMap {
     }
 };
 
+// Per-cell PARAMETERS that hold one value for the whole population (the usual case: a lattice is populated from one base
+// neuron) need not be streamed from HBM per cell and step.  The handle scans the read-only parameter arrays whenever
+// attributes were set (k_uniform_scan) and keeps {is uniform, the value's bits} per parameter in a small device table;
+// kernels read the table entry (one wave-uniform load) and fall back to the array otherwise.  Sparse / large
+// populations gain: BASELINE configs[4] streams 28 B less per neuron and 24 B less per Poisson cell and step.
+enum NeuronParam { NP_GAP = 0, NP_DT, NP_C_M, NP_V_TH, NP_A, NP_B, NP_C, NP_D, NP_TAU_M, NP_COUNT };
+enum CellParam { CP_V_TH = 0, CP_V_RESTING, CP_DT, CP_K, CP_CHANCE, CP_REFR, CP_COUNT };
+struct UniformTable {
+    uint32_t flag[16];
+    uint32_t bits[16];
+};
+__device__ __forceinline__ float uload(const UniformTable *u, int slot, const float *arr, uint32_t i)
+{
+    return u->flag[slot] ? __uint_as_float(u->bits[slot]) : arr[i];
+}
+__device__ __forceinline__ uint32_t uload(const UniformTable *u, int slot, const uint32_t *arr, uint32_t i)
+{
+    return u->flag[slot] ? u->bits[slot] : arr[i];
+}
+
 // Pointers the per-neuron update kernels need.  All arrays are device memory.
 struct NeuronArrays {
     // exchanged planes
     float *xbuf;
     XLayout xl;
+    const UniformTable *uni;         // NeuronParam slots
     // common
     float *gap_conductance, *dt, *c_m, *v_th;
     int32_t *last_firing_time;
@@ -97,6 +118,7 @@ struct NeuronArrays {
 
 // Spike-train cells (presynaptic only), length n_cells padded to 256.
 struct CellArrays {
+    const UniformTable *uni;         // CellParam slots
     float *current_voltage, *v_th, *v_resting, *dt, *k;
     float *chance_of_firing, *rate, *step;
     uint32_t *seed, *is_spiking;

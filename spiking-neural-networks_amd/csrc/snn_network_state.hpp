@@ -160,6 +160,10 @@ struct snn_network {
     float *stdp_dev = nullptr;
     uint32_t *plast_dev = nullptr;
     uint32_t *spike_list = nullptr, *spike_count = nullptr;
+    // uniform-parameter tables (UniformTable, snn_layout.hpp): rescanned when attributes were set
+    UniformTable *uni_neuron = nullptr, *uni_cell = nullptr;
+    bool uni_dirty = true;
+    int uniform_params = 1;               // 0: always read the arrays (SNN_AMD_UNIFORM_PARAMS=0)
     // deferred STDP (dense handles): the update of step t is applied by the input pass of step t + 1
     int defer_stdp = 1;                    // 0: always the standalone kernels (SNN_AMD_DEFER_STDP=0)
     bool stdp_pending = false;
@@ -317,6 +321,13 @@ int build_state(snn_network *net)
     auto &A = net->neuron_attrs;
     auto &CA = net->cell_attrs;
 
+    // uniform-parameter tables, all "not uniform" until the first scan
+    TRY(dev_alloc_t(net, &net->uni_neuron, 1));
+    TRY(dev_alloc_t(net, &net->uni_cell, 1));
+    HIP_TRY(hipMemsetAsync(net->uni_neuron, 0, sizeof(UniformTable), net->stream), SNN_ERR_BUFFER_WRITE);
+    HIP_TRY(hipMemsetAsync(net->uni_cell, 0, sizeof(UniformTable), net->stream), SNN_ERR_BUFFER_WRITE);
+    n.uni = net->uni_neuron;
+    c.uni = net->uni_cell;
     // exchanged planes
     TRY(dev_alloc_t(net, &net->xbuf, (size_t)NUM_PLANES * net->xl.stride));
     HIP_TRY(hipMemsetAsync(net->xbuf, 0, (size_t)NUM_PLANES * net->xl.stride * 4, net->stream), SNN_ERR_BUFFER_WRITE);
@@ -694,6 +705,7 @@ int attr_io(snn_network *net, uint32_t id, const char *name, AttrType type, void
     TRY(end_run(net));
     if (set && l->spike_train) net->view_dirty = true;
     if (set) net->shadow_valid = false;
+    if (set) net->uni_dirty = true;
     const uint32_t first = l->spike_train ? l->first - net->nn : l->first;   // index inside its own arrays
 
     if (!typed) {
@@ -751,6 +763,35 @@ SellGraph csr_graph(const snn_network *net)
     g.t_ptr = net->csr_t_ptr; g.t_edge = net->csr_t_edge;
     g.n_loc = net->n_loc; g.n_slices = (net->n_loc + 63) / 64;
     return g;
+}
+
+// Which read-only parameters hold one value for the whole population (UniformTable): rescanned after attribute writes
+int ensure_uniform_tables(snn_network *net)
+{
+    if (!net->uni_dirty) return SNN_OK;
+    net->uni_dirty = false;
+    HIP_TRY(hipMemsetAsync(net->uni_neuron, 0, sizeof(UniformTable), net->stream), SNN_ERR_BUFFER_WRITE);
+    HIP_TRY(hipMemsetAsync(net->uni_cell, 0, sizeof(UniformTable), net->stream), SNN_ERR_BUFFER_WRITE);
+    if (!net->uniform_params) return SNN_OK;
+    auto scan = [&](UniformTable *t, int slot, const void *arr, uint32_t n) -> int {
+        if (n == 0 || !arr) return SNN_OK;
+        const uint32_t *p = static_cast<const uint32_t *>(arr);
+        hipLaunchKernelGGL(k_uniform_begin, dim3(1), dim3(1), 0, net->stream, t, slot, p, n);
+        hipLaunchKernelGGL(k_uniform_scan, dim3(std::min<uint32_t>((n + 255) / 256, 1024)), dim3(256), 0, net->stream, t, slot, p, n);
+        HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+        return SNN_OK;
+    };
+    const NeuronArrays &n = net->na;
+    const CellArrays &c = net->ca;
+    const struct { int slot; const void *arr; } np[] = {
+        {NP_GAP, n.gap_conductance}, {NP_DT, n.dt}, {NP_C_M, n.c_m}, {NP_V_TH, n.v_th}, {NP_A, n.a}, {NP_B, n.b},
+        {NP_C, n.c}, {NP_D, n.d}, {NP_TAU_M, n.tau_m}};
+    for (const auto &e : np) TRY(scan(net->uni_neuron, e.slot, e.arr, net->nn));
+    const struct { int slot; const void *arr; } cp[] = {
+        {CP_V_TH, c.v_th}, {CP_V_RESTING, c.v_resting}, {CP_DT, c.dt}, {CP_K, c.k}, {CP_CHANCE, c.chance_of_firing},
+        {CP_REFR, c.refractoriness}};
+    for (const auto &e : cp) TRY(scan(net->uni_cell, e.slot, e.arr, net->nc));
+    return SNN_OK;
 }
 
 int ensure_counts(snn_network *net)

@@ -83,7 +83,7 @@ int launch_inputs(snn_network *net, InputsPart part = INPUTS_ALL)
     if (part == INPUTS_REMOTE) { a.hole_begin = lc_begin; a.hole_count = lc_count; grid_chunks = net->n_chunks - lc_count; }
     if (grid_chunks == 0) return SNN_OK;
     a.W = net->W; a.ld = net->ld; a.n_loc = net->n_loc; a.q0 = net->q0; a.rows = net->rowmap; a.n_neurons = net->nn; a.n_tot = net->n_tot;
-    a.xbuf = net->xbuf; a.xl = net->xl; a.gap_conductance = net->na.gap_conductance;
+    a.xbuf = net->xbuf; a.xl = net->xl; a.gap_conductance = net->na.gap_conductance; a.uni = net->uni_neuron;
     a.st_value = net->ca.presyn_value; a.st_last_firing_time = net->ca.last_firing_time;
     a.st_nt_t = net->ca.nt_t; a.st_nt_flags = net->ca.nt_flags; a.c_pad = net->c_pad;
     a.nt_flags = net->na.nt_flags; a.n_pad = net->n_pad;
@@ -471,7 +471,7 @@ int fused_step_args(snn_network *net, InputsArgs &a, UpdateArgs &u)
     a = InputsArgs{};
     a.chunk_first = 0; a.hole_begin = net->n_chunks; a.hole_count = 0;
     a.W = net->W; a.ld = net->ld; a.n_loc = net->n_loc; a.q0 = net->q0; a.rows = net->rowmap; a.n_neurons = net->nn; a.n_tot = net->n_tot;
-    a.xbuf = cur; a.xl = net->xl; a.gap_conductance = net->na.gap_conductance;
+    a.xbuf = cur; a.xl = net->xl; a.gap_conductance = net->na.gap_conductance; a.uni = net->uni_neuron;
     a.st_value = net->ca.presyn_value; a.st_last_firing_time = net->ca.last_firing_time;
     a.st_nt_t = net->ca.nt_t; a.st_nt_flags = net->ca.nt_flags; a.c_pad = net->c_pad;
     a.nt_flags = net->na.nt_flags; a.n_pad = net->n_pad;
@@ -679,6 +679,7 @@ int grow_history(snn_network *net, uint64_t extra)
 int begin_run(snn_network *net, uint64_t iterations)
 {
     TRY(ensure_counts(net));
+    TRY(ensure_uniform_tables(net));
     TRY(ensure_exchange_plan(net));
     if ((net->want_avg || net->want_eeg) && net->sharded && net->n_shards > 1 &&
         (net->x_mode != SNN_EXCHANGE_ALLGATHER || !net->electrical))
