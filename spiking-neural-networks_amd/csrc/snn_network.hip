@@ -820,7 +820,7 @@ int snn_run(snn_network_t *net, uint64_t iterations)
         TRY(step_end(net));
         if (net->profile && (net->ev_used >= 8192 || net->ev_used_pl >= 8192)) TRY(collect_profile(net));
     }
-    return end_run(net);
+    return end_run(net, /*keep_stdp=*/true);
 }
 
 int snn_step_begin_local(snn_network_t *net)
@@ -1067,7 +1067,7 @@ int snn_run_sharded_custom(snn_network_t *net, snn_exchange_fn exchange, void *u
         TRY(step_end(net));
         if (net->profile && (net->ev_used >= 8192 || net->ev_used_pl >= 8192)) TRY(collect_profile(net));
     }
-    return end_run(net);
+    return end_run(net, /*keep_stdp=*/true);
 }
 
 int snn_run_sharded(snn_network_t *net, void *nccl_comm, uint64_t iterations)
@@ -1102,7 +1102,7 @@ int snn_run_sharded(snn_network_t *net, void *nccl_comm, uint64_t iterations)
         TRY(step_end(net));
         if (net->profile && net->ev_used >= 8192) TRY(collect_profile(net));
     }
-    return end_run(net);
+    return end_run(net, /*keep_stdp=*/true);
 }
 
 int snn_set_stream(snn_network_t *net, void *hip_stream)

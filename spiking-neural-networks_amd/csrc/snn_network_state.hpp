@@ -663,7 +663,7 @@ int build_state(snn_network *net)
     return SNN_OK;
 }
 
-int end_run(snn_network *net);
+int end_run(snn_network *net, bool keep_stdp = false);
 
 // ---- attribute transfer ------------------------------------------------------------------------
 

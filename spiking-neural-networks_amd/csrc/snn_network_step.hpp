@@ -700,10 +700,13 @@ int begin_run(snn_network *net, uint64_t iterations)
 }
 
 // Closes the open run: waits for the stream and folds the steps done into the host-side lattice clocks.
-int end_run(snn_network *net)
+// keep_stdp: the end of a run call leaves a deferred STDP update pending -- it is self-contained (flags and delta vectors
+// were evaluated when the step closed) and only the weights themselves depend on it, so the NEXT run call's first input
+// pass applies it; every other entry point (getters, setters, graph access) flushes.
+int end_run(snn_network *net, bool keep_stdp)
 {
     TRY(flush_rstdp(net));
-    TRY(flush_stdp(net));
+    if (!keep_stdp) TRY(flush_stdp(net));
     HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
     if (net->run_active) {
         for (auto &c : net->st_clock) c += net->run_step_offset;

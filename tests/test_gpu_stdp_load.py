@@ -122,7 +122,7 @@ def test_deferred_stdp_in_the_streamed_input_pass_equals_oracle(snn):
     dn.set_synthetic_drive(seed, fraction, V_KICK)
     w0 = net["weights"].copy()
     done = 0
-    for k in (1, 14, 21):
+    for k in (1, 9, 14):
         dn.run(k)
         for _ in range(k):
             drive_oracle(snn, net, seed, fraction)
@@ -130,6 +130,13 @@ def test_deferred_stdp_in_the_streamed_input_pass_equals_oracle(snn):
         done += k
         parity.assert_graph_equal(net, dn)                 # host read: flushes the pending update
         parity.assert_state_equal(net, parity.pull_state(dn, net))
+    for _ in range(12):                                    # one call per step: the update stays pending ACROSS calls
+        dn.run(1)
+        drive_oracle(snn, net, seed, fraction)
+        net.run(1)
+        done += 1
+    parity.assert_graph_equal(net, dn)
+    parity.assert_state_equal(net, parity.pull_state(dn, net))
     assert done == steps and not np.array_equal(w0, net["weights"])
     assert (net["last_firing_time"] >= 0).sum() > 200
     dn.close()
