@@ -164,6 +164,7 @@ struct snn_network {
     UniformTable *uni_neuron = nullptr, *uni_cell = nullptr;
     bool uni_dirty = true;
     int uniform_params = 1;               // 0: always read the arrays (SNN_AMD_UNIFORM_PARAMS=0)
+    int force_shape = 0;                  // 1 | 2: streamed shape of the dense input pass (SNN_AMD_INPUT_SHAPE), 0: by size
     // deferred STDP (dense handles): the update of step t is applied by the input pass of step t + 1
     int defer_stdp = 1;                    // 0: always the standalone kernels (SNN_AMD_DEFER_STDP=0)
     bool stdp_pending = false;
