@@ -1184,6 +1184,22 @@ int snn_get_spike_history(snn_network_t *net, uint32_t id, uint8_t *dst, size_t 
     return SNN_OK;
 }
 
+int snn_set_option(snn_network_t *net, const char *name, int value)
+{
+    if (!net || !name) return fail(SNN_ERR_BAD_ARG, "null argument");
+    HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
+    if (net->finalized) TRY(end_run(net));            // pending deferred updates belong to the old setting
+    const std::string n(name);
+    if (n == "fused_step") net->fused_step = value != 0;
+    else if (n == "defer_rstdp") net->defer_rstdp = value != 0;
+    else if (n == "defer_stdp") net->defer_stdp = value != 0;
+    else if (n == "uniform_params") { net->uniform_params = value != 0; net->uni_dirty = true; }
+    else if (n == "input_shape") net->force_shape = (value == 1 || value == 2) ? value : 0;
+    else return fail(SNN_ERR_BAD_ARG, "unknown option '" + n + "'");
+    net->shadow_valid = false;
+    return SNN_OK;
+}
+
 int snn_profile_enable(snn_network_t *net, int enable)
 {
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");

@@ -403,6 +403,10 @@ class DeviceNetwork:
         self._check(self._L.snn_get_spike_counts(self._h, id, out.ctypes.data_as(_lib.u32p), out.size))
         return out
 
+    def set_option(self, name, value):
+        """tuning switches of include/snn_amd.h (fused_step, defer_rstdp, defer_stdp, uniform_params, input_shape)"""
+        self._check(self._L.snn_set_option(self._h, name.encode(), int(value)))
+
     # ---- measurement ----------------------------------------------------------------------
     def profile_enable(self, on=True):
         self._check(self._L.snn_profile_enable(self._h, int(on)))
