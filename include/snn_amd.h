@@ -260,6 +260,11 @@ int snn_exchange_peers(snn_network_t *net, uint64_t *send_offset, uint64_t *send
  * peers' lists are in) switches the handle to SNN_EXCHANGE_HALO.  snn_run_sharded / snn_comm_exchange_halo_lists do
  * this exchange over RCCL themselves.  Without a commit the handle all-gathers whole slots (correct, larger). */
 int snn_halo_needs(snn_network_t *net, uint32_t peer, uint32_t *indices, uint32_t capacity, uint32_t *count);
+/* Spike-train cells are replicated on every rank (deterministic generators), but a sparse shard handle of a multi-rank
+ * run advances only the cells its own rows read: snn_cells_read lists them (ascending indices into the cell population,
+ * i.e. global index - n_neurons; every cell for dense, unsharded and single-shard handles).  The state of a cell that
+ * is not listed stays at its last written value on this rank. */
+int snn_cells_read(snn_network_t *net, uint32_t *indices, uint32_t capacity, uint32_t *count);
 int snn_halo_set_sends(snn_network_t *net, uint32_t peer, const uint32_t *indices, uint32_t count);
 int snn_halo_commit(snn_network_t *net);
 

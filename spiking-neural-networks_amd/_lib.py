@@ -133,6 +133,7 @@ SIGNATURES = {
     "snn_exchange_plan_get": (C.c_int, [H, C.c_void_p]),
     "snn_exchange_peers": (C.c_int, [H, u64p, u64p, u64p, u64p]),
     "snn_halo_needs": (C.c_int, [H, C.c_uint32, u32p, C.c_uint32, u32p]),
+    "snn_cells_read": (C.c_int, [H, u32p, C.c_uint32, u32p]),
     "snn_halo_set_sends": (C.c_int, [H, C.c_uint32, u32p, C.c_uint32]),
     "snn_halo_commit": (C.c_int, [H]),
     "snn_comm_unique_id": (C.c_int, [C.c_void_p]),

@@ -95,12 +95,17 @@ struct SpikeTrainArgs {
     long long view_clock;             // network clock of the NEXT input calculation
     float *vhist_row;                 // [c_pad] or null
     int has_nt;                       // some cell releases a neurotransmitter (else the flag planes are not read)
+    // Sparse shard handles iterate only the cells their own rows read (the others are never looked at on this rank):
+    // thread i handles cell cell_list[i], i < n_listed.  null: every cell.
+    const uint32_t *cell_list;
+    uint32_t n_listed;
 };
 
 __global__ __launch_bounds__(256) void k_spike_trains(const SpikeTrainArgs a)
 {
-    const uint32_t s = blockIdx.x * 256 + threadIdx.x;
-    if (s >= a.n_cells) return;
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= (a.cell_list ? a.n_listed : a.n_cells)) return;
+    const uint32_t s = a.cell_list ? a.cell_list[i] : i;
     const CellArrays &c = a.c;
     if (a.iterate) {
         uint32_t spike;

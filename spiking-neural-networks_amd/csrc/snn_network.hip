@@ -74,6 +74,7 @@ int snn_network_destroy(snn_network_t *net)
     if (net->summ_eeg) (void)hipFree(net->summ_eeg);
     for (auto &e : net->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     for (auto &e : net->ev_pool_pl) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    if (net->cell_list_dev) (void)hipFree(net->cell_list_dev);
     for (void *p : {(void *)net->halo_send_buf, (void *)net->halo_recv_buf, (void *)net->halo_send_idx, (void *)net->halo_recv_idx,
                     (void *)net->seg_count_dev[0], (void *)net->seg_count_dev[1], (void *)net->seg_first_dev[0],
                     (void *)net->seg_first_dev[1], (void *)net->seg_offset_dev[0], (void *)net->seg_offset_dev[1],
@@ -414,6 +415,18 @@ static int set_graph_csr_impl(snn_network_t *net, const uint64_t *row_ptr, const
     net->edge_slot_host.swap(edge_slot);
     net->counts_dirty = true;
     halo_needs_from_rows(net, pre_index, nnz);      // the new rows decide what is read from the other shards
+    if (net->sharded && net->n_shards > 1 && net->nc) {
+        // ... and which spike-train cells this rank reads at all
+        std::vector<uint8_t> seen(net->nc, 0);
+        for (uint64_t e = 0; e < nnz; ++e)
+            if (pre_index[e] >= net->nn) seen[pre_index[e] - net->nn] = 1;
+        net->cell_list_host.clear();
+        for (uint32_t s = 0; s < net->nc; ++s)
+            if (seen[s]) net->cell_list_host.push_back(s);
+        TRY(upload_table(&net->cell_list_dev, net->cell_list_host));
+        net->n_cells_listed = (uint32_t)net->cell_list_host.size();
+        net->view_dirty = true;
+    }
     // a reward-modulated handle keeps modulating: zeroed traces for the new edges (the old ones went with their edges)
     if (net->any_modulation) TRY(ensure_traces(net));
     return SNN_OK;
@@ -934,6 +947,22 @@ int snn_halo_set_sends(snn_network_t *net, uint32_t peer, const uint32_t *indice
     net->halo_send[peer].assign(indices, indices + count);
     net->halo_committed = false;
     net->x_dirty = true;
+    return SNN_OK;
+}
+
+int snn_cells_read(snn_network_t *net, uint32_t *indices, uint32_t capacity, uint32_t *count)
+{
+    if (!net || !count) return fail(SNN_ERR_BAD_ARG, "null argument");
+    if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
+    if (!net->cell_list_dev) {                       // every cell
+        *count = net->nc;
+        if (indices && capacity >= net->nc)
+            for (uint32_t s = 0; s < net->nc; ++s) indices[s] = s;
+        return SNN_OK;
+    }
+    *count = net->n_cells_listed;
+    if (indices && capacity >= net->n_cells_listed && net->n_cells_listed)
+        std::memcpy(indices, net->cell_list_host.data(), (size_t)net->n_cells_listed * 4);
     return SNN_OK;
 }
 

@@ -160,6 +160,11 @@ struct snn_network {
     float *stdp_dev = nullptr;
     uint32_t *plast_dev = nullptr;
     uint32_t *spike_list = nullptr, *spike_count = nullptr;
+    // sparse shard handles: the spike-train cells the local rows read (ascending cell indices); the step iterates only
+    // those -- cells are replicated state, and what this rank never reads it need not advance
+    std::vector<uint32_t> cell_list_host;
+    uint32_t *cell_list_dev = nullptr;
+    uint32_t n_cells_listed = 0;
     // uniform-parameter tables (UniformTable, snn_layout.hpp): rescanned when attributes were set
     UniformTable *uni_neuron = nullptr, *uni_cell = nullptr;
     bool uni_dirty = true;

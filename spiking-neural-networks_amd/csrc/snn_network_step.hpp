@@ -16,7 +16,10 @@ int launch_spike_trains(snn_network *net, int iterate, long long step_offset, lo
     a.has_nt = net->any_nt_cells ? 1 : 0;
     a.view_clock = view_clock;
     a.vhist_row = (iterate && record_now(net) && net->want_vhist && net->st_vhist) ? net->st_vhist + (size_t)net->hist_steps * net->c_pad : nullptr;
-    hipLaunchKernelGGL(k_spike_trains, dim3((net->nc + 255) / 256), dim3(256), 0, net->stream, a);
+    a.cell_list = net->cell_list_dev; a.n_listed = net->n_cells_listed;
+    const uint32_t work = net->cell_list_dev ? net->n_cells_listed : net->nc;
+    if (work == 0) return SNN_OK;
+    hipLaunchKernelGGL(k_spike_trains, dim3((work + 255) / 256), dim3(256), 0, net->stream, a);
     HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
     return SNN_OK;
 }

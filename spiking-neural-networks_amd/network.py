@@ -236,6 +236,16 @@ class DeviceNetwork:
             self._check(self._L.snn_halo_needs(self._h, peer, out.ctypes.data_as(_lib.u32p), out.size, C.byref(n)))
         return out
 
+    def cells_read(self):
+        """indices (into the cell population) of the spike-train cells this handle advances: all of them, or -- sparse
+        shard handles of a multi-rank run -- the ones its own rows read"""
+        n = C.c_uint32()
+        self._check(self._L.snn_cells_read(self._h, None, 0, C.byref(n)))
+        out = np.empty(n.value, np.uint32)
+        if n.value:
+            self._check(self._L.snn_cells_read(self._h, out.ctypes.data_as(_lib.u32p), out.size, C.byref(n)))
+        return out
+
     def halo_set_sends(self, peer, indices):
         a = np.ascontiguousarray(indices, dtype=np.uint32)
         self._check(self._L.snn_halo_set_sends(self._h, peer, a.ctypes.data_as(_lib.u32p), a.size))

@@ -346,9 +346,9 @@ def test_c5_full_size_sparse_network_against_numpy(snn):
             assert np.array_equal(parity.bits(h.get_attr(k, "current_voltage")[own]), parity.bits(st["current_voltage"][lo:hi])), k
             assert np.array_equal(parity.bits(h.get_attr(k, "w_value")[own]), parity.bits(st["w_value"][lo:hi])), k
             assert np.array_equal(h.get_attr(k, "last_firing_time", dtype=np.int32)[own], lft[lo:hi]), k
-            # the replicated cells agree everywhere
-            assert np.array_equal(h.get_attr(4 + k, "seed", dtype=np.uint32), seed[k * m:(k + 1) * m]), k
-            assert np.array_equal(h.get_attr(4 + k, "last_firing_time", dtype=np.int32), st_lft[k * m:(k + 1) * m]), k
+            # the cells this handle's rows read (one per own neuron) are current
+            assert np.array_equal(h.get_attr(4 + k, "seed", dtype=np.uint32)[own], seed[lo:hi]), k
+            assert np.array_equal(h.get_attr(4 + k, "last_firing_time", dtype=np.int32)[own], st_lft[lo:hi]), k
         # what the handle reads of the others: voltage and firing times of its halo
         r = ex.plans[handles.index(h)]["shard_index"]
         for p in range(g):
@@ -383,5 +383,8 @@ def test_c5_full_size_sparse_network_against_numpy(snn):
         need = np.concatenate([h.halo_needs(p) for p in range(g) if p != r])
         assert np.array_equal(parity.bits(v_all[need]), parity.bits(st["current_voltage"][need]))
         assert np.array_equal(l_all[need], lft[need])
-        assert np.array_equal(h.get_attr(5, "seed", dtype=np.uint32), seed[m:2 * m])
+        cells = h.cells_read()
+        assert np.array_equal(cells, o)                      # one Poisson cell per own neuron, nothing else
+        seed_all = np.concatenate([h.get_attr(4 + k, "seed", dtype=np.uint32) for k in range(4)])
+        assert np.array_equal(seed_all[cells], seed[cells])
         h.close()
