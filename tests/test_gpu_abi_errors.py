@@ -98,3 +98,64 @@ def test_sharded_handle_refuses_whole_population_run(snn):
     dn.add_lattice(0, 4, 4)
     assert code(snn, lambda: dn.finalize(3, 2)) == BAD_ARG                          # shard_index >= n_shards
     dn.close()
+
+
+def test_multi_gpu_entry_points_refuse_misuse(snn):
+    """exchange plan / halo / by-lattice sharding / options / drive: documented codes, handles stay usable"""
+    import torch
+    from snn_amd import parallel
+    whole = snn.DeviceNetwork()
+    whole.add_lattice(0, 4, 4)
+    assert code(snn, lambda: whole.finalize(0, 2, by_lattice=True)) == BAD_STATE       # by lattice needs a sparse handle
+    whole.finalize()
+    assert code(snn, lambda: whole.exchange_plan()) == BAD_STATE                       # not a shard handle
+    assert code(snn, lambda: whole.halo_needs(0)) == BAD_STATE
+    assert code(snn, lambda: whole.run_sharded(12345, 1)) == BAD_STATE
+    assert code(snn, lambda: whole.set_option("no_such_switch", 1)) == BAD_ARG
+    assert code(snn, lambda: whole.set_synthetic_drive(1, 1.5, 35.0)) == BAD_ARG       # fraction outside [0, 1]
+    whole.set_option("input_shape", 2)
+    whole.set_option("defer_stdp", 0)
+    whole.run(3)
+    assert whole.clock == 3 and whole.ranges == [(0, 16)] and whole.cells_read().size == 0
+    whole.close()
+
+    dense = snn.DeviceNetwork()
+    dense.add_lattice(0, 16, 16)
+    dense.finalize(1, 2)
+    assert code(snn, lambda: dense.run(1)) == BAD_STATE                                # sharded handles are stepped with an exchange
+    assert code(snn, lambda: dense.halo_needs(0)) == BAD_STATE                         # halo plans belong to sparse handles
+    assert code(snn, lambda: dense.halo_commit()) == BAD_STATE
+    plan = dense.exchange_plan()
+    assert plan["mode"] == "allgather" and plan["n_shards"] == 2 and plan["shard_index"] == 1 and plan["plane_id"] == [0]
+    dense.set_synapses(False, True)                                                    # nothing releases a transmitter:
+    assert dense.exchange_plan()["planes"] == 0                                        # only the spike bits travel
+    dense.close()
+
+    handles = []
+    for r in range(2):
+        h = snn.DeviceNetwork(spike_train=snn.ST_POISSON)
+        for k in range(2):
+            h.add_lattice(k, 16, 16)
+        h.add_spike_train_lattice(5, 2, 2)
+        h.finalize(r, 2, csr=True, by_lattice=True)
+        handles.append(h)
+    a, b = handles
+    assert a.ranges == [(0, 128), (256, 384)] and b.ranges == [(128, 256), (384, 512)]
+    assert code(snn, lambda: a.halo_needs(2)) == BAD_ARG                               # peer out of range
+    assert code(snn, lambda: a.halo_set_sends(0, [1])) == BAD_ARG                      # a handle is not its own peer
+    assert code(snn, lambda: a.halo_set_sends(1, [200])) == DIM_MISMATCH               # neuron 200 belongs to the peer
+    with pytest.raises(ValueError):
+        a.set_graph_csr([0, 1], [3], [1.0])                                            # one row per OWNED neuron (binding check)
+    rp = np.zeros(257, np.uint64)
+    rp[1:] = 2                                                                         # ... and row_ptr must end at nnz
+    assert code(snn, lambda: a.set_graph_csr(rp, [3], [1.0])) == DIM_MISMATCH
+    assert code(snn, lambda: a.set_reduced_history(True, False, False) or a.step_begin()) == BAD_STATE   # needs every voltage
+    a.set_reduced_history(False, False, False)
+    # without rows or a committed plan the two handles trade whole ownerships and still step
+    ex = parallel.LocalExchange(handles, torch.device("cuda", 0))
+    assert [p["mode"] for p in ex.plans] == ["halo", "halo"] and ex.bytes_per_step() == [4 * (256 + 8), 4 * (256 + 8)]
+    for _ in range(3):
+        ex.step()
+    assert a.clock == 3 and b.clock == 3
+    for h in handles:
+        h.close()
