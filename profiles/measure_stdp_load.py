@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """STDP under load on BASELINE configs[3] (81 920 neurons, 26.8 GB matrix): ms per step, average input-pass launch and
 plasticity launches per step for a driven spike fraction f, with the weight update (a) riding on the next input pass
-(default), (b) as the standalone scatter kernels (SNN_AMD_DEFER_STDP=0) and (c) riding but with a_plus = a_minus = 0
+(SNN_AMD_DEFER_STDP=1), (b) as the standalone scatter kernels that evaluate STDP per synapse (=0), (b') as scatter passes
+that add the two prepared delta vectors (=2) and (c) riding but with a_plus = a_minus = 0
 (no word changes: the cost of the update path without its stores).  Usage: measure_stdp_load.py [steps]"""
 import json
 import os
@@ -18,8 +19,8 @@ steps = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 n_inh, n_exc = 128 * 128, 256 * 256
 n = n_inh + n_exc
 rows = []
-for mode in ("fused", "standalone", "fused_zero_delta"):
-    os.environ["SNN_AMD_DEFER_STDP"] = "0" if mode == "standalone" else "1"
+for mode in ("fused", "standalone", "prepared_scatter", "fused_zero_delta"):
+    os.environ["SNN_AMD_DEFER_STDP"] = {"standalone": "0", "prepared_scatter": "2"}.get(mode, "1")
     dn = snn_amd.DeviceNetwork(model=snn_amd.IZHIKEVICH)
     dn.add_lattice(0, 128, 128)
     dn.add_lattice(1, 256, 256)

@@ -12,8 +12,10 @@
 // their own pass over connections u32[N^2] + weights f32[N^2] with one work-item per column.
 //
 // Mapping (wave64, gfx950): workgroup = 256 threads = 4 waves; a workgroup owns CHUNK = 256
-// consecutive presynaptic rows x 1024 consecutive postsynaptic columns; every lane owns 4 adjacent
-// columns, so one wave-row is ONE 1 KiB global_load_dwordx4 and a workgroup-row is 4 KiB contiguous.
+// consecutive presynaptic rows x 1024 consecutive postsynaptic columns.  W is stored in quad-row order
+// (snn_layout.hpp): a lane owns VEC columns 256 apart and reads 4 consecutive ROWS of one of them with ONE
+// global_load_dwordx4; a wavefront's load is 1 KiB contiguous, the four wavefronts' 4 KiB, and the VEC
+// loads of a row group cover 16 KiB contiguous.
 // blockIdx.y = row chunk, blockIdx.x (fastest in dispatch order) = column tile rotated by the chunk index: the
 // workgroups in flight at any moment sweep whole matrix rows (long contiguous HBM bursts) while every XCD -- which
 // receives every 8th workgroup -- touches all column groups instead of a fixed eighth of them (measured: -17 % time
@@ -100,27 +102,12 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 //  STREAM == 2: the streaming shape with TWO columns per lane (512-B wave-rows): twice the wavefronts for
 //          matrices too small to fill the chip with the 4-column shape (e.g. 128x128: 4096 -> 8192 waves).
 template <int STREAM> struct InputsShape {
-    static constexpr int VEC = STREAM == 1 ? 4 : (STREAM == 2 ? 2 : 1);
+    static constexpr int VEC = STREAM == 1 ? 4 : (STREAM == 2 ? 2 : 1);      // columns per lane, THREADS apart
     static constexpr int THREADS = STREAM ? 256 : 64;
     static constexpr int TILE = VEC * THREADS;            // columns per workgroup
-    static constexpr uint32_t ROW_BATCH = STREAM ? 8 : 32;
+    static constexpr uint32_t ROW_BATCH = STREAM ? 8 : 32;                   // rows in flight per buffer ...
+    static constexpr uint32_t GROUP_BATCH = ROW_BATCH / 4;                   // ... = row groups (units per column)
 };
-
-typedef float v2f __attribute__((ext_vector_type(2)));
-
-template <int STREAM>
-__device__ __forceinline__ void load_w(const float *p, float (&w)[InputsShape<STREAM>::VEC])
-{
-    if constexpr (STREAM == 1) {
-        const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(p));
-        w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
-    } else if constexpr (STREAM == 2) {
-        const v2f v = __builtin_nontemporal_load(reinterpret_cast<const v2f *>(p));
-        w[0] = v.x; w[1] = v.y;
-    } else {
-        w[0] = *p;
-    }
-}
 
 __device__ __forceinline__ float acc_if_edge(float acc, float term, float w)
 {
@@ -136,7 +123,6 @@ __global__ __launch_bounds__(InputsShape<STREAM>::THREADS) void k_inputs_dense(c
 {
     using S = InputsShape<STREAM>;
     constexpr int VEC = S::VEC;
-    constexpr uint32_t ROW_BATCH = S::ROW_BATCH;
     constexpr int TS = CHEM ? NT : 1;                        // transmitter slots of this instantiation
 
     __shared__ float s_val[CHUNK];
@@ -156,18 +142,34 @@ __global__ __launch_bounds__(InputsShape<STREAM>::THREADS) void k_inputs_dense(c
     // Column tile of this workgroup, rotated by the chunk index: workgroups are dealt round-robin over the 8
     // XCDs, so with a power-of-two tile count an unrotated mapping would pin every XCD (and its L2 / fabric
     // ports) to the same 1/8 of the columns for the whole pass.
+    constexpr uint32_t GB = S::GROUP_BATCH;
     const uint32_t tile = (blockIdx.x + blockIdx.y) % gridDim.x;
-    const uint32_t ql = tile * S::TILE + tid * VEC;          // first of this lane's VEC local columns
-    const float *wrow = a.W + (size_t)p0 * a.ld + ql;
+    const uint32_t ql = tile * S::TILE + tid;                // the lane's column j is ql + j * THREADS
     const size_t ld = a.ld;
+    const uint32_t groups = (rows + 3u) >> 2;                // row groups of the chunk (rows are padded to 4 with NaN)
+    // unit (row group 0 of the chunk, column ql); a column past the shard's padded width would read outside the
+    // matrix: such lanes (only in the last tile) re-read their first column and never use the value
+    const v4f *gbase = reinterpret_cast<const v4f *>(a.W) + (size_t)(p0 >> 2) * ld + ql;
+    bool colv[VEC];
+    uint32_t coff[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        colv[j] = ql + (uint32_t)j * S::THREADS < a.n_loc;
+        coff[j] = colv[j] ? (uint32_t)j * S::THREADS : 0u;
+    }
+    auto load_units = [&](uint32_t grp, v4f (&w)[VEC]) {
+        const v4f *gp = gbase + (size_t)grp * ld;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) w[j] = __builtin_nontemporal_load(gp + coff[j]);
+    };
 
-    // The first batch of matrix rows is requested BEFORE the presynaptic values are staged: all workgroups of a
+    // The first batch of row groups is requested BEFORE the presynaptic values are staged: all workgroups of a
     // launch start together, and without this the whole chip would leave HBM idle for the staging round trip.
-    float pre[ROW_BATCH][VEC];
-    const bool have_pre = rows >= ROW_BATCH && ql < a.n_loc;
+    v4f pre[GB][VEC];
+    const bool have_pre = groups >= GB && ql < a.n_loc;
     if (have_pre) {
 #pragma unroll
-        for (uint32_t u = 0; u < ROW_BATCH; ++u) load_w<STREAM>(wrow + (size_t)u * ld, pre[u]);
+        for (uint32_t u = 0; u < GB; ++u) load_units(u, pre[u]);
     }
 
     // ---- stage the chunk's presynaptic values in LDS (coalesced reads, one pass per array) ----
@@ -213,6 +215,12 @@ __global__ __launch_bounds__(InputsShape<STREAM>::THREADS) void k_inputs_dense(c
         kinds_and &= kind | ~0x703u;
         kinds_or |= kind;
     }
+    // rows of the chunk's last group past n_tot are padding (their weights are the absent-edge NaN): harmless values
+    for (uint32_t i = rows + tid; i < groups * 4; i += S::THREADS) {
+        s_val[i] = 0.0f;
+        s_kind[i] = KIND_NEURON;
+        if (STDP) s_rowflag[i] = 0u;
+    }
     // Homogeneous chunks (every row a neuron; each transmitter type carried by all rows or by none -- any lattice
     // populated from one base neuron) take a row body without per-row kind tests: workgroup-uniform votes, which
     // also are the barrier that publishes the staged values.
@@ -239,7 +247,7 @@ __global__ __launch_bounds__(InputsShape<STREAM>::THREADS) void k_inputs_dense(c
     float vq[VEC], gq[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
-        const uint32_t q = ql + j;
+        const uint32_t q = ql + (uint32_t)j * S::THREADS;
         if (ELEC && q < a.n_loc) {
             vq[j] = a.xbuf[a.xl.at(a.q0 + q, PLANE_V)];
             gq[j] = a.gap_conductance[a.q0 + q];
@@ -259,7 +267,7 @@ __global__ __launch_bounds__(InputsShape<STREAM>::THREADS) void k_inputs_dense(c
         uint32_t lat_mask = 0;    // lattices among this lane's flagged columns
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
-            const uint32_t q = ql + j;
+            const uint32_t q = ql + (uint32_t)j * S::THREADS;
             const bool in = q < a.n_loc;
             cf[j] = in && a.stdp_flag[a.q0 + q] != 0u;
             clat[j] = in ? a.lattice_slot[a.q0 + q] : 0u;
@@ -272,53 +280,53 @@ __global__ __launch_bounds__(InputsShape<STREAM>::THREADS) void k_inputs_dense(c
         wave_cols = wave_mask != 0u;
         wave_lat = (wave_mask & (wave_mask - 1u)) ? 0xFFFFFFFFu : (uint32_t)__builtin_ctz(wave_mask | 0x80000000u);
     }
-    // one row of the deferred update: column delta first, then row delta (the order of the standalone kernels);
-    // absent edges stay absent; only words that changed are written back.  Branch-free per column: the delta of the
-    // row is a wave-uniform LDS broadcast (one per lattice present), selected per lane.
-    auto stdp_row = [&](uint32_t r, float (&w)[VEC], bool row_spiked) {
-        float dl[STDP_MAX_LATTICES];
-        if (wave_lat != 0xFFFFFFFFu) {
-            dl[0] = s_dcol[wave_lat][r];
-        } else {
+    // One row group of the deferred update: per row the column delta first, then the row delta (the order of the
+    // standalone kernels); absent edges stay absent.  Branch-free per element: the delta of a row is a wave-uniform LDS
+    // broadcast (one per lattice present), selected per lane.  Write-back in whole 128-byte lines: a lone small store
+    // makes the memory side read the rest of the line before it can write it, so when any lane of a 128 B-aligned group
+    // of 8 lanes (8 columns x 4 rows) changed a word, every lane of the group stores its 16-byte unit.
+    auto stdp_group = [&](uint32_t grp, v4f (&w)[VEC]) {
+        bool rs[4], any_rs = false;
 #pragma unroll
-            for (int l = 0; l < STDP_MAX_LATTICES; ++l) dl[l] = ((uint32_t)l < a.n_lattices) ? s_dcol[l][r] : 0.0f;
+        for (int k = 0; k < 4; ++k) {
+            rs[k] = __builtin_amdgcn_readfirstlane(s_rowflag[grp * 4 + k]) != 0u;
+            any_rs = any_rs || rs[k];
         }
+        if (!wave_cols && !any_rs) return;
         bool changed[VEC];
-        bool any_changed = false;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) changed[j] = false;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t r = grp * 4 + k;
+            float dl[STDP_MAX_LATTICES];
+            if (wave_lat != 0xFFFFFFFFu) {
+                dl[0] = s_dcol[wave_lat][r];
+            } else {
+#pragma unroll
+                for (int l = 0; l < STDP_MAX_LATTICES; ++l) dl[l] = ((uint32_t)l < a.n_lattices) ? s_dcol[l][r] : 0.0f;
+            }
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                float d = dl[0];
+                if (wave_lat == 0xFFFFFFFFu) {
+#pragma unroll
+                    for (int l = 1; l < STDP_MAX_LATTICES; ++l) d = (clat[j] == (uint32_t)l) ? dl[l] : d;
+                }
+                const float w0 = w[j][k];
+                float wn = cf[j] ? w0 + d : w0;
+                wn = rs[k] ? wn + dr[j] : wn;
+                const bool ch = (w0 == w0) && __float_as_uint(wn) != __float_as_uint(w0);
+                w[j][k] = ch ? wn : w0;
+                changed[j] = changed[j] || ch;
+            }
+        }
+        const uint32_t lane = tid & 63u;
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
-            float d = dl[0];
-            if (wave_lat == 0xFFFFFFFFu) {
-#pragma unroll
-                for (int l = 1; l < STDP_MAX_LATTICES; ++l) d = (clat[j] == (uint32_t)l) ? dl[l] : d;
-            }
-            const float w0 = w[j];
-            float wn = cf[j] ? w0 + d : w0;
-            wn = row_spiked ? wn + dr[j] : wn;
-            changed[j] = (w0 == w0) && __float_as_uint(wn) != __float_as_uint(w0);
-            w[j] = changed[j] ? wn : w0;
-            any_changed = any_changed || changed[j];
-        }
-        // Write-back in whole 128-byte lines: a lone 4-byte store makes the memory side read the rest of the line
-        // before it can write it; when any lane of the 128 B-aligned lane group changed a word, every lane of the
-        // group stores its (unchanged or changed) VEC words, so the line is overwritten in full.
-        constexpr uint32_t GROUP = 128 / (4 * VEC);                // lanes per 128 B: 8 (VEC 4), 16 (VEC 2)
-        const unsigned long long votes = __ballot(any_changed);
-        if (votes) {
-            const uint32_t lane = tid & 63u;
-            const unsigned long long mine = (votes >> (lane & ~(GROUP - 1u))) & ((1ull << GROUP) - 1ull);
-            if (mine) {
-                float *dst = a.W_rw + (size_t)(p0 + r) * ld + ql;
-                if constexpr (STREAM == 1) {
-                    v4f v; v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
-                    *reinterpret_cast<v4f *>(dst) = v;
-                } else if constexpr (STREAM == 2) {
-                    v2f v; v.x = w[0]; v.y = w[1];
-                    *reinterpret_cast<v2f *>(dst) = v;
-                } else {
-                    dst[0] = w[0];
-                }
-            }
+            const unsigned long long votes = __ballot(changed[j] && colv[j]);
+            if (votes && colv[j] && ((votes >> (lane & ~7u)) & 0xFFull))
+                reinterpret_cast<v4f *>(a.W_rw)[(size_t)((p0 >> 2) + grp) * ld + ql + (uint32_t)j * S::THREADS] = w[j];
         }
     };
 
@@ -331,79 +339,75 @@ __global__ __launch_bounds__(InputsShape<STREAM>::THREADS) void k_inputs_dense(c
 #pragma unroll
         for (int j = 0; j < VEC; ++j) tacc[k][j] = 0.0f;
 
-    // Rows are consumed in batches of ROW_BATCH: all loads of a batch are issued before the first use,
-    // so every wave keeps ROW_BATCH wave-rows of reads in flight regardless of the branches in the body.
+    // Row groups are consumed in batches of GROUP_BATCH (= ROW_BATCH rows): all loads of a batch are issued before the
+    // first use, so every wave keeps ROW_BATCH rows of reads per column in flight regardless of the branches in the
+    // body.  `body(row, w[VEC])` sees one presynaptic row at a time, as before the quad-row layout.
     auto sweep = [&](auto body) {
-        uint32_t r = 0;
+        auto run_group = [&](uint32_t grp, v4f (&wg)[VEC]) {
+            if (STDP && stdp_live) stdp_group(grp, wg);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float w[VEC];
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) w[j] = wg[j][k];
+                body(grp * 4 + k, w);
+            }
+        };
+        uint32_t g = 0;
         if constexpr ((STREAM == 1 && (!CHEM || NT == 1)) || STREAM == 2 || STREAM == 0) {
-            // Two register buffers, so the next batch of rows is already in flight while the current one is
-            // consumed: +1 % over a single buffer for the electrical-only 4-column pass at 256x256 (its chemical
-            // variants with 2-3 live types keep one buffer -- they need the registers for their extra accumulators),
-            // -5 % time at 96x96 for the 2-column shape, -24 % at 64x64 for the one-column cache-resident shape
-            // (2 x 32 rows).
-            constexpr uint32_t B = ROW_BATCH;
-            if (rows >= 2 * B) {
-                float (&wa)[B][VEC] = pre;        // rows 0 .. B-1, requested before the staging phase
-                float wb[B][VEC];
-                for (; r + 3 * B <= rows; r += 2 * B) {
+            // Two register buffers, so the next batch is already in flight while the current one is consumed: +1 % over
+            // a single buffer for the electrical-only 4-column pass at 256x256 (its chemical variants with 2-3 live
+            // types keep one buffer -- they need the registers for their extra accumulators), -5 % time at 96x96 for
+            // the 2-column shape, -24 % at 64x64 for the one-column cache-resident shape (2 x 32 rows).
+            constexpr uint32_t B = GB;
+            if (groups >= 2 * B) {
+                v4f (&wa)[B][VEC] = pre;          // groups 0 .. B-1, requested before the staging phase
+                v4f wb[B][VEC];
+                for (; g + 3 * B <= groups; g += 2 * B) {
 #pragma unroll
-                    for (uint32_t u = 0; u < B; ++u) load_w<STREAM>(wrow + (size_t)(r + B + u) * ld, wb[u]);
+                    for (uint32_t u = 0; u < B; ++u) load_units(g + B + u, wb[u]);
 #pragma unroll
-                    for (uint32_t u = 0; u < B; ++u) body(r + u, wa[u]);
+                    for (uint32_t u = 0; u < B; ++u) run_group(g + u, wa[u]);
 #pragma unroll
-                    for (uint32_t u = 0; u < B; ++u) load_w<STREAM>(wrow + (size_t)(r + 2 * B + u) * ld, wa[u]);
+                    for (uint32_t u = 0; u < B; ++u) load_units(g + 2 * B + u, wa[u]);
 #pragma unroll
-                    for (uint32_t u = 0; u < B; ++u) body(r + B + u, wb[u]);
+                    for (uint32_t u = 0; u < B; ++u) run_group(g + B + u, wb[u]);
                 }
-                // wa holds rows r .. r+B-1
+                // wa holds groups g .. g+B-1
 #pragma unroll
-                for (uint32_t u = 0; u < B; ++u) body(r + u, wa[u]);
-                r += B;
+                for (uint32_t u = 0; u < B; ++u) run_group(g + u, wa[u]);
+                g += B;
             }
         }
-        if (r == 0 && have_pre) {
+        if (g == 0 && have_pre) {
 #pragma unroll
-            for (uint32_t u = 0; u < ROW_BATCH; ++u) body(u, pre[u]);
-            r = ROW_BATCH;
+            for (uint32_t u = 0; u < GB; ++u) run_group(u, pre[u]);
+            g = GB;
         }
-        for (; r + ROW_BATCH <= rows; r += ROW_BATCH) {
-            float wb[ROW_BATCH][VEC];
+        for (; g + GB <= groups; g += GB) {
+            v4f wb[GB][VEC];
 #pragma unroll
-            for (uint32_t u = 0; u < ROW_BATCH; ++u) load_w<STREAM>(wrow + (size_t)(r + u) * ld, wb[u]);
+            for (uint32_t u = 0; u < GB; ++u) load_units(g + u, wb[u]);
 #pragma unroll
-            for (uint32_t u = 0; u < ROW_BATCH; ++u) body(r + u, wb[u]);
+            for (uint32_t u = 0; u < GB; ++u) run_group(g + u, wb[u]);
         }
-        for (; r < rows; ++r) {
-            float w[VEC];
-            load_w<STREAM>(wrow + (size_t)r * ld, w);
-            body(r, w);
+        for (; g < groups; ++g) {
+            v4f w[VEC];
+            load_units(g, w);
+            run_group(g, w);
         }
     };
 
     const bool plain = !CHEM && (p0 + rows <= a.n_neurons);   // workgroup-uniform
     if (plain) {
         // all presynaptic rows are neurons, electrical only: the C1/C2 inner loop
-        sweep([&](uint32_t r, const float (&w_in)[VEC]) {
-            float w[VEC];
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) w[j] = w_in[j];
-            if (STDP && stdp_live) {
-                const bool rs = __builtin_amdgcn_readfirstlane(s_rowflag[r]) != 0u;
-                if (wave_cols || rs) stdp_row(r, w, rs);
-            }
+        sweep([&](uint32_t r, const float (&w)[VEC]) {
             const float vp = s_val[r];
 #pragma unroll
             for (int j = 0; j < VEC; ++j) acc[j] = acc_if_edge(acc[j], gq[j] * (vp - vq[j]), w[j]);
         });
     } else if (uniform_chunk) {
-        sweep([&](uint32_t r, const float (&w_in)[VEC]) {
-            float w[VEC];
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) w[j] = w_in[j];
-            if (STDP && stdp_live) {
-                const bool rs = __builtin_amdgcn_readfirstlane(s_rowflag[r]) != 0u;
-                if (wave_cols || rs) stdp_row(r, w, rs);
-            }
+        sweep([&](uint32_t r, const float (&w)[VEC]) {
             if (ELEC) {
                 const float vp = s_val[r];
 #pragma unroll
@@ -419,14 +423,7 @@ __global__ __launch_bounds__(InputsShape<STREAM>::THREADS) void k_inputs_dense(c
             }
         });
     } else {
-        sweep([&](uint32_t r, const float (&w_in)[VEC]) {
-            float w[VEC];
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) w[j] = w_in[j];
-            if (STDP && stdp_live) {
-                const bool rs = __builtin_amdgcn_readfirstlane(s_rowflag[r]) != 0u;
-                if (wave_cols || rs) stdp_row(r, w, rs);
-            }
+        sweep([&](uint32_t r, const float (&w)[VEC]) {
             const uint32_t kind = __builtin_amdgcn_readfirstlane(s_kind[r]);
             if (ELEC) {
                 const float vp = s_val[r];
@@ -459,14 +456,16 @@ __global__ __launch_bounds__(InputsShape<STREAM>::THREADS) void k_inputs_dense(c
     if (ELEC) {
         float *dst = a.part_i + (size_t)chunk * a.ld + ql;
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) dst[j] = acc[j];
+        for (int j = 0; j < VEC; ++j)
+            if (colv[j]) dst[(uint32_t)j * S::THREADS] = acc[j];
     }
     if (CHEM) {
 #pragma unroll
         for (int k = 0; k < TS; ++k) {
             float *dst = a.part_t + ((size_t)a.live_type[k] * a.n_chunks + chunk) * a.ld + ql;
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) dst[j] = tacc[k][j];
+            for (int j = 0; j < VEC; ++j)
+                if (colv[j]) dst[(uint32_t)j * S::THREADS] = tacc[k][j];
         }
     }
 }
@@ -493,7 +492,7 @@ __global__ __launch_bounds__(256) void k_graph_count(const CountArgs a)
     if (q >= a.n_loc) return;
     uint32_t cnt = 0, tc[K_TYPES] = {0, 0, 0};
     for (uint32_t p = r0; p < r1; ++p) {
-        const float w = a.W[(size_t)p * a.ld + q];
+        const float w = a.W[widx(p, q, a.ld)];
         if (w == w) {
             ++cnt;
 #pragma unroll

@@ -40,7 +40,7 @@ __global__ void k_graph_import(float *W, uint32_t ld, uint32_t n_loc, uint32_t q
         const size_t i = (size_t)r * src_ld + q0 + q;
         if (src_c[i] != 0) out = src_w[i];
     }
-    W[(size_t)(row0 + r) * ld + q] = out;
+    W[widx(row0 + r, q, ld)] = out;
 }
 
 // inverse: absent edges export as weight 0 / connection 0 (graph/mod.rs:310-320)
@@ -50,11 +50,21 @@ __global__ void k_graph_export(const float *W, uint32_t ld, uint32_t n_loc, uint
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t r = blockIdx.y;
     if (q >= n_loc || r >= rows) return;
-    const float w = W[(size_t)(row0 + r) * ld + q];
+    const float w = W[widx(row0 + r, q, ld)];
     const size_t i = (size_t)r * dst_ld + q0 + q;
     const bool edge = (w == w);
     dst_w[i] = edge ? w : 0.0f;
     dst_c[i] = edge ? 1u : 0u;
+}
+
+// rows [row0, row0 + rows) of a quad-row matrix <-> a row-major staging block [rows][n_loc] (trace transfers)
+__global__ void k_rows_staging(float *M, uint32_t ld, uint32_t n_loc, uint32_t row0, uint32_t rows, float *staging, int to_matrix)
+{
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t r = blockIdx.y;
+    if (q >= n_loc || r >= rows) return;
+    if (to_matrix) M[widx(row0 + r, q, ld)] = staging[(size_t)r * n_loc + q];
+    else staging[(size_t)r * n_loc + q] = M[widx(row0 + r, q, ld)];
 }
 
 // one step's snapshot of a lattice's internal weights (AdjacencyMatrix::update_history, graph/mod.rs:278-280): [count][count],
@@ -64,22 +74,30 @@ __global__ void k_weight_snapshot(const float *W, uint32_t ld, uint32_t first, u
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t r = blockIdx.y;
     if (c >= count) return;
-    const float w = W[(size_t)(first + r) * ld + first + c];
+    const float w = W[widx(first + r, first + c, ld)];
     dst[(size_t)r * count + c] = (w == w) ? w : 0.0f;
 }
 
 __global__ void k_graph_synthetic(float *W, uint32_t ld, uint32_t n_loc, uint32_t q0, uint32_t n_neurons,
                                   uint32_t n_tot, uint64_t seed, float lo, float hi, int with_diagonal)
 {
+    // one thread = one unit (4 consecutive rows of a column): full 16-byte stores, 1 KiB contiguous per wavefront
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= ld) return;
-    for (uint32_t p = blockIdx.y; p < n_tot; p += gridDim.y) {
-        float out = quiet_nan();
-        if (q < n_loc) {
-            const uint32_t gq = q0 + q;
-            if (with_diagonal || p != gq) out = uniform_from_hash(seed, (uint64_t)p * n_neurons + gq, lo, hi);
+    const uint32_t groups = (n_tot + 3u) >> 2;
+    for (uint32_t g = blockIdx.y; g < groups; g += gridDim.y) {
+        float out[4];
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) {
+            const uint32_t p = g * 4 + k;
+            out[k] = quiet_nan();
+            if (q < n_loc && p < n_tot) {
+                const uint32_t gq = q0 + q;
+                if (with_diagonal || p != gq) out[k] = uniform_from_hash(seed, (uint64_t)p * n_neurons + gq, lo, hi);
+            }
         }
-        W[(size_t)p * ld + q] = out;
+        float4 v; v.x = out[0]; v.y = out[1]; v.z = out[2]; v.w = out[3];
+        reinterpret_cast<float4 *>(W)[(size_t)g * ld + q] = v;
     }
 }
 
@@ -283,7 +301,7 @@ __global__ __launch_bounds__(256) void k_stdp_apply_columns(const StdpArgs a)
     for (uint32_t s = blockIdx.y; s < count; s += gridDim.y) {
         const uint32_t j = a.spike_list[s];
         if (j < a.q0 || j >= a.q0 + a.n_loc) continue;
-        float *wp = a.W + (size_t)p * a.ld + (j - a.q0);
+        float *wp = a.W + widx(p, j - a.q0, a.ld);
         const float w = *wp;
         if (w == w) *wp = w + a.dcol[(size_t)a.lattice_slot[j] * a.dcol_stride + p];
     }
@@ -296,7 +314,7 @@ __global__ __launch_bounds__(256) void k_stdp_apply_rows(const StdpArgs a)
     const float d = a.drow[r];
     for (uint32_t s = blockIdx.y; s < count; s += gridDim.y) {
         const uint32_t j = a.spike_list[s];
-        float *wp = a.W + (size_t)j * a.ld + r;
+        float *wp = a.W + widx(j, r, a.ld);
         const float w = *wp;
         if (w == w) *wp = w + d;
     }
@@ -312,7 +330,7 @@ __global__ __launch_bounds__(256) void k_stdp_columns(const StdpArgs a)
     for (uint32_t s = blockIdx.y; s < count; s += gridDim.y) {
         const uint32_t j = a.spike_list[s];
         if (j < a.q0 || j >= a.q0 + a.n_loc) continue;
-        float *wp = a.W + (size_t)p * a.ld + (j - a.q0);
+        float *wp = a.W + widx(p, j - a.q0, a.ld);
         const float w = *wp;
         if (w == w) {
             const float *prm = a.stdp + PL_STRIDE * a.lattice_slot[j];
@@ -336,7 +354,7 @@ __global__ __launch_bounds__(256) void k_stdp_rows(const StdpArgs a)
     const float post_act = bcm ? a.act[gr] : 0.0f, post_avg = bcm ? a.avg[gr] : 0.0f;
     for (uint32_t s = blockIdx.y; s < count; s += gridDim.y) {
         const uint32_t j = a.spike_list[s];
-        float *wp = a.W + (size_t)j * a.ld + r;
+        float *wp = a.W + widx(j, r, a.ld);
         const float w = *wp;
         if (w == w) *wp = plasticity_weight(prm, w, a.last_firing_time[j], tr, bcm ? a.act[j] : 0.0f, post_act, post_avg);
     }

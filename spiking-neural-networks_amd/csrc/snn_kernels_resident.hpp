@@ -111,17 +111,19 @@ __global__ __launch_bounds__(64 * RESIDENT_MAX_CHUNKS) void k_step_resident(cons
                 }
             }
         }
-        const float *wrow = in.W + (size_t)(p0 + b0) * ld;   // uniform; + ql is in bounds for padding columns too
-        if (rb == 64) {
+        // quad-row order: one dwordx4 = 4 consecutive rows of this lane's column; + ql is in bounds for padding columns
+        // too; row groups past the end of the matrix = absent edges (the padding rows inside the last group are NaN)
+        const v4f *units = reinterpret_cast<const v4f *>(in.W) + (size_t)((p0 + b0) >> 2) * ld + ql;
+        const v4f none = {quiet_nan(), quiet_nan(), quiet_nan(), quiet_nan()};
 #pragma unroll
-            for (uint32_t u = 0; u < B; ++u) blk.wa[u] = (wrow + (size_t)u * ld)[ql];
+        for (uint32_t g = 0; g < B / 4; ++g) {
+            const v4f x = (4 * g < rb) ? units[(size_t)g * ld] : none;
+            blk.wa[4 * g] = x.x; blk.wa[4 * g + 1] = x.y; blk.wa[4 * g + 2] = x.z; blk.wa[4 * g + 3] = x.w;
+        }
 #pragma unroll
-            for (uint32_t u = 0; u < B; ++u) blk.wb[u] = (wrow + (size_t)(B + u) * ld)[ql];
-        } else {                                             // ragged tail: rows past the end = absent edges
-#pragma unroll
-            for (uint32_t u = 0; u < B; ++u) blk.wa[u] = (u < rb) ? (wrow + (size_t)u * ld)[ql] : quiet_nan();
-#pragma unroll
-            for (uint32_t u = 0; u < B; ++u) blk.wb[u] = (B + u < rb) ? (wrow + (size_t)(B + u) * ld)[ql] : quiet_nan();
+        for (uint32_t g = 0; g < B / 4; ++g) {
+            const v4f x = (B + 4 * g < rb) ? units[(size_t)(B / 4 + g) * ld] : none;
+            blk.wb[4 * g] = x.x; blk.wb[4 * g + 1] = x.y; blk.wb[4 * g + 2] = x.z; blk.wb[4 * g + 3] = x.w;
         }
     };
 

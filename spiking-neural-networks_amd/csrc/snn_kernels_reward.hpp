@@ -53,38 +53,38 @@ struct RewardArgs {
 };
 
 // One streaming read-modify-write pass over the neuron rows of W and C: 16 B per synapse.
-// Thread = 4 adjacent columns (dwordx4), rows grid-strided over blockIdx.y; the presynaptic side (row) is
-// wave-uniform, the postsynaptic side lives in registers.
+// Thread = one column, one unit (4 consecutive rows, dwordx4) per iteration, row groups grid-strided over blockIdx.y;
+// the presynaptic side (the 4 rows of a group) is wave-uniform, the postsynaptic side lives in registers.
 __global__ __launch_bounds__(256) void k_rstdp_dense(const RewardArgs a)
 {
-    const uint32_t c0 = (blockIdx.x * 256 + threadIdx.x) * 4;
-    if (c0 >= a.n_loc) return;
-    int32_t tq[4];
-    uint32_t sq[4];
+    const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= a.n_loc) return;
+    const uint32_t q = a.q0 + c;
+    const int32_t tq = a.last_firing_time[q];
+    const uint32_t sq = a.lattice_slot[q];
+    const uint32_t groups = (a.n_neurons + 3u) >> 2;
+    for (uint32_t g = blockIdx.y; g < groups; g += gridDim.y) {
+        uint32_t sp[4];
+        bool any = false;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const uint32_t q = a.q0 + min(c0 + j, a.n_loc - 1);
-        tq[j] = a.last_firing_time[q];
-        sq[j] = (c0 + j < a.n_loc) ? a.lattice_slot[q] : 0xFFFFFFFFu;
-    }
-    for (uint32_t p = blockIdx.y; p < a.n_neurons; p += gridDim.y) {
-        const uint32_t sp = a.lattice_slot[p];
-        if (!a.rm_on[sp]) continue;
-        if (sq[0] != sp && sq[1] != sp && sq[2] != sp && sq[3] != sp) continue;
-        const float *m = a.rm + (size_t)sp * RM_STRIDE;
-        const int32_t tp = a.last_firing_time[p];
-        v4f *wp = reinterpret_cast<v4f *>(a.W + (size_t)p * a.ld + c0);
-        v4f *cp = reinterpret_cast<v4f *>(a.C + (size_t)p * a.ld + c0);
-        v4f w = *wp, c = *cp;
+        for (uint32_t k = 0; k < 4; ++k) {
+            const uint32_t p = g * 4 + k;
+            sp[k] = (p < a.n_neurons && a.rm_on[a.lattice_slot[p]]) ? a.lattice_slot[p] : 0xFFFFFFFFu;
+            any = any || sp[k] == sq;
+        }
+        if (!any) continue;
+        v4f *wp = reinterpret_cast<v4f *>(a.W) + (size_t)g * a.ld + c;
+        v4f *cp = reinterpret_cast<v4f *>(a.C) + (size_t)g * a.ld + c;
+        v4f w = *wp, tr = *cp;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (sq[j] != sp || w[j] != w[j]) continue;      // other lattice / padding / absent edge (NaN)
-            float wj = w[j], cj = c[j];
-            rstdp_edge(wj, cj, tp, tq[j], m, a.dop);
-            w[j] = wj; c[j] = cj;
+        for (uint32_t k = 0; k < 4; ++k) {
+            if (sp[k] != sq || w[k] != w[k]) continue;       // other lattice / not modulated / absent edge (NaN)
+            float wk = w[k], ck = tr[k];
+            rstdp_edge(wk, ck, a.last_firing_time[g * 4 + k], tq, a.rm + (size_t)sq * RM_STRIDE, a.dop);
+            w[k] = wk; tr[k] = ck;
         }
         *wp = w;
-        *cp = c;
+        *cp = tr;
     }
 }
 
@@ -103,26 +103,12 @@ struct RstdpInputsArgs {
     int dop;
 };
 
-template <int STREAM>
-__device__ __forceinline__ void store_w(float *p, const float (&w)[InputsShape<STREAM>::VEC])
-{
-    if constexpr (STREAM == 1) {
-        v4f v; v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
-        __builtin_nontemporal_store(v, reinterpret_cast<v4f *>(p));
-    } else if constexpr (STREAM == 2) {
-        v2f v; v.x = w[0]; v.y = w[1];
-        __builtin_nontemporal_store(v, reinterpret_cast<v2f *>(p));
-    } else {
-        *p = w[0];
-    }
-}
-
 template <bool ELEC, bool CHEM, int STREAM>
 __global__ __launch_bounds__(InputsShape<STREAM>::THREADS) void k_inputs_rstdp(const RstdpInputsArgs ra)
 {
     using S = InputsShape<STREAM>;
     constexpr int VEC = S::VEC;
-    constexpr uint32_t ROW_BATCH = 16;         // rows of W and of the traces in flight per lane (32 spills)
+    constexpr uint32_t GB = 2;                 // row groups (8 rows) of W and of the traces in flight per lane
     constexpr uint32_t NONE = 0xFFFFFFFFu;
     const InputsArgs &a = ra.in;
 
@@ -172,18 +158,32 @@ __global__ __launch_bounds__(InputsShape<STREAM>::THREADS) void k_inputs_rstdp(c
         s_mod[i] = mod;
         s_lft[i] = lft;
     }
+    const uint32_t groups = (rows + 3u) >> 2;
+    for (uint32_t i = rows + tid; i < groups * 4; i += S::THREADS) {     // padding rows of the last group (weights NaN)
+        s_val[i] = 0.0f;
+        s_kind[i] = KIND_NEURON;
+        s_mod[i] = NONE;
+        s_lft[i] = -1;
+    }
     __syncthreads();
 
     const uint32_t tile = (blockIdx.x + blockIdx.y) % gridDim.x;
-    const uint32_t ql = tile * S::TILE + tid * VEC;
+    const uint32_t ql = tile * S::TILE + tid;                // the lane's column j is ql + j * THREADS
     if (ql >= a.n_loc) return;
+    bool colv[VEC];
+    uint32_t coff[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        colv[j] = ql + (uint32_t)j * S::THREADS < a.n_loc;
+        coff[j] = colv[j] ? (uint32_t)j * S::THREADS : 0u;
+    }
 
     float vq[VEC], gq[VEC];
     int32_t tq[VEC];
     uint32_t sq[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
-        const uint32_t q = ql + j;
+        const uint32_t q = ql + (uint32_t)j * S::THREADS;
         const bool in = q < a.n_loc;
         const uint32_t gqi = a.q0 + (in ? q : a.n_loc - 1);
         vq[j] = (ELEC && in) ? a.xbuf[a.xl.at(gqi, PLANE_V)] : 0.0f;
@@ -202,20 +202,11 @@ __global__ __launch_bounds__(InputsShape<STREAM>::THREADS) void k_inputs_rstdp(c
         for (int j = 0; j < VEC; ++j) tacc[k][j] = 0.0f;
 
     const size_t ld = a.ld;
-    float *wrow = ra.W + (size_t)p0 * ld + ql;
-    float *crow = ra.C + (size_t)p0 * ld + ql;
+    v4f *wbase = reinterpret_cast<v4f *>(ra.W) + (size_t)(p0 >> 2) * ld + ql;
+    v4f *cbase = reinterpret_cast<v4f *>(ra.C) + (size_t)(p0 >> 2) * ld + ql;
 
-    auto row = [&](uint32_t r, float (&w)[VEC], float (&c)[VEC]) {
-        const uint32_t mod = __builtin_amdgcn_readfirstlane(s_mod[r]);
-        if (mod != NONE) {
-            const float *m = ra.rm + (size_t)mod * RM_STRIDE;
-            const int32_t tp = s_lft[r];
-#pragma unroll
-            for (int j = 0; j < VEC; ++j)
-                if (sq[j] == mod && w[j] == w[j]) rstdp_edge(w[j], c[j], tp, tq[j], m, ra.dop);
-            store_w<STREAM>(wrow + (size_t)r * ld, w);
-            store_w<STREAM>(crow + (size_t)r * ld, c);
-        }
+    // one presynaptic row of the input sums (weights already updated)
+    auto row = [&](uint32_t r, const float (&w)[VEC]) {
         const uint32_t kind = __builtin_amdgcn_readfirstlane(s_kind[r]);
         if (ELEC) {
             const float vp = s_val[r];
@@ -243,34 +234,79 @@ __global__ __launch_bounds__(InputsShape<STREAM>::THREADS) void k_inputs_rstdp(c
         }
     };
 
-    uint32_t r = 0;
-    for (; r + ROW_BATCH <= rows; r += ROW_BATCH) {
-        float wb[ROW_BATCH][VEC], cb[ROW_BATCH][VEC];
+    // one row group: the reward-modulated update of its rows (units of modulated rows are rewritten in full), then the sums
+    auto group = [&](uint32_t grp, v4f (&w)[VEC], v4f (&c)[VEC]) {
+        bool dirty = false;
 #pragma unroll
-        for (uint32_t u = 0; u < ROW_BATCH; ++u) load_w<STREAM>(wrow + (size_t)(r + u) * ld, wb[u]);
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t r = grp * 4 + k;
+            const uint32_t mod = __builtin_amdgcn_readfirstlane(s_mod[r]);
+            if (mod != NONE) {
+                const float *m = ra.rm + (size_t)mod * RM_STRIDE;
+                const int32_t tp = s_lft[r];
 #pragma unroll
-        for (uint32_t u = 0; u < ROW_BATCH; ++u) load_w<STREAM>(crow + (size_t)(r + u) * ld, cb[u]);
+                for (int j = 0; j < VEC; ++j) {
+                    float wk = w[j][k], ck = c[j][k];
+                    if (sq[j] == mod && wk == wk) rstdp_edge(wk, ck, tp, tq[j], m, ra.dop);
+                    w[j][k] = wk; c[j][k] = ck;
+                }
+                dirty = true;
+            }
+        }
+        if (dirty) {
 #pragma unroll
-        for (uint32_t u = 0; u < ROW_BATCH; ++u) row(r + u, wb[u], cb[u]);
+            for (int j = 0; j < VEC; ++j) {
+                if (!colv[j]) continue;
+                __builtin_nontemporal_store(w[j], wbase + (size_t)grp * ld + coff[j]);
+                __builtin_nontemporal_store(c[j], cbase + (size_t)grp * ld + coff[j]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float wr[VEC];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) wr[j] = w[j][k];
+            row(grp * 4 + k, wr);
+        }
+    };
+
+    uint32_t g = 0;
+    for (; g + GB <= groups; g += GB) {
+        v4f wb[GB][VEC], cb[GB][VEC];
+#pragma unroll
+        for (uint32_t u = 0; u < GB; ++u)
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) wb[u][j] = __builtin_nontemporal_load(wbase + (size_t)(g + u) * ld + coff[j]);
+#pragma unroll
+        for (uint32_t u = 0; u < GB; ++u)
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) cb[u][j] = __builtin_nontemporal_load(cbase + (size_t)(g + u) * ld + coff[j]);
+#pragma unroll
+        for (uint32_t u = 0; u < GB; ++u) group(g + u, wb[u], cb[u]);
     }
-    for (; r < rows; ++r) {
-        float w[VEC], c[VEC];
-        load_w<STREAM>(wrow + (size_t)r * ld, w);
-        load_w<STREAM>(crow + (size_t)r * ld, c);
-        row(r, w, c);
+    for (; g < groups; ++g) {
+        v4f w[VEC], c[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            w[j] = __builtin_nontemporal_load(wbase + (size_t)g * ld + coff[j]);
+            c[j] = __builtin_nontemporal_load(cbase + (size_t)g * ld + coff[j]);
+        }
+        group(g, w, c);
     }
 
     if (ELEC) {
         float *dst = a.part_i + (size_t)chunk * a.ld + ql;
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) dst[j] = acc[j];
+        for (int j = 0; j < VEC; ++j)
+            if (colv[j]) dst[(uint32_t)j * S::THREADS] = acc[j];
     }
     if (CHEM) {
 #pragma unroll
         for (int k = 0; k < K_TYPES; ++k) {
             float *dst = a.part_t + ((size_t)k * a.n_chunks + chunk) * a.ld + ql;
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) dst[j] = tacc[k][j];
+            for (int j = 0; j < VEC; ++j)
+                if (colv[j]) dst[(uint32_t)j * S::THREADS] = tacc[k][j];
         }
     }
 }

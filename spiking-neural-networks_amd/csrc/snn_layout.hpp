@@ -1,8 +1,12 @@
 // Device-memory layout shared by the kernels and the host-side handle.
 //
 // HBM layout (per handle = per GPU):
-//   W        dense synapse matrix of the local postsynaptic shard, row-major
-//            [n_tot rows (presynaptic, interleaved index)][ld floats], ld = round_up(n_local, 64).
+//   W        dense synapse matrix of the local postsynaptic shard in QUAD-ROW order: the presynaptic rows are stored in
+//            groups of 4; element (p, q) sits at ((p / 4) * ld + q) * 4 + p % 4, ld = round_up(n_local, 64) -- the 16
+//            bytes at ((p / 4) * ld + q) * 16 are rows 4g .. 4g+3 of column q ("unit").  A lane that owns a column
+//            reads 4 consecutive rows of it with one dwordx4, a wavefront (64 adjacent columns) 1 KiB contiguous, and
+//            a column -- what STDP rewrites when a neuron spikes -- holds 16 contiguous bytes per row group, so its
+//            update dirties 4x fewer 128-byte lines than in a row-major matrix (widx / wcount below).
 //            An absent edge (None in the reference's Vec<Vec<Option<f32>>>, graph/mod.rs:139-150)
 //            is stored as a quiet NaN, so `connections` needs no second matrix and the averager
 //            count n_in[post] is precomputed once per graph upload.  4 B per synapse, read once
@@ -26,6 +30,14 @@ constexpr int K_TYPES = 3;
 constexpr int CHUNK = 256;        // canonical reduction chunk (SNN_REDUCTION_CHUNK)
 constexpr int NUM_PLANES = 5;
 enum Plane { PLANE_V = 0, PLANE_SPIKE = 1, PLANE_T0 = 2 };
+
+// Dense matrix addressing (quad-row order, see the head of this file): word offset of element (row p, local column q)
+__host__ __device__ __forceinline__ size_t widx(uint32_t p, uint32_t q, size_t ld)
+{
+    return (((size_t)(p >> 2)) * ld + q) * 4 + (p & 3u);
+}
+// words of a matrix with n_rows rows (rows are padded to whole groups of 4; padding rows hold the absent-edge NaN)
+__host__ __device__ __forceinline__ size_t wcount(uint32_t n_rows, size_t ld) { return (size_t)((n_rows + 3u) >> 2) * ld * 4; }
 
 // Mirror addressing: global neuron index -> word offset inside xbuf.
 struct XLayout {

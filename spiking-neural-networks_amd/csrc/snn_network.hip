@@ -41,7 +41,7 @@ int snn_network_create(int device, int neuron_model, int nt_kinetics, int recept
     net->device = device;
     if (const char *e = getenv("SNN_AMD_FUSED_STEP")) net->fused_step = (e[0] != '0');
     if (const char *e = getenv("SNN_AMD_DEFER_RSTDP")) net->defer_rstdp = (e[0] != '0');
-    if (const char *e = getenv("SNN_AMD_DEFER_STDP")) net->defer_stdp = (e[0] != '0');
+    if (const char *e = getenv("SNN_AMD_DEFER_STDP")) net->defer_stdp = (e[0] == '2') ? 2 : (e[0] != '0');
     if (const char *e = getenv("SNN_AMD_UNIFORM_PARAMS")) net->uniform_params = (e[0] != '0');
     if (const char *e = getenv("SNN_AMD_INPUT_SHAPE")) net->force_shape = (e[0] == '1') ? 1 : ((e[0] == '2') ? 2 : 0);
     net->model = neuron_model; net->nt_kind = nt_kinetics; net->rc_kind = receptor_kinetics;
@@ -311,7 +311,7 @@ int snn_fill_graph_synthetic(snn_network_t *net, uint64_t seed, float lo, float 
     HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
     TRY(end_run(net));                     // a deferred reward-modulated update belongs to the OLD weights: apply it first
     if (net->trace)                        // traces of the replaced edges do not carry over
-        HIP_TRY(hipMemsetAsync(net->trace, 0, std::max<size_t>((size_t)net->n_tot * net->ld, 64) * 4, net->stream), SNN_ERR_BUFFER_WRITE);
+        HIP_TRY(hipMemsetAsync(net->trace, 0, std::max<size_t>(wcount(net->n_tot, net->ld), 64) * 4, net->stream), SNN_ERR_BUFFER_WRITE);
     if (net->n_tot && net->ld) {
         const unsigned gy = std::min<uint32_t>(net->n_tot, 4096);
         hipLaunchKernelGGL(k_graph_synthetic, dim3((net->ld + 255) / 256, gy), dim3(256), 0, net->stream, net->W,
@@ -508,7 +508,7 @@ int snn_set_bcm(snn_network_t *net, uint32_t id, float decay, float average_scal
 }
 
 namespace {
-size_t trace_elems(const snn_network *net) { return net->csr ? (size_t)net->sell_entries : (size_t)net->n_tot * net->ld; }
+size_t trace_elems(const snn_network *net) { return net->csr ? (size_t)net->sell_entries : wcount(net->n_tot, net->ld); }
 
 int ensure_traces(snn_network *net)
 {
@@ -605,15 +605,29 @@ static int trace_rows_io(snn_network_t *net, uint32_t pre_begin, uint32_t pre_co
     TRY(end_run(net));
     TRY(ensure_traces(net));
     HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
-    float *dev = net->trace + (size_t)pre_begin * net->ld;
+    // through a row-major staging block of <= 64 MiB and <= 32768 rows per hop (the matrix is in quad-row order)
     float *host = traces + net->q0;
-    if (set)
-        HIP_TRY(hipMemcpy2D(dev, (size_t)net->ld * 4, host, (size_t)net->nn * 4, (size_t)net->n_loc * 4, pre_count,
-                            hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
-    else
-        HIP_TRY(hipMemcpy2D(host, (size_t)net->nn * 4, dev, (size_t)net->ld * 4, (size_t)net->n_loc * 4, pre_count,
-                            hipMemcpyDeviceToHost), SNN_ERR_BUFFER_READ);
-    return SNN_OK;
+    const uint32_t hop = (uint32_t)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(pre_count, 32768), ((size_t)64 << 20) / ((size_t)net->n_loc * 4)));
+    float *stage = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&stage), (size_t)hop * net->n_loc * 4), SNN_ERR_BUFFER_CREATE);
+    int rc = SNN_OK;
+    for (uint32_t r = 0; r < pre_count && rc == SNN_OK; r += hop) {
+        const uint32_t rows = std::min(hop, pre_count - r);
+        const dim3 grid((net->n_loc + 255) / 256, rows);
+        if (set) {
+            if (hipMemcpy2D(stage, (size_t)net->n_loc * 4, host + (size_t)r * net->nn, (size_t)net->nn * 4, (size_t)net->n_loc * 4, rows,
+                            hipMemcpyHostToDevice) != hipSuccess) { rc = fail(SNN_ERR_BUFFER_WRITE, "trace upload failed"); break; }
+            hipLaunchKernelGGL(k_rows_staging, grid, dim3(256), 0, net->stream, net->trace, net->ld, net->n_loc, pre_begin + r, rows, stage, 1);
+            if (hipStreamSynchronize(net->stream) != hipSuccess) rc = fail(SNN_ERR_WAIT, "trace upload wait failed");
+        } else {
+            hipLaunchKernelGGL(k_rows_staging, grid, dim3(256), 0, net->stream, net->trace, net->ld, net->n_loc, pre_begin + r, rows, stage, 0);
+            if (hipStreamSynchronize(net->stream) != hipSuccess) { rc = fail(SNN_ERR_WAIT, "trace download wait failed"); break; }
+            if (hipMemcpy2D(host + (size_t)r * net->nn, (size_t)net->nn * 4, stage, (size_t)net->n_loc * 4, (size_t)net->n_loc * 4, rows,
+                            hipMemcpyDeviceToHost) != hipSuccess) rc = fail(SNN_ERR_BUFFER_READ, "trace download failed");
+        }
+    }
+    (void)hipFree(stage);
+    return rc;
 }
 int snn_set_trace_rows(snn_network_t *net, uint32_t pre_begin, uint32_t pre_count, const float *traces)
 { return trace_rows_io(net, pre_begin, pre_count, const_cast<float *>(traces), true); }
@@ -1221,7 +1235,7 @@ int snn_set_option(snn_network_t *net, const char *name, int value)
     const std::string n(name);
     if (n == "fused_step") net->fused_step = value != 0;
     else if (n == "defer_rstdp") net->defer_rstdp = value != 0;
-    else if (n == "defer_stdp") net->defer_stdp = value != 0;
+    else if (n == "defer_stdp") net->defer_stdp = (value == 2) ? 2 : (value != 0);
     else if (n == "uniform_params") { net->uniform_params = value != 0; net->uni_dirty = true; }
     else if (n == "input_shape") net->force_shape = (value == 1 || value == 2) ? value : 0;
     else return fail(SNN_ERR_BAD_ARG, "unknown option '" + n + "'");

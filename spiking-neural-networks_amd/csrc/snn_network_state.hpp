@@ -171,7 +171,10 @@ struct snn_network {
     int uniform_params = 1;               // 0: always read the arrays (SNN_AMD_UNIFORM_PARAMS=0)
     int force_shape = 0;                  // 1 | 2: streamed shape of the dense input pass (SNN_AMD_INPUT_SHAPE), 0: by size
     // deferred STDP (dense handles): the update of step t is applied by the input pass of step t + 1
-    int defer_stdp = 1;                    // 0: always the standalone kernels (SNN_AMD_DEFER_STDP=0)
+    // 0 (default): the scatter kernels right after the step; 1: the update of step t rides on the input pass of step
+    // t + 1; 2: prepared delta vectors, applied right away by scatter passes (SNN_AMD_DEFER_STDP / "defer_stdp").
+    // Measured on the quad-row matrix: the scatter kernels win at every spike rate.
+    int defer_stdp = 0;
     bool stdp_pending = false;
     uint32_t *stdp_flag = nullptr;
     float *stdp_dcol = nullptr, *stdp_drow = nullptr;
@@ -659,7 +662,7 @@ int build_state(snn_network *net)
 
     // graph + partials + counts
     if (net->csr) net->n_chunks = 1;     // the CSR kernel writes the finished two-level sum
-    TRY(dev_alloc_t(net, &net->W, net->csr ? 0 : (size_t)net->n_tot * net->ld));
+    TRY(dev_alloc_t(net, &net->W, net->csr ? 0 : wcount(net->n_tot, net->ld)));
     TRY(dev_alloc_t(net, &net->part_i, (size_t)net->n_chunks * net->ld));
     TRY(dev_alloc_t(net, &net->part_t, (size_t)K_TYPES * net->n_chunks * net->ld));
     TRY(dev_alloc_t(net, &net->n_in, net->ld));

@@ -292,6 +292,7 @@ int launch_plasticity_kernels(snn_network *net)
         hipLaunchKernelGGL(k_stdp_prepare, dim3((std::max(net->n_tot, net->n_loc) + 255) / 256), dim3(256), 0, net->stream, a);
         HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
         net->stdp_pending = true;
+        if (net->defer_stdp == 2) TRY(flush_stdp(net));      // the prepared deltas applied right away by the scatter passes
         return SNN_OK;
     }
     if (net->csr) {
@@ -338,8 +339,8 @@ int launch_rstdp_pass(snn_network *net, int dop)
     a.W = net->W; a.C = net->trace; a.ld = net->ld; a.n_loc = net->n_loc; a.q0 = net->q0; a.n_neurons = net->nn;
     a.last_firing_time = net->na.last_firing_time; a.lattice_slot = net->lattice_slot;
     a.rm = net->rm_dev; a.rm_on = net->rm_on_dev; a.dop = dop;
-    const unsigned gx = (net->n_loc + 1023) / 1024;
-    const unsigned gy = std::max(1u, std::min<unsigned>(net->nn, 8192u / gx));     // ~8192 workgroups in flight
+    const unsigned gx = (net->n_loc + 255) / 256;
+    const unsigned gy = std::max(1u, std::min<unsigned>((net->nn + 3) / 4, std::max(1u, 8192u / gx)));     // ~8192 workgroups in flight
     hipLaunchKernelGGL(k_rstdp_dense, dim3(gx, gy), dim3(256), 0, net->stream, a);
     HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
     return SNN_OK;
@@ -404,7 +405,7 @@ int time_input_pass(snn_network *net, float *ms)
 
 int choose_matrix_placement(snn_network *net)
 {
-    const size_t count = net->csr ? 0 : (size_t)net->n_tot * net->ld;
+    const size_t count = net->csr ? 0 : wcount(net->n_tot, net->ld);
     const size_t bytes = count * sizeof(float);
     if (bytes >= ((size_t)1 << 30) && net->n_loc) {
         const int prof = net->profile;

@@ -119,6 +119,7 @@ def test_deferred_stdp_in_the_streamed_input_pass_equals_oracle(snn):
     net = build_streamed(64, 64, seed=41)
     steps, seed, fraction = 36, 5, 0.02
     dn = parity.device_from_oracle(snn, net)
+    dn.set_option("defer_stdp", 1)                          # the update rides on the next input pass (not the default)
     dn.set_synthetic_drive(seed, fraction, V_KICK)
     w0 = net["weights"].copy()
     done = 0
@@ -148,7 +149,8 @@ def test_deferred_stdp_on_streamed_shard_handles(snn):
     net = build_streamed(90, 90, seed=43)          # 8 500 neurons: each of the two shards streams a 145 MB matrix
     steps, seed, fraction, g = 14, 9, 0.02, 2
     handles = [parity.device_from_oracle(snn, net, shard=(r, g)) for r in range(g)]
-    for h in handles:
+    for r, h in enumerate(handles):
+        h.set_option("defer_stdp", 1 + r % 2)               # one shard fuses, the other scatters the prepared deltas
         h.set_synthetic_drive(seed, fraction, V_KICK)
     ex = parallel.LocalExchange(handles, torch.device("cuda", 0))
     for _ in range(steps):
@@ -168,7 +170,7 @@ def test_deferred_stdp_on_streamed_shard_handles(snn):
 
 def test_c4_size_deferred_stdp_equals_the_standalone_kernels(snn):
     """BASELINE configs[3] (81 920 neurons, 26.8 GB matrix) with 1 % of the population spiking per step: the update
-    fused into the input pass against the scatter kernels (SNN_AMD_DEFER_STDP=0), device against device; sampled rows
+    fused into the input pass (SNN_AMD_DEFER_STDP=1) against the scatter kernels (=0, the default), device against device; sampled rows
     and columns of the matrix and the whole state bit-identical."""
     import os
     n_inh, n_exc = 128 * 128, 256 * 256
