@@ -125,11 +125,12 @@ __global__ __launch_bounds__(InputsShape<STREAM>::THREADS) void k_inputs_dense(c
     constexpr int VEC = S::VEC;
     constexpr int TS = CHEM ? NT : 1;                        // transmitter slots of this instantiation
 
-    __shared__ float s_val[CHUNK];
-    __shared__ uint32_t s_kind[CHUNK];
-    __shared__ float s_t[TS][CHUNK];
-    __shared__ float s_dcol[STDP ? STDP_MAX_LATTICES : 1][STDP ? CHUNK : 1];
-    __shared__ uint32_t s_rowflag[STDP ? CHUNK : 1];
+    // 16-byte aligned: the 4 rows of a row group are read back with one ds_read_b128 per array
+    __shared__ __attribute__((aligned(16))) float s_val[CHUNK];
+    __shared__ __attribute__((aligned(16))) uint32_t s_kind[CHUNK];
+    __shared__ __attribute__((aligned(16))) float s_t[TS][CHUNK];
+    __shared__ __attribute__((aligned(16))) float s_dcol[STDP ? STDP_MAX_LATTICES : 1][STDP ? CHUNK : 4];
+    __shared__ __attribute__((aligned(16))) uint32_t s_rowflag[STDP ? CHUNK : 4];
     // the previous step's weight updates ride on this pass only if some plastic neuron spiked in it (launch-uniform)
     const bool stdp_live = STDP && *a.stdp_count != 0u;
 
@@ -147,20 +148,17 @@ __global__ __launch_bounds__(InputsShape<STREAM>::THREADS) void k_inputs_dense(c
     const uint32_t ql = tile * S::TILE + tid;                // the lane's column j is ql + j * THREADS
     const size_t ld = a.ld;
     const uint32_t groups = (rows + 3u) >> 2;                // row groups of the chunk (rows are padded to 4 with NaN)
-    // unit (row group 0 of the chunk, column ql); a column past the shard's padded width would read outside the
-    // matrix: such lanes (only in the last tile) re-read their first column and never use the value
-    const v4f *gbase = reinterpret_cast<const v4f *>(a.W) + (size_t)(p0 >> 2) * ld + ql;
+    // Addresses = a wave-uniform base (row group, tile, column slot j) + the lane's fixed 16-byte index: no per-lane
+    // 64-bit arithmetic in the loop.  A column of the last tile past the shard's width reads into the next row group
+    // (or, for the last group, into the slack the matrix is allocated with: WMATRIX_SLACK); the value is never used.
+    const v4f *ubase = reinterpret_cast<const v4f *>(a.W) + (size_t)(p0 >> 2) * ld + (size_t)tile * S::TILE;
     bool colv[VEC];
-    uint32_t coff[VEC];
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-        colv[j] = ql + (uint32_t)j * S::THREADS < a.n_loc;
-        coff[j] = colv[j] ? (uint32_t)j * S::THREADS : 0u;
-    }
+    for (int j = 0; j < VEC; ++j) colv[j] = ql + (uint32_t)j * S::THREADS < a.n_loc;
     auto load_units = [&](uint32_t grp, v4f (&w)[VEC]) {
-        const v4f *gp = gbase + (size_t)grp * ld;
+        const v4f *gp = ubase + (size_t)grp * ld;
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) w[j] = __builtin_nontemporal_load(gp + coff[j]);
+        for (int j = 0; j < VEC; ++j) w[j] = __builtin_nontemporal_load(gp + j * S::THREADS + tid);
     };
 
     // The first batch of row groups is requested BEFORE the presynaptic values are staged: all workgroups of a

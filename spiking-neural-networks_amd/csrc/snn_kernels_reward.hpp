@@ -171,12 +171,8 @@ __global__ __launch_bounds__(InputsShape<STREAM>::THREADS) void k_inputs_rstdp(c
     const uint32_t ql = tile * S::TILE + tid;                // the lane's column j is ql + j * THREADS
     if (ql >= a.n_loc) return;
     bool colv[VEC];
-    uint32_t coff[VEC];
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-        colv[j] = ql + (uint32_t)j * S::THREADS < a.n_loc;
-        coff[j] = colv[j] ? (uint32_t)j * S::THREADS : 0u;
-    }
+    for (int j = 0; j < VEC; ++j) colv[j] = ql + (uint32_t)j * S::THREADS < a.n_loc;
 
     float vq[VEC], gq[VEC];
     int32_t tq[VEC];
@@ -202,8 +198,9 @@ __global__ __launch_bounds__(InputsShape<STREAM>::THREADS) void k_inputs_rstdp(c
         for (int j = 0; j < VEC; ++j) tacc[k][j] = 0.0f;
 
     const size_t ld = a.ld;
-    v4f *wbase = reinterpret_cast<v4f *>(ra.W) + (size_t)(p0 >> 2) * ld + ql;
-    v4f *cbase = reinterpret_cast<v4f *>(ra.C) + (size_t)(p0 >> 2) * ld + ql;
+    // wave-uniform bases + the lane's fixed index (see k_inputs_dense); columns past the shard's width read slack
+    v4f *wbase = reinterpret_cast<v4f *>(ra.W) + (size_t)(p0 >> 2) * ld + (size_t)tile * S::TILE;
+    v4f *cbase = reinterpret_cast<v4f *>(ra.C) + (size_t)(p0 >> 2) * ld + (size_t)tile * S::TILE;
 
     // one presynaptic row of the input sums (weights already updated)
     auto row = [&](uint32_t r, const float (&w)[VEC]) {
@@ -257,8 +254,8 @@ __global__ __launch_bounds__(InputsShape<STREAM>::THREADS) void k_inputs_rstdp(c
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
                 if (!colv[j]) continue;
-                __builtin_nontemporal_store(w[j], wbase + (size_t)grp * ld + coff[j]);
-                __builtin_nontemporal_store(c[j], cbase + (size_t)grp * ld + coff[j]);
+                __builtin_nontemporal_store(w[j], wbase + (size_t)grp * ld + j * S::THREADS + tid);
+                __builtin_nontemporal_store(c[j], cbase + (size_t)grp * ld + j * S::THREADS + tid);
             }
         }
 #pragma unroll
@@ -276,11 +273,11 @@ __global__ __launch_bounds__(InputsShape<STREAM>::THREADS) void k_inputs_rstdp(c
 #pragma unroll
         for (uint32_t u = 0; u < GB; ++u)
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) wb[u][j] = __builtin_nontemporal_load(wbase + (size_t)(g + u) * ld + coff[j]);
+            for (int j = 0; j < VEC; ++j) wb[u][j] = __builtin_nontemporal_load(wbase + (size_t)(g + u) * ld + j * S::THREADS + tid);
 #pragma unroll
         for (uint32_t u = 0; u < GB; ++u)
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) cb[u][j] = __builtin_nontemporal_load(cbase + (size_t)(g + u) * ld + coff[j]);
+            for (int j = 0; j < VEC; ++j) cb[u][j] = __builtin_nontemporal_load(cbase + (size_t)(g + u) * ld + j * S::THREADS + tid);
 #pragma unroll
         for (uint32_t u = 0; u < GB; ++u) group(g + u, wb[u], cb[u]);
     }
@@ -288,8 +285,8 @@ __global__ __launch_bounds__(InputsShape<STREAM>::THREADS) void k_inputs_rstdp(c
         v4f w[VEC], c[VEC];
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
-            w[j] = __builtin_nontemporal_load(wbase + (size_t)g * ld + coff[j]);
-            c[j] = __builtin_nontemporal_load(cbase + (size_t)g * ld + coff[j]);
+            w[j] = __builtin_nontemporal_load(wbase + (size_t)g * ld + j * S::THREADS + tid);
+            c[j] = __builtin_nontemporal_load(cbase + (size_t)g * ld + j * S::THREADS + tid);
         }
         group(g, w, c);
     }

@@ -36,8 +36,13 @@ __host__ __device__ __forceinline__ size_t widx(uint32_t p, uint32_t q, size_t l
 {
     return (((size_t)(p >> 2)) * ld + q) * 4 + (p & 3u);
 }
-// words of a matrix with n_rows rows (rows are padded to whole groups of 4; padding rows hold the absent-edge NaN)
-__host__ __device__ __forceinline__ size_t wcount(uint32_t n_rows, size_t ld) { return (size_t)((n_rows + 3u) >> 2) * ld * 4; }
+// words of a matrix with n_rows rows (rows are padded to whole groups of 4; padding rows hold the absent-edge NaN) plus
+// the slack the streaming kernels may read past the last row group (one column tile of units, never used)
+constexpr size_t WMATRIX_SLACK = 1024 * 4;
+__host__ __device__ __forceinline__ size_t wcount(uint32_t n_rows, size_t ld)
+{
+    return (size_t)((n_rows + 3u) >> 2) * ld * 4 + WMATRIX_SLACK;
+}
 
 // Mirror addressing: global neuron index -> word offset inside xbuf.
 struct XLayout {
