@@ -167,6 +167,7 @@ SIGNATURES = {
     "snn_get_eeg_history": (C.c_int, [H, C.c_uint32, f32p, C.c_size_t]),
     "snn_get_spike_counts": (C.c_int, [H, C.c_uint32, u32p, C.c_size_t]),
     "snn_set_option": (C.c_int, [H, C.c_char_p, C.c_int]),
+    "snn_get_stat": (C.c_int, [H, C.c_char_p, u64p]),
     "snn_profile_enable": (C.c_int, [H, C.c_int]),
     "snn_profile_reset": (C.c_int, [H]),
     "snn_profile_read": (C.c_int, [H, u64p, C.POINTER(C.c_double)]),

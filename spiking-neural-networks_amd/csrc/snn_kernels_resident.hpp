@@ -216,4 +216,295 @@ __global__ __launch_bounds__(64 * RESIDENT_MAX_CHUNKS) void k_step_resident(cons
     }
 }
 
+// k_run_resident -- MANY steps of a small dense lattice in ONE launch (electrical synapses, neurons only, <= 1024 of
+// them: BASELINE configs[0], the 32 x 32 lattice).  The one-launch step above is a chain of dependent L2 round trips
+// (9.5 us per launch, of which the canonical 256-long add chain itself is well under 1 us); here
+//   * a workgroup = 64 postsynaptic columns x all rows, 16 wavefronts x 64 rows, and keeps its slab of W in REGISTERS
+//     for the whole run (64 words per lane; absent edges as weight 0 plus one presence bit per row);
+//   * per step every workgroup needs every neuron's new voltage: the owner publishes it as an 8-byte {voltage, step
+//     tag} granule (agent-scope relaxed store = write-through) into the slot of the step's parity, every thread polls
+//     ONE granule (agent-scope relaxed loads bypass L1) until the tag is the step's -- measured on MI355X: 1.0 us per
+//     all-to-all of 1024 granules among 16 workgroups (profiles/experiments/granule_exchange_probe.hip), against
+//     1.45 us for a kernel boundary alone.  Two slots suffice: a workgroup can only publish step t + 2 after it has seen
+//     every workgroup's step t + 1, which each of them publishes after it finished reading step t;
+//   * the canonical sum keeps its order: the 4 wavefronts of a chunk take turns (the running sum passes through LDS), a
+//     turn's products are packed two rows per instruction; wavefront w sits on SIMD w % 4, and turn = (w % 4 - chunk) & 3
+//     puts the four wavefronts of a turn on four different SIMDs;
+//   * an absent edge contributes product(term, 0) = +-0 instead of being skipped -- exact as long as the term is finite
+//     (the sum never holds -0, see above); a step in which some voltage is not a small finite number takes the path with
+//     explicit selects instead (workgroup-uniform).
+// Arithmetic, order of operations and the update code are those of k_step_resident / k_inputs_dense + k_update.
+constexpr uint32_t RUN_RESIDENT_MAX_NEURONS = 1024;
+constexpr uint32_t RUN_RESIDENT_SPIN_LIMIT = 1u << 24;
+
+struct ResidentRunArgs {
+    InputsArgs in;                  // W, ld, n_loc, n_tot, xbuf = the exchange buffer itself, gap conductances
+    UpdateArgs up;                  // in place: n.xbuf = xout = exchange buffer, xout2 = null; history rows of the FIRST step
+    uint32_t steps;
+    uint32_t vhist_stride, raster_stride;     // elements between consecutive history rows
+    unsigned long long *granules;   // [2][RUN_RESIDENT_MAX_NEURONS] {voltage bits, tag << 32}
+    uint32_t tag_base;              // tag of the state after step s (1-based) = tag_base + s
+    uint32_t *failed;               // host-visible word, set when a poll gave up (workgroups not co-resident)
+    unsigned long long *timing;     // null, or [gridDim.x][4] shader-clock totals of workgroup phases (SNN_AMD_RUN_TIMING=1)
+};
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// the granules of the state a run starts from (slot 0, tag = tag_base)
+__global__ __launch_bounds__(256) void k_run_resident_seed(const float *xbuf, XLayout xl, uint32_t n, unsigned long long *granules, uint32_t tag)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) granules[i] = ((unsigned long long)tag << 32) | __float_as_uint(xbuf[xl.at(i, PLANE_V)]);
+}
+
+struct ResidentRunShared {
+    float v[RUN_RESIDENT_MAX_NEURONS];           // S(t): every neuron's voltage
+    float hand[RESIDENT_MAX_CHUNKS][64];         // running sum of a chunk, from one wavefront's turn to the next
+    float pi[RESIDENT_MAX_CHUNKS][64];           // finished chunk sums
+    v4f w0[16][64];                              // the updating wavefront's weights (its registers belong to the update)
+    uint32_t ok[16], plain[16];                  // per wavefront: all its granules arrived / all its values small and finite
+};
+
+// The step loop of one wavefront.  UPDATER = wavefront 0, which also owns the neuron update of the workgroup's 64 columns: it
+// keeps its weights in LDS and, for Izhikevich neurons without transmitters, the neurons' state in registers for the whole
+// run (same expressions as update_neuron, integrate_and_fire/mod.rs:217-255); the other wavefronts keep 64 weights per lane
+// in registers.  Every wavefront passes the same five workgroup barriers per step.
+template <int MODEL, bool UPDATER, bool REGISTERS>
+__device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, ResidentRunShared &sh, const uint32_t wave)
+{
+    const InputsArgs &in = a.in;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t chunk = wave >> 2;
+    const uint32_t turn = ((wave & 3u) - chunk) & 3u;            // which quarter of the chunk, and when
+    const uint32_t row0 = chunk * CHUNK + turn * 64u;
+    const uint32_t n_tot = in.n_tot, steps = a.steps, tag_base = a.tag_base, n_chunks = in.n_chunks;
+    const bool rows_live = row0 < n_tot;
+    const bool last_of_chunk = turn == 3u || row0 + 64u >= n_tot;
+    const uint32_t ql = blockIdx.x * 64u + lane;
+    const bool col = ql < in.n_loc;
+    const float gq = col ? uload(in.uni, NP_GAP, in.gap_conductance, in.q0 + ql) : 0.0f;
+    const bool gq_small = fabsf(gq) <= 1e15f;
+    const unsigned long long *granules = a.granules;
+
+    // this lane's 64 weights (quad-row units: 4 consecutive rows of one column per load); absent edge: weight 0
+    float w[UPDATER ? 1 : 64];
+    const v4f *units = reinterpret_cast<const v4f *>(in.W) + (size_t)(row0 >> 2) * in.ld + ql;
+    {
+#pragma unroll
+        for (uint32_t g = 0; g < 16; ++g) {
+            v4f x = {quiet_nan(), quiet_nan(), quiet_nan(), quiet_nan()};
+            if (row0 + 4 * g < n_tot) x = units[(size_t)g * in.ld];
+            float e[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k) {
+                const bool edge = e[k] == e[k];
+                e[k] = edge ? e[k] : 0.0f;
+                if (!UPDATER) w[4 * g + k] = e[k];
+            }
+            if (UPDATER) sh.w0[g][lane] = v4f{e[0], e[1], e[2], e[3]};      // read back by this lane only
+        }
+    }
+
+    // Izhikevich state in registers (REGISTERS: the host launches that variant for Izhikevich lattices without transmitters
+    // and without the BCM extension)
+    constexpr bool in_registers = UPDATER && REGISTERS;
+    static_assert(!REGISTERS || MODEL == 0, "the register-resident update is the Izhikevich one");
+    float nv = 0.0f, nw = 0.0f, n_div = 1.0f, dt_cm = 0.0f, dt_tau = 0.0f, pa = 0.0f, pb = 0.0f, pc = 0.0f, pd = 0.0f, pth = 0.0f;
+    uint32_t n_spikes = 0, last_spike = 0;
+    if (in_registers && col) {
+        const NeuronArrays &n = a.up.n;
+        const uint32_t q = a.up.rows.global_of(ql);
+        nv = n.xbuf[n.xl.at(q, PLANE_V)];
+        nw = n.w_value[q];
+        const uint32_t cnt = a.up.n_in[ql];
+        n_div = cnt == 0 ? 1.0f : (float)cnt;
+        const float dt = uload(n.uni, NP_DT, n.dt, q);
+        dt_cm = dt / uload(n.uni, NP_C_M, n.c_m, q);
+        dt_tau = dt / uload(n.uni, NP_TAU_M, n.tau_m, q);
+        pa = uload(n.uni, NP_A, n.a, q); pb = uload(n.uni, NP_B, n.b, q);
+        pc = uload(n.uni, NP_C, n.c, q); pd = uload(n.uni, NP_D, n.d, q);
+        pth = uload(n.uni, NP_V_TH, n.v_th, q);
+        last_spike = reinterpret_cast<const uint32_t *>(n.xbuf)[n.xl.at(q, PLANE_SPIKE)];
+    }
+
+    unsigned long long spent[4] = {0, 0, 0, 0}, mark = a.timing ? clock64() : 0;
+    auto lap = [&](int phase) {
+        if (!UPDATER || !a.timing) return;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // keeps the phases' code on its side of the mark
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long now = clock64();
+        __builtin_amdgcn_sched_barrier(0);
+        spent[phase] += now - mark;
+        mark = now;
+    };
+
+    for (uint32_t s = 0; s < steps; ++s) {
+        // (1) S(t): every neuron's voltage, one granule per thread (those of the first step come from k_run_resident_seed:
+        // the exchange buffer itself is updated in place by workgroups that are already a step ahead)
+        float v = 0.0f;
+        bool arrived = true;
+        if (tid < n_tot) {
+            const unsigned long long *g = granules + (size_t)(s & 1u) * RUN_RESIDENT_MAX_NEURONS + tid;
+            const uint32_t tag = tag_base + s;
+            unsigned long long x;
+            uint32_t spins = 0;
+            do {
+                x = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } while ((uint32_t)(x >> 32) != tag && ++spins < RUN_RESIDENT_SPIN_LIMIT);
+            arrived = (uint32_t)(x >> 32) == tag;
+            v = __uint_as_float((uint32_t)x);
+        }
+        lap(0);
+        sh.v[tid] = v;
+        const bool all_arrived = __all(arrived), all_plain = __all(fabsf(v) <= 1e15f && gq_small);
+        if (lane == 0) { sh.ok[wave] = all_arrived; sh.plain[wave] = all_plain; }
+        __syncthreads();
+        const uint32_t flag_ok = sh.ok[lane & 15u], flag_plain = sh.plain[lane & 15u];
+        if (!__all(flag_ok != 0)) break;                         // workgroup-uniform: some poll gave up
+        const bool plain = __all(flag_plain != 0);
+        lap(1);
+
+        // (2) the canonical chunk sums, the wavefronts of a chunk in turn
+        const float vq = sh.v[ql & (RUN_RESIDENT_MAX_NEURONS - 1u)];
+#pragma unroll 1
+        for (uint32_t t = 0; t < 4; ++t) {
+            if (t == turn && rows_live) {
+                float acc = (t != 0) ? sh.hand[chunk][lane] : 0.0f;
+                // wave-uniform address = LDS broadcast; the offset is laundered through a vector register so that the values
+                // stay in vector registers (as scalars every one of them costs a v_readlane plus its wait states)
+                uint32_t zero;
+                asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
+                const v4f *pre = reinterpret_cast<const v4f *>(sh.v + row0 + zero);
+                // 16 rows per batch: the batch's LDS reads (4 x 16 B of voltages, for the updater 4 x 16 B of weights too) are
+                // issued together and the next batch's before this one is summed -- one read at a time, each waited for,
+                // costs an LDS round trip per 4 rows
+                auto load_batch = [&](uint32_t b, v4f (&vp)[4], v4f (&wr)[4]) {
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; ++k) {
+                        vp[k] = pre[4 * b + k];
+                        if (UPDATER) wr[k] = sh.w0[4 * b + k][lane];
+                    }
+                };
+                auto sweep = [&](auto group) {               // group(first row, 4 voltages, 4 weights)
+                    v4f vp[4], wr[4], vp_next[4], wr_next[4];
+                    load_batch(0, vp, wr);
+#pragma unroll
+                    for (uint32_t b = 0; b < 4; ++b) {
+                        if (b < 3) load_batch(b + 1, vp_next, wr_next);
+#pragma unroll
+                        for (uint32_t k = 0; k < 4; ++k) {
+                            const uint32_t r = 16 * b + 4 * k;
+                            if (!UPDATER) wr[k] = v4f{w[UPDATER ? 0 : r], w[UPDATER ? 0 : r + 1], w[UPDATER ? 0 : r + 2], w[UPDATER ? 0 : r + 3]};
+                            group(r, vp[k], wr[k]);
+                        }
+#pragma unroll
+                        for (uint32_t k = 0; k < 4; ++k) { vp[k] = vp_next[k]; wr[k] = wr_next[k]; }
+                    }
+                };
+                if (plain) {
+                    const v2f vq2 = {vq, vq}, gq2 = {gq, gq};
+                    sweep([&](uint32_t, const v4f &x, const v4f &y) {
+                        const v2f p0 = (gq2 * (v2f{x.x, x.y} - vq2)) * v2f{y.x, y.y};   // gap_junction neuron/mod.rs:54-60, times the weight
+                        const v2f p1 = (gq2 * (v2f{x.z, x.w} - vq2)) * v2f{y.z, y.w};
+                        acc += p0.x; acc += p0.y; acc += p1.x; acc += p1.y;
+                    });
+                } else {
+                    // some voltage is huge, infinite or NaN: absent edges are skipped explicitly -- the weights come from the
+                    // matrix again (cache resident), where an absent edge is the NaN sentinel
+#pragma unroll 1
+                    for (uint32_t g = 0; g < 16 && row0 + 4 * g < n_tot; ++g) {
+                        const v4f x = pre[g], y = units[(size_t)g * in.ld];
+                        const float e[4] = {x.x, x.y, x.z, x.w}, ww[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+                        for (uint32_t j = 0; j < 4; ++j) {
+                            const float p = (gq * (e[j] - vq)) * ww[j];
+                            acc += (ww[j] == ww[j]) ? p : 0.0f;
+                        }
+                    }
+                }
+                if (last_of_chunk) sh.pi[chunk][lane] = acc;
+                else sh.hand[chunk][lane] = acc;
+            }
+            __syncthreads();
+        }
+        lap(2);
+
+        // (3) wavefront 0: second level of the sum, the neuron update of these 64 columns, their granules
+        if (UPDATER) {
+            uint32_t spike = 0;
+            float v_new = 0.0f;
+            if (in_registers) {
+                const ResidentRunArgs &b = a;
+                float *vhist_row = b.up.vhist_row ? b.up.vhist_row + (size_t)s * b.vhist_stride : nullptr;
+                if (col) {
+                    float sum = 0.0f;
+                    for (uint32_t c = 0; c < n_chunks; ++c) sum += sh.pi[c][lane];
+                    const float i_in = sum / n_div;
+                    const float dv = (0.04f * (nv * nv) + 5.0f * nv + 140.0f - nw + i_in) * dt_cm;
+                    const float dw = (pa * (pb * nv - nw)) * dt_tau;
+                    v_new = nv + dv;
+                    float w_new = nw + dw;
+                    if (v_new >= pth) {
+                        spike = 1;
+                        v_new = pc;
+                        w_new += pd;
+                    }
+                    nv = v_new; nw = w_new;
+                    last_spike = spike;
+                    const uint32_t q = b.up.rows.global_of(ql);
+                    if (spike) {
+                        b.up.n.last_firing_time[q] = (int32_t)(b.up.clock + s);
+                        n_spikes += 1;
+                    }
+                    if (vhist_row) vhist_row[q] = v_new;
+                }
+            } else {
+                const ResidentRunArgs &b = a;
+                float *vhist_row = b.up.vhist_row ? b.up.vhist_row + (size_t)s * b.vhist_stride : nullptr;
+                if (col)
+                    spike = update_neuron_at<MODEL>(b.up, ql, LdsSums{sh.pi, nullptr, n_chunks, lane}, b.up.clock + s, vhist_row, &v_new);
+            }
+            if (a.up.spike_row) {
+                unsigned long long *spike_row = a.up.spike_row + (size_t)s * a.raster_stride;
+                const unsigned long long word = __ballot(spike != 0);
+                if (lane == 0) spike_row[(a.up.q0 + ql) >> 6] = word;
+            }
+            if (col && s + 1 < steps) {
+                unsigned long long *g = a.granules + (size_t)((s + 1) & 1u) * RUN_RESIDENT_MAX_NEURONS + in.q0 + ql;
+                const unsigned long long x = ((unsigned long long)(tag_base + s + 1) << 32) | __float_as_uint(v_new);
+                __hip_atomic_store(g, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            lap(3);
+        }
+    }
+
+    if (UPDATER) {
+        if (in_registers && col) {               // the state the registers held
+            const NeuronArrays &n = a.up.n;
+            const uint32_t q = a.up.rows.global_of(ql);
+            a.up.xout[n.xl.at(q, PLANE_V)] = nv;
+            reinterpret_cast<uint32_t *>(a.up.xout)[n.xl.at(q, PLANE_SPIKE)] = last_spike;
+            n.w_value[q] = nw;
+            if (a.up.spike_counts && n_spikes) a.up.spike_counts[q] += n_spikes;
+        }
+        if (a.timing && lane == 0)
+            for (int k = 0; k < 4; ++k) a.timing[blockIdx.x * 4 + k] = spent[k];
+    }
+}
+
+template <int MODEL, bool REGISTERS>
+__global__ __launch_bounds__(1024) void k_run_resident(const ResidentRunArgs args)
+{
+    __shared__ __attribute__((aligned(16))) ResidentRunShared sh;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (wave == 0) run_resident_steps<MODEL, true, REGISTERS>(args, sh, wave);
+    else run_resident_steps<MODEL, false, REGISTERS>(args, sh, wave);
+    // a poll that gave up ended the loop early everywhere in the workgroup
+    if (threadIdx.x == 0) {
+        bool failed = false;
+        for (int k = 0; k < 16; ++k) failed = failed || sh.ok[k] == 0u;
+        if (failed) __hip_atomic_store(args.failed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 } // namespace snn

@@ -209,9 +209,11 @@ __device__ __forceinline__ float gate_update(float state, float alpha, float bet
     return state + dt * (alpha_state - beta_state);
 }
 
-// One neuron's step (local column ql); returns its spike flag.
+// One neuron's step (local column ql) at network clock `clock`, its voltage also recorded in `vhist_row` (or null);
+// returns its spike flag (and, where asked for, the voltage it stored).
 template <int MODEL, class Sums>
-__device__ __forceinline__ uint32_t update_neuron(const UpdateArgs &a, uint32_t ql, const Sums &sums)
+__device__ __forceinline__ uint32_t update_neuron_at(const UpdateArgs &a, uint32_t ql, const Sums &sums, long long clock,
+                                                     float *vhist_row, float *v_stored = nullptr)
 {
     uint32_t spike = 0;
     {
@@ -423,11 +425,18 @@ __device__ __forceinline__ uint32_t update_neuron(const UpdateArgs &a, uint32_t 
             a.xout2[v_at] = v_new;
             reinterpret_cast<uint32_t *>(a.xout2)[s_at] = spike;
         }
-        if (spike) a.n.last_firing_time[q] = (int32_t)a.clock;   // neuron/mod.rs:964-966, 2555-2557
-        if (a.vhist_row) a.vhist_row[q] = v_new;
+        if (spike) a.n.last_firing_time[q] = (int32_t)clock;     // neuron/mod.rs:964-966, 2555-2557
+        if (vhist_row) vhist_row[q] = v_new;
         if (a.spike_counts && spike) a.spike_counts[q] += 1;
+        if (v_stored) *v_stored = v_new;
     }
     return spike;
+}
+
+template <int MODEL, class Sums>
+__device__ __forceinline__ uint32_t update_neuron(const UpdateArgs &a, uint32_t ql, const Sums &sums)
+{
+    return update_neuron_at<MODEL>(a, ql, sums, a.clock, a.vhist_row);
 }
 
 template <int MODEL>

@@ -43,6 +43,7 @@ int snn_network_create(int device, int neuron_model, int nt_kinetics, int recept
     if (const char *e = getenv("SNN_AMD_DEFER_RSTDP")) net->defer_rstdp = (e[0] != '0');
     if (const char *e = getenv("SNN_AMD_DEFER_STDP")) net->defer_stdp = (e[0] == '2') ? 2 : (e[0] != '0');
     if (const char *e = getenv("SNN_AMD_UNIFORM_PARAMS")) net->uniform_params = (e[0] != '0');
+    if (const char *e = getenv("SNN_AMD_PERSISTENT_RUN")) net->persistent_run = (e[0] != '0');
     if (const char *e = getenv("SNN_AMD_INPUT_SHAPE")) net->force_shape = (e[0] == '1') ? 1 : ((e[0] == '2') ? 2 : 0);
     net->model = neuron_model; net->nt_kind = nt_kinetics; net->rc_kind = receptor_kinetics;
     net->st_kind = spike_train_model;
@@ -69,6 +70,7 @@ int snn_network_destroy(snn_network_t *net)
     if (net->raster) (void)hipFree(net->raster);
     if (net->preset_times_dev) (void)hipFree(net->preset_times_dev);
     if (net->trace) (void)hipFree(net->trace);
+    if (net->run_failed) (void)hipHostFree(net->run_failed);
     for (float *b : net->whist) if (b) (void)hipFree(b);
     if (net->summ_avg) (void)hipFree(net->summ_avg);
     if (net->summ_eeg) (void)hipFree(net->summ_eeg);
@@ -843,12 +845,23 @@ int snn_run(snn_network_t *net, uint64_t iterations)
     if (!net->electrical && !net->chemical) return SNN_OK;           // neuron/mod.rs:1217, 2672
     HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
     TRY(begin_run(net, iterations));
-    for (uint64_t it = 0; it < iterations; ++it) {
+    uint64_t it = 0;
+    if (iterations >= 2 && run_resident_applies(net)) {
+        TRY(launch_run_resident(net, iterations));
+        it = iterations;
+    }
+    for (; it < iterations; ++it) {
         if (net->nn) TRY(step_begin(net));
         TRY(step_end(net));
         if (net->profile && (net->ev_used >= 8192 || net->ev_used_pl >= 8192)) TRY(collect_profile(net));
     }
-    return end_run(net, /*keep_stdp=*/true);
+    TRY(end_run(net, /*keep_stdp=*/true));
+    if (net->run_failed && *net->run_failed) {
+        *net->run_failed = 0u;
+        return fail(SNN_ERR_WAIT, "the workgroups of the one-launch run could not see each other (device shared with another "
+                                  "long-running kernel?); state is undefined -- set option persistent_run to 0");
+    }
+    return SNN_OK;
 }
 
 int snn_step_begin_local(snn_network_t *net)
@@ -1237,9 +1250,20 @@ int snn_set_option(snn_network_t *net, const char *name, int value)
     else if (n == "defer_rstdp") net->defer_rstdp = value != 0;
     else if (n == "defer_stdp") net->defer_stdp = (value == 2) ? 2 : (value != 0);
     else if (n == "uniform_params") { net->uniform_params = value != 0; net->uni_dirty = true; }
+    else if (n == "persistent_run") net->persistent_run = value != 0;
     else if (n == "input_shape") net->force_shape = (value == 1 || value == 2) ? value : 0;
     else return fail(SNN_ERR_BAD_ARG, "unknown option '" + n + "'");
     net->shadow_valid = false;
+    return SNN_OK;
+}
+
+int snn_get_stat(snn_network_t *net, const char *name, uint64_t *value)
+{
+    if (!net || !name || !value) return fail(SNN_ERR_BAD_ARG, "null argument");
+    const std::string n(name);
+    if (n == "persistent_run_launches") *value = net->stat_run_launches;
+    else if (n == "persistent_run_steps") *value = net->stat_run_steps;
+    else return fail(SNN_ERR_BAD_ARG, "unknown statistic '" + n + "'");
     return SNN_OK;
 }
 

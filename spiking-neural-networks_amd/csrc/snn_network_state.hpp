@@ -169,6 +169,14 @@ struct snn_network {
     UniformTable *uni_neuron = nullptr, *uni_cell = nullptr;
     bool uni_dirty = true;
     int uniform_params = 1;               // 0: always read the arrays (SNN_AMD_UNIFORM_PARAMS=0)
+    // many steps of a small lattice in one launch (k_run_resident): granule slots, the next free step tag, and a
+    // host-visible word the kernel sets when its workgroups could not see each other
+    int persistent_run = 1;               // 0: one launch per step (SNN_AMD_PERSISTENT_RUN=0)
+    unsigned long long *run_granules = nullptr;
+    uint32_t run_tag = 1;
+    uint32_t *run_failed = nullptr;       // hipHostMalloc
+    uint64_t stat_run_launches = 0, stat_run_steps = 0;
+    unsigned long long *run_timing = nullptr;   // SNN_AMD_RUN_TIMING=1: phase clocks of k_run_resident, printed per launch
     int force_shape = 0;                  // 1 | 2: streamed shape of the dense input pass (SNN_AMD_INPUT_SHAPE), 0: by size
     // deferred STDP (dense handles): the update of step t is applied by the input pass of step t + 1
     // 0 (default): the scatter kernels right after the step; 1: the update of step t rides on the input pass of step

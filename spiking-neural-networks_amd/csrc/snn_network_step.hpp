@@ -457,22 +457,26 @@ bool fused_step_applies(const snn_network *net)
 
 // Arguments of a one-launch step: S(t) is read from the current shadow of the exchange buffer, S(t+1) goes to the
 // exchange buffer and to the other shadow (flipped by the caller after the launch).
-int fused_step_args(snn_network *net, InputsArgs &a, UpdateArgs &u)
+// in_place (the many-steps launch): everything reads and writes the exchange buffer itself.
+int fused_step_args(snn_network *net, InputsArgs &a, UpdateArgs &u, bool in_place = false)
 {
     const size_t xelems = (size_t)NUM_PLANES * net->xl.stride;
-    if (!net->shadow[0]) {
+    if (in_place) {
+        net->shadow_valid = false;
+    } else if (!net->shadow[0]) {
         TRY(dev_alloc_t(net, &net->shadow[0], xelems));
         TRY(dev_alloc_t(net, &net->shadow[1], xelems));
         net->shadow_valid = false;
     }
-    if (!net->shadow_valid) {
+    if (!in_place && !net->shadow_valid) {
         // both shadows: entries the step never rewrites (absent transmitter types, padding) must agree everywhere
         for (int i = 0; i < 2; ++i)
             HIP_TRY(hipMemcpyAsync(net->shadow[i], net->xbuf, xelems * 4, hipMemcpyDeviceToDevice, net->stream),
                     SNN_ERR_BUFFER_WRITE);
         net->shadow_valid = true;
     }
-    float *cur = net->shadow[net->shadow_cur], *next = net->shadow[net->shadow_cur ^ 1];
+    float *cur = in_place ? net->xbuf : net->shadow[net->shadow_cur];
+    float *next = in_place ? nullptr : net->shadow[net->shadow_cur ^ 1];
     a = InputsArgs{};
     a.chunk_first = 0; a.hole_begin = net->n_chunks; a.hole_count = 0;
     a.W = net->W; a.ld = net->ld; a.n_loc = net->n_loc; a.q0 = net->q0; a.rows = net->rowmap; a.n_neurons = net->nn; a.n_tot = net->n_tot;
@@ -552,6 +556,76 @@ int launch_step_resident(snn_network *net)
     HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
     if (e1) HIP_TRY(hipEventRecord(e1, net->stream), SNN_ERR_QUEUE);
     net->shadow_cur ^= 1;
+    return SNN_OK;
+}
+
+// Small electrical-only lattices of neurons: ALL steps of a run call in one launch (k_run_resident) when nothing has to
+// happen between two steps on the host's side of the stream -- no cells, no weight updates, no per-step reductions, every
+// step recorded (or none), no per-launch profiling.
+bool run_resident_applies(const snn_network *net)
+{
+    return fused_step_possible(net) && net->persistent_run && net->nc == 0 && net->nn == net->n_tot && net->n_loc == net->nn &&
+           net->n_tot <= RUN_RESIDENT_MAX_NEURONS && net->electrical && !net->chemical && !net->any_plasticity &&
+           !net->any_modulation && !net->any_whist && !net->want_avg && !net->want_eeg && net->hist_every == 1 && !net->profile &&
+           net->model != SNN_MODEL_BCM_IZHIKEVICH && !net->local_inputs_done;
+}
+
+int launch_run_resident(snn_network *net, uint64_t iterations)
+{
+    if (!net->run_granules) {
+        TRY(dev_alloc_t(net, &net->run_granules, (size_t)2 * RUN_RESIDENT_MAX_NEURONS));
+        HIP_TRY(hipMemsetAsync(net->run_granules, 0, (size_t)2 * RUN_RESIDENT_MAX_NEURONS * 8, net->stream), SNN_ERR_BUFFER_WRITE);
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&net->run_failed), 4, hipHostMallocMapped), SNN_ERR_BUFFER_CREATE);
+        *net->run_failed = 0u;
+        net->run_tag = 1;
+    }
+    while (iterations) {
+        const uint32_t steps = (uint32_t)std::min<uint64_t>(iterations, 1u << 20);
+        if (net->run_tag > 0xFFFFFFFFu - steps - 2u) {           // tags would wrap: start over on clean slots
+            HIP_TRY(hipMemsetAsync(net->run_granules, 0, (size_t)2 * RUN_RESIDENT_MAX_NEURONS * 8, net->stream), SNN_ERR_BUFFER_WRITE);
+            net->run_tag = 1;
+        }
+        ResidentRunArgs r{};
+        TRY(fused_step_args(net, r.in, r.up, /*in_place=*/true));
+        r.steps = steps;
+        r.vhist_stride = net->n_pad;
+        r.raster_stride = net->n_pad / 64;
+        r.granules = net->run_granules;
+        r.tag_base = net->run_tag;
+        r.failed = net->run_failed;
+        if (!net->run_timing && getenv("SNN_AMD_RUN_TIMING")) TRY(dev_alloc_t(net, &net->run_timing, (size_t)16 * 4));
+        r.timing = net->run_timing;
+        hipLaunchKernelGGL(k_run_resident_seed, dim3((net->n_tot + 255) / 256), dim3(256), 0, net->stream, net->xbuf, net->xl,
+                           net->n_tot, net->run_granules, r.tag_base);
+        HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+        const dim3 grid((net->n_loc + 63) / 64), block(1024);
+#define SNN_RUN_RESIDENT(M) hipLaunchKernelGGL((k_run_resident<M, false>), grid, block, 0, net->stream, r)
+#if !SNN_HAVE_CUSTOM_MODEL
+        if (net->model == SNN_MODEL_IZHIKEVICH && !r.up.has_nt && !r.up.bcm)      // neuron state in registers for the whole run
+            hipLaunchKernelGGL((k_run_resident<0, true>), grid, block, 0, net->stream, r);
+        else
+            SNN_FOR_MODEL(SNN_RUN_RESIDENT);
+#else
+        (void)grid, (void)block;
+#endif
+#undef SNN_RUN_RESIDENT
+        HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+        if (net->run_timing) {          // debugging aid: workgroup 0's phases in shader clocks per step
+            unsigned long long t[64];
+            HIP_TRY(hipMemcpyAsync(t, net->run_timing, sizeof t, hipMemcpyDeviceToHost, net->stream), SNN_ERR_BUFFER_READ);
+            HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
+            for (unsigned b = 0; b < grid.x; b += (grid.x > 1 ? grid.x - 1 : 1))
+                fprintf(stderr, "k_run_resident workgroup %u: poll %.0f, barrier %.0f, turns %.0f, update+publish %.0f clocks/step (%u steps)\n",
+                        b, (double)t[b * 4] / steps, (double)t[b * 4 + 1] / steps, (double)t[b * 4 + 2] / steps, (double)t[b * 4 + 3] / steps, steps);
+        }
+        net->run_tag += steps;
+        net->stat_run_launches += 1;
+        net->stat_run_steps += steps;
+        net->clock += steps;
+        net->run_step_offset += steps;
+        if (recording(net)) { net->hist_steps += steps; net->hist_tick += steps; }
+        iterations -= steps;
+    }
     return SNN_OK;
 }
 

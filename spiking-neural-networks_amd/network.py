@@ -414,8 +414,14 @@ class DeviceNetwork:
         return out
 
     def set_option(self, name, value):
-        """tuning switches of include/snn_amd.h (fused_step, defer_rstdp, defer_stdp, uniform_params, input_shape)"""
+        """tuning switches of include/snn_amd.h (fused_step, defer_rstdp, defer_stdp, uniform_params, persistent_run, input_shape)"""
         self._check(self._L.snn_set_option(self._h, name.encode(), int(value)))
+
+    def stat(self, name):
+        """launch counters of include/snn_amd.h (persistent_run_launches, persistent_run_steps)"""
+        out = C.c_uint64(0)
+        self._check(self._L.snn_get_stat(self._h, name.encode(), C.byref(out)))
+        return int(out.value)
 
     # ---- measurement ----------------------------------------------------------------------
     def profile_enable(self, on=True):

@@ -1,0 +1,98 @@
+"""Many steps in ONE launch (k_run_resident: electrical-only lattices of <= 1024 neurons without plasticity, the shape of
+BASELINE configs[0]) against the one-launch-per-step form (option persistent_run 0) and the oracle: bit-identical
+voltages, rasters, state and spike totals, for ragged sizes, split run calls, every built-in model, sparse connectivity,
+and voltages that leave the range in which an absent edge may be summed as a zero product."""
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+import parity
+
+pytestmark = pytest.mark.gpu
+
+
+def build(model, rows, cols, seed, density=0.75):
+    net = parity.make_oracle(parity.Layout([(3, rows, cols)]), model=model, electrical=True, chemical=False)
+    n = net.n_neurons
+    lo, hi = {ob.IZHIKEVICH: (-65, 30), ob.LIF: (-80, -50), ob.HH: (-75, -40), ob.QIF: (-75, -56)}.get(model, (-70, -50))
+    net["current_voltage"] = ob.uniform_array(seed, n, lo, hi)
+    net["gap_conductance"] = ob.uniform_array(seed + 5, n, 2.0, 10.0) if model == ob.IZHIKEVICH else 3.0
+    if model in (ob.LIF, ob.QIF):
+        net["tref"] = ob.uniform_array(seed + 1, n, 0.3, 1.5)
+        net["tau_m"] = 10.0
+    rng = np.random.default_rng(seed)
+    net.fill_graph(seed + 3, 0.5, 1.5)
+    net["connections"][rng.random(net["connections"].shape) >= density] = 0
+    net["weights"][...] *= net["connections"]
+    net["do_plasticity"] = 0
+    return net
+
+
+def run_device(snn, net, calls, persistent):
+    dn = parity.device_from_oracle(snn, net)
+    dn.set_option("persistent_run", int(persistent))
+    dn.set_history(voltage=True, spikes=True)
+    dn.set_reduced_history(spike_counts=True)
+    for steps in calls:
+        dn.run(steps)
+    out = {"state": parity.pull_state(dn, net), "v": dn.voltage_history(3), "s": dn.spike_history(3),
+           "counts": dn.spike_counts(3), "launches": dn.stat("persistent_run_launches"), "steps": dn.stat("persistent_run_steps")}
+    dn.close()
+    return out
+
+
+def compare(snn, net, calls):
+    a = run_device(snn, net, calls, True)
+    b = run_device(snn, net, calls, False)
+    expected = [c for c in calls if c >= 2]
+    assert a["launches"] == len(expected) and a["steps"] == sum(expected) and b["launches"] == 0
+    total = sum(calls)
+    net.run(total, voltage_history=True, spike_history=True, spike_counts=True)
+    for out in (a, b):
+        parity.assert_state_equal(net, out["state"])
+        assert np.array_equal(out["s"], net.spike_history)
+        assert np.array_equal(parity.bits(out["v"]), parity.bits(net.voltage_history))
+        assert np.array_equal(out["counts"], net.spike_counts)
+    return a
+
+
+@pytest.mark.parametrize("rows,cols,seed", [(1, 1, 1), (5, 5, 2), (7, 9, 3), (8, 8, 4), (16, 17, 5), (30, 30, 6), (32, 32, 7), (31, 33, 8)])
+def test_izhikevich_sizes(snn, rows, cols, seed):
+    net = build(ob.IZHIKEVICH, rows, cols, seed)
+    a = compare(snn, net, [400, 1, 2, 197])
+    assert a["s"].sum() > 0
+
+
+@pytest.mark.parametrize("model", [ob.LIF, ob.HH, ob.QIF])
+def test_other_models(snn, model):
+    net = build(model, 18, 19, 11 + model)
+    a = compare(snn, net, [250, 250] if model != ob.HH else [500, 400])
+    assert a["s"].sum() > 0
+
+
+def test_sparse_connectivity_and_isolated_neurons(snn):
+    net = build(ob.IZHIKEVICH, 24, 24, 21, density=0.02)
+    net["connections"][:, 5] = 0
+    net["connections"][7, :] = 0
+    net["weights"][...] *= net["connections"]
+    a = compare(snn, net, [600])
+    assert a["s"].sum() > 0
+
+
+def test_voltages_outside_the_zero_product_range(snn):
+    """A neuron whose voltage is huge, infinite or NaN reaches only the neurons it has an edge to: steps holding such a
+    value take the path with explicit edge selects (an absent edge times an infinite term would be NaN, not zero)."""
+    def bad_net(bad):
+        net = build(ob.IZHIKEVICH, 12, 12, 31, density=0.03)
+        net["connections"][17, :] = 0
+        net["connections"][17, :10] = 1               # the bad neuron feeds ten others only
+        net["weights"][...] = net["weights"] * 0 + net["connections"]
+        v = net["current_voltage"].copy()
+        v[17] = bad
+        net["current_voltage"] = v
+        return net
+
+    for bad in (3.0e20, np.inf, np.nan):
+        a = compare(snn, bad_net(bad), [2])
+        assert np.isfinite(a["v"][-1]).sum() > 20         # neurons without an edge from it (or from those it reached)
+        compare(snn, bad_net(bad), [40])
