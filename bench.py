@@ -168,7 +168,7 @@ def build_config(args, snn_amd, synthetic, np, rank, world, local_rank):
             dn.set_reward_modulator(0, tau_c=0.05, tau_d=5.0, a_plus=0.002, a_minus=0.0015)
             dn.apply_reward(0.01)
             text = "reward-modulated (R-STDP, trace per synapse) " + text
-        # 32x32 takes the one-launch small-lattice step (inputs + update in k_step_resident)
+        # 32x32 takes the small-lattice forms: all steps of a run call in one launch (k_run_resident), else one launch per step
         return dn, n, text, ("k_step_resident<0,true,false>" if cfg == "c1" else "k_inputs_dense<true,false>")
     if cfg == "c3":
         rows = cols = 128
@@ -358,6 +358,9 @@ def main():
 
     if rank == 0:
         value = n * args.steps / elapsed
+        if not sharded and dn.stat("persistent_run_launches"):
+            # all steps of a run call in ONE launch (small electrical-only lattices): `launches` counts its steps
+            kernel_name = "k_run_resident<0,true> (many steps per launch; launches = steps)"
         bytes_per_launch = dn.input_kernel_bytes()
         avg_ms = kern_ms / max(1, launches)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if launches and avg_ms > 0 else 0.0

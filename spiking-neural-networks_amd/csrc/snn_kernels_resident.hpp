@@ -385,29 +385,41 @@ __device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, Res
                         if (UPDATER) wr[k] = sh.w0[4 * b + k][lane];
                     }
                 };
-                auto sweep = [&](auto group) {               // group(first row, 4 voltages, 4 weights)
+                if (plain) {
+                    // A lone wavefront per SIMD hides no latency by itself: the products of a batch are formed stage by stage
+                    // (8 independent packed instructions back to back, the scheduler held to that order), then its 16 adds --
+                    // measured 900-1000 clocks per 64 rows against 1600-1800 with product and add interleaved row by row
+                    // (profiles/experiments/chain_turn_probe.hip).
+                    const v2f vq2 = {vq, vq}, gq2 = {gq, gq};
                     v4f vp[4], wr[4], vp_next[4], wr_next[4];
                     load_batch(0, vp, wr);
 #pragma unroll
                     for (uint32_t b = 0; b < 4; ++b) {
                         if (b < 3) load_batch(b + 1, vp_next, wr_next);
+                        v2f d[8];
 #pragma unroll
-                        for (uint32_t k = 0; k < 4; ++k) {
+                        for (uint32_t k = 0; k < 4; ++k) {                   // gap_junction neuron/mod.rs:54-60 ...
+                            d[2 * k] = v2f{vp[k].x, vp[k].y} - vq2;
+                            d[2 * k + 1] = v2f{vp[k].z, vp[k].w} - vq2;
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (uint32_t k = 0; k < 8; ++k) d[k] = gq2 * d[k];
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (uint32_t k = 0; k < 4; ++k) {                   // ... times the weight
                             const uint32_t r = 16 * b + 4 * k;
                             if (!UPDATER) wr[k] = v4f{w[UPDATER ? 0 : r], w[UPDATER ? 0 : r + 1], w[UPDATER ? 0 : r + 2], w[UPDATER ? 0 : r + 3]};
-                            group(r, vp[k], wr[k]);
+                            d[2 * k] = d[2 * k] * v2f{wr[k].x, wr[k].y};
+                            d[2 * k + 1] = d[2 * k + 1] * v2f{wr[k].z, wr[k].w};
                         }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (uint32_t k = 0; k < 8; ++k) { acc += d[k].x; acc += d[k].y; }
+                        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (uint32_t k = 0; k < 4; ++k) { vp[k] = vp_next[k]; wr[k] = wr_next[k]; }
                     }
-                };
-                if (plain) {
-                    const v2f vq2 = {vq, vq}, gq2 = {gq, gq};
-                    sweep([&](uint32_t, const v4f &x, const v4f &y) {
-                        const v2f p0 = (gq2 * (v2f{x.x, x.y} - vq2)) * v2f{y.x, y.y};   // gap_junction neuron/mod.rs:54-60, times the weight
-                        const v2f p1 = (gq2 * (v2f{x.z, x.w} - vq2)) * v2f{y.z, y.w};
-                        acc += p0.x; acc += p0.y; acc += p1.x; acc += p1.y;
-                    });
                 } else {
                     // some voltage is huge, infinite or NaN: absent edges are skipped explicitly -- the weights come from the
                     // matrix again (cache resident), where an absent edge is the NaN sentinel

@@ -561,12 +561,12 @@ int launch_step_resident(snn_network *net)
 
 // Small electrical-only lattices of neurons: ALL steps of a run call in one launch (k_run_resident) when nothing has to
 // happen between two steps on the host's side of the stream -- no cells, no weight updates, no per-step reductions, every
-// step recorded (or none), no per-launch profiling.
+// step recorded (or none).
 bool run_resident_applies(const snn_network *net)
 {
     return fused_step_possible(net) && net->persistent_run && net->nc == 0 && net->nn == net->n_tot && net->n_loc == net->nn &&
            net->n_tot <= RUN_RESIDENT_MAX_NEURONS && net->electrical && !net->chemical && !net->any_plasticity &&
-           !net->any_modulation && !net->any_whist && !net->want_avg && !net->want_eeg && net->hist_every == 1 && !net->profile &&
+           !net->any_modulation && !net->any_whist && !net->want_avg && !net->want_eeg && net->hist_every == 1 &&
            net->model != SNN_MODEL_BCM_IZHIKEVICH && !net->local_inputs_done;
 }
 
@@ -598,6 +598,10 @@ int launch_run_resident(snn_network *net, uint64_t iterations)
         hipLaunchKernelGGL(k_run_resident_seed, dim3((net->n_tot + 255) / 256), dim3(256), 0, net->stream, net->xbuf, net->xl,
                            net->n_tot, net->run_granules, r.tag_base);
         HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+        // profiling: one event pair around the launch, counted as `steps` passes over the graph
+        hipEvent_t e1 = nullptr;
+        TRY(profile_open(net, &e1));
+        if (e1) net->ev_counts[net->ev_used - 1] = (int)steps;
         const dim3 grid((net->n_loc + 63) / 64), block(1024);
 #define SNN_RUN_RESIDENT(M) hipLaunchKernelGGL((k_run_resident<M, false>), grid, block, 0, net->stream, r)
 #if !SNN_HAVE_CUSTOM_MODEL
@@ -610,6 +614,7 @@ int launch_run_resident(snn_network *net, uint64_t iterations)
 #endif
 #undef SNN_RUN_RESIDENT
         HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+        if (e1) HIP_TRY(hipEventRecord(e1, net->stream), SNN_ERR_QUEUE);
         if (net->run_timing) {          // debugging aid: workgroup 0's phases in shader clocks per step
             unsigned long long t[64];
             HIP_TRY(hipMemcpyAsync(t, net->run_timing, sizeof t, hipMemcpyDeviceToHost, net->stream), SNN_ERR_BUFFER_READ);
