@@ -1,0 +1,9 @@
+set -u
+OUT=$PWD/gpurun_out/r02e; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp && cd "$OLDPWD"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_c1 -- python3 bench.py --config c1 --steps 2000 --warmup 50 --repeats 2 --no-cpu-baseline --no-kernel-events > $OUT/c1_bench_under_rocprof.json 2> $OUT/c1.err
+find $OUT/prof_c1 -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/c1_kernel_stats.csv
+tail -1 $OUT/c1_bench_under_rocprof.json > $OUT/x && mv $OUT/x $OUT/c1_bench_under_rocprof.json
+rm -rf $OUT/prof_c1
+head -5 $OUT/c1_kernel_stats.csv
+python bench.py --config c1 > $OUT/c1_bench_default.json 2>/dev/null; tail -1 $OUT/c1_bench_default.json | cut -c1-300
