@@ -39,21 +39,38 @@ struct UpdateArgs {
     int model_is_custom;        // the generated neuron model: it uses the library's generated receptor set, if any
 };
 
-// Second level of the canonical sum: chunk partials added in ascending chunk order from 0.0f.  The loads of
-// a batch are issued together (the adds stay strictly sequential), so a thread keeps 16 reads in flight.
+// Second level of the canonical sum: chunk partials added in ascending chunk order from 0.0f.  The adds stay strictly
+// sequential; the loads do not have to: a batch of 32 is issued together and the next batch before this one is summed, so a
+// thread keeps up to 64 reads in flight (one wavefront per CU: the kernel is a chain of memory round trips -- with batches
+// of 16 and no overlap C3's 64 chunks x 2 planes were 8 round trips, now 2).
 __device__ __forceinline__ float combine_partials(const float *p, uint32_t n_chunks, size_t ld)
 {
-    constexpr uint32_t B = 16;
+    constexpr uint32_t B = 32;
     float s = 0.0f;
-    uint32_t c = 0;
-    for (; c + B <= n_chunks; c += B) {
-        float v[B];
+    if (n_chunks == 0) return s;
+    const uint32_t last = n_chunks - 1;
+    float cur[B], nxt[B];
 #pragma unroll
-        for (uint32_t u = 0; u < B; ++u) v[u] = p[(size_t)(c + u) * ld];
+    for (uint32_t u = 0; u < B; ++u) cur[u] = p[(size_t)min(u, last) * ld];        // clamped: the tail is not added
+    for (uint32_t c = 0; c < n_chunks; c += B) {
+        const bool more = c + B < n_chunks;
+        if (more) {
 #pragma unroll
-        for (uint32_t u = 0; u < B; ++u) s += v[u];
+            for (uint32_t u = 0; u < B; ++u) nxt[u] = p[(size_t)min(c + B + u, last) * ld];
+        }
+        if (c + B <= n_chunks) {
+#pragma unroll
+            for (uint32_t u = 0; u < B; ++u) s += cur[u];
+        } else {
+#pragma unroll
+            for (uint32_t u = 0; u < B; ++u)
+                if (c + u < n_chunks) s += cur[u];
+        }
+        if (more) {
+#pragma unroll
+            for (uint32_t u = 0; u < B; ++u) cur[u] = nxt[u];
+        }
     }
-    for (; c < n_chunks; ++c) s += p[(size_t)c * ld];
     return s;
 }
 
@@ -442,7 +459,7 @@ __device__ __forceinline__ uint32_t update_neuron(const UpdateArgs &a, uint32_t 
 template <int MODEL>
 __global__ __launch_bounds__(256) void k_update(const UpdateArgs a)
 {
-    const uint32_t ql = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t ql = blockIdx.x * blockDim.x + threadIdx.x;           // blockDim.x = 64 or 256
     const uint32_t spike = (ql < a.n_loc && a.rows.active(ql, a.n_loc)) ? update_neuron<MODEL>(a, ql, GlobalSums{a, ql}) : 0u;
 
     // spike raster: one 64-bit ballot word per wavefront = one aligned 64-block of the global index space (shard

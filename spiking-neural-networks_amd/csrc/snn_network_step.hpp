@@ -240,19 +240,22 @@ int launch_update(snn_network *net)
     a.bcm = net->model == SNN_MODEL_BCM_IZHIKEVICH;
     a.model_is_custom = net->model == SNN_MODEL_CUSTOM;
     net->shadow_valid = false;            // the exchange buffer moves on without the shadows
-    dim3 grid((net->ld + 255) / 256);
+    // one wavefront per workgroup while that still leaves CUs idle: the kernel is a chain of memory round trips per wavefront,
+    // and four wavefronts on one CU share its memory queue (C3: 64 workgroups of 256 threads used 64 of the 256 CUs)
+    const uint32_t ub = (net->ld + 255) / 256 < 256 ? 64u : 256u;
+    dim3 grid((net->ld + ub - 1) / ub);
     switch (net->model) {
-    case SNN_MODEL_LIF: hipLaunchKernelGGL((k_update<1>), grid, dim3(256), 0, net->stream, a); break;
-    case SNN_MODEL_HODGKIN_HUXLEY: hipLaunchKernelGGL((k_update<2>), grid, dim3(256), 0, net->stream, a); break;
-    case SNN_MODEL_QUADRATIC_INTEGRATE_AND_FIRE: hipLaunchKernelGGL((k_update<3>), grid, dim3(256), 0, net->stream, a); break;
-    case SNN_MODEL_SIMPLE_LIF: hipLaunchKernelGGL((k_update<4>), grid, dim3(256), 0, net->stream, a); break;
-    case SNN_MODEL_ADAPTIVE_LIF: hipLaunchKernelGGL((k_update<5>), grid, dim3(256), 0, net->stream, a); break;
-    case SNN_MODEL_ADAPTIVE_EXP_LIF: hipLaunchKernelGGL((k_update<6>), grid, dim3(256), 0, net->stream, a); break;
-    case SNN_MODEL_LEAKY_IZHIKEVICH: hipLaunchKernelGGL((k_update<7>), grid, dim3(256), 0, net->stream, a); break;
+    case SNN_MODEL_LIF: hipLaunchKernelGGL((k_update<1>), grid, dim3(ub), 0, net->stream, a); break;
+    case SNN_MODEL_HODGKIN_HUXLEY: hipLaunchKernelGGL((k_update<2>), grid, dim3(ub), 0, net->stream, a); break;
+    case SNN_MODEL_QUADRATIC_INTEGRATE_AND_FIRE: hipLaunchKernelGGL((k_update<3>), grid, dim3(ub), 0, net->stream, a); break;
+    case SNN_MODEL_SIMPLE_LIF: hipLaunchKernelGGL((k_update<4>), grid, dim3(ub), 0, net->stream, a); break;
+    case SNN_MODEL_ADAPTIVE_LIF: hipLaunchKernelGGL((k_update<5>), grid, dim3(ub), 0, net->stream, a); break;
+    case SNN_MODEL_ADAPTIVE_EXP_LIF: hipLaunchKernelGGL((k_update<6>), grid, dim3(ub), 0, net->stream, a); break;
+    case SNN_MODEL_LEAKY_IZHIKEVICH: hipLaunchKernelGGL((k_update<7>), grid, dim3(ub), 0, net->stream, a); break;
 #if SNN_HAVE_CUSTOM_NEURON
-    case SNN_MODEL_CUSTOM: hipLaunchKernelGGL((k_update<CUSTOM_MODEL>), grid, dim3(256), 0, net->stream, a); break;
+    case SNN_MODEL_CUSTOM: hipLaunchKernelGGL((k_update<CUSTOM_MODEL>), grid, dim3(ub), 0, net->stream, a); break;
 #endif
-    default: hipLaunchKernelGGL((k_update<0>), grid, dim3(256), 0, net->stream, a); break;
+    default: hipLaunchKernelGGL((k_update<0>), grid, dim3(ub), 0, net->stream, a); break;
     }
     HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
     return SNN_OK;
