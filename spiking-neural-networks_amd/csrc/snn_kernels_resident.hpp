@@ -504,6 +504,23 @@ __device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, Res
     }
 }
 
+// Can `gridDim.x` workgroups of k_run_resident's shape (1024 threads, its LDS) run at the same time on this device right now?
+// Every workgroup checks in and waits (bounded, a few tens of microseconds) for all the others.  The host asks once per handle
+// and grid size before it relies on the one-launch run; a "no" (CUs masked off, the device shared) keeps one launch per step.
+__global__ __launch_bounds__(1024) void k_run_resident_probe(uint32_t *counter, uint32_t *not_resident)
+{
+    __shared__ __attribute__((aligned(16))) ResidentRunShared footprint;
+    if (threadIdx.x == 0) {
+        footprint.ok[0] = 1u;
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t spins = 0;
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x && ++spins < (1u << 16)) {}
+        if (spins >= (1u << 16)) __hip_atomic_store(not_resident, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __syncthreads();
+    if (footprint.ok[0] == 0u) *counter = 0u;   // never: keeps the LDS footprint alive
+}
+
 template <int MODEL, bool REGISTERS>
 __global__ __launch_bounds__(1024) void k_run_resident(const ResidentRunArgs args)
 {

@@ -848,7 +848,7 @@ int snn_run(snn_network_t *net, uint64_t iterations)
     uint64_t it = 0;
     if (iterations >= 2 && run_resident_applies(net)) {
         TRY(launch_run_resident(net, iterations));
-        it = iterations;
+        if (net->persistent_run) it = iterations;     // else: the co-residency probe said no, nothing was stepped
     }
     for (; it < iterations; ++it) {
         if (net->nn) TRY(step_begin(net));
@@ -856,8 +856,8 @@ int snn_run(snn_network_t *net, uint64_t iterations)
         if (net->profile && (net->ev_used >= 8192 || net->ev_used_pl >= 8192)) TRY(collect_profile(net));
     }
     TRY(end_run(net, /*keep_stdp=*/true));
-    if (net->run_failed && *net->run_failed) {
-        *net->run_failed = 0u;
+    if (net->run_failed && net->run_failed[0]) {
+        net->run_failed[0] = 0u;
         return fail(SNN_ERR_WAIT, "the workgroups of the one-launch run could not see each other (device shared with another "
                                   "long-running kernel?); state is undefined -- set option persistent_run to 0");
     }

@@ -174,7 +174,8 @@ struct snn_network {
     int persistent_run = 1;               // 0: one launch per step (SNN_AMD_PERSISTENT_RUN=0)
     unsigned long long *run_granules = nullptr;
     uint32_t run_tag = 1;
-    uint32_t *run_failed = nullptr;       // hipHostMalloc
+    uint32_t *run_failed = nullptr;       // hipHostMalloc: [0] a run gave up, [1] the co-residency probe said no
+    uint32_t run_probed_grid = 0;         // grid size the probe last vouched for
     uint64_t stat_run_launches = 0, stat_run_steps = 0;
     unsigned long long *run_timing = nullptr;   // SNN_AMD_RUN_TIMING=1: phase clocks of k_run_resident, printed per launch
     int force_shape = 0;                  // 1 | 2: streamed shape of the dense input pass (SNN_AMD_INPUT_SHAPE), 0: by size

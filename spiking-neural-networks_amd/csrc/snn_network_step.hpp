@@ -578,9 +578,26 @@ int launch_run_resident(snn_network *net, uint64_t iterations)
     if (!net->run_granules) {
         TRY(dev_alloc_t(net, &net->run_granules, (size_t)2 * RUN_RESIDENT_MAX_NEURONS));
         HIP_TRY(hipMemsetAsync(net->run_granules, 0, (size_t)2 * RUN_RESIDENT_MAX_NEURONS * 8, net->stream), SNN_ERR_BUFFER_WRITE);
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&net->run_failed), 4, hipHostMallocMapped), SNN_ERR_BUFFER_CREATE);
-        *net->run_failed = 0u;
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&net->run_failed), 8, hipHostMallocMapped), SNN_ERR_BUFFER_CREATE);
+        net->run_failed[0] = net->run_failed[1] = 0u;
         net->run_tag = 1;
+    }
+    const uint32_t n_groups = (net->n_loc + 63) / 64;
+    if (net->run_probed_grid != n_groups) {
+        // once per handle and grid size: can that many workgroups of this shape be resident together?  (the granule words
+        // double as the probe's counter: they are cleared again before any run uses them)
+        uint32_t *counter = reinterpret_cast<uint32_t *>(net->run_granules);
+        HIP_TRY(hipMemsetAsync(counter, 0, 8, net->stream), SNN_ERR_BUFFER_WRITE);
+        hipLaunchKernelGGL(k_run_resident_probe, dim3(n_groups), dim3(1024), 0, net->stream, counter, net->run_failed + 1);
+        HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+        HIP_TRY(hipMemsetAsync(counter, 0, 8, net->stream), SNN_ERR_BUFFER_WRITE);
+        HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
+        if (net->run_failed[1]) {
+            net->run_failed[1] = 0u;
+            net->persistent_run = 0;                 // one launch per step for this handle from now on
+            return SNN_OK;
+        }
+        net->run_probed_grid = n_groups;
     }
     while (iterations) {
         const uint32_t steps = (uint32_t)std::min<uint64_t>(iterations, 1u << 20);
