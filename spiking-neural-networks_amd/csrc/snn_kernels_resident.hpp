@@ -234,7 +234,17 @@ __global__ __launch_bounds__(64 * RESIDENT_MAX_CHUNKS) void k_step_resident(cons
 //     (the sum never holds -0, see above); a step in which some voltage is not a small finite number takes the path with
 //     explicit selects instead (workgroup-uniform).
 // Arithmetic, order of operations and the update code are those of k_step_resident / k_inputs_dense + k_update.
-constexpr uint32_t RUN_RESIDENT_MAX_NEURONS = 1024;
+//
+// Lattices of 1025 .. 4096 neurons (33 x 33 .. 64 x 64) take R = 2 .. 4 ROW GROUPS of 1024 rows per column tile: workgroup
+// (tile, group) holds the 64 x 1024 slab of its group and sums the group's four chunks; the groups other than 0 publish
+// their chunk sums as granules, group 0 collects them (one wavefront per remote chunk), adds all chunk sums in ascending
+// order and updates.  A workgroup polls the 1024 voltages of its own rows and the 64 of its columns.  64 x 64 fills the
+// device: 64 tiles x 4 groups = 256 workgroups of 1024 threads, one per CU.
+constexpr uint32_t RUN_RESIDENT_GROUP_ROWS = 1024;             // rows (and threads) of a workgroup
+constexpr uint32_t RUN_RESIDENT_MAX_GROUPS = 4;
+constexpr uint32_t RUN_RESIDENT_MAX_NEURONS = RUN_RESIDENT_GROUP_ROWS * RUN_RESIDENT_MAX_GROUPS;
+constexpr uint32_t RUN_RESIDENT_MAX_TILES = RUN_RESIDENT_MAX_NEURONS / 64;
+constexpr uint32_t RUN_RESIDENT_MAX_ALL_CHUNKS = RUN_RESIDENT_MAX_NEURONS / CHUNK;
 constexpr uint32_t RUN_RESIDENT_SPIN_LIMIT = 1u << 24;
 
 struct ResidentRunArgs {
@@ -243,6 +253,8 @@ struct ResidentRunArgs {
     uint32_t steps;
     uint32_t vhist_stride, raster_stride;     // elements between consecutive history rows
     unsigned long long *granules;   // [2][RUN_RESIDENT_MAX_NEURONS] {voltage bits, tag << 32}
+    unsigned long long *partials;   // [2][tiles][groups - 1][4 chunks][64] {chunk sum bits, tag << 32}; groups > 1 only
+    uint32_t n_groups;              // row groups per column tile; gridDim.x = tiles * n_groups
     uint32_t tag_base;              // tag of the state after step s (1-based) = tag_base + s
     uint32_t *failed;               // host-visible word, set when a poll gave up (workgroups not co-resident)
     unsigned long long *timing;     // null, or [gridDim.x][4] shader-clock totals of workgroup phases (SNN_AMD_RUN_TIMING=1)
@@ -258,29 +270,35 @@ __global__ __launch_bounds__(256) void k_run_resident_seed(const float *xbuf, XL
 }
 
 struct ResidentRunShared {
-    float v[RUN_RESIDENT_MAX_NEURONS];           // S(t): every neuron's voltage
+    float v[RUN_RESIDENT_GROUP_ROWS];            // S(t): the voltages of this workgroup's rows
+    float vcol[64];                              // ... and of its columns
     float hand[RESIDENT_MAX_CHUNKS][64];         // running sum of a chunk, from one wavefront's turn to the next
-    float pi[RESIDENT_MAX_CHUNKS][64];           // finished chunk sums
-    v4f w0[16][64];                              // the updating wavefront's weights (its registers belong to the update)
+    float pi[RUN_RESIDENT_MAX_ALL_CHUNKS][64];   // finished chunk sums: own group's at 4 * group .., group 0 also the collected ones
+    v4f w0[16][64];                              // wavefront 0's weights (its registers belong to the update)
     uint32_t ok[16], plain[16];                  // per wavefront: all its granules arrived / all its values small and finite
+    uint32_t gave_up;                            // sticky: some poll of chunk sums gave up
 };
 
 // The step loop of one wavefront.  UPDATER = wavefront 0, which also owns the neuron update of the workgroup's 64 columns: it
 // keeps its weights in LDS and, for Izhikevich neurons without transmitters, the neurons' state in registers for the whole
 // run (same expressions as update_neuron, integrate_and_fire/mod.rs:217-255); the other wavefronts keep 64 weights per lane
-// in registers.  Every wavefront passes the same five workgroup barriers per step.
+// in registers.  Every wavefront of a workgroup passes the same workgroup barriers per step (five; group 0 of a multi-group tile one more).
 template <int MODEL, bool UPDATER, bool REGISTERS>
 __device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, ResidentRunShared &sh, const uint32_t wave)
 {
     const InputsArgs &in = a.in;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
-    const uint32_t chunk = wave >> 2;
-    const uint32_t turn = ((wave & 3u) - chunk) & 3u;            // which quarter of the chunk, and when
-    const uint32_t row0 = chunk * CHUNK + turn * 64u;
+    const uint32_t n_groups = a.n_groups, tile = blockIdx.x / n_groups, group = blockIdx.x % n_groups;
+    const uint32_t n_tiles = gridDim.x / n_groups;
+    const uint32_t chunk_local = wave >> 2, chunk = 4u * group + chunk_local;
+    const uint32_t turn = ((wave & 3u) - chunk_local) & 3u;      // which quarter of the chunk, and when
+    const uint32_t row0 = chunk * CHUNK + turn * 64u, group_row0 = group * RUN_RESIDENT_GROUP_ROWS;
     const uint32_t n_tot = in.n_tot, steps = a.steps, tag_base = a.tag_base, n_chunks = in.n_chunks;
     const bool rows_live = row0 < n_tot;
     const bool last_of_chunk = turn == 3u || row0 + 64u >= n_tot;
-    const uint32_t ql = blockIdx.x * 64u + lane;
+    const bool updates = group == 0u;                            // this workgroup's wavefront 0 updates the tile's neurons
+    const bool cols_in_rows = (tile * 64u) / RUN_RESIDENT_GROUP_ROWS == group;   // its columns are among its rows: no second poll
+    const uint32_t ql = tile * 64u + lane;
     const bool col = ql < in.n_loc;
     const float gq = col ? uload(in.uni, NP_GAP, in.gap_conductance, in.q0 + ql) : 0.0f;
     const bool gq_small = fabsf(gq) <= 1e15f;
@@ -311,7 +329,7 @@ __device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, Res
     static_assert(!REGISTERS || MODEL == 0, "the register-resident update is the Izhikevich one");
     float nv = 0.0f, nw = 0.0f, n_div = 1.0f, dt_cm = 0.0f, dt_tau = 0.0f, pa = 0.0f, pb = 0.0f, pc = 0.0f, pd = 0.0f, pth = 0.0f;
     uint32_t n_spikes = 0, last_spike = 0;
-    if (in_registers && col) {
+    if (in_registers && updates && col) {
         const NeuronArrays &n = a.up.n;
         const uint32_t q = a.up.rows.global_of(ql);
         nv = n.xbuf[n.xl.at(q, PLANE_V)];
@@ -341,40 +359,43 @@ __device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, Res
     for (uint32_t s = 0; s < steps; ++s) {
         // (1) S(t): every neuron's voltage, one granule per thread (those of the first step come from k_run_resident_seed:
         // the exchange buffer itself is updated in place by workgroups that are already a step ahead)
-        float v = 0.0f;
-        bool arrived = true;
-        if (tid < n_tot) {
-            const unsigned long long *g = granules + (size_t)(s & 1u) * RUN_RESIDENT_MAX_NEURONS + tid;
-            const uint32_t tag = tag_base + s;
+        const unsigned long long *slot = granules + (size_t)(s & 1u) * RUN_RESIDENT_MAX_NEURONS;
+        const uint32_t tag = tag_base + s;
+        auto poll = [&](const unsigned long long *g, bool &arrived) {
             unsigned long long x;
             uint32_t spins = 0;
             do {
                 x = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } while ((uint32_t)(x >> 32) != tag && ++spins < RUN_RESIDENT_SPIN_LIMIT);
-            arrived = (uint32_t)(x >> 32) == tag;
-            v = __uint_as_float((uint32_t)x);
-        }
+            arrived = arrived && (uint32_t)(x >> 32) == tag;
+            return __uint_as_float((uint32_t)x);
+        };
+        float v = 0.0f, v_col = 0.0f;
+        bool arrived = true;
+        if (group_row0 + tid < n_tot) v = poll(slot + group_row0 + tid, arrived);
+        if (!cols_in_rows && wave == 1 && col) v_col = poll(slot + in.q0 + ql, arrived);   // the columns' voltages, by one wavefront
         lap(0);
         sh.v[tid] = v;
-        const bool all_arrived = __all(arrived), all_plain = __all(fabsf(v) <= 1e15f && gq_small);
+        if (!cols_in_rows && wave == 1) sh.vcol[lane] = v_col;
+        const bool all_arrived = __all(arrived), all_plain = __all(fabsf(v) <= 1e15f && fabsf(v_col) <= 1e15f && gq_small);
         if (lane == 0) { sh.ok[wave] = all_arrived; sh.plain[wave] = all_plain; }
         __syncthreads();
         const uint32_t flag_ok = sh.ok[lane & 15u], flag_plain = sh.plain[lane & 15u];
-        if (!__all(flag_ok != 0)) break;                         // workgroup-uniform: some poll gave up
+        if (!__all(flag_ok != 0) || *const_cast<volatile uint32_t *>(&sh.gave_up)) break;   // workgroup-uniform: some poll gave up
         const bool plain = __all(flag_plain != 0);
         lap(1);
 
         // (2) the canonical chunk sums, the wavefronts of a chunk in turn
-        const float vq = sh.v[ql & (RUN_RESIDENT_MAX_NEURONS - 1u)];
+        const float vq = cols_in_rows ? sh.v[(ql - group_row0) & (RUN_RESIDENT_GROUP_ROWS - 1u)] : sh.vcol[lane];
 #pragma unroll 1
         for (uint32_t t = 0; t < 4; ++t) {
             if (t == turn && rows_live) {
-                float acc = (t != 0) ? sh.hand[chunk][lane] : 0.0f;
+                float acc = (t != 0) ? sh.hand[chunk_local][lane] : 0.0f;
                 // wave-uniform address = LDS broadcast; the offset is laundered through a vector register so that the values
                 // stay in vector registers (as scalars every one of them costs a v_readlane plus its wait states)
                 uint32_t zero;
                 asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
-                const v4f *pre = reinterpret_cast<const v4f *>(sh.v + row0 + zero);
+                const v4f *pre = reinterpret_cast<const v4f *>(sh.v + (row0 - group_row0) + zero);
                 // 16 rows per batch: the batch's LDS reads (4 x 16 B of voltages, for the updater 4 x 16 B of weights too) are
                 // issued together and the next batch's before this one is summed -- one read at a time, each waited for,
                 // costs an LDS round trip per 4 rows
@@ -435,14 +456,41 @@ __device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, Res
                     }
                 }
                 if (last_of_chunk) sh.pi[chunk][lane] = acc;
-                else sh.hand[chunk][lane] = acc;
+                else sh.hand[chunk_local][lane] = acc;
             }
             __syncthreads();
         }
+        // (2b) several row groups per tile: the groups other than 0 publish their chunk sums, group 0 collects them -- wavefront
+        // 1 + j takes remote chunk j -- behind one more barrier of its own
+        if (n_groups > 1u) {
+            const uint32_t ptag = tag_base + s + 1u;
+            unsigned long long *pslot = a.partials + ((size_t)(s & 1u) * n_tiles + tile) * (RUN_RESIDENT_MAX_GROUPS - 1u) * 256u;
+            if (!updates) {
+                if (UPDATER) {
+#pragma unroll 1
+                    for (uint32_t c = 0; c < 4u && 4u * group + c < n_chunks; ++c) {
+                        const unsigned long long x = ((unsigned long long)ptag << 32) | __float_as_uint(sh.pi[4u * group + c][lane]);
+                        __hip_atomic_store(pslot + (group - 1u) * 256u + c * 64u + lane, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            } else {
+                const uint32_t j = wave - 1u;                      // remote chunk: group 1 + j / 4, its chunk j % 4
+                if (wave >= 1u && j < 4u * (n_groups - 1u) && 4u + j < n_chunks) {
+                    unsigned long long x;
+                    uint32_t spins = 0;
+                    do {
+                        x = __hip_atomic_load(pslot + j * 64u + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } while ((uint32_t)(x >> 32) != ptag && ++spins < RUN_RESIDENT_SPIN_LIMIT);
+                    if ((uint32_t)(x >> 32) != ptag) sh.gave_up = 1u;
+                    sh.pi[4u + j][lane] = __uint_as_float((uint32_t)x);
+                }
+                __syncthreads();
+            }
+        }
         lap(2);
 
-        // (3) wavefront 0: second level of the sum, the neuron update of these 64 columns, their granules
-        if (UPDATER) {
+        // (3) wavefront 0 of group 0: second level of the sum, the neuron update of these 64 columns, their granules
+        if (UPDATER && updates) {
             uint32_t spike = 0;
             float v_new = 0.0f;
             if (in_registers) {
@@ -491,7 +539,7 @@ __device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, Res
     }
 
     if (UPDATER) {
-        if (in_registers && col) {               // the state the registers held
+        if (in_registers && updates && col) {    // the state the registers held
             const NeuronArrays &n = a.up.n;
             const uint32_t q = a.up.rows.global_of(ql);
             a.up.xout[n.xl.at(q, PLANE_V)] = nv;
@@ -526,12 +574,14 @@ __global__ __launch_bounds__(1024) void k_run_resident(const ResidentRunArgs arg
 {
     __shared__ __attribute__((aligned(16))) ResidentRunShared sh;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (threadIdx.x == 0) sh.gave_up = 0u;                       // ordered before its first reader by the first step's barrier
     if (wave == 0) run_resident_steps<MODEL, true, REGISTERS>(args, sh, wave);
     else run_resident_steps<MODEL, false, REGISTERS>(args, sh, wave);
     // a poll that gave up ended the loop early everywhere in the workgroup
     if (threadIdx.x == 0) {
         bool failed = false;
         for (int k = 0; k < 16; ++k) failed = failed || sh.ok[k] == 0u;
+        failed = failed || sh.gave_up != 0u;
         if (failed) __hip_atomic_store(args.failed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }

@@ -173,6 +173,7 @@ struct snn_network {
     // host-visible word the kernel sets when its workgroups could not see each other
     int persistent_run = 1;               // 0: one launch per step (SNN_AMD_PERSISTENT_RUN=0)
     unsigned long long *run_granules = nullptr;
+    unsigned long long *run_partials = nullptr;
     uint32_t run_tag = 1;
     uint32_t *run_failed = nullptr;       // hipHostMalloc: [0] a run gave up, [1] the co-residency probe said no
     uint32_t run_probed_grid = 0;         // grid size the probe last vouched for

@@ -567,22 +567,30 @@ int launch_step_resident(snn_network *net)
 // step recorded (or none).
 bool run_resident_applies(const snn_network *net)
 {
-    return fused_step_possible(net) && net->persistent_run && net->nc == 0 && net->nn == net->n_tot && net->n_loc == net->nn &&
+    return !SNN_HAVE_CUSTOM_MODEL && net->fused_step && !net->csr && !net->sharded && !net->drive_threshold && net->n_loc &&
+           net->persistent_run && net->nc == 0 && net->nn == net->n_tot && net->n_loc == net->nn &&
            net->n_tot <= RUN_RESIDENT_MAX_NEURONS && net->electrical && !net->chemical && !net->any_plasticity &&
            !net->any_modulation && !net->any_whist && !net->want_avg && !net->want_eeg && net->hist_every == 1 &&
            net->model != SNN_MODEL_BCM_IZHIKEVICH && !net->local_inputs_done;
 }
+
+// chunk sums travelling between the row groups of a tile: [2][tiles][groups - 1][4 chunks][64] granules
+constexpr size_t RUN_PARTIAL_WORDS = (size_t)2 * RUN_RESIDENT_MAX_TILES * (RUN_RESIDENT_MAX_GROUPS - 1) * 256;
 
 int launch_run_resident(snn_network *net, uint64_t iterations)
 {
     if (!net->run_granules) {
         TRY(dev_alloc_t(net, &net->run_granules, (size_t)2 * RUN_RESIDENT_MAX_NEURONS));
         HIP_TRY(hipMemsetAsync(net->run_granules, 0, (size_t)2 * RUN_RESIDENT_MAX_NEURONS * 8, net->stream), SNN_ERR_BUFFER_WRITE);
+        TRY(dev_alloc_t(net, &net->run_partials, RUN_PARTIAL_WORDS));
+        HIP_TRY(hipMemsetAsync(net->run_partials, 0, RUN_PARTIAL_WORDS * 8, net->stream), SNN_ERR_BUFFER_WRITE);
         HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&net->run_failed), 8, hipHostMallocMapped), SNN_ERR_BUFFER_CREATE);
         net->run_failed[0] = net->run_failed[1] = 0u;
         net->run_tag = 1;
     }
-    const uint32_t n_groups = (net->n_loc + 63) / 64;
+    // workgroups: column tiles x row groups of 1024 rows (one group up to 1024 neurons)
+    const uint32_t row_groups = (net->n_tot + RUN_RESIDENT_GROUP_ROWS - 1) / RUN_RESIDENT_GROUP_ROWS;
+    const uint32_t n_groups = (net->n_loc + 63) / 64 * row_groups;
     if (net->run_probed_grid != n_groups) {
         // once per handle and grid size: can that many workgroups of this shape be resident together?  (the granule words
         // double as the probe's counter: they are cleared again before any run uses them)
@@ -603,6 +611,7 @@ int launch_run_resident(snn_network *net, uint64_t iterations)
         const uint32_t steps = (uint32_t)std::min<uint64_t>(iterations, 1u << 20);
         if (net->run_tag > 0xFFFFFFFFu - steps - 2u) {           // tags would wrap: start over on clean slots
             HIP_TRY(hipMemsetAsync(net->run_granules, 0, (size_t)2 * RUN_RESIDENT_MAX_NEURONS * 8, net->stream), SNN_ERR_BUFFER_WRITE);
+            HIP_TRY(hipMemsetAsync(net->run_partials, 0, RUN_PARTIAL_WORDS * 8, net->stream), SNN_ERR_BUFFER_WRITE);
             net->run_tag = 1;
         }
         ResidentRunArgs r{};
@@ -611,9 +620,11 @@ int launch_run_resident(snn_network *net, uint64_t iterations)
         r.vhist_stride = net->n_pad;
         r.raster_stride = net->n_pad / 64;
         r.granules = net->run_granules;
+        r.partials = net->run_partials;
+        r.n_groups = row_groups;
         r.tag_base = net->run_tag;
         r.failed = net->run_failed;
-        if (!net->run_timing && getenv("SNN_AMD_RUN_TIMING")) TRY(dev_alloc_t(net, &net->run_timing, (size_t)16 * 4));
+        if (!net->run_timing && getenv("SNN_AMD_RUN_TIMING")) TRY(dev_alloc_t(net, &net->run_timing, (size_t)RUN_RESIDENT_MAX_TILES * RUN_RESIDENT_MAX_GROUPS * 4));
         r.timing = net->run_timing;
         hipLaunchKernelGGL(k_run_resident_seed, dim3((net->n_tot + 255) / 256), dim3(256), 0, net->stream, net->xbuf, net->xl,
                            net->n_tot, net->run_granules, r.tag_base);
@@ -622,7 +633,7 @@ int launch_run_resident(snn_network *net, uint64_t iterations)
         hipEvent_t e1 = nullptr;
         TRY(profile_open(net, &e1));
         if (e1) net->ev_counts[net->ev_used - 1] = (int)steps;
-        const dim3 grid((net->n_loc + 63) / 64), block(1024);
+        const dim3 grid(n_groups), block(1024);
 #define SNN_RUN_RESIDENT(M) hipLaunchKernelGGL((k_run_resident<M, false>), grid, block, 0, net->stream, r)
 #if !SNN_HAVE_CUSTOM_MODEL
         if (net->model == SNN_MODEL_IZHIKEVICH && !r.up.has_nt && !r.up.bcm)      // neuron state in registers for the whole run
@@ -636,8 +647,8 @@ int launch_run_resident(snn_network *net, uint64_t iterations)
         HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
         if (e1) HIP_TRY(hipEventRecord(e1, net->stream), SNN_ERR_QUEUE);
         if (net->run_timing) {          // debugging aid: workgroup 0's phases in shader clocks per step
-            unsigned long long t[64];
-            HIP_TRY(hipMemcpyAsync(t, net->run_timing, sizeof t, hipMemcpyDeviceToHost, net->stream), SNN_ERR_BUFFER_READ);
+            std::vector<unsigned long long> t((size_t)grid.x * 4);
+            HIP_TRY(hipMemcpyAsync(t.data(), net->run_timing, t.size() * 8, hipMemcpyDeviceToHost, net->stream), SNN_ERR_BUFFER_READ);
             HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
             for (unsigned b = 0; b < grid.x; b += (grid.x > 1 ? grid.x - 1 : 1))
                 fprintf(stderr, "k_run_resident workgroup %u: poll %.0f, barrier %.0f, turns %.0f, update+publish %.0f clocks/step (%u steps)\n",

@@ -63,6 +63,20 @@ def test_izhikevich_sizes(snn, rows, cols, seed):
     assert a["s"].sum() > 0
 
 
+@pytest.mark.parametrize("rows,cols,seed", [(33, 33, 41), (32, 40, 42), (45, 45, 43), (48, 48, 44), (56, 57, 45), (64, 64, 46)])
+def test_several_row_groups_per_tile(snn, rows, cols, seed):
+    """1025 .. 4096 neurons: 2 .. 4 row groups of 1024 rows per column tile, the chunk sums of groups 1.. travel to group 0."""
+    net = build(ob.IZHIKEVICH, rows, cols, seed, density=0.5)
+    a = compare(snn, net, [150, 3, 47])
+    assert a["s"].sum() > 0
+
+
+def test_several_row_groups_generic_update(snn):
+    net = build(ob.LIF, 40, 41, 51, density=0.5)
+    a = compare(snn, net, [200])
+    assert a["s"].sum() > 0
+
+
 @pytest.mark.parametrize("model", [ob.LIF, ob.HH, ob.QIF])
 def test_other_models(snn, model):
     net = build(model, 18, 19, 11 + model)
