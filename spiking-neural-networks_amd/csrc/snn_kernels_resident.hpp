@@ -216,8 +216,8 @@ __global__ __launch_bounds__(64 * RESIDENT_MAX_CHUNKS) void k_step_resident(cons
     }
 }
 
-// k_run_resident -- MANY steps of a small dense lattice in ONE launch (electrical synapses, neurons only, <= 1024 of
-// them: BASELINE configs[0], the 32 x 32 lattice).  The one-launch step above is a chain of dependent L2 round trips
+// k_run_resident -- MANY steps of a small dense lattice in ONE launch (electrical synapses, neurons only; first for <= 1024
+// of them: BASELINE configs[0], the 32 x 32 lattice; up to 4096 with the row groups described further down).  The one-launch step above is a chain of dependent L2 round trips
 // (9.5 us per launch, of which the canonical 256-long add chain itself is well under 1 us); here
 //   * a workgroup = 64 postsynaptic columns x all rows, 16 wavefronts x 64 rows, and keeps its slab of W in REGISTERS
 //     for the whole run (64 words per lane; absent edges as weight 0 plus one presence bit per row);

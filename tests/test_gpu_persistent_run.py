@@ -1,4 +1,4 @@
-"""Many steps in ONE launch (k_run_resident: electrical-only lattices of <= 1024 neurons without plasticity, the shape of
+"""Many steps in ONE launch (k_run_resident: electrical-only lattices of <= 4096 neurons without plasticity, the shape of
 BASELINE configs[0]) against the one-launch-per-step form (option persistent_run 0) and the oracle: bit-identical
 voltages, rasters, state and spike totals, for ragged sizes, split run calls, every built-in model, sparse connectivity,
 and voltages that leave the range in which an absent edge may be summed as a zero product."""
