@@ -846,7 +846,7 @@ int snn_run(snn_network_t *net, uint64_t iterations)
     HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
     TRY(begin_run(net, iterations));
     uint64_t it = 0;
-    if (iterations >= 2 && run_resident_applies(net)) {
+    if (iterations >= 4 && run_resident_applies(net)) {          // below that the launch's fixed cost (seed, weights into registers) shows
         TRY(launch_run_resident(net, iterations));
         if (net->persistent_run) it = iterations;     // else: the co-residency probe said no, nothing was stepped
     }
