@@ -108,5 +108,5 @@ def test_voltages_outside_the_zero_product_range(snn):
 
     for bad in (3.0e20, np.inf, np.nan):
         a = compare(snn, bad_net(bad), [4])
-        assert np.isfinite(a["v"][-1]).sum() > 20         # neurons without an edge from it (or from those it reached)
+        assert np.isfinite(a["v"][0]).sum() > 100         # after one step: the neurons without an edge from it
         compare(snn, bad_net(bad), [40])
