@@ -110,3 +110,83 @@ def test_voltages_outside_the_zero_product_range(snn):
         a = compare(snn, bad_net(bad), [4])
         assert np.isfinite(a["v"][0]).sum() > 100         # after one step: the neurons without an edge from it
         compare(snn, bad_net(bad), [40])
+
+
+MODELS = [ob.IZHIKEVICH, ob.LIF, ob.HH, ob.QIF, ob.SIMPLE_LIF, ob.ADAPTIVE_LIF, ob.ADAPTIVE_EXP_LIF, ob.LEAKY_IZHIKEVICH]
+
+
+def draw(seed):
+    """1-3 electrical-only lattices of one model with per-neuron parameters, random density (0 included), negative weights."""
+    rng = np.random.default_rng(1000 + seed)
+    model = MODELS[seed % len(MODELS)]
+    big = seed % 5 == 0                                   # some networks beyond one row group
+    lattices = []
+    for i in range(int(rng.integers(1, 4))):
+        hi_side = 26 if big else 14
+        lattices.append((int(2 * i + rng.integers(0, 2)), int(rng.integers(1, hi_side)), int(rng.integers(1, hi_side))))
+    net = parity.make_oracle(parity.Layout(lattices), model=model, electrical=True, chemical=False)
+    n = net.n_neurons
+    lo, hi = {ob.IZHIKEVICH: (-65, 30), ob.LIF: (-80, -50), ob.HH: (-75, -40), ob.LEAKY_IZHIKEVICH: (-65, 30)}.get(model, (-75, -56))
+    net["current_voltage"] = ob.uniform_array(seed, n, lo, hi)
+    net["gap_conductance"] = ob.uniform_array(seed + 1, n, 0.5, 12.0)
+    if model in (ob.IZHIKEVICH, ob.LEAKY_IZHIKEVICH):
+        net["a"] = ob.uniform_array(seed + 2, n, 0.01, 0.1)
+        net["b"] = ob.uniform_array(seed + 3, n, 0.15, 0.3)
+        net["c"] = ob.uniform_array(seed + 4, n, -70.0, -50.0)
+        net["d"] = ob.uniform_array(seed + 5, n, 2.0, 9.0)
+        net["v_th"] = ob.uniform_array(seed + 6, n, 20.0, 35.0)
+    if model == ob.LEAKY_IZHIKEVICH:
+        net["w_value"] = ob.uniform_array(seed + 7, n, 0.0, 1.0)
+    if model == ob.SIMPLE_LIF:
+        net["slif_g"] = 0.3
+        net["slif_e"] = -76.0
+    if model in (ob.LIF, ob.QIF, ob.ADAPTIVE_LIF, ob.ADAPTIVE_EXP_LIF):
+        net["tref"] = ob.uniform_array(seed + 2, n, 0.2, 2.0)
+        net["tau_m"] = 10.0
+    if model in (ob.ADAPTIVE_LIF, ob.ADAPTIVE_EXP_LIF):
+        net["leak_constant"] = 1.0
+        net["c_m"] = 1.0
+        net["v_reset"] = -73.0
+        net["adp_beta"] = ob.uniform_array(seed + 7, n, 0.5, 4.0)
+    if model == ob.ADAPTIVE_EXP_LIF:
+        net["slope_factor"] = ob.uniform_array(seed + 8, n, 0.5, 3.0)
+    net.fill_graph(seed + 9, -0.5, 2.0, with_diagonal=bool(rng.integers(0, 2)))
+    density = float(rng.choice([0.0, 0.05, 0.3, 0.8, 1.0]))
+    net["connections"][...] &= (rng.random(net["connections"].shape) < density)
+    net["weights"][...] *= net["connections"]
+    net["do_plasticity"] = 0
+    calls = [int(c) for c in rng.integers(1, 120, int(rng.integers(1, 4)))]
+    return net, calls, bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_electrical_networks(snn, seed):
+    net, calls, history, counts = draw(seed)
+    outs = []
+    for persistent in (1, 0):
+        dn = parity.device_from_oracle(snn, net)
+        dn.set_option("persistent_run", persistent)
+        dn.set_history(voltage=history, spikes=history)
+        dn.set_reduced_history(spike_counts=counts)
+        for c in calls:
+            dn.run(c)
+        out = {"state": parity.pull_state(dn, net), "launches": dn.stat("persistent_run_launches")}
+        for i, _, _ in net.layout.lattices:
+            if history:
+                out[("v", i)], out[("s", i)] = dn.voltage_history(i), dn.spike_history(i)
+            if counts:
+                out[("c", i)] = dn.spike_counts(i)
+        dn.close()
+        outs.append(out)
+    assert outs[0]["launches"] == sum(1 for c in calls if c >= 4) and outs[1]["launches"] == 0
+    net.run(sum(calls), voltage_history=history, spike_history=history, spike_counts=counts)
+    rng = net.layout.ranges()
+    for out in outs:
+        parity.assert_state_equal(net, out["state"])
+        for i, _, _ in net.layout.lattices:
+            first, count, _ = rng[i]
+            if history:
+                assert np.array_equal(out[("s", i)], net.spike_history[:, first:first + count])
+                assert np.array_equal(parity.bits(out[("v", i)]), parity.bits(net.voltage_history[:, first:first + count]))
+            if counts:
+                assert np.array_equal(np.asarray(out[("c", i)]).ravel(), net.spike_counts[first:first + count])
