@@ -190,3 +190,4 @@ def test_random_electrical_networks(snn, seed):
                 assert np.array_equal(parity.bits(out[("v", i)]), parity.bits(net.voltage_history[:, first:first + count]))
             if counts:
                 assert np.array_equal(np.asarray(out[("c", i)]).ravel(), net.spike_counts[first:first + count])
+
