@@ -35,6 +35,7 @@ prof c4 --config c4 --steps 50 --warmup 10 --repeats 2
 prof c4_spiking_0p1pct --config c4 --spike-fraction 0.001 --steps 50 --warmup 100 --repeats 2
 prof c5 --config c5 --steps 500 --warmup 20 --repeats 2 --no-kernel-events
 prof c1 --config c1 --steps 2000 --warmup 50 --repeats 2 --no-kernel-events
+prof lattice64 --config c2 --rows 64 --cols 64 --steps 2000 --warmup 50 --repeats 2 --no-kernel-events
 prof c2_sharded_world1 --config c2 --force-sharded --steps 50 --warmup 10 --repeats 2
 prof c5_sharded_world1 --config c5 --force-sharded --steps 500 --warmup 20 --repeats 2 --no-kernel-events
 pmc c2 k_inputs_dense --config c2 --steps 20 --warmup 3 --repeats 1
