@@ -39,38 +39,23 @@ struct UpdateArgs {
     int model_is_custom;        // the generated neuron model: it uses the library's generated receptor set, if any
 };
 
-// Second level of the canonical sum: chunk partials added in ascending chunk order from 0.0f.  The adds stay strictly
-// sequential; the loads do not have to: a batch of 32 is issued together and the next batch before this one is summed, so a
-// thread keeps up to 64 reads in flight (one wavefront per CU: the kernel is a chain of memory round trips -- with batches
-// of 16 and no overlap C3's 64 chunks x 2 planes were 8 round trips, now 2).
+// Second level of the canonical sum: chunk partials added in ascending chunk order from 0.0f.  The loads of
+// a batch are issued together (the adds stay strictly sequential), so a thread keeps 16 reads in flight.  (Batches of 32
+// with the next batch requested early made C3's update 1.3 us faster and, at 104 registers instead of 63, the update of
+// the 1 M neurons of configs[4] on a shard handle 3.5 us slower: not kept.)
 __device__ __forceinline__ float combine_partials(const float *p, uint32_t n_chunks, size_t ld)
 {
-    constexpr uint32_t B = 32;
+    constexpr uint32_t B = 16;
     float s = 0.0f;
-    if (n_chunks == 0) return s;
-    const uint32_t last = n_chunks - 1;
-    float cur[B], nxt[B];
+    uint32_t c = 0;
+    for (; c + B <= n_chunks; c += B) {
+        float v[B];
 #pragma unroll
-    for (uint32_t u = 0; u < B; ++u) cur[u] = p[(size_t)min(u, last) * ld];        // clamped: the tail is not added
-    for (uint32_t c = 0; c < n_chunks; c += B) {
-        const bool more = c + B < n_chunks;
-        if (more) {
+        for (uint32_t u = 0; u < B; ++u) v[u] = p[(size_t)(c + u) * ld];
 #pragma unroll
-            for (uint32_t u = 0; u < B; ++u) nxt[u] = p[(size_t)min(c + B + u, last) * ld];
-        }
-        if (c + B <= n_chunks) {
-#pragma unroll
-            for (uint32_t u = 0; u < B; ++u) s += cur[u];
-        } else {
-#pragma unroll
-            for (uint32_t u = 0; u < B; ++u)
-                if (c + u < n_chunks) s += cur[u];
-        }
-        if (more) {
-#pragma unroll
-            for (uint32_t u = 0; u < B; ++u) cur[u] = nxt[u];
-        }
+        for (uint32_t u = 0; u < B; ++u) s += v[u];
     }
+    for (; c < n_chunks; ++c) s += p[(size_t)c * ld];
     return s;
 }
 

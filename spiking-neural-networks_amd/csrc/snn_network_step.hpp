@@ -240,9 +240,7 @@ int launch_update(snn_network *net)
     a.bcm = net->model == SNN_MODEL_BCM_IZHIKEVICH;
     a.model_is_custom = net->model == SNN_MODEL_CUSTOM;
     net->shadow_valid = false;            // the exchange buffer moves on without the shadows
-    // one wavefront per workgroup while that still leaves CUs idle: the kernel is a chain of memory round trips per wavefront,
-    // and four wavefronts on one CU share its memory queue (C3: 64 workgroups of 256 threads used 64 of the 256 CUs)
-    const uint32_t ub = (net->ld + 255) / 256 < 256 ? 64u : 256u;
+    const uint32_t ub = 256u;          // (one wavefront per workgroup for small launches was measured: no gain)
     dim3 grid((net->ld + ub - 1) / ub);
     switch (net->model) {
     case SNN_MODEL_LIF: hipLaunchKernelGGL((k_update<1>), grid, dim3(ub), 0, net->stream, a); break;
