@@ -298,6 +298,9 @@ __device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, Res
     const bool last_of_chunk = turn == 3u || row0 + 64u >= n_tot;
     const bool updates = group == 0u;                            // this workgroup's wavefront 0 updates the tile's neurons
     const bool cols_in_rows = (tile * 64u) / RUN_RESIDENT_GROUP_ROWS == group;   // its columns are among its rows: no second poll
+    const bool alone = gridDim.x == 1u;                          // <= 64 neurons: the only workgroup
+    const uint32_t n_turns = n_tot >= CHUNK ? 4u : (n_tot + 63u) / 64u;   // fewer than 256 rows in all: fewer turns (and barriers)
+    float v_mine = 0.0f;                                         // wavefront 0, alone: the voltage this lane's neuron was left with
     const uint32_t ql = tile * 64u + lane;
     const bool col = ql < in.n_loc;
     const float gq = col ? uload(in.uni, NP_GAP, in.gap_conductance, in.q0 + ql) : 0.0f;
@@ -372,10 +375,16 @@ __device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, Res
         };
         float v = 0.0f, v_col = 0.0f;
         bool arrived = true;
-        if (group_row0 + tid < n_tot) v = poll(slot + group_row0 + tid, arrived);
-        if (!cols_in_rows && wave == 1 && col) v_col = poll(slot + in.q0 + ql, arrived);   // the columns' voltages, by one wavefront
+        if (alone && s != 0) {
+            // a lattice of <= 64 neurons is ONE workgroup: wavefront 0 left the new voltages in sh.v itself (below), nothing
+            // travels through memory; it also knows whether they are all small finite numbers
+            v = UPDATER ? v_mine : 0.0f;
+        } else {
+            if (group_row0 + tid < n_tot) v = poll(slot + group_row0 + tid, arrived);
+            if (!cols_in_rows && wave == 1 && col) v_col = poll(slot + in.q0 + ql, arrived);   // the columns' voltages, by one wavefront
+            sh.v[tid] = v;
+        }
         lap(0);
-        sh.v[tid] = v;
         if (!cols_in_rows && wave == 1) sh.vcol[lane] = v_col;
         const bool all_arrived = __all(arrived), all_plain = __all(fabsf(v) <= 1e15f && fabsf(v_col) <= 1e15f && gq_small);
         if (lane == 0) { sh.ok[wave] = all_arrived; sh.plain[wave] = all_plain; }
@@ -388,7 +397,7 @@ __device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, Res
         // (2) the canonical chunk sums, the wavefronts of a chunk in turn
         const float vq = cols_in_rows ? sh.v[(ql - group_row0) & (RUN_RESIDENT_GROUP_ROWS - 1u)] : sh.vcol[lane];
 #pragma unroll 1
-        for (uint32_t t = 0; t < 4; ++t) {
+        for (uint32_t t = 0; t < n_turns; ++t) {
             if (t == turn && rows_live) {
                 float acc = (t != 0) ? sh.hand[chunk_local][lane] : 0.0f;
                 // wave-uniform address = LDS broadcast; the offset is laundered through a vector register so that the values
@@ -529,7 +538,10 @@ __device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, Res
                 const unsigned long long word = __ballot(spike != 0);
                 if (lane == 0) spike_row[(a.up.q0 + ql) >> 6] = word;
             }
-            if (col && s + 1 < steps) {
+            if (alone) {
+                v_mine = col ? v_new : 0.0f;
+                if (col) sh.v[ql] = v_new;                    // read behind the next step's first barrier
+            } else if (col && s + 1 < steps) {
                 unsigned long long *g = a.granules + (size_t)((s + 1) & 1u) * RUN_RESIDENT_MAX_NEURONS + in.q0 + ql;
                 const unsigned long long x = ((unsigned long long)(tag_base + s + 1) << 32) | __float_as_uint(v_new);
                 __hip_atomic_store(g, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
