@@ -217,22 +217,24 @@ __global__ __launch_bounds__(64 * RESIDENT_MAX_CHUNKS) void k_step_resident(cons
 }
 
 // k_run_resident -- MANY steps of a small dense lattice in ONE launch (electrical synapses, neurons only; first for <= 1024
-// of them: BASELINE configs[0], the 32 x 32 lattice; up to 4096 with the row groups described further down).  The one-launch step above is a chain of dependent L2 round trips
-// (9.5 us per launch, of which the canonical 256-long add chain itself is well under 1 us); here
+// of them: BASELINE configs[0], the 32 x 32 lattice; up to 4096 with the row groups described further down).  The
+// one-launch step above is a chain of dependent L2 round trips (9.5 us per launch, of which the canonical 256-long add
+// chain itself is well under 1 us); here
 //   * a workgroup = 64 postsynaptic columns x all rows, 16 wavefronts x 64 rows, and keeps its slab of W in REGISTERS
-//     for the whole run (64 words per lane; absent edges as weight 0 plus one presence bit per row);
+//     for the whole run (64 words per lane, absent edges as weight 0; wavefront 0, which also updates, keeps its in LDS);
 //   * per step every workgroup needs every neuron's new voltage: the owner publishes it as an 8-byte {voltage, step
 //     tag} granule (agent-scope relaxed store = write-through) into the slot of the step's parity, every thread polls
 //     ONE granule (agent-scope relaxed loads bypass L1) until the tag is the step's -- measured on MI355X: 1.0 us per
 //     all-to-all of 1024 granules among 16 workgroups (profiles/experiments/granule_exchange_probe.hip), against
 //     1.45 us for a kernel boundary alone.  Two slots suffice: a workgroup can only publish step t + 2 after it has seen
-//     every workgroup's step t + 1, which each of them publishes after it finished reading step t;
+//     every workgroup's step t + 1, which each of them publishes after it finished reading step t.  A lattice of <= 64
+//     neurons is one workgroup and keeps its voltages in LDS;
 //   * the canonical sum keeps its order: the 4 wavefronts of a chunk take turns (the running sum passes through LDS), a
-//     turn's products are packed two rows per instruction; wavefront w sits on SIMD w % 4, and turn = (w % 4 - chunk) & 3
-//     puts the four wavefronts of a turn on four different SIMDs;
+//     turn's products are formed two rows per (packed) instruction, batch by batch, ahead of their adds; wavefront w sits
+//     on SIMD w % 4, and turn = (w % 4 - chunk) & 3 puts the four wavefronts of a turn on four different SIMDs;
 //   * an absent edge contributes product(term, 0) = +-0 instead of being skipped -- exact as long as the term is finite
-//     (the sum never holds -0, see above); a step in which some voltage is not a small finite number takes the path with
-//     explicit selects instead (workgroup-uniform).
+//     (the sum never holds -0, see above); a step in which some voltage is not a small finite number re-reads the matrix
+//     (absent edge = NaN) and skips explicitly instead (workgroup-uniform).
 // Arithmetic, order of operations and the update code are those of k_step_resident / k_inputs_dense + k_update.
 //
 // Lattices of 1025 .. 4096 neurons (33 x 33 .. 64 x 64) take R = 2 .. 4 ROW GROUPS of 1024 rows per column tile: workgroup
