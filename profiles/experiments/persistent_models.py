@@ -6,7 +6,8 @@ import snn_amd
 from snn_amd import synthetic
 
 MODELS = [("izhikevich", snn_amd.IZHIKEVICH, (-65.0, 30.0)), ("lif", snn_amd.LIF, (-80.0, -50.0)),
-          ("hodgkin_huxley", snn_amd.HODGKIN_HUXLEY, (-75.0, -40.0)), ("qif", snn_amd.QUADRATIC_INTEGRATE_AND_FIRE, (-75.0, -56.0))]
+          ("hodgkin_huxley", snn_amd.HODGKIN_HUXLEY, (-75.0, -40.0)), ("qif", snn_amd.QUADRATIC_INTEGRATE_AND_FIRE, (-75.0, -56.0)),
+          ("simple_lif", snn_amd.SIMPLE_LIF, (-75.0, -56.0))]
 for name, model, (lo, hi) in MODELS:
     for persistent in (1, 0):
         dn = snn_amd.DeviceNetwork(model=model)

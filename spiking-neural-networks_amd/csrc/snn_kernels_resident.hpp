@@ -328,25 +328,39 @@ __device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, Res
         }
     }
 
-    // Izhikevich state in registers (REGISTERS: the host launches that variant for Izhikevich lattices without transmitters
-    // and without the BCM extension)
+    // Neuron state in registers for the whole run (REGISTERS: the host launches that variant for Izhikevich, leaky, quadratic and
+    // simple leaky integrate-and-fire lattices without transmitters and without the BCM extension).  The expressions are
+    // update_neuron's (integrate_and_fire/mod.rs:217-255, 173-215, 324-365, 1577-1630); what they read every step is read once.
     constexpr bool in_registers = UPDATER && REGISTERS;
-    static_assert(!REGISTERS || MODEL == 0, "the register-resident update is the Izhikevich one");
-    float nv = 0.0f, nw = 0.0f, n_div = 1.0f, dt_cm = 0.0f, dt_tau = 0.0f, pa = 0.0f, pb = 0.0f, pc = 0.0f, pd = 0.0f, pth = 0.0f;
+    static_assert(!REGISTERS || MODEL == 0 || MODEL == 1 || MODEL == 3 || MODEL == 4, "no register-resident update for this model");
+    float nv = 0.0f, n2 = 0.0f, n_div = 1.0f;        // voltage; Izhikevich w / refractory_count; the averager's divisor
+    float pr[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};   // the model's parameters (see below)
     uint32_t n_spikes = 0, last_spike = 0;
     if (in_registers && updates && col) {
         const NeuronArrays &n = a.up.n;
         const uint32_t q = a.up.rows.global_of(ql);
         nv = n.xbuf[n.xl.at(q, PLANE_V)];
-        nw = n.w_value[q];
         const uint32_t cnt = a.up.n_in[ql];
         n_div = cnt == 0 ? 1.0f : (float)cnt;
         const float dt = uload(n.uni, NP_DT, n.dt, q);
-        dt_cm = dt / uload(n.uni, NP_C_M, n.c_m, q);
-        dt_tau = dt / uload(n.uni, NP_TAU_M, n.tau_m, q);
-        pa = uload(n.uni, NP_A, n.a, q); pb = uload(n.uni, NP_B, n.b, q);
-        pc = uload(n.uni, NP_C, n.c, q); pd = uload(n.uni, NP_D, n.d, q);
-        pth = uload(n.uni, NP_V_TH, n.v_th, q);
+        if (MODEL == 0) {
+            n2 = n.w_value[q];
+            pr[0] = dt / uload(n.uni, NP_C_M, n.c_m, q);
+            pr[1] = dt / uload(n.uni, NP_TAU_M, n.tau_m, q);
+            pr[2] = uload(n.uni, NP_A, n.a, q); pr[3] = uload(n.uni, NP_B, n.b, q);
+            pr[4] = uload(n.uni, NP_C, n.c, q); pr[5] = uload(n.uni, NP_D, n.d, q);
+            pr[6] = uload(n.uni, NP_V_TH, n.v_th, q);
+        } else if (MODEL == 1) {
+            n2 = n.refractory_count[q];
+            pr[0] = n.leak_constant[q]; pr[1] = n.e_l[q]; pr[2] = n.integration_constant[q]; pr[3] = n.g_l[q];
+            pr[4] = dt / n.tau_m[q]; pr[5] = n.v_reset[q]; pr[6] = n.v_th[q]; pr[7] = n.tref[q] / dt;
+        } else if (MODEL == 3) {
+            n2 = n.refractory_count[q];
+            pr[0] = n.qif_alpha[q]; pr[1] = n.v_reset[q]; pr[2] = n.qif_v_c[q]; pr[3] = n.integration_constant[q];
+            pr[4] = dt / n.tau_m[q]; pr[6] = n.v_th[q]; pr[7] = n.tref[q] / dt;
+        } else {
+            pr[0] = n.slif_g[q]; pr[1] = n.slif_e[q]; pr[2] = dt; pr[5] = n.v_reset[q]; pr[6] = n.v_th[q];
+        }
         last_spike = reinterpret_cast<const uint32_t *>(n.xbuf)[n.xl.at(q, PLANE_SPIKE)];
     }
 
@@ -511,16 +525,39 @@ __device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, Res
                     float sum = 0.0f;
                     for (uint32_t c = 0; c < n_chunks; ++c) sum += sh.pi[c][lane];
                     const float i_in = sum / n_div;
-                    const float dv = (0.04f * (nv * nv) + 5.0f * nv + 140.0f - nw + i_in) * dt_cm;
-                    const float dw = (pa * (pb * nv - nw)) * dt_tau;
-                    v_new = nv + dv;
-                    float w_new = nw + dw;
-                    if (v_new >= pth) {
-                        spike = 1;
-                        v_new = pc;
-                        w_new += pd;
+                    if (MODEL == 0) {            // Izhikevich
+                        const float dv = (0.04f * (nv * nv) + 5.0f * nv + 140.0f - n2 + i_in) * pr[0];
+                        const float dw = (pr[2] * (pr[3] * nv - n2)) * pr[1];
+                        v_new = nv + dv;
+                        float w_new = n2 + dw;
+                        if (v_new >= pr[6]) {
+                            spike = 1;
+                            v_new = pr[4];
+                            w_new += pr[5];
+                        }
+                        n2 = w_new;
+                    } else if (MODEL == 4) {     // simple leaky integrate-and-fire
+                        const float dv = (pr[0] * (nv - pr[1]) + i_in) * pr[2];
+                        v_new = nv + dv;
+                        if (v_new >= pr[6]) {
+                            spike = 1;
+                            v_new = pr[5];
+                        }
+                    } else {                     // leaky (1) / quadratic (3) integrate-and-fire + handle_spiking :87-102
+                        const float dv = MODEL == 1 ? ((pr[0] * (nv - pr[1])) + (pr[2] * (i_in / pr[3]))) * pr[4]
+                                                    : ((pr[0] * (nv - pr[1]) * (nv - pr[2])) + pr[3] * i_in) * pr[4];
+                        v_new = nv + dv;
+                        const float v_reset = MODEL == 1 ? pr[5] : pr[1];
+                        if (n2 > 0.0f) {
+                            v_new = v_reset;
+                            n2 -= 1.0f;
+                        } else if (v_new >= pr[6]) {
+                            spike = 1;
+                            v_new = v_reset;
+                            n2 = pr[7];
+                        }
                     }
-                    nv = v_new; nw = w_new;
+                    nv = v_new;
                     last_spike = spike;
                     const uint32_t q = b.up.rows.global_of(ql);
                     if (spike) {
@@ -558,7 +595,8 @@ __device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, Res
             const uint32_t q = a.up.rows.global_of(ql);
             a.up.xout[n.xl.at(q, PLANE_V)] = nv;
             reinterpret_cast<uint32_t *>(a.up.xout)[n.xl.at(q, PLANE_SPIKE)] = last_spike;
-            n.w_value[q] = nw;
+            if (MODEL == 0) n.w_value[q] = n2;
+            if (MODEL == 1 || MODEL == 3) n.refractory_count[q] = n2;
             if (a.up.spike_counts && n_spikes) a.up.spike_counts[q] += n_spikes;
         }
         if (a.timing && lane == 0)

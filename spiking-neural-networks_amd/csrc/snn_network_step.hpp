@@ -634,10 +634,19 @@ int launch_run_resident(snn_network *net, uint64_t iterations)
         const dim3 grid(n_groups), block(1024);
 #define SNN_RUN_RESIDENT(M) hipLaunchKernelGGL((k_run_resident<M, false>), grid, block, 0, net->stream, r)
 #if !SNN_HAVE_CUSTOM_MODEL
-        if (net->model == SNN_MODEL_IZHIKEVICH && !r.up.has_nt && !r.up.bcm)      // neuron state in registers for the whole run
+        // neuron state in registers for the whole run where the kernel carries the model's update itself
+        const bool regs = !r.up.has_nt && !r.up.bcm;
+        if (regs && net->model == SNN_MODEL_IZHIKEVICH) {
             hipLaunchKernelGGL((k_run_resident<0, true>), grid, block, 0, net->stream, r);
-        else
+        } else if (regs && net->model == SNN_MODEL_LIF) {
+            hipLaunchKernelGGL((k_run_resident<1, true>), grid, block, 0, net->stream, r);
+        } else if (regs && net->model == SNN_MODEL_QUADRATIC_INTEGRATE_AND_FIRE) {
+            hipLaunchKernelGGL((k_run_resident<3, true>), grid, block, 0, net->stream, r);
+        } else if (regs && net->model == SNN_MODEL_SIMPLE_LIF) {
+            hipLaunchKernelGGL((k_run_resident<4, true>), grid, block, 0, net->stream, r);
+        } else {
             SNN_FOR_MODEL(SNN_RUN_RESIDENT);
+        }
 #else
         (void)grid, (void)block;
 #endif
