@@ -260,6 +260,16 @@ struct ResidentRunArgs {
     uint32_t tag_base;              // tag of the state after step s (1-based) = tag_base + s
     uint32_t *failed;               // host-visible word, set when a poll gave up (workgroups not co-resident)
     unsigned long long *timing;     // null, or [gridDim.x][4] shader-clock totals of workgroup phases (SNN_AMD_RUN_TIMING=1)
+    // spike-train cells (Poisson or Rate, no transmitters): rows n_neurons .. n_tot - 1.  Nothing about a cell depends on the
+    // rest of the network, so every workgroup advances the cells among ITS rows by itself (thread = row; the cell's state lives
+    // in the workgroup's LDS); the workgroups of column tile 0 write histories and the final state.
+    CellArrays cells;
+    int st_kind;
+    const long long *lattice_clock; // [n_st_lattices] clocks at the start of this run call
+    long long step_offset0;         // steps done since then when the launch starts
+    long long view_clock0;          // network clock of the launch's first input calculation
+    float *st_vhist_row;            // the cells' voltage history row of the FIRST step or null
+    uint32_t st_vhist_stride;
 };
 
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -279,13 +289,20 @@ struct ResidentRunShared {
     v4f w0[16][64];                              // wavefront 0's weights (its registers belong to the update)
     uint32_t ok[16], plain[16];                  // per wavefront: all its granules arrived / all its values small and finite
     uint32_t gave_up;                            // sticky: some poll of chunk sums gave up
+    // networks with cells: per row of the workgroup, its kind and -- for a cell -- its state
+    uint32_t kind[RUN_RESIDENT_GROUP_ROWS];      // KIND_NEURON / KIND_ST_SILENT / KIND_ST_FIRED
+    uint32_t cell_word[RUN_RESIDENT_GROUP_ROWS]; // Poisson: seed; Rate: step (float bits)
+    int32_t cell_lft[RUN_RESIDENT_GROUP_ROWS];
+    float cell_presyn[RUN_RESIDENT_GROUP_ROWS], cell_v[RUN_RESIDENT_GROUP_ROWS];
+    float cell_s[RUN_RESIDENT_GROUP_ROWS], cell_f[RUN_RESIDENT_GROUP_ROWS];   // this step's (s, f) of a cell row, see the step loop
+    uint32_t cell_spiking[RUN_RESIDENT_GROUP_ROWS];
 };
 
 // The step loop of one wavefront.  UPDATER = wavefront 0, which also owns the neuron update of the workgroup's 64 columns: it
 // keeps its weights in LDS and, for Izhikevich neurons without transmitters, the neurons' state in registers for the whole
 // run (same expressions as update_neuron, integrate_and_fire/mod.rs:217-255); the other wavefronts keep 64 weights per lane
 // in registers.  Every wavefront of a workgroup passes the same workgroup barriers per step (five; group 0 of a multi-group tile one more).
-template <int MODEL, bool UPDATER, bool REGISTERS>
+template <int MODEL, bool UPDATER, bool REGISTERS, bool CELLS>
 __device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, ResidentRunShared &sh, const uint32_t wave)
 {
     const InputsArgs &in = a.in;
@@ -364,6 +381,21 @@ __device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, Res
         last_spike = reinterpret_cast<const uint32_t *>(n.xbuf)[n.xl.at(q, PLANE_SPIKE)];
     }
 
+    // this thread's row as a spike-train cell (CELLS: the variant launched for networks with cells)
+    const uint32_t n_neurons = in.n_neurons, my_row = group_row0 + tid;
+    const bool is_cell = CELLS && my_row >= n_neurons && my_row < n_tot;
+    const bool all_cells = CELLS && rows_live && row0 >= n_neurons;                       // this wavefront's rows: cells only
+    const bool mixed = CELLS && rows_live && row0 < n_neurons && row0 + 64u > n_neurons;   // ... neurons and cells
+    const bool writes_cells = is_cell && tile == 0u;
+    const uint32_t cell = is_cell ? my_row - n_neurons : 0u;
+    if (is_cell) {
+        sh.cell_word[tid] = a.st_kind == 1 ? a.cells.seed[cell] : __float_as_uint(a.cells.step[cell]);
+        sh.cell_lft[tid] = a.cells.last_firing_time[cell];
+        sh.cell_presyn[tid] = a.cells.presyn_value[cell];
+        sh.cell_v[tid] = a.cells.current_voltage[cell];
+        sh.cell_spiking[tid] = a.cells.is_spiking[cell];
+    }
+
     unsigned long long spent[4] = {0, 0, 0, 0}, mark = a.timing ? clock64() : 0;
     auto lap = [&](int phase) {
         if (!UPDATER || !a.timing) return;
@@ -396,9 +428,22 @@ __device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, Res
             // travels through memory; it also knows whether they are all small finite numbers
             v = UPDATER ? v_mine : 0.0f;
         } else {
-            if (group_row0 + tid < n_tot) v = poll(slot + group_row0 + tid, arrived);
+            if (my_row < n_neurons) v = poll(slot + my_row, arrived);
             if (!cols_in_rows && wave == 1 && col) v_col = poll(slot + in.q0 + ql, arrived);   // the columns' voltages, by one wavefront
+            if (!CELLS || my_row < n_neurons) sh.v[tid] = v;
+        }
+        if (CELLS && my_row >= n_neurons) {
+            // spike_train_gap_junction (neuron/mod.rs:119-137): a cell's row carries its gap-junction value x; one that never
+            // fired enters as x, the others as g * x.  Both as  s + g * f  with (s, f) = (x, 0) resp. (0, x): exact while x is
+            // finite (+-0 is added to a sum that never holds -0), and the same two packed instructions for every row.
+            const bool silent = is_cell && sh.cell_lft[tid] < 0;
+            v = is_cell ? sh.cell_presyn[tid] : 0.0f;
             sh.v[tid] = v;
+            sh.kind[tid] = !is_cell ? KIND_NEURON : (silent ? KIND_ST_SILENT : KIND_ST_FIRED);
+            sh.cell_s[tid] = silent ? v : 0.0f;
+            sh.cell_f[tid] = silent ? 0.0f : v;
+        } else if (CELLS) {
+            sh.kind[tid] = KIND_NEURON;
         }
         lap(0);
         if (!cols_in_rows && wave == 1) sh.vcol[lane] = v_col;
@@ -431,7 +476,77 @@ __device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, Res
                         if (UPDATER) wr[k] = sh.w0[4 * b + k][lane];
                     }
                 };
-                if (plain) {
+                const uint4 *kinds = reinterpret_cast<const uint4 *>(sh.kind + (CELLS ? row0 - group_row0 : 0u) + zero);
+                auto term_of = [&](uint32_t kind, float vp) {    // gap_junction neuron/mod.rs:54-60, spike_train_gap_junction :119-137
+                    return kind == KIND_NEURON ? gq * (vp - vq) : (kind == KIND_ST_SILENT ? vp : gq * vp);
+                };
+                if (plain && mixed) {
+                    // rows that are spike-train cells: the term depends on the row's kind (few wavefronts: the last rows)
+#pragma unroll 1
+                    for (uint32_t b = 0; b < 4; ++b) {
+                        v4f vp[4], wr[4];
+                        load_batch(b, vp, wr);
+                        // the weights of a batch by a switch on the batch: registers want constant indices
+                        if (!UPDATER) {
+#pragma unroll
+                            for (uint32_t bb = 0; bb < 4; ++bb)
+                                if (bb == b) {
+#pragma unroll
+                                    for (uint32_t k = 0; k < 4; ++k) {
+                                        const uint32_t r = 16 * bb + 4 * k;
+                                        wr[k] = v4f{w[UPDATER ? 0 : r], w[UPDATER ? 0 : r + 1], w[UPDATER ? 0 : r + 2], w[UPDATER ? 0 : r + 3]};
+                                    }
+                                }
+                        }
+#pragma unroll
+                        for (uint32_t k = 0; k < 4; ++k) {
+                            const uint4 kd = kinds[4 * b + k];
+                            acc += term_of(kd.x, vp[k].x) * wr[k].x;
+                            acc += term_of(kd.y, vp[k].y) * wr[k].y;
+                            acc += term_of(kd.z, vp[k].z) * wr[k].z;
+                            acc += term_of(kd.w, vp[k].w) * wr[k].w;
+                        }
+                    }
+                } else if (plain && all_cells) {
+                    // rows that are all cells: s + g * f, times the weight -- staged like the neurons' products below
+                    const v4f *cs = reinterpret_cast<const v4f *>(sh.cell_s + (row0 - group_row0) + zero);
+                    const v4f *cf = reinterpret_cast<const v4f *>(sh.cell_f + (row0 - group_row0) + zero);
+                    const v2f gq2 = {gq, gq};
+#pragma unroll
+                    for (uint32_t b = 0; b < 4; ++b) {
+                        v4f xs[4], xf[4], wr[4];
+#pragma unroll
+                        for (uint32_t k = 0; k < 4; ++k) {
+                            xs[k] = cs[4 * b + k];
+                            xf[k] = cf[4 * b + k];
+                            if (UPDATER) wr[k] = sh.w0[4 * b + k][lane];
+                        }
+                        v2f d[8];
+#pragma unroll
+                        for (uint32_t k = 0; k < 4; ++k) {
+                            d[2 * k] = gq2 * v2f{xf[k].x, xf[k].y};
+                            d[2 * k + 1] = gq2 * v2f{xf[k].z, xf[k].w};
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (uint32_t k = 0; k < 4; ++k) {
+                            d[2 * k] = v2f{xs[k].x, xs[k].y} + d[2 * k];
+                            d[2 * k + 1] = v2f{xs[k].z, xs[k].w} + d[2 * k + 1];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (uint32_t k = 0; k < 4; ++k) {
+                            const uint32_t r = 16 * b + 4 * k;
+                            if (!UPDATER) wr[k] = v4f{w[UPDATER ? 0 : r], w[UPDATER ? 0 : r + 1], w[UPDATER ? 0 : r + 2], w[UPDATER ? 0 : r + 3]};
+                            d[2 * k] = d[2 * k] * v2f{wr[k].x, wr[k].y};
+                            d[2 * k + 1] = d[2 * k + 1] * v2f{wr[k].z, wr[k].w};
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (uint32_t k = 0; k < 8; ++k) { acc += d[k].x; acc += d[k].y; }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else if (plain) {
                     // A lone wavefront per SIMD hides no latency by itself: the products of a batch are formed stage by stage
                     // (8 independent packed instructions back to back, the scheduler held to that order), then its 16 adds --
                     // measured 900-1000 clocks per 64 rows against 1600-1800 with product and add interleaved row by row
@@ -472,10 +587,12 @@ __device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, Res
 #pragma unroll 1
                     for (uint32_t g = 0; g < 16 && row0 + 4 * g < n_tot; ++g) {
                         const v4f x = pre[g], y = units[(size_t)g * in.ld];
+                        const uint4 kd = CELLS ? kinds[g] : make_uint4(KIND_NEURON, KIND_NEURON, KIND_NEURON, KIND_NEURON);
                         const float e[4] = {x.x, x.y, x.z, x.w}, ww[4] = {y.x, y.y, y.z, y.w};
+                        const uint32_t kk[4] = {kd.x, kd.y, kd.z, kd.w};
 #pragma unroll
                         for (uint32_t j = 0; j < 4; ++j) {
-                            const float p = (gq * (e[j] - vq)) * ww[j];
+                            const float p = term_of(kk[j], e[j]) * ww[j];
                             acc += (ww[j] == ww[j]) ? p : 0.0f;
                         }
                     }
@@ -484,6 +601,41 @@ __device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, Res
                 else sh.hand[chunk_local][lane] = acc;
             }
             __syncthreads();
+        }
+        // (2a) this thread's cell advances (PoissonNeuron::iterate spike_train/mod.rs:411-435, RateSpikeTrain::iterate :1016-1031,
+        // as k_spike_trains): spike, voltage, firing time, and the gap-junction value the NEXT step's inputs read
+        if (is_cell) {
+            const CellArrays &c = a.cells;
+            const float c_dt = uload(c.uni, CP_DT, c.dt, cell);
+            uint32_t spike;
+            if (a.st_kind == 1) {
+                const uint32_t seed = xorshift32(sh.cell_word[tid]);
+                sh.cell_word[tid] = seed;
+                const float random_number = (float)seed / 4294967296.0f;   // (float) seed / 0xFFFFFFFF
+                spike = random_number < uload(c.uni, CP_CHANCE, c.chance_of_firing, cell);
+            } else {
+                const float rate = c.rate[cell];
+                float step = __uint_as_float(sh.cell_word[tid]) + c_dt;
+                spike = (rate != 0.0f) && (step >= rate);
+                if (spike) step = 0.0f;
+                sh.cell_word[tid] = __float_as_uint(step);
+            }
+            const float c_v_th = uload(c.uni, CP_V_TH, c.v_th, cell), c_v_resting = uload(c.uni, CP_V_RESTING, c.v_resting, cell);
+            const float cv = spike ? c_v_th : c_v_resting;
+            sh.cell_v[tid] = cv;
+            sh.cell_spiking[tid] = spike;
+            int32_t lft = sh.cell_lft[tid];
+            if (spike) {
+                lft = (int32_t)(a.lattice_clock[c.lattice_slot[cell]] + a.step_offset0 + (long long)s);
+                sh.cell_lft[tid] = lft;
+            }
+            if (writes_cells && a.st_vhist_row) a.st_vhist_row[(size_t)s * a.st_vhist_stride + cell] = cv;
+            const long long view_clock = a.view_clock0 + (long long)s + 1;
+            const uint32_t refr = uload(c.uni, CP_REFR, c.refractoriness, cell);
+            const float c_k = uload(c.uni, CP_K, c.k, cell);
+            sh.cell_presyn[tid] = lft < 0 ? c_v_resting
+                                          : (refr ? exponential_decay_effect(view_clock, lft, c_v_th, c_v_resting, c_k, c_dt)
+                                                  : delta_dirac_effect(view_clock, lft, c_v_th, c_v_resting, c_k, c_dt));
         }
         // (2b) several row groups per tile: the groups other than 0 publish their chunk sums, group 0 collects them -- wavefront
         // 1 + j takes remote chunk j -- behind one more barrier of its own
@@ -589,6 +741,15 @@ __device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, Res
         }
     }
 
+    if (writes_cells) {                          // the cells' state this workgroup's LDS held
+        const CellArrays &c = a.cells;
+        if (a.st_kind == 1) c.seed[cell] = sh.cell_word[tid];
+        else c.step[cell] = __uint_as_float(sh.cell_word[tid]);
+        c.last_firing_time[cell] = sh.cell_lft[tid];
+        c.presyn_value[cell] = sh.cell_presyn[tid];
+        c.current_voltage[cell] = sh.cell_v[tid];
+        c.is_spiking[cell] = sh.cell_spiking[tid];
+    }
     if (UPDATER) {
         if (in_registers && updates && col) {    // the state the registers held
             const NeuronArrays &n = a.up.n;
@@ -621,14 +782,14 @@ __global__ __launch_bounds__(1024) void k_run_resident_probe(uint32_t *counter, 
     if (footprint.ok[0] == 0u) *counter = 0u;   // never: keeps the LDS footprint alive
 }
 
-template <int MODEL, bool REGISTERS>
+template <int MODEL, bool REGISTERS, bool CELLS>
 __global__ __launch_bounds__(1024) void k_run_resident(const ResidentRunArgs args)
 {
     __shared__ __attribute__((aligned(16))) ResidentRunShared sh;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (threadIdx.x == 0) sh.gave_up = 0u;                       // ordered before its first reader by the first step's barrier
-    if (wave == 0) run_resident_steps<MODEL, true, REGISTERS>(args, sh, wave);
-    else run_resident_steps<MODEL, false, REGISTERS>(args, sh, wave);
+    if (wave == 0) run_resident_steps<MODEL, true, REGISTERS, CELLS>(args, sh, wave);
+    else run_resident_steps<MODEL, false, REGISTERS, CELLS>(args, sh, wave);
     // a poll that gave up ended the loop early everywhere in the workgroup
     if (threadIdx.x == 0) {
         bool failed = false;

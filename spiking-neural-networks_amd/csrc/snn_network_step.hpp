@@ -566,7 +566,9 @@ int launch_step_resident(snn_network *net)
 bool run_resident_applies(const snn_network *net)
 {
     return !SNN_HAVE_CUSTOM_MODEL && net->fused_step && !net->csr && !net->sharded && !net->drive_threshold && net->n_loc &&
-           net->persistent_run && net->nc == 0 && net->nn == net->n_tot && net->n_loc == net->nn &&
+           net->persistent_run && net->n_loc == net->nn && net->nn + net->nc == net->n_tot &&
+           (net->nc == 0 || ((net->st_kind == SNN_ST_POISSON || net->st_kind == SNN_ST_RATE) && !net->any_nt_cells &&
+                             !net->cell_list_dev && !SNN_HAVE_CUSTOM_REFRACTORINESS)) &&
            net->n_tot <= RUN_RESIDENT_MAX_NEURONS && net->electrical && !net->chemical && !net->any_plasticity &&
            !net->any_modulation && !net->any_whist && !net->want_avg && !net->want_eeg && net->hist_every == 1 &&
            net->model != SNN_MODEL_BCM_IZHIKEVICH && !net->local_inputs_done;
@@ -622,28 +624,38 @@ int launch_run_resident(snn_network *net, uint64_t iterations)
         r.n_groups = row_groups;
         r.tag_base = net->run_tag;
         r.failed = net->run_failed;
+        r.cells = net->ca;
+        r.st_kind = net->st_kind;
+        r.lattice_clock = net->st_clock_dev;
+        r.step_offset0 = net->run_step_offset;
+        r.view_clock0 = net->clock;
+        r.st_vhist_row = (recording(net) && net->want_vhist && net->st_vhist) ? net->st_vhist + (size_t)net->hist_steps * net->c_pad : nullptr;
+        r.st_vhist_stride = net->c_pad;
         if (!net->run_timing && getenv("SNN_AMD_RUN_TIMING")) TRY(dev_alloc_t(net, &net->run_timing, (size_t)RUN_RESIDENT_MAX_TILES * RUN_RESIDENT_MAX_GROUPS * 4));
         r.timing = net->run_timing;
-        hipLaunchKernelGGL(k_run_resident_seed, dim3((net->n_tot + 255) / 256), dim3(256), 0, net->stream, net->xbuf, net->xl,
-                           net->n_tot, net->run_granules, r.tag_base);
+        hipLaunchKernelGGL(k_run_resident_seed, dim3((net->nn + 255) / 256), dim3(256), 0, net->stream, net->xbuf, net->xl,
+                           net->nn, net->run_granules, r.tag_base);
         HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
         // profiling: one event pair around the launch, counted as `steps` passes over the graph
         hipEvent_t e1 = nullptr;
         TRY(profile_open(net, &e1));
         if (e1) net->ev_counts[net->ev_used - 1] = (int)steps;
         const dim3 grid(n_groups), block(1024);
-#define SNN_RUN_RESIDENT(M) hipLaunchKernelGGL((k_run_resident<M, false>), grid, block, 0, net->stream, r)
+#define SNN_RUN_RESIDENT(M) hipLaunchKernelGGL((k_run_resident<M, false, false>), grid, block, 0, net->stream, r)
+#define SNN_RUN_RESIDENT_CELLS(M) hipLaunchKernelGGL((k_run_resident<M, false, true>), grid, block, 0, net->stream, r)
 #if !SNN_HAVE_CUSTOM_MODEL
         // neuron state in registers for the whole run where the kernel carries the model's update itself
         const bool regs = !r.up.has_nt && !r.up.bcm;
-        if (regs && net->model == SNN_MODEL_IZHIKEVICH) {
-            hipLaunchKernelGGL((k_run_resident<0, true>), grid, block, 0, net->stream, r);
+        if (net->nc) {                                       // rows that are spike-train cells: the generic update
+            SNN_FOR_MODEL(SNN_RUN_RESIDENT_CELLS);
+        } else if (regs && net->model == SNN_MODEL_IZHIKEVICH) {
+            hipLaunchKernelGGL((k_run_resident<0, true, false>), grid, block, 0, net->stream, r);
         } else if (regs && net->model == SNN_MODEL_LIF) {
-            hipLaunchKernelGGL((k_run_resident<1, true>), grid, block, 0, net->stream, r);
+            hipLaunchKernelGGL((k_run_resident<1, true, false>), grid, block, 0, net->stream, r);
         } else if (regs && net->model == SNN_MODEL_QUADRATIC_INTEGRATE_AND_FIRE) {
-            hipLaunchKernelGGL((k_run_resident<3, true>), grid, block, 0, net->stream, r);
+            hipLaunchKernelGGL((k_run_resident<3, true, false>), grid, block, 0, net->stream, r);
         } else if (regs && net->model == SNN_MODEL_SIMPLE_LIF) {
-            hipLaunchKernelGGL((k_run_resident<4, true>), grid, block, 0, net->stream, r);
+            hipLaunchKernelGGL((k_run_resident<4, true, false>), grid, block, 0, net->stream, r);
         } else {
             SNN_FOR_MODEL(SNN_RUN_RESIDENT);
         }
@@ -651,6 +663,7 @@ int launch_run_resident(snn_network *net, uint64_t iterations)
         (void)grid, (void)block;
 #endif
 #undef SNN_RUN_RESIDENT
+#undef SNN_RUN_RESIDENT_CELLS
         HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
         if (e1) HIP_TRY(hipEventRecord(e1, net->stream), SNN_ERR_QUEUE);
         if (net->run_timing) {          // debugging aid: workgroup 0's phases in shader clocks per step

@@ -191,3 +191,72 @@ def test_random_electrical_networks(snn, seed):
             if counts:
                 assert np.array_equal(np.asarray(out[("c", i)]).ravel(), net.spike_counts[first:first + count])
 
+
+
+def build_with_cells(model, lattices, st_lattices, st_kind, seed, density=0.5):
+    """electrical-only network with Poisson / Rate spike-train lattices as presynaptic rows (no transmitters, no plasticity)"""
+    net = parity.make_oracle(parity.Layout(lattices, st_lattices), model=model, st_kind=st_kind, electrical=True, chemical=False)
+    n, nc = net.n_neurons, net.n_cells
+    rng = np.random.default_rng(seed)
+    lo, hi = {ob.IZHIKEVICH: (-65, 30), ob.LIF: (-80, -50), ob.HH: (-75, -40)}.get(model, (-75, -56))
+    net["current_voltage"] = ob.uniform_array(seed, n, lo, hi)
+    net["gap_conductance"] = ob.uniform_array(seed + 1, n, 1.0, 10.0)
+    if model in (ob.LIF, ob.QIF):
+        net["tref"] = ob.uniform_array(seed + 2, n, 0.3, 1.5)
+        net["tau_m"] = 10.0
+    net["nt_flags"][...] = 0
+    net["st_nt_flags"][...] = 0
+    net["st_seed"] = rng.integers(1, 2**32 - 1, nc, dtype=np.uint32)
+    net["st_chance_of_firing"] = ob.uniform_array(seed + 4, nc, 0.0, 0.08)
+    net["st_rate"] = ob.uniform_array(seed + 5, nc, 0.0, 6.0)                # 0: a cell that never fires
+    net["st_refractoriness"][...] = rng.integers(0, 2, nc)                   # DeltaDirac / ExponentialDecay per cell
+    net["st_k"] = ob.uniform_array(seed + 11, nc, 20.0, 10000.0)
+    net.fill_graph(seed + 6, 0.2, 2.0)
+    net["connections"][...] &= (rng.random(net["connections"].shape) < density)
+    net["weights"][...] *= net["connections"]
+    net["do_plasticity"] = 0
+    return net
+
+
+CELL_CASES = [
+    (ob.IZHIKEVICH, [(0, 6, 7)], [(5, 3, 4)], ob.ST_POISSON, 61),                      # cells inside the first 64-row block
+    (ob.IZHIKEVICH, [(0, 16, 16)], [(5, 16, 16)], ob.ST_POISSON, 62),                  # one cell per neuron (configs[4]'s wiring, small)
+    (ob.LIF, [(1, 12, 13), (3, 5, 5)], [(0, 4, 9), (2, 2, 2)], ob.ST_RATE, 63),        # two lattices, two spike-train lattices
+    (ob.IZHIKEVICH, [(0, 31, 32)], [(9, 8, 9)], ob.ST_POISSON, 64),                    # cells straddle the first row group's end
+    (ob.QIF, [(0, 36, 36)], [(1, 20, 20)], ob.ST_RATE, 65),                            # two row groups, cells in the second
+    (ob.IZHIKEVICH, [(0, 45, 45)], [(7, 30, 30)], ob.ST_POISSON, 66),                  # three row groups
+]
+
+
+@pytest.mark.parametrize("model,lattices,st_lattices,st_kind,seed", CELL_CASES)
+def test_networks_with_spike_train_cells(snn, model, lattices, st_lattices, st_kind, seed):
+    """Spike-train cells are rows every workgroup advances by itself (thread = cell): same results as k_spike_trains."""
+    net = build_with_cells(model, lattices, st_lattices, st_kind, seed)
+    calls = [120, 2, 61]
+    outs = []
+    for persistent in (1, 0):
+        dn = parity.device_from_oracle(snn, net)
+        dn.set_option("persistent_run", persistent)
+        dn.set_history(voltage=True, spikes=True)
+        for c in calls:
+            dn.run(c)
+        out = {"state": parity.pull_state(dn, net), "launches": dn.stat("persistent_run_launches")}
+        for i, _, _ in list(net.layout.lattices) + list(net.layout.st_lattices):
+            out[("v", i)] = dn.voltage_history(i)
+        for i, _, _ in net.layout.lattices:
+            out[("s", i)] = dn.spike_history(i)
+        dn.close()
+        outs.append(out)
+    assert outs[0]["launches"] == 2 and outs[1]["launches"] == 0
+    net.run(sum(calls), voltage_history=True, spike_history=True, st_voltage_history=True)
+    assert (net.st_voltage_history > 0).sum() > 10 and net.spike_history.sum() > 0
+    rng = net.layout.ranges()
+    for out in outs:
+        parity.assert_state_equal(net, out["state"])
+        for i, _, _ in net.layout.lattices:
+            first, count, _ = rng[i]
+            assert np.array_equal(out[("s", i)], net.spike_history[:, first:first + count])
+            assert np.array_equal(parity.bits(out[("v", i)]), parity.bits(net.voltage_history[:, first:first + count]))
+        for i, _, _ in net.layout.st_lattices:
+            first, count, _ = rng[i]
+            assert np.array_equal(parity.bits(out[("v", i)]), parity.bits(net.st_voltage_history[:, first:first + count]))
