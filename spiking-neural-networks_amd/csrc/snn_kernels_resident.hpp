@@ -295,6 +295,11 @@ struct ResidentRunShared {
     int32_t cell_lft[RUN_RESIDENT_GROUP_ROWS];
     float cell_presyn[RUN_RESIDENT_GROUP_ROWS], cell_v[RUN_RESIDENT_GROUP_ROWS];
     float cell_s[RUN_RESIDENT_GROUP_ROWS], cell_f[RUN_RESIDENT_GROUP_ROWS];   // this step's (s, f) of a cell row, see the step loop
+    // a cell's parameters, read once: chance of firing | rate, v_th, v_resting, dt, k, refractoriness kind, and the clock of its
+    // lattice at the launch's first step (64 bits in two words) -- read from the arrays every step they were a chain of
+    // dependent global loads per cell
+    float cell_par[5][RUN_RESIDENT_GROUP_ROWS];
+    uint32_t cell_refr[RUN_RESIDENT_GROUP_ROWS], cell_clock_lo[RUN_RESIDENT_GROUP_ROWS], cell_clock_hi[RUN_RESIDENT_GROUP_ROWS];
     uint32_t cell_spiking[RUN_RESIDENT_GROUP_ROWS];
 };
 
@@ -389,6 +394,16 @@ __device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, Res
     const bool writes_cells = is_cell && tile == 0u;
     const uint32_t cell = is_cell ? my_row - n_neurons : 0u;
     if (is_cell) {
+        const CellArrays &c = a.cells;
+        sh.cell_par[0][tid] = a.st_kind == 1 ? uload(c.uni, CP_CHANCE, c.chance_of_firing, cell) : c.rate[cell];
+        sh.cell_par[1][tid] = uload(c.uni, CP_V_TH, c.v_th, cell);
+        sh.cell_par[2][tid] = uload(c.uni, CP_V_RESTING, c.v_resting, cell);
+        sh.cell_par[3][tid] = uload(c.uni, CP_DT, c.dt, cell);
+        sh.cell_par[4][tid] = uload(c.uni, CP_K, c.k, cell);
+        sh.cell_refr[tid] = uload(c.uni, CP_REFR, c.refractoriness, cell);
+        const long long clock0 = a.lattice_clock[c.lattice_slot[cell]] + a.step_offset0;
+        sh.cell_clock_lo[tid] = (uint32_t)(unsigned long long)clock0;
+        sh.cell_clock_hi[tid] = (uint32_t)((unsigned long long)clock0 >> 32);
         sh.cell_word[tid] = a.st_kind == 1 ? a.cells.seed[cell] : __float_as_uint(a.cells.step[cell]);
         sh.cell_lft[tid] = a.cells.last_firing_time[cell];
         sh.cell_presyn[tid] = a.cells.presyn_value[cell];
@@ -552,11 +567,14 @@ __device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, Res
                     // measured 900-1000 clocks per 64 rows against 1600-1800 with product and add interleaved row by row
                     // (profiles/experiments/chain_turn_probe.hip).
                     const v2f vq2 = {vq, vq}, gq2 = {gq, gq};
+                    // (the variant for networks with cells has no registers to spare for the next batch's voltages: it would spill
+                    // weights to scratch inside this loop, 3 700 instead of 1 300 clocks per turn)
+                    constexpr bool AHEAD = !CELLS || UPDATER;
                     v4f vp[4], wr[4], vp_next[4], wr_next[4];
                     load_batch(0, vp, wr);
 #pragma unroll
                     for (uint32_t b = 0; b < 4; ++b) {
-                        if (b < 3) load_batch(b + 1, vp_next, wr_next);
+                        if (AHEAD && b < 3) load_batch(b + 1, vp_next, wr_next);
                         v2f d[8];
 #pragma unroll
                         for (uint32_t k = 0; k < 4; ++k) {                   // gap_junction neuron/mod.rs:54-60 ...
@@ -578,8 +596,12 @@ __device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, Res
 #pragma unroll
                         for (uint32_t k = 0; k < 8; ++k) { acc += d[k].x; acc += d[k].y; }
                         __builtin_amdgcn_sched_barrier(0);
+                        if (AHEAD) {
 #pragma unroll
-                        for (uint32_t k = 0; k < 4; ++k) { vp[k] = vp_next[k]; wr[k] = wr_next[k]; }
+                            for (uint32_t k = 0; k < 4; ++k) { vp[k] = vp_next[k]; wr[k] = wr_next[k]; }
+                        } else if (b < 3) {
+                            load_batch(b + 1, vp, wr);
+                        }
                     }
                 } else {
                     // some voltage is huge, infinite or NaN: absent edges are skipped explicitly -- the weights come from the
@@ -605,37 +627,34 @@ __device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, Res
         // (2a) this thread's cell advances (PoissonNeuron::iterate spike_train/mod.rs:411-435, RateSpikeTrain::iterate :1016-1031,
         // as k_spike_trains): spike, voltage, firing time, and the gap-junction value the NEXT step's inputs read
         if (is_cell) {
-            const CellArrays &c = a.cells;
-            const float c_dt = uload(c.uni, CP_DT, c.dt, cell);
+            const float par = sh.cell_par[0][tid], c_v_th = sh.cell_par[1][tid], c_v_resting = sh.cell_par[2][tid];
+            const float c_dt = sh.cell_par[3][tid], c_k = sh.cell_par[4][tid];
             uint32_t spike;
             if (a.st_kind == 1) {
                 const uint32_t seed = xorshift32(sh.cell_word[tid]);
                 sh.cell_word[tid] = seed;
                 const float random_number = (float)seed / 4294967296.0f;   // (float) seed / 0xFFFFFFFF
-                spike = random_number < uload(c.uni, CP_CHANCE, c.chance_of_firing, cell);
+                spike = random_number < par;
             } else {
-                const float rate = c.rate[cell];
                 float step = __uint_as_float(sh.cell_word[tid]) + c_dt;
-                spike = (rate != 0.0f) && (step >= rate);
+                spike = (par != 0.0f) && (step >= par);
                 if (spike) step = 0.0f;
                 sh.cell_word[tid] = __float_as_uint(step);
             }
-            const float c_v_th = uload(c.uni, CP_V_TH, c.v_th, cell), c_v_resting = uload(c.uni, CP_V_RESTING, c.v_resting, cell);
             const float cv = spike ? c_v_th : c_v_resting;
             sh.cell_v[tid] = cv;
             sh.cell_spiking[tid] = spike;
             int32_t lft = sh.cell_lft[tid];
             if (spike) {
-                lft = (int32_t)(a.lattice_clock[c.lattice_slot[cell]] + a.step_offset0 + (long long)s);
+                const long long clock0 = (long long)(((unsigned long long)sh.cell_clock_hi[tid] << 32) | sh.cell_clock_lo[tid]);
+                lft = (int32_t)(clock0 + (long long)s);
                 sh.cell_lft[tid] = lft;
             }
             if (writes_cells && a.st_vhist_row) a.st_vhist_row[(size_t)s * a.st_vhist_stride + cell] = cv;
             const long long view_clock = a.view_clock0 + (long long)s + 1;
-            const uint32_t refr = uload(c.uni, CP_REFR, c.refractoriness, cell);
-            const float c_k = uload(c.uni, CP_K, c.k, cell);
             sh.cell_presyn[tid] = lft < 0 ? c_v_resting
-                                          : (refr ? exponential_decay_effect(view_clock, lft, c_v_th, c_v_resting, c_k, c_dt)
-                                                  : delta_dirac_effect(view_clock, lft, c_v_th, c_v_resting, c_k, c_dt));
+                                          : (sh.cell_refr[tid] ? exponential_decay_effect(view_clock, lft, c_v_th, c_v_resting, c_k, c_dt)
+                                                               : delta_dirac_effect(view_clock, lft, c_v_th, c_v_resting, c_k, c_dt));
         }
         // (2b) several row groups per tile: the groups other than 0 publish their chunk sums, group 0 collects them -- wavefront
         // 1 + j takes remote chunk j -- behind one more barrier of its own
