@@ -291,10 +291,12 @@ struct ResidentRunShared {
     uint32_t gave_up;                            // sticky: some poll of chunk sums gave up
     // networks with cells: per row of the workgroup, its kind and -- for a cell -- its state
     uint32_t kind[RUN_RESIDENT_GROUP_ROWS];      // KIND_NEURON / KIND_ST_SILENT / KIND_ST_FIRED
+    uint32_t block_fired[16], block_silent[16];  // per 64-row block of the workgroup: all its cells have fired / none has
     uint32_t cell_word[RUN_RESIDENT_GROUP_ROWS]; // Poisson: seed; Rate: step (float bits)
     int32_t cell_lft[RUN_RESIDENT_GROUP_ROWS];
     float cell_presyn[RUN_RESIDENT_GROUP_ROWS], cell_v[RUN_RESIDENT_GROUP_ROWS];
-    float cell_s[RUN_RESIDENT_GROUP_ROWS], cell_f[RUN_RESIDENT_GROUP_ROWS];   // this step's (s, f) of a cell row, see the step loop
+    float cell_s[RUN_RESIDENT_GROUP_ROWS], cell_f[RUN_RESIDENT_GROUP_ROWS];   // this step's (s, f) of a row, see the step loop
+    float cell_n[RUN_RESIDENT_GROUP_ROWS];                                    // ... and n: 1 for a neuron's row, 0 for a cell's
     // a cell's parameters, read once: chance of firing | rate, v_th, v_resting, dt, k, refractoriness kind, and the clock of its
     // lattice at the launch's first step (64 bits in two words) -- read from the arrays every step they were a chain of
     // dependent global loads per cell
@@ -457,8 +459,20 @@ __device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, Res
             sh.kind[tid] = !is_cell ? KIND_NEURON : (silent ? KIND_ST_SILENT : KIND_ST_FIRED);
             sh.cell_s[tid] = silent ? v : 0.0f;
             sh.cell_f[tid] = silent ? 0.0f : v;
+            sh.cell_n[tid] = 0.0f;
         } else if (CELLS) {
+            // a neuron's row in the same form (the block that holds both kinds):  s + g * (f - n * vq)  with (s, f, n) = (0, v, 1)
             sh.kind[tid] = KIND_NEURON;
+            sh.cell_s[tid] = 0.0f;
+            sh.cell_f[tid] = v;
+            sh.cell_n[tid] = 1.0f;
+        }
+        if (CELLS) {
+            // rows past the end carry weight 0 and value 0: they fit both uniform forms
+            const bool cell_here = my_row >= n_neurons && my_row < n_tot;
+            const bool fired_here = cell_here && sh.cell_lft[tid] >= 0;
+            const bool fired_all = __all(!cell_here || fired_here), silent_all = __all(!cell_here || !fired_here);
+            if (lane == 0) { sh.block_fired[wave] = fired_all; sh.block_silent[wave] = silent_all; }
         }
         lap(0);
         if (!cols_in_rows && wave == 1) sh.vcol[lane] = v_col;
@@ -496,31 +510,83 @@ __device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, Res
                     return kind == KIND_NEURON ? gq * (vp - vq) : (kind == KIND_ST_SILENT ? vp : gq * vp);
                 };
                 if (plain && mixed) {
-                    // rows that are spike-train cells: the term depends on the row's kind (few wavefronts: the last rows)
-#pragma unroll 1
+                    // the one block that holds neurons and cells:  s + g * (f - n * vq), times the weight -- (0, v, 1) is the
+                    // neuron's g * (v - vq), (0, x, 0) and (x, 0, 0) the two kinds of cell; every step exact while all values are
+                    // finite (1 * vq == vq, 0 * vq == +-0, +-0 added to a sum that never holds -0)
+                    const v4f *cs = reinterpret_cast<const v4f *>(sh.cell_s + (row0 - group_row0) + zero);
+                    const v4f *cf = reinterpret_cast<const v4f *>(sh.cell_f + (row0 - group_row0) + zero);
+                    const v4f *cn = reinterpret_cast<const v4f *>(sh.cell_n + (row0 - group_row0) + zero);
+                    const v2f gq2 = {gq, gq}, vq2 = {vq, vq};
+#pragma unroll
                     for (uint32_t b = 0; b < 4; ++b) {
-                        v4f vp[4], wr[4];
-                        load_batch(b, vp, wr);
-                        // the weights of a batch by a switch on the batch: registers want constant indices
-                        if (!UPDATER) {
-#pragma unroll
-                            for (uint32_t bb = 0; bb < 4; ++bb)
-                                if (bb == b) {
-#pragma unroll
-                                    for (uint32_t k = 0; k < 4; ++k) {
-                                        const uint32_t r = 16 * bb + 4 * k;
-                                        wr[k] = v4f{w[UPDATER ? 0 : r], w[UPDATER ? 0 : r + 1], w[UPDATER ? 0 : r + 2], w[UPDATER ? 0 : r + 3]};
-                                    }
-                                }
-                        }
+                        v4f xs[4], xf[4], xn[4], wr[4];
 #pragma unroll
                         for (uint32_t k = 0; k < 4; ++k) {
-                            const uint4 kd = kinds[4 * b + k];
-                            acc += term_of(kd.x, vp[k].x) * wr[k].x;
-                            acc += term_of(kd.y, vp[k].y) * wr[k].y;
-                            acc += term_of(kd.z, vp[k].z) * wr[k].z;
-                            acc += term_of(kd.w, vp[k].w) * wr[k].w;
+                            xs[k] = cs[4 * b + k];
+                            xf[k] = cf[4 * b + k];
+                            xn[k] = cn[4 * b + k];
+                            if (UPDATER) wr[k] = sh.w0[4 * b + k][lane];
                         }
+                        v2f d[8];
+#pragma unroll
+                        for (uint32_t k = 0; k < 4; ++k) {
+                            d[2 * k] = v2f{xn[k].x, xn[k].y} * vq2;
+                            d[2 * k + 1] = v2f{xn[k].z, xn[k].w} * vq2;
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (uint32_t k = 0; k < 4; ++k) {
+                            d[2 * k] = v2f{xf[k].x, xf[k].y} - d[2 * k];
+                            d[2 * k + 1] = v2f{xf[k].z, xf[k].w} - d[2 * k + 1];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (uint32_t k = 0; k < 8; ++k) d[k] = gq2 * d[k];
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (uint32_t k = 0; k < 4; ++k) {
+                            d[2 * k] = v2f{xs[k].x, xs[k].y} + d[2 * k];
+                            d[2 * k + 1] = v2f{xs[k].z, xs[k].w} + d[2 * k + 1];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (uint32_t k = 0; k < 4; ++k) {
+                            const uint32_t r = 16 * b + 4 * k;
+                            if (!UPDATER) wr[k] = v4f{w[UPDATER ? 0 : r], w[UPDATER ? 0 : r + 1], w[UPDATER ? 0 : r + 2], w[UPDATER ? 0 : r + 3]};
+                            d[2 * k] = d[2 * k] * v2f{wr[k].x, wr[k].y};
+                            d[2 * k + 1] = d[2 * k + 1] * v2f{wr[k].z, wr[k].w};
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (uint32_t k = 0; k < 8; ++k) { acc += d[k].x; acc += d[k].y; }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else if (plain && all_cells && (sh.block_fired[(row0 - group_row0) >> 6] || sh.block_silent[(row0 - group_row0) >> 6])) {
+                    // rows that are all cells of ONE kind (after a warm-up: all have fired): g * x resp. x, times the weight
+                    const bool fired = sh.block_fired[(row0 - group_row0) >> 6] != 0u;
+                    const v2f g2 = fired ? v2f{gq, gq} : v2f{1.0f, 1.0f};         // 1 * x == x exactly
+                    v4f vp[4], wr[4];
+#pragma unroll
+                    for (uint32_t b = 0; b < 4; ++b) {
+                        load_batch(b, vp, wr);
+                        v2f d[8];
+#pragma unroll
+                        for (uint32_t k = 0; k < 4; ++k) {
+                            d[2 * k] = g2 * v2f{vp[k].x, vp[k].y};
+                            d[2 * k + 1] = g2 * v2f{vp[k].z, vp[k].w};
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (uint32_t k = 0; k < 4; ++k) {
+                            const uint32_t r = 16 * b + 4 * k;
+                            if (!UPDATER) wr[k] = v4f{w[UPDATER ? 0 : r], w[UPDATER ? 0 : r + 1], w[UPDATER ? 0 : r + 2], w[UPDATER ? 0 : r + 3]};
+                            d[2 * k] = d[2 * k] * v2f{wr[k].x, wr[k].y};
+                            d[2 * k + 1] = d[2 * k + 1] * v2f{wr[k].z, wr[k].w};
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (uint32_t k = 0; k < 8; ++k) { acc += d[k].x; acc += d[k].y; }
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 } else if (plain && all_cells) {
                     // rows that are all cells: s + g * f, times the weight -- staged like the neurons' products below
