@@ -646,7 +646,15 @@ int launch_run_resident(snn_network *net, uint64_t iterations)
 #if !SNN_HAVE_CUSTOM_MODEL
         // neuron state in registers for the whole run where the kernel carries the model's update itself
         const bool regs = !r.up.has_nt && !r.up.bcm;
-        if (net->nc) {                                       // rows that are spike-train cells: the generic update
+        if (net->nc && regs && net->model == SNN_MODEL_IZHIKEVICH) {               // rows that are spike-train cells
+            hipLaunchKernelGGL((k_run_resident<0, true, true>), grid, block, 0, net->stream, r);
+        } else if (net->nc && regs && net->model == SNN_MODEL_LIF) {
+            hipLaunchKernelGGL((k_run_resident<1, true, true>), grid, block, 0, net->stream, r);
+        } else if (net->nc && regs && net->model == SNN_MODEL_QUADRATIC_INTEGRATE_AND_FIRE) {
+            hipLaunchKernelGGL((k_run_resident<3, true, true>), grid, block, 0, net->stream, r);
+        } else if (net->nc && regs && net->model == SNN_MODEL_SIMPLE_LIF) {
+            hipLaunchKernelGGL((k_run_resident<4, true, true>), grid, block, 0, net->stream, r);
+        } else if (net->nc) {
             SNN_FOR_MODEL(SNN_RUN_RESIDENT_CELLS);
         } else if (regs && net->model == SNN_MODEL_IZHIKEVICH) {
             hipLaunchKernelGGL((k_run_resident<0, true, false>), grid, block, 0, net->stream, r);
