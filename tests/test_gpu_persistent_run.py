@@ -116,7 +116,8 @@ MODELS = [ob.IZHIKEVICH, ob.LIF, ob.HH, ob.QIF, ob.SIMPLE_LIF, ob.ADAPTIVE_LIF, 
 
 
 def draw(seed):
-    """1-3 electrical-only lattices of one model with per-neuron parameters, random density (0 included), negative weights."""
+    """1-3 electrical-only lattices of one model with per-neuron parameters, random density (0 included), negative weights;
+    every other network with one or two lattices of Poisson / Rate cells."""
     rng = np.random.default_rng(1000 + seed)
     model = MODELS[seed % len(MODELS)]
     big = seed % 5 == 0                                   # some networks beyond one row group
@@ -124,8 +125,21 @@ def draw(seed):
     for i in range(int(rng.integers(1, 4))):
         hi_side = 26 if big else 14
         lattices.append((int(2 * i + rng.integers(0, 2)), int(rng.integers(1, hi_side)), int(rng.integers(1, hi_side))))
-    net = parity.make_oracle(parity.Layout(lattices), model=model, electrical=True, chemical=False)
+    st_kind, st_lattices = ob.ST_NONE, []
+    if seed % 2:                                          # every other network: Poisson or Rate cells as presynaptic rows
+        st_kind = ob.ST_POISSON if seed % 4 == 1 else ob.ST_RATE
+        st_lattices = [(100 + i, int(rng.integers(1, 12)), int(rng.integers(1, 12))) for i in range(int(rng.integers(1, 3)))]
+    net = parity.make_oracle(parity.Layout(lattices, st_lattices), model=model, st_kind=st_kind, electrical=True, chemical=False)
     n = net.n_neurons
+    if net.n_cells:
+        nc = net.n_cells
+        net["nt_flags"][...] = 0
+        net["st_nt_flags"][...] = 0
+        net["st_seed"] = rng.integers(1, 2**32 - 1, nc, dtype=np.uint32)
+        net["st_chance_of_firing"] = ob.uniform_array(seed + 14, nc, 0.0, 0.08)
+        net["st_rate"] = ob.uniform_array(seed + 15, nc, 0.0, 6.0)
+        net["st_refractoriness"][...] = rng.integers(0, 2, nc)
+        net["st_k"] = ob.uniform_array(seed + 16, nc, 20.0, 10000.0)
     lo, hi = {ob.IZHIKEVICH: (-65, 30), ob.LIF: (-80, -50), ob.HH: (-75, -40), ob.LEAKY_IZHIKEVICH: (-65, 30)}.get(model, (-75, -56))
     net["current_voltage"] = ob.uniform_array(seed, n, lo, hi)
     net["gap_conductance"] = ob.uniform_array(seed + 1, n, 0.5, 12.0)
@@ -159,7 +173,7 @@ def draw(seed):
     return net, calls, bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(32))
 def test_random_electrical_networks(snn, seed):
     net, calls, history, counts = draw(seed)
     outs = []
@@ -176,13 +190,21 @@ def test_random_electrical_networks(snn, seed):
                 out[("v", i)], out[("s", i)] = dn.voltage_history(i), dn.spike_history(i)
             if counts:
                 out[("c", i)] = dn.spike_counts(i)
+        for i, _, _ in net.layout.st_lattices:
+            if history:
+                out[("v", i)] = dn.voltage_history(i)
         dn.close()
         outs.append(out)
     assert outs[0]["launches"] == sum(1 for c in calls if c >= 4) and outs[1]["launches"] == 0
-    net.run(sum(calls), voltage_history=history, spike_history=history, spike_counts=counts)
+    net.run(sum(calls), voltage_history=history, spike_history=history, spike_counts=counts,
+            st_voltage_history=history and net.n_cells > 0)
     rng = net.layout.ranges()
     for out in outs:
         parity.assert_state_equal(net, out["state"])
+        for i, _, _ in net.layout.st_lattices:
+            first, count, _ = rng[i]
+            if history:
+                assert np.array_equal(parity.bits(out[("v", i)]), parity.bits(net.st_voltage_history[:, first:first + count]))
         for i, _, _ in net.layout.lattices:
             first, count, _ = rng[i]
             if history:
