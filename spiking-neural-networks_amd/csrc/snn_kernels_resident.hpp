@@ -635,7 +635,7 @@ __device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, Res
                     const v2f vq2 = {vq, vq}, gq2 = {gq, gq};
                     // (the variant for networks with cells has no registers to spare for the next batch's voltages: it would spill
                     // weights to scratch inside this loop, 3 700 instead of 1 300 clocks per turn)
-                    constexpr bool AHEAD = !CELLS || UPDATER;
+                    constexpr bool AHEAD = !CELLS || UPDATER || REGISTERS;
                     v4f vp[4], wr[4], vp_next[4], wr_next[4];
                     load_batch(0, vp, wr);
 #pragma unroll
