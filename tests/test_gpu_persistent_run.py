@@ -282,3 +282,28 @@ def test_networks_with_spike_train_cells(snn, model, lattices, st_lattices, st_k
         for i, _, _ in net.layout.st_lattices:
             first, count, _ = rng[i]
             assert np.array_equal(parity.bits(out[("v", i)]), parity.bits(net.st_voltage_history[:, first:first + count]))
+
+
+@pytest.mark.parametrize("rows,cols,cells,steps", [(32, 32, 0, 40000), (64, 64, 0, 20000), (30, 30, 20, 20000)])
+def test_long_runs_agree(snn, rows, cols, cells, steps):
+    """Tens of thousands of steps in one launch (the hand-offs between workgroups are timing dependent: a protocol error would
+    show as a stall or as a diverging trajectory) against one launch per step: identical final state, device against device."""
+    if cells:
+        net = build_with_cells(ob.IZHIKEVICH, [(0, rows, cols)], [(5, cells, cells)], ob.ST_POISSON, 71, density=0.2)
+    else:
+        net = build(ob.IZHIKEVICH, rows, cols, 72, density=0.3)
+    states = []
+    for persistent in (1, 0):
+        dn = parity.device_from_oracle(snn, net)
+        dn.set_option("persistent_run", persistent)
+        dn.set_reduced_history(spike_counts=True)
+        dn.run(steps // 2)
+        dn.run(steps - steps // 2)
+        states.append((parity.pull_state(dn, net), [dn.spike_counts(i) for i, _, _ in net.layout.lattices],
+                       dn.stat("persistent_run_steps")))
+        dn.close()
+    assert states[0][2] == steps and states[1][2] == 0
+    for name in states[0][0]:
+        assert np.array_equal(parity.bits(states[0][0][name]), parity.bits(states[1][0][name])), name
+    for a, b in zip(states[0][1], states[1][1]):
+        assert np.array_equal(a, b) and int(np.asarray(a).sum()) > 0
