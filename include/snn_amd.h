@@ -372,9 +372,10 @@ int snn_get_spike_counts(snn_network_t *net, uint32_t id, uint32_t *dst, size_t 
  * handle is created: SNN_AMD_<NAME in upper case>): "fused_step" [1] one-launch step for small lattices; "defer_rstdp"
  * [1] reward-modulated weight updates riding on the next input pass; "defer_stdp" [0] 1: STDP updates riding on the next
  * input pass, 2: prepared delta vectors applied by scatter passes; "uniform_params" [1] population-wide parameter
- * values from a device table; "persistent_run" [1] all steps of an snn_run call on a small electrical-only lattice of
- * neurons, with or without Poisson / Rate cells (<= 4096 rows, no plasticity) in ONE launch; "input_shape" [0] 1 | 2 forces the 4- / 2-columns-per-lane shape of the streamed dense
- * input pass (0: chosen by size).  Unknown names fail with SNN_ERR_BAD_ARG. */
+ * values from a device table; "persistent_run" [1] all steps of an snn_run call (of 4 steps or more) on a small
+ * electrical-only network -- neurons, with or without Poisson / Rate cells; <= 4096 rows, no plasticity -- in ONE launch;
+ * "input_shape" [0] 1 | 2 forces the 4- / 2-columns-per-lane shape of the streamed dense input pass (0: chosen by size).
+ * Unknown names fail with SNN_ERR_BAD_ARG. */
 int snn_set_option(snn_network_t *net, const char *name, int value);
 /* Which step form the handle has used so far, as launch counts since creation: "persistent_run_launches" (k_run_resident:
  * many steps per launch), "persistent_run_steps" (steps those launches covered).  Unknown names fail with SNN_ERR_BAD_ARG. */
