@@ -308,7 +308,8 @@ struct ResidentRunShared {
 // The step loop of one wavefront.  UPDATER = wavefront 0, which also owns the neuron update of the workgroup's 64 columns: it
 // keeps its weights in LDS and, for Izhikevich neurons without transmitters, the neurons' state in registers for the whole
 // run (same expressions as update_neuron, integrate_and_fire/mod.rs:217-255); the other wavefronts keep 64 weights per lane
-// in registers.  Every wavefront of a workgroup passes the same workgroup barriers per step (five; group 0 of a multi-group tile one more).
+// in registers.  Every wavefront of a workgroup passes the same workgroup barriers per step (one behind the polls, one per turn --
+// four, fewer for networks under 256 rows --; group 0 of a multi-group tile one more).
 template <int MODEL, bool UPDATER, bool REGISTERS, bool CELLS>
 __device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, ResidentRunShared &sh, const uint32_t wave)
 {
