@@ -1,7 +1,9 @@
-"""Golden cases shared by tests/golden/make_golden.py (writes the fixtures with the oracle), the CPU test
-that pins the oracle to them, and the GPU test that holds the HIP stepper to the SAME committed vectors.
-The reference holds no golden vectors for this path (every test draws from thread_rng), so
-these are produced here by the pinned oracle; inputs are fully specified by the builders below."""
+"""Golden cases shared by tests/golden/make_golden.py (writes the fixtures with the numpy restatement
+tests/numpy_net.py), the CPU tests that pin the C oracle and that restatement to them, and the GPU test that holds the
+HIP stepper to the SAME committed vectors.  The reference holds no golden vectors for this path (every test draws from
+thread_rng), so these are produced here -- by the numpy restatement with the host libm, as SURVEY
+section 8c specifies -- and each vector therefore pins two independently written CPU implementations.  The builders below
+only lay out INPUT arrays (in an oracle-binding container, which also serves as the oracle's input)."""
 import numpy as np
 
 import oracle_binding as ob
