@@ -371,6 +371,84 @@ void snn_o_fill_graph_window_blocked(float *weights, uint8_t *connections, uint3
         }
 }
 
+/*
+ * Step 1 over a SPARSE graph given as CSR by postsynaptic neuron: row q holds the presynaptic indices
+ * pre[row_ptr[q] .. row_ptr[q+1]) in ascending order with their weights -- every stored entry is a Some(w) edge of
+ * the AdjacencyMatrix (graph/mod.rs:139-297), everything else None.  Same arithmetic as inputs_block: the canonical
+ * chunk of an entry is pre / SNN_O_CHUNK, a chunk's partial starts at 0.0f, partials are added in ascending chunk order
+ * (chunks without an entry would add a 0.0f partial: no change), n_in = the row length (mod.rs:722-729).
+ * BASELINE configs[4] (4 x 512^2 neurons + Poisson cells) is only representable this way: dense it is 4.4 TB.
+ */
+void snn_o_inputs_csr(snn_o_net *n, const uint64_t *row_ptr, const uint32_t *pre, const float *w,
+                      uint32_t q0, uint32_t q1)
+{
+    const uint32_t nn = n->n_neurons;
+    /* presynaptic value of every spike-train cell at this clock, once (spike_train_gap_junction mod.rs:119-137) */
+    float *cell_v = n->n_cells ? (float *)malloc(sizeof(float) * n->n_cells) : NULL;
+    for (uint32_t s = 0; s < n->n_cells; ++s) {
+        if (n->st_last_firing_time[s] < 0) { cell_v[s] = n->st_v_resting[s]; continue; }
+        cell_v[s] = (n->st_refractoriness && n->st_refractoriness[s] == 2) ? custom_refractoriness_effect(n, s)
+            : (n->st_refractoriness && n->st_refractoriness[s])
+            ? snn_o_exponential_decay_effect(n->clock, n->st_last_firing_time[s], n->st_v_th[s], n->st_v_resting[s],
+                                             n->st_k[s], n->st_dt[s])
+            : snn_o_delta_dirac_effect(n->clock, n->st_last_firing_time[s], n->st_v_th[s], n->st_v_resting[s],
+                                       n->st_k[s], n->st_dt[s]);
+    }
+#if defined(_OPENMP)
+    int nt = n->n_threads > 1 ? n->n_threads : 1;
+    #pragma omp parallel for schedule(static) num_threads(nt)
+#endif
+    for (int64_t qq = q0; qq < (int64_t)q1; ++qq) {
+        const uint32_t q = (uint32_t)qq;
+        const float vq = n->current_voltage[q], gq = n->gap_conductance[q];
+        float sum = 0.0f, part = 0.0f;
+        float tsum[SNN_O_K] = {0.0f, 0.0f, 0.0f}, tpart[SNN_O_K] = {0.0f, 0.0f, 0.0f};
+        uint32_t tcnt[SNN_O_K] = {0, 0, 0};
+        int64_t chunk = -1;
+        for (uint64_t e = row_ptr[q]; e < row_ptr[q + 1]; ++e) {
+            const uint32_t p = pre[e];
+            const int64_t c = p / SNN_O_CHUNK;
+            if (c != chunk) {
+                if (chunk >= 0) {
+                    sum += part;
+                    for (int k = 0; k < SNN_O_K; ++k) tsum[k] += tpart[k];
+                }
+                part = 0.0f;
+                for (int k = 0; k < SNN_O_K; ++k) tpart[k] = 0.0f;
+                chunk = c;
+            }
+            if (n->electrical) {
+                if (p < nn) part += (gq * (n->current_voltage[p] - vq)) * w[e];
+                else if (n->st_last_firing_time[p - nn] < 0) part += cell_v[p - nn] * w[e];   /* no conductance factor */
+                else part += (gq * cell_v[p - nn]) * w[e];
+            }
+            if (n->chemical) {
+                for (int k = 0; k < SNN_O_K; ++k) {
+                    uint32_t flag; float t;
+                    if (p < nn) { flag = n->nt_flags[(size_t)p * SNN_O_K + k]; t = n->nt_t[(size_t)p * SNN_O_K + k]; }
+                    else { flag = n->st_nt_flags[(size_t)(p - nn) * SNN_O_K + k]; t = n->st_nt_t[(size_t)(p - nn) * SNN_O_K + k]; }
+                    if (!flag) continue;
+                    tpart[k] += t * w[e];
+                    ++tcnt[k];
+                }
+            }
+        }
+        if (chunk >= 0) {
+            sum += part;
+            for (int k = 0; k < SNN_O_K; ++k) tsum[k] += tpart[k];
+        }
+        const uint64_t n_in = row_ptr[q + 1] - row_ptr[q];
+        n->input_current[q] = n->electrical ? sum / ((n_in == 0) ? 1.0f : (float)n_in) : 0.0f;
+        if (n->chemical) {
+            for (int k = 0; k < SNN_O_K; ++k) {
+                n->input_count[(size_t)q * SNN_O_K + k] = (float)tcnt[k];
+                n->input_t[(size_t)q * SNN_O_K + k] = tcnt[k] ? tsum[k] / (float)tcnt[k] : 0.0f;
+            }
+        }
+    }
+    free(cell_v);
+}
+
 /* ---------- step 2: neuron update ---------- */
 
 /* NeurotransmitterKinetics::apply_t_change: Approximate iterate_and_spike/mod.rs:193-196,
@@ -976,6 +1054,9 @@ void snn_o_plasticity_cols(snn_o_net *n, uint32_t c0, uint32_t c1)
 {
     const uint32_t nn = n->n_neurons;
     const uint32_t n_tot = nn + n->n_cells;
+    /* the matrix may be a column window [w_col0, w_col0 + w_ld) (full-size teacher-forced checks); [c0, c1) lies in it */
+    const size_t ld = n->w_ld ? n->w_ld : nn;
+    const uint32_t col0 = n->w_col0;
     if (!n->do_plasticity) return;
 
     for (uint32_t j = 0; j < nn; ++j) {
@@ -984,7 +1065,7 @@ void snn_o_plasticity_cols(snn_o_net *n, uint32_t c0, uint32_t c1)
         if (j >= c0 && j < c1) {
             uint32_t l = n->lattice[j];
             for (uint32_t p = 0; p < n_tot; ++p) {
-                size_t i = (size_t)p * nn + j;
+                size_t i = (size_t)p * ld + (j - col0);
                 if (!n->connections[i]) continue;
                 if (n->plasticity_kind && n->plasticity_kind[l]) {
                     float pre = (p < nn) ? n->bcm_current_activity[p] : n->st_bcm_current_activity[p - nn];
@@ -999,7 +1080,7 @@ void snn_o_plasticity_cols(snn_o_net *n, uint32_t c0, uint32_t c1)
         }
         /* outgoing edges of j */
         for (uint32_t r = c0; r < c1; ++r) {
-            size_t i = (size_t)j * nn + r;
+            size_t i = (size_t)j * ld + (r - col0);
             if (!n->connections[i]) continue;
             uint32_t l = n->lattice[r];
             if (n->plasticity_kind && n->plasticity_kind[l]) {
@@ -1194,5 +1275,24 @@ void snn_o_run(snn_o_net *n, uint64_t iterations)
                 memcpy(n->st_voltage_history + (size_t)it * n->n_cells, n->st_current_voltage,
                        sizeof(float) * n->n_cells);
         }
+    }
+}
+
+/* the same loop over a sparse graph (snn_o_inputs_csr); no plasticity, histories optional */
+void snn_o_run_csr(snn_o_net *n, const uint64_t *row_ptr, const uint32_t *pre, const float *w, uint64_t iterations)
+{
+    if (!n->electrical && !n->chemical) return;
+    for (uint64_t it = 0; it < iterations; ++it) {
+        if (n->n_neurons) {
+            snn_o_inputs_csr(n, row_ptr, pre, w, 0, n->n_neurons);
+            snn_o_update_neurons(n);
+            if (n->voltage_history)
+                memcpy(n->voltage_history + (size_t)it * n->n_neurons, n->current_voltage, sizeof(float) * n->n_neurons);
+            if (n->spike_history)
+                for (uint32_t q = 0; q < n->n_neurons; ++q)
+                    n->spike_history[(size_t)it * n->n_neurons + q] = (uint8_t)n->is_spiking[q];
+        }
+        n->clock += 1;
+        if (n->n_cells) snn_o_spike_trains(n);
     }
 }

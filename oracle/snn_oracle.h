@@ -241,6 +241,12 @@ void snn_o_reward_modulation_cols(snn_o_net *n, uint32_t c0, uint32_t c1);
 void snn_o_plasticity_cols(snn_o_net *net, uint32_t c0, uint32_t c1);
 /* Step 6: iterate every spike-train cell once. */
 void snn_o_spike_trains(snn_o_net *net);
+/* Step 1 for posts [q0, q1) over a sparse graph in CSR-by-post form (ascending presynaptic indices per row): the same
+ * canonical chunked order as the dense routine, bit-identical to it on the same graph; and the whole loop over it
+ * (no plasticity) -- BASELINE configs[4] at full size */
+void snn_o_inputs_csr(snn_o_net *net, const uint64_t *row_ptr, const uint32_t *pre, const float *w,
+                      uint32_t q0, uint32_t q1);
+void snn_o_run_csr(snn_o_net *net, const uint64_t *row_ptr, const uint32_t *pre, const float *w, uint64_t iterations);
 /* Whole loop (steps 1-6) `iterations` times, filling the optional histories. */
 void snn_o_run(snn_o_net *net, uint64_t iterations);
 /* Step 1 for [q0, q1) arranged for all-core memory bandwidth (bench.py's cpu_baseline); same results bit for bit */

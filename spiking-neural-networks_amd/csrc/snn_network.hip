@@ -1076,14 +1076,20 @@ int snn_comm_exchange_halo_lists(snn_network_t *net, void *nccl_comm)
     if (!need_flat.empty())
         HALO_STEP(hip_ok(hipMemcpy(d_need, need_flat.data(), need_flat.size() * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE, "lists upload"));
     HALO_STEP(nccl_ok(R->GroupStart(), "ncclGroupStart"));
-    for (uint32_t p = 0; p < G; ++p) {
-        if (p == me) continue;
-        if (need_off[p + 1] > need_off[p])
-            HALO_STEP(nccl_ok(R->Send(d_need + need_off[p], need_off[p + 1] - need_off[p], ncclUint32, (int)p, comm, net->stream), "ncclSend(list)"));
-        if (send_off[p + 1] > send_off[p])
-            HALO_STEP(nccl_ok(R->Recv(d_send + send_off[p], send_off[p + 1] - send_off[p], ncclUint32, (int)p, comm, net->stream), "ncclRecv(list)"));
+    {
+        // a failure inside the group still closes it (a dangling group would swallow every later RCCL call of this thread)
+        int first = SNN_OK;
+        for (uint32_t p = 0; p < G && !first; ++p) {
+            if (p == me) continue;
+            if (need_off[p + 1] > need_off[p])
+                first = nccl_ok(R->Send(d_need + need_off[p], need_off[p + 1] - need_off[p], ncclUint32, (int)p, comm, net->stream), "ncclSend(list)");
+            if (!first && send_off[p + 1] > send_off[p])
+                first = nccl_ok(R->Recv(d_send + send_off[p], send_off[p + 1] - send_off[p], ncclUint32, (int)p, comm, net->stream), "ncclRecv(list)");
+        }
+        const ncclResult_t closed = R->GroupEnd();
+        HALO_STEP(first);
+        HALO_STEP(nccl_ok(closed, "ncclGroupEnd"));
     }
-    HALO_STEP(nccl_ok(R->GroupEnd(), "ncclGroupEnd"));
     HALO_STEP(hip_ok(hipStreamSynchronize(net->stream), SNN_ERR_WAIT, "lists wait"));
     if (!send_flat.empty())
         HALO_STEP(hip_ok(hipMemcpy(send_flat.data(), d_send, send_flat.size() * 4, hipMemcpyDeviceToHost), SNN_ERR_BUFFER_READ, "lists download"));
@@ -1127,6 +1133,49 @@ int snn_run_sharded_custom(snn_network_t *net, snn_exchange_fn exchange, void *u
     return end_run(net, /*keep_stdp=*/true);
 }
 
+// The ranks of a communicator agree on HOW they exchange before the first step of a run: a rank that decided from its
+// own state alone (no graph yet, lists committed by hand while the peers' are not, other synapse kinds) would skip or
+// mismatch the collective its peers block in -- a hang instead of an error.  One word per rank is all-gathered: graph
+// form, whether the halo lists are committed, and (after the plan is built) the planes on the wire.
+static int agree_on_exchange(Rccl *R, snn_network *net, ncclComm_t comm, void *nccl_comm)
+{
+    const uint32_t G = net->n_shards, me = net->shard_index;
+    uint32_t *d_words = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_words), std::max<size_t>((size_t)G * 4, 256)), SNN_ERR_BUFFER_CREATE);
+    std::vector<uint32_t> words(G, 0);
+    auto gather = [&](uint32_t mine) -> int {
+        words.assign(G, 0);
+        words[me] = mine;
+        if (hipMemcpy(d_words, words.data(), (size_t)G * 4, hipMemcpyHostToDevice) != hipSuccess) return fail(SNN_ERR_BUFFER_WRITE, "agreement upload");
+        const ncclResult_t r = R->AllGather(d_words + me, d_words, 1, ncclUint32, comm, net->stream);
+        if (r != ncclSuccess) return fail(SNN_ERR_QUEUE, std::string("ncclAllGather(agreement): ") + R->GetErrorString(r));
+        if (hipStreamSynchronize(net->stream) != hipSuccess) return fail(SNN_ERR_WAIT, "agreement wait");
+        if (hipMemcpy(words.data(), d_words, (size_t)G * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(SNN_ERR_BUFFER_READ, "agreement download");
+        return SNN_OK;
+    };
+    int rc = gather((net->csr ? 1u : 0u) | (net->halo_committed ? 2u : 0u) | (net->block_mode ? 4u : 0u));
+    bool all_committed = true;
+    for (uint32_t p = 0; p < G && !rc; ++p) {
+        if ((words[p] & 5u) != (words[me] & 5u))
+            rc = fail(SNN_ERR_BAD_STATE, "the ranks of this communicator hold different graph forms (dense / CSR / by-lattice shards)");
+        all_committed = all_committed && (words[p] & 2u);
+    }
+    // sparse handles: unless EVERY rank has its lists committed, every rank trades them now (a rank without rows asks for nothing)
+    if (!rc && net->csr && !all_committed) rc = snn_comm_exchange_halo_lists(net, nccl_comm);
+    if (!rc) rc = ensure_exchange_plan(net);
+    if (!rc) {
+        uint32_t mask = (uint32_t)net->x_mode << 8;
+        for (uint32_t s = 0; s < net->x_planes; ++s) mask |= 1u << net->x_plane_id[s];
+        rc = gather(mask);
+        for (uint32_t p = 0; p < G && !rc; ++p)
+            if (words[p] != mask)
+                rc = fail(SNN_ERR_BAD_STATE, "the ranks of this communicator disagree on the exchange (synapse kinds / transmitter types / mode)");
+    }
+    (void)hipFree(d_words);
+    if (!rc) net->x_agreed = true;
+    return rc;
+}
+
 int snn_run_sharded(snn_network_t *net, void *nccl_comm, uint64_t iterations)
 {
     if (!net || !nccl_comm) return fail(SNN_ERR_BAD_ARG, "null argument");
@@ -1137,7 +1186,10 @@ int snn_run_sharded(snn_network_t *net, void *nccl_comm, uint64_t iterations)
     ncclComm_t comm = static_cast<ncclComm_t>(nccl_comm);
     HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
     TRY(comm_geometry(R, net, comm));
-    if (net->csr && net->n_shards > 1 && !net->halo_committed && net->csr_ptr) TRY(snn_comm_exchange_halo_lists(net, nccl_comm));
+    if (net->n_shards > 1 && (!net->x_agreed || net->x_dirty)) {
+        TRY(end_run(net));
+        TRY(agree_on_exchange(R, net, comm, nccl_comm));
+    }
     TRY(begin_run(net, iterations));
     TRY(ensure_comm_objects(net));
     // The own-rows part of step t + 1's input pass does not read what the exchange of step t delivers: it is enqueued
@@ -1157,7 +1209,7 @@ int snn_run_sharded(snn_network_t *net, void *nccl_comm, uint64_t iterations)
         }
         HIP_TRY(hipStreamWaitEvent(net->stream, net->ev_exchanged, 0), SNN_ERR_QUEUE);
         TRY(step_end(net));
-        if (net->profile && net->ev_used >= 8192) TRY(collect_profile(net));
+        if (net->profile && (net->ev_used >= 8192 || net->ev_used_pl >= 8192)) TRY(collect_profile(net));
     }
     return end_run(net, /*keep_stdp=*/true);
 }

@@ -58,6 +58,7 @@ int ensure_exchange_plan(snn_network *net)
 {
     if (!net->x_dirty) return SNN_OK;
     if (!net->sharded) { net->x_dirty = false; return SNN_OK; }
+    net->x_agreed = false;                                           // a rebuilt plan is compared with the peers' again
     HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);        // nothing in flight reads the old tables
     // planes: voltage for gap junctions; t of the types some NEURON releases for chemical synapses
     net->x_planes = 0;
@@ -203,27 +204,37 @@ struct Rccl {
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    std::string err;                              // why `lib` is null (dlerror() read ONCE, at the failing call)
 };
 
 void rccl_resolve(Rccl &r);
 
-Rccl *rccl()
+Rccl &rccl_state()
 {
     static Rccl r;
     static std::once_flag once;               // handles of different threads may reach for RCCL at the same time
     std::call_once(once, [] { rccl_resolve(r); });
-    return r.lib ? &r : nullptr;
+    return r;
 }
+Rccl *rccl() { Rccl &r = rccl_state(); return r.lib ? &r : nullptr; }
 
 void rccl_resolve(Rccl &r)
 {
     for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
         r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
         if (r.lib) break;
+        const char *e = dlerror();                // dlerror() clears itself: one call, kept
+        r.err = e ? e : "dlopen failed";
     }
     if (!r.lib) return;
+    r.err.clear();
     bool ok = true;
-    auto sym = [&](const char *n) { void *p = dlsym(r.lib, n); ok = ok && p; return p; };
+    auto sym = [&](const char *n) {
+        void *p = dlsym(r.lib, n);
+        if (!p && ok) r.err = std::string("symbol missing: ") + n;
+        ok = ok && p;
+        return p;
+    };
     r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
     r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
     r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
@@ -240,7 +251,7 @@ void rccl_resolve(Rccl &r)
 
 #define RCCL_LIB(R)                                                                               \
     Rccl *R = rccl();                                                                              \
-    if (!R) return fail(SNN_ERR_BAD_STATE, std::string("librccl.so.1 could not be loaded: ") + (dlerror() ? dlerror() : "symbols missing"))
+    if (!R) return fail(SNN_ERR_BAD_STATE, std::string("librccl.so.1 could not be loaded: ") + rccl_state().err)
 #define RCCL_TRY(R, expr)                                                                         \
     do {                                                                                           \
         ncclResult_t r_ = (expr);                                                                  \
@@ -267,14 +278,24 @@ int enqueue_exchange(Rccl *R, snn_network *net, ncclComm_t comm, hipStream_t str
         return SNN_OK;
     }
     RCCL_TRY(R, R->GroupStart());
-    for (uint32_t p = 0; p < net->n_shards; ++p) {
+    // a failing call must not leave the thread's group open (every later RCCL call of this thread would queue into it):
+    // remember the first error, always close the group, then report
+    ncclResult_t first = ncclSuccess;
+    const char *what = "";
+    for (uint32_t p = 0; p < net->n_shards && first == ncclSuccess; ++p) {
         if (p == net->shard_index) continue;
-        if (net->x_send_words[p])
-            RCCL_TRY(R, R->Send(net->halo_send_buf + net->x_send_off[p], net->x_send_words[p], ncclUint32, (int)p, comm, stream));
-        if (net->x_recv_words[p])
-            RCCL_TRY(R, R->Recv(net->halo_recv_buf + net->x_recv_off[p], net->x_recv_words[p], ncclUint32, (int)p, comm, stream));
+        if (net->x_send_words[p]) {
+            first = R->Send(net->halo_send_buf + net->x_send_off[p], net->x_send_words[p], ncclUint32, (int)p, comm, stream);
+            what = "ncclSend";
+        }
+        if (first == ncclSuccess && net->x_recv_words[p]) {
+            first = R->Recv(net->halo_recv_buf + net->x_recv_off[p], net->x_recv_words[p], ncclUint32, (int)p, comm, stream);
+            what = "ncclRecv";
+        }
     }
-    RCCL_TRY(R, R->GroupEnd());
+    const ncclResult_t closed = R->GroupEnd();
+    if (first != ncclSuccess) return fail(SNN_ERR_QUEUE, std::string(what) + ": " + R->GetErrorString(first));
+    if (closed != ncclSuccess) return fail(SNN_ERR_QUEUE, std::string("ncclGroupEnd: ") + R->GetErrorString(closed));
     return SNN_OK;
 }
 

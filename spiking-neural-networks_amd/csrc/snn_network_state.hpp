@@ -121,6 +121,7 @@ struct snn_network {
     RowMap rowmap{};
     // ---- exchange plan (snn_kernels_exchange.hpp), rebuilt by ensure_exchange_plan when x_dirty ----
     bool x_dirty = true;
+    bool x_agreed = false;                      // the ranks of the communicator compared their plans (snn_run_sharded)
     int x_mode = SNN_EXCHANGE_ALLGATHER;
     uint32_t x_planes = 0, x_plane_id[WIRE_MAX_PLANES] = {0, 0, 0, 0};
     uint64_t x_block_words = 0;                 // all-gather: words per shard slot

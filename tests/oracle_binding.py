@@ -161,6 +161,10 @@ def lib():
         L.snn_o_fill_graph_window_blocked.restype = None
         L.snn_o_inputs_tiled.argtypes = [P, C.c_uint32, C.c_uint32, C.c_uint32]
         L.snn_o_inputs_tiled.restype = None
+        L.snn_o_inputs_csr.argtypes = [P, C.POINTER(C.c_uint64), u32p, f32p, C.c_uint32, C.c_uint32]
+        L.snn_o_inputs_csr.restype = None
+        L.snn_o_run_csr.argtypes = [P, C.POINTER(C.c_uint64), u32p, f32p, C.c_uint64]
+        L.snn_o_run_csr.restype = None
         _lib = L
     return _lib
 
@@ -240,7 +244,8 @@ class Net:
 
     def __init__(self, n_neurons, model=IZHIKEVICH, n_cells=0, st_kind=ST_NONE, n_lattices=1,
                  n_st_lattices=None, nt_kind=NT_APPROX, rc_kind=RC_APPROX,
-                 electrical=True, chemical=False):
+                 electrical=True, chemical=False, dense=True):
+        """dense=False leaves the [n_tot][n_neurons] graph arrays out (sparse networks: inputs_csr / run_csr)"""
         self.n_neurons, self.n_cells = int(n_neurons), int(n_cells)
         self.n_tot = self.n_neurons + self.n_cells
         self.model, self.nt_kind, self.rc_kind, self.st_kind = model, nt_kind, rc_kind, st_kind
@@ -275,6 +280,8 @@ class Net:
             elif name == "st_clock":
                 shape = (self.n_st_lattices,)
             elif name in ("weights", "connections", "traces"):
+                if not dense:
+                    continue
                 shape = (self.n_tot, nn)
             elif name == "input_current":
                 shape = (nn,)
@@ -390,6 +397,26 @@ class Net:
         c = self._cnet()
         lib().snn_o_inputs_tiled(C.byref(c), q0, q1, block)
 
+    def _csr_args(self, row_ptr, pre, w):
+        assert row_ptr.dtype == np.uint64 and pre.dtype == np.uint32 and w.dtype == np.float32
+        assert row_ptr.size == self.n_neurons + 1 and pre.size == w.size == int(row_ptr[-1])
+        return (row_ptr.ctypes.data_as(C.POINTER(C.c_uint64)), pre.ctypes.data_as(u32p), w.ctypes.data_as(f32p))
+
+    def inputs_csr(self, row_ptr, pre, w, q0=0, q1=None):
+        """step 1 over a sparse graph (CSR by post, ascending presynaptic indices per row)"""
+        c = self._cnet()
+        lib().snn_o_inputs_csr(C.byref(c), *self._csr_args(row_ptr, pre, w), q0, self.n_neurons if q1 is None else q1)
+
+    def run_csr(self, row_ptr, pre, w, iterations, voltage_history=False, spike_history=False):
+        it = int(iterations)
+        self.voltage_history = np.zeros((it, self.n_neurons), np.float32) if voltage_history else None
+        self.spike_history = np.zeros((it, self.n_neurons), np.uint8) if spike_history else None
+        self.st_voltage_history = None
+        c = self._cnet()
+        lib().snn_o_run_csr(C.byref(c), *self._csr_args(row_ptr, pre, w), it)
+        self._sync_back(c)
+        return self
+
     def update_neurons(self, q0=None, q1=None):
         c = self._cnet()
         if q0 is None:
@@ -437,6 +464,34 @@ class Net:
         lib().snn_o_run(C.byref(c), it)
         self._sync_back(c)
         return self
+
+
+def usable_cpus(limit=64):
+    """threads worth starting: the visible CPUs capped by the container's CPU quota (cgroup v2 cpu.max / v1 cfs)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(p))))
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, int(q / p)))
+        except (OSError, ValueError):
+            pass
+    return max(1, min(n, limit))
+
+
+def mem_available_bytes():
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                return int(line.split()[1]) * 1024
+    except OSError:
+        pass
+    return 16 << 30
 
 
 def expf(x):

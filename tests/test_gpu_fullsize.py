@@ -1,14 +1,17 @@
 """Parity at BASELINE.json's full sizes.
 
-* configs[1] (256x256 Izhikevich, dense, 17.18 GB of weights generated on the device): the oracle cannot hold
-  the matrix, so it is teacher-forced on WINDOWS of postsynaptic columns -- for each step the oracle
-  recomputes, from the GPU's own state S(t) and the same counter-based weights, the inputs and the update
-  of every sampled neuron and must reproduce the GPU's S(t+1) for them bit for bit.
+* configs[1] (256x256 Izhikevich, dense, 17.18 GB of weights generated on the device): ALL 65 536 postsynaptic
+  neurons, teacher-forced -- for each step the oracle recomputes, from the GPU's own state S(t) and the same
+  counter-based weights (a 21.5 GB host copy, or column windows that cover the population when memory is short),
+  the inputs and the update of every neuron and must reproduce the GPU's S(t+1) bit for bit.
 * configs[2] (128x128 Hodgkin-Huxley + Na/K + Destexhe AMPA, electrical + chemical): full oracle run.
 * configs[3]-shaped excitatory/inhibitory network with STDP at a size the host can hold (20 480 neurons).
+* configs[3] at full size (81 920 neurons, 26.8 GB): the same for every neuron, plus the deferred STDP of every spiking
+  neuron applied to the oracle's host copy and ALL 6.7 G weights compared after the last step.
 * configs[4] (4 x 512^2 Izhikevich neurons + 4 x 512^2 Poisson cells, sparse): the oracle's dense matrix would need
-  4.4 TB; a vectorised numpy restatement of the sparse step (canonical chunked order over <= 14 sorted entries per
-  row, float32 with one rounding per operation) runs the full size next to the device.
+  4.4 TB; the oracle's CSR-by-post routine (snn_o_run_csr, same canonical chunk flush) runs the full size next to the
+  device, with a vectorised numpy restatement of the sparse step (float32, one rounding per operation) as the second
+  witness.
 """
 import numpy as np
 import pytest
@@ -19,10 +22,35 @@ import parity
 pytestmark = pytest.mark.gpu
 
 
-def test_c2_256x256_sampled_columns_teacher_forced(snn):
+def column_windows(n, n_rows, budget_bytes, block=1024):
+    """[c0, c1) windows (multiples of `block`) that together cover all n postsynaptic columns, each small enough for a
+    host copy of its [n_rows][c1 - c0] weights + connection flags (5 B per synapse) to fit the budget"""
+    fit = max(block, int(budget_bytes // (5 * n_rows)) // block * block)
+    return [(c0, min(n, c0 + fit)) for c0 in range(0, n, fit)]
+
+
+def window_net(n, n_lattices, c0, c1, seed, threads):
+    """an oracle net of n Izhikevich neurons holding the postsynaptic columns [c0, c1) of the synthetic graph"""
+    net = ob.Net(n, model=ob.IZHIKEVICH, n_lattices=n_lattices, dense=False)
+    net.arr["weights"] = np.empty((n, c1 - c0), np.float32)
+    net.arr["connections"] = np.empty((n, c1 - c0), np.uint8)
+    net.w_col0, net.w_ld = c0, c1 - c0
+    ob.lib().snn_o_fill_graph_window_blocked(net["weights"].ctypes.data_as(ob.f32p), net["connections"].ctypes.data_as(ob.u8p),
+                                             n, n, c0, c1 - c0, 1024, seed, 0.5, 1.5, 0, threads)
+    net["gap_conductance"] = 10.0
+    net.n_threads = threads
+    return net
+
+
+def test_c2_256x256_all_columns_teacher_forced(snn):
+    """BASELINE configs[1] at full size, EVERY postsynaptic neuron: for each step the oracle recomputes, from the
+    GPU's own state S(t) and the same counter-based weights, the input sum (all 65 536 presynaptic terms) and the update
+    of all 65 536 neurons and must reproduce the GPU's S(t+1) bit for bit.  The host copy of the matrix (21.5 GB) is
+    held whole when MemAvailable allows, else in column windows that together cover the population."""
     from snn_amd import synthetic
     rows = cols = 256
     n = rows * cols
+    steps = 4
     dn = snn.DeviceNetwork(model=snn.IZHIKEVICH)
     dn.add_lattice(0, rows, cols)
     dn.finalize()
@@ -39,42 +67,40 @@ def test_c2_256x256_sampled_columns_teacher_forced(snn):
         want[p] = 0.0
         assert np.array_equal(w[0].view(np.uint32), want.view(np.uint32)) and c[0].sum() == n - 1 and c[0, p] == 0
 
-    windows = [(0, 128), (960, 1088), (32768 - 64, 32768 + 64), (n - 128, n)]   # tile / shard / end boundaries
-    nets = []
-    for c0, c1 in windows:
-        net = ob.Net(n, model=ob.IZHIKEVICH)
-        net.arr["weights"] = np.empty((n, c1 - c0), np.float32)
-        net.arr["connections"] = np.empty((n, c1 - c0), np.uint8)
-        net.w_col0, net.w_ld = c0, c1 - c0
-        ob.lib().snn_o_fill_graph_window(net["weights"].ctypes.data_as(ob.f32p), net["connections"].ctypes.data_as(ob.u8p),
-                                         n, n, c0, c1 - c0, 2, 0.5, 1.5, 0)
-        net["gap_conductance"] = 10.0
-        net.n_threads = 8
-        nets.append(net)
+    def snapshot():
+        return {"current_voltage": dn.get_attr(0, "current_voltage"), "w_value": dn.get_attr(0, "w_value"),
+                "is_spiking": dn.get_attr(0, "is_spiking", dtype=np.uint32),
+                "last_firing_time": dn.get_attr(0, "last_firing_time", dtype=np.int32)}
 
-    state = {k: dn.get_attr(0, k) for k in ("current_voltage", "w_value")}
-    spikes_seen = 0
-    for step in range(6):
+    states = [snapshot()]
+    for _ in range(steps):
         dn.run(1)
-        new = {k: dn.get_attr(0, k) for k in ("current_voltage", "w_value")}
-        spk = dn.get_attr(0, "is_spiking", dtype=np.uint32)
-        lft = dn.get_attr(0, "last_firing_time", dtype=np.int32)
-        spikes_seen += int(spk.sum())
-        for net, (c0, c1) in zip(nets, windows):
-            net["current_voltage"] = state["current_voltage"]
-            net["w_value"] = state["w_value"]
-            net.clock = step
-            net.inputs(c0, c1)
-            net.update_neurons(c0, c1)
-            for k in ("current_voltage", "w_value"):
-                assert np.array_equal(net[k][c0:c1].view(np.uint32), new[k][c0:c1].view(np.uint32)), (step, k, c0)
-            assert np.array_equal(net["is_spiking"][c0:c1], spk[c0:c1])
-            hit = spk[c0:c1] != 0
-            assert np.all(lft[c0:c1][hit] == step)
-        state = new
-    assert np.isfinite(state["current_voltage"]).all()
-    assert spikes_seen >= 5
+        states.append(snapshot())
     dn.close()
+    assert np.isfinite(states[-1]["current_voltage"]).all()
+    assert sum(int(s["is_spiking"].sum()) for s in states[1:]) >= 5
+
+    threads = ob.usable_cpus()
+    windows = column_windows(n, n, ob.mem_available_bytes() // 3)
+    checked = np.zeros(n, bool)
+    for c0, c1 in windows:
+        net = window_net(n, 1, c0, c1, 2, threads)
+        for step in range(steps):
+            prev, new = states[step], states[step + 1]
+            net["current_voltage"] = prev["current_voltage"]
+            net["w_value"] = prev["w_value"]
+            net["last_firing_time"] = prev["last_firing_time"]
+            net.clock = step
+            net.inputs_tiled(c0, c1)
+            net.update_neurons(c0, c1)
+            where = f"step {step}, columns [{c0}, {c1}) of {len(windows)} window(s)"
+            for k in ("current_voltage", "w_value"):
+                assert np.array_equal(net[k][c0:c1].view(np.uint32), new[k][c0:c1].view(np.uint32)), (k, where)
+            assert np.array_equal(net["is_spiking"][c0:c1], new["is_spiking"][c0:c1]), where
+            assert np.array_equal(net["last_firing_time"][c0:c1], new["last_firing_time"][c0:c1]), where
+        checked[c0:c1] = True
+        del net
+    assert checked.all(), f"{int(checked.sum())} of {n} postsynaptic neurons checked"
 
 
 def test_c3_128x128_hodgkin_huxley_ampa_full_oracle(snn):
@@ -126,13 +152,16 @@ def test_c4_shaped_network_with_stdp_20480_neurons(snn):
     dn.close()
 
 
-def test_c4_full_size_network_with_stdp_sampled(snn):
-    """BASELINE configs[3] at FULL size (256x256 excitatory + 128x128 inhibitory = 81 920 neurons, 26.8 GB of
-    weights generated on the device, > 2^32 matrix elements): teacher-forced windows of postsynaptic columns as in
-    the configs[1] test, plus the STDP updates of sampled edges re-derived from the downloaded spike times."""
+def test_c4_full_size_network_with_stdp_all_columns(snn):
+    """BASELINE configs[3] at FULL size (256x256 excitatory + 128x128 inhibitory = 81 920 neurons, 26.8 GB of weights
+    generated on the device, > 2^32 matrix elements), EVERY postsynaptic neuron and EVERY synapse: per step the oracle
+    recomputes inputs and updates of all neurons from the GPU's S(t) (teacher-forced, as in the configs[1] test) and
+    applies the deferred STDP of every neuron that spiked to its own host copy of the matrix (33.5 GB, or column windows
+    that cover it); after the last step all 6.7 G weights on the device equal the oracle's bit for bit."""
     from snn_amd import synthetic
     n_inh, n_exc = 128 * 128, 256 * 256
     n = n_inh + n_exc
+    steps = 3
     dn = snn.DeviceNetwork(model=snn.IZHIKEVICH)
     dn.add_lattice(0, 128, 128)
     dn.add_lattice(1, 256, 256)
@@ -147,73 +176,86 @@ def test_c4_full_size_network_with_stdp_sampled(snn):
     dn.fill_graph_synthetic(5, 0.5, 1.5, with_diagonal=False)
     dn.set_plasticity(0, a_plus=1.5)
     dn.set_plasticity(1, tau_minus=3.0)
-    params = {0: (1.5, 2.0, 4.5, 4.5, 0.1), 1: (2.0, 2.0, 4.5, 3.0, 0.1)}
 
     def state(name, dtype=np.float32):
         return np.concatenate([dn.get_attr(0, name, dtype=dtype), dn.get_attr(1, name, dtype=dtype)])
 
-    windows = [(0, 64), (n_inh - 32, n_inh + 32), (n - 64, n)]
-    nets = []
-    for c0, c1 in windows:
-        net = ob.Net(n, model=ob.IZHIKEVICH)
-        net.arr["weights"] = np.empty((n, c1 - c0), np.float32)
-        net.arr["connections"] = np.empty((n, c1 - c0), np.uint8)
-        net.w_col0, net.w_ld = c0, c1 - c0
-        ob.lib().snn_o_fill_graph_window(net["weights"].ctypes.data_as(ob.f32p), net["connections"].ctypes.data_as(ob.u8p),
-                                         n, n, c0, c1 - c0, 5, 0.5, 1.5, 0)
-        net["gap_conductance"] = 10.0
-        net.n_threads = 8
-        nets.append(net)
-    L = ob.lib()
-    sample_rows = [5, n_inh, 40000, n - 2, 12345]          # rows (presynaptic) whose weights are tracked
-    w_track = {p: dn.get_graph_rows(p, 1)[0][0].copy() for p in sample_rows}
-    prev = {"current_voltage": state("current_voltage"), "w_value": state("w_value")}
-    lft_prev = state("last_firing_time", np.int32)
-    total_spikes = 0
-    for step in range(3):
+    def snapshot():
+        return {"current_voltage": state("current_voltage"), "w_value": state("w_value"),
+                "is_spiking": state("is_spiking", np.uint32), "last_firing_time": state("last_firing_time", np.int32)}
+
+    # The synthetic lattice is quiescent by itself (the gap junctions pull everything towards the mean), and STDP only
+    # moves a weight between two neurons that have BOTH fired, at different times: further groups are raised above
+    # threshold before steps 1 and 2, so that potentiation (t_pre < t_post) and depression occur on known edges.
+    inject = {1: np.array([17, n_inh + 100, 60000, 81000]), 2: np.array([5, 2222, n_inh + 7, 70000])}
+    before, after = [], []
+    for step in range(steps):
+        if step in inject:
+            v = state("current_voltage")
+            v[inject[step]] = 40.0
+            dn.set_attr(0, "current_voltage", v[:n_inh])
+            dn.set_attr(1, "current_voltage", v[n_inh:])
+        before.append(snapshot())
         dn.run(1)
-        new = {"current_voltage": state("current_voltage"), "w_value": state("w_value")}
-        spk = state("is_spiking", np.uint32)
-        lft = state("last_firing_time", np.int32)
-        total_spikes += int(spk.sum())
-        for net, (c0, c1) in zip(nets, windows):
-            net["current_voltage"] = prev["current_voltage"]
-            net["w_value"] = prev["w_value"]
+        after.append(snapshot())
+    for step, group in ((0, hot), (1, inject[1]), (2, inject[2])):
+        assert after[step]["is_spiking"][group].all(), step
+
+    threads = ob.usable_cpus()
+    windows = column_windows(n, n, ob.mem_available_bytes() // 3)
+    checked = np.zeros(n, bool)
+    touched = 0
+    for c0, c1 in windows:
+        net = window_net(n, 2, c0, c1, 5, threads)
+        net["lattice"][n_inh:] = 1
+        net["do_plasticity"] = 1
+        net["stdp_a_plus"][0] = 1.5
+        net["stdp_tau_minus"][1] = 3.0
+        for step in range(steps):
+            prev, new = before[step], after[step]
+            for k in ("current_voltage", "w_value", "last_firing_time"):
+                net[k] = prev[k]
             net.clock = step
-            net.inputs(c0, c1)              # window weights are re-synchronised with the device after every step
+            net.inputs_tiled(c0, c1)                    # from the oracle's OWN weights: STDP of the earlier steps included
             net.update_neurons(c0, c1)
+            where = f"step {step}, columns [{c0}, {c1}) of {len(windows)} window(s)"
             for k in ("current_voltage", "w_value"):
-                assert np.array_equal(net[k][c0:c1].view(np.uint32), new[k][c0:c1].view(np.uint32)), (step, k, c0)
-            assert np.array_equal(net["is_spiking"][c0:c1], spk[c0:c1])
-        # STDP of the tracked rows: every edge incident to a spiking neuron gets stdp(lft[p], lft[q]) with the
-        # plasticity of q's lattice, once per incident spiking end (neuron/mod.rs:2308-2417)
-        for p in sample_rows:
-            got = dn.get_graph_rows(p, 1)[0][0]
-            want = w_track[p].copy()
-            cols = np.nonzero(spk)[0] if not spk[p] else np.arange(n)
-            for q in cols:
-                if q == p:
-                    continue
-                prm = params[0 if q < n_inh else 1]
-                times = int(spk[q] != 0) + int(spk[p] != 0)
-                d = L.snn_o_stdp_delta(int(lft[p]), int(lft[q]), *prm)
-                for _ in range(times):
-                    want[q] = np.float32(want[q] + np.float32(d))
-            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (step, p)
-            w_track[p] = got
-        prev, lft_prev = new, lft
-        # the windows' own columns changed only if one of their neurons or a presynaptic neuron spiked: reload them
-        if spk.any():
-            rows_changed = np.nonzero(spk)[0]
-            for net, (c0, c1) in zip(nets, windows):
-                for p in rows_changed:                       # outgoing rows of spiking neurons
-                    net["weights"][p, :] = dn.get_graph_rows(int(p), 1)[0][0][c0:c1]
-                win_spk = np.nonzero(spk[c0:c1])[0]
-                if len(win_spk):                             # incoming columns of spiking window neurons
-                    for p0 in range(0, n, 8192):
-                        blk = dn.get_graph_rows(p0, min(8192, n - p0))[0]
-                        net["weights"][p0:p0 + blk.shape[0], win_spk] = blk[:, c0 + win_spk]
-    assert total_spikes >= len(hot)
+                assert np.array_equal(net[k][c0:c1].view(np.uint32), new[k][c0:c1].view(np.uint32)), (k, where)
+            assert np.array_equal(net["is_spiking"][c0:c1], new["is_spiking"][c0:c1]), where
+            assert np.array_equal(net["last_firing_time"][c0:c1], new["last_firing_time"][c0:c1]), where
+            # plasticity needs the spikes and firing times of ALL neurons (rows): the window's were just checked, the
+            # other windows check theirs
+            net["is_spiking"] = new["is_spiking"]
+            net["last_firing_time"] = new["last_firing_time"]
+            net.plasticity(c0, c1)                      # neuron/mod.rs:2308-2417 on this window's columns
+        # every weight of the window after the last step
+        block = 2048
+        for p0 in range(0, n, block):
+            nb = min(block, n - p0)
+            w, c = dn.get_graph_rows(p0, nb)
+            assert np.array_equal(c[:, c0:c1] != 0, net["connections"][p0:p0 + nb] != 0), (p0, c0)
+            got, want = w[:, c0:c1], net["weights"][p0:p0 + nb]
+            if not np.array_equal(got.view(np.uint32), want.view(np.uint32)):
+                bad = np.argwhere(got.view(np.uint32) != want.view(np.uint32))
+                r, q = bad[0]
+                raise AssertionError(f"{len(bad)} weights differ in rows [{p0}, {p0 + nb}) x columns [{c0}, {c1}); first "
+                                     f"({p0 + r}, {c0 + q}): oracle {want[r, q]!r} device {got[r, q]!r}")
+            del w, c
+        # the updates really happened: an edge from a neuron that fired in step 0 to one that fired in the last step has
+        # gained a_plus * exp(-|dt * (t_pre - t_post)| / tau_plus) over the generated weight
+        for pp in hot:
+            for q in inject[2]:
+                if pp != q and c0 <= q < c1:
+                    fresh = np.float32(ob.uniform(5, int(pp) * n + int(q), 0.5, 1.5))
+                    prm = (2.0, 2.0, 4.5, 3.0, 0.1) if q >= n_inh else (1.5, 2.0, 4.5, 4.5, 0.1)
+                    gain = np.float32(ob.lib().snn_o_stdp_delta(0, 2, *prm))
+                    if pp not in inject[2]:             # those fire in steps 0 AND 2: their pairs have t_pre == t_post
+                        assert net["weights"][pp, q - c0] == np.float32(fresh + gain), (pp, q)
+                        touched += 1
+        checked[c0:c1] = True
+        del net
+    assert checked.all()
+    assert touched == 5 * 4, touched
     dn.close()
 
 
@@ -239,10 +281,10 @@ def c5_handle(snn, side, v0, shard=None, by_lattice=False):
     return dn
 
 
-def test_c5_full_size_sparse_network_against_numpy(snn):
+def test_c5_full_size_sparse_network_against_oracle_and_numpy(snn):
     """BASELINE configs[4] at full size: 1 048 576 neurons, 1 048 576 Poisson cells, 14.6 M synapses, 30 steps.
-    Voltages, adaptation variables, spikes, firing times and the cells' generator state bit-identical to a numpy
-    restatement of the same sparse step (gap junctions from neurons and from Poisson cells with the delta-dirac
+    Voltages, adaptation variables, spikes, firing times and the cells' generator state bit-identical to the C oracle's
+    sparse routine (snn_o_run_csr) AND to a numpy restatement of the same sparse step (gap junctions from neurons and from Poisson cells with the delta-dirac
     refractoriness, the canonical 256-chunk summation order, Izhikevich update, xorshift32 cells) -- on ONE handle and
     on EIGHT shard handles (configs[4]'s multi-GPU shape on one device) that trade halo segments: per handle the
     two lattice rows either side of its slab and the half lattice the ring edge k -> k + 1 reads, not whole slots."""
@@ -314,6 +356,33 @@ def test_c5_full_size_sparse_network_against_numpy(snn):
         cs = (seed.astype(f32) / f32(4294967296.0)).astype(f32) < f32(0.01)
         st_lft[cs] = t
     assert total_spikes > 100 and (st_lft >= 0).sum() > 100_000
+
+    # ---- the C oracle over the same CSR rows (snn_o_run_csr: the pinned restatement, canonical chunk flush) ----
+    net = ob.Net(nn, model=ob.IZHIKEVICH, n_cells=nc, st_kind=ob.ST_POISSON, n_lattices=4, n_st_lattices=4, dense=False)
+    net["lattice"] = np.repeat(np.arange(4, dtype=np.uint32), m)
+    net["st_lattice"] = np.repeat(np.arange(4, dtype=np.uint32), m)
+    net["current_voltage"] = v0
+    net["gap_conductance"] = 10.0
+    net["st_chance_of_firing"] = 0.01
+    net["st_seed"] = np.arange(1, nc + 1, dtype=np.uint32)
+    net.n_threads = ob.usable_cpus()
+    net.run_csr(np.ascontiguousarray(ptr, np.uint64), np.ascontiguousarray(pre, np.uint32),
+                np.ascontiguousarray(w, np.float32), steps)
+    oracle = {"current_voltage": net["current_voltage"], "w_value": net["w_value"], "lft": net["last_firing_time"],
+              "seed": net["st_seed"], "st_lft": net["st_last_firing_time"]}
+    # the two CPU restatements agree with each other ...
+    assert np.array_equal(parity.bits(oracle["current_voltage"]), parity.bits(st["current_voltage"]))
+    assert np.array_equal(parity.bits(oracle["w_value"]), parity.bits(st["w_value"]))
+    assert np.array_equal(oracle["lft"], lft) and np.array_equal(oracle["seed"], seed) and np.array_equal(oracle["st_lft"], st_lft)
+    # ... and the device with the oracle
+    for k in range(4):
+        sl = slice(k * m, (k + 1) * m)
+        assert np.array_equal(parity.bits(dn.get_attr(k, "current_voltage")), parity.bits(oracle["current_voltage"][sl])), k
+        assert np.array_equal(parity.bits(dn.get_attr(k, "w_value")), parity.bits(oracle["w_value"][sl])), k
+        assert np.array_equal(dn.get_attr(k, "last_firing_time", dtype=np.int32), oracle["lft"][sl]), k
+        assert np.array_equal(dn.get_attr(4 + k, "seed", dtype=np.uint32), oracle["seed"][sl]), k
+        assert np.array_equal(dn.get_attr(4 + k, "last_firing_time", dtype=np.int32), oracle["st_lft"][sl]), k
+    del net
 
     for k in range(4):
         sl = slice(k * m, (k + 1) * m)
