@@ -145,6 +145,35 @@ def cpu_baseline(n, threads, budget_s=15.0):
     return sample_cols * steps / dt, dt, steps, sample_cols, threads, extra
 
 
+def state_checksum(dn, np, dist, rank, world):
+    """sha256 over (current_voltage bits, last_firing_time, is_spiking, per-neuron spike totals) of ALL neurons in global
+    index order -- each rank contributes the neurons it owns.  Post-population sharding does not change any result
+    (the reduction order is defined on the global presynaptic index), so the value must not depend on --gpus."""
+    import hashlib
+    own = np.asarray(dn.owned, dtype=np.int64)
+    cols = []
+    for name, dtype in (("current_voltage", np.float32), ("last_firing_time", np.int32), ("is_spiking", np.uint32)):
+        full = np.concatenate([dn.get_attr(i, name, dtype=dtype) for i, (_, _, st) in sorted(dn.lattices.items()) if not st])
+        cols.append(full[own].view(np.uint32))
+    counts = np.concatenate([dn.spike_counts(i) for i, (_, _, st) in sorted(dn.lattices.items()) if not st])
+    cols.append(counts[own].astype(np.uint32))
+    mine = (own, np.stack(cols))
+    parts = [mine]
+    if dist is not None and world > 1:
+        parts = [None] * world if rank == 0 else None
+        dist.gather_object(mine, parts, dst=0)
+    if rank != 0:
+        return None
+    n = sum(p[0].size for p in parts)
+    table = np.zeros((4, n), np.uint32)
+    seen = np.zeros(n, bool)
+    for idx, vals in parts:
+        table[:, idx] = vals
+        seen[idx] = True
+    assert seen.all(), "some neuron is owned by no rank"
+    return hashlib.sha256(table.tobytes()).hexdigest()
+
+
 def build_config(args, snn_amd, synthetic, np, rank, world, local_rank):
     """BASELINE.json configs as synthetic inputs.  Returns (handle, neurons, text, kernel)."""
     cfg = args.config
@@ -169,7 +198,8 @@ def build_config(args, snn_amd, synthetic, np, rank, world, local_rank):
             dn.apply_reward(0.01)
             text = "reward-modulated (R-STDP, trace per synapse) " + text
         # 32x32 takes the small-lattice forms: all steps of a run call in one launch (k_run_resident), else one launch per step
-        return dn, n, text, ("k_step_resident<0,true,false>" if cfg == "c1" else "k_inputs_dense<true,false>")
+        return dn, n, text, ("k_step_resident<0,true,false>" if cfg == "c1" else
+                             "k_inputs_rstdp<true,false> (weight + trace rewritten, 16 B per synapse)" if cfg == "c6" else "k_inputs_dense<true,false>")
     if cfg == "c3":
         rows = cols = 128
         n = rows * cols
@@ -333,13 +363,22 @@ def main():
             e = float(t.item())
         runs.append(e)
     elapsed = sorted(runs)[len(runs) // 2]
+    # N = 1 and N = 8 lines can be diffed: a checksum of the network's state right after the timed repetitions (the same
+    # number of steps for every N), every rank's own neurons gathered to rank 0 in global order
+    state_sha, state_steps = state_checksum(dn, np, dist, rank, world), args.warmup + args.steps * len(runs)
+    phases = None
     if events_after:
         spikes_timed = own_spike_total()
         dn.profile_enable(True)
         dn.profile_reset()
+        if args.config == "c1" and not sharded:
+            dn.set_option("run_timing", 1)              # shader-clock totals of the one-launch run's four phases
         barrier()
         run(args.steps)
         barrier()
+        if args.config == "c1" and not sharded and dn.stat("run_timing_steps"):
+            clocks = {k: dn.stat("run_timing_" + k) for k in ("poll", "barrier", "turns", "update")}
+            phases = {"steps": dn.stat("run_timing_steps"), "clocks_per_step": {k: v / dn.stat("run_timing_steps") for k, v in clocks.items()}}
     launches, kern_ms = dn.profile_read()
     pl_steps, pl_ms = dn.profile_read_plasticity()
     dn.profile_enable(False)
@@ -383,6 +422,7 @@ def main():
             "repeats": len(runs), "ms_per_step_runs": [r / args.steps * 1e3 for r in runs],
             "ms_per_step_min": min(runs) / args.steps * 1e3, "ms_per_step_max": max(runs) / args.steps * 1e3,
             "spikes_per_step": spikes / total_steps,
+            "state_sha256": state_sha, "state_after_steps": state_steps,
             "plasticity": ({"ms_per_step": pl_ms / pl_steps, "steps_measured": pl_steps,
                             "touched_bytes_per_step": 8.0 * (dn.n_tot + sum(e - b for b, e in dn.ranges)) * spikes / total_steps / world,
                             "note": "spike compaction + column/row weight updates of this rank, HIP events; touched bytes = "
@@ -412,6 +452,20 @@ def main():
                                              f"{sample} of {n} postsynaptic neurons x {cpu_steps} steps ({secs:.1f} s); every "
                                              f"sampled neuron sums all {n} presynaptic terms, i.e. the full per-neuron-step "
                                              f"cost; bound by host memory bandwidth (host_stream_GBps, 5 B per synapse)"}
+        if phases is not None:
+            # the one-launch run of a small lattice reads its matrix from HBM once per RUN: no HBM fraction describes it.
+            # What bounds a step is the chain poll -> barrier -> the four serial turns of the canonical sum -> update and
+            # publish; reported as measured shares of the launch (workgroup 0's shader clocks, scaled to the event time)
+            per_step_us = avg_ms * 1e3
+            tot = sum(phases["clocks_per_step"].values())
+            out["roofline"] = {"bound": "latency", "achieved": None, "peak": None, "unit": "us/step", "frac": None, "traffic": None,
+                               "kernel": kernel_name, "launches": launches, "avg_step_us": per_step_us,
+                               "phases_us_per_step": {k: per_step_us * v / tot for k, v in phases["clocks_per_step"].items()},
+                               "phases_clocks_per_step": phases["clocks_per_step"],
+                               "matrix_bytes_read_once_per_run": bytes_per_launch,
+                               "kernel_events": "one extra repetition after the timed ones",
+                               "note": "all steps of a run call in one launch; the matrix stays in registers / LDS, per step "
+                                       "only 8 B per neuron travel (L2 / fabric)"}
         result = json.dumps(out)
     else:
         result = None

@@ -375,10 +375,30 @@ int snn_get_spike_counts(snn_network_t *net, uint32_t id, uint32_t *dst, size_t 
  * values from a device table; "persistent_run" [1] all steps of an snn_run call (of 4 steps or more) on a small
  * electrical-only network -- neurons, with or without Poisson / Rate cells; <= 4096 rows, no plasticity -- in ONE launch;
  * "input_shape" [0] 1 | 2 forces the 4- / 2-columns-per-lane shape of the streamed dense input pass (0: chosen by size).
- * Unknown names fail with SNN_ERR_BAD_ARG. */
+ * Unknown names fail with SNN_ERR_BAD_ARG.
+ *
+ * Failure semantics of "persistent_run".  The one launch is a spin-wait exchange between workgroups that must all be
+ * resident on the device at once.  (1) A probe launch of the same shape, once per handle and grid size, decides whether
+ * they can be; if not the handle silently keeps one launch per step.  (2) If they lose sight of each other later all the
+ * same (e.g. another process holds compute units with a long kernel), every waiter gives up after
+ * "run_resident_spin_limit" [2^24] polls and snn_run ROLLS THE HANDLE BACK: all device state the launch may have written
+ * (every per-neuron / per-cell array, the exchange buffer, spike totals, device clocks -- copied aside by one small launch
+ * before every such run) is restored, the host clocks and history cursors are reset to their values at the start of the
+ * call, the SAME snn_run call then takes its steps with one launch per step, and the handle stays in that mode
+ * ("persistent_run" 0; snn_set_option can switch it back on).  The call returns SNN_OK with exactly the result a
+ * per-step run gives; the only trace is the statistic "persistent_run_fallbacks".  A handle is therefore never left
+ * half-stepped, and SNN_ERR_WAIT is only ever returned for a failed hipStreamSynchronize.  Handles that adopted a
+ * caller's stream (snn_set_stream) do not take the one-launch form (its outcome is read after a host synchronisation).
+ * "run_resident_fault_step" [0] is a test hook: workgroup 0 withholds the state after that step (1-based) of a launch,
+ * which forces path (2); tests/test_gpu_persistent_run.py pins the rollback with it.  "run_timing" [0] makes the one-launch
+ * run keep the shader-clock totals of workgroup 0's four phases (poll the voltages, barrier, the canonical sum's turns,
+ * update + publish) of its last launch for snn_get_stat. */
 int snn_set_option(snn_network_t *net, const char *name, int value);
 /* Which step form the handle has used so far, as launch counts since creation: "persistent_run_launches" (k_run_resident:
- * many steps per launch), "persistent_run_steps" (steps those launches covered).  Unknown names fail with SNN_ERR_BAD_ARG. */
+ * many steps per launch), "persistent_run_steps" (steps those launches covered), "persistent_run_fallbacks" (launches that
+ * gave up and were rolled back, see above); with option "run_timing": "run_timing_poll" / "_barrier" / "_turns" /
+ * "_update" (shader clocks of workgroup 0 over the last launch) and "run_timing_steps" (its steps).  Unknown names fail
+ * with SNN_ERR_BAD_ARG. */
 int snn_get_stat(snn_network_t *net, const char *name, uint64_t *value);
 
 /* ---- measurement ----------------------------------------------------------------------- */
@@ -397,7 +417,9 @@ int snn_profile_read_plasticity(snn_network_t *net, uint64_t *steps, double *tot
  * `voltage` above the spike threshold a chosen fraction of the population spikes every step, so STDP can be measured
  * under load.  Applied identically on every shard handle. */
 int snn_set_synthetic_drive(snn_network_t *net, uint64_t seed, float fraction, float voltage);
-/* Algorithmic bytes ONE launch of the synaptic-input kernel moves (DESIGN.md "Roofline") */
+/* Algorithmic bytes ONE launch of the synaptic-input kernel moves (DESIGN.md "Roofline"): 4 B per synapse of the shard
+ * (dense), 8 B per stored synapse (sparse), 16 B per internal synapse of a reward-modulated lattice whose weight update
+ * rides on the pass (k_inputs_rstdp: weight and trace read and rewritten) */
 int snn_input_kernel_bytes(const snn_network_t *net, uint64_t *bytes);
 
 /* ---- errors ----------------------------------------------------------------------------- */

@@ -21,6 +21,19 @@ __global__ void k_fill_u32(uint32_t *p, size_t n, uint32_t v)
 {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
 }
+// Snapshot / restore of a list of small arrays in one launch (the one-launch run keeps the state it started from until
+// it is known to have finished): entry = blockIdx.y, `restore` copies dst -> src.
+struct CopyEntry {
+    uint32_t *src, *dst;
+    uint32_t words, pad;
+};
+__global__ __launch_bounds__(256) void k_copy_table(const CopyEntry *table, int restore)
+{
+    const CopyEntry e = table[blockIdx.y];
+    const uint32_t *from = restore ? e.dst : e.src;
+    uint32_t *to = restore ? e.src : e.dst;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < e.words; i += gridDim.x * 256u) to[i] = from[i];
+}
 __global__ void k_iota_u32(uint32_t *p, size_t n, uint32_t first)
 {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = first + (uint32_t)i;

@@ -259,6 +259,9 @@ struct ResidentRunArgs {
     uint32_t n_groups;              // row groups per column tile; gridDim.x = tiles * n_groups
     uint32_t tag_base;              // tag of the state after step s (1-based) = tag_base + s
     uint32_t *failed;               // host-visible word, set when a poll gave up (workgroups not co-resident)
+    uint32_t spin_limit;            // polls before a waiter gives up (RUN_RESIDENT_SPIN_LIMIT; option "run_resident_spin_limit")
+    uint32_t fault_step;            // test hook (option "run_resident_fault_step"): workgroup 0 does not publish the state after
+                                    // this step (1-based; 0 = off), so every reader of its columns times out
     unsigned long long *timing;     // null, or [gridDim.x][4] shader-clock totals of workgroup phases (SNN_AMD_RUN_TIMING=1)
     // spike-train cells (Poisson or Rate, no transmitters): rows n_neurons .. n_tot - 1.  Nothing about a cell depends on the
     // rest of the network, so every workgroup advances the cells among ITS rows by itself (thread = row; the cell's state lives
@@ -435,7 +438,7 @@ __device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, Res
             uint32_t spins = 0;
             do {
                 x = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } while ((uint32_t)(x >> 32) != tag && ++spins < RUN_RESIDENT_SPIN_LIMIT);
+            } while ((uint32_t)(x >> 32) != tag && ++spins < a.spin_limit);
             arrived = arrived && (uint32_t)(x >> 32) == tag;
             return __uint_as_float((uint32_t)x);
         };
@@ -743,7 +746,7 @@ __device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, Res
                     uint32_t spins = 0;
                     do {
                         x = __hip_atomic_load(pslot + j * 64u + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    } while ((uint32_t)(x >> 32) != ptag && ++spins < RUN_RESIDENT_SPIN_LIMIT);
+                    } while ((uint32_t)(x >> 32) != ptag && ++spins < a.spin_limit);
                     if ((uint32_t)(x >> 32) != ptag) sh.gave_up = 1u;
                     sh.pi[4u + j][lane] = __uint_as_float((uint32_t)x);
                 }
@@ -818,7 +821,7 @@ __device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, Res
             if (alone) {
                 v_mine = col ? v_new : 0.0f;
                 if (col) sh.v[ql] = v_new;                    // read behind the next step's first barrier
-            } else if (col && s + 1 < steps) {
+            } else if (col && s + 1 < steps && !(a.fault_step == s + 1u && blockIdx.x == 0u)) {
                 unsigned long long *g = a.granules + (size_t)((s + 1) & 1u) * RUN_RESIDENT_MAX_NEURONS + in.q0 + ql;
                 const unsigned long long x = ((unsigned long long)(tag_base + s + 1) << 32) | __float_as_uint(v_new);
                 __hip_atomic_store(g, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -847,21 +847,43 @@ int snn_run(snn_network_t *net, uint64_t iterations)
     TRY(begin_run(net, iterations));
     uint64_t it = 0;
     if (iterations >= 4 && run_resident_applies(net)) {          // below that the launch's fixed cost (seed, weights into registers) shows
+        // The launch is a spin-wait all-to-all between workgroups that must all be resident.  A probe vouches for that
+        // once per handle; should they lose sight of each other later all the same (device shared with a long kernel),
+        // the waiters give up, the handle is put back exactly where it was -- device state from a snapshot taken in one
+        // launch, host counters from `saved` -- and the steps are taken again with one launch per step, which this handle
+        // then keeps.  The caller sees a slower call, never a half-stepped network.
+        struct { long long clock, run_step_offset; uint64_t hist_steps, hist_tick, launches, steps; size_t ev_used; } saved =
+            {net->clock, net->run_step_offset, net->hist_steps, net->hist_tick, net->stat_run_launches, net->stat_run_steps,
+             net->ev_used};
+        TRY(run_snapshot(net, /*restore=*/false));
         TRY(launch_run_resident(net, iterations));
-        if (net->persistent_run) it = iterations;     // else: the co-residency probe said no, nothing was stepped
+        if (net->persistent_run) {                    // else: the co-residency probe said no, nothing was stepped
+            HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
+            if (net->run_failed && net->run_failed[0]) {
+                net->run_failed[0] = 0u;
+                TRY(run_snapshot(net, /*restore=*/true));
+                HIP_TRY(hipMemsetAsync(net->run_granules, 0, (size_t)2 * RUN_RESIDENT_MAX_NEURONS * 8, net->stream), SNN_ERR_BUFFER_WRITE);
+                HIP_TRY(hipMemsetAsync(net->run_partials, 0, RUN_PARTIAL_WORDS * 8, net->stream), SNN_ERR_BUFFER_WRITE);
+                net->run_tag = 1;
+                net->clock = saved.clock; net->run_step_offset = saved.run_step_offset;
+                net->hist_steps = saved.hist_steps; net->hist_tick = saved.hist_tick;
+                net->stat_run_launches = saved.launches; net->stat_run_steps = saved.steps;
+                net->ev_used = saved.ev_used;
+                net->shadow_valid = false;
+                net->view_dirty = true;
+                net->persistent_run = 0;
+                net->stat_run_fallbacks += 1;
+            } else {
+                it = iterations;
+            }
+        }
     }
     for (; it < iterations; ++it) {
         if (net->nn) TRY(step_begin(net));
         TRY(step_end(net));
         if (net->profile && (net->ev_used >= 8192 || net->ev_used_pl >= 8192)) TRY(collect_profile(net));
     }
-    TRY(end_run(net, /*keep_stdp=*/true));
-    if (net->run_failed && net->run_failed[0]) {
-        net->run_failed[0] = 0u;
-        return fail(SNN_ERR_WAIT, "the workgroups of the one-launch run could not see each other (device shared with another "
-                                  "long-running kernel?); state is undefined -- set option persistent_run to 0");
-    }
-    return SNN_OK;
+    return end_run(net, /*keep_stdp=*/true);
 }
 
 int snn_step_begin_local(snn_network_t *net)
@@ -1302,7 +1324,10 @@ int snn_set_option(snn_network_t *net, const char *name, int value)
     else if (n == "defer_rstdp") net->defer_rstdp = value != 0;
     else if (n == "defer_stdp") net->defer_stdp = (value == 2) ? 2 : (value != 0);
     else if (n == "uniform_params") { net->uniform_params = value != 0; net->uni_dirty = true; }
-    else if (n == "persistent_run") net->persistent_run = value != 0;
+    else if (n == "persistent_run") { net->persistent_run = value != 0; net->run_probed_grid = 0; }
+    else if (n == "run_resident_spin_limit") net->run_spin_limit = value > 0 ? (uint32_t)std::min<long long>(value, 0x7FFFFFFF) : RUN_RESIDENT_SPIN_LIMIT;
+    else if (n == "run_resident_fault_step") net->run_fault_step = (uint32_t)std::max<long long>(value, 0);
+    else if (n == "run_timing") net->run_timing_opt = value != 0;
     else if (n == "input_shape") net->force_shape = (value == 1 || value == 2) ? value : 0;
     else return fail(SNN_ERR_BAD_ARG, "unknown option '" + n + "'");
     net->shadow_valid = false;
@@ -1315,6 +1340,12 @@ int snn_get_stat(snn_network_t *net, const char *name, uint64_t *value)
     const std::string n(name);
     if (n == "persistent_run_launches") *value = net->stat_run_launches;
     else if (n == "persistent_run_steps") *value = net->stat_run_steps;
+    else if (n == "persistent_run_fallbacks") *value = net->stat_run_fallbacks;
+    else if (n == "run_timing_poll") *value = net->run_timing_last[0];
+    else if (n == "run_timing_barrier") *value = net->run_timing_last[1];
+    else if (n == "run_timing_turns") *value = net->run_timing_last[2];
+    else if (n == "run_timing_update") *value = net->run_timing_last[3];
+    else if (n == "run_timing_steps") *value = net->run_timing_steps;
     else return fail(SNN_ERR_BAD_ARG, "unknown statistic '" + n + "'");
     return SNN_OK;
 }
@@ -1370,8 +1401,18 @@ int snn_input_kernel_bytes(const snn_network_t *net, uint64_t *bytes)
 {
     if (!net || !bytes) return fail(SNN_ERR_BAD_ARG, "null argument");
     if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
-    *bytes = net->csr ? (uint64_t)8 * net->nnz                 // sparse: index + weight of every stored synapse
-                      : (uint64_t)4 * net->n_tot * net->n_loc; // dense: every weight of the shard, read once
+    if (net->csr) { *bytes = (uint64_t)8 * net->nnz; return SNN_OK; }      // sparse: index + weight of every stored synapse
+    uint64_t b = (uint64_t)4 * net->n_tot * net->n_loc;                    // dense: every weight of the shard, read once
+    if (net->any_modulation && net->defer_rstdp) {
+        // k_inputs_rstdp: the internal edges of a reward-modulated lattice are read AND rewritten, weight and trace --
+        // 16 B per synapse instead of 4
+        for (const auto &l : net->lattices) {
+            if (l.slot >= net->rm_on_host.size() || !net->rm_on_host[l.slot]) continue;
+            const uint32_t c0 = std::max(l.first, net->q0), c1 = std::min(l.first + l.count, net->q1);
+            if (c1 > c0) b += (uint64_t)12 * l.count * (c1 - c0);
+        }
+    }
+    *bytes = b;
     return SNN_OK;
 }
 

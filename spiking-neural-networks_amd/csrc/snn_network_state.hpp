@@ -141,6 +141,7 @@ struct snn_network {
     hipEvent_t ev_packed = nullptr, ev_exchanged = nullptr;
 
     std::vector<void *> allocs;
+    std::map<void *, size_t> alloc_bytes;        // dev_alloc'ed arrays and their sizes (run_snapshot copies the small ones)
     // sparse form (CSR by local postsynaptic row); the arrays are replaced by every snn_set_graph_csr
     bool csr = false;
     uint64_t nnz = 0;
@@ -178,8 +179,19 @@ struct snn_network {
     uint32_t run_tag = 1;
     uint32_t *run_failed = nullptr;       // hipHostMalloc: [0] a run gave up, [1] the co-residency probe said no
     uint32_t run_probed_grid = 0;         // grid size the probe last vouched for
-    uint64_t stat_run_launches = 0, stat_run_steps = 0;
+    uint64_t stat_run_launches = 0, stat_run_steps = 0, stat_run_fallbacks = 0;
+    uint32_t run_spin_limit = RUN_RESIDENT_SPIN_LIMIT;   // option "run_resident_spin_limit"
+    uint32_t run_fault_step = 0;                         // option "run_resident_fault_step" (test hook, see ResidentRunArgs)
+    // every small device array of the handle (all per-neuron / per-cell state, the exchange buffer and its shadows, the
+    // device clocks) is copied aside in ONE launch before a one-launch run and copied back if the run gave up
+    CopyEntry *snap_table = nullptr;
+    uint32_t *snap_buf = nullptr;
+    uint32_t snap_entries = 0, snap_max_words = 0;
+    size_t snap_allocs_seen = 0;
     unsigned long long *run_timing = nullptr;   // SNN_AMD_RUN_TIMING=1: phase clocks of k_run_resident, printed per launch
+    int run_timing_opt = 0;                     // option "run_timing": collect them without printing (snn_get_stat)
+    unsigned long long run_timing_last[4] = {0, 0, 0, 0};   // workgroup 0, last launch: poll, barrier, turns, update + publish
+    uint32_t run_timing_steps = 0;
     int force_shape = 0;                  // 1 | 2: streamed shape of the dense input pass (SNN_AMD_INPUT_SHAPE), 0: by size
     // deferred STDP (dense handles): the update of step t is applied by the input pass of step t + 1
     // 0 (default): the scatter kernels right after the step; 1: the update of step t rides on the input pass of step
@@ -260,6 +272,7 @@ int dev_alloc(snn_network *net, void **out, size_t bytes)
     if (bytes == 0) bytes = 256;
     HIP_TRY(hipMalloc(out, bytes), SNN_ERR_BUFFER_CREATE);
     net->allocs.push_back(*out);
+    net->alloc_bytes[*out] = bytes;
     return SNN_OK;
 }
 

@@ -430,6 +430,8 @@ int choose_matrix_placement(snn_network *net)
                 fprintf(stderr, "[snn] matrix placement: held %p %.3f ms, candidate %p %.3f ms\n", (void *)a, best_ms, b, ms_b);
             if (rc == SNN_OK && ms_b < best_ms * 0.99f) {       // the candidate wins
                 for (auto &p : net->allocs) if (p == a) p = b;
+                net->alloc_bytes.erase(a);
+                net->alloc_bytes[b] = bytes;
                 losers.push_back(a);
                 best_ms = ms_b;
             } else {
@@ -571,11 +573,61 @@ bool run_resident_applies(const snn_network *net)
                              !net->cell_list_dev && !SNN_HAVE_CUSTOM_REFRACTORINESS)) &&
            net->n_tot <= RUN_RESIDENT_MAX_NEURONS && net->electrical && !net->chemical && !net->any_plasticity &&
            !net->any_modulation && !net->any_whist && !net->want_avg && !net->want_eeg && net->hist_every == 1 &&
-           net->model != SNN_MODEL_BCM_IZHIKEVICH && !net->local_inputs_done;
+           net->model != SNN_MODEL_BCM_IZHIKEVICH && !net->local_inputs_done &&
+           !net->external_stream;       // the run's outcome is read after a host synchronisation (snn_run)
 }
 
 // chunk sums travelling between the row groups of a tile: [2][tiles][groups - 1][4 chunks][64] granules
 constexpr size_t RUN_PARTIAL_WORDS = (size_t)2 * RUN_RESIDENT_MAX_TILES * (RUN_RESIDENT_MAX_GROUPS - 1) * 256;
+
+// What a one-launch run may overwrite is every SMALL array of the handle: per-neuron and per-cell state, the exchange
+// buffer and its shadows, spike totals, the device clocks (the matrix, the partial planes and the histories are either
+// read-only here, scratch, or rewritten by a repeated step).  "Small" = no larger than the exchange buffer / a typed
+// [3][pad] block.  (Re)built when the handle has allocated since.
+int run_snapshot(snn_network *net, bool restore)
+{
+    if (!restore && (!net->snap_table || net->snap_allocs_seen != net->allocs.size())) {
+        const size_t limit = 4 * std::max<size_t>({(size_t)NUM_PLANES * net->xl.stride, (size_t)K_TYPES * net->n_pad,
+                                                   (size_t)K_TYPES * net->c_pad, 256});
+        if (net->alloc_bytes.count(net->xbuf) == 0 || net->alloc_bytes[net->xbuf] > limit)
+            return fail(SNN_ERR_BAD_STATE, "exchange buffer missing from the snapshot set");
+        std::vector<CopyEntry> table;
+        size_t words = 0;
+        uint32_t max_words = 0;
+        for (const auto &kv : net->alloc_bytes) {
+            if (kv.second > limit || kv.first == net->snap_table || kv.first == net->snap_buf ||
+                kv.first == net->run_granules || kv.first == net->run_partials || kv.first == net->run_timing)
+                continue;
+            const uint32_t w = (uint32_t)(kv.second / 4);
+            table.push_back(CopyEntry{static_cast<uint32_t *>(kv.first), nullptr, w, 0u});
+            words += w;
+            max_words = std::max(max_words, w);
+        }
+        // (the two buffers are replaced, not grown: a handle allocates a handful of times in its life)
+        for (void *old : {(void *)net->snap_table, (void *)net->snap_buf})
+            if (old) {
+                (void)hipFree(old);
+                net->alloc_bytes.erase(old);
+                net->allocs.erase(std::remove(net->allocs.begin(), net->allocs.end(), old), net->allocs.end());
+            }
+        net->snap_table = nullptr; net->snap_buf = nullptr;
+        TRY(dev_alloc_t(net, &net->snap_buf, words));
+        TRY(dev_alloc_t(net, &net->snap_table, table.size()));
+        size_t off = 0;
+        for (auto &e : table) { e.dst = net->snap_buf + off; off += e.words; }
+        HIP_TRY(hipMemcpyAsync(net->snap_table, table.data(), table.size() * sizeof(CopyEntry), hipMemcpyHostToDevice, net->stream),
+                SNN_ERR_BUFFER_WRITE);
+        HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);       // `table` leaves scope
+        net->snap_entries = (uint32_t)table.size();
+        net->snap_max_words = max_words;
+        net->snap_allocs_seen = net->allocs.size();
+    }
+    if (!net->snap_entries) return SNN_OK;
+    const uint32_t bx = std::max(1u, std::min(16u, (net->snap_max_words + 1023u) / 1024u));
+    hipLaunchKernelGGL(k_copy_table, dim3(bx, net->snap_entries), dim3(256), 0, net->stream, net->snap_table, restore ? 1 : 0);
+    HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+    return SNN_OK;
+}
 
 int launch_run_resident(snn_network *net, uint64_t iterations)
 {
@@ -624,6 +676,8 @@ int launch_run_resident(snn_network *net, uint64_t iterations)
         r.n_groups = row_groups;
         r.tag_base = net->run_tag;
         r.failed = net->run_failed;
+        r.spin_limit = net->run_spin_limit;
+        r.fault_step = net->run_fault_step;
         r.cells = net->ca;
         r.st_kind = net->st_kind;
         r.lattice_clock = net->st_clock_dev;
@@ -631,7 +685,7 @@ int launch_run_resident(snn_network *net, uint64_t iterations)
         r.view_clock0 = net->clock;
         r.st_vhist_row = (recording(net) && net->want_vhist && net->st_vhist) ? net->st_vhist + (size_t)net->hist_steps * net->c_pad : nullptr;
         r.st_vhist_stride = net->c_pad;
-        if (!net->run_timing && getenv("SNN_AMD_RUN_TIMING")) TRY(dev_alloc_t(net, &net->run_timing, (size_t)RUN_RESIDENT_MAX_TILES * RUN_RESIDENT_MAX_GROUPS * 4));
+        if (!net->run_timing && (net->run_timing_opt || getenv("SNN_AMD_RUN_TIMING"))) TRY(dev_alloc_t(net, &net->run_timing, (size_t)RUN_RESIDENT_MAX_TILES * RUN_RESIDENT_MAX_GROUPS * 4));
         r.timing = net->run_timing;
         hipLaunchKernelGGL(k_run_resident_seed, dim3((net->nn + 255) / 256), dim3(256), 0, net->stream, net->xbuf, net->xl,
                            net->nn, net->run_granules, r.tag_base);
@@ -678,7 +732,9 @@ int launch_run_resident(snn_network *net, uint64_t iterations)
             std::vector<unsigned long long> t((size_t)grid.x * 4);
             HIP_TRY(hipMemcpyAsync(t.data(), net->run_timing, t.size() * 8, hipMemcpyDeviceToHost, net->stream), SNN_ERR_BUFFER_READ);
             HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
-            for (unsigned b = 0; b < grid.x; b += (grid.x > 1 ? grid.x - 1 : 1))
+            for (int k = 0; k < 4; ++k) net->run_timing_last[k] = t[k];
+            net->run_timing_steps = steps;
+            for (unsigned b = 0; getenv("SNN_AMD_RUN_TIMING") && b < grid.x; b += (grid.x > 1 ? grid.x - 1 : 1))
                 fprintf(stderr, "k_run_resident workgroup %u: poll %.0f, barrier %.0f, turns %.0f, update+publish %.0f clocks/step (%u steps)\n",
                         b, (double)t[b * 4] / steps, (double)t[b * 4 + 1] / steps, (double)t[b * 4 + 2] / steps, (double)t[b * 4 + 3] / steps, steps);
         }

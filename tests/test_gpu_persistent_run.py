@@ -307,3 +307,50 @@ def test_long_runs_agree(snn, rows, cols, cells, steps):
         assert np.array_equal(parity.bits(states[0][0][name]), parity.bits(states[1][0][name])), name
     for a, b in zip(states[0][1], states[1][1]):
         assert np.array_equal(a, b) and int(np.asarray(a).sum()) > 0
+
+
+@pytest.mark.parametrize("rows,cols,cells,model,fault", [(32, 32, 0, ob.IZHIKEVICH, 37), (48, 48, 0, ob.IZHIKEVICH, 5),
+                                                         (20, 20, 100, ob.IZHIKEVICH, 11), (24, 24, 0, ob.HH, 2)])
+def test_a_run_that_gives_up_is_rolled_back_and_repeated_per_step(snn, rows, cols, cells, model, fault):
+    """include/snn_amd.h, failure semantics of "persistent_run": a workgroup withholds its voltages after step `fault` of
+    the one launch (test hook), every reader of its columns times out (spin limit lowered so that this takes milliseconds),
+    and snn_run must hand back exactly what a per-step run gives -- state, clocks, histories, spike totals, generator
+    state of the cells -- in the SAME call, with the handle left in per-step mode and usable."""
+    if cells:
+        lay = parity.Layout([(3, rows, cols)], [(1, 10, cells // 10)])
+        net = parity.make_oracle(lay, model=model, st_kind=ob.ST_POISSON)
+        net["st_chance_of_firing"] = 0.05
+        n = net.n_neurons
+        net["current_voltage"] = ob.uniform_array(90 + fault, n, -65, 30)
+        net["gap_conductance"] = ob.uniform_array(95, n, 2.0, 10.0)
+        net.fill_graph(91, 0.5, 1.5)
+        rng = np.random.default_rng(92)
+        net["connections"][rng.random(net["connections"].shape) >= 0.75] = 0
+        net["weights"][...] *= net["connections"]
+    else:
+        net = build(model, rows, cols, 90 + fault)
+    dn = parity.device_from_oracle(snn, net)
+    dn.set_history(voltage=True, spikes=True)
+    dn.set_reduced_history(spike_counts=True)
+    dn.run(60)                                          # a clean one-launch run first: granule slots and tags are in use
+    assert dn.stat("persistent_run_launches") == 1 and dn.stat("persistent_run_fallbacks") == 0
+    dn.set_option("run_resident_spin_limit", 1 << 12)
+    dn.set_option("run_resident_fault_step", fault)
+    dn.run(80)                                          # gives up at step `fault`, rolled back, repeated per step
+    assert dn.stat("persistent_run_fallbacks") == 1
+    assert dn.stat("persistent_run_launches") == 1 and dn.stat("persistent_run_steps") == 60
+    assert dn.clock == 140
+    dn.set_option("run_resident_fault_step", 0)
+    dn.run(50)                                          # the handle keeps one launch per step ...
+    assert dn.stat("persistent_run_launches") == 1
+    dn.set_option("run_resident_spin_limit", 0)         # (0 = the default limit)
+    dn.set_option("persistent_run", 1)                  # ... until it is switched back on
+    dn.run(40)
+    assert dn.stat("persistent_run_launches") == 2 and dn.stat("persistent_run_fallbacks") == 1
+    net.run(230, voltage_history=True, spike_history=True, spike_counts=True)
+    parity.assert_state_equal(net, parity.pull_state(dn, net))
+    assert np.array_equal(dn.spike_history(3), net.spike_history)
+    assert np.array_equal(parity.bits(dn.voltage_history(3)), parity.bits(net.voltage_history))
+    assert np.array_equal(dn.spike_counts(3), net.spike_counts)
+    assert net.spike_history.sum() > 0
+    dn.close()
