@@ -281,6 +281,10 @@ int snn_exchange(snn_network_t *net, void *nccl_comm);
 /* `iterations` steps of a shard handle, every rank of the communicator calling it with its own handle: per step
  * kernels -> pack -> ncclAllGather / grouped ncclSend+ncclRecv on a second stream -> unpack -> rest of the step, with
  * the next step's own-rows input pass overlapping the collective where that is valid (see snn_step_begin_local).
+ * Sparse handles with a halo plan and no weight updates take three launches per step: k_step_csr over the BORDER
+ * slices (the 64-row slices holding a neuron some peer reads), which writes the outgoing segments itself -> the
+ * collective, overlapped by k_step_csr over the INTERIOR slices -> k_step_close (spike trains + unpack + clearing the
+ * outgoing spike bitmaps); a plan in which nothing travels skips the collective and its stream events altogether.
  * Blocks until the last step has finished.  Results are identical to (b) and (c) and to a single-GPU snn_run. */
 int snn_run_sharded(snn_network_t *net, void *nccl_comm, uint64_t iterations);
 /* The same loop with the HOST'S OWN TRANSPORT (MPI, UCX, a test harness ...) in place of RCCL: once per step, after the
@@ -290,6 +294,9 @@ int snn_run_sharded(snn_network_t *net, void *nccl_comm, uint64_t iterations);
  * non-zero return stops the run with SNN_ERR_QUEUE.  No overlap of the next step's input pass with the exchange. */
 typedef int (*snn_exchange_fn)(void *user, void *hip_stream);
 int snn_run_sharded_custom(snn_network_t *net, snn_exchange_fn exchange, void *user, uint64_t iterations);
+/* An snn_exchange_fn that moves nothing and returns 0: times what ONE rank's step costs without its exchange
+ * (profiles/measure_c5_rank_step.py); the received state is then stale, results are not meaningful. */
+int snn_exchange_noop(void *user, void *hip_stream);
 /* HIP stream the handle launches on (hipStream_t), for ordering collectives against it */
 int snn_stream(snn_network_t *net, void **hip_stream);
 /* Adopt the caller's stream (e.g. the one its RCCL collectives are ordered against); NULL returns to the

@@ -510,6 +510,22 @@ static inline void neuron_nt_update(snn_o_net *n, uint32_t q, float voltage, uin
 static inline void receptors_kinetics(snn_o_net *n, uint32_t q)
 {
     const float dt = n->dt[q];
+    if (n->model == SNN_O_CUSTOM && n->rx_ntypes && n->rx_multi) {
+        /* a generated receptor set with several states per type (`receptors: a, b`, nb_macro lib.rs:7306-7316,
+         * 7391-7404): apply_r_change(t, dt) of every state of a type present in the input AND in the set; the states and
+         * their kinetics variables are set variables (slots 5..), t is slot 3, dt slot 2 */
+        float slot[5 + 32];
+        slot[0] = slot[1] = slot[4] = 0.0f; slot[2] = dt;
+        for (uint32_t j = 0; j < n->rx_nvars; ++j) slot[5 + j] = n->rx_vars[(size_t)j * n->n_neurons + q];
+        for (uint32_t k = 0; k < n->rx_ntypes; ++k) {
+            size_t i = (size_t)q * SNN_O_K + k;
+            if (!n->rc_flags[i] || n->input_count[i] == 0.0f) continue;
+            slot[3] = n->input_t[i];
+            program_run(n->rx_code, n->rx_consts, n->rx_kin_section[k], slot, 1);
+        }
+        for (uint32_t j = 0; j < n->rx_nvars; ++j) n->rx_vars[(size_t)j * n->n_neurons + q] = slot[5 + j];
+        return;
+    }
     for (int k = 0; k < SNN_O_K; ++k) {
         size_t i = (size_t)q * SNN_O_K + k;
         if (!n->rc_flags[i]) continue;
@@ -544,7 +560,7 @@ static inline void receptors_set_currents(snn_o_net *n, uint32_t q, float v_old)
     if (n->model == SNN_O_CUSTOM && n->rx_ntypes) {
         /* generated receptor set, build_test/nb_macro/src/lib.rs:7512-7543: every receptor present iterates, in
          * declaration order, over the set's variables */
-        float slot[5 + 24];
+        float slot[5 + 32];
         slot[0] = v_old; slot[2] = slot[3] = slot[4] = 0.0f;
         for (uint32_t j = 0; j < n->rx_nvars; ++j) slot[5 + j] = n->rx_vars[(size_t)j * n->n_neurons + q];
         for (uint32_t k = 0; k < n->rx_ntypes; ++k) {
@@ -837,7 +853,8 @@ enum { OP_END = 0, OP_CONST = 1, OP_LOAD = 2, OP_STORE = 3, OP_DIFF = 4, OP_NEG 
        OP_MUL = 9, OP_DIV = 10, OP_EXP = 11, OP_EQ = 12, OP_NE = 13, OP_GE = 14, OP_LE = 15, OP_GT = 16, OP_LT = 17,
        OP_AND = 18, OP_OR = 19, OP_JZ = 20, OP_JMP = 21, OP_TANH = 22, OP_SINH = 23, OP_COSH = 24, OP_MIN = 25,
        OP_MAX = 26, OP_HEAVISIDE = 27, OP_POWI = 28, OP_MARK = 29, OP_FLUSH = 30, OP_RC_UPDATE = 31, OP_RC_SET = 32,
-       OP_RC_GET = 33, OP_NT_APPLY = 34, OP_SIN = 35, OP_COS = 36, OP_TAN = 37, OP_ISNAN = 38 };
+       OP_RC_GET = 33, OP_NT_APPLY = 34, OP_SIN = 35, OP_COS = 36, OP_TAN = 37, OP_ISNAN = 38, OP_POWF = 39,
+       OP_RPOW = 40 };
 
 static float program_run_ctx(const int32_t *c, const float *consts, uint32_t pc, float *slot, int apply_diffs,
                              const program_ctx *ctx)
@@ -893,6 +910,8 @@ static float program_run_ctx(const int32_t *c, const float *consts, uint32_t pc,
             case OP_OR: r = (a != 0.0f || b != 0.0f); break;
             case OP_MIN: r = o_min(a, b); break;
             case OP_MAX: r = o_max(a, b); break;
+            case OP_POWF: r = snn_o_powf(a, b); break;                 /* `a ^ b`: (a.powf(b)), nb_macro lib.rs:135 */
+            case OP_RPOW: r = snn_o_powf(o_max(a, 0.0f), b); break;    /* `a r^ b`: (a.max(0.0f32).powf(b)), lib.rs:136 */
             }
             stack[sp++] = r;
         } }

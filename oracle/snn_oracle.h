@@ -224,6 +224,11 @@ typedef struct snn_o_net {
     uint32_t rx_section[3];
     int32_t  rx_current_index[3];
     float    *rx_vars;                         /* [rx_nvars][n_neurons] */
+    /* several receptor states per type (`receptors: a, b`): rx_multi != 0, and rx_kin_section[k] = the program that
+     * applies the receptor kinetics to every state of type k (slots 2 dt, 3 t, 5.. the set's variables, which then hold
+     * the states' r and kinetics variables); rc_r / rc_kind are not used by such a set */
+    uint32_t rx_multi;
+    uint32_t rx_kin_section[3];
 } snn_o_net;
 
 /* Step 1 of SURVEY §8(g): electrical + chemical inputs for every neuron from state S(t). */

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """What ONE rank of G does per C5 step (configs[4] sharded by lattice), timed on one GPU: the shard handle of rank G/2
-runs the library's step loop with a do-nothing exchange (snn_run_sharded_custom; the halo contents are then stale, the
+runs the library's step loop with a do-nothing exchange (snn_run_sharded_custom + snn_exchange_noop; the halo contents are then stale, the
 timing is not affected).  Shows how far the per-rank step is from its kernel time, i.e. how launch-bound the small
 sparse step is.  Usage: measure_c5_rank_step.py [steps]"""
 import json
@@ -39,9 +39,9 @@ for g in (1, 2, 4, 8):
     if g > 1:
         dn.halo_commit()
     plan = dn.exchange_plan() if g > 1 else None
-    dn.run_sharded_custom(lambda stream: None, 50)
+    dn.run_sharded_without_exchange(50)
     t0 = time.perf_counter()
-    dn.run_sharded_custom(lambda stream: None, steps)
+    dn.run_sharded_without_exchange(steps)
     dt = time.perf_counter() - t0
     print(json.dumps({"n_shards": g, "owned_neurons": int(dn.owned.size), "us_per_step": dt / steps * 1e6,
                       "recv_bytes_per_step": (4 * int(plan["recv_words"]) if plan else 0)}), flush=True)

@@ -143,6 +143,7 @@ SIGNATURES = {
     "snn_exchange": (C.c_int, [H, C.c_void_p]),
     "snn_run_sharded": (C.c_int, [H, C.c_void_p, C.c_uint64]),
     "snn_run_sharded_custom": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_uint64]),
+    "snn_exchange_noop": (C.c_int, [C.c_void_p, C.c_void_p]),
     "snn_stream": (C.c_int, [H, C.POINTER(C.c_void_p)]),
     "snn_set_stream": (C.c_int, [H, C.c_void_p]),
     "snn_synchronize": (C.c_int, [H]),

@@ -106,6 +106,8 @@ constexpr int NSTORE = 1;
 static const char *const NAMES[NSTORE] = {""};
 static const float DEFAULTS[NSTORE] = {0.0f};
 constexpr int CURRENT_INDEX[3] = {-1, -1, -1};
+constexpr bool MULTI_STATE = false;
+__device__ __forceinline__ void update_kinetics(int, float, float, float (&)[NSTORE]) {}
 __device__ __forceinline__ void iterate(int, float, float, float (&)[NSTORE]) {}
 } // namespace custom_receptors
 } // namespace snn
@@ -119,7 +121,7 @@ constexpr int CUSTOM_KINETICS = 100;     // SNN_NT_CUSTOM / SNN_RC_CUSTOM
 constexpr int CUSTOM_MAX_VARS = 32, CUSTOM_ST_MAX_VARS = 16, CUSTOM_REFR_MAX_VARS = 8, CUSTOM_KINETICS_MAX_VARS = 8;
 static_assert(custom_nt::NVARS <= CUSTOM_KINETICS_MAX_VARS, "too many variables in the generated neurotransmitter kinetics");
 static_assert(custom_rc::NVARS <= CUSTOM_KINETICS_MAX_VARS, "too many variables in the generated receptor kinetics");
-constexpr int CUSTOM_RECEPTORS_MAX_VARS = 24;
+constexpr int CUSTOM_RECEPTORS_MAX_VARS = 32;
 static_assert(custom_receptors::NVARS <= CUSTOM_RECEPTORS_MAX_VARS, "too many variables in the generated receptor set");
 static_assert(custom::NVARS <= CUSTOM_MAX_VARS, "too many variables in the generated neuron model");
 static_assert(custom_st::NVARS <= CUSTOM_ST_MAX_VARS, "too many variables in the generated spike train");

@@ -15,6 +15,7 @@
 // For STDP the handle also keeps, in the caller's CSR edge order: the SELL slot and the local row of every
 // edge, and the transpose index t_ptr / t_edge (edges grouped by presynaptic cell).
 #pragma once
+#include "snn_kernels_exchange.hpp"
 #include "snn_kernels_inputs.hpp"
 #include "snn_kernels_misc.hpp"
 #include "snn_kernels_reward.hpp"
@@ -165,20 +166,38 @@ struct RegisterSums {
     __device__ __forceinline__ float chem(int k) const { return t[k]; }
 };
 
-// Inputs + neuron update of an unsharded sparse handle in ONE launch: row thread = neuron thread, so the sums never
-// leave registers.  Other rows may still be gathering S(t) while a neuron writes S(t+1): as in k_step_resident the
-// exchanged state is read from a shadow copy (in.xbuf = up.n.xbuf) and written to the exchange buffer and the other
-// shadow (up.xout / up.xout2).
+// Inputs + neuron update of a sparse handle in ONE launch: row thread = neuron thread, so the sums never leave
+// registers.  Other rows may still be gathering S(t) while a neuron writes S(t+1): as in k_step_resident the exchanged
+// state is read from a shadow copy (in.xbuf = up.n.xbuf) and written to the exchange buffer and the other shadow
+// (up.xout / up.xout2).
+//
+// Shard handles (halo exchange) run it twice per step: first over the BORDER slices -- the 64-row slices that hold a
+// neuron some peer reads -- whose threads also write the neuron's wire values straight into the outgoing segments
+// (PackTable: the step needs no pack launch), then, while RCCL moves those segments, over the INTERIOR slices.
+// slice_list = the slices of the launch (null: all of them).
+struct PackTable {
+    const uint32_t *ptr;            // [n_loc + 1] entries of local row q: ptr[q] .. ptr[q + 1]; null = no packing
+    const uint32_t *seg_off;        // per entry: word offset of its segment in `buf`,
+    const uint32_t *seg_count;      //            neurons of that segment,
+    const uint32_t *index;          //            and the neuron's position in it
+    uint32_t *buf;                  // outgoing segments (wire format of snn_kernels_exchange.hpp); spike bitmaps zeroed
+    uint32_t planes, plane_id[WIRE_MAX_PLANES];
+};
+
 struct CsrStepArgs {
     CsrInputsArgs c;
     UpdateArgs up;
+    const uint32_t *slice_list;
+    uint32_t n_listed;
+    PackTable pack;
 };
 
 template <int MODEL, bool ELEC, bool CHEM>
 __global__ __launch_bounds__(256) void k_step_csr(const CsrStepArgs a)
 {
-    const uint32_t q = blockIdx.x * 256 + threadIdx.x;
-    if ((q >> 6) >= a.c.g.n_slices) return;                  // whole wavefront
+    const uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6);  // wavefront = one SELL slice
+    if (a.slice_list ? w >= a.n_listed : w >= a.c.g.n_slices) return;
+    const uint32_t q = (a.slice_list ? a.slice_list[w] : w) * 64u + (threadIdx.x & 63u);
     RegisterSums s;
     csr_row_sums<ELEC, CHEM>(a.c, q, s.i, s.t);
     uint32_t spike = 0;
@@ -186,6 +205,76 @@ __global__ __launch_bounds__(256) void k_step_csr(const CsrStepArgs a)
     if (a.up.spike_row) {
         const unsigned long long word = __ballot(spike != 0);
         if ((threadIdx.x & 63u) == 0) a.up.spike_row[(a.up.q0 + q) >> 6] = word;
+    }
+    if (a.pack.ptr && q < a.c.g.n_loc) {
+        // the values this thread has just written, into every segment that carries the neuron; the spike as ONE bit
+        // OR-ed into the segment's bitmap (zeroed by k_step_close after the previous exchange; spikes are rare)
+        const uint32_t g = a.up.rows.global_of(q);
+        const uint32_t *x = reinterpret_cast<const uint32_t *>(a.up.xout);
+        for (uint32_t e = a.pack.ptr[q]; e < a.pack.ptr[q + 1]; ++e) {
+            const uint32_t count = a.pack.seg_count[e], i = a.pack.index[e];
+            uint32_t *out = a.pack.buf + a.pack.seg_off[e];
+            for (uint32_t pl = 0; pl < a.pack.planes; ++pl) out[(size_t)pl * count + i] = x[a.up.n.xl.at(g, (int)a.pack.plane_id[pl])];
+            if (spike) atomicOr(out + (size_t)a.pack.planes * count + (i >> 5), 1u << (i & 31u));
+        }
+    }
+}
+
+// The second (and last) launch of a sparse shard handle's step, after the exchange: three independent jobs side by side,
+//   blocks [0, cell_blocks)                 the spike-train cells this rank reads advance (k_spike_trains' body),
+//   blocks [cell_blocks, +unpack_blocks)    the received segments go into the mirror AND into the shadow the next step
+//                                           reads, with the last_firing_time stamp of a neuron owned elsewhere,
+//   the rest                                the spike bitmaps of the OUTGOING segments are cleared for the next step's
+//                                           in-kernel pack (RCCL has sent them: this launch waits for the exchange).
+// Valid when nothing has to happen between the unpack and the cells (no weight updates, no per-lattice reductions).
+struct StepCloseArgs {
+    SpikeTrainArgs cells;
+    WireArgs recv;                  // unpack side: segment tables of the incoming segments
+    float *xbuf2;                   // second destination of the unpack (the shadow of the next step) or null
+    uint32_t recv_total;            // neurons over all incoming segments
+    uint32_t recv_segments;
+    WireArgs send;                  // segment tables of the outgoing segments (bitmaps to clear)
+    uint32_t send_segments;
+    uint32_t send_bitmap_words;     // over all outgoing segments
+    uint32_t cell_blocks, unpack_blocks;
+};
+
+__global__ __launch_bounds__(256) void k_step_close(const StepCloseArgs a)
+{
+    if (blockIdx.x < a.cell_blocks) {
+        spike_train_cell(a.cells, blockIdx.x * 256 + threadIdx.x);
+        return;
+    }
+    if (blockIdx.x < a.cell_blocks + a.unpack_blocks) {
+        const uint32_t t = (blockIdx.x - a.cell_blocks) * 256 + threadIdx.x;
+        if (t >= a.recv_total) return;
+        // the segment of flat position t: list offsets are the running totals (at most n_shards - 1 segments)
+        uint32_t seg = 0;
+        while (seg + 1 < a.recv_segments && t >= (uint32_t)a.recv.seg_list_offset[seg + 1]) ++seg;
+        const uint32_t i = t - (uint32_t)a.recv.seg_list_offset[seg];
+        const uint32_t count = a.recv.seg_count[seg];
+        const uint32_t g = a.recv.list[t];
+        if (g >= a.recv.n_neurons) return;
+        const uint32_t *in = a.recv.buf + a.recv.seg_offset[seg];
+        uint32_t *x = reinterpret_cast<uint32_t *>(a.recv.xbuf), *x2 = reinterpret_cast<uint32_t *>(a.xbuf2);
+        for (uint32_t s = 0; s < a.recv.planes; ++s) {
+            const uint32_t v = in[(size_t)s * count + i];
+            const size_t at = a.recv.xl.at(g, (int)a.recv.plane_id[s]);
+            x[at] = v;
+            if (x2) x2[at] = v;
+        }
+        const uint32_t spike = (in[(size_t)a.recv.planes * count + (i >> 5)] >> (i & 31u)) & 1u;
+        x[a.recv.xl.at(g, PLANE_SPIKE)] = spike;
+        if (x2) x2[a.recv.xl.at(g, PLANE_SPIKE)] = spike;
+        if (spike) a.recv.last_firing_time[g] = (int32_t)a.recv.clock;
+        return;
+    }
+    uint32_t t = (blockIdx.x - a.cell_blocks - a.unpack_blocks) * 256 + threadIdx.x;
+    if (t >= a.send_bitmap_words) return;
+    for (uint32_t seg = 0; seg < a.send_segments; ++seg) {
+        const uint32_t count = a.send.seg_count[seg], words = (count + 31u) / 32u;
+        if (t < words) { a.send.buf[a.send.seg_offset[seg] + (size_t)a.send.planes * count + t] = 0u; return; }
+        t -= words;
     }
 }
 

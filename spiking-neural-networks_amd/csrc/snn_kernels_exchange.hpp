@@ -40,6 +40,7 @@ struct WireArgs {
     uint32_t skip;                  // unpack: segment that is not applied (the handle's own slot), or 0xFFFFFFFF
     int32_t *last_firing_time;      // unpack
     long long clock;                // unpack: the step being closed
+    float *xbuf2;                   // unpack: a second copy of the mirror that receives the same values, or null
 };
 
 __device__ __forceinline__ uint32_t wire_neuron(const WireArgs &a, uint32_t seg, uint32_t i)
@@ -82,10 +83,15 @@ __global__ __launch_bounds__(256) void k_exchange_unpack(const WireArgs a)
     const uint32_t g = wire_neuron(a, seg, i);
     if (g >= a.n_neurons) return;
     const uint32_t *in = a.buf + a.seg_offset[seg];
-    for (uint32_t s = 0; s < a.planes; ++s)
-        reinterpret_cast<uint32_t *>(a.xbuf)[a.xl.at(g, (int)a.plane_id[s])] = in[(size_t)s * count + i];
+    uint32_t *x = reinterpret_cast<uint32_t *>(a.xbuf), *x2 = reinterpret_cast<uint32_t *>(a.xbuf2);
+    for (uint32_t s = 0; s < a.planes; ++s) {
+        const uint32_t v = in[(size_t)s * count + i];
+        x[a.xl.at(g, (int)a.plane_id[s])] = v;
+        if (x2) x2[a.xl.at(g, (int)a.plane_id[s])] = v;
+    }
     const uint32_t spike = (in[(size_t)a.planes * count + (i >> 5)] >> (i & 31u)) & 1u;
-    reinterpret_cast<uint32_t *>(a.xbuf)[a.xl.at(g, PLANE_SPIKE)] = spike;
+    x[a.xl.at(g, PLANE_SPIKE)] = spike;
+    if (x2) x2[a.xl.at(g, PLANE_SPIKE)] = spike;
     if (spike) a.last_firing_time[g] = (int32_t)a.clock;   // neuron/mod.rs:2555-2557 for a neuron owned elsewhere
 }
 

@@ -132,9 +132,9 @@ struct SpikeTrainArgs {
     uint32_t n_listed;
 };
 
-__global__ __launch_bounds__(256) void k_spike_trains(const SpikeTrainArgs a)
+// one spike-train cell: thread i of the cell job
+__device__ __forceinline__ void spike_train_cell(const SpikeTrainArgs &a, const uint32_t i)
 {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= (a.cell_list ? a.n_listed : a.n_cells)) return;
     const uint32_t s = a.cell_list ? a.cell_list[i] : i;
     const CellArrays &c = a.c;
@@ -232,6 +232,11 @@ __global__ __launch_bounds__(256) void k_spike_trains(const SpikeTrainArgs a)
                      : delta_dirac_effect(a.view_clock, lft, p_v_th, p_v_resting, p_k, p_dt);
     }
     c.presyn_value[s] = value;
+}
+
+__global__ __launch_bounds__(256) void k_spike_trains(const SpikeTrainArgs a)
+{
+    spike_train_cell(a, blockIdx.x * 256 + threadIdx.x);
 }
 
 // ---- plasticity ------------------------------------------------------------------------------

@@ -105,6 +105,22 @@ struct GlobalSums {
 template <class Sums>
 __device__ __forceinline__ void receptors_kinetics(const UpdateArgs &a, uint32_t q, uint32_t ql, float dt, const Sums &sums)
 {
+    if (SNN_HAVE_CUSTOM_RECEPTORS && custom_receptors::MULTI_STATE && a.model_is_custom) {
+        // a generated receptor set with several states per type (nb_macro lib.rs:7306-7316, 7391-7404): the states and
+        // their kinetics variables are the set's own variables; a type absent from the input leaves its states untouched
+        float x[custom_receptors::NSTORE];
+#pragma unroll
+        for (int j = 0; j < custom_receptors::NVARS; ++j) x[j] = a.n.rx_custom[j][q];
+#pragma unroll
+        for (int k = 0; k < custom_receptors::NTYPES; ++k) {
+            if (!a.n.rc_flags[(size_t)k * a.n.n_pad + q]) continue;
+            const uint32_t cnt = a.tcount[(size_t)k * a.ld + ql];
+            if (cnt != 0) custom_receptors::update_kinetics(k, sums.chem(k) / (float)cnt, dt, x);
+        }
+#pragma unroll
+        for (int j = 0; j < custom_receptors::NVARS; ++j) a.n.rx_custom[j][q] = x[j];
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < K_TYPES; ++k) {
         const size_t i = (size_t)k * a.n.n_pad + q;

@@ -125,7 +125,7 @@ struct NeuronArrays {
     // neurotransmitters [3][n_pad] (t lives in xbuf planes 2..4)
     float *nt_t_max, *nt_clearance, *nt_v_p, *nt_k_p;
     float *nt_custom[8], *rc_custom[8];   // variables of generated kinetics (custom_nt / custom_rc), [3][n_pad] each
-    float *rx_custom[24];                 // variables of a generated receptor set (custom_receptors), [n_pad] each
+    float *rx_custom[32];                 // variables of a generated receptor set (custom_receptors), [n_pad] each
     uint32_t *nt_flags;
     // receptors [3][n_pad]
     float *rc_g, *rc_e, *rc_mg, *rc_r, *rc_alpha, *rc_beta, *rc_current;

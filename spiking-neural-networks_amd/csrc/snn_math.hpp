@@ -328,6 +328,9 @@ __device__ __forceinline__ float min_rs(float a, float b)
     return (a < b) ? a : b;
 }
 
+// nb_macro's `a r^ b` (lib.rs:136): (a.max(0.0f32).powf(b))
+__device__ __forceinline__ float rpowf_glibc(float a, float b) { return powf_glibc(max_rs(a, 0.0f), b); }
+
 // xorshift32 of the reference's Poisson kernel (spike_train/mod.rs:380-388)
 __device__ __forceinline__ uint32_t xorshift32(uint32_t x)
 {

@@ -80,7 +80,9 @@ int snn_network_destroy(snn_network_t *net)
     for (void *p : {(void *)net->halo_send_buf, (void *)net->halo_recv_buf, (void *)net->halo_send_idx, (void *)net->halo_recv_idx,
                     (void *)net->seg_count_dev[0], (void *)net->seg_count_dev[1], (void *)net->seg_first_dev[0],
                     (void *)net->seg_first_dev[1], (void *)net->seg_offset_dev[0], (void *)net->seg_offset_dev[1],
-                    (void *)net->seg_loff_dev[0], (void *)net->seg_loff_dev[1]})
+                    (void *)net->seg_loff_dev[0], (void *)net->seg_loff_dev[1], (void *)net->csr_border_dev,
+                    (void *)net->csr_interior_dev, (void *)net->pack_ptr_dev, (void *)net->pack_segoff_dev,
+                    (void *)net->pack_count_dev, (void *)net->pack_index_dev})
         if (p) (void)hipFree(p);
     if (net->comm_stream) { (void)hipStreamSynchronize(net->comm_stream); (void)hipStreamDestroy(net->comm_stream); }
     if (net->ev_packed) (void)hipEventDestroy(net->ev_packed);
@@ -893,6 +895,9 @@ int snn_step_begin_local(snn_network_t *net)
     if (!net->electrical && !net->chemical) return SNN_OK;
     HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
     TRY(begin_run(net, 1));
+    // sparse shard handles: the INTERIOR slices of the step snn_step_begin opened (its border slices and the outgoing
+    // segments are enqueued; nothing an interior row reads or writes travels) -- call it once the exchange is under way
+    if (net->interior_pending) return step_interior(net);
     // Only when nothing of the previous step is still pending for these chunks: STDP rewrites W in
     // snn_step_end and needs the gathered spikes first, so with plasticity on the split is not taken.
     if (net->nn && !net->csr && !net->any_plasticity && !net->any_modulation && !net->drive_threshold && !net->local_inputs_done) {
@@ -1137,6 +1142,8 @@ int snn_exchange(snn_network_t *net, void *nccl_comm)
     return SNN_OK;
 }
 
+int snn_exchange_noop(void *, void *) { return 0; }
+
 int snn_run_sharded_custom(snn_network_t *net, snn_exchange_fn exchange, void *user, uint64_t iterations)
 {
     if (!net || !exchange) return fail(SNN_ERR_BAD_ARG, "null argument");
@@ -1148,6 +1155,7 @@ int snn_run_sharded_custom(snn_network_t *net, snn_exchange_fn exchange, void *u
     for (uint64_t it = 0; it < iterations; ++it) {
         if (net->nn) TRY(step_begin(net));
         TRY(launch_exchange_pack(net));
+        TRY(step_interior(net));                  // sparse handles: interior slices are enqueued before the host-side exchange
         if (exchange(user, net->stream) != 0) return fail(SNN_ERR_QUEUE, "the caller's exchange function failed");
         TRY(step_end(net));
         if (net->profile && (net->ev_used >= 8192 || net->ev_used_pl >= 8192)) TRY(collect_profile(net));
@@ -1217,19 +1225,26 @@ int snn_run_sharded(snn_network_t *net, void *nccl_comm, uint64_t iterations)
     // The own-rows part of step t + 1's input pass does not read what the exchange of step t delivers: it is enqueued
     // before the compute stream waits for the collective (dense handles, no weight updates pending in step_end).
     const bool split = !net->csr && !net->any_plasticity && !net->any_modulation && !net->drive_threshold && net->n_shards > 1;
+    // a halo plan in which nothing travels (a lone shard, or peers that read nothing of each other): no collective, no
+    // cross-stream events -- the step is its kernels
+    bool travels = net->x_mode == SNN_EXCHANGE_ALLGATHER;
+    for (uint32_t p = 0; p < net->n_shards && !travels; ++p) travels = net->x_send_words[p] || net->x_recv_words[p];
     for (uint64_t it = 0; it < iterations; ++it) {
         if (net->nn) TRY(step_begin(net));
         TRY(launch_exchange_pack(net));
-        HIP_TRY(hipEventRecord(net->ev_packed, net->stream), SNN_ERR_QUEUE);
-        HIP_TRY(hipStreamWaitEvent(net->comm_stream, net->ev_packed, 0), SNN_ERR_QUEUE);
-        TRY(enqueue_exchange(R, net, comm, net->comm_stream));
-        HIP_TRY(hipEventRecord(net->ev_exchanged, net->comm_stream), SNN_ERR_QUEUE);
+        if (travels) {
+            HIP_TRY(hipEventRecord(net->ev_packed, net->stream), SNN_ERR_QUEUE);
+            HIP_TRY(hipStreamWaitEvent(net->comm_stream, net->ev_packed, 0), SNN_ERR_QUEUE);
+            TRY(enqueue_exchange(R, net, comm, net->comm_stream));
+            HIP_TRY(hipEventRecord(net->ev_exchanged, net->comm_stream), SNN_ERR_QUEUE);
+        }
+        TRY(step_interior(net));                  // sparse handles: the interior slices run while the halo travels
         if (split && it + 1 < iterations && net->nn && !net->local_inputs_done) {
             // step_end below advances the clock and the spike trains; the LOCAL chunks read neither
             TRY(launch_inputs(net, INPUTS_LOCAL));
             net->local_inputs_done = true;
         }
-        HIP_TRY(hipStreamWaitEvent(net->stream, net->ev_exchanged, 0), SNN_ERR_QUEUE);
+        if (travels) HIP_TRY(hipStreamWaitEvent(net->stream, net->ev_exchanged, 0), SNN_ERR_QUEUE);
         TRY(step_end(net));
         if (net->profile && (net->ev_used >= 8192 || net->ev_used_pl >= 8192)) TRY(collect_profile(net));
     }

@@ -110,6 +110,39 @@ int ensure_exchange_plan(snn_network *net)
         }
         TRY(upload_table(&net->halo_send_idx, send_idx));
         TRY(upload_table(&net->halo_recv_idx, recv_idx));
+        net->recv_total = (uint32_t)recv_idx.size();
+        // the one-launch sparse step: border / interior slices and the per-row pack table
+        const uint32_t n_slices = (net->n_loc + 63) / 64;
+        std::vector<uint8_t> is_border(n_slices, 0);
+        std::vector<uint32_t> pack_ptr(net->n_loc + 1, 0), pack_segoff, pack_count, pack_index;
+        auto local_row = [&](uint32_t g) { return net->block_mode ? net->local_row_host[g] : g - net->q0; };
+        for (uint32_t p = 0; p < G; ++p)
+            for (uint32_t g : net->halo_send[p]) pack_ptr[local_row(g) + 1] += 1;
+        for (uint32_t q = 0; q < net->n_loc; ++q) pack_ptr[q + 1] += pack_ptr[q];
+        pack_segoff.resize(pack_ptr[net->n_loc]); pack_count.resize(pack_ptr[net->n_loc]); pack_index.resize(pack_ptr[net->n_loc]);
+        {
+            std::vector<uint32_t> fill(pack_ptr.begin(), pack_ptr.end() - 1);
+            net->send_bitmap_words = 0;
+            for (uint32_t p = 0; p < G; ++p) {
+                const auto &sl = net->halo_send[p];
+                net->send_bitmap_words += (uint32_t)(sl.size() + 31) / 32;
+                for (uint32_t i = 0; i < sl.size(); ++i) {
+                    const uint32_t q = local_row(sl[i]), e = fill[q]++;
+                    pack_segoff[e] = (uint32_t)net->x_send_off[p]; pack_count[e] = (uint32_t)sl.size(); pack_index[e] = i;
+                    is_border[q >> 6] = 1;
+                }
+            }
+        }
+        std::vector<uint32_t> border, interior;
+        for (uint32_t sl = 0; sl < n_slices; ++sl) (is_border[sl] ? border : interior).push_back(sl);
+        net->n_border = (uint32_t)border.size(); net->n_interior = (uint32_t)interior.size();
+        TRY(upload_table(&net->csr_border_dev, border));
+        TRY(upload_table(&net->csr_interior_dev, interior));
+        TRY(upload_table(&net->pack_ptr_dev, pack_ptr));
+        TRY(upload_table(&net->pack_segoff_dev, pack_segoff));
+        TRY(upload_table(&net->pack_count_dev, pack_count));
+        TRY(upload_table(&net->pack_index_dev, pack_index));
+        net->send_bits_clean = true;                 // the send buffer is (re)created zeroed below
         for (uint32_t **b : {&net->halo_send_buf, &net->halo_recv_buf})
             if (*b) { (void)hipFree(*b); *b = nullptr; }
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&net->halo_send_buf), std::max<uint64_t>(so * 4, 256)), SNN_ERR_BUFFER_CREATE);
@@ -143,6 +176,8 @@ WireArgs wire_args(snn_network *net, int which)
     a.skip = (!halo && which == 1) ? net->shard_index : 0xFFFFFFFFu;
     a.last_firing_time = net->na.last_firing_time;
     a.clock = net->clock;
+    // sparse handles stepping with k_step_csr read S(t) from a shadow of the mirror: what arrives goes there too
+    a.xbuf2 = (which == 1 && net->csr && net->shadow_valid) ? net->shadow[net->shadow_cur] : nullptr;
     return a;
 }
 
@@ -150,6 +185,8 @@ WireArgs wire_args(snn_network *net, int which)
 int launch_exchange_pack(snn_network *net)
 {
     if (!net->sharded || net->seg_n[0] == 0 || net->seg_max[0] == 0) return SNN_OK;
+    if (net->step_packed) return SNN_OK;             // k_step_csr wrote the segments itself
+    net->send_bits_clean = false;                    // whole bitmap words, set bits included
     hipLaunchKernelGGL(k_exchange_pack, dim3((net->seg_max[0] + 255) / 256, net->seg_n[0]), dim3(256), 0, net->stream,
                        wire_args(net, 0));
     HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
@@ -163,6 +200,43 @@ int launch_exchange_unpack(snn_network *net)
     if (net->x_mode == SNN_EXCHANGE_ALLGATHER && net->n_shards == 1) return SNN_OK;
     hipLaunchKernelGGL(k_exchange_unpack, dim3((net->seg_max[1] + 255) / 256, net->seg_n[1]), dim3(256), 0, net->stream,
                        wire_args(net, 1));
+    HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+    return SNN_OK;
+}
+
+// k_step_close: spike trains (as launch_spike_trains(net, 1, run_step_offset, clock + 1)), the unpack of the halo that
+// has arrived, and the clearing of the outgoing spike bitmaps -- any subset, one launch
+int launch_step_close(snn_network *net, bool cells, bool unpack)
+{
+    StepCloseArgs a{};
+    uint32_t cell_work = 0;
+    if (cells && net->nc) {
+        SpikeTrainArgs &c = a.cells;
+        c.c = net->ca; c.n_cells = net->nc; c.st_kind = net->st_kind; c.nt_kind = net->nt_kind;
+        c.iterate = 1; c.lattice_clock = net->st_clock_dev; c.step_offset = net->run_step_offset;
+        c.has_nt = net->any_nt_cells ? 1 : 0;
+        c.view_clock = net->clock + 1;
+        c.vhist_row = (record_now(net) && net->want_vhist && net->st_vhist) ? net->st_vhist + (size_t)net->hist_steps * net->c_pad : nullptr;
+        c.cell_list = net->cell_list_dev; c.n_listed = net->n_cells_listed;
+        cell_work = net->cell_list_dev ? net->n_cells_listed : net->nc;
+    }
+    a.cell_blocks = (cell_work + 255) / 256;
+    if (unpack && net->n_shards > 1 && net->seg_n[1] && net->recv_total) {
+        a.recv = wire_args(net, 1);
+        a.xbuf2 = a.recv.xbuf2;
+        a.recv_total = net->recv_total;
+        a.recv_segments = net->seg_n[1];
+        a.unpack_blocks = (net->recv_total + 255) / 256;
+    }
+    if (!net->send_bits_clean && net->send_bitmap_words) {
+        a.send = wire_args(net, 0);
+        a.send_segments = net->seg_n[0];
+        a.send_bitmap_words = net->send_bitmap_words;
+    }
+    const uint32_t blocks = a.cell_blocks + a.unpack_blocks + (a.send_bitmap_words + 255) / 256;
+    net->send_bits_clean = true;
+    if (blocks == 0) return SNN_OK;
+    hipLaunchKernelGGL(k_step_close, dim3(blocks), dim3(256), 0, net->stream, a);
     HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
     return SNN_OK;
 }

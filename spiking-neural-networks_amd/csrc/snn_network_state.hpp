@@ -136,6 +136,16 @@ struct snn_network {
     uint32_t *seg_count_dev[2] = {nullptr, nullptr}, *seg_first_dev[2] = {nullptr, nullptr};
     uint64_t *seg_offset_dev[2] = {nullptr, nullptr}, *seg_loff_dev[2] = {nullptr, nullptr};
     uint32_t seg_n[2] = {0, 0}, seg_max[2] = {0, 0};
+    // one-launch sparse step on shard handles (halo mode, k_step_csr + k_step_close): the 64-row slices that hold a
+    // neuron some peer reads (border) and the others (interior); per local row the outgoing-segment positions of its
+    // neuron (PackTable); totals of the close launch's unpack / clear jobs
+    uint32_t *csr_border_dev = nullptr, *csr_interior_dev = nullptr;
+    uint32_t n_border = 0, n_interior = 0;
+    uint32_t *pack_ptr_dev = nullptr, *pack_segoff_dev = nullptr, *pack_count_dev = nullptr, *pack_index_dev = nullptr;
+    uint32_t recv_total = 0, send_bitmap_words = 0;
+    bool send_bits_clean = true;          // every outgoing spike bitmap is zero (what the in-kernel pack ORs into)
+    bool step_packed = false;             // this step's outgoing segments were written by k_step_csr itself
+    bool interior_pending = false;        // the border half of this step is enqueued, the interior slices are not yet
     // in-library collective (snn_run_sharded): RCCL is ordered on its own stream against the compute stream
     hipStream_t comm_stream = nullptr;
     hipEvent_t ev_packed = nullptr, ev_exchanged = nullptr;

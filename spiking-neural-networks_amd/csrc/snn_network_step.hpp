@@ -749,21 +749,46 @@ int launch_run_resident(snn_network *net, uint64_t iterations)
     return SNN_OK;
 }
 
-// Unsharded sparse handles: row sums + neuron update in one launch (k_step_csr).
+// Sparse handles: row sums + neuron update in one launch (k_step_csr).  Shard handles too: what arrives from the peers
+// is written into the shadow the next step reads as well (wire_args / k_step_close).
 bool fused_csr_step_applies(const snn_network *net)
 {
-    return !SNN_HAVE_CUSTOM_MODEL && net->fused_step && net->csr && net->csr_ptr && !net->sharded && !net->drive_threshold &&
-           net->n_loc && !net->local_inputs_done;
+    return !SNN_HAVE_CUSTOM_MODEL && net->fused_step && net->csr && net->csr_ptr && !net->drive_threshold &&
+           net->n_loc && !net->local_inputs_done &&
+           (!net->sharded || net->n_shards == 1 || net->x_mode == SNN_EXCHANGE_HALO);
 }
 
-int launch_step_csr(snn_network *net)
+// ... and, when nothing has to happen between the unpack and the spike trains (no weight updates, no per-lattice
+// reductions), the whole step of a shard handle is: k_step_csr over the border slices, packing as it goes -> [exchange]
+// -> k_step_csr over the interior slices -> k_step_close (cells + unpack + clearing the outgoing bitmaps).
+bool csr_fast_step(const snn_network *net)
+{
+    return fused_csr_step_applies(net) && net->sharded && net->x_mode == SNN_EXCHANGE_HALO && !net->any_plasticity &&
+           !net->any_modulation && !net->want_avg && !net->want_eeg && !net->any_whist;
+}
+
+enum CsrStepPart { CSR_STEP_ALL = 0, CSR_STEP_BORDER = 1, CSR_STEP_INTERIOR = 2 };
+
+int launch_step_close(snn_network *net, bool cells, bool unpack);
+
+int launch_step_csr(snn_network *net, CsrStepPart part = CSR_STEP_ALL, bool pack = false)
 {
     CsrStepArgs c{};
     TRY(fused_step_args(net, c.c.in, c.up));
     c.c.g = csr_graph(net);
+    uint32_t waves = c.c.g.n_slices;
+    if (part == CSR_STEP_BORDER) { c.slice_list = net->csr_border_dev; c.n_listed = waves = net->n_border; }
+    if (part == CSR_STEP_INTERIOR) { c.slice_list = net->csr_interior_dev; c.n_listed = waves = net->n_interior; }
+    if (pack) {
+        c.pack.ptr = net->pack_ptr_dev; c.pack.seg_off = net->pack_segoff_dev; c.pack.seg_count = net->pack_count_dev;
+        c.pack.index = net->pack_index_dev; c.pack.buf = net->halo_send_buf; c.pack.planes = net->x_planes;
+        for (int s = 0; s < WIRE_MAX_PLANES; ++s) c.pack.plane_id[s] = net->x_plane_id[s];
+    }
     hipEvent_t e1 = nullptr;
-    TRY(profile_open(net, &e1));
-    const dim3 grid((((net->n_loc + 63) / 64) * 64 + 255) / 256), block(256);
+    if (waves) {
+        TRY(profile_open(net, &e1));
+        if (e1 && part == CSR_STEP_BORDER && net->n_interior) net->ev_counts[net->ev_used - 1] = 0;   // the interior launch counts the pass
+        const dim3 grid((waves + 3) / 4), block(256);
 #define SNN_CSR_STEP(M)                                                                                              \
     do {                                                                                                             \
         if (net->electrical && net->chemical) hipLaunchKernelGGL((k_step_csr<M, true, true>), grid, block, 0, net->stream, c);  \
@@ -771,15 +796,24 @@ int launch_step_csr(snn_network *net)
         else hipLaunchKernelGGL((k_step_csr<M, false, true>), grid, block, 0, net->stream, c);                                  \
     } while (0)
 #if !SNN_HAVE_CUSTOM_MODEL
-    SNN_FOR_MODEL(SNN_CSR_STEP)
+        SNN_FOR_MODEL(SNN_CSR_STEP)
 #else
-    (void)grid, (void)block;
+        (void)grid, (void)block;
 #endif
 #undef SNN_CSR_STEP
-    HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
-    if (e1) HIP_TRY(hipEventRecord(e1, net->stream), SNN_ERR_QUEUE);
-    net->shadow_cur ^= 1;
+        HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+        if (e1) HIP_TRY(hipEventRecord(e1, net->stream), SNN_ERR_QUEUE);
+    }
+    if (part != CSR_STEP_BORDER) net->shadow_cur ^= 1;       // S(t+1) is complete once the last part is enqueued
     return SNN_OK;
+}
+
+// the interior half of a sparse shard handle's step (no-op unless step_begin left it pending)
+int step_interior(snn_network *net)
+{
+    if (!net->interior_pending) return SNN_OK;
+    net->interior_pending = false;
+    return launch_step_csr(net, CSR_STEP_INTERIOR);
 }
 
 // first half of a step: inputs from S(t) and the local neurons' update
@@ -791,6 +825,16 @@ int step_begin(snn_network *net)
         HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
     }
     if (fused_step_applies(net)) return launch_step_resident(net);
+    if (csr_fast_step(net)) {
+        // border slices first, writing the outgoing segments themselves; the interior slices follow once the caller has
+        // started the exchange (step_interior: snn_run_sharded, snn_step_begin_local, or at the latest step_end)
+        if (!net->send_bits_clean) TRY(launch_step_close(net, /*cells=*/false, /*unpack=*/false));
+        if (net->n_border) TRY(launch_step_csr(net, CSR_STEP_BORDER, /*pack=*/true));
+        net->send_bits_clean = net->n_border == 0;
+        net->step_packed = true;
+        net->interior_pending = true;
+        return SNN_OK;
+    }
     if (fused_csr_step_applies(net)) return launch_step_csr(net);
     TRY(launch_inputs(net, net->local_inputs_done ? INPUTS_REMOTE : INPUTS_ALL));
     net->local_inputs_done = false;
@@ -801,6 +845,17 @@ int step_begin(snn_network *net)
 // second half: remote last_firing_time, plasticity, histories, clock, spike trains (steps 3-6)
 int step_end(snn_network *net)
 {
+    TRY(step_interior(net));
+    if (net->step_packed) {
+        // the fast sparse step (csr_fast_step): unpack, spike trains and the clearing of the outgoing bitmaps in ONE launch
+        net->step_packed = false;
+        TRY(launch_step_close(net, /*cells=*/true, /*unpack=*/true));
+        net->clock += 1;
+        net->run_step_offset += 1;
+        if (record_now(net)) net->hist_steps += 1;
+        if (recording(net)) net->hist_tick += 1;
+        return SNN_OK;
+    }
     TRY(launch_exchange_unpack(net));      // shard handles: the other ranks' state of this step, their last_firing_time
     // weight snapshots: order 2 = before the step's weight updates (LatticeNetwork::iterate, neuron/mod.rs:2450-2461),
     // order 1 = after them (a lone Lattice, neuron/mod.rs:904-910)

@@ -88,7 +88,7 @@ MAX_POWER = 16
 MAX_ST_VARS = 16
 MAX_REFRACTORINESS_VARS = 8
 MAX_KINETICS_VARS = 8
-MAX_RECEPTOR_VARS = 24
+MAX_RECEPTOR_VARS = 32
 
 
 class ModelError(ValueError):
@@ -100,10 +100,20 @@ _TOKEN = re.compile(r"\s*(?:(\d+\.\d*(?:[eE][+-]?\d+)?|\.\d+(?:[eE][+-]?\d+)?|\d
                     r"(\|\||&&|==|!=|>=|<=|[-+*/()<>!,^]))")
 
 
+_RPOWER = re.compile(r"\s*r\^")
+
+
 def _tokens(text):
     out, pos = [], 0
     text = text.strip()
     while pos < len(text):
+        # `r^` (pest_ast/mod.rs:46) is an operator only where an operator may stand: after an operand
+        if out and (out[-1][0] in ("num", "name") or out[-1] == ("op", ")")):
+            m = _RPOWER.match(text, pos)
+            if m:
+                out.append(("op", "r^"))
+                pos = m.end()
+                continue
         m = _TOKEN.match(text, pos)
         if not m:
             raise ModelError(f"cannot read expression at: {text[pos:]!r}")
@@ -115,7 +125,7 @@ def _tokens(text):
 
 # ---- expressions: ("num", f) | ("var", name) | ("neg", e) | ("not", e) | ("bin", op, l, r) | ("call", name, [args])
 #                   | ("powi", base, n)
-_LEVELS = [("||",), ("&&",), ("==", "!=", ">=", "<=", ">", "<"), ("+", "-"), ("*", "/"), ("^",)]
+_LEVELS = [("||",), ("&&",), ("==", "!=", ">=", "<=", ">", "<"), ("+", "-"), ("*", "/"), ("^", "r^")]
 
 
 def _integer_literal(e):
@@ -134,6 +144,15 @@ def _power(base, n):
     if base[0] == "neg":
         return ("neg", _power(base[1], n))
     return ("powi", base, n)
+
+
+def _general_power(base, exponent, restricted):
+    """`base ^ y` with any exponent: (base.powf(y)); `base r^ y`: (base.max(0.0f32).powf(y)) (lib.rs:135-136) -- libm's
+    powf on both sides, so powf(0, 0) = 1 as the OpenCL form spells out (lib.rs:347).  The unary minus of the base ends
+    up outside, as in _power."""
+    if base[0] == "neg":
+        return ("neg", _general_power(base[1], exponent, restricted))
+    return ("call", "rpow" if restricted else "powf", [base, exponent])
 
 
 class _Parser:
@@ -157,9 +176,9 @@ class _Parser:
             rhs = self.expr(level + 1)
             if op == "^":
                 n = _integer_literal(rhs)
-                if n is None:
-                    raise ModelError(f"'^' needs an integer literal exponent (|n| <= {MAX_POWER})")
-                lhs = _power(lhs, n)
+                lhs = _power(lhs, n) if n is not None else _general_power(lhs, rhs, False)
+            elif op == "r^":
+                lhs = _general_power(lhs, rhs, True)
             else:
                 lhs = ("bin", op, lhs, rhs)
         return lhs
@@ -713,18 +732,31 @@ def _parse_receptors(body):
     name = m.group(1).strip() if m else ""
     if not re.fullmatch(_NAME, name):
         raise ModelError(f"bad or missing type name {name!r}")
-    groups, current, section = [{"name": None, "vars": [], "on_iteration": []}], None, None
+    groups, section = [{"name": None, "vars": [], "on_iteration": [], "states": None}], None
+    kinetics = None
     for line in body[1:]:
-        m = re.match(r"^(neurotransmitter|vars|on_iteration|receptors)\s*:\s*(.*)$", line)
+        m = re.match(r"^(neurotransmitter|vars|on_iteration|receptors|kinetics)\s*:\s*(.*)$", line)
         if m and m.group(1) == "neurotransmitter":
             nt = m.group(2).strip()
             if not re.fullmatch(_NAME, nt):
                 raise ModelError(f"bad neurotransmitter name {nt!r}")
-            groups.append({"name": nt, "vars": [], "on_iteration": []})
+            groups.append({"name": nt, "vars": [], "on_iteration": [], "states": None})
             section = None
-        elif m and m.group(1) == "receptors":
-            raise ModelError("[receptors]: several receptor states per neurotransmitter (`receptors: r1, r2`) are not "
-                             "supported -- every type has the one state `r`")
+        elif m and m.group(1) == "kinetics":              # single_kinetics_def, pest_ast/mod.rs:153
+            if groups[-1]["name"] is not None or kinetics is not None:
+                raise ModelError("[receptors]: one `kinetics: <type>` line, before the first neurotransmitter")
+            kinetics = m.group(2).strip()
+            if not re.fullmatch(_NAME, kinetics):
+                raise ModelError(f"bad kinetics type {kinetics!r}")
+            section = None
+        elif m and m.group(1) == "receptors":             # receptor_vars_def, pest_ast/mod.rs:147: the type's receptor states
+            if groups[-1]["name"] is None or groups[-1]["states"] is not None:
+                raise ModelError("[receptors]: `receptors: <state>, ...` belongs to a neurotransmitter, once")
+            states = [x.strip() for x in m.group(2).split(",") if x.strip()]
+            if not states or any(not re.fullmatch(_NAME, x) for x in states) or len(set(states)) != len(states):
+                raise ModelError(f"cannot read the receptor states {m.group(2)!r}")
+            groups[-1]["states"] = states
+            section = None
         elif m:
             section = m.group(1)
             if section == "on_iteration" and groups[-1]["name"] is None:
@@ -740,26 +772,73 @@ def _parse_receptors(body):
         raise ModelError("[receptors] takes one to three neurotransmitter types (the exchange carries three)")
     if len({g["name"] for g in types}) != len(types):
         raise ModelError("[receptors]: a neurotransmitter is listed twice")
+    model = ReceptorsModel(name, [], [], ())
+    model.kinetics = kinetics
+    # several states per type: every state (the lone `r` of a type without a `receptors:` line too) then lives in the
+    # set's own variable table, see _finish_receptors
+    model.multi = any(g["states"] is not None for g in types)
+    model._groups = groups
+    if not model.multi:
+        _finish_receptors(model, None)
+    return model
+
+
+def _finish_receptors(model, receptor_kinetics):
+    """Variable table and statements of a [receptors] block.  One state per type (the default): type k's `r` is the
+    receptor state the handle keeps per neurotransmitter type (receptors$<Type>$r$kinetics$r) and the kinetics are the
+    handle's.  Several states (`receptors: ampa_r, nmda_r`, lib.rs:7270-7316): each state is a value of the block's
+    `kinetics:` type -- its `r` and the kinetics' own variables become the set's variables
+    <Type>$<state>$kinetics$<var> -- and apply_r_change(t, dt) of a type runs the kinetics' on_iteration on each of its
+    states in declaration order (model.kinetics_code[k])."""
+    groups = model._groups
+    types = groups[1:]
     bools, variables = set(), []
-    top = _variables(groups[0]["vars"], ("v", "r", "dt", "t", "current"), bools)
+    reserved_top = ("v", "r", "dt", "t", "current")
+    top = _variables(groups[0]["vars"], reserved_top, bools)
     variables += top
     top_names = {n for n, _ in top}
-    out_types = []
+    if model.multi:
+        if receptor_kinetics is None:
+            kin_vars, kin_code, kin_bools = [], [("assign", "r", "=", ("var", "t"))], set()      # ApproximateReceptor: r = t
+            if model.kinetics not in (None, "ApproximateReceptor"):
+                raise ModelError(f"[receptors] {model.name}: kinetics type {model.kinetics!r} is not part of the description")
+        else:
+            if model.kinetics is not None and model.kinetics != receptor_kinetics.name:
+                raise ModelError(f"[receptors] {model.name}: kinetics type {model.kinetics!r} is not part of the description")
+            kin_vars, kin_code, kin_bools = receptor_kinetics.variables, receptor_kinetics.on_iteration, receptor_kinetics.bools
+    out_types, kinetics_code, all_states = [], [], []
     for g in types:
         own_bools = set()
-        own = _variables(g["vars"], ("v", "r", "dt", "t") + tuple(top_names), own_bools)
+        states = (g["states"] or ["r"]) if model.multi else []
+        own = _variables(g["vars"], ("v", "dt", "t") + (() if model.multi else ("r",)) + tuple(top_names), own_bools)
         if "current" in own_bools:
             raise ModelError("'current' is a number")
+        own_names = {n for n, _ in own}
+        if set(states) & (own_names | top_names):
+            raise ModelError(f"[receptors] {g['name']}: a receptor state shares its name with a variable")
         variables += [(f"{g['name']}${n}", d) for n, d in own]
         bools |= {f"{g['name']}${n}" for n in own_bools}
-        own_names = {n for n, _ in own}
+        code = []
+        for st in states:
+            prefix = f"{g['name']}${st}$kinetics$"
+            variables.append((prefix + "r", 0.0))
+            variables += [(prefix + n, d) for n, d in kin_vars]
+            bools |= {prefix + n for n in kin_bools if n != "r"}
+
+            def kin_rename(n, prefix=prefix):
+                return ("var", n) if n in ("t", "dt") else ("var", prefix + n)
+            code += _rename_statements(kin_code, kin_rename)
+        kinetics_code.append(code)
+        all_states.append(states)
         if not g["on_iteration"]:
             raise ModelError(f"[receptors]: neurotransmitter {g['name']} has no on_iteration")
 
-        def rename(n, g=g, own_names=own_names):
+        def rename(n, g=g, own_names=own_names, states=states):
             if n in ("v", "current_voltage"):
                 return ("var", "v")
-            if n == "r":
+            if n in states:
+                return ("var", f"{g['name']}${n}$kinetics$r")
+            if n == "r" and not model.multi:
                 return ("var", "r")
             if n in own_names:
                 return ("var", f"{g['name']}${n}")
@@ -775,13 +854,30 @@ def _parse_receptors(body):
         stmts = _convert_plain(raw, rename, assignable, "on_iteration")
         cur = f"{g['name']}$current"
         names = [n for n, _ in variables]
-        out_types.append((g["name"], stmts, names.index(cur) if cur in names else None))
+        out_types.append((g["name"], stmts, cur))
     if len(variables) > MAX_RECEPTOR_VARS:
         raise ModelError(f"more than {MAX_RECEPTOR_VARS} receptor variables")
-    model = ReceptorsModel(name, out_types, variables, bools)
-    for _, stmts, _ in out_types:
-        _check_types(stmts, bools)
+    names = [n for n, _ in variables]
+    model.types = [(nt, stmts, names.index(cur) if cur in names else None) for nt, stmts, cur in out_types]
+    model.variables, model.bools = variables, set(bools)
+    model.states, model.kinetics_code = all_states, kinetics_code
+    for _, stmts, _ in model.types:
+        _check_types(stmts, model.bools)
+    for code in kinetics_code:
+        _check_types(code, model.bools)
     return model
+
+
+def _rename_statements(stmts, rename):
+    """a copy of plain statements (assignments, [if]s, differential equations) with every variable renamed"""
+    out = []
+    for st in stmts:
+        if st[0] == "if":
+            out.append(("if", [(_map_expr(c, rename), _rename_statements(b, rename)) for c, b in st[1]],
+                        None if st[2] is None else _rename_statements(st[2], rename)))
+        else:
+            out.append((st[0], rename(st[1])[1]) + tuple(st[2:-1]) + (_map_expr(st[-1], rename),))
+    return out
 
 
 def parse_description(text):
@@ -818,6 +914,8 @@ def parse_description(text):
             desc.receptors = _parse_receptors(body)
         elif kind != "neuron":
             raise ModelError(f"[{kind}] blocks are not supported")
+    if desc.receptors is not None and desc.receptors.multi:
+        _finish_receptors(desc.receptors, desc.receptor_kinetics)
     neurons = [body for kind, body in blocks if kind == "neuron"]
     if len(neurons) > 1:
         raise ModelError("expected exactly one [neuron] ... [end] block")
@@ -850,7 +948,7 @@ def parse(text):
 
 def _parse_neuron(body, channels):
     sections, name = _sections(body, ("type", "vars", "on_spike", "spike_detection", "on_iteration",
-                                      "on_electrochemical_iteration", "ion_channels", "receptors"))
+                                      "on_electrochemical_iteration", "ion_channels", "receptors", "kinetics"))
     for need in ("on_iteration", "spike_detection"):
         if not sections.get(need):
             raise ModelError(f"section '{need}' is missing")
@@ -1072,7 +1170,8 @@ def _hip_expr(e, index):
             return f"({arg} != {arg})"
         fn = {"exp": "expf_glibc", "tanh": "tanhf_portable", "sinh": "sinhf_portable", "cosh": "coshf_portable",
               "sin": "sinf_portable", "cos": "cosf_portable", "tan": "tanf_portable",
-              "heaviside": "heaviside_rs", "min": "min_rs", "max": "max_rs"}[e[1]]
+              "heaviside": "heaviside_rs", "min": "min_rs", "max": "max_rs", "powf": "powf_glibc",
+              "rpow": "rpowf_glibc"}[e[1]]
         return f"{fn}({', '.join(_hip_expr(a, index) for a in e[2])})"
     if kind == "powi":
         return f"powif_glibc({_hip_expr(e[1], index)}, {e[2]})"
@@ -1247,6 +1346,13 @@ def _receptors_source(model):
     for k, (nt, stmts, _) in enumerate(model.types):
         bodies.append(f"    {'if' if k == 0 else '} else if'} (k == {k}) {{        // {nt}\n"
                       + _hip_statements(stmts, index, False, "        "))
+    kin = []
+    kin_index = dict(index)
+    kin_index["$base"] = {"t": "t", "dt": "dt"}
+    for k, code in enumerate(model.kinetics_code if model.multi else []):
+        kin.append(f"    {'if' if k == 0 else '} else if'} (k == {k}) {{        // {model.types[k][0]}: {', '.join(model.states[k])}\n"
+                   + _hip_statements(code, kin_index, True, "        "))
+    kin_body = (chr(10).join(kin) + "\n    }") if kin else "    (void)k; (void)t; (void)dt; (void)x;"
     nt_names = ", ".join(f'"{t[0]}"' for t in model.types) + ', ""' * (3 - len(model.types))
     cur = ", ".join(str(-1 if t[2] is None else t[2]) for t in model.types) + ", -1" * (3 - len(model.types))
     return f"""#define SNN_HAVE_CUSTOM_RECEPTORS 1
@@ -1256,6 +1362,14 @@ constexpr int NTYPES = {len(model.types)};
 static const char *const NT_NAMES[3] = {{{nt_names}}};
 {_table(model.variables)}
 constexpr int CURRENT_INDEX[3] = {{{cur}}};          // the type's `current` in x, -1: the type carries no current
+
+// several receptor states per type (`receptors: a, b`): every state's r and kinetics variables are among x, and
+// <Type>Receptor::apply_r_change (lib.rs:7306-7316) -- the kinetics' on_iteration on each state of type k -- is here
+constexpr bool MULTI_STATE = {'true' if model.multi else 'false'};
+__device__ __forceinline__ void update_kinetics(int k, float t, float dt, float (&x)[NSTORE])
+{{
+{kin_body}
+}}
 
 // <Type>Receptor::iterate of the generated receptor set (nb_macro lib.rs:7296-7340): type k's on_iteration
 __device__ __forceinline__ void iterate(int k, float v, float r, float (&x)[NSTORE])

@@ -260,6 +260,11 @@ class DeviceNetwork:
     def exchange_halo_lists(self, comm):
         self._check(self._L.snn_comm_exchange_halo_lists(self._h, C.c_void_p(int(comm))))
 
+    def run_sharded_without_exchange(self, iterations):
+        """the library's sharded step loop with snn_exchange_noop as the transport (timing of one rank's step)"""
+        fn = C.cast(self._L.snn_exchange_noop, C.c_void_p)
+        self._check(self._L.snn_run_sharded_custom(self._h, fn, None, int(iterations)))
+
     def run_sharded_custom(self, exchange, iterations):
         """the library's sharded step loop with the caller's transport: `exchange(hip_stream)` is called once per step
         after the outgoing segments were enqueued and must have moved the plan's segments when it returns"""

@@ -10,6 +10,7 @@ _FUNCTIONS = {name: np.vectorize(fn, otypes=[np.float32]) for name, fn in
               (("exp", ob.expf), ("tanh", ob.tanhf), ("sinh", ob.sinhf), ("cosh", ob.coshf), ("sin", ob.sinf),
                ("cos", ob.cosf), ("tan", ob.tanf))}
 _powif = np.vectorize(ob.powif, otypes=[np.float32])
+_powf = np.vectorize(ob.powf, otypes=[np.float32])
 
 
 def _rust_min(a, b):       # f32::min: a NaN operand yields the other one
@@ -40,6 +41,10 @@ def evaluate(e, env):
             return _rust_max(*args)
         if e[1] == "isnan":
             return np.isnan(args[0])
+        if e[1] == "powf":                         # `a ^ b`: (a.powf(b)), nb_macro lib.rs:135
+            return _powf(*np.broadcast_arrays(*args))
+        if e[1] == "rpow":                         # `a r^ b`: (a.max(0.0f32).powf(b)), lib.rs:136
+            return _powf(*np.broadcast_arrays(_rust_max(args[0], f32(0.0)), args[1]))
         if e[1] == "heaviside":                    # nb_macro lib.rs:9176-9178: x < 0 -> 0, else x
             return np.where(args[0] < 0, f32(0), args[0]).astype(f32)
         return _FUNCTIONS[e[1]](args[0])
@@ -151,7 +156,8 @@ def make_step(model):
 # ---- stack program for the C oracle (oracle/snn_oracle.c::custom_run) -------------------------------------
 _OPS = dict(END=0, CONST=1, LOAD=2, STORE=3, DIFF=4, NEG=5, NOT=6, ADD=7, SUB=8, MUL=9, DIV=10, EXP=11, EQ=12, NE=13,
             GE=14, LE=15, GT=16, LT=17, AND=18, OR=19, JZ=20, JMP=21, TANH=22, SINH=23, COSH=24, MIN=25, MAX=26,
-            HEAVISIDE=27, POWI=28, MARK=29, FLUSH=30, RC_UPDATE=31, RC_SET=32, RC_GET=33, NT_APPLY=34, SIN=35, COS=36, TAN=37, ISNAN=38)
+            HEAVISIDE=27, POWI=28, MARK=29, FLUSH=30, RC_UPDATE=31, RC_SET=32, RC_GET=33, NT_APPLY=34, SIN=35, COS=36, TAN=37, ISNAN=38,
+            POWF=39, RPOW=40)
 _BIN = {"+": "ADD", "-": "SUB", "*": "MUL", "/": "DIV", "==": "EQ", "!=": "NE", ">=": "GE", "<=": "LE", ">": "GT",
         "<": "LT", "&&": "AND", "||": "OR"}
 _BASE_SLOTS = {"v": 0, "i": 1, "dt": 2, "c_m": 3, "gap_conductance": 4}
@@ -265,7 +271,7 @@ def _stack_depth(code):
     with_operand = {_OPS[k] for k in ("CONST", "LOAD", "STORE", "DIFF", "JZ", "JMP", "POWI")}
     pop1 = {_OPS[k] for k in ("STORE", "DIFF", "JZ", "RC_SET")}
     pop_binary = {_OPS[k] for k in ("ADD", "SUB", "MUL", "DIV", "EQ", "NE", "GE", "LE", "GT", "LT", "AND", "OR", "MIN",
-                                    "MAX", "RC_GET")}
+                                    "MAX", "RC_GET", "POWF", "RPOW")}
     depth = worst = pc = 0
     while pc < len(code):
         op = code[pc]
@@ -353,15 +359,23 @@ def attach_receptor_kinetics(net, model):
     return net
 
 
-_RX_SLOTS = {"v": 0, "r": 1}
+_RX_SLOTS = {"v": 0, "r": 1, "dt": 2, "t": 3}
 
 
 def attach_receptors(net, model):
     """Give the generated neurons of an oracle Net (model=ob.CUSTOM) the generated receptor set `model`."""
-    code, consts, starts = compile_program(model, _RX_SLOTS, [("statements", stmts) for _, stmts, _ in model.types])
+    nty = len(model.types)
+    blocks = [("statements", stmts) for _, stmts, _ in model.types]
+    if getattr(model, "multi", False):          # several states per type: one kinetics program per type after the iterates
+        blocks += [("statements", code) for code in model.kinetics_code]
+    code, consts, starts = compile_program(model, _RX_SLOTS, blocks)
     net.rx_model = model
     net.arr["rx_code"], net.arr["rx_consts"] = code, consts
-    net.rx_ntypes, net.rx_nvars = len(model.types), len(model.variables)
+    net.rx_ntypes, net.rx_nvars = nty, len(model.variables)
+    net.rx_multi = int(getattr(model, "multi", False))
+    if net.rx_multi:
+        net.rx_kin_section = np.concatenate([starts[nty:], np.zeros(3 - nty, np.uint32)]).astype(np.uint32)
+        starts = starts[:nty]
     net.rx_section = np.concatenate([starts, np.zeros(3 - len(starts), np.uint32)]).astype(np.uint32)
     net.rx_current_index = np.array([(-1 if t[2] is None else t[2]) for t in model.types] + [-1] * (3 - len(model.types)),
                                     np.int32)

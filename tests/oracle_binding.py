@@ -90,6 +90,7 @@ _FIELDS = [
     ("custom_has_chem", C.c_uint32), ("custom_chem_section", C.c_uint32),
     ("rx_code", C.POINTER(C.c_int32)), ("rx_consts", f32p), ("rx_ntypes", C.c_uint32), ("rx_nvars", C.c_uint32),
     ("rx_section", C.c_uint32 * 3), ("rx_current_index", C.c_int32 * 3), ("rx_vars", f32p),
+    ("rx_multi", C.c_uint32), ("rx_kin_section", C.c_uint32 * 3),
 ]
 
 
@@ -319,6 +320,8 @@ class Net:
         self.rx_ntypes = 0
         self.rx_nvars = 0
         self.rx_section = np.zeros(3, np.uint32)
+        self.rx_multi = 0
+        self.rx_kin_section = np.zeros(3, np.uint32)
         self.rx_current_index = np.full(3, -1, np.int32)
         self.custom_chem_section = 0
         self.rc_nvars = 0
@@ -374,7 +377,7 @@ class Net:
                     setattr(c, name, arr.ctypes.data_as(ct))
             elif ct is C.c_float:
                 setattr(c, name, float(getattr(self, name)))
-            elif name in ("custom_section", "rx_section"):
+            elif name in ("custom_section", "rx_section", "rx_kin_section"):
                 setattr(c, name, (C.c_uint32 * 3)(*[int(x) for x in getattr(self, name)]))
             elif name == "rx_current_index":
                 setattr(c, name, (C.c_int32 * 3)(*[int(x) for x in self.rx_current_index]))

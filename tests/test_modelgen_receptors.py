@@ -186,7 +186,12 @@ def test_restated_ionotropic_set_equals_the_built_in_receptors():
     (MULTIPLE.replace("current = g * r * (v - e)", "current = g * r * (v - q)") + LIF.format(name="N", receptors="MultipleReceptors"),
      "unknown variable 'q'"),
     (MULTIPLE.replace("    neurotransmitter: B", "    receptors: r1, r2\n    neurotransmitter: B")
-     + LIF.format(name="N", receptors="MultipleReceptors"), "several receptor states"),
+     + LIF.format(name="N", receptors="MultipleReceptors"), "A: unknown variable 'r'"),      # A's states are r1, r2 now
+    (MULTIPLE.replace("    neurotransmitter: B", "    receptors: r1, g\n    neurotransmitter: B")
+     + LIF.format(name="N", receptors="MultipleReceptors"), "shares its name with a variable"),
+    (MULTIPLE.replace("    neurotransmitter: A", "    kinetics: Unknown\n    neurotransmitter: A").replace(
+        "    neurotransmitter: B", "    receptors: r, r2\n    neurotransmitter: B")
+     + LIF.format(name="N", receptors="MultipleReceptors"), "is not part of the description"),
     (MULTIPLE.replace("current = 2 * g * r * (v - e)", "dcurrent/dt = r") + LIF.format(name="N", receptors="MultipleReceptors"),
      "not differential equations"),
     (MULTIPLE.replace("neurotransmitter: B", "neurotransmitter: A") + LIF.format(name="N", receptors="MultipleReceptors"),
