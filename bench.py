@@ -341,10 +341,10 @@ def main():
 
     run(args.warmup)
     spikes_before = own_spike_total()
-    # HIP events around the dominant kernel: inside the timed region for the streaming configs (2 event records per step are
-    # noise next to a 0.2 - 4 ms step); for the small-step configs (c1: 4 us, c5: 43 us per step) they would cost up to 15 % of
-    # the step, so those take them in one extra repetition after the timed ones
-    events_inline = not args.no_kernel_events and args.config not in ("c1", "c5")
+    # HIP events around the dominant kernel: inside the timed region for the streaming configs with ms-scale steps (2 event
+    # records per step are noise next to a 2.5 - 13 ms step); for the short-step configs (c1: 4 us, c5: 43 us, c3: 0.19 ms per
+    # step) they would cost 2 - 15 % of the step, so those take them in one extra repetition after the timed ones
+    events_inline = not args.no_kernel_events and args.config not in ("c1", "c3", "c5")
     events_after = not args.no_kernel_events and not events_inline
     dn.profile_enable(events_inline)
     dn.profile_reset()

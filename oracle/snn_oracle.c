@@ -953,8 +953,12 @@ static uint32_t step_custom(snn_o_net *n, uint32_t q)
     } else {
         if (n->chemical) receptors_update(n, q, slot[0]);
         custom_run(n, n->custom_section[0], slot, 1);
-        if (n->chemical) slot[0] -= receptor_currents(n, q);
-        neuron_nt_update(n, q, slot[0], spiking_prev);
+        if (n->chemical) {
+            /* the generated electrical iterate_and_spike is on_iteration + handle_spiking alone (lib.rs:2266-2272); the
+             * transmitter release belongs to the neurotransmission form (lib.rs:2318-2328) */
+            slot[0] -= receptor_currents(n, q);
+            neuron_nt_update(n, q, slot[0], spiking_prev);
+        }
     }
     uint32_t spike = custom_run(n, n->custom_section[1], slot, 0) != 0.0f;
     if (spike) custom_run(n, n->custom_section[2], slot, 0);

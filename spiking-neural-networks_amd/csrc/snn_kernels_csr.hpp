@@ -159,13 +159,6 @@ __global__ __launch_bounds__(256) void k_inputs_csr(const CsrInputsArgs a)
     }
 }
 
-// Sums held in registers (the one-launch sparse step)
-struct RegisterSums {
-    float i, t[K_TYPES];
-    __device__ __forceinline__ float elec() const { return i; }
-    __device__ __forceinline__ float chem(int k) const { return t[k]; }
-};
-
 // Inputs + neuron update of a sparse handle in ONE launch: row thread = neuron thread, so the sums never leave
 // registers.  Other rows may still be gathering S(t) while a neuron writes S(t+1): as in k_step_resident the exchanged
 // state is read from a shadow copy (in.xbuf = up.n.xbuf) and written to the exchange buffer and the other shadow

@@ -1338,6 +1338,8 @@ int snn_set_option(snn_network_t *net, const char *name, int value)
     if (n == "fused_step") net->fused_step = value != 0;
     else if (n == "defer_rstdp") net->defer_rstdp = value != 0;
     else if (n == "defer_stdp") net->defer_stdp = (value == 2) ? 2 : (value != 0);
+    else if (n == "stdp_scatter") net->stdp_scatter = value != 0;
+    else if (n == "wide_update") net->wide_update = value != 0;
     else if (n == "uniform_params") { net->uniform_params = value != 0; net->uni_dirty = true; }
     else if (n == "persistent_run") { net->persistent_run = value != 0; net->run_probed_grid = 0; }
     else if (n == "run_resident_spin_limit") net->run_spin_limit = value > 0 ? (uint32_t)std::min<long long>(value, 0x7FFFFFFF) : RUN_RESIDENT_SPIN_LIMIT;

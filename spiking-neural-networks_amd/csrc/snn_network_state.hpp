@@ -208,6 +208,8 @@ struct snn_network {
     // t + 1; 2: prepared delta vectors, applied right away by scatter passes (SNN_AMD_DEFER_STDP / "defer_stdp").
     // Measured on the quad-row matrix: the scatter kernels win at every spike rate.
     int defer_stdp = 0;
+    int wide_update = 1;            // 0: k_update for every population size (option "wide_update", A/B measurements)
+    int stdp_scatter = 1;           // 0: the column and row scatter as two launches (option "stdp_scatter", A/B measurements)
     bool stdp_pending = false;
     uint32_t *stdp_flag = nullptr;
     float *stdp_dcol = nullptr, *stdp_drow = nullptr;
@@ -521,11 +523,8 @@ int build_state(snn_network *net)
     }
     reg(A, "receptors$NMDA_mg", T_F32, S_PLAIN, n.rc_mg + (size_t)1 * np, 0, 0);
     for (int j = 0; j < CUSTOM_RECEPTORS_MAX_VARS; ++j) n.rx_custom[j] = nullptr;
-    if (SNN_HAVE_CUSTOM_RECEPTORS && cust) {
-        // the generated neuron's receptor set: its variables, and the kinetics of type k under the type's own name
-        for (int j = 0; j < custom_receptors::NVARS; ++j)
-            TRY(neuron_f32(net, &n.rx_custom[j], (std::string("receptors$") + custom_receptors::NAMES[j]).c_str(),
-                           custom_receptors::DEFAULTS[j]));
+    if (SNN_HAVE_CUSTOM_RECEPTORS && cust && !custom_receptors::MULTI_STATE) {
+        // the generated neuron's receptor set with one state per type: the kinetics of type k under the type's own name
         for (int k = 0; k < custom_receptors::NTYPES; ++k) {
             const std::string p = std::string("receptors$") + custom_receptors::NT_NAMES[k];
             reg(A, (p + "$r$kinetics$r").c_str(), T_F32, S_PLAIN, n.rc_r + (size_t)k * np, 0, 0);
@@ -541,6 +540,14 @@ int build_state(snn_network *net)
                 reg(A, (std::string("receptors$") + TN[k] + "$r$kinetics$" + custom_rc::NAMES[j]).c_str(), T_F32, S_PLAIN,
                     n.rc_custom[j] + (size_t)k * np, 0, 0);
         }
+    if (SNN_HAVE_CUSTOM_RECEPTORS && cust) {
+        // the set's own variables, registered LAST: a set with several states per type keeps each state's r and kinetics
+        // variables among them (receptors$<Type>$<state>$kinetics$<var>), and a type of the set may carry the name of a
+        // built-in type (the reference's DopaGluGABA has a GABA) -- the name then means the set's variable
+        for (int j = 0; j < custom_receptors::NVARS; ++j)
+            TRY(neuron_f32(net, &n.rx_custom[j], (std::string("receptors$") + custom_receptors::NAMES[j]).c_str(),
+                           custom_receptors::DEFAULTS[j]));
+    }
 
     // lattice slot per neuron + plasticity tables
     TRY(dev_alloc_t(net, &net->lattice_slot, np));

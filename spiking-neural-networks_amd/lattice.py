@@ -126,6 +126,25 @@ class GraphPosition:                                     # graph/mod.rs:24-30
         return hash((self.id, self.pos))
 
 
+class ConnectingWeights(np.ndarray):
+    """The connecting graph's weight matrix as the reference hands it out (`connecting_weights`: rows / columns in
+    `connecting_position_to_index` order, absent edges 0), which can also be asked by position:
+    m[GraphPosition(pre), GraphPosition(post)]."""
+
+    def __new__(cls, matrix, index):
+        obj = np.asarray(matrix, np.float32).view(cls)
+        obj.index = index
+        return obj
+
+    def __array_finalize__(self, obj):
+        self.index = getattr(obj, "index", {})
+
+    def __getitem__(self, key):
+        if isinstance(key, tuple) and len(key) == 2 and all(isinstance(k, GraphPosition) for k in key):
+            key = (self.index[key[0]], self.index[key[1]])
+        return super().__getitem__(key)
+
+
 class _Neuron(_Record):
     _common = dict(is_spiking=False, last_firing_time=None)
     model = None
@@ -288,10 +307,24 @@ def description_builder(text):
         rx = desc.receptors
         out.NeurotransmitterType = enum.IntEnum(rx.name + "NeurotransmitterType", {t[0]: k for k, t in enumerate(rx.types)})
         out.receptor_types = {}
+        multi = getattr(rx, "multi", False)
+        state_kinetics = ApproximateReceptor         # the kinetics value of every receptor state (`kinetics:` of the block)
+        if multi and desc.receptor_kinetics is not None:
+            rk = desc.receptor_kinetics
+            kf = {k: (bool(v) if k in rk.bools else v) for k, v in rk.variables}
+            state_kinetics = type(rk.name, (_Record,), dict(kinetics=RC_CUSTOM, description=rk, lib_path=out.library,
+                                                            _defaults={"r": 0.0, **kf}, state_fields=tuple(kf)))
         for k, (nt, _, _) in enumerate(rx.types):
-            own = {n.split("$", 1)[1]: (bool(d) if n in rx.bools else d) for n, d in rx.variables if n.startswith(nt + "$")}
-            out.receptor_types[nt] = type(nt + "Receptor", (_Record,), dict(
-                type=out.NeurotransmitterType(k), state_fields=tuple(own), _defaults=dict(own, r=ApproximateReceptor())))
+            own = {n.split("$", 1)[1]: (bool(d) if n in rx.bools else d) for n, d in rx.variables
+                   if n.startswith(nt + "$") and "$kinetics$" not in n}
+            if multi:      # several states per type: each a kinetics value under its name (GlutamateReceptor.ampa_r.r ...)
+                states = tuple(rx.states[k])
+                out.receptor_types[nt] = type(nt + "Receptor", (_Record,), dict(
+                    type=out.NeurotransmitterType(k), state_fields=tuple(own), state_names=states,
+                    _defaults=dict(own, **{st: state_kinetics() for st in states})))
+            else:
+                out.receptor_types[nt] = type(nt + "Receptor", (_Record,), dict(
+                    type=out.NeurotransmitterType(k), state_fields=tuple(own), _defaults=dict(own, r=ApproximateReceptor())))
         receptors_type = out.Receptors = type(rx.name, (GeneratedReceptors,), dict(
             model=rx, NeurotransmitterType=out.NeurotransmitterType))
     if desc.neuron is not None:
@@ -322,9 +355,11 @@ def description_builder(text):
         out.Refractoriness = type(rf.name, (_Record,), dict(kind=REFRACTORINESS_CUSTOM, description=rf,
                                                             _defaults=dict(k=rf.decay, **dict(rf.variables)),
                                                             state_fields=tuple(n for n, _ in rf.variables)))
+    if desc.receptors is not None and getattr(desc.receptors, "multi", False):
+        out.ReceptorKinetics = state_kinetics
     for attr, model, selector in (("Neurotransmitter", desc.nt_kinetics, NT_CUSTOM),
                                   ("ReceptorKinetics", desc.receptor_kinetics, RC_CUSTOM)):
-        if model is not None:
+        if model is not None and getattr(out, attr) is None:
             fields = {k: (bool(v) if k in model.bools else v) for k, v in model.variables}
             setattr(out, attr, type(model.name, (_Record,), dict(kinetics=selector, description=model, lib_path=out.library,
                                                                  _defaults={model.state: 0.0, **fields},
@@ -405,6 +440,9 @@ class Lattice:
         self.do_plasticity = False
         self.plasticity = STDP()
         self.internal_clock = 0
+        self.parallel = False                                  # neuron/mod.rs:582 (the device path has no serial form)
+        self.history = np.zeros((0, 0, 0), np.float32)         # GridVoltageHistory: [steps][rows][cols], filled by the GPU classes
+        self.weights_history = np.zeros((0, 0, 0), np.float32)  # AdjacencyMatrix::history when update_graph_history
 
     # -- shape ------------------------------------------------------------------------------------
     @property
@@ -486,6 +524,16 @@ class Lattice:
         self.internal_clock = 0
         self.apply(lambda n: setattr(n, "last_firing_time", None))
 
+    def reset_history(self):                                    # neuron/mod.rs:398-403
+        self.history = np.zeros((0, self.rows, self.cols), np.float32)
+        self.weights_history = np.zeros((0, self.rows * self.cols, self.rows * self.cols), np.float32)
+
+    def get_weights(self):                                      # interface lattices/mod.rs:275-285: None -> 0
+        return np.where(self.connections != 0, self.weights, np.float32(0)).astype(np.float32)
+
+    def get_position_to_index_for_weights(self):
+        return self.position_to_index
+
     def run_lattice(self, iterations):
         raise NotImplementedError("this package steps lattices on the GPU only: use "
                                   f"{type(self).__name__}GPU.from_lattice(lattice).run_lattice(iterations)")
@@ -539,9 +587,17 @@ class SpikeTrainLattice:
         self.cell_grid = []
         self.update_grid_history = False
         self.internal_clock = 0
+        self.history = np.zeros((0, 0, 0), np.float32)         # SpikeTrainGridHistory: [steps][rows][cols]
 
     rows = Lattice.rows
     cols = Lattice.cols
+
+    def reset_timing(self):                                     # neuron/mod.rs:1344-1356
+        self.internal_clock = 0
+        self.apply(lambda n: setattr(n, "last_firing_time", None))
+
+    def reset_history(self):
+        self.history = np.zeros((0, self.rows, self.cols), np.float32)
 
     def populate(self, spike_train, num_rows, num_cols):
         self.cell_grid = [[copy.deepcopy(spike_train) for _ in range(num_cols)] for _ in range(num_rows)]
@@ -565,8 +621,16 @@ class LatticeNetwork:
     def __init__(self):
         self.lattices, self.spike_train_lattices = {}, {}
         self.connecting = {}              # (GraphPosition pre, GraphPosition post) -> weight
+        self.connecting_nodes = []        # nodes of the connecting graph in insertion order (its matrix index)
         self.electrical_synapse, self.chemical_synapse = True, False
         self.internal_clock = 0
+        self.parallel = False
+        self.update_connecting_graph_history = False
+        self.connecting_graph_history = []
+
+    def clear(self):                                            # neuron/mod.rs:1681-1686
+        self.lattices, self.spike_train_lattices = {}, {}
+        self.connecting, self.connecting_nodes = {}, []
 
     @classmethod
     def generate_network(cls, lattices=(), spike_train_lattices=()):
@@ -613,6 +677,10 @@ class LatticeNetwork:
         for a in ((r, c) for r in range(pre.rows) for c in range(pre.cols)):
             for b in ((r, c) for r in range(post.rows) for c in range(post.cols)):
                 key = (GraphPosition(presynaptic_id, a), GraphPosition(postsynaptic_id, b))
+                for node in key:                                 # add_node: both ends join the connecting graph
+                    if node not in self._node_set():
+                        self.connecting_nodes.append(node)
+                        self._nodes.add(node)
                 if connection_conditional(a, b):
                     self.connecting[key] = 1.0 if weight_logic is None else float(weight_logic(a, b))
                 else:
@@ -622,10 +690,165 @@ class LatticeNetwork:
         for l in list(self.lattices.values()) + list(self.spike_train_lattices.values()):
             l.set_dt(dt)
 
+    def _node_set(self):
+        if getattr(self, "_nodes", None) is None or len(self._nodes) != len(self.connecting_nodes):
+            self._nodes = set(self.connecting_nodes)
+        return self._nodes
+
+    # -- the rest of impl_network! / impl_network_gpu! (interface lattices/mod.rs:697-1448, 1450-2117) -------------
+    def _lattice(self, id):
+        if id not in self.lattices:
+            raise KeyError(f"Lattice {id} not found in network")
+        return self.lattices[id]
+
+    def _spike_train_lattice(self, id):
+        if id not in self.spike_train_lattices:
+            raise KeyError(f"Spike train lattice {id} not found in network")
+        return self.spike_train_lattices[id]
+
+    def _any(self, id):
+        if id in self.lattices:
+            return self.lattices[id]
+        if id in self.spike_train_lattices:
+            return self.spike_train_lattices[id]
+        raise KeyError(f"Id {id} not found in network")
+
+    @property
+    def connecting_position_to_index(self):
+        return {node: k for k, node in enumerate(self.connecting_nodes)}
+
+    def get_connecting_position_to_index(self):
+        return self.connecting_position_to_index
+
+    def get_connecting_weights(self):
+        """the connecting graph's matrix, absent edges 0 (interface lattices/mod.rs:893-903)"""
+        index = self.connecting_position_to_index
+        m = np.zeros((len(index), len(index)), np.float32)
+        for (pre, post), w in self.connecting.items():
+            m[index[pre], index[post]] = w
+        return ConnectingWeights(m, index)
+
+    @property
+    def connecting_weights(self):
+        return self.get_connecting_weights()
+
+    def get_weight(self, presynaptic, postsynaptic):
+        """lookup inside a lattice (same id) or in the connecting graph; an absent edge reads 0 (:914-940)"""
+        if presynaptic.id == postsynaptic.id:
+            l = self._lattice(presynaptic.id)
+            i, j = l._index(presynaptic.pos), l._index(postsynaptic.pos)
+            return float(l.weights[i, j]) if l.connections[i, j] else 0.0
+        nodes = self._node_set()
+        if presynaptic not in nodes or postsynaptic not in nodes:
+            raise KeyError("GraphError::PositionNotFound")
+        return float(self.connecting.get((presynaptic, postsynaptic), 0.0))
+
+    def get_incoming_connections_within_lattice(self, id, position):
+        return self._lattice(id).get_incoming_connections(position)
+
+    def get_outgoing_connections_within_lattice(self, id, position):
+        return self._lattice(id).get_outgoing_connections(position)
+
+    def get_incoming_connectings_across_lattices(self, id, position):
+        self._lattice(id)
+        gp = GraphPosition(id, position)
+        if gp not in self._node_set():
+            raise KeyError(f"Position {position} not found in lattice")
+        return {pre for (pre, post) in self.connecting if post == gp}
+
+    def get_outgoing_connectings_across_lattices(self, id, position):
+        self._lattice(id)
+        gp = GraphPosition(id, position)
+        if gp not in self._node_set():
+            raise KeyError(f"Position {position} not found in lattice")
+        return {post for (pre, post) in self.connecting if pre == gp}
+
+    def get_neuron(self, id, row, col):
+        return self._lattice(id).get_neuron(row, col)
+
+    def set_neuron(self, id, row, col, neuron):
+        self._lattice(id).set_neuron(row, col, neuron)
+
+    def get_spike_train(self, id, row, col):
+        l = self._spike_train_lattice(id)
+        if not (0 <= row < l.rows and 0 <= col < l.cols):
+            raise KeyError(f"Position ({row}, {col}) not found")
+        return l.get_neuron(row, col)
+
+    def set_spike_train(self, id, row, col, neuron):
+        l = self._spike_train_lattice(id)
+        if not (0 <= row < l.rows and 0 <= col < l.cols):
+            raise KeyError(f"Position ({row}, {col}) not found")
+        l.set_neuron(row, col, neuron)
+
+    def set_lattice(self, id, lattice):
+        """replace lattice `id` (the replacement takes that id, interface lattices/mod.rs:1132-1140)"""
+        self._lattice(id)
+        lattice.id = id
+        self.lattices[id] = lattice
+
+    def set_spike_train_lattice(self, id, lattice):
+        self._spike_train_lattice(id)
+        lattice.id = id
+        self.spike_train_lattices[id] = lattice
+
+    def get_do_plasticity(self, id):
+        return self._lattice(id).do_plasticity
+
+    def set_do_plasticity(self, id, flag):
+        self._lattice(id).do_plasticity = bool(flag)
+
+    def get_plasticity(self, id):
+        return copy.deepcopy(self._lattice(id).plasticity)
+
+    def set_plasticity(self, id, plasticity):
+        self._lattice(id).plasticity = copy.deepcopy(plasticity)
+
+    def reset_timing(self, id):
+        self._any(id).reset_timing()
+
+    def reset_history(self, id):
+        self._any(id).reset_history()
+
+    def get_update_grid_history(self, id):
+        return self._any(id).update_grid_history
+
+    def set_update_grid_history(self, id, flag):
+        self._any(id).update_grid_history = bool(flag)
+
+    def get_update_graph_history(self, id):
+        return self._lattice(id).update_graph_history
+
+    def set_update_graph_history(self, id, flag):
+        self._lattice(id).update_graph_history = bool(flag)
+
+    def apply_lattice(self, id, function):
+        self._lattice(id).apply(function)
+
+    def apply_spike_train_lattice(self, id, function):
+        self._spike_train_lattice(id).apply(function)
+
+    def apply_lattice_given_position(self, id, function):
+        self._lattice(id).apply_given_position(function)
+
+    def apply_spike_train_lattice_given_position(self, id, function):
+        self._spike_train_lattice(id).apply_given_position(function)
+
+    def run_lattices(self, iterations):
+        raise NotImplementedError("this package steps networks on the GPU only: use "
+                                  f"{type(self).__name__}GPU.from_network(network).run_lattices(iterations)")
+
 
 # ---------------------------------------------------------------------------------------------------
 # AoS <-> named SoA buffers (IterateAndSpikeGPU::convert_to_gpu / convert_to_cpu)
 # ---------------------------------------------------------------------------------------------------
+def _receptor_states(receptor):
+    """the receptor-kinetics values of a receptor record: its `r`, or the named states of a generated receptor with
+    several of them (`receptors: ampa_r, nmda_r`)"""
+    names = getattr(type(receptor), "state_names", None)
+    return [receptor.r] if names is None else [getattr(receptor, n) for n in names]
+
+
 def _kinetics_of(cells, default_nt=NT_APPROXIMATE, default_rc=RC_APPROXIMATE):
     nt, rc = None, None
     for c in cells:
@@ -634,9 +857,10 @@ def _kinetics_of(cells, default_nt=NT_APPROXIMATE, default_rc=RC_APPROXIMATE):
             if v.kinetics != nt:
                 raise TypeError("one neurotransmitter kinetics type per network (a type parameter in the reference)")
         for v in getattr(c, "receptors", {}).values():
-            rc = v.r.kinetics if rc is None else rc
-            if v.r.kinetics != rc:
-                raise TypeError("one receptor kinetics type per network (a type parameter in the reference)")
+            for k in _receptor_states(v):
+                rc = k.kinetics if rc is None else rc
+                if k.kinetics != rc:
+                    raise TypeError("one receptor kinetics type per network (a type parameter in the reference)")
     return (default_nt if nt is None else nt), (default_rc if rc is None else rc)
 
 
@@ -698,9 +922,15 @@ def _upload_neurons(dn, id, cells):
             flags[:, k] = [r is not None for r in recs]
             for name, default in rx.variables:
                 if name.startswith(nt + "$"):
-                    var = name.split("$", 1)[1]
+                    parts = name.split("$")
+                    if len(parts) == 4:             # <Type>$<state>$kinetics$<var>: a field of that state's kinetics value
+                        value = lambda r, parts=parts: getattr(getattr(r, parts[1]), parts[3])
+                    else:
+                        value = lambda r, parts=parts: getattr(r, parts[1])
                     dn.set_attr(id, "receptors$" + name,
-                                np.array([default if r is None else getattr(r, var) for r in recs], np.float32))
+                                np.array([default if r is None else value(r) for r in recs], np.float32))
+            if getattr(rx, "multi", False):
+                continue                            # the states are among the set's variables
             kin = lambda field, d: np.array([d if r is None else getattr(r.r, field, d) for r in recs], np.float32)
             dn.set_attr(id, f"receptors${nt}$r$kinetics$r", kin("r", 0.0))
             dn.set_attr(id, f"receptors${nt}$r$kinetics$alpha", kin("alpha", 1.0))
@@ -767,11 +997,13 @@ def _download_neurons(dn, id, cells):
                 if "$" not in name:
                     setattr(c.receptors, name, value)
                 else:
-                    nt, var = name.split("$", 1)
-                    rec = c.receptors.get([t[0] for t in rx.types].index(nt))
-                    if rec is not None:
-                        setattr(rec, var, value)
-        for k, (nt, _, _) in enumerate(rx.types):
+                    parts = name.split("$")
+                    rec = c.receptors.get([t[0] for t in rx.types].index(parts[0]))
+                    if rec is not None and len(parts) == 4:
+                        setattr(getattr(rec, parts[1]), parts[3], value)
+                    elif rec is not None:
+                        setattr(rec, parts[1], value)
+        for k, (nt, _, _) in enumerate([] if getattr(rx, "multi", False) else rx.types):
             for c, v in zip(cells, dn.get_attr(id, f"receptors${nt}$r$kinetics$r")):
                 if c.receptors.get(k) is not None:
                     c.receptors[k].r.r = float(v)
@@ -837,14 +1069,100 @@ def _flat(lattice):
 
 
 class LatticeNetworkGPU:
-    """LatticeNetworkGPU (backend/src/neuron/gpu_lattices/mod.rs:1517-3212) over one DeviceNetwork."""
+    """LatticeNetworkGPU (backend/src/neuron/gpu_lattices/mod.rs:1517-3212) over one DeviceNetwork, with the method set
+    of the reference's Python class (`impl_network_gpu!`, interface_gpu/lixirnet/src/lattices/mod.rs:1450-2117).
 
-    def __init__(self, network, device=0, graph_history_order=2):
-        self.network = network
+    The host container (`self.network`, a LatticeNetwork) holds the network between runs: building methods (connect,
+    add_lattice, set_neuron, apply_* ...) edit it and drop the device copy, the next run_lattices uploads again;
+    everything that only reads (get_weight, get_neuron, connecting_weights ...) is answered from it -- every
+    run_lattices ends with the download of state, weights and histories."""
+    network_type = None        # host container class (LatticeNetwork unless a subclass says otherwise)
+
+    def __init__(self, network=None, device=0, graph_history_order=2):
+        object.__setattr__(self, "network", network if network is not None else (self.network_type or LatticeNetwork)())
+        self._device = device
+        self._dn = None
         self._graph_hist = {}
         # when a lattice's weight snapshot is taken: 2 = before the step's weight updates (LatticeNetwork::iterate,
         # neuron/mod.rs:2450-2461), 1 = after them (a lone Lattice, neuron/mod.rs:904-910 -- what LatticeGPU passes)
         self._graph_hist_order = graph_history_order
+        if network is not None:
+            self._ensure()                      # from_network converts right away, as the reference does
+
+    @classmethod
+    def from_network(cls, network, device=0):                   # gpu_lattices/mod.rs:1636-1651
+        return cls(copy.deepcopy(network), device=device)
+
+    @classmethod
+    def generate_network(cls, lattices=(), spike_train_lattices=(), device=0):   # interface lattices/mod.rs:1465-1500
+        g = cls(device=device)
+        for l in lattices:
+            g.add_lattice(l)
+        for l in spike_train_lattices:
+            g.add_spike_train_lattice(l)
+        return g
+
+    # -- building: edits of the host container invalidate the device copy -----------------------------------------
+    _BUILDERS = ("set_dt", "add_lattice", "add_spike_train_lattice", "clear", "connect_internally", "connect",
+                 "set_neuron", "set_spike_train", "set_lattice", "set_spike_train_lattice", "set_do_plasticity",
+                 "set_plasticity", "apply_lattice", "apply_spike_train_lattice", "apply_lattice_given_position",
+                 "apply_spike_train_lattice_given_position")
+    _FLAGS = ("electrical_synapse", "chemical_synapse", "parallel", "update_connecting_graph_history")
+
+    def __getattr__(self, name):
+        # get_all_ids, get_weight, get_*_connections_*, get_neuron, get_spike_train, get_lattice, connecting_weights,
+        # connecting_position_to_index, flags ...: read from the host container; builders drop the device copy first
+        if name.startswith("_") or name == "network":
+            raise AttributeError(name)
+        target = getattr(self.network, name)
+        if name in self._BUILDERS:
+            def builder(*args, **kw):
+                if name in ("add_lattice", "add_spike_train_lattice", "set_lattice", "set_spike_train_lattice"):
+                    args = tuple(copy.deepcopy(a) for a in args)          # the container owns its lattices
+                self._dirty()
+                return target(*args, **kw)
+            return builder
+        return target
+
+    def __setattr__(self, name, value):
+        if name in self._FLAGS:
+            return setattr(self.network, name, value)
+        object.__setattr__(self, name, value)
+
+    def reset_timing(self, id=None):
+        """one lattice (the reference's method) or, without an id, the whole network"""
+        ids = self.network.get_all_ids() if id is None else [id]
+        for i in ids:
+            self.network.reset_timing(i)
+        if id is None:
+            self.network.internal_clock = 0
+            if self._dn is not None:
+                self._dn.reset_timing()      # snn_reset_timing: clocks and firing times of the whole handle
+        else:
+            self._dirty()                    # one lattice only: uploaded again with the next run
+
+    def reset_history(self, id=None):
+        for i in (self.network.get_all_ids() if id is None else [id]):
+            self.network.reset_history(i)
+        if self._dn is not None:
+            self._dn.reset_history()
+
+    def set_update_grid_history(self, id, flag):
+        self.network.set_update_grid_history(id, flag)
+
+    def set_update_graph_history(self, id, flag):
+        self.network.set_update_graph_history(id, flag)
+
+    def _dirty(self):
+        if self._dn is not None:
+            self._dn.close()
+            self._dn = None
+            self._graph_hist = {}
+
+    def _ensure(self):
+        if self._dn is not None:
+            return self._dn
+        network = self.network
         neurons = [c for l in network.lattices.values() for c in _flat(l)]
         cells = [c for l in network.spike_train_lattices.values() for c in _flat(l)]
         models = {type(c).model for c in neurons} or {IZHIKEVICH}
@@ -855,22 +1173,19 @@ class LatticeNetworkGPU:
         # generated models carry their library; everything generated in one network comes from ONE description
         libs = {getattr(type(c), "lib_path", None) for c in neurons + cells}
         libs |= {getattr(type(v), "lib_path", None) for c in neurons + cells for v in c.synaptic_neurotransmitters.values()}
-        libs |= {getattr(type(v.r), "lib_path", None) for c in neurons for v in c.receptors.values()}
+        libs |= {getattr(type(k), "lib_path", None) for c in neurons for v in c.receptors.values() for k in _receptor_states(v)}
         libs -= {None}
         if len(libs) > 1:
             raise TypeError("the generated models of one network come from one description_builder call")
         self._dn = DeviceNetwork(model=models.pop(), nt_kinetics=nt, receptor_kinetics=rc, spike_train=kinds.pop(),
-                                 device=device, lib_path=(libs.pop() if libs else None))
+                                 device=self._device, lib_path=(libs.pop() if libs else None))
         for id, l in network.lattices.items():
             self._dn.add_lattice(id, l.rows, l.cols)
         for id, l in network.spike_train_lattices.items():
             self._dn.add_spike_train_lattice(id, l.rows, l.cols)
         self._dn.finalize()
         self._upload()
-
-    @classmethod
-    def from_network(cls, network, device=0):                   # gpu_lattices/mod.rs:1636-1651
-        return cls(network, device=device)
+        return self._dn
 
     # InterleavingGraphGPU::convert_to_gpu (graph/mod.rs:644-807)
     def _upload(self):
@@ -923,10 +1238,10 @@ class LatticeNetworkGPU:
 
     def graph_history(self, id):
         """[steps][n][n] internal weights of lattice `id` after every step (AdjacencyMatrix::history)."""
-        return self._dn.graph_history(id)
+        return self._ensure().graph_history(id)
 
     def run_lattices(self, iterations):                         # gpu_lattices/mod.rs:3183-3212
-        dn, net = self._dn, self.network
+        dn, net = self._ensure(), self.network
         dn.set_synapses(net.electrical_synapse, net.chemical_synapse)
         self._history_flags()
         dn.run(iterations)
@@ -936,7 +1251,7 @@ class LatticeNetworkGPU:
         """One step preceded by RewardModulator::update(reward) on every reward-modulated lattice
         (RewardModulatedLatticeNetwork::run_lattices_with_reward, neuron/mod.rs:5385-5408).  `download=False` leaves
         the results on the device until the next downloading call (an agent loop steps thousands of times)."""
-        dn, net = self._dn, self.network
+        dn, net = self._ensure(), self.network
         dn.set_synapses(net.electrical_synapse, net.chemical_synapse)
         self._history_flags()
         dn.run_with_reward(float(reward))
@@ -980,23 +1295,26 @@ class LatticeNetworkGPU:
         if w is not None:
             for key in net.connecting:
                 net.connecting[key] = float(w[self._global(key[0]), self._global(key[1])])
-
-    def get_lattice(self, id):
-        return self.network.lattices[id]
-
-    def get_spike_train_lattice(self, id):
-        return self.network.spike_train_lattices[id]
+        # the histories the reference keeps in its lattices (GridVoltageHistory; AdjacencyMatrix::history)
+        for id, l in list(net.lattices.items()) + list(net.spike_train_lattices.items()):
+            if l.update_grid_history and l.rows * l.cols:
+                l.history = dn.voltage_history(id).reshape(-1, l.rows, l.cols)
+        for id, l in net.lattices.items():
+            if getattr(l, "update_graph_history", False) and l.rows * l.cols:
+                l.weights_history = dn.graph_history(id)
 
     def history(self, id):
         """[steps][rows][cols] voltages of lattice `id` (GridVoltageHistory, gpu_lattices/mod.rs:189-280)."""
         l = self.network.lattices.get(id) or self.network.spike_train_lattices[id]
+        if self._dn is None:
+            return np.zeros((0, l.rows, l.cols), np.float32)
         return self._dn.voltage_history(id).reshape(-1, l.rows, l.cols)
 
     # Reduced histories kept on the device (the CPU lattices' other LatticeHistory types, neuron/mod.rs:233-360;
     # the reference's GPU lattices only carry GridVoltageHistory).
     def set_reduced_history(self, average_voltage=False, eeg=False, spike_counts=False,
                             reference_voltage=0.007, distance=0.8, conductivity=251.0):
-        self._dn.set_reduced_history(average_voltage, eeg, spike_counts, reference_voltage, distance, conductivity)
+        self._ensure().set_reduced_history(average_voltage, eeg, spike_counts, reference_voltage, distance, conductivity)
 
     def average_voltage_history(self, id):
         """one value per step (AverageVoltageHistory, neuron/mod.rs:305-322)"""
@@ -1011,20 +1329,8 @@ class LatticeNetworkGPU:
         l = self.network.lattices[id]
         return self._dn.spike_counts(id).reshape(l.rows, l.cols)
 
-    def reset_history(self):
-        self._dn.reset_history()
-
-    def reset_timing(self):
-        self._dn.reset_timing()
-        for l in self.network.lattices.values():
-            l.reset_timing()
-
-    @property
-    def connecting_weights(self):
-        return dict(self.network.connecting)
-
     def close(self):
-        self._dn.close()
+        self._dirty()
 
 
 class LatticeGPU:

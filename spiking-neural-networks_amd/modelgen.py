@@ -20,10 +20,11 @@ the reference tests against is build_test/nb_macro/tests/lif_reference.rs):
     `i` is the input current;
   * on_iteration runs its statements in order; `dx/dt = expr` computes `dx = (expr) * dt` at that point and every
     `x += dx` is applied after the last statement, in statement order;
-  * electrical step: on_iteration; neurotransmitter release; is_spiking = spike_detection; on_spike if spiking;
-    with neurotransmission: receptor kinetics and currents at the old voltage first, and
-    `v -= receptor currents * (dt / c_m)` right after on_iteration (the Ionotropic AMPA/NMDA/GABA receptors of the
-    hot path stand where the generated Rust uses its receptor type);
+  * electrical step (lib.rs:2266-2272): on_iteration; is_spiking = spike_detection; on_spike if spiking.  With
+    neurotransmission (lib.rs:2318-2328): receptor kinetics and currents at the old voltage first, on_iteration,
+    `v -= receptor currents * (dt / c_m)`, the neuron's own neurotransmitter release, then the spike handling (the
+    Ionotropic AMPA/NMDA/GABA receptors of the hot path stand where the generated Rust uses its receptor type unless
+    the description brings a [receptors] block);
   * every binary operation is one float32 operation, evaluated left to right as written (no contraction).
 
   * `[if] cond [then] ... [elseif] cond [then] ... [else] ... [end]` (nestable, lib.rs:405-470) in on_iteration and
@@ -70,9 +71,12 @@ the reference tests against is build_test/nb_macro/tests/lif_reference.rs):
     of each kind.
 
 `hip_source(model)` emits the header that csrc/snn_custom_model.hpp includes when the library is compiled with
--DSNN_CUSTOM_MODEL_HEADER; `_lib.build_custom(model)` compiles such a library.  Not supported (rejected with a
-message): several receptor states per neurotransmitter (`receptors: r1, r2`), `^` with a non-literal or
-fractional exponent.  `spike_detection: continuous()`: the Rust the reference prints for it (lib.rs:984-990) reads
+-DSNN_CUSTOM_MODEL_HEADER; `_lib.build_custom(model)` compiles such a library.  `base ^ y` with any exponent is
+libm's powf (an integer literal y keeps the folded forms), `base r^ y` is `base.max(0).powf(y)` (lib.rs:135-136).
+Several receptor states per neurotransmitter (`receptors: ampa_r, nmda_r`, with the block's `kinetics:` type): every
+state's r and kinetics variables become variables of the set (receptors$<Type>$<state>$kinetics$<var>) and the
+kinetics run on each state of a type whose transmitter arrives -- the description of the reference's own Python
+module (interface_gpu/lixirnet/src/lib.rs:22-79, examples_dsl.LIXIRNET) is built this way.  `spike_detection: continuous()`: the Rust the reference prints for it (lib.rs:984-990) reads
 a `last_voltage` it never defines; the detector it spells out is the built-in HodgkinHuxleyNeuron's
 (hodgkin_huxley/mod.rs:207-220: a peak above v_th), and that is what is generated, with last_voltage = the voltage at
 the start of the iteration and the bool `was_increasing` as an extra variable.

@@ -18,6 +18,7 @@ def descriptions():
     from test_modelgen_kinetics import APPROXIMATE_NT, BOUNDED_RC, DESTEXHE_PAIR, ELECTROCHEMICAL_REF, RESTATED_STEP
     from test_modelgen_receptors import IONOTROPIC_LIKE, LIF, MIXED, STEP_NEURON
     from test_modelgen_spike_trains import BURST_DSL, RATE_DSL, REFRACTORINESS_DSL
+    from snn_amd.examples_dsl import LIXIRNET
     del random_descriptions
     facade = LEAK_NEURON.replace("vars: v_reset = -75, v_th = -55", "vars: v_reset = -75, v_th = -55, c_m = 25, ready = true") \
                         .replace("dv/dt = l.current + i", "dv/dt = (i - l.current) / c_m")
@@ -26,7 +27,7 @@ def descriptions():
             IZH_DSL + BURST_DSL + DESTEXHE_PAIR, IZH_DSL + BURST_DSL,
             MIXED + LIF.format(name="MixedIntegrateAndFire", receptors="MixedReceptors"),
             IONOTROPIC_LIKE + STEP_NEURON.format(name="OwnReceptors", receptors="receptors: AmpaGabaReceptors\n    "),
-            MIXED + STEP_NEURON.format(name="MixedStep", receptors="receptors: MixedReceptors\n    ")]
+            MIXED + STEP_NEURON.format(name="MixedStep", receptors="receptors: MixedReceptors\n    "), LIXIRNET]
 
 
 if __name__ == "__main__":

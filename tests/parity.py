@@ -185,6 +185,13 @@ def _rc_per_type(net):
     return {o: pat for o, pat in RC_PER_TYPE.items() if not any(pat.endswith(t) for t in taken)}
 
 
+def _rc_types(net, pattern):
+    """(type index, built-in type name) pairs whose attribute `pattern` is NOT a variable of the generated receptor set
+    (a set may have a type that carries a built-in type's name: the attribute then means the set's variable)"""
+    own = {"receptors$" + name for name in _kinetics_names(net, "rx_model")}
+    return [(k, t) for k, t in enumerate(TYPE_NAMES) if pattern.replace("{T}", t) not in own]
+
+
 def _kinetics_names(net, which):
     model = getattr(net, which, None)
     return [name for name, _ in model.variables] if model is not None else []
@@ -209,11 +216,11 @@ def push_state(dn, net):
             for k, name in enumerate(_kinetics_names(net, "rx_model")):
                 dn.set_attr(i, "receptors$" + name, np.ascontiguousarray(net["rx_vars"][k, sl]))
             for k, name in enumerate(_kinetics_names(net, "rc_model")):
-                for ty, t in enumerate(TYPE_NAMES):
+                for ty, t in _rc_types(net, "receptors${T}$r$kinetics$" + name):
                     dn.set_attr(i, f"receptors${t}$r$kinetics${name}", np.ascontiguousarray(net["rc_custom_vars"][k, sl, ty]))
             dn.set_attr(i, "receptors$flags", net["rc_flags"][sl])
-            for k, t in enumerate(TYPE_NAMES):
-                for o, pat in _rc_per_type(net).items():
+            for o, pat in _rc_per_type(net).items():
+                for k, t in _rc_types(net, pat):
                     dn.set_attr(i, pat.replace("{T}", t), np.ascontiguousarray(net[o][sl, k]))
             dn.set_attr(i, "receptors$NMDA_mg", np.ascontiguousarray(net["rc_mg"][sl, 1]))
         else:
@@ -268,13 +275,14 @@ def pull_state(dn, net):
             for k, name in enumerate(_kinetics_names(net, "rc_model")):
                 if "rc_custom_vars" not in out:
                     out["rc_custom_vars"] = np.zeros_like(net["rc_custom_vars"])
-                for ty, t in enumerate(TYPE_NAMES):
+                out["rc_custom_vars"][k, sl] = net["rc_custom_vars"][k, sl]
+                for ty, t in _rc_types(net, "receptors${T}$r$kinetics$" + name):
                     out["rc_custom_vars"][k, sl, ty] = dn.get_attr(i, f"receptors${t}$r$kinetics${name}")
             put("rc_flags", sl, dn.get_attr(i, "receptors$flags", dtype=np.uint32, per_type=True))
-            for k, t in enumerate(TYPE_NAMES):
-                for o, pat in _rc_per_type(net).items():
-                    if o not in out:
-                        out[o] = np.zeros_like(net[o])
+            for o, pat in _rc_per_type(net).items():
+                if o not in out:
+                    out[o] = net[o].copy()
+                for k, t in _rc_types(net, pat):
                     out[o][sl, k] = dn.get_attr(i, pat.replace("{T}", t))
         else:
             for o, a in CELL_ATTRS.items():
