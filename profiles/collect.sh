@@ -3,7 +3,7 @@
 # into profiles/rNN/).  Per config: rocprofv3 --kernel-trace --stats of bench.py (kernel stats csv + the bench line of
 # that profiled process), then two separate --pmc passes (FETCH_SIZE, WRITE_SIZE) reduced by summarize_pmc.py.
 set -u
-R=${1:-r02}
+R=${1:-r03}
 OUT=$PWD/gpurun_out/$R
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$OLDPWD"
@@ -33,6 +33,7 @@ prof c2 --config c2 --steps 50 --warmup 10 --repeats 2
 prof c3 --config c3 --steps 100 --warmup 10 --repeats 2
 prof c4 --config c4 --steps 50 --warmup 10 --repeats 2
 prof c4_spiking_0p1pct --config c4 --spike-fraction 0.001 --steps 50 --warmup 100 --repeats 2
+prof c6 --config c6 --steps 20 --warmup 3 --repeats 2
 prof c5 --config c5 --steps 500 --warmup 20 --repeats 2 --no-kernel-events
 prof c1 --config c1 --steps 2000 --warmup 50 --repeats 2 --no-kernel-events
 prof lattice64 --config c2 --rows 64 --cols 64 --steps 2000 --warmup 50 --repeats 2 --no-kernel-events
@@ -41,4 +42,5 @@ prof c5_sharded_world1 --config c5 --force-sharded --steps 500 --warmup 20 --rep
 pmc c2 k_inputs_dense --config c2 --steps 20 --warmup 3 --repeats 1
 pmc c3 k_inputs_dense --config c3 --steps 20 --warmup 3 --repeats 1
 pmc c4 k_inputs_dense --config c4 --steps 20 --warmup 3 --repeats 1
+pmc c6 k_inputs_rstdp --config c6 --steps 10 --warmup 2 --repeats 1
 ls "$OUT"

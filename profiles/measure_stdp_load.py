@@ -1,8 +1,7 @@
 #!/usr/bin/env python3
 """STDP under load on BASELINE configs[3] (81 920 neurons, 26.8 GB matrix): ms per step, average input-pass launch and
 plasticity launches per step for a driven spike fraction f, with the weight update (a) riding on the next input pass
-(SNN_AMD_DEFER_STDP=1), (b) as the standalone scatter (=0: k_stdp_scatter, one launch, deltas per thread; `standalone_two_launches`: the column and row
-kernels that evaluate STDP per synapse), (b') as scatter passes
+(SNN_AMD_DEFER_STDP=1), (b) as the standalone scatter kernels that evaluate STDP per synapse (=0), (b') as scatter passes
 that add the two prepared delta vectors (=2) and (c) riding but with a_plus = a_minus = 0
 (no word changes: the cost of the update path without its stores).  Usage: measure_stdp_load.py [steps] [mode,mode...]"""
 import json
@@ -20,9 +19,9 @@ steps = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 n_inh, n_exc = 128 * 128, 256 * 256
 n = n_inh + n_exc
 rows = []
-modes = sys.argv[2].split(",") if len(sys.argv) > 2 else ["fused", "standalone", "standalone_two_launches", "prepared_scatter", "fused_zero_delta"]
+modes = sys.argv[2].split(",") if len(sys.argv) > 2 else ["fused", "standalone", "prepared_scatter", "fused_zero_delta"]
 for mode in modes:
-    os.environ["SNN_AMD_DEFER_STDP"] = {"standalone": "0", "standalone_two_launches": "0", "prepared_scatter": "2"}.get(mode, "1")
+    os.environ["SNN_AMD_DEFER_STDP"] = {"standalone": "0", "prepared_scatter": "2"}.get(mode, "1")
     dn = snn_amd.DeviceNetwork(model=snn_amd.IZHIKEVICH)
     dn.add_lattice(0, 128, 128)
     dn.add_lattice(1, 256, 256)
@@ -34,8 +33,6 @@ for mode in modes:
     dn.set_plasticity(0, a_plus=a, a_minus=a)
     dn.set_plasticity(1, a_plus=a, a_minus=a)
     dn.set_reduced_history(False, False, True)
-    if mode == "standalone_two_launches":        # k_stdp_columns + k_stdp_rows (exp per touched synapse) instead of k_stdp_scatter
-        dn.set_option("stdp_scatter", 0)
     for f in (0.0, 0.001, 0.01):
         dn.set_attr(0, "current_voltage", synthetic.uniform(4, n_inh, -65.0, 30.0))
         dn.set_attr(1, "current_voltage", synthetic.uniform(4, n_exc, -65.0, 30.0, offset=n_inh))

@@ -402,94 +402,6 @@ __global__ __launch_bounds__(256) void k_stdp_rows(const StdpArgs a)
     }
 }
 
-// Both scatters in ONE launch, for handles whose lattices all use plain STDP (no BCM lattice: its update reads the weight
-// it rewrites, so the column pass must be complete before the row pass).  Two things make it faster than the pair above
-// under a heavy spike load (C4, 1 % of the population per step):
-//  * every listed neuron spiked at THIS step, so its last_firing_time is the clock: what an incoming edge p -> j gains
-//    depends on the row p and on j's lattice only, what an outgoing edge j -> r gains on the column r only -- the
-//    exponentials are evaluated once per thread (per lattice), not once per touched synapse;
-//  * the spike loop runs in batches of STDP_BATCH: the batch's loads are all in flight before the first add (the loop of
-//    the pair above is one dependent HBM round trip per listed neuron).
-// Same arithmetic, same values: w + stdp_delta(...) per touched word, absent edges (NaN) left alone.  A word (j, j') with
-// both ends listed is visited by both duties, each adding 0.0f (t_pre == t_post): the two writes carry the same value.
-constexpr int STDP_BATCH = 4;
-constexpr uint32_t STDP_SCATTER_MAX_LATTICES = 4;
-
-__device__ __forceinline__ void stdp_load_batch(float (&w)[STDP_BATCH], float *const (&p)[STDP_BATCH], bool stream)
-{
-    if (stream) {
-        asm volatile("global_load_dword %0, %4, off nt\n\t"
-                     "global_load_dword %1, %5, off nt\n\t"
-                     "global_load_dword %2, %6, off nt\n\t"
-                     "global_load_dword %3, %7, off nt\n\t"
-                     "s_waitcnt vmcnt(0)"
-                     : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3])
-                     : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3])
-                     : "memory");
-    } else {
-#pragma unroll
-        for (int u = 0; u < STDP_BATCH; ++u) w[u] = *p[u];
-    }
-}
-
-__global__ __launch_bounds__(256) void k_stdp_scatter(const StdpArgs a)
-{
-    const uint32_t count = *a.spike_count;
-    if (count == 0u) return;
-    const bool stream = stdp_streams(count, a.n_tot);
-    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
-    const int32_t now = (int32_t)a.clock;
-    if (t < a.n_tot) {
-        // incoming edges: row p = t of every listed local column
-        const int32_t tp = (t < a.n_neurons) ? a.last_firing_time[t] : a.st_last_firing_time[t - a.n_neurons];
-        float gain[STDP_SCATTER_MAX_LATTICES];
-#pragma unroll
-        for (uint32_t l = 0; l < STDP_SCATTER_MAX_LATTICES; ++l) {
-            const float *prm = a.stdp + PL_STRIDE * (l < a.n_lattices ? l : 0u);
-            gain[l] = stdp_delta(tp, now, prm[0], prm[1], prm[2], prm[3], prm[4]);
-        }
-        for (uint32_t s0 = blockIdx.y * STDP_BATCH; s0 < count; s0 += gridDim.y * STDP_BATCH) {
-            float *wp[STDP_BATCH];
-            float w[STDP_BATCH], d[STDP_BATCH];
-            bool on[STDP_BATCH];
-#pragma unroll
-            for (int u = 0; u < STDP_BATCH; ++u) {
-                const uint32_t s = s0 + u;
-                const uint32_t j = s < count ? a.spike_list[s] : 0xFFFFFFFFu;
-                on[u] = j >= a.q0 && j < a.q0 + a.n_loc;               // listed, local (a padding slot reads column 0, unused)
-                wp[u] = a.W + widx(t, on[u] ? j - a.q0 : 0u, a.ld);
-                const uint32_t l = on[u] ? a.lattice_slot[j] : 0u;
-                d[u] = l == 0u ? gain[0] : l == 1u ? gain[1] : l == 2u ? gain[2] : gain[3];
-            }
-            stdp_load_batch(w, wp, stream);
-#pragma unroll
-            for (int u = 0; u < STDP_BATCH; ++u)
-                if (on[u] && w[u] == w[u]) stdp_store(wp[u], w[u] + d[u], stream);
-        }
-    }
-    if (t < a.n_loc) {
-        // outgoing edges: column r = t of every listed row
-        const uint32_t gr = a.q0 + t;
-        const float *prm = a.stdp + PL_STRIDE * a.lattice_slot[gr];
-        const float d = stdp_delta(now, a.last_firing_time[gr], prm[0], prm[1], prm[2], prm[3], prm[4]);
-        for (uint32_t s0 = blockIdx.y * STDP_BATCH; s0 < count; s0 += gridDim.y * STDP_BATCH) {
-            float *wp[STDP_BATCH];
-            float w[STDP_BATCH];
-            bool on[STDP_BATCH];
-#pragma unroll
-            for (int u = 0; u < STDP_BATCH; ++u) {
-                const uint32_t s = s0 + u;
-                on[u] = s < count;
-                wp[u] = a.W + widx(on[u] ? a.spike_list[s] : 0u, t, a.ld);
-            }
-            stdp_load_batch(w, wp, stream);
-#pragma unroll
-            for (int u = 0; u < STDP_BATCH; ++u)
-                if (on[u] && w[u] == w[u]) stdp_store(wp[u], w[u] + d, stream);
-        }
-    }
-}
-
 // ---- reduced per-lattice histories ---------------------------------------------------------------
 // AverageVoltageHistory (neuron/mod.rs:305-322) and EEGHistory (:233-284) on the device: one float per lattice
 // and step instead of the T x N voltage history.  One workgroup per lattice; every thread sums one 256-neuron
@@ -554,6 +466,19 @@ __global__ __launch_bounds__(256) void k_probe_copy(const probe_v4f *src, probe_
 {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256)
         __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+}
+
+// two matrices of one layout read and written back in place, index-aligned: the four streams of k_inputs_rstdp (weights
+// and traces, read + write) without changing a bit -- times a candidate placement of the trace matrix next to W
+// (source and destination arrive as separate arguments: a store of the value just loaded from the same pointer would be
+// removed by the compiler, and the loads with it)
+__global__ __launch_bounds__(256) void k_probe_rw_pair(const probe_v4f *a, probe_v4f *a_out, const probe_v4f *b, probe_v4f *b_out, size_t n4)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const probe_v4f va = __builtin_nontemporal_load(a + i), vb = __builtin_nontemporal_load(b + i);
+        __builtin_nontemporal_store(va, a_out + i);
+        __builtin_nontemporal_store(vb, b_out + i);
+    }
 }
 
 // Synthetic drive (benchmarks and load tests only, off by default): before the step at `clock`, every neuron q with

@@ -459,83 +459,12 @@ __device__ __forceinline__ uint32_t update_neuron(const UpdateArgs &a, uint32_t 
     return update_neuron_at<MODEL>(a, ql, sums, a.clock, a.vhist_row);
 }
 
-// Sums held in registers (the one-launch sparse step; k_update_wide)
+// Sums held in registers (the one-launch sparse step)
 struct RegisterSums {
     float i, t[K_TYPES];
     __device__ __forceinline__ float elec() const { return i; }
     __device__ __forceinline__ float chem(int k) const { return t[k]; }
 };
-
-// The second level of the canonical sum with UPDATE_WIDE lanes per neuron: lane `sub` loads the partials of chunks
-// [sub * per, (sub + 1) * per) -- all planes' loads of a neuron are in flight at once, 1 / UPDATE_WIDE of them per lane --
-// and the running sum passes from lane to lane in ascending chunk order (same additions, same order as
-// combine_partials).  Returns the sum on every lane of the group.
-constexpr uint32_t UPDATE_WIDE = 4;
-constexpr uint32_t UPDATE_WIDE_MAX_PER_LANE = 16;         // chunks per lane held in registers: n_chunks <= 64
-
-__device__ __forceinline__ void wide_load(float (&v)[UPDATE_WIDE_MAX_PER_LANE], const float *p, uint32_t c0, uint32_t c1, size_t ld)
-{
-#pragma unroll
-    for (uint32_t u = 0; u < UPDATE_WIDE_MAX_PER_LANE; ++u) v[u] = (c0 + u < c1) ? p[(size_t)(c0 + u) * ld] : 0.0f;
-}
-
-__device__ __forceinline__ float wide_chain(const float (&v)[UPDATE_WIDE_MAX_PER_LANE], uint32_t c0, uint32_t c1, uint32_t sub)
-{
-    float s = 0.0f;
-    const uint32_t lane = threadIdx.x & 63u, base = lane - sub;
-#pragma unroll
-    for (uint32_t j = 0; j < UPDATE_WIDE; ++j) {
-        const float before = __shfl(s, (int)(base + (j ? j - 1u : 0u)), 64);      // the sum lane j - 1 ended with
-        if (sub == j) {
-            s = j ? before : 0.0f;
-#pragma unroll
-            for (uint32_t u = 0; u < UPDATE_WIDE_MAX_PER_LANE; ++u)
-                if (c0 + u < c1) s += v[u];
-        }
-    }
-    return __shfl(s, (int)(base + UPDATE_WIDE - 1u), 64);
-}
-
-// k_update for SMALL populations (one or two wavefronts per compute unit: the launch is a chain of memory round trips,
-// not bandwidth): UPDATE_WIDE lanes per neuron fetch its chunk partials together (one round trip per neuron instead of
-// n_chunks / 16 per plane), lane 0 of the group then runs the neuron's step with the sums in registers.  A workgroup of 256
-// threads = one aligned 64-block of neurons = one raster word.
-template <int MODEL>
-__global__ __launch_bounds__(256) void k_update_wide(const UpdateArgs a)
-{
-    __shared__ uint32_t s_spike[64];
-    const uint32_t sub = threadIdx.x % UPDATE_WIDE;
-    const uint32_t ql = blockIdx.x * 64u + threadIdx.x / UPDATE_WIDE;
-    const bool live = ql < a.n_loc && a.rows.active(ql, a.n_loc);
-    const uint32_t qc = ql < a.ld ? ql : 0u;                   // a column whose partials may be read (unused when !live)
-    const uint32_t per = (a.n_chunks + UPDATE_WIDE - 1u) / UPDATE_WIDE;
-    const uint32_t c0 = min(sub * per, a.n_chunks), c1 = min(c0 + per, a.n_chunks);
-    float vi[UPDATE_WIDE_MAX_PER_LANE], vt[K_TYPES][UPDATE_WIDE_MAX_PER_LANE];
-    if (a.electrical) wide_load(vi, a.part_i + qc, c0, c1, a.ld);
-    if (a.chemical) {
-#pragma unroll
-        for (int k = 0; k < K_TYPES; ++k) wide_load(vt[k], a.part_t + (size_t)k * a.n_chunks * a.ld + qc, c0, c1, a.ld);
-    }
-    RegisterSums sums{0.0f, {0.0f, 0.0f, 0.0f}};
-    if (a.electrical) sums.i = wide_chain(vi, c0, c1, sub);
-    if (a.chemical) {
-#pragma unroll
-        for (int k = 0; k < K_TYPES; ++k) sums.t[k] = wide_chain(vt[k], c0, c1, sub);
-    }
-    const uint32_t spike = (live && sub == 0u) ? update_neuron<MODEL>(a, ql, sums) : 0u;
-    if (a.spike_row) {
-        if (sub == 0u) s_spike[threadIdx.x / UPDATE_WIDE] = spike;
-        __syncthreads();
-        if (threadIdx.x < 64u) {
-            const unsigned long long word = __ballot(s_spike[threadIdx.x] != 0u);
-            const uint32_t q64 = blockIdx.x * 64u;
-            if (threadIdx.x == 0u && q64 < a.ld) {
-                const uint32_t g = a.rows.block ? (q64 < a.n_loc ? a.rows.block[q64 >> 6] * 64u : a.n.n_pad) : a.q0 + q64;
-                if (g < a.n.n_pad) a.spike_row[g >> 6] = word;
-            }
-        }
-    }
-}
 
 template <int MODEL>
 __global__ __launch_bounds__(256) void k_update(const UpdateArgs a)

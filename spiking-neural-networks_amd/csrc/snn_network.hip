@@ -514,12 +514,61 @@ int snn_set_bcm(snn_network_t *net, uint32_t id, float decay, float average_scal
 namespace {
 size_t trace_elems(const snn_network *net) { return net->csr ? (size_t)net->sell_entries : wcount(net->n_tot, net->ld); }
 
+// W and a (zeroed) trace candidate read and written back in place, index-aligned: the four streams of k_inputs_rstdp, no bit
+// changed.  Average of two passes after one warm pass, in ms.
+int time_rw_pass(snn_network *net, float *buf, size_t n4, float *ms)
+{
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return fail(SNN_ERR_QUEUE, "hipEventCreate failed");
+    const unsigned blocks = 256 * 16;
+    auto pass = [&]() { hipLaunchKernelGGL(k_probe_rw_pair, dim3(blocks), dim3(256), 0, net->stream, (const probe_v4f *)net->W, (probe_v4f *)net->W, (const probe_v4f *)buf, (probe_v4f *)buf, n4); };
+    pass();
+    int rc = SNN_OK;
+    if (hipGetLastError() != hipSuccess) rc = fail(SNN_ERR_QUEUE, "placement probe launch failed");
+    if (rc == SNN_OK && hipEventRecord(e0, net->stream) != hipSuccess) rc = fail(SNN_ERR_QUEUE, "hipEventRecord failed");
+    pass(); pass();
+    if (rc == SNN_OK && (hipEventRecord(e1, net->stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
+                         hipEventElapsedTime(ms, e0, e1) != hipSuccess))
+        rc = fail(SNN_ERR_WAIT, "placement timing failed");
+    *ms *= 0.5f;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return rc;
+}
+
 int ensure_traces(snn_network *net)
 {
     if (net->trace) return SNN_OK;
     const size_t n = std::max<size_t>(trace_elems(net), 64);
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&net->trace), n * 4), SNN_ERR_BUFFER_CREATE);
     HIP_TRY(hipMemsetAsync(net->trace, 0, n * 4, net->stream), SNN_ERR_BUFFER_WRITE);
+    // The trace matrix of a dense handle is rewritten every step (k_inputs_rstdp): like the synapse matrix its HBM placement
+    // decides a few per cent of the pass (choose_matrix_placement) -- up to three more candidates, each held until the
+    // choice is made, timed next to W with the pass's own four streams (k_probe_rw_pair); the fastest stays.
+    if (!net->csr && n * 4 >= ((size_t)1 << 30)) {
+        float best = 0.0f;
+        int rc = time_rw_pass(net, net->trace, n / 4, &best);
+        std::vector<void *> losers;
+        for (int cand = 0; cand < 3 && rc == SNN_OK; ++cand) {
+            size_t free_b = 0, total_b = 0;
+            void *b = nullptr;
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < n * 4 + (n >> 0) || hipMalloc(&b, n * 4) != hipSuccess) break;
+            float ms = 0.0f;
+            if (hipMemsetAsync(b, 0, n * 4, net->stream) != hipSuccess) { losers.push_back(b); break; }
+            rc = time_rw_pass(net, static_cast<float *>(b), n / 4, &ms);
+            if (getenv("SNN_DEBUG_PLACEMENT"))
+                fprintf(stderr, "[snn] trace placement (%zu vectors): held %p %.3f ms, candidate %p %.3f ms\n", n / 4, (void *)net->trace, best, b, ms);
+            if (rc == SNN_OK && ms < best * 0.99f) {
+                losers.push_back(net->trace);
+                net->trace = static_cast<float *>(b);
+                best = ms;
+            } else {
+                losers.push_back(b);
+            }
+        }
+        for (void *p : losers) (void)hipFree(p);
+        if (rc) return rc;
+    }
     return SNN_OK;
 }
 } // namespace
@@ -1338,8 +1387,6 @@ int snn_set_option(snn_network_t *net, const char *name, int value)
     if (n == "fused_step") net->fused_step = value != 0;
     else if (n == "defer_rstdp") net->defer_rstdp = value != 0;
     else if (n == "defer_stdp") net->defer_stdp = (value == 2) ? 2 : (value != 0);
-    else if (n == "stdp_scatter") net->stdp_scatter = value != 0;
-    else if (n == "wide_update") net->wide_update = value != 0;
     else if (n == "uniform_params") { net->uniform_params = value != 0; net->uni_dirty = true; }
     else if (n == "persistent_run") { net->persistent_run = value != 0; net->run_probed_grid = 0; }
     else if (n == "run_resident_spin_limit") net->run_spin_limit = value > 0 ? (uint32_t)std::min<long long>(value, 0x7FFFFFFF) : RUN_RESIDENT_SPIN_LIMIT;

@@ -208,8 +208,6 @@ struct snn_network {
     // t + 1; 2: prepared delta vectors, applied right away by scatter passes (SNN_AMD_DEFER_STDP / "defer_stdp").
     // Measured on the quad-row matrix: the scatter kernels win at every spike rate.
     int defer_stdp = 0;
-    int wide_update = 1;            // 0: k_update for every population size (option "wide_update", A/B measurements)
-    int stdp_scatter = 1;           // 0: the column and row scatter as two launches (option "stdp_scatter", A/B measurements)
     bool stdp_pending = false;
     uint32_t *stdp_flag = nullptr;
     float *stdp_dcol = nullptr, *stdp_drow = nullptr;

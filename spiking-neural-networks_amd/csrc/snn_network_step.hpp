@@ -254,18 +254,6 @@ int launch_update(snn_network *net)
     net->shadow_valid = false;            // the exchange buffer moves on without the shadows
     const uint32_t ub = 256u;          // (one wavefront per workgroup for small launches was measured: no gain)
     dim3 grid((net->ld + ub - 1) / ub);
-#if !SNN_HAVE_CUSTOM_MODEL
-    // small populations (at most two wavefronts of neurons per compute unit) whose chunk partials fit the lanes' registers:
-    // four lanes per neuron fetch them in one round trip (k_update_wide); same sums, same order
-    if (net->wide_update && net->n_loc <= 32768u && a.n_chunks && a.n_chunks <= UPDATE_WIDE * UPDATE_WIDE_MAX_PER_LANE) {
-        const dim3 wgrid((net->ld + 63) / 64);
-#define SNN_UPDATE_WIDE(M) hipLaunchKernelGGL((k_update_wide<M>), wgrid, dim3(256), 0, net->stream, a)
-        SNN_FOR_MODEL(SNN_UPDATE_WIDE)
-#undef SNN_UPDATE_WIDE
-        HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
-        return SNN_OK;
-    }
-#endif
     switch (net->model) {
     case SNN_MODEL_LIF: hipLaunchKernelGGL((k_update<1>), grid, dim3(ub), 0, net->stream, a); break;
     case SNN_MODEL_HODGKIN_HUXLEY: hipLaunchKernelGGL((k_update<2>), grid, dim3(ub), 0, net->stream, a); break;
@@ -332,14 +320,6 @@ int launch_plasticity_kernels(snn_network *net)
         return SNN_OK;
     }
     const unsigned sy = 64;   // spiking neurons processed concurrently; the rest grid-strides
-    bool plain_stdp = net->stdp_scatter && net->lattices.size() <= STDP_SCATTER_MAX_LATTICES;
-    for (size_t l = 0; l < net->lattices.size() && plain_stdp; ++l) plain_stdp = net->stdp_host[l * PL_STRIDE + 5] == 0.0f;
-    if (plain_stdp) {
-        // plain STDP everywhere: both scatters in one launch, exponentials per thread, batched loads (k_stdp_scatter)
-        hipLaunchKernelGGL(k_stdp_scatter, dim3((std::max(net->n_tot, net->n_loc) + 255) / 256, sy), dim3(256), 0, net->stream, a);
-        HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
-        return SNN_OK;
-    }
     hipLaunchKernelGGL(k_stdp_columns, dim3((net->n_tot + 255) / 256, sy), dim3(256), 0, net->stream, a);
     HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
     hipLaunchKernelGGL(k_stdp_rows, dim3((net->n_loc + 255) / 256, sy), dim3(256), 0, net->stream, a);
