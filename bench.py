@@ -23,9 +23,10 @@ ROWS = COLS = 256
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling is ~6.3 TB/s
 # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of THIS command (FETCH_SIZE and
 # WRITE_SIZE cannot share a pass); their summaries are committed under profiles/ and quoted here per launch.
-PMC_TRAFFIC = {"c2": os.path.join(ROOT, "profiles", "r02", "c2_pmc_traffic.json"),
-               "c3": os.path.join(ROOT, "profiles", "r02", "c3_pmc_traffic.json"),
-               "c4": os.path.join(ROOT, "profiles", "r02", "c4_pmc_traffic.json")}
+PMC_TRAFFIC = {"c2": os.path.join(ROOT, "profiles", "r03", "c2_pmc_traffic.json"),
+               "c3": os.path.join(ROOT, "profiles", "r03", "c3_pmc_traffic.json"),
+               "c4": os.path.join(ROOT, "profiles", "r03", "c4_pmc_traffic.json"),
+               "c6": os.path.join(ROOT, "profiles", "r03", "c6_pmc_traffic.json")}
 
 
 def pmc_traffic(config, world, rows, cols):

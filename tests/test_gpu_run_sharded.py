@@ -79,3 +79,34 @@ def test_run_sharded_from_python_with_a_library_made_communicator(snn):
     parity.assert_graph_equal(net, dn)
     dn.close()
     comm.close()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("form", ["dense", "csr", "csr_by_lattice"])
+def test_the_ranks_agreement_on_the_exchange_runs_at_world_size_one(snn, form, monkeypatch):
+    """Before the first step of snn_run_sharded the ranks compare their plans over the communicator (graph form, halo
+    lists committed or not, planes on the wire) and sparse handles trade their need lists.  With a single GPU that code
+    is skipped (one rank has nobody to disagree with); SNN_AMD_ALWAYS_AGREE walks every collective of it once -- an
+    in-place ncclAllGather of one word per rank, the list exchange, the plan comparison -- over a real RCCL communicator."""
+    from snn_amd import parallel
+    from test_gpu_csr import c5_structure
+    monkeypatch.setenv("SNN_AMD_ALWAYS_AGREE", "1")
+    os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+    os.environ.setdefault("NCCL_IB_DISABLE", "1")
+    if form == "dense":
+        net = parity.make_oracle(parity.Layout([(0, 9, 9)]))
+        net["gap_conductance"] = 10.0
+        net["current_voltage"] = ob.uniform_array(1, net.n_neurons, -65.0, 30.0)
+        net.fill_graph(2, 0.5, 1.5)
+    else:
+        net = c5_structure(8)
+    net["do_plasticity"] = 1
+    dn = parity.device_from_oracle(snn, net, shard=(0, 1), csr=(form != "dense"), by_lattice=(form == "csr_by_lattice"))
+    comm = parallel.LibraryComm(0, 1, 0)
+    dn.run_sharded(comm, 200)
+    dn.run_sharded(comm, 100)                     # agreed: no second round
+    net.run(300)
+    parity.assert_state_equal(net, parity.pull_state(dn, net))
+    parity.assert_graph_equal(net, dn)
+    dn.close()
+    comm.close()
