@@ -160,9 +160,9 @@ def state_checksum(dn, np, dist, rank, world):
     cols.append(counts[own].astype(np.uint32))
     mine = (own, np.stack(cols))
     parts = [mine]
-    if dist is not None and world > 1:
-        parts = [None] * world if rank == 0 else None
-        dist.gather_object(mine, parts, dst=0)
+    if dist is not None:                       # (also at world size 1 under --force-sharded: the same calls every N makes)
+        parts = [None] * world
+        dist.all_gather_object(parts, mine)
     if rank != 0:
         return None
     n = sum(p[0].size for p in parts)
