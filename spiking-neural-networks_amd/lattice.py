@@ -503,10 +503,10 @@ class Lattice:
         self.cell_grid[row][col] = copy.deepcopy(neuron)
 
     def get_weight(self, presynaptic, postsynaptic):
+        """lookup_weight(...).unwrap_or(0.) as the reference's Python class hands it out (interface
+        lattices/mod.rs:114-121): an absent edge reads 0, a position outside the lattice is a KeyError"""
         i, j = self._index(presynaptic), self._index(postsynaptic)
-        if not self.connections[i, j]:
-            raise KeyError("no connection")                      # lookup_weight -> None
-        return float(self.weights[i, j])
+        return float(self.weights[i, j]) if self.connections[i, j] else 0.0
 
     def get_incoming_connections(self, position):
         j = self._index(position)

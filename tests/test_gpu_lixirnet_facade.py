@@ -35,8 +35,9 @@ def test_single_lattice_electrical_using_from(snn):
             if a != b:
                 assert lattice.get_weight(a, b) == gpu_lattice.get_weight(a, b) == 5.0
         assert lattice.get_neuron(*a).current_voltage == gpu_lattice.get_neuron(*a).current_voltage
+    assert gpu_lattice.get_weight((0, 0), (0, 0)) == 0.0   # diagonal is None: unwrap_or(0.) (interface lattices/mod.rs:114-121)
     with pytest.raises(KeyError):
-        gpu_lattice.get_weight((0, 0), (0, 0))             # diagonal is None
+        gpu_lattice.get_weight((0, 0), (exc_n, 0))         # outside the lattice
     with pytest.raises(NotImplementedError):
         lattice.run_lattice(1)                              # no CPU stepper in the product
 

@@ -300,3 +300,58 @@ def test_lattices_py_procedure(ln):
     assert np.array_equal(parity.bits(np.array(gpu.history, np.float32).reshape(iterations, -1)), parity.bits(net.voltage_history))
     assert gpu.get_neuron(2, 3).current_voltage == float(net["current_voltage"][11])
     gpu.close()
+
+
+def test_dopa_testing_py_procedure(ln):
+    """interface_gpu/lixirnet/tests/dopa_testing.py: glutamate and dopamine Rate spike trains (one lattice each) drive a
+    lattice whose neurons carry a Glutamate and a Dopamine receptor (s_d1 = 1: D1 scales the NMDA exponent), chemical
+    synapses only, dt = 1"""
+    rng = np.random.default_rng(77)
+    n1, c2 = 4, 2
+    T = ln.DopaGluGABANeurotransmitterType
+    exc_neuron = ln.IzhikevichNeuron()
+    exc_neuron.gap_conductance = 10
+    exc_neuron.c_m = 25
+    exc_neurotransmitters = {T.Glutamate: ln.BoundedNeurotransmitterKinetics()}
+    dopa_neurotransmitters = {T.Dopamine: ln.BoundedNeurotransmitterKinetics()}
+    glu, dopa = ln.GlutamateReceptor(), ln.DopamineReceptor()
+    dopa.s_d1 = 1
+    dopa.s_d2 = 0
+    receptors = ln.DopaGluGABA()
+    receptors.insert(T.Glutamate, glu)
+    receptors.insert(T.Dopamine, dopa)
+    exc_neuron.set_synaptic_neurotransmitters(exc_neurotransmitters)
+    exc_neuron.set_receptors(receptors)
+    exc_spike_train = ln.RateSpikeTrain()
+    exc_spike_train.rate = 100
+    exc_spike_train.set_synaptic_neurotransmitters(exc_neurotransmitters)
+    dopa_spike_train = ln.RateSpikeTrain()
+    dopa_spike_train.rate = 100
+    dopa_spike_train.set_synaptic_neurotransmitters(dopa_neurotransmitters)
+    stl1 = ln.RateSpikeTrainLattice(1)
+    stl1.populate(exc_spike_train, n1, n1)
+    stl1.apply_given_position(get_spike_train_setup(rng.uniform(0, 100, (n1, n1))))
+    stl1.update_grid_history = True
+    stl2 = ln.RateSpikeTrainLattice(c2)
+    stl2.populate(dopa_spike_train, n1, n1)
+    stl2.apply_given_position(get_spike_train_setup(rng.uniform(0, 100, (n1, n1))))
+    stl2.update_grid_history = True
+    lattice1 = ln.IzhikevichNeuronLattice(e1)
+    lattice1.populate(exc_neuron, n1, n1)
+    lattice1.apply_given_position(get_neuron_setup(rng.uniform(exc_neuron.c, exc_neuron.v_th, (n1, n1))))
+    lattice1.connect(lambda x, y: x != y, lambda x, y: 1)
+    lattice1.update_grid_history = True
+    network = ln.IzhikevichNeuronNetwork.generate_network([lattice1], [stl1, stl2])
+    network.connect(1, e1, lambda x, y: x == y, lambda x, y: 1)
+    network.connect(c2, e1, lambda x, y: x == y, lambda x, y: 1)
+    network.electrical_synapse = False
+    network.chemical_synapse = True
+    network.parallel = True
+    network.set_dt(1)
+    gpu_network = ln.IzhikevichNeuronNetworkGPU.from_network(network)
+    net = check_against_oracle(ln, network, gpu_network, (e1,), (1, c2))
+    assert not np.all(lc.var(net, "rx_vars", "nmda_modifier") == 1.0)          # the dopamine receptor has acted
+    got = gpu_network.get_lattice(e1).get_neuron(1, 2).receptors
+    assert got.nmda_modifier == float(lc.var(net, "rx_vars", "nmda_modifier")[6])
+    assert got[T.Glutamate].nmda_r.r == float(lc.var(net, "rx_vars", "Glutamate$nmda_r$kinetics$r")[6])
+    gpu_network.close()

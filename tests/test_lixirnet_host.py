@@ -146,8 +146,9 @@ def test_lattice_interface(ln):
     lat.connect(lambda x, y: x[0] == y[0] and x != y, lambda x, y: 0.5)
     assert lat.id == 3 and lat.get_every_node() == {(r, c) for r in range(2) for c in range(3)}
     assert lat.get_weight((0, 0), (0, 2)) == 0.5
+    assert lat.get_weight((0, 0), (1, 0)) == 0.0                # lookup_weight -> None -> unwrap_or(0.)
     with pytest.raises(KeyError):
-        lat.get_weight((0, 0), (1, 0))                          # lookup_weight -> None
+        lat.get_weight((0, 0), (2, 0))                          # outside the lattice
     assert lat.get_incoming_connections((1, 1)) == {(1, 0), (1, 2)} and lat.get_outgoing_connections((0, 2)) == {(0, 0), (0, 1)}
     w = lat.get_weights()
     assert w.shape == (6, 6) and w.sum() == 0.5 * 12 and lat.get_position_to_index_for_weights()[(1, 2)] == 5
