@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A/B of the two streamed shapes of the dense input pass on ONE handle (same matrix placement), alternating:
-ab_input_shape.py [c2|c3|c4] [rounds] [steps]"""
+ab_input_shape.py [c2|c3|<side>] [rounds] [steps]  (1: 4 columns per lane, 2: two)"""
 import json
 import os
 import sys
@@ -27,7 +27,7 @@ if cfg == "c3":
     dn.fill_graph_synthetic(4, 0.5, 1.5, with_diagonal=False)
     dn.set_synapses(True, True)
 else:
-    side = 256
+    side = int(cfg) if cfg.isdigit() else 256
     n = side * side
     dn = snn_amd.DeviceNetwork(model=snn_amd.IZHIKEVICH)
     dn.add_lattice(0, side, side)

@@ -129,7 +129,9 @@ int launch_inputs(snn_network *net, InputsPart part = INPUTS_ALL)
     // 4-columns-per-lane shape, or the 2-column shape while that would leave the chip under-filled
     const bool resident = (size_t)net->n_tot * net->ld * 4 <= ((size_t)64 << 20);
     const uint64_t waves4 = (uint64_t)((net->n_loc + 255) / 256) * grid_chunks;
-    int shape = resident ? 0 : (waves4 < 8192 ? 2 : 1);     // 8192 = 256 CUs x 32 wave slots
+    // same-box A/B of the two streamed shapes (profiles/ab_input_shape.py, profiles/r03/ab_input_shape_by_size.txt): the
+    // 2-column shape wins by 0.8 - 2.4 % from 96x96 to 240x240 (waves4 up to 50 625), the 4-column shape by 0.5 % at 256x256
+    int shape = resident ? 0 : (waves4 < 57600 ? 2 : 1);
     if (net->force_shape > 0 && !resident) shape = net->force_shape;     // SNN_AMD_INPUT_SHAPE=1|2 (experiments)
     if (net->rstdp_pending && part != INPUTS_ALL) TRY(flush_rstdp(net));
     const bool stdp_fused = net->stdp_pending && !net->rstdp_pending && part == INPUTS_ALL && shape != 0;
