@@ -19,7 +19,13 @@
  * (tests/size_zero_cases.rs), Poisson->neuron spike-count behaviour
  * (tests/spike_train_neuron_interaction.rs:91-203), interleaved index
  * placement (tests/interleaving_graph_conversion.rs) -- plus hand-derived
- * single-step values of every formula cited below.
+ * single-step values of every formula cited below.  The committed golden
+ * vectors (tests/golden/ *.npz) are NOT written by this file: a second,
+ * independently written numpy restatement (tests/numpy_net.py, host libm for
+ * exp / powf) writes them, and this oracle is held to them
+ * (tests/test_golden_oracle.py) as the device is (tests/test_gpu_golden.py);
+ * tests/test_numpy_twin_randomized.py compares the two restatements on random
+ * networks of every built-in model.
  *
  * Canonical choices where the reference leaves the result unspecified
  * (DESIGN.md "Canonical semantics"):
