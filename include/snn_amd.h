@@ -229,10 +229,13 @@ int snn_step_end(snn_network_t *net);
  * trades whole ownerships with every peer (the all-gather's content as an all-to-all-v). */
 int snn_network_finalize_shard_by_lattice(snn_network_t *net, uint32_t shard_index, uint32_t n_shards);
 int snn_shard_ranges(const snn_network_t *net, uint32_t *begin, uint32_t *end, uint32_t capacity, uint32_t *count);
-/* Optional overlap: enqueue, BEFORE the exchange of the previous step has been waited for, the part of
- * this step's synaptic-input pass that only needs the shard's own neurons as presynaptic rows; the
- * following snn_step_begin then processes the remaining rows.  A no-op when plasticity is on (STDP
- * rewrites W in snn_step_end) or the graph is CSR.  Results do not depend on whether it is called. */
+/* Optional overlap of the exchange with work that does not depend on it.  Results never depend on whether it is called.
+ * Dense handles: enqueue, BEFORE the exchange of the previous step has been waited for, the part of the NEXT step's
+ * synaptic-input pass that only needs the shard's own neurons as presynaptic rows; the following snn_step_begin then
+ * processes the remaining rows.  A no-op when plasticity is on (STDP rewrites W in snn_step_end).
+ * Sparse handles with a halo plan and no weight updates: snn_step_begin has enqueued the BORDER slices of the step (the
+ * 64-row slices holding a neuron some peer reads) and written the outgoing segments; this call enqueues the INTERIOR
+ * slices of the SAME step -- call it once the exchange is under way.  snn_step_end does it itself if nobody did. */
 int snn_step_begin_local(snn_network_t *net);
 
 enum { SNN_EXCHANGE_ALLGATHER = 0, SNN_EXCHANGE_HALO = 1 };
