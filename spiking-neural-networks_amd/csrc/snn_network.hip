@@ -1466,7 +1466,12 @@ int snn_input_kernel_bytes(const snn_network_t *net, uint64_t *bytes)
 {
     if (!net || !bytes) return fail(SNN_ERR_BAD_ARG, "null argument");
     if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
-    if (net->csr) { *bytes = (uint64_t)8 * net->nnz; return SNN_OK; }      // sparse: index + weight of every stored synapse
+    if (net->csr) {
+        // sparse: index + weight of every stored synapse; the one-launch step (k_step_csr) also is the neuron update of its
+        // rows: + S = 60 B of state per Izhikevich-class neuron ("8 B x nnz + S x N")
+        *bytes = (uint64_t)8 * net->nnz + (fused_csr_step_applies(net) ? (uint64_t)60 * net->n_loc : 0u);
+        return SNN_OK;
+    }
     uint64_t b = (uint64_t)4 * net->n_tot * net->n_loc;                    // dense: every weight of the shard, read once
     if (net->any_modulation && net->defer_rstdp) {
         // k_inputs_rstdp: the internal edges of a reward-modulated lattice are read AND rewritten, weight and trace --
