@@ -379,7 +379,9 @@ int snn_get_eeg_history(snn_network_t *net, uint32_t id, float *dst, size_t step
 int snn_get_spike_counts(snn_network_t *net, uint32_t id, uint32_t *dst, size_t count);
 
 /* Tuning switches (results never depend on them; defaults in brackets, also settable through the environment when the
- * handle is created: SNN_AMD_<NAME in upper case>): "fused_step" [1] one-launch step for small lattices; "defer_rstdp"
+ * handle is created: SNN_AMD_<NAME in upper case>): "fused_step" [1] one-launch step for small lattices and for
+ * sparse handles; "cells_in_step" [1] sparse electrical-only handles without weight updates: the spike-train cells advance
+ * inside the step's launch; "defer_rstdp"
  * [1] reward-modulated weight updates riding on the next input pass; "defer_stdp" [0] 1: STDP updates riding on the next
  * input pass, 2: prepared delta vectors applied by scatter passes; "uniform_params" [1] population-wide parameter
  * values from a device table; "persistent_run" [1] all steps of an snn_run call (of 4 steps or more) on a small

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """What ONE rank of G does per C5 step (configs[4] sharded by lattice), timed on one GPU: the shard handle of rank G/2
 runs the library's step loop with a do-nothing exchange (snn_run_sharded_custom + snn_exchange_noop; the halo contents are then stale, the
-timing is not affected).  Shows how far the per-rank step is from its kernel time, i.e. how launch-bound the small
+timing is not affected).  SHARDS=8 in the environment measures that one split only.  Shows how far the per-rank step is from its kernel time, i.e. how launch-bound the small
 sparse step is.  Usage: measure_c5_rank_step.py [steps]"""
 import json
 import os
@@ -17,7 +17,7 @@ from snn_amd import synthetic  # noqa: E402
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 side = 512
 m = side * side
-for g in (1, 2, 4, 8):
+for g in ([int(os.environ['SHARDS'])] if os.environ.get('SHARDS') else (1, 2, 4, 8)):
     dn = snn_amd.DeviceNetwork(model=snn_amd.IZHIKEVICH, spike_train=snn_amd.ST_POISSON)
     for k in range(4):
         dn.add_lattice(k, side, side)

@@ -89,9 +89,9 @@ __device__ __forceinline__ void csr_row_sums(const CsrInputsArgs &a, uint32_t q,
             flags[u] = is_cell ? 1u : 0u;
             v[u] = 0.0f;
             if (ELEC) {
-                const float *src = is_cell ? in.st_value + sc : in.xbuf + in.xl.at(pn, PLANE_V);
+                const float *src = is_cell ? reinterpret_cast<const float *>(in.st_view + sc) : in.xbuf + in.xl.at(pn, PLANE_V);
                 v[u] = *src;
-                flags[u] |= (is_cell && in.st_last_firing_time[sc] < 0) ? 2u : 0u;
+                flags[u] |= (is_cell && in.st_view[sc].y) ? 2u : 0u;
             }
             if (CHEM) {
 #pragma unroll
@@ -183,12 +183,26 @@ struct CsrStepArgs {
     const uint32_t *slice_list;
     uint32_t n_listed;
     PackTable pack;
+    // the spike-train cells advancing in the same launch (the last cell_blocks blocks of the grid): rows read the cells' view of THIS step
+    // (InputsArgs::st_view), the cells write the next one (SpikeTrainArgs::view_out).  Electrical-only handles without
+    // weight updates (nothing reads a cell's own arrays between the neuron update and the cells' iteration).
+    SpikeTrainArgs cells;
+    uint32_t cell_blocks;
 };
+static_assert(sizeof(CsrStepArgs) <= 4096, "kernel arguments are limited to 4 KB");
 
 template <int MODEL, bool ELEC, bool CHEM>
 __global__ __launch_bounds__(256) void k_step_csr(const CsrStepArgs a)
 {
-    const uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6);  // wavefront = one SELL slice
+    // the cell blocks come AFTER the row blocks: they fill the tail of the rows' streaming (measured at C5, one box, step
+    // time: cells in their own launch 44.7 us; cell blocks first 41.5; spread evenly among the row blocks 45.6; last 39.3)
+    const uint32_t row_blocks = gridDim.x - a.cell_blocks;
+    if (blockIdx.x >= row_blocks) {
+        spike_train_cell(a.cells, (blockIdx.x - row_blocks) * 256 + threadIdx.x);
+        return;
+    }
+    const uint32_t row_block = blockIdx.x;
+    const uint32_t w = row_block * 4 + (threadIdx.x >> 6);  // wavefront = one SELL slice
     if (a.slice_list ? w >= a.n_listed : w >= a.c.g.n_slices) return;
     const uint32_t q = (a.slice_list ? a.slice_list[w] : w) * 64u + (threadIdx.x & 63u);
     RegisterSums s;

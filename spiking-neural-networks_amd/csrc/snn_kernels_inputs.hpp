@@ -48,6 +48,9 @@ struct InputsArgs {
     // spike-train cells
     const float *st_value;
     const int32_t *st_last_firing_time;
+    // sparse handles: {st_value as bits, 1 when the cell has never fired} per cell, the copy of this step (the cells may be
+    // advancing into the other copy inside the same launch, k_step_csr); null: st_value / st_last_firing_time are read
+    const uint2 *st_view;
     const float *st_nt_t;          // [3][c_pad]
     const uint32_t *st_nt_flags;   // [3][c_pad]
     uint32_t c_pad;

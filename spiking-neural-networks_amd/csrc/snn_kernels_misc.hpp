@@ -130,6 +130,8 @@ struct SpikeTrainArgs {
     // thread i handles cell cell_list[i], i < n_listed.  null: every cell.
     const uint32_t *cell_list;
     uint32_t n_listed;
+    // sparse handles: where the rows of the NEXT input calculation read {presyn_value, never fired} (InputsArgs::st_view)
+    uint2 *view_out;
 };
 
 // one spike-train cell: thread i of the cell job
@@ -232,6 +234,7 @@ __device__ __forceinline__ void spike_train_cell(const SpikeTrainArgs &a, const 
                      : delta_dirac_effect(a.view_clock, lft, p_v_th, p_v_resting, p_k, p_dt);
     }
     c.presyn_value[s] = value;
+    if (a.view_out) a.view_out[s] = make_uint2(__float_as_uint(value), lft < 0 ? 1u : 0u);
 }
 
 __global__ __launch_bounds__(256) void k_spike_trains(const SpikeTrainArgs a)

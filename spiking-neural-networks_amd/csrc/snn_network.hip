@@ -40,6 +40,7 @@ int snn_network_create(int device, int neuron_model, int nt_kinetics, int recept
     snn_network *net = new snn_network();
     net->device = device;
     if (const char *e = getenv("SNN_AMD_FUSED_STEP")) net->fused_step = (e[0] != '0');
+    if (const char *e = getenv("SNN_AMD_CELLS_IN_STEP")) net->cells_in_step = (e[0] != '0');
     if (const char *e = getenv("SNN_AMD_DEFER_RSTDP")) net->defer_rstdp = (e[0] != '0');
     if (const char *e = getenv("SNN_AMD_DEFER_STDP")) net->defer_stdp = (e[0] == '2') ? 2 : (e[0] != '0');
     if (const char *e = getenv("SNN_AMD_UNIFORM_PARAMS")) net->uniform_params = (e[0] != '0');
@@ -1386,6 +1387,7 @@ int snn_set_option(snn_network_t *net, const char *name, int value)
     if (net->finalized) TRY(end_run(net));            // pending deferred updates belong to the old setting
     const std::string n(name);
     if (n == "fused_step") net->fused_step = value != 0;
+    else if (n == "cells_in_step") net->cells_in_step = value != 0;
     else if (n == "defer_rstdp") net->defer_rstdp = value != 0;
     else if (n == "defer_stdp") net->defer_stdp = (value == 2) ? 2 : (value != 0);
     else if (n == "uniform_params") { net->uniform_params = value != 0; net->uni_dirty = true; }

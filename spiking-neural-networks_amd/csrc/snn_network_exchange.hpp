@@ -210,16 +210,7 @@ int launch_step_close(snn_network *net, bool cells, bool unpack)
 {
     StepCloseArgs a{};
     uint32_t cell_work = 0;
-    if (cells && net->nc) {
-        SpikeTrainArgs &c = a.cells;
-        c.c = net->ca; c.n_cells = net->nc; c.st_kind = net->st_kind; c.nt_kind = net->nt_kind;
-        c.iterate = 1; c.lattice_clock = net->st_clock_dev; c.step_offset = net->run_step_offset;
-        c.has_nt = net->any_nt_cells ? 1 : 0;
-        c.view_clock = net->clock + 1;
-        c.vhist_row = (record_now(net) && net->want_vhist && net->st_vhist) ? net->st_vhist + (size_t)net->hist_steps * net->c_pad : nullptr;
-        c.cell_list = net->cell_list_dev; c.n_listed = net->n_cells_listed;
-        cell_work = net->cell_list_dev ? net->n_cells_listed : net->nc;
-    }
+    if (cells) cell_work = spike_train_args(net, a.cells, 1, net->run_step_offset, net->clock + 1);
     a.cell_blocks = (cell_work + 255) / 256;
     if (unpack && net->n_shards > 1 && net->seg_n[1] && net->recv_total) {
         a.recv = wire_args(net, 1);

@@ -177,6 +177,12 @@ struct snn_network {
     std::vector<uint32_t> cell_list_host;
     uint32_t *cell_list_dev = nullptr;
     uint32_t n_cells_listed = 0;
+    // sparse handles: what the rows read of a cell, two copies (InputsArgs::st_view); rows read cell_view[cell_view_cur],
+    // an iteration of the cells writes the other copy and flips
+    uint2 *cell_view[2] = {nullptr, nullptr};
+    int cell_view_cur = 0;
+    bool cells_stepped = false;      // this step's cells advanced inside k_step_csr (step_end skips their launch)
+    int cells_in_step = 1;           // option "cells_in_step": 0 keeps the cells in their own launch
     // uniform-parameter tables (UniformTable, snn_layout.hpp): rescanned when attributes were set
     UniformTable *uni_neuron = nullptr, *uni_cell = nullptr;
     bool uni_dirty = true;

@@ -7,10 +7,12 @@
 
 namespace {
 
-int launch_spike_trains(snn_network *net, int iterate, long long step_offset, long long view_clock)
+// Arguments of the cells' job (k_spike_trains, or the cell blocks of k_step_csr / k_step_close); returns the number of
+// threads it needs.  iterate = 1 flips the sparse handles' view: the launch writes the copy the NEXT input calculation reads.
+uint32_t spike_train_args(snn_network *net, SpikeTrainArgs &a, int iterate, long long step_offset, long long view_clock)
 {
-    if (net->nc == 0) return SNN_OK;
-    SpikeTrainArgs a{};
+    a = SpikeTrainArgs{};
+    if (net->nc == 0) return 0;
     a.c = net->ca; a.n_cells = net->nc; a.st_kind = net->st_kind; a.nt_kind = net->nt_kind;
     a.iterate = iterate; a.lattice_clock = net->st_clock_dev; a.step_offset = step_offset;
     a.has_nt = net->any_nt_cells ? 1 : 0;
@@ -18,6 +20,17 @@ int launch_spike_trains(snn_network *net, int iterate, long long step_offset, lo
     a.vhist_row = (iterate && record_now(net) && net->want_vhist && net->st_vhist) ? net->st_vhist + (size_t)net->hist_steps * net->c_pad : nullptr;
     a.cell_list = net->cell_list_dev; a.n_listed = net->n_cells_listed;
     const uint32_t work = net->cell_list_dev ? net->n_cells_listed : net->nc;
+    if (work && net->cell_view[0]) {
+        if (iterate) net->cell_view_cur ^= 1;
+        a.view_out = net->cell_view[net->cell_view_cur];
+    }
+    return work;
+}
+
+int launch_spike_trains(snn_network *net, int iterate, long long step_offset, long long view_clock)
+{
+    SpikeTrainArgs a;
+    const uint32_t work = spike_train_args(net, a, iterate, step_offset, view_clock);
     if (work == 0) return SNN_OK;
     hipLaunchKernelGGL(k_spike_trains, dim3((work + 255) / 256), dim3(256), 0, net->stream, a);
     HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
@@ -88,6 +101,7 @@ int launch_inputs(snn_network *net, InputsPart part = INPUTS_ALL)
     a.W = net->W; a.ld = net->ld; a.n_loc = net->n_loc; a.q0 = net->q0; a.rows = net->rowmap; a.n_neurons = net->nn; a.n_tot = net->n_tot;
     a.xbuf = net->xbuf; a.xl = net->xl; a.gap_conductance = net->na.gap_conductance; a.uni = net->uni_neuron;
     a.st_value = net->ca.presyn_value; a.st_last_firing_time = net->ca.last_firing_time;
+    a.st_view = net->cell_view[net->cell_view_cur];
     a.st_nt_t = net->ca.nt_t; a.st_nt_flags = net->ca.nt_flags; a.c_pad = net->c_pad;
     a.nt_flags = net->na.nt_flags; a.n_pad = net->n_pad;
     a.part_i = net->part_i; a.part_t = net->part_t; a.n_chunks = net->n_chunks;
@@ -499,6 +513,7 @@ int fused_step_args(snn_network *net, InputsArgs &a, UpdateArgs &u, bool in_plac
     a.W = net->W; a.ld = net->ld; a.n_loc = net->n_loc; a.q0 = net->q0; a.rows = net->rowmap; a.n_neurons = net->nn; a.n_tot = net->n_tot;
     a.xbuf = cur; a.xl = net->xl; a.gap_conductance = net->na.gap_conductance; a.uni = net->uni_neuron;
     a.st_value = net->ca.presyn_value; a.st_last_firing_time = net->ca.last_firing_time;
+    a.st_view = net->cell_view[net->cell_view_cur];
     a.st_nt_t = net->ca.nt_t; a.st_nt_flags = net->ca.nt_flags; a.c_pad = net->c_pad;
     a.nt_flags = net->na.nt_flags; a.n_pad = net->n_pad;
     a.part_i = net->part_i; a.part_t = net->part_t; a.n_chunks = net->n_chunks;
@@ -769,6 +784,15 @@ bool csr_fast_step(const snn_network *net)
            !net->any_modulation && !net->want_avg && !net->want_eeg && !net->any_whist;
 }
 
+// The spike-train cells advance inside the step's (last) k_step_csr launch: nothing may read a cell's own arrays between the
+// neuron update and the cells' iteration (weight updates do: last_firing_time), and the rows must read the cells through
+// the two-copy view only (chemical synapses read the cells' transmitter planes directly).
+bool cells_ride_with_rows(const snn_network *net)
+{
+    return net->nc && net->cell_view[0] && net->electrical && !net->chemical && !net->any_plasticity && !net->any_modulation &&
+           net->cells_in_step && (!net->sharded || net->n_shards == 1 || csr_fast_step(net));
+}
+
 enum CsrStepPart { CSR_STEP_ALL = 0, CSR_STEP_BORDER = 1, CSR_STEP_INTERIOR = 2 };
 
 int launch_step_close(snn_network *net, bool cells, bool unpack);
@@ -786,11 +810,17 @@ int launch_step_csr(snn_network *net, CsrStepPart part = CSR_STEP_ALL, bool pack
         c.pack.index = net->pack_index_dev; c.pack.buf = net->halo_send_buf; c.pack.planes = net->x_planes;
         for (int s = 0; s < WIRE_MAX_PLANES; ++s) c.pack.plane_id[s] = net->x_plane_id[s];
     }
+    // the cells ride with the step's last row launch (the rows of BOTH launches read the view the cells do not write)
+    const bool last_part = part != CSR_STEP_BORDER || net->n_interior == 0;
+    if (last_part && !net->cells_stepped && cells_ride_with_rows(net)) {
+        c.cell_blocks = (spike_train_args(net, c.cells, 1, net->run_step_offset, net->clock + 1) + 255) / 256;
+        net->cells_stepped = true;
+    }
     hipEvent_t e1 = nullptr;
-    if (waves) {
+    if (waves || c.cell_blocks) {
         TRY(profile_open(net, &e1));
         if (e1 && part == CSR_STEP_BORDER && net->n_interior) net->ev_counts[net->ev_used - 1] = 0;   // the interior launch counts the pass
-        const dim3 grid((waves + 3) / 4), block(256);
+        const dim3 grid((waves + 3) / 4 + c.cell_blocks), block(256);
 #define SNN_CSR_STEP(M)                                                                                              \
     do {                                                                                                             \
         if (net->electrical && net->chemical) hipLaunchKernelGGL((k_step_csr<M, true, true>), grid, block, 0, net->stream, c);  \
@@ -851,7 +881,8 @@ int step_end(snn_network *net)
     if (net->step_packed) {
         // the fast sparse step (csr_fast_step): unpack, spike trains and the clearing of the outgoing bitmaps in ONE launch
         net->step_packed = false;
-        TRY(launch_step_close(net, /*cells=*/true, /*unpack=*/true));
+        TRY(launch_step_close(net, /*cells=*/!net->cells_stepped, /*unpack=*/true));
+        net->cells_stepped = false;
         net->clock += 1;
         net->run_step_offset += 1;
         if (record_now(net)) net->hist_steps += 1;
@@ -888,7 +919,8 @@ int step_end(snn_network *net)
         HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
     }
     net->clock += 1;
-    TRY(launch_spike_trains(net, 1, net->run_step_offset, net->clock));
+    if (!net->cells_stepped) TRY(launch_spike_trains(net, 1, net->run_step_offset, net->clock));
+    net->cells_stepped = false;
     net->run_step_offset += 1;
     if (record_now(net)) net->hist_steps += 1;
     if (recording(net)) net->hist_tick += 1;
@@ -943,6 +975,10 @@ int begin_run(snn_network *net, uint64_t iterations)
                                        "an all-gather exchange with electrical synapses on");
     TRY(grow_history(net, iterations));
     if (net->run_active) return SNN_OK;
+    if (net->nc && net->csr && !net->cell_view[0]) {
+        for (int i = 0; i < 2; ++i) TRY(dev_alloc_t(net, &net->cell_view[i], (size_t)net->c_pad));
+        net->view_dirty = true;
+    }
     if (net->nc) {
         // pageable source: the copy is staged before the call returns, so the host vector may change afterwards
         HIP_TRY(hipMemcpyAsync(net->st_clock_dev, net->st_clock.data(), net->st_clock.size() * sizeof(long long),

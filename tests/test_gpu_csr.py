@@ -107,13 +107,22 @@ def c5_structure(side, seed=11):
     return net
 
 
-def test_c5_structure_csr(snn):
+@pytest.mark.parametrize("cells_in_step", [1, 0])
+def test_c5_structure_csr(snn, cells_in_step):
+    """cells_in_step 1 (default): the Poisson cells advance inside the rows' launch, rows reading the view of the step
+    while the cells write the next one; 0: the cells' own launch after the neuron update."""
     net = c5_structure(12)
     assert net["connections"].sum(axis=0).max() == 14
     dn = parity.device_from_oracle(snn, net, csr=True)
+    dn.set_option("cells_in_step", cells_in_step)
+    dn.run(3)
+    net.run(3)
+    fired = np.where(np.arange(144) % 7 == 0, 1, -1).astype(np.int32)
+    dn.set_attr(5, "last_firing_time", fired)        # cell state changed behind the stepper's back: the view is rebuilt
+    net["st_last_firing_time"][144:288] = fired
     dn.set_history(voltage=True, spikes=True)
-    dn.run(500)
-    net.run(500, voltage_history=True, spike_history=True)
+    dn.run(497)
+    net.run(497, voltage_history=True, spike_history=True)
     assert net.spike_history.sum() > 50
     check(dn, net)
     dn.close()
