@@ -254,7 +254,7 @@ def build_config(args, snn_amd, synthetic, np, rank, world, local_rank):
             dn.set_attr(4 + k, "seed", np.arange(k * m + 1, (k + 1) * m + 1, dtype=np.uint32))   # cell index + 1
         dn.set_graph_csr(*synthetic.c5_csr(side, posts=dn.owned))
         return dn, 4 * m, (f"4 x ({side}x{side}) Izhikevich lattices (radius-2 neighbourhoods) + 4 Poisson spike-train "
-                           f"lattices one-to-one + ring k->k+1, CSR, dt=0.1"), "k_step_csr<0,true,false> (inputs + neuron update in one launch)"
+                           f"lattices one-to-one + ring k->k+1, CSR, dt=0.1"), "k_step_csr<0,true,false> (inputs + neuron update + Poisson cells in one launch)"
     raise SystemExit(f"unknown --config {cfg}")
 
 

@@ -431,7 +431,7 @@ int snn_profile_read_plasticity(snn_network_t *net, uint64_t *steps, double *tot
 int snn_set_synthetic_drive(snn_network_t *net, uint64_t seed, float fraction, float voltage);
 /* Algorithmic bytes ONE launch of the synaptic-input kernel moves (DESIGN.md "Roofline"): 4 B per synapse of the shard
  * (dense), 8 B per stored synapse (sparse; + 60 B of state per row when the launch is the one-launch step k_step_csr,
- * which also is the neuron update), 16 B per internal synapse of a reward-modulated lattice whose weight update
+ * which also is the neuron update, + 28 B per spike-train cell when the cells advance in that launch too), 16 B per internal synapse of a reward-modulated lattice whose weight update
  * rides on the pass (k_inputs_rstdp: weight and trace read and rewritten) */
 int snn_input_kernel_bytes(const snn_network_t *net, uint64_t *bytes);
 

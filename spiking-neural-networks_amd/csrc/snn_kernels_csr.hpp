@@ -188,6 +188,7 @@ struct CsrStepArgs {
     // weight updates (nothing reads a cell's own arrays between the neuron update and the cells' iteration).
     SpikeTrainArgs cells;
     uint32_t cell_blocks;
+    uint32_t xcd_bands;             // 1: row blocks are dealt to the XCDs in contiguous bands (see k_step_csr)
 };
 static_assert(sizeof(CsrStepArgs) <= 4096, "kernel arguments are limited to 4 KB");
 
@@ -201,7 +202,14 @@ __global__ __launch_bounds__(256) void k_step_csr(const CsrStepArgs a)
         spike_train_cell(a.cells, (blockIdx.x - row_blocks) * 256 + threadIdx.x);
         return;
     }
-    const uint32_t row_block = blockIdx.x;
+    // Workgroups are handed to the 8 XCDs round-robin (a placement heuristic, used for speed only): XCD x takes a
+    // contiguous band of the row blocks, so that the presynaptic state its rows gather (neighbouring rows of the same
+    // lattice) is fetched into ONE L2 instead of all eight
+    uint32_t row_block = blockIdx.x;
+    if (a.xcd_bands) {
+        const uint32_t x = blockIdx.x & 7u, per = row_blocks >> 3, extra = row_blocks & 7u;
+        row_block = x * per + min(x, extra) + (blockIdx.x >> 3);
+    }
     const uint32_t w = row_block * 4 + (threadIdx.x >> 6);  // wavefront = one SELL slice
     if (a.slice_list ? w >= a.n_listed : w >= a.c.g.n_slices) return;
     const uint32_t q = (a.slice_list ? a.slice_list[w] : w) * 64u + (threadIdx.x & 63u);

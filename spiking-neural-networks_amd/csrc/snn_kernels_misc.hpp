@@ -140,6 +140,7 @@ __device__ __forceinline__ void spike_train_cell(const SpikeTrainArgs &a, const 
     if (i >= (a.cell_list ? a.n_listed : a.n_cells)) return;
     const uint32_t s = a.cell_list ? a.cell_list[i] : i;
     const CellArrays &c = a.c;
+    int32_t lft = c.last_firing_time[s];          // requested before the iteration's own loads (one round trip less)
     if (a.iterate) {
         uint32_t spike;
         float custom_v = 0.0f;
@@ -211,12 +212,14 @@ __device__ __forceinline__ void spike_train_cell(const SpikeTrainArgs &a, const 
             c.nt_t[i] = nt_apply(a.nt_kind, c.nt_t[i], c.nt_t_max[i], c.nt_clearance[i], c.nt_v_p[i], c.nt_k_p[i],
                                  v, spike, c.dt[s]);
         }
-        if (spike) c.last_firing_time[s] = (int32_t)(a.lattice_clock[c.lattice_slot[s]] + a.step_offset);
+        if (spike) {
+            lft = (int32_t)(a.lattice_clock[c.lattice_slot[s]] + a.step_offset);
+            c.last_firing_time[s] = lft;
+        }
         if (a.vhist_row) a.vhist_row[s] = v;
     }
     // presynaptic value of the next input calculation (spike_train_gap_junction, neuron/mod.rs:119-137):
     // never fired -> v_resting (used WITHOUT the conductance factor), else the refractoriness effect
-    const int32_t lft = c.last_firing_time[s];
     const uint32_t refr = uload(c.uni, CP_REFR, c.refractoriness, s);
     const float p_v_th = uload(c.uni, CP_V_TH, c.v_th, s), p_v_resting = uload(c.uni, CP_V_RESTING, c.v_resting, s);
     const float p_dt = uload(c.uni, CP_DT, c.dt, s), p_k = uload(c.uni, CP_K, c.k, s);
@@ -233,8 +236,8 @@ __device__ __forceinline__ void spike_train_cell(const SpikeTrainArgs &a, const 
         value = refr ? exponential_decay_effect(a.view_clock, lft, p_v_th, p_v_resting, p_k, p_dt)
                      : delta_dirac_effect(a.view_clock, lft, p_v_th, p_v_resting, p_k, p_dt);
     }
-    c.presyn_value[s] = value;
-    if (a.view_out) a.view_out[s] = make_uint2(__float_as_uint(value), lft < 0 ? 1u : 0u);
+    if (a.view_out) a.view_out[s] = make_uint2(__float_as_uint(value), lft < 0 ? 1u : 0u);   // sparse handles read only the view
+    else c.presyn_value[s] = value;
 }
 
 __global__ __launch_bounds__(256) void k_spike_trains(const SpikeTrainArgs a)

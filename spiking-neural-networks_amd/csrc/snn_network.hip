@@ -40,6 +40,7 @@ int snn_network_create(int device, int neuron_model, int nt_kinetics, int recept
     snn_network *net = new snn_network();
     net->device = device;
     if (const char *e = getenv("SNN_AMD_FUSED_STEP")) net->fused_step = (e[0] != '0');
+    if (const char *e = getenv("SNN_AMD_CSR_XCD_BANDS")) net->csr_xcd_bands = (e[0] != '0');
     if (const char *e = getenv("SNN_AMD_CELLS_IN_STEP")) net->cells_in_step = (e[0] != '0');
     if (const char *e = getenv("SNN_AMD_DEFER_RSTDP")) net->defer_rstdp = (e[0] != '0');
     if (const char *e = getenv("SNN_AMD_DEFER_STDP")) net->defer_stdp = (e[0] == '2') ? 2 : (e[0] != '0');
@@ -1388,6 +1389,7 @@ int snn_set_option(snn_network_t *net, const char *name, int value)
     const std::string n(name);
     if (n == "fused_step") net->fused_step = value != 0;
     else if (n == "cells_in_step") net->cells_in_step = value != 0;
+    else if (n == "csr_xcd_bands") net->csr_xcd_bands = value != 0;
     else if (n == "defer_rstdp") net->defer_rstdp = value != 0;
     else if (n == "defer_stdp") net->defer_stdp = (value == 2) ? 2 : (value != 0);
     else if (n == "uniform_params") { net->uniform_params = value != 0; net->uni_dirty = true; }
@@ -1471,7 +1473,11 @@ int snn_input_kernel_bytes(const snn_network_t *net, uint64_t *bytes)
     if (net->csr) {
         // sparse: index + weight of every stored synapse; the one-launch step (k_step_csr) also is the neuron update of its
         // rows: + S = 60 B of state per Izhikevich-class neuron ("8 B x nnz + S x N")
+        // ... and, when the spike-train cells advance in the same launch: + 28 B per cell (seed read + written, voltage and
+        // spike flag written, last firing time read, the 8-byte view entry written)
         *bytes = (uint64_t)8 * net->nnz + (fused_csr_step_applies(net) ? (uint64_t)60 * net->n_loc : 0u);
+        if (fused_csr_step_applies(net) && cells_ride_allowed(net))
+            *bytes += (uint64_t)28 * (net->cell_list_dev ? net->n_cells_listed : net->nc);
         return SNN_OK;
     }
     uint64_t b = (uint64_t)4 * net->n_tot * net->n_loc;                    // dense: every weight of the shard, read once

@@ -182,6 +182,7 @@ struct snn_network {
     uint2 *cell_view[2] = {nullptr, nullptr};
     int cell_view_cur = 0;
     bool cells_stepped = false;      // this step's cells advanced inside k_step_csr (step_end skips their launch)
+    int csr_xcd_bands = 1;           // option "csr_xcd_bands"
     int cells_in_step = 1;           // option "cells_in_step": 0 keeps the cells in their own launch
     // uniform-parameter tables (UniformTable, snn_layout.hpp): rescanned when attributes were set
     UniformTable *uni_neuron = nullptr, *uni_cell = nullptr;

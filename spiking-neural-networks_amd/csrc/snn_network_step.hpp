@@ -787,11 +787,12 @@ bool csr_fast_step(const snn_network *net)
 // The spike-train cells advance inside the step's (last) k_step_csr launch: nothing may read a cell's own arrays between the
 // neuron update and the cells' iteration (weight updates do: last_firing_time), and the rows must read the cells through
 // the two-copy view only (chemical synapses read the cells' transmitter planes directly).
-bool cells_ride_with_rows(const snn_network *net)
+bool cells_ride_allowed(const snn_network *net)         // (before the first run the two-copy view is not allocated yet)
 {
-    return net->nc && net->cell_view[0] && net->electrical && !net->chemical && !net->any_plasticity && !net->any_modulation &&
+    return net->nc && net->electrical && !net->chemical && !net->any_plasticity && !net->any_modulation &&
            net->cells_in_step && (!net->sharded || net->n_shards == 1 || csr_fast_step(net));
 }
+bool cells_ride_with_rows(const snn_network *net) { return net->cell_view[0] && cells_ride_allowed(net); }
 
 enum CsrStepPart { CSR_STEP_ALL = 0, CSR_STEP_BORDER = 1, CSR_STEP_INTERIOR = 2 };
 
@@ -816,6 +817,7 @@ int launch_step_csr(snn_network *net, CsrStepPart part = CSR_STEP_ALL, bool pack
         c.cell_blocks = (spike_train_args(net, c.cells, 1, net->run_step_offset, net->clock + 1) + 255) / 256;
         net->cells_stepped = true;
     }
+    c.xcd_bands = net->csr_xcd_bands ? 1u : 0u;
     hipEvent_t e1 = nullptr;
     if (waves || c.cell_blocks) {
         TRY(profile_open(net, &e1));

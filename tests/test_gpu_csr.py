@@ -56,6 +56,7 @@ def test_csr_handle_equals_oracle(snn, chemical):
     assert net.spike_history.sum() > 20
     check(dn, net)
     # 8 B per stored synapse + the 60 B of neuron state per row that the one-launch step (k_step_csr) also moves
+    # (+ 28 B per spike-train cell when the cells advance in that launch: electrical-only handles without weight updates)
     assert dn.input_kernel_bytes() == 8 * int(net["connections"].sum()) + 60 * net.n_neurons
     dn.set_option("fused_step", 0)
     assert dn.input_kernel_bytes() == 8 * int(net["connections"].sum())         # k_inputs_csr alone
@@ -125,6 +126,7 @@ def test_c5_structure_csr(snn, cells_in_step):
     net.run(497, voltage_history=True, spike_history=True)
     assert net.spike_history.sum() > 50
     check(dn, net)
+    assert dn.input_kernel_bytes() == 8 * int(net["connections"].sum()) + 60 * net.n_neurons + 28 * cells_in_step * net.n_cells
     dn.close()
 
 
