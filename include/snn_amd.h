@@ -284,17 +284,24 @@ int snn_exchange(snn_network_t *net, void *nccl_comm);
 /* `iterations` steps of a shard handle, every rank of the communicator calling it with its own handle: per step
  * kernels -> pack -> ncclAllGather / grouped ncclSend+ncclRecv on a second stream -> unpack -> rest of the step, with
  * the next step's own-rows input pass overlapping the collective where that is valid (see snn_step_begin_local).
- * Sparse handles with a halo plan and no weight updates take three launches per step: k_step_csr over the BORDER
- * slices (the 64-row slices holding a neuron some peer reads), which writes the outgoing segments itself -> the
- * collective, overlapped by k_step_csr over the INTERIOR slices -> k_step_close (spike trains + unpack + clearing the
- * outgoing spike bitmaps); a plan in which nothing travels skips the collective and its stream events altogether.
- * Blocks until the last step has finished.  Results are identical to (b) and (c) and to a single-GPU snn_run. */
+ * Sparse handles with a halo plan and no weight updates take two launches per step: k_step_csr over the BORDER slices
+ * (the 64-row slices holding a neuron some peer reads), which writes the outgoing segments itself -> the collective,
+ * overlapped by k_step_csr over the INTERIOR slices, behind which ride the spike-train cells, the mirror copy (+
+ * last_firing_time stamps) of what arrived ONE STEP EARLIER and the clearing of the other set of outgoing spike bitmaps.
+ * With voltage the only plane on the wire the rows gather the halo from the received segments themselves ("halo_direct",
+ * two alternating sets of segments), so nothing is unpacked between the collective and the next step's rows; otherwise a
+ * closing launch k_step_close unpacks first (three launches).  A plan in which nothing travels skips the collective and
+ * its stream events altogether.  Blocks until the last step has finished (the mirror then holds the last arrivals).
+ * Results are identical to (b) and (c) and to a single-GPU snn_run. */
 int snn_run_sharded(snn_network_t *net, void *nccl_comm, uint64_t iterations);
 /* The same loop with the HOST'S OWN TRANSPORT (MPI, UCX, a test harness ...) in place of RCCL: once per step, after the
  * outgoing segments have been enqueued on `hip_stream`, `exchange(user, hip_stream)` must move the segments the plan
  * describes (snn_exchange_plan_get / snn_exchange_peers) and return 0; work enqueued on `hip_stream` after it returns
  * must see the received segments (a blocking implementation synchronises the stream, moves the bytes, returns).  A
- * non-zero return stops the run with SNN_ERR_QUEUE.  No overlap of the next step's input pass with the exchange. */
+ * non-zero return stops the run with SNN_ERR_QUEUE.  No overlap of the next step's input pass with the exchange.
+ * The segment pointers of snn_exchange_plan_get are fixed for such a run unless the option "halo_direct" is 2: then a
+ * sparse halo run alternates between two sets of segments and the function must read the plan's pointers anew at every
+ * call (counts and offsets do not change).  snn_exchange_noop is a transport that moves nothing (timing runs). */
 typedef int (*snn_exchange_fn)(void *user, void *hip_stream);
 int snn_run_sharded_custom(snn_network_t *net, snn_exchange_fn exchange, void *user, uint64_t iterations);
 /* An snn_exchange_fn that moves nothing and returns 0: times what ONE rank's step costs without its exchange
@@ -381,7 +388,9 @@ int snn_get_spike_counts(snn_network_t *net, uint32_t id, uint32_t *dst, size_t 
 /* Tuning switches (results never depend on them; defaults in brackets, also settable through the environment when the
  * handle is created: SNN_AMD_<NAME in upper case>): "fused_step" [1] one-launch step for small lattices and for
  * sparse handles; "cells_in_step" [1] sparse electrical-only handles without weight updates: the spike-train cells advance
- * inside the step's launch; "defer_rstdp"
+ * inside the step's launch; "csr_xcd_bands" [1] the sparse step hands its row blocks to the XCDs in contiguous bands;
+ * "halo_direct" [1] library-driven runs of sparse shard handles gather the halo from the received segments (0: never,
+ * 2: also in snn_run_sharded_custom, see there); "defer_rstdp"
  * [1] reward-modulated weight updates riding on the next input pass; "defer_stdp" [0] 1: STDP updates riding on the next
  * input pass, 2: prepared delta vectors applied by scatter passes; "uniform_params" [1] population-wide parameter
  * values from a device table; "persistent_run" [1] all steps of an snn_run call (of 4 steps or more) on a small
@@ -409,8 +418,9 @@ int snn_set_option(snn_network_t *net, const char *name, int value);
 /* Which step form the handle has used so far, as launch counts since creation: "persistent_run_launches" (k_run_resident:
  * many steps per launch), "persistent_run_steps" (steps those launches covered), "persistent_run_fallbacks" (launches that
  * gave up and were rolled back, see above); with option "run_timing": "run_timing_poll" / "_barrier" / "_turns" /
- * "_update" (shader clocks of workgroup 0 over the last launch) and "run_timing_steps" (its steps).  Unknown names fail
- * with SNN_ERR_BAD_ARG. */
+ * "_update" (shader clocks of workgroup 0 over the last launch) and "run_timing_steps" (its steps); "halo_direct_steps"
+ * (steps of library-driven runs whose rows gathered the halo from the received segments).  Unknown names fail with
+ * SNN_ERR_BAD_ARG. */
 int snn_get_stat(snn_network_t *net, const char *name, uint64_t *value);
 
 /* ---- measurement ----------------------------------------------------------------------- */

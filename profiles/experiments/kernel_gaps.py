@@ -13,7 +13,7 @@ rows = rows[skip:]
 dur = defaultdict(list)
 gap_after = defaultdict(list)
 for a, b in zip(rows, rows[1:]):
-    name = a["Kernel_Name"].split("(")[0][:60]
+    name = a["Kernel_Name"].split("(")[0][:60] + " grid " + a.get("Grid_Size", a.get("Grid_Size_X", "?"))
     dur[name].append(int(a["End_Timestamp"]) - int(a["Start_Timestamp"]))
     gap_after[name].append(int(b["Start_Timestamp"]) - int(a["End_Timestamp"]))
 med = lambda v: sorted(v)[len(v) // 2]

@@ -24,10 +24,18 @@
 namespace snn {
 
 constexpr uint32_t SELL_PAD = 0xFFFFFFFFu;     // presynaptic index of a padding entry
+constexpr uint32_t PLAN_CODE = 0x7FFFFFFFu;    // gather-plan word: the source code (all ones = padding), bit 31 = new chunk
 
 struct SellGraph {
     const uint32_t *slice_ptr;   // [n_slices + 1] element offsets (multiples of 64)
     const uint32_t *pre;         // [entries]
+    // [entries] what the row sums read instead of `pre` (k_csr_plan): bit 31 = this entry opens a new 256-index chunk of its
+    // row (the canonical flush), bits 0..30 = where the presynaptic value is gathered from: < n_neurons the exchanged
+    // state of that neuron, < halo_base the spike-train cell (code - n_neurons), else word (code - halo_base) of `halo`,
+    // the received segments themselves (shard handles in a library-driven run: no unpack before the rows); 0x7FFFFFFF pad
+    const uint32_t *plan;
+    const uint32_t *halo;
+    uint32_t halo_base;
     float *w;                    // [entries]
     const uint32_t *row_len;     // [n_slices * 64]
     const uint32_t *edge_slot;   // [nnz] CSR edge -> SELL entry
@@ -47,6 +55,8 @@ struct CsrInputsArgs {
 template <bool ELEC, bool CHEM>
 __device__ __forceinline__ void csr_row_sums(const CsrInputsArgs &a, uint32_t q, float &sum, float (&tsum)[K_TYPES])
 {
+    // entries whose loads are in flight together (16 for the electrical form -- a row of BASELINE configs[4] in ONE batch --
+    // measured slower, same box: C5 42.0 against 38.6 us per step, a G = 8 rank's step 18.9 against 18.6)
     constexpr uint32_t EDGE_BATCH = CHEM ? 4 : 8;
     const InputsArgs &in = a.in;
     const uint32_t slice = q >> 6;
@@ -62,7 +72,7 @@ __device__ __forceinline__ void csr_row_sums(const CsrInputsArgs &a, uint32_t q,
 
     float part = 0.0f;
     float tpart[K_TYPES] = {0.0f, 0.0f, 0.0f};
-    uint32_t cur_chunk = 0xFFFFFFFFu;
+    bool open = false;               // a chunk's partial is being accumulated
     sum = 0.0f;
 #pragma unroll
     for (int kk = 0; kk < K_TYPES; ++kk) tsum[kk] = 0.0f;
@@ -71,25 +81,29 @@ __device__ __forceinline__ void csr_row_sums(const CsrInputsArgs &a, uint32_t q,
         uint32_t p[EDGE_BATCH];
         float w[EDGE_BATCH], v[EDGE_BATCH], t[EDGE_BATCH][K_TYPES];
         uint32_t flags[EDGE_BATCH];       // bit 0 cell, bit 1 silent cell, bits 8.. transmitter types
-        // (1) index + weight of EDGE_BATCH consecutive entries: coalesced, independent
+        // (1) plan word + weight of EDGE_BATCH consecutive entries: coalesced, independent
 #pragma unroll
         for (uint32_t u = 0; u < EDGE_BATCH; ++u) {
             const uint32_t k = min(k0 + u, width - 1);         // clamped; the tail is dropped below
-            p[u] = a.g.pre[base + (size_t)k * 64];
+            p[u] = a.g.plan[base + (size_t)k * 64];
             w[u] = a.g.w[base + (size_t)k * 64];
             if (k0 + u >= width) p[u] = SELL_PAD;
         }
-        // (2) the gathers those indices address -- branch-free (the inapplicable source is clamped to index 0)
+        // (2) the gathers those words address -- branch-free (the inapplicable sources are clamped to index 0)
 #pragma unroll
         for (uint32_t u = 0; u < EDGE_BATCH; ++u) {
-            const bool pad = p[u] == SELL_PAD;
-            const bool is_cell = !pad && p[u] >= in.n_neurons;
-            const uint32_t pn = (pad || is_cell) ? 0u : p[u];
-            const uint32_t sc = is_cell ? p[u] - in.n_neurons : 0u;
+            const uint32_t code = p[u] & PLAN_CODE;
+            const bool pad = code == PLAN_CODE;
+            const bool is_halo = !pad && code >= a.g.halo_base;
+            const bool is_cell = !pad && !is_halo && code >= in.n_neurons;
+            const uint32_t pn = (pad || is_cell || is_halo) ? 0u : code;
+            const uint32_t sc = is_cell ? code - in.n_neurons : 0u;
             flags[u] = is_cell ? 1u : 0u;
             v[u] = 0.0f;
             if (ELEC) {
-                const float *src = is_cell ? reinterpret_cast<const float *>(in.st_view + sc) : in.xbuf + in.xl.at(pn, PLANE_V);
+                const float *src = is_cell ? reinterpret_cast<const float *>(in.st_view + sc)
+                                 : is_halo ? reinterpret_cast<const float *>(a.g.halo + (code - a.g.halo_base))
+                                           : in.xbuf + in.xl.at(pn, PLANE_V);
                 v[u] = *src;
                 flags[u] |= (is_cell && in.st_view[sc].y) ? 2u : 0u;
             }
@@ -108,10 +122,9 @@ __device__ __forceinline__ void csr_row_sums(const CsrInputsArgs &a, uint32_t q,
         // (3) the row's sum, strictly in ascending presynaptic order with the canonical chunk flush
 #pragma unroll
         for (uint32_t u = 0; u < EDGE_BATCH; ++u) {
-            if (p[u] == SELL_PAD) continue;                      // padding only ever trails a row
-            const uint32_t chunk = p[u] / CHUNK;
-            if (chunk != cur_chunk) {
-                if (cur_chunk != 0xFFFFFFFFu) {
+            if ((p[u] & PLAN_CODE) == PLAN_CODE) continue;       // padding only ever trails a row
+            if (p[u] >> 31) {                                    // first entry of a 256-index chunk: flush the previous one
+                if (open) {
                     sum += part;
 #pragma unroll
                     for (int kk = 0; kk < K_TYPES; ++kk) tsum[kk] += tpart[kk];
@@ -119,7 +132,7 @@ __device__ __forceinline__ void csr_row_sums(const CsrInputsArgs &a, uint32_t q,
                 part = 0.0f;
 #pragma unroll
                 for (int kk = 0; kk < K_TYPES; ++kk) tpart[kk] = 0.0f;
-                cur_chunk = chunk;
+                open = true;
             }
             if (ELEC) {
                 // gap_junction neuron/mod.rs:54-60; spike_train_gap_junction :119-137 (never fired: v_resting
@@ -134,7 +147,7 @@ __device__ __forceinline__ void csr_row_sums(const CsrInputsArgs &a, uint32_t q,
             }
         }
     }
-    if (cur_chunk != 0xFFFFFFFFu) {
+    if (open) {
         sum += part;
 #pragma unroll
         for (int kk = 0; kk < K_TYPES; ++kk) tsum[kk] += tpart[kk];
@@ -158,6 +171,66 @@ __global__ __launch_bounds__(256) void k_inputs_csr(const CsrInputsArgs a)
         for (int kk = 0; kk < K_TYPES; ++kk) in.part_t[(size_t)kk * in.ld + q] = tsum[kk];
     }
 }
+
+// Jobs that ride behind a sparse step's rows (the last blocks of k_step_csr) or make up the step's closing launch
+// (k_step_close), side by side:
+//   blocks [0, cell_blocks)                 the spike-train cells this rank reads advance (k_spike_trains' body),
+//   blocks [cell_blocks, +unpack_blocks)    received segments go into the mirror (and into the shadow the next step
+//                                           reads), with the last_firing_time stamp of a neuron owned elsewhere,
+//   the rest                                the spike bitmaps of outgoing segments are cleared for a later in-kernel pack.
+struct StepCloseArgs {
+    SpikeTrainArgs cells;
+    WireArgs recv;                  // unpack side: segment tables of the incoming segments
+    float *xbuf2;                   // second destination of the unpack (the shadow of the next step) or null
+    uint32_t recv_total;            // neurons over all incoming segments
+    uint32_t recv_segments;
+    WireArgs send;                  // segment tables of the outgoing segments (bitmaps to clear)
+    uint32_t send_segments;
+    uint32_t send_bitmap_words;     // over all outgoing segments
+    uint32_t cell_blocks, unpack_blocks;
+    __host__ __device__ uint32_t blocks() const { return cell_blocks + unpack_blocks + (send_bitmap_words + 255) / 256; }
+};
+
+__device__ __forceinline__ void step_close_block(const StepCloseArgs &a, const uint32_t block)
+{
+    if (block < a.cell_blocks) {
+        spike_train_cell(a.cells, block * 256 + threadIdx.x);
+        return;
+    }
+    if (block < a.cell_blocks + a.unpack_blocks) {
+        const uint32_t t = (block - a.cell_blocks) * 256 + threadIdx.x;
+        if (t >= a.recv_total) return;
+        // the segment of flat position t: list offsets are the running totals (at most n_shards - 1 segments)
+        uint32_t seg = 0;
+        while (seg + 1 < a.recv_segments && t >= (uint32_t)a.recv.seg_list_offset[seg + 1]) ++seg;
+        const uint32_t i = t - (uint32_t)a.recv.seg_list_offset[seg];
+        const uint32_t count = a.recv.seg_count[seg];
+        const uint32_t g = a.recv.list[t];
+        if (g >= a.recv.n_neurons) return;
+        const uint32_t *in = a.recv.buf + a.recv.seg_offset[seg];
+        uint32_t *x = reinterpret_cast<uint32_t *>(a.recv.xbuf), *x2 = reinterpret_cast<uint32_t *>(a.xbuf2);
+        for (uint32_t s = 0; s < a.recv.planes; ++s) {
+            const uint32_t v = in[(size_t)s * count + i];
+            const size_t at = a.recv.xl.at(g, (int)a.recv.plane_id[s]);
+            x[at] = v;
+            if (x2) x2[at] = v;
+        }
+        const uint32_t spike = (in[(size_t)a.recv.planes * count + (i >> 5)] >> (i & 31u)) & 1u;
+        x[a.recv.xl.at(g, PLANE_SPIKE)] = spike;
+        if (x2) x2[a.recv.xl.at(g, PLANE_SPIKE)] = spike;
+        if (spike) a.recv.last_firing_time[g] = (int32_t)a.recv.clock;
+        return;
+    }
+    uint32_t t = (block - a.cell_blocks - a.unpack_blocks) * 256 + threadIdx.x;
+    if (t >= a.send_bitmap_words) return;
+    for (uint32_t seg = 0; seg < a.send_segments; ++seg) {
+        const uint32_t count = a.send.seg_count[seg], words = (count + 31u) / 32u;
+        if (t < words) { a.send.buf[a.send.seg_offset[seg] + (size_t)a.send.planes * count + t] = 0u; return; }
+        t -= words;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_step_close(const StepCloseArgs a) { step_close_block(a, blockIdx.x); }
 
 // Inputs + neuron update of a sparse handle in ONE launch: row thread = neuron thread, so the sums never leave
 // registers.  Other rows may still be gathering S(t) while a neuron writes S(t+1): as in k_step_resident the exchanged
@@ -183,11 +256,13 @@ struct CsrStepArgs {
     const uint32_t *slice_list;
     uint32_t n_listed;
     PackTable pack;
-    // the spike-train cells advancing in the same launch (the last cell_blocks blocks of the grid): rows read the cells' view of THIS step
-    // (InputsArgs::st_view), the cells write the next one (SpikeTrainArgs::view_out).  Electrical-only handles without
-    // weight updates (nothing reads a cell's own arrays between the neuron update and the cells' iteration).
-    SpikeTrainArgs cells;
-    uint32_t cell_blocks;
+    // Jobs behind the rows (the last tail.blocks() blocks of the grid).  The spike-train cells advancing in the same launch:
+    // rows read the cells' view of THIS step (InputsArgs::st_view), the cells write the next one (SpikeTrainArgs::
+    // view_out) -- electrical-only handles without weight updates (nothing reads a cell's own arrays between the neuron
+    // update and the cells' iteration).  Shard handles in a library-driven run whose rows gather the halo from the received
+    // segments themselves (SellGraph::halo): the mirror copy + last_firing_time stamps of what arrived one step earlier,
+    // and the clearing of the spike bitmaps of the other set of outgoing segments.
+    StepCloseArgs tail;
     uint32_t xcd_bands;             // 1: row blocks are dealt to the XCDs in contiguous bands (see k_step_csr)
 };
 static_assert(sizeof(CsrStepArgs) <= 4096, "kernel arguments are limited to 4 KB");
@@ -195,11 +270,11 @@ static_assert(sizeof(CsrStepArgs) <= 4096, "kernel arguments are limited to 4 KB
 template <int MODEL, bool ELEC, bool CHEM>
 __global__ __launch_bounds__(256) void k_step_csr(const CsrStepArgs a)
 {
-    // the cell blocks come AFTER the row blocks: they fill the tail of the rows' streaming (measured at C5, one box, step
-    // time: cells in their own launch 44.7 us; cell blocks first 41.5; spread evenly among the row blocks 45.6; last 39.3)
-    const uint32_t row_blocks = gridDim.x - a.cell_blocks;
+    // the tail jobs come AFTER the row blocks: they fill the tail of the rows' streaming (cells at C5, one box, step time:
+    // cells in their own launch 44.7 us; cell blocks first 41.5; spread evenly among the row blocks 45.6; last 39.3)
+    const uint32_t row_blocks = gridDim.x - a.tail.blocks();
     if (blockIdx.x >= row_blocks) {
-        spike_train_cell(a.cells, (blockIdx.x - row_blocks) * 256 + threadIdx.x);
+        step_close_block(a.tail, blockIdx.x - row_blocks);
         return;
     }
     // Workgroups are handed to the 8 XCDs round-robin (a placement heuristic, used for speed only): XCD x takes a
@@ -213,83 +288,38 @@ __global__ __launch_bounds__(256) void k_step_csr(const CsrStepArgs a)
     const uint32_t w = row_block * 4 + (threadIdx.x >> 6);  // wavefront = one SELL slice
     if (a.slice_list ? w >= a.n_listed : w >= a.c.g.n_slices) return;
     const uint32_t q = (a.slice_list ? a.slice_list[w] : w) * 64u + (threadIdx.x & 63u);
+    // the row's entries of the pack table are requested BEFORE the row sums (they depend on nothing the sums produce): a
+    // border launch of a few workgroups is a chain of dependent memory round trips, these two overlap with the sums'
+    uint32_t pack_begin = 0, pack_end = 0, seg0_count = 0, seg0_index = 0, seg0_off = 0;
+    if (a.pack.ptr && q < a.c.g.n_loc) {
+        pack_begin = a.pack.ptr[q]; pack_end = a.pack.ptr[q + 1];
+        if (pack_end > pack_begin) {
+            seg0_count = a.pack.seg_count[pack_begin]; seg0_index = a.pack.index[pack_begin]; seg0_off = a.pack.seg_off[pack_begin];
+        }
+    }
     RegisterSums s;
     csr_row_sums<ELEC, CHEM>(a.c, q, s.i, s.t);
     uint32_t spike = 0;
-    if (q < a.c.g.n_loc) spike = update_neuron<MODEL>(a.up, q, s);
+    float v_new = 0.0f;
+    if (q < a.c.g.n_loc) spike = update_neuron_at<MODEL>(a.up, q, s, a.up.clock, a.up.vhist_row, &v_new);
     if (a.up.spike_row) {
         const unsigned long long word = __ballot(spike != 0);
         if ((threadIdx.x & 63u) == 0) a.up.spike_row[(a.up.q0 + q) >> 6] = word;
     }
-    if (a.pack.ptr && q < a.c.g.n_loc) {
-        // the values this thread has just written, into every segment that carries the neuron; the spike as ONE bit
-        // OR-ed into the segment's bitmap (zeroed by k_step_close after the previous exchange; spikes are rare)
+    if (pack_end > pack_begin) {
+        // the values this thread has just written, into every segment that carries the neuron (the voltage from its
+        // register); the spike as ONE bit OR-ed into the segment's bitmap (zeroed after the previous exchange; spikes are rare)
         const uint32_t g = a.up.rows.global_of(q);
         const uint32_t *x = reinterpret_cast<const uint32_t *>(a.up.xout);
-        for (uint32_t e = a.pack.ptr[q]; e < a.pack.ptr[q + 1]; ++e) {
-            const uint32_t count = a.pack.seg_count[e], i = a.pack.index[e];
-            uint32_t *out = a.pack.buf + a.pack.seg_off[e];
-            for (uint32_t pl = 0; pl < a.pack.planes; ++pl) out[(size_t)pl * count + i] = x[a.up.n.xl.at(g, (int)a.pack.plane_id[pl])];
+        for (uint32_t e = pack_begin; e < pack_end; ++e) {
+            const bool first = e == pack_begin;
+            const uint32_t count = first ? seg0_count : a.pack.seg_count[e], i = first ? seg0_index : a.pack.index[e];
+            uint32_t *out = a.pack.buf + (first ? seg0_off : a.pack.seg_off[e]);
+            for (uint32_t pl = 0; pl < a.pack.planes; ++pl)
+                out[(size_t)pl * count + i] = a.pack.plane_id[pl] == PLANE_V ? __float_as_uint(v_new)
+                                                                             : x[a.up.n.xl.at(g, (int)a.pack.plane_id[pl])];
             if (spike) atomicOr(out + (size_t)a.pack.planes * count + (i >> 5), 1u << (i & 31u));
         }
-    }
-}
-
-// The second (and last) launch of a sparse shard handle's step, after the exchange: three independent jobs side by side,
-//   blocks [0, cell_blocks)                 the spike-train cells this rank reads advance (k_spike_trains' body),
-//   blocks [cell_blocks, +unpack_blocks)    the received segments go into the mirror AND into the shadow the next step
-//                                           reads, with the last_firing_time stamp of a neuron owned elsewhere,
-//   the rest                                the spike bitmaps of the OUTGOING segments are cleared for the next step's
-//                                           in-kernel pack (RCCL has sent them: this launch waits for the exchange).
-// Valid when nothing has to happen between the unpack and the cells (no weight updates, no per-lattice reductions).
-struct StepCloseArgs {
-    SpikeTrainArgs cells;
-    WireArgs recv;                  // unpack side: segment tables of the incoming segments
-    float *xbuf2;                   // second destination of the unpack (the shadow of the next step) or null
-    uint32_t recv_total;            // neurons over all incoming segments
-    uint32_t recv_segments;
-    WireArgs send;                  // segment tables of the outgoing segments (bitmaps to clear)
-    uint32_t send_segments;
-    uint32_t send_bitmap_words;     // over all outgoing segments
-    uint32_t cell_blocks, unpack_blocks;
-};
-
-__global__ __launch_bounds__(256) void k_step_close(const StepCloseArgs a)
-{
-    if (blockIdx.x < a.cell_blocks) {
-        spike_train_cell(a.cells, blockIdx.x * 256 + threadIdx.x);
-        return;
-    }
-    if (blockIdx.x < a.cell_blocks + a.unpack_blocks) {
-        const uint32_t t = (blockIdx.x - a.cell_blocks) * 256 + threadIdx.x;
-        if (t >= a.recv_total) return;
-        // the segment of flat position t: list offsets are the running totals (at most n_shards - 1 segments)
-        uint32_t seg = 0;
-        while (seg + 1 < a.recv_segments && t >= (uint32_t)a.recv.seg_list_offset[seg + 1]) ++seg;
-        const uint32_t i = t - (uint32_t)a.recv.seg_list_offset[seg];
-        const uint32_t count = a.recv.seg_count[seg];
-        const uint32_t g = a.recv.list[t];
-        if (g >= a.recv.n_neurons) return;
-        const uint32_t *in = a.recv.buf + a.recv.seg_offset[seg];
-        uint32_t *x = reinterpret_cast<uint32_t *>(a.recv.xbuf), *x2 = reinterpret_cast<uint32_t *>(a.xbuf2);
-        for (uint32_t s = 0; s < a.recv.planes; ++s) {
-            const uint32_t v = in[(size_t)s * count + i];
-            const size_t at = a.recv.xl.at(g, (int)a.recv.plane_id[s]);
-            x[at] = v;
-            if (x2) x2[at] = v;
-        }
-        const uint32_t spike = (in[(size_t)a.recv.planes * count + (i >> 5)] >> (i & 31u)) & 1u;
-        x[a.recv.xl.at(g, PLANE_SPIKE)] = spike;
-        if (x2) x2[a.recv.xl.at(g, PLANE_SPIKE)] = spike;
-        if (spike) a.recv.last_firing_time[g] = (int32_t)a.recv.clock;
-        return;
-    }
-    uint32_t t = (blockIdx.x - a.cell_blocks - a.unpack_blocks) * 256 + threadIdx.x;
-    if (t >= a.send_bitmap_words) return;
-    for (uint32_t seg = 0; seg < a.send_segments; ++seg) {
-        const uint32_t count = a.send.seg_count[seg], words = (count + 31u) / 32u;
-        if (t < words) { a.send.buf[a.send.seg_offset[seg] + (size_t)a.send.planes * count + t] = 0u; return; }
-        t -= words;
     }
 }
 
@@ -321,6 +351,30 @@ __global__ __launch_bounds__(256) void k_csr_count(const CsrCountArgs a)
     a.n_in[q] = len;
 #pragma unroll
     for (int kk = 0; kk < K_TYPES; ++kk) a.tcount[(size_t)kk * a.ld + q] = tc[kk];
+}
+
+// The gather plan of the row sums (SellGraph::plan) from the SELL indices: one thread per row.  halo_word: per neuron the
+// word of the receive buffer that carries its voltage (0xFFFFFFFF: read from the exchanged state), or null.
+__global__ __launch_bounds__(256) void k_csr_plan(SellGraph g, uint32_t *plan, const uint32_t *halo_word, uint32_t n_neurons,
+                                                  uint32_t halo_base)
+{
+    const uint32_t q = blockIdx.x * 256 + threadIdx.x;
+    if ((q >> 6) >= g.n_slices) return;
+    const uint32_t s0 = g.slice_ptr[q >> 6];
+    const uint32_t width = (g.slice_ptr[(q >> 6) + 1] - s0) >> 6;
+    uint32_t prev = 0;
+    for (uint32_t k = 0; k < width; ++k) {
+        const size_t e = s0 + (q & 63u) + (size_t)k * 64;
+        const uint32_t p = g.pre[e];
+        uint32_t word = SELL_PAD;
+        if (p != SELL_PAD) {
+            uint32_t code = p;
+            if (halo_word && p < n_neurons && halo_word[p] != 0xFFFFFFFFu) code = halo_base + halo_word[p];
+            word = code | ((k == 0 || p / CHUNK != prev / CHUNK) ? 0x80000000u : 0u);
+            prev = p;
+        }
+        plan[e] = word;
+    }
 }
 
 // STDP on the sparse form: incoming edges of a listed local neuron are its SELL row; outgoing edges of a listed

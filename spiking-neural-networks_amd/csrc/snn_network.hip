@@ -41,6 +41,7 @@ int snn_network_create(int device, int neuron_model, int nt_kinetics, int recept
     net->device = device;
     if (const char *e = getenv("SNN_AMD_FUSED_STEP")) net->fused_step = (e[0] != '0');
     if (const char *e = getenv("SNN_AMD_CSR_XCD_BANDS")) net->csr_xcd_bands = (e[0] != '0');
+    if (const char *e = getenv("SNN_AMD_HALO_DIRECT")) net->halo_direct = (e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1;
     if (const char *e = getenv("SNN_AMD_CELLS_IN_STEP")) net->cells_in_step = (e[0] != '0');
     if (const char *e = getenv("SNN_AMD_DEFER_RSTDP")) net->defer_rstdp = (e[0] != '0');
     if (const char *e = getenv("SNN_AMD_DEFER_STDP")) net->defer_stdp = (e[0] == '2') ? 2 : (e[0] != '0');
@@ -65,7 +66,8 @@ int snn_network_destroy(snn_network_t *net)
     if (net->stream) (void)hipStreamSynchronize(net->stream);
     for (void *p : net->allocs) (void)hipFree(p);
     for (void *p : {(void *)net->csr_ptr, (void *)net->csr_pre, (void *)net->csr_post, (void *)net->csr_t_ptr,
-                    (void *)net->csr_t_edge, (void *)net->csr_w, (void *)net->csr_row_len, (void *)net->csr_edge_slot})
+                    (void *)net->csr_t_edge, (void *)net->csr_w, (void *)net->csr_row_len, (void *)net->csr_edge_slot,
+                    (void *)net->csr_plan})
         if (p) (void)hipFree(p);
     if (net->vhist) (void)hipFree(net->vhist);
     if (net->st_vhist) (void)hipFree(net->st_vhist);
@@ -79,6 +81,8 @@ int snn_network_destroy(snn_network_t *net)
     for (auto &e : net->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     for (auto &e : net->ev_pool_pl) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (net->cell_list_dev) (void)hipFree(net->cell_list_dev);
+    for (void *p : {(void *)net->halo_send_buf2, (void *)net->halo_recv_buf2, (void *)net->csr_plan_direct, (void *)net->halo_word_dev})
+        if (p) (void)hipFree(p);
     for (void *p : {(void *)net->halo_send_buf, (void *)net->halo_recv_buf, (void *)net->halo_send_idx, (void *)net->halo_recv_idx,
                     (void *)net->seg_count_dev[0], (void *)net->seg_count_dev[1], (void *)net->seg_first_dev[0],
                     (void *)net->seg_first_dev[1], (void *)net->seg_offset_dev[0], (void *)net->seg_offset_dev[1],
@@ -398,7 +402,7 @@ static int set_graph_csr_impl(snn_network_t *net, const uint64_t *row_ptr, const
     TRY(end_run(net));
     for (void **p : {(void **)&net->csr_ptr, (void **)&net->csr_pre, (void **)&net->csr_post, (void **)&net->csr_t_ptr,
                      (void **)&net->csr_t_edge, (void **)&net->csr_w, (void **)&net->csr_row_len,
-                     (void **)&net->csr_edge_slot}) {
+                     (void **)&net->csr_edge_slot, (void **)&net->csr_plan}) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
     }
@@ -415,9 +419,15 @@ static int set_graph_csr_impl(snn_network_t *net, const uint64_t *row_ptr, const
     TRY(up((void **)&net->csr_post, post.data(), nnz * 4));
     TRY(up((void **)&net->csr_t_ptr, t_ptr.data(), t_ptr.size() * 4));
     TRY(up((void **)&net->csr_t_edge, t_edge.data(), nnz * 4));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&net->csr_plan), std::max<size_t>(entries * 4, 256)), SNN_ERR_BUFFER_CREATE);
     if (net->trace) { (void)hipFree(net->trace); net->trace = nullptr; }      // traces belong to the replaced edges
     net->nnz = nnz;
     net->sell_entries = entries;
+    if (n_slices) {
+        hipLaunchKernelGGL(k_csr_plan, dim3((n_slices * 64 + 255) / 256), dim3(256), 0, net->stream, csr_graph(net),
+                           net->csr_plan, (const uint32_t *)nullptr, net->nn, PLAN_CODE);
+        HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+    }
     net->edge_slot_host.swap(edge_slot);
     net->counts_dirty = true;
     halo_needs_from_rows(net, pre_index, nnz);      // the new rows decide what is read from the other shards
@@ -1001,8 +1011,9 @@ int snn_exchange_plan_get(snn_network_t *net, snn_exchange_plan *plan)
         plan->send_words = net->x_block_words;
         plan->recv_words = net->x_block_words * net->n_shards;
     } else {
-        plan->send = net->halo_send_buf;
-        plan->recv = net->halo_recv_buf;
+        // (inside a direct run, i.e. from the exchange function of snn_run_sharded_custom: the sets of the current step)
+        plan->send = (net->direct_run && net->hx_par) ? net->halo_send_buf2 : net->halo_send_buf;
+        plan->recv = (net->direct_run && net->hx_par) ? net->halo_recv_buf2 : net->halo_recv_buf;
         for (uint32_t p = 0; p < net->n_shards; ++p) {
             plan->send_words += net->x_send_words[p];
             plan->recv_words += net->x_recv_words[p];
@@ -1203,14 +1214,21 @@ int snn_run_sharded_custom(snn_network_t *net, snn_exchange_fn exchange, void *u
     if (!net->electrical && !net->chemical) return SNN_OK;
     HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
     TRY(begin_run(net, iterations));
-    for (uint64_t it = 0; it < iterations; ++it) {
-        if (net->nn) TRY(step_begin(net));
-        TRY(launch_exchange_pack(net));
-        TRY(step_interior(net));                  // sparse handles: interior slices are enqueued before the host-side exchange
-        if (exchange(user, net->stream) != 0) return fail(SNN_ERR_QUEUE, "the caller's exchange function failed");
-        TRY(step_end(net));
-        if (net->profile && (net->ev_used >= 8192 || net->ev_used_pl >= 8192)) TRY(collect_profile(net));
+    // the direct form of a sparse halo run (rows gather from the received segments): with the do-nothing transport, or when
+    // the caller's function reads the segment pointers of every step from snn_exchange_plan_get ("halo_direct" 2)
+    if (net->halo_direct == 2 || exchange == &snn_exchange_noop) TRY(direct_begin(net));
+    int rc = SNN_OK;
+    for (uint64_t it = 0; it < iterations && rc == SNN_OK; ++it) {
+        if (net->nn) rc = step_begin(net);
+        if (!rc) rc = launch_exchange_pack(net);
+        if (!rc) rc = step_interior(net);         // sparse handles: interior slices are enqueued before the host-side exchange
+        if (!rc && exchange(user, net->stream) != 0) rc = fail(SNN_ERR_QUEUE, "the caller's exchange function failed");
+        if (!rc) rc = step_end(net);
+        if (!rc && net->profile && (net->ev_used >= 8192 || net->ev_used_pl >= 8192)) rc = collect_profile(net);
     }
+    const int rc_end = direct_end(net);
+    if (rc) return rc;
+    TRY(rc_end);
     return end_run(net, /*keep_stdp=*/true);
 }
 
@@ -1281,25 +1299,31 @@ int snn_run_sharded(snn_network_t *net, void *nccl_comm, uint64_t iterations)
     // cross-stream events -- the step is its kernels
     bool travels = net->x_mode == SNN_EXCHANGE_ALLGATHER;
     for (uint32_t p = 0; p < net->n_shards && !travels; ++p) travels = net->x_send_words[p] || net->x_recv_words[p];
-    for (uint64_t it = 0; it < iterations; ++it) {
-        if (net->nn) TRY(step_begin(net));
-        TRY(launch_exchange_pack(net));
-        if (travels) {
-            HIP_TRY(hipEventRecord(net->ev_packed, net->stream), SNN_ERR_QUEUE);
-            HIP_TRY(hipStreamWaitEvent(net->comm_stream, net->ev_packed, 0), SNN_ERR_QUEUE);
-            TRY(enqueue_exchange(R, net, comm, net->comm_stream));
-            HIP_TRY(hipEventRecord(net->ev_exchanged, net->comm_stream), SNN_ERR_QUEUE);
+    if (travels) TRY(direct_begin(net));          // sparse halo runs: the rows gather from the received segments themselves
+    int rc = SNN_OK;
+    auto hip_step = [&](hipError_t e, int code) { if (!rc && e != hipSuccess) rc = fail(code, hipGetErrorString(e)); };
+    for (uint64_t it = 0; it < iterations && rc == SNN_OK; ++it) {
+        if (net->nn) rc = step_begin(net);
+        if (!rc) rc = launch_exchange_pack(net);
+        if (!rc && travels) {
+            hip_step(hipEventRecord(net->ev_packed, net->stream), SNN_ERR_QUEUE);
+            hip_step(hipStreamWaitEvent(net->comm_stream, net->ev_packed, 0), SNN_ERR_QUEUE);
+            if (!rc) rc = enqueue_exchange(R, net, comm, net->comm_stream);
+            hip_step(hipEventRecord(net->ev_exchanged, net->comm_stream), SNN_ERR_QUEUE);
         }
-        TRY(step_interior(net));                  // sparse handles: the interior slices run while the halo travels
-        if (split && it + 1 < iterations && net->nn && !net->local_inputs_done) {
+        if (!rc) rc = step_interior(net);         // sparse handles: the interior slices run while the halo travels
+        if (!rc && split && it + 1 < iterations && net->nn && !net->local_inputs_done) {
             // step_end below advances the clock and the spike trains; the LOCAL chunks read neither
-            TRY(launch_inputs(net, INPUTS_LOCAL));
+            rc = launch_inputs(net, INPUTS_LOCAL);
             net->local_inputs_done = true;
         }
-        if (travels) HIP_TRY(hipStreamWaitEvent(net->stream, net->ev_exchanged, 0), SNN_ERR_QUEUE);
-        TRY(step_end(net));
-        if (net->profile && (net->ev_used >= 8192 || net->ev_used_pl >= 8192)) TRY(collect_profile(net));
+        if (!rc && travels) hip_step(hipStreamWaitEvent(net->stream, net->ev_exchanged, 0), SNN_ERR_QUEUE);
+        if (!rc) rc = step_end(net);
+        if (!rc && net->profile && (net->ev_used >= 8192 || net->ev_used_pl >= 8192)) rc = collect_profile(net);
     }
+    const int rc_end = direct_end(net);
+    if (rc) return rc;
+    TRY(rc_end);
     return end_run(net, /*keep_stdp=*/true);
 }
 
@@ -1389,6 +1413,7 @@ int snn_set_option(snn_network_t *net, const char *name, int value)
     const std::string n(name);
     if (n == "fused_step") net->fused_step = value != 0;
     else if (n == "cells_in_step") net->cells_in_step = value != 0;
+    else if (n == "halo_direct") net->halo_direct = (value >= 0 && value <= 2) ? value : 1;
     else if (n == "csr_xcd_bands") net->csr_xcd_bands = value != 0;
     else if (n == "defer_rstdp") net->defer_rstdp = value != 0;
     else if (n == "defer_stdp") net->defer_stdp = (value == 2) ? 2 : (value != 0);
@@ -1410,6 +1435,7 @@ int snn_get_stat(snn_network_t *net, const char *name, uint64_t *value)
     if (n == "persistent_run_launches") *value = net->stat_run_launches;
     else if (n == "persistent_run_steps") *value = net->stat_run_steps;
     else if (n == "persistent_run_fallbacks") *value = net->stat_run_fallbacks;
+    else if (n == "halo_direct_steps") *value = net->stat_direct_steps;
     else if (n == "run_timing_poll") *value = net->run_timing_last[0];
     else if (n == "run_timing_barrier") *value = net->run_timing_last[1];
     else if (n == "run_timing_turns") *value = net->run_timing_last[2];

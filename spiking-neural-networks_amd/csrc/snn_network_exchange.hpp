@@ -78,6 +78,7 @@ int ensure_exchange_plan(snn_network *net)
     std::vector<uint32_t> cnt[2], first[2];
     std::vector<uint64_t> off[2], loff[2];
     net->x_mode = ((net->csr && net->halo_committed) || net->block_mode) ? SNN_EXCHANGE_HALO : SNN_EXCHANGE_ALLGATHER;
+    net->direct_capable = false;
     if (net->block_mode && !net->halo_committed) synthesize_full_lists(net);
     if (net->x_mode == SNN_EXCHANGE_ALLGATHER) {
         net->x_block_words = segment_words(P, net->shard_stride);
@@ -143,12 +144,35 @@ int ensure_exchange_plan(snn_network *net)
         TRY(upload_table(&net->pack_count_dev, pack_count));
         TRY(upload_table(&net->pack_index_dev, pack_index));
         net->send_bits_clean = true;                 // the send buffer is (re)created zeroed below
-        for (uint32_t **b : {&net->halo_send_buf, &net->halo_recv_buf})
+        for (uint32_t **b : {&net->halo_send_buf, &net->halo_recv_buf, &net->halo_send_buf2, &net->halo_recv_buf2,
+                             &net->csr_plan_direct, &net->halo_word_dev})
             if (*b) { (void)hipFree(*b); *b = nullptr; }
-        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&net->halo_send_buf), std::max<uint64_t>(so * 4, 256)), SNN_ERR_BUFFER_CREATE);
-        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&net->halo_recv_buf), std::max<uint64_t>(ro * 4, 256)), SNN_ERR_BUFFER_CREATE);
-        HIP_TRY(hipMemset(net->halo_send_buf, 0, std::max<uint64_t>(so * 4, 256)), SNN_ERR_BUFFER_WRITE);
-        HIP_TRY(hipMemset(net->halo_recv_buf, 0, std::max<uint64_t>(ro * 4, 256)), SNN_ERR_BUFFER_WRITE);
+        // the direct form (see snn_network_state.hpp): voltage is the only plane, so a halo neuron's value is ONE word
+        net->direct_capable = net->csr && net->csr_pre && net->electrical && !net->chemical && P == 1 &&
+                              (uint64_t)net->nn + net->nc + ro < PLAN_CODE && net->n_loc;
+        for (uint32_t **b : {&net->halo_send_buf, net->direct_capable ? &net->halo_send_buf2 : nullptr}) {
+            if (!b) continue;
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(b), std::max<uint64_t>(so * 4, 256)), SNN_ERR_BUFFER_CREATE);
+            HIP_TRY(hipMemset(*b, 0, std::max<uint64_t>(so * 4, 256)), SNN_ERR_BUFFER_WRITE);
+        }
+        for (uint32_t **b : {&net->halo_recv_buf, net->direct_capable ? &net->halo_recv_buf2 : nullptr}) {
+            if (!b) continue;
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(b), std::max<uint64_t>(ro * 4, 256)), SNN_ERR_BUFFER_CREATE);
+            HIP_TRY(hipMemset(*b, 0, std::max<uint64_t>(ro * 4, 256)), SNN_ERR_BUFFER_WRITE);
+        }
+        if (net->direct_capable) {
+            std::vector<uint32_t> halo_word(net->nn, 0xFFFFFFFFu);
+            for (uint32_t p = 0; p < G; ++p)
+                for (size_t i = 0; i < net->halo_need[p].size(); ++i)
+                    halo_word[net->halo_need[p][i]] = (uint32_t)(net->x_recv_off[p] + i);       // plane 0 of the segment
+            TRY(upload_table(&net->halo_word_dev, halo_word));
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&net->csr_plan_direct), std::max<size_t>(net->sell_entries * 4, 256)),
+                    SNN_ERR_BUFFER_CREATE);
+            hipLaunchKernelGGL(k_csr_plan, dim3((n_slices * 64 + 255) / 256), dim3(256), 0, net->stream, csr_graph(net),
+                               net->csr_plan_direct, net->halo_word_dev, net->nn, net->nn + net->nc);
+            HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+            HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
+        }
     }
     for (int w = 0; w < 2; ++w) {
         net->seg_n[w] = (uint32_t)cnt[w].size();
@@ -163,13 +187,15 @@ int ensure_exchange_plan(snn_network *net)
     return SNN_OK;
 }
 
-WireArgs wire_args(snn_network *net, int which)
+// which = 0 outgoing, 1 incoming; set = which of the two sets of halo segments (direct runs; 0 otherwise)
+WireArgs wire_args(snn_network *net, int which, int set)
 {
     WireArgs a{};
     a.xbuf = net->xbuf; a.xl = net->xl; a.n_neurons = net->nn; a.planes = net->x_planes;
     for (int s = 0; s < WIRE_MAX_PLANES; ++s) a.plane_id[s] = net->x_plane_id[s];
     const bool halo = net->x_mode == SNN_EXCHANGE_HALO;
-    a.buf = halo ? (which == 0 ? net->halo_send_buf : net->halo_recv_buf) : net->wire;
+    a.buf = halo ? (which == 0 ? (set ? net->halo_send_buf2 : net->halo_send_buf) : (set ? net->halo_recv_buf2 : net->halo_recv_buf))
+                 : net->wire;
     a.seg_count = net->seg_count_dev[which]; a.seg_offset = net->seg_offset_dev[which];
     a.seg_first = net->seg_first_dev[which]; a.seg_list_offset = net->seg_loff_dev[which];
     a.list = halo ? (which == 0 ? net->halo_send_idx : net->halo_recv_idx) : nullptr;
@@ -219,13 +245,14 @@ int launch_step_close(snn_network *net, bool cells, bool unpack)
         a.recv_segments = net->seg_n[1];
         a.unpack_blocks = (net->recv_total + 255) / 256;
     }
-    if (!net->send_bits_clean && net->send_bitmap_words) {
+    const bool clear = !net->send_bits_clean && net->send_bitmap_words && !net->direct_run;   // (direct runs clear behind the rows)
+    if (clear) {
         a.send = wire_args(net, 0);
         a.send_segments = net->seg_n[0];
         a.send_bitmap_words = net->send_bitmap_words;
     }
-    const uint32_t blocks = a.cell_blocks + a.unpack_blocks + (a.send_bitmap_words + 255) / 256;
-    net->send_bits_clean = true;
+    const uint32_t blocks = a.blocks();
+    if (!net->direct_run) net->send_bits_clean = true;
     if (blocks == 0) return SNN_OK;
     hipLaunchKernelGGL(k_step_close, dim3(blocks), dim3(256), 0, net->stream, a);
     HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
@@ -350,17 +377,56 @@ int enqueue_exchange(Rccl *R, snn_network *net, ncclComm_t comm, hipStream_t str
     for (uint32_t p = 0; p < net->n_shards && first == ncclSuccess; ++p) {
         if (p == net->shard_index) continue;
         if (net->x_send_words[p]) {
-            first = R->Send(net->halo_send_buf + net->x_send_off[p], net->x_send_words[p], ncclUint32, (int)p, comm, stream);
+            first = R->Send((net->direct_run && net->hx_par ? net->halo_send_buf2 : net->halo_send_buf) + net->x_send_off[p],
+                            net->x_send_words[p], ncclUint32, (int)p, comm, stream);
             what = "ncclSend";
         }
         if (first == ncclSuccess && net->x_recv_words[p]) {
-            first = R->Recv(net->halo_recv_buf + net->x_recv_off[p], net->x_recv_words[p], ncclUint32, (int)p, comm, stream);
+            first = R->Recv((net->direct_run && net->hx_par ? net->halo_recv_buf2 : net->halo_recv_buf) + net->x_recv_off[p],
+                            net->x_recv_words[p], ncclUint32, (int)p, comm, stream);
             what = "ncclRecv";
         }
     }
     const ncclResult_t closed = R->GroupEnd();
     if (first != ncclSuccess) return fail(SNN_ERR_QUEUE, std::string(what) + ": " + R->GetErrorString(first));
     if (closed != ncclSuccess) return fail(SNN_ERR_QUEUE, std::string("ncclGroupEnd: ") + R->GetErrorString(closed));
+    return SNN_OK;
+}
+
+// Opens / closes the direct form of a library-driven run (snn_network_state.hpp).  Begin: the receive set the first step reads
+// is filled from the mirror (what earlier exchanges left there), both sets of outgoing bitmaps are zeroed.  End: the arrivals
+// of the last step go into the mirror and the current shadow, as the closing launch of an ordinary step would have done.
+int direct_begin(snn_network *net)
+{
+    net->direct_run = false;
+    if (!net->halo_direct || !net->direct_capable || !csr_fast_step(net) || net->n_shards < 2 || !net->csr_plan_direct) return SNN_OK;
+    uint64_t so = 0;
+    for (uint32_t p = 0; p < net->n_shards; ++p) so += net->x_send_words[p];
+    HIP_TRY(hipMemsetAsync(net->halo_send_buf, 0, std::max<uint64_t>(so * 4, 256), net->stream), SNN_ERR_BUFFER_WRITE);
+    HIP_TRY(hipMemsetAsync(net->halo_send_buf2, 0, std::max<uint64_t>(so * 4, 256), net->stream), SNN_ERR_BUFFER_WRITE);
+    net->hx_par = 0;
+    net->stamp_pending = false;
+    if (net->seg_n[1] && net->seg_max[1]) {
+        WireArgs a = wire_args(net, 1, /*set=*/1);                // the set step 0 reads: hx_par ^ 1
+        hipLaunchKernelGGL(k_exchange_pack, dim3((net->seg_max[1] + 255) / 256, net->seg_n[1]), dim3(256), 0, net->stream, a);
+        HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+    }
+    net->direct_run = true;
+    return SNN_OK;
+}
+
+int direct_end(snn_network *net)
+{
+    if (!net->direct_run) return SNN_OK;
+    net->direct_run = false;
+    net->send_bits_clean = false;                                 // an ordinary step clears set 0's bitmaps before it packs
+    if (!net->stamp_pending) return SNN_OK;
+    net->stamp_pending = false;
+    if (!net->seg_n[1] || !net->seg_max[1] || !net->nn) return SNN_OK;
+    WireArgs a = wire_args(net, 1, net->hx_par ^ 1);              // the set the last step's exchange filled
+    a.clock = net->clock - 1;
+    hipLaunchKernelGGL(k_exchange_unpack, dim3((net->seg_max[1] + 255) / 256, net->seg_n[1]), dim3(256), 0, net->stream, a);
+    HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
     return SNN_OK;
 }
 

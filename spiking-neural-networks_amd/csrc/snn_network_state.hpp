@@ -146,6 +146,21 @@ struct snn_network {
     bool send_bits_clean = true;          // every outgoing spike bitmap is zero (what the in-kernel pack ORs into)
     bool step_packed = false;             // this step's outgoing segments were written by k_step_csr itself
     bool interior_pending = false;        // the border half of this step is enqueued, the interior slices are not yet
+    // Library-driven runs of such a handle (snn_run_sharded): the rows gather the halo from the received segments themselves
+    // (csr_plan_direct remaps every halo index to its word of the receive buffer), so nothing is unpacked before the next
+    // step's rows.  Two sets of segments alternate (hx_par = set of the step being computed): step t packs into send set
+    // t % 2, the exchange fills receive set t % 2, the rows of step t + 1 read it while the exchange of step t + 1 fills the
+    // other one.  The mirror copy + last_firing_time stamps of a step's arrivals ride behind the NEXT step's rows
+    // (stamp_pending), the last one at the end of the run.
+    uint32_t *halo_send_buf2 = nullptr, *halo_recv_buf2 = nullptr;
+    uint32_t *csr_plan_direct = nullptr, *halo_word_dev = nullptr;
+    bool direct_capable = false;          // the plan has the direct form (sparse, halo mode, voltage the only plane)
+    bool direct_run = false;              // ... and the run in progress uses it
+    int hx_par = 0;
+    bool stamp_pending = false;
+    uint64_t stat_direct_steps = 0;       // statistic "halo_direct_steps"
+    bool tail_done = false;               // this step's jobs behind the rows are enqueued
+    int halo_direct = 1;                  // option "halo_direct": 0 never, 1 snn_run_sharded, 2 also snn_run_sharded_custom
     // in-library collective (snn_run_sharded): RCCL is ordered on its own stream against the compute stream
     hipStream_t comm_stream = nullptr;
     hipEvent_t ev_packed = nullptr, ev_exchanged = nullptr;
@@ -179,6 +194,7 @@ struct snn_network {
     uint32_t n_cells_listed = 0;
     // sparse handles: what the rows read of a cell, two copies (InputsArgs::st_view); rows read cell_view[cell_view_cur],
     // an iteration of the cells writes the other copy and flips
+    uint32_t *csr_plan = nullptr;            // gather plan of the row sums (SellGraph::plan), built from csr_pre
     uint2 *cell_view[2] = {nullptr, nullptr};
     int cell_view_cur = 0;
     bool cells_stepped = false;      // this step's cells advanced inside k_step_csr (step_end skips their launch)
@@ -817,6 +833,7 @@ SellGraph csr_graph(const snn_network *net)
     g.edge_slot = net->csr_edge_slot; g.edge_post = net->csr_post;
     g.t_ptr = net->csr_t_ptr; g.t_edge = net->csr_t_edge;
     g.n_loc = net->n_loc; g.n_slices = (net->n_loc + 63) / 64;
+    g.plan = net->csr_plan; g.halo = nullptr; g.halo_base = PLAN_CODE;      // (the received segments are not read directly)
     return g;
 }
 

@@ -797,6 +797,7 @@ bool cells_ride_with_rows(const snn_network *net) { return net->cell_view[0] && 
 enum CsrStepPart { CSR_STEP_ALL = 0, CSR_STEP_BORDER = 1, CSR_STEP_INTERIOR = 2 };
 
 int launch_step_close(snn_network *net, bool cells, bool unpack);
+WireArgs wire_args(snn_network *net, int which, int set = 0);
 
 int launch_step_csr(snn_network *net, CsrStepPart part = CSR_STEP_ALL, bool pack = false)
 {
@@ -806,23 +807,49 @@ int launch_step_csr(snn_network *net, CsrStepPart part = CSR_STEP_ALL, bool pack
     uint32_t waves = c.c.g.n_slices;
     if (part == CSR_STEP_BORDER) { c.slice_list = net->csr_border_dev; c.n_listed = waves = net->n_border; }
     if (part == CSR_STEP_INTERIOR) { c.slice_list = net->csr_interior_dev; c.n_listed = waves = net->n_interior; }
+    if (net->direct_run) {       // the halo is gathered from the received segments of the previous step
+        c.c.g.plan = net->csr_plan_direct;
+        c.c.g.halo = net->hx_par ? net->halo_recv_buf : net->halo_recv_buf2;
+        c.c.g.halo_base = net->nn + net->nc;
+    }
     if (pack) {
         c.pack.ptr = net->pack_ptr_dev; c.pack.seg_off = net->pack_segoff_dev; c.pack.seg_count = net->pack_count_dev;
-        c.pack.index = net->pack_index_dev; c.pack.buf = net->halo_send_buf; c.pack.planes = net->x_planes;
+        c.pack.index = net->pack_index_dev; c.pack.planes = net->x_planes;
+        c.pack.buf = (net->direct_run && net->hx_par) ? net->halo_send_buf2 : net->halo_send_buf;
         for (int s = 0; s < WIRE_MAX_PLANES; ++s) c.pack.plane_id[s] = net->x_plane_id[s];
     }
     // the cells ride with the step's last row launch (the rows of BOTH launches read the view the cells do not write)
     const bool last_part = part != CSR_STEP_BORDER || net->n_interior == 0;
     if (last_part && !net->cells_stepped && cells_ride_with_rows(net)) {
-        c.cell_blocks = (spike_train_args(net, c.cells, 1, net->run_step_offset, net->clock + 1) + 255) / 256;
+        c.tail.cell_blocks = (spike_train_args(net, c.tail.cells, 1, net->run_step_offset, net->clock + 1) + 255) / 256;
         net->cells_stepped = true;
     }
+    if (last_part && net->direct_run && !net->tail_done) {
+        net->tail_done = true;
+        // behind the rows: the previous step's arrivals into the mirror (+ their last_firing_time stamps), and the bitmaps of
+        // the outgoing set the NEXT step packs into (its last send completed before this step's first launch)
+        if (net->stamp_pending && net->seg_n[1] && net->recv_total) {
+            c.tail.recv = wire_args(net, 1, net->hx_par ^ 1);
+            c.tail.recv.clock = net->clock - 1;
+            c.tail.recv.xbuf2 = nullptr;
+            c.tail.recv_total = net->recv_total;
+            c.tail.recv_segments = net->seg_n[1];
+            c.tail.unpack_blocks = (net->recv_total + 255) / 256;
+        }
+        net->stamp_pending = false;
+        if (net->send_bitmap_words) {
+            c.tail.send = wire_args(net, 0, net->hx_par ^ 1);
+            c.tail.send_segments = net->seg_n[0];
+            c.tail.send_bitmap_words = net->send_bitmap_words;
+        }
+    }
+    const uint32_t tail_blocks = c.tail.blocks();
     c.xcd_bands = net->csr_xcd_bands ? 1u : 0u;
     hipEvent_t e1 = nullptr;
-    if (waves || c.cell_blocks) {
+    if (waves || tail_blocks) {
         TRY(profile_open(net, &e1));
         if (e1 && part == CSR_STEP_BORDER && net->n_interior) net->ev_counts[net->ev_used - 1] = 0;   // the interior launch counts the pass
-        const dim3 grid((waves + 3) / 4 + c.cell_blocks), block(256);
+        const dim3 grid((waves + 3) / 4 + tail_blocks), block(256);
 #define SNN_CSR_STEP(M)                                                                                              \
     do {                                                                                                             \
         if (net->electrical && net->chemical) hipLaunchKernelGGL((k_step_csr<M, true, true>), grid, block, 0, net->stream, c);  \
@@ -862,9 +889,10 @@ int step_begin(snn_network *net)
     if (csr_fast_step(net)) {
         // border slices first, writing the outgoing segments themselves; the interior slices follow once the caller has
         // started the exchange (step_interior: snn_run_sharded, snn_step_begin_local, or at the latest step_end)
-        if (!net->send_bits_clean) TRY(launch_step_close(net, /*cells=*/false, /*unpack=*/false));
+        // (direct runs: the set this step packs into was cleared behind the previous step's rows, or at the run's start)
+        if (!net->send_bits_clean && !net->direct_run) TRY(launch_step_close(net, /*cells=*/false, /*unpack=*/false));
         if (net->n_border) TRY(launch_step_csr(net, CSR_STEP_BORDER, /*pack=*/true));
-        net->send_bits_clean = net->n_border == 0;
+        net->send_bits_clean = net->n_border == 0 && !net->direct_run;
         net->step_packed = true;
         net->interior_pending = true;
         return SNN_OK;
@@ -883,7 +911,16 @@ int step_end(snn_network *net)
     if (net->step_packed) {
         // the fast sparse step (csr_fast_step): unpack, spike trains and the clearing of the outgoing bitmaps in ONE launch
         net->step_packed = false;
-        TRY(launch_step_close(net, /*cells=*/!net->cells_stepped, /*unpack=*/true));
+        if (net->direct_run) {
+            // nothing to unpack before the next rows: they read the received segments themselves
+            if (!net->cells_stepped) TRY(launch_step_close(net, /*cells=*/true, /*unpack=*/false));
+            net->stamp_pending = true;
+            net->stat_direct_steps += 1;
+            net->tail_done = false;
+            net->hx_par ^= 1;
+        } else {
+            TRY(launch_step_close(net, /*cells=*/!net->cells_stepped, /*unpack=*/true));
+        }
         net->cells_stepped = false;
         net->clock += 1;
         net->run_step_offset += 1;

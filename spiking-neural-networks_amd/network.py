@@ -267,7 +267,8 @@ class DeviceNetwork:
 
     def run_sharded_custom(self, exchange, iterations):
         """the library's sharded step loop with the caller's transport: `exchange(hip_stream)` is called once per step
-        after the outgoing segments were enqueued and must have moved the plan's segments when it returns"""
+        after the outgoing segments were enqueued and must have moved the plan's segments when it returns (with the option
+        "halo_direct" 2 it reads the pointers of `exchange_plan()` anew at every call: two sets of segments alternate)"""
         err = []
 
         def thunk(_user, stream):

@@ -1,0 +1,118 @@
+"""Sparse shard handles in a library-driven run (snn_run_sharded / snn_run_sharded_custom): the rows gather the halo from the
+received segments themselves, two sets of segments alternate, nothing is unpacked before the next step's rows and the step is
+one or two launches (k_step_csr over the border slices, then over the interior slices with the cells, the mirror copy of
+the previous step's arrivals and the bitmap clearing behind them).
+
+G handles of ONE process, each driven by its own thread through snn_run_sharded_custom; the exchange function copies the
+peers' CURRENT outgoing segments (snn_exchange_plan_get inside the function) device to device.  Against the oracle."""
+import threading
+
+import numpy as np
+import pytest
+
+import parity
+from test_gpu_csr import c5_structure
+
+pytestmark = pytest.mark.gpu
+
+
+def run_in_lockstep(handles, calls):
+    """every handle runs `calls` (a list of step counts) with the library's loop; a failing thread breaks the barrier"""
+    import torch
+    from snn_amd import parallel
+    g = len(handles)
+    dev = torch.device("cuda", 0)
+    barrier = threading.Barrier(g)
+    static = [h.exchange_plan() for h in handles]          # counts and offsets (the pointers change from step to step)
+    current = [None] * g
+    errors = []
+
+    def exchange_of(r):
+        def exchange(_stream):
+            torch.cuda.synchronize()                         # every handle's step so far (one device)
+            current[r] = handles[r].exchange_plan()
+            barrier.wait()
+            mine = current[r]
+            recv = parallel.device_words(mine["recv"], mine["recv_words"], dev)
+            for p in range(g):
+                n = int(static[p]["send_count"][r]) if p != r else 0
+                if n == 0:
+                    continue
+                assert n == int(static[r]["recv_count"][p])
+                send = parallel.device_words(current[p]["send"], current[p]["send_words"], dev)
+                so, ro = int(static[p]["send_offset"][r]), int(static[r]["recv_offset"][p])
+                recv[ro:ro + n].copy_(send[so:so + n])
+            torch.cuda.synchronize()
+            barrier.wait()                                   # nobody packs its next step while a peer still copies
+        return exchange
+
+    def work(r):
+        try:
+            for steps in calls:
+                handles[r].run_sharded_custom(exchange_of(r), steps)
+        except BaseException as e:       # noqa: BLE001 -- reported by the main thread
+            errors.append(e)
+            barrier.abort()
+
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(g)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0]
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("n_shards,by_lattice,direct", [(2, True, 2), (4, True, 2), (3, True, 2), (2, False, 2), (4, False, 2),
+                                                        (8, False, 2), (4, True, 0)])
+def test_direct_halo_runs_equal_the_oracle(snn, n_shards, by_lattice, direct):
+    import torch
+    from snn_amd import parallel
+    net = c5_structure(16 if by_lattice else 8)
+    handles = [parity.device_from_oracle(snn, net, shard=(r, n_shards), csr=True, by_lattice=by_lattice) for r in range(n_shards)]
+    for h in handles:
+        h.set_option("halo_direct", direct)
+    ex = parallel.LocalExchange(handles, torch.device("cuda", 0), halo=True)          # wires and commits the halo lists
+    run_in_lockstep(handles, [40, 1, 59])
+    for _ in range(7):                                      # host-driven steps in between: the ordinary protocol
+        ex.step()
+    run_in_lockstep(handles, [93])
+    net.run(200, spike_history=True)
+    assert net.spike_history.sum() > (20 if by_lattice else 5)
+    for r, h in enumerate(handles):
+        if h.owned.size:                                    # (a shard without neurons may or may not take the direct form)
+            assert h.stat("halo_direct_steps") == (193 if direct else 0)
+        known = np.zeros(net.n_neurons, bool)
+        known[h.owned] = True
+        for p in range(n_shards):
+            if p != r:
+                known[h.halo_needs(p)] = True
+        st = parity.pull_state(h, net)
+        for name in ("current_voltage", "is_spiking", "last_firing_time"):
+            assert np.array_equal(parity.bits(st[name][known]), parity.bits(net[name][known])), (name, r)
+        cells = h.cells_read()
+        for name in ("st_last_firing_time", "st_seed"):
+            assert np.array_equal(parity.bits(st[name][cells]), parity.bits(net[name][cells])), (name, r)
+        assert np.array_equal(parity.bits(st["w_value"][h.owned]), parity.bits(net["w_value"][h.owned]))
+        h.close()
+
+
+def test_direct_form_needs_the_fast_step(snn):
+    """weight updates between the unpack and the cells: the ordinary protocol, whatever the option says"""
+    import torch
+    from snn_amd import parallel
+    net = c5_structure(8)
+    net["do_plasticity"] = 1
+    handles = [parity.device_from_oracle(snn, net, shard=(r, 2), csr=True) for r in range(2)]
+    for h in handles:
+        h.set_option("halo_direct", 2)
+    parallel.LocalExchange(handles, torch.device("cuda", 0), halo=True)
+    run_in_lockstep(handles, [60])
+    net.run(60)
+    for h in handles:
+        assert h.stat("halo_direct_steps") == 0
+        st = parity.pull_state(h, net)
+        assert np.array_equal(parity.bits(st["current_voltage"][h.owned]), parity.bits(net["current_voltage"][h.owned]))
+        parity.assert_graph_equal(net, h)
+        h.close()
