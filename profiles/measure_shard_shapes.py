@@ -17,7 +17,7 @@ from snn_amd import synthetic  # noqa: E402
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rows = cols = 256
 n = rows * cols
-for g in (1, 2, 4, 8):
+for g in ([int(os.environ['SHARDS'])] if os.environ.get('SHARDS') else (1, 2, 4, 8)):
     dn = snn_amd.DeviceNetwork(model=snn_amd.IZHIKEVICH)
     dn.add_lattice(0, rows, cols)
     dn.finalize(g // 2, g)
@@ -45,5 +45,11 @@ for g in (1, 2, 4, 8):
         dn.profile_enable(False)
         out[mode] = {"input_pass_ms": ms / max(1, launches), "GBps": out["matrix_GB"] / (ms / max(1, launches)) * 1e3,
                      "host_loop_ms_per_step": dt / steps * 1e3}
+    # the library's own step loop with a transport that moves nothing (snn_run_sharded_custom + snn_exchange_noop): what ONE
+    # rank's step costs besides its exchange -- kernels, launches and the gaps between them, no host call per step
+    dn.run_sharded_without_exchange(10)
+    t0 = time.perf_counter()
+    dn.run_sharded_without_exchange(steps)
+    out["library_loop_ms_per_step"] = (time.perf_counter() - t0) / steps * 1e3
     print(json.dumps(out), flush=True)
     dn.close()

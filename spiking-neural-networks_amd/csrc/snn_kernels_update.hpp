@@ -37,6 +37,11 @@ struct UpdateArgs {
     int has_nt;                 // some neuron of the handle releases a neurotransmitter (else the flag planes are not read)
     int bcm;                    // BCMIzhikevichNeuron: keep the activity bookkeeping (the step itself is Izhikevich's)
     int model_is_custom;        // the generated neuron model: it uses the library's generated receptor set, if any
+    // Dense shard handles (all-gather exchange): k_update writes the handle's own slot of the wire buffer itself -- per plane
+    // wire_count words, then the spike bits, the wire format of snn_kernels_exchange.hpp -- so the step needs no pack launch.
+    // wire_out = the slot (null: no packing); neuron ql of the shard is entry ql of the slot.
+    uint32_t *wire_out;
+    uint32_t wire_count, wire_planes, wire_plane_id[1 + K_TYPES];
 };
 
 // Second level of the canonical sum: chunk partials added in ascending chunk order from 0.0f.  The loads of
@@ -470,7 +475,24 @@ template <int MODEL>
 __global__ __launch_bounds__(256) void k_update(const UpdateArgs a)
 {
     const uint32_t ql = blockIdx.x * blockDim.x + threadIdx.x;           // blockDim.x = 64 or 256
-    const uint32_t spike = (ql < a.n_loc && a.rows.active(ql, a.n_loc)) ? update_neuron<MODEL>(a, ql, GlobalSums{a, ql}) : 0u;
+    const bool active = ql < a.n_loc && a.rows.active(ql, a.n_loc);
+    float v_new = 0.0f;
+    const uint32_t spike = active ? update_neuron_at<MODEL>(a, ql, GlobalSums{a, ql}, a.clock, a.vhist_row, &v_new) : 0u;
+    if (a.wire_out) {
+        // entries past the shard's neurons (slot padding) stay zero: nothing ever writes them
+        if (active) {
+            const uint32_t q = a.rows.global_of(ql);
+            const uint32_t *x = reinterpret_cast<const uint32_t *>(a.xout);
+            for (uint32_t pl = 0; pl < a.wire_planes; ++pl)
+                a.wire_out[(size_t)pl * a.wire_count + ql] = a.wire_plane_id[pl] == PLANE_V ? __float_as_uint(v_new)
+                                                                                           : x[a.n.xl.at(q, (int)a.wire_plane_id[pl])];
+        }
+        const unsigned long long bits = __ballot(spike != 0);
+        const uint32_t lane = threadIdx.x & 63u, w0 = (ql >> 6) * 2, n_words = (a.wire_count + 31) / 32;
+        uint32_t *out = a.wire_out + (size_t)a.wire_planes * a.wire_count;
+        if (lane == 0 && w0 < n_words) out[w0] = (uint32_t)bits;
+        if (lane == 32 && w0 + 1 < n_words) out[w0 + 1] = (uint32_t)(bits >> 32);
+    }
 
     // spike raster: one 64-bit ballot word per wavefront = one aligned 64-block of the global index space (shard
     // boundaries are multiples of 64; a range-set shard maps every wavefront to such a block, holes contribute 0)

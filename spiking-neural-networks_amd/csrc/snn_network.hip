@@ -42,6 +42,7 @@ int snn_network_create(int device, int neuron_model, int nt_kinetics, int recept
     if (const char *e = getenv("SNN_AMD_FUSED_STEP")) net->fused_step = (e[0] != '0');
     if (const char *e = getenv("SNN_AMD_CSR_XCD_BANDS")) net->csr_xcd_bands = (e[0] != '0');
     if (const char *e = getenv("SNN_AMD_HALO_DIRECT")) net->halo_direct = (e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1;
+    if (const char *e = getenv("SNN_AMD_UPDATE_PACKS")) net->update_packs = (e[0] != '0');
     if (const char *e = getenv("SNN_AMD_CELLS_IN_STEP")) net->cells_in_step = (e[0] != '0');
     if (const char *e = getenv("SNN_AMD_DEFER_RSTDP")) net->defer_rstdp = (e[0] != '0');
     if (const char *e = getenv("SNN_AMD_DEFER_STDP")) net->defer_stdp = (e[0] == '2') ? 2 : (e[0] != '0');
@@ -1413,6 +1414,7 @@ int snn_set_option(snn_network_t *net, const char *name, int value)
     const std::string n(name);
     if (n == "fused_step") net->fused_step = value != 0;
     else if (n == "cells_in_step") net->cells_in_step = value != 0;
+    else if (n == "update_packs") net->update_packs = value != 0;
     else if (n == "halo_direct") net->halo_direct = (value >= 0 && value <= 2) ? value : 1;
     else if (n == "csr_xcd_bands") net->csr_xcd_bands = value != 0;
     else if (n == "defer_rstdp") net->defer_rstdp = value != 0;

@@ -82,6 +82,10 @@ int ensure_exchange_plan(snn_network *net)
     if (net->block_mode && !net->halo_committed) synthesize_full_lists(net);
     if (net->x_mode == SNN_EXCHANGE_ALLGATHER) {
         net->x_block_words = segment_words(P, net->shard_stride);
+        // a new plan lays the slots out anew: no word of the old layout may survive where the new one expects padding zeros
+        // (k_update writes only the entries of the shard's own neurons)
+        if (net->wire && net->wire_words)
+            HIP_TRY(hipMemsetAsync(net->wire, 0, net->wire_words * 4, net->stream), SNN_ERR_BUFFER_WRITE);
         for (uint32_t p = 0; p < G; ++p) {
             net->x_send_off[p] = 0; net->x_send_words[p] = net->x_block_words;
             net->x_recv_off[p] = (uint64_t)p * net->x_block_words; net->x_recv_words[p] = net->x_block_words;
@@ -212,6 +216,7 @@ int launch_exchange_pack(snn_network *net)
 {
     if (!net->sharded || net->seg_n[0] == 0 || net->seg_max[0] == 0) return SNN_OK;
     if (net->step_packed) return SNN_OK;             // k_step_csr wrote the segments itself
+    if (net->update_packed) { net->update_packed = false; return SNN_OK; }    // ... or k_update did (dense shard handles)
     net->send_bits_clean = false;                    // whole bitmap words, set bits included
     hipLaunchKernelGGL(k_exchange_pack, dim3((net->seg_max[0] + 255) / 256, net->seg_n[0]), dim3(256), 0, net->stream,
                        wire_args(net, 0));

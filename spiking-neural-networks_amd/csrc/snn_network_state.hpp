@@ -126,6 +126,7 @@ struct snn_network {
     uint32_t x_planes = 0, x_plane_id[WIRE_MAX_PLANES] = {0, 0, 0, 0};
     uint64_t x_block_words = 0;                 // all-gather: words per shard slot
     uint32_t *wire = nullptr;                   // all-gather: [n_shards][block words at the largest plan]
+    size_t wire_words = 0;
     // halo (sparse handles): per peer, the neurons of that peer this handle's rows read (need) and the own neurons
     // that peer reads (send); buffers and segment tables sized by the plan
     std::vector<std::vector<uint32_t>> halo_need, halo_send;
@@ -144,6 +145,8 @@ struct snn_network {
     uint32_t *pack_ptr_dev = nullptr, *pack_segoff_dev = nullptr, *pack_count_dev = nullptr, *pack_index_dev = nullptr;
     uint32_t recv_total = 0, send_bitmap_words = 0;
     bool send_bits_clean = true;          // every outgoing spike bitmap is zero (what the in-kernel pack ORs into)
+    bool update_packed = false;           // this step's own slot of the all-gather buffer was written by k_update
+    int update_packs = 1;                 // option "update_packs"
     bool step_packed = false;             // this step's outgoing segments were written by k_step_csr itself
     bool interior_pending = false;        // the border half of this step is enqueued, the interior slices are not yet
     // Library-driven runs of such a handle (snn_run_sharded): the rows gather the halo from the received segments themselves
@@ -401,6 +404,7 @@ int build_state(snn_network *net)
         // all-gather wire buffer at its largest plan: 4 planes + the spike bitmap per slot
         const size_t words = (size_t)net->n_shards * ((size_t)WIRE_MAX_PLANES * net->shard_stride + net->shard_stride / 32);
         TRY(dev_alloc_t(net, &net->wire, words));
+        net->wire_words = words;
         HIP_TRY(hipMemsetAsync(net->wire, 0, words * 4, net->stream), SNN_ERR_BUFFER_WRITE);
     }
     n.xbuf = net->xbuf;

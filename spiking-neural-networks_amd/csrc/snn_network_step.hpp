@@ -267,6 +267,15 @@ int launch_update(snn_network *net)
     a.has_nt = net->any_nt_neurons ? 1 : 0;
     a.bcm = net->model == SNN_MODEL_BCM_IZHIKEVICH;
     a.model_is_custom = net->model == SNN_MODEL_CUSTOM;
+    // dense shard handles: the own slot of the all-gather buffer is written by this launch (no pack launch)
+    net->update_packed = false;
+    if (net->sharded && !net->csr && net->update_packs && !net->x_dirty && net->x_mode == SNN_EXCHANGE_ALLGATHER &&
+        net->wire && net->x_block_words && net->n_loc <= net->shard_stride) {
+        a.wire_out = net->wire + (size_t)net->shard_index * net->x_block_words;
+        a.wire_count = net->shard_stride; a.wire_planes = net->x_planes;
+        for (uint32_t s = 0; s < net->x_planes; ++s) a.wire_plane_id[s] = net->x_plane_id[s];
+        net->update_packed = true;
+    }
     net->shadow_valid = false;            // the exchange buffer moves on without the shadows
     const uint32_t ub = 256u;          // (one wavefront per workgroup for small launches was measured: no gain)
     dim3 grid((net->ld + ub - 1) / ub);
