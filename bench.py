@@ -26,6 +26,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured
 PMC_TRAFFIC = {"c2": os.path.join(ROOT, "profiles", "r03", "c2_pmc_traffic.json"),
                "c3": os.path.join(ROOT, "profiles", "r03", "c3_pmc_traffic.json"),
                "c4": os.path.join(ROOT, "profiles", "r03", "c4_pmc_traffic.json"),
+               "c5": os.path.join(ROOT, "profiles", "r03", "c5_pmc_traffic.json"),
                "c6": os.path.join(ROOT, "profiles", "r03", "c6_pmc_traffic.json")}
 
 

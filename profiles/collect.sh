@@ -14,7 +14,7 @@ prof() {   # name, bench args...
     rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_$name" -- python3 bench.py "$@" --no-cpu-baseline \
         > "$OUT/${name}_bench_under_rocprof.json" 2> "$OUT/${name}_rocprof.err"
     find "$OUT/prof_$name" -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} "$OUT/${name}_kernel_stats.csv"
-    tail -1 "$OUT/${name}_bench_under_rocprof.json" > "$OUT/${name}_bench_line.json"; mv "$OUT/${name}_bench_line.json" "$OUT/${name}_bench_under_rocprof.json"
+    grep '^{"metric"' "$OUT/${name}_bench_under_rocprof.json" | tail -1 > "$OUT/${name}_bench_line.json"; mv "$OUT/${name}_bench_line.json" "$OUT/${name}_bench_under_rocprof.json"
     rm -rf "$OUT/prof_$name"
     head -4 "$OUT/${name}_kernel_stats.csv"
 }
@@ -43,4 +43,14 @@ pmc c2 k_inputs_dense --config c2 --steps 20 --warmup 3 --repeats 1
 pmc c3 k_inputs_dense --config c3 --steps 20 --warmup 3 --repeats 1
 pmc c4 k_inputs_dense --config c4 --steps 20 --warmup 3 --repeats 1
 pmc c6 k_inputs_rstdp --config c6 --steps 10 --warmup 2 --repeats 1
+# (c5: 4-byte-per-lane accesses, a width the guide calls uncalibrated; the doubled FETCH_SIZE is kept because the undoubled
+#  figure, 79 MB, is below the 117 MB of plan words + weights the launch has to stream)
+pmc c5 k_step_csr --config c5 --steps 50 --warmup 5 --repeats 1
+# what ONE rank of G does per step, without its exchange (the library's loop with a transport that moves nothing)
+python3 profiles/measure_c5_rank_step.py 2000 > "$OUT/c5_rank_step.jsonl" 2> /dev/null
+python3 profiles/measure_shard_shapes.py 200 > "$OUT/c2_shard_shapes.jsonl" 2> /dev/null
+rm -rf "$OUT/trace_g8"
+( cd /tmp && SHARDS=8 rocprofv3 --kernel-trace --output-format csv -d "$OUT/trace_g8" -- python3 "$OLDPWD/profiles/measure_c5_rank_step.py" 1000 > /dev/null 2>&1 )
+python3 profiles/experiments/kernel_gaps.py "$(find "$OUT/trace_g8" -name '*kernel_trace.csv' | head -1)" 400 > "$OUT/c5_rank_step_g8_kernel_trace_summary.json"
+rm -rf "$OUT/trace_g8"
 ls "$OUT"
