@@ -116,3 +116,49 @@ def test_direct_form_needs_the_fast_step(snn):
         assert np.array_equal(parity.bits(st["current_voltage"][h.owned]), parity.bits(net["current_voltage"][h.owned]))
         parity.assert_graph_equal(net, h)
         h.close()
+
+
+@pytest.mark.timeout(600)
+def test_one_way_coupling_and_uncoupled_shards(snn):
+    """Edge cases of the plan: a shard that only sends (no halo of its own), one that only receives (no border slices) and --
+    a second network -- shards that trade nothing at all."""
+    import torch
+    import oracle_binding as ob
+    from snn_amd import parallel
+    for coupled in (True, False):
+        lay = parity.Layout([(0, 8, 8), (1, 8, 8)], [(2, 8, 8)])
+        net = parity.make_oracle(lay, st_kind=ob.ST_POISSON)
+        n = 64
+        net["current_voltage"] = ob.uniform_array(21, 2 * n, -65.0, 30.0)
+        net["gap_conductance"] = 10.0
+        net["st_chance_of_firing"] = 0.02
+        net["st_seed"] = np.arange(3, 3 + n, dtype=np.uint32)
+        conn = net["connections"]
+        for k in range(2):
+            for i in range(n):
+                conn[k * n + (i + 1) % n, k * n + i] = 1                 # a ring inside each lattice
+                conn[k * n + (i + 7) % n, k * n + i] = 1
+        for i in range(n):
+            conn[2 * n + i, i] = 1                                       # Poisson cells drive lattice 0
+            if coupled:
+                conn[i, n + (i * 5) % n] = 1                             # lattice 0 -> lattice 1, never back
+        net["weights"][...] = conn * np.float32(1.5)
+        handles = [parity.device_from_oracle(snn, net, shard=(r, 2), csr=True) for r in range(2)]     # shard r = lattice r
+        for h in handles:
+            h.set_option("halo_direct", 2)
+        parallel.LocalExchange(handles, torch.device("cuda", 0), halo=True)
+        plans = [h.exchange_plan() for h in handles]
+        assert int(plans[0]["recv_words"]) == 0 and int(plans[1]["send_words"]) == 0
+        assert (int(plans[1]["recv_words"]) > 0) == coupled
+        run_in_lockstep(handles, [150, 50])
+        net.run(200, spike_history=True)
+        assert net.spike_history[:, :n].sum() > 3
+        for r, h in enumerate(handles):
+            st = parity.pull_state(h, net)
+            known = np.zeros(2 * n, bool)
+            known[h.owned] = True
+            known[h.halo_needs(1 - r)] = True
+            assert known.sum() == (n if r == 0 or not coupled else 2 * n)
+            for name in ("current_voltage", "is_spiking", "last_firing_time"):
+                assert np.array_equal(parity.bits(st[name][known]), parity.bits(net[name][known])), (name, r, coupled)
+            h.close()
