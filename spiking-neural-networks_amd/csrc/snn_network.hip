@@ -553,7 +553,7 @@ int ensure_traces(snn_network *net)
 {
     if (net->trace) return SNN_OK;
     const size_t n = std::max<size_t>(trace_elems(net), 64);
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&net->trace), n * 4), SNN_ERR_BUFFER_CREATE);
+    HIP_TRY(alloc_streamed(reinterpret_cast<void **>(&net->trace), n * 4), SNN_ERR_BUFFER_CREATE);
     HIP_TRY(hipMemsetAsync(net->trace, 0, n * 4, net->stream), SNN_ERR_BUFFER_WRITE);
     // The trace matrix of a dense handle is rewritten every step (k_inputs_rstdp): like the synapse matrix its HBM placement
     // decides a few per cent of the pass (choose_matrix_placement) -- up to three more candidates, each held until the
@@ -565,7 +565,7 @@ int ensure_traces(snn_network *net)
         for (int cand = 0; cand < 3 && rc == SNN_OK; ++cand) {
             size_t free_b = 0, total_b = 0;
             void *b = nullptr;
-            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < n * 4 + (n >> 0) || hipMalloc(&b, n * 4) != hipSuccess) break;
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < n * 4 + (n >> 0) || alloc_streamed(&b, n * 4) != hipSuccess) break;
             float ms = 0.0f;
             if (hipMemsetAsync(b, 0, n * 4, net->stream) != hipSuccess) { losers.push_back(b); break; }
             rc = time_rw_pass(net, static_cast<float *>(b), n / 4, &ms);

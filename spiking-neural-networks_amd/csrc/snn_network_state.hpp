@@ -302,11 +302,24 @@ inline bool record_now(const snn_network *net)
 
 namespace {
 
+// Big streamed arrays (the synapse matrix, the trace matrix).  SNN_AMD_CONTIGUOUS=1 asks for PHYSICALLY CONTIGUOUS memory
+// first (larger page-table fragments).  Off by default: it is not a uniform gain -- C3's input pass 164.4 against 171.3 us in
+// one call, 175.5 against 171.5 us in another, the reward-modulated pass 11.38 against 10.74 ms (profiles/experiments/README.md).
+hipError_t alloc_streamed(void **out, size_t bytes)
+{
+    static const bool contiguous = [] { const char *e = getenv("SNN_AMD_CONTIGUOUS"); return e && e[0] == '1'; }();
+    if (contiguous && bytes >= ((size_t)256 << 20) &&
+        hipExtMallocWithFlags(out, bytes, hipDeviceMallocContiguous) == hipSuccess)
+        return hipSuccess;
+    (void)hipGetLastError();
+    return hipMalloc(out, bytes);
+}
+
 int dev_alloc(snn_network *net, void **out, size_t bytes)
 {
     *out = nullptr;
     if (bytes == 0) bytes = 256;
-    HIP_TRY(hipMalloc(out, bytes), SNN_ERR_BUFFER_CREATE);
+    HIP_TRY(alloc_streamed(out, bytes), SNN_ERR_BUFFER_CREATE);
     net->allocs.push_back(*out);
     net->alloc_bytes[*out] = bytes;
     return SNN_OK;

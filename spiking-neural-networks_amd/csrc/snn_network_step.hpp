@@ -461,7 +461,7 @@ int choose_matrix_placement(snn_network *net)
             size_t free_b = 0, total_b = 0;
             void *b = nullptr;
             if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + (bytes >> 2) ||
-                hipMalloc(&b, bytes) != hipSuccess)
+                alloc_streamed(&b, bytes) != hipSuccess)
                 break;
             float *a = net->W;
             float ms_b = 0.0f;
