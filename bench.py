@@ -403,6 +403,24 @@ def main():
         hist_value = n * hsteps / (time.perf_counter() - t0)
         dn.set_history(voltage=False, spikes=False)
 
+    spiking_value = None
+    if not sharded and args.config == "c2" and args.spike_fraction == 0:
+        # the lattice falls silent within the warm-up (gap junctions pull the voltages together): also report the rate with
+        # 0.1 % of the population driven above threshold before every step (10 Hz at dt = 0.1 ms), so that the raster ballots,
+        # spike totals and last_firing_time stamps are exercised -- AFTER the state checksum, which stays that of the plain run
+        dn.set_synthetic_drive(12345, 0.001, 35.0)
+        dsteps = min(args.steps, 100)
+        run(10)
+        before = own_spike_total()
+        barrier()
+        t0 = time.perf_counter()
+        run(dsteps)
+        barrier()
+        dt_drive = time.perf_counter() - t0
+        spiking_value = {"value": n * dsteps / dt_drive, "spikes_per_step": (own_spike_total() - before) / dsteps,
+                         "what": "0.1 % of the neurons raised above threshold before every step (snn_set_synthetic_drive)"}
+        dn.set_synthetic_drive(12345, 0.0, 35.0)
+
     ceilings = None
     if rank == 0 and not sharded and args.config == "c2":
         dn.synchronize()
@@ -435,6 +453,7 @@ def main():
             "config": {"workload": workload, "neurons": n,
                        "parallelism": f"post-population shards x{world}" if world > 1 else "single GPU"},
             "value_with_voltage_and_spike_history": hist_value,
+            "value_with_0p1pct_of_the_neurons_spiking_per_step": spiking_value,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic(args.config, world, args.rows, args.cols),
