@@ -311,8 +311,23 @@ def main():
     comm = None
     if sharded and args.stepper == "library":
         # the whole step loop inside libsnn_amd.so: kernels -> pack -> RCCL (called by the library on its own second
-        # stream) -> unpack -> kernels, ONE host call per run; torch.distributed only carries the 128-byte RCCL id
-        comm = parallel.LibraryComm(rank, world, local_rank)
+        # stream) -> unpack -> kernels, ONE host call per run; torch.distributed only carries the 128-byte RCCL id.
+        # If ANY rank cannot make its communicator, every rank falls back to the torch.distributed stepper (agreed on
+        # through the process group, so that no rank is left alone in a collective).
+        try:
+            comm = parallel.LibraryComm(rank, world, local_rank)
+            made = 1
+        except Exception as e:          # noqa: BLE001
+            print(f"[bench] rank {rank}: library communicator failed ({e}); falling back to --stepper torch", file=sys.stderr)
+            made = 0
+        flag = torch.tensor([made], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            if comm is not None:
+                comm.close()
+            comm = None
+            args.stepper = "torch"
+    if comm is not None:
 
         def run(k):
             dn.run_sharded(comm, k)

@@ -52,9 +52,13 @@ class LibraryComm:
         self._L = lib or _lib.load()
         self._check = lambda code: _lib.check(code, self._L)
         ident = C.create_string_buffer(128)
+        raw, failure = None, None
         if rank == 0:
-            self._check(self._L.snn_comm_unique_id(ident))
-        raw = bytes(ident.raw)
+            try:
+                self._check(self._L.snn_comm_unique_id(ident))
+                raw = bytes(ident.raw)
+            except Exception as e:       # noqa: BLE001 -- told to the other ranks first: they wait in the broadcast below
+                failure = e
         if world_size > 1:
             if broadcast is None:
                 import torch.distributed as dist
@@ -62,7 +66,11 @@ class LibraryComm:
                 dist.broadcast_object_list(box, src=0)
                 raw = box[0]
             else:
-                raw = broadcast(raw)
+                raw = broadcast(raw if raw is not None else b"")
+        if failure is not None:
+            raise failure
+        if not raw or len(raw) != 128:
+            raise RuntimeError("rank 0 could not create the RCCL unique id")
         h = C.c_void_p()
         self._check(self._L.snn_comm_init_rank(C.create_string_buffer(raw, 128), world_size, rank, device, C.byref(h)))
         self._h = h.value
