@@ -301,10 +301,17 @@ __global__ __launch_bounds__(256) void k_step_csr(const CsrStepArgs a)
     csr_row_sums<ELEC, CHEM>(a.c, q, s.i, s.t);
     uint32_t spike = 0;
     float v_new = 0.0f;
-    if (q < a.c.g.n_loc) spike = update_neuron_at<MODEL>(a.up, q, s, a.up.clock, a.up.vhist_row, &v_new);
+    // (a range-set shard owns whole 64-blocks of the global index space only in part: the rows of the neurons it does not own
+    // are holes -- no synapses, no update, k_update's rule)
+    if (q < a.c.g.n_loc && a.up.rows.active(q, a.c.g.n_loc)) spike = update_neuron_at<MODEL>(a.up, q, s, a.up.clock, a.up.vhist_row, &v_new);
     if (a.up.spike_row) {
+        // one raster word per wavefront = one aligned 64-block of the GLOBAL index space (as in k_update: a range-set shard maps
+        // every slice to such a block; rows it does not own contribute 0)
         const unsigned long long word = __ballot(spike != 0);
-        if ((threadIdx.x & 63u) == 0) a.up.spike_row[(a.up.q0 + q) >> 6] = word;
+        if ((threadIdx.x & 63u) == 0 && q < a.c.g.n_loc) {
+            const uint32_t g = a.up.rows.block ? a.up.rows.block[q >> 6] * 64u : a.up.q0 + q;
+            if (g < a.up.n.n_pad) a.up.spike_row[g >> 6] = word;
+        }
     }
     if (pack_end > pack_begin) {
         // the values this thread has just written, into every segment that carries the neuron (the voltage from its

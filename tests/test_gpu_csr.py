@@ -198,3 +198,48 @@ def test_csr_validation(snn):
     dn.run(5)                                        # no graph set: no edges, still steps
     assert dn.clock == 5
     dn.close()
+
+
+def test_range_set_shards_leave_foreign_rows_alone_and_keep_histories(snn):
+    """Sparse shards BY LATTICE of lattices whose first index is not a multiple of 64: a shard's 64-row blocks then hold rows
+    of neurons it does not own.  With chemical synapses only (no voltage on the wire) a foreign row stepped by mistake runs
+    on its own and stamps last_firing_time; histories of a shard are indexed by GLOBAL 64-blocks."""
+    import torch
+    from snn_amd import parallel
+    lay = parity.Layout([(0, 2, 6), (3, 8, 11), (5, 2, 4)], [(9, 3, 7)])
+    net = parity.make_oracle(lay, st_kind=ob.ST_POISSON, chemical=True, electrical=False)
+    nn, nc = net.n_neurons, net.n_cells
+    rng = np.random.default_rng(77)
+    net["current_voltage"] = ob.uniform_array(5, nn, -65.0, 29.0)
+    net["nt_flags"][:, 0] = 1
+    net["rc_flags"][:, 0] = 1
+    net["rc_g"][:, 0] = 4.0
+    net["st_nt_flags"][:, 0] = 1
+    net["st_chance_of_firing"] = 0.1
+    net["st_seed"] = np.arange(11, 11 + nc, dtype=np.uint32)
+    net.fill_graph(3, 0.5, 2.5, with_diagonal=True)
+    net["connections"][...] = rng.random(net["connections"].shape) < 0.08
+    net["weights"][...] *= net["connections"]
+    handles = [parity.device_from_oracle(snn, net, shard=(r, 3), csr=True, by_lattice=True) for r in range(3)]
+    for h in handles:
+        h.set_history(voltage=True, spikes=True)
+    ex = parallel.LocalExchange(handles, torch.device("cuda", 0), halo=True)
+    assert all(p["plane_id"] == [2] for p in ex.plans)           # one transmitter plane, no voltage
+    for _ in range(250):
+        ex.step()
+    net.run(250, voltage_history=True, spike_history=True)
+    assert net.spike_history.sum() > 20
+    rngs = net.layout.ranges()
+    for h in handles:
+        st = parity.pull_state(h, net)
+        parity.assert_shard_view_equal(h, st, net)
+        own = np.zeros(nn, bool)
+        own[h.owned] = True
+        for i, _, _ in net.layout.lattices:
+            first, count, _ = rngs[i]
+            m = own[first:first + count]
+            if not m.any():
+                continue
+            assert np.array_equal(h.spike_history(i)[:, m], net.spike_history[:, first:first + count][:, m])
+            assert np.array_equal(parity.bits(h.voltage_history(i)[:, m]), parity.bits(net.voltage_history[:, first:first + count][:, m]))
+        h.close()

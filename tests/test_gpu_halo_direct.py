@@ -162,3 +162,45 @@ def test_one_way_coupling_and_uncoupled_shards(snn):
             for name in ("current_voltage", "is_spiking", "last_firing_time"):
                 assert np.array_equal(parity.bits(st[name][known]), parity.bits(net[name][known])), (name, r, coupled)
             h.close()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_direct_halo_runs_on_random_sparse_networks(snn, seed):
+    """random sparse electrical networks (two lattices of unequal size, Poisson cells, rows without inputs or outputs), a random
+    number of contiguous shards, random splits of the run"""
+    import torch
+    from snn_amd import parallel
+    from test_gpu_csr import random_sparse_net
+    rng = np.random.default_rng(100 + seed)
+    net = random_sparse_net(False, density=float(rng.choice([0.02, 0.05, 0.15])), seed=40 + seed)
+    net["do_plasticity"] = 0
+    g = int(rng.integers(2, 6))
+    handles = [parity.device_from_oracle(snn, net, shard=(r, g), csr=True) for r in range(g)]
+    for h in handles:
+        h.set_option("halo_direct", 2)
+        h.set_option("cells_in_step", int(rng.integers(0, 2)))
+    ex = parallel.LocalExchange(handles, torch.device("cuda", 0), halo=True)
+    calls = [int(x) for x in rng.integers(120, 260, size=3)]
+    run_in_lockstep(handles, calls[:2])
+    ex.step()
+    run_in_lockstep(handles, calls[2:])
+    steps = sum(calls) + 1
+    net.run(steps, spike_history=True)
+    assert net.spike_history.sum() > 0
+    for r, h in enumerate(handles):
+        if h.owned.size:
+            assert h.stat("halo_direct_steps") == sum(calls)
+        known = np.zeros(net.n_neurons, bool)
+        known[h.owned] = True
+        for p in range(g):
+            if p != r:
+                known[h.halo_needs(p)] = True
+        st = parity.pull_state(h, net)
+        for name in ("current_voltage", "is_spiking", "last_firing_time"):
+            assert np.array_equal(parity.bits(st[name][known]), parity.bits(net[name][known])), (name, r)
+        cells = h.cells_read()
+        for name in ("st_last_firing_time", "st_seed"):
+            assert np.array_equal(parity.bits(st[name][cells]), parity.bits(net[name][cells])), (name, r)
+        assert h.clock == steps
+        h.close()

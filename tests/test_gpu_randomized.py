@@ -3,6 +3,8 @@ receptor kinetics (4 x 3), synapse kinds, lattice shapes, connectivity density, 
 preset, BCM Poisson), per-lattice plasticity (none / STDP / BCM / reward-modulated with a random reward sequence), graph form (dense /
 sparse), whole or sharded stepping, run split into several calls, reduced histories with a random stride -- each
 compared bit for bit with the oracle."""
+import os
+
 import numpy as np
 import pytest
 
@@ -146,7 +148,9 @@ def check_modulation(dn, net, plan):
             assert np.array_equal(parity.bits(np.array([dn.dopamine(i)])), parity.bits(net["rm_dopamine"][slot:slot + 1]))
 
 
-@pytest.mark.parametrize("seed", list(range(72)))
+# SNN_RANDOM_SEEDS=n widens the sweep (an occasional long campaign; the suite keeps 72)
+# (583: found by a 900-seed campaign -- a range-set sparse shard stepped rows of its blocks that it does not own)
+@pytest.mark.parametrize("seed", sorted(set(range(int(os.environ.get("SNN_RANDOM_SEEDS", "72")))) | {583}))
 def test_random_network(snn, seed):
     import torch
     from snn_amd import parallel
