@@ -5,6 +5,7 @@ the previous step's arrivals and the bitmap clearing behind them).
 
 G handles of ONE process, each driven by its own thread through snn_run_sharded_custom; the exchange function copies the
 peers' CURRENT outgoing segments (snn_exchange_plan_get inside the function) device to device.  Against the oracle."""
+import os
 import threading
 
 import numpy as np
@@ -165,7 +166,7 @@ def test_one_way_coupling_and_uncoupled_shards(snn):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("seed", list(range(12)))
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("SNN_RANDOM_SEEDS_DIRECT", "12")))))     # (env: a longer campaign)
 def test_direct_halo_runs_on_random_sparse_networks(snn, seed):
     """random sparse electrical networks (two lattices of unequal size, Poisson cells, rows without inputs or outputs), a random
     number of contiguous shards, random splits of the run"""

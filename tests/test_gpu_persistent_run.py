@@ -2,6 +2,8 @@
 BASELINE configs[0]) against the one-launch-per-step form (option persistent_run 0) and the oracle: bit-identical
 voltages, rasters, state and spike totals, for ragged sizes, split run calls, every built-in model, sparse connectivity,
 and voltages that leave the range in which an absent edge may be summed as a zero product."""
+import os
+
 import numpy as np
 import pytest
 
@@ -173,7 +175,7 @@ def draw(seed):
     return net, calls, bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
 
 
-@pytest.mark.parametrize("seed", range(32))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SNN_RANDOM_SEEDS_PERSISTENT", "32"))))     # (env: a longer campaign)
 def test_random_electrical_networks(snn, seed):
     net, calls, history, counts = draw(seed)
     outs = []
