@@ -110,6 +110,18 @@ def draw(seed):
     return net, plan
 
 
+SWITCHES = {"fused_step": (0, 1), "defer_stdp": (0, 1, 2), "defer_rstdp": (0, 1), "uniform_params": (0, 1), "persistent_run": (0, 1),
+            "cells_in_step": (0, 1), "csr_xcd_bands": (0, 1), "update_packs": (0, 1), "input_shape": (0, 1, 2)}
+
+
+def tuning_switches(seed):
+    """results never depend on the tuning switches (include/snn_amd.h): two seeds in three run with a random setting of them"""
+    if seed % 3 == 0:
+        return {}
+    rng = np.random.default_rng(50_000 + seed)
+    return {name: int(rng.choice(values)) for name, values in SWITCHES.items() if rng.integers(0, 2)}
+
+
 RM_KEYS = ("rm_dopamine", "rm_tau_d", "rm_tau_c", "rm_a_plus", "rm_a_minus", "rm_tau_plus", "rm_tau_minus", "rm_dt")
 
 
@@ -156,8 +168,11 @@ def test_random_network(snn, seed):
     from snn_amd import parallel
     net, plan = draw(1000 + seed)
     steps = plan["steps"]
+    switches = tuning_switches(seed)
     if plan["shards"] == 1:
         dn = make_handle(snn, net, plan)
+        for name, value in switches.items():
+            dn.set_option(name, value)
         dn.set_history(voltage=True, spikes=True)
         dn.set_reduced_history(True, True, True)
         dn.set_history_stride(plan["stride"])
@@ -189,6 +204,9 @@ def test_random_network(snn, seed):
         return
     g = plan["shards"]
     handles = [make_handle(snn, net, plan, shard=(r, g)) for r in range(g)]
+    for h in handles:
+        for name, value in switches.items():
+            h.set_option(name, value)
     ex = parallel.LocalExchange(handles, torch.device("cuda", 0), halo=plan["csr"] and bool(plan.get("halo", True)))
     for step in range(steps):
         for h in handles:
