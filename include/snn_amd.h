@@ -277,6 +277,23 @@ int snn_halo_commit(snn_network_t *net);
 int snn_comm_unique_id(void *id_128_bytes);
 int snn_comm_init_rank(const void *id_128_bytes, int world_size, int rank, int device, void **nccl_comm);
 int snn_comm_destroy(void *nccl_comm);
+/* The collectives behind snn_run_sharded / snn_exchange / snn_comm_exchange_halo_lists, replaceable PROCESS-WIDE: a host with
+ * another transport (MPI, UCX, a test harness that runs several ranks as threads of one process) keeps the library's loop with
+ * its overlap of the exchange and the own-rows work.  Signatures are RCCL's (ncclCommCount, ncclCommUserRank, ncclAllGather,
+ * ncclSend, ncclRecv, ncclGroupStart, ncclGroupEnd) with void * for ncclComm_t and hipStream_t and int for the data type (always
+ * ncclUint32 = 3) and the result (0 = success); `comm` is whatever the host passes to snn_run_sharded.  The functions are
+ * called from the thread that runs the library call and must order their work after what that thread has enqueued on `stream`
+ * (as RCCL does).  NULL restores RCCL.  snn_comm_unique_id / _init_rank / _destroy keep calling RCCL. */
+typedef struct snn_collectives {
+    int (*comm_count)(void *comm, int *count);
+    int (*comm_user_rank)(void *comm, int *rank);
+    int (*all_gather)(const void *send, void *recv, size_t count, int datatype, void *comm, void *hip_stream);
+    int (*send)(const void *buf, size_t count, int datatype, int peer, void *comm, void *hip_stream);
+    int (*recv)(void *buf, size_t count, int datatype, int peer, void *comm, void *hip_stream);
+    int (*group_start)(void);
+    int (*group_end)(void);
+} snn_collectives;
+int snn_set_collectives(const snn_collectives *table);
 /* CSR shard handles: all ranks call it once after snn_set_graph_csr; trades the need lists and commits the halo plan */
 int snn_comm_exchange_halo_lists(snn_network_t *net, void *nccl_comm);
 /* One exchange of the packed segments, enqueued on the handle's stream (between snn_step_begin and snn_step_end) */

@@ -79,6 +79,18 @@ EXCHANGE_ALLGATHER, EXCHANGE_HALO = 0, 1
 
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)      # snn_exchange_fn(user, hip_stream)
 
+# snn_collectives of include/snn_amd.h (snn_set_collectives)
+COMM_QUERY_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int))
+ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p)
+SEND_RECV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p)
+GROUP_FN = C.CFUNCTYPE(C.c_int)
+
+
+class Collectives(C.Structure):
+    _fields_ = [("comm_count", COMM_QUERY_FN), ("comm_user_rank", COMM_QUERY_FN), ("all_gather", ALL_GATHER_FN),
+                ("send", SEND_RECV_FN), ("recv", SEND_RECV_FN), ("group_start", GROUP_FN), ("group_end", GROUP_FN)]
+
+
 f32p = C.POINTER(C.c_float)
 u32p = C.POINTER(C.c_uint32)
 i32p = C.POINTER(C.c_int32)
@@ -139,6 +151,7 @@ SIGNATURES = {
     "snn_comm_unique_id": (C.c_int, [C.c_void_p]),
     "snn_comm_init_rank": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "snn_comm_destroy": (C.c_int, [C.c_void_p]),
+    "snn_set_collectives": (C.c_int, [C.c_void_p]),
     "snn_comm_exchange_halo_lists": (C.c_int, [H, C.c_void_p]),
     "snn_exchange": (C.c_int, [H, C.c_void_p]),
     "snn_run_sharded": (C.c_int, [H, C.c_void_p, C.c_uint64]),

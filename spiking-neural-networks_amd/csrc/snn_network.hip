@@ -1095,6 +1095,30 @@ int snn_halo_commit(snn_network_t *net)
     return ensure_exchange_plan(net);
 }
 
+int snn_set_collectives(const snn_collectives *table)
+{
+    Rccl &r = rccl_state();
+    static const Rccl resolved = r;               // what dlopen / dlsym found (possibly nothing), for the way back
+    if (!table) {
+        r = resolved;
+        return SNN_OK;
+    }
+    if (!table->comm_count || !table->comm_user_rank || !table->all_gather || !table->send || !table->recv ||
+        !table->group_start || !table->group_end)
+        return fail(SNN_ERR_BAD_ARG, "every entry of the table must be set");
+    // RCCL's own types at the call sites: an enum result and data type (int-sized), ncclComm_t and hipStream_t pointers
+    r.CommCount = reinterpret_cast<decltype(r.CommCount)>(table->comm_count);
+    r.CommUserRank = reinterpret_cast<decltype(r.CommUserRank)>(table->comm_user_rank);
+    r.AllGather = reinterpret_cast<decltype(r.AllGather)>(table->all_gather);
+    r.Send = reinterpret_cast<decltype(r.Send)>(table->send);
+    r.Recv = reinterpret_cast<decltype(r.Recv)>(table->recv);
+    r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(table->group_start);
+    r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(table->group_end);
+    r.GetErrorString = [](ncclResult_t) -> const char * { return "the host's collective reported a failure"; };
+    r.replaced = true;
+    return SNN_OK;
+}
+
 int snn_comm_unique_id(void *id_128_bytes)
 {
     if (!id_128_bytes) return fail(SNN_ERR_BAD_ARG, "null argument");

@@ -302,6 +302,7 @@ struct Rccl {
     ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     std::string err;                              // why `lib` is null (dlerror() read ONCE, at the failing call)
+    bool replaced = false;                        // snn_set_collectives: the host's functions stand in for RCCL's
 };
 
 void rccl_resolve(Rccl &r);
@@ -313,7 +314,7 @@ Rccl &rccl_state()
     std::call_once(once, [] { rccl_resolve(r); });
     return r;
 }
-Rccl *rccl() { Rccl &r = rccl_state(); return r.lib ? &r : nullptr; }
+Rccl *rccl() { Rccl &r = rccl_state(); return (r.lib || r.replaced) ? &r : nullptr; }
 
 void rccl_resolve(Rccl &r)
 {

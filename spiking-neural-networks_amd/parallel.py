@@ -147,6 +147,129 @@ class LocalExchange:
                 for r, p in enumerate(self.plans)]
 
 
+class ThreadCollectives:
+    """The collectives of the library's own sharded loop (snn_run_sharded, snn_exchange, snn_comm_exchange_halo_lists) for G
+    shard handles that live in ONE process, one host thread per rank -- the single-GPU emulation of a multi-GPU run, where RCCL
+    refuses two ranks on one device.  Installed process-wide through snn_set_collectives; rank r passes `comm(r)` where a
+    ncclComm_t goes.  Every operation is blocking: a rank waits for the device, meets the others at a barrier, copies what its
+    peers send device to device and meets them again (nobody overwrites a buffer a peer still reads)."""
+
+    def __init__(self, world_size, device, lib=None):
+        import threading
+        import torch
+        from . import _lib
+        self._lib = _lib
+        self._L = lib or _lib.load()
+        self._torch, self._device = torch, device
+        self.world = world_size
+        self._barrier = threading.Barrier(world_size)
+        self._ranks = (C.c_int * world_size)(*range(world_size))         # comm(r) = the address of entry r
+        self._posted = [None] * world_size                               # what rank r offers in the operation in progress
+        self._local = threading.local()
+        import queue
+        self._mail = {(a, b): queue.Queue() for a in range(world_size) for b in range(world_size)}   # sends of a to b, in order
+        self.timeout = 120.0
+        self.calls = {"all_gather": 0, "groups": 0}
+        self._table = _lib.Collectives(_lib.COMM_QUERY_FN(self._count), _lib.COMM_QUERY_FN(self._user_rank),
+                                       _lib.ALL_GATHER_FN(self._all_gather), _lib.SEND_RECV_FN(self._send),
+                                       _lib.SEND_RECV_FN(self._recv), _lib.GROUP_FN(self._group_start), _lib.GROUP_FN(self._group_end))
+        _lib.check(self._L.snn_set_collectives(C.byref(self._table)), self._L)
+
+    def comm(self, rank):
+        return C.addressof(self._ranks) + rank * C.sizeof(C.c_int)
+
+    def close(self):
+        self._lib.check(self._L.snn_set_collectives(None), self._L)
+
+    def abort(self):
+        """a rank failed: release the others from the barrier (their calls then fail too)"""
+        self._barrier.abort()
+
+    def _rank_of(self, comm):
+        return (int(comm) - C.addressof(self._ranks)) // C.sizeof(C.c_int)
+
+    def _guard(self, fn):
+        try:
+            fn()
+            return 0
+        except BaseException:            # noqa: BLE001 -- a failure becomes the collective's error code (and breaks the barrier)
+            self._barrier.abort()
+            return 1
+
+    def _count(self, comm, out):
+        out[0] = self.world
+        return 0
+
+    def _user_rank(self, comm, out):
+        out[0] = self._rank_of(comm)
+        return 0
+
+    def _copy(self, dst, src, words):
+        d = device_words(dst, words, self._device)
+        d.copy_(device_words(src, words, self._device))
+
+    def _all_gather(self, send, recv, count, _dtype, comm, _stream):
+        def run():
+            r = self._rank_of(comm)
+            self._torch.cuda.synchronize()
+            self._posted[r] = (int(send), int(count))
+            self._barrier.wait()
+            for p in range(self.world):
+                src, n = self._posted[p]
+                assert n == count
+                if n and int(recv) + 4 * p * n != src:                      # (in place: the own slot already is where it goes)
+                    self._copy(int(recv) + 4 * p * n, src, n)
+            self._torch.cuda.synchronize()
+            self._barrier.wait()
+            if r == 0:
+                self.calls["all_gather"] += 1
+        return self._guard(run)
+
+    def _group_start(self):
+        self._local.ops = []
+        return 0
+
+    def _send(self, buf, count, _dtype, peer, comm, _stream):
+        self._local.ops.append(("send", int(buf), int(count), int(peer), self._rank_of(comm)))
+        return 0
+
+    def _recv(self, buf, count, _dtype, peer, comm, _stream):
+        self._local.ops.append(("recv", int(buf), int(count), int(peer), self._rank_of(comm)))
+        return 0
+
+    def _group_end(self):
+        # point to point, as RCCL's: only the ranks of a pair meet.  Every rank posts all its sends first (buffer, size and an
+        # event the receiver sets once it has copied), then serves its receives, then waits until its own sends were taken.
+        def run():
+            import threading
+            ops = self._local.ops
+            self._local.ops = []
+            if not ops:
+                return
+            r = ops[0][4]
+            self._torch.cuda.synchronize()
+            taken = []
+            for kind, buf, n, peer, _ in ops:
+                if kind == "send":
+                    done = threading.Event()
+                    self._mail[(r, peer)].put((buf, n, done))
+                    taken.append(done)
+            for kind, buf, n, peer, _ in ops:
+                if kind == "recv":
+                    src, m, done = self._mail[(peer, r)].get(timeout=self.timeout)
+                    assert m == n, "send and receive sizes disagree"
+                    if n:
+                        self._copy(buf, src, n)
+                    self._torch.cuda.synchronize()
+                    done.set()
+            for done in taken:
+                if not done.wait(self.timeout):
+                    raise TimeoutError("a peer never received")
+            if r == 0:
+                self.calls["groups"] += 1
+        return self._guard(run)
+
+
 def shard_geometry(n_neurons, n_shards):
     """Slot size and [begin, end) of every shard -- same rule as snn_network_finalize_shard."""
     per = -(-n_neurons // n_shards)            # ceil
