@@ -207,16 +207,26 @@ def test_random_network(snn, seed):
     for h in handles:
         for name, value in switches.items():
             h.set_option(name, value)
-    ex = parallel.LocalExchange(handles, torch.device("cuda", 0), halo=plan["csr"] and bool(plan.get("halo", True)))
-    for step in range(steps):
-        for h in handles:
-            if plan["rewards"] is not None:
-                h.apply_reward(float(plan["rewards"][step]))
-            h.step_begin_local()
-            h.step_begin()
-        ex.exchange()
-        for h in handles:
-            h.step_end()
+    if plan["rewards"] is None and seed % 2:
+        # the library's own loop (snn_run_sharded), one host thread per rank, the collectives replaced by device copies
+        from test_gpu_library_loop_threads import run_ranks
+        tc = parallel.ThreadCollectives(g, torch.device("cuda", 0))
+        try:
+            first = steps // plan["calls"]
+            run_ranks(handles, tc, [first, steps - first] if plan["calls"] > 1 else [steps])
+        finally:
+            tc.close()
+    else:
+        ex = parallel.LocalExchange(handles, torch.device("cuda", 0), halo=plan["csr"] and bool(plan.get("halo", True)))
+        for step in range(steps):
+            for h in handles:
+                if plan["rewards"] is not None:
+                    h.apply_reward(float(plan["rewards"][step]))
+                h.step_begin_local()
+                h.step_begin()
+            ex.exchange()
+            for h in handles:
+                h.step_end()
     net.run(steps, rewards=plan["rewards"])
     for h in handles:
         check_modulation(h, net, plan)

@@ -96,14 +96,24 @@ def test_random_streamed_network(snn, seed):
     for h in handles:
         for name, value in plan["switches"].items():
             h.set_option(name, value)
-    ex = parallel.LocalExchange(handles, torch.device("cuda", 0), halo=plan["csr"])
-    for _ in range(steps):
-        for h in handles:
-            h.step_begin_local()
-            h.step_begin()
-        ex.exchange()
-        for h in handles:
-            h.step_end()
+    if seed % 2:
+        # the library's own loop (snn_run_sharded) with one host thread per rank: the own-rows chunks of the streamed input pass
+        # are enqueued before the loop waits for the collective
+        from test_gpu_library_loop_threads import run_ranks
+        tc = parallel.ThreadCollectives(g, torch.device("cuda", 0))
+        try:
+            run_ranks(handles, tc, [steps // 2, steps - steps // 2] if plan["calls"] > 1 else [steps])
+        finally:
+            tc.close()
+    else:
+        ex = parallel.LocalExchange(handles, torch.device("cuda", 0), halo=plan["csr"])
+        for _ in range(steps):
+            for h in handles:
+                h.step_begin_local()
+                h.step_begin()
+            ex.exchange()
+            for h in handles:
+                h.step_end()
     net.run(steps)
     for h in handles:
         st = parity.pull_state(h, net)
