@@ -207,6 +207,9 @@ def test_random_network(snn, seed):
     for h in handles:
         for name, value in switches.items():
             h.set_option(name, value)
+        h.set_history(voltage=True, spikes=True)              # a shard records its own neurons (global 64-blocks of the raster)
+        h.set_reduced_history(False, False, True)
+        h.set_history_stride(plan["stride"])
     if plan["rewards"] is None and seed % 2:
         # the library's own loop (snn_run_sharded), one host thread per rank, the collectives replaced by device copies
         from test_gpu_library_loop_threads import run_ranks
@@ -227,11 +230,23 @@ def test_random_network(snn, seed):
             ex.exchange()
             for h in handles:
                 h.step_end()
-    net.run(steps, rewards=plan["rewards"])
+    net.run(steps, voltage_history=True, spike_history=True, spike_counts=True, rewards=plan["rewards"])
+    keep = np.arange(0, steps, plan["stride"])
+    rngs = net.layout.ranges()
     for h in handles:
         check_modulation(h, net, plan)
         st = parity.pull_state(h, net)
         parity.assert_shard_view_equal(h, st, net)
+        own = np.zeros(net.n_neurons, bool)
+        own[h.owned] = True
+        for i, _, _ in net.layout.lattices:
+            first, count, _ = rngs[i]
+            m = own[first:first + count]
+            if not m.any():
+                continue
+            assert np.array_equal(h.spike_history(i)[:, m], net.spike_history[keep, first:first + count][:, m])
+            assert np.array_equal(parity.bits(h.voltage_history(i)[:, m]), parity.bits(net.voltage_history[keep, first:first + count][:, m]))
+            assert np.array_equal(h.spike_counts(i)[m], net.spike_counts[first:first + count][m])
         b, e = h.post_begin, h.post_end
         for name in ("rc_r", "rc_current"):
             assert np.array_equal(parity.bits(st[name][h.owned]), parity.bits(net[name][h.owned])), name
