@@ -1,0 +1,121 @@
+"""Random SEQUENCES of C-ABI calls on one handle against the same sequence on the oracle: runs of random length interleaved with
+writes behind the stepper's back (voltages, the cells' firing times), tuning switches, reads of weights and state (which flush
+pending deferred updates), plasticity and synapse-kind toggles and reset_timing.  Exercises the handle's bookkeeping between run
+calls: the spike-train view, the shadows of the exchange buffer, pending weight updates, the exchange-independent caches.
+SNN_RANDOM_SEEDS_SEQUENCES=n widens the sweep (the suite keeps 40)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+import parity
+from test_gpu_randomized import SWITCHES, draw, make_handle
+
+pytestmark = pytest.mark.gpu
+
+
+def usable(seed):
+    net, plan = draw(1000 + seed)
+    return plan["rewards"] is None and not net["plasticity_kind"].any() and net.n_neurons > 0
+
+
+SEEDS = [s for s in range(int(os.environ.get("SNN_RANDOM_SEEDS_SEQUENCES", "90"))) if usable(s)]
+
+
+@pytest.mark.parametrize("seed", SEEDS)
+def test_random_call_sequence(snn, seed):
+    net, plan = draw(1000 + seed)
+    rng = np.random.default_rng(300_000 + seed)
+    dn = make_handle(snn, net, plan)
+    ranges = net.layout.ranges()
+    lattices = [i for i, _, _ in net.layout.lattices if ranges[i][1]]
+    cells = [i for i, _, _ in net.layout.st_lattices if ranges[i][1]]
+    lo, hi = float(net["current_voltage"].min()) - 1.0, float(net["current_voltage"].max()) + 1.0
+    log = []
+    for _ in range(int(rng.integers(4, 10))):
+        op = int(rng.integers(0, 13))
+        if op <= 2:
+            k = int(rng.integers(1, 70))
+            dn.run(k)
+            net.run(k)
+            log.append(("run", k))
+        elif op == 3:
+            i = int(rng.choice(lattices))
+            first, count, _ = ranges[i]
+            v = rng.uniform(lo, hi, count).astype(np.float32)
+            dn.set_attr(i, "current_voltage", v)
+            net["current_voltage"][first:first + count] = v
+            log.append(("voltage", i))
+        elif op == 4 and cells:
+            i = int(rng.choice(cells))
+            first, count, _ = ranges[i]
+            t = np.where(rng.random(count) < 0.5, -1, rng.integers(0, max(1, net.clock + 1), count)).astype(np.int32)
+            dn.set_attr(i, "last_firing_time", t)
+            net["st_last_firing_time"][first:first + count] = t
+            log.append(("cell firing times", i))
+        elif op == 5:
+            name = str(rng.choice(list(SWITCHES)))
+            dn.set_option(name, int(rng.choice(SWITCHES[name])))
+            log.append(("switch", name))
+        elif op == 6:
+            parity.assert_graph_equal(net, dn)
+            if rng.integers(0, 2):
+                parity.assert_state_equal(net, parity.pull_state(dn, net))
+            log.append(("read",))
+        elif op == 7:
+            slot = int(rng.integers(0, len(net.layout.lattices)))
+            i = net.layout.lattices[slot][0]
+            on = bool(rng.integers(0, 2))
+            dn.set_plasticity(i, float(net["stdp_a_plus"][slot]), float(net["stdp_a_minus"][slot]), float(net["stdp_tau_plus"][slot]),
+                              float(net["stdp_tau_minus"][slot]), float(net["stdp_dt"][slot]), on)
+            net["do_plasticity"][slot] = int(on)
+            log.append(("plasticity", i, on))
+        elif op == 8:
+            dn.reset_timing()
+            net.clock = 0                                    # neuron/mod.rs:405-420, 1710-1717
+            net["last_firing_time"][...] = -1
+            if net.n_cells:
+                net["st_last_firing_time"][...] = -1
+                net["st_clock"][...] = 0
+            log.append(("reset_timing",))
+        elif op == 9:
+            # parameters and flags rewritten wholesale (uniform-parameter table, static counts, live transmitter types)
+            nn = net.n_neurons
+            net["gap_conductance"] = float(rng.uniform(0.5, 12.0)) if rng.integers(0, 2) else rng.uniform(0.5, 12.0, nn).astype(np.float32)
+            net["nt_flags"][...] = rng.random((nn, 3)) < 0.5
+            net["nt_t"][...] = net["nt_t"] * net["nt_flags"]
+            net["rc_flags"][...] = rng.random((nn, 3)) < 0.5
+            parity.push_state(dn, net)
+            log.append(("parameters",))
+        elif op == 10:
+            el, ch = [(True, False), (True, True), (False, True)][int(rng.integers(0, 3))]
+            dn.set_synapses(el, ch)
+            net.electrical, net.chemical = el, ch
+            log.append(("synapses", el, ch))
+        elif op == 11 and net.n_tot:
+            # the weights of the existing edges rewritten (same mask)
+            w = rng.uniform(-0.5, 2.0, net["weights"].shape).astype(np.float32) * net["connections"]
+            net["weights"][...] = w
+            if plan["csr"]:
+                dn.set_graph_csr(*parity.csr_for_posts(net, dn.owned))
+            else:
+                dn.set_graph_rows(0, net["weights"], net["connections"].astype(np.uint32))
+            log.append(("weights",))
+        elif op == 12 and cells:
+            i = int(rng.choice(cells))
+            first, count, _ = ranges[i]
+            if net.st_kind in (ob.ST_POISSON, ob.ST_BCM_POISSON):
+                seeds = rng.integers(1, 2**32 - 1, count, dtype=np.uint32)
+                dn.set_attr(i, "seed", seeds)
+                net["st_seed"][first:first + count] = seeds
+                log.append(("seeds", i))
+    dn.run(5)
+    net.run(5)
+    try:
+        parity.assert_state_equal(net, parity.pull_state(dn, net))
+        parity.assert_graph_equal(net, dn)
+        assert dn.clock == net.clock
+    except AssertionError as e:
+        raise AssertionError(f"{e}; sequence: {log}") from e
+    dn.close()
