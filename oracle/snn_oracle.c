@@ -103,7 +103,9 @@ float snn_o_powf_export(float x, float y) { return snn_o_powf(x, y); }
  * 3 powf(x, y).  All cores; the GPU parity test walks the whole 2^32 pattern space in chunks with it. */
 void snn_o_math_bits(int which, uint32_t first, uint32_t stride, uint64_t count, float y, float *out)
 {
-#pragma omp parallel for schedule(static)
+    /* (a handful of values is evaluated by the caller's thread: a team of as many threads as the box shows CPUs -- 256 on the
+     * GPU boxes, of which a container may use 16 -- costs tens of milliseconds per region once the cores are oversubscribed) */
+#pragma omp parallel for schedule(static) if (count >= 4096)
     for (uint64_t i = 0; i < count; i++) {
         const float x = snn_o_asfloat(first + (uint32_t)i * stride);
         out[i] = which == 0 ? snn_o_expf(x) : which == 1 ? snn_o_pow3f(x) : which == 2 ? snn_o_pow4f(x) : snn_o_powf(x, y);

@@ -18,6 +18,16 @@ def pytest_configure(config):
     subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=True)
 
 
+def pytest_collection_modifyitems(config, items):
+    # no test may sit on a GPU box for ever: with pytest-timeout present every test without its own limit gets 15 minutes
+    # (the slowest one, the full-size C4 check, takes 20 s) and a hang ends in a stack dump of all threads
+    if not config.pluginmanager.hasplugin("timeout"):
+        return
+    for item in items:
+        if item.get_closest_marker("timeout") is None:
+            item.add_marker(pytest.mark.timeout(900))
+
+
 @pytest.fixture(scope="session")
 def snn():
     """The product package with its HIP library loaded (fails loudly when the .so is missing)."""
