@@ -238,6 +238,14 @@ int snn_shard_ranges(const snn_network_t *net, uint32_t *begin, uint32_t *end, u
  * slices of the SAME step -- call it once the exchange is under way.  snn_step_end does it itself if nobody did. */
 int snn_step_begin_local(snn_network_t *net);
 
+/* A shard handle knows of the neurons owned elsewhere what past exchanges carried.  When the plan comes to need a plane that
+ * was not on the wire -- gap junctions or chemical synapses switched on with snn_set_synapses between two steps -- the owners'
+ * CURRENT state has to travel once before the next step: every rank calls snn_refresh_begin (packs; *needed = 0 and nothing
+ * else when the mirror is current), moves the plan's segments as after snn_step_begin, and calls snn_refresh_end.
+ * snn_run_sharded and snn_run_sharded_custom do this by themselves. */
+int snn_refresh_begin(snn_network_t *net, int *needed);
+int snn_refresh_end(snn_network_t *net);
+
 enum { SNN_EXCHANGE_ALLGATHER = 0, SNN_EXCHANGE_HALO = 1 };
 typedef struct snn_exchange_plan {
     int32_t mode;                 /* SNN_EXCHANGE_ALLGATHER | SNN_EXCHANGE_HALO */

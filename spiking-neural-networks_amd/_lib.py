@@ -142,6 +142,8 @@ SIGNATURES = {
     "snn_step_begin": (C.c_int, [H]),
     "snn_step_end": (C.c_int, [H]),
     "snn_step_begin_local": (C.c_int, [H]),
+    "snn_refresh_begin": (C.c_int, [H, C.POINTER(C.c_int)]),
+    "snn_refresh_end": (C.c_int, [H]),
     "snn_exchange_plan_get": (C.c_int, [H, C.c_void_p]),
     "snn_exchange_peers": (C.c_int, [H, u64p, u64p, u64p, u64p]),
     "snn_halo_needs": (C.c_int, [H, C.c_uint32, u32p, C.c_uint32, u32p]),

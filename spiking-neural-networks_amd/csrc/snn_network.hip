@@ -994,6 +994,31 @@ int snn_step_end(snn_network_t *net)
     return SNN_OK;
 }
 
+int snn_refresh_begin(snn_network_t *net, int *needed)
+{
+    if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
+    if (!net->finalized || !net->sharded) return fail(SNN_ERR_BAD_STATE, "not a finalized shard handle");
+    HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
+    TRY(end_run(net));
+    TRY(ensure_exchange_plan(net));
+    const bool stale = mirror_stale(net);
+    if (needed) *needed = stale ? 1 : 0;
+    if (!stale) return SNN_OK;
+    TRY(refresh_pack(net));
+    if (!net->external_stream) HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
+    return SNN_OK;
+}
+
+int snn_refresh_end(snn_network_t *net)
+{
+    if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
+    if (!net->finalized || !net->sharded) return fail(SNN_ERR_BAD_STATE, "not a finalized shard handle");
+    HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
+    TRY(refresh_unpack(net));
+    if (!net->external_stream) HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
+    return SNN_OK;
+}
+
 int snn_exchange_plan_get(snn_network_t *net, snn_exchange_plan *plan)
 {
     if (!net || !plan) return fail(SNN_ERR_BAD_ARG, "null argument");
@@ -1241,6 +1266,11 @@ int snn_run_sharded_custom(snn_network_t *net, snn_exchange_fn exchange, void *u
     TRY(begin_run(net, iterations));
     // the direct form of a sparse halo run (rows gather from the received segments): with the do-nothing transport, or when
     // the caller's function reads the segment pointers of every step from snn_exchange_plan_get ("halo_direct" 2)
+    if (mirror_stale(net)) {
+        TRY(refresh_pack(net));
+        if (exchange(user, net->stream) != 0) return fail(SNN_ERR_QUEUE, "the caller's exchange function failed");
+        TRY(refresh_unpack(net));
+    }
     if (net->halo_direct == 2 || exchange == &snn_exchange_noop) TRY(direct_begin(net));
     int rc = SNN_OK;
     for (uint64_t it = 0; it < iterations && rc == SNN_OK; ++it) {
@@ -1324,6 +1354,18 @@ int snn_run_sharded(snn_network_t *net, void *nccl_comm, uint64_t iterations)
     // cross-stream events -- the step is its kernels
     bool travels = net->x_mode == SNN_EXCHANGE_ALLGATHER;
     for (uint32_t p = 0; p < net->n_shards && !travels; ++p) travels = net->x_send_words[p] || net->x_recv_words[p];
+    if (mirror_stale(net)) {
+        // a plane the plan needs was not on the wire so far: the owners' current state travels once before the first step
+        TRY(refresh_pack(net));
+        if (travels) {
+            HIP_TRY(hipEventRecord(net->ev_packed, net->stream), SNN_ERR_QUEUE);
+            HIP_TRY(hipStreamWaitEvent(net->comm_stream, net->ev_packed, 0), SNN_ERR_QUEUE);
+            TRY(enqueue_exchange(R, net, comm, net->comm_stream));
+            HIP_TRY(hipEventRecord(net->ev_exchanged, net->comm_stream), SNN_ERR_QUEUE);
+            HIP_TRY(hipStreamWaitEvent(net->stream, net->ev_exchanged, 0), SNN_ERR_QUEUE);
+        }
+        TRY(refresh_unpack(net));
+    }
     if (travels) TRY(direct_begin(net));          // sparse halo runs: the rows gather from the received segments themselves
     int rc = SNN_OK;
     auto hip_step = [&](hipError_t e, int code) { if (!rc && e != hipSuccess) rc = fail(code, hipGetErrorString(e)); };

@@ -399,6 +399,40 @@ int enqueue_exchange(Rccl *R, snn_network *net, ncclComm_t comm, hipStream_t str
     return SNN_OK;
 }
 
+// The mirror of a shard handle holds, of the neurons owned elsewhere, what past exchanges carried.  When the plan asks for a
+// plane that was not on the wire (gap junctions or chemical synapses switched on between two runs) the owners' CURRENT values of
+// the plan's planes travel once before the next step: refresh_pack -> the exchange -> refresh_unpack.  (The spike bits travel
+// with them and restate the last step's flags and stamps: idempotent.)
+uint32_t plan_plane_mask(const snn_network *net)
+{
+    uint32_t m = 0;
+    for (uint32_t s = 0; s < net->x_planes; ++s) m |= 1u << net->x_plane_id[s];
+    return m;
+}
+bool mirror_stale(const snn_network *net)
+{
+    return net->sharded && net->n_shards > 1 && (plan_plane_mask(net) & ~net->mirror_mask) != 0;
+}
+int refresh_pack(snn_network *net)
+{
+    if (!net->seg_n[0] || !net->seg_max[0]) return SNN_OK;
+    hipLaunchKernelGGL(k_exchange_pack, dim3((net->seg_max[0] + 255) / 256, net->seg_n[0]), dim3(256), 0, net->stream, wire_args(net, 0));
+    HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+    net->send_bits_clean = false;
+    return SNN_OK;
+}
+int refresh_unpack(snn_network *net)
+{
+    if (net->seg_n[1] && net->seg_max[1] && net->nn) {
+        WireArgs a = wire_args(net, 1);
+        a.clock = net->clock - 1;                                 // the step whose spike flags are restated
+        hipLaunchKernelGGL(k_exchange_unpack, dim3((net->seg_max[1] + 255) / 256, net->seg_n[1]), dim3(256), 0, net->stream, a);
+        HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+    }
+    net->mirror_mask |= plan_plane_mask(net);
+    return SNN_OK;
+}
+
 // Opens / closes the direct form of a library-driven run (snn_network_state.hpp).  Begin: the receive set the first step reads
 // is filled from the mirror (what earlier exchanges left there), both sets of outgoing bitmaps are zeroed.  End: the arrivals
 // of the last step go into the mirror and the current shadow, as the closing launch of an ordinary step would have done.

@@ -121,6 +121,10 @@ struct snn_network {
     RowMap rowmap{};
     // ---- exchange plan (snn_kernels_exchange.hpp), rebuilt by ensure_exchange_plan when x_dirty ----
     bool x_dirty = true;
+    // planes (bit = plane id) whose values of the neurons owned ELSEWHERE are current in this handle's mirror: everything after
+    // the attributes were written, then only what the exchange carried.  A plan that needs more (a synapse kind switched on
+    // between two runs) calls for one exchange of the current state before the next step (refresh_*, snn_network_exchange.hpp)
+    uint32_t mirror_mask = 0xFFFFFFFFu;
     bool x_agreed = false;                      // the ranks of the communicator compared their plans (snn_run_sharded)
     int x_mode = SNN_EXCHANGE_ALLGATHER;
     uint32_t x_planes = 0, x_plane_id[WIRE_MAX_PLANES] = {0, 0, 0, 0};

@@ -917,9 +917,13 @@ int step_begin(snn_network *net)
     return SNN_OK;
 }
 
+uint32_t plan_plane_mask(const snn_network *net);
+
 // second half: remote last_firing_time, plasticity, histories, clock, spike trains (steps 3-6)
 int step_end(snn_network *net)
 {
+    // of the neurons owned elsewhere only what this step's exchange carries stays current in the mirror
+    if (net->sharded && net->n_shards > 1) net->mirror_mask = plan_plane_mask(net);
     TRY(step_interior(net));
     if (net->step_packed) {
         // the fast sparse step (csr_fast_step): unpack, spike trains and the clearing of the outgoing bitmaps in ONE launch

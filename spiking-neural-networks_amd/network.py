@@ -212,6 +212,15 @@ class DeviceNetwork:
     def step_begin_local(self):
         self._check(self._L.snn_step_begin_local(self._h))
 
+    def refresh_begin(self):
+        """packs the current state of the plan's planes when the mirror lacks one of them (snn_refresh_begin); True if so"""
+        needed = C.c_int(0)
+        self._check(self._L.snn_refresh_begin(self._h, C.byref(needed)))
+        return bool(needed.value)
+
+    def refresh_end(self):
+        self._check(self._L.snn_refresh_end(self._h))
+
     def exchange_plan(self):
         """The shard handle's exchange plan (snn_exchange_plan + per-peer segments): a dict with mode ("allgather" |
         "halo"), n_shards, shard_index, shard_stride, planes, plane_id, send / recv (device pointers), send_words /

@@ -134,6 +134,16 @@ class LocalExchange:
             import torch
             torch.cuda.synchronize()
 
+    def refresh_state(self):
+        """after snn_set_synapses switched a synapse kind ON: the owners' current state of the plan's planes travels once"""
+        self.refresh()
+        needed = [h.refresh_begin() for h in self.handles]
+        if any(needed):
+            assert all(needed), "the ranks disagree on whether their mirrors are current"
+            self.exchange()
+            for h in self.handles:
+                h.refresh_end()
+
     def step(self, sync=True):
         for h in self.handles:
             h.step_begin()

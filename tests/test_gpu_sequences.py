@@ -119,3 +119,111 @@ def test_random_call_sequence(snn, seed):
     except AssertionError as e:
         raise AssertionError(f"{e}; sequence: {log}") from e
     dn.close()
+
+
+def usable_sharded(seed):
+    net, plan = draw(1000 + seed)
+    return plan["rewards"] is None and not net["plasticity_kind"].any() and net.n_neurons > 0 and plan["shards"] > 1
+
+
+SHARDED_SEEDS = [s for s in range(int(os.environ.get("SNN_RANDOM_SEEDS_SEQUENCES", "90")) * 2) if usable_sharded(s)]
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("seed", SHARDED_SEEDS)
+def test_random_call_sequence_on_shard_handles(snn, seed):
+    """the same idea on G shard handles: stretches of the library's own loop (snn_run_sharded, one host thread per rank, replaced
+    collectives) alternate with host-driven steps, and between them the exchange plan is made to change (synapse kinds), state
+    is rewritten, switches are flipped -- the plan, its agreement between the ranks and the direct form are rebuilt on the way"""
+    import torch
+    from snn_amd import parallel
+    from test_gpu_library_loop_threads import run_ranks
+    net, plan = draw(1000 + seed)
+    rng = np.random.default_rng(400_000 + seed)
+    g = plan["shards"]
+    handles = [make_handle(snn, net, plan, shard=(r, g)) for r in range(g)]
+    dev = torch.device("cuda", 0)
+    ex = parallel.LocalExchange(handles, dev, halo=plan["csr"])
+    ranges = net.layout.ranges()
+    lattices = [i for i, _, _ in net.layout.lattices if ranges[i][1]]
+    lo, hi = float(net["current_voltage"].min()) - 1.0, float(net["current_voltage"].max()) + 1.0
+    log = []
+    for _ in range(int(rng.integers(3, 8))):
+        op = int(rng.integers(0, 8))
+        if op <= 1:
+            k = int(rng.integers(1, 50))
+            tc = parallel.ThreadCollectives(g, dev)
+            try:
+                run_ranks(handles, tc, [k])
+            finally:
+                tc.close()
+            net.run(k)
+            log.append(("library loop", k))
+        elif op == 2:
+            k = int(rng.integers(1, 20))
+            ex.refresh_state()                    # (a synapse kind may have been switched on: the mirrors catch up first)
+            for _ in range(k):
+                for h in handles:
+                    h.step_begin_local()
+                    h.step_begin()
+                ex.exchange()
+                for h in handles:
+                    h.step_end()
+            net.run(k)
+            log.append(("host-driven", k))
+        elif op == 3:
+            i = int(rng.choice(lattices))
+            first, count, _ = ranges[i]
+            v = rng.uniform(lo, hi, count).astype(np.float32)
+            for h in handles:
+                h.set_attr(i, "current_voltage", v)
+            net["current_voltage"][first:first + count] = v
+            log.append(("voltage", i))
+        elif op == 4:
+            name = str(rng.choice(list(SWITCHES) + ["halo_direct", "cells_in_step"]))
+            value = int(rng.choice(SWITCHES.get(name, (0, 1))))
+            for h in handles:
+                h.set_option(name, value)
+            log.append(("switch", name, value))
+        elif op == 5:
+            el, ch = [(True, False), (True, True), (False, True)][int(rng.integers(0, 3))]
+            for h in handles:
+                h.set_synapses(el, ch)
+            net.electrical, net.chemical = el, ch
+            log.append(("synapses", el, ch))
+        elif op == 6:
+            slot = int(rng.integers(0, len(net.layout.lattices)))
+            i = net.layout.lattices[slot][0]
+            on = bool(rng.integers(0, 2))
+            for h in handles:
+                h.set_plasticity(i, float(net["stdp_a_plus"][slot]), float(net["stdp_a_minus"][slot]), float(net["stdp_tau_plus"][slot]),
+                                 float(net["stdp_tau_minus"][slot]), float(net["stdp_dt"][slot]), on)
+            net["do_plasticity"][slot] = int(on)
+            log.append(("plasticity", i, on))
+        elif op == 7:
+            for h in handles:
+                if h.csr:
+                    parity.assert_graph_equal(net, h)
+            log.append(("read",))
+    tc = parallel.ThreadCollectives(g, dev)
+    try:
+        run_ranks(handles, tc, [4])
+    finally:
+        tc.close()
+    net.run(4)
+    try:
+        for h in handles:
+            st = parity.pull_state(h, net)
+            parity.assert_shard_view_equal(h, st, net)
+            assert h.clock == net.clock
+            if h.csr:
+                parity.assert_graph_equal(net, h)
+            elif net.n_tot:
+                b, e = h.post_begin, h.post_end
+                w, _ = h.get_graph_rows(0, net.n_tot)
+                ow = np.where(net["connections"] != 0, net["weights"], np.float32(0))
+                assert np.array_equal(parity.bits(w[:, b:e]), parity.bits(ow[:, b:e])), "weights"
+    except AssertionError as e:
+        raise AssertionError(f"{e}; sequence: {log}") from e
+    for h in handles:
+        h.close()
