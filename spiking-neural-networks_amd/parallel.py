@@ -317,6 +317,14 @@ class ShardedStepper:
         assert self.plan["n_shards"] == self.world and self.plan["shard_index"] == self.rank
         self.is_cuda = self.recv.is_cuda or self.send.is_cuda
 
+    def refresh_state(self):
+        """after a synapse kind was switched ON (set_synapses / transmitter flags): re-read the plan and let the owners' current
+        state of its planes travel once, so that the mirrors hold what the next step reads (every rank calls it)"""
+        self.refresh_plan()
+        if hasattr(self.backend, "refresh_begin") and self.backend.refresh_begin():
+            self.exchange()
+            self.backend.refresh_end()
+
     def exchange(self, async_op=False):
         """move the packed segments; async_op=True returns the pending work handle"""
         if self.world == 1 and not self._always:
