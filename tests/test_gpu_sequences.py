@@ -34,7 +34,7 @@ def test_random_call_sequence(snn, seed):
     lo, hi = float(net["current_voltage"].min()) - 1.0, float(net["current_voltage"].max()) + 1.0
     log = []
     for _ in range(int(rng.integers(4, 10))):
-        op = int(rng.integers(0, 13))
+        op = int(rng.integers(0, 14))
         if op <= 2:
             k = int(rng.integers(1, 70))
             dn.run(k)
@@ -110,6 +110,22 @@ def test_random_call_sequence(snn, seed):
                 dn.set_attr(i, "seed", seeds)
                 net["st_seed"][first:first + count] = seeds
                 log.append(("seeds", i))
+        elif op == 13:
+            # a recorded stretch: histories switched on (strided capture), compared, switched off again
+            k, every = int(rng.integers(1, 40)), int(rng.choice([1, 1, 2, 3]))
+            dn.reset_history()
+            dn.set_history(voltage=True, spikes=True)
+            dn.set_history_stride(every)
+            dn.run(k)
+            net.run(k, voltage_history=True, spike_history=True)
+            keep = np.arange(0, k, every)
+            for i in lattices:
+                first, count, _ = ranges[i]
+                assert np.array_equal(dn.spike_history(i), net.spike_history[keep, first:first + count]), f"raster; sequence: {log}"
+                assert np.array_equal(parity.bits(dn.voltage_history(i)), parity.bits(net.voltage_history[keep, first:first + count])), f"trace; sequence: {log}"
+            dn.set_history(voltage=False, spikes=False)
+            dn.set_history_stride(1)
+            log.append(("recorded", k, every))
     dn.run(5)
     net.run(5)
     try:
