@@ -55,11 +55,15 @@ def run_in_lockstep(handles, calls):
             errors.append(e)
             barrier.abort()
 
-    threads = [threading.Thread(target=work, args=(r,)) for r in range(g)]
+    threads = [threading.Thread(target=work, args=(r,), daemon=True) for r in range(g)]
     for t in threads:
         t.start()
-    for t in threads:
-        t.join()
+    try:
+        for t in threads:
+            t.join()
+    except BaseException:                # (pytest-timeout interrupts the join: release the ranks, do not outlive the test)
+        barrier.abort()
+        raise
     if errors:
         raise errors[0]
 

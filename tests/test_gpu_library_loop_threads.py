@@ -27,11 +27,17 @@ def run_ranks(handles, tc, calls):
             errors.append(e)
             tc.abort()
 
-    threads = [threading.Thread(target=work, args=(r,)) for r in range(len(handles))]
+    # daemon threads, and a barrier that is broken when the waiting main thread is interrupted (pytest-timeout): a stuck rank
+    # must neither outlive the test nor keep the interpreter from exiting
+    threads = [threading.Thread(target=work, args=(r,), daemon=True) for r in range(len(handles))]
     for t in threads:
         t.start()
-    for t in threads:
-        t.join()
+    try:
+        for t in threads:
+            t.join()
+    except BaseException:
+        tc.abort()
+        raise
     if errors:
         raise errors[0]
 
