@@ -124,3 +124,27 @@ def test_replaced_collectives_are_restored(snn, collectives):
     assert np.array_equal(parity.bits(st["current_voltage"]), parity.bits(net["current_voltage"]))
     dn.close()
     comm.close()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("n_shards,by_lattice", [(4, True), (5, False), (7, False)])
+def test_larger_sparse_network_in_the_library_loop(snn, collectives, n_shards, by_lattice):
+    """4 x (32 x 32) neurons + Poisson cells: every rank has several workgroups of rows (dealt to the XCDs in bands), border and
+    interior slices, a halo of more than one segment; shard counts that do not divide the population"""
+    net = c5_structure(32)
+    handles = [parity.device_from_oracle(snn, net, shard=(r, n_shards), csr=True, by_lattice=by_lattice) for r in range(n_shards)]
+    tc = collectives(n_shards)
+    run_ranks(handles, tc, [210, 90])
+    net.n_threads = 8
+    net.run(300, spike_history=True)
+    assert net.spike_history.sum() > 20
+    for h in handles:
+        assert h.clock == 300
+        if h.owned.size:
+            assert h.stat("halo_direct_steps") == 300
+        st = parity.pull_state(h, net)
+        parity.assert_shard_view_equal(h, st, net)
+        cells = h.cells_read()
+        assert np.array_equal(parity.bits(st["st_seed"][cells]), parity.bits(net["st_seed"][cells]))
+        assert np.array_equal(parity.bits(st["w_value"][h.owned]), parity.bits(net["w_value"][h.owned]))
+        h.close()
