@@ -1,6 +1,21 @@
 import os
 import sys
 
+# The oracle's OpenMP runtime (libgomp, shared with torch) sees every CPU of the box (256 on the GPU boxes) while the container may
+# run 16 of them: with its default active waiting, teams sized for the visible CPUs spin against the quota and single calls take
+# tens of milliseconds once the process holds a few more threads (the full GPU suite went from 5 to 19 minutes, one oracle call in
+# a loop sat for 15).  Before anything loads libgomp: sleep at barriers, and size default teams by what the container may use.
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+if "OMP_NUM_THREADS" not in os.environ:
+    _cpus = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        _quota, _period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if _quota != "max":
+            _cpus = min(_cpus, max(1, int(int(_quota) / int(_period))))
+    except (OSError, ValueError):
+        pass
+    os.environ["OMP_NUM_THREADS"] = str(max(1, min(_cpus, 64)))
+
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
