@@ -18,9 +18,6 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# (the CPU baseline's OpenMP teams sleep at their barriers: the box shows more CPUs than the container may run, and threads
-#  spinning against that quota slow the host side of the whole run down; set before anything loads libgomp)
-os.environ.setdefault("OMP_WAIT_POLICY", "passive")
 
 ROWS = COLS = 256
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling is ~6.3 TB/s
