@@ -217,7 +217,9 @@ int snn_run(snn_network_t *net, uint64_t iterations);
  *   (c) snn_step_begin -> the caller moves the segments described by snn_exchange_plan_get / snn_exchange_peers with
  *       its own transport (torch.distributed, device-to-device copies between handles of one process) -> snn_step_end.
  * snn_step_begin computes the local neurons' step and packs the outgoing segments; snn_step_end applies the incoming
- * segments (state mirror, last_firing_time), then plasticity on the local columns, histories, clock, spike trains. */
+ * segments (state mirror, last_firing_time), then plasticity on the local columns, histories, clock, spike trains.
+ * (After a synapse kind was switched ON between two steps, (b) and (c) start with snn_refresh_begin -> the exchange ->
+ * snn_refresh_end, see below; (a) does it by itself.) */
 int snn_step_begin(snn_network_t *net);
 int snn_step_end(snn_network_t *net);
 /* Sparse handles may shard BY LATTICE instead of by one contiguous slot of the index space: shard s owns slab s (equal
