@@ -447,8 +447,12 @@ int snn_set_option(snn_network_t *net, const char *name, int value);
  * many steps per launch), "persistent_run_steps" (steps those launches covered), "persistent_run_fallbacks" (launches that
  * gave up and were rolled back, see above); with option "run_timing": "run_timing_poll" / "_barrier" / "_turns" /
  * "_update" (shader clocks of workgroup 0 over the last launch) and "run_timing_steps" (its steps); "halo_direct_steps"
- * (steps of library-driven runs whose rows gathered the halo from the received segments).  Unknown names fail with
- * SNN_ERR_BAD_ARG. */
+ * (steps of library-driven runs whose rows gathered the halo from the received segments); the form every step outside a
+ * one-launch run took: "steps_dense_one_launch" (k_step_resident), "steps_sparse_one_launch" (k_step_csr over all rows),
+ * "steps_sparse_split" (border + interior launches of a shard handle), "steps_two_kernel" (input pass + k_update); and
+ * what happened between run calls: "shadow_refreshes" (the two shadow copies of the exchanged state were rebuilt),
+ * "view_refreshes" (the spike-train cells' gap-junction values were recomputed), "history_regrows" (the history buffers
+ * were reallocated).  Unknown names fail with SNN_ERR_BAD_ARG. */
 int snn_get_stat(snn_network_t *net, const char *name, uint64_t *value);
 
 /* ---- measurement ----------------------------------------------------------------------- */

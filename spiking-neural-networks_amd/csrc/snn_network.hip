@@ -1504,6 +1504,13 @@ int snn_get_stat(snn_network_t *net, const char *name, uint64_t *value)
     else if (n == "persistent_run_steps") *value = net->stat_run_steps;
     else if (n == "persistent_run_fallbacks") *value = net->stat_run_fallbacks;
     else if (n == "halo_direct_steps") *value = net->stat_direct_steps;
+    else if (n == "steps_dense_one_launch") *value = net->stat_steps_dense_one_launch;
+    else if (n == "steps_sparse_one_launch") *value = net->stat_steps_sparse_one_launch;
+    else if (n == "steps_sparse_split") *value = net->stat_steps_sparse_split;
+    else if (n == "steps_two_kernel") *value = net->stat_steps_two_kernel;
+    else if (n == "shadow_refreshes") *value = net->stat_shadow_refreshes;
+    else if (n == "view_refreshes") *value = net->stat_view_refreshes;
+    else if (n == "history_regrows") *value = net->stat_history_regrows;
     else if (n == "run_timing_poll") *value = net->run_timing_last[0];
     else if (n == "run_timing_barrier") *value = net->run_timing_last[1];
     else if (n == "run_timing_turns") *value = net->run_timing_last[2];

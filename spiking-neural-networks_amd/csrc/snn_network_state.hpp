@@ -220,6 +220,10 @@ struct snn_network {
     uint32_t *run_failed = nullptr;       // hipHostMalloc: [0] a run gave up, [1] the co-residency probe said no
     uint32_t run_probed_grid = 0;         // grid size the probe last vouched for
     uint64_t stat_run_launches = 0, stat_run_steps = 0, stat_run_fallbacks = 0;
+    // which form each step took (statistics "steps_*"): k_step_resident, k_step_csr whole, k_step_csr border + interior,
+    // input pass + k_update
+    uint64_t stat_steps_dense_one_launch = 0, stat_steps_sparse_one_launch = 0, stat_steps_sparse_split = 0, stat_steps_two_kernel = 0;
+    uint64_t stat_shadow_refreshes = 0, stat_view_refreshes = 0, stat_history_regrows = 0;
     uint32_t run_spin_limit = RUN_RESIDENT_SPIN_LIMIT;   // option "run_resident_spin_limit"
     uint32_t run_fault_step = 0;                         // option "run_resident_fault_step" (test hook, see ResidentRunArgs)
     // every small device array of the handle (all per-neuron / per-cell state, the exchange buffer and its shadows, the

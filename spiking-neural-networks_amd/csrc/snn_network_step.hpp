@@ -518,6 +518,7 @@ int fused_step_args(snn_network *net, InputsArgs &a, UpdateArgs &u, bool in_plac
             HIP_TRY(hipMemcpyAsync(net->shadow[i], net->xbuf, xelems * 4, hipMemcpyDeviceToDevice, net->stream),
                     SNN_ERR_BUFFER_WRITE);
         net->shadow_valid = true;
+        net->stat_shadow_refreshes += 1;
     }
     float *cur = in_place ? net->xbuf : net->shadow[net->shadow_cur];
     float *next = in_place ? nullptr : net->shadow[net->shadow_cur ^ 1];
@@ -898,8 +899,9 @@ int step_begin(snn_network *net)
                            net->nn, net->drive_seed, net->clock, net->drive_threshold, net->drive_voltage);
         HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
     }
-    if (fused_step_applies(net)) return launch_step_resident(net);
+    if (fused_step_applies(net)) { net->stat_steps_dense_one_launch += 1; return launch_step_resident(net); }
     if (csr_fast_step(net)) {
+        net->stat_steps_sparse_split += 1;
         // border slices first, writing the outgoing segments themselves; the interior slices follow once the caller has
         // started the exchange (step_interior: snn_run_sharded, snn_step_begin_local, or at the latest step_end)
         // (direct runs: the set this step packs into was cleared behind the previous step's rows, or at the run's start)
@@ -910,7 +912,8 @@ int step_begin(snn_network *net)
         net->interior_pending = true;
         return SNN_OK;
     }
-    if (fused_csr_step_applies(net)) return launch_step_csr(net);
+    if (fused_csr_step_applies(net)) { net->stat_steps_sparse_one_launch += 1; return launch_step_csr(net); }
+    net->stat_steps_two_kernel += 1;
     TRY(launch_inputs(net, net->local_inputs_done ? INPUTS_REMOTE : INPUTS_ALL));
     net->local_inputs_done = false;
     TRY(launch_update(net));
@@ -1014,6 +1017,7 @@ int grow_history(snn_network *net, uint64_t extra)
     for (const auto &l : net->lattices)
         TRY(regrow(reinterpret_cast<void **>(&net->whist[l.slot]), (size_t)l.count * l.count * 4, net->want_whist[l.slot] != 0));
     net->hist_cap = cap;
+    net->stat_history_regrows += 1;
     return SNN_OK;
 }
 
@@ -1039,7 +1043,7 @@ int begin_run(snn_network *net, uint64_t iterations)
         // pageable source: the copy is staged before the call returns, so the host vector may change afterwards
         HIP_TRY(hipMemcpyAsync(net->st_clock_dev, net->st_clock.data(), net->st_clock.size() * sizeof(long long),
                                hipMemcpyHostToDevice, net->stream), SNN_ERR_BUFFER_WRITE);
-        if (net->view_dirty) TRY(launch_spike_trains(net, 0, 0, net->clock));
+        if (net->view_dirty) { net->stat_view_refreshes += 1; TRY(launch_spike_trains(net, 0, 0, net->clock)); }
     }
     net->view_dirty = false;
     net->run_step_offset = 0;

@@ -1,0 +1,150 @@
+"""Contention campaign for the randomized differential tests (test infrastructure; runs on the GPU box).
+
+    python3 tests/campaign.py --minutes 20 --workers 6 --streamers 2 --out gpurun_out/campaign_a \\
+        --tests test_gpu_randomized:test_random_network,test_gpu_persistent_run:test_random_fault_injection
+
+Reproduces deliberately what the long pytest-xdist campaigns of round 3 did by accident: several PROCESSES on one GPU.
+`workers` processes each walk their own stripe of seeds through the listed seeded test functions (called directly, the
+`snn` fixture is the package); `streamers` processes keep the device busy with C2-shaped input passes over a matrix of a few
+GiB, so that the workers' launches queue behind long kernels and the one-launch forms have to share the CUs.  Every
+mismatch leaves a repro bundle (tests/repro.py) under <out>/repro; <out>/summary.json holds executions and failures per test
+function.  One line per worker and minute goes to stdout."""
+import argparse
+import importlib
+import json
+import os
+import subprocess
+import sys
+import time
+import traceback
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+for p in (ROOT, HERE):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def small_dense_case(seed):
+    """test_random_network cases of the class both round-3 failures fell in: one handle, dense graph, one or few workgroups"""
+    import test_gpu_randomized as t
+    net, plan = t.draw(1000 + seed)
+    return plan["shards"] == 1 and not plan["csr"] and net.n_neurons + net.n_cells <= 256
+
+
+FILTERS = {"small_dense": small_dense_case}
+
+
+def worker(args):
+    import conftest  # noqa: F401  (OpenMP settings of the oracle before libgomp loads)
+    os.environ["SNN_CAMPAIGN"] = "1"
+    os.environ["SNN_REPRO_DIR"] = os.path.join(args.out, "repro")
+    import snn_amd
+    snn_amd._lib.load()
+    fns = []
+    for spec in args.tests.split(","):
+        mod, name = spec.split(":")
+        fns.append((spec, getattr(importlib.import_module(mod), name)))
+    accept = FILTERS.get(args.filter)
+    deadline = time.time() + args.minutes * 60
+    counts = {spec: [0, 0] for spec, _ in fns}            # executions, failures
+    log = open(os.path.join(args.out, f"worker-{args.index}.jsonl"), "a")
+    seed, last_report, recent = args.first_seed + args.index, time.time(), []
+    while time.time() < deadline and not os.path.exists(os.path.join(args.out, "stop")):
+        if accept is None or accept(seed):
+            for spec, fn in fns:
+                counts[spec][0] += 1
+                recent = (recent + [[spec, seed]])[-12:]
+                try:
+                    fn(snn_amd, seed)
+                except BaseException as e:           # noqa: BLE001 -- a campaign records everything and goes on
+                    if isinstance(e, KeyboardInterrupt):
+                        raise
+                    if type(e).__name__ == "Skipped":
+                        continue
+                    counts[spec][1] += 1
+                    log.write(json.dumps({"worker": args.index, "test": spec, "seed": seed, "error": type(e).__name__,
+                                          "message": str(e)[:6000], "preceding": recent,
+                                          "traceback": traceback.format_exc()[-3000:]}) + "\n")
+                    log.flush()
+                    print(f"[worker {args.index}] FAILURE {spec} seed {seed}: {str(e)[:300]}", flush=True)
+        seed += args.workers
+        if time.time() - last_report > 60:
+            last_report = time.time()
+            print(f"[worker {args.index}] seed {seed} " + " ".join(f"{s.split(':')[1]}={c[0]}/{c[1]}" for s, c in counts.items()), flush=True)
+    log.write(json.dumps({"worker": args.index, "done": True, "counts": counts, "next_seed": seed}) + "\n")
+    log.close()
+
+
+def streamer(args):
+    """C2-shaped passes over a dense matrix of `side`^4 * 4 bytes until the campaign ends"""
+    import snn_amd
+    n = args.side * args.side
+    net = snn_amd.DeviceNetwork(model=0)
+    net.add_lattice(0, args.side, args.side)
+    net.finalize()
+    net.fill_graph_synthetic(7 + args.index, 0.5, 1.5)
+    net.set_synapses(True, False)
+    deadline = time.time() + args.minutes * 60
+    runs = 0
+    while time.time() < deadline and not os.path.exists(os.path.join(args.out, "stop")):
+        net.run(args.streamer_steps)
+        runs += 1
+        if args.streamer_pause_ms:
+            time.sleep(args.streamer_pause_ms / 1000.0)
+    net.close()
+    print(f"[streamer {args.index}] {runs} runs of {args.streamer_steps} steps over {n} neurons", flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--role", default="main", choices=["main", "worker", "streamer"])
+    ap.add_argument("--index", type=int, default=0)
+    ap.add_argument("--workers", type=int, default=6)
+    ap.add_argument("--streamers", type=int, default=2)
+    ap.add_argument("--minutes", type=float, default=10.0)
+    ap.add_argument("--first-seed", type=int, default=100_000)
+    ap.add_argument("--tests", default="test_gpu_randomized:test_random_network")
+    ap.add_argument("--filter", default="")
+    ap.add_argument("--side", type=int, default=160)                 # 160^2 neurons: a 2.6 GB matrix per streamer
+    ap.add_argument("--streamer-steps", type=int, default=20)
+    ap.add_argument("--streamer-pause-ms", type=float, default=0.0)
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "campaign"))
+    args = ap.parse_args()
+    os.makedirs(os.path.join(args.out, "repro"), exist_ok=True)
+    if args.role == "worker":
+        return worker(args)
+    if args.role == "streamer":
+        return streamer(args)
+    stop = os.path.join(args.out, "stop")
+    if os.path.exists(stop):
+        os.remove(stop)
+    base = [sys.executable, os.path.abspath(__file__)] + [a for a in sys.argv[1:]]
+    t0 = time.time()
+    procs = [subprocess.Popen(base + ["--role", "streamer", "--index", str(i)]) for i in range(args.streamers)]
+    procs += [subprocess.Popen(base + ["--role", "worker", "--index", str(i)]) for i in range(args.workers)]
+    rcs = [p.wait() for p in procs]
+    total, failures = {}, []
+    for i in range(args.workers):
+        path = os.path.join(args.out, f"worker-{i}.jsonl")
+        for line in open(path) if os.path.exists(path) else ():
+            rec = json.loads(line)
+            if rec.get("done"):
+                for spec, (n, f) in rec["counts"].items():
+                    t = total.setdefault(spec, [0, 0])
+                    t[0] += n
+                    t[1] += f
+            else:
+                failures.append({k: rec[k] for k in ("worker", "test", "seed", "error", "message", "preceding")})
+    summary = {"minutes": args.minutes, "wall_s": round(time.time() - t0, 1), "workers": args.workers, "streamers": args.streamers,
+               "streamer_side": args.side, "tests": args.tests, "filter": args.filter, "first_seed": args.first_seed,
+               "executions_and_failures": total, "executions": sum(t[0] for t in total.values()),
+               "failures": sum(t[1] for t in total.values()), "failure_records": failures, "exit_codes": rcs,
+               "environment": {k: v for k, v in os.environ.items() if k.startswith(("SNN_", "AMD_", "HIP_", "HSA_", "OMP_"))}}
+    with open(os.path.join(args.out, "summary.json"), "w") as f:
+        json.dump(summary, f, indent=1)
+    print(json.dumps({k: summary[k] for k in ("wall_s", "executions", "failures", "executions_and_failures", "exit_codes")}))
+
+
+if __name__ == "__main__":
+    main()

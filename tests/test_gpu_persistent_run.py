@@ -217,6 +217,82 @@ def test_random_electrical_networks(snn, seed):
 
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SNN_RANDOM_SEEDS_FAULT", "24"))))          # (env: a longer campaign)
+def test_random_fault_injection(snn, seed):
+    """The give-up -> rollback -> per-step-repeat path of the one-launch run on RANDOM networks (cells, histories, several run
+    calls, voltages rewritten between calls): a random step of a random call withholds workgroup 0's voltages (test hook
+    "run_resident_fault_step", spin limit lowered), the handle may be switched back to the one-launch form afterwards and
+    faulted again.  Everything snn_run hands back must be what the oracle gives, whatever mixture of forms the calls took.
+    A mismatch leaves a repro bundle (tests/repro.py)."""
+    import repro
+    net, calls, history, counts = draw(seed)
+    rng = np.random.default_rng(90_000 + seed)
+    calls = calls + [int(rng.integers(8, 90))]
+    dn = parity.device_from_oracle(snn, net)
+    dn.set_history(voltage=history, spikes=history)
+    dn.set_reduced_history(spike_counts=counts)
+    dn.set_option("run_resident_spin_limit", 1 << int(rng.integers(8, 13)))
+    nn = net.n_neurons
+    alone = nn <= 64 and nn + net.n_cells <= 1024           # one workgroup: nothing travels, nothing can be withheld
+    lo, hi = {ob.IZHIKEVICH: (-65, 30), ob.LIF: (-80, -50), ob.HH: (-75, -40), ob.LEAKY_IZHIKEVICH: (-65, 30)}.get(net.model, (-75, -56))
+    rngs = net.layout.ranges()
+    persistent, want_fallbacks, want_launches, log = True, 0, 0, []
+    hist = {"v": [], "s": [], "stv": []}
+    for k, c in enumerate(calls):
+        fault = int(rng.integers(1, c)) if persistent and c >= 4 and rng.random() < 0.6 else 0     # 1 <= fault < c
+        dn.set_option("run_resident_fault_step", fault)
+        dn.run(c)
+        if persistent and c >= 4:
+            if fault and not alone:
+                want_fallbacks, persistent = want_fallbacks + 1, False
+            else:
+                want_launches += 1
+        net.run(c, voltage_history=history, spike_history=history, spike_counts=counts, st_voltage_history=history and net.n_cells > 0)
+        if history:
+            hist["v"].append(net.voltage_history), hist["s"].append(net.spike_history)
+            if net.n_cells:
+                hist["stv"].append(net.st_voltage_history)
+        entry = {"call": k, "steps": c, "fault_step": fault, "stats_after": repro.device_stats(dn)}
+        if not persistent and rng.random() < 0.5:
+            dn.set_option("persistent_run", 1)
+            persistent, entry["switched_back_on"] = True, True
+        if nn and rng.random() < 0.4:                        # a write behind the stepper's back between two calls
+            v = ob.uniform_array(seed * 100 + k, nn, lo, hi)
+            net["current_voltage"] = v
+            for i, _, _ in net.layout.lattices:
+                first, count, _ = rngs[i]
+                if count:
+                    dn.set_attr(i, "current_voltage", v[first:first + count])
+            entry["voltages_rewritten"] = True
+        log.append(entry)
+    obs, ref = {}, {}
+    for name, a in parity.pull_state(dn, net).items():
+        obs[f"state/{name}"], ref[f"state/{name}"] = a, net[name]
+    for i, _, _ in net.layout.lattices:
+        first, count, _ = rngs[i]
+        if history:
+            obs[f"spikes/{i}"], ref[f"spikes/{i}"] = dn.spike_history(i), np.concatenate(hist["s"])[:, first:first + count]
+            obs[f"voltage/{i}"], ref[f"voltage/{i}"] = dn.voltage_history(i), np.concatenate(hist["v"])[:, first:first + count]
+        if counts:
+            obs[f"counts/{i}"], ref[f"counts/{i}"] = np.asarray(dn.spike_counts(i)).ravel(), net.spike_counts[first:first + count]
+    for i, _, _ in net.layout.st_lattices:
+        first, count, _ = rngs[i]
+        if history:
+            obs[f"voltage/{i}"], ref[f"voltage/{i}"] = dn.voltage_history(i), np.concatenate(hist["stv"])[:, first:first + count]
+    obs["clock"], ref["clock"] = np.array([dn.clock]), np.array([net.clock])
+    stats = repro.device_stats(dn)
+    dn.close()
+    diffs = repro.differences(obs, ref)
+    quiet = "SNN_CAMPAIGN" not in os.environ                # a shared device may fail the co-residency probe: no form is promised then
+    forms_ok = not quiet or (stats["persistent_run_fallbacks"] == want_fallbacks and stats["persistent_run_launches"] == want_launches)
+    if diffs or not forms_ok:
+        meta = {"test": "test_gpu_persistent_run.py::test_random_fault_injection", "seed": seed, "calls": calls, "log": log,
+                "history": history, "counts": counts, "stats": stats, "want_fallbacks": want_fallbacks,
+                "want_launches": want_launches, "differences": diffs}
+        path = repro.dump(f"fault-{seed}", meta, obs, ref)
+        raise AssertionError(f"seed {seed}: {repro.describe(diffs) or 'step forms differ from the plan'} (bundle: {path})")
+
+
 def build_with_cells(model, lattices, st_lattices, st_kind, seed, density=0.5):
     """electrical-only network with Poisson / Rate spike-train lattices as presynaptic rows (no transmitters, no plasticity)"""
     net = parity.make_oracle(parity.Layout(lattices, st_lattices), model=model, st_kind=st_kind, electrical=True, chemical=False)
