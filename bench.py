@@ -20,6 +20,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 ROWS = COLS = 256
+MIN_TIMED_S, MAX_REPEATS = 1.0, 400     # the timed repetitions add up to at least a second (short steps: more repetitions)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling is ~6.3 TB/s
 # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of THIS command (FETCH_SIZE and
 # WRITE_SIZE cannot share a pass); their summaries are committed under profiles/ and quoted here per launch.
@@ -46,6 +47,31 @@ def pmc_source(config, world, rows, cols):
     return {"file": os.path.relpath(path, ROOT), "collected": json.load(open(path)).get("collected"),
             "how": "two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of this command, gfx950 corrections of "
                    "MI355X_MICROARCH.md, per launch of the dominant kernel"}
+
+
+def self_launch(gpus):
+    """`python bench.py --gpus N` (N > 1) without a launcher's environment: start the N ranks as a FRESH child --
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <same
+    arguments>` -- before this process imports torch or makes any GPU call (a process that touched the GPU must never be
+    replaced or re-executed on this pool), relay its stdout (rank 0's JSON line is its last line) and return its exit code.
+    SNN_BENCH_LAUNCHER replaces the `python -m torch.distributed.run` prefix (tests/test_host_logic.py stubs it)."""
+    import shlex
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    prefix = os.environ.get("SNN_BENCH_LAUNCHER")
+    cmd = shlex.split(prefix) if prefix else [sys.executable, "-m", "torch.distributed.run"]
+    cmd += ["--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+            os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    sys.stdout.write(proc.stdout)
+    sys.stdout.flush()
+    if proc.returncode != 0:
+        print(f"[bench] the launched ranks exited with code {proc.returncode}: {' '.join(cmd)}", file=sys.stderr)
+    return proc.returncode
 
 
 def mem_available_bytes():
@@ -238,11 +264,14 @@ def build_config(args, snn_amd, synthetic, np, rank, world, local_rank):
                        "matrix (81 920 neurons), STDP on both lattices, dt=0.1"), "k_inputs_dense<true,false>"
     if cfg == "c5":
         side = args.rows if args.rows != ROWS else 512
-        m = side * side
+        # weak scaling: the lattices grow to (side * world) x side, so that slab r of every lattice -- what rank r owns -- stays
+        # side x side: 4 * side^2 neurons (1 M at the default) per rank whatever N is
+        rows5 = side * world if args.scaling == "weak" else side
+        m = rows5 * side
         dn = snn_amd.DeviceNetwork(model=snn_amd.IZHIKEVICH, spike_train=snn_amd.ST_POISSON, device=local_rank)
         for k in range(4):
-            dn.add_lattice(k, side, side)
-            dn.add_spike_train_lattice(4 + k, side, side)
+            dn.add_lattice(k, rows5, side)
+            dn.add_spike_train_lattice(4 + k, rows5, side)
         if sharded:
             # every rank owns the same slab of each of the four lattices: the ring edge k -> k+1 stays inside a rank
             dn.finalize(rank, world, csr=True, by_lattice=True)
@@ -253,8 +282,8 @@ def build_config(args, snn_amd, synthetic, np, rank, world, local_rank):
             dn.set_attr(k, "current_voltage", synthetic.uniform(6, m, -65.0, 30.0, offset=k * m))
             dn.set_attr(4 + k, "chance_of_firing", np.full(m, 0.01, np.float32))
             dn.set_attr(4 + k, "seed", np.arange(k * m + 1, (k + 1) * m + 1, dtype=np.uint32))   # cell index + 1
-        dn.set_graph_csr(*synthetic.c5_csr(side, posts=dn.owned))
-        return dn, 4 * m, (f"4 x ({side}x{side}) Izhikevich lattices (radius-2 neighbourhoods) + 4 Poisson spike-train "
+        dn.set_graph_csr(*synthetic.c5_csr(rows5, cols=side, posts=dn.owned))
+        return dn, 4 * m, (f"4 x ({rows5}x{side}) Izhikevich lattices (radius-2 neighbourhoods) + 4 Poisson spike-train "
                            f"lattices one-to-one + ring k->k+1, CSR, dt=0.1"), "k_step_csr<0,true,false> (inputs + neuron update + Poisson cells in one launch)"
     raise SystemExit(f"unknown --config {cfg}")
 
@@ -282,7 +311,14 @@ def main():
                          "parallel.ShardedStepper (torch.distributed moves the segments)")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not bracket k_inputs_dense with HIP events (roofline.achieved is then null)")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="--gpus N > 1: strong = the SAME network sharded N ways (default); weak = the network grows with N so that "
+                         "every rank keeps the N = 1 share (c5 only: 4 lattices of 512 N x 512, 1 M neurons per rank)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
+    if args.scaling == "weak" and args.config != "c5":
+        raise SystemExit("--scaling weak is defined for --config c5 (a dense lattice N times the size does not fit N times the memory per rank)")
 
     # dmabuf IPC is the only mode the host driver supports (RCCL across processes); exported by the harness, kept here
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -295,8 +331,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE)")
+    if local_rank >= torch.cuda.device_count():          # (counting devices does not initialise the GPU)
+        raise SystemExit(f"rank {rank}: --gpus {args.gpus} needs device {local_rank}, {torch.cuda.device_count()} visible")
     torch.cuda.set_device(local_rank)
     dist = None
     sharded = world > 1 or args.force_sharded
@@ -367,8 +404,10 @@ def main():
     dn.profile_reset()
     # the timed region (EXACTLY --steps steps between barrier + synchronize on both sides, max over ranks)
     # is repeated --repeats times back to back; the line reports the MEDIAN repetition and lists all of them
+    # ... and, for short steps, as many more as it takes for the timed regions to add up to MIN_TIMED_S (the same count on every
+    # rank: decided from the max-over-ranks times)
     runs = []
-    for _ in range(max(1, args.repeats)):
+    while len(runs) < max(1, args.repeats) or (sum(runs) < MIN_TIMED_S and len(runs) < MAX_REPEATS):
         barrier()
         t0 = time.perf_counter()
         run(args.steps)
@@ -379,10 +418,11 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             e = float(t.item())
         runs.append(e)
+        if len(runs) == max(1, args.repeats):
+            # N = 1 and N = 8 lines can be diffed: a checksum of the network's state right after the --repeats repetitions asked
+            # for (the same number of steps for every N, whatever is added below), every rank's own neurons gathered to rank 0
+            state_sha, state_steps = state_checksum(dn, np, dist, rank, world), args.warmup + args.steps * len(runs)
     elapsed = sorted(runs)[len(runs) // 2]
-    # N = 1 and N = 8 lines can be diffed: a checksum of the network's state right after the timed repetitions (the same
-    # number of steps for every N), every rank's own neurons gathered to rank 0 in global order
-    state_sha, state_steps = state_checksum(dn, np, dist, rank, world), args.warmup + args.steps * len(runs)
     phases = None
     if events_after:
         spikes_timed = own_spike_total()
@@ -442,6 +482,13 @@ def main():
         rd, cp = snn_amd.probe_bandwidth(8 << 30, 5, local_rank)     # this device's own HBM ceilings
         ceilings = {"read_only_GBps": rd, "copy_GBps": cp}
 
+    # evidence of the transport: ncclCommCount of the communicator the library's loop called RCCL on, and what this rank
+    # puts on / takes off the wire per step (the exchange plan's segments, 4 B per word)
+    rccl_ranks = comm.count()[0] if comm is not None else None
+    exchange_bytes = None
+    if sharded:
+        plan = dn.exchange_plan()
+        exchange_bytes = {"mode": plan["mode"], "sent": 4 * int(plan["send_words"]), "received": 4 * int(plan["recv_words"])}
     if rank == 0:
         value = n * args.steps / elapsed
         if not sharded and dn.stat("persistent_run_launches"):
@@ -454,7 +501,7 @@ def main():
             "metric": "neuron-steps/sec", "value": value, "unit": "neuron-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "repeats": len(runs), "ms_per_step_runs": [r / args.steps * 1e3 for r in runs],
+            "repeats": len(runs), "timed_s": sum(runs), "ms_per_step_runs": [r / args.steps * 1e3 for r in runs[:32]],
             "ms_per_step_min": min(runs) / args.steps * 1e3, "ms_per_step_max": max(runs) / args.steps * 1e3,
             "spikes_per_step": spikes / total_steps,
             "state_sha256": state_sha, "state_after_steps": state_steps,
@@ -462,7 +509,11 @@ def main():
                             "touched_bytes_per_step": 8.0 * (dn.n_tot + sum(e - b for b, e in dn.ranges)) * spikes / total_steps / world,
                             "note": "spike compaction + column/row weight updates of this rank, HIP events; touched bytes = "
                                     "8 B x (n_tot + n_local) per spiking neuron"} if pl_steps else None),
-            "scaling": "strong",      # --gpus N shards the SAME lattice: total work fixed as N grows
+            # strong: --gpus N shards the SAME network (total work fixed as N grows); weak (c5): every rank keeps the N = 1 share
+            "scaling": args.scaling,
+            "stepper": (("library (snn_run_sharded, RCCL called by libsnn_amd.so)" if comm is not None else
+                         "torch (parallel.ShardedStepper, torch.distributed moves the segments)") if sharded else None),
+            "rccl_ranks": rccl_ranks, "exchange_bytes_per_rank_step": exchange_bytes,
             "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "neurons": n,
@@ -481,9 +532,13 @@ def main():
                          "algorithmic_bytes_per_launch": bytes_per_launch},
         }
         if world == 1 and not args.no_cpu_baseline and args.config in ("c1", "c2"):
-            threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-            v, secs, cpu_steps, sample, threads, extra = cpu_baseline(n, threads)
-            out["cpu_baseline"] = {"value": v, "unit": "neuron-steps/s", "cores": threads, "kind": "port", **extra,
+            visible_cpus = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            v, secs, cpu_steps, sample, threads, extra = cpu_baseline(n, visible_cpus)
+            quota = cgroup_cpu_quota()
+            cores = int(min(visible_cpus, quota)) if quota else visible_cpus
+            # cores = what the container may run at once (CPU affinity capped by the cgroup quota); threads = the OpenMP team
+            # the thread-count probe picked (more threads than cores can still stream faster: they hide memory latency)
+            out["cpu_baseline"] = {"value": v, "unit": "neuron-steps/s", "cores": max(1, cores), "threads": threads, "kind": "port", **extra,
                                    "sample": f"oracle (C restatement, OpenMP x{threads}, tiles of 1024 columns x 256 rows) on "
                                              f"{sample} of {n} postsynaptic neurons x {cpu_steps} steps ({secs:.1f} s); every "
                                              f"sampled neuron sums all {n} presynaptic terms, i.e. the full per-neuron-step "

@@ -287,13 +287,19 @@ int snn_halo_commit(snn_network_t *net);
 int snn_comm_unique_id(void *id_128_bytes);
 int snn_comm_init_rank(const void *id_128_bytes, int world_size, int rank, int device, void **nccl_comm);
 int snn_comm_destroy(void *nccl_comm);
+/* ncclCommCount / ncclCommUserRank of a communicator (rank may be null): what a benchmark line quotes as evidence that RCCL
+ * itself spans the ranks. */
+int snn_comm_count(void *nccl_comm, int *world_size, int *rank);
 /* The collectives behind snn_run_sharded / snn_exchange / snn_comm_exchange_halo_lists, replaceable PROCESS-WIDE: a host with
  * another transport (MPI, UCX, a test harness that runs several ranks as threads of one process) keeps the library's loop with
  * its overlap of the exchange and the own-rows work.  Signatures are RCCL's (ncclCommCount, ncclCommUserRank, ncclAllGather,
  * ncclSend, ncclRecv, ncclGroupStart, ncclGroupEnd) with void * for ncclComm_t and hipStream_t and int for the data type (always
  * ncclUint32 = 3) and the result (0 = success); `comm` is whatever the host passes to snn_run_sharded.  The functions are
  * called from the thread that runs the library call and must order their work after what that thread has enqueued on `stream`
- * (as RCCL does).  NULL restores RCCL.  snn_comm_unique_id / _init_rank / _destroy keep calling RCCL. */
+ * (as RCCL does).  NULL restores RCCL.  While the table is replaced the communicators are the host's own objects:
+ * snn_comm_unique_id / _init_rank / _destroy fail with SNN_ERR_BAD_STATE (as they do when librccl is absent), and the table
+ * cannot be swapped (SNN_ERR_BAD_STATE) while a thread is inside snn_run_sharded, snn_exchange or
+ * snn_comm_exchange_halo_lists.  The library keeps the function pointers until the table is restored. */
 typedef struct snn_collectives {
     int (*comm_count)(void *comm, int *count);
     int (*comm_user_rank)(void *comm, int *rank);

@@ -153,6 +153,7 @@ SIGNATURES = {
     "snn_comm_unique_id": (C.c_int, [C.c_void_p]),
     "snn_comm_init_rank": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "snn_comm_destroy": (C.c_int, [C.c_void_p]),
+    "snn_comm_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "snn_set_collectives": (C.c_int, [C.c_void_p]),
     "snn_comm_exchange_halo_lists": (C.c_int, [H, C.c_void_p]),
     "snn_exchange": (C.c_int, [H, C.c_void_p]),

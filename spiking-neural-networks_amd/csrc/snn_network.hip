@@ -1124,6 +1124,8 @@ int snn_set_collectives(const snn_collectives *table)
 {
     Rccl &r = rccl_state();
     static const Rccl resolved = r;               // what dlopen / dlsym found (possibly nothing), for the way back
+    if (g_collective_users.load() != 0)
+        return fail(SNN_ERR_BAD_STATE, "the collective table cannot change while a library-driven run or a list exchange is in progress");
     if (!table) {
         r = resolved;
         return SNN_OK;
@@ -1148,7 +1150,7 @@ int snn_comm_unique_id(void *id_128_bytes)
 {
     if (!id_128_bytes) return fail(SNN_ERR_BAD_ARG, "null argument");
     static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
-    RCCL_LIB(R);
+    RCCL_REAL(R, GetUniqueId);
     ncclUniqueId id;
     RCCL_TRY(R, R->GetUniqueId(&id));
     std::memcpy(id_128_bytes, &id, sizeof id);
@@ -1159,7 +1161,7 @@ int snn_comm_init_rank(const void *id_128_bytes, int world_size, int rank, int d
 {
     if (!id_128_bytes || !nccl_comm) return fail(SNN_ERR_BAD_ARG, "null argument");
     if (world_size < 1 || rank < 0 || rank >= world_size) return fail(SNN_ERR_BAD_ARG, "rank must be in [0, world_size)");
-    RCCL_LIB(R);
+    RCCL_REAL(R, CommInitRank);
     HIP_TRY(hipSetDevice(device), SNN_ERR_GET_DEVICE);
     ncclUniqueId id;
     std::memcpy(&id, id_128_bytes, sizeof id);
@@ -1172,8 +1174,18 @@ int snn_comm_init_rank(const void *id_128_bytes, int world_size, int rank, int d
 int snn_comm_destroy(void *nccl_comm)
 {
     if (!nccl_comm) return SNN_OK;
-    RCCL_LIB(R);
+    RCCL_REAL(R, CommDestroy);
     RCCL_TRY(R, R->CommDestroy(static_cast<ncclComm_t>(nccl_comm)));
+    return SNN_OK;
+}
+
+int snn_comm_count(void *nccl_comm, int *world_size, int *rank)
+{
+    if (!nccl_comm || !world_size) return fail(SNN_ERR_BAD_ARG, "null argument");
+    RCCL_LIB(R);
+    if (!R->CommCount || !R->CommUserRank) return fail(SNN_ERR_BAD_STATE, "the collective table has no communicator queries");
+    RCCL_TRY(R, R->CommCount(static_cast<ncclComm_t>(nccl_comm), world_size));
+    if (rank) RCCL_TRY(R, R->CommUserRank(static_cast<ncclComm_t>(nccl_comm), rank));
     return SNN_OK;
 }
 
@@ -1182,6 +1194,7 @@ int snn_comm_exchange_halo_lists(snn_network_t *net, void *nccl_comm)
     if (!net || !nccl_comm) return fail(SNN_ERR_BAD_ARG, "null argument");
     if (!net->finalized || !net->sharded || !net->csr) return fail(SNN_ERR_BAD_STATE, "halo plans belong to finalized CSR shard handles");
     RCCL_LIB(R);
+    CollectiveUser in_use;
     ncclComm_t comm = static_cast<ncclComm_t>(nccl_comm);
     HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
     TRY(comm_geometry(R, net, comm));
@@ -1246,6 +1259,7 @@ int snn_exchange(snn_network_t *net, void *nccl_comm)
     if (!net || !nccl_comm) return fail(SNN_ERR_BAD_ARG, "null argument");
     if (!net->finalized || !net->sharded) return fail(SNN_ERR_BAD_STATE, "not a finalized shard handle");
     RCCL_LIB(R);
+    CollectiveUser in_use;
     HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
     TRY(ensure_exchange_plan(net));
     TRY(comm_geometry(R, net, static_cast<ncclComm_t>(nccl_comm)));
@@ -1337,6 +1351,7 @@ int snn_run_sharded(snn_network_t *net, void *nccl_comm, uint64_t iterations)
     if (iterations == 0 || net->n_tot == 0) return SNN_OK;
     if (!net->electrical && !net->chemical) return SNN_OK;
     RCCL_LIB(R);
+    CollectiveUser in_use;
     ncclComm_t comm = static_cast<ncclComm_t>(nccl_comm);
     HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
     TRY(comm_geometry(R, net, comm));

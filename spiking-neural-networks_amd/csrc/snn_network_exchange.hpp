@@ -3,6 +3,7 @@
 // sharded step loop snn_run_sharded.  Kernels and wire format: snn_kernels_exchange.hpp.
 // Included by snn_network.hip only (one translation unit).
 #pragma once
+#include <atomic>
 #include <dlfcn.h>
 #include <mutex>
 #include <rccl/rccl.h>
@@ -350,6 +351,18 @@ void rccl_resolve(Rccl &r)
 #define RCCL_LIB(R)                                                                               \
     Rccl *R = rccl();                                                                              \
     if (!R) return fail(SNN_ERR_BAD_STATE, std::string("librccl.so.1 could not be loaded: ") + rccl_state().err)
+// the communicator's life cycle is RCCL's own: not available from a replaced table (snn_set_collectives), nor without librccl
+#define RCCL_REAL(R, fn)                                                                           \
+    Rccl *R = rccl();                                                                              \
+    if (!R || !R->lib) return fail(SNN_ERR_BAD_STATE, std::string("librccl.so.1 could not be loaded: ") + rccl_state().err); \
+    if (R->replaced) return fail(SNN_ERR_BAD_STATE, "the collectives are replaced (snn_set_collectives): communicators are the host's"); \
+    if (!R->fn) return fail(SNN_ERR_BAD_STATE, "RCCL entry point missing")
+// entry points that call the collectives count themselves in: snn_set_collectives refuses to swap the table under them
+std::atomic<int> g_collective_users{0};
+struct CollectiveUser {
+    CollectiveUser() { g_collective_users.fetch_add(1); }
+    ~CollectiveUser() { g_collective_users.fetch_sub(1); }
+};
 #define RCCL_TRY(R, expr)                                                                         \
     do {                                                                                           \
         ncclResult_t r_ = (expr);                                                                  \

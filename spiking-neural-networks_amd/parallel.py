@@ -78,6 +78,12 @@ class LibraryComm:
     def __int__(self):
         return int(self._h)
 
+    def count(self):
+        """(ncclCommCount, ncclCommUserRank) of the communicator"""
+        world, rank = C.c_int(0), C.c_int(-1)
+        self._check(self._L.snn_comm_count(C.c_void_p(self._h), C.byref(world), C.byref(rank)))
+        return world.value, rank.value
+
     def close(self):
         if self._h:
             self._check(self._L.snn_comm_destroy(C.c_void_p(self._h)))
@@ -189,7 +195,22 @@ class ThreadCollectives:
         return C.addressof(self._ranks) + rank * C.sizeof(C.c_int)
 
     def close(self):
-        self._lib.check(self._L.snn_set_collectives(None), self._L)
+        """restores RCCL's table (the library holds raw pointers to this object's thunks until then)"""
+        if self._table is not None:
+            self._lib.check(self._L.snn_set_collectives(None), self._L)
+            self._table = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # noqa: BLE001 -- interpreter shutdown
+            pass
 
     def abort(self):
         """a rank failed: release the others from the barrier (their calls then fail too)"""

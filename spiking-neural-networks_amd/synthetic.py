@@ -26,28 +26,30 @@ def uniform(seed, count, lo, hi, offset=0):
     return (np.float32(lo) + (np.float32(hi) - np.float32(lo)) * u).astype(np.float32)
 
 
-def c5_csr(side, q0=None, q1=None, posts=None):
-    """CSR rows (posts q0..q1, or the ascending global indices `posts`) of BASELINE configs[4]: four side x side neuron
+def c5_csr(side, q0=None, q1=None, posts=None, cols=None):
+    """CSR rows (posts q0..q1, or the ascending global indices `posts`) of BASELINE configs[4]: four side x side
+    (side x cols when `cols` is given: the weak-scaling form of bench.py) neuron
     lattices (ids 0-3), internal radius-<=2 neighbourhood (<= 12 in-edges, w = 1), one Poisson lattice per
     neuron lattice (ids 4-7) wired one-to-one (w = 1), lattice k -> k+1 (mod 4) one-to-one (w = 1).
     Returns (row_ptr uint64, pre_index uint32 ascending per row, weights float32)."""
-    m = side * side
+    cols_ = side if cols is None else cols
+    m = side * cols_
     nn = 4 * m
     q0 = 0 if q0 is None else q0
     q1 = nn if q1 is None else q1
     q = np.arange(q0, q1, dtype=np.int64) if posts is None else np.asarray(posts, dtype=np.int64)
     k, rem = q // m, q % m
-    r, c = rem // side, rem % side
+    r, c = rem // cols_, rem % cols_
     offs = [(dr, dc) for dr in range(-2, 3) for dc in range(-2, 3) if 0 < dr * dr + dc * dc <= 4]
     sentinel = np.iinfo(np.int64).max
-    cols = []
+    entries = []
     for dr, dc in offs:
         rr, cc = r + dr, c + dc
-        ok = (rr >= 0) & (rr < side) & (cc >= 0) & (cc < side)
-        cols.append(np.where(ok, k * m + rr * side + cc, sentinel))
-    cols.append(((k - 1) % 4) * m + rem)            # previous lattice, same position
-    cols.append(nn + k * m + rem)                   # its Poisson cell
-    pre = np.sort(np.stack(cols, axis=1), axis=1)
+        ok = (rr >= 0) & (rr < side) & (cc >= 0) & (cc < cols_)
+        entries.append(np.where(ok, k * m + rr * cols_ + cc, sentinel))
+    entries.append(((k - 1) % 4) * m + rem)            # previous lattice, same position
+    entries.append(nn + k * m + rem)                   # its Poisson cell
+    pre = np.sort(np.stack(entries, axis=1), axis=1)
     valid = pre != sentinel
     row_ptr = np.concatenate([[0], np.cumsum(valid.sum(axis=1))]).astype(np.uint64)
     pre_index = pre[valid].astype(np.uint32)

@@ -72,3 +72,25 @@ def test_product_never_touches_the_oracle():
                 src = open(os.path.join(dirpath, f), errors="replace").read()
                 for needle in ("oracle/", "snn_oracle", "oracle_binding", "libsnn_oracle", "snn_o_"):
                     assert needle not in src, f"{f} references the oracle ({needle})"
+
+
+def test_comm_lifecycle_is_refused_while_the_collectives_are_replaced():
+    """snn_set_collectives swaps the seven per-step entry points only: a communicator then is the host's own object, and the
+    three RCCL life-cycle calls must fail with SNN_ERR_BAD_STATE instead of handing it to ncclCommDestroy (or calling through a
+    null pointer when librccl is absent).  No device call is made."""
+    L = _lib.load()
+    q = _lib.COMM_QUERY_FN(lambda comm, out: 0)
+    table = _lib.Collectives(q, q, _lib.ALL_GATHER_FN(lambda *a: 0), _lib.SEND_RECV_FN(lambda *a: 0),
+                             _lib.SEND_RECV_FN(lambda *a: 0), _lib.GROUP_FN(lambda: 0), _lib.GROUP_FN(lambda: 0))
+    assert L.snn_set_collectives(ctypes.byref(table)) == 0
+    try:
+        ident = ctypes.create_string_buffer(128)
+        fake = ctypes.c_int(0)
+        out = ctypes.c_void_p()
+        assert L.snn_comm_unique_id(ident) == 12   # SNN_ERR_BAD_STATE
+        assert L.snn_comm_init_rank(ident, 1, 0, 0, ctypes.byref(out)) == 12
+        assert L.snn_comm_destroy(ctypes.cast(ctypes.pointer(fake), ctypes.c_void_p)) == 12
+        world, rank = ctypes.c_int(-1), ctypes.c_int(-1)
+        assert L.snn_comm_count(ctypes.cast(ctypes.pointer(fake), ctypes.c_void_p), ctypes.byref(world), ctypes.byref(rank)) == 0
+    finally:
+        assert L.snn_set_collectives(None) == 0

@@ -1,4 +1,5 @@
 """Host-side logic that needs no GPU: shard geometry, exchange-buffer layout, synthetic data."""
+import os
 import numpy as np
 
 import snn_amd
@@ -27,3 +28,74 @@ def test_synthetic_uniform_is_counter_based():
     b = snn_amd.synthetic.uniform(2, 1064, 0.5, 1.5)[1000:]
     assert np.array_equal(a, b) and a.dtype == np.float32
     assert 0.5 <= a.min() and a.max() < 1.5
+
+
+def _bench_under_stub(tmp_path, argv, launcher_rc=0):
+    """runs `python bench.py <argv>` with a stub in place of `python -m torch.distributed.run` and a `torch` package that
+    refuses to be imported: returns (CompletedProcess, what the stub was started with)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    record = tmp_path / "launched.json"
+    stub = tmp_path / "launcher.py"
+    stub.write_text("import json, os, sys\n"
+                    f"json.dump({{'argv': sys.argv[1:], 'ipc': os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')}}, open({str(record)!r}, 'w'))\n"
+                    "print('RCCL version banner')\n"
+                    "print(json.dumps({'metric': 'neuron-steps/sec', 'n_gpus': 2, 'rccl_ranks': 2}))\n"
+                    f"sys.exit({launcher_rc})\n")
+    fake = tmp_path / "fake" / "torch"
+    fake.mkdir(parents=True)
+    (fake / "__init__.py").write_text("raise ImportError('the launching process must not import torch')\n")
+    env = dict(os.environ, SNN_BENCH_LAUNCHER=f"{sys.executable} {stub}", PYTHONPATH=str(tmp_path / "fake"))
+    env.pop("WORLD_SIZE", None)
+    proc = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + argv, env=env, capture_output=True, text=True, timeout=120)
+    return proc, (json.load(open(record)) if record.exists() else None)
+
+
+def test_bench_starts_its_own_ranks_before_any_gpu_call(tmp_path):
+    """`python bench.py --gpus 2` without a launcher's environment: a fresh child `torch.distributed.run --nproc-per-node 2
+    bench.py <same arguments>` is started before torch is imported (the stub torch would raise), its stdout is relayed
+    with the JSON line last, and its exit code is the bench's"""
+    import json
+    proc, launched = _bench_under_stub(tmp_path, ["--gpus", "2", "--steps", "7", "--config", "c5", "--scaling", "weak"])
+    assert proc.returncode == 0, proc.stderr
+    line = json.loads(proc.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2
+    a = launched["argv"]
+    assert "--nnodes=1" in a and "--nproc-per-node=2" in a and a[a.index("--master-addr") + 1] == "127.0.0.1"
+    assert int(a[a.index("--master-port") + 1]) > 0
+    script = [x for x in a if x.endswith("bench.py")]
+    assert script and a[a.index(script[0]) + 1:] == ["--gpus", "2", "--steps", "7", "--config", "c5", "--scaling", "weak"]
+    assert launched["ipc"] == "0"                      # dmabuf IPC: the only mode RCCL across processes works in here
+
+
+def test_bench_relays_a_failing_launch(tmp_path):
+    proc, _ = _bench_under_stub(tmp_path, ["--gpus", "4"], launcher_rc=3)
+    assert proc.returncode == 3 and "exited with code 3" in proc.stderr
+
+
+def test_bench_single_gpu_stays_in_process(tmp_path):
+    """--gpus 1 (the default) launches nothing: it goes straight on to import torch in this process"""
+    proc, launched = _bench_under_stub(tmp_path, ["--steps", "3"])
+    assert launched is None and proc.returncode != 0 and "must not import torch" in proc.stderr
+
+
+def test_c5_structure_on_rectangular_lattices():
+    """the weak-scaling form of bench.py --config c5: four (rows x cols) lattices; checked against a plain double loop"""
+    from snn_amd import synthetic
+    rows, cols = 6, 4
+    m, nn = rows * cols, 4 * rows * cols
+    ptr, pre, w = synthetic.c5_csr(rows, cols=cols)
+    assert ptr[-1] == pre.size == w.size and np.all(w == 1.0)
+    for q in range(nn):
+        k, rem = divmod(q, m)
+        r, c = divmod(rem, cols)
+        want = {k * m + rr * cols + cc for rr in range(rows) for cc in range(cols)
+                if 0 < (rr - r) ** 2 + (cc - c) ** 2 <= 4}
+        want |= {((k - 1) % 4) * m + rem, nn + k * m + rem}
+        got = pre[int(ptr[q]):int(ptr[q + 1])]
+        assert list(got) == sorted(want)
+    sq = synthetic.c5_csr(5)
+    sq2 = synthetic.c5_csr(5, cols=5)
+    assert all(np.array_equal(a, b) for a, b in zip(sq, sq2))
