@@ -428,7 +428,9 @@ int snn_get_spike_counts(snn_network_t *net, uint32_t id, uint32_t *dst, size_t 
  * [1] reward-modulated weight updates riding on the next input pass; "defer_stdp" [0] 1: STDP updates riding on the next
  * input pass, 2: prepared delta vectors applied by scatter passes; "uniform_params" [1] population-wide parameter
  * values from a device table; "persistent_run" [1] all steps of an snn_run call (of 4 steps or more) on a small
- * electrical-only network -- neurons, with or without Poisson / Rate cells; <= 4096 rows, no plasticity -- in ONE launch;
+ * network -- neurons, with or without Poisson / Rate cells that release no transmitter; no plasticity; electrical synapses only:
+ * <= 4096 rows; with chemical synapses (built-in kinetics): <= 1024 rows -- in ONE launch; "persistent_chem" [1] 0 keeps
+ * networks with chemical synapses on the one-launch-per-step forms;
  * "input_shape" [0] 1 | 2 forces the 4- / 2-columns-per-lane shape of the streamed dense input pass (0: chosen by size).
  * Unknown names fail with SNN_ERR_BAD_ARG.
  *
@@ -477,10 +479,12 @@ int snn_profile_read_plasticity(snn_network_t *net, uint64_t *steps, double *tot
  * `voltage` above the spike threshold a chosen fraction of the population spikes every step, so STDP can be measured
  * under load.  Applied identically on every shard handle. */
 int snn_set_synthetic_drive(snn_network_t *net, uint64_t seed, float fraction, float voltage);
-/* Algorithmic bytes ONE launch of the synaptic-input kernel moves (DESIGN.md "Roofline"): 4 B per synapse of the shard
- * (dense), 8 B per stored synapse (sparse; + 60 B of state per row when the launch is the one-launch step k_step_csr,
- * which also is the neuron update, + 28 B per spike-train cell when the cells advance in that launch too), 16 B per internal synapse of a reward-modulated lattice whose weight update
- * rides on the pass (k_inputs_rstdp: weight and trace read and rewritten) */
+/* ALGORITHMIC bytes ONE launch of the synaptic-input kernel moves (DESIGN.md "Roofline"; what the step has to move, not
+ * what the counters saw): 4 B per synapse of the shard (dense); 8 B per stored synapse (sparse) + S bytes of state per OWNED
+ * row when the launch is the one-launch step k_step_csr, which also is the neuron update (S by model: Izhikevich 60, leaky
+ * 68, Hodgkin-Huxley 140, ...; + 44 B per live transmitter type with chemical synapses) + 28 B per spike-train cell when
+ * the cells advance in that launch too; 16 B per internal synapse of a reward-modulated lattice whose weight update rides
+ * on the pass (k_inputs_rstdp: weight and trace read and rewritten). */
 int snn_input_kernel_bytes(const snn_network_t *net, uint64_t *bytes);
 
 /* ---- errors ----------------------------------------------------------------------------- */

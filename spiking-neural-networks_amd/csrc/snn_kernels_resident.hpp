@@ -248,13 +248,15 @@ constexpr uint32_t RUN_RESIDENT_MAX_NEURONS = RUN_RESIDENT_GROUP_ROWS * RUN_RESI
 constexpr uint32_t RUN_RESIDENT_MAX_TILES = RUN_RESIDENT_MAX_NEURONS / 64;
 constexpr uint32_t RUN_RESIDENT_MAX_ALL_CHUNKS = RUN_RESIDENT_MAX_NEURONS / CHUNK;
 constexpr uint32_t RUN_RESIDENT_SPIN_LIMIT = 1u << 24;
+constexpr uint32_t RUN_GRANULE_PLANES = 1 + K_TYPES;
 
 struct ResidentRunArgs {
     InputsArgs in;                  // W, ld, n_loc, n_tot, xbuf = the exchange buffer itself, gap conductances
     UpdateArgs up;                  // in place: n.xbuf = xout = exchange buffer, xout2 = null; history rows of the FIRST step
     uint32_t steps;
     uint32_t vhist_stride, raster_stride;     // elements between consecutive history rows
-    unsigned long long *granules;   // [2][RUN_RESIDENT_MAX_NEURONS] {voltage bits, tag << 32}
+    unsigned long long *granules;   // [2][RUN_GRANULE_PLANES][RUN_RESIDENT_MAX_NEURONS] {value bits, tag << 32}: plane 0 the voltage,
+                                    // plane 1 + j what the neuron releases of live transmitter type j (CHEM)
     unsigned long long *partials;   // [2][tiles][groups - 1][4 chunks][64] {chunk sum bits, tag << 32}; groups > 1 only
     uint32_t n_groups;              // row groups per column tile; gridDim.x = tiles * n_groups
     uint32_t tag_base;              // tag of the state after step s (1-based) = tag_base + s
@@ -273,15 +275,26 @@ struct ResidentRunArgs {
     long long view_clock0;          // network clock of the launch's first input calculation
     float *st_vhist_row;            // the cells' voltage history row of the FIRST step or null
     uint32_t st_vhist_stride;
+    // chemical synapses (CHEM variants): the transmitter types some neuron releases, ascending; a neuron's concentration of a
+    // type it does not release travels as 0 (the presence test of the canonical sum becomes a zero product)
+    uint32_t n_live, live_type[K_TYPES];
 };
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-// the granules of the state a run starts from (slot 0, tag = tag_base)
-__global__ __launch_bounds__(256) void k_run_resident_seed(const float *xbuf, XLayout xl, uint32_t n, unsigned long long *granules, uint32_t tag)
+// the granules of the state a run starts from (slot 0, tag = tag_base): voltages, and per live transmitter type what each neuron
+// releases of it
+__global__ __launch_bounds__(256) void k_run_resident_seed(const float *xbuf, XLayout xl, uint32_t n, unsigned long long *granules, uint32_t tag,
+                                                           const uint32_t *nt_flags, uint32_t n_pad, uint32_t n_live, uint32_t live0, uint32_t live1, uint32_t live2)
 {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) granules[i] = ((unsigned long long)tag << 32) | __float_as_uint(xbuf[xl.at(i, PLANE_V)]);
+    if (i >= n) return;
+    granules[i] = ((unsigned long long)tag << 32) | __float_as_uint(xbuf[xl.at(i, PLANE_V)]);
+    const uint32_t live[K_TYPES] = {live0, live1, live2};
+    for (uint32_t j = 0; j < n_live; ++j) {
+        const float t = nt_flags[(size_t)live[j] * n_pad + i] ? xbuf[xl.at(i, PLANE_T0 + live[j])] : 0.0f;
+        granules[(size_t)(1 + j) * RUN_RESIDENT_MAX_NEURONS + i] = ((unsigned long long)tag << 32) | __float_as_uint(t);
+    }
 }
 
 struct ResidentRunShared {
@@ -306,6 +319,12 @@ struct ResidentRunShared {
     float cell_par[5][RUN_RESIDENT_GROUP_ROWS];
     uint32_t cell_refr[RUN_RESIDENT_GROUP_ROWS], cell_clock_lo[RUN_RESIDENT_GROUP_ROWS], cell_clock_hi[RUN_RESIDENT_GROUP_ROWS];
     uint32_t cell_spiking[RUN_RESIDENT_GROUP_ROWS];
+    // chemical synapses: per live transmitter type the concentrations of the rows, the running sum of a chunk between turns,
+    // and -- by TYPE, as LdsSums reads them -- the finished chunk sums (one row group: at most 4 chunks)
+    float t[K_TYPES][RUN_RESIDENT_GROUP_ROWS];
+    float hand_t[K_TYPES][RESIDENT_MAX_CHUNKS][64];
+    float pt[K_TYPES][RESIDENT_MAX_CHUNKS][64];
+    uint32_t w_finite[16];                       // per wavefront: every weight it holds is finite
 };
 
 // The step loop of one wavefront.  UPDATER = wavefront 0, which also owns the neuron update of the workgroup's 64 columns: it
@@ -313,7 +332,7 @@ struct ResidentRunShared {
 // run (same expressions as update_neuron, integrate_and_fire/mod.rs:217-255); the other wavefronts keep 64 weights per lane
 // in registers.  Every wavefront of a workgroup passes the same workgroup barriers per step (one behind the polls, one per turn --
 // four, fewer for networks under 256 rows --; group 0 of a multi-group tile one more).
-template <int MODEL, bool UPDATER, bool REGISTERS, bool CELLS>
+template <int MODEL, bool UPDATER, bool REGISTERS, bool CELLS, bool CHEM>
 __device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, ResidentRunShared &sh, const uint32_t wave)
 {
     const InputsArgs &in = a.in;
@@ -339,6 +358,7 @@ __device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, Res
 
     // this lane's 64 weights (quad-row units: 4 consecutive rows of one column per load); absent edge: weight 0
     float w[UPDATER ? 1 : 64];
+    bool w_all_finite = true;
     const v4f *units = reinterpret_cast<const v4f *>(in.W) + (size_t)(row0 >> 2) * in.ld + ql;
     {
 #pragma unroll
@@ -350,11 +370,27 @@ __device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, Res
             for (uint32_t k = 0; k < 4; ++k) {
                 const bool edge = e[k] == e[k];
                 e[k] = edge ? e[k] : 0.0f;
+                w_all_finite = w_all_finite && fabsf(e[k]) <= 3.0e38f;
                 if (!UPDATER) w[4 * g + k] = e[k];
             }
             if (UPDATER) sh.w0[g][lane] = v4f{e[0], e[1], e[2], e[3]};      // read back by this lane only
         }
     }
+    // CHEM: a concentration that travels as 0 (the neuron does not release the type) stands for a skipped term only while its
+    // product with the weight is a zero: every weight finite (wave-uniform, fixed for the run)
+    if (CHEM) {
+        const bool all = __all(w_all_finite);
+        if (lane == 0) sh.w_finite[wave] = all;
+    }
+    const uint32_t n_live = CHEM ? a.n_live : 0u;
+    // the transmitter types this lane's neuron releases (UPDATER, CHEM): bit k
+    uint32_t my_nt_mask = 0u;
+    if (CHEM && UPDATER && updates && col && a.up.has_nt) {
+        const uint32_t q = a.up.rows.global_of(ql);
+#pragma unroll
+        for (int k = 0; k < K_TYPES; ++k) my_nt_mask |= a.up.n.nt_flags[(size_t)k * a.up.n.n_pad + q] ? (1u << k) : 0u;
+    }
+    float t_mine[K_TYPES] = {0.0f, 0.0f, 0.0f};     // wavefront 0, alone: what this lane's neuron released (by live slot)
 
     // Neuron state in registers for the whole run (REGISTERS: the host launches that variant for Izhikevich, leaky, quadratic and
     // simple leaky integrate-and-fire lattices without transmitters and without the BCM extension).  The expressions are
@@ -428,10 +464,22 @@ __device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, Res
         mark = now;
     };
 
+    const uint32_t tid_outer = tid;
     for (uint32_t s = 0; s < steps; ++s) {
+        // What a step derives from the thread's index is derived again in every step (the index passes through an opaque
+        // instruction): kept across the loop, these values and the 64-bit addresses built on them cost the registers the
+        // weights need, and the compiler spilled them to scratch inside the loop.
+        uint32_t tid_l = tid_outer;
+        asm volatile("" : "+v"(tid_l));
+        const uint32_t tid = tid_l, lane = tid & 63u, ql = tile * 64u + lane, my_row = group_row0 + tid;
+        const bool col = ql < in.n_loc;
+        const bool is_cell = CELLS && my_row >= n_neurons && my_row < n_tot;
+        const bool writes_cells = is_cell && tile == 0u;
+        const uint32_t cell = is_cell ? my_row - n_neurons : 0u;
+        const v4f *units = reinterpret_cast<const v4f *>(in.W) + (size_t)(row0 >> 2) * in.ld + ql;
         // (1) S(t): every neuron's voltage, one granule per thread (those of the first step come from k_run_resident_seed:
         // the exchange buffer itself is updated in place by workgroups that are already a step ahead)
-        const unsigned long long *slot = granules + (size_t)(s & 1u) * RUN_RESIDENT_MAX_NEURONS;
+        const unsigned long long *slot = granules + (size_t)(s & 1u) * RUN_GRANULE_PLANES * RUN_RESIDENT_MAX_NEURONS;
         const uint32_t tag = tag_base + s;
         auto poll = [&](const unsigned long long *g, bool &arrived) {
             unsigned long long x;
@@ -443,15 +491,47 @@ __device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, Res
             return __uint_as_float((uint32_t)x);
         };
         float v = 0.0f, v_col = 0.0f;
+        float tv[K_TYPES] = {0.0f, 0.0f, 0.0f};      // CHEM: this row's concentrations, by live slot
         bool arrived = true;
         if (alone && s != 0) {
             // a lattice of <= 64 neurons is ONE workgroup: wavefront 0 left the new voltages in sh.v itself (below), nothing
             // travels through memory; it also knows whether they are all small finite numbers
             v = UPDATER ? v_mine : 0.0f;
+            if (CHEM && UPDATER) { tv[0] = t_mine[0]; tv[1] = t_mine[1]; tv[2] = t_mine[2]; }
         } else {
-            if (my_row < n_neurons) v = poll(slot + my_row, arrived);
+            if (CHEM) {
+                // the voltage and the live concentrations of this row: 1 + n_live granules, each with its own tag, requested
+                // together (one round trip, not one per plane)
+                if (my_row < n_neurons) {
+                    unsigned long long x[RUN_GRANULE_PLANES];
+                    uint32_t spins = 0;
+                    bool all;
+                    do {
+                        all = true;
+#pragma unroll
+                        for (uint32_t j = 0; j < RUN_GRANULE_PLANES; ++j)
+                            if (j <= n_live) x[j] = __hip_atomic_load(slot + (size_t)j * RUN_RESIDENT_MAX_NEURONS + my_row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                        for (uint32_t j = 0; j < RUN_GRANULE_PLANES; ++j)
+                            if (j <= n_live) all = all && (uint32_t)(x[j] >> 32) == tag;
+                    } while (!all && ++spins < a.spin_limit);
+                    arrived = arrived && all;
+                    v = __uint_as_float((uint32_t)x[0]);
+#pragma unroll
+                    for (uint32_t j = 0; j < K_TYPES; ++j)
+                        if (j < n_live) tv[j] = __uint_as_float((uint32_t)x[1 + j]);
+                }
+            } else if (my_row < n_neurons) {
+                v = poll(slot + my_row, arrived);
+            }
             if (!cols_in_rows && wave == 1 && col) v_col = poll(slot + in.q0 + ql, arrived);   // the columns' voltages, by one wavefront
             if (!CELLS || my_row < n_neurons) sh.v[tid] = v;
+            if (CHEM) {
+                // (a spike-train cell's row carries 0: cells with transmitters keep the network on the per-step forms)
+#pragma unroll
+                for (uint32_t j = 0; j < K_TYPES; ++j)
+                    if (j < n_live) sh.t[j][tid] = tv[j];
+            }
         }
         if (CELLS && my_row >= n_neurons) {
             // spike_train_gap_junction (neuron/mod.rs:119-137): a cell's row carries its gap-junction value x; one that never
@@ -480,12 +560,14 @@ __device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, Res
         }
         lap(0);
         if (!cols_in_rows && wave == 1) sh.vcol[lane] = v_col;
-        const bool all_arrived = __all(arrived), all_plain = __all(fabsf(v) <= 1e15f && fabsf(v_col) <= 1e15f && gq_small);
+        const bool all_arrived = __all(arrived), all_plain = __all(fabsf(v) <= 1e15f && fabsf(v_col) <= 1e15f && gq_small &&
+                                                                   (!CHEM || (fabsf(tv[0]) <= 1e15f && fabsf(tv[1]) <= 1e15f && fabsf(tv[2]) <= 1e15f)));
         if (lane == 0) { sh.ok[wave] = all_arrived; sh.plain[wave] = all_plain; }
         __syncthreads();
         const uint32_t flag_ok = sh.ok[lane & 15u], flag_plain = sh.plain[lane & 15u];
         if (!__all(flag_ok != 0) || *const_cast<volatile uint32_t *>(&sh.gave_up)) break;   // workgroup-uniform: some poll gave up
         const bool plain = __all(flag_plain != 0);
+        const bool plain_t = CHEM && plain && __all(sh.w_finite[lane & 15u] != 0u);
         lap(1);
 
         // (2) the canonical chunk sums, the wavefronts of a chunk in turn
@@ -493,6 +575,7 @@ __device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, Res
 #pragma unroll 1
         for (uint32_t t = 0; t < n_turns; ++t) {
             if (t == turn && rows_live) {
+              if (!CHEM || a.up.electrical) {
                 float acc = (t != 0) ? sh.hand[chunk_local][lane] : 0.0f;
                 // wave-uniform address = LDS broadcast; the offset is laundered through a vector register so that the values
                 // stay in vector registers (as scalars every one of them costs a v_readlane plus its wait states)
@@ -516,53 +599,55 @@ __device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, Res
                 if (plain && mixed) {
                     // the one block that holds neurons and cells:  s + g * (f - n * vq), times the weight -- (0, v, 1) is the
                     // neuron's g * (v - vq), (0, x, 0) and (x, 0, 0) the two kinds of cell; every step exact while all values are
-                    // finite (1 * vq == vq, 0 * vq == +-0, +-0 added to a sum that never holds -0)
+                    // finite (1 * vq == vq, 0 * vq == +-0, +-0 added to a sum that never holds -0).  Batches of 8 rows: at most one
+                    // wavefront of a workgroup takes this form, and with 16 rows in flight its three operand streams pushed the
+                    // weights out of the registers (spills inside the step loop).
                     const v4f *cs = reinterpret_cast<const v4f *>(sh.cell_s + (row0 - group_row0) + zero);
                     const v4f *cf = reinterpret_cast<const v4f *>(sh.cell_f + (row0 - group_row0) + zero);
                     const v4f *cn = reinterpret_cast<const v4f *>(sh.cell_n + (row0 - group_row0) + zero);
                     const v2f gq2 = {gq, gq}, vq2 = {vq, vq};
 #pragma unroll
-                    for (uint32_t b = 0; b < 4; ++b) {
-                        v4f xs[4], xf[4], xn[4], wr[4];
+                    for (uint32_t b = 0; b < 8; ++b) {
+                        v4f xs[2], xf[2], xn[2], wr[2];
 #pragma unroll
-                        for (uint32_t k = 0; k < 4; ++k) {
-                            xs[k] = cs[4 * b + k];
-                            xf[k] = cf[4 * b + k];
-                            xn[k] = cn[4 * b + k];
-                            if (UPDATER) wr[k] = sh.w0[4 * b + k][lane];
+                        for (uint32_t k = 0; k < 2; ++k) {
+                            xs[k] = cs[2 * b + k];
+                            xf[k] = cf[2 * b + k];
+                            xn[k] = cn[2 * b + k];
+                            if (UPDATER) wr[k] = sh.w0[2 * b + k][lane];
                         }
-                        v2f d[8];
+                        v2f d[4];
 #pragma unroll
-                        for (uint32_t k = 0; k < 4; ++k) {
+                        for (uint32_t k = 0; k < 2; ++k) {
                             d[2 * k] = v2f{xn[k].x, xn[k].y} * vq2;
                             d[2 * k + 1] = v2f{xn[k].z, xn[k].w} * vq2;
                         }
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (uint32_t k = 0; k < 4; ++k) {
+                        for (uint32_t k = 0; k < 2; ++k) {
                             d[2 * k] = v2f{xf[k].x, xf[k].y} - d[2 * k];
                             d[2 * k + 1] = v2f{xf[k].z, xf[k].w} - d[2 * k + 1];
                         }
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (uint32_t k = 0; k < 8; ++k) d[k] = gq2 * d[k];
+                        for (uint32_t k = 0; k < 4; ++k) d[k] = gq2 * d[k];
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (uint32_t k = 0; k < 4; ++k) {
+                        for (uint32_t k = 0; k < 2; ++k) {
                             d[2 * k] = v2f{xs[k].x, xs[k].y} + d[2 * k];
                             d[2 * k + 1] = v2f{xs[k].z, xs[k].w} + d[2 * k + 1];
                         }
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (uint32_t k = 0; k < 4; ++k) {
-                            const uint32_t r = 16 * b + 4 * k;
+                        for (uint32_t k = 0; k < 2; ++k) {
+                            const uint32_t r = 8 * b + 4 * k;
                             if (!UPDATER) wr[k] = v4f{w[UPDATER ? 0 : r], w[UPDATER ? 0 : r + 1], w[UPDATER ? 0 : r + 2], w[UPDATER ? 0 : r + 3]};
                             d[2 * k] = d[2 * k] * v2f{wr[k].x, wr[k].y};
                             d[2 * k + 1] = d[2 * k + 1] * v2f{wr[k].z, wr[k].w};
                         }
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (uint32_t k = 0; k < 8; ++k) { acc += d[k].x; acc += d[k].y; }
+                        for (uint32_t k = 0; k < 4; ++k) { acc += d[k].x; acc += d[k].y; }
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 } else if (plain && all_cells && (sh.block_fired[(row0 - group_row0) >> 6] || sh.block_silent[(row0 - group_row0) >> 6])) {
@@ -691,6 +776,61 @@ __device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, Res
                 }
                 if (last_of_chunk) sh.pi[chunk][lane] = acc;
                 else sh.hand[chunk_local][lane] = acc;
+              }
+              if (CHEM) {
+                // weighted transmitter concentrations (weight_neurotransmitter_concentration, iterate_and_spike/mod.rs:2837-2866): per live
+                // type the same ascending chain over this wavefront's rows, t * w, the running sum handed on through LDS
+#pragma unroll 1
+                for (uint32_t j = 0; j < n_live; ++j) {
+                    float acc_t = (t != 0) ? sh.hand_t[j][chunk_local][lane] : 0.0f;
+                    uint32_t zero;
+                    asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
+                    const v4f *tp = reinterpret_cast<const v4f *>(sh.t[j] + (row0 - group_row0) + zero);
+                    if (plain_t) {
+                        // (batches of 8 rows where the wavefront also carries spike-train cells: the registers are the weights')
+                        constexpr uint32_t Q = (CELLS && !UPDATER) ? 2u : 4u;          // 16-byte units (4 rows each) per batch
+#pragma unroll
+                        for (uint32_t b = 0; b < 16u / Q; ++b) {
+                            v4f x[Q], wr[Q];
+#pragma unroll
+                            for (uint32_t k = 0; k < Q; ++k) {
+                                x[k] = tp[Q * b + k];
+                                if (UPDATER) wr[k] = sh.w0[Q * b + k][lane];
+                            }
+                            v2f d[2 * Q];
+#pragma unroll
+                            for (uint32_t k = 0; k < Q; ++k) {
+                                const uint32_t r = 4 * Q * b + 4 * k;
+                                if (!UPDATER) wr[k] = v4f{w[UPDATER ? 0 : r], w[UPDATER ? 0 : r + 1], w[UPDATER ? 0 : r + 2], w[UPDATER ? 0 : r + 3]};
+                                d[2 * k] = v2f{x[k].x, x[k].y} * v2f{wr[k].x, wr[k].y};
+                                d[2 * k + 1] = v2f{x[k].z, x[k].w} * v2f{wr[k].z, wr[k].w};
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (uint32_t k = 0; k < 2 * Q; ++k) { acc_t += d[k].x; acc_t += d[k].y; }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    } else {
+                        // some value is not a small finite number: terms are skipped explicitly -- weights from the matrix again
+                        // (absent edge = NaN), the presence of the type from the flag planes
+                        const uint32_t type = a.live_type[j];
+#pragma unroll 1
+                        for (uint32_t g = 0; g < 16 && row0 + 4 * g < n_tot; ++g) {
+                            const v4f x = tp[g], y = units[(size_t)g * in.ld];
+                            const float e[4] = {x.x, x.y, x.z, x.w}, ww[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+                            for (uint32_t jj = 0; jj < 4; ++jj) {
+                                const uint32_t p = row0 + 4 * g + jj;
+                                const bool has = p < n_neurons && in.nt_flags[(size_t)type * in.n_pad + p] != 0u;
+                                const float pr = e[jj] * ww[jj];
+                                acc_t += (has && ww[jj] == ww[jj]) ? pr : 0.0f;
+                            }
+                        }
+                    }
+                    if (last_of_chunk) sh.pt[a.live_type[j]][chunk_local][lane] = acc_t;
+                    else sh.hand_t[j][chunk_local][lane] = acc_t;
+                }
+              }
             }
             __syncthreads();
         }
@@ -723,8 +863,8 @@ __device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, Res
             if (writes_cells && a.st_vhist_row) a.st_vhist_row[(size_t)s * a.st_vhist_stride + cell] = cv;
             const long long view_clock = a.view_clock0 + (long long)s + 1;
             sh.cell_presyn[tid] = lft < 0 ? c_v_resting
-                                          : (sh.cell_refr[tid] ? exponential_decay_effect(view_clock, lft, c_v_th, c_v_resting, c_k, c_dt)
-                                                               : delta_dirac_effect(view_clock, lft, c_v_th, c_v_resting, c_k, c_dt));
+                                          : (sh.cell_refr[tid] ? exponential_decay_effect<true>(view_clock, lft, c_v_th, c_v_resting, c_k, c_dt)
+                                                               : delta_dirac_effect<true>(view_clock, lft, c_v_th, c_v_resting, c_k, c_dt));
         }
         // (2b) several row groups per tile: the groups other than 0 publish their chunk sums, group 0 collects them -- wavefront
         // 1 + j takes remote chunk j -- behind one more barrier of its own
@@ -759,6 +899,7 @@ __device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, Res
         if (UPDATER && updates) {
             uint32_t spike = 0;
             float v_new = 0.0f;
+            float t_new[K_TYPES] = {0.0f, 0.0f, 0.0f};       // CHEM: by TYPE, what the neuron releases after this step (0: not its type)
             if (in_registers) {
                 const ResidentRunArgs &b = a;
                 float *vhist_row = b.up.vhist_row ? b.up.vhist_row + (size_t)s * b.vhist_stride : nullptr;
@@ -811,20 +952,48 @@ __device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, Res
                 const ResidentRunArgs &b = a;
                 float *vhist_row = b.up.vhist_row ? b.up.vhist_row + (size_t)s * b.vhist_stride : nullptr;
                 if (col)
-                    spike = update_neuron_at<MODEL>(b.up, ql, LdsSums{sh.pi, nullptr, n_chunks, lane}, b.up.clock + s, vhist_row, &v_new);
+                    spike = update_neuron_at<MODEL>(b.up, ql, LdsSums{sh.pi, CHEM ? sh.pt : nullptr, n_chunks, lane}, b.up.clock + s, vhist_row,
+                                                    &v_new, CHEM ? t_new : nullptr);
             }
             if (a.up.spike_row) {
                 unsigned long long *spike_row = a.up.spike_row + (size_t)s * a.raster_stride;
                 const unsigned long long word = __ballot(spike != 0);
                 if (lane == 0) spike_row[(a.up.q0 + ql) >> 6] = word;
             }
+            // CHEM: a type the neuron does not release travels as 0 (t_new stays 0 where neuron_nt_update skipped the type; a
+            // neuron without the flag may still HOLD a concentration, which nobody reads)
+            float t_out[K_TYPES] = {0.0f, 0.0f, 0.0f};       // by live slot
+            if (CHEM) {
+#pragma unroll
+                for (uint32_t j = 0; j < K_TYPES; ++j)
+                    if (j < n_live) {
+                        const uint32_t type = a.live_type[j];
+                        const float tt = type == 0u ? t_new[0] : (type == 1u ? t_new[1] : t_new[2]);
+                        t_out[j] = (my_nt_mask >> type & 1u) ? tt : 0.0f;
+                    }
+            }
             if (alone) {
                 v_mine = col ? v_new : 0.0f;
                 if (col) sh.v[ql] = v_new;                    // read behind the next step's first barrier
+                if (CHEM) {
+#pragma unroll
+                    for (uint32_t j = 0; j < K_TYPES; ++j) {
+                        t_mine[j] = col ? t_out[j] : 0.0f;
+                        if (col && j < n_live) sh.t[j][ql] = t_out[j];
+                    }
+                }
             } else if (col && s + 1 < steps && !(a.fault_step == s + 1u && blockIdx.x == 0u)) {
-                unsigned long long *g = a.granules + (size_t)((s + 1) & 1u) * RUN_RESIDENT_MAX_NEURONS + in.q0 + ql;
+                unsigned long long *g = a.granules + (size_t)((s + 1) & 1u) * RUN_GRANULE_PLANES * RUN_RESIDENT_MAX_NEURONS + in.q0 + ql;
                 const unsigned long long x = ((unsigned long long)(tag_base + s + 1) << 32) | __float_as_uint(v_new);
                 __hip_atomic_store(g, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (CHEM) {
+#pragma unroll
+                    for (uint32_t j = 0; j < K_TYPES; ++j)
+                        if (j < n_live) {
+                            const unsigned long long y = ((unsigned long long)(tag_base + s + 1) << 32) | __float_as_uint(t_out[j]);
+                            __hip_atomic_store(g + (size_t)(1 + j) * RUN_RESIDENT_MAX_NEURONS, y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                }
             }
             lap(3);
         }
@@ -871,14 +1040,15 @@ __global__ __launch_bounds__(1024) void k_run_resident_probe(uint32_t *counter, 
     if (footprint.ok[0] == 0u) *counter = 0u;   // never: keeps the LDS footprint alive
 }
 
-template <int MODEL, bool REGISTERS, bool CELLS>
+template <int MODEL, bool REGISTERS, bool CELLS, bool CHEM = false>
 __global__ __launch_bounds__(1024) void k_run_resident(const ResidentRunArgs args)
 {
+    static_assert(!CHEM || !REGISTERS, "the register-resident update carries no receptors");
     __shared__ __attribute__((aligned(16))) ResidentRunShared sh;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (threadIdx.x == 0) sh.gave_up = 0u;                       // ordered before its first reader by the first step's barrier
-    if (wave == 0) run_resident_steps<MODEL, true, REGISTERS, CELLS>(args, sh, wave);
-    else run_resident_steps<MODEL, false, REGISTERS, CELLS>(args, sh, wave);
+    if (wave == 0) run_resident_steps<MODEL, true, REGISTERS, CELLS, CHEM>(args, sh, wave);
+    else run_resident_steps<MODEL, false, REGISTERS, CELLS, CHEM>(args, sh, wave);
     // a poll that gave up ended the loop early everywhere in the workgroup
     if (threadIdx.x == 0) {
         bool failed = false;

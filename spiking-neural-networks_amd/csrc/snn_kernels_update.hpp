@@ -66,8 +66,10 @@ __device__ __forceinline__ float combine_partials(const float *p, uint32_t n_chu
 
 // NeurotransmitterKinetics::apply_t_change: Approximate iterate_and_spike/mod.rs:193-196,
 // Destexhe :148-150
+// t_capture (or null): [K_TYPES], receives the new concentration of every type the neuron releases (the one-launch run
+// publishes it without reading it back)
 __device__ __forceinline__ void neuron_nt_update(const UpdateArgs &a, uint32_t q, float voltage,
-                                                 uint32_t spiking_prev, float dt)
+                                                 uint32_t spiking_prev, float dt, float *t_capture = nullptr)
 {
     if (!a.has_nt) return;
 #pragma unroll
@@ -91,6 +93,7 @@ __device__ __forceinline__ void neuron_nt_update(const UpdateArgs &a, uint32_t q
         }
         a.xout[at] = t;
         if (a.xout2) a.xout2[at] = t;
+        if (t_capture) t_capture[k] = t;
     }
 }
 
@@ -219,10 +222,11 @@ struct ChemicalStep {
     uint32_t q, ql, spiking_prev;
     float dt;
     const Sums &sums;
+    float *t_capture;
     __device__ __forceinline__ void update_receptor_kinetics() { receptors_kinetics(a, q, ql, dt, sums); }
     __device__ __forceinline__ void set_receptor_currents(float voltage) { receptors_set_currents(a, q, voltage); }
     __device__ __forceinline__ float get_receptor_currents(float step, float c_m) { return receptor_currents(a, q, step, c_m); }
-    __device__ __forceinline__ void apply_t_changes(float voltage) { neuron_nt_update(a, q, voltage, spiking_prev, dt); }
+    __device__ __forceinline__ void apply_t_changes(float voltage) { neuron_nt_update(a, q, voltage, spiking_prev, dt, t_capture); }
 };
 
 __device__ __forceinline__ float gate_update(float state, float alpha, float beta, float dt)
@@ -236,7 +240,7 @@ __device__ __forceinline__ float gate_update(float state, float alpha, float bet
 // returns its spike flag (and, where asked for, the voltage it stored).
 template <int MODEL, class Sums>
 __device__ __forceinline__ uint32_t update_neuron_at(const UpdateArgs &a, uint32_t ql, const Sums &sums, long long clock,
-                                                     float *vhist_row, float *v_stored = nullptr)
+                                                     float *vhist_row, float *v_stored = nullptr, float *t_capture = nullptr)
 {
     uint32_t spike = 0;
     {
@@ -278,7 +282,7 @@ __device__ __forceinline__ uint32_t update_neuron_at(const UpdateArgs &a, uint32
                 v_new = v + dv;
             }
             float w_new = w + dw;
-            neuron_nt_update(a, q, v_new, spiking_prev, dt);
+            neuron_nt_update(a, q, v_new, spiking_prev, dt, t_capture);
             if (v_new >= uload(a.n.uni, NP_V_TH, a.n.v_th, q)) {
                 spike = 1;
                 v_new = uload(a.n.uni, NP_C, a.n.c, q);
@@ -294,7 +298,7 @@ __device__ __forceinline__ uint32_t update_neuron_at(const UpdateArgs &a, uint32
             } else {
                 v_new = v + dv;
             }
-            neuron_nt_update(a, q, v_new, spiking_prev, dt);
+            neuron_nt_update(a, q, v_new, spiking_prev, dt, t_capture);
             float rc = a.n.refractory_count[q];
             if (rc > 0.0f) {
                 v_new = a.n.v_reset[q];
@@ -314,7 +318,7 @@ __device__ __forceinline__ uint32_t update_neuron_at(const UpdateArgs &a, uint32
             } else {
                 v_new = v + dv;
             }
-            neuron_nt_update(a, q, v_new, spiking_prev, dt);
+            neuron_nt_update(a, q, v_new, spiking_prev, dt, t_capture);
             float rc = a.n.refractory_count[q];
             if (rc > 0.0f) {
                 v_new = a.n.v_reset[q];
@@ -333,7 +337,7 @@ __device__ __forceinline__ uint32_t update_neuron_at(const UpdateArgs &a, uint32
             } else {
                 v_new = v + dv;
             }
-            neuron_nt_update(a, q, v_new, spiking_prev, dt);
+            neuron_nt_update(a, q, v_new, spiking_prev, dt, t_capture);
             if (v_new >= a.n.v_th[q]) {
                 spike = 1;
                 v_new = a.n.v_reset[q];
@@ -356,7 +360,7 @@ __device__ __forceinline__ uint32_t update_neuron_at(const UpdateArgs &a, uint32
                 v_new = v + dv;
             }
             float w_new = w + dw;
-            neuron_nt_update(a, q, v_new, spiking_prev, dt);
+            neuron_nt_update(a, q, v_new, spiking_prev, dt, t_capture);
             float rc = a.n.refractory_count[q];
             if (rc > 0.0f) {
                 v_new = a.n.v_reset[q];
@@ -380,7 +384,7 @@ __device__ __forceinline__ uint32_t update_neuron_at(const UpdateArgs &a, uint32
                 v_new = v + dv;
             }
             float w_new = w + dw;
-            neuron_nt_update(a, q, v_new, spiking_prev, dt);
+            neuron_nt_update(a, q, v_new, spiking_prev, dt, t_capture);
             if (v_new >= a.n.v_th[q]) {
                 spike = 1;
                 v_new = a.n.c[q];
@@ -397,13 +401,13 @@ __device__ __forceinline__ uint32_t update_neuron_at(const UpdateArgs &a, uint32
             const float g_gap = a.n.gap_conductance[q];
             float vc = v;
             if (own_chemical_step && a.chemical) {
-                ChemicalStep<Sums> chem{a, q, ql, spiking_prev, dt, sums};
+                ChemicalStep<Sums> chem{a, q, ql, spiking_prev, dt, sums, t_capture};
                 custom::on_electrochemical_iteration(vc, x, i_in, dt, c_m, g_gap, chem);
             } else {
                 custom::on_iteration(vc, x, i_in, dt, c_m, g_gap);
                 if (a.chemical) {          // the electrical form is on_iteration + spike handling alone (lib.rs:2266-2272)
                     vc -= receptor_currents(a, q, dt, c_m);
-                    neuron_nt_update(a, q, vc, spiking_prev, dt);
+                    neuron_nt_update(a, q, vc, spiking_prev, dt, t_capture);
                 }
             }
             spike = custom::spike_detection(vc, x, i_in, dt, c_m, g_gap) ? 1u : 0u;
@@ -436,7 +440,7 @@ __device__ __forceinline__ uint32_t update_neuron_at(const UpdateArgs &a, uint32
             const float i_sum = i_in - (i_na + i_k + i_kl);
             v_new = v + (dt * i_sum / c_m - i_ligand_gates);
 
-            neuron_nt_update(a, q, v_new, spiking_prev, dt);
+            neuron_nt_update(a, q, v_new, spiking_prev, dt, t_capture);
 
             const uint32_t increasing_right_now = v < v_new;
             const uint32_t threshold_crossed = v_new > a.n.v_th[q];

@@ -74,6 +74,10 @@ constexpr double EXP2F_C0 = 0x1.c6af84b912394p-5, EXP2F_C1 = 0x1.ebfce50fac4f3p-
 
 // expf as glibc computes it (e_expf.c, FMA build): k + r = x * 32/ln2 without rounding the product on its own,
 // 2^(k/32) from the table, a cubic in r.
+// LOCAL_CONSTANTS: the cubic's constant term is materialised where it is used (it is the accumulator of an FMA and has to sit
+// in a register pair; inside a long-lived loop the compiler otherwise keeps that pair alive across the loop -- and spilled it
+// in k_run_resident, whose registers are the weights').  Same arithmetic.
+template <bool LOCAL_CONSTANTS = false>
 __device__ __forceinline__ float expf_glibc(float x)
 {
     constexpr double inv_ln2_n = 0x1.71547652b82fep+0 * 32.0;
@@ -93,7 +97,14 @@ __device__ __forceinline__ float expf_glibc(float x)
     kd -= shift;
     const double r = __builtin_fma(inv_ln2_n, xd, -kd);
     const double s = __longlong_as_double((long long)(EXP2F_TAB[ki & 31] + (ki << 47)));
-    const double z = __builtin_fma(r, EXP2F_C0 / 32.0 / 32.0 / 32.0, EXP2F_C1 / 32.0 / 32.0);
+    double c1 = EXP2F_C1 / 32.0 / 32.0;
+    if (LOCAL_CONSTANTS) {
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(c1);
+        uint32_t lo = (uint32_t)bits, hi = (uint32_t)(bits >> 32);
+        asm volatile("" : "+s"(lo), "+s"(hi));       // two scalar literals here, moved into the register pair at the use
+        c1 = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+    }
+    const double z = __builtin_fma(r, EXP2F_C0 / 32.0 / 32.0 / 32.0, c1);
     const double r2 = r * r;
     double y = __builtin_fma(r, EXP2F_C2 / 32.0, 1.0);
     y = __builtin_fma(z, r2, y);
@@ -341,21 +352,23 @@ __device__ __forceinline__ uint32_t xorshift32(uint32_t x)
 }
 
 // DeltaDiracRefractoriness::get_effect (spike_train/mod.rs:67-88)
+template <bool LOCAL_CONSTANTS = false>
 __device__ __forceinline__ float delta_dirac_effect(long long timestep, int last_firing_time,
                                                     float v_th, float v_resting, float k, float dt)
 {
     const float a = v_th - v_resting;
     const float td = (float)(timestep - (long long)last_firing_time);
-    return a * expf_glibc((-1.0f / (k / dt)) * (td * td)) + v_resting;
+    return a * expf_glibc<LOCAL_CONSTANTS>((-1.0f / (k / dt)) * (td * td)) + v_resting;
 }
 
 // ExponentialDecayRefractoriness::get_effect (spike_train/mod.rs:164-178)
+template <bool LOCAL_CONSTANTS = false>
 __device__ __forceinline__ float exponential_decay_effect(long long timestep, int last_firing_time,
                                                           float v_th, float v_resting, float k, float dt)
 {
     const float a = v_th - v_resting;
     const float td = (float)(timestep - (long long)last_firing_time);
-    return a * expf_glibc((-1.0f / (k / dt)) * td) + v_resting;
+    return a * expf_glibc<LOCAL_CONSTANTS>((-1.0f / (k / dt)) * td) + v_resting;
 }
 
 // STDP::update_weight (plasticity/mod.rs:45-66): the delta added to the weight

@@ -352,6 +352,7 @@ static int set_graph_csr_impl(snn_network_t *net, const uint64_t *row_ptr, const
     if (!net->csr) return fail(SNN_ERR_BAD_STATE, "handle holds a dense graph: call snn_network_use_csr before finalize");
     if (!row_ptr || (nnz && (!pre_index || !weights))) return fail(SNN_ERR_BAD_ARG, "null graph pointer");
     if (nnz >= 0xFFFFFFFFull) return fail(SNN_ERR_DIM_MISMATCH, "more than 2^32-1 stored synapses per handle");
+    if ((uint64_t)net->nn + net->nc >= PLAN_CODE) return fail(SNN_ERR_DIM_MISMATCH, "the gather plan addresses fewer than 2^31-1 presynaptic rows");
     // the caller's rows are the OWNED neurons in ascending order; a range-set shard places them on its local rows
     // (global 64-blocks, holes in between keep length 0)
     const uint32_t n_loc = net->n_loc, n_rows = net->n_owned;
@@ -531,6 +532,7 @@ size_t trace_elems(const snn_network *net) { return net->csr ? (size_t)net->sell
 // changed.  Average of two passes after one warm pass, in ms.
 int time_rw_pass(snn_network *net, float *buf, size_t n4, float *ms)
 {
+    *ms = 0.0f;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return fail(SNN_ERR_QUEUE, "hipEventCreate failed");
     const unsigned blocks = 256 * 16;
@@ -926,7 +928,7 @@ int snn_run(snn_network_t *net, uint64_t iterations)
             if (net->run_failed && net->run_failed[0]) {
                 net->run_failed[0] = 0u;
                 TRY(run_snapshot(net, /*restore=*/true));
-                HIP_TRY(hipMemsetAsync(net->run_granules, 0, (size_t)2 * RUN_RESIDENT_MAX_NEURONS * 8, net->stream), SNN_ERR_BUFFER_WRITE);
+                HIP_TRY(hipMemsetAsync(net->run_granules, 0, RUN_GRANULE_WORDS * 8, net->stream), SNN_ERR_BUFFER_WRITE);
                 HIP_TRY(hipMemsetAsync(net->run_partials, 0, RUN_PARTIAL_WORDS * 8, net->stream), SNN_ERR_BUFFER_WRITE);
                 net->run_tag = 1;
                 net->clock = saved.clock; net->run_step_offset = saved.run_step_offset;
@@ -1502,6 +1504,7 @@ int snn_set_option(snn_network_t *net, const char *name, int value)
     else if (n == "defer_stdp") net->defer_stdp = (value == 2) ? 2 : (value != 0);
     else if (n == "uniform_params") { net->uniform_params = value != 0; net->uni_dirty = true; }
     else if (n == "persistent_run") { net->persistent_run = value != 0; net->run_probed_grid = 0; }
+    else if (n == "persistent_chem") net->persistent_chem = value != 0;
     else if (n == "run_resident_spin_limit") net->run_spin_limit = value > 0 ? (uint32_t)std::min<long long>(value, 0x7FFFFFFF) : RUN_RESIDENT_SPIN_LIMIT;
     else if (n == "run_resident_fault_step") net->run_fault_step = (uint32_t)std::max<long long>(value, 0);
     else if (n == "run_timing") net->run_timing_opt = value != 0;
@@ -1588,10 +1591,19 @@ int snn_input_kernel_bytes(const snn_network_t *net, uint64_t *bytes)
     if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
     if (net->csr) {
         // sparse: index + weight of every stored synapse; the one-launch step (k_step_csr) also is the neuron update of its
-        // rows: + S = 60 B of state per Izhikevich-class neuron ("8 B x nnz + S x N")
-        // ... and, when the spike-train cells advance in the same launch: + 28 B per cell (seed read + written, voltage and
-        // spike flag written, last firing time read, the 8-byte view entry written)
-        *bytes = (uint64_t)8 * net->nnz + (fused_csr_step_applies(net) ? (uint64_t)60 * net->n_loc : 0u);
+        // OWNED rows (the hole rows of a range-set shard move nothing): + S bytes of state per neuron ("8 B x nnz +
+        // S x N"), S by model -- the words update_neuron reads and writes per step: state read + written, parameters and the
+        // averager's count read, spike flag and raster bit written; Izhikevich 60 B as SURVEY 8d counts it -- plus, with
+        // chemical synapses, 44 B per live transmitter type (t read + written, two kinetics parameters, receptor r read +
+        // written, g, e, current, two flag words).  ... and, when the spike-train cells advance in the same launch: + 28 B per
+        // cell (seed read + written, voltage and spike flag written, last firing time read, the 8-byte view entry written).
+        // ALGORITHMIC bytes: what the step has to move, not what the counters saw.
+        static const uint32_t S_MODEL[8] = {60, 68, 140, 64, 44, 80, 88, 64};
+        uint64_t per_neuron = net->model == SNN_MODEL_CUSTOM ? (uint64_t)8 * custom::NVARS + 28
+                                                            : S_MODEL[net->model == SNN_MODEL_BCM_IZHIKEVICH ? 0 : net->model & 7];
+        if (net->model == SNN_MODEL_BCM_IZHIKEVICH) per_neuron += 36;       // activities, window clock, period, spike count
+        if (net->chemical) per_neuron += (uint64_t)44 * net->n_live;
+        *bytes = (uint64_t)8 * net->nnz + (fused_csr_step_applies(net) ? per_neuron * net->n_owned : 0u);
         if (fused_csr_step_applies(net) && cells_ride_allowed(net))
             *bytes += (uint64_t)28 * (net->cell_list_dev ? net->n_cells_listed : net->nc);
         return SNN_OK;

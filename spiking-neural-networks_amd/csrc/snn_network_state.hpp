@@ -214,6 +214,7 @@ struct snn_network {
     // many steps of a small lattice in one launch (k_run_resident): granule slots, the next free step tag, and a
     // host-visible word the kernel sets when its workgroups could not see each other
     int persistent_run = 1;               // 0: one launch per step (SNN_AMD_PERSISTENT_RUN=0)
+    int persistent_chem = 1;              // option "persistent_chem": 0 keeps networks with chemical synapses on the per-step forms
     unsigned long long *run_granules = nullptr;
     unsigned long long *run_partials = nullptr;
     uint32_t run_tag = 1;

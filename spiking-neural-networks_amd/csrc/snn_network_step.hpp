@@ -428,6 +428,7 @@ int flush_rstdp(snn_network *net)
 // kernel is timed on both (one warm + one timed pass each, once per handle) and the faster allocation is kept.
 int time_input_pass(snn_network *net, float *ms)
 {
+    *ms = 0.0f;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return fail(SNN_ERR_QUEUE, "hipEventCreate failed");
     // a pass over a matrix of a few GiB is short: several timed passes per candidate, or the 1 % decision threshold is noise
@@ -593,22 +594,26 @@ int launch_step_resident(snn_network *net)
     return SNN_OK;
 }
 
-// Small electrical-only lattices of neurons: ALL steps of a run call in one launch (k_run_resident) when nothing has to
-// happen between two steps on the host's side of the stream -- no cells, no weight updates, no per-step reductions, every
-// step recorded (or none).
+// Small lattices of neurons: ALL steps of a run call in one launch (k_run_resident) when nothing has to happen between two
+// steps on the host's side of the stream -- no weight updates, no per-step reductions, every step recorded (or none), cells
+// (if any) Poisson or Rate without transmitters.  Electrical synapses: up to 4096 rows; with chemical synapses (built-in
+// kinetics): one row group, up to 1024 rows.
 bool run_resident_applies(const snn_network *net)
 {
+    const bool chem_ok = !net->chemical || (net->n_tot <= RUN_RESIDENT_GROUP_ROWS && net->persistent_chem &&
+                                            net->nt_kind != SNN_NT_CUSTOM && net->rc_kind != SNN_RC_CUSTOM);
     return !SNN_HAVE_CUSTOM_MODEL && net->fused_step && !net->csr && !net->sharded && !net->drive_threshold && net->n_loc &&
            net->persistent_run && net->n_loc == net->nn && net->nn + net->nc == net->n_tot &&
            (net->nc == 0 || ((net->st_kind == SNN_ST_POISSON || net->st_kind == SNN_ST_RATE) && !net->any_nt_cells &&
                              !net->cell_list_dev && !SNN_HAVE_CUSTOM_REFRACTORINESS)) &&
-           net->n_tot <= RUN_RESIDENT_MAX_NEURONS && net->electrical && !net->chemical && !net->any_plasticity &&
+           net->n_tot <= RUN_RESIDENT_MAX_NEURONS && (net->electrical || net->chemical) && chem_ok && !net->any_plasticity &&
            !net->any_modulation && !net->any_whist && !net->want_avg && !net->want_eeg && net->hist_every == 1 &&
            net->model != SNN_MODEL_BCM_IZHIKEVICH && !net->local_inputs_done &&
            !net->external_stream;       // the run's outcome is read after a host synchronisation (snn_run)
 }
 
 // chunk sums travelling between the row groups of a tile: [2][tiles][groups - 1][4 chunks][64] granules
+constexpr size_t RUN_GRANULE_WORDS = (size_t)2 * RUN_GRANULE_PLANES * RUN_RESIDENT_MAX_NEURONS;
 constexpr size_t RUN_PARTIAL_WORDS = (size_t)2 * RUN_RESIDENT_MAX_TILES * (RUN_RESIDENT_MAX_GROUPS - 1) * 256;
 
 // What a one-launch run may overwrite is every SMALL array of the handle: per-neuron and per-cell state, the exchange
@@ -663,8 +668,8 @@ int run_snapshot(snn_network *net, bool restore)
 int launch_run_resident(snn_network *net, uint64_t iterations)
 {
     if (!net->run_granules) {
-        TRY(dev_alloc_t(net, &net->run_granules, (size_t)2 * RUN_RESIDENT_MAX_NEURONS));
-        HIP_TRY(hipMemsetAsync(net->run_granules, 0, (size_t)2 * RUN_RESIDENT_MAX_NEURONS * 8, net->stream), SNN_ERR_BUFFER_WRITE);
+        TRY(dev_alloc_t(net, &net->run_granules, RUN_GRANULE_WORDS));
+        HIP_TRY(hipMemsetAsync(net->run_granules, 0, RUN_GRANULE_WORDS * 8, net->stream), SNN_ERR_BUFFER_WRITE);
         TRY(dev_alloc_t(net, &net->run_partials, RUN_PARTIAL_WORDS));
         HIP_TRY(hipMemsetAsync(net->run_partials, 0, RUN_PARTIAL_WORDS * 8, net->stream), SNN_ERR_BUFFER_WRITE);
         HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&net->run_failed), 8, hipHostMallocMapped), SNN_ERR_BUFFER_CREATE);
@@ -693,7 +698,7 @@ int launch_run_resident(snn_network *net, uint64_t iterations)
     while (iterations) {
         const uint32_t steps = (uint32_t)std::min<uint64_t>(iterations, 1u << 20);
         if (net->run_tag > 0xFFFFFFFFu - steps - 2u) {           // tags would wrap: start over on clean slots
-            HIP_TRY(hipMemsetAsync(net->run_granules, 0, (size_t)2 * RUN_RESIDENT_MAX_NEURONS * 8, net->stream), SNN_ERR_BUFFER_WRITE);
+            HIP_TRY(hipMemsetAsync(net->run_granules, 0, RUN_GRANULE_WORDS * 8, net->stream), SNN_ERR_BUFFER_WRITE);
             HIP_TRY(hipMemsetAsync(net->run_partials, 0, RUN_PARTIAL_WORDS * 8, net->stream), SNN_ERR_BUFFER_WRITE);
             net->run_tag = 1;
         }
@@ -718,8 +723,13 @@ int launch_run_resident(snn_network *net, uint64_t iterations)
         r.st_vhist_stride = net->c_pad;
         if (!net->run_timing && (net->run_timing_opt || getenv("SNN_AMD_RUN_TIMING"))) TRY(dev_alloc_t(net, &net->run_timing, (size_t)RUN_RESIDENT_MAX_TILES * RUN_RESIDENT_MAX_GROUPS * 4));
         r.timing = net->run_timing;
+        // chemical synapses: the transmitter types some NEURON releases travel (cells with transmitters keep the per-step forms)
+        if (net->chemical)
+            for (uint32_t k = 0; k < K_TYPES; ++k)
+                if (net->live_mask_applied != 0xFFFFFFFFu && (net->live_mask_applied >> k & 1u)) r.live_type[r.n_live++] = k;
         hipLaunchKernelGGL(k_run_resident_seed, dim3((net->nn + 255) / 256), dim3(256), 0, net->stream, net->xbuf, net->xl,
-                           net->nn, net->run_granules, r.tag_base);
+                           net->nn, net->run_granules, r.tag_base, net->na.nt_flags, net->n_pad, r.n_live, r.live_type[0],
+                           r.live_type[1], r.live_type[2]);
         HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
         // profiling: one event pair around the launch, counted as `steps` passes over the graph
         hipEvent_t e1 = nullptr;
@@ -728,10 +738,16 @@ int launch_run_resident(snn_network *net, uint64_t iterations)
         const dim3 grid(n_groups), block(1024);
 #define SNN_RUN_RESIDENT(M) hipLaunchKernelGGL((k_run_resident<M, false, false>), grid, block, 0, net->stream, r)
 #define SNN_RUN_RESIDENT_CELLS(M) hipLaunchKernelGGL((k_run_resident<M, false, true>), grid, block, 0, net->stream, r)
+#define SNN_RUN_RESIDENT_CHEM(M) hipLaunchKernelGGL((k_run_resident<M, false, false, true>), grid, block, 0, net->stream, r)
+#define SNN_RUN_RESIDENT_CHEM_CELLS(M) hipLaunchKernelGGL((k_run_resident<M, false, true, true>), grid, block, 0, net->stream, r)
 #if !SNN_HAVE_CUSTOM_MODEL
         // neuron state in registers for the whole run where the kernel carries the model's update itself
-        const bool regs = !r.up.has_nt && !r.up.bcm;
-        if (net->nc && regs && net->model == SNN_MODEL_IZHIKEVICH) {               // rows that are spike-train cells
+        const bool regs = !r.up.has_nt && !r.up.bcm && !net->chemical;
+        if (net->chemical && net->nc) {                                            // chemical synapses: the generic update
+            SNN_FOR_MODEL(SNN_RUN_RESIDENT_CHEM_CELLS);
+        } else if (net->chemical) {
+            SNN_FOR_MODEL(SNN_RUN_RESIDENT_CHEM);
+        } else if (net->nc && regs && net->model == SNN_MODEL_IZHIKEVICH) {        // rows that are spike-train cells
             hipLaunchKernelGGL((k_run_resident<0, true, true>), grid, block, 0, net->stream, r);
         } else if (net->nc && regs && net->model == SNN_MODEL_LIF) {
             hipLaunchKernelGGL((k_run_resident<1, true, true>), grid, block, 0, net->stream, r);
@@ -757,6 +773,8 @@ int launch_run_resident(snn_network *net, uint64_t iterations)
 #endif
 #undef SNN_RUN_RESIDENT
 #undef SNN_RUN_RESIDENT_CELLS
+#undef SNN_RUN_RESIDENT_CHEM
+#undef SNN_RUN_RESIDENT_CHEM_CELLS
         HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
         if (e1) HIP_TRY(hipEventRecord(e1, net->stream), SNN_ERR_QUEUE);
         if (net->run_timing) {          // debugging aid: workgroup 0's phases in shader clocks per step

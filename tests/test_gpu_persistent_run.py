@@ -118,11 +118,13 @@ MODELS = [ob.IZHIKEVICH, ob.LIF, ob.HH, ob.QIF, ob.SIMPLE_LIF, ob.ADAPTIVE_LIF, 
 
 
 def draw(seed):
-    """1-3 electrical-only lattices of one model with per-neuron parameters, random density (0 included), negative weights;
-    every other network with one or two lattices of Poisson / Rate cells."""
+    """1-3 lattices of one model with per-neuron parameters, random density (0 included), negative weights; every other
+    network with one or two lattices of Poisson / Rate cells; every third one with chemical synapses (with or without gap
+    junctions, random transmitter / receptor flags and kinetics, one row group: <= 1024 rows), the others electrical only."""
     rng = np.random.default_rng(1000 + seed)
     model = MODELS[seed % len(MODELS)]
-    big = seed % 5 == 0                                   # some networks beyond one row group
+    chem = seed % 3 == 2
+    big = seed % 5 == 0 and not chem                      # some networks beyond one row group
     lattices = []
     for i in range(int(rng.integers(1, 4))):
         hi_side = 26 if big else 14
@@ -131,11 +133,20 @@ def draw(seed):
     if seed % 2:                                          # every other network: Poisson or Rate cells as presynaptic rows
         st_kind = ob.ST_POISSON if seed % 4 == 1 else ob.ST_RATE
         st_lattices = [(100 + i, int(rng.integers(1, 12)), int(rng.integers(1, 12))) for i in range(int(rng.integers(1, 3)))]
-    net = parity.make_oracle(parity.Layout(lattices, st_lattices), model=model, st_kind=st_kind, electrical=True, chemical=False)
+    electrical = not chem or bool(rng.integers(0, 2))
+    kinetics = dict(nt_kind=int(rng.integers(0, 4)), rc_kind=int(rng.integers(0, 3))) if chem else {}
+    net = parity.make_oracle(parity.Layout(lattices, st_lattices), model=model, st_kind=st_kind, electrical=electrical, chemical=chem,
+                             **kinetics)
     n = net.n_neurons
+    net["nt_flags"][...] = 0
+    if chem:
+        live = rng.random(3) < 0.6                        # transmitter types nobody releases stay off the wire
+        net["nt_flags"][...] = (rng.random((n, 3)) < 0.5) & live
+        net["rc_flags"][...] = rng.random((n, 3)) < 0.6
+        net["rc_g"][...] *= ob.uniform_array(seed + 23, 3 * n, 0.5, 3.0).reshape(n, 3)
+        net["nt_t"][...] = rng.random((n, 3)).astype(np.float32)     # also where the flag is off: held, never released
     if net.n_cells:
         nc = net.n_cells
-        net["nt_flags"][...] = 0
         net["st_nt_flags"][...] = 0
         net["st_seed"] = rng.integers(1, 2**32 - 1, nc, dtype=np.uint32)
         net["st_chance_of_firing"] = ob.uniform_array(seed + 14, nc, 0.0, 0.08)
@@ -173,6 +184,73 @@ def draw(seed):
     net["do_plasticity"] = 0
     calls = [int(c) for c in rng.integers(1, 120, int(rng.integers(1, 4)))]
     return net, calls, bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+
+
+def build_chemical(model, rows, cols, seed, types, nt_kind, rc_kind, electrical=True, density=0.75):
+    net = parity.make_oracle(parity.Layout([(3, rows, cols)]), model=model, electrical=electrical, chemical=True, nt_kind=nt_kind, rc_kind=rc_kind)
+    n = net.n_neurons
+    rng = np.random.default_rng(seed)
+    lo, hi = {ob.IZHIKEVICH: (-65, 30), ob.LIF: (-80, -50), ob.HH: (-75, -40), ob.QIF: (-75, -56)}.get(model, (-70, -50))
+    net["current_voltage"] = ob.uniform_array(seed, n, lo, hi)
+    net["gap_conductance"] = ob.uniform_array(seed + 5, n, 2.0, 10.0)
+    if model in (ob.LIF, ob.QIF):
+        net["tref"] = ob.uniform_array(seed + 1, n, 0.3, 1.5)
+        net["tau_m"] = 10.0
+    flags = np.zeros((n, 3), bool)
+    flags[:, list(types)] = rng.random((n, len(types))) < 0.7
+    net["nt_flags"][...] = flags
+    net["rc_flags"][...] = rng.random((n, 3)) < 0.7
+    net["rc_g"][...] *= ob.uniform_array(seed + 23, 3 * n, 0.5, 2.0).reshape(n, 3)
+    net["nt_t"][...] = rng.random((n, 3)).astype(np.float32)
+    net.fill_graph(seed + 3, 0.5, 1.5)
+    net["connections"][rng.random(net["connections"].shape) >= density] = 0
+    net["weights"][...] *= net["connections"]
+    net["do_plasticity"] = 0
+    return net
+
+
+@pytest.mark.parametrize("model,rows,cols,types,nt_kind,rc_kind,electrical,seed", [
+    (ob.IZHIKEVICH, 4, 4, (0,), 0, 0, True, 61), (ob.IZHIKEVICH, 16, 16, (0,), 0, 0, True, 62), (ob.IZHIKEVICH, 32, 32, (0,), 0, 0, True, 63),
+    (ob.IZHIKEVICH, 31, 33, (0, 1, 2), 1, 1, True, 64), (ob.IZHIKEVICH, 20, 20, (1, 2), 2, 2, False, 65),
+    (ob.HH, 12, 12, (0,), 1, 1, True, 66), (ob.LIF, 9, 30, (0, 2), 3, 0, True, 67), (ob.QIF, 8, 8, (), 0, 0, True, 68)])
+def test_chemical_synapses_in_the_one_launch_run(snn, model, rows, cols, types, nt_kind, rc_kind, electrical, seed):
+    """k_run_resident<..., CHEM>: the released concentrations travel as granules of their own next to the voltages, the weighted
+    sums of every live transmitter type keep the canonical order -- bit-identical to the one-launch-per-step form and the
+    oracle, for every kinetics pair, several live types, no live type at all, and chemical synapses alone."""
+    net = build_chemical(model, rows, cols, seed, types, nt_kind, rc_kind, electrical)
+    a = compare(snn, net, [150, 2, 5, 43])
+    assert a["launches"] == 3
+
+
+def test_chemical_run_with_cells_and_rollback(snn):
+    """cells that release nothing ride along (Poisson rows); a faulted launch is rolled back and repeated per step"""
+    lay = parity.Layout([(3, 18, 18)], [(1, 6, 10)])
+    net = parity.make_oracle(lay, model=ob.IZHIKEVICH, st_kind=ob.ST_POISSON, electrical=True, chemical=True, nt_kind=0, rc_kind=0)
+    n = net.n_neurons
+    rng = np.random.default_rng(71)
+    net["st_chance_of_firing"] = 0.05
+    net["st_nt_flags"][...] = 0
+    net["current_voltage"] = ob.uniform_array(71, n, -65, 30)
+    net["gap_conductance"] = ob.uniform_array(72, n, 2.0, 10.0)
+    net["nt_flags"][...] = rng.random((n, 3)) < 0.6
+    net["rc_flags"][...] = rng.random((n, 3)) < 0.6
+    net["nt_t"][...] = rng.random((n, 3)).astype(np.float32) * net["nt_flags"]
+    net.fill_graph(73, 0.5, 1.5)
+    net["connections"][rng.random(net["connections"].shape) >= 0.6] = 0
+    net["weights"][...] *= net["connections"]
+    dn = parity.device_from_oracle(snn, net)
+    dn.set_history(voltage=True, spikes=True)
+    dn.run(70)
+    assert dn.stat("persistent_run_launches") == 1
+    dn.set_option("run_resident_spin_limit", 1 << 11)
+    dn.set_option("run_resident_fault_step", 23)
+    dn.run(60)
+    assert dn.stat("persistent_run_fallbacks") == 1
+    net.run(130, voltage_history=True, spike_history=True)
+    parity.assert_state_equal(net, parity.pull_state(dn, net))
+    assert np.array_equal(dn.spike_history(3), net.spike_history)
+    assert np.array_equal(parity.bits(dn.voltage_history(3)), parity.bits(net.voltage_history))
+    dn.close()
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("SNN_RANDOM_SEEDS_PERSISTENT", "32"))))     # (env: a longer campaign)
