@@ -17,7 +17,7 @@ import snn_amd              # noqa: E402
 from snn_amd import synthetic   # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 4000
-CASES = [(8, 1, "el+AMPA"), (16, 1, "el+AMPA"), (24, 1, "el+AMPA"), (32, 1, "el+AMPA"), (32, 3, "el+AMPA+NMDA+GABA"), (16, 0, "el only"), (32, 0, "el only")]
+CASES = [(int(c.split(":")[0]), int(c.split(":")[1]), c) for c in os.environ["SNN_CASES"].split(",")] if "SNN_CASES" in os.environ else [(8, 1, "el+AMPA"), (16, 1, "el+AMPA"), (24, 1, "el+AMPA"), (32, 1, "el+AMPA"), (32, 3, "el+AMPA+NMDA+GABA"), (16, 0, "el only"), (32, 0, "el only")]
 for side, types, what in CASES:
     for persistent in (1, 0):
         n = side * side
@@ -29,10 +29,10 @@ for side, types, what in CASES:
         dn.fill_graph_synthetic(2, 0.5, 1.5, with_diagonal=False)
         if types:
             flags = np.zeros((n, 3), np.uint32)
-            flags[:, :types] = 1
+            flags[:, :max(types, 0)] = 1                      # (types < 0: chemical synapses on, nobody releases anything)
             dn.set_attr(0, "neurotransmitters$flags", flags)
             dn.set_attr(0, "receptors$flags", flags)
-        dn.set_synapses(True, types > 0)
+        dn.set_synapses(True, types != 0)
         dn.set_option("persistent_chem" if types else "persistent_run", persistent)
         dn.set_reduced_history(False, False, True)
         dn.run(200)
@@ -42,7 +42,16 @@ for side, types, what in CASES:
             dn.run(steps)
             reps.append((time.perf_counter() - t0) / steps * 1e6)
         spikes = int(dn.spike_counts(0).sum())
+        phases = None
+        if dn.stat("persistent_run_launches"):
+            # shader-clock totals of workgroup 0's four phases over one more launch (option "run_timing"), as shares of a step
+            dn.set_option("run_timing", 1)
+            dn.run(steps)
+            n = max(1, dn.stat("run_timing_steps"))
+            clocks = {k: dn.stat("run_timing_" + k) / n for k in ("poll", "barrier", "turns", "update")}
+            tot = sum(clocks.values()) or 1.0
+            phases = {k: sorted(reps)[2] * v / tot for k, v in clocks.items()}
         print(json.dumps({"lattice": f"{side}x{side}", "synapses": what, "one_launch_run": bool(dn.stat("persistent_run_launches")),
                           "us_per_step": sorted(reps)[2], "us_per_step_runs": reps, "steps": steps,
-                          "spikes_per_step": spikes / (200 + 5 * steps), "fallbacks": dn.stat("persistent_run_fallbacks")}), flush=True)
+                          "spikes_per_step": spikes / (200 + 5 * steps), "phases_us_per_step": phases, "fallbacks": dn.stat("persistent_run_fallbacks")}), flush=True)
         dn.close()

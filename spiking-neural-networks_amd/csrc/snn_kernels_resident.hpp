@@ -14,6 +14,7 @@
 //     xout2); the host flips the shadows every step.
 // Arithmetic and update code are those of k_inputs_dense / k_update: results are bit-identical.
 #pragma once
+#include <cstddef>
 #include "snn_kernels_inputs.hpp"
 #include "snn_kernels_update.hpp"
 
@@ -297,35 +298,48 @@ __global__ __launch_bounds__(256) void k_run_resident_seed(const float *xbuf, XL
     }
 }
 
+// Order matters: on gfx950 LDS addresses above 64 KB are several times slower than the first 64 KB (measured here: the same
+// broadcast reads of a 64-row chain took 1.56 us from an array at 96 KB and 0.52 us from one at 4 KB).  What the turns read row by
+// row and batch by batch comes first; what a thread touches once per step (the cells' own state) lies above the line.
 struct ResidentRunShared {
+    // ---- below 64 KB: read inside the chains ----
     float v[RUN_RESIDENT_GROUP_ROWS];            // S(t): the voltages of this workgroup's rows
     float vcol[64];                              // ... and of its columns
+    // chemical synapses: per live transmitter type the concentrations of the rows, the running sum of a chunk between turns,
+    // and -- by TYPE, as LdsSums reads them -- the finished chunk sums (one row group: at most 4 chunks)
+    float t[K_TYPES][RUN_RESIDENT_GROUP_ROWS];
+    float hand_t[K_TYPES][RESIDENT_MAX_CHUNKS][64];
+    float pt[K_TYPES][RESIDENT_MAX_CHUNKS][64];
     float hand[RESIDENT_MAX_CHUNKS][64];         // running sum of a chunk, from one wavefront's turn to the next
     float pi[RUN_RESIDENT_MAX_ALL_CHUNKS][64];   // finished chunk sums: own group's at 4 * group .., group 0 also the collected ones
     v4f w0[16][64];                              // wavefront 0's weights (its registers belong to the update)
     uint32_t ok[16], plain[16];                  // per wavefront: all its granules arrived / all its values small and finite
+    uint32_t w_finite[16];                       // per wavefront: every weight it holds is finite
     uint32_t gave_up;                            // sticky: some poll of chunk sums gave up
-    // networks with cells: per row of the workgroup, its kind and -- for a cell -- its state
-    uint32_t kind[RUN_RESIDENT_GROUP_ROWS];      // KIND_NEURON / KIND_ST_SILENT / KIND_ST_FIRED
     uint32_t block_fired[16], block_silent[16];  // per 64-row block of the workgroup: all its cells have fired / none has
+    // wavefront 0, CHEM with the update in registers: the per-neuron constants of the receptors and transmitters, [slot][lane]
+    // (per type k: alpha, beta, g, e of the receptor, t_max, clearance, v_p, k_p of the transmitter at 8 * k ..; slot 24: NMDA mg)
+    float chem_par[25][64];
+    float chem_state[9][64];                     // ... and their state: r, current, t of type k at 3 * k ..
+    uint32_t chem_cnt[K_TYPES][64];              // ... and the receptor's input count per type
+    // networks with cells: per row of the workgroup, its kind and this step's (s, f) of a row (see the step loop) and n: 1 for a
+    // neuron's row, 0 for a cell's
+    float cell_s[RUN_RESIDENT_GROUP_ROWS], cell_f[RUN_RESIDENT_GROUP_ROWS];
+    float cell_n[RUN_RESIDENT_GROUP_ROWS];
+    uint32_t kind[RUN_RESIDENT_GROUP_ROWS];      // KIND_NEURON / KIND_ST_SILENT / KIND_ST_FIRED (read where a value is not finite)
+    // ---- above 64 KB: a cell's own state, touched by its thread once per step ----
     uint32_t cell_word[RUN_RESIDENT_GROUP_ROWS]; // Poisson: seed; Rate: step (float bits)
     int32_t cell_lft[RUN_RESIDENT_GROUP_ROWS];
     float cell_presyn[RUN_RESIDENT_GROUP_ROWS], cell_v[RUN_RESIDENT_GROUP_ROWS];
-    float cell_s[RUN_RESIDENT_GROUP_ROWS], cell_f[RUN_RESIDENT_GROUP_ROWS];   // this step's (s, f) of a row, see the step loop
-    float cell_n[RUN_RESIDENT_GROUP_ROWS];                                    // ... and n: 1 for a neuron's row, 0 for a cell's
     // a cell's parameters, read once: chance of firing | rate, v_th, v_resting, dt, k, refractoriness kind, and the clock of its
     // lattice at the launch's first step (64 bits in two words) -- read from the arrays every step they were a chain of
     // dependent global loads per cell
     float cell_par[5][RUN_RESIDENT_GROUP_ROWS];
     uint32_t cell_refr[RUN_RESIDENT_GROUP_ROWS], cell_clock_lo[RUN_RESIDENT_GROUP_ROWS], cell_clock_hi[RUN_RESIDENT_GROUP_ROWS];
     uint32_t cell_spiking[RUN_RESIDENT_GROUP_ROWS];
-    // chemical synapses: per live transmitter type the concentrations of the rows, the running sum of a chunk between turns,
-    // and -- by TYPE, as LdsSums reads them -- the finished chunk sums (one row group: at most 4 chunks)
-    float t[K_TYPES][RUN_RESIDENT_GROUP_ROWS];
-    float hand_t[K_TYPES][RESIDENT_MAX_CHUNKS][64];
-    float pt[K_TYPES][RESIDENT_MAX_CHUNKS][64];
-    uint32_t w_finite[16];                       // per wavefront: every weight it holds is finite
 };
+static_assert(offsetof(ResidentRunShared, cell_n) <= 65536, "the arrays the chains read must lie in the first 64 KB of LDS");
+
 
 // The step loop of one wavefront.  UPDATER = wavefront 0, which also owns the neuron update of the workgroup's 64 columns: it
 // keeps its weights in LDS and, for Izhikevich neurons without transmitters, the neurons' state in registers for the whole
@@ -400,6 +414,11 @@ __device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, Res
     float nv = 0.0f, n2 = 0.0f, n_div = 1.0f;        // voltage; Izhikevich w / refractory_count; the averager's divisor
     float pr[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};   // the model's parameters (see below)
     uint32_t n_spikes = 0, last_spike = 0;
+    // ... and, CHEM (Izhikevich only): per type the receptor (r, current, g, e, kinetics parameters, input count) and the
+    // transmitter (t, its kinetics parameters); c_flags bit k: receptor present, bit 8 + k: the neuron releases the type
+    // (the constants of the kinetics wait in LDS: ResidentRunShared::chem_par)
+    float c_dt = 0.0f;
+    uint32_t c_flags = 0u;
     if (in_registers && updates && col) {
         const NeuronArrays &n = a.up.n;
         const uint32_t q = a.up.rows.global_of(ql);
@@ -426,6 +445,26 @@ __device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, Res
             pr[0] = n.slif_g[q]; pr[1] = n.slif_e[q]; pr[2] = dt; pr[5] = n.v_reset[q]; pr[6] = n.v_th[q];
         }
         last_spike = reinterpret_cast<const uint32_t *>(n.xbuf)[n.xl.at(q, PLANE_SPIKE)];
+        if (CHEM) {
+            // Izhikevich with chemical synapses, built-in kinetics: receptors and transmitters in registers too (ChemStep's
+            // arithmetic, snn_kernels_update.hpp; iterate_and_spike/mod.rs:1186-1304, 148-196)
+            c_dt = dt;
+            sh.chem_par[24][lane] = n.rc_mg[(size_t)1 * n.n_pad + q];
+#pragma unroll
+            for (int k = 0; k < K_TYPES; ++k) {
+                const size_t i = (size_t)k * n.n_pad + q;
+                c_flags |= n.rc_flags[i] ? (1u << k) : 0u;
+                c_flags |= (a.up.has_nt && n.nt_flags[i]) ? (0x100u << k) : 0u;
+                sh.chem_cnt[k][lane] = a.up.tcount[(size_t)k * a.up.ld + ql];
+                sh.chem_state[3 * k][lane] = n.rc_r[i];
+                sh.chem_state[3 * k + 1][lane] = n.rc_current[i];
+                sh.chem_state[3 * k + 2][lane] = n.xbuf[n.xl.at(q, PLANE_T0 + k)];
+                sh.chem_par[8 * k + 0][lane] = n.rc_alpha[i]; sh.chem_par[8 * k + 1][lane] = n.rc_beta[i];
+                sh.chem_par[8 * k + 2][lane] = n.rc_g[i]; sh.chem_par[8 * k + 3][lane] = n.rc_e[i];
+                sh.chem_par[8 * k + 4][lane] = n.nt_t_max[i]; sh.chem_par[8 * k + 5][lane] = n.nt_clearance[i];
+                sh.chem_par[8 * k + 6][lane] = n.nt_v_p[i]; sh.chem_par[8 * k + 7][lane] = n.nt_k_p[i];
+            }
+        }
     }
 
     // this thread's row as a spike-train cell (CELLS: the variant launched for networks with cells)
@@ -908,9 +947,45 @@ __device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, Res
                     for (uint32_t c = 0; c < n_chunks; ++c) sum += sh.pi[c][lane];
                     const float i_in = sum / n_div;
                     if (MODEL == 0) {            // Izhikevich
-                        const float dv = (0.04f * (nv * nv) + 5.0f * nv + 140.0f - n2 + i_in) * pr[0];
+                        const float dv = (0.04f * (nv * nv) + 5.0f * nv + 140.0f - n2 + (CHEM && !b.up.electrical ? 0.0f : i_in)) * pr[0];
                         const float dw = (pr[2] * (pr[3] * nv - n2)) * pr[1];
-                        v_new = nv + dv;
+                        if (CHEM) {
+                            // receptor kinetics from this step's transmitter input, currents at the old voltage, their sum
+                            float total = 0.0f;
+#pragma unroll
+                            for (int k = 0; k < K_TYPES; ++k) {
+                                const uint32_t c_cnt = sh.chem_cnt[k][lane];
+                                const bool on = (c_flags >> k & 1u) != 0u, fed = on && c_cnt != 0u;
+                                float c_r = sh.chem_state[3 * k][lane];
+                                if (fed) {
+                                    float st = 0.0f;
+                                    for (uint32_t c = 0; c < n_chunks; ++c) st += sh.pt[k][c][lane];
+                                    c_r = rc_apply(b.up.rc_kind, c_r, st / (float)c_cnt, sh.chem_par[8 * k][lane], sh.chem_par[8 * k + 1][lane], c_dt);
+                                    sh.chem_state[3 * k][lane] = c_r;
+                                }
+                                if (on) {
+                                    const float c_g = sh.chem_par[8 * k + 2][lane], c_e = sh.chem_par[8 * k + 3][lane];
+                                    const float c_cur = k == 1 ? ((1.0f / (1.0f + ((expf_glibc(-0.062f * nv) * sh.chem_par[24][lane]) / 3.75f)) * c_g) * c_r) * (nv - c_e)
+                                                               : (c_g * c_r) * (nv - c_e);
+                                    sh.chem_state[3 * k + 1][lane] = c_cur;
+                                    total += c_cur;
+                                }
+                            }
+                            const float neurotransmitter_dv = -(total * pr[0]);
+                            v_new = nv + (dv + neurotransmitter_dv);
+                            // the neuron's own release: previous spike flag, the voltage before the reset
+#pragma unroll
+                            for (int k = 0; k < K_TYPES; ++k) {
+                                t_new[k] = 0.0f;
+                                if (c_flags >> (8 + k) & 1u) {
+                                    t_new[k] = nt_apply(b.up.nt_kind, sh.chem_state[3 * k + 2][lane], sh.chem_par[8 * k + 4][lane], sh.chem_par[8 * k + 5][lane],
+                                                        sh.chem_par[8 * k + 6][lane], sh.chem_par[8 * k + 7][lane], v_new, last_spike, c_dt);
+                                    sh.chem_state[3 * k + 2][lane] = t_new[k];
+                                }
+                            }
+                        } else {
+                            v_new = nv + dv;
+                        }
                         float w_new = n2 + dw;
                         if (v_new >= pr[6]) {
                             spike = 1;
@@ -1016,6 +1091,14 @@ __device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, Res
             reinterpret_cast<uint32_t *>(a.up.xout)[n.xl.at(q, PLANE_SPIKE)] = last_spike;
             if (MODEL == 0) n.w_value[q] = n2;
             if (MODEL == 1 || MODEL == 3) n.refractory_count[q] = n2;
+            if (CHEM) {
+#pragma unroll
+                for (int k = 0; k < K_TYPES; ++k) {
+                    const size_t i = (size_t)k * n.n_pad + q;
+                    if (c_flags >> k & 1u) { n.rc_r[i] = sh.chem_state[3 * k][lane]; n.rc_current[i] = sh.chem_state[3 * k + 1][lane]; }
+                    if (c_flags >> (8 + k) & 1u) a.up.xout[n.xl.at(q, PLANE_T0 + k)] = sh.chem_state[3 * k + 2][lane];
+                }
+            }
             if (a.up.spike_counts && n_spikes) a.up.spike_counts[q] += n_spikes;
         }
         if (a.timing && lane == 0)
@@ -1043,7 +1126,7 @@ __global__ __launch_bounds__(1024) void k_run_resident_probe(uint32_t *counter, 
 template <int MODEL, bool REGISTERS, bool CELLS, bool CHEM = false>
 __global__ __launch_bounds__(1024) void k_run_resident(const ResidentRunArgs args)
 {
-    static_assert(!CHEM || !REGISTERS, "the register-resident update carries no receptors");
+    static_assert(!CHEM || !REGISTERS || MODEL == 0, "receptors in registers: Izhikevich only");
     __shared__ __attribute__((aligned(16))) ResidentRunShared sh;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (threadIdx.x == 0) sh.gave_up = 0u;                       // ordered before its first reader by the first step's barrier

@@ -35,6 +35,8 @@ struct UpdateArgs {
     // shadow copy (n.xbuf) while it writes S(t+1) to the exchange buffer and to the other shadow (`xout2`).
     float *xout, *xout2;
     int has_nt;                 // some neuron of the handle releases a neurotransmitter (else the flag planes are not read)
+    uint32_t live_mask;         // bit k: some neuron or cell of the handle releases transmitter type k (all ones: unknown).  A
+                                // type nobody releases has count 0 at every receptor: its kinetics inputs are never loaded
     int bcm;                    // BCMIzhikevichNeuron: keep the activity bookkeeping (the step itself is Izhikevich's)
     int model_is_custom;        // the generated neuron model: it uses the library's generated receptor set, if any
     // Dense shard handles (all-gather exchange): k_update writes the handle's own slot of the wire buffer itself -- per plane
@@ -215,6 +217,101 @@ __device__ __forceinline__ float receptor_currents(const UpdateArgs &a, uint32_t
     return total * (dt / c_m);
 }
 
+// ---- the built-in chemical step with every load ahead of every store ------------------------------------------------
+// A neuron's update is one wavefront walking a dozen small arrays; as the reference writes it (kinetics, then currents,
+// then the sum of the currents, then the transmitter release, each type behind a flag test) every flagged type costs a chain
+// of dependent memory round trips -- flag -> count -> r -> store r -> load r -> store current -> load current -- because a
+// store may alias the next load.  Measured on MI355X: 1.9 us per live type in the one-launch run of a 32 x 32 lattice, and
+// the better part of k_update<2>'s 12 us at BASELINE configs[2].  Same arithmetic, restated as: load everything the step
+// can need (independent loads, one round trip), compute in registers, store at the end of update_neuron_at.
+struct ChemStep {
+    bool rc_on = false, nt_on = false;     // the fused forms are in use (built-in kinetics)
+    float total = 0.0f;                    // (I_AMPA + I_NMDA + I_GABA) of the receptors present, in that order
+    float r_new[K_TYPES], cur_new[K_TYPES];
+    uint32_t store_r = 0, store_cur = 0;   // bit k: write r_new[k] / cur_new[k] back
+    uint32_t nt_flags = 0;                 // bit k: the neuron releases type k
+    float nt_t[K_TYPES], nt_t_max[K_TYPES], nt_c[K_TYPES], nt_v_p[K_TYPES], nt_k_p[K_TYPES], nt_new[K_TYPES];
+};
+
+// Ionotropic::update_receptor_kinetics + set_receptor_currents + the sum of get_receptor_currents
+// (iterate_and_spike/mod.rs:1186-1205, 1260-1304), built-in receptor kinetics
+template <class Sums>
+__device__ __forceinline__ void chem_receptors(const UpdateArgs &a, uint32_t q, uint32_t ql, float v_old, float dt, const Sums &sums, ChemStep &c)
+{
+    uint32_t fl[K_TYPES], cnt[K_TYPES];
+    float r[K_TYPES], al[K_TYPES], be[K_TYPES], g[K_TYPES], e[K_TYPES], s[K_TYPES];
+    const float mg = a.n.rc_mg[(size_t)1 * a.n.n_pad + q];
+#pragma unroll
+    for (int k = 0; k < K_TYPES; ++k) {
+        const size_t i = (size_t)k * a.n.n_pad + q;
+        const bool live = (a.live_mask >> k & 1u) != 0u;                 // launch-uniform
+        fl[k] = a.n.rc_flags[i];
+        r[k] = a.n.rc_r[i]; g[k] = a.n.rc_g[i]; e[k] = a.n.rc_e[i];
+        cnt[k] = 0u; al[k] = 0.0f; be[k] = 0.0f; s[k] = 0.0f;
+        if (live) {
+            cnt[k] = a.tcount[(size_t)k * a.ld + ql];
+            al[k] = a.n.rc_alpha[i]; be[k] = a.n.rc_beta[i];
+            s[k] = sums.chem(k);                                         // second level of the canonical sum
+        }
+    }
+    c.rc_on = true;
+    c.total = 0.0f;
+#pragma unroll
+    for (int k = 0; k < K_TYPES; ++k) {
+        const bool on = fl[k] != 0u, fed = on && cnt[k] != 0u;           // a type absent from the input leaves r untouched
+        const float t = s[k] / (float)(fed ? cnt[k] : 1u);               // the per-type average
+        const float rk = fed ? rc_apply(a.rc_kind, r[k], t, al[k], be[k], dt) : r[k];
+        const float cur = k == 1 ? ((1.0f / (1.0f + ((expf_glibc(-0.062f * v_old) * mg) / 3.75f)) * g[k]) * rk) * (v_old - e[k])
+                                 : (g[k] * rk) * (v_old - e[k]);
+        c.r_new[k] = rk; c.cur_new[k] = cur;
+        c.store_r |= fed ? (1u << k) : 0u;
+        c.store_cur |= on ? (1u << k) : 0u;
+        if (on) c.total += cur;
+    }
+}
+
+// the loads of NeurotransmitterKinetics::apply_t_change for the types the neuron releases (built-in kinetics)
+__device__ __forceinline__ void chem_nt_load(const UpdateArgs &a, uint32_t q, ChemStep &c)
+{
+    c.nt_on = true;
+    if (!a.has_nt) return;
+#pragma unroll
+    for (int k = 0; k < K_TYPES; ++k) {
+        c.nt_t[k] = 0.0f; c.nt_t_max[k] = 0.0f; c.nt_c[k] = 0.0f; c.nt_v_p[k] = 0.0f; c.nt_k_p[k] = 1.0f;
+        if (!(a.live_mask >> k & 1u)) continue;                          // launch-uniform: nobody releases this type
+        const size_t i = (size_t)k * a.n.n_pad + q;
+        c.nt_flags |= a.n.nt_flags[i] ? (1u << k) : 0u;
+        c.nt_t[k] = a.n.xbuf[a.n.xl.at(q, PLANE_T0 + k)];
+        c.nt_t_max[k] = a.n.nt_t_max[i]; c.nt_c[k] = a.n.nt_clearance[i]; c.nt_v_p[k] = a.n.nt_v_p[i]; c.nt_k_p[k] = a.n.nt_k_p[i];
+    }
+}
+
+// ... its arithmetic (at the place the reference calls apply_t_changes: after the voltage update, before the spike test) ...
+__device__ __forceinline__ void chem_nt_apply(const UpdateArgs &a, ChemStep &c, float voltage, uint32_t spiking_prev, float dt)
+{
+#pragma unroll
+    for (int k = 0; k < K_TYPES; ++k)
+        c.nt_new[k] = (c.nt_flags >> k & 1u) ? nt_apply(a.nt_kind, c.nt_t[k], c.nt_t_max[k], c.nt_c[k], c.nt_v_p[k], c.nt_k_p[k], voltage, spiking_prev, dt)
+                                             : 0.0f;
+}
+
+// ... and every store of the chemical step, at the end of the neuron's update
+__device__ __forceinline__ void chem_store(const UpdateArgs &a, uint32_t q, const ChemStep &c, float *t_capture)
+{
+#pragma unroll
+    for (int k = 0; k < K_TYPES; ++k) {
+        const size_t i = (size_t)k * a.n.n_pad + q;
+        if (c.rc_on && (c.store_r >> k & 1u)) a.n.rc_r[i] = c.r_new[k];
+        if (c.rc_on && (c.store_cur >> k & 1u)) a.n.rc_current[i] = c.cur_new[k];
+        if (c.nt_on && (c.nt_flags >> k & 1u)) {
+            const size_t at = a.n.xl.at(q, PLANE_T0 + k);
+            a.xout[at] = c.nt_new[k];
+            if (a.xout2) a.xout2[at] = c.nt_new[k];
+            if (t_capture) t_capture[k] = c.nt_new[k];
+        }
+    }
+}
+
 // What a generated on_electrochemical_iteration (nb_macro lib.rs:2280-2316) may call on its neuron
 template <class Sums>
 struct ChemicalStep {
@@ -267,7 +364,24 @@ __device__ __forceinline__ uint32_t update_neuron_at(const UpdateArgs &a, uint32
         }
 
         constexpr bool own_chemical_step = MODEL == CUSTOM_MODEL && custom::HAS_ELECTROCHEMICAL;
-        if (a.chemical && !own_chemical_step) receptors_update(a, q, ql, v, dt, sums);
+        // built-in kinetics (every library without generated code): the chemical step loads first and stores last (ChemStep)
+        const bool fused_rc = MODEL != CUSTOM_MODEL && !(SNN_HAVE_CUSTOM_RECEPTORS && a.model_is_custom) &&
+                              !(SNN_HAVE_CUSTOM_RC && a.rc_kind == CUSTOM_KINETICS);
+        const bool fused_nt = MODEL != CUSTOM_MODEL && !(SNN_HAVE_CUSTOM_NT && a.nt_kind == CUSTOM_KINETICS);
+        ChemStep cs;
+        if (a.chemical && !own_chemical_step) {
+            if (fused_rc) chem_receptors(a, q, ql, v, dt, sums, cs);
+            else receptors_update(a, q, ql, v, dt, sums);
+        }
+        if (fused_nt) chem_nt_load(a, q, cs);
+        // (the reference's get_receptor_currents / apply_t_changes at their places in the model's step)
+        auto receptor_currents = [&](const UpdateArgs &aa, uint32_t qq, float step, float cm) {
+            return cs.rc_on ? cs.total * (step / cm) : snn::receptor_currents(aa, qq, step, cm);
+        };
+        auto neuron_nt_update = [&](const UpdateArgs &aa, uint32_t qq, float voltage, uint32_t prev, float step, float *capture) {
+            if (cs.nt_on) chem_nt_apply(aa, cs, voltage, prev, step);
+            else snn::neuron_nt_update(aa, qq, voltage, prev, step, capture);
+        };
 
         float v_new;
         if (MODEL == 0) {            // Izhikevich
@@ -431,6 +545,8 @@ __device__ __forceinline__ uint32_t update_neuron_at(const UpdateArgs &a, uint32
 
             const float i_kl = a.n.g_k_leak[q] * (v - a.n.e_k_leak[q]);
 
+            const float hh_v_th = a.n.v_th[q];                       // (loaded ahead of the stores below: a store may alias a later load)
+            const uint32_t hh_was_increasing = a.n.was_increasing[q];
             a.n.m_alpha[q] = m_a; a.n.m_beta[q] = m_b; a.n.h_alpha[q] = h_a; a.n.h_beta[q] = h_b;
             a.n.n_alpha[q] = n_a; a.n.n_beta[q] = n_b;
             a.n.m_state[q] = m; a.n.h_state[q] = h; a.n.n_state[q] = ng;
@@ -443,11 +559,12 @@ __device__ __forceinline__ uint32_t update_neuron_at(const UpdateArgs &a, uint32
             neuron_nt_update(a, q, v_new, spiking_prev, dt, t_capture);
 
             const uint32_t increasing_right_now = v < v_new;
-            const uint32_t threshold_crossed = v_new > a.n.v_th[q];
-            spike = threshold_crossed && a.n.was_increasing[q] && !increasing_right_now;
+            const uint32_t threshold_crossed = v_new > hh_v_th;
+            spike = threshold_crossed && hh_was_increasing && !increasing_right_now;
             a.n.was_increasing[q] = increasing_right_now;
         }
 
+        chem_store(a, q, cs, t_capture);
         a.xout[v_at] = v_new;
         reinterpret_cast<uint32_t *>(a.xout)[s_at] = spike;
         if (a.xout2) {

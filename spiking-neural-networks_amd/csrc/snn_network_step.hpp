@@ -265,6 +265,7 @@ int launch_update(snn_network *net)
     a.spike_counts = net->want_counts ? net->spike_counts : nullptr;
     a.xout = net->xbuf; a.xout2 = nullptr;
     a.has_nt = net->any_nt_neurons ? 1 : 0;
+    a.live_mask = net->live_mask_applied;       // transmitter types some neuron or cell releases (ensure_counts; all ones: unknown)
     a.bcm = net->model == SNN_MODEL_BCM_IZHIKEVICH;
     a.model_is_custom = net->model == SNN_MODEL_CUSTOM;
     // dense shard handles: the own slot of the all-gather buffer is written by this launch (no pack launch)
@@ -545,6 +546,7 @@ int fused_step_args(snn_network *net, InputsArgs &a, UpdateArgs &u, bool in_plac
     u.spike_counts = net->want_counts ? net->spike_counts : nullptr;
     u.xout = net->xbuf; u.xout2 = next;
     u.has_nt = net->any_nt_neurons ? 1 : 0;
+    u.live_mask = net->live_mask_applied;
     u.bcm = net->model == SNN_MODEL_BCM_IZHIKEVICH;
     return SNN_OK;
 }
@@ -745,6 +747,8 @@ int launch_run_resident(snn_network *net, uint64_t iterations)
         const bool regs = !r.up.has_nt && !r.up.bcm && !net->chemical;
         if (net->chemical && net->nc) {                                            // chemical synapses: the generic update
             SNN_FOR_MODEL(SNN_RUN_RESIDENT_CHEM_CELLS);
+        } else if (net->chemical && net->model == SNN_MODEL_IZHIKEVICH) {          // ... Izhikevich: receptors and transmitters resident too
+            hipLaunchKernelGGL((k_run_resident<0, true, false, true>), grid, block, 0, net->stream, r);
         } else if (net->chemical) {
             SNN_FOR_MODEL(SNN_RUN_RESIDENT_CHEM);
         } else if (net->nc && regs && net->model == SNN_MODEL_IZHIKEVICH) {        // rows that are spike-train cells

@@ -55,9 +55,10 @@ def test_csr_handle_equals_oracle(snn, chemical):
     net.run(600, voltage_history=True, spike_history=True)
     assert net.spike_history.sum() > 20
     check(dn, net)
-    # 8 B per stored synapse + the 60 B of neuron state per row that the one-launch step (k_step_csr) also moves
+    # 8 B per stored synapse + the 60 B of Izhikevich state per owned row that the one-launch step (k_step_csr) also moves, + 44 B
+    # per row and live transmitter type with chemical synapses (here AMPA and GABA)
     # (+ 28 B per spike-train cell when the cells advance in that launch: electrical-only handles without weight updates)
-    assert dn.input_kernel_bytes() == 8 * int(net["connections"].sum()) + 60 * net.n_neurons
+    assert dn.input_kernel_bytes() == 8 * int(net["connections"].sum()) + (60 + (88 if chemical else 0)) * net.n_neurons
     dn.set_option("fused_step", 0)
     assert dn.input_kernel_bytes() == 8 * int(net["connections"].sum())         # k_inputs_csr alone
     dn.close()

@@ -17,7 +17,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # <MODEL, REGISTERS, CELLS, CHEM> as launch_run_resident (csrc/snn_network_step.hpp) picks them
 VARIANTS = ([(m, False, c, True) for m in range(8) for c in (False, True)] +
             [(m, False, c, False) for m in range(8) for c in (False, True)] +
-            [(m, True, c, False) for m in (0, 1, 3, 4) for c in (False, True)])
+            [(m, True, c, False) for m in (0, 1, 3, 4) for c in (False, True)] + [(0, True, False, True)])
 
 
 @pytest.fixture(scope="module")
