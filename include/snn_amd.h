@@ -454,7 +454,9 @@ int snn_set_option(snn_network_t *net, const char *name, int value);
 /* Which step form the handle has used so far, as launch counts since creation: "persistent_run_launches" (k_run_resident:
  * many steps per launch), "persistent_run_steps" (steps those launches covered), "persistent_run_fallbacks" (launches that
  * gave up and were rolled back, see above); with option "run_timing": "run_timing_poll" / "_barrier" / "_turns" /
- * "_update" (shader clocks of workgroup 0 over the last launch) and "run_timing_steps" (its steps); "halo_direct_steps"
+ * "_update" (shader clocks of workgroup 0 over the last launch) and "run_timing_steps" (its steps); "persistent_run_external_stream" (run calls of 4
+ * steps or more that stayed on one launch per step ONLY because the handle runs on a caller's stream, snn_set_stream: the
+ * one-launch run reads its outcome after a host synchronisation); "halo_direct_steps"
  * (steps of library-driven runs whose rows gathered the halo from the received segments); the form every step outside a
  * one-launch run took: "steps_dense_one_launch" (k_step_resident), "steps_sparse_one_launch" (k_step_csr over all rows),
  * "steps_sparse_split" (border + interior launches of a shard handle), "steps_two_kernel" (input pass + k_update); and

@@ -912,6 +912,7 @@ int snn_run(snn_network_t *net, uint64_t iterations)
     HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
     TRY(begin_run(net, iterations));
     uint64_t it = 0;
+    if (iterations >= 4 && net->external_stream && run_resident_shape(net)) net->stat_run_external_stream += 1;
     if (iterations >= 4 && run_resident_applies(net)) {          // below that the launch's fixed cost (seed, weights into registers) shows
         // The launch is a spin-wait all-to-all between workgroups that must all be resident.  A probe vouches for that
         // once per handle; should they lose sight of each other later all the same (device shared with a long kernel),
@@ -1336,10 +1337,18 @@ static int agree_on_exchange(Rccl *R, snn_network *net, ncclComm_t comm, void *n
     if (!rc) {
         uint32_t mask = (uint32_t)net->x_mode << 8;
         for (uint32_t s = 0; s < net->x_planes; ++s) mask |= 1u << net->x_plane_id[s];
-        rc = gather(mask);
-        for (uint32_t p = 0; p < G && !rc; ++p)
-            if (words[p] != mask)
+        // bit 31: this rank's mirror lacks a plane of the plan (mirror_stale).  A plane can only go missing when the plan
+        // grows -- which is when this agreement runs -- and whether it is missing is rank-local history (host-driven steps,
+        // attributes written on some ranks only): if ANY rank is stale, EVERY rank sends its current state once before the
+        // first step (idempotent), instead of one rank entering a collective its peers never post.
+        rc = gather(mask | (mirror_stale(net) ? 0x80000000u : 0u));
+        bool any_stale = false;
+        for (uint32_t p = 0; p < G && !rc; ++p) {
+            any_stale = any_stale || (words[p] >> 31) != 0u;
+            if ((words[p] & 0x7FFFFFFFu) != mask)
                 rc = fail(SNN_ERR_BAD_STATE, "the ranks of this communicator disagree on the exchange (synapse kinds / transmitter types / mode)");
+        }
+        if (!rc) net->refresh_agreed = any_stale;
     }
     (void)hipFree(d_words);
     if (!rc) net->x_agreed = true;
@@ -1371,8 +1380,10 @@ int snn_run_sharded(snn_network_t *net, void *nccl_comm, uint64_t iterations)
     // cross-stream events -- the step is its kernels
     bool travels = net->x_mode == SNN_EXCHANGE_ALLGATHER;
     for (uint32_t p = 0; p < net->n_shards && !travels; ++p) travels = net->x_send_words[p] || net->x_recv_words[p];
-    if (mirror_stale(net)) {
-        // a plane the plan needs was not on the wire so far: the owners' current state travels once before the first step
+    if (mirror_stale(net) || net->refresh_agreed) {
+        // a plane the plan needs was not on the wire so far (here, or on some other rank: agree_on_exchange): the owners'
+        // current state travels once before the first step
+        net->refresh_agreed = false;
         TRY(refresh_pack(net));
         if (travels) {
             HIP_TRY(hipEventRecord(net->ev_packed, net->stream), SNN_ERR_QUEUE);
@@ -1522,6 +1533,7 @@ int snn_get_stat(snn_network_t *net, const char *name, uint64_t *value)
     else if (n == "persistent_run_steps") *value = net->stat_run_steps;
     else if (n == "persistent_run_fallbacks") *value = net->stat_run_fallbacks;
     else if (n == "halo_direct_steps") *value = net->stat_direct_steps;
+    else if (n == "persistent_run_external_stream") *value = net->stat_run_external_stream;
     else if (n == "steps_dense_one_launch") *value = net->stat_steps_dense_one_launch;
     else if (n == "steps_sparse_one_launch") *value = net->stat_steps_sparse_one_launch;
     else if (n == "steps_sparse_split") *value = net->stat_steps_sparse_split;

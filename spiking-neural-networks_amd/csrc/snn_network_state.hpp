@@ -126,6 +126,7 @@ struct snn_network {
     // between two runs) calls for one exchange of the current state before the next step (refresh_*, snn_network_exchange.hpp)
     uint32_t mirror_mask = 0xFFFFFFFFu;
     bool x_agreed = false;                      // the ranks of the communicator compared their plans (snn_run_sharded)
+    bool refresh_agreed = false;                // ... and some rank's mirror lacked a plane: all refresh before the next run's first step
     int x_mode = SNN_EXCHANGE_ALLGATHER;
     uint32_t x_planes = 0, x_plane_id[WIRE_MAX_PLANES] = {0, 0, 0, 0};
     uint64_t x_block_words = 0;                 // all-gather: words per shard slot
@@ -221,6 +222,7 @@ struct snn_network {
     uint32_t *run_failed = nullptr;       // hipHostMalloc: [0] a run gave up, [1] the co-residency probe said no
     uint32_t run_probed_grid = 0;         // grid size the probe last vouched for
     uint64_t stat_run_launches = 0, stat_run_steps = 0, stat_run_fallbacks = 0;
+    uint64_t stat_run_external_stream = 0;      // run calls that kept one launch per step only because the handle runs on a caller's stream
     // which form each step took (statistics "steps_*"): k_step_resident, k_step_csr whole, k_step_csr border + interior,
     // input pass + k_update
     uint64_t stat_steps_dense_one_launch = 0, stat_steps_sparse_one_launch = 0, stat_steps_sparse_split = 0, stat_steps_two_kernel = 0;

@@ -600,7 +600,13 @@ int launch_step_resident(snn_network *net)
 // steps on the host's side of the stream -- no weight updates, no per-step reductions, every step recorded (or none), cells
 // (if any) Poisson or Rate without transmitters.  Electrical synapses: up to 4096 rows; with chemical synapses (built-in
 // kinetics): one row group, up to 1024 rows.
+bool run_resident_shape(const snn_network *net);
 bool run_resident_applies(const snn_network *net)
+{
+    // the run's outcome is read after a host synchronisation (snn_run): not on a caller's stream
+    return run_resident_shape(net) && !net->external_stream;
+}
+bool run_resident_shape(const snn_network *net)
 {
     const bool chem_ok = !net->chemical || (net->n_tot <= RUN_RESIDENT_GROUP_ROWS && net->persistent_chem &&
                                             net->nt_kind != SNN_NT_CUSTOM && net->rc_kind != SNN_RC_CUSTOM);
@@ -610,8 +616,7 @@ bool run_resident_applies(const snn_network *net)
                              !net->cell_list_dev && !SNN_HAVE_CUSTOM_REFRACTORINESS)) &&
            net->n_tot <= RUN_RESIDENT_MAX_NEURONS && (net->electrical || net->chemical) && chem_ok && !net->any_plasticity &&
            !net->any_modulation && !net->any_whist && !net->want_avg && !net->want_eeg && net->hist_every == 1 &&
-           net->model != SNN_MODEL_BCM_IZHIKEVICH && !net->local_inputs_done &&
-           !net->external_stream;       // the run's outcome is read after a host synchronisation (snn_run)
+           net->model != SNN_MODEL_BCM_IZHIKEVICH && !net->local_inputs_done;
 }
 
 // chunk sums travelling between the row groups of a tile: [2][tiles][groups - 1][4 chunks][64] granules

@@ -510,3 +510,22 @@ def test_a_run_that_gives_up_is_rolled_back_and_repeated_per_step(snn, rows, col
     assert np.array_equal(dn.spike_counts(3), net.spike_counts)
     assert net.spike_history.sum() > 0 or model != ob.IZHIKEVICH
     dn.close()
+
+
+def test_a_callers_stream_keeps_one_launch_per_step_and_says_so(snn):
+    """snn_set_stream: the one-launch run reads its outcome after a host synchronisation, so a handle on a caller's stream keeps
+    the per-step form -- counted by the statistic "persistent_run_external_stream", gone when the stream is handed back"""
+    import torch
+    net = build(ob.IZHIKEVICH, 12, 12, 77)
+    dn = parity.device_from_oracle(snn, net)
+    side = torch.cuda.Stream()
+    dn.set_stream(side.cuda_stream)
+    dn.run(40)
+    dn.synchronize()
+    assert dn.stat("persistent_run_launches") == 0 and dn.stat("persistent_run_external_stream") == 1
+    dn.set_stream(None)
+    dn.run(40)
+    assert dn.stat("persistent_run_launches") == 1 and dn.stat("persistent_run_external_stream") == 1
+    net.run(80)
+    parity.assert_state_equal(net, parity.pull_state(dn, net))
+    dn.close()
