@@ -74,6 +74,31 @@ def self_launch(gpus):
     return proc.returncode
 
 
+def plasticity_report(dn, pl_ms, pl_steps, spikes_per_step, config):
+    """the weight-update launches of a step (spike compaction + STDP scatter), HIP events: time, the bytes the rule has to touch
+    and -- dense handles -- the 128-byte LINES those bytes sit in, which is what the scatter moves (its roofline)"""
+    if not pl_steps:
+        return None
+    n_local = sum(e - b for b, e in dn.ranges)
+    ms = pl_ms / pl_steps
+    useful = 8.0 * (dn.n_tot + n_local) * spikes_per_step
+    out = {"ms_per_step": ms, "steps_measured": pl_steps, "touched_bytes_per_step": useful,
+           "note": "spike compaction + column/row weight updates of this rank, HIP events; touched bytes = 8 B x (n_tot + n_local) "
+                   "per spiking neuron (SURVEY 8d)"}
+    if config in ("c2", "c4") and spikes_per_step > 0:
+        # quad-row layout: a spiking neuron's column lies in n_tot / 4 lines (16 B of each), its row in n_local / 8 lines
+        # (4 B of every fourth word); each line is read and written back
+        lines = spikes_per_step * (dn.n_tot / 4.0 + n_local / 8.0)
+        line_bytes = lines * 128.0 * 2.0
+        out["roofline"] = {"bound": "hbm (line traffic of a scatter)", "line_bytes_per_step": line_bytes,
+                           "achieved_line_GBps": line_bytes / (ms * 1e-3) / 1e9, "useful_GBps": useful / (ms * 1e-3) / 1e9,
+                           "useful_over_line_bytes": useful / line_bytes, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac_of_peak_useful": useful / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                           "frac_of_peak_lines": line_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                           "compare_with": "measured_device_ceilings.copy_GBps of the default c2 line (read + write)"}
+    return out
+
+
 def mem_available_bytes():
     try:
         for line in open("/proc/meminfo"):
@@ -505,10 +530,7 @@ def main():
             "ms_per_step_min": min(runs) / args.steps * 1e3, "ms_per_step_max": max(runs) / args.steps * 1e3,
             "spikes_per_step": spikes / total_steps,
             "state_sha256": state_sha, "state_after_steps": state_steps,
-            "plasticity": ({"ms_per_step": pl_ms / pl_steps, "steps_measured": pl_steps,
-                            "touched_bytes_per_step": 8.0 * (dn.n_tot + sum(e - b for b, e in dn.ranges)) * spikes / total_steps / world,
-                            "note": "spike compaction + column/row weight updates of this rank, HIP events; touched bytes = "
-                                    "8 B x (n_tot + n_local) per spiking neuron"} if pl_steps else None),
+            "plasticity": plasticity_report(dn, pl_ms, pl_steps, spikes / total_steps / world, args.config),
             # strong: --gpus N shards the SAME network (total work fixed as N grows); weak (c5): every rank keeps the N = 1 share
             "scaling": args.scaling,
             "stepper": (("library (snn_run_sharded, RCCL called by libsnn_amd.so)" if comm is not None else

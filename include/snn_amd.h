@@ -310,6 +310,31 @@ typedef struct snn_collectives {
     int (*group_end)(void);
 } snn_collectives;
 int snn_set_collectives(const snn_collectives *table);
+
+/* ---- the peer form of a library-driven run (sparse shard handles, halo exchange, voltage the only plane) ------------
+ * One launch per step and no collective: the rows of a shard that a peer reads store {voltage, step tag | spike flag} as ONE
+ * 8-byte granule straight into that peer's receive set (peer-mapped memory: the same process, or an IPC mapping), the rows
+ * of the next step read a granule when its tag is the step's, and a done counter per peer -- stored by the last workgroup of
+ * a step's launch into the neighbours' memory -- says when a set may be overwritten.  RCCL is only needed to trade the
+ * addresses (or not at all: they are plain numbers).  Used by snn_run_sharded / snn_run_sharded_custom once the handle is
+ * connected: snn_p2p_local on every rank -> the four numbers travel by the host's means -> snn_p2p_connect for every peer
+ * this rank exchanges with -> snn_p2p_commit.  A rebuilt exchange plan (other synapse kinds, new halo lists) starts
+ * unconnected again.  Failure: a value or a done counter that does not arrive within "halo_peer_spin_limit" polls ends the
+ * run call with SNN_ERR_WAIT (the handle is then in the middle of a step; there is no roll-back across ranks).
+ * Options: "halo_peer" [1] 0 keeps the collective on a connected handle.  Statistic: "halo_peer_steps".
+ * Status: built and tested with 2 - 8 shard handles of ONE process on one GPU (tests/test_gpu_halo_peer.py); the IPC pair
+ * below wraps hipIpcGetMemHandle / hipIpcOpenMemHandle for ranks in different processes and has not run across devices. */
+/* addresses (in THIS process) of the handle's two receive sets and its done counters; per shard p the granule offset and
+ * count of what arrives from p (recv_offsets / recv_counts: [n_shards], may be null) */
+int snn_p2p_local(snn_network_t *net, uint64_t *recv0, uint64_t *recv1, uint64_t *flags, uint64_t *recv_offsets, uint64_t *recv_counts);
+/* where this handle's values go on shard `peer`: that peer's receive sets and done counters as mapped in this process, and the
+ * peer's recv_offsets[this shard] */
+int snn_p2p_connect(snn_network_t *net, uint32_t peer, uint64_t peer_recv0, uint64_t peer_recv1, uint64_t peer_flags,
+                    uint64_t peer_recv_offset);
+int snn_p2p_commit(snn_network_t *net);
+/* ranks in different processes: three 64-byte IPC handles (receive set 0, set 1, done counters) of a handle; the peer opens them */
+int snn_p2p_ipc_export(snn_network_t *net, void *handles_3x64_bytes);
+int snn_p2p_ipc_import(int device, const void *handles_3x64_bytes, uint64_t *recv0, uint64_t *recv1, uint64_t *flags);
 /* CSR shard handles: all ranks call it once after snn_set_graph_csr; trades the need lists and commits the halo plan */
 int snn_comm_exchange_halo_lists(snn_network_t *net, void *nccl_comm);
 /* One exchange of the packed segments, enqueued on the handle's stream (between snn_step_begin and snn_step_end) */

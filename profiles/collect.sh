@@ -3,7 +3,7 @@
 # into profiles/rNN/).  Per config: rocprofv3 --kernel-trace --stats of bench.py (kernel stats csv + the bench line of
 # that profiled process), then two separate --pmc passes (FETCH_SIZE, WRITE_SIZE) reduced by summarize_pmc.py.
 set -u
-R=${1:-r03}
+R=${1:-r04}
 OUT=$PWD/gpurun_out/$R
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$OLDPWD"
@@ -48,7 +48,15 @@ pmc c6 k_inputs_rstdp --config c6 --steps 10 --warmup 2 --repeats 1
 pmc c5 k_step_csr --config c5 --steps 50 --warmup 5 --repeats 1
 # what ONE rank of G does per step, without its exchange (the library's loop with a transport that moves nothing)
 python3 profiles/measure_c5_rank_step.py 2000 > "$OUT/c5_rank_step.jsonl" 2> /dev/null
+PEER=1 python3 profiles/measure_c5_rank_step.py 2000 > "$OUT/c5_rank_step_peer_form.jsonl" 2> /dev/null
 python3 profiles/measure_shard_shapes.py 200 > "$OUT/c2_shard_shapes.jsonl" 2> /dev/null
+# small lattices with chemical synapses: the one-launch run against one launch per step
+python3 profiles/measure_small_chem.py 3000 2> /dev/null | grep lattice > "$OUT/small_chemical_lattices.jsonl"
+# the default lines (no profiler): headline, c1 with the latency roofline, c3, c5
+python3 bench.py > "$OUT/bench_default.json" 2> /dev/null
+python3 bench.py --config c1 --no-cpu-baseline > "$OUT/c1_bench_default.json" 2> /dev/null
+python3 bench.py --config c3 --no-cpu-baseline > "$OUT/c3_bench_default.json" 2> /dev/null
+python3 bench.py --config c5 --no-cpu-baseline > "$OUT/c5_bench_default.json" 2> /dev/null
 rm -rf "$OUT/trace_g8"
 ( cd /tmp && SHARDS=8 rocprofv3 --kernel-trace --output-format csv -d "$OUT/trace_g8" -- python3 "$OLDPWD/profiles/measure_c5_rank_step.py" 1000 > /dev/null 2>&1 )
 python3 profiles/experiments/kernel_gaps.py "$(find "$OUT/trace_g8" -name '*kernel_trace.csv' | head -1)" 400 > "$OUT/c5_rank_step_g8_kernel_trace_summary.json"

@@ -39,10 +39,21 @@ for g in ([int(os.environ['SHARDS'])] if os.environ.get('SHARDS') else (1, 2, 4,
     if g > 1:
         dn.halo_commit()
     plan = dn.exchange_plan() if g > 1 else None
+    if g > 1 and os.environ.get("PEER"):
+        # the peer form, looped back: what this rank would store into its neighbours goes into its OWN receive sets (the
+        # mirror-image lists have the same sizes), and its own done counter stands in for theirs -- one launch per step, the
+        # granules and counters travel through the same fine-grained memory a neighbour's would
+        me = g // 2
+        loc = dn.p2p_local()
+        for p in range(g):
+            if p != me and loc["counts"][p]:
+                dn.p2p_connect(p, loc["recv"][0], loc["recv"][1], loc["flags"] + 4 * (p - me), loc["offsets"][p])
+        dn.p2p_commit()
     dn.run_sharded_without_exchange(50)
     t0 = time.perf_counter()
     dn.run_sharded_without_exchange(steps)
     dt = time.perf_counter() - t0
     print(json.dumps({"n_shards": g, "owned_neurons": int(dn.owned.size), "us_per_step": dt / steps * 1e6,
+                      "form": "peer (one launch per step, looped back)" if dn.stat("halo_peer_steps") else "two launches per step",
                       "recv_bytes_per_step": (4 * int(plan["recv_words"]) if plan else 0)}), flush=True)
     dn.close()

@@ -154,6 +154,11 @@ SIGNATURES = {
     "snn_comm_init_rank": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "snn_comm_destroy": (C.c_int, [C.c_void_p]),
     "snn_comm_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "snn_p2p_local": (C.c_int, [H, u64p, u64p, u64p, u64p, u64p]),
+    "snn_p2p_connect": (C.c_int, [H, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64]),
+    "snn_p2p_commit": (C.c_int, [H]),
+    "snn_p2p_ipc_export": (C.c_int, [H, C.c_void_p]),
+    "snn_p2p_ipc_import": (C.c_int, [C.c_int, C.c_void_p, u64p, u64p, u64p]),
     "snn_set_collectives": (C.c_int, [C.c_void_p]),
     "snn_comm_exchange_halo_lists": (C.c_int, [H, C.c_void_p]),
     "snn_exchange": (C.c_int, [H, C.c_void_p]),

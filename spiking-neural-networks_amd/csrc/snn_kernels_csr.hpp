@@ -26,6 +26,9 @@ namespace snn {
 constexpr uint32_t SELL_PAD = 0xFFFFFFFFu;     // presynaptic index of a padding entry
 constexpr uint32_t PLAN_CODE = 0x7FFFFFFFu;    // gather-plan word: the source code (all ones = padding), bit 31 = new chunk
 
+// peer form: where a poll that gives up says so (see peer_give_up)
+struct PeerFailure { uint32_t *word[2]; };
+
 struct SellGraph {
     const uint32_t *slice_ptr;   // [n_slices + 1] element offsets (multiples of 64)
     const uint32_t *pre;         // [entries]
@@ -36,6 +39,12 @@ struct SellGraph {
     const uint32_t *plan;
     const uint32_t *halo;
     uint32_t halo_base;
+    // PEER form of a library-driven run (snn_network_exchange.hpp, "peer form"): the halo arrives as 8-byte granules
+    // {value bits, tag | spike << 31} that the peers' border rows store straight into this handle's receive set; word
+    // (code - halo_base) of `halo` is granule (code - halo_base) of `halo64`, read when its tag is the step's.
+    const unsigned long long *halo64;
+    uint32_t halo_tag, spin_limit;
+    PeerFailure failed;          // set when a poll gave up
     float *w;                    // [entries]
     const uint32_t *row_len;     // [n_slices * 64]
     const uint32_t *edge_slot;   // [nnz] CSR edge -> SELL entry
@@ -49,6 +58,28 @@ struct CsrInputsArgs {
     SellGraph g;
     InputsArgs in;      // presynaptic state pointers / sizes; ld = stride of the partial rows
 };
+
+// One granule of the peer form: spins until its tag is `tag` (bounded: a peer that never arrives ends the run with an error
+// instead of a hang).  System scope: the writer may be another device.
+// `failed` = two words: [0] host-visible (read by the run call when the stream has drained), [1] on the device -- once set, every
+// later poll of the run gives up at once (the launches already enqueued behind a failure must not each wait out the limit).
+__device__ __forceinline__ void peer_give_up(uint32_t *const *failed)
+{
+    __hip_atomic_store(failed[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(failed[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long peer_granule(const unsigned long long *g, uint32_t tag, uint32_t spin_limit, const PeerFailure &f)
+{
+    unsigned long long x = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (((uint32_t)(x >> 32) & 0x7FFFFFFFu) == tag) return x;
+    if (__hip_atomic_load(f.word[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return x;     // the run has already failed
+    uint32_t spins = 0;
+    do {
+        x = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    } while (((uint32_t)(x >> 32) & 0x7FFFFFFFu) != tag && ++spins < spin_limit);
+    if (((uint32_t)(x >> 32) & 0x7FFFFFFFu) != tag) peer_give_up(f.word);
+    return x;
+}
 
 // The canonical sums of one postsynaptic row (thread q of a wavefront = row q of a SELL slice).  Returns with
 // `sum` / `tsum` holding the second-level sums; rows past n_loc compute on row 0 and are discarded by the caller.
@@ -80,7 +111,8 @@ __device__ __forceinline__ void csr_row_sums(const CsrInputsArgs &a, uint32_t q,
     for (uint32_t k0 = 0; k0 < width; k0 += EDGE_BATCH) {
         uint32_t p[EDGE_BATCH];
         float w[EDGE_BATCH], v[EDGE_BATCH], t[EDGE_BATCH][K_TYPES];
-        uint32_t flags[EDGE_BATCH];       // bit 0 cell, bit 1 silent cell, bits 8.. transmitter types
+        uint32_t flags[EDGE_BATCH];       // bit 0 cell, bit 1 silent cell, bit 2 a granule of the peer form, bits 8.. transmitter types
+        unsigned long long g64[EDGE_BATCH];
         // (1) plan word + weight of EDGE_BATCH consecutive entries: coalesced, independent
 #pragma unroll
         for (uint32_t u = 0; u < EDGE_BATCH; ++u) {
@@ -101,10 +133,19 @@ __device__ __forceinline__ void csr_row_sums(const CsrInputsArgs &a, uint32_t q,
             flags[u] = is_cell ? 1u : 0u;
             v[u] = 0.0f;
             if (ELEC) {
+                const bool granule = is_halo && a.g.halo64;
                 const float *src = is_cell ? reinterpret_cast<const float *>(in.st_view + sc)
-                                 : is_halo ? reinterpret_cast<const float *>(a.g.halo + (code - a.g.halo_base))
-                                           : in.xbuf + in.xl.at(pn, PLANE_V);
+                                 : (is_halo && !granule) ? reinterpret_cast<const float *>(a.g.halo + (code - a.g.halo_base))
+                                                         : in.xbuf + in.xl.at(pn, PLANE_V);
                 v[u] = *src;
+                if (a.g.halo64) {
+                    // peer form (launch-uniform): the entry's granule is requested with the rest of the batch -- one plain load, no
+                    // loop here: a loop inside the gather would take the batch's loads out of flight for EVERY row -- and looked
+                    // at below
+                    g64[u] = 0ull;
+                    if (granule) g64[u] = __hip_atomic_load(a.g.halo64 + (code - a.g.halo_base), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    flags[u] |= granule ? 4u : 0u;
+                }
                 flags[u] |= (is_cell && in.st_view[sc].y) ? 2u : 0u;
             }
             if (CHEM) {
@@ -117,6 +158,16 @@ __device__ __forceinline__ void csr_row_sums(const CsrInputsArgs &a, uint32_t q,
                     flags[u] |= (*fsrc != 0) ? (0x100u << kk) : 0u;
                     t[u][kk] = *tsrc;
                 }
+            }
+        }
+        if (ELEC && a.g.halo64) {
+            // peer form: a granule whose tag is not yet the step's (the neighbour's border rows are still on their way) is polled
+#pragma unroll
+            for (uint32_t u = 0; u < EDGE_BATCH; ++u) {
+                if (!(flags[u] & 4u)) continue;
+                if (((uint32_t)(g64[u] >> 32) & 0x7FFFFFFFu) != a.g.halo_tag)
+                    g64[u] = peer_granule(a.g.halo64 + ((p[u] & PLAN_CODE) - a.g.halo_base), a.g.halo_tag, a.g.spin_limit, a.g.failed);
+                v[u] = __uint_as_float((uint32_t)g64[u]);
             }
         }
         // (3) the row's sum, strictly in ascending presynaptic order with the canonical chunk flush
@@ -187,6 +238,10 @@ struct StepCloseArgs {
     WireArgs send;                  // segment tables of the outgoing segments (bitmaps to clear)
     uint32_t send_segments;
     uint32_t send_bitmap_words;     // over all outgoing segments
+    // peer form: the arrivals of the previous step as granules (null: words of recv.buf) and their tag
+    const unsigned long long *recv64;
+    uint32_t recv_tag, spin_limit;
+    PeerFailure failed;
     uint32_t cell_blocks, unpack_blocks;
     __host__ __device__ uint32_t blocks() const { return cell_blocks + unpack_blocks + (send_bitmap_words + 255) / 256; }
 };
@@ -207,8 +262,20 @@ __device__ __forceinline__ void step_close_block(const StepCloseArgs &a, const u
         const uint32_t count = a.recv.seg_count[seg];
         const uint32_t g = a.recv.list[t];
         if (g >= a.recv.n_neurons) return;
-        const uint32_t *in = a.recv.buf + a.recv.seg_offset[seg];
         uint32_t *x = reinterpret_cast<uint32_t *>(a.recv.xbuf), *x2 = reinterpret_cast<uint32_t *>(a.xbuf2);
+        if (a.recv64) {
+            // one plane (the voltage), one granule per neuron: value, and the spike flag in the tag word's top bit
+            const unsigned long long g64 = peer_granule(a.recv64 + a.recv.seg_offset[seg] + i, a.recv_tag, a.spin_limit, a.failed);
+            const size_t at = a.recv.xl.at(g, (int)a.recv.plane_id[0]);
+            x[at] = (uint32_t)g64;
+            if (x2) x2[at] = (uint32_t)g64;
+            const uint32_t spike = (uint32_t)(g64 >> 63);
+            x[a.recv.xl.at(g, PLANE_SPIKE)] = spike;
+            if (x2) x2[a.recv.xl.at(g, PLANE_SPIKE)] = spike;
+            if (spike) a.recv.last_firing_time[g] = (int32_t)a.recv.clock;
+            return;
+        }
+        const uint32_t *in = a.recv.buf + a.recv.seg_offset[seg];
         for (uint32_t s = 0; s < a.recv.planes; ++s) {
             const uint32_t v = in[(size_t)s * count + i];
             const size_t at = a.recv.xl.at(g, (int)a.recv.plane_id[s]);
@@ -232,6 +299,22 @@ __device__ __forceinline__ void step_close_block(const StepCloseArgs &a, const u
 
 __global__ __launch_bounds__(256) void k_step_close(const StepCloseArgs a) { step_close_block(a, blockIdx.x); }
 
+// peer form, start of a library-driven run: the receive set the first step reads, filled from the mirror (what earlier exchanges
+// left there) as granules tagged for that step
+__global__ __launch_bounds__(256) void k_peer_prefill(const WireArgs recv, uint32_t total, uint32_t segments, unsigned long long *set, uint32_t tag)
+{
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    uint32_t seg = 0;
+    while (seg + 1 < segments && t >= (uint32_t)recv.seg_list_offset[seg + 1]) ++seg;
+    const uint32_t i = t - (uint32_t)recv.seg_list_offset[seg];
+    const uint32_t g = recv.list[t];
+    if (g >= recv.n_neurons) return;
+    const uint32_t *x = reinterpret_cast<const uint32_t *>(recv.xbuf);
+    const uint32_t spike = x[recv.xl.at(g, PLANE_SPIKE)] ? 0x80000000u : 0u;
+    set[recv.seg_offset[seg] + i] = ((unsigned long long)(tag | spike) << 32) | x[recv.xl.at(g, (int)recv.plane_id[0])];
+}
+
 // Inputs + neuron update of a sparse handle in ONE launch: row thread = neuron thread, so the sums never leave
 // registers.  Other rows may still be gathering S(t) while a neuron writes S(t+1): as in k_step_resident the exchanged
 // state is read from a shadow copy (in.xbuf = up.n.xbuf) and written to the exchange buffer and the other shadow
@@ -248,6 +331,21 @@ struct PackTable {
     const uint32_t *index;          //            and the neuron's position in it
     uint32_t *buf;                  // outgoing segments (wire format of snn_kernels_exchange.hpp); spike bitmaps zeroed
     uint32_t planes, plane_id[WIRE_MAX_PLANES];
+    // peer form: per entry the granule of the PEER's receive set (this step's parity) that carries the neuron, and the peer;
+    // a set may be overwritten once the peer has finished the step that read it: flags[peer] >= need_done (the peers' done
+    // counters, stored into this handle's memory by their last workgroup)
+    unsigned long long *const *dst; // [entries] or null
+    const uint32_t *peer;           // [entries]
+    const uint32_t *flags;          // [n_shards]
+    uint32_t tag_out, need_done, spin_limit;
+    PeerFailure failed;
+};
+
+// peer form: a step's launch tells every neighbour which epoch this handle has COMPLETED (done_value: the one before the
+// launch's own) by storing it into the neighbour's done counters
+struct PeerSignal {
+    uint32_t *const *signal;                  // [n_signal] addresses of the neighbours' flags[this shard]; null: not the peer form
+    uint32_t n_signal, done_value;
 };
 
 struct CsrStepArgs {
@@ -264,11 +362,12 @@ struct CsrStepArgs {
     // and the clearing of the spike bitmaps of the other set of outgoing segments.
     StepCloseArgs tail;
     uint32_t xcd_bands;             // 1: row blocks are dealt to the XCDs in contiguous bands (see k_step_csr)
+    PeerSignal peer;
 };
 static_assert(sizeof(CsrStepArgs) <= 4096, "kernel arguments are limited to 4 KB");
 
 template <int MODEL, bool ELEC, bool CHEM>
-__global__ __launch_bounds__(256) void k_step_csr(const CsrStepArgs a)
+__device__ __forceinline__ void step_csr_block(const CsrStepArgs &a)
 {
     // the tail jobs come AFTER the row blocks: they fill the tail of the rows' streaming (cells at C5, one box, step time:
     // cells in their own launch 44.7 us; cell blocks first 41.5; spread evenly among the row blocks 45.6; last 39.3)
@@ -313,7 +412,22 @@ __global__ __launch_bounds__(256) void k_step_csr(const CsrStepArgs a)
             if (g < a.up.n.n_pad) a.up.spike_row[g >> 6] = word;
         }
     }
-    if (pack_end > pack_begin) {
+    if (pack_end > pack_begin && a.pack.dst) {
+        // peer form: the voltage (from its register) and the spike flag as ONE granule per reading peer, stored into that
+        // peer's receive set -- once the peer is done with the step that read the set's previous contents
+        for (uint32_t e = pack_begin; e < pack_end; ++e) {
+            const uint32_t peer = a.pack.peer[e];
+            if (__hip_atomic_load(a.pack.flags + peer, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < a.pack.need_done &&
+                !__hip_atomic_load(a.pack.failed.word[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                uint32_t spins = 0;
+                while (__hip_atomic_load(a.pack.flags + peer, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < a.pack.need_done &&
+                       ++spins < a.pack.spin_limit) {}
+                if (spins >= a.pack.spin_limit) peer_give_up(a.pack.failed.word);
+            }
+            const unsigned long long x = ((unsigned long long)(a.pack.tag_out | (spike ? 0x80000000u : 0u)) << 32) | __float_as_uint(v_new);
+            __hip_atomic_store(a.pack.dst[e], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    } else if (pack_end > pack_begin) {
         // the values this thread has just written, into every segment that carries the neuron (the voltage from its
         // register); the spike as ONE bit OR-ed into the segment's bitmap (zeroed after the previous exchange; spikes are rare)
         const uint32_t g = a.up.rows.global_of(q);
@@ -328,6 +442,19 @@ __global__ __launch_bounds__(256) void k_step_csr(const CsrStepArgs a)
             if (spike) atomicOr(out + (size_t)a.pack.planes * count + (i >> 5), 1u << (i & 31u));
         }
     }
+}
+
+template <int MODEL, bool ELEC, bool CHEM>
+__global__ __launch_bounds__(256) void k_step_csr(const CsrStepArgs a)
+{
+    // peer form: THIS launch running means the previous one of the stream is over -- every row and the mirror job of the step
+    // before have read what they had to read -- which is what the neighbours wait for before they overwrite a receive set.  One
+    // thread says so.  (A counter of finished workgroups at the END of the launch was measured first: 2048 atomics on one
+    // address cost 27 us of a 35 us step.)
+    if (a.peer.signal && blockIdx.x == 0 && threadIdx.x == 0)
+        for (uint32_t i = 0; i < a.peer.n_signal; ++i)
+            __hip_atomic_store(a.peer.signal[i], a.peer.done_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    step_csr_block<MODEL, ELEC, CHEM>(a);
 }
 
 // static counts of a sparse graph: n_in = row length, tcount[k] = entries whose presynaptic cell carries type k

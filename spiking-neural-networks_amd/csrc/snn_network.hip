@@ -91,6 +91,8 @@ int snn_network_destroy(snn_network_t *net)
                     (void *)net->csr_interior_dev, (void *)net->pack_ptr_dev, (void *)net->pack_segoff_dev,
                     (void *)net->pack_count_dev, (void *)net->pack_index_dev})
         if (p) (void)hipFree(p);
+    (void)p2p_release(net);
+    if (net->p2p_failed) (void)hipHostFree(net->p2p_failed);
     if (net->comm_stream) { (void)hipStreamSynchronize(net->comm_stream); (void)hipStreamDestroy(net->comm_stream); }
     if (net->ev_packed) (void)hipEventDestroy(net->ev_packed);
     if (net->ev_exchanged) (void)hipEventDestroy(net->ev_exchanged);
@@ -1257,6 +1259,76 @@ int snn_comm_exchange_halo_lists(snn_network_t *net, void *nccl_comm)
     return snn_halo_commit(net);
 }
 
+int snn_p2p_local(snn_network_t *net, uint64_t *recv0, uint64_t *recv1, uint64_t *flags, uint64_t *recv_offsets, uint64_t *recv_counts)
+{
+    if (!net || !recv0 || !recv1 || !flags) return fail(SNN_ERR_BAD_ARG, "null argument");
+    if (!net->finalized || !net->sharded || !net->csr) return fail(SNN_ERR_BAD_STATE, "the peer form belongs to finalized CSR shard handles");
+    HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
+    TRY(end_run(net));
+    TRY(ensure_exchange_plan(net));
+    if (!net->direct_capable || !net->p2p_recv[0])
+        return fail(SNN_ERR_BAD_STATE, "the peer form needs a committed halo plan with the voltage as the only plane on the wire");
+    *recv0 = reinterpret_cast<uint64_t>(net->p2p_recv[0]);
+    *recv1 = reinterpret_cast<uint64_t>(net->p2p_recv[1]);
+    *flags = reinterpret_cast<uint64_t>(net->p2p_flags);
+    for (uint32_t p = 0; p < net->n_shards; ++p) {
+        if (recv_offsets) recv_offsets[p] = net->x_recv_off[p];
+        if (recv_counts) recv_counts[p] = net->halo_need[p].size();
+    }
+    return SNN_OK;
+}
+
+int snn_p2p_connect(snn_network_t *net, uint32_t peer, uint64_t peer_recv0, uint64_t peer_recv1, uint64_t peer_flags, uint64_t peer_recv_offset)
+{
+    if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
+    if (!net->finalized || !net->sharded || !net->csr) return fail(SNN_ERR_BAD_STATE, "the peer form belongs to finalized CSR shard handles");
+    HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
+    TRY(end_run(net));
+    TRY(ensure_exchange_plan(net));
+    if (!net->direct_capable || !net->p2p_recv[0]) return fail(SNN_ERR_BAD_STATE, "the handle's exchange plan has no peer form");
+    if (peer >= net->n_shards) return fail(SNN_ERR_BAD_ARG, "peer out of range");
+    if (!peer_recv0 || !peer_recv1 || !peer_flags) return fail(SNN_ERR_BAD_ARG, "null peer address");
+    snn_network::P2pPeer &pp = net->p2p_peers[peer];
+    pp.recv[0] = peer_recv0; pp.recv[1] = peer_recv1; pp.flags = peer_flags; pp.recv_offset = peer_recv_offset; pp.set = true;
+    net->p2p_connected = false;                   // until snn_p2p_commit
+    return SNN_OK;
+}
+
+int snn_p2p_commit(snn_network_t *net)
+{
+    if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
+    if (!net->finalized || !net->sharded || !net->csr) return fail(SNN_ERR_BAD_STATE, "the peer form belongs to finalized CSR shard handles");
+    HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
+    TRY(end_run(net));
+    TRY(ensure_exchange_plan(net));
+    if (!net->direct_capable || !net->p2p_recv[0]) return fail(SNN_ERR_BAD_STATE, "the handle's exchange plan has no peer form");
+    return p2p_build_tables(net);
+}
+
+int snn_p2p_ipc_export(snn_network_t *net, void *handles_3x64_bytes)
+{
+    if (!net || !handles_3x64_bytes) return fail(SNN_ERR_BAD_ARG, "null argument");
+    if (!net->p2p_recv[0]) return fail(SNN_ERR_BAD_STATE, "the handle's exchange plan has no peer form");
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
+    HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
+    hipIpcMemHandle_t *h = static_cast<hipIpcMemHandle_t *>(handles_3x64_bytes);
+    HIP_TRY(hipIpcGetMemHandle(&h[0], net->p2p_recv[0]), SNN_ERR_BUFFER_CREATE);
+    HIP_TRY(hipIpcGetMemHandle(&h[1], net->p2p_recv[1]), SNN_ERR_BUFFER_CREATE);
+    HIP_TRY(hipIpcGetMemHandle(&h[2], net->p2p_flags), SNN_ERR_BUFFER_CREATE);
+    return SNN_OK;
+}
+
+int snn_p2p_ipc_import(int device, const void *handles_3x64_bytes, uint64_t *recv0, uint64_t *recv1, uint64_t *flags)
+{
+    if (!handles_3x64_bytes || !recv0 || !recv1 || !flags) return fail(SNN_ERR_BAD_ARG, "null argument");
+    HIP_TRY(hipSetDevice(device), SNN_ERR_GET_DEVICE);
+    const hipIpcMemHandle_t *h = static_cast<const hipIpcMemHandle_t *>(handles_3x64_bytes);
+    void *p[3] = {nullptr, nullptr, nullptr};
+    for (int i = 0; i < 3; ++i) HIP_TRY(hipIpcOpenMemHandle(&p[i], h[i], hipIpcMemLazyEnablePeerAccess), SNN_ERR_BUFFER_CREATE);
+    *recv0 = reinterpret_cast<uint64_t>(p[0]); *recv1 = reinterpret_cast<uint64_t>(p[1]); *flags = reinterpret_cast<uint64_t>(p[2]);
+    return SNN_OK;
+}
+
 int snn_exchange(snn_network_t *net, void *nccl_comm)
 {
     if (!net || !nccl_comm) return fail(SNN_ERR_BAD_ARG, "null argument");
@@ -1272,6 +1344,17 @@ int snn_exchange(snn_network_t *net, void *nccl_comm)
 }
 
 int snn_exchange_noop(void *, void *) { return 0; }
+
+// peer form: a poll that gave up (a peer that never stored, or never finished) has left the handle in the middle of a step
+static int p2p_outcome(snn_network *net)
+{
+    if (net->p2p_failed && net->p2p_failed[0]) {
+        net->p2p_failed[0] = 0u;
+        if (net->p2p_done_blocks) (void)hipMemsetAsync(net->p2p_done_blocks, 0, 256, net->stream);     // block counter + device abort word
+        return fail(SNN_ERR_WAIT, "peer form: a neighbour's values or its done counter did not arrive within the spin limit; the handle is mid-step");
+    }
+    return SNN_OK;
+}
 
 int snn_run_sharded_custom(snn_network_t *net, snn_exchange_fn exchange, void *user, uint64_t iterations)
 {
@@ -1301,7 +1384,8 @@ int snn_run_sharded_custom(snn_network_t *net, snn_exchange_fn exchange, void *u
     const int rc_end = direct_end(net);
     if (rc) return rc;
     TRY(rc_end);
-    return end_run(net, /*keep_stdp=*/true);
+    TRY(end_run(net, /*keep_stdp=*/true));
+    return p2p_outcome(net);
 }
 
 // The ranks of a communicator agree on HOW they exchange before the first step of a run: a rank that decided from its
@@ -1400,7 +1484,7 @@ int snn_run_sharded(snn_network_t *net, void *nccl_comm, uint64_t iterations)
     for (uint64_t it = 0; it < iterations && rc == SNN_OK; ++it) {
         if (net->nn) rc = step_begin(net);
         if (!rc) rc = launch_exchange_pack(net);
-        if (!rc && travels) {
+        if (!rc && travels && !net->peer_run) {          // (peer form: the border rows stored into the peers themselves)
             hip_step(hipEventRecord(net->ev_packed, net->stream), SNN_ERR_QUEUE);
             hip_step(hipStreamWaitEvent(net->comm_stream, net->ev_packed, 0), SNN_ERR_QUEUE);
             if (!rc) rc = enqueue_exchange(R, net, comm, net->comm_stream);
@@ -1412,14 +1496,15 @@ int snn_run_sharded(snn_network_t *net, void *nccl_comm, uint64_t iterations)
             rc = launch_inputs(net, INPUTS_LOCAL);
             net->local_inputs_done = true;
         }
-        if (!rc && travels) hip_step(hipStreamWaitEvent(net->stream, net->ev_exchanged, 0), SNN_ERR_QUEUE);
+        if (!rc && travels && !net->peer_run) hip_step(hipStreamWaitEvent(net->stream, net->ev_exchanged, 0), SNN_ERR_QUEUE);
         if (!rc) rc = step_end(net);
         if (!rc && net->profile && (net->ev_used >= 8192 || net->ev_used_pl >= 8192)) rc = collect_profile(net);
     }
     const int rc_end = direct_end(net);
     if (rc) return rc;
     TRY(rc_end);
-    return end_run(net, /*keep_stdp=*/true);
+    TRY(end_run(net, /*keep_stdp=*/true));
+    return p2p_outcome(net);
 }
 
 int snn_set_stream(snn_network_t *net, void *hip_stream)
@@ -1510,6 +1595,8 @@ int snn_set_option(snn_network_t *net, const char *name, int value)
     else if (n == "cells_in_step") net->cells_in_step = value != 0;
     else if (n == "update_packs") net->update_packs = value != 0;
     else if (n == "halo_direct") net->halo_direct = (value >= 0 && value <= 2) ? value : 1;
+    else if (n == "halo_peer") net->halo_peer = value != 0;
+    else if (n == "halo_peer_spin_limit") net->p2p_spin_limit = value > 0 ? (uint32_t)value : (1u << 26);
     else if (n == "csr_xcd_bands") net->csr_xcd_bands = value != 0;
     else if (n == "defer_rstdp") net->defer_rstdp = value != 0;
     else if (n == "defer_stdp") net->defer_stdp = (value == 2) ? 2 : (value != 0);
@@ -1533,6 +1620,7 @@ int snn_get_stat(snn_network_t *net, const char *name, uint64_t *value)
     else if (n == "persistent_run_steps") *value = net->stat_run_steps;
     else if (n == "persistent_run_fallbacks") *value = net->stat_run_fallbacks;
     else if (n == "halo_direct_steps") *value = net->stat_direct_steps;
+    else if (n == "halo_peer_steps") *value = net->stat_peer_steps;
     else if (n == "persistent_run_external_stream") *value = net->stat_run_external_stream;
     else if (n == "steps_dense_one_launch") *value = net->stat_steps_dense_one_launch;
     else if (n == "steps_sparse_one_launch") *value = net->stat_steps_sparse_one_launch;

@@ -54,6 +54,21 @@ void synthesize_full_lists(snn_network *net)
     }
 }
 
+// the peer form's buffers and connection belong to ONE plan: a rebuilt plan starts unconnected
+int p2p_release(snn_network *net)
+{
+    for (void *b : {(void *)net->p2p_recv[0], (void *)net->p2p_recv[1], (void *)net->p2p_flags, (void *)net->p2p_done_blocks,
+                    (void *)net->p2p_dst_dev[0], (void *)net->p2p_dst_dev[1], (void *)net->p2p_peer_dev, (void *)net->p2p_signal_dev})
+        if (b) (void)hipFree(b);
+    net->p2p_recv[0] = net->p2p_recv[1] = nullptr;
+    net->p2p_flags = nullptr; net->p2p_done_blocks = nullptr;
+    net->p2p_dst_dev[0] = net->p2p_dst_dev[1] = nullptr; net->p2p_peer_dev = nullptr; net->p2p_signal_dev = nullptr;
+    net->p2p_n_signal = 0; net->p2p_recv_words = 0;
+    net->p2p_peers.clear();
+    net->p2p_connected = false;
+    return SNN_OK;
+}
+
 // (Re)builds the plan: planes on the wire, per-peer segments, device tables.  which = 0 pack, 1 unpack.
 int ensure_exchange_plan(snn_network *net)
 {
@@ -164,6 +179,28 @@ int ensure_exchange_plan(snn_network *net)
             if (!b) continue;
             HIP_TRY(hipMalloc(reinterpret_cast<void **>(b), std::max<uint64_t>(ro * 4, 256)), SNN_ERR_BUFFER_CREATE);
             HIP_TRY(hipMemset(*b, 0, std::max<uint64_t>(ro * 4, 256)), SNN_ERR_BUFFER_WRITE);
+        }
+        TRY(p2p_release(net));
+        if (net->direct_capable && ro) {
+            // the peer form's receive sets and done counters: fine-grained memory (another device may store into it while
+            // kernels of this one read it), zeroed (tag 0 is never expected: epochs start at 1)
+            net->p2p_recv_words = ro;
+            for (int i = 0; i < 2; ++i) {
+                HIP_TRY(hipExtMallocWithFlags(reinterpret_cast<void **>(&net->p2p_recv[i]), std::max<uint64_t>(ro * 8, 256), hipDeviceMallocFinegrained),
+                        SNN_ERR_BUFFER_CREATE);
+                HIP_TRY(hipMemset(net->p2p_recv[i], 0, std::max<uint64_t>(ro * 8, 256)), SNN_ERR_BUFFER_WRITE);
+            }
+            HIP_TRY(hipExtMallocWithFlags(reinterpret_cast<void **>(&net->p2p_flags), std::max<size_t>((size_t)G * 4, 256), hipDeviceMallocFinegrained),
+                    SNN_ERR_BUFFER_CREATE);
+            HIP_TRY(hipMemset(net->p2p_flags, 0, std::max<size_t>((size_t)G * 4, 256)), SNN_ERR_BUFFER_WRITE);
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&net->p2p_done_blocks), 256), SNN_ERR_BUFFER_CREATE);
+            HIP_TRY(hipMemset(net->p2p_done_blocks, 0, 256), SNN_ERR_BUFFER_WRITE);
+            if (!net->p2p_failed) {
+                HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&net->p2p_failed), 8, hipHostMallocMapped), SNN_ERR_BUFFER_CREATE);
+                net->p2p_failed[0] = 0u;
+            }
+            net->p2p_peers.assign(G, snn_network::P2pPeer{});
+            net->p2p_epoch = 1;
         }
         if (net->direct_capable) {
             std::vector<uint32_t> halo_word(net->nn, 0xFFFFFFFFu);
@@ -459,7 +496,16 @@ int direct_begin(snn_network *net)
     HIP_TRY(hipMemsetAsync(net->halo_send_buf2, 0, std::max<uint64_t>(so * 4, 256), net->stream), SNN_ERR_BUFFER_WRITE);
     net->hx_par = 0;
     net->stamp_pending = false;
-    if (net->seg_n[1] && net->seg_max[1]) {
+    net->peer_run = net->halo_peer && net->p2p_connected && net->p2p_recv[0];
+    if (net->peer_run) {
+        // the peer form: the set the first step reads -- values "produced by step epoch - 1" -- from the mirror, tagged for it
+        if (net->p2p_epoch > 0x7FFFFF00u) return fail(SNN_ERR_BAD_STATE, "peer form: step tags exhausted (2^31 steps): rebuild the exchange plan");
+        if (net->recv_total) {
+            hipLaunchKernelGGL(k_peer_prefill, dim3((net->recv_total + 255) / 256), dim3(256), 0, net->stream, wire_args(net, 1), net->recv_total,
+                               net->seg_n[1], net->p2p_recv[(net->p2p_epoch + 1u) & 1u], net->p2p_epoch);
+            HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+        }
+    } else if (net->seg_n[1] && net->seg_max[1]) {
         WireArgs a = wire_args(net, 1, /*set=*/1);                // the set step 0 reads: hx_par ^ 1
         hipLaunchKernelGGL(k_exchange_pack, dim3((net->seg_max[1] + 255) / 256, net->seg_n[1]), dim3(256), 0, net->stream, a);
         HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
@@ -472,14 +518,69 @@ int direct_end(snn_network *net)
 {
     if (!net->direct_run) return SNN_OK;
     net->direct_run = false;
+    const bool peer = net->peer_run;
+    net->peer_run = false;
     net->send_bits_clean = false;                                 // an ordinary step clears set 0's bitmaps before it packs
     if (!net->stamp_pending) return SNN_OK;
     net->stamp_pending = false;
     if (!net->seg_n[1] || !net->seg_max[1] || !net->nn) return SNN_OK;
+    if (peer) {
+        // the last step's arrivals (granules of set (epoch - 1) % 2, tagged epoch) into the mirror and the current shadow
+        StepCloseArgs c{};
+        c.recv = wire_args(net, 1);
+        c.recv.clock = net->clock - 1;
+        c.xbuf2 = c.recv.xbuf2;
+        c.recv_total = net->recv_total; c.recv_segments = net->seg_n[1];
+        c.unpack_blocks = (net->recv_total + 255) / 256;
+        c.recv64 = net->p2p_recv[(net->p2p_epoch + 1u) & 1u]; c.recv_tag = net->p2p_epoch;
+        c.spin_limit = net->p2p_spin_limit; c.failed = PeerFailure{{net->p2p_failed, net->p2p_done_blocks + 1}};
+        if (c.unpack_blocks) hipLaunchKernelGGL(k_step_close, dim3(c.unpack_blocks), dim3(256), 0, net->stream, c);
+        HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+        return SNN_OK;
+    }
     WireArgs a = wire_args(net, 1, net->hx_par ^ 1);              // the set the last step's exchange filled
     a.clock = net->clock - 1;
     hipLaunchKernelGGL(k_exchange_unpack, dim3((net->seg_max[1] + 255) / 256, net->seg_n[1]), dim3(256), 0, net->stream, a);
     HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+    return SNN_OK;
+}
+
+// peer form: the device tables of a connected handle -- per pack entry the peer's granule (both sets) and the peer, and the
+// neighbours' done-counter words this handle signals (every shard it RECEIVES from stores into this handle's sets and waits
+// for this handle's counter in its own memory)
+int p2p_build_tables(snn_network *net)
+{
+    const uint32_t G = net->n_shards, me = net->shard_index;
+    auto local_row = [&](uint32_t g) { return net->block_mode ? net->local_row_host[g] : g - net->q0; };
+    std::vector<uint32_t> pack_ptr(net->n_loc + 1, 0);
+    for (uint32_t p = 0; p < G; ++p)
+        for (uint32_t g : net->halo_send[p]) pack_ptr[local_row(g) + 1] += 1;
+    for (uint32_t q = 0; q < net->n_loc; ++q) pack_ptr[q + 1] += pack_ptr[q];
+    const size_t entries = pack_ptr[net->n_loc];
+    std::vector<unsigned long long> dst[2] = {std::vector<unsigned long long>(entries), std::vector<unsigned long long>(entries)};
+    std::vector<uint32_t> peer(entries);
+    std::vector<uint32_t> fill(pack_ptr.begin(), pack_ptr.end() - 1);
+    for (uint32_t p = 0; p < G; ++p) {
+        const auto &sl = net->halo_send[p];
+        if (sl.empty()) continue;
+        if (!net->p2p_peers[p].set) return fail(SNN_ERR_BAD_STATE, "peer form: shard " + std::to_string(p) + " reads this shard but is not connected");
+        for (uint32_t i = 0; i < sl.size(); ++i) {
+            const uint32_t e = fill[local_row(sl[i])]++;            // the order ensure_exchange_plan gave the pack table
+            for (int k = 0; k < 2; ++k) dst[k][e] = net->p2p_peers[p].recv[k] + 8ull * (net->p2p_peers[p].recv_offset + i);
+            peer[e] = p;
+        }
+    }
+    std::vector<unsigned long long> signal;
+    for (uint32_t p = 0; p < G; ++p) {
+        if (p == me || net->halo_need[p].empty()) continue;
+        if (!net->p2p_peers[p].set) return fail(SNN_ERR_BAD_STATE, "peer form: shard " + std::to_string(p) + " is read by this shard but is not connected");
+        signal.push_back(net->p2p_peers[p].flags + 4ull * me);
+    }
+    for (int k = 0; k < 2; ++k) TRY(upload_table(reinterpret_cast<unsigned long long **>(&net->p2p_dst_dev[k]), dst[k]));
+    TRY(upload_table(&net->p2p_peer_dev, peer));
+    TRY(upload_table(reinterpret_cast<unsigned long long **>(&net->p2p_signal_dev), signal));
+    net->p2p_n_signal = (uint32_t)signal.size();
+    net->p2p_connected = true;
     return SNN_OK;
 }
 

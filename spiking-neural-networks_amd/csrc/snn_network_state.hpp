@@ -169,6 +169,26 @@ struct snn_network {
     uint64_t stat_direct_steps = 0;       // statistic "halo_direct_steps"
     bool tail_done = false;               // this step's jobs behind the rows are enqueued
     int halo_direct = 1;                  // option "halo_direct": 0 never, 1 snn_run_sharded, 2 also snn_run_sharded_custom
+    // PEER form of such a run (snn_network_exchange.hpp): the border rows store {value, tag | spike} granules straight into the
+    // peers' receive sets, the rows of the next step read them when their tag says so, and a done counter per peer says when a
+    // set may be overwritten -- no collective, ONE launch per step.  Needs the peers' addresses (snn_p2p_connect / _commit).
+    unsigned long long *p2p_recv[2] = {nullptr, nullptr};     // [recv words] granules each, fine-grained
+    uint32_t *p2p_flags = nullptr;                            // [n_shards] done counters, written by the peers (fine-grained)
+    uint32_t *p2p_done_blocks = nullptr;
+    uint32_t *p2p_failed = nullptr;                           // host-mapped word: a poll gave up
+    uint64_t p2p_recv_words = 0;
+    struct P2pPeer { uint64_t recv[2] = {0, 0}, flags = 0, recv_offset = 0; bool set = false; };
+    std::vector<P2pPeer> p2p_peers;                           // per shard: where this handle's values go on that peer
+    unsigned long long **p2p_dst_dev[2] = {nullptr, nullptr}; // per pack entry: the peer's granule, per set
+    uint32_t *p2p_peer_dev = nullptr;                         // per pack entry: the peer
+    uint32_t **p2p_signal_dev = nullptr;                      // the neighbours' flags[this shard]
+    uint32_t p2p_n_signal = 0;
+    bool p2p_connected = false;
+    bool peer_run = false;                                    // the run in progress uses the peer form
+    uint32_t p2p_epoch = 0;                                   // steps of peer-form runs done so far (tags and done counters)
+    uint32_t p2p_spin_limit = 1u << 26;
+    int halo_peer = 1;                                        // option "halo_peer": 0 keeps the collective even when connected
+    uint64_t stat_peer_steps = 0;                             // statistic "halo_peer_steps"
     // in-library collective (snn_run_sharded): RCCL is ordered on its own stream against the compute stream
     hipStream_t comm_stream = nullptr;
     hipEvent_t ev_packed = nullptr, ev_exchanged = nullptr;

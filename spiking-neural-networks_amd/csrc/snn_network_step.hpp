@@ -853,11 +853,29 @@ int launch_step_csr(snn_network *net, CsrStepPart part = CSR_STEP_ALL, bool pack
         c.c.g.halo = net->hx_par ? net->halo_recv_buf : net->halo_recv_buf2;
         c.c.g.halo_base = net->nn + net->nc;
     }
+    if (net->peer_run) {         // ... which the peers stored as granules into this handle's set of the previous step's parity
+        c.c.g.halo64 = net->p2p_recv[(net->p2p_epoch + 1u) & 1u];
+        c.c.g.halo_tag = net->p2p_epoch;
+        c.c.g.spin_limit = net->p2p_spin_limit;
+        c.c.g.failed = PeerFailure{{net->p2p_failed, net->p2p_done_blocks + 1}};
+    }
     if (pack) {
         c.pack.ptr = net->pack_ptr_dev; c.pack.seg_off = net->pack_segoff_dev; c.pack.seg_count = net->pack_count_dev;
         c.pack.index = net->pack_index_dev; c.pack.planes = net->x_planes;
         c.pack.buf = (net->direct_run && net->hx_par) ? net->halo_send_buf2 : net->halo_send_buf;
         for (int s = 0; s < WIRE_MAX_PLANES; ++s) c.pack.plane_id[s] = net->x_plane_id[s];
+        if (net->peer_run) {
+            c.pack.dst = net->p2p_dst_dev[net->p2p_epoch & 1u];
+            c.pack.peer = net->p2p_peer_dev;
+            c.pack.flags = net->p2p_flags;
+            // the set was last read by the peer's step of epoch - 1 (rows and mirror job): its counter says when that is over
+            c.pack.tag_out = net->p2p_epoch + 1u; c.pack.need_done = net->p2p_epoch - 1u;
+            c.pack.spin_limit = net->p2p_spin_limit; c.pack.failed = PeerFailure{{net->p2p_failed, net->p2p_done_blocks + 1}};
+        }
+    }
+    if (net->peer_run) {
+        c.peer.signal = net->p2p_signal_dev; c.peer.n_signal = net->p2p_n_signal;
+        c.peer.done_value = net->p2p_epoch - 1u;     // this launch running = the step of the epoch before is over
     }
     // the cells ride with the step's last row launch (the rows of BOTH launches read the view the cells do not write)
     const bool last_part = part != CSR_STEP_BORDER || net->n_interior == 0;
@@ -876,9 +894,13 @@ int launch_step_csr(snn_network *net, CsrStepPart part = CSR_STEP_ALL, bool pack
             c.tail.recv_total = net->recv_total;
             c.tail.recv_segments = net->seg_n[1];
             c.tail.unpack_blocks = (net->recv_total + 255) / 256;
+            if (net->peer_run) {         // the same set the rows of this launch read
+                c.tail.recv64 = net->p2p_recv[(net->p2p_epoch + 1u) & 1u]; c.tail.recv_tag = net->p2p_epoch;
+                c.tail.spin_limit = net->p2p_spin_limit; c.tail.failed = PeerFailure{{net->p2p_failed, net->p2p_done_blocks + 1}};
+            }
         }
         net->stamp_pending = false;
-        if (net->send_bitmap_words) {
+        if (net->send_bitmap_words && !net->peer_run) {
             c.tail.send = wire_args(net, 0, net->hx_par ^ 1);
             c.tail.send_segments = net->seg_n[0];
             c.tail.send_bitmap_words = net->send_bitmap_words;
@@ -927,6 +949,14 @@ int step_begin(snn_network *net)
         HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
     }
     if (fused_step_applies(net)) { net->stat_steps_dense_one_launch += 1; return launch_step_resident(net); }
+    if (csr_fast_step(net) && net->peer_run) {
+        // peer form: nothing to overlap with -- border and interior slices in ONE launch, the border rows store into the peers
+        net->stat_steps_sparse_one_launch += 1;
+        TRY(launch_step_csr(net, CSR_STEP_ALL, /*pack=*/true));
+        net->step_packed = true;
+        net->interior_pending = false;
+        return SNN_OK;
+    }
     if (csr_fast_step(net)) {
         net->stat_steps_sparse_split += 1;
         // border slices first, writing the outgoing segments themselves; the interior slices follow once the caller has
@@ -965,6 +995,7 @@ int step_end(snn_network *net)
             net->stat_direct_steps += 1;
             net->tail_done = false;
             net->hx_par ^= 1;
+            if (net->peer_run) { net->p2p_epoch += 1; net->stat_peer_steps += 1; }
         } else {
             TRY(launch_step_close(net, /*cells=*/!net->cells_stepped, /*unpack=*/true));
         }

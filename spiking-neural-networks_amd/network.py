@@ -236,6 +236,21 @@ class DeviceNetwork:
                 "send_words": plan.send_words, "recv_words": plan.recv_words,
                 "send_offset": arrs[0], "send_count": arrs[1], "recv_offset": arrs[2], "recv_count": arrs[3]}
 
+    def p2p_local(self):
+        """the peer form's endpoints of this handle (snn_p2p_local): recv0, recv1, flags addresses + per-shard offsets / counts"""
+        r0, r1, fl = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        g = self.exchange_plan()["n_shards"]
+        off, cnt = np.zeros(g, np.uint64), np.zeros(g, np.uint64)
+        self._check(self._L.snn_p2p_local(self._h, C.byref(r0), C.byref(r1), C.byref(fl), off.ctypes.data_as(_lib.u64p),
+                                          cnt.ctypes.data_as(_lib.u64p)))
+        return {"recv": (r0.value, r1.value), "flags": fl.value, "offsets": off, "counts": cnt}
+
+    def p2p_connect(self, peer, recv0, recv1, flags, recv_offset):
+        self._check(self._L.snn_p2p_connect(self._h, peer, int(recv0), int(recv1), int(flags), int(recv_offset)))
+
+    def p2p_commit(self):
+        self._check(self._L.snn_p2p_commit(self._h))
+
     def halo_needs(self, peer):
         """ascending global indices of shard `peer`'s neurons that this handle's CSR rows read"""
         n = C.c_uint32()

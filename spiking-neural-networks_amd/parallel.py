@@ -102,6 +102,31 @@ def wire_halo_lists(handles):
         h.halo_commit()
 
 
+def connect_peers(handles):
+    """The peer form (include/snn_amd.h, snn_p2p_*) between G sparse shard handles of ONE process: every handle learns where its
+    values go on every peer it exchanges with, then all commit.  Halo lists must be committed (wire_halo_lists or the
+    library's own exchange of the lists).  Returns False -- and connects nobody -- when some handle that exchanges anything has
+    no peer form (more planes than the voltage on the wire, a dense handle); handles that exchange nothing are left out."""
+    g = len(handles)
+    plans = [h.exchange_plan() for h in handles]
+    busy = [int(p["send_words"]) + int(p["recv_words"]) > 0 for p in plans]
+    local = [None] * g
+    for r, h in enumerate(handles):
+        if busy[r]:
+            try:
+                local[r] = h.p2p_local()
+            except Exception:        # noqa: BLE001 -- SnnError 12: this plan has no peer form
+                return False
+    for r, h in enumerate(handles):
+        for p in range(g):
+            if p != r and busy[r] and busy[p] and (local[p]["counts"][r] or local[r]["counts"][p]):
+                h.p2p_connect(p, local[p]["recv"][0], local[p]["recv"][1], local[p]["flags"], local[p]["offsets"][r])
+    for r, h in enumerate(handles):
+        if busy[r]:
+            h.p2p_commit()
+    return True
+
+
 def copy_segments(plans, tensors):
     """The exchange between G shard handles of one process: device-to-device (or host) copies of every segment
     plans[r] sends to p into plans[p]'s receive segment for r.  tensors[r] = (send, recv)."""

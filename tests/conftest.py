@@ -16,6 +16,11 @@ if "OMP_NUM_THREADS" not in os.environ:
         pass
     os.environ["OMP_NUM_THREADS"] = str(max(1, min(_cpus, 64)))
 
+# Several shard handles of ONE process stand in for the ranks of a multi-GPU run (tests of the sharded loops): each rank's
+# stream must own a hardware queue, or a kernel that waits for a neighbour's values can sit in front of the very kernel that
+# produces them (the runtime spreads streams over 4 queues by default).  One rank per process -- the real thing -- never shares.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

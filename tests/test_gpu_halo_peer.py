@@ -1,0 +1,107 @@
+"""The PEER form of a library-driven run on sparse shard handles (include/snn_amd.h, snn_p2p_*): ONE launch per step and no
+collective -- border rows store {voltage, tag | spike} granules straight into the peers' receive sets, the next step's rows
+read them when the tag is the step's, done counters say when a set may be overwritten.  2 - 8 shard handles of one process on
+one GPU (peer = same device), every rank a host thread inside snn_run_sharded; against the oracle, and against the same
+run over the collective."""
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+import parity
+from test_gpu_csr import c5_structure
+from test_gpu_library_loop_threads import collectives, run_ranks  # noqa: F401  (fixture)
+
+pytestmark = pytest.mark.gpu
+
+
+def check_against_oracle(handles, net, steps):
+    for h in handles:
+        assert h.clock == steps
+        st = parity.pull_state(h, net)
+        parity.assert_shard_view_equal(h, st, net)
+        cells = h.cells_read()
+        for name in ("st_last_firing_time", "st_seed"):
+            assert np.array_equal(parity.bits(st[name][cells]), parity.bits(net[name][cells])), name
+        assert np.array_equal(parity.bits(st["w_value"][h.owned]), parity.bits(net["w_value"][h.owned]))
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("n_shards,by_lattice,side", [(2, True, 16), (4, True, 16), (3, False, 8), (8, False, 8), (8, True, 32)])
+def test_peer_form_equals_the_oracle(snn, collectives, n_shards, by_lattice, side):
+    from snn_amd import parallel
+    net = c5_structure(side)
+    handles = [parity.device_from_oracle(snn, net, shard=(r, n_shards), csr=True, by_lattice=by_lattice) for r in range(n_shards)]
+    parallel.wire_halo_lists(handles)
+    assert parallel.connect_peers(handles)
+    for h in handles:
+        h.set_option("halo_peer_spin_limit", 1 << 20)
+    tc = collectives(n_shards)
+    # (8 ranks on one device: their launches share hardware queues, where a kernel that waits for a neighbour's values may sit in
+    # front of the kernel that produces them -- a limit of this emulation, not of one rank per GPU; those cases step call by call,
+    # which keeps every rank's launches of one step ahead of anybody's next)
+    calls = [150, 1, 49] if n_shards <= 4 else [1] * 60
+    run_ranks(handles, tc, calls)
+    steps = sum(calls)
+    net.n_threads = 8
+    net.run(steps, spike_history=True)
+    assert net.spike_history.sum() > 5 or steps < 100
+    for h in handles:
+        plan = h.exchange_plan()
+        if h.owned.size and int(plan["send_words"]) + int(plan["recv_words"]):
+            assert h.stat("halo_peer_steps") == steps and h.stat("steps_sparse_one_launch") == steps, \
+                (h.stat("halo_peer_steps"), h.stat("steps_sparse_one_launch"), h.stat("steps_sparse_split"), steps)
+    check_against_oracle(handles, net, steps)
+    for h in handles:
+        h.close()
+
+
+@pytest.mark.timeout(120)
+def test_peer_form_between_other_steps_and_switched_off(snn, collectives):
+    """runs of the peer form alternate with host-driven steps (which move the halo through the ordinary segments) and with the
+    collective form (option halo_peer 0): the mirror, the tags and the done counters carry over"""
+    import torch
+    from snn_amd import parallel
+    n_shards = 4
+    net = c5_structure(16)
+    handles = [parity.device_from_oracle(snn, net, shard=(r, n_shards), csr=True, by_lattice=True) for r in range(n_shards)]
+    ex = parallel.LocalExchange(handles, torch.device("cuda", 0), halo=True)       # (commits the halo lists: before connecting)
+    assert parallel.connect_peers(handles)
+    for h in handles:
+        h.set_option("halo_peer_spin_limit", 1 << 20)
+    tc = collectives(n_shards)
+    run_ranks(handles, tc, [60])
+    for _ in range(7):                                   # host-driven steps in between
+        for h in handles:
+            h.step_begin_local()
+            h.step_begin()
+        ex.exchange()
+        for h in handles:
+            h.step_end()
+    run_ranks(handles, tc, [40])
+    for h in handles:
+        h.set_option("halo_peer", 0)
+    run_ranks(handles, tc, [30])
+    for h in handles:
+        h.set_option("halo_peer", 1)
+    run_ranks(handles, tc, [25])
+    net.n_threads = 8
+    net.run(162)
+    assert all(h.stat("halo_peer_steps") in (0, 125) for h in handles) and any(h.stat("halo_peer_steps") == 125 for h in handles)
+    check_against_oracle(handles, net, 162)
+    for h in handles:
+        h.close()
+
+
+def test_a_missing_peer_ends_the_run_with_an_error(snn, collectives):
+    """a rank whose neighbour never steps gives up after the spin limit: SNN_ERR_WAIT, no hang"""
+    from snn_amd import parallel
+    net = c5_structure(8)
+    handles = [parity.device_from_oracle(snn, net, shard=(r, 2), csr=True, by_lattice=False) for r in range(2)]
+    parallel.wire_halo_lists(handles)
+    parallel.connect_peers(handles)
+    handles[0].set_option("halo_peer_spin_limit", 1 << 14)
+    with pytest.raises(snn.SnnError) as e:
+        handles[0].run_sharded_without_exchange(3)            # rank 1 never runs: its values for step 1 and its done counter never come
+    assert e.value.code == 6                             # SNN_ERR_WAIT
+    for h in handles:
+        h.close()
