@@ -336,6 +336,10 @@ def main():
                          "parallel.ShardedStepper (torch.distributed moves the segments)")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not bracket k_inputs_dense with HIP events (roofline.achieved is then null)")
+    ap.add_argument("--peer-form", action="store_true",
+                    help="--config c5, --gpus N > 1: after the warm-up the ranks map each other's receive sets (IPC handles through "
+                         "torch.distributed) and step in the peer form -- one launch per step, no collective (include/snn_amd.h, "
+                         "snn_p2p_*).  Off by default: across DEVICES the form has never run (tested across processes on one device)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="--gpus N > 1: strong = the SAME network sharded N ways (default); weak = the network grows with N so that "
                          "every rank keeps the N = 1 share (c5 only: 4 lattices of 512 N x 512, 1 M neurons per rank)")
@@ -419,6 +423,24 @@ def main():
         return sum(int(dn.spike_counts(i).sum()) for i, (_, _, st) in dn.lattices.items() if not st)
 
     run(args.warmup)
+    if args.peer_form and sharded and world > 1 and args.config == "c5" and comm is not None:
+        # the warm-up ran over the collective and left the halo lists committed; now every rank maps its neighbours' memory
+        plan = dn.exchange_plan()
+        busy = int(plan["send_words"]) + int(plan["recv_words"]) > 0
+        mine = None
+        if busy:
+            loc = dn.p2p_local()
+            mine = (dn.p2p_ipc_export(), [int(x) for x in loc["offsets"]], [int(x) for x in loc["counts"]])
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine)
+        for p in range(world):
+            if busy and p != rank and everyone[p] is not None and (everyone[p][2][rank] or mine[2][p]):
+                r0, r1, fl = dn.p2p_ipc_import(everyone[p][0], device=local_rank)
+                dn.p2p_connect(p, r0, r1, fl, everyone[p][1][rank])
+        if busy:
+            dn.p2p_commit()
+        dist.barrier()
+        run(args.warmup)
     spikes_before = own_spike_total()
     # HIP events around the dominant kernel: inside the timed region for the streaming configs with ms-scale steps (2 event
     # records per step are noise next to a 2.5 - 13 ms step); for the short-step configs (c1: 4 us, c5: 43 us, c3: 0.19 ms per
@@ -536,6 +558,7 @@ def main():
             "stepper": (("library (snn_run_sharded, RCCL called by libsnn_amd.so)" if comm is not None else
                          "torch (parallel.ShardedStepper, torch.distributed moves the segments)") if sharded else None),
             "rccl_ranks": rccl_ranks, "exchange_bytes_per_rank_step": exchange_bytes,
+            "halo_peer_steps": (dn.stat("halo_peer_steps") if sharded else None),
             "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "neurons": n,

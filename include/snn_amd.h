@@ -322,8 +322,9 @@ int snn_set_collectives(const snn_collectives *table);
  * unconnected again.  Failure: a value or a done counter that does not arrive within "halo_peer_spin_limit" polls ends the
  * run call with SNN_ERR_WAIT (the handle is then in the middle of a step; there is no roll-back across ranks).
  * Options: "halo_peer" [1] 0 keeps the collective on a connected handle.  Statistic: "halo_peer_steps".
- * Status: built and tested with 2 - 8 shard handles of ONE process on one GPU (tests/test_gpu_halo_peer.py); the IPC pair
- * below wraps hipIpcGetMemHandle / hipIpcOpenMemHandle for ranks in different processes and has not run across devices. */
+ * Status: tested with 2 - 8 shard handles of ONE process on one GPU (tests/test_gpu_halo_peer.py) and with 2 - 4 PROCESSES on
+ * one GPU through the IPC pair below (tests/test_gpu_two_processes.py, forms "*_peer"); across DEVICES (peer access over
+ * xGMI) it has never run -- bench.py takes it only with --peer-form. */
 /* addresses (in THIS process) of the handle's two receive sets and its done counters; per shard p the granule offset and
  * count of what arrives from p (recv_offsets / recv_counts: [n_shards], may be null) */
 int snn_p2p_local(snn_network_t *net, uint64_t *recv0, uint64_t *recv1, uint64_t *flags, uint64_t *recv_offsets, uint64_t *recv_counts);

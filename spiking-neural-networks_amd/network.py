@@ -245,6 +245,18 @@ class DeviceNetwork:
                                           cnt.ctypes.data_as(_lib.u64p)))
         return {"recv": (r0.value, r1.value), "flags": fl.value, "offsets": off, "counts": cnt}
 
+    def p2p_ipc_export(self):
+        """192 bytes: the IPC handles of the two receive sets and the done counters (snn_p2p_ipc_export), for a peer in ANOTHER process"""
+        buf = C.create_string_buffer(192)
+        self._check(self._L.snn_p2p_ipc_export(self._h, buf))
+        return bytes(buf.raw)
+
+    def p2p_ipc_import(self, handles, device=0):
+        """maps a peer's exported handles into this process: (recv0, recv1, flags) addresses for p2p_connect"""
+        r0, r1, fl = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self._check(self._L.snn_p2p_ipc_import(device, C.create_string_buffer(handles, 192), C.byref(r0), C.byref(r1), C.byref(fl)))
+        return r0.value, r1.value, fl.value
+
     def p2p_connect(self, peer, recv0, recv1, flags, recv_offset):
         self._check(self._L.snn_p2p_connect(self._h, peer, int(recv0), int(recv1), int(flags), int(recv_offset)))
 

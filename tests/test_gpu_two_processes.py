@@ -21,8 +21,8 @@ def build(form):
     import parity
     if form.startswith("csr"):
         from test_gpu_csr import c5_structure
-        net = c5_structure(16 if form == "csr_by_lattice" else 8)
-        net["do_plasticity"] = 1
+        net = c5_structure(16 if form.startswith("csr_by_lattice") else 8)
+        net["do_plasticity"] = 0 if form.endswith("_peer") else 1       # (the peer form is the step without weight updates)
         return net
     lay = parity.Layout([(0, 9, 10), (3, 12, 12)], [(5, 3, 4)])
     net = parity.make_oracle(lay, st_kind=ob.ST_RATE, chemical=True)
@@ -52,7 +52,7 @@ def worker(rank, world, init_file, out_dir, form):
     dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
     net = build(form)
     dn = parity.device_from_oracle(snn_amd, net, shard=(rank, world), csr=form.startswith("csr"),
-                                   by_lattice=(form == "csr_by_lattice"))
+                                   by_lattice=form.startswith("csr_by_lattice"))
     if form.startswith("csr"):
         # the need lists cross the process boundary too: what I read of peer p becomes p's send list for me
         needs = [dn.halo_needs(p) if p != rank else np.zeros(0, np.uint32) for p in range(world)]
@@ -64,6 +64,27 @@ def worker(rank, world, init_file, out_dir, form):
         dn.halo_commit()
     plan = dn.exchange_plan()
     dev = torch.device("cuda", 0)
+    if form.endswith("_peer"):
+        # the PEER form across a real process boundary: IPC handles of the receive sets and done counters travel (gloo), every
+        # rank maps its neighbours' and the border rows store straight into them -- no transport function at all
+        busy = int(plan["send_words"]) + int(plan["recv_words"]) > 0          # (a rank that owns nothing exchanges nothing)
+        mine = None
+        if busy:
+            loc = dn.p2p_local()
+            mine = (dn.p2p_ipc_export(), [int(x) for x in loc["offsets"]], [int(x) for x in loc["counts"]])
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine)
+        for p in range(world):
+            if busy and p != rank and everyone[p] is not None and (everyone[p][2][rank] or mine[2][p]):
+                r0, r1, fl = dn.p2p_ipc_import(everyone[p][0])
+                dn.p2p_connect(p, r0, r1, fl, everyone[p][1][rank])
+        if busy:
+            dn.p2p_commit()
+        dist.barrier()
+        dn.run_sharded_without_exchange(STEPS // 2)
+        dn.run_sharded_without_exchange(STEPS - STEPS // 2)
+        assert dn.stat("halo_peer_steps") == (STEPS if busy else 0)
+        exchange = None
     send, recv = parallel.exchange_tensors(plan, dev)
 
     def exchange(_stream):
@@ -86,8 +107,9 @@ def worker(rank, world, init_file, out_dir, form):
     def dn_stream_sync():
         torch.cuda.synchronize()            # the handle's stream is a blocking-free stream of this device: wait for all
 
-    dn.run_sharded_custom(exchange, STEPS // 2)
-    dn.run_sharded_custom(exchange, STEPS - STEPS // 2)
+    if not form.endswith("_peer"):
+        dn.run_sharded_custom(exchange, STEPS // 2)
+        dn.run_sharded_custom(exchange, STEPS - STEPS // 2)
     st = parity.pull_state(dn, net)
     known = np.zeros(net.n_neurons, bool)
     own = np.zeros(net.n_neurons, bool)
@@ -108,7 +130,8 @@ def worker(rank, world, init_file, out_dir, form):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("form,world", [("dense", 2), ("csr", 2), ("csr", 3), ("csr_by_lattice", 2)])
+@pytest.mark.parametrize("form,world", [("dense", 2), ("csr", 2), ("csr", 3), ("csr_by_lattice", 2), ("csr_peer", 2), ("csr_peer", 3),
+                                        ("csr_by_lattice_peer", 2), ("csr_by_lattice_peer", 4)])
 def test_library_step_loop_across_processes_on_one_gpu(snn, form, world):
     import torch.multiprocessing as mp
     import parity
@@ -123,10 +146,10 @@ def test_library_step_loop_across_processes_on_one_gpu(snn, form, world):
             z = np.load(os.path.join(d, f"rank{r}.npz"))
             own, k = z["own"], z["known"]
             assert str(z["mode"]) == ("halo" if form.startswith("csr") else "allgather") and int(z["clock"]) == STEPS
-            if form == "csr" and world > 2:
+            if form in ("csr", "csr_peer") and world > 2:
                 assert not k.all()                     # a genuinely partial view
-            if form == "csr_by_lattice":               # only the slab borders travel: 2 lattice rows x 16 x 4 lattices
-                assert int(z["recv_words"]) <= 4 * 2 * 16 + 8
+            if form.startswith("csr_by_lattice"):      # only the slab borders travel: 2 lattice rows x 16 x 4 lattices
+                assert int(z["recv_words"]) <= (2 if world > 2 else 1) * (4 * 2 * 16 + 8)       # (two neighbours from 3 ranks up)
             covered |= own
             for name in ("current_voltage", "is_spiking", "last_firing_time"):
                 assert np.array_equal(parity.bits(z[name][k]), parity.bits(ref[name][k])), (r, name)
