@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 ROWS = COLS = 256
-MIN_TIMED_S, MAX_REPEATS = 1.0, 400     # the timed repetitions add up to at least a second (short steps: more repetitions)
+MIN_TIMED_S, MAX_REPEATS = 1.0, 4000    # the timed repetitions add up to at least a second (short steps: more repetitions)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling is ~6.3 TB/s
 # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of THIS command (FETCH_SIZE and
 # WRITE_SIZE cannot share a pass); their summaries are committed under profiles/ and quoted here per launch.

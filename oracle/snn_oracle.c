@@ -1075,6 +1075,14 @@ static inline float bcm_weight(const snn_o_net *n, uint32_t l, float w, float pr
     return w + (activity_term * pre_activity - weight_decay) * n->bcm_dt[l];
 }
 
+/* kind of the connection (presynaptic row p -> a neuron of lattice l): see snn_o_net::conn_kind */
+static inline uint32_t conn_kind_of(const snn_o_net *n, uint32_t p, uint32_t l)
+{
+    if (!n->conn_kind) return 0;
+    const uint32_t source = (p < n->n_neurons) ? n->lattice[p] : n->n_lattices + n->st_lattice[p - n->n_neurons];
+    return n->conn_kind[(size_t)source * n->n_lattices + l];
+}
+
 void snn_o_plasticity_cols(snn_o_net *n, uint32_t c0, uint32_t c1)
 {
     const uint32_t nn = n->n_neurons;
@@ -1092,6 +1100,7 @@ void snn_o_plasticity_cols(snn_o_net *n, uint32_t c0, uint32_t c1)
             for (uint32_t p = 0; p < n_tot; ++p) {
                 size_t i = (size_t)p * ld + (j - col0);
                 if (!n->connections[i]) continue;
+                if (conn_kind_of(n, p, l)) continue;         /* a connection of the reward-modulated network: snn_o_reward_cross */
                 if (n->plasticity_kind && n->plasticity_kind[l]) {
                     float pre = (p < nn) ? n->bcm_current_activity[p] : n->st_bcm_current_activity[p - nn];
                     n->weights[i] = bcm_weight(n, l, n->weights[i], pre, j);
@@ -1108,6 +1117,7 @@ void snn_o_plasticity_cols(snn_o_net *n, uint32_t c0, uint32_t c1)
             size_t i = (size_t)j * ld + (r - col0);
             if (!n->connections[i]) continue;
             uint32_t l = n->lattice[r];
+            if (conn_kind_of(n, j, l)) continue;
             if (n->plasticity_kind && n->plasticity_kind[l]) {
                 n->weights[i] = bcm_weight(n, l, n->weights[i], n->bcm_current_activity[j], r);
                 continue;
@@ -1166,6 +1176,59 @@ void snn_o_reward_modulation_cols(snn_o_net *n, uint32_t c0, uint32_t c1)
             n->traces[i] = c;
         }
     }
+}
+
+/* RewardModulatedLatticeNetwork::update_weights_from_neurons_across_reward_lattices, the INCOMING half (neuron/mod.rs:4859-4924):
+ * every neuron q of a reward-modulated lattice l (do_update is always true, plasticity/mod.rs:239-241: every neuron, every step)
+ * visits each connection p -> q that comes from ANOTHER lattice or from a spike-train lattice:
+ *   RewardModulatedConnection::Weight (kind 2), p in a plain lattice lp (:4869-4883):
+ *       lp's STDP rule -- the PRESYNAPTIC lattice's -- adds its delta, spike or no spike; other sources: untouched;
+ *   RewardModulatedConnection::RewardModulatedWeight (kind 1), any source (:4885-4921):
+ *       l's reward modulator -- the POSTSYNAPTIC lattice's -- visits the weight ONCE (RewardModulatedSTDP::update_weight,
+ *       plasticity/mod.rs:203-237): dw += delta; the first of two visits only sets the counter, the second folds dw into the
+ *       trace and clears both; then weight += c * dopamine.  One visit per step, so dw and the counter live across steps.
+ * The OUTGOING half of the same function (:4926-4974) looks up the REVERSE edge and unwraps it: defined only where that edge
+ * exists, and then it overwrites the forward edge with the updated reverse one -- not restated.
+ * Such connections are left alone by the plain network's rule (snn_o_plasticity_cols). */
+void snn_o_reward_cross(snn_o_net *n)
+{
+    const uint32_t nn = n->n_neurons, n_tot = nn + n->n_cells;
+    if (!n->conn_kind || !n->rm_do_modulation) return;
+    for (uint32_t q = 0; q < nn; ++q) {
+        const uint32_t l = n->lattice[q];
+        if (!n->rm_do_modulation[l]) continue;
+        const float dopamine = n->rm_dopamine[l], dt = n->rm_dt[l], tau_c = n->rm_tau_c[l];
+        const float decay = snn_o_expf(-dt / tau_c);
+        const uint32_t second = n->rm_cross_counter ? n->rm_cross_counter[l] : 0u;
+        for (uint32_t p = 0; p < n_tot; ++p) {
+            size_t i = (size_t)p * nn + q;
+            if (!n->connections[i]) continue;
+            const uint32_t kind = conn_kind_of(n, p, l);
+            if (kind == 0 || (p < nn && n->lattice[p] == l)) continue;
+            const int32_t tp = (p < nn) ? n->last_firing_time[p] : n->st_last_firing_time[p - nn];
+            if (kind == 2) {
+                if (p >= nn || n->rm_do_modulation[n->lattice[p]]) continue;
+                const uint32_t lp = n->lattice[p];
+                n->weights[i] += snn_o_stdp_delta(tp, n->last_firing_time[q], n->stdp_a_plus[lp], n->stdp_a_minus[lp],
+                                                  n->stdp_tau_plus[lp], n->stdp_tau_minus[lp], n->stdp_dt[lp]);
+                continue;
+            }
+            float delta_w = snn_o_stdp_delta(tp, n->last_firing_time[q], n->rm_a_plus[l], n->rm_a_minus[l], n->rm_tau_plus[l],
+                                             n->rm_tau_minus[l], dt);
+            float dw = n->pending[i], c = n->traces[i];
+            dw += delta_w;
+            if (second) {
+                c = c * decay + tau_c * dw;
+                dw = 0.0f;
+            }
+            n->weights[i] += c * dopamine;
+            n->pending[i] = dw;
+            n->traces[i] = c;
+        }
+    }
+    if (n->rm_cross_counter)
+        for (uint32_t l = 0; l < n->n_lattices; ++l)
+            if (n->rm_do_modulation[l]) n->rm_cross_counter[l] ^= 1u;
 }
 
 /* ---------- step 6: spike trains ---------- */
@@ -1283,6 +1346,7 @@ void snn_o_run(snn_o_net *n, uint64_t iterations)
             snn_o_update_neurons(n);
             snn_o_plasticity(n);
             snn_o_reward_modulation(n);
+            snn_o_reward_cross(n);
             if (n->voltage_history)
                 memcpy(n->voltage_history + (size_t)it * n->n_neurons, n->current_voltage,
                        sizeof(float) * n->n_neurons);

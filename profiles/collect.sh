@@ -1,15 +1,18 @@
 #!/bin/bash
-# Collects the per-round evidence on a GPU box:  bash profiles/collect.sh rNN  (writes gpurun_out/rNN/, to be copied
-# into profiles/rNN/).  Per config: rocprofv3 --kernel-trace --stats of bench.py (kernel stats csv + the bench line of
+# Collects the per-round evidence on a GPU box:  bash profiles/collect.sh rNN [only]  (writes gpurun_out/rNN/, to be copied
+# into profiles/rNN/; `only` = a substring of the names to (re)collect, e.g. c5).  Per config: rocprofv3 --kernel-trace --stats of bench.py (kernel stats csv + the bench line of
 # that profiled process), then two separate --pmc passes (FETCH_SIZE, WRITE_SIZE) reduced by summarize_pmc.py.
 set -u
 R=${1:-r04}
+ONLY=${2:-}
+want() { [ -z "$ONLY" ] || [[ "$1" == *"$ONLY"* ]]; }
 OUT=$PWD/gpurun_out/$R
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$OLDPWD"
 DATE=$(date -u +%Y-%m-%d)
 prof() {   # name, bench args...
     local name=$1; shift
+    want "$name" || return 0
     rm -rf "$OUT/prof_$name"
     rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_$name" -- python3 bench.py "$@" --no-cpu-baseline \
         > "$OUT/${name}_bench_under_rocprof.json" 2> "$OUT/${name}_rocprof.err"
@@ -20,6 +23,7 @@ prof() {   # name, bench args...
 }
 pmc() {    # name, kernel substring, bench args...
     local name=$1 needle=$2; shift 2
+    want "$name" || return 0
     for c in FETCH_SIZE WRITE_SIZE; do
         rm -rf "$OUT/pmc_${name}_$c"
         rocprofv3 --pmc $c --output-format csv -d "$OUT/pmc_${name}_$c" -- python3 bench.py "$@" --no-cpu-baseline --no-kernel-events \
@@ -46,9 +50,17 @@ pmc c6 k_inputs_rstdp --config c6 --steps 10 --warmup 2 --repeats 1
 # (c5: 4-byte-per-lane accesses, a width the guide calls uncalibrated; the doubled FETCH_SIZE is kept because the undoubled
 #  figure, 79 MB, is below the 117 MB of plan words + weights the launch has to stream)
 pmc c5 k_step_csr --config c5 --steps 50 --warmup 5 --repeats 1
+if want c5; then
 # what ONE rank of G does per step, without its exchange (the library's loop with a transport that moves nothing)
 python3 profiles/measure_c5_rank_step.py 2000 > "$OUT/c5_rank_step.jsonl" 2> /dev/null
 PEER=1 python3 profiles/measure_c5_rank_step.py 2000 > "$OUT/c5_rank_step_peer_form.jsonl" 2> /dev/null
+python3 bench.py --config c5 --no-cpu-baseline > "$OUT/c5_bench_default.json" 2> /dev/null
+rm -rf "$OUT/trace_g8"
+( cd /tmp && SHARDS=8 rocprofv3 --kernel-trace --output-format csv -d "$OUT/trace_g8" -- python3 "$OLDPWD/profiles/measure_c5_rank_step.py" 1000 > /dev/null 2>&1 )
+python3 profiles/experiments/kernel_gaps.py "$(find "$OUT/trace_g8" -name '*kernel_trace.csv' | head -1)" 400 > "$OUT/c5_rank_step_g8_kernel_trace_summary.json"
+rm -rf "$OUT/trace_g8"
+fi
+if [ -z "$ONLY" ]; then
 python3 profiles/measure_shard_shapes.py 200 > "$OUT/c2_shard_shapes.jsonl" 2> /dev/null
 # small lattices with chemical synapses: the one-launch run against one launch per step
 python3 profiles/measure_small_chem.py 3000 2> /dev/null | grep lattice > "$OUT/small_chemical_lattices.jsonl"
@@ -56,9 +68,5 @@ python3 profiles/measure_small_chem.py 3000 2> /dev/null | grep lattice > "$OUT/
 python3 bench.py > "$OUT/bench_default.json" 2> /dev/null
 python3 bench.py --config c1 --no-cpu-baseline > "$OUT/c1_bench_default.json" 2> /dev/null
 python3 bench.py --config c3 --no-cpu-baseline > "$OUT/c3_bench_default.json" 2> /dev/null
-python3 bench.py --config c5 --no-cpu-baseline > "$OUT/c5_bench_default.json" 2> /dev/null
-rm -rf "$OUT/trace_g8"
-( cd /tmp && SHARDS=8 rocprofv3 --kernel-trace --output-format csv -d "$OUT/trace_g8" -- python3 "$OLDPWD/profiles/measure_c5_rank_step.py" 1000 > /dev/null 2>&1 )
-python3 profiles/experiments/kernel_gaps.py "$(find "$OUT/trace_g8" -name '*kernel_trace.csv' | head -1)" 400 > "$OUT/c5_rank_step_g8_kernel_trace_summary.json"
-rm -rf "$OUT/trace_g8"
+fi
 ls "$OUT"

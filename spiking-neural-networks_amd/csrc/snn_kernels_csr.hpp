@@ -83,7 +83,9 @@ __device__ __forceinline__ unsigned long long peer_granule(const unsigned long l
 
 // The canonical sums of one postsynaptic row (thread q of a wavefront = row q of a SELL slice).  Returns with
 // `sum` / `tsum` holding the second-level sums; rows past n_loc compute on row 0 and are discarded by the caller.
-template <bool ELEC, bool CHEM>
+// PEER: the halo arrives as granules (the peer form of a library-driven run) -- its own instantiation: the extra registers of the
+// granule path cost the plain step two wavefronts of occupancy per SIMD (80 against 50 VGPRs, C5 41.8 against 38.7 us)
+template <bool ELEC, bool CHEM, bool PEER = false>
 __device__ __forceinline__ void csr_row_sums(const CsrInputsArgs &a, uint32_t q, float &sum, float (&tsum)[K_TYPES])
 {
     // entries whose loads are in flight together (16 for the electrical form -- a row of BASELINE configs[4] in ONE batch --
@@ -112,7 +114,7 @@ __device__ __forceinline__ void csr_row_sums(const CsrInputsArgs &a, uint32_t q,
         uint32_t p[EDGE_BATCH];
         float w[EDGE_BATCH], v[EDGE_BATCH], t[EDGE_BATCH][K_TYPES];
         uint32_t flags[EDGE_BATCH];       // bit 0 cell, bit 1 silent cell, bit 2 a granule of the peer form, bits 8.. transmitter types
-        unsigned long long g64[EDGE_BATCH];
+        unsigned long long g64[PEER ? EDGE_BATCH : 1];
         // (1) plan word + weight of EDGE_BATCH consecutive entries: coalesced, independent
 #pragma unroll
         for (uint32_t u = 0; u < EDGE_BATCH; ++u) {
@@ -133,17 +135,17 @@ __device__ __forceinline__ void csr_row_sums(const CsrInputsArgs &a, uint32_t q,
             flags[u] = is_cell ? 1u : 0u;
             v[u] = 0.0f;
             if (ELEC) {
-                const bool granule = is_halo && a.g.halo64;
+                const bool granule = PEER && is_halo && a.g.halo64;
                 const float *src = is_cell ? reinterpret_cast<const float *>(in.st_view + sc)
                                  : (is_halo && !granule) ? reinterpret_cast<const float *>(a.g.halo + (code - a.g.halo_base))
                                                          : in.xbuf + in.xl.at(pn, PLANE_V);
                 v[u] = *src;
-                if (a.g.halo64) {
+                if (PEER && a.g.halo64) {
                     // peer form (launch-uniform): the entry's granule is requested with the rest of the batch -- one plain load, no
                     // loop here: a loop inside the gather would take the batch's loads out of flight for EVERY row -- and looked
                     // at below
-                    g64[u] = 0ull;
-                    if (granule) g64[u] = __hip_atomic_load(a.g.halo64 + (code - a.g.halo_base), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    g64[PEER ? u : 0] = 0ull;
+                    if (granule) g64[PEER ? u : 0] = __hip_atomic_load(a.g.halo64 + (code - a.g.halo_base), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     flags[u] |= granule ? 4u : 0u;
                 }
                 flags[u] |= (is_cell && in.st_view[sc].y) ? 2u : 0u;
@@ -160,10 +162,10 @@ __device__ __forceinline__ void csr_row_sums(const CsrInputsArgs &a, uint32_t q,
                 }
             }
         }
-        if (ELEC && a.g.halo64) {
+        if (PEER && ELEC && a.g.halo64) {
             // peer form: a granule whose tag is not yet the step's (the neighbour's border rows are still on their way) is polled
 #pragma unroll
-            for (uint32_t u = 0; u < EDGE_BATCH; ++u) {
+            for (uint32_t u = 0; u < (PEER ? EDGE_BATCH : 1u); ++u) {
                 if (!(flags[u] & 4u)) continue;
                 if (((uint32_t)(g64[u] >> 32) & 0x7FFFFFFFu) != a.g.halo_tag)
                     g64[u] = peer_granule(a.g.halo64 + ((p[u] & PLAN_CODE) - a.g.halo_base), a.g.halo_tag, a.g.spin_limit, a.g.failed);
@@ -246,6 +248,7 @@ struct StepCloseArgs {
     __host__ __device__ uint32_t blocks() const { return cell_blocks + unpack_blocks + (send_bitmap_words + 255) / 256; }
 };
 
+template <bool PEER = true>
 __device__ __forceinline__ void step_close_block(const StepCloseArgs &a, const uint32_t block)
 {
     if (block < a.cell_blocks) {
@@ -263,7 +266,7 @@ __device__ __forceinline__ void step_close_block(const StepCloseArgs &a, const u
         const uint32_t g = a.recv.list[t];
         if (g >= a.recv.n_neurons) return;
         uint32_t *x = reinterpret_cast<uint32_t *>(a.recv.xbuf), *x2 = reinterpret_cast<uint32_t *>(a.xbuf2);
-        if (a.recv64) {
+        if (PEER && a.recv64) {
             // one plane (the voltage), one granule per neuron: value, and the spike flag in the tag word's top bit
             const unsigned long long g64 = peer_granule(a.recv64 + a.recv.seg_offset[seg] + i, a.recv_tag, a.spin_limit, a.failed);
             const size_t at = a.recv.xl.at(g, (int)a.recv.plane_id[0]);
@@ -366,14 +369,14 @@ struct CsrStepArgs {
 };
 static_assert(sizeof(CsrStepArgs) <= 4096, "kernel arguments are limited to 4 KB");
 
-template <int MODEL, bool ELEC, bool CHEM>
+template <int MODEL, bool ELEC, bool CHEM, bool PEER>
 __device__ __forceinline__ void step_csr_block(const CsrStepArgs &a)
 {
     // the tail jobs come AFTER the row blocks: they fill the tail of the rows' streaming (cells at C5, one box, step time:
     // cells in their own launch 44.7 us; cell blocks first 41.5; spread evenly among the row blocks 45.6; last 39.3)
     const uint32_t row_blocks = gridDim.x - a.tail.blocks();
     if (blockIdx.x >= row_blocks) {
-        step_close_block(a.tail, blockIdx.x - row_blocks);
+        step_close_block<PEER>(a.tail, blockIdx.x - row_blocks);
         return;
     }
     // Workgroups are handed to the 8 XCDs round-robin (a placement heuristic, used for speed only): XCD x takes a
@@ -397,7 +400,7 @@ __device__ __forceinline__ void step_csr_block(const CsrStepArgs &a)
         }
     }
     RegisterSums s;
-    csr_row_sums<ELEC, CHEM>(a.c, q, s.i, s.t);
+    csr_row_sums<ELEC, CHEM, PEER>(a.c, q, s.i, s.t);
     uint32_t spike = 0;
     float v_new = 0.0f;
     // (a range-set shard owns whole 64-blocks of the global index space only in part: the rows of the neurons it does not own
@@ -412,7 +415,7 @@ __device__ __forceinline__ void step_csr_block(const CsrStepArgs &a)
             if (g < a.up.n.n_pad) a.up.spike_row[g >> 6] = word;
         }
     }
-    if (pack_end > pack_begin && a.pack.dst) {
+    if (PEER && pack_end > pack_begin && a.pack.dst) {
         // peer form: the voltage (from its register) and the spike flag as ONE granule per reading peer, stored into that
         // peer's receive set -- once the peer is done with the step that read the set's previous contents
         for (uint32_t e = pack_begin; e < pack_end; ++e) {
@@ -444,17 +447,18 @@ __device__ __forceinline__ void step_csr_block(const CsrStepArgs &a)
     }
 }
 
-template <int MODEL, bool ELEC, bool CHEM>
+template <int MODEL, bool ELEC, bool CHEM, bool PEER = false>
 __global__ __launch_bounds__(256) void k_step_csr(const CsrStepArgs a)
 {
+    static_assert(!PEER || (ELEC && !CHEM), "the peer form carries the voltage alone");
     // peer form: THIS launch running means the previous one of the stream is over -- every row and the mirror job of the step
     // before have read what they had to read -- which is what the neighbours wait for before they overwrite a receive set.  One
     // thread says so.  (A counter of finished workgroups at the END of the launch was measured first: 2048 atomics on one
     // address cost 27 us of a 35 us step.)
-    if (a.peer.signal && blockIdx.x == 0 && threadIdx.x == 0)
+    if (PEER && a.peer.signal && blockIdx.x == 0 && threadIdx.x == 0)
         for (uint32_t i = 0; i < a.peer.n_signal; ++i)
             __hip_atomic_store(a.peer.signal[i], a.peer.done_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    step_csr_block<MODEL, ELEC, CHEM>(a);
+    step_csr_block<MODEL, ELEC, CHEM, PEER>(a);
 }
 
 // static counts of a sparse graph: n_in = row length, tcount[k] = entries whose presynaptic cell carries type k

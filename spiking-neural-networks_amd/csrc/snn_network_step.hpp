@@ -916,6 +916,7 @@ int launch_step_csr(snn_network *net, CsrStepPart part = CSR_STEP_ALL, bool pack
 #define SNN_CSR_STEP(M)                                                                                              \
     do {                                                                                                             \
         if (net->electrical && net->chemical) hipLaunchKernelGGL((k_step_csr<M, true, true>), grid, block, 0, net->stream, c);  \
+        else if (net->electrical && net->peer_run) hipLaunchKernelGGL((k_step_csr<M, true, false, true>), grid, block, 0, net->stream, c); \
         else if (net->electrical) hipLaunchKernelGGL((k_step_csr<M, true, false>), grid, block, 0, net->stream, c);             \
         else hipLaunchKernelGGL((k_step_csr<M, false, true>), grid, block, 0, net->stream, c);                                  \
     } while (0)

@@ -391,14 +391,15 @@ class NumpyNet:
         def params(l):
             return tuple(float(a[k][l]) for k in ("stdp_a_plus", "stdp_a_minus", "stdp_tau_plus", "stdp_tau_minus", "stdp_dt"))
 
+        kinds = self.connection_kinds()                         # [n_tot, n_lattices]: connections of a reward-modulated network are not ours
         for j in np.nonzero(spike)[0]:
             if not a["do_plasticity"][lat[j]]:
                 continue
-            rows = conn[:, j]                                   # incoming edges: the plasticity of j's lattice
+            rows = conn[:, j] & (kinds[:, lat[j]] == 0)         # incoming edges: the plasticity of j's lattice
             d = stdp_delta(lft_all[rows], lft_all[j], *params(lat[j]))
             w[rows, j] = (w[rows, j] + d).astype(f32)
             for l in np.unique(lat):                            # outgoing edges: the plasticity of the target's lattice
-                cols = conn[j, :] & (lat == l)
+                cols = conn[j, :] & (lat == l) & (kinds[j, l] == 0)
                 if cols.any():
                     d = stdp_delta(lft_all[j], a["last_firing_time"][cols], *params(l))
                     w[j, cols] = (w[j, cols] + d).astype(f32)
@@ -428,6 +429,56 @@ class NumpyNet:
                 w = (w + (c * dop).astype(f32)).astype(f32)
             a["weights"][p, q] = w
             a["traces"][p, q] = c
+
+    def connection_kinds(self):
+        """per presynaptic row and post lattice: 0 a plain network's edge, 1 RewardModulatedConnection::RewardModulatedWeight,
+        2 RewardModulatedConnection::Weight (conn_kind is indexed by the SOURCE lattice: neuron lattices, then spike-train ones)"""
+        a = self.a
+        nl = int(a["lattice_count"].size)
+        if "conn_kind" not in a or not a["conn_kind"].any():
+            return np.zeros((self.nn + self.nc, nl), np.uint8)
+        source = np.concatenate([a["lattice"], nl + a["st_lattice"]]).astype(np.int64)
+        return a["conn_kind"][source]
+
+    def reward_cross(self):
+        """the incoming half of RewardModulatedLatticeNetwork::update_weights_from_neurons_across_reward_lattices
+        (neuron/mod.rs:4859-4924): every neuron of a modulated lattice l visits its connections from other lattices once per step --
+        a plain Weight from a plain lattice lp takes lp's STDP delta (:4869-4883); a RewardModulatedWeight takes one visit of l's
+        modulator (plasticity/mod.rs:203-237): dw += delta, every second visit folds dw into the trace, weight += c * dopamine"""
+        a, nn = self.a, self.nn
+        if "conn_kind" not in a or not a["conn_kind"].any() or not a["rm_do_modulation"].any():
+            return
+        kinds = self.connection_kinds()
+        lat = a["lattice"]
+        lft_all = np.concatenate([a["last_firing_time"], a["st_last_firing_time"]])
+        conn = a["connections"] != 0
+        for l in np.nonzero(a["rm_do_modulation"])[0]:
+            post = lat == l
+            other = np.concatenate([lat != l, np.ones(self.nc, bool)])
+            # kind 2: the presynaptic lattice's STDP, plain lattices only
+            plain_pre = np.concatenate([a["rm_do_modulation"][lat] == 0, np.zeros(self.nc, bool)])
+            p, q = np.nonzero(conn & (kinds[:, l] == 2)[:, None] & (other & plain_pre)[:, None] & post[None, :])
+            for lp in np.unique(lat[p]) if p.size else ():
+                m = lat[p] == lp
+                d = stdp_delta(lft_all[p[m]], lft_all[q[m]], *(float(a[k][lp]) for k in
+                                                                 ("stdp_a_plus", "stdp_a_minus", "stdp_tau_plus", "stdp_tau_minus", "stdp_dt")))
+                a["weights"][p[m], q[m]] = (a["weights"][p[m], q[m]] + d).astype(f32)
+            # kind 1: one visit of l's modulator
+            p, q = np.nonzero(conn & (kinds[:, l] == 1)[:, None] & other[:, None] & post[None, :])
+            if p.size:
+                dop, dt, tau_c = f32(a["rm_dopamine"][l]), f32(a["rm_dt"][l]), f32(a["rm_tau_c"][l])
+                delta = stdp_delta(lft_all[p], lft_all[q], float(a["rm_a_plus"][l]), float(a["rm_a_minus"][l]),
+                                   float(a["rm_tau_plus"][l]), float(a["rm_tau_minus"][l]), float(dt))
+                decay = expf(np.array([(-dt) / tau_c], f32))[0]
+                w, c, dw = a["weights"][p, q], a["traces"][p, q], a["pending"][p, q]
+                with np.errstate(all="ignore"):
+                    dw = (dw + delta).astype(f32)
+                    if a["rm_cross_counter"][l]:
+                        c = ((c * decay).astype(f32) + (tau_c * dw).astype(f32)).astype(f32)
+                        dw = np.zeros_like(dw)
+                    w = (w + (c * dop).astype(f32)).astype(f32)
+                a["weights"][p, q], a["traces"][p, q], a["pending"][p, q] = w, c, dw
+            a["rm_cross_counter"][l] ^= 1
 
     # ---- step 6: spike trains  neuron/mod.rs:1377-1393 --------------------------------------------------------
     def spike_trains(self):
@@ -474,6 +525,7 @@ class NumpyNet:
                 spike = self.update_neurons(i_in, t_in, t_cnt)
                 self.plasticity(spike)
                 self.reward_modulation()
+                self.reward_cross()
                 vh.append(self.a["current_voltage"].copy())
                 sh.append(spike.astype(np.uint8))
             self.clock += 1

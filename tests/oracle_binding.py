@@ -91,6 +91,7 @@ _FIELDS = [
     ("rx_code", C.POINTER(C.c_int32)), ("rx_consts", f32p), ("rx_ntypes", C.c_uint32), ("rx_nvars", C.c_uint32),
     ("rx_section", C.c_uint32 * 3), ("rx_current_index", C.c_int32 * 3), ("rx_vars", f32p),
     ("rx_multi", C.c_uint32), ("rx_kin_section", C.c_uint32 * 3),
+    ("conn_kind", u8p), ("pending", f32p), ("rm_cross_counter", u32p),
 ]
 
 
@@ -280,10 +281,14 @@ class Net:
                 shape = (nn,)
             elif name == "st_clock":
                 shape = (self.n_st_lattices,)
-            elif name in ("weights", "connections", "traces"):
+            elif name in ("weights", "connections", "traces", "pending"):
                 if not dense:
                     continue
                 shape = (self.n_tot, nn)
+            elif name == "conn_kind":
+                shape = (self.n_lattices + self.n_st_lattices, self.n_lattices)
+            elif name == "rm_cross_counter":
+                shape = (self.n_lattices,)
             elif name == "input_current":
                 shape = (nn,)
             else:   # histories: allocated per run
