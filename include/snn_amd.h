@@ -409,6 +409,24 @@ int snn_run_with_reward(snn_network_t *net, float reward);
  * edge order of snn_set_graph_csr. */
 int snn_set_trace_rows(snn_network_t *net, uint32_t pre_begin, uint32_t pre_count, const float *traces);
 int snn_get_trace_rows(snn_network_t *net, uint32_t pre_begin, uint32_t pre_count, float *traces);
+/* ---- connections BETWEEN lattices in a reward-modulated network (RewardModulatedLatticeNetwork, neuron/mod.rs:3419-3453) ----
+ * The reference's connecting graph holds RewardModulatedConnection::{Weight, RewardModulatedWeight}; what happens to such a
+ * connection when it ENDS in a reward-modulated lattice is the incoming half of
+ * update_weights_from_neurons_across_reward_lattices (neuron/mod.rs:4859-4924), once per step for every neuron of the lattice:
+ *   kind 2 (Weight): the STDP rule of the PRESYNAPTIC lattice adds its delta -- plain neuron lattices only, spike or no spike;
+ *   kind 1 (RewardModulatedWeight): ONE visit of the postsynaptic lattice's modulator (plasticity/mod.rs:203-237): the delta
+ *     goes into TraceRSTDP::dw, every second visit folds dw into the trace c, the weight gains c * dopamine.
+ * snn_set_connection_kind(pre_id, post_id, kind) tags every connection from lattice (or spike-train lattice) pre_id into
+ * neuron lattice post_id (kind 0, the default: the plain LatticeNetwork's rule of snn_set_plasticity).  dw is the `pending`
+ * matrix (rows as snn_set_trace_rows), the counter of the two-visit cycle one bit per postsynaptic lattice
+ * (snn_connection_counter: set != 0 writes *counter, else reads it).  Dense, unsharded handles.  NOT restated: the outgoing
+ * half of the same function (:4926-4974) -- it looks up the REVERSE edge and unwraps it, i.e. it is defined only where that
+ * edge exists and then overwrites the forward connection with it; and such connections into PLAIN lattices
+ * (update_weights_from_neurons_across_lattices, :4707-4802). */
+int snn_set_connection_kind(snn_network_t *net, uint32_t pre_id, uint32_t post_id, int kind);
+int snn_set_pending_rows(snn_network_t *net, uint32_t pre_begin, uint32_t pre_count, const float *pending);
+int snn_get_pending_rows(snn_network_t *net, uint32_t pre_begin, uint32_t pre_count, float *pending);
+int snn_connection_counter(snn_network_t *net, uint32_t post_id, int set, uint32_t *counter);
 int snn_set_traces_csr(snn_network_t *net, const float *traces, uint64_t nnz);
 int snn_get_traces_csr(snn_network_t *net, float *traces, uint64_t nnz);
 

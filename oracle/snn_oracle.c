@@ -1194,6 +1194,11 @@ void snn_o_reward_cross(snn_o_net *n)
 {
     const uint32_t nn = n->n_neurons, n_tot = nn + n->n_cells;
     if (!n->conn_kind || !n->rm_do_modulation) return;
+    {
+        uint32_t any = 0;       /* no connection of these kinds: a plain network, nothing is visited and no counter moves */
+        for (size_t i = 0; i < (size_t)(n->n_lattices + n->n_st_lattices) * n->n_lattices; ++i) any |= n->conn_kind[i];
+        if (!any) return;
+    }
     for (uint32_t q = 0; q < nn; ++q) {
         const uint32_t l = n->lattice[q];
         if (!n->rm_do_modulation[l]) continue;

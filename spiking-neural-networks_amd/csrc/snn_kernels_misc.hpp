@@ -267,7 +267,18 @@ struct StdpArgs {
     float *drow;                          // [ld]
     uint32_t dcol_stride, n_lattices;
     long long clock;                      // the step being closed (= last_firing_time of the listed neurons)
+    // connections of a reward-modulated network (snn_set_connection_kind): [source][post lattice], source = the lattice slot of a
+    // presynaptic neuron or n_lattices + the spike-train lattice slot of a cell; a non-zero kind belongs to k_reward_cross, not
+    // to the plain rule.  null: none.
+    const uint8_t *conn_kind;
+    const uint32_t *st_lattice_slot;      // [c_pad] cell -> spike-train lattice slot
 };
+__device__ __forceinline__ bool plain_connection(const StdpArgs &a, uint32_t p, uint32_t post_slot)
+{
+    if (!a.conn_kind) return true;
+    const uint32_t source = p < a.n_neurons ? a.lattice_slot[p] : a.n_lattices + a.st_lattice_slot[p - a.n_neurons];
+    return a.conn_kind[(size_t)source * a.n_lattices + post_slot] == 0;
+}
 
 // Wave-ballot + popcount prefix compaction of the neurons that spiked in this step and whose
 // lattice has do_plasticity set (the reference's positions_to_update, neuron/mod.rs:2544-2563).
@@ -379,7 +390,7 @@ __global__ __launch_bounds__(256) void k_stdp_columns(const StdpArgs a)
         if (j < a.q0 || j >= a.q0 + a.n_loc) continue;
         float *wp = a.W + widx(p, j - a.q0, a.ld);
         const float w = stdp_load(wp, stream);
-        if (w == w) {
+        if (w == w && plain_connection(a, p, a.lattice_slot[j])) {
             const float *prm = a.stdp + PL_STRIDE * a.lattice_slot[j];
             const bool bcm = prm[5] != 0.0f;
             const float pre = bcm ? ((p < a.n_neurons) ? a.act[p] : a.st_act[p - a.n_neurons]) : 0.0f;
@@ -404,7 +415,8 @@ __global__ __launch_bounds__(256) void k_stdp_rows(const StdpArgs a)
         const uint32_t j = a.spike_list[s];
         float *wp = a.W + widx(j, r, a.ld);
         const float w = stdp_load(wp, stream);
-        if (w == w) stdp_store(wp, plasticity_weight(prm, w, a.last_firing_time[j], tr, bcm ? a.act[j] : 0.0f, post_act, post_avg), stream);
+        if (w == w && plain_connection(a, j, a.lattice_slot[gr]))
+            stdp_store(wp, plasticity_weight(prm, w, a.last_firing_time[j], tr, bcm ? a.act[j] : 0.0f, post_act, post_avg), stream);
     }
 }
 

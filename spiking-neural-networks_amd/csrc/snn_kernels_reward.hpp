@@ -88,6 +88,77 @@ __global__ __launch_bounds__(256) void k_rstdp_dense(const RewardArgs a)
     }
 }
 
+// RewardModulatedLatticeNetwork::update_weights_from_neurons_across_reward_lattices, the incoming half (neuron/mod.rs:4859-4924):
+// every neuron q of a modulated lattice visits, once per step, its connections from OTHER lattices and from spike-train cells --
+//   kind 2 (RewardModulatedConnection::Weight), source in a plain neuron lattice lp: w += lp's STDP delta (:4869-4883);
+//   kind 1 (RewardModulatedConnection::RewardModulatedWeight): one visit of q's lattice's modulator (plasticity/mod.rs:203-237):
+//       dw += delta; every second visit  c = c * exp(-dt / tau_c) + tau_c * dw, dw = 0;  w += c * dopamine.
+// One visit per step: TraceRSTDP::dw lives across steps (`pending`, the layout of W), and the counter is the same for every such
+// connection of a lattice (bit l of `second`).  Thread = one column, 4 rows per unit, as k_rstdp_dense.
+struct RewardCrossArgs {
+    float *W, *C, *P;                      // weights, TraceRSTDP::c, TraceRSTDP::dw
+    uint32_t ld, n_loc, q0, n_neurons, n_tot, n_lattices;
+    const int32_t *last_firing_time, *st_last_firing_time;
+    const uint32_t *lattice_slot, *st_lattice_slot;
+    const float *rm, *stdp;
+    const uint32_t *rm_on;
+    const uint8_t *conn_kind;
+    unsigned long long second;             // bit l: this is the second of a pair of visits for lattice l
+};
+
+__global__ __launch_bounds__(256) void k_reward_cross(const RewardCrossArgs a)
+{
+    const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= a.n_loc) return;
+    const uint32_t q = a.q0 + c;
+    const uint32_t sq = a.lattice_slot[q];
+    if (!a.rm_on[sq]) return;
+    const int32_t tq = a.last_firing_time[q];
+    const float *m = a.rm + (size_t)sq * RM_STRIDE;
+    const bool second = (a.second >> sq & 1ull) != 0ull;
+    const uint32_t groups = (a.n_tot + 3u) >> 2;
+    for (uint32_t g = blockIdx.y; g < groups; g += gridDim.y) {
+        uint32_t kind[4];
+        bool any = false;
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) {
+            const uint32_t p = g * 4 + k;
+            kind[k] = 0;
+            if (p < a.n_tot) {
+                const uint32_t source = p < a.n_neurons ? a.lattice_slot[p] : a.n_lattices + a.st_lattice_slot[p - a.n_neurons];
+                if (!(p < a.n_neurons && source == sq)) kind[k] = a.conn_kind[(size_t)source * a.n_lattices + sq];
+            }
+            any = any || kind[k] != 0;
+        }
+        if (!any) continue;
+        v4f *wp = reinterpret_cast<v4f *>(a.W) + (size_t)g * a.ld + c;
+        v4f *cp = reinterpret_cast<v4f *>(a.C) + (size_t)g * a.ld + c;
+        v4f *pp = reinterpret_cast<v4f *>(a.P) + (size_t)g * a.ld + c;
+        v4f w = *wp, tr = *cp, pd = *pp;
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) {
+            const uint32_t p = g * 4 + k;
+            if (kind[k] == 0 || w[k] != w[k]) continue;                      // a plain network's edge / absent edge (NaN)
+            const int32_t tp = p < a.n_neurons ? a.last_firing_time[p] : a.st_last_firing_time[p - a.n_neurons];
+            if (kind[k] == 2) {
+                if (p >= a.n_neurons || a.rm_on[a.lattice_slot[p]]) continue;
+                const float *prm = a.stdp + PL_STRIDE * a.lattice_slot[p];
+                w[k] = w[k] + stdp_delta(tp, tq, prm[0], prm[1], prm[2], prm[3], prm[4]);
+                continue;
+            }
+            float dw = pd[k], ck = tr[k];
+            dw += stdp_delta(tp, tq, m[3], m[4], m[5], m[6], m[7]);
+            if (second) {
+                ck = ck * m[8] + m[2] * dw;
+                dw = 0.0f;
+            }
+            w[k] = w[k] + ck * m[RM_DOPAMINE];
+            pd[k] = dw; tr[k] = ck;
+        }
+        *wp = w; *cp = tr; *pp = pd;
+    }
+}
+
 // The same update FUSED into the next step's synaptic-input pass: W and the trace are read, updated, written back,
 // and the fresh weight feeds the input sums -- 16 B per synapse per step for a reward-modulated lattice instead of
 // 16 (k_rstdp_dense) + 4 (k_inputs_dense).  The host defers the update of step t to the start of step t+1 (nothing

@@ -75,6 +75,8 @@ int snn_network_destroy(snn_network_t *net)
     if (net->raster) (void)hipFree(net->raster);
     if (net->preset_times_dev) (void)hipFree(net->preset_times_dev);
     if (net->trace) (void)hipFree(net->trace);
+    if (net->pending) (void)hipFree(net->pending);
+    if (net->conn_kind_dev) (void)hipFree(net->conn_kind_dev);
     if (net->run_failed) (void)hipHostFree(net->run_failed);
     for (float *b : net->whist) if (b) (void)hipFree(b);
     if (net->summ_avg) (void)hipFree(net->summ_avg);
@@ -663,7 +665,20 @@ int snn_run_with_reward(snn_network_t *net, float reward)
 
 // TraceRSTDP::c of the edges in presynaptic rows [pre_begin, pre_begin + pre_count), row-major [pre_count][n_neurons];
 // a shard handle reads / writes its own columns only.
-static int trace_rows_io(snn_network_t *net, uint32_t pre_begin, uint32_t pre_count, float *traces, bool set)
+namespace {
+// TraceRSTDP::dw of the connections of a reward-modulated network (k_reward_cross): allocated with the first such connection
+int ensure_pending(snn_network *net)
+{
+    if (net->pending) return SNN_OK;
+    const size_t n = std::max<size_t>(wcount(net->n_tot, net->ld), 64);
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&net->pending), n * 4), SNN_ERR_BUFFER_CREATE);
+    HIP_TRY(hipMemsetAsync(net->pending, 0, n * 4, net->stream), SNN_ERR_BUFFER_WRITE);
+    HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
+    return SNN_OK;
+}
+} // namespace
+
+static int trace_rows_io(snn_network_t *net, uint32_t pre_begin, uint32_t pre_count, float *traces, bool set, bool pending = false)
 {
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
     if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
@@ -674,6 +689,8 @@ static int trace_rows_io(snn_network_t *net, uint32_t pre_begin, uint32_t pre_co
     HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
     TRY(end_run(net));
     TRY(ensure_traces(net));
+    if (pending) TRY(ensure_pending(net));
+    float *matrix = pending ? net->pending : net->trace;
     HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
     // through a row-major staging block of <= 64 MiB and <= 32768 rows per hop (the matrix is in quad-row order)
     float *host = traces + net->q0;
@@ -687,10 +704,10 @@ static int trace_rows_io(snn_network_t *net, uint32_t pre_begin, uint32_t pre_co
         if (set) {
             if (hipMemcpy2D(stage, (size_t)net->n_loc * 4, host + (size_t)r * net->nn, (size_t)net->nn * 4, (size_t)net->n_loc * 4, rows,
                             hipMemcpyHostToDevice) != hipSuccess) { rc = fail(SNN_ERR_BUFFER_WRITE, "trace upload failed"); break; }
-            hipLaunchKernelGGL(k_rows_staging, grid, dim3(256), 0, net->stream, net->trace, net->ld, net->n_loc, pre_begin + r, rows, stage, 1);
+            hipLaunchKernelGGL(k_rows_staging, grid, dim3(256), 0, net->stream, matrix, net->ld, net->n_loc, pre_begin + r, rows, stage, 1);
             if (hipStreamSynchronize(net->stream) != hipSuccess) rc = fail(SNN_ERR_WAIT, "trace upload wait failed");
         } else {
-            hipLaunchKernelGGL(k_rows_staging, grid, dim3(256), 0, net->stream, net->trace, net->ld, net->n_loc, pre_begin + r, rows, stage, 0);
+            hipLaunchKernelGGL(k_rows_staging, grid, dim3(256), 0, net->stream, matrix, net->ld, net->n_loc, pre_begin + r, rows, stage, 0);
             if (hipStreamSynchronize(net->stream) != hipSuccess) { rc = fail(SNN_ERR_WAIT, "trace download wait failed"); break; }
             if (hipMemcpy2D(host + (size_t)r * net->nn, (size_t)net->nn * 4, stage, (size_t)net->n_loc * 4, (size_t)net->n_loc * 4, rows,
                             hipMemcpyDeviceToHost) != hipSuccess) rc = fail(SNN_ERR_BUFFER_READ, "trace download failed");
@@ -703,6 +720,51 @@ int snn_set_trace_rows(snn_network_t *net, uint32_t pre_begin, uint32_t pre_coun
 { return trace_rows_io(net, pre_begin, pre_count, const_cast<float *>(traces), true); }
 int snn_get_trace_rows(snn_network_t *net, uint32_t pre_begin, uint32_t pre_count, float *traces)
 { return trace_rows_io(net, pre_begin, pre_count, traces, false); }
+int snn_set_pending_rows(snn_network_t *net, uint32_t pre_begin, uint32_t pre_count, const float *pending)
+{ return trace_rows_io(net, pre_begin, pre_count, const_cast<float *>(pending), true, true); }
+int snn_get_pending_rows(snn_network_t *net, uint32_t pre_begin, uint32_t pre_count, float *pending)
+{ return trace_rows_io(net, pre_begin, pre_count, pending, false, true); }
+
+int snn_set_connection_kind(snn_network_t *net, uint32_t pre_id, uint32_t post_id, int kind)
+{
+    if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
+    if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
+    if (kind < 0 || kind > 2) return fail(SNN_ERR_BAD_ARG, "kind: 0 a plain network's connection, 1 reward-modulated weights, 2 plain weights of a reward-modulated network");
+    const LatticeInfo *pre = find_lattice(net, pre_id), *post = find_lattice(net, post_id);
+    if (!pre || !post || post->spike_train) return fail(SNN_ERR_BAD_ARG, "connections end in neuron lattices");
+    if (pre_id == post_id) return fail(SNN_ERR_BAD_ARG, "a lattice's own edges follow its own rule (snn_set_plasticity / snn_set_reward_modulator)");
+    if (net->csr || net->sharded) return fail(SNN_ERR_BAD_STATE, "connections of a reward-modulated network: dense, unsharded handles");
+    const size_t nl = net->lattices.size(), ns = net->st_lattices.size();
+    if (nl > 64) return fail(SNN_ERR_BAD_STATE, "connections of a reward-modulated network: at most 64 neuron lattices");
+    HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
+    TRY(end_run(net));
+    if (net->conn_kind_host.empty()) {
+        net->conn_kind_host.assign((nl + ns) * nl, 0);
+        net->rm_cross_counter.assign(nl, 0);
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&net->conn_kind_dev), std::max<size_t>((nl + ns) * nl, 256)), SNN_ERR_BUFFER_CREATE);
+    }
+    const size_t source = pre->spike_train ? nl + pre->slot : pre->slot;
+    net->conn_kind_host[source * nl + post->slot] = (uint8_t)kind;
+    net->any_conn_kind = false;
+    for (uint8_t k : net->conn_kind_host) net->any_conn_kind |= k != 0;
+    HIP_TRY(hipMemcpy(net->conn_kind_dev, net->conn_kind_host.data(), net->conn_kind_host.size(), hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
+    if (kind) {
+        TRY(ensure_traces(net));
+        TRY(ensure_pending(net));
+    }
+    return SNN_OK;
+}
+
+int snn_connection_counter(snn_network_t *net, uint32_t post_id, int set, uint32_t *counter)
+{
+    if (!net || !counter) return fail(SNN_ERR_BAD_ARG, "null argument");
+    const LatticeInfo *post = net->finalized ? find_lattice(net, post_id) : nullptr;
+    if (!post || post->spike_train) return fail(SNN_ERR_BAD_ARG, "no such neuron lattice");
+    if (net->rm_cross_counter.empty()) { if (!set) *counter = 0; return set ? fail(SNN_ERR_BAD_STATE, "no connection kind has been set") : SNN_OK; }
+    if (set) { TRY(end_run(net)); net->rm_cross_counter[post->slot] = *counter & 1u; }
+    else *counter = net->rm_cross_counter[post->slot];
+    return SNN_OK;
+}
 
 static int traces_csr_io(snn_network_t *net, float *traces, uint64_t nnz, bool set)
 {

@@ -95,6 +95,14 @@ struct snn_network {
     float *rm_dev = nullptr;
     uint32_t *rm_on_dev = nullptr;
     float *trace = nullptr;                // dense: [n_tot][ld]; CSR: [sell_entries]
+    // connections of a reward-modulated NETWORK that end in a modulated lattice (snn_set_connection_kind, k_reward_cross):
+    // conn_kind [n_lattices + n_st_lattices][n_lattices], TraceRSTDP::dw per edge (`pending`, allocated on first use, layout of W),
+    // TraceRSTDP::counter per post lattice
+    std::vector<uint8_t> conn_kind_host;
+    uint8_t *conn_kind_dev = nullptr;
+    bool any_conn_kind = false;
+    float *pending = nullptr;
+    std::vector<uint32_t> rm_cross_counter;
     // Dense handles defer the weight update of step t to the input pass of step t+1 (k_inputs_rstdp: one pass over
     // W and the traces instead of two); any host access to weights / traces / timing flushes it first.
     int defer_rstdp = 1;                   // 0: always the standalone pass (SNN_AMD_DEFER_RSTDP=0)

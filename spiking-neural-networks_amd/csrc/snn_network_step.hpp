@@ -53,7 +53,7 @@ inline bool matrix_streamed(const snn_network *net)
 bool stdp_deferral_applies(const snn_network *net)
 {
     if (SNN_HAVE_CUSTOM_MODEL) return false;      // a library carrying generated code keeps the standalone kernels (shorter compile)
-    if (!net->defer_stdp || !net->any_plasticity || net->any_modulation || net->any_whist || !matrix_streamed(net) ||
+    if (!net->defer_stdp || !net->any_plasticity || net->any_modulation || net->any_whist || !matrix_streamed(net) || net->any_conn_kind ||
         net->lattices.size() > (size_t)STDP_MAX_LATTICES || net->n_loc == 0)
         return false;
     for (size_t l = 0; l < net->lattices.size(); ++l)
@@ -73,6 +73,8 @@ StdpArgs stdp_args(snn_network *net)
     a.flag = nullptr; a.dcol = net->stdp_dcol; a.drow = net->stdp_drow;
     a.dcol_stride = net->dcol_stride; a.n_lattices = (uint32_t)net->lattices.size();
     a.clock = net->clock;
+    a.conn_kind = net->any_conn_kind ? net->conn_kind_dev : nullptr;
+    a.st_lattice_slot = net->ca.lattice_slot;
     return a;
 }
 // snn_network_exchange.hpp
@@ -382,6 +384,29 @@ int launch_rstdp_pass(snn_network *net, int dop)
     const unsigned gy = std::max(1u, std::min<unsigned>((net->nn + 3) / 4, std::max(1u, 8192u / gx)));     // ~8192 workgroups in flight
     hipLaunchKernelGGL(k_rstdp_dense, dim3(gx, gy), dim3(256), 0, net->stream, a);
     HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+    return SNN_OK;
+}
+
+// the connections of a reward-modulated network that end in a modulated lattice (k_reward_cross), right after the lattices' own
+// edges; the counters of the visited lattices flip
+int launch_reward_cross(snn_network *net)
+{
+    if (!net->any_conn_kind || !net->any_modulation || net->nn == 0 || net->n_loc == 0 || !net->trace || !net->pending) return SNN_OK;
+    RewardCrossArgs a{};
+    a.W = net->W; a.C = net->trace; a.P = net->pending;
+    a.ld = net->ld; a.n_loc = net->n_loc; a.q0 = net->q0; a.n_neurons = net->nn; a.n_tot = net->n_tot;
+    a.n_lattices = (uint32_t)net->lattices.size();
+    a.last_firing_time = net->na.last_firing_time; a.st_last_firing_time = net->ca.last_firing_time;
+    a.lattice_slot = net->lattice_slot; a.st_lattice_slot = net->ca.lattice_slot;
+    a.rm = net->rm_dev; a.stdp = net->stdp_dev; a.rm_on = net->rm_on_dev; a.conn_kind = net->conn_kind_dev;
+    for (size_t l = 0; l < net->rm_cross_counter.size() && l < 64; ++l)
+        if (net->rm_cross_counter[l]) a.second |= 1ull << l;
+    const unsigned gx = (net->n_loc + 255) / 256;
+    const unsigned gy = std::max(1u, std::min<unsigned>((net->n_tot + 3) / 4, std::max(1u, 8192u / gx)));
+    hipLaunchKernelGGL(k_reward_cross, dim3(gx, gy), dim3(256), 0, net->stream, a);
+    HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+    for (size_t l = 0; l < net->rm_cross_counter.size(); ++l)
+        if (net->rm_on_host[l]) net->rm_cross_counter[l] ^= 1u;
     return SNN_OK;
 }
 
@@ -1024,6 +1049,7 @@ int step_end(snn_network *net)
     TRY(snapshots(2));
     TRY(launch_plasticity(net));
     TRY(launch_reward_modulation(net));
+    TRY(launch_reward_cross(net));
     TRY(snapshots(1));
     if ((net->want_avg || net->want_eeg) && record_now(net) && !net->lattices.empty()) {
         // after the exchange, so that a sharded handle reduces over every lattice's full population

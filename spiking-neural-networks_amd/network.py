@@ -398,6 +398,27 @@ class DeviceNetwork:
         self._check(self._L.snn_get_trace_rows(self._h, pre_begin, pre_count, t.ctypes.data_as(_lib.f32p)))
         return t
 
+    # ---- connections between lattices of a reward-modulated network (include/snn_amd.h, snn_set_connection_kind) ----
+    def set_connection_kind(self, pre_id, post_id, kind):
+        """0 a plain network's connection, 1 RewardModulatedConnection::RewardModulatedWeight, 2 RewardModulatedConnection::Weight"""
+        self._check(self._L.snn_set_connection_kind(self._h, pre_id, post_id, int(kind)))
+
+    def set_pending_rows(self, pre_begin, pending):
+        t = np.ascontiguousarray(pending, dtype=np.float32)
+        if t.ndim != 2 or t.shape[1] != self.n_neurons:
+            raise ValueError("pending must be [rows][n_neurons]")
+        self._check(self._L.snn_set_pending_rows(self._h, pre_begin, t.shape[0], t.ctypes.data_as(_lib.f32p)))
+
+    def get_pending_rows(self, pre_begin, pre_count):
+        t = np.zeros((pre_count, self.n_neurons), np.float32)
+        self._check(self._L.snn_get_pending_rows(self._h, pre_begin, pre_count, t.ctypes.data_as(_lib.f32p)))
+        return t
+
+    def connection_counter(self, post_id, value=None):
+        c = C.c_uint32(0 if value is None else int(value))
+        self._check(self._L.snn_connection_counter(self._h, post_id, int(value is not None), C.byref(c)))
+        return int(c.value)
+
     def set_traces_csr(self, traces):
         t = np.ascontiguousarray(traces, dtype=np.float32)
         self._check(self._L.snn_set_traces_csr(self._h, t.ctypes.data_as(_lib.f32p), t.size))

@@ -143,6 +143,35 @@ def reward_modulated_4x4():
     return net, 900
 
 
+def reward_modulated_network():
+    """RewardModulatedLatticeNetwork (neuron/mod.rs:3419-3453): a reward-modulated lattice (id 1) fed by a plain STDP lattice (id 0)
+    through RewardModulatedConnection::RewardModulatedWeight, by another plain lattice (id 2) through
+    RewardModulatedConnection::Weight and by Poisson cells through reward-modulated weights -- the incoming half of
+    update_weights_from_neurons_across_reward_lattices (:4859-4924): one modulator visit per connection and step (dw and the
+    counter live across steps), the presynaptic lattice's STDP on the plain weights; constant dopamine"""
+    lay = parity.Layout([(0, 3, 3), (1, 3, 4), (2, 2, 3)], [(5, 2, 3)])
+    net = parity.make_oracle(lay, st_kind=ob.ST_POISSON)
+    nn = net.n_neurons
+    net["current_voltage"] = ob.uniform_array(21, nn, -65.0, 30.0)
+    net["gap_conductance"] = 10.0
+    net.fill_graph(22, 0.5, 1.5)
+    net["st_chance_of_firing"] = 0.15
+    net["st_seed"] = np.arange(31, 37, dtype=np.uint32)
+    net["rm_do_modulation"][1] = 1
+    net["rm_dopamine"][1] = 0.015
+    net["rm_tau_c"][1] = 0.05
+    net["rm_a_plus"][1] = 0.01
+    net["rm_a_minus"][1] = 0.012
+    net["do_plasticity"][0] = net["do_plasticity"][2] = 1
+    net["stdp_a_plus"][0] = 0.8
+    net["stdp_a_minus"][2] = 0.5
+    net["conn_kind"][0, 1] = 1          # lattice 0 -> lattice 1: reward-modulated weights
+    net["conn_kind"][2, 1] = 2          # lattice 2 -> lattice 1: plain weights of the reward-modulated network
+    net["conn_kind"][3, 1] = 1          # the cells (source slot n_lattices + 0) -> lattice 1: reward-modulated weights
+    net["traces"][...] = ob.uniform_array(23, net["traces"].size, -0.01, 0.01).reshape(net["traces"].shape) * net["connections"]
+    return net, 701                     # (an odd count: the two-visit cycle of the traces ends half way)
+
+
 def generated_morris_lecar_3x3():
     """a generated model (SNN_MODEL_CUSTOM): the three-channel Morris-Lecar description of test_modelgen_channels.py in a
     3x3 lattice driven by two Poisson cells; the oracle steps it as a stack program, the device as generated HIP"""
@@ -165,14 +194,15 @@ def generated_morris_lecar_3x3():
 
 CASES = {f.__name__: f for f in (izh_4x4_ones, izh_4x4_random, izh_32x32_random, stdp_3_neurons, hh_pair, ampa_pair,
                                  spike_trains_poisson, spike_trains_rate, adaptive_exp_lif_3x3, leaky_izhikevich_3x3,
-                                 preset_exponential_decay_kinetics, reward_modulated_4x4, generated_morris_lecar_3x3)}
+                                 preset_exponential_decay_kinetics, reward_modulated_4x4, reward_modulated_network,
+                                 generated_morris_lecar_3x3)}
 
 EXTRA = {"hh_pair": ("m_state", "h_state", "n_state"), "stdp_3_neurons": ("weights",),
          "ampa_pair": ("nt_t", "rc_r", "rc_current"), "spike_trains_poisson": ("st_seed", "st_last_firing_time"),
          "spike_trains_rate": ("st_step", "st_last_firing_time"),
          "adaptive_exp_lif_3x3": ("w_value", "refractory_count"), "leaky_izhikevich_3x3": ("w_value",),
          "preset_exponential_decay_kinetics": ("nt_t", "rc_r", "st_step", "st_counter", "st_last_firing_time"),
-         "reward_modulated_4x4": ("weights", "traces"), "generated_morris_lecar_3x3": ("custom_vars", "weights")}
+         "reward_modulated_4x4": ("weights", "traces"), "reward_modulated_network": ("weights", "traces", "pending", "rm_cross_counter"), "generated_morris_lecar_3x3": ("custom_vars", "weights")}
 
 
 def outputs(name, net, steps):

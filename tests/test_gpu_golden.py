@@ -24,13 +24,15 @@ def test_hip_matches_golden(snn, name):
             dn.set_reward_modulator(i, *(float(net[k][slot]) for k in (
                 "rm_dopamine", "rm_tau_d", "rm_tau_c", "rm_a_plus", "rm_a_minus", "rm_tau_plus", "rm_tau_minus", "rm_dt")))
             dn.set_trace_rows(0, net["traces"])
+    parity.push_connection_kinds(dn, net)
     dn.set_history(voltage=True, spikes=True)
     dn.run(steps)
-    lat = net.layout.lattices[0][0]
-    raster = dn.spike_history(lat)
+    ids = [i for i, _, _ in net.layout.lattices]          # the fixtures hold all lattices side by side, in layout order
+    raster = np.concatenate([dn.spike_history(i) for i in ids], axis=1)
     assert np.packbits(raster, axis=1).tobytes() == want["raster"].tobytes()
     stride = int(want["trace_stride"])
-    assert dn.voltage_history(lat)[::stride].tobytes() == want["voltage_trace"].tobytes()
+    trace = np.concatenate([dn.voltage_history(i) for i in ids], axis=1)
+    assert np.ascontiguousarray(trace[::stride]).tobytes() == want["voltage_trace"].tobytes()
     st = parity.pull_state(dn, net)
     assert st["current_voltage"].tobytes() == want["final_voltage"].tobytes()
     assert st["last_firing_time"].tobytes() == want["last_firing_time"].tobytes()
@@ -43,6 +45,11 @@ def test_hip_matches_golden(snn, name):
             assert w.tobytes() == np.where(net["connections"] != 0, want[k], np.float32(0)).astype(np.float32).tobytes()
         elif k == "traces":
             assert dn.get_trace_rows(0, net.n_tot).tobytes() == want[k].tobytes()
+        elif k == "pending":
+            assert dn.get_pending_rows(0, net.n_tot).tobytes() == want[k].tobytes()
+        elif k == "rm_cross_counter":
+            got = np.array([dn.connection_counter(i) for i, _, _ in net.layout.lattices], np.uint32)
+            assert got.tobytes() == want[k].tobytes()
         else:
             assert st[k].tobytes() == want[k].tobytes(), k
     dn.close()
