@@ -24,11 +24,11 @@ MIN_TIMED_S, MAX_REPEATS = 1.0, 4000    # the timed repetitions add up to at lea
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling is ~6.3 TB/s
 # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of THIS command (FETCH_SIZE and
 # WRITE_SIZE cannot share a pass); their summaries are committed under profiles/ and quoted here per launch.
-PMC_TRAFFIC = {"c2": os.path.join(ROOT, "profiles", "r03", "c2_pmc_traffic.json"),
-               "c3": os.path.join(ROOT, "profiles", "r03", "c3_pmc_traffic.json"),
-               "c4": os.path.join(ROOT, "profiles", "r03", "c4_pmc_traffic.json"),
-               "c5": os.path.join(ROOT, "profiles", "r03", "c5_pmc_traffic.json"),
-               "c6": os.path.join(ROOT, "profiles", "r03", "c6_pmc_traffic.json")}
+PMC_TRAFFIC = {"c2": os.path.join(ROOT, "profiles", "r04", "c2_pmc_traffic.json"),
+               "c3": os.path.join(ROOT, "profiles", "r04", "c3_pmc_traffic.json"),
+               "c4": os.path.join(ROOT, "profiles", "r04", "c4_pmc_traffic.json"),
+               "c5": os.path.join(ROOT, "profiles", "r04", "c5_pmc_traffic.json"),
+               "c6": os.path.join(ROOT, "profiles", "r04", "c6_pmc_traffic.json")}
 
 
 def pmc_traffic(config, world, rows, cols):

@@ -410,23 +410,32 @@ int snn_run_with_reward(snn_network_t *net, float reward);
 int snn_set_trace_rows(snn_network_t *net, uint32_t pre_begin, uint32_t pre_count, const float *traces);
 int snn_get_trace_rows(snn_network_t *net, uint32_t pre_begin, uint32_t pre_count, float *traces);
 /* ---- connections BETWEEN lattices in a reward-modulated network (RewardModulatedLatticeNetwork, neuron/mod.rs:3419-3453) ----
- * The reference's connecting graph holds RewardModulatedConnection::{Weight, RewardModulatedWeight}; what happens to such a
- * connection when it ENDS in a reward-modulated lattice is the incoming half of
- * update_weights_from_neurons_across_reward_lattices (neuron/mod.rs:4859-4924), once per step for every neuron of the lattice:
- *   kind 2 (Weight): the STDP rule of the PRESYNAPTIC lattice adds its delta -- plain neuron lattices only, spike or no spike;
- *   kind 1 (RewardModulatedWeight): ONE visit of the postsynaptic lattice's modulator (plasticity/mod.rs:203-237): the delta
- *     goes into TraceRSTDP::dw, every second visit folds dw into the trace c, the weight gains c * dopamine.
+ * The reference's connecting graph holds RewardModulatedConnection::{Weight, RewardModulatedWeight}.  After the neurons of a step
+ * have been updated (post_neuron_update_step, :5030-5043) it visits the spiking neurons of plain lattices with do_plasticity
+ * (update_weights_from_neurons_across_lattices, :4707-4802), then EVERY neuron of the reward-modulated lattices
+ * (update_weights_from_neurons_across_reward_lattices, :4855-4977).  A visit of z handles, per partner o in another lattice:
+ *   incoming o -> z, kind 2 (Weight):  z plain: the STDP rule of z's lattice adds its delta; z modulated: the rule of o's lattice
+ *     -- the PRESYNAPTIC one -- when o sits in a plain lattice, nothing otherwise;
+ *   incoming o -> z, kind 1 (RewardModulatedWeight):  ONE visit of the modulator of z's lattice (z modulated) or of o's lattice
+ *     (z plain) (plasticity/mod.rs:203-237): the delta goes into TraceRSTDP::dw, every second visit folds dw into the trace c and
+ *     clears it, the weight gains c * dopamine;
+ *   outgoing z -> o:  the reference looks up the REVERSE connection o -> z (:4768-4771, :4929-4932), applies the rule once more
+ *     to that copy with (pre = z, post = o) and stores it as z -> o: weight, trace, dw and counter of z -> o are replaced.
+ * Lattices are visited in the order they were added (the reference walks a HashMap; its order between lattices is unspecified).
  * snn_set_connection_kind(pre_id, post_id, kind) tags every connection from lattice (or spike-train lattice) pre_id into
- * neuron lattice post_id (kind 0, the default: the plain LatticeNetwork's rule of snn_set_plasticity).  dw is the `pending`
- * matrix (rows as snn_set_trace_rows), the counter of the two-visit cycle one bit per postsynaptic lattice
- * (snn_connection_counter: set != 0 writes *counter, else reads it).  Dense, unsharded handles.  NOT restated: the outgoing
- * half of the same function (:4926-4974) -- it looks up the REVERSE edge and unwraps it, i.e. it is defined only where that
- * edge exists and then overwrites the forward connection with it; and such connections into PLAIN lattices
- * (update_weights_from_neurons_across_lattices, :4707-4802). */
+ * neuron lattice post_id (kind 0, the default: the plain LatticeNetwork's rule of snn_set_plasticity, forward lookups only).
+ * dw is the `pending` matrix and the counter of the two-visit cycle the `counter` matrix, both per connection (rows as
+ * snn_set_trace_rows; counters 0 / 1, one byte each).  Dense, unsharded handles.
+ * Outside the domain where the reference's visits are defined (it unwraps None there) the next run call returns
+ * SNN_ERR_BAD_STATE and snn_last_error names the case: a connection of a visited lattice (modulated, or plain with
+ * do_plasticity) without a reverse connection of the same kind; kind 1 where no side has a modulator while one side is plastic,
+ * or from a spike train into a plastic plain lattice; kind 2 between a plastic plain lattice and a reward-modulated one; a BCM
+ * lattice on such a connection. */
 int snn_set_connection_kind(snn_network_t *net, uint32_t pre_id, uint32_t post_id, int kind);
 int snn_set_pending_rows(snn_network_t *net, uint32_t pre_begin, uint32_t pre_count, const float *pending);
 int snn_get_pending_rows(snn_network_t *net, uint32_t pre_begin, uint32_t pre_count, float *pending);
-int snn_connection_counter(snn_network_t *net, uint32_t post_id, int set, uint32_t *counter);
+int snn_set_counter_rows(snn_network_t *net, uint32_t pre_begin, uint32_t pre_count, const uint8_t *counters);
+int snn_get_counter_rows(snn_network_t *net, uint32_t pre_begin, uint32_t pre_count, uint8_t *counters);
 int snn_set_traces_csr(snn_network_t *net, const float *traces, uint64_t nnz);
 int snn_get_traces_csr(snn_network_t *net, float *traces, uint64_t nnz);
 

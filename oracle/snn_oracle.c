@@ -1178,62 +1178,143 @@ void snn_o_reward_modulation_cols(snn_o_net *n, uint32_t c0, uint32_t c1)
     }
 }
 
-/* RewardModulatedLatticeNetwork::update_weights_from_neurons_across_reward_lattices, the INCOMING half (neuron/mod.rs:4859-4924):
- * every neuron q of a reward-modulated lattice l (do_update is always true, plasticity/mod.rs:239-241: every neuron, every step)
- * visits each connection p -> q that comes from ANOTHER lattice or from a spike-train lattice:
- *   RewardModulatedConnection::Weight (kind 2), p in a plain lattice lp (:4869-4883):
- *       lp's STDP rule -- the PRESYNAPTIC lattice's -- adds its delta, spike or no spike; other sources: untouched;
- *   RewardModulatedConnection::RewardModulatedWeight (kind 1), any source (:4885-4921):
- *       l's reward modulator -- the POSTSYNAPTIC lattice's -- visits the weight ONCE (RewardModulatedSTDP::update_weight,
- *       plasticity/mod.rs:203-237): dw += delta; the first of two visits only sets the counter, the second folds dw into the
- *       trace and clears both; then weight += c * dopamine.  One visit per step, so dw and the counter live across steps.
- * The OUTGOING half of the same function (:4926-4974) looks up the REVERSE edge and unwraps it: defined only where that edge
- * exists, and then it overwrites the forward edge with the updated reverse one -- not restated.
- * Such connections are left alone by the plain network's rule (snn_o_plasticity_cols). */
+/* RewardModulatedLatticeNetwork: the connections BETWEEN lattices that carry a RewardModulatedConnection (conn_kind 1 =
+ * RewardModulatedWeight, 2 = Weight).  post_neuron_update_step (neuron/mod.rs:5030-5043) visits, in this order,
+ *   1. every SPIKING neuron of a plain lattice with do_plasticity: update_weights_from_neurons_across_lattices (:4707-4802),
+ *   2. EVERY neuron of a reward-modulated lattice (RewardModulatedSTDP::do_update is always true, plasticity/mod.rs:239-241):
+ *      update_weights_from_neurons_across_reward_lattices (:4855-4977),
+ * lattices in layout order here (the reference walks a HashMap: its order between lattices is unspecified), neurons by index.
+ * A visit of neuron x handles first the connections p -> x (incoming half), then the connections x -> o (outgoing half).
+ *
+ * incoming p -> x:
+ *   Weight, x plain (:4721-4741):      x's lattice's STDP adds its delta for (p, x);
+ *   Weight, x modulated (:4869-4883):  p's lattice's STDP -- the PRESYNAPTIC lattice's -- when p sits in a plain lattice, else nothing;
+ *   RewardModulatedWeight, x plain (:4742-4756):      the modulator of p's lattice visits the TraceRSTDP once;
+ *   RewardModulatedWeight, x modulated (:4885-4921):  the modulator of x's lattice visits it once (p: any lattice or spike train).
+ * outgoing x -> o: the reference looks up the REVERSE connection o -> x (`lookup_weight(&output_pos, pos)`, :4768-4771 and
+ * :4929-4932), unwraps it, updates that COPY with (pre = x, post = o) and stores it as the connection x -> o:
+ *   Weight, x plain (:4774-4787):      copy.weight + delta of x's lattice's STDP;
+ *   Weight, x modulated (:4935-4950):  copy.weight + delta of o's lattice's STDP when o sits in a plain lattice, else untouched;
+ *   RewardModulatedWeight, x plain (:4788-4801):      one visit by the modulator of o's lattice on the copy;
+ *   RewardModulatedWeight, x modulated (:4952-4972):  one visit by the modulator of x's lattice on the copy;
+ *   weight, trace, dw and counter of x -> o are all REPLACED by the copy's.
+ * One visit (RewardModulatedSTDP::update_weight, plasticity/mod.rs:203-237): dw += delta; counter 0: counter = 1; counter 1: the
+ * trace folds dw in, dw = 0, counter = 0; then weight += c * dopamine.  dw (`pending`) and the counter (`edge_counter`) are per
+ * connection and live across steps.
+ * The reference panics (unwrap of None) outside this domain; snn_o_reward_cross_check names the case and the stepper refuses it:
+ *   1 a connection u -> v of a visited lattice without its reverse v -> u, or with a reverse of another kind (:4768-4771, :4929-4932);
+ *   2 RewardModulatedWeight where the visit has no modulator: both lattices plain and one of them plastic (:4743, :4789),
+ *     or from a spike train into a plastic plain lattice (:4743);
+ *   3 Weight between a plastic plain lattice and a reward-modulated one (:4729-4733 takes the source for a spike train, :4778
+ *     looks the target up among the plain lattices);
+ *   4 a plain lattice with the BCM rule on such a connection (the reference's network is generic over ONE plasticity rule).
+ * Connections of kind 0 are left to the plain network's rule (snn_o_plasticity_cols), which skips kinds 1 and 2. */
+static inline int cross_visited(const snn_o_net *n, uint32_t l)
+{
+    return n->rm_do_modulation[l] || (n->do_plasticity && n->do_plasticity[l]);
+}
+
+int snn_o_reward_cross_check(const snn_o_net *n)
+{
+    const uint32_t nn = n->n_neurons, n_tot = nn + n->n_cells, nl = n->n_lattices;
+    if (!n->conn_kind || !n->rm_do_modulation) return 0;
+    for (uint32_t p = 0; p < n_tot; ++p)
+        for (uint32_t q = 0; q < nn; ++q) {
+            if (!n->connections[(size_t)p * nn + q]) continue;
+            const uint32_t lq = n->lattice[q], kind = conn_kind_of(n, p, lq);
+            if (kind == 0) continue;
+            const int mod_q = n->rm_do_modulation[lq] != 0, plastic_q = !mod_q && cross_visited(n, lq);
+            if (plastic_q && n->plasticity_kind && n->plasticity_kind[lq]) return 4;
+            if (p >= nn) {                                           /* spike train -> q: incoming half of q only */
+                if (kind == 1 && plastic_q) return 2;
+                continue;
+            }
+            const uint32_t lp = n->lattice[p];
+            if (lp == lq) continue;
+            const int mod_p = n->rm_do_modulation[lp] != 0, plastic_p = !mod_p && cross_visited(n, lp);
+            if (plastic_p && n->plasticity_kind && n->plasticity_kind[lp]) return 4;
+            if (kind == 1 && !mod_p && !mod_q && (plastic_p || plastic_q)) return 2;
+            if (kind == 2 && ((plastic_p && mod_q) || (plastic_q && mod_p))) return 3;
+            if (cross_visited(n, lp)) {                              /* p's outgoing half needs q -> p */
+                if (!n->connections[(size_t)q * nn + p] || n->conn_kind[(size_t)lq * nl + lp] != kind) return 1;
+            }
+        }
+    return 0;
+}
+
+/* one RewardModulatedSTDP::update_weight with the modulator of lattice m */
+static void cross_trace_visit(const snn_o_net *n, uint32_t m, int32_t t_pre, int32_t t_post, float *w, float *c, float *dw, uint8_t *counter)
+{
+    const float dt = n->rm_dt[m], tau_c = n->rm_tau_c[m];
+    *dw += snn_o_stdp_delta(t_pre, t_post, n->rm_a_plus[m], n->rm_a_minus[m], n->rm_tau_plus[m], n->rm_tau_minus[m], dt);
+    if (*counter == 0) {
+        *counter = 1;
+    } else {
+        *c = *c * snn_o_expf(-dt / tau_c) + tau_c * *dw;
+        *counter = 0;
+        *dw = 0.0f;
+    }
+    *w += *c * n->rm_dopamine[m];
+}
+
+static inline float cross_stdp(const snn_o_net *n, uint32_t l, int32_t t_pre, int32_t t_post)
+{
+    return snn_o_stdp_delta(t_pre, t_post, n->stdp_a_plus[l], n->stdp_a_minus[l], n->stdp_tau_plus[l], n->stdp_tau_minus[l], n->stdp_dt[l]);
+}
+
+static void cross_visit(snn_o_net *n, uint32_t x)
+{
+    const uint32_t nn = n->n_neurons, n_tot = nn + n->n_cells, lx = n->lattice[x];
+    const int mod_x = n->rm_do_modulation[lx] != 0;
+    const int32_t tx = n->last_firing_time[x];
+    for (uint32_t p = 0; p < n_tot; ++p) {                           /* incoming half */
+        const size_t i = (size_t)p * nn + x;
+        if (!n->connections[i]) continue;
+        const uint32_t kind = conn_kind_of(n, p, lx);
+        if (kind == 0 || (p < nn && n->lattice[p] == lx)) continue;
+        const int32_t tp = (p < nn) ? n->last_firing_time[p] : n->st_last_firing_time[p - nn];
+        if (kind == 2) {
+            if (!mod_x) n->weights[i] += cross_stdp(n, lx, tp, tx);
+            else if (p < nn && !n->rm_do_modulation[n->lattice[p]]) n->weights[i] += cross_stdp(n, n->lattice[p], tp, tx);
+        } else {
+            const uint32_t m = mod_x ? lx : n->lattice[p];
+            cross_trace_visit(n, m, tp, tx, &n->weights[i], &n->traces[i], &n->pending[i], &n->edge_counter[i]);
+        }
+    }
+    for (uint32_t o = 0; o < nn; ++o) {                              /* outgoing half */
+        const size_t f = (size_t)x * nn + o, r = (size_t)o * nn + x;
+        const uint32_t lo = n->lattice[o];
+        if (!n->connections[f] || lo == lx) continue;
+        const uint32_t kind = conn_kind_of(n, x, lo);
+        if (kind == 0 || !n->connections[r]) continue;               /* (no reverse: outside the domain, see the check) */
+        const int32_t to = n->last_firing_time[o];
+        if (kind == 2) {
+            if (!mod_x) n->weights[f] = n->weights[r] + cross_stdp(n, lx, tx, to);
+            else if (!n->rm_do_modulation[lo]) n->weights[f] = n->weights[r] + cross_stdp(n, lo, tx, to);
+        } else {
+            float w = n->weights[r], c = n->traces[r], dw = n->pending[r];
+            uint8_t counter = n->edge_counter[r];
+            cross_trace_visit(n, mod_x ? lx : lo, tx, to, &w, &c, &dw, &counter);
+            n->weights[f] = w; n->traces[f] = c; n->pending[f] = dw; n->edge_counter[f] = counter;
+        }
+    }
+}
+
 void snn_o_reward_cross(snn_o_net *n)
 {
-    const uint32_t nn = n->n_neurons, n_tot = nn + n->n_cells;
+    const uint32_t nn = n->n_neurons;
     if (!n->conn_kind || !n->rm_do_modulation) return;
     {
-        uint32_t any = 0;       /* no connection of these kinds: a plain network, nothing is visited and no counter moves */
+        uint32_t any = 0;       /* no connection of these kinds: a plain network, nothing is visited */
         for (size_t i = 0; i < (size_t)(n->n_lattices + n->n_st_lattices) * n->n_lattices; ++i) any |= n->conn_kind[i];
         if (!any) return;
     }
-    for (uint32_t q = 0; q < nn; ++q) {
-        const uint32_t l = n->lattice[q];
-        if (!n->rm_do_modulation[l]) continue;
-        const float dopamine = n->rm_dopamine[l], dt = n->rm_dt[l], tau_c = n->rm_tau_c[l];
-        const float decay = snn_o_expf(-dt / tau_c);
-        const uint32_t second = n->rm_cross_counter ? n->rm_cross_counter[l] : 0u;
-        for (uint32_t p = 0; p < n_tot; ++p) {
-            size_t i = (size_t)p * nn + q;
-            if (!n->connections[i]) continue;
-            const uint32_t kind = conn_kind_of(n, p, l);
-            if (kind == 0 || (p < nn && n->lattice[p] == l)) continue;
-            const int32_t tp = (p < nn) ? n->last_firing_time[p] : n->st_last_firing_time[p - nn];
-            if (kind == 2) {
-                if (p >= nn || n->rm_do_modulation[n->lattice[p]]) continue;
-                const uint32_t lp = n->lattice[p];
-                n->weights[i] += snn_o_stdp_delta(tp, n->last_firing_time[q], n->stdp_a_plus[lp], n->stdp_a_minus[lp],
-                                                  n->stdp_tau_plus[lp], n->stdp_tau_minus[lp], n->stdp_dt[lp]);
-                continue;
-            }
-            float delta_w = snn_o_stdp_delta(tp, n->last_firing_time[q], n->rm_a_plus[l], n->rm_a_minus[l], n->rm_tau_plus[l],
-                                             n->rm_tau_minus[l], dt);
-            float dw = n->pending[i], c = n->traces[i];
-            dw += delta_w;
-            if (second) {
-                c = c * decay + tau_c * dw;
-                dw = 0.0f;
-            }
-            n->weights[i] += c * dopamine;
-            n->pending[i] = dw;
-            n->traces[i] = c;
-        }
+    for (uint32_t x = 0; x < nn; ++x) {
+        const uint32_t l = n->lattice[x];
+        if (!n->rm_do_modulation[l] && n->do_plasticity && n->do_plasticity[l] && n->is_spiking[x]) cross_visit(n, x);
     }
-    if (n->rm_cross_counter)
-        for (uint32_t l = 0; l < n->n_lattices; ++l)
-            if (n->rm_do_modulation[l]) n->rm_cross_counter[l] ^= 1u;
+    for (uint32_t x = 0; x < nn; ++x)
+        if (n->rm_do_modulation[n->lattice[x]]) cross_visit(n, x);
 }
 
 /* ---------- step 6: spike trains ---------- */

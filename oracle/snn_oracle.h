@@ -235,16 +235,15 @@ typedef struct snn_o_net {
      * the states' r and kinetics variables); rc_r / rc_kind are not used by such a set */
     uint32_t rx_multi;
     uint32_t rx_kin_section[3];
-    /* RewardModulatedLatticeNetwork: connections BETWEEN lattices that end in a reward-modulated lattice (the incoming half of
-     * update_weights_from_neurons_across_reward_lattices, neuron/mod.rs:4859-4924; see snn_o_reward_cross).
+    /* RewardModulatedLatticeNetwork: connections BETWEEN lattices that carry a RewardModulatedConnection
+     * (update_weights_from_neurons_across_lattices / _across_reward_lattices, neuron/mod.rs:4707-4977; see snn_o_reward_cross).
      * conn_kind[source * n_lattices + post lattice], source = the lattice slot of a presynaptic neuron or n_lattices + the
      * spike-train lattice slot of a cell: 0 = an edge of a plain LatticeNetwork (the default), 1 =
-     * RewardModulatedConnection::RewardModulatedWeight, 2 = RewardModulatedConnection::Weight.  `pending` = TraceRSTDP::dw per
-     * edge in the layout of `weights`; rm_cross_counter = TraceRSTDP::counter, one per post lattice (every such edge of a
-     * lattice is visited once per step, so they all carry the same counter).  NULL: no such connection. */
+     * RewardModulatedConnection::RewardModulatedWeight, 2 = RewardModulatedConnection::Weight.  `pending` = TraceRSTDP::dw and
+     * `edge_counter` = TraceRSTDP::counter per edge, both in the layout of `weights`.  NULL: no such connection. */
     uint8_t  *conn_kind;
     float    *pending;
-    uint32_t *rm_cross_counter;
+    uint8_t  *edge_counter;
 } snn_o_net;
 
 /* Step 1 of SURVEY §8(g): electrical + chemical inputs for every neuron from state S(t). */
@@ -259,6 +258,8 @@ void snn_o_plasticity(snn_o_net *net);
 void snn_o_apply_reward(snn_o_net *n, float reward);
 void snn_o_reward_modulation(snn_o_net *n);
 void snn_o_reward_cross(snn_o_net *n);
+/* 0 = every connection of kind 1 / 2 lies where the reference defines it; 1..4: see snn_o_reward_cross */
+int snn_o_reward_cross_check(const snn_o_net *n);
 void snn_o_reward_modulation_cols(snn_o_net *n, uint32_t c0, uint32_t c1);
 void snn_o_plasticity_cols(snn_o_net *net, uint32_t c0, uint32_t c1);
 /* Step 6: iterate every spike-train cell once. */

@@ -157,7 +157,8 @@ SIGNATURES = {
     "snn_set_connection_kind": (C.c_int, [H, C.c_uint32, C.c_uint32, C.c_int]),
     "snn_set_pending_rows": (C.c_int, [H, C.c_uint32, C.c_uint32, f32p]),
     "snn_get_pending_rows": (C.c_int, [H, C.c_uint32, C.c_uint32, f32p]),
-    "snn_connection_counter": (C.c_int, [H, C.c_uint32, C.c_int, u32p]),
+    "snn_set_counter_rows": (C.c_int, [H, C.c_uint32, C.c_uint32, u8p]),
+    "snn_get_counter_rows": (C.c_int, [H, C.c_uint32, C.c_uint32, u8p]),
     "snn_p2p_local": (C.c_int, [H, u64p, u64p, u64p, u64p, u64p]),
     "snn_p2p_connect": (C.c_int, [H, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64]),
     "snn_p2p_commit": (C.c_int, [H]),

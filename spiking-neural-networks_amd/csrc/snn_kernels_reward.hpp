@@ -2,6 +2,7 @@
 // the synaptic-input pass.
 #pragma once
 #include "snn_kernels_inputs.hpp"
+#include "snn_kernels_misc.hpp"
 
 namespace snn {
 
@@ -88,75 +89,151 @@ __global__ __launch_bounds__(256) void k_rstdp_dense(const RewardArgs a)
     }
 }
 
-// RewardModulatedLatticeNetwork::update_weights_from_neurons_across_reward_lattices, the incoming half (neuron/mod.rs:4859-4924):
-// every neuron q of a modulated lattice visits, once per step, its connections from OTHER lattices and from spike-train cells --
-//   kind 2 (RewardModulatedConnection::Weight), source in a plain neuron lattice lp: w += lp's STDP delta (:4869-4883);
-//   kind 1 (RewardModulatedConnection::RewardModulatedWeight): one visit of q's lattice's modulator (plasticity/mod.rs:203-237):
-//       dw += delta; every second visit  c = c * exp(-dt / tau_c) + tau_c * dw, dw = 0;  w += c * dopamine.
-// One visit per step: TraceRSTDP::dw lives across steps (`pending`, the layout of W), and the counter is the same for every such
-// connection of a lattice (bit l of `second`).  Thread = one column, 4 rows per unit, as k_rstdp_dense.
+// The connections BETWEEN lattices of a RewardModulatedLatticeNetwork (snn_set_connection_kind: 1 = RewardModulatedConnection::
+// RewardModulatedWeight, 2 = ::Weight).  post_neuron_update_step (neuron/mod.rs:5030-5043) visits the spiking neurons of plastic
+// plain lattices (update_weights_from_neurons_across_lattices, :4707-4802), then every neuron of the reward-modulated lattices
+// (_across_reward_lattices, :4855-4977).  A visit of z handles, for each partner o in another lattice,
+//   incoming o -> z:  Weight: z plain: z's lattice's STDP delta; z modulated: o's lattice's STDP delta when o sits in a plain
+//                     lattice;  RewardModulatedWeight: one visit of the modulator of z's lattice (z modulated) or o's (z plain);
+//   outgoing z -> o:  the reference looks up the REVERSE connection o -> z (:4768-4771, :4929-4932), applies the rule once more
+//                     to that copy with (pre = z, post = o) and stores it as z -> o (weight, trace, dw and counter).
+// The two connections of a PAIR of neurons are touched by the visits of those two neurons only, so a thread owns one pair (x < y)
+// and replays its visits in the reference's order: plain visits first, then modulated ones, each by neuron index.  Cells are
+// never visited and have no incoming connections: a pair (x, cell) is the incoming half of x alone.
+// One modulator visit (plasticity/mod.rs:203-237): dw += delta; counter 0 -> 1; counter 1: c = c * exp(-dt / tau_c) + tau_c * dw,
+// dw = 0, counter = 0; then w += c * dopamine.  dw (`P`) and the counter (`K`, 0.0 / 1.0) are per connection, in the layout of W.
 struct RewardCrossArgs {
-    float *W, *C, *P;                      // weights, TraceRSTDP::c, TraceRSTDP::dw
-    uint32_t ld, n_loc, q0, n_neurons, n_tot, n_lattices;
-    const int32_t *last_firing_time, *st_last_firing_time;
-    const uint32_t *lattice_slot, *st_lattice_slot;
-    const float *rm, *stdp;
+    StdpArgs s;                            // W, ld, sizes, firing times, lattice slots, STDP table, do_plasticity, spike plane, kinds
+    float *C, *P, *K;                      // TraceRSTDP::c, ::dw, ::counter
+    const float *rm;
     const uint32_t *rm_on;
-    const uint8_t *conn_kind;
-    unsigned long long second;             // bit l: this is the second of a pair of visits for lattice l
+    uint32_t *bad;                         // k_reward_cross_check: the highest refusal class found
 };
+
+struct CrossEdge {
+    float w, c, dw, k;
+    bool exists;
+    uint32_t kind;
+};
+
+__device__ __forceinline__ size_t cross_at(const StdpArgs &s, uint32_t pre, uint32_t post)
+{
+    return ((size_t)(pre >> 2) * s.ld + post) * 4u + (pre & 3u);
+}
+__device__ __forceinline__ uint32_t cross_kind(const StdpArgs &s, uint32_t pre, uint32_t post_slot)
+{
+    const uint32_t source = pre < s.n_neurons ? s.lattice_slot[pre] : s.n_lattices + s.st_lattice_slot[pre - s.n_neurons];
+    return s.conn_kind[(size_t)source * s.n_lattices + post_slot];
+}
+__device__ __forceinline__ void cross_trace_visit(CrossEdge &e, const float *m, int t_pre, int t_post)
+{
+    e.dw += stdp_delta(t_pre, t_post, m[3], m[4], m[5], m[6], m[7]);
+    if (e.k == 0.0f) {
+        e.k = 1.0f;
+    } else {
+        e.c = e.c * m[8] + m[2] * e.dw;
+        e.k = 0.0f;
+        e.dw = 0.0f;
+    }
+    e.w = e.w + e.c * m[RM_DOPAMINE];
+}
+
+// one visit of z (lattice lz) with partner o: `in` = o -> z, `out` = z -> o
+__device__ __forceinline__ void cross_visit(const RewardCrossArgs &a, CrossEdge &in, CrossEdge &out, uint32_t lz, uint32_t lo,
+                                            bool o_is_neuron, int tz, int to)
+{
+    const bool mod_z = a.rm_on[lz] != 0u, mod_o = o_is_neuron && a.rm_on[lo] != 0u;
+    const float *plain = a.s.stdp + PL_STRIDE * (mod_z ? lo : lz);
+    const float *m = a.rm + (size_t)(mod_z ? lz : lo) * RM_STRIDE;
+    if (in.exists && in.kind == 2u && (!mod_z || (o_is_neuron && !mod_o)))
+        in.w = in.w + stdp_delta(to, tz, plain[0], plain[1], plain[2], plain[3], plain[4]);
+    if (in.exists && in.kind == 1u) cross_trace_visit(in, m, to, tz);
+    if (!(out.exists && in.exists && o_is_neuron)) return;
+    if (out.kind == 2u && (!mod_z || !mod_o)) out.w = in.w + stdp_delta(tz, to, plain[0], plain[1], plain[2], plain[3], plain[4]);
+    if (out.kind == 1u) {
+        CrossEdge copy = in;
+        cross_trace_visit(copy, m, tz, to);
+        out.w = copy.w; out.c = copy.c; out.dw = copy.dw; out.k = copy.k;
+    }
+}
 
 __global__ __launch_bounds__(256) void k_reward_cross(const RewardCrossArgs a)
 {
-    const uint32_t c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= a.n_loc) return;
-    const uint32_t q = a.q0 + c;
-    const uint32_t sq = a.lattice_slot[q];
-    if (!a.rm_on[sq]) return;
-    const int32_t tq = a.last_firing_time[q];
-    const float *m = a.rm + (size_t)sq * RM_STRIDE;
-    const bool second = (a.second >> sq & 1ull) != 0ull;
-    const uint32_t groups = (a.n_tot + 3u) >> 2;
-    for (uint32_t g = blockIdx.y; g < groups; g += gridDim.y) {
-        uint32_t kind[4];
-        bool any = false;
-#pragma unroll
-        for (uint32_t k = 0; k < 4; ++k) {
-            const uint32_t p = g * 4 + k;
-            kind[k] = 0;
-            if (p < a.n_tot) {
-                const uint32_t source = p < a.n_neurons ? a.lattice_slot[p] : a.n_lattices + a.st_lattice_slot[p - a.n_neurons];
-                if (!(p < a.n_neurons && source == sq)) kind[k] = a.conn_kind[(size_t)source * a.n_lattices + sq];
-            }
-            any = any || kind[k] != 0;
+    const StdpArgs &s = a.s;
+    const uint32_t x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= s.n_neurons) return;
+    const uint32_t lx = s.lattice_slot[x];
+    const int tx = s.last_firing_time[x];
+    const bool x_mod = a.rm_on[lx] != 0u;
+    const bool x_plain = !x_mod && s.do_plasticity[lx] && reinterpret_cast<const uint32_t *>(s.xbuf)[s.xl.at(x, PLANE_SPIKE)] != 0u;
+    for (uint32_t y = blockIdx.y; y < s.n_tot; y += gridDim.y) {
+        if (y <= x) continue;
+        const bool y_neuron = y < s.n_neurons;
+        const uint32_t ly = y_neuron ? s.lattice_slot[y] : 0u;
+        if (y_neuron && ly == lx) continue;
+        CrossEdge yx{}, xy{};
+        const size_t i_yx = cross_at(s, y, x), i_xy = y_neuron ? cross_at(s, x, y) : 0;
+        yx.kind = cross_kind(s, y, lx);
+        yx.w = s.W[i_yx];
+        yx.exists = yx.kind != 0u && yx.w == yx.w;                     // (NaN = no such connection)
+        if (y_neuron) {
+            xy.kind = cross_kind(s, x, ly);
+            xy.w = s.W[i_xy];
+            xy.exists = xy.kind != 0u && xy.w == xy.w;
         }
-        if (!any) continue;
-        v4f *wp = reinterpret_cast<v4f *>(a.W) + (size_t)g * a.ld + c;
-        v4f *cp = reinterpret_cast<v4f *>(a.C) + (size_t)g * a.ld + c;
-        v4f *pp = reinterpret_cast<v4f *>(a.P) + (size_t)g * a.ld + c;
-        v4f w = *wp, tr = *cp, pd = *pp;
-#pragma unroll
-        for (uint32_t k = 0; k < 4; ++k) {
-            const uint32_t p = g * 4 + k;
-            if (kind[k] == 0 || w[k] != w[k]) continue;                      // a plain network's edge / absent edge (NaN)
-            const int32_t tp = p < a.n_neurons ? a.last_firing_time[p] : a.st_last_firing_time[p - a.n_neurons];
-            if (kind[k] == 2) {
-                if (p >= a.n_neurons || a.rm_on[a.lattice_slot[p]]) continue;
-                const float *prm = a.stdp + PL_STRIDE * a.lattice_slot[p];
-                w[k] = w[k] + stdp_delta(tp, tq, prm[0], prm[1], prm[2], prm[3], prm[4]);
-                continue;
-            }
-            float dw = pd[k], ck = tr[k];
-            dw += stdp_delta(tp, tq, m[3], m[4], m[5], m[6], m[7]);
-            if (second) {
-                ck = ck * m[8] + m[2] * dw;
-                dw = 0.0f;
-            }
-            w[k] = w[k] + ck * m[RM_DOPAMINE];
-            pd[k] = dw; tr[k] = ck;
-        }
-        *wp = w; *cp = tr; *pp = pd;
+        if (!yx.exists && !xy.exists) continue;
+        const bool y_mod = y_neuron && a.rm_on[ly] != 0u;
+        const bool y_plain = y_neuron && !y_mod && s.do_plasticity[ly] &&
+                             reinterpret_cast<const uint32_t *>(s.xbuf)[s.xl.at(y, PLANE_SPIKE)] != 0u;
+        if (!(x_mod || x_plain || y_mod || y_plain)) continue;
+        if (yx.exists) { yx.c = a.C[i_yx]; yx.dw = a.P[i_yx]; yx.k = a.K[i_yx]; }
+        if (xy.exists) { xy.c = a.C[i_xy]; xy.dw = a.P[i_xy]; xy.k = a.K[i_xy]; }
+        const int ty = y_neuron ? s.last_firing_time[y] : s.st_last_firing_time[y - s.n_neurons];
+        if (x_plain) cross_visit(a, yx, xy, lx, ly, y_neuron, tx, ty);
+        if (y_plain) cross_visit(a, xy, yx, ly, lx, true, ty, tx);
+        if (x_mod) cross_visit(a, yx, xy, lx, ly, y_neuron, tx, ty);
+        if (y_mod) cross_visit(a, xy, yx, ly, lx, true, ty, tx);
+        if (yx.exists) { s.W[i_yx] = yx.w; a.C[i_yx] = yx.c; a.P[i_yx] = yx.dw; a.K[i_yx] = yx.k; }
+        if (xy.exists) { s.W[i_xy] = xy.w; a.C[i_xy] = xy.c; a.P[i_xy] = xy.dw; a.K[i_xy] = xy.k; }
     }
+}
+
+// Where the reference's visits are defined (it unwraps None elsewhere); the highest class found goes to *bad:
+//   1 a connection u -> v of a visited lattice (modulated, or plain with do_plasticity) without its reverse v -> u of the same kind
+//     (neuron/mod.rs:4768-4771, :4929-4932);
+//   2 RewardModulatedWeight with no modulator on either side while one side is plastic, or from a spike train into a plastic
+//     plain lattice (:4743, :4789);
+//   3 Weight between a plastic plain lattice and a reward-modulated one (:4729-4733, :4778);
+//   4 a plastic plain lattice with the BCM rule on such a connection.
+__global__ __launch_bounds__(256) void k_reward_cross_check(const RewardCrossArgs a)
+{
+    const StdpArgs &s = a.s;
+    const uint32_t q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= s.n_neurons) return;
+    const uint32_t lq = s.lattice_slot[q];
+    const bool mod_q = a.rm_on[lq] != 0u, plastic_q = !mod_q && s.do_plasticity[lq] != 0u;
+    uint32_t bad = 0;
+    for (uint32_t p = blockIdx.y; p < s.n_tot; p += gridDim.y) {
+        const uint32_t kind = cross_kind(s, p, lq);
+        const float w = s.W[cross_at(s, p, q)];
+        if (kind == 0u || w != w) continue;
+        if (plastic_q && s.stdp[PL_STRIDE * lq + 5] != 0.0f) bad = max(bad, 4u);
+        if (p >= s.n_neurons) {
+            if (kind == 1u && plastic_q) bad = max(bad, 2u);
+            continue;
+        }
+        const uint32_t lp = s.lattice_slot[p];
+        if (lp == lq) continue;
+        const bool mod_p = a.rm_on[lp] != 0u, plastic_p = !mod_p && s.do_plasticity[lp] != 0u;
+        if (plastic_p && s.stdp[PL_STRIDE * lp + 5] != 0.0f) bad = max(bad, 4u);
+        if (kind == 1u && !mod_p && !mod_q && (plastic_p || plastic_q)) bad = max(bad, 2u);
+        if (kind == 2u && ((plastic_p && mod_q) || (plastic_q && mod_p))) bad = max(bad, 3u);
+        if (mod_p || plastic_p) {
+            const float r = s.W[cross_at(s, q, p)];
+            if (r != r || s.conn_kind[(size_t)lq * s.n_lattices + lp] != kind) bad = max(bad, 1u);
+        }
+    }
+    if (bad) atomicMax(a.bad, bad);
 }
 
 // The same update FUSED into the next step's synaptic-input pass: W and the trace are read, updated, written back,

@@ -76,6 +76,8 @@ int snn_network_destroy(snn_network_t *net)
     if (net->preset_times_dev) (void)hipFree(net->preset_times_dev);
     if (net->trace) (void)hipFree(net->trace);
     if (net->pending) (void)hipFree(net->pending);
+    if (net->edge_counter) (void)hipFree(net->edge_counter);
+    if (net->cross_bad) (void)hipFree(net->cross_bad);
     if (net->conn_kind_dev) (void)hipFree(net->conn_kind_dev);
     if (net->run_failed) (void)hipHostFree(net->run_failed);
     for (float *b : net->whist) if (b) (void)hipFree(b);
@@ -293,6 +295,7 @@ int snn_get_attr_i32(snn_network_t *net, uint32_t id, const char *name, int32_t 
 int snn_set_graph_rows(snn_network_t *net, uint32_t pre_begin, uint32_t pre_count, const float *weights,
                        const uint32_t *connections)
 {
+    if (net) net->cross_checked = false;
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
     return graph_rows_io(net, pre_begin, pre_count, const_cast<float *>(weights),
                          const_cast<uint32_t *>(connections), net->nn, true);
@@ -304,6 +307,7 @@ int snn_get_graph_rows(snn_network_t *net, uint32_t pre_begin, uint32_t pre_coun
 }
 int snn_set_graph_dense(snn_network_t *net, const float *weights, const uint32_t *connections, size_t n_tot)
 {
+    if (net) net->cross_checked = false;
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
     if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
     if (n_tot != net->n_tot) return fail(SNN_ERR_DIM_MISMATCH, "graph size does not match the network");
@@ -320,6 +324,7 @@ int snn_get_graph_dense(snn_network_t *net, float *weights, uint32_t *connection
 
 int snn_fill_graph_synthetic(snn_network_t *net, uint64_t seed, float lo, float hi, int with_diagonal)
 {
+    if (net) net->cross_checked = false;
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
     if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
     if (net->csr) return fail(SNN_ERR_BAD_STATE, "the synthetic dense graph needs a dense handle");
@@ -492,6 +497,7 @@ int snn_set_synapses(snn_network_t *net, int electrical_synapse, int chemical_sy
 int snn_set_plasticity(snn_network_t *net, uint32_t id, float a_plus, float a_minus, float tau_plus,
                        float tau_minus, float dt, int do_plasticity)
 {
+    if (net) net->cross_checked = false;
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
     if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
     const LatticeInfo *l = find_lattice(net, id);
@@ -510,6 +516,7 @@ int snn_set_plasticity(snn_network_t *net, uint32_t id, float a_plus, float a_mi
 
 int snn_set_bcm(snn_network_t *net, uint32_t id, float decay, float average_scalar, float dt, int do_plasticity)
 {
+    if (net) net->cross_checked = false;
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
     if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
     const LatticeInfo *l = find_lattice(net, id);
@@ -595,6 +602,7 @@ int ensure_traces(snn_network *net)
 int snn_set_reward_modulator(snn_network_t *net, uint32_t id, float dopamine, float tau_d, float tau_c, float a_plus,
                              float a_minus, float tau_plus, float tau_minus, float dt, int do_modulation)
 {
+    if (net) net->cross_checked = false;
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
     if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
     const LatticeInfo *l = find_lattice(net, id);
@@ -666,19 +674,23 @@ int snn_run_with_reward(snn_network_t *net, float reward)
 // TraceRSTDP::c of the edges in presynaptic rows [pre_begin, pre_begin + pre_count), row-major [pre_count][n_neurons];
 // a shard handle reads / writes its own columns only.
 namespace {
-// TraceRSTDP::dw of the connections of a reward-modulated network (k_reward_cross): allocated with the first such connection
+// TraceRSTDP::dw and ::counter of the connections of a reward-modulated network (k_reward_cross): allocated with the first such
+// connection, both in the layout of W (the counter as 0.0 / 1.0)
 int ensure_pending(snn_network *net)
 {
     if (net->pending) return SNN_OK;
     const size_t n = std::max<size_t>(wcount(net->n_tot, net->ld), 64);
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&net->pending), n * 4), SNN_ERR_BUFFER_CREATE);
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&net->edge_counter), n * 4), SNN_ERR_BUFFER_CREATE);
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&net->cross_bad), 256), SNN_ERR_BUFFER_CREATE);
     HIP_TRY(hipMemsetAsync(net->pending, 0, n * 4, net->stream), SNN_ERR_BUFFER_WRITE);
+    HIP_TRY(hipMemsetAsync(net->edge_counter, 0, n * 4, net->stream), SNN_ERR_BUFFER_WRITE);
     HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
     return SNN_OK;
 }
 } // namespace
 
-static int trace_rows_io(snn_network_t *net, uint32_t pre_begin, uint32_t pre_count, float *traces, bool set, bool pending = false)
+static int trace_rows_io(snn_network_t *net, uint32_t pre_begin, uint32_t pre_count, float *traces, bool set, int plane = 0)
 {
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
     if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
@@ -689,8 +701,8 @@ static int trace_rows_io(snn_network_t *net, uint32_t pre_begin, uint32_t pre_co
     HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
     TRY(end_run(net));
     TRY(ensure_traces(net));
-    if (pending) TRY(ensure_pending(net));
-    float *matrix = pending ? net->pending : net->trace;
+    if (plane) TRY(ensure_pending(net));
+    float *matrix = plane == 2 ? net->edge_counter : plane == 1 ? net->pending : net->trace;
     HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
     // through a row-major staging block of <= 64 MiB and <= 32768 rows per hop (the matrix is in quad-row order)
     float *host = traces + net->q0;
@@ -721,9 +733,27 @@ int snn_set_trace_rows(snn_network_t *net, uint32_t pre_begin, uint32_t pre_coun
 int snn_get_trace_rows(snn_network_t *net, uint32_t pre_begin, uint32_t pre_count, float *traces)
 { return trace_rows_io(net, pre_begin, pre_count, traces, false); }
 int snn_set_pending_rows(snn_network_t *net, uint32_t pre_begin, uint32_t pre_count, const float *pending)
-{ return trace_rows_io(net, pre_begin, pre_count, const_cast<float *>(pending), true, true); }
+{ return trace_rows_io(net, pre_begin, pre_count, const_cast<float *>(pending), true, 1); }
 int snn_get_pending_rows(snn_network_t *net, uint32_t pre_begin, uint32_t pre_count, float *pending)
-{ return trace_rows_io(net, pre_begin, pre_count, pending, false, true); }
+{ return trace_rows_io(net, pre_begin, pre_count, pending, false, 1); }
+// TraceRSTDP::counter of the same connections (0 / 1), one byte each
+int snn_set_counter_rows(snn_network_t *net, uint32_t pre_begin, uint32_t pre_count, const uint8_t *counters)
+{
+    if (!net || !counters) return fail(SNN_ERR_BAD_ARG, "null argument");
+    if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
+    std::vector<float> rows((size_t)pre_count * net->nn);
+    for (size_t i = 0; i < rows.size(); ++i) rows[i] = counters[i] ? 1.0f : 0.0f;
+    return trace_rows_io(net, pre_begin, pre_count, rows.data(), true, 2);
+}
+int snn_get_counter_rows(snn_network_t *net, uint32_t pre_begin, uint32_t pre_count, uint8_t *counters)
+{
+    if (!net || !counters) return fail(SNN_ERR_BAD_ARG, "null argument");
+    if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
+    std::vector<float> rows((size_t)pre_count * net->nn, 0.0f);
+    TRY(trace_rows_io(net, pre_begin, pre_count, rows.data(), false, 2));
+    for (size_t i = 0; i < rows.size(); ++i) counters[i] = rows[i] != 0.0f ? 1 : 0;
+    return SNN_OK;
+}
 
 int snn_set_connection_kind(snn_network_t *net, uint32_t pre_id, uint32_t post_id, int kind)
 {
@@ -740,29 +770,18 @@ int snn_set_connection_kind(snn_network_t *net, uint32_t pre_id, uint32_t post_i
     TRY(end_run(net));
     if (net->conn_kind_host.empty()) {
         net->conn_kind_host.assign((nl + ns) * nl, 0);
-        net->rm_cross_counter.assign(nl, 0);
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&net->conn_kind_dev), std::max<size_t>((nl + ns) * nl, 256)), SNN_ERR_BUFFER_CREATE);
     }
     const size_t source = pre->spike_train ? nl + pre->slot : pre->slot;
     net->conn_kind_host[source * nl + post->slot] = (uint8_t)kind;
     net->any_conn_kind = false;
+    net->cross_checked = false;
     for (uint8_t k : net->conn_kind_host) net->any_conn_kind |= k != 0;
     HIP_TRY(hipMemcpy(net->conn_kind_dev, net->conn_kind_host.data(), net->conn_kind_host.size(), hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
     if (kind) {
         TRY(ensure_traces(net));
         TRY(ensure_pending(net));
     }
-    return SNN_OK;
-}
-
-int snn_connection_counter(snn_network_t *net, uint32_t post_id, int set, uint32_t *counter)
-{
-    if (!net || !counter) return fail(SNN_ERR_BAD_ARG, "null argument");
-    const LatticeInfo *post = net->finalized ? find_lattice(net, post_id) : nullptr;
-    if (!post || post->spike_train) return fail(SNN_ERR_BAD_ARG, "no such neuron lattice");
-    if (net->rm_cross_counter.empty()) { if (!set) *counter = 0; return set ? fail(SNN_ERR_BAD_STATE, "no connection kind has been set") : SNN_OK; }
-    if (set) { TRY(end_run(net)); net->rm_cross_counter[post->slot] = *counter & 1u; }
-    else *counter = net->rm_cross_counter[post->slot];
     return SNN_OK;
 }
 

@@ -102,7 +102,9 @@ struct snn_network {
     uint8_t *conn_kind_dev = nullptr;
     bool any_conn_kind = false;
     float *pending = nullptr;
-    std::vector<uint32_t> rm_cross_counter;
+    float *edge_counter = nullptr;
+    uint32_t *cross_bad = nullptr;
+    bool cross_checked = false;           // the connection kinds lie where the reference defines their updates (check_reward_cross)
     // Dense handles defer the weight update of step t to the input pass of step t+1 (k_inputs_rstdp: one pass over
     // W and the traces instead of two); any host access to weights / traces / timing flushes it first.
     int defer_rstdp = 1;                   // 0: always the standalone pass (SNN_AMD_DEFER_RSTDP=0)

@@ -387,26 +387,47 @@ int launch_rstdp_pass(snn_network *net, int dop)
     return SNN_OK;
 }
 
-// the connections of a reward-modulated network that end in a modulated lattice (k_reward_cross), right after the lattices' own
-// edges; the counters of the visited lattices flip
+// the connections between the lattices of a reward-modulated network (k_reward_cross), right after the lattices' own edges
+static RewardCrossArgs reward_cross_args(snn_network *net)
+{
+    RewardCrossArgs a{};
+    a.s = stdp_args(net);
+    a.s.conn_kind = net->conn_kind_dev;
+    a.C = net->trace; a.P = net->pending; a.K = net->edge_counter;
+    a.rm = net->rm_dev; a.rm_on = net->rm_on_dev; a.bad = net->cross_bad;
+    return a;
+}
+
 int launch_reward_cross(snn_network *net)
 {
-    if (!net->any_conn_kind || !net->any_modulation || net->nn == 0 || net->n_loc == 0 || !net->trace || !net->pending) return SNN_OK;
-    RewardCrossArgs a{};
-    a.W = net->W; a.C = net->trace; a.P = net->pending;
-    a.ld = net->ld; a.n_loc = net->n_loc; a.q0 = net->q0; a.n_neurons = net->nn; a.n_tot = net->n_tot;
-    a.n_lattices = (uint32_t)net->lattices.size();
-    a.last_firing_time = net->na.last_firing_time; a.st_last_firing_time = net->ca.last_firing_time;
-    a.lattice_slot = net->lattice_slot; a.st_lattice_slot = net->ca.lattice_slot;
-    a.rm = net->rm_dev; a.stdp = net->stdp_dev; a.rm_on = net->rm_on_dev; a.conn_kind = net->conn_kind_dev;
-    for (size_t l = 0; l < net->rm_cross_counter.size() && l < 64; ++l)
-        if (net->rm_cross_counter[l]) a.second |= 1ull << l;
-    const unsigned gx = (net->n_loc + 255) / 256;
-    const unsigned gy = std::max(1u, std::min<unsigned>((net->n_tot + 3) / 4, std::max(1u, 8192u / gx)));
-    hipLaunchKernelGGL(k_reward_cross, dim3(gx, gy), dim3(256), 0, net->stream, a);
+    if (!net->any_conn_kind || net->nn == 0 || !net->trace || !net->pending) return SNN_OK;
+    const unsigned gx = (net->nn + 255) / 256;
+    const unsigned gy = std::max(1u, std::min<unsigned>(net->n_tot, std::max(1u, 16384u / gx)));
+    hipLaunchKernelGGL(k_reward_cross, dim3(gx, gy), dim3(256), 0, net->stream, reward_cross_args(net));
     HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
-    for (size_t l = 0; l < net->rm_cross_counter.size(); ++l)
-        if (net->rm_on_host[l]) net->rm_cross_counter[l] ^= 1u;
+    return SNN_OK;
+}
+
+// Refuses, before the first step, connection kinds that lie where the reference's visits unwrap None (k_reward_cross_check);
+// repeated after anything that may change the answer (kinds, graph, plasticity, modulators).
+int check_reward_cross(snn_network *net)
+{
+    if (!net->any_conn_kind || net->cross_checked || net->nn == 0 || !net->pending) return SNN_OK;
+    HIP_TRY(hipMemsetAsync(net->cross_bad, 0, 4, net->stream), SNN_ERR_BUFFER_WRITE);
+    const unsigned gx = (net->nn + 255) / 256;
+    const unsigned gy = std::max(1u, std::min<unsigned>(net->n_tot, std::max(1u, 16384u / gx)));
+    hipLaunchKernelGGL(k_reward_cross_check, dim3(gx, gy), dim3(256), 0, net->stream, reward_cross_args(net));
+    HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+    uint32_t bad = 0;
+    HIP_TRY(hipMemcpyAsync(&bad, net->cross_bad, 4, hipMemcpyDeviceToHost, net->stream), SNN_ERR_BUFFER_READ);
+    HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
+    static const char *why[] = {"", "a connection of a visited lattice has no reverse connection of the same kind: the reference's outgoing half "
+        "looks the reverse connection up and unwraps it (neuron/mod.rs:4768-4771, 4929-4932)",
+        "reward-modulated weights where no side has a modulator, or from a spike train into a plastic plain lattice (neuron/mod.rs:4743, 4789)",
+        "plain weights between a plastic plain lattice and a reward-modulated one (neuron/mod.rs:4729-4733, 4778)",
+        "a BCM lattice on a connection of a reward-modulated network (the reference's network has one plasticity rule)"};
+    if (bad) return fail(SNN_ERR_BAD_STATE, why[bad < 5 ? bad : 1]);
+    net->cross_checked = true;
     return SNN_OK;
 }
 
@@ -1131,6 +1152,7 @@ int begin_run(snn_network *net, uint64_t iterations)
         if (net->view_dirty) { net->stat_view_refreshes += 1; TRY(launch_spike_trains(net, 0, 0, net->clock)); }
     }
     net->view_dirty = false;
+    TRY(check_reward_cross(net));
     net->run_step_offset = 0;
     net->run_active = true;
     return SNN_OK;

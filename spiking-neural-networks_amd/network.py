@@ -414,10 +414,17 @@ class DeviceNetwork:
         self._check(self._L.snn_get_pending_rows(self._h, pre_begin, pre_count, t.ctypes.data_as(_lib.f32p)))
         return t
 
-    def connection_counter(self, post_id, value=None):
-        c = C.c_uint32(0 if value is None else int(value))
-        self._check(self._L.snn_connection_counter(self._h, post_id, int(value is not None), C.byref(c)))
-        return int(c.value)
+    def set_counter_rows(self, pre_begin, counters):
+        """TraceRSTDP::counter (0 / 1) per connection, rows as set_pending_rows"""
+        t = np.ascontiguousarray(counters, dtype=np.uint8)
+        if t.ndim != 2 or t.shape[1] != self.n_neurons:
+            raise ValueError("counters must be [rows][n_neurons]")
+        self._check(self._L.snn_set_counter_rows(self._h, pre_begin, t.shape[0], t.ctypes.data_as(_lib.u8p)))
+
+    def get_counter_rows(self, pre_begin, pre_count):
+        t = np.zeros((pre_count, self.n_neurons), np.uint8)
+        self._check(self._L.snn_get_counter_rows(self._h, pre_begin, pre_count, t.ctypes.data_as(_lib.u8p)))
+        return t
 
     def set_traces_csr(self, traces):
         t = np.ascontiguousarray(traces, dtype=np.float32)

@@ -144,12 +144,12 @@ def reward_modulated_4x4():
 
 
 def reward_modulated_network():
-    """RewardModulatedLatticeNetwork (neuron/mod.rs:3419-3453): a reward-modulated lattice (id 1) fed by a plain STDP lattice (id 0)
-    through RewardModulatedConnection::RewardModulatedWeight, by another plain lattice (id 2) through
-    RewardModulatedConnection::Weight and by Poisson cells through reward-modulated weights -- the incoming half of
-    update_weights_from_neurons_across_reward_lattices (:4859-4924): one modulator visit per connection and step (dw and the
-    counter live across steps), the presynaptic lattice's STDP on the plain weights; constant dopamine"""
-    lay = parity.Layout([(0, 3, 3), (1, 3, 4), (2, 2, 3)], [(5, 2, 3)])
+    """RewardModulatedLatticeNetwork (neuron/mod.rs:3419-3453), every connection between lattices a RewardModulatedConnection: a
+    plastic plain lattice (id 0), two reward-modulated lattices (ids 1, 3), a plain lattice without plasticity (id 2) and Poisson
+    cells.  RewardModulatedWeight between 0, 1 and 3 (and from the cells into 1 and 3), Weight everywhere else; all connections
+    exist in both directions, which the outgoing halves of update_weights_from_neurons_across_lattices (:4707-4802) and
+    _across_reward_lattices (:4855-4977) need (they look up the reverse connection).  Constant dopamine."""
+    lay = parity.Layout([(0, 3, 3), (1, 3, 4), (2, 2, 3), (3, 2, 2)], [(5, 2, 3)])
     net = parity.make_oracle(lay, st_kind=ob.ST_POISSON)
     nn = net.n_neurons
     net["current_voltage"] = ob.uniform_array(21, nn, -65.0, 30.0)
@@ -157,18 +157,22 @@ def reward_modulated_network():
     net.fill_graph(22, 0.5, 1.5)
     net["st_chance_of_firing"] = 0.15
     net["st_seed"] = np.arange(31, 37, dtype=np.uint32)
-    net["rm_do_modulation"][1] = 1
-    net["rm_dopamine"][1] = 0.015
-    net["rm_tau_c"][1] = 0.05
-    net["rm_a_plus"][1] = 0.01
-    net["rm_a_minus"][1] = 0.012
-    net["do_plasticity"][0] = net["do_plasticity"][2] = 1
+    for l, dopamine in ((1, 0.015), (3, -0.01)):
+        net["rm_do_modulation"][l] = 1
+        net["rm_dopamine"][l] = dopamine
+        net["rm_tau_c"][l] = 0.05
+        net["rm_a_plus"][l] = 0.01
+        net["rm_a_minus"][l] = 0.012
+    net["do_plasticity"][0] = 1
     net["stdp_a_plus"][0] = 0.8
     net["stdp_a_minus"][2] = 0.5
-    net["conn_kind"][0, 1] = 1          # lattice 0 -> lattice 1: reward-modulated weights
-    net["conn_kind"][2, 1] = 2          # lattice 2 -> lattice 1: plain weights of the reward-modulated network
-    net["conn_kind"][3, 1] = 1          # the cells (source slot n_lattices + 0) -> lattice 1: reward-modulated weights
+    net["conn_kind"][...] = 2           # RewardModulatedConnection::Weight ...
+    for a, b in ((0, 1), (0, 3), (1, 3)):
+        net["conn_kind"][a, b] = net["conn_kind"][b, a] = 1          # ... RewardModulatedWeight among 0, 1 and 3
+    net["conn_kind"][4, 1] = net["conn_kind"][4, 3] = 1              # and from the cells (source slot n_lattices + 0) into 1 and 3
+    net["conn_kind"][np.arange(4), np.arange(4)] = 0                 # (a lattice's own edges follow its own rule)
     net["traces"][...] = ob.uniform_array(23, net["traces"].size, -0.01, 0.01).reshape(net["traces"].shape) * net["connections"]
+    assert net.reward_cross_check() == 0
     return net, 701                     # (an odd count: the two-visit cycle of the traces ends half way)
 
 
@@ -202,7 +206,7 @@ EXTRA = {"hh_pair": ("m_state", "h_state", "n_state"), "stdp_3_neurons": ("weigh
          "spike_trains_rate": ("st_step", "st_last_firing_time"),
          "adaptive_exp_lif_3x3": ("w_value", "refractory_count"), "leaky_izhikevich_3x3": ("w_value",),
          "preset_exponential_decay_kinetics": ("nt_t", "rc_r", "st_step", "st_counter", "st_last_firing_time"),
-         "reward_modulated_4x4": ("weights", "traces"), "reward_modulated_network": ("weights", "traces", "pending", "rm_cross_counter"), "generated_morris_lecar_3x3": ("custom_vars", "weights")}
+         "reward_modulated_4x4": ("weights", "traces"), "reward_modulated_network": ("weights", "traces", "pending", "edge_counter"), "generated_morris_lecar_3x3": ("custom_vars", "weights")}
 
 
 def outputs(name, net, steps):

@@ -97,6 +97,19 @@ def stdp_delta(tp, tq, a_plus, a_minus, tau_plus, tau_minus, dt):
     return out
 
 
+def stdp_delta_each(tp, tq, a_plus, a_minus, tau_plus, tau_minus, dt):
+    """stdp_delta with one rule PER ELEMENT (f32 arrays of the shape of tp / tq)"""
+    tp, tq = np.asarray(tp, np.int64), np.asarray(tq, np.int64)
+    fp, fq = tp.astype(f32), tq.astype(f32)
+    both = (tp >= 0) & (tq >= 0)
+    with np.errstate(all="ignore"):
+        x = (f32(-1.0) * np.abs(((fp - fq).astype(f32) * dt).astype(f32))).astype(f32)
+        pot = (a_plus * expf((x / tau_plus).astype(f32))).astype(f32)
+        y = (f32(-1.0) * np.abs(((fq - fp).astype(f32) * dt).astype(f32))).astype(f32)
+        dep = ((f32(-1.0) * a_minus).astype(f32) * expf((y / tau_minus).astype(f32))).astype(f32)
+    return np.where(both & (fp < fq), pot, np.where(both & (fp > fq), dep, f32(0))).astype(f32)
+
+
 class NumpyNet:
     """State = float32 / integer arrays under the oracle binding's names (so a golden-case builder's INPUT arrays can be
     taken over as they are); nothing of the oracle's code runs here."""
@@ -441,44 +454,87 @@ class NumpyNet:
         return a["conn_kind"][source]
 
     def reward_cross(self):
-        """the incoming half of RewardModulatedLatticeNetwork::update_weights_from_neurons_across_reward_lattices
-        (neuron/mod.rs:4859-4924): every neuron of a modulated lattice l visits its connections from other lattices once per step --
-        a plain Weight from a plain lattice lp takes lp's STDP delta (:4869-4883); a RewardModulatedWeight takes one visit of l's
-        modulator (plasticity/mod.rs:203-237): dw += delta, every second visit folds dw into the trace, weight += c * dopamine"""
-        a, nn = self.a, self.nn
-        if "conn_kind" not in a or not a["conn_kind"].any() or not a["rm_do_modulation"].any():
+        """The connections between lattices of a RewardModulatedLatticeNetwork (update_weights_from_neurons_across_lattices,
+        neuron/mod.rs:4707-4802, and _across_reward_lattices, :4855-4977), PAIR by pair: the two connections x -> y and y -> x of
+        neurons in different lattices are touched by the visits of x and of y only, so each pair is a sequence of at most two
+        visits -- the spiking neurons of plastic plain lattices first, then the neurons of modulated lattices, by index.  A visit
+        of z with partner o: the connection o -> z takes its rule (incoming half), then z -> o is REPLACED by a copy of o -> z that
+        took the rule once more with (pre = z, post = o) (outgoing half: the reference looks up the reverse connection)."""
+        a, nn, nc = self.a, self.nn, self.nc
+        if "conn_kind" not in a or not a["conn_kind"].any():
             return
-        kinds = self.connection_kinds()
-        lat = a["lattice"]
-        lft_all = np.concatenate([a["last_firing_time"], a["st_last_firing_time"]])
+        kinds = self.connection_kinds()                           # [n_tot][n_lattices]
+        lat = a["lattice"].astype(np.int64)
+        mod = a["rm_do_modulation"].astype(bool)
+        plastic = a["do_plasticity"].astype(bool) & ~mod
         conn = a["connections"] != 0
-        for l in np.nonzero(a["rm_do_modulation"])[0]:
-            post = lat == l
-            other = np.concatenate([lat != l, np.ones(self.nc, bool)])
-            # kind 2: the presynaptic lattice's STDP, plain lattices only
-            plain_pre = np.concatenate([a["rm_do_modulation"][lat] == 0, np.zeros(self.nc, bool)])
-            p, q = np.nonzero(conn & (kinds[:, l] == 2)[:, None] & (other & plain_pre)[:, None] & post[None, :])
-            for lp in np.unique(lat[p]) if p.size else ():
-                m = lat[p] == lp
-                d = stdp_delta(lft_all[p[m]], lft_all[q[m]], *(float(a[k][lp]) for k in
-                                                                 ("stdp_a_plus", "stdp_a_minus", "stdp_tau_plus", "stdp_tau_minus", "stdp_dt")))
-                a["weights"][p[m], q[m]] = (a["weights"][p[m], q[m]] + d).astype(f32)
-            # kind 1: one visit of l's modulator
-            p, q = np.nonzero(conn & (kinds[:, l] == 1)[:, None] & other[:, None] & post[None, :])
-            if p.size:
-                dop, dt, tau_c = f32(a["rm_dopamine"][l]), f32(a["rm_dt"][l]), f32(a["rm_tau_c"][l])
-                delta = stdp_delta(lft_all[p], lft_all[q], float(a["rm_a_plus"][l]), float(a["rm_a_minus"][l]),
-                                   float(a["rm_tau_plus"][l]), float(a["rm_tau_minus"][l]), float(dt))
-                decay = expf(np.array([(-dt) / tau_c], f32))[0]
-                w, c, dw = a["weights"][p, q], a["traces"][p, q], a["pending"][p, q]
-                with np.errstate(all="ignore"):
-                    dw = (dw + delta).astype(f32)
-                    if a["rm_cross_counter"][l]:
-                        c = ((c * decay).astype(f32) + (tau_c * dw).astype(f32)).astype(f32)
-                        dw = np.zeros_like(dw)
-                    w = (w + (c * dop).astype(f32)).astype(f32)
-                a["weights"][p, q], a["traces"][p, q], a["pending"][p, q] = w, c, dw
-            a["rm_cross_counter"][l] ^= 1
+        lft = np.concatenate([a["last_firing_time"], a["st_last_firing_time"]]).astype(np.int64)
+        spiking = a["is_spiking"].astype(bool)
+        # the pairs: x a neuron, y a later neuron of another lattice or a cell (cells are never visited and have no incoming edge)
+        xs, ys = np.nonzero(np.triu(np.ones((nn, nn + nc), bool), 1))
+        keep = (ys >= nn) | (lat[xs] != lat[np.minimum(ys, nn - 1)])
+        xs, ys = xs[keep], ys[keep]
+        y_cell = ys >= nn
+        yn = np.minimum(ys, nn - 1)
+        ex = {"yx": conn[ys, xs], "xy": np.where(y_cell, False, conn[xs, yn])}
+        kind = {"yx": kinds[ys, lat[xs]], "xy": np.where(y_cell, 0, kinds[xs, lat[yn]])}
+        st = {}
+        for name in ("weights", "traces", "pending", "edge_counter"):
+            st[name, "yx"] = a[name][ys, xs].copy()
+            st[name, "xy"] = np.where(y_cell, 0, a[name][xs, yn]).astype(a[name].dtype)
+
+        def rule(l, which):
+            return a[which][l].astype(f32)
+
+        def stdp(l, tp, tq):          # the STDP rule of lattice l (arrays), pre / post firing times
+            return stdp_delta_each(tp, tq, rule(l, "stdp_a_plus"), rule(l, "stdp_a_minus"), rule(l, "stdp_tau_plus"),
+                                   rule(l, "stdp_tau_minus"), rule(l, "stdp_dt"))
+
+        def trace_visit(sel, m, tp, tq, w, c, dw, cnt):
+            """RewardModulatedSTDP::update_weight (plasticity/mod.rs:203-237) of lattice m's modulator, where sel"""
+            dt, tau_c = rule(m, "rm_dt"), rule(m, "rm_tau_c")
+            delta = stdp_delta_each(tp, tq, rule(m, "rm_a_plus"), rule(m, "rm_a_minus"), rule(m, "rm_tau_plus"), rule(m, "rm_tau_minus"), dt)
+            with np.errstate(all="ignore"):
+                dw2 = (dw + delta).astype(f32)
+                second = cnt != 0
+                decay = expf(((-dt) / tau_c).astype(f32))
+                c2 = np.where(second, ((c * decay).astype(f32) + (tau_c * dw2).astype(f32)).astype(f32), c)
+                dw2 = np.where(second, f32(0), dw2).astype(f32)
+                w2 = (w + (c2 * rule(m, "rm_dopamine")).astype(f32)).astype(f32)
+            return (np.where(sel, w2, w), np.where(sel, c2, c), np.where(sel, dw2, dw), np.where(sel, cnt ^ 1, cnt).astype(cnt.dtype))
+
+        def visit(visited, z, o, o_is_neuron, inn, out):
+            lz, lo = lat[z], lat[np.minimum(o, nn - 1)]
+            mod_z, mod_o = mod[lz], mod[lo] & o_is_neuron
+            tz, to = lft[z], lft[o]
+            k_in = np.where(visited & ex[inn], kind[inn], 0)
+            with np.errstate(all="ignore"):
+                # incoming o -> z
+                plain_rule = np.where(mod_z, lo, lz)
+                do2 = (k_in == 2) & (~mod_z | (o_is_neuron & ~mod_o))
+                st["weights", inn] = np.where(do2, (st["weights", inn] + stdp(plain_rule, to, tz)).astype(f32), st["weights", inn])
+                m = np.where(mod_z, lz, lo)
+                st["weights", inn], st["traces", inn], st["pending", inn], st["edge_counter", inn] = trace_visit(
+                    k_in == 1, m, to, tz, st["weights", inn], st["traces", inn], st["pending", inn], st["edge_counter", inn])
+                # outgoing z -> o: the reverse connection, updated once more, replaces it
+                k_out = np.where(visited & ex[out] & ex[inn] & o_is_neuron, kind[out], 0)
+                do2 = (k_out == 2) & (~mod_z | ~mod_o)
+                st["weights", out] = np.where(do2, (st["weights", inn] + stdp(plain_rule, tz, to)).astype(f32), st["weights", out])
+                w, c, dw, cnt = trace_visit(k_out == 1, m, tz, to, st["weights", inn], st["traces", inn], st["pending", inn], st["edge_counter", inn])
+                for name, v in (("weights", w), ("traces", c), ("pending", dw), ("edge_counter", cnt)):
+                    st[name, out] = np.where(k_out == 1, v, st[name, out]).astype(st[name, out].dtype)
+
+        x_plain = plastic[lat[xs]] & spiking[xs]
+        y_plain = ~y_cell & plastic[lat[yn]] & spiking[yn]
+        visit(x_plain, xs, ys, ~y_cell, "yx", "xy")
+        visit(y_plain, yn, xs, np.ones(xs.size, bool), "xy", "yx")
+        visit(mod[lat[xs]], xs, ys, ~y_cell, "yx", "xy")
+        visit(~y_cell & mod[lat[yn]], yn, xs, np.ones(xs.size, bool), "xy", "yx")
+        for name in ("weights", "traces", "pending", "edge_counter"):
+            sel = ex["yx"]
+            a[name][ys[sel], xs[sel]] = st[name, "yx"][sel]
+            sel = ex["xy"]
+            a[name][xs[sel], yn[sel]] = st[name, "xy"][sel]
 
     # ---- step 6: spike trains  neuron/mod.rs:1377-1393 --------------------------------------------------------
     def spike_trains(self):
@@ -515,11 +571,22 @@ class NumpyNet:
         a["st_clock"] += 1
 
     # ---- the loop  run_lattice_* neuron/mod.rs:1035-1088, run_lattices_* :2598-2651 ----------------------------
-    def run(self, steps, voltage_history=True, spike_history=True, st_voltage_history=False):
+    def apply_reward(self, reward):
+        """RewardModulatedSTDP::update (plasticity/mod.rs:199-201) on every modulated lattice"""
+        a = self.a
+        on = a["rm_do_modulation"] != 0
+        with np.errstate(all="ignore"):
+            decay = expf(((-a["rm_dt"]) / a["rm_tau_d"]).astype(f32))
+            new = ((a["rm_dopamine"] * decay).astype(f32) + (a["rm_tau_d"] * f32(reward)).astype(f32)).astype(f32)
+        a["rm_dopamine"] = np.where(on, new, a["rm_dopamine"]).astype(f32)
+
+    def run(self, steps, voltage_history=True, spike_history=True, st_voltage_history=False, rewards=None):
         vh, sh, ch = [], [], []
         if not (self.electrical or self.chemical):
             steps = 0
-        for _ in range(steps):
+        for it in range(steps):
+            if rewards is not None:
+                self.apply_reward(rewards[it])
             if self.nn:
                 i_in, t_in, t_cnt = self.inputs()
                 spike = self.update_neurons(i_in, t_in, t_cnt)

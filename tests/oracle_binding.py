@@ -91,7 +91,7 @@ _FIELDS = [
     ("rx_code", C.POINTER(C.c_int32)), ("rx_consts", f32p), ("rx_ntypes", C.c_uint32), ("rx_nvars", C.c_uint32),
     ("rx_section", C.c_uint32 * 3), ("rx_current_index", C.c_int32 * 3), ("rx_vars", f32p),
     ("rx_multi", C.c_uint32), ("rx_kin_section", C.c_uint32 * 3),
-    ("conn_kind", u8p), ("pending", f32p), ("rm_cross_counter", u32p),
+    ("conn_kind", u8p), ("pending", f32p), ("edge_counter", u8p),
 ]
 
 
@@ -128,6 +128,8 @@ def lib():
         L.snn_o_reward_modulation_cols.argtypes = [P, C.c_uint32, C.c_uint32]
         L.snn_o_reward_modulation_cols.restype = None
         L.snn_o_run.argtypes = [P, C.c_uint64]
+        L.snn_o_reward_cross_check.argtypes = [P]
+        L.snn_o_reward_cross_check.restype = C.c_int
         L.snn_o_run.restype = None
         for fn in ("snn_o_expf_export", "snn_o_pow3f_export", "snn_o_pow4f_export", "snn_o_tanhf_export",
                    "snn_o_sinhf_export", "snn_o_coshf_export", "snn_o_sinf_export", "snn_o_cosf_export",
@@ -281,14 +283,12 @@ class Net:
                 shape = (nn,)
             elif name == "st_clock":
                 shape = (self.n_st_lattices,)
-            elif name in ("weights", "connections", "traces", "pending"):
+            elif name in ("weights", "connections", "traces", "pending", "edge_counter"):
                 if not dense:
                     continue
                 shape = (self.n_tot, nn)
             elif name == "conn_kind":
                 shape = (self.n_lattices + self.n_st_lattices, self.n_lattices)
-            elif name == "rm_cross_counter":
-                shape = (self.n_lattices,)
             elif name == "input_current":
                 shape = (nn,)
             else:   # histories: allocated per run
@@ -453,6 +453,10 @@ class Net:
     def spike_trains(self):
         c = self._cnet()
         lib().snn_o_spike_trains(C.byref(c))
+
+    def reward_cross_check(self):
+        """0 when every connection of kind 1 / 2 lies where the reference defines its update (snn_o_reward_cross_check)"""
+        return int(lib().snn_o_reward_cross_check(C.byref(self._cnet())))
 
     def run(self, iterations, voltage_history=False, spike_history=False, st_voltage_history=False,
             summaries=False, spike_counts=False, rewards=None):

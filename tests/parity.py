@@ -163,7 +163,7 @@ def device_from_oracle(snn, net, shard=None, device=0, csr=False, by_lattice=Fal
 
 
 def push_connection_kinds(dn, net):
-    """the connections of a reward-modulated network (conn_kind / pending / rm_cross_counter of the oracle net) onto a device handle;
+    """the connections of a reward-modulated network (conn_kind / pending / edge_counter of the oracle net) onto a device handle;
     call after the reward modulators and traces are set"""
     kinds = net["conn_kind"]
     if not kinds.any():
@@ -175,9 +175,7 @@ def push_connection_kinds(dn, net):
             if kinds[s, l]:
                 dn.set_connection_kind(pre, post, int(kinds[s, l]))
     dn.set_pending_rows(0, net["pending"])
-    for l, (post, _, _) in enumerate(lay.lattices):
-        if net["rm_cross_counter"][l]:
-            dn.connection_counter(post, int(net["rm_cross_counter"][l]))
+    dn.set_counter_rows(0, net["edge_counter"])
 
 
 def _neuron_names(net):

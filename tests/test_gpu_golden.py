@@ -47,9 +47,8 @@ def test_hip_matches_golden(snn, name):
             assert dn.get_trace_rows(0, net.n_tot).tobytes() == want[k].tobytes()
         elif k == "pending":
             assert dn.get_pending_rows(0, net.n_tot).tobytes() == want[k].tobytes()
-        elif k == "rm_cross_counter":
-            got = np.array([dn.connection_counter(i) for i, _, _ in net.layout.lattices], np.uint32)
-            assert got.tobytes() == want[k].tobytes()
+        elif k == "edge_counter":
+            assert dn.get_counter_rows(0, net.n_tot).tobytes() == want[k].tobytes()
         else:
             assert st[k].tobytes() == want[k].tobytes(), k
     dn.close()
