@@ -475,7 +475,8 @@ int snn_get_spike_counts(snn_network_t *net, uint32_t id, uint32_t *dst, size_t 
  * handle is created: SNN_AMD_<NAME in upper case>): "fused_step" [1] one-launch step for small lattices and for
  * sparse handles; "cells_in_step" [1] sparse electrical-only handles without weight updates: the spike-train cells advance
  * inside the step's launch; "update_packs" [1] dense shard handles: the neuron update writes the handle's own slot of
- * the all-gather buffer itself (no pack launch); "csr_xcd_bands" [1] the sparse step hands its row blocks to the XCDs in contiguous bands;
+ * the all-gather buffer itself (no pack launch); "update_all_planes" [1] dense handles with chemical synapses: the neuron update
+ * requests the chunk partials of all planes together; "csr_xcd_bands" [1] the sparse step hands its row blocks to the XCDs in contiguous bands;
  * "halo_direct" [1] library-driven runs of sparse shard handles gather the halo from the received segments (0: never,
  * 2: also in snn_run_sharded_custom, see there); "defer_rstdp"
  * [1] reward-modulated weight updates riding on the next input pass; "defer_stdp" [0] 1: STDP updates riding on the next

@@ -592,13 +592,64 @@ struct RegisterSums {
     __device__ __forceinline__ float chem(int k) const { return t[k]; }
 };
 
-template <int MODEL>
+// The second-level sums of a network with chemical synapses, all planes at once: the loads of a batch of every plane the
+// step needs (gap junctions + the live transmitter types) are in flight together, the adds of each plane stay strictly
+// ascending from 0.0f.  One plane after the other (GlobalSums) the update of configs[2] (64 chunks, two planes) waited for 8
+// dependent round trips of 16 loads; this way for 2 of 64.
+__device__ __forceinline__ RegisterSums combine_all_planes(const UpdateArgs &a, uint32_t ql)
+{
+    constexpr uint32_t B = 32;
+    RegisterSums out{};
+    const float *plane[1 + K_TYPES];
+    bool on[1 + K_TYPES];
+    plane[0] = a.part_i + ql;
+    on[0] = a.electrical != 0;
+#pragma unroll
+    for (int k = 0; k < K_TYPES; ++k) {
+        plane[1 + k] = a.part_t + (size_t)k * a.n_chunks * a.ld + ql;
+        on[1 + k] = (a.live_mask >> k & 1u) != 0u;                       // (the planes of the other types hold zeros)
+    }
+    float sum[1 + K_TYPES] = {0.0f, 0.0f, 0.0f, 0.0f};
+    uint32_t c = 0;
+    for (; c + B <= a.n_chunks; c += B) {
+        float v[1 + K_TYPES][B];
+#pragma unroll
+        for (int pl = 0; pl < 1 + K_TYPES; ++pl)
+            if (on[pl]) {                                                // launch-uniform
+#pragma unroll
+                for (uint32_t u = 0; u < B; ++u) v[pl][u] = plane[pl][(size_t)(c + u) * a.ld];
+            }
+#pragma unroll
+        for (int pl = 0; pl < 1 + K_TYPES; ++pl)
+            if (on[pl]) {
+#pragma unroll
+                for (uint32_t u = 0; u < B; ++u) sum[pl] += v[pl][u];
+            }
+    }
+    for (; c < a.n_chunks; ++c) {
+#pragma unroll
+        for (int pl = 0; pl < 1 + K_TYPES; ++pl)
+            if (on[pl]) sum[pl] += plane[pl][(size_t)c * a.ld];
+    }
+    out.i = sum[0];
+#pragma unroll
+    for (int k = 0; k < K_TYPES; ++k) out.t[k] = sum[1 + k];
+    return out;
+}
+
+// ALL_PLANES: a dense handle with chemical synapses (its own instantiation: the batch registers of combine_all_planes would
+// otherwise cost the electrical-only update its occupancy)
+template <int MODEL, bool ALL_PLANES = false>
 __global__ __launch_bounds__(256) void k_update(const UpdateArgs a)
 {
     const uint32_t ql = blockIdx.x * blockDim.x + threadIdx.x;           // blockDim.x = 64 or 256
     const bool active = ql < a.n_loc && a.rows.active(ql, a.n_loc);
     float v_new = 0.0f;
-    const uint32_t spike = active ? update_neuron_at<MODEL>(a, ql, GlobalSums{a, ql}, a.clock, a.vhist_row, &v_new) : 0u;
+    uint32_t spike = 0u;
+    if (active) {
+        if (ALL_PLANES) spike = update_neuron_at<MODEL>(a, ql, combine_all_planes(a, ql), a.clock, a.vhist_row, &v_new);
+        else spike = update_neuron_at<MODEL>(a, ql, GlobalSums{a, ql}, a.clock, a.vhist_row, &v_new);
+    }
     if (a.wire_out) {
         // entries past the shard's neurons (slot padding) stay zero: nothing ever writes them
         if (active) {

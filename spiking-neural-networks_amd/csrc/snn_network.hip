@@ -43,6 +43,7 @@ int snn_network_create(int device, int neuron_model, int nt_kinetics, int recept
     if (const char *e = getenv("SNN_AMD_CSR_XCD_BANDS")) net->csr_xcd_bands = (e[0] != '0');
     if (const char *e = getenv("SNN_AMD_HALO_DIRECT")) net->halo_direct = (e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1;
     if (const char *e = getenv("SNN_AMD_UPDATE_PACKS")) net->update_packs = (e[0] != '0');
+    if (const char *e = getenv("SNN_AMD_UPDATE_ALL_PLANES")) net->update_all_planes = (e[0] != '0');
     if (const char *e = getenv("SNN_AMD_CELLS_IN_STEP")) net->cells_in_step = (e[0] != '0');
     if (const char *e = getenv("SNN_AMD_DEFER_RSTDP")) net->defer_rstdp = (e[0] != '0');
     if (const char *e = getenv("SNN_AMD_DEFER_STDP")) net->defer_stdp = (e[0] == '2') ? 2 : (e[0] != '0');
@@ -1675,6 +1676,7 @@ int snn_set_option(snn_network_t *net, const char *name, int value)
     if (n == "fused_step") net->fused_step = value != 0;
     else if (n == "cells_in_step") net->cells_in_step = value != 0;
     else if (n == "update_packs") net->update_packs = value != 0;
+    else if (n == "update_all_planes") net->update_all_planes = value != 0;
     else if (n == "halo_direct") net->halo_direct = (value >= 0 && value <= 2) ? value : 1;
     else if (n == "halo_peer") net->halo_peer = value != 0;
     else if (n == "halo_peer_spin_limit") net->p2p_spin_limit = value > 0 ? (uint32_t)value : (1u << 26);

@@ -162,6 +162,7 @@ struct snn_network {
     bool send_bits_clean = true;          // every outgoing spike bitmap is zero (what the in-kernel pack ORs into)
     bool update_packed = false;           // this step's own slot of the all-gather buffer was written by k_update
     int update_packs = 1;                 // option "update_packs"
+    int update_all_planes = 1;            // option "update_all_planes"
     bool step_packed = false;             // this step's outgoing segments were written by k_step_csr itself
     bool interior_pending = false;        // the border half of this step is enqueued, the interior slices are not yet
     // Library-driven runs of such a handle (snn_run_sharded): the rows gather the halo from the received segments themselves

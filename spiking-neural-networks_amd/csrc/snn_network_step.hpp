@@ -282,19 +282,25 @@ int launch_update(snn_network *net)
     net->shadow_valid = false;            // the exchange buffer moves on without the shadows
     const uint32_t ub = 256u;          // (one wavefront per workgroup for small launches was measured: no gain)
     dim3 grid((net->ld + ub - 1) / ub);
+    // built-in models on dense handles with chemical synapses: the partials of every plane requested together
+    const bool all_planes = net->update_all_planes && net->chemical && !net->csr && net->model != SNN_MODEL_CUSTOM;
+#define SNN_LAUNCH_UPDATE(M) do { \
+        if (all_planes) hipLaunchKernelGGL((k_update<M, true>), grid, dim3(ub), 0, net->stream, a); \
+        else hipLaunchKernelGGL((k_update<M, false>), grid, dim3(ub), 0, net->stream, a); } while (0)
     switch (net->model) {
-    case SNN_MODEL_LIF: hipLaunchKernelGGL((k_update<1>), grid, dim3(ub), 0, net->stream, a); break;
-    case SNN_MODEL_HODGKIN_HUXLEY: hipLaunchKernelGGL((k_update<2>), grid, dim3(ub), 0, net->stream, a); break;
-    case SNN_MODEL_QUADRATIC_INTEGRATE_AND_FIRE: hipLaunchKernelGGL((k_update<3>), grid, dim3(ub), 0, net->stream, a); break;
-    case SNN_MODEL_SIMPLE_LIF: hipLaunchKernelGGL((k_update<4>), grid, dim3(ub), 0, net->stream, a); break;
-    case SNN_MODEL_ADAPTIVE_LIF: hipLaunchKernelGGL((k_update<5>), grid, dim3(ub), 0, net->stream, a); break;
-    case SNN_MODEL_ADAPTIVE_EXP_LIF: hipLaunchKernelGGL((k_update<6>), grid, dim3(ub), 0, net->stream, a); break;
-    case SNN_MODEL_LEAKY_IZHIKEVICH: hipLaunchKernelGGL((k_update<7>), grid, dim3(ub), 0, net->stream, a); break;
+    case SNN_MODEL_LIF: SNN_LAUNCH_UPDATE(1); break;
+    case SNN_MODEL_HODGKIN_HUXLEY: SNN_LAUNCH_UPDATE(2); break;
+    case SNN_MODEL_QUADRATIC_INTEGRATE_AND_FIRE: SNN_LAUNCH_UPDATE(3); break;
+    case SNN_MODEL_SIMPLE_LIF: SNN_LAUNCH_UPDATE(4); break;
+    case SNN_MODEL_ADAPTIVE_LIF: SNN_LAUNCH_UPDATE(5); break;
+    case SNN_MODEL_ADAPTIVE_EXP_LIF: SNN_LAUNCH_UPDATE(6); break;
+    case SNN_MODEL_LEAKY_IZHIKEVICH: SNN_LAUNCH_UPDATE(7); break;
 #if SNN_HAVE_CUSTOM_NEURON
-    case SNN_MODEL_CUSTOM: hipLaunchKernelGGL((k_update<CUSTOM_MODEL>), grid, dim3(ub), 0, net->stream, a); break;
+    case SNN_MODEL_CUSTOM: hipLaunchKernelGGL((k_update<CUSTOM_MODEL, false>), grid, dim3(ub), 0, net->stream, a); break;
 #endif
-    default: hipLaunchKernelGGL((k_update<0>), grid, dim3(ub), 0, net->stream, a); break;
+    default: SNN_LAUNCH_UPDATE(0); break;
     }
+#undef SNN_LAUNCH_UPDATE
     HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
     return SNN_OK;
 }
