@@ -611,11 +611,19 @@ __device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, Res
 
         // (2) the canonical chunk sums, the wavefronts of a chunk in turn
         const float vq = cols_in_rows ? sh.v[(ql - group_row0) & (RUN_RESIDENT_GROUP_ROWS - 1u)] : sh.vcol[lane];
+        // With chemical synapses the chains of a wavefront are STAGGERED over the slots: slot t = its gap-junction chain's turn,
+        // slot t + 1 + j its chain of live type j -- while the next wavefront of the chunk (another SIMD) already sums its
+        // gap-junction rows.  The hand-over of every chain still runs turn 0 -> 3, one barrier apart; 4 + n_live slots instead
+        // of 4 x (1 + n_live) chains one after the other.
+        // (the variants that also carry spike-train cells have no register to spare for it: their chains stay in one slot)
+        constexpr bool STAGGER = CHEM && !CELLS;
+        const uint32_t chem_off = (STAGGER && a.up.electrical) ? 1u : 0u;
+        const uint32_t n_slots = STAGGER ? n_turns + chem_off + n_live - 1u : n_turns;
 #pragma unroll 1
-        for (uint32_t t = 0; t < n_turns; ++t) {
-            if (t == turn && rows_live) {
-              if (!CHEM || a.up.electrical) {
-                float acc = (t != 0) ? sh.hand[chunk_local][lane] : 0.0f;
+        for (uint32_t t = 0; t < n_slots; ++t) {
+            if (rows_live) {
+              if (t == turn && (!CHEM || a.up.electrical)) {
+                float acc = (turn != 0) ? sh.hand[chunk_local][lane] : 0.0f;
                 // wave-uniform address = LDS broadcast; the offset is laundered through a vector register so that the values
                 // stay in vector registers (as scalars every one of them costs a v_readlane plus its wait states)
                 uint32_t zero;
@@ -820,8 +828,10 @@ __device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, Res
                 // weighted transmitter concentrations (weight_neurotransmitter_concentration, iterate_and_spike/mod.rs:2837-2866): per live
                 // type the same ascending chain over this wavefront's rows, t * w, the running sum handed on through LDS
 #pragma unroll 1
-                for (uint32_t j = 0; j < n_live; ++j) {
-                    float acc_t = (t != 0) ? sh.hand_t[j][chunk_local][lane] : 0.0f;
+                for (uint32_t jj = 0; jj < (STAGGER ? 1u : n_live); ++jj) {
+                    const uint32_t j = STAGGER ? t - turn - chem_off : jj;   // the live type this wavefront sums in this slot
+                    if (STAGGER ? j >= n_live : t != turn) continue;         // (wraps when it is none)
+                    float acc_t = (turn != 0) ? sh.hand_t[j][chunk_local][lane] : 0.0f;
                     uint32_t zero;
                     asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
                     const v4f *tp = reinterpret_cast<const v4f *>(sh.t[j] + (row0 - group_row0) + zero);
