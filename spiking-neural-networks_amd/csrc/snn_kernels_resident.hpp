@@ -279,7 +279,17 @@ struct ResidentRunArgs {
     // chemical synapses (CHEM variants): the transmitter types some neuron releases, ascending; a neuron's concentration of a
     // type it does not release travels as 0 (the presence test of the canonical sum becomes a zero product)
     uint32_t n_live, live_type[K_TYPES];
+    // STDP inside the run (STDP variants: electrical synapses, neurons only, one row group): the rule per lattice
+    // ([n_lattices][PL_STRIDE], at most RUN_STDP_MAX_LATTICES), who is plastic, the lattice of every neuron, and where the
+    // workgroups leave their weights when the run has completed (the layout of W; the host copies it over W on success, so a
+    // run that gives up leaves W as it was)
+    const float *stdp_table;
+    const uint32_t *stdp_on;
+    const uint32_t *stdp_lattice;
+    uint32_t stdp_lattices;
+    float *w_out;
 };
+constexpr uint32_t RUN_STDP_MAX_LATTICES = 4;
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
@@ -322,6 +332,13 @@ struct ResidentRunShared {
     float chem_par[25][64];
     float chem_state[9][64];                     // ... and their state: r, current, t of type k at 3 * k ..
     uint32_t chem_cnt[K_TYPES][64];              // ... and the receptor's input count per type
+    // STDP variants (no cells: the rows' arrays of the cells serve -- cell_s: the column deltas of the lattice in hand, cell_f:
+    // every row's last firing time (int32 bits), kind: 1 where a plastic row spiked in the previous step): the rule of each
+    // column's lattice, the table of all rules, per lattice the columns of this tile that belong to it, the plastic columns that
+    // spiked in the previous step, per wavefront whether one of its polled rows spiked
+    float stdp_par[5][64];
+    float stdp_tab[RUN_STDP_MAX_LATTICES][PL_STRIDE];
+    uint32_t stdp_latmask[RUN_STDP_MAX_LATTICES][2], stdp_colmask[2], stdp_any[16];
     // networks with cells: per row of the workgroup, its kind and this step's (s, f) of a row (see the step loop) and n: 1 for a
     // neuron's row, 0 for a cell's
     float cell_s[RUN_RESIDENT_GROUP_ROWS], cell_f[RUN_RESIDENT_GROUP_ROWS];
@@ -346,7 +363,7 @@ static_assert(offsetof(ResidentRunShared, cell_n) <= 65536, "the arrays the chai
 // run (same expressions as update_neuron, integrate_and_fire/mod.rs:217-255); the other wavefronts keep 64 weights per lane
 // in registers.  Every wavefront of a workgroup passes the same workgroup barriers per step (one behind the polls, one per turn --
 // four, fewer for networks under 256 rows --; group 0 of a multi-group tile one more).
-template <int MODEL, bool UPDATER, bool REGISTERS, bool CELLS, bool CHEM>
+template <int MODEL, bool UPDATER, bool REGISTERS, bool CELLS, bool CHEM, bool STDP = false>
 __device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, ResidentRunShared &sh, const uint32_t wave)
 {
     const InputsArgs &in = a.in;
@@ -372,6 +389,7 @@ __device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, Res
 
     // this lane's 64 weights (quad-row units: 4 consecutive rows of one column per load); absent edge: weight 0
     float w[UPDATER ? 1 : 64];
+    uint32_t ex_lo = 0u, ex_hi = 0u;             // STDP: bit k = this lane's column has an edge from row row0 + k
     bool w_all_finite = true;
     const v4f *units = reinterpret_cast<const v4f *>(in.W) + (size_t)(row0 >> 2) * in.ld + ql;
     {
@@ -383,6 +401,7 @@ __device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, Res
 #pragma unroll
             for (uint32_t k = 0; k < 4; ++k) {
                 const bool edge = e[k] == e[k];
+                if (STDP && edge) { if (g < 8) ex_lo |= 1u << (4 * g + k); else ex_hi |= 1u << (4 * (g - 8) + k); }
                 e[k] = edge ? e[k] : 0.0f;
                 w_all_finite = w_all_finite && fabsf(e[k]) <= 3.0e38f;
                 if (!UPDATER) w[4 * g + k] = e[k];
@@ -492,6 +511,36 @@ __device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, Res
         sh.cell_spiking[tid] = a.cells.is_spiking[cell];
     }
 
+    // STDP inside the run: this thread's ROW (its last firing time, whether its lattice is plastic) and, for the wavefront
+    // that updates, this lane's COLUMN; the rule of every column's lattice and the table of all rules go to LDS
+    // (the row's two values live in LDS -- cell_f: last firing time, cell_n: 1 where the row's lattice is plastic -- the registers
+    // are the weights')
+    bool col_plastic = false;
+    uint32_t spk_mine = 0u;                      // alone: whether this lane's neuron spiked in the previous step (wavefront 0)
+    if (STDP) {
+        int32_t lft_row = -1;
+        bool row_plastic = false;
+        if (my_row < n_neurons) {
+            lft_row = a.up.n.last_firing_time[my_row];
+            row_plastic = a.stdp_on[a.stdp_lattice[my_row]] != 0u;
+        }
+        reinterpret_cast<int32_t *>(sh.cell_f)[tid] = lft_row;
+        sh.cell_n[tid] = row_plastic ? 1.0f : 0.0f;
+        sh.kind[tid] = 0u;
+        if (tid < a.stdp_lattices * (uint32_t)PL_STRIDE) (&sh.stdp_tab[0][0])[tid] = a.stdp_table[tid];
+        const uint32_t lat = col ? a.stdp_lattice[in.q0 + ql] : 0u;
+        col_plastic = col && a.stdp_on[lat] != 0u;
+        if (wave == 1u || alone) {
+#pragma unroll
+            for (int i = 0; i < 5; ++i) sh.stdp_par[i][lane] = a.stdp_table[(size_t)lat * PL_STRIDE + i];
+            for (uint32_t l = 0; l < a.stdp_lattices; ++l) {
+                const unsigned long long m = __ballot(col && lat == l);
+                if (lane == 0) { sh.stdp_latmask[l][0] = (uint32_t)m; sh.stdp_latmask[l][1] = (uint32_t)(m >> 32); }
+            }
+        }
+        if (tid == 0) { sh.stdp_colmask[0] = 0u; sh.stdp_colmask[1] = 0u; }
+    }
+
     unsigned long long spent[4] = {0, 0, 0, 0}, mark = a.timing ? clock64() : 0;
     auto lap = [&](int phase) {
         if (!UPDATER || !a.timing) return;
@@ -504,6 +553,7 @@ __device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, Res
     };
 
     const uint32_t tid_outer = tid;
+    bool completed = true;                       // (a poll that gives up ends the loop early: the weights then stay where they are)
     for (uint32_t s = 0; s < steps; ++s) {
         // What a step derives from the thread's index is derived again in every step (the index passes through an opaque
         // instruction): kept across the loop, these values and the 64-bit addresses built on them cost the registers the
@@ -532,7 +582,9 @@ __device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, Res
         float v = 0.0f, v_col = 0.0f;
         float tv[K_TYPES] = {0.0f, 0.0f, 0.0f};      // CHEM: this row's concentrations, by live slot
         bool arrived = true;
+        uint32_t spk_row = 0u;                       // STDP: this thread's row spiked in the previous step
         if (alone && s != 0) {
+            if (STDP && UPDATER) spk_row = spk_mine;
             // a lattice of <= 64 neurons is ONE workgroup: wavefront 0 left the new voltages in sh.v itself (below), nothing
             // travels through memory; it also knows whether they are all small finite numbers
             v = UPDATER ? v_mine : 0.0f;
@@ -560,6 +612,16 @@ __device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, Res
                     for (uint32_t j = 0; j < K_TYPES; ++j)
                         if (j < n_live) tv[j] = __uint_as_float((uint32_t)x[1 + j]);
                 }
+            } else if (STDP && my_row < n_neurons) {
+                // bit 31 of the tag word: the neuron spiked in the step that produced this voltage
+                unsigned long long x;
+                uint32_t spins = 0;
+                do {
+                    x = __hip_atomic_load(slot + my_row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } while (((uint32_t)(x >> 32) & 0x7FFFFFFFu) != tag && ++spins < a.spin_limit);
+                arrived = arrived && ((uint32_t)(x >> 32) & 0x7FFFFFFFu) == tag;
+                spk_row = (uint32_t)(x >> 63);
+                v = __uint_as_float((uint32_t)x);
             } else if (my_row < n_neurons) {
                 v = poll(slot + my_row, arrived);
             }
@@ -599,15 +661,90 @@ __device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, Res
         }
         lap(0);
         if (!cols_in_rows && wave == 1) sh.vcol[lane] = v_col;
+        if (STDP && s != 0u) {
+            if (spk_row) reinterpret_cast<int32_t *>(sh.cell_f)[tid] = (int32_t)(a.up.clock + (long long)s - 1);
+            sh.kind[tid] = (spk_row && sh.cell_n[tid] != 0.0f) ? 1u : 0u;
+        }
         const bool all_arrived = __all(arrived), all_plain = __all(fabsf(v) <= 1e15f && fabsf(v_col) <= 1e15f && gq_small &&
                                                                    (!CHEM || (fabsf(tv[0]) <= 1e15f && fabsf(tv[1]) <= 1e15f && fabsf(tv[2]) <= 1e15f)));
         if (lane == 0) { sh.ok[wave] = all_arrived; sh.plain[wave] = all_plain; }
         __syncthreads();
         const uint32_t flag_ok = sh.ok[lane & 15u], flag_plain = sh.plain[lane & 15u];
-        if (!__all(flag_ok != 0) || *const_cast<volatile uint32_t *>(&sh.gave_up)) break;   // workgroup-uniform: some poll gave up
+        if (!__all(flag_ok != 0) || *const_cast<volatile uint32_t *>(&sh.gave_up)) { completed = false; break; }   // workgroup-uniform: some poll gave up
         const bool plain = __all(flag_plain != 0);
         const bool plain_t = CHEM && plain && __all(sh.w_finite[lane & 15u] != 0u);
         lap(1);
+
+        // (1b) STDP of the previous step (the deferred form, as k_spike_compact + k_stdp_columns + k_stdp_rows leave it): for
+        // every plastic neuron j that spiked, the incoming edges p -> j gain delta(last_firing_time[p], now) under the rule of
+        // j's lattice, then the outgoing edges j -> r gain delta(now, last_firing_time[r]) under the rule of r's lattice
+        // (plasticity/mod.rs:45-66, neuron/mod.rs:2308-2417); the weights are this workgroup's registers / LDS.
+        if (STDP && s != 0u) {
+            const int32_t t_now = (int32_t)(a.up.clock + (long long)s - 1);
+            uint32_t zero;
+            asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
+            auto exists = [&](uint32_t k) { return ((k < 32u ? ex_lo >> k : ex_hi >> (k - 32u)) & 1u) != 0u; };
+            const uint32_t cm0 = __builtin_amdgcn_readfirstlane(sh.stdp_colmask[0]), cm1 = __builtin_amdgcn_readfirstlane(sh.stdp_colmask[1]);
+            if ((cm0 | cm1) != 0u) {                                   // workgroup-uniform: a plastic column of this tile spiked
+                for (uint32_t l = 0; l < a.stdp_lattices; ++l) {
+                    const uint32_t m0 = cm0 & __builtin_amdgcn_readfirstlane(sh.stdp_latmask[l][0]);
+                    const uint32_t m1 = cm1 & __builtin_amdgcn_readfirstlane(sh.stdp_latmask[l][1]);
+                    if ((m0 | m1) == 0u) continue;
+                    // the column deltas of lattice l: one per row, computed by the row's thread
+                    sh.cell_s[tid] = stdp_delta(reinterpret_cast<const int32_t *>(sh.cell_f)[tid], t_now, sh.stdp_tab[l][0], sh.stdp_tab[l][1], sh.stdp_tab[l][2], sh.stdp_tab[l][3], sh.stdp_tab[l][4]);
+                    __syncthreads();
+                    const bool mine = ((lane < 32u ? m0 >> lane : m1 >> (lane - 32u)) & 1u) != 0u;
+                    if (rows_live) {
+                        const v4f *dc = reinterpret_cast<const v4f *>(sh.cell_s + (row0 - group_row0) + zero);
+#pragma unroll
+                        for (uint32_t g = 0; g < 16; ++g) {
+                            const v4f d = dc[g];
+                            const float dd[4] = {d.x, d.y, d.z, d.w};
+                            if (UPDATER) {
+                                v4f x = sh.w0[g][lane];
+                                float xx[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+                                for (uint32_t k = 0; k < 4; ++k) xx[k] = (mine && exists(4 * g + k)) ? xx[k] + dd[k] : xx[k];
+                                sh.w0[g][lane] = v4f{xx[0], xx[1], xx[2], xx[3]};
+                            } else {
+#pragma unroll
+                                for (uint32_t k = 0; k < 4; ++k) {
+                                    const uint32_t r = UPDATER ? 0u : 4 * g + k;
+                                    w[r] = (mine && exists(4 * g + k)) ? w[r] + dd[k] : w[r];
+                                }
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                    __syncthreads();                                    // the deltas are done with (another lattice may follow)
+                }
+            }
+            if (rows_live) {
+                const unsigned long long rm = __ballot(sh.kind[(row0 - group_row0) + lane] != 0u);    // my rows that spiked (plastic)
+                if (rm != 0ull) {
+                    const int32_t lft_col = reinterpret_cast<const int32_t *>(sh.cell_f)[(ql - group_row0) & (RUN_RESIDENT_GROUP_ROWS - 1u)];
+                    const float drow = stdp_delta(t_now, lft_col, sh.stdp_par[0][lane], sh.stdp_par[1][lane], sh.stdp_par[2][lane],
+                                                  sh.stdp_par[3][lane], sh.stdp_par[4][lane]);
+#pragma unroll
+                    for (uint32_t g = 0; g < 16; ++g) {
+                        if (((rm >> (4 * g)) & 0xFull) == 0ull) continue;                              // wave-uniform
+                        if (UPDATER) {
+                            v4f x = sh.w0[g][lane];
+                            float xx[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+                            for (uint32_t k = 0; k < 4; ++k) xx[k] = (((rm >> (4 * g + k)) & 1ull) != 0ull && exists(4 * g + k)) ? xx[k] + drow : xx[k];
+                            sh.w0[g][lane] = v4f{xx[0], xx[1], xx[2], xx[3]};
+                        } else {
+#pragma unroll
+                            for (uint32_t k = 0; k < 4; ++k) {
+                                const uint32_t r = UPDATER ? 0u : 4 * g + k;
+                                if ((rm >> (4 * g + k)) & 1ull) w[r] = exists(4 * g + k) ? w[r] + drow : w[r];
+                            }
+                        }
+                    }
+                }
+            }
+        }
 
         // (2) the canonical chunk sums, the wavefronts of a chunk in turn
         const float vq = cols_in_rows ? sh.v[(ql - group_row0) & (RUN_RESIDENT_GROUP_ROWS - 1u)] : sh.vcol[lane];
@@ -1057,6 +1194,12 @@ __device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, Res
                         t_out[j] = (my_nt_mask >> type & 1u) ? tt : 0.0f;
                     }
             }
+            if (STDP) {
+                // the plastic columns of this tile that spiked now: next step's column updates (read behind its first barrier)
+                const unsigned long long cm = __ballot(spike != 0u && col_plastic);
+                if (lane == 0) { sh.stdp_colmask[0] = (uint32_t)cm; sh.stdp_colmask[1] = (uint32_t)(cm >> 32); }
+                spk_mine = spike;
+            }
             if (alone) {
                 v_mine = col ? v_new : 0.0f;
                 if (col) sh.v[ql] = v_new;                    // read behind the next step's first barrier
@@ -1069,7 +1212,8 @@ __device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, Res
                 }
             } else if (col && s + 1 < steps && !(a.fault_step == s + 1u && blockIdx.x == 0u)) {
                 unsigned long long *g = a.granules + (size_t)((s + 1) & 1u) * RUN_GRANULE_PLANES * RUN_RESIDENT_MAX_NEURONS + in.q0 + ql;
-                const unsigned long long x = ((unsigned long long)(tag_base + s + 1) << 32) | __float_as_uint(v_new);
+                const uint32_t tag_word = (tag_base + s + 1) | ((STDP && spike) ? 0x80000000u : 0u);
+                const unsigned long long x = ((unsigned long long)tag_word << 32) | __float_as_uint(v_new);
                 __hip_atomic_store(g, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (CHEM) {
 #pragma unroll
@@ -1081,6 +1225,25 @@ __device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, Res
                 }
             }
             lap(3);
+        }
+    }
+
+    if (STDP && completed && rows_live) {
+        // the weights as the run leaves them (the updates of its last step's spikes are the host's: the plain kernels), absent
+        // edges as the NaN they are in W; every lane writes, padding columns included (they hold what was loaded)
+        v4f *out = reinterpret_cast<v4f *>(a.w_out) + (size_t)(row0 >> 2) * in.ld + ql;
+#pragma unroll
+        for (uint32_t g = 0; g < 16; ++g) {
+            if (row0 + 4 * g >= n_tot) continue;
+            float e[4];
+            if (UPDATER) { const v4f x = sh.w0[g][lane]; e[0] = x.x; e[1] = x.y; e[2] = x.z; e[3] = x.w; }
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k) {
+                const float val = UPDATER ? e[k] : w[UPDATER ? 0 : 4 * g + k];
+                const bool edge = ((4 * g + k < 32u ? ex_lo >> (4 * g + k) : ex_hi >> (4 * g + k - 32u)) & 1u) != 0u;
+                e[k] = edge ? val : quiet_nan();
+            }
+            out[(size_t)g * in.ld] = v4f{e[0], e[1], e[2], e[3]};
         }
     }
 
@@ -1133,15 +1296,16 @@ __global__ __launch_bounds__(1024) void k_run_resident_probe(uint32_t *counter, 
     if (footprint.ok[0] == 0u) *counter = 0u;   // never: keeps the LDS footprint alive
 }
 
-template <int MODEL, bool REGISTERS, bool CELLS, bool CHEM = false>
+template <int MODEL, bool REGISTERS, bool CELLS, bool CHEM = false, bool STDP = false>
 __global__ __launch_bounds__(1024) void k_run_resident(const ResidentRunArgs args)
 {
     static_assert(!CHEM || !REGISTERS || MODEL == 0, "receptors in registers: Izhikevich only");
+    static_assert(!STDP || (!CELLS && !CHEM), "weight updates inside the run: electrical synapses, neurons only");
     __shared__ __attribute__((aligned(16))) ResidentRunShared sh;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (threadIdx.x == 0) sh.gave_up = 0u;                       // ordered before its first reader by the first step's barrier
-    if (wave == 0) run_resident_steps<MODEL, true, REGISTERS, CELLS, CHEM>(args, sh, wave);
-    else run_resident_steps<MODEL, false, REGISTERS, CELLS, CHEM>(args, sh, wave);
+    if (wave == 0) run_resident_steps<MODEL, true, REGISTERS, CELLS, CHEM, STDP>(args, sh, wave);
+    else run_resident_steps<MODEL, false, REGISTERS, CELLS, CHEM, STDP>(args, sh, wave);
     // a poll that gave up ended the loop early everywhere in the workgroup
     if (threadIdx.x == 0) {
         bool failed = false;

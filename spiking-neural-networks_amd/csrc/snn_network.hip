@@ -199,9 +199,9 @@ static int finalize_impl(snn_network_t *net, int kind, uint32_t post_begin, uint
         if (blocks.empty()) { blocks.push_back(0); masks.push_back(0ull); }
         net->q0 = 0; net->q1 = 0;
         net->n_loc = (uint32_t)blocks.size() * 64u;
-        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&net->own_block_dev), blocks.size() * 4), SNN_ERR_BUFFER_CREATE);
-        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&net->own_mask_dev), masks.size() * 8), SNN_ERR_BUFFER_CREATE);
-        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&net->local_row_dev), (size_t)net->n_pad * 4), SNN_ERR_BUFFER_CREATE);
+        HIP_TRY(snn_malloc(&net->own_block_dev, blocks.size() * 4), SNN_ERR_BUFFER_CREATE);
+        HIP_TRY(snn_malloc(&net->own_mask_dev, masks.size() * 8), SNN_ERR_BUFFER_CREATE);
+        HIP_TRY(snn_malloc(&net->local_row_dev, (size_t)net->n_pad * 4), SNN_ERR_BUFFER_CREATE);
         HIP_TRY(hipMemcpy(net->own_block_dev, blocks.data(), blocks.size() * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
         HIP_TRY(hipMemcpy(net->own_mask_dev, masks.data(), masks.size() * 8, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
         HIP_TRY(hipMemcpy(net->local_row_dev, net->local_row_host.data(), (size_t)net->n_pad * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
@@ -419,7 +419,7 @@ static int set_graph_csr_impl(snn_network_t *net, const uint64_t *row_ptr, const
         *p = nullptr;
     }
     auto up = [&](void **dst, const void *src, size_t bytes) -> int {
-        HIP_TRY(hipMalloc(dst, std::max<size_t>(bytes, 256)), SNN_ERR_BUFFER_CREATE);
+        HIP_TRY(snn_malloc(dst, std::max<size_t>(bytes, 256)), SNN_ERR_BUFFER_CREATE);
         if (bytes) HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
         return SNN_OK;
     };
@@ -431,7 +431,7 @@ static int set_graph_csr_impl(snn_network_t *net, const uint64_t *row_ptr, const
     TRY(up((void **)&net->csr_post, post.data(), nnz * 4));
     TRY(up((void **)&net->csr_t_ptr, t_ptr.data(), t_ptr.size() * 4));
     TRY(up((void **)&net->csr_t_edge, t_edge.data(), nnz * 4));
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&net->csr_plan), std::max<size_t>(entries * 4, 256)), SNN_ERR_BUFFER_CREATE);
+    HIP_TRY(snn_malloc(&net->csr_plan, std::max<size_t>(entries * 4, 256)), SNN_ERR_BUFFER_CREATE);
     if (net->trace) { (void)hipFree(net->trace); net->trace = nullptr; }      // traces belong to the replaced edges
     net->nnz = nnz;
     net->sell_entries = entries;
@@ -681,9 +681,9 @@ int ensure_pending(snn_network *net)
 {
     if (net->pending) return SNN_OK;
     const size_t n = std::max<size_t>(wcount(net->n_tot, net->ld), 64);
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&net->pending), n * 4), SNN_ERR_BUFFER_CREATE);
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&net->edge_counter), n * 4), SNN_ERR_BUFFER_CREATE);
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&net->cross_bad), 256), SNN_ERR_BUFFER_CREATE);
+    HIP_TRY(snn_malloc(&net->pending, n * 4), SNN_ERR_BUFFER_CREATE);
+    HIP_TRY(snn_malloc(&net->edge_counter, n * 4), SNN_ERR_BUFFER_CREATE);
+    HIP_TRY(snn_malloc(&net->cross_bad, 256), SNN_ERR_BUFFER_CREATE);
     HIP_TRY(hipMemsetAsync(net->pending, 0, n * 4, net->stream), SNN_ERR_BUFFER_WRITE);
     HIP_TRY(hipMemsetAsync(net->edge_counter, 0, n * 4, net->stream), SNN_ERR_BUFFER_WRITE);
     HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
@@ -709,7 +709,7 @@ static int trace_rows_io(snn_network_t *net, uint32_t pre_begin, uint32_t pre_co
     float *host = traces + net->q0;
     const uint32_t hop = (uint32_t)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(pre_count, 32768), ((size_t)64 << 20) / ((size_t)net->n_loc * 4)));
     float *stage = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&stage), (size_t)hop * net->n_loc * 4), SNN_ERR_BUFFER_CREATE);
+    HIP_TRY(snn_malloc(&stage, (size_t)hop * net->n_loc * 4), SNN_ERR_BUFFER_CREATE);
     int rc = SNN_OK;
     for (uint32_t r = 0; r < pre_count && rc == SNN_OK; r += hop) {
         const uint32_t rows = std::min(hop, pre_count - r);
@@ -771,7 +771,7 @@ int snn_set_connection_kind(snn_network_t *net, uint32_t pre_id, uint32_t post_i
     TRY(end_run(net));
     if (net->conn_kind_host.empty()) {
         net->conn_kind_host.assign((nl + ns) * nl, 0);
-        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&net->conn_kind_dev), std::max<size_t>((nl + ns) * nl, 256)), SNN_ERR_BUFFER_CREATE);
+        HIP_TRY(snn_malloc(&net->conn_kind_dev, std::max<size_t>((nl + ns) * nl, 256)), SNN_ERR_BUFFER_CREATE);
     }
     const size_t source = pre->spike_train ? nl + pre->slot : pre->slot;
     net->conn_kind_host[source * nl + post->slot] = (uint8_t)kind;
@@ -861,7 +861,7 @@ int snn_set_firing_times(snn_network_t *net, uint32_t id, const uint32_t *cell_p
     }
     for (size_t s = net->nc; s <= net->c_pad; ++s) ptr[s] = (uint32_t)flat.size();
     float *nt = nullptr;
-    HIP_TRY(hipMalloc(&nt, std::max<size_t>(256, flat.size() * 4)), SNN_ERR_BUFFER_CREATE);
+    HIP_TRY(snn_malloc(&nt, std::max<size_t>(256, flat.size() * 4)), SNN_ERR_BUFFER_CREATE);
     if (!flat.empty()) HIP_TRY(hipMemcpy(nt, flat.data(), flat.size() * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
     HIP_TRY(hipMemcpy(const_cast<uint32_t *>(net->ca.preset_ptr), ptr.data(), ptr.size() * 4, hipMemcpyHostToDevice),
             SNN_ERR_BUFFER_WRITE);
@@ -1292,7 +1292,7 @@ int snn_comm_exchange_halo_lists(snn_network_t *net, void *nccl_comm)
     std::vector<uint32_t> counts((size_t)G * G, 0);
     for (uint32_t p = 0; p < G; ++p) counts[(size_t)me * G + p] = (uint32_t)net->halo_need[p].size();
     uint32_t *d_counts = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_counts), counts.size() * 4), SNN_ERR_BUFFER_CREATE);
+    HIP_TRY(snn_malloc(&d_counts, counts.size() * 4), SNN_ERR_BUFFER_CREATE);
     int rc = SNN_OK;
     uint32_t *d_need = nullptr, *d_send = nullptr;
     auto cleanup = [&]() { (void)hipFree(d_counts); if (d_need) (void)hipFree(d_need); if (d_send) (void)hipFree(d_send); };
@@ -1310,8 +1310,8 @@ int snn_comm_exchange_halo_lists(snn_network_t *net, void *nccl_comm)
     }
     std::vector<uint32_t> need_flat(need_off[G]), send_flat(send_off[G]);
     for (uint32_t p = 0; p < G; ++p) std::copy(net->halo_need[p].begin(), net->halo_need[p].end(), need_flat.begin() + need_off[p]);
-    HALO_STEP(hip_ok(hipMalloc(reinterpret_cast<void **>(&d_need), std::max<size_t>(need_flat.size() * 4, 256)), SNN_ERR_BUFFER_CREATE, "hipMalloc"));
-    HALO_STEP(hip_ok(hipMalloc(reinterpret_cast<void **>(&d_send), std::max<size_t>(send_flat.size() * 4, 256)), SNN_ERR_BUFFER_CREATE, "hipMalloc"));
+    HALO_STEP(hip_ok(snn_malloc(&d_need, std::max<size_t>(need_flat.size() * 4, 256)), SNN_ERR_BUFFER_CREATE, "hipMalloc"));
+    HALO_STEP(hip_ok(snn_malloc(&d_send, std::max<size_t>(send_flat.size() * 4, 256)), SNN_ERR_BUFFER_CREATE, "hipMalloc"));
     if (!need_flat.empty())
         HALO_STEP(hip_ok(hipMemcpy(d_need, need_flat.data(), need_flat.size() * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE, "lists upload"));
     HALO_STEP(nccl_ok(R->GroupStart(), "ncclGroupStart"));
@@ -1478,7 +1478,7 @@ static int agree_on_exchange(Rccl *R, snn_network *net, ncclComm_t comm, void *n
 {
     const uint32_t G = net->n_shards, me = net->shard_index;
     uint32_t *d_words = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_words), std::max<size_t>((size_t)G * 4, 256)), SNN_ERR_BUFFER_CREATE);
+    HIP_TRY(snn_malloc(&d_words, std::max<size_t>((size_t)G * 4, 256)), SNN_ERR_BUFFER_CREATE);
     std::vector<uint32_t> words(G, 0);
     auto gather = [&](uint32_t mine) -> int {
         words.assign(G, 0);
@@ -1677,6 +1677,7 @@ int snn_set_option(snn_network_t *net, const char *name, int value)
     else if (n == "cells_in_step") net->cells_in_step = value != 0;
     else if (n == "update_packs") net->update_packs = value != 0;
     else if (n == "update_all_planes") net->update_all_planes = value != 0;
+    else if (n == "persistent_stdp") net->persistent_stdp = value != 0;
     else if (n == "halo_direct") net->halo_direct = (value >= 0 && value <= 2) ? value : 1;
     else if (n == "halo_peer") net->halo_peer = value != 0;
     else if (n == "halo_peer_spin_limit") net->p2p_spin_limit = value > 0 ? (uint32_t)value : (1u << 26);
@@ -1701,6 +1702,7 @@ int snn_get_stat(snn_network_t *net, const char *name, uint64_t *value)
     const std::string n(name);
     if (n == "persistent_run_launches") *value = net->stat_run_launches;
     else if (n == "persistent_run_steps") *value = net->stat_run_steps;
+    else if (n == "persistent_run_stdp_steps") *value = net->stat_run_stdp_steps;
     else if (n == "persistent_run_fallbacks") *value = net->stat_run_fallbacks;
     else if (n == "halo_direct_steps") *value = net->stat_direct_steps;
     else if (n == "halo_peer_steps") *value = net->stat_peer_steps;
@@ -1813,8 +1815,8 @@ int snn_probe_bandwidth(int device, uint64_t bytes, int repeats, double *read_gb
     const size_t n4 = bytes / 16;
     void *a = nullptr, *b = nullptr;
     float *sink = nullptr;
-    HIP_TRY(hipMalloc(&a, n4 * 16), SNN_ERR_BUFFER_CREATE);
-    if (hipMalloc(&b, n4 * 16) != hipSuccess || hipMalloc(reinterpret_cast<void **>(&sink), 256) != hipSuccess) {
+    HIP_TRY(snn_malloc(&a, n4 * 16), SNN_ERR_BUFFER_CREATE);
+    if (snn_malloc(&b, n4 * 16) != hipSuccess || snn_malloc(&sink, 256) != hipSuccess) {
         (void)hipFree(a);
         if (b) (void)hipFree(b);
         return fail(SNN_ERR_BUFFER_CREATE, "probe allocation failed");
@@ -1856,8 +1858,8 @@ int snn_probe_math(int device, int which, const float *in, float *out, size_t co
     HIP_TRY(hipSetDevice(device), SNN_ERR_GET_DEVICE);
     if (count == 0) return SNN_OK;
     float *di = nullptr, *dout = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&di), count * 4), SNN_ERR_BUFFER_CREATE);
-    if (hipMalloc(reinterpret_cast<void **>(&dout), count * 4) != hipSuccess) { (void)hipFree(di); return fail(SNN_ERR_BUFFER_CREATE, "hipMalloc failed"); }
+    HIP_TRY(snn_malloc(&di, count * 4), SNN_ERR_BUFFER_CREATE);
+    if (snn_malloc(&dout, count * 4) != hipSuccess) { (void)hipFree(di); return fail(SNN_ERR_BUFFER_CREATE, "hipMalloc failed"); }
     int rc = SNN_OK;
     if (hipMemcpy(di, in, count * 4, hipMemcpyHostToDevice) != hipSuccess) rc = fail(SNN_ERR_BUFFER_WRITE, "upload failed");
     if (rc == SNN_OK) {
@@ -1877,7 +1879,7 @@ int snn_probe_math_bits(int device, int which, uint32_t first, uint32_t stride, 
     HIP_TRY(hipSetDevice(device), SNN_ERR_GET_DEVICE);
     if (count == 0) return SNN_OK;
     float *dout = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dout), count * 4), SNN_ERR_BUFFER_CREATE);
+    HIP_TRY(snn_malloc(&dout, count * 4), SNN_ERR_BUFFER_CREATE);
     int rc = SNN_OK;
     hipLaunchKernelGGL(k_probe_math_bits, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, 0, which, first, stride, y, dout, count);
     if (hipDeviceSynchronize() != hipSuccess) rc = fail(SNN_ERR_WAIT, "probe kernel failed");

@@ -18,7 +18,7 @@ template <typename T>
 int upload_table(T **dev, const std::vector<T> &host)
 {
     if (*dev) { (void)hipFree(*dev); *dev = nullptr; }
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(dev), std::max<size_t>(host.size() * sizeof(T), 256)), SNN_ERR_BUFFER_CREATE);
+    HIP_TRY(snn_malloc(dev, std::max<size_t>(host.size() * sizeof(T), 256)), SNN_ERR_BUFFER_CREATE);
     if (!host.empty())
         HIP_TRY(hipMemcpy(*dev, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
     return SNN_OK;
@@ -172,12 +172,12 @@ int ensure_exchange_plan(snn_network *net)
                               (uint64_t)net->nn + net->nc + ro < PLAN_CODE && net->n_loc;
         for (uint32_t **b : {&net->halo_send_buf, net->direct_capable ? &net->halo_send_buf2 : nullptr}) {
             if (!b) continue;
-            HIP_TRY(hipMalloc(reinterpret_cast<void **>(b), std::max<uint64_t>(so * 4, 256)), SNN_ERR_BUFFER_CREATE);
+            HIP_TRY(snn_malloc(b, std::max<uint64_t>(so * 4, 256)), SNN_ERR_BUFFER_CREATE);
             HIP_TRY(hipMemset(*b, 0, std::max<uint64_t>(so * 4, 256)), SNN_ERR_BUFFER_WRITE);
         }
         for (uint32_t **b : {&net->halo_recv_buf, net->direct_capable ? &net->halo_recv_buf2 : nullptr}) {
             if (!b) continue;
-            HIP_TRY(hipMalloc(reinterpret_cast<void **>(b), std::max<uint64_t>(ro * 4, 256)), SNN_ERR_BUFFER_CREATE);
+            HIP_TRY(snn_malloc(b, std::max<uint64_t>(ro * 4, 256)), SNN_ERR_BUFFER_CREATE);
             HIP_TRY(hipMemset(*b, 0, std::max<uint64_t>(ro * 4, 256)), SNN_ERR_BUFFER_WRITE);
         }
         TRY(p2p_release(net));
@@ -193,7 +193,7 @@ int ensure_exchange_plan(snn_network *net)
             HIP_TRY(hipExtMallocWithFlags(reinterpret_cast<void **>(&net->p2p_flags), std::max<size_t>((size_t)G * 4, 256), hipDeviceMallocFinegrained),
                     SNN_ERR_BUFFER_CREATE);
             HIP_TRY(hipMemset(net->p2p_flags, 0, std::max<size_t>((size_t)G * 4, 256)), SNN_ERR_BUFFER_WRITE);
-            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&net->p2p_done_blocks), 256), SNN_ERR_BUFFER_CREATE);
+            HIP_TRY(snn_malloc(&net->p2p_done_blocks, 256), SNN_ERR_BUFFER_CREATE);
             HIP_TRY(hipMemset(net->p2p_done_blocks, 0, 256), SNN_ERR_BUFFER_WRITE);
             if (!net->p2p_failed) {
                 HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&net->p2p_failed), 8, hipHostMallocMapped), SNN_ERR_BUFFER_CREATE);
@@ -208,7 +208,7 @@ int ensure_exchange_plan(snn_network *net)
                 for (size_t i = 0; i < net->halo_need[p].size(); ++i)
                     halo_word[net->halo_need[p][i]] = (uint32_t)(net->x_recv_off[p] + i);       // plane 0 of the segment
             TRY(upload_table(&net->halo_word_dev, halo_word));
-            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&net->csr_plan_direct), std::max<size_t>(net->sell_entries * 4, 256)),
+            HIP_TRY(snn_malloc(&net->csr_plan_direct, std::max<size_t>(net->sell_entries * 4, 256)),
                     SNN_ERR_BUFFER_CREATE);
             hipLaunchKernelGGL(k_csr_plan, dim3((n_slices * 64 + 255) / 256), dim3(256), 0, net->stream, csr_graph(net),
                                net->csr_plan_direct, net->halo_word_dev, net->nn, net->nn + net->nc);

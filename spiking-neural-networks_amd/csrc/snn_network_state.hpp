@@ -250,6 +250,9 @@ struct snn_network {
     unsigned long long *run_granules = nullptr;
     unsigned long long *run_partials = nullptr;
     uint32_t run_tag = 1;
+    float *run_w_out = nullptr;           // STDP inside the one-launch run: where the workgroups leave their weights (layout of W)
+    int persistent_stdp = 1;              // option "persistent_stdp"
+    uint64_t stat_run_stdp_steps = 0;
     uint32_t *run_failed = nullptr;       // hipHostMalloc: [0] a run gave up, [1] the co-residency probe said no
     uint32_t run_probed_grid = 0;         // grid size the probe last vouched for
     uint64_t stat_run_launches = 0, stat_run_steps = 0, stat_run_fallbacks = 0;
@@ -347,6 +350,24 @@ namespace {
 // Big streamed arrays (the synapse matrix, the trace matrix).  SNN_AMD_CONTIGUOUS=1 asks for PHYSICALLY CONTIGUOUS memory
 // first (larger page-table fragments).  Off by default: it is not a uniform gain -- C3's input pass 164.4 against 171.3 us in
 // one call, 175.5 against 171.5 us in another, the reward-modulated pass 11.38 against 10.74 ms (profiles/experiments/README.md).
+// (alloc_streamed, below)
+// hipMalloc, and -- debugging aid, SNN_AMD_POISON=<hex word> (e.g. 7fc12345) -- every fresh allocation filled with that word
+// instead of what the allocator hands out (zeros in a young process, another handle's remains in an old one): a read of
+// memory nobody initialised then shows in EVERY run
+inline hipError_t poison_if_asked(void *p, size_t bytes)
+{
+    static const char *poison = getenv("SNN_AMD_POISON");
+    if (!poison || !p) return hipSuccess;
+    hipError_t e = hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(p), (int)strtoul(poison, nullptr, 16), bytes / 4);
+    return e != hipSuccess ? e : hipDeviceSynchronize();
+}
+template <typename T>
+inline hipError_t snn_malloc(T **out, size_t bytes)
+{
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(out), bytes);
+    return e != hipSuccess ? e : poison_if_asked(*out, bytes);
+}
+
 hipError_t alloc_streamed(void **out, size_t bytes)
 {
     static const bool contiguous = [] { const char *e = getenv("SNN_AMD_CONTIGUOUS"); return e && e[0] == '1'; }();
@@ -364,6 +385,7 @@ int dev_alloc(snn_network *net, void **out, size_t bytes)
     HIP_TRY(alloc_streamed(out, bytes), SNN_ERR_BUFFER_CREATE);
     net->allocs.push_back(*out);
     net->alloc_bytes[*out] = bytes;
+    HIP_TRY(poison_if_asked(*out, bytes), SNN_ERR_BUFFER_WRITE);
     return SNN_OK;
 }
 

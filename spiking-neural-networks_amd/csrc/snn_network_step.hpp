@@ -653,10 +653,23 @@ int launch_step_resident(snn_network *net)
 // (if any) Poisson or Rate without transmitters.  Electrical synapses: up to 4096 rows; with chemical synapses (built-in
 // kinetics): one row group, up to 1024 rows.
 bool run_resident_shape(const snn_network *net);
+bool run_resident_stdp_ok(const snn_network *net);
+int launch_plasticity(snn_network *net);
 bool run_resident_applies(const snn_network *net)
 {
     // the run's outcome is read after a host synchronisation (snn_run): not on a caller's stream
     return run_resident_shape(net) && !net->external_stream;
+}
+// STDP inside the run: electrical synapses, neurons only, one row group, at most four lattices, the STDP rule (no BCM), no
+// connection kinds of a reward-modulated network, the scatter form of the weight update (defer_stdp 0)
+bool run_resident_stdp_ok(const snn_network *net)
+{
+    if (!net->persistent_stdp || net->chemical || net->nc || net->n_tot > RUN_RESIDENT_GROUP_ROWS || net->any_conn_kind || net->defer_stdp ||
+        net->lattices.size() > RUN_STDP_MAX_LATTICES)
+        return false;
+    for (size_t l = 0; l < net->lattices.size(); ++l)
+        if (net->plast_host[l] && net->stdp_host[l * PL_STRIDE + 5] != 0.0f) return false;
+    return true;
 }
 bool run_resident_shape(const snn_network *net)
 {
@@ -666,7 +679,8 @@ bool run_resident_shape(const snn_network *net)
            net->persistent_run && net->n_loc == net->nn && net->nn + net->nc == net->n_tot &&
            (net->nc == 0 || ((net->st_kind == SNN_ST_POISSON || net->st_kind == SNN_ST_RATE) && !net->any_nt_cells &&
                              !net->cell_list_dev && !SNN_HAVE_CUSTOM_REFRACTORINESS)) &&
-           net->n_tot <= RUN_RESIDENT_MAX_NEURONS && (net->electrical || net->chemical) && chem_ok && !net->any_plasticity &&
+           net->n_tot <= RUN_RESIDENT_MAX_NEURONS && (net->electrical || net->chemical) && chem_ok &&
+           (!net->any_plasticity || run_resident_stdp_ok(net)) &&
            !net->any_modulation && !net->any_whist && !net->want_avg && !net->want_eeg && net->hist_every == 1 &&
            net->model != SNN_MODEL_BCM_IZHIKEVICH && !net->local_inputs_done;
 }
@@ -756,7 +770,7 @@ int launch_run_resident(snn_network *net, uint64_t iterations)
     }
     while (iterations) {
         const uint32_t steps = (uint32_t)std::min<uint64_t>(iterations, 1u << 20);
-        if (net->run_tag > 0xFFFFFFFFu - steps - 2u) {           // tags would wrap: start over on clean slots
+        if (net->run_tag > 0x7FFFFFFFu - steps - 2u) {           // tags would wrap (bit 31 carries a spike): start over on clean slots
             HIP_TRY(hipMemsetAsync(net->run_granules, 0, RUN_GRANULE_WORDS * 8, net->stream), SNN_ERR_BUFFER_WRITE);
             HIP_TRY(hipMemsetAsync(net->run_partials, 0, RUN_PARTIAL_WORDS * 8, net->stream), SNN_ERR_BUFFER_WRITE);
             net->run_tag = 1;
@@ -786,6 +800,13 @@ int launch_run_resident(snn_network *net, uint64_t iterations)
         if (net->chemical)
             for (uint32_t k = 0; k < K_TYPES; ++k)
                 if (net->live_mask_applied != 0xFFFFFFFFu && (net->live_mask_applied >> k & 1u)) r.live_type[r.n_live++] = k;
+        const bool stdp = net->any_plasticity;                  // (run_resident_shape let it through: run_resident_stdp_ok)
+        if (stdp) {
+            if (!net->run_w_out) TRY(dev_alloc_t(net, &net->run_w_out, wcount(net->n_tot, net->ld)));
+            r.stdp_table = net->stdp_dev; r.stdp_on = net->plast_dev; r.stdp_lattice = net->lattice_slot;
+            r.stdp_lattices = (uint32_t)net->lattices.size();
+            r.w_out = net->run_w_out;
+        }
         hipLaunchKernelGGL(k_run_resident_seed, dim3((net->nn + 255) / 256), dim3(256), 0, net->stream, net->xbuf, net->xl,
                            net->nn, net->run_granules, r.tag_base, net->na.nt_flags, net->n_pad, r.n_live, r.live_type[0],
                            r.live_type[1], r.live_type[2]);
@@ -799,10 +820,15 @@ int launch_run_resident(snn_network *net, uint64_t iterations)
 #define SNN_RUN_RESIDENT_CELLS(M) hipLaunchKernelGGL((k_run_resident<M, false, true>), grid, block, 0, net->stream, r)
 #define SNN_RUN_RESIDENT_CHEM(M) hipLaunchKernelGGL((k_run_resident<M, false, false, true>), grid, block, 0, net->stream, r)
 #define SNN_RUN_RESIDENT_CHEM_CELLS(M) hipLaunchKernelGGL((k_run_resident<M, false, true, true>), grid, block, 0, net->stream, r)
+#define SNN_RUN_RESIDENT_STDP(M) hipLaunchKernelGGL((k_run_resident<M, false, false, false, true>), grid, block, 0, net->stream, r)
 #if !SNN_HAVE_CUSTOM_MODEL
         // neuron state in registers for the whole run where the kernel carries the model's update itself
         const bool regs = !r.up.has_nt && !r.up.bcm && !net->chemical;
-        if (net->chemical && net->nc) {                                            // chemical synapses: the generic update
+        if (stdp && regs && net->model == SNN_MODEL_IZHIKEVICH) {                  // weight updates inside the run
+            hipLaunchKernelGGL((k_run_resident<0, true, false, false, true>), grid, block, 0, net->stream, r);
+        } else if (stdp) {
+            SNN_FOR_MODEL(SNN_RUN_RESIDENT_STDP);
+        } else if (net->chemical && net->nc) {                                     // chemical synapses: the generic update
             SNN_FOR_MODEL(SNN_RUN_RESIDENT_CHEM_CELLS);
         } else if (net->chemical && net->model == SNN_MODEL_IZHIKEVICH) {          // ... Izhikevich: receptors and transmitters resident too
             hipLaunchKernelGGL((k_run_resident<0, true, false, true>), grid, block, 0, net->stream, r);
@@ -836,6 +862,7 @@ int launch_run_resident(snn_network *net, uint64_t iterations)
 #undef SNN_RUN_RESIDENT_CELLS
 #undef SNN_RUN_RESIDENT_CHEM
 #undef SNN_RUN_RESIDENT_CHEM_CELLS
+#undef SNN_RUN_RESIDENT_STDP
         HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
         if (e1) HIP_TRY(hipEventRecord(e1, net->stream), SNN_ERR_QUEUE);
         if (net->run_timing) {          // debugging aid: workgroup 0's phases in shader clocks per step
@@ -847,6 +874,19 @@ int launch_run_resident(snn_network *net, uint64_t iterations)
             for (unsigned b = 0; getenv("SNN_AMD_RUN_TIMING") && b < grid.x; b += (grid.x > 1 ? grid.x - 1 : 1))
                 fprintf(stderr, "k_run_resident workgroup %u: poll %.0f, barrier %.0f, turns %.0f, update+publish %.0f clocks/step (%u steps)\n",
                         b, (double)t[b * 4] / steps, (double)t[b * 4 + 1] / steps, (double)t[b * 4 + 2] / steps, (double)t[b * 4 + 3] / steps, steps);
+        }
+        if (stdp) {
+            // The workgroups applied the weight updates of every step but the last and left their weights in run_w_out -- unless
+            // the run gave up, in which case W is as it was and the caller rolls the handle back.  On success: W <- run_w_out, then
+            // the last step's updates with the plain kernels (they read the spike flags and firing times the run left).
+            HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
+            if (net->run_failed[0]) return SNN_OK;
+            HIP_TRY(hipMemcpyAsync(net->W, net->run_w_out, (size_t)4 * ((net->n_tot + 3) / 4) * net->ld * 4, hipMemcpyDeviceToDevice, net->stream),
+                    SNN_ERR_BUFFER_WRITE);
+            net->clock += steps - 1;
+            TRY(launch_plasticity(net));
+            net->clock -= steps - 1;
+            net->stat_run_stdp_steps += steps;
         }
         net->run_tag += steps;
         net->stat_run_launches += 1;
@@ -1112,7 +1152,7 @@ int grow_history(snn_network *net, uint64_t extra)
     auto regrow = [&](void **buf, size_t row_bytes, bool wanted) -> int {
         if (!wanted || row_bytes == 0) return SNN_OK;
         void *nb = nullptr;
-        HIP_TRY(hipMalloc(&nb, std::max<size_t>(256, cap * row_bytes)), SNN_ERR_BUFFER_CREATE);
+        HIP_TRY(snn_malloc(&nb, std::max<size_t>(256, cap * row_bytes)), SNN_ERR_BUFFER_CREATE);
         if (*buf && net->hist_steps)
             HIP_TRY(hipMemcpyAsync(nb, *buf, net->hist_steps * row_bytes, hipMemcpyDeviceToDevice, net->stream),
                     SNN_ERR_BUFFER_WRITE);
@@ -1217,8 +1257,8 @@ int graph_rows_io(snn_network *net, uint32_t pre_begin, uint32_t pre_count, floa
                                                                         (64u << 20) / (host_ld * 4)));
     float *dw = nullptr;
     uint32_t *dc = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dw), (size_t)hop * host_ld * 4), SNN_ERR_BUFFER_CREATE);
-    if (hipMalloc(reinterpret_cast<void **>(&dc), (size_t)hop * host_ld * 4) != hipSuccess) {
+    HIP_TRY(snn_malloc(&dw, (size_t)hop * host_ld * 4), SNN_ERR_BUFFER_CREATE);
+    if (snn_malloc(&dc, (size_t)hop * host_ld * 4) != hipSuccess) {
         (void)hipFree(dw);
         return fail(SNN_ERR_BUFFER_CREATE, "staging allocation failed");
     }
