@@ -482,9 +482,12 @@ int snn_get_spike_counts(snn_network_t *net, uint32_t id, uint32_t *dst, size_t 
  * [1] reward-modulated weight updates riding on the next input pass; "defer_stdp" [0] 1: STDP updates riding on the next
  * input pass, 2: prepared delta vectors applied by scatter passes; "uniform_params" [1] population-wide parameter
  * values from a device table; "persistent_run" [1] all steps of an snn_run call (of 4 steps or more) on a small
- * network -- neurons, with or without Poisson / Rate cells that release no transmitter; no plasticity; electrical synapses only:
- * <= 4096 rows; with chemical synapses (built-in kinetics): <= 1024 rows -- in ONE launch; "persistent_chem" [1] 0 keeps
- * networks with chemical synapses on the one-launch-per-step forms;
+ * network -- neurons, with or without Poisson / Rate cells that release no transmitter; electrical synapses only:
+ * <= 4096 rows; with chemical synapses (built-in kinetics): <= 1024 rows; with STDP (electrical synapses, neurons only,
+ * at most four lattices, "defer_stdp" 0): <= 1024 rows, the weights live in the workgroups' registers for the run and are
+ * committed to the matrix when it has completed -- in ONE launch; "persistent_chem" [1] / "persistent_stdp" [1]: 0 keeps
+ * networks with chemical synapses / with STDP on the one-launch-per-step forms
+ * (snn_get_stat "persistent_run_stdp_steps": steps whose weight updates ran inside such a launch);
  * "input_shape" [0] 1 | 2 forces the 4- / 2-columns-per-lane shape of the streamed dense input pass (0: chosen by size).
  * Unknown names fail with SNN_ERR_BAD_ARG.
  *

@@ -64,6 +64,8 @@ if [ -z "$ONLY" ]; then
 python3 profiles/measure_shard_shapes.py 200 > "$OUT/c2_shard_shapes.jsonl" 2> /dev/null
 # small lattices with chemical synapses: the one-launch run against one launch per step
 python3 profiles/measure_small_chem.py 3000 2> /dev/null | grep lattice > "$OUT/small_chemical_lattices.jsonl"
+# small plastic lattices: the STDP updates inside the one-launch run against one launch per step + the scatter kernels
+python3 profiles/measure_small_stdp.py 3000 2> /dev/null | grep lattice > "$OUT/small_stdp_lattices.jsonl"
 # the default lines (no profiler): headline, c1 with the latency roofline, c3, c5
 python3 bench.py > "$OUT/bench_default.json" 2> /dev/null
 python3 bench.py --config c1 --no-cpu-baseline > "$OUT/c1_bench_default.json" 2> /dev/null

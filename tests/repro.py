@@ -16,7 +16,7 @@ import numpy as np
 import parity
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-STATS = ("persistent_run_launches", "persistent_run_steps", "persistent_run_fallbacks", "halo_direct_steps",
+STATS = ("persistent_run_launches", "persistent_run_steps", "persistent_run_stdp_steps", "persistent_run_fallbacks", "halo_direct_steps",
          "steps_dense_one_launch", "steps_sparse_one_launch", "steps_sparse_split", "steps_two_kernel",
          "shadow_refreshes", "view_refreshes", "history_regrows")
 
