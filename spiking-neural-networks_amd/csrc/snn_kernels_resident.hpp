@@ -942,6 +942,24 @@ __device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, Res
                             load_batch(b + 1, vp, wr);
                         }
                     }
+                } else if (STDP) {
+                    // (as below, but the matrix in memory is stale while the run updates its weights: the resident weights and this
+                    // lane's existence bits instead)
+#pragma unroll
+                    for (uint32_t g = 0; g < 16; ++g) {
+                        if (row0 + 4 * g >= n_tot) continue;
+                        const v4f x = pre[g];
+                        const float e[4] = {x.x, x.y, x.z, x.w};
+                        float ww[4];
+                        if (UPDATER) { const v4f y = sh.w0[g][lane]; ww[0] = y.x; ww[1] = y.y; ww[2] = y.z; ww[3] = y.w; }
+#pragma unroll
+                        for (uint32_t j = 0; j < 4; ++j) {
+                            const float wj = UPDATER ? ww[j] : w[UPDATER ? 0 : 4 * g + j];
+                            const bool edge = ((4 * g + j < 32u ? ex_lo >> (4 * g + j) : ex_hi >> (4 * g + j - 32u)) & 1u) != 0u;
+                            const float p = term_of(KIND_NEURON, e[j]) * wj;
+                            acc += edge ? p : 0.0f;
+                        }
+                    }
                 } else {
                     // some voltage is huge, infinite or NaN: absent edges are skipped explicitly -- the weights come from the
                     // matrix again (cache resident), where an absent edge is the NaN sentinel

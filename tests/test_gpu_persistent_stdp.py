@@ -102,3 +102,11 @@ def test_networks_outside_its_reach_keep_one_launch_per_step(snn):
     net.run(50, voltage_history=True, spike_history=True)
     assert a["launches"] == 0
     check(net, a)
+
+
+@pytest.mark.parametrize("seed", [2008404, 2002804, 2008236])
+def test_voltages_that_leave_the_plain_range_use_the_resident_weights(snn, seed):
+    """found by the contention campaign: networks whose voltages explode (beyond 1e15 the chains skip absent edges explicitly) read
+    their weights from the matrix in memory, which is stale while the run updates them in registers"""
+    import test_gpu_persistent_run as tp
+    tp.test_random_electrical_networks(snn, seed)
