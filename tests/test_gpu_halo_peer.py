@@ -25,7 +25,7 @@ def check_against_oracle(handles, net, steps):
         assert np.array_equal(parity.bits(st["w_value"][h.owned]), parity.bits(net["w_value"][h.owned]))
 
 
-@pytest.mark.timeout(120)
+@pytest.mark.timeout(300)
 @pytest.mark.parametrize("n_shards,by_lattice,side", [(2, True, 16), (4, True, 16), (3, False, 8), (8, False, 8), (8, True, 32)])
 def test_peer_form_equals_the_oracle(snn, collectives, n_shards, by_lattice, side):
     from snn_amd import parallel
@@ -34,7 +34,9 @@ def test_peer_form_equals_the_oracle(snn, collectives, n_shards, by_lattice, sid
     parallel.wire_halo_lists(handles)
     assert parallel.connect_peers(handles)
     for h in handles:
-        h.set_option("halo_peer_spin_limit", 1 << 20)
+        # (8 ranks as threads of one process on ONE device wait for each other's launches through shared hardware queues: a
+        # generous limit -- once in a full run of the suite the 1 << 20 of the smaller cases was not enough)
+        h.set_option("halo_peer_spin_limit", 1 << (20 if n_shards <= 4 else 24))
     tc = collectives(n_shards)
     # (8 ranks on one device: their launches share hardware queues, where a kernel that waits for a neighbour's values may sit in
     # front of the kernel that produces them -- a limit of this emulation, not of one rank per GPU; those cases step call by call,
@@ -42,7 +44,6 @@ def test_peer_form_equals_the_oracle(snn, collectives, n_shards, by_lattice, sid
     calls = [150, 1, 49] if n_shards <= 4 else [1] * 60
     run_ranks(handles, tc, calls)
     steps = sum(calls)
-    net.n_threads = 8
     net.run(steps, spike_history=True)
     assert net.spike_history.sum() > 5 or steps < 100
     for h in handles:
