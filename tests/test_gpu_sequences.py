@@ -23,11 +23,29 @@ def usable(seed):
 SEEDS = [s for s in range(int(os.environ.get("SNN_RANDOM_SEEDS_SEQUENCES", "90"))) if usable(s)]
 
 
-@pytest.mark.parametrize("seed", SEEDS)
-def test_random_call_sequence(snn, seed):
+class _Absent:
+    """stands in for the side a replay leaves out: every call is accepted and does nothing"""
+    clock = 0
+
+    def __getattr__(self, name):
+        return lambda *a, **k: None
+
+
+def play(snn, seed, device=True, oracle=True, names=()):
+    """One random sequence of calls (a function of the seed alone) on a device handle and on the oracle; `device` / `oracle` False
+    replays it on ONE side only (the other side's calls are dropped, the oracle's container still supplies the numbers the
+    sequence draws from).  Returns (device state, oracle state, log); compares on the way only when both sides run."""
     net, plan = draw(1000 + seed)
     rng = np.random.default_rng(300_000 + seed)
-    dn = make_handle(snn, net, plan)
+    both = device and oracle
+    dn = make_handle(snn, net, plan) if device else _Absent()
+    real_run = net.run
+
+    def oracle_run(k, **kw):
+        if oracle:
+            return real_run(k, **kw)
+        net.clock += k                                       # the sequence draws firing times below the clock
+    net.run = oracle_run
     ranges = net.layout.ranges()
     lattices = [i for i, _, _ in net.layout.lattices if ranges[i][1]]
     cells = [i for i, _, _ in net.layout.st_lattices if ranges[i][1]]
@@ -59,9 +77,15 @@ def test_random_call_sequence(snn, seed):
             dn.set_option(name, int(rng.choice(SWITCHES[name])))
             log.append(("switch", name))
         elif op == 6:
-            parity.assert_graph_equal(net, dn)
-            if rng.integers(0, 2):
-                parity.assert_state_equal(net, parity.pull_state(dn, net))
+            check_state = bool(rng.integers(0, 2))
+            if both:
+                parity.assert_graph_equal(net, dn)
+                if check_state:
+                    parity.assert_state_equal(net, parity.pull_state(dn, net))
+            elif device:
+                dn.get_graph_rows(0, net.n_tot) if not plan["csr"] else dn.get_graph_csr()      # (a read flushes pending updates)
+                if check_state:
+                    parity.pull_state(dn, net)
             log.append(("read",))
         elif op == 7:
             slot = int(rng.integers(0, len(net.layout.lattices)))
@@ -86,7 +110,8 @@ def test_random_call_sequence(snn, seed):
             net["nt_flags"][...] = rng.random((nn, 3)) < 0.5
             net["nt_t"][...] = net["nt_t"] * net["nt_flags"]
             net["rc_flags"][...] = rng.random((nn, 3)) < 0.5
-            parity.push_state(dn, net)
+            if device:
+                parity.push_state(dn, net)
             log.append(("parameters",))
         elif op == 10:
             el, ch = [(True, False), (True, True), (False, True)][int(rng.integers(0, 3))]
@@ -97,7 +122,9 @@ def test_random_call_sequence(snn, seed):
             # the weights of the existing edges rewritten (same mask)
             w = rng.uniform(-0.5, 2.0, net["weights"].shape).astype(np.float32) * net["connections"]
             net["weights"][...] = w
-            if plan["csr"]:
+            if not device:
+                pass
+            elif plan["csr"]:
                 dn.set_graph_csr(*parity.csr_for_posts(net, dn.owned))
             else:
                 dn.set_graph_rows(0, net["weights"], net["connections"].astype(np.uint32))
@@ -119,7 +146,7 @@ def test_random_call_sequence(snn, seed):
             dn.run(k)
             net.run(k, voltage_history=True, spike_history=True)
             keep = np.arange(0, k, every)
-            for i in lattices:
+            for i in (lattices if both else ()):
                 first, count, _ = ranges[i]
                 assert np.array_equal(dn.spike_history(i), net.spike_history[keep, first:first + count]), f"raster; sequence: {log}"
                 assert np.array_equal(parity.bits(dn.voltage_history(i)), parity.bits(net.voltage_history[keep, first:first + count])), f"trace; sequence: {log}"
@@ -128,13 +155,42 @@ def test_random_call_sequence(snn, seed):
             log.append(("recorded", k, every))
     dn.run(5)
     net.run(5)
-    try:
-        parity.assert_state_equal(net, parity.pull_state(dn, net))
-        parity.assert_graph_equal(net, dn)
-        assert dn.clock == net.clock
-    except AssertionError as e:
-        raise AssertionError(f"{e}; sequence: {log}") from e
+    dev = parity.pull_state(dn, net) if device else None
+    orc = {k: np.array(net[k], copy=True) for k in (dev if dev is not None else names)} if oracle else None
+    if both:
+        try:
+            parity.assert_state_equal(net, dev)
+            parity.assert_graph_equal(net, dn)
+            assert dn.clock == net.clock
+        except AssertionError as e:
+            dn.close()
+            e.sides = (dev, orc, log)
+            raise
     dn.close()
+    return dev, orc, log
+
+
+def same(a, b):
+    return all(np.array_equal(parity.bits(a[k]) if a[k].dtype == np.float32 else a[k], parity.bits(b[k]) if b[k].dtype == np.float32 else b[k])
+               for k in a)
+
+
+@pytest.mark.parametrize("seed", SEEDS)
+def test_random_call_sequence(snn, seed):
+    """On a mismatch BOTH sides are replayed alone, from the seed, in this process: the message says which side the replay
+    reproduces -- a device that differs from its own replay points at the stepper, an oracle that does at the checker."""
+    try:
+        play(snn, seed)
+    except AssertionError as e:
+        dev, orc, log = getattr(e, "sides", (None, None, []))
+        verdict = "no replay (the mismatch came from a comparison inside the sequence)"
+        if dev is not None:
+            dev2 = play(snn, seed, oracle=False)[0]
+            orc2 = play(snn, seed, device=False, names=tuple(dev))[1]
+            verdict = (f"replay of the device alone {'REPRODUCES' if same(dev, dev2) else 'DIFFERS FROM'} the failing run's device state; "
+                       f"replay of the oracle alone {'REPRODUCES' if same(orc, orc2) else 'DIFFERS FROM'} the failing run's oracle state; "
+                       f"the two replays {'AGREE' if same(dev2, orc2) else 'disagree'} with each other")
+        raise AssertionError(f"{e}; sequence: {log}; {verdict}") from e
 
 
 def usable_sharded(seed):
