@@ -333,12 +333,13 @@ struct ResidentRunShared {
     float chem_state[9][64];                     // ... and their state: r, current, t of type k at 3 * k ..
     uint32_t chem_cnt[K_TYPES][64];              // ... and the receptor's input count per type
     // STDP variants (no cells: the rows' arrays of the cells serve -- cell_s: the column deltas of the lattice in hand, cell_f:
-    // every row's last firing time (int32 bits), kind: 1 where a plastic row spiked in the previous step): the rule of each
+    // every row's last firing time (int32 bits), cell_n: 1 where the row's lattice is plastic, kind: 1 where a plastic row spiked in
+    // the previous step): the rule of each
     // column's lattice, the table of all rules, per lattice the columns of this tile that belong to it, the plastic columns that
-    // spiked in the previous step, per wavefront whether one of its polled rows spiked
+    // spiked in the previous step
     float stdp_par[5][64];
     float stdp_tab[RUN_STDP_MAX_LATTICES][PL_STRIDE];
-    uint32_t stdp_latmask[RUN_STDP_MAX_LATTICES][2], stdp_colmask[2], stdp_any[16];
+    uint32_t stdp_latmask[RUN_STDP_MAX_LATTICES][2], stdp_colmask[2];
     // networks with cells: per row of the workgroup, its kind and this step's (s, f) of a row (see the step loop) and n: 1 for a
     // neuron's row, 0 for a cell's
     float cell_s[RUN_RESIDENT_GROUP_ROWS], cell_f[RUN_RESIDENT_GROUP_ROWS];
