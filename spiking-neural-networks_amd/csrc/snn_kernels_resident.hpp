@@ -364,7 +364,7 @@ static_assert(offsetof(ResidentRunShared, cell_n) <= 65536, "the arrays the chai
 // run (same expressions as update_neuron, integrate_and_fire/mod.rs:217-255); the other wavefronts keep 64 weights per lane
 // in registers.  Every wavefront of a workgroup passes the same workgroup barriers per step (one behind the polls, one per turn --
 // four, fewer for networks under 256 rows --; group 0 of a multi-group tile one more).
-template <int MODEL, bool UPDATER, bool REGISTERS, bool CELLS, bool CHEM, bool STDP = false>
+template <int MODEL, bool UPDATER, bool REGISTERS, bool CELLS, bool CHEM, bool STDP = false, bool LEND = false>
 __device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, ResidentRunShared &sh, const uint32_t wave)
 {
     const InputsArgs &in = a.in;
@@ -373,8 +373,13 @@ __device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, Res
     const uint32_t n_tiles = gridDim.x / n_groups;
     const uint32_t chunk_local = wave >> 2, chunk = 4u * group + chunk_local;
     const uint32_t turn = ((wave & 3u) - chunk_local) & 3u;      // which quarter of the chunk, and when
-    const uint32_t row0 = chunk * CHUNK + turn * 64u, group_row0 = group * RUN_RESIDENT_GROUP_ROWS;
     const uint32_t n_tot = in.n_tot, steps = a.steps, tag_base = a.tag_base, n_chunks = in.n_chunks;
+    // LEND (the host launches it for networks of one chunk at most, <= 256 rows, with gap junctions AND transmitters): the
+    // wavefronts of the idle chunks 1 + j take the chain of live type j over chunk 0's rows -- in the same slot as the
+    // gap-junction chain of those rows, on another SIMD ((wave & 3) differs by the chunk index) -- so all chains of a turn run
+    // side by side: 4 slots instead of 4 + n_live
+    const bool shadow = LEND && chunk_local >= 1u && chunk_local <= a.n_live;
+    const uint32_t row0 = (shadow ? 0u : chunk) * CHUNK + turn * 64u, group_row0 = group * RUN_RESIDENT_GROUP_ROWS;
     const bool rows_live = row0 < n_tot;
     const bool last_of_chunk = turn == 3u || row0 + 64u >= n_tot;
     const bool updates = group == 0u;                            // this workgroup's wavefront 0 updates the tile's neurons
@@ -756,11 +761,11 @@ __device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, Res
         // (the variants that also carry spike-train cells have no register to spare for it: their chains stay in one slot)
         constexpr bool STAGGER = CHEM && !CELLS;
         const uint32_t chem_off = (STAGGER && a.up.electrical) ? 1u : 0u;
-        const uint32_t n_slots = STAGGER ? n_turns + chem_off + n_live - 1u : n_turns;
+        const uint32_t n_slots = (STAGGER && !LEND) ? n_turns + chem_off + n_live - 1u : n_turns;
 #pragma unroll 1
         for (uint32_t t = 0; t < n_slots; ++t) {
             if (rows_live) {
-              if (t == turn && (!CHEM || a.up.electrical)) {
+              if (t == turn && (!CHEM || a.up.electrical) && !shadow) {
                 float acc = (turn != 0) ? sh.hand[chunk_local][lane] : 0.0f;
                 // wave-uniform address = LDS broadcast; the offset is laundered through a vector register so that the values
                 // stay in vector registers (as scalars every one of them costs a v_readlane plus its wait states)
@@ -985,9 +990,11 @@ __device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, Res
                 // type the same ascending chain over this wavefront's rows, t * w, the running sum handed on through LDS
 #pragma unroll 1
                 for (uint32_t jj = 0; jj < (STAGGER ? 1u : n_live); ++jj) {
-                    const uint32_t j = STAGGER ? t - turn - chem_off : jj;   // the live type this wavefront sums in this slot
-                    if (STAGGER ? j >= n_live : t != turn) continue;         // (wraps when it is none)
-                    float acc_t = (turn != 0) ? sh.hand_t[j][chunk_local][lane] : 0.0f;
+                    // the live type this wavefront sums in this slot (wraps when it is none); a lent wavefront: its own type, in turn
+                    const uint32_t j = LEND ? ((shadow && t == turn) ? chunk_local - 1u : 0xFFFFFFFFu) : (STAGGER ? t - turn - chem_off : jj);
+                    if (STAGGER ? j >= n_live : t != turn) continue;
+                    const uint32_t cl = shadow ? 0u : chunk_local;            // (a lent wavefront sums chunk 0)
+                    float acc_t = (turn != 0) ? sh.hand_t[j][cl][lane] : 0.0f;
                     uint32_t zero;
                     asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
                     const v4f *tp = reinterpret_cast<const v4f *>(sh.t[j] + (row0 - group_row0) + zero);
@@ -1032,8 +1039,8 @@ __device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, Res
                             }
                         }
                     }
-                    if (last_of_chunk) sh.pt[a.live_type[j]][chunk_local][lane] = acc_t;
-                    else sh.hand_t[j][chunk_local][lane] = acc_t;
+                    if (last_of_chunk) sh.pt[a.live_type[j]][cl][lane] = acc_t;
+                    else sh.hand_t[j][cl][lane] = acc_t;
                 }
               }
             }
@@ -1315,16 +1322,18 @@ __global__ __launch_bounds__(1024) void k_run_resident_probe(uint32_t *counter, 
     if (footprint.ok[0] == 0u) *counter = 0u;   // never: keeps the LDS footprint alive
 }
 
-template <int MODEL, bool REGISTERS, bool CELLS, bool CHEM = false, bool STDP = false>
+// LEND: networks of one chunk at most (<= 256 rows) with gap junctions AND transmitters -- see `shadow` in run_resident_steps
+template <int MODEL, bool REGISTERS, bool CELLS, bool CHEM = false, bool STDP = false, bool LEND = false>
 __global__ __launch_bounds__(1024) void k_run_resident(const ResidentRunArgs args)
 {
+    static_assert(!LEND || (CHEM && !CELLS && !STDP), "lent wavefronts: chemical + electrical synapses, neurons only");
     static_assert(!CHEM || !REGISTERS || MODEL == 0, "receptors in registers: Izhikevich only");
     static_assert(!STDP || (!CELLS && !CHEM), "weight updates inside the run: electrical synapses, neurons only");
     __shared__ __attribute__((aligned(16))) ResidentRunShared sh;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (threadIdx.x == 0) sh.gave_up = 0u;                       // ordered before its first reader by the first step's barrier
-    if (wave == 0) run_resident_steps<MODEL, true, REGISTERS, CELLS, CHEM, STDP>(args, sh, wave);
-    else run_resident_steps<MODEL, false, REGISTERS, CELLS, CHEM, STDP>(args, sh, wave);
+    if (wave == 0) run_resident_steps<MODEL, true, REGISTERS, CELLS, CHEM, STDP, LEND>(args, sh, wave);
+    else run_resident_steps<MODEL, false, REGISTERS, CELLS, CHEM, STDP, LEND>(args, sh, wave);
     // a poll that gave up ended the loop early everywhere in the workgroup
     if (threadIdx.x == 0) {
         bool failed = false;

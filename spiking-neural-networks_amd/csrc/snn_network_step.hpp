@@ -820,6 +820,7 @@ int launch_run_resident(snn_network *net, uint64_t iterations)
 #define SNN_RUN_RESIDENT_CELLS(M) hipLaunchKernelGGL((k_run_resident<M, false, true>), grid, block, 0, net->stream, r)
 #define SNN_RUN_RESIDENT_CHEM(M) hipLaunchKernelGGL((k_run_resident<M, false, false, true>), grid, block, 0, net->stream, r)
 #define SNN_RUN_RESIDENT_CHEM_CELLS(M) hipLaunchKernelGGL((k_run_resident<M, false, true, true>), grid, block, 0, net->stream, r)
+#define SNN_RUN_RESIDENT_CHEM_LEND(M) hipLaunchKernelGGL((k_run_resident<M, false, false, true, false, true>), grid, block, 0, net->stream, r)
 #define SNN_RUN_RESIDENT_STDP(M) hipLaunchKernelGGL((k_run_resident<M, false, false, false, true>), grid, block, 0, net->stream, r)
 #if !SNN_HAVE_CUSTOM_MODEL
         // neuron state in registers for the whole run where the kernel carries the model's update itself
@@ -830,6 +831,11 @@ int launch_run_resident(snn_network *net, uint64_t iterations)
             SNN_FOR_MODEL(SNN_RUN_RESIDENT_STDP);
         } else if (net->chemical && net->nc) {                                     // chemical synapses: the generic update
             SNN_FOR_MODEL(SNN_RUN_RESIDENT_CHEM_CELLS);
+        } else if (net->chemical && net->electrical && net->n_tot <= CHUNK && net->model == SNN_MODEL_IZHIKEVICH) {
+            // (one chunk at most, both kinds of synapse: the idle wavefronts take the transmitter chains)
+            hipLaunchKernelGGL((k_run_resident<0, true, false, true, false, true>), grid, block, 0, net->stream, r);
+        } else if (net->chemical && net->electrical && net->n_tot <= CHUNK) {
+            SNN_FOR_MODEL(SNN_RUN_RESIDENT_CHEM_LEND);
         } else if (net->chemical && net->model == SNN_MODEL_IZHIKEVICH) {          // ... Izhikevich: receptors and transmitters resident too
             hipLaunchKernelGGL((k_run_resident<0, true, false, true>), grid, block, 0, net->stream, r);
         } else if (net->chemical) {
@@ -863,6 +869,7 @@ int launch_run_resident(snn_network *net, uint64_t iterations)
 #undef SNN_RUN_RESIDENT_CHEM
 #undef SNN_RUN_RESIDENT_CHEM_CELLS
 #undef SNN_RUN_RESIDENT_STDP
+#undef SNN_RUN_RESIDENT_CHEM_LEND
         HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
         if (e1) HIP_TRY(hipEventRecord(e1, net->stream), SNN_ERR_QUEUE);
         if (net->run_timing) {          // debugging aid: workgroup 0's phases in shader clocks per step

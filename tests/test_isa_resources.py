@@ -15,19 +15,21 @@ CSRC = os.path.join(ROOT, "spiking-neural-networks_amd", "csrc")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 # <MODEL, REGISTERS, CELLS, CHEM> as launch_run_resident (csrc/snn_network_step.hpp) picks them
-# (the fifth parameter, STDP = weight updates inside the run, exists for electrical networks of neurons only)
-VARIANTS = ([(m, False, c, True, False) for m in range(8) for c in (False, True)] +
-            [(m, False, c, False, False) for m in range(8) for c in (False, True)] +
-            [(m, True, c, False, False) for m in (0, 1, 3, 4) for c in (False, True)] + [(0, True, False, True, False)] +
-            [(m, False, False, False, True) for m in range(8)] + [(0, True, False, False, True)])
+# (the fifth parameter, STDP = weight updates inside the run, exists for electrical networks of neurons only; the sixth, LEND =
+# idle wavefronts take the transmitter chains, for networks of at most 256 rows with both kinds of synapse)
+VARIANTS = ([(m, False, c, True, False, False) for m in range(8) for c in (False, True)] +
+            [(m, False, c, False, False, False) for m in range(8) for c in (False, True)] +
+            [(m, True, c, False, False, False) for m in (0, 1, 3, 4) for c in (False, True)] + [(0, True, False, True, False, False)] +
+            [(m, False, False, False, True, False) for m in range(8)] + [(0, True, False, False, True, False)] +
+            [(m, False, False, True, False, True) for m in range(8)] + [(0, True, False, True, False, True)])
 
 
 @pytest.fixture(scope="module")
 def assembly(tmp_path_factory):
     d = tmp_path_factory.mktemp("isa")
     src = d / "resident_only.hip"
-    inst = "\n".join(f"template __global__ void snn::k_run_resident<{m}, {str(r).lower()}, {str(c).lower()}, {str(h).lower()}, {str(p).lower()}>"
-                     f"(const snn::ResidentRunArgs);" for m, r, c, h, p in VARIANTS)
+    inst = "\n".join(f"template __global__ void snn::k_run_resident<{m}, {str(r).lower()}, {str(c).lower()}, {str(h).lower()}, {str(p).lower()}, "
+                     f"{str(e).lower()}>(const snn::ResidentRunArgs);" for m, r, c, h, p, e in VARIANTS)
     src.write_text(f'#include "{ROOT}/include/snn_amd.h"\n#include "snn_kernels_misc.hpp"\n#include "snn_kernels_resident.hpp"\n{inst}\n')
     subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-unused-result",
                     "-Wno-pass-failed", "-save-temps", f"-I{CSRC}", "-o", "lib.so", src.name], cwd=d, check=True, capture_output=True)
