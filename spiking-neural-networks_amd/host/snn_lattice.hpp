@@ -602,6 +602,31 @@ public:
     }
     snn_network_t *handle() const { return h_; }
 
+  private:
+    template <class V>
+    std::vector<std::vector<V>> cross_rows(size_t pre, size_t post, bool counter)
+    {
+        uint32_t pf = 0, pc = 0, qf = 0, qc = 0, nn = 0;
+        check(snn_network_lattice_range(h_, (uint32_t)pre, &pf, &pc));
+        check(snn_network_lattice_range(h_, (uint32_t)post, &qf, &qc));
+        check(snn_network_sizes(h_, &nn, nullptr, nullptr, nullptr));
+        std::vector<std::vector<V>> out(pc, std::vector<V>(qc));
+        if (counter) {
+            std::vector<uint8_t> rows((size_t)pc * nn);
+            check(snn_get_counter_rows(h_, pf, pc, rows.data()));
+            for (uint32_t p = 0; p < pc; ++p)
+                for (uint32_t q = 0; q < qc; ++q) out[p][q] = (V)rows[(size_t)p * nn + qf + q];
+        } else {
+            std::vector<float> rows((size_t)pc * nn);
+            check(snn_get_pending_rows(h_, pf, pc, rows.data()));
+            for (uint32_t p = 0; p < pc; ++p)
+                for (uint32_t q = 0; q < qc; ++q) out[p][q] = (V)rows[(size_t)p * nn + qf + q];
+        }
+        return out;
+    }
+
+  public:
+
     // Reward modulation of lattice `id`'s internal edges (RewardModulatedLattice, neuron/mod.rs:2719-3417): the
     // lattice's weights become TraceRSTDP::weight, traces start at 0.  update_and_apply_reward = one step preceded by
     // RewardModulator::update(reward) (Agent, :3402-3407); results stay on the device until sync().
@@ -635,6 +660,19 @@ public:
             for (uint32_t q = 0; q < count; ++q) out[p][q] = rows[(size_t)p * nn + first + q];
         return out;
     }
+    // RewardModulatedLatticeNetwork (neuron/mod.rs:3419-3453): every connection from lattice (or spike-train lattice) `pre` into
+    // lattice `post` is a RewardModulatedConnection -- reward_modulated = true: ::RewardModulatedWeight (the TraceRSTDP's c, dw and
+    // counter live in the trace / pending / counter rows of the C ABI), false: ::Weight.  A configuration in which the
+    // reference's visits would unwrap None (update_weights_from_neurons_across_lattices :4707-4802, _across_reward_lattices
+    // :4855-4977) makes the next run throw with the reference line in the message.
+    void set_connection(size_t pre, size_t post, bool reward_modulated)
+    {
+        check(snn_set_connection_kind(h_, (uint32_t)pre, (uint32_t)post, reward_modulated ? 1 : 2));
+    }
+    // TraceRSTDP::dw / ::counter of the connections from lattice `pre` into lattice `post`, [n_pre][n_post]
+    std::vector<std::vector<float>> pending(size_t pre, size_t post) { return cross_rows<float>(pre, post, false); }
+    std::vector<std::vector<float>> counters(size_t pre, size_t post) { return cross_rows<float>(pre, post, true); }
+
     // BCM rule for lattice `id` (needs BCMActivity neurons: SNN_MODEL_BCM_IZHIKEVICH)
     void set_bcm(size_t id, const BCM &b, bool do_plasticity = true)
     {
