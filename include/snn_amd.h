@@ -155,6 +155,10 @@ int snn_get_attr_i32(snn_network_t *net, uint32_t id, const char *name, int32_t 
 /* The reference's flattened form: weights f32[n_tot*n_tot], connections u32[n_tot*n_tot],
  * element [pre*n_tot + post]; connections == 0 means None (graph/mod.rs:310-320, 729-770).
  * Columns of spike-train cells are ignored (they are never postsynaptic). */
+/* A connected edge (connections != 0) whose weight is NaN is refused with SNN_ERR_BAD_ARG, here and in snn_set_graph_rows /
+ * snn_set_graph_csr: NaN is how the device matrix marks an absent edge, so the reference's Some(NaN) (graph/mod.rs:204-213 --
+ * an edge that turns its postsynaptic neuron's input into NaN) cannot be stored.  The dense forms report it after the rows
+ * of the call have been imported with those edges absent; the sparse form before anything changes. */
 int snn_set_graph_dense(snn_network_t *net, const float *weights, const uint32_t *connections, size_t n_tot);
 int snn_get_graph_dense(snn_network_t *net, float *weights, uint32_t *connections, size_t n_tot);
 /* Row-block form for matrices that do not fit one host buffer: presynaptic rows
@@ -189,6 +193,12 @@ int snn_set_plasticity(snn_network_t *net, uint32_t id, float a_plus, float a_mi
 int snn_set_history(snn_network_t *net, int voltage_history, int spike_history);
 int snn_reset_history(snn_network_t *net);
 int snn_get_clock(const snn_network_t *net, uint64_t *clock);
+/* internal_clock of the network as LatticeNetworkGPU::from_network hands it over (neuron/gpu_lattices/mod.rs:1630), and the
+ * spike-train lattices' own clocks (SpikeTrainLattice::internal_clock, neuron/mod.rs:1318): a network that has already run
+ * on the host continues at its clock -- last_firing_time values are absolute step numbers. */
+int snn_set_clock(snn_network_t *net, uint64_t clock);
+int snn_set_spike_train_clock(snn_network_t *net, uint32_t id, uint64_t clock);
+int snn_get_spike_train_clock(snn_network_t *net, uint32_t id, uint64_t *clock);
 /* reset_timing (neuron/mod.rs:405-420, 1710-1717): clock = 0, last_firing_time = None everywhere */
 int snn_reset_timing(snn_network_t *net);
 
@@ -336,6 +346,13 @@ int snn_p2p_commit(snn_network_t *net);
 /* ranks in different processes: three 64-byte IPC handles (receive set 0, set 1, done counters) of a handle; the peer opens them */
 int snn_p2p_ipc_export(snn_network_t *net, void *handles_3x64_bytes);
 int snn_p2p_ipc_import(int device, const void *handles_3x64_bytes, uint64_t *recv0, uint64_t *recv1, uint64_t *flags);
+/* unmaps what snn_p2p_ipc_import mapped (a 0 address is skipped).  Order of a plan rebuild across ranks: every rank that holds a
+ * connection to the handle whose plan changes drops it (closes its mappings, reconnects after the new snn_p2p_local numbers have
+ * travelled); until a handle commits a new connection -- or is destroyed -- it keeps the receive sets and done counters of its
+ * previous plan alive, so a late store of a neighbour lands in memory that still belongs to it.  Whether a run takes the peer
+ * form is part of what the ranks of snn_run_sharded agree on before its first step: all of them or none
+ * (SNN_ERR_BAD_STATE otherwise, instead of one rank polling granules while another posts a collective). */
+int snn_p2p_ipc_close(int device, uint64_t recv0, uint64_t recv1, uint64_t flags);
 /* CSR shard handles: all ranks call it once after snn_set_graph_csr; trades the need lists and commits the halo plan */
 int snn_comm_exchange_halo_lists(snn_network_t *net, void *nccl_comm);
 /* One exchange of the packed segments, enqueued on the handle's stream (between snn_step_begin and snn_step_end) */
@@ -521,6 +538,21 @@ int snn_set_option(snn_network_t *net, const char *name, int value);
  * "view_refreshes" (the spike-train cells' gap-junction values were recomputed), "history_regrows" (the history buffers
  * were reallocated).  Unknown names fail with SNN_ERR_BAD_ARG. */
 int snn_get_stat(snn_network_t *net, const char *name, uint64_t *value);
+
+/* ---- test support ------------------------------------------------------------------------ */
+
+/* Option "verify" [0] (SNN_AMD_VERIFY=1): every snn_run call on a handle without weight updates takes its steps TWICE from the
+ * same device snapshot and compares the two outcomes word for word on the device -- a stepper that is not deterministic shows
+ * without any oracle.  Statistics "verify_runs", "verify_mismatches", "verify_skipped" (the first one-launch run of a handle
+ * lays its snapshot out anew); snn_debug_verify_report names the array, word and the two values of the last mismatch (also
+ * printed to stderr).  Option "run_resident_chunk_steps" [2^20]: steps per launch of the one-launch run (a run call of more steps
+ * takes several launches, each with its own rollback point); "stdp_columns_form" [0] 1: the incoming-edge scatter of STDP with
+ * one lane per 16-byte unit (k_stdp_columns_quads). */
+const char *snn_debug_verify_report(snn_network_t *net);
+/* restore = 0: keeps a copy of everything a later run call reads (device arrays up to 256 MiB in all, the stepper's host-side
+ * cursors) in host memory; restore = 1 puts it back -- the SAME call can then be executed again from identical inputs.  Valid
+ * while the handle's structure is unchanged (run calls, attribute and weight writes in between are fine). */
+int snn_debug_checkpoint(snn_network_t *net, int restore);
 
 /* ---- measurement ----------------------------------------------------------------------- */
 

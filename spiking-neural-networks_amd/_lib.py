@@ -29,17 +29,76 @@ class SnnError(RuntimeError):
         self.code = code
 
 
+def _hipcc():
+    return os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+_hipcc_version_cache = {}
+
+
+def hipcc_version():
+    """first line of `hipcc --version` that names the compiler (cached)"""
+    exe = _hipcc()
+    if exe not in _hipcc_version_cache:
+        try:
+            out = subprocess.run([exe, "--version"], capture_output=True, text=True, timeout=60).stdout
+            lines = [ln.strip() for ln in out.splitlines() if "version" in ln.lower()]
+            _hipcc_version_cache[exe] = "; ".join(lines[:2]) or "unknown"
+        except Exception:                       # noqa: BLE001
+            _hipcc_version_cache[exe] = "unknown"
+    return _hipcc_version_cache[exe]
+
+
+def source_hash(extra_files=(), defines=()):
+    """sha256 over what a library is compiled from: every .hip / .hpp of csrc/ (sorted by name), the header, the generated
+    header of a custom library, the flags and the compiler's version -- the CONTENT decides whether a built library is
+    current, not a time stamp (an edit made while hipcc runs would otherwise pass as built)"""
+    import hashlib
+    h = hashlib.sha256()
+    files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".hpp"))] + [HEADER] + list(extra_files)
+    for path in files:
+        h.update(os.path.basename(path).encode() + b"\0")
+        with open(path, "rb") as f:
+            h.update(f.read())
+        h.update(b"\0")
+    h.update(" ".join(HIPCC_FLAGS + list(defines)).encode())
+    h.update(hipcc_version().encode())
+    return h.hexdigest()
+
+
+def _build_one(out, cmd_tail, digest, force, what):
+    """compiles `out` unless a library built from exactly these sources is already there; one line of provenance on stderr"""
+    import sys
+    stamp = out + ".hash"
+    have = open(stamp).read().strip() if os.path.exists(stamp) else None
+    if not force and os.path.exists(out) and have == digest:
+        print(f"[snn_amd build] reused {what}: {os.path.relpath(out)} source_sha256={digest[:16]} hipcc=\"{hipcc_version()}\"", file=sys.stderr)
+        return out
+    why = "forced" if force else ("no library" if not os.path.exists(out) else ("no hash on record" if have is None else "sources changed"))
+    tmp = out + ".tmp"
+    subprocess.run([_hipcc()] + HIPCC_FLAGS + cmd_tail + ["-o", tmp, os.path.join(CSRC, "snn_network.hip")], check=True, cwd=CSRC)
+    # the sources may have been edited while the compiler ran: the hash on record is the one taken BEFORE the compile
+    # started only if they still hash the same now; otherwise the library is kept but marked stale (no hash)
+    os.replace(tmp, out)
+    after = source_hash(*_hash_args.get(out, ((), ())))
+    if after == digest:
+        with open(stamp, "w") as f:
+            f.write(digest + "\n")
+    elif os.path.exists(stamp):
+        os.remove(stamp)
+    print(f"[snn_amd build] compiled {what} ({why}): {os.path.relpath(out)} source_sha256={digest[:16]} hipcc=\"{hipcc_version()}\""
+          + ("" if after == digest else " -- SOURCES CHANGED DURING THE COMPILE: not recorded as current"), file=sys.stderr)
+    return out
+
+
+_hash_args = {}
+
+
 def build(force=False):
-    """Compile every HIP source for gfx950 into csrc/libsnn_amd.so (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".hpp"))]
-    srcs.append(HEADER)
-    if not force and os.path.exists(LIB_PATH):
-        if os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(s) for s in srcs):
-            return LIB_PATH
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIB_PATH, os.path.join(CSRC, "snn_network.hip")]
-    subprocess.run(cmd, check=True, cwd=CSRC)
-    return LIB_PATH
+    """Compile every HIP source for gfx950 into csrc/libsnn_amd.so (hipcc cross-compiles without a GPU).  Reuses the library
+    only when the hash of its sources (source_hash) is the one on record next to it (libsnn_amd.so.hash)."""
+    _hash_args[LIB_PATH] = ((), ())
+    return _build_one(LIB_PATH, [], source_hash(), force, "libsnn_amd.so")
 
 
 def build_custom(model, force=False):
@@ -58,14 +117,9 @@ def build_custom(model, force=False):
     if force or not os.path.exists(header) or open(header).read() != text:
         with open(header, "w") as f:
             f.write(text)
-    srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".hpp"))] + [HEADER, header]
-    if not force and os.path.exists(out) and os.path.getmtime(out) >= max(os.path.getmtime(s) for s in srcs):
-        return out
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     define = '-DSNN_CUSTOM_MODEL_HEADER="generated/%s.hpp"' % stem
-    cmd = [hipcc] + HIPCC_FLAGS + [define, "-o", out, os.path.join(CSRC, "snn_network.hip")]
-    subprocess.run(cmd, check=True, cwd=CSRC)
-    return out
+    _hash_args[out] = ((header,), (define,))
+    return _build_one(out, [define], source_hash((header,), (define,)), force, f"custom library {stem}")
 
 
 class ExchangePlan(C.Structure):
@@ -137,6 +191,9 @@ SIGNATURES = {
     "snn_set_history": (C.c_int, [H, C.c_int, C.c_int]),
     "snn_reset_history": (C.c_int, [H]),
     "snn_get_clock": (C.c_int, [H, u64p]),
+    "snn_set_clock": (C.c_int, [H, C.c_uint64]),
+    "snn_set_spike_train_clock": (C.c_int, [H, C.c_uint32, C.c_uint64]),
+    "snn_get_spike_train_clock": (C.c_int, [H, C.c_uint32, u64p]),
     "snn_reset_timing": (C.c_int, [H]),
     "snn_run": (C.c_int, [H, C.c_uint64]),
     "snn_step_begin": (C.c_int, [H]),
@@ -164,6 +221,7 @@ SIGNATURES = {
     "snn_p2p_commit": (C.c_int, [H]),
     "snn_p2p_ipc_export": (C.c_int, [H, C.c_void_p]),
     "snn_p2p_ipc_import": (C.c_int, [C.c_int, C.c_void_p, u64p, u64p, u64p]),
+    "snn_p2p_ipc_close": (C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.c_uint64]),
     "snn_set_collectives": (C.c_int, [C.c_void_p]),
     "snn_comm_exchange_halo_lists": (C.c_int, [H, C.c_void_p]),
     "snn_exchange": (C.c_int, [H, C.c_void_p]),
@@ -195,6 +253,8 @@ SIGNATURES = {
     "snn_get_spike_counts": (C.c_int, [H, C.c_uint32, u32p, C.c_size_t]),
     "snn_set_option": (C.c_int, [H, C.c_char_p, C.c_int]),
     "snn_get_stat": (C.c_int, [H, C.c_char_p, u64p]),
+    "snn_debug_verify_report": (C.c_char_p, [H]),
+    "snn_debug_checkpoint": (C.c_int, [H, C.c_int]),
     "snn_profile_enable": (C.c_int, [H, C.c_int]),
     "snn_profile_reset": (C.c_int, [H]),
     "snn_profile_read": (C.c_int, [H, u64p, C.POINTER(C.c_double)]),

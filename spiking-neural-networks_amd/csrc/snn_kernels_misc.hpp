@@ -34,6 +34,33 @@ __global__ __launch_bounds__(256) void k_copy_table(const CopyEntry *table, int 
     uint32_t *to = restore ? e.src : e.dst;
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < e.words; i += gridDim.x * 256u) to[i] = from[i];
 }
+// Self-check of the stepper (option "verify", tests only): the table's arrays copied to a SECOND buffer laid out like the
+// snapshot (dst - base + alt), and compared with it word for word after the same steps have been taken again from the same
+// snapshot.  Words that are NaN as binary32 on both sides count as equal (their payload is not part of the contract); entries
+// with pad != 0 hold what legitimately depends on the order of atomics (the compacted spike list) and are skipped.
+// report: [0] differing words, [1] entry + 1 of the lowest differing entry seen, [2] its word, [3] / [4] the two values.
+__global__ __launch_bounds__(256) void k_copy_table_alt(const CopyEntry *table, const uint32_t *base, uint32_t *alt, int restore)
+{
+    const CopyEntry e = table[blockIdx.y];
+    uint32_t *side = alt + (e.dst - base);
+    const uint32_t *from = restore ? side : e.src;
+    uint32_t *to = restore ? e.src : side;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < e.words; i += gridDim.x * 256u) to[i] = from[i];
+}
+__global__ __launch_bounds__(256) void k_compare_table_alt(const CopyEntry *table, const uint32_t *base, const uint32_t *alt, uint32_t *report)
+{
+    const CopyEntry e = table[blockIdx.y];
+    if (e.pad) return;
+    const uint32_t *was = alt + (e.dst - base);
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < e.words; i += gridDim.x * 256u) {
+        const uint32_t x = was[i], y = e.src[i];
+        const bool both_nan = (x & 0x7FFFFFFFu) > 0x7F800000u && (y & 0x7FFFFFFFu) > 0x7F800000u;
+        if (x == y || both_nan) continue;
+        if (atomicAdd(&report[0], 1u) == 0u) {
+            report[1] = blockIdx.y + 1u; report[2] = i; report[3] = x; report[4] = y;
+        }
+    }
+}
 __global__ void k_iota_u32(uint32_t *p, size_t n, uint32_t first)
 {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = first + (uint32_t)i;
@@ -42,8 +69,10 @@ __global__ void k_iota_u32(uint32_t *p, size_t n, uint32_t first)
 // ---- graph import / export ----------------------------------------------------------------
 // src rows are `src_ld` wide and hold GLOBAL postsynaptic columns; the handle keeps columns
 // [q0, q0+n_loc).  Rows [row0, row0+rows) of W are written; padding columns get the sentinel.
+// A connected edge whose weight is NaN cannot be stored (NaN IS the absent-edge sentinel; the reference's Some(NaN),
+// graph/mod.rs:204-213, would be an edge that poisons its postsynaptic neuron): bad[0] counts them, bad[1] / bad[2] name one.
 __global__ void k_graph_import(float *W, uint32_t ld, uint32_t n_loc, uint32_t q0, uint32_t row0, uint32_t rows,
-                               const float *src_w, const uint32_t *src_c, size_t src_ld)
+                               const float *src_w, const uint32_t *src_c, size_t src_ld, uint32_t *bad)
 {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t r = blockIdx.y;
@@ -51,7 +80,10 @@ __global__ void k_graph_import(float *W, uint32_t ld, uint32_t n_loc, uint32_t q
     float out = quiet_nan();
     if (q < n_loc) {
         const size_t i = (size_t)r * src_ld + q0 + q;
-        if (src_c[i] != 0) out = src_w[i];
+        if (src_c[i] != 0) {
+            out = src_w[i];
+            if (out != out && atomicAdd(&bad[0], 1u) == 0u) { bad[1] = row0 + r; bad[2] = q0 + q; }
+        }
     }
     W[widx(row0 + r, q, ld)] = out;
 }
@@ -395,6 +427,62 @@ __global__ __launch_bounds__(256) void k_stdp_columns(const StdpArgs a)
             const bool bcm = prm[5] != 0.0f;
             const float pre = bcm ? ((p < a.n_neurons) ? a.act[p] : a.st_act[p - a.n_neurons]) : 0.0f;
             stdp_store(wp, plasticity_weight(prm, w, tp, a.last_firing_time[j], pre, bcm ? a.act[j] : 0.0f, bcm ? a.avg[j] : 0.0f), stream);
+        }
+    }
+}
+
+// The same column scatter with the wavefront turned by 90 degrees (the form many spikes per step take, round 5): a lane owns the
+// 16-byte unit (4 presynaptic rows) of ONE listed column, the 64 lanes of a wavefront hold 64 DIFFERENT listed columns of the
+// SAME row group and walk the row groups of their slab together.  What k_stdp_columns asks of the memory system per
+// instruction is 16 units that lie ld * 16 bytes apart (1.3 MB at C4: one page and one DRAM row each); here every
+// instruction stays inside one row group's ld * 16 bytes, the presynaptic firing times are wave-uniform (scalar loads) and
+// QUADS_IN_FLIGHT units per lane are requested before the first is used.  Same function of the same operands per
+// synapse: bit-identical to k_stdp_columns.
+typedef float stdp_v4f __attribute__((ext_vector_type(4)));
+constexpr uint32_t STDP_QUADS_IN_FLIGHT = 4;
+__global__ __launch_bounds__(256) void k_stdp_columns_quads(const StdpArgs a)
+{
+    const uint32_t count = *a.spike_count;
+    const uint32_t groups = (a.n_tot + 3u) >> 2;
+    const uint32_t per_slab = (groups + gridDim.y - 1) / gridDim.y;
+    const uint32_t g0 = blockIdx.y * per_slab, g1 = min(groups, g0 + per_slab);
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    for (uint32_t s0 = (blockIdx.x * 4u + wave) * 64u; s0 < count; s0 += gridDim.x * 256u) {
+        const uint32_t s = s0 + lane;
+        uint32_t j = s < count ? a.spike_list[s] : 0xFFFFFFFFu;
+        const bool on = j != 0xFFFFFFFFu && j >= a.q0 && j < a.q0 + a.n_loc;
+        if (!on) j = a.q0;                                   // an idle lane walks column 0 and stores nothing
+        const uint32_t slot = a.lattice_slot[j];
+        const float *prm = a.stdp + PL_STRIDE * slot;
+        const bool bcm = prm[5] != 0.0f;
+        const int32_t tj = a.last_firing_time[j];
+        const float post_act = bcm ? a.act[j] : 0.0f, post_avg = bcm ? a.avg[j] : 0.0f;
+        stdp_v4f *col = reinterpret_cast<stdp_v4f *>(a.W) + (j - a.q0);
+        for (uint32_t g = g0; g < g1; g += STDP_QUADS_IN_FLIGHT) {
+            stdp_v4f w[STDP_QUADS_IN_FLIGHT];
+#pragma unroll
+            for (uint32_t u = 0; u < STDP_QUADS_IN_FLIGHT; ++u)
+                if (g + u < g1) w[u] = col[(size_t)(g + u) * a.ld];
+#pragma unroll
+            for (uint32_t u = 0; u < STDP_QUADS_IN_FLIGHT; ++u) {
+                if (g + u >= g1) break;
+                const stdp_v4f w0 = w[u];
+                bool changed = false;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t p = (g + u) * 4u + (uint32_t)k;                  // wave-uniform
+                    if (p >= a.n_tot) break;
+                    const int32_t tp = (p < a.n_neurons) ? a.last_firing_time[p] : a.st_last_firing_time[p - a.n_neurons];
+                    const float pre = bcm ? ((p < a.n_neurons) ? a.act[p] : a.st_act[p - a.n_neurons]) : 0.0f;
+                    const float x = w0[k];
+                    if (x == x && plain_connection(a, p, slot)) {
+                        const float y = plasticity_weight(prm, x, tp, tj, pre, post_act, post_avg);
+                        changed = changed || __float_as_uint(y) != __float_as_uint(x);
+                        w[u][k] = y;
+                    }
+                }
+                if (on && changed) col[(size_t)(g + u) * a.ld] = w[u];
+            }
         }
     }
 }

@@ -49,6 +49,11 @@ int snn_network_create(int device, int neuron_model, int nt_kinetics, int recept
     if (const char *e = getenv("SNN_AMD_DEFER_STDP")) net->defer_stdp = (e[0] == '2') ? 2 : (e[0] != '0');
     if (const char *e = getenv("SNN_AMD_UNIFORM_PARAMS")) net->uniform_params = (e[0] != '0');
     if (const char *e = getenv("SNN_AMD_PERSISTENT_RUN")) net->persistent_run = (e[0] != '0');
+    if (const char *e = getenv("SNN_AMD_PERSISTENT_CHEM")) net->persistent_chem = (e[0] != '0');
+    if (const char *e = getenv("SNN_AMD_PERSISTENT_STDP")) net->persistent_stdp = (e[0] != '0');
+    if (const char *e = getenv("SNN_AMD_HALO_PEER")) net->halo_peer = (e[0] != '0');
+    if (const char *e = getenv("SNN_AMD_STDP_COLUMNS_FORM")) net->stdp_columns_form = (e[0] == '1') ? 1 : 0;
+    if (const char *e = getenv("SNN_AMD_VERIFY")) net->verify = (e[0] != '0');
     if (const char *e = getenv("SNN_AMD_INPUT_SHAPE")) net->force_shape = (e[0] == '1') ? 1 : ((e[0] == '2') ? 2 : 0);
     net->model = neuron_model; net->nt_kind = nt_kinetics; net->rc_kind = receptor_kinetics;
     net->st_kind = spike_train_model;
@@ -81,6 +86,8 @@ int snn_network_destroy(snn_network_t *net)
     if (net->cross_bad) (void)hipFree(net->cross_bad);
     if (net->conn_kind_dev) (void)hipFree(net->conn_kind_dev);
     if (net->run_failed) (void)hipHostFree(net->run_failed);
+    if (net->st_clock_pinned) (void)hipHostFree(net->st_clock_pinned);
+    if (net->verify_report) (void)hipFree(net->verify_report);
     for (float *b : net->whist) if (b) (void)hipFree(b);
     if (net->summ_avg) (void)hipFree(net->summ_avg);
     if (net->summ_eeg) (void)hipFree(net->summ_eeg);
@@ -96,7 +103,7 @@ int snn_network_destroy(snn_network_t *net)
                     (void *)net->csr_interior_dev, (void *)net->pack_ptr_dev, (void *)net->pack_segoff_dev,
                     (void *)net->pack_count_dev, (void *)net->pack_index_dev})
         if (p) (void)hipFree(p);
-    (void)p2p_release(net);
+    (void)p2p_release(net, /*final=*/true);
     if (net->p2p_failed) (void)hipHostFree(net->p2p_failed);
     if (net->comm_stream) { (void)hipStreamSynchronize(net->comm_stream); (void)hipStreamDestroy(net->comm_stream); }
     if (net->ev_packed) (void)hipEventDestroy(net->ev_packed);
@@ -202,9 +209,9 @@ static int finalize_impl(snn_network_t *net, int kind, uint32_t post_begin, uint
         HIP_TRY(snn_malloc(&net->own_block_dev, blocks.size() * 4), SNN_ERR_BUFFER_CREATE);
         HIP_TRY(snn_malloc(&net->own_mask_dev, masks.size() * 8), SNN_ERR_BUFFER_CREATE);
         HIP_TRY(snn_malloc(&net->local_row_dev, (size_t)net->n_pad * 4), SNN_ERR_BUFFER_CREATE);
-        HIP_TRY(hipMemcpy(net->own_block_dev, blocks.data(), blocks.size() * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
-        HIP_TRY(hipMemcpy(net->own_mask_dev, masks.data(), masks.size() * 8, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
-        HIP_TRY(hipMemcpy(net->local_row_dev, net->local_row_host.data(), (size_t)net->n_pad * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
+        HIP_TRY(copy_sync(net, net->own_block_dev, blocks.data(), blocks.size() * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
+        HIP_TRY(copy_sync(net, net->own_mask_dev, masks.data(), masks.size() * 8, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
+        HIP_TRY(copy_sync(net, net->local_row_dev, net->local_row_host.data(), (size_t)net->n_pad * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
         net->allocs.push_back(net->own_block_dev);
         net->allocs.push_back(net->own_mask_dev);
         net->allocs.push_back(net->local_row_dev);
@@ -379,6 +386,8 @@ static int set_graph_csr_impl(snn_network_t *net, const uint64_t *row_ptr, const
             if (pre_index[e] >= net->n_tot) return fail(SNN_ERR_DIM_MISMATCH, "presynaptic index out of range");
             if (e > row_ptr[k] && pre_index[e] <= pre_index[e - 1])
                 return fail(SNN_ERR_BAD_ARG, "presynaptic indices of a row must be strictly ascending");
+            if (weights[e] != weights[e])          // (the dense form cannot hold such an edge: the two forms refuse alike)
+                return fail(SNN_ERR_BAD_ARG, "stored edge " + std::to_string(e) + " (pre " + std::to_string(pre_index[e]) + ") carries a NaN weight");
             post[e] = q;
             ++t_ptr[pre_index[e] + 1];
         }
@@ -420,7 +429,7 @@ static int set_graph_csr_impl(snn_network_t *net, const uint64_t *row_ptr, const
     }
     auto up = [&](void **dst, const void *src, size_t bytes) -> int {
         HIP_TRY(snn_malloc(dst, std::max<size_t>(bytes, 256)), SNN_ERR_BUFFER_CREATE);
-        if (bytes) HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
+        if (bytes) HIP_TRY(copy_sync(net, *dst, src, bytes, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
         return SNN_OK;
     };
     TRY(up((void **)&net->csr_ptr, slice_ptr.data(), slice_ptr.size() * 4));
@@ -451,7 +460,7 @@ static int set_graph_csr_impl(snn_network_t *net, const uint64_t *row_ptr, const
         net->cell_list_host.clear();
         for (uint32_t s = 0; s < net->nc; ++s)
             if (seen[s]) net->cell_list_host.push_back(s);
-        TRY(upload_table(&net->cell_list_dev, net->cell_list_host));
+        TRY(upload_table(net, &net->cell_list_dev, net->cell_list_host));
         net->n_cells_listed = (uint32_t)net->cell_list_host.size();
         net->view_dirty = true;
     }
@@ -481,7 +490,7 @@ int snn_get_graph_csr(snn_network_t *net, float *weights, uint64_t nnz)
     HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
     TRY(end_run(net));
     std::vector<float> sell((size_t)net->sell_entries);
-    HIP_TRY(hipMemcpy(sell.data(), net->csr_w, sell.size() * 4, hipMemcpyDeviceToHost), SNN_ERR_BUFFER_READ);
+    HIP_TRY(copy_sync(net, sell.data(), net->csr_w, sell.size() * 4, hipMemcpyDeviceToHost), SNN_ERR_BUFFER_READ);
     for (uint64_t e = 0; e < nnz; ++e) weights[e] = sell[net->edge_slot_host[e]];
     return SNN_OK;
 }
@@ -510,8 +519,8 @@ int snn_set_plasticity(snn_network_t *net, uint32_t id, float a_plus, float a_mi
     net->any_plasticity = false;
     for (uint32_t p : net->plast_host) net->any_plasticity |= (p != 0);
     TRY(end_run(net));
-    HIP_TRY(hipMemcpy(net->stdp_dev, net->stdp_host.data(), net->stdp_host.size() * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
-    HIP_TRY(hipMemcpy(net->plast_dev, net->plast_host.data(), net->plast_host.size() * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
+    HIP_TRY(copy_sync(net, net->stdp_dev, net->stdp_host.data(), net->stdp_host.size() * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
+    HIP_TRY(copy_sync(net, net->plast_dev, net->plast_host.data(), net->plast_host.size() * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
     return SNN_OK;
 }
 
@@ -532,8 +541,8 @@ int snn_set_bcm(snn_network_t *net, uint32_t id, float decay, float average_scal
     net->any_plasticity = false;
     for (uint32_t p : net->plast_host) net->any_plasticity |= (p != 0);
     TRY(end_run(net));
-    HIP_TRY(hipMemcpy(net->stdp_dev, net->stdp_host.data(), net->stdp_host.size() * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
-    HIP_TRY(hipMemcpy(net->plast_dev, net->plast_host.data(), net->plast_host.size() * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
+    HIP_TRY(copy_sync(net, net->stdp_dev, net->stdp_host.data(), net->stdp_host.size() * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
+    HIP_TRY(copy_sync(net, net->plast_dev, net->plast_host.data(), net->plast_host.size() * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
     return SNN_OK;
 }
 
@@ -612,7 +621,7 @@ int snn_set_reward_modulator(snn_network_t *net, uint32_t id, float dopamine, fl
     TRY(end_run(net));
     const size_t nl = net->rm_on_host.size();
     // dopamine of the other lattices evolves on the device: refresh the host copy before rewriting the table
-    HIP_TRY(hipMemcpy(net->rm_host.data(), net->rm_dev, nl * RM_STRIDE * 4, hipMemcpyDeviceToHost), SNN_ERR_BUFFER_READ);
+    HIP_TRY(copy_sync(net, net->rm_host.data(), net->rm_dev, nl * RM_STRIDE * 4, hipMemcpyDeviceToHost), SNN_ERR_BUFFER_READ);
     float *m = &net->rm_host[(size_t)l->slot * RM_STRIDE];
     m[0] = dopamine; m[1] = tau_d; m[2] = tau_c; m[3] = a_plus; m[4] = a_minus; m[5] = tau_plus; m[6] = tau_minus; m[7] = dt;
     m[RM_DOPAMINE_BEFORE] = dopamine;
@@ -624,12 +633,12 @@ int snn_set_reward_modulator(snn_network_t *net, uint32_t id, float dopamine, fl
         net->plast_host[l->slot] = 0;
         net->any_plasticity = false;
         for (uint32_t p : net->plast_host) net->any_plasticity |= (p != 0);
-        HIP_TRY(hipMemcpy(net->plast_dev, net->plast_host.data(), net->plast_host.size() * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
+        HIP_TRY(copy_sync(net, net->plast_dev, net->plast_host.data(), net->plast_host.size() * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
         if (net->csr && !net->csr_ptr) return fail(SNN_ERR_BAD_STATE, "set the sparse graph before enabling reward modulation");
         TRY(ensure_traces(net));
     }
-    HIP_TRY(hipMemcpy(net->rm_dev, net->rm_host.data(), nl * RM_STRIDE * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
-    HIP_TRY(hipMemcpy(net->rm_on_dev, net->rm_on_host.data(), nl * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
+    HIP_TRY(copy_sync(net, net->rm_dev, net->rm_host.data(), nl * RM_STRIDE * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
+    HIP_TRY(copy_sync(net, net->rm_on_dev, net->rm_on_host.data(), nl * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
     hipLaunchKernelGGL(k_modulator_update, dim3((unsigned)((nl + 63) / 64)), dim3(64), 0, net->stream, net->rm_dev,
                        net->rm_on_dev, (uint32_t)nl, 0.0f, 1);
     HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
@@ -644,7 +653,7 @@ int snn_get_dopamine(snn_network_t *net, uint32_t id, float *dopamine)
     if (!l || l->spike_train) return fail(SNN_ERR_BAD_ARG, "reward modulation belongs to neuron lattices");
     HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
     TRY(end_run(net));
-    HIP_TRY(hipMemcpy(dopamine, net->rm_dev + (size_t)l->slot * RM_STRIDE, 4, hipMemcpyDeviceToHost), SNN_ERR_BUFFER_READ);
+    HIP_TRY(copy_sync(net, dopamine, net->rm_dev + (size_t)l->slot * RM_STRIDE, 4, hipMemcpyDeviceToHost), SNN_ERR_BUFFER_READ);
     return SNN_OK;
 }
 
@@ -715,14 +724,14 @@ static int trace_rows_io(snn_network_t *net, uint32_t pre_begin, uint32_t pre_co
         const uint32_t rows = std::min(hop, pre_count - r);
         const dim3 grid((net->n_loc + 255) / 256, rows);
         if (set) {
-            if (hipMemcpy2D(stage, (size_t)net->n_loc * 4, host + (size_t)r * net->nn, (size_t)net->nn * 4, (size_t)net->n_loc * 4, rows,
+            if (copy2d_sync(net, stage, (size_t)net->n_loc * 4, host + (size_t)r * net->nn, (size_t)net->nn * 4, (size_t)net->n_loc * 4, rows,
                             hipMemcpyHostToDevice) != hipSuccess) { rc = fail(SNN_ERR_BUFFER_WRITE, "trace upload failed"); break; }
             hipLaunchKernelGGL(k_rows_staging, grid, dim3(256), 0, net->stream, matrix, net->ld, net->n_loc, pre_begin + r, rows, stage, 1);
             if (hipStreamSynchronize(net->stream) != hipSuccess) rc = fail(SNN_ERR_WAIT, "trace upload wait failed");
         } else {
             hipLaunchKernelGGL(k_rows_staging, grid, dim3(256), 0, net->stream, matrix, net->ld, net->n_loc, pre_begin + r, rows, stage, 0);
             if (hipStreamSynchronize(net->stream) != hipSuccess) { rc = fail(SNN_ERR_WAIT, "trace download wait failed"); break; }
-            if (hipMemcpy2D(host + (size_t)r * net->nn, (size_t)net->nn * 4, stage, (size_t)net->n_loc * 4, (size_t)net->n_loc * 4, rows,
+            if (copy2d_sync(net, host + (size_t)r * net->nn, (size_t)net->nn * 4, stage, (size_t)net->n_loc * 4, (size_t)net->n_loc * 4, rows,
                             hipMemcpyDeviceToHost) != hipSuccess) rc = fail(SNN_ERR_BUFFER_READ, "trace download failed");
         }
     }
@@ -742,17 +751,29 @@ int snn_set_counter_rows(snn_network_t *net, uint32_t pre_begin, uint32_t pre_co
 {
     if (!net || !counters) return fail(SNN_ERR_BAD_ARG, "null argument");
     if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
-    std::vector<float> rows((size_t)pre_count * net->nn);
-    for (size_t i = 0; i < rows.size(); ++i) rows[i] = counters[i] ? 1.0f : 0.0f;
-    return trace_rows_io(net, pre_begin, pre_count, rows.data(), true, 2);
+    if (net->csr) return fail(SNN_ERR_BAD_STATE, "handle holds a CSR graph");
+    if ((uint64_t)pre_begin + pre_count > net->n_tot) return fail(SNN_ERR_DIM_MISMATCH, "row range exceeds n_tot");
+    try {
+        std::vector<float> rows((size_t)pre_count * net->nn);
+        for (size_t i = 0; i < rows.size(); ++i) rows[i] = counters[i] ? 1.0f : 0.0f;
+        return trace_rows_io(net, pre_begin, pre_count, rows.data(), true, 2);
+    } catch (const std::bad_alloc &) {
+        return fail(SNN_ERR_BUFFER_CREATE, "out of host memory for the counter rows");
+    }
 }
 int snn_get_counter_rows(snn_network_t *net, uint32_t pre_begin, uint32_t pre_count, uint8_t *counters)
 {
     if (!net || !counters) return fail(SNN_ERR_BAD_ARG, "null argument");
     if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
-    std::vector<float> rows((size_t)pre_count * net->nn, 0.0f);
-    TRY(trace_rows_io(net, pre_begin, pre_count, rows.data(), false, 2));
-    for (size_t i = 0; i < rows.size(); ++i) counters[i] = rows[i] != 0.0f ? 1 : 0;
+    if (net->csr) return fail(SNN_ERR_BAD_STATE, "handle holds a CSR graph");
+    if ((uint64_t)pre_begin + pre_count > net->n_tot) return fail(SNN_ERR_DIM_MISMATCH, "row range exceeds n_tot");
+    try {
+        std::vector<float> rows((size_t)pre_count * net->nn, 0.0f);
+        TRY(trace_rows_io(net, pre_begin, pre_count, rows.data(), false, 2));
+        for (size_t i = 0; i < rows.size(); ++i) counters[i] = rows[i] != 0.0f ? 1 : 0;
+    } catch (const std::bad_alloc &) {
+        return fail(SNN_ERR_BUFFER_CREATE, "out of host memory for the counter rows");
+    }
     return SNN_OK;
 }
 
@@ -778,7 +799,7 @@ int snn_set_connection_kind(snn_network_t *net, uint32_t pre_id, uint32_t post_i
     net->any_conn_kind = false;
     net->cross_checked = false;
     for (uint8_t k : net->conn_kind_host) net->any_conn_kind |= k != 0;
-    HIP_TRY(hipMemcpy(net->conn_kind_dev, net->conn_kind_host.data(), net->conn_kind_host.size(), hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
+    HIP_TRY(copy_sync(net, net->conn_kind_dev, net->conn_kind_host.data(), net->conn_kind_host.size(), hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
     if (kind) {
         TRY(ensure_traces(net));
         TRY(ensure_pending(net));
@@ -799,10 +820,10 @@ static int traces_csr_io(snn_network_t *net, float *traces, uint64_t nnz, bool s
     TRY(ensure_traces(net));
     HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
     std::vector<float> sell((size_t)net->sell_entries);
-    HIP_TRY(hipMemcpy(sell.data(), net->trace, sell.size() * 4, hipMemcpyDeviceToHost), SNN_ERR_BUFFER_READ);
+    HIP_TRY(copy_sync(net, sell.data(), net->trace, sell.size() * 4, hipMemcpyDeviceToHost), SNN_ERR_BUFFER_READ);
     if (set) {
         for (uint64_t e = 0; e < nnz; ++e) sell[net->edge_slot_host[e]] = traces[e];
-        HIP_TRY(hipMemcpy(net->trace, sell.data(), sell.size() * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
+        HIP_TRY(copy_sync(net, net->trace, sell.data(), sell.size() * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
     } else {
         for (uint64_t e = 0; e < nnz; ++e) traces[e] = sell[net->edge_slot_host[e]];
     }
@@ -832,7 +853,7 @@ int snn_reset_history(snn_network_t *net)
     if (net->finalized && net->spike_counts) {
         HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
         TRY(end_run(net));
-        HIP_TRY(hipMemset(net->spike_counts, 0, (size_t)net->n_pad * 4), SNN_ERR_BUFFER_WRITE);
+        HIP_TRY(memset_sync(net, net->spike_counts, 0, (size_t)net->n_pad * 4), SNN_ERR_BUFFER_WRITE);
     }
     return SNN_OK;
 }
@@ -862,8 +883,8 @@ int snn_set_firing_times(snn_network_t *net, uint32_t id, const uint32_t *cell_p
     for (size_t s = net->nc; s <= net->c_pad; ++s) ptr[s] = (uint32_t)flat.size();
     float *nt = nullptr;
     HIP_TRY(snn_malloc(&nt, std::max<size_t>(256, flat.size() * 4)), SNN_ERR_BUFFER_CREATE);
-    if (!flat.empty()) HIP_TRY(hipMemcpy(nt, flat.data(), flat.size() * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
-    HIP_TRY(hipMemcpy(const_cast<uint32_t *>(net->ca.preset_ptr), ptr.data(), ptr.size() * 4, hipMemcpyHostToDevice),
+    if (!flat.empty()) HIP_TRY(copy_sync(net, nt, flat.data(), flat.size() * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
+    HIP_TRY(copy_sync(net, const_cast<uint32_t *>(net->ca.preset_ptr), ptr.data(), ptr.size() * 4, hipMemcpyHostToDevice),
             SNN_ERR_BUFFER_WRITE);
     if (net->preset_times_dev) (void)hipFree(net->preset_times_dev);
     net->preset_times_dev = nt;
@@ -900,7 +921,7 @@ int snn_get_graph_history(snn_network_t *net, uint32_t id, float *dst, size_t st
     if (!dst) return fail(SNN_ERR_BAD_ARG, "dst is null");
     HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
     TRY(end_run(net));
-    HIP_TRY(hipMemcpy(dst, net->whist[l->slot], steps * (size_t)l->count * l->count * 4, hipMemcpyDeviceToHost), SNN_ERR_BUFFER_READ);
+    HIP_TRY(copy_sync(net, dst, net->whist[l->slot], steps * (size_t)l->count * l->count * 4, hipMemcpyDeviceToHost), SNN_ERR_BUFFER_READ);
     return SNN_OK;
 }
 
@@ -940,7 +961,7 @@ static int get_summary(snn_network_t *net, uint32_t id, float *dst, size_t steps
     TRY(end_run(net));
     const size_t nl = net->lattices.size();
     const float *src = (eeg ? net->summ_eeg : net->summ_avg) + l->slot;
-    HIP_TRY(hipMemcpy2D(dst, 4, src, nl * 4, 4, steps, hipMemcpyDeviceToHost), SNN_ERR_BUFFER_READ);
+    HIP_TRY(copy2d_sync(net, dst, 4, src, nl * 4, 4, steps, hipMemcpyDeviceToHost), SNN_ERR_BUFFER_READ);
     return SNN_OK;
 }
 
@@ -960,7 +981,7 @@ int snn_get_spike_counts(snn_network_t *net, uint32_t id, uint32_t *dst, size_t 
     if (!dst) return fail(SNN_ERR_BAD_ARG, "dst is null");
     HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
     TRY(end_run(net));
-    HIP_TRY(hipMemcpy(dst, net->spike_counts + l->first, count * 4, hipMemcpyDeviceToHost), SNN_ERR_BUFFER_READ);
+    HIP_TRY(copy_sync(net, dst, net->spike_counts + l->first, count * 4, hipMemcpyDeviceToHost), SNN_ERR_BUFFER_READ);
     return SNN_OK;
 }
 
@@ -986,6 +1007,219 @@ int snn_reset_timing(snn_network_t *net)
     return SNN_OK;
 }
 
+int snn_set_clock(snn_network_t *net, uint64_t clock)
+{
+    if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
+    if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
+    if (clock > 0x7FFFFFFFull) return fail(SNN_ERR_BAD_ARG, "the clock must fit the firing times' 31 bits");
+    HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
+    TRY(end_run(net));
+    net->clock = (long long)clock;
+    net->view_dirty = true;            // the cells' gap-junction values are functions of the clock
+    return SNN_OK;
+}
+
+int snn_set_spike_train_clock(snn_network_t *net, uint32_t id, uint64_t clock)
+{
+    if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
+    if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
+    const LatticeInfo *l = find_lattice(net, id);
+    if (!l || !l->spike_train) return fail(SNN_ERR_BAD_ARG, "no such spike-train lattice");
+    if (clock > 0x7FFFFFFFull) return fail(SNN_ERR_BAD_ARG, "the clock must fit the firing times' 31 bits");
+    HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
+    TRY(end_run(net));
+    net->st_clock[l->slot] = (long long)clock;
+    return SNN_OK;
+}
+
+int snn_get_spike_train_clock(snn_network_t *net, uint32_t id, uint64_t *clock)
+{
+    if (!net || !clock) return fail(SNN_ERR_BAD_ARG, "null argument");
+    if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
+    const LatticeInfo *l = find_lattice(net, id);
+    if (!l || !l->spike_train) return fail(SNN_ERR_BAD_ARG, "no such spike-train lattice");
+    HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
+    TRY(end_run(net));
+    *clock = (uint64_t)net->st_clock[l->slot];
+    return SNN_OK;
+}
+
+const char *snn_debug_verify_report(snn_network_t *net) { return net ? net->verify_text.c_str() : ""; }
+
+// Test support (tests/checkpoint.py): everything a later run call reads -- every device array of the handle up to 256 MiB in
+// all, the sparse weights, traces, and the host-side cursors of the stepper -- kept in host memory; restore puts it back.
+// Valid between calls that leave the handle's STRUCTURE alone (run calls, attribute and weight writes): a restore after a
+// structural call (a new sparse graph, a rebuilt exchange plan, histories switched) fails with SNN_ERR_BAD_STATE.
+int snn_debug_checkpoint(snn_network_t *net, int restore)
+{
+    if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
+    if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
+    HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
+    TRY(end_run(net));
+    auto &cp = net->checkpoint;
+    std::vector<std::pair<void *, size_t>> arrays;
+    for (const auto &kv : net->alloc_bytes)
+        if (kv.first != (void *)net->snap_buf && kv.first != (void *)net->snap_table && kv.first != (void *)net->verify_buf &&
+            kv.first != (void *)net->run_granules && kv.first != (void *)net->run_partials && kv.first != (void *)net->run_timing)
+            arrays.emplace_back(kv.first, kv.second);
+    if (net->csr_w) arrays.emplace_back(net->csr_w, (size_t)net->sell_entries * 4);
+    if (net->trace) arrays.emplace_back(net->trace, std::max<size_t>(trace_elems(net), 64) * 4);
+    for (void *m : {(void *)net->pending, (void *)net->edge_counter})
+        if (m) arrays.emplace_back(m, std::max<size_t>(wcount(net->n_tot, net->ld), 64) * 4);
+    size_t total = 0;
+    for (const auto &a : arrays) total += a.second;
+    if (total > ((size_t)256 << 20)) return fail(SNN_ERR_BAD_STATE, "checkpoints are for small handles (256 MiB of device state at most)");
+    if (!restore) {
+        cp.arrays.clear();
+        for (const auto &a : arrays) {
+            cp.arrays.emplace_back(a.first, std::vector<uint8_t>(a.second));
+            HIP_TRY(hipMemcpyAsync(cp.arrays.back().second.data(), a.first, a.second, hipMemcpyDeviceToHost, net->stream), SNN_ERR_BUFFER_READ);
+        }
+        HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
+        cp.clock = net->clock; cp.st_clock = net->st_clock; cp.hist_steps = net->hist_steps; cp.hist_tick = net->hist_tick;
+        cp.shadow_cur = net->shadow_cur; cp.shadow_valid = net->shadow_valid; cp.cell_view_cur = net->cell_view_cur;
+        cp.view_dirty = net->view_dirty; cp.counts_dirty = net->counts_dirty; cp.uni_dirty = net->uni_dirty;
+        cp.live_mask_applied = net->live_mask_applied; cp.n_live = net->n_live;
+        for (int k = 0; k < K_TYPES; ++k) cp.live_type[k] = net->live_type[k];
+        cp.persistent_run = net->persistent_run; cp.mirror_mask = net->mirror_mask;
+        cp.valid = true;
+        return SNN_OK;
+    }
+    if (!cp.valid) return fail(SNN_ERR_BAD_STATE, "no checkpoint was taken");
+    // every array of the checkpoint must still be the handle's (arrays allocated since -- shadows, views, granules -- are caches
+    // whose validity flags are put back below)
+    std::map<void *, size_t> current(arrays.begin(), arrays.end());
+    for (const auto &a : cp.arrays) {
+        const auto it = current.find(a.first);
+        if (it == current.end() || it->second != a.second.size())
+            return fail(SNN_ERR_BAD_STATE, "the handle's structure changed since the checkpoint");
+    }
+    for (const auto &a : cp.arrays)
+        HIP_TRY(hipMemcpyAsync(a.first, a.second.data(), a.second.size(), hipMemcpyHostToDevice, net->stream), SNN_ERR_BUFFER_WRITE);
+    HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
+    net->clock = cp.clock; net->st_clock = cp.st_clock; net->hist_steps = cp.hist_steps; net->hist_tick = cp.hist_tick;
+    net->shadow_cur = cp.shadow_cur; net->shadow_valid = cp.shadow_valid; net->cell_view_cur = cp.cell_view_cur;
+    net->view_dirty = cp.view_dirty; net->counts_dirty = cp.counts_dirty; net->uni_dirty = cp.uni_dirty;
+    net->live_mask_applied = cp.live_mask_applied; net->n_live = cp.n_live;
+    for (int k = 0; k < K_TYPES; ++k) net->live_type[k] = cp.live_type[k];
+    net->persistent_run = cp.persistent_run; net->mirror_mask = cp.mirror_mask;
+    net->stdp_pending = false; net->rstdp_pending = false; net->reward_since_defer = false;
+    net->cells_stepped = false; net->local_inputs_done = false; net->run_tag = 1;
+    if (net->run_granules) {
+        HIP_TRY(hipMemsetAsync(net->run_granules, 0, RUN_GRANULE_WORDS * 8, net->stream), SNN_ERR_BUFFER_WRITE);
+        HIP_TRY(hipMemsetAsync(net->run_partials, 0, RUN_PARTIAL_WORDS * 8, net->stream), SNN_ERR_BUFFER_WRITE);
+        HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
+    }
+    return SNN_OK;
+}
+
+extern "C++" {
+namespace {
+// host-side cursors a run moves: what a rollback (or the second pass of "verify") puts back
+struct RunCursors {
+    long long clock, run_step_offset;
+    uint64_t hist_steps, hist_tick, launches, steps, stdp_steps;
+    size_t ev_used;
+};
+RunCursors run_cursors(const snn_network *net)
+{
+    return {net->clock, net->run_step_offset, net->hist_steps, net->hist_tick, net->stat_run_launches, net->stat_run_steps,
+            net->stat_run_stdp_steps, net->ev_used};
+}
+void restore_cursors(snn_network *net, const RunCursors &c)
+{
+    net->clock = c.clock; net->run_step_offset = c.run_step_offset;
+    net->hist_steps = c.hist_steps; net->hist_tick = c.hist_tick;
+    net->stat_run_launches = c.launches; net->stat_run_steps = c.steps; net->stat_run_stdp_steps = c.stdp_steps;
+    net->ev_used = c.ev_used;
+}
+
+// The steps of a run call, between begin_run and end_run.
+int run_steps(snn_network *net, uint64_t iterations)
+{
+    uint64_t it = 0;
+    if (iterations >= 4 && net->external_stream && run_resident_shape(net)) net->stat_run_external_stream += 1;
+    // below 4 steps the launch's fixed cost (seed, weights into registers) shows
+    while (iterations - it >= 4 && run_resident_applies(net)) {
+        // The launch is a spin-wait all-to-all between workgroups that must all be resident.  A probe vouches for that
+        // once per handle; should they lose sight of each other later all the same (device shared with a long kernel),
+        // the waiters give up, the handle is put back exactly where the CHUNK started -- device state from a snapshot taken
+        // in one launch, host cursors from `saved` -- and the remaining steps are taken with one launch per step, which this
+        // handle then keeps.  The caller sees a slower call, never a half-stepped network.  The unit of the rollback is the
+        // chunk (at most run_chunk_steps steps): what earlier chunks of the call committed -- the weights of STDP inside
+        // the run among it -- is never replayed.
+        const uint64_t chunk = std::min<uint64_t>(iterations - it, std::max<uint32_t>(4u, net->run_chunk_steps));
+        const RunCursors saved = run_cursors(net);
+        TRY(run_snapshot(net, /*restore=*/false));
+        TRY(launch_run_resident(net, chunk, it));
+        if (!net->persistent_run) break;              // the co-residency probe said no, nothing was stepped
+        HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
+        if (net->run_failed && net->run_failed[0]) {
+            net->run_failed[0] = 0u;
+            TRY(run_snapshot(net, /*restore=*/true));
+            HIP_TRY(hipMemsetAsync(net->run_granules, 0, RUN_GRANULE_WORDS * 8, net->stream), SNN_ERR_BUFFER_WRITE);
+            HIP_TRY(hipMemsetAsync(net->run_partials, 0, RUN_PARTIAL_WORDS * 8, net->stream), SNN_ERR_BUFFER_WRITE);
+            net->run_tag = 1;
+            restore_cursors(net, saved);
+            net->shadow_valid = false;
+            net->view_dirty = true;
+            net->persistent_run = 0;
+            net->stat_run_fallbacks += 1;
+            break;
+        }
+        it += chunk;
+    }
+    for (; it < iterations; ++it) {
+        if (net->nn) TRY(step_begin(net));
+        TRY(step_end(net));
+        if (net->profile && (net->ev_used >= 8192 || net->ev_used_pl >= 8192)) TRY(collect_profile(net));
+    }
+    return SNN_OK;
+}
+
+// "verify": what may be stepped twice from one snapshot -- no weight updates (the matrices are not in the snapshot), nothing
+// measured, the handle's own stream
+bool verify_applies(const snn_network *net)
+{
+    return net->verify && !net->any_plasticity && !net->any_modulation && !net->any_conn_kind && !net->profile &&
+           !net->external_stream && !net->sharded && net->nn;
+}
+
+// name of the array a snapshot entry covers, for the report of a "verify" mismatch
+std::string describe_array(const snn_network *net, const void *ptr, uint32_t word)
+{
+    const char *p = static_cast<const char *>(ptr);
+    auto inside = [&](const void *base, size_t bytes) { return base && p >= (const char *)base && p < (const char *)base + bytes; };
+    const size_t plane = (size_t)net->xl.stride * 4;
+    if (inside(net->xbuf, plane * NUM_PLANES)) return "exchange buffer, plane " + std::to_string(word / net->xl.stride) + ", neuron " + std::to_string(word % net->xl.stride);
+    for (int i = 0; i < 2; ++i)
+        if (inside(net->shadow[i], plane * NUM_PLANES)) return "shadow " + std::to_string(i) + ", plane " + std::to_string(word / net->xl.stride) + ", neuron " + std::to_string(word % net->xl.stride);
+    for (int i = 0; i < 2; ++i)
+        if (inside(net->cell_view[i], (size_t)net->c_pad * 8)) return "cell view " + std::to_string(i) + ", word " + std::to_string(word);
+    const struct { const void *base; const char *name; } known[] = {
+        {net->part_i, "part_i"}, {net->part_t, "part_t"}, {net->n_in, "n_in"}, {net->tcount, "tcount"}, {net->W, "W"},
+        {net->spike_counts, "spike_counts"}, {net->spike_count, "spike_count"}, {net->st_clock_dev, "st_clock_dev"},
+        {net->uni_neuron, "uniform table (neurons)"}, {net->uni_cell, "uniform table (cells)"}, {net->ca.presyn_value, "cells: presyn_value"},
+        {net->ca.seed, "cells: seed"}, {net->ca.step, "cells: step"}, {net->ca.counter, "cells: counter"}, {net->lattice_slot, "lattice_slot"}};
+    for (const auto &k : known)
+        if (k.base == ptr) return std::string(k.name) + ", word " + std::to_string(word);
+    for (const auto *table : {&net->neuron_attrs, &net->cell_attrs})
+        for (const auto &kv : *table) {
+            const Attr &a = kv.second;
+            if (!a.base) continue;
+            const uint32_t pad = table == &net->neuron_attrs ? net->n_pad : net->c_pad;
+            const size_t bytes = (size_t)pad * 4 * ((a.store == S_PLAIN_K) ? K_TYPES : 1);
+            if (inside(a.base, bytes))
+                return std::string(table == &net->neuron_attrs ? "neurons: " : "cells: ") + kv.first + ", word " +
+                       std::to_string(word + (uint32_t)((p - (const char *)a.base) / 4));
+        }
+    char buf[64];
+    snprintf(buf, sizeof buf, "array at %p, word %u", ptr, word);
+    return buf;
+}
+} // namespace
+} // extern "C++"
+
 int snn_run(snn_network_t *net, uint64_t iterations)
 {
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
@@ -995,44 +1229,72 @@ int snn_run(snn_network_t *net, uint64_t iterations)
     if (!net->electrical && !net->chemical) return SNN_OK;           // neuron/mod.rs:1217, 2672
     HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
     TRY(begin_run(net, iterations));
-    uint64_t it = 0;
-    if (iterations >= 4 && net->external_stream && run_resident_shape(net)) net->stat_run_external_stream += 1;
-    if (iterations >= 4 && run_resident_applies(net)) {          // below that the launch's fixed cost (seed, weights into registers) shows
-        // The launch is a spin-wait all-to-all between workgroups that must all be resident.  A probe vouches for that
-        // once per handle; should they lose sight of each other later all the same (device shared with a long kernel),
-        // the waiters give up, the handle is put back exactly where it was -- device state from a snapshot taken in one
-        // launch, host counters from `saved` -- and the steps are taken again with one launch per step, which this handle
-        // then keeps.  The caller sees a slower call, never a half-stepped network.
-        struct { long long clock, run_step_offset; uint64_t hist_steps, hist_tick, launches, steps; size_t ev_used; } saved =
-            {net->clock, net->run_step_offset, net->hist_steps, net->hist_tick, net->stat_run_launches, net->stat_run_steps,
-             net->ev_used};
-        TRY(run_snapshot(net, /*restore=*/false));
-        TRY(launch_run_resident(net, iterations));
-        if (net->persistent_run) {                    // else: the co-residency probe said no, nothing was stepped
-            HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
-            if (net->run_failed && net->run_failed[0]) {
-                net->run_failed[0] = 0u;
-                TRY(run_snapshot(net, /*restore=*/true));
-                HIP_TRY(hipMemsetAsync(net->run_granules, 0, RUN_GRANULE_WORDS * 8, net->stream), SNN_ERR_BUFFER_WRITE);
-                HIP_TRY(hipMemsetAsync(net->run_partials, 0, RUN_PARTIAL_WORDS * 8, net->stream), SNN_ERR_BUFFER_WRITE);
-                net->run_tag = 1;
-                net->clock = saved.clock; net->run_step_offset = saved.run_step_offset;
-                net->hist_steps = saved.hist_steps; net->hist_tick = saved.hist_tick;
-                net->stat_run_launches = saved.launches; net->stat_run_steps = saved.steps;
-                net->ev_used = saved.ev_used;
-                net->shadow_valid = false;
-                net->view_dirty = true;
-                net->persistent_run = 0;
-                net->stat_run_fallbacks += 1;
-            } else {
-                it = iterations;
-            }
-        }
+    if (!verify_applies(net)) {
+        TRY(run_steps(net, iterations));
+        return end_run(net, /*keep_stdp=*/true);
     }
-    for (; it < iterations; ++it) {
-        if (net->nn) TRY(step_begin(net));
-        TRY(step_end(net));
-        if (net->profile && (net->ev_used >= 8192 || net->ev_used_pl >= 8192)) TRY(collect_profile(net));
+    // ---- "verify": the same steps twice from the same snapshot, the outcomes compared on the device -------------------
+    TRY(run_snapshot(net, /*restore=*/false));                    // (builds the table; its own copy of S(t) is not used here)
+    if (!net->verify_buf || net->verify_words < net->snap_words) {
+        if (net->verify_buf) {
+            (void)hipFree(net->verify_buf);
+            net->alloc_bytes.erase(net->verify_buf);
+            net->allocs.erase(std::remove(net->allocs.begin(), net->allocs.end(), (void *)net->verify_buf), net->allocs.end());
+            net->verify_buf = nullptr;
+        }
+        net->verify_words = net->snap_words + net->snap_words / 4 + 1024;
+        TRY(dev_alloc_t(net, &net->verify_buf, 2 * net->verify_words));
+        TRY(run_snapshot(net, /*restore=*/false));                // the handle has allocated: the table is laid out anew
+    }
+    if (!net->verify_report) HIP_TRY(snn_malloc(&net->verify_report, 256), SNN_ERR_BUFFER_CREATE);
+    if (!net->snap_entries || net->snap_words > net->verify_words) {
+        TRY(run_steps(net, iterations));
+        return end_run(net, /*keep_stdp=*/true);
+    }
+    const CopyEntry *table = net->snap_table;
+    const uint32_t *base = net->snap_buf;
+    const uint64_t generation = net->snap_generation;
+    const dim3 grid(std::max(1u, std::min(16u, (net->snap_max_words + 1023u) / 1024u)), net->snap_entries);
+    uint32_t *start = net->verify_buf, *first = net->verify_buf + net->verify_words;
+    const RunCursors c0 = run_cursors(net);
+    const int shadow_cur = net->shadow_cur, view_cur = net->cell_view_cur;
+    const bool shadow_valid = net->shadow_valid;
+    hipLaunchKernelGGL(k_copy_table_alt, grid, dim3(256), 0, net->stream, table, base, start, 0);
+    HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+    TRY(run_steps(net, iterations));
+    if (net->snap_generation != generation) {
+        // the run allocated and laid the table out anew (first one-launch run of a handle): nothing to compare with this time
+        net->stat_verify_skipped += 1;
+        return end_run(net, /*keep_stdp=*/true);
+    }
+    hipLaunchKernelGGL(k_copy_table_alt, grid, dim3(256), 0, net->stream, table, base, first, 0);
+    hipLaunchKernelGGL(k_copy_table_alt, grid, dim3(256), 0, net->stream, table, base, start, 1);
+    HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+    restore_cursors(net, c0);
+    net->shadow_cur = shadow_cur; net->shadow_valid = shadow_valid; net->cell_view_cur = view_cur;
+    net->cells_stepped = false; net->local_inputs_done = false;
+    TRY(run_steps(net, iterations));
+    net->stat_verify_runs += 1;
+    if (net->snap_generation == generation) {
+        uint32_t report[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        HIP_TRY(hipMemsetAsync(net->verify_report, 0, 32, net->stream), SNN_ERR_BUFFER_WRITE);
+        hipLaunchKernelGGL(k_compare_table_alt, grid, dim3(256), 0, net->stream, table, base, first, net->verify_report);
+        HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+        HIP_TRY(copy_sync(net, report, net->verify_report, 32, hipMemcpyDeviceToHost), SNN_ERR_BUFFER_READ);
+        if (report[0]) {
+            const uint32_t n = report[0], e = report[1], w = report[2];
+            char vals[96];
+            snprintf(vals, sizeof vals, "first pass 0x%08x (%g), second pass 0x%08x (%g)", report[3],
+                     (double)__builtin_bit_cast(float, report[3]), report[4], (double)__builtin_bit_cast(float, report[4]));
+            const void *arr = (e >= 1 && e <= net->snap_table_host.size()) ? (const void *)net->snap_table_host[e - 1].src : nullptr;
+            net->verify_text = "run of " + std::to_string(iterations) + " steps ending at clock " + std::to_string(net->clock) + ": " +
+                               std::to_string(n) + " words differ between two executions from the same state; e.g. " +
+                               describe_array(net, arr, w) + ": " + vals;
+            net->stat_verify_mismatches += 1;
+            fprintf(stderr, "[snn verify] MISMATCH %s\n", net->verify_text.c_str());
+        }
+    } else {
+        net->stat_verify_skipped += 1;
     }
     return end_run(net, /*keep_stdp=*/true);
 }
@@ -1299,10 +1561,10 @@ int snn_comm_exchange_halo_lists(snn_network_t *net, void *nccl_comm)
 #define HALO_STEP(expr) do { rc = (expr); if (rc) { cleanup(); return rc; } } while (0)
     auto hip_ok = [&](hipError_t e, int code, const char *what) { return e == hipSuccess ? SNN_OK : fail(code, std::string(what) + ": " + hipGetErrorString(e)); };
     auto nccl_ok = [&](ncclResult_t r, const char *what) { return r == ncclSuccess ? SNN_OK : fail(SNN_ERR_QUEUE, std::string(what) + ": " + R->GetErrorString(r)); };
-    HALO_STEP(hip_ok(hipMemcpy(d_counts, counts.data(), counts.size() * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE, "counts upload"));
+    HALO_STEP(hip_ok(copy_sync(net, d_counts, counts.data(), counts.size() * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE, "counts upload"));
     HALO_STEP(nccl_ok(R->AllGather(d_counts + (size_t)me * G, d_counts, G, ncclUint32, comm, net->stream), "ncclAllGather(counts)"));
     HALO_STEP(hip_ok(hipStreamSynchronize(net->stream), SNN_ERR_WAIT, "counts wait"));
-    HALO_STEP(hip_ok(hipMemcpy(counts.data(), d_counts, counts.size() * 4, hipMemcpyDeviceToHost), SNN_ERR_BUFFER_READ, "counts download"));
+    HALO_STEP(hip_ok(copy_sync(net, counts.data(), d_counts, counts.size() * 4, hipMemcpyDeviceToHost), SNN_ERR_BUFFER_READ, "counts download"));
     std::vector<uint64_t> need_off(G + 1, 0), send_off(G + 1, 0);
     for (uint32_t p = 0; p < G; ++p) {
         need_off[p + 1] = need_off[p] + counts[(size_t)me * G + p];        // what I ask of p
@@ -1313,7 +1575,7 @@ int snn_comm_exchange_halo_lists(snn_network_t *net, void *nccl_comm)
     HALO_STEP(hip_ok(snn_malloc(&d_need, std::max<size_t>(need_flat.size() * 4, 256)), SNN_ERR_BUFFER_CREATE, "hipMalloc"));
     HALO_STEP(hip_ok(snn_malloc(&d_send, std::max<size_t>(send_flat.size() * 4, 256)), SNN_ERR_BUFFER_CREATE, "hipMalloc"));
     if (!need_flat.empty())
-        HALO_STEP(hip_ok(hipMemcpy(d_need, need_flat.data(), need_flat.size() * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE, "lists upload"));
+        HALO_STEP(hip_ok(copy_sync(net, d_need, need_flat.data(), need_flat.size() * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE, "lists upload"));
     HALO_STEP(nccl_ok(R->GroupStart(), "ncclGroupStart"));
     {
         // a failure inside the group still closes it (a dangling group would swallow every later RCCL call of this thread)
@@ -1331,7 +1593,7 @@ int snn_comm_exchange_halo_lists(snn_network_t *net, void *nccl_comm)
     }
     HALO_STEP(hip_ok(hipStreamSynchronize(net->stream), SNN_ERR_WAIT, "lists wait"));
     if (!send_flat.empty())
-        HALO_STEP(hip_ok(hipMemcpy(send_flat.data(), d_send, send_flat.size() * 4, hipMemcpyDeviceToHost), SNN_ERR_BUFFER_READ, "lists download"));
+        HALO_STEP(hip_ok(copy_sync(net, send_flat.data(), d_send, send_flat.size() * 4, hipMemcpyDeviceToHost), SNN_ERR_BUFFER_READ, "lists download"));
 #undef HALO_STEP
     cleanup();
     for (uint32_t p = 0; p < G; ++p) {
@@ -1373,6 +1635,7 @@ int snn_p2p_connect(snn_network_t *net, uint32_t peer, uint64_t peer_recv0, uint
     snn_network::P2pPeer &pp = net->p2p_peers[peer];
     pp.recv[0] = peer_recv0; pp.recv[1] = peer_recv1; pp.flags = peer_flags; pp.recv_offset = peer_recv_offset; pp.set = true;
     net->p2p_connected = false;                   // until snn_p2p_commit
+    net->x_agreed = false;
     return SNN_OK;
 }
 
@@ -1406,9 +1669,27 @@ int snn_p2p_ipc_import(int device, const void *handles_3x64_bytes, uint64_t *rec
     HIP_TRY(hipSetDevice(device), SNN_ERR_GET_DEVICE);
     const hipIpcMemHandle_t *h = static_cast<const hipIpcMemHandle_t *>(handles_3x64_bytes);
     void *p[3] = {nullptr, nullptr, nullptr};
-    for (int i = 0; i < 3; ++i) HIP_TRY(hipIpcOpenMemHandle(&p[i], h[i], hipIpcMemLazyEnablePeerAccess), SNN_ERR_BUFFER_CREATE);
+    for (int i = 0; i < 3; ++i) {
+        const hipError_t e = hipIpcOpenMemHandle(&p[i], h[i], hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) {
+            for (int j = 0; j < i; ++j) (void)hipIpcCloseMemHandle(p[j]);       // nothing half-opened is left behind
+            return fail(SNN_ERR_BUFFER_CREATE, std::string("hipIpcOpenMemHandle: ") + hipGetErrorString(e));
+        }
+    }
     *recv0 = reinterpret_cast<uint64_t>(p[0]); *recv1 = reinterpret_cast<uint64_t>(p[1]); *flags = reinterpret_cast<uint64_t>(p[2]);
     return SNN_OK;
+}
+
+int snn_p2p_ipc_close(int device, uint64_t recv0, uint64_t recv1, uint64_t flags)
+{
+    HIP_TRY(hipSetDevice(device), SNN_ERR_GET_DEVICE);
+    int rc = SNN_OK;
+    for (uint64_t a : {recv0, recv1, flags}) {
+        if (!a) continue;
+        const hipError_t e = hipIpcCloseMemHandle(reinterpret_cast<void *>(a));
+        if (e != hipSuccess && rc == SNN_OK) rc = fail(SNN_ERR_BAD_ARG, std::string("hipIpcCloseMemHandle: ") + hipGetErrorString(e));
+    }
+    return rc;
 }
 
 int snn_exchange(snn_network_t *net, void *nccl_comm)
@@ -1483,11 +1764,11 @@ static int agree_on_exchange(Rccl *R, snn_network *net, ncclComm_t comm, void *n
     auto gather = [&](uint32_t mine) -> int {
         words.assign(G, 0);
         words[me] = mine;
-        if (hipMemcpy(d_words, words.data(), (size_t)G * 4, hipMemcpyHostToDevice) != hipSuccess) return fail(SNN_ERR_BUFFER_WRITE, "agreement upload");
+        if (copy_sync(net, d_words, words.data(), (size_t)G * 4, hipMemcpyHostToDevice) != hipSuccess) return fail(SNN_ERR_BUFFER_WRITE, "agreement upload");
         const ncclResult_t r = R->AllGather(d_words + me, d_words, 1, ncclUint32, comm, net->stream);
         if (r != ncclSuccess) return fail(SNN_ERR_QUEUE, std::string("ncclAllGather(agreement): ") + R->GetErrorString(r));
         if (hipStreamSynchronize(net->stream) != hipSuccess) return fail(SNN_ERR_WAIT, "agreement wait");
-        if (hipMemcpy(words.data(), d_words, (size_t)G * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(SNN_ERR_BUFFER_READ, "agreement download");
+        if (copy_sync(net, words.data(), d_words, (size_t)G * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(SNN_ERR_BUFFER_READ, "agreement download");
         return SNN_OK;
     };
     int rc = gather((net->csr ? 1u : 0u) | (net->halo_committed ? 2u : 0u) | (net->block_mode ? 4u : 0u));
@@ -1503,6 +1784,11 @@ static int agree_on_exchange(Rccl *R, snn_network *net, ncclComm_t comm, void *n
     if (!rc) {
         uint32_t mask = (uint32_t)net->x_mode << 8;
         for (uint32_t s = 0; s < net->x_planes; ++s) mask |= 1u << net->x_plane_id[s];
+        // bit 30: this rank will step in the PEER form (connected, committed, "halo_peer" on).  A rank that is not, next to one
+        // that is, would post ncclSend / ncclRecv nobody answers while the other polls granules nobody stores.
+        const bool peer_form = net->halo_peer && net->p2p_connected && net->p2p_recv[0] && net->direct_capable && net->halo_direct && net->csr_plan_direct &&
+                               csr_fast_step(net);
+        mask |= peer_form ? 0x40000000u : 0u;
         // bit 31: this rank's mirror lacks a plane of the plan (mirror_stale).  A plane can only go missing when the plan
         // grows -- which is when this agreement runs -- and whether it is missing is rank-local history (host-driven steps,
         // attributes written on some ranks only): if ANY rank is stale, EVERY rank sends its current state once before the
@@ -1511,8 +1797,12 @@ static int agree_on_exchange(Rccl *R, snn_network *net, ncclComm_t comm, void *n
         bool any_stale = false;
         for (uint32_t p = 0; p < G && !rc; ++p) {
             any_stale = any_stale || (words[p] >> 31) != 0u;
-            if ((words[p] & 0x7FFFFFFFu) != mask)
+            if ((words[p] & 0x3FFFFFFFu) != (mask & 0x3FFFFFFFu))
                 rc = fail(SNN_ERR_BAD_STATE, "the ranks of this communicator disagree on the exchange (synapse kinds / transmitter types / mode)");
+            else if ((words[p] & 0x40000000u) != (mask & 0x40000000u))
+                rc = fail(SNN_ERR_BAD_STATE, "the ranks of this communicator disagree on the peer form: rank " + std::to_string(p) +
+                                                 ((words[p] & 0x40000000u) ? " is connected (snn_p2p_commit, \"halo_peer\" 1), this rank is not"
+                                                                           : " is not connected, this rank is") + "; every rank or none");
         }
         if (!rc) net->refresh_agreed = any_stale;
     }
@@ -1639,7 +1929,7 @@ int snn_get_voltage_history(snn_network_t *net, uint32_t id, float *dst, size_t 
     TRY(end_run(net));
     const float *src = l->spike_train ? net->st_vhist + (l->first - net->nn) : net->vhist + l->first;
     const size_t pitch = (size_t)(l->spike_train ? net->c_pad : net->n_pad) * 4;
-    HIP_TRY(hipMemcpy2D(dst, (size_t)l->count * 4, src, pitch, (size_t)l->count * 4, net->hist_steps, hipMemcpyDeviceToHost),
+    HIP_TRY(copy2d_sync(net, dst, (size_t)l->count * 4, src, pitch, (size_t)l->count * 4, net->hist_steps, hipMemcpyDeviceToHost),
             SNN_ERR_BUFFER_READ);
     return SNN_OK;
 }
@@ -1658,7 +1948,7 @@ int snn_get_spike_history(snn_network_t *net, uint32_t id, uint8_t *dst, size_t 
     TRY(end_run(net));
     const size_t words = net->n_pad / 64;
     std::vector<unsigned long long> host(net->hist_steps * words);
-    HIP_TRY(hipMemcpy(host.data(), net->raster, host.size() * 8, hipMemcpyDeviceToHost), SNN_ERR_BUFFER_READ);
+    HIP_TRY(copy_sync(net, host.data(), net->raster, host.size() * 8, hipMemcpyDeviceToHost), SNN_ERR_BUFFER_READ);
     for (uint64_t s = 0; s < net->hist_steps; ++s)
         for (uint32_t i = 0; i < l->count; ++i) {
             const uint32_t q = l->first + i;
@@ -1679,7 +1969,7 @@ int snn_set_option(snn_network_t *net, const char *name, int value)
     else if (n == "update_all_planes") net->update_all_planes = value != 0;
     else if (n == "persistent_stdp") net->persistent_stdp = value != 0;
     else if (n == "halo_direct") net->halo_direct = (value >= 0 && value <= 2) ? value : 1;
-    else if (n == "halo_peer") net->halo_peer = value != 0;
+    else if (n == "halo_peer") { net->halo_peer = value != 0; net->x_agreed = false; }
     else if (n == "halo_peer_spin_limit") net->p2p_spin_limit = value > 0 ? (uint32_t)value : (1u << 26);
     else if (n == "csr_xcd_bands") net->csr_xcd_bands = value != 0;
     else if (n == "defer_rstdp") net->defer_rstdp = value != 0;
@@ -1691,6 +1981,9 @@ int snn_set_option(snn_network_t *net, const char *name, int value)
     else if (n == "run_resident_fault_step") net->run_fault_step = (uint32_t)std::max<long long>(value, 0);
     else if (n == "run_timing") net->run_timing_opt = value != 0;
     else if (n == "input_shape") net->force_shape = (value == 1 || value == 2) ? value : 0;
+    else if (n == "stdp_columns_form") net->stdp_columns_form = value == 1 ? 1 : 0;
+    else if (n == "verify") net->verify = value != 0;
+    else if (n == "run_resident_chunk_steps") net->run_chunk_steps = value >= 4 ? (uint32_t)std::min<long long>(value, 1 << 20) : (1u << 20);
     else return fail(SNN_ERR_BAD_ARG, "unknown option '" + n + "'");
     net->shadow_valid = false;
     return SNN_OK;
@@ -1714,6 +2007,9 @@ int snn_get_stat(snn_network_t *net, const char *name, uint64_t *value)
     else if (n == "shadow_refreshes") *value = net->stat_shadow_refreshes;
     else if (n == "view_refreshes") *value = net->stat_view_refreshes;
     else if (n == "history_regrows") *value = net->stat_history_regrows;
+    else if (n == "verify_runs") *value = net->stat_verify_runs;
+    else if (n == "verify_mismatches") *value = net->stat_verify_mismatches;
+    else if (n == "verify_skipped") *value = net->stat_verify_skipped;
     else if (n == "run_timing_poll") *value = net->run_timing_last[0];
     else if (n == "run_timing_barrier") *value = net->run_timing_last[1];
     else if (n == "run_timing_turns") *value = net->run_timing_last[2];

@@ -15,12 +15,12 @@ namespace {
 inline uint64_t segment_words(uint32_t planes, uint64_t count) { return (uint64_t)planes * count + (count + 31) / 32; }
 
 template <typename T>
-int upload_table(T **dev, const std::vector<T> &host)
+int upload_table(snn_network *net, T **dev, const std::vector<T> &host)
 {
     if (*dev) { (void)hipFree(*dev); *dev = nullptr; }
     HIP_TRY(snn_malloc(dev, std::max<size_t>(host.size() * sizeof(T), 256)), SNN_ERR_BUFFER_CREATE);
     if (!host.empty())
-        HIP_TRY(hipMemcpy(*dev, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
+        HIP_TRY(copy_sync(net, *dev, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
     return SNN_OK;
 }
 
@@ -55,10 +55,20 @@ void synthesize_full_lists(snn_network *net)
 }
 
 // the peer form's buffers and connection belong to ONE plan: a rebuilt plan starts unconnected
-int p2p_release(snn_network *net)
+int p2p_release(snn_network *net, bool final = false)
 {
-    for (void *b : {(void *)net->p2p_recv[0], (void *)net->p2p_recv[1], (void *)net->p2p_flags, (void *)net->p2p_done_blocks,
-                    (void *)net->p2p_dst_dev[0], (void *)net->p2p_dst_dev[1], (void *)net->p2p_peer_dev, (void *)net->p2p_signal_dev})
+    // What PEERS may still address -- the two receive sets and the done counters, by committed tables or IPC mappings of the
+    // old plan -- is not freed here but kept until this handle commits a new connection or is destroyed: a neighbour that
+    // announces "my previous launch is over" at the start of its next run stores into these words (include/snn_amd.h: peers
+    // reconnect after a plan rebuild; until they have, their stores land in memory that is still this handle's).
+    for (void *b : {(void *)net->p2p_recv[0], (void *)net->p2p_recv[1], (void *)net->p2p_flags})
+        if (b) net->p2p_retired.push_back(b);
+    if (final) {
+        for (void *b : net->p2p_retired) (void)hipFree(b);
+        net->p2p_retired.clear();
+    }
+    for (void *b : {(void *)net->p2p_done_blocks, (void *)net->p2p_dst_dev[0], (void *)net->p2p_dst_dev[1], (void *)net->p2p_peer_dev,
+                    (void *)net->p2p_signal_dev})
         if (b) (void)hipFree(b);
     net->p2p_recv[0] = net->p2p_recv[1] = nullptr;
     net->p2p_flags = nullptr; net->p2p_done_blocks = nullptr;
@@ -129,8 +139,8 @@ int ensure_exchange_plan(snn_network *net)
             so += net->x_send_words[p];
             ro += net->x_recv_words[p];
         }
-        TRY(upload_table(&net->halo_send_idx, send_idx));
-        TRY(upload_table(&net->halo_recv_idx, recv_idx));
+        TRY(upload_table(net, &net->halo_send_idx, send_idx));
+        TRY(upload_table(net, &net->halo_recv_idx, recv_idx));
         net->recv_total = (uint32_t)recv_idx.size();
         // the one-launch sparse step: border / interior slices and the per-row pack table
         const uint32_t n_slices = (net->n_loc + 63) / 64;
@@ -157,12 +167,12 @@ int ensure_exchange_plan(snn_network *net)
         std::vector<uint32_t> border, interior;
         for (uint32_t sl = 0; sl < n_slices; ++sl) (is_border[sl] ? border : interior).push_back(sl);
         net->n_border = (uint32_t)border.size(); net->n_interior = (uint32_t)interior.size();
-        TRY(upload_table(&net->csr_border_dev, border));
-        TRY(upload_table(&net->csr_interior_dev, interior));
-        TRY(upload_table(&net->pack_ptr_dev, pack_ptr));
-        TRY(upload_table(&net->pack_segoff_dev, pack_segoff));
-        TRY(upload_table(&net->pack_count_dev, pack_count));
-        TRY(upload_table(&net->pack_index_dev, pack_index));
+        TRY(upload_table(net, &net->csr_border_dev, border));
+        TRY(upload_table(net, &net->csr_interior_dev, interior));
+        TRY(upload_table(net, &net->pack_ptr_dev, pack_ptr));
+        TRY(upload_table(net, &net->pack_segoff_dev, pack_segoff));
+        TRY(upload_table(net, &net->pack_count_dev, pack_count));
+        TRY(upload_table(net, &net->pack_index_dev, pack_index));
         net->send_bits_clean = true;                 // the send buffer is (re)created zeroed below
         for (uint32_t **b : {&net->halo_send_buf, &net->halo_recv_buf, &net->halo_send_buf2, &net->halo_recv_buf2,
                              &net->csr_plan_direct, &net->halo_word_dev})
@@ -173,12 +183,12 @@ int ensure_exchange_plan(snn_network *net)
         for (uint32_t **b : {&net->halo_send_buf, net->direct_capable ? &net->halo_send_buf2 : nullptr}) {
             if (!b) continue;
             HIP_TRY(snn_malloc(b, std::max<uint64_t>(so * 4, 256)), SNN_ERR_BUFFER_CREATE);
-            HIP_TRY(hipMemset(*b, 0, std::max<uint64_t>(so * 4, 256)), SNN_ERR_BUFFER_WRITE);
+            HIP_TRY(memset_sync(net, *b, 0, std::max<uint64_t>(so * 4, 256)), SNN_ERR_BUFFER_WRITE);
         }
         for (uint32_t **b : {&net->halo_recv_buf, net->direct_capable ? &net->halo_recv_buf2 : nullptr}) {
             if (!b) continue;
             HIP_TRY(snn_malloc(b, std::max<uint64_t>(ro * 4, 256)), SNN_ERR_BUFFER_CREATE);
-            HIP_TRY(hipMemset(*b, 0, std::max<uint64_t>(ro * 4, 256)), SNN_ERR_BUFFER_WRITE);
+            HIP_TRY(memset_sync(net, *b, 0, std::max<uint64_t>(ro * 4, 256)), SNN_ERR_BUFFER_WRITE);
         }
         TRY(p2p_release(net));
         if (net->direct_capable && ro) {
@@ -188,13 +198,13 @@ int ensure_exchange_plan(snn_network *net)
             for (int i = 0; i < 2; ++i) {
                 HIP_TRY(hipExtMallocWithFlags(reinterpret_cast<void **>(&net->p2p_recv[i]), std::max<uint64_t>(ro * 8, 256), hipDeviceMallocFinegrained),
                         SNN_ERR_BUFFER_CREATE);
-                HIP_TRY(hipMemset(net->p2p_recv[i], 0, std::max<uint64_t>(ro * 8, 256)), SNN_ERR_BUFFER_WRITE);
+                HIP_TRY(memset_sync(net, net->p2p_recv[i], 0, std::max<uint64_t>(ro * 8, 256)), SNN_ERR_BUFFER_WRITE);
             }
             HIP_TRY(hipExtMallocWithFlags(reinterpret_cast<void **>(&net->p2p_flags), std::max<size_t>((size_t)G * 4, 256), hipDeviceMallocFinegrained),
                     SNN_ERR_BUFFER_CREATE);
-            HIP_TRY(hipMemset(net->p2p_flags, 0, std::max<size_t>((size_t)G * 4, 256)), SNN_ERR_BUFFER_WRITE);
+            HIP_TRY(memset_sync(net, net->p2p_flags, 0, std::max<size_t>((size_t)G * 4, 256)), SNN_ERR_BUFFER_WRITE);
             HIP_TRY(snn_malloc(&net->p2p_done_blocks, 256), SNN_ERR_BUFFER_CREATE);
-            HIP_TRY(hipMemset(net->p2p_done_blocks, 0, 256), SNN_ERR_BUFFER_WRITE);
+            HIP_TRY(memset_sync(net, net->p2p_done_blocks, 0, 256), SNN_ERR_BUFFER_WRITE);
             if (!net->p2p_failed) {
                 HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&net->p2p_failed), 8, hipHostMallocMapped), SNN_ERR_BUFFER_CREATE);
                 net->p2p_failed[0] = 0u;
@@ -207,7 +217,7 @@ int ensure_exchange_plan(snn_network *net)
             for (uint32_t p = 0; p < G; ++p)
                 for (size_t i = 0; i < net->halo_need[p].size(); ++i)
                     halo_word[net->halo_need[p][i]] = (uint32_t)(net->x_recv_off[p] + i);       // plane 0 of the segment
-            TRY(upload_table(&net->halo_word_dev, halo_word));
+            TRY(upload_table(net, &net->halo_word_dev, halo_word));
             HIP_TRY(snn_malloc(&net->csr_plan_direct, std::max<size_t>(net->sell_entries * 4, 256)),
                     SNN_ERR_BUFFER_CREATE);
             hipLaunchKernelGGL(k_csr_plan, dim3((n_slices * 64 + 255) / 256), dim3(256), 0, net->stream, csr_graph(net),
@@ -220,10 +230,10 @@ int ensure_exchange_plan(snn_network *net)
         net->seg_n[w] = (uint32_t)cnt[w].size();
         net->seg_max[w] = 0;
         for (uint32_t c : cnt[w]) net->seg_max[w] = std::max(net->seg_max[w], c);
-        TRY(upload_table(&net->seg_count_dev[w], cnt[w]));
-        TRY(upload_table(&net->seg_offset_dev[w], off[w]));
-        TRY(upload_table(&net->seg_first_dev[w], first[w]));
-        TRY(upload_table(&net->seg_loff_dev[w], loff[w]));
+        TRY(upload_table(net, &net->seg_count_dev[w], cnt[w]));
+        TRY(upload_table(net, &net->seg_offset_dev[w], off[w]));
+        TRY(upload_table(net, &net->seg_first_dev[w], first[w]));
+        TRY(upload_table(net, &net->seg_loff_dev[w], loff[w]));
     }
     net->x_dirty = false;
     return SNN_OK;
@@ -496,10 +506,12 @@ int direct_begin(snn_network *net)
     HIP_TRY(hipMemsetAsync(net->halo_send_buf2, 0, std::max<uint64_t>(so * 4, 256), net->stream), SNN_ERR_BUFFER_WRITE);
     net->hx_par = 0;
     net->stamp_pending = false;
-    net->peer_run = net->halo_peer && net->p2p_connected && net->p2p_recv[0];
+    net->peer_run = false;
+    const bool peer = net->halo_peer && net->p2p_connected && net->p2p_recv[0];
+    if (peer && net->p2p_epoch > 0x7FFFFF00u) return fail(SNN_ERR_BAD_STATE, "peer form: step tags exhausted (2^31 steps): rebuild the exchange plan");
+    net->peer_run = peer;
     if (net->peer_run) {
         // the peer form: the set the first step reads -- values "produced by step epoch - 1" -- from the mirror, tagged for it
-        if (net->p2p_epoch > 0x7FFFFF00u) return fail(SNN_ERR_BAD_STATE, "peer form: step tags exhausted (2^31 steps): rebuild the exchange plan");
         if (net->recv_total) {
             hipLaunchKernelGGL(k_peer_prefill, dim3((net->recv_total + 255) / 256), dim3(256), 0, net->stream, wire_args(net, 1), net->recv_total,
                                net->seg_n[1], net->p2p_recv[(net->p2p_epoch + 1u) & 1u], net->p2p_epoch);
@@ -576,11 +588,15 @@ int p2p_build_tables(snn_network *net)
         if (!net->p2p_peers[p].set) return fail(SNN_ERR_BAD_STATE, "peer form: shard " + std::to_string(p) + " is read by this shard but is not connected");
         signal.push_back(net->p2p_peers[p].flags + 4ull * me);
     }
-    for (int k = 0; k < 2; ++k) TRY(upload_table(reinterpret_cast<unsigned long long **>(&net->p2p_dst_dev[k]), dst[k]));
-    TRY(upload_table(&net->p2p_peer_dev, peer));
-    TRY(upload_table(reinterpret_cast<unsigned long long **>(&net->p2p_signal_dev), signal));
+    for (int k = 0; k < 2; ++k) TRY(upload_table(net, reinterpret_cast<unsigned long long **>(&net->p2p_dst_dev[k]), dst[k]));
+    TRY(upload_table(net, &net->p2p_peer_dev, peer));
+    TRY(upload_table(net, reinterpret_cast<unsigned long long **>(&net->p2p_signal_dev), signal));
     net->p2p_n_signal = (uint32_t)signal.size();
     net->p2p_connected = true;
+    net->x_agreed = false;                         // whether a run takes the peer form is part of what the ranks agree on
+    // receive sets of earlier plans: every peer that addressed them has been reconnected by now (or never will step again)
+    for (void *b : net->p2p_retired) (void)hipFree(b);
+    net->p2p_retired.clear();
     return SNN_OK;
 }
 

@@ -195,6 +195,7 @@ struct snn_network {
     uint32_t **p2p_signal_dev = nullptr;                      // the neighbours' flags[this shard]
     uint32_t p2p_n_signal = 0;
     bool p2p_connected = false;
+    std::vector<void *> p2p_retired;                          // receive sets / done counters of earlier plans, see p2p_release
     bool peer_run = false;                                    // the run in progress uses the peer form
     uint32_t p2p_epoch = 0;                                   // steps of peer-form runs done so far (tags and done counters)
     uint32_t p2p_spin_limit = 1u << 26;
@@ -269,6 +270,29 @@ struct snn_network {
     uint32_t *snap_buf = nullptr;
     uint32_t snap_entries = 0, snap_max_words = 0;
     size_t snap_allocs_seen = 0;
+    size_t snap_words = 0;
+    std::vector<CopyEntry> snap_table_host;     // the table as uploaded (names of the arrays in a "verify" report)
+    size_t verify_words = 0;                    // capacity of each half of verify_buf
+    uint32_t run_chunk_steps = 1u << 20;        // option "run_resident_chunk_steps" (test hook): steps per one-launch chunk
+    // option "verify" (SNN_AMD_VERIFY=1; tests and campaigns): every snn_run call on a handle without weight updates takes its
+    // steps TWICE from the same snapshot and compares the two outcomes on the device (k_compare_table_alt)
+    int verify = 0;
+    uint32_t *verify_buf = nullptr;             // the first outcome, laid out like snap_buf
+    uint32_t *verify_report = nullptr;          // device words, see k_compare_table_alt
+    uint64_t snap_generation = 0;               // how often the snapshot table has been laid out
+    uint64_t stat_verify_runs = 0, stat_verify_mismatches = 0, stat_verify_skipped = 0;
+    std::string verify_text;                    // what the last mismatch was (snn_debug_verify_report)
+    // snn_debug_checkpoint (test support): device arrays and the stepper's host-side cursors as they were at the call
+    struct Checkpoint {
+        bool valid = false;
+        std::vector<std::pair<void *, std::vector<uint8_t>>> arrays;
+        long long clock = 0;
+        std::vector<long long> st_clock;
+        uint64_t hist_steps = 0, hist_tick = 0;
+        int shadow_cur = 0, cell_view_cur = 0, persistent_run = 1;
+        bool shadow_valid = false, view_dirty = true, counts_dirty = true, uni_dirty = true;
+        uint32_t live_mask_applied = 0xFFFFFFFFu, n_live = K_TYPES, live_type[K_TYPES] = {0, 1, 2}, mirror_mask = 0xFFFFFFFFu;
+    } checkpoint;
     unsigned long long *run_timing = nullptr;   // SNN_AMD_RUN_TIMING=1: phase clocks of k_run_resident, printed per launch
     int run_timing_opt = 0;                     // option "run_timing": collect them without printing (snn_get_stat)
     unsigned long long run_timing_last[4] = {0, 0, 0, 0};   // workgroup 0, last launch: poll, barrier, turns, update + publish
@@ -279,11 +303,13 @@ struct snn_network {
     // t + 1; 2: prepared delta vectors, applied right away by scatter passes (SNN_AMD_DEFER_STDP / "defer_stdp").
     // Measured on the quad-row matrix: the scatter kernels win at every spike rate.
     int defer_stdp = 0;
+    int stdp_columns_form = 0;            // option "stdp_columns_form": 0 one thread per presynaptic row, 1 one lane per 16-byte unit (k_stdp_columns_quads)
     bool stdp_pending = false;
     uint32_t *stdp_flag = nullptr;
     float *stdp_dcol = nullptr, *stdp_drow = nullptr;
     uint32_t dcol_stride = 0;
     long long *st_clock_dev = nullptr;
+    long long *st_clock_pinned = nullptr;   // page-locked staging of st_clock for the asynchronous upload that opens a run
     long long run_step_offset = 0;
     bool run_active = false;        // a (possibly externally driven) run is open: device clocks are ahead of st_clock
     // fused small-lattice step (k_step_resident): two shadow copies of the exchange buffer + per-tile tickets
@@ -366,6 +392,27 @@ inline hipError_t snn_malloc(T **out, size_t bytes)
 {
     hipError_t e = hipMalloc(reinterpret_cast<void **>(out), bytes);
     return e != hipSuccess ? e : poison_if_asked(*out, bytes);
+}
+
+// Host <-> device transfers of the setters / getters and the fills of fresh buffers: on the HANDLE'S OWN stream, and waited
+// for.  The handle's stream is hipStreamNonBlocking -- nothing orders it against the null stream -- so a blocking null-stream
+// hipMemcpy / hipMemset in front of a kernel on it is correct only as long as the runtime completes the transfer before it
+// returns; with everything on one stream the order no longer rests on that (round 5: no null-stream call after finalize).
+inline hipError_t copy_sync(snn_network *net, void *dst, const void *src, size_t bytes, hipMemcpyKind kind)
+{
+    const hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, net->stream);
+    return e != hipSuccess ? e : hipStreamSynchronize(net->stream);
+}
+inline hipError_t copy2d_sync(snn_network *net, void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t height,
+                              hipMemcpyKind kind)
+{
+    const hipError_t e = hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, kind, net->stream);
+    return e != hipSuccess ? e : hipStreamSynchronize(net->stream);
+}
+inline hipError_t memset_sync(snn_network *net, void *dst, int value, size_t bytes)
+{
+    const hipError_t e = hipMemsetAsync(dst, value, bytes, net->stream);
+    return e != hipSuccess ? e : hipStreamSynchronize(net->stream);
 }
 
 hipError_t alloc_streamed(void **out, size_t bytes)
@@ -661,8 +708,8 @@ int build_state(snn_network *net)
         for (const auto &l : net->lattices) { lf[l.slot] = l.first; lc[l.slot] = l.count; }
         TRY(dev_alloc_t(net, &net->lat_first_dev, nl));
         TRY(dev_alloc_t(net, &net->lat_count_dev, nl));
-        HIP_TRY(hipMemcpy(net->lat_first_dev, lf.data(), nl * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
-        HIP_TRY(hipMemcpy(net->lat_count_dev, lc.data(), nl * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
+        HIP_TRY(copy_sync(net, net->lat_first_dev, lf.data(), nl * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
+        HIP_TRY(copy_sync(net, net->lat_count_dev, lc.data(), nl * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
         TRY(dev_alloc_t(net, &net->spike_counts, np));
         TRY(fill_u32(net, net->spike_counts, np, 0));
     }
@@ -802,6 +849,8 @@ int build_state(snn_network *net)
         TRY(fill_u32(net, c.lattice_slot + (l.first - net->nn), l.count, l.slot));
     net->st_clock.assign(std::max<size_t>(1, net->st_lattices.size()), 0);
     TRY(dev_alloc_t(net, &net->st_clock_dev, net->st_clock.size()));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&net->st_clock_pinned), net->st_clock.size() * sizeof(long long), hipHostMallocDefault),
+            SNN_ERR_BUFFER_CREATE);
 
     // graph + partials + counts
     if (net->csr) net->n_chunks = 1;     // the CSR kernel writes the finished two-level sum
@@ -823,8 +872,8 @@ int end_run(snn_network *net, bool keep_stdp = false);
 int xplane_copy(snn_network *net, int plane, uint32_t first, uint32_t count, void *host, bool to_device)
 {
     float *dev = net->xbuf + net->xl.at(first, plane);
-    if (to_device) HIP_TRY(hipMemcpy(dev, host, (size_t)count * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
-    else HIP_TRY(hipMemcpy(host, dev, (size_t)count * 4, hipMemcpyDeviceToHost), SNN_ERR_BUFFER_READ);
+    if (to_device) HIP_TRY(copy_sync(net, dev, host, (size_t)count * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
+    else HIP_TRY(copy_sync(net, host, dev, (size_t)count * 4, hipMemcpyDeviceToHost), SNN_ERR_BUFFER_READ);
     return SNN_OK;
 }
 
@@ -863,8 +912,8 @@ int attr_io(snn_network *net, uint32_t id, const char *name, AttrType type, void
     if (!typed) {
         if (a.store == S_PLAIN) {
             char *dev = static_cast<char *>(a.base) + (size_t)first * 4;
-            if (set) HIP_TRY(hipMemcpy(dev, host, count * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
-            else HIP_TRY(hipMemcpy(host, dev, count * 4, hipMemcpyDeviceToHost), SNN_ERR_BUFFER_READ);
+            if (set) HIP_TRY(copy_sync(net, dev, host, count * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
+            else HIP_TRY(copy_sync(net, host, dev, count * 4, hipMemcpyDeviceToHost), SNN_ERR_BUFFER_READ);
         } else {
             TRY(xplane_copy(net, a.plane, first, l->count, host, set));
         }
@@ -876,8 +925,8 @@ int attr_io(snn_network *net, uint32_t id, const char *name, AttrType type, void
             if (set) for (uint32_t i = 0; i < l->count; ++i) tmp[i] = h[(size_t)i * K_TYPES + k];
             if (a.store == S_PLAIN_K) {
                 char *dev = static_cast<char *>(a.base) + ((size_t)k * a.pad + first) * 4;
-                if (set) HIP_TRY(hipMemcpy(dev, tmp.data(), (size_t)l->count * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
-                else HIP_TRY(hipMemcpy(tmp.data(), dev, (size_t)l->count * 4, hipMemcpyDeviceToHost), SNN_ERR_BUFFER_READ);
+                if (set) HIP_TRY(copy_sync(net, dev, tmp.data(), (size_t)l->count * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
+                else HIP_TRY(copy_sync(net, tmp.data(), dev, (size_t)l->count * 4, hipMemcpyDeviceToHost), SNN_ERR_BUFFER_READ);
             } else {
                 TRY(xplane_copy(net, a.plane + k, first, l->count, tmp.data(), set));
             }

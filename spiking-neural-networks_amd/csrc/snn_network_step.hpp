@@ -354,7 +354,14 @@ int launch_plasticity_kernels(snn_network *net)
         return SNN_OK;
     }
     const unsigned sy = 64;   // spiking neurons processed concurrently; the rest grid-strides
-    hipLaunchKernelGGL(k_stdp_columns, dim3((net->n_tot + 255) / 256, sy), dim3(256), 0, net->stream, a);
+    if (net->stdp_columns_form == 1) {
+        // quad form: 256 listed columns per workgroup (64 per wavefront) x slabs of row groups
+        const uint32_t groups = (net->n_tot + 3u) / 4u;
+        const unsigned slabs = std::max(1u, std::min(256u, groups / 16u));
+        hipLaunchKernelGGL(k_stdp_columns_quads, dim3(4, slabs), dim3(256), 0, net->stream, a);
+    } else {
+        hipLaunchKernelGGL(k_stdp_columns, dim3((net->n_tot + 255) / 256, sy), dim3(256), 0, net->stream, a);
+    }
     HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
     hipLaunchKernelGGL(k_stdp_rows, dim3((net->n_loc + 255) / 256, sy), dim3(256), 0, net->stream, a);
     HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
@@ -705,10 +712,11 @@ int run_snapshot(snn_network *net, bool restore)
         uint32_t max_words = 0;
         for (const auto &kv : net->alloc_bytes) {
             if (kv.second > limit || kv.first == net->snap_table || kv.first == net->snap_buf ||
-                kv.first == net->run_granules || kv.first == net->run_partials || kv.first == net->run_timing)
+                kv.first == net->run_granules || kv.first == net->run_partials || kv.first == net->run_timing || kv.first == net->verify_buf)
                 continue;
             const uint32_t w = (uint32_t)(kv.second / 4);
-            table.push_back(CopyEntry{static_cast<uint32_t *>(kv.first), nullptr, w, 0u});
+            // pad = 1: contents depend on the order of atomics (the compacted spike list) -- copied, but not compared by "verify"
+            table.push_back(CopyEntry{static_cast<uint32_t *>(kv.first), nullptr, w, kv.first == (void *)net->spike_list ? 1u : 0u});
             words += w;
             max_words = std::max(max_words, w);
         }
@@ -721,12 +729,15 @@ int run_snapshot(snn_network *net, bool restore)
             }
         net->snap_table = nullptr; net->snap_buf = nullptr;
         TRY(dev_alloc_t(net, &net->snap_buf, words));
+        net->snap_words = words;
         TRY(dev_alloc_t(net, &net->snap_table, table.size()));
         size_t off = 0;
         for (auto &e : table) { e.dst = net->snap_buf + off; off += e.words; }
         HIP_TRY(hipMemcpyAsync(net->snap_table, table.data(), table.size() * sizeof(CopyEntry), hipMemcpyHostToDevice, net->stream),
                 SNN_ERR_BUFFER_WRITE);
         HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);       // `table` leaves scope
+        net->snap_table_host = table;
+        net->snap_generation += 1;
         net->snap_entries = (uint32_t)table.size();
         net->snap_max_words = max_words;
         net->snap_allocs_seen = net->allocs.size();
@@ -738,7 +749,7 @@ int run_snapshot(snn_network *net, bool restore)
     return SNN_OK;
 }
 
-int launch_run_resident(snn_network *net, uint64_t iterations)
+int launch_run_resident(snn_network *net, uint64_t iterations, uint64_t steps_before = 0)
 {
     if (!net->run_granules) {
         TRY(dev_alloc_t(net, &net->run_granules, RUN_GRANULE_WORDS));
@@ -768,8 +779,10 @@ int launch_run_resident(snn_network *net, uint64_t iterations)
         }
         net->run_probed_grid = n_groups;
     }
-    while (iterations) {
-        const uint32_t steps = (uint32_t)std::min<uint64_t>(iterations, 1u << 20);
+    {
+        // ONE chunk per call (at most RUN_RESIDENT_CHUNK_STEPS steps): the caller takes its snapshot per chunk, so a chunk that
+        // gives up is rolled back to ITS start -- the weights and counters the earlier chunks committed stay
+        const uint32_t steps = (uint32_t)iterations;
         if (net->run_tag > 0x7FFFFFFFu - steps - 2u) {           // tags would wrap (bit 31 carries a spike): start over on clean slots
             HIP_TRY(hipMemsetAsync(net->run_granules, 0, RUN_GRANULE_WORDS * 8, net->stream), SNN_ERR_BUFFER_WRITE);
             HIP_TRY(hipMemsetAsync(net->run_partials, 0, RUN_PARTIAL_WORDS * 8, net->stream), SNN_ERR_BUFFER_WRITE);
@@ -786,7 +799,8 @@ int launch_run_resident(snn_network *net, uint64_t iterations)
         r.tag_base = net->run_tag;
         r.failed = net->run_failed;
         r.spin_limit = net->run_spin_limit;
-        r.fault_step = net->run_fault_step;
+        // (the test hook counts steps of the RUN CALL: a fault can be placed in a later chunk of it)
+        r.fault_step = (net->run_fault_step > steps_before && net->run_fault_step <= steps_before + steps) ? (uint32_t)(net->run_fault_step - steps_before) : 0u;
         r.cells = net->ca;
         r.st_kind = net->st_kind;
         r.lattice_clock = net->st_clock_dev;
@@ -901,7 +915,6 @@ int launch_run_resident(snn_network *net, uint64_t iterations)
         net->clock += steps;
         net->run_step_offset += steps;
         if (recording(net)) { net->hist_steps += steps; net->hist_tick += steps; }
-        iterations -= steps;
     }
     return SNN_OK;
 }
@@ -1199,8 +1212,10 @@ int begin_run(snn_network *net, uint64_t iterations)
         net->view_dirty = true;
     }
     if (net->nc) {
-        // pageable source: the copy is staged before the call returns, so the host vector may change afterwards
-        HIP_TRY(hipMemcpyAsync(net->st_clock_dev, net->st_clock.data(), net->st_clock.size() * sizeof(long long),
+        // from a page-locked staging copy: the transfer may read its source any time until the stream has drained, and the
+        // staging words are next written by the begin_run after this run's end_run (which waits for the stream)
+        for (size_t i = 0; i < net->st_clock.size(); ++i) net->st_clock_pinned[i] = net->st_clock[i];
+        HIP_TRY(hipMemcpyAsync(net->st_clock_dev, net->st_clock_pinned, net->st_clock.size() * sizeof(long long),
                                hipMemcpyHostToDevice, net->stream), SNN_ERR_BUFFER_WRITE);
         if (net->view_dirty) { net->stat_view_refreshes += 1; TRY(launch_spike_trains(net, 0, 0, net->clock)); }
     }
@@ -1270,6 +1285,12 @@ int graph_rows_io(snn_network *net, uint32_t pre_begin, uint32_t pre_count, floa
         return fail(SNN_ERR_BUFFER_CREATE, "staging allocation failed");
     }
     int rc = SNN_OK;
+    uint32_t *bad = nullptr;
+    if (set && (snn_malloc(&bad, 256) != hipSuccess || hipMemsetAsync(bad, 0, 256, net->stream) != hipSuccess)) {
+        (void)hipFree(dw); (void)hipFree(dc);
+        if (bad) (void)hipFree(bad);
+        return fail(SNN_ERR_BUFFER_CREATE, "staging allocation failed");
+    }
     for (uint32_t r = 0; r < pre_count && rc == SNN_OK; r += hop) {
         const uint32_t rows = std::min(hop, pre_count - r);
         const size_t bytes = (size_t)rows * host_ld * 4;
@@ -1280,7 +1301,7 @@ int graph_rows_io(snn_network *net, uint32_t pre_begin, uint32_t pre_count, floa
                 break;
             }
             hipLaunchKernelGGL(k_graph_import, dim3((net->ld + 255) / 256, rows), dim3(256), 0, net->stream,
-                               net->W, net->ld, net->n_loc, net->q0, pre_begin + r, rows, dw, dc, host_ld);
+                               net->W, net->ld, net->n_loc, net->q0, pre_begin + r, rows, dw, dc, host_ld, bad);
         } else {
             // columns outside the shard are left untouched in the caller's buffers
             if (hipMemcpyAsync(dw, weights + (size_t)r * host_ld, bytes, hipMemcpyHostToDevice, net->stream) != hipSuccess ||
@@ -1300,9 +1321,16 @@ int graph_rows_io(snn_network *net, uint32_t pre_begin, uint32_t pre_count, floa
         if (hipGetLastError() != hipSuccess) { rc = fail(SNN_ERR_QUEUE, "graph kernel launch failed"); break; }
         if (hipStreamSynchronize(net->stream) != hipSuccess) { rc = fail(SNN_ERR_WAIT, "graph transfer wait failed"); break; }
     }
+    uint32_t bad_host[3] = {0, 0, 0};
+    if (set && rc == SNN_OK && copy_sync(net, bad_host, bad, 12, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(SNN_ERR_BUFFER_READ, "graph check download failed");
     (void)hipFree(dw);
     (void)hipFree(dc);
+    if (bad) (void)hipFree(bad);
     if (set) net->counts_dirty = true;
+    if (rc == SNN_OK && bad_host[0])
+        return fail(SNN_ERR_BAD_ARG, std::to_string(bad_host[0]) + " connected edge(s) carry a NaN weight, e.g. (pre " + std::to_string(bad_host[1]) +
+                    ", post " + std::to_string(bad_host[2]) + "): NaN is the absent-edge sentinel of the device matrix, such an edge cannot be "
+                    "stored (graph/mod.rs:204-213); the rows of this call were imported with those edges absent");
     return rc;
 }
 

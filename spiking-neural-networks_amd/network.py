@@ -8,6 +8,7 @@ neuron/iterate_and_spike/mod.rs:3156-3189), the flattened graph
 The Lixirnet-style classes in `lattice.py` sit on top of this.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -25,6 +26,20 @@ REFRACTORINESS_CUSTOM = 2   # neural_refractoriness$kind of the generated refrac
 NUM_NT_TYPES = 3
 
 _DT = {np.dtype(np.float32): "f32", np.dtype(np.uint32): "u32", np.dtype(np.int32): "i32"}
+_POISON = os.environ.get("SNN_HOST_POISON", "")
+
+
+def _out(shape, dtype=np.float32):
+    """A buffer the library is about to fill.  SNN_HOST_POISON=1 (campaigns): pre-filled with a pattern no result holds --
+    a signalling-NaN-like word for floats, 0xDB bytes otherwise -- so that a getter which returns before its transfer has
+    landed, or fills less than it reports, shows in every comparison instead of depending on what the allocator handed out."""
+    a = np.empty(shape, dtype)
+    if _POISON:
+        if a.dtype == np.float32:
+            a.view(np.uint32)[...] = 0x7FA0DEAD
+        else:
+            a.view(np.uint8)[...] = 0xDB
+    return a
 _PTR = {"f32": _lib.f32p, "u32": _lib.u32p, "i32": _lib.i32p}
 
 
@@ -118,7 +133,7 @@ class DeviceNetwork:
     def get_attr(self, id, name, dtype=np.float32, per_type=False):
         rows, cols, _ = self.lattices[id]
         n = rows * cols
-        out = np.empty((n, NUM_NT_TYPES) if per_type else (n,), dtype=dtype)
+        out = _out((n, NUM_NT_TYPES) if per_type else (n,), dtype=dtype)
         kind = _DT[np.dtype(dtype)]
         fn = getattr(self._L, f"snn_get_attr_{kind}")
         self._check(fn(self._h, id, name.encode(), out.ctypes.data_as(_PTR[kind]), out.size))
@@ -169,7 +184,7 @@ class DeviceNetwork:
                                              w.ctypes.data_as(_lib.f32p), w.size))
 
     def get_graph_csr(self):
-        w = np.empty(getattr(self, "_nnz", 0), np.float32)
+        w = _out(getattr(self, "_nnz", 0), np.float32)
         self._check(self._L.snn_get_graph_csr(self._h, w.ctypes.data_as(_lib.f32p), w.size))
         return w
 
@@ -198,6 +213,30 @@ class DeviceNetwork:
         v = C.c_uint64()
         self._check(self._L.snn_get_clock(self._h, C.byref(v)))
         return v.value
+
+    def set_clock(self, clock):
+        """internal_clock of the network (LatticeNetworkGPU::from_network): firing times are absolute step numbers"""
+        self._check(self._L.snn_set_clock(self._h, int(clock)))
+
+    def set_spike_train_clock(self, id, clock):
+        self._check(self._L.snn_set_spike_train_clock(self._h, id, int(clock)))
+
+    def spike_train_clock(self, id):
+        v = C.c_uint64()
+        self._check(self._L.snn_get_spike_train_clock(self._h, id, C.byref(v)))
+        return v.value
+
+    # ---- test support ---------------------------------------------------------------------
+    def checkpoint(self):
+        """keeps everything a later run call reads (snn_debug_checkpoint); restore_checkpoint puts it back"""
+        self._check(self._L.snn_debug_checkpoint(self._h, 0))
+
+    def restore_checkpoint(self):
+        self._check(self._L.snn_debug_checkpoint(self._h, 1))
+
+    def verify_report(self):
+        """what the last mismatch of the option "verify" was ("" when there was none)"""
+        return (self._L.snn_debug_verify_report(self._h) or b"").decode()
 
     # ---- stepping -------------------------------------------------------------------------
     def run(self, iterations):
@@ -267,7 +306,7 @@ class DeviceNetwork:
         """ascending global indices of shard `peer`'s neurons that this handle's CSR rows read"""
         n = C.c_uint32()
         self._check(self._L.snn_halo_needs(self._h, peer, None, 0, C.byref(n)))
-        out = np.empty(n.value, np.uint32)
+        out = _out(n.value, np.uint32)
         if n.value:
             self._check(self._L.snn_halo_needs(self._h, peer, out.ctypes.data_as(_lib.u32p), out.size, C.byref(n)))
         return out
@@ -277,7 +316,7 @@ class DeviceNetwork:
         shard handles of a multi-rank run -- the ones its own rows read"""
         n = C.c_uint32()
         self._check(self._L.snn_cells_read(self._h, None, 0, C.byref(n)))
-        out = np.empty(n.value, np.uint32)
+        out = _out(n.value, np.uint32)
         if n.value:
             self._check(self._L.snn_cells_read(self._h, out.ctypes.data_as(_lib.u32p), out.size, C.byref(n)))
         return out
@@ -355,14 +394,14 @@ class DeviceNetwork:
     def voltage_history(self, id):
         rows, cols, _ = self.lattices[id]
         steps = self.history_steps()
-        out = np.empty((steps, rows * cols), np.float32)
+        out = _out((steps, rows * cols), np.float32)
         self._check(self._L.snn_get_voltage_history(self._h, id, out.ctypes.data_as(_lib.f32p), out.size))
         return out
 
     def spike_history(self, id):
         rows, cols, _ = self.lattices[id]
         steps = self.history_steps()
-        out = np.empty((steps, rows * cols), np.uint8)
+        out = _out((steps, rows * cols), np.uint8)
         self._check(self._L.snn_get_spike_history(self._h, id, out.ctypes.data_as(_lib.u8p), out.size))
         return out
 
@@ -431,7 +470,7 @@ class DeviceNetwork:
         self._check(self._L.snn_set_traces_csr(self._h, t.ctypes.data_as(_lib.f32p), t.size))
 
     def get_traces_csr(self):
-        t = np.empty(getattr(self, "_nnz", 0), np.float32)
+        t = _out(getattr(self, "_nnz", 0), np.float32)
         self._check(self._L.snn_get_traces_csr(self._h, t.ctypes.data_as(_lib.f32p), t.size))
         return t
 
@@ -455,7 +494,7 @@ class DeviceNetwork:
         """[steps][n][n] snapshots of lattice `id`'s internal weights (update_graph_history)"""
         rows, cols, _ = self.lattices[id]
         n = rows * cols
-        out = np.empty((self.history_steps(), n, n), np.float32)
+        out = _out((self.history_steps(), n, n), np.float32)
         self._check(self._L.snn_get_graph_history(self._h, id, out.ctypes.data_as(_lib.f32p), out.shape[0]))
         return out
 
@@ -468,18 +507,18 @@ class DeviceNetwork:
                                                    reference_voltage, distance, conductivity))
 
     def average_voltage_history(self, id):
-        out = np.empty(self.history_steps(), np.float32)
+        out = _out(self.history_steps(), np.float32)
         self._check(self._L.snn_get_average_voltage_history(self._h, id, out.ctypes.data_as(_lib.f32p), out.size))
         return out
 
     def eeg_history(self, id):
-        out = np.empty(self.history_steps(), np.float32)
+        out = _out(self.history_steps(), np.float32)
         self._check(self._L.snn_get_eeg_history(self._h, id, out.ctypes.data_as(_lib.f32p), out.size))
         return out
 
     def spike_counts(self, id):
         rows, cols, _ = self.lattices[id]
-        out = np.empty(rows * cols, np.uint32)
+        out = _out(rows * cols, np.uint32)
         self._check(self._L.snn_get_spike_counts(self._h, id, out.ctypes.data_as(_lib.u32p), out.size))
         return out
 
@@ -525,7 +564,7 @@ def probe_math(which, x, device=0):
     """Evaluate the stepper's device functions (0 exp, 1 pow3, 2 pow4) on the GPU."""
     L = _lib.load()
     a = np.ascontiguousarray(x, dtype=np.float32)
-    out = np.empty_like(a)
+    out = _out(a.shape, a.dtype)
     _lib.check(L.snn_probe_math(device, which, a.ctypes.data_as(_lib.f32p), out.ctypes.data_as(_lib.f32p), a.size))
     return out
 
@@ -533,7 +572,7 @@ def probe_math(which, x, device=0):
 def probe_math_bits(which, first, count, stride=1, y=0.0, device=0):
     """The same over float BIT PATTERNS first + i * stride formed on the device; which = 3: powf(x, y)."""
     L = _lib.load()
-    out = np.empty(count, np.float32)
+    out = _out(count, np.float32)
     _lib.check(L.snn_probe_math_bits(device, which, first & 0xFFFFFFFF, stride, float(y), out.ctypes.data_as(_lib.f32p),
                                      count))
     return out

@@ -82,7 +82,8 @@ def worker(args):
         if time.time() - last_report > 60:
             last_report = time.time()
             print(f"[worker {args.index}] seed {seed} " + " ".join(f"{s.split(':')[1]}={c[0]}/{c[1]}" for s, c in counts.items()), flush=True)
-    log.write(json.dumps({"worker": args.index, "done": True, "counts": counts, "next_seed": seed}) + "\n")
+    log.write(json.dumps({"worker": args.index, "done": True, "counts": counts, "next_seed": seed,
+                          "armed": {k: os.environ.get(k) for k in ("SNN_AMD_VERIFY", "MALLOC_PERTURB_", "SNN_HOST_POISON", "SNN_CHECKPOINTS")}}) + "\n")
     log.close()
 
 
@@ -120,6 +121,7 @@ def main():
     ap.add_argument("--streamer-steps", type=int, default=20)
     ap.add_argument("--streamer-pause-ms", type=float, default=0.0)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "campaign"))
+    ap.add_argument("--plain", action="store_true", help="workers without the verify / malloc-perturb / host-poison arming")
     args = ap.parse_args()
     os.makedirs(os.path.join(args.out, "repro"), exist_ok=True)
     if args.role == "worker":
@@ -131,9 +133,20 @@ def main():
         os.remove(stop)
     base = [sys.executable, os.path.abspath(__file__)] + [a for a in sys.argv[1:]]
     t0 = time.time()
+    import checkpoint
+    ras_before = checkpoint.ras_counters()
+    # the workers run ARMED: comparisons at every run-call boundary with checkpoints (tests/checkpoint.py; the default), and unless
+    # --plain: the device steps every run call twice and compares with itself (SNN_AMD_VERIFY), glibc fills every malloc'ed and
+    # freed block with a byte pattern (MALLOC_PERTURB_), the binding pre-fills its output buffers (SNN_HOST_POISON)
+    worker_env = dict(os.environ)
+    if not args.plain:
+        worker_env.setdefault("SNN_AMD_VERIFY", "1")
+        worker_env.setdefault("MALLOC_PERTURB_", "165")
+        worker_env.setdefault("SNN_HOST_POISON", "1")
     procs = [subprocess.Popen(base + ["--role", "streamer", "--index", str(i)]) for i in range(args.streamers)]
-    procs += [subprocess.Popen(base + ["--role", "worker", "--index", str(i)]) for i in range(args.workers)]
+    procs += [subprocess.Popen(base + ["--role", "worker", "--index", str(i)], env=worker_env) for i in range(args.workers)]
     rcs = [p.wait() for p in procs]
+    ras_after = checkpoint.ras_counters()
     total, failures = {}, []
     for i in range(args.workers):
         path = os.path.join(args.out, f"worker-{i}.jsonl")
@@ -150,7 +163,9 @@ def main():
                "streamer_side": args.side, "tests": args.tests, "filter": args.filter, "first_seed": args.first_seed,
                "executions_and_failures": total, "executions": sum(t[0] for t in total.values()),
                "failures": sum(t[1] for t in total.values()), "failure_records": failures, "exit_codes": rcs,
-               "environment": {k: v for k, v in os.environ.items() if k.startswith(("SNN_", "AMD_", "HIP_", "HSA_", "OMP_"))}}
+               "environment": {k: v for k, v in worker_env.items() if k.startswith(("SNN_", "AMD_", "HIP_", "HSA_", "OMP_", "MALLOC_", "GPU_"))},
+               "ras_errors_before_ue_ce": checkpoint.ras_totals(ras_before), "ras_errors_after_ue_ce": checkpoint.ras_totals(ras_after),
+               "ras_before": ras_before, "ras_after": ras_after}
     with open(os.path.join(args.out, "summary.json"), "w") as f:
         json.dump(summary, f, indent=1)
     print(json.dumps({k: summary[k] for k in ("wall_s", "executions", "failures", "executions_and_failures", "exit_codes")}))

@@ -19,7 +19,11 @@ if "OMP_NUM_THREADS" not in os.environ:
 # Several shard handles of ONE process stand in for the ranks of a multi-GPU run (tests of the sharded loops): each rank's
 # stream must own a hardware queue, or a kernel that waits for a neighbour's values can sit in front of the very kernel that
 # produces them (the runtime spreads streams over 4 queues by default).  One rank per process -- the real thing -- never shares.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+# Only the tests that do this (marker `emulated_ranks`) run with more queues, in a child pytest process of their own
+# (tests/test_gpu_emulated_ranks.py): every other test keeps the runtime's default stream-to-queue mapping, the one production uses.
+EMULATED_RANKS_CHILD = os.environ.get("SNN_EMULATED_RANKS_CHILD") == "1"
+if EMULATED_RANKS_CHILD:
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 
 import pytest
 
@@ -31,6 +35,8 @@ for p in (ROOT, os.path.dirname(os.path.abspath(__file__))):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "emulated_ranks: several shard handles of ONE process stepped concurrently as if they were ranks "
+                                       "(needs GPU_MAX_HW_QUEUES=24: runs in the child process of tests/test_gpu_emulated_ranks.py)")
     # the in-tree native pieces are git-ignored build products: (re)build them when missing or stale
     import subprocess
     import snn_amd
@@ -41,6 +47,11 @@ def pytest_configure(config):
 def pytest_collection_modifyitems(config, items):
     # no test may sit on a GPU box for ever: with pytest-timeout present every test without its own limit gets 15 minutes
     # (the slowest one, the full-size C4 check, takes 20 s) and a hang ends in a stack dump of all threads
+    if not EMULATED_RANKS_CHILD:
+        skip = pytest.mark.skip(reason="ranks emulated by threads: runs in the child process of tests/test_gpu_emulated_ranks.py (GPU_MAX_HW_QUEUES=24)")
+        for item in items:
+            if item.get_closest_marker("emulated_ranks") is not None:
+                item.add_marker(skip)
     if not config.pluginmanager.hasplugin("timeout"):
         return
     for item in items:

@@ -94,3 +94,91 @@ def test_comm_lifecycle_is_refused_while_the_collectives_are_replaced():
         assert L.snn_comm_count(ctypes.cast(ctypes.pointer(fake), ctypes.c_void_p), ctypes.byref(world), ctypes.byref(rank)) == 0
     finally:
         assert L.snn_set_collectives(None) == 0
+
+
+# ---- the three statements of the boundary agree: the header, the ctypes binding, the Rust stub of INTEGRATION.md -------------
+INTEGRATION = os.path.join(os.path.dirname(HEADER), "..", "INTEGRATION.md")
+
+_C_SCALARS = {"int": ctypes.c_int, "uint32_t": ctypes.c_uint32, "uint64_t": ctypes.c_uint64, "size_t": ctypes.c_size_t,
+              "float": ctypes.c_float, "double": ctypes.c_double, "int32_t": ctypes.c_int32, "uint8_t": ctypes.c_uint8}
+_RUST_TO_C = {"c_int": "int", "u32": "uint32_t", "u64": "uint64_t", "usize": "size_t", "f32": "float", "f64": "double", "i32": "int32_t",
+              "u8": "uint8_t", "c_char": "char", "c_void": "void", "SnnNetwork": "snn_network_t", "SnnExchangePlan": "snn_exchange_plan",
+              "SnnCollectives": "snn_collectives"}
+
+
+def header_prototypes():
+    """name -> (return type, [parameter types]) of every function the header declares; types as C text without names / spaces"""
+    text = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    text = re.sub(r"typedef\s+struct\s+\w+\s*\{.*?\}\s*\w+\s*;", "", text, flags=re.S)        # (function-pointer members are not prototypes)
+    out = {}
+    for ret, name, params in re.findall(r"([A-Za-z_][\w\s\*]*?)\b(snn_[a-z0-9_]+)\s*\(([^()]*)\)\s*;", text):
+        types = []
+        for p in [q.strip() for q in params.split(",")]:
+            if p in ("void", ""):
+                continue
+            m = re.match(r"(.*?)(\b[A-Za-z_]\w*)?$", p)          # the trailing identifier is the parameter's name
+            t = m.group(1) if (m.group(2) and (m.group(1).strip())) else p
+            types.append(t.replace(" ", ""))
+        out[name] = (ret.replace("extern", "").replace(" ", ""), types)
+    return out
+
+
+def rust_prototypes():
+    """the `fn snn_*` declarations inside the extern "C" blocks of INTEGRATION.md, translated to the header's spelling"""
+    text = open(INTEGRATION).read()
+    out = {}
+    for block in re.findall(r"extern \"C\" \{(.*?)\n\s*\}", text, flags=re.S):
+        block = re.sub(r"//[^\n]*", "", block)
+        for name, params, ret in re.findall(r"fn\s+(snn_[a-z0-9_]+)\s*\(([^)]*)\)\s*(?:->\s*([^;]+))?;", block, flags=re.S):
+            def c_type(t):
+                t = t.strip()
+                stars = ""
+                const = False
+                while t.startswith("*"):
+                    kind, t = t.split(None, 1)
+                    const = const or (kind == "*const" and stars == "")      # constness of the pointee of the innermost pointer is what C spells
+                    inner_const = kind == "*const"
+                    stars += "*"
+                    t = t.strip()
+                    last_const = inner_const
+                base = _RUST_TO_C.get(t, t)
+                if stars:
+                    return ("const" if last_const else "") + base + stars
+                return base
+            types = [c_type(p.split(":", 1)[1]) for p in params.split(",") if ":" in p]
+            out[name] = (c_type(ret) if ret else "void", types)
+    return out
+
+
+def test_rust_stub_of_the_integration_document_matches_the_header():
+    """INTEGRATION.md's extern "C" declarations are what a maintainer of the reference would paste: name, arity and every
+    scalar / pointer type must be the header's (the document cannot be compiled here -- no rustc -- so it is parsed)"""
+    head, rust = header_prototypes(), rust_prototypes()
+    assert len(rust) >= 25, f"only {len(rust)} declarations found in INTEGRATION.md"
+    for name, (ret, types) in rust.items():
+        assert name in head, f"INTEGRATION.md declares {name}, which the header does not"
+        hret, htypes = head[name]
+        assert ret == hret, f"{name}: returns {ret} in INTEGRATION.md, {hret} in the header"
+        assert len(types) == len(htypes), f"{name}: {len(types)} parameters in INTEGRATION.md, {len(htypes)} in the header"
+        for i, (a, b) in enumerate(zip(types, htypes)):
+            # a `*mut T` may stand where C says `const T *` only for the opaque handle (Rust has no const handle type in the stub)
+            if a != b and not (a.replace("const", "") == b.replace("const", "") and "snn_network_t" in a):
+                raise AssertionError(f"{name}, parameter {i}: {a} in INTEGRATION.md, {b} in the header")
+
+
+def test_ctypes_signatures_match_the_header():
+    head = header_prototypes()
+    for name, (res, args) in _lib.SIGNATURES.items():
+        hret, htypes = head[name]
+        assert len(args) == len(htypes), f"{name}: {len(args)} ctypes arguments, {len(htypes)} header parameters"
+        want_ret = _C_SCALARS.get(hret)
+        if want_ret is not None:
+            assert res is want_ret, f"{name}: returns {hret}, bound as {res}"
+        else:
+            assert res in (ctypes.c_char_p, ctypes.c_void_p), f"{name}: returns {hret}, bound as {res}"
+        for i, (a, t) in enumerate(zip(args, htypes)):
+            if "*" in t or "snn_exchange_fn" in t:
+                assert a in (ctypes.c_void_p, ctypes.c_char_p) or hasattr(a, "_type_") or hasattr(a, "contents"), \
+                    f"{name}, parameter {i}: {t} bound as {a}"
+            else:
+                assert a is _C_SCALARS[t], f"{name}, parameter {i}: {t} bound as {a}"

@@ -159,3 +159,48 @@ def test_multi_gpu_entry_points_refuse_misuse(snn):
     assert a.clock == 3 and b.clock == 3
     for h in handles:
         h.close()
+
+
+def test_a_nan_weight_on_a_connected_edge_is_refused(snn):
+    """Some(NaN) is an edge in the reference (graph/mod.rs:204-213); the device matrix marks ABSENT edges with NaN, so such an edge
+    cannot be stored: both graph forms refuse it with SNN_ERR_BAD_ARG instead of silently dropping it"""
+    import numpy as np
+    n = 12
+    w = np.full((n, n), 0.5, np.float32)
+    c = np.ones((n, n), np.uint32)
+    w[3, 7] = np.nan
+    dn = snn.DeviceNetwork()
+    dn.add_lattice(0, 3, 4)
+    dn.finalize()
+    with pytest.raises(snn.SnnError) as e:
+        dn.set_graph_dense(w, c)
+    assert e.value.code == 11 and "NaN" in str(e.value) and "pre 3" in str(e.value) and "post 7" in str(e.value)
+    c[3, 7] = 0                                    # the same weight on an ABSENT edge is nobody's business
+    dn.set_graph_dense(w, c)
+    got_w, got_c = dn.get_graph_dense()
+    assert got_c[3, 7] == 0 and got_c.sum() == n * n - 1
+    dn.close()
+    dn = snn.DeviceNetwork()
+    dn.add_lattice(0, 3, 4)
+    dn.finalize(csr=True)
+    ptr = np.arange(0, n * 2 + 1, 2, dtype=np.uint64)
+    pre = np.tile(np.array([1, 5], np.uint32), n)
+    ws = np.ones(2 * n, np.float32)
+    ws[9] = np.nan
+    with pytest.raises(snn.SnnError) as e:
+        dn.set_graph_csr(ptr, pre, ws)
+    assert e.value.code == 11 and "NaN" in str(e.value)
+    ws[9] = 1.0
+    dn.set_graph_csr(ptr, pre, ws)
+    dn.close()
+
+
+def test_counter_rows_check_their_range_before_they_allocate(snn):
+    import ctypes
+    dn = snn.DeviceNetwork()
+    dn.add_lattice(0, 4, 4)
+    dn.finalize()
+    buf = (ctypes.c_uint8 * 16)()
+    assert dn._L.snn_set_counter_rows(dn._h, 0, 0xFFFFFFF0, buf) == 10          # SNN_ERR_DIM_MISMATCH, not std::bad_alloc
+    assert dn._L.snn_get_counter_rows(dn._h, 10, 0xFFFFFFF0, buf) == 10
+    dn.close()

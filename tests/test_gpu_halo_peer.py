@@ -11,7 +11,7 @@ import parity
 from test_gpu_csr import c5_structure
 from test_gpu_library_loop_threads import collectives, run_ranks  # noqa: F401  (fixture)
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.emulated_ranks]
 
 
 def check_against_oracle(handles, net, steps):

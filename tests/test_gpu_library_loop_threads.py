@@ -13,7 +13,7 @@ import parity
 from test_gpu_csr import c5_structure
 from test_gpu_sharded import build as dense_net
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.emulated_ranks]
 
 
 def run_ranks(handles, tc, calls):

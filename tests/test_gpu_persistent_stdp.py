@@ -36,9 +36,11 @@ def build(model, lattices, seed, density=0.8, drive=(-70, 29.9)):
     return net
 
 
-def run_device(snn, net, calls, persistent, fault=0):
+def run_device(snn, net, calls, persistent, fault=0, chunk=0):
     dn = parity.device_from_oracle(snn, net)
     dn.set_option("persistent_run", int(persistent))
+    if chunk:
+        dn.set_option("run_resident_chunk_steps", chunk)
     if fault:
         dn.set_option("run_resident_fault_step", fault)
         dn.set_option("run_resident_spin_limit", 20000)
@@ -92,6 +94,27 @@ def test_a_faulted_run_leaves_the_weights_to_the_per_step_repeat(snn):
     a = run_device(snn, net, [90, 40], True, fault=37)
     net.run(130, voltage_history=True, spike_history=True)
     assert a["fallbacks"] == 1 and a["stdp_steps"] == 0
+    check(net, a)
+
+
+@pytest.mark.parametrize("fault", [5, 21, 40, 63])
+def test_a_fault_in_a_later_chunk_rolls_back_to_that_chunk_only(snn, fault):
+    """A run call longer than one launch's chunk (2^20 steps; 16 here through the test hook) commits the weights of every
+    completed chunk.  A launch that gives up later in the call must be rolled back to ITS start: replaying the whole call per step
+    would apply the committed chunks' STDP updates a second time (round-4 review of snn_network_step.hpp:890)."""
+    net = build(ob.IZHIKEVICH, [(0, 12, 12), (1, 10, 10)], 23)
+    a = run_device(snn, net, [64, 30], True, fault=fault, chunk=16)
+    net.run(94, voltage_history=True, spike_history=True)
+    assert a["fallbacks"] == 1
+    assert a["stdp_steps"] == 16 * ((fault - 1) // 16), "the chunks before the faulted one stay committed"
+    check(net, a)
+
+
+def test_chunked_runs_equal_one_launch(snn):
+    net = build(ob.IZHIKEVICH, [(0, 9, 9), (1, 7, 11)], 24)
+    a = run_device(snn, net, [100, 7], True, chunk=16)
+    net.run(107, voltage_history=True, spike_history=True)
+    assert a["launches"] == 7 + 1 and a["fallbacks"] == 0          # 6 chunks of 16 + one of 4, then 7 steps in one launch
     check(net, a)
 
 

@@ -65,8 +65,13 @@ def draw(seed):
     return net, plan
 
 
+def threaded(seed):
+    return draw(seed)[1]["shards"] > 1 and seed % 2 == 1
+
+
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("seed", list(range(int(os.environ.get("SNN_RANDOM_SEEDS_STREAMED", "6")))))
+@pytest.mark.parametrize("seed", [pytest.param(s, marks=pytest.mark.emulated_ranks) if threaded(s) else s
+                                  for s in range(int(os.environ.get("SNN_RANDOM_SEEDS_STREAMED", "6")))])
 def test_random_streamed_network(snn, seed):
     import torch
     from snn_amd import parallel
