@@ -336,10 +336,11 @@ def main():
                          "parallel.ShardedStepper (torch.distributed moves the segments)")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not bracket k_inputs_dense with HIP events (roofline.achieved is then null)")
-    ap.add_argument("--peer-form", action="store_true",
-                    help="--config c5, --gpus N > 1: after the warm-up the ranks map each other's receive sets (IPC handles through "
-                         "torch.distributed) and step in the peer form -- one launch per step, no collective (include/snn_amd.h, "
-                         "snn_p2p_*).  Off by default: across DEVICES the form has never run (tested across processes on one device)")
+    ap.add_argument("--no-peer-form", action="store_true",
+                    help="--config c5, --gpus N > 1: do NOT try the peer form.  By default the ranks map each other's receive sets after the "
+                         "warm-up (IPC handles through torch.distributed) and step in the peer form -- one launch per step, no collective "
+                         "(include/snn_amd.h, snn_p2p_*) -- after a trial run; if any rank cannot connect or its trial gives up, EVERY rank "
+                         "keeps the collective (the line says which: peer_form)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="--gpus N > 1: strong = the SAME network sharded N ways (default); weak = the network grows with N so that "
                          "every rank keeps the N = 1 share (c5 only: 4 lattices of 512 N x 512, 1 M neurons per rank)")
@@ -423,22 +424,61 @@ def main():
         return sum(int(dn.spike_counts(i).sum()) for i, (_, _, st) in dn.lattices.items() if not st)
 
     run(args.warmup)
-    if args.peer_form and sharded and world > 1 and args.config == "c5" and comm is not None:
-        # the warm-up ran over the collective and left the halo lists committed; now every rank maps its neighbours' memory
-        plan = dn.exchange_plan()
-        busy = int(plan["send_words"]) + int(plan["recv_words"]) > 0
-        mine = None
-        if busy:
-            loc = dn.p2p_local()
-            mine = (dn.p2p_ipc_export(), [int(x) for x in loc["offsets"]], [int(x) for x in loc["counts"]])
-        everyone = [None] * world
-        dist.all_gather_object(everyone, mine)
-        for p in range(world):
-            if busy and p != rank and everyone[p] is not None and (everyone[p][2][rank] or mine[2][p]):
-                r0, r1, fl = dn.p2p_ipc_import(everyone[p][0], device=local_rank)
-                dn.p2p_connect(p, r0, r1, fl, everyone[p][1][rank])
-        if busy:
-            dn.p2p_commit()
+    peer_note = None
+    if not args.no_peer_form and sharded and world > 1 and args.config == "c5" and comm is not None:
+        # The PEER form of the sparse shard step (one launch per step, no collective: include/snn_amd.h snn_p2p_*), TRIED, with a
+        # fallback every rank agrees on: (1) each rank maps its neighbours' receive sets through IPC handles and commits; if any
+        # rank could not, all keep the collective ("halo_peer" 0).  (2) A trial run over the peer form; a rank whose polls give up
+        # (SNN_ERR_WAIT) has left its handle mid-step, so if ANY rank failed every rank rebuilds its handle and keeps the
+        # collective.  The warm-up ran over the collective and left the halo lists committed.
+        def connect():
+            plan = dn.exchange_plan()
+            busy = int(plan["send_words"]) + int(plan["recv_words"]) > 0
+            mine, err = None, None
+            try:
+                if busy:
+                    loc = dn.p2p_local()
+                    mine = (dn.p2p_ipc_export(), [int(x) for x in loc["offsets"]], [int(x) for x in loc["counts"]])
+            except Exception as e:      # noqa: BLE001
+                err = repr(e)
+            everyone = [None] * world
+            dist.all_gather_object(everyone, (mine, err))
+            if any(e for _, e in everyone):
+                return next(e for _, e in everyone if e)
+            try:
+                for p in range(world):
+                    theirs = everyone[p][0]
+                    if busy and p != rank and theirs is not None and (theirs[2][rank] or mine[2][p]):
+                        r0, r1, fl = dn.p2p_ipc_import(theirs[0], device=local_rank)
+                        dn.p2p_connect(p, r0, r1, fl, theirs[1][rank])
+                if busy:
+                    dn.p2p_commit()
+            except Exception as e:      # noqa: BLE001
+                err = repr(e)
+            errs = [None] * world
+            dist.all_gather_object(errs, err)
+            return next((e for e in errs if e), None)
+
+        failed = connect()
+        if failed is None:
+            try:
+                run(8)
+                trial = None
+            except Exception as e:      # noqa: BLE001
+                trial = repr(e)
+            trials = [None] * world
+            dist.all_gather_object(trials, trial)
+            failed = next((t for t in trials if t), None)
+            if failed is not None:
+                # mid-step handles cannot be rolled back across ranks: start over on the collective
+                dn.close()
+                dn, n, workload, kernel_name = build_config(args, snn_amd, synthetic, np, rank, world, local_rank)
+                dn.set_option("halo_peer", 0)
+                dn.set_reduced_history(False, False, True)
+                run(args.warmup)
+        else:
+            dn.set_option("halo_peer", 0)
+        peer_note = "taken" if failed is None else f"fell back to the collective: {failed[:200]}"
         dist.barrier()
         run(args.warmup)
     spikes_before = own_spike_total()
@@ -558,7 +598,7 @@ def main():
             "stepper": (("library (snn_run_sharded, RCCL called by libsnn_amd.so)" if comm is not None else
                          "torch (parallel.ShardedStepper, torch.distributed moves the segments)") if sharded else None),
             "rccl_ranks": rccl_ranks, "exchange_bytes_per_rank_step": exchange_bytes,
-            "halo_peer_steps": (dn.stat("halo_peer_steps") if sharded else None),
+            "halo_peer_steps": (dn.stat("halo_peer_steps") if sharded else None), "peer_form": peer_note,
             "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "neurons": n,

@@ -45,6 +45,11 @@ struct SellGraph {
     const unsigned long long *halo64;
     uint32_t halo_tag, spin_limit;
     PeerFailure failed;          // set when a poll gave up
+    // ... with chemical synapses a halo neuron has one granule per plane on the wire, adjacent: granule (code - halo_base) + slot;
+    // halo_slot_v = slot of the voltage (0xFFFFFFFF: not on the wire), halo_slot_t[k] = slot of transmitter type k.  A
+    // transmitter granule carries, in bit 30 of its tag word, whether the neuron releases that type (neurotransmitters$flags).
+    uint32_t halo_slot_v, halo_slot_t[K_TYPES];
+    uint32_t delay, delay_seed;  // option "halo_peer_delay": injected latency in front of the polls (peer_delay)
     float *w;                    // [entries]
     const uint32_t *row_len;     // [n_slices * 64]
     const uint32_t *edge_slot;   // [nnz] CSR edge -> SELL entry
@@ -68,16 +73,27 @@ __device__ __forceinline__ void peer_give_up(uint32_t *const *failed)
     __hip_atomic_store(failed[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(failed[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// a granule's second word: bits 0..29 the step tag, bit 30 "the neuron releases this transmitter type" (transmitter granules),
+// bit 31 "the neuron spiked in the step that produced this value"
+constexpr uint32_t PEER_TAG_MASK = 0x3FFFFFFFu, PEER_FLAG_BIT = 0x40000000u, PEER_SPIKE_BIT = 0x80000000u;
+// Injected delay (option "halo_peer_delay", tests): up to `max_sleeps` s_sleep(127) (about 3 us each), pseudo-random per call site --
+// a stand-in for the latencies of a real interconnect in front of stores, polls and done announcements
+__device__ __forceinline__ void peer_delay(uint32_t max_sleeps, uint32_t seed, uint32_t salt)
+{
+    if (max_sleeps == 0u) return;
+    const uint32_t n = hash32(seed, ((uint64_t)salt << 32) | (blockIdx.x * 4u + (threadIdx.x >> 6))) % (max_sleeps + 1u);
+    for (uint32_t i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
+}
 __device__ __forceinline__ unsigned long long peer_granule(const unsigned long long *g, uint32_t tag, uint32_t spin_limit, const PeerFailure &f)
 {
     unsigned long long x = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (((uint32_t)(x >> 32) & 0x7FFFFFFFu) == tag) return x;
+    if (((uint32_t)(x >> 32) & PEER_TAG_MASK) == tag) return x;
     if (__hip_atomic_load(f.word[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return x;     // the run has already failed
     uint32_t spins = 0;
     do {
         x = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    } while (((uint32_t)(x >> 32) & 0x7FFFFFFFu) != tag && ++spins < spin_limit);
-    if (((uint32_t)(x >> 32) & 0x7FFFFFFFu) != tag) peer_give_up(f.word);
+    } while (((uint32_t)(x >> 32) & PEER_TAG_MASK) != tag && ++spins < spin_limit);
+    if (((uint32_t)(x >> 32) & PEER_TAG_MASK) != tag) peer_give_up(f.word);
     return x;
 }
 
@@ -103,6 +119,7 @@ __device__ __forceinline__ void csr_row_sums(const CsrInputsArgs &a, uint32_t q,
     const float vq = ELEC ? in.xbuf[in.xl.at(gq_index, PLANE_V)] : 0.0f;
     const float gq = ELEC ? uload(in.uni, NP_GAP, in.gap_conductance, gq_index) : 0.0f;
 
+    if (PEER) peer_delay(a.g.delay, a.g.delay_seed, a.g.halo_tag * 4u + 3u);
     float part = 0.0f;
     float tpart[K_TYPES] = {0.0f, 0.0f, 0.0f};
     bool open = false;               // a chunk's partial is being accumulated
@@ -115,6 +132,7 @@ __device__ __forceinline__ void csr_row_sums(const CsrInputsArgs &a, uint32_t q,
         float w[EDGE_BATCH], v[EDGE_BATCH], t[EDGE_BATCH][K_TYPES];
         uint32_t flags[EDGE_BATCH];       // bit 0 cell, bit 1 silent cell, bit 2 a granule of the peer form, bits 8.. transmitter types
         unsigned long long g64[PEER ? EDGE_BATCH : 1];
+        unsigned long long t64[(PEER && CHEM) ? EDGE_BATCH : 1][K_TYPES];
         // (1) plan word + weight of EDGE_BATCH consecutive entries: coalesced, independent
 #pragma unroll
         for (uint32_t u = 0; u < EDGE_BATCH; ++u) {
@@ -132,21 +150,20 @@ __device__ __forceinline__ void csr_row_sums(const CsrInputsArgs &a, uint32_t q,
             const bool is_cell = !pad && !is_halo && code >= in.n_neurons;
             const uint32_t pn = (pad || is_cell || is_halo) ? 0u : code;
             const uint32_t sc = is_cell ? code - in.n_neurons : 0u;
-            flags[u] = is_cell ? 1u : 0u;
+            // peer form (launch-uniform): the entry's granules are requested with the rest of the batch -- plain loads, no loop
+            // here: a loop inside the gather would take the batch's loads out of flight for EVERY row -- and looked at below
+            const bool granule = PEER && is_halo && a.g.halo64;
+            const unsigned long long *gbase = granule ? a.g.halo64 + (code - a.g.halo_base) : a.g.halo64;
+            flags[u] = (is_cell ? 1u : 0u) | (granule ? 4u : 0u);
             v[u] = 0.0f;
             if (ELEC) {
-                const bool granule = PEER && is_halo && a.g.halo64;
                 const float *src = is_cell ? reinterpret_cast<const float *>(in.st_view + sc)
                                  : (is_halo && !granule) ? reinterpret_cast<const float *>(a.g.halo + (code - a.g.halo_base))
                                                          : in.xbuf + in.xl.at(pn, PLANE_V);
                 v[u] = *src;
                 if (PEER && a.g.halo64) {
-                    // peer form (launch-uniform): the entry's granule is requested with the rest of the batch -- one plain load, no
-                    // loop here: a loop inside the gather would take the batch's loads out of flight for EVERY row -- and looked
-                    // at below
                     g64[PEER ? u : 0] = 0ull;
-                    if (granule) g64[PEER ? u : 0] = __hip_atomic_load(a.g.halo64 + (code - a.g.halo_base), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    flags[u] |= granule ? 4u : 0u;
+                    if (granule) g64[PEER ? u : 0] = __hip_atomic_load(gbase + a.g.halo_slot_v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 }
                 flags[u] |= (is_cell && in.st_view[sc].y) ? 2u : 0u;
             }
@@ -157,19 +174,39 @@ __device__ __forceinline__ void csr_row_sums(const CsrInputsArgs &a, uint32_t q,
                                                    : in.nt_flags + (size_t)kk * in.n_pad + pn;
                     const float *tsrc = is_cell ? in.st_nt_t + (size_t)kk * in.c_pad + sc
                                                 : in.xbuf + in.xl.at(pn, PLANE_T0 + kk);
-                    flags[u] |= (*fsrc != 0) ? (0x100u << kk) : 0u;
+                    // (a granule entry takes flag and value from its granule below: the clamped neuron 0 is not it)
+                    flags[u] |= (!granule && *fsrc != 0) ? (0x100u << kk) : 0u;
                     t[u][kk] = *tsrc;
+                    if (PEER && CHEM && a.g.halo64) {
+                        t64[(PEER && CHEM) ? u : 0][kk] = 0ull;
+                        if (granule && a.g.halo_slot_t[kk] != 0xFFFFFFFFu)
+                            t64[(PEER && CHEM) ? u : 0][kk] = __hip_atomic_load(gbase + a.g.halo_slot_t[kk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
                 }
             }
         }
-        if (PEER && ELEC && a.g.halo64) {
+        if (PEER && a.g.halo64) {
             // peer form: a granule whose tag is not yet the step's (the neighbour's border rows are still on their way) is polled
 #pragma unroll
             for (uint32_t u = 0; u < (PEER ? EDGE_BATCH : 1u); ++u) {
                 if (!(flags[u] & 4u)) continue;
-                if (((uint32_t)(g64[u] >> 32) & 0x7FFFFFFFu) != a.g.halo_tag)
-                    g64[u] = peer_granule(a.g.halo64 + ((p[u] & PLAN_CODE) - a.g.halo_base), a.g.halo_tag, a.g.spin_limit, a.g.failed);
-                v[u] = __uint_as_float((uint32_t)g64[u]);
+                const unsigned long long *gbase = a.g.halo64 + ((p[u] & PLAN_CODE) - a.g.halo_base);
+                if (ELEC) {
+                    if (((uint32_t)(g64[u] >> 32) & PEER_TAG_MASK) != a.g.halo_tag)
+                        g64[u] = peer_granule(gbase + a.g.halo_slot_v, a.g.halo_tag, a.g.spin_limit, a.g.failed);
+                    v[u] = __uint_as_float((uint32_t)g64[u]);
+                }
+                if (PEER && CHEM) {
+#pragma unroll
+                    for (int kk = 0; kk < K_TYPES; ++kk) {
+                        if (a.g.halo_slot_t[kk] == 0xFFFFFFFFu) continue;          // nobody releases the type: no plane, no flag
+                        unsigned long long x = t64[(PEER && CHEM) ? u : 0][kk];
+                        if (((uint32_t)(x >> 32) & PEER_TAG_MASK) != a.g.halo_tag)
+                            x = peer_granule(gbase + a.g.halo_slot_t[kk], a.g.halo_tag, a.g.spin_limit, a.g.failed);
+                        t[u][kk] = __uint_as_float((uint32_t)x);
+                        flags[u] |= ((uint32_t)(x >> 32) & PEER_FLAG_BIT) ? (0x100u << kk) : 0u;
+                    }
+                }
             }
         }
         // (3) the row's sum, strictly in ascending presynaptic order with the canonical chunk flush
@@ -267,12 +304,16 @@ __device__ __forceinline__ void step_close_block(const StepCloseArgs &a, const u
         if (g >= a.recv.n_neurons) return;
         uint32_t *x = reinterpret_cast<uint32_t *>(a.recv.xbuf), *x2 = reinterpret_cast<uint32_t *>(a.xbuf2);
         if (PEER && a.recv64) {
-            // one plane (the voltage), one granule per neuron: value, and the spike flag in the tag word's top bit
-            const unsigned long long g64 = peer_granule(a.recv64 + a.recv.seg_offset[seg] + i, a.recv_tag, a.spin_limit, a.failed);
-            const size_t at = a.recv.xl.at(g, (int)a.recv.plane_id[0]);
-            x[at] = (uint32_t)g64;
-            if (x2) x2[at] = (uint32_t)g64;
-            const uint32_t spike = (uint32_t)(g64 >> 63);
+            // one granule per neuron and plane on the wire, adjacent: value, and the spike flag in the tag word's top bit
+            uint32_t spike = 0u;
+            for (uint32_t s = 0; s < a.recv.planes; ++s) {
+                const unsigned long long g64 = peer_granule(a.recv64 + a.recv.seg_offset[seg] + (size_t)i * a.recv.planes + s, a.recv_tag,
+                                                            a.spin_limit, a.failed);
+                const size_t at = a.recv.xl.at(g, (int)a.recv.plane_id[s]);
+                x[at] = (uint32_t)g64;
+                if (x2) x2[at] = (uint32_t)g64;
+                spike = (uint32_t)(g64 >> 63);              // (every granule of the neuron carries it)
+            }
             x[a.recv.xl.at(g, PLANE_SPIKE)] = spike;
             if (x2) x2[a.recv.xl.at(g, PLANE_SPIKE)] = spike;
             if (spike) a.recv.last_firing_time[g] = (int32_t)a.recv.clock;
@@ -304,7 +345,8 @@ __global__ __launch_bounds__(256) void k_step_close(const StepCloseArgs a) { ste
 
 // peer form, start of a library-driven run: the receive set the first step reads, filled from the mirror (what earlier exchanges
 // left there) as granules tagged for that step
-__global__ __launch_bounds__(256) void k_peer_prefill(const WireArgs recv, uint32_t total, uint32_t segments, unsigned long long *set, uint32_t tag)
+__global__ __launch_bounds__(256) void k_peer_prefill(const WireArgs recv, uint32_t total, uint32_t segments, unsigned long long *set, uint32_t tag,
+                                                      const uint32_t *nt_flags, uint32_t n_pad)
 {
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
     if (t >= total) return;
@@ -314,8 +356,13 @@ __global__ __launch_bounds__(256) void k_peer_prefill(const WireArgs recv, uint3
     const uint32_t g = recv.list[t];
     if (g >= recv.n_neurons) return;
     const uint32_t *x = reinterpret_cast<const uint32_t *>(recv.xbuf);
-    const uint32_t spike = x[recv.xl.at(g, PLANE_SPIKE)] ? 0x80000000u : 0u;
-    set[recv.seg_offset[seg] + i] = ((unsigned long long)(tag | spike) << 32) | x[recv.xl.at(g, (int)recv.plane_id[0])];
+    const uint32_t spike = x[recv.xl.at(g, PLANE_SPIKE)] ? PEER_SPIKE_BIT : 0u;
+    for (uint32_t s = 0; s < recv.planes; ++s) {
+        const uint32_t plane = recv.plane_id[s];
+        // (neurotransmitters$flags are parameters every rank holds for every neuron)
+        const uint32_t flag = (plane >= (uint32_t)PLANE_T0 && nt_flags[(size_t)(plane - PLANE_T0) * n_pad + g]) ? PEER_FLAG_BIT : 0u;
+        set[recv.seg_offset[seg] + (size_t)i * recv.planes + s] = ((unsigned long long)(tag | spike | flag) << 32) | x[recv.xl.at(g, (int)plane)];
+    }
 }
 
 // Inputs + neuron update of a sparse handle in ONE launch: row thread = neuron thread, so the sums never leave
@@ -342,6 +389,9 @@ struct PackTable {
     const uint32_t *flags;          // [n_shards]
     uint32_t tag_out, need_done, spin_limit;
     PeerFailure failed;
+    const uint32_t *nt_flags;       // [3][n_pad] which transmitter types a neuron releases (bit 30 of a transmitter granule's tag word)
+    uint32_t n_pad;
+    uint32_t delay, delay_seed;     // option "halo_peer_delay": injected latencies (peer_delay)
 };
 
 // peer form: a step's launch tells every neighbour which epoch this handle has COMPLETED (done_value: the one before the
@@ -349,6 +399,7 @@ struct PackTable {
 struct PeerSignal {
     uint32_t *const *signal;                  // [n_signal] addresses of the neighbours' flags[this shard]; null: not the peer form
     uint32_t n_signal, done_value;
+    uint32_t delay, delay_seed;               // injected latency in front of the announcement (peer_delay)
 };
 
 struct CsrStepArgs {
@@ -418,6 +469,9 @@ __device__ __forceinline__ void step_csr_block(const CsrStepArgs &a)
     if (PEER && pack_end > pack_begin && a.pack.dst) {
         // peer form: the voltage (from its register) and the spike flag as ONE granule per reading peer, stored into that
         // peer's receive set -- once the peer is done with the step that read the set's previous contents
+        const uint32_t g = a.up.rows.global_of(q);
+        const uint32_t *xo = reinterpret_cast<const uint32_t *>(a.up.xout);
+        peer_delay(a.pack.delay, a.pack.delay_seed, a.pack.tag_out * 4u + 1u);
         for (uint32_t e = pack_begin; e < pack_end; ++e) {
             const uint32_t peer = a.pack.peer[e];
             if (__hip_atomic_load(a.pack.flags + peer, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < a.pack.need_done &&
@@ -427,8 +481,15 @@ __device__ __forceinline__ void step_csr_block(const CsrStepArgs &a)
                        ++spins < a.pack.spin_limit) {}
                 if (spins >= a.pack.spin_limit) peer_give_up(a.pack.failed.word);
             }
-            const unsigned long long x = ((unsigned long long)(a.pack.tag_out | (spike ? 0x80000000u : 0u)) << 32) | __float_as_uint(v_new);
-            __hip_atomic_store(a.pack.dst[e], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            // one granule per plane on the wire, adjacent in the peer's set (the voltage from its register, a transmitter
+            // concentration as this thread has just written it)
+            for (uint32_t pl = 0; pl < a.pack.planes; ++pl) {
+                const uint32_t plane = a.pack.plane_id[pl];
+                const uint32_t value = plane == (uint32_t)PLANE_V ? __float_as_uint(v_new) : xo[a.up.n.xl.at(g, (int)plane)];
+                const uint32_t flag = (plane >= (uint32_t)PLANE_T0 && a.pack.nt_flags[(size_t)(plane - PLANE_T0) * a.pack.n_pad + g]) ? PEER_FLAG_BIT : 0u;
+                const unsigned long long x = ((unsigned long long)(a.pack.tag_out | (spike ? PEER_SPIKE_BIT : 0u) | flag) << 32) | value;
+                __hip_atomic_store(a.pack.dst[e] + pl, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
     } else if (pack_end > pack_begin) {
         // the values this thread has just written, into every segment that carries the neuron (the voltage from its
@@ -450,14 +511,15 @@ __device__ __forceinline__ void step_csr_block(const CsrStepArgs &a)
 template <int MODEL, bool ELEC, bool CHEM, bool PEER = false>
 __global__ __launch_bounds__(256) void k_step_csr(const CsrStepArgs a)
 {
-    static_assert(!PEER || (ELEC && !CHEM), "the peer form carries the voltage alone");
     // peer form: THIS launch running means the previous one of the stream is over -- every row and the mirror job of the step
     // before have read what they had to read -- which is what the neighbours wait for before they overwrite a receive set.  One
     // thread says so.  (A counter of finished workgroups at the END of the launch was measured first: 2048 atomics on one
     // address cost 27 us of a 35 us step.)
-    if (PEER && a.peer.signal && blockIdx.x == 0 && threadIdx.x == 0)
+    if (PEER && a.peer.signal && blockIdx.x == 0 && threadIdx.x == 0) {
+        peer_delay(a.peer.delay, a.peer.delay_seed, a.peer.done_value * 4u + 2u);
         for (uint32_t i = 0; i < a.peer.n_signal; ++i)
             __hip_atomic_store(a.peer.signal[i], a.peer.done_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     step_csr_block<MODEL, ELEC, CHEM, PEER>(a);
 }
 

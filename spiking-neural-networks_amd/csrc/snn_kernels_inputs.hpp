@@ -73,6 +73,7 @@ struct InputsArgs {
     const uint32_t *stdp_flag;        // [n_pad] 1 for those neurons
     const float *stdp_dcol;           // [n_lattices][dcol_stride] delta of edge (p -> a post of lattice l that just spiked)
     const float *stdp_drow;           // [ld] delta of edge (a pre that just spiked -> local post r)
+    const uint32_t *stdp_rowbits;     // STDP == 2: one bit per presynaptic row (neuron) that spiked in the previous step, [n_chunks][8] words
     const uint32_t *lattice_slot;     // [n_pad]
     uint32_t dcol_stride, n_lattices;
 };
@@ -121,7 +122,11 @@ __device__ __forceinline__ float acc_if_edge(float acc, float term, float w)
 // NT: number of live transmitter types the launch is specialised on (1..3; only read when CHEM).  A network whose
 // cells all release one type (BASELINE configs[2]: AMPA) then carries VEC accumulators for it instead of 3 * VEC, no
 // per-row tests of the other types, and the two-register-buffer sweep of the electrical pass.
-template <bool ELEC, bool CHEM, int STREAM = 1, int NT = K_TYPES, bool STDP = false>
+// STDP: 0 the plain pass; 1 the previous step's whole STDP update rides on it (columns and rows, "defer_stdp" 1); 2 its ROW half
+// only ("defer_stdp" 3: the outgoing edges of the neurons that spiked; the incoming edges were scattered by k_stdp_columns when
+// the step closed).  The row half costs the pass no fetch and only full-line stores: a flagged row group is rewritten by every
+// lane of the wavefront, 1 KiB contiguous per store instruction.
+template <bool ELEC, bool CHEM, int STREAM = 1, int NT = K_TYPES, int STDP = 0>
 __global__ __launch_bounds__(InputsShape<STREAM>::THREADS) void k_inputs_dense(const InputsArgs a)
 {
     using S = InputsShape<STREAM>;
@@ -132,8 +137,8 @@ __global__ __launch_bounds__(InputsShape<STREAM>::THREADS) void k_inputs_dense(c
     __shared__ __attribute__((aligned(16))) float s_val[CHUNK];
     __shared__ __attribute__((aligned(16))) uint32_t s_kind[CHUNK];
     __shared__ __attribute__((aligned(16))) float s_t[TS][CHUNK];
-    __shared__ __attribute__((aligned(16))) float s_dcol[STDP ? STDP_MAX_LATTICES : 1][STDP ? CHUNK : 4];
-    __shared__ __attribute__((aligned(16))) uint32_t s_rowflag[STDP ? CHUNK : 4];
+    __shared__ __attribute__((aligned(16))) float s_dcol[STDP == 1 ? STDP_MAX_LATTICES : 1][STDP == 1 ? CHUNK : 4];
+    __shared__ __attribute__((aligned(16))) uint32_t s_rowflag[STDP == 1 ? CHUNK : 4];
     // the previous step's weight updates ride on this pass only if some plastic neuron spiked in it (launch-uniform)
     const bool stdp_live = STDP && *a.stdp_count != 0u;
 
@@ -205,7 +210,7 @@ __global__ __launch_bounds__(InputsShape<STREAM>::THREADS) void k_inputs_dense(c
                 }
             }
         }
-        if (STDP && stdp_live) {
+        if (STDP == 1 && stdp_live) {
             s_rowflag[i] = (p < a.n_neurons) ? a.stdp_flag[p] : 0u;
 #pragma unroll
             for (int l = 0; l < STDP_MAX_LATTICES; ++l)
@@ -220,7 +225,7 @@ __global__ __launch_bounds__(InputsShape<STREAM>::THREADS) void k_inputs_dense(c
     for (uint32_t i = rows + tid; i < groups * 4; i += S::THREADS) {
         s_val[i] = 0.0f;
         s_kind[i] = KIND_NEURON;
-        if (STDP) s_rowflag[i] = 0u;
+        if (STDP == 1) s_rowflag[i] = 0u;
     }
     // Homogeneous chunks (every row a neuron; each transmitter type carried by all rows or by none -- any lattice
     // populated from one base neuron) take a row body without per-row kind tests: workgroup-uniform votes, which
@@ -264,7 +269,26 @@ __global__ __launch_bounds__(InputsShape<STREAM>::THREADS) void k_inputs_dense(c
     float dr[VEC];
     bool wave_cols = false;
     uint32_t wave_lat = 0;        // lattice of the wave's flagged columns when they share one (the usual case), else ~0
-    if (STDP && stdp_live) {
+    // STDP == 2: the chunk's 256 row bits in 8 scalars (wave-uniform loads), the row-update delta of this lane's columns
+    uint32_t rowbits[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool rows_live = false;
+    if (STDP == 2 && stdp_live) {
+        uint32_t any = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            rowbits[i] = a.stdp_rowbits[(size_t)chunk * 8 + i];
+            any |= rowbits[i];
+        }
+        rows_live = any != 0u;                                 // chunk-uniform: most chunks have no spiking row at all
+        if (rows_live) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const uint32_t q = ql + (uint32_t)j * S::THREADS;
+                dr[j] = q < a.n_loc ? a.stdp_drow[q] : 0.0f;
+            }
+        }
+    }
+    if (STDP == 1 && stdp_live) {
         uint32_t lat_mask = 0;    // lattices among this lane's flagged columns
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
@@ -286,6 +310,23 @@ __global__ __launch_bounds__(InputsShape<STREAM>::THREADS) void k_inputs_dense(c
     // broadcast (one per lattice present), selected per lane.  Write-back in whole 128-byte lines: a lone small store
     // makes the memory side read the rest of the line before it can write it, so when any lane of a 128 B-aligned group
     // of 8 lanes (8 columns x 4 rows) changed a word, every lane of the group stores its 16-byte unit.
+    auto stdp_rows_group = [&](uint32_t grp, v4f (&w)[VEC]) {
+        const uint32_t bits = (rowbits[grp >> 3] >> ((grp & 7u) * 4u)) & 0xFu;      // rows 4 grp .. 4 grp + 3 of the chunk
+        if (bits == 0u) return;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (!((bits >> k) & 1u)) continue;                 // wave-uniform
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const float w0 = w[j][k];
+                w[j][k] = (w0 == w0) ? w0 + dr[j] : w0;        // absent edges stay absent
+            }
+        }
+        // the whole row group of this wavefront's columns goes back: full 128-byte lines, 1 KiB contiguous per instruction
+#pragma unroll
+        for (int j = 0; j < VEC; ++j)
+            if (colv[j]) reinterpret_cast<v4f *>(a.W_rw)[(size_t)((p0 >> 2) + grp) * ld + ql + (uint32_t)j * S::THREADS] = w[j];
+    };
     auto stdp_group = [&](uint32_t grp, v4f (&w)[VEC]) {
         bool rs[4], any_rs = false;
 #pragma unroll
@@ -345,7 +386,8 @@ __global__ __launch_bounds__(InputsShape<STREAM>::THREADS) void k_inputs_dense(c
     // body.  `body(row, w[VEC])` sees one presynaptic row at a time, as before the quad-row layout.
     auto sweep = [&](auto body) {
         auto run_group = [&](uint32_t grp, v4f (&wg)[VEC]) {
-            if (STDP && stdp_live) stdp_group(grp, wg);
+            if (STDP == 1 && stdp_live) stdp_group(grp, wg);
+            if (STDP == 2 && rows_live) stdp_rows_group(grp, wg);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 float w[VEC];

@@ -358,6 +358,25 @@ __global__ __launch_bounds__(256) void k_stdp_prepare(const StdpArgs a)
     }
 }
 
+// "defer_stdp" 3: the ROW half of the update rides on the next input pass (k_inputs_dense<..., STDP = 2>).  At the end of the step
+// that produced the spike list: drow as above, and one bit per listed neuron in rowbits ([n_chunks][8] words, zeroed before).
+__global__ __launch_bounds__(256) void k_stdp_prepare_rows(const StdpArgs a, uint32_t *rowbits)
+{
+    const uint32_t count = *a.spike_count;
+    if (count == 0u) return;
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const int32_t now = (int32_t)a.clock;
+    if (i < a.n_loc) {
+        const uint32_t gr = a.q0 + i;
+        const float *prm = a.stdp + PL_STRIDE * a.lattice_slot[gr];
+        a.drow[i] = stdp_delta(now, a.last_firing_time[gr], prm[0], prm[1], prm[2], prm[3], prm[4]);
+    }
+    if (i < count) {
+        const uint32_t j = a.spike_list[i];
+        atomicOr(&rowbits[j >> 5], 1u << (j & 31u));
+    }
+}
+
 // How the STDP scatter kernels touch the matrix.  Few spikes (up to n_tot / 256): non-temporal accesses, so that the touched
 // lines are not left dirty in L2 / Infinity Cache, where their write-back slowed the next streaming input pass by 0.2 ms at
 // C4 with 83 spikes per step.  Many spikes: plain accesses -- the non-temporal read-modify-write is slower per line (0.12

@@ -46,7 +46,7 @@ int snn_network_create(int device, int neuron_model, int nt_kinetics, int recept
     if (const char *e = getenv("SNN_AMD_UPDATE_ALL_PLANES")) net->update_all_planes = (e[0] != '0');
     if (const char *e = getenv("SNN_AMD_CELLS_IN_STEP")) net->cells_in_step = (e[0] != '0');
     if (const char *e = getenv("SNN_AMD_DEFER_RSTDP")) net->defer_rstdp = (e[0] != '0');
-    if (const char *e = getenv("SNN_AMD_DEFER_STDP")) net->defer_stdp = (e[0] == '2') ? 2 : (e[0] != '0');
+    if (const char *e = getenv("SNN_AMD_DEFER_STDP")) net->defer_stdp = (e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : 1;
     if (const char *e = getenv("SNN_AMD_UNIFORM_PARAMS")) net->uniform_params = (e[0] != '0');
     if (const char *e = getenv("SNN_AMD_PERSISTENT_RUN")) net->persistent_run = (e[0] != '0');
     if (const char *e = getenv("SNN_AMD_PERSISTENT_CHEM")) net->persistent_chem = (e[0] != '0');
@@ -1103,7 +1103,7 @@ int snn_debug_checkpoint(snn_network_t *net, int restore)
     net->live_mask_applied = cp.live_mask_applied; net->n_live = cp.n_live;
     for (int k = 0; k < K_TYPES; ++k) net->live_type[k] = cp.live_type[k];
     net->persistent_run = cp.persistent_run; net->mirror_mask = cp.mirror_mask;
-    net->stdp_pending = false; net->rstdp_pending = false; net->reward_since_defer = false;
+    net->stdp_pending = false; net->stdp_pending_rows_only = false; net->rstdp_pending = false; net->reward_since_defer = false;
     net->cells_stepped = false; net->local_inputs_done = false; net->run_tag = 1;
     if (net->run_granules) {
         HIP_TRY(hipMemsetAsync(net->run_granules, 0, RUN_GRANULE_WORDS * 8, net->stream), SNN_ERR_BUFFER_WRITE);
@@ -1610,8 +1610,8 @@ int snn_p2p_local(snn_network_t *net, uint64_t *recv0, uint64_t *recv1, uint64_t
     HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
     TRY(end_run(net));
     TRY(ensure_exchange_plan(net));
-    if (!net->direct_capable || !net->p2p_recv[0])
-        return fail(SNN_ERR_BAD_STATE, "the peer form needs a committed halo plan with the voltage as the only plane on the wire");
+    if (!net->peer_capable || !net->p2p_recv[0])
+        return fail(SNN_ERR_BAD_STATE, "the peer form needs a committed halo plan in which something travels");
     *recv0 = reinterpret_cast<uint64_t>(net->p2p_recv[0]);
     *recv1 = reinterpret_cast<uint64_t>(net->p2p_recv[1]);
     *flags = reinterpret_cast<uint64_t>(net->p2p_flags);
@@ -1629,7 +1629,7 @@ int snn_p2p_connect(snn_network_t *net, uint32_t peer, uint64_t peer_recv0, uint
     HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
     TRY(end_run(net));
     TRY(ensure_exchange_plan(net));
-    if (!net->direct_capable || !net->p2p_recv[0]) return fail(SNN_ERR_BAD_STATE, "the handle's exchange plan has no peer form");
+    if (!net->peer_capable || !net->p2p_recv[0]) return fail(SNN_ERR_BAD_STATE, "the handle's exchange plan has no peer form");
     if (peer >= net->n_shards) return fail(SNN_ERR_BAD_ARG, "peer out of range");
     if (!peer_recv0 || !peer_recv1 || !peer_flags) return fail(SNN_ERR_BAD_ARG, "null peer address");
     snn_network::P2pPeer &pp = net->p2p_peers[peer];
@@ -1646,7 +1646,7 @@ int snn_p2p_commit(snn_network_t *net)
     HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
     TRY(end_run(net));
     TRY(ensure_exchange_plan(net));
-    if (!net->direct_capable || !net->p2p_recv[0]) return fail(SNN_ERR_BAD_STATE, "the handle's exchange plan has no peer form");
+    if (!net->peer_capable || !net->p2p_recv[0]) return fail(SNN_ERR_BAD_STATE, "the handle's exchange plan has no peer form");
     return p2p_build_tables(net);
 }
 
@@ -1786,7 +1786,7 @@ static int agree_on_exchange(Rccl *R, snn_network *net, ncclComm_t comm, void *n
         for (uint32_t s = 0; s < net->x_planes; ++s) mask |= 1u << net->x_plane_id[s];
         // bit 30: this rank will step in the PEER form (connected, committed, "halo_peer" on).  A rank that is not, next to one
         // that is, would post ncclSend / ncclRecv nobody answers while the other polls granules nobody stores.
-        const bool peer_form = net->halo_peer && net->p2p_connected && net->p2p_recv[0] && net->direct_capable && net->halo_direct && net->csr_plan_direct &&
+        const bool peer_form = net->halo_peer && net->p2p_connected && net->p2p_recv[0] && net->peer_capable && net->halo_direct && net->csr_plan_direct &&
                                csr_fast_step(net);
         mask |= peer_form ? 0x40000000u : 0u;
         // bit 31: this rank's mirror lacks a plane of the plan (mirror_stale).  A plane can only go missing when the plan
@@ -1970,10 +1970,11 @@ int snn_set_option(snn_network_t *net, const char *name, int value)
     else if (n == "persistent_stdp") net->persistent_stdp = value != 0;
     else if (n == "halo_direct") net->halo_direct = (value >= 0 && value <= 2) ? value : 1;
     else if (n == "halo_peer") { net->halo_peer = value != 0; net->x_agreed = false; }
+    else if (n == "halo_peer_delay") net->peer_delay = (uint32_t)std::max(0, std::min(value, 64));
     else if (n == "halo_peer_spin_limit") net->p2p_spin_limit = value > 0 ? (uint32_t)value : (1u << 26);
     else if (n == "csr_xcd_bands") net->csr_xcd_bands = value != 0;
     else if (n == "defer_rstdp") net->defer_rstdp = value != 0;
-    else if (n == "defer_stdp") net->defer_stdp = (value == 2) ? 2 : (value != 0);
+    else if (n == "defer_stdp") net->defer_stdp = (value >= 0 && value <= 3) ? value : 1;
     else if (n == "uniform_params") { net->uniform_params = value != 0; net->uni_dirty = true; }
     else if (n == "persistent_run") { net->persistent_run = value != 0; net->run_probed_grid = 0; }
     else if (n == "persistent_chem") net->persistent_chem = value != 0;

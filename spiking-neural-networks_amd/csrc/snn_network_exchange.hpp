@@ -105,6 +105,7 @@ int ensure_exchange_plan(snn_network *net)
     std::vector<uint64_t> off[2], loff[2];
     net->x_mode = ((net->csr && net->halo_committed) || net->block_mode) ? SNN_EXCHANGE_HALO : SNN_EXCHANGE_ALLGATHER;
     net->direct_capable = false;
+    net->peer_capable = false;
     if (net->block_mode && !net->halo_committed) synthesize_full_lists(net);
     if (net->x_mode == SNN_EXCHANGE_ALLGATHER) {
         net->x_block_words = segment_words(P, net->shard_stride);
@@ -180,6 +181,9 @@ int ensure_exchange_plan(snn_network *net)
         // the direct form (see snn_network_state.hpp): voltage is the only plane, so a halo neuron's value is ONE word
         net->direct_capable = net->csr && net->csr_pre && net->electrical && !net->chemical && P == 1 &&
                               (uint64_t)net->nn + net->nc + ro < PLAN_CODE && net->n_loc;
+        // the PEER form carries every plane of the plan: one granule per neuron and plane (P adjacent granules per halo neuron
+        // fit the words of its segment: P * count + ceil(count / 32) >= P * count)
+        net->peer_capable = net->csr && net->csr_pre && P >= 1 && (uint64_t)net->nn + net->nc + ro < PLAN_CODE && net->n_loc;
         for (uint32_t **b : {&net->halo_send_buf, net->direct_capable ? &net->halo_send_buf2 : nullptr}) {
             if (!b) continue;
             HIP_TRY(snn_malloc(b, std::max<uint64_t>(so * 4, 256)), SNN_ERR_BUFFER_CREATE);
@@ -191,7 +195,7 @@ int ensure_exchange_plan(snn_network *net)
             HIP_TRY(memset_sync(net, *b, 0, std::max<uint64_t>(ro * 4, 256)), SNN_ERR_BUFFER_WRITE);
         }
         TRY(p2p_release(net));
-        if (net->direct_capable && ro) {
+        if (net->peer_capable && ro) {
             // the peer form's receive sets and done counters: fine-grained memory (another device may store into it while
             // kernels of this one read it), zeroed (tag 0 is never expected: epochs start at 1)
             net->p2p_recv_words = ro;
@@ -212,11 +216,13 @@ int ensure_exchange_plan(snn_network *net)
             net->p2p_peers.assign(G, snn_network::P2pPeer{});
             net->p2p_epoch = 1;
         }
-        if (net->direct_capable) {
+        if (net->direct_capable || net->peer_capable) {
+            // word of the receive buffer (direct form: plane 0 of the segment, P == 1) = first granule of the receive set (peer
+            // form: P adjacent granules per neuron) that carries a halo neuron
             std::vector<uint32_t> halo_word(net->nn, 0xFFFFFFFFu);
             for (uint32_t p = 0; p < G; ++p)
                 for (size_t i = 0; i < net->halo_need[p].size(); ++i)
-                    halo_word[net->halo_need[p][i]] = (uint32_t)(net->x_recv_off[p] + i);       // plane 0 of the segment
+                    halo_word[net->halo_need[p][i]] = (uint32_t)(net->x_recv_off[p] + i * P);
             TRY(upload_table(net, &net->halo_word_dev, halo_word));
             HIP_TRY(snn_malloc(&net->csr_plan_direct, std::max<size_t>(net->sell_entries * 4, 256)),
                     SNN_ERR_BUFFER_CREATE);
@@ -499,22 +505,23 @@ int refresh_unpack(snn_network *net)
 int direct_begin(snn_network *net)
 {
     net->direct_run = false;
-    if (!net->halo_direct || !net->direct_capable || !csr_fast_step(net) || net->n_shards < 2 || !net->csr_plan_direct) return SNN_OK;
+    net->peer_run = false;
+    if (!net->halo_direct || !csr_fast_step(net) || net->n_shards < 2 || !net->csr_plan_direct) return SNN_OK;
+    const bool peer = net->halo_peer && net->peer_capable && net->p2p_connected && net->p2p_recv[0];
+    if (!net->direct_capable && !peer) return SNN_OK;        // (several planes on the wire: only the peer form gathers them itself)
     uint64_t so = 0;
     for (uint32_t p = 0; p < net->n_shards; ++p) so += net->x_send_words[p];
     HIP_TRY(hipMemsetAsync(net->halo_send_buf, 0, std::max<uint64_t>(so * 4, 256), net->stream), SNN_ERR_BUFFER_WRITE);
-    HIP_TRY(hipMemsetAsync(net->halo_send_buf2, 0, std::max<uint64_t>(so * 4, 256), net->stream), SNN_ERR_BUFFER_WRITE);
+    if (net->halo_send_buf2) HIP_TRY(hipMemsetAsync(net->halo_send_buf2, 0, std::max<uint64_t>(so * 4, 256), net->stream), SNN_ERR_BUFFER_WRITE);
     net->hx_par = 0;
     net->stamp_pending = false;
-    net->peer_run = false;
-    const bool peer = net->halo_peer && net->p2p_connected && net->p2p_recv[0];
-    if (peer && net->p2p_epoch > 0x7FFFFF00u) return fail(SNN_ERR_BAD_STATE, "peer form: step tags exhausted (2^31 steps): rebuild the exchange plan");
+    if (peer && net->p2p_epoch > 0x3FFFFF00u) return fail(SNN_ERR_BAD_STATE, "peer form: step tags exhausted (2^30 steps): rebuild the exchange plan");
     net->peer_run = peer;
     if (net->peer_run) {
         // the peer form: the set the first step reads -- values "produced by step epoch - 1" -- from the mirror, tagged for it
         if (net->recv_total) {
             hipLaunchKernelGGL(k_peer_prefill, dim3((net->recv_total + 255) / 256), dim3(256), 0, net->stream, wire_args(net, 1), net->recv_total,
-                               net->seg_n[1], net->p2p_recv[(net->p2p_epoch + 1u) & 1u], net->p2p_epoch);
+                               net->seg_n[1], net->p2p_recv[(net->p2p_epoch + 1u) & 1u], net->p2p_epoch, net->na.nt_flags, net->n_pad);
             HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
         }
     } else if (net->seg_n[1] && net->seg_max[1]) {
@@ -578,7 +585,7 @@ int p2p_build_tables(snn_network *net)
         if (!net->p2p_peers[p].set) return fail(SNN_ERR_BAD_STATE, "peer form: shard " + std::to_string(p) + " reads this shard but is not connected");
         for (uint32_t i = 0; i < sl.size(); ++i) {
             const uint32_t e = fill[local_row(sl[i])]++;            // the order ensure_exchange_plan gave the pack table
-            for (int k = 0; k < 2; ++k) dst[k][e] = net->p2p_peers[p].recv[k] + 8ull * (net->p2p_peers[p].recv_offset + i);
+            for (int k = 0; k < 2; ++k) dst[k][e] = net->p2p_peers[p].recv[k] + 8ull * (net->p2p_peers[p].recv_offset + (uint64_t)i * net->x_planes);
             peer[e] = p;
         }
     }

@@ -174,6 +174,8 @@ struct snn_network {
     uint32_t *halo_send_buf2 = nullptr, *halo_recv_buf2 = nullptr;
     uint32_t *csr_plan_direct = nullptr, *halo_word_dev = nullptr;
     bool direct_capable = false;          // the plan has the direct form (sparse, halo mode, voltage the only plane)
+    bool peer_capable = false;            // the plan has the PEER form (sparse, halo mode, any planes)
+    uint32_t peer_delay = 0;              // option "halo_peer_delay": injected latencies, in s_sleep(127) units (tests)
     bool direct_run = false;              // ... and the run in progress uses it
     int hx_par = 0;
     bool stamp_pending = false;
@@ -305,6 +307,8 @@ struct snn_network {
     int defer_stdp = 0;
     int stdp_columns_form = 0;            // option "stdp_columns_form": 0 one thread per presynaptic row, 1 one lane per 16-byte unit (k_stdp_columns_quads)
     bool stdp_pending = false;
+    bool stdp_pending_rows_only = false;   // ... and it is the ROW half only ("defer_stdp" 3)
+    uint32_t *stdp_rowbits = nullptr;       // [n_chunks][8] one bit per presynaptic row that spiked in the step just closed
     uint32_t *stdp_flag = nullptr;
     float *stdp_dcol = nullptr, *stdp_drow = nullptr;
     uint32_t dcol_stride = 0;
@@ -751,6 +755,7 @@ int build_state(snn_network *net)
         TRY(fill_u32(net, net->stdp_flag, np, 0));
         TRY(dev_alloc_t(net, &net->stdp_dcol, (size_t)STDP_MAX_LATTICES * net->dcol_stride));
         TRY(dev_alloc_t(net, &net->stdp_drow, net->ld));
+        TRY(dev_alloc_t(net, &net->stdp_rowbits, (size_t)net->n_chunks * 8));
     }
 
     // spike-train cells (spike_train/mod.rs:299-313, 998-1013, 50-56)

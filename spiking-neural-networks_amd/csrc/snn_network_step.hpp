@@ -156,13 +156,18 @@ int launch_inputs(snn_network *net, InputsPart part = INPUTS_ALL)
     if (stdp_fused) {
         // the STDP update of the previous step rides on this pass over W
         net->stdp_pending = false;
+        const bool rows_only = net->stdp_pending_rows_only;
+        net->stdp_pending_rows_only = false;
         a.W_rw = net->W; a.stdp_count = net->spike_count; a.stdp_flag = net->stdp_flag;
         a.stdp_dcol = net->stdp_dcol; a.stdp_drow = net->stdp_drow; a.lattice_slot = net->lattice_slot;
         a.dcol_stride = net->dcol_stride; a.n_lattices = (uint32_t)net->lattices.size();
+        a.stdp_rowbits = net->stdp_rowbits;
 #define SNN_LAUNCH_SSHAPE(E, C, SH)                                                                       \
-    hipLaunchKernelGGL((k_inputs_dense<E, C, SH, K_TYPES, true>),                                        \
-                       dim3((net->n_loc + InputsShape<SH>::TILE - 1) / InputsShape<SH>::TILE, grid_chunks), \
-                       dim3(InputsShape<SH>::THREADS), 0, net->stream, a)
+    do {                                                                                                 \
+        const dim3 g_((net->n_loc + InputsShape<SH>::TILE - 1) / InputsShape<SH>::TILE, grid_chunks);    \
+        if (rows_only) hipLaunchKernelGGL((k_inputs_dense<E, C, SH, K_TYPES, 2>), g_, dim3(InputsShape<SH>::THREADS), 0, net->stream, a); \
+        else hipLaunchKernelGGL((k_inputs_dense<E, C, SH, K_TYPES, 1>), g_, dim3(InputsShape<SH>::THREADS), 0, net->stream, a); \
+    } while (0)
 #define SNN_LAUNCH_SINPUTS(E, C)                                                                         \
     do {                                                                                                 \
         if (shape == 1) SNN_LAUNCH_SSHAPE(E, C, 1);                                                      \
@@ -334,6 +339,18 @@ int launch_plasticity_kernels(snn_network *net)
     hipLaunchKernelGGL(k_spike_compact, dim3((net->nn + 255) / 256), dim3(256), 0, net->stream, a);
     HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
     if (net->n_loc == 0) return SNN_OK;
+    if (defer && net->defer_stdp == 3) {
+        // the incoming edges now (the column scatter), the outgoing edges with the next input pass: the row half costs that pass
+        // no fetch and only full-line stores, where k_stdp_rows reads and writes back every line of the listed rows
+        hipLaunchKernelGGL(k_stdp_columns, dim3((net->n_tot + 255) / 256, 64), dim3(256), 0, net->stream, a);
+        HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+        HIP_TRY(hipMemsetAsync(net->stdp_rowbits, 0, (size_t)net->n_chunks * 32, net->stream), SNN_ERR_BUFFER_WRITE);
+        hipLaunchKernelGGL(k_stdp_prepare_rows, dim3((std::max(net->nn, net->n_loc) + 255) / 256), dim3(256), 0, net->stream, a, net->stdp_rowbits);
+        HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+        net->stdp_pending = true;
+        net->stdp_pending_rows_only = true;
+        return SNN_OK;
+    }
     if (defer) {
         // only the two delta vectors now; the weights are rewritten by the next input pass (or by flush_stdp)
         hipLaunchKernelGGL(k_stdp_prepare, dim3((std::max(net->n_tot, net->n_loc) + 255) / 256), dim3(256), 0, net->stream, a);
@@ -464,11 +481,15 @@ int flush_stdp(snn_network *net)
 {
     if (!net->stdp_pending) return SNN_OK;
     net->stdp_pending = false;
-    if (net->n_loc == 0 || net->nn == 0) return SNN_OK;
+    if (net->n_loc == 0 || net->nn == 0) { net->stdp_pending_rows_only = false; return SNN_OK; }
     StdpArgs a = stdp_args(net);
     const unsigned sy = 64;
-    hipLaunchKernelGGL(k_stdp_apply_columns, dim3((net->n_tot + 255) / 256, sy), dim3(256), 0, net->stream, a);
-    HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+    if (net->stdp_pending_rows_only) {          // "defer_stdp" 3: the columns were scattered when the step closed
+        net->stdp_pending_rows_only = false;
+    } else {
+        hipLaunchKernelGGL(k_stdp_apply_columns, dim3((net->n_tot + 255) / 256, sy), dim3(256), 0, net->stream, a);
+        HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+    }
     hipLaunchKernelGGL(k_stdp_apply_rows, dim3((net->n_loc + 255) / 256, sy), dim3(256), 0, net->stream, a);
     HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
     return SNN_OK;
@@ -970,6 +991,14 @@ int launch_step_csr(snn_network *net, CsrStepPart part = CSR_STEP_ALL, bool pack
         c.c.g.halo_tag = net->p2p_epoch;
         c.c.g.spin_limit = net->p2p_spin_limit;
         c.c.g.failed = PeerFailure{{net->p2p_failed, net->p2p_done_blocks + 1}};
+        // a halo neuron's granules are adjacent, one per plane of the plan, in the plan's order
+        c.c.g.halo_slot_v = 0xFFFFFFFFu;
+        for (int k = 0; k < K_TYPES; ++k) c.c.g.halo_slot_t[k] = 0xFFFFFFFFu;
+        for (uint32_t s = 0; s < net->x_planes; ++s) {
+            if (net->x_plane_id[s] == (uint32_t)PLANE_V) c.c.g.halo_slot_v = s;
+            else c.c.g.halo_slot_t[net->x_plane_id[s] - PLANE_T0] = s;
+        }
+        c.c.g.delay = net->peer_delay; c.c.g.delay_seed = net->shard_index * 7919u + 1u;
     }
     if (pack) {
         c.pack.ptr = net->pack_ptr_dev; c.pack.seg_off = net->pack_segoff_dev; c.pack.seg_count = net->pack_count_dev;
@@ -983,11 +1012,14 @@ int launch_step_csr(snn_network *net, CsrStepPart part = CSR_STEP_ALL, bool pack
             // the set was last read by the peer's step of epoch - 1 (rows and mirror job): its counter says when that is over
             c.pack.tag_out = net->p2p_epoch + 1u; c.pack.need_done = net->p2p_epoch - 1u;
             c.pack.spin_limit = net->p2p_spin_limit; c.pack.failed = PeerFailure{{net->p2p_failed, net->p2p_done_blocks + 1}};
+            c.pack.nt_flags = net->na.nt_flags; c.pack.n_pad = net->n_pad;
+            c.pack.delay = net->peer_delay; c.pack.delay_seed = net->shard_index * 7919u + 2u;
         }
     }
     if (net->peer_run) {
         c.peer.signal = net->p2p_signal_dev; c.peer.n_signal = net->p2p_n_signal;
         c.peer.done_value = net->p2p_epoch - 1u;     // this launch running = the step of the epoch before is over
+        c.peer.delay = net->peer_delay; c.peer.delay_seed = net->shard_index * 7919u + 3u;
     }
     // the cells ride with the step's last row launch (the rows of BOTH launches read the view the cells do not write)
     const bool last_part = part != CSR_STEP_BORDER || net->n_interior == 0;
@@ -1027,8 +1059,10 @@ int launch_step_csr(snn_network *net, CsrStepPart part = CSR_STEP_ALL, bool pack
         const dim3 grid((waves + 3) / 4 + tail_blocks), block(256);
 #define SNN_CSR_STEP(M)                                                                                              \
     do {                                                                                                             \
-        if (net->electrical && net->chemical) hipLaunchKernelGGL((k_step_csr<M, true, true>), grid, block, 0, net->stream, c);  \
-        else if (net->electrical && net->peer_run) hipLaunchKernelGGL((k_step_csr<M, true, false, true>), grid, block, 0, net->stream, c); \
+        if (net->peer_run && net->electrical && net->chemical) hipLaunchKernelGGL((k_step_csr<M, true, true, true>), grid, block, 0, net->stream, c); \
+        else if (net->peer_run && net->electrical) hipLaunchKernelGGL((k_step_csr<M, true, false, true>), grid, block, 0, net->stream, c); \
+        else if (net->peer_run) hipLaunchKernelGGL((k_step_csr<M, false, true, true>), grid, block, 0, net->stream, c);        \
+        else if (net->electrical && net->chemical) hipLaunchKernelGGL((k_step_csr<M, true, true>), grid, block, 0, net->stream, c);  \
         else if (net->electrical) hipLaunchKernelGGL((k_step_csr<M, true, false>), grid, block, 0, net->stream, c);             \
         else hipLaunchKernelGGL((k_step_csr<M, false, true>), grid, block, 0, net->stream, c);                                  \
     } while (0)

@@ -40,6 +40,11 @@ def seed_is_valid(spec, seed):
     if spec == "test_gpu_sequences:test_random_call_sequence":
         import test_gpu_sequences
         return test_gpu_sequences.usable(seed)
+    if spec == "test_gpu_randomized:test_random_network":
+        # (cases that step shard handles by one host thread per rank need GPU_MAX_HW_QUEUES=24 -- tests/test_gpu_emulated_ranks.py;
+        # the campaign's workers keep the runtime's default queues, the mapping a one-rank-per-process run has)
+        import test_gpu_randomized
+        return not test_gpu_randomized.threaded(seed)
     return True
 
 

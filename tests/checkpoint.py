@@ -263,7 +263,14 @@ def ras_counters():
 
 
 def ras_totals(c):
-    """(uncorrectable, correctable) totals of the sysfs counters of ras_counters()"""
+    """(uncorrectable, correctable) error totals: amd-smi's ECC totals when it answered, else the sysfs counters"""
+    try:
+        data = json.loads(c.get("amd-smi", ""))
+        gpus = data.get("gpu_data", data) if isinstance(data, dict) else data
+        return (sum(int(g["ecc"]["total_uncorrectable_count"]) + int(g["ecc"].get("total_deferred_count", 0)) for g in gpus),
+                sum(int(g["ecc"]["total_correctable_count"]) for g in gpus))
+    except Exception:                           # noqa: BLE001
+        pass
     ue = ce = 0
     for text in c.get("sysfs", {}).values():
         for part in text.replace(";", "\n").splitlines():

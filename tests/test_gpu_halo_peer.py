@@ -56,6 +56,80 @@ def test_peer_form_equals_the_oracle(snn, collectives, n_shards, by_lattice, sid
         h.close()
 
 
+def with_transmitters(net, seed, electrical=True):
+    """chemical synapses on the C5 structure: two thirds of the neurons release a transmitter of their own choice of types, every
+    neuron has receptors, a third of the Poisson cells release too (the halo then carries up to three transmitter planes)"""
+    rng = np.random.default_rng(seed)
+    nn, nc = net.n_neurons, net.n_cells
+    net.electrical, net.chemical = electrical, True
+    net["nt_flags"][...] = (rng.random((nn, 3)) < 0.5) & (rng.random((nn, 1)) < 0.67)
+    net["nt_t"][...] = rng.random((nn, 3)).astype(np.float32) * net["nt_flags"]
+    net["rc_flags"][...] = rng.random((nn, 3)) < 0.6
+    net["st_nt_flags"][...] = (rng.random((nc, 3)) < 0.5) & (rng.random((nc, 1)) < 0.33)
+    net["weights"][...] *= ob.uniform_array(seed + 1, net["weights"].size, 0.2, 1.2).reshape(net["weights"].shape)
+    return net
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("n_shards,by_lattice,electrical,delay", [(2, True, True, 0), (4, True, True, 0), (3, False, False, 0), (4, False, True, 0),
+                                                                  (2, True, True, 30), (4, True, True, 30), (3, False, True, 12),
+                                                                  (8, True, True, 0), (8, False, True, 8)])
+def test_peer_form_with_transmitter_planes_and_injected_delays(snn, collectives, n_shards, by_lattice, electrical, delay):
+    """BASELINE configs[4]'s network with chemical synapses (the reference's network chemical inputs, neuron/gpu_lattices/mod.rs:
+    1278-1382): a halo neuron travels as one granule per plane -- voltage and the transmitter types some neuron releases -- and a
+    transmitter granule carries "this neuron releases the type" in its tag word.  delay > 0: every store of granules, every row's
+    first poll and every done announcement waits a pseudo-random time of up to delay x 3 us first (halo_peer_delay), different
+    per rank, wavefront and step -- what first contact with a real interconnect would do to the protocol."""
+    from snn_amd import parallel
+    net = with_transmitters(c5_structure(16), 100 + n_shards, electrical)
+    handles = [parity.device_from_oracle(snn, net, shard=(r, n_shards), csr=True, by_lattice=by_lattice) for r in range(n_shards)]
+    parallel.wire_halo_lists(handles)
+    assert parallel.connect_peers(handles)
+    for h in handles:
+        h.set_option("halo_peer_spin_limit", 1 << 24)
+        h.set_option("halo_peer_delay", delay)
+    tc = collectives(n_shards)
+    calls = [40, 1, 19] if n_shards <= 4 else [1] * 30
+    run_ranks(handles, tc, calls)
+    steps = sum(calls)
+    net.n_threads = 8
+    net.run(steps)
+    busy = 0
+    for h in handles:
+        plan = h.exchange_plan()
+        assert plan["planes"] >= (2 if electrical else 1)
+        if h.owned.size and int(plan["send_words"]) + int(plan["recv_words"]):
+            busy += 1
+            assert h.stat("halo_peer_steps") == steps and h.stat("steps_sparse_one_launch") == steps, \
+                (h.stat("halo_peer_steps"), h.stat("steps_sparse_one_launch"), h.stat("steps_sparse_split"), steps)
+    assert busy >= 2
+    check_against_oracle(handles, net, steps)
+    for h in handles:
+        st = parity.pull_state(h, net)
+        for name in ("rc_r", "rc_current"):
+            assert np.array_equal(parity.bits(st[name][h.owned]), parity.bits(net[name][h.owned])), name
+        h.close()
+
+
+@pytest.mark.timeout(300)
+def test_injected_delays_leave_the_electrical_peer_form_bit_exact(snn, collectives):
+    from snn_amd import parallel
+    n_shards = 4
+    net = c5_structure(16)
+    handles = [parity.device_from_oracle(snn, net, shard=(r, n_shards), csr=True, by_lattice=True) for r in range(n_shards)]
+    parallel.wire_halo_lists(handles)
+    assert parallel.connect_peers(handles)
+    for h in handles:
+        h.set_option("halo_peer_spin_limit", 1 << 24)
+        h.set_option("halo_peer_delay", 33)                 # up to 100 us per call site
+    run_ranks(handles, collectives(n_shards), [80, 20])
+    net.run(100)
+    assert all(h.stat("halo_peer_steps") == 100 for h in handles)
+    check_against_oracle(handles, net, 100)
+    for h in handles:
+        h.close()
+
+
 @pytest.mark.timeout(120)
 def test_peer_form_between_other_steps_and_switched_off(snn, collectives):
     """runs of the peer form alternate with host-driven steps (which move the halo through the ordinary segments) and with the

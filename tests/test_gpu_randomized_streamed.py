@@ -12,7 +12,7 @@ import parity
 
 pytestmark = pytest.mark.gpu
 
-SWITCHES = {"defer_stdp": (0, 1, 2), "uniform_params": (0, 1), "update_packs": (0, 1), "input_shape": (0, 1, 2), "fused_step": (0, 1)}
+SWITCHES = {"defer_stdp": (0, 1, 2, 3), "uniform_params": (0, 1), "update_packs": (0, 1), "input_shape": (0, 1, 2), "fused_step": (0, 1)}
 
 
 def draw(seed):

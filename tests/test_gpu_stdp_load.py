@@ -113,13 +113,15 @@ def build_streamed(side_rows, side_cols, seed, st=True):
     return net
 
 
-def test_deferred_stdp_in_the_streamed_input_pass_equals_oracle(snn):
+@pytest.mark.parametrize("mode", [1, 3])
+def test_deferred_stdp_in_the_streamed_input_pass_equals_oracle(snn, mode):
     """4 500 neurons (81 MB matrix): weights, state and rasters bit for bit with the oracle, with a host read of the
-    weights in the middle (which applies the pending update through the standalone pass) and a resumed run."""
+    weights in the middle (which applies the pending update through the standalone pass) and a resumed run.
+    mode 1: the whole update rides on the next input pass; mode 3: its row half only (the columns are scattered at once)."""
     net = build_streamed(64, 64, seed=41)
     steps, seed, fraction = 36, 5, 0.02
     dn = parity.device_from_oracle(snn, net)
-    dn.set_option("defer_stdp", 1)                          # the update rides on the next input pass (not the default)
+    dn.set_option("defer_stdp", mode)                       # the update rides on the next input pass
     dn.set_synthetic_drive(seed, fraction, V_KICK)
     w0 = net["weights"].copy()
     done = 0
@@ -150,7 +152,7 @@ def test_deferred_stdp_on_streamed_shard_handles(snn):
     steps, seed, fraction, g = 14, 9, 0.02, 2
     handles = [parity.device_from_oracle(snn, net, shard=(r, g)) for r in range(g)]
     for r, h in enumerate(handles):
-        h.set_option("defer_stdp", 1 + r % 2)               # one shard fuses, the other scatters the prepared deltas
+        h.set_option("defer_stdp", (1, 3)[r % 2])           # one shard fuses the whole update, the other its row half
         h.set_synthetic_drive(seed, fraction, V_KICK)
     ex = parallel.LocalExchange(handles, torch.device("cuda", 0))
     for _ in range(steps):
@@ -176,7 +178,7 @@ def test_c4_size_deferred_stdp_equals_the_standalone_kernels(snn):
     n_inh, n_exc = 128 * 128, 256 * 256
     n = n_inh + n_exc
     out = []
-    for defer in ("1", "0"):
+    for defer in ("1", "0", "3"):
         old = os.environ.get("SNN_AMD_DEFER_STDP")
         os.environ["SNN_AMD_DEFER_STDP"] = defer
         try:
@@ -208,8 +210,9 @@ def test_c4_size_deferred_stdp_equals_the_standalone_kernels(snn):
         lft = np.concatenate([dn.get_attr(i, "last_firing_time", dtype=np.int32) for i in (0, 1)])
         out.append((w, v, lft, w_init))
         dn.close()
-    a, b = out
+    a, b, c = out
     assert (a[2] >= 0).sum() > 3000, "the drive must have made thousands of neurons spike"
     assert (a[0][6] != a[3]).mean() > 0.01, "the outgoing / incoming weights of spiking neurons must have moved"
-    for x, y in zip(a, b):
-        assert np.array_equal(parity.bits(np.asarray(x)), parity.bits(np.asarray(y)))
+    for other in (b, c):
+        for x, y in zip(a, other):
+            assert np.array_equal(parity.bits(np.asarray(x)), parity.bits(np.asarray(y)))
