@@ -23,6 +23,10 @@
 
 namespace snn {
 
+#ifndef SNN_CSR_PREFETCH
+#define SNN_CSR_PREFETCH 0
+#endif
+constexpr bool CSR_PREFETCH = SNN_CSR_PREFETCH != 0;     // (A/B switch of the build: profiles/r05/README.md)
 constexpr uint32_t SELL_PAD = 0xFFFFFFFFu;     // presynaptic index of a padding entry
 constexpr uint32_t PLAN_CODE = 0x7FFFFFFFu;    // gather-plan word: the source code (all ones = padding), bit 31 = new chunk
 
@@ -127,19 +131,36 @@ __device__ __forceinline__ void csr_row_sums(const CsrInputsArgs &a, uint32_t q,
 #pragma unroll
     for (int kk = 0; kk < K_TYPES; ++kk) tsum[kk] = 0.0f;
 
+    // (1) plan word + weight of EDGE_BATCH consecutive entries: coalesced, independent.  PREFETCH (the electrical step without
+    // the peer form): the NEXT batch's words are requested before this batch's gathers -- the streamed loads of batch k + 1 are
+    // in flight while the gathers of batch k come back from L2, one dependent round trip less per batch after the first
+    constexpr bool PREFETCH = CSR_PREFETCH && ELEC && !CHEM && !PEER;
+    auto load_batch = [&](uint32_t k0, uint32_t (&pp)[EDGE_BATCH], float (&ww)[EDGE_BATCH]) {
+#pragma unroll
+        for (uint32_t u = 0; u < EDGE_BATCH; ++u) {
+            const uint32_t k = min(k0 + u, width - 1);         // clamped; the tail is dropped below
+            pp[u] = a.g.plan[base + (size_t)k * 64];
+            ww[u] = a.g.w[base + (size_t)k * 64];
+            if (k0 + u >= width) pp[u] = SELL_PAD;
+        }
+    };
+    uint32_t p_next[PREFETCH ? EDGE_BATCH : 1];
+    float w_next[PREFETCH ? EDGE_BATCH : 1];
+    if constexpr (PREFETCH) {
+        if (width) load_batch(0, p_next, w_next);
+    }
     for (uint32_t k0 = 0; k0 < width; k0 += EDGE_BATCH) {
         uint32_t p[EDGE_BATCH];
         float w[EDGE_BATCH], v[EDGE_BATCH], t[EDGE_BATCH][K_TYPES];
         uint32_t flags[EDGE_BATCH];       // bit 0 cell, bit 1 silent cell, bit 2 a granule of the peer form, bits 8.. transmitter types
         unsigned long long g64[PEER ? EDGE_BATCH : 1];
         unsigned long long t64[(PEER && CHEM) ? EDGE_BATCH : 1][K_TYPES];
-        // (1) plan word + weight of EDGE_BATCH consecutive entries: coalesced, independent
+        if constexpr (PREFETCH) {
 #pragma unroll
-        for (uint32_t u = 0; u < EDGE_BATCH; ++u) {
-            const uint32_t k = min(k0 + u, width - 1);         // clamped; the tail is dropped below
-            p[u] = a.g.plan[base + (size_t)k * 64];
-            w[u] = a.g.w[base + (size_t)k * 64];
-            if (k0 + u >= width) p[u] = SELL_PAD;
+            for (uint32_t u = 0; u < EDGE_BATCH; ++u) { p[u] = p_next[u]; w[u] = w_next[u]; }
+            if (k0 + EDGE_BATCH < width) load_batch(k0 + EDGE_BATCH, p_next, w_next);
+        } else {
+            load_batch(k0, p, w);
         }
         // (2) the gathers those words address -- branch-free (the inapplicable sources are clamped to index 0)
 #pragma unroll
@@ -508,8 +529,10 @@ __device__ __forceinline__ void step_csr_block(const CsrStepArgs &a)
     }
 }
 
+// (second launch bound = wavefronts per SIMD the register allocation must leave room for: the prefetching electrical step sits
+// two registers above the 64 that 8 wavefronts allow, and 16 384 wavefronts of BASELINE configs[4] are two full rounds of 8)
 template <int MODEL, bool ELEC, bool CHEM, bool PEER = false>
-__global__ __launch_bounds__(256) void k_step_csr(const CsrStepArgs a)
+__global__ __launch_bounds__(256, (CSR_PREFETCH && ELEC && !CHEM && !PEER) ? 8 : 1) void k_step_csr(const CsrStepArgs a)
 {
     // peer form: THIS launch running means the previous one of the stream is over -- every row and the mirror job of the step
     // before have read what they had to read -- which is what the neighbours wait for before they overwrite a receive set.  One

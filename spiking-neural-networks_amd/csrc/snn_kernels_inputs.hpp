@@ -126,8 +126,10 @@ __device__ __forceinline__ float acc_if_edge(float acc, float term, float w)
 // only ("defer_stdp" 3: the outgoing edges of the neurons that spiked; the incoming edges were scattered by k_stdp_columns when
 // the step closed).  The row half costs the pass no fetch and only full-line stores: a flagged row group is rewritten by every
 // lane of the wavefront, 1 KiB contiguous per store instruction.
+// (second launch bound of the row-half variant: the plain electrical pass runs three wavefronts per SIMD -- 138 registers -- and
+// the variant must keep that occupancy: unbounded it took 174 and the pass 5.16 instead of 4.11 ms at C4)
 template <bool ELEC, bool CHEM, int STREAM = 1, int NT = K_TYPES, int STDP = 0>
-__global__ __launch_bounds__(InputsShape<STREAM>::THREADS) void k_inputs_dense(const InputsArgs a)
+__global__ __launch_bounds__(InputsShape<STREAM>::THREADS, (STDP == 2 && STREAM == 1 && !CHEM) ? 3 : 1) void k_inputs_dense(const InputsArgs a)
 {
     using S = InputsShape<STREAM>;
     constexpr int VEC = S::VEC;
@@ -323,9 +325,11 @@ __global__ __launch_bounds__(InputsShape<STREAM>::THREADS) void k_inputs_dense(c
             }
         }
         // the whole row group of this wavefront's columns goes back: full 128-byte lines, 1 KiB contiguous per instruction
+        // (through the address the load used: W_rw is W)
+        v4f *gp = const_cast<v4f *>(ubase) + (size_t)grp * ld;
 #pragma unroll
         for (int j = 0; j < VEC; ++j)
-            if (colv[j]) reinterpret_cast<v4f *>(a.W_rw)[(size_t)((p0 >> 2) + grp) * ld + ql + (uint32_t)j * S::THREADS] = w[j];
+            if (colv[j]) gp[j * S::THREADS + tid] = w[j];
     };
     auto stdp_group = [&](uint32_t grp, v4f (&w)[VEC]) {
         bool rs[4], any_rs = false;

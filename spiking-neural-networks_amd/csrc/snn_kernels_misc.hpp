@@ -61,6 +61,8 @@ __global__ __launch_bounds__(256) void k_compare_table_alt(const CopyEntry *tabl
         }
     }
 }
+// test hook of "verify": one bit of one word flipped between the two passes' outcome and the comparison
+__global__ void k_flip_bit(uint32_t *p, size_t word) { p[word] ^= 1u; }
 __global__ void k_iota_u32(uint32_t *p, size_t n, uint32_t first)
 {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = first + (uint32_t)i;

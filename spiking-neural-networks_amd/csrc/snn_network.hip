@@ -1278,6 +1278,10 @@ int snn_run(snn_network_t *net, uint64_t iterations)
     if (net->snap_generation == generation) {
         uint32_t report[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         HIP_TRY(hipMemsetAsync(net->verify_report, 0, 32, net->stream), SNN_ERR_BUFFER_WRITE);
+        if (net->verify_fault) {          // option "verify_fault" (test hook): the second outcome is not the first
+            hipLaunchKernelGGL(k_flip_bit, dim3(1), dim3(1), 0, net->stream, reinterpret_cast<uint32_t *>(net->xbuf), (size_t)(net->verify_fault - 1));
+            net->verify_fault = 0;
+        }
         hipLaunchKernelGGL(k_compare_table_alt, grid, dim3(256), 0, net->stream, table, base, first, net->verify_report);
         HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
         HIP_TRY(copy_sync(net, report, net->verify_report, 32, hipMemcpyDeviceToHost), SNN_ERR_BUFFER_READ);
@@ -1789,17 +1793,22 @@ static int agree_on_exchange(Rccl *R, snn_network *net, ncclComm_t comm, void *n
         const bool peer_form = net->halo_peer && net->p2p_connected && net->p2p_recv[0] && net->peer_capable && net->halo_direct && net->csr_plan_direct &&
                                csr_fast_step(net);
         mask |= peer_form ? 0x40000000u : 0u;
+        // bit 29: nothing travels to or from this rank (a lone shard, an empty one, rows that read no neighbour): it posts no
+        // collective and polls no granule either way, so its vote on the peer form does not count
+        bool exchanges = net->x_mode == SNN_EXCHANGE_ALLGATHER;
+        for (uint32_t p = 0; p < G && !exchanges; ++p) exchanges = net->x_send_words[p] || net->x_recv_words[p];
+        const uint32_t idle = exchanges ? 0u : 0x20000000u;
         // bit 31: this rank's mirror lacks a plane of the plan (mirror_stale).  A plane can only go missing when the plan
         // grows -- which is when this agreement runs -- and whether it is missing is rank-local history (host-driven steps,
         // attributes written on some ranks only): if ANY rank is stale, EVERY rank sends its current state once before the
         // first step (idempotent), instead of one rank entering a collective its peers never post.
-        rc = gather(mask | (mirror_stale(net) ? 0x80000000u : 0u));
+        rc = gather(mask | idle | (mirror_stale(net) ? 0x80000000u : 0u));
         bool any_stale = false;
         for (uint32_t p = 0; p < G && !rc; ++p) {
             any_stale = any_stale || (words[p] >> 31) != 0u;
-            if ((words[p] & 0x3FFFFFFFu) != (mask & 0x3FFFFFFFu))
+            if ((words[p] & 0x1FFFFFFFu) != (mask & 0x1FFFFFFFu))
                 rc = fail(SNN_ERR_BAD_STATE, "the ranks of this communicator disagree on the exchange (synapse kinds / transmitter types / mode)");
-            else if ((words[p] & 0x40000000u) != (mask & 0x40000000u))
+            else if (!idle && !(words[p] & 0x20000000u) && (words[p] & 0x40000000u) != (mask & 0x40000000u))
                 rc = fail(SNN_ERR_BAD_STATE, "the ranks of this communicator disagree on the peer form: rank " + std::to_string(p) +
                                                  ((words[p] & 0x40000000u) ? " is connected (snn_p2p_commit, \"halo_peer\" 1), this rank is not"
                                                                            : " is not connected, this rank is") + "; every rank or none");
@@ -1984,6 +1993,7 @@ int snn_set_option(snn_network_t *net, const char *name, int value)
     else if (n == "input_shape") net->force_shape = (value == 1 || value == 2) ? value : 0;
     else if (n == "stdp_columns_form") net->stdp_columns_form = value == 1 ? 1 : 0;
     else if (n == "verify") net->verify = value != 0;
+    else if (n == "verify_fault") net->verify_fault = value > 0 ? (uint32_t)value : 0u;
     else if (n == "run_resident_chunk_steps") net->run_chunk_steps = value >= 4 ? (uint32_t)std::min<long long>(value, 1 << 20) : (1u << 20);
     else return fail(SNN_ERR_BAD_ARG, "unknown option '" + n + "'");
     net->shadow_valid = false;

@@ -279,6 +279,7 @@ struct snn_network {
     // option "verify" (SNN_AMD_VERIFY=1; tests and campaigns): every snn_run call on a handle without weight updates takes its
     // steps TWICE from the same snapshot and compares the two outcomes on the device (k_compare_table_alt)
     int verify = 0;
+    uint32_t verify_fault = 0;                  // option "verify_fault" (test hook): word + 1 of the exchange buffer to disturb once
     uint32_t *verify_buf = nullptr;             // the first outcome, laid out like snap_buf
     uint32_t *verify_report = nullptr;          // device words, see k_compare_table_alt
     uint64_t snap_generation = 0;               // how often the snapshot table has been laid out

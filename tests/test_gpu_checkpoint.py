@@ -83,6 +83,23 @@ def test_the_self_check_steps_every_call_twice_and_agrees(snn, seed):
     dn.close()
 
 
+def test_the_self_check_reports_a_planted_difference(snn, capfd):
+    net, plan = draw(1000 + SEEDS[0])
+    net["do_plasticity"][...] = 0
+    dn = make_handle(snn, net, plan)
+    dn.set_option("verify", 1)
+    dn.run(9)                                                  # (the first run may lay the snapshot out anew: skipped or compared)
+    dn.set_option("verify_fault", 1)                           # the voltage of neuron 0, after the second pass
+    dn.run(12)
+    assert dn.stat("verify_mismatches") == 1
+    text = dn.verify_report()
+    assert "1 words differ" in text and "exchange buffer, plane 0, neuron 0" in text and "run of 12 steps" in text, text
+    assert "[snn verify] MISMATCH" in capfd.readouterr().err
+    dn.run(5)
+    assert dn.stat("verify_mismatches") == 1                    # (the hook fires once)
+    dn.close()
+
+
 class FaultyHandle:
     """a device handle whose `fault_on`-th run call ends with one voltage nudged -- a transient of the device's side"""
 
