@@ -412,8 +412,12 @@ int snn_set_bcm(snn_network_t *net, uint32_t id, float decay, float average_scal
  * `weight` is the graph weight, `c` the trace, 0 initially) and are updated EVERY step by RewardModulatedSTDP
  * (:158-242; defaults dopamine 0, tau_d 20, tau_c 0.0001, a_plus/a_minus 2, tau_plus/tau_minus 4.5, dt 0.1) in the
  * deferred form (both per-step visits of an edge see the step's final last_firing_times; the reference's in-loop
- * form depends on HashSet order).  do_modulation = RewardModulatedLattice::do_modulation; enabling it switches the
- * lattice's STDP off.  16 B per internal synapse are streamed per step. */
+ * form depends on HashSet order).  do_modulation = RewardModulatedLattice::do_modulation (neuron/mod.rs:2744).  The call makes
+ * the lattice a reward-modulated lattice for good, whatever do_modulation says: it has no STDP rule of its own from then on
+ * (snn_set_plasticity keeps its parameters but not its switch), rewards reach its modulator (:5287-5291), and for the
+ * connection visits of OTHER lattices (snn_set_connection_kind) it is a modulated partner; do_modulation 0 only means that
+ * its own weights are not updated and its neurons are not visited (:3076, :5113).  16 B per internal synapse are streamed
+ * per step. */
 int snn_set_reward_modulator(snn_network_t *net, uint32_t id, float dopamine, float tau_d, float tau_c, float a_plus,
                              float a_minus, float tau_plus, float tau_minus, float dt, int do_modulation);
 int snn_get_dopamine(snn_network_t *net, uint32_t id, float *dopamine);
@@ -442,7 +446,9 @@ int snn_get_trace_rows(snn_network_t *net, uint32_t pre_begin, uint32_t pre_coun
  * snn_set_connection_kind(pre_id, post_id, kind) tags every connection from lattice (or spike-train lattice) pre_id into
  * neuron lattice post_id (kind 0, the default: the plain LatticeNetwork's rule of snn_set_plasticity, forward lookups only).
  * dw is the `pending` matrix and the counter of the two-visit cycle the `counter` matrix, both per connection (rows as
- * snn_set_trace_rows; counters 0 / 1, one byte each).  Dense, unsharded handles.
+ * snn_set_trace_rows; counters 0 / 1, one byte each; sparse handles: per stored edge in the order of snn_set_graph_csr, the
+ * _csr forms below, after the graph is set -- a new sparse graph drops traces, dw and counters with the edges they belonged
+ * to).  Unsharded handles, dense or sparse (k_reward_cross / k_reward_cross_csr).
  * Outside the domain where the reference's visits are defined (it unwraps None there) the next run call returns
  * SNN_ERR_BAD_STATE and snn_last_error names the case: a connection of a visited lattice (modulated, or plain with
  * do_plasticity) without a reverse connection of the same kind; kind 1 where no side has a modulator while one side is plastic,
@@ -455,6 +461,10 @@ int snn_set_counter_rows(snn_network_t *net, uint32_t pre_begin, uint32_t pre_co
 int snn_get_counter_rows(snn_network_t *net, uint32_t pre_begin, uint32_t pre_count, uint8_t *counters);
 int snn_set_traces_csr(snn_network_t *net, const float *traces, uint64_t nnz);
 int snn_get_traces_csr(snn_network_t *net, float *traces, uint64_t nnz);
+int snn_set_pending_csr(snn_network_t *net, const float *pending, uint64_t nnz);
+int snn_get_pending_csr(snn_network_t *net, float *pending, uint64_t nnz);
+int snn_set_counters_csr(snn_network_t *net, const uint8_t *counters, uint64_t nnz);
+int snn_get_counters_csr(snn_network_t *net, uint8_t *counters, uint64_t nnz);
 
 /* PresetSpikeTrain::firing_times (spike_train/mod.rs:772) of every cell of spike-train lattice `id`: cell i (row-major)
  * fires through times[cell_ptr[i] .. cell_ptr[i+1]), cyclically; cell_ptr has rows*cols + 1 entries, starts at 0 and

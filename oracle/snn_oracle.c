@@ -1083,6 +1083,12 @@ static inline uint32_t conn_kind_of(const snn_o_net *n, uint32_t p, uint32_t l)
     return n->conn_kind[(size_t)source * n->n_lattices + l];
 }
 
+/* lattice l is held by the network's reward_modulated_lattices map (see snn_oracle.h, rm_is_modulated) */
+static inline int lattice_is_modulated(const snn_o_net *n, uint32_t l)
+{
+    return (n->rm_do_modulation && n->rm_do_modulation[l]) || (n->rm_is_modulated && n->rm_is_modulated[l]);
+}
+
 void snn_o_plasticity_cols(snn_o_net *n, uint32_t c0, uint32_t c1)
 {
     const uint32_t nn = n->n_neurons;
@@ -1094,6 +1100,7 @@ void snn_o_plasticity_cols(snn_o_net *n, uint32_t c0, uint32_t c1)
 
     for (uint32_t j = 0; j < nn; ++j) {
         if (!(n->is_spiking[j] && n->do_plasticity[n->lattice[j]])) continue;
+        if (lattice_is_modulated(n, n->lattice[j])) continue;          /* a RewardModulatedLattice has no STDP rule of its own */
         /* incoming edges of j */
         if (j >= c0 && j < c1) {
             uint32_t l = n->lattice[j];
@@ -1131,12 +1138,13 @@ void snn_o_plasticity_cols(snn_o_net *n, uint32_t c0, uint32_t c1)
 
 /* ---------- reward modulation ---------- */
 
+
 /* RewardModulatedSTDP::update, plasticity/mod.rs:199-201, on every modulated lattice */
 void snn_o_apply_reward(snn_o_net *n, float reward)
 {
     if (!n->rm_do_modulation) return;
     for (uint32_t l = 0; l < n->n_lattices; ++l) {
-        if (!n->rm_do_modulation[l]) continue;
+        if (!lattice_is_modulated(n, l)) continue;                  /* (a paused modulator still takes the reward, :5287-5291) */
         n->rm_dopamine[l] = n->rm_dopamine[l] * snn_o_expf(-n->rm_dt[l] / n->rm_tau_d[l]) + n->rm_tau_d[l] * reward;
     }
 }
@@ -1211,7 +1219,7 @@ void snn_o_reward_modulation_cols(snn_o_net *n, uint32_t c0, uint32_t c1)
  * Connections of kind 0 are left to the plain network's rule (snn_o_plasticity_cols), which skips kinds 1 and 2. */
 static inline int cross_visited(const snn_o_net *n, uint32_t l)
 {
-    return n->rm_do_modulation[l] || (n->do_plasticity && n->do_plasticity[l]);
+    return lattice_is_modulated(n, l) ? (n->rm_do_modulation[l] != 0) : (n->do_plasticity && n->do_plasticity[l]);
 }
 
 int snn_o_reward_cross_check(const snn_o_net *n)
@@ -1223,7 +1231,7 @@ int snn_o_reward_cross_check(const snn_o_net *n)
             if (!n->connections[(size_t)p * nn + q]) continue;
             const uint32_t lq = n->lattice[q], kind = conn_kind_of(n, p, lq);
             if (kind == 0) continue;
-            const int mod_q = n->rm_do_modulation[lq] != 0, plastic_q = !mod_q && cross_visited(n, lq);
+            const int mod_q = lattice_is_modulated(n, lq), plastic_q = !mod_q && cross_visited(n, lq);
             if (plastic_q && n->plasticity_kind && n->plasticity_kind[lq]) return 4;
             if (p >= nn) {                                           /* spike train -> q: incoming half of q only */
                 if (kind == 1 && plastic_q) return 2;
@@ -1231,7 +1239,7 @@ int snn_o_reward_cross_check(const snn_o_net *n)
             }
             const uint32_t lp = n->lattice[p];
             if (lp == lq) continue;
-            const int mod_p = n->rm_do_modulation[lp] != 0, plastic_p = !mod_p && cross_visited(n, lp);
+            const int mod_p = lattice_is_modulated(n, lp), plastic_p = !mod_p && cross_visited(n, lp);
             if (plastic_p && n->plasticity_kind && n->plasticity_kind[lp]) return 4;
             if (kind == 1 && !mod_p && !mod_q && (plastic_p || plastic_q)) return 2;
             if (kind == 2 && ((plastic_p && mod_q) || (plastic_q && mod_p))) return 3;
@@ -1265,7 +1273,7 @@ static inline float cross_stdp(const snn_o_net *n, uint32_t l, int32_t t_pre, in
 static void cross_visit(snn_o_net *n, uint32_t x)
 {
     const uint32_t nn = n->n_neurons, n_tot = nn + n->n_cells, lx = n->lattice[x];
-    const int mod_x = n->rm_do_modulation[lx] != 0;
+    const int mod_x = lattice_is_modulated(n, lx);
     const int32_t tx = n->last_firing_time[x];
     for (uint32_t p = 0; p < n_tot; ++p) {                           /* incoming half */
         const size_t i = (size_t)p * nn + x;
@@ -1275,7 +1283,7 @@ static void cross_visit(snn_o_net *n, uint32_t x)
         const int32_t tp = (p < nn) ? n->last_firing_time[p] : n->st_last_firing_time[p - nn];
         if (kind == 2) {
             if (!mod_x) n->weights[i] += cross_stdp(n, lx, tp, tx);
-            else if (p < nn && !n->rm_do_modulation[n->lattice[p]]) n->weights[i] += cross_stdp(n, n->lattice[p], tp, tx);
+            else if (p < nn && !lattice_is_modulated(n, n->lattice[p])) n->weights[i] += cross_stdp(n, n->lattice[p], tp, tx);
         } else {
             const uint32_t m = mod_x ? lx : n->lattice[p];
             cross_trace_visit(n, m, tp, tx, &n->weights[i], &n->traces[i], &n->pending[i], &n->edge_counter[i]);
@@ -1290,7 +1298,7 @@ static void cross_visit(snn_o_net *n, uint32_t x)
         const int32_t to = n->last_firing_time[o];
         if (kind == 2) {
             if (!mod_x) n->weights[f] = n->weights[r] + cross_stdp(n, lx, tx, to);
-            else if (!n->rm_do_modulation[lo]) n->weights[f] = n->weights[r] + cross_stdp(n, lo, tx, to);
+            else if (!lattice_is_modulated(n, lo)) n->weights[f] = n->weights[r] + cross_stdp(n, lo, tx, to);
         } else {
             float w = n->weights[r], c = n->traces[r], dw = n->pending[r];
             uint8_t counter = n->edge_counter[r];
@@ -1311,10 +1319,10 @@ void snn_o_reward_cross(snn_o_net *n)
     }
     for (uint32_t x = 0; x < nn; ++x) {
         const uint32_t l = n->lattice[x];
-        if (!n->rm_do_modulation[l] && n->do_plasticity && n->do_plasticity[l] && n->is_spiking[x]) cross_visit(n, x);
+        if (!lattice_is_modulated(n, l) && n->do_plasticity && n->do_plasticity[l] && n->is_spiking[x]) cross_visit(n, x);
     }
     for (uint32_t x = 0; x < nn; ++x)
-        if (n->rm_do_modulation[n->lattice[x]]) cross_visit(n, x);
+        if (n->rm_do_modulation[n->lattice[x]]) cross_visit(n, x);      /* (modulated AND do_modulation, :5113) */
 }
 
 /* ---------- step 6: spike trains ---------- */

@@ -244,6 +244,13 @@ typedef struct snn_o_net {
     uint8_t  *conn_kind;
     float    *pending;
     uint8_t  *edge_counter;
+    /* Which MAP of the reference's network holds a lattice (RewardModulatedLatticeNetwork::lattices vs
+     * ::reward_modulated_lattices, neuron/mod.rs:3419-3453) is one thing, RewardModulatedLattice::do_modulation (:2744) another:
+     * a modulated lattice whose do_modulation is false is never visited (:5113) and updates no weight of its own (:3076), but
+     * as a PARTNER of another lattice's visit it is still a modulated lattice (:4729, :4869, :4937), it has no STDP rule, and its
+     * modulator still takes every reward (:5287-5291).  rm_is_modulated[l] != 0 or rm_do_modulation[l] != 0: lattice l is a
+     * reward-modulated lattice.  NULL: the lattices with do_modulation set are. */
+    uint32_t *rm_is_modulated;
 } snn_o_net;
 
 /* Step 1 of SURVEY §8(g): electrical + chemical inputs for every neuron from state S(t). */

@@ -243,6 +243,10 @@ SIGNATURES = {
     "snn_get_trace_rows": (C.c_int, [H, C.c_uint32, C.c_uint32, f32p]),
     "snn_set_traces_csr": (C.c_int, [H, f32p, C.c_uint64]),
     "snn_get_traces_csr": (C.c_int, [H, f32p, C.c_uint64]),
+    "snn_set_pending_csr": (C.c_int, [H, f32p, C.c_uint64]),
+    "snn_get_pending_csr": (C.c_int, [H, f32p, C.c_uint64]),
+    "snn_set_counters_csr": (C.c_int, [H, u8p, C.c_uint64]),
+    "snn_get_counters_csr": (C.c_int, [H, u8p, C.c_uint64]),
     "snn_set_firing_times": (C.c_int, [H, C.c_uint32, u32p, f32p, C.c_size_t]),
     "snn_set_graph_history": (C.c_int, [H, C.c_uint32, C.c_int]),
     "snn_get_graph_history": (C.c_int, [H, C.c_uint32, f32p, C.c_size_t]),

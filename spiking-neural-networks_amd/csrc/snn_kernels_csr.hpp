@@ -625,6 +625,7 @@ __global__ __launch_bounds__(64) void k_stdp_csr_in(const CsrStdpArgs a)
             const uint32_t p = a.g.pre[e];
             const int32_t tp = (p < a.s.n_neurons) ? a.s.last_firing_time[p] : a.s.st_last_firing_time[p - a.s.n_neurons];
             const float pre = bcm ? ((p < a.s.n_neurons) ? a.s.act[p] : a.s.st_act[p - a.s.n_neurons]) : 0.0f;
+            if (!plain_connection(a.s, p, a.s.lattice_slot[j])) continue;      // (a connection of a reward-modulated network)
             a.g.w[e] = plasticity_weight(prm, a.g.w[e], tp, tj, pre, post_act, post_avg);
         }
     }
@@ -642,6 +643,7 @@ __global__ __launch_bounds__(64) void k_stdp_csr_out(const CsrStdpArgs a)
             const uint32_t gr = a.s.rows.global_of(a.g.edge_post[edge]);
             const float *prm = a.s.stdp + PL_STRIDE * a.s.lattice_slot[gr];
             const bool bcm = prm[5] != 0.0f;
+            if (!plain_connection(a.s, j, a.s.lattice_slot[gr])) continue;
             a.g.w[e] = plasticity_weight(prm, a.g.w[e], tj, a.s.last_firing_time[gr], bcm ? a.s.act[j] : 0.0f,
                                          bcm ? a.s.act[gr] : 0.0f, bcm ? a.s.avg[gr] : 0.0f);
         }
@@ -667,7 +669,7 @@ __global__ __launch_bounds__(256) void k_rstdp_csr(const CsrRewardArgs a)
     if (q >= a.g.n_loc || !a.rows.active(q, a.g.n_loc)) return;
     const uint32_t gq = a.rows.global_of(q);
     const uint32_t sq = a.lattice_slot[gq];
-    if (!a.rm_on[sq]) return;
+    if (!(a.rm_on[sq] & RM_DO_MODULATION)) return;
     const float *m = a.rm + (size_t)sq * RM_STRIDE;
     const int32_t tq = a.last_firing_time[gq];
     const uint32_t base = a.g.slice_ptr[q >> 6] + (q & 63u);
@@ -681,6 +683,111 @@ __global__ __launch_bounds__(256) void k_rstdp_csr(const CsrRewardArgs a)
         a.g.w[e] = w;
         a.c[e] = c;
     }
+}
+
+// ---- connections between the lattices of a reward-modulated network on the sparse form (round 5) -------------------------------
+// k_reward_cross with the pair (x < y) found from the stored edges: a thread walks the entries of one postsynaptic row; an entry
+// p -> q of kind 1 / 2 between two lattices is half of the pair (min, max); its reverse is looked up by binary search in the row of
+// p (rows are sorted by presynaptic index).  The pair is replayed by the thread that holds the edge FROM the higher index (y -> x),
+// or, when that edge does not exist, by the one that holds x -> y.  Trace, dw and counter are per stored entry (C, P, K).
+// Unsharded handles: every row is local.
+struct CsrRewardCrossArgs {
+    SellGraph g;
+    RewardCrossArgs r;             // r.s.W is unused: the weights are g.w
+};
+
+__device__ __forceinline__ uint32_t csr_find_entry(const SellGraph &g, uint32_t row, uint32_t pre)
+{
+    const uint32_t base = g.slice_ptr[row >> 6] + (row & 63u), len = g.row_len[row];
+    uint32_t lo = 0, hi = len;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (g.pre[base + (size_t)mid * 64] < pre) lo = mid + 1; else hi = mid;
+    }
+    return (lo < len && g.pre[base + (size_t)lo * 64] == pre) ? base + lo * 64u : 0xFFFFFFFFu;
+}
+
+__global__ __launch_bounds__(256) void k_reward_cross_csr(const CsrRewardCrossArgs a)
+{
+    const StdpArgs &s = a.r.s;
+    const uint32_t q = blockIdx.x * 256 + threadIdx.x;                 // local row = neuron (unsharded)
+    if (q >= a.g.n_loc || q >= s.n_neurons) return;
+    const uint32_t lq = s.lattice_slot[q];
+    const uint32_t base = a.g.slice_ptr[q >> 6] + (q & 63u), len = a.g.row_len[q];
+    const uint32_t *spike = reinterpret_cast<const uint32_t *>(s.xbuf);
+    for (uint32_t k = 0; k < len; ++k) {
+        const uint32_t e = base + k * 64u;
+        const uint32_t p = a.g.pre[e];
+        const bool p_neuron = p < s.n_neurons;
+        if (p_neuron && s.lattice_slot[p] == lq) continue;
+        const uint32_t kind_e = cross_kind(s, p, lq);
+        if (kind_e == 0u) continue;
+        // the pair: x < y; yx = the edge y -> x, xy = the edge x -> y
+        const bool e_is_yx = p > q;
+        const uint32_t x = e_is_yx ? q : p, y = e_is_yx ? p : q;
+        const bool y_neuron = y < s.n_neurons;
+        uint32_t e_yx = e_is_yx ? e : 0xFFFFFFFFu, e_xy = e_is_yx ? 0xFFFFFFFFu : e;
+        const uint32_t lx = s.lattice_slot[x], ly = y_neuron ? s.lattice_slot[y] : 0u;
+        if (e_is_yx) {
+            if (y_neuron) e_xy = csr_find_entry(a.g, y, x);                                  // row of y holds x -> y
+            if (e_xy != 0xFFFFFFFFu && cross_kind(s, x, ly) == 0u) e_xy = 0xFFFFFFFFu;
+        } else {
+            e_yx = csr_find_entry(a.g, x, y);                                                // row of x holds y -> x
+            if (e_yx != 0xFFFFFFFFu && cross_kind(s, y, lx) != 0u) continue;                 // that entry's thread replays the pair
+            e_yx = 0xFFFFFFFFu;
+        }
+        CrossEdge yx{}, xy{};
+        yx.exists = e_yx != 0xFFFFFFFFu; xy.exists = e_xy != 0xFFFFFFFFu;
+        if (yx.exists) { yx.kind = cross_kind(s, y, lx); yx.w = a.g.w[e_yx]; }
+        if (xy.exists) { xy.kind = cross_kind(s, x, ly); xy.w = a.g.w[e_xy]; }
+        const bool x_is_mod = (a.r.rm_on[lx] & RM_IS_MODULATED) != 0u, y_is_mod = y_neuron && (a.r.rm_on[ly] & RM_IS_MODULATED) != 0u;
+        const bool x_mod = x_is_mod && (a.r.rm_on[lx] & RM_DO_MODULATION) != 0u, y_mod = y_is_mod && (a.r.rm_on[ly] & RM_DO_MODULATION) != 0u;
+        const bool x_plain = !x_is_mod && s.do_plasticity[lx] && spike[s.xl.at(x, PLANE_SPIKE)] != 0u;
+        const bool y_plain = y_neuron && !y_is_mod && s.do_plasticity[ly] && spike[s.xl.at(y, PLANE_SPIKE)] != 0u;
+        if (!(x_mod || x_plain || y_mod || y_plain)) continue;
+        if (yx.exists) { yx.c = a.r.C[e_yx]; yx.dw = a.r.P[e_yx]; yx.k = a.r.K[e_yx]; }
+        if (xy.exists) { xy.c = a.r.C[e_xy]; xy.dw = a.r.P[e_xy]; xy.k = a.r.K[e_xy]; }
+        const int tx = s.last_firing_time[x];
+        const int ty = y_neuron ? s.last_firing_time[y] : s.st_last_firing_time[y - s.n_neurons];
+        if (x_plain) cross_visit(a.r, yx, xy, lx, ly, y_neuron, tx, ty);
+        if (y_plain) cross_visit(a.r, xy, yx, ly, lx, true, ty, tx);
+        if (x_mod) cross_visit(a.r, yx, xy, lx, ly, y_neuron, tx, ty);
+        if (y_mod) cross_visit(a.r, xy, yx, ly, lx, true, ty, tx);
+        if (yx.exists) { a.g.w[e_yx] = yx.w; a.r.C[e_yx] = yx.c; a.r.P[e_yx] = yx.dw; a.r.K[e_yx] = yx.k; }
+        if (xy.exists) { a.g.w[e_xy] = xy.w; a.r.C[e_xy] = xy.c; a.r.P[e_xy] = xy.dw; a.r.K[e_xy] = xy.k; }
+    }
+}
+
+// k_reward_cross_check on the sparse form (same refusal classes)
+__global__ __launch_bounds__(256) void k_reward_cross_check_csr(const CsrRewardCrossArgs a)
+{
+    const StdpArgs &s = a.r.s;
+    const uint32_t q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= a.g.n_loc || q >= s.n_neurons) return;
+    const uint32_t lq = s.lattice_slot[q];
+    const bool mod_q = (a.r.rm_on[lq] & RM_IS_MODULATED) != 0u, plastic_q = !mod_q && s.do_plasticity[lq] != 0u;
+    const uint32_t base = a.g.slice_ptr[q >> 6] + (q & 63u), len = a.g.row_len[q];
+    uint32_t bad = 0;
+    for (uint32_t k = 0; k < len; ++k) {
+        const uint32_t p = a.g.pre[base + k * 64u];
+        const uint32_t kind = cross_kind(s, p, lq);
+        if (kind == 0u) continue;
+        if (plastic_q && s.stdp[PL_STRIDE * lq + 5] != 0.0f) bad = max(bad, 4u);
+        if (p >= s.n_neurons) {
+            if (kind == 1u && plastic_q) bad = max(bad, 2u);
+            continue;
+        }
+        const uint32_t lp = s.lattice_slot[p];
+        if (lp == lq) continue;
+        const bool mod_p = (a.r.rm_on[lp] & RM_IS_MODULATED) != 0u, plastic_p = !mod_p && s.do_plasticity[lp] != 0u;
+        if (plastic_p && s.stdp[PL_STRIDE * lp + 5] != 0.0f) bad = max(bad, 4u);
+        if (kind == 1u && !mod_p && !mod_q && (plastic_p || plastic_q)) bad = max(bad, 2u);
+        if (kind == 2u && ((plastic_p && mod_q) || (plastic_q && mod_p))) bad = max(bad, 3u);
+        if ((mod_p && (a.r.rm_on[lp] & RM_DO_MODULATION)) || plastic_p) {
+            if (csr_find_entry(a.g, p, q) == 0xFFFFFFFFu || s.conn_kind[(size_t)lq * s.n_lattices + lp] != kind) bad = max(bad, 1u);
+        }
+    }
+    if (bad) atomicMax(a.r.bad, bad);
 }
 
 } // namespace snn

@@ -14,6 +14,11 @@ namespace snn {
 // has been applied in between.
 constexpr int RM_STRIDE = 10;
 constexpr int RM_DOPAMINE = 0, RM_DOPAMINE_BEFORE = 9;
+// rm_on[lattice]: bit 0 RewardModulatedLattice::do_modulation (neuron/mod.rs:2744), bit 1 the lattice IS a reward-modulated
+// lattice (held by the network's reward_modulated_lattices map, :3419-3453): set by snn_set_reward_modulator whatever its
+// do_modulation argument.  A modulated lattice with do_modulation off updates no weight of its own and is never visited, but its
+// modulator takes every reward and it stays a modulated PARTNER of other lattices' visits.
+constexpr uint32_t RM_DO_MODULATION = 1u, RM_IS_MODULATED = 2u;
 
 // RewardModulatedSTDP::update (plasticity/mod.rs:199-201) on every modulated lattice; reward < 0 or > 0 alike.
 // `refresh_only`: recompute the cached trace decay after the parameters changed.
@@ -23,7 +28,7 @@ __global__ void k_modulator_update(float *rm, const uint32_t *rm_on, uint32_t n_
     if (l >= n_lattices) return;
     float *m = rm + (size_t)l * RM_STRIDE;
     m[8] = expf_glibc(-m[7] / m[2]);
-    if (refresh_only || !rm_on[l]) return;
+    if (refresh_only || !(rm_on[l] & RM_IS_MODULATED)) return;          // (a paused modulator still takes the reward, neuron/mod.rs:5287-5291)
     m[RM_DOPAMINE_BEFORE] = m[RM_DOPAMINE];
     m[RM_DOPAMINE] = m[RM_DOPAMINE] * expf_glibc(-m[7] / m[1]) + m[1] * reward;
 }
@@ -70,7 +75,7 @@ __global__ __launch_bounds__(256) void k_rstdp_dense(const RewardArgs a)
 #pragma unroll
         for (uint32_t k = 0; k < 4; ++k) {
             const uint32_t p = g * 4 + k;
-            sp[k] = (p < a.n_neurons && a.rm_on[a.lattice_slot[p]]) ? a.lattice_slot[p] : 0xFFFFFFFFu;
+            sp[k] = (p < a.n_neurons && (a.rm_on[a.lattice_slot[p]] & RM_DO_MODULATION)) ? a.lattice_slot[p] : 0xFFFFFFFFu;
             any = any || sp[k] == sq;
         }
         if (!any) continue;
@@ -142,7 +147,7 @@ __device__ __forceinline__ void cross_trace_visit(CrossEdge &e, const float *m, 
 __device__ __forceinline__ void cross_visit(const RewardCrossArgs &a, CrossEdge &in, CrossEdge &out, uint32_t lz, uint32_t lo,
                                             bool o_is_neuron, int tz, int to)
 {
-    const bool mod_z = a.rm_on[lz] != 0u, mod_o = o_is_neuron && a.rm_on[lo] != 0u;
+    const bool mod_z = (a.rm_on[lz] & RM_IS_MODULATED) != 0u, mod_o = o_is_neuron && (a.rm_on[lo] & RM_IS_MODULATED) != 0u;
     const float *plain = a.s.stdp + PL_STRIDE * (mod_z ? lo : lz);
     const float *m = a.rm + (size_t)(mod_z ? lz : lo) * RM_STRIDE;
     if (in.exists && in.kind == 2u && (!mod_z || (o_is_neuron && !mod_o)))
@@ -164,8 +169,10 @@ __global__ __launch_bounds__(256) void k_reward_cross(const RewardCrossArgs a)
     if (x >= s.n_neurons) return;
     const uint32_t lx = s.lattice_slot[x];
     const int tx = s.last_firing_time[x];
-    const bool x_mod = a.rm_on[lx] != 0u;
-    const bool x_plain = !x_mod && s.do_plasticity[lx] && reinterpret_cast<const uint32_t *>(s.xbuf)[s.xl.at(x, PLANE_SPIKE)] != 0u;
+    // which map of the reference's network holds a lattice (modulated or plain) decides its role; whether the neurons of a modulated
+    // lattice are visited is its do_modulation (neuron/mod.rs:5113)
+    const bool x_is_mod = (a.rm_on[lx] & RM_IS_MODULATED) != 0u, x_mod = x_is_mod && (a.rm_on[lx] & RM_DO_MODULATION) != 0u;
+    const bool x_plain = !x_is_mod && s.do_plasticity[lx] && reinterpret_cast<const uint32_t *>(s.xbuf)[s.xl.at(x, PLANE_SPIKE)] != 0u;
     for (uint32_t y = blockIdx.y; y < s.n_tot; y += gridDim.y) {
         if (y <= x) continue;
         const bool y_neuron = y < s.n_neurons;
@@ -182,8 +189,8 @@ __global__ __launch_bounds__(256) void k_reward_cross(const RewardCrossArgs a)
             xy.exists = xy.kind != 0u && xy.w == xy.w;
         }
         if (!yx.exists && !xy.exists) continue;
-        const bool y_mod = y_neuron && a.rm_on[ly] != 0u;
-        const bool y_plain = y_neuron && !y_mod && s.do_plasticity[ly] &&
+        const bool y_is_mod = y_neuron && (a.rm_on[ly] & RM_IS_MODULATED) != 0u, y_mod = y_is_mod && (a.rm_on[ly] & RM_DO_MODULATION) != 0u;
+        const bool y_plain = y_neuron && !y_is_mod && s.do_plasticity[ly] &&
                              reinterpret_cast<const uint32_t *>(s.xbuf)[s.xl.at(y, PLANE_SPIKE)] != 0u;
         if (!(x_mod || x_plain || y_mod || y_plain)) continue;
         if (yx.exists) { yx.c = a.C[i_yx]; yx.dw = a.P[i_yx]; yx.k = a.K[i_yx]; }
@@ -211,7 +218,7 @@ __global__ __launch_bounds__(256) void k_reward_cross_check(const RewardCrossArg
     const uint32_t q = blockIdx.x * 256 + threadIdx.x;
     if (q >= s.n_neurons) return;
     const uint32_t lq = s.lattice_slot[q];
-    const bool mod_q = a.rm_on[lq] != 0u, plastic_q = !mod_q && s.do_plasticity[lq] != 0u;
+    const bool mod_q = (a.rm_on[lq] & RM_IS_MODULATED) != 0u, plastic_q = !mod_q && s.do_plasticity[lq] != 0u;
     uint32_t bad = 0;
     for (uint32_t p = blockIdx.y; p < s.n_tot; p += gridDim.y) {
         const uint32_t kind = cross_kind(s, p, lq);
@@ -224,11 +231,11 @@ __global__ __launch_bounds__(256) void k_reward_cross_check(const RewardCrossArg
         }
         const uint32_t lp = s.lattice_slot[p];
         if (lp == lq) continue;
-        const bool mod_p = a.rm_on[lp] != 0u, plastic_p = !mod_p && s.do_plasticity[lp] != 0u;
+        const bool mod_p = (a.rm_on[lp] & RM_IS_MODULATED) != 0u, plastic_p = !mod_p && s.do_plasticity[lp] != 0u;
         if (plastic_p && s.stdp[PL_STRIDE * lp + 5] != 0.0f) bad = max(bad, 4u);
         if (kind == 1u && !mod_p && !mod_q && (plastic_p || plastic_q)) bad = max(bad, 2u);
         if (kind == 2u && ((plastic_p && mod_q) || (plastic_q && mod_p))) bad = max(bad, 3u);
-        if (mod_p || plastic_p) {
+        if ((mod_p && (a.rm_on[lp] & RM_DO_MODULATION)) || plastic_p) {          // p's lattice is visited: its outgoing half needs q -> p
             const float r = s.W[cross_at(s, q, p)];
             if (r != r || s.conn_kind[(size_t)lq * s.n_lattices + lp] != kind) bad = max(bad, 1u);
         }
@@ -287,7 +294,7 @@ __global__ __launch_bounds__(InputsShape<STREAM>::THREADS) void k_inputs_rstdp(c
                 }
             }
             const uint32_t slot = ra.lattice_slot[p];
-            if (ra.rm_on[slot]) mod = slot;
+            if (ra.rm_on[slot] & RM_DO_MODULATION) mod = slot;
             lft = ra.last_firing_time[p];
         } else {
             const uint32_t s = p - a.n_neurons;

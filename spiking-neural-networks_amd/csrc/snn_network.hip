@@ -359,7 +359,7 @@ int snn_network_use_csr(snn_network_t *net, int enable)
     return SNN_OK;
 }
 
-namespace { int ensure_traces(snn_network *net); }
+namespace { int ensure_traces(snn_network *net); int ensure_pending(snn_network *net); }
 
 static int set_graph_csr_impl(snn_network_t *net, const uint64_t *row_ptr, const uint32_t *pre_index, const float *weights,
                               uint64_t nnz)
@@ -442,6 +442,9 @@ static int set_graph_csr_impl(snn_network_t *net, const uint64_t *row_ptr, const
     TRY(up((void **)&net->csr_t_edge, t_edge.data(), nnz * 4));
     HIP_TRY(snn_malloc(&net->csr_plan, std::max<size_t>(entries * 4, 256)), SNN_ERR_BUFFER_CREATE);
     if (net->trace) { (void)hipFree(net->trace); net->trace = nullptr; }      // traces belong to the replaced edges
+    for (float **m : {&net->pending, &net->edge_counter})                     // ... and so do dw and the counters of its connections
+        if (*m) { (void)hipFree(*m); *m = nullptr; }
+    net->cross_checked = false;
     net->nnz = nnz;
     net->sell_entries = entries;
     if (n_slices) {
@@ -465,7 +468,8 @@ static int set_graph_csr_impl(snn_network_t *net, const uint64_t *row_ptr, const
         net->view_dirty = true;
     }
     // a reward-modulated handle keeps modulating: zeroed traces for the new edges (the old ones went with their edges)
-    if (net->any_modulation) TRY(ensure_traces(net));
+    if (net->any_modulation || net->any_conn_kind) TRY(ensure_traces(net));
+    if (net->any_conn_kind) TRY(ensure_pending(net));
     return SNN_OK;
 }
 
@@ -515,7 +519,8 @@ int snn_set_plasticity(snn_network_t *net, uint32_t id, float a_plus, float a_mi
     HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
     float *s = &net->stdp_host[(size_t)l->slot * PL_STRIDE];
     s[0] = a_plus; s[1] = a_minus; s[2] = tau_plus; s[3] = tau_minus; s[4] = dt; s[5] = 0.0f;
-    net->plast_host[l->slot] = do_plasticity ? 1u : 0u;
+    // (a reward-modulated lattice keeps the parameters -- a partner's visit may borrow them -- but has no rule of its own)
+    net->plast_host[l->slot] = (do_plasticity && !(l->slot < net->rm_on_host.size() && (net->rm_on_host[l->slot] & RM_IS_MODULATED))) ? 1u : 0u;
     net->any_plasticity = false;
     for (uint32_t p : net->plast_host) net->any_plasticity |= (p != 0);
     TRY(end_run(net));
@@ -537,7 +542,8 @@ int snn_set_bcm(snn_network_t *net, uint32_t id, float decay, float average_scal
     HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
     float *s = &net->stdp_host[(size_t)l->slot * PL_STRIDE];
     s[4] = dt; s[5] = 1.0f; s[6] = decay; s[7] = average_scalar;
-    net->plast_host[l->slot] = do_plasticity ? 1u : 0u;
+    // (a reward-modulated lattice keeps the parameters -- a partner's visit may borrow them -- but has no rule of its own)
+    net->plast_host[l->slot] = (do_plasticity && !(l->slot < net->rm_on_host.size() && (net->rm_on_host[l->slot] & RM_IS_MODULATED))) ? 1u : 0u;
     net->any_plasticity = false;
     for (uint32_t p : net->plast_host) net->any_plasticity |= (p != 0);
     TRY(end_run(net));
@@ -625,15 +631,18 @@ int snn_set_reward_modulator(snn_network_t *net, uint32_t id, float dopamine, fl
     float *m = &net->rm_host[(size_t)l->slot * RM_STRIDE];
     m[0] = dopamine; m[1] = tau_d; m[2] = tau_c; m[3] = a_plus; m[4] = a_minus; m[5] = tau_plus; m[6] = tau_minus; m[7] = dt;
     m[RM_DOPAMINE_BEFORE] = dopamine;
-    net->rm_on_host[l->slot] = do_modulation ? 1u : 0u;
-    net->any_modulation = false;
-    for (uint32_t v : net->rm_on_host) net->any_modulation |= (v != 0);
-    if (do_modulation) {
-        // a RewardModulatedLattice has no STDP rule of its own
+    // bit 0 do_modulation, bit 1 "this is a reward-modulated lattice" (snn_kernels_reward.hpp): the call makes the lattice one for good
+    net->rm_on_host[l->slot] = (do_modulation ? RM_DO_MODULATION : 0u) | RM_IS_MODULATED;
+    net->any_modulation = net->any_modulated = false;
+    for (uint32_t v : net->rm_on_host) { net->any_modulation |= (v & RM_DO_MODULATION) != 0; net->any_modulated |= (v & RM_IS_MODULATED) != 0; }
+    {
+        // a RewardModulatedLattice has no STDP rule of its own, whether or not it is modulating
         net->plast_host[l->slot] = 0;
         net->any_plasticity = false;
         for (uint32_t p : net->plast_host) net->any_plasticity |= (p != 0);
         HIP_TRY(copy_sync(net, net->plast_dev, net->plast_host.data(), net->plast_host.size() * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
+    }
+    if (do_modulation) {
         if (net->csr && !net->csr_ptr) return fail(SNN_ERR_BAD_STATE, "set the sparse graph before enabling reward modulation");
         TRY(ensure_traces(net));
     }
@@ -661,7 +670,7 @@ int snn_apply_reward(snn_network_t *net, float reward)
 {
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
     if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
-    if (!net->any_modulation) return SNN_OK;
+    if (!net->any_modulated) return SNN_OK;
     HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
     // a deferred weight update keeps ONE earlier dopamine value: a second reward before the next step applies it first
     if (net->rstdp_pending && net->reward_since_defer) TRY(flush_rstdp(net));
@@ -689,10 +698,10 @@ namespace {
 int ensure_pending(snn_network *net)
 {
     if (net->pending) return SNN_OK;
-    const size_t n = std::max<size_t>(wcount(net->n_tot, net->ld), 64);
+    const size_t n = std::max<size_t>(trace_elems(net), 64);           // dense: the layout of W; sparse: one word per stored entry
     HIP_TRY(snn_malloc(&net->pending, n * 4), SNN_ERR_BUFFER_CREATE);
     HIP_TRY(snn_malloc(&net->edge_counter, n * 4), SNN_ERR_BUFFER_CREATE);
-    HIP_TRY(snn_malloc(&net->cross_bad, 256), SNN_ERR_BUFFER_CREATE);
+    if (!net->cross_bad) HIP_TRY(snn_malloc(&net->cross_bad, 256), SNN_ERR_BUFFER_CREATE);
     HIP_TRY(hipMemsetAsync(net->pending, 0, n * 4, net->stream), SNN_ERR_BUFFER_WRITE);
     HIP_TRY(hipMemsetAsync(net->edge_counter, 0, n * 4, net->stream), SNN_ERR_BUFFER_WRITE);
     HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
@@ -785,7 +794,8 @@ int snn_set_connection_kind(snn_network_t *net, uint32_t pre_id, uint32_t post_i
     const LatticeInfo *pre = find_lattice(net, pre_id), *post = find_lattice(net, post_id);
     if (!pre || !post || post->spike_train) return fail(SNN_ERR_BAD_ARG, "connections end in neuron lattices");
     if (pre_id == post_id) return fail(SNN_ERR_BAD_ARG, "a lattice's own edges follow its own rule (snn_set_plasticity / snn_set_reward_modulator)");
-    if (net->csr || net->sharded) return fail(SNN_ERR_BAD_STATE, "connections of a reward-modulated network: dense, unsharded handles");
+    if (net->sharded && net->n_shards > 1) return fail(SNN_ERR_BAD_STATE, "connections of a reward-modulated network: unsharded handles");
+    if (net->csr && !net->csr_ptr) return fail(SNN_ERR_BAD_STATE, "set the sparse graph before tagging its connections");
     const size_t nl = net->lattices.size(), ns = net->st_lattices.size();
     if (nl > 64) return fail(SNN_ERR_BAD_STATE, "connections of a reward-modulated network: at most 64 neuron lattices");
     HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
@@ -807,7 +817,7 @@ int snn_set_connection_kind(snn_network_t *net, uint32_t pre_id, uint32_t post_i
     return SNN_OK;
 }
 
-static int traces_csr_io(snn_network_t *net, float *traces, uint64_t nnz, bool set)
+static int traces_csr_io(snn_network_t *net, float *traces, uint64_t nnz, bool set, int plane = 0)
 {
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
     if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
@@ -818,12 +828,14 @@ static int traces_csr_io(snn_network_t *net, float *traces, uint64_t nnz, bool s
     HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
     TRY(end_run(net));
     TRY(ensure_traces(net));
+    if (plane) TRY(ensure_pending(net));
+    float *array = plane == 2 ? net->edge_counter : plane == 1 ? net->pending : net->trace;
     HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
     std::vector<float> sell((size_t)net->sell_entries);
-    HIP_TRY(copy_sync(net, sell.data(), net->trace, sell.size() * 4, hipMemcpyDeviceToHost), SNN_ERR_BUFFER_READ);
+    HIP_TRY(copy_sync(net, sell.data(), array, sell.size() * 4, hipMemcpyDeviceToHost), SNN_ERR_BUFFER_READ);
     if (set) {
         for (uint64_t e = 0; e < nnz; ++e) sell[net->edge_slot_host[e]] = traces[e];
-        HIP_TRY(copy_sync(net, net->trace, sell.data(), sell.size() * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
+        HIP_TRY(copy_sync(net, array, sell.data(), sell.size() * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
     } else {
         for (uint64_t e = 0; e < nnz; ++e) traces[e] = sell[net->edge_slot_host[e]];
     }
@@ -833,6 +845,35 @@ int snn_set_traces_csr(snn_network_t *net, const float *traces, uint64_t nnz)
 { return traces_csr_io(net, const_cast<float *>(traces), nnz, true); }
 int snn_get_traces_csr(snn_network_t *net, float *traces, uint64_t nnz)
 { return traces_csr_io(net, traces, nnz, false); }
+int snn_set_pending_csr(snn_network_t *net, const float *pending, uint64_t nnz)
+{ return traces_csr_io(net, const_cast<float *>(pending), nnz, true, 1); }
+int snn_get_pending_csr(snn_network_t *net, float *pending, uint64_t nnz)
+{ return traces_csr_io(net, pending, nnz, false, 1); }
+int snn_set_counters_csr(snn_network_t *net, const uint8_t *counters, uint64_t nnz)
+{
+    if (!net || (nnz && !counters)) return fail(SNN_ERR_BAD_ARG, "null argument");
+    if (net->finalized && net->csr && nnz != net->nnz) return fail(SNN_ERR_DIM_MISMATCH, "nnz does not match the stored graph");
+    try {
+        std::vector<float> v(nnz);
+        for (uint64_t e = 0; e < nnz; ++e) v[e] = counters[e] ? 1.0f : 0.0f;
+        return traces_csr_io(net, v.data(), nnz, true, 2);
+    } catch (const std::bad_alloc &) {
+        return fail(SNN_ERR_BUFFER_CREATE, "out of host memory for the counters");
+    }
+}
+int snn_get_counters_csr(snn_network_t *net, uint8_t *counters, uint64_t nnz)
+{
+    if (!net || (nnz && !counters)) return fail(SNN_ERR_BAD_ARG, "null argument");
+    if (net->finalized && net->csr && nnz != net->nnz) return fail(SNN_ERR_DIM_MISMATCH, "nnz does not match the stored graph");
+    try {
+        std::vector<float> v(nnz, 0.0f);
+        TRY(traces_csr_io(net, v.data(), nnz, false, 2));
+        for (uint64_t e = 0; e < nnz; ++e) counters[e] = v[e] != 0.0f ? 1 : 0;
+    } catch (const std::bad_alloc &) {
+        return fail(SNN_ERR_BUFFER_CREATE, "out of host memory for the counters");
+    }
+    return SNN_OK;
+}
 
 int snn_set_history(snn_network_t *net, int voltage_history, int spike_history)
 {
@@ -1065,7 +1106,7 @@ int snn_debug_checkpoint(snn_network_t *net, int restore)
     if (net->csr_w) arrays.emplace_back(net->csr_w, (size_t)net->sell_entries * 4);
     if (net->trace) arrays.emplace_back(net->trace, std::max<size_t>(trace_elems(net), 64) * 4);
     for (void *m : {(void *)net->pending, (void *)net->edge_counter})
-        if (m) arrays.emplace_back(m, std::max<size_t>(wcount(net->n_tot, net->ld), 64) * 4);
+        if (m) arrays.emplace_back(m, std::max<size_t>(trace_elems(net), 64) * 4);
     size_t total = 0;
     for (const auto &a : arrays) total += a.second;
     if (total > ((size_t)256 << 20)) return fail(SNN_ERR_BAD_STATE, "checkpoints are for small handles (256 MiB of device state at most)");
@@ -2105,7 +2146,7 @@ int snn_input_kernel_bytes(const snn_network_t *net, uint64_t *bytes)
         // k_inputs_rstdp: the internal edges of a reward-modulated lattice are read AND rewritten, weight and trace --
         // 16 B per synapse instead of 4
         for (const auto &l : net->lattices) {
-            if (l.slot >= net->rm_on_host.size() || !net->rm_on_host[l.slot]) continue;
+            if (l.slot >= net->rm_on_host.size() || !(net->rm_on_host[l.slot] & RM_DO_MODULATION)) continue;
             const uint32_t c0 = std::max(l.first, net->q0), c1 = std::min(l.first + l.count, net->q1);
             if (c1 > c0) b += (uint64_t)12 * l.count * (c1 - c0);
         }

@@ -89,7 +89,8 @@ struct snn_network {
     uint32_t n_live = K_TYPES, live_type[K_TYPES] = {0, 1, 2};
     uint32_t live_mask_applied = 0xFFFFFFFFu;
     // reward modulation (RewardModulatedLattice): per-lattice modulator table + per-edge trace, allocated on first use
-    bool any_modulation = false;
+    bool any_modulation = false;           // some lattice has do_modulation set
+    bool any_modulated = false;            // some lattice is a reward-modulated lattice (modulating or paused): rewards reach its modulator
     std::vector<float> rm_host;            // [n_lattices][RM_STRIDE]
     std::vector<uint32_t> rm_on_host;
     float *rm_dev = nullptr;

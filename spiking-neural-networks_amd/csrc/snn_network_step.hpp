@@ -431,6 +431,15 @@ static RewardCrossArgs reward_cross_args(snn_network *net)
 int launch_reward_cross(snn_network *net)
 {
     if (!net->any_conn_kind || net->nn == 0 || !net->trace || !net->pending) return SNN_OK;
+    if (net->csr) {
+        if (!net->csr_ptr || net->n_loc == 0) return SNN_OK;
+        CsrRewardCrossArgs c{};
+        c.g = csr_graph(net);
+        c.r = reward_cross_args(net);
+        hipLaunchKernelGGL(k_reward_cross_csr, dim3((net->n_loc + 255) / 256), dim3(256), 0, net->stream, c);
+        HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+        return SNN_OK;
+    }
     const unsigned gx = (net->nn + 255) / 256;
     const unsigned gy = std::max(1u, std::min<unsigned>(net->n_tot, std::max(1u, 16384u / gx)));
     hipLaunchKernelGGL(k_reward_cross, dim3(gx, gy), dim3(256), 0, net->stream, reward_cross_args(net));
@@ -446,7 +455,16 @@ int check_reward_cross(snn_network *net)
     HIP_TRY(hipMemsetAsync(net->cross_bad, 0, 4, net->stream), SNN_ERR_BUFFER_WRITE);
     const unsigned gx = (net->nn + 255) / 256;
     const unsigned gy = std::max(1u, std::min<unsigned>(net->n_tot, std::max(1u, 16384u / gx)));
-    hipLaunchKernelGGL(k_reward_cross_check, dim3(gx, gy), dim3(256), 0, net->stream, reward_cross_args(net));
+    if (net->csr) {
+        if (net->csr_ptr && net->n_loc) {
+            CsrRewardCrossArgs c{};
+            c.g = csr_graph(net);
+            c.r = reward_cross_args(net);
+            hipLaunchKernelGGL(k_reward_cross_check_csr, dim3((net->n_loc + 255) / 256), dim3(256), 0, net->stream, c);
+        }
+    } else {
+        hipLaunchKernelGGL(k_reward_cross_check, dim3(gx, gy), dim3(256), 0, net->stream, reward_cross_args(net));
+    }
     HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
     uint32_t bad = 0;
     HIP_TRY(hipMemcpyAsync(&bad, net->cross_bad, 4, hipMemcpyDeviceToHost, net->stream), SNN_ERR_BUFFER_READ);

@@ -474,6 +474,25 @@ class DeviceNetwork:
         self._check(self._L.snn_get_traces_csr(self._h, t.ctypes.data_as(_lib.f32p), t.size))
         return t
 
+    def set_pending_csr(self, pending):
+        """TraceRSTDP::dw per stored edge of a sparse handle, in the edge order of set_graph_csr"""
+        t = np.ascontiguousarray(pending, dtype=np.float32)
+        self._check(self._L.snn_set_pending_csr(self._h, t.ctypes.data_as(_lib.f32p), t.size))
+
+    def get_pending_csr(self):
+        t = _out(getattr(self, "_nnz", 0), np.float32)
+        self._check(self._L.snn_get_pending_csr(self._h, t.ctypes.data_as(_lib.f32p), t.size))
+        return t
+
+    def set_counters_csr(self, counters):
+        t = np.ascontiguousarray(counters, dtype=np.uint8)
+        self._check(self._L.snn_set_counters_csr(self._h, t.ctypes.data_as(_lib.u8p), t.size))
+
+    def get_counters_csr(self):
+        t = _out(getattr(self, "_nnz", 0), np.uint8)
+        self._check(self._L.snn_get_counters_csr(self._h, t.ctypes.data_as(_lib.u8p), t.size))
+        return t
+
     def set_firing_times(self, id, cell_ptr, times):
         """PresetSpikeTrain firing times of spike-train lattice `id`: cell i fires through
         times[cell_ptr[i]:cell_ptr[i+1]] cyclically (spike_train/mod.rs:753-833)."""

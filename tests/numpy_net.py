@@ -405,8 +405,9 @@ class NumpyNet:
             return tuple(float(a[k][l]) for k in ("stdp_a_plus", "stdp_a_minus", "stdp_tau_plus", "stdp_tau_minus", "stdp_dt"))
 
         kinds = self.connection_kinds()                         # [n_tot, n_lattices]: connections of a reward-modulated network are not ours
+        is_mod = self.modulated()
         for j in np.nonzero(spike)[0]:
-            if not a["do_plasticity"][lat[j]]:
+            if not a["do_plasticity"][lat[j]] or is_mod[lat[j]]:          # (a RewardModulatedLattice has no STDP rule of its own)
                 continue
             rows = conn[:, j] & (kinds[:, lat[j]] == 0)         # incoming edges: the plasticity of j's lattice
             d = stdp_delta(lft_all[rows], lft_all[j], *params(lat[j]))
@@ -443,6 +444,13 @@ class NumpyNet:
             a["weights"][p, q] = w
             a["traces"][p, q] = c
 
+    def modulated(self):
+        """per lattice: held by the network's reward_modulated_lattices map -- do_modulation set, or marked so while paused
+        (rm_is_modulated; neuron/mod.rs:2744, 3419-3453)"""
+        a = self.a
+        on = a["rm_do_modulation"].astype(bool) if "rm_do_modulation" in a else np.zeros(int(a["lattice_count"].size), bool)
+        return on | a["rm_is_modulated"].astype(bool) if "rm_is_modulated" in a else on
+
     def connection_kinds(self):
         """per presynaptic row and post lattice: 0 a plain network's edge, 1 RewardModulatedConnection::RewardModulatedWeight,
         2 RewardModulatedConnection::Weight (conn_kind is indexed by the SOURCE lattice: neuron lattices, then spike-train ones)"""
@@ -465,7 +473,8 @@ class NumpyNet:
             return
         kinds = self.connection_kinds()                           # [n_tot][n_lattices]
         lat = a["lattice"].astype(np.int64)
-        mod = a["rm_do_modulation"].astype(bool)
+        mod = self.modulated()                                    # which map holds the lattice ...
+        mod_visits = mod & a["rm_do_modulation"].astype(bool)     # ... and whether its neurons are visited (:5113)
         plastic = a["do_plasticity"].astype(bool) & ~mod
         conn = a["connections"] != 0
         lft = np.concatenate([a["last_firing_time"], a["st_last_firing_time"]]).astype(np.int64)
@@ -528,8 +537,8 @@ class NumpyNet:
         y_plain = ~y_cell & plastic[lat[yn]] & spiking[yn]
         visit(x_plain, xs, ys, ~y_cell, "yx", "xy")
         visit(y_plain, yn, xs, np.ones(xs.size, bool), "xy", "yx")
-        visit(mod[lat[xs]], xs, ys, ~y_cell, "yx", "xy")
-        visit(~y_cell & mod[lat[yn]], yn, xs, np.ones(xs.size, bool), "xy", "yx")
+        visit(mod_visits[lat[xs]], xs, ys, ~y_cell, "yx", "xy")
+        visit(~y_cell & mod_visits[lat[yn]], yn, xs, np.ones(xs.size, bool), "xy", "yx")
         for name in ("weights", "traces", "pending", "edge_counter"):
             sel = ex["yx"]
             a[name][ys[sel], xs[sel]] = st[name, "yx"][sel]
@@ -574,7 +583,7 @@ class NumpyNet:
     def apply_reward(self, reward):
         """RewardModulatedSTDP::update (plasticity/mod.rs:199-201) on every modulated lattice"""
         a = self.a
-        on = a["rm_do_modulation"] != 0
+        on = self.modulated()                                     # (a paused modulator still takes the reward, :5287-5291)
         with np.errstate(all="ignore"):
             decay = expf(((-a["rm_dt"]) / a["rm_tau_d"]).astype(f32))
             new = ((a["rm_dopamine"] * decay).astype(f32) + (a["rm_tau_d"] * f32(reward)).astype(f32)).astype(f32)

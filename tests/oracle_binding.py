@@ -92,6 +92,7 @@ _FIELDS = [
     ("rx_section", C.c_uint32 * 3), ("rx_current_index", C.c_int32 * 3), ("rx_vars", f32p),
     ("rx_multi", C.c_uint32), ("rx_kin_section", C.c_uint32 * 3),
     ("conn_kind", u8p), ("pending", f32p), ("edge_counter", u8p),
+    ("rm_is_modulated", u32p),
 ]
 
 
@@ -240,7 +241,7 @@ _PER_CELL = {"st_current_voltage", "st_v_th", "st_v_resting", "st_dt", "st_k", "
              "st_bcm_period", "st_bcm_num_spikes"}
 _PER_CELL_K = {"st_nt_t", "st_nt_t_max", "st_nt_clearance", "st_nt_v_p", "st_nt_k_p", "st_nt_flags"}
 _PER_LATTICE = {"stdp_a_plus", "stdp_a_minus", "stdp_tau_plus", "stdp_tau_minus", "stdp_dt", "do_plasticity",
-                "lattice_first", "lattice_count", "rm_do_modulation", *RM_DEFAULTS, "plasticity_kind", *BCM_DEFAULTS}
+                "lattice_first", "lattice_count", "rm_do_modulation", "rm_is_modulated", *RM_DEFAULTS, "plasticity_kind", *BCM_DEFAULTS}
 
 
 class Net:

@@ -174,8 +174,19 @@ def push_connection_kinds(dn, net):
         for l, (post, _, _) in enumerate(lay.lattices):
             if kinds[s, l]:
                 dn.set_connection_kind(pre, post, int(kinds[s, l]))
+    if getattr(dn, "csr", False):
+        dn.set_pending_csr(csr_values(net, net["pending"], dn.owned))
+        dn.set_counters_csr(csr_values(net, net["edge_counter"], dn.owned))
+        return
     dn.set_pending_rows(0, net["pending"])
     dn.set_counter_rows(0, net["edge_counter"])
+
+
+def csr_values(net, dense, posts):
+    """values of a dense [n_tot][n_neurons] array in the CSR-by-post edge order of the columns `posts`"""
+    ptr, pre, _ = csr_for_posts(net, posts)
+    return (np.concatenate([dense[pre[ptr[k]:ptr[k + 1]], q] for k, q in enumerate(posts)]) if len(posts)
+            else np.zeros(0, dense.dtype))
 
 
 def _neuron_names(net):

@@ -14,7 +14,9 @@ ALLOWED = {(MOD, MOD): (0, 1, 1, 2), (MOD, PLASTIC): (0, 1, 1), (MOD, FIXED): (0
 FROM_CELLS = {MOD: (0, 1, 1, 2), PLASTIC: (0, 2), FIXED: (0, 1, 2)}
 
 
-def draw(seed, violation=0):
+def draw(seed, violation=0, paused=False):
+    """paused: one of the reward-modulated lattices has do_modulation switched off -- it stays a reward-modulated lattice for its
+    partners' visits (which map of the reference's network holds it), takes every reward, but is never visited itself"""
     rng = np.random.default_rng(4000 + seed)
     n_lat = int(rng.integers(2, 5))
     lattices = [(2 * i + int(rng.integers(0, 2)), int(rng.integers(1, 6)), int(rng.integers(1, 7))) for i in range(n_lat)]
@@ -92,6 +94,10 @@ def draw(seed, violation=0):
     dt = float(rng.choice([0.05, 0.1, 0.2]))
     for k in ("dt", "st_dt", "stdp_dt", "rm_dt"):
         net[k] = dt
+    if paused:
+        slot = int(np.flatnonzero(role == MOD)[seed % int((role == MOD).sum())])
+        net["rm_do_modulation"][slot] = 0
+        net["rm_is_modulated"][slot] = 1
     steps = int(rng.integers(60, 200))
     rewards = ob.uniform_array(seed + 11, steps, -0.02, 0.03)
     rewards[::3] = 0.0

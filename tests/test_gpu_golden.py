@@ -52,3 +52,32 @@ def test_hip_matches_golden(snn, name):
         else:
             assert st[k].tobytes() == want[k].tobytes(), k
     dn.close()
+
+
+def test_sparse_handle_matches_the_golden_reward_network(snn):
+    """the committed vectors of `reward_modulated_network` (connections of kind 1 / 2 between lattices, written by the numpy twin)
+    against a SPARSE handle: k_reward_cross_csr, trace / dw / counter per stored edge"""
+    name = "reward_modulated_network"
+    net, steps = golden_cases.CASES[name]()
+    want = np.load(os.path.join(GOLDEN, name + ".npz"))
+    dn = parity.device_from_oracle(snn, net, csr=True)
+    for slot, (i, _, _) in enumerate(net.layout.lattices):
+        if net["rm_do_modulation"][slot]:
+            dn.set_reward_modulator(i, *(float(net[k][slot]) for k in (
+                "rm_dopamine", "rm_tau_d", "rm_tau_c", "rm_a_plus", "rm_a_minus", "rm_tau_plus", "rm_tau_minus", "rm_dt")))
+    dn.set_traces_csr(parity.csr_values(net, net["traces"], dn.owned))
+    parity.push_connection_kinds(dn, net)
+    dn.set_history(voltage=True, spikes=True)
+    dn.run(steps)
+    ids = [i for i, _, _ in net.layout.lattices]
+    raster = np.concatenate([dn.spike_history(i) for i in ids], axis=1)
+    assert np.packbits(raster, axis=1).tobytes() == want["raster"].tobytes()
+    st = parity.pull_state(dn, net)
+    assert st["current_voltage"].tobytes() == want["final_voltage"].tobytes()
+    assert st["last_firing_time"].tobytes() == want["last_firing_time"].tobytes()
+    posts = dn.owned
+    assert dn.get_graph_csr().tobytes() == parity.csr_values(net, want["weights"], posts).astype(np.float32).tobytes()
+    assert dn.get_traces_csr().tobytes() == parity.csr_values(net, want["traces"], posts).tobytes()
+    assert dn.get_pending_csr().tobytes() == parity.csr_values(net, want["pending"], posts).tobytes()
+    assert dn.get_counters_csr().tobytes() == parity.csr_values(net, want["edge_counter"], posts).tobytes()
+    dn.close()
