@@ -461,7 +461,7 @@ __global__ __launch_bounds__(256) void k_stdp_columns(const StdpArgs a)
 // synapse: bit-identical to k_stdp_columns.
 typedef float stdp_v4f __attribute__((ext_vector_type(4)));
 constexpr uint32_t STDP_QUADS_IN_FLIGHT = 4;
-__global__ __launch_bounds__(256) void k_stdp_columns_quads(const StdpArgs a)
+__global__ __launch_bounds__(256, 6) void k_stdp_columns_quads(const StdpArgs a)
 {
     const uint32_t count = *a.spike_count;
     const uint32_t groups = (a.n_tot + 3u) >> 2;
@@ -484,12 +484,13 @@ __global__ __launch_bounds__(256) void k_stdp_columns_quads(const StdpArgs a)
 #pragma unroll
             for (uint32_t u = 0; u < STDP_QUADS_IN_FLIGHT; ++u)
                 if (g + u < g1) w[u] = col[(size_t)(g + u) * a.ld];
-#pragma unroll
+            // (the arithmetic is not unrolled: sixteen inlined exponentials kept 197 registers alive -- two wavefronts per SIMD)
+#pragma unroll 1
             for (uint32_t u = 0; u < STDP_QUADS_IN_FLIGHT; ++u) {
                 if (g + u >= g1) break;
                 const stdp_v4f w0 = w[u];
                 bool changed = false;
-#pragma unroll
+#pragma unroll 1
                 for (int k = 0; k < 4; ++k) {
                     const uint32_t p = (g + u) * 4u + (uint32_t)k;                  // wave-uniform
                     if (p >= a.n_tot) break;
@@ -526,6 +527,64 @@ __global__ __launch_bounds__(256) void k_stdp_rows(const StdpArgs a)
         const float w = stdp_load(wp, stream);
         if (w == w && plain_connection(a, j, a.lattice_slot[gr]))
             stdp_store(wp, plasticity_weight(prm, w, a.last_firing_time[j], tr, bcm ? a.act[j] : 0.0f, post_act, post_avg), stream);
+    }
+}
+
+// Small dense networks (<= 1024 rows, the sizes of the one-launch step): compaction, column scatter and row scatter in ONE launch
+// instead of four (counter fill 3.8 + k_spike_compact 3.6 + k_stdp_columns 2.6 + k_stdp_rows 2.4 us at 32 x 32, against 9.1 us for
+// the neuron step itself: profiles/r04/small_stdp_kernel_stats.csv).  Every workgroup compacts the spike flags by itself (<= 1024
+// loads, ballot + LDS prefix: the list comes out in ascending neuron order) and takes the listed neurons blockIdx.x, + gridDim.x,
+// ...: thread p updates the incoming edge p -> j, thread r the outgoing edge j -> r.  STDP only (the host keeps BCM lattices on the
+// separate kernels): a weight both of whose ends spiked in the step gets stdp_delta(t, t) = 0 from its column visit and from its
+// row visit, possibly by two workgroups at once -- both store the same bits (w + 0.0f), whichever order they run in; every other
+// weight is touched by one visit only.  Workgroup 0 also leaves the list and its length where the separate kernels would.
+__global__ __launch_bounds__(1024) void k_stdp_small(const StdpArgs a)
+{
+    __shared__ uint32_t s_list[1024];
+    __shared__ uint32_t s_wave[16];
+    const uint32_t q = threadIdx.x, lane = q & 63u, wave = q >> 6;
+    bool hit = false;
+    if (q < a.n_neurons) {
+        const uint32_t spk = reinterpret_cast<const uint32_t *>(a.xbuf)[a.xl.at(q, PLANE_SPIKE)];
+        hit = spk && a.do_plasticity[a.lattice_slot[q]];
+    }
+    const unsigned long long mask = __ballot(hit);
+    if (lane == 0) s_wave[wave] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    uint32_t base = 0, count = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < 16; ++w) {
+        base += w < wave ? s_wave[w] : 0u;
+        count += s_wave[w];
+    }
+    if (hit) s_list[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = q;
+    __syncthreads();
+    if (blockIdx.x == 0) {
+        if (q < count) a.spike_list[q] = s_list[q];
+        if (q == 0) *a.spike_count = count;
+    }
+    const uint32_t p = q;                                      // the thread's presynaptic row ...
+    const uint32_t r = q;                                      // ... and its local postsynaptic column
+    const int32_t tp = p < a.n_tot ? ((p < a.n_neurons) ? a.last_firing_time[p] : a.st_last_firing_time[p - a.n_neurons]) : -1;
+    const uint32_t gr = a.q0 + r;
+    const int32_t tr = r < a.n_loc ? a.last_firing_time[gr] : -1;
+    const float *prm_r = a.stdp + PL_STRIDE * (r < a.n_loc ? a.lattice_slot[gr] : 0u);
+    for (uint32_t s = blockIdx.x; s < count; s += gridDim.x) {
+        const uint32_t j = s_list[s];
+        const int32_t tj = a.last_firing_time[j];
+        if (p < a.n_tot && j >= a.q0 && j < a.q0 + a.n_loc) {                    // incoming edge p -> j (k_stdp_columns)
+            float *wp = a.W + widx(p, j - a.q0, a.ld);
+            const float w = *wp;
+            if (w == w && plain_connection(a, p, a.lattice_slot[j])) {
+                const float *prm = a.stdp + PL_STRIDE * a.lattice_slot[j];
+                *wp = plasticity_weight(prm, w, tp, tj, 0.0f, 0.0f, 0.0f);
+            }
+        }
+        if (r < a.n_loc) {                                                       // outgoing edge j -> r (k_stdp_rows)
+            float *wp = a.W + widx(j, r, a.ld);
+            const float w = *wp;
+            if (w == w && plain_connection(a, j, a.lattice_slot[gr])) *wp = plasticity_weight(prm_r, w, tj, tr, 0.0f, 0.0f, 0.0f);
+        }
     }
 }
 

@@ -53,6 +53,7 @@ int snn_network_create(int device, int neuron_model, int nt_kinetics, int recept
     if (const char *e = getenv("SNN_AMD_PERSISTENT_STDP")) net->persistent_stdp = (e[0] != '0');
     if (const char *e = getenv("SNN_AMD_HALO_PEER")) net->halo_peer = (e[0] != '0');
     if (const char *e = getenv("SNN_AMD_STDP_COLUMNS_FORM")) net->stdp_columns_form = (e[0] == '1') ? 1 : 0;
+    if (const char *e = getenv("SNN_AMD_STDP_SMALL")) net->stdp_small = (e[0] != '0');
     if (const char *e = getenv("SNN_AMD_VERIFY")) net->verify = (e[0] != '0');
     if (const char *e = getenv("SNN_AMD_INPUT_SHAPE")) net->force_shape = (e[0] == '1') ? 1 : ((e[0] == '2') ? 2 : 0);
     net->model = neuron_model; net->nt_kind = nt_kinetics; net->rc_kind = receptor_kinetics;
@@ -2033,6 +2034,7 @@ int snn_set_option(snn_network_t *net, const char *name, int value)
     else if (n == "run_timing") net->run_timing_opt = value != 0;
     else if (n == "input_shape") net->force_shape = (value == 1 || value == 2) ? value : 0;
     else if (n == "stdp_columns_form") net->stdp_columns_form = value == 1 ? 1 : 0;
+    else if (n == "stdp_small") net->stdp_small = value != 0;
     else if (n == "verify") net->verify = value != 0;
     else if (n == "verify_fault") net->verify_fault = value > 0 ? (uint32_t)value : 0u;
     else if (n == "run_resident_chunk_steps") net->run_chunk_steps = value >= 4 ? (uint32_t)std::min<long long>(value, 1 << 20) : (1u << 20);

@@ -307,6 +307,7 @@ struct snn_network {
     // t + 1; 2: prepared delta vectors, applied right away by scatter passes (SNN_AMD_DEFER_STDP / "defer_stdp").
     // Measured on the quad-row matrix: the scatter kernels win at every spike rate.
     int defer_stdp = 0;
+    int stdp_small = 1;                   // option "stdp_small": networks of <= 1024 rows take compaction + both scatters in ONE launch (k_stdp_small)
     int stdp_columns_form = 0;            // option "stdp_columns_form": 0 one thread per presynaptic row, 1 one lane per 16-byte unit (k_stdp_columns_quads)
     bool stdp_pending = false;
     bool stdp_pending_rows_only = false;   // ... and it is the ROW half only ("defer_stdp" 3)

@@ -330,9 +330,23 @@ int launch_plasticity(snn_network *net)
     return SNN_OK;
 }
 
+// small dense unsharded networks under STDP (no BCM lattice among the plastic ones): compaction and both scatters in one launch
+bool stdp_small_applies(const snn_network *net)
+{
+    if (!net->stdp_small || net->csr || net->sharded || net->n_tot > 1024u || net->n_loc != net->nn || net->nn == 0) return false;
+    for (size_t l = 0; l < net->lattices.size(); ++l)
+        if (net->plast_host[l] && net->stdp_host[l * PL_STRIDE + 5] != 0.0f) return false;
+    return true;
+}
+
 int launch_plasticity_kernels(snn_network *net)
 {
     StdpArgs a = stdp_args(net);
+    if (stdp_small_applies(net)) {
+        hipLaunchKernelGGL(k_stdp_small, dim3(16), dim3(1024), 0, net->stream, a);
+        HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+        return SNN_OK;
+    }
     const bool defer = stdp_deferral_applies(net);
     if (defer) a.flag = net->stdp_flag;
     HIP_TRY(hipMemsetAsync(net->spike_count, 0, 4, net->stream), SNN_ERR_BUFFER_WRITE);
@@ -374,7 +388,7 @@ int launch_plasticity_kernels(snn_network *net)
     if (net->stdp_columns_form == 1) {
         // quad form: 256 listed columns per workgroup (64 per wavefront) x slabs of row groups
         const uint32_t groups = (net->n_tot + 3u) / 4u;
-        const unsigned slabs = std::max(1u, std::min(256u, groups / 16u));
+        const unsigned slabs = std::max(1u, std::min(1024u, groups / 16u));
         hipLaunchKernelGGL(k_stdp_columns_quads, dim3(4, slabs), dim3(256), 0, net->stream, a);
     } else {
         hipLaunchKernelGGL(k_stdp_columns, dim3((net->n_tot + 255) / 256, sy), dim3(256), 0, net->stream, a);

@@ -113,7 +113,7 @@ def draw(seed):
 
 
 SWITCHES = {"fused_step": (0, 1), "defer_stdp": (0, 1, 2, 3), "defer_rstdp": (0, 1), "uniform_params": (0, 1), "persistent_run": (0, 1), "persistent_chem": (0, 1),
-            "cells_in_step": (0, 1), "csr_xcd_bands": (0, 1), "update_packs": (0, 1), "input_shape": (0, 1, 2), "stdp_columns_form": (0, 1)}
+            "cells_in_step": (0, 1), "csr_xcd_bands": (0, 1), "update_packs": (0, 1), "input_shape": (0, 1, 2), "stdp_columns_form": (0, 1), "stdp_small": (0, 1)}
 
 
 def tuning_switches(seed):
