@@ -24,11 +24,11 @@ MIN_TIMED_S, MAX_REPEATS = 1.0, 4000    # the timed repetitions add up to at lea
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling is ~6.3 TB/s
 # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of THIS command (FETCH_SIZE and
 # WRITE_SIZE cannot share a pass); their summaries are committed under profiles/ and quoted here per launch.
-PMC_TRAFFIC = {"c2": os.path.join(ROOT, "profiles", "r04", "c2_pmc_traffic.json"),
-               "c3": os.path.join(ROOT, "profiles", "r04", "c3_pmc_traffic.json"),
-               "c4": os.path.join(ROOT, "profiles", "r04", "c4_pmc_traffic.json"),
-               "c5": os.path.join(ROOT, "profiles", "r04", "c5_pmc_traffic.json"),
-               "c6": os.path.join(ROOT, "profiles", "r04", "c6_pmc_traffic.json")}
+PMC_TRAFFIC = {"c2": os.path.join(ROOT, "profiles", "r05", "c2_pmc_traffic.json"),
+               "c3": os.path.join(ROOT, "profiles", "r05", "c3_pmc_traffic.json"),
+               "c4": os.path.join(ROOT, "profiles", "r05", "c4_pmc_traffic.json"),
+               "c5": os.path.join(ROOT, "profiles", "r05", "c5_pmc_traffic.json"),
+               "c6": os.path.join(ROOT, "profiles", "r05", "c6_pmc_traffic.json")}
 
 
 def pmc_traffic(config, world, rows, cols):
@@ -581,6 +581,9 @@ def main():
         if not sharded and dn.stat("persistent_run_launches"):
             # all steps of a run call in ONE launch (small electrical-only lattices): `launches` counts its steps
             kernel_name = "k_run_resident<0,true> (many steps per launch; launches = steps)"
+        elif not sharded and dn.stat("steps_dense_close"):
+            # streamed dense matrices: the last workgroup of a column tile also updates the tile's neurons (one launch per step)
+            kernel_name = kernel_name.replace("k_inputs_dense<", "k_inputs_dense_close<model,")
         bytes_per_launch = dn.input_kernel_bytes()
         avg_ms = kern_ms / max(1, launches)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if launches and avg_ms > 0 else 0.0

@@ -500,7 +500,8 @@ int snn_get_spike_counts(snn_network_t *net, uint32_t id, uint32_t *dst, size_t 
 
 /* Tuning switches (results never depend on them; defaults in brackets, also settable through the environment when the
  * handle is created: SNN_AMD_<NAME in upper case>): "fused_step" [1] one-launch step for small lattices and for
- * sparse handles; "cells_in_step" [1] sparse electrical-only handles without weight updates: the spike-train cells advance
+ * sparse handles; "dense_close" [1] streamed dense matrices on unsharded handles with gap junctions: the last workgroup of a column
+ * tile of the input pass updates the tile's neurons in the same launch (k_inputs_dense_close; 0: input pass + k_update); "cells_in_step" [1] sparse electrical-only handles without weight updates: the spike-train cells advance
  * inside the step's launch; "update_packs" [1] dense shard handles: the neuron update writes the handle's own slot of
  * the all-gather buffer itself (no pack launch); "update_all_planes" [1] dense handles with chemical synapses: the neuron update
  * requests the chunk partials of all planes together; "csr_xcd_bands" [1] the sparse step hands its row blocks to the XCDs in contiguous bands;
@@ -543,7 +544,8 @@ int snn_set_option(snn_network_t *net, const char *name, int value);
  * one-launch run reads its outcome after a host synchronisation); "halo_direct_steps"
  * (steps of library-driven runs whose rows gathered the halo from the received segments); the form every step outside a
  * one-launch run took: "steps_dense_one_launch" (k_step_resident), "steps_sparse_one_launch" (k_step_csr over all rows),
- * "steps_sparse_split" (border + interior launches of a shard handle), "steps_two_kernel" (input pass + k_update); and
+ * "steps_sparse_split" (border + interior launches of a shard handle), "steps_dense_close" (k_inputs_dense_close),
+ * "steps_two_kernel" (input pass + k_update); and
  * what happened between run calls: "shadow_refreshes" (the two shadow copies of the exchanged state were rebuilt),
  * "view_refreshes" (the spike-train cells' gap-junction values were recomputed), "history_regrows" (the history buffers
  * were reallocated).  Unknown names fail with SNN_ERR_BAD_ARG. */
@@ -551,9 +553,10 @@ int snn_get_stat(snn_network_t *net, const char *name, uint64_t *value);
 
 /* ---- test support ------------------------------------------------------------------------ */
 
-/* Option "verify" [0] (SNN_AMD_VERIFY=1): every snn_run call on a handle without weight updates takes its steps TWICE from the
- * same device snapshot and compares the two outcomes word for word on the device -- a stepper that is not deterministic shows
- * without any oracle.  Statistics "verify_runs", "verify_mismatches", "verify_skipped" (the first one-launch run of a handle
+/* Option "verify" [0] (SNN_AMD_VERIFY=1): every snn_run call on an unsharded handle takes its steps TWICE from the same device
+ * snapshot and compares the two outcomes word for word on the device -- a stepper that is not deterministic shows without any
+ * oracle.  Handles with weight updates (STDP, BCM, reward modulation) are covered while their matrices -- weights, traces, dw,
+ * counters -- fit a 64 MiB side copy; weight updates a previous call left deferred are applied first.  Statistics "verify_runs", "verify_mismatches", "verify_skipped" (the first one-launch run of a handle
  * lays its snapshot out anew); snn_debug_verify_report names the array, word and the two values of the last mismatch (also
  * printed to stderr).  Option "run_resident_chunk_steps" [2^20]: steps per launch of the one-launch run (a run call of more steps
  * takes several launches, each with its own rollback point); "stdp_columns_form" [0] 1: the incoming-edge scatter of STDP with

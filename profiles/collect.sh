@@ -3,7 +3,7 @@
 # into profiles/rNN/; `only` = a substring of the names to (re)collect, e.g. c5).  Per config: rocprofv3 --kernel-trace --stats of bench.py (kernel stats csv + the bench line of
 # that profiled process), then two separate --pmc passes (FETCH_SIZE, WRITE_SIZE) reduced by summarize_pmc.py.
 set -u
-R=${1:-r04}
+R=${1:-r05}
 ONLY=${2:-}
 want() { [ -z "$ONLY" ] || [[ "$1" == *"$ONLY"* ]]; }
 OUT=$PWD/gpurun_out/$R
@@ -70,5 +70,10 @@ python3 profiles/measure_small_stdp.py 3000 2> /dev/null | grep lattice > "$OUT/
 python3 bench.py > "$OUT/bench_default.json" 2> /dev/null
 python3 bench.py --config c1 --no-cpu-baseline > "$OUT/c1_bench_default.json" 2> /dev/null
 python3 bench.py --config c3 --no-cpu-baseline > "$OUT/c3_bench_default.json" 2> /dev/null
+# round 5: C3 in four fresh processes, with and without the closing input pass; C4 with 1 % of the neurons spiking; small plastic lattices
+for i in 1 2 3 4; do python3 bench.py --config c3 --no-cpu-baseline > "$OUT/c3_fresh_process_$i.json" 2> /dev/null; done
+for i in 1 2; do SNN_AMD_DENSE_CLOSE=0 python3 bench.py --config c3 --no-cpu-baseline > "$OUT/c3_two_kernels_process_$i.json" 2> /dev/null; done
+python3 bench.py --config c4 --spike-fraction 0.01 --steps 50 --warmup 100 --repeats 2 --no-cpu-baseline > "$OUT/c4_spiking_1pct_bench.json" 2> /dev/null
+python3 profiles/measure_small_plastic.py 3000 > "$OUT/small_plastic_lattices.jsonl" 2> /dev/null
 fi
 ls "$OUT"

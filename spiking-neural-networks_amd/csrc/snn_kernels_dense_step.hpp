@@ -1,0 +1,63 @@
+// k_inputs_dense_close -- the streamed dense step in ONE launch (round 5).
+//
+// The two-kernel step of a streamed matrix is k_inputs_dense (chunk partials of every column) + k_update (second level of
+// the canonical sum, the neuron's step).  At BASELINE configs[2] (128 x 128 Hodgkin-Huxley + AMPA, a 1 GiB matrix) the pass
+// takes 161 us, the update 9.8 us and the two kernel boundaries another 7 -- a tenth of the step spent outside the kernel
+// that is bound by HBM.  Here the workgroups of a column tile count themselves off as they finish (one agent-scope atomic
+// per workgroup); the LAST one of a tile finds every chunk partial of its columns in memory and runs the update of those
+// columns itself, with the code of k_update, while the other tiles still stream.  The pass reads S(t) from a shadow of the
+// exchange buffer and the update writes S(t+1) to the buffer and to the other shadow (as k_step_resident does): a tile that
+// closes early must not disturb the presynaptic values the other tiles still stage.
+//
+// Order of the sums: unchanged -- partials per chunk in memory, combined in ascending chunk order by ONE thread per column
+// (GlobalSums).  Bit-identical to the two-kernel step (tests/test_gpu_dense_close.py).
+#pragma once
+#include "snn_kernels_inputs.hpp"
+#include "snn_kernels_update.hpp"
+
+namespace snn {
+
+struct DenseStepArgs {
+    InputsArgs in;              // in.xbuf = the shadow holding S(t)
+    UpdateArgs up;              // up.n.xbuf = the same shadow; up.xout = exchange buffer; up.xout2 = other shadow
+    uint32_t *tile_done;        // [column tiles] workgroups of the tile that have stored their partials; 0 between launches
+};
+
+template <int MODEL, bool ELEC, bool CHEM, int STREAM, int NT>
+__global__ __launch_bounds__(InputsShape<STREAM>::THREADS) void k_inputs_dense_close(const DenseStepArgs a)
+{
+    using S = InputsShape<STREAM>;
+    __shared__ uint32_t s_last;
+    inputs_dense_pass<ELEC, CHEM, STREAM, NT, 0>(a.in);
+
+    // the partials of this workgroup are in memory before it is counted (release), the counting workgroup's view of the
+    // other workgroups' partials is fresh (acquire): agent scope -- the workgroups of a tile sit on different XCDs
+    __threadfence();
+    __syncthreads();
+    const uint32_t tile = (blockIdx.x + blockIdx.y) % gridDim.x;          // as inputs_dense_pass maps it
+    if (threadIdx.x == 0) {
+        const uint32_t before = __hip_atomic_fetch_add(a.tile_done + tile, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        const bool last = before + 1u == gridDim.y;
+        if (last) __hip_atomic_store(a.tile_done + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        s_last = last ? 1u : 0u;
+    }
+    __syncthreads();
+    if (s_last == 0u) return;
+    __threadfence();
+
+    // ---- the tile's columns: second level of the canonical sum + the neuron's step (k_update's code) ----
+    const UpdateArgs &u = a.up;
+#pragma unroll 1
+    for (int j = 0; j < S::VEC; ++j) {
+        const uint32_t ql = tile * S::TILE + (uint32_t)j * S::THREADS + threadIdx.x;
+        if (tile * S::TILE + (uint32_t)j * S::THREADS >= u.ld) break;     // (workgroup-uniform: the raster's ballot below is whole)
+        uint32_t spike = 0u;
+        if (ql < u.n_loc) spike = update_neuron_at<MODEL>(u, ql, GlobalSums{u, ql}, u.clock, u.vhist_row);
+        if (u.spike_row) {
+            const unsigned long long word = __ballot(spike != 0);
+            if ((threadIdx.x & 63u) == 0u && ql < u.ld && u.q0 + ql < u.n.n_pad) u.spike_row[(u.q0 + ql) >> 6] = word;
+        }
+    }
+}
+
+} // namespace snn

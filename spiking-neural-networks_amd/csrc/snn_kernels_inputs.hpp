@@ -128,8 +128,10 @@ __device__ __forceinline__ float acc_if_edge(float acc, float term, float w)
 // lane of the wavefront, 1 KiB contiguous per store instruction.
 // (second launch bound of the row-half variant: the plain electrical pass runs three wavefronts per SIMD -- 138 registers -- and
 // the variant must keep that occupancy: unbounded it took 174 and the pass 5.16 instead of 4.11 ms at C4)
+// (the pass as a function: k_inputs_dense below, and k_inputs_dense_close -- snn_kernels_dense_step.hpp -- whose last workgroup of
+// a column tile goes on to update the tile's neurons)
 template <bool ELEC, bool CHEM, int STREAM = 1, int NT = K_TYPES, int STDP = 0>
-__global__ __launch_bounds__(InputsShape<STREAM>::THREADS, (STDP == 2 && STREAM == 1 && !CHEM) ? 3 : 1) void k_inputs_dense(const InputsArgs a)
+__device__ __forceinline__ void inputs_dense_pass(const InputsArgs &a)
 {
     using S = InputsShape<STREAM>;
     constexpr int VEC = S::VEC;
@@ -515,6 +517,12 @@ __global__ __launch_bounds__(InputsShape<STREAM>::THREADS, (STDP == 2 && STREAM 
                 if (colv[j]) dst[(uint32_t)j * S::THREADS] = tacc[k][j];
         }
     }
+}
+
+template <bool ELEC, bool CHEM, int STREAM = 1, int NT = K_TYPES, int STDP = 0>
+__global__ __launch_bounds__(InputsShape<STREAM>::THREADS, (STDP == 2 && STREAM == 1 && !CHEM) ? 3 : 1) void k_inputs_dense(const InputsArgs a)
+{
+    inputs_dense_pass<ELEC, CHEM, STREAM, NT, STDP>(a);
 }
 
 // Static per-column counts, recomputed when the graph or the neurotransmitter flags change:

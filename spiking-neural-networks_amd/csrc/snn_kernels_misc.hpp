@@ -61,6 +61,18 @@ __global__ __launch_bounds__(256) void k_compare_table_alt(const CopyEntry *tabl
         }
     }
 }
+// the same comparison of two plain arrays (the matrices of a run with weight updates); `entry` names the array in the report
+__global__ __launch_bounds__(256) void k_compare_words(const uint32_t *was, const uint32_t *now, size_t words, uint32_t entry, uint32_t *report)
+{
+    for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < words; i += (size_t)gridDim.x * 256u) {
+        const uint32_t x = was[i], y = now[i];
+        const bool both_nan = (x & 0x7FFFFFFFu) > 0x7F800000u && (y & 0x7FFFFFFFu) > 0x7F800000u;
+        if (x == y || both_nan) continue;
+        if (atomicAdd(&report[0], 1u) == 0u) {
+            report[1] = entry; report[2] = (uint32_t)i; report[3] = x; report[4] = y;
+        }
+    }
+}
 // test hook of "verify": one bit of one word flipped between the two passes' outcome and the comparison
 __global__ void k_flip_bit(uint32_t *p, size_t word) { p[word] ^= 1u; }
 __global__ void k_iota_u32(uint32_t *p, size_t n, uint32_t first)

@@ -40,6 +40,7 @@ int snn_network_create(int device, int neuron_model, int nt_kinetics, int recept
     snn_network *net = new snn_network();
     net->device = device;
     if (const char *e = getenv("SNN_AMD_FUSED_STEP")) net->fused_step = (e[0] != '0');
+    if (const char *e = getenv("SNN_AMD_DENSE_CLOSE")) net->dense_close = (e[0] != '0');
     if (const char *e = getenv("SNN_AMD_CSR_XCD_BANDS")) net->csr_xcd_bands = (e[0] != '0');
     if (const char *e = getenv("SNN_AMD_HALO_DIRECT")) net->halo_direct = (e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1;
     if (const char *e = getenv("SNN_AMD_UPDATE_PACKS")) net->update_packs = (e[0] != '0');
@@ -89,6 +90,7 @@ int snn_network_destroy(snn_network_t *net)
     if (net->run_failed) (void)hipHostFree(net->run_failed);
     if (net->st_clock_pinned) (void)hipHostFree(net->st_clock_pinned);
     if (net->verify_report) (void)hipFree(net->verify_report);
+    if (net->verify_big) (void)hipFree(net->verify_big);
     for (float *b : net->whist) if (b) (void)hipFree(b);
     if (net->summ_avg) (void)hipFree(net->summ_avg);
     if (net->summ_eeg) (void)hipFree(net->summ_eeg);
@@ -1219,12 +1221,28 @@ int run_steps(snn_network *net, uint64_t iterations)
     return SNN_OK;
 }
 
-// "verify": what may be stepped twice from one snapshot -- no weight updates (the matrices are not in the snapshot), nothing
-// measured, the handle's own stream
+// "verify": the matrices a run with weight updates rewrites (the snapshot table holds the small arrays only): synapse matrix or
+// sparse weights, traces, dw, counters, the weights a one-launch run with STDP leaves behind
+std::vector<std::pair<void *, size_t>> verify_matrices(const snn_network *net)
+{
+    std::vector<std::pair<void *, size_t>> m;
+    if (!net->any_plasticity && !net->any_modulation && !net->any_conn_kind) return m;
+    if (net->csr) { if (net->csr_w) m.emplace_back(net->csr_w, (size_t)net->sell_entries * 4); }
+    else if (net->W) m.emplace_back(net->W, wcount(net->n_tot, net->ld) * 4);
+    const size_t edges = std::max<size_t>(net->csr ? (size_t)net->sell_entries : wcount(net->n_tot, net->ld), 64) * 4;
+    for (void *a : {(void *)net->trace, (void *)net->pending, (void *)net->edge_counter})
+        if (a) m.emplace_back(a, edges);
+    return m;
+}
+
+// "verify": what may be stepped twice from one snapshot -- nothing measured, the handle's own stream, unsharded; with weight updates
+// only while the matrices fit a side buffer (64 MiB: the networks of the randomized tests)
 bool verify_applies(const snn_network *net)
 {
-    return net->verify && !net->any_plasticity && !net->any_modulation && !net->any_conn_kind && !net->profile &&
-           !net->external_stream && !net->sharded && net->nn;
+    if (!net->verify || net->profile || net->external_stream || net->sharded || !net->nn) return false;
+    size_t bytes = 0;
+    for (const auto &m : verify_matrices(net)) bytes += m.second;
+    return bytes <= ((size_t)64 << 20);
 }
 
 // name of the array a snapshot entry covers, for the report of a "verify" mismatch
@@ -1242,7 +1260,9 @@ std::string describe_array(const snn_network *net, const void *ptr, uint32_t wor
         {net->part_i, "part_i"}, {net->part_t, "part_t"}, {net->n_in, "n_in"}, {net->tcount, "tcount"}, {net->W, "W"},
         {net->spike_counts, "spike_counts"}, {net->spike_count, "spike_count"}, {net->st_clock_dev, "st_clock_dev"},
         {net->uni_neuron, "uniform table (neurons)"}, {net->uni_cell, "uniform table (cells)"}, {net->ca.presyn_value, "cells: presyn_value"},
-        {net->ca.seed, "cells: seed"}, {net->ca.step, "cells: step"}, {net->ca.counter, "cells: counter"}, {net->lattice_slot, "lattice_slot"}};
+        {net->ca.seed, "cells: seed"}, {net->ca.step, "cells: step"}, {net->ca.counter, "cells: counter"}, {net->lattice_slot, "lattice_slot"},
+        {net->csr_w, "sparse weights"}, {net->trace, "traces"}, {net->pending, "dw of reward-modulated connections"},
+        {net->edge_counter, "counters of reward-modulated connections"}};
     for (const auto &k : known)
         if (k.base == ptr) return std::string(k.name) + ", word " + std::to_string(word);
     for (const auto *table : {&net->neuron_attrs, &net->cell_attrs})
@@ -1276,6 +1296,9 @@ int snn_run(snn_network_t *net, uint64_t iterations)
         return end_run(net, /*keep_stdp=*/true);
     }
     // ---- "verify": the same steps twice from the same snapshot, the outcomes compared on the device -------------------
+    // (weight updates a previous call deferred are applied first: the delta vectors they read are rewritten by the steps below)
+    TRY(flush_rstdp(net));
+    TRY(flush_stdp(net));
     TRY(run_snapshot(net, /*restore=*/false));                    // (builds the table; its own copy of S(t) is not used here)
     if (!net->verify_buf || net->verify_words < net->snap_words) {
         if (net->verify_buf) {
@@ -1301,30 +1324,73 @@ int snn_run(snn_network_t *net, uint64_t iterations)
     const RunCursors c0 = run_cursors(net);
     const int shadow_cur = net->shadow_cur, view_cur = net->cell_view_cur;
     const bool shadow_valid = net->shadow_valid;
+    // the matrices (runs with weight updates): [start state | first outcome], one after the other in a side buffer
+    const auto matrices = verify_matrices(net);
+    size_t big = 0;
+    for (const auto &m : matrices) big += m.second;
+    if (big > net->verify_big_bytes) {
+        if (net->verify_big) (void)hipFree(net->verify_big);
+        net->verify_big = nullptr; net->verify_big_bytes = 0;
+        HIP_TRY(snn_malloc(&net->verify_big, 2 * big), SNN_ERR_BUFFER_CREATE);
+        net->verify_big_bytes = big;
+    }
+    auto matrices_copy = [&](int half, bool restore) -> int {
+        size_t off = (size_t)half * net->verify_big_bytes;
+        for (const auto &m : matrices) {
+            void *side = net->verify_big + off;
+            HIP_TRY(hipMemcpyAsync(restore ? m.first : side, restore ? side : m.first, m.second, hipMemcpyDeviceToDevice, net->stream), SNN_ERR_BUFFER_WRITE);
+            off += m.second;
+        }
+        return SNN_OK;
+    };
     hipLaunchKernelGGL(k_copy_table_alt, grid, dim3(256), 0, net->stream, table, base, start, 0);
     HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+    TRY(matrices_copy(0, false));
     TRY(run_steps(net, iterations));
     if (net->snap_generation != generation) {
         // the run allocated and laid the table out anew (first one-launch run of a handle): nothing to compare with this time
         net->stat_verify_skipped += 1;
         return end_run(net, /*keep_stdp=*/true);
     }
+    // (a deferred weight update still pending at the end of the first pass belongs to its outcome: applied before the copy)
+    TRY(flush_rstdp(net));
+    TRY(flush_stdp(net));
     hipLaunchKernelGGL(k_copy_table_alt, grid, dim3(256), 0, net->stream, table, base, first, 0);
     hipLaunchKernelGGL(k_copy_table_alt, grid, dim3(256), 0, net->stream, table, base, start, 1);
     HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+    TRY(matrices_copy(1, false));
+    TRY(matrices_copy(0, true));
     restore_cursors(net, c0);
     net->shadow_cur = shadow_cur; net->shadow_valid = shadow_valid; net->cell_view_cur = view_cur;
     net->cells_stepped = false; net->local_inputs_done = false;
     TRY(run_steps(net, iterations));
+    TRY(flush_rstdp(net));
+    TRY(flush_stdp(net));
     net->stat_verify_runs += 1;
     if (net->snap_generation == generation) {
         uint32_t report[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         HIP_TRY(hipMemsetAsync(net->verify_report, 0, 32, net->stream), SNN_ERR_BUFFER_WRITE);
         if (net->verify_fault) {          // option "verify_fault" (test hook): the second outcome is not the first
-            hipLaunchKernelGGL(k_flip_bit, dim3(1), dim3(1), 0, net->stream, reinterpret_cast<uint32_t *>(net->xbuf), (size_t)(net->verify_fault - 1));
+            // (values from 2^30: that word of the first matrix -- the weights -- of a handle with weight updates)
+            const bool in_matrix = net->verify_fault >= (1u << 30) && !matrices.empty();
+            hipLaunchKernelGGL(k_flip_bit, dim3(1), dim3(1), 0, net->stream,
+                               in_matrix ? static_cast<uint32_t *>(matrices[0].first) : reinterpret_cast<uint32_t *>(net->xbuf),
+                               in_matrix ? (size_t)(net->verify_fault - (1u << 30)) : (size_t)(net->verify_fault - 1));
             net->verify_fault = 0;
         }
         hipLaunchKernelGGL(k_compare_table_alt, grid, dim3(256), 0, net->stream, table, base, first, net->verify_report);
+        {
+            // the matrices of the two outcomes, word for word (entry numbers past the table's: 1000 + matrix index)
+            size_t off = net->verify_big_bytes;
+            uint32_t k = 0;
+            for (const auto &m : matrices) {
+                hipLaunchKernelGGL(k_compare_words, dim3(std::min<size_t>(1024, (m.second / 4 + 255) / 256)), dim3(256), 0, net->stream,
+                                   reinterpret_cast<const uint32_t *>(net->verify_big + off), static_cast<const uint32_t *>(m.first), m.second / 4,
+                                   1000u + k, net->verify_report);
+                off += m.second;
+                ++k;
+            }
+        }
         HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
         HIP_TRY(copy_sync(net, report, net->verify_report, 32, hipMemcpyDeviceToHost), SNN_ERR_BUFFER_READ);
         if (report[0]) {
@@ -1332,7 +1398,8 @@ int snn_run(snn_network_t *net, uint64_t iterations)
             char vals[96];
             snprintf(vals, sizeof vals, "first pass 0x%08x (%g), second pass 0x%08x (%g)", report[3],
                      (double)__builtin_bit_cast(float, report[3]), report[4], (double)__builtin_bit_cast(float, report[4]));
-            const void *arr = (e >= 1 && e <= net->snap_table_host.size()) ? (const void *)net->snap_table_host[e - 1].src : nullptr;
+            const void *arr = (e >= 1 && e <= net->snap_table_host.size()) ? (const void *)net->snap_table_host[e - 1].src
+                            : (e > 1000 && e - 1001 < matrices.size()) ? matrices[e - 1001].first : nullptr;
             net->verify_text = "run of " + std::to_string(iterations) + " steps ending at clock " + std::to_string(net->clock) + ": " +
                                std::to_string(n) + " words differ between two executions from the same state; e.g. " +
                                describe_array(net, arr, w) + ": " + vals;
@@ -2015,6 +2082,7 @@ int snn_set_option(snn_network_t *net, const char *name, int value)
     if (net->finalized) TRY(end_run(net));            // pending deferred updates belong to the old setting
     const std::string n(name);
     if (n == "fused_step") net->fused_step = value != 0;
+    else if (n == "dense_close") net->dense_close = value != 0;
     else if (n == "cells_in_step") net->cells_in_step = value != 0;
     else if (n == "update_packs") net->update_packs = value != 0;
     else if (n == "update_all_planes") net->update_all_planes = value != 0;
@@ -2055,6 +2123,7 @@ int snn_get_stat(snn_network_t *net, const char *name, uint64_t *value)
     else if (n == "halo_peer_steps") *value = net->stat_peer_steps;
     else if (n == "persistent_run_external_stream") *value = net->stat_run_external_stream;
     else if (n == "steps_dense_one_launch") *value = net->stat_steps_dense_one_launch;
+    else if (n == "steps_dense_close") *value = net->stat_steps_dense_close;
     else if (n == "steps_sparse_one_launch") *value = net->stat_steps_sparse_one_launch;
     else if (n == "steps_sparse_split") *value = net->stat_steps_sparse_split;
     else if (n == "steps_two_kernel") *value = net->stat_steps_two_kernel;

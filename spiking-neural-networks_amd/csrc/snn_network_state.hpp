@@ -18,6 +18,7 @@
 
 #include "../../include/snn_amd.h"
 #include "snn_kernels_csr.hpp"
+#include "snn_kernels_dense_step.hpp"
 #include "snn_kernels_exchange.hpp"
 #include "snn_kernels_inputs.hpp"
 #include "snn_kernels_misc.hpp"
@@ -264,6 +265,7 @@ struct snn_network {
     // which form each step took (statistics "steps_*"): k_step_resident, k_step_csr whole, k_step_csr border + interior,
     // input pass + k_update
     uint64_t stat_steps_dense_one_launch = 0, stat_steps_sparse_one_launch = 0, stat_steps_sparse_split = 0, stat_steps_two_kernel = 0;
+    uint64_t stat_steps_dense_close = 0;         // streamed dense steps whose input pass also updated the neurons (k_inputs_dense_close)
     uint64_t stat_shadow_refreshes = 0, stat_view_refreshes = 0, stat_history_regrows = 0;
     uint32_t run_spin_limit = RUN_RESIDENT_SPIN_LIMIT;   // option "run_resident_spin_limit"
     uint32_t run_fault_step = 0;                         // option "run_resident_fault_step" (test hook, see ResidentRunArgs)
@@ -280,9 +282,11 @@ struct snn_network {
     // option "verify" (SNN_AMD_VERIFY=1; tests and campaigns): every snn_run call on a handle without weight updates takes its
     // steps TWICE from the same snapshot and compares the two outcomes on the device (k_compare_table_alt)
     int verify = 0;
-    uint32_t verify_fault = 0;                  // option "verify_fault" (test hook): word + 1 of the exchange buffer to disturb once
+    uint32_t verify_fault = 0;                  // option "verify_fault" (test hook): word + 1 of the exchange buffer (2^30 + word of the weights) to disturb once
     uint32_t *verify_buf = nullptr;             // the first outcome, laid out like snap_buf
     uint32_t *verify_report = nullptr;          // device words, see k_compare_table_alt
+    char *verify_big = nullptr;                 // runs with weight updates: [the matrices at the start | after the first pass]
+    size_t verify_big_bytes = 0;
     uint64_t snap_generation = 0;               // how often the snapshot table has been laid out
     uint64_t stat_verify_runs = 0, stat_verify_mismatches = 0, stat_verify_skipped = 0;
     std::string verify_text;                    // what the last mismatch was (snn_debug_verify_report)
@@ -324,6 +328,9 @@ struct snn_network {
     int shadow_cur = 0;
     bool shadow_valid = false;      // shadow[shadow_cur] == exchange buffer
     int fused_step = 1;             // 0: always take the two-kernel path (SNN_AMD_FUSED_STEP=0)
+    int dense_close = 1;            // streamed dense matrices: the last workgroup of a column tile updates its neurons (SNN_AMD_DENSE_CLOSE=0: two kernels)
+    uint32_t *tile_done = nullptr;  // k_inputs_dense_close: per column tile, the workgroups that have stored their partials (0 between launches)
+    uint32_t tile_done_len = 0;
     bool view_dirty = true;         // spike-train gap-junction values must be refreshed before the next inputs
     bool local_inputs_done = false; // this step's LOCAL chunk partials are already enqueued
 

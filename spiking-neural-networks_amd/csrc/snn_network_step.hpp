@@ -708,6 +708,61 @@ int launch_step_resident(snn_network *net)
     return SNN_OK;
 }
 
+// Streamed dense matrices on an unsharded handle: the input pass closes the step itself (k_inputs_dense_close) -- no pending weight
+// update to carry, no drive kernel in front, gap junctions on (the chemical-only pass keeps its two kernels).
+bool dense_close_applies(const snn_network *net)
+{
+    return !SNN_HAVE_CUSTOM_MODEL && net->dense_close && !net->csr && !net->sharded && !net->drive_threshold && net->n_loc && net->n_tot &&
+           net->n_loc == net->nn && net->electrical && matrix_streamed(net) && !net->local_inputs_done && !net->stdp_pending &&
+           !net->rstdp_pending && net->force_shape == 0;
+}
+
+int launch_dense_close(snn_network *net)
+{
+    DenseStepArgs r{};
+    TRY(fused_step_args(net, r.in, r.up));
+    const uint64_t waves4 = (uint64_t)((net->n_loc + 255) / 256) * net->n_chunks;
+    const int shape = waves4 < 57600 ? 2 : 1;                                  // as launch_inputs chooses
+    const uint32_t tiles = shape == 1 ? (net->n_loc + InputsShape<1>::TILE - 1) / InputsShape<1>::TILE
+                                      : (net->n_loc + InputsShape<2>::TILE - 1) / InputsShape<2>::TILE;
+    if (net->tile_done_len < tiles) {
+        net->tile_done = nullptr;                                              // (a handle's width is fixed after finalize: allocated once)
+        TRY(dev_alloc_t(net, &net->tile_done, (size_t)tiles));
+        HIP_TRY(memset_sync(net, net->tile_done, 0, (size_t)tiles * 4), SNN_ERR_BUFFER_WRITE);
+        net->tile_done_len = tiles;
+        TRY(fused_step_args(net, r.in, r.up));                                 // (nothing moved; the arguments are cheap to rebuild)
+    }
+    r.tile_done = net->tile_done;
+    // one live transmitter type: the pass specialised on it (the planes of the other types hold zeros, which the update adds)
+    const bool one_type = net->chemical && net->n_live == 1;
+    if (one_type) for (int k = 0; k < K_TYPES; ++k) r.in.live_type[k] = net->live_type[k];
+    hipEvent_t e1 = nullptr;
+    TRY(profile_open(net, &e1));
+    const dim3 grid(tiles, net->n_chunks), block(256);
+#define SNN_DENSE_CLOSE_SHAPE(M, SH)                                                                                                  \
+    do {                                                                                                                              \
+        if (!net->chemical) hipLaunchKernelGGL((k_inputs_dense_close<M, true, false, SH, 3>), grid, block, 0, net->stream, r);        \
+        else if (one_type) hipLaunchKernelGGL((k_inputs_dense_close<M, true, true, SH, 1>), grid, block, 0, net->stream, r);          \
+        else hipLaunchKernelGGL((k_inputs_dense_close<M, true, true, SH, 3>), grid, block, 0, net->stream, r);                        \
+    } while (0)
+#define SNN_DENSE_CLOSE(M)                                                                                                            \
+    do {                                                                                                                              \
+        if (shape == 1) SNN_DENSE_CLOSE_SHAPE(M, 1);                                                                                  \
+        else SNN_DENSE_CLOSE_SHAPE(M, 2);                                                                                             \
+    } while (0)
+#if !SNN_HAVE_CUSTOM_MODEL
+    SNN_FOR_MODEL(SNN_DENSE_CLOSE)
+#else
+    (void)grid, (void)block;
+#endif
+#undef SNN_DENSE_CLOSE
+#undef SNN_DENSE_CLOSE_SHAPE
+    HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+    if (e1) HIP_TRY(hipEventRecord(e1, net->stream), SNN_ERR_QUEUE);
+    net->shadow_cur ^= 1;
+    return SNN_OK;
+}
+
 // Small lattices of neurons: ALL steps of a run call in one launch (k_run_resident) when nothing has to happen between two
 // steps on the host's side of the stream -- no weight updates, no per-step reductions, every step recorded (or none), cells
 // (if any) Poisson or Rate without transmitters.  Electrical synapses: up to 4096 rows; with chemical synapses (built-in
@@ -1128,6 +1183,7 @@ int step_begin(snn_network *net)
         HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
     }
     if (fused_step_applies(net)) { net->stat_steps_dense_one_launch += 1; return launch_step_resident(net); }
+    if (dense_close_applies(net)) { net->stat_steps_dense_close += 1; return launch_dense_close(net); }
     if (csr_fast_step(net) && net->peer_run) {
         // peer form: nothing to overlap with -- border and interior slices in ONE launch, the border rows store into the peers
         net->stat_steps_sparse_one_launch += 1;

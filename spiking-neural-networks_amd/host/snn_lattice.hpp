@@ -576,6 +576,10 @@ public:
             check(snn_network_add_spike_train_lattice(g.h_, (uint32_t)id, (uint32_t)l.rows(), (uint32_t)l.cols()));
         check(snn_network_finalize(g.h_));
         g.upload();
+        // internal_clock: lattice_network.internal_clock (gpu_lattices/mod.rs:1630): a network that has run on the host goes on
+        // at its clock -- the firing times uploaded above are absolute step numbers; each spike-train lattice keeps its own
+        check(snn_set_clock(g.h_, (uint64_t)net.internal_clock));
+        for (const auto &[id, l] : net.spike_train_lattices) check(snn_set_spike_train_clock(g.h_, (uint32_t)id, (uint64_t)l.internal_clock));
         return g;
     }
     LatticeNetworkGPU() = default;

@@ -1221,6 +1221,11 @@ class LatticeNetworkGPU:
                 t = np.zeros((count, nn), np.float32)
                 t[:, first:first + count] = l.traces
                 dn.set_trace_rows(first, t)
+        # internal_clock: lattice_network.internal_clock (gpu_lattices/mod.rs:1630): a network that has already run goes on at its
+        # clock (last_firing_time values are absolute step numbers); every spike-train lattice keeps its own
+        dn.set_clock(int(getattr(net, "internal_clock", 0) or 0))
+        for id, l in net.spike_train_lattices.items():
+            dn.set_spike_train_clock(id, int(getattr(l, "internal_clock", 0) or 0))
 
     def _global(self, gp):
         first, _ = self._dn.lattice_range(gp.id)
@@ -1276,6 +1281,7 @@ class LatticeNetworkGPU:
                     l.traces = dn.get_trace_rows(first, count)[:, first:first + count].copy()
                     l.reward_modulator.dopamine = float(dn.dopamine(id))
         for id, l in net.spike_train_lattices.items():
+            l.internal_clock = dn.spike_train_clock(id)             # SpikeTrainLattice::internal_clock, neuron/mod.rs:1318
             cells = _flat(l)
             if cells:
                 for cell, v, s, t in zip(cells, dn.get_attr(id, "current_voltage"),

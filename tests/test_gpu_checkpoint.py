@@ -61,10 +61,9 @@ def test_a_handle_built_from_a_running_network_continues_at_its_clocks(snn, seed
     dn.close()
 
 
-@pytest.mark.parametrize("seed", SEEDS[:12])
+@pytest.mark.parametrize("seed", SEEDS)
 def test_the_self_check_steps_every_call_twice_and_agrees(snn, seed):
     net, plan = draw(1000 + seed)
-    static = not net["do_plasticity"].any()
     dn = make_handle(snn, net, plan)
     dn.set_option("verify", 1)
     dn.set_history(voltage=True, spikes=True)
@@ -72,7 +71,7 @@ def test_the_self_check_steps_every_call_twice_and_agrees(snn, seed):
         dn.run(k)
     net.run(64, voltage_history=True, spike_history=True)
     assert dn.stat("verify_mismatches") == 0, dn.verify_report()
-    assert dn.stat("verify_runs") + dn.stat("verify_skipped") == (3 if static else 0)
+    assert dn.stat("verify_runs") + dn.stat("verify_skipped") == 3 and dn.stat("verify_runs") >= 2
     assert dn.clock == 64 and dn.history_steps() == 64
     assert not checkpoint.state_diffs(net, *checkpoint.pull_all(dn, net))
     rng = net.layout.ranges()
@@ -97,6 +96,47 @@ def test_the_self_check_reports_a_planted_difference(snn, capfd):
     assert "[snn verify] MISMATCH" in capfd.readouterr().err
     dn.run(5)
     assert dn.stat("verify_mismatches") == 1                    # (the hook fires once)
+    dn.close()
+
+
+@pytest.mark.parametrize("csr", [False, True])
+@pytest.mark.parametrize("seed", range(8))
+def test_the_self_check_covers_runs_with_weight_updates(snn, seed, csr):
+    """reward-modulated networks with connections between their lattices: weights, traces, dw and counters are part of what is
+    put back before the second pass and of what is compared after it"""
+    import reward_network_cases as cases
+    from test_gpu_reward_network import device_for
+    net, steps, rewards = cases.draw(seed)
+    dn = device_for(snn, net, csr=csr)
+    dn.set_option("verify", 1)
+    if seed % 4 == 1:
+        dn.run(steps)
+        rewards = None
+    else:
+        for r in rewards:
+            dn.run_with_reward(float(r))
+    net.run(steps, rewards=rewards)
+    assert dn.stat("verify_mismatches") == 0, dn.verify_report()
+    assert dn.stat("verify_runs") >= (1 if rewards is None else steps - 1)
+    parity.assert_state_equal(net, parity.pull_state(dn, net))
+    parity.assert_graph_equal(net, dn)
+    if csr:
+        assert np.array_equal(parity.bits(dn.get_traces_csr()), parity.bits(parity.csr_values(net, net["traces"], dn.owned)))
+    else:
+        assert np.array_equal(parity.bits(dn.get_trace_rows(0, net.n_tot)), parity.bits(net["traces"]))
+    dn.close()
+
+
+def test_the_self_check_reports_a_planted_difference_in_the_weights(snn):
+    net, plan = draw(1000 + next(s for s in SEEDS if draw(1000 + s)[0]["do_plasticity"].any()))
+    dn = make_handle(snn, net, plan)
+    dn.set_option("verify", 1)
+    dn.run(9)
+    dn.set_option("verify_fault", (1 << 30) + 1)
+    dn.run(12)
+    assert dn.stat("verify_mismatches") == 1
+    text = dn.verify_report()
+    assert "1 words differ" in text and ("W, word 1" in text or "sparse weights, word 1" in text), text
     dn.close()
 
 
