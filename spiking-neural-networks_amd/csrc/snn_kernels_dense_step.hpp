@@ -10,7 +10,7 @@
 // closes early must not disturb the presynaptic values the other tiles still stage.
 //
 // Order of the sums: unchanged -- partials per chunk in memory, combined in ascending chunk order by ONE thread per column
-// (GlobalSums).  Bit-identical to the two-kernel step (tests/test_gpu_dense_close.py).
+// (combine_tile_columns).  Bit-identical to the two-kernel step (tests/test_gpu_dense_close.py).
 #pragma once
 #include "snn_kernels_inputs.hpp"
 #include "snn_kernels_update.hpp"
@@ -23,8 +23,55 @@ struct DenseStepArgs {
     uint32_t *tile_done;        // [column tiles] workgroups of the tile that have stored their partials; 0 between launches
 };
 
+// Second-level sums of the VEC columns a thread of the closing workgroup owns (columns THREADS apart), every plane the step needs:
+// the loads of a batch of ALL its columns are in flight together, the adds of each column stay strictly ascending from 0.0f (the
+// order of combine_partials).  One closing workgroup per tile is all the parallelism the tail has; column after column it would
+// wait VEC x planes x n_chunks / 16 dependent round trips (64 at BASELINE configs[1]), this way planes x n_chunks / 16.
+template <int VEC, int THREADS>
+__device__ __forceinline__ void combine_tile_columns(const UpdateArgs &a, uint32_t ql0, RegisterSums (&out)[VEC])
+{
+    constexpr uint32_t B = 16;
+    uint32_t col[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) col[j] = min(ql0 + (uint32_t)j * THREADS, a.ld - 1u);      // (columns past the row: value unused)
+#pragma unroll
+    for (int pl = 0; pl < 1 + K_TYPES; ++pl) {
+        const bool on = pl == 0 ? a.electrical != 0 : (a.chemical != 0 && ((a.live_mask >> (pl - 1)) & 1u) != 0u);   // launch-uniform
+        float sum[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) sum[j] = 0.0f;
+        if (on) {
+            const float *plane = pl == 0 ? a.part_i : a.part_t + (size_t)(pl - 1) * a.n_chunks * a.ld;
+            uint32_t c = 0;
+            for (; c + B <= a.n_chunks; c += B) {
+                float v[VEC][B];
+#pragma unroll
+                for (uint32_t u = 0; u < B; ++u) {
+                    const float *row = plane + (size_t)(c + u) * a.ld;       // wave-uniform base + the lane's 32-bit column offset
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) v[j][u] = row[col[j]];
+                }
+#pragma unroll
+                for (int j = 0; j < VEC; ++j)
+#pragma unroll
+                    for (uint32_t u = 0; u < B; ++u) sum[j] += v[j][u];
+            }
+            for (; c < a.n_chunks; ++c) {
+                const float *row = plane + (size_t)c * a.ld;
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) sum[j] += row[col[j]];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            if (pl == 0) out[j].i = sum[j];
+            else out[j].t[pl - 1] = sum[j];
+        }
+    }
+}
+
 template <int MODEL, bool ELEC, bool CHEM, int STREAM, int NT>
-__global__ __launch_bounds__(InputsShape<STREAM>::THREADS) void k_inputs_dense_close(const DenseStepArgs a)
+__global__ __launch_bounds__(InputsShape<STREAM>::THREADS, STREAM == 1 ? 3 : 4) void k_inputs_dense_close(const DenseStepArgs a)
 {
     using S = InputsShape<STREAM>;
     __shared__ uint32_t s_last;
@@ -47,12 +94,18 @@ __global__ __launch_bounds__(InputsShape<STREAM>::THREADS) void k_inputs_dense_c
 
     // ---- the tile's columns: second level of the canonical sum + the neuron's step (k_update's code) ----
     const UpdateArgs &u = a.up;
+    RegisterSums sums[S::VEC];
+    combine_tile_columns<S::VEC, S::THREADS>(u, tile * S::TILE + threadIdx.x, sums);
 #pragma unroll 1
     for (int j = 0; j < S::VEC; ++j) {
         const uint32_t ql = tile * S::TILE + (uint32_t)j * S::THREADS + threadIdx.x;
         if (tile * S::TILE + (uint32_t)j * S::THREADS >= u.ld) break;     // (workgroup-uniform: the raster's ballot below is whole)
         uint32_t spike = 0u;
-        if (ql < u.n_loc) spike = update_neuron_at<MODEL>(u, ql, GlobalSums{u, ql}, u.clock, u.vhist_row);
+        RegisterSums mine = sums[0];                 // (selected, not indexed: the sums stay in registers)
+#pragma unroll
+        for (int k = 1; k < S::VEC; ++k)
+            if (j == k) mine = sums[k];
+        if (ql < u.n_loc) spike = update_neuron_at<MODEL>(u, ql, mine, u.clock, u.vhist_row);
         if (u.spike_row) {
             const unsigned long long word = __ballot(spike != 0);
             if ((threadIdx.x & 63u) == 0u && ql < u.ld && u.q0 + ql < u.n.n_pad) u.spike_row[(u.q0 + ql) >> 6] = word;

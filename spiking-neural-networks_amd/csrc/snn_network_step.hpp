@@ -402,7 +402,9 @@ int launch_plasticity_kernels(snn_network *net)
 // sizes served by the one-launch small-lattice step (snn_kernels_resident.hpp)
 bool fused_step_possible(const snn_network *net)
 {
-    return !SNN_HAVE_CUSTOM_MODEL && net->fused_step && !net->csr && !net->sharded && !net->drive_threshold && net->n_loc && net->n_tot &&
+    // (a library carrying generated code has the one-launch step for ITS neuron model only: shorter compile)
+    const bool compiled = !SNN_HAVE_CUSTOM_MODEL || (SNN_HAVE_CUSTOM_NEURON && net->model == SNN_MODEL_CUSTOM);
+    return compiled && net->fused_step && !net->csr && !net->sharded && !net->drive_threshold && net->n_loc && net->n_tot &&
            net->n_chunks <= RESIDENT_MAX_CHUNKS && (size_t)net->n_tot * net->ld * 4 <= ((size_t)64 << 20);
 }
 
@@ -660,6 +662,7 @@ int fused_step_args(snn_network *net, InputsArgs &a, UpdateArgs &u, bool in_plac
     u.has_nt = net->any_nt_neurons ? 1 : 0;
     u.live_mask = net->live_mask_applied;
     u.bcm = net->model == SNN_MODEL_BCM_IZHIKEVICH;
+    u.model_is_custom = net->model == SNN_MODEL_CUSTOM;
     return SNN_OK;
 }
 
@@ -696,8 +699,10 @@ int launch_step_resident(snn_network *net)
         else if (net->electrical) hipLaunchKernelGGL((k_step_resident<M, true, false>), grid, block, 0, net->stream, r);             \
         else hipLaunchKernelGGL((k_step_resident<M, false, true>), grid, block, 0, net->stream, r);                                  \
     } while (0)
-#if !SNN_HAVE_CUSTOM_MODEL        // a library carrying a generated model keeps to the two-kernel step (shorter compile)
+#if !SNN_HAVE_CUSTOM_MODEL        // a library carrying a generated model has the one-launch step for that model only (shorter compile)
     SNN_FOR_MODEL(SNN_RESIDENT)
+#elif SNN_HAVE_CUSTOM_NEURON
+    SNN_RESIDENT(CUSTOM_MODEL);
 #else
     (void)grid, (void)block;
 #endif

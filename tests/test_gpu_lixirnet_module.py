@@ -234,6 +234,9 @@ def test_networks_py_procedure(ln, chemical, spike_trains):
     net = check_against_oracle(ln, network, gpu_network, (e1, second), (c1,) if spike_trains else ())
     if chemical:
         assert np.abs(lc.var(net, "rx_vars", "Glutamate$current")).max() > 0
+    # the generated library carries the one-launch step for its own neuron model (round 5): inputs + update of a step in one launch
+    dn = gpu_network._dn
+    assert dn.stat("steps_dense_one_launch") == iterations and dn.stat("steps_two_kernel") == 0
     gpu_network.close()
 
 

@@ -55,3 +55,35 @@ def test_no_run_resident_variant_touches_scratch(assembly):
     for name, body in bodies.items():
         hits = [l.strip() for l in body.splitlines() if re.match(r"\s*(scratch_|buffer_(load|store).*offen)", l)]
         assert not hits, (name, hits[:4])
+
+
+# ---- the closing input pass (k_inputs_dense_close): the neuron update shares the streaming pass's register allocation -----------
+CLOSE_VARIANTS = [(m, chem, shape, nt) for m in range(8) for (chem, nt) in ((False, 3), (True, 1), (True, 3)) for shape in (1, 2)]
+
+
+@pytest.fixture(scope="module")
+def close_assembly(tmp_path_factory):
+    d = tmp_path_factory.mktemp("isa_close")
+    src = d / "close_only.hip"
+    inst = "\n".join(f"template __global__ void snn::k_inputs_dense_close<{m}, true, {str(c).lower()}, {s}, {nt}>(const snn::DenseStepArgs);"
+                     for m, c, s, nt in CLOSE_VARIANTS)
+    plain = "\n".join(f"template __global__ void snn::k_inputs_dense<true, {str(c).lower()}, {s}, {nt}, 0>(const snn::InputsArgs);"
+                      for c, nt in ((False, 3), (True, 1), (True, 3)) for s in (1, 2))
+    src.write_text(f'#include "{ROOT}/include/snn_amd.h"\n#include "snn_kernels_dense_step.hpp"\n{inst}\n{plain}\n')
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-c", "--cuda-device-only", "-Wno-unused-result",
+                    "-Wno-pass-failed", "-save-temps", f"-I{CSRC}", "-o", "close.o", src.name], cwd=d, check=True, capture_output=True)
+    return str(d / "close_only-hip-amdgcn-amd-amdhsa-gfx950.s")
+
+
+def test_the_closing_pass_keeps_the_occupancy_of_the_plain_pass(close_assembly):
+    """wavefronts per SIMD = 512 // registers: the closing form of a pass must not run fewer than the plain pass does (three for the
+    4-column shape, four for the 2-column shape), and nothing may spill"""
+    table = isa_metadata.parse(close_assembly)
+    close = {k: v for k, v in table.items() if k.startswith("snn::k_inputs_dense_close<")}
+    assert len(close) == len(CLOSE_VARIANTS)
+    for name, r in close.items():
+        assert r["vgpr_spill"] == 0 and r["scratch"] == 0, (name, r)
+        m, _, chem, shape, nt = [x.strip() for x in name[name.index("<") + 1:name.rindex(">")].split(",")]
+        plain = table[f"snn::k_inputs_dense<true, {chem}, {shape}, {nt}, 0>"]
+        want = min(512 // plain["vgpr"], 3 if shape == "1" else 4)
+        assert 512 // (r["vgpr"] + r["agpr"]) >= want, (name, r["vgpr"], "plain", plain["vgpr"])
