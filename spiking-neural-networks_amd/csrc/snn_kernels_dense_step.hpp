@@ -5,7 +5,14 @@
 // takes 161 us, the update 9.8 us and the two kernel boundaries another 7 -- a tenth of the step spent outside the kernel
 // that is bound by HBM.  Here the workgroups of a column tile count themselves off as they finish (one agent-scope atomic
 // per workgroup); the LAST one of a tile finds every chunk partial of its columns in memory and runs the update of those
-// columns itself, with the code of k_update, while the other tiles still stream.  The pass reads S(t) from a shadow of the
+// columns itself, with the code of k_update, while the other tiles still stream.
+//
+// Visibility inside the launch: the workgroups of a tile sit on different XCDs, whose L2s do not see each other's dirty lines.
+// The partials therefore leave as agent-scope relaxed atomic stores (write-through) and the closing workgroup reads them with
+// agent-scope relaxed atomic loads (not served from a stale line) -- the granule traffic of k_run_resident.  NO fence: the first
+// form of this kernel released and acquired with __threadfence(), i.e. an L2 write-back and an L2 invalidate per wavefront, and
+// the pass took 680 instead of 161 us (profiles/r05/c3_close_with_fences_kernel_stats.csv).  Everything else the update touches was
+// written by an earlier launch.  The pass reads S(t) from a shadow of the
 // exchange buffer and the update writes S(t+1) to the buffer and to the other shadow (as k_step_resident does): a tile that
 // closes early must not disturb the presynaptic values the other tiles still stage.
 //
@@ -49,7 +56,7 @@ __device__ __forceinline__ void combine_tile_columns(const UpdateArgs &a, uint32
                 for (uint32_t u = 0; u < B; ++u) {
                     const float *row = plane + (size_t)(c + u) * a.ld;       // wave-uniform base + the lane's 32-bit column offset
 #pragma unroll
-                    for (int j = 0; j < VEC; ++j) v[j][u] = row[col[j]];
+                    for (int j = 0; j < VEC; ++j) v[j][u] = __hip_atomic_load(row + col[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
 #pragma unroll
                 for (int j = 0; j < VEC; ++j)
@@ -59,7 +66,7 @@ __device__ __forceinline__ void combine_tile_columns(const UpdateArgs &a, uint32
             for (; c < a.n_chunks; ++c) {
                 const float *row = plane + (size_t)c * a.ld;
 #pragma unroll
-                for (int j = 0; j < VEC; ++j) sum[j] += row[col[j]];
+                for (int j = 0; j < VEC; ++j) sum[j] += __hip_atomic_load(row + col[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
 #pragma unroll
@@ -75,22 +82,20 @@ __global__ __launch_bounds__(InputsShape<STREAM>::THREADS, STREAM == 1 ? 3 : 4) 
 {
     using S = InputsShape<STREAM>;
     __shared__ uint32_t s_last;
-    inputs_dense_pass<ELEC, CHEM, STREAM, NT, 0>(a.in);
+    inputs_dense_pass<ELEC, CHEM, STREAM, NT, 0, /*AGENT_STORES=*/true>(a.in);
 
-    // the partials of this workgroup are in memory before it is counted (release), the counting workgroup's view of the
-    // other workgroups' partials is fresh (acquire): agent scope -- the workgroups of a tile sit on different XCDs
-    __threadfence();
+    // every thread's partials have been acknowledged by the memory side before the workgroup is counted
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const uint32_t tile = (blockIdx.x + blockIdx.y) % gridDim.x;          // as inputs_dense_pass maps it
     if (threadIdx.x == 0) {
-        const uint32_t before = __hip_atomic_fetch_add(a.tile_done + tile, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t before = __hip_atomic_fetch_add(a.tile_done + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const bool last = before + 1u == gridDim.y;
         if (last) __hip_atomic_store(a.tile_done + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
         s_last = last ? 1u : 0u;
     }
     __syncthreads();
     if (s_last == 0u) return;
-    __threadfence();
 
     // ---- the tile's columns: second level of the canonical sum + the neuron's step (k_update's code) ----
     const UpdateArgs &u = a.up;

@@ -130,7 +130,9 @@ __device__ __forceinline__ float acc_if_edge(float acc, float term, float w)
 // the variant must keep that occupancy: unbounded it took 174 and the pass 5.16 instead of 4.11 ms at C4)
 // (the pass as a function: k_inputs_dense below, and k_inputs_dense_close -- snn_kernels_dense_step.hpp -- whose last workgroup of
 // a column tile goes on to update the tile's neurons)
-template <bool ELEC, bool CHEM, int STREAM = 1, int NT = K_TYPES, int STDP = 0>
+// AGENT_STORES: the partials leave as agent-scope relaxed atomic stores (write-through past this XCD's L2), for a reader in the
+// SAME launch on another XCD (k_inputs_dense_close); the plain kernel's partials are read by the next launch and stay ordinary stores
+template <bool ELEC, bool CHEM, int STREAM = 1, int NT = K_TYPES, int STDP = 0, bool AGENT_STORES = false>
 __device__ __forceinline__ void inputs_dense_pass(const InputsArgs &a)
 {
     using S = InputsShape<STREAM>;
@@ -502,11 +504,15 @@ __device__ __forceinline__ void inputs_dense_pass(const InputsArgs &a)
         });
     }
 
+    auto put = [](float *p, float x) {
+        if (AGENT_STORES) __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else *p = x;
+    };
     if (ELEC) {
         float *dst = a.part_i + (size_t)chunk * a.ld + ql;
 #pragma unroll
         for (int j = 0; j < VEC; ++j)
-            if (colv[j]) dst[(uint32_t)j * S::THREADS] = acc[j];
+            if (colv[j]) put(dst + (uint32_t)j * S::THREADS, acc[j]);
     }
     if (CHEM) {
 #pragma unroll
@@ -514,7 +520,7 @@ __device__ __forceinline__ void inputs_dense_pass(const InputsArgs &a)
             float *dst = a.part_t + ((size_t)a.live_type[k] * a.n_chunks + chunk) * a.ld + ql;
 #pragma unroll
             for (int j = 0; j < VEC; ++j)
-                if (colv[j]) dst[(uint32_t)j * S::THREADS] = tacc[k][j];
+                if (colv[j]) put(dst + (uint32_t)j * S::THREADS, tacc[k][j]);
         }
     }
 }

@@ -41,6 +41,7 @@ int snn_network_create(int device, int neuron_model, int nt_kinetics, int recept
     net->device = device;
     if (const char *e = getenv("SNN_AMD_FUSED_STEP")) net->fused_step = (e[0] != '0');
     if (const char *e = getenv("SNN_AMD_DENSE_CLOSE")) net->dense_close = (e[0] != '0');
+    if (const char *e = getenv("SNN_AMD_DENSE_CLOSE_MAX_CHUNKS")) net->dense_close_max_chunks = (uint32_t)strtoul(e, nullptr, 10);
     if (const char *e = getenv("SNN_AMD_CSR_XCD_BANDS")) net->csr_xcd_bands = (e[0] != '0');
     if (const char *e = getenv("SNN_AMD_HALO_DIRECT")) net->halo_direct = (e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1;
     if (const char *e = getenv("SNN_AMD_UPDATE_PACKS")) net->update_packs = (e[0] != '0');
@@ -1227,7 +1228,7 @@ std::vector<std::pair<void *, size_t>> verify_matrices(const snn_network *net)
 {
     std::vector<std::pair<void *, size_t>> m;
     if (!net->any_plasticity && !net->any_modulation && !net->any_conn_kind) return m;
-    if (net->csr) { if (net->csr_w) m.emplace_back(net->csr_w, (size_t)net->sell_entries * 4); }
+    if (net->csr) { if (net->csr_w && net->sell_entries) m.emplace_back(net->csr_w, (size_t)net->sell_entries * 4); }
     else if (net->W) m.emplace_back(net->W, wcount(net->n_tot, net->ld) * 4);
     const size_t edges = std::max<size_t>(net->csr ? (size_t)net->sell_entries : wcount(net->n_tot, net->ld), 64) * 4;
     for (void *a : {(void *)net->trace, (void *)net->pending, (void *)net->edge_counter})
@@ -1380,13 +1381,13 @@ int snn_run(snn_network_t *net, uint64_t iterations)
         }
         hipLaunchKernelGGL(k_compare_table_alt, grid, dim3(256), 0, net->stream, table, base, first, net->verify_report);
         {
-            // the matrices of the two outcomes, word for word (entry numbers past the table's: 1000 + matrix index)
+            // the matrices of the two outcomes, word for word (entry numbers past the table's: 2^20 + matrix index)
             size_t off = net->verify_big_bytes;
             uint32_t k = 0;
             for (const auto &m : matrices) {
                 hipLaunchKernelGGL(k_compare_words, dim3(std::min<size_t>(1024, (m.second / 4 + 255) / 256)), dim3(256), 0, net->stream,
                                    reinterpret_cast<const uint32_t *>(net->verify_big + off), static_cast<const uint32_t *>(m.first), m.second / 4,
-                                   1000u + k, net->verify_report);
+                                   (1u << 20) + k, net->verify_report);
                 off += m.second;
                 ++k;
             }
@@ -1399,7 +1400,7 @@ int snn_run(snn_network_t *net, uint64_t iterations)
             snprintf(vals, sizeof vals, "first pass 0x%08x (%g), second pass 0x%08x (%g)", report[3],
                      (double)__builtin_bit_cast(float, report[3]), report[4], (double)__builtin_bit_cast(float, report[4]));
             const void *arr = (e >= 1 && e <= net->snap_table_host.size()) ? (const void *)net->snap_table_host[e - 1].src
-                            : (e > 1000 && e - 1001 < matrices.size()) ? matrices[e - 1001].first : nullptr;
+                            : (e >= (1u << 20) && e - (1u << 20) < matrices.size()) ? matrices[e - (1u << 20)].first : nullptr;
             net->verify_text = "run of " + std::to_string(iterations) + " steps ending at clock " + std::to_string(net->clock) + ": " +
                                std::to_string(n) + " words differ between two executions from the same state; e.g. " +
                                describe_array(net, arr, w) + ": " + vals;

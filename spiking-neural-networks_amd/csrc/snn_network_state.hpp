@@ -329,6 +329,7 @@ struct snn_network {
     bool shadow_valid = false;      // shadow[shadow_cur] == exchange buffer
     int fused_step = 1;             // 0: always take the two-kernel path (SNN_AMD_FUSED_STEP=0)
     int dense_close = 1;            // streamed dense matrices: the last workgroup of a column tile updates its neurons (SNN_AMD_DENSE_CLOSE=0: two kernels)
+    uint32_t dense_close_max_chunks = 1u << 30;   // ... only up to this many chunks of presynaptic rows (SNN_AMD_DENSE_CLOSE_MAX_CHUNKS; experiments)
     uint32_t *tile_done = nullptr;  // k_inputs_dense_close: per column tile, the workgroups that have stored their partials (0 between launches)
     uint32_t tile_done_len = 0;
     bool view_dirty = true;         // spike-train gap-junction values must be refreshed before the next inputs

@@ -719,7 +719,7 @@ bool dense_close_applies(const snn_network *net)
 {
     return !SNN_HAVE_CUSTOM_MODEL && net->dense_close && !net->csr && !net->sharded && !net->drive_threshold && net->n_loc && net->n_tot &&
            net->n_loc == net->nn && net->electrical && matrix_streamed(net) && !net->local_inputs_done && !net->stdp_pending &&
-           !net->rstdp_pending && net->force_shape == 0;
+           !net->rstdp_pending && net->force_shape == 0 && net->n_chunks <= net->dense_close_max_chunks;
 }
 
 int launch_dense_close(snn_network *net)
