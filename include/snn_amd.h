@@ -500,8 +500,9 @@ int snn_get_spike_counts(snn_network_t *net, uint32_t id, uint32_t *dst, size_t 
 
 /* Tuning switches (results never depend on them; defaults in brackets, also settable through the environment when the
  * handle is created: SNN_AMD_<NAME in upper case>): "fused_step" [1] one-launch step for small lattices and for
- * sparse handles; "dense_close" [1] streamed dense matrices on unsharded handles with gap junctions: the last workgroup of a column
- * tile of the input pass updates the tile's neurons in the same launch (k_inputs_dense_close; 0: input pass + k_update); "cells_in_step" [1] sparse electrical-only handles without weight updates: the spike-train cells advance
+ * sparse handles; "dense_close" [0] 1: streamed dense matrices on unsharded handles with gap junctions: the last workgroup of a column
+ * tile of the input pass updates the tile's neurons in the same launch (k_inputs_dense_close; measured slower than input pass +
+ * k_update); "cells_in_step" [1] sparse electrical-only handles without weight updates: the spike-train cells advance
  * inside the step's launch; "update_packs" [1] dense shard handles: the neuron update writes the handle's own slot of
  * the all-gather buffer itself (no pack launch); "update_all_planes" [1] dense handles with chemical synapses: the neuron update
  * requests the chunk partials of all planes together; "csr_xcd_bands" [1] the sparse step hands its row blocks to the XCDs in contiguous bands;

@@ -47,10 +47,15 @@ __global__ __launch_bounds__(256) void k_copy_table_alt(const CopyEntry *table, 
     uint32_t *to = restore ? e.src : side;
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < e.words; i += gridDim.x * 256u) to[i] = from[i];
 }
-__global__ __launch_bounds__(256) void k_compare_table_alt(const CopyEntry *table, const uint32_t *base, const uint32_t *alt, uint32_t *report)
+// entries (1-based) a comparison leaves out: scratch the step forms use differently, caches whose validity flags differ
+struct SkipSet { uint32_t n, entry[8]; };
+__global__ __launch_bounds__(256) void k_compare_table_alt(const CopyEntry *table, const uint32_t *base, const uint32_t *alt, uint32_t *report,
+                                                           SkipSet skip)
 {
     const CopyEntry e = table[blockIdx.y];
     if (e.pad) return;
+    for (uint32_t k = 0; k < skip.n; ++k)
+        if (skip.entry[k] == blockIdx.y + 1u) return;
     const uint32_t *was = alt + (e.dst - base);
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < e.words; i += gridDim.x * 256u) {
         const uint32_t x = was[i], y = e.src[i];

@@ -285,6 +285,8 @@ struct snn_network {
     uint32_t verify_fault = 0;                  // option "verify_fault" (test hook): word + 1 of the exchange buffer (2^30 + word of the weights) to disturb once
     uint32_t *verify_buf = nullptr;             // the first outcome, laid out like snap_buf
     uint32_t *verify_report = nullptr;          // device words, see k_compare_table_alt
+    uint32_t *verify_third = nullptr;           // on a mismatch: the second outcome, while a third execution decides which one repeats
+    size_t verify_third_words = 0;
     char *verify_big = nullptr;                 // runs with weight updates: [the matrices at the start | after the first pass]
     size_t verify_big_bytes = 0;
     uint64_t snap_generation = 0;               // how often the snapshot table has been laid out
@@ -328,7 +330,7 @@ struct snn_network {
     int shadow_cur = 0;
     bool shadow_valid = false;      // shadow[shadow_cur] == exchange buffer
     int fused_step = 1;             // 0: always take the two-kernel path (SNN_AMD_FUSED_STEP=0)
-    int dense_close = 1;            // streamed dense matrices: the last workgroup of a column tile updates its neurons (SNN_AMD_DENSE_CLOSE=0: two kernels)
+    int dense_close = 0;            // 1: streamed dense matrices: the last workgroup of a column tile updates its neurons (measured: slower than two kernels)
     uint32_t dense_close_max_chunks = 1u << 30;   // ... only up to this many chunks of presynaptic rows (SNN_AMD_DENSE_CLOSE_MAX_CHUNKS; experiments)
     uint32_t *tile_done = nullptr;  // k_inputs_dense_close: per column tile, the workgroups that have stored their partials (0 between launches)
     uint32_t tile_done_len = 0;

@@ -48,6 +48,57 @@ def seed_is_valid(spec, seed):
     return True
 
 
+def install_oracle_guard(snn_amd, record):
+    """The oracle's arrays are written by the oracle and by the test, never while a call into the device library is under way (the
+    tests are single-threaded).  Every public DeviceNetwork method is wrapped: the arrays of all live oracle containers are copied
+    (CRC for the large ones) before the call and compared after it.  A difference is memory of THIS process that the library, the
+    HIP runtime or one of its threads wrote behind the test's back -- the kind of event that makes device and oracle disagree once
+    and never again -- and `record` gets the method, the array, the first index and both values."""
+    import weakref
+    import zlib
+    import numpy as np
+    import oracle_binding as ob
+    nets = weakref.WeakSet()
+    init = ob.Net.__init__
+
+    def tracked_init(self, *a, **k):
+        init(self, *a, **k)
+        nets.add(self)
+    ob.Net.__init__ = tracked_init
+
+    def picture():
+        out = {}
+        for n in list(nets):
+            items = list(n.arr.items()) + [(h, getattr(n, h, None)) for h in ("voltage_history", "spike_history", "st_voltage_history")]
+            for name, a in items:
+                if isinstance(a, np.ndarray) and a.size and a.flags["C_CONTIGUOUS"]:
+                    out[(id(n), name)] = (a, a.copy() if a.nbytes <= (1 << 18) else None, zlib.crc32(a.reshape(-1).view(np.uint8)))
+        return out
+
+    def wrap(name, fn):
+        def guarded(self, *a, **k):
+            before = picture()
+            try:
+                return fn(self, *a, **k)
+            finally:
+                for key, (arr, copy, crc) in before.items():
+                    if zlib.crc32(arr.reshape(-1).view(np.uint8)) == crc:
+                        continue
+                    rec = {"oracle_memory_changed_during": name, "array": key[1], "address": hex(arr.ctypes.data), "bytes": int(arr.nbytes)}
+                    if copy is not None:
+                        was, now = copy.reshape(-1).view(np.uint8), arr.reshape(-1).view(np.uint8)
+                        idx = np.flatnonzero(was != now)
+                        rec.update({"changed_bytes": int(idx.size), "first_byte": int(idx[0]), "last_byte": int(idx[-1]),
+                                    "was": was[idx[0]:idx[0] + 16].tolist(), "now": now[idx[0]:idx[0] + 16].tolist()})
+                    record(rec)
+        guarded.__name__ = name
+        return guarded
+    cls = snn_amd.DeviceNetwork
+    for name, fn in list(vars(cls).items()):
+        if callable(fn) and (not name.startswith("_") or name == "__init__") and not isinstance(fn, (staticmethod, classmethod, property)):
+            setattr(cls, name, wrap(name, fn))
+
+
 def worker(args):
     import conftest  # noqa: F401  (OpenMP settings of the oracle before libgomp loads)
     os.environ["SNN_CAMPAIGN"] = "1"
@@ -63,12 +114,26 @@ def worker(args):
     counts = {spec: [0, 0] for spec, _ in fns}            # executions, failures
     log = open(os.path.join(args.out, f"worker-{args.index}.jsonl"), "a")
     seed, last_report, recent = args.first_seed + args.index, time.time(), []
+    # what the device's self-check (SNN_AMD_VERIFY) prints goes to a file per worker too, so that every report can be tied to the test
+    # and seed that was running (a report does not fail a test by itself: the handle goes on with the outcome that repeated)
+    vlog = os.path.join(args.out, f"worker-{args.index}.verify.log")
+    os.environ["SNN_AMD_VERIFY_LOG"] = vlog
+    vseen = os.path.getsize(vlog) if os.path.exists(vlog) else 0
+    current = [None, None]
+    if not args.plain:
+        def guard_record(rec):
+            rec.update({"worker": args.index, "test": current[0], "seed": current[1]})
+            log.write(json.dumps(rec) + "\n")
+            log.flush()
+            print(f"[worker {args.index}] ORACLE MEMORY CHANGED during {rec['oracle_memory_changed_during']} ({current[0]} seed {current[1]}): {rec}", flush=True)
+        install_oracle_guard(snn_amd, guard_record)
     while time.time() < deadline and not os.path.exists(os.path.join(args.out, "stop")):
         if accept is None or accept(seed):
             for spec, fn in fns:
                 if not seed_is_valid(spec, seed):
                     continue
                 counts[spec][0] += 1
+                current[0], current[1] = spec, seed
                 recent = (recent + [[spec, seed]])[-12:]
                 try:
                     fn(snn_amd, seed)
@@ -83,6 +148,14 @@ def worker(args):
                                           "traceback": traceback.format_exc()[-3000:]}) + "\n")
                     log.flush()
                     print(f"[worker {args.index}] FAILURE {spec} seed {seed}: {str(e)[:300]}", flush=True)
+                size = os.path.getsize(vlog) if os.path.exists(vlog) else 0
+                if size > vseen:
+                    with open(vlog) as f:
+                        f.seek(vseen)
+                        lines = f.read().splitlines()
+                    vseen = size
+                    log.write(json.dumps({"worker": args.index, "verify_reports": lines[:8], "test": spec, "seed": seed}) + "\n")
+                    log.flush()
         seed += args.workers
         if time.time() - last_report > 60:
             last_report = time.time()
@@ -152,7 +225,7 @@ def main():
     procs += [subprocess.Popen(base + ["--role", "worker", "--index", str(i)], env=worker_env) for i in range(args.workers)]
     rcs = [p.wait() for p in procs]
     ras_after = checkpoint.ras_counters()
-    total, failures = {}, []
+    total, failures, verify_reports, guard_reports = {}, [], [], []
     for i in range(args.workers):
         path = os.path.join(args.out, f"worker-{i}.jsonl")
         for line in open(path) if os.path.exists(path) else ():
@@ -162,12 +235,17 @@ def main():
                     t = total.setdefault(spec, [0, 0])
                     t[0] += n
                     t[1] += f
+            elif "verify_reports" in rec:
+                verify_reports.append(rec)
+            elif "oracle_memory_changed_during" in rec:
+                guard_reports.append(rec)
             else:
                 failures.append({k: rec[k] for k in ("worker", "test", "seed", "error", "message", "preceding")})
     summary = {"minutes": args.minutes, "wall_s": round(time.time() - t0, 1), "workers": args.workers, "streamers": args.streamers,
                "streamer_side": args.side, "tests": args.tests, "filter": args.filter, "first_seed": args.first_seed,
                "executions_and_failures": total, "executions": sum(t[0] for t in total.values()),
                "failures": sum(t[1] for t in total.values()), "failure_records": failures, "exit_codes": rcs,
+               "oracle_memory_reports": guard_reports[:50], "self_check_reports": len(verify_reports), "self_check_records": verify_reports[:200],
                "environment": {k: v for k, v in worker_env.items() if k.startswith(("SNN_", "AMD_", "HIP_", "HSA_", "OMP_", "MALLOC_", "GPU_"))},
                "ras_errors_before_ue_ce": checkpoint.ras_totals(ras_before), "ras_errors_after_ue_ce": checkpoint.ras_totals(ras_after),
                "ras_before": ras_before, "ras_after": ras_after}

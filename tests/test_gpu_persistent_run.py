@@ -275,7 +275,8 @@ def test_random_electrical_networks(snn, seed):
         dn.set_reduced_history(spike_counts=counts)
         for c in calls:
             dn.run(c)
-        out = {"state": parity.pull_state(dn, net), "launches": dn.stat("persistent_run_launches"), "w": dn.get_graph_rows(0, net.n_tot)[0]}
+        out = {"state": parity.pull_state(dn, net), "launches": dn.stat("persistent_run_launches"), "w": dn.get_graph_rows(0, net.n_tot)[0],
+               "gave_up": dn.stat("persistent_run_fallbacks")}
         for i, _, _ in net.layout.lattices:
             if history:
                 out[("v", i)], out[("s", i)] = dn.voltage_history(i), dn.spike_history(i)
@@ -286,7 +287,10 @@ def test_random_electrical_networks(snn, seed):
                 out[("v", i)] = dn.voltage_history(i)
         dn.close()
         outs.append(out)
-    assert outs[0]["launches"] == sum(1 for c in calls if c >= 4) and outs[1]["launches"] == 0
+    # (a run whose workgroups lost sight of each other -- a device shared with many other processes -- is rolled back and repeated with
+    # one launch per step, and the handle stays in that form: fewer one-launch runs then, the same results)
+    want = sum(1 for c in calls if c >= 4)
+    assert (outs[0]["launches"] == want if not outs[0]["gave_up"] else outs[0]["launches"] <= want) and outs[1]["launches"] == 0
     net.run(sum(calls), voltage_history=history, spike_history=history, spike_counts=counts,
             st_voltage_history=history and net.n_cells > 0)
     rng = net.layout.ranges()
