@@ -97,6 +97,7 @@ def install_oracle_guard(snn_amd, record):
     for name, fn in list(vars(cls).items()):
         if callable(fn) and (not name.startswith("_") or name == "__init__") and not isinstance(fn, (staticmethod, classmethod, property)):
             setattr(cls, name, wrap(name, fn))
+    return nets.clear            # called when a test starts: only the containers of the running test are watched
 
 
 def worker(args):
@@ -120,13 +121,14 @@ def worker(args):
     os.environ["SNN_AMD_VERIFY_LOG"] = vlog
     vseen = os.path.getsize(vlog) if os.path.exists(vlog) else 0
     current = [None, None]
+    forget = lambda: None
     if not args.plain:
         def guard_record(rec):
             rec.update({"worker": args.index, "test": current[0], "seed": current[1]})
             log.write(json.dumps(rec) + "\n")
             log.flush()
             print(f"[worker {args.index}] ORACLE MEMORY CHANGED during {rec['oracle_memory_changed_during']} ({current[0]} seed {current[1]}): {rec}", flush=True)
-        install_oracle_guard(snn_amd, guard_record)
+        forget = install_oracle_guard(snn_amd, guard_record)
     while time.time() < deadline and not os.path.exists(os.path.join(args.out, "stop")):
         if accept is None or accept(seed):
             for spec, fn in fns:
@@ -134,6 +136,7 @@ def worker(args):
                     continue
                 counts[spec][0] += 1
                 current[0], current[1] = spec, seed
+                forget()
                 recent = (recent + [[spec, seed]])[-12:]
                 try:
                     fn(snn_amd, seed)
@@ -160,6 +163,8 @@ def worker(args):
         if time.time() - last_report > 60:
             last_report = time.time()
             print(f"[worker {args.index}] seed {seed} " + " ".join(f"{s.split(':')[1]}={c[0]}/{c[1]}" for s, c in counts.items()), flush=True)
+            log.write(json.dumps({"worker": args.index, "progress": True, "counts": counts, "next_seed": seed}) + "\n")
+            log.flush()
     log.write(json.dumps({"worker": args.index, "done": True, "counts": counts, "next_seed": seed,
                           "armed": {k: os.environ.get(k) for k in ("SNN_AMD_VERIFY", "MALLOC_PERTURB_", "SNN_HOST_POISON", "SNN_CHECKPOINTS")}}) + "\n")
     log.close()
@@ -223,24 +228,38 @@ def main():
         worker_env.setdefault("SNN_HOST_POISON", "1")
     procs = [subprocess.Popen(base + ["--role", "streamer", "--index", str(i)]) for i in range(args.streamers)]
     procs += [subprocess.Popen(base + ["--role", "worker", "--index", str(i)], env=worker_env) for i in range(args.workers)]
-    rcs = [p.wait() for p in procs]
+    # a process still busy two and a half minutes after the deadline (starved by thirty others, or stuck) is stopped: the summary is
+    # written from what the workers recorded until then
+    rcs, stop_at = [], t0 + args.minutes * 60 + 150
+    for p in procs:
+        try:
+            rcs.append(p.wait(timeout=max(1.0, stop_at - time.time())))
+        except subprocess.TimeoutExpired:
+            p.terminate()
+            try:
+                rcs.append(p.wait(timeout=20))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                rcs.append(p.wait())
     ras_after = checkpoint.ras_counters()
     total, failures, verify_reports, guard_reports = {}, [], [], []
     for i in range(args.workers):
         path = os.path.join(args.out, f"worker-{i}.jsonl")
+        latest = {}
         for line in open(path) if os.path.exists(path) else ():
             rec = json.loads(line)
-            if rec.get("done"):
-                for spec, (n, f) in rec["counts"].items():
-                    t = total.setdefault(spec, [0, 0])
-                    t[0] += n
-                    t[1] += f
+            if rec.get("done") or rec.get("progress"):
+                latest = rec["counts"]            # (cumulative: the last record of a worker counts)
             elif "verify_reports" in rec:
                 verify_reports.append(rec)
             elif "oracle_memory_changed_during" in rec:
                 guard_reports.append(rec)
             else:
                 failures.append({k: rec[k] for k in ("worker", "test", "seed", "error", "message", "preceding")})
+        for spec, (n, f) in latest.items():
+            t = total.setdefault(spec, [0, 0])
+            t[0] += n
+            t[1] += f
     summary = {"minutes": args.minutes, "wall_s": round(time.time() - t0, 1), "workers": args.workers, "streamers": args.streamers,
                "streamer_side": args.side, "tests": args.tests, "filter": args.filter, "first_seed": args.first_seed,
                "executions_and_failures": total, "executions": sum(t[0] for t in total.values()),
