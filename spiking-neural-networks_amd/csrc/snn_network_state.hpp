@@ -285,6 +285,8 @@ struct snn_network {
     uint32_t verify_fault = 0;                  // option "verify_fault" (test hook): word + 1 of the exchange buffer (2^30 + word of the weights) to disturb once
     uint32_t *verify_buf = nullptr;             // the first outcome, laid out like snap_buf
     uint32_t *verify_report = nullptr;          // device words, see k_compare_table_alt
+    int pinned_copies = 0;                      // option "pinned_copies": see copy_sync
+    void *copy_stage = nullptr;                 // its page-locked staging buffer (8 MiB, allocated with the first such copy)
     uint32_t *verify_third = nullptr;           // on a mismatch: the second outcome, while a third execution decides which one repeats
     size_t verify_third_words = 0;
     char *verify_big = nullptr;                 // runs with weight updates: [the matrices at the start | after the first pass]
@@ -415,8 +417,32 @@ inline hipError_t snn_malloc(T **out, size_t bytes)
 // for.  The handle's stream is hipStreamNonBlocking -- nothing orders it against the null stream -- so a blocking null-stream
 // hipMemcpy / hipMemset in front of a kernel on it is correct only as long as the runtime completes the transfer before it
 // returns; with everything on one stream the order no longer rests on that (round 5: no null-stream call after finalize).
+// "pinned_copies" (SNN_AMD_PINNED_COPIES=1; an experiment for the next campaign, off by default): host <-> device copies never hand
+// the runtime a pageable pointer.  The device side of the transfer goes to / from a page-locked buffer of the handle -- a DMA
+// whose completion is the stream's -- and the bytes move between that buffer and the caller's memory by memcpy on the calling
+// thread.  What it excludes: the runtime's own staging of pageable copies, whose host-side half runs on a runtime thread
+// (campaign E, profiles/r05/README.md: under 24 worker processes on 16 cores one execution ended with two words of the oracle's
+// memory overwritten by what looks like a spike-raster word, another with a voltage history that did not match its own final state).
 inline hipError_t copy_sync(snn_network *net, void *dst, const void *src, size_t bytes, hipMemcpyKind kind)
 {
+    if (net->pinned_copies && bytes && (kind == hipMemcpyDeviceToHost || kind == hipMemcpyHostToDevice)) {
+        constexpr size_t STAGE = (size_t)8 << 20;
+        if (!net->copy_stage) {
+            const hipError_t e = hipHostMalloc(&net->copy_stage, STAGE, hipHostMallocDefault);
+            if (e != hipSuccess) return e;
+        }
+        for (size_t off = 0; off < bytes; off += STAGE) {
+            const size_t n = std::min(STAGE, bytes - off);
+            if (kind == hipMemcpyHostToDevice) memcpy(net->copy_stage, static_cast<const char *>(src) + off, n);
+            hipError_t e = hipMemcpyAsync(kind == hipMemcpyHostToDevice ? static_cast<char *>(dst) + off : static_cast<char *>(net->copy_stage),
+                                          kind == hipMemcpyHostToDevice ? static_cast<const char *>(net->copy_stage) : static_cast<const char *>(src) + off,
+                                          n, kind, net->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(net->stream);
+            if (e != hipSuccess) return e;
+            if (kind == hipMemcpyDeviceToHost) memcpy(static_cast<char *>(dst) + off, net->copy_stage, n);
+        }
+        return hipSuccess;
+    }
     const hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, net->stream);
     return e != hipSuccess ? e : hipStreamSynchronize(net->stream);
 }
