@@ -561,8 +561,8 @@ int snn_get_stat(snn_network_t *net, const char *name, uint64_t *value);
  * lays its snapshot out anew); snn_debug_verify_report names the array, word and the two values of the last mismatch (also
  * printed to stderr).  Option "run_resident_chunk_steps" [2^20]: steps per launch of the one-launch run (a run call of more steps
  * takes several launches, each with its own rollback point); "stdp_columns_form" [0] 1: the incoming-edge scatter of STDP with
- * one lane per 16-byte unit (k_stdp_columns_quads); "pinned_copies" [0] 1: every host <-> device copy of the setters and getters goes through a page-locked buffer of the
- * handle and a memcpy on the calling thread (the runtime never stages a pageable pointer); "stdp_small" [1]: dense unsharded networks of at most 1024 rows under STDP
+ * one lane per 16-byte unit (k_stdp_columns_quads); "pinned_copies" [1] every host <-> device copy of the setters and getters goes through a page-locked buffer of the
+ * handle and a memcpy on the calling thread (0: the runtime stages the caller's pageable pointer itself); "stdp_small" [1]: dense unsharded networks of at most 1024 rows under STDP
  * take spike compaction and both weight scatters of a step in ONE launch (k_stdp_small) instead of four. */
 const char *snn_debug_verify_report(snn_network_t *net);
 /* restore = 0: keeps a copy of everything a later run call reads (device arrays up to 256 MiB in all, the stepper's host-side

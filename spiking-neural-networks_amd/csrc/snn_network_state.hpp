@@ -285,7 +285,7 @@ struct snn_network {
     uint32_t verify_fault = 0;                  // option "verify_fault" (test hook): word + 1 of the exchange buffer (2^30 + word of the weights) to disturb once
     uint32_t *verify_buf = nullptr;             // the first outcome, laid out like snap_buf
     uint32_t *verify_report = nullptr;          // device words, see k_compare_table_alt
-    int pinned_copies = 0;                      // option "pinned_copies": see copy_sync
+    int pinned_copies = 1;                      // option "pinned_copies" [1]: see copy_sync (SNN_AMD_PINNED_COPIES=0: the runtime stages pageable pointers itself)
     void *copy_stage = nullptr;                 // its page-locked staging buffer (8 MiB, allocated with the first such copy)
     uint32_t *verify_third = nullptr;           // on a mismatch: the second outcome, while a third execution decides which one repeats
     size_t verify_third_words = 0;
@@ -417,7 +417,7 @@ inline hipError_t snn_malloc(T **out, size_t bytes)
 // for.  The handle's stream is hipStreamNonBlocking -- nothing orders it against the null stream -- so a blocking null-stream
 // hipMemcpy / hipMemset in front of a kernel on it is correct only as long as the runtime completes the transfer before it
 // returns; with everything on one stream the order no longer rests on that (round 5: no null-stream call after finalize).
-// "pinned_copies" (SNN_AMD_PINNED_COPIES=1; an experiment for the next campaign, off by default): host <-> device copies never hand
+// "pinned_copies" (on by default since the end of round 5; SNN_AMD_PINNED_COPIES=0 switches it off): host <-> device copies never hand
 // the runtime a pageable pointer.  The device side of the transfer goes to / from a page-locked buffer of the handle -- a DMA
 // whose completion is the stream's -- and the bytes move between that buffer and the caller's memory by memcpy on the calling
 // thread.  What it excludes: the runtime's own staging of pageable copies, whose host-side half runs on a runtime thread
