@@ -331,7 +331,9 @@ int snn_set_collectives(const snn_collectives *table);
  * this rank exchanges with -> snn_p2p_commit.  A rebuilt exchange plan (other synapse kinds, new halo lists) starts
  * unconnected again.  Failure: a value or a done counter that does not arrive within "halo_peer_spin_limit" polls ends the
  * run call with SNN_ERR_WAIT (the handle is then in the middle of a step; there is no roll-back across ranks).
- * Options: "halo_peer" [1] 0 keeps the collective on a connected handle.  Statistic: "halo_peer_steps".
+ * Options: "halo_peer" [1] 0 keeps the collective on a connected handle; "halo_peer_delay" [0] (tests) n = 1 .. 64: up to n sleeps
+ * of about 3 us, pseudo-random per call site and step, in front of the granule stores, the polls and the done announcements.
+ * Statistic: "halo_peer_steps".
  * Status: tested with 2 - 8 shard handles of ONE process on one GPU (tests/test_gpu_halo_peer.py) and with 2 - 4 PROCESSES on
  * one GPU through the IPC pair below (tests/test_gpu_two_processes.py, forms "*_peer"); across DEVICES (peer access over
  * xGMI) it has never run -- bench.py takes it only with --peer-form. */
@@ -560,7 +562,8 @@ int snn_get_stat(snn_network_t *net, const char *name, uint64_t *value);
  * counters -- fit a 64 MiB side copy; weight updates a previous call left deferred are applied first.  Statistics "verify_runs", "verify_mismatches", "verify_skipped" (the first one-launch run of a handle
  * lays its snapshot out anew); snn_debug_verify_report names the array, word and the two values of the last mismatch (also
  * printed to stderr).  Option "run_resident_chunk_steps" [2^20]: steps per launch of the one-launch run (a run call of more steps
- * takes several launches, each with its own rollback point); "stdp_columns_form" [0] 1: the incoming-edge scatter of STDP with
+ * takes several launches, each with its own rollback point); "verify_fault" (the self-check's own test hook) w + 1: word w of the
+ * exchange buffer, 2^30 + w: word w of the weights, disturbed once after the second pass; "stdp_columns_form" [0] 1: the incoming-edge scatter of STDP with
  * one lane per 16-byte unit (k_stdp_columns_quads); "pinned_copies" [1] every host <-> device copy of the setters and getters goes through a page-locked buffer of the
  * handle and a memcpy on the calling thread (0: the runtime stages the caller's pageable pointer itself); "stdp_small" [1]: dense unsharded networks of at most 1024 rows under STDP
  * take spike compaction and both weight scatters of a step in ONE launch (k_stdp_small) instead of four. */

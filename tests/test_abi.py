@@ -182,3 +182,18 @@ def test_ctypes_signatures_match_the_header():
                     f"{name}, parameter {i}: {t} bound as {a}"
             else:
                 assert a is _C_SCALARS[t], f"{name}, parameter {i}: {t} bound as {a}"
+
+
+def test_every_option_and_statistic_is_documented_in_the_header():
+    """snn_set_option / snn_get_stat names are part of the boundary: each name the library accepts appears, quoted, in the header"""
+    src = open(os.path.join(os.path.dirname(_lib.__file__), "csrc", "snn_network.hip")).read()
+    head = open(HEADER).read()
+    quoted = set(re.findall(r'"([a-z][a-z_0-9]+)"', head))
+    a, b = src.index("int snn_set_option"), src.index("int snn_get_stat")
+    options = set(re.findall(r'n == "([a-z_0-9]+)"', src[a:b]))
+    stats = set(re.findall(r'n == "([a-z_0-9]+)"', src[b:b + 12000]))
+    assert len(options) >= 25 and len(stats) >= 20
+    # (the header spells the run_timing_* family once: "run_timing_poll" / "_barrier" / "_turns" / "_update")
+    stats -= {"run_timing_barrier", "run_timing_turns", "run_timing_update"}
+    assert not (options - quoted), f"options the header does not name: {sorted(options - quoted)}"
+    assert not (stats - quoted), f"statistics the header does not name: {sorted(stats - quoted)}"
