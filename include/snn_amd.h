@@ -565,7 +565,8 @@ int snn_get_stat(snn_network_t *net, const char *name, uint64_t *value);
  * takes several launches, each with its own rollback point); "verify_fault" (the self-check's own test hook) w + 1: word w of the
  * exchange buffer, 2^30 + w: word w of the weights, disturbed once after the second pass; "stdp_columns_form" [0] 1: the incoming-edge scatter of STDP with
  * one lane per 16-byte unit (k_stdp_columns_quads); "pinned_copies" [1] every host <-> device copy of the setters and getters goes through a page-locked buffer of the
- * handle and a memcpy on the calling thread (0: the runtime stages the caller's pageable pointer itself); "stdp_small" [1]: dense unsharded networks of at most 1024 rows under STDP
+ * handle and a memcpy on the calling thread (0: the runtime stages the caller's pageable pointer itself; 2: the 2-D copies of
+ * the history and row transfers too -- written after the round's last GPU run, untested); "stdp_small" [1]: dense unsharded networks of at most 1024 rows under STDP
  * take spike compaction and both weight scatters of a step in ONE launch (k_stdp_small) instead of four. */
 const char *snn_debug_verify_report(snn_network_t *net);
 /* restore = 0: keeps a copy of everything a later run call reads (device arrays up to 256 MiB in all, the stepper's host-side

@@ -42,7 +42,7 @@ int snn_network_create(int device, int neuron_model, int nt_kinetics, int recept
     if (const char *e = getenv("SNN_AMD_FUSED_STEP")) net->fused_step = (e[0] != '0');
     if (const char *e = getenv("SNN_AMD_DENSE_CLOSE")) net->dense_close = (e[0] != '0');
     if (const char *e = getenv("SNN_AMD_DENSE_CLOSE_MAX_CHUNKS")) net->dense_close_max_chunks = (uint32_t)strtoul(e, nullptr, 10);
-    if (const char *e = getenv("SNN_AMD_PINNED_COPIES")) net->pinned_copies = (e[0] != '0');
+    if (const char *e = getenv("SNN_AMD_PINNED_COPIES")) net->pinned_copies = (e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1;
     if (const char *e = getenv("SNN_AMD_CSR_XCD_BANDS")) net->csr_xcd_bands = (e[0] != '0');
     if (const char *e = getenv("SNN_AMD_HALO_DIRECT")) net->halo_direct = (e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1;
     if (const char *e = getenv("SNN_AMD_UPDATE_PACKS")) net->update_packs = (e[0] != '0');
@@ -2151,7 +2151,7 @@ int snn_set_option(snn_network_t *net, const char *name, int value)
     if (net->finalized) TRY(end_run(net));            // pending deferred updates belong to the old setting
     const std::string n(name);
     if (n == "fused_step") net->fused_step = value != 0;
-    else if (n == "pinned_copies") net->pinned_copies = value != 0;
+    else if (n == "pinned_copies") net->pinned_copies = (value >= 0 && value <= 2) ? value : 1;
     else if (n == "dense_close") net->dense_close = value != 0;
     else if (n == "cells_in_step") net->cells_in_step = value != 0;
     else if (n == "update_packs") net->update_packs = value != 0;

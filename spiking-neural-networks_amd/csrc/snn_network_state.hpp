@@ -446,9 +446,36 @@ inline hipError_t copy_sync(snn_network *net, void *dst, const void *src, size_t
     const hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, net->stream);
     return e != hipSuccess ? e : hipStreamSynchronize(net->stream);
 }
+// ("pinned_copies" 2 -- not the default: written after the round's last GPU minute, so never run -- takes the 2-D copies of the
+// history and row getters / setters the same way: rows packed in the page-locked buffer, moved row by row on the calling thread)
 inline hipError_t copy2d_sync(snn_network *net, void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t height,
                               hipMemcpyKind kind)
 {
+    if (net->pinned_copies >= 2 && width && height && (kind == hipMemcpyDeviceToHost || kind == hipMemcpyHostToDevice)) {
+        constexpr size_t STAGE = (size_t)8 << 20;
+        if (width > STAGE) return hipErrorInvalidValue;
+        if (!net->copy_stage) {
+            const hipError_t e = hipHostMalloc(&net->copy_stage, STAGE, hipHostMallocDefault);
+            if (e != hipSuccess) return e;
+        }
+        const size_t rows_per_hop = std::max<size_t>(1, STAGE / width);
+        char *stage = static_cast<char *>(net->copy_stage);
+        for (size_t r = 0; r < height; r += rows_per_hop) {
+            const size_t rows = std::min(rows_per_hop, height - r);
+            hipError_t e;
+            if (kind == hipMemcpyHostToDevice) {
+                for (size_t i = 0; i < rows; ++i) memcpy(stage + i * width, static_cast<const char *>(src) + (r + i) * spitch, width);
+                e = hipMemcpy2DAsync(static_cast<char *>(dst) + r * dpitch, dpitch, stage, width, width, rows, kind, net->stream);
+            } else {
+                e = hipMemcpy2DAsync(stage, width, static_cast<const char *>(src) + r * spitch, spitch, width, rows, kind, net->stream);
+            }
+            if (e == hipSuccess) e = hipStreamSynchronize(net->stream);
+            if (e != hipSuccess) return e;
+            if (kind == hipMemcpyDeviceToHost)
+                for (size_t i = 0; i < rows; ++i) memcpy(static_cast<char *>(dst) + (r + i) * dpitch, stage + i * width, width);
+        }
+        return hipSuccess;
+    }
     const hipError_t e = hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, kind, net->stream);
     return e != hipSuccess ? e : hipStreamSynchronize(net->stream);
 }
