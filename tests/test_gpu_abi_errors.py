@@ -204,3 +204,29 @@ def test_counter_rows_check_their_range_before_they_allocate(snn):
     assert dn._L.snn_set_counter_rows(dn._h, 0, 0xFFFFFFF0, buf) == 10          # SNN_ERR_DIM_MISMATCH, not std::bad_alloc
     assert dn._L.snn_get_counter_rows(dn._h, 10, 0xFFFFFFF0, buf) == 10
     dn.close()
+
+
+@pytest.mark.parametrize("pinned", [0, 1])
+def test_setters_and_getters_agree_with_and_without_the_page_locked_buffer(snn, pinned):
+    """option "pinned_copies": the same bytes arrive whether a transfer goes through the handle's page-locked buffer (default) or the
+    caller's pointer is handed to the runtime (0)"""
+    dn = snn.DeviceNetwork(model=snn.IZHIKEVICH)
+    dn.add_lattice(0, 20, 30)
+    dn.finalize()
+    dn.set_option("pinned_copies", pinned)
+    n = 600
+    rng = np.random.default_rng(5)
+    v = rng.uniform(-70, 20, n).astype(np.float32)
+    dn.set_attr(0, "current_voltage", v)
+    assert np.array_equal(dn.get_attr(0, "current_voltage"), v)
+    flags = (rng.random((n, 3)) < 0.5).astype(np.uint32)
+    dn.set_attr(0, "neurotransmitters$flags", flags)
+    assert np.array_equal(dn.get_attr(0, "neurotransmitters$flags", dtype=np.uint32, per_type=True), flags)
+    dn.fill_graph_synthetic(3, 0.5, 1.5)
+    dn.set_synapses(True, False)
+    dn.set_history(voltage=True, spikes=True)
+    dn.run(12)
+    hist, spikes = dn.voltage_history(0), dn.spike_history(0)
+    assert hist.shape == (12, n) and spikes.shape == (12, n) and np.isfinite(hist).all()
+    assert np.array_equal(dn.get_attr(0, "current_voltage"), hist[-1])        # (a row of the history is the state after its step)
+    dn.close()
