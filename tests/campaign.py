@@ -135,6 +135,14 @@ def worker(args):
             log.flush()
             print(f"[worker {args.index}] ORACLE MEMORY CHANGED during {rec['oracle_memory_changed_during']} ({current[0]} seed {current[1]}): {rec}", flush=True)
         forget = install_oracle_guard(snn_amd, guard_record)
+    # the trap (tests/guard_arena.py): every host buffer the library sees ends at an inaccessible page and is retired to an
+    # inaccessible (or canary) state when its call returns; the oracle's arrays are read-only during library calls; a fault is
+    # reported with thread, pc and backtrace into <out>/guard-<pid>.log and the access completes
+    trap = None
+    if args.trap and not args.plain:
+        import guard_arena
+        trap = guard_arena.install(snn_amd, args.out)
+        trap_faults_seen = 0
     while time.time() < deadline and not os.path.exists(os.path.join(args.out, "stop")):
         if accept is None or accept(seed):
             for spec, fn in fns:
@@ -143,6 +151,8 @@ def worker(args):
                 counts[spec][0] += 1
                 current[0], current[1] = spec, seed
                 forget()
+                if trap is not None:
+                    trap.context = f"{spec.split(':')[1]} seed {seed}"
                 recent = (recent + [[spec, seed]])[-12:]
                 try:
                     fn(snn_amd, seed)
@@ -157,6 +167,18 @@ def worker(args):
                                           "traceback": traceback.format_exc()[-3000:]}) + "\n")
                     log.flush()
                     print(f"[worker {args.index}] FAILURE {spec} seed {seed}: {str(e)[:300]}", flush=True)
+                if trap is not None:
+                    for rec in trap.check():
+                        rec.update({"worker": args.index, "trap_report": True, "test": spec, "seed": seed})
+                        log.write(json.dumps(rec) + "\n")
+                        log.flush()
+                        print(f"[worker {args.index}] TRAP REPORT {spec} seed {seed}: {rec}", flush=True)
+                    if trap.faults() > trap_faults_seen:
+                        log.write(json.dumps({"worker": args.index, "trap_faults": trap.faults() - trap_faults_seen, "test": spec, "seed": seed,
+                                              "log": os.path.basename(trap.log_path)}) + "\n")
+                        log.flush()
+                        print(f"[worker {args.index}] TRAP FAULT during {spec} seed {seed}: see {trap.log_path}", flush=True)
+                        trap_faults_seen = trap.faults()
                 size = os.path.getsize(vlog) if os.path.exists(vlog) else 0
                 if size > vseen:
                     with open(vlog) as f:
@@ -171,6 +193,11 @@ def worker(args):
             print(f"[worker {args.index}] seed {seed} " + " ".join(f"{s.split(':')[1]}={c[0]}/{c[1]}" for s, c in counts.items()), flush=True)
             log.write(json.dumps({"worker": args.index, "progress": True, "counts": counts, "next_seed": seed}) + "\n")
             log.flush()
+    if trap is not None:
+        for rec in trap.check(everything=True):
+            rec.update({"worker": args.index, "trap_report": True, "test": "(end of the worker)", "seed": seed})
+            log.write(json.dumps(rec) + "\n")
+        log.write(json.dumps({"worker": args.index, "trap_stats": trap.stats()}) + "\n")
     log.write(json.dumps({"worker": args.index, "done": True, "counts": counts, "next_seed": seed,
                           "armed": {k: os.environ.get(k) for k in ("SNN_AMD_VERIFY", "MALLOC_PERTURB_", "SNN_HOST_POISON", "SNN_CHECKPOINTS")}}) + "\n")
     log.close()
@@ -211,6 +238,7 @@ def main():
     ap.add_argument("--streamer-pause-ms", type=float, default=0.0)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "campaign"))
     ap.add_argument("--plain", action="store_true", help="workers without the verify / malloc-perturb / host-poison arming")
+    ap.add_argument("--trap", type=int, default=1, help="armed workers also run the guard arena (tests/guard_arena.py)")
     args = ap.parse_args()
     os.makedirs(os.path.join(args.out, "repro"), exist_ok=True)
     if args.role == "worker":
@@ -248,7 +276,7 @@ def main():
                 p.kill()
                 rcs.append(p.wait())
     ras_after = checkpoint.ras_counters()
-    total, failures, verify_reports, guard_reports = {}, [], [], []
+    total, failures, verify_reports, guard_reports, trap_reports, trap_faults, trap_stats = {}, [], [], [], [], [], []
     for i in range(args.workers):
         path = os.path.join(args.out, f"worker-{i}.jsonl")
         latest = {}
@@ -260,6 +288,12 @@ def main():
                 verify_reports.append(rec)
             elif "oracle_memory_changed_during" in rec:
                 guard_reports.append(rec)
+            elif rec.get("trap_report"):
+                trap_reports.append(rec)
+            elif "trap_faults" in rec:
+                trap_faults.append(rec)
+            elif "trap_stats" in rec:
+                trap_stats.append(rec["trap_stats"])
             else:
                 failures.append({k: rec[k] for k in ("worker", "test", "seed", "error", "message", "preceding")})
         for spec, (n, f) in latest.items():
@@ -270,13 +304,16 @@ def main():
                "streamer_side": args.side, "tests": args.tests, "filter": args.filter, "first_seed": args.first_seed,
                "executions_and_failures": total, "executions": sum(t[0] for t in total.values()),
                "failures": sum(t[1] for t in total.values()), "failure_records": failures, "exit_codes": rcs,
-               "oracle_memory_reports": guard_reports[:50], "self_check_reports": len(verify_reports), "self_check_records": verify_reports[:200],
+               "oracle_memory_reports": guard_reports[:50], "trap_armed": bool(args.trap and not args.plain),
+               "trap_faults": sum(r["trap_faults"] for r in trap_faults), "trap_fault_records": trap_faults[:50], "trap_reports": trap_reports[:50],
+               "trap_calls": sum(t["calls"] for t in trap_stats), "trap_buffers_retired": sum(t["buffers_retired"] for t in trap_stats),
+               "self_check_reports": len(verify_reports), "self_check_records": verify_reports[:200],
                "environment": {k: v for k, v in worker_env.items() if k.startswith(("SNN_", "AMD_", "HIP_", "HSA_", "OMP_", "MALLOC_", "GPU_"))},
                "ras_errors_before_ue_ce": checkpoint.ras_totals(ras_before), "ras_errors_after_ue_ce": checkpoint.ras_totals(ras_after),
                "ras_before": ras_before, "ras_after": ras_after}
     with open(os.path.join(args.out, "summary.json"), "w") as f:
         json.dump(summary, f, indent=1)
-    print(json.dumps({k: summary[k] for k in ("wall_s", "executions", "failures", "executions_and_failures", "exit_codes")}))
+    print(json.dumps({k: summary[k] for k in ("wall_s", "executions", "failures", "trap_faults", "trap_calls", "executions_and_failures", "exit_codes")}))
 
 
 if __name__ == "__main__":
