@@ -336,11 +336,19 @@ def main():
                          "parallel.ShardedStepper (torch.distributed moves the segments)")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not bracket k_inputs_dense with HIP events (roofline.achieved is then null)")
-    ap.add_argument("--no-peer-form", action="store_true",
-                    help="--config c5, --gpus N > 1: do NOT try the peer form.  By default the ranks map each other's receive sets after the "
-                         "warm-up (IPC handles through torch.distributed) and step in the peer form -- one launch per step, no collective "
-                         "(include/snn_amd.h, snn_p2p_*) -- after a trial run; if any rank cannot connect or its trial gives up, EVERY rank "
-                         "keeps the collective (the line says which: peer_form)")
+    ap.add_argument("--peer-form", action="store_true",
+                    help="--config c5, --gpus N > 1: TRY the peer form of the sparse shard step.  The ranks map each other's receive sets "
+                         "after the warm-up (IPC handles through torch.distributed) and step in the peer form -- one launch per step, no "
+                         "collective (include/snn_amd.h, snn_p2p_*) -- after a trial run; if any rank cannot connect or its trial gives up, "
+                         "EVERY rank returns to the collective on a fresh handle (the line says which: peer_form).  Opt-in: the form has "
+                         "never run across devices (DESIGN.md section 6); the default is the RCCL halo exchange")
+    ap.add_argument("--no-peer-form", action="store_true", help="(the default since round 6; accepted for old command lines)")
+    ap.add_argument("--emulate-ranks-on-one-gpu", action="store_true",
+                    help="--gpus N > 1 on a box with ONE GPU: every rank is a process on device 0, the process group is gloo and the "
+                         "library's collectives go through host memory (parallel.ProcessCollectives).  A rehearsal of the multi-rank "
+                         "code path -- agreement, snn_run_sharded, peer-form trial, fall-back, checksums -- NOT a measurement: the line "
+                         "says so (transport) and its value means nothing")
+    ap.add_argument("--sabotage-peer-trial", type=int, default=-1, help=argparse.SUPPRESS)     # tests: this rank skips its trial run
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="--gpus N > 1: strong = the SAME network sharded N ways (default); weak = the network grows with N so that "
                          "every rank keeps the N = 1 share (c5 only: 4 lattices of 512 N x 512, 1 M neurons per rank)")
@@ -362,16 +370,23 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE)")
+    emulated = args.emulate_ranks_on_one_gpu
+    if emulated:
+        local_rank = 0                                   # every rank on device 0; nothing below may call RCCL
     if local_rank >= torch.cuda.device_count():          # (counting devices does not initialise the GPU)
         raise SystemExit(f"rank {rank}: --gpus {args.gpus} needs device {local_rank}, {torch.cuda.device_count()} visible")
     torch.cuda.set_device(local_rank)
     dist = None
     sharded = world > 1 or args.force_sharded
+    red = "cpu" if emulated else "cuda"                  # where the few scalars the ranks reduce live (gloo reduces host tensors)
     if sharded:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if emulated:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     dn, n, workload, kernel_name = build_config(args, snn_amd, synthetic, np, rank, world, local_rank)
 
@@ -382,12 +397,13 @@ def main():
         # If ANY rank cannot make its communicator, every rank falls back to the torch.distributed stepper (agreed on
         # through the process group, so that no rank is left alone in a collective).
         try:
-            comm = parallel.LibraryComm(rank, world, local_rank)
+            comm = (parallel.ProcessCollectives(dist, rank, world, torch.device("cuda", 0)) if emulated else
+                    parallel.LibraryComm(rank, world, local_rank))
             made = 1
         except Exception as e:          # noqa: BLE001
             print(f"[bench] rank {rank}: library communicator failed ({e}); falling back to --stepper torch", file=sys.stderr)
             made = 0
-        flag = torch.tensor([made], dtype=torch.int32, device="cuda")
+        flag = torch.tensor([made], dtype=torch.int32, device=red)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 0:
             if comm is not None:
@@ -424,63 +440,26 @@ def main():
         return sum(int(dn.spike_counts(i).sum()) for i, (_, _, st) in dn.lattices.items() if not st)
 
     run(args.warmup)
-    peer_note = None
-    if not args.no_peer_form and sharded and world > 1 and args.config == "c5" and comm is not None:
-        # The PEER form of the sparse shard step (one launch per step, no collective: include/snn_amd.h snn_p2p_*), TRIED, with a
-        # fallback every rank agrees on: (1) each rank maps its neighbours' receive sets through IPC handles and commits; if any
-        # rank could not, all keep the collective ("halo_peer" 0).  (2) A trial run over the peer form; a rank whose polls give up
-        # (SNN_ERR_WAIT) has left its handle mid-step, so if ANY rank failed every rank rebuilds its handle and keeps the
-        # collective.  The warm-up ran over the collective and left the halo lists committed.
-        def connect():
-            plan = dn.exchange_plan()
-            busy = int(plan["send_words"]) + int(plan["recv_words"]) > 0
-            mine, err = None, None
-            try:
-                if busy:
-                    loc = dn.p2p_local()
-                    mine = (dn.p2p_ipc_export(), [int(x) for x in loc["offsets"]], [int(x) for x in loc["counts"]])
-            except Exception as e:      # noqa: BLE001
-                err = repr(e)
-            everyone = [None] * world
-            dist.all_gather_object(everyone, (mine, err))
-            if any(e for _, e in everyone):
-                return next(e for _, e in everyone if e)
-            try:
-                for p in range(world):
-                    theirs = everyone[p][0]
-                    if busy and p != rank and theirs is not None and (theirs[2][rank] or mine[2][p]):
-                        r0, r1, fl = dn.p2p_ipc_import(theirs[0], device=local_rank)
-                        dn.p2p_connect(p, r0, r1, fl, theirs[1][rank])
-                if busy:
-                    dn.p2p_commit()
-            except Exception as e:      # noqa: BLE001
-                err = repr(e)
-            errs = [None] * world
-            dist.all_gather_object(errs, err)
-            return next((e for e in errs if e), None)
-
-        failed = connect()
-        if failed is None:
-            try:
-                run(8)
-                trial = None
-            except Exception as e:      # noqa: BLE001
-                trial = repr(e)
-            trials = [None] * world
-            dist.all_gather_object(trials, trial)
-            failed = next((t for t in trials if t), None)
-            if failed is not None:
-                # mid-step handles cannot be rolled back across ranks: start over on the collective
-                dn.close()
-                dn, n, workload, kernel_name = build_config(args, snn_amd, synthetic, np, rank, world, local_rank)
-                dn.set_option("halo_peer", 0)
-                dn.set_reduced_history(False, False, True)
-                run(args.warmup)
-        else:
-            dn.set_option("halo_peer", 0)
-        peer_note = "taken" if failed is None else f"fell back to the collective: {failed[:200]}"
-        dist.barrier()
+    peer_note, extra_steps = None, 0
+    if args.peer_form and args.config == "c5":
+        if sharded and world > 1 and comm is not None:
+            # parallel.try_peer_form: connect through IPC handles, a trial run, and -- if any rank could not -- every rank back on
+            # the collective with a FRESH handle that carries everything this one was given (drive, spike totals, warm-up)
+            def rebuild():
+                fresh, *_ = build_config(args, snn_amd, synthetic, np, rank, world, local_rank)
+                if args.spike_fraction > 0:
+                    fresh.set_synthetic_drive(12345, args.spike_fraction, 35.0)
+                fresh.set_reduced_history(False, False, True)
+                fresh.run_sharded(comm, args.warmup)
+                return fresh
+            dn, peer_note = parallel.try_peer_form(dn, dist, rank, world, local_rank, run, rebuild,
+                                                   sabotage_rank=args.sabotage_peer_trial if args.sabotage_peer_trial >= 0 else None)
+        # the step count of the line does not depend on the outcome, nor on N: a completed trial is 8 steps, then a second warm-up
+        if peer_note != "taken":
+            run(8)
+        barrier()
         run(args.warmup)
+        extra_steps = 8 + args.warmup
     spikes_before = own_spike_total()
     # HIP events around the dominant kernel: inside the timed region for the streaming configs with ms-scale steps (2 event
     # records per step are noise next to a 2.5 - 13 ms step); for the short-step configs (c1: 4 us, c5: 43 us, c3: 0.19 ms per
@@ -501,14 +480,14 @@ def main():
         barrier()
         e = time.perf_counter() - t0
         if dist is not None:
-            t = torch.tensor([e], dtype=torch.float64, device="cuda")
+            t = torch.tensor([e], dtype=torch.float64, device=red)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             e = float(t.item())
         runs.append(e)
         if len(runs) == max(1, args.repeats):
             # N = 1 and N = 8 lines can be diffed: a checksum of the network's state right after the --repeats repetitions asked
             # for (the same number of steps for every N, whatever is added below), every rank's own neurons gathered to rank 0
-            state_sha, state_steps = state_checksum(dn, np, dist, rank, world), args.warmup + args.steps * len(runs)
+            state_sha, state_steps = state_checksum(dn, np, dist, rank, world), args.warmup + extra_steps + args.steps * len(runs)
     elapsed = sorted(runs)[len(runs) // 2]
     phases = None
     if events_after:
@@ -528,7 +507,7 @@ def main():
     dn.profile_enable(False)
     spikes = (spikes_timed if events_after else own_spike_total()) - spikes_before           # of this rank's own neurons
     if dist is not None:
-        t = torch.tensor([spikes], dtype=torch.float64, device="cuda")
+        t = torch.tensor([spikes], dtype=torch.float64, device=red)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         spikes = int(t.item())
     total_steps = args.steps * len(runs)
@@ -562,6 +541,29 @@ def main():
         spiking_value = {"value": n * dsteps / dt_drive, "spikes_per_step": (own_spike_total() - before) / dsteps,
                          "what": "0.1 % of the neurons raised above threshold before every step (snn_set_synthetic_drive)"}
         dn.set_synthetic_drive(12345, 0.0, 35.0)
+
+    # per-rank clocks (first contact with a multi-GPU node: which rank is slow, and how much of a step is the exchange): every
+    # rank's own time for --steps steps of the full step, and -- collective form -- of the same loop with a transport that moves
+    # nothing (snn_exchange_noop; the state is stale afterwards, which is why this comes after the checksum)
+    rank_times = None
+    if sharded and world > 1 and comm is not None:
+        barrier()
+        t0 = time.perf_counter()
+        run(args.steps)
+        torch.cuda.synchronize()
+        full_ms = (time.perf_counter() - t0) / args.steps * 1e3
+        only_ms = None
+        if peer_note != "taken":
+            barrier()
+            t0 = time.perf_counter()
+            dn.run_sharded_without_exchange(args.steps)
+            torch.cuda.synchronize()
+            only_ms = (time.perf_counter() - t0) / args.steps * 1e3
+        parts = [None] * world
+        dist.all_gather_object(parts, (full_ms, only_ms))
+        rank_times = {"step_ms_by_rank": [a for a, _ in parts],
+                      "compute_only_ms_by_rank": [b for _, b in parts] if only_ms is not None else None,
+                      "exchange_ms_by_rank": [a - b for a, b in parts] if only_ms is not None else None}
 
     ceilings = None
     if rank == 0 and not sharded and args.config == "c2":
@@ -600,8 +602,10 @@ def main():
             "scaling": args.scaling,
             "stepper": (("library (snn_run_sharded, RCCL called by libsnn_amd.so)" if comm is not None else
                          "torch (parallel.ShardedStepper, torch.distributed moves the segments)") if sharded else None),
-            "rccl_ranks": rccl_ranks, "exchange_bytes_per_rank_step": exchange_bytes,
-            "halo_peer_steps": (dn.stat("halo_peer_steps") if sharded else None), "peer_form": peer_note,
+            "rccl_ranks": None if emulated else rccl_ranks, "exchange_bytes_per_rank_step": exchange_bytes,
+            "transport": ("EMULATION: every rank a process on ONE GPU, collectives through host memory and gloo -- not a measurement"
+                          if emulated else ("RCCL" if sharded else None)),
+            "halo_peer_steps": (dn.stat("halo_peer_steps") if sharded else None), "peer_form": peer_note, "rank_times": rank_times,
             "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "neurons": n,

@@ -573,6 +573,12 @@ const char *snn_debug_verify_report(snn_network_t *net);
  * cursors) in host memory; restore = 1 puts it back -- the SAME call can then be executed again from identical inputs.  Valid
  * while the handle's structure is unchanged (run calls, attribute and weight writes in between are fine). */
 int snn_debug_checkpoint(snn_network_t *net, int restore);
+/* Error-path test hook: the n-th allocation the library makes from this call on -- device memory, page-locked memory or a
+ * host-side table -- fails once (hipErrorOutOfMemory / std::bad_alloc inside, a status code outside: no exception crosses this
+ * ABI, every entry point is a function-try-block); n <= 0 disarms.  Process-wide.  *allocations_so_far (may be null) receives
+ * the number of allocations made since the library was loaded, so that a test can walk n over exactly the allocations of a
+ * call sequence.  Environment: SNN_AMD_FAIL_ALLOC_AT=n arms it at load time. */
+int snn_debug_fail_alloc_at(int64_t n, uint64_t *allocations_so_far);
 
 /* ---- measurement ----------------------------------------------------------------------- */
 

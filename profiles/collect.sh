@@ -72,7 +72,8 @@ python3 bench.py --config c1 --no-cpu-baseline > "$OUT/c1_bench_default.json" 2>
 python3 bench.py --config c3 --no-cpu-baseline > "$OUT/c3_bench_default.json" 2> /dev/null
 # round 5: C3 in four fresh processes, with and without the closing input pass; C4 with 1 % of the neurons spiking; small plastic lattices
 for i in 1 2 3 4; do python3 bench.py --config c3 --no-cpu-baseline > "$OUT/c3_fresh_process_$i.json" 2> /dev/null; done
-for i in 1 2; do SNN_AMD_DENSE_CLOSE=0 python3 bench.py --config c3 --no-cpu-baseline > "$OUT/c3_two_kernels_process_$i.json" 2> /dev/null; done
+# (the two-kernel step is the default -- the four lines above; this arm is the closing pass, option "dense_close" 1)
+for i in 1 2; do SNN_AMD_DENSE_CLOSE=1 python3 bench.py --config c3 --no-cpu-baseline > "$OUT/c3_closing_pass_process_$i.json" 2> /dev/null; done
 python3 bench.py --config c4 --spike-fraction 0.01 --steps 50 --warmup 100 --repeats 2 --no-cpu-baseline > "$OUT/c4_spiking_1pct_bench.json" 2> /dev/null
 python3 profiles/measure_small_plastic.py 3000 > "$OUT/small_plastic_lattices.jsonl" 2> /dev/null
 fi

@@ -75,7 +75,13 @@ def _build_one(out, cmd_tail, digest, force, what):
         print(f"[snn_amd build] reused {what}: {os.path.relpath(out)} source_sha256={digest[:16]} hipcc=\"{hipcc_version()}\"", file=sys.stderr)
         return out
     why = "forced" if force else ("no library" if not os.path.exists(out) else ("no hash on record" if have is None else "sources changed"))
-    tmp = out + ".tmp"
+    if not force and os.path.exists(out) and have is not None and hipcc_version() == "unknown":
+        # no compiler on this box (a pushed, prebuilt library): the version is part of the hash, so it can never match -- the
+        # library on disk is all there is; say so instead of failing in a compile that cannot start
+        print(f"[snn_amd build] reused {what} WITHOUT a compiler to check it against: {os.path.relpath(out)} recorded={have[:16]} "
+              f"(hipcc not found: {_hipcc()})", file=sys.stderr)
+        return out
+    tmp = out + ".tmp.%d" % os.getpid()        # (concurrent builders -- campaign workers -- never write each other's file)
     subprocess.run([_hipcc()] + HIPCC_FLAGS + cmd_tail + ["-o", tmp, os.path.join(CSRC, "snn_network.hip")], check=True, cwd=CSRC)
     # the sources may have been edited while the compiler ran: the hash on record is the one taken BEFORE the compile
     # started only if they still hash the same now; otherwise the library is kept but marked stale (no hash)
@@ -259,6 +265,7 @@ SIGNATURES = {
     "snn_get_stat": (C.c_int, [H, C.c_char_p, u64p]),
     "snn_debug_verify_report": (C.c_char_p, [H]),
     "snn_debug_checkpoint": (C.c_int, [H, C.c_int]),
+    "snn_debug_fail_alloc_at": (C.c_int, [C.c_int64, u64p]),
     "snn_profile_enable": (C.c_int, [H, C.c_int]),
     "snn_profile_reset": (C.c_int, [H]),
     "snn_profile_read": (C.c_int, [H, u64p, C.POINTER(C.c_double)]),

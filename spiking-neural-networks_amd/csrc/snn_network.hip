@@ -10,17 +10,17 @@
 // ================================================================================================
 extern "C" {
 
-int snn_abi_version(void) { return SNN_ABI_VERSION; }
-const char *snn_custom_model(void) { return custom::TYPE_NAME; }
-const char *snn_custom_spike_train(void) { return custom_st::TYPE_NAME; }
-const char *snn_custom_refractoriness(void) { return custom_refr::TYPE_NAME; }
-const char *snn_custom_neurotransmitter_kinetics(void) { return custom_nt::TYPE_NAME; }
-const char *snn_custom_receptor_kinetics(void) { return custom_rc::TYPE_NAME; }
-const char *snn_custom_receptors(void) { return custom_receptors::TYPE_NAME; }
-const char *snn_last_error(void) { return g_last_error.c_str(); }
+int snn_abi_version(void) ABI_TRY { return SNN_ABI_VERSION; } ABI_CATCH
+const char *snn_custom_model(void) ABI_TRY { return custom::TYPE_NAME; } ABI_CATCH_PTR
+const char *snn_custom_spike_train(void) ABI_TRY { return custom_st::TYPE_NAME; } ABI_CATCH_PTR
+const char *snn_custom_refractoriness(void) ABI_TRY { return custom_refr::TYPE_NAME; } ABI_CATCH_PTR
+const char *snn_custom_neurotransmitter_kinetics(void) ABI_TRY { return custom_nt::TYPE_NAME; } ABI_CATCH_PTR
+const char *snn_custom_receptor_kinetics(void) ABI_TRY { return custom_rc::TYPE_NAME; } ABI_CATCH_PTR
+const char *snn_custom_receptors(void) ABI_TRY { return custom_receptors::TYPE_NAME; } ABI_CATCH_PTR
+const char *snn_last_error(void) ABI_TRY { return g_last_error.c_str(); } ABI_CATCH_PTR
 
 int snn_network_create(int device, int neuron_model, int nt_kinetics, int receptor_kinetics,
-                       int spike_train_model, snn_network_t **out)
+                       int spike_train_model, snn_network_t **out) ABI_TRY
 {
     if (!out) return fail(SNN_ERR_BAD_ARG, "out is null");
     *out = nullptr;
@@ -69,8 +69,9 @@ int snn_network_create(int device, int neuron_model, int nt_kinetics, int recept
     *out = net;
     return SNN_OK;
 }
+ABI_CATCH
 
-int snn_network_destroy(snn_network_t *net)
+int snn_network_destroy(snn_network_t *net) ABI_TRY
 {
     if (!net) return SNN_OK;
     (void)hipSetDevice(net->device);
@@ -119,6 +120,7 @@ int snn_network_destroy(snn_network_t *net)
     delete net;
     return SNN_OK;
 }
+ABI_CATCH
 
 static int add_lattice_impl(snn_network_t *net, uint32_t id, uint32_t rows, uint32_t cols, bool st)
 {
@@ -133,14 +135,16 @@ static int add_lattice_impl(snn_network_t *net, uint32_t id, uint32_t rows, uint
     return SNN_OK;
 }
 
-int snn_network_add_lattice(snn_network_t *net, uint32_t id, uint32_t rows, uint32_t cols)
+int snn_network_add_lattice(snn_network_t *net, uint32_t id, uint32_t rows, uint32_t cols) ABI_TRY
 {
     return add_lattice_impl(net, id, rows, cols, false);
 }
-int snn_network_add_spike_train_lattice(snn_network_t *net, uint32_t id, uint32_t rows, uint32_t cols)
+ABI_CATCH
+int snn_network_add_spike_train_lattice(snn_network_t *net, uint32_t id, uint32_t rows, uint32_t cols) ABI_TRY
 {
     return add_lattice_impl(net, id, rows, cols, true);
 }
+ABI_CATCH
 
 // kind: 0 whole population, 1 contiguous shard [post_begin, post_end), 2 by lattice (slab shard_index of every lattice)
 static int finalize_impl(snn_network_t *net, int kind, uint32_t post_begin, uint32_t post_end, uint32_t n_shards,
@@ -191,8 +195,8 @@ static int finalize_impl(snn_network_t *net, int kind, uint32_t post_begin, uint
         net->block_mode = true;
         net->lattice_slab.assign(net->lattices.size(), 64);
         net->local_row_host.assign(net->n_pad, 0xFFFFFFFFu);
-        std::vector<uint32_t> blocks;
-        std::vector<unsigned long long> masks;
+        hvec<uint32_t> blocks;
+        hvec<unsigned long long> masks;
         net->n_owned = 0;
         for (const auto &l : net->lattices) {
             const uint32_t slab = std::max<uint32_t>(64, round_up((l.count + n_shards - 1) / n_shards, 64));
@@ -237,17 +241,18 @@ static int finalize_impl(snn_network_t *net, int kind, uint32_t post_begin, uint
     return SNN_OK;
 }
 
-int snn_network_finalize(snn_network_t *net) { return finalize_impl(net, 0, 0, 0, 1, 0, 0); }
+int snn_network_finalize(snn_network_t *net) ABI_TRY { return finalize_impl(net, 0, 0, 0, 1, 0, 0); } ABI_CATCH
 
-int snn_network_finalize_shard_by_lattice(snn_network_t *net, uint32_t shard_index, uint32_t n_shards)
+int snn_network_finalize_shard_by_lattice(snn_network_t *net, uint32_t shard_index, uint32_t n_shards) ABI_TRY
 {
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
     if (n_shards == 0 || shard_index >= n_shards) return fail(SNN_ERR_BAD_ARG, "shard_index must be < n_shards");
     if (!net->csr) return fail(SNN_ERR_BAD_STATE, "sharding by lattice needs a sparse handle: call snn_network_use_csr first");
     return finalize_impl(net, 2, 0, 0, n_shards, 64, shard_index);
 }
+ABI_CATCH
 
-int snn_shard_ranges(const snn_network_t *net, uint32_t *begin, uint32_t *end, uint32_t capacity, uint32_t *count)
+int snn_shard_ranges(const snn_network_t *net, uint32_t *begin, uint32_t *end, uint32_t capacity, uint32_t *count) ABI_TRY
 {
     if (!net || !count) return fail(SNN_ERR_BAD_ARG, "null argument");
     if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
@@ -256,8 +261,9 @@ int snn_shard_ranges(const snn_network_t *net, uint32_t *begin, uint32_t *end, u
         for (size_t i = 0; i < net->ranges.size(); ++i) { begin[i] = net->ranges[i].first; end[i] = net->ranges[i].second; }
     return SNN_OK;
 }
+ABI_CATCH
 
-int snn_network_finalize_shard(snn_network_t *net, uint32_t shard_index, uint32_t n_shards)
+int snn_network_finalize_shard(snn_network_t *net, uint32_t shard_index, uint32_t n_shards) ABI_TRY
 {
     // equal slots: stride = ceil(n_neurons / n_shards) rounded up to a wavefront (64 neurons); shard r owns
     // neurons [r*stride, min(n, (r+1)*stride)) -- trailing shards may be short or empty
@@ -270,9 +276,10 @@ int snn_network_finalize_shard(snn_network_t *net, uint32_t shard_index, uint32_
     const uint32_t end = (uint32_t)std::min<uint64_t>(nn, (uint64_t)begin + stride);
     return finalize_impl(net, 1, begin, end, n_shards, stride, shard_index);
 }
+ABI_CATCH
 
 int snn_network_sizes(const snn_network_t *net, uint32_t *n_neurons, uint32_t *n_cells, uint32_t *post_begin,
-                      uint32_t *post_end)
+                      uint32_t *post_end) ABI_TRY
 {
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
     if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
@@ -282,8 +289,9 @@ int snn_network_sizes(const snn_network_t *net, uint32_t *n_neurons, uint32_t *n
     if (post_end) *post_end = net->q1;
     return SNN_OK;
 }
+ABI_CATCH
 
-int snn_network_lattice_range(const snn_network_t *net, uint32_t id, uint32_t *first, uint32_t *count)
+int snn_network_lattice_range(const snn_network_t *net, uint32_t id, uint32_t *first, uint32_t *count) ABI_TRY
 {
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
     if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
@@ -293,34 +301,43 @@ int snn_network_lattice_range(const snn_network_t *net, uint32_t id, uint32_t *f
     if (count) *count = l->count;
     return SNN_OK;
 }
+ABI_CATCH
 
-int snn_set_attr_f32(snn_network_t *net, uint32_t id, const char *name, const float *src, size_t count)
+int snn_set_attr_f32(snn_network_t *net, uint32_t id, const char *name, const float *src, size_t count) ABI_TRY
 { return attr_io(net, id, name, T_F32, const_cast<float *>(src), count, true); }
-int snn_get_attr_f32(snn_network_t *net, uint32_t id, const char *name, float *dst, size_t count)
+ABI_CATCH
+int snn_get_attr_f32(snn_network_t *net, uint32_t id, const char *name, float *dst, size_t count) ABI_TRY
 { return attr_io(net, id, name, T_F32, dst, count, false); }
-int snn_set_attr_u32(snn_network_t *net, uint32_t id, const char *name, const uint32_t *src, size_t count)
+ABI_CATCH
+int snn_set_attr_u32(snn_network_t *net, uint32_t id, const char *name, const uint32_t *src, size_t count) ABI_TRY
 { return attr_io(net, id, name, T_U32, const_cast<uint32_t *>(src), count, true); }
-int snn_get_attr_u32(snn_network_t *net, uint32_t id, const char *name, uint32_t *dst, size_t count)
+ABI_CATCH
+int snn_get_attr_u32(snn_network_t *net, uint32_t id, const char *name, uint32_t *dst, size_t count) ABI_TRY
 { return attr_io(net, id, name, T_U32, dst, count, false); }
-int snn_set_attr_i32(snn_network_t *net, uint32_t id, const char *name, const int32_t *src, size_t count)
+ABI_CATCH
+int snn_set_attr_i32(snn_network_t *net, uint32_t id, const char *name, const int32_t *src, size_t count) ABI_TRY
 { return attr_io(net, id, name, T_I32, const_cast<int32_t *>(src), count, true); }
-int snn_get_attr_i32(snn_network_t *net, uint32_t id, const char *name, int32_t *dst, size_t count)
+ABI_CATCH
+int snn_get_attr_i32(snn_network_t *net, uint32_t id, const char *name, int32_t *dst, size_t count) ABI_TRY
 { return attr_io(net, id, name, T_I32, dst, count, false); }
+ABI_CATCH
 
 int snn_set_graph_rows(snn_network_t *net, uint32_t pre_begin, uint32_t pre_count, const float *weights,
-                       const uint32_t *connections)
+                       const uint32_t *connections) ABI_TRY
 {
     if (net) net->cross_checked = false;
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
     return graph_rows_io(net, pre_begin, pre_count, const_cast<float *>(weights),
                          const_cast<uint32_t *>(connections), net->nn, true);
 }
-int snn_get_graph_rows(snn_network_t *net, uint32_t pre_begin, uint32_t pre_count, float *weights, uint32_t *connections)
+ABI_CATCH
+int snn_get_graph_rows(snn_network_t *net, uint32_t pre_begin, uint32_t pre_count, float *weights, uint32_t *connections) ABI_TRY
 {
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
     return graph_rows_io(net, pre_begin, pre_count, weights, connections, net->nn, false);
 }
-int snn_set_graph_dense(snn_network_t *net, const float *weights, const uint32_t *connections, size_t n_tot)
+ABI_CATCH
+int snn_set_graph_dense(snn_network_t *net, const float *weights, const uint32_t *connections, size_t n_tot) ABI_TRY
 {
     if (net) net->cross_checked = false;
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
@@ -329,15 +346,17 @@ int snn_set_graph_dense(snn_network_t *net, const float *weights, const uint32_t
     return graph_rows_io(net, 0, net->n_tot, const_cast<float *>(weights), const_cast<uint32_t *>(connections),
                          net->n_tot, true);
 }
-int snn_get_graph_dense(snn_network_t *net, float *weights, uint32_t *connections, size_t n_tot)
+ABI_CATCH
+int snn_get_graph_dense(snn_network_t *net, float *weights, uint32_t *connections, size_t n_tot) ABI_TRY
 {
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
     if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
     if (n_tot != net->n_tot) return fail(SNN_ERR_DIM_MISMATCH, "graph size does not match the network");
     return graph_rows_io(net, 0, net->n_tot, weights, connections, net->n_tot, false);
 }
+ABI_CATCH
 
-int snn_fill_graph_synthetic(snn_network_t *net, uint64_t seed, float lo, float hi, int with_diagonal)
+int snn_fill_graph_synthetic(snn_network_t *net, uint64_t seed, float lo, float hi, int with_diagonal) ABI_TRY
 {
     if (net) net->cross_checked = false;
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
@@ -357,14 +376,16 @@ int snn_fill_graph_synthetic(snn_network_t *net, uint64_t seed, float lo, float 
     net->counts_dirty = true;
     return SNN_OK;
 }
+ABI_CATCH
 
-int snn_network_use_csr(snn_network_t *net, int enable)
+int snn_network_use_csr(snn_network_t *net, int enable) ABI_TRY
 {
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
     if (net->finalized) return fail(SNN_ERR_BAD_STATE, "the graph form is fixed at finalize");
     net->csr = enable != 0;
     return SNN_OK;
 }
+ABI_CATCH
 
 namespace { int ensure_traces(snn_network *net); int ensure_pending(snn_network *net); }
 
@@ -383,7 +404,7 @@ static int set_graph_csr_impl(snn_network_t *net, const uint64_t *row_ptr, const
     auto local = [&](uint32_t k) { return net->block_mode ? net->owned_local_host[k] : k; };
     if (row_ptr[0] != 0 || row_ptr[n_rows] != nnz) return fail(SNN_ERR_DIM_MISMATCH, "row_ptr must run from 0 to nnz");
     const uint32_t n_slices = (n_loc + 63) / 64;
-    std::vector<uint32_t> slice_ptr((size_t)n_slices + 1, 0), row_len((size_t)n_slices * 64, 0), post(nnz),
+    hvec<uint32_t> slice_ptr((size_t)n_slices + 1, 0), row_len((size_t)n_slices * 64, 0), post(nnz),
         t_ptr((size_t)net->n_tot + 1, 0), t_edge(nnz), edge_slot(nnz);
     for (uint32_t k = 0; k < n_rows; ++k) {
         const uint32_t q = local(k);
@@ -409,8 +430,8 @@ static int set_graph_csr_impl(snn_network_t *net, const uint64_t *row_ptr, const
         if (entries >= 0xFFFFFFFFull) return fail(SNN_ERR_DIM_MISMATCH, "sparse graph too large for 32-bit slots");
     }
     slice_ptr[n_slices] = (uint32_t)entries;
-    std::vector<uint32_t> sell_pre(entries, SELL_PAD);
-    std::vector<float> sell_w(entries, 0.0f);
+    hvec<uint32_t> sell_pre(entries, SELL_PAD);
+    hvec<float> sell_w(entries, 0.0f);
     for (uint32_t k = 0; k < n_rows; ++k) {
         const uint32_t q = local(k);
         const uint32_t base = slice_ptr[q >> 6] + (q & 63u);
@@ -423,7 +444,7 @@ static int set_graph_csr_impl(snn_network_t *net, const uint64_t *row_ptr, const
     }
     for (size_t p = 0; p < net->n_tot; ++p) t_ptr[p + 1] += t_ptr[p];
     {
-        std::vector<uint32_t> fill(t_ptr.begin(), t_ptr.end() - 1);
+        hvec<uint32_t> fill(t_ptr.begin(), t_ptr.end() - 1);
         for (uint64_t e = 0; e < nnz; ++e) t_edge[fill[pre_index[e]]++] = (uint32_t)e;
     }
     HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
@@ -464,7 +485,7 @@ static int set_graph_csr_impl(snn_network_t *net, const uint64_t *row_ptr, const
     halo_needs_from_rows(net, pre_index, nnz);      // the new rows decide what is read from the other shards
     if (net->sharded && net->n_shards > 1 && net->nc) {
         // ... and which spike-train cells this rank reads at all
-        std::vector<uint8_t> seen(net->nc, 0);
+        hvec<uint8_t> seen(net->nc, 0);
         for (uint64_t e = 0; e < nnz; ++e)
             if (pre_index[e] >= net->nn) seen[pre_index[e] - net->nn] = 1;
         net->cell_list_host.clear();
@@ -481,7 +502,7 @@ static int set_graph_csr_impl(snn_network_t *net, const uint64_t *row_ptr, const
 }
 
 int snn_set_graph_csr(snn_network_t *net, const uint64_t *row_ptr, const uint32_t *pre_index, const float *weights,
-                      uint64_t nnz)
+                      uint64_t nnz) ABI_TRY
 {
     try {
         return set_graph_csr_impl(net, row_ptr, pre_index, weights, nnz);
@@ -489,8 +510,9 @@ int snn_set_graph_csr(snn_network_t *net, const uint64_t *row_ptr, const uint32_
         return fail(SNN_ERR_BUFFER_CREATE, "out of host memory while building the sparse graph");
     }
 }
+ABI_CATCH
 
-int snn_get_graph_csr(snn_network_t *net, float *weights, uint64_t nnz)
+int snn_get_graph_csr(snn_network_t *net, float *weights, uint64_t nnz) ABI_TRY
 {
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
     if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
@@ -500,13 +522,14 @@ int snn_get_graph_csr(snn_network_t *net, float *weights, uint64_t nnz)
     if (!weights) return fail(SNN_ERR_BAD_ARG, "weights is null");
     HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
     TRY(end_run(net));
-    std::vector<float> sell((size_t)net->sell_entries);
+    hvec<float> sell((size_t)net->sell_entries);
     HIP_TRY(copy_sync(net, sell.data(), net->csr_w, sell.size() * 4, hipMemcpyDeviceToHost), SNN_ERR_BUFFER_READ);
     for (uint64_t e = 0; e < nnz; ++e) weights[e] = sell[net->edge_slot_host[e]];
     return SNN_OK;
 }
+ABI_CATCH
 
-int snn_set_synapses(snn_network_t *net, int electrical_synapse, int chemical_synapse)
+int snn_set_synapses(snn_network_t *net, int electrical_synapse, int chemical_synapse) ABI_TRY
 {
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
     net->electrical = electrical_synapse ? 1 : 0;
@@ -514,9 +537,10 @@ int snn_set_synapses(snn_network_t *net, int electrical_synapse, int chemical_sy
     net->x_dirty = true;                 // which planes travel between shards follows the synapse kinds
     return SNN_OK;
 }
+ABI_CATCH
 
 int snn_set_plasticity(snn_network_t *net, uint32_t id, float a_plus, float a_minus, float tau_plus,
-                       float tau_minus, float dt, int do_plasticity)
+                       float tau_minus, float dt, int do_plasticity) ABI_TRY
 {
     if (net) net->cross_checked = false;
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
@@ -535,8 +559,9 @@ int snn_set_plasticity(snn_network_t *net, uint32_t id, float a_plus, float a_mi
     HIP_TRY(copy_sync(net, net->plast_dev, net->plast_host.data(), net->plast_host.size() * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
     return SNN_OK;
 }
+ABI_CATCH
 
-int snn_set_bcm(snn_network_t *net, uint32_t id, float decay, float average_scalar, float dt, int do_plasticity)
+int snn_set_bcm(snn_network_t *net, uint32_t id, float decay, float average_scalar, float dt, int do_plasticity) ABI_TRY
 {
     if (net) net->cross_checked = false;
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
@@ -558,6 +583,7 @@ int snn_set_bcm(snn_network_t *net, uint32_t id, float decay, float average_scal
     HIP_TRY(copy_sync(net, net->plast_dev, net->plast_host.data(), net->plast_host.size() * 4, hipMemcpyHostToDevice), SNN_ERR_BUFFER_WRITE);
     return SNN_OK;
 }
+ABI_CATCH
 
 namespace {
 size_t trace_elems(const snn_network *net) { return net->csr ? (size_t)net->sell_entries : wcount(net->n_tot, net->ld); }
@@ -597,7 +623,7 @@ int ensure_traces(snn_network *net)
     if (!net->csr && n * 4 >= ((size_t)1 << 30)) {
         float best = 0.0f;
         int rc = time_rw_pass(net, net->trace, n / 4, &best);
-        std::vector<void *> losers;
+        hvec<void *> losers;
         for (int cand = 0; cand < 3 && rc == SNN_OK; ++cand) {
             size_t free_b = 0, total_b = 0;
             void *b = nullptr;
@@ -623,7 +649,7 @@ int ensure_traces(snn_network *net)
 } // namespace
 
 int snn_set_reward_modulator(snn_network_t *net, uint32_t id, float dopamine, float tau_d, float tau_c, float a_plus,
-                             float a_minus, float tau_plus, float tau_minus, float dt, int do_modulation)
+                             float a_minus, float tau_plus, float tau_minus, float dt, int do_modulation) ABI_TRY
 {
     if (net) net->cross_checked = false;
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
@@ -660,8 +686,9 @@ int snn_set_reward_modulator(snn_network_t *net, uint32_t id, float dopamine, fl
     HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
     return SNN_OK;
 }
+ABI_CATCH
 
-int snn_get_dopamine(snn_network_t *net, uint32_t id, float *dopamine)
+int snn_get_dopamine(snn_network_t *net, uint32_t id, float *dopamine) ABI_TRY
 {
     if (!net || !dopamine) return fail(SNN_ERR_BAD_ARG, "null pointer");
     if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
@@ -672,8 +699,9 @@ int snn_get_dopamine(snn_network_t *net, uint32_t id, float *dopamine)
     HIP_TRY(copy_sync(net, dopamine, net->rm_dev + (size_t)l->slot * RM_STRIDE, 4, hipMemcpyDeviceToHost), SNN_ERR_BUFFER_READ);
     return SNN_OK;
 }
+ABI_CATCH
 
-int snn_apply_reward(snn_network_t *net, float reward)
+int snn_apply_reward(snn_network_t *net, float reward) ABI_TRY
 {
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
     if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
@@ -688,14 +716,16 @@ int snn_apply_reward(snn_network_t *net, float reward)
     HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
     return SNN_OK;
 }
+ABI_CATCH
 
-int snn_run_with_reward(snn_network_t *net, float reward)
+int snn_run_with_reward(snn_network_t *net, float reward) ABI_TRY
 {
     // run_lattice_with_reward does nothing at all with both synapse kinds off (neuron/mod.rs:3250-3257)
     if (net && net->finalized && !net->electrical && !net->chemical) return SNN_OK;
     int rc = snn_apply_reward(net, reward);
     return rc ? rc : snn_run(net, 1);
 }
+ABI_CATCH
 
 // TraceRSTDP::c of the edges in presynaptic rows [pre_begin, pre_begin + pre_count), row-major [pre_count][n_neurons];
 // a shard handle reads / writes its own columns only.
@@ -754,37 +784,42 @@ static int trace_rows_io(snn_network_t *net, uint32_t pre_begin, uint32_t pre_co
     (void)hipFree(stage);
     return rc;
 }
-int snn_set_trace_rows(snn_network_t *net, uint32_t pre_begin, uint32_t pre_count, const float *traces)
+int snn_set_trace_rows(snn_network_t *net, uint32_t pre_begin, uint32_t pre_count, const float *traces) ABI_TRY
 { return trace_rows_io(net, pre_begin, pre_count, const_cast<float *>(traces), true); }
-int snn_get_trace_rows(snn_network_t *net, uint32_t pre_begin, uint32_t pre_count, float *traces)
+ABI_CATCH
+int snn_get_trace_rows(snn_network_t *net, uint32_t pre_begin, uint32_t pre_count, float *traces) ABI_TRY
 { return trace_rows_io(net, pre_begin, pre_count, traces, false); }
-int snn_set_pending_rows(snn_network_t *net, uint32_t pre_begin, uint32_t pre_count, const float *pending)
+ABI_CATCH
+int snn_set_pending_rows(snn_network_t *net, uint32_t pre_begin, uint32_t pre_count, const float *pending) ABI_TRY
 { return trace_rows_io(net, pre_begin, pre_count, const_cast<float *>(pending), true, 1); }
-int snn_get_pending_rows(snn_network_t *net, uint32_t pre_begin, uint32_t pre_count, float *pending)
+ABI_CATCH
+int snn_get_pending_rows(snn_network_t *net, uint32_t pre_begin, uint32_t pre_count, float *pending) ABI_TRY
 { return trace_rows_io(net, pre_begin, pre_count, pending, false, 1); }
+ABI_CATCH
 // TraceRSTDP::counter of the same connections (0 / 1), one byte each
-int snn_set_counter_rows(snn_network_t *net, uint32_t pre_begin, uint32_t pre_count, const uint8_t *counters)
+int snn_set_counter_rows(snn_network_t *net, uint32_t pre_begin, uint32_t pre_count, const uint8_t *counters) ABI_TRY
 {
     if (!net || !counters) return fail(SNN_ERR_BAD_ARG, "null argument");
     if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
     if (net->csr) return fail(SNN_ERR_BAD_STATE, "handle holds a CSR graph");
     if ((uint64_t)pre_begin + pre_count > net->n_tot) return fail(SNN_ERR_DIM_MISMATCH, "row range exceeds n_tot");
     try {
-        std::vector<float> rows((size_t)pre_count * net->nn);
+        hvec<float> rows((size_t)pre_count * net->nn);
         for (size_t i = 0; i < rows.size(); ++i) rows[i] = counters[i] ? 1.0f : 0.0f;
         return trace_rows_io(net, pre_begin, pre_count, rows.data(), true, 2);
     } catch (const std::bad_alloc &) {
         return fail(SNN_ERR_BUFFER_CREATE, "out of host memory for the counter rows");
     }
 }
-int snn_get_counter_rows(snn_network_t *net, uint32_t pre_begin, uint32_t pre_count, uint8_t *counters)
+ABI_CATCH
+int snn_get_counter_rows(snn_network_t *net, uint32_t pre_begin, uint32_t pre_count, uint8_t *counters) ABI_TRY
 {
     if (!net || !counters) return fail(SNN_ERR_BAD_ARG, "null argument");
     if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
     if (net->csr) return fail(SNN_ERR_BAD_STATE, "handle holds a CSR graph");
     if ((uint64_t)pre_begin + pre_count > net->n_tot) return fail(SNN_ERR_DIM_MISMATCH, "row range exceeds n_tot");
     try {
-        std::vector<float> rows((size_t)pre_count * net->nn, 0.0f);
+        hvec<float> rows((size_t)pre_count * net->nn, 0.0f);
         TRY(trace_rows_io(net, pre_begin, pre_count, rows.data(), false, 2));
         for (size_t i = 0; i < rows.size(); ++i) counters[i] = rows[i] != 0.0f ? 1 : 0;
     } catch (const std::bad_alloc &) {
@@ -792,8 +827,9 @@ int snn_get_counter_rows(snn_network_t *net, uint32_t pre_begin, uint32_t pre_co
     }
     return SNN_OK;
 }
+ABI_CATCH
 
-int snn_set_connection_kind(snn_network_t *net, uint32_t pre_id, uint32_t post_id, int kind)
+int snn_set_connection_kind(snn_network_t *net, uint32_t pre_id, uint32_t post_id, int kind) ABI_TRY
 {
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
     if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
@@ -823,6 +859,7 @@ int snn_set_connection_kind(snn_network_t *net, uint32_t pre_id, uint32_t post_i
     }
     return SNN_OK;
 }
+ABI_CATCH
 
 static int traces_csr_io(snn_network_t *net, float *traces, uint64_t nnz, bool set, int plane = 0)
 {
@@ -838,7 +875,7 @@ static int traces_csr_io(snn_network_t *net, float *traces, uint64_t nnz, bool s
     if (plane) TRY(ensure_pending(net));
     float *array = plane == 2 ? net->edge_counter : plane == 1 ? net->pending : net->trace;
     HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
-    std::vector<float> sell((size_t)net->sell_entries);
+    hvec<float> sell((size_t)net->sell_entries);
     HIP_TRY(copy_sync(net, sell.data(), array, sell.size() * 4, hipMemcpyDeviceToHost), SNN_ERR_BUFFER_READ);
     if (set) {
         for (uint64_t e = 0; e < nnz; ++e) sell[net->edge_slot_host[e]] = traces[e];
@@ -848,32 +885,37 @@ static int traces_csr_io(snn_network_t *net, float *traces, uint64_t nnz, bool s
     }
     return SNN_OK;
 }
-int snn_set_traces_csr(snn_network_t *net, const float *traces, uint64_t nnz)
+int snn_set_traces_csr(snn_network_t *net, const float *traces, uint64_t nnz) ABI_TRY
 { return traces_csr_io(net, const_cast<float *>(traces), nnz, true); }
-int snn_get_traces_csr(snn_network_t *net, float *traces, uint64_t nnz)
+ABI_CATCH
+int snn_get_traces_csr(snn_network_t *net, float *traces, uint64_t nnz) ABI_TRY
 { return traces_csr_io(net, traces, nnz, false); }
-int snn_set_pending_csr(snn_network_t *net, const float *pending, uint64_t nnz)
+ABI_CATCH
+int snn_set_pending_csr(snn_network_t *net, const float *pending, uint64_t nnz) ABI_TRY
 { return traces_csr_io(net, const_cast<float *>(pending), nnz, true, 1); }
-int snn_get_pending_csr(snn_network_t *net, float *pending, uint64_t nnz)
+ABI_CATCH
+int snn_get_pending_csr(snn_network_t *net, float *pending, uint64_t nnz) ABI_TRY
 { return traces_csr_io(net, pending, nnz, false, 1); }
-int snn_set_counters_csr(snn_network_t *net, const uint8_t *counters, uint64_t nnz)
+ABI_CATCH
+int snn_set_counters_csr(snn_network_t *net, const uint8_t *counters, uint64_t nnz) ABI_TRY
 {
     if (!net || (nnz && !counters)) return fail(SNN_ERR_BAD_ARG, "null argument");
     if (net->finalized && net->csr && nnz != net->nnz) return fail(SNN_ERR_DIM_MISMATCH, "nnz does not match the stored graph");
     try {
-        std::vector<float> v(nnz);
+        hvec<float> v(nnz);
         for (uint64_t e = 0; e < nnz; ++e) v[e] = counters[e] ? 1.0f : 0.0f;
         return traces_csr_io(net, v.data(), nnz, true, 2);
     } catch (const std::bad_alloc &) {
         return fail(SNN_ERR_BUFFER_CREATE, "out of host memory for the counters");
     }
 }
-int snn_get_counters_csr(snn_network_t *net, uint8_t *counters, uint64_t nnz)
+ABI_CATCH
+int snn_get_counters_csr(snn_network_t *net, uint8_t *counters, uint64_t nnz) ABI_TRY
 {
     if (!net || (nnz && !counters)) return fail(SNN_ERR_BAD_ARG, "null argument");
     if (net->finalized && net->csr && nnz != net->nnz) return fail(SNN_ERR_DIM_MISMATCH, "nnz does not match the stored graph");
     try {
-        std::vector<float> v(nnz, 0.0f);
+        hvec<float> v(nnz, 0.0f);
         TRY(traces_csr_io(net, v.data(), nnz, false, 2));
         for (uint64_t e = 0; e < nnz; ++e) counters[e] = v[e] != 0.0f ? 1 : 0;
     } catch (const std::bad_alloc &) {
@@ -881,8 +923,9 @@ int snn_get_counters_csr(snn_network_t *net, uint8_t *counters, uint64_t nnz)
     }
     return SNN_OK;
 }
+ABI_CATCH
 
-int snn_set_history(snn_network_t *net, int voltage_history, int spike_history)
+int snn_set_history(snn_network_t *net, int voltage_history, int spike_history) ABI_TRY
 {
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
     if ((voltage_history != 0) != (net->want_vhist != 0) || (spike_history != 0) != (net->want_raster != 0)) {
@@ -893,8 +936,9 @@ int snn_set_history(snn_network_t *net, int voltage_history, int spike_history)
     net->want_raster = spike_history ? 1 : 0;
     return SNN_OK;
 }
+ABI_CATCH
 
-int snn_reset_history(snn_network_t *net)
+int snn_reset_history(snn_network_t *net) ABI_TRY
 {
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
     net->hist_steps = 0; net->hist_tick = 0;
@@ -905,8 +949,9 @@ int snn_reset_history(snn_network_t *net)
     }
     return SNN_OK;
 }
+ABI_CATCH
 
-int snn_set_firing_times(snn_network_t *net, uint32_t id, const uint32_t *cell_ptr, const float *times, size_t n_times)
+int snn_set_firing_times(snn_network_t *net, uint32_t id, const uint32_t *cell_ptr, const float *times, size_t n_times) ABI_TRY
 {
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
     if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
@@ -922,8 +967,8 @@ int snn_set_firing_times(snn_network_t *net, uint32_t id, const uint32_t *cell_p
     TRY(end_run(net));
     const uint32_t c0 = l->first - net->nn;
     for (uint32_t i = 0; i < l->count; ++i) net->preset_host[c0 + i].assign(times + cell_ptr[i], times + cell_ptr[i + 1]);
-    std::vector<uint32_t> ptr((size_t)net->c_pad + 1, 0);
-    std::vector<float> flat;
+    hvec<uint32_t> ptr((size_t)net->c_pad + 1, 0);
+    hvec<float> flat;
     for (uint32_t s = 0; s < net->nc; ++s) {
         ptr[s] = (uint32_t)flat.size();
         flat.insert(flat.end(), net->preset_host[s].begin(), net->preset_host[s].end());
@@ -939,8 +984,9 @@ int snn_set_firing_times(snn_network_t *net, uint32_t id, const uint32_t *cell_p
     net->ca.preset_times = nt;
     return SNN_OK;
 }
+ABI_CATCH
 
-int snn_set_graph_history(snn_network_t *net, uint32_t id, int enable)
+int snn_set_graph_history(snn_network_t *net, uint32_t id, int enable) ABI_TRY
 {
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
     if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
@@ -956,8 +1002,9 @@ int snn_set_graph_history(snn_network_t *net, uint32_t id, int enable)
     for (int v : net->want_whist) net->any_whist |= (v != 0);
     return SNN_OK;
 }
+ABI_CATCH
 
-int snn_get_graph_history(snn_network_t *net, uint32_t id, float *dst, size_t steps)
+int snn_get_graph_history(snn_network_t *net, uint32_t id, float *dst, size_t steps) ABI_TRY
 {
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
     if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
@@ -972,8 +1019,9 @@ int snn_get_graph_history(snn_network_t *net, uint32_t id, float *dst, size_t st
     HIP_TRY(copy_sync(net, dst, net->whist[l->slot], steps * (size_t)l->count * l->count * 4, hipMemcpyDeviceToHost), SNN_ERR_BUFFER_READ);
     return SNN_OK;
 }
+ABI_CATCH
 
-int snn_set_history_stride(snn_network_t *net, uint32_t every)
+int snn_set_history_stride(snn_network_t *net, uint32_t every) ABI_TRY
 {
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
     if (every == 0) return fail(SNN_ERR_BAD_ARG, "stride must be at least 1");
@@ -981,9 +1029,10 @@ int snn_set_history_stride(snn_network_t *net, uint32_t every)
     net->hist_every = every;
     return SNN_OK;
 }
+ABI_CATCH
 
 int snn_set_reduced_history(snn_network_t *net, int average_voltage, int eeg, int spike_counts,
-                            float reference_voltage, float distance, float conductivity)
+                            float reference_voltage, float distance, float conductivity) ABI_TRY
 {
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
     if ((average_voltage != 0) != (net->want_avg != 0) || (eeg != 0) != (net->want_eeg != 0))
@@ -994,6 +1043,7 @@ int snn_set_reduced_history(snn_network_t *net, int average_voltage, int eeg, in
     net->eeg_ref = reference_voltage; net->eeg_dist = distance; net->eeg_cond = conductivity;
     return SNN_OK;
 }
+ABI_CATCH
 
 static int get_summary(snn_network_t *net, uint32_t id, float *dst, size_t steps, bool eeg)
 {
@@ -1013,12 +1063,14 @@ static int get_summary(snn_network_t *net, uint32_t id, float *dst, size_t steps
     return SNN_OK;
 }
 
-int snn_get_average_voltage_history(snn_network_t *net, uint32_t id, float *dst, size_t steps)
+int snn_get_average_voltage_history(snn_network_t *net, uint32_t id, float *dst, size_t steps) ABI_TRY
 { return get_summary(net, id, dst, steps, false); }
-int snn_get_eeg_history(snn_network_t *net, uint32_t id, float *dst, size_t steps)
+ABI_CATCH
+int snn_get_eeg_history(snn_network_t *net, uint32_t id, float *dst, size_t steps) ABI_TRY
 { return get_summary(net, id, dst, steps, true); }
+ABI_CATCH
 
-int snn_get_spike_counts(snn_network_t *net, uint32_t id, uint32_t *dst, size_t count)
+int snn_get_spike_counts(snn_network_t *net, uint32_t id, uint32_t *dst, size_t count) ABI_TRY
 {
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
     if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
@@ -1032,15 +1084,17 @@ int snn_get_spike_counts(snn_network_t *net, uint32_t id, uint32_t *dst, size_t 
     HIP_TRY(copy_sync(net, dst, net->spike_counts + l->first, count * 4, hipMemcpyDeviceToHost), SNN_ERR_BUFFER_READ);
     return SNN_OK;
 }
+ABI_CATCH
 
-int snn_get_clock(const snn_network_t *net, uint64_t *clock)
+int snn_get_clock(const snn_network_t *net, uint64_t *clock) ABI_TRY
 {
     if (!net || !clock) return fail(SNN_ERR_BAD_ARG, "null argument");
     *clock = (uint64_t)net->clock;
     return SNN_OK;
 }
+ABI_CATCH
 
-int snn_reset_timing(snn_network_t *net)
+int snn_reset_timing(snn_network_t *net) ABI_TRY
 {
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
     if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
@@ -1054,8 +1108,9 @@ int snn_reset_timing(snn_network_t *net)
     HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
     return SNN_OK;
 }
+ABI_CATCH
 
-int snn_set_clock(snn_network_t *net, uint64_t clock)
+int snn_set_clock(snn_network_t *net, uint64_t clock) ABI_TRY
 {
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
     if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
@@ -1066,8 +1121,9 @@ int snn_set_clock(snn_network_t *net, uint64_t clock)
     net->view_dirty = true;            // the cells' gap-junction values are functions of the clock
     return SNN_OK;
 }
+ABI_CATCH
 
-int snn_set_spike_train_clock(snn_network_t *net, uint32_t id, uint64_t clock)
+int snn_set_spike_train_clock(snn_network_t *net, uint32_t id, uint64_t clock) ABI_TRY
 {
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
     if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
@@ -1079,8 +1135,9 @@ int snn_set_spike_train_clock(snn_network_t *net, uint32_t id, uint64_t clock)
     net->st_clock[l->slot] = (long long)clock;
     return SNN_OK;
 }
+ABI_CATCH
 
-int snn_get_spike_train_clock(snn_network_t *net, uint32_t id, uint64_t *clock)
+int snn_get_spike_train_clock(snn_network_t *net, uint32_t id, uint64_t *clock) ABI_TRY
 {
     if (!net || !clock) return fail(SNN_ERR_BAD_ARG, "null argument");
     if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
@@ -1091,21 +1148,33 @@ int snn_get_spike_train_clock(snn_network_t *net, uint32_t id, uint64_t *clock)
     *clock = (uint64_t)net->st_clock[l->slot];
     return SNN_OK;
 }
+ABI_CATCH
 
-const char *snn_debug_verify_report(snn_network_t *net) { return net ? net->verify_text.c_str() : ""; }
+const char *snn_debug_verify_report(snn_network_t *net) ABI_TRY { return net ? net->verify_text.c_str() : ""; } ABI_CATCH_PTR
+
+// Test support for the exception barrier and the error paths (snn_network_state.hpp, alloc_fault_now): the n-th allocation the
+// library makes from now on -- device, page-locked or a host table -- fails once (n <= 0 disarms); process-wide.
+int snn_debug_fail_alloc_at(int64_t n, uint64_t *allocations_so_far) ABI_TRY
+{
+    AllocFault &f = alloc_fault();
+    if (allocations_so_far) *allocations_so_far = f.seen.load(std::memory_order_relaxed);
+    f.countdown.store(n > 0 ? n : 0, std::memory_order_relaxed);
+    return SNN_OK;
+}
+ABI_CATCH
 
 // Test support (tests/checkpoint.py): everything a later run call reads -- every device array of the handle up to 256 MiB in
 // all, the sparse weights, traces, and the host-side cursors of the stepper -- kept in host memory; restore puts it back.
 // Valid between calls that leave the handle's STRUCTURE alone (run calls, attribute and weight writes): a restore after a
 // structural call (a new sparse graph, a rebuilt exchange plan, histories switched) fails with SNN_ERR_BAD_STATE.
-int snn_debug_checkpoint(snn_network_t *net, int restore)
+int snn_debug_checkpoint(snn_network_t *net, int restore) ABI_TRY
 {
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
     if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
     HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
     TRY(end_run(net));
     auto &cp = net->checkpoint;
-    std::vector<std::pair<void *, size_t>> arrays;
+    hvec<std::pair<void *, size_t>> arrays;
     for (const auto &kv : net->alloc_bytes)
         if (kv.first != (void *)net->snap_buf && kv.first != (void *)net->snap_table && kv.first != (void *)net->verify_buf &&
             kv.first != (void *)net->run_granules && kv.first != (void *)net->run_partials && kv.first != (void *)net->run_timing)
@@ -1120,7 +1189,7 @@ int snn_debug_checkpoint(snn_network_t *net, int restore)
     if (!restore) {
         cp.arrays.clear();
         for (const auto &a : arrays) {
-            cp.arrays.emplace_back(a.first, std::vector<uint8_t>(a.second));
+            cp.arrays.emplace_back(a.first, hvec<uint8_t>(a.second));
             HIP_TRY(hipMemcpyAsync(cp.arrays.back().second.data(), a.first, a.second, hipMemcpyDeviceToHost, net->stream), SNN_ERR_BUFFER_READ);
         }
         HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
@@ -1160,6 +1229,7 @@ int snn_debug_checkpoint(snn_network_t *net, int restore)
     }
     return SNN_OK;
 }
+ABI_CATCH
 
 extern "C++" {
 namespace {
@@ -1227,9 +1297,9 @@ int run_steps(snn_network *net, uint64_t iterations)
 
 // "verify": the matrices a run with weight updates rewrites (the snapshot table holds the small arrays only): synapse matrix or
 // sparse weights, traces, dw, counters, the weights a one-launch run with STDP leaves behind
-std::vector<std::pair<void *, size_t>> verify_matrices(const snn_network *net)
+hvec<std::pair<void *, size_t>> verify_matrices(const snn_network *net)
 {
-    std::vector<std::pair<void *, size_t>> m;
+    hvec<std::pair<void *, size_t>> m;
     if (!net->any_plasticity && !net->any_modulation && !net->any_conn_kind) return m;
     if (net->csr) { if (net->csr_w && net->sell_entries) m.emplace_back(net->csr_w, (size_t)net->sell_entries * 4); }
     else if (net->W) m.emplace_back(net->W, wcount(net->n_tot, net->ld) * 4);
@@ -1286,7 +1356,7 @@ std::string describe_array(const snn_network *net, const void *ptr, uint32_t wor
 } // namespace
 } // extern "C++"
 
-int snn_run(snn_network_t *net, uint64_t iterations)
+int snn_run(snn_network_t *net, uint64_t iterations) ABI_TRY
 {
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
     if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
@@ -1480,8 +1550,9 @@ int snn_run(snn_network_t *net, uint64_t iterations)
     }
     return end_run(net, /*keep_stdp=*/true);
 }
+ABI_CATCH
 
-int snn_step_begin_local(snn_network_t *net)
+int snn_step_begin_local(snn_network_t *net) ABI_TRY
 {
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
     if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
@@ -1499,8 +1570,9 @@ int snn_step_begin_local(snn_network_t *net)
     }
     return SNN_OK;
 }
+ABI_CATCH
 
-int snn_step_begin(snn_network_t *net)
+int snn_step_begin(snn_network_t *net) ABI_TRY
 {
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
     if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
@@ -1512,8 +1584,9 @@ int snn_step_begin(snn_network_t *net)
     if (!net->external_stream) HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
     return SNN_OK;
 }
+ABI_CATCH
 
-int snn_step_end(snn_network_t *net)
+int snn_step_end(snn_network_t *net) ABI_TRY
 {
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
     if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
@@ -1524,8 +1597,9 @@ int snn_step_end(snn_network_t *net)
     if (!net->external_stream) HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
     return SNN_OK;
 }
+ABI_CATCH
 
-int snn_refresh_begin(snn_network_t *net, int *needed)
+int snn_refresh_begin(snn_network_t *net, int *needed) ABI_TRY
 {
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
     if (!net->finalized || !net->sharded) return fail(SNN_ERR_BAD_STATE, "not a finalized shard handle");
@@ -1539,8 +1613,9 @@ int snn_refresh_begin(snn_network_t *net, int *needed)
     if (!net->external_stream) HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
     return SNN_OK;
 }
+ABI_CATCH
 
-int snn_refresh_end(snn_network_t *net)
+int snn_refresh_end(snn_network_t *net) ABI_TRY
 {
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
     if (!net->finalized || !net->sharded) return fail(SNN_ERR_BAD_STATE, "not a finalized shard handle");
@@ -1549,8 +1624,9 @@ int snn_refresh_end(snn_network_t *net)
     if (!net->external_stream) HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
     return SNN_OK;
 }
+ABI_CATCH
 
-int snn_exchange_plan_get(snn_network_t *net, snn_exchange_plan *plan)
+int snn_exchange_plan_get(snn_network_t *net, snn_exchange_plan *plan) ABI_TRY
 {
     if (!net || !plan) return fail(SNN_ERR_BAD_ARG, "null argument");
     if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
@@ -1578,9 +1654,10 @@ int snn_exchange_plan_get(snn_network_t *net, snn_exchange_plan *plan)
     }
     return SNN_OK;
 }
+ABI_CATCH
 
 int snn_exchange_peers(snn_network_t *net, uint64_t *send_offset, uint64_t *send_words, uint64_t *recv_offset,
-                       uint64_t *recv_words)
+                       uint64_t *recv_words) ABI_TRY
 {
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
     if (!net->finalized || !net->sharded) return fail(SNN_ERR_BAD_STATE, "not a finalized shard handle");
@@ -1594,8 +1671,9 @@ int snn_exchange_peers(snn_network_t *net, uint64_t *send_offset, uint64_t *send
     }
     return SNN_OK;
 }
+ABI_CATCH
 
-int snn_halo_needs(snn_network_t *net, uint32_t peer, uint32_t *indices, uint32_t capacity, uint32_t *count)
+int snn_halo_needs(snn_network_t *net, uint32_t peer, uint32_t *indices, uint32_t capacity, uint32_t *count) ABI_TRY
 {
     if (!net || !count) return fail(SNN_ERR_BAD_ARG, "null argument");
     if (!net->finalized || !net->sharded || !net->csr) return fail(SNN_ERR_BAD_STATE, "halo plans belong to finalized CSR shard handles");
@@ -1606,8 +1684,9 @@ int snn_halo_needs(snn_network_t *net, uint32_t peer, uint32_t *indices, uint32_
     if (indices && capacity >= l.size() && !l.empty()) std::memcpy(indices, l.data(), l.size() * 4);
     return SNN_OK;
 }
+ABI_CATCH
 
-int snn_halo_set_sends(snn_network_t *net, uint32_t peer, const uint32_t *indices, uint32_t count)
+int snn_halo_set_sends(snn_network_t *net, uint32_t peer, const uint32_t *indices, uint32_t count) ABI_TRY
 {
     if (!net || (count && !indices)) return fail(SNN_ERR_BAD_ARG, "null argument");
     if (!net->finalized || !net->sharded || !net->csr) return fail(SNN_ERR_BAD_STATE, "halo plans belong to finalized CSR shard handles");
@@ -1622,8 +1701,9 @@ int snn_halo_set_sends(snn_network_t *net, uint32_t peer, const uint32_t *indice
     net->x_dirty = true;
     return SNN_OK;
 }
+ABI_CATCH
 
-int snn_cells_read(snn_network_t *net, uint32_t *indices, uint32_t capacity, uint32_t *count)
+int snn_cells_read(snn_network_t *net, uint32_t *indices, uint32_t capacity, uint32_t *count) ABI_TRY
 {
     if (!net || !count) return fail(SNN_ERR_BAD_ARG, "null argument");
     if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
@@ -1638,8 +1718,9 @@ int snn_cells_read(snn_network_t *net, uint32_t *indices, uint32_t capacity, uin
         std::memcpy(indices, net->cell_list_host.data(), (size_t)net->n_cells_listed * 4);
     return SNN_OK;
 }
+ABI_CATCH
 
-int snn_halo_commit(snn_network_t *net)
+int snn_halo_commit(snn_network_t *net) ABI_TRY
 {
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
     if (!net->finalized || !net->sharded || !net->csr) return fail(SNN_ERR_BAD_STATE, "halo plans belong to finalized CSR shard handles");
@@ -1650,8 +1731,9 @@ int snn_halo_commit(snn_network_t *net)
     net->x_dirty = true;
     return ensure_exchange_plan(net);
 }
+ABI_CATCH
 
-int snn_set_collectives(const snn_collectives *table)
+int snn_set_collectives(const snn_collectives *table) ABI_TRY
 {
     Rccl &r = rccl_state();
     static const Rccl resolved = r;               // what dlopen / dlsym found (possibly nothing), for the way back
@@ -1676,8 +1758,9 @@ int snn_set_collectives(const snn_collectives *table)
     r.replaced = true;
     return SNN_OK;
 }
+ABI_CATCH
 
-int snn_comm_unique_id(void *id_128_bytes)
+int snn_comm_unique_id(void *id_128_bytes) ABI_TRY
 {
     if (!id_128_bytes) return fail(SNN_ERR_BAD_ARG, "null argument");
     static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
@@ -1687,8 +1770,9 @@ int snn_comm_unique_id(void *id_128_bytes)
     std::memcpy(id_128_bytes, &id, sizeof id);
     return SNN_OK;
 }
+ABI_CATCH
 
-int snn_comm_init_rank(const void *id_128_bytes, int world_size, int rank, int device, void **nccl_comm)
+int snn_comm_init_rank(const void *id_128_bytes, int world_size, int rank, int device, void **nccl_comm) ABI_TRY
 {
     if (!id_128_bytes || !nccl_comm) return fail(SNN_ERR_BAD_ARG, "null argument");
     if (world_size < 1 || rank < 0 || rank >= world_size) return fail(SNN_ERR_BAD_ARG, "rank must be in [0, world_size)");
@@ -1701,16 +1785,18 @@ int snn_comm_init_rank(const void *id_128_bytes, int world_size, int rank, int d
     *nccl_comm = comm;
     return SNN_OK;
 }
+ABI_CATCH
 
-int snn_comm_destroy(void *nccl_comm)
+int snn_comm_destroy(void *nccl_comm) ABI_TRY
 {
     if (!nccl_comm) return SNN_OK;
     RCCL_REAL(R, CommDestroy);
     RCCL_TRY(R, R->CommDestroy(static_cast<ncclComm_t>(nccl_comm)));
     return SNN_OK;
 }
+ABI_CATCH
 
-int snn_comm_count(void *nccl_comm, int *world_size, int *rank)
+int snn_comm_count(void *nccl_comm, int *world_size, int *rank) ABI_TRY
 {
     if (!nccl_comm || !world_size) return fail(SNN_ERR_BAD_ARG, "null argument");
     RCCL_LIB(R);
@@ -1719,8 +1805,9 @@ int snn_comm_count(void *nccl_comm, int *world_size, int *rank)
     if (rank) RCCL_TRY(R, R->CommUserRank(static_cast<ncclComm_t>(nccl_comm), rank));
     return SNN_OK;
 }
+ABI_CATCH
 
-int snn_comm_exchange_halo_lists(snn_network_t *net, void *nccl_comm)
+int snn_comm_exchange_halo_lists(snn_network_t *net, void *nccl_comm) ABI_TRY
 {
     if (!net || !nccl_comm) return fail(SNN_ERR_BAD_ARG, "null argument");
     if (!net->finalized || !net->sharded || !net->csr) return fail(SNN_ERR_BAD_STATE, "halo plans belong to finalized CSR shard handles");
@@ -1733,7 +1820,7 @@ int snn_comm_exchange_halo_lists(snn_network_t *net, void *nccl_comm)
     if (net->halo_need.size() != net->n_shards) halo_reset(net);
     const uint32_t G = net->n_shards, me = net->shard_index;
     // (1) counts: row `me` of a G x G matrix, all-gathered; (2) the lists themselves, grouped send / recv
-    std::vector<uint32_t> counts((size_t)G * G, 0);
+    hvec<uint32_t> counts((size_t)G * G, 0);
     for (uint32_t p = 0; p < G; ++p) counts[(size_t)me * G + p] = (uint32_t)net->halo_need[p].size();
     uint32_t *d_counts = nullptr;
     HIP_TRY(snn_malloc(&d_counts, counts.size() * 4), SNN_ERR_BUFFER_CREATE);
@@ -1747,12 +1834,12 @@ int snn_comm_exchange_halo_lists(snn_network_t *net, void *nccl_comm)
     HALO_STEP(nccl_ok(R->AllGather(d_counts + (size_t)me * G, d_counts, G, ncclUint32, comm, net->stream), "ncclAllGather(counts)"));
     HALO_STEP(hip_ok(hipStreamSynchronize(net->stream), SNN_ERR_WAIT, "counts wait"));
     HALO_STEP(hip_ok(copy_sync(net, counts.data(), d_counts, counts.size() * 4, hipMemcpyDeviceToHost), SNN_ERR_BUFFER_READ, "counts download"));
-    std::vector<uint64_t> need_off(G + 1, 0), send_off(G + 1, 0);
+    hvec<uint64_t> need_off(G + 1, 0), send_off(G + 1, 0);
     for (uint32_t p = 0; p < G; ++p) {
         need_off[p + 1] = need_off[p] + counts[(size_t)me * G + p];        // what I ask of p
         send_off[p + 1] = send_off[p] + counts[(size_t)p * G + me];        // what p asks of me
     }
-    std::vector<uint32_t> need_flat(need_off[G]), send_flat(send_off[G]);
+    hvec<uint32_t> need_flat(need_off[G]), send_flat(send_off[G]);
     for (uint32_t p = 0; p < G; ++p) std::copy(net->halo_need[p].begin(), net->halo_need[p].end(), need_flat.begin() + need_off[p]);
     HALO_STEP(hip_ok(snn_malloc(&d_need, std::max<size_t>(need_flat.size() * 4, 256)), SNN_ERR_BUFFER_CREATE, "hipMalloc"));
     HALO_STEP(hip_ok(snn_malloc(&d_send, std::max<size_t>(send_flat.size() * 4, 256)), SNN_ERR_BUFFER_CREATE, "hipMalloc"));
@@ -1784,8 +1871,9 @@ int snn_comm_exchange_halo_lists(snn_network_t *net, void *nccl_comm)
     }
     return snn_halo_commit(net);
 }
+ABI_CATCH
 
-int snn_p2p_local(snn_network_t *net, uint64_t *recv0, uint64_t *recv1, uint64_t *flags, uint64_t *recv_offsets, uint64_t *recv_counts)
+int snn_p2p_local(snn_network_t *net, uint64_t *recv0, uint64_t *recv1, uint64_t *flags, uint64_t *recv_offsets, uint64_t *recv_counts) ABI_TRY
 {
     if (!net || !recv0 || !recv1 || !flags) return fail(SNN_ERR_BAD_ARG, "null argument");
     if (!net->finalized || !net->sharded || !net->csr) return fail(SNN_ERR_BAD_STATE, "the peer form belongs to finalized CSR shard handles");
@@ -1803,8 +1891,9 @@ int snn_p2p_local(snn_network_t *net, uint64_t *recv0, uint64_t *recv1, uint64_t
     }
     return SNN_OK;
 }
+ABI_CATCH
 
-int snn_p2p_connect(snn_network_t *net, uint32_t peer, uint64_t peer_recv0, uint64_t peer_recv1, uint64_t peer_flags, uint64_t peer_recv_offset)
+int snn_p2p_connect(snn_network_t *net, uint32_t peer, uint64_t peer_recv0, uint64_t peer_recv1, uint64_t peer_flags, uint64_t peer_recv_offset) ABI_TRY
 {
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
     if (!net->finalized || !net->sharded || !net->csr) return fail(SNN_ERR_BAD_STATE, "the peer form belongs to finalized CSR shard handles");
@@ -1820,8 +1909,9 @@ int snn_p2p_connect(snn_network_t *net, uint32_t peer, uint64_t peer_recv0, uint
     net->x_agreed = false;
     return SNN_OK;
 }
+ABI_CATCH
 
-int snn_p2p_commit(snn_network_t *net)
+int snn_p2p_commit(snn_network_t *net) ABI_TRY
 {
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
     if (!net->finalized || !net->sharded || !net->csr) return fail(SNN_ERR_BAD_STATE, "the peer form belongs to finalized CSR shard handles");
@@ -1831,8 +1921,9 @@ int snn_p2p_commit(snn_network_t *net)
     if (!net->peer_capable || !net->p2p_recv[0]) return fail(SNN_ERR_BAD_STATE, "the handle's exchange plan has no peer form");
     return p2p_build_tables(net);
 }
+ABI_CATCH
 
-int snn_p2p_ipc_export(snn_network_t *net, void *handles_3x64_bytes)
+int snn_p2p_ipc_export(snn_network_t *net, void *handles_3x64_bytes) ABI_TRY
 {
     if (!net || !handles_3x64_bytes) return fail(SNN_ERR_BAD_ARG, "null argument");
     if (!net->p2p_recv[0]) return fail(SNN_ERR_BAD_STATE, "the handle's exchange plan has no peer form");
@@ -1844,8 +1935,9 @@ int snn_p2p_ipc_export(snn_network_t *net, void *handles_3x64_bytes)
     HIP_TRY(hipIpcGetMemHandle(&h[2], net->p2p_flags), SNN_ERR_BUFFER_CREATE);
     return SNN_OK;
 }
+ABI_CATCH
 
-int snn_p2p_ipc_import(int device, const void *handles_3x64_bytes, uint64_t *recv0, uint64_t *recv1, uint64_t *flags)
+int snn_p2p_ipc_import(int device, const void *handles_3x64_bytes, uint64_t *recv0, uint64_t *recv1, uint64_t *flags) ABI_TRY
 {
     if (!handles_3x64_bytes || !recv0 || !recv1 || !flags) return fail(SNN_ERR_BAD_ARG, "null argument");
     HIP_TRY(hipSetDevice(device), SNN_ERR_GET_DEVICE);
@@ -1861,8 +1953,9 @@ int snn_p2p_ipc_import(int device, const void *handles_3x64_bytes, uint64_t *rec
     *recv0 = reinterpret_cast<uint64_t>(p[0]); *recv1 = reinterpret_cast<uint64_t>(p[1]); *flags = reinterpret_cast<uint64_t>(p[2]);
     return SNN_OK;
 }
+ABI_CATCH
 
-int snn_p2p_ipc_close(int device, uint64_t recv0, uint64_t recv1, uint64_t flags)
+int snn_p2p_ipc_close(int device, uint64_t recv0, uint64_t recv1, uint64_t flags) ABI_TRY
 {
     HIP_TRY(hipSetDevice(device), SNN_ERR_GET_DEVICE);
     int rc = SNN_OK;
@@ -1873,8 +1966,9 @@ int snn_p2p_ipc_close(int device, uint64_t recv0, uint64_t recv1, uint64_t flags
     }
     return rc;
 }
+ABI_CATCH
 
-int snn_exchange(snn_network_t *net, void *nccl_comm)
+int snn_exchange(snn_network_t *net, void *nccl_comm) ABI_TRY
 {
     if (!net || !nccl_comm) return fail(SNN_ERR_BAD_ARG, "null argument");
     if (!net->finalized || !net->sharded) return fail(SNN_ERR_BAD_STATE, "not a finalized shard handle");
@@ -1887,8 +1981,9 @@ int snn_exchange(snn_network_t *net, void *nccl_comm)
     if (!net->external_stream) HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
     return SNN_OK;
 }
+ABI_CATCH
 
-int snn_exchange_noop(void *, void *) { return 0; }
+int snn_exchange_noop(void *, void *) ABI_TRY { return 0; } ABI_CATCH
 
 // peer form: a poll that gave up (a peer that never stored, or never finished) has left the handle in the middle of a step
 static int p2p_outcome(snn_network *net)
@@ -1901,7 +1996,7 @@ static int p2p_outcome(snn_network *net)
     return SNN_OK;
 }
 
-int snn_run_sharded_custom(snn_network_t *net, snn_exchange_fn exchange, void *user, uint64_t iterations)
+int snn_run_sharded_custom(snn_network_t *net, snn_exchange_fn exchange, void *user, uint64_t iterations) ABI_TRY
 {
     if (!net || !exchange) return fail(SNN_ERR_BAD_ARG, "null argument");
     if (!net->finalized || !net->sharded) return fail(SNN_ERR_BAD_STATE, "not a finalized shard handle");
@@ -1932,6 +2027,7 @@ int snn_run_sharded_custom(snn_network_t *net, snn_exchange_fn exchange, void *u
     TRY(end_run(net, /*keep_stdp=*/true));
     return p2p_outcome(net);
 }
+ABI_CATCH
 
 // The ranks of a communicator agree on HOW they exchange before the first step of a run: a rank that decided from its
 // own state alone (no graph yet, lists committed by hand while the peers' are not, other synapse kinds) would skip or
@@ -1942,7 +2038,7 @@ static int agree_on_exchange(Rccl *R, snn_network *net, ncclComm_t comm, void *n
     const uint32_t G = net->n_shards, me = net->shard_index;
     uint32_t *d_words = nullptr;
     HIP_TRY(snn_malloc(&d_words, std::max<size_t>((size_t)G * 4, 256)), SNN_ERR_BUFFER_CREATE);
-    std::vector<uint32_t> words(G, 0);
+    hvec<uint32_t> words(G, 0);
     auto gather = [&](uint32_t mine) -> int {
         words.assign(G, 0);
         words[me] = mine;
@@ -1998,7 +2094,7 @@ static int agree_on_exchange(Rccl *R, snn_network *net, ncclComm_t comm, void *n
     return rc;
 }
 
-int snn_run_sharded(snn_network_t *net, void *nccl_comm, uint64_t iterations)
+int snn_run_sharded(snn_network_t *net, void *nccl_comm, uint64_t iterations) ABI_TRY
 {
     if (!net || !nccl_comm) return fail(SNN_ERR_BAD_ARG, "null argument");
     if (!net->finalized || !net->sharded) return fail(SNN_ERR_BAD_STATE, "not a finalized shard handle");
@@ -2065,8 +2161,9 @@ int snn_run_sharded(snn_network_t *net, void *nccl_comm, uint64_t iterations)
     TRY(end_run(net, /*keep_stdp=*/true));
     return p2p_outcome(net);
 }
+ABI_CATCH
 
-int snn_set_stream(snn_network_t *net, void *hip_stream)
+int snn_set_stream(snn_network_t *net, void *hip_stream) ABI_TRY
 {
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
     HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
@@ -2080,29 +2177,33 @@ int snn_set_stream(snn_network_t *net, void *hip_stream)
     }
     return SNN_OK;
 }
+ABI_CATCH
 
-int snn_synchronize(snn_network_t *net)
+int snn_synchronize(snn_network_t *net) ABI_TRY
 {
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
     HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
     return end_run(net);
 }
+ABI_CATCH
 
-int snn_stream(snn_network_t *net, void **hip_stream)
+int snn_stream(snn_network_t *net, void **hip_stream) ABI_TRY
 {
     if (!net || !hip_stream) return fail(SNN_ERR_BAD_ARG, "null argument");
     *hip_stream = net->stream;
     return SNN_OK;
 }
+ABI_CATCH
 
-int snn_history_steps(const snn_network_t *net, uint64_t *steps)
+int snn_history_steps(const snn_network_t *net, uint64_t *steps) ABI_TRY
 {
     if (!net || !steps) return fail(SNN_ERR_BAD_ARG, "null argument");
     *steps = net->hist_steps;
     return SNN_OK;
 }
+ABI_CATCH
 
-int snn_get_voltage_history(snn_network_t *net, uint32_t id, float *dst, size_t count)
+int snn_get_voltage_history(snn_network_t *net, uint32_t id, float *dst, size_t count) ABI_TRY
 {
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
     if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
@@ -2120,8 +2221,9 @@ int snn_get_voltage_history(snn_network_t *net, uint32_t id, float *dst, size_t 
             SNN_ERR_BUFFER_READ);
     return SNN_OK;
 }
+ABI_CATCH
 
-int snn_get_spike_history(snn_network_t *net, uint32_t id, uint8_t *dst, size_t count)
+int snn_get_spike_history(snn_network_t *net, uint32_t id, uint8_t *dst, size_t count) ABI_TRY
 {
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
     if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
@@ -2134,7 +2236,7 @@ int snn_get_spike_history(snn_network_t *net, uint32_t id, uint8_t *dst, size_t 
     HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
     TRY(end_run(net));
     const size_t words = net->n_pad / 64;
-    std::vector<unsigned long long> host(net->hist_steps * words);
+    hvec<unsigned long long> host(net->hist_steps * words);
     HIP_TRY(copy_sync(net, host.data(), net->raster, host.size() * 8, hipMemcpyDeviceToHost), SNN_ERR_BUFFER_READ);
     for (uint64_t s = 0; s < net->hist_steps; ++s)
         for (uint32_t i = 0; i < l->count; ++i) {
@@ -2143,8 +2245,9 @@ int snn_get_spike_history(snn_network_t *net, uint32_t id, uint8_t *dst, size_t 
         }
     return SNN_OK;
 }
+ABI_CATCH
 
-int snn_set_option(snn_network_t *net, const char *name, int value)
+int snn_set_option(snn_network_t *net, const char *name, int value) ABI_TRY
 {
     if (!net || !name) return fail(SNN_ERR_BAD_ARG, "null argument");
     HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
@@ -2180,8 +2283,9 @@ int snn_set_option(snn_network_t *net, const char *name, int value)
     net->shadow_valid = false;
     return SNN_OK;
 }
+ABI_CATCH
 
-int snn_get_stat(snn_network_t *net, const char *name, uint64_t *value)
+int snn_get_stat(snn_network_t *net, const char *name, uint64_t *value) ABI_TRY
 {
     if (!net || !name || !value) return fail(SNN_ERR_BAD_ARG, "null argument");
     const std::string n(name);
@@ -2211,14 +2315,16 @@ int snn_get_stat(snn_network_t *net, const char *name, uint64_t *value)
     else return fail(SNN_ERR_BAD_ARG, "unknown statistic '" + n + "'");
     return SNN_OK;
 }
+ABI_CATCH
 
-int snn_profile_enable(snn_network_t *net, int enable)
+int snn_profile_enable(snn_network_t *net, int enable) ABI_TRY
 {
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
     net->profile = enable ? 1 : 0;
     return SNN_OK;
 }
-int snn_profile_reset(snn_network_t *net)
+ABI_CATCH
+int snn_profile_reset(snn_network_t *net) ABI_TRY
 {
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
     HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
@@ -2227,7 +2333,8 @@ int snn_profile_reset(snn_network_t *net)
     net->ev_used_pl = 0; net->prof_launches_pl = 0; net->prof_ms_pl = 0.0;
     return SNN_OK;
 }
-int snn_profile_read(snn_network_t *net, uint64_t *launches, double *total_ms)
+ABI_CATCH
+int snn_profile_read(snn_network_t *net, uint64_t *launches, double *total_ms) ABI_TRY
 {
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
     HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
@@ -2236,7 +2343,8 @@ int snn_profile_read(snn_network_t *net, uint64_t *launches, double *total_ms)
     if (total_ms) *total_ms = net->prof_ms;
     return SNN_OK;
 }
-int snn_profile_read_plasticity(snn_network_t *net, uint64_t *steps, double *total_ms)
+ABI_CATCH
+int snn_profile_read_plasticity(snn_network_t *net, uint64_t *steps, double *total_ms) ABI_TRY
 {
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
     HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
@@ -2245,8 +2353,9 @@ int snn_profile_read_plasticity(snn_network_t *net, uint64_t *steps, double *tot
     if (total_ms) *total_ms = net->prof_ms_pl;
     return SNN_OK;
 }
+ABI_CATCH
 
-int snn_set_synthetic_drive(snn_network_t *net, uint64_t seed, float fraction, float voltage)
+int snn_set_synthetic_drive(snn_network_t *net, uint64_t seed, float fraction, float voltage) ABI_TRY
 {
     if (!net) return fail(SNN_ERR_BAD_ARG, "net is null");
     if (!(fraction >= 0.0f && fraction <= 1.0f)) return fail(SNN_ERR_BAD_ARG, "fraction must be in [0, 1]");
@@ -2258,8 +2367,9 @@ int snn_set_synthetic_drive(snn_network_t *net, uint64_t seed, float fraction, f
     net->shadow_valid = false;
     return SNN_OK;
 }
+ABI_CATCH
 
-int snn_input_kernel_bytes(const snn_network_t *net, uint64_t *bytes)
+int snn_input_kernel_bytes(const snn_network_t *net, uint64_t *bytes) ABI_TRY
 {
     if (!net || !bytes) return fail(SNN_ERR_BAD_ARG, "null argument");
     if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
@@ -2295,8 +2405,9 @@ int snn_input_kernel_bytes(const snn_network_t *net, uint64_t *bytes)
     *bytes = b;
     return SNN_OK;
 }
+ABI_CATCH
 
-int snn_probe_bandwidth(int device, uint64_t bytes, int repeats, double *read_gbps, double *copy_gbps)
+int snn_probe_bandwidth(int device, uint64_t bytes, int repeats, double *read_gbps, double *copy_gbps) ABI_TRY
 {
     if (!read_gbps || !copy_gbps) return fail(SNN_ERR_BAD_ARG, "null argument");
     if (bytes < (1u << 20) || repeats <= 0) return fail(SNN_ERR_BAD_ARG, "need >= 1 MiB and >= 1 repeat");
@@ -2339,8 +2450,9 @@ int snn_probe_bandwidth(int device, uint64_t bytes, int repeats, double *read_gb
     (void)hipFree(a); (void)hipFree(b); (void)hipFree(sink);
     return rc;
 }
+ABI_CATCH
 
-int snn_probe_math(int device, int which, const float *in, float *out, size_t count)
+int snn_probe_math(int device, int which, const float *in, float *out, size_t count) ABI_TRY
 {
     if (!in || !out) return fail(SNN_ERR_BAD_ARG, "null argument");
     if (which < 0 || which > 2) return fail(SNN_ERR_BAD_ARG, "unknown function selector");
@@ -2360,8 +2472,9 @@ int snn_probe_math(int device, int which, const float *in, float *out, size_t co
     (void)hipFree(dout);
     return rc;
 }
+ABI_CATCH
 
-int snn_probe_math_bits(int device, int which, uint32_t first, uint32_t stride, float y, float *out, size_t count)
+int snn_probe_math_bits(int device, int which, uint32_t first, uint32_t stride, float y, float *out, size_t count) ABI_TRY
 {
     if (!out) return fail(SNN_ERR_BAD_ARG, "null argument");
     if (which < 0 || which > 3) return fail(SNN_ERR_BAD_ARG, "unknown function selector");
@@ -2376,5 +2489,6 @@ int snn_probe_math_bits(int device, int which, uint32_t first, uint32_t stride, 
     (void)hipFree(dout);
     return rc;
 }
+ABI_CATCH
 
 } // extern "C"

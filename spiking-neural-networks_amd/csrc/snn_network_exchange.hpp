@@ -15,7 +15,7 @@ namespace {
 inline uint64_t segment_words(uint32_t planes, uint64_t count) { return (uint64_t)planes * count + (count + 31) / 32; }
 
 template <typename T>
-int upload_table(snn_network *net, T **dev, const std::vector<T> &host)
+int upload_table(snn_network *net, T **dev, const hvec<T> &host)
 {
     if (*dev) { (void)hipFree(*dev); *dev = nullptr; }
     HIP_TRY(snn_malloc(dev, std::max<size_t>(host.size() * sizeof(T), 256)), SNN_ERR_BUFFER_CREATE);
@@ -58,7 +58,7 @@ void synthesize_full_lists(snn_network *net)
 int p2p_release(snn_network *net, bool final = false)
 {
     // What PEERS may still address -- the two receive sets and the done counters, by committed tables or IPC mappings of the
-    // old plan -- is not freed here but kept until this handle commits a new connection or is destroyed: a neighbour that
+    // old plan -- is not freed here but kept until this handle is destroyed: a neighbour that
     // announces "my previous launch is over" at the start of its next run stores into these words (include/snn_amd.h: peers
     // reconnect after a plan rebuild; until they have, their stores land in memory that is still this handle's).
     for (void *b : {(void *)net->p2p_recv[0], (void *)net->p2p_recv[1], (void *)net->p2p_flags})
@@ -101,8 +101,8 @@ int ensure_exchange_plan(snn_network *net)
     const uint32_t G = net->n_shards, me = net->shard_index, P = net->x_planes;
     net->x_send_off.assign(G, 0); net->x_send_words.assign(G, 0);
     net->x_recv_off.assign(G, 0); net->x_recv_words.assign(G, 0);
-    std::vector<uint32_t> cnt[2], first[2];
-    std::vector<uint64_t> off[2], loff[2];
+    hvec<uint32_t> cnt[2], first[2];
+    hvec<uint64_t> off[2], loff[2];
     net->x_mode = ((net->csr && net->halo_committed) || net->block_mode) ? SNN_EXCHANGE_HALO : SNN_EXCHANGE_ALLGATHER;
     net->direct_capable = false;
     net->peer_capable = false;
@@ -122,7 +122,7 @@ int ensure_exchange_plan(snn_network *net)
         cnt[0].push_back(net->shard_stride); off[0].push_back((uint64_t)me * net->x_block_words);
         first[0].push_back(me * net->shard_stride); loff[0].push_back(0);
     } else {
-        std::vector<uint32_t> send_idx, recv_idx;
+        hvec<uint32_t> send_idx, recv_idx;
         uint64_t so = 0, ro = 0;
         for (uint32_t p = 0; p < G; ++p) {
             const auto &sl = net->halo_send[p];
@@ -145,15 +145,15 @@ int ensure_exchange_plan(snn_network *net)
         net->recv_total = (uint32_t)recv_idx.size();
         // the one-launch sparse step: border / interior slices and the per-row pack table
         const uint32_t n_slices = (net->n_loc + 63) / 64;
-        std::vector<uint8_t> is_border(n_slices, 0);
-        std::vector<uint32_t> pack_ptr(net->n_loc + 1, 0), pack_segoff, pack_count, pack_index;
+        hvec<uint8_t> is_border(n_slices, 0);
+        hvec<uint32_t> pack_ptr(net->n_loc + 1, 0), pack_segoff, pack_count, pack_index;
         auto local_row = [&](uint32_t g) { return net->block_mode ? net->local_row_host[g] : g - net->q0; };
         for (uint32_t p = 0; p < G; ++p)
             for (uint32_t g : net->halo_send[p]) pack_ptr[local_row(g) + 1] += 1;
         for (uint32_t q = 0; q < net->n_loc; ++q) pack_ptr[q + 1] += pack_ptr[q];
         pack_segoff.resize(pack_ptr[net->n_loc]); pack_count.resize(pack_ptr[net->n_loc]); pack_index.resize(pack_ptr[net->n_loc]);
         {
-            std::vector<uint32_t> fill(pack_ptr.begin(), pack_ptr.end() - 1);
+            hvec<uint32_t> fill(pack_ptr.begin(), pack_ptr.end() - 1);
             net->send_bitmap_words = 0;
             for (uint32_t p = 0; p < G; ++p) {
                 const auto &sl = net->halo_send[p];
@@ -165,7 +165,7 @@ int ensure_exchange_plan(snn_network *net)
                 }
             }
         }
-        std::vector<uint32_t> border, interior;
+        hvec<uint32_t> border, interior;
         for (uint32_t sl = 0; sl < n_slices; ++sl) (is_border[sl] ? border : interior).push_back(sl);
         net->n_border = (uint32_t)border.size(); net->n_interior = (uint32_t)interior.size();
         TRY(upload_table(net, &net->csr_border_dev, border));
@@ -200,17 +200,17 @@ int ensure_exchange_plan(snn_network *net)
             // kernels of this one read it), zeroed (tag 0 is never expected: epochs start at 1)
             net->p2p_recv_words = ro;
             for (int i = 0; i < 2; ++i) {
-                HIP_TRY(hipExtMallocWithFlags(reinterpret_cast<void **>(&net->p2p_recv[i]), std::max<uint64_t>(ro * 8, 256), hipDeviceMallocFinegrained),
+                HIP_TRY(ext_malloc(reinterpret_cast<void **>(&net->p2p_recv[i]), std::max<uint64_t>(ro * 8, 256), hipDeviceMallocFinegrained),
                         SNN_ERR_BUFFER_CREATE);
                 HIP_TRY(memset_sync(net, net->p2p_recv[i], 0, std::max<uint64_t>(ro * 8, 256)), SNN_ERR_BUFFER_WRITE);
             }
-            HIP_TRY(hipExtMallocWithFlags(reinterpret_cast<void **>(&net->p2p_flags), std::max<size_t>((size_t)G * 4, 256), hipDeviceMallocFinegrained),
+            HIP_TRY(ext_malloc(reinterpret_cast<void **>(&net->p2p_flags), std::max<size_t>((size_t)G * 4, 256), hipDeviceMallocFinegrained),
                     SNN_ERR_BUFFER_CREATE);
             HIP_TRY(memset_sync(net, net->p2p_flags, 0, std::max<size_t>((size_t)G * 4, 256)), SNN_ERR_BUFFER_WRITE);
             HIP_TRY(snn_malloc(&net->p2p_done_blocks, 256), SNN_ERR_BUFFER_CREATE);
             HIP_TRY(memset_sync(net, net->p2p_done_blocks, 0, 256), SNN_ERR_BUFFER_WRITE);
             if (!net->p2p_failed) {
-                HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&net->p2p_failed), 8, hipHostMallocMapped), SNN_ERR_BUFFER_CREATE);
+                HIP_TRY(host_malloc(reinterpret_cast<void **>(&net->p2p_failed), 8, hipHostMallocMapped), SNN_ERR_BUFFER_CREATE);
                 net->p2p_failed[0] = 0u;
             }
             net->p2p_peers.assign(G, snn_network::P2pPeer{});
@@ -219,7 +219,7 @@ int ensure_exchange_plan(snn_network *net)
         if (net->direct_capable || net->peer_capable) {
             // word of the receive buffer (direct form: plane 0 of the segment, P == 1) = first granule of the receive set (peer
             // form: P adjacent granules per neuron) that carries a halo neuron
-            std::vector<uint32_t> halo_word(net->nn, 0xFFFFFFFFu);
+            hvec<uint32_t> halo_word(net->nn, 0xFFFFFFFFu);
             for (uint32_t p = 0; p < G; ++p)
                 for (size_t i = 0; i < net->halo_need[p].size(); ++i)
                     halo_word[net->halo_need[p][i]] = (uint32_t)(net->x_recv_off[p] + i * P);
@@ -332,7 +332,7 @@ void halo_needs_from_rows(snn_network *net, const uint32_t *pre_index, uint64_t 
 {
     halo_reset(net);
     if (!net->sharded || net->n_shards < 2) return;
-    std::vector<uint8_t> seen(net->nn, 0);
+    hvec<uint8_t> seen(net->nn, 0);
     for (uint64_t e = 0; e < nnz; ++e) {
         const uint32_t p = pre_index[e];
         if (p < net->nn && !owns(net, p)) seen[p] = 1;
@@ -571,14 +571,14 @@ int p2p_build_tables(snn_network *net)
 {
     const uint32_t G = net->n_shards, me = net->shard_index;
     auto local_row = [&](uint32_t g) { return net->block_mode ? net->local_row_host[g] : g - net->q0; };
-    std::vector<uint32_t> pack_ptr(net->n_loc + 1, 0);
+    hvec<uint32_t> pack_ptr(net->n_loc + 1, 0);
     for (uint32_t p = 0; p < G; ++p)
         for (uint32_t g : net->halo_send[p]) pack_ptr[local_row(g) + 1] += 1;
     for (uint32_t q = 0; q < net->n_loc; ++q) pack_ptr[q + 1] += pack_ptr[q];
     const size_t entries = pack_ptr[net->n_loc];
-    std::vector<unsigned long long> dst[2] = {std::vector<unsigned long long>(entries), std::vector<unsigned long long>(entries)};
-    std::vector<uint32_t> peer(entries);
-    std::vector<uint32_t> fill(pack_ptr.begin(), pack_ptr.end() - 1);
+    hvec<unsigned long long> dst[2] = {hvec<unsigned long long>(entries), hvec<unsigned long long>(entries)};
+    hvec<uint32_t> peer(entries);
+    hvec<uint32_t> fill(pack_ptr.begin(), pack_ptr.end() - 1);
     for (uint32_t p = 0; p < G; ++p) {
         const auto &sl = net->halo_send[p];
         if (sl.empty()) continue;
@@ -589,7 +589,7 @@ int p2p_build_tables(snn_network *net)
             peer[e] = p;
         }
     }
-    std::vector<unsigned long long> signal;
+    hvec<unsigned long long> signal;
     for (uint32_t p = 0; p < G; ++p) {
         if (p == me || net->halo_need[p].empty()) continue;
         if (!net->p2p_peers[p].set) return fail(SNN_ERR_BAD_STATE, "peer form: shard " + std::to_string(p) + " is read by this shard but is not connected");
@@ -601,9 +601,10 @@ int p2p_build_tables(snn_network *net)
     net->p2p_n_signal = (uint32_t)signal.size();
     net->p2p_connected = true;
     net->x_agreed = false;                         // whether a run takes the peer form is part of what the ranks agree on
-    // receive sets of earlier plans: every peer that addressed them has been reconnected by now (or never will step again)
-    for (void *b : net->p2p_retired) (void)hipFree(b);
-    net->p2p_retired.clear();
+    // Receive sets of earlier plans stay allocated until the handle is destroyed (p2p_release(final)): THIS handle's commit says
+    // nothing about its peers -- one that has not run its own connect / commit yet still holds tables or IPC mappings into them
+    // and would store its next granules or done counters into freed, possibly reallocated memory.  A plan rebuild is rare and a
+    // receive set small (8 B per halo neuron), so nothing is gained by freeing earlier.
     return SNN_OK;
 }
 

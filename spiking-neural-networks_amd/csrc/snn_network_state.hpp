@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -12,6 +13,7 @@
 #include <cstring>
 #include <map>
 #include <new>
+#include <stdexcept>
 #include <string>
 #include <utility>
 #include <vector>
@@ -36,6 +38,82 @@ int fail(int code, const std::string &msg)
 {
     g_last_error = msg;
     return code;
+}
+
+// ---- the exception barrier of the C ABI ------------------------------------------------------------------------------------
+// The reference's seam returns Result<_, GPUError> (error/mod.rs:221-238, gpu_lattices/mod.rs:1089-1091) and include/snn_amd.h
+// promises "never abort": no C++ exception may leave an extern "C" entry point (it would terminate a C / Rust / ctypes host).
+// EVERY exported definition in snn_network.hip is a function-try-block -- `int snn_x(...) ABI_TRY { ... } ABI_CATCH` -- whose
+// handler turns whatever arrives into a status code and a message (tests/test_abi.py checks the translation unit for it):
+// std::bad_alloc / std::length_error (a host-side table sized by the caller's numbers) -> SNN_ERR_BUFFER_CREATE, anything else ->
+// SNN_ERR_BAD_STATE.  The handle stays destroyable: device allocations are on record in net->allocs the moment they exist.
+int abi_exception(const char *entry) noexcept
+{
+    int code = SNN_ERR_BAD_STATE;
+    const char *what = "unknown exception";
+    char text[160];
+    try {
+        throw;
+    } catch (const std::bad_alloc &) {
+        code = SNN_ERR_BUFFER_CREATE; what = "host allocation failed (std::bad_alloc)";
+    } catch (const std::length_error &e) {
+        code = SNN_ERR_BUFFER_CREATE; snprintf(text, sizeof text, "host table too large (std::length_error: %s)", e.what()); what = text;
+    } catch (const std::exception &e) {
+        snprintf(text, sizeof text, "%s", e.what()); what = text;
+    } catch (...) {
+    }
+    try {
+        g_last_error.assign(entry).append(": ").append(what);
+    } catch (...) {          // (the message itself could not be stored: the code still says what happened)
+    }
+    return code;
+}
+#define ABI_TRY try
+#define ABI_CATCH catch (...) { return abi_exception(__func__); }
+#define ABI_CATCH_PTR catch (...) { (void)abi_exception(__func__); return nullptr; }
+
+// ---- allocation-failure hook (test support: snn_debug_fail_alloc_at, SNN_AMD_FAIL_ALLOC_AT) ----------------------------------
+// Every allocation the library makes passes alloc_fault_now(): device and page-locked memory through snn_malloc / alloc_streamed /
+// the host_malloc and ext_malloc wrappers below, host tables through the allocator of hvec (every std::vector of the library).
+// Armed with n, the n-th allocation from then on fails -- hipErrorOutOfMemory or std::bad_alloc -- once.  Process-wide, off by
+// default; a relaxed load of one word per allocation when off.
+struct AllocFault {
+    std::atomic<long long> countdown{0};       // > 0: armed, fails when it reaches 0
+    std::atomic<unsigned long long> seen{0};   // allocations since the process started
+    AllocFault() { if (const char *e = getenv("SNN_AMD_FAIL_ALLOC_AT")) countdown.store(atoll(e)); }
+};
+inline AllocFault &alloc_fault() { static AllocFault f; return f; }
+inline bool alloc_fault_now()
+{
+    AllocFault &f = alloc_fault();
+    f.seen.fetch_add(1, std::memory_order_relaxed);
+    if (f.countdown.load(std::memory_order_relaxed) <= 0) return false;
+    return f.countdown.fetch_sub(1, std::memory_order_relaxed) == 1;
+}
+template <typename T>
+struct HostAlloc {
+    using value_type = T;
+    HostAlloc() = default;
+    template <typename U> HostAlloc(const HostAlloc<U> &) {}
+    T *allocate(size_t n)
+    {
+        if (alloc_fault_now() || n > SIZE_MAX / sizeof(T)) throw std::bad_alloc();
+        return static_cast<T *>(::operator new(n * sizeof(T)));
+    }
+    void deallocate(T *p, size_t) noexcept { ::operator delete(p); }
+    template <typename U> bool operator==(const HostAlloc<U> &) const { return true; }
+    template <typename U> bool operator!=(const HostAlloc<U> &) const { return false; }
+};
+template <typename T> using hvec = std::vector<T, HostAlloc<T>>;
+inline hipError_t host_malloc(void **out, size_t bytes, unsigned flags)
+{
+    if (alloc_fault_now()) { *out = nullptr; return hipErrorOutOfMemory; }
+    return hipHostMalloc(out, bytes, flags);
+}
+inline hipError_t ext_malloc(void **out, size_t bytes, unsigned flags)
+{
+    if (alloc_fault_now()) { *out = nullptr; return hipErrorOutOfMemory; }
+    return hipExtMallocWithFlags(out, bytes, flags);
 }
 
 #define HIP_TRY(expr, code)                                                                      \
@@ -76,11 +154,11 @@ struct snn_network {
     int electrical = 1, chemical = 0;
     long long clock = 0;
 
-    std::vector<LatticeInfo> lattices;      // neuron lattices, ascending id after finalize
-    std::vector<LatticeInfo> st_lattices;   // spike-train lattices
-    std::vector<long long> st_clock;        // own clocks of the spike-train lattices
-    std::vector<float> stdp_host;           // [n_lattices][PL_STRIDE], see plasticity_weight
-    std::vector<uint32_t> plast_host;       // [n_lattices]
+    hvec<LatticeInfo> lattices;      // neuron lattices, ascending id after finalize
+    hvec<LatticeInfo> st_lattices;   // spike-train lattices
+    hvec<long long> st_clock;        // own clocks of the spike-train lattices
+    hvec<float> stdp_host;           // [n_lattices][PL_STRIDE], see plasticity_weight
+    hvec<uint32_t> plast_host;       // [n_lattices]
     bool any_plasticity = false;
     std::map<uint32_t, bool> lattice_has_nt;    // lattice id -> some neurotransmitters$flags entry is set
     bool any_nt_neurons = false, any_nt_cells = false;
@@ -92,15 +170,15 @@ struct snn_network {
     // reward modulation (RewardModulatedLattice): per-lattice modulator table + per-edge trace, allocated on first use
     bool any_modulation = false;           // some lattice has do_modulation set
     bool any_modulated = false;            // some lattice is a reward-modulated lattice (modulating or paused): rewards reach its modulator
-    std::vector<float> rm_host;            // [n_lattices][RM_STRIDE]
-    std::vector<uint32_t> rm_on_host;
+    hvec<float> rm_host;            // [n_lattices][RM_STRIDE]
+    hvec<uint32_t> rm_on_host;
     float *rm_dev = nullptr;
     uint32_t *rm_on_dev = nullptr;
     float *trace = nullptr;                // dense: [n_tot][ld]; CSR: [sell_entries]
     // connections of a reward-modulated NETWORK that end in a modulated lattice (snn_set_connection_kind, k_reward_cross):
     // conn_kind [n_lattices + n_st_lattices][n_lattices], TraceRSTDP::dw per edge (`pending`, allocated on first use, layout of W),
     // TraceRSTDP::counter per post lattice
-    std::vector<uint8_t> conn_kind_host;
+    hvec<uint8_t> conn_kind_host;
     uint8_t *conn_kind_dev = nullptr;
     bool any_conn_kind = false;
     float *pending = nullptr;
@@ -123,11 +201,11 @@ struct snn_network {
     // Range-set ownership (snn_network_finalize_shard_by_lattice, sparse handles): shard s owns slab s of EVERY neuron
     // lattice; local rows = the global 64-blocks that hold an owned neuron (RowMap, snn_layout.hpp)
     bool block_mode = false;
-    std::vector<uint32_t> lattice_slab;                         // per neuron lattice slot: neurons per slab
-    std::vector<std::pair<uint32_t, uint32_t>> ranges;          // owned [begin, end), ascending (every handle has them)
+    hvec<uint32_t> lattice_slab;                         // per neuron lattice slot: neurons per slab
+    hvec<std::pair<uint32_t, uint32_t>> ranges;          // owned [begin, end), ascending (every handle has them)
     uint32_t n_owned = 0;
-    std::vector<uint32_t> owned_local_host;                     // k-th owned neuron (ascending) -> local row
-    std::vector<uint32_t> local_row_host;                       // [nn] global neuron -> local row or 0xFFFFFFFF
+    hvec<uint32_t> owned_local_host;                     // k-th owned neuron (ascending) -> local row
+    hvec<uint32_t> local_row_host;                       // [nn] global neuron -> local row or 0xFFFFFFFF
     uint32_t *own_block_dev = nullptr, *local_row_dev = nullptr;
     unsigned long long *own_mask_dev = nullptr;
     RowMap rowmap{};
@@ -146,10 +224,10 @@ struct snn_network {
     size_t wire_words = 0;
     // halo (sparse handles): per peer, the neurons of that peer this handle's rows read (need) and the own neurons
     // that peer reads (send); buffers and segment tables sized by the plan
-    std::vector<std::vector<uint32_t>> halo_need, halo_send;
+    hvec<hvec<uint32_t>> halo_need, halo_send;
     bool halo_committed = false;
     uint32_t *halo_send_buf = nullptr, *halo_recv_buf = nullptr, *halo_send_idx = nullptr, *halo_recv_idx = nullptr;
-    std::vector<uint64_t> x_send_off, x_send_words, x_recv_off, x_recv_words;     // per peer, in words
+    hvec<uint64_t> x_send_off, x_send_words, x_recv_off, x_recv_words;     // per peer, in words
     // device segment tables of the pack / unpack launches: {count, offset, first, list offset} per segment
     uint32_t *seg_count_dev[2] = {nullptr, nullptr}, *seg_first_dev[2] = {nullptr, nullptr};
     uint64_t *seg_offset_dev[2] = {nullptr, nullptr}, *seg_loff_dev[2] = {nullptr, nullptr};
@@ -193,13 +271,13 @@ struct snn_network {
     uint32_t *p2p_failed = nullptr;                           // host-mapped word: a poll gave up
     uint64_t p2p_recv_words = 0;
     struct P2pPeer { uint64_t recv[2] = {0, 0}, flags = 0, recv_offset = 0; bool set = false; };
-    std::vector<P2pPeer> p2p_peers;                           // per shard: where this handle's values go on that peer
+    hvec<P2pPeer> p2p_peers;                           // per shard: where this handle's values go on that peer
     unsigned long long **p2p_dst_dev[2] = {nullptr, nullptr}; // per pack entry: the peer's granule, per set
     uint32_t *p2p_peer_dev = nullptr;                         // per pack entry: the peer
     uint32_t **p2p_signal_dev = nullptr;                      // the neighbours' flags[this shard]
     uint32_t p2p_n_signal = 0;
     bool p2p_connected = false;
-    std::vector<void *> p2p_retired;                          // receive sets / done counters of earlier plans, see p2p_release
+    hvec<void *> p2p_retired;                          // receive sets / done counters of earlier plans, see p2p_release
     bool peer_run = false;                                    // the run in progress uses the peer form
     uint32_t p2p_epoch = 0;                                   // steps of peer-form runs done so far (tags and done counters)
     uint32_t p2p_spin_limit = 1u << 26;
@@ -209,7 +287,7 @@ struct snn_network {
     hipStream_t comm_stream = nullptr;
     hipEvent_t ev_packed = nullptr, ev_exchanged = nullptr;
 
-    std::vector<void *> allocs;
+    hvec<void *> allocs;
     std::map<void *, size_t> alloc_bytes;        // dev_alloc'ed arrays and their sizes (run_snapshot copies the small ones)
     // sparse form (CSR by local postsynaptic row); the arrays are replaced by every snn_set_graph_csr
     bool csr = false;
@@ -219,7 +297,7 @@ struct snn_network {
     uint32_t *csr_row_len = nullptr, *csr_edge_slot = nullptr;
     float *csr_w = nullptr;
     uint64_t sell_entries = 0;
-    std::vector<uint32_t> edge_slot_host;   // CSR edge -> SELL entry (for snn_get_graph_csr)
+    hvec<uint32_t> edge_slot_host;   // CSR edge -> SELL entry (for snn_get_graph_csr)
     float *W = nullptr;
     float *xbuf = nullptr;
     float *part_i = nullptr, *part_t = nullptr;
@@ -233,7 +311,7 @@ struct snn_network {
     uint32_t *spike_list = nullptr, *spike_count = nullptr;
     // sparse shard handles: the spike-train cells the local rows read (ascending cell indices); the step iterates only
     // those -- cells are replicated state, and what this rank never reads it need not advance
-    std::vector<uint32_t> cell_list_host;
+    hvec<uint32_t> cell_list_host;
     uint32_t *cell_list_dev = nullptr;
     uint32_t n_cells_listed = 0;
     // sparse handles: what the rows read of a cell, two copies (InputsArgs::st_view); rows read cell_view[cell_view_cur],
@@ -276,7 +354,7 @@ struct snn_network {
     uint32_t snap_entries = 0, snap_max_words = 0;
     size_t snap_allocs_seen = 0;
     size_t snap_words = 0;
-    std::vector<CopyEntry> snap_table_host;     // the table as uploaded (names of the arrays in a "verify" report)
+    hvec<CopyEntry> snap_table_host;     // the table as uploaded (names of the arrays in a "verify" report)
     size_t verify_words = 0;                    // capacity of each half of verify_buf
     uint32_t run_chunk_steps = 1u << 20;        // option "run_resident_chunk_steps" (test hook): steps per one-launch chunk
     // option "verify" (SNN_AMD_VERIFY=1; tests and campaigns): every snn_run call on a handle without weight updates takes its
@@ -297,9 +375,9 @@ struct snn_network {
     // snn_debug_checkpoint (test support): device arrays and the stepper's host-side cursors as they were at the call
     struct Checkpoint {
         bool valid = false;
-        std::vector<std::pair<void *, std::vector<uint8_t>>> arrays;
+        hvec<std::pair<void *, hvec<uint8_t>>> arrays;
         long long clock = 0;
-        std::vector<long long> st_clock;
+        hvec<long long> st_clock;
         uint64_t hist_steps = 0, hist_tick = 0;
         int shadow_cur = 0, cell_view_cur = 0, persistent_run = 1;
         bool shadow_valid = false, view_dirty = true, counts_dirty = true, uni_dirty = true;
@@ -346,14 +424,14 @@ struct snn_network {
     // reduced histories: per-lattice average voltage / EEG value per step, per-neuron spike totals
     int want_avg = 0, want_eeg = 0, want_counts = 0;
     // per-lattice weight snapshots (update_graph_history): [cap][count*count] per neuron lattice slot
-    std::vector<int> want_whist;
-    std::vector<float *> whist;
+    hvec<int> want_whist;
+    hvec<float *> whist;
     bool any_whist = false;
     float eeg_ref = 0.007f, eeg_dist = 0.8f, eeg_cond = 251.0f;     // EEGHistory defaults, neuron/mod.rs:246-255
     float *summ_avg = nullptr, *summ_eeg = nullptr;                 // [cap][n_lattices]
     uint32_t *spike_counts = nullptr, *lat_first_dev = nullptr, *lat_count_dev = nullptr;
     uint64_t hist_steps = 0, hist_cap = 0;
-    std::vector<std::vector<float>> preset_host;   // PresetSpikeTrain firing times per cell
+    hvec<hvec<float>> preset_host;   // PresetSpikeTrain firing times per cell
     float *preset_times_dev = nullptr;
     uint64_t hist_tick = 0;                // steps seen since the record was (re)started
     uint32_t hist_every = 1;               // a row is stored when hist_tick % hist_every == 0
@@ -365,14 +443,14 @@ struct snn_network {
     uint32_t drive_threshold = 0;
     float drive_voltage = 0.0f;
     // profiling of the plasticity launches (spike compaction + weight updates), same switch as below
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool_pl;
+    hvec<std::pair<hipEvent_t, hipEvent_t>> ev_pool_pl;
     size_t ev_used_pl = 0;
     uint64_t prof_launches_pl = 0;
     double prof_ms_pl = 0.0;
     // profiling of the synaptic-input kernel
     int profile = 0;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
-    std::vector<int> ev_counts;     // 1: the launch closes a pass over the graph, 0: first half of a split pass
+    hvec<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    hvec<int> ev_counts;     // 1: the launch closes a pass over the graph, 0: first half of a split pass
     size_t ev_used = 0;
     uint64_t prof_launches = 0;
     double prof_ms = 0.0;
@@ -409,6 +487,7 @@ inline hipError_t poison_if_asked(void *p, size_t bytes)
 template <typename T>
 inline hipError_t snn_malloc(T **out, size_t bytes)
 {
+    if (alloc_fault_now()) { *out = nullptr; return hipErrorOutOfMemory; }
     hipError_t e = hipMalloc(reinterpret_cast<void **>(out), bytes);
     return e != hipSuccess ? e : poison_if_asked(*out, bytes);
 }
@@ -428,7 +507,7 @@ inline hipError_t copy_sync(snn_network *net, void *dst, const void *src, size_t
     if (net->pinned_copies && bytes && (kind == hipMemcpyDeviceToHost || kind == hipMemcpyHostToDevice)) {
         constexpr size_t STAGE = (size_t)8 << 20;
         if (!net->copy_stage) {
-            const hipError_t e = hipHostMalloc(&net->copy_stage, STAGE, hipHostMallocDefault);
+            const hipError_t e = host_malloc(&net->copy_stage, STAGE, hipHostMallocDefault);
             if (e != hipSuccess) return e;
         }
         for (size_t off = 0; off < bytes; off += STAGE) {
@@ -455,7 +534,7 @@ inline hipError_t copy2d_sync(snn_network *net, void *dst, size_t dpitch, const 
         constexpr size_t STAGE = (size_t)8 << 20;
         if (width > STAGE) return hipErrorInvalidValue;
         if (!net->copy_stage) {
-            const hipError_t e = hipHostMalloc(&net->copy_stage, STAGE, hipHostMallocDefault);
+            const hipError_t e = host_malloc(&net->copy_stage, STAGE, hipHostMallocDefault);
             if (e != hipSuccess) return e;
         }
         const size_t rows_per_hop = std::max<size_t>(1, STAGE / width);
@@ -488,6 +567,7 @@ inline hipError_t memset_sync(snn_network *net, void *dst, int value, size_t byt
 hipError_t alloc_streamed(void **out, size_t bytes)
 {
     static const bool contiguous = [] { const char *e = getenv("SNN_AMD_CONTIGUOUS"); return e && e[0] == '1'; }();
+    if (alloc_fault_now()) { *out = nullptr; return hipErrorOutOfMemory; }
     if (contiguous && bytes >= ((size_t)256 << 20) &&
         hipExtMallocWithFlags(out, bytes, hipDeviceMallocContiguous) == hipSuccess)
         return hipSuccess;
@@ -774,7 +854,7 @@ int build_state(snn_network *net)
     for (const auto &l : net->lattices) TRY(fill_u32(net, net->lattice_slot + l.first, l.count, l.slot));
     const size_t nl = std::max<size_t>(1, net->lattices.size());
     {
-        std::vector<uint32_t> lf(nl, 0), lc(nl, 0);
+        hvec<uint32_t> lf(nl, 0), lc(nl, 0);
         for (const auto &l : net->lattices) { lf[l.slot] = l.first; lc[l.slot] = l.count; }
         TRY(dev_alloc_t(net, &net->lat_first_dev, nl));
         TRY(dev_alloc_t(net, &net->lat_count_dev, nl));
@@ -920,7 +1000,7 @@ int build_state(snn_network *net)
         TRY(fill_u32(net, c.lattice_slot + (l.first - net->nn), l.count, l.slot));
     net->st_clock.assign(std::max<size_t>(1, net->st_lattices.size()), 0);
     TRY(dev_alloc_t(net, &net->st_clock_dev, net->st_clock.size()));
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&net->st_clock_pinned), net->st_clock.size() * sizeof(long long), hipHostMallocDefault),
+    HIP_TRY(host_malloc(reinterpret_cast<void **>(&net->st_clock_pinned), net->st_clock.size() * sizeof(long long), hipHostMallocDefault),
             SNN_ERR_BUFFER_CREATE);
 
     // graph + partials + counts
@@ -990,7 +1070,7 @@ int attr_io(snn_network *net, uint32_t id, const char *name, AttrType type, void
         }
     } else {
         // host layout [cell*3 + k] (gpu_lattices/mod.rs:117-127) <-> device type-major planes
-        std::vector<uint32_t> tmp(l->count);
+        hvec<uint32_t> tmp(l->count);
         uint32_t *h = static_cast<uint32_t *>(host);
         for (int k = 0; k < K_TYPES; ++k) {
             if (set) for (uint32_t i = 0; i < l->count; ++i) tmp[i] = h[(size_t)i * K_TYPES + k];

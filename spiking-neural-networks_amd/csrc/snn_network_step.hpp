@@ -334,8 +334,11 @@ int launch_plasticity(snn_network *net)
 bool stdp_small_applies(const snn_network *net)
 {
     if (!net->stdp_small || net->csr || net->sharded || net->n_tot > 1024u || net->n_loc != net->nn || net->nn == 0) return false;
+    // ANY lattice under the BCM rule rules the form out, plastic or not (as in stdp_deferral_applies): k_stdp_small visits the
+    // outgoing edge j -> r under the rule of r's lattice with zero activities, which is not what k_stdp_rows computes for a BCM
+    // lattice whose own do_plasticity is off but which receives edges from a plastic STDP lattice
     for (size_t l = 0; l < net->lattices.size(); ++l)
-        if (net->plast_host[l] && net->stdp_host[l * PL_STRIDE + 5] != 0.0f) return false;
+        if (net->stdp_host[l * PL_STRIDE + 5] != 0.0f) return false;
     return true;
 }
 
@@ -572,7 +575,7 @@ int choose_matrix_placement(snn_network *net)
         int rc = time_input_pass(net, &best_ms);
         // up to four more candidates; every loser stays allocated until the end so that each new candidate is
         // forced into a different HBM region (a freed block would simply be handed out again)
-        std::vector<void *> losers;
+        hvec<void *> losers;
         for (int cand = 0; cand < 4 && rc == SNN_OK; ++cand) {
             size_t free_b = 0, total_b = 0;
             void *b = nullptr;
@@ -820,7 +823,7 @@ int run_snapshot(snn_network *net, bool restore)
                                                    (size_t)K_TYPES * net->c_pad, 256});
         if (net->alloc_bytes.count(net->xbuf) == 0 || net->alloc_bytes[net->xbuf] > limit)
             return fail(SNN_ERR_BAD_STATE, "exchange buffer missing from the snapshot set");
-        std::vector<CopyEntry> table;
+        hvec<CopyEntry> table;
         size_t words = 0;
         uint32_t max_words = 0;
         for (const auto &kv : net->alloc_bytes) {
@@ -869,7 +872,7 @@ int launch_run_resident(snn_network *net, uint64_t iterations, uint64_t steps_be
         HIP_TRY(hipMemsetAsync(net->run_granules, 0, RUN_GRANULE_WORDS * 8, net->stream), SNN_ERR_BUFFER_WRITE);
         TRY(dev_alloc_t(net, &net->run_partials, RUN_PARTIAL_WORDS));
         HIP_TRY(hipMemsetAsync(net->run_partials, 0, RUN_PARTIAL_WORDS * 8, net->stream), SNN_ERR_BUFFER_WRITE);
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&net->run_failed), 8, hipHostMallocMapped), SNN_ERR_BUFFER_CREATE);
+        HIP_TRY(host_malloc(reinterpret_cast<void **>(&net->run_failed), 8, hipHostMallocMapped), SNN_ERR_BUFFER_CREATE);
         net->run_failed[0] = net->run_failed[1] = 0u;
         net->run_tag = 1;
     }
@@ -1000,7 +1003,7 @@ int launch_run_resident(snn_network *net, uint64_t iterations, uint64_t steps_be
         HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
         if (e1) HIP_TRY(hipEventRecord(e1, net->stream), SNN_ERR_QUEUE);
         if (net->run_timing) {          // debugging aid: workgroup 0's phases in shader clocks per step
-            std::vector<unsigned long long> t((size_t)grid.x * 4);
+            hvec<unsigned long long> t((size_t)grid.x * 4);
             HIP_TRY(hipMemcpyAsync(t.data(), net->run_timing, t.size() * 8, hipMemcpyDeviceToHost, net->stream), SNN_ERR_BUFFER_READ);
             HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
             for (int k = 0; k < 4; ++k) net->run_timing_last[k] = t[k];

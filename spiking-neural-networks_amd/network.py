@@ -296,6 +296,10 @@ class DeviceNetwork:
         self._check(self._L.snn_p2p_ipc_import(device, C.create_string_buffer(handles, 192), C.byref(r0), C.byref(r1), C.byref(fl)))
         return r0.value, r1.value, fl.value
 
+    def p2p_ipc_close(self, recv0, recv1, flags, device=0):
+        """unmaps what p2p_ipc_import mapped (after the peers have stopped stepping in the peer form)"""
+        self._check(self._L.snn_p2p_ipc_close(device, int(recv0), int(recv1), int(flags)))
+
     def p2p_connect(self, peer, recv0, recv1, flags, recv_offset):
         self._check(self._L.snn_p2p_connect(self._h, peer, int(recv0), int(recv1), int(flags), int(recv_offset)))
 

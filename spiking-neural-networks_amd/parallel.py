@@ -326,6 +326,193 @@ class ThreadCollectives:
         return self._guard(run)
 
 
+class ProcessCollectives:
+    """The collectives of the library's own sharded loop for ranks that are PROCESSES without RCCL between them: the bytes go
+    device -> host -> torch.distributed (gloo) -> host -> device.  What it is for: the whole multi-rank path of `bench.py --gpus N`
+    and of the first-contact script -- one process per rank, the agreement before a run, snn_run_sharded, the peer-form trial
+    and its fall-back -- on a box with ONE GPU, where RCCL refuses two ranks on one device.  Blocking, slow, and no evidence
+    about xGMI; the arithmetic and the protocol are the real ones.  Installed process-wide (snn_set_collectives); `comm()`
+    stands where a ncclComm_t goes."""
+
+    def __init__(self, dist, rank, world_size, device, lib=None):
+        import torch
+        from . import _lib
+        self._lib, self._L = _lib, lib or _lib.load()
+        self._torch, self._dist, self._device = torch, dist, device
+        self.rank, self.world = rank, world_size
+        self._token = C.c_int(rank)
+        self._ops = []
+        self.calls = {"all_gather": 0, "groups": 0}
+        self._table = _lib.Collectives(_lib.COMM_QUERY_FN(self._count), _lib.COMM_QUERY_FN(self._user_rank),
+                                       _lib.ALL_GATHER_FN(self._all_gather), _lib.SEND_RECV_FN(self._send),
+                                       _lib.SEND_RECV_FN(self._recv), _lib.GROUP_FN(self._group_start), _lib.GROUP_FN(self._group_end))
+        _lib.check(self._L.snn_set_collectives(C.byref(self._table)), self._L)
+
+    def comm(self):
+        return C.addressof(self._token)
+
+    def __int__(self):
+        return self.comm()
+
+    def count(self):
+        return self.world, self.rank
+
+    def close(self):
+        if self._table is not None:
+            self._lib.check(self._L.snn_set_collectives(None), self._L)
+            self._table = None
+
+    def _guard(self, fn):
+        try:
+            fn()
+            return 0
+        except BaseException as e:       # noqa: BLE001 -- a failure becomes the collective's error code
+            import sys
+            print(f"[ProcessCollectives] rank {self.rank}: {e!r}", file=sys.stderr)
+            return 1
+
+    def _count(self, comm, out):
+        out[0] = self.world
+        return 0
+
+    def _user_rank(self, comm, out):
+        out[0] = self.rank
+        return 0
+
+    def _all_gather(self, send, recv, count, _dtype, comm, _stream):
+        def run():
+            torch = self._torch
+            torch.cuda.synchronize()
+            n = int(count)
+            mine = device_words(int(send), n, self._device).cpu()
+            parts = [torch.empty(n, dtype=torch.int32) for _ in range(self.world)]
+            self._dist.all_gather(parts, mine)
+            for p in range(self.world):
+                if n and int(recv) + 4 * p * n != int(send):
+                    device_words(int(recv) + 4 * p * n, n, self._device).copy_(parts[p])
+            torch.cuda.synchronize()
+            self.calls["all_gather"] += 1
+        return self._guard(run)
+
+    def _group_start(self):
+        self._ops = []
+        return 0
+
+    def _send(self, buf, count, _dtype, peer, comm, _stream):
+        self._ops.append(("send", int(buf), int(count), int(peer)))
+        return 0
+
+    def _recv(self, buf, count, _dtype, peer, comm, _stream):
+        self._ops.append(("recv", int(buf), int(count), int(peer)))
+        return 0
+
+    def _group_end(self):
+        def run():
+            torch, dist = self._torch, self._dist
+            ops, self._ops = self._ops, []
+            if not ops:
+                return
+            torch.cuda.synchronize()
+            work, landing = [], []
+            for kind, buf, n, peer in ops:
+                if not n:
+                    continue
+                if kind == "send":
+                    work.append(dist.isend(device_words(buf, n, self._device).cpu(), dst=peer))
+                else:
+                    host = torch.empty(n, dtype=torch.int32)
+                    work.append(dist.irecv(host, src=peer))
+                    landing.append((buf, n, host))
+            for w in work:
+                w.wait()
+            for buf, n, host in landing:
+                device_words(buf, n, self._device).copy_(host)
+            torch.cuda.synchronize()
+            self.calls["groups"] += 1
+        return self._guard(run)
+
+
+def try_peer_form(dn, dist, rank, world, device_index, run, rebuild, trial_steps=8, sabotage_rank=None):
+    """The PEER form of the sparse shard step (one launch per step, no collective per step: include/snn_amd.h, snn_p2p_*), TRIED,
+    with a fall-back every rank agrees on.  `dn` has run at least one step over the collective (its halo lists are committed).
+      1. every rank that exchanges anything exports IPC handles of its receive sets, maps its neighbours' and commits; if any
+         rank could not, every rank switches "halo_peer" off and keeps the collective;
+      2. a trial of `trial_steps` steps through `run(k)`; a rank whose polls give up (SNN_ERR_WAIT) has left its handle mid-step
+         and handles cannot be rolled back across ranks, so if ANY rank failed EVERY rank unmaps what it imported, closes its
+         handle and gets a fresh one from `rebuild()` (which must re-apply everything the caller had set on the old one:
+         synthetic drive, history options, warm-up), with "halo_peer" off;
+      3. after a trial that every rank completed, the ranks compare their clocks.
+    `sabotage_rank` (tests): that rank skips its trial, so its neighbours' polls give up.
+    Returns (handle, note); note is "taken" or "fell back to the collective: <why>"."""
+    imported = []
+
+    def connect():
+        plan = dn.exchange_plan()
+        busy = int(plan["send_words"]) + int(plan["recv_words"]) > 0
+        mine, err = None, None
+        try:
+            if busy:
+                loc = dn.p2p_local()
+                mine = (dn.p2p_ipc_export(), [int(x) for x in loc["offsets"]], [int(x) for x in loc["counts"]])
+        except Exception as e:      # noqa: BLE001
+            err = repr(e)
+        everyone = [None] * world
+        dist.all_gather_object(everyone, (mine, err))
+        if any(e for _, e in everyone):
+            return next(e for _, e in everyone if e)
+        try:
+            for p in range(world):
+                theirs = everyone[p][0]
+                if busy and p != rank and theirs is not None and (theirs[2][rank] or mine[2][p]):
+                    r0, r1, fl = dn.p2p_ipc_import(theirs[0], device=device_index)
+                    imported.append((r0, r1, fl))
+                    dn.p2p_connect(p, r0, r1, fl, theirs[1][rank])
+            if busy:
+                dn.p2p_commit()
+        except Exception as e:      # noqa: BLE001
+            err = repr(e)
+        errs = [None] * world
+        dist.all_gather_object(errs, err)
+        return next((e for e in errs if e), None)
+
+    def unmap():
+        for r0, r1, fl in imported:
+            try:
+                dn.p2p_ipc_close(r0, r1, fl, device=device_index)
+            except Exception:       # noqa: BLE001 -- the mapping goes with the process at the latest
+                pass
+        imported.clear()
+
+    failed = connect()
+    if failed is not None:
+        dn.set_option("halo_peer", 0)
+        dist.barrier()
+        unmap()
+        return dn, f"fell back to the collective: {failed[:200]}"
+    trial = None
+    if rank == sabotage_rank:
+        trial = "trial skipped on this rank (test hook)"
+    else:
+        try:
+            run(trial_steps)
+        except Exception as e:      # noqa: BLE001
+            trial = repr(e)
+    trials = [None] * world
+    dist.all_gather_object(trials, (trial, None if trial else int(dn.clock)))
+    failed = next((t for t, _ in trials if t), None)
+    if failed is None and len({c for _, c in trials}) != 1:
+        failed = f"the ranks' clocks differ after the trial: {[c for _, c in trials]}"
+    if failed is None:
+        return dn, "taken"
+    dist.barrier()                  # nobody unmaps while a neighbour's launch may still store into the sets
+    unmap()
+    dn.close()
+    dist.barrier()
+    dn = rebuild()
+    dn.set_option("halo_peer", 0)
+    return dn, f"fell back to the collective: {failed[:200]}"
+
+
 def shard_geometry(n_neurons, n_shards):
     """Slot size and [begin, end) of every shard -- same rule as snn_network_finalize_shard."""
     per = -(-n_neurons // n_shards)            # ceil

@@ -100,7 +100,8 @@ def test_comm_lifecycle_is_refused_while_the_collectives_are_replaced():
 INTEGRATION = os.path.join(os.path.dirname(HEADER), "..", "INTEGRATION.md")
 
 _C_SCALARS = {"int": ctypes.c_int, "uint32_t": ctypes.c_uint32, "uint64_t": ctypes.c_uint64, "size_t": ctypes.c_size_t,
-              "float": ctypes.c_float, "double": ctypes.c_double, "int32_t": ctypes.c_int32, "uint8_t": ctypes.c_uint8}
+              "float": ctypes.c_float, "double": ctypes.c_double, "int32_t": ctypes.c_int32, "uint8_t": ctypes.c_uint8,
+              "int64_t": ctypes.c_int64}
 _RUST_TO_C = {"c_int": "int", "u32": "uint32_t", "u64": "uint64_t", "usize": "size_t", "f32": "float", "f64": "double", "i32": "int32_t",
               "u8": "uint8_t", "c_char": "char", "c_void": "void", "SnnNetwork": "snn_network_t", "SnnExchangePlan": "snn_exchange_plan",
               "SnnCollectives": "snn_collectives"}
@@ -197,3 +198,39 @@ def test_every_option_and_statistic_is_documented_in_the_header():
     stats -= {"run_timing_barrier", "run_timing_turns", "run_timing_update"}
     assert not (options - quoted), f"options the header does not name: {sorted(options - quoted)}"
     assert not (stats - quoted), f"statistics the header does not name: {sorted(stats - quoted)}"
+
+
+def test_every_exported_definition_is_a_function_try_block():
+    """The exception barrier of the C ABI (csrc/snn_network_state.hpp, abi_exception): every entry point the header declares is
+    defined in snn_network.hip as `... snn_x(...) ABI_TRY { ... } ABI_CATCH` -- a function-try-block whose handler turns any C++
+    exception into a status code.  Checked on the text of the translation unit: no definition may be added without it."""
+    src = open(os.path.join(os.path.dirname(_lib.__file__), "csrc", "snn_network.hip")).read()
+    state = open(os.path.join(os.path.dirname(_lib.__file__), "csrc", "snn_network_state.hpp")).read()
+    assert "#define ABI_TRY try" in state and "catch (...) { return abi_exception(__func__); }" in state
+    for name in declared_functions():
+        m = re.search(rf"^(?:int|const char \*)\s*{name}\(", src, flags=re.M)
+        assert m, f"{name} is declared in the header but not defined at the top level of snn_network.hip"
+        depth, j = 0, m.end() - 1
+        while True:                                   # the end of the parameter list
+            depth += {"(": 1, ")": -1}.get(src[j], 0)
+            if depth == 0:
+                break
+            j += 1
+        assert src[j + 1:].lstrip().startswith("ABI_TRY"), f"{name}: the definition does not open with ABI_TRY"
+        # the body's closing brace (braces in string literals do not occur unbalanced in this file) is followed by the handler
+        k = src.index("{", j)
+        depth = 0
+        while True:
+            depth += {"{": 1, "}": -1}.get(src[k], 0)
+            if depth == 0:
+                break
+            k += 1
+        want = "ABI_CATCH_PTR" if src[m.start():m.end()].startswith("const char") else "ABI_CATCH"
+        tail = src[k + 1:k + 40].lstrip()
+        assert tail.startswith(want) and (want == "ABI_CATCH_PTR" or not tail.startswith("ABI_CATCH_PTR")), \
+            f"{name}: the definition does not end with {want}"
+    # and nothing else in the library may use std::vector with the default allocator (every host table counts as an allocation of the
+    # failure hook, snn_debug_fail_alloc_at)
+    for f in ("snn_network.hip", "snn_network_state.hpp", "snn_network_step.hpp", "snn_network_exchange.hpp"):
+        text = re.sub(r"//.*", "", open(os.path.join(os.path.dirname(_lib.__file__), "csrc", f)).read())
+        assert text.count("std::vector<") == (1 if f == "snn_network_state.hpp" else 0), f

@@ -1,5 +1,7 @@
 """Host-side logic that needs no GPU: shard geometry, exchange-buffer layout, synthetic data."""
 import os
+import sys
+
 import numpy as np
 
 import snn_amd
@@ -99,3 +101,60 @@ def test_c5_structure_on_rectangular_lattices():
     sq = synthetic.c5_csr(5)
     sq2 = synthetic.c5_csr(5, cols=5)
     assert all(np.array_equal(a, b) for a, b in zip(sq, sq2))
+
+
+def _first_contact(tmp_path, behaviour):
+    """profiles/first_contact.py against a stub bench: `behaviour` is Python source that may change `line` or exit"""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    stub = tmp_path / "stub_bench.py"
+    stub.write_text(
+        "import argparse, hashlib, json, sys\n"
+        "ap = argparse.ArgumentParser()\n"
+        "for f in ('--gpus', '--steps', '--warmup', '--rows', '--cols'): ap.add_argument(f, type=int, default=1)\n"
+        "ap.add_argument('--config'); ap.add_argument('--scaling', default='strong')\n"
+        "for f in ('--peer-form', '--no-cpu-baseline', '--emulate-ranks-on-one-gpu'): ap.add_argument(f, action='store_true')\n"
+        "a = ap.parse_args()\n"
+        "extra = 8 + a.warmup if a.peer_form else 0\n"
+        "steps = a.warmup + extra + 5 * a.steps\n"
+        "net = (a.config, a.gpus if a.scaling == 'weak' else 1, steps)\n"
+        "line = {'value': 1e6 * a.gpus * 0.9, 'ms_per_step': 1.0 / a.gpus, 'n_gpus': a.gpus, 'rccl_ranks': a.gpus if a.gpus > 1 else None,\n"
+        "        'peer_form': 'taken' if a.peer_form and a.gpus > 1 else None, 'halo_peer_steps': 99 if a.peer_form and a.gpus > 1 else 0,\n"
+        "        'state_sha256': hashlib.sha256(repr(net).encode()).hexdigest(), 'state_after_steps': steps,\n"
+        "        'rank_times': {'step_ms_by_rank': [1.0] * a.gpus, 'compute_only_ms_by_rank': None, 'exchange_ms_by_rank': None},\n"
+        "        'roofline': {'frac': 0.5}}\n"
+        + behaviour +
+        "\nprint('noise before the line')\nprint(json.dumps(line))\n")
+    out = tmp_path / "out"
+    p = subprocess.run([sys.executable, os.path.join(root, "profiles", "first_contact.py"), "--skip-tests", "--gpus-list", "1,2,4", "--steps", "10",
+                        "--warmup", "3", "--out", str(out), "--bench", f"{sys.executable} {stub}"], capture_output=True, text=True, timeout=300)
+    return p, json.load(open(out / "first_contact.json"))
+
+
+def test_first_contact_script_collects_one_table(tmp_path):
+    p, rep = _first_contact(tmp_path, "")
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert rep["ok"] and len(rep["rows"]) == 5 * 3 and not rep["problems"]
+    by = {(r["series"], r["n_gpus"]): r for r in rep["rows"]}
+    assert by[("c2 strong", 4)]["efficiency_vs_first_n"] == 1.0 and by[("c5 strong peer form", 2)]["peer_form"] == "taken"
+    # the collective series of c5 is given the step count of the peer-form series: their checksums are comparable (and equal here)
+    assert by[("c5 strong collective", 2)]["state_after_steps"] == by[("c5 strong peer form", 2)]["state_after_steps"]
+    assert by[("c5 strong collective", 2)]["state_sha256"] == by[("c5 strong peer form", 2)]["state_sha256"]
+    assert "| c5 weak peer form | 4 |" in p.stdout and "no problems" in p.stdout
+
+
+def test_first_contact_script_fails_on_a_checksum_difference(tmp_path):
+    p, rep = _first_contact(tmp_path, "if a.config == 'c5' and a.gpus == 2 and not a.peer_form and a.scaling == 'strong': line['state_sha256'] = 'f' * 64")
+    assert p.returncode == 1 and not rep["ok"]
+    text = " ".join(rep["problems"])
+    assert "c5 strong collective: the checksum at N = 2 differs from N = 1" in text
+    assert "c5 strong, N = 2: the peer form's checksum differs from the collective's" in text
+
+
+def test_first_contact_script_fails_on_a_failed_run_or_a_missing_communicator(tmp_path):
+    p, rep = _first_contact(tmp_path, "if a.config == 'c2' and a.gpus == 4: sys.exit(3)\nif a.config == 'c5' and a.gpus == 2: line['rccl_ranks'] = 1\n"
+                                      "if a.peer_form and a.gpus == 4: line['peer_form'] = 'fell back to the collective: hipIpcOpenMemHandle'")
+    assert p.returncode == 1
+    text = " ".join(rep["problems"])
+    assert "c2 strong, N = 4: no bench line (exit 3)" in text and "rccl_ranks is 1" in text and "the peer form was not taken" in text
