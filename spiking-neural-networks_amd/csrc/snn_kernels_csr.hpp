@@ -267,6 +267,135 @@ __device__ __forceinline__ void csr_row_sums(const CsrInputsArgs &a, uint32_t q,
     // can hold (it starts at +0.0f, so it is never -0.0f): skipping them is exact.
 }
 
+// ---- the STEP IMAGE of a sparse graph (round 6) -------------------------------------------------------------------------------
+// What the one-launch step reads per row when the weights are static (no weight update of any kind) and only gap junctions are on
+// -- BASELINE configs[4].  Derived from the SELL arrays, rebuilt when the graph or a weight changes (ensure_step_image):
+//   * records: TWO consecutive entries of a row as one 16-byte record {plan word, weight bits, plan word, weight bits}, record j of a
+//     slice's lane at rec[first + j * 64 + lane]: a wavefront's load is 1 KiB contiguous (the dense pass's shape) where the plain
+//     form issues four 256-byte loads; the same 8 B per stored synapse.
+//   * per slice a header of IMG_HDR_WORDS words at a fixed address (slice * IMG_HDR_WORDS): {first record, records per lane,
+//     window pieces, 0} and up to IMG_MAX_PIECES pieces {source code of the first word, words <= 64}.  The pieces are the
+//     run-length union of everything the slice's 64 rows gather (neighbouring rows of a lattice read neighbouring neurons:
+//     configs[4] reads 12 + 1 + 1 sources per row, 5.3 distinct words per row).  The wavefront requests them with coalesced loads
+//     TOGETHER with its records -- neither depends on the other -- and parks them in its 4 KiB of LDS; a staged slice's plan word
+//     is the LDS word of its source (bits 0..15; bit 30: a spike-train cell, whose two view words sit side by side; bit 31: the
+//     entry opens a new 256-index chunk, as in the plain plan), so the gather is a ds_read: one dependent memory round trip per
+//     row instead of two per batch, 5.3 words from L2 per row instead of 14 scattered ones.  A slice whose union needs more
+//     than IMG_MAX_PIECES pieces (an unstructured graph) has no pieces: its plan words are the plain codes and the rows gather
+//     from global memory as before -- still through 16-byte records.
+// The sums are the canonical ones (ascending, chunk flush): bit-identical to csr_row_sums and to the dense kernel.
+constexpr uint32_t IMG_HDR_WORDS = 40, IMG_MAX_PIECES = 16, IMG_PIECE_WORDS = 64, IMG_CELL_BIT = 0x40000000u;
+#ifndef SNN_IMG_RING
+#define SNN_IMG_RING 4
+#endif
+constexpr uint32_t IMG_RING = SNN_IMG_RING;               // records (16 B each) a lane keeps in flight; even
+constexpr uint32_t IMG_WIN_WORDS = IMG_MAX_PIECES * IMG_PIECE_WORDS;           // LDS words per wavefront
+struct CsrImage {
+    const uint32_t *hdr;         // [n_slices][IMG_HDR_WORDS]; null: the launch takes the plain form
+    const uint4 *rec;
+};
+
+// the sums of one row over its records; STAGED: the gathers are reads of the wavefront's window
+template <bool STAGED>
+__device__ __forceinline__ void csr_img_sums(const InputsArgs &in, const uint4 *rec, uint32_t pairs, const uint32_t *win, const uint32_t *xv,
+                                             const uint32_t *cv, float vq, float gq, uint4 (&r)[IMG_RING], float &sum)
+{
+    constexpr uint32_t RING = IMG_RING;
+    float part = 0.0f;
+    bool open = false;
+    sum = 0.0f;
+    for (uint32_t j0 = 0; j0 < pairs; j0 += RING) {
+#pragma unroll
+        for (uint32_t u = 0; u < RING; u += 2) {
+            // two records = four entries: their gathers together, then their adds in ascending order
+            uint32_t word[4] = {r[u].x, r[u].z, r[u + 1].x, r[u + 1].z};
+            const float w[4] = {__uint_as_float(r[u].y), __uint_as_float(r[u].w), __uint_as_float(r[u + 1].y), __uint_as_float(r[u + 1].w)};
+            if (j0 + u >= pairs) word[0] = word[1] = PLAN_CODE;              // (a clamped load past the row: dropped)
+            if (j0 + u + 1 >= pairs) word[2] = word[3] = PLAN_CODE;
+            float v[4];
+            uint32_t silent[4];
+#pragma unroll
+            for (uint32_t e = 0; e < 4; ++e) {
+                const bool is_pad = (word[e] & PLAN_CODE) == PLAN_CODE;
+                if (STAGED) {
+                    const uint32_t off = is_pad ? 0u : (word[e] & 0xFFFFu);
+                    v[e] = __uint_as_float(win[off]);
+                    silent[e] = win[off + 1u];                               // (read for every entry: branch-free; used for cells)
+                } else {
+                    // an unstaged slice: the plain codes, gathered from the exchanged state / the cells' view
+                    const uint32_t code = word[e] & PLAN_CODE;
+                    const bool is_cell = !is_pad && code >= in.n_neurons;
+                    const uint32_t *src = is_cell ? cv + 2u * (size_t)(code - in.n_neurons) : xv + (is_pad ? 0u : code);
+                    v[e] = __uint_as_float(src[0]);
+                    silent[e] = is_cell ? src[1] : 0u;
+                    if (!is_pad) word[e] = (word[e] & 0x80000000u) | (is_cell ? IMG_CELL_BIT : 0u);
+                }
+            }
+            // these two register sets are free: the records RING further on (clamped: a row without them re-reads its last one)
+            r[u] = rec[(size_t)min(j0 + RING + u, pairs - 1) * 64];
+            r[u + 1] = rec[(size_t)min(j0 + RING + u + 1, pairs - 1) * 64];
+#pragma unroll
+            for (uint32_t e = 0; e < 4; ++e) {
+                if ((word[e] & PLAN_CODE) == PLAN_CODE) continue;            // padding only ever trails a row
+                if (word[e] >> 31) {                                         // first entry of a 256-index chunk: flush the previous one
+                    if (open) sum += part;
+                    part = 0.0f;
+                    open = true;
+                }
+                // gap_junction neuron/mod.rs:54-60; spike_train_gap_junction :119-137 (never fired: v_resting without the conductance)
+                const float term = (word[e] & IMG_CELL_BIT) ? (silent[e] ? v[e] : gq * v[e]) : gq * (v[e] - vq);
+                part += term * w[e];
+            }
+        }
+    }
+    if (open) sum += part;
+}
+
+__device__ __forceinline__ void csr_row_sums_img(const CsrInputsArgs &a, const CsrImage &im, uint32_t q, uint32_t *win, float &sum)
+{
+    // records in flight per lane: IMG_RING x 16 bytes (4 KiB per wavefront, 128 KiB per CU at full occupancy -- several times what
+    // the memory side needs in flight); each register set is reloaded as soon as its record has been summed (a ring: the
+    // stream never waits for the sums, and no gather ever waits for memory)
+    constexpr uint32_t RING = IMG_RING;
+    const InputsArgs &in = a.in;
+    const uint32_t slice = __builtin_amdgcn_readfirstlane(q >> 6), lane = q & 63u;
+    // (the header is read-only for the launch and its address wave-uniform: through the constant address space it arrives by
+    // scalar loads, header and pieces in three instructions, instead of one vector load and one wait per word)
+    typedef uint32_t words4 __attribute__((ext_vector_type(4)));
+    typedef uint32_t words16 __attribute__((ext_vector_type(16)));
+    const uint32_t *hdr_at = im.hdr + (size_t)slice * IMG_HDR_WORDS;
+    const words4 head = *(const __attribute__((address_space(4))) words4 *)hdr_at;
+    const words16 pc0 = *(const __attribute__((address_space(4))) words16 *)(hdr_at + 4), pc1 = *(const __attribute__((address_space(4))) words16 *)(hdr_at + 20);
+    const uint32_t first = head.x, pairs = head.y, n_pieces = head.z;          // wave-uniform
+    sum = 0.0f;
+    if (pairs == 0) return;
+    const bool row_valid = q < a.g.n_loc;
+    const uint32_t qq = row_valid ? q : 0u;
+    const uint32_t gq_index = in.rows.global_of(qq);
+    const float vq = in.xbuf[in.xl.at(gq_index, PLANE_V)];
+    const float gq = uload(in.uni, NP_GAP, in.gap_conductance, gq_index);
+    const uint4 *rec = im.rec + first + lane;
+    uint4 r[RING];
+#pragma unroll
+    for (uint32_t u = 0; u < RING; ++u) r[u] = rec[(size_t)min(u, pairs - 1) * 64];
+    // The window: every piece one LDS-DMA load (global_load_lds_dword) of at most 64 words -- no register holds a window word
+    // (the rows' records own the register file) and there is no ds_write pass; the destination of a wave instruction is
+    // base + lane * 4, which is what a piece is.  Pieces the slice does not have are 0 words long: no lane takes part.
+    const uint32_t *xv = reinterpret_cast<const uint32_t *>(in.xbuf) + in.xl.at(0, PLANE_V);
+    const uint32_t *cv = reinterpret_cast<const uint32_t *>(in.st_view);
+#pragma unroll
+    for (uint32_t u = 0; u < IMG_MAX_PIECES; ++u) {
+        const uint32_t code = u < 8 ? pc0[2 * (u & 7u)] : pc1[2 * (u & 7u)], words = u < 8 ? pc0[2 * (u & 7u) + 1] : pc1[2 * (u & 7u) + 1];
+        const uint32_t *src = code < in.n_neurons ? xv + code : cv + 2u * (size_t)(code - in.n_neurons);
+        if (lane < words)
+            __builtin_amdgcn_global_load_lds(src + lane, (__attribute__((address_space(3))) uint32_t *)(win + u * IMG_PIECE_WORDS), 4, 0, 0);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0070 | 0x0F00 | 0xC000);         // vmcnt(0): records and window have landed (expcnt / lgkmcnt left alone)
+    __builtin_amdgcn_wave_barrier();                              // (one wavefront fills and reads its own window: no workgroup barrier)
+    if (n_pieces) csr_img_sums<true>(in, rec, pairs, win, xv, cv, vq, gq, r, sum);
+    else csr_img_sums<false>(in, rec, pairs, win, xv, cv, vq, gq, r, sum);
+}
+
 template <bool ELEC, bool CHEM>
 __global__ __launch_bounds__(256) void k_inputs_csr(const CsrInputsArgs a)
 {
@@ -438,11 +567,12 @@ struct CsrStepArgs {
     StepCloseArgs tail;
     uint32_t xcd_bands;             // 1: row blocks are dealt to the XCDs in contiguous bands (see k_step_csr)
     PeerSignal peer;
+    CsrImage img;                   // k_step_csr<..., IMG = true>: the step image the rows read
 };
 static_assert(sizeof(CsrStepArgs) <= 4096, "kernel arguments are limited to 4 KB");
 
-template <int MODEL, bool ELEC, bool CHEM, bool PEER>
-__device__ __forceinline__ void step_csr_block(const CsrStepArgs &a)
+template <int MODEL, bool ELEC, bool CHEM, bool PEER, bool IMG = false>
+__device__ __forceinline__ void step_csr_block(const CsrStepArgs &a, uint32_t *win = nullptr)
 {
     // the tail jobs come AFTER the row blocks: they fill the tail of the rows' streaming (cells at C5, one box, step time:
     // cells in their own launch 44.7 us; cell blocks first 41.5; spread evenly among the row blocks 45.6; last 39.3)
@@ -465,14 +595,19 @@ __device__ __forceinline__ void step_csr_block(const CsrStepArgs &a)
     // the row's entries of the pack table are requested BEFORE the row sums (they depend on nothing the sums produce): a
     // border launch of a few workgroups is a chain of dependent memory round trips, these two overlap with the sums'
     uint32_t pack_begin = 0, pack_end = 0, seg0_count = 0, seg0_index = 0, seg0_off = 0;
-    if (a.pack.ptr && q < a.c.g.n_loc) {
+    if (!IMG && a.pack.ptr && q < a.c.g.n_loc) {
         pack_begin = a.pack.ptr[q]; pack_end = a.pack.ptr[q + 1];
         if (pack_end > pack_begin) {
             seg0_count = a.pack.seg_count[pack_begin]; seg0_index = a.pack.index[pack_begin]; seg0_off = a.pack.seg_off[pack_begin];
         }
     }
     RegisterSums s;
-    csr_row_sums<ELEC, CHEM, PEER>(a.c, q, s.i, s.t);
+    if constexpr (IMG) {
+        s.t[0] = s.t[1] = s.t[2] = 0.0f;
+        csr_row_sums_img(a.c, a.img, q, win + (threadIdx.x >> 6) * IMG_WIN_WORDS, s.i);
+    } else {
+        csr_row_sums<ELEC, CHEM, PEER>(a.c, q, s.i, s.t);
+    }
     uint32_t spike = 0;
     float v_new = 0.0f;
     // (a range-set shard owns whole 64-blocks of the global index space only in part: the rows of the neurons it does not own
@@ -544,6 +679,32 @@ __global__ __launch_bounds__(256, (CSR_PREFETCH && ELEC && !CHEM && !PEER) ? 8 :
             __hip_atomic_store(a.peer.signal[i], a.peer.done_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     step_csr_block<MODEL, ELEC, CHEM, PEER>(a);
+}
+
+// the electrical step over the step image (static weights, no peer form): 16 KiB of LDS per workgroup, one window per wavefront.
+// (No second launch bound: with a ring of four records every model but Hodgkin-Huxley allocates at most 64 registers by itself --
+// eight wavefronts per SIMD, tests/test_isa_resources.py -- and forcing Hodgkin-Huxley there makes it spill.)
+template <int MODEL>
+__global__ __launch_bounds__(256) void k_step_csr_img(const CsrStepArgs a)
+{
+    __shared__ uint32_t win[4 * IMG_WIN_WORDS];
+    step_csr_block<MODEL, true, false, false, true>(a, win);
+}
+
+// the records of the step image from the SELL arrays: {plan_win[k], w[k], plan_win[k + 1], w[k + 1]} per lane and pair
+__global__ __launch_bounds__(256) void k_csr_image(SellGraph g, const uint32_t *plan_win, const uint32_t *hdr, uint4 *rec)
+{
+    const uint32_t q = blockIdx.x * 256 + threadIdx.x;
+    if ((q >> 6) >= g.n_slices) return;
+    const uint32_t s0 = g.slice_ptr[q >> 6];
+    const uint32_t width = (g.slice_ptr[(q >> 6) + 1] - s0) >> 6;
+    const uint32_t first = hdr[(size_t)(q >> 6) * IMG_HDR_WORDS];
+    for (uint32_t j = 0; 2 * j < width; ++j) {
+        const size_t e0 = s0 + (q & 63u) + (size_t)(2 * j) * 64, e1 = e0 + 64;
+        uint4 r{plan_win[e0], __float_as_uint(g.w[e0]), PLAN_CODE, 0u};
+        if (2 * j + 1 < width) { r.z = plan_win[e1]; r.w = __float_as_uint(g.w[e1]); }
+        rec[first + (size_t)j * 64 + (q & 63u)] = r;
+    }
 }
 
 // static counts of a sparse graph: n_in = row length, tcount[k] = entries whose presynaptic cell carries type k

@@ -637,19 +637,10 @@ __device__ __forceinline__ RegisterSums combine_all_planes(const UpdateArgs &a, 
     return out;
 }
 
-// ALL_PLANES: a dense handle with chemical synapses (its own instantiation: the batch registers of combine_all_planes would
-// otherwise cost the electrical-only update its occupancy)
-template <int MODEL, bool ALL_PLANES = false>
-__global__ __launch_bounds__(256) void k_update(const UpdateArgs a)
+// what follows a wavefront's neuron updates: the handle's own slot of the wire buffer (dense shard handles) and the raster word.
+// ql = the local column of this lane; every lane of the wavefront calls it (ballots)
+__device__ __forceinline__ void update_epilogue(const UpdateArgs &a, uint32_t ql, bool active, uint32_t spike, float v_new)
 {
-    const uint32_t ql = blockIdx.x * blockDim.x + threadIdx.x;           // blockDim.x = 64 or 256
-    const bool active = ql < a.n_loc && a.rows.active(ql, a.n_loc);
-    float v_new = 0.0f;
-    uint32_t spike = 0u;
-    if (active) {
-        if (ALL_PLANES) spike = update_neuron_at<MODEL>(a, ql, combine_all_planes(a, ql), a.clock, a.vhist_row, &v_new);
-        else spike = update_neuron_at<MODEL>(a, ql, GlobalSums{a, ql}, a.clock, a.vhist_row, &v_new);
-    }
     if (a.wire_out) {
         // entries past the shard's neurons (slot padding) stay zero: nothing ever writes them
         if (active) {
@@ -676,6 +667,111 @@ __global__ __launch_bounds__(256) void k_update(const UpdateArgs a)
             if (g < a.n.n_pad) a.spike_row[g >> 6] = word;
         }
     }
+}
+
+// ALL_PLANES: a dense handle with chemical synapses (its own instantiation: the batch registers of combine_all_planes would
+// otherwise cost the electrical-only update its occupancy)
+template <int MODEL, bool ALL_PLANES = false>
+__global__ __launch_bounds__(256) void k_update(const UpdateArgs a)
+{
+    const uint32_t ql = blockIdx.x * blockDim.x + threadIdx.x;           // blockDim.x = 64 or 256
+    const bool active = ql < a.n_loc && a.rows.active(ql, a.n_loc);
+    float v_new = 0.0f;
+    uint32_t spike = 0u;
+    if (active) {
+        if (ALL_PLANES) spike = update_neuron_at<MODEL>(a, ql, combine_all_planes(a, ql), a.clock, a.vhist_row, &v_new);
+        else spike = update_neuron_at<MODEL>(a, ql, GlobalSums{a, ql}, a.clock, a.vhist_row, &v_new);
+    }
+    update_epilogue(a, ql, active, spike, v_new);
+}
+
+// The update of a dense handle with chemical synapses, WIDE (round 6): a workgroup is 64 columns x 4 wavefronts; wavefront s
+// requests ITS quarter of every live plane's chunk partials at once (configs[2]: 64 chunks, two planes -- 32 loads per lane, one
+// round trip where k_update<MODEL, true> made two of 64), the running sums pass from wavefront to wavefront through LDS -- wavefront
+// 0 adds chunks [0, per) from 0.0f, wavefront 1 continues with [per, 2 per) ...: the canonical ascending order, add for add -- and
+// wavefront 3 updates the neurons.  While the partials are on their way the other three wavefronts TOUCH the arrays the update is
+// about to read (TouchList, one load per array and lane, result dropped): the update's loads then hit the CU's cache instead of
+// making a second trip to memory behind the first.  Four times the workgroups of k_update (configs[2]: 256, one per CU).
+struct TouchList {
+    const uint32_t *by_neuron[56];     // arrays indexed by the global neuron
+    const uint32_t *by_column[8];      // ... by the local column (static counts)
+    uint32_t n_neuron, n_column;
+};
+
+template <int MODEL>
+__global__ __launch_bounds__(256) void k_update_wide(const UpdateArgs a, const TouchList touch)
+{
+    constexpr uint32_t B = 16;
+    __shared__ float run[1 + K_TYPES][64];
+    const uint32_t lane = threadIdx.x & 63u, seg = threadIdx.x >> 6;
+    const uint32_t ql = blockIdx.x * 64u + lane;                         // < ld: the grid is ld / 64 workgroups
+    const uint32_t per = (a.n_chunks + 3u) / 4u;
+    const uint32_t c0 = min(seg * per, a.n_chunks), c1 = min(c0 + per, a.n_chunks);
+    const float *plane[1 + K_TYPES];
+    bool on[1 + K_TYPES];
+    plane[0] = a.part_i + ql;
+    on[0] = a.electrical != 0;
+#pragma unroll
+    for (int k = 0; k < K_TYPES; ++k) {
+        plane[1 + k] = a.part_t + (size_t)k * a.n_chunks * a.ld + ql;
+        on[1 + k] = a.chemical && (a.live_mask >> k & 1u) != 0u;         // (the planes of the other types hold zeros)
+    }
+    // the first batch of this wavefront's partials: requested before anything is waited for
+    float v[1 + K_TYPES][B];
+#pragma unroll
+    for (int pl = 0; pl < 1 + K_TYPES; ++pl)
+        if (on[pl]) {                                                    // launch-uniform
+#pragma unroll
+            for (uint32_t u = 0; u < B; ++u) v[pl][u] = plane[pl][(size_t)min(c0 + u, a.n_chunks - 1u) * a.ld];
+        }
+    const bool active = ql < a.n_loc && a.rows.active(ql, a.n_loc);
+    if (seg != 3u && active) {
+        const uint32_t q = a.rows.global_of(ql);
+        for (uint32_t i = seg; i < touch.n_neuron; i += 3u) { const uint32_t x = touch.by_neuron[i][q]; asm volatile("" ::"v"(x)); }
+        for (uint32_t i = seg; i < touch.n_column; i += 3u) { const uint32_t x = touch.by_column[i][ql]; asm volatile("" ::"v"(x)); }
+    }
+    float sum[1 + K_TYPES] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (uint32_t turn = 0; turn < 4u; ++turn) {
+        if (seg == turn) {
+            if (turn) {
+#pragma unroll
+                for (int pl = 0; pl < 1 + K_TYPES; ++pl) sum[pl] = run[pl][lane];
+            }
+            for (uint32_t c = c0; c < c1; c += B) {
+                if (c != c0) {                                           // (more than B chunks per wavefront: further batches)
+#pragma unroll
+                    for (int pl = 0; pl < 1 + K_TYPES; ++pl)
+                        if (on[pl]) {
+#pragma unroll
+                            for (uint32_t u = 0; u < B; ++u) v[pl][u] = plane[pl][(size_t)min(c + u, a.n_chunks - 1u) * a.ld];
+                        }
+                }
+#pragma unroll
+                for (int pl = 0; pl < 1 + K_TYPES; ++pl)
+                    if (on[pl]) {
+#pragma unroll
+                        for (uint32_t u = 0; u < B; ++u)
+                            if (c + u < c1) sum[pl] += v[pl][u];         // (wave-uniform bound)
+                    }
+            }
+            if (turn < 3u) {
+#pragma unroll
+                for (int pl = 0; pl < 1 + K_TYPES; ++pl) run[pl][lane] = sum[pl];
+            }
+        }
+        if (turn < 3u) __syncthreads();
+    }
+    if (seg != 3u) return;
+    float v_new = 0.0f;
+    uint32_t spike = 0u;
+    if (active) {
+        RegisterSums s;
+        s.i = sum[0];
+#pragma unroll
+        for (int k = 0; k < K_TYPES; ++k) s.t[k] = sum[1 + k];
+        spike = update_neuron_at<MODEL>(a, ql, s, a.clock, a.vhist_row, &v_new);
+    }
+    update_epilogue(a, ql, active, spike, v_new);
 }
 
 } // namespace snn

@@ -44,9 +44,10 @@ int snn_network_create(int device, int neuron_model, int nt_kinetics, int recept
     if (const char *e = getenv("SNN_AMD_DENSE_CLOSE_MAX_CHUNKS")) net->dense_close_max_chunks = (uint32_t)strtoul(e, nullptr, 10);
     if (const char *e = getenv("SNN_AMD_PINNED_COPIES")) net->pinned_copies = (e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1;
     if (const char *e = getenv("SNN_AMD_CSR_XCD_BANDS")) net->csr_xcd_bands = (e[0] != '0');
+    if (const char *e = getenv("SNN_AMD_CSR_IMAGE")) net->csr_image = (e[0] != '0');
     if (const char *e = getenv("SNN_AMD_HALO_DIRECT")) net->halo_direct = (e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1;
     if (const char *e = getenv("SNN_AMD_UPDATE_PACKS")) net->update_packs = (e[0] != '0');
-    if (const char *e = getenv("SNN_AMD_UPDATE_ALL_PLANES")) net->update_all_planes = (e[0] != '0');
+    if (const char *e = getenv("SNN_AMD_UPDATE_ALL_PLANES")) net->update_all_planes = (e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 2;
     if (const char *e = getenv("SNN_AMD_CELLS_IN_STEP")) net->cells_in_step = (e[0] != '0');
     if (const char *e = getenv("SNN_AMD_DEFER_RSTDP")) net->defer_rstdp = (e[0] != '0');
     if (const char *e = getenv("SNN_AMD_DEFER_STDP")) net->defer_stdp = (e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : 1;
@@ -79,7 +80,7 @@ int snn_network_destroy(snn_network_t *net) ABI_TRY
     for (void *p : net->allocs) (void)hipFree(p);
     for (void *p : {(void *)net->csr_ptr, (void *)net->csr_pre, (void *)net->csr_post, (void *)net->csr_t_ptr,
                     (void *)net->csr_t_edge, (void *)net->csr_w, (void *)net->csr_row_len, (void *)net->csr_edge_slot,
-                    (void *)net->csr_plan})
+                    (void *)net->csr_plan, (void *)net->csr_img_hdr, (void *)net->csr_plan_win, (void *)net->csr_img_rec})
         if (p) (void)hipFree(p);
     if (net->vhist) (void)hipFree(net->vhist);
     if (net->st_vhist) (void)hipFree(net->st_vhist);
@@ -389,6 +390,71 @@ ABI_CATCH
 
 namespace { int ensure_traces(snn_network *net); int ensure_pending(snn_network *net); }
 
+// The host-built half of the step image (snn_kernels_csr.hpp, "STEP IMAGE").  Per slice: the sorted set of everything its 64 rows
+// gather, cut greedily into pieces -- a piece starts at the first source not yet covered and spans at most 64 LDS words of
+// consecutive sources of one kind (a neuron is one word, a spike-train cell the two words of its view entry), trimmed to the last
+// source it holds.  A slice that needs more than IMG_MAX_PIECES pieces stays unstaged (no pieces, plain codes).
+static void build_step_image_plan(const snn_network *net, const hvec<uint32_t> &slice_ptr, const hvec<uint32_t> &sell_pre, uint32_t n_slices,
+                                  hvec<uint32_t> &hdr, hvec<uint32_t> &plan_win, uint64_t &records, uint64_t &staged_slices)
+{
+    hdr.assign((size_t)n_slices * IMG_HDR_WORDS, 0u);
+    plan_win.assign(sell_pre.size(), PLAN_CODE);
+    records = 0; staged_slices = 0;
+    hvec<uint32_t> codes, offs;
+    for (uint32_t sl = 0; sl < n_slices; ++sl) {
+        const uint32_t s0 = slice_ptr[sl], s1 = slice_ptr[sl + 1], width = (s1 - s0) >> 6;
+        uint32_t *h = &hdr[(size_t)sl * IMG_HDR_WORDS];
+        h[0] = (uint32_t)records; h[1] = (width + 1) / 2;
+        records += (uint64_t)h[1] * 64;
+        if (width == 0) continue;
+        codes.clear();
+        for (uint32_t e = s0; e < s1; ++e)
+            if (sell_pre[e] != SELL_PAD) codes.push_back(sell_pre[e]);
+        std::sort(codes.begin(), codes.end());
+        codes.erase(std::unique(codes.begin(), codes.end()), codes.end());
+        offs.assign(codes.size(), 0u);
+        uint32_t n_pieces = 0;
+        bool staged = !codes.empty();
+        for (size_t i = 0; i < codes.size() && staged;) {
+            const uint32_t start = codes[i];
+            const bool cell = start >= net->nn;
+            const uint32_t per = cell ? 2u : 1u, span = IMG_PIECE_WORDS / per;
+            if (n_pieces == IMG_MAX_PIECES) { staged = false; break; }
+            size_t j = i;
+            while (j < codes.size() && codes[j] - start < span && (codes[j] >= net->nn) == cell) {
+                offs[j] = n_pieces * IMG_PIECE_WORDS + (codes[j] - start) * per;
+                ++j;
+            }
+            h[4 + 2 * n_pieces] = start;
+            h[5 + 2 * n_pieces] = (codes[j - 1] - start + 1) * per;
+            ++n_pieces;
+            i = j;
+        }
+        if (!staged) {
+            n_pieces = 0;
+            for (uint32_t k = 0; k < 2 * IMG_MAX_PIECES; ++k) h[4 + k] = 0u;
+        }
+        h[2] = n_pieces;
+        staged_slices += staged ? 1 : 0;
+        for (uint32_t lane = 0; lane < 64; ++lane) {
+            uint32_t prev = 0;
+            for (uint32_t k = 0; k < width; ++k) {
+                const size_t e = s0 + lane + (size_t)k * 64;
+                const uint32_t p = sell_pre[e];
+                if (p == SELL_PAD) break;                   // padding only ever trails a row
+                const uint32_t chunk_bit = (k == 0 || p / CHUNK != prev / CHUNK) ? 0x80000000u : 0u;
+                prev = p;
+                if (staged) {
+                    const size_t at = std::lower_bound(codes.begin(), codes.end(), p) - codes.begin();
+                    plan_win[e] = offs[at] | (p >= net->nn ? IMG_CELL_BIT : 0u) | chunk_bit;
+                } else {
+                    plan_win[e] = p | chunk_bit;
+                }
+            }
+        }
+    }
+}
+
 static int set_graph_csr_impl(snn_network_t *net, const uint64_t *row_ptr, const uint32_t *pre_index, const float *weights,
                               uint64_t nnz)
 {
@@ -451,7 +517,8 @@ static int set_graph_csr_impl(snn_network_t *net, const uint64_t *row_ptr, const
     TRY(end_run(net));
     for (void **p : {(void **)&net->csr_ptr, (void **)&net->csr_pre, (void **)&net->csr_post, (void **)&net->csr_t_ptr,
                      (void **)&net->csr_t_edge, (void **)&net->csr_w, (void **)&net->csr_row_len,
-                     (void **)&net->csr_edge_slot, (void **)&net->csr_plan}) {
+                     (void **)&net->csr_edge_slot, (void **)&net->csr_plan, (void **)&net->csr_img_hdr, (void **)&net->csr_plan_win,
+                     (void **)&net->csr_img_rec}) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
     }
@@ -469,6 +536,15 @@ static int set_graph_csr_impl(snn_network_t *net, const uint64_t *row_ptr, const
     TRY(up((void **)&net->csr_t_ptr, t_ptr.data(), t_ptr.size() * 4));
     TRY(up((void **)&net->csr_t_edge, t_edge.data(), nnz * 4));
     HIP_TRY(snn_malloc(&net->csr_plan, std::max<size_t>(entries * 4, 256)), SNN_ERR_BUFFER_CREATE);
+    {
+        // the step image's host-built half: slice headers with the window pieces, and the plan words that go with them
+        hvec<uint32_t> img_hdr, plan_win;
+        build_step_image_plan(net, slice_ptr, sell_pre, n_slices, img_hdr, plan_win, net->img_records, net->img_staged_slices);
+        TRY(up((void **)&net->csr_img_hdr, img_hdr.data(), img_hdr.size() * 4));
+        TRY(up((void **)&net->csr_plan_win, plan_win.data(), plan_win.size() * 4));
+        HIP_TRY(snn_malloc(&net->csr_img_rec, std::max<size_t>((size_t)net->img_records * 16, 256)), SNN_ERR_BUFFER_CREATE);
+        net->img_stale = true;
+    }
     if (net->trace) { (void)hipFree(net->trace); net->trace = nullptr; }      // traces belong to the replaced edges
     for (float **m : {&net->pending, &net->edge_counter})                     // ... and so do dw and the counters of its connections
         if (*m) { (void)hipFree(*m); *m = nullptr; }
@@ -1173,6 +1249,7 @@ int snn_debug_checkpoint(snn_network_t *net, int restore) ABI_TRY
     if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
     HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
     TRY(end_run(net));
+    if (restore) net->img_stale = true;          // the sparse weights come back: the step image's records are rebuilt
     auto &cp = net->checkpoint;
     hvec<std::pair<void *, size_t>> arrays;
     for (const auto &kv : net->alloc_bytes)
@@ -1410,6 +1487,7 @@ int snn_run(snn_network_t *net, uint64_t iterations) ABI_TRY
     }
     auto matrices_copy = [&](int half, bool restore) -> int {
         size_t off = (size_t)half * net->verify_big_bytes;
+        if (restore) net->img_stale = true;
         for (const auto &m : matrices) {
             void *side = net->verify_big + off;
             HIP_TRY(hipMemcpyAsync(restore ? m.first : side, restore ? side : m.first, m.second, hipMemcpyDeviceToDevice, net->stream), SNN_ERR_BUFFER_WRITE);
@@ -2258,13 +2336,14 @@ int snn_set_option(snn_network_t *net, const char *name, int value) ABI_TRY
     else if (n == "dense_close") net->dense_close = value != 0;
     else if (n == "cells_in_step") net->cells_in_step = value != 0;
     else if (n == "update_packs") net->update_packs = value != 0;
-    else if (n == "update_all_planes") net->update_all_planes = value != 0;
+    else if (n == "update_all_planes") net->update_all_planes = (value >= 0 && value <= 2) ? value : 2;
     else if (n == "persistent_stdp") net->persistent_stdp = value != 0;
     else if (n == "halo_direct") net->halo_direct = (value >= 0 && value <= 2) ? value : 1;
     else if (n == "halo_peer") { net->halo_peer = value != 0; net->x_agreed = false; }
     else if (n == "halo_peer_delay") net->peer_delay = (uint32_t)std::max(0, std::min(value, 64));
     else if (n == "halo_peer_spin_limit") net->p2p_spin_limit = value > 0 ? (uint32_t)value : (1u << 26);
     else if (n == "csr_xcd_bands") net->csr_xcd_bands = value != 0;
+    else if (n == "csr_image") net->csr_image = value != 0;
     else if (n == "defer_rstdp") net->defer_rstdp = value != 0;
     else if (n == "defer_stdp") net->defer_stdp = (value >= 0 && value <= 3) ? value : 1;
     else if (n == "uniform_params") { net->uniform_params = value != 0; net->uni_dirty = true; }
@@ -2299,6 +2378,8 @@ int snn_get_stat(snn_network_t *net, const char *name, uint64_t *value) ABI_TRY
     else if (n == "steps_dense_one_launch") *value = net->stat_steps_dense_one_launch;
     else if (n == "steps_dense_close") *value = net->stat_steps_dense_close;
     else if (n == "steps_sparse_one_launch") *value = net->stat_steps_sparse_one_launch;
+    else if (n == "steps_sparse_image") *value = net->stat_steps_sparse_image;
+    else if (n == "image_staged_slices") *value = net->img_staged_slices;
     else if (n == "steps_sparse_split") *value = net->stat_steps_sparse_split;
     else if (n == "steps_two_kernel") *value = net->stat_steps_two_kernel;
     else if (n == "shadow_refreshes") *value = net->stat_shadow_refreshes;

@@ -242,7 +242,7 @@ struct snn_network {
     bool send_bits_clean = true;          // every outgoing spike bitmap is zero (what the in-kernel pack ORs into)
     bool update_packed = false;           // this step's own slot of the all-gather buffer was written by k_update
     int update_packs = 1;                 // option "update_packs"
-    int update_all_planes = 1;            // option "update_all_planes"
+    int update_all_planes = 2;            // option "update_all_planes": 1 all planes' partials in one thread, 2 the wide update (k_update_wide)
     bool step_packed = false;             // this step's outgoing segments were written by k_step_csr itself
     bool interior_pending = false;        // the border half of this step is enqueued, the interior slices are not yet
     // Library-driven runs of such a handle (snn_run_sharded): the rows gather the halo from the received segments themselves
@@ -317,6 +317,13 @@ struct snn_network {
     // sparse handles: what the rows read of a cell, two copies (InputsArgs::st_view); rows read cell_view[cell_view_cur],
     // an iteration of the cells writes the other copy and flips
     uint32_t *csr_plan = nullptr;            // gather plan of the row sums (SellGraph::plan), built from csr_pre
+    // the step image (snn_kernels_csr.hpp, "STEP IMAGE"): headers + window pieces and the image's plan words are built on the
+    // host with the graph; the records {plan word, weight} x 2 are packed on the device when the image is first needed and again
+    // after anything changed a weight (img_stale)
+    uint32_t *csr_img_hdr = nullptr, *csr_plan_win = nullptr;
+    uint4 *csr_img_rec = nullptr;
+    uint64_t img_records = 0, img_staged_slices = 0;
+    bool img_stale = true, csr_image = true;      // csr_image: option "csr_image"
     uint2 *cell_view[2] = {nullptr, nullptr};
     int cell_view_cur = 0;
     bool cells_stepped = false;      // this step's cells advanced inside k_step_csr (step_end skips their launch)
@@ -342,6 +349,7 @@ struct snn_network {
     uint64_t stat_run_external_stream = 0;      // run calls that kept one launch per step only because the handle runs on a caller's stream
     // which form each step took (statistics "steps_*"): k_step_resident, k_step_csr whole, k_step_csr border + interior,
     // input pass + k_update
+    uint64_t stat_steps_sparse_image = 0;
     uint64_t stat_steps_dense_one_launch = 0, stat_steps_sparse_one_launch = 0, stat_steps_sparse_split = 0, stat_steps_two_kernel = 0;
     uint64_t stat_steps_dense_close = 0;         // streamed dense steps whose input pass also updated the neurons (k_inputs_dense_close)
     uint64_t stat_shadow_refreshes = 0, stat_view_refreshes = 0, stat_history_regrows = 0;

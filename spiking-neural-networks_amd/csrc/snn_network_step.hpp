@@ -246,6 +246,15 @@ int launch_inputs(snn_network *net, InputsPart part = INPUTS_ALL)
     return SNN_OK;
 }
 
+// -DSNN_LAB_BUILD: a library for kernel experiments (profiles/experiments/README.md) that instantiates the model-templated kernels
+// for Izhikevich and Hodgkin-Huxley only -- a quarter of the compile time; never the library the tests or the bench load by default
+#ifdef SNN_LAB_BUILD
+#define SNN_FOR_MODEL(MACRO)                                                                                         \
+    switch (net->model) {                                                                                            \
+    case 2: MACRO(2); break;                                                                                         \
+    default: MACRO(0); break;                                                                                        \
+    }
+#else
 #define SNN_FOR_MODEL(MACRO)                                                                                         \
     switch (net->model) {                                                                                            \
     case 1: MACRO(1); break;                                                                                         \
@@ -257,6 +266,7 @@ int launch_inputs(snn_network *net, InputsPart part = INPUTS_ALL)
     case 7: MACRO(7); break;                                                                                         \
     default: MACRO(0); break;                                                                                        \
     }
+#endif
 
 int launch_update(snn_network *net)
 {
@@ -289,17 +299,41 @@ int launch_update(snn_network *net)
     dim3 grid((net->ld + ub - 1) / ub);
     // built-in models on dense handles with chemical synapses: the partials of every plane requested together
     const bool all_planes = net->update_all_planes && net->chemical && !net->csr && net->model != SNN_MODEL_CUSTOM;
+    // ... and, by default, WIDE: four wavefronts share a column's partials and three of them warm the cache for the fourth
+    const bool wide = all_planes && net->update_all_planes >= 2 && a.n_chunks >= 4 && (a.n_chunks + 3) / 4 <= 32;
+    TouchList touch{};
+    if (wide) {
+        grid = dim3(net->ld / 64);
+        auto add = [&](const void *p) {
+            if (!p || touch.n_neuron >= 56) return;
+            for (uint32_t i = 0; i < touch.n_neuron; ++i) if (touch.by_neuron[i] == p) return;
+            touch.by_neuron[touch.n_neuron++] = static_cast<const uint32_t *>(p);
+        };
+        for (const auto &kv : net->neuron_attrs) {
+            const Attr &at = kv.second;
+            if (at.store == S_PLAIN) add(at.base);
+            else if (at.store == S_PLAIN_K)
+                for (int k = 0; k < K_TYPES; ++k) if (a.live_mask >> k & 1u) add(static_cast<const uint32_t *>(at.base) + (size_t)k * at.pad);
+        }
+        for (int pl : {PLANE_V, PLANE_SPIKE}) add(net->xbuf + net->xl.at(0, pl));
+        for (int k = 0; k < K_TYPES; ++k) if (a.live_mask >> k & 1u) add(net->xbuf + net->xl.at(0, PLANE_T0 + k));
+        touch.by_column[touch.n_column++] = net->n_in;
+        for (int k = 0; k < K_TYPES; ++k) if (a.live_mask >> k & 1u) touch.by_column[touch.n_column++] = net->tcount + (size_t)k * net->ld;
+    }
 #define SNN_LAUNCH_UPDATE(M) do { \
-        if (all_planes) hipLaunchKernelGGL((k_update<M, true>), grid, dim3(ub), 0, net->stream, a); \
+        if (wide) hipLaunchKernelGGL((k_update_wide<M>), grid, dim3(256), 0, net->stream, a, touch); \
+        else if (all_planes) hipLaunchKernelGGL((k_update<M, true>), grid, dim3(ub), 0, net->stream, a); \
         else hipLaunchKernelGGL((k_update<M, false>), grid, dim3(ub), 0, net->stream, a); } while (0)
     switch (net->model) {
-    case SNN_MODEL_LIF: SNN_LAUNCH_UPDATE(1); break;
     case SNN_MODEL_HODGKIN_HUXLEY: SNN_LAUNCH_UPDATE(2); break;
+#ifndef SNN_LAB_BUILD
+    case SNN_MODEL_LIF: SNN_LAUNCH_UPDATE(1); break;
     case SNN_MODEL_QUADRATIC_INTEGRATE_AND_FIRE: SNN_LAUNCH_UPDATE(3); break;
     case SNN_MODEL_SIMPLE_LIF: SNN_LAUNCH_UPDATE(4); break;
     case SNN_MODEL_ADAPTIVE_LIF: SNN_LAUNCH_UPDATE(5); break;
     case SNN_MODEL_ADAPTIVE_EXP_LIF: SNN_LAUNCH_UPDATE(6); break;
     case SNN_MODEL_LEAKY_IZHIKEVICH: SNN_LAUNCH_UPDATE(7); break;
+#endif
 #if SNN_HAVE_CUSTOM_NEURON
     case SNN_MODEL_CUSTOM: hipLaunchKernelGGL((k_update<CUSTOM_MODEL, false>), grid, dim3(ub), 0, net->stream, a); break;
 #endif
@@ -381,6 +415,7 @@ int launch_plasticity_kernels(snn_network *net)
         CsrStdpArgs ca{};
         ca.g = csr_graph(net);
         ca.s = a;
+        net->img_stale = true;              // (weights change: the step image's records are behind)
         hipLaunchKernelGGL(k_stdp_csr_in, dim3(1024), dim3(64), 0, net->stream, ca);
         HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
         hipLaunchKernelGGL(k_stdp_csr_out, dim3(1024), dim3(64), 0, net->stream, ca);
@@ -421,6 +456,7 @@ int launch_rstdp_pass(snn_network *net, int dop)
         a.g = csr_graph(net); a.c = net->trace; a.q0 = net->q0; a.rows = net->rowmap; a.n_neurons = net->nn;
         a.last_firing_time = net->na.last_firing_time; a.lattice_slot = net->lattice_slot;
         a.rm = net->rm_dev; a.rm_on = net->rm_on_dev; a.dop = dop;
+        net->img_stale = true;              // (weights change: the step image's records are behind)
         hipLaunchKernelGGL(k_rstdp_csr, dim3((net->n_loc + 255) / 256), dim3(256), 0, net->stream, a);
         HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
         return SNN_OK;
@@ -455,6 +491,7 @@ int launch_reward_cross(snn_network *net)
         CsrRewardCrossArgs c{};
         c.g = csr_graph(net);
         c.r = reward_cross_args(net);
+        net->img_stale = true;              // (weights change: the step image's records are behind)
         hipLaunchKernelGGL(k_reward_cross_csr, dim3((net->n_loc + 255) / 256), dim3(256), 0, net->stream, c);
         HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
         return SNN_OK;
@@ -1147,6 +1184,23 @@ int launch_step_csr(snn_network *net, CsrStepPart part = CSR_STEP_ALL, bool pack
     }
     const uint32_t tail_blocks = c.tail.blocks();
     c.xcd_bands = net->csr_xcd_bands ? 1u : 0u;
+    // the step image (static weights, gap junctions only, every source in this handle's own arrays): records of 16 bytes and the
+    // slices' presynaptic windows in LDS
+    const bool image = net->csr_image && part == CSR_STEP_ALL && !pack && !net->direct_run && !net->peer_run && net->electrical &&
+                       !net->chemical && !net->any_plasticity && !net->any_modulation && !net->any_conn_kind && net->csr_img_hdr &&
+                       net->model != SNN_MODEL_CUSTOM && (net->nc == 0 || c.c.in.st_view);
+    if (image) {
+        if (net->img_stale) {
+            hipLaunchKernelGGL(k_csr_image, dim3((c.c.g.n_slices * 64 + 255) / 256), dim3(256), 0, net->stream, c.c.g, net->csr_plan_win,
+                               net->csr_img_hdr, net->csr_img_rec);
+            HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
+            net->img_stale = false;
+        }
+        c.img.hdr = net->csr_img_hdr; c.img.rec = net->csr_img_rec;
+        net->stat_steps_sparse_image += 1;
+    } else if (net->any_plasticity || net->any_modulation || net->any_conn_kind) {
+        net->img_stale = true;          // this step's weight updates leave the records behind
+    }
     hipEvent_t e1 = nullptr;
     if (waves || tail_blocks) {
         TRY(profile_open(net, &e1));
@@ -1154,7 +1208,8 @@ int launch_step_csr(snn_network *net, CsrStepPart part = CSR_STEP_ALL, bool pack
         const dim3 grid((waves + 3) / 4 + tail_blocks), block(256);
 #define SNN_CSR_STEP(M)                                                                                              \
     do {                                                                                                             \
-        if (net->peer_run && net->electrical && net->chemical) hipLaunchKernelGGL((k_step_csr<M, true, true, true>), grid, block, 0, net->stream, c); \
+        if (image) hipLaunchKernelGGL((k_step_csr_img<M>), grid, block, 0, net->stream, c);                                    \
+        else if (net->peer_run && net->electrical && net->chemical) hipLaunchKernelGGL((k_step_csr<M, true, true, true>), grid, block, 0, net->stream, c); \
         else if (net->peer_run && net->electrical) hipLaunchKernelGGL((k_step_csr<M, true, false, true>), grid, block, 0, net->stream, c); \
         else if (net->peer_run) hipLaunchKernelGGL((k_step_csr<M, false, true, true>), grid, block, 0, net->stream, c);        \
         else if (net->electrical && net->chemical) hipLaunchKernelGGL((k_step_csr<M, true, true>), grid, block, 0, net->stream, c);  \
