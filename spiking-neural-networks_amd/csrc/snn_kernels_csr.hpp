@@ -301,6 +301,7 @@ __device__ __forceinline__ void csr_img_sums(const InputsArgs &in, const uint4 *
                                              const uint32_t *cv, float vq, float gq, uint4 (&r)[IMG_RING], float &sum)
 {
     constexpr uint32_t RING = IMG_RING;
+    const uint32_t last = pairs ? pairs - 1u : 0u;
     float part = 0.0f;
     bool open = false;
     sum = 0.0f;
@@ -332,8 +333,8 @@ __device__ __forceinline__ void csr_img_sums(const InputsArgs &in, const uint4 *
                 }
             }
             // these two register sets are free: the records RING further on (clamped: a row without them re-reads its last one)
-            r[u] = rec[(size_t)min(j0 + RING + u, pairs - 1) * 64];
-            r[u + 1] = rec[(size_t)min(j0 + RING + u + 1, pairs - 1) * 64];
+            r[u] = rec[(size_t)min(j0 + RING + u, last) * 64];
+            r[u + 1] = rec[(size_t)min(j0 + RING + u + 1, last) * 64];
 #pragma unroll
             for (uint32_t e = 0; e < 4; ++e) {
                 if ((word[e] & PLAN_CODE) == PLAN_CODE) continue;            // padding only ever trails a row
@@ -367,17 +368,18 @@ __device__ __forceinline__ void csr_row_sums_img(const CsrInputsArgs &a, const C
     const words4 head = *(const __attribute__((address_space(4))) words4 *)hdr_at;
     const words16 pc0 = *(const __attribute__((address_space(4))) words16 *)(hdr_at + 4), pc1 = *(const __attribute__((address_space(4))) words16 *)(hdr_at + 20);
     const uint32_t first = head.x, pairs = head.y, n_pieces = head.z;          // wave-uniform
+    const uint32_t last = pairs ? pairs - 1u : 0u;       // (a slice without entries reads one record of slack and sums nothing)
     sum = 0.0f;
-    if (pairs == 0) return;
+    // the records first: everything else the row needs queues behind them
+    const uint4 *rec = im.rec + first + lane;
+    uint4 r[RING];
+#pragma unroll
+    for (uint32_t u = 0; u < RING; ++u) r[u] = rec[(size_t)min(u, last) * 64];
     const bool row_valid = q < a.g.n_loc;
     const uint32_t qq = row_valid ? q : 0u;
     const uint32_t gq_index = in.rows.global_of(qq);
     const float vq = in.xbuf[in.xl.at(gq_index, PLANE_V)];
     const float gq = uload(in.uni, NP_GAP, in.gap_conductance, gq_index);
-    const uint4 *rec = im.rec + first + lane;
-    uint4 r[RING];
-#pragma unroll
-    for (uint32_t u = 0; u < RING; ++u) r[u] = rec[(size_t)min(u, pairs - 1) * 64];
     // The window: every piece one LDS-DMA load (global_load_lds_dword) of at most 64 words -- no register holds a window word
     // (the rows' records own the register file) and there is no ds_write pass; the destination of a wave instruction is
     // base + lane * 4, which is what a piece is.  Pieces the slice does not have are 0 words long: no lane takes part.

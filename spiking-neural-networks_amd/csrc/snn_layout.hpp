@@ -86,13 +86,19 @@ struct UniformTable {
     uint32_t flag[16];
     uint32_t bits[16];
 };
+// (The table is written by an earlier launch and its address is wave-uniform: read through the constant address space its
+// entries arrive by SCALAR loads -- no vector-memory round trip in front of the load they decide about, and none at all when the
+// parameter is uniform.  Round 6: as vector loads the flags of a step's parameters were a dependent trip of their own.)
+typedef const __attribute__((address_space(4))) UniformTable *UniformTableK;
 __device__ __forceinline__ float uload(const UniformTable *u, int slot, const float *arr, uint32_t i)
 {
-    return u->flag[slot] ? __uint_as_float(u->bits[slot]) : arr[i];
+    const UniformTableK t = (UniformTableK)u;
+    return t->flag[slot] ? __uint_as_float(t->bits[slot]) : arr[i];
 }
 __device__ __forceinline__ uint32_t uload(const UniformTable *u, int slot, const uint32_t *arr, uint32_t i)
 {
-    return u->flag[slot] ? u->bits[slot] : arr[i];
+    const UniformTableK t = (UniformTableK)u;
+    return t->flag[slot] ? t->bits[slot] : arr[i];
 }
 
 // Pointers the per-neuron update kernels need.  All arrays are device memory.

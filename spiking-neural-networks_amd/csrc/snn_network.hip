@@ -47,7 +47,7 @@ int snn_network_create(int device, int neuron_model, int nt_kinetics, int recept
     if (const char *e = getenv("SNN_AMD_CSR_IMAGE")) net->csr_image = (e[0] != '0');
     if (const char *e = getenv("SNN_AMD_HALO_DIRECT")) net->halo_direct = (e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1;
     if (const char *e = getenv("SNN_AMD_UPDATE_PACKS")) net->update_packs = (e[0] != '0');
-    if (const char *e = getenv("SNN_AMD_UPDATE_ALL_PLANES")) net->update_all_planes = (e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 2;
+    if (const char *e = getenv("SNN_AMD_UPDATE_ALL_PLANES")) net->update_all_planes = (e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : 1;
     if (const char *e = getenv("SNN_AMD_CELLS_IN_STEP")) net->cells_in_step = (e[0] != '0');
     if (const char *e = getenv("SNN_AMD_DEFER_RSTDP")) net->defer_rstdp = (e[0] != '0');
     if (const char *e = getenv("SNN_AMD_DEFER_STDP")) net->defer_stdp = (e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : 1;
@@ -542,7 +542,7 @@ static int set_graph_csr_impl(snn_network_t *net, const uint64_t *row_ptr, const
         build_step_image_plan(net, slice_ptr, sell_pre, n_slices, img_hdr, plan_win, net->img_records, net->img_staged_slices);
         TRY(up((void **)&net->csr_img_hdr, img_hdr.data(), img_hdr.size() * 4));
         TRY(up((void **)&net->csr_plan_win, plan_win.data(), plan_win.size() * 4));
-        HIP_TRY(snn_malloc(&net->csr_img_rec, std::max<size_t>((size_t)net->img_records * 16, 256)), SNN_ERR_BUFFER_CREATE);
+        HIP_TRY(snn_malloc(&net->csr_img_rec, (size_t)net->img_records * 16 + 4096), SNN_ERR_BUFFER_CREATE);    // (+ a wavefront's load of slack)
         net->img_stale = true;
     }
     if (net->trace) { (void)hipFree(net->trace); net->trace = nullptr; }      // traces belong to the replaced edges
@@ -2336,7 +2336,7 @@ int snn_set_option(snn_network_t *net, const char *name, int value) ABI_TRY
     else if (n == "dense_close") net->dense_close = value != 0;
     else if (n == "cells_in_step") net->cells_in_step = value != 0;
     else if (n == "update_packs") net->update_packs = value != 0;
-    else if (n == "update_all_planes") net->update_all_planes = (value >= 0 && value <= 2) ? value : 2;
+    else if (n == "update_all_planes") net->update_all_planes = (value >= 0 && value <= 3) ? value : 1;
     else if (n == "persistent_stdp") net->persistent_stdp = value != 0;
     else if (n == "halo_direct") net->halo_direct = (value >= 0 && value <= 2) ? value : 1;
     else if (n == "halo_peer") { net->halo_peer = value != 0; net->x_agreed = false; }

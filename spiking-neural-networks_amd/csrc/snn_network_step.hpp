@@ -319,6 +319,7 @@ int launch_update(snn_network *net)
         for (int k = 0; k < K_TYPES; ++k) if (a.live_mask >> k & 1u) add(net->xbuf + net->xl.at(0, PLANE_T0 + k));
         touch.by_column[touch.n_column++] = net->n_in;
         for (int k = 0; k < K_TYPES; ++k) if (a.live_mask >> k & 1u) touch.by_column[touch.n_column++] = net->tcount + (size_t)k * net->ld;
+        if (net->update_all_planes == 3) touch.n_neuron = touch.n_column = 0;      // (A/B: the wide form without the cache warming)
     }
 #define SNN_LAUNCH_UPDATE(M) do { \
         if (wide) hipLaunchKernelGGL((k_update_wide<M>), grid, dim3(256), 0, net->stream, a, touch); \

@@ -442,7 +442,7 @@ def try_peer_form(dn, dist, rank, world, device_index, run, rebuild, trial_steps
          handle and gets a fresh one from `rebuild()` (which must re-apply everything the caller had set on the old one:
          synthetic drive, history options, warm-up), with "halo_peer" off;
       3. after a trial that every rank completed, the ranks compare their clocks.
-    `sabotage_rank` (tests): that rank skips its trial, so its neighbours' polls give up.
+    `sabotage_rank` (tests): that rank's polls give up at once while its neighbours store late.
     Returns (handle, note); note is "taken" or "fell back to the collective: <why>"."""
     imported = []
 
@@ -490,13 +490,18 @@ def try_peer_form(dn, dist, rank, world, device_index, run, rebuild, trial_steps
         unmap()
         return dn, f"fell back to the collective: {failed[:200]}"
     trial = None
-    if rank == sabotage_rank:
-        trial = "trial skipped on this rank (test hook)"
-    else:
-        try:
-            run(trial_steps)
-        except Exception as e:      # noqa: BLE001
-            trial = repr(e)
+    if sabotage_rank is not None:
+        # (tests) every rank enters the trial -- the agreement before a run is a collective -- but the sabotaged rank gives up at
+        # its first unanswered poll while the others store late: its run ends with SNN_ERR_WAIT, as a peer that is too slow would
+        if rank == sabotage_rank:
+            dn.set_option("halo_peer_spin_limit", 1)
+        else:
+            dn.set_option("halo_peer_delay", 30)
+            dn.set_option("halo_peer_spin_limit", 2_000_000)
+    try:
+        run(trial_steps)
+    except Exception as e:      # noqa: BLE001
+        trial = repr(e)
     trials = [None] * world
     dist.all_gather_object(trials, (trial, None if trial else int(dn.clock)))
     failed = next((t for t, _ in trials if t), None)

@@ -128,7 +128,7 @@ def worker(args):
     vseen = os.path.getsize(vlog) if os.path.exists(vlog) else 0
     current = [None, None]
     forget = lambda: None
-    if not args.plain:
+    if not args.plain and not args.lean:
         def guard_record(rec):
             rec.update({"worker": args.index, "test": current[0], "seed": current[1]})
             log.write(json.dumps(rec) + "\n")
@@ -239,6 +239,10 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "campaign"))
     ap.add_argument("--plain", action="store_true", help="workers without the verify / malloc-perturb / host-poison arming")
     ap.add_argument("--trap", type=int, default=1, help="armed workers also run the guard arena (tests/guard_arena.py)")
+    ap.add_argument("--lean", action="store_true",
+                    help="the trap with as little else as possible, so that it sees many executions per minute: no device self-check, no "
+                         "checkpoints at the call boundaries, no digest guard (the trap's read-only oracle memory covers what that one "
+                         "watches for CPU writers); malloc perturbation and host poison stay")
     args = ap.parse_args()
     os.makedirs(os.path.join(args.out, "repro"), exist_ok=True)
     if args.role == "worker":
@@ -257,9 +261,11 @@ def main():
     # freed block with a byte pattern (MALLOC_PERTURB_), the binding pre-fills its output buffers (SNN_HOST_POISON)
     worker_env = dict(os.environ)
     if not args.plain:
-        worker_env.setdefault("SNN_AMD_VERIFY", "1")
+        worker_env.setdefault("SNN_AMD_VERIFY", "0" if args.lean else "1")
         worker_env.setdefault("MALLOC_PERTURB_", "165")
         worker_env.setdefault("SNN_HOST_POISON", "1")
+        if args.lean:
+            worker_env.setdefault("SNN_CHECKPOINTS", "0")
     procs = [subprocess.Popen(base + ["--role", "streamer", "--index", str(i)]) for i in range(args.streamers)]
     procs += [subprocess.Popen(base + ["--role", "worker", "--index", str(i)], env=worker_env) for i in range(args.workers)]
     # a process still busy two and a half minutes after the deadline (starved by thirty others, or stuck) is stopped: the summary is
@@ -301,7 +307,7 @@ def main():
             t[0] += n
             t[1] += f
     summary = {"minutes": args.minutes, "wall_s": round(time.time() - t0, 1), "workers": args.workers, "streamers": args.streamers,
-               "streamer_side": args.side, "tests": args.tests, "filter": args.filter, "first_seed": args.first_seed,
+               "streamer_side": args.side, "lean": args.lean, "tests": args.tests, "filter": args.filter, "first_seed": args.first_seed,
                "executions_and_failures": total, "executions": sum(t[0] for t in total.values()),
                "failures": sum(t[1] for t in total.values()), "failure_records": failures, "exit_codes": rcs,
                "oracle_memory_reports": guard_reports[:50], "trap_armed": bool(args.trap and not args.plain),

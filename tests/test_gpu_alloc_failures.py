@@ -90,7 +90,7 @@ def test_every_allocation_of_a_sequence_may_fail(snn, name):
                 arm(snn, 0)
             # the library had a fall-back for this allocation (or it was one of a path the armed pass did not take): same results
             for k in want:
-                assert np.array_equal(np.asarray(got[k]).view(np.uint8), np.asarray(want[k]).view(np.uint8)), (n, k)
+                assert np.array_equal(np.atleast_1d(got[k]).view(np.uint8), np.atleast_1d(want[k]).view(np.uint8)), (n, k)
             outcomes["unchanged"] += 1
         assert outcomes["error"] >= total * 0.8, (outcomes, total)
         assert any("bad_alloc" in m for m in messages), "no host-side table among the failed allocations?"
@@ -98,7 +98,7 @@ def test_every_allocation_of_a_sequence_may_fail(snn, name):
         # after total failures the process still computes the oracle's results
         got = whole_sequence(snn, case, net)
         for k in want:
-            assert np.array_equal(np.asarray(got[k]).view(np.uint8), np.asarray(want[k]).view(np.uint8)), k
+            assert np.array_equal(np.atleast_1d(got[k]).view(np.uint8), np.atleast_1d(want[k]).view(np.uint8)), k
         onet = make_oracle(case, 11)
         onet.run(case["steps"] + 3, voltage_history=True)
         assert np.array_equal(onet["current_voltage"].view(np.uint32), want["v"].view(np.uint32))

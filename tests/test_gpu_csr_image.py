@@ -84,18 +84,19 @@ def sparse(layout, st_layout, seed, st_kind=ob.ST_RATE, density=0.04, band=None,
 def test_an_unstructured_graph_goes_through_the_records_with_plain_codes(snn):
     net = sparse([(0, 30, 30), (3, 17, 19)], [(5, 6, 6)], seed=21, density=0.05)
     st = run_both(snn, net, 80)
-    assert st["image_staged_slices"] < (net.n_neurons + 63) // 64        # (1223 sources per slice do not fit 16 pieces)
+    assert st["image_staged_slices"] == 0                                # (3 of 64 sources per piece: sixteen pieces never cover a slice)
 
 
 def test_staged_and_unstaged_slices_in_one_launch_with_ragged_and_long_rows(snn):
     # banded rows (stageable) + a few rows that read 60 % of everything (their slices are not), an empty row, rows past a ragged end
-    net = sparse([(0, 25, 25), (2, 9, 11)], [(4, 5, 7)], seed=33, density=0.5, band=6, long_rows=(3, 300, 701))
+    # (a window holds 1024 words: a network must be larger than that for a slice's sources not to fit)
+    net = sparse([(0, 40, 40), (2, 9, 11)], [(4, 5, 7)], seed=33, density=0.5, band=6, long_rows=(3, 300, 1501))
     net["connections"][:, 77] = 0
     net["weights"][:, 77] = 0
-    st = run_both(snn, net, 70)
+    st = run_both(snn, net, 40)
     n_slices = (net.n_neurons + 63) // 64
     assert 0 < st["image_staged_slices"] < n_slices
-    assert net["connections"].sum(axis=0).max() > 200                   # far past the ring of four records
+    assert net["connections"].sum(axis=0).max() > 500                   # far past the ring of four records
 
 
 @pytest.mark.parametrize("st_kind", [ob.ST_RATE, ob.ST_POISSON])
