@@ -632,8 +632,9 @@ int snn_probe_bandwidth(int device, uint64_t bytes, int repeats, double *read_gb
 int snn_probe_math(int device, int which, const float *in, float *out, size_t count);
 
 /* The same over a range of binary32 BIT PATTERNS formed on the device: out[i] = f(x_i), x_i = the float with bits
- * first + i * stride (mod 2^32); which = 3 evaluates powf(x_i, y) (generated models, `x ^ n`).  The GPU parity test
- * walks all 2^32 patterns with it. */
+ * first + i * stride (mod 2^32); which = 3 evaluates powf(x_i, y) (generated models, `x ^ n`); which = 4, 5, 6 = exp, pow3, pow4
+ * through the branch-free main paths with the full function as fall-back (the form of the Hodgkin-Huxley step).  The GPU parity
+ * test walks all 2^32 patterns with it. */
 int snn_probe_math_bits(int device, int which, uint32_t first, uint32_t stride, float y, float *out, size_t count);
 
 #ifdef __cplusplus

@@ -723,6 +723,14 @@ __global__ void k_probe_math_bits(int which, uint32_t first, uint32_t stride, fl
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float x = __uint_as_float(first + (uint32_t)i * stride);
+    if (which >= 4) {
+        // the form the Hodgkin-Huxley step uses: the branch-free main path, the full function where that one says "special"
+        bool special = false;
+        float r = which == 4 ? expf_glibc_main(x, special) : which == 5 ? powf_glibc_main(x, 3.0f, special) : powf_glibc_main(x, 4.0f, special);
+        if (special) r = which == 4 ? expf_glibc(x) : which == 5 ? pow3f_glibc(x) : pow4f_glibc(x);
+        out[i] = r;
+        return;
+    }
     out[i] = which == 0 ? expf_glibc(x) : which == 1 ? pow3f_glibc(x) : which == 2 ? pow4f_glibc(x) : powf_glibc(x, y);
 }
 

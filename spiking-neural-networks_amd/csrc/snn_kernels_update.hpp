@@ -530,18 +530,34 @@ __device__ __forceinline__ uint32_t update_neuron_at(const UpdateArgs &a, uint32
 #pragma unroll
             for (int k = 0; k < custom::NVARS; ++k) a.n.custom[k][q] = x[k];
         } else {                     // Hodgkin-Huxley
-            const float m_a = 0.1f * ((v + 40.0f) / (1.0f - expf_glibc(-(v + 40.0f) / 10.0f)));
-            const float m_b = 4.0f * expf_glibc(-(v + 65.0f) / 18.0f);
-            const float h_a = 0.07f * expf_glibc(-(v + 65.0f) / 20.0f);
-            const float h_b = 1.0f / (expf_glibc(-(v + 35.0f) / 10.0f) + 1.0f);
-            const float m = gate_update(a.n.m_state[q], m_a, m_b, dt);
-            const float h = gate_update(a.n.h_state[q], h_a, h_b, dt);
-            const float i_na = pow3f_glibc(m) * h * a.n.g_na[q] * (v - a.n.e_na[q]);
-
-            const float n_a = 0.01f * (v + 55.0f) / (1.0f - expf_glibc(-(v + 55.0f) / 10.0f));
-            const float n_b = 0.125f * expf_glibc(-(v + 65.0f) / 80.0f);
-            const float ng = gate_update(a.n.n_state[q], n_a, n_b, dt);
-            const float i_k = pow4f_glibc(ng) * a.n.g_k[q] * (v - a.n.e_k[q]);
+            // The six exponentials of the rates and the two powers of the gates through the MAIN paths of expf / powf (snn_math.hpp):
+            // branch-free, so that their table loads are in flight together -- one round trip for the exponentials, two for the
+            // powers, where the full functions made eleven, one after the other.  An argument outside a main path (a gate at
+            // exactly 0 -- the first step -- or a voltage on its way to infinity) sets `special`: the full functions then.
+            const float m_state = a.n.m_state[q], h_state = a.n.h_state[q], n_state = a.n.n_state[q];
+            bool special = false;
+            float e_ma = expf_glibc_main(-(v + 40.0f) / 10.0f, special), e_mb = expf_glibc_main(-(v + 65.0f) / 18.0f, special);
+            float e_ha = expf_glibc_main(-(v + 65.0f) / 20.0f, special), e_hb = expf_glibc_main(-(v + 35.0f) / 10.0f, special);
+            float e_na_ = expf_glibc_main(-(v + 55.0f) / 10.0f, special), e_nb = expf_glibc_main(-(v + 65.0f) / 80.0f, special);
+            if (special) {
+                e_ma = expf_glibc(-(v + 40.0f) / 10.0f); e_mb = expf_glibc(-(v + 65.0f) / 18.0f);
+                e_ha = expf_glibc(-(v + 65.0f) / 20.0f); e_hb = expf_glibc(-(v + 35.0f) / 10.0f);
+                e_na_ = expf_glibc(-(v + 55.0f) / 10.0f); e_nb = expf_glibc(-(v + 65.0f) / 80.0f);
+            }
+            const float m_a = 0.1f * ((v + 40.0f) / (1.0f - e_ma));
+            const float m_b = 4.0f * e_mb;
+            const float h_a = 0.07f * e_ha;
+            const float h_b = 1.0f / (e_hb + 1.0f);
+            const float m = gate_update(m_state, m_a, m_b, dt);
+            const float h = gate_update(h_state, h_a, h_b, dt);
+            const float n_a = 0.01f * (v + 55.0f) / (1.0f - e_na_);
+            const float n_b = 0.125f * e_nb;
+            const float ng = gate_update(n_state, n_a, n_b, dt);
+            bool special_pow = false;
+            float m3 = powf_glibc_main(m, 3.0f, special_pow), n4 = powf_glibc_main(ng, 4.0f, special_pow);
+            if (special_pow) { m3 = pow3f_glibc(m); n4 = pow4f_glibc(ng); }
+            const float i_na = m3 * h * a.n.g_na[q] * (v - a.n.e_na[q]);
+            const float i_k = n4 * a.n.g_k[q] * (v - a.n.e_k[q]);
 
             const float i_kl = a.n.g_k_leak[q] * (v - a.n.e_k_leak[q]);
 

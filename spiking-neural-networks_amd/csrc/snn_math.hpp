@@ -72,26 +72,17 @@ static __device__ const double POWF_LOG2_TAB[16][2] = {
 };
 constexpr double EXP2F_C0 = 0x1.c6af84b912394p-5, EXP2F_C1 = 0x1.ebfce50fac4f3p-3, EXP2F_C2 = 0x1.62e42ff0c52d6p-1;
 
-// expf as glibc computes it (e_expf.c, FMA build): k + r = x * 32/ln2 without rounding the product on its own,
-// 2^(k/32) from the table, a cubic in r.
-// LOCAL_CONSTANTS: the cubic's constant term is materialised where it is used (it is the accumulator of an FMA and has to sit
-// in a register pair; inside a long-lived loop the compiler otherwise keeps that pair alive across the loop -- and spilled it
-// in k_run_resident, whose registers are the weights').  Same arithmetic.
+// The main path of expf_glibc (|x| < 88, not NaN) on its own, branch-free: several independent calls in one basic block have their
+// table loads in flight together, where the full function's early exits put each call -- and its dependent table load -- into a
+// block of its own (round 6: the seven exponentials of a Hodgkin-Huxley step were seven round trips to the table).  Outside the
+// main path the value returned is meaningless and `special` is set: the caller then evaluates expf_glibc.
 template <bool LOCAL_CONSTANTS = false>
-__device__ __forceinline__ float expf_glibc(float x)
+__device__ __forceinline__ float expf_glibc_main(float x, bool &special)
 {
     constexpr double inv_ln2_n = 0x1.71547652b82fep+0 * 32.0;
     constexpr double shift = 0x1.8p+52;
-    const uint32_t ux = __float_as_uint(x);
-    const uint32_t abstop = (ux >> 20) & 0x7ff;
+    special = special || ((__float_as_uint(x) >> 20) & 0x7ff) >= 0x42b;
     const double xd = (double)x;
-    if (abstop >= 0x42b) {                                   // |x| >= 88 or NaN
-        if (ux == 0xff800000u) return 0.0f;
-        if (abstop >= 0x7f8) return x + x;
-        if (x > 0x1.62e42ep6f) return __builtin_inff();      // x > log(2^128)
-        if (x < -0x1.9fe368p6f) return 0.0f;                 // x < log(2^-150)
-        if (x < -0x1.9d1d9ep6f) return 0x1p-149f;            // x < log(2^-149)
-    }
     double kd = __builtin_fma(inv_ln2_n, xd, shift);
     const uint64_t ki = (uint64_t)__double_as_longlong(kd);
     kd -= shift;
@@ -112,6 +103,27 @@ __device__ __forceinline__ float expf_glibc(float x)
     return (float)y;
 }
 
+// expf as glibc computes it (e_expf.c, FMA build): k + r = x * 32/ln2 without rounding the product on its own,
+// 2^(k/32) from the table, a cubic in r.
+// LOCAL_CONSTANTS: the cubic's constant term is materialised where it is used (it is the accumulator of an FMA and has to sit
+// in a register pair; inside a long-lived loop the compiler otherwise keeps that pair alive across the loop -- and spilled it
+// in k_run_resident, whose registers are the weights').  Same arithmetic.
+template <bool LOCAL_CONSTANTS = false>
+__device__ __forceinline__ float expf_glibc(float x)
+{
+    const uint32_t ux = __float_as_uint(x);
+    const uint32_t abstop = (ux >> 20) & 0x7ff;
+    if (abstop >= 0x42b) {                                   // |x| >= 88 or NaN
+        if (ux == 0xff800000u) return 0.0f;
+        if (abstop >= 0x7f8) return x + x;
+        if (x > 0x1.62e42ep6f) return __builtin_inff();      // x > log(2^128)
+        if (x < -0x1.9fe368p6f) return 0.0f;                 // x < log(2^-150)
+        if (x < -0x1.9d1d9ep6f) return 0x1p-149f;            // x < log(2^-149)
+    }
+    bool unused = false;
+    return expf_glibc_main<LOCAL_CONSTANTS>(x, unused);
+}
+
 // checkint of e_powf.c: 0 = not an integer, 1 = odd, 2 = even
 __device__ __forceinline__ int powf_checkint(uint32_t iy)
 {
@@ -123,6 +135,57 @@ __device__ __forceinline__ int powf_checkint(uint32_t iy)
     return 2;
 }
 __device__ __forceinline__ bool powf_zeroinfnan(uint32_t ix) { return 2 * ix - 1 >= 2u * 0x7f800000u - 1; }
+
+// log2(x) * y and 2^that of powf_glibc's main path (x a positive normal number after the caller's adjustments): the caller has
+// dealt with the special operands; `big` = |y log2 x| >= 126 (overflow / underflow handling of the full function)
+__device__ __forceinline__ float powf_glibc_core(uint32_t ix, float y, uint64_t sign_bias, bool &big, double &ylogx_out)
+{
+    const uint32_t tmp = ix - 0x3f330000u;
+    const int i = (int)((tmp >> 19) & 15);
+    const uint32_t top = tmp & 0xff800000u;
+    const uint32_t iz = ix - top;
+    const int k = (int32_t)top >> 23;
+    const double invc = POWF_LOG2_TAB[i][0], logc = POWF_LOG2_TAB[i][1];
+    const double z = (double)__uint_as_float(iz);
+    const double r = __builtin_fma(z, invc, -1.0);
+    const double y0 = logc + (double)k;
+    constexpr double A0 = 0x1.27616c9496e0bp-2, A1 = -0x1.71969a075c67ap-2, A2 = 0x1.ec70a6ca7baddp-2,
+                     A3 = -0x1.7154748bef6c8p-1, A4 = 0x1.71547652ab82bp0;
+    const double r2 = r * r;
+    double yy = __builtin_fma(A0, r, A1);
+    const double p = __builtin_fma(A2, r, A3);
+    const double r4 = r2 * r2;
+    double q = __builtin_fma(A4, r, y0);
+    q = __builtin_fma(p, r2, q);
+    yy = __builtin_fma(yy, r4, q);
+    const double ylogx = (double)y * yy;
+    ylogx_out = ylogx;
+    big = ((uint64_t)__double_as_longlong(ylogx) >> 47 & 0xffff) >= (0x405f800000000000ull >> 47);   // |y log2 x| >= 126
+    constexpr double shift_scaled = 0x1.8p+52 / 32.0;
+    double kd = ylogx + shift_scaled;
+    const uint64_t ki = (uint64_t)__double_as_longlong(kd);
+    kd -= shift_scaled;
+    const double rr = ylogx - kd;
+    const double s = __longlong_as_double((long long)(EXP2F_TAB[ki & 31] + ((ki + sign_bias) << 47)));
+    const double zz = __builtin_fma(EXP2F_C0, rr, EXP2F_C1);
+    const double rr2 = rr * rr;
+    double out = __builtin_fma(EXP2F_C2, rr, 1.0);
+    out = __builtin_fma(zz, rr2, out);
+    out = out * s;
+    return (float)out;
+}
+
+// the main path of powf_glibc on its own, branch-free (see expf_glibc_main): x a positive normal number, y finite and non-zero,
+// |y log2 x| < 126; otherwise `special` is set and the value meaningless
+__device__ __forceinline__ float powf_glibc_main(float x, float y, bool &special)
+{
+    const uint32_t ix = __float_as_uint(x), iy = __float_as_uint(y);
+    bool big;
+    double ylogx;
+    const float out = powf_glibc_core(ix, y, 0, big, ylogx);
+    special = special || big || ix - 0x00800000u >= 0x7f800000u - 0x00800000u || powf_zeroinfnan(iy);
+    return out;
+}
 
 // powf as glibc computes it (e_powf.c, FMA build): log2(x) from a 16-entry table + quartic, times y, then exp2.
 // With a literal y (3.f, 4.f) the compiler folds every test on y.
@@ -159,42 +222,15 @@ __device__ __forceinline__ float powf_glibc(float x, float y)
             ix -= 23u << 23;
         }
     }
-    const uint32_t tmp = ix - 0x3f330000u;
-    const int i = (int)((tmp >> 19) & 15);
-    const uint32_t top = tmp & 0xff800000u;
-    const uint32_t iz = ix - top;
-    const int k = (int32_t)top >> 23;
-    const double invc = POWF_LOG2_TAB[i][0], logc = POWF_LOG2_TAB[i][1];
-    const double z = (double)__uint_as_float(iz);
-    const double r = __builtin_fma(z, invc, -1.0);
-    const double y0 = logc + (double)k;
-    constexpr double A0 = 0x1.27616c9496e0bp-2, A1 = -0x1.71969a075c67ap-2, A2 = 0x1.ec70a6ca7baddp-2,
-                     A3 = -0x1.7154748bef6c8p-1, A4 = 0x1.71547652ab82bp0;
-    const double r2 = r * r;
-    double yy = __builtin_fma(A0, r, A1);
-    const double p = __builtin_fma(A2, r, A3);
-    const double r4 = r2 * r2;
-    double q = __builtin_fma(A4, r, y0);
-    q = __builtin_fma(p, r2, q);
-    yy = __builtin_fma(yy, r4, q);
-    const double ylogx = (double)y * yy;
-    if (((uint64_t)__double_as_longlong(ylogx) >> 47 & 0xffff) >= (0x405f800000000000ull >> 47)) {   // |y log2 x| >= 126
+    bool big;
+    double ylogx;
+    const float out = powf_glibc_core(ix, y, sign_bias, big, ylogx);
+    if (big) {
         if (ylogx > 0x1.fffffffd1d571p+6) return sign_bias ? -__builtin_inff() : __builtin_inff();
         if (ylogx <= -150.0) return sign_bias ? -0.0f : 0.0f;
         if (ylogx < -149.0) return sign_bias ? -0x1p-149f : 0x1p-149f;
     }
-    constexpr double shift_scaled = 0x1.8p+52 / 32.0;
-    double kd = ylogx + shift_scaled;
-    const uint64_t ki = (uint64_t)__double_as_longlong(kd);
-    kd -= shift_scaled;
-    const double rr = ylogx - kd;
-    const double s = __longlong_as_double((long long)(EXP2F_TAB[ki & 31] + ((ki + sign_bias) << 47)));
-    const double zz = __builtin_fma(EXP2F_C0, rr, EXP2F_C1);
-    const double rr2 = rr * rr;
-    double out = __builtin_fma(EXP2F_C2, rr, 1.0);
-    out = __builtin_fma(zz, rr2, out);
-    out = out * s;
-    return (float)out;
+    return out;
 }
 
 // f32::tanh / sinh / cosh of generated models (build_test/nb_macro/src/lib.rs:9152-9163 forward to the platform

@@ -2558,7 +2558,7 @@ ABI_CATCH
 int snn_probe_math_bits(int device, int which, uint32_t first, uint32_t stride, float y, float *out, size_t count) ABI_TRY
 {
     if (!out) return fail(SNN_ERR_BAD_ARG, "null argument");
-    if (which < 0 || which > 3) return fail(SNN_ERR_BAD_ARG, "unknown function selector");
+    if (which < 0 || which > 6) return fail(SNN_ERR_BAD_ARG, "unknown function selector");
     HIP_TRY(hipSetDevice(device), SNN_ERR_GET_DEVICE);
     if (count == 0) return SNN_OK;
     float *dout = nullptr;
