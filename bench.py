@@ -24,11 +24,14 @@ MIN_TIMED_S, MAX_REPEATS = 1.0, 4000    # the timed repetitions add up to at lea
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling is ~6.3 TB/s
 # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of THIS command (FETCH_SIZE and
 # WRITE_SIZE cannot share a pass); their summaries are committed under profiles/ and quoted here per launch.
-PMC_TRAFFIC = {"c2": os.path.join(ROOT, "profiles", "r05", "c2_pmc_traffic.json"),
-               "c3": os.path.join(ROOT, "profiles", "r05", "c3_pmc_traffic.json"),
-               "c4": os.path.join(ROOT, "profiles", "r05", "c4_pmc_traffic.json"),
-               "c5": os.path.join(ROOT, "profiles", "r05", "c5_pmc_traffic.json"),
-               "c6": os.path.join(ROOT, "profiles", "r05", "c6_pmc_traffic.json")}
+def _latest_profile(name):
+    """profiles/rNN/<name> of the latest round that holds one"""
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]", name)))
+    return found[-1] if found else None
+
+
+PMC_TRAFFIC = {c: _latest_profile(f"{c}_pmc_traffic.json") for c in ("c2", "c3", "c4", "c5", "c6")}
 
 
 def pmc_traffic(config, world, rows, cols):
@@ -583,6 +586,9 @@ def main():
         if not sharded and dn.stat("persistent_run_launches"):
             # all steps of a run call in ONE launch (small electrical-only lattices): `launches` counts its steps
             kernel_name = "k_run_resident<0,true> (many steps per launch; launches = steps)"
+        elif dn.stat("steps_sparse_image"):
+            # static weights, gap junctions only: the rows read the step image (16-byte records, presynaptic windows in LDS)
+            kernel_name = kernel_name.replace("k_step_csr<0,true,false>", "k_step_csr_img<0>")
         elif not sharded and dn.stat("steps_dense_close"):
             # streamed dense matrices: the last workgroup of a column tile also updates the tile's neurons (one launch per step)
             kernel_name = kernel_name.replace("k_inputs_dense<", "k_inputs_dense_close<model,")

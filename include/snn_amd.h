@@ -506,8 +506,9 @@ int snn_get_spike_counts(snn_network_t *net, uint32_t id, uint32_t *dst, size_t 
  * tile of the input pass updates the tile's neurons in the same launch (k_inputs_dense_close; measured slower than input pass +
  * k_update); "cells_in_step" [1] sparse electrical-only handles without weight updates: the spike-train cells advance
  * inside the step's launch; "update_packs" [1] dense shard handles: the neuron update writes the handle's own slot of
- * the all-gather buffer itself (no pack launch); "update_all_planes" [2] dense handles with chemical synapses: 1: the neuron update
- * requests the chunk partials of all planes together, 2: four wavefronts share a column's partials and warm the cache for the update (k_update_wide), 0: plane after plane; "csr_xcd_bands" [1] the sparse step hands its row blocks to the XCDs in contiguous bands;
+ * the all-gather buffer itself (no pack launch); "update_all_planes" [1] dense handles with chemical synapses: 1: the neuron update
+ * requests the chunk partials of all planes together, 2: four wavefronts share a column's partials and warm the cache for the update
+ * (k_update_wide; 3: without the warming) -- measured slower than 1, 0: plane after plane; "csr_xcd_bands" [1] the sparse step hands its row blocks to the XCDs in contiguous bands;
  * "halo_direct" [1] library-driven runs of sparse shard handles gather the halo from the received segments (0: never,
  * 2: also in snn_run_sharded_custom, see there); "defer_rstdp"
  * [1] reward-modulated weight updates riding on the next input pass; "defer_stdp" [0] 1: STDP updates riding on the next
@@ -548,7 +549,8 @@ int snn_set_option(snn_network_t *net, const char *name, int value);
  * (steps of library-driven runs whose rows gathered the halo from the received segments); the form every step outside a
  * one-launch run took: "steps_dense_one_launch" (k_step_resident), "steps_sparse_one_launch" (k_step_csr over all rows; of those "steps_sparse_image" read the step image -- option "csr_image" [1]:
  * static weights and gap junctions only: 16-byte records of two entries and the slices' presynaptic windows staged in LDS;
- * "image_staged_slices" = slices of the current sparse graph whose window fits),
+ * "image_staged_slices" = slices of the current sparse graph whose window fits, "image_staged_slices_direct" = the same for the image
+ * of a shard handle's direct runs, whose halo sources are words of the receive buffer),
  * "steps_sparse_split" (border + interior launches of a shard handle), "steps_dense_close" (k_inputs_dense_close),
  * "steps_two_kernel" (input pass + k_update); and
  * what happened between run calls: "shadow_refreshes" (the two shadow copies of the exchanged state were rebuilt),

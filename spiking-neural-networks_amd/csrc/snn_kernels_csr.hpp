@@ -298,7 +298,8 @@ struct CsrImage {
 // the sums of one row over its records; STAGED: the gathers are reads of the wavefront's window
 template <bool STAGED>
 __device__ __forceinline__ void csr_img_sums(const InputsArgs &in, const uint4 *rec, uint32_t pairs, const uint32_t *win, const uint32_t *xv,
-                                             const uint32_t *cv, float vq, float gq, uint4 (&r)[IMG_RING], float &sum)
+                                             const uint32_t *cv, const uint32_t *halo, uint32_t halo_base, float vq, float gq,
+                                             uint4 (&r)[IMG_RING], float &sum)
 {
     constexpr uint32_t RING = IMG_RING;
     const uint32_t last = pairs ? pairs - 1u : 0u;
@@ -325,8 +326,10 @@ __device__ __forceinline__ void csr_img_sums(const InputsArgs &in, const uint4 *
                 } else {
                     // an unstaged slice: the plain codes, gathered from the exchanged state / the cells' view
                     const uint32_t code = word[e] & PLAN_CODE;
-                    const bool is_cell = !is_pad && code >= in.n_neurons;
-                    const uint32_t *src = is_cell ? cv + 2u * (size_t)(code - in.n_neurons) : xv + (is_pad ? 0u : code);
+                    const bool is_halo = !is_pad && code >= halo_base;
+                    const bool is_cell = !is_pad && !is_halo && code >= in.n_neurons;
+                    const uint32_t *src = is_halo ? halo + (code - halo_base)
+                                                  : is_cell ? cv + 2u * (size_t)(code - in.n_neurons) : xv + (is_pad ? 0u : code);
                     v[e] = __uint_as_float(src[0]);
                     silent[e] = is_cell ? src[1] : 0u;
                     if (!is_pad) word[e] = (word[e] & 0x80000000u) | (is_cell ? IMG_CELL_BIT : 0u);
@@ -388,14 +391,17 @@ __device__ __forceinline__ void csr_row_sums_img(const CsrInputsArgs &a, const C
 #pragma unroll
     for (uint32_t u = 0; u < IMG_MAX_PIECES; ++u) {
         const uint32_t code = u < 8 ? pc0[2 * (u & 7u)] : pc1[2 * (u & 7u)], words = u < 8 ? pc0[2 * (u & 7u) + 1] : pc1[2 * (u & 7u) + 1];
-        const uint32_t *src = code < in.n_neurons ? xv + code : cv + 2u * (size_t)(code - in.n_neurons);
+        // a piece's sources are of one kind: neurons of the exchanged state, spike-train cells (two words each), or -- shard handles
+        // in a direct run -- words of the received halo segments
+        const uint32_t *src = code < in.n_neurons ? xv + code
+                                                  : code < a.g.halo_base ? cv + 2u * (size_t)(code - in.n_neurons) : a.g.halo + (code - a.g.halo_base);
         if (lane < words)
             __builtin_amdgcn_global_load_lds(src + lane, (__attribute__((address_space(3))) uint32_t *)(win + u * IMG_PIECE_WORDS), 4, 0, 0);
     }
     __builtin_amdgcn_s_waitcnt(0x0070 | 0x0F00 | 0xC000);         // vmcnt(0): records and window have landed (expcnt / lgkmcnt left alone)
     __builtin_amdgcn_wave_barrier();                              // (one wavefront fills and reads its own window: no workgroup barrier)
-    if (n_pieces) csr_img_sums<true>(in, rec, pairs, win, xv, cv, vq, gq, r, sum);
-    else csr_img_sums<false>(in, rec, pairs, win, xv, cv, vq, gq, r, sum);
+    if (n_pieces) csr_img_sums<true>(in, rec, pairs, win, xv, cv, a.g.halo, a.g.halo_base, vq, gq, r, sum);
+    else csr_img_sums<false>(in, rec, pairs, win, xv, cv, a.g.halo, a.g.halo_base, vq, gq, r, sum);
 }
 
 template <bool ELEC, bool CHEM>
@@ -573,7 +579,7 @@ struct CsrStepArgs {
 };
 static_assert(sizeof(CsrStepArgs) <= 4096, "kernel arguments are limited to 4 KB");
 
-template <int MODEL, bool ELEC, bool CHEM, bool PEER, bool IMG = false>
+template <int MODEL, bool ELEC, bool CHEM, bool PEER, bool IMG = false, bool PACK = true>
 __device__ __forceinline__ void step_csr_block(const CsrStepArgs &a, uint32_t *win = nullptr)
 {
     // the tail jobs come AFTER the row blocks: they fill the tail of the rows' streaming (cells at C5, one box, step time:
@@ -597,7 +603,7 @@ __device__ __forceinline__ void step_csr_block(const CsrStepArgs &a, uint32_t *w
     // the row's entries of the pack table are requested BEFORE the row sums (they depend on nothing the sums produce): a
     // border launch of a few workgroups is a chain of dependent memory round trips, these two overlap with the sums'
     uint32_t pack_begin = 0, pack_end = 0, seg0_count = 0, seg0_index = 0, seg0_off = 0;
-    if (!IMG && a.pack.ptr && q < a.c.g.n_loc) {
+    if (PACK && a.pack.ptr && q < a.c.g.n_loc) {
         pack_begin = a.pack.ptr[q]; pack_end = a.pack.ptr[q + 1];
         if (pack_end > pack_begin) {
             seg0_count = a.pack.seg_count[pack_begin]; seg0_index = a.pack.index[pack_begin]; seg0_off = a.pack.seg_off[pack_begin];
@@ -686,11 +692,13 @@ __global__ __launch_bounds__(256, (CSR_PREFETCH && ELEC && !CHEM && !PEER) ? 8 :
 // the electrical step over the step image (static weights, no peer form): 16 KiB of LDS per workgroup, one window per wavefront.
 // (No second launch bound: with a ring of four records every model but Hodgkin-Huxley allocates at most 64 registers by itself --
 // eight wavefronts per SIMD, tests/test_isa_resources.py -- and forcing Hodgkin-Huxley there makes it spill.)
-template <int MODEL>
+// PACK: the launch's rows write their wire values into outgoing segments (border slices of a shard handle) -- its own
+// instantiation: the pack table's preloaded words cost the 65th register, i.e. one of eight wavefronts per SIMD
+template <int MODEL, bool PACK = false>
 __global__ __launch_bounds__(256) void k_step_csr_img(const CsrStepArgs a)
 {
     __shared__ uint32_t win[4 * IMG_WIN_WORDS];
-    step_csr_block<MODEL, true, false, false, true>(a, win);
+    step_csr_block<MODEL, true, false, false, true, PACK>(a, win);
 }
 
 // the records of the step image from the SELL arrays: {plan_win[k], w[k], plan_win[k + 1], w[k + 1]} per lane and pair

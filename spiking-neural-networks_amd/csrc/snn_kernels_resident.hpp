@@ -389,7 +389,7 @@ __device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, Res
     float v_mine = 0.0f;                                         // wavefront 0, alone: the voltage this lane's neuron was left with
     const uint32_t ql = tile * 64u + lane;
     const bool col = ql < in.n_loc;
-    const float gq = col ? uload(in.uni, NP_GAP, in.gap_conductance, in.q0 + ql) : 0.0f;
+    const float gq = col ? uload_vector(in.uni, NP_GAP, in.gap_conductance, in.q0 + ql) : 0.0f;
     const bool gq_small = fabsf(gq) <= 1e15f;
     const unsigned long long *granules = a.granules;
 
@@ -450,14 +450,14 @@ __device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, Res
         nv = n.xbuf[n.xl.at(q, PLANE_V)];
         const uint32_t cnt = a.up.n_in[ql];
         n_div = cnt == 0 ? 1.0f : (float)cnt;
-        const float dt = uload(n.uni, NP_DT, n.dt, q);
+        const float dt = uload_vector(n.uni, NP_DT, n.dt, q);
         if (MODEL == 0) {
             n2 = n.w_value[q];
-            pr[0] = dt / uload(n.uni, NP_C_M, n.c_m, q);
-            pr[1] = dt / uload(n.uni, NP_TAU_M, n.tau_m, q);
-            pr[2] = uload(n.uni, NP_A, n.a, q); pr[3] = uload(n.uni, NP_B, n.b, q);
-            pr[4] = uload(n.uni, NP_C, n.c, q); pr[5] = uload(n.uni, NP_D, n.d, q);
-            pr[6] = uload(n.uni, NP_V_TH, n.v_th, q);
+            pr[0] = dt / uload_vector(n.uni, NP_C_M, n.c_m, q);
+            pr[1] = dt / uload_vector(n.uni, NP_TAU_M, n.tau_m, q);
+            pr[2] = uload_vector(n.uni, NP_A, n.a, q); pr[3] = uload_vector(n.uni, NP_B, n.b, q);
+            pr[4] = uload_vector(n.uni, NP_C, n.c, q); pr[5] = uload_vector(n.uni, NP_D, n.d, q);
+            pr[6] = uload_vector(n.uni, NP_V_TH, n.v_th, q);
         } else if (MODEL == 1) {
             n2 = n.refractory_count[q];
             pr[0] = n.leak_constant[q]; pr[1] = n.e_l[q]; pr[2] = n.integration_constant[q]; pr[3] = n.g_l[q];
@@ -501,12 +501,12 @@ __device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, Res
     const uint32_t cell = is_cell ? my_row - n_neurons : 0u;
     if (is_cell) {
         const CellArrays &c = a.cells;
-        sh.cell_par[0][tid] = a.st_kind == 1 ? uload(c.uni, CP_CHANCE, c.chance_of_firing, cell) : c.rate[cell];
-        sh.cell_par[1][tid] = uload(c.uni, CP_V_TH, c.v_th, cell);
-        sh.cell_par[2][tid] = uload(c.uni, CP_V_RESTING, c.v_resting, cell);
-        sh.cell_par[3][tid] = uload(c.uni, CP_DT, c.dt, cell);
-        sh.cell_par[4][tid] = uload(c.uni, CP_K, c.k, cell);
-        sh.cell_refr[tid] = uload(c.uni, CP_REFR, c.refractoriness, cell);
+        sh.cell_par[0][tid] = a.st_kind == 1 ? uload_vector(c.uni, CP_CHANCE, c.chance_of_firing, cell) : c.rate[cell];
+        sh.cell_par[1][tid] = uload_vector(c.uni, CP_V_TH, c.v_th, cell);
+        sh.cell_par[2][tid] = uload_vector(c.uni, CP_V_RESTING, c.v_resting, cell);
+        sh.cell_par[3][tid] = uload_vector(c.uni, CP_DT, c.dt, cell);
+        sh.cell_par[4][tid] = uload_vector(c.uni, CP_K, c.k, cell);
+        sh.cell_refr[tid] = uload_vector(c.uni, CP_REFR, c.refractoriness, cell);
         const long long clock0 = a.lattice_clock[c.lattice_slot[cell]] + a.step_offset0;
         sh.cell_clock_lo[tid] = (uint32_t)(unsigned long long)clock0;
         sh.cell_clock_hi[tid] = (uint32_t)((unsigned long long)clock0 >> 32);
@@ -1200,7 +1200,7 @@ __device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, Res
                 const ResidentRunArgs &b = a;
                 float *vhist_row = b.up.vhist_row ? b.up.vhist_row + (size_t)s * b.vhist_stride : nullptr;
                 if (col)
-                    spike = update_neuron_at<MODEL>(b.up, ql, LdsSums{sh.pi, CHEM ? sh.pt : nullptr, n_chunks, lane}, b.up.clock + s, vhist_row,
+                    spike = update_neuron_at<MODEL, LdsSums, false>(b.up, ql, LdsSums{sh.pi, CHEM ? sh.pt : nullptr, n_chunks, lane}, b.up.clock + s, vhist_row,
                                                     &v_new, CHEM ? t_new : nullptr);
             }
             if (a.up.spike_row) {

@@ -335,7 +335,9 @@ __device__ __forceinline__ float gate_update(float state, float alpha, float bet
 
 // One neuron's step (local column ql) at network clock `clock`, its voltage also recorded in `vhist_row` (or null);
 // returns its spike flag (and, where asked for, the voltage it stored).
-template <int MODEL, class Sums>
+// HOIST: Hodgkin-Huxley's exponentials and powers through the branch-free main paths (more registers live at once: the one-launch
+// run, whose registers are the weights', keeps the plain calls)
+template <int MODEL, class Sums, bool HOIST = true>
 __device__ __forceinline__ uint32_t update_neuron_at(const UpdateArgs &a, uint32_t ql, const Sums &sums, long long clock,
                                                      float *vhist_row, float *v_stored = nullptr, float *t_capture = nullptr)
 {
@@ -535,10 +537,14 @@ __device__ __forceinline__ uint32_t update_neuron_at(const UpdateArgs &a, uint32
             // powers, where the full functions made eleven, one after the other.  An argument outside a main path (a gate at
             // exactly 0 -- the first step -- or a voltage on its way to infinity) sets `special`: the full functions then.
             const float m_state = a.n.m_state[q], h_state = a.n.h_state[q], n_state = a.n.n_state[q];
-            bool special = false;
-            float e_ma = expf_glibc_main(-(v + 40.0f) / 10.0f, special), e_mb = expf_glibc_main(-(v + 65.0f) / 18.0f, special);
-            float e_ha = expf_glibc_main(-(v + 65.0f) / 20.0f, special), e_hb = expf_glibc_main(-(v + 35.0f) / 10.0f, special);
-            float e_na_ = expf_glibc_main(-(v + 55.0f) / 10.0f, special), e_nb = expf_glibc_main(-(v + 65.0f) / 80.0f, special);
+            float e_ma = 0.0f, e_mb = 0.0f, e_ha = 0.0f, e_hb = 0.0f, e_na_ = 0.0f, e_nb = 0.0f;
+            bool special = true;
+            if constexpr (HOIST) {
+                special = false;
+                e_ma = expf_glibc_main(-(v + 40.0f) / 10.0f, special); e_mb = expf_glibc_main(-(v + 65.0f) / 18.0f, special);
+                e_ha = expf_glibc_main(-(v + 65.0f) / 20.0f, special); e_hb = expf_glibc_main(-(v + 35.0f) / 10.0f, special);
+                e_na_ = expf_glibc_main(-(v + 55.0f) / 10.0f, special); e_nb = expf_glibc_main(-(v + 65.0f) / 80.0f, special);
+            }
             if (special) {
                 e_ma = expf_glibc(-(v + 40.0f) / 10.0f); e_mb = expf_glibc(-(v + 65.0f) / 18.0f);
                 e_ha = expf_glibc(-(v + 65.0f) / 20.0f); e_hb = expf_glibc(-(v + 35.0f) / 10.0f);
@@ -553,8 +559,12 @@ __device__ __forceinline__ uint32_t update_neuron_at(const UpdateArgs &a, uint32
             const float n_a = 0.01f * (v + 55.0f) / (1.0f - e_na_);
             const float n_b = 0.125f * e_nb;
             const float ng = gate_update(n_state, n_a, n_b, dt);
-            bool special_pow = false;
-            float m3 = powf_glibc_main(m, 3.0f, special_pow), n4 = powf_glibc_main(ng, 4.0f, special_pow);
+            float m3 = 0.0f, n4 = 0.0f;
+            bool special_pow = true;
+            if constexpr (HOIST) {
+                special_pow = false;
+                m3 = powf_glibc_main(m, 3.0f, special_pow); n4 = powf_glibc_main(ng, 4.0f, special_pow);
+            }
             if (special_pow) { m3 = pow3f_glibc(m); n4 = pow4f_glibc(ng); }
             const float i_na = m3 * h * a.n.g_na[q] * (v - a.n.e_na[q]);
             const float i_k = n4 * a.n.g_k[q] * (v - a.n.e_k[q]);

@@ -100,6 +100,16 @@ __device__ __forceinline__ uint32_t uload(const UniformTable *u, int slot, const
     const UniformTableK t = (UniformTableK)u;
     return t->flag[slot] ? t->bits[slot] : arr[i];
 }
+// (the table entry by a vector load, as before round 6: the one-launch run, whose register budget is the weights', spills two
+// registers when the entries of its prologue arrive in scalar registers)
+__device__ __forceinline__ float uload_vector(const UniformTable *u, int slot, const float *arr, uint32_t i)
+{
+    return u->flag[slot] ? __uint_as_float(u->bits[slot]) : arr[i];
+}
+__device__ __forceinline__ uint32_t uload_vector(const UniformTable *u, int slot, const uint32_t *arr, uint32_t i)
+{
+    return u->flag[slot] ? u->bits[slot] : arr[i];
+}
 
 // Pointers the per-neuron update kernels need.  All arrays are device memory.
 struct NeuronArrays {

@@ -80,7 +80,8 @@ int snn_network_destroy(snn_network_t *net) ABI_TRY
     for (void *p : net->allocs) (void)hipFree(p);
     for (void *p : {(void *)net->csr_ptr, (void *)net->csr_pre, (void *)net->csr_post, (void *)net->csr_t_ptr,
                     (void *)net->csr_t_edge, (void *)net->csr_w, (void *)net->csr_row_len, (void *)net->csr_edge_slot,
-                    (void *)net->csr_plan, (void *)net->csr_img_hdr, (void *)net->csr_plan_win, (void *)net->csr_img_rec})
+                    (void *)net->csr_plan, (void *)net->csr_img_hdr, (void *)net->csr_plan_win, (void *)net->csr_img_rec,
+                    (void *)net->csr_img_hdr_direct, (void *)net->csr_plan_win_direct, (void *)net->csr_img_rec_direct})
         if (p) (void)hipFree(p);
     if (net->vhist) (void)hipFree(net->vhist);
     if (net->st_vhist) (void)hipFree(net->st_vhist);
@@ -390,71 +391,6 @@ ABI_CATCH
 
 namespace { int ensure_traces(snn_network *net); int ensure_pending(snn_network *net); }
 
-// The host-built half of the step image (snn_kernels_csr.hpp, "STEP IMAGE").  Per slice: the sorted set of everything its 64 rows
-// gather, cut greedily into pieces -- a piece starts at the first source not yet covered and spans at most 64 LDS words of
-// consecutive sources of one kind (a neuron is one word, a spike-train cell the two words of its view entry), trimmed to the last
-// source it holds.  A slice that needs more than IMG_MAX_PIECES pieces stays unstaged (no pieces, plain codes).
-static void build_step_image_plan(const snn_network *net, const hvec<uint32_t> &slice_ptr, const hvec<uint32_t> &sell_pre, uint32_t n_slices,
-                                  hvec<uint32_t> &hdr, hvec<uint32_t> &plan_win, uint64_t &records, uint64_t &staged_slices)
-{
-    hdr.assign((size_t)n_slices * IMG_HDR_WORDS, 0u);
-    plan_win.assign(sell_pre.size(), PLAN_CODE);
-    records = 0; staged_slices = 0;
-    hvec<uint32_t> codes, offs;
-    for (uint32_t sl = 0; sl < n_slices; ++sl) {
-        const uint32_t s0 = slice_ptr[sl], s1 = slice_ptr[sl + 1], width = (s1 - s0) >> 6;
-        uint32_t *h = &hdr[(size_t)sl * IMG_HDR_WORDS];
-        h[0] = (uint32_t)records; h[1] = (width + 1) / 2;
-        records += (uint64_t)h[1] * 64;
-        if (width == 0) continue;
-        codes.clear();
-        for (uint32_t e = s0; e < s1; ++e)
-            if (sell_pre[e] != SELL_PAD) codes.push_back(sell_pre[e]);
-        std::sort(codes.begin(), codes.end());
-        codes.erase(std::unique(codes.begin(), codes.end()), codes.end());
-        offs.assign(codes.size(), 0u);
-        uint32_t n_pieces = 0;
-        bool staged = !codes.empty();
-        for (size_t i = 0; i < codes.size() && staged;) {
-            const uint32_t start = codes[i];
-            const bool cell = start >= net->nn;
-            const uint32_t per = cell ? 2u : 1u, span = IMG_PIECE_WORDS / per;
-            if (n_pieces == IMG_MAX_PIECES) { staged = false; break; }
-            size_t j = i;
-            while (j < codes.size() && codes[j] - start < span && (codes[j] >= net->nn) == cell) {
-                offs[j] = n_pieces * IMG_PIECE_WORDS + (codes[j] - start) * per;
-                ++j;
-            }
-            h[4 + 2 * n_pieces] = start;
-            h[5 + 2 * n_pieces] = (codes[j - 1] - start + 1) * per;
-            ++n_pieces;
-            i = j;
-        }
-        if (!staged) {
-            n_pieces = 0;
-            for (uint32_t k = 0; k < 2 * IMG_MAX_PIECES; ++k) h[4 + k] = 0u;
-        }
-        h[2] = n_pieces;
-        staged_slices += staged ? 1 : 0;
-        for (uint32_t lane = 0; lane < 64; ++lane) {
-            uint32_t prev = 0;
-            for (uint32_t k = 0; k < width; ++k) {
-                const size_t e = s0 + lane + (size_t)k * 64;
-                const uint32_t p = sell_pre[e];
-                if (p == SELL_PAD) break;                   // padding only ever trails a row
-                const uint32_t chunk_bit = (k == 0 || p / CHUNK != prev / CHUNK) ? 0x80000000u : 0u;
-                prev = p;
-                if (staged) {
-                    const size_t at = std::lower_bound(codes.begin(), codes.end(), p) - codes.begin();
-                    plan_win[e] = offs[at] | (p >= net->nn ? IMG_CELL_BIT : 0u) | chunk_bit;
-                } else {
-                    plan_win[e] = p | chunk_bit;
-                }
-            }
-        }
-    }
-}
-
 static int set_graph_csr_impl(snn_network_t *net, const uint64_t *row_ptr, const uint32_t *pre_index, const float *weights,
                               uint64_t nnz)
 {
@@ -557,6 +493,9 @@ static int set_graph_csr_impl(snn_network_t *net, const uint64_t *row_ptr, const
         HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
     }
     net->edge_slot_host.swap(edge_slot);
+    if (net->sharded && net->n_shards > 1) { net->sell_pre_host.swap(sell_pre); net->slice_ptr_host.swap(slice_ptr); }
+    else { net->sell_pre_host.clear(); net->slice_ptr_host.clear(); }
+    net->img_stale_direct = true;
     net->counts_dirty = true;
     halo_needs_from_rows(net, pre_index, nnz);      // the new rows decide what is read from the other shards
     if (net->sharded && net->n_shards > 1 && net->nc) {
@@ -1249,7 +1188,7 @@ int snn_debug_checkpoint(snn_network_t *net, int restore) ABI_TRY
     if (!net->finalized) return fail(SNN_ERR_BAD_STATE, "network not finalized");
     HIP_TRY(hipSetDevice(net->device), SNN_ERR_GET_DEVICE);
     TRY(end_run(net));
-    if (restore) net->img_stale = true;          // the sparse weights come back: the step image's records are rebuilt
+    if (restore) net->img_stale = net->img_stale_direct = true;          // the sparse weights come back: the step image's records are rebuilt
     auto &cp = net->checkpoint;
     hvec<std::pair<void *, size_t>> arrays;
     for (const auto &kv : net->alloc_bytes)
@@ -1487,7 +1426,7 @@ int snn_run(snn_network_t *net, uint64_t iterations) ABI_TRY
     }
     auto matrices_copy = [&](int half, bool restore) -> int {
         size_t off = (size_t)half * net->verify_big_bytes;
-        if (restore) net->img_stale = true;
+        if (restore) net->img_stale = net->img_stale_direct = true;
         for (const auto &m : matrices) {
             void *side = net->verify_big + off;
             HIP_TRY(hipMemcpyAsync(restore ? m.first : side, restore ? side : m.first, m.second, hipMemcpyDeviceToDevice, net->stream), SNN_ERR_BUFFER_WRITE);
@@ -2380,6 +2319,7 @@ int snn_get_stat(snn_network_t *net, const char *name, uint64_t *value) ABI_TRY
     else if (n == "steps_sparse_one_launch") *value = net->stat_steps_sparse_one_launch;
     else if (n == "steps_sparse_image") *value = net->stat_steps_sparse_image;
     else if (n == "image_staged_slices") *value = net->img_staged_slices;
+    else if (n == "image_staged_slices_direct") *value = net->img_staged_slices_direct;
     else if (n == "steps_sparse_split") *value = net->stat_steps_sparse_split;
     else if (n == "steps_two_kernel") *value = net->stat_steps_two_kernel;
     else if (n == "shadow_refreshes") *value = net->stat_shadow_refreshes;

@@ -230,6 +230,21 @@ int ensure_exchange_plan(snn_network *net)
                                net->csr_plan_direct, net->halo_word_dev, net->nn, net->nn + net->nc);
             HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
             HIP_TRY(hipStreamSynchronize(net->stream), SNN_ERR_WAIT);
+            // the step image of direct runs (voltage the only plane on the wire: a halo neuron is ONE word of the receive buffer)
+            for (void **q : {(void **)&net->csr_img_hdr_direct, (void **)&net->csr_plan_win_direct, (void **)&net->csr_img_rec_direct}) {
+                if (*q) (void)hipFree(*q);
+                *q = nullptr;
+            }
+            if (net->direct_capable && P == 1 && !net->sell_pre_host.empty()) {
+                hvec<uint32_t> img_hdr, plan_win;
+                uint64_t records = 0;
+                build_step_image_plan(net, net->slice_ptr_host, net->sell_pre_host, n_slices, img_hdr, plan_win, records, net->img_staged_slices_direct,
+                                      halo_word.data());
+                TRY(upload_table(net, &net->csr_img_hdr_direct, img_hdr));
+                TRY(upload_table(net, &net->csr_plan_win_direct, plan_win));
+                HIP_TRY(snn_malloc(&net->csr_img_rec_direct, (size_t)records * 16 + 4096), SNN_ERR_BUFFER_CREATE);
+                net->img_stale_direct = true;
+            }
         }
     }
     for (int w = 0; w < 2; ++w) {

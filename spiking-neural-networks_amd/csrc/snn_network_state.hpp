@@ -242,7 +242,7 @@ struct snn_network {
     bool send_bits_clean = true;          // every outgoing spike bitmap is zero (what the in-kernel pack ORs into)
     bool update_packed = false;           // this step's own slot of the all-gather buffer was written by k_update
     int update_packs = 1;                 // option "update_packs"
-    int update_all_planes = 2;            // option "update_all_planes": 1 all planes' partials in one thread, 2 the wide update (k_update_wide)
+    int update_all_planes = 1;            // option "update_all_planes": 1 all planes' partials in one thread (default), 2 / 3 the wide update (k_update_wide; measured slower)
     bool step_packed = false;             // this step's outgoing segments were written by k_step_csr itself
     bool interior_pending = false;        // the border half of this step is enqueued, the interior slices are not yet
     // Library-driven runs of such a handle (snn_run_sharded): the rows gather the halo from the received segments themselves
@@ -324,6 +324,13 @@ struct snn_network {
     uint4 *csr_img_rec = nullptr;
     uint64_t img_records = 0, img_staged_slices = 0;
     bool img_stale = true, csr_image = true;      // csr_image: option "csr_image"
+    // ... and its twin for the runs of a shard handle whose rows gather the halo from the received segments (csr_plan_direct):
+    // the same graph with every halo neuron's source moved to its word of the receive buffer; built with the exchange plan
+    uint32_t *csr_img_hdr_direct = nullptr, *csr_plan_win_direct = nullptr;
+    uint4 *csr_img_rec_direct = nullptr;
+    uint64_t img_staged_slices_direct = 0;
+    bool img_stale_direct = true;
+    hvec<uint32_t> sell_pre_host, slice_ptr_host;     // the SELL indices as set (shard handles: the direct image is built from them)
     uint2 *cell_view[2] = {nullptr, nullptr};
     int cell_view_cur = 0;
     bool cells_stepped = false;      // this step's cells advanced inside k_step_csr (step_end skips their launch)
@@ -1114,6 +1121,78 @@ int attr_io(snn_network *net, uint32_t id, const char *name, AttrType type, void
 }
 
 // ---- per-step launches -------------------------------------------------------------------------
+
+// The host-built half of the step image (snn_kernels_csr.hpp, "STEP IMAGE").  Per slice: the sorted set of everything its 64 rows
+// gather, cut greedily into pieces -- a piece starts at the first source not yet covered and spans at most 64 LDS words of
+// consecutive sources of one kind (a neuron is one word, a spike-train cell the two words of its view entry), trimmed to the last
+// source it holds.  A slice that needs more than IMG_MAX_PIECES pieces stays unstaged (no pieces, plain codes).
+// halo_word (shard handles, the image of direct runs): per neuron the word of the receive buffer that carries it (0xFFFFFFFF: read
+// from the exchanged state); such a source has code halo_base + word, a third kind of piece next to neurons and cells.
+void build_step_image_plan(const snn_network *net, const hvec<uint32_t> &slice_ptr, const hvec<uint32_t> &sell_pre, uint32_t n_slices,
+                           hvec<uint32_t> &hdr, hvec<uint32_t> &plan_win, uint64_t &records, uint64_t &staged_slices,
+                           const uint32_t *halo_word = nullptr)
+{
+    const uint32_t halo_base = net->nn + net->nc;
+    auto code_of = [&](uint32_t p) { return (halo_word && p < net->nn && halo_word[p] != 0xFFFFFFFFu) ? halo_base + halo_word[p] : p; };
+    auto kind_of = [&](uint32_t code) { return code < net->nn ? 0 : (code < halo_base ? 1 : 2); };
+    hdr.assign((size_t)n_slices * IMG_HDR_WORDS, 0u);
+    plan_win.assign(sell_pre.size(), PLAN_CODE);
+    records = 0; staged_slices = 0;
+    hvec<uint32_t> codes, offs;
+    for (uint32_t sl = 0; sl < n_slices; ++sl) {
+        const uint32_t s0 = slice_ptr[sl], s1 = slice_ptr[sl + 1], width = (s1 - s0) >> 6;
+        uint32_t *h = &hdr[(size_t)sl * IMG_HDR_WORDS];
+        h[0] = (uint32_t)records; h[1] = (width + 1) / 2;
+        records += (uint64_t)h[1] * 64;
+        if (width == 0) continue;
+        codes.clear();
+        for (uint32_t e = s0; e < s1; ++e)
+            if (sell_pre[e] != SELL_PAD) codes.push_back(code_of(sell_pre[e]));
+        std::sort(codes.begin(), codes.end());
+        codes.erase(std::unique(codes.begin(), codes.end()), codes.end());
+        offs.assign(codes.size(), 0u);
+        uint32_t n_pieces = 0;
+        bool staged = !codes.empty();
+        for (size_t i = 0; i < codes.size() && staged;) {
+            const uint32_t start = codes[i];
+            const int kind = kind_of(start);
+            const uint32_t per = kind == 1 ? 2u : 1u, span = IMG_PIECE_WORDS / per;
+            if (n_pieces == IMG_MAX_PIECES) { staged = false; break; }
+            size_t j = i;
+            while (j < codes.size() && codes[j] - start < span && kind_of(codes[j]) == kind) {
+                offs[j] = n_pieces * IMG_PIECE_WORDS + (codes[j] - start) * per;
+                ++j;
+            }
+            h[4 + 2 * n_pieces] = start;
+            h[5 + 2 * n_pieces] = (codes[j - 1] - start + 1) * per;
+            ++n_pieces;
+            i = j;
+        }
+        if (!staged) {
+            n_pieces = 0;
+            for (uint32_t k = 0; k < 2 * IMG_MAX_PIECES; ++k) h[4 + k] = 0u;
+        }
+        h[2] = n_pieces;
+        staged_slices += staged ? 1 : 0;
+        for (uint32_t lane = 0; lane < 64; ++lane) {
+            uint32_t prev = 0;
+            for (uint32_t k = 0; k < width; ++k) {
+                const size_t e = s0 + lane + (size_t)k * 64;
+                const uint32_t p = sell_pre[e];
+                if (p == SELL_PAD) break;                   // padding only ever trails a row
+                const uint32_t chunk_bit = (k == 0 || p / CHUNK != prev / CHUNK) ? 0x80000000u : 0u;
+                prev = p;
+                const uint32_t code = code_of(p);
+                if (staged) {
+                    const size_t at = std::lower_bound(codes.begin(), codes.end(), code) - codes.begin();
+                    plan_win[e] = offs[at] | (kind_of(code) == 1 ? IMG_CELL_BIT : 0u) | chunk_bit;
+                } else {
+                    plan_win[e] = code | chunk_bit;
+                }
+            }
+        }
+    }
+}
 
 SellGraph csr_graph(const snn_network *net)
 {

@@ -416,7 +416,7 @@ int launch_plasticity_kernels(snn_network *net)
         CsrStdpArgs ca{};
         ca.g = csr_graph(net);
         ca.s = a;
-        net->img_stale = true;              // (weights change: the step image's records are behind)
+        net->img_stale = net->img_stale_direct = true;              // (weights change: the step image's records are behind)
         hipLaunchKernelGGL(k_stdp_csr_in, dim3(1024), dim3(64), 0, net->stream, ca);
         HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
         hipLaunchKernelGGL(k_stdp_csr_out, dim3(1024), dim3(64), 0, net->stream, ca);
@@ -457,7 +457,7 @@ int launch_rstdp_pass(snn_network *net, int dop)
         a.g = csr_graph(net); a.c = net->trace; a.q0 = net->q0; a.rows = net->rowmap; a.n_neurons = net->nn;
         a.last_firing_time = net->na.last_firing_time; a.lattice_slot = net->lattice_slot;
         a.rm = net->rm_dev; a.rm_on = net->rm_on_dev; a.dop = dop;
-        net->img_stale = true;              // (weights change: the step image's records are behind)
+        net->img_stale = net->img_stale_direct = true;              // (weights change: the step image's records are behind)
         hipLaunchKernelGGL(k_rstdp_csr, dim3((net->n_loc + 255) / 256), dim3(256), 0, net->stream, a);
         HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
         return SNN_OK;
@@ -492,7 +492,7 @@ int launch_reward_cross(snn_network *net)
         CsrRewardCrossArgs c{};
         c.g = csr_graph(net);
         c.r = reward_cross_args(net);
-        net->img_stale = true;              // (weights change: the step image's records are behind)
+        net->img_stale = net->img_stale_direct = true;              // (weights change: the step image's records are behind)
         hipLaunchKernelGGL(k_reward_cross_csr, dim3((net->n_loc + 255) / 256), dim3(256), 0, net->stream, c);
         HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
         return SNN_OK;
@@ -1187,20 +1187,27 @@ int launch_step_csr(snn_network *net, CsrStepPart part = CSR_STEP_ALL, bool pack
     c.xcd_bands = net->csr_xcd_bands ? 1u : 0u;
     // the step image (static weights, gap junctions only, every source in this handle's own arrays): records of 16 bytes and the
     // slices' presynaptic windows in LDS
-    const bool image = net->csr_image && part == CSR_STEP_ALL && !pack && !net->direct_run && !net->peer_run && net->electrical &&
-                       !net->chemical && !net->any_plasticity && !net->any_modulation && !net->any_conn_kind && net->csr_img_hdr &&
-                       net->model != SNN_MODEL_CUSTOM && (net->nc == 0 || c.c.in.st_view);
+    // ... shard handles too: border and interior launches, the border rows packing as they go; in a direct run (the halo gathered
+    // from the received segments) the image is the one built with the exchange plan -- a halo neuron's source is its word of the
+    // receive buffer.  Not the peer form (a granule is polled, not copied).
+    const bool direct_image = net->direct_run && !net->peer_run;
+    const bool image = net->csr_image && !net->peer_run && net->electrical && !net->chemical && !net->any_plasticity && !net->any_modulation &&
+                       !net->any_conn_kind && net->model != SNN_MODEL_CUSTOM && (net->nc == 0 || c.c.in.st_view) &&
+                       (direct_image ? net->csr_img_hdr_direct != nullptr : (net->csr_img_hdr != nullptr && !net->direct_run));
     if (image) {
-        if (net->img_stale) {
-            hipLaunchKernelGGL(k_csr_image, dim3((c.c.g.n_slices * 64 + 255) / 256), dim3(256), 0, net->stream, c.c.g, net->csr_plan_win,
-                               net->csr_img_hdr, net->csr_img_rec);
+        bool &stale = direct_image ? net->img_stale_direct : net->img_stale;
+        uint32_t *hdr = direct_image ? net->csr_img_hdr_direct : net->csr_img_hdr;
+        uint4 *rec = direct_image ? net->csr_img_rec_direct : net->csr_img_rec;
+        if (stale) {
+            hipLaunchKernelGGL(k_csr_image, dim3((c.c.g.n_slices * 64 + 255) / 256), dim3(256), 0, net->stream, c.c.g,
+                               direct_image ? net->csr_plan_win_direct : net->csr_plan_win, hdr, rec);
             HIP_TRY(hipGetLastError(), SNN_ERR_QUEUE);
-            net->img_stale = false;
+            stale = false;
         }
-        c.img.hdr = net->csr_img_hdr; c.img.rec = net->csr_img_rec;
-        net->stat_steps_sparse_image += 1;
+        c.img.hdr = hdr; c.img.rec = rec;
+        if (part != CSR_STEP_BORDER || net->n_interior == 0) net->stat_steps_sparse_image += 1;
     } else if (net->any_plasticity || net->any_modulation || net->any_conn_kind) {
-        net->img_stale = true;          // this step's weight updates leave the records behind
+        net->img_stale = net->img_stale_direct = true;          // this step's weight updates leave the records behind
     }
     hipEvent_t e1 = nullptr;
     if (waves || tail_blocks) {
@@ -1209,7 +1216,8 @@ int launch_step_csr(snn_network *net, CsrStepPart part = CSR_STEP_ALL, bool pack
         const dim3 grid((waves + 3) / 4 + tail_blocks), block(256);
 #define SNN_CSR_STEP(M)                                                                                              \
     do {                                                                                                             \
-        if (image) hipLaunchKernelGGL((k_step_csr_img<M>), grid, block, 0, net->stream, c);                                    \
+        if (image && c.pack.ptr) hipLaunchKernelGGL((k_step_csr_img<M, true>), grid, block, 0, net->stream, c);              \
+        else if (image) hipLaunchKernelGGL((k_step_csr_img<M, false>), grid, block, 0, net->stream, c);                        \
         else if (net->peer_run && net->electrical && net->chemical) hipLaunchKernelGGL((k_step_csr<M, true, true, true>), grid, block, 0, net->stream, c); \
         else if (net->peer_run && net->electrical) hipLaunchKernelGGL((k_step_csr<M, true, false, true>), grid, block, 0, net->stream, c); \
         else if (net->peer_run) hipLaunchKernelGGL((k_step_csr<M, false, true, true>), grid, block, 0, net->stream, c);        \

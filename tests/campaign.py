@@ -266,6 +266,9 @@ def main():
         worker_env.setdefault("SNN_HOST_POISON", "1")
         if args.lean:
             worker_env.setdefault("SNN_CHECKPOINTS", "0")
+            # (every mprotect of the arena interrupts the CPUs the process's threads ran on: a worker's oracle needs no team)
+            worker_env["OMP_NUM_THREADS"] = "1"
+            worker_env.setdefault("MKL_NUM_THREADS", "1")
     procs = [subprocess.Popen(base + ["--role", "streamer", "--index", str(i)]) for i in range(args.streamers)]
     procs += [subprocess.Popen(base + ["--role", "worker", "--index", str(i)], env=worker_env) for i in range(args.workers)]
     # a process still busy two and a half minutes after the deadline (starved by thirty others, or stuck) is stopped: the summary is

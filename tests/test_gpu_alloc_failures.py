@@ -101,7 +101,7 @@ def test_every_allocation_of_a_sequence_may_fail(snn, name):
             assert np.array_equal(np.atleast_1d(got[k]).view(np.uint8), np.atleast_1d(want[k]).view(np.uint8)), k
         onet = make_oracle(case, 11)
         onet.run(case["steps"] + 3, voltage_history=True)
-        assert np.array_equal(onet["current_voltage"].view(np.uint32), want["v"].view(np.uint32))
+        assert np.array_equal(onet["current_voltage"][:want["v"].size].view(np.uint32), want["v"].view(np.uint32))      # (lattice 0 = the first neurons)
     finally:
         arm(snn, 0)
 

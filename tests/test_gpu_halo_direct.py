@@ -88,6 +88,9 @@ def test_direct_halo_runs_equal_the_oracle(snn, n_shards, by_lattice, direct):
     for r, h in enumerate(handles):
         if h.owned.size:                                    # (a shard without neurons may or may not take the direct form)
             assert h.stat("halo_direct_steps") == (193 if direct else 0)
+            # every step read the step image (round 6): in the direct runs the one whose halo sources are words of the receive
+            # buffer, in the host-driven steps the plain one, the border launches packing as they go
+            assert h.stat("steps_sparse_image") == 200 and h.stat("image_staged_slices_direct" if direct else "image_staged_slices") > 0
         known = np.zeros(net.n_neurons, bool)
         known[h.owned] = True
         for p in range(n_shards):

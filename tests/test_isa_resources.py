@@ -94,7 +94,7 @@ def test_the_closing_pass_keeps_the_occupancy_of_the_plain_pass(close_assembly):
 def image_assembly(tmp_path_factory):
     d = tmp_path_factory.mktemp("isa_image")
     src = d / "image_only.hip"
-    inst = "\n".join(f"template __global__ void snn::k_step_csr_img<{m}>(const snn::CsrStepArgs);" for m in range(8))
+    inst = "\n".join(f"template __global__ void snn::k_step_csr_img<{m}, false>(const snn::CsrStepArgs);" for m in range(8))
     src.write_text(f'#include "{ROOT}/include/snn_amd.h"\n#include "snn_kernels_csr.hpp"\n{inst}\n'
                    "template __global__ void snn::k_step_csr<0, true, false, false>(const snn::CsrStepArgs);\n")
     subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-c", "--cuda-device-only", "-Wno-unused-result",
@@ -108,11 +108,12 @@ def test_the_image_step_keeps_eight_wavefronts_per_simd_and_stages_by_lds_dma(im
     assert len(img) == 8
     for name, r in img.items():
         # 64 registers = 8 wavefronts per SIMD, 16 KiB of LDS per workgroup of 4 wavefronts = 128 KiB per CU at that occupancy
-        # (Hodgkin-Huxley's update needs 85 with or without the image: five wavefronts, as its plain step)
-        limit = 96 if name == "snn::k_step_csr_img<2>" else 64
+        # (Hodgkin-Huxley's update, its exponentials' table loads in flight together, needs 98 with or without the image: five
+        # wavefronts per SIMD, as its plain step)
+        limit = 102 if name == "snn::k_step_csr_img<2, false>" else 64
         assert r["vgpr_spill"] == 0 and r["scratch"] == 0 and r["vgpr"] + r["agpr"] <= limit and r["lds"] == 16384, (name, r)
     text = open(image_assembly, errors="replace").read()
-    body = re.search(r"^_ZN3snn14k_step_csr_imgILi0EEEvNS_11CsrStepArgsE:.*?\n(.*?)\.end_amdhsa_kernel", text, re.S | re.M).group(1)
+    body = re.search(r"^_ZN3snn14k_step_csr_imgILi0ELb0EEEvNS_11CsrStepArgsE:.*?\n(.*?)\.end_amdhsa_kernel", text, re.S | re.M).group(1)
     assert len(re.findall(r"global_load_lds_dword\b", body)) == 16           # one LDS-DMA load per window piece, no ds_write pass
     assert len(re.findall(r"s_load_dwordx16", body)) >= 2                     # the slice header's pieces arrive in scalar registers
     assert len(re.findall(r"global_load_dwordx4", body)) >= 8                 # records of two entries: 16 bytes per lane and load
