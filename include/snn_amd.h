@@ -583,6 +583,14 @@ int snn_debug_checkpoint(snn_network_t *net, int restore);
  * the number of allocations made since the library was loaded, so that a test can walk n over exactly the allocations of a
  * call sequence.  Environment: SNN_AMD_FAIL_ALLOC_AT=n arms it at load time. */
 int snn_debug_fail_alloc_at(int64_t n, uint64_t *allocations_so_far);
+/* Stray-write hunt (tests/guard_arena.py): every host-side table the library allocates from now on -- including the temporaries
+ * its getters download into before they unpack into the caller's array -- comes from `alloc(bytes, tag)` and is handed back
+ * through `release(p, bytes)` (which returns 1 when p was its memory, 0 otherwise); both null restores the default.  With a
+ * protected arena behind the two functions a transfer that lands in a table after the call that owned it returned faults at
+ * the writing instruction.  Process-wide; keep the functions alive for the life of the process. */
+typedef void *(*snn_host_alloc_fn)(size_t bytes, const char *tag);
+typedef int (*snn_host_release_fn)(void *p, size_t bytes);
+int snn_debug_set_host_allocator(snn_host_alloc_fn alloc, snn_host_release_fn release);
 
 /* ---- measurement ----------------------------------------------------------------------- */
 

@@ -3,7 +3,7 @@
 # into profiles/rNN/; `only` = a substring of the names to (re)collect, e.g. c5).  Per config: rocprofv3 --kernel-trace --stats of bench.py (kernel stats csv + the bench line of
 # that profiled process), then two separate --pmc passes (FETCH_SIZE, WRITE_SIZE) reduced by summarize_pmc.py.
 set -u
-R=${1:-r05}
+R=${1:-r06}
 ONLY=${2:-}
 want() { [ -z "$ONLY" ] || [[ "$1" == *"$ONLY"* ]]; }
 OUT=$PWD/gpurun_out/$R
@@ -39,6 +39,8 @@ prof c4 --config c4 --steps 50 --warmup 10 --repeats 2
 prof c4_spiking_0p1pct --config c4 --spike-fraction 0.001 --steps 50 --warmup 100 --repeats 2
 prof c6 --config c6 --steps 20 --warmup 3 --repeats 2
 prof c5 --config c5 --steps 500 --warmup 20 --repeats 2 --no-kernel-events
+# (round 6: the same without the step image -- the plain one-launch step k_step_csr)
+SNN_AMD_CSR_IMAGE=0 prof c5_plain_step --config c5 --steps 500 --warmup 20 --repeats 2 --no-kernel-events
 prof c1 --config c1 --steps 2000 --warmup 50 --repeats 2 --no-kernel-events
 prof lattice64 --config c2 --rows 64 --cols 64 --steps 2000 --warmup 50 --repeats 2 --no-kernel-events
 prof c2_sharded_world1 --config c2 --force-sharded --steps 50 --warmup 10 --repeats 2

@@ -266,6 +266,7 @@ SIGNATURES = {
     "snn_debug_verify_report": (C.c_char_p, [H]),
     "snn_debug_checkpoint": (C.c_int, [H, C.c_int]),
     "snn_debug_fail_alloc_at": (C.c_int, [C.c_int64, u64p]),
+    "snn_debug_set_host_allocator": (C.c_int, [C.c_void_p, C.c_void_p]),
     "snn_profile_enable": (C.c_int, [H, C.c_int]),
     "snn_profile_reset": (C.c_int, [H]),
     "snn_profile_read": (C.c_int, [H, u64p, C.POINTER(C.c_double)]),

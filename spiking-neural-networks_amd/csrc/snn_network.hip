@@ -1178,6 +1178,20 @@ int snn_debug_fail_alloc_at(int64_t n, uint64_t *allocations_so_far) ABI_TRY
 }
 ABI_CATCH
 
+// Test support for the hunt after stray host writes (snn_network_state.hpp, HostAllocHooks): from now on every host table of the
+// library comes from `alloc` and goes back through `release`; both null: the default allocator again (tables taken from the
+// hooks before that still go back to them: keep the functions alive).  Process-wide.
+int snn_debug_set_host_allocator(snn_host_alloc_fn alloc, snn_host_release_fn release) ABI_TRY
+{
+    static HostAllocHooks hooks;                   // (one set per process: a later call replaces the functions in place)
+    if ((alloc == nullptr) != (release == nullptr)) return fail(SNN_ERR_BAD_ARG, "both functions or none");
+    if (!alloc) { host_alloc_hooks().store(nullptr, std::memory_order_release); return SNN_OK; }
+    hooks.alloc = alloc; hooks.release = release;
+    host_alloc_hooks().store(&hooks, std::memory_order_release);
+    return SNN_OK;
+}
+ABI_CATCH
+
 // Test support (tests/checkpoint.py): everything a later run call reads -- every device array of the handle up to 256 MiB in
 // all, the sparse weights, traces, and the host-side cursors of the stepper -- kept in host memory; restore puts it back.
 // Valid between calls that leave the handle's STRUCTURE alone (run calls, attribute and weight writes): a restore after a

@@ -90,6 +90,15 @@ inline bool alloc_fault_now()
     if (f.countdown.load(std::memory_order_relaxed) <= 0) return false;
     return f.countdown.fetch_sub(1, std::memory_order_relaxed) == 1;
 }
+// Test support (snn_debug_set_host_allocator): the host tables of the library -- among them the temporaries a getter downloads
+// into before it unpacks into the caller's array -- can be taken from a caller-supplied allocator.  tests/guard_arena.py hands
+// in its protected arena: a table then ends at an inaccessible page and becomes inaccessible for good the moment it is freed, so
+// that a transfer that lands AFTER the call that owned the table returned faults at the instruction that writes it.
+struct HostAllocHooks {
+    void *(*alloc)(size_t bytes, const char *tag);
+    int (*release)(void *p, size_t bytes);          // 1: p was the hook's (and is retired now), 0: not its memory
+};
+inline std::atomic<const HostAllocHooks *> &host_alloc_hooks() { static std::atomic<const HostAllocHooks *> h{nullptr}; return h; }
 template <typename T>
 struct HostAlloc {
     using value_type = T;
@@ -98,9 +107,16 @@ struct HostAlloc {
     T *allocate(size_t n)
     {
         if (alloc_fault_now() || n > SIZE_MAX / sizeof(T)) throw std::bad_alloc();
+        if (const HostAllocHooks *h = host_alloc_hooks().load(std::memory_order_acquire))
+            if (void *p = h->alloc(n * sizeof(T), "libsnn_amd host table")) return static_cast<T *>(p);
         return static_cast<T *>(::operator new(n * sizeof(T)));
     }
-    void deallocate(T *p, size_t) noexcept { ::operator delete(p); }
+    void deallocate(T *p, size_t n) noexcept
+    {
+        if (const HostAllocHooks *h = host_alloc_hooks().load(std::memory_order_acquire))
+            if (h->release(p, n * sizeof(T))) return;
+        ::operator delete(p);
+    }
     template <typename U> bool operator==(const HostAlloc<U> &) const { return true; }
     template <typename U> bool operator!=(const HostAlloc<U> &) const { return false; }
 };

@@ -316,6 +316,7 @@ def main():
                "oracle_memory_reports": guard_reports[:50], "trap_armed": bool(args.trap and not args.plain),
                "trap_faults": sum(r["trap_faults"] for r in trap_faults), "trap_fault_records": trap_faults[:50], "trap_reports": trap_reports[:50],
                "trap_calls": sum(t["calls"] for t in trap_stats), "trap_buffers_retired": sum(t["buffers_retired"] for t in trap_stats),
+               "trap_library_host_tables": sum(t.get("library_host_tables", 0) for t in trap_stats),
                "self_check_reports": len(verify_reports), "self_check_records": verify_reports[:200],
                "environment": {k: v for k, v in worker_env.items() if k.startswith(("SNN_", "AMD_", "HIP_", "HSA_", "OMP_", "MALLOC_", "GPU_"))},
                "ras_errors_before_ue_ce": checkpoint.ras_totals(ras_before), "ras_errors_after_ue_ce": checkpoint.ras_totals(ras_after),

@@ -212,6 +212,22 @@ int snn_guard_retag(void *p, const char *tag)
     return 0;
 }
 
+/* the two functions libsnn_amd.so takes through snn_debug_set_host_allocator: its host tables live in the arena */
+static volatile uint64_t g_host_tables;
+void *snn_guard_host_alloc(size_t bytes, const char *tag)
+{
+    __atomic_add_fetch(&g_host_tables, 1, __ATOMIC_RELAXED);
+    return snn_guard_alloc(bytes ? bytes : 1, tag);
+}
+int snn_guard_host_release(void *p, size_t bytes)
+{
+    (void)bytes;
+    if (!p || (uintptr_t)p < g_base || (uintptr_t)p >= g_end) return 0;
+    snn_guard_set_state(p, ST_QUARANTINE);
+    return 1;
+}
+uint64_t snn_guard_host_table_count(void) { return __atomic_load_n(&g_host_tables, __ATOMIC_RELAXED); }
+
 uint64_t snn_guard_fault_count(void) { return __atomic_load_n(&g_faults, __ATOMIC_RELAXED); }
 uint64_t snn_guard_region_count(void) { return __atomic_load_n(&g_count, __ATOMIC_ACQUIRE); }
 uint64_t snn_guard_bytes_reserved(void) { return g_base ? g_next - g_base : 0; }

@@ -58,7 +58,7 @@ def lib():
             getattr(L, fn).argtypes = [C.c_void_p]
         L.snn_guard_set_state.argtypes = [C.c_void_p, C.c_int]
         L.snn_guard_retag.argtypes = [C.c_void_p, C.c_char_p]
-        for fn in ("snn_guard_fault_count", "snn_guard_region_count", "snn_guard_bytes_reserved"):
+        for fn in ("snn_guard_fault_count", "snn_guard_region_count", "snn_guard_bytes_reserved", "snn_guard_host_table_count"):
             getattr(L, fn).restype = C.c_uint64
         L.snn_guard_note.argtypes = [C.c_char_p]
         _lib = L
@@ -237,25 +237,44 @@ class Guard:
         return out
 
     def stats(self):
-        return {"calls": self.calls, "buffers_retired": self.retired, "regions": int(self.L.snn_guard_region_count()),
+        return {"calls": self.calls, "buffers_retired": self.retired, "library_host_tables": int(self.L.snn_guard_host_table_count()),
+                "regions": int(self.L.snn_guard_region_count()),
                 "arena_bytes": int(self.L.snn_guard_bytes_reserved()), "faults": self.faults(), "log": self.log_path}
 
 
-def install(snn_amd, log_dir, **options):
-    """arms the calling process (see the module's docstring); returns the Guard"""
+def install(snn_amd, log_dir, internal_tables=True, **options):
+    """arms the calling process (see the module's docstring); returns the Guard.  internal_tables: the library's own host tables
+    come from the arena as well (snn_debug_set_host_allocator)"""
     import oracle_binding as ob
+    options_internal_tables = internal_tables
     guard = Guard._instance or Guard(log_dir, **options)
     L = snn_amd._lib
     names = list(L.SIGNATURES)
     declare = L._declare
     if not hasattr(declare, "unguarded"):
         def guarded_declare(path):
-            return guard.wrap_library(declare(path), names)
+            cdll = guard.wrap_library(declare(path), names)
+            if options_internal_tables:
+                fn = cdll.snn_debug_set_host_allocator
+                L.check(getattr(fn, "unguarded", fn)(C.cast(guard.L.snn_guard_host_alloc, C.c_void_p), C.cast(guard.L.snn_guard_host_release, C.c_void_p)), cdll)
+            return cdll
         guarded_declare.unguarded = declare
         L._declare = guarded_declare
     for cdll in [L._lib] + list(L._custom_libs.values()):
         if cdll is not None:
             guard.wrap_library(cdll, names)
+    # the library's OWN host tables -- the temporaries its getters download into -- live in the arena too: a transfer that lands
+    # after the call that owned the table returned faults (every library loaded from now on as well: guarded_declare below)
+    hooks = (C.cast(guard.L.snn_guard_host_alloc, C.c_void_p), C.cast(guard.L.snn_guard_host_release, C.c_void_p))
+
+    def hand_over(cdll):
+        fn = getattr(cdll, "snn_debug_set_host_allocator")
+        fn = getattr(fn, "unguarded", fn)
+        L.check(fn(*hooks), cdll)
+    if options_internal_tables:
+        for cdll in [L._lib] + list(L._custom_libs.values()):
+            if cdll is not None:
+                hand_over(cdll)
     init = ob.Net.__init__
     if not hasattr(init, "unguarded"):
         counter = [0]

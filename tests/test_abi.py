@@ -178,7 +178,7 @@ def test_ctypes_signatures_match_the_header():
         else:
             assert res in (ctypes.c_char_p, ctypes.c_void_p), f"{name}: returns {hret}, bound as {res}"
         for i, (a, t) in enumerate(zip(args, htypes)):
-            if "*" in t or "snn_exchange_fn" in t:
+            if "*" in t or "snn_exchange_fn" in t or "snn_host_alloc_fn" in t or "snn_host_release_fn" in t:
                 assert a in (ctypes.c_void_p, ctypes.c_char_p) or hasattr(a, "_type_") or hasattr(a, "contents"), \
                     f"{name}, parameter {i}: {t} bound as {a}"
             else:

@@ -54,3 +54,5 @@ def test_seeded_tests_through_the_trap_report_nothing(tmp_path, pinned):
     log = open(res["stats"]["log"]).read() if os.path.exists(res["stats"]["log"]) else ""
     assert res["stats"]["faults"] == 0 and res["reports"] == [], (res, log[-6000:])
     assert res["ran"] >= 20 and res["stats"]["calls"] > 500 and res["stats"]["buffers_retired"] > 200, res
+    # the library's own host tables (the temporaries of its getters among them) came from the arena too
+    assert res["stats"]["library_host_tables"] > 500, res
