@@ -9,6 +9,8 @@ set -u
 OUT=$PWD/gpurun_out/r06_s5
 mkdir -p $OUT
 export TMPDIR=/tmp
+timeout 600 python3 -m pytest tests/test_gpu_halo_direct.py -m gpu -q > $OUT/test_gpu_halo_direct.log 2>&1
+echo "halo direct (step image on shard handles): exit $?"; tail -2 $OUT/test_gpu_halo_direct.log | cut -c1-200
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o /tmp/late_copy_probe tests/cpp/late_copy_probe.cpp -pthread 2> $OUT/probe_build.err
 /tmp/late_copy_probe 60 8 > $OUT/probe_alone.json 2> $OUT/probe_alone.err; echo "probe alone: exit $?"; cat $OUT/probe_alone.json; head -5 $OUT/probe_alone.err
 for i in 1 2 3; do python3 bench.py --config c2 --steps 4000 --warmup 5 --repeats 1 --no-cpu-baseline > /dev/null 2>&1 & done

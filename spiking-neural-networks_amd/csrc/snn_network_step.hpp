@@ -1205,7 +1205,7 @@ int launch_step_csr(snn_network *net, CsrStepPart part = CSR_STEP_ALL, bool pack
             stale = false;
         }
         c.img.hdr = hdr; c.img.rec = rec;
-        if (part != CSR_STEP_BORDER || net->n_interior == 0) net->stat_steps_sparse_image += 1;
+        if (part != CSR_STEP_INTERIOR) net->stat_steps_sparse_image += 1;      // (a step is one ALL launch, or a BORDER launch and perhaps an INTERIOR one)
     } else if (net->any_plasticity || net->any_modulation || net->any_conn_kind) {
         net->img_stale = net->img_stale_direct = true;          // this step's weight updates leave the records behind
     }
