@@ -504,7 +504,8 @@ int snn_get_spike_counts(snn_network_t *net, uint32_t id, uint32_t *dst, size_t 
  * handle is created: SNN_AMD_<NAME in upper case>): "fused_step" [1] one-launch step for small lattices and for
  * sparse handles; "dense_close" [0] 1: streamed dense matrices on unsharded handles with gap junctions: the last workgroup of a column
  * tile of the input pass updates the tile's neurons in the same launch (k_inputs_dense_close; measured slower than input pass +
- * k_update); "cells_in_step" [1] sparse electrical-only handles without weight updates: the spike-train cells advance
+ * k_update); "resident_quarters" [1] the one-launch step of small dense networks (at most 512 presynaptic rows) spreads a chunk's 256 rows
+ * over four wavefronts -- products in parallel, adds in turn (k_step_resident_q); "cells_in_step" [1] sparse electrical-only handles without weight updates: the spike-train cells advance
  * inside the step's launch; "update_packs" [1] dense shard handles: the neuron update writes the handle's own slot of
  * the all-gather buffer itself (no pack launch); "update_all_planes" [1] dense handles with chemical synapses: 1: the neuron update
  * requests the chunk partials of all planes together, 2: four wavefronts share a column's partials and warm the cache for the update

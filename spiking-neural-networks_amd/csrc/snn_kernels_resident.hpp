@@ -217,6 +217,158 @@ __global__ __launch_bounds__(64 * RESIDENT_MAX_CHUNKS) void k_step_resident(cons
     }
 }
 
+// k_step_resident_q -- the same step with a chunk's 256 rows spread over FOUR wavefronts (round 6).  In k_step_resident one
+// wavefront walks a chunk's rows alone: broadcast, difference, two products, the absent-edge select and the add are a dependent
+// instruction stream of about a hundred clocks per row and synapse kind -- 16x16 with gap junctions and one transmitter type:
+// 17.9 us per step of which the sums are 13.  Here wavefront (chunk c, quarter r) owns rows [256 c + 64 r, + 64): it forms the 64
+// products of a plane on its own (independent instructions), and only the adds are taken in turn -- quarter 0 from 0.0f, quarter
+// 1 continuing from the running sum quarter 0 left in LDS, ... : the canonical ascending order, add for add.  The planes (gap
+// junctions, then every live transmitter type) are staggered: in turn t quarter r adds plane t - r and then forms the products
+// of its next plane while the other quarters add.  4 + planes - 1 turns, a workgroup barrier between two turns.
+// Workgroup = 64 columns x 4 quarters x chunks: up to 512 threads (two chunks: 512 presynaptic rows); larger networks keep
+// k_step_resident.  Registers: 64 weights + 64 products per lane.
+template <int MODEL, bool ELEC, bool CHEM>
+__global__ __launch_bounds__(512) void k_step_resident_q(const ResidentArgs a)
+{
+    constexpr uint32_t R = 64;                        // rows per wavefront
+    __shared__ float s_pi[RESIDENT_MAX_CHUNKS][64];
+    __shared__ float s_pt[CHEM ? K_TYPES : 1][RESIDENT_MAX_CHUNKS][64];
+
+    const InputsArgs &in = a.in;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t chunk = wave >> 2, quarter = wave & 3u;
+    const uint32_t ql = blockIdx.x * 64 + lane;              // W rows are padded to a multiple of 64 columns (NaN)
+    const bool col = ql < in.n_loc;
+    const float vq = (ELEC && col) ? in.xbuf[in.xl.at(in.q0 + ql, PLANE_V)] : 0.0f;
+    const float gq = (ELEC && col) ? in.gap_conductance[in.q0 + ql] : 0.0f;
+
+    const uint32_t c0 = chunk * CHUNK;
+    const uint32_t chunk_rows = min((uint32_t)CHUNK, in.n_tot - c0);
+    const uint32_t p0 = c0 + quarter * R;
+    const uint32_t rb = chunk_rows > quarter * R ? min(R, chunk_rows - quarter * R) : 0u;      // rows of this wavefront (wave-uniform)
+
+    // the presynaptic state of row p0 + lane (one row per lane, broadcast with v_readlane) and this lane's 64 weights
+    float val = 0.0f, tval[CHEM ? K_TYPES : 1];
+    uint32_t kind = KIND_NEURON;
+#pragma unroll
+    for (int k = 0; k < (CHEM ? K_TYPES : 1); ++k) tval[k] = 0.0f;
+    if (lane < rb) {
+        const uint32_t p = p0 + lane;
+        if (p < in.n_neurons) {
+            val = in.xbuf[in.xl.at(p, PLANE_V)];
+            if (CHEM) {
+#pragma unroll
+                for (int k = 0; k < K_TYPES; ++k) {
+                    kind |= in.nt_flags[(size_t)k * in.n_pad + p] ? (0x100u << k) : 0u;
+                    tval[k] = in.xbuf[in.xl.at(p, PLANE_T0 + k)];
+                }
+            }
+        } else {
+            const uint32_t s = p - in.n_neurons;
+            val = in.st_value[s];
+            kind = (in.st_last_firing_time[s] < 0) ? KIND_ST_SILENT : KIND_ST_FIRED;
+            if (CHEM) {
+#pragma unroll
+                for (int k = 0; k < K_TYPES; ++k) {
+                    kind |= in.st_nt_flags[(size_t)k * in.c_pad + s] ? (0x100u << k) : 0u;
+                    tval[k] = in.st_nt_t[(size_t)k * in.c_pad + s];
+                }
+            }
+        }
+    }
+    float w[R];
+    {
+        // quad-row order: one dwordx4 = 4 consecutive rows of this lane's column; row groups past the end of the matrix = absent edges
+        const v4f *units = reinterpret_cast<const v4f *>(in.W) + (size_t)(p0 >> 2) * in.ld + ql;
+        const v4f none = {quiet_nan(), quiet_nan(), quiet_nan(), quiet_nan()};
+#pragma unroll
+        for (uint32_t g = 0; g < R / 4; ++g) {
+            const v4f x = (4 * g < rb) ? units[(size_t)g * in.ld] : none;
+            w[4 * g] = x.x; w[4 * g + 1] = x.y; w[4 * g + 2] = x.z; w[4 * g + 3] = x.w;
+        }
+    }
+    const unsigned long long live = (rb == 64) ? ~0ull : ((1ull << rb) - 1ull);
+    const bool all_neurons = (__ballot((kind & 3u) == KIND_NEURON) & live) == live;
+    auto bcast = [&](float x, uint32_t r) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), r)); };
+
+    // plane ids of the launch (uniform): 0 = gap junctions, 1 + k = transmitter type k (the live ones)
+    uint32_t plane_id[1 + K_TYPES], n_planes = 0;
+    if (ELEC) plane_id[n_planes++] = 0u;
+    if (CHEM) {
+#pragma unroll
+        for (int k = 0; k < K_TYPES; ++k)
+            if (a.up.live_mask >> k & 1u) plane_id[n_planes++] = 1u + (uint32_t)k;
+    }
+    // the 64 products of one plane: formed unconditionally (NaN for an absent edge), an absent edge or a row without the plane
+    // contributes +0.0f (the sum starts at +0.0f and never holds -0.0f: x + 0.0f == x bit for bit), as in k_step_resident
+    float pr[R];
+    auto form = [&](uint32_t id) {
+        if (id == 0u) {
+            if (all_neurons) {                               // gap_junction neuron/mod.rs:54-60
+#pragma unroll
+                for (uint32_t u = 0; u < R; ++u) {
+                    const float p = (gq * (bcast(val, u) - vq)) * w[u];
+                    pr[u] = (w[u] == w[u]) ? p : 0.0f;
+                }
+            } else {                                         // + spike_train_gap_junction :119-137
+#pragma unroll
+                for (uint32_t u = 0; u < R; ++u) {
+                    const uint32_t src = __builtin_amdgcn_readlane(kind, u) & 3u;
+                    const float vp = bcast(val, u);
+                    const float term = (src == KIND_NEURON) ? gq * (vp - vq) : ((src == KIND_ST_SILENT) ? vp : gq * vp);
+                    const float p = term * w[u];
+                    pr[u] = (w[u] == w[u]) ? p : 0.0f;
+                }
+            }
+        } else if (CHEM) {
+#pragma unroll
+            for (int k = 0; k < K_TYPES; ++k) {
+                if (id != 1u + (uint32_t)k) continue;
+#pragma unroll
+                for (uint32_t u = 0; u < R; ++u) {
+                    const float p = bcast(tval[k], u) * w[u];
+                    const bool has = (__builtin_amdgcn_readlane(kind, u) & (0x100u << k)) != 0;
+                    pr[u] = (w[u] == w[u] && has) ? p : 0.0f;
+                }
+            }
+        }
+    };
+    if (n_planes) form(plane_id[0]);
+    const uint32_t turns = n_planes ? 4u + n_planes - 1u : 0u;
+    for (uint32_t t = 0; t < turns; ++t) {
+        const uint32_t pi = t - quarter;                     // (wraps below zero: not this wavefront's turn yet)
+        if (pi < n_planes) {
+            const uint32_t id = plane_id[pi];
+            float *slot = id == 0u ? &s_pi[chunk][lane] : &s_pt[CHEM ? id - 1u : 0u][chunk][lane];
+            float sum = quarter ? *slot : 0.0f;
+#pragma unroll
+            for (uint32_t u = 0; u < R; ++u) sum += pr[u];
+            *slot = sum;
+            if (pi + 1u < n_planes) form(plane_id[pi + 1u]);
+        }
+        __syncthreads();
+    }
+    if (CHEM) {
+        // the planes of types nobody releases hold zeros (k_step_resident leaves its accumulators at 0.0f for them)
+        if (quarter == 3u) {
+#pragma unroll
+            for (int k = 0; k < K_TYPES; ++k)
+                if (!(a.up.live_mask >> k & 1u)) s_pt[k][chunk][lane] = 0.0f;
+        }
+        __syncthreads();
+    }
+    if (wave != 0) return;
+
+    // ---- wavefront 0: second level of the canonical sum + the neuron update of these 64 columns ----
+    uint32_t spike = 0;
+    if (col) spike = update_neuron<MODEL>(a.up, ql, LdsSums{s_pi, s_pt, in.n_chunks, lane});
+    if (a.up.spike_row) {
+        const unsigned long long word = __ballot(spike != 0);
+        if (lane == 0) a.up.spike_row[(a.up.q0 + ql) >> 6] = word;
+    }
+}
+
 // k_run_resident -- MANY steps of a small dense lattice in ONE launch (electrical synapses, neurons only; first for <= 1024
 // of them: BASELINE configs[0], the 32 x 32 lattice; up to 4096 with the row groups described further down).  The
 // one-launch step above is a chain of dependent L2 round trips (9.5 us per launch, of which the canonical 256-long add

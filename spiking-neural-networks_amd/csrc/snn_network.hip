@@ -45,6 +45,7 @@ int snn_network_create(int device, int neuron_model, int nt_kinetics, int recept
     if (const char *e = getenv("SNN_AMD_PINNED_COPIES")) net->pinned_copies = (e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1;
     if (const char *e = getenv("SNN_AMD_CSR_XCD_BANDS")) net->csr_xcd_bands = (e[0] != '0');
     if (const char *e = getenv("SNN_AMD_CSR_IMAGE")) net->csr_image = (e[0] != '0');
+    if (const char *e = getenv("SNN_AMD_RESIDENT_QUARTERS")) net->resident_quarters = (e[0] != '0');
     if (const char *e = getenv("SNN_AMD_HALO_DIRECT")) net->halo_direct = (e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1;
     if (const char *e = getenv("SNN_AMD_UPDATE_PACKS")) net->update_packs = (e[0] != '0');
     if (const char *e = getenv("SNN_AMD_UPDATE_ALL_PLANES")) net->update_all_planes = (e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : 1;
@@ -2297,6 +2298,7 @@ int snn_set_option(snn_network_t *net, const char *name, int value) ABI_TRY
     else if (n == "halo_peer_spin_limit") net->p2p_spin_limit = value > 0 ? (uint32_t)value : (1u << 26);
     else if (n == "csr_xcd_bands") net->csr_xcd_bands = value != 0;
     else if (n == "csr_image") net->csr_image = value != 0;
+    else if (n == "resident_quarters") net->resident_quarters = value != 0;
     else if (n == "defer_rstdp") net->defer_rstdp = value != 0;
     else if (n == "defer_stdp") net->defer_stdp = (value >= 0 && value <= 3) ? value : 1;
     else if (n == "uniform_params") { net->uniform_params = value != 0; net->uni_dirty = true; }

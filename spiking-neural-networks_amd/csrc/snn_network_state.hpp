@@ -258,6 +258,7 @@ struct snn_network {
     bool send_bits_clean = true;          // every outgoing spike bitmap is zero (what the in-kernel pack ORs into)
     bool update_packed = false;           // this step's own slot of the all-gather buffer was written by k_update
     int update_packs = 1;                 // option "update_packs"
+    bool resident_quarters = true;        // option "resident_quarters": the one-launch step with a chunk's rows over four wavefronts
     int update_all_planes = 1;            // option "update_all_planes": 1 all planes' partials in one thread (default), 2 / 3 the wide update (k_update_wide; measured slower)
     bool step_packed = false;             // this step's outgoing segments were written by k_step_csr itself
     bool interior_pending = false;        // the border half of this step is enqueued, the interior slices are not yet

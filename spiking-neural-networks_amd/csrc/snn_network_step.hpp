@@ -733,10 +733,15 @@ int launch_step_resident(snn_network *net)
     TRY(fused_step_args(net, r.in, r.up));
     hipEvent_t e1 = nullptr;
     TRY(profile_open(net, &e1));
-    const dim3 grid((net->n_loc + 63) / 64), block(64 * net->n_chunks);
+    // a chunk's rows over four wavefronts (k_step_resident_q) where the workgroup stays within 512 threads: at most two chunks
+    const bool quarters = net->resident_quarters && net->n_chunks <= 2;
+    const dim3 grid((net->n_loc + 63) / 64), block(64 * net->n_chunks * (quarters ? 4 : 1));
 #define SNN_RESIDENT(M)                                                                                              \
     do {                                                                                                             \
-        if (net->electrical && net->chemical) hipLaunchKernelGGL((k_step_resident<M, true, true>), grid, block, 0, net->stream, r);  \
+        if (quarters && net->electrical && net->chemical) hipLaunchKernelGGL((k_step_resident_q<M, true, true>), grid, block, 0, net->stream, r); \
+        else if (quarters && net->electrical) hipLaunchKernelGGL((k_step_resident_q<M, true, false>), grid, block, 0, net->stream, r);            \
+        else if (quarters) hipLaunchKernelGGL((k_step_resident_q<M, false, true>), grid, block, 0, net->stream, r);                              \
+        else if (net->electrical && net->chemical) hipLaunchKernelGGL((k_step_resident<M, true, true>), grid, block, 0, net->stream, r);  \
         else if (net->electrical) hipLaunchKernelGGL((k_step_resident<M, true, false>), grid, block, 0, net->stream, r);             \
         else hipLaunchKernelGGL((k_step_resident<M, false, true>), grid, block, 0, net->stream, r);                                  \
     } while (0)

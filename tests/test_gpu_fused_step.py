@@ -41,7 +41,8 @@ def build(model, electrical, chemical, lattices, st, seed):
     return net
 
 
-def run_device(snn, net, steps, fused, csr=False):
+def run_device(snn, net, steps, fused, csr=False, quarters=True):
+    """quarters: the one-launch step with a chunk's rows over four wavefronts (k_step_resident_q, the default up to two chunks)"""
     old = os.environ.get("SNN_AMD_FUSED_STEP")
     os.environ["SNN_AMD_FUSED_STEP"] = "1" if fused else "0"
     try:
@@ -51,10 +52,11 @@ def run_device(snn, net, steps, fused, csr=False):
             del os.environ["SNN_AMD_FUSED_STEP"]
         else:
             os.environ["SNN_AMD_FUSED_STEP"] = old
+    dn.set_option("resident_quarters", int(quarters))
     dn.set_history(voltage=True, spikes=True)
     dn.run(steps // 3)
     dn.run(steps - steps // 3)
-    out = {"state": parity.pull_state(dn, net),
+    out = {"state": parity.pull_state(dn, net), "one_launch_steps": dn.stat("steps_dense_one_launch"),
            "graph": (dn.get_graph_csr(),) if csr else dn.get_graph_rows(0, net.n_tot)}
     for i, _, _ in net.layout.lattices:
         out[("v", i)] = dn.voltage_history(i)
@@ -82,13 +84,16 @@ def test_fused_step_equals_two_kernel_step_and_oracle(snn, model, electrical, ch
     steps = 300 if (model != ob.HH and (chemical or model != ob.IZHIKEVICH)) else 900
     a = run_device(snn, net, steps, fused=True)
     b = run_device(snn, net, steps, fused=False)
-    for key in a:
-        if key in ("state", "graph"):
-            continue
-        assert np.array_equal(parity.bits(a[key]), parity.bits(b[key])), key
-    for name in a["state"]:
-        assert np.array_equal(parity.bits(a["state"][name]), parity.bits(b["state"][name])), name
-    assert np.array_equal(parity.bits(a["graph"][0]), parity.bits(b["graph"][0]))
+    c = run_device(snn, net, steps, fused=True, quarters=False)          # one wavefront per chunk (k_step_resident)
+    assert a["one_launch_steps"] == c["one_launch_steps"] and b["one_launch_steps"] == 0
+    for other in (b, c):
+        for key in a:
+            if key in ("state", "graph", "one_launch_steps"):
+                continue
+            assert np.array_equal(parity.bits(a[key]), parity.bits(other[key])), key
+        for name in a["state"]:
+            assert np.array_equal(parity.bits(a["state"][name]), parity.bits(other["state"][name])), name
+        assert np.array_equal(parity.bits(a["graph"][0]), parity.bits(other["graph"][0]))
     net.run(steps, voltage_history=True, spike_history=True)
     parity.assert_state_equal(net, a["state"])
     rng = net.layout.ranges()
@@ -107,7 +112,7 @@ def test_fused_sparse_step_equals_two_kernel_step_and_oracle(snn, model, electri
     a = run_device(snn, net, steps, fused=True, csr=True)
     b = run_device(snn, net, steps, fused=False, csr=True)
     for key in a:
-        if key in ("state", "graph"):
+        if key in ("state", "graph", "one_launch_steps"):
             continue
         assert np.array_equal(parity.bits(a[key]), parity.bits(b[key])), key
     for name in a["state"]:
