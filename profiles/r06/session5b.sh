@@ -5,15 +5,15 @@ set -u
 OUT=$PWD/gpurun_out/r06_s5b
 mkdir -p $OUT
 export TMPDIR=/tmp
-timeout 1500 python3 -m pytest tests/test_gpu_fused_step.py tests/test_gpu_network.py tests/test_gpu_models.py tests/test_gpu_golden.py tests/test_gpu_lixirnet_module.py tests/test_gpu_modelgen.py tests/test_gpu_randomized.py tests/test_gpu_reward_network.py tests/test_gpu_bcm.py -m gpu -q > $OUT/tests.log 2>&1
-echo "tests: exit $?"; tail -4 $OUT/tests.log | cut -c1-300
+true
+true
 for case in "8 0" "8 1" "16 0" "16 1" "22 0" "22 1"; do
   set -- $case
   for q in 1 0; do
     rm -rf $OUT/prof
     SNN_AMD_RESIDENT_QUARTERS=$q rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 profiles/trace_small_step.py $1 $2 0 3000 > /dev/null 2> $OUT/trace.err
     f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1)
-    cp $f $OUT/small_step_side$1_chem$2_quarters$q_kernel_stats.csv 2>/dev/null
+    cp $f $OUT/small_step_side${1}_chem${2}_quarters${q}_kernel_stats.csv 2>/dev/null
     echo "side $1 chem $2 quarters $q: $(grep k_step_resident $f | cut -d, -f1-4 | cut -c1-120)"
   done
 done

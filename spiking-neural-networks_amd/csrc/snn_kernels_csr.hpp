@@ -620,7 +620,7 @@ __device__ __forceinline__ void step_csr_block(const CsrStepArgs &a, uint32_t *w
     float v_new = 0.0f;
     // (a range-set shard owns whole 64-blocks of the global index space only in part: the rows of the neurons it does not own
     // are holes -- no synapses, no update, k_update's rule)
-    if (q < a.c.g.n_loc && a.up.rows.active(q, a.c.g.n_loc)) spike = update_neuron_at<MODEL>(a.up, q, s, a.up.clock, a.up.vhist_row, &v_new);
+    if (q < a.c.g.n_loc && a.up.rows.active(q, a.c.g.n_loc)) spike = update_neuron_at<MODEL, RegisterSums, true, CHEM>(a.up, q, s, a.up.clock, a.up.vhist_row, &v_new);
     if (a.up.spike_row) {
         // one raster word per wavefront = one aligned 64-block of the GLOBAL index space (as in k_update: a range-set shard maps
         // every slice to such a block; rows it does not own contribute 0)

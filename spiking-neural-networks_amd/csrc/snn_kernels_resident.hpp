@@ -210,7 +210,7 @@ __global__ __launch_bounds__(64 * RESIDENT_MAX_CHUNKS) void k_step_resident(cons
 
     // ---- wavefront 0: second level of the canonical sum + the neuron update of these 64 columns ----
     uint32_t spike = 0;
-    if (col) spike = update_neuron<MODEL>(a.up, ql, LdsSums{s_pi, s_pt, in.n_chunks, lane});
+    if (col) spike = update_neuron<MODEL, LdsSums, CHEM>(a.up, ql, LdsSums{s_pi, s_pt, in.n_chunks, lane});
     if (a.up.spike_row) {
         const unsigned long long word = __ballot(spike != 0);
         if (lane == 0) a.up.spike_row[(a.up.q0 + ql) >> 6] = word;
@@ -303,8 +303,18 @@ __global__ __launch_bounds__(512) void k_step_resident_q(const ResidentArgs a)
     // the 64 products of one plane: formed unconditionally (NaN for an absent edge), an absent edge or a row without the plane
     // contributes +0.0f (the sum starts at +0.0f and never holds -0.0f: x + 0.0f == x bit for bit), as in k_step_resident
     float pr[R];
+    bool pr_zero = false;                                    // the products just formed are all +0.0f (wave-uniform): the adds are skipped
+    bool all_k[CHEM ? K_TYPES : 1], any_k[CHEM ? K_TYPES : 1];
+#pragma unroll
+    for (int k = 0; k < (CHEM ? K_TYPES : 1); ++k) {
+        const unsigned long long has = CHEM ? (__ballot((kind & (0x100u << k)) != 0) & live) : 0ull;
+        all_k[k] = has == live && rb != 0u;
+        any_k[k] = has != 0ull;
+    }
     auto form = [&](uint32_t id) {
+        pr_zero = false;
         if (id == 0u) {
+            if (rb == 0u) { pr_zero = true; return; }        // a quarter past the end of the chunk
             if (all_neurons) {                               // gap_junction neuron/mod.rs:54-60
 #pragma unroll
                 for (uint32_t u = 0; u < R; ++u) {
@@ -325,11 +335,20 @@ __global__ __launch_bounds__(512) void k_step_resident_q(const ResidentArgs a)
 #pragma unroll
             for (int k = 0; k < K_TYPES; ++k) {
                 if (id != 1u + (uint32_t)k) continue;
+                if (!any_k[k]) { pr_zero = true; continue; }         // no row of this wavefront carries the type: nothing to add
+                if (all_k[k]) {
 #pragma unroll
-                for (uint32_t u = 0; u < R; ++u) {
-                    const float p = bcast(tval[k], u) * w[u];
-                    const bool has = (__builtin_amdgcn_readlane(kind, u) & (0x100u << k)) != 0;
-                    pr[u] = (w[u] == w[u] && has) ? p : 0.0f;
+                    for (uint32_t u = 0; u < R; ++u) {
+                        const float p = bcast(tval[k], u) * w[u];
+                        pr[u] = (w[u] == w[u]) ? p : 0.0f;
+                    }
+                } else {
+#pragma unroll
+                    for (uint32_t u = 0; u < R; ++u) {
+                        const float p = bcast(tval[k], u) * w[u];
+                        const bool has = (__builtin_amdgcn_readlane(kind, u) & (0x100u << k)) != 0;
+                        pr[u] = (w[u] == w[u] && has) ? p : 0.0f;
+                    }
                 }
             }
         }
@@ -342,9 +361,11 @@ __global__ __launch_bounds__(512) void k_step_resident_q(const ResidentArgs a)
             const uint32_t id = plane_id[pi];
             float *slot = id == 0u ? &s_pi[chunk][lane] : &s_pt[CHEM ? id - 1u : 0u][chunk][lane];
             float sum = quarter ? *slot : 0.0f;
+            if (!pr_zero) {
 #pragma unroll
-            for (uint32_t u = 0; u < R; ++u) sum += pr[u];
-            *slot = sum;
+                for (uint32_t u = 0; u < R; ++u) sum += pr[u];
+            }
+            if (!pr_zero || quarter == 0u) *slot = sum;
             if (pi + 1u < n_planes) form(plane_id[pi + 1u]);
         }
         __syncthreads();
@@ -362,7 +383,7 @@ __global__ __launch_bounds__(512) void k_step_resident_q(const ResidentArgs a)
 
     // ---- wavefront 0: second level of the canonical sum + the neuron update of these 64 columns ----
     uint32_t spike = 0;
-    if (col) spike = update_neuron<MODEL>(a.up, ql, LdsSums{s_pi, s_pt, in.n_chunks, lane});
+    if (col) spike = update_neuron<MODEL, LdsSums, CHEM>(a.up, ql, LdsSums{s_pi, s_pt, in.n_chunks, lane});
     if (a.up.spike_row) {
         const unsigned long long word = __ballot(spike != 0);
         if (lane == 0) a.up.spike_row[(a.up.q0 + ql) >> 6] = word;
@@ -1352,7 +1373,7 @@ __device__ __forceinline__ void run_resident_steps(const ResidentRunArgs &a, Res
                 const ResidentRunArgs &b = a;
                 float *vhist_row = b.up.vhist_row ? b.up.vhist_row + (size_t)s * b.vhist_stride : nullptr;
                 if (col)
-                    spike = update_neuron_at<MODEL, LdsSums, false>(b.up, ql, LdsSums{sh.pi, CHEM ? sh.pt : nullptr, n_chunks, lane}, b.up.clock + s, vhist_row,
+                    spike = update_neuron_at<MODEL, LdsSums, false, CHEM>(b.up, ql, LdsSums{sh.pi, CHEM ? sh.pt : nullptr, n_chunks, lane}, b.up.clock + s, vhist_row,
                                                     &v_new, CHEM ? t_new : nullptr);
             }
             if (a.up.spike_row) {

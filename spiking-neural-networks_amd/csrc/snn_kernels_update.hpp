@@ -235,34 +235,45 @@ struct ChemStep {
 
 // Ionotropic::update_receptor_kinetics + set_receptor_currents + the sum of get_receptor_currents
 // (iterate_and_spike/mod.rs:1186-1205, 1260-1304), built-in receptor kinetics
-template <class Sums>
-__device__ __forceinline__ void chem_receptors(const UpdateArgs &a, uint32_t q, uint32_t ql, float v_old, float dt, const Sums &sums, ChemStep &c)
-{
+// what the receptor step reads of a neuron: requested at the very start of the neuron's update (round 6), together with everything
+// else the update reads -- every load of the update in ONE round trip; the arithmetic follows when the sums are there
+struct RcLoaded {
     uint32_t fl[K_TYPES], cnt[K_TYPES];
-    float r[K_TYPES], al[K_TYPES], be[K_TYPES], g[K_TYPES], e[K_TYPES], s[K_TYPES];
-    const float mg = a.n.rc_mg[(size_t)1 * a.n.n_pad + q];
+    float r[K_TYPES], al[K_TYPES], be[K_TYPES], g[K_TYPES], e[K_TYPES], mg;
+};
+__device__ __forceinline__ void chem_receptors_load(const UpdateArgs &a, uint32_t q, uint32_t ql, RcLoaded &l)
+{
+    l.mg = a.n.rc_mg[(size_t)1 * a.n.n_pad + q];
 #pragma unroll
     for (int k = 0; k < K_TYPES; ++k) {
         const size_t i = (size_t)k * a.n.n_pad + q;
         const bool live = (a.live_mask >> k & 1u) != 0u;                 // launch-uniform
-        fl[k] = a.n.rc_flags[i];
-        r[k] = a.n.rc_r[i]; g[k] = a.n.rc_g[i]; e[k] = a.n.rc_e[i];
-        cnt[k] = 0u; al[k] = 0.0f; be[k] = 0.0f; s[k] = 0.0f;
+        l.fl[k] = a.n.rc_flags[i];
+        l.r[k] = a.n.rc_r[i]; l.g[k] = a.n.rc_g[i]; l.e[k] = a.n.rc_e[i];
+        l.cnt[k] = 0u; l.al[k] = 0.0f; l.be[k] = 0.0f;
         if (live) {
-            cnt[k] = a.tcount[(size_t)k * a.ld + ql];
-            al[k] = a.n.rc_alpha[i]; be[k] = a.n.rc_beta[i];
-            s[k] = sums.chem(k);                                         // second level of the canonical sum
+            l.cnt[k] = a.tcount[(size_t)k * a.ld + ql];
+            l.al[k] = a.n.rc_alpha[i]; l.be[k] = a.n.rc_beta[i];
         }
     }
+}
+
+// ... and the arithmetic, once the sums are there
+template <class Sums>
+__device__ __forceinline__ void chem_receptors(const UpdateArgs &a, const RcLoaded &l, float v_old, float dt, const Sums &sums, ChemStep &c)
+{
+    float s[K_TYPES];
+#pragma unroll
+    for (int k = 0; k < K_TYPES; ++k) s[k] = (a.live_mask >> k & 1u) ? sums.chem(k) : 0.0f;      // second level of the canonical sum
     c.rc_on = true;
     c.total = 0.0f;
 #pragma unroll
     for (int k = 0; k < K_TYPES; ++k) {
-        const bool on = fl[k] != 0u, fed = on && cnt[k] != 0u;           // a type absent from the input leaves r untouched
-        const float t = s[k] / (float)(fed ? cnt[k] : 1u);               // the per-type average
-        const float rk = fed ? rc_apply(a.rc_kind, r[k], t, al[k], be[k], dt) : r[k];
-        const float cur = k == 1 ? ((1.0f / (1.0f + ((expf_glibc(-0.062f * v_old) * mg) / 3.75f)) * g[k]) * rk) * (v_old - e[k])
-                                 : (g[k] * rk) * (v_old - e[k]);
+        const bool on = l.fl[k] != 0u, fed = on && l.cnt[k] != 0u;       // a type absent from the input leaves r untouched
+        const float t = s[k] / (float)(fed ? l.cnt[k] : 1u);             // the per-type average
+        const float rk = fed ? rc_apply(a.rc_kind, l.r[k], t, l.al[k], l.be[k], dt) : l.r[k];
+        const float cur = k == 1 ? ((1.0f / (1.0f + ((expf_glibc(-0.062f * v_old) * l.mg) / 3.75f)) * l.g[k]) * rk) * (v_old - l.e[k])
+                                 : (l.g[k] * rk) * (v_old - l.e[k]);
         c.r_new[k] = rk; c.cur_new[k] = cur;
         c.store_r |= fed ? (1u << k) : 0u;
         c.store_cur |= on ? (1u << k) : 0u;
@@ -337,10 +348,13 @@ __device__ __forceinline__ float gate_update(float state, float alpha, float bet
 // returns its spike flag (and, where asked for, the voltage it stored).
 // HOIST: Hodgkin-Huxley's exponentials and powers through the branch-free main paths (more registers live at once: the one-launch
 // run, whose registers are the weights', keeps the plain calls)
-template <int MODEL, class Sums, bool HOIST = true>
+// CHEM_OK = false: the caller is a kernel instantiated for gap junctions only -- the receptor step is compiled out (its preloaded
+// operands would otherwise cost the sparse electrical step its eighth wavefront per SIMD)
+template <int MODEL, class Sums, bool HOIST = true, bool CHEM_OK = true>
 __device__ __forceinline__ uint32_t update_neuron_at(const UpdateArgs &a, uint32_t ql, const Sums &sums, long long clock,
                                                      float *vhist_row, float *v_stored = nullptr, float *t_capture = nullptr)
 {
+    const int a_chemical = CHEM_OK ? a.chemical : 0;
     uint32_t spike = 0;
     {
         const uint32_t q = a.rows.global_of(ql);
@@ -349,11 +363,36 @@ __device__ __forceinline__ uint32_t update_neuron_at(const UpdateArgs &a, uint32
         const float dt = uload(a.n.uni, NP_DT, a.n.dt, q);
         const float c_m = uload(a.n.uni, NP_C_M, a.n.c_m, q);
         const uint32_t spiking_prev = reinterpret_cast<const uint32_t *>(a.n.xbuf)[s_at];
+        // ---- every load of the update, up front (round 6).  The receptor step, the transmitter release and the model's own state
+        // used to be loaded where they were used -- behind the sums, behind each other's arithmetic and its branches: three to
+        // five dependent round trips per neuron.  Nothing below stores before it has been read here. ----
+        constexpr bool own_chemical_step = MODEL == CUSTOM_MODEL && custom::HAS_ELECTROCHEMICAL;
+        // built-in kinetics (every library without generated code): the chemical step loads first and stores last (ChemStep)
+        const bool fused_rc = MODEL != CUSTOM_MODEL && !(SNN_HAVE_CUSTOM_RECEPTORS && a.model_is_custom) &&
+                              !(SNN_HAVE_CUSTOM_RC && a.rc_kind == CUSTOM_KINETICS);
+        const bool fused_nt = MODEL != CUSTOM_MODEL && !(SNN_HAVE_CUSTOM_NT && a.nt_kind == CUSTOM_KINETICS);
+        ChemStep cs;
+        RcLoaded rcl;
+        const bool rc_fused_now = a_chemical && !own_chemical_step && fused_rc;
+        if (rc_fused_now) chem_receptors_load(a, q, ql, rcl);
+        if (fused_nt) chem_nt_load(a, q, cs);
+        const uint32_t cnt_in = a.electrical ? a.n_in[ql] : 0u;
+        float izh_w = 0.0f;
+        if (MODEL == 0) izh_w = a.n.w_value[q];
+        float hh_m = 0.0f, hh_h = 0.0f, hh_n = 0.0f, hh_g_na = 0.0f, hh_e_na = 0.0f, hh_g_k = 0.0f, hh_e_k = 0.0f, hh_g_kl = 0.0f, hh_e_kl = 0.0f,
+              hh_v_th = 0.0f;
+        uint32_t hh_was_increasing = 0u;
+        if (MODEL == 2) {
+            hh_m = a.n.m_state[q]; hh_h = a.n.h_state[q]; hh_n = a.n.n_state[q];
+            hh_g_na = a.n.g_na[q]; hh_e_na = a.n.e_na[q]; hh_g_k = a.n.g_k[q]; hh_e_k = a.n.e_k[q];
+            hh_g_kl = a.n.g_k_leak[q]; hh_e_kl = a.n.e_k_leak[q];
+            hh_v_th = a.n.v_th[q]; hh_was_increasing = a.n.was_increasing[q];
+        }
         if (MODEL == 0 && a.bcm) {
             // BCMIzhikevichNeuron::iterate_and_spike, integrate_and_fire/mod.rs:1458-1469 (electrical) / :1484-1495
             float cur = a.n.bcm_cur[q], avg = a.n.bcm_avg[q], clock = a.n.bcm_clock[q];
             const uint32_t num = a.n.bcm_num_spikes[q] + (spiking_prev ? 1u : 0u);
-            bcm_window_update(clock, a.n.bcm_window[q], dt, num, a.n.bcm_period[q], cur, avg, !a.chemical);
+            bcm_window_update(clock, a.n.bcm_window[q], dt, num, a.n.bcm_period[q], cur, avg, !a_chemical);
             a.n.bcm_cur[q] = cur; a.n.bcm_avg[q] = avg; a.n.bcm_clock[q] = clock; a.n.bcm_num_spikes[q] = num;
         }
 
@@ -361,21 +400,13 @@ __device__ __forceinline__ uint32_t update_neuron_at(const UpdateArgs &a, uint32
         float i_in = 0.0f;
         if (a.electrical) {
             const float s = sums.elec();
-            const uint32_t cnt = a.n_in[ql];
-            i_in = s / (cnt == 0 ? 1.0f : (float)cnt);
+            i_in = s / (cnt_in == 0 ? 1.0f : (float)cnt_in);
         }
 
-        constexpr bool own_chemical_step = MODEL == CUSTOM_MODEL && custom::HAS_ELECTROCHEMICAL;
-        // built-in kinetics (every library without generated code): the chemical step loads first and stores last (ChemStep)
-        const bool fused_rc = MODEL != CUSTOM_MODEL && !(SNN_HAVE_CUSTOM_RECEPTORS && a.model_is_custom) &&
-                              !(SNN_HAVE_CUSTOM_RC && a.rc_kind == CUSTOM_KINETICS);
-        const bool fused_nt = MODEL != CUSTOM_MODEL && !(SNN_HAVE_CUSTOM_NT && a.nt_kind == CUSTOM_KINETICS);
-        ChemStep cs;
-        if (a.chemical && !own_chemical_step) {
-            if (fused_rc) chem_receptors(a, q, ql, v, dt, sums, cs);
+        if (a_chemical && !own_chemical_step) {
+            if (fused_rc) chem_receptors(a, rcl, v, dt, sums, cs);
             else receptors_update(a, q, ql, v, dt, sums);
         }
-        if (fused_nt) chem_nt_load(a, q, cs);
         // (the reference's get_receptor_currents / apply_t_changes at their places in the model's step)
         auto receptor_currents = [&](const UpdateArgs &aa, uint32_t qq, float step, float cm) {
             return cs.rc_on ? cs.total * (step / cm) : snn::receptor_currents(aa, qq, step, cm);
@@ -387,11 +418,11 @@ __device__ __forceinline__ uint32_t update_neuron_at(const UpdateArgs &a, uint32
 
         float v_new;
         if (MODEL == 0) {            // Izhikevich
-            const float w = a.n.w_value[q];
+            const float w = izh_w;
             const float dv = (0.04f * (v * v) + 5.0f * v + 140.0f - w + i_in) * (dt / c_m);
             const float dw = (uload(a.n.uni, NP_A, a.n.a, q) * (uload(a.n.uni, NP_B, a.n.b, q) * v - w)) *
                              (dt / uload(a.n.uni, NP_TAU_M, a.n.tau_m, q));
-            if (a.chemical) {
+            if (a_chemical) {
                 const float neurotransmitter_dv = -receptor_currents(a, q, dt, c_m);
                 v_new = v + (dv + neurotransmitter_dv);
             } else {
@@ -408,7 +439,7 @@ __device__ __forceinline__ uint32_t update_neuron_at(const UpdateArgs &a, uint32
         } else if (MODEL == 1) {     // leaky integrate-and-fire
             const float dv = ((a.n.leak_constant[q] * (v - a.n.e_l[q])) +
                               (a.n.integration_constant[q] * (i_in / a.n.g_l[q]))) * (dt / a.n.tau_m[q]);
-            if (a.chemical) {
+            if (a_chemical) {
                 const float neurotransmitter_dv = -receptor_currents(a, q, dt, c_m);
                 v_new = v + (dv + neurotransmitter_dv);
             } else {
@@ -428,7 +459,7 @@ __device__ __forceinline__ uint32_t update_neuron_at(const UpdateArgs &a, uint32
         } else if (MODEL == 3) {     // quadratic integrate-and-fire (integrate_and_fire/mod.rs:324-365)
             const float dv = ((a.n.qif_alpha[q] * (v - a.n.v_reset[q]) * (v - a.n.qif_v_c[q])) +
                               a.n.integration_constant[q] * i_in) * (dt / a.n.tau_m[q]);
-            if (a.chemical) {
+            if (a_chemical) {
                 const float neurotransmitter_dv = -receptor_currents(a, q, dt, c_m);
                 v_new = v + (dv + neurotransmitter_dv);
             } else {
@@ -447,7 +478,7 @@ __device__ __forceinline__ uint32_t update_neuron_at(const UpdateArgs &a, uint32
             a.n.refractory_count[q] = rc;
         } else if (MODEL == 4) {     // simple leaky integrate-and-fire (integrate_and_fire/mod.rs:1577-1630)
             const float dv = (a.n.slif_g[q] * (v - a.n.slif_e[q]) + i_in) * dt;
-            if (a.chemical) {
+            if (a_chemical) {
                 const float neurotransmitter_dv = -receptor_currents(a, q, dt, c_m);
                 v_new = v + (dv + neurotransmitter_dv);
             } else {
@@ -469,7 +500,7 @@ __device__ __forceinline__ uint32_t update_neuron_at(const UpdateArgs &a, uint32
             }
             const float dv = (acc + (a.n.integration_constant[q] * (i_in / g_l)) - (w / g_l)) * (dt / c_m);
             const float dw = (a.n.adp_alpha[q] * (v - e_l) - w) * (dt / a.n.tau_m[q]);
-            if (a.chemical) {
+            if (a_chemical) {
                 const float neurotransmitter_dv = -receptor_currents(a, q, dt, c_m);
                 v_new = v + (dv + neurotransmitter_dv);
             } else {
@@ -493,7 +524,7 @@ __device__ __forceinline__ uint32_t update_neuron_at(const UpdateArgs &a, uint32
             const float w = a.n.w_value[q];
             const float dv = (0.04f * (v * v) + 5.0f * v + 140.0f - w * (v - a.n.e_l[q]) + i_in) * (dt / c_m);
             const float dw = (a.n.a[q] * (a.n.b[q] * v - w)) * (dt / a.n.tau_m[q]);
-            if (a.chemical) {
+            if (a_chemical) {
                 const float neurotransmitter_dv = -receptor_currents(a, q, dt, c_m);
                 v_new = v + (dv + neurotransmitter_dv);
             } else {
@@ -516,12 +547,12 @@ __device__ __forceinline__ uint32_t update_neuron_at(const UpdateArgs &a, uint32
             for (int k = 0; k < custom::NVARS; ++k) x[k] = a.n.custom[k][q];
             const float g_gap = a.n.gap_conductance[q];
             float vc = v;
-            if (own_chemical_step && a.chemical) {
+            if (own_chemical_step && a_chemical) {
                 ChemicalStep<Sums> chem{a, q, ql, spiking_prev, dt, sums, t_capture};
                 custom::on_electrochemical_iteration(vc, x, i_in, dt, c_m, g_gap, chem);
             } else {
                 custom::on_iteration(vc, x, i_in, dt, c_m, g_gap);
-                if (a.chemical) {          // the electrical form is on_iteration + spike handling alone (lib.rs:2266-2272)
+                if (a_chemical) {          // the electrical form is on_iteration + spike handling alone (lib.rs:2266-2272)
                     vc -= receptor_currents(a, q, dt, c_m);
                     neuron_nt_update(a, q, vc, spiking_prev, dt, t_capture);
                 }
@@ -536,7 +567,7 @@ __device__ __forceinline__ uint32_t update_neuron_at(const UpdateArgs &a, uint32
             // branch-free, so that their table loads are in flight together -- one round trip for the exponentials, two for the
             // powers, where the full functions made eleven, one after the other.  An argument outside a main path (a gate at
             // exactly 0 -- the first step -- or a voltage on its way to infinity) sets `special`: the full functions then.
-            const float m_state = a.n.m_state[q], h_state = a.n.h_state[q], n_state = a.n.n_state[q];
+            const float m_state = hh_m, h_state = hh_h, n_state = hh_n;
             float e_ma = 0.0f, e_mb = 0.0f, e_ha = 0.0f, e_hb = 0.0f, e_na_ = 0.0f, e_nb = 0.0f;
             bool special = true;
             if constexpr (HOIST) {
@@ -566,13 +597,11 @@ __device__ __forceinline__ uint32_t update_neuron_at(const UpdateArgs &a, uint32
                 m3 = powf_glibc_main(m, 3.0f, special_pow); n4 = powf_glibc_main(ng, 4.0f, special_pow);
             }
             if (special_pow) { m3 = pow3f_glibc(m); n4 = pow4f_glibc(ng); }
-            const float i_na = m3 * h * a.n.g_na[q] * (v - a.n.e_na[q]);
-            const float i_k = n4 * a.n.g_k[q] * (v - a.n.e_k[q]);
+            const float i_na = m3 * h * hh_g_na * (v - hh_e_na);
+            const float i_k = n4 * hh_g_k * (v - hh_e_k);
 
-            const float i_kl = a.n.g_k_leak[q] * (v - a.n.e_k_leak[q]);
+            const float i_kl = hh_g_kl * (v - hh_e_kl);
 
-            const float hh_v_th = a.n.v_th[q];                       // (loaded ahead of the stores below: a store may alias a later load)
-            const uint32_t hh_was_increasing = a.n.was_increasing[q];
             a.n.m_alpha[q] = m_a; a.n.m_beta[q] = m_b; a.n.h_alpha[q] = h_a; a.n.h_beta[q] = h_b;
             a.n.n_alpha[q] = n_a; a.n.n_beta[q] = n_b;
             a.n.m_state[q] = m; a.n.h_state[q] = h; a.n.n_state[q] = ng;
@@ -605,10 +634,10 @@ __device__ __forceinline__ uint32_t update_neuron_at(const UpdateArgs &a, uint32
     return spike;
 }
 
-template <int MODEL, class Sums>
+template <int MODEL, class Sums, bool CHEM_OK = true>
 __device__ __forceinline__ uint32_t update_neuron(const UpdateArgs &a, uint32_t ql, const Sums &sums)
 {
-    return update_neuron_at<MODEL>(a, ql, sums, a.clock, a.vhist_row);
+    return update_neuron_at<MODEL, Sums, true, CHEM_OK>(a, ql, sums, a.clock, a.vhist_row);
 }
 
 // Sums held in registers (the one-launch sparse step)

@@ -734,7 +734,8 @@ int launch_step_resident(snn_network *net)
     hipEvent_t e1 = nullptr;
     TRY(profile_open(net, &e1));
     // a chunk's rows over four wavefronts (k_step_resident_q) where the workgroup stays within 512 threads: at most two chunks
-    const bool quarters = net->resident_quarters && net->n_chunks <= 2;
+    // (a network of at most 64 rows has one quarter's worth of them: nothing to spread, and the turns cost 1 - 8 us)
+    const bool quarters = net->resident_quarters && net->n_chunks <= 2 && net->n_tot > 64;
     const dim3 grid((net->n_loc + 63) / 64), block(64 * net->n_chunks * (quarters ? 4 : 1));
 #define SNN_RESIDENT(M)                                                                                              \
     do {                                                                                                             \
