@@ -142,7 +142,10 @@ def test_peer_form_between_other_steps_and_switched_off(snn, collectives):
     ex = parallel.LocalExchange(handles, torch.device("cuda", 0), halo=True)       # (commits the halo lists: before connecting)
     assert parallel.connect_peers(handles)
     for h in handles:
-        h.set_option("halo_peer_spin_limit", 1 << 20)
+        # (2^24 polls, as the other multi-phase tests: the four ranks are Python threads whose collectives are Python callbacks --
+        # after the collective phase one of them can reach its first peer-form launch a second behind the others; with 2^20
+        # the last phase gave up once in five fresh processes in round 6)
+        h.set_option("halo_peer_spin_limit", 1 << 24)
     tc = collectives(n_shards)
     run_ranks(handles, tc, [60])
     for _ in range(7):                                   # host-driven steps in between
