@@ -243,6 +243,9 @@ __global__ __launch_bounds__(512) void k_step_resident_q(const ResidentArgs a)
     const float vq = (ELEC && col) ? in.xbuf[in.xl.at(in.q0 + ql, PLANE_V)] : 0.0f;
     const float gq = (ELEC && col) ? in.gap_conductance[in.q0 + ql] : 0.0f;
 
+#ifdef SNN_LAB_TIMING
+    const unsigned long long lab_t0 = __builtin_amdgcn_s_memtime();
+#endif
     const uint32_t c0 = chunk * CHUNK;
     const uint32_t chunk_rows = min((uint32_t)CHUNK, in.n_tot - c0);
     const uint32_t p0 = c0 + quarter * R;
@@ -353,7 +356,13 @@ __global__ __launch_bounds__(512) void k_step_resident_q(const ResidentArgs a)
             }
         }
     };
+#ifdef SNN_LAB_TIMING
+    const unsigned long long lab_t1 = __builtin_amdgcn_s_memtime();      // loads issued (not waited for)
+#endif
     if (n_planes) form(plane_id[0]);
+#ifdef SNN_LAB_TIMING
+    const unsigned long long lab_t2 = __builtin_amdgcn_s_memtime();      // first plane's products formed (= the loads have landed)
+#endif
     const uint32_t turns = n_planes ? 4u + n_planes - 1u : 0u;
     for (uint32_t t = 0; t < turns; ++t) {
         const uint32_t pi = t - quarter;                     // (wraps below zero: not this wavefront's turn yet)
@@ -380,6 +389,9 @@ __global__ __launch_bounds__(512) void k_step_resident_q(const ResidentArgs a)
         __syncthreads();
     }
     if (wave != 0) return;
+#ifdef SNN_LAB_TIMING
+    const unsigned long long lab_t3 = __builtin_amdgcn_s_memtime();      // turns over
+#endif
 
     // ---- wavefront 0: second level of the canonical sum + the neuron update of these 64 columns ----
     uint32_t spike = 0;
@@ -388,6 +400,13 @@ __global__ __launch_bounds__(512) void k_step_resident_q(const ResidentArgs a)
         const unsigned long long word = __ballot(spike != 0);
         if (lane == 0) a.up.spike_row[(a.up.q0 + ql) >> 6] = word;
     }
+#ifdef SNN_LAB_TIMING
+    __builtin_amdgcn_s_waitcnt(0);
+    const unsigned long long lab_t4 = __builtin_amdgcn_s_memtime();
+    if (blockIdx.x == 0 && lane == 0 && (a.up.clock % 500) == 250)
+        printf("k_step_resident_q clock %lld planes %u: issue %llu, loads+form %llu, turns %llu, update %llu (memtime ticks, 100 MHz)\n", a.up.clock, n_planes,
+               lab_t1 - lab_t0, lab_t2 - lab_t1, lab_t3 - lab_t2, lab_t4 - lab_t3);
+#endif
 }
 
 // k_run_resident -- MANY steps of a small dense lattice in ONE launch (electrical synapses, neurons only; first for <= 1024
