@@ -305,8 +305,14 @@ __global__ __launch_bounds__(512) void k_step_resident_q(const ResidentArgs a)
     }
     // the 64 products of one plane: formed unconditionally (NaN for an absent edge), an absent edge or a row without the plane
     // contributes +0.0f (the sum starts at +0.0f and never holds -0.0f: x + 0.0f == x bit for bit), as in k_step_resident
-    float pr[R];
-    bool pr_zero = false;                                    // the products just formed are all +0.0f (wave-uniform): the adds are skipped
+    // TWO product buffers (round 6, after the phase clocks of the first form: with one buffer every turn carried somebody's
+    // "add, then form the next plane" -- 2 400 clocks -- behind the barrier; 16x16 + AMPA spent 10 400 clocks in its five turns):
+    // the products of the first two planes are formed by all quarters at once BEFORE the first turn, the turns are adds alone; a
+    // third or fourth plane is formed into the buffer its plane-minus-two has just left.
+    // (the second buffer IS the weights' registers: with at most two planes nothing needs a weight once both sets of products
+    // exist; three or four planes -- NMDA / GABA next to AMPA -- keep the one-buffer schedule)
+    float prA[R];
+    bool zeroA = false, zeroB = false;                       // a buffer's products are all +0.0f (wave-uniform): its adds are skipped
     bool all_k[CHEM ? K_TYPES : 1], any_k[CHEM ? K_TYPES : 1];
 #pragma unroll
     for (int k = 0; k < (CHEM ? K_TYPES : 1); ++k) {
@@ -314,7 +320,7 @@ __global__ __launch_bounds__(512) void k_step_resident_q(const ResidentArgs a)
         all_k[k] = has == live && rb != 0u;
         any_k[k] = has != 0ull;
     }
-    auto form = [&](uint32_t id) {
+    auto form = [&](uint32_t id, auto &pr, bool &pr_zero) {
         pr_zero = false;
         if (id == 0u) {
             if (rb == 0u) { pr_zero = true; return; }        // a quarter past the end of the chunk
@@ -357,25 +363,37 @@ __global__ __launch_bounds__(512) void k_step_resident_q(const ResidentArgs a)
         }
     };
 #ifdef SNN_LAB_TIMING
-    const unsigned long long lab_t1 = __builtin_amdgcn_s_memtime();      // loads issued (not waited for)
+    const unsigned long long lab_t1 = __builtin_amdgcn_s_memtime();      // loads issued; the transmitter flags waited for (ballots)
 #endif
-    if (n_planes) form(plane_id[0]);
+    const bool two_buffers = n_planes <= 2u;
+    if (n_planes) form(plane_id[0], prA, zeroA);
+    if constexpr (CHEM) {
+        if (two_buffers && n_planes > 1u) form(plane_id[1], w, zeroB);          // in place: w[u] becomes the product of row u
+    }
 #ifdef SNN_LAB_TIMING
-    const unsigned long long lab_t2 = __builtin_amdgcn_s_memtime();      // first plane's products formed (= the loads have landed)
+    const unsigned long long lab_t2 = __builtin_amdgcn_s_memtime();      // the first two planes' products formed (= the weights have landed)
 #endif
     const uint32_t turns = n_planes ? 4u + n_planes - 1u : 0u;
+    auto take_turn = [&](uint32_t pi, auto &pr, bool &pr_zero) {
+        const uint32_t id = plane_id[pi];
+        float *slot = id == 0u ? &s_pi[chunk][lane] : &s_pt[CHEM ? id - 1u : 0u][chunk][lane];
+        float sum = quarter ? *slot : 0.0f;
+        if (!pr_zero) {
+#pragma unroll
+            for (uint32_t u = 0; u < R; ++u) sum += pr[u];
+        }
+        if (!pr_zero || quarter == 0u) *slot = sum;
+    };
     for (uint32_t t = 0; t < turns; ++t) {
         const uint32_t pi = t - quarter;                     // (wraps below zero: not this wavefront's turn yet)
         if (pi < n_planes) {
-            const uint32_t id = plane_id[pi];
-            float *slot = id == 0u ? &s_pi[chunk][lane] : &s_pt[CHEM ? id - 1u : 0u][chunk][lane];
-            float sum = quarter ? *slot : 0.0f;
-            if (!pr_zero) {
-#pragma unroll
-                for (uint32_t u = 0; u < R; ++u) sum += pr[u];
+            if (two_buffers) {
+                if (pi == 0u) take_turn(pi, prA, zeroA);
+                else if constexpr (CHEM) take_turn(pi, w, zeroB);
+            } else {
+                take_turn(pi, prA, zeroA);                    // one buffer: add, then form the next plane's products
+                if (pi + 1u < n_planes) form(plane_id[pi + 1u], prA, zeroA);
             }
-            if (!pr_zero || quarter == 0u) *slot = sum;
-            if (pi + 1u < n_planes) form(plane_id[pi + 1u]);
         }
         __syncthreads();
     }
@@ -404,7 +422,7 @@ __global__ __launch_bounds__(512) void k_step_resident_q(const ResidentArgs a)
     __builtin_amdgcn_s_waitcnt(0);
     const unsigned long long lab_t4 = __builtin_amdgcn_s_memtime();
     if (blockIdx.x == 0 && lane == 0 && (a.up.clock % 500) == 250)
-        printf("k_step_resident_q clock %lld planes %u: issue %llu, loads+form %llu, turns %llu, update %llu (memtime ticks, 100 MHz)\n", a.up.clock, n_planes,
+        printf("k_step_resident_q clock %lld planes %u: issue %llu, loads+form %llu, turns %llu, update %llu (shader clocks)\n", a.up.clock, n_planes,
                lab_t1 - lab_t0, lab_t2 - lab_t1, lab_t3 - lab_t2, lab_t4 - lab_t3);
 #endif
 }
