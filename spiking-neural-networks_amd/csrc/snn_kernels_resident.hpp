@@ -384,18 +384,26 @@ __global__ __launch_bounds__(512) void k_step_resident_q(const ResidentArgs a)
         }
         if (!pr_zero || quarter == 0u) *slot = sum;
     };
-    for (uint32_t t = 0; t < turns; ++t) {
-        const uint32_t pi = t - quarter;                     // (wraps below zero: not this wavefront's turn yet)
-        if (pi < n_planes) {
-            if (two_buffers) {
-                if (pi == 0u) take_turn(pi, prA, zeroA);
-                else if constexpr (CHEM) take_turn(pi, w, zeroB);
-            } else {
+    if (two_buffers) {
+        // (a loop of its own: no register array changes inside it -- with the one-buffer schedule in the same loop the compiler
+        // carried both arrays around the back edge, 128 moves per turn)
+        for (uint32_t t = 0; t < turns; ++t) {
+            const uint32_t pi = t - quarter;                 // (wraps below zero: not this wavefront's turn yet)
+            if (pi == 0u) take_turn(0u, prA, zeroA);
+            if constexpr (CHEM) {
+                if (pi == 1u && n_planes > 1u) take_turn(1u, w, zeroB);
+            }
+            __syncthreads();
+        }
+    } else {
+        for (uint32_t t = 0; t < turns; ++t) {
+            const uint32_t pi = t - quarter;
+            if (pi < n_planes) {
                 take_turn(pi, prA, zeroA);                    // one buffer: add, then form the next plane's products
                 if (pi + 1u < n_planes) form(plane_id[pi + 1u], prA, zeroA);
             }
+            __syncthreads();
         }
-        __syncthreads();
     }
     if (CHEM) {
         // the planes of types nobody releases hold zeros (k_step_resident leaves its accumulators at 0.0f for them)
