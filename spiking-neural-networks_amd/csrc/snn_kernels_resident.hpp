@@ -251,35 +251,30 @@ __global__ __launch_bounds__(512) void k_step_resident_q(const ResidentArgs a)
     const uint32_t p0 = c0 + quarter * R;
     const uint32_t rb = chunk_rows > quarter * R ? min(R, chunk_rows - quarter * R) : 0u;      // rows of this wavefront (wave-uniform)
 
-    // the presynaptic state of row p0 + lane (one row per lane, broadcast with v_readlane) and this lane's 64 weights
-    float val = 0.0f, tval[CHEM ? K_TYPES : 1];
-    uint32_t kind = KIND_NEURON;
+    // Every load of the prologue is requested before any of them is looked at: ONE round trip to memory (a launch starts with
+    // cold caches).  The row state used to be loaded and tested inside branches -- neuron or spike-train row, which transmitter
+    // types -- whose waits the compiler keeps inside them, so the weights, requested after the branches, were a second round trip:
+    // 5 400 + 3 900 shader clocks before the first turn at 16x16 + AMPA.  Here the branches choose ADDRESSES (a lane without a
+    // row reads row 0; a neuron row reads word 0 of the exchange buffer where a spike-train row reads its last firing time).
+    const bool has_row = lane < rb;
+    const uint32_t p = has_row ? p0 + lane : 0u;
+    const bool is_neuron = p < in.n_neurons;
+    const uint32_t s = is_neuron ? 0u : p - in.n_neurons;
+    const float raw_val = *(is_neuron ? in.xbuf + in.xl.at(p, PLANE_V) : in.st_value + s);
+    const int32_t raw_lft = *(is_neuron ? reinterpret_cast<const int32_t *>(in.xbuf) : in.st_last_firing_time + s);
+    uint32_t raw_flag[CHEM ? K_TYPES : 1];
+    float raw_t[CHEM ? K_TYPES : 1];
+    if (CHEM) {
 #pragma unroll
-    for (int k = 0; k < (CHEM ? K_TYPES : 1); ++k) tval[k] = 0.0f;
-    if (lane < rb) {
-        const uint32_t p = p0 + lane;
-        if (p < in.n_neurons) {
-            val = in.xbuf[in.xl.at(p, PLANE_V)];
-            if (CHEM) {
-#pragma unroll
-                for (int k = 0; k < K_TYPES; ++k) {
-                    kind |= in.nt_flags[(size_t)k * in.n_pad + p] ? (0x100u << k) : 0u;
-                    tval[k] = in.xbuf[in.xl.at(p, PLANE_T0 + k)];
-                }
-            }
-        } else {
-            const uint32_t s = p - in.n_neurons;
-            val = in.st_value[s];
-            kind = (in.st_last_firing_time[s] < 0) ? KIND_ST_SILENT : KIND_ST_FIRED;
-            if (CHEM) {
-#pragma unroll
-                for (int k = 0; k < K_TYPES; ++k) {
-                    kind |= in.st_nt_flags[(size_t)k * in.c_pad + s] ? (0x100u << k) : 0u;
-                    tval[k] = in.st_nt_t[(size_t)k * in.c_pad + s];
-                }
-            }
+        for (int k = 0; k < K_TYPES; ++k) {
+            raw_flag[k] = *(is_neuron ? in.nt_flags + (size_t)k * in.n_pad + p : in.st_nt_flags + (size_t)k * in.c_pad + s);
+            raw_t[k] = *(is_neuron ? in.xbuf + in.xl.at(p, PLANE_T0 + k) : in.st_nt_t + (size_t)k * in.c_pad + s);
         }
     }
+    // what the neuron update at the end of this launch will read (update_touch_load; a column past the end reads column 0's)
+    UpdateTouch touch;
+    update_touch_load<MODEL, CHEM>(a.up, col ? ql : 0u, touch);
+    // this lane's 64 weights
     float w[R];
     {
         // quad-row order: one dwordx4 = 4 consecutive rows of this lane's column; row groups past the end of the matrix = absent edges
@@ -291,6 +286,15 @@ __global__ __launch_bounds__(512) void k_step_resident_q(const ResidentArgs a)
             w[4 * g] = x.x; w[4 * g + 1] = x.y; w[4 * g + 2] = x.z; w[4 * g + 3] = x.w;
         }
     }
+    // the presynaptic state of row p0 + lane (one row per lane, broadcast with v_readlane)
+    float val = has_row ? raw_val : 0.0f, tval[CHEM ? K_TYPES : 1];
+    uint32_t kind = (!has_row || is_neuron) ? KIND_NEURON : ((raw_lft < 0) ? KIND_ST_SILENT : KIND_ST_FIRED);
+#pragma unroll
+    for (int k = 0; k < (CHEM ? K_TYPES : 1); ++k) {
+        tval[k] = (CHEM && has_row) ? raw_t[k] : 0.0f;
+        if (CHEM) kind |= (has_row && raw_flag[k]) ? (0x100u << k) : 0u;
+    }
+    const uint32_t touched = update_touch_fold<MODEL>(a.up, touch);
     const unsigned long long live = (rb == 64) ? ~0ull : ((1ull << rb) - 1ull);
     const bool all_neurons = (__ballot((kind & 3u) == KIND_NEURON) & live) == live;
     auto bcast = [&](float x, uint32_t r) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), r)); };
@@ -365,6 +369,7 @@ __global__ __launch_bounds__(512) void k_step_resident_q(const ResidentArgs a)
 #ifdef SNN_LAB_TIMING
     const unsigned long long lab_t1 = __builtin_amdgcn_s_memtime();      // loads issued; the transmitter flags waited for (ballots)
 #endif
+    asm volatile("" :: "v"(touched));                        // (landed: the weights were requested before it)
     const bool two_buffers = n_planes <= 2u;
     if (n_planes) form(plane_id[0], prA, zeroA);
     if constexpr (CHEM) {

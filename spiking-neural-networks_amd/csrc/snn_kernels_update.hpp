@@ -634,6 +634,76 @@ __device__ __forceinline__ uint32_t update_neuron_at(const UpdateArgs &a, uint32
     return spike;
 }
 
+// The loads update_neuron_at<MODEL, ., ., CHEM_OK> starts with, issued EARLY by a kernel that has work between its own start and
+// the update (k_step_resident_q: the weights, the products, the turns): every value folded into one word the caller throws away
+// once the loads have landed.  A launch starts with cold caches, so the update's first round trip goes to memory (about 2 500
+// shader clocks measured in that kernel); requested two phases earlier its cache lines are in the CU's L1 when the update asks.
+// Nothing read here is written by this launch before the update reads it.
+struct UpdateTouch {
+    RcLoaded l;
+    uint32_t ntw[K_TYPES][6];
+    uint32_t word[3], hh[11];
+    bool rc = false, nt = false;
+};
+// ... the loads (no value is looked at here: nothing waits) ...
+template <int MODEL, bool CHEM_OK>
+__device__ __forceinline__ void update_touch_load(const UpdateArgs &a, uint32_t ql, UpdateTouch &t)
+{
+    const uint32_t q = a.rows.global_of(ql);
+    t.word[0] = reinterpret_cast<const uint32_t *>(a.n.xbuf)[a.n.xl.at(q, PLANE_SPIKE)];
+    t.word[1] = t.word[2] = 0u;
+    if (MODEL == CUSTOM_MODEL) return;
+    const bool fused_rc = !(SNN_HAVE_CUSTOM_RECEPTORS && a.model_is_custom) && !(SNN_HAVE_CUSTOM_RC && a.rc_kind == CUSTOM_KINETICS);
+    const bool fused_nt = !(SNN_HAVE_CUSTOM_NT && a.nt_kind == CUSTOM_KINETICS);
+    t.rc = CHEM_OK && a.chemical && fused_rc;
+    t.nt = fused_nt;
+    if (t.rc) chem_receptors_load(a, q, ql, t.l);
+#pragma unroll
+    for (int k = 0; k < K_TYPES; ++k) {
+        // chem_nt_load's loads (it tests the flag where it loads it: a wait)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) t.ntw[k][j] = 0u;
+        if (!t.nt || !a.has_nt || !(a.live_mask >> k & 1u)) continue;
+        const size_t i = (size_t)k * a.n.n_pad + q;
+        t.ntw[k][0] = a.n.nt_flags[i];
+        t.ntw[k][1] = __float_as_uint(a.n.xbuf[a.n.xl.at(q, PLANE_T0 + k)]);
+        t.ntw[k][2] = __float_as_uint(a.n.nt_t_max[i]); t.ntw[k][3] = __float_as_uint(a.n.nt_clearance[i]);
+        t.ntw[k][4] = __float_as_uint(a.n.nt_v_p[i]); t.ntw[k][5] = __float_as_uint(a.n.nt_k_p[i]);
+    }
+    if (a.electrical) t.word[1] = a.n_in[ql];
+    if (MODEL == 0) t.word[2] = __float_as_uint(a.n.w_value[q]);
+    if (MODEL == 2) {
+        const float *hh[10] = {a.n.m_state, a.n.h_state, a.n.n_state, a.n.g_na, a.n.e_na, a.n.g_k, a.n.e_k, a.n.g_k_leak, a.n.e_k_leak, a.n.v_th};
+#pragma unroll
+        for (int i = 0; i < 10; ++i) t.hh[i] = __float_as_uint(hh[i][q]);
+        t.hh[10] = a.n.was_increasing[q];
+    }
+}
+// ... and the fold, wherever the caller has to wait for older loads anyway
+template <int MODEL>
+__device__ __forceinline__ uint32_t update_touch_fold(const UpdateArgs &a, const UpdateTouch &t)
+{
+    uint32_t h = t.word[0] ^ t.word[1] ^ t.word[2];
+    if (MODEL == CUSTOM_MODEL) return h;
+    if (t.rc) {
+        h ^= __float_as_uint(t.l.mg);
+#pragma unroll
+        for (int k = 0; k < K_TYPES; ++k)
+            h ^= t.l.fl[k] ^ t.l.cnt[k] ^ __float_as_uint(t.l.r[k]) ^ __float_as_uint(t.l.al[k]) ^ __float_as_uint(t.l.be[k]) ^
+                 __float_as_uint(t.l.g[k]) ^ __float_as_uint(t.l.e[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < K_TYPES; ++k) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) h ^= t.ntw[k][j];
+    }
+    if (MODEL == 2) {
+#pragma unroll
+        for (int i = 0; i < 11; ++i) h ^= t.hh[i];
+    }
+    return h;
+}
+
 template <int MODEL, class Sums, bool CHEM_OK = true>
 __device__ __forceinline__ uint32_t update_neuron(const UpdateArgs &a, uint32_t ql, const Sums &sums)
 {
