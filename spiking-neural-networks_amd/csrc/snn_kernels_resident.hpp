@@ -271,9 +271,11 @@ __global__ __launch_bounds__(512) void k_step_resident_q(const ResidentArgs a)
             raw_t[k] = *(is_neuron ? in.xbuf + in.xl.at(p, PLANE_T0 + k) : in.st_nt_t + (size_t)k * in.c_pad + s);
         }
     }
-    // what the neuron update at the end of this launch will read (update_touch_load; a column past the end reads column 0's)
-    UpdateTouch touch;
-    update_touch_load<MODEL, CHEM>(a.up, col ? ql : 0u, touch);
+    // what the neuron update at the end of this launch will read (update_touch_load; a column past the end reads column 0's):
+    // requested by the wavefront that will update, alone -- by all eight the 30 extra loads each kept the CU's address unit busy
+    // for longer than the update saved (session 8c: 8 800 clocks to the first ballot instead of 5 400)
+    UpdateTouch touch{};
+    if (wave == 0) update_touch_load<MODEL, CHEM>(a.up, col ? ql : 0u, touch);
     // this lane's 64 weights
     float w[R];
     {
@@ -294,7 +296,7 @@ __global__ __launch_bounds__(512) void k_step_resident_q(const ResidentArgs a)
         tval[k] = (CHEM && has_row) ? raw_t[k] : 0.0f;
         if (CHEM) kind |= (has_row && raw_flag[k]) ? (0x100u << k) : 0u;
     }
-    const uint32_t touched = update_touch_fold<MODEL>(a.up, touch);
+    const uint32_t touched = wave == 0 ? update_touch_fold<MODEL>(a.up, touch) : 0u;
     const unsigned long long live = (rb == 64) ? ~0ull : ((1ull << rb) - 1ull);
     const bool all_neurons = (__ballot((kind & 3u) == KIND_NEURON) & live) == live;
     auto bcast = [&](float x, uint32_t r) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), r)); };

@@ -116,6 +116,7 @@ int snn_network_destroy(snn_network_t *net) ABI_TRY
         if (p) (void)hipFree(p);
     (void)p2p_release(net, /*final=*/true);
     if (net->p2p_failed) (void)hipHostFree(net->p2p_failed);
+    if (net->agree_words_dev) (void)hipFree(net->agree_words_dev);
     if (net->comm_stream) { (void)hipStreamSynchronize(net->comm_stream); (void)hipStreamDestroy(net->comm_stream); }
     if (net->ev_packed) (void)hipEventDestroy(net->ev_packed);
     if (net->ev_exchanged) (void)hipEventDestroy(net->ev_exchanged);
@@ -2068,8 +2069,16 @@ ABI_CATCH
 static int agree_on_exchange(Rccl *R, snn_network *net, ncclComm_t comm, void *nccl_comm)
 {
     const uint32_t G = net->n_shards, me = net->shard_index;
-    uint32_t *d_words = nullptr;
-    HIP_TRY(snn_malloc(&d_words, std::max<size_t>((size_t)G * 4, 256)), SNN_ERR_BUFFER_CREATE);
+    // (the handle's for good: hipFree waits for EVERY stream of the device -- with the ranks emulated as threads of one process a
+    // rank that freed these words here waited for a neighbour's first peer-form launch, which was polling for this rank's: a
+    // give-up after the spin limit, 3 of 16 runs of the emulated-rank tests in round 6.  And a run path has no business
+    // synchronising the device.)
+    if (net->agree_words_dev && net->agree_words_cap < G) { (void)hipFree(net->agree_words_dev); net->agree_words_dev = nullptr; }
+    if (!net->agree_words_dev) {
+        HIP_TRY(snn_malloc(&net->agree_words_dev, std::max<size_t>((size_t)G * 4, 256)), SNN_ERR_BUFFER_CREATE);
+        net->agree_words_cap = G;
+    }
+    uint32_t *const d_words = net->agree_words_dev;
     hvec<uint32_t> words(G, 0);
     auto gather = [&](uint32_t mine) -> int {
         words.assign(G, 0);
@@ -2121,7 +2130,6 @@ static int agree_on_exchange(Rccl *R, snn_network *net, ncclComm_t comm, void *n
         }
         if (!rc) net->refresh_agreed = any_stale;
     }
-    (void)hipFree(d_words);
     if (!rc) net->x_agreed = true;
     return rc;
 }

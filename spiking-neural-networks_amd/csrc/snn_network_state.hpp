@@ -286,6 +286,8 @@ struct snn_network {
     uint32_t *p2p_flags = nullptr;                            // [n_shards] done counters, written by the peers (fine-grained)
     uint32_t *p2p_done_blocks = nullptr;
     uint32_t *p2p_failed = nullptr;                           // host-mapped word: a poll gave up
+    uint32_t *agree_words_dev = nullptr;                      // agree_on_exchange's one word per rank (kept: no hipFree in a run path)
+    uint32_t agree_words_cap = 0;
     uint64_t p2p_recv_words = 0;
     struct P2pPeer { uint64_t recv[2] = {0, 0}, flags = 0, recv_offset = 0; bool set = false; };
     hvec<P2pPeer> p2p_peers;                           // per shard: where this handle's values go on that peer

@@ -193,7 +193,11 @@ class ThreadCollectives:
     shard handles that live in ONE process, one host thread per rank -- the single-GPU emulation of a multi-GPU run, where RCCL
     refuses two ranks on one device.  Installed process-wide through snn_set_collectives; rank r passes `comm(r)` where a
     ncclComm_t goes.  Every operation is blocking: a rank waits for the device, meets the others at a barrier, copies what its
-    peers send device to device and meets them again (nobody overwrites a buffer a peer still reads)."""
+    peers send device to device and meets them again (nobody overwrites a buffer a peer still reads).
+    "Waits for the device" = for the STREAM the library posts the operation on and for the stream the copies run on, never
+    torch.cuda.synchronize(): that waits for every stream of the device, the other ranks' too -- and a rank that has left the
+    operation may already have launched a peer-form step that polls for THIS rank's next launch (round 6: the give-ups of the
+    emulated-rank tests after a spin limit of seconds, 3 of 16 runs)."""
 
     def __init__(self, world_size, device, lib=None):
         import threading
@@ -264,10 +268,20 @@ class ThreadCollectives:
         d = device_words(dst, words, self._device)
         d.copy_(device_words(src, words, self._device))
 
-    def _all_gather(self, send, recv, count, _dtype, comm, _stream):
+    def _wait_stream(self, stream):
+        """the work the library has enqueued on `stream` (a hipStream_t) in front of the operation"""
+        if stream:
+            self._torch.cuda.ExternalStream(int(stream), device=self._device).synchronize()
+        else:
+            self._torch.cuda.default_stream(self._device).synchronize()
+
+    def _wait_copies(self):
+        self._torch.cuda.current_stream(self._device).synchronize()
+
+    def _all_gather(self, send, recv, count, _dtype, comm, stream):
         def run():
             r = self._rank_of(comm)
-            self._torch.cuda.synchronize()
+            self._wait_stream(stream)
             self._posted[r] = (int(send), int(count))
             self._barrier.wait()
             for p in range(self.world):
@@ -275,7 +289,7 @@ class ThreadCollectives:
                 assert n == count
                 if n and int(recv) + 4 * p * n != src:                      # (in place: the own slot already is where it goes)
                     self._copy(int(recv) + 4 * p * n, src, n)
-            self._torch.cuda.synchronize()
+            self._wait_copies()
             self._barrier.wait()
             if r == 0:
                 self.calls["all_gather"] += 1
@@ -285,12 +299,12 @@ class ThreadCollectives:
         self._local.ops = []
         return 0
 
-    def _send(self, buf, count, _dtype, peer, comm, _stream):
-        self._local.ops.append(("send", int(buf), int(count), int(peer), self._rank_of(comm)))
+    def _send(self, buf, count, _dtype, peer, comm, stream):
+        self._local.ops.append(("send", int(buf), int(count), int(peer), self._rank_of(comm), int(stream or 0)))
         return 0
 
-    def _recv(self, buf, count, _dtype, peer, comm, _stream):
-        self._local.ops.append(("recv", int(buf), int(count), int(peer), self._rank_of(comm)))
+    def _recv(self, buf, count, _dtype, peer, comm, stream):
+        self._local.ops.append(("recv", int(buf), int(count), int(peer), self._rank_of(comm), int(stream or 0)))
         return 0
 
     def _group_end(self):
@@ -303,20 +317,21 @@ class ThreadCollectives:
             if not ops:
                 return
             r = ops[0][4]
-            self._torch.cuda.synchronize()
+            for stream in sorted({op[5] for op in ops}):
+                self._wait_stream(stream)
             taken = []
-            for kind, buf, n, peer, _ in ops:
+            for kind, buf, n, peer, _, _ in ops:
                 if kind == "send":
                     done = threading.Event()
                     self._mail[(r, peer)].put((buf, n, done))
                     taken.append(done)
-            for kind, buf, n, peer, _ in ops:
+            for kind, buf, n, peer, _, _ in ops:
                 if kind == "recv":
                     src, m, done = self._mail[(peer, r)].get(timeout=self.timeout)
                     assert m == n, "send and receive sizes disagree"
                     if n:
                         self._copy(buf, src, n)
-                    self._torch.cuda.synchronize()
+                    self._wait_copies()
                     done.set()
             for done in taken:
                 if not done.wait(self.timeout):
