@@ -3,7 +3,7 @@
 # wavefront 0: parity, phase clocks, kernel times; (b) the emulated-rank peer-form tests, repeated, after the two device-wide
 # synchronisations were taken out of their path (hipFree in agree_on_exchange, torch.cuda.synchronize in ThreadCollectives)
 set -u
-OUT=$PWD/gpurun_out/r06_s9
+OUT=$PWD/gpurun_out/${SESSION_DIR:-r06_s9}
 mkdir -p $OUT
 export TMPDIR=/tmp
 timeout 900 python3 -m pytest tests/test_gpu_fused_step.py tests/test_gpu_network.py tests/test_gpu_models.py tests/test_gpu_randomized.py tests/test_gpu_sequences.py tests/test_gpu_persistent_run.py tests/test_gpu_library_loop_threads.py tests/test_gpu_emulated_ranks.py -m gpu -q > $OUT/tests.log 2>&1
