@@ -53,6 +53,7 @@ template <int MODEL, bool ELEC, bool CHEM>
 __global__ __launch_bounds__(64 * RESIDENT_MAX_CHUNKS) void k_step_resident(const ResidentArgs a)
 {
     constexpr uint32_t B = 32;                       // rows per register batch
+    warm_kernel_arguments<sizeof(ResidentArgs)>();
     __shared__ float s_pi[RESIDENT_MAX_CHUNKS][64];
     __shared__ float s_pt[CHEM ? K_TYPES : 1][RESIDENT_MAX_CHUNKS][64];
 
@@ -231,6 +232,7 @@ template <int MODEL, bool ELEC, bool CHEM>
 __global__ __launch_bounds__(512) void k_step_resident_q(const ResidentArgs a)
 {
     constexpr uint32_t R = 64;                        // rows per wavefront
+    warm_kernel_arguments<sizeof(ResidentArgs)>();
     __shared__ float s_pi[RESIDENT_MAX_CHUNKS][64];
     __shared__ float s_pt[CHEM ? K_TYPES : 1][RESIDENT_MAX_CHUNKS][64];
 
@@ -254,20 +256,8 @@ __global__ __launch_bounds__(512) void k_step_resident_q(const ResidentArgs a)
     // Every load of the prologue is requested before any of them is looked at: ONE round trip to memory (a launch starts with
     // cold caches).  The row state used to be loaded and tested inside branches -- neuron or spike-train row, which transmitter
     // types -- whose waits the compiler keeps inside them, so the weights, requested after the branches, were a second round trip:
-    // 5 400 + 3 900 shader clocks before the first turn at 16x16 + AMPA.  Here the weights go first and the branches choose ADDRESSES (a lane without a
+    // 5 400 + 3 900 shader clocks before the first turn at 16x16 + AMPA.  Here the branches choose ADDRESSES (a lane without a
     // row reads row 0; a neuron row reads word 0 of the exchange buffer where a spike-train row reads its last firing time).
-    // this lane's 64 weights: the first requests of the launch (everything below waits for them anyway: loads return in order)
-    float w[R];
-    {
-        // quad-row order: one dwordx4 = 4 consecutive rows of this lane's column; row groups past the end of the matrix = absent edges
-        const v4f *units = reinterpret_cast<const v4f *>(in.W) + (size_t)(p0 >> 2) * in.ld + ql;
-        const v4f none = {quiet_nan(), quiet_nan(), quiet_nan(), quiet_nan()};
-#pragma unroll
-        for (uint32_t g = 0; g < R / 4; ++g) {
-            const v4f x = (4 * g < rb) ? units[(size_t)g * in.ld] : none;
-            w[4 * g] = x.x; w[4 * g + 1] = x.y; w[4 * g + 2] = x.z; w[4 * g + 3] = x.w;
-        }
-    }
     const bool has_row = lane < rb;
     const uint32_t p = has_row ? p0 + lane : 0u;
     const bool is_neuron = p < in.n_neurons;
@@ -288,6 +278,18 @@ __global__ __launch_bounds__(512) void k_step_resident_q(const ResidentArgs a)
     // for longer than the update saved (session 8c: 8 800 clocks to the first ballot instead of 5 400)
     UpdateTouch touch{};
     if (wave == 0) update_touch_load<MODEL, CHEM>(a.up, col ? ql : 0u, touch);
+    // this lane's 64 weights
+    float w[R];
+    {
+        // quad-row order: one dwordx4 = 4 consecutive rows of this lane's column; row groups past the end of the matrix = absent edges
+        const v4f *units = reinterpret_cast<const v4f *>(in.W) + (size_t)(p0 >> 2) * in.ld + ql;
+        const v4f none = {quiet_nan(), quiet_nan(), quiet_nan(), quiet_nan()};
+#pragma unroll
+        for (uint32_t g = 0; g < R / 4; ++g) {
+            const v4f x = (4 * g < rb) ? units[(size_t)g * in.ld] : none;
+            w[4 * g] = x.x; w[4 * g + 1] = x.y; w[4 * g + 2] = x.z; w[4 * g + 3] = x.w;
+        }
+    }
     // the presynaptic state of row p0 + lane (one row per lane, broadcast with v_readlane)
     float val = has_row ? raw_val : 0.0f, tval[CHEM ? K_TYPES : 1];
     uint32_t kind = (!has_row || is_neuron) ? KIND_NEURON : ((raw_lft < 0) ? KIND_ST_SILENT : KIND_ST_FIRED);
@@ -296,6 +298,7 @@ __global__ __launch_bounds__(512) void k_step_resident_q(const ResidentArgs a)
         tval[k] = (CHEM && has_row) ? raw_t[k] : 0.0f;
         if (CHEM) kind |= (has_row && raw_flag[k]) ? (0x100u << k) : 0u;
     }
+    const uint32_t touched = wave == 0 ? update_touch_fold<MODEL>(a.up, touch) : 0u;
     const unsigned long long live = (rb == 64) ? ~0ull : ((1ull << rb) - 1ull);
     const bool all_neurons = (__ballot((kind & 3u) == KIND_NEURON) & live) == live;
     auto bcast = [&](float x, uint32_t r) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), r)); };
@@ -370,21 +373,11 @@ __global__ __launch_bounds__(512) void k_step_resident_q(const ResidentArgs a)
 #ifdef SNN_LAB_TIMING
     const unsigned long long lab_t1 = __builtin_amdgcn_s_memtime();      // loads issued; the transmitter flags waited for (ballots)
 #endif
-    // (Hodgkin-Huxley's touched words are twice Izhikevich's: held across the products they spill -- looked at before them)
-    constexpr bool TOUCH_FOLD_LATE = MODEL != 2;
-    if constexpr (!TOUCH_FOLD_LATE) {
-        const uint32_t touched = wave == 0 ? update_touch_fold<MODEL>(a.up, touch) : 0u;
-        asm volatile("" :: "v"(touched));
-    }
+    asm volatile("" :: "v"(touched));                        // (landed: the weights were requested before it)
     const bool two_buffers = n_planes <= 2u;
     if (n_planes) form(plane_id[0], prA, zeroA);
     if constexpr (CHEM) {
         if (two_buffers && n_planes > 1u) form(plane_id[1], w, zeroB);          // in place: w[u] becomes the product of row u
-    }
-    if constexpr (TOUCH_FOLD_LATE) {
-        // (the touched lines: requested last, looked at here -- behind the products, which only needed the weights)
-        const uint32_t touched = wave == 0 ? update_touch_fold<MODEL>(a.up, touch) : 0u;
-        asm volatile("" :: "v"(touched));
     }
 #ifdef SNN_LAB_TIMING
     const unsigned long long lab_t2 = __builtin_amdgcn_s_memtime();      // the first two planes' products formed (= the weights have landed)

@@ -799,6 +799,7 @@ __device__ __forceinline__ void update_epilogue(const UpdateArgs &a, uint32_t ql
 template <int MODEL, bool ALL_PLANES = false>
 __global__ __launch_bounds__(256) void k_update(const UpdateArgs a)
 {
+    warm_kernel_arguments<sizeof(UpdateArgs)>();                         // (snn_layout.hpp: the arguments' lines in one round trip)
     const uint32_t ql = blockIdx.x * blockDim.x + threadIdx.x;           // blockDim.x = 64 or 256
     const bool active = ql < a.n_loc && a.rows.active(ql, a.n_loc);
     float v_new = 0.0f;

@@ -111,6 +111,41 @@ __device__ __forceinline__ uint32_t uload_vector(const UniformTable *u, int slot
     return u->flag[slot] ? u->bits[slot] : arr[i];
 }
 
+// A launch's arguments live in memory (the kernarg segment) and reach a wavefront by scalar loads, one 64-byte line at a time,
+// WHERE the compiler needs a field: a kernel with 1.6 KB of pointers and far more of them than scalar registers (the one-launch
+// steps: 200 spilled SGPRs) walks its lines in a chain of load-wait rounds, each a miss of the scalar cache at the start of a
+// launch -- 6 to 25 rounds before the first vector load of k_step_resident_q (round 6, session 10: 6 500 shader clocks to the
+// first ballot with transmitters, 2 500 without, whatever the order of the vector loads).  warm_kernel_arguments<BYTES>() asks
+// for one word of every line at once and waits once: the rounds that follow hit.
+template <uint32_t BYTES>
+__device__ __forceinline__ void warm_kernel_arguments()
+{
+    const auto args = __builtin_amdgcn_kernarg_segment_ptr();
+    // lines in fours (what lies behind the arguments for up to three lines more are the launch's implicit arguments, 256 bytes);
+    // ONE statement per size, loads and wait together: the four scratch registers are written when a load returns, not where it
+    // is issued -- nothing of the compiler's may sit between
+    constexpr uint32_t LINES = ((BYTES + 63u) / 64u + 3u) & ~3u;
+    static_assert(LINES >= 4u && LINES <= 32u, "extend the list below");
+    uint32_t t0, t1, t2, t3;
+    if constexpr (LINES == 4u)
+        asm volatile("s_load_dword %0, %4, 0x0\n\ts_load_dword %1, %4, 0x40\n\ts_load_dword %2, %4, 0x80\n\ts_load_dword %3, %4, 0xc0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3) : "s"(args) : "memory");
+    else if constexpr (LINES == 8u)
+        asm volatile("s_load_dword %0, %4, 0x0\n\ts_load_dword %1, %4, 0x40\n\ts_load_dword %2, %4, 0x80\n\ts_load_dword %3, %4, 0xc0\n\ts_load_dword %0, %4, 0x100\n\ts_load_dword %1, %4, 0x140\n\ts_load_dword %2, %4, 0x180\n\ts_load_dword %3, %4, 0x1c0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3) : "s"(args) : "memory");
+    else if constexpr (LINES == 12u)
+        asm volatile("s_load_dword %0, %4, 0x0\n\ts_load_dword %1, %4, 0x40\n\ts_load_dword %2, %4, 0x80\n\ts_load_dword %3, %4, 0xc0\n\ts_load_dword %0, %4, 0x100\n\ts_load_dword %1, %4, 0x140\n\ts_load_dword %2, %4, 0x180\n\ts_load_dword %3, %4, 0x1c0\n\ts_load_dword %0, %4, 0x200\n\ts_load_dword %1, %4, 0x240\n\ts_load_dword %2, %4, 0x280\n\ts_load_dword %3, %4, 0x2c0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3) : "s"(args) : "memory");
+    else if constexpr (LINES == 16u)
+        asm volatile("s_load_dword %0, %4, 0x0\n\ts_load_dword %1, %4, 0x40\n\ts_load_dword %2, %4, 0x80\n\ts_load_dword %3, %4, 0xc0\n\ts_load_dword %0, %4, 0x100\n\ts_load_dword %1, %4, 0x140\n\ts_load_dword %2, %4, 0x180\n\ts_load_dword %3, %4, 0x1c0\n\ts_load_dword %0, %4, 0x200\n\ts_load_dword %1, %4, 0x240\n\ts_load_dword %2, %4, 0x280\n\ts_load_dword %3, %4, 0x2c0\n\ts_load_dword %0, %4, 0x300\n\ts_load_dword %1, %4, 0x340\n\ts_load_dword %2, %4, 0x380\n\ts_load_dword %3, %4, 0x3c0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3) : "s"(args) : "memory");
+    else if constexpr (LINES == 20u)
+        asm volatile("s_load_dword %0, %4, 0x0\n\ts_load_dword %1, %4, 0x40\n\ts_load_dword %2, %4, 0x80\n\ts_load_dword %3, %4, 0xc0\n\ts_load_dword %0, %4, 0x100\n\ts_load_dword %1, %4, 0x140\n\ts_load_dword %2, %4, 0x180\n\ts_load_dword %3, %4, 0x1c0\n\ts_load_dword %0, %4, 0x200\n\ts_load_dword %1, %4, 0x240\n\ts_load_dword %2, %4, 0x280\n\ts_load_dword %3, %4, 0x2c0\n\ts_load_dword %0, %4, 0x300\n\ts_load_dword %1, %4, 0x340\n\ts_load_dword %2, %4, 0x380\n\ts_load_dword %3, %4, 0x3c0\n\ts_load_dword %0, %4, 0x400\n\ts_load_dword %1, %4, 0x440\n\ts_load_dword %2, %4, 0x480\n\ts_load_dword %3, %4, 0x4c0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3) : "s"(args) : "memory");
+    else if constexpr (LINES == 24u)
+        asm volatile("s_load_dword %0, %4, 0x0\n\ts_load_dword %1, %4, 0x40\n\ts_load_dword %2, %4, 0x80\n\ts_load_dword %3, %4, 0xc0\n\ts_load_dword %0, %4, 0x100\n\ts_load_dword %1, %4, 0x140\n\ts_load_dword %2, %4, 0x180\n\ts_load_dword %3, %4, 0x1c0\n\ts_load_dword %0, %4, 0x200\n\ts_load_dword %1, %4, 0x240\n\ts_load_dword %2, %4, 0x280\n\ts_load_dword %3, %4, 0x2c0\n\ts_load_dword %0, %4, 0x300\n\ts_load_dword %1, %4, 0x340\n\ts_load_dword %2, %4, 0x380\n\ts_load_dword %3, %4, 0x3c0\n\ts_load_dword %0, %4, 0x400\n\ts_load_dword %1, %4, 0x440\n\ts_load_dword %2, %4, 0x480\n\ts_load_dword %3, %4, 0x4c0\n\ts_load_dword %0, %4, 0x500\n\ts_load_dword %1, %4, 0x540\n\ts_load_dword %2, %4, 0x580\n\ts_load_dword %3, %4, 0x5c0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3) : "s"(args) : "memory");
+    else if constexpr (LINES == 28u)
+        asm volatile("s_load_dword %0, %4, 0x0\n\ts_load_dword %1, %4, 0x40\n\ts_load_dword %2, %4, 0x80\n\ts_load_dword %3, %4, 0xc0\n\ts_load_dword %0, %4, 0x100\n\ts_load_dword %1, %4, 0x140\n\ts_load_dword %2, %4, 0x180\n\ts_load_dword %3, %4, 0x1c0\n\ts_load_dword %0, %4, 0x200\n\ts_load_dword %1, %4, 0x240\n\ts_load_dword %2, %4, 0x280\n\ts_load_dword %3, %4, 0x2c0\n\ts_load_dword %0, %4, 0x300\n\ts_load_dword %1, %4, 0x340\n\ts_load_dword %2, %4, 0x380\n\ts_load_dword %3, %4, 0x3c0\n\ts_load_dword %0, %4, 0x400\n\ts_load_dword %1, %4, 0x440\n\ts_load_dword %2, %4, 0x480\n\ts_load_dword %3, %4, 0x4c0\n\ts_load_dword %0, %4, 0x500\n\ts_load_dword %1, %4, 0x540\n\ts_load_dword %2, %4, 0x580\n\ts_load_dword %3, %4, 0x5c0\n\ts_load_dword %0, %4, 0x600\n\ts_load_dword %1, %4, 0x640\n\ts_load_dword %2, %4, 0x680\n\ts_load_dword %3, %4, 0x6c0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3) : "s"(args) : "memory");
+    else if constexpr (LINES == 32u)
+        asm volatile("s_load_dword %0, %4, 0x0\n\ts_load_dword %1, %4, 0x40\n\ts_load_dword %2, %4, 0x80\n\ts_load_dword %3, %4, 0xc0\n\ts_load_dword %0, %4, 0x100\n\ts_load_dword %1, %4, 0x140\n\ts_load_dword %2, %4, 0x180\n\ts_load_dword %3, %4, 0x1c0\n\ts_load_dword %0, %4, 0x200\n\ts_load_dword %1, %4, 0x240\n\ts_load_dword %2, %4, 0x280\n\ts_load_dword %3, %4, 0x2c0\n\ts_load_dword %0, %4, 0x300\n\ts_load_dword %1, %4, 0x340\n\ts_load_dword %2, %4, 0x380\n\ts_load_dword %3, %4, 0x3c0\n\ts_load_dword %0, %4, 0x400\n\ts_load_dword %1, %4, 0x440\n\ts_load_dword %2, %4, 0x480\n\ts_load_dword %3, %4, 0x4c0\n\ts_load_dword %0, %4, 0x500\n\ts_load_dword %1, %4, 0x540\n\ts_load_dword %2, %4, 0x580\n\ts_load_dword %3, %4, 0x5c0\n\ts_load_dword %0, %4, 0x600\n\ts_load_dword %1, %4, 0x640\n\ts_load_dword %2, %4, 0x680\n\ts_load_dword %3, %4, 0x6c0\n\ts_load_dword %0, %4, 0x700\n\ts_load_dword %1, %4, 0x740\n\ts_load_dword %2, %4, 0x780\n\ts_load_dword %3, %4, 0x7c0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3) : "s"(args) : "memory");
+    (void)t0; (void)t1; (void)t2; (void)t3;
+}
+
 // Pointers the per-neuron update kernels need.  All arrays are device memory.
 struct NeuronArrays {
     // exchanged planes
