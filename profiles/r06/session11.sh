@@ -1,8 +1,8 @@
 #!/bin/bash
-# round 6, GPU session 11: the kernel arguments' lines requested in one round trip (warm_kernel_arguments) in k_update and the
+# round 6, GPU sessions 11 and 12 (SESSION_DIR=r06_s12): the kernel arguments' lines requested in one round trip (warm_kernel_arguments) in k_update and the
 # one-launch steps: C3's update under rocprofv3, the small-step kernels, parity of the paths touched
 set -u
-OUT=$PWD/gpurun_out/r06_s11
+OUT=$PWD/gpurun_out/${SESSION_DIR:-r06_s11}
 mkdir -p $OUT
 export TMPDIR=/tmp
 timeout 900 python3 -m pytest tests/test_gpu_fused_step.py tests/test_gpu_network.py tests/test_gpu_models.py tests/test_gpu_golden.py tests/test_gpu_randomized.py tests/test_gpu_sequences.py tests/test_gpu_persistent_run.py tests/test_gpu_modelgen.py tests/test_gpu_lixirnet_module.py -m gpu -q > $OUT/tests.log 2>&1
@@ -28,3 +28,20 @@ done
 rm -rf $OUT/prof
 python3 profiles/measure_small_plastic.py 3000 > $OUT/small_plastic_lattices.jsonl 2> /dev/null
 python3 profiles/measure_small_chem.py 3000 2> /dev/null | grep lattice > $OUT/small_chemical_lattices.jsonl
+# session 12: the sparse step with its arguments warmed -- C5 under rocprofv3 and what one rank of G does per step
+rm -rf $OUT/prof_c5
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_c5 -- python3 bench.py --config c5 --steps 500 --warmup 20 --repeats 2 --no-kernel-events --no-cpu-baseline > $OUT/c5_bench_under_rocprof.json 2> $OUT/c5_rocprof.err
+find $OUT/prof_c5 -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/c5_kernel_stats.csv
+rm -rf $OUT/prof_c5
+head -3 $OUT/c5_kernel_stats.csv | cut -c1-200
+python3 bench.py --config c5 --no-cpu-baseline > $OUT/c5_bench_default.json 2> /dev/null
+python3 profiles/measure_c5_rank_step.py 2000 > $OUT/c5_rank_step.jsonl 2> /dev/null
+python3 - <<'PY'
+import json, os
+out = os.environ.get("SESSION_DIR", "r06_s11")
+d = json.loads(open(f"gpurun_out/{out}/c5_bench_default.json").read().strip().splitlines()[-1])
+print("c5 default: us_per_step", round(d["ms_per_step"] * 1e3, 2), "events frac", round(d["roofline"]["frac"], 4))
+for l in open(f"gpurun_out/{out}/c5_rank_step.jsonl"):
+    if l.startswith("{"):
+        r = json.loads(l); print("rank step", {k: (round(v, 2) if isinstance(v, float) else v) for k, v in r.items() if not isinstance(v, (list, dict))})
+PY

@@ -125,7 +125,7 @@ __device__ __forceinline__ void warm_kernel_arguments()
     // ONE statement per size, loads and wait together: the four scratch registers are written when a load returns, not where it
     // is issued -- nothing of the compiler's may sit between
     constexpr uint32_t LINES = ((BYTES + 63u) / 64u + 3u) & ~3u;
-    static_assert(LINES >= 4u && LINES <= 32u, "extend the list below");
+    static_assert(LINES >= 4u && LINES <= 64u, "extend the list below");
     uint32_t t0, t1, t2, t3;
     if constexpr (LINES == 4u)
         asm volatile("s_load_dword %0, %4, 0x0\n\ts_load_dword %1, %4, 0x40\n\ts_load_dword %2, %4, 0x80\n\ts_load_dword %3, %4, 0xc0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3) : "s"(args) : "memory");
@@ -143,6 +143,22 @@ __device__ __forceinline__ void warm_kernel_arguments()
         asm volatile("s_load_dword %0, %4, 0x0\n\ts_load_dword %1, %4, 0x40\n\ts_load_dword %2, %4, 0x80\n\ts_load_dword %3, %4, 0xc0\n\ts_load_dword %0, %4, 0x100\n\ts_load_dword %1, %4, 0x140\n\ts_load_dword %2, %4, 0x180\n\ts_load_dword %3, %4, 0x1c0\n\ts_load_dword %0, %4, 0x200\n\ts_load_dword %1, %4, 0x240\n\ts_load_dword %2, %4, 0x280\n\ts_load_dword %3, %4, 0x2c0\n\ts_load_dword %0, %4, 0x300\n\ts_load_dword %1, %4, 0x340\n\ts_load_dword %2, %4, 0x380\n\ts_load_dword %3, %4, 0x3c0\n\ts_load_dword %0, %4, 0x400\n\ts_load_dword %1, %4, 0x440\n\ts_load_dword %2, %4, 0x480\n\ts_load_dword %3, %4, 0x4c0\n\ts_load_dword %0, %4, 0x500\n\ts_load_dword %1, %4, 0x540\n\ts_load_dword %2, %4, 0x580\n\ts_load_dword %3, %4, 0x5c0\n\ts_load_dword %0, %4, 0x600\n\ts_load_dword %1, %4, 0x640\n\ts_load_dword %2, %4, 0x680\n\ts_load_dword %3, %4, 0x6c0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3) : "s"(args) : "memory");
     else if constexpr (LINES == 32u)
         asm volatile("s_load_dword %0, %4, 0x0\n\ts_load_dword %1, %4, 0x40\n\ts_load_dword %2, %4, 0x80\n\ts_load_dword %3, %4, 0xc0\n\ts_load_dword %0, %4, 0x100\n\ts_load_dword %1, %4, 0x140\n\ts_load_dword %2, %4, 0x180\n\ts_load_dword %3, %4, 0x1c0\n\ts_load_dword %0, %4, 0x200\n\ts_load_dword %1, %4, 0x240\n\ts_load_dword %2, %4, 0x280\n\ts_load_dword %3, %4, 0x2c0\n\ts_load_dword %0, %4, 0x300\n\ts_load_dword %1, %4, 0x340\n\ts_load_dword %2, %4, 0x380\n\ts_load_dword %3, %4, 0x3c0\n\ts_load_dword %0, %4, 0x400\n\ts_load_dword %1, %4, 0x440\n\ts_load_dword %2, %4, 0x480\n\ts_load_dword %3, %4, 0x4c0\n\ts_load_dword %0, %4, 0x500\n\ts_load_dword %1, %4, 0x540\n\ts_load_dword %2, %4, 0x580\n\ts_load_dword %3, %4, 0x5c0\n\ts_load_dword %0, %4, 0x600\n\ts_load_dword %1, %4, 0x640\n\ts_load_dword %2, %4, 0x680\n\ts_load_dword %3, %4, 0x6c0\n\ts_load_dword %0, %4, 0x700\n\ts_load_dword %1, %4, 0x740\n\ts_load_dword %2, %4, 0x780\n\ts_load_dword %3, %4, 0x7c0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3) : "s"(args) : "memory");
+    else if constexpr (LINES == 36u)
+        asm volatile("s_load_dword %0, %4, 0x0\n\ts_load_dword %1, %4, 0x40\n\ts_load_dword %2, %4, 0x80\n\ts_load_dword %3, %4, 0xc0\n\ts_load_dword %0, %4, 0x100\n\ts_load_dword %1, %4, 0x140\n\ts_load_dword %2, %4, 0x180\n\ts_load_dword %3, %4, 0x1c0\n\ts_load_dword %0, %4, 0x200\n\ts_load_dword %1, %4, 0x240\n\ts_load_dword %2, %4, 0x280\n\ts_load_dword %3, %4, 0x2c0\n\ts_load_dword %0, %4, 0x300\n\ts_load_dword %1, %4, 0x340\n\ts_load_dword %2, %4, 0x380\n\ts_load_dword %3, %4, 0x3c0\n\ts_load_dword %0, %4, 0x400\n\ts_load_dword %1, %4, 0x440\n\ts_load_dword %2, %4, 0x480\n\ts_load_dword %3, %4, 0x4c0\n\ts_load_dword %0, %4, 0x500\n\ts_load_dword %1, %4, 0x540\n\ts_load_dword %2, %4, 0x580\n\ts_load_dword %3, %4, 0x5c0\n\ts_load_dword %0, %4, 0x600\n\ts_load_dword %1, %4, 0x640\n\ts_load_dword %2, %4, 0x680\n\ts_load_dword %3, %4, 0x6c0\n\ts_load_dword %0, %4, 0x700\n\ts_load_dword %1, %4, 0x740\n\ts_load_dword %2, %4, 0x780\n\ts_load_dword %3, %4, 0x7c0\n\ts_load_dword %0, %4, 0x800\n\ts_load_dword %1, %4, 0x840\n\ts_load_dword %2, %4, 0x880\n\ts_load_dword %3, %4, 0x8c0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3) : "s"(args) : "memory");
+    else if constexpr (LINES == 40u)
+        asm volatile("s_load_dword %0, %4, 0x0\n\ts_load_dword %1, %4, 0x40\n\ts_load_dword %2, %4, 0x80\n\ts_load_dword %3, %4, 0xc0\n\ts_load_dword %0, %4, 0x100\n\ts_load_dword %1, %4, 0x140\n\ts_load_dword %2, %4, 0x180\n\ts_load_dword %3, %4, 0x1c0\n\ts_load_dword %0, %4, 0x200\n\ts_load_dword %1, %4, 0x240\n\ts_load_dword %2, %4, 0x280\n\ts_load_dword %3, %4, 0x2c0\n\ts_load_dword %0, %4, 0x300\n\ts_load_dword %1, %4, 0x340\n\ts_load_dword %2, %4, 0x380\n\ts_load_dword %3, %4, 0x3c0\n\ts_load_dword %0, %4, 0x400\n\ts_load_dword %1, %4, 0x440\n\ts_load_dword %2, %4, 0x480\n\ts_load_dword %3, %4, 0x4c0\n\ts_load_dword %0, %4, 0x500\n\ts_load_dword %1, %4, 0x540\n\ts_load_dword %2, %4, 0x580\n\ts_load_dword %3, %4, 0x5c0\n\ts_load_dword %0, %4, 0x600\n\ts_load_dword %1, %4, 0x640\n\ts_load_dword %2, %4, 0x680\n\ts_load_dword %3, %4, 0x6c0\n\ts_load_dword %0, %4, 0x700\n\ts_load_dword %1, %4, 0x740\n\ts_load_dword %2, %4, 0x780\n\ts_load_dword %3, %4, 0x7c0\n\ts_load_dword %0, %4, 0x800\n\ts_load_dword %1, %4, 0x840\n\ts_load_dword %2, %4, 0x880\n\ts_load_dword %3, %4, 0x8c0\n\ts_load_dword %0, %4, 0x900\n\ts_load_dword %1, %4, 0x940\n\ts_load_dword %2, %4, 0x980\n\ts_load_dword %3, %4, 0x9c0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3) : "s"(args) : "memory");
+    else if constexpr (LINES == 44u)
+        asm volatile("s_load_dword %0, %4, 0x0\n\ts_load_dword %1, %4, 0x40\n\ts_load_dword %2, %4, 0x80\n\ts_load_dword %3, %4, 0xc0\n\ts_load_dword %0, %4, 0x100\n\ts_load_dword %1, %4, 0x140\n\ts_load_dword %2, %4, 0x180\n\ts_load_dword %3, %4, 0x1c0\n\ts_load_dword %0, %4, 0x200\n\ts_load_dword %1, %4, 0x240\n\ts_load_dword %2, %4, 0x280\n\ts_load_dword %3, %4, 0x2c0\n\ts_load_dword %0, %4, 0x300\n\ts_load_dword %1, %4, 0x340\n\ts_load_dword %2, %4, 0x380\n\ts_load_dword %3, %4, 0x3c0\n\ts_load_dword %0, %4, 0x400\n\ts_load_dword %1, %4, 0x440\n\ts_load_dword %2, %4, 0x480\n\ts_load_dword %3, %4, 0x4c0\n\ts_load_dword %0, %4, 0x500\n\ts_load_dword %1, %4, 0x540\n\ts_load_dword %2, %4, 0x580\n\ts_load_dword %3, %4, 0x5c0\n\ts_load_dword %0, %4, 0x600\n\ts_load_dword %1, %4, 0x640\n\ts_load_dword %2, %4, 0x680\n\ts_load_dword %3, %4, 0x6c0\n\ts_load_dword %0, %4, 0x700\n\ts_load_dword %1, %4, 0x740\n\ts_load_dword %2, %4, 0x780\n\ts_load_dword %3, %4, 0x7c0\n\ts_load_dword %0, %4, 0x800\n\ts_load_dword %1, %4, 0x840\n\ts_load_dword %2, %4, 0x880\n\ts_load_dword %3, %4, 0x8c0\n\ts_load_dword %0, %4, 0x900\n\ts_load_dword %1, %4, 0x940\n\ts_load_dword %2, %4, 0x980\n\ts_load_dword %3, %4, 0x9c0\n\ts_load_dword %0, %4, 0xa00\n\ts_load_dword %1, %4, 0xa40\n\ts_load_dword %2, %4, 0xa80\n\ts_load_dword %3, %4, 0xac0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3) : "s"(args) : "memory");
+    else if constexpr (LINES == 48u)
+        asm volatile("s_load_dword %0, %4, 0x0\n\ts_load_dword %1, %4, 0x40\n\ts_load_dword %2, %4, 0x80\n\ts_load_dword %3, %4, 0xc0\n\ts_load_dword %0, %4, 0x100\n\ts_load_dword %1, %4, 0x140\n\ts_load_dword %2, %4, 0x180\n\ts_load_dword %3, %4, 0x1c0\n\ts_load_dword %0, %4, 0x200\n\ts_load_dword %1, %4, 0x240\n\ts_load_dword %2, %4, 0x280\n\ts_load_dword %3, %4, 0x2c0\n\ts_load_dword %0, %4, 0x300\n\ts_load_dword %1, %4, 0x340\n\ts_load_dword %2, %4, 0x380\n\ts_load_dword %3, %4, 0x3c0\n\ts_load_dword %0, %4, 0x400\n\ts_load_dword %1, %4, 0x440\n\ts_load_dword %2, %4, 0x480\n\ts_load_dword %3, %4, 0x4c0\n\ts_load_dword %0, %4, 0x500\n\ts_load_dword %1, %4, 0x540\n\ts_load_dword %2, %4, 0x580\n\ts_load_dword %3, %4, 0x5c0\n\ts_load_dword %0, %4, 0x600\n\ts_load_dword %1, %4, 0x640\n\ts_load_dword %2, %4, 0x680\n\ts_load_dword %3, %4, 0x6c0\n\ts_load_dword %0, %4, 0x700\n\ts_load_dword %1, %4, 0x740\n\ts_load_dword %2, %4, 0x780\n\ts_load_dword %3, %4, 0x7c0\n\ts_load_dword %0, %4, 0x800\n\ts_load_dword %1, %4, 0x840\n\ts_load_dword %2, %4, 0x880\n\ts_load_dword %3, %4, 0x8c0\n\ts_load_dword %0, %4, 0x900\n\ts_load_dword %1, %4, 0x940\n\ts_load_dword %2, %4, 0x980\n\ts_load_dword %3, %4, 0x9c0\n\ts_load_dword %0, %4, 0xa00\n\ts_load_dword %1, %4, 0xa40\n\ts_load_dword %2, %4, 0xa80\n\ts_load_dword %3, %4, 0xac0\n\ts_load_dword %0, %4, 0xb00\n\ts_load_dword %1, %4, 0xb40\n\ts_load_dword %2, %4, 0xb80\n\ts_load_dword %3, %4, 0xbc0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3) : "s"(args) : "memory");
+    else if constexpr (LINES == 52u)
+        asm volatile("s_load_dword %0, %4, 0x0\n\ts_load_dword %1, %4, 0x40\n\ts_load_dword %2, %4, 0x80\n\ts_load_dword %3, %4, 0xc0\n\ts_load_dword %0, %4, 0x100\n\ts_load_dword %1, %4, 0x140\n\ts_load_dword %2, %4, 0x180\n\ts_load_dword %3, %4, 0x1c0\n\ts_load_dword %0, %4, 0x200\n\ts_load_dword %1, %4, 0x240\n\ts_load_dword %2, %4, 0x280\n\ts_load_dword %3, %4, 0x2c0\n\ts_load_dword %0, %4, 0x300\n\ts_load_dword %1, %4, 0x340\n\ts_load_dword %2, %4, 0x380\n\ts_load_dword %3, %4, 0x3c0\n\ts_load_dword %0, %4, 0x400\n\ts_load_dword %1, %4, 0x440\n\ts_load_dword %2, %4, 0x480\n\ts_load_dword %3, %4, 0x4c0\n\ts_load_dword %0, %4, 0x500\n\ts_load_dword %1, %4, 0x540\n\ts_load_dword %2, %4, 0x580\n\ts_load_dword %3, %4, 0x5c0\n\ts_load_dword %0, %4, 0x600\n\ts_load_dword %1, %4, 0x640\n\ts_load_dword %2, %4, 0x680\n\ts_load_dword %3, %4, 0x6c0\n\ts_load_dword %0, %4, 0x700\n\ts_load_dword %1, %4, 0x740\n\ts_load_dword %2, %4, 0x780\n\ts_load_dword %3, %4, 0x7c0\n\ts_load_dword %0, %4, 0x800\n\ts_load_dword %1, %4, 0x840\n\ts_load_dword %2, %4, 0x880\n\ts_load_dword %3, %4, 0x8c0\n\ts_load_dword %0, %4, 0x900\n\ts_load_dword %1, %4, 0x940\n\ts_load_dword %2, %4, 0x980\n\ts_load_dword %3, %4, 0x9c0\n\ts_load_dword %0, %4, 0xa00\n\ts_load_dword %1, %4, 0xa40\n\ts_load_dword %2, %4, 0xa80\n\ts_load_dword %3, %4, 0xac0\n\ts_load_dword %0, %4, 0xb00\n\ts_load_dword %1, %4, 0xb40\n\ts_load_dword %2, %4, 0xb80\n\ts_load_dword %3, %4, 0xbc0\n\ts_load_dword %0, %4, 0xc00\n\ts_load_dword %1, %4, 0xc40\n\ts_load_dword %2, %4, 0xc80\n\ts_load_dword %3, %4, 0xcc0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3) : "s"(args) : "memory");
+    else if constexpr (LINES == 56u)
+        asm volatile("s_load_dword %0, %4, 0x0\n\ts_load_dword %1, %4, 0x40\n\ts_load_dword %2, %4, 0x80\n\ts_load_dword %3, %4, 0xc0\n\ts_load_dword %0, %4, 0x100\n\ts_load_dword %1, %4, 0x140\n\ts_load_dword %2, %4, 0x180\n\ts_load_dword %3, %4, 0x1c0\n\ts_load_dword %0, %4, 0x200\n\ts_load_dword %1, %4, 0x240\n\ts_load_dword %2, %4, 0x280\n\ts_load_dword %3, %4, 0x2c0\n\ts_load_dword %0, %4, 0x300\n\ts_load_dword %1, %4, 0x340\n\ts_load_dword %2, %4, 0x380\n\ts_load_dword %3, %4, 0x3c0\n\ts_load_dword %0, %4, 0x400\n\ts_load_dword %1, %4, 0x440\n\ts_load_dword %2, %4, 0x480\n\ts_load_dword %3, %4, 0x4c0\n\ts_load_dword %0, %4, 0x500\n\ts_load_dword %1, %4, 0x540\n\ts_load_dword %2, %4, 0x580\n\ts_load_dword %3, %4, 0x5c0\n\ts_load_dword %0, %4, 0x600\n\ts_load_dword %1, %4, 0x640\n\ts_load_dword %2, %4, 0x680\n\ts_load_dword %3, %4, 0x6c0\n\ts_load_dword %0, %4, 0x700\n\ts_load_dword %1, %4, 0x740\n\ts_load_dword %2, %4, 0x780\n\ts_load_dword %3, %4, 0x7c0\n\ts_load_dword %0, %4, 0x800\n\ts_load_dword %1, %4, 0x840\n\ts_load_dword %2, %4, 0x880\n\ts_load_dword %3, %4, 0x8c0\n\ts_load_dword %0, %4, 0x900\n\ts_load_dword %1, %4, 0x940\n\ts_load_dword %2, %4, 0x980\n\ts_load_dword %3, %4, 0x9c0\n\ts_load_dword %0, %4, 0xa00\n\ts_load_dword %1, %4, 0xa40\n\ts_load_dword %2, %4, 0xa80\n\ts_load_dword %3, %4, 0xac0\n\ts_load_dword %0, %4, 0xb00\n\ts_load_dword %1, %4, 0xb40\n\ts_load_dword %2, %4, 0xb80\n\ts_load_dword %3, %4, 0xbc0\n\ts_load_dword %0, %4, 0xc00\n\ts_load_dword %1, %4, 0xc40\n\ts_load_dword %2, %4, 0xc80\n\ts_load_dword %3, %4, 0xcc0\n\ts_load_dword %0, %4, 0xd00\n\ts_load_dword %1, %4, 0xd40\n\ts_load_dword %2, %4, 0xd80\n\ts_load_dword %3, %4, 0xdc0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3) : "s"(args) : "memory");
+    else if constexpr (LINES == 60u)
+        asm volatile("s_load_dword %0, %4, 0x0\n\ts_load_dword %1, %4, 0x40\n\ts_load_dword %2, %4, 0x80\n\ts_load_dword %3, %4, 0xc0\n\ts_load_dword %0, %4, 0x100\n\ts_load_dword %1, %4, 0x140\n\ts_load_dword %2, %4, 0x180\n\ts_load_dword %3, %4, 0x1c0\n\ts_load_dword %0, %4, 0x200\n\ts_load_dword %1, %4, 0x240\n\ts_load_dword %2, %4, 0x280\n\ts_load_dword %3, %4, 0x2c0\n\ts_load_dword %0, %4, 0x300\n\ts_load_dword %1, %4, 0x340\n\ts_load_dword %2, %4, 0x380\n\ts_load_dword %3, %4, 0x3c0\n\ts_load_dword %0, %4, 0x400\n\ts_load_dword %1, %4, 0x440\n\ts_load_dword %2, %4, 0x480\n\ts_load_dword %3, %4, 0x4c0\n\ts_load_dword %0, %4, 0x500\n\ts_load_dword %1, %4, 0x540\n\ts_load_dword %2, %4, 0x580\n\ts_load_dword %3, %4, 0x5c0\n\ts_load_dword %0, %4, 0x600\n\ts_load_dword %1, %4, 0x640\n\ts_load_dword %2, %4, 0x680\n\ts_load_dword %3, %4, 0x6c0\n\ts_load_dword %0, %4, 0x700\n\ts_load_dword %1, %4, 0x740\n\ts_load_dword %2, %4, 0x780\n\ts_load_dword %3, %4, 0x7c0\n\ts_load_dword %0, %4, 0x800\n\ts_load_dword %1, %4, 0x840\n\ts_load_dword %2, %4, 0x880\n\ts_load_dword %3, %4, 0x8c0\n\ts_load_dword %0, %4, 0x900\n\ts_load_dword %1, %4, 0x940\n\ts_load_dword %2, %4, 0x980\n\ts_load_dword %3, %4, 0x9c0\n\ts_load_dword %0, %4, 0xa00\n\ts_load_dword %1, %4, 0xa40\n\ts_load_dword %2, %4, 0xa80\n\ts_load_dword %3, %4, 0xac0\n\ts_load_dword %0, %4, 0xb00\n\ts_load_dword %1, %4, 0xb40\n\ts_load_dword %2, %4, 0xb80\n\ts_load_dword %3, %4, 0xbc0\n\ts_load_dword %0, %4, 0xc00\n\ts_load_dword %1, %4, 0xc40\n\ts_load_dword %2, %4, 0xc80\n\ts_load_dword %3, %4, 0xcc0\n\ts_load_dword %0, %4, 0xd00\n\ts_load_dword %1, %4, 0xd40\n\ts_load_dword %2, %4, 0xd80\n\ts_load_dword %3, %4, 0xdc0\n\ts_load_dword %0, %4, 0xe00\n\ts_load_dword %1, %4, 0xe40\n\ts_load_dword %2, %4, 0xe80\n\ts_load_dword %3, %4, 0xec0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3) : "s"(args) : "memory");
+    else if constexpr (LINES == 64u)
+        asm volatile("s_load_dword %0, %4, 0x0\n\ts_load_dword %1, %4, 0x40\n\ts_load_dword %2, %4, 0x80\n\ts_load_dword %3, %4, 0xc0\n\ts_load_dword %0, %4, 0x100\n\ts_load_dword %1, %4, 0x140\n\ts_load_dword %2, %4, 0x180\n\ts_load_dword %3, %4, 0x1c0\n\ts_load_dword %0, %4, 0x200\n\ts_load_dword %1, %4, 0x240\n\ts_load_dword %2, %4, 0x280\n\ts_load_dword %3, %4, 0x2c0\n\ts_load_dword %0, %4, 0x300\n\ts_load_dword %1, %4, 0x340\n\ts_load_dword %2, %4, 0x380\n\ts_load_dword %3, %4, 0x3c0\n\ts_load_dword %0, %4, 0x400\n\ts_load_dword %1, %4, 0x440\n\ts_load_dword %2, %4, 0x480\n\ts_load_dword %3, %4, 0x4c0\n\ts_load_dword %0, %4, 0x500\n\ts_load_dword %1, %4, 0x540\n\ts_load_dword %2, %4, 0x580\n\ts_load_dword %3, %4, 0x5c0\n\ts_load_dword %0, %4, 0x600\n\ts_load_dword %1, %4, 0x640\n\ts_load_dword %2, %4, 0x680\n\ts_load_dword %3, %4, 0x6c0\n\ts_load_dword %0, %4, 0x700\n\ts_load_dword %1, %4, 0x740\n\ts_load_dword %2, %4, 0x780\n\ts_load_dword %3, %4, 0x7c0\n\ts_load_dword %0, %4, 0x800\n\ts_load_dword %1, %4, 0x840\n\ts_load_dword %2, %4, 0x880\n\ts_load_dword %3, %4, 0x8c0\n\ts_load_dword %0, %4, 0x900\n\ts_load_dword %1, %4, 0x940\n\ts_load_dword %2, %4, 0x980\n\ts_load_dword %3, %4, 0x9c0\n\ts_load_dword %0, %4, 0xa00\n\ts_load_dword %1, %4, 0xa40\n\ts_load_dword %2, %4, 0xa80\n\ts_load_dword %3, %4, 0xac0\n\ts_load_dword %0, %4, 0xb00\n\ts_load_dword %1, %4, 0xb40\n\ts_load_dword %2, %4, 0xb80\n\ts_load_dword %3, %4, 0xbc0\n\ts_load_dword %0, %4, 0xc00\n\ts_load_dword %1, %4, 0xc40\n\ts_load_dword %2, %4, 0xc80\n\ts_load_dword %3, %4, 0xcc0\n\ts_load_dword %0, %4, 0xd00\n\ts_load_dword %1, %4, 0xd40\n\ts_load_dword %2, %4, 0xd80\n\ts_load_dword %3, %4, 0xdc0\n\ts_load_dword %0, %4, 0xe00\n\ts_load_dword %1, %4, 0xe40\n\ts_load_dword %2, %4, 0xe80\n\ts_load_dword %3, %4, 0xec0\n\ts_load_dword %0, %4, 0xf00\n\ts_load_dword %1, %4, 0xf40\n\ts_load_dword %2, %4, 0xf80\n\ts_load_dword %3, %4, 0xfc0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3) : "s"(args) : "memory");
     (void)t0; (void)t1; (void)t2; (void)t3;
 }
 
