@@ -681,7 +681,9 @@ __global__ __launch_bounds__(256, (CSR_PREFETCH && ELEC && !CHEM && !PEER) ? 8 :
     // before have read what they had to read -- which is what the neighbours wait for before they overwrite a receive set.  One
     // thread says so.  (A counter of finished workgroups at the END of the launch was measured first: 2048 atomics on one
     // address cost 27 us of a 35 us step.)
-    warm_kernel_arguments<sizeof(CsrStepArgs)>();            // (snn_layout.hpp: 46 lines of arguments in one round trip)
+    // (snn_layout.hpp: 46 lines of arguments in one round trip -- by the workgroups that start on a cold scalar cache; all 4 096
+    // of BASELINE configs[4]'s launch doing it cost that launch 0.6 us of 33, session 12)
+    if (blockIdx.x < 512u) warm_kernel_arguments<sizeof(CsrStepArgs)>();
     if (PEER && a.peer.signal && blockIdx.x == 0 && threadIdx.x == 0) {
         peer_delay(a.peer.delay, a.peer.delay_seed, a.peer.done_value * 4u + 2u);
         for (uint32_t i = 0; i < a.peer.n_signal; ++i)
@@ -699,7 +701,7 @@ template <int MODEL, bool PACK = false>
 __global__ __launch_bounds__(256) void k_step_csr_img(const CsrStepArgs a)
 {
     __shared__ uint32_t win[4 * IMG_WIN_WORDS];
-    warm_kernel_arguments<sizeof(CsrStepArgs)>();
+    if (blockIdx.x < 512u) warm_kernel_arguments<sizeof(CsrStepArgs)>();
     step_csr_block<MODEL, true, false, false, true, PACK>(a, win);
 }
 

@@ -328,27 +328,15 @@ __global__ __launch_bounds__(512) void k_step_resident_q(const ResidentArgs a)
         all_k[k] = has == live && rb != 0u;
         any_k[k] = has != 0ull;
     }
-    // (IN_PLACE: the products replace the weights they were formed from.  Its "is the edge there" test is spelled on the bits: given
-    // the same `w[u] == w[u]` as the first plane's, the compiler keeps the 64 lane masks of the first plane in scalar registers it
-    // does not have -- 125 v_writelane / v_readlane pairs with their wait states -- instead of 64 compares)
-    auto form = [&](uint32_t id, auto &pr, bool &pr_zero, auto in_place) {
-        auto there = [&](float x) {
-            if constexpr (decltype(in_place)::value) return (__float_as_uint(x) & 0x7FFFFFFFu) <= 0x7F800000u;
-            else return x == x;
-        };
+    auto form = [&](uint32_t id, auto &pr, bool &pr_zero) {
         pr_zero = false;
         if (id == 0u) {
-            if (rb == 0u) {                                  // a quarter past the end of the chunk: nothing to add
-                pr_zero = true;
-#pragma unroll
-                for (uint32_t u = 0; u < R; ++u) pr[u] = 0.0f;   // (+0.0f: the two-buffer turns add a buffer whatever it holds)
-                return;
-            }
+            if (rb == 0u) { pr_zero = true; return; }        // a quarter past the end of the chunk
             if (all_neurons) {                               // gap_junction neuron/mod.rs:54-60
 #pragma unroll
                 for (uint32_t u = 0; u < R; ++u) {
                     const float p = (gq * (bcast(val, u) - vq)) * w[u];
-                    pr[u] = there(w[u]) ? p : 0.0f;
+                    pr[u] = (w[u] == w[u]) ? p : 0.0f;
                 }
             } else {                                         // + spike_train_gap_junction :119-137
 #pragma unroll
@@ -357,31 +345,26 @@ __global__ __launch_bounds__(512) void k_step_resident_q(const ResidentArgs a)
                     const float vp = bcast(val, u);
                     const float term = (src == KIND_NEURON) ? gq * (vp - vq) : ((src == KIND_ST_SILENT) ? vp : gq * vp);
                     const float p = term * w[u];
-                    pr[u] = there(w[u]) ? p : 0.0f;
+                    pr[u] = (w[u] == w[u]) ? p : 0.0f;
                 }
             }
         } else if (CHEM) {
 #pragma unroll
             for (int k = 0; k < K_TYPES; ++k) {
                 if (id != 1u + (uint32_t)k) continue;
-                if (!any_k[k]) {                                     // no row of this wavefront carries the type: nothing to add
-                    pr_zero = true;
-#pragma unroll
-                    for (uint32_t u = 0; u < R; ++u) pr[u] = 0.0f;
-                    continue;
-                }
+                if (!any_k[k]) { pr_zero = true; continue; }         // no row of this wavefront carries the type: nothing to add
                 if (all_k[k]) {
 #pragma unroll
                     for (uint32_t u = 0; u < R; ++u) {
                         const float p = bcast(tval[k], u) * w[u];
-                        pr[u] = there(w[u]) ? p : 0.0f;
+                        pr[u] = (w[u] == w[u]) ? p : 0.0f;
                     }
                 } else {
 #pragma unroll
                     for (uint32_t u = 0; u < R; ++u) {
                         const float p = bcast(tval[k], u) * w[u];
                         const bool has = (__builtin_amdgcn_readlane(kind, u) & (0x100u << k)) != 0;
-                        pr[u] = (there(w[u]) && has) ? p : 0.0f;
+                        pr[u] = (w[u] == w[u] && has) ? p : 0.0f;
                     }
                 }
             }
@@ -392,9 +375,9 @@ __global__ __launch_bounds__(512) void k_step_resident_q(const ResidentArgs a)
 #endif
     asm volatile("" :: "v"(touched));                        // (landed: the weights were requested before it)
     const bool two_buffers = n_planes <= 2u;
-    if (n_planes) form(plane_id[0], prA, zeroA, std::false_type{});
+    if (n_planes) form(plane_id[0], prA, zeroA);
     if constexpr (CHEM) {
-        if (two_buffers && n_planes > 1u) form(plane_id[1], w, zeroB, std::true_type{});          // in place: w[u] becomes the product of row u
+        if (two_buffers && n_planes > 1u) form(plane_id[1], w, zeroB);          // in place: w[u] becomes the product of row u
     }
 #ifdef SNN_LAB_TIMING
     const unsigned long long lab_t2 = __builtin_amdgcn_s_memtime();      // the first two planes' products formed (= the weights have landed)
@@ -411,31 +394,13 @@ __global__ __launch_bounds__(512) void k_step_resident_q(const ResidentArgs a)
         if (!pr_zero || quarter == 0u) *slot = sum;
     };
     if (two_buffers) {
-        // Both sets of products exist before the first turn, so a quarter adds BOTH planes in its turn -- two independent chains
-        // of dependent adds, interleaved: a dependent v_add_f32 issues every 9 to 10 clocks (740 clocks per turn of 64 adds,
-        // session 11), two chains fit in the same time.  Four turns instead of 4 + planes - 1; the order of the adds of each
-        // plane is what it was.  (A loop of its own: with the one-buffer schedule in the same loop the compiler carried both
-        // register arrays around the back edge, 128 moves per turn.)
-        float *slotA = nullptr, *slotB = nullptr;
-        if (n_planes) slotA = plane_id[0] == 0u ? &s_pi[chunk][lane] : &s_pt[CHEM ? plane_id[0] - 1u : 0u][chunk][lane];
-        if (CHEM && n_planes > 1u) slotB = &s_pt[plane_id[1] - 1u][chunk][lane];
-        for (uint32_t t = 0; t < (n_planes ? 4u : 0u); ++t) {
-            if (t == quarter) {
-                // no test of "this buffer is all zeros" in here: x + 0.0f == x bit for bit (the sums start at +0.0f and never
-                // hold -0.0f), and with the tests the compiler runs the two chains one after the other.  With one plane the second
-                // chain adds the weights into a sum nobody stores.
-                float sumA = (quarter && slotA) ? *slotA : 0.0f, sumB = (quarter && slotB) ? *slotB : 0.0f;
-                if constexpr (CHEM) {
-                    // (the pair spelled out: left to itself the compiler issues chain A's 64 adds, then chain B's)
-#pragma unroll
-                    for (uint32_t u = 0; u < R; ++u)
-                        asm("v_add_f32 %0, %0, %2\n\tv_add_f32 %1, %1, %3" : "+v"(sumA), "+v"(sumB) : "v"(prA[u]), "v"(w[u]));
-                } else {
-#pragma unroll
-                    for (uint32_t u = 0; u < R; ++u) sumA += prA[u];
-                }
-                if (slotA) *slotA = sumA;
-                if (slotB) *slotB = sumB;
+        // (a loop of its own: no register array changes inside it -- with the one-buffer schedule in the same loop the compiler
+        // carried both arrays around the back edge, 128 moves per turn)
+        for (uint32_t t = 0; t < turns; ++t) {
+            const uint32_t pi = t - quarter;                 // (wraps below zero: not this wavefront's turn yet)
+            if (pi == 0u) take_turn(0u, prA, zeroA);
+            if constexpr (CHEM) {
+                if (pi == 1u && n_planes > 1u) take_turn(1u, w, zeroB);
             }
             __syncthreads();
         }
@@ -444,7 +409,7 @@ __global__ __launch_bounds__(512) void k_step_resident_q(const ResidentArgs a)
             const uint32_t pi = t - quarter;
             if (pi < n_planes) {
                 take_turn(pi, prA, zeroA);                    // one buffer: add, then form the next plane's products
-                if (pi + 1u < n_planes) form(plane_id[pi + 1u], prA, zeroA, std::false_type{});
+                if (pi + 1u < n_planes) form(plane_id[pi + 1u], prA, zeroA);
             }
             __syncthreads();
         }
