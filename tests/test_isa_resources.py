@@ -119,3 +119,40 @@ def test_the_image_step_keeps_eight_wavefronts_per_simd_and_stages_by_lds_dma(im
     assert len(re.findall(r"global_load_dwordx4", body)) >= 8                 # records of two entries: 16 bytes per lane and load
     plain = table["snn::k_step_csr<0, true, false, false>"]
     assert plain["lds"] == 0 and plain["vgpr"] <= 64                          # the plain step is untouched
+
+
+# ---- the one-launch step over four wavefronts per chunk (k_step_resident_q) and the argument warm-up (warm_kernel_arguments) --------
+@pytest.fixture(scope="module")
+def quarter_assembly(tmp_path_factory):
+    d = tmp_path_factory.mktemp("isa_quarters")
+    src = d / "quarters_only.hip"
+    inst = "\n".join(f"template __global__ void snn::k_step_resident_q<{m}, true, {c}>(const snn::ResidentArgs);" for m in range(8) for c in ("true", "false"))
+    src.write_text(f'#include "{ROOT}/include/snn_amd.h"\n#include "snn_kernels_misc.hpp"\n#include "snn_kernels_resident.hpp"\n{inst}\n'
+                   "template __global__ void snn::k_update<2, true>(const snn::UpdateArgs);\n")
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-c", "--cuda-device-only", "-Wno-unused-result",
+                    "-Wno-pass-failed", "-save-temps", f"-I{CSRC}", "-o", "quarters.o", src.name], cwd=d, check=True, capture_output=True)
+    return str(d / "quarters_only-hip-amdgcn-amd-amdhsa-gfx950.s")
+
+
+def test_the_quarter_step_fits_two_chunks_and_its_arguments_arrive_in_one_round_trip(quarter_assembly):
+    table = isa_metadata.parse(quarter_assembly)
+    q = {k: v for k, v in table.items() if k.startswith("snn::k_step_resident_q<")}
+    assert len(q) == 16
+    for name, r in q.items():
+        # 512 threads = 8 wavefronts on a CU, two per SIMD: 256 registers each; 64 weights + 64 products per lane are half of that
+        assert r["vgpr_spill"] == 0 and r["scratch"] == 0 and r["vgpr"] + r["agpr"] <= 256 and r["max_threads"] == 512, (name, r)
+    text = open(quarter_assembly, errors="replace").read()
+    for label, nbytes in (("_ZN3snn17k_step_resident_qILi0ELb1ELb1EEEvNS_12ResidentArgsE", 1640), ("_ZN3snn8k_updateILi2ELb1EEEvNS_10UpdateArgsE", 1368)):
+        body = re.search(rf"^{label}:.*?\n(.*?)\.end_amdhsa_kernel", text, re.S | re.M).group(1)
+        # ONE inline-assembly statement: a word of every 64-byte line of the arguments, then the wait -- nothing of the compiler's
+        # between the loads and the wait (the scratch registers are written when a load returns)
+        block = re.search(r";;#ASMSTART\n(.*?);;#ASMEND", body, re.S).group(1)
+        lines = [l.strip() for l in block.strip().splitlines()]
+        loads = [l for l in lines if l.startswith("s_load_dword ")]
+        assert lines[-1] == "s_waitcnt lgkmcnt(0)" and len(loads) == len(lines) - 1, lines[-3:]
+        offsets = sorted(int(l.rsplit(",", 1)[1], 0) for l in loads)
+        want = ((nbytes + 63) // 64 + 3) // 4 * 4
+        assert offsets == [64 * i for i in range(want)], (label, offsets[-3:], want)
+        assert offsets[-1] + 4 <= nbytes + 256               # what lies behind the explicit arguments: the implicit ones
+        # and it is the first thing the kernel does with memory: no vector load in front of it
+        assert not re.search(r"global_load|buffer_load", body[:body.index(";;#ASMSTART")])
