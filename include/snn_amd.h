@@ -571,7 +571,9 @@ int snn_get_stat(snn_network_t *net, const char *name, uint64_t *value);
  * exchange buffer, 2^30 + w: word w of the weights, disturbed once after the second pass; "stdp_columns_form" [0] 1: the incoming-edge scatter of STDP with
  * one lane per 16-byte unit (k_stdp_columns_quads); "pinned_copies" [1] every host <-> device copy of the setters and getters goes through a page-locked buffer of the
  * handle and a memcpy on the calling thread (0: the runtime stages the caller's pageable pointer itself; 2: the 2-D copies of
- * the history and row transfers too -- written after the round's last GPU run, untested); "stdp_small" [1]: dense unsharded networks of at most 1024 rows under STDP
+ * the history and row transfers too -- run in round 6: tests/test_gpu_abi_errors.py (setters and getters with and without the buffer), the seeded tests through the trap and a
+ * campaign under it, profiles/r06/README.md; the buffer is the handle's own, like everything else a call on a handle uses: calls
+ * on one handle are not re-entrant); "stdp_small" [1]: dense unsharded networks of at most 1024 rows under STDP
  * take spike compaction and both weight scatters of a step in ONE launch (k_stdp_small) instead of four. */
 const char *snn_debug_verify_report(snn_network_t *net);
 /* restore = 0: keeps a copy of everything a later run call reads (device arrays up to 256 MiB in all, the stepper's host-side
