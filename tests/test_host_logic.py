@@ -158,3 +158,12 @@ def test_first_contact_script_fails_on_a_failed_run_or_a_missing_communicator(tm
     assert p.returncode == 1
     text = " ".join(rep["problems"])
     assert "c2 strong, N = 4: no bench line (exit 3)" in text and "rccl_ranks is 1" in text and "the peer form was not taken" in text
+
+
+def test_scratch_and_the_lab_build_do_not_ship_to_the_gpu_box():
+    """.gpurunignore: the snapshot matches the bare directory name -- `scratch/` alone shipped 145 MiB with every lease of round 6"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lines = open(os.path.join(root, ".gpurunignore")).read().split()
+    assert "scratch" in lines and "spiking-neural-networks_amd/csrc/lab" in lines
+    # what the GPU tests load must NOT be listed: the built libraries travel with the snapshot
+    assert not any(l.endswith(".so") or l.rstrip("/").endswith("csrc") or "generated" in l for l in lines)
