@@ -151,8 +151,12 @@ def test_the_quarter_step_fits_two_chunks_and_its_arguments_arrive_in_one_round_
         loads = [l for l in lines if l.startswith("s_load_dword ")]
         assert lines[-1] == "s_waitcnt lgkmcnt(0)" and len(loads) == len(lines) - 1, lines[-3:]
         offsets = sorted(int(l.rsplit(",", 1)[1], 0) for l in loads)
-        want = ((nbytes + 63) // 64 + 3) // 4 * 4
+        want = (nbytes + 63) // 64
         assert offsets == [64 * i for i in range(want)], (label, offsets[-3:], want)
-        assert offsets[-1] + 4 <= nbytes + 256               # what lies behind the explicit arguments: the implicit ones
+        assert offsets[-1] + 4 <= nbytes                     # never past the explicit arguments: a kernel without implicit ones has
+                                                             # nothing behind them (.kernarg_segment_size = sizeof the struct)
+        notes = text[:re.search(rf"\.name:\s*{label}\s", text).start()]
+        size = int(re.findall(r"\.kernarg_segment_size:\s*(\d+)", notes)[-1])       # (the entry's fields are in alphabetical order)
+        assert offsets[-1] + 4 <= size, (label, size)
         # and it is the first thing the kernel does with memory: no vector load in front of it
         assert not re.search(r"global_load|buffer_load", body[:body.index(";;#ASMSTART")])
